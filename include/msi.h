@@ -1,0 +1,244 @@
+/*
+ * msi.h — C ABI of libmsi.so: the MI355X-native query-time scoring path for
+ * Meilisearch's `milli` (vector k-NN scan, typo-tolerant term lookup, dense
+ * docid-set algebra, scoring arithmetic).
+ *
+ * This is the drop-in boundary (SURVEY.md §8 b).  There is no FFI in the
+ * reference today: the seams are Rust method calls inside crates/milli.  Every
+ * entry point below cites the reference interface (file:line under
+ * /root/reference) that a Rust shim would route to it; INTEGRATION.md shows
+ * the `extern "C"` block and the safe wrappers a milli maintainer would add.
+ *
+ * Conventions
+ *  - every function returns int32_t status: 0 = MSI_OK, negative = MSI_E_*;
+ *    msi_last_error() returns a thread-local, NUL-terminated description.
+ *  - opaque handles are owned by the library and released by *_destroy.
+ *  - inputs are borrowed for the duration of the call; outputs are caller
+ *    allocated.  No exception ever crosses the boundary.
+ *  - all entry points are thread-safe (callers are tokio spawn_blocking
+ *    threads, crates/meilisearch/src/search/federated/perform.rs:224).
+ *    Calls on one context serialise on the context's stream lock.
+ *  - "_device" variants take device pointers and enqueue on the context's HIP
+ *    stream without synchronising (multi-GPU gather, benchmarks).
+ *  - there is NO CPU fallback inside the library: if no gfx950 device is
+ *    usable msi_ctx_create fails with MSI_E_NO_DEVICE.
+ */
+#ifndef MSI_H
+#define MSI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSI_ABI_VERSION 1
+
+enum {
+  MSI_OK = 0,
+  MSI_E_INVALID = -1,     /* bad argument                                  */
+  MSI_E_NO_DEVICE = -2,   /* no usable HIP device / wrong architecture     */
+  MSI_E_HIP = -3,         /* a HIP runtime call failed                     */
+  MSI_E_OOM = -4,         /* device or host allocation failed              */
+  MSI_E_UNSUPPORTED = -5, /* valid request outside the implemented range   */
+  MSI_E_CANCELLED = -6,   /* the caller's cancel flag was raised           */
+  MSI_E_NOT_SORTED = -7,  /* input that must be sorted/unique is not       */
+  MSI_E_INTERNAL = -8
+};
+
+typedef struct msi_ctx msi_ctx;   /* one per (process, GPU)                 */
+typedef struct msi_vs msi_vs;     /* one vector store (one arroy/hannoy index) */
+typedef struct msi_dict msi_dict; /* one words-FST dictionary in HBM        */
+typedef struct msi_bits msi_bits; /* a pool of dense docid sets in HBM      */
+
+/* ------------------------------------------------------------------ context */
+
+int32_t msi_abi_version(void);
+const char *msi_last_error(void);
+
+/* device < 0: use $LOCAL_RANK if set, else device 0. */
+int32_t msi_ctx_create(int32_t device, msi_ctx **out);
+void msi_ctx_destroy(msi_ctx *ctx);
+/* The context's hipStream_t (as void*), e.g. to bracket work with HIP events. */
+void *msi_ctx_stream(msi_ctx *ctx);
+int32_t msi_ctx_synchronize(msi_ctx *ctx);
+int32_t msi_ctx_device(msi_ctx *ctx);
+/* When enabled, the dominant kernels (vs_scan's main pass, dict_match) are
+ * bracketed by HIP events on the context stream; msi_vs_scan_time /
+ * msi_dict_match_time synchronise and return the accumulated kernel time. */
+int32_t msi_ctx_set_profiling(msi_ctx *ctx, int32_t enable);
+
+/* ------------------------------------------------- S1: vector k-NN (cosine) */
+/*
+ * Replaces VectorStore::nns_by_vector / nns_by_item for ONE store
+ * (crates/milli/src/vector/store.rs:615-675, 1036-1093): the `limit` nearest
+ * rows to each query under arroy/hannoy's cosine distance
+ *     d = pn*qn > f32::EPSILON ? (1 - pq/(pn*qn)) / 2 : 0        (all f32)
+ * restricted to an optional candidate set, returned ascending by
+ * (distance, docid).  The scan is exact (the reference's linear mode,
+ * store.rs:22-27,1079-1080); distances are the reference's scalar f32
+ * arithmetic (sequential mul+add dot product), so results are reproducible
+ * bit for bit on any device count.
+ */
+int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out);
+void msi_vs_destroy(msi_vs *vs);
+
+/* Replace the store's contents.  `docids[n_rows]` strictly ascending (one row
+ * per document and store, as in arroy), `rows` row-major [n_rows][dim] f32.
+ * Host pointers; data is copied to HBM and re-tiled for the scan kernel. */
+int32_t msi_vs_upload(msi_vs *vs, const uint32_t *docids, const float *rows,
+                      uint64_t n_rows);
+/* Same with device pointers (synchronises the context stream before return). */
+int32_t msi_vs_upload_device(msi_vs *vs, const uint32_t *d_docids,
+                             const float *d_rows, uint64_t n_rows);
+
+uint64_t msi_vs_len(const msi_vs *vs);
+uint32_t msi_vs_dim(const msi_vs *vs);
+
+/* store.rs:1004-1034 (nns_by_item reads the item's stored vector first). */
+int32_t msi_vs_get_vector(msi_vs *vs, uint32_t docid, float *out_row,
+                          int32_t *out_found);
+
+/*
+ * queries      [n_queries][dim] f32, row major (host)
+ * k            results per query (limit = from + length, vector_sort.rs:68-71)
+ * filter_bits  nullable; bit i (LSB-first in 64-bit words) set = docid i allowed
+ *              (dense form of the RoaringBitmap `filter`, store.rs:641-643)
+ * cancel       nullable; polled between kernel phases; non-zero → MSI_E_CANCELLED
+ *              (hannoy's cancellation closure, store.rs:1085-1086)
+ * out_docids   [n_queries][k]   out_dist [n_queries][k]   out_counts [n_queries]
+ */
+int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries,
+                      uint32_t k, const uint64_t *filter_bits,
+                      uint64_t filter_nbits, const volatile int32_t *cancel,
+                      uint32_t *out_docids, float *out_dist,
+                      uint32_t *out_counts);
+
+/* Device-pointer variant: all pointers are device memory, work is enqueued on
+ * msi_ctx_stream() and NOT synchronised.  n_queries <= 16 per call (one MFMA
+ * query tile).  `d_inexact[n_queries]` (nullable) receives 1 where the
+ * exactness proof failed and the host variant would have re-run exhaustively. */
+int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries,
+                             uint32_t n_queries, uint32_t k,
+                             const uint64_t *d_filter_bits,
+                             uint64_t filter_nbits, uint32_t *d_out_docids,
+                             float *d_out_dist, uint32_t *d_out_counts,
+                             uint32_t *d_inexact);
+
+/* Introspection for benchmarks/tests. */
+typedef struct msi_vs_stats {
+  uint64_t scan_launches;      /* vs_scan kernel launches so far           */
+  uint64_t scan_tiles;         /* 16-row tiles streamed by those launches  */
+  uint64_t exhaustive_reruns;  /* queries that needed the exhaustive path  */
+  uint64_t bytes_per_tile;     /* algorithmic HBM bytes per tile           */
+} msi_vs_stats;
+int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out);
+/* Accumulated duration of the main-pass vs_scan launches recorded while
+ * profiling was enabled (HIP events on the launch stream); resets the counters. */
+int32_t msi_vs_scan_time(msi_vs *vs, uint64_t *out_launches, double *out_ms_total);
+
+/* --------------------------------------------- S2: typo-tolerant term lookup */
+/*
+ * Replaces find_one_typo_derivations / find_one_two_typo_derivations
+ * (crates/milli/src/search/new/query_term/compute_derivations.rs:75-168):
+ * Levenshtein-DFA(transposition=1 edit) ∩ words FST, with the first-letter
+ * rule and the 150/50 caps (search/new/limits.rs:7-9).
+ */
+int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat,
+                        const uint32_t *offsets /* n_words+1 */,
+                        uint32_t n_words /* byte-lexicographic, unique, UTF-8 */,
+                        msi_dict **out);
+void msi_dict_destroy(msi_dict *dict);
+uint32_t msi_dict_len(const msi_dict *dict);
+
+typedef struct msi_typo_query {
+  const uint8_t *word; /* normalised query word, UTF-8, not NUL terminated */
+  uint32_t len;        /* bytes, 1..250 (MAX_WORD_LENGTH, milli/src/lib.rs) */
+  uint8_t max_typos;   /* 1 or 2 (budget 0 never reaches the dictionary)   */
+  uint8_t is_prefix;   /* build_prefix_dfa vs build_dfa (search/mod.rs:565-577) */
+  uint16_t _pad;
+} msi_typo_query;
+
+/*
+ * out_one_idx [n][cap_one], out_two_idx [n][cap_two]: dictionary indices in
+ * ascending (= byte-lexicographic = fst stream) order; out_*_cnt [n].
+ * cap_one/cap_two are MAX_ONE_TYPO_COUNT / MAX_TWO_TYPOS_COUNT (150 / 50).
+ */
+int32_t msi_dict_lookup(msi_dict *dict, const msi_typo_query *queries,
+                        uint32_t n, uint32_t cap_one, uint32_t cap_two,
+                        uint32_t *out_one_idx, uint32_t *out_one_cnt,
+                        uint32_t *out_two_idx, uint32_t *out_two_cnt);
+
+/* Packed device-side form: words are concatenated in `d_qbytes`, described by
+ * d_qoff[n+1], d_qflags[n] = max_typos | is_prefix<<2.  Outputs are device
+ * memory; work is enqueued on msi_ctx_stream() and NOT synchronised. */
+int32_t msi_dict_lookup_device(msi_dict *dict, const uint8_t *d_qbytes,
+                               const uint32_t *d_qoff, const uint8_t *d_qflags,
+                               uint32_t n, uint32_t cap_one, uint32_t cap_two,
+                               uint32_t *d_out_one_idx, uint32_t *d_out_one_cnt,
+                               uint32_t *d_out_two_idx, uint32_t *d_out_two_cnt);
+
+typedef struct msi_dict_stats {
+  uint64_t lookup_launches;
+  uint64_t pairs_scanned;   /* (query, word) pairs that reached a kernel lane */
+  uint64_t dict_bytes;      /* HBM bytes of the staged dictionary            */
+} msi_dict_stats;
+int32_t msi_dict_get_stats(const msi_dict *dict, msi_dict_stats *out);
+int32_t msi_dict_match_time(msi_dict *dict, uint64_t *out_launches, double *out_ms_total);
+
+/* ------------------------------------------------- S3: dense docid-set algebra */
+/*
+ * Device replacement for the RoaringBitmap algebra of the ranking-rule graph
+ * (compute_query_term_subset_docids, resolve_query_graph.rs:33-59; the ∩/∪/−
+ * of visit_path_condition, graph_based_ranking_rule.rs:383-437; bucket_sort's
+ * universe bookkeeping, bucket_sort.rs:23-343).  A pool holds `n_slots` dense
+ * sets of `n_docs` bits each; slot ids are the handles.
+ */
+int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots,
+                        msi_bits **out);
+void msi_bits_destroy(msi_bits *pool);
+/* slot := {docids}; docids need not be sorted. */
+int32_t msi_bits_set_from_docids(msi_bits *pool, uint32_t slot,
+                                 const uint32_t *docids, uint64_t n);
+/* slot := decode of a CboRoaringBitmapCodec value
+ * (heed_codec/roaring_bitmap/cbo_roaring_bitmap_codec.rs:53-85). */
+int32_t msi_bits_set_from_cbo(msi_bits *pool, uint32_t slot,
+                              const uint8_t *bytes, size_t len);
+int32_t msi_bits_set_from_words(msi_bits *pool, uint32_t slot,
+                                const uint64_t *words, uint64_t n_words);
+int32_t msi_bits_fill(msi_bits *pool, uint32_t slot, int32_t ones);
+enum { MSI_BITS_AND = 0, MSI_BITS_OR = 1, MSI_BITS_ANDNOT = 2, MSI_BITS_XOR = 3 };
+/* dst := a OP b */
+int32_t msi_bits_op(msi_bits *pool, uint32_t dst, uint32_t a, uint32_t b,
+                    int32_t op);
+/* dst := (OR of srcs[0..n)) AND universe   (universe == UINT32_MAX: no AND) */
+int32_t msi_bits_union_many_and(msi_bits *pool, uint32_t dst,
+                                const uint32_t *srcs, uint32_t n,
+                                uint32_t universe);
+int32_t msi_bits_count(msi_bits *pool, uint32_t slot, uint64_t *out);
+/* first (ascending) `k` docids of the set; returns how many were written. */
+int32_t msi_bits_first_k(msi_bits *pool, uint32_t slot, uint32_t k,
+                         uint32_t *out_docids, uint32_t *out_n);
+int32_t msi_bits_read_words(msi_bits *pool, uint32_t slot, uint64_t *out_words);
+/* Device address of a slot (n_docs bits, 64-bit words) — e.g. as the
+ * `d_filter_bits` of msi_vs_search_device. */
+const uint64_t *msi_bits_device_ptr(msi_bits *pool, uint32_t slot);
+
+/* ---------------------------------------------------- scoring arithmetic (host) */
+/* DistributionShift::shift (crates/milli/src/vector/distribution.rs:103-130). */
+float msi_distribution_shift(float mean, float sigma, float score);
+/* Rank::merge folded over (rank,max_rank) pairs then local_score
+ * (crates/milli/src/score_details.rs:512-547). */
+double msi_rank_global_score(const uint32_t *ranks, const uint32_t *max_ranks,
+                             uint32_t n);
+/* compare_scores restricted to ScoreValue::Score lists
+ * (crates/milli/src/search/hybrid.rs:32-80): returns -1/0/+1. */
+int32_t msi_compare_scores(const double *left, uint32_t n_left, float left_ratio,
+                           const double *right, uint32_t n_right,
+                           float right_ratio);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSI_H */

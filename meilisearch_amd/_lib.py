@@ -1,0 +1,114 @@
+"""ctypes binding of include/msi.h.  Loud failure if libmsi.so is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK = 0
+ERRORS = {
+    -1: "MSI_E_INVALID", -2: "MSI_E_NO_DEVICE", -3: "MSI_E_HIP", -4: "MSI_E_OOM",
+    -5: "MSI_E_UNSUPPORTED", -6: "MSI_E_CANCELLED", -7: "MSI_E_NOT_SORTED", -8: "MSI_E_INTERNAL",
+}
+
+
+class MsiError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{ERRORS.get(status, status)}: {message}")
+        self.status = status
+
+
+class TypoQuery(C.Structure):
+    _fields_ = [("word", C.c_void_p), ("len", C.c_uint32), ("max_typos", C.c_uint8),
+                ("is_prefix", C.c_uint8), ("_pad", C.c_uint16)]
+
+
+class VsStats(C.Structure):
+    _fields_ = [("scan_launches", C.c_uint64), ("scan_tiles", C.c_uint64),
+                ("exhaustive_reruns", C.c_uint64), ("bytes_per_tile", C.c_uint64)]
+
+
+class DictStats(C.Structure):
+    _fields_ = [("lookup_launches", C.c_uint64), ("pairs_scanned", C.c_uint64),
+                ("dict_bytes", C.c_uint64)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmsi.so")
+
+
+# name -> (restype, argtypes); every symbol include/msi.h declares
+_VP = C.c_void_p
+_U32, _U64, _I32, _F32, _F64 = C.c_uint32, C.c_uint64, C.c_int32, C.c_float, C.c_double
+PROTOTYPES = {
+    "msi_abi_version": (_I32, []),
+    "msi_last_error": (C.c_char_p, []),
+    "msi_ctx_create": (_I32, [_I32, C.POINTER(_VP)]),
+    "msi_ctx_destroy": (None, [_VP]),
+    "msi_ctx_stream": (_VP, [_VP]),
+    "msi_ctx_synchronize": (_I32, [_VP]),
+    "msi_ctx_device": (_I32, [_VP]),
+    "msi_ctx_set_profiling": (_I32, [_VP, _I32]),
+    "msi_vs_create": (_I32, [_VP, _U32, C.POINTER(_VP)]),
+    "msi_vs_destroy": (None, [_VP]),
+    "msi_vs_upload": (_I32, [_VP, _VP, _VP, _U64]),
+    "msi_vs_upload_device": (_I32, [_VP, _VP, _VP, _U64]),
+    "msi_vs_len": (_U64, [_VP]),
+    "msi_vs_dim": (_U32, [_VP]),
+    "msi_vs_get_vector": (_I32, [_VP, _U32, _VP, C.POINTER(_I32)]),
+    "msi_vs_search": (_I32, [_VP, _VP, _U32, _U32, _VP, _U64, _VP, _VP, _VP, _VP]),
+    "msi_vs_search_device": (_I32, [_VP, _VP, _U32, _U32, _VP, _U64, _VP, _VP, _VP, _VP]),
+    "msi_vs_get_stats": (_I32, [_VP, C.POINTER(VsStats)]),
+    "msi_vs_scan_time": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_F64)]),
+    "msi_dict_create": (_I32, [_VP, _VP, _VP, _U32, C.POINTER(_VP)]),
+    "msi_dict_destroy": (None, [_VP]),
+    "msi_dict_len": (_U32, [_VP]),
+    "msi_dict_lookup": (_I32, [_VP, C.POINTER(TypoQuery), _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
+    "msi_dict_lookup_device": (_I32, [_VP, _VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
+    "msi_dict_get_stats": (_I32, [_VP, C.POINTER(DictStats)]),
+    "msi_dict_match_time": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_F64)]),
+    "msi_bits_create": (_I32, [_VP, _U64, _U32, C.POINTER(_VP)]),
+    "msi_bits_destroy": (None, [_VP]),
+    "msi_bits_set_from_docids": (_I32, [_VP, _U32, _VP, _U64]),
+    "msi_bits_set_from_cbo": (_I32, [_VP, _U32, _VP, C.c_size_t]),
+    "msi_bits_set_from_words": (_I32, [_VP, _U32, _VP, _U64]),
+    "msi_bits_fill": (_I32, [_VP, _U32, _I32]),
+    "msi_bits_op": (_I32, [_VP, _U32, _U32, _U32, _I32]),
+    "msi_bits_union_many_and": (_I32, [_VP, _U32, _VP, _U32, _U32]),
+    "msi_bits_count": (_I32, [_VP, _U32, C.POINTER(_U64)]),
+    "msi_bits_first_k": (_I32, [_VP, _U32, _U32, _VP, C.POINTER(_U32)]),
+    "msi_bits_read_words": (_I32, [_VP, _U32, _VP]),
+    "msi_bits_device_ptr": (_VP, [_VP, _U32]),
+    "msi_distribution_shift": (_F32, [_F32, _F32, _F32]),
+    "msi_rank_global_score": (_F64, [_VP, _VP, _U32]),
+    "msi_compare_scores": (_I32, [_VP, _U32, _F32, _VP, _U32, _F32]),
+}
+
+
+def lib():
+    """Load libmsi.so.  No fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  meilisearch_amd has no CPU fallback.")
+        L = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        if L.msi_abi_version() != 1:
+            raise ImportError(f"libmsi ABI {L.msi_abi_version()} != 1")
+        _LIB = L
+    return _LIB
+
+
+def abi_version():
+    return lib().msi_abi_version()
+
+
+def check(status):
+    if status != OK:
+        raise MsiError(status, lib().msi_last_error().decode("utf-8", "replace"))

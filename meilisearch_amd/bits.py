@@ -1,0 +1,76 @@
+"""Python binding of the dense docid-set pool (S3 seam, msi_bits_*)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+from .device import np_ptr
+
+AND, OR, ANDNOT, XOR = 0, 1, 2, 3
+NO_UNIVERSE = 0xFFFFFFFF
+
+
+class BitsPool:
+    def __init__(self, ctx, n_docs, n_slots):
+        self.ctx = ctx
+        self.n_docs = int(n_docs)
+        self.n_slots = int(n_slots)
+        self._h = C.c_void_p()
+        check(lib().msi_bits_create(ctx.handle, self.n_docs, self.n_slots, C.byref(self._h)))
+
+    def set_from_docids(self, slot, docids):
+        d = np.ascontiguousarray(docids, dtype=np.uint32)
+        check(lib().msi_bits_set_from_docids(self._h, slot, np_ptr(d) if d.size else None, d.size))
+
+    def set_from_cbo(self, slot, data):
+        b = np.frombuffer(bytes(data), dtype=np.uint8)
+        check(lib().msi_bits_set_from_cbo(self._h, slot, np_ptr(b) if b.size else None, b.size))
+
+    def set_from_words(self, slot, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        check(lib().msi_bits_set_from_words(self._h, slot, np_ptr(w) if w.size else None, w.size))
+
+    def fill(self, slot, ones):
+        check(lib().msi_bits_fill(self._h, slot, 1 if ones else 0))
+
+    def op(self, dst, a, b, op):
+        check(lib().msi_bits_op(self._h, dst, a, b, op))
+
+    def union_many_and(self, dst, srcs, universe=NO_UNIVERSE):
+        s = np.ascontiguousarray(srcs, dtype=np.uint32)
+        check(lib().msi_bits_union_many_and(self._h, dst, np_ptr(s) if s.size else None, s.size, universe))
+
+    def count(self, slot):
+        out = C.c_uint64(0)
+        check(lib().msi_bits_count(self._h, slot, C.byref(out)))
+        return int(out.value)
+
+    def first_k(self, slot, k):
+        out = np.zeros(max(k, 1), dtype=np.uint32)
+        n = C.c_uint32(0)
+        check(lib().msi_bits_first_k(self._h, slot, k, np_ptr(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def read_words(self, slot):
+        out = np.zeros((self.n_docs + 63) // 64 or 1, dtype=np.uint64)
+        check(lib().msi_bits_read_words(self._h, slot, np_ptr(out)))
+        return out[:(self.n_docs + 63) // 64]
+
+    def to_docids(self, slot):
+        w = self.read_words(slot)
+        bits = np.unpackbits(w.view(np.uint8), bitorder="little")[:self.n_docs]
+        return np.nonzero(bits)[0].astype(np.uint32)
+
+    def device_ptr(self, slot):
+        return lib().msi_bits_device_ptr(self._h, slot)
+
+    def close(self):
+        if self._h:
+            lib().msi_bits_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,500 @@
+// msi_bits.hip — S3: dense docid-set algebra in HBM, gfx950.
+//
+// Device replacement for the RoaringBitmap algebra on milli's ranking path:
+// compute_query_term_subset_docids (search/new/resolve_query_graph.rs:33-59),
+// the ∩/∪/− of visit_path_condition (graph_based_ranking_rule.rs:383-437) and
+// bucket_sort's universe bookkeeping (bucket_sort.rs:23-343).  A pool owns
+// n_slots dense sets of n_docs bits; every operation is one HBM-bound pass of
+// 16-byte loads/stores (algorithmic bytes = words touched x 8).
+//
+// Posting lists arrive in milli's on-disk form (CboRoaringBitmapCodec,
+// heed_codec/roaring_bitmap/cbo_roaring_bitmap_codec.rs:53-85) and are decoded
+// on the device: the host only parses the container headers of the standard
+// Roaring serialisation (RoaringFormatSpec: cookies 12346 / 12347).
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "msi_common.h"
+
+typedef unsigned long long u64;
+
+struct msi_bits {
+  msi_ctx *ctx = nullptr;
+  uint64_t n_docs = 0;
+  uint64_t n_words = 0;  // per slot, multiple of 2 (16-byte vector access)
+  uint32_t n_slots = 0;
+  DevBuf pool, tmp, small, stage, desc;
+  u64 *slot(uint32_t s) const { return pool.as<u64>() + (uint64_t)s * n_words; }
+};
+
+namespace {
+
+constexpr int BT = 256;
+
+struct Container {
+  uint32_t key;     // high 16 bits of the docids
+  uint32_t type;    // 0 array, 1 bitmap, 2 run
+  uint32_t card;    // array: #values, run: #runs
+  uint32_t offset;  // byte offset of the body inside the staged buffer
+};
+
+__global__ void bits_fill_kernel(u64 *__restrict__ dst, uint64_t n_words, uint64_t n_docs, int ones) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_words) return;
+  u64 v = 0;
+  if (ones) {
+    uint64_t lo = i * 64;
+    if (lo + 64 <= n_docs) v = ~0ull;
+    else if (lo < n_docs) v = (~0ull) >> (64 - (n_docs - lo));
+  }
+  dst[i] = v;
+}
+
+template <int OP>
+__global__ void bits_op_kernel(u64 *__restrict__ dst, const u64 *__restrict__ a,
+                               const u64 *__restrict__ b, uint64_t n_pairs) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n_pairs; i += stride) {
+    const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(a)[i];
+    const ulonglong2 y = reinterpret_cast<const ulonglong2 *>(b)[i];
+    ulonglong2 r;
+    if (OP == MSI_BITS_AND) { r.x = x.x & y.x; r.y = x.y & y.y; }
+    else if (OP == MSI_BITS_OR) { r.x = x.x | y.x; r.y = x.y | y.y; }
+    else if (OP == MSI_BITS_ANDNOT) { r.x = x.x & ~y.x; r.y = x.y & ~y.y; }
+    else { r.x = x.x ^ y.x; r.y = x.y ^ y.y; }
+    reinterpret_cast<ulonglong2 *>(dst)[i] = r;
+  }
+}
+
+// dst = (OR_i pool[srcs[i]]) & pool[universe]
+__global__ void bits_union_many_kernel(u64 *__restrict__ pool, uint64_t n_words, uint32_t dst,
+                                       const uint32_t *__restrict__ srcs, uint32_t n, uint32_t universe) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t n_pairs = n_words / 2;
+  for (; i < n_pairs; i += stride) {
+    ulonglong2 acc = make_ulonglong2(0, 0);
+    for (uint32_t s = 0; s < n; ++s) {
+      const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(pool + (uint64_t)srcs[s] * n_words)[i];
+      acc.x |= v.x;
+      acc.y |= v.y;
+    }
+    if (universe != 0xFFFFFFFFu) {
+      const ulonglong2 u = reinterpret_cast<const ulonglong2 *>(pool + (uint64_t)universe * n_words)[i];
+      acc.x &= u.x;
+      acc.y &= u.y;
+    }
+    reinterpret_cast<ulonglong2 *>(pool + (uint64_t)dst * n_words)[i] = acc;
+  }
+}
+
+__global__ void bits_count_kernel(const u64 *__restrict__ a, uint64_t n_words, u64 *__restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t c = 0;
+  for (; i < n_words; i += stride) c += __popcll(a[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (u64)c);
+}
+
+__global__ void bits_set_docids_kernel(u64 *__restrict__ dst, uint64_t n_docs,
+                                       const uint32_t *__restrict__ ids, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t id = ids[i];
+  if ((uint64_t)id < n_docs) atomicOr(&dst[id >> 6], 1ull << (id & 63));
+}
+
+// One block per Roaring container.
+__global__ void bits_decode_roaring_kernel(u64 *__restrict__ dst, uint64_t n_docs,
+                                           const uint8_t *__restrict__ bytes,
+                                           const Container *__restrict__ cs) {
+  const Container c = cs[blockIdx.x];
+  const uint64_t base = (uint64_t)c.key << 16;
+  const uint8_t *body = bytes + c.offset;
+  if (c.type == 0) {
+    for (uint32_t i = threadIdx.x; i < c.card; i += blockDim.x) {
+      const uint64_t id = base + ((uint32_t)body[2 * i] | ((uint32_t)body[2 * i + 1] << 8));
+      if (id < n_docs) atomicOr(&dst[id >> 6], 1ull << (id & 63));
+    }
+  } else if (c.type == 1) {
+    for (uint32_t w = threadIdx.x; w < 1024; w += blockDim.x) {
+      u64 v = 0;
+      for (int b = 0; b < 8; ++b) v |= (u64)body[8 * w + b] << (8 * b);
+      const uint64_t wi = (base >> 6) + w;
+      if (v && wi * 64 < n_docs) atomicOr(&dst[wi], v);
+    }
+  } else {
+    for (uint32_t r = 0; r < c.card; ++r) {
+      const uint32_t start = (uint32_t)body[4 * r] | ((uint32_t)body[4 * r + 1] << 8);
+      const uint32_t len = ((uint32_t)body[4 * r + 2] | ((uint32_t)body[4 * r + 3] << 8)) + 1;
+      for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint64_t id = base + start + i;
+        if (id < n_docs) atomicOr(&dst[id >> 6], 1ull << (id & 63));
+      }
+    }
+  }
+}
+
+// first_k: (1) per-block popcounts, (2) single-block exclusive scan, (3) emit.
+__global__ void bits_block_counts_kernel(const u64 *__restrict__ a, uint64_t n_words,
+                                         uint32_t *__restrict__ blk) {
+  __shared__ uint32_t sh[BT / 64];
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = i < n_words ? __popcll(a[i]) : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < BT / 64; ++w) t += sh[w];
+    blk[blockIdx.x] = t;
+  }
+}
+
+__global__ void bits_scan_counts_kernel(uint32_t *__restrict__ blk, uint32_t n_blocks,
+                                        uint32_t *__restrict__ total) {
+  // single block; serial over chunks of blockDim.x
+  __shared__ uint32_t sh[BT];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_blocks; base += BT) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n_blocks ? blk[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t o = 1; o < BT; o <<= 1) {
+      uint32_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const uint32_t incl = sh[threadIdx.x];
+    if (i < n_blocks) blk[i] = carry + incl - v;  // exclusive
+    __syncthreads();
+    if (threadIdx.x == BT - 1) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void bits_emit_first_k_kernel(const u64 *__restrict__ a, uint64_t n_words,
+                                         const uint32_t *__restrict__ blk_excl, uint32_t k,
+                                         uint32_t *__restrict__ out) {
+  __shared__ uint32_t sh[BT];
+  const uint32_t blk_base = blk_excl[blockIdx.x];
+  if (blk_base >= k) return;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 w = i < n_words ? a[i] : 0;
+  const uint32_t c = __popcll(w);
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (uint32_t o = 1; o < BT; o <<= 1) {
+    uint32_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t rank = blk_base + sh[threadIdx.x] - c;
+  while (w && rank < k) {
+    const uint32_t b = __ffsll((long long)w) - 1;
+    out[rank++] = (uint32_t)(i * 64 + b);
+    w &= w - 1;
+  }
+}
+
+uint32_t grid_for(uint64_t n, uint32_t cap_blocks) {
+  uint64_t b = (n + BT - 1) / BT;
+  if (b < 1) b = 1;
+  return (uint32_t)std::min<uint64_t>(b, cap_blocks);
+}
+
+int32_t check_slot(const msi_bits *p, uint32_t s, const char *what) {
+  if (!p || s >= p->n_slots) {
+    msi_set_error("%s: slot %u out of range", what, s);
+    return MSI_E_INVALID;
+  }
+  return MSI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bits **out) {
+  if (!ctx || !out || n_slots == 0) {
+    msi_set_error("msi_bits_create: invalid argument");
+    return MSI_E_INVALID;
+  }
+  *out = nullptr;
+  DeviceGuard g(ctx->device);
+  msi_bits *p = new msi_bits();
+  p->ctx = ctx;
+  p->n_docs = n_docs;
+  p->n_words = std::max<uint64_t>(2, ((n_docs + 127) / 128) * 2);
+  p->n_slots = n_slots;
+  int32_t s = p->pool.ensure((size_t)p->n_words * n_slots * sizeof(u64));
+  if (s == MSI_OK) s = p->small.ensure(64);
+  if (s != MSI_OK) {
+    p->pool.release();
+    delete p;
+    return s;
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  hipError_t e = hipMemsetAsync(p->pool.p, 0, (size_t)p->n_words * n_slots * sizeof(u64), ctx->stream);
+  if (e != hipSuccess) {
+    msi_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+    p->pool.release();
+    delete p;
+    return MSI_E_HIP;
+  }
+  *out = p;
+  return MSI_OK;
+}
+
+void msi_bits_destroy(msi_bits *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->stream);
+  p->pool.release();
+  p->tmp.release();
+  p->small.release();
+  p->stage.release();
+  p->desc.release();
+  delete p;
+}
+
+int32_t msi_bits_fill(msi_bits *p, uint32_t slot, int32_t ones) {
+  MSI_TRY(check_slot(p, slot, "msi_bits_fill"));
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  hipLaunchKernelGGL(bits_fill_kernel, dim3((uint32_t)((p->n_words + BT - 1) / BT)), dim3(BT), 0,
+                     p->ctx->stream, p->slot(slot), p->n_words, p->n_docs, ones);
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+int32_t msi_bits_set_from_docids(msi_bits *p, uint32_t slot, const uint32_t *docids, uint64_t n) {
+  MSI_TRY(check_slot(p, slot, "msi_bits_set_from_docids"));
+  if (n && !docids) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->ctx->stream;
+  MSI_HIP_TRY(hipMemsetAsync(p->slot(slot), 0, p->n_words * sizeof(u64), st));
+  if (n) {
+    MSI_TRY(p->stage.ensure(n * sizeof(uint32_t)));
+    MSI_HIP_TRY(hipMemcpyAsync(p->stage.p, docids, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bits_set_docids_kernel, dim3((uint32_t)((n + BT - 1) / BT)), dim3(BT), 0, st,
+                       p->slot(slot), p->n_docs, p->stage.as<uint32_t>(), n);
+    MSI_HIP_TRY(hipGetLastError());
+    MSI_HIP_TRY(hipStreamSynchronize(st));  // docids is borrowed only for the call
+  }
+  return MSI_OK;
+}
+
+int32_t msi_bits_set_from_words(msi_bits *p, uint32_t slot, const uint64_t *words, uint64_t n_words) {
+  MSI_TRY(check_slot(p, slot, "msi_bits_set_from_words"));
+  if (n_words > p->n_words || (n_words && !words)) {
+    msi_set_error("msi_bits_set_from_words: %llu words > slot size %llu", (unsigned long long)n_words,
+                  (unsigned long long)p->n_words);
+    return MSI_E_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->ctx->stream;
+  MSI_HIP_TRY(hipMemsetAsync(p->slot(slot), 0, p->n_words * sizeof(u64), st));
+  if (n_words) MSI_HIP_TRY(hipMemcpyAsync(p->slot(slot), words, n_words * sizeof(u64), hipMemcpyHostToDevice, st));
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  return MSI_OK;
+}
+
+// CboRoaringBitmapCodec::deserialize_from (cbo_roaring_bitmap_codec.rs:53-69).
+int32_t msi_bits_set_from_cbo(msi_bits *p, uint32_t slot, const uint8_t *bytes, size_t len) {
+  MSI_TRY(check_slot(p, slot, "msi_bits_set_from_cbo"));
+  if (len && !bytes) return MSI_E_INVALID;
+  const size_t THRESHOLD = 7;  // cbo_roaring_bitmap_codec.rs:15
+  if (len <= THRESHOLD * sizeof(uint32_t)) {
+    // native-endian u32s; a trailing partial integer is ignored (read_u32 fails)
+    uint32_t ids[THRESHOLD];
+    const size_t n = len / 4;
+    memcpy(ids, bytes, n * 4);
+    return msi_bits_set_from_docids(p, slot, ids, n);
+  }
+  // Standard Roaring serialisation (portable format).
+  auto rd16 = [&](size_t o) -> uint32_t { return (uint32_t)bytes[o] | ((uint32_t)bytes[o + 1] << 8); };
+  auto rd32 = [&](size_t o) -> uint32_t { return rd16(o) | (rd16(o + 2) << 16); };
+  size_t pos = 0;
+  if (len < 8) goto corrupt;
+  {
+    const uint32_t cookie = rd32(0);
+    uint32_t n_cont = 0;
+    bool has_runs = false;
+    const uint8_t *run_flags = nullptr;
+    if ((cookie & 0xFFFF) == 12347) {
+      has_runs = true;
+      n_cont = (cookie >> 16) + 1;
+      pos = 4;
+      run_flags = bytes + pos;
+      pos += (n_cont + 7) / 8;
+    } else if (cookie == 12346) {
+      n_cont = rd32(4);
+      pos = 8;
+    } else {
+      goto corrupt;
+    }
+    if (n_cont > 65536 || pos + (size_t)n_cont * 4 > len) goto corrupt;
+    std::vector<Container> cs(n_cont);
+    for (uint32_t i = 0; i < n_cont; ++i) {
+      cs[i].key = rd16(pos + 4 * i);
+      cs[i].card = rd16(pos + 4 * i + 2) + 1;
+      const bool is_run = has_runs && ((run_flags[i / 8] >> (i % 8)) & 1);
+      cs[i].type = is_run ? 2 : (cs[i].card > 4096 ? 1 : 0);
+    }
+    pos += (size_t)n_cont * 4;
+    if (!has_runs || n_cont >= 4) pos += (size_t)n_cont * 4;  // offset header (recomputed below)
+    for (uint32_t i = 0; i < n_cont; ++i) {
+      if (pos > len) goto corrupt;
+      cs[i].offset = (uint32_t)pos;
+      if (cs[i].type == 0) pos += (size_t)cs[i].card * 2;
+      else if (cs[i].type == 1) pos += 8192;
+      else {
+        if (pos + 2 > len) goto corrupt;
+        const uint32_t n_runs = rd16(pos);
+        cs[i].offset = (uint32_t)pos + 2;
+        cs[i].card = n_runs;
+        pos += 2 + (size_t)n_runs * 4;
+      }
+    }
+    if (pos > len) goto corrupt;
+    std::lock_guard<std::mutex> lk(p->ctx->mu);
+    DeviceGuard g(p->ctx->device);
+    hipStream_t st = p->ctx->stream;
+    MSI_HIP_TRY(hipMemsetAsync(p->slot(slot), 0, p->n_words * sizeof(u64), st));
+    if (n_cont) {
+      MSI_TRY(p->stage.ensure(len));
+      MSI_TRY(p->desc.ensure(n_cont * sizeof(Container)));
+      MSI_HIP_TRY(hipMemcpyAsync(p->stage.p, bytes, len, hipMemcpyHostToDevice, st));
+      MSI_HIP_TRY(hipMemcpyAsync(p->desc.p, cs.data(), n_cont * sizeof(Container), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(bits_decode_roaring_kernel, dim3(n_cont), dim3(BT), 0, st, p->slot(slot), p->n_docs,
+                         p->stage.as<uint8_t>(), p->desc.as<Container>());
+      MSI_HIP_TRY(hipGetLastError());
+    }
+    MSI_HIP_TRY(hipStreamSynchronize(st));
+    return MSI_OK;
+  }
+corrupt:
+  msi_set_error("msi_bits_set_from_cbo: malformed Roaring serialisation (%zu bytes)", len);
+  return MSI_E_INVALID;
+}
+
+int32_t msi_bits_op(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int32_t op) {
+  MSI_TRY(check_slot(p, dst, "msi_bits_op"));
+  MSI_TRY(check_slot(p, a, "msi_bits_op"));
+  MSI_TRY(check_slot(p, b, "msi_bits_op"));
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  const uint64_t n_pairs = p->n_words / 2;
+  const dim3 grid(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 8)), block(BT);
+  hipStream_t st = p->ctx->stream;
+  switch (op) {
+    case MSI_BITS_AND:
+      hipLaunchKernelGGL(bits_op_kernel<MSI_BITS_AND>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs);
+      break;
+    case MSI_BITS_OR:
+      hipLaunchKernelGGL(bits_op_kernel<MSI_BITS_OR>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs);
+      break;
+    case MSI_BITS_ANDNOT:
+      hipLaunchKernelGGL(bits_op_kernel<MSI_BITS_ANDNOT>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs);
+      break;
+    case MSI_BITS_XOR:
+      hipLaunchKernelGGL(bits_op_kernel<MSI_BITS_XOR>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs);
+      break;
+    default:
+      msi_set_error("msi_bits_op: unknown op %d", op);
+      return MSI_E_INVALID;
+  }
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+int32_t msi_bits_union_many_and(msi_bits *p, uint32_t dst, const uint32_t *srcs, uint32_t n, uint32_t universe) {
+  MSI_TRY(check_slot(p, dst, "msi_bits_union_many_and"));
+  if (universe != 0xFFFFFFFFu) MSI_TRY(check_slot(p, universe, "msi_bits_union_many_and"));
+  for (uint32_t i = 0; i < n; ++i) MSI_TRY(check_slot(p, srcs[i], "msi_bits_union_many_and"));
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->ctx->stream;
+  MSI_TRY(p->desc.ensure(std::max<uint32_t>(1, n) * sizeof(uint32_t)));
+  if (n) MSI_HIP_TRY(hipMemcpyAsync(p->desc.p, srcs, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(bits_union_many_kernel, dim3(grid_for(p->n_words / 2, (uint32_t)p->ctx->n_cu * 8)), dim3(BT),
+                     0, st, p->pool.as<u64>(), p->n_words, dst, p->desc.as<uint32_t>(), n, universe);
+  MSI_HIP_TRY(hipGetLastError());
+  MSI_HIP_TRY(hipStreamSynchronize(st));  // srcs is borrowed; desc is reused
+  return MSI_OK;
+}
+
+int32_t msi_bits_count(msi_bits *p, uint32_t slot, uint64_t *out) {
+  MSI_TRY(check_slot(p, slot, "msi_bits_count"));
+  if (!out) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->ctx->stream;
+  MSI_HIP_TRY(hipMemsetAsync(p->small.p, 0, sizeof(u64), st));
+  hipLaunchKernelGGL(bits_count_kernel, dim3(grid_for(p->n_words, (uint32_t)p->ctx->n_cu * 8)), dim3(BT), 0, st,
+                     p->slot(slot), p->n_words, p->small.as<u64>());
+  MSI_HIP_TRY(hipGetLastError());
+  u64 v = 0;
+  MSI_HIP_TRY(hipMemcpyAsync(&v, p->small.p, sizeof(u64), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  *out = v;
+  return MSI_OK;
+}
+
+int32_t msi_bits_first_k(msi_bits *p, uint32_t slot, uint32_t k, uint32_t *out_docids, uint32_t *out_n) {
+  MSI_TRY(check_slot(p, slot, "msi_bits_first_k"));
+  if (!out_n || (k && !out_docids)) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->ctx->stream;
+  const uint32_t n_blocks = (uint32_t)((p->n_words + BT - 1) / BT);
+  MSI_TRY(p->tmp.ensure(((size_t)n_blocks + std::max<uint32_t>(1, k)) * sizeof(uint32_t)));
+  uint32_t *blk = p->tmp.as<uint32_t>();
+  uint32_t *d_out = blk + n_blocks;
+  hipLaunchKernelGGL(bits_block_counts_kernel, dim3(n_blocks), dim3(BT), 0, st, p->slot(slot), p->n_words, blk);
+  hipLaunchKernelGGL(bits_scan_counts_kernel, dim3(1), dim3(BT), 0, st, blk, n_blocks, p->small.as<uint32_t>() + 4);
+  if (k) hipLaunchKernelGGL(bits_emit_first_k_kernel, dim3(n_blocks), dim3(BT), 0, st, p->slot(slot), p->n_words, blk, k, d_out);
+  MSI_HIP_TRY(hipGetLastError());
+  uint32_t total = 0;
+  MSI_HIP_TRY(hipMemcpyAsync(&total, p->small.as<uint32_t>() + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  const uint32_t n = std::min(total, k);
+  if (n) MSI_HIP_TRY(hipMemcpy(out_docids, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  *out_n = n;
+  return MSI_OK;
+}
+
+int32_t msi_bits_read_words(msi_bits *p, uint32_t slot, uint64_t *out_words) {
+  MSI_TRY(check_slot(p, slot, "msi_bits_read_words"));
+  if (!out_words) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->ctx->stream;
+  const uint64_t words = (p->n_docs + 63) / 64;
+  if (words) MSI_HIP_TRY(hipMemcpyAsync(out_words, p->slot(slot), words * sizeof(u64), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  return MSI_OK;
+}
+
+const uint64_t *msi_bits_device_ptr(msi_bits *p, uint32_t slot) {
+  if (!p || slot >= p->n_slots) return nullptr;
+  return (const uint64_t *)p->slot(slot);
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// msi_common.h — internal helpers shared by the libmsi translation units.
+// gfx950 (MI355X / CDNA4) only: 64-wide wavefronts are assumed everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/msi.h"
+
+#define MSI_WAVE 64
+
+void msi_set_error(const char *fmt, ...);
+
+#define MSI_HIP_TRY(expr)                                                          \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      msi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                    __LINE__);                                                     \
+      return _e == hipErrorOutOfMemory ? MSI_E_OOM : MSI_E_HIP;                    \
+    }                                                                              \
+  } while (0)
+
+#define MSI_TRY(expr)              \
+  do {                             \
+    int32_t _s = (expr);           \
+    if (_s != MSI_OK) return _s;   \
+  } while (0)
+
+struct msi_ctx {
+  int device = 0;
+  int n_cu = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;  // serialises use of the stream + per-object scratch
+  bool profiling = false;
+};
+
+// HIP-event bracket around one kernel (only when msi_ctx::profiling).
+struct KernelTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_;
+  hipEvent_t cur_start = nullptr, cur_stop = nullptr;
+  void begin(msi_ctx *ctx) {
+    if (!ctx->profiling) return;
+    if (free_.empty()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      free_.push_back({a, b});
+    }
+    cur_start = free_.back().first;
+    cur_stop = free_.back().second;
+    free_.pop_back();
+    (void)hipEventRecord(cur_start, ctx->stream);
+  }
+  void end(msi_ctx *ctx) {
+    if (!cur_start) return;
+    (void)hipEventRecord(cur_stop, ctx->stream);
+    pending.push_back({cur_start, cur_stop});
+    cur_start = cur_stop = nullptr;
+  }
+  // stream must be synchronised by the caller
+  void drain(uint64_t *launches, double *ms) {
+    *launches = 0;
+    *ms = 0.0;
+    for (auto &p : pending) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) {
+        *ms += t;
+        ++*launches;
+      }
+      free_.push_back(p);
+    }
+    pending.clear();
+  }
+  void release() {
+    for (auto &p : pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : free_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    pending.clear();
+    free_.clear();
+  }
+};
+
+// Growable device buffer (never shrinks); not thread-safe by itself (callers
+// hold msi_ctx::mu).
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int32_t ensure(size_t bytes) {
+    if (bytes <= cap) return MSI_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      msi_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+      p = nullptr;
+      return MSI_E_OOM;
+    }
+    cap = want;
+    return MSI_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T *as() const {
+    return reinterpret_cast<T *>(p);
+  }
+};
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// ---- device helpers -------------------------------------------------------
+
+// Monotone map f32 -> u32 (a < b  <=>  ord(a) < ord(b), -0 < +0, NaNs at the ends).
+__host__ __device__ inline uint32_t f32_to_ord(float f) {
+  uint32_t b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  b = __float_as_uint(f);
+#else
+  memcpy(&b, &f, 4);
+#endif
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float ord_to_f32(uint32_t o) {
+  uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(b);
+#else
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+#endif
+}
+
+static inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }

@@ -1,0 +1,136 @@
+// msi_ctx.hip — context (device + stream), error string, host-side scoring
+// arithmetic entry points of include/msi.h.
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "msi_common.h"
+
+static thread_local char g_err[512] = "";
+
+void msi_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+int32_t msi_abi_version(void) { return MSI_ABI_VERSION; }
+const char *msi_last_error(void) { return g_err; }
+
+int32_t msi_ctx_create(int32_t device, msi_ctx **out) {
+  if (!out) {
+    msi_set_error("msi_ctx_create: out is NULL");
+    return MSI_E_INVALID;
+  }
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    msi_set_error("no HIP device available (%s); libmsi has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return MSI_E_NO_DEVICE;
+  }
+  if (device < 0) {
+    const char *lr = getenv("LOCAL_RANK");
+    device = lr ? atoi(lr) % count : 0;
+  }
+  if (device >= count) {
+    msi_set_error("device %d out of range (count %d)", device, count);
+    return MSI_E_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  MSI_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    msi_set_error("device %d is %s; libmsi is built for gfx950 (MI355X) only", device,
+                  prop.gcnArchName);
+    return MSI_E_NO_DEVICE;
+  }
+  DeviceGuard g(device);
+  msi_ctx *c = new msi_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    msi_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete c;
+    return MSI_E_HIP;
+  }
+  *out = c;
+  return MSI_OK;
+}
+
+void msi_ctx_destroy(msi_ctx *ctx) {
+  if (!ctx) return;
+  DeviceGuard g(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+}
+
+void *msi_ctx_stream(msi_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int32_t msi_ctx_device(msi_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int32_t msi_ctx_set_profiling(msi_ctx *ctx, int32_t enable) {
+  if (!ctx) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->profiling = enable != 0;
+  return MSI_OK;
+}
+
+int32_t msi_ctx_synchronize(msi_ctx *ctx) {
+  if (!ctx) return MSI_E_INVALID;
+  DeviceGuard g(ctx->device);
+  MSI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MSI_OK;
+}
+
+// ---- scoring arithmetic (host; these run on the Rust caller's thread) -------
+
+// DistributionShift::shift — crates/milli/src/vector/distribution.rs:103-130.
+float msi_distribution_shift(float mean, float sigma, float score) {
+  const float target_mean = 0.5f, target_sigma = 0.4f;
+  volatile float factor = target_sigma / sigma;
+  volatile float fm = factor * mean;  // volatile: keep mul and add unfused
+  float offset = target_mean - fm;
+  volatile float fs = factor * score;
+  float s = fs + offset;
+  if (s <= 0.0f) s = FLT_EPSILON;
+  if (s > 1.0f) s = 1.0f;
+  return s;
+}
+
+// Rank::global_score — crates/milli/src/score_details.rs:517-546.
+double msi_rank_global_score(const uint32_t *ranks, const uint32_t *max_ranks, uint32_t n) {
+  uint32_t rank = 1, max_rank = 1;
+  for (uint32_t i = 0; i < n; ++i) {
+    rank = rank ? rank - 1 : 0;  // saturating_sub(1)
+    rank *= max_ranks[i];
+    max_rank *= max_ranks[i];
+    rank += ranks[i];
+  }
+  return (double)rank / (double)max_rank;
+}
+
+// compare_scores over ScoreValue::Score sequences — search/hybrid.rs:32-80.
+int32_t msi_compare_scores(const double *left, uint32_t n_left, float left_ratio,
+                           const double *right, uint32_t n_right, float right_ratio) {
+  for (uint32_t i = 0;; ++i) {
+    bool hl = i < n_left, hr = i < n_right;
+    if (!hl && !hr) return 0;
+    if (!hl) return -1;
+    if (!hr) return 1;
+    double a = left[i] * (double)left_ratio;
+    double b = right[i] * (double)right_ratio;
+    if (fabs(a - b) <= DBL_EPSILON) continue;
+    return a < b ? -1 : 1;
+  }
+}
+
+}  // extern "C"

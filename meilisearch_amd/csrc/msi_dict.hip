@@ -1,0 +1,795 @@
+// msi_dict.hip — S2: batched typo-tolerant term lookup over the words
+// dictionary staged in HBM, gfx950.
+//
+// Replaces find_one_typo_derivations / find_one_two_typo_derivations
+// (crates/milli/src/search/new/query_term/compute_derivations.rs:75-168), i.e.
+// `fst.search_with_state(Levenshtein DFA ∩/∪ StartsWith)` with the 150/50 caps
+// (search/new/limits.rs:7-9).  Design:
+//
+//   HBM layout  the sorted dictionary is staged as 16-byte slots (one word per
+//               slot, zero padded) + byte/char lengths; words longer than 16
+//               bytes keep their bytes in a flat side array and are matched by a
+//               second, much smaller launch of the same kernel.
+//   dict_match  one lane per dictionary word, 64 consecutive words per wave tile,
+//               words live in registers as a 128-bit byte queue while the wave
+//               loops over the queries of its chunk.  Distance = banded (2k+1
+//               diagonals) optimal-string-alignment DP over code points, all lanes
+//               in lock step so the query characters are wave-uniform scalars.
+//               The first-letter rule turns into index ranges: the words that
+//               share the query's first char are one contiguous range [lo,hi) of
+//               the sorted dictionary; outside it only "distance <= 1" can match
+//               and a 3-compare prefilter removes almost every word.
+//   ordering    every wave owns a contiguous dictionary segment, so ballots +
+//               v_mbcnt give per-segment lists already in fst stream order;
+//               dict_finalize concatenates segments and applies the cap logic.
+//
+// Closed form of the reference's sequential cap logic (derived in DESIGN.md):
+//   S1/S2 = same-first-char words at distance exactly 1 / 2, X = other-first-char
+//   words at distance <= 1, all in dictionary order;
+//   two  = first cap_two of (X ∪ S2);  t* = its last element if it is full;
+//   one  = first cap_one of (S1 ∪ {x in X : x > t*}).
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "msi_common.h"
+
+typedef unsigned long long u64;
+
+namespace {
+
+constexpr int QC = 32;            // queries per wave chunk
+constexpr int DW = 4;             // waves per workgroup
+constexpr int QSTRIDE = 256;      // code points reserved per query
+constexpr int DINF = 1 << 20;
+
+struct QueryMeta {
+  uint32_t m;        // chars
+  uint32_t budget;   // 1 or 2 (0 = skip)
+  uint32_t prefix;
+  uint32_t q0, q1;   // first two code points (q1 = 0xFFFFFFFF when m < 2)
+  uint32_t lo, hi;   // dictionary range of words starting with q0
+  uint32_t _pad;
+};
+
+__device__ __forceinline__ uint32_t utf8_len(uint32_t b0) {
+  return b0 < 0x80 ? 1u : (b0 < 0xE0 ? 2u : (b0 < 0xF0 ? 3u : 4u));
+}
+
+// ---- word readers ----------------------------------------------------------
+
+// 16-byte word held in registers as a little-endian byte queue.
+template <bool ASCII>
+struct SlotReader {
+  uint32_t w0, w1, w2, w3;
+  __device__ __forceinline__ uint32_t next_char() {
+    const uint32_t lo = w0;
+    const uint32_t b0 = lo & 0xFF;
+    if (ASCII) {
+      w0 = __funnelshift_r(w0, w1, 8);
+      w1 = __funnelshift_r(w1, w2, 8);
+      w2 = __funnelshift_r(w2, w3, 8);
+      w3 >>= 8;
+      return b0;
+    }
+    const uint32_t clen = utf8_len(b0);
+    const uint32_t b1 = (lo >> 8) & 0x3F, b2 = (lo >> 16) & 0x3F, b3 = (lo >> 24) & 0x3F;
+    const uint32_t cp2 = ((b0 & 0x1F) << 6) | b1;
+    const uint32_t cp3 = ((b0 & 0x0F) << 12) | (b1 << 6) | b2;
+    const uint32_t cp4 = ((b0 & 0x07) << 18) | (b1 << 12) | (b2 << 6) | b3;
+    const uint32_t cp = clen == 1 ? b0 : (clen == 2 ? cp2 : (clen == 3 ? cp3 : cp4));
+    const uint32_t sh = (clen - 1) * 8;  // 0..24, then a constant 8
+    uint32_t a0 = __funnelshift_r(w0, w1, sh), a1 = __funnelshift_r(w1, w2, sh),
+             a2 = __funnelshift_r(w2, w3, sh), a3 = w3 >> sh;
+    w0 = __funnelshift_r(a0, a1, 8);
+    w1 = __funnelshift_r(a1, a2, 8);
+    w2 = __funnelshift_r(a2, a3, 8);
+    w3 = a3 >> 8;
+    return cp;
+  }
+};
+
+// Word of any length read byte-wise from the flat dictionary bytes (long words).
+struct FlatReader {
+  const uint8_t *p;
+  const uint8_t *end;
+  __device__ __forceinline__ uint32_t next_char() {
+    if (p >= end) return 0;
+    const uint32_t b0 = *p;
+    const uint32_t clen = utf8_len(b0);
+    uint32_t cp = clen == 1 ? b0 : (clen == 2 ? (b0 & 0x1F) : (clen == 3 ? (b0 & 0x0F) : (b0 & 0x07)));
+    for (uint32_t e = 1; e < clen; ++e) cp = (cp << 6) | ((p + e < end ? p[e] : 0) & 0x3F);
+    p += clen;
+    return cp;
+  }
+};
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Banded optimal-string-alignment distance (insert / delete / substitute /
+// adjacent transposition, each cost 1 — levenshtein_automata 0.2.1 with
+// transposition_cost_one = true, crates/milli/src/search/mod.rs:32-34) between
+// the query chars qc[0..m) and the lane's word (nch chars), exact whenever the
+// true value is <= K.  prefix: minimum over the prefixes of the word
+// (build_prefix_dfa, search/mod.rs:572-573).  Returns > K when not matched.
+// All lanes step through the word positions together; `qc` and `m` are
+// wave-uniform.
+template <int K, class Reader>
+__device__ __forceinline__ int osa_banded(Reader rd, int nch, bool active,
+                                          const uint32_t *__restrict__ qc, int m, bool prefix) {
+  constexpr int W = 2 * K + 1;
+  int prev2[W], prev[W], cur[W];
+#pragma unroll
+  for (int d = 0; d < W; ++d) {
+    prev2[d] = DINF;
+    const int i = d - K;
+    prev[d] = (i >= 0 && i <= m) ? i : DINF;
+  }
+  int best = (prefix && m <= K) ? m : DINF;  // the empty prefix
+  const int ne = active ? min(nch, m + K) : 0;
+  const int nmax = wave_max_i32(ne);
+  uint32_t wprev = 0xFFFFFFFEu;
+  for (int j = 1; j <= nmax; ++j) {
+    const uint32_t wc = rd.next_char();
+    const bool upd = j <= ne;
+    int bandmin = DINF;
+#pragma unroll
+    for (int d = 0; d < W; ++d) {
+      const int i = j + d - K;  // wave-uniform
+      int v;
+      if (i < 0 || i > m) {
+        v = DINF;
+      } else if (i == 0) {
+        v = j;
+      } else {
+        const uint32_t qi = qc[i - 1];
+        v = prev[d] + (qi != wc ? 1 : 0);
+        if (d > 0) v = min(v, cur[d - 1] + 1);
+        if (d < W - 1) v = min(v, prev[d + 1] + 1);
+        if (i >= 2 && j >= 2) {
+          const uint32_t qim = qc[i - 2];
+          if (qi == wprev && qim == wc) v = min(v, prev2[d] + 1);
+        }
+      }
+      cur[d] = v;
+      bandmin = min(bandmin, v);
+    }
+#pragma unroll
+    for (int d = 0; d < W; ++d) {
+      prev2[d] = upd ? prev[d] : prev2[d];
+      prev[d] = upd ? cur[d] : prev[d];
+    }
+    wprev = upd ? wc : wprev;
+    if (prefix) {
+      const int dm = m - j + K;  // wave-uniform
+#pragma unroll
+      for (int d = 0; d < W; ++d)
+        if (dm == d && upd) best = min(best, cur[d]);
+    }
+    if (!__any(upd && bandmin <= K)) break;  // every still-running lane is out of budget
+  }
+  if (prefix) return best;
+  const int dm = m - nch + K;  // per lane
+  int res = DINF;
+#pragma unroll
+  for (int d = 0; d < W; ++d)
+    if (dm == d) res = prev[d];
+  return (active && nch <= m + K) ? res : DINF;
+}
+
+// ---- matching kernel -----------------------------------------------------------
+
+struct DictArgs {
+  const uint4 *slots;       // [n_words]
+  const uint8_t *blen;      // [n_words] byte length
+  const uint8_t *nchars;    // [n_words] char count
+  const uint8_t *flat;      // concatenated bytes
+  const uint32_t *offs;     // [n_words+1]
+  const uint32_t *long_idx; // [n_long] indices of words longer than 16 bytes (ascending)
+  uint32_t n_words;
+  uint32_t n_items;         // words handled by this launch (n_words or n_long)
+  const QueryMeta *qm;      // [nq]
+  const uint32_t *qchars;   // [nq][QSTRIDE]
+  uint32_t nq;
+  uint32_t nseg;
+  uint32_t cap1, cap2, capx;
+  uint32_t *lists;          // [nq][nseg][cap1+cap2+capx]
+  uint32_t *cnts;           // [nq][nseg][3]
+  u64 *pairs;               // stats: (query, word) pairs that reached a lane
+};
+
+template <bool LONG>
+__global__ __launch_bounds__(DW * 64) void dict_match_kernel(DictArgs a) {
+  __shared__ uint32_t s_cnt[DW][QC][3];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t gw = blockIdx.x * DW + wave;
+  const uint32_t seg = gw % a.nseg;
+  const uint32_t chunk = gw / a.nseg;
+  const uint32_t q_begin = chunk * QC;
+  if (q_begin >= a.nq) return;
+  const uint32_t q_end = min(a.nq, q_begin + QC);
+  for (uint32_t i = lane; i < QC * 3; i += 64) (&s_cnt[wave][0][0])[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+
+  const uint32_t n_tiles = (a.n_items + 63) / 64;
+  const uint32_t t0 = (uint32_t)((u64)n_tiles * seg / a.nseg);
+  const uint32_t t1 = (uint32_t)((u64)n_tiles * (seg + 1) / a.nseg);
+  const uint32_t stride_l = a.cap1 + a.cap2 + a.capx;
+  u64 pairs = 0;
+
+  for (uint32_t t = t0; t < t1; ++t) {
+    const uint32_t item = t * 64 + lane;
+    const bool in_range = item < a.n_items;
+    uint32_t idx = 0xFFFFFFFFu;
+    if (in_range) idx = LONG ? a.long_idx[item] : item;
+    uint32_t bl = 0, nc = 0;
+    uint4 slot = make_uint4(0, 0, 0, 0);
+    if (in_range) {
+      bl = a.blen[idx];
+      nc = a.nchars[idx];
+      slot = a.slots[idx];
+    }
+    // words longer than a slot belong to the LONG launch; empty words never match
+    const bool mine = in_range && bl > 0 && (LONG ? true : bl <= 16);
+    const bool tile_ascii = !LONG && (__ballot(mine && nc != bl) == 0);
+    // first two chars (prefilter of the other-first-char class)
+    uint32_t wc0, wc1;
+    {
+      SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
+      wc0 = r.next_char();
+      wc1 = nc >= 2 ? r.next_char() : 0xFFFFFFFDu;
+    }
+    // dictionary index range covered by this tile (ascending within the tile)
+    const uint32_t idx_first = __shfl(idx, 0);
+    uint32_t idx_last = idx;
+    {
+      const u64 bm = __ballot(in_range);
+      const int last_lane = 63 - __clzll((long long)bm);
+      idx_last = __shfl(idx, last_lane);
+    }
+
+    for (uint32_t q = q_begin; q < q_end; ++q) {
+      const QueryMeta qm = a.qm[q];
+      if (qm.budget == 0) continue;
+      const int m = (int)qm.m;
+      const bool prefix = qm.prefix != 0;
+      const uint32_t *qc = a.qchars + (size_t)q * QSTRIDE;
+      const bool tile_hits_s = idx_last >= qm.lo && idx_first < qm.hi;
+      const bool tile_all_s = idx_first >= qm.lo && idx_last < qm.hi;
+      const bool same_first = mine && idx >= qm.lo && idx < qm.hi;
+      bool f1 = false, f2 = false, fx = false;
+
+      // --- same first char: exact distance with the budget's automaton --------
+      if (tile_hits_s) {
+        const int K = (int)qm.budget;
+        const bool act = same_first && (prefix ? (int)nc + K >= m : ((int)nc + K >= m && (int)nc <= m + K));
+        if (__any(act)) {
+          int d;
+          if (LONG) {
+            FlatReader r{a.flat + a.offs[in_range ? idx : 0], a.flat + a.offs[in_range ? idx + 1 : 0]};
+            d = K == 1 ? osa_banded<1>(r, (int)nc, act, qc, m, prefix) : osa_banded<2>(r, (int)nc, act, qc, m, prefix);
+          } else if (tile_ascii) {
+            SlotReader<true> r{slot.x, slot.y, slot.z, slot.w};
+            d = K == 1 ? osa_banded<1>(r, (int)nc, act, qc, m, prefix) : osa_banded<2>(r, (int)nc, act, qc, m, prefix);
+          } else {
+            SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
+            d = K == 1 ? osa_banded<1>(r, (int)nc, act, qc, m, prefix) : osa_banded<2>(r, (int)nc, act, qc, m, prefix);
+          }
+          f1 = act && d == 1;
+          f2 = act && K == 2 && d == 2;
+          pairs += __popcll(__ballot(act));
+        }
+      }
+      // --- other first char (budget 2 only): distance <= 1 ------------------------
+      if (qm.budget == 2 && !tile_all_s) {
+        bool cand = mine && !same_first;
+        if (m >= 3) cand = cand && (wc0 == qm.q1 || wc1 == qm.q1 || wc1 == qm.q0);
+        cand = cand && (prefix ? (int)nc + 1 >= m : ((int)nc + 1 >= m && (int)nc <= m + 1));
+        if (__any(cand)) {
+          int d;
+          if (LONG) {
+            FlatReader r{a.flat + a.offs[in_range ? idx : 0], a.flat + a.offs[in_range ? idx + 1 : 0]};
+            d = osa_banded<1>(r, (int)nc, cand, qc, m, prefix);
+          } else if (tile_ascii) {
+            SlotReader<true> r{slot.x, slot.y, slot.z, slot.w};
+            d = osa_banded<1>(r, (int)nc, cand, qc, m, prefix);
+          } else {
+            SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
+            d = osa_banded<1>(r, (int)nc, cand, qc, m, prefix);
+          }
+          fx = cand && d <= 1;
+          pairs += __popcll(__ballot(cand));
+        }
+      }
+      // --- ordered append (lanes ascend with the dictionary index) ----------------
+      const uint32_t ql = q - q_begin;
+      uint32_t *lst = a.lists + ((size_t)q * a.nseg + seg) * stride_l;
+      const u64 lower = (1ull << lane) - 1ull;
+      {
+        const u64 mk = __ballot(f1);
+        if (mk) {
+          const uint32_t base = s_cnt[wave][ql][0];
+          const uint32_t pos = base + __popcll(mk & lower);
+          if (f1 && pos < a.cap1) lst[pos] = idx;
+          if (lane == 0) s_cnt[wave][ql][0] = base + __popcll(mk);
+        }
+      }
+      {
+        const u64 mk = __ballot(f2);
+        if (mk) {
+          const uint32_t base = s_cnt[wave][ql][1];
+          const uint32_t pos = base + __popcll(mk & lower);
+          if (f2 && pos < a.cap2) lst[a.cap1 + pos] = idx;
+          if (lane == 0) s_cnt[wave][ql][1] = base + __popcll(mk);
+        }
+      }
+      {
+        const u64 mk = __ballot(fx);
+        if (mk) {
+          const uint32_t base = s_cnt[wave][ql][2];
+          const uint32_t pos = base + __popcll(mk & lower);
+          if (fx && pos < a.capx) lst[a.cap1 + a.cap2 + pos] = idx;
+          if (lane == 0) s_cnt[wave][ql][2] = base + __popcll(mk);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = lane; i < (q_end - q_begin) * 3; i += 64) {
+    const uint32_t ql = i / 3, c = i % 3;
+    const uint32_t cap = c == 0 ? a.cap1 : (c == 1 ? a.cap2 : a.capx);
+    a.cnts[((size_t)(q_begin + ql) * a.nseg + seg) * 3 + c] = min(s_cnt[wave][ql][c], cap);
+  }
+  if (lane == 0 && pairs) atomicAdd(a.pairs, pairs);
+}
+
+// ---- query preparation -------------------------------------------------------------
+
+// One thread per query: decode UTF-8, derive the first-char dictionary range.
+__global__ void dict_prep_kernel(const uint8_t *__restrict__ qbytes, const uint32_t *__restrict__ qoff,
+                                 const uint8_t *__restrict__ qflags, uint32_t nq,
+                                 const uint4 *__restrict__ slots, uint32_t n_words,
+                                 QueryMeta *__restrict__ qm, uint32_t *__restrict__ qchars) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const uint8_t *s = qbytes + qoff[q];
+  const uint32_t len = qoff[q + 1] - qoff[q];
+  QueryMeta r;
+  r.m = 0;
+  r.budget = 0;
+  r.prefix = (qflags[q] >> 2) & 1;
+  r.q0 = r.q1 = 0xFFFFFFFFu;
+  r.lo = r.hi = 0;
+  r._pad = 0;
+  const uint32_t bud = qflags[q] & 3;
+  if (len >= 1 && len <= 250 && bud >= 1) {  // MAX_WORD_LENGTH, compute_derivations.rs:180-192
+    uint32_t *out = qchars + (size_t)q * QSTRIDE;
+    uint32_t n = 0, i = 0;
+    while (i < len) {
+      const uint32_t b0 = s[i];
+      const uint32_t cl = utf8_len(b0);
+      uint32_t cp = cl == 1 ? b0 : (cl == 2 ? (b0 & 0x1F) : (cl == 3 ? (b0 & 0x0F) : (b0 & 0x07)));
+      for (uint32_t e = 1; e < cl; ++e) cp = (cp << 6) | ((i + e < len ? s[i + e] : 0) & 0x3F);
+      i += cl;
+      out[n++] = cp;
+    }
+    r.m = n;
+    r.budget = bud > 2 ? 2 : bud;
+    r.q0 = out[0];
+    if (n >= 2) r.q1 = out[1];
+    // words starting with the first char: compare the first c0len bytes (big endian)
+    const uint32_t c0len = utf8_len(s[0]);
+    uint32_t key = 0;
+    for (uint32_t e = 0; e < c0len; ++e) key = (key << 8) | (e < len ? s[e] : 0);
+    auto head = [&](uint32_t idx) -> uint32_t {
+      const uint32_t w = slots[idx].x;  // little-endian bytes 0..3
+      uint32_t v = 0;
+      for (uint32_t e = 0; e < c0len; ++e) v = (v << 8) | ((w >> (8 * e)) & 0xFF);
+      return v;
+    };
+    uint32_t lo = 0, hi = n_words;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (head(mid) < key) lo = mid + 1;
+      else hi = mid;
+    }
+    r.lo = lo;
+    hi = n_words;
+    uint32_t l2 = lo;
+    while (l2 < hi) {
+      const uint32_t mid = l2 + (hi - l2) / 2;
+      if (head(mid) <= key) l2 = mid + 1;
+      else hi = mid;
+    }
+    r.hi = l2;
+  }
+  qm[q] = r;
+}
+
+// ---- finalisation --------------------------------------------------------------------
+
+// Sequential reader over the per-segment lists of one class, merged (by
+// dictionary index) with the long-word launch's lists of the same class.
+struct ClassStream {
+  const uint32_t *lists;
+  const uint32_t *cnts;
+  uint32_t nseg, stride_l, off, c;
+  uint32_t seg, pos;
+  __device__ void init(const uint32_t *l, const uint32_t *cn, uint32_t ns, uint32_t st, uint32_t o, uint32_t cls) {
+    lists = l; cnts = cn; nseg = ns; stride_l = st; off = o; c = cls; seg = 0; pos = 0;
+    skip();
+  }
+  __device__ void skip() {
+    while (seg < nseg && pos >= cnts[seg * 3 + c]) { ++seg; pos = 0; }
+  }
+  __device__ bool done() const { return seg >= nseg; }
+  __device__ uint32_t peek() const { return lists[(size_t)seg * stride_l + off + pos]; }
+  __device__ void pop() { ++pos; skip(); }
+};
+
+struct MergedStream {  // main ∪ long, ascending
+  ClassStream a, b;
+  __device__ bool done() const { return a.done() && b.done(); }
+  __device__ uint32_t peek() const {
+    if (a.done()) return b.peek();
+    if (b.done()) return a.peek();
+    const uint32_t x = a.peek(), y = b.peek();
+    return x < y ? x : y;
+  }
+  __device__ void pop() {
+    if (a.done()) { b.pop(); return; }
+    if (b.done()) { a.pop(); return; }
+    if (a.peek() < b.peek()) a.pop(); else b.pop();
+  }
+};
+
+struct FinalArgs {
+  const QueryMeta *qm;
+  const uint32_t *lists, *cnts;       // main launch
+  const uint32_t *llists, *lcnts;     // long-word launch
+  uint32_t nq, nseg, lnseg, cap1, cap2, capx;
+  uint32_t *out_one, *out_one_cnt, *out_two, *out_two_cnt;
+};
+
+__global__ void dict_finalize_kernel(FinalArgs f) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= f.nq) return;
+  uint32_t *one = f.out_one + (size_t)q * f.cap1;
+  uint32_t *two = f.out_two + (size_t)q * f.cap2;
+  uint32_t n1 = 0, n2 = 0;
+  if (f.qm[q].budget != 0) {
+    const uint32_t st = f.cap1 + f.cap2 + f.capx;
+    auto mk = [&](uint32_t cls, uint32_t off) {
+      MergedStream s;
+      s.a.init(f.lists + (size_t)q * f.nseg * st, f.cnts + (size_t)q * f.nseg * 3, f.nseg, st, off, cls);
+      s.b.init(f.llists + (size_t)q * f.lnseg * st, f.lcnts + (size_t)q * f.lnseg * 3, f.lnseg, st, off, cls);
+      return s;
+    };
+    // two = first cap2 of (X ∪ S2)
+    uint32_t tstar = 0xFFFFFFFFu;
+    {
+      MergedStream s2 = mk(1, f.cap1), sx = mk(2, f.cap1 + f.cap2);
+      while (n2 < f.cap2 && !(s2.done() && sx.done())) {
+        uint32_t v;
+        if (s2.done()) { v = sx.peek(); sx.pop(); }
+        else if (sx.done()) { v = s2.peek(); s2.pop(); }
+        else if (s2.peek() < sx.peek()) { v = s2.peek(); s2.pop(); }
+        else { v = sx.peek(); sx.pop(); }
+        two[n2++] = v;
+      }
+      if (n2 == f.cap2 && n2 > 0) tstar = two[n2 - 1];
+    }
+    // one = first cap1 of (S1 ∪ {x in X : x > t*})
+    {
+      MergedStream s1 = mk(0, 0), sx = mk(2, f.cap1 + f.cap2);
+      if (tstar == 0xFFFFFFFFu) {
+        while (!sx.done()) sx.pop();  // two never filled: no X word reaches `one`
+      } else {
+        while (!sx.done() && sx.peek() <= tstar) sx.pop();
+      }
+      while (n1 < f.cap1 && !(s1.done() && sx.done())) {
+        uint32_t v;
+        if (s1.done()) { v = sx.peek(); sx.pop(); }
+        else if (sx.done()) { v = s1.peek(); s1.pop(); }
+        else if (s1.peek() < sx.peek()) { v = s1.peek(); s1.pop(); }
+        else { v = sx.peek(); sx.pop(); }
+        one[n1++] = v;
+      }
+    }
+  }
+  f.out_one_cnt[q] = n1;
+  f.out_two_cnt[q] = n2;
+}
+
+}  // namespace
+
+// ================================================================== host object
+
+struct msi_dict {
+  msi_ctx *ctx = nullptr;
+  uint32_t n_words = 0, n_long = 0;
+  DevBuf slots, blen, nchars, flat, offs, long_idx;
+  // scratch (guarded by ctx->mu)
+  DevBuf qbytes, qoff, qflags, qm, qchars, lists, cnts, llists, lcnts, pairs, out1, out1c, out2, out2c;
+  uint64_t lookup_launches = 0, dict_bytes = 0;
+  KernelTimer match_timer;
+};
+
+namespace {
+
+int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_qoff, const uint8_t *d_qflags,
+                       uint32_t n, uint32_t cap1, uint32_t cap2, uint32_t *d_one, uint32_t *d_one_cnt,
+                       uint32_t *d_two, uint32_t *d_two_cnt) {
+  msi_ctx *ctx = d->ctx;
+  hipStream_t st = ctx->stream;
+  if (cap1 == 0 || cap2 == 0 || cap1 > 4096 || cap2 > 4096) {
+    msi_set_error("msi_dict_lookup: caps must be in 1..4096");
+    return MSI_E_INVALID;
+  }
+  const uint32_t capx = cap1 + cap2;
+  const uint32_t stride_l = cap1 + cap2 + capx;
+  MSI_TRY(d->qm.ensure((size_t)n * sizeof(QueryMeta)));
+  MSI_TRY(d->qchars.ensure((size_t)n * QSTRIDE * sizeof(uint32_t)));
+  hipLaunchKernelGGL(dict_prep_kernel, dim3((n + 127) / 128), dim3(128), 0, st, d_qbytes, d_qoff, d_qflags, n,
+                     d->slots.as<uint4>(), d->n_words, d->qm.as<QueryMeta>(), d->qchars.as<uint32_t>());
+  const uint32_t nchunks = (n + QC - 1) / QC;
+  const uint32_t target_waves = (uint32_t)ctx->n_cu * 16;
+  auto seg_for = [&](uint32_t n_items) -> uint32_t {
+    const uint32_t n_tiles = std::max<uint32_t>(1, (n_items + 63) / 64);
+    uint32_t nseg = (target_waves + nchunks - 1) / nchunks;
+    // bound the scratch lists to ~256 MiB
+    const uint64_t per_seg = (uint64_t)n * stride_l * sizeof(uint32_t);
+    const uint32_t mem_cap = (uint32_t)std::max<uint64_t>(1, (256ull << 20) / std::max<uint64_t>(1, per_seg));
+    nseg = std::min(nseg, mem_cap);
+    return std::max<uint32_t>(1, std::min(nseg, n_tiles));
+  };
+  const uint32_t nseg = seg_for(d->n_words);
+  const uint32_t lnseg = seg_for(d->n_long);
+  MSI_TRY(d->lists.ensure((size_t)n * nseg * stride_l * sizeof(uint32_t)));
+  MSI_TRY(d->cnts.ensure((size_t)n * nseg * 3 * sizeof(uint32_t)));
+  MSI_TRY(d->llists.ensure((size_t)n * lnseg * stride_l * sizeof(uint32_t)));
+  MSI_TRY(d->lcnts.ensure((size_t)n * lnseg * 3 * sizeof(uint32_t)));
+  MSI_HIP_TRY(hipMemsetAsync(d->lcnts.p, 0, (size_t)n * lnseg * 3 * sizeof(uint32_t), st));
+  MSI_HIP_TRY(hipMemsetAsync(d->cnts.p, 0, (size_t)n * nseg * 3 * sizeof(uint32_t), st));
+  DictArgs a;
+  a.slots = d->slots.as<uint4>();
+  a.blen = d->blen.as<uint8_t>();
+  a.nchars = d->nchars.as<uint8_t>();
+  a.flat = d->flat.as<uint8_t>();
+  a.offs = d->offs.as<uint32_t>();
+  a.long_idx = d->long_idx.as<uint32_t>();
+  a.n_words = d->n_words;
+  a.qm = d->qm.as<QueryMeta>();
+  a.qchars = d->qchars.as<uint32_t>();
+  a.nq = n;
+  a.cap1 = cap1;
+  a.cap2 = cap2;
+  a.capx = capx;
+  a.pairs = d->pairs.as<u64>();
+  if (d->n_words) {
+    a.n_items = d->n_words;
+    a.nseg = nseg;
+    a.lists = d->lists.as<uint32_t>();
+    a.cnts = d->cnts.as<uint32_t>();
+    const uint32_t waves = nseg * nchunks;
+    d->match_timer.begin(ctx);
+    hipLaunchKernelGGL(dict_match_kernel<false>, dim3((waves + DW - 1) / DW), dim3(DW * 64), 0, st, a);
+    d->match_timer.end(ctx);
+  }
+  if (d->n_long) {
+    a.n_items = d->n_long;
+    a.nseg = lnseg;
+    a.lists = d->llists.as<uint32_t>();
+    a.cnts = d->lcnts.as<uint32_t>();
+    const uint32_t waves = lnseg * nchunks;
+    hipLaunchKernelGGL(dict_match_kernel<true>, dim3((waves + DW - 1) / DW), dim3(DW * 64), 0, st, a);
+  }
+  FinalArgs f;
+  f.qm = d->qm.as<QueryMeta>();
+  f.lists = d->lists.as<uint32_t>();
+  f.cnts = d->cnts.as<uint32_t>();
+  f.llists = d->llists.as<uint32_t>();
+  f.lcnts = d->lcnts.as<uint32_t>();
+  f.nq = n;
+  f.nseg = nseg;
+  f.lnseg = lnseg;
+  f.cap1 = cap1;
+  f.cap2 = cap2;
+  f.capx = capx;
+  f.out_one = d_one;
+  f.out_one_cnt = d_one_cnt;
+  f.out_two = d_two;
+  f.out_two_cnt = d_two_cnt;
+  hipLaunchKernelGGL(dict_finalize_kernel, dim3((n + 63) / 64), dim3(64), 0, st, f);
+  MSI_HIP_TRY(hipGetLastError());
+  d->lookup_launches++;
+  return MSI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_t *offsets, uint32_t n_words,
+                        msi_dict **out) {
+  if (!ctx || !out || (n_words && (!words_concat || !offsets))) {
+    msi_set_error("msi_dict_create: invalid argument");
+    return MSI_E_INVALID;
+  }
+  *out = nullptr;
+  // host-side staging: slots, lengths, long-word list; sortedness check
+  std::vector<uint4> slots(std::max<uint32_t>(1, n_words));
+  std::vector<uint8_t> blen(std::max<uint32_t>(1, n_words)), nch(std::max<uint32_t>(1, n_words));
+  std::vector<uint32_t> long_idx;
+  for (uint32_t i = 0; i < n_words; ++i) {
+    const uint32_t o = offsets[i], len = offsets[i + 1] - o;
+    if (offsets[i + 1] < o || len > 255) {
+      msi_set_error("msi_dict_create: word %u has invalid length %u (max 255 bytes)", i, len);
+      return MSI_E_INVALID;
+    }
+    const uint8_t *w = words_concat + o;
+    if (i > 0) {
+      const uint32_t po = offsets[i - 1], pl = o - po;
+      const int c = memcmp(words_concat + po, w, std::min(pl, len));
+      if (c > 0 || (c == 0 && pl >= len)) {
+        msi_set_error("msi_dict_create: words must be byte-lexicographically sorted and unique (at %u)", i);
+        return MSI_E_NOT_SORTED;
+      }
+    }
+    uint8_t buf[16] = {0};
+    memcpy(buf, w, std::min<uint32_t>(len, 16));
+    memcpy(&slots[i], buf, 16);
+    blen[i] = (uint8_t)len;
+    uint32_t chars = 0;
+    for (uint32_t b = 0; b < len; ++b) chars += (w[b] & 0xC0) != 0x80;
+    nch[i] = (uint8_t)chars;
+    if (len > 16) long_idx.push_back(i);
+  }
+  DeviceGuard g(ctx->device);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  msi_dict *d = new msi_dict();
+  d->ctx = ctx;
+  d->n_words = n_words;
+  d->n_long = (uint32_t)long_idx.size();
+  const size_t flat_bytes = n_words ? offsets[n_words] : 0;
+  hipStream_t st = ctx->stream;
+  int32_t s = MSI_OK;
+  auto up = [&](DevBuf &b, const void *src, size_t bytes) {
+    if (s != MSI_OK) return;
+    s = b.ensure(std::max<size_t>(16, bytes));
+    if (s == MSI_OK && bytes) {
+      hipError_t e = hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) {
+        msi_set_error("hipMemcpyAsync failed: %s", hipGetErrorString(e));
+        s = MSI_E_HIP;
+      }
+    }
+  };
+  up(d->slots, slots.data(), (size_t)n_words * sizeof(uint4));
+  up(d->blen, blen.data(), n_words);
+  up(d->nchars, nch.data(), n_words);
+  up(d->flat, words_concat, flat_bytes);
+  up(d->offs, offsets, ((size_t)n_words + 1) * sizeof(uint32_t));
+  up(d->long_idx, long_idx.data(), long_idx.size() * sizeof(uint32_t));
+  if (s == MSI_OK) s = d->pairs.ensure(sizeof(u64));
+  if (s == MSI_OK && hipMemsetAsync(d->pairs.p, 0, sizeof(u64), st) != hipSuccess) s = MSI_E_HIP;
+  if (s == MSI_OK && hipStreamSynchronize(st) != hipSuccess) {
+    msi_set_error("msi_dict_create: stream synchronize failed");
+    s = MSI_E_HIP;
+  }
+  if (s != MSI_OK) {
+    DevBuf *bufs[] = {&d->slots, &d->blen, &d->nchars, &d->flat, &d->offs, &d->long_idx, &d->pairs};
+    for (DevBuf *b : bufs) b->release();
+    delete d;
+    return s;
+  }
+  d->dict_bytes = (uint64_t)n_words * (sizeof(uint4) + 2) + flat_bytes + ((uint64_t)n_words + 1) * 4;
+  *out = d;
+  return MSI_OK;
+}
+
+void msi_dict_destroy(msi_dict *d) {
+  if (!d) return;
+  std::lock_guard<std::mutex> lk(d->ctx->mu);
+  DeviceGuard g(d->ctx->device);
+  (void)hipStreamSynchronize(d->ctx->stream);
+  DevBuf *bufs[] = {&d->slots, &d->blen, &d->nchars, &d->flat, &d->offs, &d->long_idx, &d->qbytes, &d->qoff,
+                    &d->qflags, &d->qm, &d->qchars, &d->lists, &d->cnts, &d->llists, &d->lcnts, &d->pairs,
+                    &d->out1, &d->out1c, &d->out2, &d->out2c};
+  for (DevBuf *b : bufs) b->release();
+  d->match_timer.release();
+  delete d;
+}
+
+uint32_t msi_dict_len(const msi_dict *d) { return d ? d->n_words : 0; }
+
+int32_t msi_dict_lookup_device(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_qoff, const uint8_t *d_qflags,
+                               uint32_t n, uint32_t cap_one, uint32_t cap_two, uint32_t *d_out_one_idx,
+                               uint32_t *d_out_one_cnt, uint32_t *d_out_two_idx, uint32_t *d_out_two_cnt) {
+  if (!d || !n || !d_qbytes || !d_qoff || !d_qflags || !d_out_one_idx || !d_out_one_cnt || !d_out_two_idx ||
+      !d_out_two_cnt) {
+    msi_set_error("msi_dict_lookup_device: invalid argument");
+    return MSI_E_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(d->ctx->mu);
+  DeviceGuard g(d->ctx->device);
+  return enqueue_lookup(d, d_qbytes, d_qoff, d_qflags, n, cap_one, cap_two, d_out_one_idx, d_out_one_cnt,
+                        d_out_two_idx, d_out_two_cnt);
+}
+
+int32_t msi_dict_lookup(msi_dict *d, const msi_typo_query *queries, uint32_t n, uint32_t cap_one, uint32_t cap_two,
+                        uint32_t *out_one_idx, uint32_t *out_one_cnt, uint32_t *out_two_idx, uint32_t *out_two_cnt) {
+  if (!d || (n && (!queries || !out_one_idx || !out_one_cnt || !out_two_idx || !out_two_cnt))) {
+    msi_set_error("msi_dict_lookup: invalid argument");
+    return MSI_E_INVALID;
+  }
+  if (n == 0) return MSI_OK;
+  std::vector<uint8_t> bytes, flags(n);
+  std::vector<uint32_t> off(n + 1, 0);
+  for (uint32_t i = 0; i < n; ++i) {
+    const msi_typo_query &q = queries[i];
+    if (q.len && !q.word) {
+      msi_set_error("msi_dict_lookup: query %u has a NULL word", i);
+      return MSI_E_INVALID;
+    }
+    bytes.insert(bytes.end(), q.word, q.word + q.len);
+    off[i + 1] = (uint32_t)bytes.size();
+    flags[i] = (uint8_t)((q.max_typos > 2 ? 2 : q.max_typos) | (q.is_prefix ? 4 : 0));
+  }
+  std::lock_guard<std::mutex> lk(d->ctx->mu);
+  DeviceGuard g(d->ctx->device);
+  hipStream_t st = d->ctx->stream;
+  MSI_TRY(d->qbytes.ensure(std::max<size_t>(16, bytes.size())));
+  MSI_TRY(d->qoff.ensure((n + 1) * sizeof(uint32_t)));
+  MSI_TRY(d->qflags.ensure(n));
+  MSI_TRY(d->out1.ensure((size_t)n * cap_one * sizeof(uint32_t)));
+  MSI_TRY(d->out2.ensure((size_t)n * cap_two * sizeof(uint32_t)));
+  MSI_TRY(d->out1c.ensure(n * sizeof(uint32_t)));
+  MSI_TRY(d->out2c.ensure(n * sizeof(uint32_t)));
+  if (!bytes.empty()) MSI_HIP_TRY(hipMemcpyAsync(d->qbytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice, st));
+  MSI_HIP_TRY(hipMemcpyAsync(d->qoff.p, off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  MSI_HIP_TRY(hipMemcpyAsync(d->qflags.p, flags.data(), n, hipMemcpyHostToDevice, st));
+  MSI_TRY(enqueue_lookup(d, d->qbytes.as<uint8_t>(), d->qoff.as<uint32_t>(), d->qflags.as<uint8_t>(), n, cap_one,
+                         cap_two, d->out1.as<uint32_t>(), d->out1c.as<uint32_t>(), d->out2.as<uint32_t>(),
+                         d->out2c.as<uint32_t>()));
+  MSI_HIP_TRY(hipMemcpyAsync(out_one_idx, d->out1.p, (size_t)n * cap_one * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipMemcpyAsync(out_two_idx, d->out2.p, (size_t)n * cap_two * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipMemcpyAsync(out_one_cnt, d->out1c.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipMemcpyAsync(out_two_cnt, d->out2c.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  return MSI_OK;
+}
+
+int32_t msi_dict_match_time(msi_dict *d, uint64_t *out_launches, double *out_ms_total) {
+  if (!d || !out_launches || !out_ms_total) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(d->ctx->mu);
+  DeviceGuard g(d->ctx->device);
+  MSI_HIP_TRY(hipStreamSynchronize(d->ctx->stream));
+  d->match_timer.drain(out_launches, out_ms_total);
+  return MSI_OK;
+}
+
+int32_t msi_dict_get_stats(const msi_dict *d, msi_dict_stats *out) {
+  if (!d || !out) return MSI_E_INVALID;
+  out->lookup_launches = d->lookup_launches;
+  out->dict_bytes = d->dict_bytes;
+  out->pairs_scanned = 0;
+  if (d->pairs.p) {
+    std::lock_guard<std::mutex> lk(d->ctx->mu);
+    DeviceGuard g(d->ctx->device);
+    u64 v = 0;
+    if (hipStreamSynchronize(d->ctx->stream) == hipSuccess &&
+        hipMemcpy(&v, d->pairs.p, sizeof(u64), hipMemcpyDeviceToHost) == hipSuccess)
+      out->pairs_scanned = v;
+  }
+  return MSI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure; never imported by the product)."""
+    from oracle import oracle as orc
+    orc.build()
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def cpubase():
+    from oracle import cpubase
+    cpubase.lib()
+    return cpubase
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One libmsi context for the whole GPU session.  No skip, no fallback: if the
+    HIP library or the device is missing the GPU tests must fail loudly."""
+    import meilisearch_amd as ma
+    c = ma.Context(0)
+    yield c
+    c.close()

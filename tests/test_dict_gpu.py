@@ -1,0 +1,96 @@
+"""S2 parity: libmsi's typo lookup (through the C ABI) against the literal CPU
+restatement of compute_derivations.rs:75-168.  Bar: identical index lists."""
+import numpy as np
+import pytest
+
+import meilisearch_amd as ma
+from meilisearch_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(oracle, words, queries, caps=(150, 50), ctx=None):
+    concat, off = synth.flatten_words(words)
+    odic = oracle.Dictionary.from_flat(concat, off)
+    gdic = ma.GpuDictionary(ctx, concat=concat, offsets=off)
+    assert len(gdic) == len(words)
+    got = gdic.lookup(queries, cap_one=caps[0], cap_two=caps[1])
+    for (w, b, p), (g1, g2) in zip(queries, got):
+        e1, e2 = oracle.typo_lookup(odic, w, b, p, cap_one=caps[0], cap_two=caps[1])
+        assert g1.tolist() == e1.tolist(), ("one", w, b, p, caps, g1[:8], e1[:8])
+        assert g2.tolist() == e2.tolist(), ("two", w, b, p, caps, g2[:8], e2[:8])
+    return gdic
+
+
+def test_reference_words(ctx, oracle):
+    # corpus words of crates/milli/src/search/new/tests/typo.rs and tests/search/typo_tolerance.rs
+    words = sorted(set(
+        "the quick brown fox jumps over the lazy dog quickest quickly quack quickbrownfox brow browny "
+        "brownie foxes jumped jump jumper lazily dogs zeal zealand zealot zoo netwolk network wolk wol "
+        "zean zealemd".split()), key=lambda w: w.encode())
+    g = ma.GpuDictionary(ctx, words=words)
+    assert "quick" in g.find_one_typo_derivations("quack", False)
+    assert "quickest" in g.find_one_typo_derivations("quicest", False)
+    assert "jumps" in g.find_one_typo_derivations("jummps", False)
+    one, two = g.find_one_two_typo_derivations("zuickest", False)
+    assert "quickest" in two and "quickest" not in one          # first-letter typo = 2 typos
+    assert g.find_one_typo_derivations("zuickest", False) == []
+    assert "quick" not in g.find_one_typo_derivations("quick", False)
+    # typo_tolerance.rs:37-175: zeal/zean (1 typo), zealand/zealemd (2 typos)
+    assert "zeal" in g.find_one_typo_derivations("zean", False)
+    one, two = g.find_one_two_typo_derivations("zealemd", False)
+    assert "zealand" in two
+    queries = [(w, b, p) for w in ["quack", "quicest", "jummps", "zuickest", "quick", "zean", "zealemd",
+                                   "brow", "netwolk", "qu", "t"] for b in (1, 2) for p in (False, True)]
+    compare(oracle, words, queries, ctx=ctx)
+    compare(oracle, words, queries, caps=(2, 1), ctx=ctx)
+
+
+def test_cap_interplay(ctx, oracle):
+    words = sorted(["aello", "bello", "cello", "dello", "hallo", "hella", "hello", "hellos", "jello",
+                    "hxllo", "hexlo", "helxo", "hellx", "helol", "ehllo", "yello", "zello"],
+                   key=lambda w: w.encode())
+    queries = [("hello", 2, False), ("hello", 2, True), ("hello", 1, False), ("hell", 1, True)]
+    for caps in [(150, 50), (3, 2), (1, 1), (2, 5), (5, 1)]:
+        compare(oracle, words, queries, caps=caps, ctx=ctx)
+
+
+def test_synthetic_dictionary_all_paths(ctx, oracle):
+    words = synth.make_dictionary(20000, seed=17)
+    extra = ["internationalisationally", "internationalization", "антидисестаблишментарианизм",
+             "ünïcödé", "日本語のテキスト", "日本語", "😀smile", "a", "ab", "abc",
+             "pneumonoultramicroscopicsilicovolcanoconiosis", "x" * 250]
+    words = sorted(set(words + extra), key=lambda w: w.encode())
+    queries = synth.make_typo_queries(words, 400, seed=19)
+    queries += [("internationalisationaly", 2, False), ("internationalizatio", 2, True),
+                ("антидисестаблишментарианизн", 2, False), ("ünïcodé", 1, False), ("日本誤", 1, False),
+                ("日本語のテキス", 2, True), ("😀smil", 1, True), ("pneumonoultramicroscopicsilicovolcanoconiosi", 2, False),
+                ("x" * 249, 2, False), ("y" + "x" * 249, 2, False), ("q", 1, True), ("ab", 2, True), ("a", 2, False),
+                ("z" * 251, 2, False), ("", 1, False)]
+    for caps in [(150, 50), (4, 3)]:
+        g = compare(oracle, words, queries, caps=caps, ctx=ctx)
+    assert g.stats()["pairs_scanned"] > 0
+
+
+def test_batch_sizes_and_determinism(ctx, oracle):
+    words = synth.make_dictionary(5000, seed=23)
+    queries = synth.make_typo_queries(words, 1500, seed=29)     # > one chunk, many segments
+    g = compare(oracle, words, queries, ctx=ctx)
+    a = g.lookup(queries[:100])
+    b = g.lookup(queries[:100])
+    for (a1, a2), (b1, b2) in zip(a, b):
+        assert a1.tolist() == b1.tolist() and a2.tolist() == b2.tolist()
+    # one query at a time gives the same answer as the batch
+    for i in (0, 17, 99):
+        s1, s2 = g.lookup([queries[i]])[0]
+        assert s1.tolist() == a[i][0].tolist() and s2.tolist() == a[i][1].tolist()
+
+
+def test_errors(ctx):
+    with pytest.raises(ma.MsiError) as e:
+        ma.GpuDictionary(ctx, words=["b", "a"])
+    assert "MSI_E_NOT_SORTED" in str(e.value)
+    with pytest.raises(ma.MsiError):
+        ma.GpuDictionary(ctx, words=["a", "a"])
+    g = ma.GpuDictionary(ctx, words=[])
+    assert g.lookup([("hello", 2, False)])[0][0].size == 0

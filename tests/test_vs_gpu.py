@@ -1,0 +1,187 @@
+"""S1 parity: libmsi's vector k-NN (through the C ABI) against the CPU oracle.
+Bar: identical docids in identical order, distances bit-identical (the device
+rescoring uses the reference's scalar f32 arithmetic), goldens within 1e-5."""
+import numpy as np
+import pytest
+
+import meilisearch_amd as ma
+from meilisearch_amd import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def check_against_oracle(oracle, store, rows, ids, queries, k, fb=None, nb=0):
+    d, s, c = store.search(queries, k, fb, nb)
+    for j in range(queries.shape[0]):
+        e_ids, e_dist = oracle.vs_topk(rows, ids, queries[j], k, fb, nb)
+        n = int(c[j])
+        assert n == e_ids.size, (j, n, e_ids.size)
+        assert d[j, :n].tolist() == e_ids.tolist(), (j, d[j, :n][:8], e_ids[:8])
+        assert s[j, :n].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist(), j
+
+
+def test_reference_literals(ctx, oracle):
+    # crates/meilisearch/tests/search/hybrid.rs:47-68,296-406,758 ; similar/mod.rs:19-43,281-335
+    st = ma.GpuStore(ctx, 2)
+    st.upload([1, 2, 3], [[1, 3], [1, 2], [2, 3]])
+    d, s, c = st.search(np.array([[1, 1], [1, 0]], dtype=f32), 3)
+    assert d[0].tolist() == [3, 2, 1] and d[1].tolist() == [3, 2, 1]
+    sims = 1.0 - s.astype(np.float64)
+    gold = [[0.990290343761444, 0.974341630935669, 0.9472135901451112],
+            [0.7773500680923462, 0.7236068248748779, 0.6581138968467712]]
+    assert np.abs(sims - np.array(gold)).max() <= 1e-5
+    assert ((f32(1.0) - s) == np.array(gold, dtype=f32)).all()  # bit-exact as f32
+    st3 = ma.GpuStore(ctx, 3)
+    ids = [143, 166428, 287947, 299537, 522681]
+    vecs = [[-0.5, 0.3, 0.85], [0.7, 0.7, -0.4], [0.8, 0.4, -0.5], [0.6, 0.8, -0.2], [0.1, 0.6, 0.8]]
+    st3.upload(ids, vecs)
+    v = st3.get_vector(143)
+    assert v.tolist() == f32(vecs[0]).tolist()
+    fb, nb = ma.dense_filter([i for i in ids if i != 143])   # Similar::execute removes the item
+    d, s, c = st3.search(v[None, :], 4, fb, nb)
+    assert d[0].tolist() == [522681, 299537, 166428, 287947]
+    gold3 = f32([0.890957772731781, 0.39060014486312866, 0.2819308042526245, 0.1662663221359253])
+    assert ((f32(1.0) - s[0]) == gold3).all()
+
+
+def test_tie_order_ascending_docid(ctx, oracle):
+    # crates/milli/src/search/new/tests/cutoff.rs:507-626
+    st = ma.GpuStore(ctx, 2)
+    rows = np.array([[0.1, 0.1], [-0.1, 0.1], [0.1, -0.1], [-0.1, -0.1]], dtype=f32)
+    st.upload([0, 1, 2, 3], rows)
+    d, s, c = st.search(np.array([[1, -1]], dtype=f32), 10)
+    assert c[0] == 4 and d[0, :4].tolist() == [2, 0, 3, 1]
+    assert np.allclose(1.0 - s[0, :4], [1.0, 0.5, 0.5, 0.0], atol=1e-6)
+
+
+@pytest.mark.parametrize("n,dim,k", [(1, 7, 5), (15, 3, 4), (16, 16, 16), (1000, 96, 20), (5003, 130, 1),
+                                      (20000, 384, 20), (4097, 64, 100), (3000, 32, 500)])
+def test_random_vs_oracle(ctx, oracle, n, dim, k):
+    rows = synth.make_embeddings(n, dim, seed=n + dim)
+    ids = (np.arange(n, dtype=np.uint32) * 3 + 7)
+    qs = synth.make_embeddings(5, dim, seed=1000 + n)
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    assert len(st) == n
+    check_against_oracle(oracle, st, rows, ids, qs, k)
+
+
+def test_more_than_one_query_tile(ctx, oracle):
+    rows = synth.make_embeddings(6000, 128, seed=21)
+    ids = np.arange(6000, dtype=np.uint32)
+    qs = synth.make_embeddings(37, 128, seed=22)
+    st = ma.GpuStore(ctx, 128)
+    st.upload(ids, rows)
+    check_against_oracle(oracle, st, rows, ids, qs, 20)
+
+
+@pytest.mark.parametrize("selectivity", [0.5, 0.05, 0.002])
+def test_filtered_search(ctx, oracle, selectivity):
+    n, dim = 30000, 64
+    rows = synth.make_embeddings(n, dim, seed=31)
+    ids = np.sort(np.random.default_rng(5).choice(100000, n, replace=False)).astype(np.uint32)
+    rng = np.random.default_rng(int(selectivity * 1e6))
+    allowed = ids[rng.random(n) < selectivity]
+    # also docids that are not in the store, and ids beyond nbits are not allowed
+    fb, nb = ma.dense_filter(list(allowed) + [1, 5], nbits=90000)
+    qs = synth.make_embeddings(4, dim, seed=32)
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    check_against_oracle(oracle, st, rows, ids, qs, 20, fb, nb)
+    # empty filter
+    fb0, nb0 = ma.dense_filter([], nbits=64)
+    d, s, c = st.search(qs, 20, fb0, nb0)
+    assert c.tolist() == [0, 0, 0, 0]
+
+
+def test_duplicates_zero_rows_and_zero_query(ctx, oracle):
+    dim = 48
+    base = synth.make_embeddings(50, dim, seed=41)
+    rows = np.concatenate([np.repeat(base[:1], 200, axis=0),      # 200 identical rows: ties > K'
+                           base, np.zeros((5, dim), dtype=f32),   # zero vectors: distance 0 by definition
+                           (base[:20] * f32(1e-30))])              # tiny norms: pn*qn <= EPS
+    n = rows.shape[0]
+    ids = np.arange(n, dtype=np.uint32) + 10
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    qs = np.concatenate([base[:1] * f32(2.0), synth.make_embeddings(2, dim, seed=42),
+                         np.zeros((1, dim), dtype=f32)])
+    before = st.stats()["exhaustive_reruns"]
+    check_against_oracle(oracle, st, rows, ids, qs, 20)
+    assert st.stats()["exhaustive_reruns"] > before   # the ties forced the exhaustive path
+
+
+def test_large_scan_and_sample_pass(ctx, oracle):
+    # large enough for the strided sample pass (thresholds) to run
+    n, dim = 300000, 128
+    rows = synth.make_embeddings(n, dim, seed=51)
+    ids = np.arange(n, dtype=np.uint32)
+    qs = synth.make_embeddings(16, dim, seed=52)
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    s0 = st.stats()
+    check_against_oracle(oracle, st, rows, ids, qs[:3], 20)
+    s1 = st.stats()
+    assert s1["scan_launches"] - s0["scan_launches"] == 2      # sample + main
+    assert s1["exhaustive_reruns"] == s0["exhaustive_reruns"]
+
+
+def test_round_trip_and_idempotence(ctx):
+    # size-independent properties: every stored row's nearest neighbour is itself
+    # (distance ~0) and a repeated search returns identical bits
+    n, dim = 50000, 96
+    rows = synth.make_embeddings(n, dim, seed=61)
+    st = ma.GpuStore(ctx, dim)
+    st.upload(np.arange(n, dtype=np.uint32), rows)
+    pick = np.array([0, 1, 777, 4999, n - 1])
+    d, s, c = st.search(rows[pick], 3)
+    assert d[:, 0].tolist() == pick.tolist()
+    assert np.abs(s[:, 0]).max() <= 1e-6
+    assert (np.diff(s.astype(np.float64), axis=1) >= 0).all()     # sorted ascending
+    d2, s2, c2 = st.search(rows[pick], 3)
+    assert (d == d2).all() and (s.view(np.uint32) == s2.view(np.uint32)).all()
+    for p in pick:
+        assert (st.get_vector(int(p)) == rows[p]).all()
+    assert st.get_vector(n + 5) is None
+
+
+def test_multi_store_vector_store_mirror(ctx, oracle):
+    # documents with several embeddings: store i holds each doc's i-th vector
+    # (store.rs:752-786); results are concatenated and sorted (store.rs:1036-1062)
+    dim = 24
+    rng = np.random.default_rng(71)
+    emb = {int(d): [rng.standard_normal(dim).astype(f32) for _ in range(1 + (d % 3))] for d in range(0, 400, 2)}
+    vs = ma.VectorStore(ctx, dim)
+    vs.add_documents(emb)
+    q = rng.standard_normal(dim).astype(f32)
+    got = vs.nns_by_vector(q, 10)
+    exp = []
+    for sid in range(3):
+        docs = [d for d in emb if len(emb[d]) > sid]
+        rows = np.stack([emb[d][sid] for d in docs])
+        e_ids, e_dist = oracle.vs_topk(rows, np.array(docs, dtype=np.uint32), q, 10)
+        exp += list(zip(e_ids.tolist(), e_dist.tolist()))
+    exp.sort(key=lambda t: (t[1], t[0]))
+    assert [g[0] for g in got] == [e[0] for e in exp]
+    assert [f32(g[1]) for g in got] == [f32(e[1]) for e in exp]
+    assert len(vs.item_vectors(4)) == 1 + (4 % 3)
+    sim = vs.nns_by_item(4, 5, filter_docids=[d for d in emb if d != 4])
+    assert all(d != 4 for d, _ in sim) and len(sim) == 5 * (1 + (4 % 3))
+
+
+def test_errors(ctx):
+    st = ma.GpuStore(ctx, 8)
+    with pytest.raises(ma.MsiError) as e:
+        st.upload([3, 2, 1], np.zeros((3, 8), dtype=f32))
+    assert "MSI_E_NOT_SORTED" in str(e.value)
+    st.upload([1, 2, 3], np.ones((3, 8), dtype=f32))
+    with pytest.raises(ma.MsiError) as e:
+        st.search(np.ones((1, 8), dtype=f32), 5000)
+    assert "MSI_E_UNSUPPORTED" in str(e.value)
+    cancel = np.array([1], dtype=np.int32)
+    with pytest.raises(ma.MsiError) as e:
+        st.search(np.ones((1, 8), dtype=f32), 2, cancel=cancel)
+    assert "MSI_E_CANCELLED" in str(e.value)
+    d, s, c = st.search(np.ones((2, 8), dtype=f32), 0)
+    assert c.tolist() == [0, 0]
