@@ -85,6 +85,32 @@ PROTOTYPES = {
 }
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own
+    libamdhip64.so (SONAME libamdhip64.so.7) and ask for it as "libamdhip64.so";
+    libmsi.so asks for "libamdhip64.so.7".  If libmsi is loaded first the dynamic
+    loader resolves it to /opt/rocm's copy and a later `import torch` maps a SECOND
+    runtime ("No HIP GPUs are available").  When torch is installed, map its copy
+    first so that both resolve to the same object (torch is not imported here and
+    is not required: without it libmsi uses the system ROCm runtime)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libmsi.so.  No fallback: a missing library is an error."""
     global _LIB
@@ -94,6 +120,7 @@ def lib():
             raise ImportError(
                 f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  meilisearch_amd has no CPU fallback.")
+        _share_torch_hip_runtime()
         L = C.CDLL(path)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if the ABI is incomplete

@@ -254,14 +254,17 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
     delete p;
     return MSI_E_HIP;
   }
+  msi_ctx_retain(ctx);
   *out = p;
   return MSI_OK;
 }
 
 void msi_bits_destroy(msi_bits *p) {
   if (!p) return;
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
-  DeviceGuard g(p->ctx->device);
+  msi_ctx *ctx = p->ctx;
+  {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  DeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
   p->pool.release();
   p->tmp.release();
@@ -269,6 +272,8 @@ void msi_bits_destroy(msi_bits *p) {
   p->stage.release();
   p->desc.release();
   delete p;
+  }
+  msi_ctx_release(ctx);
 }
 
 int32_t msi_bits_fill(msi_bits *p, uint32_t slot, int32_t ones) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -36,7 +37,13 @@ struct msi_ctx {
   hipStream_t stream = nullptr;
   std::mutex mu;  // serialises use of the stream + per-object scratch
   bool profiling = false;
+  // The caller's handle holds one reference, every object created on the
+  // context (msi_vs / msi_dict / msi_bits) one more: msi_ctx_destroy only drops
+  // the caller's, so objects may be destroyed after their context in any order.
+  std::atomic<int> refs{1};
 };
+void msi_ctx_retain(msi_ctx *ctx);
+void msi_ctx_release(msi_ctx *ctx);
 
 // HIP-event bracket around one kernel (only when msi_ctx::profiling).
 struct KernelTimer {
@@ -147,5 +154,13 @@ __host__ __device__ inline float ord_to_f32(uint32_t o) {
   return f;
 #endif
 }
+
+// Correctly rounded f32 sqrt / divide for the reference-arithmetic ("canonical")
+// paths.  HIP's __fsqrt_rn lowers to the ~1-ulp native v_sqrt_f32 and the rounding
+// of `a / b` depends on a compiler flag, so both go through f64: the f64 result of
+// one sqrt / divide of f32 operands rounds to the correctly rounded f32 (53 >= 2*24+2
+// makes the double rounding innocuous).  Not used on any hot path.
+__device__ __forceinline__ float msi_sqrt_rn(float x) { return (float)__builtin_sqrt((double)x); }
+__device__ __forceinline__ float msi_div_rn(float a, float b) { return (float)((double)a / (double)b); }
 
 static inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }

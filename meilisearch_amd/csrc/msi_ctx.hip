@@ -64,8 +64,15 @@ int32_t msi_ctx_create(int32_t device, msi_ctx **out) {
   return MSI_OK;
 }
 
-void msi_ctx_destroy(msi_ctx *ctx) {
+void msi_ctx_destroy(msi_ctx *ctx) { msi_ctx_release(ctx); }
+
+}  // extern "C"
+
+void msi_ctx_retain(msi_ctx *ctx) { ctx->refs.fetch_add(1, std::memory_order_relaxed); }
+
+void msi_ctx_release(msi_ctx *ctx) {
   if (!ctx) return;
+  if (ctx->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
   DeviceGuard g(ctx->device);
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -73,6 +80,8 @@ void msi_ctx_destroy(msi_ctx *ctx) {
   }
   delete ctx;
 }
+
+extern "C" {
 
 void *msi_ctx_stream(msi_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int32_t msi_ctx_device(msi_ctx *ctx) { return ctx ? ctx->device : -1; }

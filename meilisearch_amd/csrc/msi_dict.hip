@@ -691,14 +691,17 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
     return s;
   }
   d->dict_bytes = (uint64_t)n_words * (sizeof(uint4) + 2) + flat_bytes + ((uint64_t)n_words + 1) * 4;
+  msi_ctx_retain(ctx);
   *out = d;
   return MSI_OK;
 }
 
 void msi_dict_destroy(msi_dict *d) {
   if (!d) return;
-  std::lock_guard<std::mutex> lk(d->ctx->mu);
-  DeviceGuard g(d->ctx->device);
+  msi_ctx *ctx = d->ctx;
+  {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  DeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(d->ctx->stream);
   DevBuf *bufs[] = {&d->slots, &d->blen, &d->nchars, &d->flat, &d->offs, &d->long_idx, &d->qbytes, &d->qoff,
                     &d->qflags, &d->qm, &d->qchars, &d->lists, &d->cnts, &d->llists, &d->lcnts, &d->pairs,
@@ -706,6 +709,8 @@ void msi_dict_destroy(msi_dict *d) {
   for (DevBuf *b : bufs) b->release();
   d->match_timer.release();
   delete d;
+  }
+  msi_ctx_release(ctx);
 }
 
 uint32_t msi_dict_len(const msi_dict *d) { return d ? d->n_words : 0; }

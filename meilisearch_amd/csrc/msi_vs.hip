@@ -107,7 +107,7 @@ __global__ void vs_row_norms_kernel(const float4 *__restrict__ tiles, uint64_t r
       acc = __fadd_rn(acc, __fmul_rn(v.w, v.w));
     }
   }
-  float n = __fsqrt_rn(acc);
+  float n = msi_sqrt_rn(acc);
   norm[r] = n;
   inv_norm[r] = 1.0f / n;  // +inf for zero rows: always "degenerate" in the scan
 }
@@ -151,7 +151,7 @@ __global__ void vs_prep_queries_kernel(const float *__restrict__ q, uint32_t nq,
         float x = q[(uint64_t)tid * dim + k];
         acc = __fadd_rn(acc, __fmul_rn(x, x));
       }
-    float n = __fsqrt_rn(acc);
+    float n = msi_sqrt_rn(acc);
     qn[tid] = n;
     inv_qn[tid] = n > 0.f ? 1.0f / n : 0.f;
     // row is (conservatively) degenerate when pn*qn <= EPS  <=>  1/pn >= qn/EPS
@@ -551,8 +551,8 @@ __device__ __forceinline__ float canonical_dot(const float4 *__restrict__ tiles,
 __device__ __forceinline__ float canonical_distance(float pq, float pn, float qn) {
   const float pnqn = __fmul_rn(pn, qn);
   if (pnqn > FLT_EPSILON) {
-    const float c = __fdiv_rn(pq, pnqn);
-    return __fdiv_rn(__fsub_rn(1.0f, c), 2.0f);
+    const float c = msi_div_rn(pq, pnqn);
+    return __fsub_rn(1.0f, c) * 0.5f;  // /2 is exact
   }
   return 0.0f;
 }
@@ -1009,6 +1009,7 @@ int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out) {
   }
   msi_vs *vs = new msi_vs();
   vs->ctx = ctx;
+  msi_ctx_retain(ctx);
   vs->dim = dim;
   vs->dpad = dpad;
   vs->KB = KB;
@@ -1019,8 +1020,10 @@ int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out) {
 
 void msi_vs_destroy(msi_vs *vs) {
   if (!vs) return;
-  std::lock_guard<std::mutex> lk(vs->ctx->mu);
-  DeviceGuard g(vs->ctx->device);
+  msi_ctx *ctx = vs->ctx;
+  {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  DeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(vs->ctx->stream);
   DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qrow,
                     &vs->qsmall, &vs->gkeys, &vs->gsmall, &vs->sel_keys, &vs->tmask, &vs->tlist, &vs->fbits,
@@ -1028,6 +1031,8 @@ void msi_vs_destroy(msi_vs *vs) {
   for (DevBuf *b : bufs) b->release();
   vs->scan_timer.release();
   delete vs;
+  }
+  msi_ctx_release(ctx);
 }
 
 int32_t msi_vs_upload(msi_vs *vs, const uint32_t *docids, const float *rows, uint64_t n_rows) {

@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Per-config measurements of BASELINE.md §3 (C2: vector scan, C3: typo lookup)
+on one MI355X.  bench.py stays the driver's contract (the C4 line); this tool
+prints one JSON line per (config, batch size) so the numbers quoted in DESIGN.md
+and profiles/ can be regenerated:
+
+    python tools/bench_configs.py c2 [--rows 1000000 --dim 384]
+    python tools/bench_configs.py c3 [--dict-words 2000000]
+
+Inputs are resident in HBM before the timed region; results stay on the device
+(the D2H of B*k*8 bytes is included in bench.py, not here).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def timed(fn, sync, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    sync()
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        s0 = time.perf_counter()
+        fn()
+        sync()
+        lat.append((time.perf_counter() - s0) * 1e3)
+    return (time.perf_counter() - t0) / reps * 1e3, statistics.median(lat)
+
+
+def run_c2(args):
+    import torch
+    import meilisearch_amd as ma
+    dev = torch.device("cuda", 0)
+    ctx = ma.Context(0)
+    n, d, k = args.rows, args.dim, args.k
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    rows = torch.empty((n, d), dtype=torch.float32, device=dev).normal_(generator=gen)
+    ids = torch.arange(n, dtype=torch.int32, device=dev)
+    store = ma.GpuStore(ctx, d)
+    store.upload_device(ids, rows)
+    del rows
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(5678)
+    q = torch.empty((1024, d), dtype=torch.float32, device=dev).normal_(generator=gq)
+    bytes_per_sweep = ((n + 15) // 16) * store.stats()["bytes_per_tile"]
+    for B in args.batches:
+        out_ids = torch.zeros((B, k), dtype=torch.int32, device=dev)
+        out_dist = torch.zeros((B, k), dtype=torch.float32, device=dev)
+        out_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        inexact = torch.zeros(B, dtype=torch.int32, device=dev)
+
+        def step():
+            for q0 in range(0, B, 16):
+                q1 = min(B, q0 + 16)
+                store.search_device(q[q0:q1], k, out_ids[q0:q1], out_dist[q0:q1], out_cnt[q0:q1], inexact[q0:q1])
+
+        ctx.set_profiling(False)
+        ms, p50 = timed(step, ctx.synchronize, args.reps)
+        ctx.set_profiling(True)
+        store.scan_time()
+        step()
+        ctx.synchronize()
+        ln, lms = store.scan_time()
+        scan_ms = lms / max(1, ln)
+        print(json.dumps({
+            "config": "C2", "rows": n, "dim": d, "k": k, "batch": B,
+            "ms_per_batch": round(ms, 4), "p50_ms": round(p50, 4), "qps": round(B / ms * 1e3, 1),
+            "sweeps_per_batch": (B + 15) // 16, "scan_kernel_ms": round(scan_ms, 4),
+            "scan_GBps": round(bytes_per_sweep / (scan_ms * 1e-3) / 1e9, 1),
+            "scan_frac_of_8TBps": round(bytes_per_sweep / (scan_ms * 1e-3) / 8e12, 4),
+            "inexact": int(inexact.sum().item())}), flush=True)
+
+
+def run_c3(args):
+    import torch
+    import meilisearch_amd as ma
+    from meilisearch_amd import synth
+    from oracle import cpubase  # packing helper + the CPU baseline leg only
+    dev = torch.device("cuda", 0)
+    ctx = ma.Context(0)
+    words = synth.make_dictionary(args.dict_words, seed=99)
+    concat, off = synth.flatten_words(words)
+    gdict = ma.GpuDictionary(ctx, concat=concat, offsets=off)
+    all_q = synth.make_typo_queries(words, max(args.batches), seed=7)
+    cpu = None
+    if not args.no_cpu:
+        cores = cpubase.host_threads()
+        cdict = cpubase.CpuDictionary(concat, off)
+        sample = all_q[:args.cpu_sample]
+        qb, qoff, qfl = cpubase.pack_queries(sample)
+        cdict.lookup_packed(qb, qoff[:9], qfl[:8], threads=cores)
+        t0 = time.perf_counter()
+        cdict.lookup_packed(qb, qoff, qfl, threads=cores)
+        t_all = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        qb1, qoff1, qfl1 = cpubase.pack_queries(sample[:64])
+        cdict.lookup_packed(qb1, qoff1, qfl1, threads=1)
+        t_one = (time.perf_counter() - t0) / 64
+        cpu = {"cores": cores, "words_per_s_all_cores": round(len(sample) / t_all, 1),
+               "words_per_s_one_core": round(1.0 / t_one, 1), "sample_words": len(sample)}
+    for B in args.batches:
+        tq = all_q[:B]
+        qb, qoff, qfl = cpubase.pack_queries(tq)
+        qb_t = torch.from_numpy(qb).to(dev)
+        qoff_t = torch.from_numpy(qoff.astype(np.int32)).to(dev)
+        qfl_t = torch.from_numpy(qfl).to(dev)
+        one_t = torch.zeros((B, 150), dtype=torch.int32, device=dev)
+        two_t = torch.zeros((B, 50), dtype=torch.int32, device=dev)
+        one_c = torch.zeros(B, dtype=torch.int32, device=dev)
+        two_c = torch.zeros(B, dtype=torch.int32, device=dev)
+
+        def step():
+            gdict.lookup_device(qb_t, qoff_t, qfl_t, B, one_t, one_c, two_t, two_c)
+
+        ctx.set_profiling(False)
+        p0 = gdict.stats()["pairs_scanned"]
+        step()
+        ctx.synchronize()
+        pairs = gdict.stats()["pairs_scanned"] - p0
+        ms, p50 = timed(step, ctx.synchronize, args.reps)
+        ctx.set_profiling(True)
+        gdict.match_time()
+        step()
+        ctx.synchronize()
+        ln, lms = gdict.match_time()
+        out = {"config": "C3", "dict_words": len(words), "batch": B, "ms_per_batch": round(ms, 4),
+               "p50_ms": round(p50, 4), "words_per_s": round(B / ms * 1e3, 1),
+               "match_kernel_ms": round(lms / max(1, ln), 4), "dp_pairs_per_batch": int(pairs),
+               "dict_pairs_per_s": round(B * len(words) / ms * 1e3, 1),
+               "hits_one": int(one_c.sum().item()), "hits_two": int(two_c.sum().item())}
+        if cpu:
+            out["cpu_baseline"] = cpu
+            out["x_cpu_all_cores"] = round(out["words_per_s"] / cpu["words_per_s_all_cores"], 2)
+        print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", choices=["c2", "c3"])
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--dict-words", type=int, default=2_000_000)
+    ap.add_argument("--batches", type=int, nargs="*", default=None)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    args = ap.parse_args()
+    if args.batches is None:
+        args.batches = [1, 16, 256] if args.config == "c2" else [1, 64, 1024, 8192]
+    (run_c2 if args.config == "c2" else run_c3)(args)
+
+
+if __name__ == "__main__":
+    main()
