@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=20)
-    ap.add_argument("--queries", type=int, default=64, help="hybrid queries per step per GPU")
+    ap.add_argument("--queries", type=int, default=96, help="hybrid queries per step per GPU")
     ap.add_argument("--words-per-query", type=int, default=2)
     ap.add_argument("--dict-words", type=int, default=2_000_000)
     ap.add_argument("--no-typo", action="store_true")
@@ -125,9 +125,7 @@ def main():
         gather_buf = torch.zeros((world, Q, k), dtype=torch.float32, device=dev)
 
     def step():
-        for q0 in range(0, Q, 16):
-            q1 = min(Q, q0 + 16)
-            store.search_device(q_t[q0:q1], k, out_ids[q0:q1], out_dist[q0:q1], out_cnt[q0:q1], inexact[q0:q1])
+        store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
         if gdict is not None:
             gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
         ctx.synchronize()
@@ -200,7 +198,7 @@ def main():
                         f"+ {args.words_per_query} typo-tolerant words/query over a {args.dict_words}-term dictionary",
             "queries_per_step_per_gpu": Q,
             "words_per_step_per_gpu": n_words_q,
-            "queries_per_hbm_sweep": 16,
+            "queries_per_hbm_sweep": store.max_batch,
             "sharding": "queries sharded, index replicated per GPU, all_gather of per-rank top-k (RCCL)",
             "step_includes": ["vs_scan + select + reference rescoring", "dict_match + cap logic", "D2H of results"],
             "step_excludes": ["ranking-rule bucket sort", "hybrid merge"],

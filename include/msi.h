@@ -95,6 +95,11 @@ int32_t msi_vs_upload_device(msi_vs *vs, const uint32_t *d_docids,
 
 uint64_t msi_vs_len(const msi_vs *vs);
 uint32_t msi_vs_dim(const msi_vs *vs);
+/* Queries answered by ONE sweep of the store through HBM (16, 32 or 48: as many
+ * 16-query MFMA tiles as the store's dimension leaves room for in LDS).  Larger
+ * batches are processed in chunks of this size; a micro-batching caller should
+ * aim for multiples of it. */
+uint32_t msi_vs_max_batch(const msi_vs *vs);
 
 /* store.rs:1004-1034 (nns_by_item reads the item's stored vector first). */
 int32_t msi_vs_get_vector(msi_vs *vs, uint32_t docid, float *out_row,
@@ -116,9 +121,9 @@ int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries,
                       uint32_t *out_counts);
 
 /* Device-pointer variant: all pointers are device memory, work is enqueued on
- * msi_ctx_stream() and NOT synchronised.  n_queries <= 16 per call (one MFMA
- * query tile).  `d_inexact[n_queries]` (nullable) receives 1 where the
- * exactness proof failed and the host variant would have re-run exhaustively. */
+ * msi_ctx_stream() and NOT synchronised.  `d_inexact[n_queries]` (nullable)
+ * receives 1 where the exactness proof failed and the host variant would have
+ * re-run the query exhaustively (the caller must do so: msi_vs_search). */
 int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries,
                              uint32_t n_queries, uint32_t k,
                              const uint64_t *d_filter_bits,
@@ -128,13 +133,13 @@ int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries,
 
 /* Introspection for benchmarks/tests. */
 typedef struct msi_vs_stats {
-  uint64_t scan_launches;      /* vs_scan kernel launches so far           */
+  uint64_t scan_launches;      /* vs_scan kernel launches so far (sample + full sweeps) */
   uint64_t scan_tiles;         /* 16-row tiles streamed by those launches  */
   uint64_t exhaustive_reruns;  /* queries that needed the exhaustive path  */
   uint64_t bytes_per_tile;     /* algorithmic HBM bytes per tile           */
 } msi_vs_stats;
 int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out);
-/* Accumulated duration of the main-pass vs_scan launches recorded while
+/* Accumulated duration of the full-sweep vs_scan launches recorded while
  * profiling was enabled (HIP events on the launch stream); resets the counters. */
 int32_t msi_vs_scan_time(msi_vs *vs, uint64_t *out_launches, double *out_ms_total);
 

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "msi_vs_upload_device": (_I32, [_VP, _VP, _VP, _U64]),
     "msi_vs_len": (_U64, [_VP]),
     "msi_vs_dim": (_U32, [_VP]),
+    "msi_vs_max_batch": (_U32, [_VP]),
     "msi_vs_get_vector": (_I32, [_VP, _U32, _VP, C.POINTER(_I32)]),
     "msi_vs_search": (_I32, [_VP, _VP, _U32, _U32, _VP, _U64, _VP, _VP, _VP, _VP]),
     "msi_vs_search_device": (_I32, [_VP, _VP, _U32, _U32, _VP, _U64, _VP, _VP, _VP, _VP]),

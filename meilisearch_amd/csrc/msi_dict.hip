@@ -415,27 +415,17 @@ __global__ void dict_prep_kernel(const uint8_t *__restrict__ qbytes, const uint3
 
 // ---- finalisation --------------------------------------------------------------------
 
-// Sequential reader over the per-segment lists of one class, merged (by
-// dictionary index) with the long-word launch's lists of the same class.
-struct ClassStream {
-  const uint32_t *lists;
-  const uint32_t *cnts;
-  uint32_t nseg, stride_l, off, c;
-  uint32_t seg, pos;
-  __device__ void init(const uint32_t *l, const uint32_t *cn, uint32_t ns, uint32_t st, uint32_t o, uint32_t cls) {
-    lists = l; cnts = cn; nseg = ns; stride_l = st; off = o; c = cls; seg = 0; pos = 0;
-    skip();
-  }
-  __device__ void skip() {
-    while (seg < nseg && pos >= cnts[seg * 3 + c]) { ++seg; pos = 0; }
-  }
-  __device__ bool done() const { return seg >= nseg; }
-  __device__ uint32_t peek() const { return lists[(size_t)seg * stride_l + off + pos]; }
-  __device__ void pop() { ++pos; skip(); }
+// Ascending list of dictionary indices.
+struct ArrStream {
+  const uint32_t *p;
+  uint32_t n, i;
+  __device__ bool done() const { return i >= n; }
+  __device__ uint32_t peek() const { return p[i]; }
+  __device__ void pop() { ++i; }
 };
 
 struct MergedStream {  // main ∪ long, ascending
-  ClassStream a, b;
+  ArrStream a, b;
   __device__ bool done() const { return a.done() && b.done(); }
   __device__ uint32_t peek() const {
     if (a.done()) return b.peek();
@@ -455,27 +445,80 @@ struct FinalArgs {
   const uint32_t *lists, *cnts;       // main launch
   const uint32_t *llists, *lcnts;     // long-word launch
   uint32_t nq, nseg, lnseg, cap1, cap2, capx;
+  uint32_t *comp;                     // [nq][2][cap1+cap2+capx] compacted class lists
   uint32_t *out_one, *out_one_cnt, *out_two, *out_two_cnt;
 };
 
-__global__ void dict_finalize_kernel(FinalArgs f) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= f.nq) return;
+constexpr int FIN_THREADS = 256;
+
+// One workgroup per query.  Phase 1 (parallel): the per-segment lists of each class
+// are concatenated (segments are contiguous dictionary ranges, so concatenation in
+// segment order is ascending) into one list per (launch, class) with a block-wide
+// prefix sum over the segment counts.  Phase 2 (one lane): the reference's cap
+// logic in its closed form over those six short lists.
+__global__ __launch_bounds__(FIN_THREADS) void dict_finalize_kernel(FinalArgs f) {
+  __shared__ uint32_t s_scan[3][FIN_THREADS];
+  __shared__ uint32_t s_tot[2][3];
+  const uint32_t q = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t st = f.cap1 + f.cap2 + f.capx;
+  const uint32_t caps[3] = {f.cap1, f.cap2, f.capx};
+  const uint32_t offs[3] = {0, f.cap1, f.cap1 + f.cap2};
+  uint32_t *comp = f.comp + (size_t)q * 2 * st;
+  const bool live = f.qm[q].budget != 0;
+  if (live) {
+    for (uint32_t src = 0; src < 2; ++src) {
+      const uint32_t ns = src ? f.lnseg : f.nseg;
+      const uint32_t *lists = (src ? f.llists : f.lists) + (size_t)q * ns * st;
+      const uint32_t *cnts = (src ? f.lcnts : f.cnts) + (size_t)q * ns * 3;
+      const uint32_t per = (ns + FIN_THREADS - 1) / FIN_THREADS;
+      const uint32_t seg0 = min(ns, tid * per), seg1 = min(ns, seg0 + per);
+      uint32_t loc[3] = {0, 0, 0};
+      for (uint32_t seg = seg0; seg < seg1; ++seg) {
+        loc[0] += cnts[seg * 3 + 0];
+        loc[1] += cnts[seg * 3 + 1];
+        loc[2] += cnts[seg * 3 + 2];
+      }
+      __syncthreads();  // s_scan reuse
+      for (int c = 0; c < 3; ++c) s_scan[c][tid] = loc[c];
+      __syncthreads();
+      for (uint32_t o = 1; o < FIN_THREADS; o <<= 1) {
+        uint32_t v[3];
+        for (int c = 0; c < 3; ++c) v[c] = tid >= o ? s_scan[c][tid - o] : 0;
+        __syncthreads();
+        for (int c = 0; c < 3; ++c) s_scan[c][tid] += v[c];
+        __syncthreads();
+      }
+      for (int c = 0; c < 3; ++c) {
+        uint32_t pos = s_scan[c][tid] - loc[c];  // exclusive
+        if (loc[c] && pos < caps[c]) {
+          for (uint32_t seg = seg0; seg < seg1 && pos < caps[c]; ++seg) {
+            const uint32_t n = cnts[seg * 3 + c];
+            const uint32_t *src_l = lists + (size_t)seg * st + offs[c];
+            for (uint32_t i = 0; i < n && pos < caps[c]; ++i) comp[src * st + offs[c] + pos++] = src_l[i];
+          }
+        }
+        if (tid == FIN_THREADS - 1) s_tot[src][c] = min(s_scan[c][tid], caps[c]);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid != 0) return;
   uint32_t *one = f.out_one + (size_t)q * f.cap1;
   uint32_t *two = f.out_two + (size_t)q * f.cap2;
   uint32_t n1 = 0, n2 = 0;
-  if (f.qm[q].budget != 0) {
-    const uint32_t st = f.cap1 + f.cap2 + f.capx;
-    auto mk = [&](uint32_t cls, uint32_t off) {
+  if (live) {
+    __threadfence_block();
+    auto mk = [&](uint32_t cls) {
       MergedStream s;
-      s.a.init(f.lists + (size_t)q * f.nseg * st, f.cnts + (size_t)q * f.nseg * 3, f.nseg, st, off, cls);
-      s.b.init(f.llists + (size_t)q * f.lnseg * st, f.lcnts + (size_t)q * f.lnseg * 3, f.lnseg, st, off, cls);
+      s.a = ArrStream{comp + offs[cls], s_tot[0][cls], 0};
+      s.b = ArrStream{comp + st + offs[cls], s_tot[1][cls], 0};
       return s;
     };
     // two = first cap2 of (X ∪ S2)
     uint32_t tstar = 0xFFFFFFFFu;
     {
-      MergedStream s2 = mk(1, f.cap1), sx = mk(2, f.cap1 + f.cap2);
+      MergedStream s2 = mk(1), sx = mk(2);
       while (n2 < f.cap2 && !(s2.done() && sx.done())) {
         uint32_t v;
         if (s2.done()) { v = sx.peek(); sx.pop(); }
@@ -488,7 +531,7 @@ __global__ void dict_finalize_kernel(FinalArgs f) {
     }
     // one = first cap1 of (S1 ∪ {x in X : x > t*})
     {
-      MergedStream s1 = mk(0, 0), sx = mk(2, f.cap1 + f.cap2);
+      MergedStream s1 = mk(0), sx = mk(2);
       if (tstar == 0xFFFFFFFFu) {
         while (!sx.done()) sx.pop();  // two never filled: no X word reaches `one`
       } else {
@@ -517,7 +560,7 @@ struct msi_dict {
   uint32_t n_words = 0, n_long = 0;
   DevBuf slots, blen, nchars, flat, offs, long_idx;
   // scratch (guarded by ctx->mu)
-  DevBuf qbytes, qoff, qflags, qm, qchars, lists, cnts, llists, lcnts, pairs, out1, out1c, out2, out2c;
+  DevBuf qbytes, qoff, qflags, qm, qchars, lists, cnts, llists, lcnts, comp, pairs, out1, out1c, out2, out2c;
   uint64_t lookup_launches = 0, dict_bytes = 0;
   KernelTimer match_timer;
 };
@@ -556,6 +599,7 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   MSI_TRY(d->cnts.ensure((size_t)n * nseg * 3 * sizeof(uint32_t)));
   MSI_TRY(d->llists.ensure((size_t)n * lnseg * stride_l * sizeof(uint32_t)));
   MSI_TRY(d->lcnts.ensure((size_t)n * lnseg * 3 * sizeof(uint32_t)));
+  MSI_TRY(d->comp.ensure((size_t)n * 2 * stride_l * sizeof(uint32_t)));
   MSI_HIP_TRY(hipMemsetAsync(d->lcnts.p, 0, (size_t)n * lnseg * 3 * sizeof(uint32_t), st));
   MSI_HIP_TRY(hipMemsetAsync(d->cnts.p, 0, (size_t)n * nseg * 3 * sizeof(uint32_t), st));
   DictArgs a;
@@ -603,11 +647,12 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   f.cap1 = cap1;
   f.cap2 = cap2;
   f.capx = capx;
+  f.comp = d->comp.as<uint32_t>();
   f.out_one = d_one;
   f.out_one_cnt = d_one_cnt;
   f.out_two = d_two;
   f.out_two_cnt = d_two_cnt;
-  hipLaunchKernelGGL(dict_finalize_kernel, dim3((n + 63) / 64), dim3(64), 0, st, f);
+  hipLaunchKernelGGL(dict_finalize_kernel, dim3(n), dim3(FIN_THREADS), 0, st, f);
   MSI_HIP_TRY(hipGetLastError());
   d->lookup_launches++;
   return MSI_OK;
@@ -704,7 +749,7 @@ void msi_dict_destroy(msi_dict *d) {
   DeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(d->ctx->stream);
   DevBuf *bufs[] = {&d->slots, &d->blen, &d->nchars, &d->flat, &d->offs, &d->long_idx, &d->qbytes, &d->qoff,
-                    &d->qflags, &d->qm, &d->qchars, &d->lists, &d->cnts, &d->llists, &d->lcnts, &d->pairs,
+                    &d->qflags, &d->qm, &d->qchars, &d->lists, &d->cnts, &d->llists, &d->lcnts, &d->comp, &d->pairs,
                     &d->out1, &d->out1c, &d->out2, &d->out2c};
   for (DevBuf *b : bufs) b->release();
   d->match_timer.release();

@@ -9,13 +9,17 @@
 //                holds float4 #l (l = g*16+i) = row 16t+i, columns 16kb+4g..+3.
 //                One wave-wide 16-byte load therefore reads one contiguous KiB
 //                and lands directly in v_mfma_f32_16x16x4_f32's A layout.
-//   vs_scan      streams every (allowed) tile once: D[16 rows][16 queries] +=
-//                A·B with the query fragments in LDS; the epilogue scales by
-//                1/|row|, compares against a per-query threshold and only the rare
-//                survivors take the slow path into a per-wave LDS candidate list.
-//   thresholds   a strided sample pass (sqrt(K'·N) rows) gives each query a
-//                valid lower bound on its K'-th best score, so the main pass
-//                keeps ~K'·N/S rows per query instead of warming up per wave.
+//   vs_scan      streams every (allowed) tile once per batch of up to 48 queries:
+//                D[16 rows][16 queries] += A·B per 16-query tile, query fragments
+//                in LDS (the only LDS use).  Two epilogues:
+//                  dense   every score is written to a [query][row] matrix (the
+//                          strided sample pass, and stores too small to sample);
+//                  sparse  scores are compared with a per-query threshold and the
+//                          rare survivors are appended to per-query global lists.
+//   thresholds   the dense sample pass (~2·sqrt(K'·N) rows) gives each query the
+//                r-th best sampled score; r is chosen so that fewer than K'
+//                survivors is a <1e-5 event, and that event is detected
+//                (survivors < K') and re-run exhaustively — never silently wrong.
 //   vs_select    radix-select of the K' best 64-bit keys (score desc, row asc).
 //   vs_rescore   recomputes the K' candidates with the REFERENCE arithmetic
 //                (sequential f32 mul+add, arroy/hannoy's scalar path), orders
@@ -27,6 +31,7 @@
 // distance is the reference's scalar f32 arithmetic.
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -39,13 +44,15 @@ typedef unsigned long long u64;
 namespace {
 
 constexpr int SCAN_WAVES = 8;            // waves per workgroup (512 threads)
-constexpr int SCAN_CAP = 64;             // per-wave, per-query LDS candidate slots
 constexpr int SCAN_GROUP = 8;            // KiB blocks per software-pipeline stage
-constexpr uint32_t LOCAL_KP_MAX = SCAN_CAP - 16;  // K' up to which waves self-compact
 constexpr uint32_t KP_MAX = 1024;        // K' supported by select/rescore
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_SORTCAP = 2048;        // u64 keys sorted in LDS by vs_select
-constexpr int QT = 16;                   // queries per pass (one MFMA tile)
+constexpr int QT = 16;                   // queries per MFMA tile
+constexpr int NQT_MAX = 3;               // query tiles per HBM sweep
+constexpr int NQ_MAX = QT * NQT_MAX;     // queries per HBM sweep
+constexpr int CNT_PAD = 32;              // u32 stride of the per-query counters (one 128-B line each)
+constexpr size_t LDS_MAX = 160 * 1024;
 
 __device__ __forceinline__ u64 make_key_desc(float s, uint32_t row) {
   return ((u64)(~f32_to_ord(s)) << 32) | row;
@@ -80,7 +87,7 @@ __global__ void vs_tile_rows_kernel(const float *__restrict__ rows, uint64_t row
   tiles[(row0 / 16) * KB * 64 + idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// Canonical row norms from the tiled layout: pn = sqrtf(sum_k x_k*x_k), sequential
+// Canonical row norms from the tiled layout: pn = sqrt(sum_k x_k*x_k), sequential
 // f32 mul+add in column order (arroy/hannoy scalar path).  One thread per row.
 __global__ void vs_row_norms_kernel(const float4 *__restrict__ tiles, uint64_t row0,
                                     uint64_t n_rows_total, uint32_t KB, float *__restrict__ norm,
@@ -120,69 +127,99 @@ __global__ void vs_check_sorted_kernel(const uint32_t *__restrict__ docids, uint
 
 // ------------------------------------------------------------- query preparation
 
-// queries row-major [nq][dim] -> MFMA B fragments [KB][64] float4 (lane l=g*16+j:
-// query j, columns 16kb+4g..+3), canonical |q|, thresholds for degenerate rows.
-__global__ void vs_prep_queries_kernel(const float *__restrict__ q, uint32_t nq, uint32_t dim,
-                                       uint32_t KB, float4 *__restrict__ qfrag,
-                                       float *__restrict__ qrow /*[QT][KB*16]*/,
-                                       float *__restrict__ qn, float *__restrict__ inv_qn,
-                                       float *__restrict__ degth) {
-  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t total = KB * 64;
-  uint32_t dpad = KB * 16;
-  for (uint32_t idx = tid; idx < total; idx += gridDim.x * blockDim.x) {
-    uint32_t lane = idx & 63, kb = idx >> 6;
-    uint32_t j = lane & 15, g = lane >> 4;
-    uint32_t k0 = kb * 16 + g * 4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (j < nq)
-      for (int c = 0; c < 4; ++c)
-        if (k0 + c < dim) v[c] = q[(uint64_t)j * dim + k0 + c];
-    qfrag[idx] = make_float4(v[0], v[1], v[2], v[3]);
+// One workgroup per query slot j (0 .. 16*nqt): queries row-major [nq][dim] ->
+//   qfrag [nqt][KB][64] float4 — MFMA B fragments (tile t = j/16, lane l = g*16 + j%16:
+//         query j, columns 16kb+4g..+3),
+//   qrow  [16*nqt][dpad] — zero-padded rows for the canonical rescoring,
+//   canonical |q| (sequential f32 mul+add, then correctly rounded sqrt), its
+//   reciprocal and the threshold that marks a row degenerate (pn*qn <= EPS).
+__global__ __launch_bounds__(256) void vs_prep_queries_kernel(
+    const float *__restrict__ q, uint32_t nq, uint32_t dim, uint32_t KB, float4 *__restrict__ qfrag,
+    float *__restrict__ qrow, float *__restrict__ qn, float *__restrict__ inv_qn,
+    float *__restrict__ degth) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *row = reinterpret_cast<float *>(smem);  // [dpad]
+  const uint32_t j = blockIdx.x;
+  const uint32_t dpad = KB * 16;
+  for (uint32_t k = threadIdx.x; k < dpad; k += blockDim.x)
+    row[k] = (j < nq && k < dim) ? q[(uint64_t)j * dim + k] : 0.f;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < dpad; k += blockDim.x) qrow[(uint64_t)j * dpad + k] = row[k];
+  const uint32_t t = j / QT, jj = j % QT;
+  for (uint32_t idx = threadIdx.x; idx < KB * 4; idx += blockDim.x) {
+    const uint32_t kb = idx >> 2, g = idx & 3;
+    const float4 v = *reinterpret_cast<const float4 *>(row + kb * 16 + g * 4);
+    qfrag[((uint64_t)t * KB + kb) * 64 + g * 16 + jj] = v;
   }
-  for (uint32_t idx = tid; idx < QT * dpad; idx += gridDim.x * blockDim.x) {
-    uint32_t j = idx / dpad, k = idx % dpad;
-    qrow[idx] = (j < nq && k < dim) ? q[(uint64_t)j * dim + k] : 0.f;
-  }
-  if (tid < QT) {
+  if (threadIdx.x == 0) {
     float acc = 0.f;
-    if (tid < nq)
-      for (uint32_t k = 0; k < dim; ++k) {
-        float x = q[(uint64_t)tid * dim + k];
-        acc = __fadd_rn(acc, __fmul_rn(x, x));
-      }
-    float n = msi_sqrt_rn(acc);
-    qn[tid] = n;
-    inv_qn[tid] = n > 0.f ? 1.0f / n : 0.f;
+    for (uint32_t k = 0; k < dim; ++k) acc = __fadd_rn(acc, __fmul_rn(row[k], row[k]));
+    const float n = msi_sqrt_rn(acc);
+    qn[j] = n;
+    inv_qn[j] = n > 0.f ? 1.0f / n : 0.f;
     // row is (conservatively) degenerate when pn*qn <= EPS  <=>  1/pn >= qn/EPS
-    degth[tid] = n * (0.999f / FLT_EPSILON);
+    degth[j] = n * (0.999f / FLT_EPSILON);
   }
 }
 
 // ------------------------------------------------------------------- filter path
 
-// Per-tile 16-bit "row allowed" masks + compacted list of tiles with any allowed
-// row.  One thread per row; a wave covers 4 tiles.
-__global__ void vs_filter_tiles_kernel(const uint32_t *__restrict__ docids, uint64_t n_rows,
-                                       const u64 *__restrict__ fbits, uint64_t nbits,
-                                       uint16_t *__restrict__ tmask, uint32_t *__restrict__ list,
-                                       uint32_t *__restrict__ n_items) {
-  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t padded = ((n_rows + 15) / 16) * 16;
-  bool ok = false;
-  if (r < n_rows) {
-    uint32_t id = docids[r];
-    if ((uint64_t)id < nbits) ok = (fbits[id >> 6] >> (id & 63)) & 1ull;
+// Per-tile 16-bit "row allowed" masks + compacted list of the tiles with any
+// allowed row.  A workgroup of 1024 threads covers FT_SUB*64 consecutive tiles and
+// reserves its slice of the list with ONE global atomic (the list is ordered
+// inside a workgroup; workgroups land in arrival order, which only permutes the
+// order tiles are streamed in).
+constexpr int FT_SUB = 8;
+__global__ __launch_bounds__(1024) void vs_filter_tiles_kernel(
+    const uint32_t *__restrict__ docids, uint64_t n_rows, const u64 *__restrict__ fbits,
+    uint64_t nbits, uint16_t *__restrict__ tmask, uint32_t *__restrict__ list,
+    uint32_t *__restrict__ n_items) {
+  __shared__ uint32_t s_cnt[FT_SUB * 16];
+  __shared__ uint32_t s_base;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t padded = ((n_rows + 15) / 16) * 16;
+  const uint64_t blk_row0 = (uint64_t)blockIdx.x * (1024ull * FT_SUB);
+  u64 bal[FT_SUB];  // wave-uniform: allowed rows of this wave's 4 tiles, per sub-chunk
+#pragma unroll
+  for (int u = 0; u < FT_SUB; ++u) {
+    const uint64_t r = blk_row0 + (uint64_t)u * 1024 + threadIdx.x;
+    bool ok = false;
+    if (r < n_rows) {
+      const uint32_t id = docids[r];
+      if ((uint64_t)id < nbits) ok = (fbits[id >> 6] >> (id & 63)) & 1ull;
+    }
+    const u64 b = __ballot(ok);
+    bal[u] = b;
+    uint32_t c = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c += ((b >> (16 * t)) & 0xFFFFull) != 0;
+    if (lane == 0) s_cnt[u * 16 + wave] = c;
   }
-  u64 b = __ballot(ok);
-  uint32_t lane = threadIdx.x & 63;
-  if (r < padded && (lane & 15) == 0) {
-    uint16_t m = (uint16_t)((b >> lane) & 0xFFFFull);
-    uint64_t t = r >> 4;
-    tmask[t] = m;
-    if (m) {
-      uint32_t slot = atomicAdd(n_items, 1u);
-      list[slot] = (uint32_t)t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int i = 0; i < FT_SUB * 16; ++i) {
+      const uint32_t c = s_cnt[i];
+      s_cnt[i] = tot;
+      tot += c;
+    }
+    s_base = tot ? atomicAdd(n_items, tot) : 0;
+  }
+  __syncthreads();
+  const uint32_t base = s_base;
+  const uint32_t ts = lane >> 4;  // tile slot of this lane inside the wave-row
+#pragma unroll
+  for (int u = 0; u < FT_SUB; ++u) {
+    const uint64_t r = blk_row0 + (uint64_t)u * 1024 + threadIdx.x;
+    if (r < padded && (lane & 15) == 0) {
+      const u64 b = bal[u];
+      const uint16_t m = (uint16_t)((b >> (16 * ts)) & 0xFFFFull);
+      tmask[r >> 4] = m;
+      if (m) {
+        uint32_t before = 0;
+        for (uint32_t t = 0; t < ts; ++t) before += ((b >> (16 * t)) & 0xFFFFull) != 0;
+        list[base + s_cnt[u * 16 + wave] + before] = (uint32_t)(r >> 4);
+      }
     }
   }
 }
@@ -192,41 +229,26 @@ __global__ void vs_filter_tiles_kernel(const uint32_t *__restrict__ docids, uint
 struct ScanArgs {
   const float4 *tiles;
   const float *inv_norm;
-  const float4 *qfrag;
-  const float *theta;            // [QT] pass if !(score < theta)
-  const float *degth;            // [QT]
+  const float4 *qfrag;           // [nqt][KB][64]
+  const float *theta;            // [NQ_MAX] sparse: pass if !(score < theta)
+  const float *degth;            // [NQ_MAX]
   const uint32_t *n_items_ptr;   // number of entries of `list` (or tiles when list==null)
   const uint32_t *list;          // nullable: active tile ids
   const uint16_t *tmask;         // nullable: per-tile allowed-row masks
-  u64 *gkeys;                    // [QT][capg]
-  uint32_t *gcnt;                // [QT]
-  uint32_t *overflow;            // set to 1 if a global buffer overflowed
+  u64 *gkeys;                    // sparse: [NQ_MAX][capg]
+  uint32_t *gcnt;                // sparse: [NQ_MAX][CNT_PAD]
+  uint32_t *overflow;            // set to 1 if a global list overflowed
+  float *dense;                  // dense: [NQ_MAX][dstride], entry = item*16 + row_in_tile
   uint64_t n_rows;
+  uint32_t dstride;
   uint32_t capg;
   uint32_t KB;
   uint32_t stride;               // 1 = every item, S = every S-th item (sample pass)
-  uint32_t kp;                   // K'
+  uint32_t nq;
 };
 
-// 64-lane bitonic sort, ascending, one key per lane.
-__device__ __forceinline__ u64 wave_sort64(u64 key, uint32_t lane) {
-#pragma unroll
-  for (uint32_t k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      u64 other = __shfl_xor(key, (int)j);
-      bool up = ((lane & k) == 0);
-      bool lower = ((lane & j) == 0);
-      bool take_min = (up == lower);
-      u64 mn = key < other ? key : other;
-      u64 mx = key < other ? other : key;
-      key = take_min ? mn : mx;
-    }
-  }
-  return key;
-}
-
-template <int WAVES>
+// NQT = 16-query tiles per sweep; DENSE selects the epilogue.
+template <int WAVES, int NQT, bool DENSE>
 __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x;
@@ -235,25 +257,17 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   const uint32_t KB = a.KB;
 
   float4 *qf = reinterpret_cast<float4 *>(smem);
-  size_t off = (size_t)KB * 64 * sizeof(float4);
-  volatile u64 *ckeys = reinterpret_cast<volatile u64 *>(smem + off) + (size_t)wave * QT * SCAN_CAP;
-  off += (size_t)WAVES * QT * SCAN_CAP * sizeof(u64);
-  volatile uint32_t *ccnt = reinterpret_cast<volatile uint32_t *>(smem + off) + wave * QT;
-  off += (size_t)WAVES * QT * sizeof(uint32_t);
-  volatile float *cth = reinterpret_cast<volatile float *>(smem + off) + wave * QT;
-
-  for (uint32_t i = tid; i < KB * 64; i += WAVES * 64) qf[i] = a.qfrag[i];
-  if (lane < QT) {
-    ccnt[lane] = 0;
-    cth[lane] = a.theta[lane];
-  }
+  for (uint32_t i = tid; i < NQT * KB * 64; i += WAVES * 64) qf[i] = a.qfrag[i];
   __syncthreads();
 
-  const uint32_t qj = lane & 15;   // this lane's query (D column)
+  const uint32_t qj = lane & 15;   // this lane's query inside a tile (D column)
   const uint32_t g = lane >> 4;    // this lane's row group: rows 4g..4g+3 of the tile
-  float th = cth[qj];
-  const float dth = a.degth[qj];
-  const bool local_mode = a.kp <= LOCAL_KP_MAX;
+  float th[NQT], dth[NQT];
+#pragma unroll
+  for (int t = 0; t < NQT; ++t) {
+    th[t] = DENSE ? 0.f : a.theta[t * QT + qj];
+    dth[t] = a.degth[t * QT + qj];
+  }
 
   // this wave's contiguous share of the item list
   const uint32_t n_all = *a.n_items_ptr;
@@ -262,141 +276,124 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   const uint64_t GW = (uint64_t)gridDim.x * WAVES;
   const uint32_t it0 = (uint32_t)((uint64_t)n_items * gw / GW);
   const uint32_t it1 = (uint32_t)((uint64_t)n_items * (gw + 1) / GW);
+  if (it0 >= it1) return;
 
   const uint32_t GPT = KB / SCAN_GROUP;  // pipeline groups per tile
 
   auto tile_of = [&](uint32_t it) -> uint32_t {
-    uint32_t idx = it * a.stride;
+    const uint32_t idx = it * a.stride;
     return a.list ? a.list[idx] : idx;
   };
 
-  // ---- epilogue: scale, threshold, rare slow path -------------------------
-  auto epilogue = [&](uint32_t tile, f32x4 acc) {
+  // ---- epilogue -----------------------------------------------------------------
+  auto epilogue = [&](uint32_t tile, uint32_t it, const f32x4(&acc)[NQT][2]) {
     const uint64_t row0 = (uint64_t)tile * 16 + g * 4;
     const float4 inv = *reinterpret_cast<const float4 *>(a.inv_norm + row0);
     uint32_t allowed = 0xF;
     if (a.tmask) allowed = (a.tmask[tile] >> (g * 4)) & 0xF;
     else if (row0 + 4 > a.n_rows) allowed = row0 >= a.n_rows ? 0u : ((1u << (a.n_rows - row0)) - 1u);
-    float s[4];
-    s[0] = acc[0] * inv.x;
-    s[1] = acc[1] * inv.y;
-    s[2] = acc[2] * inv.z;
-    s[3] = acc[3] * inv.w;
     const float iv[4] = {inv.x, inv.y, inv.z, inv.w};
-    uint32_t pass = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (iv[r] >= dth) s[r] = FLT_MAX;          // pn*qn <= EPS: reference distance is 0
-      if (!(s[r] < th)) pass |= 1u << r;         // NaN passes; fixed up below
-    }
-    pass &= allowed;
-    if (__ballot(pass != 0) == 0) return;
-    // slow path (rare): append survivors to this wave's list for query qj
+    for (int t = 0; t < NQT; ++t) {
+      float s[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (pass & (1u << r)) {
-        float sc = s[r];
-        if (!(sc == sc)) sc = FLT_MAX;
-        uint32_t slot = atomicAdd(const_cast<uint32_t *>(&ccnt[qj]), 1u);
-        ckeys[qj * SCAN_CAP + slot] = make_key_desc(sc, (uint32_t)(row0 + r));
+      for (int r = 0; r < 4; ++r) {
+        float v = (acc[t][0][r] + acc[t][1][r]) * iv[r];
+        if (iv[r] >= dth[t]) v = FLT_MAX;   // pn*qn <= EPS: reference distance is 0 (best)
+        if (!(v == v)) v = FLT_MAX;         // NaN: let the canonical rescoring decide
+        s[r] = v;
       }
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint32_t c = lane < QT ? ccnt[lane] : 0;
-    u64 need = __ballot(c > (uint32_t)(SCAN_CAP - 16));
-    while (need) {
-      const uint32_t j = (uint32_t)__ffsll((long long)need) - 1;
-      need &= need - 1;
-      const uint32_t cj = ccnt[j];
-      u64 key = lane < cj ? ckeys[j * SCAN_CAP + lane] : ~0ull;
-      if (local_mode) {
-        key = wave_sort64(key, lane);
-        if (lane < a.kp) ckeys[j * SCAN_CAP + lane] = key;
-        u64 kth = __shfl(key, (int)(a.kp - 1));
-        if (lane == 0) {
-          ccnt[j] = cj < a.kp ? cj : a.kp;
-          if (cj >= a.kp) cth[j] = key_desc_score(kth);
-        }
+      const uint32_t q = t * QT + qj;
+      if (DENSE) {
+        float4 o;
+        o.x = (allowed & 1u) ? s[0] : -INFINITY;
+        o.y = (allowed & 2u) ? s[1] : -INFINITY;
+        o.z = (allowed & 4u) ? s[2] : -INFINITY;
+        o.w = (allowed & 8u) ? s[3] : -INFINITY;
+        *reinterpret_cast<float4 *>(a.dense + (uint64_t)q * a.dstride + (uint64_t)it * 16 + g * 4) = o;
       } else {
-        // flush mode (large K'): move the list to the global buffer unchanged
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&a.gcnt[j], cj);
-        base = __shfl(base, 0);
-        if (lane < cj) {
-          if (base + lane < a.capg) a.gkeys[(uint64_t)j * a.capg + base + lane] = key;
-          else *a.overflow = 1;
+        uint32_t pass = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (!(s[r] < th[t])) pass |= 1u << r;
+        pass &= allowed;
+        if (q >= a.nq) pass = 0;
+        if (pass) {  // rare: the thresholds leave ~1e3 survivors per query and sweep
+          uint32_t slot = atomicAdd(&a.gcnt[q * CNT_PAD], (uint32_t)__popc(pass));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (pass & (1u << r)) {
+              if (slot < a.capg) a.gkeys[(uint64_t)q * a.capg + slot] = make_key_desc(s[r], (uint32_t)(row0 + r));
+              else *a.overflow = 1;
+              ++slot;
+            }
+          }
         }
-        if (lane == 0) ccnt[j] = 0;
       }
-      __builtin_amdgcn_wave_barrier();
     }
-    th = cth[qj];
   };
 
-  if (it0 < it1) {
-    float4 xa[SCAN_GROUP], xb[SCAN_GROUP];
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-
-    uint32_t it_load = it0, sub_load = 0;   // next group to load
-    uint32_t it_cmp = it0, sub_cmp = 0;     // next group to compute
-    uint32_t tile_load = tile_of(it_load);
-    uint32_t tile_cmp = tile_load;
-
-    auto load_group = [&](float4(&x)[SCAN_GROUP]) {
-      const float4 *p = a.tiles + ((uint64_t)tile_load * KB + (uint64_t)sub_load * SCAN_GROUP) * 64 + lane;
+  float4 xa[SCAN_GROUP], xb[SCAN_GROUP];
+  f32x4 acc[NQT][2];
 #pragma unroll
-      for (int u = 0; u < SCAN_GROUP; ++u) x[u] = p[u * 64];
-      if (++sub_load == GPT) {
-        sub_load = 0;
-        ++it_load;
-        if (it_load < it1) tile_load = tile_of(it_load);
-      }
-    };
-    auto compute_group = [&](const float4(&x)[SCAN_GROUP]) {
-      const float4 *qp = qf + (size_t)sub_cmp * SCAN_GROUP * 64 + lane;
-#pragma unroll
-      for (int u = 0; u < SCAN_GROUP; ++u) {
-        const float4 q = qp[u * 64];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].x, q.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].y, q.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].z, q.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].w, q.w, acc, 0, 0, 0);
-      }
-      if (++sub_cmp == GPT) {
-        epilogue(tile_cmp, acc);
-        acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        sub_cmp = 0;
-        ++it_cmp;
-        if (it_cmp < it1) tile_cmp = tile_of(it_cmp);
-      }
-    };
-
-    // Software pipeline: loads run one group (8 KiB per wave) ahead of the MFMAs.
-    load_group(xa);
-    for (;;) {
-      bool more = it_load < it1;
-      if (more) load_group(xb);
-      compute_group(xa);
-      if (!more) break;
-      more = it_load < it1;
-      if (more) load_group(xa);
-      compute_group(xb);
-      if (!more) break;
-    }
+  for (int t = 0; t < NQT; ++t) {
+    acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- flush this wave's lists to the global per-query buffers ---------------
-  __builtin_amdgcn_wave_barrier();
-  for (uint32_t j = 0; j < QT; ++j) {
-    const uint32_t cj = ccnt[j];
-    if (cj == 0) continue;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&a.gcnt[j], cj);
-    base = __shfl(base, 0);
-    if (lane < cj) {
-      if (base + lane < a.capg) a.gkeys[(uint64_t)j * a.capg + base + lane] = ckeys[j * SCAN_CAP + lane];
-      else *a.overflow = 1;
+  uint32_t it_load = it0, sub_load = 0;   // next group to load
+  uint32_t it_cmp = it0, sub_cmp = 0;     // next group to compute
+  uint32_t tile_load = tile_of(it_load);
+  uint32_t tile_cmp = tile_load;
+
+  auto load_group = [&](float4(&x)[SCAN_GROUP]) {
+    const float4 *p = a.tiles + ((uint64_t)tile_load * KB + (uint64_t)sub_load * SCAN_GROUP) * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < SCAN_GROUP; ++u) x[u] = p[u * 64];
+    if (++sub_load == GPT) {
+      sub_load = 0;
+      ++it_load;
+      if (it_load < it1) tile_load = tile_of(it_load);
     }
+  };
+  auto compute_group = [&](const float4(&x)[SCAN_GROUP]) {
+    const float4 *qp = qf + (size_t)sub_cmp * SCAN_GROUP * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < SCAN_GROUP; ++u) {
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {
+        const float4 q = qp[(size_t)t * KB * 64 + u * 64];
+        // two independent accumulators per query tile: no dependent-MFMA stall
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].x, q.x, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].y, q.y, acc[t][1], 0, 0, 0);
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].z, q.z, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].w, q.w, acc[t][1], 0, 0, 0);
+      }
+    }
+    if (++sub_cmp == GPT) {
+      epilogue(tile_cmp, it_cmp, acc);
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {
+        acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      sub_cmp = 0;
+      ++it_cmp;
+      if (it_cmp < it1) tile_cmp = tile_of(it_cmp);
+    }
+  };
+
+  // Software pipeline: loads run one group (8 KiB per wave) ahead of the MFMAs.
+  load_group(xa);
+  for (;;) {
+    bool more = it_load < it1;
+    if (more) load_group(xb);
+    compute_group(xa);
+    if (!more) break;
+    more = it_load < it1;
+    if (more) load_group(xa);
+    compute_group(xb);
+    if (!more) break;
   }
 }
 
@@ -428,14 +425,33 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t v) {
   return p;
 }
 
-// Leaves the min(c,K) smallest keys of keys[0..c), ascending, in sbuf[0..) and
+// Where vs_select reads its candidates from: a list of keys (sparse scan, the
+// exhaustive path) or a dense score matrix row (dense scan) whose entry i belongs
+// to row tile_of(i/16)*16 + i%16; -inf entries (disallowed rows) become the
+// sentinel key ~0, which sorts last and is dropped by the callers.
+struct KeySrc {
+  const u64 *keys;
+  const float *dense;
+  const uint32_t *list;
+  uint32_t stride;
+  __device__ __forceinline__ u64 get(uint32_t i) const {
+    if (keys) return keys[i];
+    const float s = dense[i];
+    if (s == -INFINITY) return ~0ull;
+    const uint32_t item = (i >> 4) * stride;
+    const uint32_t tile = list ? list[item] : item;
+    return make_key_desc(s, tile * 16 + (i & 15));
+  }
+};
+
+// Leaves the min(c,K) smallest keys of src[0..c), ascending, in sbuf[0..) and
 // returns their count.  K <= KP_MAX, sbuf has SEL_SORTCAP entries, hist 2048.
-__device__ uint32_t block_select_smallest(const u64 *__restrict__ keys, uint32_t c, uint32_t K,
-                                          u64 *sbuf, uint32_t *hist, uint32_t *sh) {
+__device__ uint32_t block_select_smallest(const KeySrc &src, uint32_t c, uint32_t K, u64 *sbuf,
+                                          uint32_t *hist, uint32_t *sh) {
   const uint32_t tid = threadIdx.x;
   if (c <= SEL_SORTCAP) {
     uint32_t n = next_pow2(c < 2 ? 2 : c);
-    for (uint32_t i = tid; i < n; i += blockDim.x) sbuf[i] = i < c ? keys[i] : ~0ull;
+    for (uint32_t i = tid; i < n; i += blockDim.x) sbuf[i] = i < c ? src.get(i) : ~0ull;
     __syncthreads();
     block_bitonic_sort(sbuf, n);
     return c < K ? c : K;
@@ -450,7 +466,7 @@ __device__ uint32_t block_select_smallest(const u64 *__restrict__ keys, uint32_t
     for (uint32_t i = tid; i < 2048; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < c; i += blockDim.x) {
-      u64 key = keys[i];
+      u64 key = src.get(i);
       if (pbits == 0 || (key >> (64 - pbits)) == prefix)
         atomicAdd(&hist[(uint32_t)(key >> shift) & ((1u << dbits) - 1u)], 1u);
     }
@@ -476,7 +492,7 @@ __device__ uint32_t block_select_smallest(const u64 *__restrict__ keys, uint32_t
       if (tid == 0) sh[3] = 0;
       __syncthreads();
       for (uint32_t i = tid; i < c; i += blockDim.x) {
-        u64 key = keys[i];
+        u64 key = src.get(i);
         if ((key >> shift) <= newprefix) {
           uint32_t slot = atomicAdd(&sh[3], 1u);
           if (slot < SEL_SORTCAP) sbuf[slot] = key;
@@ -497,33 +513,67 @@ __device__ uint32_t block_select_smallest(const u64 *__restrict__ keys, uint32_t
   return 0;  // unreachable
 }
 
+// Number of leading non-sentinel keys among sbuf[0..got) (sorted ascending).
+__device__ uint32_t block_count_valid(const u64 *sbuf, uint32_t got, uint32_t *sh_valid) {
+  if (threadIdx.x == 0) *sh_valid = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < got; i += blockDim.x)
+    if (sbuf[i] != ~0ull) atomicAdd(sh_valid, 1u);
+  __syncthreads();
+  return *sh_valid;
+}
+
 struct SelectArgs {
-  const u64 *gkeys;    // [QT][capg]
-  uint32_t *gcnt;      // [QT]; reset to 0 on exit
+  // input: sparse lists ...
+  const u64 *gkeys;            // [NQ_MAX][capg]
+  const uint32_t *gcnt;        // [NQ_MAX][CNT_PAD]
   uint32_t capg;
-  uint32_t kp;
-  u64 *sel_keys;       // [QT][KP_MAX]   (mode 1)
-  uint32_t *sel_cnt;   // [QT]           (mode 1)
-  float *theta;        // [QT]           (mode 0: threshold for the main pass)
-  int mode;            // 0 = threshold only, 1 = keep the keys
+  // ... or the dense score matrix of a dense scan
+  const float *dense;          // [NQ_MAX][dstride]; null = sparse input
+  uint32_t dstride;
+  const uint32_t *n_items_ptr;
+  const uint32_t *list;
+  uint32_t stride;
+  // output
+  uint32_t K;                  // mode 0: the threshold rank r, mode 1: K'
+  u64 *sel_keys;               // [NQ_MAX][KP_MAX]   (mode 1)
+  uint32_t *sel_cnt;           // [NQ_MAX]           (mode 1)
+  float *theta;                // [NQ_MAX]           (mode 0: threshold for the sparse pass)
+  int mode;                    // 0 = threshold only, 1 = keep the keys
 };
 
 __global__ __launch_bounds__(SEL_THREADS) void vs_select_kernel(SelectArgs a) {
   __shared__ u64 sbuf[SEL_SORTCAP];
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t sh[4];
+  __shared__ uint32_t sh_valid;
   const uint32_t j = blockIdx.x;
-  uint32_t c = a.gcnt[j];
-  if (c > a.capg) c = a.capg;
-  const uint32_t got = block_select_smallest(a.gkeys + (uint64_t)j * a.capg, c, a.kp, sbuf, hist, sh);
-  __syncthreads();
-  if (a.mode == 0) {
-    if (threadIdx.x == 0) a.theta[j] = got >= a.kp ? key_desc_score(sbuf[a.kp - 1]) : -INFINITY;
+  KeySrc src;
+  uint32_t c;
+  if (a.dense) {
+    src.keys = nullptr;
+    src.dense = a.dense + (uint64_t)j * a.dstride;
+    src.list = a.list;
+    src.stride = a.stride;
+    const uint32_t n_all = *a.n_items_ptr;
+    c = ((n_all + a.stride - 1) / a.stride) * 16;
   } else {
-    for (uint32_t i = threadIdx.x; i < got; i += blockDim.x) a.sel_keys[(uint64_t)j * KP_MAX + i] = sbuf[i];
-    if (threadIdx.x == 0) a.sel_cnt[j] = got;
+    src.keys = a.gkeys + (uint64_t)j * a.capg;
+    src.dense = nullptr;
+    src.list = nullptr;
+    src.stride = 1;
+    c = a.gcnt[j * CNT_PAD];
+    if (c > a.capg) c = a.capg;
   }
-  if (threadIdx.x == 0) a.gcnt[j] = 0;
+  const uint32_t got = block_select_smallest(src, c, a.K, sbuf, hist, sh);
+  __syncthreads();
+  const uint32_t valid = block_count_valid(sbuf, got, &sh_valid);
+  if (a.mode == 0) {
+    if (threadIdx.x == 0) a.theta[j] = valid >= a.K ? key_desc_score(sbuf[a.K - 1]) : -INFINITY;
+  } else {
+    for (uint32_t i = threadIdx.x; i < valid; i += blockDim.x) a.sel_keys[(uint64_t)j * KP_MAX + i] = sbuf[i];
+    if (threadIdx.x == 0) a.sel_cnt[j] = valid;
+  }
 }
 
 // --------------------------------------------------------------------- rescore
@@ -561,11 +611,11 @@ struct RescoreArgs {
   const float4 *tiles;
   const float *norm;
   const uint32_t *docids;
-  const float *qrow;       // [QT][dpad]
-  const float *qn;         // [QT]
-  const float *inv_qn;     // [QT]
-  const u64 *sel_keys;     // [QT][KP_MAX]
-  const uint32_t *sel_cnt; // [QT]
+  const float *qrow;       // [NQ_MAX][dpad]
+  const float *qn;         // [NQ_MAX]
+  const float *inv_qn;     // [NQ_MAX]
+  const u64 *sel_keys;     // [NQ_MAX][KP_MAX]
+  const uint32_t *sel_cnt; // [NQ_MAX]
   uint32_t KB;
   uint32_t kp;
   uint32_t k;
@@ -575,6 +625,7 @@ struct RescoreArgs {
   uint32_t *out_counts;    // [nq]
   uint32_t *inexact;       // [nq]
   const uint32_t *overflow;
+  const float *theta;      // nullable: thresholds the sparse pass ran with
 };
 
 __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) {
@@ -617,6 +668,8 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) 
     // Exactness proof.  Unselected rows have fast cos <= cmin, hence reference
     // cos <= cmin + eps, hence reference distance >= (1 - cmin - eps)/2 - 2e-7.
     uint32_t bad = *a.overflow ? 1u : 0u;
+    // a thresholded pass that kept fewer than K' rows may have cut real neighbours
+    if (a.theta && a.theta[j] > -INFINITY && cnt < a.kp) bad = 1;
     if (cnt == a.kp && out_n > 0) {
       const float smin = key_desc_score(a.sel_keys[(uint64_t)j * KP_MAX + cnt - 1]);
       const float cmin = smin * a.inv_qn[j];
@@ -664,16 +717,16 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_exhaustive_select_kernel(
   __shared__ u64 sbuf[SEL_SORTCAP];
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t sh[4];
-  uint32_t got = block_select_smallest(keys, c, k, sbuf, hist, sh);
+  __shared__ uint32_t sh_valid;
+  KeySrc src;
+  src.keys = keys;
+  src.dense = nullptr;
+  src.list = nullptr;
+  src.stride = 1;
+  const uint32_t got = block_select_smallest(src, c, k, sbuf, hist, sh);
   __syncthreads();
   // disallowed rows carry key ~0: drop them
-  __shared__ uint32_t valid;
-  if (threadIdx.x == 0) valid = 0;
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < got; i += blockDim.x)
-    if (sbuf[i] != ~0ull) atomicAdd(&valid, 1u);
-  __syncthreads();
-  const uint32_t out_n = valid;
+  const uint32_t out_n = block_count_valid(sbuf, got, &sh_valid);
   for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
     uint32_t id = 0xFFFFFFFFu;
     float d = INFINITY;
@@ -703,15 +756,15 @@ __global__ void vs_gather_row_kernel(const float4 *__restrict__ tiles, uint32_t 
 struct msi_vs {
   msi_ctx *ctx = nullptr;
   uint32_t dim = 0, dpad = 0, KB = 0;
+  uint32_t nqt_max = 1;            // query tiles per sweep the LDS admits for this dim
   uint64_t n_rows = 0, n_tiles = 0;
   DevBuf tiles, norm, inv_norm, docids;
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
   // scratch (guarded by ctx->mu)
-  DevBuf qraw, qfrag, qrow, qsmall /* qn, inv_qn, degth, theta[2] */, gkeys, gsmall, sel_keys,
-      tmask, tlist, fbits, out_docids, out_dist, out_small, exh_keys, rowtmp;
+  DevBuf qraw, qfrag, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fbits, out_docids,
+      out_dist, exh_keys, rowtmp;
   uint32_t capg = 0;
   uint32_t scan_grid = 0;
-  uint32_t waves = SCAN_WAVES;
   // stats
   uint64_t scan_launches = 0, scan_tiles = 0, exhaustive_reruns = 0;
   KernelTimer scan_timer;
@@ -722,43 +775,51 @@ namespace {
 // layout of the small scratch arrays
 struct Small {
   float *qn, *inv_qn, *degth, *theta_inf, *theta;
-  uint32_t *gcnt, *sel_cnt, *n_tiles, *n_items, *overflow, *inexact, *counts, *bad;
+  uint32_t *sel_cnt, *n_tiles, *n_items, *overflow, *bad, *inexact, *counts;
 };
 
 Small small_of(msi_vs *vs) {
   Small s;
   float *f = vs->qsmall.as<float>();
   s.qn = f;
-  s.inv_qn = f + QT;
-  s.degth = f + 2 * QT;
-  s.theta_inf = f + 3 * QT;
-  s.theta = f + 4 * QT;
+  s.inv_qn = f + NQ_MAX;
+  s.degth = f + 2 * NQ_MAX;
+  s.theta_inf = f + 3 * NQ_MAX;
+  s.theta = f + 4 * NQ_MAX;
   uint32_t *u = vs->gsmall.as<uint32_t>();
-  s.gcnt = u;
-  s.sel_cnt = u + QT;
-  s.n_tiles = u + 2 * QT;
-  s.n_items = u + 2 * QT + 1;
-  s.overflow = u + 2 * QT + 2;
-  s.bad = u + 2 * QT + 3;
-  s.inexact = u + 3 * QT;
-  s.counts = u + 4 * QT;
+  s.sel_cnt = u;
+  s.inexact = u + NQ_MAX;
+  s.counts = u + 2 * NQ_MAX;
+  s.n_tiles = u + 3 * NQ_MAX;
+  s.n_items = u + 3 * NQ_MAX + 1;
+  s.overflow = u + 3 * NQ_MAX + 2;
+  s.bad = u + 3 * NQ_MAX + 3;
   return s;
 }
 
-size_t scan_lds_bytes(uint32_t KB, uint32_t waves) {
-  return (size_t)KB * 64 * sizeof(float4) + (size_t)waves * QT * SCAN_CAP * sizeof(u64) +
-         (size_t)waves * QT * (sizeof(uint32_t) + sizeof(float));
+size_t scan_lds_bytes(uint32_t KB, uint32_t nqt) { return (size_t)nqt * KB * 64 * sizeof(float4); }
+
+// Threshold rank r for the sample pass: the smallest r for which "fewer than kp
+// rows of the whole store beat the r-th best of a p-fraction sample" has
+// probability C(kp+r-1, r) p^r <= 1e-5 (a detected, exhaustively re-run event).
+uint32_t threshold_rank(uint32_t kp, double p) {
+  for (uint32_t r = 1; r < kp; ++r) {
+    double lg = 0.0;  // log C(kp+r-1, r) + r log p
+    for (uint32_t i = 1; i <= r; ++i) lg += log((double)(kp - 1 + i) / (double)i);
+    lg += r * log(p);
+    if (lg <= log(1e-5)) return r;
+  }
+  return kp;
 }
 
-void launch_scan(msi_vs *vs, const ScanArgs &sa);
-
 int32_t ensure_scratch(msi_vs *vs) {
-  MSI_TRY(vs->qraw.ensure((size_t)QT * vs->dim * sizeof(float)));
-  MSI_TRY(vs->qfrag.ensure((size_t)vs->KB * 64 * sizeof(float4)));
-  MSI_TRY(vs->qrow.ensure((size_t)QT * vs->dpad * sizeof(float)));
-  MSI_TRY(vs->qsmall.ensure(5 * QT * sizeof(float)));
-  MSI_TRY(vs->gsmall.ensure(6 * QT * sizeof(uint32_t)));
-  MSI_TRY(vs->sel_keys.ensure((size_t)QT * KP_MAX * sizeof(u64)));
+  MSI_TRY(vs->qraw.ensure((size_t)NQ_MAX * vs->dim * sizeof(float)));
+  MSI_TRY(vs->qfrag.ensure((size_t)NQT_MAX * vs->KB * 64 * sizeof(float4)));
+  MSI_TRY(vs->qrow.ensure((size_t)NQ_MAX * vs->dpad * sizeof(float)));
+  MSI_TRY(vs->qsmall.ensure(5 * NQ_MAX * sizeof(float)));
+  MSI_TRY(vs->gsmall.ensure((3 * NQ_MAX + 8) * sizeof(uint32_t)));
+  MSI_TRY(vs->gcnt.ensure((size_t)NQ_MAX * CNT_PAD * sizeof(uint32_t)));
+  MSI_TRY(vs->sel_keys.ensure((size_t)NQ_MAX * KP_MAX * sizeof(u64)));
   return MSI_OK;
 }
 
@@ -812,8 +873,8 @@ int32_t upload_common(msi_vs *vs, const uint32_t *docids, bool docids_on_device,
                        vs->inv_norm.as<float>());
   uint32_t nt32 = (uint32_t)n_tiles;
   MSI_HIP_TRY(hipMemcpyAsync(s.n_tiles, &nt32, sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  float ninf[QT];
-  for (int i = 0; i < QT; ++i) ninf[i] = -INFINITY;  // threshold of the first pass
+  float ninf[NQ_MAX];
+  for (int i = 0; i < NQ_MAX; ++i) ninf[i] = -INFINITY;  // "everything passes"
   MSI_HIP_TRY(hipMemcpyAsync(s.theta_inf, ninf, sizeof(ninf), hipMemcpyHostToDevice, st));
   uint32_t bad = 0;
   MSI_HIP_TRY(hipMemcpyAsync(&bad, s.bad, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -831,15 +892,32 @@ int32_t upload_common(msi_vs *vs, const uint32_t *docids, bool docids_on_device,
   }
   vs->n_rows = n_rows;
   vs->n_tiles = n_tiles;
-  // per-query global candidate buffers: every wave may flush SCAN_CAP keys per query
-  vs->scan_grid = (uint32_t)ctx->n_cu;
-  vs->capg = vs->scan_grid * vs->waves * SCAN_CAP * 2;
-  MSI_TRY(vs->gkeys.ensure((size_t)QT * vs->capg * sizeof(u64)));
-  MSI_HIP_TRY(hipMemsetAsync(vs->gsmall.p, 0, 2 * QT * sizeof(uint32_t), st));  // gcnt, sel_cnt
+  // sparse-pass candidate lists: room for 256 Ki keys per query (the thresholds
+  // leave ~1e3; an overflow is detected and re-run exhaustively)
+  vs->capg = 1u << 18;
+  MSI_TRY(vs->gkeys.ensure((size_t)NQ_MAX * vs->capg * sizeof(u64)));
   return MSI_OK;
 }
 
-// Enqueue the full pipeline for <= QT queries already in device memory.
+// Launch one sweep.  `dense` selects the epilogue, nqt the number of 16-query tiles.
+void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense) {
+  const size_t lds = scan_lds_bytes(vs->KB, nqt);
+  const dim3 grid(vs->scan_grid), block(SCAN_WAVES * 64);
+  hipStream_t st = vs->ctx->stream;
+#define MSI_SCAN_CASE(N)                                                                          \
+  case N:                                                                                         \
+    if (dense) hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, true>), grid, block, lds, st, sa); \
+    else hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, false>), grid, block, lds, st, sa);      \
+    break;
+  switch (nqt) {
+    MSI_SCAN_CASE(1)
+    MSI_SCAN_CASE(2)
+    MSI_SCAN_CASE(3)
+  }
+#undef MSI_SCAN_CASE
+}
+
+// Enqueue the full pipeline for <= 16*nqt_max queries already in device memory.
 // d_fbits nullable.  Outputs are device pointers.
 int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t k, const u64 *d_fbits,
                        uint64_t nbits, uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_counts,
@@ -847,16 +925,17 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   msi_ctx *ctx = vs->ctx;
   hipStream_t st = ctx->stream;
   Small s = small_of(vs);
-  const uint32_t slack = std::max<uint32_t>(12, k / 4);
-  uint32_t kp = k + slack;
-  if (kp > KP_MAX) kp = KP_MAX;
   if (k > KP_MAX) {
     msi_set_error("msi_vs_search: k=%u above the supported maximum %u", k, KP_MAX);
     return MSI_E_UNSUPPORTED;
   }
+  const uint32_t slack = std::max<uint32_t>(12, k / 4);
+  const uint32_t kp = std::min<uint32_t>(k + slack, KP_MAX);
+  const uint32_t nqt = (nq + QT - 1) / QT;
   // 1. queries
-  hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(16), dim3(256), 0, st, d_queries, nq, vs->dim, vs->KB,
-                     vs->qfrag.as<float4>(), vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth);
+  hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
+                     d_queries, nq, vs->dim, vs->KB, vs->qfrag.as<float4>(), vs->qrow.as<float>(), s.qn,
+                     s.inv_qn, s.degth);
   MSI_HIP_TRY(hipMemsetAsync(s.overflow, 0, sizeof(uint32_t), st));
   // 2. filter
   const uint32_t *list = nullptr;
@@ -867,67 +946,96 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
     MSI_TRY(vs->tlist.ensure(vs->n_tiles * sizeof(uint32_t)));
     MSI_HIP_TRY(hipMemsetAsync(s.n_items, 0, sizeof(uint32_t), st));
     const uint64_t padded = vs->n_tiles * 16;
-    hipLaunchKernelGGL(vs_filter_tiles_kernel, dim3((uint32_t)((padded + 255) / 256)), dim3(256), 0, st,
-                       vs->docids.as<uint32_t>(), vs->n_rows, d_fbits, nbits, vs->tmask.as<uint16_t>(),
-                       vs->tlist.as<uint32_t>(), s.n_items);
+    const uint64_t rows_per_block = 1024ull * FT_SUB;
+    hipLaunchKernelGGL(vs_filter_tiles_kernel, dim3((uint32_t)((padded + rows_per_block - 1) / rows_per_block)),
+                       dim3(1024), 0, st, vs->docids.as<uint32_t>(), vs->n_rows, d_fbits, nbits,
+                       vs->tmask.as<uint16_t>(), vs->tlist.as<uint32_t>(), s.n_items);
     list = vs->tlist.as<uint32_t>();
     tmask = vs->tmask.as<uint16_t>();
     n_items_ptr = s.n_items;
   }
+  // 3. plan: small stores are scored densely in one sweep; larger ones get a dense
+  //    strided sample sweep (thresholds) followed by the sparse full sweep.
+  const uint64_t n_tiles = vs->n_tiles;
+  const uint64_t n_rows_pad = n_tiles * 16;
+  uint32_t stride = 1;
+  uint32_t thr_rank = kp;
+  if (n_rows_pad > 32768) {
+    const double s_rows = std::min<double>((double)n_rows_pad / 4.0,
+                                           std::max(4096.0, 2.0 * sqrt((double)kp * (double)n_rows_pad)));
+    stride = (uint32_t)std::max<uint64_t>(1, (uint64_t)((double)n_rows_pad / s_rows));
+    if (stride > 1) thr_rank = std::min(kp, threshold_rank(kp, 1.0 / (double)stride));
+  }
+  const uint64_t dense_items = (n_tiles + stride - 1) / stride;
+  const uint32_t dstride = (uint32_t)(dense_items * 16);
+  MSI_TRY(vs->dense.ensure((size_t)NQ_MAX * std::max<uint32_t>(16, dstride) * sizeof(float)));
+
   ScanArgs sa;
   sa.tiles = vs->tiles.as<float4>();
   sa.inv_norm = vs->inv_norm.as<float>();
   sa.qfrag = vs->qfrag.as<float4>();
+  sa.theta = s.theta_inf;
   sa.degth = s.degth;
   sa.n_items_ptr = n_items_ptr;
   sa.list = list;
   sa.tmask = tmask;
   sa.gkeys = vs->gkeys.as<u64>();
-  sa.gcnt = s.gcnt;
+  sa.gcnt = vs->gcnt.as<uint32_t>();
   sa.overflow = s.overflow;
+  sa.dense = vs->dense.as<float>();
   sa.n_rows = vs->n_rows;
+  sa.dstride = dstride;
   sa.capg = vs->capg;
   sa.KB = vs->KB;
-  sa.kp = kp;
+  sa.stride = stride;
+  sa.nq = nq;
   SelectArgs se;
   se.gkeys = vs->gkeys.as<u64>();
-  se.gcnt = s.gcnt;
+  se.gcnt = vs->gcnt.as<uint32_t>();
   se.capg = vs->capg;
-  se.kp = kp;
+  se.dense = vs->dense.as<float>();
+  se.dstride = dstride;
+  se.n_items_ptr = n_items_ptr;
+  se.list = list;
+  se.stride = stride;
   se.sel_keys = vs->sel_keys.as<u64>();
   se.sel_cnt = s.sel_cnt;
   se.theta = s.theta;
-  // 3. sample pass -> thresholds.  Sample ~sqrt(K'*N) rows, skipped for small stores.
-  const uint64_t n_tiles = vs->n_tiles;
-  uint32_t stride = 1;
-  if (n_tiles) {
-    const double s_rows = sqrt((double)kp * (double)(n_tiles * 16)) * 2.0;
-    const uint64_t s_tiles = std::max<uint64_t>(64, (uint64_t)(s_rows / 16.0));
-    if (n_tiles >= s_tiles * 8) stride = (uint32_t)(n_tiles / s_tiles);
-  }
-  const float *theta = s.theta_inf;
-  if (stride > 1) {
-    sa.theta = s.theta_inf;
-    sa.stride = stride;
-    launch_scan(vs, sa);
-    se.mode = 0;
-    hipLaunchKernelGGL(vs_select_kernel, dim3(QT), dim3(SEL_THREADS), 0, st, se);
-    theta = s.theta;
+  const float *theta_used = nullptr;
+  if (stride == 1) {
+    // dense main sweep; the K' best come straight out of the score matrix
+    vs->scan_timer.begin(ctx);
+    launch_scan(vs, sa, nqt, true);
+    vs->scan_timer.end(ctx);
     vs->scan_launches++;
-    vs->scan_tiles += n_tiles / stride;
+    vs->scan_tiles += n_tiles;
+    se.K = kp;
+    se.mode = 1;
+    hipLaunchKernelGGL(vs_select_kernel, dim3(nq), dim3(SEL_THREADS), 0, st, se);
+  } else {
+    // sample sweep -> thresholds
+    launch_scan(vs, sa, nqt, true);
+    vs->scan_launches++;
+    vs->scan_tiles += dense_items;
+    se.K = thr_rank;
+    se.mode = 0;
+    hipLaunchKernelGGL(vs_select_kernel, dim3(nqt * QT), dim3(SEL_THREADS), 0, st, se);
+    // full sweep, sparse epilogue
+    MSI_HIP_TRY(hipMemsetAsync(vs->gcnt.p, 0, (size_t)NQ_MAX * CNT_PAD * sizeof(uint32_t), st));
+    sa.theta = s.theta;
+    sa.stride = 1;
+    vs->scan_timer.begin(ctx);
+    launch_scan(vs, sa, nqt, false);
+    vs->scan_timer.end(ctx);
+    vs->scan_launches++;
+    vs->scan_tiles += n_tiles;
+    se.dense = nullptr;
+    se.K = kp;
+    se.mode = 1;
+    hipLaunchKernelGGL(vs_select_kernel, dim3(nq), dim3(SEL_THREADS), 0, st, se);
+    theta_used = s.theta;
   }
-  // 4. main pass
-  sa.theta = theta;
-  sa.stride = 1;
-  vs->scan_timer.begin(ctx);
-  launch_scan(vs, sa);
-  vs->scan_timer.end(ctx);
-  vs->scan_launches++;
-  vs->scan_tiles += n_tiles;
-  // 5. select K' best per query
-  se.mode = 1;
-  hipLaunchKernelGGL(vs_select_kernel, dim3(QT), dim3(SEL_THREADS), 0, st, se);
-  // 6. rescore with the reference arithmetic, order, prove exactness
+  // rescore with the reference arithmetic, order, prove exactness
   RescoreArgs ra;
   ra.tiles = vs->tiles.as<float4>();
   ra.norm = vs->norm.as<float>();
@@ -946,19 +1054,12 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   ra.out_counts = d_out_counts;
   ra.inexact = d_inexact;
   ra.overflow = s.overflow;
+  ra.theta = theta_used;
   if (k > 0)
     hipLaunchKernelGGL(vs_rescore_kernel, dim3(nq), dim3(SEL_THREADS),
                        KP_MAX * sizeof(u64) + (size_t)vs->dpad * sizeof(float), st, ra);
   MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
-}
-
-void launch_scan(msi_vs *vs, const ScanArgs &sa) {
-  const size_t lds = scan_lds_bytes(vs->KB, vs->waves);
-  if (vs->waves == 8)
-    hipLaunchKernelGGL(vs_scan_kernel<8>, dim3(vs->scan_grid), dim3(8 * 64), lds, vs->ctx->stream, sa);
-  else
-    hipLaunchKernelGGL(vs_scan_kernel<4>, dim3(vs->scan_grid), dim3(4 * 64), lds, vs->ctx->stream, sa);
 }
 
 int32_t exhaustive_one(msi_vs *vs, uint32_t qj, uint32_t k, const u64 *d_fbits, uint64_t nbits,
@@ -990,22 +1091,31 @@ int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out) {
   *out = nullptr;
   const uint32_t dpad = ((dim + 127) / 128) * 128;  // KB multiple of SCAN_GROUP
   const uint32_t KB = dpad / 16;
-  uint32_t waves = SCAN_WAVES;
-  if (scan_lds_bytes(KB, waves) > 160 * 1024) waves = 4;
-  if (scan_lds_bytes(KB, waves) > 160 * 1024) {
-    msi_set_error("msi_vs_create: dim %u needs %zu B of LDS for one query tile (max 163840)", dim,
-                  scan_lds_bytes(KB, waves));
+  if (scan_lds_bytes(KB, 1) > LDS_MAX) {
+    msi_set_error("msi_vs_create: dim %u needs %zu B of LDS for one query tile (max %zu)", dim,
+                  scan_lds_bytes(KB, 1), LDS_MAX);
     return MSI_E_UNSUPPORTED;
   }
+  uint32_t nqt_max = 1;
+  while (nqt_max < (uint32_t)NQT_MAX && scan_lds_bytes(KB, nqt_max + 1) <= LDS_MAX) ++nqt_max;
+  if (const char *e = getenv("MSI_VS_MAX_QUERY_TILES")) {  // tuning/testing knob
+    const int v = atoi(e);
+    if (v >= 1 && (uint32_t)v < nqt_max) nqt_max = (uint32_t)v;
+  }
   DeviceGuard g(ctx->device);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vs_scan_kernel<8>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vs_scan_kernel<4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) {
-    msi_set_error("hipFuncSetAttribute(vs_scan) failed: %s", hipGetErrorString(e));
-    return MSI_E_HIP;
+  const void *fns[] = {
+      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 1, true>),
+      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 1, false>),
+      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 2, true>),
+      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 2, false>),
+      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 3, true>),
+      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 3, false>)};
+  for (const void *fn : fns) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    if (e != hipSuccess) {
+      msi_set_error("hipFuncSetAttribute(vs_scan) failed: %s", hipGetErrorString(e));
+      return MSI_E_HIP;
+    }
   }
   msi_vs *vs = new msi_vs();
   vs->ctx = ctx;
@@ -1013,7 +1123,14 @@ int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out) {
   vs->dim = dim;
   vs->dpad = dpad;
   vs->KB = KB;
-  vs->waves = waves;
+  vs->nqt_max = nqt_max;
+  // workgroups per CU: two when the query fragments leave room (more loads in flight)
+  uint32_t wg_per_cu = scan_lds_bytes(KB, nqt_max) <= LDS_MAX / 2 ? 2 : 1;
+  if (const char *e = getenv("MSI_VS_WG_PER_CU")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 4) wg_per_cu = (uint32_t)v;
+  }
+  vs->scan_grid = (uint32_t)ctx->n_cu * wg_per_cu;
   *out = vs;
   return MSI_OK;
 }
@@ -1022,15 +1139,15 @@ void msi_vs_destroy(msi_vs *vs) {
   if (!vs) return;
   msi_ctx *ctx = vs->ctx;
   {
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  DeviceGuard g(ctx->device);
-  (void)hipStreamSynchronize(vs->ctx->stream);
-  DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qrow,
-                    &vs->qsmall, &vs->gkeys, &vs->gsmall, &vs->sel_keys, &vs->tmask, &vs->tlist, &vs->fbits,
-                    &vs->out_docids, &vs->out_dist, &vs->out_small, &vs->exh_keys, &vs->rowtmp};
-  for (DevBuf *b : bufs) b->release();
-  vs->scan_timer.release();
-  delete vs;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qrow,
+                      &vs->qsmall, &vs->gkeys, &vs->gcnt, &vs->gsmall, &vs->sel_keys, &vs->dense, &vs->tmask,
+                      &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp};
+    for (DevBuf *b : bufs) b->release();
+    vs->scan_timer.release();
+    delete vs;
   }
   msi_ctx_release(ctx);
 }
@@ -1057,6 +1174,7 @@ int32_t msi_vs_upload_device(msi_vs *vs, const uint32_t *d_docids, const float *
 
 uint64_t msi_vs_len(const msi_vs *vs) { return vs ? vs->n_rows : 0; }
 uint32_t msi_vs_dim(const msi_vs *vs) { return vs ? vs->dim : 0; }
+uint32_t msi_vs_max_batch(const msi_vs *vs) { return vs ? vs->nqt_max * QT : 0; }
 
 int32_t msi_vs_get_vector(msi_vs *vs, uint32_t docid, float *out_row, int32_t *out_found) {
   if (!vs || !out_row || !out_found) {
@@ -1072,7 +1190,7 @@ int32_t msi_vs_get_vector(msi_vs *vs, uint32_t docid, float *out_row, int32_t *o
   }
   const uint32_t row = (uint32_t)(it - vs->h_docids.begin());
   hipStream_t st = vs->ctx->stream;
-  MSI_TRY(vs->qraw.ensure((size_t)QT * vs->dim * sizeof(float)));
+  MSI_TRY(vs->qraw.ensure((size_t)NQ_MAX * vs->dim * sizeof(float)));
   hipLaunchKernelGGL(vs_gather_row_kernel, dim3(ceil_div_u32(vs->dim, 256)), dim3(256), 0, st,
                      vs->tiles.as<float4>(), vs->KB, row, vs->dim, vs->qraw.as<float>());
   MSI_HIP_TRY(hipMemcpyAsync(out_row, vs->qraw.p, vs->dim * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1084,8 +1202,8 @@ int32_t msi_vs_get_vector(msi_vs *vs, uint32_t docid, float *out_row, int32_t *o
 int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries, uint32_t n_queries, uint32_t k,
                              const uint64_t *d_filter_bits, uint64_t filter_nbits, uint32_t *d_out_docids,
                              float *d_out_dist, uint32_t *d_out_counts, uint32_t *d_inexact) {
-  if (!vs || !d_queries || n_queries == 0 || n_queries > QT || !d_out_docids || !d_out_dist || !d_out_counts) {
-    msi_set_error("msi_vs_search_device: invalid argument (1..16 queries per call)");
+  if (!vs || !d_queries || n_queries == 0 || !d_out_docids || !d_out_dist || !d_out_counts) {
+    msi_set_error("msi_vs_search_device: invalid argument");
     return MSI_E_INVALID;
   }
   std::lock_guard<std::mutex> lk(vs->ctx->mu);
@@ -1095,8 +1213,15 @@ int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries, uint32_t n_quer
     if (d_inexact) MSI_HIP_TRY(hipMemsetAsync(d_inexact, 0, n_queries * sizeof(uint32_t), vs->ctx->stream));
     return MSI_OK;
   }
-  return enqueue_search(vs, d_queries, n_queries, k, (const u64 *)d_filter_bits, filter_nbits, d_out_docids,
-                        d_out_dist, d_out_counts, d_inexact);
+  // one HBM sweep per chunk of msi_vs_max_batch() queries
+  const uint32_t step = vs->nqt_max * QT;
+  for (uint32_t q0 = 0; q0 < n_queries; q0 += step) {
+    const uint32_t nq = std::min(step, n_queries - q0);
+    MSI_TRY(enqueue_search(vs, d_queries + (size_t)q0 * vs->dim, nq, k, (const u64 *)d_filter_bits, filter_nbits,
+                           d_out_docids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k, d_out_counts + q0,
+                           d_inexact ? d_inexact + q0 : nullptr));
+  }
+  return MSI_OK;
 }
 
 int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries, uint32_t k,
@@ -1122,14 +1247,15 @@ int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries, uint
     d_fbits = vs->fbits.as<u64>();
   }
   const uint32_t kk = std::max<uint32_t>(1, k);
-  MSI_TRY(vs->out_docids.ensure((size_t)QT * kk * sizeof(uint32_t)));
-  MSI_TRY(vs->out_dist.ensure((size_t)QT * kk * sizeof(float)));
-  for (uint32_t q0 = 0; q0 < n_queries; q0 += QT) {
+  const uint32_t step = vs->nqt_max * QT;
+  MSI_TRY(vs->out_docids.ensure((size_t)NQ_MAX * kk * sizeof(uint32_t)));
+  MSI_TRY(vs->out_dist.ensure((size_t)NQ_MAX * kk * sizeof(float)));
+  for (uint32_t q0 = 0; q0 < n_queries; q0 += step) {
     if (cancel && *cancel) {
       msi_set_error("msi_vs_search: cancelled");
       return MSI_E_CANCELLED;
     }
-    const uint32_t nq = std::min<uint32_t>(QT, n_queries - q0);
+    const uint32_t nq = std::min<uint32_t>(step, n_queries - q0);
     if (k == 0 || vs->n_rows == 0) {
       for (uint32_t j = 0; j < nq; ++j) out_counts[q0 + j] = 0;
       continue;
@@ -1138,7 +1264,7 @@ int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries, uint
                                hipMemcpyHostToDevice, st));
     MSI_TRY(enqueue_search(vs, vs->qraw.as<float>(), nq, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>(),
                            vs->out_dist.as<float>(), s.counts, s.inexact));
-    uint32_t h_inexact[QT];
+    uint32_t h_inexact[NQ_MAX];
     MSI_HIP_TRY(hipMemcpyAsync(h_inexact, s.inexact, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipStreamSynchronize(st));
     for (uint32_t j = 0; j < nq; ++j) {

@@ -52,6 +52,11 @@ class GpuStore:
     def __len__(self):
         return int(lib().msi_vs_len(self._h))
 
+    @property
+    def max_batch(self):
+        """Queries answered by one HBM sweep (16/32/48, by dimension)."""
+        return int(lib().msi_vs_max_batch(self._h))
+
     def get_vector(self, docid):
         out = np.zeros(self.dim, dtype=np.float32)
         found = C.c_int32(0)
@@ -77,7 +82,8 @@ class GpuStore:
 
     def search_device(self, q_t, k, out_docids_t, out_dist_t, out_counts_t, inexact_t=None,
                       filter_ptr=None, filter_nbits=0):
-        """Enqueue one <=16-query search on the context stream; no sync."""
+        """Enqueue a search on the context stream (chunks of `max_batch` queries
+        per HBM sweep); no sync."""
         nq = q_t.shape[0]
         check(lib().msi_vs_search_device(
             self._h, C.c_void_p(q_t.data_ptr()), nq, k, filter_ptr, filter_nbits,

@@ -127,6 +127,40 @@ def test_large_scan_and_sample_pass(ctx, oracle):
     assert s1["exhaustive_reruns"] == s0["exhaustive_reruns"]
 
 
+def test_three_query_tiles_sparse_and_filtered(ctx, oracle):
+    # 40 queries = three 16-query MFMA tiles in ONE sweep (dim 128 leaves room for 48),
+    # on a store large enough for the sample + sparse passes; then the same with a filter
+    n, dim = 120000, 128
+    rows = synth.make_embeddings(n, dim, seed=81)
+    ids = np.arange(n, dtype=np.uint32) * 2 + 1
+    qs = synth.make_embeddings(40, dim, seed=82)
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    assert st.max_batch == 48
+    s0 = st.stats()
+    check_against_oracle(oracle, st, rows, ids, qs, 20)
+    s1 = st.stats()
+    assert s1["scan_launches"] - s0["scan_launches"] == 2      # one sample + one full sweep for all 40
+    assert s1["exhaustive_reruns"] == s0["exhaustive_reruns"]
+    rng = np.random.default_rng(83)
+    for sel in (0.3, 0.01, 0.0005):
+        allowed = ids[rng.random(n) < sel]
+        fb, nb = ma.dense_filter(allowed, nbits=int(ids.max()) + 1)
+        check_against_oracle(oracle, st, rows, ids, qs[:19], 20, fb, nb)
+    # a single query (15 idle columns in the MFMA tile) and an odd batch
+    check_against_oracle(oracle, st, rows, ids, qs[:1], 20)
+    check_against_oracle(oracle, st, rows, ids, qs[:17], 5)
+
+
+def test_objects_may_outlive_their_context():
+    c2 = ma.Context(0)
+    st = ma.GpuStore(c2, 8)
+    st.upload([1, 2, 3], np.ones((3, 8), dtype=f32))
+    d, s, c = st.search(np.ones((1, 8), dtype=f32), 2)
+    c2.close()          # drops the caller's reference only
+    st.close()          # the store's reference frees the context
+
+
 def test_round_trip_and_idempotence(ctx):
     # size-independent properties: every stored row's nearest neighbour is itself
     # (distance ~0) and a repeated search returns identical bits
