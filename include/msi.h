@@ -131,6 +131,19 @@ int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries,
                              float *d_out_dist, uint32_t *d_out_counts,
                              uint32_t *d_inexact);
 
+/*
+ * Host-side merge of `n_lists` ascending result lists (list l occupies
+ * docids/dist[l*list_stride .. + counts[l])) into the `k_out` best by
+ * (distance, docid): the concatenate + sort_unstable_by_key tail of
+ * nns_by_vector over an embedder's stores (store.rs:1059,1090), and the final
+ * step of a row-sharded search (one list per GPU after the all-gather).
+ * Returns the number of entries written.  No device work.
+ */
+uint32_t msi_merge_topk(const uint32_t *docids, const float *dist,
+                        const uint32_t *counts, uint32_t n_lists,
+                        uint32_t list_stride, uint32_t k_out,
+                        uint32_t *out_docids, float *out_dist);
+
 /* Introspection for benchmarks/tests. */
 typedef struct msi_vs_stats {
   uint64_t scan_launches;      /* vs_scan kernel launches so far (sample + full sweeps) */

@@ -6,6 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
 #include "msi_common.h"
 
 static thread_local char g_err[512] = "";
@@ -98,6 +102,36 @@ int32_t msi_ctx_synchronize(msi_ctx *ctx) {
   DeviceGuard g(ctx->device);
   MSI_HIP_TRY(hipStreamSynchronize(ctx->stream));
   return MSI_OK;
+}
+
+// ---- host-side list merge ------------------------------------------------------
+
+// The tail of VectorStore::nns_by_vector (crates/milli/src/vector/store.rs:1059,1090):
+// the per-store result lists are concatenated and sorted by distance.  Also the
+// final step of a row-sharded search (one list per GPU).  Ties: ascending docid
+// (search/new/tests/cutoff.rs:507-626), which makes the result independent of the
+// number of shards.  No device work.
+uint32_t msi_merge_topk(const uint32_t *docids, const float *dist, const uint32_t *counts,
+                        uint32_t n_lists, uint32_t list_stride, uint32_t k_out,
+                        uint32_t *out_docids, float *out_dist) {
+  if (!docids || !dist || !counts || (k_out && (!out_docids || !out_dist))) return 0;
+  std::vector<uint64_t> pos;
+  for (uint32_t l = 0; l < n_lists; ++l) {
+    const uint32_t c = std::min(counts[l], list_stride);
+    for (uint32_t i = 0; i < c; ++i) pos.push_back((uint64_t)l * list_stride + i);
+  }
+  auto less = [&](uint64_t a, uint64_t b) {
+    const uint32_t oa = f32_to_ord(dist[a]), ob = f32_to_ord(dist[b]);
+    if (oa != ob) return oa < ob;
+    return docids[a] < docids[b];
+  };
+  const size_t n = std::min<size_t>(pos.size(), k_out);
+  std::partial_sort(pos.begin(), pos.begin() + n, pos.end(), less);
+  for (size_t i = 0; i < n; ++i) {
+    out_docids[i] = docids[pos[i]];
+    out_dist[i] = dist[pos[i]];
+  }
+  return (uint32_t)n;
 }
 
 // ---- scoring arithmetic (host; these run on the Rust caller's thread) -------

@@ -39,19 +39,33 @@ typedef unsigned long long u64;
 
 namespace {
 
-constexpr int QC = 32;            // queries per wave chunk
-constexpr int DW = 4;             // waves per workgroup
+constexpr int QC = 64;            // queries per workgroup chunk (6-bit query slot in a pair)
+constexpr int DW = 4;             // waves per workgroup (all on the same query chunk)
 constexpr int QSTRIDE = 256;      // code points reserved per query
+constexpr int QL = 32;            // query code points staged in LDS (longer queries read HBM)
+constexpr int PQ = 256;           // pair-queue ring entries per wave (power of two, >= 63 + 128)
 constexpr int DINF = 1 << 20;
+constexpr uint32_t QNONE = 0xFFFFFFFFu;  // "no such query char": never equals a word char
+constexpr uint32_t WNONE = 0xFFFFFFFDu;  // "no such word char"
 
-struct QueryMeta {
+struct alignas(64) QueryMeta {   // one 64-byte scalar load per (tile, query) step
   uint32_t m;        // chars
   uint32_t budget;   // 1 or 2 (0 = skip)
   uint32_t prefix;
-  uint32_t q0, q1;   // first two code points (q1 = 0xFFFFFFFF when m < 2)
-  uint32_t lo, hi;   // dictionary range of words starting with q0
   uint32_t _pad;
+  uint32_t lo, hi;   // dictionary range of the words starting with the query's first char
+  u64 sig;           // char-presence signature (bit = sig_bit(code point))
+  // (first, second) char pairs of the four one-edit shapes that change the first char
+  u64 p12;           // (q1, q2): substitute q0 -> w[1..2];  delete q0 -> w[0..1]
+  u64 p01;           // (q0, q1): insert before q0 -> w[1..2]
+  u64 p10;           // (q1, q0): swap q0 q1 -> w[0..1]
+  u64 _pad2;
 };
+static_assert(sizeof(QueryMeta) == 64, "QueryMeta is one 64-byte line");
+
+// 6-bit hash of a code point for the char-presence signatures.
+__host__ __device__ __forceinline__ uint32_t sig_bit(uint32_t cp) { return (cp * 0x9E3779B1u) >> 26; }
+__device__ __forceinline__ u64 pair_key(uint32_t a, uint32_t b) { return (u64)a | ((u64)b << 32); }
 
 __device__ __forceinline__ uint32_t utf8_len(uint32_t b0) {
   return b0 < 0x80 ? 1u : (b0 < 0xE0 ? 2u : (b0 < 0xF0 ? 3u : 4u));
@@ -111,28 +125,45 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
+// Query code points of the lane's OWN query: the first QL from LDS, the rest from HBM.
+struct QChars {
+  const uint32_t *lds;   // this lane's row of the staged chunk
+  const uint32_t *glb;   // this lane's row of a.qchars
+  int m;
+  __device__ __forceinline__ uint32_t at(int t) const {  // t is wave-uniform
+    if (t < 0 || t >= m) return QNONE;
+    return t < QL ? lds[t] : glb[t];
+  }
+};
+
 // Banded optimal-string-alignment distance (insert / delete / substitute /
 // adjacent transposition, each cost 1 — levenshtein_automata 0.2.1 with
 // transposition_cost_one = true, crates/milli/src/search/mod.rs:32-34) between
-// the query chars qc[0..m) and the lane's word (nch chars), exact whenever the
-// true value is <= K.  prefix: minimum over the prefixes of the word
-// (build_prefix_dfa, search/mod.rs:572-573).  Returns > K when not matched.
-// All lanes step through the word positions together; `qc` and `m` are
-// wave-uniform.
-template <int K, class Reader>
-__device__ __forceinline__ int osa_banded(Reader rd, int nch, bool active,
-                                          const uint32_t *__restrict__ qc, int m, bool prefix) {
-  constexpr int W = 2 * K + 1;
+// the lane's query (m chars) and the lane's word (nch chars): every lane of the
+// wave works on its OWN (query, word) pair.  The band is 5 diagonals (|i-j| <= 2)
+// for every lane; the result is exact whenever the true value is <= K (K = 1 or 2
+// per lane) and > K otherwise.  prefix: minimum over the prefixes of the word
+// (build_prefix_dfa, search/mod.rs:572-573).  All lanes step through the word
+// positions together, so the cell index i = j + d - 2 is wave-uniform and the
+// query window slides by one LDS read per step.
+template <class Reader>
+__device__ __forceinline__ int osa_pair(Reader rd, int nch, bool active, const QChars &qs, int K, bool prefix) {
+  constexpr int W = 5, KB2 = 2;
+  const int m = qs.m;
   int prev2[W], prev[W], cur[W];
 #pragma unroll
   for (int d = 0; d < W; ++d) {
     prev2[d] = DINF;
-    const int i = d - K;
+    const int i = d - KB2;
     prev[d] = (i >= 0 && i <= m) ? i : DINF;
   }
   int best = (prefix && m <= K) ? m : DINF;  // the empty prefix
   const int ne = active ? min(nch, m + K) : 0;
   const int nmax = wave_max_i32(ne);
+  // qw[t] = q[j - 4 + t] at step j (0-based chars); cell d uses q[i-1] = qw[d+1], q[i-2] = qw[d]
+  uint32_t qw[W + 1];
+#pragma unroll
+  for (int t = 0; t < W + 1; ++t) qw[t] = qs.at(t - 3);  // step j = 1
   uint32_t wprev = 0xFFFFFFFEu;
   for (int j = 1; j <= nmax; ++j) {
     const uint32_t wc = rd.next_char();
@@ -140,21 +171,22 @@ __device__ __forceinline__ int osa_banded(Reader rd, int nch, bool active,
     int bandmin = DINF;
 #pragma unroll
     for (int d = 0; d < W; ++d) {
-      const int i = j + d - K;  // wave-uniform
+      const int i = j + d - KB2;  // wave-uniform
       int v;
-      if (i < 0 || i > m) {
+      if (i < 0) {
         v = DINF;
       } else if (i == 0) {
         v = j;
       } else {
-        const uint32_t qi = qc[i - 1];
+        const uint32_t qi = qw[d + 1];
         v = prev[d] + (qi != wc ? 1 : 0);
         if (d > 0) v = min(v, cur[d - 1] + 1);
         if (d < W - 1) v = min(v, prev[d + 1] + 1);
         if (i >= 2 && j >= 2) {
-          const uint32_t qim = qc[i - 2];
+          const uint32_t qim = qw[d];
           if (qi == wprev && qim == wc) v = min(v, prev2[d] + 1);
         }
+        if (i > m) v = DINF;  // per lane
       }
       cur[d] = v;
       bandmin = min(bandmin, v);
@@ -166,20 +198,47 @@ __device__ __forceinline__ int osa_banded(Reader rd, int nch, bool active,
     }
     wprev = upd ? wc : wprev;
     if (prefix) {
-      const int dm = m - j + K;  // wave-uniform
+      const int dm = m - j + KB2;  // per lane
 #pragma unroll
       for (int d = 0; d < W; ++d)
         if (dm == d && upd) best = min(best, cur[d]);
     }
     if (!__any(upd && bandmin <= K)) break;  // every still-running lane is out of budget
+#pragma unroll
+    for (int t = 0; t < W; ++t) qw[t] = qw[t + 1];
+    qw[W] = qs.at(j + 2);
   }
   if (prefix) return best;
-  const int dm = m - nch + K;  // per lane
+  const int dm = m - nch + KB2;  // per lane
   int res = DINF;
 #pragma unroll
   for (int d = 0; d < W; ++d)
     if (dm == d) res = prev[d];
   return (active && nch <= m + K) ? res : DINF;
+}
+
+// First three chars (WNONE when absent) and char-presence signature of the lane's word.
+struct WordKeys {
+  u64 w01, w12, sig;
+};
+template <class Reader>
+__device__ __forceinline__ WordKeys scan_word(Reader rd, int nc, int nmax) {
+  uint32_t wc0 = WNONE, wc1 = WNONE, wc2 = WNONE;
+  u64 sig = 0;
+  for (int j = 0; j < nmax; ++j) {
+    const uint32_t c = rd.next_char();
+    if (j < nc) {
+      sig |= 1ull << sig_bit(c);
+      wc0 = j == 0 ? c : wc0;
+      wc1 = j == 1 ? c : wc1;
+      wc2 = j == 2 ? c : wc2;
+    }
+  }
+  WordKeys k;
+  k.w01 = pair_key(wc0, wc1);
+  k.w12 = pair_key(wc1, wc2);
+  k.sig = sig;
+  return k;
 }
 
 // ---- matching kernel -----------------------------------------------------------
@@ -196,32 +255,124 @@ struct DictArgs {
   const QueryMeta *qm;      // [nq]
   const uint32_t *qchars;   // [nq][QSTRIDE]
   uint32_t nq;
-  uint32_t nseg;
+  uint32_t nseg;            // dictionary segments (a multiple of DW)
   uint32_t cap1, cap2, capx;
   uint32_t *lists;          // [nq][nseg][cap1+cap2+capx]
   uint32_t *cnts;           // [nq][nseg][3]
-  u64 *pairs;               // stats: (query, word) pairs that reached a lane
+  u64 *pairs;               // stats: (query, word) pairs that reached a DP lane
 };
 
+// Two phases per 64-word tile, both with every lane busy:
+//   filter  lane = word; the wave walks the queries of its chunk (wave-uniform
+//           query data) and applies the length / first-char tests; survivors are
+//           appended, in lane order, to a per-wave ring of (word lane, query, class)
+//           pairs with ballots (no atomics);
+//   match   whenever 64 pairs are queued (and at the end of the tile) every lane
+//           takes ONE pair — its own word and its own query — and runs the banded
+//           OSA DP, so the DP lanes are dense instead of following the ~5 % of the
+//           (word, query) grid that survives the filter.
+// Hits are appended to the per-(query, segment, class) lists in dictionary order:
+// pairs of one (query, class) are contiguous in the ring and ordered by word.
 template <bool LONG>
-__global__ __launch_bounds__(DW * 64) void dict_match_kernel(DictArgs a) {
+__global__ __launch_bounds__(DW * 64) void dict_match_kernel(DictArgs a, const QueryMeta *__restrict__ qmeta) {
+  __shared__ uint32_t s_qch[QC][QL];          // staged query code points
+  __shared__ uint32_t s_qmb[QC];              // m | budget << 16 | prefix << 24
+  __shared__ uint4 s_slot[DW][64];            // the wave's current tile
+  __shared__ uint32_t s_wmeta[DW][64];        // nc | bl << 8
+  __shared__ uint32_t s_widx[DW][64];
+  __shared__ uint32_t s_pq[DW][PQ];
   __shared__ uint32_t s_cnt[DW][QC][3];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t gw = blockIdx.x * DW + wave;
-  const uint32_t seg = gw % a.nseg;
-  const uint32_t chunk = gw / a.nseg;
+  const uint32_t bps = a.nseg / DW;           // workgroups per query chunk
+  const uint32_t chunk = blockIdx.x / bps;
+  const uint32_t seg = (blockIdx.x % bps) * DW + wave;
   const uint32_t q_begin = chunk * QC;
-  if (q_begin >= a.nq) return;
-  const uint32_t q_end = min(a.nq, q_begin + QC);
+  const uint32_t nqc = min((uint32_t)QC, a.nq - q_begin);
+  for (uint32_t i = threadIdx.x; i < nqc * QL; i += DW * 64)
+    s_qch[i / QL][i % QL] = a.qchars[(size_t)(q_begin + i / QL) * QSTRIDE + (i % QL)];
+  for (uint32_t i = threadIdx.x; i < nqc; i += DW * 64) {
+    const QueryMeta &q = a.qm[q_begin + i];
+    s_qmb[i] = q.m | (q.budget << 16) | (q.prefix << 24);
+  }
   for (uint32_t i = lane; i < QC * 3; i += 64) (&s_cnt[wave][0][0])[i] = 0;
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
 
   const uint32_t n_tiles = (a.n_items + 63) / 64;
   const uint32_t t0 = (uint32_t)((u64)n_tiles * seg / a.nseg);
   const uint32_t t1 = (uint32_t)((u64)n_tiles * (seg + 1) / a.nseg);
   const uint32_t stride_l = a.cap1 + a.cap2 + a.capx;
+  const u64 lower = (1ull << lane) - 1ull;
   u64 pairs = 0;
+  uint32_t head = 0, qn = 0;  // ring state (wave-uniform)
+  bool tile_ascii = false;
+
+  // ---- match phase: lanes [0, n) take one queued pair each ---------------------
+  auto drain = [&](uint32_t n) {
+    const bool act = lane < n;
+    const uint32_t desc = s_pq[wave][(head + lane) & (PQ - 1)];
+    const uint32_t wl = desc & 63, ql = (desc >> 6) & 63, cls = (desc >> 12) & 1;
+    const uint32_t qlc = act ? ql : 0;
+    const uint4 slot = s_slot[wave][wl];
+    const uint32_t wm = s_wmeta[wave][wl];
+    const uint32_t widx = s_widx[wave][wl];
+    const int nc = (int)(wm & 0xFF);
+    const uint32_t qmb = s_qmb[qlc];
+    const int m = (int)(qmb & 0xFFFF);
+    const uint32_t budget = (qmb >> 16) & 0xFF;
+    const bool prefix = (qmb >> 24) != 0;
+    const int K = cls ? 1 : (int)budget;
+    QChars qs;
+    qs.lds = &s_qch[qlc][0];
+    qs.glb = a.qchars + (size_t)(q_begin + qlc) * QSTRIDE;
+    qs.m = act ? m : 0;
+    int d;
+    if (LONG) {
+      const uint32_t o0 = act ? a.offs[widx] : 0, o1 = act ? a.offs[widx + 1] : 0;
+      FlatReader r{a.flat + o0, a.flat + o1};
+      d = osa_pair(r, nc, act, qs, K, prefix);
+    } else if (tile_ascii) {
+      SlotReader<true> r{slot.x, slot.y, slot.z, slot.w};
+      d = osa_pair(r, nc, act, qs, K, prefix);
+    } else {
+      SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
+      d = osa_pair(r, nc, act, qs, K, prefix);
+    }
+    // category: 0 = S1 (same first char, distance 1), 1 = S2 (distance 2), 2 = X
+    uint32_t cat = 3;
+    if (act) {
+      if (cls == 0) cat = d == 1 ? 0u : ((budget == 2 && d == 2) ? 1u : 3u);
+      else cat = d <= 1 ? 2u : 3u;
+    }
+    // pairs of one query are contiguous: segment = run of equal query slots
+    const uint32_t prev_ql = __shfl_up(ql, 1);
+    const bool is_start = act && (lane == 0 || prev_ql != ql);
+    const u64 starts = __ballot(is_start);
+    const u64 upto = lower | (1ull << lane);
+    const uint32_t p = 63 - __clzll((long long)(starts & upto));      // segment start (act lanes only)
+    const u64 above = starts & ~upto;
+    const uint32_t nxt = above ? (uint32_t)__ffsll((long long)above) - 1 : n;
+    const u64 segmask = (nxt >= 64 ? ~0ull : ((1ull << nxt) - 1ull)) & ~((1ull << p) - 1ull);
+    uint32_t *lst = a.lists + ((size_t)(q_begin + qlc) * a.nseg + seg) * stride_l;
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+      const u64 hb = __ballot(cat == c);
+      if (hb == 0) continue;
+      const uint32_t cap = c == 0 ? a.cap1 : (c == 1 ? a.cap2 : a.capx);
+      const uint32_t off = c == 0 ? 0 : (c == 1 ? a.cap1 : a.cap1 + a.cap2);
+      const uint32_t base = act ? s_cnt[wave][qlc][c] : 0;
+      if (cat == c) {
+        const uint32_t pos = base + __popcll(hb & segmask & lower);
+        if (pos < cap) lst[off + pos] = widx;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (is_start) s_cnt[wave][qlc][c] = base + __popcll(hb & segmask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    pairs += n;
+    head = (head + n) & (PQ - 1);
+    qn -= n;
+  };
 
   for (uint32_t t = t0; t < t1; ++t) {
     const uint32_t item = t * 64 + lane;
@@ -237,112 +388,86 @@ __global__ __launch_bounds__(DW * 64) void dict_match_kernel(DictArgs a) {
     }
     // words longer than a slot belong to the LONG launch; empty words never match
     const bool mine = in_range && bl > 0 && (LONG ? true : bl <= 16);
-    const bool tile_ascii = !LONG && (__ballot(mine && nc != bl) == 0);
-    // first two chars (prefilter of the other-first-char class)
-    uint32_t wc0, wc1;
+    tile_ascii = !LONG && (__ballot(mine && nc != bl) == 0);
+    s_slot[wave][lane] = slot;
+    s_wmeta[wave][lane] = nc | (bl << 8);
+    s_widx[wave][lane] = idx;
+    // per-word filter keys: first three chars as (w0,w1) / (w1,w2) pairs and the
+    // char-presence signature of the whole word
+    WordKeys wk;
     {
-      SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
-      wc0 = r.next_char();
-      wc1 = nc >= 2 ? r.next_char() : 0xFFFFFFFDu;
+      const int ncm = mine ? (int)nc : 0;
+      const int nmax = wave_max_i32(ncm);
+      if (LONG) {
+        const uint32_t o0 = mine ? a.offs[idx] : 0, o1 = mine ? a.offs[idx + 1] : 0;
+        wk = scan_word(FlatReader{a.flat + o0, a.flat + o1}, ncm, nmax);
+      } else if (tile_ascii) {
+        wk = scan_word(SlotReader<true>{slot.x, slot.y, slot.z, slot.w}, ncm, nmax);
+      } else {
+        wk = scan_word(SlotReader<false>{slot.x, slot.y, slot.z, slot.w}, ncm, nmax);
+      }
     }
+    const u64 w01 = wk.w01, w12 = wk.w12, wsig = wk.sig;
     // dictionary index range covered by this tile (ascending within the tile)
-    const uint32_t idx_first = __shfl(idx, 0);
-    uint32_t idx_last = idx;
+    const uint32_t idx_first = __builtin_amdgcn_readfirstlane(__shfl(idx, 0));
+    uint32_t idx_last;
     {
       const u64 bm = __ballot(in_range);
       const int last_lane = 63 - __clzll((long long)bm);
-      idx_last = __shfl(idx, last_lane);
+      idx_last = __builtin_amdgcn_readfirstlane(__shfl(idx, last_lane));
     }
+    __builtin_amdgcn_wave_barrier();
 
-    for (uint32_t q = q_begin; q < q_end; ++q) {
-      const QueryMeta qm = a.qm[q];
-      if (qm.budget == 0) continue;
+    // ---- filter phase: query data is wave-uniform (scalar loads), tests branch-free --
+    QueryMeta qnext = qmeta[q_begin];
+    for (uint32_t ql = 0; ql < nqc; ++ql) {
+      const QueryMeta qm = qnext;
+      qnext = qmeta[q_begin + min(ql + 1, nqc - 1)];   // prefetch: hides the scalar-load latency
+      const uint32_t budget = qm.budget;
+      if (budget == 0) continue;
+      const uint32_t lo = qm.lo, hi = qm.hi;
+      const bool tile_hits_s = (idx_last >= lo) & (idx_first < hi);
+      const bool tile_all_s = (idx_first >= lo) & (idx_last < hi);
+      if (!tile_hits_s & (budget != 2)) continue;   // one-typo words only live in [lo, hi)
       const int m = (int)qm.m;
       const bool prefix = qm.prefix != 0;
-      const uint32_t *qc = a.qchars + (size_t)q * QSTRIDE;
-      const bool tile_hits_s = idx_last >= qm.lo && idx_first < qm.hi;
-      const bool tile_all_s = idx_first >= qm.lo && idx_last < qm.hi;
-      const bool same_first = mine && idx >= qm.lo && idx < qm.hi;
-      bool f1 = false, f2 = false, fx = false;
-
-      // --- same first char: exact distance with the budget's automaton --------
-      if (tile_hits_s) {
-        const int K = (int)qm.budget;
-        const bool act = same_first && (prefix ? (int)nc + K >= m : ((int)nc + K >= m && (int)nc <= m + K));
-        if (__any(act)) {
-          int d;
-          if (LONG) {
-            FlatReader r{a.flat + a.offs[in_range ? idx : 0], a.flat + a.offs[in_range ? idx + 1 : 0]};
-            d = K == 1 ? osa_banded<1>(r, (int)nc, act, qc, m, prefix) : osa_banded<2>(r, (int)nc, act, qc, m, prefix);
-          } else if (tile_ascii) {
-            SlotReader<true> r{slot.x, slot.y, slot.z, slot.w};
-            d = K == 1 ? osa_banded<1>(r, (int)nc, act, qc, m, prefix) : osa_banded<2>(r, (int)nc, act, qc, m, prefix);
-          } else {
-            SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
-            d = K == 1 ? osa_banded<1>(r, (int)nc, act, qc, m, prefix) : osa_banded<2>(r, (int)nc, act, qc, m, prefix);
-          }
-          f1 = act && d == 1;
-          f2 = act && K == 2 && d == 2;
-          pairs += __popcll(__ballot(act));
-        }
+      const int K = (int)budget;
+      const bool same_first = mine & (idx >= lo) & (idx < hi);
+      // every char of the query but <= K must occur in the word (and, without the
+      // prefix rule, vice versa): each edit introduces at most one new char
+      const uint32_t q_not_w = __popcll(qm.sig & ~wsig);
+      const uint32_t w_not_q = prefix ? 0u : __popcll(wsig & ~qm.sig);
+      const uint32_t sigd = max(q_not_w, w_not_q);
+      // length window for K edits: nc + K >= m, and nc <= m + K unless the prefix rule applies
+      const int ncK_s = (int)nc + K, ncK_x = (int)nc + 1;
+      const bool len_s = (ncK_s >= m) & (prefix | ((int)nc <= m + K));
+      const bool len_x = (ncK_x >= m) & (prefix | ((int)nc <= m + 1));
+      const bool act_s = tile_hits_s & same_first & len_s & (sigd <= (uint32_t)K);
+      // A word with another first char can only be at distance <= 1 through ONE edit
+      // that touches position 0: substitute q0 (w[1..] = q[1..]), delete q0 (w = q[1..]),
+      // insert before q0 (w[1..] = q), or swap q0 q1 (w = q1 q0 q[2..]).  Two chars of
+      // each shape are tested here; the DP decides.  (Queries under 3 chars: no char test.)
+      const bool shape = (m < 3) | (w12 == qm.p12) | (w01 == qm.p12) | (w12 == qm.p01) | (w01 == qm.p10);
+      const bool act_x = (budget == 2) & !tile_all_s & mine & !same_first & len_x & (sigd <= 1u) & shape;
+      const u64 ms = __ballot(act_s);
+      const u64 mx = __ballot(act_x);
+      if ((ms | mx) == 0) continue;
+      if (ms) {
+        if (act_s) s_pq[wave][(head + qn + __popcll(ms & lower)) & (PQ - 1)] = lane | (ql << 6);
+        qn += __popcll(ms);
       }
-      // --- other first char (budget 2 only): distance <= 1 ------------------------
-      if (qm.budget == 2 && !tile_all_s) {
-        bool cand = mine && !same_first;
-        if (m >= 3) cand = cand && (wc0 == qm.q1 || wc1 == qm.q1 || wc1 == qm.q0);
-        cand = cand && (prefix ? (int)nc + 1 >= m : ((int)nc + 1 >= m && (int)nc <= m + 1));
-        if (__any(cand)) {
-          int d;
-          if (LONG) {
-            FlatReader r{a.flat + a.offs[in_range ? idx : 0], a.flat + a.offs[in_range ? idx + 1 : 0]};
-            d = osa_banded<1>(r, (int)nc, cand, qc, m, prefix);
-          } else if (tile_ascii) {
-            SlotReader<true> r{slot.x, slot.y, slot.z, slot.w};
-            d = osa_banded<1>(r, (int)nc, cand, qc, m, prefix);
-          } else {
-            SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
-            d = osa_banded<1>(r, (int)nc, cand, qc, m, prefix);
-          }
-          fx = cand && d <= 1;
-          pairs += __popcll(__ballot(cand));
-        }
-      }
-      // --- ordered append (lanes ascend with the dictionary index) ----------------
-      const uint32_t ql = q - q_begin;
-      uint32_t *lst = a.lists + ((size_t)q * a.nseg + seg) * stride_l;
-      const u64 lower = (1ull << lane) - 1ull;
-      {
-        const u64 mk = __ballot(f1);
-        if (mk) {
-          const uint32_t base = s_cnt[wave][ql][0];
-          const uint32_t pos = base + __popcll(mk & lower);
-          if (f1 && pos < a.cap1) lst[pos] = idx;
-          if (lane == 0) s_cnt[wave][ql][0] = base + __popcll(mk);
-        }
-      }
-      {
-        const u64 mk = __ballot(f2);
-        if (mk) {
-          const uint32_t base = s_cnt[wave][ql][1];
-          const uint32_t pos = base + __popcll(mk & lower);
-          if (f2 && pos < a.cap2) lst[a.cap1 + pos] = idx;
-          if (lane == 0) s_cnt[wave][ql][1] = base + __popcll(mk);
-        }
-      }
-      {
-        const u64 mk = __ballot(fx);
-        if (mk) {
-          const uint32_t base = s_cnt[wave][ql][2];
-          const uint32_t pos = base + __popcll(mk & lower);
-          if (fx && pos < a.capx) lst[a.cap1 + a.cap2 + pos] = idx;
-          if (lane == 0) s_cnt[wave][ql][2] = base + __popcll(mk);
-        }
+      if (mx) {
+        if (act_x) s_pq[wave][(head + qn + __popcll(mx & lower)) & (PQ - 1)] = lane | (ql << 6) | (1u << 12);
+        qn += __popcll(mx);
       }
       __builtin_amdgcn_wave_barrier();
+      while (qn >= 64) drain(64);
     }
+    while (qn > 0) drain(qn < 64 ? qn : 64);  // the ring refers to this tile's lanes
+    __builtin_amdgcn_wave_barrier();
   }
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = lane; i < (q_end - q_begin) * 3; i += 64) {
+  for (uint32_t i = lane; i < nqc * 3; i += 64) {
     const uint32_t ql = i / 3, c = i % 3;
     const uint32_t cap = c == 0 ? a.cap1 : (c == 1 ? a.cap2 : a.capx);
     a.cnts[((size_t)(q_begin + ql) * a.nseg + seg) * 3 + c] = min(s_cnt[wave][ql][c], cap);
@@ -365,9 +490,11 @@ __global__ void dict_prep_kernel(const uint8_t *__restrict__ qbytes, const uint3
   r.m = 0;
   r.budget = 0;
   r.prefix = (qflags[q] >> 2) & 1;
-  r.q0 = r.q1 = 0xFFFFFFFFu;
-  r.lo = r.hi = 0;
   r._pad = 0;
+  r._pad2 = 0;
+  r.lo = r.hi = 0;
+  r.sig = 0;
+  r.p12 = r.p01 = r.p10 = 0;
   const uint32_t bud = qflags[q] & 3;
   if (len >= 1 && len <= 250 && bud >= 1) {  // MAX_WORD_LENGTH, compute_derivations.rs:180-192
     uint32_t *out = qchars + (size_t)q * QSTRIDE;
@@ -382,33 +509,39 @@ __global__ void dict_prep_kernel(const uint8_t *__restrict__ qbytes, const uint3
     }
     r.m = n;
     r.budget = bud > 2 ? 2 : bud;
-    r.q0 = out[0];
-    if (n >= 2) r.q1 = out[1];
-    // words starting with the first char: compare the first c0len bytes (big endian)
-    const uint32_t c0len = utf8_len(s[0]);
-    uint32_t key = 0;
-    for (uint32_t e = 0; e < c0len; ++e) key = (key << 8) | (e < len ? s[e] : 0);
-    auto head = [&](uint32_t idx) -> uint32_t {
-      const uint32_t w = slots[idx].x;  // little-endian bytes 0..3
-      uint32_t v = 0;
-      for (uint32_t e = 0; e < c0len; ++e) v = (v << 8) | ((w >> (8 * e)) & 0xFF);
-      return v;
+    for (uint32_t c = 0; c < n; ++c) r.sig |= 1ull << sig_bit(out[c]);
+    const uint32_t q0 = out[0], q1 = n >= 2 ? out[1] : QNONE, q2 = n >= 3 ? out[2] : QNONE;
+    r.p12 = pair_key(q1, q2);
+    r.p01 = pair_key(q0, q1);
+    r.p10 = pair_key(q1, q0);
+    // words starting with a given char: compare the first clen bytes (big endian)
+    auto range_of = [&](const uint8_t *c, uint32_t avail, uint32_t &rlo, uint32_t &rhi) {
+      const uint32_t clen = utf8_len(c[0]);
+      uint32_t key = 0;
+      for (uint32_t e = 0; e < clen; ++e) key = (key << 8) | (e < avail ? c[e] : 0);
+      auto head = [&](uint32_t idx) -> uint32_t {
+        const uint32_t w = slots[idx].x;  // little-endian bytes 0..3
+        uint32_t v = 0;
+        for (uint32_t e = 0; e < clen; ++e) v = (v << 8) | ((w >> (8 * e)) & 0xFF);
+        return v;
+      };
+      uint32_t lo = 0, hi = n_words;
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (head(mid) < key) lo = mid + 1;
+        else hi = mid;
+      }
+      rlo = lo;
+      hi = n_words;
+      uint32_t l2 = lo;
+      while (l2 < hi) {
+        const uint32_t mid = l2 + (hi - l2) / 2;
+        if (head(mid) <= key) l2 = mid + 1;
+        else hi = mid;
+      }
+      rhi = l2;
     };
-    uint32_t lo = 0, hi = n_words;
-    while (lo < hi) {
-      const uint32_t mid = lo + (hi - lo) / 2;
-      if (head(mid) < key) lo = mid + 1;
-      else hi = mid;
-    }
-    r.lo = lo;
-    hi = n_words;
-    uint32_t l2 = lo;
-    while (l2 < hi) {
-      const uint32_t mid = l2 + (hi - l2) / 2;
-      if (head(mid) <= key) l2 = mid + 1;
-      else hi = mid;
-    }
-    r.hi = l2;
+    range_of(s, len, r.lo, r.hi);
   }
   qm[q] = r;
 }
@@ -583,15 +716,16 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   hipLaunchKernelGGL(dict_prep_kernel, dim3((n + 127) / 128), dim3(128), 0, st, d_qbytes, d_qoff, d_qflags, n,
                      d->slots.as<uint4>(), d->n_words, d->qm.as<QueryMeta>(), d->qchars.as<uint32_t>());
   const uint32_t nchunks = (n + QC - 1) / QC;
-  const uint32_t target_waves = (uint32_t)ctx->n_cu * 16;
+  const uint32_t target_waves = (uint32_t)ctx->n_cu * 20;  // 5 waves per SIMD
   auto seg_for = [&](uint32_t n_items) -> uint32_t {
     const uint32_t n_tiles = std::max<uint32_t>(1, (n_items + 63) / 64);
     uint32_t nseg = (target_waves + nchunks - 1) / nchunks;
-    // bound the scratch lists to ~256 MiB
+    // bound the scratch lists to ~1 GiB (of 288 GB)
     const uint64_t per_seg = (uint64_t)n * stride_l * sizeof(uint32_t);
-    const uint32_t mem_cap = (uint32_t)std::max<uint64_t>(1, (256ull << 20) / std::max<uint64_t>(1, per_seg));
+    const uint32_t mem_cap = (uint32_t)std::max<uint64_t>(1, (1024ull << 20) / std::max<uint64_t>(1, per_seg));
     nseg = std::min(nseg, mem_cap);
-    return std::max<uint32_t>(1, std::min(nseg, n_tiles));
+    nseg = std::max<uint32_t>(1, std::min(nseg, n_tiles));
+    return ((nseg + DW - 1) / DW) * DW;  // the DW waves of a workgroup share a query chunk
   };
   const uint32_t nseg = seg_for(d->n_words);
   const uint32_t lnseg = seg_for(d->n_long);
@@ -622,9 +756,8 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
     a.nseg = nseg;
     a.lists = d->lists.as<uint32_t>();
     a.cnts = d->cnts.as<uint32_t>();
-    const uint32_t waves = nseg * nchunks;
     d->match_timer.begin(ctx);
-    hipLaunchKernelGGL(dict_match_kernel<false>, dim3((waves + DW - 1) / DW), dim3(DW * 64), 0, st, a);
+    hipLaunchKernelGGL(dict_match_kernel<false>, dim3((nseg / DW) * nchunks), dim3(DW * 64), 0, st, a, a.qm);
     d->match_timer.end(ctx);
   }
   if (d->n_long) {
@@ -632,8 +765,7 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
     a.nseg = lnseg;
     a.lists = d->llists.as<uint32_t>();
     a.cnts = d->lcnts.as<uint32_t>();
-    const uint32_t waves = lnseg * nchunks;
-    hipLaunchKernelGGL(dict_match_kernel<true>, dim3((waves + DW - 1) / DW), dim3(DW * 64), 0, st, a);
+    hipLaunchKernelGGL(dict_match_kernel<true>, dim3((lnseg / DW) * nchunks), dim3(DW * 64), 0, st, a, a.qm);
   }
   FinalArgs f;
   f.qm = d->qm.as<QueryMeta>();
