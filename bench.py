@@ -199,6 +199,8 @@ def main():
             "queries_per_step_per_gpu": Q,
             "words_per_step_per_gpu": n_words_q,
             "queries_per_hbm_sweep": store.max_batch,
+            "scan_math": os.environ.get("MSI_VS_SCAN_MATH", "bf16x3") + " candidate scan (f32 rows in HBM, f32 accumulate)"
+                         " + exact f32 reference rescoring of K' candidates with an exactness proof",
             "sharding": "queries sharded, index replicated per GPU, all_gather of per-rank top-k (RCCL)",
             "step_includes": ["vs_scan + select + reference rescoring", "dict_match + cap logic", "D2H of results"],
             "step_excludes": ["ranking-rule bucket sort", "hybrid merge"],

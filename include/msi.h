@@ -152,6 +152,11 @@ typedef struct msi_vs_stats {
   uint64_t bytes_per_tile;     /* algorithmic HBM bytes per tile           */
 } msi_vs_stats;
 int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out);
+/* Test instrumentation: the fast scan's raw scores (dot / |row|; -inf for padding)
+ * of every row for <= msi_vs_max_batch() host queries — out_scores [n_queries][len] —
+ * and the bound the exactness proof assumes for |fast cos - reference cos|. */
+int32_t msi_vs_debug_fast_scores(msi_vs *vs, const float *queries, uint32_t n_queries,
+                                 float *out_scores, float *out_eps);
 /* Accumulated duration of the full-sweep vs_scan launches recorded while
  * profiling was enabled (HIP events on the launch stream); resets the counters. */
 int32_t msi_vs_scan_time(msi_vs *vs, uint64_t *out_launches, double *out_ms_total);

@@ -419,10 +419,8 @@ __global__ __launch_bounds__(DW * 64) void dict_match_kernel(DictArgs a, const Q
     __builtin_amdgcn_wave_barrier();
 
     // ---- filter phase: query data is wave-uniform (scalar loads), tests branch-free --
-    QueryMeta qnext = qmeta[q_begin];
     for (uint32_t ql = 0; ql < nqc; ++ql) {
-      const QueryMeta qm = qnext;
-      qnext = qmeta[q_begin + min(ql + 1, nqc - 1)];   // prefetch: hides the scalar-load latency
+      const QueryMeta qm = qmeta[q_begin + ql];   // one 64-byte line, scalar loads
       const uint32_t budget = qm.budget;
       if (budget == 0) continue;
       const uint32_t lo = qm.lo, hi = qm.hi;

@@ -39,6 +39,7 @@
 #include "msi_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
 namespace {
@@ -135,8 +136,8 @@ __global__ void vs_check_sorted_kernel(const uint32_t *__restrict__ docids, uint
 //   reciprocal and the threshold that marks a row degenerate (pn*qn <= EPS).
 __global__ __launch_bounds__(256) void vs_prep_queries_kernel(
     const float *__restrict__ q, uint32_t nq, uint32_t dim, uint32_t KB, float4 *__restrict__ qfrag,
-    float *__restrict__ qrow, float *__restrict__ qn, float *__restrict__ inv_qn,
-    float *__restrict__ degth) {
+    bf16x8 *__restrict__ qfrag_bf, float *__restrict__ qrow, float *__restrict__ qn,
+    float *__restrict__ inv_qn, float *__restrict__ degth) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *row = reinterpret_cast<float *>(smem);  // [dpad]
   const uint32_t j = blockIdx.x;
@@ -150,6 +151,23 @@ __global__ __launch_bounds__(256) void vs_prep_queries_kernel(
     const uint32_t kb = idx >> 2, g = idx & 3;
     const float4 v = *reinterpret_cast<const float4 *>(row + kb * 16 + g * 4);
     qfrag[((uint64_t)t * KB + kb) * 64 + g * 16 + jj] = v;
+  }
+  // bf16x3 fragments: block pair p = (2p, 2p+1), lane (g, jj) holds the 8 columns
+  // 32p+4g..+3 and 32p+16+4g..+3 (the same 8 a row lane holds after two 16-byte
+  // loads), split as hi = bf16(x), lo = bf16(x - hi); layout [t][KB/2][hi|lo][64].
+  for (uint32_t idx = threadIdx.x; idx < (KB / 2) * 4; idx += blockDim.x) {
+    const uint32_t p = idx >> 2, g = idx & 3;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = row[p * 32 + (e >> 2) * 16 + g * 4 + (e & 3)];
+      const __bf16 h = (__bf16)x;
+      hi[e] = h;
+      lo[e] = (__bf16)(x - (float)h);
+    }
+    const uint64_t base = (((uint64_t)t * (KB / 2) + p) * 2) * 64 + g * 16 + jj;
+    qfrag_bf[base] = hi;
+    qfrag_bf[base + 64] = lo;
   }
   if (threadIdx.x == 0) {
     float acc = 0.f;
@@ -247,8 +265,15 @@ struct ScanArgs {
   uint32_t nq;
 };
 
-// NQT = 16-query tiles per sweep; DENSE selects the epilogue.
-template <int WAVES, int NQT, bool DENSE>
+// NQT = 16-query tiles per sweep; DENSE selects the epilogue; BF3 the contraction:
+//   false  v_mfma_f32_16x16x4_f32 on the f32 rows (exact products, 1/16 of the bf16 rate);
+//   true   bf16x3: rows and queries are split x = hi + lo (two bf16 each) in registers and
+//          hi·hi + hi·lo + lo·hi runs on v_mfma_f32_16x16x32_bf16 — 3 instructions of 8
+//          passes per 32 columns instead of 8 of 8 passes, ~5x less matrix time, so 48
+//          queries per sweep stay HBM-bound.  The dropped lo·lo term and the bf16 rounding
+//          of lo cost <= 3·2^-18 relative per product, which the exactness proof's eps
+//          carries; returned distances never see it (canonical rescoring).
+template <int WAVES, int NQT, bool DENSE, bool BF3>
 __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x;
@@ -357,17 +382,41 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
     }
   };
   auto compute_group = [&](const float4(&x)[SCAN_GROUP]) {
-    const float4 *qp = qf + (size_t)sub_cmp * SCAN_GROUP * 64 + lane;
+    if (BF3) {
+      // LDS: [t][KB/2][hi|lo][64] bf16x8; this group covers pairs sub_cmp*4 .. +3
+      const bf16x8 *qb = reinterpret_cast<const bf16x8 *>(qf) + (size_t)sub_cmp * (SCAN_GROUP / 2) * 128 + lane;
 #pragma unroll
-    for (int u = 0; u < SCAN_GROUP; ++u) {
+      for (int u = 0; u < SCAN_GROUP; u += 2) {
+        const float v[8] = {x[u].x, x[u].y, x[u].z, x[u].w, x[u + 1].x, x[u + 1].y, x[u + 1].z, x[u + 1].w};
+        bf16x8 hi, lo;
 #pragma unroll
-      for (int t = 0; t < NQT; ++t) {
-        const float4 q = qp[(size_t)t * KB * 64 + u * 64];
-        // two independent accumulators per query tile: no dependent-MFMA stall
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].x, q.x, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].y, q.y, acc[t][1], 0, 0, 0);
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].z, q.z, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].w, q.w, acc[t][1], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 h = (__bf16)v[e];
+          hi[e] = h;
+          lo[e] = (__bf16)(v[e] - (float)h);
+        }
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+          const bf16x8 *qt = qb + (size_t)t * (KB / 2) * 128 + (u / 2) * 128;
+          const bf16x8 qh = qt[0], ql = qt[64];
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, qh, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, ql, acc[t][1], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, qh, acc[t][1], 0, 0, 0);
+        }
+      }
+    } else {
+      const float4 *qp = qf + (size_t)sub_cmp * SCAN_GROUP * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < SCAN_GROUP; ++u) {
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+          const float4 q = qp[(size_t)t * KB * 64 + u * 64];
+          // two independent accumulators per query tile: no dependent-MFMA stall
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].x, q.x, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].y, q.y, acc[t][1], 0, 0, 0);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].z, q.z, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u].w, q.w, acc[t][1], 0, 0, 0);
+        }
       }
     }
     if (++sub_cmp == GPT) {
@@ -757,11 +806,12 @@ struct msi_vs {
   msi_ctx *ctx = nullptr;
   uint32_t dim = 0, dpad = 0, KB = 0;
   uint32_t nqt_max = 1;            // query tiles per sweep the LDS admits for this dim
+  bool bf3 = true;                 // contraction of the fast scan: bf16x3 (default) or f32 MFMA
   uint64_t n_rows = 0, n_tiles = 0;
   DevBuf tiles, norm, inv_norm, docids;
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
   // scratch (guarded by ctx->mu)
-  DevBuf qraw, qfrag, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fbits, out_docids,
+  DevBuf qraw, qfrag, qfrag_bf, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fbits, out_docids,
       out_dist, exh_keys, rowtmp;
   uint32_t capg = 0;
   uint32_t scan_grid = 0;
@@ -815,6 +865,7 @@ uint32_t threshold_rank(uint32_t kp, double p) {
 int32_t ensure_scratch(msi_vs *vs) {
   MSI_TRY(vs->qraw.ensure((size_t)NQ_MAX * vs->dim * sizeof(float)));
   MSI_TRY(vs->qfrag.ensure((size_t)NQT_MAX * vs->KB * 64 * sizeof(float4)));
+  MSI_TRY(vs->qfrag_bf.ensure((size_t)NQT_MAX * vs->KB * 64 * sizeof(float4)));
   MSI_TRY(vs->qrow.ensure((size_t)NQ_MAX * vs->dpad * sizeof(float)));
   MSI_TRY(vs->qsmall.ensure(5 * NQ_MAX * sizeof(float)));
   MSI_TRY(vs->gsmall.ensure((3 * NQ_MAX + 8) * sizeof(uint32_t)));
@@ -904,16 +955,23 @@ void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense) {
   const size_t lds = scan_lds_bytes(vs->KB, nqt);
   const dim3 grid(vs->scan_grid), block(SCAN_WAVES * 64);
   hipStream_t st = vs->ctx->stream;
-#define MSI_SCAN_CASE(N)                                                                          \
-  case N:                                                                                         \
-    if (dense) hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, true>), grid, block, lds, st, sa); \
-    else hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, false>), grid, block, lds, st, sa);      \
+#define MSI_SCAN_LAUNCH(N, D, B) hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, D, B>), grid, block, lds, st, sa)
+#define MSI_SCAN_CASE(N)                                       \
+  case N:                                                      \
+    if (dense) {                                               \
+      if (vs->bf3) MSI_SCAN_LAUNCH(N, true, true);             \
+      else MSI_SCAN_LAUNCH(N, true, false);                    \
+    } else {                                                   \
+      if (vs->bf3) MSI_SCAN_LAUNCH(N, false, true);            \
+      else MSI_SCAN_LAUNCH(N, false, false);                   \
+    }                                                          \
     break;
   switch (nqt) {
     MSI_SCAN_CASE(1)
     MSI_SCAN_CASE(2)
     MSI_SCAN_CASE(3)
   }
+#undef MSI_SCAN_LAUNCH
 #undef MSI_SCAN_CASE
 }
 
@@ -934,8 +992,8 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   const uint32_t nqt = (nq + QT - 1) / QT;
   // 1. queries
   hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
-                     d_queries, nq, vs->dim, vs->KB, vs->qfrag.as<float4>(), vs->qrow.as<float>(), s.qn,
-                     s.inv_qn, s.degth);
+                     d_queries, nq, vs->dim, vs->KB, vs->qfrag.as<float4>(), vs->qfrag_bf.as<bf16x8>(),
+                     vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth);
   MSI_HIP_TRY(hipMemsetAsync(s.overflow, 0, sizeof(uint32_t), st));
   // 2. filter
   const uint32_t *list = nullptr;
@@ -973,7 +1031,7 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   ScanArgs sa;
   sa.tiles = vs->tiles.as<float4>();
   sa.inv_norm = vs->inv_norm.as<float>();
-  sa.qfrag = vs->qfrag.as<float4>();
+  sa.qfrag = vs->bf3 ? vs->qfrag_bf.as<float4>() : vs->qfrag.as<float4>();
   sa.theta = s.theta_inf;
   sa.degth = s.degth;
   sa.n_items_ptr = n_items_ptr;
@@ -1048,7 +1106,10 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   ra.KB = vs->KB;
   ra.kp = kp;
   ra.k = k;
-  ra.eps = (2.0f * (float)vs->dpad + 32.0f) * 5.9604645e-8f;
+  // bound on |fast cos - reference cos|: f32 accumulation of n terms (gamma_n, n = dpad or
+  // 3·dpad, with a factor 2 for the MFMA adder tree) + the bf16x3 split's 3·2^-18 per product
+  ra.eps = vs->bf3 ? (6.0f * (float)vs->dpad + 64.0f) * 5.9604645e-8f + 3.0f * 3.8146973e-6f
+                   : (2.0f * (float)vs->dpad + 32.0f) * 5.9604645e-8f;
   ra.out_docids = d_out_docids;
   ra.out_dist = d_out_dist;
   ra.out_counts = d_out_counts;
@@ -1104,12 +1165,12 @@ int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out) {
   }
   DeviceGuard g(ctx->device);
   const void *fns[] = {
-      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 1, true>),
-      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 1, false>),
-      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 2, true>),
-      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 2, false>),
-      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 3, true>),
-      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, 3, false>)};
+#define MSI_F(N, D, B) reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, B>)
+      MSI_F(1, true, true), MSI_F(1, true, false), MSI_F(1, false, true), MSI_F(1, false, false),
+      MSI_F(2, true, true), MSI_F(2, true, false), MSI_F(2, false, true), MSI_F(2, false, false),
+      MSI_F(3, true, true), MSI_F(3, true, false), MSI_F(3, false, true), MSI_F(3, false, false)
+#undef MSI_F
+  };
   for (const void *fn : fns) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
     if (e != hipSuccess) {
@@ -1124,6 +1185,7 @@ int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out) {
   vs->dpad = dpad;
   vs->KB = KB;
   vs->nqt_max = nqt_max;
+  if (const char *e = getenv("MSI_VS_SCAN_MATH")) vs->bf3 = strcmp(e, "f32") != 0;  // "f32" | "bf16x3"
   // workgroups per CU: two when the query fragments leave room (more loads in flight)
   uint32_t wg_per_cu = scan_lds_bytes(KB, nqt_max) <= LDS_MAX / 2 ? 2 : 1;
   if (const char *e = getenv("MSI_VS_WG_PER_CU")) {
@@ -1142,7 +1204,7 @@ void msi_vs_destroy(msi_vs *vs) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qrow,
+    DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qfrag_bf, &vs->qrow,
                       &vs->qsmall, &vs->gkeys, &vs->gcnt, &vs->gsmall, &vs->sel_keys, &vs->dense, &vs->tmask,
                       &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp};
     for (DevBuf *b : bufs) b->release();
@@ -1283,6 +1345,61 @@ int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries, uint
     MSI_HIP_TRY(hipMemcpyAsync(out_counts + q0, s.counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipStreamSynchronize(st));
   }
+  return MSI_OK;
+}
+
+// Test instrumentation: the fast scan's raw scores (dot / |row|, before any
+// thresholding) of every row for <= msi_vs_max_batch() host queries, and the bound
+// `eps` the exactness proof assumes for |fast cos - reference cos|.
+int32_t msi_vs_debug_fast_scores(msi_vs *vs, const float *queries, uint32_t n_queries, float *out_scores,
+                                 float *out_eps) {
+  if (!vs || !queries || !out_scores || n_queries == 0 || n_queries > vs->nqt_max * QT) {
+    msi_set_error("msi_vs_debug_fast_scores: invalid argument");
+    return MSI_E_INVALID;
+  }
+  if (vs->n_rows > (1u << 22)) {
+    msi_set_error("msi_vs_debug_fast_scores: store too large for the debug path");
+    return MSI_E_UNSUPPORTED;
+  }
+  std::lock_guard<std::mutex> lk(vs->ctx->mu);
+  DeviceGuard g(vs->ctx->device);
+  hipStream_t st = vs->ctx->stream;
+  Small s = small_of(vs);
+  const uint32_t nqt = (n_queries + QT - 1) / QT;
+  const uint32_t dstride = (uint32_t)(vs->n_tiles * 16);
+  MSI_TRY(vs->dense.ensure((size_t)NQ_MAX * std::max<uint32_t>(16, dstride) * sizeof(float)));
+  MSI_HIP_TRY(hipMemcpyAsync(vs->qraw.p, queries, (size_t)n_queries * vs->dim * sizeof(float), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
+                     vs->qraw.as<float>(), n_queries, vs->dim, vs->KB, vs->qfrag.as<float4>(),
+                     vs->qfrag_bf.as<bf16x8>(), vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth);
+  ScanArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.tiles = vs->tiles.as<float4>();
+  sa.inv_norm = vs->inv_norm.as<float>();
+  sa.qfrag = vs->bf3 ? vs->qfrag_bf.as<float4>() : vs->qfrag.as<float4>();
+  sa.theta = s.theta_inf;
+  sa.degth = s.degth;
+  sa.n_items_ptr = s.n_tiles;
+  sa.gkeys = vs->gkeys.as<u64>();
+  sa.gcnt = vs->gcnt.as<uint32_t>();
+  sa.overflow = s.overflow;
+  sa.dense = vs->dense.as<float>();
+  sa.n_rows = vs->n_rows;
+  sa.dstride = dstride;
+  sa.capg = vs->capg;
+  sa.KB = vs->KB;
+  sa.stride = 1;
+  sa.nq = n_queries;
+  if (vs->n_rows) launch_scan(vs, sa, nqt, true);
+  MSI_HIP_TRY(hipGetLastError());
+  for (uint32_t j = 0; j < n_queries; ++j)
+    if (vs->n_rows)
+      MSI_HIP_TRY(hipMemcpyAsync(out_scores + (size_t)j * vs->n_rows, vs->dense.as<float>() + (size_t)j * dstride,
+                                 vs->n_rows * sizeof(float), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  if (out_eps)
+    *out_eps = vs->bf3 ? (6.0f * (float)vs->dpad + 64.0f) * 5.9604645e-8f + 3.0f * 3.8146973e-6f
+                       : (2.0f * (float)vs->dpad + 32.0f) * 5.9604645e-8f;
   return MSI_OK;
 }
 

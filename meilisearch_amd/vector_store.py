@@ -91,6 +91,14 @@ class GpuStore:
             C.c_void_p(out_counts_t.data_ptr()),
             C.c_void_p(inexact_t.data_ptr()) if inexact_t is not None else None))
 
+    def debug_fast_scores(self, queries):
+        """(scores [B, len] of the fast scan = dot/|row|, eps assumed by the proof)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        out = np.zeros((q.shape[0], len(self)), dtype=np.float32)
+        eps = C.c_float(0.0)
+        check(lib().msi_vs_debug_fast_scores(self._h, np_ptr(q), q.shape[0], np_ptr(out), C.byref(eps)))
+        return out, float(eps.value)
+
     def scan_time(self):
         """(launches, total ms) of the main-pass vs_scan kernel since the last call
         (HIP events on the launch stream; needs Context.set_profiling(True))."""

@@ -152,6 +152,29 @@ def test_three_query_tiles_sparse_and_filtered(ctx, oracle):
     check_against_oracle(oracle, st, rows, ids, qs[:17], 5)
 
 
+@pytest.mark.parametrize("dim,scale", [(768, 1.0), (384, 1.0), (100, 1e3), (1024, 1e-3)])
+def test_fast_scan_error_is_inside_the_proof_bound(ctx, dim, scale):
+    # the exactness proof is only sound if |fast cos - reference cos| <= eps for EVERY row;
+    # check it against an f64 reference, including heavy-tailed rows and a skewed query
+    n = 3000
+    rng = np.random.default_rng(dim)
+    rows = (rng.standard_normal((n, dim)) * scale).astype(f32)
+    rows[:200] *= rng.lognormal(0, 3, size=(200, dim)).astype(f32)       # wild dynamic range
+    rows[200:300] = np.abs(rows[200:300])                                   # no cancellation
+    qs = rng.standard_normal((20, dim)).astype(f32)
+    qs[1] = np.abs(qs[1])
+    qs[2] *= rng.lognormal(0, 3, size=dim).astype(f32)
+    st = ma.GpuStore(ctx, dim)
+    st.upload(np.arange(n, dtype=np.uint32), rows)
+    fast, eps = st.debug_fast_scores(qs)
+    r64, q64 = rows.astype(np.float64), qs.astype(np.float64)
+    ref = (q64 @ r64.T) / (np.linalg.norm(q64, axis=1)[:, None] * np.linalg.norm(r64, axis=1)[None, :])
+    got = fast.astype(np.float64) / np.linalg.norm(q64, axis=1)[:, None]
+    err = np.abs(got - ref).max()
+    assert err <= eps, (err, eps)
+    assert err <= 0.25 * eps, ("the bound should be comfortable", err, eps)
+
+
 def test_objects_may_outlive_their_context():
     c2 = ma.Context(0)
     st = ma.GpuStore(c2, 8)
