@@ -248,6 +248,39 @@ int32_t msi_bits_read_words(msi_bits *pool, uint32_t slot, uint64_t *out_words);
  * `d_filter_bits` of msi_vs_search_device. */
 const uint64_t *msi_bits_device_ptr(msi_bits *pool, uint32_t slot);
 
+/* ------------------------------------- S3: ranking-rule bucket sort (Words, Typo) */
+/*
+ * bucket_sort (crates/milli/src/search/new/bucket_sort.rs:23-343) over the
+ * ranking rules Words (graph_based_ranking_rule.rs + ranking_rule_graph/words/
+ * mod.rs:22-53) and Typo (ranking_rule_graph/typo/mod.rs:23-85) for a query graph
+ * that is a chain of single-word terms.  Each term hands over, as slots of a
+ * msi_bits pool, the documents that contain one of its derivations with exactly
+ * 0 / 1 / 2 typos — what compute_query_term_subset_docids
+ * (resolve_query_graph.rs:33-130) returns for the zero / one (incl. split words)
+ * / two typo subsets — and its max_typo_cost (query_term/mod.rs:340-370).
+ * Returns documents [from, from+length) of the bucket order: matched-word prefix
+ * longest first (Words; strategy Last drops terms from the end, never the first
+ * one — query_graph.rs:346-406; strategy All keeps only full matches), then
+ * total typos ascending (Typo, when use_typo), then ascending docid
+ * (bucket_sort.rs:382-460), with the ScoreDetails of both rules:
+ *   Words{matching_words, max_matching_words = n_terms}
+ *   Typo{typo_count, max_typo_count = sum of max_typo_cost over the kept terms}
+ */
+#define MSI_RANK_MAX_TERMS 10          /* words_limit, crates/milli/src/search/mod.rs:111 */
+#define MSI_NO_SLOT 0xFFFFFFFFu
+enum { MSI_TERMS_LAST = 0, MSI_TERMS_ALL = 1 };
+typedef struct msi_rank_term {
+  uint32_t level_slot[3];  /* pool slot of the 0 / 1 / 2 typo documents, or MSI_NO_SLOT */
+  uint32_t max_typo_cost;  /* 0..2 */
+} msi_rank_term;
+int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms,
+                            uint32_t n_terms, uint32_t universe_slot,
+                            uint32_t scratch_slot, int32_t strategy,
+                            int32_t use_typo, uint32_t from, uint32_t length,
+                            uint32_t *out_docids, uint32_t *out_matching_words,
+                            uint32_t *out_typo_count, uint32_t *out_max_typo_count,
+                            uint32_t *out_n, uint64_t *out_candidates);
+
 /* ---------------------------------------------------- scoring arithmetic (host) */
 /* DistributionShift::shift (crates/milli/src/vector/distribution.rs:103-130). */
 float msi_distribution_shift(float mean, float sigma, float score);

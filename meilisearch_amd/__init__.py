@@ -11,3 +11,4 @@ from .vector_store import GpuStore, VectorStore, dense_filter  # noqa: F401
 from .typo import GpuDictionary, number_of_typos_allowed  # noqa: F401
 from .bits import BitsPool  # noqa: F401
 from . import scoring  # noqa: F401
+from . import ranking  # noqa: F401

@@ -23,6 +23,10 @@ class TypoQuery(C.Structure):
                 ("is_prefix", C.c_uint8), ("_pad", C.c_uint16)]
 
 
+class RankTerm(C.Structure):
+    _fields_ = [("level_slot", C.c_uint32 * 3), ("max_typo_cost", C.c_uint32)]
+
+
 class VsStats(C.Structure):
     _fields_ = [("scan_launches", C.c_uint64), ("scan_tiles", C.c_uint64),
                 ("exhaustive_reruns", C.c_uint64), ("bytes_per_tile", C.c_uint64)]
@@ -82,6 +86,8 @@ PROTOTYPES = {
     "msi_bits_first_k": (_I32, [_VP, _U32, _U32, _VP, C.POINTER(_U32)]),
     "msi_bits_read_words": (_I32, [_VP, _U32, _VP]),
     "msi_bits_device_ptr": (_VP, [_VP, _U32]),
+    "msi_rank_words_typo": (_I32, [_VP, _VP, _U32, _U32, _U32, _I32, _I32, _U32, _U32, _VP, _VP, _VP, _VP,
+                                   C.POINTER(_U32), C.POINTER(_U64)]),
     "msi_distribution_shift": (_F32, [_F32, _F32, _F32]),
     "msi_rank_global_score": (_F64, [_VP, _VP, _U32]),
     "msi_compare_scores": (_I32, [_VP, _U32, _F32, _VP, _U32, _F32]),

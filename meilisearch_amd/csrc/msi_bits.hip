@@ -29,6 +29,13 @@ struct msi_bits {
   u64 *slot(uint32_t s) const { return pool.as<u64>() + (uint64_t)s * n_words; }
 };
 
+// accessors for the other translation units (msi_rank.hip)
+msi_ctx *msi_bits_ctx(msi_bits *p) { return p->ctx; }
+u64 *msi_bits_slot_ptr(msi_bits *p, uint32_t slot) { return p->slot(slot); }
+uint64_t msi_bits_words_per_slot(msi_bits *p) { return p->n_words; }
+uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
+uint64_t msi_bits_n_docs(msi_bits *p) { return p->n_docs; }
+
 namespace {
 
 constexpr int BT = 256;

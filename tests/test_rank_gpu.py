@@ -1,0 +1,149 @@
+"""S3 parity: the device Words -> Typo bucket sort against (1) the reference's own
+snapshot literals (crates/milli/src/search/new/tests/typo.rs) replayed on a toy index,
+with the typo derivations coming from the device dictionary (S2 -> S3 end to end), and
+(2) a brute-force per-document restatement on random corpora."""
+import numpy as np
+import pytest
+
+import meilisearch_amd as ma
+from meilisearch_amd import ranking as R
+from toy_index import ToyIndex, brute_force_order
+
+pytestmark = pytest.mark.gpu
+
+# crates/milli/src/search/new/tests/typo.rs:27-148 (field "text" only; docs 24/25 use another field)
+TYPO_RS_DOCS = {
+    0: "the quick brown fox jumps over the lazy dog",
+    1: "the quick brown foxes jump over the lazy dog",
+    2: "the quick brown fax sends a letter to the dog",
+    3: "the quickest brownest fox jumps over the laziest dog",
+    4: "a fox doesn't quack, that crown goes to the duck.",
+    5: "the quicker browner fox jumped over the lazier dog",
+    6: "the extravagant fox skyrocketed over the languorous dog",
+    7: "the quick brown fox jumps over the lazy",
+    8: "the quick brown fox jumps over the",
+    9: "the quick brown fox jumps over",
+    10: "the quick brown fox jumps",
+    11: "the quick brown fox",
+    12: "the quick brown",
+    13: "the quick",
+    14: "netwolk interconections sunflawar",
+    15: "network interconnections sunflawer",
+    16: "network interconnection sunflower",
+    17: "network interconnection sun flower",
+    18: "network interconnection sunflowering",
+    19: "network interconnection sun flowering",
+    20: "network interconnection sunflowar",
+    21: "the fast brownish fox jumps over the lackadaisical dog",
+    22: "the quick brown fox jumps over the lackadaisical dog",
+    23: "the quivk brown fox jumps over the lazy dog",
+}
+
+
+class Harness:
+    def __init__(self, ctx, docs, n_slots=64):
+        self.ctx = ctx
+        self.idx = ToyIndex(docs)
+        self.gdict = ma.GpuDictionary(ctx, words=self.idx.words)
+        self.pool = ma.BitsPool(ctx, self.idx.n_docs, n_slots)
+
+    def lookup(self, word, budget, is_prefix):
+        one, two = self.gdict.lookup([(word, budget, is_prefix)])[0]
+        return one.tolist(), two.tolist()
+
+    def search(self, query, strategy_all=False, use_typo=True, offset=0, limit=100, **kw):
+        words = query.split()
+        sets = [self.idx.term_sets(w, i == len(words) - 1, self.lookup, **kw) for i, w in enumerate(words)]
+        slot = 2
+        terms = []
+        for z, o, t, mc in sets:
+            sl = []
+            for s in (z, o, t):
+                self.pool.set_from_docids(slot, np.array(sorted(s), dtype=np.uint32))
+                sl.append(slot)
+                slot += 1
+            terms.append((sl[0], sl[1], sl[2], mc))
+        self.pool.set_from_docids(0, np.array(sorted(self.idx.docs), dtype=np.uint32))   # universe
+        got, cand = R.bucket_sort_words_typo(self.pool, terms, 0, 1, R.TERMS_ALL if strategy_all else R.TERMS_LAST,
+                                             use_typo, offset, limit)
+        exp = brute_force_order(self.idx.n_docs, sets, set(self.idx.docs), strategy_all, use_typo)
+        assert cand == len(exp)
+        assert got == exp[offset:offset + limit], (query, got[:8], exp[:8])
+        return got
+
+
+def test_reference_snapshots_typo_rs(ctx):
+    h = Harness(ctx, TYPO_RS_DOCS)
+    # typo.rs:462-516: criteria [Typo] (Words is inserted implicitly, search/new/mod.rs:536-551), strategy Last
+    got = h.search("the quick brown fox jumps over the lazy dog")
+    assert [g[0] for g in got] == [0, 23, 7, 8, 9, 22, 10, 11, 1, 2, 12, 13, 4, 3, 5, 6, 21]
+    # snapshots/…typo_ranking_rule_not_preceded_by_words_ranking_rule-2.snap (first entries)
+    assert got[0][1:] == (9, 0, 9) and got[1][1:] == (9, 1, 9) and got[2][1:] == (8, 0, 8) and got[3][1:] == (7, 0, 7)
+    # typo.rs:521-594 test_typo_bucketing: criteria [Words] then [Typo], strategy All
+    got = h.search("network interconnection sunflower", strategy_all=True, use_typo=False)
+    assert [g[0] for g in got] == [14, 15, 16, 17, 18, 20]
+    got = h.search("network interconnection sunflower", strategy_all=True)
+    assert [g[0] for g in got] == [16, 18, 17, 20, 15, 14]
+    # snapshots/…typo_bucketing-5.snap: typo counts 0,0,1,1,2,5 of max 5
+    assert [g[2] for g in got] == [0, 0, 1, 1, 2, 5] and all(g[3] == 5 for g in got)
+    # typo.rs:176-233 test_default_typo (criteria [Words], strategy All)
+    assert [g[0] for g in h.search("the quick brown fox jumps over the lazy dog", True, False)] == [0, 23]
+    assert [g[0] for g in h.search("the quack brown fox jumps over the lazy dog", True, False)] == [0]
+    assert [g[0] for g in h.search("the quicest brownest fox jummps over the laziest dog", True, False)] == [3]
+    # typo.rs:150-174 test_no_typo
+    assert [g[0] for g in h.search("the quick brown fox jumps over the lazy dog", True, False,
+                                   authorize_typos=False)] == [0]
+    # typo.rs:252-323 test_typo_exact_word
+    ew = ("quick", "quack", "sunflower")
+    assert [g[0] for g in h.search("the quick brown fox jumps over the lazy dog", True, False, exact_words=ew)] == [0]
+    assert [g[0] for g in h.search("the quack brown fox jumps over the lazy dog", True, False, exact_words=ew)] == []
+    assert [g[0] for g in h.search("network interconnection sunflower", True, False, exact_words=ew)] == [16, 17, 18]
+
+
+def test_offset_limit_and_pages(ctx):
+    h = Harness(ctx, TYPO_RS_DOCS)
+    full = h.search("the quick brown fox jumps over the lazy dog")
+    for off, lim in [(0, 1), (1, 3), (2, 5), (5, 100), (16, 4), (17, 4), (3, 0)]:
+        assert h.search("the quick brown fox jumps over the lazy dog", offset=off, limit=lim) == full[off:off + lim]
+
+
+@pytest.mark.parametrize("seed,n_docs,n_terms", [(1, 300, 3), (2, 5000, 5), (3, 70000, 10), (4, 64, 1)])
+def test_random_corpus_vs_brute_force(ctx, seed, n_docs, n_terms):
+    rng = np.random.default_rng(seed)
+    pool = ma.BitsPool(ctx, n_docs, 3 * n_terms + 2)
+    universe = set(np.nonzero(rng.random(n_docs) < 0.9)[0].tolist())
+    sets, terms, slot = [], [], 2
+    for i in range(n_terms):
+        mc = int(rng.integers(0, 3))
+        lv = [set(np.nonzero(rng.random(n_docs) < p)[0].tolist()) for p in (0.5, 0.3, 0.2)]
+        if rng.random() < 0.2:
+            lv[1] = set()
+        sets.append((lv[0], lv[1], lv[2], mc))
+        sl = []
+        for s in lv:
+            if s or rng.random() < 0.5:
+                pool.set_from_docids(slot, np.array(sorted(s), dtype=np.uint32))
+                sl.append(slot)
+            else:
+                sl.append(None)      # MSI_NO_SLOT = empty set
+            slot += 1
+        terms.append((sl[0], sl[1], sl[2], mc))
+    pool.set_from_docids(0, np.array(sorted(universe), dtype=np.uint32))
+    for strategy_all in (False, True):
+        for use_typo in (True, False):
+            exp = brute_force_order(n_docs, sets, universe, strategy_all, use_typo)
+            for off, lim in [(0, 50), (37, 200), (max(0, len(exp) - 5), 10)]:
+                got, cand = R.bucket_sort_words_typo(pool, terms, 0, 1, R.TERMS_ALL if strategy_all else R.TERMS_LAST,
+                                                     use_typo, off, lim)
+                assert cand == len(exp)
+                assert got == exp[off:off + lim], (strategy_all, use_typo, off, lim)
+
+
+def test_errors(ctx):
+    pool = ma.BitsPool(ctx, 100, 4)
+    with pytest.raises(ma.MsiError):
+        R.bucket_sort_words_typo(pool, [], 0, 1)
+    with pytest.raises(ma.MsiError):
+        R.bucket_sort_words_typo(pool, [(2, None, None, 0)] * 11, 0, 1)
+    with pytest.raises(ma.MsiError):
+        R.bucket_sort_words_typo(pool, [(9, None, None, 0)], 0, 1)

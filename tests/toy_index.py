@@ -1,0 +1,100 @@
+"""TEST INFRASTRUCTURE: a toy inverted index built the way milli's write path builds
+its databases and the host-side term derivation of
+crates/milli/src/search/new/query_term/{parse_query.rs,compute_derivations.rs}, so
+that the reference's snapshot tests (search/new/tests/typo.rs) can be replayed
+against the device bucket sort.  Also a brute-force, per-document restatement of
+the Words -> Typo order used as the oracle for random corpora."""
+import re
+
+import numpy as np
+
+MAX_ONE, MAX_TWO, MAX_PREFIX = 150, 50, 1000   # search/new/limits.rs:5-9
+
+
+def tokenize(text):
+    return re.findall(r"[0-9a-zà-ÿа-я]+", text.lower())
+
+
+class ToyIndex:
+    def __init__(self, docs):
+        """docs: {docid: text}.  word_docids + word_pair_proximity_docids(prox = 1)."""
+        self.docs = dict(docs)
+        self.n_docs = max(self.docs) + 1 if self.docs else 0
+        self.word_docids = {}
+        self.pair1 = {}   # (left, right) adjacent -> docids
+        for d, text in self.docs.items():
+            toks = tokenize(text)
+            for t in toks:
+                self.word_docids.setdefault(t, set()).add(d)
+            for a, b in zip(toks, toks[1:]):
+                self.pair1.setdefault((a, b), set()).add(d)
+        self.words = sorted(self.word_docids, key=lambda w: w.encode())   # words-fst order
+
+    def budget(self, word, exact_words=(), authorize_typos=True):
+        # number_of_typos_allowed, parse_query.rs:204-225 (5 / 9 chars)
+        n = len(word)
+        if not authorize_typos or n < 5 or word in exact_words:
+            return 0
+        return 1 if n < 9 else 2
+
+    def split_best_frequency(self, word):
+        # compute_derivations.rs:363-383
+        best = None
+        for i in range(1, len(word)):
+            l, r = word[:i], word[i:]
+            f = len(self.pair1.get((l, r), ()))
+            if f and (best is None or f > best[0]):
+                best = (f, l, r)
+        return (best[1], best[2]) if best else None
+
+    def term_sets(self, word, is_prefix, lookup, exact_words=(), authorize_typos=True):
+        """-> (zero, one, two docid sets, max_typo_cost) of a single-word term:
+        compute_query_term_subset_docids (resolve_query_graph.rs:33-130) over the zero /
+        one / two typo subsets; max_typo_cost as query_term/mod.rs:340-370 (full subsets)."""
+        b = self.budget(word, exact_words, authorize_typos)
+        zero = set(self.word_docids.get(word, ()))
+        if is_prefix:   # find_zero_typo_prefix_derivations (no prefix DB on a toy corpus)
+            n = 0
+            for w in self.words:
+                if w.startswith(word) and w != word:
+                    zero |= self.word_docids[w]
+                    n += 1
+                    if n >= MAX_PREFIX:
+                        break
+        one_words, two_words = [], []
+        if b >= 1:
+            o, t = lookup(word, b, is_prefix)
+            one_words, two_words = [self.words[i] for i in o], [self.words[i] for i in t]
+        one = set()
+        for w in one_words:
+            one |= self.word_docids[w]
+        sp = self.split_best_frequency(word)      # split words sit in the one-typo subterm
+        if sp:
+            one |= self.pair1[sp]
+        two = set()
+        for w in two_words:
+            two |= self.word_docids[w]
+        max_cost = 1 if b <= 1 else 2             # budget 0: split words allowed -> 1
+        return zero, one, two, max_cost
+
+
+def brute_force_order(n_docs, terms, universe, strategy_all, use_typo):
+    """terms: [(zero, one, two, max_cost)] as python sets.  Per-document sort key by
+    definition: longest matched prefix of terms (first term mandatory), then the sum
+    over the kept terms of the smallest typo level the document matches, then docid."""
+    n = len(terms)
+    out = []
+    for d in sorted(universe):
+        k, cost = 0, 0
+        for z, o, t, mc in terms:
+            lv = 0 if d in z else (1 if (d in o and mc >= 1) else (2 if (d in t and mc >= 2) else None))
+            if lv is None:
+                break
+            k += 1
+            cost += lv
+        if k == 0 or (strategy_all and k < n):
+            continue
+        maxc = sum(mc for _, _, _, mc in terms[:k])
+        out.append((-k, cost if use_typo else 0, d, k, cost if use_typo else 0, maxc))
+    out.sort()
+    return [(d, k, c, m) for _, _, d, k, c, m in out]
