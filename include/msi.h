@@ -273,6 +273,26 @@ typedef struct msi_rank_term {
   uint32_t level_slot[3];  /* pool slot of the 0 / 1 / 2 typo documents, or MSI_NO_SLOT */
   uint32_t max_typo_cost;  /* 0..2 */
 } msi_rank_term;
+/* The same over the full query graph: nodes are the single terms plus the 2-gram and
+ * 3-gram nodes of adjacent terms (query_graph.rs:96-180, make_ngram
+ * parse_query.rs:227-300); an n-gram node has the base typo cost n
+ * (typo/mod.rs:41-45) and matching_words counts the terms it covers.  At most one
+ * node per (first_term, last_term), last_term - first_term <= 2.
+ * max_typo_count is the largest cost of a path that matches a document of the Words
+ * bucket (exact for chains; with n-grams the reference derives it from the paths its
+ * DFS found non-empty, which can be smaller when one path shadows another). */
+typedef struct msi_rank_node {
+  uint32_t first_term, last_term; /* 0-based, inclusive */
+  uint32_t level_slot[3];
+  uint32_t max_typo_cost;
+} msi_rank_node;
+int32_t msi_rank_query_graph(msi_bits *pool, const msi_rank_node *nodes,
+                             uint32_t n_nodes, uint32_t n_terms, uint32_t universe_slot,
+                             uint32_t scratch_slot, int32_t strategy, int32_t use_typo,
+                             uint32_t from, uint32_t length, uint32_t *out_docids,
+                             uint32_t *out_matching_words, uint32_t *out_typo_count,
+                             uint32_t *out_max_typo_count, uint32_t *out_n,
+                             uint64_t *out_candidates);
 int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms,
                             uint32_t n_terms, uint32_t universe_slot,
                             uint32_t scratch_slot, int32_t strategy,
@@ -293,6 +313,27 @@ double msi_rank_global_score(const uint32_t *ranks, const uint32_t *max_ranks,
 int32_t msi_compare_scores(const double *left, uint32_t n_left, float left_ratio,
                            const double *right, uint32_t n_right,
                            float right_ratio);
+
+/* ------------------------------------------- semantic / hybrid result tail (host) */
+/* VectorSort as the only ranking rule (search/new/vector_sort.rs:58-168) over the
+ * output of msi_vs_search / msi_merge_topk: first occurrence of a docid wins,
+ * similarity = 1 - distance, optional DistributionShift; returns [from, from+length). */
+uint32_t msi_vector_sort(const uint32_t *docids, const float *dist, uint32_t n,
+                         int32_t has_shift, float mean, float sigma, uint32_t from,
+                         uint32_t length, uint32_t *out_docids, float *out_similarity);
+/* ScoreWithRatioResult::merge (search/hybrid.rs:102-235; no pins, no distinct).
+ * Each hit has a list of score values (ScoreDetails::score_values: one value per run
+ * of rank-based rules, score_details.rs:156-175), hit i of the vector list owns
+ * v_scores[v_off[i] .. v_off[i+1]).  v_ratio = semantic_ratio, k_ratio = 1 - it. */
+uint32_t msi_hybrid_merge(const uint32_t *v_docids, const double *v_scores,
+                          const uint32_t *v_off, uint32_t n_v, float v_ratio,
+                          const uint32_t *k_docids, const double *k_scores,
+                          const uint32_t *k_off, uint32_t n_k, float k_ratio,
+                          uint32_t from, uint32_t length, uint32_t *out_docids,
+                          uint8_t *out_is_semantic, uint32_t *out_semantic_hit_count);
+/* Search::results_good_enough (search/hybrid.rs:367-386). */
+int32_t msi_results_good_enough(const double *keyword_global_scores, uint32_t n,
+                                uint32_t limit_plus_offset, float semantic_ratio);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,11 @@ class RankTerm(C.Structure):
     _fields_ = [("level_slot", C.c_uint32 * 3), ("max_typo_cost", C.c_uint32)]
 
 
+class RankNode(C.Structure):
+    _fields_ = [("first_term", C.c_uint32), ("last_term", C.c_uint32), ("level_slot", C.c_uint32 * 3),
+                ("max_typo_cost", C.c_uint32)]
+
+
 class VsStats(C.Structure):
     _fields_ = [("scan_launches", C.c_uint64), ("scan_tiles", C.c_uint64),
                 ("exhaustive_reruns", C.c_uint64), ("bytes_per_tile", C.c_uint64)]
@@ -86,8 +91,14 @@ PROTOTYPES = {
     "msi_bits_first_k": (_I32, [_VP, _U32, _U32, _VP, C.POINTER(_U32)]),
     "msi_bits_read_words": (_I32, [_VP, _U32, _VP]),
     "msi_bits_device_ptr": (_VP, [_VP, _U32]),
+    "msi_rank_query_graph": (_I32, [_VP, _VP, _U32, _U32, _U32, _U32, _I32, _I32, _U32, _U32, _VP, _VP, _VP, _VP,
+                                    C.POINTER(_U32), C.POINTER(_U64)]),
     "msi_rank_words_typo": (_I32, [_VP, _VP, _U32, _U32, _U32, _I32, _I32, _U32, _U32, _VP, _VP, _VP, _VP,
                                    C.POINTER(_U32), C.POINTER(_U64)]),
+    "msi_vector_sort": (_U32, [_VP, _VP, _U32, _I32, _F32, _F32, _U32, _U32, _VP, _VP]),
+    "msi_hybrid_merge": (_U32, [_VP, _VP, _VP, _U32, _F32, _VP, _VP, _VP, _U32, _F32, _U32, _U32, _VP, _VP,
+                                C.POINTER(_U32)]),
+    "msi_results_good_enough": (_I32, [_VP, _U32, _U32, _F32]),
     "msi_distribution_shift": (_F32, [_F32, _F32, _F32]),
     "msi_rank_global_score": (_F64, [_VP, _VP, _U32]),
     "msi_compare_scores": (_I32, [_VP, _U32, _F32, _VP, _U32, _F32]),

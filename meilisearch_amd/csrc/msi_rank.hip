@@ -27,7 +27,11 @@
 //                                                            ∩ distributes over ∪, so this equals the
 //                                                            union over all paths of cost t)
 //   bucket(k,t) = P_k & ~P_{k+1} & F_{k-1}(t) & ~(F_{k-1}(0) | … | F_{k-1}(t-1))
-// evaluated for 64 documents per lane with u64 bit operations: one HBM pass over
+// With n-gram nodes (query_graph.rs:96-180) the chain becomes a DAG over term
+// positions and the same recurrence runs over positions: a 2-gram / 3-gram node that
+// ends at position p reads F at p-2 / p-3 and adds its base cost 2 / 3
+// (typo/mod.rs:41-45); a document's Words bucket is the LARGEST position it reaches.
+// Evaluated for 64 documents per lane with u64 bit operations: one HBM pass over
 // the 3n+1 input sets gives the histogram of all buckets, a second pass
 // materialises only the buckets that intersect [from, from+length).
 // Algorithmic bytes: (3·n_terms + 1) · n_docs/8 per pass.
@@ -54,98 +58,163 @@ constexpr int NT_MAX = MSI_RANK_MAX_TERMS;   // words_limit, crates/milli/src/se
 constexpr int TC_MAX = 2 * NT_MAX;           // largest total typo cost
 constexpr int RT = 256;
 
+// Node of the query graph that ENDS at term position p (1-based end): kind 0 = the
+// single term p-1, kind 1 = the 2-gram of terms p-2..p-1, kind 2 = the 3-gram
+// (query_graph.rs:96-180).  An n-gram has the base typo cost n (typo/mod.rs:41-45).
+struct NodeArg {
+  const u64 *level[3];   // nullptr = empty set / node absent
+  uint32_t max_cost;     // 0..2 ; 0xFFFFFFFF = node absent
+};
+
 struct RankArgs {
-  const u64 *level[NT_MAX][3];   // nullptr = empty set
-  uint32_t max_cost[NT_MAX];
+  NodeArg node[NT_MAX][3];   // [end position - 1][kind]
   const u64 *universe;
   uint64_t n_words;
   uint32_t n_terms;
   uint32_t strategy_all;
   uint32_t use_typo;
-  // histogram pass
-  u64 *hist;                     // [NT_MAX + 1][TC_MAX + 1]
-  // materialise pass
+  u64 *hist;                 // [NT_MAX + 1][TC_MAX + 1]
   u64 *dst;
   uint32_t sel_k, sel_t;
 };
 
-// MATERIALISE = false: histogram of every bucket; true: write bucket (sel_k, sel_t).
-template <bool MATERIALISE>
-__global__ __launch_bounds__(RT) void rank_words_typo_kernel(RankArgs a) {
+enum { MODE_HIST = 0, MODE_STRUCT = 1, MODE_MATERIALISE = 2 };
+
+// MODE_HIST         histogram of every (kept terms, total typo cost) bucket
+// MODE_STRUCT       histogram of (kept terms, largest possible cost of a matched path): the
+//                   Typo rule's max_typo_count for that Words bucket
+// MODE_MATERIALISE  write bucket (sel_k, sel_t) to dst
+template <int MODE>
+__global__ __launch_bounds__(RT) void rank_query_graph_kernel(RankArgs a) {
   __shared__ uint32_t s_hist[(NT_MAX + 1) * (TC_MAX + 1)];
-  if (!MATERIALISE) {
+  if (MODE != MODE_MATERIALISE) {
     for (uint32_t i = threadIdx.x; i < (NT_MAX + 1) * (TC_MAX + 1); i += RT) s_hist[i] = 0;
     __syncthreads();
   }
   const uint64_t stride = (uint64_t)gridDim.x * RT;
   for (uint64_t w = (uint64_t)blockIdx.x * RT + threadIdx.x; w < a.n_words; w += stride) {
     const u64 U = a.universe[w];
-    u64 L[NT_MAX][3];
-    u64 A[NT_MAX + 1];
+    // ---- sweep 1: which positions does a document reach (any typo level)? --------
+    u64 R[NT_MAX + 1];
+    R[0] = U;
 #pragma unroll
-    for (int j = 0; j < NT_MAX; ++j) {
-      u64 any = 0;
+    for (int p = 1; p <= NT_MAX; ++p) {
+      u64 r = 0;
+      if (p <= (int)a.n_terms) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        u64 v = 0;
-        if (j < (int)a.n_terms && a.level[j][s] && s <= (int)a.max_cost[j]) v = a.level[j][s][w];
-        L[j][s] = v;
-        any |= v;
-      }
-      A[j] = any;
-    }
-    A[NT_MAX] = 0;
-    u64 F[TC_MAX + 1];
+        for (int kind = 0; kind < 3; ++kind) {
+          if (kind < p) {
+            const NodeArg &nd = a.node[p - 1][kind];
+            if (nd.max_cost != 0xFFFFFFFFu) {
+              u64 any = 0;
 #pragma unroll
-    for (int t = 0; t <= TC_MAX; ++t) F[t] = 0;
-    F[0] = U;              // zero terms matched at cost 0, inside the universe
-    u64 P = U;             // P_k
-    u64 out = 0;
-#pragma unroll
-    for (int j = 0; j < NT_MAX; ++j) {
-      if (j < (int)a.n_terms) {
-        // F_j from F_{j-1}
-        u64 G[TC_MAX + 1];
-#pragma unroll
-        for (int t = 0; t <= TC_MAX; ++t) {
-          u64 v = F[t] & L[j][0];
-          if (t >= 1) v |= F[t - 1] & L[j][1];
-          if (t >= 2) v |= F[t - 2] & L[j][2];
-          G[t] = v;
-        }
-#pragma unroll
-        for (int t = 0; t <= TC_MAX; ++t) F[t] = G[t];
-        P &= A[j];
-        const uint32_t k = j + 1;
-        const bool last = k == a.n_terms;
-        if (last || !a.strategy_all) {
-          const u64 next = last ? 0ull : (P & A[j + 1]);
-          const u64 D = P & ~next;          // documents whose longest matched prefix is k terms
-          if (a.use_typo) {
-            u64 seen = 0;
-#pragma unroll
-            for (int t = 0; t <= TC_MAX; ++t) {
-              const u64 b = D & F[t] & ~seen;
-              seen |= F[t];
-              if (MATERIALISE) {
-                if (k == a.sel_k && (uint32_t)t == a.sel_t) out = b;
-              } else if (b) {
-                atomicAdd(&s_hist[k * (TC_MAX + 1) + t], (uint32_t)__popcll(b));
-              }
-            }
-          } else {
-            if (MATERIALISE) {
-              if (k == a.sel_k) out = D;
-            } else if (D) {
-              atomicAdd(&s_hist[k * (TC_MAX + 1)], (uint32_t)__popcll(D));
+              for (int s = 0; s < 3; ++s)
+                if (nd.level[s] && s <= (int)nd.max_cost) any |= nd.level[s][w];
+              r |= R[p - 1 - kind] & any;
             }
           }
         }
       }
+      R[p] = r;
     }
-    if (MATERIALISE) a.dst[w] = out;
+    // D[p] = documents whose LONGEST matched prefix is p terms (Words bucket n - p)
+    u64 later = 0;
+    u64 D[NT_MAX + 1];
+#pragma unroll
+    for (int p = NT_MAX; p >= 1; --p) {
+      u64 d = 0;
+      if (p <= (int)a.n_terms && (p == (int)a.n_terms || !a.strategy_all)) d = R[p] & ~later;
+      D[p] = d;
+      later |= R[p];
+    }
+    // ---- sweep 2: cost DP over positions, rolling window of 4 ---------------------
+    u64 F[4][TC_MAX + 1];   // F[i] = position p-1-i after the shift below
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t <= TC_MAX; ++t) F[i][t] = 0;
+    F[0][0] = U;
+    u64 out = 0;
+#pragma unroll
+    for (int p = 1; p <= NT_MAX; ++p) {
+      if (p <= (int)a.n_terms) {
+        u64 G[TC_MAX + 1];
+#pragma unroll
+        for (int t = 0; t <= TC_MAX; ++t) G[t] = 0;
+#pragma unroll
+        for (int kind = 0; kind < 3; ++kind) {
+          if (kind < p) {
+            const NodeArg &nd = a.node[p - 1][kind];
+            if (nd.max_cost != 0xFFFFFFFFu) {
+              const int base = kind == 0 ? 0 : kind + 1;
+              if (MODE == MODE_STRUCT) {
+                u64 any = 0;
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                  if (nd.level[s] && s <= (int)nd.max_cost) any |= nd.level[s][w];
+                // one pseudo level: the node's largest cost (max_cost is wave-uniform)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                  if (s == (int)nd.max_cost) {
+#pragma unroll
+                    for (int t = base + s; t <= TC_MAX; ++t) G[t] |= F[kind][t - base - s] & any;
+                  }
+                }
+              } else {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                  if (nd.level[s] && s <= (int)nd.max_cost) {
+                    const u64 lv = nd.level[s][w];
+#pragma unroll
+                    for (int t = base + s; t <= TC_MAX; ++t) G[t] |= F[kind][t - base - s] & lv;
+                  }
+                }
+              }
+            }
+          }
+        }
+        // shift the window: F[0] becomes position p
+#pragma unroll
+        for (int t = 0; t <= TC_MAX; ++t) {
+          F[3][t] = F[2][t];
+          F[2][t] = F[1][t];
+          F[1][t] = F[0][t];
+          F[0][t] = G[t];
+        }
+        const u64 Dp = D[p];
+        if (MODE == MODE_STRUCT) {
+          // largest structural cost of a path that matches the document
+          u64 seen = 0;
+#pragma unroll
+          for (int t = TC_MAX; t >= 0; --t) {
+            const u64 b = Dp & F[0][t] & ~seen;
+            seen |= F[0][t];
+            if (b) atomicAdd(&s_hist[p * (TC_MAX + 1) + t], (uint32_t)__popcll(b));
+          }
+        } else if (a.use_typo) {
+          u64 seen = 0;
+#pragma unroll
+          for (int t = 0; t <= TC_MAX; ++t) {
+            const u64 b = Dp & F[0][t] & ~seen;
+            seen |= F[0][t];
+            if (MODE == MODE_MATERIALISE) {
+              if ((uint32_t)p == a.sel_k && (uint32_t)t == a.sel_t) out = b;
+            } else if (b) {
+              atomicAdd(&s_hist[p * (TC_MAX + 1) + t], (uint32_t)__popcll(b));
+            }
+          }
+        } else {
+          if (MODE == MODE_MATERIALISE) {
+            if ((uint32_t)p == a.sel_k) out = Dp;
+          } else if (Dp) {
+            atomicAdd(&s_hist[p * (TC_MAX + 1)], (uint32_t)__popcll(Dp));
+          }
+        }
+      }
+    }
+    if (MODE == MODE_MATERIALISE) a.dst[w] = out;
   }
-  if (!MATERIALISE) {
+  if (MODE != MODE_MATERIALISE) {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (NT_MAX + 1) * (TC_MAX + 1); i += RT)
       if (s_hist[i]) atomicAdd(&a.hist[i], (u64)s_hist[i]);
@@ -156,37 +225,47 @@ __global__ __launch_bounds__(RT) void rank_words_typo_kernel(RankArgs a) {
 
 extern "C" {
 
-int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms, uint32_t n_terms,
-                            uint32_t universe_slot, uint32_t scratch_slot, int32_t strategy, int32_t use_typo,
-                            uint32_t from, uint32_t length, uint32_t *out_docids,
-                            uint32_t *out_matching_words, uint32_t *out_typo_count,
-                            uint32_t *out_max_typo_count, uint32_t *out_n, uint64_t *out_candidates) {
-  if (!pool || !terms || n_terms == 0 || n_terms > (uint32_t)NT_MAX || !out_n ||
+int32_t msi_rank_query_graph(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes, uint32_t n_terms,
+                             uint32_t universe_slot, uint32_t scratch_slot, int32_t strategy, int32_t use_typo,
+                             uint32_t from, uint32_t length, uint32_t *out_docids,
+                             uint32_t *out_matching_words, uint32_t *out_typo_count,
+                             uint32_t *out_max_typo_count, uint32_t *out_n, uint64_t *out_candidates) {
+  if (!pool || !nodes || n_nodes == 0 || n_terms == 0 || n_terms > (uint32_t)NT_MAX || !out_n ||
       (length && (!out_docids || !out_matching_words || !out_typo_count || !out_max_typo_count))) {
-    msi_set_error("msi_rank_words_typo: invalid argument (1..%d terms)", NT_MAX);
+    msi_set_error("msi_rank_query_graph: invalid argument (1..%d terms)", NT_MAX);
     return MSI_E_INVALID;
   }
   const uint32_t n_slots = msi_bits_n_slots(pool);
   if (universe_slot >= n_slots || scratch_slot >= n_slots || scratch_slot == universe_slot) {
-    msi_set_error("msi_rank_words_typo: universe/scratch slot out of range");
+    msi_set_error("msi_rank_query_graph: universe/scratch slot out of range");
     return MSI_E_INVALID;
   }
   RankArgs a;
   memset(&a, 0, sizeof(a));
-  for (uint32_t i = 0; i < n_terms; ++i) {
-    if (terms[i].max_typo_cost > 2) {
-      msi_set_error("msi_rank_words_typo: term %u has max_typo_cost %u > 2", i, terms[i].max_typo_cost);
+  for (int p = 0; p < NT_MAX; ++p)
+    for (int kind = 0; kind < 3; ++kind) a.node[p][kind].max_cost = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < n_nodes; ++i) {
+    const msi_rank_node &nd = nodes[i];
+    if (nd.last_term >= n_terms || nd.first_term > nd.last_term || nd.last_term - nd.first_term > 2 ||
+        nd.max_typo_cost > 2) {
+      msi_set_error("msi_rank_query_graph: node %u is not a 1/2/3-gram of the %u terms (or max_typo_cost > 2)", i,
+                    n_terms);
       return MSI_E_INVALID;
     }
-    a.max_cost[i] = terms[i].max_typo_cost;
+    NodeArg &na = a.node[nd.last_term][nd.last_term - nd.first_term];
+    if (na.max_cost != 0xFFFFFFFFu) {
+      msi_set_error("msi_rank_query_graph: two nodes cover terms %u..%u", nd.first_term, nd.last_term);
+      return MSI_E_INVALID;
+    }
+    na.max_cost = nd.max_typo_cost;
     for (int s = 0; s < 3; ++s) {
-      const uint32_t sl = terms[i].level_slot[s];
+      const uint32_t sl = nd.level_slot[s];
       if (sl == MSI_NO_SLOT) continue;
       if (sl >= n_slots || sl == scratch_slot) {
-        msi_set_error("msi_rank_words_typo: term %u level %d slot %u invalid", i, s, sl);
+        msi_set_error("msi_rank_query_graph: node %u level %d slot %u invalid", i, s, sl);
         return MSI_E_INVALID;
       }
-      a.level[i][s] = msi_bits_slot_ptr(pool, sl);
+      na.level[s] = msi_bits_slot_ptr(pool, sl);
     }
   }
   msi_ctx *ctx = msi_bits_ctx(pool);
@@ -201,27 +280,36 @@ int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms, uint32_t
   a.dst = msi_bits_slot_ptr(pool, scratch_slot);
   const size_t hist_n = (size_t)(NT_MAX + 1) * (TC_MAX + 1);
   u64 *d_hist = nullptr;
-  MSI_HIP_TRY(hipMalloc(&d_hist, hist_n * sizeof(u64)));
+  MSI_HIP_TRY(hipMalloc(&d_hist, 2 * hist_n * sizeof(u64)));
   struct Free {
     void *p;
     ~Free() { (void)hipFree(p); }
   } free_hist{d_hist};
-  MSI_HIP_TRY(hipMemsetAsync(d_hist, 0, hist_n * sizeof(u64), st));
+  MSI_HIP_TRY(hipMemsetAsync(d_hist, 0, 2 * hist_n * sizeof(u64), st));
+  const uint32_t grid =
+      std::max(1u, (uint32_t)std::min<uint64_t>((a.n_words + RT - 1) / RT, (uint64_t)ctx->n_cu * 8));
   a.hist = d_hist;
-  const uint32_t grid = (uint32_t)std::min<uint64_t>((a.n_words + RT - 1) / RT, (uint64_t)ctx->n_cu * 8);
-  hipLaunchKernelGGL(rank_words_typo_kernel<false>, dim3(std::max(1u, grid)), dim3(RT), 0, st, a);
+  hipLaunchKernelGGL(rank_query_graph_kernel<MODE_HIST>, dim3(grid), dim3(RT), 0, st, a);
+  if (use_typo) {
+    a.hist = d_hist + hist_n;
+    hipLaunchKernelGGL(rank_query_graph_kernel<MODE_STRUCT>, dim3(grid), dim3(RT), 0, st, a);
+  }
   MSI_HIP_TRY(hipGetLastError());
-  std::vector<u64> hist(hist_n);
-  MSI_HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist_n * sizeof(u64), hipMemcpyDeviceToHost, st));
+  std::vector<u64> hist(2 * hist_n);
+  MSI_HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, 2 * hist_n * sizeof(u64), hipMemcpyDeviceToHost, st));
   MSI_HIP_TRY(hipStreamSynchronize(st));
   // bucket order: kept terms descending (Words), total typos ascending (Typo)
   uint64_t total = 0, skipped = 0;
-  for (u64 v : hist) total += v;
+  for (size_t i = 0; i < hist_n; ++i) total += hist[i];
   if (out_candidates) *out_candidates = total;
+  uint32_t max_cost_of[NT_MAX + 1] = {0};
+  for (uint32_t k = 1; k <= n_terms; ++k)
+    for (int t = TC_MAX; t >= 0; --t)
+      if (hist[hist_n + (size_t)k * (TC_MAX + 1) + t]) {
+        max_cost_of[k] = (uint32_t)t;
+        break;
+      }
   uint32_t written = 0;
-  uint32_t max_so_far[NT_MAX + 1];
-  max_so_far[0] = 0;
-  for (uint32_t i = 0; i < n_terms; ++i) max_so_far[i + 1] = max_so_far[i] + terms[i].max_typo_cost;
   lk.unlock();  // msi_bits_first_k takes the context lock itself
   for (int k = (int)n_terms; k >= 1 && written < length; --k) {
     for (int t = 0; t <= TC_MAX && written < length; ++t) {
@@ -238,7 +326,7 @@ int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms, uint32_t
         DeviceGuard g2(ctx->device);
         a.sel_k = (uint32_t)k;
         a.sel_t = (uint32_t)t;
-        hipLaunchKernelGGL(rank_words_typo_kernel<true>, dim3(std::max(1u, grid)), dim3(RT), 0, st, a);
+        hipLaunchKernelGGL(rank_query_graph_kernel<MODE_MATERIALISE>, dim3(grid), dim3(RT), 0, st, a);
         MSI_HIP_TRY(hipGetLastError());
       }
       std::vector<uint32_t> ids((size_t)(skip_here + want));
@@ -248,7 +336,7 @@ int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms, uint32_t
         out_docids[written] = ids[i];
         out_matching_words[written] = (uint32_t)k;
         out_typo_count[written] = (uint32_t)t;
-        out_max_typo_count[written] = max_so_far[k];
+        out_max_typo_count[written] = max_cost_of[k];
         ++written;
       }
       skipped += c;
@@ -256,6 +344,27 @@ int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms, uint32_t
   }
   *out_n = written;
   return MSI_OK;
+}
+
+// Chain of single-word terms: the query graph without n-gram nodes.
+int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms, uint32_t n_terms,
+                            uint32_t universe_slot, uint32_t scratch_slot, int32_t strategy, int32_t use_typo,
+                            uint32_t from, uint32_t length, uint32_t *out_docids,
+                            uint32_t *out_matching_words, uint32_t *out_typo_count,
+                            uint32_t *out_max_typo_count, uint32_t *out_n, uint64_t *out_candidates) {
+  if (!terms || n_terms == 0 || n_terms > (uint32_t)NT_MAX) {
+    msi_set_error("msi_rank_words_typo: invalid argument (1..%d terms)", NT_MAX);
+    return MSI_E_INVALID;
+  }
+  msi_rank_node nodes[NT_MAX];
+  for (uint32_t i = 0; i < n_terms; ++i) {
+    nodes[i].first_term = nodes[i].last_term = i;
+    for (int s = 0; s < 3; ++s) nodes[i].level_slot[s] = terms[i].level_slot[s];
+    nodes[i].max_typo_cost = terms[i].max_typo_cost;
+  }
+  return msi_rank_query_graph(pool, nodes, n_terms, n_terms, universe_slot, scratch_slot, strategy, use_typo, from,
+                              length, out_docids, out_matching_words, out_typo_count, out_max_typo_count, out_n,
+                              out_candidates);
 }
 
 }  // extern "C"

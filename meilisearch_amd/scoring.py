@@ -26,3 +26,48 @@ def compare_scores(left, left_ratio, right, right_ratio):
     r = np.array(right, dtype=np.float64)
     return int(lib().msi_compare_scores(np_ptr(l) if l.size else None, len(left), left_ratio,
                                         np_ptr(r) if r.size else None, len(right), right_ratio))
+
+
+def vector_sort(docids, dist, offset=0, limit=20, distribution=None):
+    """VectorSort as the only ranking rule — search/new/vector_sort.rs:58-168."""
+    d = np.ascontiguousarray(docids, dtype=np.uint32)
+    s = np.ascontiguousarray(dist, dtype=np.float32)
+    out_d = np.zeros(max(limit, 1), dtype=np.uint32)
+    out_s = np.zeros(max(limit, 1), dtype=np.float32)
+    mean, sigma = distribution if distribution else (0.0, 1.0)
+    n = lib().msi_vector_sort(np_ptr(d) if d.size else None, np_ptr(s) if s.size else None, d.size,
+                              1 if distribution else 0, mean, sigma, offset, limit, np_ptr(out_d), np_ptr(out_s))
+    return out_d[:n].copy(), out_s[:n].copy()
+
+
+def _flatten(score_lists):
+    off = np.zeros(len(score_lists) + 1, dtype=np.uint32)
+    if score_lists:
+        np.cumsum([len(x) for x in score_lists], out=off[1:])
+    flat = np.array([v for x in score_lists for v in x], dtype=np.float64)
+    if flat.size == 0:
+        flat = np.zeros(1, dtype=np.float64)
+    return flat, off
+
+
+def hybrid_merge(vector_hits, keyword_hits, semantic_ratio, offset=0, limit=20):
+    """ScoreWithRatioResult::merge — search/hybrid.rs:102-235.  hits: [(docid, [score values])].
+    Returns ([(docid, is_semantic)], semantic_hit_count)."""
+    vd = np.array([h[0] for h in vector_hits], dtype=np.uint32)
+    kd = np.array([h[0] for h in keyword_hits], dtype=np.uint32)
+    vs, vo = _flatten([h[1] for h in vector_hits])
+    ks, ko = _flatten([h[1] for h in keyword_hits])
+    out_d = np.zeros(max(limit, 1), dtype=np.uint32)
+    out_s = np.zeros(max(limit, 1), dtype=np.uint8)
+    cnt = C.c_uint32(0)
+    n = lib().msi_hybrid_merge(np_ptr(vd) if vd.size else None, np_ptr(vs), np_ptr(vo), vd.size,
+                               np.float32(semantic_ratio), np_ptr(kd) if kd.size else None, np_ptr(ks), np_ptr(ko),
+                               kd.size, np.float32(1.0) - np.float32(semantic_ratio), offset, limit, np_ptr(out_d),
+                               np_ptr(out_s), C.byref(cnt))
+    return [(int(out_d[i]), bool(out_s[i])) for i in range(n)], int(cnt.value)
+
+
+def results_good_enough(keyword_global_scores, limit_plus_offset, semantic_ratio):
+    s = np.array(keyword_global_scores, dtype=np.float64)
+    return bool(lib().msi_results_good_enough(np_ptr(s) if s.size else None, s.size, limit_plus_offset,
+                                              semantic_ratio))

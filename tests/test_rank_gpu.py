@@ -7,7 +7,7 @@ import pytest
 
 import meilisearch_amd as ma
 from meilisearch_amd import ranking as R
-from toy_index import ToyIndex, brute_force_order
+from toy_index import ToyIndex, brute_force_graph_order, brute_force_order
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,81 @@ class Harness:
         assert cand == len(exp)
         assert got == exp[offset:offset + limit], (query, got[:8], exp[:8])
         return got
+
+
+    def search_graph(self, query, strategy_all=False, use_typo=True, offset=0, limit=100, **kw):
+        """Full query graph (terms + 2-grams + 3-grams)."""
+        words = query.split()
+        gn = self.idx.graph_nodes(words, self.lookup, **kw)
+        slot, nodes = 2, []
+        for first, last, z, o, t, mc in gn:
+            sl = []
+            for s in (z, o, t):
+                if s:
+                    self.pool.set_from_docids(slot, np.array(sorted(s), dtype=np.uint32))
+                    sl.append(slot)
+                    slot += 1
+                else:
+                    sl.append(None)
+            nodes.append((first, last, sl[0], sl[1], sl[2], mc))
+        self.pool.set_from_docids(0, np.array(sorted(self.idx.docs), dtype=np.uint32))
+        got, cand = R.bucket_sort_query_graph(self.pool, nodes, len(words), 0, 1,
+                                              R.TERMS_ALL if strategy_all else R.TERMS_LAST, use_typo, offset, limit)
+        exp = brute_force_graph_order(gn, len(words), set(self.idx.docs), strategy_all, use_typo)
+        assert cand == len(exp)
+        assert got == exp[offset:offset + limit], (query, got[:8], exp[:8])
+        return got
+
+
+def test_reference_snapshots_with_ngrams(ctx):
+    h = Harness(ctx, TYPO_RS_DOCS, n_slots=128)
+    # typo.rs:576-594 + snapshots/…typo_bucketing-8.snap: "sun flower" also matches the 2-gram
+    # "sunflower" at base cost 2 (criteria [Typo], strategy All)
+    got = h.search_graph("network interconnection sun flower", strategy_all=True)
+    assert [g[0] for g in got] == [17, 19, 16, 18, 20, 15]
+    assert [g[2] for g in got] == [0, 0, 2, 2, 3, 4] and all(g[3] == 6 for g in got)
+    # the chain-only snapshots are unchanged by the n-gram nodes
+    got = h.search_graph("the quick brown fox jumps over the lazy dog")
+    assert [g[0] for g in got] == [0, 23, 7, 8, 9, 22, 10, 11, 1, 2, 12, 13, 4, 3, 5, 6, 21]
+    assert got[0][1:] == (9, 0, 9) and got[1][1:] == (9, 1, 9) and got[2][1:] == (8, 0, 8)
+    got = h.search_graph("network interconnection sunflower", strategy_all=True)
+    assert [g[0] for g in got] == [16, 18, 17, 20, 15, 14] and [g[2] for g in got] == [0, 0, 1, 1, 2, 5]
+    # typo.rs:432-459 test_ngram_typos: a 2gram may carry one typo, a 3gram none
+    assert [g[0] for g in h.search_graph("the extra lagant fox skyrocketed over the languorous dog", True, False)] == [6]
+    assert [g[0] for g in h.search_graph("the ex tra lagant fox skyrocketed over the languorous dog", True, False)] == []
+
+
+@pytest.mark.parametrize("seed,n_docs,n_terms", [(11, 400, 2), (12, 3000, 4), (13, 50000, 7), (14, 999, 10)])
+def test_random_query_graph_vs_brute_force(ctx, seed, n_docs, n_terms):
+    rng = np.random.default_rng(seed)
+    universe = set(np.nonzero(rng.random(n_docs) < 0.95)[0].tolist())
+    gn = []
+    for last in range(n_terms):
+        for size in (1, 2, 3):
+            first = last - size + 1
+            if first < 0 or (size > 1 and rng.random() < 0.3):
+                continue
+            dens = (0.6, 0.3, 0.2) if size == 1 else (0.15, 0.1, 0.05)
+            lv = [set(np.nonzero(rng.random(n_docs) < p)[0].tolist()) for p in dens]
+            gn.append((first, last, lv[0], lv[1], lv[2], int(rng.integers(0, 3))))
+    pool = ma.BitsPool(ctx, n_docs, 3 * len(gn) + 2)
+    slot, nodes = 2, []
+    for first, last, z, o, t, mc in gn:
+        sl = []
+        for s in (z, o, t):
+            pool.set_from_docids(slot, np.array(sorted(s), dtype=np.uint32))
+            sl.append(slot)
+            slot += 1
+        nodes.append((first, last, sl[0], sl[1], sl[2], mc))
+    pool.set_from_docids(0, np.array(sorted(universe), dtype=np.uint32))
+    for strategy_all in (False, True):
+        for use_typo in (True, False):
+            exp = brute_force_graph_order(gn, n_terms, universe, strategy_all, use_typo)
+            for off, lim in [(0, 60), (23, 500)]:
+                got, cand = R.bucket_sort_query_graph(pool, nodes, n_terms, 0, 1,
+                                                      R.TERMS_ALL if strategy_all else R.TERMS_LAST, use_typo, off, lim)
+                assert cand == len(exp)
+                assert got == exp[off:off + lim], (strategy_all, use_typo, off, lim)
 
 
 def test_reference_snapshots_typo_rs(ctx):

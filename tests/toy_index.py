@@ -47,11 +47,34 @@ class ToyIndex:
                 best = (f, l, r)
         return (best[1], best[2]) if best else None
 
-    def term_sets(self, word, is_prefix, lookup, exact_words=(), authorize_typos=True):
+    def graph_nodes(self, words, lookup, exact_words=(), authorize_typos=True):
+        """Query graph of QueryGraph::from_query (query_graph.rs:96-180): every term, every
+        2-gram and 3-gram of adjacent terms (make_ngram, parse_query.rs:227-300: the
+        concatenation, typo budget = budget(concat) - (n-1) saturating, prefix flag of its
+        last term).  -> [(first, last, zero, one, two, max_typo_cost)]."""
+        n = len(words)
+        nodes = []
+        for last in range(n):
+            for size in (1, 2, 3):
+                first = last - size + 1
+                if first < 0:
+                    continue
+                is_prefix = last == n - 1
+                if size == 1:
+                    z, o, t, mc = self.term_sets(words[last], is_prefix, lookup, exact_words, authorize_typos)
+                else:
+                    z, o, t, mc = self.term_sets("".join(words[first:last + 1]), is_prefix, lookup, exact_words,
+                                                 authorize_typos, ngram_of=words[first:last + 1])
+                nodes.append((first, last, z, o, t, mc))
+        return nodes
+
+    def term_sets(self, word, is_prefix, lookup, exact_words=(), authorize_typos=True, ngram_of=None):
         """-> (zero, one, two docid sets, max_typo_cost) of a single-word term:
         compute_query_term_subset_docids (resolve_query_graph.rs:33-130) over the zero /
         one / two typo subsets; max_typo_cost as query_term/mod.rs:340-370 (full subsets)."""
         b = self.budget(word, exact_words, authorize_typos)
+        if ngram_of:
+            b = max(0, b - (len(ngram_of) - 1))
         zero = set(self.word_docids.get(word, ()))
         if is_prefix:   # find_zero_typo_prefix_derivations (no prefix DB on a toy corpus)
             n = 0
@@ -69,6 +92,8 @@ class ToyIndex:
         for w in one_words:
             one |= self.word_docids[w]
         sp = self.split_best_frequency(word)      # split words sit in the one-typo subterm
+        if sp and ngram_of and list(sp) == list(ngram_of):
+            sp = None                              # compute_derivations.rs:296-309
         if sp:
             one |= self.pair1[sp]
         two = set()
@@ -94,7 +119,41 @@ def brute_force_order(n_docs, terms, universe, strategy_all, use_typo):
             cost += lv
         if k == 0 or (strategy_all and k < n):
             continue
-        maxc = sum(mc for _, _, _, mc in terms[:k])
+        maxc = sum(mc for _, _, _, mc in terms[:k]) if use_typo else 0   # no Typo rule: no Typo score
         out.append((-k, cost if use_typo else 0, d, k, cost if use_typo else 0, maxc))
     out.sort()
+    return [(d, k, c, m) for _, _, d, k, c, m in out]
+
+
+def brute_force_graph_order(nodes, n_terms, universe, strategy_all, use_typo):
+    """Per-document restatement over the n-gram DAG: positions reached, the smallest typo
+    cost at the LARGEST reached position (n-gram base cost = its length), docid."""
+    per_doc = []
+    for d in sorted(universe):
+        INF = 10 ** 9
+        best = {0: 0}         # position -> min cost
+        worst = {0: 0}        # position -> max structural cost of a matching path
+        for p in range(1, n_terms + 1):
+            for first, last, z, o, t, mc in nodes:
+                if last != p - 1 or first not in best:
+                    continue
+                size = last - first + 1
+                base = 0 if size == 1 else size
+                lv = 0 if d in z else (1 if (d in o and mc >= 1) else (2 if (d in t and mc >= 2) else None))
+                if lv is None:
+                    continue
+                c = best[first] + base + lv
+                if c < best.get(p, INF):
+                    best[p] = c
+                w = worst[first] + base + mc
+                if w > worst.get(p, -1):
+                    worst[p] = w
+        k = max(best)
+        if k == 0 or (strategy_all and k < n_terms):
+            continue
+        per_doc.append((d, k, best[k] if use_typo else 0, worst[k]))
+    maxc = {}
+    for d, k, c, w in per_doc:
+        maxc[k] = max(maxc.get(k, 0), w)
+    out = sorted((-k, c, d, k, c, maxc[k] if use_typo else 0) for d, k, c, w in per_doc)
     return [(d, k, c, m) for _, _, d, k, c, m in out]
