@@ -179,6 +179,19 @@ def main():
     algo_bytes = ((n + 15) // 16) * stats["bytes_per_tile"]  # one sweep of the tiled store
     scan_avg_ms = scan_ms / max(1, scan_n)
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
+    # HBM traffic of the dominant kernel from the PMC pass committed under profiles/
+    # (rocprofv3 --pmc FETCH_SIZE on this same command; counters cannot be read in-process)
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_fetch.json")
+    if os.path.exists(pmc_path) and n == 10_000_000 and d == 768:
+        try:
+            kernels = json.load(open(pmc_path))["kernels"]
+            for name, e in kernels.items():
+                if name.startswith("vs_scan_kernel") and "false" in name.split(",")[2] and "FETCH_SIZE" in e:
+                    traffic = round(e["hbm_read_bytes_per_launch_avg"] / 1e9, 3)
+                    traffic_src = f"profiles/r1_pmc_fetch.json ({name}; FETCH_SIZE KB x 1024 x 2, gfx950 correction)"
+        except Exception:
+            traffic = None
     out = {
         "metric": "hybrid-search hot path queries/sec (10M-doc index, 768-d cosine top-20 + 2-typo term lookup)",
         "value": round(qps, 2),
@@ -214,7 +227,9 @@ def main():
             "peak": 8000.0,
             "unit": "GB/s",
             "frac": round(achieved / 8000.0, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "GB per launch (HBM reads, PMC)",
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": round(scan_avg_ms, 4),
             "launches_timed": scan_n,

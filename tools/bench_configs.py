@@ -144,9 +144,44 @@ def run_c3(args):
         print(json.dumps(out), flush=True)
 
 
+def run_rank(args):
+    """Words -> Typo bucket sort over dense docid sets (S3): n_terms query terms with
+    random zero/one/two-typo posting sets over `rows` documents, top-`k`."""
+    import torch  # noqa: F401  (one HIP runtime per process)
+    import meilisearch_amd as ma
+    from meilisearch_amd import ranking as R
+    ctx = ma.Context(0)
+    n, nt = args.rows, args.terms
+    rng = np.random.default_rng(77)
+    pool = ma.BitsPool(ctx, n, 3 * nt + 2)
+    words = (n + 63) // 64
+    dens = [(0.30, 0.05, 0.02), (0.10, 0.02, 0.01), (0.02, 0.005, 0.002)]
+    terms, slot = [], 2
+    for i in range(nt):
+        sl = []
+        for p in dens[i % 3]:
+            bits = rng.random(words * 64) < p
+            pool.set_from_words(slot, np.packbits(bits, bitorder="little").view(np.uint64))
+            sl.append(slot)
+            slot += 1
+        terms.append((sl[0], sl[1], sl[2], 2 if i % 2 else 1))
+    pool.fill(0, True)
+    for strategy, name in ((R.TERMS_LAST, "last"), (R.TERMS_ALL, "all")):
+        def step():
+            return R.bucket_sort_words_typo(pool, terms, 0, 1, strategy, True, 0, args.k)
+        ms, p50 = timed(step, ctx.synchronize, args.reps)
+        got, cand = step()
+        sets_bytes = (3 * nt + 1) * words * 8
+        print(json.dumps({"config": "rank", "docs": n, "terms": nt, "strategy": name, "k": args.k,
+                          "ms_per_query": round(ms, 4), "p50_ms": round(p50, 4), "candidates": cand,
+                          "returned": len(got), "algorithmic_bytes_per_pass": sets_bytes,
+                          "first": got[:3]}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c2", "c3"])
+    ap.add_argument("config", choices=["c2", "c3", "rank"])
+    ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=20)
@@ -157,8 +192,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048)
     args = ap.parse_args()
     if args.batches is None:
-        args.batches = [1, 16, 48, 240] if args.config == "c2" else [1, 64, 1024, 8192]
-    (run_c2 if args.config == "c2" else run_c3)(args)
+        args.batches = [1, 16, 48, 240] if args.config != "c3" else [1, 64, 1024, 8192]
+    {"c2": run_c2, "c3": run_c3, "rank": run_rank}[args.config](args)
 
 
 if __name__ == "__main__":
