@@ -120,6 +120,15 @@ int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries,
                       uint32_t *out_docids, float *out_dist,
                       uint32_t *out_counts);
 
+/* Micro-batching of concurrent callers (each tokio spawn_blocking search thread
+ * calls msi_vs_search with ONE query): with max_wait_us > 0, unfiltered calls that
+ * arrive within that window are fused into one HBM sweep (up to msi_vs_max_batch()
+ * queries; the largest k of the group is computed and every caller receives its
+ * prefix, which is its exact answer).  0 (default) = every call runs on its own. */
+int32_t msi_vs_set_microbatch(msi_vs *vs, uint32_t max_wait_us);
+int32_t msi_vs_microbatch_stats(msi_vs *vs, uint64_t *out_fused_calls,
+                                uint64_t *out_fused_sweeps);
+
 /* Device-pointer variant: all pointers are device memory, work is enqueued on
  * msi_ctx_stream() and NOT synchronised.  `d_inexact[n_queries]` (nullable)
  * receives 1 where the exactness proof failed and the host variant would have

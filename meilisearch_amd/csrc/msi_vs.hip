@@ -35,6 +35,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 
 #include "msi_common.h"
 
@@ -818,6 +821,24 @@ struct msi_vs {
   // stats
   uint64_t scan_launches = 0, scan_tiles = 0, exhaustive_reruns = 0;
   KernelTimer scan_timer;
+  // micro-batcher: concurrent unfiltered msi_vs_search calls are fused into one sweep
+  struct Pending {
+    const float *queries;
+    uint32_t n, k;
+    uint32_t *out_docids;
+    float *out_dist;
+    uint32_t *out_counts;
+    int32_t status = MSI_OK;
+    std::string error;
+    bool done = false;
+  };
+  std::mutex bmu;
+  std::condition_variable bcv;
+  std::vector<Pending *> bqueue;
+  uint32_t bqueued_queries = 0;
+  bool bleader_active = false;
+  uint32_t microbatch_wait_us = 0;   // 0 = off
+  uint64_t fused_calls = 0, fused_sweeps = 0;
 };
 
 namespace {
@@ -1286,6 +1307,110 @@ int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries, uint32_t n_quer
   return MSI_OK;
 }
 
+}  // extern "C"
+
+static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_queries, uint32_t k,
+                                const uint64_t *filter_bits, uint64_t filter_nbits,
+                                const volatile int32_t *cancel, uint32_t *out_docids, float *out_dist,
+                                uint32_t *out_counts);
+
+// Micro-batcher (SURVEY §8 b: callers are up to 4 x cores tokio spawn_blocking threads,
+// crates/meilisearch/src/search/federated/perform.rs:224).  The first caller to arrive
+// becomes the leader: it waits until a full sweep worth of queries is queued or
+// `microbatch_wait_us` elapsed, runs ONE search for everybody with the largest k
+// (a top-k list is a prefix of the top-k' list for k <= k', so every caller gets its exact
+// answer) and hands the rows out.
+static int32_t vs_search_fused(msi_vs *vs, const float *queries, uint32_t n_queries, uint32_t k,
+                               uint32_t *out_docids, float *out_dist, uint32_t *out_counts) {
+  msi_vs::Pending me;
+  me.queries = queries;
+  me.n = n_queries;
+  me.k = k;
+  me.out_docids = out_docids;
+  me.out_dist = out_dist;
+  me.out_counts = out_counts;
+  std::unique_lock<std::mutex> lk(vs->bmu);
+  vs->bqueue.push_back(&me);
+  vs->bqueued_queries += n_queries;
+  const uint32_t full = vs->nqt_max * QT;
+  if (vs->bleader_active) {
+    vs->bcv.notify_all();  // the leader may now have a full sweep
+    vs->bcv.wait(lk, [&] { return me.done || !vs->bleader_active; });
+    if (me.done) {
+      if (me.status != MSI_OK) msi_set_error("%s", me.error.c_str());
+      return me.status;
+    }
+    // the previous leader left without taking this request: lead the next batch
+  }
+  vs->bleader_active = true;
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(vs->microbatch_wait_us);
+  vs->bcv.wait_until(lk, deadline, [&] { return vs->bqueued_queries >= full; });
+  std::vector<msi_vs::Pending *> batch;
+  batch.swap(vs->bqueue);
+  vs->bqueued_queries = 0;
+  lk.unlock();
+  // one fused search
+  uint32_t total = 0, kmax = 0;
+  for (auto *p : batch) {
+    total += p->n;
+    kmax = std::max(kmax, p->k);
+  }
+  std::vector<float> q((size_t)total * vs->dim);
+  std::vector<uint32_t> d((size_t)total * std::max(1u, kmax)), c(total);
+  std::vector<float> s((size_t)total * std::max(1u, kmax));
+  size_t off = 0;
+  for (auto *p : batch) {
+    memcpy(q.data() + off * vs->dim, p->queries, (size_t)p->n * vs->dim * sizeof(float));
+    off += p->n;
+  }
+  const int32_t st = vs_search_direct(vs, q.data(), total, kmax, nullptr, 0, nullptr, d.data(), s.data(), c.data());
+  const std::string err = st == MSI_OK ? std::string() : std::string(msi_last_error());
+  off = 0;
+  for (auto *p : batch) {
+    if (st == MSI_OK) {
+      for (uint32_t j = 0; j < p->n; ++j) {
+        const uint32_t cnt = std::min(c[off + j], p->k);
+        p->out_counts[j] = cnt;
+        if (p->k) {
+          memcpy(p->out_docids + (size_t)j * p->k, d.data() + (off + j) * kmax, (size_t)cnt * sizeof(uint32_t));
+          memcpy(p->out_dist + (size_t)j * p->k, s.data() + (off + j) * kmax, (size_t)cnt * sizeof(float));
+        }
+      }
+    }
+    off += p->n;
+  }
+  lk.lock();
+  vs->fused_calls += batch.size();
+  vs->fused_sweeps += (total + full - 1) / full;
+  for (auto *p : batch) {
+    p->status = st;
+    p->error = err;
+    p->done = true;
+  }
+  vs->bleader_active = false;
+  lk.unlock();
+  vs->bcv.notify_all();
+  if (st != MSI_OK) msi_set_error("%s", err.c_str());
+  return st;
+}
+
+extern "C" {
+
+int32_t msi_vs_set_microbatch(msi_vs *vs, uint32_t max_wait_us) {
+  if (!vs) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(vs->bmu);
+  vs->microbatch_wait_us = max_wait_us;
+  return MSI_OK;
+}
+
+int32_t msi_vs_microbatch_stats(msi_vs *vs, uint64_t *out_fused_calls, uint64_t *out_fused_sweeps) {
+  if (!vs || !out_fused_calls || !out_fused_sweeps) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(vs->bmu);
+  *out_fused_calls = vs->fused_calls;
+  *out_fused_sweeps = vs->fused_sweeps;
+  return MSI_OK;
+}
+
 int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries, uint32_t k,
                       const uint64_t *filter_bits, uint64_t filter_nbits, const volatile int32_t *cancel,
                       uint32_t *out_docids, float *out_dist, uint32_t *out_counts) {
@@ -1293,6 +1418,23 @@ int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries, uint
     msi_set_error("msi_vs_search: invalid argument");
     return MSI_E_INVALID;
   }
+  if (k > KP_MAX) {
+    msi_set_error("msi_vs_search: k=%u above the supported maximum %u", k, KP_MAX);
+    return MSI_E_UNSUPPORTED;
+  }
+  // unfiltered, uncancellable small requests may share a sweep with concurrent callers
+  if (vs->microbatch_wait_us && !filter_bits && !cancel && n_queries && n_queries < vs->nqt_max * QT && k)
+    return vs_search_fused(vs, queries, n_queries, k, out_docids, out_dist, out_counts);
+  return vs_search_direct(vs, queries, n_queries, k, filter_bits, filter_nbits, cancel, out_docids, out_dist,
+                          out_counts);
+}
+
+}  // extern "C"
+
+static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_queries, uint32_t k,
+                                const uint64_t *filter_bits, uint64_t filter_nbits,
+                                const volatile int32_t *cancel, uint32_t *out_docids, float *out_dist,
+                                uint32_t *out_counts) {
   if (k > KP_MAX) {
     msi_set_error("msi_vs_search: k=%u above the supported maximum %u", k, KP_MAX);
     return MSI_E_UNSUPPORTED;
@@ -1347,6 +1489,8 @@ int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries, uint
   }
   return MSI_OK;
 }
+
+extern "C" {
 
 // Test instrumentation: the fast scan's raw scores (dot / |row|, before any
 // thresholding) of every row for <= msi_vs_max_batch() host queries, and the bound

@@ -91,6 +91,15 @@ class GpuStore:
             C.c_void_p(out_counts_t.data_ptr()),
             C.c_void_p(inexact_t.data_ptr()) if inexact_t is not None else None))
 
+    def set_microbatch(self, max_wait_us):
+        """Fuse concurrent unfiltered `search` calls (other threads) into shared HBM sweeps."""
+        check(lib().msi_vs_set_microbatch(self._h, int(max_wait_us)))
+
+    def microbatch_stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().msi_vs_microbatch_stats(self._h, C.byref(a), C.byref(b)))
+        return {"fused_calls": int(a.value), "fused_sweeps": int(b.value)}
+
     def debug_fast_scores(self, queries):
         """(scores [B, len] of the fast scan = dot/|row|, eps assumed by the proof)."""
         q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)

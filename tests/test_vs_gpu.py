@@ -175,6 +175,44 @@ def test_fast_scan_error_is_inside_the_proof_bound(ctx, dim, scale):
     assert err <= 0.25 * eps, ("the bound should be comfortable", err, eps)
 
 
+def test_microbatcher_fuses_concurrent_callers(ctx, oracle):
+    # 40 threads, one query each (the shape of milli's spawn_blocking searches): every caller
+    # must get exactly its own answer, and the sweeps must be shared
+    import threading
+    n, dim = 60000, 64
+    rows = synth.make_embeddings(n, dim, seed=91)
+    ids = np.arange(n, dtype=np.uint32)
+    qs = synth.make_embeddings(40, dim, seed=92)
+    ks = [20 if j % 3 else 7 for j in range(40)]        # mixed k inside one fused sweep
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    st.set_microbatch(20000)
+    out = [None] * 40
+    barrier = threading.Barrier(40)
+
+    def worker(j):
+        barrier.wait()
+        out[j] = st.search(qs[j:j + 1], ks[j])
+    th = [threading.Thread(target=worker, args=(j,)) for j in range(40)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for j in range(40):
+        d, s, c = out[j]
+        e_ids, e_dist = oracle.vs_topk(rows, ids, qs[j], ks[j])
+        assert c[0] == e_ids.size and d[0, :c[0]].tolist() == e_ids.tolist()
+        assert s[0, :c[0]].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist()
+    stats = st.microbatch_stats()
+    assert stats["fused_calls"] == 40
+    assert stats["fused_sweeps"] < 40, stats             # sweeps were shared
+    # filtered / multi-sweep calls bypass the batcher and still work with it enabled
+    fb, nb = ma.dense_filter(ids[::5])
+    check_against_oracle(oracle, st, rows, ids, qs[:3], 10, fb, nb)
+    st.set_microbatch(0)
+    check_against_oracle(oracle, st, rows, ids, qs[:2], 10)
+
+
 def test_objects_may_outlive_their_context():
     c2 = ma.Context(0)
     st = ma.GpuStore(c2, 8)
