@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=96, help="hybrid queries per step per GPU")
     ap.add_argument("--words-per-query", type=int, default=2)
     ap.add_argument("--dict-words", type=int, default=2_000_000)
+    ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
+                    help="row storage in HBM (f32 = the reference's; bf16 = BASELINE.json config 5's build-side choice)")
     ap.add_argument("--no-typo", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
@@ -82,7 +84,7 @@ def main():
         rows_t[r0:r1].normal_(generator=gen)
     ids_t = torch.arange(n, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    store = ma.GpuStore(ctx, d)
+    store = ma.GpuStore(ctx, d, storage=args.storage)
     store.upload_device(ids_t, rows_t)
     cpu_rows = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -183,7 +185,7 @@ def main():
     # (rocprofv3 --pmc FETCH_SIZE on this same command; counters cannot be read in-process)
     traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_fetch.json")
-    if os.path.exists(pmc_path) and n == 10_000_000 and d == 768:
+    if os.path.exists(pmc_path) and n == 10_000_000 and d == 768 and args.storage == "f32":
         try:
             kernels = json.load(open(pmc_path))["kernels"]
             for name, e in kernels.items():
@@ -204,10 +206,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.storage == "f32" else "bf16 rows, f32 arithmetic",
         "data": "synthetic (rows N(0,1) seed 1234; dictionary seed 99; query words seed 7; BASELINE.md C4/C3)",
         "config": {
-            "workload": f"C4 on one GPU per rank: {n} docs x {d}-d f32 exact cosine top-{k} "
+            "workload": f"C4 on one GPU per rank: {n} docs x {d}-d {args.storage} exact cosine top-{k} "
                         f"+ {args.words_per_query} typo-tolerant words/query over a {args.dict_words}-term dictionary",
             "queries_per_step_per_gpu": Q,
             "words_per_step_per_gpu": n_words_q,

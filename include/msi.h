@@ -60,7 +60,10 @@ const char *msi_last_error(void);
 /* device < 0: use $LOCAL_RANK if set, else device 0. */
 int32_t msi_ctx_create(int32_t device, msi_ctx **out);
 void msi_ctx_destroy(msi_ctx *ctx);
-/* The context's hipStream_t (as void*), e.g. to bracket work with HIP events. */
+/* The context's main hipStream_t (as void*): vector stores, docid sets, ranking.
+ * Dictionaries (msi_dict_*) run on a second stream of the context so that the
+ * VALU-bound typo lookup overlaps the HBM-bound scan; msi_ctx_synchronize waits
+ * for both. */
 void *msi_ctx_stream(msi_ctx *ctx);
 int32_t msi_ctx_synchronize(msi_ctx *ctx);
 int32_t msi_ctx_device(msi_ctx *ctx);
@@ -82,6 +85,12 @@ int32_t msi_ctx_set_profiling(msi_ctx *ctx, int32_t enable);
  * bit for bit on any device count.
  */
 int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out);
+/* Storage type of the rows in HBM.  MSI_VS_BF16 is a build-side choice (the
+ * reference stores f32 or 1-bit quantised vectors, store.rs:1095-1109): rows are
+ * rounded to bf16 (nearest even) at upload, every distance is the reference
+ * arithmetic on the ROUNDED rows, HBM bytes per row halve (BASELINE.json config 5). */
+enum { MSI_VS_F32 = 0, MSI_VS_BF16 = 1 };
+int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs **out);
 void msi_vs_destroy(msi_vs *vs);
 
 /* Replace the store's contents.  `docids[n_rows]` strictly ascending (one row

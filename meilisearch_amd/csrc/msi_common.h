@@ -34,8 +34,10 @@ void msi_set_error(const char *fmt, ...);
 struct msi_ctx {
   int device = 0;
   int n_cu = 0;
-  hipStream_t stream = nullptr;
-  std::mutex mu;  // serialises use of the stream + per-object scratch
+  hipStream_t stream = nullptr;      // vector stores, docid sets, ranking
+  std::mutex mu;                     // serialises use of `stream` + per-object scratch
+  hipStream_t stream_aux = nullptr;  // dictionaries: the VALU-bound typo lookup overlaps the
+  std::mutex mu_aux;                 // HBM-bound scan when both are enqueued (separate HIP streams)
   bool profiling = false;
   // The caller's handle holds one reference, every object created on the
   // context (msi_vs / msi_dict / msi_bits) one more: msi_ctx_destroy only drops
@@ -49,8 +51,10 @@ void msi_ctx_release(msi_ctx *ctx);
 struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_;
   hipEvent_t cur_start = nullptr, cur_stop = nullptr;
-  void begin(msi_ctx *ctx) {
+  hipStream_t st_ = nullptr;
+  void begin(msi_ctx *ctx, hipStream_t st = nullptr) {
     if (!ctx->profiling) return;
+    st_ = st ? st : ctx->stream;
     if (free_.empty()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -59,11 +63,11 @@ struct KernelTimer {
     cur_start = free_.back().first;
     cur_stop = free_.back().second;
     free_.pop_back();
-    (void)hipEventRecord(cur_start, ctx->stream);
+    (void)hipEventRecord(cur_start, st_);
   }
   void end(msi_ctx *ctx) {
     if (!cur_start) return;
-    (void)hipEventRecord(cur_stop, ctx->stream);
+    (void)hipEventRecord(cur_stop, st_);
     pending.push_back({cur_start, cur_stop});
     cur_start = cur_stop = nullptr;
   }

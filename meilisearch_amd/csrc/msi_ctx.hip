@@ -59,6 +59,7 @@ int32_t msi_ctx_create(int32_t device, msi_ctx **out) {
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking);
   if (e != hipSuccess) {
     msi_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
     delete c;
@@ -82,6 +83,10 @@ void msi_ctx_release(msi_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
+  if (ctx->stream_aux) {
+    (void)hipStreamSynchronize(ctx->stream_aux);
+    (void)hipStreamDestroy(ctx->stream_aux);
+  }
   delete ctx;
 }
 
@@ -93,6 +98,7 @@ int32_t msi_ctx_device(msi_ctx *ctx) { return ctx ? ctx->device : -1; }
 int32_t msi_ctx_set_profiling(msi_ctx *ctx, int32_t enable) {
   if (!ctx) return MSI_E_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk2(ctx->mu_aux);
   ctx->profiling = enable != 0;
   return MSI_OK;
 }
@@ -101,6 +107,7 @@ int32_t msi_ctx_synchronize(msi_ctx *ctx) {
   if (!ctx) return MSI_E_INVALID;
   DeviceGuard g(ctx->device);
   MSI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  MSI_HIP_TRY(hipStreamSynchronize(ctx->stream_aux));
   return MSI_OK;
 }
 

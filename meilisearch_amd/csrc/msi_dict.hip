@@ -690,7 +690,7 @@ struct msi_dict {
   msi_ctx *ctx = nullptr;
   uint32_t n_words = 0, n_long = 0;
   DevBuf slots, blen, nchars, flat, offs, long_idx;
-  // scratch (guarded by ctx->mu)
+  // scratch (guarded by ctx->mu_aux)
   DevBuf qbytes, qoff, qflags, qm, qchars, lists, cnts, llists, lcnts, comp, pairs, out1, out1c, out2, out2c;
   uint64_t lookup_launches = 0, dict_bytes = 0;
   KernelTimer match_timer;
@@ -702,7 +702,7 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
                        uint32_t n, uint32_t cap1, uint32_t cap2, uint32_t *d_one, uint32_t *d_one_cnt,
                        uint32_t *d_two, uint32_t *d_two_cnt) {
   msi_ctx *ctx = d->ctx;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->stream_aux;
   if (cap1 == 0 || cap2 == 0 || cap1 > 4096 || cap2 > 4096) {
     msi_set_error("msi_dict_lookup: caps must be in 1..4096");
     return MSI_E_INVALID;
@@ -754,7 +754,7 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
     a.nseg = nseg;
     a.lists = d->lists.as<uint32_t>();
     a.cnts = d->cnts.as<uint32_t>();
-    d->match_timer.begin(ctx);
+    d->match_timer.begin(ctx, st);
     hipLaunchKernelGGL(dict_match_kernel<false>, dim3((nseg / DW) * nchunks), dim3(DW * 64), 0, st, a, a.qm);
     d->match_timer.end(ctx);
   }
@@ -828,13 +828,13 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
     if (len > 16) long_idx.push_back(i);
   }
   DeviceGuard g(ctx->device);
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->mu_aux);
   msi_dict *d = new msi_dict();
   d->ctx = ctx;
   d->n_words = n_words;
   d->n_long = (uint32_t)long_idx.size();
   const size_t flat_bytes = n_words ? offsets[n_words] : 0;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->stream_aux;
   int32_t s = MSI_OK;
   auto up = [&](DevBuf &b, const void *src, size_t bytes) {
     if (s != MSI_OK) return;
@@ -875,9 +875,9 @@ void msi_dict_destroy(msi_dict *d) {
   if (!d) return;
   msi_ctx *ctx = d->ctx;
   {
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(ctx->mu_aux);
   DeviceGuard g(ctx->device);
-  (void)hipStreamSynchronize(d->ctx->stream);
+  (void)hipStreamSynchronize(d->ctx->stream_aux);
   DevBuf *bufs[] = {&d->slots, &d->blen, &d->nchars, &d->flat, &d->offs, &d->long_idx, &d->qbytes, &d->qoff,
                     &d->qflags, &d->qm, &d->qchars, &d->lists, &d->cnts, &d->llists, &d->lcnts, &d->comp, &d->pairs,
                     &d->out1, &d->out1c, &d->out2, &d->out2c};
@@ -898,7 +898,7 @@ int32_t msi_dict_lookup_device(msi_dict *d, const uint8_t *d_qbytes, const uint3
     msi_set_error("msi_dict_lookup_device: invalid argument");
     return MSI_E_INVALID;
   }
-  std::lock_guard<std::mutex> lk(d->ctx->mu);
+  std::lock_guard<std::mutex> lk(d->ctx->mu_aux);
   DeviceGuard g(d->ctx->device);
   return enqueue_lookup(d, d_qbytes, d_qoff, d_qflags, n, cap_one, cap_two, d_out_one_idx, d_out_one_cnt,
                         d_out_two_idx, d_out_two_cnt);
@@ -923,9 +923,9 @@ int32_t msi_dict_lookup(msi_dict *d, const msi_typo_query *queries, uint32_t n, 
     off[i + 1] = (uint32_t)bytes.size();
     flags[i] = (uint8_t)((q.max_typos > 2 ? 2 : q.max_typos) | (q.is_prefix ? 4 : 0));
   }
-  std::lock_guard<std::mutex> lk(d->ctx->mu);
+  std::lock_guard<std::mutex> lk(d->ctx->mu_aux);
   DeviceGuard g(d->ctx->device);
-  hipStream_t st = d->ctx->stream;
+  hipStream_t st = d->ctx->stream_aux;
   MSI_TRY(d->qbytes.ensure(std::max<size_t>(16, bytes.size())));
   MSI_TRY(d->qoff.ensure((n + 1) * sizeof(uint32_t)));
   MSI_TRY(d->qflags.ensure(n));
@@ -949,9 +949,9 @@ int32_t msi_dict_lookup(msi_dict *d, const msi_typo_query *queries, uint32_t n, 
 
 int32_t msi_dict_match_time(msi_dict *d, uint64_t *out_launches, double *out_ms_total) {
   if (!d || !out_launches || !out_ms_total) return MSI_E_INVALID;
-  std::lock_guard<std::mutex> lk(d->ctx->mu);
+  std::lock_guard<std::mutex> lk(d->ctx->mu_aux);
   DeviceGuard g(d->ctx->device);
-  MSI_HIP_TRY(hipStreamSynchronize(d->ctx->stream));
+  MSI_HIP_TRY(hipStreamSynchronize(d->ctx->stream_aux));
   d->match_timer.drain(out_launches, out_ms_total);
   return MSI_OK;
 }
@@ -962,10 +962,10 @@ int32_t msi_dict_get_stats(const msi_dict *d, msi_dict_stats *out) {
   out->dict_bytes = d->dict_bytes;
   out->pairs_scanned = 0;
   if (d->pairs.p) {
-    std::lock_guard<std::mutex> lk(d->ctx->mu);
+    std::lock_guard<std::mutex> lk(d->ctx->mu_aux);
     DeviceGuard g(d->ctx->device);
     u64 v = 0;
-    if (hipStreamSynchronize(d->ctx->stream) == hipSuccess &&
+    if (hipStreamSynchronize(d->ctx->stream_aux) == hipSuccess &&
         hipMemcpy(&v, d->pairs.p, sizeof(u64), hipMemcpyDeviceToHost) == hipSuccess)
       out->pairs_scanned = v;
   }

@@ -91,6 +91,66 @@ __global__ void vs_tile_rows_kernel(const float *__restrict__ rows, uint64_t row
   tiles[(row0 / 16) * KB * 64 + idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// bf16 store: row-major f32 chunk -> bf16 (round to nearest even) tiles.  Block (t,kb)
+// holds, for lane l = g*16+i, the 8 bf16 = row 16t+i, columns 32kb+8g..+7: one
+// wave-wide 16-byte load is the A operand of v_mfma_f32_16x16x32_bf16 as it is.
+__global__ void vs_tile_rows_bf16_kernel(const float *__restrict__ rows, uint64_t row0, uint64_t n_chunk,
+                                         uint32_t dim, uint32_t KB, bf16x8 *__restrict__ tiles) {
+  uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 16-byte slot inside chunk
+  uint64_t chunk_tiles = (n_chunk + 15) / 16;
+  uint64_t total = chunk_tiles * KB * 64;
+  if (idx >= total) return;
+  uint32_t lane = idx & 63;
+  uint64_t blk = idx >> 6;
+  uint32_t kb = blk % KB;
+  uint64_t t = blk / KB;
+  uint32_t i = lane & 15, g = lane >> 4;
+  uint64_t r = t * 16 + i;
+  uint32_t k0 = kb * 32 + g * 8;
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float x = 0.f;
+    if (r < n_chunk && k0 + j < dim) x = rows[r * (uint64_t)dim + k0 + j];
+    v[j] = (__bf16)x;
+  }
+  tiles[(row0 / 16) * KB * 64 + idx] = v;
+}
+
+// Element (row, column) of the tiled store as f32, for the canonical (sequential) paths.
+template <bool S16>
+__device__ __forceinline__ float tile_elem(const void *__restrict__ tiles, uint32_t KB, uint32_t row, uint32_t k) {
+  if (S16) {
+    const __bf16 *p = reinterpret_cast<const __bf16 *>(tiles);
+    const uint64_t slot = ((uint64_t)(row >> 4) * KB + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (row & 15);
+    return (float)p[slot * 8 + (k & 7)];
+  }
+  const float *p = reinterpret_cast<const float *>(tiles);
+  const uint64_t slot = ((uint64_t)(row >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (row & 15);
+  return p[slot * 4 + (k & 3)];
+}
+
+// Canonical row norms of a bf16 store (values are the rounded ones).
+__global__ void vs_row_norms_bf16_kernel(const void *__restrict__ tiles, uint64_t n_rows_total, uint32_t KB,
+                                         uint32_t dim, float *__restrict__ norm, float *__restrict__ inv_norm) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t padded = ((n_rows_total + 15) / 16) * 16;
+  if (r >= padded) return;
+  if (r >= n_rows_total) {
+    norm[r] = 0.f;
+    inv_norm[r] = 0.f;
+    return;
+  }
+  float acc = 0.f;
+  for (uint32_t k = 0; k < dim; ++k) {
+    const float x = tile_elem<true>(tiles, KB, (uint32_t)r, k);
+    acc = __fadd_rn(acc, __fmul_rn(x, x));
+  }
+  const float n = msi_sqrt_rn(acc);
+  norm[r] = n;
+  inv_norm[r] = 1.0f / n;
+}
+
 // Canonical row norms from the tiled layout: pn = sqrt(sum_k x_k*x_k), sequential
 // f32 mul+add in column order (arroy/hannoy scalar path).  One thread per row.
 __global__ void vs_row_norms_kernel(const float4 *__restrict__ tiles, uint64_t row0,
@@ -140,35 +200,39 @@ __global__ void vs_check_sorted_kernel(const uint32_t *__restrict__ docids, uint
 __global__ __launch_bounds__(256) void vs_prep_queries_kernel(
     const float *__restrict__ q, uint32_t nq, uint32_t dim, uint32_t KB, float4 *__restrict__ qfrag,
     bf16x8 *__restrict__ qfrag_bf, float *__restrict__ qrow, float *__restrict__ qn,
-    float *__restrict__ inv_qn, float *__restrict__ degth) {
+    float *__restrict__ inv_qn, float *__restrict__ degth, uint32_t store16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *row = reinterpret_cast<float *>(smem);  // [dpad]
   const uint32_t j = blockIdx.x;
-  const uint32_t dpad = KB * 16;
+  const uint32_t dpad = store16 ? KB * 32 : KB * 16;
   for (uint32_t k = threadIdx.x; k < dpad; k += blockDim.x)
     row[k] = (j < nq && k < dim) ? q[(uint64_t)j * dim + k] : 0.f;
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < dpad; k += blockDim.x) qrow[(uint64_t)j * dpad + k] = row[k];
   const uint32_t t = j / QT, jj = j % QT;
-  for (uint32_t idx = threadIdx.x; idx < KB * 4; idx += blockDim.x) {
-    const uint32_t kb = idx >> 2, g = idx & 3;
-    const float4 v = *reinterpret_cast<const float4 *>(row + kb * 16 + g * 4);
-    qfrag[((uint64_t)t * KB + kb) * 64 + g * 16 + jj] = v;
+  if (!store16) {
+    for (uint32_t idx = threadIdx.x; idx < KB * 4; idx += blockDim.x) {
+      const uint32_t kb = idx >> 2, g = idx & 3;
+      const float4 v = *reinterpret_cast<const float4 *>(row + kb * 16 + g * 4);
+      qfrag[((uint64_t)t * KB + kb) * 64 + g * 16 + jj] = v;
+    }
   }
   // bf16x3 fragments: block pair p = (2p, 2p+1), lane (g, jj) holds the 8 columns
   // 32p+4g..+3 and 32p+16+4g..+3 (the same 8 a row lane holds after two 16-byte
   // loads), split as hi = bf16(x), lo = bf16(x - hi); layout [t][KB/2][hi|lo][64].
-  for (uint32_t idx = threadIdx.x; idx < (KB / 2) * 4; idx += blockDim.x) {
+  // (bf16 store: KB counts 32-column blocks and lane (g, jj) holds columns 32p+8g..+7)
+  const uint32_t n_pairs = store16 ? KB : KB / 2;
+  for (uint32_t idx = threadIdx.x; idx < n_pairs * 4; idx += blockDim.x) {
     const uint32_t p = idx >> 2, g = idx & 3;
     bf16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float x = row[p * 32 + (e >> 2) * 16 + g * 4 + (e & 3)];
+      const float x = store16 ? row[p * 32 + g * 8 + e] : row[p * 32 + (e >> 2) * 16 + g * 4 + (e & 3)];
       const __bf16 h = (__bf16)x;
       hi[e] = h;
       lo[e] = (__bf16)(x - (float)h);
     }
-    const uint64_t base = (((uint64_t)t * (KB / 2) + p) * 2) * 64 + g * 16 + jj;
+    const uint64_t base = (((uint64_t)t * n_pairs + p) * 2) * 64 + g * 16 + jj;
     qfrag_bf[base] = hi;
     qfrag_bf[base + 64] = lo;
   }
@@ -276,7 +340,10 @@ struct ScanArgs {
 //          queries per sweep stay HBM-bound.  The dropped lo·lo term and the bf16 rounding
 //          of lo cost <= 3·2^-18 relative per product, which the exactness proof's eps
 //          carries; returned distances never see it (canonical rescoring).
-template <int WAVES, int NQT, bool DENSE, bool BF3>
+//   S16    the store holds bf16 rows (half the HBM bytes per row): the 16-byte loads ARE
+//          the bf16 A operands, x·(q_hi + q_lo) needs 2 MFMAs per 32 columns and no
+//          conversion; LDS holds q_hi and q_lo (2 KiB per 32 columns and query tile).
+template <int WAVES, int NQT, bool DENSE, bool BF3, bool S16>
 __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x;
@@ -285,7 +352,7 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   const uint32_t KB = a.KB;
 
   float4 *qf = reinterpret_cast<float4 *>(smem);
-  for (uint32_t i = tid; i < NQT * KB * 64; i += WAVES * 64) qf[i] = a.qfrag[i];
+  for (uint32_t i = tid; i < NQT * KB * 64 * (S16 ? 2 : 1); i += WAVES * 64) qf[i] = a.qfrag[i];
   __syncthreads();
 
   const uint32_t qj = lane & 15;   // this lane's query inside a tile (D column)
@@ -385,7 +452,21 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
     }
   };
   auto compute_group = [&](const float4(&x)[SCAN_GROUP]) {
-    if (BF3) {
+    if (S16) {
+      // LDS: [t][KB][hi|lo][64] bf16x8; this group covers blocks sub_cmp*8 .. +7
+      const bf16x8 *qb = reinterpret_cast<const bf16x8 *>(qf) + (size_t)sub_cmp * SCAN_GROUP * 128 + lane;
+#pragma unroll
+      for (int u = 0; u < SCAN_GROUP; ++u) {
+        bf16x8 xa8;
+        __builtin_memcpy(&xa8, &x[u], 16);
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+          const bf16x8 *qt = qb + (size_t)t * KB * 128 + u * 128;
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa8, qt[0], acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa8, qt[64], acc[t][1], 0, 0, 0);
+        }
+      }
+    } else if (BF3) {
       // LDS: [t][KB/2][hi|lo][64] bf16x8; this group covers pairs sub_cmp*4 .. +3
       const bf16x8 *qb = reinterpret_cast<const bf16x8 *>(qf) + (size_t)sub_cmp * (SCAN_GROUP / 2) * 128 + lane;
 #pragma unroll
@@ -632,10 +713,15 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_select_kernel(SelectArgs a) {
 
 // Reference arithmetic for one (row, query) pair from the tiled layout:
 // sequential f32 mul+add in column order, then arroy/hannoy's cosine distance.
-__device__ __forceinline__ float canonical_dot(const float4 *__restrict__ tiles, uint32_t KB,
-                                               uint32_t row, const float *__restrict__ q) {
-  const float4 *base = tiles + (uint64_t)(row >> 4) * KB * 64 + (row & 15);
+template <bool S16>
+__device__ __forceinline__ float canonical_dot_t(const void *__restrict__ tiles, uint32_t KB, uint32_t row,
+                                                 const float *__restrict__ q, uint32_t dpad) {
   float acc = 0.f;
+  if (S16) {
+    for (uint32_t k = 0; k < dpad; ++k) acc = __fadd_rn(acc, __fmul_rn(tile_elem<true>(tiles, KB, row, k), q[k]));
+    return acc;
+  }
+  const float4 *base = reinterpret_cast<const float4 *>(tiles) + (uint64_t)(row >> 4) * KB * 64 + (row & 15);
   for (uint32_t kb = 0; kb < KB; ++kb) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -649,6 +735,10 @@ __device__ __forceinline__ float canonical_dot(const float4 *__restrict__ tiles,
   }
   return acc;
 }
+__device__ __forceinline__ float canonical_dot(const void *__restrict__ tiles, uint32_t KB, uint32_t row,
+                                               const float *__restrict__ q, uint32_t dpad, bool s16) {
+  return s16 ? canonical_dot_t<true>(tiles, KB, row, q, dpad) : canonical_dot_t<false>(tiles, KB, row, q, dpad);
+}
 
 __device__ __forceinline__ float canonical_distance(float pq, float pn, float qn) {
   const float pnqn = __fmul_rn(pn, qn);
@@ -660,7 +750,9 @@ __device__ __forceinline__ float canonical_distance(float pq, float pn, float qn
 }
 
 struct RescoreArgs {
-  const float4 *tiles;
+  const void *tiles;
+  uint32_t dpad;
+  uint32_t s16;
   const float *norm;
   const uint32_t *docids;
   const float *qrow;       // [NQ_MAX][dpad]
@@ -685,7 +777,7 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) 
   u64 *sbuf = reinterpret_cast<u64 *>(dyn);                          // [KP_MAX]
   float *qs = reinterpret_cast<float *>(dyn + KP_MAX * sizeof(u64)); // [dpad]
   const uint32_t j = blockIdx.x;
-  const uint32_t dpad = a.KB * 16;
+  const uint32_t dpad = a.dpad;
   for (uint32_t i = threadIdx.x; i < dpad; i += blockDim.x) qs[i] = a.qrow[(uint64_t)j * dpad + i];
   const uint32_t cnt = a.sel_cnt[j];
   const uint32_t n = next_pow2(cnt < 2 ? 2 : cnt);
@@ -695,7 +787,7 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) 
     u64 key = ~0ull;
     if (i < cnt) {
       const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
-      const float pq = canonical_dot(a.tiles, a.KB, row, qs);
+      const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
       const float d = canonical_distance(pq, a.norm[row], qn);
       key = ((u64)f32_to_ord(d) << 32) | row;  // rows ascend with docids
     }
@@ -737,14 +829,13 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) 
 
 // Reference distance of EVERY allowed row for one query (fallback when the
 // exactness proof fails, e.g. more than K' rows tie at the cut).
-__global__ void vs_exhaustive_kernel(const float4 *__restrict__ tiles, const float *__restrict__ norm,
+__global__ void vs_exhaustive_kernel(const void *__restrict__ tiles, const float *__restrict__ norm,
                                      const uint32_t *__restrict__ docids, uint64_t n_rows, uint32_t KB,
                                      const float *__restrict__ qrow, const float *__restrict__ qn_p,
                                      uint32_t qj, const u64 *__restrict__ fbits, uint64_t nbits,
-                                     u64 *__restrict__ keys) {
+                                     u64 *__restrict__ keys, uint32_t dpad, uint32_t s16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
   float *qs = reinterpret_cast<float *>(dyn);
-  const uint32_t dpad = KB * 16;
   for (uint32_t i = threadIdx.x; i < dpad; i += blockDim.x) qs[i] = qrow[(uint64_t)qj * dpad + i];
   __syncthreads();
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,7 +847,7 @@ __global__ void vs_exhaustive_kernel(const float4 *__restrict__ tiles, const flo
   }
   u64 key = ~0ull;
   if (ok) {
-    const float pq = canonical_dot(tiles, KB, (uint32_t)r, qs);
+    const float pq = canonical_dot(tiles, KB, (uint32_t)r, qs, dpad, s16 != 0);
     const float d = canonical_distance(pq, norm[r], qn_p[qj]);
     key = ((u64)f32_to_ord(d) << 32) | (uint32_t)r;
   }
@@ -792,13 +883,11 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_exhaustive_select_kernel(
   if (threadIdx.x == 0) *out_count = out_n;
 }
 
-__global__ void vs_gather_row_kernel(const float4 *__restrict__ tiles, uint32_t KB, uint32_t row,
-                                     uint32_t dim, float *__restrict__ out) {
+__global__ void vs_gather_row_kernel(const void *__restrict__ tiles, uint32_t KB, uint32_t row,
+                                     uint32_t dim, float *__restrict__ out, uint32_t s16) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= dim) return;
-  const float4 v = tiles[((uint64_t)(row >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (row & 15)];
-  const float c[4] = {v.x, v.y, v.z, v.w};
-  out[k] = c[k & 3];
+  out[k] = s16 ? tile_elem<true>(tiles, KB, row, k) : tile_elem<false>(tiles, KB, row, k);
 }
 
 }  // namespace
@@ -810,6 +899,7 @@ struct msi_vs {
   uint32_t dim = 0, dpad = 0, KB = 0;
   uint32_t nqt_max = 1;            // query tiles per sweep the LDS admits for this dim
   bool bf3 = true;                 // contraction of the fast scan: bf16x3 (default) or f32 MFMA
+  bool s16 = false;                // rows stored as bf16 (MSI_VS_BF16)
   uint64_t n_rows = 0, n_tiles = 0;
   DevBuf tiles, norm, inv_norm, docids;
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
@@ -868,7 +958,9 @@ Small small_of(msi_vs *vs) {
   return s;
 }
 
-size_t scan_lds_bytes(uint32_t KB, uint32_t nqt) { return (size_t)nqt * KB * 64 * sizeof(float4); }
+size_t scan_lds_bytes(uint32_t KB, uint32_t nqt, bool s16 = false) {
+  return (size_t)nqt * KB * 64 * sizeof(float4) * (s16 ? 2 : 1);
+}
 
 // Threshold rank r for the sample pass: the smallest r for which "fewer than kp
 // rows of the whole store beat the r-th best of a p-fraction sample" has
@@ -883,10 +975,20 @@ uint32_t threshold_rank(uint32_t kp, double p) {
   return kp;
 }
 
+// Bound on |fast cos - reference cos| assumed by the exactness proof: f32 accumulation
+// of n terms (gamma_n with a factor 2 for the MFMA adder tree; n = dpad, 2·dpad or 3·dpad
+// products per row) plus the bf16 split terms (2^-18 relative per dropped/rounded part).
+float scan_eps(const msi_vs *vs) {
+  const float u = 5.9604645e-8f, h = 3.8146973e-6f;
+  if (vs->s16) return (4.0f * (float)vs->dpad + 64.0f) * u + 1.0f * h;
+  if (vs->bf3) return (6.0f * (float)vs->dpad + 64.0f) * u + 3.0f * h;
+  return (2.0f * (float)vs->dpad + 32.0f) * u;
+}
+
 int32_t ensure_scratch(msi_vs *vs) {
   MSI_TRY(vs->qraw.ensure((size_t)NQ_MAX * vs->dim * sizeof(float)));
   MSI_TRY(vs->qfrag.ensure((size_t)NQT_MAX * vs->KB * 64 * sizeof(float4)));
-  MSI_TRY(vs->qfrag_bf.ensure((size_t)NQT_MAX * vs->KB * 64 * sizeof(float4)));
+  MSI_TRY(vs->qfrag_bf.ensure((size_t)NQT_MAX * vs->KB * 64 * sizeof(float4) * (vs->s16 ? 2 : 1)));
   MSI_TRY(vs->qrow.ensure((size_t)NQ_MAX * vs->dpad * sizeof(float)));
   MSI_TRY(vs->qsmall.ensure(5 * NQ_MAX * sizeof(float)));
   MSI_TRY(vs->gsmall.ensure((3 * NQ_MAX + 8) * sizeof(uint32_t)));
@@ -935,11 +1037,18 @@ int32_t upload_common(msi_vs *vs, const uint32_t *docids, bool docids_on_device,
       src = vs->rowtmp.as<float>();
     }
     const uint64_t total = ((nc + 15) / 16) * vs->KB * 64;
-    hipLaunchKernelGGL(vs_tile_rows_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, src,
-                       r0, nc, vs->dim, vs->KB, vs->tiles.as<float4>());
+    if (vs->s16)
+      hipLaunchKernelGGL(vs_tile_rows_bf16_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, src,
+                         r0, nc, vs->dim, vs->KB, vs->tiles.as<bf16x8>());
+    else
+      hipLaunchKernelGGL(vs_tile_rows_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, src,
+                         r0, nc, vs->dim, vs->KB, vs->tiles.as<float4>());
     if (!rows_on_device) MSI_HIP_TRY(hipStreamSynchronize(st));  // rowtmp is reused
   }
-  if (padded)
+  if (padded && vs->s16)
+    hipLaunchKernelGGL(vs_row_norms_bf16_kernel, dim3((uint32_t)((padded + 255) / 256)), dim3(256), 0, st,
+                       vs->tiles.p, n_rows, vs->KB, vs->dim, vs->norm.as<float>(), vs->inv_norm.as<float>());
+  else if (padded)
     hipLaunchKernelGGL(vs_row_norms_kernel, dim3((uint32_t)((padded + 255) / 256)), dim3(256), 0, st,
                        vs->tiles.as<float4>(), (uint64_t)0, n_rows, vs->KB, vs->norm.as<float>(),
                        vs->inv_norm.as<float>());
@@ -973,19 +1082,23 @@ int32_t upload_common(msi_vs *vs, const uint32_t *docids, bool docids_on_device,
 
 // Launch one sweep.  `dense` selects the epilogue, nqt the number of 16-query tiles.
 void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense) {
-  const size_t lds = scan_lds_bytes(vs->KB, nqt);
+  const size_t lds = scan_lds_bytes(vs->KB, nqt, vs->s16);
   const dim3 grid(vs->scan_grid), block(SCAN_WAVES * 64);
   hipStream_t st = vs->ctx->stream;
-#define MSI_SCAN_LAUNCH(N, D, B) hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, D, B>), grid, block, lds, st, sa)
-#define MSI_SCAN_CASE(N)                                       \
-  case N:                                                      \
-    if (dense) {                                               \
-      if (vs->bf3) MSI_SCAN_LAUNCH(N, true, true);             \
-      else MSI_SCAN_LAUNCH(N, true, false);                    \
-    } else {                                                   \
-      if (vs->bf3) MSI_SCAN_LAUNCH(N, false, true);            \
-      else MSI_SCAN_LAUNCH(N, false, false);                   \
-    }                                                          \
+#define MSI_SCAN_LAUNCH(N, D, B, S) \
+  hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, D, B, S>), grid, block, lds, st, sa)
+#define MSI_SCAN_CASE(N)                                              \
+  case N:                                                             \
+    if (vs->s16) {                                                    \
+      if (dense) MSI_SCAN_LAUNCH(N, true, true, true);                \
+      else MSI_SCAN_LAUNCH(N, false, true, true);                     \
+    } else if (dense) {                                               \
+      if (vs->bf3) MSI_SCAN_LAUNCH(N, true, true, false);             \
+      else MSI_SCAN_LAUNCH(N, true, false, false);                    \
+    } else {                                                          \
+      if (vs->bf3) MSI_SCAN_LAUNCH(N, false, true, false);            \
+      else MSI_SCAN_LAUNCH(N, false, false, false);                   \
+    }                                                                 \
     break;
   switch (nqt) {
     MSI_SCAN_CASE(1)
@@ -1014,7 +1127,7 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   // 1. queries
   hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
                      d_queries, nq, vs->dim, vs->KB, vs->qfrag.as<float4>(), vs->qfrag_bf.as<bf16x8>(),
-                     vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth);
+                     vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth, vs->s16 ? 1u : 0u);
   MSI_HIP_TRY(hipMemsetAsync(s.overflow, 0, sizeof(uint32_t), st));
   // 2. filter
   const uint32_t *list = nullptr;
@@ -1052,7 +1165,7 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   ScanArgs sa;
   sa.tiles = vs->tiles.as<float4>();
   sa.inv_norm = vs->inv_norm.as<float>();
-  sa.qfrag = vs->bf3 ? vs->qfrag_bf.as<float4>() : vs->qfrag.as<float4>();
+  sa.qfrag = (vs->bf3 || vs->s16) ? vs->qfrag_bf.as<float4>() : vs->qfrag.as<float4>();
   sa.theta = s.theta_inf;
   sa.degth = s.degth;
   sa.n_items_ptr = n_items_ptr;
@@ -1116,7 +1229,9 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   }
   // rescore with the reference arithmetic, order, prove exactness
   RescoreArgs ra;
-  ra.tiles = vs->tiles.as<float4>();
+  ra.tiles = vs->tiles.p;
+  ra.dpad = vs->dpad;
+  ra.s16 = vs->s16 ? 1u : 0u;
   ra.norm = vs->norm.as<float>();
   ra.docids = vs->docids.as<uint32_t>();
   ra.qrow = vs->qrow.as<float>();
@@ -1129,8 +1244,7 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   ra.k = k;
   // bound on |fast cos - reference cos|: f32 accumulation of n terms (gamma_n, n = dpad or
   // 3·dpad, with a factor 2 for the MFMA adder tree) + the bf16x3 split's 3·2^-18 per product
-  ra.eps = vs->bf3 ? (6.0f * (float)vs->dpad + 64.0f) * 5.9604645e-8f + 3.0f * 3.8146973e-6f
-                   : (2.0f * (float)vs->dpad + 32.0f) * 5.9604645e-8f;
+  ra.eps = scan_eps(vs);
   ra.out_docids = d_out_docids;
   ra.out_dist = d_out_dist;
   ra.out_counts = d_out_counts;
@@ -1151,9 +1265,9 @@ int32_t exhaustive_one(msi_vs *vs, uint32_t qj, uint32_t k, const u64 *d_fbits, 
   MSI_TRY(vs->exh_keys.ensure(std::max<uint64_t>(1, vs->n_rows) * sizeof(u64)));
   if (vs->n_rows)
     hipLaunchKernelGGL(vs_exhaustive_kernel, dim3((uint32_t)((vs->n_rows + 255) / 256)), dim3(256),
-                       (size_t)vs->dpad * sizeof(float), st, vs->tiles.as<float4>(), vs->norm.as<float>(),
+                       (size_t)vs->dpad * sizeof(float), st, vs->tiles.p, vs->norm.as<float>(),
                        vs->docids.as<uint32_t>(), vs->n_rows, vs->KB, vs->qrow.as<float>(), s.qn, qj, d_fbits,
-                       nbits, vs->exh_keys.as<u64>());
+                       nbits, vs->exh_keys.as<u64>(), vs->dpad, vs->s16 ? 1u : 0u);
   hipLaunchKernelGGL(vs_exhaustive_select_kernel, dim3(1), dim3(SEL_THREADS), 0, st, vs->exh_keys.as<u64>(),
                      (uint32_t)vs->n_rows, k, vs->docids.as<uint32_t>(), d_out_docids, d_out_dist, d_out_count);
   MSI_HIP_TRY(hipGetLastError());
@@ -1166,31 +1280,40 @@ int32_t exhaustive_one(msi_vs *vs, uint32_t qj, uint32_t k, const u64 *d_fbits, 
 extern "C" {
 
 int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out) {
-  if (!ctx || !out || dim == 0) {
+  return msi_vs_create_typed(ctx, dim, MSI_VS_F32, out);
+}
+
+int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs **out) {
+  if (!ctx || !out || dim == 0 || (storage != MSI_VS_F32 && storage != MSI_VS_BF16)) {
     msi_set_error("msi_vs_create: invalid argument");
     return MSI_E_INVALID;
   }
   *out = nullptr;
-  const uint32_t dpad = ((dim + 127) / 128) * 128;  // KB multiple of SCAN_GROUP
-  const uint32_t KB = dpad / 16;
-  if (scan_lds_bytes(KB, 1) > LDS_MAX) {
+  const bool s16 = storage == MSI_VS_BF16;
+  // a tile is KB blocks of 1 KiB; KB must be a multiple of SCAN_GROUP
+  const uint32_t dpad = s16 ? ((dim + 255) / 256) * 256 : ((dim + 127) / 128) * 128;
+  const uint32_t KB = s16 ? dpad / 32 : dpad / 16;
+  if (scan_lds_bytes(KB, 1, s16) > LDS_MAX) {
     msi_set_error("msi_vs_create: dim %u needs %zu B of LDS for one query tile (max %zu)", dim,
-                  scan_lds_bytes(KB, 1), LDS_MAX);
+                  scan_lds_bytes(KB, 1, s16), LDS_MAX);
     return MSI_E_UNSUPPORTED;
   }
   uint32_t nqt_max = 1;
-  while (nqt_max < (uint32_t)NQT_MAX && scan_lds_bytes(KB, nqt_max + 1) <= LDS_MAX) ++nqt_max;
+  while (nqt_max < (uint32_t)NQT_MAX && scan_lds_bytes(KB, nqt_max + 1, s16) <= LDS_MAX) ++nqt_max;
   if (const char *e = getenv("MSI_VS_MAX_QUERY_TILES")) {  // tuning/testing knob
     const int v = atoi(e);
     if (v >= 1 && (uint32_t)v < nqt_max) nqt_max = (uint32_t)v;
   }
   DeviceGuard g(ctx->device);
   const void *fns[] = {
-#define MSI_F(N, D, B) reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, B>)
+#define MSI_F(N, D, B) reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, B, false>)
+#define MSI_G(N, D) reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, true, true>)
       MSI_F(1, true, true), MSI_F(1, true, false), MSI_F(1, false, true), MSI_F(1, false, false),
       MSI_F(2, true, true), MSI_F(2, true, false), MSI_F(2, false, true), MSI_F(2, false, false),
-      MSI_F(3, true, true), MSI_F(3, true, false), MSI_F(3, false, true), MSI_F(3, false, false)
+      MSI_F(3, true, true), MSI_F(3, true, false), MSI_F(3, false, true), MSI_F(3, false, false),
+      MSI_G(1, true), MSI_G(1, false), MSI_G(2, true), MSI_G(2, false), MSI_G(3, true), MSI_G(3, false)
 #undef MSI_F
+#undef MSI_G
   };
   for (const void *fn : fns) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
@@ -1206,9 +1329,10 @@ int32_t msi_vs_create(msi_ctx *ctx, uint32_t dim, msi_vs **out) {
   vs->dpad = dpad;
   vs->KB = KB;
   vs->nqt_max = nqt_max;
+  vs->s16 = s16;
   if (const char *e = getenv("MSI_VS_SCAN_MATH")) vs->bf3 = strcmp(e, "f32") != 0;  // "f32" | "bf16x3"
   // workgroups per CU: two when the query fragments leave room (more loads in flight)
-  uint32_t wg_per_cu = scan_lds_bytes(KB, nqt_max) <= LDS_MAX / 2 ? 2 : 1;
+  uint32_t wg_per_cu = scan_lds_bytes(KB, nqt_max, s16) <= LDS_MAX / 2 ? 2 : 1;
   if (const char *e = getenv("MSI_VS_WG_PER_CU")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4) wg_per_cu = (uint32_t)v;
@@ -1275,7 +1399,7 @@ int32_t msi_vs_get_vector(msi_vs *vs, uint32_t docid, float *out_row, int32_t *o
   hipStream_t st = vs->ctx->stream;
   MSI_TRY(vs->qraw.ensure((size_t)NQ_MAX * vs->dim * sizeof(float)));
   hipLaunchKernelGGL(vs_gather_row_kernel, dim3(ceil_div_u32(vs->dim, 256)), dim3(256), 0, st,
-                     vs->tiles.as<float4>(), vs->KB, row, vs->dim, vs->qraw.as<float>());
+                     vs->tiles.p, vs->KB, row, vs->dim, vs->qraw.as<float>(), vs->s16 ? 1u : 0u);
   MSI_HIP_TRY(hipMemcpyAsync(out_row, vs->qraw.p, vs->dim * sizeof(float), hipMemcpyDeviceToHost, st));
   MSI_HIP_TRY(hipStreamSynchronize(st));
   *out_found = 1;
@@ -1515,12 +1639,12 @@ int32_t msi_vs_debug_fast_scores(msi_vs *vs, const float *queries, uint32_t n_qu
   MSI_HIP_TRY(hipMemcpyAsync(vs->qraw.p, queries, (size_t)n_queries * vs->dim * sizeof(float), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
                      vs->qraw.as<float>(), n_queries, vs->dim, vs->KB, vs->qfrag.as<float4>(),
-                     vs->qfrag_bf.as<bf16x8>(), vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth);
+                     vs->qfrag_bf.as<bf16x8>(), vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth, vs->s16 ? 1u : 0u);
   ScanArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.tiles = vs->tiles.as<float4>();
   sa.inv_norm = vs->inv_norm.as<float>();
-  sa.qfrag = vs->bf3 ? vs->qfrag_bf.as<float4>() : vs->qfrag.as<float4>();
+  sa.qfrag = (vs->bf3 || vs->s16) ? vs->qfrag_bf.as<float4>() : vs->qfrag.as<float4>();
   sa.theta = s.theta_inf;
   sa.degth = s.degth;
   sa.n_items_ptr = s.n_tiles;
@@ -1542,8 +1666,7 @@ int32_t msi_vs_debug_fast_scores(msi_vs *vs, const float *queries, uint32_t n_qu
                                  vs->n_rows * sizeof(float), hipMemcpyDeviceToHost, st));
   MSI_HIP_TRY(hipStreamSynchronize(st));
   if (out_eps)
-    *out_eps = vs->bf3 ? (6.0f * (float)vs->dpad + 64.0f) * 5.9604645e-8f + 3.0f * 3.8146973e-6f
-                       : (2.0f * (float)vs->dpad + 32.0f) * 5.9604645e-8f;
+    *out_eps = scan_eps(vs);
   return MSI_OK;
 }
 

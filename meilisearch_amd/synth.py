@@ -78,3 +78,11 @@ def make_embeddings(n, d, seed=1234):
     """C2/C4: rows ~ N(0,1)^d, not normalised (numpy, host)."""
     rng = np.random.default_rng(seed)
     return rng.standard_normal((n, d), dtype=np.float32)
+
+
+def round_to_bf16(x):
+    """f32 array -> f32 array holding the nearest-even bf16 values (what a
+    storage="bf16" store keeps; v_cvt_pk_bf16_f32 semantics for finite inputs)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    bias = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + bias) & np.uint32(0xFFFF0000)).view(np.float32)

@@ -30,11 +30,12 @@ def dense_filter(docids, nbits=None):
 class GpuStore:
     """One vector store resident in HBM (msi_vs)."""
 
-    def __init__(self, ctx, dim):
+    def __init__(self, ctx, dim, storage="f32"):
         self.ctx = ctx
         self.dim = int(dim)
+        self.storage = storage
         self._h = C.c_void_p()
-        check(lib().msi_vs_create(ctx.handle, self.dim, C.byref(self._h)))
+        check(lib().msi_vs_create_typed(ctx.handle, self.dim, {"f32": 0, "bf16": 1}[storage], C.byref(self._h)))
 
     def upload(self, docids, rows):
         docids = np.ascontiguousarray(docids, dtype=np.uint32)
@@ -45,6 +46,8 @@ class GpuStore:
     def upload_device(self, docids_t, rows_t):
         """docids_t: cuda int32/uint32-compatible tensor, rows_t: cuda f32 [n, dim]."""
         assert rows_t.is_cuda and rows_t.is_contiguous() and docids_t.is_cuda
+        import torch
+        torch.cuda.current_stream(rows_t.device).synchronize()   # libmsi works on its own stream
         n = rows_t.shape[0]
         check(lib().msi_vs_upload_device(self._h, C.c_void_p(docids_t.data_ptr()),
                                          C.c_void_p(rows_t.data_ptr()), n))

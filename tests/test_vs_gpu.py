@@ -175,6 +175,28 @@ def test_fast_scan_error_is_inside_the_proof_bound(ctx, dim, scale):
     assert err <= 0.25 * eps, ("the bound should be comfortable", err, eps)
 
 
+@pytest.mark.parametrize("n,dim,k", [(37, 5, 10), (3000, 96, 20), (70000, 300, 20), (40000, 1024, 50)])
+def test_bf16_store_vs_oracle_on_rounded_rows(ctx, oracle, n, dim, k):
+    # BASELINE.json config 5 stores bf16: parity is against the f32 oracle on the ROUNDED rows
+    rows = synth.make_embeddings(n, dim, seed=n + dim + 1)
+    rb = synth.round_to_bf16(rows)
+    ids = np.arange(n, dtype=np.uint32) * 2
+    qs = synth.make_embeddings(19, dim, seed=n + 2)
+    st = ma.GpuStore(ctx, dim, storage="bf16")
+    st.upload(ids, rows)                       # rounded on the device at upload
+    assert (st.get_vector(int(ids[n // 2])) == rb[n // 2]).all()
+    check_against_oracle(oracle, st, rb, ids, qs, k)
+    allowed = ids[np.random.default_rng(3).random(n) < 0.2]
+    fb, nb = ma.dense_filter(allowed, nbits=int(ids.max()) + 1)
+    check_against_oracle(oracle, st, rb, ids, qs[:5], k, fb, nb)
+    # the proof bound holds for the bf16 path as well
+    fast, eps = st.debug_fast_scores(qs[:4])
+    r64, q64 = rb.astype(np.float64), qs[:4].astype(np.float64)
+    ref = (q64 @ r64.T) / (np.linalg.norm(q64, axis=1)[:, None] * np.maximum(np.linalg.norm(r64, axis=1), 1e-300)[None, :])
+    got = fast.astype(np.float64) / np.linalg.norm(q64, axis=1)[:, None]
+    assert np.abs(got - ref).max() <= 0.25 * eps
+
+
 def test_microbatcher_fuses_concurrent_callers(ctx, oracle):
     # 40 threads, one query each (the shape of milli's spawn_blocking searches): every caller
     # must get exactly its own answer, and the sweeps must be shared

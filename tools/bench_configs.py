@@ -48,7 +48,7 @@ def run_c2(args):
     gen.manual_seed(1234)
     rows = torch.empty((n, d), dtype=torch.float32, device=dev).normal_(generator=gen)
     ids = torch.arange(n, dtype=torch.int32, device=dev)
-    store = ma.GpuStore(ctx, d)
+    store = ma.GpuStore(ctx, d, storage=args.storage)
     store.upload_device(ids, rows)
     del rows
     gq = torch.Generator(device=dev)
@@ -73,7 +73,7 @@ def run_c2(args):
         ln, lms = store.scan_time()
         scan_ms = lms / max(1, ln)
         print(json.dumps({
-            "config": "C2", "rows": n, "dim": d, "k": k, "batch": B,
+            "config": "C2", "storage": args.storage, "rows": n, "dim": d, "k": k, "batch": B,
             "ms_per_batch": round(ms, 4), "p50_ms": round(p50, 4), "qps": round(B / ms * 1e3, 1),
             "sweeps_per_batch": (B + store.max_batch - 1) // store.max_batch, "scan_kernel_ms": round(scan_ms, 4),
             "scan_GBps": round(bytes_per_sweep / (scan_ms * 1e-3) / 1e9, 1),
@@ -144,6 +144,56 @@ def run_c3(args):
         print(json.dumps(out), flush=True)
 
 
+def run_filtered(args):
+    """Filtered vector search (the C5 shape on one GPU's shard, f32): random candidate
+    bitsets of 10 % / 1 % / 0.1 % of the documents, resident in HBM (msi_bits slot), 48
+    queries per sweep; only tiles that hold an allowed row are streamed."""
+    import torch
+    import meilisearch_amd as ma
+    dev = torch.device("cuda", 0)
+    ctx = ma.Context(0)
+    n, d, k = args.rows, args.dim, args.k
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    rows = torch.empty((n, d), dtype=torch.float32, device=dev).normal_(generator=gen)
+    ids = torch.arange(n, dtype=torch.int32, device=dev)
+    store = ma.GpuStore(ctx, d)
+    store.upload_device(ids, rows)
+    del rows
+    B = store.max_batch
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(5678)
+    q = torch.empty((B, d), dtype=torch.float32, device=dev).normal_(generator=gq)
+    out_ids = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    out_dist = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    out_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    inexact = torch.zeros(B, dtype=torch.int32, device=dev)
+    pool = ma.BitsPool(ctx, n, 1)
+    rng = np.random.default_rng(31)
+    bytes_per_sweep = ((n + 15) // 16) * store.stats()["bytes_per_tile"]
+    for sel in (1.0, 0.1, 0.01, 0.001):
+        words = (n + 63) // 64
+        bits = rng.random(words * 64) < sel
+        pool.set_from_words(0, np.packbits(bits, bitorder="little").view(np.uint64))
+        fptr = pool.device_ptr(0)
+
+        def step():
+            store.search_device(q, k, out_ids, out_dist, out_cnt, inexact, filter_ptr=fptr, filter_nbits=n)
+
+        ms, p50 = timed(step, ctx.synchronize, args.reps)
+        ctx.set_profiling(True)
+        store.scan_time()
+        step()
+        ctx.synchronize()
+        ln, lms = store.scan_time()
+        ctx.set_profiling(False)
+        print(json.dumps({"config": "filtered", "rows": n, "dim": d, "k": k, "batch": B, "selectivity": sel,
+                          "ms_per_batch": round(ms, 4), "qps": round(B / ms * 1e3, 1),
+                          "full_sweep_kernel_ms": round(lms / max(1, ln), 4),
+                          "store_GB": round(bytes_per_sweep / 1e9, 2),
+                          "min_results": int(out_cnt.min().item()), "inexact": int(inexact.sum().item())}), flush=True)
+
+
 def run_rank(args):
     """Words -> Typo bucket sort over dense docid sets (S3): n_terms query terms with
     random zero/one/two-typo posting sets over `rows` documents, top-`k`."""
@@ -180,8 +230,9 @@ def run_rank(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c2", "c3", "rank"])
+    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered"])
     ap.add_argument("--terms", type=int, default=3)
+    ap.add_argument("--storage", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=20)
@@ -193,7 +244,7 @@ def main():
     args = ap.parse_args()
     if args.batches is None:
         args.batches = [1, 16, 48, 240] if args.config != "c3" else [1, 64, 1024, 8192]
-    {"c2": run_c2, "c3": run_c3, "rank": run_rank}[args.config](args)
+    {"c2": run_c2, "c3": run_c3, "rank": run_rank, "filtered": run_filtered}[args.config](args)
 
 
 if __name__ == "__main__":
