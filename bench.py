@@ -122,9 +122,10 @@ def main():
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
-    gather_buf = None
+    gather_buf = gather_ids = None
     if world > 1:
         gather_buf = torch.zeros((world, Q, k), dtype=torch.float32, device=dev)
+        gather_ids = torch.zeros((world, Q, k), dtype=torch.int32, device=dev)
 
     def step():
         store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
@@ -137,7 +138,10 @@ def main():
             res += (one_c.cpu(), two_c.cpu(), one_t.cpu(), two_t.cpu())
         if world > 1:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(gather_buf, out_dist)  # per-rank top-k over xGMI (RCCL)
+            # the one exchange step: per-rank top-k lists (Q*k*8 bytes) over xGMI (RCCL)
+            dist.all_gather_into_tensor(gather_buf, out_dist)
+            dist.all_gather_into_tensor(gather_ids, out_ids)
+            torch.cuda.current_stream().synchronize()
         return res
 
     for _ in range(args.warmup):
