@@ -222,3 +222,36 @@ def test_errors(ctx):
         R.bucket_sort_words_typo(pool, [(2, None, None, 0)] * 11, 0, 1)
     with pytest.raises(ma.MsiError):
         R.bucket_sort_words_typo(pool, [(9, None, None, 0)], 0, 1)
+
+
+def test_hybrid_search_end_to_end(ctx, oracle):
+    """Search::execute_hybrid (search/hybrid.rs:264-366) on a toy index, every stage on the
+    product path: keyword = device dictionary -> device bucket sort -> Rank::global_score;
+    semantic = device k-NN -> msi_vector_sort; then msi_hybrid_merge.  Checked against the
+    same pipeline built from the CPU oracle + the literal Python restatements."""
+    from test_hybrid_cpu import py_merge
+    h = Harness(ctx, TYPO_RS_DOCS)
+    rng = np.random.default_rng(7)
+    dim = 16
+    ids = np.array(sorted(TYPO_RS_DOCS), dtype=np.uint32)
+    emb = rng.standard_normal((ids.size, dim)).astype(np.float32)
+    store = ma.GpuStore(ctx, dim)
+    store.upload(ids, emb)
+    qv = rng.standard_normal(dim).astype(np.float32)
+    limit = 8
+    # keyword leg (criteria [Words, Typo], strategy Last)
+    kw = h.search("the quick brown fox", limit=limit)
+    kw_hits = [(d, [ma.scoring.rank_global_score([(w, 4), (mt + 1 - t, mt + 1)])]) for d, w, t, mt in kw]
+    # semantic leg
+    d, s, c = store.search(qv[None, :], limit)
+    vd, vs = ma.scoring.vector_sort(d[0, :c[0]], s[0, :c[0]], 0, limit)
+    e_ids, e_dist = oracle.vs_topk(emb, ids, qv, limit)
+    assert vd.tolist() == e_ids.tolist()
+    assert vs.tolist() == [float(np.float32(1.0) - x) for x in e_dist]
+    v_hits = [(int(a), [float(b)]) for a, b in zip(vd, vs)]
+    for ratio in (0.0, 0.2, 0.5, 0.8, 1.0):
+        got = ma.scoring.hybrid_merge(v_hits, kw_hits, ratio, 0, limit)
+        assert got == py_merge(v_hits, kw_hits, ratio, 0, limit), ratio
+        assert len(got[0]) == limit and len({x for x, _ in got[0]}) == limit
+    assert ma.scoring.hybrid_merge(v_hits, kw_hits, 1.0, 0, limit)[1] == limit      # all semantic
+    assert [x for x, _ in ma.scoring.hybrid_merge(v_hits, kw_hits, 0.0, 0, 4)[0]] == [k_[0] for k_ in kw[:4]]
