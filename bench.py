@@ -43,6 +43,10 @@ def parse_args():
     ap.add_argument("--dict-words", type=int, default=2_000_000)
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
                     help="row storage in HBM (f32 = the reference's; bf16 = BASELINE.json config 5's build-side choice)")
+    ap.add_argument("--shard", choices=["queries", "rows"], default="queries",
+                    help="queries: replicas, each rank answers its own batch (weak scaling, the default); "
+                         "rows: every rank holds rows/world of the store and scans it for the SAME batch, "
+                         "all-gather of per-shard top-k + device merge (strong scaling)")
     ap.add_argument("--no-typo", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
@@ -72,6 +76,12 @@ def main():
 
     ctx = ma.Context(local_rank)
     n, d, k, Q = args.rows, args.dim, args.k, args.queries
+    n_total = n
+    row_sharded = args.shard == "rows" and world > 1
+    if row_sharded:
+        from meilisearch_amd.distributed import row_range
+        r0, r1 = row_range(n_total, rank, world)
+        n = r1 - r0          # this rank's shard; docids stay global
 
     # ---- vector store: rows ~ N(0,1)^d, seed 1234, generated in HBM -----------
     t_setup = time.time()
@@ -83,6 +93,9 @@ def main():
         r1 = min(n, r0 + chunk)
         rows_t[r0:r1].normal_(generator=gen)
     ids_t = torch.arange(n, dtype=torch.int32, device=dev)
+    if row_sharded:
+        ids_t += r0
+        gen.manual_seed(1234 + rank)   # distinct rows per shard
     torch.cuda.synchronize()
     store = ma.GpuStore(ctx, d, storage=args.storage)
     store.upload_device(ids_t, rows_t)
@@ -92,9 +105,9 @@ def main():
     del rows_t
     torch.cuda.empty_cache()
 
-    # query vectors (seed 5678 + rank), resident on the device
+    # query vectors (seed 5678 + rank; the same batch on every rank when rows are sharded)
     gq = torch.Generator(device=dev)
-    gq.manual_seed(5678 + rank)
+    gq.manual_seed(5678 + (0 if row_sharded else rank))
     q_t = torch.empty((Q, d), dtype=torch.float32, device=dev).normal_(generator=gq)
     out_ids = torch.zeros((Q, k), dtype=torch.int32, device=dev)
     out_dist = torch.zeros((Q, k), dtype=torch.float32, device=dev)
@@ -126,12 +139,31 @@ def main():
     if world > 1:
         gather_buf = torch.zeros((world, Q, k), dtype=torch.float32, device=dev)
         gather_ids = torch.zeros((world, Q, k), dtype=torch.int32, device=dev)
+        gather_cnt = torch.zeros((world, Q), dtype=torch.int32, device=dev)
+        m_ids = torch.zeros((Q, k), dtype=torch.int32, device=dev)
+        m_dist = torch.zeros((Q, k), dtype=torch.float32, device=dev)
+        m_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
 
     def step():
         store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
         if gdict is not None:
             gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
         ctx.synchronize()
+        if row_sharded:
+            import torch.distributed as dist
+            from meilisearch_amd.distributed import merge_topk_device
+            # the one exchange step: per-shard top-k (Q*k*8 B per rank) over xGMI, then the
+            # k-way merge kernel; every rank ends up with the global top-k
+            dist.all_gather_into_tensor(gather_buf, out_dist)
+            dist.all_gather_into_tensor(gather_ids, out_ids)
+            dist.all_gather_into_tensor(gather_cnt, out_cnt)
+            torch.cuda.current_stream().synchronize()
+            merge_topk_device(ctx, gather_ids, gather_buf, gather_cnt, m_ids, m_dist, m_cnt)
+            ctx.synchronize()
+            res = (m_ids.cpu(), m_dist.cpu(), m_cnt.cpu())
+            if gdict is not None:
+                res += (one_c.cpu(), two_c.cpu(), one_t.cpu(), two_t.cpu())
+            return res
         # results to the host (what the Rust caller receives)
         res = (out_ids.cpu(), out_dist.cpu(), out_cnt.cpu())
         if gdict is not None:
@@ -180,7 +212,7 @@ def main():
 
     if rank != 0:
         return
-    total_queries = Q * world * args.steps
+    total_queries = Q * (1 if row_sharded else world) * args.steps
     qps = total_queries / elapsed
     algo_bytes = ((n + 15) // 16) * stats["bytes_per_tile"]  # one sweep of the tiled store
     scan_avg_ms = scan_ms / max(1, scan_n)
@@ -208,7 +240,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "p50_latency_ms": round(statistics.median(lat), 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if row_sharded else "weak",
         "vs_baseline": None,
         "dtype": "f32" if args.storage == "f32" else "bf16 rows, f32 arithmetic",
         "data": "synthetic (rows N(0,1) seed 1234; dictionary seed 99; query words seed 7; BASELINE.md C4/C3)",
@@ -220,7 +252,9 @@ def main():
             "queries_per_hbm_sweep": store.max_batch,
             "scan_math": os.environ.get("MSI_VS_SCAN_MATH", "bf16x3") + " candidate scan (f32 rows in HBM, f32 accumulate)"
                          " + exact f32 reference rescoring of K' candidates with an exactness proof",
-            "sharding": "queries sharded, index replicated per GPU, all_gather of per-rank top-k (RCCL)",
+            "sharding": ("rows sharded (%d per GPU of %d), same query batch on every GPU, all_gather of per-shard "
+                         "top-k (RCCL) + device k-way merge" % (n, n_total)) if row_sharded else
+                        "queries sharded, index replicated per GPU, all_gather of per-rank top-k (RCCL)",
             "step_includes": ["vs_scan + select + reference rescoring", "dict_match + cap logic", "D2H of results"],
             "step_excludes": ["ranking-rule bucket sort", "hybrid merge"],
             "inexact_queries_last_step": n_inexact,

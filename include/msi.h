@@ -162,6 +162,15 @@ uint32_t msi_merge_topk(const uint32_t *docids, const float *dist,
                         uint32_t list_stride, uint32_t k_out,
                         uint32_t *out_docids, float *out_dist);
 
+/* The same merge on the device for a row-sharded search: after the all-gather (RCCL
+ * over xGMI) every rank holds d_docids/d_dist [n_lists][n_queries][k] and d_counts
+ * [n_lists][n_queries]; one workgroup per query writes the k best by (distance, docid).
+ * n_lists*k <= 2048.  Enqueued on msi_ctx_stream(), not synchronised. */
+int32_t msi_merge_topk_device(msi_ctx *ctx, const uint32_t *d_docids, const float *d_dist,
+                              const uint32_t *d_counts, uint32_t n_lists, uint32_t n_queries,
+                              uint32_t k, uint32_t *d_out_docids, float *d_out_dist,
+                              uint32_t *d_out_counts);
+
 /* Introspection for benchmarks/tests. */
 typedef struct msi_vs_stats {
   uint64_t scan_launches;      /* vs_scan kernel launches so far (sample + full sweeps) */

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "msi_vs_microbatch_stats": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_U64)]),
     "msi_vs_search_device": (_I32, [_VP, _VP, _U32, _U32, _VP, _U64, _VP, _VP, _VP, _VP]),
     "msi_merge_topk": (_U32, [_VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP]),
+    "msi_merge_topk_device": (_I32, [_VP, _VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP]),
     "msi_vs_get_stats": (_I32, [_VP, C.POINTER(VsStats)]),
     "msi_vs_debug_fast_scores": (_I32, [_VP, _VP, _U32, _VP, C.POINTER(_F32)]),
     "msi_vs_scan_time": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_F64)]),

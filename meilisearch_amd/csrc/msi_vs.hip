@@ -890,6 +890,43 @@ __global__ void vs_gather_row_kernel(const void *__restrict__ tiles, uint32_t KB
   out[k] = s16 ? tile_elem<true>(tiles, KB, row, k) : tile_elem<false>(tiles, KB, row, k);
 }
 
+// k-way merge of per-shard result lists on the device (row-sharded search: after the
+// all-gather every rank holds [n_lists][n_queries][k] (distance, docid) lists).  One
+// workgroup per query sorts the n_lists*k keys (ord(distance) << 32 | docid) in LDS and
+// writes the k best — the concatenate + sort tail of store.rs:1059,1090.
+__global__ __launch_bounds__(SEL_THREADS) void vs_merge_lists_kernel(
+    const uint32_t *__restrict__ docids, const float *__restrict__ dist, const uint32_t *__restrict__ counts,
+    uint32_t n_lists, uint32_t n_queries, uint32_t k, uint32_t *__restrict__ out_docids,
+    float *__restrict__ out_dist, uint32_t *__restrict__ out_counts) {
+  __shared__ u64 sbuf[SEL_SORTCAP];
+  const uint32_t j = blockIdx.x;
+  const uint32_t total = n_lists * k;
+  const uint32_t n = next_pow2(total < 2 ? 2 : total);
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    u64 key = ~0ull;
+    if (i < total) {
+      const uint32_t l = i / k, r = i % k;
+      const uint32_t c = min(counts[(size_t)l * n_queries + j], k);
+      if (r < c) {
+        const size_t at = ((size_t)l * n_queries + j) * k + r;
+        key = ((u64)f32_to_ord(dist[at]) << 32) | docids[at];
+      }
+    }
+    sbuf[i] = key;
+  }
+  __syncthreads();
+  block_bitonic_sort(sbuf, n);
+  uint32_t valid = 0;
+  for (uint32_t l = 0; l < n_lists; ++l) valid += min(counts[(size_t)l * n_queries + j], k);
+  const uint32_t out_n = valid < k ? valid : k;
+  for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+    const bool ok = i < out_n;
+    out_docids[(size_t)j * k + i] = ok ? (uint32_t)sbuf[i] : 0xFFFFFFFFu;
+    out_dist[(size_t)j * k + i] = ok ? ord_to_f32((uint32_t)(sbuf[i] >> 32)) : INFINITY;
+  }
+  if (threadIdx.x == 0) out_counts[j] = out_n;
+}
+
 }  // namespace
 
 // ============================================================== host-side object
@@ -1519,6 +1556,28 @@ static int32_t vs_search_fused(msi_vs *vs, const float *queries, uint32_t n_quer
 }
 
 extern "C" {
+
+int32_t msi_merge_topk_device(msi_ctx *ctx, const uint32_t *d_docids, const float *d_dist,
+                              const uint32_t *d_counts, uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                              uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_counts) {
+  if (!ctx || !d_docids || !d_dist || !d_counts || !d_out_docids || !d_out_dist || !d_out_counts || k == 0 ||
+      n_lists == 0) {
+    msi_set_error("msi_merge_topk_device: invalid argument");
+    return MSI_E_INVALID;
+  }
+  if ((uint64_t)n_lists * k > SEL_SORTCAP) {
+    msi_set_error("msi_merge_topk_device: n_lists*k = %llu above %d (merge on the host: msi_merge_topk)",
+                  (unsigned long long)n_lists * k, SEL_SORTCAP);
+    return MSI_E_UNSUPPORTED;
+  }
+  if (n_queries == 0) return MSI_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  DeviceGuard g(ctx->device);
+  hipLaunchKernelGGL(vs_merge_lists_kernel, dim3(n_queries), dim3(SEL_THREADS), 0, ctx->stream, d_docids, d_dist,
+                     d_counts, n_lists, n_queries, k, d_out_docids, d_out_dist, d_out_counts);
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
 
 int32_t msi_vs_set_microbatch(msi_vs *vs, uint32_t max_wait_us) {
   if (!vs) return MSI_E_INVALID;

@@ -113,3 +113,14 @@ def shard_queries(local_search, queries, k, device=None):
     out_s = np.concatenate([gs[r, :query_range(b, r, world)[1] - query_range(b, r, world)[0]] for r in range(world)])
     out_c = np.concatenate([gc[r, :query_range(b, r, world)[1] - query_range(b, r, world)[0]] for r in range(world)])
     return out_d, out_s, out_c
+
+
+def merge_topk_device(ctx, docids_t, dist_t, counts_t, out_docids_t, out_dist_t, out_counts_t):
+    """Device k-way merge (msi_merge_topk_device): docids_t/dist_t [L, B, k], counts_t [L, B]
+    torch CUDA tensors (the all-gathered per-shard lists); outputs [B, k] / [B]."""
+    from ._lib import check
+    n_lists, b, k = docids_t.shape
+    check(lib().msi_merge_topk_device(ctx.handle, C.c_void_p(docids_t.data_ptr()), C.c_void_p(dist_t.data_ptr()),
+                                      C.c_void_p(counts_t.data_ptr()), n_lists, b, k,
+                                      C.c_void_p(out_docids_t.data_ptr()), C.c_void_p(out_dist_t.data_ptr()),
+                                      C.c_void_p(out_counts_t.data_ptr())))

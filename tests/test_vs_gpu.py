@@ -197,6 +197,41 @@ def test_bf16_store_vs_oracle_on_rounded_rows(ctx, oracle, n, dim, k):
     assert np.abs(got - ref).max() <= 0.25 * eps
 
 
+def test_row_sharded_search_with_device_merge(ctx, oracle):
+    # three row shards on one GPU stand in for three GPUs: per-shard device search, then the
+    # device k-way merge of the "all-gathered" lists must equal the unsharded oracle
+    import torch
+    from meilisearch_amd.distributed import merge_topk_device, row_range
+    n, dim, k, B, W = 9001, 40, 15, 21, 3
+    rows = synth.make_embeddings(n, dim, seed=111)
+    rows[4000:4050] = rows[100]                       # ties that straddle shards
+    ids = np.arange(n, dtype=np.uint32) * 2 + 5
+    qs = synth.make_embeddings(B, dim, seed=112)
+    dev = torch.device("cuda", ctx.device)
+    g_ids = torch.zeros((W, B, k), dtype=torch.int32, device=dev)
+    g_dist = torch.zeros((W, B, k), dtype=torch.float32, device=dev)
+    g_cnt = torch.zeros((W, B), dtype=torch.int32, device=dev)
+    q_t = torch.from_numpy(qs).to(dev)
+    stores = []
+    for r in range(W):
+        r0, r1 = row_range(n, r, W)
+        st = ma.GpuStore(ctx, dim)
+        st.upload(ids[r0:r1], rows[r0:r1])
+        st.search_device(q_t, k, g_ids[r], g_dist[r], g_cnt[r])
+        stores.append(st)
+    m_ids = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    m_dist = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    m_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    merge_topk_device(ctx, g_ids, g_dist, g_cnt, m_ids, m_dist, m_cnt)
+    ctx.synchronize()
+    got_ids = m_ids.cpu().numpy().view(np.uint32)
+    got_dist = m_dist.cpu().numpy()
+    for j in range(B):
+        e_ids, e_dist = oracle.vs_topk(rows, ids, qs[j], k)
+        assert int(m_cnt[j]) == e_ids.size and got_ids[j].tolist() == e_ids.tolist()
+        assert got_dist[j].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist()
+
+
 def test_microbatcher_fuses_concurrent_callers(ctx, oracle):
     # 40 threads, one query each (the shape of milli's spawn_blocking searches): every caller
     # must get exactly its own answer, and the sweeps must be shared
