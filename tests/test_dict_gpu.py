@@ -86,6 +86,27 @@ def test_batch_sizes_and_determinism(ctx, oracle):
         assert s1.tolist() == a[i][0].tolist() and s2.tolist() == a[i][1].tolist()
 
 
+@pytest.mark.parametrize("alphabet,seed", [("ab", 1), ("abc", 2), ("aé", 3), ("aбc日", 4)])
+def test_dense_hit_regime_tiny_alphabet(ctx, oracle, alphabet, seed):
+    # words over a 2-4 letter alphabet: thousands of words within distance 2 of any query, so
+    # the caps, the first-letter classes, the signature/shape filters and the in-order
+    # appends are all saturated (multi-byte letters take the non-ASCII tile path)
+    rng = np.random.default_rng(seed)
+    words = set()
+    while len(words) < 6000:
+        L = int(rng.integers(3, 14))
+        words.add("".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), L)))
+    words = sorted(words, key=lambda w: w.encode())
+    queries = []
+    for _ in range(120):
+        L = int(rng.integers(5, 13))
+        w = "".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), L))
+        queries.append((w, 1 if L < 9 else 2, bool(rng.random() < 0.4)))
+    queries += [(w, 2, False) for w in words[::997]] + [(w[:6], 2, True) for w in words[::1499] if len(w) >= 6]
+    for caps in [(150, 50), (7, 3), (1000, 1000)]:
+        compare(oracle, words, queries, caps=caps, ctx=ctx)
+
+
 def test_errors(ctx):
     with pytest.raises(ma.MsiError) as e:
         ma.GpuDictionary(ctx, words=["b", "a"])

@@ -67,6 +67,24 @@ def test_random_vs_oracle(ctx, oracle, n, dim, k):
     check_against_oracle(oracle, st, rows, ids, qs, k)
 
 
+def test_large_k_and_k_above_store_size(ctx, oracle):
+    rows = synth.make_embeddings(5000, 48, seed=71)
+    ids = np.arange(5000, dtype=np.uint32)
+    st = ma.GpuStore(ctx, 48)
+    st.upload(ids, rows)
+    qs = synth.make_embeddings(3, 48, seed=72)
+    check_against_oracle(oracle, st, rows, ids, qs, 1000)          # K' clamps at 1024
+    small = ma.GpuStore(ctx, 48)
+    small.upload(ids[:13], rows[:13])
+    d, s, c = small.search(qs, 50)                                  # fewer rows than k
+    assert c.tolist() == [13, 13, 13]
+    check_against_oracle(oracle, small, rows[:13], ids[:13], qs, 50)
+    big = synth.make_embeddings(90000, 48, seed=73)                 # sparse path with a large k
+    st2 = ma.GpuStore(ctx, 48)
+    st2.upload(np.arange(90000, dtype=np.uint32), big)
+    check_against_oracle(oracle, st2, big, np.arange(90000, dtype=np.uint32), qs[:2], 700)
+
+
 def test_more_than_one_query_tile(ctx, oracle):
     rows = synth.make_embeddings(6000, 128, seed=21)
     ids = np.arange(6000, dtype=np.uint32)
