@@ -328,6 +328,55 @@ int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms,
                             uint32_t *out_typo_count, uint32_t *out_max_typo_count,
                             uint32_t *out_n, uint64_t *out_candidates);
 
+/* ------------------------------------------ keyword leg of Search::execute (host) */
+/*
+ * The keyword search for the ranking rules [Words, Typo] end to end, on top of an index
+ * the caller owns: tokens (already normalised single words, <= 10; words_limit) ->
+ * query graph with 2-/3-gram nodes (parse_query.rs:28-300, query_graph.rs:96-180) ->
+ * typo budgets (parse_query.rs:204-225) -> derivations: ONE batched msi_dict lookup,
+ * zero-typo prefix derivations from the dictionary (compute_derivations.rs:40-73),
+ * split words (:363-383) -> posting sets per node and typo level
+ * (resolve_query_graph.rs:33-59; postings arrive as the CboRoaringBitmap bytes they
+ * are stored as and are decoded on the device) -> msi_rank_query_graph.
+ * Phrases, synonyms, the word-prefix databases and the other ranking rules stay on
+ * the reference path.  The pool needs 2 + 3·(number of graph nodes) <= 83 slots; slots
+ * 0 and 1 are the universe and scratch.
+ */
+typedef struct msi_index_vtable {
+  void *user;
+  /* Posting list of `word` as CboRoaringBitmap bytes (valid until the next callback):
+   * original != 0: word_docids ∪ exact_word_docids (Word::Original, db_cache.rs), else
+   * word_docids only (Word::Derived).  *n = 0 when absent.  Negative return = error. */
+  int32_t (*word_docids)(void *user, const uint8_t *word, uint32_t len, int32_t original,
+                         const uint8_t **bytes, size_t *n);
+  /* word_pair_proximity_docids(proximity, left, right); nullable = no split words. */
+  int32_t (*word_pair_proximity_docids)(void *user, uint32_t proximity, const uint8_t *left,
+                                        uint32_t left_len, const uint8_t *right,
+                                        uint32_t right_len, const uint8_t **bytes, size_t *n);
+  /* exact_words FST membership; nullable. */
+  int32_t (*is_exact_word)(void *user, const uint8_t *word, uint32_t len);
+} msi_index_vtable;
+typedef struct msi_query_token {
+  const uint8_t *word;
+  uint32_t len;
+  uint32_t is_prefix; /* the last token of a query that does not end with a separator */
+} msi_query_token;
+typedef struct msi_keyword_params {
+  uint32_t authorize_typos;         /* index.authorize_typos */
+  uint32_t min_word_len_one_typo;   /* 5 */
+  uint32_t min_word_len_two_typos;  /* 9 */
+  int32_t strategy;                 /* MSI_TERMS_LAST | MSI_TERMS_ALL */
+  int32_t use_typo;                 /* Typo rule present after Words */
+  uint32_t from, length;
+} msi_keyword_params;
+int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtable *index,
+                           const msi_query_token *tokens, uint32_t n_tokens,
+                           const msi_keyword_params *params, const uint8_t *universe_cbo,
+                           size_t universe_len, uint32_t *out_docids,
+                           uint32_t *out_matching_words, uint32_t *out_typo_count,
+                           uint32_t *out_max_typo_count, uint32_t *out_n,
+                           uint64_t *out_candidates);
+
 /* ---------------------------------------------------- scoring arithmetic (host) */
 /* DistributionShift::shift (crates/milli/src/vector/distribution.rs:103-130). */
 float msi_distribution_shift(float mean, float sigma, float score);

@@ -32,6 +32,28 @@ class RankNode(C.Structure):
                 ("max_typo_cost", C.c_uint32)]
 
 
+WORD_DOCIDS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_int32,
+                            C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t))
+PAIR_DOCIDS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32,
+                            C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t))
+EXACT_WORD_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32)
+
+
+class IndexVtable(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("word_docids", WORD_DOCIDS_FN),
+                ("word_pair_proximity_docids", PAIR_DOCIDS_FN), ("is_exact_word", EXACT_WORD_FN)]
+
+
+class QueryToken(C.Structure):
+    _fields_ = [("word", C.c_void_p), ("len", C.c_uint32), ("is_prefix", C.c_uint32)]
+
+
+class KeywordParams(C.Structure):
+    _fields_ = [("authorize_typos", C.c_uint32), ("min_word_len_one_typo", C.c_uint32),
+                ("min_word_len_two_typos", C.c_uint32), ("strategy", C.c_int32), ("use_typo", C.c_int32),
+                ("from_", C.c_uint32), ("length", C.c_uint32)]
+
+
 class VsStats(C.Structure):
     _fields_ = [("scan_launches", C.c_uint64), ("scan_tiles", C.c_uint64),
                 ("exhaustive_reruns", C.c_uint64), ("bytes_per_tile", C.c_uint64)]
@@ -103,6 +125,9 @@ PROTOTYPES = {
     "msi_hybrid_merge": (_U32, [_VP, _VP, _VP, _U32, _F32, _VP, _VP, _VP, _U32, _F32, _U32, _U32, _VP, _VP,
                                 C.POINTER(_U32)]),
     "msi_results_good_enough": (_I32, [_VP, _U32, _U32, _F32]),
+    "msi_keyword_search": (_I32, [_VP, _VP, C.POINTER(IndexVtable), C.POINTER(QueryToken), _U32,
+                                  C.POINTER(KeywordParams), _VP, C.c_size_t, _VP, _VP, _VP, _VP,
+                                  C.POINTER(_U32), C.POINTER(_U64)]),
     "msi_distribution_shift": (_F32, [_F32, _F32, _F32]),
     "msi_rank_global_score": (_F64, [_VP, _VP, _U32]),
     "msi_compare_scores": (_I32, [_VP, _U32, _F32, _VP, _U32, _F32]),

@@ -40,12 +40,7 @@ namespace {
 
 constexpr int BT = 256;
 
-struct Container {
-  uint32_t key;     // high 16 bits of the docids
-  uint32_t type;    // 0 array, 1 bitmap, 2 run
-  uint32_t card;    // array: #values, run: #runs
-  uint32_t offset;  // byte offset of the body inside the staged buffer
-};
+typedef MsiContainer Container;
 
 __global__ void bits_fill_kernel(u64 *__restrict__ dst, uint64_t n_words, uint64_t n_docs, int ones) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,83 +322,147 @@ int32_t msi_bits_set_from_words(msi_bits *p, uint32_t slot, const uint64_t *word
   return MSI_OK;
 }
 
+}  // extern "C"
+
+// ---- batched posting-list decode (shared with msi_keyword.hip) ----------------------
+
+// Host-side parse of one CboRoaringBitmapCodec value
+// (cbo_roaring_bitmap_codec.rs:53-69): <= 7 integers are raw native-endian u32s,
+// otherwise the portable Roaring serialisation (cookies 12346 / 12347), whose
+// containers are appended to the batch with offsets into the batch buffer.
+// Returns false on a malformed value.
+bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len) {
+  const size_t THRESHOLD = 7;  // cbo_roaring_bitmap_codec.rs:15
+  if (len <= THRESHOLD * sizeof(uint32_t)) {
+    // a trailing partial integer is ignored (read_u32 fails)
+    for (size_t i = 0; i + 4 <= len; i += 4) {
+      uint32_t v;
+      memcpy(&v, bytes + i, 4);
+      batch.small_ids.push_back(v);
+    }
+    return true;
+  }
+  auto rd16 = [&](size_t o) -> uint32_t { return (uint32_t)bytes[o] | ((uint32_t)bytes[o + 1] << 8); };
+  auto rd32 = [&](size_t o) -> uint32_t { return rd16(o) | (rd16(o + 2) << 16); };
+  size_t pos = 0;
+  if (len < 8) return false;
+  const uint32_t cookie = rd32(0);
+  uint32_t n_cont = 0;
+  bool has_runs = false;
+  const uint8_t *run_flags = nullptr;
+  if ((cookie & 0xFFFF) == 12347) {
+    has_runs = true;
+    n_cont = (cookie >> 16) + 1;
+    pos = 4;
+    run_flags = bytes + pos;
+    pos += (n_cont + 7) / 8;
+  } else if (cookie == 12346) {
+    n_cont = rd32(4);
+    pos = 8;
+  } else {
+    return false;
+  }
+  if (n_cont > 65536 || pos + (size_t)n_cont * 4 > len) return false;
+  const size_t base = batch.bytes.size();
+  const size_t first = batch.containers.size();
+  batch.containers.resize(first + n_cont);
+  MsiContainer *cs = batch.containers.data() + first;
+  for (uint32_t i = 0; i < n_cont; ++i) {
+    cs[i].key = rd16(pos + 4 * i);
+    cs[i].card = rd16(pos + 4 * i + 2) + 1;
+    const bool is_run = has_runs && ((run_flags[i / 8] >> (i % 8)) & 1);
+    cs[i].type = is_run ? 2 : (cs[i].card > 4096 ? 1 : 0);
+  }
+  pos += (size_t)n_cont * 4;
+  if (!has_runs || n_cont >= 4) pos += (size_t)n_cont * 4;  // offset header (recomputed below)
+  bool ok = true;
+  for (uint32_t i = 0; i < n_cont && ok; ++i) {
+    if (pos > len) { ok = false; break; }
+    cs[i].offset = (uint32_t)(base + pos);
+    if (cs[i].type == 0) pos += (size_t)cs[i].card * 2;
+    else if (cs[i].type == 1) pos += 8192;
+    else {
+      if (pos + 2 > len) { ok = false; break; }
+      const uint32_t n_runs = rd16(pos);
+      cs[i].offset = (uint32_t)(base + pos + 2);
+      cs[i].card = n_runs;
+      pos += 2 + (size_t)n_runs * 4;
+    }
+  }
+  if (!ok || pos > len || base + len > 0xFFFFFFFFull) {
+    batch.containers.resize(first);
+    return false;
+  }
+  batch.bytes.insert(batch.bytes.end(), bytes, bytes + len);
+  return true;
+}
+
+// Number of documents of a CboRoaringBitmap value without decoding the bodies
+// (the descriptive header stores cardinality - 1 per container).
+uint64_t msi_cbo_cardinality(const uint8_t *bytes, size_t len) {
+  if (len <= 7 * sizeof(uint32_t)) return len / 4;
+  auto rd16 = [&](size_t o) -> uint32_t { return (uint32_t)bytes[o] | ((uint32_t)bytes[o + 1] << 8); };
+  auto rd32 = [&](size_t o) -> uint32_t { return rd16(o) | (rd16(o + 2) << 16); };
+  if (len < 8) return 0;
+  const uint32_t cookie = rd32(0);
+  uint32_t n_cont = 0;
+  size_t pos = 0;
+  if ((cookie & 0xFFFF) == 12347) {
+    n_cont = (cookie >> 16) + 1;
+    pos = 4 + (n_cont + 7) / 8;
+  } else if (cookie == 12346) {
+    n_cont = rd32(4);
+    pos = 8;
+  } else {
+    return 0;
+  }
+  if (n_cont > 65536 || pos + (size_t)n_cont * 4 > len) return 0;
+  uint64_t c = 0;
+  for (uint32_t i = 0; i < n_cont; ++i) c += rd16(pos + 4 * i + 2) + 1;
+  return c;
+}
+
+// slot := (clear ? {} : slot) ∪ every value appended to the batch.  Takes the context lock.
+int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &batch, bool clear) {
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->ctx->stream;
+  if (clear) MSI_HIP_TRY(hipMemsetAsync(p->slot(slot), 0, p->n_words * sizeof(u64), st));
+  const size_t n_cont = batch.containers.size();
+  if (n_cont) {
+    MSI_TRY(p->stage.ensure(batch.bytes.size()));
+    MSI_TRY(p->desc.ensure(n_cont * sizeof(Container)));
+    MSI_HIP_TRY(hipMemcpyAsync(p->stage.p, batch.bytes.data(), batch.bytes.size(), hipMemcpyHostToDevice, st));
+    MSI_HIP_TRY(hipMemcpyAsync(p->desc.p, batch.containers.data(), n_cont * sizeof(Container),
+                               hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bits_decode_roaring_kernel, dim3((uint32_t)n_cont), dim3(BT), 0, st, p->slot(slot),
+                       p->n_docs, p->stage.as<uint8_t>(), p->desc.as<Container>());
+    MSI_HIP_TRY(hipGetLastError());
+  }
+  if (!batch.small_ids.empty()) {
+    const size_t n = batch.small_ids.size();
+    MSI_TRY(p->tmp.ensure(n * sizeof(uint32_t)));
+    MSI_HIP_TRY(hipMemcpyAsync(p->tmp.p, batch.small_ids.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bits_set_docids_kernel, dim3((uint32_t)((n + BT - 1) / BT)), dim3(BT), 0, st, p->slot(slot),
+                       p->n_docs, p->tmp.as<uint32_t>(), n);
+    MSI_HIP_TRY(hipGetLastError());
+  }
+  MSI_HIP_TRY(hipStreamSynchronize(st));  // the batch buffers are borrowed
+  return MSI_OK;
+}
+
+extern "C" {
+
 // CboRoaringBitmapCodec::deserialize_from (cbo_roaring_bitmap_codec.rs:53-69).
 int32_t msi_bits_set_from_cbo(msi_bits *p, uint32_t slot, const uint8_t *bytes, size_t len) {
   MSI_TRY(check_slot(p, slot, "msi_bits_set_from_cbo"));
   if (len && !bytes) return MSI_E_INVALID;
-  const size_t THRESHOLD = 7;  // cbo_roaring_bitmap_codec.rs:15
-  if (len <= THRESHOLD * sizeof(uint32_t)) {
-    // native-endian u32s; a trailing partial integer is ignored (read_u32 fails)
-    uint32_t ids[THRESHOLD];
-    const size_t n = len / 4;
-    memcpy(ids, bytes, n * 4);
-    return msi_bits_set_from_docids(p, slot, ids, n);
+  MsiCboBatch batch;
+  if (!msi_cbo_batch_append(batch, bytes, len)) {
+    msi_set_error("msi_bits_set_from_cbo: malformed Roaring serialisation (%zu bytes)", len);
+    return MSI_E_INVALID;
   }
-  // Standard Roaring serialisation (portable format).
-  auto rd16 = [&](size_t o) -> uint32_t { return (uint32_t)bytes[o] | ((uint32_t)bytes[o + 1] << 8); };
-  auto rd32 = [&](size_t o) -> uint32_t { return rd16(o) | (rd16(o + 2) << 16); };
-  size_t pos = 0;
-  if (len < 8) goto corrupt;
-  {
-    const uint32_t cookie = rd32(0);
-    uint32_t n_cont = 0;
-    bool has_runs = false;
-    const uint8_t *run_flags = nullptr;
-    if ((cookie & 0xFFFF) == 12347) {
-      has_runs = true;
-      n_cont = (cookie >> 16) + 1;
-      pos = 4;
-      run_flags = bytes + pos;
-      pos += (n_cont + 7) / 8;
-    } else if (cookie == 12346) {
-      n_cont = rd32(4);
-      pos = 8;
-    } else {
-      goto corrupt;
-    }
-    if (n_cont > 65536 || pos + (size_t)n_cont * 4 > len) goto corrupt;
-    std::vector<Container> cs(n_cont);
-    for (uint32_t i = 0; i < n_cont; ++i) {
-      cs[i].key = rd16(pos + 4 * i);
-      cs[i].card = rd16(pos + 4 * i + 2) + 1;
-      const bool is_run = has_runs && ((run_flags[i / 8] >> (i % 8)) & 1);
-      cs[i].type = is_run ? 2 : (cs[i].card > 4096 ? 1 : 0);
-    }
-    pos += (size_t)n_cont * 4;
-    if (!has_runs || n_cont >= 4) pos += (size_t)n_cont * 4;  // offset header (recomputed below)
-    for (uint32_t i = 0; i < n_cont; ++i) {
-      if (pos > len) goto corrupt;
-      cs[i].offset = (uint32_t)pos;
-      if (cs[i].type == 0) pos += (size_t)cs[i].card * 2;
-      else if (cs[i].type == 1) pos += 8192;
-      else {
-        if (pos + 2 > len) goto corrupt;
-        const uint32_t n_runs = rd16(pos);
-        cs[i].offset = (uint32_t)pos + 2;
-        cs[i].card = n_runs;
-        pos += 2 + (size_t)n_runs * 4;
-      }
-    }
-    if (pos > len) goto corrupt;
-    std::lock_guard<std::mutex> lk(p->ctx->mu);
-    DeviceGuard g(p->ctx->device);
-    hipStream_t st = p->ctx->stream;
-    MSI_HIP_TRY(hipMemsetAsync(p->slot(slot), 0, p->n_words * sizeof(u64), st));
-    if (n_cont) {
-      MSI_TRY(p->stage.ensure(len));
-      MSI_TRY(p->desc.ensure(n_cont * sizeof(Container)));
-      MSI_HIP_TRY(hipMemcpyAsync(p->stage.p, bytes, len, hipMemcpyHostToDevice, st));
-      MSI_HIP_TRY(hipMemcpyAsync(p->desc.p, cs.data(), n_cont * sizeof(Container), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(bits_decode_roaring_kernel, dim3(n_cont), dim3(BT), 0, st, p->slot(slot), p->n_docs,
-                         p->stage.as<uint8_t>(), p->desc.as<Container>());
-      MSI_HIP_TRY(hipGetLastError());
-    }
-    MSI_HIP_TRY(hipStreamSynchronize(st));
-    return MSI_OK;
-  }
-corrupt:
-  msi_set_error("msi_bits_set_from_cbo: malformed Roaring serialisation (%zu bytes)", len);
-  return MSI_E_INVALID;
+  return msi_bits_decode_batch(p, slot, batch, true);
 }
 
 int32_t msi_bits_op(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int32_t op) {

@@ -136,6 +136,23 @@ struct DeviceGuard {
   }
 };
 
+// ---- batched CboRoaringBitmap decode (msi_bits.hip; used by msi_keyword.hip) ----------
+struct MsiContainer {
+  uint32_t key;     // high 16 bits of the docids
+  uint32_t type;    // 0 array, 1 bitmap, 2 run
+  uint32_t card;    // array: #values, run: #runs
+  uint32_t offset;  // byte offset of the body inside the staged buffer
+};
+struct MsiCboBatch {
+  std::vector<uint8_t> bytes;            // concatenated Roaring serialisations
+  std::vector<MsiContainer> containers;  // their containers, offsets into `bytes`
+  std::vector<uint32_t> small_ids;       // documents of the <= 7-integer raw values
+};
+struct msi_bits;
+bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len);
+uint64_t msi_cbo_cardinality(const uint8_t *bytes, size_t len);
+int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &batch, bool clear);
+
 // ---- device helpers -------------------------------------------------------
 
 // Monotone map f32 -> u32 (a < b  <=>  ord(a) < ord(b), -0 < +0, NaNs at the ends).

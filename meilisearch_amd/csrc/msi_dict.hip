@@ -694,7 +694,40 @@ struct msi_dict {
   DevBuf qbytes, qoff, qflags, qm, qchars, lists, cnts, llists, lcnts, comp, pairs, out1, out1c, out2, out2c;
   uint64_t lookup_launches = 0, dict_bytes = 0;
   KernelTimer match_timer;
+  // host copy of the sorted words (prefix ranges, idx -> word for the keyword pipeline)
+  std::vector<uint8_t> h_flat;
+  std::vector<uint32_t> h_offs;
 };
+
+// accessors for msi_keyword.hip
+bool msi_dict_word(const msi_dict *d, uint32_t idx, const uint8_t **w, uint32_t *len) {
+  if (!d || idx >= d->n_words) return false;
+  *w = d->h_flat.data() + d->h_offs[idx];
+  *len = d->h_offs[idx + 1] - d->h_offs[idx];
+  return true;
+}
+// [lo, hi) = dictionary words that start with `prefix` (byte-lexicographic order).
+void msi_dict_prefix_range(const msi_dict *d, const uint8_t *prefix, uint32_t plen, uint32_t *lo, uint32_t *hi) {
+  auto cmp = [&](uint32_t idx) {  // <0: word < prefix-range, 0: has prefix, >0: beyond
+    const uint8_t *w = d->h_flat.data() + d->h_offs[idx];
+    const uint32_t wl = d->h_offs[idx + 1] - d->h_offs[idx];
+    const int c = memcmp(w, prefix, std::min(wl, plen));
+    if (c != 0) return c;
+    return wl < plen ? -1 : 0;
+  };
+  uint32_t a = 0, b = d->n_words;
+  while (a < b) {
+    const uint32_t m = a + (b - a) / 2;
+    if (cmp(m) < 0) a = m + 1; else b = m;
+  }
+  *lo = a;
+  b = d->n_words;
+  while (a < b) {
+    const uint32_t m = a + (b - a) / 2;
+    if (cmp(m) <= 0) a = m + 1; else b = m;
+  }
+  *hi = a;
+}
 
 namespace {
 
@@ -866,6 +899,9 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
     return s;
   }
   d->dict_bytes = (uint64_t)n_words * (sizeof(uint4) + 2) + flat_bytes + ((uint64_t)n_words + 1) * 4;
+  d->h_flat.assign(words_concat, words_concat + flat_bytes);
+  d->h_offs.assign(offsets, offsets + n_words + 1);
+  if (n_words == 0) d->h_offs.assign(1, 0);
   msi_ctx_retain(ctx);
   *out = d;
   return MSI_OK;

@@ -6,7 +6,8 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import RankNode, RankTerm, check, lib
+from ._lib import (EXACT_WORD_FN, PAIR_DOCIDS_FN, WORD_DOCIDS_FN, IndexVtable, KeywordParams, QueryToken, RankNode,
+                   RankTerm, check, lib)
 from .device import np_ptr
 
 NO_SLOT = 0xFFFFFFFF
@@ -58,3 +59,75 @@ def bucket_sort_query_graph(pool, nodes, n_terms, universe_slot, scratch_slot, s
                                      np_ptr(maxt), C.byref(out_n), C.byref(cand)))
     k = out_n.value
     return [(int(ids[i]), int(words[i]), int(typos[i]), int(maxt[i])) for i in range(k)], int(cand.value)
+
+
+class IndexCallbacks:
+    """Adapter from a Python index object to msi_index_vtable.  `index` provides
+    word_docids_bytes(word: str, original: bool) -> bytes|None,
+    pair_docids_bytes(prox: int, left: str, right: str) -> bytes|None and
+    is_exact_word(word: str) -> bool — the LMDB gets of db_cache.rs on the Rust side."""
+
+    def __init__(self, index):
+        self.index = index
+        self._keep = None   # the bytes handed out stay alive until the next callback
+
+        def hand_out(data, out_bytes, out_n):
+            if not data:
+                out_n[0] = 0
+                return 0
+            self._keep = C.create_string_buffer(data, len(data))
+            out_bytes[0] = C.cast(self._keep, C.POINTER(C.c_uint8))
+            out_n[0] = len(data)
+            return 0
+
+        def word_docids(user, w, n, original, out_bytes, out_n):
+            try:
+                return hand_out(index.word_docids_bytes(bytes(w[:n]).decode("utf-8"), bool(original)), out_bytes, out_n)
+            except Exception:
+                return -1
+
+        def pair_docids(user, prox, l, ln, r, rn, out_bytes, out_n):
+            try:
+                return hand_out(index.pair_docids_bytes(prox, bytes(l[:ln]).decode("utf-8"),
+                                                        bytes(r[:rn]).decode("utf-8")), out_bytes, out_n)
+            except Exception:
+                return -1
+
+        def is_exact(user, w, n):
+            try:
+                return 1 if index.is_exact_word(bytes(w[:n]).decode("utf-8")) else 0
+            except Exception:
+                return 0
+        self._fns = (WORD_DOCIDS_FN(word_docids), PAIR_DOCIDS_FN(pair_docids), EXACT_WORD_FN(is_exact))
+        self.vtable = IndexVtable(None, *self._fns)
+
+
+def keyword_search(gdict, pool, callbacks, words, last_is_prefix=True, strategy=TERMS_LAST, use_typo=True,
+                   offset=0, limit=20, authorize_typos=True, min_one=5, min_two=9, universe_cbo=None):
+    """msi_keyword_search: the keyword leg for the rules [Words, Typo] on the product path.
+    words: normalised single-word tokens in query order."""
+    n = len(words)
+    toks = (QueryToken * max(n, 1))()
+    keep = []
+    for i, w in enumerate(words):
+        b = w.encode("utf-8")
+        buf = C.create_string_buffer(b, len(b))
+        keep.append(buf)
+        toks[i].word = C.cast(buf, C.c_void_p)
+        toks[i].len = len(b)
+        toks[i].is_prefix = 1 if (last_is_prefix and i == n - 1) else 0
+    params = KeywordParams(1 if authorize_typos else 0, min_one, min_two, strategy, 1 if use_typo else 0, offset, limit)
+    ids = np.zeros(max(limit, 1), dtype=np.uint32)
+    mw = np.zeros(max(limit, 1), dtype=np.uint32)
+    tc = np.zeros(max(limit, 1), dtype=np.uint32)
+    mt = np.zeros(max(limit, 1), dtype=np.uint32)
+    out_n = C.c_uint32(0)
+    cand = C.c_uint64(0)
+    ub = None
+    if universe_cbo is not None:
+        ub = np.frombuffer(universe_cbo, dtype=np.uint8)
+    check(lib().msi_keyword_search(gdict._h, pool._h, C.byref(callbacks.vtable), toks, n, C.byref(params),
+                                   np_ptr(ub) if ub is not None else None, 0 if ub is None else ub.size,
+                                   np_ptr(ids), np_ptr(mw), np_ptr(tc), np_ptr(mt), C.byref(out_n), C.byref(cand)))
+    k = out_n.value
+    return [(int(ids[i]), int(mw[i]), int(tc[i]), int(mt[i])) for i in range(k)], int(cand.value)

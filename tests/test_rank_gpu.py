@@ -255,3 +255,41 @@ def test_hybrid_search_end_to_end(ctx, oracle):
         assert len(got[0]) == limit and len({x for x, _ in got[0]}) == limit
     assert ma.scoring.hybrid_merge(v_hits, kw_hits, 1.0, 0, limit)[1] == limit      # all semantic
     assert [x for x, _ in ma.scoring.hybrid_merge(v_hits, kw_hits, 0.0, 0, 4)[0]] == [k_[0] for k_ in kw[:4]]
+
+
+def test_keyword_search_product_path(ctx):
+    """msi_keyword_search: tokens -> query graph -> batched device derivations -> posting sets
+    decoded on the device -> device bucket sort, all inside libmsi; the index is reached
+    through msi_index_vtable callbacks that return CboRoaringBitmap bytes.  Same reference
+    snapshots as above (typo.rs), plus the harness' brute-force order."""
+    h = Harness(ctx, TYPO_RS_DOCS, n_slots=128)
+    cb = R.IndexCallbacks(h.idx)
+
+    def run(query, strategy_all=False, use_typo=True, **kw):
+        got, cand = R.keyword_search(h.gdict, h.pool, cb, query.split(), True,
+                                     R.TERMS_ALL if strategy_all else R.TERMS_LAST, use_typo, 0, 100, **kw)
+        words = query.split()
+        gn = h.idx.graph_nodes(words, h.lookup, h.idx.exact_words, kw.get("authorize_typos", True))
+        exp = brute_force_graph_order(gn, len(words), set(h.idx.docs), strategy_all, use_typo)
+        assert cand == len(exp) and got == exp, (query, got[:6], exp[:6])
+        return got
+    got = run("the quick brown fox jumps over the lazy dog")
+    assert [g[0] for g in got] == [0, 23, 7, 8, 9, 22, 10, 11, 1, 2, 12, 13, 4, 3, 5, 6, 21]     # typo.rs:476
+    assert got[0][1:] == (9, 0, 9) and got[1][1:] == (9, 1, 9) and got[2][1:] == (8, 0, 8)
+    got = run("network interconnection sunflower", True)
+    assert [g[0] for g in got] == [16, 18, 17, 20, 15, 14] and [g[2] for g in got] == [0, 0, 1, 1, 2, 5]
+    got = run("network interconnection sun flower", True)
+    assert [g[0] for g in got] == [17, 19, 16, 18, 20, 15] and [g[2] for g in got] == [0, 0, 2, 2, 3, 4]
+    assert [g[0] for g in run("the quack brown fox jumps over the lazy dog", True, False)] == [0]
+    assert [g[0] for g in run("the quicest brownest fox jummps over the laziest dog", True, False)] == [3]
+    assert [g[0] for g in run("the quick brown fox jumps over the lazy dog", True, False, authorize_typos=False)] == [0]
+    h.idx.exact_words = ("quick", "quack", "sunflower")                                            # typo.rs:252-323
+    assert [g[0] for g in run("the quack brown fox jumps over the lazy dog", True, False)] == []
+    assert [g[0] for g in run("network interconnection sunflower", True, False)] == [16, 17, 18]
+    h.idx.exact_words = ()
+    # a filtered universe (the `filter` of a search arrives as a bitmap)
+    from toy_index import cbo_bytes
+    uni = [d for d in TYPO_RS_DOCS if d % 2 == 0]
+    got, cand = R.keyword_search(h.gdict, h.pool, cb, "the quick brown fox".split(), True, R.TERMS_LAST, True, 0, 100,
+                                 universe_cbo=cbo_bytes(uni))
+    assert got and all(g[0] % 2 == 0 for g in got)

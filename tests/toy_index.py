@@ -11,6 +11,29 @@ import numpy as np
 MAX_ONE, MAX_TWO, MAX_PREFIX = 150, 50, 1000   # search/new/limits.rs:5-9
 
 
+def cbo_bytes(ids):
+    """CboRoaringBitmapCodec::serialize_into_writer (cbo_roaring_bitmap_codec.rs:33-51): <= 7
+    documents as raw native-endian u32s, else the portable Roaring serialisation."""
+    import struct
+    ids = np.unique(np.asarray(sorted(ids), dtype=np.uint32))
+    if ids.size <= 7:
+        return ids.astype("=u4").tobytes()
+    keys = np.unique(ids >> 16)
+    conts = [(int(k), (ids[(ids >> 16) == k] & 0xFFFF).astype(np.uint16)) for k in keys]
+    out = bytearray(struct.pack("<II", 12346, len(conts)))
+    for k, v in conts:
+        out += struct.pack("<HH", k, len(v) - 1)
+    out += b"\0" * (4 * len(conts))
+    for k, v in conts:
+        if len(v) <= 4096:
+            out += v.astype("<u2").tobytes()
+        else:
+            words = np.zeros(1024, dtype=np.uint64)
+            np.bitwise_or.at(words, (v >> 6).astype(np.int64), np.uint64(1) << (v & 63).astype(np.uint64))
+            out += words.astype("<u8").tobytes()
+    return bytes(out)
+
+
 def tokenize(text):
     return re.findall(r"[0-9a-zà-ÿа-я]+", text.lower())
 
@@ -29,6 +52,20 @@ class ToyIndex:
             for a, b in zip(toks, toks[1:]):
                 self.pair1.setdefault((a, b), set()).add(d)
         self.words = sorted(self.word_docids, key=lambda w: w.encode())   # words-fst order
+
+    # -- the index side of msi_index_vtable (what the Rust shim answers from LMDB) --------
+    exact_words = ()
+
+    def word_docids_bytes(self, word, original):
+        s = self.word_docids.get(word)
+        return cbo_bytes(s) if s else None
+
+    def pair_docids_bytes(self, prox, left, right):
+        s = self.pair1.get((left, right)) if prox == 1 else None
+        return cbo_bytes(s) if s else None
+
+    def is_exact_word(self, word):
+        return word in self.exact_words
 
     def budget(self, word, exact_words=(), authorize_typos=True):
         # number_of_typos_allowed, parse_query.rs:204-225 (5 / 9 chars)
