@@ -123,8 +123,7 @@ def main():
         gdict = ma.GpuDictionary(ctx, concat=concat, offsets=off)
         tq = synth.make_typo_queries(words, Q * args.words_per_query, seed=7 + rank)
         n_words_q = len(tq)
-        from oracle import cpubase  # only for pack_queries' byte packing + the cpu_baseline leg
-        qb, qoff, qfl = cpubase.pack_queries(tq)
+        qb, qoff, qfl = ma.pack_queries(tq)
         qb_t = torch.from_numpy(qb).to(dev)
         qoff_t = torch.from_numpy(qoff.astype(np.int32)).to(dev)
         qfl_t = torch.from_numpy(qfl).to(dev)

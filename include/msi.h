@@ -129,6 +129,14 @@ int32_t msi_vs_search(msi_vs *vs, const float *queries, uint32_t n_queries,
                       uint32_t *out_docids, float *out_dist,
                       uint32_t *out_counts);
 
+/* nns_by_item for one store (store.rs:615-637,980-1034): the query is the stored vector of
+ * `docid` (*out_found = 0 and no results when the store has none).  Similar::execute
+ * (search/similar.rs:67-153) passes a filter without the item itself. */
+int32_t msi_vs_search_by_item(msi_vs *vs, uint32_t docid, uint32_t k,
+                              const uint64_t *filter_bits, uint64_t filter_nbits,
+                              uint32_t *out_docids, float *out_dist, uint32_t *out_count,
+                              int32_t *out_found);
+
 /* Micro-batching of concurrent callers (each tokio spawn_blocking search thread
  * calls msi_vs_search with ONE query): with max_wait_us > 0, unfiltered calls that
  * arrive within that window are fused into one HBM sweep (up to msi_vs_max_batch()

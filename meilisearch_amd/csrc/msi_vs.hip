@@ -1443,6 +1443,23 @@ int32_t msi_vs_get_vector(msi_vs *vs, uint32_t docid, float *out_row, int32_t *o
   return MSI_OK;
 }
 
+// VectorStore::nns_by_item for one store (store.rs:615-637,980-1034): the query is the
+// item's own stored vector; Similar::execute (search/similar.rs:67-153) passes a filter
+// that excludes the item itself.
+int32_t msi_vs_search_by_item(msi_vs *vs, uint32_t docid, uint32_t k, const uint64_t *filter_bits,
+                              uint64_t filter_nbits, uint32_t *out_docids, float *out_dist, uint32_t *out_count,
+                              int32_t *out_found) {
+  if (!vs || !out_count || !out_found || (k && (!out_docids || !out_dist))) {
+    msi_set_error("msi_vs_search_by_item: invalid argument");
+    return MSI_E_INVALID;
+  }
+  std::vector<float> v(vs->dim);
+  MSI_TRY(msi_vs_get_vector(vs, docid, v.data(), out_found));
+  *out_count = 0;
+  if (!*out_found) return MSI_OK;   // the item has no vector in this store
+  return msi_vs_search(vs, v.data(), 1, k, filter_bits, filter_nbits, nullptr, out_docids, out_dist, out_count);
+}
+
 int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries, uint32_t n_queries, uint32_t k,
                              const uint64_t *d_filter_bits, uint64_t filter_nbits, uint32_t *d_out_docids,
                              float *d_out_dist, uint32_t *d_out_counts, uint32_t *d_inexact) {

@@ -30,6 +30,20 @@ def number_of_typos_allowed(word, authorize_typos=True, min_len_one_typo=5, min_
     return 2
 
 
+def pack_queries(queries):
+    """[(word, max_typos, is_prefix)] -> (bytes u8, offsets u32, flags u8): the packed
+    device-side form of msi_dict_lookup_device (flags = max_typos | is_prefix << 2)."""
+    bs = [w.encode("utf-8") if isinstance(w, str) else bytes(w) for w, _, _ in queries]
+    qb = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    if qb.size == 0:
+        qb = np.zeros(1, np.uint8)
+    off = np.zeros(len(bs) + 1, dtype=np.uint32)
+    if bs:
+        np.cumsum([len(b) for b in bs], out=off[1:])
+    fl = np.array([(min(mt, 2) & 3) | (4 if pf else 0) for _, mt, pf in queries], dtype=np.uint8)
+    return qb, off, fl
+
+
 class GpuDictionary:
     """Sorted, unique word list (the keys of `word_docids`, index.rs:1238-1243)."""
 

@@ -94,6 +94,18 @@ class GpuStore:
             C.c_void_p(out_counts_t.data_ptr()),
             C.c_void_p(inexact_t.data_ptr()) if inexact_t is not None else None))
 
+    def search_by_item(self, docid, k, filter_bits=None, filter_nbits=0):
+        """nns_by_item for this store -> (docids, dist) or None when the item has no vector here."""
+        out_d = np.zeros(max(k, 1), dtype=np.uint32)
+        out_s = np.zeros(max(k, 1), dtype=np.float32)
+        cnt, found = C.c_uint32(0), C.c_int32(0)
+        fb = None if filter_bits is None else np.ascontiguousarray(filter_bits, dtype=np.uint64)
+        check(lib().msi_vs_search_by_item(self._h, int(docid), k, np_ptr(fb), filter_nbits, np_ptr(out_d), np_ptr(out_s),
+                                          C.byref(cnt), C.byref(found)))
+        if not found.value:
+            return None
+        return out_d[:cnt.value].copy(), out_s[:cnt.value].copy()
+
     def set_microbatch(self, max_wait_us):
         """Fuse concurrent unfiltered `search` calls (other threads) into shared HBM sweeps."""
         check(lib().msi_vs_set_microbatch(self._h, int(max_wait_us)))
@@ -192,11 +204,10 @@ class VectorStore:
             fb, nb = dense_filter(filter_docids)
         results = []
         for st in self._readers():
-            v = st.get_vector(item)
-            if v is None:
+            r = st.search_by_item(item, limit, fb, nb)
+            if r is None:
                 continue
-            d, s, c = st.search(v[None, :], limit, fb, nb)
-            results += [(int(d[0, i]), float(s[0, i])) for i in range(int(c[0]))]
+            results += [(int(a), float(b)) for a, b in zip(*r)]
         results.sort(key=lambda t: (t[1], t[0]))
         return results
 

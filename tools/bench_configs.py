@@ -72,8 +72,13 @@ def run_c2(args):
         ctx.synchronize()
         ln, lms = store.scan_time()
         scan_ms = lms / max(1, ln)
+        # the same batch through the HOST entry point (H2D of the queries, D2H of the results,
+        # stream synchronisations): the PCIe-inclusive rate
+        qh = q[:B].cpu().numpy()
+        host_ms, _ = timed(lambda: store.search(qh, k), lambda: None, max(3, args.reps // 2))
         print(json.dumps({
-            "config": "C2", "storage": args.storage, "rows": n, "dim": d, "k": k, "batch": B,
+            "config": "C2", "storage": args.storage, "host_api_ms_per_batch": round(host_ms, 4),
+            "host_api_qps": round(B / host_ms * 1e3, 1), "rows": n, "dim": d, "k": k, "batch": B,
             "ms_per_batch": round(ms, 4), "p50_ms": round(p50, 4), "qps": round(B / ms * 1e3, 1),
             "sweeps_per_batch": (B + store.max_batch - 1) // store.max_batch, "scan_kernel_ms": round(scan_ms, 4),
             "scan_GBps": round(bytes_per_sweep / (scan_ms * 1e-3) / 1e9, 1),
@@ -85,7 +90,7 @@ def run_c3(args):
     import torch
     import meilisearch_amd as ma
     from meilisearch_amd import synth
-    from oracle import cpubase  # packing helper + the CPU baseline leg only
+    from oracle import cpubase  # the CPU baseline leg only
     dev = torch.device("cuda", 0)
     ctx = ma.Context(0)
     words = synth.make_dictionary(args.dict_words, seed=99)
@@ -110,7 +115,7 @@ def run_c3(args):
                "words_per_s_one_core": round(1.0 / t_one, 1), "sample_words": len(sample)}
     for B in args.batches:
         tq = all_q[:B]
-        qb, qoff, qfl = cpubase.pack_queries(tq)
+        qb, qoff, qfl = ma.pack_queries(tq)
         qb_t = torch.from_numpy(qb).to(dev)
         qoff_t = torch.from_numpy(qoff.astype(np.int32)).to(dev)
         qfl_t = torch.from_numpy(qfl).to(dev)
