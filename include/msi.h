@@ -328,6 +328,23 @@ int32_t msi_rank_query_graph(msi_bits *pool, const msi_rank_node *nodes,
                              uint32_t *out_matching_words, uint32_t *out_typo_count,
                              uint32_t *out_max_typo_count, uint32_t *out_n,
                              uint64_t *out_candidates);
+/* The two steps of msi_rank_query_graph on their own, for rule lists that continue after
+ * Typo (Proximity, Attribute, … stay on the reference's CPU path): the buckets of
+ * [Words, Typo] in bucket-sort order with their sizes and ScoreDetails, and one bucket
+ * as a docid set in `dst_slot` (read it back with msi_bits_read_words, or keep it in HBM
+ * as the universe of the next rule). */
+typedef struct msi_rank_bucket {
+  uint32_t matching_words, typo_count, max_typo_count, _pad;
+  uint64_t count;
+} msi_rank_bucket;
+int32_t msi_rank_buckets(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes,
+                         uint32_t n_terms, uint32_t universe_slot, uint32_t scratch_slot,
+                         int32_t strategy, int32_t use_typo, msi_rank_bucket *out_buckets,
+                         uint32_t cap, uint32_t *out_n);
+int32_t msi_rank_materialise(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes,
+                             uint32_t n_terms, uint32_t universe_slot, int32_t strategy,
+                             int32_t use_typo, uint32_t matching_words, uint32_t typo_count,
+                             uint32_t dst_slot);
 int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms,
                             uint32_t n_terms, uint32_t universe_slot,
                             uint32_t scratch_slot, int32_t strategy,

@@ -223,24 +223,21 @@ __global__ __launch_bounds__(RT) void rank_query_graph_kernel(RankArgs a) {
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int32_t msi_rank_query_graph(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes, uint32_t n_terms,
-                             uint32_t universe_slot, uint32_t scratch_slot, int32_t strategy, int32_t use_typo,
-                             uint32_t from, uint32_t length, uint32_t *out_docids,
-                             uint32_t *out_matching_words, uint32_t *out_typo_count,
-                             uint32_t *out_max_typo_count, uint32_t *out_n, uint64_t *out_candidates) {
-  if (!pool || !nodes || n_nodes == 0 || n_terms == 0 || n_terms > (uint32_t)NT_MAX || !out_n ||
-      (length && (!out_docids || !out_matching_words || !out_typo_count || !out_max_typo_count))) {
-    msi_set_error("msi_rank_query_graph: invalid argument (1..%d terms)", NT_MAX);
+// Validate the nodes and fill the kernel arguments (everything except hist/dst/sel).
+int32_t build_args(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes, uint32_t n_terms,
+                   uint32_t universe_slot, uint32_t forbidden_slot, int32_t strategy, int32_t use_typo,
+                   RankArgs &a) {
+  if (!pool || !nodes || n_nodes == 0 || n_terms == 0 || n_terms > (uint32_t)NT_MAX) {
+    msi_set_error("msi_rank: invalid argument (1..%d terms)", NT_MAX);
     return MSI_E_INVALID;
   }
   const uint32_t n_slots = msi_bits_n_slots(pool);
-  if (universe_slot >= n_slots || scratch_slot >= n_slots || scratch_slot == universe_slot) {
-    msi_set_error("msi_rank_query_graph: universe/scratch slot out of range");
+  if (universe_slot >= n_slots || forbidden_slot >= n_slots || forbidden_slot == universe_slot) {
+    msi_set_error("msi_rank: universe/destination slot out of range");
     return MSI_E_INVALID;
   }
-  RankArgs a;
   memset(&a, 0, sizeof(a));
   for (int p = 0; p < NT_MAX; ++p)
     for (int kind = 0; kind < 3; ++kind) a.node[p][kind].max_cost = 0xFFFFFFFFu;
@@ -248,36 +245,44 @@ int32_t msi_rank_query_graph(msi_bits *pool, const msi_rank_node *nodes, uint32_
     const msi_rank_node &nd = nodes[i];
     if (nd.last_term >= n_terms || nd.first_term > nd.last_term || nd.last_term - nd.first_term > 2 ||
         nd.max_typo_cost > 2) {
-      msi_set_error("msi_rank_query_graph: node %u is not a 1/2/3-gram of the %u terms (or max_typo_cost > 2)", i,
-                    n_terms);
+      msi_set_error("msi_rank: node %u is not a 1/2/3-gram of the %u terms (or max_typo_cost > 2)", i, n_terms);
       return MSI_E_INVALID;
     }
     NodeArg &na = a.node[nd.last_term][nd.last_term - nd.first_term];
     if (na.max_cost != 0xFFFFFFFFu) {
-      msi_set_error("msi_rank_query_graph: two nodes cover terms %u..%u", nd.first_term, nd.last_term);
+      msi_set_error("msi_rank: two nodes cover terms %u..%u", nd.first_term, nd.last_term);
       return MSI_E_INVALID;
     }
     na.max_cost = nd.max_typo_cost;
     for (int s = 0; s < 3; ++s) {
       const uint32_t sl = nd.level_slot[s];
       if (sl == MSI_NO_SLOT) continue;
-      if (sl >= n_slots || sl == scratch_slot) {
-        msi_set_error("msi_rank_query_graph: node %u level %d slot %u invalid", i, s, sl);
+      if (sl >= n_slots || sl == forbidden_slot) {
+        msi_set_error("msi_rank: node %u level %d slot %u invalid", i, s, sl);
         return MSI_E_INVALID;
       }
       na.level[s] = msi_bits_slot_ptr(pool, sl);
     }
   }
-  msi_ctx *ctx = msi_bits_ctx(pool);
-  std::unique_lock<std::mutex> lk(ctx->mu);
-  DeviceGuard g(ctx->device);
-  hipStream_t st = ctx->stream;
   a.universe = msi_bits_slot_ptr(pool, universe_slot);
   a.n_words = msi_bits_words_per_slot(pool);
   a.n_terms = n_terms;
   a.strategy_all = strategy == MSI_TERMS_ALL;
   a.use_typo = use_typo != 0;
-  a.dst = msi_bits_slot_ptr(pool, scratch_slot);
+  a.dst = msi_bits_slot_ptr(pool, forbidden_slot);
+  return MSI_OK;
+}
+
+uint32_t rank_grid(msi_ctx *ctx, const RankArgs &a) {
+  return std::max(1u, (uint32_t)std::min<uint64_t>((a.n_words + RT - 1) / RT, (uint64_t)ctx->n_cu * 8));
+}
+
+// Histogram passes -> the non-empty buckets in bucket-sort order.
+int32_t list_buckets(msi_bits *pool, RankArgs &a, uint32_t n_terms, std::vector<msi_rank_bucket> &out) {
+  msi_ctx *ctx = msi_bits_ctx(pool);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  DeviceGuard g(ctx->device);
+  hipStream_t st = ctx->stream;
   const size_t hist_n = (size_t)(NT_MAX + 1) * (TC_MAX + 1);
   u64 *d_hist = nullptr;
   MSI_HIP_TRY(hipMalloc(&d_hist, 2 * hist_n * sizeof(u64)));
@@ -286,11 +291,10 @@ int32_t msi_rank_query_graph(msi_bits *pool, const msi_rank_node *nodes, uint32_
     ~Free() { (void)hipFree(p); }
   } free_hist{d_hist};
   MSI_HIP_TRY(hipMemsetAsync(d_hist, 0, 2 * hist_n * sizeof(u64), st));
-  const uint32_t grid =
-      std::max(1u, (uint32_t)std::min<uint64_t>((a.n_words + RT - 1) / RT, (uint64_t)ctx->n_cu * 8));
+  const uint32_t grid = rank_grid(ctx, a);
   a.hist = d_hist;
   hipLaunchKernelGGL(rank_query_graph_kernel<MODE_HIST>, dim3(grid), dim3(RT), 0, st, a);
-  if (use_typo) {
+  if (a.use_typo) {
     a.hist = d_hist + hist_n;
     hipLaunchKernelGGL(rank_query_graph_kernel<MODE_STRUCT>, dim3(grid), dim3(RT), 0, st, a);
   }
@@ -298,49 +302,106 @@ int32_t msi_rank_query_graph(msi_bits *pool, const msi_rank_node *nodes, uint32_
   std::vector<u64> hist(2 * hist_n);
   MSI_HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, 2 * hist_n * sizeof(u64), hipMemcpyDeviceToHost, st));
   MSI_HIP_TRY(hipStreamSynchronize(st));
+  out.clear();
   // bucket order: kept terms descending (Words), total typos ascending (Typo)
-  uint64_t total = 0, skipped = 0;
-  for (size_t i = 0; i < hist_n; ++i) total += hist[i];
-  if (out_candidates) *out_candidates = total;
-  uint32_t max_cost_of[NT_MAX + 1] = {0};
-  for (uint32_t k = 1; k <= n_terms; ++k)
+  for (int k = (int)n_terms; k >= 1; --k) {
+    uint32_t max_cost = 0;
     for (int t = TC_MAX; t >= 0; --t)
       if (hist[hist_n + (size_t)k * (TC_MAX + 1) + t]) {
-        max_cost_of[k] = (uint32_t)t;
+        max_cost = (uint32_t)t;
         break;
       }
-  uint32_t written = 0;
-  lk.unlock();  // msi_bits_first_k takes the context lock itself
-  for (int k = (int)n_terms; k >= 1 && written < length; --k) {
-    for (int t = 0; t <= TC_MAX && written < length; ++t) {
+    for (int t = 0; t <= TC_MAX; ++t) {
       const u64 c = hist[(size_t)k * (TC_MAX + 1) + t];
       if (c == 0) continue;
-      if (skipped + c <= from) {  // bucket entirely before `from` (bucket_sort.rs:382-400)
-        skipped += c;
-        continue;
-      }
-      const uint64_t skip_here = from > skipped ? from - skipped : 0;
-      const uint64_t want = std::min<uint64_t>(c - skip_here, length - written);
-      {
-        std::lock_guard<std::mutex> lk2(ctx->mu);
-        DeviceGuard g2(ctx->device);
-        a.sel_k = (uint32_t)k;
-        a.sel_t = (uint32_t)t;
-        hipLaunchKernelGGL(rank_query_graph_kernel<MODE_MATERIALISE>, dim3(grid), dim3(RT), 0, st, a);
-        MSI_HIP_TRY(hipGetLastError());
-      }
-      std::vector<uint32_t> ids((size_t)(skip_here + want));
-      uint32_t got = 0;
-      MSI_TRY(msi_bits_first_k(pool, scratch_slot, (uint32_t)ids.size(), ids.data(), &got));
-      for (uint64_t i = skip_here; i < got && written < length; ++i) {
-        out_docids[written] = ids[i];
-        out_matching_words[written] = (uint32_t)k;
-        out_typo_count[written] = (uint32_t)t;
-        out_max_typo_count[written] = max_cost_of[k];
-        ++written;
-      }
-      skipped += c;
+      msi_rank_bucket b;
+      b.matching_words = (uint32_t)k;
+      b.typo_count = (uint32_t)t;
+      b.max_typo_count = max_cost;
+      b._pad = 0;
+      b.count = c;
+      out.push_back(b);
     }
+  }
+  return MSI_OK;
+}
+
+int32_t materialise(msi_bits *pool, RankArgs &a, uint32_t k, uint32_t t) {
+  msi_ctx *ctx = msi_bits_ctx(pool);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  DeviceGuard g(ctx->device);
+  a.sel_k = k;
+  a.sel_t = t;
+  hipLaunchKernelGGL(rank_query_graph_kernel<MODE_MATERIALISE>, dim3(rank_grid(ctx, a)), dim3(RT), 0, ctx->stream, a);
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t msi_rank_buckets(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes, uint32_t n_terms,
+                         uint32_t universe_slot, uint32_t scratch_slot, int32_t strategy, int32_t use_typo,
+                         msi_rank_bucket *out_buckets, uint32_t cap, uint32_t *out_n) {
+  if (!out_n || (cap && !out_buckets)) {
+    msi_set_error("msi_rank_buckets: invalid argument");
+    return MSI_E_INVALID;
+  }
+  RankArgs a;
+  MSI_TRY(build_args(pool, nodes, n_nodes, n_terms, universe_slot, scratch_slot, strategy, use_typo, a));
+  std::vector<msi_rank_bucket> b;
+  MSI_TRY(list_buckets(pool, a, n_terms, b));
+  *out_n = (uint32_t)b.size();
+  for (uint32_t i = 0; i < b.size() && i < cap; ++i) out_buckets[i] = b[i];
+  return MSI_OK;
+}
+
+int32_t msi_rank_materialise(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes, uint32_t n_terms,
+                             uint32_t universe_slot, int32_t strategy, int32_t use_typo, uint32_t matching_words,
+                             uint32_t typo_count, uint32_t dst_slot) {
+  RankArgs a;
+  MSI_TRY(build_args(pool, nodes, n_nodes, n_terms, universe_slot, dst_slot, strategy, use_typo, a));
+  return materialise(pool, a, matching_words, typo_count);
+}
+
+int32_t msi_rank_query_graph(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes, uint32_t n_terms,
+                             uint32_t universe_slot, uint32_t scratch_slot, int32_t strategy, int32_t use_typo,
+                             uint32_t from, uint32_t length, uint32_t *out_docids,
+                             uint32_t *out_matching_words, uint32_t *out_typo_count,
+                             uint32_t *out_max_typo_count, uint32_t *out_n, uint64_t *out_candidates) {
+  if (!out_n || (length && (!out_docids || !out_matching_words || !out_typo_count || !out_max_typo_count))) {
+    msi_set_error("msi_rank_query_graph: invalid argument");
+    return MSI_E_INVALID;
+  }
+  RankArgs a;
+  MSI_TRY(build_args(pool, nodes, n_nodes, n_terms, universe_slot, scratch_slot, strategy, use_typo, a));
+  std::vector<msi_rank_bucket> buckets;
+  MSI_TRY(list_buckets(pool, a, n_terms, buckets));
+  uint64_t total = 0, skipped = 0;
+  for (const auto &b : buckets) total += b.count;
+  if (out_candidates) *out_candidates = total;
+  uint32_t written = 0;
+  for (const auto &b : buckets) {
+    if (written >= length) break;
+    if (skipped + b.count <= from) {  // bucket entirely before `from` (bucket_sort.rs:382-400)
+      skipped += b.count;
+      continue;
+    }
+    const uint64_t skip_here = from > skipped ? from - skipped : 0;
+    const uint64_t want = std::min<uint64_t>(b.count - skip_here, length - written);
+    MSI_TRY(materialise(pool, a, b.matching_words, b.typo_count));
+    std::vector<uint32_t> ids((size_t)(skip_here + want));
+    uint32_t got = 0;
+    MSI_TRY(msi_bits_first_k(pool, scratch_slot, (uint32_t)ids.size(), ids.data(), &got));
+    for (uint64_t i = skip_here; i < got && written < length; ++i) {
+      out_docids[written] = ids[i];
+      out_matching_words[written] = b.matching_words;
+      out_typo_count[written] = b.typo_count;
+      out_max_typo_count[written] = b.max_typo_count;
+      ++written;
+    }
+    skipped += b.count;
   }
   *out_n = written;
   return MSI_OK;

@@ -6,8 +6,8 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (EXACT_WORD_FN, PAIR_DOCIDS_FN, WORD_DOCIDS_FN, IndexVtable, KeywordParams, QueryToken, RankNode,
-                   RankTerm, check, lib)
+from ._lib import (EXACT_WORD_FN, PAIR_DOCIDS_FN, WORD_DOCIDS_FN, IndexVtable, KeywordParams, QueryToken, RankBucket,
+                   RankNode, RankTerm, check, lib)
 from .device import np_ptr
 
 NO_SLOT = 0xFFFFFFFF
@@ -59,6 +59,33 @@ def bucket_sort_query_graph(pool, nodes, n_terms, universe_slot, scratch_slot, s
                                      np_ptr(maxt), C.byref(out_n), C.byref(cand)))
     k = out_n.value
     return [(int(ids[i]), int(words[i]), int(typos[i]), int(maxt[i])) for i in range(k)], int(cand.value)
+
+
+def _node_array(nodes):
+    arr = (RankNode * max(len(nodes), 1))()
+    for i, (a, b, s0, s1, s2, mc) in enumerate(nodes):
+        arr[i].first_term, arr[i].last_term = int(a), int(b)
+        for j, s in enumerate((s0, s1, s2)):
+            arr[i].level_slot[j] = NO_SLOT if s is None else int(s)
+        arr[i].max_typo_cost = int(mc)
+    return arr
+
+
+def rank_buckets(pool, nodes, n_terms, universe_slot, scratch_slot, strategy=TERMS_LAST, use_typo=True):
+    """Buckets of [Words, Typo] in order: [(matching_words, typo_count, max_typo_count, count)]."""
+    out = (RankBucket * 256)()
+    n = C.c_uint32(0)
+    check(lib().msi_rank_buckets(pool._h, _node_array(nodes), len(nodes), n_terms, universe_slot, scratch_slot,
+                                 strategy, 1 if use_typo else 0, out, 256, C.byref(n)))
+    return [(out[i].matching_words, out[i].typo_count, out[i].max_typo_count, int(out[i].count))
+            for i in range(min(n.value, 256))]
+
+
+def rank_materialise(pool, nodes, n_terms, universe_slot, dst_slot, matching_words, typo_count,
+                     strategy=TERMS_LAST, use_typo=True):
+    """One bucket as a docid set in `dst_slot` (the universe handed to the next ranking rule)."""
+    check(lib().msi_rank_materialise(pool._h, _node_array(nodes), len(nodes), n_terms, universe_slot, strategy,
+                                     1 if use_typo else 0, matching_words, typo_count, dst_slot))
 
 
 class IndexCallbacks:

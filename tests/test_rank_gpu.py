@@ -147,6 +147,36 @@ def test_random_query_graph_vs_brute_force(ctx, seed, n_docs, n_terms):
                 assert got == exp[off:off + lim], (strategy_all, use_typo, off, lim)
 
 
+def test_buckets_and_materialise_for_rules_after_typo(ctx):
+    # the hand-over to the rules that stay on the CPU path: bucket list + bucket bitmaps
+    h = Harness(ctx, TYPO_RS_DOCS, n_slots=128)
+    words = "the quick brown fox jumps over the lazy dog".split()
+    gn = h.idx.graph_nodes(words, h.lookup)
+    slot, nodes = 2, []
+    for first, last, z, o, t, mc in gn:
+        sl = []
+        for s in (z, o, t):
+            if s:
+                h.pool.set_from_docids(slot, np.array(sorted(s), dtype=np.uint32))
+                sl.append(slot)
+                slot += 1
+            else:
+                sl.append(None)
+        nodes.append((first, last, sl[0], sl[1], sl[2], mc))
+    h.pool.set_from_docids(0, np.array(sorted(h.idx.docs), dtype=np.uint32))
+    exp = brute_force_graph_order(gn, len(words), set(h.idx.docs), False, True)
+    buckets = R.rank_buckets(h.pool, nodes, len(words), 0, 1)
+    assert sum(b[3] for b in buckets) == len(exp)
+    flat = []
+    for mw, tc, mt, cnt in buckets:
+        R.rank_materialise(h.pool, nodes, len(words), 0, 100, mw, tc)
+        ids = h.pool.to_docids(100).tolist()
+        assert len(ids) == cnt
+        flat += [(d, mw, tc, mt) for d in ids]
+    assert flat == exp
+    assert buckets[0][:3] == (9, 0, 9) and buckets[1][:3] == (9, 1, 9)
+
+
 def test_reference_snapshots_typo_rs(ctx):
     h = Harness(ctx, TYPO_RS_DOCS)
     # typo.rs:462-516: criteria [Typo] (Words is inserted implicitly, search/new/mod.rs:536-551), strategy Last
