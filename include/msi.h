@@ -345,6 +345,20 @@ int32_t msi_rank_materialise(msi_bits *pool, const msi_rank_node *nodes, uint32_
                              uint32_t n_terms, uint32_t universe_slot, int32_t strategy,
                              int32_t use_typo, uint32_t matching_words, uint32_t typo_count,
                              uint32_t dst_slot);
+/* Batched form for serving throughput: many queries per launch (histograms,
+ * materialisation and ordered extraction run with one grid row per query), so a batch
+ * costs a handful of launches and synchronisations.  Outputs are [n_queries][length]
+ * (rows padded; out_n[q] valid entries).  Each query owns 4 consecutive scratch slots. */
+typedef struct msi_rank_query {
+  const msi_rank_node *nodes;
+  uint32_t n_nodes, n_terms, universe_slot, scratch_slot;
+} msi_rank_query;
+int32_t msi_rank_query_graph_batch(msi_bits *pool, const msi_rank_query *queries,
+                                   uint32_t n_queries, int32_t strategy, int32_t use_typo,
+                                   uint32_t from, uint32_t length, uint32_t *out_docids,
+                                   uint32_t *out_matching_words, uint32_t *out_typo_count,
+                                   uint32_t *out_max_typo_count, uint32_t *out_n,
+                                   uint64_t *out_candidates);
 int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms,
                             uint32_t n_terms, uint32_t universe_slot,
                             uint32_t scratch_slot, int32_t strategy,

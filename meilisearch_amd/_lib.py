@@ -27,6 +27,11 @@ class RankTerm(C.Structure):
     _fields_ = [("level_slot", C.c_uint32 * 3), ("max_typo_cost", C.c_uint32)]
 
 
+class RankQuery(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint32), ("n_terms", C.c_uint32),
+                ("universe_slot", C.c_uint32), ("scratch_slot", C.c_uint32)]
+
+
 class RankBucket(C.Structure):
     _fields_ = [("matching_words", C.c_uint32), ("typo_count", C.c_uint32), ("max_typo_count", C.c_uint32),
                 ("_pad", C.c_uint32), ("count", C.c_uint64)]
@@ -125,6 +130,7 @@ PROTOTYPES = {
     "msi_bits_device_ptr": (_VP, [_VP, _U32]),
     "msi_rank_query_graph": (_I32, [_VP, _VP, _U32, _U32, _U32, _U32, _I32, _I32, _U32, _U32, _VP, _VP, _VP, _VP,
                                     C.POINTER(_U32), C.POINTER(_U64)]),
+    "msi_rank_query_graph_batch": (_I32, [_VP, _VP, _U32, _I32, _I32, _U32, _U32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "msi_rank_buckets": (_I32, [_VP, _VP, _U32, _U32, _U32, _U32, _I32, _I32, _VP, _U32, C.POINTER(_U32)]),
     "msi_rank_materialise": (_I32, [_VP, _VP, _U32, _U32, _U32, _I32, _I32, _U32, _U32, _U32]),
     "msi_rank_words_typo": (_I32, [_VP, _VP, _U32, _U32, _U32, _I32, _I32, _U32, _U32, _VP, _VP, _VP, _VP,

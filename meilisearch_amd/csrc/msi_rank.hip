@@ -74,8 +74,9 @@ struct RankArgs {
   uint32_t strategy_all;
   uint32_t use_typo;
   u64 *hist;                 // [NT_MAX + 1][TC_MAX + 1]
-  u64 *dst;
-  uint32_t sel_k, sel_t;
+  u64 *dst[4];               // materialise: up to 4 buckets per pass
+  uint32_t sel_k[4], sel_t[4];
+  uint32_t n_sel;
 };
 
 enum { MODE_HIST = 0, MODE_STRUCT = 1, MODE_MATERIALISE = 2 };
@@ -85,8 +86,7 @@ enum { MODE_HIST = 0, MODE_STRUCT = 1, MODE_MATERIALISE = 2 };
 //                   Typo rule's max_typo_count for that Words bucket
 // MODE_MATERIALISE  write bucket (sel_k, sel_t) to dst
 template <int MODE>
-__global__ __launch_bounds__(RT) void rank_query_graph_kernel(RankArgs a) {
-  __shared__ uint32_t s_hist[(NT_MAX + 1) * (TC_MAX + 1)];
+__device__ __forceinline__ void rank_body(const RankArgs &a, uint32_t *s_hist) {
   if (MODE != MODE_MATERIALISE) {
     for (uint32_t i = threadIdx.x; i < (NT_MAX + 1) * (TC_MAX + 1); i += RT) s_hist[i] = 0;
     __syncthreads();
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(RT) void rank_query_graph_kernel(RankArgs a) {
 #pragma unroll
       for (int t = 0; t <= TC_MAX; ++t) F[i][t] = 0;
     F[0][0] = U;
-    u64 out = 0;
+    u64 out[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int p = 1; p <= NT_MAX; ++p) {
       if (p <= (int)a.n_terms) {
@@ -198,26 +198,101 @@ __global__ __launch_bounds__(RT) void rank_query_graph_kernel(RankArgs a) {
             const u64 b = Dp & F[0][t] & ~seen;
             seen |= F[0][t];
             if (MODE == MODE_MATERIALISE) {
-              if ((uint32_t)p == a.sel_k && (uint32_t)t == a.sel_t) out = b;
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if ((uint32_t)p == a.sel_k[i] && (uint32_t)t == a.sel_t[i]) out[i] = b;
             } else if (b) {
               atomicAdd(&s_hist[p * (TC_MAX + 1) + t], (uint32_t)__popcll(b));
             }
           }
         } else {
           if (MODE == MODE_MATERIALISE) {
-            if ((uint32_t)p == a.sel_k) out = Dp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if ((uint32_t)p == a.sel_k[i]) out[i] = Dp;
           } else if (Dp) {
             atomicAdd(&s_hist[p * (TC_MAX + 1)], (uint32_t)__popcll(Dp));
           }
         }
       }
     }
-    if (MODE == MODE_MATERIALISE) a.dst[w] = out;
+    if (MODE == MODE_MATERIALISE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < (int)a.n_sel) a.dst[i][w] = out[i];
+    }
   }
   if (MODE != MODE_MATERIALISE) {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (NT_MAX + 1) * (TC_MAX + 1); i += RT)
       if (s_hist[i]) atomicAdd(&a.hist[i], (u64)s_hist[i]);
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(RT) void rank_query_graph_kernel(RankArgs a) {
+  __shared__ uint32_t s_hist[(NT_MAX + 1) * (TC_MAX + 1)];
+  rank_body<MODE>(a, s_hist);
+}
+
+// Batched form: blockIdx.y selects the query; its arguments live in HBM and are staged in LDS.
+template <int MODE>
+__global__ __launch_bounds__(RT) void rank_query_graph_batch_kernel(const RankArgs *__restrict__ args,
+                                                                    const uint32_t *__restrict__ active) {
+  __shared__ uint32_t s_hist[(NT_MAX + 1) * (TC_MAX + 1)];
+  __shared__ RankArgs sa;
+  const uint32_t q = active ? active[blockIdx.y] : blockIdx.y;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(args + q);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&sa);
+  for (uint32_t i = threadIdx.x; i < sizeof(RankArgs) / 4; i += RT) dst[i] = src[i];
+  __syncthreads();
+  rank_body<MODE>(sa, s_hist);
+}
+
+// Ascending docids of up to 4 materialised buckets of one query, in bucket order:
+// one workgroup walks each bucket's bitmap 256 words at a time (popcount + block
+// prefix sum) and stops as soon as skip + want documents went by.
+struct ExtractArgs {
+  const u64 *slot[4];
+  uint32_t skip[4], want[4], out_off[4];
+  uint32_t n_sel;
+  uint32_t q_out;   // row of the output matrix
+};
+__global__ __launch_bounds__(RT) void rank_extract_kernel(const ExtractArgs *__restrict__ ex, uint64_t n_words,
+                                                          uint32_t length, uint32_t *__restrict__ out) {
+  __shared__ uint32_t sh[RT];
+  __shared__ uint32_t s_run;
+  const ExtractArgs e = ex[blockIdx.x];
+  for (uint32_t i = 0; i < e.n_sel; ++i) {
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    const uint32_t lim = e.skip[i] + e.want[i];
+    for (uint64_t base = 0; base < n_words; base += RT) {
+      const uint64_t w = base + threadIdx.x;
+      u64 bits = w < n_words ? e.slot[i][w] : 0;
+      const uint32_t c = __popcll(bits);
+      sh[threadIdx.x] = c;
+      __syncthreads();
+      for (uint32_t o = 1; o < RT; o <<= 1) {
+        const uint32_t t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+      }
+      const uint32_t run = s_run;
+      uint32_t rank = run + sh[threadIdx.x] - c;
+      while (bits && rank < lim) {
+        const uint32_t b = __ffsll((long long)bits) - 1;
+        if (rank >= e.skip[i]) out[(size_t)e.q_out * length + e.out_off[i] + (rank - e.skip[i])] = (uint32_t)(w * 64 + b);
+        ++rank;
+        bits &= bits - 1;
+      }
+      __syncthreads();
+      if (threadIdx.x == RT - 1) s_run = run + sh[RT - 1];
+      __syncthreads();
+      if (s_run >= lim) break;
+    }
+    __syncthreads();
   }
 }
 
@@ -269,12 +344,19 @@ int32_t build_args(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes,
   a.n_terms = n_terms;
   a.strategy_all = strategy == MSI_TERMS_ALL;
   a.use_typo = use_typo != 0;
-  a.dst = msi_bits_slot_ptr(pool, forbidden_slot);
+  a.dst[0] = msi_bits_slot_ptr(pool, forbidden_slot);
+  a.n_sel = 1;
+  for (int i = 0; i < 4; ++i) a.sel_k[i] = 0xFFFFFFFFu;
   return MSI_OK;
 }
 
 uint32_t rank_grid(msi_ctx *ctx, const RankArgs &a) {
   return std::max(1u, (uint32_t)std::min<uint64_t>((a.n_words + RT - 1) / RT, (uint64_t)ctx->n_cu * 8));
+}
+
+void hist_to_buckets_impl(const u64 *hist, const u64 *hist_struct, uint32_t n_terms, std::vector<msi_rank_bucket> &out);
+inline void hist_to_buckets(const u64 *hist, const u64 *hist_struct, uint32_t n_terms, std::vector<msi_rank_bucket> &out) {
+  hist_to_buckets_impl(hist, hist_struct, n_terms, out);
 }
 
 // Histogram passes -> the non-empty buckets in bucket-sort order.
@@ -302,12 +384,23 @@ int32_t list_buckets(msi_bits *pool, RankArgs &a, uint32_t n_terms, std::vector<
   std::vector<u64> hist(2 * hist_n);
   MSI_HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, 2 * hist_n * sizeof(u64), hipMemcpyDeviceToHost, st));
   MSI_HIP_TRY(hipStreamSynchronize(st));
+  hist_to_buckets(hist.data(), hist.data() + hist_n, n_terms, out);
+  return MSI_OK;
+}
+
+}  // namespace
+
+namespace {
+
+void hist_to_buckets_impl(const u64 *hist, const u64 *hist_struct, uint32_t n_terms, std::vector<msi_rank_bucket> &out) {
   out.clear();
+  const size_t hist_n = (size_t)(NT_MAX + 1) * (TC_MAX + 1);
+  (void)hist_n;
   // bucket order: kept terms descending (Words), total typos ascending (Typo)
   for (int k = (int)n_terms; k >= 1; --k) {
     uint32_t max_cost = 0;
     for (int t = TC_MAX; t >= 0; --t)
-      if (hist[hist_n + (size_t)k * (TC_MAX + 1) + t]) {
+      if (hist_struct[(size_t)k * (TC_MAX + 1) + t]) {
         max_cost = (uint32_t)t;
         break;
       }
@@ -323,15 +416,15 @@ int32_t list_buckets(msi_bits *pool, RankArgs &a, uint32_t n_terms, std::vector<
       out.push_back(b);
     }
   }
-  return MSI_OK;
 }
 
 int32_t materialise(msi_bits *pool, RankArgs &a, uint32_t k, uint32_t t) {
   msi_ctx *ctx = msi_bits_ctx(pool);
   std::lock_guard<std::mutex> lk(ctx->mu);
   DeviceGuard g(ctx->device);
-  a.sel_k = k;
-  a.sel_t = t;
+  a.sel_k[0] = k;
+  a.sel_t[0] = t;
+  a.n_sel = 1;
   hipLaunchKernelGGL(rank_query_graph_kernel<MODE_MATERIALISE>, dim3(rank_grid(ctx, a)), dim3(RT), 0, ctx->stream, a);
   MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
@@ -404,6 +497,146 @@ int32_t msi_rank_query_graph(msi_bits *pool, const msi_rank_node *nodes, uint32_
     skipped += b.count;
   }
   *out_n = written;
+  return MSI_OK;
+}
+
+// Many queries per launch: the histogram passes, the materialise pass and the ordered
+// extraction run with blockIdx.y = query, so a batch costs a few launches and
+// synchronisations instead of ~8 per query.  Per query: 4 consecutive scratch slots.
+int32_t msi_rank_query_graph_batch(msi_bits *pool, const msi_rank_query *queries, uint32_t n_queries,
+                                   int32_t strategy, int32_t use_typo, uint32_t from, uint32_t length,
+                                   uint32_t *out_docids, uint32_t *out_matching_words, uint32_t *out_typo_count,
+                                   uint32_t *out_max_typo_count, uint32_t *out_n, uint64_t *out_candidates) {
+  if (!pool || !queries || n_queries == 0 || !out_n ||
+      (length && (!out_docids || !out_matching_words || !out_typo_count || !out_max_typo_count))) {
+    msi_set_error("msi_rank_query_graph_batch: invalid argument");
+    return MSI_E_INVALID;
+  }
+  const uint32_t n_slots = msi_bits_n_slots(pool);
+  std::vector<RankArgs> args(n_queries);
+  for (uint32_t q = 0; q < n_queries; ++q) {
+    const msi_rank_query &rq = queries[q];
+    if (rq.scratch_slot + 4 > n_slots) {
+      msi_set_error("msi_rank_query_graph_batch: query %u needs 4 scratch slots from %u", q, rq.scratch_slot);
+      return MSI_E_INVALID;
+    }
+    MSI_TRY(build_args(pool, rq.nodes, rq.n_nodes, rq.n_terms, rq.universe_slot, rq.scratch_slot, strategy, use_typo,
+                       args[q]));
+    for (int i = 0; i < 4; ++i) args[q].dst[i] = msi_bits_slot_ptr(pool, rq.scratch_slot + i);
+  }
+  msi_ctx *ctx = msi_bits_ctx(pool);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  DeviceGuard g(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t hist_n = (size_t)(NT_MAX + 1) * (TC_MAX + 1);
+  const size_t sz_args = (size_t)n_queries * sizeof(RankArgs);
+  const size_t sz_hist = 2 * (size_t)n_queries * hist_n * sizeof(u64);
+  const size_t sz_ex = (size_t)n_queries * sizeof(ExtractArgs);
+  const size_t sz_act = (size_t)n_queries * sizeof(uint32_t);
+  const size_t sz_out = (size_t)n_queries * std::max(1u, length) * sizeof(uint32_t);
+  unsigned char *d_all = nullptr;
+  MSI_HIP_TRY(hipMalloc(&d_all, sz_args + sz_hist + sz_ex + sz_act + sz_out + 64));
+  struct Free {
+    void *p;
+    ~Free() { (void)hipFree(p); }
+  } free_all{d_all};
+  RankArgs *d_args = reinterpret_cast<RankArgs *>(d_all);
+  u64 *d_hist = reinterpret_cast<u64 *>(d_all + sz_args);
+  ExtractArgs *d_ex = reinterpret_cast<ExtractArgs *>(d_all + sz_args + sz_hist);
+  uint32_t *d_act = reinterpret_cast<uint32_t *>(d_all + sz_args + sz_hist + sz_ex);
+  uint32_t *d_out = reinterpret_cast<uint32_t *>(d_all + sz_args + sz_hist + sz_ex + sz_act);
+  const uint64_t n_words = args[0].n_words;
+  const uint32_t gx = std::max(1u, (uint32_t)std::min<uint64_t>((n_words + RT - 1) / RT, 2048));
+  // ---- pass 1: histograms of every query --------------------------------------------------
+  MSI_HIP_TRY(hipMemsetAsync(d_hist, 0, sz_hist, st));
+  for (uint32_t q = 0; q < n_queries; ++q) args[q].hist = d_hist + (size_t)q * hist_n;
+  MSI_HIP_TRY(hipMemcpyAsync(d_args, args.data(), sz_args, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(rank_query_graph_batch_kernel<MODE_HIST>, dim3(gx, n_queries), dim3(RT), 0, st, d_args,
+                     (const uint32_t *)nullptr);
+  std::vector<u64> hist(2 * (size_t)n_queries * hist_n);
+  MSI_HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, (size_t)n_queries * hist_n * sizeof(u64), hipMemcpyDeviceToHost, st));
+  if (use_typo) {
+    MSI_HIP_TRY(hipStreamSynchronize(st));  // args is re-uploaded with the second histogram base
+    for (uint32_t q = 0; q < n_queries; ++q) args[q].hist = d_hist + ((size_t)n_queries + q) * hist_n;
+    MSI_HIP_TRY(hipMemcpyAsync(d_args, args.data(), sz_args, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rank_query_graph_batch_kernel<MODE_STRUCT>, dim3(gx, n_queries), dim3(RT), 0, st, d_args,
+                       (const uint32_t *)nullptr);
+    MSI_HIP_TRY(hipMemcpyAsync(hist.data() + (size_t)n_queries * hist_n, d_hist + (size_t)n_queries * hist_n,
+                               (size_t)n_queries * hist_n * sizeof(u64), hipMemcpyDeviceToHost, st));
+  }
+  MSI_HIP_TRY(hipGetLastError());
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  // ---- plan: which buckets does each query need for [from, from + length)? -------------------
+  struct Need {
+    uint32_t k, t, max_t, skip, want, out_off;
+  };
+  std::vector<std::vector<Need>> needs(n_queries);
+  for (uint32_t q = 0; q < n_queries; ++q) {
+    std::vector<msi_rank_bucket> buckets;
+    hist_to_buckets(hist.data() + (size_t)q * hist_n, hist.data() + ((size_t)n_queries + q) * hist_n,
+                    queries[q].n_terms, buckets);
+    uint64_t total = 0, skipped = 0;
+    for (const auto &b : buckets) total += b.count;
+    if (out_candidates) out_candidates[q] = total;
+    uint32_t written = 0;
+    for (const auto &b : buckets) {
+      if (written >= length) break;
+      if (skipped + b.count <= from) {
+        skipped += b.count;
+        continue;
+      }
+      const uint64_t skip_here = from > skipped ? from - skipped : 0;
+      const uint32_t want = (uint32_t)std::min<uint64_t>(b.count - skip_here, length - written);
+      needs[q].push_back(Need{b.matching_words, b.typo_count, b.max_typo_count, (uint32_t)skip_here, want, written});
+      for (uint32_t i = 0; i < want; ++i) {
+        out_matching_words[(size_t)q * length + written + i] = b.matching_words;
+        out_typo_count[(size_t)q * length + written + i] = b.typo_count;
+        out_max_typo_count[(size_t)q * length + written + i] = b.max_typo_count;
+      }
+      written += want;
+      skipped += b.count;
+    }
+    out_n[q] = written;
+  }
+  // ---- pass 2: rounds of (materialise <= 4 buckets per query, extract) -------------------------
+  std::vector<ExtractArgs> ex(n_queries);
+  std::vector<uint32_t> act(n_queries);
+  for (size_t round = 0;; ++round) {
+    uint32_t n_act = 0;
+    for (uint32_t q = 0; q < n_queries; ++q) {
+      const size_t b0 = round * 4;
+      if (b0 >= needs[q].size()) continue;
+      const uint32_t n_sel = (uint32_t)std::min<size_t>(4, needs[q].size() - b0);
+      ExtractArgs &e = ex[n_act];
+      memset(&e, 0, sizeof(e));
+      for (int i = 0; i < 4; ++i) args[q].sel_k[i] = 0xFFFFFFFFu;
+      for (uint32_t i = 0; i < n_sel; ++i) {
+        const Need &nd = needs[q][b0 + i];
+        args[q].sel_k[i] = nd.k;
+        args[q].sel_t[i] = nd.t;
+        e.slot[i] = args[q].dst[i];
+        e.skip[i] = nd.skip;
+        e.want[i] = nd.want;
+        e.out_off[i] = nd.out_off;
+      }
+      args[q].n_sel = n_sel;
+      e.n_sel = n_sel;
+      e.q_out = q;
+      act[n_act++] = q;
+    }
+    if (n_act == 0) break;
+    MSI_HIP_TRY(hipMemcpyAsync(d_args, args.data(), sz_args, hipMemcpyHostToDevice, st));
+    MSI_HIP_TRY(hipMemcpyAsync(d_act, act.data(), n_act * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    MSI_HIP_TRY(hipMemcpyAsync(d_ex, ex.data(), n_act * sizeof(ExtractArgs), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rank_query_graph_batch_kernel<MODE_MATERIALISE>, dim3(gx, n_act), dim3(RT), 0, st, d_args,
+                       (const uint32_t *)d_act);
+    hipLaunchKernelGGL(rank_extract_kernel, dim3(n_act), dim3(RT), 0, st, (const ExtractArgs *)d_ex, n_words,
+                       length, d_out);
+    MSI_HIP_TRY(hipGetLastError());
+    MSI_HIP_TRY(hipStreamSynchronize(st));  // the host vectors are reused by the next round
+  }
+  if (length)
+    MSI_HIP_TRY(hipMemcpy(out_docids, d_out, (size_t)n_queries * length * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return MSI_OK;
 }
 

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import (EXACT_WORD_FN, PAIR_DOCIDS_FN, WORD_DOCIDS_FN, IndexVtable, KeywordParams, QueryToken, RankBucket,
-                   RankNode, RankTerm, check, lib)
+                   RankNode, RankQuery, RankTerm, check, lib)
 from .device import np_ptr
 
 NO_SLOT = 0xFFFFFFFF
@@ -86,6 +86,37 @@ def rank_materialise(pool, nodes, n_terms, universe_slot, dst_slot, matching_wor
     """One bucket as a docid set in `dst_slot` (the universe handed to the next ranking rule)."""
     check(lib().msi_rank_materialise(pool._h, _node_array(nodes), len(nodes), n_terms, universe_slot, strategy,
                                      1 if use_typo else 0, matching_words, typo_count, dst_slot))
+
+
+class RankBatch:
+    """A prepared batch for msi_rank_query_graph_batch: queries = [(nodes, n_terms, universe_slot,
+    first_of_4_scratch_slots)]; `run` can be called repeatedly (bench)."""
+
+    def __init__(self, pool, queries):
+        self.pool = pool
+        self.n = len(queries)
+        self._node_arrays = [_node_array(q[0]) for q in queries]
+        self._q = (RankQuery * max(self.n, 1))()
+        for i, (nodes, n_terms, uni, scratch) in enumerate(queries):
+            self._q[i].nodes = C.cast(self._node_arrays[i], C.c_void_p)
+            self._q[i].n_nodes = len(nodes)
+            self._q[i].n_terms = n_terms
+            self._q[i].universe_slot = uni
+            self._q[i].scratch_slot = scratch
+
+    def run(self, strategy=TERMS_LAST, use_typo=True, offset=0, limit=20):
+        n, L = self.n, max(limit, 1)
+        self.ids = np.zeros((n, L), dtype=np.uint32)
+        self.words = np.zeros((n, L), dtype=np.uint32)
+        self.typos = np.zeros((n, L), dtype=np.uint32)
+        self.maxt = np.zeros((n, L), dtype=np.uint32)
+        self.counts = np.zeros(n, dtype=np.uint32)
+        self.cand = np.zeros(n, dtype=np.uint64)
+        check(lib().msi_rank_query_graph_batch(self.pool._h, self._q, n, strategy, 1 if use_typo else 0, offset, limit,
+                                               np_ptr(self.ids), np_ptr(self.words), np_ptr(self.typos),
+                                               np_ptr(self.maxt), np_ptr(self.counts), np_ptr(self.cand)))
+        return [[(int(self.ids[q, i]), int(self.words[q, i]), int(self.typos[q, i]), int(self.maxt[q, i]))
+                 for i in range(int(self.counts[q]))] for q in range(n)], self.cand.tolist()
 
 
 class IndexCallbacks:

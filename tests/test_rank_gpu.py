@@ -177,6 +177,47 @@ def test_buckets_and_materialise_for_rules_after_typo(ctx):
     assert buckets[0][:3] == (9, 0, 9) and buckets[1][:3] == (9, 1, 9)
 
 
+def test_batched_rank_equals_single_queries(ctx):
+    # 13 random query graphs over one pool, ranked in ONE batch: every row must equal the
+    # single-query call (which is checked against the brute force above)
+    rng = np.random.default_rng(21)
+    n_docs, nq = 30000, 13
+    per_query_slots = 3 * 12 + 1 + 4
+    pool = ma.BitsPool(ctx, n_docs, nq * per_query_slots + 2)
+    queries, graphs = [], []
+    slot = 0
+    for q in range(nq):
+        n_terms = int(rng.integers(1, 6))
+        uni, scratch = slot, slot + 1
+        slot += 5
+        pool.set_from_docids(uni, np.nonzero(rng.random(n_docs) < 0.9)[0].astype(np.uint32))
+        nodes = []
+        for last in range(n_terms):
+            for size in (1, 2, 3):
+                first = last - size + 1
+                if first < 0 or (size > 1 and rng.random() < 0.5):
+                    continue
+                dens = (0.5, 0.2, 0.1) if size == 1 else (0.05, 0.03, 0.02)
+                sl = []
+                for p_ in dens:
+                    if rng.random() < 0.15:
+                        sl.append(None)
+                        continue
+                    pool.set_from_docids(slot, np.nonzero(rng.random(n_docs) < p_)[0].astype(np.uint32))
+                    sl.append(slot)
+                    slot += 1
+                nodes.append((first, last, sl[0], sl[1], sl[2], int(rng.integers(0, 3))))
+        queries.append((nodes, n_terms, uni, scratch))
+    batch = R.RankBatch(pool, queries)
+    for strategy in (R.TERMS_LAST, R.TERMS_ALL):
+        for use_typo in (True, False):
+            for off, lim in [(0, 20), (7, 300), (0, 1)]:
+                got, cand = batch.run(strategy, use_typo, off, lim)
+                for q, (nodes, n_terms, uni, scratch) in enumerate(queries):
+                    e, ec = R.bucket_sort_query_graph(pool, nodes, n_terms, uni, scratch, strategy, use_typo, off, lim)
+                    assert cand[q] == ec and got[q] == e, (q, strategy, use_typo, off, lim)
+
+
 def test_reference_snapshots_typo_rs(ctx):
     h = Harness(ctx, TYPO_RS_DOCS)
     # typo.rs:462-516: criteria [Typo] (Words is inserted implicitly, search/new/mod.rs:536-551), strategy Last
