@@ -48,6 +48,8 @@ def parse_args():
                          "rows: every rank holds rows/world of the store and scans it for the SAME batch, "
                          "all-gather of per-shard top-k + device merge (strong scaling)")
     ap.add_argument("--no-typo", action="store_true")
+    ap.add_argument("--no-rank", action="store_true",
+                    help="leave the keyword ranking (Words->Typo bucket sort) and the hybrid merge out of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--cpu-sample-words", type=int, default=512)
@@ -131,6 +133,42 @@ def main():
         two_t = torch.zeros((n_words_q, 50), dtype=torch.int32, device=dev)
         one_c = torch.zeros(n_words_q, dtype=torch.int32, device=dev)
         two_c = torch.zeros(n_words_q, dtype=torch.int32, device=dev)
+    # ---- keyword ranking leg: Words -> Typo bucket sort over dense posting sets ---------
+    # Every query has `words_per_query` terms (+ their 2-gram node); a term offers the documents
+    # matching it with 0 / 1 / 2 typos.  18 seeded random posting sets (densities 1 % / 0.2 % /
+    # 0.05 % of the documents, 0.01 % for n-grams) are shared by the queries in different
+    # combinations; all sets are resident in HBM before the timed region, like the store.
+    rank_batch = None
+    if not args.no_rank:
+        from meilisearch_amd import ranking as R
+        n_docs_rank = n_total if row_sharded else n
+        wpq = max(1, min(args.words_per_query, 3))
+        n_sets = 18
+        pool = ma.BitsPool(ctx, n_docs_rank, 1 + n_sets + 4 * Q)
+        pool.fill(0, True)
+        words64 = (n_docs_rank + 63) // 64
+        rng_r = np.random.default_rng(4242)
+        dens = [0.01, 0.002, 0.0005] * 5 + [0.0001] * 3
+        gbits = torch.Generator(device=dev)
+        gbits.manual_seed(4242)
+        for si in range(n_sets):
+            # 64 Bernoulli(p) bits per word: OR of sparse random positions is cheap to make on the device
+            bits = (torch.rand((words64, 64), device=dev, generator=gbits) < dens[si])
+            weights = (2 ** torch.arange(0, 63, device=dev, dtype=torch.int64))
+            w = (bits[:, :63].to(torch.int64) * weights).sum(dim=1)
+            w = torch.where(bits[:, 63], w | torch.tensor(-2 ** 63, device=dev, dtype=torch.int64), w)
+            pool.set_from_words(1 + si, w.cpu().numpy().view(np.uint64))
+            del bits, w
+        rqueries = []
+        for qi in range(Q):
+            nodes = []
+            for ti in range(wpq):
+                base = 1 + 3 * int(rng_r.integers(0, 5))
+                nodes.append((ti, ti, base, base + 1, base + 2, 2 if rng_r.random() < 0.5 else 1))
+                if ti >= 1:
+                    nodes.append((ti - 1, ti, 1 + 15 + int(rng_r.integers(0, 3)), None, None, 1))
+            rqueries.append((nodes, wpq, 0, 1 + n_sets + 4 * qi))
+        rank_batch = R.RankBatch(pool, rqueries)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
@@ -142,6 +180,20 @@ def main():
         m_ids = torch.zeros((Q, k), dtype=torch.int32, device=dev)
         m_dist = torch.zeros((Q, k), dtype=torch.float32, device=dev)
         m_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
+
+    n_terms_arr = np.full(Q, max(1, min(args.words_per_query, 3)), dtype=np.uint32)
+
+    def keyword_and_merge(res):
+        """Keyword leg: one batched Words->Typo bucket sort for the Q queries, then the hybrid
+        merge (ScoreWithRatioResult::merge, semanticRatio 0.5) of every query's two lists."""
+        if rank_batch is None:
+            return res
+        rank_batch.run(R.TERMS_LAST, True, 0, k)
+        merged = ma.scoring.hybrid_merge_batch(res[0].numpy().view(np.uint32), res[1].numpy(),
+                                               res[2].numpy().view(np.uint32), rank_batch.ids, rank_batch.words,
+                                               rank_batch.typos, rank_batch.maxt, rank_batch.counts, n_terms_arr,
+                                               0.5, 0, k)
+        return res + (merged,)
 
     def step():
         store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
@@ -162,11 +214,12 @@ def main():
             res = (m_ids.cpu(), m_dist.cpu(), m_cnt.cpu())
             if gdict is not None:
                 res += (one_c.cpu(), two_c.cpu(), one_t.cpu(), two_t.cpu())
-            return res
+            return keyword_and_merge(res)
         # results to the host (what the Rust caller receives)
         res = (out_ids.cpu(), out_dist.cpu(), out_cnt.cpu())
         if gdict is not None:
             res += (one_c.cpu(), two_c.cpu(), one_t.cpu(), two_t.cpu())
+        res = keyword_and_merge(res)
         if world > 1:
             import torch.distributed as dist
             # the one exchange step: per-rank top-k lists (Q*k*8 bytes) over xGMI (RCCL)
@@ -254,8 +307,11 @@ def main():
             "sharding": ("rows sharded (%d per GPU of %d), same query batch on every GPU, all_gather of per-shard "
                          "top-k (RCCL) + device k-way merge" % (n, n_total)) if row_sharded else
                         "queries sharded, index replicated per GPU, all_gather of per-rank top-k (RCCL)",
-            "step_includes": ["vs_scan + select + reference rescoring", "dict_match + cap logic", "D2H of results"],
-            "step_excludes": ["ranking-rule bucket sort", "hybrid merge"],
+            "step_includes": ["vs_scan + select + reference rescoring", "dict_match + cap logic", "D2H of results"]
+                             + ([] if args.no_rank else ["Words->Typo bucket sort (batched, %d terms + n-grams per query)"
+                                                         % args.words_per_query, "hybrid merge (semanticRatio 0.5)"]),
+            "step_excludes": ["ranking-rule bucket sort", "hybrid merge"] if args.no_rank else
+                             ["ranking rules after Typo (reference CPU path)"],
             "inexact_queries_last_step": n_inexact,
             "setup_seconds": round(setup_s, 1),
         },

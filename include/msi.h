@@ -446,6 +446,18 @@ uint32_t msi_hybrid_merge(const uint32_t *v_docids, const double *v_scores,
                           const uint32_t *k_off, uint32_t n_k, float k_ratio,
                           uint32_t from, uint32_t length, uint32_t *out_docids,
                           uint8_t *out_is_semantic, uint32_t *out_semantic_hit_count);
+/* The same for a batch, straight from the outputs of msi_vs_search (v_*: [n_queries][v_stride])
+ * and msi_rank_query_graph_batch (k_*: [n_queries][k_stride]); scores are computed here:
+ * similarity = 1 - distance, keyword = Rank::global_score of [Words, Typo]. */
+int32_t msi_hybrid_merge_batch(const uint32_t *v_docids, const float *v_dist,
+                               const uint32_t *v_counts, uint32_t v_stride,
+                               const uint32_t *k_docids, const uint32_t *k_matching_words,
+                               const uint32_t *k_typo_count, const uint32_t *k_max_typo_count,
+                               const uint32_t *k_counts, uint32_t k_stride,
+                               const uint32_t *n_terms, uint32_t n_queries, float semantic_ratio,
+                               uint32_t from, uint32_t length, uint32_t *out_docids,
+                               uint8_t *out_is_semantic, uint32_t *out_counts,
+                               uint32_t *out_semantic_hit_counts);
 /* Search::results_good_enough (search/hybrid.rs:367-386). */
 int32_t msi_results_good_enough(const double *keyword_global_scores, uint32_t n,
                                 uint32_t limit_plus_offset, float semantic_ratio);

@@ -138,6 +138,8 @@ PROTOTYPES = {
     "msi_vector_sort": (_U32, [_VP, _VP, _U32, _I32, _F32, _F32, _U32, _U32, _VP, _VP]),
     "msi_hybrid_merge": (_U32, [_VP, _VP, _VP, _U32, _F32, _VP, _VP, _VP, _U32, _F32, _U32, _U32, _VP, _VP,
                                 C.POINTER(_U32)]),
+    "msi_hybrid_merge_batch": (_I32, [_VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP, _U32, _VP, _U32, _F32, _U32, _U32,
+                                      _VP, _VP, _VP, _VP]),
     "msi_results_good_enough": (_I32, [_VP, _U32, _U32, _F32]),
     "msi_keyword_search": (_I32, [_VP, _VP, C.POINTER(IndexVtable), C.POINTER(QueryToken), _U32,
                                   C.POINTER(KeywordParams), _VP, C.c_size_t, _VP, _VP, _VP, _VP,

@@ -15,6 +15,7 @@
 #include <math.h>
 #include <float.h>
 
+#include <algorithm>
 #include <unordered_set>
 #include <vector>
 
@@ -68,6 +69,56 @@ uint32_t msi_hybrid_merge(const uint32_t *v_docids, const double *v_scores, cons
   }
   if (out_semantic_hit_count) *out_semantic_hit_count = semantic;
   return written;
+}
+
+// The hybrid tail for a whole batch, straight from the outputs of msi_vs_search and
+// msi_rank_query_graph_batch: vector hit score = similarity = 1 - distance (vector_sort.rs:86),
+// keyword hit score = Rank::global_score of [Words{matching_words, n_terms},
+// Typo{typo_count, max_typo_count}] (score_details.rs:440-547), then
+// ScoreWithRatioResult::merge per query.
+int32_t msi_hybrid_merge_batch(const uint32_t *v_docids, const float *v_dist, const uint32_t *v_counts,
+                               uint32_t v_stride, const uint32_t *k_docids, const uint32_t *k_matching_words,
+                               const uint32_t *k_typo_count, const uint32_t *k_max_typo_count,
+                               const uint32_t *k_counts, uint32_t k_stride, const uint32_t *n_terms,
+                               uint32_t n_queries, float semantic_ratio, uint32_t from, uint32_t length,
+                               uint32_t *out_docids, uint8_t *out_is_semantic, uint32_t *out_counts,
+                               uint32_t *out_semantic_hit_counts) {
+  if (!v_docids || !v_dist || !v_counts || !k_docids || !k_matching_words || !k_typo_count || !k_max_typo_count ||
+      !k_counts || !n_terms || !out_docids || !out_counts) {
+    msi_set_error("msi_hybrid_merge_batch: invalid argument");
+    return MSI_E_INVALID;
+  }
+  std::vector<double> vs, ks;
+  std::vector<uint32_t> voff, koff;
+  for (uint32_t q = 0; q < n_queries; ++q) {
+    const uint32_t nv = std::min(v_counts[q], v_stride), nk = std::min(k_counts[q], k_stride);
+    vs.resize(nv);
+    ks.resize(nk);
+    voff.resize(nv + 1);
+    koff.resize(nk + 1);
+    for (uint32_t i = 0; i < nv; ++i) {
+      volatile float sim = 1.0f - v_dist[(size_t)q * v_stride + i];
+      vs[i] = (double)sim;
+      voff[i] = i;
+    }
+    voff[nv] = nv;
+    for (uint32_t i = 0; i < nk; ++i) {
+      const size_t at = (size_t)q * k_stride + i;
+      const uint32_t mt = k_max_typo_count[at];
+      const uint32_t ranks[2] = {k_matching_words[at], mt + 1 - std::min(k_typo_count[at], mt + 1)};
+      const uint32_t maxs[2] = {n_terms[q], mt + 1};
+      ks[i] = msi_rank_global_score(ranks, maxs, 2);
+      koff[i] = i;
+    }
+    koff[nk] = nk;
+    uint32_t sem = 0;
+    out_counts[q] = msi_hybrid_merge(v_docids + (size_t)q * v_stride, vs.data(), voff.data(), nv, semantic_ratio,
+                                     k_docids + (size_t)q * k_stride, ks.data(), koff.data(), nk,
+                                     1.0f - semantic_ratio, from, length, out_docids + (size_t)q * length,
+                                     out_is_semantic ? out_is_semantic + (size_t)q * length : nullptr, &sem);
+    if (out_semantic_hit_counts) out_semantic_hit_counts[q] = sem;
+  }
+  return MSI_OK;
 }
 
 int32_t msi_results_good_enough(const double *keyword_global_scores, uint32_t n, uint32_t limit_plus_offset,

@@ -61,18 +61,23 @@ constexpr int RT = 256;
 // Node of the query graph that ENDS at term position p (1-based end): kind 0 = the
 // single term p-1, kind 1 = the 2-gram of terms p-2..p-1, kind 2 = the 3-gram
 // (query_graph.rs:96-180).  An n-gram has the base typo cost n (typo/mod.rs:41-45).
+// level[s] is ALWAYS a readable pointer (the universe when the set is absent) and
+// mask[s] is ~0 / 0, so the loads of a word are unconditional and issue back to back.
 struct NodeArg {
-  const u64 *level[3];   // nullptr = empty set / node absent
+  uint32_t level[3];     // offset of the set inside the pool, in 64-bit words (the universe's when absent)
+  uint32_t present;      // bit s = level s exists
   uint32_t max_cost;     // 0..2 ; 0xFFFFFFFF = node absent
 };
 
 struct RankArgs {
   NodeArg node[NT_MAX][3];   // [end position - 1][kind]
+  const u64 *pool;           // slot 0 of the pool; sets are addressed by 32-bit word offsets
   const u64 *universe;
   uint64_t n_words;
   uint32_t n_terms;
   uint32_t strategy_all;
   uint32_t use_typo;
+  uint32_t tmax;             // largest total cost any path of this query can have (<= TC_MAX)
   u64 *hist;                 // [NT_MAX + 1][TC_MAX + 1]
   u64 *dst[4];               // materialise: up to 4 buckets per pass
   uint32_t sel_k[4], sel_t[4];
@@ -84,89 +89,98 @@ enum { MODE_HIST = 0, MODE_STRUCT = 1, MODE_MATERIALISE = 2 };
 // MODE_HIST         histogram of every (kept terms, total typo cost) bucket
 // MODE_STRUCT       histogram of (kept terms, largest possible cost of a matched path): the
 //                   Typo rule's max_typo_count for that Words bucket
-// MODE_MATERIALISE  write bucket (sel_k, sel_t) to dst
-template <int MODE>
+// MODE_MATERIALISE  write up to 4 selected buckets to dst[]
+// NT / TC: compile-time bounds on the number of terms and on the total cost (the host
+// picks the smallest instantiation that fits the query), so small queries keep every
+// posting word of a document block in registers and run short cost loops.
+template <int MODE, int NT, int TC>
 __device__ __forceinline__ void rank_body(const RankArgs &a, uint32_t *s_hist) {
   if (MODE != MODE_MATERIALISE) {
     for (uint32_t i = threadIdx.x; i < (NT_MAX + 1) * (TC_MAX + 1); i += RT) s_hist[i] = 0;
     __syncthreads();
   }
+  const int n_terms = (int)a.n_terms;
+  const int tmax = (int)a.tmax;
   const uint64_t stride = (uint64_t)gridDim.x * RT;
   for (uint64_t w = (uint64_t)blockIdx.x * RT + threadIdx.x; w < a.n_words; w += stride) {
+    // ---- all posting words of this document block, unconditional loads ------------
     const u64 U = a.universe[w];
+    u64 L[NT][3][3];
+#pragma unroll
+    for (int p = 1; p <= NT; ++p)
+#pragma unroll
+      for (int kind = 0; kind < 3; ++kind)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          if (kind < p) {
+            // wave-uniform offset -> scalar register; the load itself is unconditional
+            const uint32_t off = __builtin_amdgcn_readfirstlane(a.node[p - 1][kind].level[s]);
+            const uint32_t on = __builtin_amdgcn_readfirstlane(a.node[p - 1][kind].present) >> s & 1u;
+            const u64 v = a.pool[(uint32_t)(off + (uint32_t)w)];
+            L[p - 1][kind][s] = on ? v : 0ull;
+          } else {
+            L[p - 1][kind][s] = 0ull;
+          }
     // ---- sweep 1: which positions does a document reach (any typo level)? --------
-    u64 R[NT_MAX + 1];
+    u64 R[NT + 1];
     R[0] = U;
 #pragma unroll
-    for (int p = 1; p <= NT_MAX; ++p) {
+    for (int p = 1; p <= NT; ++p) {
       u64 r = 0;
-      if (p <= (int)a.n_terms) {
 #pragma unroll
-        for (int kind = 0; kind < 3; ++kind) {
-          if (kind < p) {
-            const NodeArg &nd = a.node[p - 1][kind];
-            if (nd.max_cost != 0xFFFFFFFFu) {
-              u64 any = 0;
-#pragma unroll
-              for (int s = 0; s < 3; ++s)
-                if (nd.level[s] && s <= (int)nd.max_cost) any |= nd.level[s][w];
-              r |= R[p - 1 - kind] & any;
-            }
-          }
-        }
-      }
-      R[p] = r;
+      for (int kind = 0; kind < 3; ++kind)
+        if (kind < p) r |= R[p - 1 - kind] & (L[p - 1][kind][0] | L[p - 1][kind][1] | L[p - 1][kind][2]);
+      R[p] = r;   // masks are 0 beyond n_terms
     }
     // D[p] = documents whose LONGEST matched prefix is p terms (Words bucket n - p)
     u64 later = 0;
-    u64 D[NT_MAX + 1];
+    u64 D[NT + 1];
 #pragma unroll
-    for (int p = NT_MAX; p >= 1; --p) {
+    for (int p = NT; p >= 1; --p) {
       u64 d = 0;
-      if (p <= (int)a.n_terms && (p == (int)a.n_terms || !a.strategy_all)) d = R[p] & ~later;
+      if (p <= n_terms && (p == n_terms || !a.strategy_all)) d = R[p] & ~later;
       D[p] = d;
       later |= R[p];
     }
     // ---- sweep 2: cost DP over positions, rolling window of 4 ---------------------
-    u64 F[4][TC_MAX + 1];   // F[i] = position p-1-i after the shift below
+    u64 F[4][TC + 1];   // F[i] = position p-1-i after the shift below
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int t = 0; t <= TC_MAX; ++t) F[i][t] = 0;
+      for (int t = 0; t <= TC; ++t) F[i][t] = 0;
     F[0][0] = U;
     u64 out[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int p = 1; p <= NT_MAX; ++p) {
-      if (p <= (int)a.n_terms) {
-        u64 G[TC_MAX + 1];
+    for (int p = 1; p <= NT; ++p) {
+      if (p <= n_terms) {
+        u64 G[TC + 1];
 #pragma unroll
-        for (int t = 0; t <= TC_MAX; ++t) G[t] = 0;
+        for (int t = 0; t <= TC; ++t) G[t] = 0;
 #pragma unroll
         for (int kind = 0; kind < 3; ++kind) {
           if (kind < p) {
-            const NodeArg &nd = a.node[p - 1][kind];
-            if (nd.max_cost != 0xFFFFFFFFu) {
+            const uint32_t mc = a.node[p - 1][kind].max_cost;
+            if (mc != 0xFFFFFFFFu) {
               const int base = kind == 0 ? 0 : kind + 1;
               if (MODE == MODE_STRUCT) {
-                u64 any = 0;
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-                  if (nd.level[s] && s <= (int)nd.max_cost) any |= nd.level[s][w];
-                // one pseudo level: the node's largest cost (max_cost is wave-uniform)
+                const u64 any = L[p - 1][kind][0] | L[p - 1][kind][1] | L[p - 1][kind][2];
+                // one pseudo level: the node's largest cost (wave-uniform)
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                  if (s == (int)nd.max_cost) {
+                  if (s == (int)mc) {
 #pragma unroll
-                    for (int t = base + s; t <= TC_MAX; ++t) G[t] |= F[kind][t - base - s] & any;
+                    for (int t = base + s; t <= TC; ++t)
+                      if (t <= tmax) G[t] |= F[kind][t - base - s] & any;
                   }
                 }
               } else {
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                  if (nd.level[s] && s <= (int)nd.max_cost) {
-                    const u64 lv = nd.level[s][w];
+                  if (s <= (int)mc) {
+                    const u64 lv = L[p - 1][kind][s];
 #pragma unroll
-                    for (int t = base + s; t <= TC_MAX; ++t) G[t] |= F[kind][t - base - s] & lv;
+                    for (int t = base + s; t <= TC; ++t)
+                      if (t <= tmax) G[t] |= F[kind][t - base - s] & lv;
                   }
                 }
               }
@@ -175,34 +189,40 @@ __device__ __forceinline__ void rank_body(const RankArgs &a, uint32_t *s_hist) {
         }
         // shift the window: F[0] becomes position p
 #pragma unroll
-        for (int t = 0; t <= TC_MAX; ++t) {
-          F[3][t] = F[2][t];
-          F[2][t] = F[1][t];
-          F[1][t] = F[0][t];
-          F[0][t] = G[t];
+        for (int t = 0; t <= TC; ++t) {
+          if (t <= tmax) {
+            F[3][t] = F[2][t];
+            F[2][t] = F[1][t];
+            F[1][t] = F[0][t];
+            F[0][t] = G[t];
+          }
         }
         const u64 Dp = D[p];
         if (MODE == MODE_STRUCT) {
           // largest structural cost of a path that matches the document
           u64 seen = 0;
 #pragma unroll
-          for (int t = TC_MAX; t >= 0; --t) {
-            const u64 b = Dp & F[0][t] & ~seen;
-            seen |= F[0][t];
-            if (b) atomicAdd(&s_hist[p * (TC_MAX + 1) + t], (uint32_t)__popcll(b));
+          for (int t = TC; t >= 0; --t) {
+            if (t <= tmax) {
+              const u64 b = Dp & F[0][t] & ~seen;
+              seen |= F[0][t];
+              if (b) atomicAdd(&s_hist[p * (TC_MAX + 1) + t], (uint32_t)__popcll(b));
+            }
           }
         } else if (a.use_typo) {
           u64 seen = 0;
 #pragma unroll
-          for (int t = 0; t <= TC_MAX; ++t) {
-            const u64 b = Dp & F[0][t] & ~seen;
-            seen |= F[0][t];
-            if (MODE == MODE_MATERIALISE) {
+          for (int t = 0; t <= TC; ++t) {
+            if (t <= tmax) {
+              const u64 b = Dp & F[0][t] & ~seen;
+              seen |= F[0][t];
+              if (MODE == MODE_MATERIALISE) {
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if ((uint32_t)p == a.sel_k[i] && (uint32_t)t == a.sel_t[i]) out[i] = b;
-            } else if (b) {
-              atomicAdd(&s_hist[p * (TC_MAX + 1) + t], (uint32_t)__popcll(b));
+                for (int i = 0; i < 4; ++i)
+                  if ((uint32_t)p == a.sel_k[i] && (uint32_t)t == a.sel_t[i]) out[i] = b;
+              } else if (b) {
+                atomicAdd(&s_hist[p * (TC_MAX + 1) + t], (uint32_t)__popcll(b));
+              }
             }
           }
         } else {
@@ -229,14 +249,14 @@ __device__ __forceinline__ void rank_body(const RankArgs &a, uint32_t *s_hist) {
   }
 }
 
-template <int MODE>
+template <int MODE, int NT, int TC>
 __global__ __launch_bounds__(RT) void rank_query_graph_kernel(RankArgs a) {
   __shared__ uint32_t s_hist[(NT_MAX + 1) * (TC_MAX + 1)];
-  rank_body<MODE>(a, s_hist);
+  rank_body<MODE, NT, TC>(a, s_hist);
 }
 
 // Batched form: blockIdx.y selects the query; its arguments live in HBM and are staged in LDS.
-template <int MODE>
+template <int MODE, int NT, int TC>
 __global__ __launch_bounds__(RT) void rank_query_graph_batch_kernel(const RankArgs *__restrict__ args,
                                                                     const uint32_t *__restrict__ active) {
   __shared__ uint32_t s_hist[(NT_MAX + 1) * (TC_MAX + 1)];
@@ -246,8 +266,25 @@ __global__ __launch_bounds__(RT) void rank_query_graph_batch_kernel(const RankAr
   uint32_t *dst = reinterpret_cast<uint32_t *>(&sa);
   for (uint32_t i = threadIdx.x; i < sizeof(RankArgs) / 4; i += RT) dst[i] = src[i];
   __syncthreads();
-  rank_body<MODE>(sa, s_hist);
+  rank_body<MODE, NT, TC>(sa, s_hist);
 }
+
+// Size classes: (terms, total cost) bounds of the instantiations.
+struct RankClass {
+  int nt, tc;
+};
+constexpr RankClass RANK_CLASSES[3] = {{3, 8}, {6, 14}, {NT_MAX, TC_MAX}};
+inline int rank_class_of(uint32_t n_terms, uint32_t tmax) {
+  for (int c = 0; c < 3; ++c)
+    if ((int)n_terms <= RANK_CLASSES[c].nt && (int)tmax <= RANK_CLASSES[c].tc) return c;
+  return 2;
+}
+#define MSI_RANK_DISPATCH(CLS, CALL)                      \
+  switch (CLS) {                                          \
+    case 0: { constexpr int NT_ = 3, TC_ = 8; CALL; } break;   \
+    case 1: { constexpr int NT_ = 6, TC_ = 14; CALL; } break;  \
+    default: { constexpr int NT_ = NT_MAX, TC_ = TC_MAX; CALL; } break; \
+  }
 
 // Ascending docids of up to 4 materialised buckets of one query, in bucket order:
 // one workgroup walks each bucket's bitmap 256 words at a time (popcount + block
@@ -262,7 +299,7 @@ __global__ __launch_bounds__(RT) void rank_extract_kernel(const ExtractArgs *__r
                                                           uint32_t length, uint32_t *__restrict__ out) {
   __shared__ uint32_t sh[RT];
   __shared__ uint32_t s_run;
-  const ExtractArgs e = ex[blockIdx.x];
+  const ExtractArgs &e = ex[blockIdx.x];   // read through the pointer: no private copy
   for (uint32_t i = 0; i < e.n_sel; ++i) {
     if (threadIdx.x == 0) s_run = 0;
     __syncthreads();
@@ -314,8 +351,19 @@ int32_t build_args(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes,
     return MSI_E_INVALID;
   }
   memset(&a, 0, sizeof(a));
+  a.universe = msi_bits_slot_ptr(pool, universe_slot);
+  a.pool = msi_bits_slot_ptr(pool, 0);
+  const uint64_t wps = msi_bits_words_per_slot(pool);
+  if ((uint64_t)n_slots * wps > 0xFFFFFFFFull) {
+    msi_set_error("msi_rank: pool larger than 2^32 words (32 GiB)");
+    return MSI_E_UNSUPPORTED;
+  }
   for (int p = 0; p < NT_MAX; ++p)
-    for (int kind = 0; kind < 3; ++kind) a.node[p][kind].max_cost = 0xFFFFFFFFu;
+    for (int kind = 0; kind < 3; ++kind) {
+      a.node[p][kind].max_cost = 0xFFFFFFFFu;
+      a.node[p][kind].present = 0;
+      for (int s = 0; s < 3; ++s) a.node[p][kind].level[s] = (uint32_t)(universe_slot * wps);  // readable placeholder
+    }
   for (uint32_t i = 0; i < n_nodes; ++i) {
     const msi_rank_node &nd = nodes[i];
     if (nd.last_term >= n_terms || nd.first_term > nd.last_term || nd.last_term - nd.first_term > 2 ||
@@ -336,14 +384,31 @@ int32_t build_args(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes,
         msi_set_error("msi_rank: node %u level %d slot %u invalid", i, s, sl);
         return MSI_E_INVALID;
       }
-      na.level[s] = msi_bits_slot_ptr(pool, sl);
+      if ((uint32_t)s > nd.max_typo_cost) continue;   // edges exist for 0..=max_typo_cost only
+      na.level[s] = (uint32_t)(sl * wps);
+      na.present |= 1u << s;
     }
   }
-  a.universe = msi_bits_slot_ptr(pool, universe_slot);
   a.n_words = msi_bits_words_per_slot(pool);
   a.n_terms = n_terms;
   a.strategy_all = strategy == MSI_TERMS_ALL;
   a.use_typo = use_typo != 0;
+  // largest total cost of any path: longest-path DP over positions
+  {
+    int best[NT_MAX + 1];
+    for (int p = 0; p <= NT_MAX; ++p) best[p] = -1;
+    best[0] = 0;
+    for (uint32_t p = 1; p <= n_terms; ++p)
+      for (int kind = 0; kind < 3 && kind < (int)p; ++kind) {
+        const NodeArg &na = a.node[p - 1][kind];
+        if (na.max_cost == 0xFFFFFFFFu || best[p - 1 - kind] < 0) continue;
+        const int c = best[p - 1 - kind] + (kind == 0 ? 0 : kind + 1) + (int)na.max_cost;
+        best[p] = std::max(best[p], c);
+      }
+    int tm = 0;
+    for (uint32_t p = 1; p <= n_terms; ++p) tm = std::max(tm, best[p]);
+    a.tmax = (uint32_t)std::min(tm, TC_MAX);
+  }
   a.dst[0] = msi_bits_slot_ptr(pool, forbidden_slot);
   a.n_sel = 1;
   for (int i = 0; i < 4; ++i) a.sel_k[i] = 0xFFFFFFFFu;
@@ -351,7 +416,8 @@ int32_t build_args(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes,
 }
 
 uint32_t rank_grid(msi_ctx *ctx, const RankArgs &a) {
-  return std::max(1u, (uint32_t)std::min<uint64_t>((a.n_words + RT - 1) / RT, (uint64_t)ctx->n_cu * 8));
+  // >= 8 words per thread so the per-workgroup histogram set-up and flush amortise
+  return std::max(1u, (uint32_t)std::min<uint64_t>((a.n_words + 8 * RT - 1) / (8 * RT), (uint64_t)ctx->n_cu * 8));
 }
 
 void hist_to_buckets_impl(const u64 *hist, const u64 *hist_struct, uint32_t n_terms, std::vector<msi_rank_bucket> &out);
@@ -375,10 +441,11 @@ int32_t list_buckets(msi_bits *pool, RankArgs &a, uint32_t n_terms, std::vector<
   MSI_HIP_TRY(hipMemsetAsync(d_hist, 0, 2 * hist_n * sizeof(u64), st));
   const uint32_t grid = rank_grid(ctx, a);
   a.hist = d_hist;
-  hipLaunchKernelGGL(rank_query_graph_kernel<MODE_HIST>, dim3(grid), dim3(RT), 0, st, a);
+  const int cls = rank_class_of(a.n_terms, a.tmax);
+  MSI_RANK_DISPATCH(cls, hipLaunchKernelGGL((rank_query_graph_kernel<MODE_HIST, NT_, TC_>), dim3(grid), dim3(RT), 0, st, a));
   if (a.use_typo) {
     a.hist = d_hist + hist_n;
-    hipLaunchKernelGGL(rank_query_graph_kernel<MODE_STRUCT>, dim3(grid), dim3(RT), 0, st, a);
+    MSI_RANK_DISPATCH(cls, hipLaunchKernelGGL((rank_query_graph_kernel<MODE_STRUCT, NT_, TC_>), dim3(grid), dim3(RT), 0, st, a));
   }
   MSI_HIP_TRY(hipGetLastError());
   std::vector<u64> hist(2 * hist_n);
@@ -425,7 +492,9 @@ int32_t materialise(msi_bits *pool, RankArgs &a, uint32_t k, uint32_t t) {
   a.sel_k[0] = k;
   a.sel_t[0] = t;
   a.n_sel = 1;
-  hipLaunchKernelGGL(rank_query_graph_kernel<MODE_MATERIALISE>, dim3(rank_grid(ctx, a)), dim3(RT), 0, ctx->stream, a);
+  const int cls = rank_class_of(a.n_terms, a.tmax);
+  MSI_RANK_DISPATCH(cls, hipLaunchKernelGGL((rank_query_graph_kernel<MODE_MATERIALISE, NT_, TC_>),
+                                            dim3(rank_grid(ctx, a)), dim3(RT), 0, ctx->stream, a));
   MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
 }
@@ -546,21 +615,23 @@ int32_t msi_rank_query_graph_batch(msi_bits *pool, const msi_rank_query *queries
   uint32_t *d_act = reinterpret_cast<uint32_t *>(d_all + sz_args + sz_hist + sz_ex);
   uint32_t *d_out = reinterpret_cast<uint32_t *>(d_all + sz_args + sz_hist + sz_ex + sz_act);
   const uint64_t n_words = args[0].n_words;
-  const uint32_t gx = std::max(1u, (uint32_t)std::min<uint64_t>((n_words + RT - 1) / RT, 2048));
+  const uint32_t gx = std::max(1u, (uint32_t)std::min<uint64_t>((n_words + 8 * RT - 1) / (8 * RT), 2048));
   // ---- pass 1: histograms of every query --------------------------------------------------
   MSI_HIP_TRY(hipMemsetAsync(d_hist, 0, sz_hist, st));
   for (uint32_t q = 0; q < n_queries; ++q) args[q].hist = d_hist + (size_t)q * hist_n;
   MSI_HIP_TRY(hipMemcpyAsync(d_args, args.data(), sz_args, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(rank_query_graph_batch_kernel<MODE_HIST>, dim3(gx, n_queries), dim3(RT), 0, st, d_args,
-                     (const uint32_t *)nullptr);
+  int cls = 0;   // one size class for the batch: the largest any query needs
+  for (uint32_t q = 0; q < n_queries; ++q) cls = std::max(cls, rank_class_of(args[q].n_terms, args[q].tmax));
+  MSI_RANK_DISPATCH(cls, hipLaunchKernelGGL((rank_query_graph_batch_kernel<MODE_HIST, NT_, TC_>), dim3(gx, n_queries),
+                                            dim3(RT), 0, st, d_args, (const uint32_t *)nullptr));
   std::vector<u64> hist(2 * (size_t)n_queries * hist_n);
   MSI_HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, (size_t)n_queries * hist_n * sizeof(u64), hipMemcpyDeviceToHost, st));
   if (use_typo) {
     MSI_HIP_TRY(hipStreamSynchronize(st));  // args is re-uploaded with the second histogram base
     for (uint32_t q = 0; q < n_queries; ++q) args[q].hist = d_hist + ((size_t)n_queries + q) * hist_n;
     MSI_HIP_TRY(hipMemcpyAsync(d_args, args.data(), sz_args, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(rank_query_graph_batch_kernel<MODE_STRUCT>, dim3(gx, n_queries), dim3(RT), 0, st, d_args,
-                       (const uint32_t *)nullptr);
+    MSI_RANK_DISPATCH(cls, hipLaunchKernelGGL((rank_query_graph_batch_kernel<MODE_STRUCT, NT_, TC_>),
+                                              dim3(gx, n_queries), dim3(RT), 0, st, d_args, (const uint32_t *)nullptr));
     MSI_HIP_TRY(hipMemcpyAsync(hist.data() + (size_t)n_queries * hist_n, d_hist + (size_t)n_queries * hist_n,
                                (size_t)n_queries * hist_n * sizeof(u64), hipMemcpyDeviceToHost, st));
   }
@@ -628,8 +699,8 @@ int32_t msi_rank_query_graph_batch(msi_bits *pool, const msi_rank_query *queries
     MSI_HIP_TRY(hipMemcpyAsync(d_args, args.data(), sz_args, hipMemcpyHostToDevice, st));
     MSI_HIP_TRY(hipMemcpyAsync(d_act, act.data(), n_act * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     MSI_HIP_TRY(hipMemcpyAsync(d_ex, ex.data(), n_act * sizeof(ExtractArgs), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(rank_query_graph_batch_kernel<MODE_MATERIALISE>, dim3(gx, n_act), dim3(RT), 0, st, d_args,
-                       (const uint32_t *)d_act);
+    MSI_RANK_DISPATCH(cls, hipLaunchKernelGGL((rank_query_graph_batch_kernel<MODE_MATERIALISE, NT_, TC_>),
+                                              dim3(gx, n_act), dim3(RT), 0, st, d_args, (const uint32_t *)d_act));
     hipLaunchKernelGGL(rank_extract_kernel, dim3(n_act), dim3(RT), 0, st, (const ExtractArgs *)d_ex, n_words,
                        length, d_out);
     MSI_HIP_TRY(hipGetLastError());

@@ -115,8 +115,12 @@ class RankBatch:
         check(lib().msi_rank_query_graph_batch(self.pool._h, self._q, n, strategy, 1 if use_typo else 0, offset, limit,
                                                np_ptr(self.ids), np_ptr(self.words), np_ptr(self.typos),
                                                np_ptr(self.maxt), np_ptr(self.counts), np_ptr(self.cand)))
+        return self
+
+    def rows(self):
+        """Results of the last run as [[(docid, matching_words, typo_count, max_typo_count)]], candidates."""
         return [[(int(self.ids[q, i]), int(self.words[q, i]), int(self.typos[q, i]), int(self.maxt[q, i]))
-                 for i in range(int(self.counts[q]))] for q in range(n)], self.cand.tolist()
+                 for i in range(int(self.counts[q]))] for q in range(self.n)], self.cand.tolist()
 
 
 class IndexCallbacks:

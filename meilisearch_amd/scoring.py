@@ -71,3 +71,24 @@ def results_good_enough(keyword_global_scores, limit_plus_offset, semantic_ratio
     s = np.array(keyword_global_scores, dtype=np.float64)
     return bool(lib().msi_results_good_enough(np_ptr(s) if s.size else None, s.size, limit_plus_offset,
                                               semantic_ratio))
+
+
+def hybrid_merge_batch(v_docids, v_dist, v_counts, k_docids, k_words, k_typos, k_maxt, k_counts, n_terms,
+                       semantic_ratio, offset=0, limit=20):
+    """msi_hybrid_merge_batch over [Q, stride] arrays -> (docids [Q, limit], is_semantic, counts, semantic_hits)."""
+    from ._lib import check
+    q = v_docids.shape[0]
+    arrs = [np.ascontiguousarray(a, dtype=t) for a, t in
+            ((v_docids, np.uint32), (v_dist, np.float32), (v_counts, np.uint32), (k_docids, np.uint32),
+             (k_words, np.uint32), (k_typos, np.uint32), (k_maxt, np.uint32), (k_counts, np.uint32),
+             (n_terms, np.uint32))]
+    out_d = np.zeros((q, max(limit, 1)), dtype=np.uint32)
+    out_s = np.zeros((q, max(limit, 1)), dtype=np.uint8)
+    out_c = np.zeros(q, dtype=np.uint32)
+    out_h = np.zeros(q, dtype=np.uint32)
+    check(lib().msi_hybrid_merge_batch(np_ptr(arrs[0]), np_ptr(arrs[1]), np_ptr(arrs[2]), arrs[0].shape[1],
+                                       np_ptr(arrs[3]), np_ptr(arrs[4]), np_ptr(arrs[5]), np_ptr(arrs[6]),
+                                       np_ptr(arrs[7]), arrs[3].shape[1], np_ptr(arrs[8]), q,
+                                       np.float32(semantic_ratio), offset, limit, np_ptr(out_d), np_ptr(out_s),
+                                       np_ptr(out_c), np_ptr(out_h)))
+    return out_d, out_s, out_c, out_h

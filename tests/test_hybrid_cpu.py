@@ -97,3 +97,29 @@ def test_results_good_enough():
     assert not ma.scoring.results_good_enough([0.95, 0.89], 2, 0.5)      # 0.89 * 0.5 < 0.45
     assert not ma.scoring.results_good_enough([0.95], 2, 0.5)            # not enough hits
     assert not ma.scoring.results_good_enough([1.0, 1.0], 2, 0.9)
+
+
+def test_hybrid_merge_batch_equals_per_query():
+    import meilisearch_amd as ma
+    rng = np.random.default_rng(9)
+    Q, k = 11, 8
+    v_ids = np.stack([rng.choice(50, k, replace=False) for _ in range(Q)]).astype(np.uint32)
+    v_dist = np.sort(rng.random((Q, k)).astype(np.float32) * 0.5, axis=1)
+    v_cnt = rng.integers(0, k + 1, Q).astype(np.uint32)
+    k_ids = np.stack([rng.choice(50, k, replace=False) for _ in range(Q)]).astype(np.uint32)
+    n_terms = rng.integers(1, 5, Q).astype(np.uint32)
+    k_words = np.sort(np.stack([rng.integers(1, n_terms[q] + 1, k) for q in range(Q)]), axis=1)[:, ::-1].astype(np.uint32)
+    k_maxt = np.full((Q, k), 3, dtype=np.uint32)
+    k_typos = rng.integers(0, 4, (Q, k)).astype(np.uint32)
+    k_cnt = rng.integers(0, k + 1, Q).astype(np.uint32)
+    for ratio in (0.0, 0.5, 0.9):
+        d, s, c, h = ma.scoring.hybrid_merge_batch(v_ids, v_dist, v_cnt, k_ids, k_words, k_typos, k_maxt, k_cnt,
+                                                    n_terms, ratio, 1, 6)
+        for q in range(Q):
+            vh = [(int(v_ids[q, i]), [float(f32(1.0) - v_dist[q, i])]) for i in range(int(v_cnt[q]))]
+            kh = [(int(k_ids[q, i]), [ma.scoring.rank_global_score([(int(k_words[q, i]), int(n_terms[q])),
+                                                                      (int(k_maxt[q, i] + 1 - k_typos[q, i]), int(k_maxt[q, i] + 1))])])
+                  for i in range(int(k_cnt[q]))]
+            exp, sem = ma.scoring.hybrid_merge(vh, kh, ratio, 1, 6)
+            assert c[q] == len(exp) and h[q] == sem
+            assert [(int(d[q, i]), bool(s[q, i])) for i in range(int(c[q]))] == exp

@@ -212,7 +212,7 @@ def test_batched_rank_equals_single_queries(ctx):
     for strategy in (R.TERMS_LAST, R.TERMS_ALL):
         for use_typo in (True, False):
             for off, lim in [(0, 20), (7, 300), (0, 1)]:
-                got, cand = batch.run(strategy, use_typo, off, lim)
+                got, cand = batch.run(strategy, use_typo, off, lim).rows()
                 for q, (nodes, n_terms, uni, scratch) in enumerate(queries):
                     e, ec = R.bucket_sort_query_graph(pool, nodes, n_terms, uni, scratch, strategy, use_typo, off, lim)
                     assert cand[q] == ec and got[q] == e, (q, strategy, use_typo, off, lim)
