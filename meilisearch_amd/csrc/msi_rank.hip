@@ -416,8 +416,9 @@ int32_t build_args(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes,
 }
 
 uint32_t rank_grid(msi_ctx *ctx, const RankArgs &a) {
-  // >= 8 words per thread so the per-workgroup histogram set-up and flush amortise
-  return std::max(1u, (uint32_t)std::min<uint64_t>((a.n_words + 8 * RT - 1) / (8 * RT), (uint64_t)ctx->n_cu * 8));
+  // single query: fill the chip first (one word per thread until ~4 workgroups per CU),
+  // then grow the per-thread share so the histogram set-up and flush amortise
+  return std::max(1u, (uint32_t)std::min<uint64_t>((a.n_words + RT - 1) / RT, (uint64_t)ctx->n_cu * 4));
 }
 
 void hist_to_buckets_impl(const u64 *hist, const u64 *hist_struct, uint32_t n_terms, std::vector<msi_rank_bucket> &out);
