@@ -228,6 +228,13 @@ int32_t msi_dict_lookup(msi_dict *dict, const msi_typo_query *queries,
                         uint32_t *out_one_idx, uint32_t *out_one_cnt,
                         uint32_t *out_two_idx, uint32_t *out_two_cnt);
 
+/* Micro-batching of concurrent callers (every search derives the typos of its few words
+ * with one small lookup): with max_wait_us > 0, calls of fewer than `target_words` words
+ * that arrive within that window and use the same caps are fused into one launch. */
+int32_t msi_dict_set_microbatch(msi_dict *dict, uint32_t max_wait_us, uint32_t target_words);
+int32_t msi_dict_microbatch_stats(msi_dict *dict, uint64_t *out_fused_calls,
+                                  uint64_t *out_fused_launches);
+
 /* Packed device-side form: words are concatenated in `d_qbytes`, described by
  * d_qoff[n+1], d_qflags[n] = max_typos | is_prefix<<2.  Outputs are device
  * memory; work is enqueued on msi_ctx_stream() and NOT synchronised. */

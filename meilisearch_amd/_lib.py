@@ -113,6 +113,8 @@ PROTOTYPES = {
     "msi_dict_destroy": (None, [_VP]),
     "msi_dict_len": (_U32, [_VP]),
     "msi_dict_lookup": (_I32, [_VP, C.POINTER(TypoQuery), _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
+    "msi_dict_set_microbatch": (_I32, [_VP, _U32, _U32]),
+    "msi_dict_microbatch_stats": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_U64)]),
     "msi_dict_lookup_device": (_I32, [_VP, _VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "msi_dict_get_stats": (_I32, [_VP, C.POINTER(DictStats)]),
     "msi_dict_match_time": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_F64)]),

@@ -31,6 +31,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <vector>
 
 #include "msi_common.h"
@@ -697,6 +699,21 @@ struct msi_dict {
   // host copy of the sorted words (prefix ranges, idx -> word for the keyword pipeline)
   std::vector<uint8_t> h_flat;
   std::vector<uint32_t> h_offs;
+  // micro-batcher: concurrent msi_dict_lookup callers with the same caps share one launch
+  struct Pending {
+    const msi_typo_query *queries;
+    uint32_t n, cap_one, cap_two;
+    uint32_t *one_idx, *one_cnt, *two_idx, *two_cnt;
+    int32_t status = MSI_OK;
+    std::string error;
+    bool done = false;
+  };
+  std::mutex bmu;
+  std::condition_variable bcv;
+  std::vector<Pending *> bqueue;
+  bool bleader_active = false;
+  uint32_t microbatch_wait_us = 0, microbatch_target = 256;
+  uint64_t fused_calls = 0, fused_launches = 0;
 };
 
 // accessors for msi_keyword.hip
@@ -940,6 +957,108 @@ int32_t msi_dict_lookup_device(msi_dict *d, const uint8_t *d_qbytes, const uint3
                         d_out_two_idx, d_out_two_cnt);
 }
 
+}  // extern "C"
+
+static int32_t dict_lookup_direct(msi_dict *d, const msi_typo_query *queries, uint32_t n, uint32_t cap_one,
+                                  uint32_t cap_two, uint32_t *out_one_idx, uint32_t *out_one_cnt,
+                                  uint32_t *out_two_idx, uint32_t *out_two_cnt);
+
+// Micro-batcher: a search derives the typos of its <= 10 words (+ n-grams) with one small
+// lookup; under load many searches do so at once (4 x cores spawn_blocking threads).  The
+// first caller leads: it waits until `microbatch_target` words are queued or
+// `microbatch_wait_us` elapsed, runs ONE launch for every queued request with its caps and
+// hands the rows out.  Requests with other caps wait for the next leader.
+static int32_t dict_lookup_fused(msi_dict *d, const msi_typo_query *queries, uint32_t n, uint32_t cap_one,
+                                 uint32_t cap_two, uint32_t *one_idx, uint32_t *one_cnt, uint32_t *two_idx,
+                                 uint32_t *two_cnt) {
+  msi_dict::Pending me;
+  me.queries = queries;
+  me.n = n;
+  me.cap_one = cap_one;
+  me.cap_two = cap_two;
+  me.one_idx = one_idx;
+  me.one_cnt = one_cnt;
+  me.two_idx = two_idx;
+  me.two_cnt = two_cnt;
+  std::unique_lock<std::mutex> lk(d->bmu);
+  d->bqueue.push_back(&me);
+  auto queued_words = [&] {
+    uint32_t w = 0;
+    for (auto *p : d->bqueue) w += p->n;
+    return w;
+  };
+  for (;;) {
+    if (d->bleader_active) {
+      d->bcv.notify_all();
+      d->bcv.wait(lk, [&] { return me.done || !d->bleader_active; });
+      if (me.done) {
+        if (me.status != MSI_OK) msi_set_error("%s", me.error.c_str());
+        return me.status;
+      }
+    }
+    d->bleader_active = true;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(d->microbatch_wait_us);
+    d->bcv.wait_until(lk, deadline, [&] { return queued_words() >= d->microbatch_target; });
+    // take every request with MY caps (always includes me); leave the others queued
+    std::vector<msi_dict::Pending *> batch, rest;
+    for (auto *p : d->bqueue) (p->cap_one == cap_one && p->cap_two == cap_two ? batch : rest).push_back(p);
+    d->bqueue.swap(rest);
+    lk.unlock();
+    uint32_t total = 0;
+    for (auto *p : batch) total += p->n;
+    std::vector<msi_typo_query> q(total);
+    std::vector<uint32_t> o1((size_t)total * cap_one), o2((size_t)total * cap_two), c1(total), c2(total);
+    size_t off = 0;
+    for (auto *p : batch) {
+      memcpy(q.data() + off, p->queries, (size_t)p->n * sizeof(msi_typo_query));
+      off += p->n;
+    }
+    const int32_t st = dict_lookup_direct(d, q.data(), total, cap_one, cap_two, o1.data(), c1.data(), o2.data(), c2.data());
+    const std::string err = st == MSI_OK ? std::string() : std::string(msi_last_error());
+    off = 0;
+    for (auto *p : batch) {
+      if (st == MSI_OK) {
+        memcpy(p->one_idx, o1.data() + off * cap_one, (size_t)p->n * cap_one * sizeof(uint32_t));
+        memcpy(p->two_idx, o2.data() + off * cap_two, (size_t)p->n * cap_two * sizeof(uint32_t));
+        memcpy(p->one_cnt, c1.data() + off, (size_t)p->n * sizeof(uint32_t));
+        memcpy(p->two_cnt, c2.data() + off, (size_t)p->n * sizeof(uint32_t));
+      }
+      off += p->n;
+    }
+    lk.lock();
+    d->fused_calls += batch.size();
+    d->fused_launches += 1;
+    for (auto *p : batch) {
+      p->status = st;
+      p->error = err;
+      p->done = true;
+    }
+    d->bleader_active = false;
+    lk.unlock();
+    d->bcv.notify_all();
+    if (st != MSI_OK) msi_set_error("%s", err.c_str());
+    return st;   // my own request was in the batch
+  }
+}
+
+extern "C" {
+
+int32_t msi_dict_set_microbatch(msi_dict *d, uint32_t max_wait_us, uint32_t target_words) {
+  if (!d) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(d->bmu);
+  d->microbatch_wait_us = max_wait_us;
+  if (target_words) d->microbatch_target = target_words;
+  return MSI_OK;
+}
+
+int32_t msi_dict_microbatch_stats(msi_dict *d, uint64_t *out_fused_calls, uint64_t *out_fused_launches) {
+  if (!d || !out_fused_calls || !out_fused_launches) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(d->bmu);
+  *out_fused_calls = d->fused_calls;
+  *out_fused_launches = d->fused_launches;
+  return MSI_OK;
+}
+
 int32_t msi_dict_lookup(msi_dict *d, const msi_typo_query *queries, uint32_t n, uint32_t cap_one, uint32_t cap_two,
                         uint32_t *out_one_idx, uint32_t *out_one_cnt, uint32_t *out_two_idx, uint32_t *out_two_cnt) {
   if (!d || (n && (!queries || !out_one_idx || !out_one_cnt || !out_two_idx || !out_two_cnt))) {
@@ -947,6 +1066,16 @@ int32_t msi_dict_lookup(msi_dict *d, const msi_typo_query *queries, uint32_t n, 
     return MSI_E_INVALID;
   }
   if (n == 0) return MSI_OK;
+  if (d->microbatch_wait_us && n < d->microbatch_target)
+    return dict_lookup_fused(d, queries, n, cap_one, cap_two, out_one_idx, out_one_cnt, out_two_idx, out_two_cnt);
+  return dict_lookup_direct(d, queries, n, cap_one, cap_two, out_one_idx, out_one_cnt, out_two_idx, out_two_cnt);
+}
+
+}  // extern "C"
+
+static int32_t dict_lookup_direct(msi_dict *d, const msi_typo_query *queries, uint32_t n, uint32_t cap_one,
+                                  uint32_t cap_two, uint32_t *out_one_idx, uint32_t *out_one_cnt,
+                                  uint32_t *out_two_idx, uint32_t *out_two_cnt) {
   std::vector<uint8_t> bytes, flags(n);
   std::vector<uint32_t> off(n + 1, 0);
   for (uint32_t i = 0; i < n; ++i) {
@@ -982,6 +1111,8 @@ int32_t msi_dict_lookup(msi_dict *d, const msi_typo_query *queries, uint32_t n, 
   MSI_HIP_TRY(hipStreamSynchronize(st));
   return MSI_OK;
 }
+
+extern "C" {
 
 int32_t msi_dict_match_time(msi_dict *d, uint64_t *out_launches, double *out_ms_total) {
   if (!d || !out_launches || !out_ms_total) return MSI_E_INVALID;

@@ -100,6 +100,15 @@ class GpuDictionary:
             C.c_void_p(one_cnt_t.data_ptr()), C.c_void_p(two_t.data_ptr()),
             C.c_void_p(two_cnt_t.data_ptr())))
 
+    def set_microbatch(self, max_wait_us, target_words=256):
+        """Fuse concurrent small `lookup` calls (other threads) into shared launches."""
+        check(lib().msi_dict_set_microbatch(self._h, int(max_wait_us), int(target_words)))
+
+    def microbatch_stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().msi_dict_microbatch_stats(self._h, C.byref(a), C.byref(b)))
+        return {"fused_calls": int(a.value), "fused_launches": int(b.value)}
+
     def match_time(self):
         n, ms = C.c_uint64(0), C.c_double(0.0)
         check(lib().msi_dict_match_time(self._h, C.byref(n), C.byref(ms)))

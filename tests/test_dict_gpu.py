@@ -107,6 +107,35 @@ def test_dense_hit_regime_tiny_alphabet(ctx, oracle, alphabet, seed):
         compare(oracle, words, queries, caps=caps, ctx=ctx)
 
 
+def test_microbatcher_fuses_concurrent_lookups(ctx, oracle):
+    import threading
+    words = synth.make_dictionary(8000, seed=31)
+    concat, off = synth.flatten_words(words)
+    odic = oracle.Dictionary.from_flat(concat, off)
+    g = ma.GpuDictionary(ctx, concat=concat, offsets=off)
+    g.set_microbatch(20000, 10 ** 6)
+    queries = synth.make_typo_queries(words, 36 * 3, seed=33)
+    out = [None] * 36
+    barrier = threading.Barrier(36)
+
+    def worker(j):
+        barrier.wait()
+        caps = (150, 50) if j % 4 else (9, 4)          # a second caps group in the same window
+        out[j] = (caps, g.lookup(queries[3 * j:3 * j + 3], cap_one=caps[0], cap_two=caps[1]))
+    th = [threading.Thread(target=worker, args=(j,)) for j in range(36)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for j in range(36):
+        caps, got = out[j]
+        for (w, b, p), (g1, g2) in zip(queries[3 * j:3 * j + 3], got):
+            e1, e2 = oracle.typo_lookup(odic, w, b, p, cap_one=caps[0], cap_two=caps[1])
+            assert g1.tolist() == e1.tolist() and g2.tolist() == e2.tolist()
+    st = g.microbatch_stats()
+    assert st["fused_calls"] == 36 and st["fused_launches"] < 36, st
+
+
 def test_errors(ctx):
     with pytest.raises(ma.MsiError) as e:
         ma.GpuDictionary(ctx, words=["b", "a"])
