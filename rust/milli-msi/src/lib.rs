@@ -1,0 +1,201 @@
+//! Safe wrappers over libmsi.  Error policy: every failure is an `Err(GpuError)`; the
+//! caller (milli) logs it and falls back to its own arroy/hannoy/fst path — a search never fails because
+//! the accelerator did (same policy as `search/hybrid.rs:326-336` on embedding failure).
+pub mod sys;
+
+use std::ffi::CStr;
+use std::ptr::{self, NonNull};
+
+use roaring::RoaringBitmap;
+
+#[derive(Debug)]
+pub struct GpuError { pub status: i32, pub message: String }
+
+fn check(status: i32) -> Result<(), GpuError> {
+    if status == sys::MSI_OK { return Ok(()); }
+    let message = unsafe { CStr::from_ptr(sys::msi_last_error()) }.to_string_lossy().into_owned();
+    Err(GpuError { status, message })
+}
+
+/// One per (process, GPU).  Objects created on it keep it alive inside the library, so drop order is free.
+pub struct GpuContext(NonNull<sys::msi_ctx>);
+unsafe impl Send for GpuContext {}
+unsafe impl Sync for GpuContext {} // every entry point is thread-safe; calls serialise on the stream locks
+impl GpuContext {
+    /// `device < 0`: `$LOCAL_RANK` if set, else device 0.  Fails unless a gfx950 device is present.
+    pub fn new(device: i32) -> Result<Self, GpuError> {
+        let mut p = ptr::null_mut();
+        check(unsafe { sys::msi_ctx_create(device, &mut p) })?;
+        Ok(Self(NonNull::new(p).expect("msi_ctx_create returned NULL with MSI_OK")))
+    }
+}
+impl Drop for GpuContext { fn drop(&mut self) { unsafe { sys::msi_ctx_destroy(self.0.as_ptr()) } } }
+
+/// Dense words (bit i = docid i) of a `RoaringBitmap` — the boundary form of `filter`/`candidates`.
+pub fn dense_words(bitmap: &RoaringBitmap) -> Vec<u64> {
+    let n = bitmap.max().map_or(0, |m| m as usize / 64 + 1);
+    let mut w = vec![0u64; n];
+    for id in bitmap { w[id as usize >> 6] |= 1u64 << (id & 63); }
+    w
+}
+
+/// One arroy/hannoy store (one (embedder, store id) pair) resident in HBM.
+pub struct GpuVectorStore { h: NonNull<sys::msi_vs>, dim: usize }
+unsafe impl Send for GpuVectorStore {}
+unsafe impl Sync for GpuVectorStore {}
+impl GpuVectorStore {
+    pub fn new(ctx: &GpuContext, dim: usize, bf16: bool) -> Result<Self, GpuError> {
+        let mut p = ptr::null_mut();
+        let storage = if bf16 { sys::MSI_VS_BF16 } else { sys::MSI_VS_F32 };
+        check(unsafe { sys::msi_vs_create_typed(ctx.0.as_ptr(), dim as u32, storage, &mut p) })?;
+        let this = Self { h: NonNull::new(p).unwrap(), dim };
+        // concurrent spawn_blocking searches share HBM sweeps (up to 16/32/48 queries each)
+        check(unsafe { sys::msi_vs_set_microbatch(this.h.as_ptr(), 200) })?;
+        Ok(this)
+    }
+    /// `docids` strictly ascending (arroy's item iteration order), `rows` row-major `[n][dim]`.
+    pub fn upload(&mut self, docids: &[u32], rows: &[f32]) -> Result<(), GpuError> {
+        assert_eq!(rows.len(), docids.len() * self.dim);
+        check(unsafe { sys::msi_vs_upload(self.h.as_ptr(), docids.as_ptr(), rows.as_ptr(), docids.len() as u64) })
+    }
+    /// `VectorStore::nns_by_vector` for this store (crates/milli/src/vector/store.rs:638-675).
+    pub fn nns_by_vector(&self, vector: &[f32], limit: usize, filter: Option<&RoaringBitmap>,
+                         cancel: Option<&std::sync::atomic::AtomicI32>) -> Result<Vec<(u32, f32)>, GpuError> {
+        assert_eq!(vector.len(), self.dim);
+        let words = filter.map(dense_words);
+        let (fp, fb) = words.as_ref().map_or((ptr::null(), 0), |w| (w.as_ptr(), w.len() as u64 * 64));
+        let (mut ids, mut dist, mut n) = (vec![0u32; limit], vec![0f32; limit], 0u32);
+        let cp = cancel.map_or(ptr::null(), |c| c.as_ptr() as *const i32);
+        check(unsafe { sys::msi_vs_search(self.h.as_ptr(), vector.as_ptr(), 1, limit as u32, fp, fb, cp,
+                                          ids.as_mut_ptr(), dist.as_mut_ptr(), &mut n) })?;
+        Ok(ids.into_iter().zip(dist).take(n as usize).collect())
+    }
+    /// `VectorStore::nns_by_item` (store.rs:615-637): `None` when the item has no vector in this store.
+    pub fn nns_by_item(&self, item: u32, limit: usize, filter: Option<&RoaringBitmap>)
+        -> Result<Option<Vec<(u32, f32)>>, GpuError> {
+        let words = filter.map(dense_words);
+        let (fp, fb) = words.as_ref().map_or((ptr::null(), 0), |w| (w.as_ptr(), w.len() as u64 * 64));
+        let (mut ids, mut dist, mut n, mut found) = (vec![0u32; limit], vec![0f32; limit], 0u32, 0i32);
+        check(unsafe { sys::msi_vs_search_by_item(self.h.as_ptr(), item, limit as u32, fp, fb, ids.as_mut_ptr(),
+                                                  dist.as_mut_ptr(), &mut n, &mut found) })?;
+        Ok((found != 0).then(|| ids.into_iter().zip(dist).take(n as usize).collect()))
+    }
+}
+impl Drop for GpuVectorStore { fn drop(&mut self) { unsafe { sys::msi_vs_destroy(self.h.as_ptr()) } } }
+
+/// The words FST staged flat in HBM (`fst.stream()` order = byte-lexicographic).
+pub struct GpuDictionary { h: NonNull<sys::msi_dict>, concat: Vec<u8>, offsets: Vec<u32> }
+unsafe impl Send for GpuDictionary {}
+unsafe impl Sync for GpuDictionary {}
+impl GpuDictionary {
+    pub fn from_sorted_words<'a>(ctx: &GpuContext, words: impl Iterator<Item = &'a [u8]>) -> Result<Self, GpuError> {
+        let (mut concat, mut offsets) = (Vec::new(), vec![0u32]);
+        for w in words { concat.extend_from_slice(w); offsets.push(concat.len() as u32); }
+        let mut p = ptr::null_mut();
+        check(unsafe { sys::msi_dict_create(ctx.0.as_ptr(), concat.as_ptr(), offsets.as_ptr(),
+                                            offsets.len() as u32 - 1, &mut p) })?;
+        let this = Self { h: NonNull::new(p).unwrap(), concat, offsets };
+        check(unsafe { sys::msi_dict_set_microbatch(this.h.as_ptr(), 200, 256) })?;
+        Ok(this)
+    }
+    pub fn word(&self, idx: u32) -> &str {
+        let (a, b) = (self.offsets[idx as usize] as usize, self.offsets[idx as usize + 1] as usize);
+        std::str::from_utf8(&self.concat[a..b]).expect("dictionary words are UTF-8")
+    }
+    /// `find_one_typo_derivations` (max_typos = 1) / `find_one_two_typo_derivations` (2):
+    /// (one-typo indices, two-typo indices), in fst stream order.
+    pub fn derivations(&self, word: &str, max_typos: u8, is_prefix: bool) -> Result<(Vec<u32>, Vec<u32>), GpuError> {
+        const CAP1: usize = 150; // MAX_ONE_TYPO_COUNT, search/new/limits.rs:7
+        const CAP2: usize = 50;  // MAX_TWO_TYPOS_COUNT, limits.rs:9
+        let q = sys::msi_typo_query { word: word.as_ptr(), len: word.len() as u32, max_typos, is_prefix: is_prefix as u8, _pad: 0 };
+        let (mut one, mut two, mut n1, mut n2) = (vec![0u32; CAP1], vec![0u32; CAP2], 0u32, 0u32);
+        check(unsafe { sys::msi_dict_lookup(self.h.as_ptr(), &q, 1, CAP1 as u32, CAP2 as u32, one.as_mut_ptr(),
+                                            &mut n1, two.as_mut_ptr(), &mut n2) })?;
+        one.truncate(n1 as usize);
+        two.truncate(n2 as usize);
+        Ok((one, two))
+    }
+}
+impl Drop for GpuDictionary { fn drop(&mut self) { unsafe { sys::msi_dict_destroy(self.h.as_ptr()) } } }
+
+/// A pool of dense docid sets in HBM (slots are the handles).
+pub struct GpuDocidSets { h: NonNull<sys::msi_bits>, pub n_slots: u32 }
+unsafe impl Send for GpuDocidSets {}
+impl GpuDocidSets {
+    pub fn new(ctx: &GpuContext, n_docs: u64, n_slots: u32) -> Result<Self, GpuError> {
+        let mut p = ptr::null_mut();
+        check(unsafe { sys::msi_bits_create(ctx.0.as_ptr(), n_docs, n_slots, &mut p) })?;
+        Ok(Self { h: NonNull::new(p).unwrap(), n_slots })
+    }
+    /// slot := decode of a `CboRoaringBitmapCodec` value, exactly the bytes LMDB returns.
+    pub fn set_from_cbo(&mut self, slot: u32, bytes: &[u8]) -> Result<(), GpuError> {
+        check(unsafe { sys::msi_bits_set_from_cbo(self.h.as_ptr(), slot, bytes.as_ptr(), bytes.len()) })
+    }
+    pub fn raw(&self) -> *mut sys::msi_bits { self.h.as_ptr() }
+}
+impl Drop for GpuDocidSets { fn drop(&mut self) { unsafe { sys::msi_bits_destroy(self.h.as_ptr()) } } }
+
+/// One hit of the keyword leg with the `ScoreDetails` of the two rules.
+#[derive(Debug, Clone, Copy)]
+pub struct KeywordHit { pub docid: u32, pub matching_words: u32, pub max_matching_words: u32, pub typo_count: u32, pub max_typo_count: u32 }
+
+/// What `msi_keyword_search` needs from the index (LMDB gets of `db_cache.rs`), as a trait the shim
+/// implements on `SearchContext`.  The byte slices are the stored `CboRoaringBitmap` values.
+pub trait PostingSource {
+    fn word_docids(&mut self, word: &str, original: bool) -> Option<&[u8]>;
+    fn word_pair_proximity_docids(&mut self, proximity: u8, left: &str, right: &str) -> Option<&[u8]>;
+    fn is_exact_word(&mut self, word: &str) -> bool;
+}
+
+// The three trampolines turn the trait object back into the C vtable (user = *mut &mut dyn PostingSource).
+unsafe extern "C" fn tramp_word(user: *mut std::ffi::c_void, w: *const u8, n: u32, original: i32,
+                                out: *mut *const u8, out_n: *mut usize) -> i32 {
+    let src = &mut **(user as *mut &mut dyn PostingSource);
+    let Ok(word) = std::str::from_utf8(std::slice::from_raw_parts(w, n as usize)) else { return -1 };
+    match src.word_docids(word, original != 0) {
+        Some(b) => { *out = b.as_ptr(); *out_n = b.len(); }
+        None => { *out_n = 0; }
+    }
+    0
+}
+unsafe extern "C" fn tramp_pair(user: *mut std::ffi::c_void, prox: u32, l: *const u8, ln: u32, r: *const u8, rn: u32,
+                                out: *mut *const u8, out_n: *mut usize) -> i32 {
+    let src = &mut **(user as *mut &mut dyn PostingSource);
+    let (Ok(l), Ok(r)) = (std::str::from_utf8(std::slice::from_raw_parts(l, ln as usize)),
+                          std::str::from_utf8(std::slice::from_raw_parts(r, rn as usize))) else { return -1 };
+    match src.word_pair_proximity_docids(prox as u8, l, r) {
+        Some(b) => { *out = b.as_ptr(); *out_n = b.len(); }
+        None => { *out_n = 0; }
+    }
+    0
+}
+unsafe extern "C" fn tramp_exact(user: *mut std::ffi::c_void, w: *const u8, n: u32) -> i32 {
+    let src = &mut **(user as *mut &mut dyn PostingSource);
+    std::str::from_utf8(std::slice::from_raw_parts(w, n as usize)).map_or(0, |w| src.is_exact_word(w) as i32)
+}
+
+/// The keyword leg for the rule list `[Words, Typo]` (bucket_sort.rs:23-343 over those two rules).
+#[allow(clippy::too_many_arguments)]
+pub fn keyword_search(dict: &GpuDictionary, sets: &mut GpuDocidSets, source: &mut dyn PostingSource,
+                      words: &[&str], last_is_prefix: bool, all_terms: bool, use_typo: bool,
+                      min_one: u32, min_two: u32, authorize_typos: bool, universe: Option<&[u8]>,
+                      from: usize, length: usize) -> Result<(Vec<KeywordHit>, u64), GpuError> {
+    let tokens: Vec<_> = words.iter().enumerate().map(|(i, w)| sys::msi_query_token {
+        word: w.as_ptr(), len: w.len() as u32, is_prefix: (last_is_prefix && i + 1 == words.len()) as u32 }).collect();
+    let params = sys::msi_keyword_params {
+        authorize_typos: authorize_typos as u32, min_word_len_one_typo: min_one, min_word_len_two_typos: min_two,
+        strategy: if all_terms { sys::MSI_TERMS_ALL } else { sys::MSI_TERMS_LAST }, use_typo: use_typo as i32,
+        from: from as u32, length: length as u32 };
+    let mut src_ref: &mut dyn PostingSource = source;
+    let vt = sys::msi_index_vtable { user: &mut src_ref as *mut _ as *mut _, word_docids: Some(tramp_word),
+        word_pair_proximity_docids: Some(tramp_pair), is_exact_word: Some(tramp_exact) };
+    let (mut ids, mut mw, mut tc, mut mt) = (vec![0u32; length], vec![0u32; length], vec![0u32; length], vec![0u32; length]);
+    let (mut n, mut cand) = (0u32, 0u64);
+    let (up, ul) = universe.map_or((ptr::null(), 0), |u| (u.as_ptr(), u.len()));
+    check(unsafe { sys::msi_keyword_search(dict.h.as_ptr(), sets.raw(), &vt, tokens.as_ptr(), tokens.len() as u32,
+                                           &params, up, ul, ids.as_mut_ptr(), mw.as_mut_ptr(), tc.as_mut_ptr(),
+                                           mt.as_mut_ptr(), &mut n, &mut cand) })?;
+    let hits = (0..n as usize).map(|i| KeywordHit { docid: ids[i], matching_words: mw[i],
+        max_matching_words: words.len() as u32, typo_count: tc[i], max_typo_count: mt[i] }).collect();
+    Ok((hits, cand))
+}

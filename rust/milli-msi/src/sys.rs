@@ -1,0 +1,131 @@
+//! Raw bindings: one item per declaration of include/msi.h (ABI version 1).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_void};
+
+#[repr(C)] pub struct msi_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct msi_vs { _p: [u8; 0] }
+#[repr(C)] pub struct msi_dict { _p: [u8; 0] }
+#[repr(C)] pub struct msi_bits { _p: [u8; 0] }
+
+pub const MSI_OK: i32 = 0;
+pub const MSI_E_INVALID: i32 = -1;
+pub const MSI_E_NO_DEVICE: i32 = -2;
+pub const MSI_E_HIP: i32 = -3;
+pub const MSI_E_OOM: i32 = -4;
+pub const MSI_E_UNSUPPORTED: i32 = -5;
+pub const MSI_E_CANCELLED: i32 = -6;
+pub const MSI_E_NOT_SORTED: i32 = -7;
+pub const MSI_E_INTERNAL: i32 = -8;
+
+pub const MSI_VS_F32: i32 = 0;
+pub const MSI_VS_BF16: i32 = 1;
+pub const MSI_BITS_AND: i32 = 0;
+pub const MSI_BITS_OR: i32 = 1;
+pub const MSI_BITS_ANDNOT: i32 = 2;
+pub const MSI_BITS_XOR: i32 = 3;
+pub const MSI_TERMS_LAST: i32 = 0;
+pub const MSI_TERMS_ALL: i32 = 1;
+pub const MSI_NO_SLOT: u32 = 0xFFFF_FFFF;
+pub const MSI_RANK_MAX_TERMS: usize = 10;
+
+#[repr(C)]
+pub struct msi_typo_query { pub word: *const u8, pub len: u32, pub max_typos: u8, pub is_prefix: u8, pub _pad: u16 }
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct msi_rank_node { pub first_term: u32, pub last_term: u32, pub level_slot: [u32; 3], pub max_typo_cost: u32 }
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct msi_rank_bucket { pub matching_words: u32, pub typo_count: u32, pub max_typo_count: u32, pub _pad: u32, pub count: u64 }
+#[repr(C)]
+pub struct msi_rank_query { pub nodes: *const msi_rank_node, pub n_nodes: u32, pub n_terms: u32, pub universe_slot: u32, pub scratch_slot: u32 }
+#[repr(C)]
+pub struct msi_query_token { pub word: *const u8, pub len: u32, pub is_prefix: u32 }
+#[repr(C)]
+pub struct msi_keyword_params {
+    pub authorize_typos: u32, pub min_word_len_one_typo: u32, pub min_word_len_two_typos: u32,
+    pub strategy: i32, pub use_typo: i32, pub from: u32, pub length: u32,
+}
+pub type word_docids_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, i32, *mut *const u8, *mut usize) -> i32;
+pub type pair_docids_fn = unsafe extern "C" fn(*mut c_void, u32, *const u8, u32, *const u8, u32, *mut *const u8, *mut usize) -> i32;
+pub type exact_word_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32) -> i32;
+#[repr(C)]
+pub struct msi_index_vtable {
+    pub user: *mut c_void,
+    pub word_docids: Option<word_docids_fn>,
+    pub word_pair_proximity_docids: Option<pair_docids_fn>,
+    pub is_exact_word: Option<exact_word_fn>,
+}
+
+extern "C" {
+    pub fn msi_abi_version() -> i32;
+    pub fn msi_last_error() -> *const c_char;
+    pub fn msi_ctx_create(device: i32, out: *mut *mut msi_ctx) -> i32;
+    pub fn msi_ctx_destroy(ctx: *mut msi_ctx);
+    pub fn msi_ctx_synchronize(ctx: *mut msi_ctx) -> i32;
+
+    pub fn msi_vs_create(ctx: *mut msi_ctx, dim: u32, out: *mut *mut msi_vs) -> i32;
+    pub fn msi_vs_create_typed(ctx: *mut msi_ctx, dim: u32, storage: i32, out: *mut *mut msi_vs) -> i32;
+    pub fn msi_vs_destroy(vs: *mut msi_vs);
+    pub fn msi_vs_upload(vs: *mut msi_vs, docids: *const u32, rows: *const f32, n_rows: u64) -> i32;
+    pub fn msi_vs_len(vs: *const msi_vs) -> u64;
+    pub fn msi_vs_dim(vs: *const msi_vs) -> u32;
+    pub fn msi_vs_max_batch(vs: *const msi_vs) -> u32;
+    pub fn msi_vs_get_vector(vs: *mut msi_vs, docid: u32, out_row: *mut f32, found: *mut i32) -> i32;
+    pub fn msi_vs_search(vs: *mut msi_vs, queries: *const f32, n_queries: u32, k: u32, filter_bits: *const u64,
+                         filter_nbits: u64, cancel: *const i32, out_docids: *mut u32, out_dist: *mut f32,
+                         out_counts: *mut u32) -> i32;
+    pub fn msi_vs_search_by_item(vs: *mut msi_vs, docid: u32, k: u32, filter_bits: *const u64, filter_nbits: u64,
+                                 out_docids: *mut u32, out_dist: *mut f32, out_count: *mut u32, out_found: *mut i32) -> i32;
+    pub fn msi_vs_set_microbatch(vs: *mut msi_vs, max_wait_us: u32) -> i32;
+    pub fn msi_merge_topk(docids: *const u32, dist: *const f32, counts: *const u32, n_lists: u32, list_stride: u32,
+                          k_out: u32, out_docids: *mut u32, out_dist: *mut f32) -> u32;
+
+    pub fn msi_dict_create(ctx: *mut msi_ctx, words_concat: *const u8, offsets: *const u32, n_words: u32,
+                           out: *mut *mut msi_dict) -> i32;
+    pub fn msi_dict_destroy(d: *mut msi_dict);
+    pub fn msi_dict_len(d: *const msi_dict) -> u32;
+    pub fn msi_dict_lookup(d: *mut msi_dict, queries: *const msi_typo_query, n: u32, cap_one: u32, cap_two: u32,
+                           out_one_idx: *mut u32, out_one_cnt: *mut u32, out_two_idx: *mut u32, out_two_cnt: *mut u32) -> i32;
+    pub fn msi_dict_set_microbatch(d: *mut msi_dict, max_wait_us: u32, target_words: u32) -> i32;
+
+    pub fn msi_bits_create(ctx: *mut msi_ctx, n_docs: u64, n_slots: u32, out: *mut *mut msi_bits) -> i32;
+    pub fn msi_bits_destroy(p: *mut msi_bits);
+    pub fn msi_bits_set_from_cbo(p: *mut msi_bits, slot: u32, bytes: *const u8, len: usize) -> i32;
+    pub fn msi_bits_set_from_docids(p: *mut msi_bits, slot: u32, docids: *const u32, n: u64) -> i32;
+    pub fn msi_bits_fill(p: *mut msi_bits, slot: u32, ones: i32) -> i32;
+    pub fn msi_bits_op(p: *mut msi_bits, dst: u32, a: u32, b: u32, op: i32) -> i32;
+    pub fn msi_bits_union_many_and(p: *mut msi_bits, dst: u32, srcs: *const u32, n: u32, universe: u32) -> i32;
+    pub fn msi_bits_count(p: *mut msi_bits, slot: u32, out: *mut u64) -> i32;
+    pub fn msi_bits_first_k(p: *mut msi_bits, slot: u32, k: u32, out: *mut u32, out_n: *mut u32) -> i32;
+    pub fn msi_bits_read_words(p: *mut msi_bits, slot: u32, out_words: *mut u64) -> i32;
+
+    pub fn msi_rank_query_graph(p: *mut msi_bits, nodes: *const msi_rank_node, n_nodes: u32, n_terms: u32,
+                                universe_slot: u32, scratch_slot: u32, strategy: i32, use_typo: i32, from: u32,
+                                length: u32, out_docids: *mut u32, out_matching_words: *mut u32,
+                                out_typo_count: *mut u32, out_max_typo_count: *mut u32, out_n: *mut u32,
+                                out_candidates: *mut u64) -> i32;
+    pub fn msi_rank_query_graph_batch(p: *mut msi_bits, queries: *const msi_rank_query, n_queries: u32, strategy: i32,
+                                      use_typo: i32, from: u32, length: u32, out_docids: *mut u32,
+                                      out_matching_words: *mut u32, out_typo_count: *mut u32,
+                                      out_max_typo_count: *mut u32, out_n: *mut u32, out_candidates: *mut u64) -> i32;
+    pub fn msi_rank_buckets(p: *mut msi_bits, nodes: *const msi_rank_node, n_nodes: u32, n_terms: u32,
+                            universe_slot: u32, scratch_slot: u32, strategy: i32, use_typo: i32,
+                            out_buckets: *mut msi_rank_bucket, cap: u32, out_n: *mut u32) -> i32;
+    pub fn msi_rank_materialise(p: *mut msi_bits, nodes: *const msi_rank_node, n_nodes: u32, n_terms: u32,
+                                universe_slot: u32, strategy: i32, use_typo: i32, matching_words: u32,
+                                typo_count: u32, dst_slot: u32) -> i32;
+    pub fn msi_keyword_search(d: *mut msi_dict, p: *mut msi_bits, index: *const msi_index_vtable,
+                              tokens: *const msi_query_token, n_tokens: u32, params: *const msi_keyword_params,
+                              universe_cbo: *const u8, universe_len: usize, out_docids: *mut u32,
+                              out_matching_words: *mut u32, out_typo_count: *mut u32, out_max_typo_count: *mut u32,
+                              out_n: *mut u32, out_candidates: *mut u64) -> i32;
+
+    pub fn msi_vector_sort(docids: *const u32, dist: *const f32, n: u32, has_shift: i32, mean: f32, sigma: f32,
+                           from: u32, length: u32, out_docids: *mut u32, out_similarity: *mut f32) -> u32;
+    pub fn msi_hybrid_merge(v_docids: *const u32, v_scores: *const f64, v_off: *const u32, n_v: u32, v_ratio: f32,
+                            k_docids: *const u32, k_scores: *const f64, k_off: *const u32, n_k: u32, k_ratio: f32,
+                            from: u32, length: u32, out_docids: *mut u32, out_is_semantic: *mut u8,
+                            out_semantic_hit_count: *mut u32) -> u32;
+    pub fn msi_results_good_enough(keyword_global_scores: *const f64, n: u32, limit_plus_offset: u32,
+                                   semantic_ratio: f32) -> i32;
+    pub fn msi_distribution_shift(mean: f32, sigma: f32, score: f32) -> f32;
+    pub fn msi_rank_global_score(ranks: *const u32, max_ranks: *const u32, n: u32) -> f64;
+}
