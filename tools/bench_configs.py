@@ -199,6 +199,88 @@ def run_filtered(args):
                           "min_results": int(out_cnt.min().item()), "inexact": int(inexact.sum().item())}), flush=True)
 
 
+def run_c5(args):
+    """One GPU's shard of C5 (BASELINE.json configs[4]: 100 M x 1024 bf16 over 8 GPUs = 12.5 M rows
+    per GPU): filtered vector search (random 10 % / 1 % / 0.1 % candidate bitsets resident in HBM)
+    with k = 1000, then the ranking-rule rerank: Words -> Typo bucket sort of a 3-term keyword
+    query restricted to each query's top-1000 (universe = those docids), top 20 returned."""
+    import torch
+    import meilisearch_amd as ma
+    from meilisearch_amd import ranking as R
+    dev = torch.device("cuda", 0)
+    ctx = ma.Context(0)
+    n, d, k = args.rows, args.dim, 1000
+    store = ma.GpuStore(ctx, d, "bf16")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    rows = torch.empty((n, d), dtype=torch.float32, device=dev).normal_(generator=gen)
+    ids = torch.arange(n, dtype=torch.int32, device=dev)
+    store.upload_device(ids, rows)
+    del rows
+    torch.cuda.empty_cache()
+    B = store.max_batch
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(5678)
+    q = torch.empty((B, d), dtype=torch.float32, device=dev).normal_(generator=gq)
+    out_ids = torch.zeros((B, k), dtype=torch.int32, device=dev)
+    out_dist = torch.zeros((B, k), dtype=torch.float32, device=dev)
+    out_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    inexact = torch.zeros(B, dtype=torch.int32, device=dev)
+    nt = 3
+    FILTER, POST, UNI = 0, 1, 1 + 3 * nt
+    pool = ma.BitsPool(ctx, n, UNI + 5 * B)
+    rng = np.random.default_rng(31)
+    words = (n + 63) // 64
+    dens = [(0.30, 0.05, 0.02), (0.10, 0.02, 0.01), (0.02, 0.005, 0.002)]
+    terms, slot = [], POST
+    for i in range(nt):
+        sl = []
+        for p in dens[i % 3]:
+            bits = rng.random(words * 64) < p
+            pool.set_from_words(slot, np.packbits(bits, bitorder="little").view(np.uint64))
+            sl.append(slot)
+            slot += 1
+        terms.append((sl[0], sl[1], sl[2], 2 if i % 2 else 1))
+    nodes = [(i, i, t[0], t[1], t[2], t[3]) for i, t in enumerate(terms)]
+    batch = R.RankBatch(pool, [(nodes, nt, UNI + 5 * i, UNI + 5 * i + 1) for i in range(B)])
+    bytes_per_sweep = ((n + 15) // 16) * store.stats()["bytes_per_tile"]
+    for sel in (0.1, 0.01, 0.001):
+        bits = rng.random(words * 64) < sel
+        pool.set_from_words(FILTER, np.packbits(bits, bitorder="little").view(np.uint64))
+        fptr = pool.device_ptr(FILTER)
+
+        def scan():
+            store.search_device(q, k, out_ids, out_dist, out_cnt, inexact, filter_ptr=fptr, filter_nbits=n)
+
+        def step():
+            scan()
+            ctx.synchronize()
+            h_ids = out_ids.cpu().numpy().view(np.uint32)
+            h_cnt = out_cnt.cpu().numpy()
+            for i in range(B):
+                pool.set_from_docids(UNI + 5 * i, np.sort(h_ids[i, :h_cnt[i]]))
+            return batch.run(R.TERMS_LAST, True, 0, 20)
+
+        ms_scan, _ = timed(scan, ctx.synchronize, args.reps)
+        ms, p50 = timed(step, ctx.synchronize, args.reps)
+        res = step()
+        ctx.set_profiling(True)
+        store.scan_time()
+        scan()
+        ctx.synchronize()
+        ln, lms = store.scan_time()
+        ctx.set_profiling(False)
+        print(json.dumps({"config": "c5_shard", "rows": n, "dim": d, "storage": "bf16", "k": k, "batch": B,
+                          "selectivity": sel, "scan_ms_per_batch": round(ms_scan, 4),
+                          "scan_qps": round(B / ms_scan * 1e3, 1),
+                          "ms_per_batch_with_rerank": round(ms, 4), "p50_ms": round(p50, 4),
+                          "qps_with_rerank": round(B / ms * 1e3, 1),
+                          "scan_kernel_ms": round(lms / max(1, ln), 4), "store_GB": round(bytes_per_sweep / 1e9, 2),
+                          "min_results": int(out_cnt.min().item()), "inexact": int(inexact.sum().item()),
+                          "rerank_returned_min": int(res.counts.min()),
+                          "rerank_candidates_mean": float(np.mean(res.cand))}), flush=True)
+
+
 def run_rank(args):
     """Words -> Typo bucket sort over dense docid sets (S3): n_terms query terms with
     random zero/one/two-typo posting sets over `rows` documents, top-`k`."""
@@ -235,7 +317,7 @@ def run_rank(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered"])
+    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered", "c5"])
     ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--rows", type=int, default=1_000_000)
@@ -249,7 +331,7 @@ def main():
     args = ap.parse_args()
     if args.batches is None:
         args.batches = [1, 16, 48, 240] if args.config != "c3" else [1, 64, 1024, 8192]
-    {"c2": run_c2, "c3": run_c3, "rank": run_rank, "filtered": run_filtered}[args.config](args)
+    {"c2": run_c2, "c3": run_c3, "rank": run_rank, "filtered": run_filtered, "c5": run_c5}[args.config](args)
 
 
 if __name__ == "__main__":
