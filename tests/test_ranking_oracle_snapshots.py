@@ -1,0 +1,80 @@
+"""Pins oracle/ranking_oracle.py (the CPU restatement of milli's keyword ranking) against the reference's
+own golden vectors: every search of search/new/tests/{proximity,attribute_fid,word_position,exactness,
+words_tms,typo_proximity,proximity_typo,ngram_split_words,typo}.rs that the toy index can express
+(tests/golden/ranking_snapshots.json, extracted by tests/golden/make_ranking_fixtures.py): expected docid
+order and, where the reference snapshots them, the score details of every hit."""
+import json
+import os
+
+import pytest
+
+from oracle import oracle as O
+from oracle import ranking_oracle as R
+from tests.toy_milli import ToyMilli
+
+FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ranking_snapshots.json")))
+
+# Cases that need a feature the toy index does not model (reason -> skipped, not failed).
+UNSUPPORTED = {
+    "xyz wilting": "synonyms",
+    "best s": "word-prefix databases (prefix `s` is in the prefix DB)",
+    "best win": "word-prefix databases",
+    "best wi": "word-prefix databases",
+}
+
+
+def make_ctx(index):
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    return R.Ctx(index, lookup)
+
+
+def build_index(cfg):
+    return ToyMilli(cfg["docs"], searchable=cfg.get("searchable"), exact_attributes=cfg.get("exact_attributes", ()),
+                    exact_words=cfg.get("exact_words", ()), criteria=cfg.get("criteria"),
+                    min_one=cfg.get("min_one", 5), min_two=cfg.get("min_two", 9),
+                    authorize_typos=cfg.get("authorize_typos", True))
+
+
+def debug_score(s):
+    """Rust `{:#?}` of ScoreDetails with the whitespace removed."""
+    k = s[0]
+    if k == "Words":
+        return f"Words(Words{{matching_words:{s[1]},max_matching_words:{s[2]},}},)"
+    if k == "Typo":
+        return f"Typo(Typo{{typo_count:{s[1]},max_typo_count:{s[2]},}},)"
+    if k == "ExactWords":
+        return f"ExactWords(ExactWords{{matching_words:{s[1]},max_matching_words:{s[2]},}},)"
+    if k == "ExactAttribute":
+        return f"ExactAttribute({s[1]},)"
+    return f"{k}(Rank{{rank:{s[1]},max_rank:{s[2]},}},)"
+
+
+def debug_scores(scores):
+    return "[" + "".join("[" + "".join(debug_score(s) + "," for s in hit) + "]," for hit in scores) + "]"
+
+
+def debug_ids_scores(ids, scores):
+    return "[" + "".join(f"({i},[" + "".join(debug_score(s) + "," for s in hit) + "],)," for i, hit in zip(ids, scores)) + "]"
+
+
+CASES = [c for c in FIX["cases"]]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f'{c["src"].split("::")[1]}:{c["query"]}' for c in CASES])
+def test_reference_snapshot(case):
+    cfg = FIX["indexes"][case["index"]]
+    if cfg.get("unsupported") or case["query"] in UNSUPPORTED:
+        pytest.skip("needs " + str(cfg.get("unsupported") or UNSUPPORTED[case["query"]]))
+    index = build_index(cfg)
+    ids, scores, _ = R.search(make_ctx(index), case["query"], tms=case["tms"], offset=case["offset"],
+                              length=case["limit"], detailed=case["detailed"])
+    if case["ids"] is not None:
+        assert ids == case["ids"]
+    if case.get("scores"):
+        assert debug_scores(scores) == case["scores"]
+    if case.get("ids_scores"):
+        assert debug_ids_scores(ids, scores) == case["ids_scores"]

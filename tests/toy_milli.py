@@ -1,0 +1,153 @@
+"""TEST INFRASTRUCTURE: a toy index with every database the ranking rules read, built the
+way milli's write path builds them, so that the reference's snapshot
+tests (crates/milli/src/search/new/tests/*.rs) can be replayed.  Not part of the product.
+
+  word_docids / exact_word_docids          extract_word_docids.rs:76-81
+  word_fid_docids, word_position_docids    extract_word_docids.rs:91-99 (bucketed_position, lib.rs:248-262)
+  field_id_word_count_docids (<= 30 words) extract_word_docids.rs:169-190
+  word_pair_proximity_docids               extract_word_pair_proximity_docids.rs:504-515 (forward pairs, prox 1..3,
+                                           the minimum proximity of a pair per document: :232-233)
+  positions                                tokenize_document.rs:131-157 (+1 per word, +8 over a hard separator)
+  words fst                                keys of word_docids only (post_processing/mod.rs:192-208)
+"""
+import re
+
+from oracle.ranking_oracle import bucketed_position
+from tests.toy_index import cbo_bytes  # noqa: F401  (re-exported for the device tests)
+
+HARD_RE = re.compile(r"[.,]\s|[!;?]")       # charabia CONTEXT_SEPARATORS (Latin subset): ". " ", " "!" ";" "?"
+WORD_RE = re.compile(r"[0-9a-zà-öø-ÿ]+")
+MAX_COUNTED_WORDS = 30
+MAX_POSITION_PER_ATTRIBUTE = 1 << 16      # lib.rs (u16 relative positions)
+INDEX_MAX_DISTANCE = 8      # tokenize_document.rs:13
+MAX_DISTANCE = 4            # proximity.rs:7
+
+
+def tokenize_with_positions(text, start=0):
+    """[(word, position)]: process_tokens, tokenize_document.rs:131-157."""
+    text = text.lower()
+    out, pos, prev_end, first = [], start, 0, True
+    for m in WORD_RE.finditer(text):
+        sep = text[prev_end:m.start()]
+        if first:
+            first = False
+        else:
+            hard = bool(HARD_RE.search(sep))
+            pos += INDEX_MAX_DISTANCE if hard else 1
+        out.append((m.group(0), pos))
+        prev_end = m.end()
+    return out
+
+
+class ToyMilli:
+    def __init__(self, docs, searchable=None, exact_attributes=(), exact_words=(), criteria=None,
+                 min_one=5, min_two=9, authorize_typos=True, primary_key="id"):
+        self.min_one, self.min_two, self.authorize_typos = min_one, min_two, authorize_typos
+        self.exact_words = set(exact_words)
+        self.criteria = criteria or ["words", "typo", "proximity", "attributeRank", "sort", "wordPosition", "exactness"]
+        # internal docids in order of first appearance of the external id; a later document with
+        # the same id replaces the earlier one
+        ext, merged = {}, []
+        for d in docs:
+            k = d[primary_key]
+            if k in ext:
+                merged[ext[k]] = d
+            else:
+                ext[k] = len(merged)
+                merged.append(d)
+        self.docs = merged
+        self.n_docs = len(merged)
+        self.fields = {}
+        for d in merged:
+            for name in d:
+                self.fields.setdefault(name, len(self.fields))
+        if searchable is None:
+            self.searchable = [n for n in self.fields]
+            self.weights = {self.fields[n]: 0 for n in self.searchable}
+            self.max_weight = None
+        else:
+            self.searchable = [n for n in searchable if n in self.fields]
+            self.weights = {self.fields[n]: i for i, n in enumerate(searchable) if n in self.fields}
+            self.max_weight = max(len(searchable) - 1, 0)
+        self.searchable_fids = [self.fields[n] for n in self.searchable]
+        exact_attr = set(exact_attributes)
+        self.word_docids, self.exact_word_docids = {}, {}
+        self.word_fid_docids, self.word_position_docids = {}, {}
+        self.fid_word_count, self.pair = {}, {}
+        for docid, d in enumerate(merged):
+            pairs = {}
+            for name in self.searchable:
+                if name not in d or not isinstance(d[name], (str, int, float)) or isinstance(d[name], bool):
+                    continue
+                fid = self.fields[name]
+                toks = tokenize_with_positions(str(d[name]))
+                toks = [(w, p) for w, p in toks if p < MAX_POSITION_PER_ATTRIBUTE]
+                target = self.exact_word_docids if name in exact_attr else self.word_docids
+                for w, p in toks:
+                    target.setdefault(w, set()).add(docid)
+                    self.word_fid_docids.setdefault((w, fid), set()).add(docid)
+                    self.word_position_docids.setdefault((w, bucketed_position(p)), set()).add(docid)
+                if 0 < len(toks) <= MAX_COUNTED_WORDS:
+                    self.fid_word_count.setdefault((fid, len(toks)), set()).add(docid)
+                for i, (w1, p1) in enumerate(toks):
+                    for w2, p2 in toks[i + 1:]:
+                        prox = min(p2 - p1, MAX_DISTANCE)
+                        if 0 < prox < MAX_DISTANCE:
+                            key = (w1, w2)
+                            if key not in pairs or prox < pairs[key]:
+                                pairs[key] = prox
+            for (w1, w2), prox in pairs.items():
+                self.pair.setdefault((prox, w1, w2), set()).add(docid)
+        self.words = sorted(self.word_docids, key=lambda w: w.encode())      # words fst
+        self.all_words = sorted(set(self.word_docids) | set(self.exact_word_docids), key=lambda w: w.encode())
+        self._fids_of, self._pos_of = {}, {}
+        for (w, fid) in self.word_fid_docids:
+            self._fids_of.setdefault(w, []).append(fid)
+        for (w, p) in self.word_position_docids:
+            self._pos_of.setdefault(w, []).append(p)
+
+    # ---- the reads of search/new/db_cache.rs ----------------------------------------
+    def all_docids(self):
+        return set(range(self.n_docs))
+
+    def contains_word(self, w):
+        return w in self.word_docids or w in self.exact_word_docids
+
+    def get_word_docids(self, w, original):
+        """SearchContext::word_docids (db_cache.rs:183-205): Original = exact | tolerant, Derived = tolerant."""
+        t = self.word_docids.get(w)
+        if not original:
+            return t
+        e = self.exact_word_docids.get(w)
+        if t is None and e is None:
+            return None
+        return (t or set()) | (e or set())
+
+    def get_pair(self, prox, w1, w2):
+        return self.pair.get((prox, w1, w2))
+
+    def get_word_fid_docids(self, w, fid):
+        return self.word_fid_docids.get((w, fid))
+
+    def get_word_position_docids(self, w, pos):
+        return self.word_position_docids.get((w, pos))
+
+    def get_word_fids(self, w):
+        return sorted(self._fids_of.get(w, ()))
+
+    def get_word_positions(self, w):
+        return sorted(self._pos_of.get(w, ()))
+
+    def get_fid_word_count_docids(self, fid, count):
+        return self.fid_word_count.get((fid, count))
+
+    def prefix_words(self, prefix):
+        """word_docids and exact_word_docids keys with the prefix, merged in key order
+        (find_zero_typo_prefix_derivations, compute_derivations.rs:40-73)."""
+        return [w for w in self.all_words if w.startswith(prefix)]
+
+    def budget(self, word):
+        n = len(word)
+        if not self.authorize_typos or n < self.min_one or word in self.exact_words:
+            return 0
+        return 1 if n < self.min_two else 2
