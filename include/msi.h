@@ -277,6 +277,10 @@ enum { MSI_BITS_AND = 0, MSI_BITS_OR = 1, MSI_BITS_ANDNOT = 2, MSI_BITS_XOR = 3 
 /* dst := a OP b */
 int32_t msi_bits_op(msi_bits *pool, uint32_t dst, uint32_t a, uint32_t b,
                     int32_t op);
+/* dst = a OP b and its cardinality in one pass (the `&` + `is_empty()` of visit_path_condition,
+ * graph_based_ranking_rule.rs:383-437). */
+int32_t msi_bits_op_count(msi_bits *pool, uint32_t dst, uint32_t a, uint32_t b, int32_t op,
+                          uint64_t *out_count);
 /* dst := (OR of srcs[0..n)) AND universe   (universe == UINT32_MAX: no AND) */
 int32_t msi_bits_union_many_and(msi_bits *pool, uint32_t dst,
                                 const uint32_t *srcs, uint32_t n,
@@ -401,6 +405,22 @@ typedef struct msi_index_vtable {
                                         uint32_t right_len, const uint8_t **bytes, size_t *n);
   /* exact_words FST membership; nullable. */
   int32_t (*is_exact_word)(void *user, const uint8_t *word, uint32_t len);
+  /* The reads of the attribute / position / exactness rules (msi_keyword_search_ranked only;
+   * nullable when those rules are not in the criteria).  db_cache.rs:533-552,629-650:
+   * word_fid_docids(word, fid), word_position_docids(word, bucketed position) as stored bytes;
+   * the fids / bucketed positions a word has entries for (db_cache.rs:575-599, prefix_iter over the
+   * same databases; *n receives the count, at most `cap` written);
+   * field_id_word_count_docids(fid, count) (exact_attribute.rs:187-200). */
+  int32_t (*word_fid_docids)(void *user, const uint8_t *word, uint32_t len, uint32_t fid,
+                             const uint8_t **bytes, size_t *n);
+  int32_t (*word_position_docids)(void *user, const uint8_t *word, uint32_t len, uint32_t position,
+                                  const uint8_t **bytes, size_t *n);
+  int32_t (*word_fids)(void *user, const uint8_t *word, uint32_t len, uint16_t *out, uint32_t cap,
+                       uint32_t *n);
+  int32_t (*word_positions)(void *user, const uint8_t *word, uint32_t len, uint16_t *out, uint32_t cap,
+                            uint32_t *n);
+  int32_t (*field_id_word_count_docids)(void *user, uint32_t fid, uint32_t count,
+                                        const uint8_t **bytes, size_t *n);
 } msi_index_vtable;
 typedef struct msi_query_token {
   const uint8_t *word;
@@ -422,6 +442,66 @@ int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtabl
                            uint32_t *out_matching_words, uint32_t *out_typo_count,
                            uint32_t *out_max_typo_count, uint32_t *out_n,
                            uint64_t *out_candidates);
+
+/* ------------------------- keyword leg with every graph-based ranking rule (host + device sets) */
+/*
+ * bucket_sort (bucket_sort.rs:23-343) over the rule list get_ranking_rules_for_query_graph_search
+ * builds from index.criteria (search/new/mod.rs:510-649): Words, Typo, Proximity, Attribute (Fid +
+ * Position), AttributeRank, WordPosition, Exactness (ExactAttribute + Exactness); Sort / Asc / Desc are
+ * skipped (not keyword rules).  Every rule is the generic GraphBasedRankingRule
+ * (graph_based_ranking_rule.rs:136-368) over ranking_rule_graph/{words,typo,proximity,fid,position,
+ * exactness}; between rules the query graph is rebuilt from the paths that matched
+ * (QueryGraph::build_from_paths, query_graph.rs:470-544).  Terms: single words (typo derivations from the
+ * device dictionary, prefix derivations, split words, 2-/3-grams) and quoted phrases
+ * (compute_phrase_docids, resolve_query_graph.rs:187-268).  The control flow (small graphs) runs on the
+ * caller's thread; every docid set lives in the msi_bits pool and every set operation — posting decode,
+ * union, intersection, difference, cardinality, ordered extraction — is a device kernel.
+ * Not handled: synonyms, the word-prefix databases, distinct, pins, ranking score threshold, deadline.
+ * The tokenizer stays with the caller: it hands over the located terms of
+ * located_query_terms_from_tokens (parse_query.rs:28-202).
+ */
+enum {
+  MSI_CRIT_WORDS = 0, MSI_CRIT_TYPO = 1, MSI_CRIT_PROXIMITY = 2, MSI_CRIT_ATTRIBUTE = 3,
+  MSI_CRIT_ATTRIBUTE_RANK = 4, MSI_CRIT_WORD_POSITION = 5, MSI_CRIT_EXACTNESS = 6, MSI_CRIT_SORT = 7
+};
+enum { /* ScoreDetails variants, score_details.rs:10-27 */
+  MSI_SCORE_WORDS = 0,           /* a = matching_words, b = max_matching_words */
+  MSI_SCORE_TYPO = 1,            /* a = typo_count, b = max_typo_count */
+  MSI_SCORE_PROXIMITY = 2,       /* a = rank, b = max_rank */
+  MSI_SCORE_FID = 3,             /* a = rank, b = max_rank */
+  MSI_SCORE_POSITION = 4,        /* a = rank, b = max_rank */
+  MSI_SCORE_EXACT_ATTRIBUTE = 5, /* a = 3 ExactMatch | 2 MatchesStart | 1 NoExactMatch, b = 3 */
+  MSI_SCORE_EXACT_WORDS = 6      /* a = matching_words, b = max_matching_words */
+};
+#define MSI_MAX_SCORE_DETAILS 8
+typedef struct msi_score_detail {
+  uint32_t kind, a, b;
+} msi_score_detail;
+typedef struct msi_located_term {
+  const msi_query_token *words; /* one word, or the words of a quoted phrase (len 0 = a stop word) */
+  uint32_t n_words;
+  uint32_t is_phrase;
+  uint32_t position_start, position_end; /* parse_query.rs:60-120: +1 per word, +7 more over a hard separator */
+} msi_located_term;
+typedef struct msi_search_params {
+  uint32_t authorize_typos, min_word_len_one_typo, min_word_len_two_typos;
+  int32_t strategy;                    /* MSI_TERMS_LAST | MSI_TERMS_ALL */
+  const int32_t *criteria;             /* index.criteria as MSI_CRIT_* */
+  uint32_t n_criteria;
+  const uint16_t *searchable_fids;     /* searchable_fields_ids, with their weights (fieldids_weights_map) */
+  const uint16_t *searchable_weights;
+  uint32_t n_searchable;
+  int32_t max_weight;                  /* max_searchable_attribute_weight, -1 = None (index.rs:689-698) */
+  uint32_t from, length;
+  int32_t detailed_scores;             /* ScoringStrategy::Detailed (else Skip) */
+} msi_search_params;
+/* out_scores: [length][MSI_MAX_SCORE_DETAILS], out_n_scores: [length].  The pool needs at least 64 free
+ * slots above slot 0 (more for long queries: one per live condition of every active rule). */
+int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, const msi_index_vtable *index,
+                                  const msi_located_term *terms, uint32_t n_terms,
+                                  const msi_search_params *params, const uint8_t *universe_cbo,
+                                  size_t universe_len, uint32_t *out_docids, msi_score_detail *out_scores,
+                                  uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates);
 
 /* ---------------------------------------------------- scoring arithmetic (host) */
 /* DistributionShift::shift (crates/milli/src/vector/distribution.rs:103-130). */

@@ -49,9 +49,37 @@ PAIR_DOCIDS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_ui
 EXACT_WORD_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32)
 
 
+WORD_KEY_DOCIDS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32,
+                                C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t))
+WORD_KEYS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint16), C.c_uint32,
+                          C.POINTER(C.c_uint32))
+FID_COUNT_DOCIDS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(C.c_uint8)),
+                                 C.POINTER(C.c_size_t))
+
+
 class IndexVtable(C.Structure):
     _fields_ = [("user", C.c_void_p), ("word_docids", WORD_DOCIDS_FN),
-                ("word_pair_proximity_docids", PAIR_DOCIDS_FN), ("is_exact_word", EXACT_WORD_FN)]
+                ("word_pair_proximity_docids", PAIR_DOCIDS_FN), ("is_exact_word", EXACT_WORD_FN),
+                ("word_fid_docids", WORD_KEY_DOCIDS_FN), ("word_position_docids", WORD_KEY_DOCIDS_FN),
+                ("word_fids", WORD_KEYS_FN), ("word_positions", WORD_KEYS_FN),
+                ("field_id_word_count_docids", FID_COUNT_DOCIDS_FN)]
+
+
+class ScoreDetail(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32)]
+
+
+class LocatedTerm(C.Structure):
+    _fields_ = [("words", C.c_void_p), ("n_words", C.c_uint32), ("is_phrase", C.c_uint32),
+                ("position_start", C.c_uint32), ("position_end", C.c_uint32)]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("authorize_typos", C.c_uint32), ("min_word_len_one_typo", C.c_uint32),
+                ("min_word_len_two_typos", C.c_uint32), ("strategy", C.c_int32), ("criteria", C.c_void_p),
+                ("n_criteria", C.c_uint32), ("searchable_fids", C.c_void_p), ("searchable_weights", C.c_void_p),
+                ("n_searchable", C.c_uint32), ("max_weight", C.c_int32), ("from_", C.c_uint32),
+                ("length", C.c_uint32), ("detailed_scores", C.c_int32)]
 
 
 class QueryToken(C.Structure):
@@ -125,6 +153,7 @@ PROTOTYPES = {
     "msi_bits_set_from_words": (_I32, [_VP, _U32, _VP, _U64]),
     "msi_bits_fill": (_I32, [_VP, _U32, _I32]),
     "msi_bits_op": (_I32, [_VP, _U32, _U32, _U32, _I32]),
+    "msi_bits_op_count": (_I32, [_VP, _U32, _U32, _U32, _I32, C.POINTER(_U64)]),
     "msi_bits_union_many_and": (_I32, [_VP, _U32, _VP, _U32, _U32]),
     "msi_bits_count": (_I32, [_VP, _U32, C.POINTER(_U64)]),
     "msi_bits_first_k": (_I32, [_VP, _U32, _U32, _VP, C.POINTER(_U32)]),
@@ -146,6 +175,9 @@ PROTOTYPES = {
     "msi_keyword_search": (_I32, [_VP, _VP, C.POINTER(IndexVtable), C.POINTER(QueryToken), _U32,
                                   C.POINTER(KeywordParams), _VP, C.c_size_t, _VP, _VP, _VP, _VP,
                                   C.POINTER(_U32), C.POINTER(_U64)]),
+    "msi_keyword_search_ranked": (_I32, [_VP, _VP, C.POINTER(IndexVtable), C.POINTER(LocatedTerm), _U32,
+                                         C.POINTER(SearchParams), _VP, C.c_size_t, _VP, _VP, _VP,
+                                         C.POINTER(_U32), C.POINTER(_U64)]),
     "msi_distribution_shift": (_F32, [_F32, _F32, _F32]),
     "msi_rank_global_score": (_F64, [_VP, _VP, _U32]),
     "msi_compare_scores": (_I32, [_VP, _U32, _F32, _VP, _U32, _F32]),

@@ -71,6 +71,29 @@ __global__ void bits_op_kernel(u64 *__restrict__ dst, const u64 *__restrict__ a,
   }
 }
 
+// dst = a OP b, *out += |dst|
+template <int OP>
+__global__ void bits_op_count_kernel(u64 *__restrict__ dst, const u64 *__restrict__ a,
+                                     const u64 *__restrict__ b, uint64_t n_pairs, u64 *__restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t c = 0;
+  for (; i < n_pairs; i += stride) {
+    const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(a)[i];
+    const ulonglong2 y = reinterpret_cast<const ulonglong2 *>(b)[i];
+    ulonglong2 r;
+    if (OP == MSI_BITS_AND) { r.x = x.x & y.x; r.y = x.y & y.y; }
+    else if (OP == MSI_BITS_OR) { r.x = x.x | y.x; r.y = x.y | y.y; }
+    else if (OP == MSI_BITS_ANDNOT) { r.x = x.x & ~y.x; r.y = x.y & ~y.y; }
+    else { r.x = x.x ^ y.x; r.y = x.y ^ y.y; }
+    reinterpret_cast<ulonglong2 *>(dst)[i] = r;
+    c += __popcll(r.x) + __popcll(r.y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (u64)c);
+}
+
 // dst = (OR_i pool[srcs[i]]) & pool[universe]
 __global__ void bits_union_many_kernel(u64 *__restrict__ pool, uint64_t n_words, uint32_t dst,
                                        const uint32_t *__restrict__ srcs, uint32_t n, uint32_t universe) {
@@ -492,6 +515,43 @@ int32_t msi_bits_op(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int32_t o
       return MSI_E_INVALID;
   }
   MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+int32_t msi_bits_op_count(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int32_t op, uint64_t *out_count) {
+  MSI_TRY(check_slot(p, dst, "msi_bits_op_count"));
+  MSI_TRY(check_slot(p, a, "msi_bits_op_count"));
+  MSI_TRY(check_slot(p, b, "msi_bits_op_count"));
+  if (!out_count) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  const uint64_t n_pairs = p->n_words / 2;
+  const dim3 grid(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 8)), block(BT);
+  hipStream_t st = p->ctx->stream;
+  u64 *cnt = p->small.as<u64>();
+  MSI_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(u64), st));
+  switch (op) {
+    case MSI_BITS_AND:
+      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_AND>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, cnt);
+      break;
+    case MSI_BITS_OR:
+      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_OR>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, cnt);
+      break;
+    case MSI_BITS_ANDNOT:
+      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_ANDNOT>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, cnt);
+      break;
+    case MSI_BITS_XOR:
+      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_XOR>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, cnt);
+      break;
+    default:
+      msi_set_error("msi_bits_op_count: unknown op %d", op);
+      return MSI_E_INVALID;
+  }
+  MSI_HIP_TRY(hipGetLastError());
+  u64 v = 0;
+  MSI_HIP_TRY(hipMemcpyAsync(&v, cnt, sizeof(u64), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  *out_count = v;
   return MSI_OK;
 }
 

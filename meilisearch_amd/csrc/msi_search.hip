@@ -1,0 +1,1556 @@
+// msi_search.hip — the keyword leg of Search::execute() with every graph-based ranking rule.
+//
+// Host side of the scorer (S3): the query graph and the rule graphs are tiny (tens of nodes) and
+// stay on the caller's thread; every docid set is a slot of the msi_bits pool in HBM and every
+// set operation is a device kernel (msi_bits.hip): batched CboRoaringBitmap decode of all the
+// postings of a condition in one launch, and / or / andnot, fused op + cardinality, ordered
+// extraction.  No set is ever materialised on the host.
+//
+// Restates, in crates/milli/src/search/new/:
+//   query_term/{mod.rs,ntypo_subset.rs}                      term subsets
+//   query_term/parse_query.rs:227-300                        make_ngram
+//   query_term/compute_derivations.rs:21-383                 derivations (device dictionary, batched)
+//   query_graph.rs:96-180,200-305,346-440,470-544            from_query, edges, removal order, build_from_paths
+//   resolve_query_graph.rs:33-268                            term / phrase / graph docids
+//   ranking_rule_graph/build.rs:12-91                        rule graph (edge order = DFS order)
+//   ranking_rule_graph/cheapest_paths.rs:94-310              paths of a given cost, nodes_to_skip
+//   ranking_rule_graph/{words,typo,proximity,fid,position,exactness}/
+//   graph_based_ranking_rule.rs:136-368                      buckets by increasing cost
+//   exact_attribute.rs:17-302, bucket_sort.rs:23-460, mod.rs:273-301,510-649
+// The reference's DeadEndsCache only prunes paths that resolve to no document; here a path is not
+// extended past a prefix whose documents are exhausted, which visits the same non-empty paths in
+// the same order.  fid/mod.rs and position/mod.rs push their edges in hash-map order (unspecified);
+// here ascending fid / ascending cost.
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "msi_common.h"
+
+struct msi_dict;
+bool msi_dict_word(const msi_dict *d, uint32_t idx, const uint8_t **w, uint32_t *len);
+void msi_dict_prefix_range(const msi_dict *d, const uint8_t *prefix, uint32_t plen, uint32_t *lo, uint32_t *hi);
+uint32_t msi_bits_n_slots(msi_bits *p);
+
+namespace {
+
+constexpr uint32_t MAX_PREFIX_COUNT = 1000, MAX_ONE_TYPO_COUNT = 150, MAX_TWO_TYPOS_COUNT = 50;  // limits.rs
+constexpr uint32_t MAX_WORD_LENGTH = 250;                                                        // lib.rs:146
+constexpr uint32_t MAX_DISTANCE = 4;                                                             // proximity.rs:7
+
+struct Fail {
+  int32_t code;
+};
+void ck(int32_t st) {
+  if (st != MSI_OK) throw Fail{st};
+}
+[[noreturn]] void fail(int32_t code, const char *msg) {
+  msi_set_error("msi_keyword_search_ranked: %s", msg);
+  throw Fail{code};
+}
+
+// ---- device sets ------------------------------------------------------------------------------
+struct SetPool {
+  msi_bits *p;
+  std::vector<uint32_t> free_;
+  SetPool(msi_bits *p_, uint32_t first) : p(p_) {
+    for (uint32_t s = msi_bits_n_slots(p_); s-- > first;) free_.push_back(s);
+  }
+};
+struct SetH {
+  SetPool *pool;
+  uint32_t slot;
+  ~SetH() { pool->free_.push_back(slot); }
+};
+using Set = std::shared_ptr<SetH>;
+
+struct Dev {
+  SetPool pool;
+  explicit Dev(msi_bits *p) : pool(p, 0) {}
+  Set alloc() {
+    if (pool.free_.empty()) fail(MSI_E_OOM, "the msi_bits pool has no free slot left (create it with more slots)");
+    const uint32_t s = pool.free_.back();
+    pool.free_.pop_back();
+    return Set(new SetH{&pool, s});
+  }
+  Set zeros() {
+    Set s = alloc();
+    ck(msi_bits_fill(pool.p, s->slot, 0));
+    return s;
+  }
+  Set ones() {
+    Set s = alloc();
+    ck(msi_bits_fill(pool.p, s->slot, 1));
+    return s;
+  }
+  Set clone(const Set &a) {
+    Set s = alloc();
+    ck(msi_bits_op(pool.p, s->slot, a->slot, a->slot, MSI_BITS_AND));
+    return s;
+  }
+  void and_(const Set &d, const Set &a) { ck(msi_bits_op(pool.p, d->slot, d->slot, a->slot, MSI_BITS_AND)); }
+  void or_(const Set &d, const Set &a) { ck(msi_bits_op(pool.p, d->slot, d->slot, a->slot, MSI_BITS_OR)); }
+  void sub_(const Set &d, const Set &a) { ck(msi_bits_op(pool.p, d->slot, d->slot, a->slot, MSI_BITS_ANDNOT)); }
+  Set and_new(const Set &a, const Set &b, uint64_t *count) {
+    Set s = alloc();
+    if (count) ck(msi_bits_op_count(pool.p, s->slot, a->slot, b->slot, MSI_BITS_AND, count));
+    else ck(msi_bits_op(pool.p, s->slot, a->slot, b->slot, MSI_BITS_AND));
+    return s;
+  }
+  uint64_t count(const Set &a) {
+    uint64_t c = 0;
+    ck(msi_bits_count(pool.p, a->slot, &c));
+    return c;
+  }
+  Set decode(const MsiCboBatch &b) {
+    Set s = alloc();
+    if (b.containers.empty() && b.small_ids.empty()) ck(msi_bits_fill(pool.p, s->slot, 0));
+    else ck(msi_bits_decode_batch(pool.p, s->slot, b, true));
+    return s;
+  }
+  std::vector<uint32_t> first_k(const Set &a, uint32_t k) {
+    std::vector<uint32_t> ids(std::max<uint32_t>(k, 1));
+    uint32_t n = 0;
+    ck(msi_bits_first_k(pool.p, a->slot, k, ids.data(), &n));
+    ids.resize(n);
+    return ids;
+  }
+};
+
+// ---- terms and subsets (query_term/mod.rs, ntypo_subset.rs) -------------------------------------------
+using Phrase = std::vector<int32_t>;  // word ids, -1 = a stop word inside the phrase
+
+struct NTypo {
+  uint8_t kind = 1;  // 0 Nothing, 1 All, 2 Subset
+  std::set<uint32_t> words, phrases;
+  bool is_empty() const { return kind == 0 || (kind == 2 && words.empty() && phrases.empty()); }
+  bool has_word(uint32_t w) const { return kind == 1 || (kind == 2 && words.count(w)); }
+  bool has_phrase(uint32_t p) const { return kind == 1 || (kind == 2 && phrases.count(p)); }
+  void intersect(const NTypo &o) {
+    if (kind == 1) { *this = o; return; }
+    if (kind == 0 || o.kind == 1) return;
+    if (o.kind == 0) { *this = NTypo{0, {}, {}}; return; }
+    std::set<uint32_t> w, p;
+    for (uint32_t x : words) if (o.words.count(x)) w.insert(x);
+    for (uint32_t x : phrases) if (o.phrases.count(x)) p.insert(x);
+    words.swap(w);
+    phrases.swap(p);
+  }
+  auto key() const { return std::tie(kind, words, phrases); }
+  bool operator<(const NTypo &o) const { return key() < o.key(); }
+  bool operator==(const NTypo &o) const { return key() == o.key(); }
+};
+const NTypo NT_NONE{0, {}, {}};
+
+struct Subset {
+  uint32_t term = 0;
+  NTypo zero, one, two;
+  bool mandatory = false;
+  auto key() const { return std::tie(term, zero, one, two, mandatory); }
+  bool operator<(const Subset &o) const { return key() < o.key(); }
+  bool operator==(const Subset &o) const { return key() == o.key(); }
+};
+struct Located {
+  Subset subset;
+  uint32_t pos_lo = 0, pos_hi = 0, id_lo = 0, id_hi = 0;
+  uint32_t n_ids() const { return id_hi - id_lo + 1; }
+  auto key() const { return std::tie(subset, pos_lo, pos_hi, id_lo, id_hi); }
+  bool operator<(const Located &o) const { return key() < o.key(); }
+  bool operator==(const Located &o) const { return key() == o.key(); }
+};
+
+struct Term {
+  uint32_t original = 0;
+  bool is_ngram = false;
+  std::vector<uint32_t> ngram_words;
+  int32_t phrase = -1;
+  uint32_t max_lev = 0;
+  bool is_prefix = false;
+  int32_t exact = -1;
+  std::vector<uint32_t> prefix_of, one_typo, two_typos;
+  int32_t split_words = -1;
+  bool too_long = false;
+};
+
+enum RuleKind { R_WORDS, R_TYPO, R_PROXIMITY, R_FID, R_POSITION, R_EXACTNESS, R_EXACT_ATTRIBUTE };
+enum CondKind { C_TERM, C_TYPO, C_PROX, C_FID, C_POSITION, C_EXACT, C_ANY };
+
+struct Condition {
+  int kind = C_TERM;
+  Located term;            // destination term
+  Located left;            // C_PROX
+  bool has_left = false;
+  uint32_t x = 0;          // typo count / proximity cost / fid
+  bool has_fid = false;    // C_FID
+  std::vector<uint16_t> positions;
+  auto key() const { return std::tie(kind, term, has_left, left, x, has_fid, positions); }
+  bool operator<(const Condition &o) const { return key() < o.key(); }
+};
+
+struct GNode {
+  int kind = 0;  // 0 start, 1 end, 2 term, 3 deleted
+  Located term;
+  std::set<uint32_t> preds, succs;
+};
+struct Graph {
+  std::vector<GNode> nodes;
+  static constexpr uint32_t ROOT = 0, END = 1;
+};
+using PathSubsets = std::vector<std::pair<std::pair<bool, Located>, Located>>;  // (start?, dest) per condition
+
+struct Score {
+  uint32_t kind, a, b;
+};
+
+// ---- the search context ---------------------------------------------------------------------
+struct Ctx {
+  msi_dict *dict;
+  const msi_index_vtable *ix;
+  const msi_search_params *prm;
+  Dev dev;
+  std::vector<std::string> words;
+  std::map<std::string, uint32_t> word_ids;
+  std::vector<Phrase> phrases;
+  std::map<Phrase, uint32_t> phrase_ids;
+  std::vector<Term> terms;
+  std::map<uint32_t, Set> phrase_cache;
+
+  Ctx(msi_dict *d, msi_bits *pool, const msi_index_vtable *i, const msi_search_params *p)
+      : dict(d), ix(i), prm(p), dev(pool) {}
+
+  uint32_t word(const std::string &w) {
+    auto it = word_ids.find(w);
+    if (it != word_ids.end()) return it->second;
+    words.push_back(w);
+    return word_ids[w] = (uint32_t)words.size() - 1;
+  }
+  uint32_t phrase(const Phrase &p) {
+    auto it = phrase_ids.find(p);
+    if (it != phrase_ids.end()) return it->second;
+    phrases.push_back(p);
+    return phrase_ids[p] = (uint32_t)phrases.size() - 1;
+  }
+
+  // -- the index reads (postings arrive as stored bytes and go straight into a decode batch) -----
+  void take(MsiCboBatch &b, int32_t st, const uint8_t *bytes, size_t n, const char *what) {
+    if (st < 0) {
+      msi_set_error("msi_keyword_search_ranked: %s callback failed (%d)", what, st);
+      throw Fail{MSI_E_INTERNAL};
+    }
+    if (n && bytes && !msi_cbo_batch_append(b, bytes, n)) {
+      msi_set_error("msi_keyword_search_ranked: malformed posting list from %s", what);
+      throw Fail{MSI_E_INVALID};
+    }
+  }
+  bool add_word(MsiCboBatch &b, uint32_t w, bool original) {
+    const std::string &s = words[w];
+    const uint8_t *bytes = nullptr;
+    size_t n = 0;
+    const int32_t st = ix->word_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), original ? 1 : 0, &bytes, &n);
+    take(b, st, bytes, n, "word_docids");
+    return n != 0;
+  }
+  uint64_t add_pair(MsiCboBatch *b, uint32_t prox, uint32_t w1, uint32_t w2) {  // returns the cardinality
+    if (!ix->word_pair_proximity_docids) return 0;
+    const std::string &l = words[w1], &r = words[w2];
+    const uint8_t *bytes = nullptr;
+    size_t n = 0;
+    const int32_t st = ix->word_pair_proximity_docids(ix->user, prox, (const uint8_t *)l.data(), (uint32_t)l.size(),
+                                                      (const uint8_t *)r.data(), (uint32_t)r.size(), &bytes, &n);
+    if (st < 0) fail(MSI_E_INTERNAL, "word_pair_proximity_docids callback failed");
+    if (!n || !bytes) return 0;
+    const uint64_t card = msi_cbo_cardinality(bytes, n);
+    if (b) take(*b, st, bytes, n, "word_pair_proximity_docids");
+    return card;
+  }
+  void add_word_fid(MsiCboBatch &b, uint32_t w, uint32_t fid) {
+    if (!ix->word_fid_docids) fail(MSI_E_INVALID, "the index vtable has no word_fid_docids (attribute / exactness rule)");
+    const std::string &s = words[w];
+    const uint8_t *bytes = nullptr;
+    size_t n = 0;
+    take(b, ix->word_fid_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), fid, &bytes, &n), bytes, n,
+         "word_fid_docids");
+  }
+  void add_word_position(MsiCboBatch &b, uint32_t w, uint32_t pos) {
+    if (!ix->word_position_docids)
+      fail(MSI_E_INVALID, "the index vtable has no word_position_docids (position / exactness rule)");
+    const std::string &s = words[w];
+    const uint8_t *bytes = nullptr;
+    size_t n = 0;
+    take(b, ix->word_position_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), pos, &bytes, &n), bytes, n,
+         "word_position_docids");
+  }
+  std::vector<uint16_t> list_of(decltype(msi_index_vtable::word_fids) fn, uint32_t w, const char *what) {
+    if (!fn) {
+      msi_set_error("msi_keyword_search_ranked: the index vtable has no %s", what);
+      throw Fail{MSI_E_INVALID};
+    }
+    const std::string &s = words[w];
+    std::vector<uint16_t> out(64);
+    for (;;) {
+      uint32_t n = 0;
+      if (fn(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), out.data(), (uint32_t)out.size(), &n) < 0)
+        fail(MSI_E_INTERNAL, "word_fids / word_positions callback failed");
+      if (n <= out.size()) {
+        out.resize(n);
+        return out;
+      }
+      out.resize(n);
+    }
+  }
+
+  uint32_t budget(const std::string &w) {  // number_of_typos_allowed, parse_query.rs:204-225 (chars, not bytes)
+    uint32_t chars = 0;
+    for (unsigned char c : w) chars += (c & 0xC0) != 0x80;
+    const bool exact = ix->is_exact_word && ix->is_exact_word(ix->user, (const uint8_t *)w.data(), (uint32_t)w.size()) > 0;
+    if (!prm->authorize_typos || chars < prm->min_word_len_one_typo || exact) return 0;
+    return chars < prm->min_word_len_two_typos ? 1 : 2;
+  }
+
+  // partially_initialized_term_from_word, compute_derivations.rs:170-253 (no prefix DB, no synonyms)
+  Term term_from_word(const std::string &w, uint32_t max_typo, bool is_prefix) {
+    Term t;
+    t.original = word(w);
+    if (w.size() > MAX_WORD_LENGTH) {
+      t.too_long = true;
+      return t;
+    }
+    t.max_lev = max_typo;
+    t.is_prefix = is_prefix;
+    MsiCboBatch probe;
+    if (add_word(probe, t.original, true)) t.exact = (int32_t)t.original;  // Index::contains_word
+    if (is_prefix) {
+      uint32_t lo = 0, hi = 0;
+      msi_dict_prefix_range(dict, (const uint8_t *)w.data(), (uint32_t)w.size(), &lo, &hi);
+      for (uint32_t i = lo; i < hi && t.prefix_of.size() < MAX_PREFIX_COUNT; ++i) {
+        const uint8_t *dw;
+        uint32_t dl;
+        msi_dict_word(dict, i, &dw, &dl);
+        if (dl == w.size()) continue;
+        t.prefix_of.push_back(word(std::string((const char *)dw, dl)));
+      }
+    }
+    return t;
+  }
+
+  // compute_fully_if_needed for every term of the query: ONE batched device dictionary lookup
+  void compute_derivations() {
+    std::vector<msi_typo_query> tq;
+    std::vector<uint32_t> owner;
+    for (uint32_t ti = 0; ti < terms.size(); ++ti) {
+      Term &t = terms[ti];
+      if (t.phrase >= 0 || t.too_long || t.max_lev == 0) continue;
+      const std::string &w = words[t.original];
+      msi_typo_query q;
+      q.word = (const uint8_t *)w.data();
+      q.len = (uint32_t)w.size();
+      q.max_typos = (uint8_t)t.max_lev;
+      q.is_prefix = t.is_prefix ? 1 : 0;
+      q._pad = 0;
+      tq.push_back(q);
+      owner.push_back(ti);
+    }
+    std::vector<uint32_t> one(tq.size() * MAX_ONE_TYPO_COUNT), two(tq.size() * MAX_TWO_TYPOS_COUNT), n1(tq.size()),
+        n2(tq.size());
+    if (!tq.empty())
+      ck(msi_dict_lookup(dict, tq.data(), (uint32_t)tq.size(), MAX_ONE_TYPO_COUNT, MAX_TWO_TYPOS_COUNT, one.data(),
+                         n1.data(), two.data(), n2.data()));
+    auto dict_word = [&](uint32_t idx) {
+      const uint8_t *dw;
+      uint32_t dl;
+      msi_dict_word(dict, idx, &dw, &dl);
+      return word(std::string((const char *)dw, dl));
+    };
+    for (size_t k = 0; k < owner.size(); ++k) {
+      Term &t = terms[owner[k]];
+      for (uint32_t i = 0; i < n1[k]; ++i) t.one_typo.push_back(dict_word(one[k * MAX_ONE_TYPO_COUNT + i]));
+      if (t.max_lev > 1)
+        for (uint32_t i = 0; i < n2[k]; ++i) t.two_typos.push_back(dict_word(two[k * MAX_TWO_TYPOS_COUNT + i]));
+    }
+    // split words: the most frequent adjacent pair (compute_derivations.rs:363-383), part of the
+    // one-typo subterm for every budget; not for phrases; an n-gram (budget <= 1) is not split back
+    // into its own words (:296-309)
+    for (Term &t : terms) {
+      if (t.phrase >= 0 || t.too_long || !ix->word_pair_proximity_docids) continue;
+      const std::string w = words[t.original];
+      uint64_t best = 0;
+      size_t at = 0;
+      for (size_t i = 1; i < w.size(); ++i) {
+        if ((w[i] & 0xC0) == 0x80) continue;
+        const uint64_t f = add_pair(nullptr, 1, word(w.substr(0, i)), word(w.substr(i)));
+        if (f > best) {
+          best = f;
+          at = i;
+        }
+      }
+      if (!best) continue;
+      Phrase sp{(int32_t)word(w.substr(0, at)), (int32_t)word(w.substr(at))};
+      if (t.max_lev <= 1 && t.is_ngram && t.ngram_words.size() == 2 && (int32_t)t.ngram_words[0] == sp[0] &&
+          (int32_t)t.ngram_words[1] == sp[1])
+        continue;
+      t.split_words = (int32_t)phrase(sp);
+    }
+  }
+
+  // -- QueryTermSubset ---------------------------------------------------------------------------
+  Subset full(uint32_t ti) {
+    Subset s;
+    s.term = ti;
+    return s;
+  }
+  // -> (kind 0 none / 1 phrase / 2 word, id)
+  std::pair<int, uint32_t> exact_term(const Subset &ss) {
+    const Term &t = terms[ss.term];
+    if (t.is_ngram) return {0, 0};
+    if (t.phrase >= 0) return ss.zero.has_phrase((uint32_t)t.phrase) ? std::make_pair(1, (uint32_t)t.phrase) : std::make_pair(0, 0u);
+    if (t.exact >= 0) return ss.zero.has_word((uint32_t)t.exact) ? std::make_pair(2, (uint32_t)t.exact) : std::make_pair(0, 0u);
+    return {0, 0};
+  }
+  std::set<std::pair<uint32_t, bool>> all_single_words(const Subset &ss) {  // (word, Word::Original?)
+    const Term &t = terms[ss.term];
+    const bool orig = !t.is_ngram;
+    std::set<std::pair<uint32_t, bool>> out;
+    if (ss.zero.kind != 0) {
+      if (t.exact >= 0 && ss.zero.has_word((uint32_t)t.exact)) out.insert({(uint32_t)t.exact, orig});
+      for (uint32_t w : t.prefix_of)
+        if (ss.zero.has_word(w)) out.insert({w, orig});
+    }
+    if (ss.one.kind != 0)
+      for (uint32_t w : t.one_typo)
+        if (ss.one.has_word(w)) out.insert({w, false});
+    if (ss.two.kind != 0)
+      for (uint32_t w : t.two_typos)
+        if (ss.two.has_word(w)) out.insert({w, false});
+    return out;
+  }
+  std::set<uint32_t> all_phrases(const Subset &ss) {
+    const Term &t = terms[ss.term];
+    std::set<uint32_t> out;
+    if (t.phrase >= 0) out.insert((uint32_t)t.phrase);  // regardless of the zero-typo subset, as the reference
+    if (ss.one.kind != 0 && t.split_words >= 0 && ss.one.has_phrase((uint32_t)t.split_words))
+      out.insert((uint32_t)t.split_words);
+    return out;
+  }
+  int32_t original_phrase(const Subset &ss) {
+    const Term &t = terms[ss.term];
+    return (t.phrase >= 0 && ss.zero.has_phrase((uint32_t)t.phrase)) ? t.phrase : -1;
+  }
+  uint32_t max_typo_cost(const Subset &ss) {  // query_term/mod.rs:340-370
+    const Term &t = terms[ss.term];
+    if (t.max_lev == 0) return t.phrase < 0 ? 1 : 0;
+    if (t.max_lev == 1) return ss.one.is_empty() ? 0 : 1;
+    if (ss.two.is_empty()) return ss.one.is_empty() ? 0 : 1;
+    return 2;
+  }
+  Subset keep_only_exact_term(Subset ss) {
+    auto e = exact_term(ss);
+    if (e.first == 0) return ss;
+    NTypo z{2, {}, {}};
+    if (e.first == 1) z.phrases.insert(e.second);
+    else z.words.insert(e.second);
+    ss.zero = z;
+    ss.one = NT_NONE;
+    ss.two = NT_NONE;
+    return ss;
+  }
+
+  // -- docids (resolve_query_graph.rs), all on the device -----------------------------------------
+  Set word_docids(uint32_t w, bool original) {
+    MsiCboBatch b;
+    add_word(b, w, original);
+    return dev.decode(b);
+  }
+  Set pair_union(uint32_t w1, uint32_t w2, uint32_t max_prox) {  // union of pair(prox = 1..max_prox)
+    MsiCboBatch b;
+    for (uint32_t p = 1; p <= max_prox; ++p) add_pair(&b, p, w1, w2);
+    return dev.decode(b);
+  }
+  // compute_phrase_docids :187-268.  The result is the intersection of the words' documents with, for
+  // every window of <= 3 words and every pair (i < j) in it, the documents where the pair is within
+  // j - i; the reference's early returns are all "the intersection is already empty".
+  Set phrase_docids(uint32_t pid) {
+    auto it = phrase_cache.find(pid);
+    if (it != phrase_cache.end()) return it->second;
+    const Phrase p = phrases[pid];
+    Set cand;
+    {
+      MsiCboBatch none;
+      bool any = false;
+      for (int32_t w : p) {
+        if (w < 0) continue;
+        Set d = word_docids((uint32_t)w, true);
+        if (!any) cand = d;
+        else dev.and_(cand, d);
+        any = true;
+      }
+      if (!any) cand = dev.zeros();
+    }
+    const size_t win = std::min<size_t>(p.size(), 3);
+    for (size_t s = 0; s + win <= p.size() && win > 0; ++s)
+      for (size_t a = 0; a < win; ++a) {
+        if (p[s + a] < 0) continue;
+        for (size_t b = a + 1; b < win; ++b) {
+          if (p[s + b] < 0) continue;
+          Set m = pair_union((uint32_t)p[s + a], (uint32_t)p[s + b], (uint32_t)(b - a));
+          dev.and_(cand, m);
+        }
+      }
+    return phrase_cache[pid] = cand;
+  }
+  // compute_query_term_subset_docids :33-59
+  Set subset_docids(const Set *universe, const Subset &ss) {
+    MsiCboBatch b;
+    for (auto &w : all_single_words(ss)) add_word(b, w.first, w.second);
+    Set d = dev.decode(b);
+    for (uint32_t p : all_phrases(ss)) dev.or_(d, phrase_docids(p));
+    if (universe) dev.and_(d, *universe);
+    return d;
+  }
+  // ..._within_field_id / ..._within_position :61-130 (which: 0 fid, 1 position)
+  Set subset_docids_within(const Set &universe, const Subset &ss, int which, uint32_t key) {
+    MsiCboBatch b;
+    for (auto &w : all_single_words(ss)) {
+      if (which == 0) add_word_fid(b, w.first, key);
+      else add_word_position(b, w.first, key);
+    }
+    Set d = dev.decode(b);
+    for (uint32_t p : all_phrases(ss)) {
+      int32_t first = -1;
+      for (int32_t w : phrases[p])
+        if (w >= 0) {
+          first = w;
+          break;
+        }
+      if (first < 0) continue;
+      MsiCboBatch fb;
+      if (which == 0) add_word_fid(fb, (uint32_t)first, key);
+      else add_word_position(fb, (uint32_t)first, key);
+      Set f = dev.decode(fb);
+      dev.and_(f, phrase_docids(p));
+      dev.or_(d, f);
+    }
+    dev.and_(d, universe);
+    return d;
+  }
+};
+
+// ---- QueryGraph (query_graph.rs) -----------------------------------------------------------------
+void build_initial_edges(Graph &g) {
+  for (GNode &n : g.nodes) {
+    n.preds.clear();
+    n.succs.clear();
+  }
+  for (uint32_t i = 0; i < g.nodes.size(); ++i) {
+    GNode &n = g.nodes[i];
+    int end_prev;
+    if (n.kind == 2) end_prev = (int)n.term.id_hi;
+    else if (n.kind == 0) end_prev = -1;
+    else continue;
+    std::set<uint32_t> succ;
+    int mn = 1 << 30;
+    for (uint32_t j = 0; j < g.nodes.size(); ++j) {
+      const GNode &m = g.nodes[j];
+      int st;
+      if (m.kind == 2) st = (int)m.term.id_lo;
+      else if (m.kind == 1) st = 1 << 29;
+      else continue;
+      if (st <= end_prev) continue;
+      if (st < mn) {
+        mn = st;
+        succ.clear();
+        succ.insert(j);
+      } else if (st == mn) {
+        succ.insert(j);
+      }
+    }
+    n.succs = succ;
+    for (uint32_t j : succ) g.nodes[j].preds.insert(i);
+  }
+}
+
+void remove_nodes_keep_edges(Graph &g, const std::vector<uint32_t> &ids) {
+  for (uint32_t i : ids) {
+    const std::set<uint32_t> pr = g.nodes[i].preds, su = g.nodes[i].succs;
+    for (uint32_t p : pr) {
+      g.nodes[p].succs.erase(i);
+      g.nodes[p].succs.insert(su.begin(), su.end());
+    }
+    for (uint32_t s : su) {
+      g.nodes[s].preds.erase(i);
+      g.nodes[s].preds.insert(pr.begin(), pr.end());
+    }
+    g.nodes[i] = GNode();
+    g.nodes[i].kind = 3;
+  }
+}
+
+// removal_order_for_terms_matching_strategy_last :346-406 — groups of nodes, first removed first
+std::vector<std::set<uint32_t>> removal_order_last(Ctx &c, const Graph &g) {
+  uint32_t first = 255, last = 0;
+  for (const GNode &n : g.nodes)
+    if (n.kind == 2) {
+      last = std::max(last, n.term.id_hi);
+      first = std::min(first, n.term.id_lo);
+    }
+  if (first >= last) return {};
+  std::map<uint32_t, std::set<uint32_t>> groups;
+  bool mandatory = false;
+  for (uint32_t i = 0; i < g.nodes.size(); ++i) {
+    const GNode &n = g.nodes[i];
+    if (n.kind != 2) continue;
+    if (c.original_phrase(n.term.subset) >= 0 || n.term.subset.mandatory) {
+      mandatory = true;
+      continue;
+    }
+    groups[1 + last - n.term.id_lo].insert(i);  // max over the term ids of (1 + last - id)
+  }
+  std::vector<std::set<uint32_t>> res;
+  for (auto &kv : groups) res.push_back(kv.second);
+  if (!mandatory && !res.empty()) res.pop_back();
+  return res;
+}
+
+uint32_t words_in_phrases_count(Ctx &c, const Graph &g) {
+  uint32_t n = 0;
+  for (const GNode &nd : g.nodes)
+    if (nd.kind == 2) {
+      const int32_t p = c.original_phrase(nd.term.subset);
+      if (p >= 0)
+        for (int32_t w : c.phrases[(uint32_t)p]) n += w >= 0;
+    }
+  return n;
+}
+
+// QueryGraph::build_from_paths :470-544 (nodes shared by (term, suffix of the path))
+Graph build_from_paths(const std::vector<PathSubsets> &paths) {
+  std::vector<std::vector<Located>> singles;
+  for (const PathSubsets &path : paths) {
+    std::vector<Located> out;
+    bool has_prev = false;
+    Located prev;
+    for (const auto &cond : path) {
+      const bool has_start = cond.first.first;
+      Located start = cond.first.second;
+      if (has_prev) {
+        if (has_start) {
+          if (start.id_lo == prev.id_lo && start.id_hi == prev.id_hi) {
+            start.subset.zero.intersect(prev.subset.zero);
+            start.subset.one.intersect(prev.subset.one);
+            start.subset.two.intersect(prev.subset.two);
+            out.push_back(start);
+          } else {
+            out.push_back(prev);
+            out.push_back(start);
+          }
+        } else {
+          out.push_back(prev);
+        }
+      } else if (has_start) {
+        out.push_back(start);
+      }
+      prev = cond.second;
+      has_prev = true;
+    }
+    if (has_prev) out.push_back(prev);
+    singles.push_back(std::move(out));
+  }
+  Graph g;
+  g.nodes.resize(2);
+  g.nodes[0].kind = 0;
+  g.nodes[1].kind = 1;
+  std::map<std::vector<Located>, uint32_t> ids;  // keyed by the suffix starting at the term
+  std::vector<std::vector<uint32_t>> id_paths;
+  for (const auto &path : singles) {
+    std::vector<uint32_t> p;
+    for (size_t k = 0; k < path.size(); ++k) {
+      std::vector<Located> suffix(path.begin() + k, path.end());
+      auto it = ids.find(suffix);
+      if (it == ids.end()) {
+        GNode n;
+        n.kind = 2;
+        n.term = path[k];
+        g.nodes.push_back(n);
+        it = ids.emplace(std::move(suffix), (uint32_t)g.nodes.size() - 1).first;
+      }
+      p.push_back(it->second);
+    }
+    id_paths.push_back(std::move(p));
+  }
+  for (const auto &p : id_paths) {
+    uint32_t prev = 0;
+    for (uint32_t i : p) {
+      g.nodes[prev].succs.insert(i);
+      g.nodes[i].preds.insert(prev);
+      prev = i;
+    }
+    g.nodes[prev].succs.insert(1);
+    g.nodes[1].preds.insert(prev);
+  }
+  return g;
+}
+
+// compute_query_graph_docids :133-185
+Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe) {
+  std::set<uint32_t> resolved;
+  std::map<uint32_t, Set> docs;
+  std::vector<uint32_t> queue{Graph::ROOT};
+  size_t guard = 0;
+  while (!queue.empty()) {
+    if (++guard > 100000) fail(MSI_E_INTERNAL, "query graph is not a DAG");
+    const uint32_t i = queue.front();
+    queue.erase(queue.begin());
+    const GNode &n = g.nodes[i];
+    bool ready = true;
+    for (uint32_t p : n.preds) ready &= resolved.count(p) != 0;
+    if (!ready) {
+      queue.push_back(i);
+      continue;
+    }
+    Set pd = c.dev.zeros();
+    for (uint32_t p : n.preds) c.dev.or_(pd, docs[p]);
+    Set nd;
+    if (n.kind == 2) nd = c.subset_docids(&pd, n.term.subset);
+    else if (n.kind == 0) nd = c.dev.clone(universe);
+    else if (n.kind == 1) return pd;
+    else fail(MSI_E_INTERNAL, "deleted node reached");
+    resolved.insert(i);
+    docs[i] = nd;
+    for (uint32_t s : n.succs)
+      if (!resolved.count(s) && std::find(queue.begin(), queue.end(), s) == queue.end()) queue.push_back(s);
+  }
+  fail(MSI_E_INTERNAL, "query graph has no end node");
+}
+
+// ---- rule plug-ins -------------------------------------------------------------------------------
+uint32_t cost_from_distance(uint32_t d) {  // position/mod.rs:127-143
+  static const uint32_t lim[] = {0, 1, 4, 7, 11, 16, 24, 64, 256, 1024};
+  for (uint32_t c = 0; c < 10; ++c)
+    if (d <= lim[c]) return c;
+  return 10;
+}
+
+std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const Located *src, const Located &dst) {
+  std::vector<std::pair<uint32_t, Condition>> out;
+  const uint32_t n = dst.n_ids();
+  auto cond = [&](int k) {
+    Condition x;
+    x.kind = k;
+    x.term = dst;
+    return x;
+  };
+  switch (kind) {
+    case R_WORDS:
+      out.push_back({0, cond(C_TERM)});
+      break;
+    case R_TYPO: {  // typo/mod.rs:41-80
+      const uint32_t base = n == 1 ? 0 : n;
+      const uint32_t mx = c.max_typo_cost(dst.subset);
+      for (uint32_t k = 0; k <= mx; ++k) {
+        Condition x = cond(C_TYPO);
+        if (k != 0) x.term.subset.zero = NT_NONE;
+        if (k != 1) x.term.subset.one = NT_NONE;
+        if (k != 2) x.term.subset.two = NT_NONE;
+        x.x = k;
+        out.push_back({k + base, x});
+      }
+      break;
+    }
+    case R_PROXIMITY: {  // proximity/build.rs:10-56
+      const uint32_t ng = n - 1;
+      if (!src || src->pos_hi + 1 != dst.pos_lo) {
+        out.push_back({ng, cond(C_TERM)});
+        break;
+      }
+      for (uint32_t cost = ng; cost < MAX_DISTANCE - 1 + ng; ++cost) {
+        Condition x = cond(C_PROX);
+        x.left = *src;
+        x.has_left = true;
+        x.x = cost + 1;
+        out.push_back({cost, x});
+      }
+      out.push_back({MAX_DISTANCE - 1 + ng, cond(C_TERM)});
+      break;
+    }
+    case R_FID: {  // fid/mod.rs:51-121
+      std::set<uint16_t> fids;
+      for (auto &w : c.all_single_words(dst.subset))
+        for (uint16_t f : c.list_of(c.ix->word_fids, w.first, "word_fids")) fids.insert(f);
+      for (uint32_t p : c.all_phrases(dst.subset))
+        for (int32_t w : c.phrases[p])
+          if (w >= 0)
+            for (uint16_t f : c.list_of(c.ix->word_fids, (uint32_t)w, "word_fids")) fids.insert(f);
+      uint32_t cur_max = 0;
+      for (uint16_t f : fids) {
+        int32_t weight = -1;
+        for (uint32_t i = 0; i < c.prm->n_searchable; ++i)
+          if (c.prm->searchable_fids[i] == f) weight = c.prm->searchable_weights[i];
+        if (weight < 0) continue;
+        cur_max = std::max(cur_max, (uint32_t)weight);
+        Condition x = cond(C_FID);
+        x.x = f;
+        x.has_fid = true;
+        out.push_back({(uint32_t)weight * n, x});
+      }
+      if (c.prm->max_weight >= 0 && cur_max < (uint32_t)c.prm->max_weight) {
+        Condition x = cond(C_FID);
+        out.push_back({(uint32_t)c.prm->max_weight * n, x});
+      }
+      break;
+    }
+    case R_POSITION: {  // position/mod.rs:50-125
+      std::set<uint16_t> positions;
+      for (auto &w : c.all_single_words(dst.subset))
+        for (uint16_t p : c.list_of(c.ix->word_positions, w.first, "word_positions")) positions.insert(p);
+      for (uint32_t p : c.all_phrases(dst.subset))
+        for (int32_t w : c.phrases[p])
+          if (w >= 0) {
+            for (uint16_t q : c.list_of(c.ix->word_positions, (uint32_t)w, "word_positions")) positions.insert(q);
+            break;
+          }
+      std::map<uint32_t, std::vector<uint16_t>> by_cost;
+      for (uint16_t pos : positions) {
+        const uint32_t dist = pos > dst.pos_lo ? pos - dst.pos_lo : dst.pos_lo - pos;
+        uint32_t cost = 0;
+        for (uint32_t i = 0; i < n; ++i) cost += cost_from_distance(dist + i);
+        by_cost[cost].push_back(pos);
+      }
+      for (auto &kv : by_cost) {
+        Condition x = cond(C_POSITION);
+        x.positions = kv.second;
+        out.push_back({kv.first, x});
+      }
+      if (!by_cost.count(n * 10)) out.push_back({n * 10, cond(C_POSITION)});
+      break;
+    }
+    case R_EXACTNESS:  // exactness/mod.rs:73-87
+      out.push_back({0, cond(C_EXACT)});
+      out.push_back({n, cond(C_ANY)});
+      break;
+  }
+  return out;
+}
+
+struct Resolved {
+  Set docs;
+  bool has_start = false;
+  Located start, end;
+};
+
+// proximity/compute_docids.rs:15-212 (no prefix DB)
+Set proximity_docids(Ctx &c, const Condition &cd, const Set &universe) {
+  const uint32_t rn = cd.term.n_ids();
+  const uint32_t forward = 1 + cd.x - rn, backward = cd.x - rn;
+  std::set<std::pair<int32_t, uint32_t>> lefts, rights;  // (phrase or -1, word)
+  for (auto &w : c.all_single_words(cd.left.subset)) lefts.insert({-1, w.first});
+  for (uint32_t p : c.all_phrases(cd.left.subset))
+    if (c.phrases[p].back() >= 0) lefts.insert({(int32_t)p, (uint32_t)c.phrases[p].back()});
+  for (auto &w : c.all_single_words(cd.term.subset)) rights.insert({-1, w.first});
+  for (uint32_t p : c.all_phrases(cd.term.subset))
+    if (c.phrases[p].front() >= 0) rights.insert({(int32_t)p, (uint32_t)c.phrases[p].front()});
+  Set docids = c.dev.zeros();
+  // all the word-word pairs resolve against the same universe: one decode launch for all of them
+  std::map<std::pair<int32_t, int32_t>, MsiCboBatch> groups;
+  for (auto &l : lefts)
+    for (auto &r : rights) {
+      MsiCboBatch &b = groups[{l.first, r.first}];
+      c.add_pair(&b, forward, l.second, r.second);
+      if (backward >= 1 && l.first < 0 && r.first < 0) c.add_pair(&b, backward, r.second, l.second);
+    }
+  for (auto &kv : groups) {
+    if (kv.second.containers.empty() && kv.second.small_ids.empty()) continue;
+    Set d = c.dev.decode(kv.second);
+    if (kv.first.first >= 0) c.dev.and_(d, c.phrase_docids((uint32_t)kv.first.first));
+    if (kv.first.second >= 0) c.dev.and_(d, c.phrase_docids((uint32_t)kv.first.second));
+    c.dev.or_(docids, d);
+  }
+  c.dev.and_(docids, universe);
+  return docids;
+}
+
+Resolved resolve_condition(Ctx &c, const Condition &cd, const Set &universe) {
+  Resolved r;
+  r.end = cd.term;
+  switch (cd.kind) {
+    case C_TERM:
+    case C_TYPO:
+    case C_ANY:
+      r.docs = c.subset_docids(&universe, cd.term.subset);
+      break;
+    case C_FID:
+      r.docs = cd.has_fid ? c.subset_docids_within(universe, cd.term.subset, 0, cd.x) : c.dev.zeros();
+      break;
+    case C_POSITION:
+      r.docs = c.dev.zeros();
+      for (uint16_t pos : cd.positions) c.dev.or_(r.docs, c.subset_docids_within(universe, cd.term.subset, 1, pos));
+      break;
+    case C_EXACT: {
+      r.end.subset = c.keep_only_exact_term(cd.term.subset);
+      r.end.subset.mandatory = true;
+      auto e = c.exact_term(cd.term.subset);
+      if (e.first == 0) r.docs = c.dev.zeros();
+      else if (e.first == 1) r.docs = c.dev.and_new(c.phrase_docids(e.second), universe, nullptr);
+      else {
+        r.docs = c.word_docids(e.second, true);
+        c.dev.and_(r.docs, universe);
+      }
+      break;
+    }
+    case C_PROX:
+      r.docs = proximity_docids(c, cd, universe);
+      r.has_start = true;
+      r.start = cd.left;
+      break;
+  }
+  return r;
+}
+
+// ---- rules ---------------------------------------------------------------------------------------
+struct Bucket {
+  Graph graph;
+  Set docs;
+  uint64_t count = 0;
+  Score score{0, 0, 0};
+};
+
+struct Rule {
+  int kind;
+  int tms;  // -1 none, MSI_TERMS_LAST, MSI_TERMS_ALL
+  Rule(int k, int t) : kind(k), tms(t) {}
+  virtual ~Rule() {}
+  virtual void start(Ctx &c, const Set &universe, const Graph &g) = 0;
+  virtual bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) = 0;
+  virtual void end() = 0;
+};
+
+struct Edge {
+  uint32_t cost;
+  int32_t cond;  // -1: unconditional
+  uint32_t dest;
+  std::set<uint32_t> skip;
+};
+
+struct GraphRule : Rule {
+  Graph g;
+  std::vector<Condition> conds;
+  std::vector<std::vector<Edge>> edges;
+  std::vector<std::vector<uint64_t>> costs;
+  std::vector<char> costs_done;
+  std::map<int32_t, Resolved> cache;
+  uint64_t next_max_cost = 1, cur_cost = 0;
+
+  // per next_bucket state
+  Ctx *cx = nullptr;
+  Set uni, bucket;
+  uint64_t uni_count = 0, bucket_count = 0;
+  struct StackE {
+    int32_t cond;
+    Set docs;
+    bool stale;
+    uint64_t count;
+  };
+  std::vector<StackE> stack;
+  std::vector<std::vector<int32_t>> good;
+  bool stop = false;
+
+  GraphRule(int k, int t) : Rule(k, t) {}
+
+  void start(Ctx &c, const Set &, const Graph &graph) override {
+    g = graph;
+    conds.clear();
+    cache.clear();
+    next_max_cost = 1;
+    cur_cost = 0;
+    std::map<uint32_t, std::pair<uint32_t, std::set<uint32_t>>> skip_cost;
+    if (tms >= 0) {
+      const uint32_t wp = words_in_phrases_count(c, g);
+      next_max_cost += wp > 0 ? wp - 1 : 0;
+      if (tms == MSI_TERMS_LAST) {
+        std::set<uint32_t> forbidden;
+        for (auto &ns : removal_order_last(c, g)) {
+          for (uint32_t n : ns) skip_cost[n] = {1, forbidden};
+          forbidden.insert(ns.begin(), ns.end());
+        }
+      }
+    }
+    std::map<Condition, int32_t> cond_id;
+    edges.assign(g.nodes.size(), {});
+    for (uint32_t i = 0; i < g.nodes.size(); ++i) {
+      const GNode &n = g.nodes[i];
+      if (n.kind != 0 && n.kind != 2) continue;
+      std::set<std::tuple<uint32_t, uint32_t, int32_t>> seen;  // (dest, cost, cond): Edge equality, mod.rs:62-70
+      auto push = [&](Edge e) {
+        if (seen.insert({e.dest, e.cost, e.cond}).second) edges[i].push_back(std::move(e));
+      };
+      for (uint32_t d : n.succs) {
+        const GNode &dn = g.nodes[d];
+        if (dn.kind == 1) {
+          push(Edge{0, -1, d, {}});
+          continue;
+        }
+        auto sk = skip_cost.find(d);
+        if (sk != skip_cost.end()) push(Edge{sk->second.first * dn.term.n_ids(), -1, d, sk->second.second});
+        for (auto &ce : build_edges(c, kind, n.kind == 2 ? &n.term : nullptr, dn.term)) {
+          auto it = cond_id.find(ce.second);
+          if (it == cond_id.end()) {
+            conds.push_back(ce.second);
+            it = cond_id.emplace(ce.second, (int32_t)conds.size() - 1).first;
+          }
+          push(Edge{ce.first, it->second, d, {}});
+        }
+      }
+    }
+    costs.assign(g.nodes.size(), {});
+    costs_done.assign(g.nodes.size(), 0);
+    const auto &rc = costs_to_end(Graph::ROOT);
+    next_max_cost += rc.empty() ? 0 : rc.back();
+  }
+
+  const std::vector<uint64_t> &costs_to_end(uint32_t i) {  // find_all_costs_to_end, cheapest_paths.rs:312-340
+    if (costs_done[i]) return costs[i];
+    costs_done[i] = 1;
+    if (i == Graph::END) {
+      costs[i] = {0};
+      return costs[i];
+    }
+    std::set<uint64_t> out;
+    for (const Edge &e : edges[i])
+      for (uint64_t cc : costs_to_end(e.dest)) out.insert(e.cost + cc);
+    costs[i].assign(out.begin(), out.end());
+    return costs[i];
+  }
+
+  bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) override {
+    const auto &rc = costs[Graph::ROOT];
+    auto it = std::lower_bound(rc.begin(), rc.end(), cur_cost);
+    if (it == rc.end()) return false;
+    const uint64_t cost = *it;
+    cur_cost = cost + 1;
+    const uint32_t rank = (uint32_t)(next_max_cost - cost), mx = (uint32_t)next_max_cost;
+    switch (kind) {  // rank_to_score of each rule + score_details.rs:440-509
+      case R_WORDS: out.score = {MSI_SCORE_WORDS, rank, mx}; break;
+      case R_TYPO: out.score = {MSI_SCORE_TYPO, mx - rank, mx - 1}; break;
+      case R_PROXIMITY: out.score = {MSI_SCORE_PROXIMITY, rank, mx}; break;
+      case R_FID: out.score = {MSI_SCORE_FID, rank, mx}; break;
+      case R_POSITION: out.score = {MSI_SCORE_POSITION, rank, mx}; break;
+      default: out.score = {MSI_SCORE_EXACT_WORDS, rank > 0 ? rank - 1 : 0, mx > 0 ? mx - 1 : 0}; break;
+    }
+    cx = &c;
+    uni = c.dev.clone(universe);
+    uni_count = universe_count;
+    bucket = c.dev.zeros();
+    bucket_count = 0;
+    stack.clear();
+    good.clear();
+    stop = false;
+    std::set<uint32_t> visited, to_skip;
+    visit(Graph::ROOT, cost, visited, to_skip);
+    std::vector<PathSubsets> paths;
+    for (auto &p : good) {
+      PathSubsets ps;
+      for (int32_t ci : p) {
+        const Resolved &r = cache[ci];
+        ps.push_back({{r.has_start, r.start}, r.end});
+      }
+      paths.push_back(std::move(ps));
+    }
+    out.graph = build_from_paths(paths);
+    out.docs = bucket;
+    out.count = bucket_count;
+    uni.reset();
+    bucket.reset();
+    stack.clear();
+    return true;
+  }
+
+  const Resolved &resolved(int32_t ci) {
+    auto it = cache.find(ci);
+    if (it == cache.end()) it = cache.emplace(ci, resolve_condition(*cx, conds[ci], uni)).first;
+    return it->second;
+  }
+
+  // cheapest_paths.rs:147-310: edges in insertion order; a conditional edge cannot enter a node that
+  // must be skipped, nor be taken once a node named by its skip list was traversed
+  void visit(uint32_t node, uint64_t remaining, std::set<uint32_t> &visited, const std::set<uint32_t> &to_skip) {
+    for (const Edge &e : edges[node]) {
+      if (stop) return;
+      if (remaining < e.cost) continue;
+      const uint64_t rem = remaining - e.cost;
+      const auto &dc = costs[e.dest];
+      if (!std::binary_search(dc.begin(), dc.end(), rem)) continue;
+      if (e.cond < 0) {
+        if (e.dest == Graph::END) {
+          emit();
+        } else {
+          std::set<uint32_t> ts = to_skip;
+          ts.insert(e.skip.begin(), e.skip.end());
+          visit(e.dest, rem, visited, ts);
+        }
+        continue;
+      }
+      if (to_skip.count(e.dest)) continue;
+      bool blocked = false;
+      for (uint32_t s : e.skip) blocked |= visited.count(s) != 0;
+      if (blocked) continue;
+      const Resolved &r = resolved(e.cond);
+      uint64_t cnt = 0;
+      // stack entries are subsets of the current universe, so only the first condition needs it
+      Set d = cx->dev.and_new(r.docs, stack.empty() ? uni : stack.back().docs, &cnt);
+      if (!cnt) continue;  // every extension of an empty prefix is empty
+      stack.push_back({e.cond, d, false, cnt});
+      visited.insert(e.dest);
+      std::set<uint32_t> ts = to_skip;
+      ts.insert(e.skip.begin(), e.skip.end());
+      visit(e.dest, rem, visited, ts);
+      visited.erase(e.dest);
+      stack.pop_back();
+    }
+  }
+
+  void emit() {
+    if (!uni_count) {
+      stop = true;
+      return;
+    }
+    Set docs;
+    uint64_t cnt;
+    if (stack.empty()) {
+      docs = cx->dev.clone(uni);
+      cnt = uni_count;
+    } else {
+      StackE &top = stack.back();
+      if (top.stale) {
+        top.count = cx->dev.count(top.docs);
+        top.stale = false;
+      }
+      cnt = top.count;
+      if (!cnt) return;
+      docs = cx->dev.clone(top.docs);
+    }
+    std::vector<int32_t> path;
+    for (auto &s : stack) path.push_back(s.cond);
+    good.push_back(std::move(path));
+    cx->dev.or_(bucket, docs);
+    bucket_count += cnt;
+    cx->dev.sub_(uni, docs);
+    uni_count -= cnt;
+    for (auto &s : stack) {
+      cx->dev.sub_(s.docs, docs);
+      s.stale = true;
+    }
+    if (!stack.empty()) {
+      stack.back().stale = false;
+      stack.back().count = 0;
+    }
+    if (!uni_count) stop = true;
+  }
+
+  void end() override {
+    cache.clear();
+    conds.clear();
+    edges.clear();
+  }
+};
+
+// exact_attribute.rs:17-302.  The reference's `is_empty()` shortcuts only skip work: an empty candidate
+// set yields empty ExactMatch / MatchesStart buckets, which bucket_sort drops.
+struct ExactAttributeRule : Rule {
+  Graph g;
+  int state = 0;  // 0 empty, 1 exact attribute, 2 attribute starts
+  std::vector<std::pair<Set, Set>> per_attr;  // (start_with_exact, exact_word_count)
+  ExactAttributeRule() : Rule(R_EXACT_ATTRIBUTE, -1) {}
+
+  static uint32_t bucketed_position(uint32_t rel) {  // lib.rs:248-262
+    if (rel < 16) return rel;
+    if (rel < 24) return 24;
+    uint32_t p = 1;
+    while (p < rel) p <<= 1;
+    return p;
+  }
+
+  void start(Ctx &c, const Set &universe, const Graph &graph) override {
+    g = graph;
+    state = 0;
+    per_attr.clear();
+    struct Info {
+      uint32_t start_id;
+      std::pair<int, uint32_t> exact;
+      uint32_t start_pos, n_pos;
+    };
+    std::vector<Info> infos;
+    for (const GNode &n : g.nodes) {
+      if (n.kind != 2) continue;
+      auto e = c.exact_term(n.term.subset);
+      if (e.first == 0) continue;
+      infos.push_back({n.term.id_lo, e, n.term.pos_lo, n.term.pos_hi - n.term.pos_lo + 1});
+    }
+    std::stable_sort(infos.begin(), infos.end(), [](const Info &a, const Info &b) { return a.start_id < b.start_id; });
+    std::vector<Info> ded;
+    for (auto &x : infos)
+      if (ded.empty() || ded.back().start_id != x.start_id) ded.push_back(x);
+    uint32_t count_all = 0;
+    for (auto &x : ded) count_all += x.n_pos;
+    if (ded.empty() || ded[0].start_id != 0) return;
+    uint32_t prev = 0;
+    for (auto &x : ded) {
+      if (x.start_id < prev || x.start_id - prev > 1) return;
+      prev = x.start_id;
+    }
+    std::vector<std::pair<Phrase, uint32_t>> words_positions;
+    for (auto &x : ded) {
+      Phrase ws;
+      if (x.exact.first == 1) ws = c.phrases[x.exact.second];
+      else ws.push_back((int32_t)x.exact.second);
+      words_positions.push_back({ws, x.start_pos});
+    }
+    Set cand = c.dev.clone(universe);
+    for (auto &wp : words_positions)
+      for (size_t off = 0; off < wp.first.size(); ++off) {
+        if (wp.first[off] < 0) continue;
+        MsiCboBatch b;
+        c.add_word_position(b, (uint32_t)wp.first[off], bucketed_position(wp.second + (uint32_t)off));
+        c.dev.and_(cand, c.dev.decode(b));
+      }
+    if (!c.ix->field_id_word_count_docids)
+      fail(MSI_E_INVALID, "the index vtable has no field_id_word_count_docids (exactness rule)");
+    for (uint32_t i = 0; i < c.prm->n_searchable; ++i) {
+      const uint32_t fid = c.prm->searchable_fids[i];
+      Set inter = c.dev.clone(cand);
+      for (auto &wp : words_positions)
+        for (int32_t w : wp.first) {
+          if (w < 0) continue;
+          MsiCboBatch b;
+          c.add_word_fid(b, (uint32_t)w, fid);
+          c.dev.and_(inter, c.dev.decode(b));
+        }
+      MsiCboBatch wc;
+      if (count_all < 255) {
+        const uint8_t *bytes = nullptr;
+        size_t n = 0;
+        c.take(wc, c.ix->field_id_word_count_docids(c.ix->user, fid, count_all, &bytes, &n), bytes, n,
+               "field_id_word_count_docids");
+      }
+      Set wcs = c.dev.decode(wc);
+      c.dev.and_(wcs, universe);
+      per_attr.push_back({inter, wcs});
+    }
+    state = 1;
+  }
+
+  bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) override {
+    out.graph = g;
+    if (state == 0) {
+      out.docs = c.dev.clone(universe);
+      out.count = universe_count;
+      out.score = {MSI_SCORE_EXACT_ATTRIBUTE, 1, 3};
+      return true;
+    }
+    Set u = c.dev.zeros();
+    for (auto &pa : per_attr) {
+      Set t = c.dev.clone(pa.first);
+      if (state == 1) c.dev.and_(t, pa.second);
+      else c.dev.sub_(t, pa.second);
+      c.dev.or_(u, t);
+    }
+    out.docs = c.dev.and_new(u, universe, &out.count);
+    out.score = {MSI_SCORE_EXACT_ATTRIBUTE, state == 1 ? 3u : 2u, 3};
+    state = state == 1 ? 2 : 0;
+    if (state == 0) per_attr.clear();
+    return true;
+  }
+  void end() override {
+    per_attr.clear();
+    state = 0;
+  }
+};
+
+// get_ranking_rules_for_query_graph_search, mod.rs:510-649
+std::vector<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
+  std::vector<std::unique_ptr<Rule>> rules;
+  bool words = p->strategy == MSI_TERMS_ALL, typo = false, prox = false, attribute = false, attr_rank = false,
+       word_pos = false, exact = false;
+  auto add_words = [&]() {
+    if (!words) {
+      rules.emplace_back(new GraphRule(R_WORDS, p->strategy));
+      words = true;
+    }
+  };
+  for (uint32_t i = 0; i < p->n_criteria; ++i) {
+    const int32_t c = p->criteria[i];
+    if (c == MSI_CRIT_TYPO || c == MSI_CRIT_ATTRIBUTE || c == MSI_CRIT_ATTRIBUTE_RANK || c == MSI_CRIT_WORD_POSITION ||
+        c == MSI_CRIT_PROXIMITY || c == MSI_CRIT_EXACTNESS)
+      add_words();
+    switch (c) {
+      case MSI_CRIT_WORDS: add_words(); break;
+      case MSI_CRIT_TYPO:
+        if (!typo) rules.emplace_back(new GraphRule(R_TYPO, -1));
+        typo = true;
+        break;
+      case MSI_CRIT_PROXIMITY:
+        if (!prox) rules.emplace_back(new GraphRule(R_PROXIMITY, -1));
+        prox = true;
+        break;
+      case MSI_CRIT_ATTRIBUTE:
+        if (attribute || attr_rank || word_pos) break;
+        attribute = true;
+        rules.emplace_back(new GraphRule(R_FID, -1));
+        rules.emplace_back(new GraphRule(R_POSITION, -1));
+        break;
+      case MSI_CRIT_ATTRIBUTE_RANK:
+        if (attribute || attr_rank) break;
+        attr_rank = true;
+        rules.emplace_back(new GraphRule(R_FID, -1));
+        break;
+      case MSI_CRIT_WORD_POSITION:
+        if (attribute || word_pos) break;
+        word_pos = true;
+        rules.emplace_back(new GraphRule(R_POSITION, -1));
+        break;
+      case MSI_CRIT_EXACTNESS:
+        if (exact) break;
+        exact = true;
+        rules.emplace_back(new ExactAttributeRule());
+        rules.emplace_back(new GraphRule(R_EXACTNESS, -1));
+        break;
+      default: break;  // Sort / Asc / Desc: not keyword rules
+    }
+  }
+  return rules;
+}
+
+// make_ngram, parse_query.rs:227-300 -> term index or -1
+int32_t make_ngram(Ctx &c, const std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> &ts, size_t lo, size_t hi) {
+  for (size_t i = lo; i <= hi; ++i)
+    if (c.terms[ts[i].first].phrase >= 0) return -1;
+  for (size_t i = lo; i < hi; ++i)
+    if (ts[i].second.second + 1 != ts[i + 1].second.first) return -1;
+  std::string s;
+  std::vector<uint32_t> ws;
+  for (size_t i = lo; i <= hi; ++i) {
+    const Term &t = c.terms[ts[i].first];
+    if (t.is_ngram) return -1;
+    ws.push_back(t.original);
+    s += c.words[t.original];
+  }
+  if (s.size() > MAX_WORD_LENGTH) return -1;
+  const bool is_prefix = c.terms[ts[hi].first].is_prefix;
+  const uint32_t b = c.budget(s), n1 = (uint32_t)(hi - lo);
+  const uint32_t max_typos = b > n1 ? b - n1 : 0;
+  Term t = c.term_from_word(s, max_typos, is_prefix);
+  t.is_ngram = true;
+  t.ngram_words = ws;
+  t.is_prefix = is_prefix;
+  t.max_lev = max_typos;
+  c.terms.push_back(t);
+  return (int32_t)c.terms.size() - 1;
+}
+
+void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t *universe_cbo, size_t universe_len,
+            uint32_t *out_docids, msi_score_detail *out_scores, uint32_t *out_n_scores, uint32_t *out_n,
+            uint64_t *out_candidates) {
+  const msi_search_params *p = c.prm;
+  // ---- located terms -> terms -----------------------------------------------------------------
+  std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> ts;  // (term, positions)
+  for (uint32_t i = 0; i < n_terms; ++i) {
+    const msi_located_term &l = lt[i];
+    if (!l.words || l.n_words == 0) fail(MSI_E_INVALID, "a located term has no word");
+    if (l.is_phrase) {
+      Phrase ph;
+      std::string desc;
+      for (uint32_t k = 0; k < l.n_words; ++k) {
+        if (!l.words[k].len) {
+          ph.push_back(-1);
+          continue;
+        }
+        const std::string w((const char *)l.words[k].word, l.words[k].len);
+        ph.push_back((int32_t)c.word(w));
+        if (!desc.empty()) desc += " ";
+        desc += w;
+      }
+      Term t;
+      t.original = c.word(desc);
+      t.phrase = (int32_t)c.phrase(ph);
+      c.terms.push_back(t);
+    } else {
+      const std::string w((const char *)l.words[0].word, l.words[0].len);
+      c.terms.push_back(c.term_from_word(w, c.budget(w), l.words[0].is_prefix != 0));
+    }
+    ts.push_back({(uint32_t)c.terms.size() - 1, {l.position_start, l.position_end}});
+  }
+  // ---- QueryGraph::from_query -----------------------------------------------------------------
+  Graph g;
+  g.nodes.resize(2);
+  g.nodes[0].kind = 0;
+  g.nodes[1].kind = 1;
+  auto add_node = [&](uint32_t ti, uint32_t plo, uint32_t phi, uint32_t ilo, uint32_t ihi) {
+    GNode n;
+    n.kind = 2;
+    n.term.subset = c.full(ti);
+    n.term.pos_lo = plo;
+    n.term.pos_hi = phi;
+    n.term.id_lo = ilo;
+    n.term.id_hi = ihi;
+    g.nodes.push_back(n);
+  };
+  for (size_t i = 0; i < ts.size(); ++i) {
+    add_node(ts[i].first, ts[i].second.first, ts[i].second.second, (uint32_t)i, (uint32_t)i);
+    for (size_t n = 2; n <= 3; ++n) {
+      if (i + 1 < n) continue;
+      const size_t lo = i + 1 - n;
+      const int32_t ng = make_ngram(c, ts, lo, i);
+      if (ng >= 0) add_node((uint32_t)ng, ts[lo].second.first, ts[i].second.second, (uint32_t)lo, (uint32_t)i);
+    }
+  }
+  build_initial_edges(g);
+  c.compute_derivations();
+
+  // ---- universe (resolve_universe, mod.rs:273-301) ---------------------------------------------
+  Set universe;
+  if (universe_cbo) {
+    MsiCboBatch ub;
+    if (!msi_cbo_batch_append(ub, universe_cbo, universe_len)) fail(MSI_E_INVALID, "malformed universe bitmap");
+    universe = c.dev.decode(ub);
+  } else {
+    universe = c.dev.ones();
+  }
+  {
+    Graph reduced = g;
+    if (p->strategy == MSI_TERMS_LAST) {
+      std::vector<uint32_t> rm;
+      for (auto &ns : removal_order_last(c, g)) rm.insert(rm.end(), ns.begin(), ns.end());
+      remove_nodes_keep_edges(reduced, rm);
+    }
+    Set d = query_graph_docids(c, reduced, universe);
+    c.dev.and_(universe, d);
+  }
+  uint64_t universe_count = c.dev.count(universe);
+
+  // ---- bucket_sort (bucket_sort.rs:23-343; no distinct, pins, deadline, score threshold) ---------
+  auto rules = ranking_rules(p);
+  const uint32_t from = p->from, length = p->length;
+  const bool detailed = p->detailed_scores != 0;
+  uint32_t n_out = 0;
+  *out_n = 0;
+  if (out_candidates) *out_candidates = universe_count;
+  if (universe_count < from || length == 0) return;
+  if (rules.empty()) {
+    auto ids = c.dev.first_k(universe, from + length);
+    for (size_t i = from; i < ids.size(); ++i) {
+      out_docids[n_out] = ids[i];
+      out_n_scores[n_out++] = 0;
+    }
+    *out_n = n_out;
+    return;
+  }
+  const size_t nr = rules.size();
+  std::vector<Set> unis(nr);
+  std::vector<uint64_t> uni_counts(nr, 0);
+  std::vector<Score> scores;
+  unis[0] = c.dev.clone(universe);
+  uni_counts[0] = universe_count;
+  rules[0]->start(c, universe, g);
+  size_t cur = 0;
+  uint64_t cur_off = 0;
+  auto add = [&](const Set &cands, uint64_t count) {  // maybe_add_to_results :382-460
+    if (!count) return;
+    uint64_t skip = 0;
+    if (cur_off < from) {
+      if (cur_off + count < from) {
+        cur_off += count;
+        return;
+      }
+      skip = from - cur_off;
+    }
+    const uint32_t take = (uint32_t)std::min<uint64_t>(count - skip, length - n_out);
+    if (take) {
+      auto ids = c.dev.first_k(cands, (uint32_t)(skip + take));
+      for (size_t i = (size_t)skip; i < ids.size(); ++i) {
+        out_docids[n_out] = ids[i];
+        const uint32_t ns = (uint32_t)std::min<size_t>(scores.size(), MSI_MAX_SCORE_DETAILS);
+        for (uint32_t s = 0; s < ns; ++s)
+          out_scores[(size_t)n_out * MSI_MAX_SCORE_DETAILS + s] = msi_score_detail{scores[s].kind, scores[s].a, scores[s].b};
+        out_n_scores[n_out] = ns;
+        ++n_out;
+      }
+    }
+    cur_off += count;
+  };
+  auto back = [&]() -> bool {  // false: iteration over
+    unis[cur].reset();
+    uni_counts[cur] = 0;
+    rules[cur]->end();
+    if (cur == 0) return false;
+    --cur;
+    if (scores.size() > cur) scores.pop_back();
+    return true;
+  };
+  while (n_out < length) {
+    if (uni_counts[cur] == 0 || (!detailed && uni_counts[cur] == 1)) {
+      if (uni_counts[cur]) add(unis[cur], uni_counts[cur]);
+      if (!back()) break;
+      continue;
+    }
+    Bucket b;
+    if (!rules[cur]->next(c, unis[cur], uni_counts[cur], b)) {
+      if (!back()) break;
+      continue;
+    }
+    scores.push_back(b.score);
+    c.dev.sub_(unis[cur], b.docs);
+    uni_counts[cur] -= b.count;
+    if (cur == nr - 1 || (!detailed && b.count <= 1) || cur_off + b.count < from) {
+      add(b.docs, b.count);
+      scores.pop_back();
+      continue;
+    }
+    ++cur;
+    unis[cur] = b.docs;
+    uni_counts[cur] = b.count;
+    rules[cur]->start(c, b.docs, b.graph);
+  }
+  *out_n = n_out;
+}
+
+}  // namespace
+
+extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, const msi_index_vtable *index,
+                                             const msi_located_term *terms, uint32_t n_terms,
+                                             const msi_search_params *params, const uint8_t *universe_cbo,
+                                             size_t universe_len, uint32_t *out_docids, msi_score_detail *out_scores,
+                                             uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates) {
+  if (!dict || !pool || !index || !index->word_docids || !params || !out_n || (n_terms && !terms) ||
+      n_terms > MSI_RANK_MAX_TERMS || (params->length && (!out_docids || !out_scores || !out_n_scores)) ||
+      (params->n_criteria && !params->criteria) ||
+      (params->n_searchable && (!params->searchable_fids || !params->searchable_weights))) {
+    msi_set_error("msi_keyword_search_ranked: invalid argument (<= %d terms)", MSI_RANK_MAX_TERMS);
+    return MSI_E_INVALID;
+  }
+  if (msi_bits_n_slots(pool) < 64) {
+    msi_set_error("msi_keyword_search_ranked: the pool needs at least 64 slots, has %u", msi_bits_n_slots(pool));
+    return MSI_E_INVALID;
+  }
+  *out_n = 0;
+  if (out_candidates) *out_candidates = 0;
+  if (n_terms == 0) {
+    msi_set_error("msi_keyword_search_ranked: no query term (placeholder search is not a keyword search)");
+    return MSI_E_INVALID;
+  }
+  try {
+    Ctx c(dict, pool, index, params);
+    search(c, terms, n_terms, universe_cbo, universe_len, out_docids, out_scores, out_n_scores, out_n, out_candidates);
+    return MSI_OK;
+  } catch (const Fail &f) {
+    return f.code;
+  } catch (const std::bad_alloc &) {
+    msi_set_error("msi_keyword_search_ranked: out of host memory");
+    return MSI_E_OOM;
+  } catch (const std::exception &e) {
+    msi_set_error("msi_keyword_search_ranked: %s", e.what());
+    return MSI_E_INTERNAL;
+  }
+}

@@ -6,7 +6,8 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (EXACT_WORD_FN, PAIR_DOCIDS_FN, WORD_DOCIDS_FN, IndexVtable, KeywordParams, QueryToken, RankBucket,
+from ._lib import (EXACT_WORD_FN, FID_COUNT_DOCIDS_FN, PAIR_DOCIDS_FN, WORD_DOCIDS_FN, WORD_KEY_DOCIDS_FN, WORD_KEYS_FN,
+                   IndexVtable, KeywordParams, LocatedTerm, QueryToken, RankBucket, ScoreDetail, SearchParams,
                    RankNode, RankQuery, RankTerm, check, lib)
 from .device import np_ptr
 
@@ -160,7 +161,42 @@ class IndexCallbacks:
                 return 1 if index.is_exact_word(bytes(w[:n]).decode("utf-8")) else 0
             except Exception:
                 return 0
+        def word_fid(user, w, n, fid, out_bytes, out_n):
+            try:
+                return hand_out(index.word_fid_docids_bytes(bytes(w[:n]).decode("utf-8"), fid), out_bytes, out_n)
+            except Exception:
+                return -1
+
+        def word_position(user, w, n, pos, out_bytes, out_n):
+            try:
+                return hand_out(index.word_position_docids_bytes(bytes(w[:n]).decode("utf-8"), pos), out_bytes, out_n)
+            except Exception:
+                return -1
+
+        def keys(getter):
+            def fn(user, w, n, out, cap, out_n):
+                try:
+                    vals = getter(bytes(w[:n]).decode("utf-8"))
+                    out_n[0] = len(vals)
+                    for i, v in enumerate(vals[:cap]):
+                        out[i] = v
+                    return 0
+                except Exception:
+                    return -1
+            return fn
+
+        def fid_count(user, fid, count, out_bytes, out_n):
+            try:
+                return hand_out(index.fid_word_count_docids_bytes(fid, count), out_bytes, out_n)
+            except Exception:
+                return -1
         self._fns = (WORD_DOCIDS_FN(word_docids), PAIR_DOCIDS_FN(pair_docids), EXACT_WORD_FN(is_exact))
+        full = all(hasattr(index, m) for m in ("word_fid_docids_bytes", "word_position_docids_bytes", "word_fids",
+                                                "word_positions", "fid_word_count_docids_bytes"))
+        if full:
+            self._fns += (WORD_KEY_DOCIDS_FN(word_fid), WORD_KEY_DOCIDS_FN(word_position),
+                          WORD_KEYS_FN(keys(index.word_fids)), WORD_KEYS_FN(keys(index.word_positions)),
+                          FID_COUNT_DOCIDS_FN(fid_count))
         self.vtable = IndexVtable(None, *self._fns)
 
 
@@ -193,3 +229,57 @@ def keyword_search(gdict, pool, callbacks, words, last_is_prefix=True, strategy=
                                    np_ptr(ids), np_ptr(mw), np_ptr(tc), np_ptr(mt), C.byref(out_n), C.byref(cand)))
     k = out_n.value
     return [(int(ids[i]), int(mw[i]), int(tc[i]), int(mt[i])) for i in range(k)], int(cand.value)
+
+
+CRITERIA = {"words": 0, "typo": 1, "proximity": 2, "attribute": 3, "attributeRank": 4, "wordPosition": 5,
+            "exactness": 6, "sort": 7}
+SCORE_KINDS = ["Words", "Typo", "Proximity", "Fid", "Position", "ExactAttribute", "ExactWords"]
+MAX_SCORE_DETAILS = 8
+
+
+def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERMS_LAST, offset=0, limit=20,
+                          detailed=False, searchable_fids=(), searchable_weights=(), max_weight=None,
+                          authorize_typos=True, min_one=5, min_two=9, universe_cbo=None):
+    """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
+    terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
+    (words: [str | None], None = a stop word inside a phrase).
+    -> ([(docid, [(kind name, a, b)])], candidates)."""
+    n = len(terms)
+    lt = (LocatedTerm * max(n, 1))()
+    keep = []
+    for i, (words, is_phrase, ps, pe, is_prefix) in enumerate(terms):
+        toks = (QueryToken * len(words))()
+        for k, w in enumerate(words):
+            b = (w or "").encode("utf-8")
+            buf = C.create_string_buffer(b, len(b))
+            keep.append(buf)
+            toks[k].word = C.cast(buf, C.c_void_p)
+            toks[k].len = len(b)
+            toks[k].is_prefix = 1 if (is_prefix and not is_phrase) else 0
+        keep.append(toks)
+        lt[i].words = C.cast(toks, C.c_void_p)
+        lt[i].n_words = len(words)
+        lt[i].is_phrase = 1 if is_phrase else 0
+        lt[i].position_start, lt[i].position_end = ps, pe
+    crit = np.array([CRITERIA[c] for c in criteria], dtype=np.int32)
+    fids = np.array(list(searchable_fids), dtype=np.uint16)
+    wts = np.array(list(searchable_weights), dtype=np.uint16)
+    prm = SearchParams(1 if authorize_typos else 0, min_one, min_two, strategy, np_ptr(crit) if crit.size else None,
+                       crit.size, np_ptr(fids) if fids.size else None, np_ptr(wts) if wts.size else None, fids.size,
+                       -1 if max_weight is None else int(max_weight), offset, limit, 1 if detailed else 0)
+    L = max(limit, 1)
+    ids = np.zeros(L, dtype=np.uint32)
+    sc = (ScoreDetail * (L * MAX_SCORE_DETAILS))()
+    nsc = np.zeros(L, dtype=np.uint32)
+    out_n, cand = C.c_uint32(0), C.c_uint64(0)
+    ub = np.frombuffer(universe_cbo, dtype=np.uint8) if universe_cbo is not None else None
+    check(lib().msi_keyword_search_ranked(gdict._h, pool._h, C.byref(callbacks.vtable), lt, n, C.byref(prm),
+                                          np_ptr(ub) if ub is not None else None, 0 if ub is None else ub.size,
+                                          np_ptr(ids), C.cast(sc, C.c_void_p), np_ptr(nsc), C.byref(out_n),
+                                          C.byref(cand)))
+    hits = []
+    for i in range(out_n.value):
+        det = [(SCORE_KINDS[sc[i * MAX_SCORE_DETAILS + k].kind], int(sc[i * MAX_SCORE_DETAILS + k].a),
+                int(sc[i * MAX_SCORE_DETAILS + k].b)) for k in range(int(nsc[i]))]
+        hits.append((int(ids[i]), det))
+    return hits, int(cand.value)

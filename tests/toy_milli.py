@@ -151,3 +151,76 @@ class ToyMilli:
         if not self.authorize_typos or n < self.min_one or word in self.exact_words:
             return 0
         return 1 if n < self.min_two else 2
+
+    # ---- the index side of msi_index_vtable (what the Rust shim answers from LMDB) -------------
+    def word_docids_bytes(self, word, original):
+        s = self.get_word_docids(word, original)
+        return cbo_bytes(s) if s else None
+
+    def pair_docids_bytes(self, prox, left, right):
+        s = self.pair.get((prox, left, right))
+        return cbo_bytes(s) if s else None
+
+    def is_exact_word(self, word):
+        return word in self.exact_words
+
+    def word_fid_docids_bytes(self, word, fid):
+        s = self.word_fid_docids.get((word, fid))
+        return cbo_bytes(s) if s else None
+
+    def word_position_docids_bytes(self, word, pos):
+        s = self.word_position_docids.get((word, pos))
+        return cbo_bytes(s) if s else None
+
+    def word_fids(self, word):
+        return self.get_word_fids(word)
+
+    def word_positions(self, word):
+        return self.get_word_positions(word)
+
+    def fid_word_count_docids_bytes(self, fid, count):
+        s = self.fid_word_count.get((fid, count))
+        return cbo_bytes(s) if s else None
+
+
+TOKEN_RE = re.compile(r"[0-9a-zà-öø-ÿ]+|[^0-9a-zà-öø-ÿ]+")
+
+
+def query_terms(query, words_limit=10):
+    """The located terms of located_query_terms_from_tokens (parse_query.rs:28-202) for the Latin subset of
+    charabia: [(words, is_phrase, position_start, position_end, is_prefix)] — what the Rust shim hands to
+    msi_keyword_search_ranked.  Negative operators are not modelled."""
+    toks = TOKEN_RE.findall(query.lower())
+    terms, phrase, position = [], None, -1
+
+    def close(ph):
+        if ph:
+            terms.append(([w for w, _ in ph], True, ph[0][1], ph[-1][1], False))
+
+    for k, tok in enumerate(toks):
+        if len(terms) >= words_limit:
+            break
+        if WORD_RE.match(tok):
+            position += 1
+            if phrase is not None:
+                phrase.append((tok, position))
+            else:
+                terms.append(([tok], False, position, position, k == len(toks) - 1))
+        else:
+            if HARD_RE.search(tok):
+                position += 7
+                if phrase is not None:
+                    close(phrase)
+                    phrase = []
+            q = tok.count('"')
+            if q == 0:
+                continue
+            if phrase is not None:
+                q -= 1
+                close(phrase)
+                phrase = None
+            if q % 2 == 1:
+                phrase = []
+    if phrase is not None:
+        close(phrase)
+    return terms
