@@ -503,6 +503,11 @@ int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, const msi_inde
                                   size_t universe_len, uint32_t *out_docids, msi_score_detail *out_scores,
                                   uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates);
 
+/* Diagnostics: counters of the last msi_keyword_search_ranked on the calling thread —
+ * [kernel launches, stream syncs, decode batches, index callbacks, posting bytes decoded, matching paths,
+ *  buckets, callback microseconds, device-wait microseconds, total microseconds]. */
+int32_t msi_search_last_stats(uint64_t out[10]);
+
 /* ---------------------------------------------------- scoring arithmetic (host) */
 /* DistributionShift::shift (crates/milli/src/vector/distribution.rs:103-130). */
 float msi_distribution_shift(float mean, float sigma, float score);

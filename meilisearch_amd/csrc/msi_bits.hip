@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "msi_common.h"
@@ -25,7 +26,15 @@ struct msi_bits {
   uint64_t n_docs = 0;
   uint64_t n_words = 0;  // per slot, multiple of 2 (16-byte vector access)
   uint32_t n_slots = 0;
-  DevBuf pool, tmp, small, stage, desc;
+  DevBuf pool, tmp, small, stage, desc, small_ids;
+  // Completion signalling without a stream synchronisation: the last workgroup of a counting kernel
+  // writes {value, sequence number} into fine-grained pinned host memory and the caller polls it.
+  volatile uint64_t *h_sig = nullptr;  // [0] value, [1] sequence
+  u64 *d_acc = nullptr;                // [0] running sum, [1] workgroups done (self-resetting)
+  uint64_t seq = 0;
+  // pinned staging ring for posting bytes: decodes are enqueued without waiting for the copy
+  uint8_t *h_ring = nullptr;
+  size_t ring_cap = 0, ring_pos = 0;
   u64 *slot(uint32_t s) const { return pool.as<u64>() + (uint64_t)s * n_words; }
 };
 
@@ -71,10 +80,35 @@ __global__ void bits_op_kernel(u64 *__restrict__ dst, const u64 *__restrict__ a,
   }
 }
 
+// Block partial -> device accumulator; the last workgroup publishes the total to the host and
+// re-arms the accumulator (no memset, no device-to-host copy, no stream synchronisation).
+__device__ __forceinline__ void publish_count(uint32_t c, u64 *__restrict__ acc, volatile uint64_t *__restrict__ sig,
+                                              uint64_t seq) {
+  __shared__ uint32_t part[BT / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 b = 0;
+    for (int i = 0; i < BT / 64; ++i) b += part[i];
+    if (b) atomicAdd(&acc[0], b);
+    __threadfence();
+    const u64 done = atomicAdd(&acc[1], 1ull);
+    if (done == gridDim.x - 1) {
+      const u64 total = atomicExch(&acc[0], 0ull);
+      acc[1] = 0;
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[0]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // dst = a OP b, *out += |dst|
 template <int OP>
 __global__ void bits_op_count_kernel(u64 *__restrict__ dst, const u64 *__restrict__ a,
-                                     const u64 *__restrict__ b, uint64_t n_pairs, u64 *__restrict__ out) {
+                                     const u64 *__restrict__ b, uint64_t n_pairs, u64 *__restrict__ acc,
+                                     volatile uint64_t *__restrict__ sig, uint64_t seq) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   uint32_t c = 0;
@@ -89,9 +123,89 @@ __global__ void bits_op_count_kernel(u64 *__restrict__ dst, const u64 *__restric
     reinterpret_cast<ulonglong2 *>(dst)[i] = r;
     c += __popcll(r.x) + __popcll(r.y);
   }
+  publish_count(c, acc, sig, seq);
+}
+
+struct ManyArgs {
+  const u64 *cond[MSI_BITS_MANY];
+  u64 *dst[MSI_BITS_MANY];
+  u64 *stack[MSI_BITS_MANY];
+};
+
+// dst[i] = prefix & cond[i] with |dst[i]| for every i < n; the last workgroup publishes the n counts.
+__global__ void bits_and_many_kernel(ManyArgs a, const u64 *__restrict__ prefix, uint32_t n, uint64_t n_pairs,
+                                     u64 *__restrict__ acc, volatile uint64_t *__restrict__ sig, uint64_t seq) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t c[MSI_BITS_MANY];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (u64)c);
+  for (uint32_t k = 0; k < MSI_BITS_MANY; ++k) c[k] = 0;
+  for (; i < n_pairs; i += stride) {
+    const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(prefix)[i];
+#pragma unroll
+    for (uint32_t k = 0; k < MSI_BITS_MANY; ++k) {
+      if (k < n) {
+        const ulonglong2 y = reinterpret_cast<const ulonglong2 *>(a.cond[k])[i];
+        ulonglong2 r;
+        r.x = x.x & y.x;
+        r.y = x.y & y.y;
+        reinterpret_cast<ulonglong2 *>(a.dst[k])[i] = r;
+        c[k] += __popcll(r.x) + __popcll(r.y);
+      }
+    }
+  }
+  __shared__ uint32_t part[MSI_BITS_MANY];
+  if (threadIdx.x < MSI_BITS_MANY) part[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < MSI_BITS_MANY; ++k) {
+    if (k < n) {
+      uint32_t v = c[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+      if ((threadIdx.x & 63) == 0 && v) atomicAdd(&part[k], v);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t k = 0; k < n; ++k)
+      if (part[k]) atomicAdd(&acc[2 + k], (u64)part[k]);
+    __threadfence();
+    const u64 done = atomicAdd(&acc[1], 1ull);
+    if (done == gridDim.x - 1) {
+      for (uint32_t k = 0; k < n; ++k) {
+        const u64 total = atomicExch(&acc[2 + k], 0ull);
+        __hip_atomic_store(const_cast<uint64_t *>(&sig[2 + k]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      acc[1] = 0;
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// bucket |= docs; universe &= ~docs; stack[i] &= ~docs (docs is read before any of them is written)
+__global__ void bits_claim_kernel(ManyArgs a, const u64 *docs, u64 *bucket, u64 *universe, uint32_t n_stack,
+                                  uint64_t n_pairs) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n_pairs; i += stride) {
+    const ulonglong2 d = reinterpret_cast<const ulonglong2 *>(docs)[i];
+    if (!(d.x | d.y)) continue;
+    ulonglong2 b = reinterpret_cast<ulonglong2 *>(bucket)[i];
+    b.x |= d.x;
+    b.y |= d.y;
+    reinterpret_cast<ulonglong2 *>(bucket)[i] = b;
+    ulonglong2 u = reinterpret_cast<ulonglong2 *>(universe)[i];
+    u.x &= ~d.x;
+    u.y &= ~d.y;
+    reinterpret_cast<ulonglong2 *>(universe)[i] = u;
+    for (uint32_t k = 0; k < n_stack; ++k) {
+      ulonglong2 s = reinterpret_cast<ulonglong2 *>(a.stack[k])[i];
+      s.x &= ~d.x;
+      s.y &= ~d.y;
+      reinterpret_cast<ulonglong2 *>(a.stack[k])[i] = s;
+    }
+  }
 }
 
 // dst = (OR_i pool[srcs[i]]) & pool[universe]
@@ -116,14 +230,13 @@ __global__ void bits_union_many_kernel(u64 *__restrict__ pool, uint64_t n_words,
   }
 }
 
-__global__ void bits_count_kernel(const u64 *__restrict__ a, uint64_t n_words, u64 *__restrict__ out) {
+__global__ void bits_count_kernel(const u64 *__restrict__ a, uint64_t n_words, u64 *__restrict__ acc,
+                                  volatile uint64_t *__restrict__ sig, uint64_t seq) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   uint32_t c = 0;
   for (; i < n_words; i += stride) c += __popcll(a[i]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (u64)c);
+  publish_count(c, acc, sig, seq);
 }
 
 __global__ void bits_set_docids_kernel(u64 *__restrict__ dst, uint64_t n_docs,
@@ -240,6 +353,26 @@ uint32_t grid_for(uint64_t n, uint32_t cap_blocks) {
   return (uint32_t)std::min<uint64_t>(b, cap_blocks);
 }
 
+// Waits for the counting kernel launched with sequence number `seq`; spins on the pinned signal and
+// falls back to a stream synchronisation if the signal does not arrive promptly.
+int32_t wait_count(msi_bits *p, uint64_t seq, uint64_t *out) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 0;; ++spin) {
+    if (__atomic_load_n(const_cast<uint64_t *>(&p->h_sig[1]), __ATOMIC_ACQUIRE) == seq) break;
+    if ((spin & 1023) == 1023 &&
+        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 2000.0) {
+      MSI_HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+      if (__atomic_load_n(const_cast<uint64_t *>(&p->h_sig[1]), __ATOMIC_ACQUIRE) != seq) {
+        msi_set_error("count kernel finished without publishing its result");
+        return MSI_E_INTERNAL;
+      }
+      break;
+    }
+  }
+  *out = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[0]), __ATOMIC_RELAXED);
+  return MSI_OK;
+}
+
 int32_t check_slot(const msi_bits *p, uint32_t s, const char *what) {
   if (!p || s >= p->n_slots) {
     msi_set_error("%s: slot %u out of range", what, s);
@@ -266,8 +399,23 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   p->n_slots = n_slots;
   int32_t s = p->pool.ensure((size_t)p->n_words * n_slots * sizeof(u64));
   if (s == MSI_OK) s = p->small.ensure(64);
+  if (s == MSI_OK) {
+    void *h = nullptr;
+    if (hipHostMalloc(&h, (2 + MSI_BITS_MANY) * sizeof(uint64_t), hipHostMallocCoherent) != hipSuccess ||
+        hipMalloc((void **)&p->d_acc, (2 + MSI_BITS_MANY) * sizeof(u64)) != hipSuccess ||
+        hipMemset(p->d_acc, 0, (2 + MSI_BITS_MANY) * sizeof(u64)) != hipSuccess) {
+      msi_set_error("msi_bits_create: allocating the completion signal failed");
+      s = MSI_E_OOM;
+    } else {
+      p->h_sig = (volatile uint64_t *)h;
+      p->h_sig[0] = p->h_sig[1] = 0;
+    }
+  }
   if (s != MSI_OK) {
     p->pool.release();
+    p->small.release();
+    if (p->h_sig) (void)hipHostFree((void *)p->h_sig);
+    if (p->d_acc) (void)hipFree(p->d_acc);
     delete p;
     return s;
   }
@@ -296,6 +444,10 @@ void msi_bits_destroy(msi_bits *p) {
   p->small.release();
   p->stage.release();
   p->desc.release();
+  p->small_ids.release();
+  if (p->h_sig) (void)hipHostFree((void *)p->h_sig);
+  if (p->d_acc) (void)hipFree(p->d_acc);
+  if (p->h_ring) (void)hipHostFree(p->h_ring);
   delete p;
   }
   msi_ctx_release(ctx);
@@ -446,6 +598,78 @@ uint64_t msi_cbo_cardinality(const uint8_t *bytes, size_t len) {
 }
 
 // slot := (clear ? {} : slot) ∪ every value appended to the batch.  Takes the context lock.
+int32_t msi_bits_and_many_count(msi_bits *p, uint32_t prefix, uint32_t n, const uint32_t *cond, const uint32_t *dst,
+                                uint64_t *counts) {
+  if (!p || !n || n > MSI_BITS_MANY || !cond || !dst || !counts) return MSI_E_INVALID;
+  MSI_TRY(check_slot(p, prefix, "msi_bits_and_many_count"));
+  ManyArgs a;
+  for (uint32_t k = 0; k < n; ++k) {
+    MSI_TRY(check_slot(p, cond[k], "msi_bits_and_many_count"));
+    MSI_TRY(check_slot(p, dst[k], "msi_bits_and_many_count"));
+    a.cond[k] = p->slot(cond[k]);
+    a.dst[k] = p->slot(dst[k]);
+  }
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  const uint64_t n_pairs = p->n_words / 2;
+  const uint64_t seq = ++p->seq;
+  hipLaunchKernelGGL(bits_and_many_kernel, dim3(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 4)), dim3(BT), 0,
+                     p->ctx->stream, a, p->slot(prefix), n, n_pairs, p->d_acc, p->h_sig, seq);
+  MSI_HIP_TRY(hipGetLastError());
+  uint64_t ignored = 0;
+  MSI_TRY(wait_count(p, seq, &ignored));
+  for (uint32_t k = 0; k < n; ++k) counts[k] = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2 + k]), __ATOMIC_RELAXED);
+  return MSI_OK;
+}
+
+int32_t msi_bits_claim(msi_bits *p, uint32_t docs, uint32_t bucket, uint32_t universe, uint32_t n_stack,
+                       const uint32_t *stack) {
+  if (!p || n_stack > MSI_BITS_MANY || (n_stack && !stack)) return MSI_E_INVALID;
+  MSI_TRY(check_slot(p, docs, "msi_bits_claim"));
+  MSI_TRY(check_slot(p, bucket, "msi_bits_claim"));
+  MSI_TRY(check_slot(p, universe, "msi_bits_claim"));
+  ManyArgs a;
+  for (uint32_t k = 0; k < n_stack; ++k) {
+    MSI_TRY(check_slot(p, stack[k], "msi_bits_claim"));
+    a.stack[k] = p->slot(stack[k]);
+  }
+  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  DeviceGuard g(p->ctx->device);
+  const uint64_t n_pairs = p->n_words / 2;
+  hipLaunchKernelGGL(bits_claim_kernel, dim3(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 4)), dim3(BT), 0,
+                     p->ctx->stream, a, p->slot(docs), p->slot(bucket), p->slot(universe), n_stack, n_pairs);
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+// A region of the pinned staging ring (copies from it are truly asynchronous; the stream is only
+// waited for when the ring wraps, so a run of decodes is enqueued without a single synchronisation).
+static int32_t ring_alloc(msi_bits *p, size_t bytes, uint8_t **out) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes > p->ring_cap) {
+    MSI_HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    if (p->h_ring) (void)hipHostFree(p->h_ring);
+    p->h_ring = nullptr;
+    p->ring_cap = 0;
+    size_t cap = std::max<size_t>(bytes * 2, (size_t)8 << 20);
+    void *h = nullptr;
+    if (hipHostMalloc(&h, cap, hipHostMallocDefault) != hipSuccess) {
+      msi_set_error("hipHostMalloc(%zu) for the posting staging ring failed", cap);
+      return MSI_E_OOM;
+    }
+    p->h_ring = (uint8_t *)h;
+    p->ring_cap = cap;
+    p->ring_pos = 0;
+  }
+  if (p->ring_pos + bytes > p->ring_cap) {
+    MSI_HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    p->ring_pos = 0;
+  }
+  *out = p->h_ring + p->ring_pos;
+  p->ring_pos += bytes;
+  return MSI_OK;
+}
+
 int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &batch, bool clear) {
   std::lock_guard<std::mutex> lk(p->ctx->mu);
   DeviceGuard g(p->ctx->device);
@@ -453,25 +677,33 @@ int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &bat
   if (clear) MSI_HIP_TRY(hipMemsetAsync(p->slot(slot), 0, p->n_words * sizeof(u64), st));
   const size_t n_cont = batch.containers.size();
   if (n_cont) {
-    MSI_TRY(p->stage.ensure(batch.bytes.size()));
-    MSI_TRY(p->desc.ensure(n_cont * sizeof(Container)));
-    MSI_HIP_TRY(hipMemcpyAsync(p->stage.p, batch.bytes.data(), batch.bytes.size(), hipMemcpyHostToDevice, st));
-    MSI_HIP_TRY(hipMemcpyAsync(p->desc.p, batch.containers.data(), n_cont * sizeof(Container),
-                               hipMemcpyHostToDevice, st));
+    if (batch.bytes.size() > p->stage.cap)
+      MSI_TRY(p->stage.ensure(std::max<size_t>({batch.bytes.size(), p->stage.cap * 2, (size_t)1 << 20})));
+    if (n_cont * sizeof(Container) > p->desc.cap)
+      MSI_TRY(p->desc.ensure(std::max<size_t>({n_cont * sizeof(Container), p->desc.cap * 2, (size_t)64 << 10})));
+    uint8_t *hb = nullptr, *hc = nullptr;
+    MSI_TRY(ring_alloc(p, batch.bytes.size(), &hb));
+    MSI_TRY(ring_alloc(p, n_cont * sizeof(Container), &hc));
+    memcpy(hb, batch.bytes.data(), batch.bytes.size());
+    memcpy(hc, batch.containers.data(), n_cont * sizeof(Container));
+    MSI_HIP_TRY(hipMemcpyAsync(p->stage.p, hb, batch.bytes.size(), hipMemcpyHostToDevice, st));
+    MSI_HIP_TRY(hipMemcpyAsync(p->desc.p, hc, n_cont * sizeof(Container), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(bits_decode_roaring_kernel, dim3((uint32_t)n_cont), dim3(BT), 0, st, p->slot(slot),
                        p->n_docs, p->stage.as<uint8_t>(), p->desc.as<Container>());
     MSI_HIP_TRY(hipGetLastError());
   }
   if (!batch.small_ids.empty()) {
     const size_t n = batch.small_ids.size();
-    MSI_TRY(p->tmp.ensure(n * sizeof(uint32_t)));
-    MSI_HIP_TRY(hipMemcpyAsync(p->tmp.p, batch.small_ids.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    MSI_TRY(p->small_ids.ensure(n * sizeof(uint32_t)));
+    uint8_t *hs = nullptr;
+    MSI_TRY(ring_alloc(p, n * sizeof(uint32_t), &hs));
+    memcpy(hs, batch.small_ids.data(), n * sizeof(uint32_t));
+    MSI_HIP_TRY(hipMemcpyAsync(p->small_ids.p, hs, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(bits_set_docids_kernel, dim3((uint32_t)((n + BT - 1) / BT)), dim3(BT), 0, st, p->slot(slot),
-                       p->n_docs, p->tmp.as<uint32_t>(), n);
+                       p->n_docs, p->small_ids.as<uint32_t>(), n);
     MSI_HIP_TRY(hipGetLastError());
   }
-  MSI_HIP_TRY(hipStreamSynchronize(st));  // the batch buffers are borrowed
-  return MSI_OK;
+  return MSI_OK;   // in-stream order makes the slot valid for every later operation of this pool
 }
 
 extern "C" {
@@ -528,31 +760,28 @@ int32_t msi_bits_op_count(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int
   const uint64_t n_pairs = p->n_words / 2;
   const dim3 grid(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 8)), block(BT);
   hipStream_t st = p->ctx->stream;
-  u64 *cnt = p->small.as<u64>();
-  MSI_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(u64), st));
+  const uint64_t seq = ++p->seq;
+  u64 *acc = p->d_acc;
+  volatile uint64_t *sig = p->h_sig;
   switch (op) {
     case MSI_BITS_AND:
-      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_AND>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, cnt);
+      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_AND>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, acc, sig, seq);
       break;
     case MSI_BITS_OR:
-      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_OR>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, cnt);
+      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_OR>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, acc, sig, seq);
       break;
     case MSI_BITS_ANDNOT:
-      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_ANDNOT>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, cnt);
+      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_ANDNOT>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, acc, sig, seq);
       break;
     case MSI_BITS_XOR:
-      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_XOR>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, cnt);
+      hipLaunchKernelGGL(bits_op_count_kernel<MSI_BITS_XOR>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs, acc, sig, seq);
       break;
     default:
       msi_set_error("msi_bits_op_count: unknown op %d", op);
       return MSI_E_INVALID;
   }
   MSI_HIP_TRY(hipGetLastError());
-  u64 v = 0;
-  MSI_HIP_TRY(hipMemcpyAsync(&v, cnt, sizeof(u64), hipMemcpyDeviceToHost, st));
-  MSI_HIP_TRY(hipStreamSynchronize(st));
-  *out_count = v;
-  return MSI_OK;
+  return wait_count(p, seq, out_count);
 }
 
 int32_t msi_bits_union_many_and(msi_bits *p, uint32_t dst, const uint32_t *srcs, uint32_t n, uint32_t universe) {
@@ -577,15 +806,11 @@ int32_t msi_bits_count(msi_bits *p, uint32_t slot, uint64_t *out) {
   std::lock_guard<std::mutex> lk(p->ctx->mu);
   DeviceGuard g(p->ctx->device);
   hipStream_t st = p->ctx->stream;
-  MSI_HIP_TRY(hipMemsetAsync(p->small.p, 0, sizeof(u64), st));
+  const uint64_t seq = ++p->seq;
   hipLaunchKernelGGL(bits_count_kernel, dim3(grid_for(p->n_words, (uint32_t)p->ctx->n_cu * 8)), dim3(BT), 0, st,
-                     p->slot(slot), p->n_words, p->small.as<u64>());
+                     p->slot(slot), p->n_words, p->d_acc, p->h_sig, seq);
   MSI_HIP_TRY(hipGetLastError());
-  u64 v = 0;
-  MSI_HIP_TRY(hipMemcpyAsync(&v, p->small.p, sizeof(u64), hipMemcpyDeviceToHost, st));
-  MSI_HIP_TRY(hipStreamSynchronize(st));
-  *out = v;
-  return MSI_OK;
+  return wait_count(p, seq, out);
 }
 
 int32_t msi_bits_first_k(msi_bits *p, uint32_t slot, uint32_t k, uint32_t *out_docids, uint32_t *out_n) {

@@ -152,6 +152,14 @@ struct msi_bits;
 bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len);
 uint64_t msi_cbo_cardinality(const uint8_t *bytes, size_t len);
 int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &batch, bool clear);
+// Fused set steps of the path search (msi_search.hip), one launch each:
+//   and_many:  dst[i] = prefix & cond[i], counts[i] = |dst[i]|   (n <= MSI_BITS_MANY; one completion signal)
+//   claim:     bucket |= docs; universe &= ~docs; stack[i] &= ~docs   (docs may be one of the stack slots)
+constexpr uint32_t MSI_BITS_MANY = 16;
+int32_t msi_bits_and_many_count(msi_bits *p, uint32_t prefix, uint32_t n, const uint32_t *cond, const uint32_t *dst,
+                                uint64_t *counts);
+int32_t msi_bits_claim(msi_bits *p, uint32_t docs, uint32_t bucket, uint32_t universe, uint32_t n_stack,
+                       const uint32_t *stack);
 
 // ---- device helpers -------------------------------------------------------
 

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <set>
@@ -46,6 +47,17 @@ constexpr uint32_t MAX_DISTANCE = 4;                                            
 
 struct Fail {
   int32_t code;
+};
+
+// counters of the last search on this thread (msi_search_last_stats)
+struct Stats {
+  uint64_t launches = 0, syncs = 0, decodes = 0, callbacks = 0, postings_bytes = 0, paths = 0, buckets = 0;
+  double callback_ms = 0, device_wait_ms = 0, total_ms = 0;
+};
+thread_local Stats g_stats;
+struct Clock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 void ck(int32_t st) {
   if (st != MSI_OK) throw Fail{st};
@@ -79,45 +91,104 @@ struct Dev {
     pool.free_.pop_back();
     return Set(new SetH{&pool, s});
   }
+  void op(uint32_t d, uint32_t a, uint32_t b, int32_t o) {
+    ++g_stats.launches;
+    ck(msi_bits_op(pool.p, d, a, b, o));
+  }
+  void fill(uint32_t d, int ones) {
+    ++g_stats.launches;
+    ck(msi_bits_fill(pool.p, d, ones));
+  }
   Set zeros() {
     Set s = alloc();
-    ck(msi_bits_fill(pool.p, s->slot, 0));
+    fill(s->slot, 0);
     return s;
   }
   Set ones() {
     Set s = alloc();
-    ck(msi_bits_fill(pool.p, s->slot, 1));
+    fill(s->slot, 1);
     return s;
   }
   Set clone(const Set &a) {
     Set s = alloc();
-    ck(msi_bits_op(pool.p, s->slot, a->slot, a->slot, MSI_BITS_AND));
+    op(s->slot, a->slot, a->slot, MSI_BITS_AND);
     return s;
   }
-  void and_(const Set &d, const Set &a) { ck(msi_bits_op(pool.p, d->slot, d->slot, a->slot, MSI_BITS_AND)); }
-  void or_(const Set &d, const Set &a) { ck(msi_bits_op(pool.p, d->slot, d->slot, a->slot, MSI_BITS_OR)); }
-  void sub_(const Set &d, const Set &a) { ck(msi_bits_op(pool.p, d->slot, d->slot, a->slot, MSI_BITS_ANDNOT)); }
+  void and_(const Set &d, const Set &a) { op(d->slot, d->slot, a->slot, MSI_BITS_AND); }
+  void or_(const Set &d, const Set &a) { op(d->slot, d->slot, a->slot, MSI_BITS_OR); }
+  void sub_(const Set &d, const Set &a) { op(d->slot, d->slot, a->slot, MSI_BITS_ANDNOT); }
   Set and_new(const Set &a, const Set &b, uint64_t *count) {
     Set s = alloc();
-    if (count) ck(msi_bits_op_count(pool.p, s->slot, a->slot, b->slot, MSI_BITS_AND, count));
-    else ck(msi_bits_op(pool.p, s->slot, a->slot, b->slot, MSI_BITS_AND));
+    if (count) {
+      Clock ck_;
+      ++g_stats.launches;
+      ++g_stats.syncs;
+      ck(msi_bits_op_count(pool.p, s->slot, a->slot, b->slot, MSI_BITS_AND, count));
+      g_stats.device_wait_ms += ck_.ms();
+    } else {
+      op(s->slot, a->slot, b->slot, MSI_BITS_AND);
+    }
     return s;
+  }
+  // dst[i] = prefix & cond[i] with the cardinalities, one launch and one completion wait for all of them
+  std::vector<std::pair<Set, uint64_t>> and_many(const Set &prefix, const std::vector<Set> &conds) {
+    std::vector<std::pair<Set, uint64_t>> out;
+    for (size_t base = 0; base < conds.size(); base += MSI_BITS_MANY) {
+      const uint32_t n = (uint32_t)std::min<size_t>(MSI_BITS_MANY, conds.size() - base);
+      uint32_t cs[MSI_BITS_MANY], ds[MSI_BITS_MANY];
+      uint64_t counts[MSI_BITS_MANY];
+      std::vector<Set> dst;
+      for (uint32_t k = 0; k < n; ++k) {
+        dst.push_back(alloc());
+        cs[k] = conds[base + k]->slot;
+        ds[k] = dst[k]->slot;
+      }
+      Clock ck_;
+      ++g_stats.launches;
+      ++g_stats.syncs;
+      ck(msi_bits_and_many_count(pool.p, prefix->slot, n, cs, ds, counts));
+      g_stats.device_wait_ms += ck_.ms();
+      for (uint32_t k = 0; k < n; ++k) out.push_back({dst[k], counts[k]});
+    }
+    return out;
+  }
+  void claim(const Set &docs, const Set &bucket, const Set &universe, const std::vector<Set> &stack) {
+    uint32_t ss[MSI_BITS_MANY];
+    if (stack.size() > MSI_BITS_MANY) fail(MSI_E_INTERNAL, "path longer than the claim kernel supports");
+    for (size_t k = 0; k < stack.size(); ++k) ss[k] = stack[k]->slot;
+    ++g_stats.launches;
+    ck(msi_bits_claim(pool.p, docs->slot, bucket->slot, universe->slot, (uint32_t)stack.size(), ss));
   }
   uint64_t count(const Set &a) {
     uint64_t c = 0;
+    Clock ck_;
+    ++g_stats.launches;
+    ++g_stats.syncs;
     ck(msi_bits_count(pool.p, a->slot, &c));
+    g_stats.device_wait_ms += ck_.ms();
     return c;
   }
   Set decode(const MsiCboBatch &b) {
     Set s = alloc();
-    if (b.containers.empty() && b.small_ids.empty()) ck(msi_bits_fill(pool.p, s->slot, 0));
-    else ck(msi_bits_decode_batch(pool.p, s->slot, b, true));
+    if (b.containers.empty() && b.small_ids.empty()) {
+      fill(s->slot, 0);
+    } else {
+      Clock ck_;
+      ++g_stats.decodes;
+      g_stats.postings_bytes += b.bytes.size() + 4 * b.small_ids.size();
+      ck(msi_bits_decode_batch(pool.p, s->slot, b, true));
+      g_stats.device_wait_ms += ck_.ms();
+    }
     return s;
   }
   std::vector<uint32_t> first_k(const Set &a, uint32_t k) {
     std::vector<uint32_t> ids(std::max<uint32_t>(k, 1));
     uint32_t n = 0;
+    Clock ck_;
+    g_stats.launches += 3;
+    ++g_stats.syncs;
     ck(msi_bits_first_k(pool.p, a->slot, k, ids.data(), &n));
+    g_stats.device_wait_ms += ck_.ms();
     ids.resize(n);
     return ids;
   }
@@ -220,6 +291,20 @@ struct Ctx {
   std::map<Phrase, uint32_t> phrase_ids;
   std::vector<Term> terms;
   std::map<uint32_t, Set> phrase_cache;
+  // Document sets that do not depend on a universe, decoded once per search and then only intersected:
+  // the rules of a search resolve the same term subsets again and again (every bucket of a rule restarts
+  // the rules below it).
+  std::map<Subset, Set> subset_cache;
+  std::map<std::tuple<Subset, int, uint32_t>, Set> within_cache;
+  std::map<std::tuple<Subset, Subset, uint32_t, uint32_t>, Set> prox_cache;
+  std::map<std::pair<uint32_t, bool>, Set> word_cache;
+  void relieve() {  // keep the pool from running dry on long queries: drop what can be recomputed
+    if (dev.pool.free_.size() >= 48) return;
+    subset_cache.clear();
+    within_cache.clear();
+    prox_cache.clear();
+    word_cache.clear();
+  }
 
   Ctx(msi_dict *d, msi_bits *pool, const msi_index_vtable *i, const msi_search_params *p)
       : dict(d), ix(i), prm(p), dev(pool) {}
@@ -248,10 +333,18 @@ struct Ctx {
       throw Fail{MSI_E_INVALID};
     }
   }
+  struct Cb {
+    Clock c;
+    ~Cb() {
+      ++g_stats.callbacks;
+      g_stats.callback_ms += c.ms();
+    }
+  };
   bool add_word(MsiCboBatch &b, uint32_t w, bool original) {
     const std::string &s = words[w];
     const uint8_t *bytes = nullptr;
     size_t n = 0;
+    Cb cb_;
     const int32_t st = ix->word_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), original ? 1 : 0, &bytes, &n);
     take(b, st, bytes, n, "word_docids");
     return n != 0;
@@ -261,6 +354,7 @@ struct Ctx {
     const std::string &l = words[w1], &r = words[w2];
     const uint8_t *bytes = nullptr;
     size_t n = 0;
+    Cb cb_;
     const int32_t st = ix->word_pair_proximity_docids(ix->user, prox, (const uint8_t *)l.data(), (uint32_t)l.size(),
                                                       (const uint8_t *)r.data(), (uint32_t)r.size(), &bytes, &n);
     if (st < 0) fail(MSI_E_INTERNAL, "word_pair_proximity_docids callback failed");
@@ -274,6 +368,7 @@ struct Ctx {
     const std::string &s = words[w];
     const uint8_t *bytes = nullptr;
     size_t n = 0;
+    Cb cb_;
     take(b, ix->word_fid_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), fid, &bytes, &n), bytes, n,
          "word_fid_docids");
   }
@@ -283,6 +378,7 @@ struct Ctx {
     const std::string &s = words[w];
     const uint8_t *bytes = nullptr;
     size_t n = 0;
+    Cb cb_;
     take(b, ix->word_position_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), pos, &bytes, &n), bytes, n,
          "word_position_docids");
   }
@@ -293,6 +389,7 @@ struct Ctx {
     }
     const std::string &s = words[w];
     std::vector<uint16_t> out(64);
+    Cb cb_;
     for (;;) {
       uint32_t n = 0;
       if (fn(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), out.data(), (uint32_t)out.size(), &n) < 0)
@@ -461,10 +558,15 @@ struct Ctx {
   }
 
   // -- docids (resolve_query_graph.rs), all on the device -----------------------------------------
-  Set word_docids(uint32_t w, bool original) {
-    MsiCboBatch b;
-    add_word(b, w, original);
-    return dev.decode(b);
+  Set word_docids(uint32_t w, bool original) {  // a fresh set the caller may modify
+    auto it = word_cache.find({w, original});
+    if (it == word_cache.end()) {
+      relieve();
+      MsiCboBatch b;
+      add_word(b, w, original);
+      it = word_cache.emplace(std::make_pair(w, original), dev.decode(b)).first;
+    }
+    return dev.clone(it->second);
   }
   Set pair_union(uint32_t w1, uint32_t w2, uint32_t max_prox) {  // union of pair(prox = 1..max_prox)
     MsiCboBatch b;
@@ -480,7 +582,6 @@ struct Ctx {
     const Phrase p = phrases[pid];
     Set cand;
     {
-      MsiCboBatch none;
       bool any = false;
       for (int32_t w : p) {
         if (w < 0) continue;
@@ -505,15 +606,32 @@ struct Ctx {
   }
   // compute_query_term_subset_docids :33-59
   Set subset_docids(const Set *universe, const Subset &ss) {
-    MsiCboBatch b;
-    for (auto &w : all_single_words(ss)) add_word(b, w.first, w.second);
-    Set d = dev.decode(b);
-    for (uint32_t p : all_phrases(ss)) dev.or_(d, phrase_docids(p));
-    if (universe) dev.and_(d, *universe);
-    return d;
+    Subset key = ss;
+    key.mandatory = false;
+    auto it = subset_cache.find(key);
+    if (it == subset_cache.end()) {
+      relieve();
+      MsiCboBatch b;
+      for (auto &w : all_single_words(ss)) add_word(b, w.first, w.second);
+      Set d = dev.decode(b);
+      for (uint32_t p : all_phrases(ss)) dev.or_(d, phrase_docids(p));
+      it = subset_cache.emplace(key, d).first;
+    }
+    return universe ? dev.and_new(it->second, *universe, nullptr) : dev.clone(it->second);
   }
   // ..._within_field_id / ..._within_position :61-130 (which: 0 fid, 1 position)
   Set subset_docids_within(const Set &universe, const Subset &ss, int which, uint32_t key) {
+    Subset sk = ss;
+    sk.mandatory = false;
+    auto ck_ = std::make_tuple(sk, which, key);
+    auto it = within_cache.find(ck_);
+    if (it == within_cache.end()) {
+      relieve();
+      it = within_cache.emplace(ck_, subset_docids_within_full(ss, which, key)).first;
+    }
+    return dev.and_new(it->second, universe, nullptr);
+  }
+  Set subset_docids_within_full(const Subset &ss, int which, uint32_t key) {
     MsiCboBatch b;
     for (auto &w : all_single_words(ss)) {
       if (which == 0) add_word_fid(b, w.first, key);
@@ -535,7 +653,6 @@ struct Ctx {
       dev.and_(f, phrase_docids(p));
       dev.or_(d, f);
     }
-    dev.and_(d, universe);
     return d;
   }
 };
@@ -846,6 +963,12 @@ struct Resolved {
 Set proximity_docids(Ctx &c, const Condition &cd, const Set &universe) {
   const uint32_t rn = cd.term.n_ids();
   const uint32_t forward = 1 + cd.x - rn, backward = cd.x - rn;
+  Subset lk = cd.left.subset, rk = cd.term.subset;
+  lk.mandatory = rk.mandatory = false;
+  auto key = std::make_tuple(lk, rk, forward, backward);
+  auto hit = c.prox_cache.find(key);
+  if (hit != c.prox_cache.end()) return c.dev.and_new(hit->second, universe, nullptr);
+  c.relieve();
   std::set<std::pair<int32_t, uint32_t>> lefts, rights;  // (phrase or -1, word)
   for (auto &w : c.all_single_words(cd.left.subset)) lefts.insert({-1, w.first});
   for (uint32_t p : c.all_phrases(cd.left.subset))
@@ -869,8 +992,8 @@ Set proximity_docids(Ctx &c, const Condition &cd, const Set &universe) {
     if (kv.first.second >= 0) c.dev.and_(d, c.phrase_docids((uint32_t)kv.first.second));
     c.dev.or_(docids, d);
   }
-  c.dev.and_(docids, universe);
-  return docids;
+  c.prox_cache.emplace(key, docids);
+  return c.dev.and_new(docids, universe, nullptr);
 }
 
 Resolved resolve_condition(Ctx &c, const Condition &cd, const Set &universe) {
@@ -957,6 +1080,7 @@ struct GraphRule : Rule {
   std::vector<StackE> stack;
   std::vector<std::vector<int32_t>> good;
   bool stop = false;
+  uint64_t emit_epoch = 0;
 
   GraphRule(int k, int t) : Rule(k, t) {}
 
@@ -1075,14 +1199,35 @@ struct GraphRule : Rule {
   }
 
   // cheapest_paths.rs:147-310: edges in insertion order; a conditional edge cannot enter a node that
-  // must be skipped, nor be taken once a node named by its skip list was traversed
+  // must be skipped, nor be taken once a node named by its skip list was traversed.  All the conditional
+  // edges that leave a node are intersected with the path prefix in ONE launch (and one completion wait);
+  // a sibling evaluated before an earlier sibling claimed documents is re-intersected when its turn comes.
   void visit(uint32_t node, uint64_t remaining, std::set<uint32_t> &visited, const std::set<uint32_t> &to_skip) {
+    std::vector<const Edge *> cand;
     for (const Edge &e : edges[node]) {
-      if (stop) return;
       if (remaining < e.cost) continue;
-      const uint64_t rem = remaining - e.cost;
       const auto &dc = costs[e.dest];
-      if (!std::binary_search(dc.begin(), dc.end(), rem)) continue;
+      if (!std::binary_search(dc.begin(), dc.end(), remaining - e.cost)) continue;
+      if (e.cond >= 0) {
+        if (to_skip.count(e.dest)) continue;
+        bool blocked = false;
+        for (uint32_t s : e.skip) blocked |= visited.count(s) != 0;
+        if (blocked) continue;
+      }
+      cand.push_back(&e);
+    }
+    std::vector<Set> cs;
+    for (const Edge *e : cand)
+      if (e->cond >= 0) cs.push_back(resolved(e->cond).docs);
+    // stack entries are subsets of the current universe, so only the first condition needs it
+    std::vector<std::pair<Set, uint64_t>> pre;
+    if (!cs.empty() && !stop) pre = cx->dev.and_many(stack.empty() ? uni : stack.back().docs, cs);
+    const uint64_t epoch0 = emit_epoch;
+    size_t k = 0;
+    for (const Edge *ep : cand) {
+      if (stop) return;
+      const Edge &e = *ep;
+      const uint64_t rem = remaining - e.cost;
       if (e.cond < 0) {
         if (e.dest == Graph::END) {
           emit();
@@ -1093,15 +1238,13 @@ struct GraphRule : Rule {
         }
         continue;
       }
-      if (to_skip.count(e.dest)) continue;
-      bool blocked = false;
-      for (uint32_t s : e.skip) blocked |= visited.count(s) != 0;
-      if (blocked) continue;
-      const Resolved &r = resolved(e.cond);
-      uint64_t cnt = 0;
-      // stack entries are subsets of the current universe, so only the first condition needs it
-      Set d = cx->dev.and_new(r.docs, stack.empty() ? uni : stack.back().docs, &cnt);
-      if (!cnt) continue;  // every extension of an empty prefix is empty
+      Set d = pre[k].first;
+      uint64_t cnt = pre[k].second;
+      pre[k].first.reset();
+      ++k;
+      if (!cnt) continue;  // every extension of an empty prefix is empty (sets only shrink)
+      if (emit_epoch != epoch0) d = cx->dev.and_new(cs[k - 1], stack.empty() ? uni : stack.back().docs, &cnt);
+      if (!cnt) continue;
       stack.push_back({e.cond, d, false, cnt});
       visited.insert(e.dest);
       std::set<uint32_t> ts = to_skip;
@@ -1117,11 +1260,13 @@ struct GraphRule : Rule {
       stop = true;
       return;
     }
-    Set docs;
     uint64_t cnt;
-    if (stack.empty()) {
-      docs = cx->dev.clone(uni);
+    std::vector<int32_t> path;
+    for (auto &s : stack) path.push_back(s.cond);
+    if (stack.empty()) {  // a path without any condition takes the whole universe
       cnt = uni_count;
+      cx->dev.or_(bucket, uni);
+      cx->dev.sub_(uni, uni);
     } else {
       StackE &top = stack.back();
       if (top.stale) {
@@ -1130,23 +1275,18 @@ struct GraphRule : Rule {
       }
       cnt = top.count;
       if (!cnt) return;
-      docs = cx->dev.clone(top.docs);
+      std::vector<Set> ss;
+      for (auto &s : stack) ss.push_back(s.docs);
+      cx->dev.claim(top.docs, bucket, uni, ss);
+      for (auto &s : stack) s.stale = true;
+      top.stale = false;
+      top.count = 0;
     }
-    std::vector<int32_t> path;
-    for (auto &s : stack) path.push_back(s.cond);
     good.push_back(std::move(path));
-    cx->dev.or_(bucket, docs);
+    ++g_stats.paths;
+    ++emit_epoch;
     bucket_count += cnt;
-    cx->dev.sub_(uni, docs);
     uni_count -= cnt;
-    for (auto &s : stack) {
-      cx->dev.sub_(s.docs, docs);
-      s.stale = true;
-    }
-    if (!stack.empty()) {
-      stack.back().stale = false;
-      stack.back().count = 0;
-    }
     if (!uni_count) stop = true;
   }
 
@@ -1500,6 +1640,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       if (!back()) break;
       continue;
     }
+    ++g_stats.buckets;
     scores.push_back(b.score);
     c.dev.sub_(unis[cur], b.docs);
     uni_counts[cur] -= b.count;
@@ -1540,9 +1681,12 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
     msi_set_error("msi_keyword_search_ranked: no query term (placeholder search is not a keyword search)");
     return MSI_E_INVALID;
   }
+  g_stats = Stats();
+  Clock total;
   try {
     Ctx c(dict, pool, index, params);
     search(c, terms, n_terms, universe_cbo, universe_len, out_docids, out_scores, out_n_scores, out_n, out_candidates);
+    g_stats.total_ms = total.ms();
     return MSI_OK;
   } catch (const Fail &f) {
     return f.code;
@@ -1553,4 +1697,15 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
     msi_set_error("msi_keyword_search_ranked: %s", e.what());
     return MSI_E_INTERNAL;
   }
+}
+
+// Counters of the last msi_keyword_search_ranked on the calling thread: [launches, syncs, decode batches,
+// index callbacks, posting bytes decoded, matching paths, buckets, callback us, device wait us, total us].
+extern "C" int32_t msi_search_last_stats(uint64_t out[10]) {
+  if (!out) return MSI_E_INVALID;
+  const Stats &s = g_stats;
+  const uint64_t v[10] = {s.launches, s.syncs, s.decodes, s.callbacks, s.postings_bytes, s.paths, s.buckets,
+                          (uint64_t)(s.callback_ms * 1e3), (uint64_t)(s.device_wait_ms * 1e3), (uint64_t)(s.total_ms * 1e3)};
+  memcpy(out, v, sizeof(v));
+  return MSI_OK;
 }

@@ -283,3 +283,12 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
                 int(sc[i * MAX_SCORE_DETAILS + k].b)) for k in range(int(nsc[i]))]
         hits.append((int(ids[i]), det))
     return hits, int(cand.value)
+
+
+def search_last_stats():
+    """Counters of the last keyword_search_ranked on this thread."""
+    v = (C.c_uint64 * 10)()
+    check(lib().msi_search_last_stats(v))
+    names = ["launches", "syncs", "decode_batches", "callbacks", "posting_bytes", "paths", "buckets", "callback_us",
+             "device_wait_us", "total_us"]
+    return dict(zip(names, [int(x) for x in v]))

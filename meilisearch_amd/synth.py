@@ -86,3 +86,118 @@ def round_to_bf16(x):
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
     bias = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
     return ((u + bias) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
+def cbo_serialize(ids):
+    """CboRoaringBitmapCodec::serialize_into_writer (cbo_roaring_bitmap_codec.rs:33-51) of a sorted unique
+    u32 array: <= 7 documents as raw native-endian u32s, else the portable Roaring serialisation (array
+    containers up to 4096 values, bitmap containers above; no run containers)."""
+    import struct
+    ids = np.asarray(ids, dtype=np.uint32)
+    if ids.size <= 7:
+        return ids.astype("=u4").tobytes()
+    hi = (ids >> 16).astype(np.uint32)
+    keys, starts = np.unique(hi, return_index=True)
+    ends = np.append(starts[1:], ids.size)
+    out = bytearray(struct.pack("<II", 12346, len(keys)))
+    for k, a, b in zip(keys, starts, ends):
+        out += struct.pack("<HH", int(k), int(b - a) - 1)
+    out += b"\0" * (4 * len(keys))
+    for a, b in zip(starts, ends):
+        v = (ids[a:b] & 0xFFFF).astype(np.uint16)
+        if v.size <= 4096:
+            out += v.astype("<u2").tobytes()
+        else:
+            words = np.zeros(1024, dtype=np.uint64)
+            np.bitwise_or.at(words, (v >> 6).astype(np.int64), np.uint64(1) << (v & 63).astype(np.uint64))
+            out += words.astype("<u8").tobytes()
+    return bytes(out)
+
+
+class SynthIndex:
+    """A synthetic inverted index at scale behind msi_index_vtable (what the Rust shim would answer from
+    LMDB): Zipf word frequencies over `n_docs` documents, 3 searchable fields, bucketed positions, word
+    pairs at proximities 1..3.  Postings are generated lazily from a per-key seed and cached as the
+    CboRoaringBitmap bytes milli stores."""
+    FIDS = (1, 2, 3)
+    POSITIONS = tuple(range(16)) + (24, 32, 64, 128)
+
+    def __init__(self, n_docs, words, seed=4242):
+        self.n_docs, self.seed = n_docs, seed
+        self.words = sorted(set(words), key=lambda w: w.encode())
+        self.rank = {w: i for i, w in enumerate(np.random.default_rng(seed).permutation(self.words))}
+        self.exact_words = ()
+        self._ids, self._bytes = {}, {}
+        self.searchable_fids = list(self.FIDS)
+        self.weights = {1: 0, 2: 1, 3: 2}
+        self.max_weight = 2
+
+    def _rng(self, *key):
+        import zlib
+        return np.random.default_rng(zlib.crc32(repr((self.seed,) + key).encode()))
+
+    def ids(self, word):
+        if word not in self._ids:
+            if word not in self.rank:
+                self._ids[word] = None
+            else:
+                p = min(0.4, 0.6 / (1 + self.rank[word]) ** 0.9)       # Zipf-like document frequency
+                k = max(1, int(self.n_docs * p))
+                self._ids[word] = np.unique(self._rng("w", word).integers(0, self.n_docs, k, dtype=np.uint32))
+        return self._ids[word]
+
+    def _cached(self, key, make):
+        if key not in self._bytes:
+            ids = make()
+            self._bytes[key] = cbo_serialize(ids) if ids is not None and ids.size else None
+        return self._bytes[key]
+
+    def _part(self, word, salt, n_parts):
+        ids = self.ids(word)
+        h = (ids.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(salt * 0x632BE5AB + 1)) >> np.uint64(40)
+        return ids, (h % np.uint64(n_parts)).astype(np.int64)
+
+    def word_docids_bytes(self, word, original):
+        return self._cached(("w", word), lambda: self.ids(word))
+
+    def is_exact_word(self, word):
+        return False
+
+    def word_fid_docids_bytes(self, word, fid):
+        def make():
+            if self.ids(word) is None:
+                return None
+            ids, part = self._part(word, 1, 4)          # a document holds the word in 1-2 fields
+            f = self.FIDS.index(fid)
+            return ids[(part == f) | (part == 3) & (f < 2)]
+        return self._cached(("f", word, fid), make) if fid in self.FIDS else None
+
+    def word_position_docids_bytes(self, word, pos):
+        def make():
+            if self.ids(word) is None:
+                return None
+            ids, part = self._part(word, 2, len(self.POSITIONS))
+            return ids[part == self.POSITIONS.index(pos)]
+        return self._cached(("p", word, pos), make) if pos in self.POSITIONS else None
+
+    def word_fids(self, word):
+        return list(self.FIDS) if self.ids(word) is not None else []
+
+    def word_positions(self, word):
+        return list(self.POSITIONS) if self.ids(word) is not None else []
+
+    def pair_docids_bytes(self, prox, left, right):
+        def make():
+            a, b = self.ids(left), self.ids(right)
+            if a is None or b is None or not 1 <= prox <= 3:
+                return None
+            both = np.intersect1d(a, b, assume_unique=True)
+            h = (both.astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93) >> np.uint64(37)) % np.uint64(6)
+            return both[h == np.uint64(prox - 1)]          # half of the co-occurrences are close
+        return self._cached(("pp", prox, left, right), make)
+
+    def fid_word_count_docids_bytes(self, fid, count):
+        def make():
+            k = max(1, self.n_docs // 200)
+            return np.unique(self._rng("c", fid, count).integers(0, self.n_docs, k, dtype=np.uint32))
+        return self._cached(("c", fid, count), make) if count <= 30 else None

@@ -281,6 +281,52 @@ def run_c5(args):
                           "rerank_candidates_mean": float(np.mean(res.cand))}), flush=True)
 
 
+def run_ranked(args):
+    """The keyword leg with the default criteria [words, typo, proximity, attributeRank, sort, wordPosition,
+    exactness] (msi_keyword_search_ranked) over a synthetic index of `rows` documents: host rule graphs,
+    every docid set in HBM.  Postings come through the Python vtable adapter (cached bytes), so the host
+    share includes ctypes callback overhead a Rust shim would not have."""
+    import torch  # noqa: F401  (one HIP runtime per process)
+    import meilisearch_amd as ma
+    from meilisearch_amd import ranking as R
+    from meilisearch_amd import synth
+    ctx = ma.Context(0)
+    n = args.rows
+    words = synth.make_dictionary(args.dict_words, seed=99)
+    index = synth.SynthIndex(n, words)
+    gdict = ma.GpuDictionary(ctx, [w.encode() for w in index.words])
+    pool = ma.BitsPool(ctx, n, args.slots)
+    cb = R.IndexCallbacks(index)
+    rng = np.random.default_rng(11)
+    by_rank = sorted((w for w in index.words if w.isascii() and w.isalpha() and 4 <= len(w) <= 9),
+                     key=lambda w: index.rank[w])
+    criteria = ["words", "typo", "proximity", "attributeRank", "sort", "wordPosition", "exactness"]
+    for nt in (1, 2, 3, 5):
+        lat, hits_n, cands, stats = [], [], [], []
+        for q in range(args.reps):
+            ws = [by_rank[int(rng.integers(0, 300))] for _ in range(nt)]
+            terms = [([w], False, i, i, i == nt - 1) for i, w in enumerate(ws)]
+
+            def go():
+                return R.keyword_search_ranked(gdict, pool, cb, terms, criteria, strategy=R.TERMS_LAST, limit=20,
+                                               searchable_fids=index.searchable_fids,
+                                               searchable_weights=[index.weights[f] for f in index.searchable_fids],
+                                               max_weight=index.max_weight)
+            go()                       # fills the posting cache of the synthetic index
+            t0 = time.perf_counter()
+            hits, cand = go()
+            lat.append((time.perf_counter() - t0) * 1e3)
+            stats.append(R.search_last_stats())
+            hits_n.append(len(hits))
+            cands.append(cand)
+        print(json.dumps({"config": "ranked", "docs": n, "terms": nt, "criteria": criteria, "queries": args.reps,
+                          "p50_ms": round(statistics.median(lat), 3), "mean_ms": round(statistics.mean(lat), 3),
+                          "max_ms": round(max(lat), 3), "hits_min": min(hits_n),
+                          "candidates_mean": float(np.mean(cands)), "set_bytes": ((n + 127) // 128) * 16,
+                          "mean_stats": {k: round(float(np.mean([s_[k] for s_ in stats])), 1) for k in stats[0]}}),
+              flush=True)
+
+
 def run_rank(args):
     """Words -> Typo bucket sort over dense docid sets (S3): n_terms query terms with
     random zero/one/two-typo posting sets over `rows` documents, top-`k`."""
@@ -317,7 +363,7 @@ def run_rank(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered", "c5"])
+    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered", "c5", "ranked"])
     ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--rows", type=int, default=1_000_000)
@@ -328,10 +374,11 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--slots", type=int, default=1024)
     args = ap.parse_args()
     if args.batches is None:
         args.batches = [1, 16, 48, 240] if args.config != "c3" else [1, 64, 1024, 8192]
-    {"c2": run_c2, "c3": run_c3, "rank": run_rank, "filtered": run_filtered, "c5": run_c5}[args.config](args)
+    {"c2": run_c2, "c3": run_c3, "rank": run_rank, "filtered": run_filtered, "c5": run_c5, "ranked": run_ranked}[args.config](args)
 
 
 if __name__ == "__main__":
