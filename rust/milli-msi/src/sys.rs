@@ -46,12 +46,32 @@ pub struct msi_keyword_params {
 pub type word_docids_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, i32, *mut *const u8, *mut usize) -> i32;
 pub type pair_docids_fn = unsafe extern "C" fn(*mut c_void, u32, *const u8, u32, *const u8, u32, *mut *const u8, *mut usize) -> i32;
 pub type exact_word_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32) -> i32;
+pub type word_key_docids_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, u32, *mut *const u8, *mut usize) -> i32;
+pub type word_keys_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, *mut u16, u32, *mut u32) -> i32;
+pub type fid_count_docids_fn = unsafe extern "C" fn(*mut c_void, u32, u32, *mut *const u8, *mut usize) -> i32;
 #[repr(C)]
 pub struct msi_index_vtable {
     pub user: *mut c_void,
     pub word_docids: Option<word_docids_fn>,
     pub word_pair_proximity_docids: Option<pair_docids_fn>,
     pub is_exact_word: Option<exact_word_fn>,
+    pub word_fid_docids: Option<word_key_docids_fn>,
+    pub word_position_docids: Option<word_key_docids_fn>,
+    pub word_fids: Option<word_keys_fn>,
+    pub word_positions: Option<word_keys_fn>,
+    pub field_id_word_count_docids: Option<fid_count_docids_fn>,
+}
+pub const MSI_MAX_SCORE_DETAILS: usize = 8;
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct msi_score_detail { pub kind: u32, pub a: u32, pub b: u32 }
+#[repr(C)]
+pub struct msi_located_term { pub words: *const msi_query_token, pub n_words: u32, pub is_phrase: u32, pub position_start: u32, pub position_end: u32 }
+#[repr(C)]
+pub struct msi_search_params {
+    pub authorize_typos: u32, pub min_word_len_one_typo: u32, pub min_word_len_two_typos: u32, pub strategy: i32,
+    pub criteria: *const i32, pub n_criteria: u32,
+    pub searchable_fids: *const u16, pub searchable_weights: *const u16, pub n_searchable: u32,
+    pub max_weight: i32, pub from: u32, pub length: u32, pub detailed_scores: i32,
 }
 
 extern "C" {
@@ -117,6 +137,13 @@ extern "C" {
                               universe_cbo: *const u8, universe_len: usize, out_docids: *mut u32,
                               out_matching_words: *mut u32, out_typo_count: *mut u32, out_max_typo_count: *mut u32,
                               out_n: *mut u32, out_candidates: *mut u64) -> i32;
+
+    pub fn msi_keyword_search_ranked(d: *mut msi_dict, p: *mut msi_bits, index: *const msi_index_vtable,
+                                     terms: *const msi_located_term, n_terms: u32, params: *const msi_search_params,
+                                     universe_cbo: *const u8, universe_len: usize, out_docids: *mut u32,
+                                     out_scores: *mut msi_score_detail, out_n_scores: *mut u32, out_n: *mut u32,
+                                     out_candidates: *mut u64) -> i32;
+    pub fn msi_bits_op_count(p: *mut msi_bits, dst: u32, a: u32, b: u32, op: i32, out_count: *mut u64) -> i32;
 
     pub fn msi_vector_sort(docids: *const u32, dist: *const f32, n: u32, has_shift: i32, mean: f32, sigma: f32,
                            from: u32, length: u32, out_docids: *mut u32, out_similarity: *mut f32) -> u32;
