@@ -263,6 +263,11 @@ int32_t msi_dict_match_time(msi_dict *dict, uint64_t *out_launches, double *out_
 int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots,
                         msi_bits **out);
 void msi_bits_destroy(msi_bits *pool);
+/* By default a pool works on its context's stream (in order with the vector scan that may read one of its
+ * slots as a filter).  A pool that serves one keyword search at a time can take a private stream so that
+ * many searches (one pool each, one caller thread each) are in flight on the device together.  Call right
+ * after msi_bits_create. */
+int32_t msi_bits_use_private_stream(msi_bits *pool);
 /* slot := {docids}; docids need not be sorted. */
 int32_t msi_bits_set_from_docids(msi_bits *pool, uint32_t slot,
                                  const uint32_t *docids, uint64_t n);

@@ -148,6 +148,7 @@ PROTOTYPES = {
     "msi_dict_match_time": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_F64)]),
     "msi_bits_create": (_I32, [_VP, _U64, _U32, C.POINTER(_VP)]),
     "msi_bits_destroy": (None, [_VP]),
+    "msi_bits_use_private_stream": (_I32, [_VP]),
     "msi_bits_set_from_docids": (_I32, [_VP, _U32, _VP, _U64]),
     "msi_bits_set_from_cbo": (_I32, [_VP, _U32, _VP, C.c_size_t]),
     "msi_bits_set_from_words": (_I32, [_VP, _U32, _VP, _U64]),

@@ -11,12 +11,14 @@ NO_UNIVERSE = 0xFFFFFFFF
 
 
 class BitsPool:
-    def __init__(self, ctx, n_docs, n_slots):
+    def __init__(self, ctx, n_docs, n_slots, private_stream=False):
         self.ctx = ctx
         self.n_docs = int(n_docs)
         self.n_slots = int(n_slots)
         self._h = C.c_void_p()
         check(lib().msi_bits_create(ctx.handle, self.n_docs, self.n_slots, C.byref(self._h)))
+        if private_stream:
+            check(lib().msi_bits_use_private_stream(self._h))
 
     def set_from_docids(self, slot, docids):
         d = np.ascontiguousarray(docids, dtype=np.uint32)

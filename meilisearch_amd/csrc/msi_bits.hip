@@ -35,11 +35,20 @@ struct msi_bits {
   // pinned staging ring for posting bytes: decodes are enqueued without waiting for the copy
   uint8_t *h_ring = nullptr;
   size_t ring_cap = 0, ring_pos = 0;
+  // The stream and lock every operation of this pool uses: the context's by default (in-stream order with
+  // the vector scan and the ranking kernels), a private pair after msi_bits_use_private_stream (one search
+  // per pool, many searches in flight).
+  hipStream_t stream = nullptr;
+  std::mutex own_mu;
+  std::mutex *mu = nullptr;
+  bool private_stream = false;
   u64 *slot(uint32_t s) const { return pool.as<u64>() + (uint64_t)s * n_words; }
 };
 
 // accessors for the other translation units (msi_rank.hip)
 msi_ctx *msi_bits_ctx(msi_bits *p) { return p->ctx; }
+hipStream_t msi_bits_stream(msi_bits *p) { return p->stream; }
+std::mutex &msi_bits_mutex(msi_bits *p) { return *p->mu; }
 u64 *msi_bits_slot_ptr(msi_bits *p, uint32_t slot) { return p->slot(slot); }
 uint64_t msi_bits_words_per_slot(msi_bits *p) { return p->n_words; }
 uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
@@ -361,7 +370,7 @@ int32_t wait_count(msi_bits *p, uint64_t seq, uint64_t *out) {
     if (__atomic_load_n(const_cast<uint64_t *>(&p->h_sig[1]), __ATOMIC_ACQUIRE) == seq) break;
     if ((spin & 1023) == 1023 &&
         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 2000.0) {
-      MSI_HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+      MSI_HIP_TRY(hipStreamSynchronize(p->stream));
       if (__atomic_load_n(const_cast<uint64_t *>(&p->h_sig[1]), __ATOMIC_ACQUIRE) != seq) {
         msi_set_error("count kernel finished without publishing its result");
         return MSI_E_INTERNAL;
@@ -394,6 +403,8 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   DeviceGuard g(ctx->device);
   msi_bits *p = new msi_bits();
   p->ctx = ctx;
+  p->stream = ctx->stream;
+  p->mu = &ctx->mu;
   p->n_docs = n_docs;
   p->n_words = std::max<uint64_t>(2, ((n_docs + 127) / 128) * 2);
   p->n_slots = n_slots;
@@ -432,13 +443,29 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   return MSI_OK;
 }
 
+int32_t msi_bits_use_private_stream(msi_bits *p) {
+  if (!p) return MSI_E_INVALID;
+  if (p->private_stream) return MSI_OK;
+  DeviceGuard g(p->ctx->device);
+  {
+    std::lock_guard<std::mutex> lk(*p->mu);
+    MSI_HIP_TRY(hipStreamSynchronize(p->stream));  // the creation memset ran on the context stream
+  }
+  hipStream_t st = nullptr;
+  MSI_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  p->stream = st;
+  p->mu = &p->own_mu;
+  p->private_stream = true;
+  return MSI_OK;
+}
+
 void msi_bits_destroy(msi_bits *p) {
   if (!p) return;
   msi_ctx *ctx = p->ctx;
   {
   std::lock_guard<std::mutex> lk(ctx->mu);
   DeviceGuard g(ctx->device);
-  (void)hipStreamSynchronize(p->ctx->stream);
+  (void)hipStreamSynchronize(p->stream);
   p->pool.release();
   p->tmp.release();
   p->small.release();
@@ -448,6 +475,7 @@ void msi_bits_destroy(msi_bits *p) {
   if (p->h_sig) (void)hipHostFree((void *)p->h_sig);
   if (p->d_acc) (void)hipFree(p->d_acc);
   if (p->h_ring) (void)hipHostFree(p->h_ring);
+  if (p->private_stream) (void)hipStreamDestroy(p->stream);
   delete p;
   }
   msi_ctx_release(ctx);
@@ -455,10 +483,10 @@ void msi_bits_destroy(msi_bits *p) {
 
 int32_t msi_bits_fill(msi_bits *p, uint32_t slot, int32_t ones) {
   MSI_TRY(check_slot(p, slot, "msi_bits_fill"));
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::lock_guard<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   hipLaunchKernelGGL(bits_fill_kernel, dim3((uint32_t)((p->n_words + BT - 1) / BT)), dim3(BT), 0,
-                     p->ctx->stream, p->slot(slot), p->n_words, p->n_docs, ones);
+                     p->stream, p->slot(slot), p->n_words, p->n_docs, ones);
   MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
 }
@@ -466,9 +494,9 @@ int32_t msi_bits_fill(msi_bits *p, uint32_t slot, int32_t ones) {
 int32_t msi_bits_set_from_docids(msi_bits *p, uint32_t slot, const uint32_t *docids, uint64_t n) {
   MSI_TRY(check_slot(p, slot, "msi_bits_set_from_docids"));
   if (n && !docids) return MSI_E_INVALID;
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::lock_guard<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
-  hipStream_t st = p->ctx->stream;
+  hipStream_t st = p->stream;
   MSI_HIP_TRY(hipMemsetAsync(p->slot(slot), 0, p->n_words * sizeof(u64), st));
   if (n) {
     MSI_TRY(p->stage.ensure(n * sizeof(uint32_t)));
@@ -488,9 +516,9 @@ int32_t msi_bits_set_from_words(msi_bits *p, uint32_t slot, const uint64_t *word
                   (unsigned long long)p->n_words);
     return MSI_E_INVALID;
   }
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::lock_guard<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
-  hipStream_t st = p->ctx->stream;
+  hipStream_t st = p->stream;
   MSI_HIP_TRY(hipMemsetAsync(p->slot(slot), 0, p->n_words * sizeof(u64), st));
   if (n_words) MSI_HIP_TRY(hipMemcpyAsync(p->slot(slot), words, n_words * sizeof(u64), hipMemcpyHostToDevice, st));
   MSI_HIP_TRY(hipStreamSynchronize(st));
@@ -609,13 +637,14 @@ int32_t msi_bits_and_many_count(msi_bits *p, uint32_t prefix, uint32_t n, const 
     a.cond[k] = p->slot(cond[k]);
     a.dst[k] = p->slot(dst[k]);
   }
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   const uint64_t n_pairs = p->n_words / 2;
   const uint64_t seq = ++p->seq;
   hipLaunchKernelGGL(bits_and_many_kernel, dim3(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 4)), dim3(BT), 0,
-                     p->ctx->stream, a, p->slot(prefix), n, n_pairs, p->d_acc, p->h_sig, seq);
+                     p->stream, a, p->slot(prefix), n, n_pairs, p->d_acc, p->h_sig, seq);
   MSI_HIP_TRY(hipGetLastError());
+  lk.unlock();  // other pools that share the stream keep enqueueing while this one waits
   uint64_t ignored = 0;
   MSI_TRY(wait_count(p, seq, &ignored));
   for (uint32_t k = 0; k < n; ++k) counts[k] = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2 + k]), __ATOMIC_RELAXED);
@@ -633,11 +662,11 @@ int32_t msi_bits_claim(msi_bits *p, uint32_t docs, uint32_t bucket, uint32_t uni
     MSI_TRY(check_slot(p, stack[k], "msi_bits_claim"));
     a.stack[k] = p->slot(stack[k]);
   }
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::lock_guard<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   const uint64_t n_pairs = p->n_words / 2;
   hipLaunchKernelGGL(bits_claim_kernel, dim3(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 4)), dim3(BT), 0,
-                     p->ctx->stream, a, p->slot(docs), p->slot(bucket), p->slot(universe), n_stack, n_pairs);
+                     p->stream, a, p->slot(docs), p->slot(bucket), p->slot(universe), n_stack, n_pairs);
   MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
 }
@@ -647,7 +676,7 @@ int32_t msi_bits_claim(msi_bits *p, uint32_t docs, uint32_t bucket, uint32_t uni
 static int32_t ring_alloc(msi_bits *p, size_t bytes, uint8_t **out) {
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes > p->ring_cap) {
-    MSI_HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    MSI_HIP_TRY(hipStreamSynchronize(p->stream));
     if (p->h_ring) (void)hipHostFree(p->h_ring);
     p->h_ring = nullptr;
     p->ring_cap = 0;
@@ -662,7 +691,7 @@ static int32_t ring_alloc(msi_bits *p, size_t bytes, uint8_t **out) {
     p->ring_pos = 0;
   }
   if (p->ring_pos + bytes > p->ring_cap) {
-    MSI_HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    MSI_HIP_TRY(hipStreamSynchronize(p->stream));
     p->ring_pos = 0;
   }
   *out = p->h_ring + p->ring_pos;
@@ -671,9 +700,9 @@ static int32_t ring_alloc(msi_bits *p, size_t bytes, uint8_t **out) {
 }
 
 int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &batch, bool clear) {
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::lock_guard<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
-  hipStream_t st = p->ctx->stream;
+  hipStream_t st = p->stream;
   if (clear) MSI_HIP_TRY(hipMemsetAsync(p->slot(slot), 0, p->n_words * sizeof(u64), st));
   const size_t n_cont = batch.containers.size();
   if (n_cont) {
@@ -724,11 +753,11 @@ int32_t msi_bits_op(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int32_t o
   MSI_TRY(check_slot(p, dst, "msi_bits_op"));
   MSI_TRY(check_slot(p, a, "msi_bits_op"));
   MSI_TRY(check_slot(p, b, "msi_bits_op"));
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::lock_guard<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   const uint64_t n_pairs = p->n_words / 2;
   const dim3 grid(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 8)), block(BT);
-  hipStream_t st = p->ctx->stream;
+  hipStream_t st = p->stream;
   switch (op) {
     case MSI_BITS_AND:
       hipLaunchKernelGGL(bits_op_kernel<MSI_BITS_AND>, grid, block, 0, st, p->slot(dst), p->slot(a), p->slot(b), n_pairs);
@@ -755,11 +784,11 @@ int32_t msi_bits_op_count(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int
   MSI_TRY(check_slot(p, a, "msi_bits_op_count"));
   MSI_TRY(check_slot(p, b, "msi_bits_op_count"));
   if (!out_count) return MSI_E_INVALID;
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   const uint64_t n_pairs = p->n_words / 2;
   const dim3 grid(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 8)), block(BT);
-  hipStream_t st = p->ctx->stream;
+  hipStream_t st = p->stream;
   const uint64_t seq = ++p->seq;
   u64 *acc = p->d_acc;
   volatile uint64_t *sig = p->h_sig;
@@ -781,6 +810,7 @@ int32_t msi_bits_op_count(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int
       return MSI_E_INVALID;
   }
   MSI_HIP_TRY(hipGetLastError());
+  lk.unlock();
   return wait_count(p, seq, out_count);
 }
 
@@ -788,9 +818,9 @@ int32_t msi_bits_union_many_and(msi_bits *p, uint32_t dst, const uint32_t *srcs,
   MSI_TRY(check_slot(p, dst, "msi_bits_union_many_and"));
   if (universe != 0xFFFFFFFFu) MSI_TRY(check_slot(p, universe, "msi_bits_union_many_and"));
   for (uint32_t i = 0; i < n; ++i) MSI_TRY(check_slot(p, srcs[i], "msi_bits_union_many_and"));
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::lock_guard<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
-  hipStream_t st = p->ctx->stream;
+  hipStream_t st = p->stream;
   MSI_TRY(p->desc.ensure(std::max<uint32_t>(1, n) * sizeof(uint32_t)));
   if (n) MSI_HIP_TRY(hipMemcpyAsync(p->desc.p, srcs, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(bits_union_many_kernel, dim3(grid_for(p->n_words / 2, (uint32_t)p->ctx->n_cu * 8)), dim3(BT),
@@ -803,22 +833,23 @@ int32_t msi_bits_union_many_and(msi_bits *p, uint32_t dst, const uint32_t *srcs,
 int32_t msi_bits_count(msi_bits *p, uint32_t slot, uint64_t *out) {
   MSI_TRY(check_slot(p, slot, "msi_bits_count"));
   if (!out) return MSI_E_INVALID;
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
-  hipStream_t st = p->ctx->stream;
+  hipStream_t st = p->stream;
   const uint64_t seq = ++p->seq;
   hipLaunchKernelGGL(bits_count_kernel, dim3(grid_for(p->n_words, (uint32_t)p->ctx->n_cu * 8)), dim3(BT), 0, st,
                      p->slot(slot), p->n_words, p->d_acc, p->h_sig, seq);
   MSI_HIP_TRY(hipGetLastError());
+  lk.unlock();
   return wait_count(p, seq, out);
 }
 
 int32_t msi_bits_first_k(msi_bits *p, uint32_t slot, uint32_t k, uint32_t *out_docids, uint32_t *out_n) {
   MSI_TRY(check_slot(p, slot, "msi_bits_first_k"));
   if (!out_n || (k && !out_docids)) return MSI_E_INVALID;
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::lock_guard<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
-  hipStream_t st = p->ctx->stream;
+  hipStream_t st = p->stream;
   const uint32_t n_blocks = (uint32_t)((p->n_words + BT - 1) / BT);
   MSI_TRY(p->tmp.ensure(((size_t)n_blocks + std::max<uint32_t>(1, k)) * sizeof(uint32_t)));
   uint32_t *blk = p->tmp.as<uint32_t>();
@@ -839,9 +870,9 @@ int32_t msi_bits_first_k(msi_bits *p, uint32_t slot, uint32_t k, uint32_t *out_d
 int32_t msi_bits_read_words(msi_bits *p, uint32_t slot, uint64_t *out_words) {
   MSI_TRY(check_slot(p, slot, "msi_bits_read_words"));
   if (!out_words) return MSI_E_INVALID;
-  std::lock_guard<std::mutex> lk(p->ctx->mu);
+  std::lock_guard<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
-  hipStream_t st = p->ctx->stream;
+  hipStream_t st = p->stream;
   const uint64_t words = (p->n_docs + 63) / 64;
   if (words) MSI_HIP_TRY(hipMemcpyAsync(out_words, p->slot(slot), words * sizeof(u64), hipMemcpyDeviceToHost, st));
   MSI_HIP_TRY(hipStreamSynchronize(st));

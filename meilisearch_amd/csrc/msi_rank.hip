@@ -47,6 +47,8 @@ typedef unsigned long long u64;
 // msi_bits internals (msi_bits.hip)
 struct msi_bits;
 msi_ctx *msi_bits_ctx(msi_bits *p);
+hipStream_t msi_bits_stream(msi_bits *p);
+std::mutex &msi_bits_mutex(msi_bits *p);
 u64 *msi_bits_slot_ptr(msi_bits *p, uint32_t slot);
 uint64_t msi_bits_words_per_slot(msi_bits *p);
 uint32_t msi_bits_n_slots(msi_bits *p);
@@ -429,9 +431,9 @@ inline void hist_to_buckets(const u64 *hist, const u64 *hist_struct, uint32_t n_
 // Histogram passes -> the non-empty buckets in bucket-sort order.
 int32_t list_buckets(msi_bits *pool, RankArgs &a, uint32_t n_terms, std::vector<msi_rank_bucket> &out) {
   msi_ctx *ctx = msi_bits_ctx(pool);
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(msi_bits_mutex(pool));
   DeviceGuard g(ctx->device);
-  hipStream_t st = ctx->stream;
+  hipStream_t st = msi_bits_stream(pool);
   const size_t hist_n = (size_t)(NT_MAX + 1) * (TC_MAX + 1);
   u64 *d_hist = nullptr;
   MSI_HIP_TRY(hipMalloc(&d_hist, 2 * hist_n * sizeof(u64)));
@@ -488,14 +490,14 @@ void hist_to_buckets_impl(const u64 *hist, const u64 *hist_struct, uint32_t n_te
 
 int32_t materialise(msi_bits *pool, RankArgs &a, uint32_t k, uint32_t t) {
   msi_ctx *ctx = msi_bits_ctx(pool);
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(msi_bits_mutex(pool));
   DeviceGuard g(ctx->device);
   a.sel_k[0] = k;
   a.sel_t[0] = t;
   a.n_sel = 1;
   const int cls = rank_class_of(a.n_terms, a.tmax);
   MSI_RANK_DISPATCH(cls, hipLaunchKernelGGL((rank_query_graph_kernel<MODE_MATERIALISE, NT_, TC_>),
-                                            dim3(rank_grid(ctx, a)), dim3(RT), 0, ctx->stream, a));
+                                            dim3(rank_grid(ctx, a)), dim3(RT), 0, msi_bits_stream(pool), a));
   MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
 }
@@ -595,9 +597,9 @@ int32_t msi_rank_query_graph_batch(msi_bits *pool, const msi_rank_query *queries
     for (int i = 0; i < 4; ++i) args[q].dst[i] = msi_bits_slot_ptr(pool, rq.scratch_slot + i);
   }
   msi_ctx *ctx = msi_bits_ctx(pool);
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::mutex> lk(msi_bits_mutex(pool));
   DeviceGuard g(ctx->device);
-  hipStream_t st = ctx->stream;
+  hipStream_t st = msi_bits_stream(pool);
   const size_t hist_n = (size_t)(NT_MAX + 1) * (TC_MAX + 1);
   const size_t sz_args = (size_t)n_queries * sizeof(RankArgs);
   const size_t sz_hist = 2 * (size_t)n_queries * hist_n * sizeof(u64);

@@ -146,3 +146,34 @@ def oracle_score(s):
     if s[0] == "ExactAttribute":
         return ("ExactAttribute", {"ExactMatch": 3, "MatchesStart": 2, "NoExactMatch": 1}[s[1]], 3)
     return tuple(s)
+
+
+def test_concurrent_searches_on_private_streams():
+    """One pool with a private stream per caller thread: the results of 4 threads x 6 queries x 2 strategies
+    equal the single-threaded ones (completion signals, staging rings and slot allocators are per pool)."""
+    import threading
+    import meilisearch_amd as ma
+    from tests.toy_milli import ToyMilli
+    index = ToyMilli(random_corpus(7, 400), searchable=["title", "body"])
+    base = Harness(index)
+    want = {(q, tms): base.search(q, tms=tms, detailed=True) for q in QUERIES[:6] for tms in ("last", "all")}
+    errors = []
+
+    def worker(k):
+        try:
+            h = Harness.__new__(Harness)
+            h.R, h.index, h.ctx, h.dict = base.R, index, base.ctx, base.dict
+            h.pool = ma.BitsPool(base.ctx, index.n_docs, 512, private_stream=True)
+            h.cb = base.R.IndexCallbacks(index)
+            for (q, tms), w in want.items():
+                got = h.search(q, tms=tms, detailed=True)
+                if got != w:
+                    errors.append((k, q, tms))
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors[:5]

@@ -327,6 +327,49 @@ def run_ranked(args):
               flush=True)
 
 
+    # serving throughput: one caller thread per in-flight search, one pool (private stream) per thread
+    import threading
+    nt = 3
+    queries = []
+    for q in range(64):
+        ws = [by_rank[int(rng.integers(0, 300))] for _ in range(nt)]
+        queries.append([([w], False, i, i, i == nt - 1) for i, w in enumerate(ws)])
+
+    def run_one(pool_, cb_, terms):
+        return R.keyword_search_ranked(gdict, pool_, cb_, terms, criteria, strategy=R.TERMS_LAST, limit=20,
+                                       searchable_fids=index.searchable_fids,
+                                       searchable_weights=[index.weights[f] for f in index.searchable_fids],
+                                       max_weight=index.max_weight)
+    for t in queries:
+        run_one(pool, cb, t)                   # fills the posting cache of the synthetic index
+    for n_threads in (1, 2, 4, 8, 16):
+        pools = [ma.BitsPool(ctx, n, args.slots, private_stream=True) for _ in range(n_threads)]
+        cbs = [R.IndexCallbacks(index) for _ in range(n_threads)]
+        nxt, lock, lats = [0], threading.Lock(), []
+
+        def worker(k):
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= len(queries) * 2:
+                    return
+                t0 = time.perf_counter()
+                run_one(pools[k], cbs[k], queries[i % len(queries)])
+                lats.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(n_threads)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": "ranked_throughput", "docs": n, "terms": nt, "threads": n_threads,
+                          "queries": len(lats), "queries_per_s": round(len(lats) / dt, 1),
+                          "p50_ms": round(statistics.median(lats), 3), "max_ms": round(max(lats), 3)}), flush=True)
+        del pools
+
+
 def run_rank(args):
     """Words -> Typo bucket sort over dense docid sets (S3): n_terms query terms with
     random zero/one/two-typo posting sets over `rows` documents, top-`k`."""
