@@ -397,6 +397,8 @@ int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms,
  * the reference path.  The pool needs 2 + 3·(number of graph nodes) <= 83 slots; slots
  * 0 and 1 are the universe and scratch.
  */
+/* Receives one stored CboRoaringBitmap value; returns 0, or negative to make the callback stop. */
+typedef int32_t (*msi_posting_sink)(void *sink, const uint8_t *bytes, size_t n);
 typedef struct msi_index_vtable {
   void *user;
   /* Posting list of `word` as CboRoaringBitmap bytes (valid until the next callback):
@@ -426,6 +428,29 @@ typedef struct msi_index_vtable {
                             uint32_t *n);
   int32_t (*field_id_word_count_docids)(void *user, uint32_t fid, uint32_t count,
                                         const uint8_t **bytes, size_t *n);
+  /* The word-prefix databases (a prefix term whose word is a key of word_prefix_docids uses them instead of
+   * enumerating its derivations: compute_derivations.rs:193-205, query_term/mod.rs:183-203).  All nullable
+   * (= the index has no prefix databases).  A lookup may have to hand over several stored values (tolerant +
+   * exact database, or every key of a prefix_iter), so these push each value into the sink the engine
+   * passes; the return value is the number of values pushed (0 = the key does not exist), negative = error:
+   *   word_prefix_docids(prefix, original)       word_prefix_docids (+ exact_word_prefix_docids if original)
+   *   word_prefix_fid_docids(prefix, fid), word_prefix_position_docids(prefix, position)
+   *   word_prefix_pair_proximity_docids(prox, word1, prefix2): every word_pair_proximity_docids value whose key
+   *       starts with (prox, word1, prefix2…)   (db_cache.rs:451-520)
+   *   word_prefix_fids / word_prefix_positions: as word_fids / word_positions. */
+  int32_t (*word_prefix_docids)(void *user, const uint8_t *prefix, uint32_t len, int32_t original,
+                                msi_posting_sink push, void *sink);
+  int32_t (*word_prefix_fid_docids)(void *user, const uint8_t *prefix, uint32_t len, uint32_t fid,
+                                    msi_posting_sink push, void *sink);
+  int32_t (*word_prefix_position_docids)(void *user, const uint8_t *prefix, uint32_t len, uint32_t position,
+                                         msi_posting_sink push, void *sink);
+  int32_t (*word_prefix_pair_proximity_docids)(void *user, uint32_t proximity, const uint8_t *word1,
+                                               uint32_t len1, const uint8_t *prefix2, uint32_t len2,
+                                               msi_posting_sink push, void *sink);
+  int32_t (*word_prefix_fids)(void *user, const uint8_t *prefix, uint32_t len, uint16_t *out, uint32_t cap,
+                              uint32_t *n);
+  int32_t (*word_prefix_positions)(void *user, const uint8_t *prefix, uint32_t len, uint16_t *out,
+                                   uint32_t cap, uint32_t *n);
 } msi_index_vtable;
 typedef struct msi_query_token {
   const uint8_t *word;
@@ -461,7 +486,7 @@ int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtabl
  * (compute_phrase_docids, resolve_query_graph.rs:187-268).  The control flow (small graphs) runs on the
  * caller's thread; every docid set lives in the msi_bits pool and every set operation — posting decode,
  * union, intersection, difference, cardinality, ordered extraction — is a device kernel.
- * Not handled: synonyms, the word-prefix databases, distinct, pins, ranking score threshold, deadline.
+ * Not handled: synonyms, negative words, distinct, pins, ranking score threshold, deadline.
  * The tokenizer stays with the caller: it hands over the located terms of
  * located_query_terms_from_tokens (parse_query.rs:28-202).
  */

@@ -57,12 +57,24 @@ FID_COUNT_DOCIDS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.c_size_t))
 
 
+POSTING_SINK_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+PREFIX_DOCIDS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_int32, POSTING_SINK_FN, C.c_void_p)
+PREFIX_KEY_DOCIDS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, POSTING_SINK_FN,
+                                  C.c_void_p)
+PREFIX_PAIR_DOCIDS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32,
+                                   C.POINTER(C.c_uint8), C.c_uint32, POSTING_SINK_FN, C.c_void_p)
+
+
 class IndexVtable(C.Structure):
     _fields_ = [("user", C.c_void_p), ("word_docids", WORD_DOCIDS_FN),
                 ("word_pair_proximity_docids", PAIR_DOCIDS_FN), ("is_exact_word", EXACT_WORD_FN),
                 ("word_fid_docids", WORD_KEY_DOCIDS_FN), ("word_position_docids", WORD_KEY_DOCIDS_FN),
                 ("word_fids", WORD_KEYS_FN), ("word_positions", WORD_KEYS_FN),
-                ("field_id_word_count_docids", FID_COUNT_DOCIDS_FN)]
+                ("field_id_word_count_docids", FID_COUNT_DOCIDS_FN),
+                ("word_prefix_docids", PREFIX_DOCIDS_FN), ("word_prefix_fid_docids", PREFIX_KEY_DOCIDS_FN),
+                ("word_prefix_position_docids", PREFIX_KEY_DOCIDS_FN),
+                ("word_prefix_pair_proximity_docids", PREFIX_PAIR_DOCIDS_FN),
+                ("word_prefix_fids", WORD_KEYS_FN), ("word_prefix_positions", WORD_KEYS_FN)]
 
 
 class ScoreDetail(C.Structure):

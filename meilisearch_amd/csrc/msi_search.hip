@@ -246,6 +246,7 @@ struct Term {
   int32_t exact = -1;
   std::vector<uint32_t> prefix_of, one_typo, two_typos;
   int32_t split_words = -1;
+  int32_t use_prefix_db = -1;  // the word itself when it is a key of the word-prefix databases
   bool too_long = false;
 };
 
@@ -382,6 +383,54 @@ struct Ctx {
     take(b, ix->word_position_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), pos, &bytes, &n), bytes, n,
          "word_position_docids");
   }
+  // sink of the word-prefix callbacks: every stored value goes straight into the decode batch
+  struct Sink {
+    Ctx *c;
+    MsiCboBatch *b;
+    bool bad = false;
+  };
+  static int32_t sink_push(void *sink, const uint8_t *bytes, size_t n) {
+    Sink *s = (Sink *)sink;
+    if (n && bytes && s->b && !msi_cbo_batch_append(*s->b, bytes, n)) {
+      s->bad = true;
+      return -1;
+    }
+    return 0;
+  }
+  int32_t finish(Sink &s, int32_t st, const char *what) {
+    if (st < 0 || s.bad) {
+      msi_set_error("msi_keyword_search_ranked: %s callback failed or returned a malformed posting list (%d)", what, st);
+      throw Fail{s.bad ? MSI_E_INVALID : MSI_E_INTERNAL};
+    }
+    return st;
+  }
+  int32_t add_prefix(MsiCboBatch *b, uint32_t w, bool original) {  // -> number of stored values (0: no such key)
+    if (!ix->word_prefix_docids) return 0;
+    const std::string &s = words[w];
+    Sink sk{this, b};
+    Cb cb_;
+    return finish(sk, ix->word_prefix_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), original ? 1 : 0,
+                                             sink_push, &sk), "word_prefix_docids");
+  }
+  void add_prefix_key(MsiCboBatch &b, uint32_t w, int which, uint32_t key) {
+    auto fn = which == 0 ? ix->word_prefix_fid_docids : ix->word_prefix_position_docids;
+    if (!fn) fail(MSI_E_INVALID, "the index vtable has word_prefix_docids but not word_prefix_fid/position_docids");
+    const std::string &s = words[w];
+    Sink sk{this, &b};
+    Cb cb_;
+    finish(sk, fn(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), key, sink_push, &sk), "word_prefix_*_docids");
+  }
+  void add_prefix_pair(MsiCboBatch &b, uint32_t prox, uint32_t w1, uint32_t prefix2) {
+    if (!ix->word_prefix_pair_proximity_docids)
+      fail(MSI_E_INVALID, "the index vtable has word_prefix_docids but not word_prefix_pair_proximity_docids");
+    const std::string &l = words[w1], &r = words[prefix2];
+    Sink sk{this, &b};
+    Cb cb_;
+    finish(sk, ix->word_prefix_pair_proximity_docids(ix->user, prox, (const uint8_t *)l.data(), (uint32_t)l.size(),
+                                                      (const uint8_t *)r.data(), (uint32_t)r.size(), sink_push, &sk),
+           "word_prefix_pair_proximity_docids");
+  }
+
   std::vector<uint16_t> list_of(decltype(msi_index_vtable::word_fids) fn, uint32_t w, const char *what) {
     if (!fn) {
       msi_set_error("msi_keyword_search_ranked: the index vtable has no %s", what);
@@ -411,7 +460,7 @@ struct Ctx {
   }
 
   // partially_initialized_term_from_word, compute_derivations.rs:170-253 (no prefix DB, no synonyms)
-  Term term_from_word(const std::string &w, uint32_t max_typo, bool is_prefix) {
+  Term term_from_word(const std::string &w, uint32_t max_typo, bool is_prefix, bool is_ngram = false) {
     Term t;
     t.original = word(w);
     if (w.size() > MAX_WORD_LENGTH) {
@@ -422,7 +471,9 @@ struct Ctx {
     t.is_prefix = is_prefix;
     MsiCboBatch probe;
     if (add_word(probe, t.original, true)) t.exact = (int32_t)t.original;  // Index::contains_word
-    if (is_prefix) {
+    // word_prefix_docids has the word, or (not for n-grams) exact_word_prefix_docids (:193-205)
+    if (is_prefix && add_prefix(nullptr, t.original, !is_ngram) > 0) t.use_prefix_db = (int32_t)t.original;
+    if (is_prefix && t.use_prefix_db < 0) {
       uint32_t lo = 0, hi = 0;
       msi_dict_prefix_range(dict, (const uint8_t *)w.data(), (uint32_t)w.size(), &lo, &hi);
       for (uint32_t i = lo; i < hi && t.prefix_of.size() < MAX_PREFIX_COUNT; ++i) {
@@ -508,6 +559,12 @@ struct Ctx {
     if (t.phrase >= 0) return ss.zero.has_phrase((uint32_t)t.phrase) ? std::make_pair(1, (uint32_t)t.phrase) : std::make_pair(0, 0u);
     if (t.exact >= 0) return ss.zero.has_word((uint32_t)t.exact) ? std::make_pair(2, (uint32_t)t.exact) : std::make_pair(0, 0u);
     return {0, 0};
+  }
+  // QueryTermSubset::use_prefix_db, query_term/mod.rs:183-203 -> word or -1 (original? = !is_ngram)
+  int32_t use_prefix_db(const Subset &ss) {
+    const Term &t = terms[ss.term];
+    if (t.use_prefix_db < 0 || !ss.zero.has_word((uint32_t)t.use_prefix_db)) return -1;
+    return t.use_prefix_db;
   }
   std::set<std::pair<uint32_t, bool>> all_single_words(const Subset &ss) {  // (word, Word::Original?)
     const Term &t = terms[ss.term];
@@ -613,6 +670,8 @@ struct Ctx {
       relieve();
       MsiCboBatch b;
       for (auto &w : all_single_words(ss)) add_word(b, w.first, w.second);
+      const int32_t pf = use_prefix_db(ss);
+      if (pf >= 0) add_prefix(&b, (uint32_t)pf, !terms[ss.term].is_ngram);
       Set d = dev.decode(b);
       for (uint32_t p : all_phrases(ss)) dev.or_(d, phrase_docids(p));
       it = subset_cache.emplace(key, d).first;
@@ -637,6 +696,8 @@ struct Ctx {
       if (which == 0) add_word_fid(b, w.first, key);
       else add_word_position(b, w.first, key);
     }
+    const int32_t pf = use_prefix_db(ss);
+    if (pf >= 0) add_prefix_key(b, (uint32_t)pf, which, key);
     Set d = dev.decode(b);
     for (uint32_t p : all_phrases(ss)) {
       int32_t first = -1;
@@ -902,6 +963,11 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
         for (int32_t w : c.phrases[p])
           if (w >= 0)
             for (uint16_t f : c.list_of(c.ix->word_fids, (uint32_t)w, "word_fids")) fids.insert(f);
+      {
+        const int32_t pf = c.use_prefix_db(dst.subset);
+        if (pf >= 0)
+          for (uint16_t f : c.list_of(c.ix->word_prefix_fids, (uint32_t)pf, "word_prefix_fids")) fids.insert(f);
+      }
       uint32_t cur_max = 0;
       for (uint16_t f : fids) {
         int32_t weight = -1;
@@ -930,6 +996,11 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
             for (uint16_t q : c.list_of(c.ix->word_positions, (uint32_t)w, "word_positions")) positions.insert(q);
             break;
           }
+      {
+        const int32_t pf = c.use_prefix_db(dst.subset);
+        if (pf >= 0)
+          for (uint16_t q : c.list_of(c.ix->word_prefix_positions, (uint32_t)pf, "word_prefix_positions")) positions.insert(q);
+      }
       std::map<uint32_t, std::vector<uint16_t>> by_cost;
       for (uint16_t pos : positions) {
         const uint32_t dist = pos > dst.pos_lo ? pos - dst.pos_lo : dst.pos_lo - pos;
@@ -979,6 +1050,13 @@ Set proximity_docids(Ctx &c, const Condition &cd, const Set &universe) {
   Set docids = c.dev.zeros();
   // all the word-word pairs resolve against the same universe: one decode launch for all of them
   std::map<std::pair<int32_t, int32_t>, MsiCboBatch> groups;
+  const int32_t pf = c.use_prefix_db(cd.term.subset);
+  if (pf >= 0)  // compute_prefix_edges :97-147: (left word, right prefix) forward, (right prefix as a word, left word) backward
+    for (auto &l : lefts) {
+      MsiCboBatch &b = groups[{l.first, -1}];
+      c.add_prefix_pair(b, forward, l.second, (uint32_t)pf);
+      if (l.first < 0 && backward >= 1) c.add_pair(&b, backward, (uint32_t)pf, l.second);
+    }
   for (auto &l : lefts)
     for (auto &r : rights) {
       MsiCboBatch &b = groups[{l.first, r.first}];
@@ -1481,7 +1559,7 @@ int32_t make_ngram(Ctx &c, const std::vector<std::pair<uint32_t, std::pair<uint3
   const bool is_prefix = c.terms[ts[hi].first].is_prefix;
   const uint32_t b = c.budget(s), n1 = (uint32_t)(hi - lo);
   const uint32_t max_typos = b > n1 ? b - n1 : 0;
-  Term t = c.term_from_word(s, max_typos, is_prefix);
+  Term t = c.term_from_word(s, max_typos, is_prefix, true);
   t.is_ngram = true;
   t.ngram_words = ws;
   t.is_prefix = is_prefix;

@@ -6,7 +6,8 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (EXACT_WORD_FN, FID_COUNT_DOCIDS_FN, PAIR_DOCIDS_FN, WORD_DOCIDS_FN, WORD_KEY_DOCIDS_FN, WORD_KEYS_FN,
+from ._lib import (EXACT_WORD_FN, FID_COUNT_DOCIDS_FN, PAIR_DOCIDS_FN, PREFIX_DOCIDS_FN, PREFIX_KEY_DOCIDS_FN,
+                   PREFIX_PAIR_DOCIDS_FN, WORD_DOCIDS_FN, WORD_KEY_DOCIDS_FN, WORD_KEYS_FN,
                    IndexVtable, KeywordParams, LocatedTerm, QueryToken, RankBucket, ScoreDetail, SearchParams,
                    RankNode, RankQuery, RankTerm, check, lib)
 from .device import np_ptr
@@ -197,6 +198,43 @@ class IndexCallbacks:
             self._fns += (WORD_KEY_DOCIDS_FN(word_fid), WORD_KEY_DOCIDS_FN(word_position),
                           WORD_KEYS_FN(keys(index.word_fids)), WORD_KEYS_FN(keys(index.word_positions)),
                           FID_COUNT_DOCIDS_FN(fid_count))
+        if full and hasattr(index, "word_prefix_docids_values"):
+            def push_all(values, push, sink):
+                n = 0
+                for data in values or ():
+                    buf = C.create_string_buffer(data, len(data))
+                    if push(sink, C.cast(buf, C.POINTER(C.c_uint8)), len(data)) < 0:
+                        return -1
+                    n += 1
+                return n
+
+            def pfx_docids(user, w, n, original, push, sink):
+                try:
+                    return push_all(index.word_prefix_docids_values(bytes(w[:n]).decode("utf-8"), bool(original)), push, sink)
+                except Exception:
+                    return -1
+
+            def pfx_fid(user, w, n, fid, push, sink):
+                try:
+                    return push_all(index.word_prefix_fid_docids_values(bytes(w[:n]).decode("utf-8"), fid), push, sink)
+                except Exception:
+                    return -1
+
+            def pfx_pos(user, w, n, pos, push, sink):
+                try:
+                    return push_all(index.word_prefix_position_docids_values(bytes(w[:n]).decode("utf-8"), pos), push, sink)
+                except Exception:
+                    return -1
+
+            def pfx_pair(user, prox, l, ln, r, rn, push, sink):
+                try:
+                    return push_all(index.word_prefix_pair_values(prox, bytes(l[:ln]).decode("utf-8"),
+                                                                  bytes(r[:rn]).decode("utf-8")), push, sink)
+                except Exception:
+                    return -1
+            self._fns += (PREFIX_DOCIDS_FN(pfx_docids), PREFIX_KEY_DOCIDS_FN(pfx_fid), PREFIX_KEY_DOCIDS_FN(pfx_pos),
+                          PREFIX_PAIR_DOCIDS_FN(pfx_pair), WORD_KEYS_FN(keys(index.get_word_prefix_fids)),
+                          WORD_KEYS_FN(keys(index.get_word_prefix_positions)))
         self.vtable = IndexVtable(None, *self._fns)
 
 

@@ -72,7 +72,7 @@ class QueryTerm:
     def __init__(self, original, max_lev, is_prefix, ngram_words=None, phrase=None):
         self.original, self.max_lev, self.is_prefix = original, max_lev, is_prefix
         self.ngram_words, self.phrase = ngram_words, phrase
-        self.exact, self.prefix_of, self.synonyms = None, [], []
+        self.exact, self.prefix_of, self.synonyms, self.use_prefix_db = None, [], [], None
         self.one_typo = self.two_typos = self.split_words = None
         self.computed = False
 
@@ -94,7 +94,9 @@ class Ctx:
         t = QueryTerm(word, max_typo, is_prefix)
         if self.index.contains_word(word):
             t.exact = word
-        if is_prefix:
+        if is_prefix and self.index.has_prefix(word, not is_ngram):
+            t.use_prefix_db = word
+        if is_prefix and t.use_prefix_db is None:
             for w in self.index.prefix_words(word):
                 if w != word:
                     t.prefix_of.append(w)
@@ -148,6 +150,13 @@ class Ctx:
         if t.exact is not None:
             return ("word", t.exact) if nt_contains_word(ss.zero, t.exact) else None
         return None
+
+    def use_prefix_db(self, ss):
+        """QueryTermSubset::use_prefix_db, query_term/mod.rs:183-203 -> (prefix, original?) | None."""
+        t = self.terms[ss.term]
+        if t.use_prefix_db is None or not nt_contains_word(ss.zero, t.use_prefix_db):
+            return None
+        return (t.use_prefix_db, t.ngram_words is None)
 
     def all_single_words(self, ss):
         """all_single_words_except_prefix_db -> {(word, original?)}."""
@@ -273,9 +282,12 @@ class Ctx:
                 d |= s
         for p in self.all_phrases(ss):
             d |= self.phrase_docids(p)
+        pf = self.use_prefix_db(ss)
+        if pf is not None:
+            d |= self.index.get_word_prefix_docids(pf[0], pf[1]) or set()
         return d if universe is None else d & universe
 
-    def subset_docids_within(self, universe, ss, getter, key):
+    def subset_docids_within(self, universe, ss, getter, key, prefix_getter=None):
         """…_within_field_id / …_within_position, :61-130 (no final intersection with the universe beyond
         the per-lookup one, as in the reference)."""
         d = set()
@@ -290,6 +302,11 @@ class Ctx:
                 if s is not None:
                     s = s if universe is None else s & universe
                     d |= self.phrase_docids(p) & s
+        pf = self.use_prefix_db(ss)
+        if pf is not None and prefix_getter is not None:
+            s = prefix_getter(pf[0], key)
+            if s is not None:
+                d |= s if universe is None else s & universe
         return d
 
 
@@ -543,6 +560,9 @@ def build_edges(ctx, kind, src, dst):
             for w in p:
                 if w is not None:
                     fids.update(ctx.index.get_word_fids(w))
+        pf = ctx.use_prefix_db(dst.subset)
+        if pf is not None:
+            fids.update(ctx.index.get_word_prefix_fids(pf[0]))
         out, cur_max = [], 0
         for fid in sorted(fids):
             w = ctx.index.weights.get(fid)
@@ -562,6 +582,9 @@ def build_edges(ctx, kind, src, dst):
             first = next((w for w in p if w is not None), None)
             if first is not None:
                 positions.update(ctx.index.get_word_positions(first))
+        pf = ctx.use_prefix_db(dst.subset)
+        if pf is not None:
+            positions.update(ctx.index.get_word_prefix_positions(pf[0]))
         by_cost = {}
         for pos in positions:
             dist = abs(pos - dst.positions[0])
@@ -583,12 +606,14 @@ def resolve_condition(ctx, cond, universe):
         return ctx.subset_docids(universe, cond[1].subset), None, cond[1]
     if k == "fid":
         d = set() if cond[2] is None else ctx.subset_docids_within(universe, cond[1].subset,
-                                                                  ctx.index.get_word_fid_docids, cond[2])
+                                                                  ctx.index.get_word_fid_docids, cond[2],
+                                                                  ctx.index.get_word_prefix_fid_docids)
         return d, None, cond[1]
     if k == "position":
         d = set()
         for pos in cond[2]:
-            d |= ctx.subset_docids_within(universe, cond[1].subset, ctx.index.get_word_position_docids, pos)
+            d |= ctx.subset_docids_within(universe, cond[1].subset, ctx.index.get_word_position_docids, pos,
+                                          ctx.index.get_word_prefix_position_docids)
         return d, None, cond[1]
     if k == "exact":
         dst = cond[1]
@@ -617,6 +642,19 @@ def proximity_docids(ctx, cond, universe):
     for p in ctx.all_phrases(left.subset):
         if p[-1] is not None:
             lefts.add((p, p[-1]))
+    pf = ctx.use_prefix_db(right.subset)
+    if pf is not None:                       # compute_prefix_edges, :97-147
+        for lp, lw in lefts:
+            u = set(universe)
+            if lp is not None:
+                u &= ctx.phrase_docids(lp)
+                if not u:
+                    continue
+            docids |= ctx.index.get_word_prefix_pair(forward, lw, pf[0]) & u
+            if lp is None:
+                m = ctx.index.get_pair(backward, pf[0], lw)
+                if m:
+                    docids |= m & u
     rights = {(w, None) for w, _ in ctx.all_single_words(right.subset)}
     for p in ctx.all_phrases(right.subset):
         if p[0] is not None:

@@ -17,9 +17,6 @@ FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ranking_
 # Cases that need a feature the toy index does not model (reason -> skipped, not failed).
 UNSUPPORTED = {
     "xyz wilting": "synonyms",
-    "best s": "word-prefix databases (prefix `s` is in the prefix DB)",
-    "best win": "word-prefix databases",
-    "best wi": "word-prefix databases",
 }
 
 

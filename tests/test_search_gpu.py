@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ranking_snapshots.json")))
-UNSUPPORTED = {"xyz wilting": "synonyms", "best s": "prefix DB", "best win": "prefix DB", "best wi": "prefix DB"}
+UNSUPPORTED = {"xyz wilting": "synonyms"}
 
 
 class Harness:
@@ -108,20 +108,22 @@ RULESETS = [
     ["words", "proximity"], ["words", "typo", "proximity"], ["attribute"], ["exactness"], ["words", "exactness", "typo"],
     ["typo", "words"], ["proximity", "typo"],
 ]
-QUERIES = ["the quick brown fox", "sunflower", "sun flower holiday", "quick fox jumps over the lazy dog",
+QUERIES = ["the qui", "brown f", "s", "sun fl", "lazy d", "the quick brown fox", "sunflower", "sun flower holiday", "quick fox jumps over the lazy dog",
            "beautiful summer", "delicious sweet dessert", "\"quick brown\" fox", "the \"lazy dog\" jumps",
            "quik brwn fox", "network interconection", "winter holi", "fox", "dog the"]
 
 
-@pytest.mark.parametrize("seed", [1, 2])
-def test_matches_oracle_on_random_corpora(seed):
+@pytest.mark.parametrize("seed,prefix_threshold", [(1, 100), (2, 100), (3, 3)])
+def test_matches_oracle_on_random_corpora(seed, prefix_threshold):
+    """prefix_threshold = 3 gives the toy corpus word-prefix databases (use_prefix_db terms)."""
     from oracle import oracle as O
     from oracle import ranking_oracle as RO
     from tests.toy_milli import ToyMilli
     docs = random_corpus(seed, 300)
     checked = 0
     for criteria in RULESETS:
-        index = ToyMilli(docs, searchable=["title", "body"], criteria=criteria)
+        index = ToyMilli(docs, searchable=["title", "body"], criteria=criteria, prefix_threshold=prefix_threshold)
+        assert (len(index.prefixes) > 0) == (prefix_threshold == 3)
         dic = O.Dictionary(index.words)
 
         def lookup(word, max_typos, is_prefix):

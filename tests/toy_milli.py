@@ -18,6 +18,7 @@ from tests.toy_index import cbo_bytes  # noqa: F401  (re-exported for the device
 HARD_RE = re.compile(r"[.,]\s|[!;?]")       # charabia CONTEXT_SEPARATORS (Latin subset): ". " ", " "!" ";" "?"
 WORD_RE = re.compile(r"[0-9a-zà-öø-ÿ]+")
 MAX_COUNTED_WORDS = 30
+PREFIX_MAX_LEN = 4
 MAX_POSITION_PER_ATTRIBUTE = 1 << 16      # lib.rs (u16 relative positions)
 INDEX_MAX_DISTANCE = 8      # tokenize_document.rs:13
 MAX_DISTANCE = 4            # proximity.rs:7
@@ -41,7 +42,7 @@ def tokenize_with_positions(text, start=0):
 
 class ToyMilli:
     def __init__(self, docs, searchable=None, exact_attributes=(), exact_words=(), criteria=None,
-                 min_one=5, min_two=9, authorize_typos=True, primary_key="id"):
+                 min_one=5, min_two=9, authorize_typos=True, primary_key="id", prefix_threshold=100):
         self.min_one, self.min_two, self.authorize_typos = min_one, min_two, authorize_typos
         self.exact_words = set(exact_words)
         self.criteria = criteria or ["words", "typo", "proximity", "attributeRank", "sort", "wordPosition", "exactness"]
@@ -100,6 +101,35 @@ class ToyMilli:
                 self.pair.setdefault((prox, w1, w2), set()).add(docid)
         self.words = sorted(self.word_docids, key=lambda w: w.encode())      # words fst
         self.all_words = sorted(set(self.word_docids) | set(self.exact_word_docids), key=lambda w: w.encode())
+        # word-prefix databases: prefixes of 1..4 bytes (at a char boundary) shared by >= 100 words of the words
+        # fst (word_fst_builder.rs:100-140, index.rs:1884-1887), each with the union of its words' postings
+        # (update/new/words_prefix_docids.rs)
+        counts = {}
+        for w in self.words:
+            b = w.encode()
+            for n in range(1, PREFIX_MAX_LEN + 1):
+                try:
+                    pfx = b[:n].decode()
+                except UnicodeDecodeError:
+                    continue
+                if len(b) >= n:
+                    counts[pfx] = counts.get(pfx, 0) + 1
+        self.prefixes = {p_ for p_, c in counts.items() if c >= prefix_threshold}
+        self.word_prefix_docids, self.exact_word_prefix_docids = {}, {}
+        self.word_prefix_fid_docids, self.word_prefix_position_docids = {}, {}
+        for pfx in self.prefixes:
+            for w, s_ in self.word_docids.items():
+                if w.startswith(pfx):
+                    self.word_prefix_docids.setdefault(pfx, set()).update(s_)
+            for w, s_ in self.exact_word_docids.items():
+                if w.startswith(pfx):
+                    self.exact_word_prefix_docids.setdefault(pfx, set()).update(s_)
+            for (w, fid), s_ in self.word_fid_docids.items():
+                if w.startswith(pfx):
+                    self.word_prefix_fid_docids.setdefault((pfx, fid), set()).update(s_)
+            for (w, pos), s_ in self.word_position_docids.items():
+                if w.startswith(pfx):
+                    self.word_prefix_position_docids.setdefault((pfx, pos), set()).update(s_)
         self._fids_of, self._pos_of = {}, {}
         for (w, fid) in self.word_fid_docids:
             self._fids_of.setdefault(w, []).append(fid)
@@ -141,6 +171,40 @@ class ToyMilli:
     def get_fid_word_count_docids(self, fid, count):
         return self.fid_word_count.get((fid, count))
 
+    # -- word-prefix databases ----------------------------------------------------------------------
+    def get_word_prefix_docids(self, pfx, original):
+        """SearchContext::word_prefix_docids (db_cache.rs:272-294)."""
+        t = self.word_prefix_docids.get(pfx)
+        if not original:
+            return t
+        e = self.exact_word_prefix_docids.get(pfx)
+        if t is None and e is None:
+            return None
+        return (t or set()) | (e or set())
+
+    def has_prefix(self, pfx, include_exact):
+        return pfx in self.word_prefix_docids or (include_exact and pfx in self.exact_word_prefix_docids)
+
+    def get_word_prefix_fid_docids(self, pfx, fid):
+        return self.word_prefix_fid_docids.get((pfx, fid))
+
+    def get_word_prefix_position_docids(self, pfx, pos):
+        return self.word_prefix_position_docids.get((pfx, pos))
+
+    def get_word_prefix_fids(self, pfx):
+        return sorted({f for (p_, f) in self.word_prefix_fid_docids if p_ == pfx})
+
+    def get_word_prefix_positions(self, pfx):
+        return sorted({q for (p_, q) in self.word_prefix_position_docids if p_ == pfx})
+
+    def get_word_prefix_pair(self, prox, w1, pfx2):
+        """get_db_word_prefix_pair_proximity_docids (db_cache.rs:451-520): prefix_iter over word_pair_proximity."""
+        out = set()
+        for (p_, a, b), s_ in self.pair.items():
+            if p_ == prox and a == w1 and b.startswith(pfx2):
+                out |= s_
+        return out
+
     def prefix_words(self, prefix):
         """word_docids and exact_word_docids keys with the prefix, merged in key order
         (find_zero_typo_prefix_derivations, compute_derivations.rs:40-73)."""
@@ -181,6 +245,23 @@ class ToyMilli:
     def fid_word_count_docids_bytes(self, fid, count):
         s = self.fid_word_count.get((fid, count))
         return cbo_bytes(s) if s else None
+
+
+    def word_prefix_docids_values(self, pfx, original):
+        vals = [self.word_prefix_docids.get(pfx)] + ([self.exact_word_prefix_docids.get(pfx)] if original else [])
+        return [cbo_bytes(v) for v in vals if v]
+
+    def word_prefix_fid_docids_values(self, pfx, fid):
+        v = self.word_prefix_fid_docids.get((pfx, fid))
+        return [cbo_bytes(v)] if v else []
+
+    def word_prefix_position_docids_values(self, pfx, pos):
+        v = self.word_prefix_position_docids.get((pfx, pos))
+        return [cbo_bytes(v)] if v else []
+
+    def word_prefix_pair_values(self, prox, w1, pfx2):
+        return [cbo_bytes(s_) for (p_, a, b), s_ in sorted(self.pair.items())
+                if p_ == prox and a == w1 and b.startswith(pfx2) and s_]
 
 
 TOKEN_RE = re.compile(r"[0-9a-zà-öø-ÿ]+|[^0-9a-zà-öø-ÿ]+")
