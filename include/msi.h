@@ -399,6 +399,8 @@ int32_t msi_rank_words_typo(msi_bits *pool, const msi_rank_term *terms,
  */
 /* Receives one stored CboRoaringBitmap value; returns 0, or negative to make the callback stop. */
 typedef int32_t (*msi_posting_sink)(void *sink, const uint8_t *bytes, size_t n);
+struct msi_query_token;
+typedef int32_t (*msi_synonym_sink)(void *sink, const struct msi_query_token *words, uint32_t n_words);
 typedef struct msi_index_vtable {
   void *user;
   /* Posting list of `word` as CboRoaringBitmap bytes (valid until the next callback):
@@ -451,6 +453,10 @@ typedef struct msi_index_vtable {
                               uint32_t *n);
   int32_t (*word_prefix_positions)(void *user, const uint8_t *prefix, uint32_t len, uint16_t *out,
                                    uint32_t cap, uint32_t *n);
+  /* index.synonyms.get(words) (compute_derivations.rs:217-236 for one word, parse_query.rs:277-285 for the
+   * words of an n-gram): pushes every synonym as its tokenised words, in stored order.  Nullable. */
+  int32_t (*synonyms)(void *user, const struct msi_query_token *words, uint32_t n_words,
+                      msi_synonym_sink push, void *sink);
 } msi_index_vtable;
 typedef struct msi_query_token {
   const uint8_t *word;
@@ -486,7 +492,7 @@ int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtabl
  * (compute_phrase_docids, resolve_query_graph.rs:187-268).  The control flow (small graphs) runs on the
  * caller's thread; every docid set lives in the msi_bits pool and every set operation — posting decode,
  * union, intersection, difference, cardinality, ordered extraction — is a device kernel.
- * Not handled: synonyms, negative words, distinct, pins, ranking score threshold, deadline.
+ * Not handled: negative words, distinct, pins, ranking score threshold, deadline.
  * The tokenizer stays with the caller: it hands over the located terms of
  * located_query_terms_from_tokens (parse_query.rs:28-202).
  */

@@ -43,6 +43,7 @@ namespace {
 
 constexpr uint32_t MAX_PREFIX_COUNT = 1000, MAX_ONE_TYPO_COUNT = 150, MAX_TWO_TYPOS_COUNT = 50;  // limits.rs
 constexpr uint32_t MAX_WORD_LENGTH = 250;                                                        // lib.rs:146
+constexpr uint32_t MAX_SYNONYM_PHRASE_COUNT = 50, MAX_SYNONYM_WORD_COUNT = 100;                    // limits.rs
 constexpr uint32_t MAX_DISTANCE = 4;                                                             // proximity.rs:7
 
 struct Fail {
@@ -246,6 +247,7 @@ struct Term {
   int32_t exact = -1;
   std::vector<uint32_t> prefix_of, one_typo, two_typos;
   int32_t split_words = -1;
+  std::vector<uint32_t> synonyms;  // phrase ids
   int32_t use_prefix_db = -1;  // the word itself when it is a key of the word-prefix databases
   bool too_long = false;
 };
@@ -431,6 +433,30 @@ struct Ctx {
            "word_prefix_pair_proximity_docids");
   }
 
+  struct SynSink {
+    Ctx *c;
+    std::vector<Phrase> out;
+  };
+  static int32_t syn_push(void *sink, const msi_query_token *ws, uint32_t n) {
+    SynSink *s = (SynSink *)sink;
+    Phrase p;
+    for (uint32_t i = 0; i < n; ++i) p.push_back((int32_t)s->c->word(std::string((const char *)ws[i].word, ws[i].len)));
+    s->out.push_back(std::move(p));
+    return 0;
+  }
+  std::vector<Phrase> synonyms_of(const std::vector<uint32_t> &ws) {
+    if (!ix->synonyms) return {};
+    std::vector<msi_query_token> toks(ws.size());
+    std::vector<std::string> keep;
+    for (uint32_t w : ws) keep.push_back(words[w]);
+    for (size_t i = 0; i < ws.size(); ++i) toks[i] = msi_query_token{(const uint8_t *)keep[i].data(), (uint32_t)keep[i].size(), 0};
+    SynSink sk{this, {}};
+    Cb cb_;
+    if (ix->synonyms(ix->user, toks.data(), (uint32_t)toks.size(), syn_push, &sk) < 0)
+      fail(MSI_E_INTERNAL, "synonyms callback failed");
+    return sk.out;
+  }
+
   std::vector<uint16_t> list_of(decltype(msi_index_vtable::word_fids) fn, uint32_t w, const char *what) {
     if (!fn) {
       msi_set_error("msi_keyword_search_ranked: the index vtable has no %s", what);
@@ -471,6 +497,15 @@ struct Ctx {
     t.is_prefix = is_prefix;
     MsiCboBatch probe;
     if (add_word(probe, t.original, true)) t.exact = (int32_t)t.original;  // Index::contains_word
+    {  // synonyms of the word: at most 50 phrases and 100 words in total (:217-236)
+      uint32_t n_words = 0, n_phr = 0;
+      for (Phrase &syn : synonyms_of({t.original})) {
+        if (n_phr++ >= MAX_SYNONYM_PHRASE_COUNT) break;
+        if (n_words + syn.size() > MAX_SYNONYM_WORD_COUNT) continue;
+        n_words += (uint32_t)syn.size();
+        t.synonyms.push_back(phrase(syn));
+      }
+    }
     // word_prefix_docids has the word, or (not for n-grams) exact_word_prefix_docids (:193-205)
     if (is_prefix && add_prefix(nullptr, t.original, !is_ngram) > 0) t.use_prefix_db = (int32_t)t.original;
     if (is_prefix && t.use_prefix_db < 0) {
@@ -587,6 +622,7 @@ struct Ctx {
     const Term &t = terms[ss.term];
     std::set<uint32_t> out;
     if (t.phrase >= 0) out.insert((uint32_t)t.phrase);  // regardless of the zero-typo subset, as the reference
+    for (uint32_t p : t.synonyms) out.insert(p);
     if (ss.one.kind != 0 && t.split_words >= 0 && ss.one.has_phrase((uint32_t)t.split_words))
       out.insert((uint32_t)t.split_words);
     return out;
@@ -1560,6 +1596,7 @@ int32_t make_ngram(Ctx &c, const std::vector<std::pair<uint32_t, std::pair<uint3
   const uint32_t b = c.budget(s), n1 = (uint32_t)(hi - lo);
   const uint32_t max_typos = b > n1 ? b - n1 : 0;
   Term t = c.term_from_word(s, max_typos, is_prefix, true);
+  for (Phrase &syn : c.synonyms_of(ws)) t.synonyms.push_back(c.phrase(syn));  // parse_query.rs:277-285
   t.is_ngram = true;
   t.ngram_words = ws;
   t.is_prefix = is_prefix;

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import (EXACT_WORD_FN, FID_COUNT_DOCIDS_FN, PAIR_DOCIDS_FN, PREFIX_DOCIDS_FN, PREFIX_KEY_DOCIDS_FN,
-                   PREFIX_PAIR_DOCIDS_FN, WORD_DOCIDS_FN, WORD_KEY_DOCIDS_FN, WORD_KEYS_FN,
+                   PREFIX_PAIR_DOCIDS_FN, SYNONYMS_FN, WORD_DOCIDS_FN, WORD_KEY_DOCIDS_FN, WORD_KEYS_FN,
                    IndexVtable, KeywordParams, LocatedTerm, QueryToken, RankBucket, ScoreDetail, SearchParams,
                    RankNode, RankQuery, RankTerm, check, lib)
 from .device import np_ptr
@@ -232,9 +232,27 @@ class IndexCallbacks:
                                                                   bytes(r[:rn]).decode("utf-8")), push, sink)
                 except Exception:
                     return -1
+            def synonyms(user, words, n, push, sink):
+                try:
+                    toks = C.cast(words, C.POINTER(QueryToken))
+                    key = [C.string_at(toks[i].word, toks[i].len).decode("utf-8") for i in range(n)]
+                    for syn in index.get_synonyms(key):
+                        arr = (QueryToken * max(len(syn), 1))()
+                        keep = []
+                        for i, w in enumerate(syn):
+                            b = w.encode("utf-8")
+                            buf = C.create_string_buffer(b, len(b))
+                            keep.append(buf)
+                            arr[i].word = C.cast(buf, C.c_void_p)
+                            arr[i].len = len(b)
+                        if push(sink, C.cast(arr, C.c_void_p), len(syn)) < 0:
+                            return -1
+                    return 0
+                except Exception:
+                    return -1
             self._fns += (PREFIX_DOCIDS_FN(pfx_docids), PREFIX_KEY_DOCIDS_FN(pfx_fid), PREFIX_KEY_DOCIDS_FN(pfx_pos),
                           PREFIX_PAIR_DOCIDS_FN(pfx_pair), WORD_KEYS_FN(keys(index.get_word_prefix_fids)),
-                          WORD_KEYS_FN(keys(index.get_word_prefix_positions)))
+                          WORD_KEYS_FN(keys(index.get_word_prefix_positions)), SYNONYMS_FN(synonyms))
         self.vtable = IndexVtable(None, *self._fns)
 
 

@@ -26,6 +26,7 @@ from collections import namedtuple
 
 ALL, NONE = "all", "none"
 MAX_ONE, MAX_TWO, MAX_PREFIX = 150, 50, 1000      # limits.rs
+MAX_SYNONYM_PHRASE_COUNT, MAX_SYNONYM_WORD_COUNT = 50, 100
 MAX_WORD_LENGTH = 250
 MAX_DISTANCE = 4                                   # proximity.rs:7
 
@@ -86,7 +87,7 @@ class Ctx:
 
     # -- terms -------------------------------------------------------------------------------------
     def term_from_word(self, word, max_typo, is_prefix, is_ngram):
-        """partially_initialized_term_from_word, compute_derivations.rs:170-253 (no prefix DB, no synonyms)."""
+        """partially_initialized_term_from_word, compute_derivations.rs:170-253."""
         if len(word.encode()) > MAX_WORD_LENGTH:
             t = QueryTerm(word, 0, False)
             t.one_typo, t.two_typos, t.computed = [], [], True
@@ -94,6 +95,12 @@ class Ctx:
         t = QueryTerm(word, max_typo, is_prefix)
         if self.index.contains_word(word):
             t.exact = word
+        n_syn_words = 0                          # compute_derivations.rs:217-236
+        for syn in self.index.get_synonyms((word,))[:MAX_SYNONYM_PHRASE_COUNT]:
+            if n_syn_words + len(syn) > MAX_SYNONYM_WORD_COUNT:
+                continue
+            n_syn_words += len(syn)
+            t.synonyms.append(tuple(syn))
         if is_prefix and self.index.has_prefix(word, not is_ngram):
             t.use_prefix_db = word
         if is_prefix and t.use_prefix_db is None:
@@ -487,6 +494,8 @@ def make_ngram(ctx, terms):
     is_prefix = ctx.terms[terms[-1][0]].is_prefix
     max_typos = max(0, ctx.index.budget(s) - (len(terms) - 1))
     t = ctx.term_from_word(s, max_typos, is_prefix, True)
+    for syn in ctx.index.get_synonyms(tuple(words)):        # parse_query.rs:277-285
+        t.synonyms.append(tuple(syn))
     t.ngram_words, t.is_prefix, t.max_lev = words, is_prefix, max_typos
     return ctx.push(t), (terms[0][1][0], terms[-1][1][1])
 

@@ -107,7 +107,12 @@ def parse_settings(body, cfg):
     m = re.search(r"set_min_word_len_two_typos\((\d+)\)", body)
     if m:
         cfg["min_two"] = int(m.group(1))
-    for feat in ("set_synonyms", "set_stop_words", "set_dictionary", "set_separator_tokens", "set_proximity_precision",
+    syn = {}
+    for m in re.finditer(r'\w+\.insert\("([^"]+)"\.to_owned\(\),\s*vec!\[(.*?)\]\)', body, re.S):
+        syn[m.group(1)] = re.findall(r'"([^"]+)"', m.group(2))
+    if syn and "set_synonyms" in body:
+        cfg["synonyms"] = syn
+    for feat in ("set_stop_words", "set_dictionary", "set_separator_tokens", "set_proximity_precision",
                  "set_searchable_fields(vec![])", "set_distinct_field", "set_sortable"):
         if feat in body:
             cfg.setdefault("unsupported", []).append(feat)

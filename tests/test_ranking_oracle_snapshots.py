@@ -1,6 +1,6 @@
 """Pins oracle/ranking_oracle.py (the CPU restatement of milli's keyword ranking) against the reference's
 own golden vectors: every search of search/new/tests/{proximity,attribute_fid,word_position,exactness,
-words_tms,typo_proximity,proximity_typo,ngram_split_words,typo}.rs that the toy index can express
+words_tms,typo_proximity,proximity_typo,ngram_split_words,typo}.rs 
 (tests/golden/ranking_snapshots.json, extracted by tests/golden/make_ranking_fixtures.py): expected docid
 order and, where the reference snapshots them, the score details of every hit."""
 import json
@@ -15,9 +15,7 @@ from tests.toy_milli import ToyMilli
 FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ranking_snapshots.json")))
 
 # Cases that need a feature the toy index does not model (reason -> skipped, not failed).
-UNSUPPORTED = {
-    "xyz wilting": "synonyms",
-}
+UNSUPPORTED = {}
 
 
 def make_ctx(index):
@@ -33,7 +31,7 @@ def build_index(cfg):
     return ToyMilli(cfg["docs"], searchable=cfg.get("searchable"), exact_attributes=cfg.get("exact_attributes", ()),
                     exact_words=cfg.get("exact_words", ()), criteria=cfg.get("criteria"),
                     min_one=cfg.get("min_one", 5), min_two=cfg.get("min_two", 9),
-                    authorize_typos=cfg.get("authorize_typos", True))
+                    authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"))
 
 
 def debug_score(s):

@@ -1,6 +1,6 @@
 """msi_keyword_search_ranked (the product: host rule graphs + device docid sets) against
   1. the reference's own snapshots (tests/golden/ranking_snapshots.json: docid order and the score details
-     of every hit for the searches of search/new/tests/*.rs the toy index can express), and
+     of every hit for the searches of search/new/tests/*.rs ), and
   2. the CPU oracle (oracle/ranking_oracle.py, itself pinned to the same snapshots) on random corpora,
      all rule lists, both terms-matching strategies."""
 import json
@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ranking_snapshots.json")))
-UNSUPPORTED = {"xyz wilting": "synonyms"}
+UNSUPPORTED = {}
 
 
 class Harness:
@@ -54,7 +54,7 @@ def build_index(cfg):
     return ToyMilli(cfg["docs"], searchable=cfg.get("searchable"), exact_attributes=cfg.get("exact_attributes", ()),
                     exact_words=cfg.get("exact_words", ()), criteria=cfg.get("criteria"),
                     min_one=cfg.get("min_one", 5), min_two=cfg.get("min_two", 9),
-                    authorize_typos=cfg.get("authorize_typos", True))
+                    authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"))
 
 
 _H = {}

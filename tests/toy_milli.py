@@ -42,9 +42,12 @@ def tokenize_with_positions(text, start=0):
 
 class ToyMilli:
     def __init__(self, docs, searchable=None, exact_attributes=(), exact_words=(), criteria=None,
-                 min_one=5, min_two=9, authorize_typos=True, primary_key="id", prefix_threshold=100):
+                 min_one=5, min_two=9, authorize_typos=True, primary_key="id", prefix_threshold=100, synonyms=None):
         self.min_one, self.min_two, self.authorize_typos = min_one, min_two, authorize_typos
         self.exact_words = set(exact_words)
+        # index.synonyms: normalised key words -> synonym phrases as word lists (settings: "a b" -> ["c d", ...])
+        self.synonyms = {tuple(WORD_RE.findall(k.lower())): [WORD_RE.findall(v.lower()) for v in vs]
+                         for k, vs in (synonyms or {}).items()}
         self.criteria = criteria or ["words", "typo", "proximity", "attributeRank", "sort", "wordPosition", "exactness"]
         # internal docids in order of first appearance of the external id; a later document with
         # the same id replaces the earlier one
@@ -246,6 +249,9 @@ class ToyMilli:
         s = self.fid_word_count.get((fid, count))
         return cbo_bytes(s) if s else None
 
+
+    def get_synonyms(self, words):
+        return self.synonyms.get(tuple(words), [])
 
     def word_prefix_docids_values(self, pfx, original):
         vals = [self.word_prefix_docids.get(pfx)] + ([self.exact_word_prefix_docids.get(pfx)] if original else [])
