@@ -539,6 +539,11 @@ int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, const msi_inde
                                   size_t universe_len, uint32_t *out_docids, msi_score_detail *out_scores,
                                   uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates);
 
+/* ScoreDetails::global_score over the details of one hit (score_details.rs:123-154, ranks per variant
+ * :103-121: Typo -> (max_typo_count + 1 - typo_count, max_typo_count + 1), ExactWords -> (matching + 1, max + 1),
+ * ExactAttribute -> (a, 3)): the keyword score value msi_hybrid_merge weighs against the semantic one. */
+double msi_score_details_global_score(const msi_score_detail *details, uint32_t n);
+
 /* Diagnostics: counters of the last msi_keyword_search_ranked on the calling thread —
  * [kernel launches, stream syncs, decode batches, index callbacks, posting bytes decoded, matching paths,
  *  buckets, callback microseconds, device-wait microseconds, total microseconds]. */

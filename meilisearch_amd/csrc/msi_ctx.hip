@@ -168,6 +168,33 @@ double msi_rank_global_score(const uint32_t *ranks, const uint32_t *max_ranks, u
   return (double)rank / (double)max_rank;
 }
 
+// ScoreDetails::global_score of the details msi_keyword_search_ranked returns for one hit.
+double msi_score_details_global_score(const msi_score_detail *details, uint32_t n) {
+  uint32_t rank = 1, max_rank = 1;
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t r, m;
+    switch (details[i].kind) {
+      case MSI_SCORE_TYPO:
+        m = details[i].b + 1;
+        r = m > details[i].a ? m - details[i].a : 0;
+        break;
+      case MSI_SCORE_EXACT_WORDS:
+        r = details[i].a + 1;
+        m = details[i].b + 1;
+        break;
+      default:
+        r = details[i].a;
+        m = details[i].b;
+        break;
+    }
+    rank = rank ? rank - 1 : 0;  // Rank::merge, score_details.rs:536-546
+    rank *= m;
+    max_rank *= m;
+    rank += r;
+  }
+  return (double)rank / (double)max_rank;
+}
+
 // compare_scores over ScoreValue::Score sequences — search/hybrid.rs:32-80.
 int32_t msi_compare_scores(const double *left, uint32_t n_left, float left_ratio,
                            const double *right, uint32_t n_right, float right_ratio) {

@@ -348,3 +348,11 @@ def search_last_stats():
     names = ["launches", "syncs", "decode_batches", "callbacks", "posting_bytes", "paths", "buckets", "callback_us",
              "device_wait_us", "total_us"]
     return dict(zip(names, [int(x) for x in v]))
+
+
+def score_details_global_score(details):
+    """ScoreDetails::global_score of one hit's [(kind name, a, b)]."""
+    arr = (ScoreDetail * max(len(details), 1))()
+    for i, (k, a, b) in enumerate(details):
+        arr[i].kind, arr[i].a, arr[i].b = SCORE_KINDS.index(k), a, b
+    return float(lib().msi_score_details_global_score(C.cast(arr, C.c_void_p), len(details)))

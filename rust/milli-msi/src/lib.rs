@@ -190,7 +190,9 @@ pub fn keyword_search(dict: &GpuDictionary, sets: &mut GpuDocidSets, source: &mu
     let vt = sys::msi_index_vtable { user: &mut src_ref as *mut _ as *mut _, word_docids: Some(tramp_word),
         word_pair_proximity_docids: Some(tramp_pair), is_exact_word: Some(tramp_exact),
         word_fid_docids: None, word_position_docids: None, word_fids: None, word_positions: None,
-        field_id_word_count_docids: None };
+        field_id_word_count_docids: None, word_prefix_docids: None, word_prefix_fid_docids: None,
+        word_prefix_position_docids: None, word_prefix_pair_proximity_docids: None, word_prefix_fids: None,
+        word_prefix_positions: None, synonyms: None };
     let (mut ids, mut mw, mut tc, mut mt) = (vec![0u32; length], vec![0u32; length], vec![0u32; length], vec![0u32; length]);
     let (mut n, mut cand) = (0u32, 0u64);
     let (up, ul) = universe.map_or((ptr::null(), 0), |u| (u.as_ptr(), u.len()));

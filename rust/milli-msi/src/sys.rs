@@ -48,6 +48,12 @@ pub type pair_docids_fn = unsafe extern "C" fn(*mut c_void, u32, *const u8, u32,
 pub type exact_word_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32) -> i32;
 pub type word_key_docids_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, u32, *mut *const u8, *mut usize) -> i32;
 pub type word_keys_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, *mut u16, u32, *mut u32) -> i32;
+pub type msi_posting_sink = unsafe extern "C" fn(*mut c_void, *const u8, usize) -> i32;
+pub type msi_synonym_sink = unsafe extern "C" fn(*mut c_void, *const msi_query_token, u32) -> i32;
+pub type prefix_docids_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, i32, msi_posting_sink, *mut c_void) -> i32;
+pub type prefix_key_docids_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, u32, msi_posting_sink, *mut c_void) -> i32;
+pub type prefix_pair_docids_fn = unsafe extern "C" fn(*mut c_void, u32, *const u8, u32, *const u8, u32, msi_posting_sink, *mut c_void) -> i32;
+pub type synonyms_fn = unsafe extern "C" fn(*mut c_void, *const msi_query_token, u32, msi_synonym_sink, *mut c_void) -> i32;
 pub type fid_count_docids_fn = unsafe extern "C" fn(*mut c_void, u32, u32, *mut *const u8, *mut usize) -> i32;
 #[repr(C)]
 pub struct msi_index_vtable {
@@ -60,6 +66,13 @@ pub struct msi_index_vtable {
     pub word_fids: Option<word_keys_fn>,
     pub word_positions: Option<word_keys_fn>,
     pub field_id_word_count_docids: Option<fid_count_docids_fn>,
+    pub word_prefix_docids: Option<prefix_docids_fn>,
+    pub word_prefix_fid_docids: Option<prefix_key_docids_fn>,
+    pub word_prefix_position_docids: Option<prefix_key_docids_fn>,
+    pub word_prefix_pair_proximity_docids: Option<prefix_pair_docids_fn>,
+    pub word_prefix_fids: Option<word_keys_fn>,
+    pub word_prefix_positions: Option<word_keys_fn>,
+    pub synonyms: Option<synonyms_fn>,
 }
 pub const MSI_MAX_SCORE_DETAILS: usize = 8;
 #[repr(C)] #[derive(Clone, Copy, Default)]
@@ -143,6 +156,8 @@ extern "C" {
                                      universe_cbo: *const u8, universe_len: usize, out_docids: *mut u32,
                                      out_scores: *mut msi_score_detail, out_n_scores: *mut u32, out_n: *mut u32,
                                      out_candidates: *mut u64) -> i32;
+    pub fn msi_score_details_global_score(details: *const msi_score_detail, n: u32) -> f64;
+    pub fn msi_bits_use_private_stream(p: *mut msi_bits) -> i32;
     pub fn msi_bits_op_count(p: *mut msi_bits, dst: u32, a: u32, b: u32, op: i32, out_count: *mut u64) -> i32;
 
     pub fn msi_vector_sort(docids: *const u32, dist: *const f32, n: u32, has_shift: i32, mean: f32, sigma: f32,

@@ -123,3 +123,18 @@ def test_hybrid_merge_batch_equals_per_query():
             exp, sem = ma.scoring.hybrid_merge(vh, kh, ratio, 1, 6)
             assert c[q] == len(exp) and h[q] == sem
             assert [(int(d[q, i]), bool(s[q, i])) for i in range(int(c[q]))] == exp
+
+
+def test_score_details_global_score_matches_reference_literals():
+    """cutoff.rs:330-470: Words 3/3 then Typo k of 3 -> 1.0000 0.9167 0.8333 0.7500 (Rank::merge); and the
+    oracle's ScoreDetails::global_score on every variant."""
+    from meilisearch_amd import ranking as R
+    from oracle import ranking_oracle as RO
+    for typo, want in ((0, "1.0000"), (1, "0.9167"), (2, "0.8333"), (3, "0.7500")):
+        got = R.score_details_global_score([("Words", 3, 3), ("Typo", typo, 3)])
+        assert f"{got:.4f}" == want
+    details = [("Words", 2, 3), ("Typo", 1, 4), ("Proximity", 5, 8), ("Fid", 3, 7), ("Position", 11, 21),
+               ("ExactAttribute", 2, 3), ("ExactWords", 1, 3)]
+    want = RO.global_score([("Words", 2, 3), ("Typo", 1, 4), ("Proximity", 5, 8), ("Fid", 3, 7), ("Position", 11, 21),
+                            ("ExactAttribute", "MatchesStart"), ("ExactWords", 1, 3)])
+    assert R.score_details_global_score(details) == want
