@@ -217,6 +217,64 @@ __global__ void bits_claim_kernel(ManyArgs a, const u64 *docs, u64 *bucket, u64 
   }
 }
 
+// Paths of one cost level, in DFS order: every 16-byte chunk of documents is independent, so the sequential
+// "a path claims what the earlier paths left" is a loop per thread.  steps[path_off[k] .. path_off[k+1]) are the
+// condition sets of path k.
+__global__ void bits_paths_kernel(const u64 *const *__restrict__ steps, const uint32_t *__restrict__ path_off,
+                                  uint32_t n_paths, u64 *__restrict__ bucket, u64 *__restrict__ universe,
+                                  uint64_t n_pairs, u64 *__restrict__ acc_counts, u64 *__restrict__ acc,
+                                  volatile uint64_t *__restrict__ sig_counts, volatile uint64_t *__restrict__ sig,
+                                  uint64_t seq) {
+  __shared__ uint32_t cnt[MSI_BITS_MAX_PATHS];
+  for (uint32_t k = threadIdx.x; k < n_paths; k += blockDim.x) cnt[k] = 0;
+  __syncthreads();
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n_pairs; i += stride) {
+    ulonglong2 u = reinterpret_cast<ulonglong2 *>(universe)[i];
+    if (!(u.x | u.y)) continue;
+    ulonglong2 b = reinterpret_cast<ulonglong2 *>(bucket)[i];
+    for (uint32_t k = 0; k < n_paths && (u.x | u.y); ++k) {
+      ulonglong2 m = u;
+      for (uint32_t s = path_off[k]; s < path_off[k + 1] && (m.x | m.y); ++s) {
+        const ulonglong2 c = reinterpret_cast<const ulonglong2 *>(steps[s])[i];
+        m.x &= c.x;
+        m.y &= c.y;
+      }
+      if (m.x | m.y) {
+        b.x |= m.x;
+        b.y |= m.y;
+        u.x &= ~m.x;
+        u.y &= ~m.y;
+        atomicAdd(&cnt[k], (uint32_t)(__popcll(m.x) + __popcll(m.y)));
+      }
+    }
+    reinterpret_cast<ulonglong2 *>(bucket)[i] = b;
+    reinterpret_cast<ulonglong2 *>(universe)[i] = u;
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n_paths; k += blockDim.x)
+    if (cnt[k]) atomicAdd(&acc_counts[k], (u64)cnt[k]);
+  __threadfence();
+  __syncthreads();
+  __shared__ bool last;
+  if (threadIdx.x == 0) last = atomicAdd(&acc[1], 1ull) == gridDim.x - 1;
+  __syncthreads();
+  if (last) {
+    __threadfence();
+    for (uint32_t k = threadIdx.x; k < n_paths; k += blockDim.x) {
+      const u64 total = atomicExch(&acc_counts[k], 0ull);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig_counts[k]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      acc[1] = 0;
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // dst = (OR_i pool[srcs[i]]) & pool[universe]
 __global__ void bits_union_many_kernel(u64 *__restrict__ pool, uint64_t n_words, uint32_t dst,
                                        const uint32_t *__restrict__ srcs, uint32_t n, uint32_t universe) {
@@ -412,9 +470,9 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   if (s == MSI_OK) s = p->small.ensure(64);
   if (s == MSI_OK) {
     void *h = nullptr;
-    if (hipHostMalloc(&h, (2 + MSI_BITS_MANY) * sizeof(uint64_t), hipHostMallocCoherent) != hipSuccess ||
-        hipMalloc((void **)&p->d_acc, (2 + MSI_BITS_MANY) * sizeof(u64)) != hipSuccess ||
-        hipMemset(p->d_acc, 0, (2 + MSI_BITS_MANY) * sizeof(u64)) != hipSuccess) {
+    if (hipHostMalloc(&h, (2 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(uint64_t), hipHostMallocCoherent) != hipSuccess ||
+        hipMalloc((void **)&p->d_acc, (2 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess ||
+        hipMemset(p->d_acc, 0, (2 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess) {
       msi_set_error("msi_bits_create: allocating the completion signal failed");
       s = MSI_E_OOM;
     } else {
@@ -696,6 +754,40 @@ static int32_t ring_alloc(msi_bits *p, size_t bytes, uint8_t **out) {
   }
   *out = p->h_ring + p->ring_pos;
   p->ring_pos += bytes;
+  return MSI_OK;
+}
+
+int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
+                             uint32_t bucket, uint32_t universe, uint64_t *counts) {
+  if (!p || !n_paths || n_paths > MSI_BITS_MAX_PATHS || !path_off || !counts) return MSI_E_INVALID;
+  const uint32_t n_steps = path_off[n_paths];
+  if (n_steps > MSI_BITS_MAX_STEPS || (n_steps && !step_slots)) return MSI_E_INVALID;
+  MSI_TRY(check_slot(p, bucket, "msi_bits_paths_claim"));
+  MSI_TRY(check_slot(p, universe, "msi_bits_paths_claim"));
+  for (uint32_t s = 0; s < n_steps; ++s) MSI_TRY(check_slot(p, step_slots[s], "msi_bits_paths_claim"));
+  std::unique_lock<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->stream;
+  const size_t steps_bytes = std::max<size_t>(1, n_steps) * sizeof(u64 *), off_bytes = (n_paths + 1) * sizeof(uint32_t);
+  if (steps_bytes + off_bytes > p->desc.cap) MSI_TRY(p->desc.ensure(std::max<size_t>(steps_bytes + off_bytes, (size_t)64 << 10)));
+  uint8_t *h = nullptr;
+  MSI_TRY(ring_alloc(p, steps_bytes + off_bytes, &h));
+  u64 **hs = (u64 **)h;
+  for (uint32_t s = 0; s < n_steps; ++s) hs[s] = p->slot(step_slots[s]);
+  memcpy(h + steps_bytes, path_off, off_bytes);
+  MSI_HIP_TRY(hipMemcpyAsync(p->desc.p, h, steps_bytes + off_bytes, hipMemcpyHostToDevice, st));
+  const uint64_t n_pairs = p->n_words / 2;
+  const uint64_t seq = ++p->seq;
+  hipLaunchKernelGGL(bits_paths_kernel, dim3(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 4)), dim3(BT), 0, st,
+                     (const u64 *const *)p->desc.p, (const uint32_t *)((uint8_t *)p->desc.p + steps_bytes), n_paths,
+                     p->slot(bucket), p->slot(universe), n_pairs, p->d_acc + 2 + MSI_BITS_MANY, p->d_acc,
+                     p->h_sig + 2 + MSI_BITS_MANY, p->h_sig, seq);
+  MSI_HIP_TRY(hipGetLastError());
+  lk.unlock();
+  uint64_t ignored = 0;
+  MSI_TRY(wait_count(p, seq, &ignored));
+  for (uint32_t k = 0; k < n_paths; ++k)
+    counts[k] = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2 + MSI_BITS_MANY + k]), __ATOMIC_RELAXED);
   return MSI_OK;
 }
 

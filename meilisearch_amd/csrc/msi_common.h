@@ -160,6 +160,11 @@ int32_t msi_bits_and_many_count(msi_bits *p, uint32_t prefix, uint32_t n, const 
                                 uint64_t *counts);
 int32_t msi_bits_claim(msi_bits *p, uint32_t docs, uint32_t bucket, uint32_t universe, uint32_t n_stack,
                        const uint32_t *stack);
+//   paths_claim: for path k = 0..n-1 in order: docs = universe & AND(steps of k); bucket |= docs; universe &= ~docs;
+//                counts[k] = |docs|  — a whole cost level of a rule graph in one launch and one completion signal
+constexpr uint32_t MSI_BITS_MAX_PATHS = 256, MSI_BITS_MAX_STEPS = 4096;
+int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
+                             uint32_t bucket, uint32_t universe, uint64_t *counts);
 
 // ---- device helpers -------------------------------------------------------
 

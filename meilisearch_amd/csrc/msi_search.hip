@@ -153,6 +153,22 @@ struct Dev {
     }
     return out;
   }
+  // a whole cost level: path k claims universe & AND(its condition sets), in order; returns the cardinalities
+  std::vector<uint64_t> paths_claim(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe) {
+    std::vector<uint32_t> off{0}, steps;
+    for (auto &p : paths) {
+      for (auto &s : p) steps.push_back(s->slot);
+      off.push_back((uint32_t)steps.size());
+    }
+    std::vector<uint64_t> counts(paths.size(), 0);
+    Clock ck_;
+    ++g_stats.launches;
+    ++g_stats.syncs;
+    ck(msi_bits_paths_claim(pool.p, (uint32_t)paths.size(), off.data(), steps.data(), bucket->slot, universe->slot,
+                            counts.data()));
+    g_stats.device_wait_ms += ck_.ms();
+    return counts;
+  }
   void claim(const Set &docs, const Set &bucket, const Set &universe, const std::vector<Set> &stack) {
     uint32_t ss[MSI_BITS_MANY];
     if (stack.size() > MSI_BITS_MANY) fail(MSI_E_INTERNAL, "path longer than the claim kernel supports");
@@ -298,7 +314,8 @@ struct Ctx {
   // the rules of a search resolve the same term subsets again and again (every bucket of a rule restarts
   // the rules below it).
   std::map<Subset, Set> subset_cache;
-  std::map<std::tuple<Subset, int, uint32_t>, Set> within_cache;
+  std::map<std::tuple<Subset, int, std::vector<uint32_t>>, Set> within_cache;
+  std::map<std::string, std::pair<Set, Set>> exact_attr_cache;
   std::map<std::tuple<Subset, Subset, uint32_t, uint32_t>, Set> prox_cache;
   std::map<std::pair<uint32_t, bool>, Set> word_cache;
   void relieve() {  // keep the pool from running dry on long queries: drop what can be recomputed
@@ -307,6 +324,7 @@ struct Ctx {
     within_cache.clear();
     prox_cache.clear();
     word_cache.clear();
+    exact_attr_cache.clear();
   }
 
   Ctx(msi_dict *d, msi_bits *pool, const msi_index_vtable *i, const msi_search_params *p)
@@ -651,7 +669,14 @@ struct Ctx {
   }
 
   // -- docids (resolve_query_graph.rs), all on the device -----------------------------------------
-  Set word_docids(uint32_t w, bool original) {  // a fresh set the caller may modify
+  // Every set returned by the *_full functions is universe-independent, cached for the whole search and
+  // SHARED: callers never modify it, they intersect it into a set of their own.
+  Set empty_;
+  Set empty_set() {
+    if (!empty_) empty_ = dev.zeros();
+    return empty_;
+  }
+  Set word_full(uint32_t w, bool original) {
     auto it = word_cache.find({w, original});
     if (it == word_cache.end()) {
       relieve();
@@ -659,9 +684,9 @@ struct Ctx {
       add_word(b, w, original);
       it = word_cache.emplace(std::make_pair(w, original), dev.decode(b)).first;
     }
-    return dev.clone(it->second);
+    return it->second;
   }
-  Set pair_union(uint32_t w1, uint32_t w2, uint32_t max_prox) {  // union of pair(prox = 1..max_prox)
+  Set pair_union(uint32_t w1, uint32_t w2, uint32_t max_prox) {  // union of pair(prox = 1..max_prox), fresh
     MsiCboBatch b;
     for (uint32_t p = 1; p <= max_prox; ++p) add_pair(&b, p, w1, w2);
     return dev.decode(b);
@@ -674,17 +699,12 @@ struct Ctx {
     if (it != phrase_cache.end()) return it->second;
     const Phrase p = phrases[pid];
     Set cand;
-    {
-      bool any = false;
-      for (int32_t w : p) {
-        if (w < 0) continue;
-        Set d = word_docids((uint32_t)w, true);
-        if (!any) cand = d;
-        else dev.and_(cand, d);
-        any = true;
-      }
-      if (!any) cand = dev.zeros();
+    for (int32_t w : p) {
+      if (w < 0) continue;
+      if (!cand) cand = dev.clone(word_full((uint32_t)w, true));
+      else dev.and_(cand, word_full((uint32_t)w, true));
     }
+    if (!cand) cand = dev.zeros();
     const size_t win = std::min<size_t>(p.size(), 3);
     for (size_t s = 0; s + win <= p.size() && win > 0; ++s)
       for (size_t a = 0; a < win; ++a) {
@@ -697,8 +717,8 @@ struct Ctx {
       }
     return phrase_cache[pid] = cand;
   }
-  // compute_query_term_subset_docids :33-59
-  Set subset_docids(const Set *universe, const Subset &ss) {
+  // compute_query_term_subset_docids :33-59 without the universe
+  Set subset_full(const Subset &ss) {
     Subset key = ss;
     key.mandatory = false;
     auto it = subset_cache.find(key);
@@ -712,28 +732,26 @@ struct Ctx {
       for (uint32_t p : all_phrases(ss)) dev.or_(d, phrase_docids(p));
       it = subset_cache.emplace(key, d).first;
     }
-    return universe ? dev.and_new(it->second, *universe, nullptr) : dev.clone(it->second);
+    return it->second;
   }
-  // ..._within_field_id / ..._within_position :61-130 (which: 0 fid, 1 position)
-  Set subset_docids_within(const Set &universe, const Subset &ss, int which, uint32_t key) {
+  // ..._within_field_id / ..._within_position :61-130 for one fid (which 0) or a set of positions (which 1):
+  // every posting of the condition goes into ONE decode batch
+  Set within_full(const Subset &ss, int which, const std::vector<uint32_t> &keys) {
     Subset sk = ss;
     sk.mandatory = false;
-    auto ck_ = std::make_tuple(sk, which, key);
+    auto ck_ = std::make_tuple(sk, which, keys);
     auto it = within_cache.find(ck_);
-    if (it == within_cache.end()) {
-      relieve();
-      it = within_cache.emplace(ck_, subset_docids_within_full(ss, which, key)).first;
-    }
-    return dev.and_new(it->second, universe, nullptr);
-  }
-  Set subset_docids_within_full(const Subset &ss, int which, uint32_t key) {
+    if (it != within_cache.end()) return it->second;
+    relieve();
     MsiCboBatch b;
-    for (auto &w : all_single_words(ss)) {
-      if (which == 0) add_word_fid(b, w.first, key);
-      else add_word_position(b, w.first, key);
-    }
     const int32_t pf = use_prefix_db(ss);
-    if (pf >= 0) add_prefix_key(b, (uint32_t)pf, which, key);
+    for (uint32_t key : keys) {
+      for (auto &w : all_single_words(ss)) {
+        if (which == 0) add_word_fid(b, w.first, key);
+        else add_word_position(b, w.first, key);
+      }
+      if (pf >= 0) add_prefix_key(b, (uint32_t)pf, which, key);
+    }
     Set d = dev.decode(b);
     for (uint32_t p : all_phrases(ss)) {
       int32_t first = -1;
@@ -744,13 +762,15 @@ struct Ctx {
         }
       if (first < 0) continue;
       MsiCboBatch fb;
-      if (which == 0) add_word_fid(fb, (uint32_t)first, key);
-      else add_word_position(fb, (uint32_t)first, key);
+      for (uint32_t key : keys) {
+        if (which == 0) add_word_fid(fb, (uint32_t)first, key);
+        else add_word_position(fb, (uint32_t)first, key);
+      }
       Set f = dev.decode(fb);
       dev.and_(f, phrase_docids(p));
       dev.or_(d, f);
     }
-    return d;
+    return within_cache.emplace(ck_, d).first->second;
   }
 };
 
@@ -929,7 +949,7 @@ Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe) {
     Set pd = c.dev.zeros();
     for (uint32_t p : n.preds) c.dev.or_(pd, docs[p]);
     Set nd;
-    if (n.kind == 2) nd = c.subset_docids(&pd, n.term.subset);
+    if (n.kind == 2) nd = c.dev.and_new(c.subset_full(n.term.subset), pd, nullptr);
     else if (n.kind == 0) nd = c.dev.clone(universe);
     else if (n.kind == 1) return pd;
     else fail(MSI_E_INTERNAL, "deleted node reached");
@@ -1067,14 +1087,14 @@ struct Resolved {
 };
 
 // proximity/compute_docids.rs:15-212 (no prefix DB)
-Set proximity_docids(Ctx &c, const Condition &cd, const Set &universe) {
+Set proximity_full(Ctx &c, const Condition &cd) {
   const uint32_t rn = cd.term.n_ids();
   const uint32_t forward = 1 + cd.x - rn, backward = cd.x - rn;
   Subset lk = cd.left.subset, rk = cd.term.subset;
   lk.mandatory = rk.mandatory = false;
   auto key = std::make_tuple(lk, rk, forward, backward);
   auto hit = c.prox_cache.find(key);
-  if (hit != c.prox_cache.end()) return c.dev.and_new(hit->second, universe, nullptr);
+  if (hit != c.prox_cache.end()) return hit->second;
   c.relieve();
   std::set<std::pair<int32_t, uint32_t>> lefts, rights;  // (phrase or -1, word)
   for (auto &w : c.all_single_words(cd.left.subset)) lefts.insert({-1, w.first});
@@ -1107,39 +1127,38 @@ Set proximity_docids(Ctx &c, const Condition &cd, const Set &universe) {
     c.dev.or_(docids, d);
   }
   c.prox_cache.emplace(key, docids);
-  return c.dev.and_new(docids, universe, nullptr);
+  return docids;
 }
 
-Resolved resolve_condition(Ctx &c, const Condition &cd, const Set &universe) {
+// The documents of a condition WITHOUT the universe (shared, never modified): the path search intersects
+// them with a prefix that is already inside the current universe.
+Resolved resolve_condition(Ctx &c, const Condition &cd) {
   Resolved r;
   r.end = cd.term;
   switch (cd.kind) {
     case C_TERM:
     case C_TYPO:
     case C_ANY:
-      r.docs = c.subset_docids(&universe, cd.term.subset);
+      r.docs = c.subset_full(cd.term.subset);
       break;
     case C_FID:
-      r.docs = cd.has_fid ? c.subset_docids_within(universe, cd.term.subset, 0, cd.x) : c.dev.zeros();
+      r.docs = cd.has_fid ? c.within_full(cd.term.subset, 0, {cd.x}) : c.empty_set();
       break;
     case C_POSITION:
-      r.docs = c.dev.zeros();
-      for (uint16_t pos : cd.positions) c.dev.or_(r.docs, c.subset_docids_within(universe, cd.term.subset, 1, pos));
+      r.docs = cd.positions.empty() ? c.empty_set()
+                                    : c.within_full(cd.term.subset, 1, std::vector<uint32_t>(cd.positions.begin(), cd.positions.end()));
       break;
     case C_EXACT: {
       r.end.subset = c.keep_only_exact_term(cd.term.subset);
       r.end.subset.mandatory = true;
       auto e = c.exact_term(cd.term.subset);
-      if (e.first == 0) r.docs = c.dev.zeros();
-      else if (e.first == 1) r.docs = c.dev.and_new(c.phrase_docids(e.second), universe, nullptr);
-      else {
-        r.docs = c.word_docids(e.second, true);
-        c.dev.and_(r.docs, universe);
-      }
+      if (e.first == 0) r.docs = c.empty_set();
+      else if (e.first == 1) r.docs = c.phrase_docids(e.second);
+      else r.docs = c.word_full(e.second, true);
       break;
     }
     case C_PROX:
-      r.docs = proximity_docids(c, cd, universe);
+      r.docs = proximity_full(c, cd);
       r.has_start = true;
       r.start = cd.left;
       break;
@@ -1153,6 +1172,7 @@ struct Bucket {
   Set docs;
   uint64_t count = 0;
   Score score{0, 0, 0};
+  bool universe_reduced = false;  // the rule already removed `docs` from the universe it was given
 };
 
 struct Rule {
@@ -1279,7 +1299,7 @@ struct GraphRule : Rule {
       default: out.score = {MSI_SCORE_EXACT_WORDS, rank > 0 ? rank - 1 : 0, mx > 0 ? mx - 1 : 0}; break;
     }
     cx = &c;
-    uni = c.dev.clone(universe);
+    uni = universe;  // worked on in place: what is left after the paths claimed their documents IS universe - bucket
     uni_count = universe_count;
     bucket = c.dev.zeros();
     bucket_count = 0;
@@ -1287,7 +1307,7 @@ struct GraphRule : Rule {
     good.clear();
     stop = false;
     std::set<uint32_t> visited, to_skip;
-    visit(Graph::ROOT, cost, visited, to_skip);
+    if (!fused_level(cost)) visit(Graph::ROOT, cost, visited, to_skip);
     std::vector<PathSubsets> paths;
     for (auto &p : good) {
       PathSubsets ps;
@@ -1300,15 +1320,80 @@ struct GraphRule : Rule {
     out.graph = build_from_paths(paths);
     out.docs = bucket;
     out.count = bucket_count;
+    out.universe_reduced = true;
     uni.reset();
     bucket.reset();
     stack.clear();
     return true;
   }
 
+  // All the paths of this cost, in the order the search would visit them, WITHOUT evaluating anything
+  // (cheapest_paths.rs:147-310 minus the dead-end pruning).  False when there are too many for one launch.
+  bool enumerate(uint32_t node, uint64_t remaining, std::set<uint32_t> &visited, const std::set<uint32_t> &to_skip,
+                 std::vector<int32_t> &cur, std::vector<std::vector<int32_t>> &out, size_t &steps) {
+    for (const Edge &e : edges[node]) {
+      if (remaining < e.cost) continue;
+      const uint64_t rem = remaining - e.cost;
+      const auto &dc = costs[e.dest];
+      if (!std::binary_search(dc.begin(), dc.end(), rem)) continue;
+      if (e.cond < 0) {
+        if (e.dest == Graph::END) {
+          steps += cur.size();
+          if (out.size() >= MSI_BITS_MAX_PATHS || steps > MSI_BITS_MAX_STEPS) return false;
+          out.push_back(cur);
+        } else {
+          std::set<uint32_t> ts = to_skip;
+          ts.insert(e.skip.begin(), e.skip.end());
+          if (!enumerate(e.dest, rem, visited, ts, cur, out, steps)) return false;
+        }
+        continue;
+      }
+      if (to_skip.count(e.dest)) continue;
+      bool blocked = false;
+      for (uint32_t s : e.skip) blocked |= visited.count(s) != 0;
+      if (blocked) continue;
+      cur.push_back(e.cond);
+      visited.insert(e.dest);
+      std::set<uint32_t> ts = to_skip;
+      ts.insert(e.skip.begin(), e.skip.end());
+      const bool ok = enumerate(e.dest, rem, visited, ts, cur, out, steps);
+      visited.erase(e.dest);
+      cur.pop_back();
+      if (!ok) return false;
+    }
+    return true;
+  }
+
+  // One launch for the whole cost level: every 16-byte chunk of documents walks the paths in order and a
+  // path claims what the earlier paths left (msi_bits_paths_claim) — the same documents per path as the
+  // path-by-path search, because claims never cross documents.
+  bool fused_level(uint64_t cost) {
+    std::vector<std::vector<int32_t>> all;
+    std::vector<int32_t> cur;
+    std::set<uint32_t> visited, to_skip;
+    size_t steps = 0;
+    if (!enumerate(Graph::ROOT, cost, visited, to_skip, cur, all, steps)) return false;
+    if (all.empty()) return true;
+    std::vector<std::vector<Set>> sets;
+    for (auto &p : all) {
+      std::vector<Set> ps;
+      for (int32_t ci : p) ps.push_back(resolved(ci).docs);
+      sets.push_back(std::move(ps));
+    }
+    const std::vector<uint64_t> counts = cx->dev.paths_claim(sets, bucket, uni);
+    for (size_t k = 0; k < all.size(); ++k) {
+      if (!counts[k]) continue;
+      good.push_back(all[k]);
+      ++g_stats.paths;
+      bucket_count += counts[k];
+      uni_count -= counts[k];
+    }
+    return true;
+  }
+
   const Resolved &resolved(int32_t ci) {
     auto it = cache.find(ci);
-    if (it == cache.end()) it = cache.emplace(ci, resolve_condition(*cx, conds[ci], uni)).first;
+    if (it == cache.end()) it = cache.emplace(ci, resolve_condition(*cx, conds[ci])).first;
     return it->second;
   }
 
@@ -1416,7 +1501,7 @@ struct GraphRule : Rule {
 struct ExactAttributeRule : Rule {
   Graph g;
   int state = 0;  // 0 empty, 1 exact attribute, 2 attribute starts
-  std::vector<std::pair<Set, Set>> per_attr;  // (start_with_exact, exact_word_count)
+  Set exact_match, matches_start;  // universe-independent, shared (Ctx::exact_attr_cache)
   ExactAttributeRule() : Rule(R_EXACT_ATTRIBUTE, -1) {}
 
   static uint32_t bucketed_position(uint32_t rel) {  // lib.rs:248-262
@@ -1430,7 +1515,6 @@ struct ExactAttributeRule : Rule {
   void start(Ctx &c, const Set &universe, const Graph &graph) override {
     g = graph;
     state = 0;
-    per_attr.clear();
     struct Info {
       uint32_t start_id;
       std::pair<int, uint32_t> exact;
@@ -1456,43 +1540,62 @@ struct ExactAttributeRule : Rule {
       prev = x.start_id;
     }
     std::vector<std::pair<Phrase, uint32_t>> words_positions;
+    std::string sig = std::to_string(count_all);
     for (auto &x : ded) {
       Phrase ws;
       if (x.exact.first == 1) ws = c.phrases[x.exact.second];
       else ws.push_back((int32_t)x.exact.second);
+      for (int32_t w : ws) sig += "," + std::to_string(w);
+      sig += "@" + std::to_string(x.start_pos);
       words_positions.push_back({ws, x.start_pos});
     }
-    Set cand = c.dev.clone(universe);
-    for (auto &wp : words_positions)
-      for (size_t off = 0; off < wp.first.size(); ++off) {
-        if (wp.first[off] < 0) continue;
-        MsiCboBatch b;
-        c.add_word_position(b, (uint32_t)wp.first[off], bucketed_position(wp.second + (uint32_t)off));
-        c.dev.and_(cand, c.dev.decode(b));
-      }
-    if (!c.ix->field_id_word_count_docids)
-      fail(MSI_E_INVALID, "the index vtable has no field_id_word_count_docids (exactness rule)");
-    for (uint32_t i = 0; i < c.prm->n_searchable; ++i) {
-      const uint32_t fid = c.prm->searchable_fids[i];
-      Set inter = c.dev.clone(cand);
+    // Both buckets are universe-independent up to a final intersection:
+    //   P = AND_(word, offset) word_position_docids(word, bucketed(start + offset))
+    //   per searchable field: S = P AND_word word_fid_docids(word, fid);  W = field_id_word_count_docids(fid, #positions)
+    //   ExactMatch = OR_fid (S & W),  MatchesStart = OR_fid (S - W)
+    auto hit = c.exact_attr_cache.find(sig);
+    if (hit == c.exact_attr_cache.end()) {
+      c.relieve();
+      if (!c.ix->field_id_word_count_docids)
+        fail(MSI_E_INVALID, "the index vtable has no field_id_word_count_docids (exactness rule)");
+      Set P;
       for (auto &wp : words_positions)
-        for (int32_t w : wp.first) {
-          if (w < 0) continue;
+        for (size_t off = 0; off < wp.first.size(); ++off) {
+          if (wp.first[off] < 0) continue;
           MsiCboBatch b;
-          c.add_word_fid(b, (uint32_t)w, fid);
-          c.dev.and_(inter, c.dev.decode(b));
+          c.add_word_position(b, (uint32_t)wp.first[off], bucketed_position(wp.second + (uint32_t)off));
+          if (!P) P = c.dev.decode(b);
+          else c.dev.and_(P, c.dev.decode(b));
         }
-      MsiCboBatch wc;
-      if (count_all < 255) {
-        const uint8_t *bytes = nullptr;
-        size_t n = 0;
-        c.take(wc, c.ix->field_id_word_count_docids(c.ix->user, fid, count_all, &bytes, &n), bytes, n,
-               "field_id_word_count_docids");
+      if (!P) P = c.dev.ones();
+      Set e1 = c.dev.zeros(), e2 = c.dev.zeros();
+      for (uint32_t i = 0; i < c.prm->n_searchable; ++i) {
+        const uint32_t fid = c.prm->searchable_fids[i];
+        Set S = c.dev.clone(P);
+        for (auto &wp : words_positions)
+          for (int32_t w : wp.first) {
+            if (w < 0) continue;
+            MsiCboBatch b;
+            c.add_word_fid(b, (uint32_t)w, fid);
+            c.dev.and_(S, c.dev.decode(b));
+          }
+        MsiCboBatch wc;
+        if (count_all < 255) {
+          const uint8_t *bytes = nullptr;
+          size_t n = 0;
+          c.take(wc, c.ix->field_id_word_count_docids(c.ix->user, fid, count_all, &bytes, &n), bytes, n,
+                 "field_id_word_count_docids");
+        }
+        Set W = c.dev.decode(wc);
+        Set both = c.dev.and_new(S, W, nullptr);
+        c.dev.or_(e1, both);
+        c.dev.sub_(S, W);
+        c.dev.or_(e2, S);
       }
-      Set wcs = c.dev.decode(wc);
-      c.dev.and_(wcs, universe);
-      per_attr.push_back({inter, wcs});
+      hit = c.exact_attr_cache.emplace(sig, std::make_pair(e1, e2)).first;
     }
+    exact_match = hit->second.first;
+    matches_start = hit->second.second;
     state = 1;
   }
 
@@ -1504,21 +1607,14 @@ struct ExactAttributeRule : Rule {
       out.score = {MSI_SCORE_EXACT_ATTRIBUTE, 1, 3};
       return true;
     }
-    Set u = c.dev.zeros();
-    for (auto &pa : per_attr) {
-      Set t = c.dev.clone(pa.first);
-      if (state == 1) c.dev.and_(t, pa.second);
-      else c.dev.sub_(t, pa.second);
-      c.dev.or_(u, t);
-    }
-    out.docs = c.dev.and_new(u, universe, &out.count);
+    out.docs = c.dev.and_new(state == 1 ? exact_match : matches_start, universe, &out.count);
     out.score = {MSI_SCORE_EXACT_ATTRIBUTE, state == 1 ? 3u : 2u, 3};
     state = state == 1 ? 2 : 0;
-    if (state == 0) per_attr.clear();
     return true;
   }
   void end() override {
-    per_attr.clear();
+    exact_match.reset();
+    matches_start.reset();
     state = 0;
   }
 };
@@ -1757,7 +1853,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     }
     ++g_stats.buckets;
     scores.push_back(b.score);
-    c.dev.sub_(unis[cur], b.docs);
+    if (!b.universe_reduced) c.dev.sub_(unis[cur], b.docs);
     uni_counts[cur] -= b.count;
     if (cur == nr - 1 || (!detailed && b.count <= 1) || cur_off + b.count < from) {
       add(b.docs, b.count);

@@ -1,0 +1,325 @@
+// tools/ranked_bench.cpp — native driver for msi_keyword_search_ranked: serving throughput of the keyword
+// leg (default criteria) with one caller thread and one msi_bits pool (private stream) per in-flight search,
+// as milli's spawn_blocking threads would call it.  The index behind the vtable is synthetic and lives in
+// host memory as the CboRoaringBitmap bytes milli stores (Zipf document frequencies, 3 searchable fields, 20
+// bucketed positions, word pairs at proximities 1..3), generated lazily per key and cached.
+//
+//   hipcc -O2 -std=c++17 -Iinclude tools/ranked_bench.cpp -Lmeilisearch_amd -lmsi -Wl,-rpath,$PWD/meilisearch_amd -o /tmp/ranked_bench
+//   /tmp/ranked_bench <n_docs> <n_dictionary_words> <terms per query> <queries per thread> <threads...>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "msi.h"
+
+namespace {
+
+using Bytes = std::vector<uint8_t>;
+
+Bytes cbo_serialize(const std::vector<uint32_t> &ids) {  // cbo_roaring_bitmap_codec.rs:33-51 (array / bitmap containers)
+  Bytes out;
+  auto put16 = [&](uint16_t v) { out.push_back(v & 255); out.push_back(v >> 8); };
+  auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; ++i) out.push_back((v >> (8 * i)) & 255); };
+  if (ids.size() <= 7) {
+    for (uint32_t v : ids) put32(v);
+    return out;
+  }
+  std::vector<std::pair<size_t, size_t>> runs;  // [begin, end) per high key
+  for (size_t i = 0; i < ids.size();) {
+    size_t j = i;
+    while (j < ids.size() && (ids[j] >> 16) == (ids[i] >> 16)) ++j;
+    runs.push_back({i, j});
+    i = j;
+  }
+  put32(12346);
+  put32((uint32_t)runs.size());
+  for (auto &r : runs) {
+    put16((uint16_t)(ids[r.first] >> 16));
+    put16((uint16_t)(r.second - r.first - 1));
+  }
+  for (size_t i = 0; i < runs.size(); ++i) put32(0);
+  for (auto &r : runs) {
+    const size_t n = r.second - r.first;
+    if (n <= 4096) {
+      for (size_t i = r.first; i < r.second; ++i) put16((uint16_t)(ids[i] & 0xFFFF));
+    } else {
+      const size_t at = out.size();
+      out.resize(at + 8192, 0);
+      for (size_t i = r.first; i < r.second; ++i) {
+        const uint32_t v = ids[i] & 0xFFFF;
+        out[at + (v >> 3)] |= (uint8_t)(1u << (v & 7));
+      }
+    }
+  }
+  return out;
+}
+
+uint64_t mix(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+
+struct Index {
+  uint64_t n_docs;
+  std::vector<std::string> words;                 // sorted
+  std::map<std::string, uint32_t> rank;           // frequency rank
+  std::mutex mu;
+  std::map<std::string, std::shared_ptr<std::vector<uint32_t>>> ids;
+  std::map<std::string, std::shared_ptr<Bytes>> blobs;
+  static constexpr uint32_t N_POS = 20;
+  static uint32_t position(uint32_t i) { static const uint32_t p[N_POS] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,24,32,64,128}; return p[i]; }
+
+  std::shared_ptr<std::vector<uint32_t>> posting(const std::string &w) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = ids.find(w);
+      if (it != ids.end()) return it->second;
+    }
+    auto r = rank.find(w);
+    auto v = std::make_shared<std::vector<uint32_t>>();
+    if (r != rank.end()) {
+      const double p = std::min(0.4, 0.6 / std::pow(1.0 + r->second, 0.9));
+      const uint64_t k = std::max<uint64_t>(1, (uint64_t)(n_docs * p));
+      std::mt19937_64 g(mix(std::hash<std::string>{}(w)));
+      v->reserve(k);
+      for (uint64_t i = 0; i < k; ++i) v->push_back((uint32_t)(g() % n_docs));
+      std::sort(v->begin(), v->end());
+      v->erase(std::unique(v->begin(), v->end()), v->end());
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    return ids.emplace(w, v).first->second;
+  }
+  template <typename F>
+  const Bytes *blob(const std::string &key, F make) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = blobs.find(key);
+      if (it != blobs.end()) return it->second->empty() ? nullptr : it->second.get();
+    }
+    auto b = std::make_shared<Bytes>(cbo_serialize(make()));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = blobs.emplace(key, b).first;
+    return it->second->empty() ? nullptr : it->second.get();
+  }
+};
+
+int32_t hand(const Bytes *b, const uint8_t **bytes, size_t *n) {
+  if (!b) { *n = 0; return 0; }
+  *bytes = b->data();
+  *n = b->size();
+  return 0;
+}
+std::string str(const uint8_t *w, uint32_t n) { return std::string((const char *)w, n); }
+
+int32_t cb_word(void *u, const uint8_t *w, uint32_t n, int32_t, const uint8_t **bytes, size_t *out) {
+  Index *ix = (Index *)u;
+  const std::string s = str(w, n);
+  return hand(ix->blob("w/" + s, [&] { return *ix->posting(s); }), bytes, out);
+}
+int32_t cb_pair(void *u, uint32_t prox, const uint8_t *l, uint32_t ln, const uint8_t *r, uint32_t rn, const uint8_t **bytes, size_t *out) {
+  Index *ix = (Index *)u;
+  const std::string a = str(l, ln), b = str(r, rn);
+  if (prox < 1 || prox > 3) { *out = 0; return 0; }
+  return hand(ix->blob("p/" + std::to_string(prox) + "/" + a + "/" + b, [&] {
+    auto pa = ix->posting(a), pb = ix->posting(b);
+    std::vector<uint32_t> both, sel;
+    std::set_intersection(pa->begin(), pa->end(), pb->begin(), pb->end(), std::back_inserter(both));
+    for (uint32_t d : both) if (mix(d * 0x9E3779B97F4A7C15ULL + 7) % 6 == prox - 1) sel.push_back(d);
+    return sel;
+  }), bytes, out);
+}
+int32_t cb_exact(void *, const uint8_t *, uint32_t) { return 0; }
+int32_t cb_fid(void *u, const uint8_t *w, uint32_t n, uint32_t fid, const uint8_t **bytes, size_t *out) {
+  Index *ix = (Index *)u;
+  const std::string s = str(w, n);
+  if (fid < 1 || fid > 3) { *out = 0; return 0; }
+  return hand(ix->blob("f/" + std::to_string(fid) + "/" + s, [&] {
+    std::vector<uint32_t> sel;
+    for (uint32_t d : *ix->posting(s)) {
+      const uint64_t part = mix(d + 0x51ULL * s.size()) % 4;
+      if (part == fid - 1 || (part == 3 && fid <= 2)) sel.push_back(d);
+    }
+    return sel;
+  }), bytes, out);
+}
+int32_t cb_pos(void *u, const uint8_t *w, uint32_t n, uint32_t pos, const uint8_t **bytes, size_t *out) {
+  Index *ix = (Index *)u;
+  const std::string s = str(w, n);
+  return hand(ix->blob("q/" + std::to_string(pos) + "/" + s, [&] {
+    std::vector<uint32_t> sel;
+    for (uint32_t d : *ix->posting(s)) if (Index::position((uint32_t)(mix(d + 0x77ULL * s.size()) % Index::N_POS)) == pos) sel.push_back(d);
+    return sel;
+  }), bytes, out);
+}
+int32_t cb_fids(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t cap, uint32_t *cnt) {
+  Index *ix = (Index *)u;
+  const bool has = !ix->posting(str(w, n))->empty();
+  *cnt = has ? 3 : 0;
+  for (uint32_t i = 0; has && i < 3 && i < cap; ++i) out[i] = (uint16_t)(i + 1);
+  return 0;
+}
+int32_t cb_positions(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t cap, uint32_t *cnt) {
+  Index *ix = (Index *)u;
+  const bool has = !ix->posting(str(w, n))->empty();
+  *cnt = has ? Index::N_POS : 0;
+  for (uint32_t i = 0; has && i < Index::N_POS && i < cap; ++i) out[i] = (uint16_t)Index::position(i);
+  return 0;
+}
+int32_t cb_count(void *u, uint32_t fid, uint32_t count, const uint8_t **bytes, size_t *out) {
+  Index *ix = (Index *)u;
+  if (count > 30) { *out = 0; return 0; }
+  return hand(ix->blob("c/" + std::to_string(fid) + "/" + std::to_string(count), [&] {
+    std::vector<uint32_t> v;
+    std::mt19937_64 g(fid * 1000 + count);
+    for (uint64_t i = 0; i < std::max<uint64_t>(1, ix->n_docs / 200); ++i) v.push_back((uint32_t)(g() % ix->n_docs));
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    return v;
+  }), bytes, out);
+}
+
+#define CK(x) do { int32_t s_ = (x); if (s_ != MSI_OK) { fprintf(stderr, "%s -> %d: %s\n", #x, s_, msi_last_error()); exit(1); } } while (0)
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < 6) { fprintf(stderr, "usage: %s n_docs n_words terms queries threads...\n", argv[0]); return 2; }
+  const uint64_t n_docs = strtoull(argv[1], nullptr, 10);
+  const uint32_t n_words = atoi(argv[2]), n_terms = atoi(argv[3]), n_queries = atoi(argv[4]);
+  Index ix;
+  ix.n_docs = n_docs;
+  std::mt19937_64 g(99);
+  {
+    std::map<std::string, int> seen;
+    const char *letters = "etaoinshrdlcumwfgypbvkjxqz";
+    while (seen.size() < n_words) {
+      const int len = 4 + (int)(g() % 6);
+      std::string w;
+      for (int i = 0; i < len; ++i) w.push_back(letters[(size_t)(std::pow((double)(g() % 10000) / 10000.0, 1.7) * 26)]);
+      seen[w] = 1;
+    }
+    for (auto &kv : seen) ix.words.push_back(kv.first);
+    std::vector<std::string> perm = ix.words;
+    std::shuffle(perm.begin(), perm.end(), g);
+    for (uint32_t i = 0; i < perm.size(); ++i) ix.rank[perm[i]] = i;
+  }
+  std::vector<std::string> frequent(300);
+  for (auto &kv : ix.rank) if (kv.second < 300) frequent[kv.second] = kv.first;
+
+  msi_ctx *ctx = nullptr;
+  CK(msi_ctx_create(-1, &ctx));
+  std::vector<uint8_t> concat;
+  std::vector<uint32_t> offs{0};
+  for (auto &w : ix.words) { concat.insert(concat.end(), w.begin(), w.end()); offs.push_back((uint32_t)concat.size()); }
+  msi_dict *dict = nullptr;
+  CK(msi_dict_create(ctx, concat.data(), offs.data(), (uint32_t)ix.words.size(), &dict));
+  CK(msi_dict_set_microbatch(dict, 100, 64));
+
+  msi_index_vtable vt;
+  memset(&vt, 0, sizeof(vt));
+  vt.user = &ix;
+  vt.word_docids = cb_word;
+  vt.word_pair_proximity_docids = cb_pair;
+  vt.is_exact_word = cb_exact;
+  vt.word_fid_docids = cb_fid;
+  vt.word_position_docids = cb_pos;
+  vt.word_fids = cb_fids;
+  vt.word_positions = cb_positions;
+  vt.field_id_word_count_docids = cb_count;
+
+  const int32_t criteria[] = {MSI_CRIT_WORDS, MSI_CRIT_TYPO, MSI_CRIT_PROXIMITY, MSI_CRIT_ATTRIBUTE_RANK, MSI_CRIT_SORT,
+                              MSI_CRIT_WORD_POSITION, MSI_CRIT_EXACTNESS};
+  const uint16_t fids[] = {1, 2, 3}, weights[] = {0, 1, 2};
+  msi_search_params prm;
+  memset(&prm, 0, sizeof(prm));
+  prm.authorize_typos = 1;
+  prm.min_word_len_one_typo = 5;
+  prm.min_word_len_two_typos = 9;
+  prm.strategy = MSI_TERMS_LAST;
+  prm.criteria = criteria;
+  prm.n_criteria = 7;
+  prm.searchable_fids = fids;
+  prm.searchable_weights = weights;
+  prm.n_searchable = 3;
+  prm.max_weight = 2;
+  prm.from = 0;
+  prm.length = 20;
+
+  // the query set (shared by every configuration)
+  std::vector<std::vector<std::string>> queries(64);
+  for (auto &q : queries) for (uint32_t i = 0; i < n_terms; ++i) q.push_back(frequent[g() % 300]);
+
+  auto run_query = [&](msi_bits *pool, const std::vector<std::string> &q, uint64_t stats[10]) {
+    std::vector<msi_query_token> toks(q.size());
+    std::vector<msi_located_term> terms(q.size());
+    for (size_t i = 0; i < q.size(); ++i) {
+      toks[i] = msi_query_token{(const uint8_t *)q[i].data(), (uint32_t)q[i].size(), i + 1 == q.size() ? 1u : 0u};
+      terms[i] = msi_located_term{&toks[i], 1, 0, (uint32_t)i, (uint32_t)i};
+    }
+    uint32_t ids[20], nsc[20], n = 0;
+    msi_score_detail sc[20 * MSI_MAX_SCORE_DETAILS];
+    uint64_t cand = 0;
+    CK(msi_keyword_search_ranked(dict, pool, &vt, terms.data(), (uint32_t)terms.size(), &prm, nullptr, 0, ids, sc, nsc, &n, &cand));
+    if (stats) msi_search_last_stats(stats);
+    return n;
+  };
+  {  // warm the synthetic index (posting generation is not what is measured)
+    msi_bits *pool = nullptr;
+    CK(msi_bits_create(ctx, n_docs, 1024, &pool));
+    for (auto &q : queries) run_query(pool, q, nullptr);
+    msi_bits_destroy(pool);
+  }
+  for (int a = 5; a < argc; ++a) {
+    const int n_threads = atoi(argv[a]);
+    std::vector<msi_bits *> pools(n_threads);
+    for (auto &p : pools) {
+      CK(msi_bits_create(ctx, n_docs, 1024, &p));
+      CK(msi_bits_use_private_stream(p));
+    }
+    std::vector<std::vector<double>> lat(n_threads);
+    std::vector<std::vector<uint64_t>> sums(n_threads, std::vector<uint64_t>(10, 0));
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> ths;
+    for (int t = 0; t < n_threads; ++t)
+      ths.emplace_back([&, t] {
+        for (uint32_t i = 0; i < n_queries; ++i) {
+          const auto s0 = std::chrono::steady_clock::now();
+          uint64_t st[10];
+          run_query(pools[t], queries[(t * 17 + i) % queries.size()], st);
+          lat[t].push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s0).count());
+          for (int k = 0; k < 10; ++k) sums[t][k] += st[k];
+        }
+      });
+    for (auto &th : ths) th.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<double> all;
+    std::vector<uint64_t> tot(10, 0);
+    for (int t = 0; t < n_threads; ++t) {
+      all.insert(all.end(), lat[t].begin(), lat[t].end());
+      for (int k = 0; k < 10; ++k) tot[k] += sums[t][k];
+    }
+    std::sort(all.begin(), all.end());
+    const double nq = (double)all.size();
+    printf("{\"config\": \"ranked_native\", \"docs\": %llu, \"dictionary_words\": %u, \"terms\": %u, \"threads\": %d, "
+           "\"queries\": %zu, \"queries_per_s\": %.1f, \"p50_ms\": %.3f, \"p99_ms\": %.3f, \"launches_per_query\": %.1f, "
+           "\"waits_per_query\": %.1f, \"decode_batches_per_query\": %.1f, \"callbacks_per_query\": %.1f, "
+           "\"callback_us_per_query\": %.1f, \"device_wait_us_per_query\": %.1f}\n",
+           (unsigned long long)n_docs, n_words, n_terms, n_threads, all.size(), nq / dt, all[all.size() / 2],
+           all[(size_t)(all.size() * 0.99)], tot[0] / nq, tot[1] / nq, tot[2] / nq, tot[3] / nq, tot[7] / nq, tot[8] / nq);
+    fflush(stdout);
+    for (auto &p : pools) msi_bits_destroy(p);
+  }
+  msi_dict_destroy(dict);
+  msi_ctx_destroy(ctx);
+  return 0;
+}
