@@ -49,7 +49,7 @@ namespace {
 
 constexpr int SCAN_WAVES = 8;            // waves per workgroup (512 threads)
 constexpr int SCAN_GROUP = 8;            // KiB blocks per software-pipeline stage
-constexpr uint32_t KP_MAX = 1024;        // K' supported by select/rescore
+constexpr uint32_t KP_MAX = 2048;        // K' supported by select/rescore (k <= 2048; k + max(12, k/4) candidates are rescored)
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_SORTCAP = 2048;        // u64 keys sorted in LDS by vs_select
 constexpr int QT = 16;                   // queries per MFMA tile

@@ -73,7 +73,7 @@ def test_large_k_and_k_above_store_size(ctx, oracle):
     st = ma.GpuStore(ctx, 48)
     st.upload(ids, rows)
     qs = synth.make_embeddings(3, 48, seed=72)
-    check_against_oracle(oracle, st, rows, ids, qs, 1000)          # K' clamps at 1024
+    check_against_oracle(oracle, st, rows, ids, qs, 1000)          # K' = 1250
     small = ma.GpuStore(ctx, 48)
     small.upload(ids[:13], rows[:13])
     d, s, c = small.search(qs, 50)                                  # fewer rows than k
