@@ -494,7 +494,8 @@ int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtabl
  * union, intersection, difference, cardinality, ordered extraction — is a device kernel.
  * Not handled: negative words, distinct, pins, ranking score threshold, deadline.
  * The tokenizer stays with the caller: it hands over the located terms of
- * located_query_terms_from_tokens (parse_query.rs:28-202).
+ * located_query_terms_from_tokens (parse_query.rs:28-202); stop words are its business (dropped, or empty
+ * tokens inside a phrase); n_terms = 0 (only stop words) is a placeholder search: the universe in docid order.
  */
 enum {
   MSI_CRIT_WORDS = 0, MSI_CRIT_TYPO = 1, MSI_CRIT_PROXIMITY = 2, MSI_CRIT_ATTRIBUTE = 3,

@@ -1769,6 +1769,22 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   } else {
     universe = c.dev.ones();
   }
+  if (n_terms == 0) {
+    // only stop words (or nothing) survived the tokenizer: a placeholder search — no keyword rule applies
+    // (mod.rs:770-800), the universe in ascending docid order
+    const uint64_t count = c.dev.count(universe);
+    if (out_candidates) *out_candidates = count;
+    *out_n = 0;
+    if (count < p->from || p->length == 0) return;
+    auto ids = c.dev.first_k(universe, p->from + p->length);
+    uint32_t n = 0;
+    for (size_t i = p->from; i < ids.size(); ++i) {
+      out_docids[n] = ids[i];
+      out_n_scores[n++] = 0;
+    }
+    *out_n = n;
+    return;
+  }
   {
     Graph reduced = g;
     if (p->strategy == MSI_TERMS_LAST) {
@@ -1888,10 +1904,6 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
   }
   *out_n = 0;
   if (out_candidates) *out_candidates = 0;
-  if (n_terms == 0) {
-    msi_set_error("msi_keyword_search_ranked: no query term (placeholder search is not a keyword search)");
-    return MSI_E_INVALID;
-  }
   g_stats = Stats();
   Clock total;
   try {

@@ -1046,7 +1046,7 @@ def parse_query(ctx, query, words_limit=10):
     """-> [(term_index, positions)]: words, "quoted phrases"; the last word is a prefix when the query does not
     end with a separator.  Negative operators are not restated."""
     import re
-    toks = re.findall(r"[0-9a-zà-öø-ÿ]+|[^0-9a-zà-öø-ÿ]+", query.lower())
+    toks = re.findall(r"[0-9a-zA-Zà-öø-ÿÀ-ÖØ-ß]+|[^0-9a-zA-Zà-öø-ÿÀ-ÖØ-ß]+", query)
     terms, phrase, position = [], None, -1
 
     def close_phrase(ph):
@@ -1054,17 +1054,24 @@ def parse_query(ctx, query, words_limit=10):
             words = tuple(w for w, _ in ph)
             t = QueryTerm(" ".join(w for w in words if w is not None), 0, False, phrase=words)
             t.one_typo, t.two_typos, t.computed = [], [], True
-            terms.append((ctx.push(t), (ph[0][1], ph[-1][1])))
+            # PhraseBuilder::push_word (parse_query.rs:318-335): `start` follows the pushes until the first
+            # non-stop word, so leading stop words are outside the positions but inside `words`
+            start = next(p_ for w, p_ in ph if w is not None)
+            terms.append((ctx.push(t), (start, ph[-1][1])))
 
     for k, tok in enumerate(toks):
         if len(terms) >= words_limit:
             break
-        if re.match(r"[0-9a-zà-öø-ÿ]", tok):
+        if re.match(r"[0-9a-zA-Zà-öø-ÿÀ-ÖØ-ß]", tok):
             position += 1
+            stop = tok in getattr(ctx.index, "stop_words", ())     # on the token as written (case sensitive)
+            tok = tok.lower()
             if phrase is not None:
-                phrase.append((tok, position))
+                phrase.append((None if stop else tok, position))
             else:
                 last = k == len(toks) - 1
+                if stop and not last:
+                    continue                 # TokenKind::StopWord in the middle of the query: no term
                 t = ctx.term_from_word(tok, ctx.index.budget(tok), last, False)
                 terms.append((ctx.push(t), (position, position)))
         else:
@@ -1091,8 +1098,10 @@ def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=
     """execute_search, mod.rs:808-880 for a keyword query."""
     index = ctx.index
     terms = parse_query(ctx, query)
-    graph = QueryGraph.from_query(ctx, terms)
     universe = index.all_docids() if universe is None else set(universe)
+    if not terms:          # only stop words: a placeholder search (no keyword rule applies), mod.rs:770-800
+        return bucket_sort(ctx, [], None, universe, offset, length, detailed)
+    graph = QueryGraph.from_query(ctx, terms)
     rules = ranking_rules(criteria if criteria is not None else index.criteria, tms)
     reduced = graph.clone()
     if tms == "last":

@@ -14,7 +14,7 @@ import re
 REF = "/root/reference/crates/milli/src/search/new/tests"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ranking_snapshots.json")
 FILES = ["proximity", "attribute_fid", "word_position", "exactness", "words_tms", "typo_proximity",
-         "proximity_typo", "ngram_split_words", "typo"]
+         "proximity_typo", "ngram_split_words", "typo", "stop_words"]
 CRIT = {"Words": "words", "Typo": "typo", "Proximity": "proximity", "Attribute": "attribute",
         "AttributeRank": "attributeRank", "WordPosition": "wordPosition", "Exactness": "exactness", "Sort": "sort"}
 
@@ -107,12 +107,15 @@ def parse_settings(body, cfg):
     m = re.search(r"set_min_word_len_two_typos\((\d+)\)", body)
     if m:
         cfg["min_two"] = int(m.group(1))
+    m = re.search(r"set_stop_words\(BTreeSet::from_iter\(\[(.*?)\]\)\)", body, re.S)
+    if m:
+        cfg["stop_words"] = re.findall(r'"([^"]+)"', m.group(1))
     syn = {}
     for m in re.finditer(r'\w+\.insert\("([^"]+)"\.to_owned\(\),\s*vec!\[(.*?)\]\)', body, re.S):
         syn[m.group(1)] = re.findall(r'"([^"]+)"', m.group(2))
     if syn and "set_synonyms" in body:
         cfg["synonyms"] = syn
-    for feat in ("set_stop_words", "set_dictionary", "set_separator_tokens", "set_proximity_precision",
+    for feat in ("set_dictionary", "set_separator_tokens", "set_proximity_precision",
                  "set_searchable_fields(vec![])", "set_distinct_field", "set_sortable"):
         if feat in body:
             cfg.setdefault("unsupported", []).append(feat)

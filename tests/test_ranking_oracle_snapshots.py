@@ -31,7 +31,8 @@ def build_index(cfg):
     return ToyMilli(cfg["docs"], searchable=cfg.get("searchable"), exact_attributes=cfg.get("exact_attributes", ()),
                     exact_words=cfg.get("exact_words", ()), criteria=cfg.get("criteria"),
                     min_one=cfg.get("min_one", 5), min_two=cfg.get("min_two", 9),
-                    authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"))
+                    authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"),
+                    stop_words=cfg.get("stop_words", ()))
 
 
 def debug_score(s):

@@ -30,7 +30,7 @@ class Harness:
         from tests.toy_milli import query_terms
         R, ix = self.R, self.index
         return R.keyword_search_ranked(
-            self.dict, self.pool, self.cb, query_terms(query), criteria if criteria is not None else ix.criteria,
+            self.dict, self.pool, self.cb, query_terms(query, stop_words=ix.stop_words), criteria if criteria is not None else ix.criteria,
             strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
             searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
             max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two)
@@ -54,7 +54,8 @@ def build_index(cfg):
     return ToyMilli(cfg["docs"], searchable=cfg.get("searchable"), exact_attributes=cfg.get("exact_attributes", ()),
                     exact_words=cfg.get("exact_words", ()), criteria=cfg.get("criteria"),
                     min_one=cfg.get("min_one", 5), min_two=cfg.get("min_two", 9),
-                    authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"))
+                    authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"),
+                    stop_words=cfg.get("stop_words", ()))
 
 
 _H = {}

@@ -24,9 +24,10 @@ INDEX_MAX_DISTANCE = 8      # tokenize_document.rs:13
 MAX_DISTANCE = 4            # proximity.rs:7
 
 
-def tokenize_with_positions(text, start=0):
-    """[(word, position)]: process_tokens, tokenize_document.rs:131-157."""
-    text = text.lower()
+def tokenize_with_positions(text, start=0, stop_words=()):
+    """[(word, position)]: process_tokens, tokenize_document.rs:131-157.  Stop words (matched on the token as
+    written: "The" is not "the", stop_words.rs:5) keep their position but are dropped."""
+    raw, text = text, text.lower()
     out, pos, prev_end, first = [], start, 0, True
     for m in WORD_RE.finditer(text):
         sep = text[prev_end:m.start()]
@@ -35,16 +36,19 @@ def tokenize_with_positions(text, start=0):
         else:
             hard = bool(HARD_RE.search(sep))
             pos += INDEX_MAX_DISTANCE if hard else 1
-        out.append((m.group(0), pos))
+        if raw[m.start():m.end()] not in stop_words:
+            out.append((m.group(0), pos))
         prev_end = m.end()
     return out
 
 
 class ToyMilli:
     def __init__(self, docs, searchable=None, exact_attributes=(), exact_words=(), criteria=None,
-                 min_one=5, min_two=9, authorize_typos=True, primary_key="id", prefix_threshold=100, synonyms=None):
+                 min_one=5, min_two=9, authorize_typos=True, primary_key="id", prefix_threshold=100, synonyms=None,
+                 stop_words=()):
         self.min_one, self.min_two, self.authorize_typos = min_one, min_two, authorize_typos
         self.exact_words = set(exact_words)
+        self.stop_words = set(stop_words)      # case sensitive, compared with the token as written
         # index.synonyms: normalised key words -> synonym phrases as word lists (settings: "a b" -> ["c d", ...])
         self.synonyms = {tuple(WORD_RE.findall(k.lower())): [WORD_RE.findall(v.lower()) for v in vs]
                          for k, vs in (synonyms or {}).items()}
@@ -84,7 +88,7 @@ class ToyMilli:
                 if name not in d or not isinstance(d[name], (str, int, float)) or isinstance(d[name], bool):
                     continue
                 fid = self.fields[name]
-                toks = tokenize_with_positions(str(d[name]))
+                toks = tokenize_with_positions(str(d[name]), stop_words=self.stop_words)
                 toks = [(w, p) for w, p in toks if p < MAX_POSITION_PER_ATTRIBUTE]
                 target = self.exact_word_docids if name in exact_attr else self.word_docids
                 for w, p in toks:
@@ -270,29 +274,35 @@ class ToyMilli:
                 if p_ == prox and a == w1 and b.startswith(pfx2) and s_]
 
 
+TOKEN_RE_CS = re.compile(r"[0-9a-zA-Zà-öø-ÿÀ-ÖØ-ß]+|[^0-9a-zA-Zà-öø-ÿÀ-ÖØ-ß]+")
 TOKEN_RE = re.compile(r"[0-9a-zà-öø-ÿ]+|[^0-9a-zà-öø-ÿ]+")
 
 
-def query_terms(query, words_limit=10):
+def query_terms(query, words_limit=10, stop_words=()):
     """The located terms of located_query_terms_from_tokens (parse_query.rs:28-202) for the Latin subset of
     charabia: [(words, is_phrase, position_start, position_end, is_prefix)] — what the Rust shim hands to
     msi_keyword_search_ranked.  Negative operators are not modelled."""
-    toks = TOKEN_RE.findall(query.lower())
+    toks = TOKEN_RE_CS.findall(query)
     terms, phrase, position = [], None, -1
 
     def close(ph):
-        if ph:
-            terms.append(([w for w, _ in ph], True, ph[0][1], ph[-1][1], False))
+        if ph and any(w is not None for w, _ in ph):
+            start = next(p_ for w, p_ in ph if w is not None)     # PhraseBuilder::push_word, parse_query.rs:318-335
+            terms.append(([w for w, _ in ph], True, start, ph[-1][1], False))
 
     for k, tok in enumerate(toks):
         if len(terms) >= words_limit:
             break
-        if WORD_RE.match(tok):
+        if WORD_RE.match(tok.lower()):
             position += 1
+            stop = tok in stop_words
+            tok = tok.lower()
             if phrase is not None:
-                phrase.append((tok, position))
-            else:
-                terms.append(([tok], False, position, position, k == len(toks) - 1))
+                phrase.append((None if stop else tok, position))
+            elif k == len(toks) - 1:
+                terms.append(([tok], False, position, position, True))      # the last word is kept even if a stop word
+            elif not stop:
+                terms.append(([tok], False, position, position, False))
         else:
             if HARD_RE.search(tok):
                 position += 7
