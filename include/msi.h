@@ -492,7 +492,7 @@ int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtabl
  * (compute_phrase_docids, resolve_query_graph.rs:187-268).  The control flow (small graphs) runs on the
  * caller's thread; every docid set lives in the msi_bits pool and every set operation — posting decode,
  * union, intersection, difference, cardinality, ordered extraction — is a device kernel.
- * Not handled: negative words, distinct, pins, ranking score threshold, deadline.
+ * Not handled: distinct, pins, ranking score threshold, deadline.
  * The tokenizer stays with the caller: it hands over the located terms of
  * located_query_terms_from_tokens (parse_query.rs:28-202); stop words are its business (dropped, or empty
  * tokens inside a phrase); n_terms = 0 (only stop words) is a placeholder search: the universe in docid order.
@@ -517,9 +517,12 @@ typedef struct msi_score_detail {
 typedef struct msi_located_term {
   const msi_query_token *words; /* one word, or the words of a quoted phrase (len 0 = a stop word) */
   uint32_t n_words;
-  uint32_t is_phrase;
+  uint32_t is_phrase;   /* bit 0: quoted phrase; bit 1 (MSI_TERM_NEGATIVE): `-word` / `-"phrase"` — its documents are
+                         * removed from the universe (search/mod.rs:431-440) and it is no term of the query graph */
   uint32_t position_start, position_end; /* parse_query.rs:60-120: +1 per word, +7 more over a hard separator */
 } msi_located_term;
+#define MSI_TERM_PHRASE 1u
+#define MSI_TERM_NEGATIVE 2u
 typedef struct msi_search_params {
   uint32_t authorize_typos, min_word_len_one_typo, min_word_len_two_typos;
   int32_t strategy;                    /* MSI_TERMS_LAST | MSI_TERMS_ALL */

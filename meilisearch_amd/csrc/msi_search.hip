@@ -1707,10 +1707,15 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   const msi_search_params *p = c.prm;
   // ---- located terms -> terms -----------------------------------------------------------------
   std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> ts;  // (term, positions)
+  std::vector<uint32_t> negatives;
   for (uint32_t i = 0; i < n_terms; ++i) {
     const msi_located_term &l = lt[i];
     if (!l.words || l.n_words == 0) fail(MSI_E_INVALID, "a located term has no word");
-    if (l.is_phrase) {
+    if (l.is_phrase & MSI_TERM_NEGATIVE) {
+      negatives.push_back(i);
+      continue;
+    }
+    if (l.is_phrase & MSI_TERM_PHRASE) {
       Phrase ph;
       std::string desc;
       for (uint32_t k = 0; k < l.n_words; ++k) {
@@ -1769,7 +1774,19 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   } else {
     universe = c.dev.ones();
   }
-  if (n_terms == 0) {
+  // resolve_negative_words / resolve_negative_phrases (mod.rs:323-351), applied by Search::execute (mod.rs:431-440)
+  for (uint32_t i : negatives) {
+    const msi_located_term &l = lt[i];
+    if (l.is_phrase & MSI_TERM_PHRASE) {
+      Phrase ph;
+      for (uint32_t k = 0; k < l.n_words; ++k)
+        ph.push_back(l.words[k].len ? (int32_t)c.word(std::string((const char *)l.words[k].word, l.words[k].len)) : -1);
+      c.dev.sub_(universe, c.phrase_docids(c.phrase(ph)));
+    } else {
+      c.dev.sub_(universe, c.word_full(c.word(std::string((const char *)l.words[0].word, l.words[0].len)), true));
+    }
+  }
+  if (ts.empty()) {
     // only stop words (or nothing) survived the tokenizer: a placeholder search — no keyword rule applies
     // (mod.rs:770-800), the universe in ascending docid order
     const uint64_t count = c.dev.count(universe);

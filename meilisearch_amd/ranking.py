@@ -298,12 +298,14 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
                           authorize_typos=True, min_one=5, min_two=9, universe_cbo=None):
     """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
     terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
-    (words: [str | None], None = a stop word inside a phrase).
+    (words: [str | None], None = a stop word inside a phrase; an optional 6th element True marks a negative term).
     -> ([(docid, [(kind name, a, b)])], candidates)."""
     n = len(terms)
     lt = (LocatedTerm * max(n, 1))()
     keep = []
-    for i, (words, is_phrase, ps, pe, is_prefix) in enumerate(terms):
+    for i, term in enumerate(terms):
+        words, is_phrase, ps, pe, is_prefix = term[:5]
+        negative = len(term) > 5 and term[5]
         toks = (QueryToken * len(words))()
         for k, w in enumerate(words):
             b = (w or "").encode("utf-8")
@@ -315,7 +317,7 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
         keep.append(toks)
         lt[i].words = C.cast(toks, C.c_void_p)
         lt[i].n_words = len(words)
-        lt[i].is_phrase = 1 if is_phrase else 0
+        lt[i].is_phrase = (1 if is_phrase else 0) | (2 if negative else 0)
         lt[i].position_start, lt[i].position_end = ps, pe
     crit = np.array([CRITERIA[c] for c in criteria], dtype=np.int32)
     fids = np.array(list(searchable_fids), dtype=np.uint16)

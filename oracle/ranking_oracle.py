@@ -1094,11 +1094,17 @@ def parse_query(ctx, query, words_limit=10):
     return terms
 
 
-def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=False, universe=None):
-    """execute_search, mod.rs:808-880 for a keyword query."""
+def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=False, universe=None, negatives=()):
+    """execute_search, mod.rs:808-880 for a keyword query.  negatives: [word | (phrase words…)] whose documents
+    Search::execute removes from the universe first (search/mod.rs:431-440, new/mod.rs:323-351)."""
     index = ctx.index
     terms = parse_query(ctx, query)
     universe = index.all_docids() if universe is None else set(universe)
+    for neg in negatives:
+        if isinstance(neg, str):
+            universe -= ctx.word_docids(None, neg, True) or set()
+        else:
+            universe -= ctx.phrase_docids(tuple(neg))
     if not terms:          # only stop words: a placeholder search (no keyword rule applies), mod.rs:770-800
         return bucket_sort(ctx, [], None, universe, offset, length, detailed)
     graph = QueryGraph.from_query(ctx, terms)

@@ -180,3 +180,29 @@ def test_concurrent_searches_on_private_streams():
     for t in ths:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_negative_words_and_phrases():
+    """`-word` / `-"a phrase"`: their documents leave the universe before anything else (search/mod.rs:431-440)."""
+    from oracle import oracle as O
+    from oracle import ranking_oracle as RO
+    from tests.toy_milli import ToyMilli, query_terms
+    index = ToyMilli(random_corpus(11, 300), searchable=["title", "body"])
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    h = Harness(index)
+    R = h.R
+    for q, negs in (("the quick fox", ["brown"]), ("sun flower", [("lazy", "dog")]), ("dog", ["the", ("quick", "brown")])):
+        want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms="last", detailed=True, negatives=negs)
+        terms = query_terms(q)
+        for ng in negs:
+            terms.append(([ng], False, 0, 0, False, True) if isinstance(ng, str) else (list(ng), True, 0, 0, False, True))
+        hits, cand = R.keyword_search_ranked(h.dict, h.pool, h.cb, terms, index.criteria, detailed=True,
+                                             searchable_fids=index.searchable_fids,
+                                             searchable_weights=[index.weights[f] for f in index.searchable_fids],
+                                             max_weight=index.max_weight)
+        assert [d for d, _ in hits] == want_ids and cand == len(want_cand)
+        assert want_ids, "the case should keep some documents"
