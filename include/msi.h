@@ -492,7 +492,7 @@ int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtabl
  * (compute_phrase_docids, resolve_query_graph.rs:187-268).  The control flow (small graphs) runs on the
  * caller's thread; every docid set lives in the msi_bits pool and every set operation — posting decode,
  * union, intersection, difference, cardinality, ordered extraction — is a device kernel.
- * Not handled: distinct, pins, ranking score threshold, deadline.
+ * Not handled: distinct, pins, ranking score threshold.
  * The tokenizer stays with the caller: it hands over the located terms of
  * located_query_terms_from_tokens (parse_query.rs:28-202); stop words are its business (dropped, or empty
  * tokens inside a phrase); n_terms = 0 (only stop words) is a placeholder search: the universe in docid order.
@@ -508,7 +508,8 @@ enum { /* ScoreDetails variants, score_details.rs:10-27 */
   MSI_SCORE_FID = 3,             /* a = rank, b = max_rank */
   MSI_SCORE_POSITION = 4,        /* a = rank, b = max_rank */
   MSI_SCORE_EXACT_ATTRIBUTE = 5, /* a = 3 ExactMatch | 2 MatchesStart | 1 NoExactMatch, b = 3 */
-  MSI_SCORE_EXACT_WORDS = 6      /* a = matching_words, b = max_matching_words */
+  MSI_SCORE_EXACT_WORDS = 6,     /* a = matching_words, b = max_matching_words */
+  MSI_SCORE_SKIPPED = 7          /* the deadline cut the ranking short here; rank 0 of 1 */
 };
 #define MSI_MAX_SCORE_DETAILS 8
 typedef struct msi_score_detail {
@@ -534,6 +535,13 @@ typedef struct msi_search_params {
   int32_t max_weight;                  /* max_searchable_attribute_weight, -1 = None (index.rs:689-698) */
   uint32_t from, length;
   int32_t detailed_scores;             /* ScoringStrategy::Detailed (else Skip) */
+  /* The search cutoff (Deadline, lib.rs:150-231; bucket_sort.rs:206-264): once the budget is spent, what is
+   * left of every rule's universe is returned unranked with a Skipped score detail and *out_degraded = 1.
+   * time_budget_us: 0 = none.  stop_after: >= 0 = "exceeded from the (n+1)-th check on" (the reference's test
+   * hook Deadline::with_stop_after, which then ignores the time budget), -1 = off. */
+  uint64_t time_budget_us;
+  int32_t stop_after;
+  int32_t _pad;
 } msi_search_params;
 /* out_scores: [length][MSI_MAX_SCORE_DETAILS], out_n_scores: [length].  The pool needs at least 64 free
  * slots above slot 0 (more for long queries: one per live condition of every active rule). */
@@ -541,7 +549,8 @@ int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, const msi_inde
                                   const msi_located_term *terms, uint32_t n_terms,
                                   const msi_search_params *params, const uint8_t *universe_cbo,
                                   size_t universe_len, uint32_t *out_docids, msi_score_detail *out_scores,
-                                  uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates);
+                                  uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates,
+                                  int32_t *out_degraded /* nullable */);
 
 /* ScoreDetails::global_score over the details of one hit (score_details.rs:123-154, ranks per variant
  * :103-121: Typo -> (max_typo_count + 1 - typo_count, max_typo_count + 1), ExactWords -> (matching + 1, max + 1),

@@ -96,7 +96,8 @@ class SearchParams(C.Structure):
                 ("min_word_len_two_typos", C.c_uint32), ("strategy", C.c_int32), ("criteria", C.c_void_p),
                 ("n_criteria", C.c_uint32), ("searchable_fids", C.c_void_p), ("searchable_weights", C.c_void_p),
                 ("n_searchable", C.c_uint32), ("max_weight", C.c_int32), ("from_", C.c_uint32),
-                ("length", C.c_uint32), ("detailed_scores", C.c_int32)]
+                ("length", C.c_uint32), ("detailed_scores", C.c_int32), ("time_budget_us", C.c_uint64),
+                ("stop_after", C.c_int32), ("_pad", C.c_int32)]
 
 
 class QueryToken(C.Structure):
@@ -195,7 +196,7 @@ PROTOTYPES = {
                                   C.POINTER(_U32), C.POINTER(_U64)]),
     "msi_keyword_search_ranked": (_I32, [_VP, _VP, C.POINTER(IndexVtable), C.POINTER(LocatedTerm), _U32,
                                          C.POINTER(SearchParams), _VP, C.c_size_t, _VP, _VP, _VP,
-                                         C.POINTER(_U32), C.POINTER(_U64)]),
+                                         C.POINTER(_U32), C.POINTER(_U64), C.POINTER(_I32)]),
     "msi_search_last_stats": (_I32, [C.POINTER(_U64)]),
     "msi_score_details_global_score": (_F64, [_VP, _U32]),
     "msi_distribution_shift": (_F32, [_F32, _F32, _F32]),

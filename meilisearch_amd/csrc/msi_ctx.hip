@@ -182,6 +182,10 @@ double msi_score_details_global_score(const msi_score_detail *details, uint32_t 
         r = details[i].a + 1;
         m = details[i].b + 1;
         break;
+      case MSI_SCORE_SKIPPED:  // score_details.rs:118
+        r = 0;
+        m = 1;
+        break;
       default:
         r = details[i].a;
         m = details[i].b;

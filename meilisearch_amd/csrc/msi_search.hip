@@ -1703,7 +1703,14 @@ int32_t make_ngram(Ctx &c, const std::vector<std::pair<uint32_t, std::pair<uint3
 
 void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t *universe_cbo, size_t universe_len,
             uint32_t *out_docids, msi_score_detail *out_scores, uint32_t *out_n_scores, uint32_t *out_n,
-            uint64_t *out_candidates) {
+            uint64_t *out_candidates, int32_t *out_degraded) {
+  const Clock started;
+  uint32_t deadline_checks = 0;
+  auto deadline_exceeded = [&]() {  // Deadline::exceeded, lib.rs:211-226
+    const msi_search_params *q = c.prm;
+    if (q->stop_after >= 0) return deadline_checks++ >= (uint32_t)q->stop_after;
+    return q->time_budget_us != 0 && started.ms() * 1e3 > (double)q->time_budget_us;
+  };
   const msi_search_params *p = c.prm;
   // ---- located terms -> terms -----------------------------------------------------------------
   std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> ts;  // (term, positions)
@@ -1879,6 +1886,25 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       if (!back()) break;
       continue;
     }
+    if (deadline_exceeded()) {
+      // graph-based rules never answer non_blocking_next_bucket (ranking_rules.rs:67-74): what is left of every
+      // universe on the stack goes out unranked under a Skipped detail (bucket_sort.rs:206-264)
+      for (;;) {
+        scores.push_back(Score{MSI_SCORE_SKIPPED, 0, 1});
+        add(unis[cur], uni_counts[cur]);
+        scores.pop_back();
+        unis[cur].reset();
+        uni_counts[cur] = 0;
+        if (cur == 0) {
+          if (out_degraded) *out_degraded = 1;
+          *out_n = n_out;
+          return;
+        }
+        rules[cur]->end();
+        --cur;
+        if (scores.size() > cur) scores.pop_back();
+      }
+    }
     Bucket b;
     if (!rules[cur]->next(c, unis[cur], uni_counts[cur], b)) {
       if (!back()) break;
@@ -1907,7 +1933,8 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
                                              const msi_located_term *terms, uint32_t n_terms,
                                              const msi_search_params *params, const uint8_t *universe_cbo,
                                              size_t universe_len, uint32_t *out_docids, msi_score_detail *out_scores,
-                                             uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates) {
+                                             uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates,
+                                             int32_t *out_degraded) {
   if (!dict || !pool || !index || !index->word_docids || !params || !out_n || (n_terms && !terms) ||
       n_terms > MSI_RANK_MAX_TERMS || (params->length && (!out_docids || !out_scores || !out_n_scores)) ||
       (params->n_criteria && !params->criteria) ||
@@ -1921,11 +1948,13 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
   }
   *out_n = 0;
   if (out_candidates) *out_candidates = 0;
+  if (out_degraded) *out_degraded = 0;
   g_stats = Stats();
   Clock total;
   try {
     Ctx c(dict, pool, index, params);
-    search(c, terms, n_terms, universe_cbo, universe_len, out_docids, out_scores, out_n_scores, out_n, out_candidates);
+    search(c, terms, n_terms, universe_cbo, universe_len, out_docids, out_scores, out_n_scores, out_n, out_candidates,
+           out_degraded);
     g_stats.total_ms = total.ms();
     return MSI_OK;
   } catch (const Fail &f) {

@@ -289,13 +289,14 @@ def keyword_search(gdict, pool, callbacks, words, last_is_prefix=True, strategy=
 
 CRITERIA = {"words": 0, "typo": 1, "proximity": 2, "attribute": 3, "attributeRank": 4, "wordPosition": 5,
             "exactness": 6, "sort": 7}
-SCORE_KINDS = ["Words", "Typo", "Proximity", "Fid", "Position", "ExactAttribute", "ExactWords"]
+SCORE_KINDS = ["Words", "Typo", "Proximity", "Fid", "Position", "ExactAttribute", "ExactWords", "Skipped"]
 MAX_SCORE_DETAILS = 8
 
 
 def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERMS_LAST, offset=0, limit=20,
                           detailed=False, searchable_fids=(), searchable_weights=(), max_weight=None,
-                          authorize_typos=True, min_one=5, min_two=9, universe_cbo=None):
+                          authorize_typos=True, min_one=5, min_two=9, universe_cbo=None, time_budget_us=0,
+                          stop_after=None, return_degraded=False):
     """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
     terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
     (words: [str | None], None = a stop word inside a phrase; an optional 6th element True marks a negative term).
@@ -324,22 +325,25 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
     wts = np.array(list(searchable_weights), dtype=np.uint16)
     prm = SearchParams(1 if authorize_typos else 0, min_one, min_two, strategy, np_ptr(crit) if crit.size else None,
                        crit.size, np_ptr(fids) if fids.size else None, np_ptr(wts) if wts.size else None, fids.size,
-                       -1 if max_weight is None else int(max_weight), offset, limit, 1 if detailed else 0)
+                       -1 if max_weight is None else int(max_weight), offset, limit, 1 if detailed else 0,
+                       int(time_budget_us), -1 if stop_after is None else int(stop_after), 0)
     L = max(limit, 1)
     ids = np.zeros(L, dtype=np.uint32)
     sc = (ScoreDetail * (L * MAX_SCORE_DETAILS))()
     nsc = np.zeros(L, dtype=np.uint32)
-    out_n, cand = C.c_uint32(0), C.c_uint64(0)
+    out_n, cand, degraded = C.c_uint32(0), C.c_uint64(0), C.c_int32(0)
     ub = np.frombuffer(universe_cbo, dtype=np.uint8) if universe_cbo is not None else None
     check(lib().msi_keyword_search_ranked(gdict._h, pool._h, C.byref(callbacks.vtable), lt, n, C.byref(prm),
                                           np_ptr(ub) if ub is not None else None, 0 if ub is None else ub.size,
                                           np_ptr(ids), C.cast(sc, C.c_void_p), np_ptr(nsc), C.byref(out_n),
-                                          C.byref(cand)))
+                                          C.byref(cand), C.byref(degraded)))
     hits = []
     for i in range(out_n.value):
         det = [(SCORE_KINDS[sc[i * MAX_SCORE_DETAILS + k].kind], int(sc[i * MAX_SCORE_DETAILS + k].a),
                 int(sc[i * MAX_SCORE_DETAILS + k].b)) for k in range(int(nsc[i]))]
         hits.append((int(ids[i]), det))
+    if return_degraded:
+        return hits, int(cand.value), bool(degraded.value)
     return hits, int(cand.value)
 
 

@@ -703,6 +703,8 @@ def rank_to_score(kind, rank, max_rank):
 def score_rank(score):
     """ScoreDetails::rank, score_details.rs:103-121."""
     k = score[0]
+    if k == "Skipped":
+        return (0, 1)
     if k == "Typo":
         return (max(0, score[2] + 1 - score[1]), score[2] + 1)
     if k == "ExactWords":
@@ -975,9 +977,26 @@ def ranking_rules(criteria, tms):
     return rules
 
 
-def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False):
-    """bucket_sort.rs:23-343 without distinct, pins, deadline and score threshold.
-    -> (docids, [score details per hit], all_candidates)."""
+class Deadline:
+    """lib.rs:150-231: `stop_after = n` makes exceeded() true from the (n+1)-th call on (the reference's test hook);
+    None = never."""
+
+    def __init__(self, stop_after=None):
+        self.stop_after, self.calls = stop_after, 0
+
+    def exceeded(self):
+        if self.stop_after is None:
+            return False
+        self.calls += 1
+        return self.calls > self.stop_after
+
+
+def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, deadline=None):
+    """bucket_sort.rs:23-343 without distinct, pins and score threshold.
+    -> (docids, [score details per hit], all_candidates); `bucket_sort.degraded` tells whether the deadline cut
+    the last call short (graph-based rules never answer non_blocking_next_bucket: ranking_rules.rs:67-74)."""
+    deadline = deadline or Deadline()
+    bucket_sort.degraded = False
     universe = set(universe)
     if len(universe) < offset:
         return [], [], universe
@@ -1018,6 +1037,19 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False):
             if len(scores) > cur:
                 scores.pop()
             continue
+        if deadline.exceeded():
+            # every rule from here up is `Pending`: what is left of each universe goes out unranked (Skipped)
+            while True:
+                b, unis[cur] = unis[cur], set()
+                scores.append(("Skipped",))
+                add(b)
+                scores.pop()
+                if cur == 0:
+                    bucket_sort.degraded = True
+                    return out_ids, out_scores, all_cand
+                cur -= 1
+                if len(scores) > cur:
+                    scores.pop()
         nb = rules[cur].next_bucket(unis[cur])
         if nb is None:
             unis[cur] = set()
@@ -1094,7 +1126,8 @@ def parse_query(ctx, query, words_limit=10):
     return terms
 
 
-def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=False, universe=None, negatives=()):
+def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=False, universe=None, negatives=(),
+           stop_after=None):
     """execute_search, mod.rs:808-880 for a keyword query.  negatives: [word | (phrase words…)] whose documents
     Search::execute removes from the universe first (search/mod.rs:431-440, new/mod.rs:323-351)."""
     index = ctx.index
@@ -1113,4 +1146,4 @@ def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=
     if tms == "last":
         reduced.remove_nodes_keep_edges([n for ns in graph.removal_order_last(ctx) for n in sorted(ns)])
     universe &= query_graph_docids(ctx, reduced, universe)
-    return bucket_sort(ctx, rules, graph, universe, offset, length, detailed)
+    return bucket_sort(ctx, rules, graph, universe, offset, length, detailed, Deadline(stop_after))

@@ -85,6 +85,7 @@ pub struct msi_search_params {
     pub criteria: *const i32, pub n_criteria: u32,
     pub searchable_fids: *const u16, pub searchable_weights: *const u16, pub n_searchable: u32,
     pub max_weight: i32, pub from: u32, pub length: u32, pub detailed_scores: i32,
+    pub time_budget_us: u64, pub stop_after: i32, pub _pad: i32,
 }
 
 extern "C" {
@@ -155,7 +156,7 @@ extern "C" {
                                      terms: *const msi_located_term, n_terms: u32, params: *const msi_search_params,
                                      universe_cbo: *const u8, universe_len: usize, out_docids: *mut u32,
                                      out_scores: *mut msi_score_detail, out_n_scores: *mut u32, out_n: *mut u32,
-                                     out_candidates: *mut u64) -> i32;
+                                     out_candidates: *mut u64, out_degraded: *mut i32) -> i32;
     pub fn msi_score_details_global_score(details: *const msi_score_detail, n: u32) -> f64;
     pub fn msi_bits_use_private_stream(p: *mut msi_bits) -> i32;
     pub fn msi_bits_op_count(p: *mut msi_bits, dst: u32, a: u32, b: u32, op: i32, out_count: *mut u64) -> i32;

@@ -134,6 +134,31 @@ def unescape(s):
     return json.loads('"' + s + '"')
 
 
+def cutoff_cases(indexes, cases):
+    """cutoff.rs::degraded_search_and_score_details: the same search with Deadline::never().with_stop_after(n)."""
+    src = strip_comments(open(f"{REF}/cutoff.rs").read())
+    fns = functions(src)
+    cfg = {"docs": parse_documents(fns["create_index"])}
+    parse_settings(fns["create_index"], cfg)
+    cfg.pop("unsupported", None)
+    indexes["cutoff::create_index"] = cfg
+    body = fns["degraded_search_and_score_details"]
+    parts = re.split(r"search\.deadline\(", body)
+    for part in parts[1:]:
+        m = re.match(r"Deadline::never\(\)(?:\.with_stop_after\((\d+)\))?", part)
+        snap = re.search(r'snapshot!\(.*?@r#*"(.*?)"#*\);', part, re.S)
+        if not m or not snap:
+            continue
+        text = snap.group(1)
+        ids = json.loads(re.search(r"IDs: (\[[^\]]*\])", text).group(1))
+        scores = re.search(r"Scores: ([0-9. ]+)", text).group(1).split()
+        details = text[text.index("Score Details:") + len("Score Details:"):]
+        cases.append({"src": "crates/milli/src/search/new/tests/cutoff.rs::degraded_search_and_score_details",
+                      "index": "cutoff::create_index", "query": "hello puppy kefir", "tms": "last", "detailed": True,
+                      "limit": 4, "offset": 0, "ids": ids, "scores": re.sub(r"\s+", "", details),
+                      "global_scores": scores, "stop_after": int(m.group(1)) if m.group(1) else None})
+
+
 def main():
     indexes, cases = {}, []
     for mod in FILES:
@@ -216,6 +241,7 @@ def main():
                 if case["index"] not in indexes:
                     indexes[case["index"]] = cfg
                 cases.append(case)
+    cutoff_cases(indexes, cases)
     json.dump({"indexes": indexes, "cases": cases}, open(OUT, "w"), indent=0, ensure_ascii=False, sort_keys=True)
     print(len(indexes), "indexes,", len(cases), "cases ->", OUT, os.path.getsize(OUT), "bytes")
 

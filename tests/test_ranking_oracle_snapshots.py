@@ -46,6 +46,8 @@ def debug_score(s):
         return f"ExactWords(ExactWords{{matching_words:{s[1]},max_matching_words:{s[2]},}},)"
     if k == "ExactAttribute":
         return f"ExactAttribute({s[1]},)"
+    if k == "Skipped":
+        return "Skipped"
     return f"{k}(Rank{{rank:{s[1]},max_rank:{s[2]},}},)"
 
 
@@ -67,10 +69,12 @@ def test_reference_snapshot(case):
         pytest.skip("needs " + str(cfg.get("unsupported") or UNSUPPORTED[case["query"]]))
     index = build_index(cfg)
     ids, scores, _ = R.search(make_ctx(index), case["query"], tms=case["tms"], offset=case["offset"],
-                              length=case["limit"], detailed=case["detailed"])
+                              length=case["limit"], detailed=case["detailed"], stop_after=case.get("stop_after"))
     if case["ids"] is not None:
         assert ids == case["ids"]
     if case.get("scores"):
         assert debug_scores(scores) == case["scores"]
+    if case.get("global_scores"):
+        assert [f"{R.global_score(sc):.4f}" for sc in scores] == case["global_scores"]
     if case.get("ids_scores"):
         assert debug_ids_scores(ids, scores) == case["ids_scores"]

@@ -26,14 +26,15 @@ class Harness:
         self.pool = ma.BitsPool(self.ctx, max(index.n_docs, 1), n_slots)
         self.cb = R.IndexCallbacks(index)
 
-    def search(self, query, tms="last", criteria=None, offset=0, limit=20, detailed=False):
+    def search(self, query, tms="last", criteria=None, offset=0, limit=20, detailed=False, stop_after=None):
         from tests.toy_milli import query_terms
         R, ix = self.R, self.index
         return R.keyword_search_ranked(
             self.dict, self.pool, self.cb, query_terms(query, stop_words=ix.stop_words), criteria if criteria is not None else ix.criteria,
             strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
             searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
-            max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two)
+            max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,
+            stop_after=stop_after)
 
 
 def debug_score(s):
@@ -46,6 +47,8 @@ def debug_score(s):
         return f"ExactWords(ExactWords{{matching_words:{s[1]},max_matching_words:{s[2]},}},)"
     if k == "ExactAttribute":
         return "ExactAttribute(%s,)" % {3: "ExactMatch", 2: "MatchesStart", 1: "NoExactMatch"}[s[1]]
+    if k == "Skipped":
+        return "Skipped"
     return f"{k}(Rank{{rank:{s[1]},max_rank:{s[2]},}},)"
 
 
@@ -74,8 +77,10 @@ CASES = [c for c in FIX["cases"] if not FIX["indexes"][c["index"]].get("unsuppor
 def test_reference_snapshot(case):
     h = harness_for(case["index"])
     hits, _ = h.search(case["query"], tms=case["tms"], offset=case["offset"], limit=case["limit"],
-                       detailed=case["detailed"])
+                       detailed=case["detailed"], stop_after=case.get("stop_after"))
     ids = [d for d, _ in hits]
+    if case.get("global_scores"):
+        assert [f"{h.R.score_details_global_score(sc):.4f}" for _, sc in hits] == case["global_scores"]
     if case["ids"] is not None:
         assert ids == case["ids"]
     if case.get("scores"):

@@ -254,6 +254,7 @@ int main(int argc, char **argv) {
   prm.max_weight = 2;
   prm.from = 0;
   prm.length = 20;
+  prm.stop_after = -1;
 
   // the query set (shared by every configuration)
   std::vector<std::vector<std::string>> queries(64);
@@ -269,7 +270,7 @@ int main(int argc, char **argv) {
     uint32_t ids[20], nsc[20], n = 0;
     msi_score_detail sc[20 * MSI_MAX_SCORE_DETAILS];
     uint64_t cand = 0;
-    CK(msi_keyword_search_ranked(dict, pool, &vt, terms.data(), (uint32_t)terms.size(), &prm, nullptr, 0, ids, sc, nsc, &n, &cand));
+    CK(msi_keyword_search_ranked(dict, pool, &vt, terms.data(), (uint32_t)terms.size(), &prm, nullptr, 0, ids, sc, nsc, &n, &cand, nullptr));
     if (stats) msi_search_last_stats(stats);
     return n;
   };
