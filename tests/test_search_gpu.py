@@ -211,3 +211,44 @@ def test_negative_words_and_phrases():
                                              max_weight=index.max_weight)
         assert [d for d, _ in hits] == want_ids and cand == len(want_cand)
         assert want_ids, "the case should keep some documents"
+
+
+SETTINGS = [
+    dict(exact_attributes=["title"]),
+    dict(exact_words=["quick", "sunflower"], min_one=4, min_two=7),
+    dict(authorize_typos=False),
+    dict(synonyms={"fast": ["quick"], "sunflower": ["sun flower", "helianthus"], "lazy dog": ["sleepy hound"]},
+         stop_words=["the", "over"]),
+    dict(prefix_threshold=2, exact_attributes=["body"]),
+]
+
+
+@pytest.mark.parametrize("settings", SETTINGS, ids=[",".join(s_) for s_ in SETTINGS])
+def test_matches_oracle_under_index_settings(settings):
+    """Exact attributes / exact words / typo thresholds / synonyms + stop words / prefix databases on a three-field
+    corpus, default criteria, both strategies, with and without an offset."""
+    from oracle import oracle as O
+    from oracle import ranking_oracle as RO
+    from tests.toy_milli import ToyMilli, query_terms
+    rng = random.Random(5)
+    docs = []
+    for d in random_corpus(21, 250):
+        d["tags"] = " ".join(rng.choice(VOCAB) for _ in range(rng.randint(0, 3)))
+        docs.append(d)
+    index = ToyMilli(docs, searchable=["title", "body", "tags"], **settings)
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    h = Harness(index)
+    queries = QUERIES + ["fast brown fox", "sunflower holiday", "the lazy dog jumps", "quick", "qu", "\"sun flower\" the"]
+    for q in queries:
+        for tms in ("last", "all"):
+            for detailed, offset in ((True, 0), (False, 2)):
+                want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms=tms, offset=offset, length=30,
+                                                         detailed=detailed)
+                hits, cand = h.search(q, tms=tms, offset=offset, limit=30, detailed=detailed)
+                assert [d for d, _ in hits] == want_ids, (q, tms, detailed, offset)
+                assert [[tuple(s) for s in sc] for _, sc in hits] == [[oracle_score(s) for s in sc] for sc in want_sc], (q, tms)
+                assert cand == len(want_cand)
