@@ -492,7 +492,7 @@ int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtabl
  * (compute_phrase_docids, resolve_query_graph.rs:187-268).  The control flow (small graphs) runs on the
  * caller's thread; every docid set lives in the msi_bits pool and every set operation — posting decode,
  * union, intersection, difference, cardinality, ordered extraction — is a device kernel.
- * Not handled: distinct, pins, ranking score threshold.
+ * Not handled: distinct, pins.
  * The tokenizer stays with the caller: it hands over the located terms of
  * located_query_terms_from_tokens (parse_query.rs:28-202); stop words are its business (dropped, or empty
  * tokens inside a phrase); n_terms = 0 (only stop words) is a placeholder search: the universe in docid order.
@@ -541,7 +541,10 @@ typedef struct msi_search_params {
    * hook Deadline::with_stop_after, which then ignores the time budget), -1 = off. */
   uint64_t time_budget_us;
   int32_t stop_after;
-  int32_t _pad;
+  int32_t has_score_threshold;
+  /* ranking_score_threshold (bucket_sort.rs:286-306): a bucket whose ScoreDetails::global_score so far is below
+   * it is dropped together with what is left of that rule's universe; *out_candidates excludes both. */
+  double score_threshold;
 } msi_search_params;
 /* out_scores: [length][MSI_MAX_SCORE_DETAILS], out_n_scores: [length].  The pool needs at least 64 free
  * slots above slot 0 (more for long queries: one per live condition of every active rule). */

@@ -97,7 +97,7 @@ class SearchParams(C.Structure):
                 ("n_criteria", C.c_uint32), ("searchable_fids", C.c_void_p), ("searchable_weights", C.c_void_p),
                 ("n_searchable", C.c_uint32), ("max_weight", C.c_int32), ("from_", C.c_uint32),
                 ("length", C.c_uint32), ("detailed_scores", C.c_int32), ("time_budget_us", C.c_uint64),
-                ("stop_after", C.c_int32), ("_pad", C.c_int32)]
+                ("stop_after", C.c_int32), ("has_score_threshold", C.c_int32), ("score_threshold", C.c_double)]
 
 
 class QueryToken(C.Structure):

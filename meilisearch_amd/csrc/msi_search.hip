@@ -1619,6 +1619,13 @@ struct ExactAttributeRule : Rule {
   }
 };
 
+// ScoreDetails::global_score of the details pushed so far (score_details.rs:123-154)
+double global_score(const std::vector<Score> &scores) {
+  std::vector<msi_score_detail> d;
+  for (const Score &s : scores) d.push_back(msi_score_detail{s.kind, s.a, s.b});
+  return msi_score_details_global_score(d.data(), (uint32_t)d.size());
+}
+
 // get_ranking_rules_for_query_graph_search, mod.rs:510-649
 std::vector<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
   std::vector<std::unique_ptr<Rule>> rules;
@@ -1871,6 +1878,12 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     }
     cur_off += count;
   };
+  Set excluded;  // documents a ranking score threshold removed from all_candidates
+  auto exclude = [&](const Set &docs, uint64_t count) {
+    if (!count) return;
+    if (!excluded) excluded = c.dev.zeros();
+    c.dev.or_(excluded, docs);
+  };
   auto back = [&]() -> bool {  // false: iteration over
     unis[cur].reset();
     uni_counts[cur] = 0;
@@ -1891,13 +1904,15 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       // universe on the stack goes out unranked under a Skipped detail (bucket_sort.rs:206-264)
       for (;;) {
         scores.push_back(Score{MSI_SCORE_SKIPPED, 0, 1});
-        add(unis[cur], uni_counts[cur]);
+        if (p->has_score_threshold && global_score(scores) < p->score_threshold) exclude(unis[cur], uni_counts[cur]);
+        else add(unis[cur], uni_counts[cur]);
         scores.pop_back();
         unis[cur].reset();
         uni_counts[cur] = 0;
         if (cur == 0) {
           if (out_degraded) *out_degraded = 1;
           *out_n = n_out;
+          if (excluded && out_candidates) *out_candidates = universe_count - c.dev.count(excluded);
           return;
         }
         rules[cur]->end();
@@ -1912,10 +1927,16 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     }
     ++g_stats.buckets;
     scores.push_back(b.score);
+    const bool below = p->has_score_threshold && global_score(scores) < p->score_threshold;
     if (!b.universe_reduced) c.dev.sub_(unis[cur], b.docs);
     uni_counts[cur] -= b.count;
-    if (cur == nr - 1 || (!detailed && b.count <= 1) || cur_off + b.count < from) {
-      add(b.docs, b.count);
+    if (cur == nr - 1 || (!detailed && b.count <= 1) || cur_off + b.count < from || below) {
+      if (below) {
+        exclude(b.docs, b.count);
+        exclude(unis[cur], uni_counts[cur]);
+      } else {
+        add(b.docs, b.count);
+      }
       scores.pop_back();
       continue;
     }
@@ -1925,6 +1946,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     rules[cur]->start(c, b.docs, b.graph);
   }
   *out_n = n_out;
+  if (excluded && out_candidates) *out_candidates = universe_count - c.dev.count(excluded);
 }
 
 }  // namespace

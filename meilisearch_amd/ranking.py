@@ -296,7 +296,7 @@ MAX_SCORE_DETAILS = 8
 def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERMS_LAST, offset=0, limit=20,
                           detailed=False, searchable_fids=(), searchable_weights=(), max_weight=None,
                           authorize_typos=True, min_one=5, min_two=9, universe_cbo=None, time_budget_us=0,
-                          stop_after=None, return_degraded=False):
+                          stop_after=None, return_degraded=False, score_threshold=None):
     """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
     terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
     (words: [str | None], None = a stop word inside a phrase; an optional 6th element True marks a negative term).
@@ -326,7 +326,8 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
     prm = SearchParams(1 if authorize_typos else 0, min_one, min_two, strategy, np_ptr(crit) if crit.size else None,
                        crit.size, np_ptr(fids) if fids.size else None, np_ptr(wts) if wts.size else None, fids.size,
                        -1 if max_weight is None else int(max_weight), offset, limit, 1 if detailed else 0,
-                       int(time_budget_us), -1 if stop_after is None else int(stop_after), 0)
+                       int(time_budget_us), -1 if stop_after is None else int(stop_after),
+                       0 if score_threshold is None else 1, 0.0 if score_threshold is None else float(score_threshold))
     L = max(limit, 1)
     ids = np.zeros(L, dtype=np.uint32)
     sc = (ScoreDetail * (L * MAX_SCORE_DETAILS))()

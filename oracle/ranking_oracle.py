@@ -991,8 +991,8 @@ class Deadline:
         return self.calls > self.stop_after
 
 
-def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, deadline=None):
-    """bucket_sort.rs:23-343 without distinct, pins and score threshold.
+def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, deadline=None, threshold=None):
+    """bucket_sort.rs:23-343 without distinct and pins (threshold = ranking_score_threshold, :286-306).
     -> (docids, [score details per hit], all_candidates); `bucket_sort.degraded` tells whether the deadline cut
     the last call short (graph-based rules never answer non_blocking_next_bucket: ranking_rules.rs:67-74)."""
     deadline = deadline or Deadline()
@@ -1042,7 +1042,10 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
             while True:
                 b, unis[cur] = unis[cur], set()
                 scores.append(("Skipped",))
-                add(b)
+                if threshold is not None and global_score(scores) < threshold:
+                    all_cand.difference_update(b)
+                else:
+                    add(b)
                 scores.pop()
                 if cur == 0:
                     bucket_sort.degraded = True
@@ -1062,9 +1065,14 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
         g2, cands, score = nb
         scores.append(score)
         assert cands <= unis[cur]
+        below = threshold is not None and global_score(scores) < threshold
         unis[cur] -= cands
-        if cur == n - 1 or (not detailed and len(cands) <= 1) or cur_off + len(cands) < offset:
-            add(cands)
+        if cur == n - 1 or (not detailed and len(cands) <= 1) or cur_off + len(cands) < offset or below:
+            if below:
+                all_cand.difference_update(cands)
+                all_cand.difference_update(unis[cur])
+            else:
+                add(cands)
             scores.pop()
             continue
         cur += 1
@@ -1127,7 +1135,7 @@ def parse_query(ctx, query, words_limit=10):
 
 
 def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=False, universe=None, negatives=(),
-           stop_after=None):
+           stop_after=None, threshold=None):
     """execute_search, mod.rs:808-880 for a keyword query.  negatives: [word | (phrase words…)] whose documents
     Search::execute removes from the universe first (search/mod.rs:431-440, new/mod.rs:323-351)."""
     index = ctx.index
@@ -1146,4 +1154,4 @@ def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=
     if tms == "last":
         reduced.remove_nodes_keep_edges([n for ns in graph.removal_order_last(ctx) for n in sorted(ns)])
     universe &= query_graph_docids(ctx, reduced, universe)
-    return bucket_sort(ctx, rules, graph, universe, offset, length, detailed, Deadline(stop_after))
+    return bucket_sort(ctx, rules, graph, universe, offset, length, detailed, Deadline(stop_after), threshold)

@@ -85,7 +85,7 @@ pub struct msi_search_params {
     pub criteria: *const i32, pub n_criteria: u32,
     pub searchable_fids: *const u16, pub searchable_weights: *const u16, pub n_searchable: u32,
     pub max_weight: i32, pub from: u32, pub length: u32, pub detailed_scores: i32,
-    pub time_budget_us: u64, pub stop_after: i32, pub _pad: i32,
+    pub time_budget_us: u64, pub stop_after: i32, pub has_score_threshold: i32, pub score_threshold: f64,
 }
 
 extern "C" {

@@ -252,3 +252,34 @@ def test_matches_oracle_under_index_settings(settings):
                 assert [d for d, _ in hits] == want_ids, (q, tms, detailed, offset)
                 assert [[tuple(s) for s in sc] for _, sc in hits] == [[oracle_score(s) for s in sc] for sc in want_sc], (q, tms)
                 assert cand == len(want_cand)
+
+
+def test_ranking_score_threshold():
+    """bucket_sort.rs:286-306: buckets whose global score so far is below the threshold are dropped together with
+    the rest of that rule's universe; the candidate count excludes them."""
+    from oracle import oracle as O
+    from oracle import ranking_oracle as RO
+    from tests.toy_milli import ToyMilli, query_terms
+    index = ToyMilli(random_corpus(13, 300), searchable=["title", "body"])
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    h = Harness(index)
+    seen_cut = 0
+    for q in ("the quick brown fox", "sun flower holiday", "quick brwn fox", "lazy dog the"):
+        for thr in (0.2, 0.5, 0.8, 0.95):
+            for detailed in (True, False):
+                want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms="last", length=300,
+                                                         detailed=detailed, threshold=thr)
+                hits, cand = h.R.keyword_search_ranked(
+                    h.dict, h.pool, h.cb, query_terms(q), index.criteria, limit=300, detailed=detailed,
+                    searchable_fids=index.searchable_fids,
+                    searchable_weights=[index.weights[f] for f in index.searchable_fids], max_weight=index.max_weight,
+                    score_threshold=thr)
+                assert [d for d, _ in hits] == want_ids, (q, thr, detailed)
+                assert cand == len(want_cand), (q, thr, detailed)
+                base = RO.search(RO.Ctx(index, lookup), q, tms="last", length=300, detailed=detailed)
+                seen_cut += len(want_cand) < len(base[2])
+    assert seen_cut > 4
