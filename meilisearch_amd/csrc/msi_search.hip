@@ -1854,8 +1854,10 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   rules[0]->start(c, universe, g);
   size_t cur = 0;
   uint64_t cur_off = 0;
+  Set excluded;  // documents a ranking score threshold removed from all_candidates
   auto add = [&](const Set &cands, uint64_t count) {  // maybe_add_to_results :382-460
     if (!count) return;
+    if (excluded) c.dev.sub_(excluded, cands);  // `*all_candidates |= &candidates`
     uint64_t skip = 0;
     if (cur_off < from) {
       if (cur_off + count < from) {
@@ -1878,7 +1880,6 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     }
     cur_off += count;
   };
-  Set excluded;  // documents a ranking score threshold removed from all_candidates
   auto exclude = [&](const Set &docs, uint64_t count) {
     if (!count) return;
     if (!excluded) excluded = c.dev.zeros();

@@ -1,0 +1,8 @@
+set -x
+mkdir -p gpurun_out
+timeout 400 python -m pytest tests -m gpu -q 2>&1 | tail -4
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 400 python bench.py > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err; echo bench rc=$?; cat gpurun_out/bench_c4.json | cut -c1-900; tail -2 gpurun_out/bench_c4.err
+cd /tmp && export TMPDIR=/tmp
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_bench -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1; echo rocprof rc=$?
+cd $GRAFT_REPO_ROOT; f=$(find gpurun_out/prof_bench -name "*kernel_stats.csv" | head -1); echo $f; head -12 "$f" | cut -c1-200
