@@ -273,6 +273,13 @@ int32_t msi_bits_set_from_docids(msi_bits *pool, uint32_t slot,
                                  const uint32_t *docids, uint64_t n);
 /* slot := decode of a CboRoaringBitmapCodec value
  * (heed_codec/roaring_bitmap/cbo_roaring_bitmap_codec.rs:53-85). */
+/* slot(first_slot + i * slot_stride) := the documents of the i-th device-resident list
+ * (d_docids[i * list_stride .. + min(d_counts[i], list_stride)); ids >= n_docs are ignored) — e.g. the top-k of a
+ * vector search as the universes of a ranking-rule rerank, without a trip through the host.  The lists must have
+ * been produced on the pool's stream (its context's stream unless msi_bits_use_private_stream). */
+int32_t msi_bits_set_from_docid_lists_device(msi_bits *pool, uint32_t first_slot, uint32_t slot_stride,
+                                             const uint32_t *d_docids, uint32_t list_stride,
+                                             const uint32_t *d_counts, uint32_t n_lists);
 int32_t msi_bits_set_from_cbo(msi_bits *pool, uint32_t slot,
                               const uint8_t *bytes, size_t len);
 int32_t msi_bits_set_from_words(msi_bits *pool, uint32_t slot,

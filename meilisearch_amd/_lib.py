@@ -168,6 +168,7 @@ PROTOTYPES = {
     "msi_bits_destroy": (None, [_VP]),
     "msi_bits_use_private_stream": (_I32, [_VP]),
     "msi_bits_set_from_docids": (_I32, [_VP, _U32, _VP, _U64]),
+    "msi_bits_set_from_docid_lists_device": (_I32, [_VP, _U32, _U32, _VP, _U32, _VP, _U32]),
     "msi_bits_set_from_cbo": (_I32, [_VP, _U32, _VP, C.c_size_t]),
     "msi_bits_set_from_words": (_I32, [_VP, _U32, _VP, _U64]),
     "msi_bits_fill": (_I32, [_VP, _U32, _I32]),

@@ -24,6 +24,12 @@ class BitsPool:
         d = np.ascontiguousarray(docids, dtype=np.uint32)
         check(lib().msi_bits_set_from_docids(self._h, slot, np_ptr(d) if d.size else None, d.size))
 
+    def set_from_docid_lists_device(self, first_slot, slot_stride, docids_t, counts_t):
+        """docids_t: cuda int32/uint32 [n_lists, list_stride], counts_t: cuda int32 [n_lists] (same stream as the pool)."""
+        n_lists, list_stride = docids_t.shape
+        check(lib().msi_bits_set_from_docid_lists_device(self._h, first_slot, slot_stride, C.c_void_p(docids_t.data_ptr()),
+                                                        list_stride, C.c_void_p(counts_t.data_ptr()), n_lists))
+
     def set_from_cbo(self, slot, data):
         b = np.frombuffer(bytes(data), dtype=np.uint8)
         check(lib().msi_bits_set_from_cbo(self._h, slot, np_ptr(b) if b.size else None, b.size))

@@ -314,6 +314,25 @@ __global__ void bits_set_docids_kernel(u64 *__restrict__ dst, uint64_t n_docs,
   if ((uint64_t)id < n_docs) atomicOr(&dst[id >> 6], 1ull << (id & 63));
 }
 
+// slot(first + y * stride) := the documents of list y (device-resident lists, e.g. the top-k rows of a vector
+// search: the rerank universes of many queries in two launches)
+__global__ void bits_clear_slots_kernel(u64 *__restrict__ pool, uint64_t n_words, uint32_t first, uint32_t stride) {
+  u64 *dst = pool + (uint64_t)(first + blockIdx.y * stride) * n_words;
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n_words / 2; i += step) reinterpret_cast<ulonglong2 *>(dst)[i] = make_ulonglong2(0, 0);
+}
+__global__ void bits_set_lists_kernel(u64 *__restrict__ pool, uint64_t n_words, uint64_t n_docs, uint32_t first,
+                                      uint32_t stride, const uint32_t *__restrict__ ids, uint32_t list_stride,
+                                      const uint32_t *__restrict__ counts) {
+  u64 *dst = pool + (uint64_t)(first + blockIdx.y * stride) * n_words;
+  const uint32_t n = counts[blockIdx.y] < list_stride ? counts[blockIdx.y] : list_stride;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t id = ids[(uint64_t)blockIdx.y * list_stride + i];
+    if ((uint64_t)id < n_docs) atomicOr(&dst[id >> 6], 1ull << (id & 63));
+  }
+}
+
 // One block per Roaring container.
 __global__ void bits_decode_roaring_kernel(u64 *__restrict__ dst, uint64_t n_docs,
                                            const uint8_t *__restrict__ bytes,
@@ -564,6 +583,24 @@ int32_t msi_bits_set_from_docids(msi_bits *p, uint32_t slot, const uint32_t *doc
     MSI_HIP_TRY(hipGetLastError());
     MSI_HIP_TRY(hipStreamSynchronize(st));  // docids is borrowed only for the call
   }
+  return MSI_OK;
+}
+
+int32_t msi_bits_set_from_docid_lists_device(msi_bits *p, uint32_t first_slot, uint32_t slot_stride,
+                                             const uint32_t *d_docids, uint32_t list_stride, const uint32_t *d_counts,
+                                             uint32_t n_lists) {
+  if (!p || !n_lists || !slot_stride || !d_docids || !d_counts || !list_stride) return MSI_E_INVALID;
+  MSI_TRY(check_slot(p, first_slot, "msi_bits_set_from_docid_lists_device"));
+  MSI_TRY(check_slot(p, first_slot + (n_lists - 1) * slot_stride, "msi_bits_set_from_docid_lists_device"));
+  std::lock_guard<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->stream;
+  const uint32_t gx = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (p->n_words / 2 + BT - 1) / BT), 64);
+  hipLaunchKernelGGL(bits_clear_slots_kernel, dim3(gx, n_lists), dim3(BT), 0, st, p->pool.as<u64>(), p->n_words,
+                     first_slot, slot_stride);
+  hipLaunchKernelGGL(bits_set_lists_kernel, dim3((list_stride + BT - 1) / BT, n_lists), dim3(BT), 0, st,
+                     p->pool.as<u64>(), p->n_words, p->n_docs, first_slot, slot_stride, d_docids, list_stride, d_counts);
+  MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
 }
 

@@ -770,7 +770,28 @@ struct RescoreArgs {
   uint32_t *inexact;       // [nq]
   const uint32_t *overflow;
   const float *theta;      // nullable: thresholds the sparse pass ran with
+  u64 *pre_keys;           // nullable [NQ_MAX][KP_MAX]: distances computed by vs_rescore_dots_kernel (large K')
 };
+
+// Large K' (k in the hundreds: the rerank pool of BASELINE config 5): the reference-arithmetic dot products are
+// the expensive part and one workgroup per query leaves the chip idle, so they get their own launch with one
+// thread per (query, candidate); vs_rescore_kernel then only sorts, emits and proves.
+__global__ __launch_bounds__(SEL_THREADS) void vs_rescore_dots_kernel(RescoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  float *qs = reinterpret_cast<float *>(dyn);  // [dpad]
+  const uint32_t j = blockIdx.y;
+  const uint32_t dpad = a.dpad;
+  const uint32_t cnt = a.sel_cnt[j];
+  if (blockIdx.x * blockDim.x >= cnt) return;
+  for (uint32_t i = threadIdx.x; i < dpad; i += blockDim.x) qs[i] = a.qrow[(uint64_t)j * dpad + i];
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
+  const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
+  const float d = canonical_distance(pq, a.norm[row], a.qn[j]);
+  a.pre_keys[(uint64_t)j * KP_MAX + i] = ((u64)f32_to_ord(d) << 32) | row;
+}
 
 __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
@@ -786,10 +807,14 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) 
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     u64 key = ~0ull;
     if (i < cnt) {
-      const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
-      const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
-      const float d = canonical_distance(pq, a.norm[row], qn);
-      key = ((u64)f32_to_ord(d) << 32) | row;  // rows ascend with docids
+      if (a.pre_keys) {
+        key = a.pre_keys[(uint64_t)j * KP_MAX + i];
+      } else {
+        const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
+        const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
+        const float d = canonical_distance(pq, a.norm[row], qn);
+        key = ((u64)f32_to_ord(d) << 32) | row;  // rows ascend with docids
+      }
     }
     sbuf[i] = key;
   }
@@ -942,7 +967,7 @@ struct msi_vs {
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
   // scratch (guarded by ctx->mu)
   DevBuf qraw, qfrag, qfrag_bf, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fbits, out_docids,
-      out_dist, exh_keys, rowtmp;
+      out_dist, exh_keys, rowtmp, resc_keys;
   uint32_t capg = 0;
   uint32_t scan_grid = 0;
   // stats
@@ -1288,6 +1313,13 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   ra.inexact = d_inexact;
   ra.overflow = s.overflow;
   ra.theta = theta_used;
+  ra.pre_keys = nullptr;
+  if (k > 0 && kp > 2 * SEL_THREADS) {
+    MSI_TRY(vs->resc_keys.ensure((size_t)NQ_MAX * KP_MAX * sizeof(u64)));
+    ra.pre_keys = vs->resc_keys.as<u64>();
+    hipLaunchKernelGGL(vs_rescore_dots_kernel, dim3((kp + SEL_THREADS - 1) / SEL_THREADS, nq), dim3(SEL_THREADS),
+                       (size_t)vs->dpad * sizeof(float), st, ra);
+  }
   if (k > 0)
     hipLaunchKernelGGL(vs_rescore_kernel, dim3(nq), dim3(SEL_THREADS),
                        KP_MAX * sizeof(u64) + (size_t)vs->dpad * sizeof(float), st, ra);
@@ -1388,7 +1420,7 @@ void msi_vs_destroy(msi_vs *vs) {
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qfrag_bf, &vs->qrow,
                       &vs->qsmall, &vs->gkeys, &vs->gcnt, &vs->gsmall, &vs->sel_keys, &vs->dense, &vs->tmask,
-                      &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp};
+                      &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp, &vs->resc_keys};
     for (DevBuf *b : bufs) b->release();
     vs->scan_timer.release();
     delete vs;

@@ -145,3 +145,27 @@ def test_bits_as_vector_filter(ctx, oracle):
         e_ids, e_dist = oracle.vs_topk(rows, ids, q[j], 10, fb, nb)
         assert out_d[j].cpu().numpy().astype(np.uint32).tolist() == e_ids.tolist()
         assert inex[j].item() == 0
+
+
+def test_set_from_docid_lists_device():
+    """Device-resident docid lists (a vector search's top-k) -> one slot per list, in two launches."""
+    import torch
+    import meilisearch_amd as ma
+    ctx = ma.Context(0)
+    n_docs, n_lists, stride = 100_000, 7, 300
+    pool = ma.BitsPool(ctx, n_docs, 2 + 3 * n_lists)
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, n_docs, (n_lists, stride), dtype=np.int64).astype(np.uint32)
+    ids[2, 5] = 0xFFFFFFFF                       # a padding entry is ignored
+    counts = np.array([300, 0, 17, 299, 1, 150, 300], dtype=np.int32)
+    for s_ in range(2 + 3 * n_lists):
+        pool.fill(s_, True)                       # stale content must be cleared
+    dev = torch.device("cuda", 0)
+    ids_t = torch.from_numpy(ids.view(np.int32)).to(dev)
+    cnt_t = torch.from_numpy(counts).to(dev)
+    torch.cuda.synchronize()
+    pool.set_from_docid_lists_device(2, 3, ids_t, cnt_t)
+    for i in range(n_lists):
+        want = sorted(set(int(x) for x in ids[i, :counts[i]] if x < n_docs))
+        assert pool.to_docids(2 + 3 * i).tolist() == want
+        assert pool.count(2 + 3 * i + 1) == n_docs   # neighbours untouched
