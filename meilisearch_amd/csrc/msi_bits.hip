@@ -333,6 +333,16 @@ __global__ void bits_set_lists_kernel(u64 *__restrict__ pool, uint64_t n_words, 
   }
 }
 
+struct ClearArgs {
+  u64 *slot[MSI_BITS_CLEAR_MAX];
+};
+__global__ void bits_clear_many_kernel(ClearArgs a, uint64_t n_pairs) {
+  u64 *dst = a.slot[blockIdx.y];
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n_pairs; i += step) reinterpret_cast<ulonglong2 *>(dst)[i] = make_ulonglong2(0, 0);
+}
+
 // One block per Roaring container.
 __global__ void bits_decode_roaring_kernel(u64 *__restrict__ dst, uint64_t n_docs,
                                            const uint8_t *__restrict__ bytes,
@@ -791,6 +801,22 @@ static int32_t ring_alloc(msi_bits *p, size_t bytes, uint8_t **out) {
   }
   *out = p->h_ring + p->ring_pos;
   p->ring_pos += bytes;
+  return MSI_OK;
+}
+
+int32_t msi_bits_clear_slots(msi_bits *p, uint32_t n, const uint32_t *slots) {
+  if (!p || !n || n > MSI_BITS_CLEAR_MAX || !slots) return MSI_E_INVALID;
+  ClearArgs a;
+  for (uint32_t k = 0; k < n; ++k) {
+    MSI_TRY(check_slot(p, slots[k], "msi_bits_clear_slots"));
+    a.slot[k] = p->slot(slots[k]);
+  }
+  std::lock_guard<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  const uint64_t n_pairs = p->n_words / 2;
+  const uint32_t gx = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (n_pairs + BT - 1) / BT), 32);
+  hipLaunchKernelGGL(bits_clear_many_kernel, dim3(gx, n), dim3(BT), 0, p->stream, a, n_pairs);
+  MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
 }
 

@@ -163,6 +163,9 @@ int32_t msi_bits_claim(msi_bits *p, uint32_t docs, uint32_t bucket, uint32_t uni
 //   paths_claim: for path k = 0..n-1 in order: docs = universe & AND(steps of k); bucket |= docs; universe &= ~docs;
 //                counts[k] = |docs|  — a whole cost level of a rule graph in one launch and one completion signal
 constexpr uint32_t MSI_BITS_MAX_PATHS = 256, MSI_BITS_MAX_STEPS = 4096;
+//   clear_slots: zero up to MSI_BITS_CLEAR_MAX slots in one launch (the engine hands out pre-zeroed slots)
+constexpr uint32_t MSI_BITS_CLEAR_MAX = 64;
+int32_t msi_bits_clear_slots(msi_bits *p, uint32_t n, const uint32_t *slots);
 int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
                              uint32_t bucket, uint32_t universe, uint64_t *counts);
 
