@@ -275,6 +275,73 @@ __global__ void bits_paths_kernel(const u64 *const *__restrict__ steps, const ui
   }
 }
 
+// The common case of a cost level — few distinct conditions (<= 32), <= 64 paths — with everything in the kernel
+// arguments (no descriptor copy) and every condition chunk loaded ONCE, up front and independently, into LDS:
+// the path loop then runs on LDS instead of a chain of dependent global loads.
+constexpr uint32_t PS_CONDS = 32, PS_PATHS = 64, PS_STEPS = 448, PS_T = 64;
+struct PathsSmall {
+  const u64 *cond[PS_CONDS];
+  uint16_t off[PS_PATHS + 1];
+  uint8_t step[PS_STEPS];
+};
+__global__ __launch_bounds__(PS_T) void bits_paths_small_kernel(PathsSmall a, uint32_t n_conds, uint32_t n_paths,
+                                                                 u64 *__restrict__ bucket, u64 *__restrict__ universe,
+                                                                 uint64_t n_pairs, u64 *__restrict__ acc_counts,
+                                                                 u64 *__restrict__ acc,
+                                                                 volatile uint64_t *__restrict__ sig_counts,
+                                                                 volatile uint64_t *__restrict__ sig, uint64_t seq) {
+  __shared__ ulonglong2 cv[PS_CONDS][PS_T];
+  __shared__ uint32_t cnt[PS_PATHS];
+  const uint32_t tid = threadIdx.x;
+  if (tid < n_paths) cnt[tid] = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * PS_T + tid;
+  if (i < n_pairs) {
+    ulonglong2 u = reinterpret_cast<ulonglong2 *>(universe)[i];
+    if (u.x | u.y) {
+      for (uint32_t c = 0; c < n_conds; ++c) cv[c][tid] = reinterpret_cast<const ulonglong2 *>(a.cond[c])[i];
+      ulonglong2 b = reinterpret_cast<ulonglong2 *>(bucket)[i];
+      for (uint32_t k = 0; k < n_paths && (u.x | u.y); ++k) {
+        ulonglong2 m = u;
+        for (uint32_t s = a.off[k]; s < a.off[k + 1] && (m.x | m.y); ++s) {
+          const ulonglong2 c = cv[a.step[s]][tid];
+          m.x &= c.x;
+          m.y &= c.y;
+        }
+        if (m.x | m.y) {
+          b.x |= m.x;
+          b.y |= m.y;
+          u.x &= ~m.x;
+          u.y &= ~m.y;
+          atomicAdd(&cnt[k], (uint32_t)(__popcll(m.x) + __popcll(m.y)));
+        }
+      }
+      reinterpret_cast<ulonglong2 *>(bucket)[i] = b;
+      reinterpret_cast<ulonglong2 *>(universe)[i] = u;
+    }
+  }
+  __syncthreads();
+  if (tid < n_paths && cnt[tid]) atomicAdd(&acc_counts[tid], (u64)cnt[tid]);
+  __threadfence();
+  __syncthreads();
+  __shared__ bool last;
+  if (tid == 0) last = atomicAdd(&acc[1], 1ull) == gridDim.x - 1;
+  __syncthreads();
+  if (last) {
+    __threadfence();
+    if (tid < n_paths) {
+      const u64 total = atomicExch(&acc_counts[tid], 0ull);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig_counts[tid]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      acc[1] = 0;
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // dst = (OR_i pool[srcs[i]]) & pool[universe]
 __global__ void bits_union_many_kernel(u64 *__restrict__ pool, uint64_t n_words, uint32_t dst,
                                        const uint32_t *__restrict__ srcs, uint32_t n, uint32_t universe) {
@@ -831,6 +898,40 @@ int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   hipStream_t st = p->stream;
+  const uint64_t n_pairs_ = p->n_words / 2;
+  if (n_paths <= PS_PATHS && n_steps <= PS_STEPS) {
+    // distinct conditions -> table indices
+    PathsSmall a;
+    uint32_t slots[PS_CONDS], n_conds = 0;
+    bool small = true;
+    for (uint32_t s = 0; s < n_steps && small; ++s) {
+      uint32_t c = 0;
+      while (c < n_conds && slots[c] != step_slots[s]) ++c;
+      if (c == n_conds) {
+        if (n_conds == PS_CONDS) {
+          small = false;
+          break;
+        }
+        slots[n_conds] = step_slots[s];
+        a.cond[n_conds++] = p->slot(step_slots[s]);
+      }
+      a.step[s] = (uint8_t)c;
+    }
+    if (small) {
+      for (uint32_t k = 0; k <= n_paths; ++k) a.off[k] = (uint16_t)path_off[k];
+      const uint64_t seq = ++p->seq;
+      hipLaunchKernelGGL(bits_paths_small_kernel, dim3((uint32_t)((n_pairs_ + PS_T - 1) / PS_T)), dim3(PS_T), 0, st, a,
+                         n_conds, n_paths, p->slot(bucket), p->slot(universe), n_pairs_, p->d_acc + 2 + MSI_BITS_MANY,
+                         p->d_acc, p->h_sig + 2 + MSI_BITS_MANY, p->h_sig, seq);
+      MSI_HIP_TRY(hipGetLastError());
+      lk.unlock();
+      uint64_t ignored = 0;
+      MSI_TRY(wait_count(p, seq, &ignored));
+      for (uint32_t k = 0; k < n_paths; ++k)
+        counts[k] = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2 + MSI_BITS_MANY + k]), __ATOMIC_RELAXED);
+      return MSI_OK;
+    }
+  }
   const size_t steps_bytes = std::max<size_t>(1, n_steps) * sizeof(u64 *), off_bytes = (n_paths + 1) * sizeof(uint32_t);
   if (steps_bytes + off_bytes > p->desc.cap) MSI_TRY(p->desc.ensure(std::max<size_t>(steps_bytes + off_bytes, (size_t)64 << 10)));
   uint8_t *h = nullptr;

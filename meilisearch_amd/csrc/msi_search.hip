@@ -1520,7 +1520,8 @@ struct GraphRule : Rule {
 struct ExactAttributeRule : Rule {
   Graph g;
   int state = 0;  // 0 empty, 1 exact attribute, 2 attribute starts
-  Set exact_match, matches_start;  // universe-independent, shared (Ctx::exact_attr_cache)
+  Set exact_match, matches_start;  // this iteration's two buckets (already inside the universe)
+  uint64_t exact_count = 0, start_count = 0;
   ExactAttributeRule() : Rule(R_EXACT_ATTRIBUTE, -1) {}
 
   static uint32_t bucketed_position(uint32_t rel) {  // lib.rs:248-262
@@ -1611,10 +1612,16 @@ struct ExactAttributeRule : Rule {
         c.dev.sub_(S, W);
         c.dev.or_(e2, S);
       }
+      c.dev.sub_(e2, e1);  // a document can match exactly in one field and only start another: ExactMatch wins
       hit = c.exact_attr_cache.emplace(sig, std::make_pair(e1, e2)).first;
     }
-    exact_match = hit->second.first;
-    matches_start = hit->second.second;
+    // both buckets against this universe in one launch and one wait (they are disjoint, so taking the first out
+    // of the universe does not change the second)
+    auto both = c.dev.and_many(universe, {hit->second.first, hit->second.second});
+    exact_match = both[0].first;
+    matches_start = both[1].first;
+    exact_count = both[0].second;
+    start_count = both[1].second;
     state = 1;
   }
 
@@ -1626,7 +1633,8 @@ struct ExactAttributeRule : Rule {
       out.score = {MSI_SCORE_EXACT_ATTRIBUTE, 1, 3};
       return true;
     }
-    out.docs = c.dev.and_new(state == 1 ? exact_match : matches_start, universe, &out.count);
+    out.docs = state == 1 ? exact_match : matches_start;
+    out.count = state == 1 ? exact_count : start_count;
     out.score = {MSI_SCORE_EXACT_ATTRIBUTE, state == 1 ? 3u : 2u, 3};
     state = state == 1 ? 2 : 0;
     return true;
