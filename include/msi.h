@@ -228,6 +228,17 @@ int32_t msi_dict_lookup(msi_dict *dict, const msi_typo_query *queries,
                         uint32_t *out_one_idx, uint32_t *out_one_cnt,
                         uint32_t *out_two_idx, uint32_t *out_two_cnt);
 
+/* Facet search (crates/milli/src/search/facet/search.rs:122-190): the values of one facet's FST that
+ * `fst.search(build_dfa(query, typos, is_prefix = true))` streams — every value with a prefix within max_typos
+ * (0..2) edits of the query, distance 0 included, no first-letter rule, no per-class caps — as indices in stream
+ * order.  The same derivation kernel answers it: the values are staged behind a common sentinel byte, which
+ * makes all first letters equal.  max_typos is the caller's (query.len() < 5: 0, < 9: 1, else 2 — bytes here,
+ * search.rs:147-155).  *out_truncated = 1 when more than `cap` (or more than 4096 per distance class) matched. */
+int32_t msi_dict_create_values(msi_ctx *ctx, const uint8_t *values_concat, const uint32_t *offsets,
+                               uint32_t n_values, msi_dict **out);
+int32_t msi_dict_search_values(msi_dict *dict, const uint8_t *query, uint32_t len, uint32_t max_typos,
+                               uint32_t cap, uint32_t *out_idx, uint32_t *out_n, int32_t *out_truncated);
+
 /* Micro-batching of concurrent callers (every search derives the typos of its few words
  * with one small lookup): with max_wait_us > 0, calls of fewer than `target_words` words
  * that arrive within that window and use the same caps are fused into one launch. */

@@ -159,6 +159,8 @@ PROTOTYPES = {
     "msi_dict_destroy": (None, [_VP]),
     "msi_dict_len": (_U32, [_VP]),
     "msi_dict_lookup": (_I32, [_VP, C.POINTER(TypoQuery), _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
+    "msi_dict_create_values": (_I32, [_VP, _VP, _VP, _U32, C.POINTER(_VP)]),
+    "msi_dict_search_values": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, C.POINTER(_U32), C.POINTER(_I32)]),
     "msi_dict_set_microbatch": (_I32, [_VP, _U32, _U32]),
     "msi_dict_microbatch_stats": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_U64)]),
     "msi_dict_lookup_device": (_I32, [_VP, _VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),

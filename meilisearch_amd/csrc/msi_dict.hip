@@ -714,6 +714,7 @@ struct msi_dict {
   bool bleader_active = false;
   uint32_t microbatch_wait_us = 0, microbatch_target = 256;
   uint64_t fused_calls = 0, fused_launches = 0;
+  bool values_mode = false;  // msi_dict_create_values: every word carries the sentinel first byte
 };
 
 // accessors for msi_keyword.hip
@@ -1042,6 +1043,76 @@ static int32_t dict_lookup_fused(msi_dict *d, const msi_typo_query *queries, uin
 }
 
 extern "C" {
+
+// ---- facet search (search/facet/search.rs:122-190) ----------------------------------------------
+// `fst.search(build_dfa(query, typos, is_prefix = true))` over a facet's values: every value with a prefix within
+// `typos` edits of the query — no first-letter rule, no per-class caps, distance 0 included.  The derivation
+// kernel applies the first-letter rule by dictionary ranges and classes; staging every value behind one common
+// sentinel byte makes all first letters equal, so the same kernel answers this question unchanged (the
+// sentinel costs no edit and does not change the order).
+static const uint8_t VALUES_SENTINEL = 0x01;
+
+int32_t msi_dict_create_values(msi_ctx *ctx, const uint8_t *values_concat, const uint32_t *offsets, uint32_t n_values,
+                               msi_dict **out) {
+  if (!ctx || !out || (n_values && (!values_concat || !offsets))) {
+    msi_set_error("msi_dict_create_values: invalid argument");
+    return MSI_E_INVALID;
+  }
+  std::vector<uint8_t> concat;
+  std::vector<uint32_t> offs(1, 0);
+  concat.reserve((n_values ? offsets[n_values] : 0) + n_values);
+  for (uint32_t i = 0; i < n_values; ++i) {
+    if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 254) {
+      msi_set_error("msi_dict_create_values: value %u has invalid length (max 254 bytes)", i);
+      return MSI_E_INVALID;
+    }
+    concat.push_back(VALUES_SENTINEL);
+    concat.insert(concat.end(), values_concat + offsets[i], values_concat + offsets[i + 1]);
+    offs.push_back((uint32_t)concat.size());
+  }
+  MSI_TRY(msi_dict_create(ctx, concat.data(), offs.data(), n_values, out));
+  (*out)->values_mode = true;
+  return MSI_OK;
+}
+
+int32_t msi_dict_search_values(msi_dict *d, const uint8_t *query, uint32_t len, uint32_t max_typos, uint32_t cap,
+                               uint32_t *out_idx, uint32_t *out_n, int32_t *out_truncated) {
+  if (!d || !d->values_mode || (len && !query) || !out_n || (cap && !out_idx) || max_typos > 2 || len > 249) {
+    msi_set_error("msi_dict_search_values: invalid argument (dictionary from msi_dict_create_values, typos 0..2, "
+                  "query <= 249 bytes)");
+    return MSI_E_INVALID;
+  }
+  std::vector<uint8_t> q(1, VALUES_SENTINEL);
+  q.insert(q.end(), query, query + len);
+  std::vector<uint32_t> found;
+  bool truncated = false;
+  uint32_t lo = 0, hi = 0;  // distance 0: the values the query is a prefix of
+  msi_dict_prefix_range(d, q.data(), (uint32_t)q.size(), &lo, &hi);
+  for (uint32_t i = lo; i < hi; ++i) found.push_back(i);
+  if (max_typos > 0 && d->n_words) {
+    const uint32_t c = std::min<uint32_t>(std::max<uint32_t>(cap, 1), 4096);
+    std::vector<uint32_t> one(c), two(c);
+    uint32_t n1 = 0, n2 = 0;
+    msi_typo_query tq;
+    tq.word = q.data();
+    tq.len = (uint32_t)q.size();
+    tq.max_typos = (uint8_t)max_typos;
+    tq.is_prefix = 1;
+    tq._pad = 0;
+    MSI_TRY(msi_dict_lookup(d, &tq, 1, c, c, one.data(), &n1, two.data(), &n2));
+    truncated = n1 >= c || n2 >= c;
+    found.insert(found.end(), one.begin(), one.begin() + n1);
+    if (max_typos > 1) found.insert(found.end(), two.begin(), two.begin() + n2);
+  }
+  std::sort(found.begin(), found.end());  // FST stream order
+  found.erase(std::unique(found.begin(), found.end()), found.end());
+  if (found.size() > cap) truncated = true;
+  const uint32_t n = (uint32_t)std::min<size_t>(found.size(), cap);
+  for (uint32_t i = 0; i < n; ++i) out_idx[i] = found[i];
+  *out_n = n;
+  if (out_truncated) *out_truncated = truncated ? 1 : 0;
+  return MSI_OK;
+}
 
 int32_t msi_dict_set_microbatch(msi_dict *d, uint32_t max_wait_us, uint32_t target_words) {
   if (!d) return MSI_E_INVALID;

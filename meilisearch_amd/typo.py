@@ -47,8 +47,11 @@ def pack_queries(queries):
 class GpuDictionary:
     """Sorted, unique word list (the keys of `word_docids`, index.rs:1238-1243)."""
 
-    def __init__(self, ctx, words=None, concat=None, offsets=None):
+    def __init__(self, ctx, words=None, concat=None, offsets=None, facet_values=False):
+        """facet_values=True stages the (sorted, unique, normalised) values of one facet for `search_values`
+        (msi_dict_create_values)."""
         self.ctx = ctx
+        self.facet_values = facet_values
         if words is not None:
             bs = [w.encode("utf-8") if isinstance(w, str) else bytes(w) for w in words]
             concat = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
@@ -59,14 +62,24 @@ class GpuDictionary:
         self.offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
         self._h = C.c_void_p()
         cc = self.concat if self.concat.size else np.zeros(1, np.uint8)
-        check(lib().msi_dict_create(ctx.handle, np_ptr(cc), np_ptr(self.offsets),
-                                    self.offsets.size - 1, C.byref(self._h)))
+        create = lib().msi_dict_create_values if facet_values else lib().msi_dict_create
+        check(create(ctx.handle, np_ptr(cc), np_ptr(self.offsets), self.offsets.size - 1, C.byref(self._h)))
 
     def __len__(self):
         return int(lib().msi_dict_len(self._h))
 
     def word(self, i):
         return bytes(self.concat[self.offsets[i]:self.offsets[i + 1]]).decode("utf-8")
+
+    def search_values(self, query, max_typos, cap=1000):
+        """Facet search (search/facet/search.rs:122-190): indices of the values with a prefix within `max_typos`
+        edits of `query`, in stream order; -> (indices, truncated)."""
+        q = np.frombuffer(query.encode("utf-8") if isinstance(query, str) else bytes(query), dtype=np.uint8)
+        out = np.zeros(max(cap, 1), dtype=np.uint32)
+        n, trunc = C.c_uint32(0), C.c_int32(0)
+        check(lib().msi_dict_search_values(self._h, np_ptr(q) if q.size else None, q.size, max_typos, cap, np_ptr(out),
+                                           C.byref(n), C.byref(trunc)))
+        return out[:n.value].copy(), bool(trunc.value)
 
     def lookup(self, queries, cap_one=MAX_ONE_TYPO_COUNT, cap_two=MAX_TWO_TYPOS_COUNT):
         """queries: list of (word, max_typos, is_prefix).  Returns a list of

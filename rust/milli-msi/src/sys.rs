@@ -118,6 +118,12 @@ extern "C" {
     pub fn msi_dict_len(d: *const msi_dict) -> u32;
     pub fn msi_dict_lookup(d: *mut msi_dict, queries: *const msi_typo_query, n: u32, cap_one: u32, cap_two: u32,
                            out_one_idx: *mut u32, out_one_cnt: *mut u32, out_two_idx: *mut u32, out_two_cnt: *mut u32) -> i32;
+    pub fn msi_dict_create_values(ctx: *mut msi_ctx, values_concat: *const u8, offsets: *const u32, n_values: u32,
+                                  out: *mut *mut msi_dict) -> i32;
+    pub fn msi_dict_search_values(d: *mut msi_dict, query: *const u8, len: u32, max_typos: u32, cap: u32,
+                                  out_idx: *mut u32, out_n: *mut u32, out_truncated: *mut i32) -> i32;
+    pub fn msi_bits_set_from_docid_lists_device(p: *mut msi_bits, first_slot: u32, slot_stride: u32, d_docids: *const u32,
+                                                list_stride: u32, d_counts: *const u32, n_lists: u32) -> i32;
     pub fn msi_dict_set_microbatch(d: *mut msi_dict, max_wait_us: u32, target_words: u32) -> i32;
 
     pub fn msi_bits_create(ctx: *mut msi_ctx, n_docs: u64, n_slots: u32, out: *mut *mut msi_bits) -> i32;

@@ -144,3 +144,37 @@ def test_errors(ctx):
         ma.GpuDictionary(ctx, words=["a", "a"])
     g = ma.GpuDictionary(ctx, words=[])
     assert g.lookup([("hello", 2, False)])[0][0].size == 0
+
+
+def test_facet_search_values_match_the_prefix_dfa():
+    """search/facet/search.rs:122-190: `fst.search(build_dfa(query, typos, is_prefix = true))` over a facet's values —
+    every value with a prefix within `typos` OSA edits of the query, distance 0 included, NO first-letter rule,
+    stream order.  Checked value by value against the oracle's prefix distance."""
+    import meilisearch_amd as ma
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    letters = list("abcdeilnorst")
+    values = set()
+    while len(values) < 1500:
+        n = int(rng.integers(1, 14))
+        w = "".join(rng.choice(letters) for _ in range(n))
+        if rng.random() < 0.1:
+            w += " " + "".join(rng.choice(letters) for _ in range(int(rng.integers(2, 8))))
+        values.add(w)
+    values |= {"é" + "".join(rng.choice(letters) for _ in range(4)) for _ in range(20)}
+    values = sorted(values, key=lambda v: v.encode())
+    ctx = ma.Context(0)
+    d = ma.GpuDictionary(ctx, values, facet_values=True)
+    queries = ["", "a", "sta", "rose", "lion", "stone", "alert", "oriental", "é", "ébcd", "xyz", "tionals", "rest in"]
+    queries += [values[int(i)][: int(rng.integers(1, 9))] for i in rng.integers(0, len(values), 12)]
+    checked = 0
+    for q in queries:
+        for typos in (0, 1, 2):
+            got, trunc = d.search_values(q, typos, cap=4000)
+            want = [i for i, v in enumerate(values) if O.osa_distance(q, v, prefix=True) <= typos]
+            assert not trunc
+            assert got.tolist() == want, (q, typos)
+            checked += len(want)
+    assert checked > 2000
+    got, trunc = d.search_values("a", 1, cap=5)
+    assert trunc and len(got) == 5
