@@ -21,6 +21,7 @@
 // extended past a prefix whose documents are exhausted, which visits the same non-empty paths in
 // the same order.  fid/mod.rs and position/mod.rs push their edges in hash-map order (unspecified);
 // here ascending fid / ascending cost.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -1387,6 +1388,10 @@ struct GraphRule : Rule {
   // path claims what the earlier paths left (msi_bits_paths_claim) — the same documents per path as the
   // path-by-path search, because claims never cross documents.
   bool fused_level(uint64_t cost) {
+    // MSI_SEARCH_FUSED_LEVELS=0 forces the path-by-path search (the fallback for levels with > 256 paths), so
+    // that the tests can hold both against the oracle
+    const char *knob = getenv("MSI_SEARCH_FUSED_LEVELS");
+    if (knob && knob[0] == '0') return false;
     std::vector<std::vector<int32_t>> all;
     std::vector<int32_t> cur;
     std::set<uint32_t> visited, to_skip;

@@ -283,3 +283,11 @@ def test_ranking_score_threshold():
                 base = RO.search(RO.Ctx(index, lookup), q, tms="last", length=300, detailed=detailed)
                 seen_cut += len(want_cand) < len(base[2])
     assert seen_cut > 4
+
+
+def test_path_by_path_fallback_matches_too(monkeypatch):
+    """Cost levels with more than 256 paths fall back to the path-by-path search (batched sibling intersections +
+    claim kernel); MSI_SEARCH_FUSED_LEVELS=0 forces it everywhere: the reference snapshots must still replay."""
+    monkeypatch.setenv("MSI_SEARCH_FUSED_LEVELS", "0")
+    for case in CASES[::3]:
+        test_reference_snapshot(case)
