@@ -203,3 +203,195 @@ pub fn keyword_search(dict: &GpuDictionary, sets: &mut GpuDocidSets, source: &mu
         max_matching_words: words.len() as u32, typo_count: tc[i], max_typo_count: mt[i] }).collect();
     Ok((hits, cand))
 }
+
+// ------------------------------------------------------------------------------------------------------
+// The keyword leg with every graph-based ranking rule (msi_keyword_search_ranked)
+// ------------------------------------------------------------------------------------------------------
+
+/// Everything the ranked search reads from the index: the LMDB gets of `search/new/db_cache.rs`, each returning
+/// the stored `CboRoaringBitmap` bytes untouched.  `SearchContext` implements it in the shim.
+pub trait RankingSource: PostingSource {
+    fn word_fid_docids(&mut self, word: &str, fid: u16) -> Option<&[u8]>;
+    fn word_position_docids(&mut self, word: &str, position: u16) -> Option<&[u8]>;
+    fn word_fids(&mut self, word: &str) -> Vec<u16>;
+    fn word_positions(&mut self, word: &str) -> Vec<u16>;
+    fn field_id_word_count_docids(&mut self, fid: u16, count: u8) -> Option<&[u8]>;
+    /// `word_prefix_docids` (+ `exact_word_prefix_docids` when `original`): every stored value goes to `push`;
+    /// returns how many there were (0 = the prefix is not a key, the engine enumerates derivations instead).
+    fn word_prefix_docids(&mut self, prefix: &str, original: bool, push: &mut dyn FnMut(&[u8])) -> usize;
+    fn word_prefix_fid_docids(&mut self, prefix: &str, fid: u16, push: &mut dyn FnMut(&[u8])) -> usize;
+    fn word_prefix_position_docids(&mut self, prefix: &str, position: u16, push: &mut dyn FnMut(&[u8])) -> usize;
+    /// `prefix_iter` over `word_pair_proximity_docids` with the key (proximity, word1, prefix2…), db_cache.rs:451-520.
+    fn word_prefix_pair_proximity_docids(&mut self, proximity: u8, word1: &str, prefix2: &str,
+                                         push: &mut dyn FnMut(&[u8])) -> usize;
+    fn word_prefix_fids(&mut self, prefix: &str) -> Vec<u16>;
+    fn word_prefix_positions(&mut self, prefix: &str) -> Vec<u16>;
+    /// `index.synonyms.get(words)`, each synonym tokenised.
+    fn synonyms(&mut self, words: &[&str]) -> Vec<Vec<String>>;
+}
+
+/// One located query term of `located_query_terms_from_tokens` (parse_query.rs:28-202).
+pub struct LocatedTerm<'a> {
+    /// one word, or the words of a quoted phrase (`None` = a stop word inside the phrase)
+    pub words: Vec<Option<&'a str>>,
+    pub is_phrase: bool,
+    pub is_negative: bool,
+    pub is_prefix: bool,
+    pub positions: std::ops::RangeInclusive<u16>,
+}
+
+/// `ScoreDetails` of the keyword rules (score_details.rs:10-27) as the engine reports them.
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum RankedScore {
+    Words { matching_words: u32, max_matching_words: u32 },
+    Typo { typo_count: u32, max_typo_count: u32 },
+    Proximity { rank: u32, max_rank: u32 },
+    Fid { rank: u32, max_rank: u32 },
+    Position { rank: u32, max_rank: u32 },
+    ExactAttribute { rank: u32 },           // 3 ExactMatch, 2 MatchesStart, 1 NoExactMatch
+    ExactWords { matching_words: u32, max_matching_words: u32 },
+    Skipped,
+}
+
+pub struct RankedSearch<'a> {
+    pub criteria: &'a [i32],                // index.criteria() as sys::MSI_CRIT_*
+    pub all_terms: bool,
+    pub searchable: &'a [(u16, u16)],       // (fid, weight) of searchable_fields_ids / fieldids_weights_map
+    pub max_weight: Option<u16>,
+    pub authorize_typos: bool,
+    pub min_word_len_one_typo: u32,
+    pub min_word_len_two_typos: u32,
+    pub from: usize,
+    pub length: usize,
+    pub detailed_scores: bool,
+    pub time_budget: Option<std::time::Duration>,
+    pub ranking_score_threshold: Option<f64>,
+}
+
+pub struct RankedOutput {
+    pub hits: Vec<(u32, Vec<RankedScore>)>,
+    pub candidates: u64,
+    pub degraded: bool,
+}
+
+type Src<'a> = &'a mut dyn RankingSource;
+unsafe fn src<'a>(user: *mut std::ffi::c_void) -> &'a mut Src<'a> { &mut *(user as *mut Src<'a>) }
+unsafe fn s<'a>(p: *const u8, n: u32) -> Option<&'a str> { std::str::from_utf8(std::slice::from_raw_parts(p, n as usize)).ok() }
+unsafe fn hand(b: Option<&[u8]>, out: *mut *const u8, out_n: *mut usize) -> i32 {
+    match b { Some(b) => { *out = b.as_ptr(); *out_n = b.len(); } None => { *out_n = 0; } }
+    0
+}
+unsafe fn keys(v: Vec<u16>, out: *mut u16, cap: u32, n: *mut u32) -> i32 {
+    *n = v.len() as u32;
+    for (i, k) in v.iter().take(cap as usize).enumerate() { *out.add(i) = *k; }
+    0
+}
+unsafe extern "C" fn r_word(u: *mut std::ffi::c_void, w: *const u8, n: u32, original: i32, o: *mut *const u8, on: *mut usize) -> i32 {
+    let Some(w) = s(w, n) else { return -1 }; hand(src(u).word_docids(w, original != 0), o, on)
+}
+unsafe extern "C" fn r_pair(u: *mut std::ffi::c_void, prox: u32, l: *const u8, ln: u32, r: *const u8, rn: u32, o: *mut *const u8, on: *mut usize) -> i32 {
+    let (Some(l), Some(r)) = (s(l, ln), s(r, rn)) else { return -1 }; hand(src(u).word_pair_proximity_docids(prox as u8, l, r), o, on)
+}
+unsafe extern "C" fn r_exact(u: *mut std::ffi::c_void, w: *const u8, n: u32) -> i32 { s(w, n).map_or(0, |w| src(u).is_exact_word(w) as i32) }
+unsafe extern "C" fn r_fid(u: *mut std::ffi::c_void, w: *const u8, n: u32, fid: u32, o: *mut *const u8, on: *mut usize) -> i32 {
+    let Some(w) = s(w, n) else { return -1 }; hand(src(u).word_fid_docids(w, fid as u16), o, on)
+}
+unsafe extern "C" fn r_pos(u: *mut std::ffi::c_void, w: *const u8, n: u32, pos: u32, o: *mut *const u8, on: *mut usize) -> i32 {
+    let Some(w) = s(w, n) else { return -1 }; hand(src(u).word_position_docids(w, pos as u16), o, on)
+}
+unsafe extern "C" fn r_fids(u: *mut std::ffi::c_void, w: *const u8, n: u32, out: *mut u16, cap: u32, cnt: *mut u32) -> i32 {
+    let Some(w) = s(w, n) else { return -1 }; keys(src(u).word_fids(w), out, cap, cnt)
+}
+unsafe extern "C" fn r_positions(u: *mut std::ffi::c_void, w: *const u8, n: u32, out: *mut u16, cap: u32, cnt: *mut u32) -> i32 {
+    let Some(w) = s(w, n) else { return -1 }; keys(src(u).word_positions(w), out, cap, cnt)
+}
+unsafe extern "C" fn r_count(u: *mut std::ffi::c_void, fid: u32, count: u32, o: *mut *const u8, on: *mut usize) -> i32 {
+    hand(src(u).field_id_word_count_docids(fid as u16, count as u8), o, on)
+}
+fn pusher(push: sys::msi_posting_sink, sink: *mut std::ffi::c_void) -> impl FnMut(&[u8]) {
+    move |b: &[u8]| unsafe { push(sink, b.as_ptr(), b.len()); }
+}
+unsafe extern "C" fn r_pfx(u: *mut std::ffi::c_void, p: *const u8, n: u32, original: i32, push: sys::msi_posting_sink, sink: *mut std::ffi::c_void) -> i32 {
+    let Some(p) = s(p, n) else { return -1 }; src(u).word_prefix_docids(p, original != 0, &mut pusher(push, sink)) as i32
+}
+unsafe extern "C" fn r_pfx_fid(u: *mut std::ffi::c_void, p: *const u8, n: u32, fid: u32, push: sys::msi_posting_sink, sink: *mut std::ffi::c_void) -> i32 {
+    let Some(p) = s(p, n) else { return -1 }; src(u).word_prefix_fid_docids(p, fid as u16, &mut pusher(push, sink)) as i32
+}
+unsafe extern "C" fn r_pfx_pos(u: *mut std::ffi::c_void, p: *const u8, n: u32, pos: u32, push: sys::msi_posting_sink, sink: *mut std::ffi::c_void) -> i32 {
+    let Some(p) = s(p, n) else { return -1 }; src(u).word_prefix_position_docids(p, pos as u16, &mut pusher(push, sink)) as i32
+}
+unsafe extern "C" fn r_pfx_pair(u: *mut std::ffi::c_void, prox: u32, w: *const u8, wn: u32, p: *const u8, pn: u32, push: sys::msi_posting_sink, sink: *mut std::ffi::c_void) -> i32 {
+    let (Some(w), Some(p)) = (s(w, wn), s(p, pn)) else { return -1 };
+    src(u).word_prefix_pair_proximity_docids(prox as u8, w, p, &mut pusher(push, sink)) as i32
+}
+unsafe extern "C" fn r_pfx_fids(u: *mut std::ffi::c_void, p: *const u8, n: u32, out: *mut u16, cap: u32, cnt: *mut u32) -> i32 {
+    let Some(p) = s(p, n) else { return -1 }; keys(src(u).word_prefix_fids(p), out, cap, cnt)
+}
+unsafe extern "C" fn r_pfx_positions(u: *mut std::ffi::c_void, p: *const u8, n: u32, out: *mut u16, cap: u32, cnt: *mut u32) -> i32 {
+    let Some(p) = s(p, n) else { return -1 }; keys(src(u).word_prefix_positions(p), out, cap, cnt)
+}
+unsafe extern "C" fn r_syn(u: *mut std::ffi::c_void, ws: *const sys::msi_query_token, n: u32, push: sys::msi_synonym_sink, sink: *mut std::ffi::c_void) -> i32 {
+    let toks = std::slice::from_raw_parts(ws, n as usize);
+    let Some(words) = toks.iter().map(|t| s(t.word, t.len)).collect::<Option<Vec<_>>>() else { return -1 };
+    for syn in src(u).synonyms(&words) {
+        let t: Vec<_> = syn.iter().map(|w| sys::msi_query_token { word: w.as_ptr(), len: w.len() as u32, is_prefix: 0 }).collect();
+        if push(sink, t.as_ptr(), t.len() as u32) < 0 { return -1; }
+    }
+    0
+}
+
+/// `execute_search` for a keyword query (search/new/mod.rs:808-880) on the device-set engine.
+pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, source: &mut dyn RankingSource,
+                             terms: &[LocatedTerm<'_>], universe: Option<&[u8]>, q: &RankedSearch<'_>)
+                             -> Result<RankedOutput, GpuError> {
+    let tokens: Vec<Vec<sys::msi_query_token>> = terms.iter().map(|t| t.words.iter().map(|w| match w {
+        Some(w) => sys::msi_query_token { word: w.as_ptr(), len: w.len() as u32, is_prefix: (t.is_prefix && !t.is_phrase) as u32 },
+        None => sys::msi_query_token { word: ptr::null(), len: 0, is_prefix: 0 },
+    }).collect()).collect();
+    let located: Vec<_> = terms.iter().zip(&tokens).map(|(t, toks)| sys::msi_located_term {
+        words: toks.as_ptr(), n_words: toks.len() as u32,
+        is_phrase: (t.is_phrase as u32) | ((t.is_negative as u32) << 1),
+        position_start: *t.positions.start() as u32, position_end: *t.positions.end() as u32 }).collect();
+    let (fids, weights): (Vec<u16>, Vec<u16>) = q.searchable.iter().copied().unzip();
+    let params = sys::msi_search_params {
+        authorize_typos: q.authorize_typos as u32, min_word_len_one_typo: q.min_word_len_one_typo,
+        min_word_len_two_typos: q.min_word_len_two_typos,
+        strategy: if q.all_terms { sys::MSI_TERMS_ALL } else { sys::MSI_TERMS_LAST },
+        criteria: q.criteria.as_ptr(), n_criteria: q.criteria.len() as u32,
+        searchable_fids: fids.as_ptr(), searchable_weights: weights.as_ptr(), n_searchable: fids.len() as u32,
+        max_weight: q.max_weight.map_or(-1, |w| w as i32), from: q.from as u32, length: q.length as u32,
+        detailed_scores: q.detailed_scores as i32,
+        time_budget_us: q.time_budget.map_or(0, |d| d.as_micros().max(1) as u64), stop_after: -1,
+        has_score_threshold: q.ranking_score_threshold.is_some() as i32,
+        score_threshold: q.ranking_score_threshold.unwrap_or(0.0) };
+    let mut src_ref: Src<'_> = source;
+    let vt = sys::msi_index_vtable { user: &mut src_ref as *mut _ as *mut _, word_docids: Some(r_word),
+        word_pair_proximity_docids: Some(r_pair), is_exact_word: Some(r_exact), word_fid_docids: Some(r_fid),
+        word_position_docids: Some(r_pos), word_fids: Some(r_fids), word_positions: Some(r_positions),
+        field_id_word_count_docids: Some(r_count), word_prefix_docids: Some(r_pfx), word_prefix_fid_docids: Some(r_pfx_fid),
+        word_prefix_position_docids: Some(r_pfx_pos), word_prefix_pair_proximity_docids: Some(r_pfx_pair),
+        word_prefix_fids: Some(r_pfx_fids), word_prefix_positions: Some(r_pfx_positions), synonyms: Some(r_syn) };
+    let len = q.length.max(1);
+    let mut ids = vec![0u32; len];
+    let mut details = vec![sys::msi_score_detail::default(); len * sys::MSI_MAX_SCORE_DETAILS];
+    let mut n_details = vec![0u32; len];
+    let (mut n, mut cand, mut degraded) = (0u32, 0u64, 0i32);
+    let (up, ul) = universe.map_or((ptr::null(), 0), |u| (u.as_ptr(), u.len()));
+    check(unsafe { sys::msi_keyword_search_ranked(dict.h.as_ptr(), sets.raw(), &vt, located.as_ptr(), located.len() as u32,
+                                                  &params, up, ul, ids.as_mut_ptr(), details.as_mut_ptr(),
+                                                  n_details.as_mut_ptr(), &mut n, &mut cand, &mut degraded) })?;
+    let hits = (0..n as usize).map(|i| {
+        let d = &details[i * sys::MSI_MAX_SCORE_DETAILS..][..n_details[i] as usize];
+        (ids[i], d.iter().map(|d| match d.kind {
+            0 => RankedScore::Words { matching_words: d.a, max_matching_words: d.b },
+            1 => RankedScore::Typo { typo_count: d.a, max_typo_count: d.b },
+            2 => RankedScore::Proximity { rank: d.a, max_rank: d.b },
+            3 => RankedScore::Fid { rank: d.a, max_rank: d.b },
+            4 => RankedScore::Position { rank: d.a, max_rank: d.b },
+            5 => RankedScore::ExactAttribute { rank: d.a },
+            6 => RankedScore::ExactWords { matching_words: d.a, max_matching_words: d.b },
+            _ => RankedScore::Skipped,
+        }).collect())
+    }).collect();
+    Ok(RankedOutput { hits, candidates: cand, degraded: degraded != 0 })
+}
