@@ -296,7 +296,7 @@ MAX_SCORE_DETAILS = 8
 def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERMS_LAST, offset=0, limit=20,
                           detailed=False, searchable_fids=(), searchable_weights=(), max_weight=None,
                           authorize_typos=True, min_one=5, min_two=9, universe_cbo=None, time_budget_us=0,
-                          stop_after=None, return_degraded=False, score_threshold=None):
+                          stop_after=None, return_degraded=False, score_threshold=None, _entry=None):
     """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
     terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
     (words: [str | None], None = a stop word inside a phrase; an optional 6th element True marks a negative term).
@@ -334,7 +334,8 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
     nsc = np.zeros(L, dtype=np.uint32)
     out_n, cand, degraded = C.c_uint32(0), C.c_uint64(0), C.c_int32(0)
     ub = np.frombuffer(universe_cbo, dtype=np.uint8) if universe_cbo is not None else None
-    check(lib().msi_keyword_search_ranked(gdict._h, pool._h, C.byref(callbacks.vtable), lt, n, C.byref(prm),
+    entry = _entry or lib().msi_keyword_search_ranked   # _entry: the CPU test tier's host-logic build (tests/hostlogic)
+    check(entry(gdict._h, pool._h, C.byref(callbacks.vtable), lt, n, C.byref(prm),
                                           np_ptr(ub) if ub is not None else None, 0 if ub is None else ub.size,
                                           np_ptr(ids), C.cast(sc, C.c_void_p), np_ptr(nsc), C.byref(out_n),
                                           C.byref(cand), C.byref(degraded)))

@@ -1,0 +1,191 @@
+// TEST DOUBLE — not part of the product, never linked into libmsi.so, never loaded by meilisearch_amd.
+//
+// Plain-C++ stand-ins for the device-set pool (msi_bits_*) and the device dictionary (msi_dict_*) so that the HOST
+// logic of msi_search.hip (query graph, rule graphs, path enumeration, bucket sort, caches) can be exercised by the
+// CPU test tier: tests/test_search_hostlogic_cpu.py compiles msi_search.hip together with this file into
+// tests/hostlogic/_build/libmsi_hostlogic_test.so and replays the reference snapshots through it.  The GPU tier
+// (tests/test_search_gpu.py) runs the same cases through the real kernels.
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "msi_common.h"
+
+struct msi_bits {
+  uint64_t n_docs = 0, n_words = 0;
+  uint32_t n_slots = 0;
+  std::vector<uint64_t> pool;
+  uint64_t *slot(uint32_t s) { return pool.data() + (uint64_t)s * n_words; }
+};
+
+typedef int32_t (*mock_lookup_fn)(const uint8_t *word, uint32_t len, uint32_t max_typos, uint32_t is_prefix, uint32_t cap_one,
+                                  uint32_t cap_two, uint32_t *one, uint32_t *n_one, uint32_t *two, uint32_t *n_two);
+struct msi_dict {
+  std::vector<std::string> words;  // sorted
+  mock_lookup_fn lookup = nullptr;
+};
+
+uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
+
+bool msi_dict_word(const msi_dict *d, uint32_t idx, const uint8_t **w, uint32_t *len) {
+  if (idx >= d->words.size()) return false;
+  *w = (const uint8_t *)d->words[idx].data();
+  *len = (uint32_t)d->words[idx].size();
+  return true;
+}
+void msi_dict_prefix_range(const msi_dict *d, const uint8_t *prefix, uint32_t plen, uint32_t *lo, uint32_t *hi) {
+  const std::string p((const char *)prefix, plen);
+  uint32_t a = 0;
+  while (a < d->words.size() && d->words[a].compare(0, plen, p) < 0) ++a;
+  uint32_t b = a;
+  while (b < d->words.size() && d->words[b].size() >= plen && d->words[b].compare(0, plen, p) == 0) ++b;
+  *lo = a;
+  *hi = b;
+}
+
+static uint64_t popcount_slot(msi_bits *p, uint32_t s) {
+  uint64_t c = 0;
+  for (uint64_t i = 0; i < p->n_words; ++i) c += (uint64_t)__builtin_popcountll(p->slot(s)[i]);
+  return c;
+}
+
+int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &b, bool clear) {
+  uint64_t *dst = p->slot(slot);
+  if (clear) std::fill(dst, dst + p->n_words, 0ull);
+  auto set = [&](uint64_t id) {
+    if (id < p->n_docs) dst[id >> 6] |= 1ull << (id & 63);
+  };
+  for (const MsiContainer &c : b.containers) {
+    const uint8_t *body = b.bytes.data() + c.offset;
+    const uint64_t hi = (uint64_t)c.key << 16;
+    auto rd16 = [&](size_t o) { return (uint32_t)body[o] | ((uint32_t)body[o + 1] << 8); };
+    if (c.type == 0) {
+      for (uint32_t i = 0; i < c.card; ++i) set(hi | rd16(2 * i));
+    } else if (c.type == 1) {
+      for (uint32_t v = 0; v < 65536; ++v)
+        if ((body[v >> 3] >> (v & 7)) & 1) set(hi | v);
+    } else {
+      for (uint32_t r = 0; r < c.card; ++r) {
+        const uint32_t start = rd16(4 * r), len = rd16(4 * r + 2);
+        for (uint32_t v = start; v <= start + len; ++v) set(hi | v);
+      }
+    }
+  }
+  for (uint32_t id : b.small_ids) set(id);
+  return MSI_OK;
+}
+
+int32_t msi_bits_and_many_count(msi_bits *p, uint32_t prefix, uint32_t n, const uint32_t *cond, const uint32_t *dst,
+                                uint64_t *counts) {
+  for (uint32_t k = 0; k < n; ++k) {
+    for (uint64_t i = 0; i < p->n_words; ++i) p->slot(dst[k])[i] = p->slot(prefix)[i] & p->slot(cond[k])[i];
+    counts[k] = popcount_slot(p, dst[k]);
+  }
+  return MSI_OK;
+}
+
+int32_t msi_bits_claim(msi_bits *p, uint32_t docs, uint32_t bucket, uint32_t universe, uint32_t n_stack,
+                       const uint32_t *stack) {
+  for (uint64_t i = 0; i < p->n_words; ++i) {
+    const uint64_t d = p->slot(docs)[i];
+    p->slot(bucket)[i] |= d;
+    p->slot(universe)[i] &= ~d;
+    for (uint32_t k = 0; k < n_stack; ++k) p->slot(stack[k])[i] &= ~d;
+  }
+  return MSI_OK;
+}
+
+int32_t msi_bits_clear_slots(msi_bits *p, uint32_t n, const uint32_t *slots) {
+  for (uint32_t k = 0; k < n; ++k) std::fill(p->slot(slots[k]), p->slot(slots[k]) + p->n_words, 0ull);
+  return MSI_OK;
+}
+
+int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
+                             uint32_t bucket, uint32_t universe, uint64_t *counts) {
+  for (uint32_t k = 0; k < n_paths; ++k) counts[k] = 0;
+  for (uint64_t i = 0; i < p->n_words; ++i) {
+    uint64_t u = p->slot(universe)[i], b = p->slot(bucket)[i];
+    for (uint32_t k = 0; k < n_paths && u; ++k) {
+      uint64_t m = u;
+      for (uint32_t s = path_off[k]; s < path_off[k + 1]; ++s) m &= p->slot(step_slots[s])[i];
+      if (m) {
+        b |= m;
+        u &= ~m;
+        counts[k] += (uint64_t)__builtin_popcountll(m);
+      }
+    }
+    p->slot(universe)[i] = u;
+    p->slot(bucket)[i] = b;
+  }
+  return MSI_OK;
+}
+
+extern "C" {
+
+int32_t msi_bits_fill(msi_bits *p, uint32_t slot, int32_t ones) {
+  uint64_t *d = p->slot(slot);
+  std::fill(d, d + p->n_words, 0ull);
+  if (ones)
+    for (uint64_t i = 0; i < p->n_docs; ++i) d[i >> 6] |= 1ull << (i & 63);
+  return MSI_OK;
+}
+
+int32_t msi_bits_op(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int32_t op) {
+  for (uint64_t i = 0; i < p->n_words; ++i) {
+    const uint64_t x = p->slot(a)[i], y = p->slot(b)[i];
+    p->slot(dst)[i] = op == MSI_BITS_AND ? (x & y) : op == MSI_BITS_OR ? (x | y) : op == MSI_BITS_ANDNOT ? (x & ~y) : (x ^ y);
+  }
+  return MSI_OK;
+}
+
+int32_t msi_bits_op_count(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int32_t op, uint64_t *out_count) {
+  msi_bits_op(p, dst, a, b, op);
+  *out_count = popcount_slot(p, dst);
+  return MSI_OK;
+}
+
+int32_t msi_bits_count(msi_bits *p, uint32_t slot, uint64_t *out) {
+  *out = popcount_slot(p, slot);
+  return MSI_OK;
+}
+
+int32_t msi_bits_first_k(msi_bits *p, uint32_t slot, uint32_t k, uint32_t *out_docids, uint32_t *out_n) {
+  uint32_t n = 0;
+  for (uint64_t i = 0; i < p->n_docs && n < k; ++i)
+    if ((p->slot(slot)[i >> 6] >> (i & 63)) & 1) out_docids[n++] = (uint32_t)i;
+  *out_n = n;
+  return MSI_OK;
+}
+
+int32_t msi_dict_lookup(msi_dict *d, const msi_typo_query *q, uint32_t n, uint32_t cap_one, uint32_t cap_two,
+                        uint32_t *out_one_idx, uint32_t *out_one_cnt, uint32_t *out_two_idx, uint32_t *out_two_cnt) {
+  for (uint32_t i = 0; i < n; ++i) {
+    const int32_t st = d->lookup(q[i].word, q[i].len, q[i].max_typos, q[i].is_prefix, cap_one, cap_two,
+                                 out_one_idx + (size_t)i * cap_one, out_one_cnt + i, out_two_idx + (size_t)i * cap_two,
+                                 out_two_cnt + i);
+    if (st != MSI_OK) return st;
+  }
+  return MSI_OK;
+}
+
+// ---- constructors for the test harness -----------------------------------------------------------
+msi_bits *mock_bits_create(uint64_t n_docs, uint32_t n_slots) {
+  msi_bits *p = new msi_bits();
+  p->n_docs = n_docs;
+  p->n_words = std::max<uint64_t>(2, ((n_docs + 127) / 128) * 2);
+  p->n_slots = n_slots;
+  p->pool.assign((size_t)p->n_words * n_slots, 0xDEADBEEFDEADBEEFull);  // stale content must never leak into results
+  return p;
+}
+void mock_bits_destroy(msi_bits *p) { delete p; }
+msi_dict *mock_dict_create(const uint8_t *concat, const uint32_t *offsets, uint32_t n, mock_lookup_fn lookup) {
+  msi_dict *d = new msi_dict();
+  for (uint32_t i = 0; i < n; ++i) d->words.emplace_back((const char *)concat + offsets[i], offsets[i + 1] - offsets[i]);
+  d->lookup = lookup;
+  return d;
+}
+void mock_dict_destroy(msi_dict *d) { delete d; }
+
+}  // extern "C"

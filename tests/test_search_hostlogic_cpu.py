@@ -1,0 +1,169 @@
+"""CPU tier for the HOST logic of msi_keyword_search_ranked (query graph, rule graphs, path enumeration, bucket sort,
+caches, deadline, threshold): meilisearch_amd/csrc/msi_search.hip is compiled together with a plain-C++ test double
+of the device-set pool and the device dictionary (tests/hostlogic/mock_device.cpp — NOT part of the product, never
+loaded by meilisearch_amd) and the reference's snapshot searches are replayed through it.  The GPU tier
+(tests/test_search_gpu.py) replays the same cases through the real kernels."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from meilisearch_amd import _lib
+from meilisearch_amd import ranking as R
+from oracle import oracle as O
+from tests.toy_milli import ToyMilli, query_terms
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "hostlogic", "_build")
+SO = os.path.join(BUILD, "libmsi_hostlogic_test.so")
+SOURCES = [os.path.join(ROOT, "tests", "hostlogic", "mock_device.cpp"),
+           os.path.join(ROOT, "meilisearch_amd", "csrc", "msi_search.hip"),
+           os.path.join(ROOT, "meilisearch_amd", "csrc", "msi_common.h"), os.path.join(ROOT, "include", "msi.h")]
+FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "ranking_snapshots.json")))
+
+LOOKUP_FN = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    _lib.lib()   # the product library first (one HIP runtime; msi_set_error / parsers come from it)
+    if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in SOURCES + [_lib.lib_path()]):
+        os.makedirs(BUILD, exist_ok=True)
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared",
+                               "-I" + os.path.join(ROOT, "meilisearch_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                               SOURCES[0], SOURCES[1], "-L" + os.path.join(ROOT, "meilisearch_amd"), "-lmsi",
+                               "-Wl,-rpath," + os.path.join(ROOT, "meilisearch_amd"), "-o", SO])
+    L = C.CDLL(SO)
+    L.msi_keyword_search_ranked.restype, L.msi_keyword_search_ranked.argtypes = _lib.PROTOTYPES["msi_keyword_search_ranked"]
+    L.mock_bits_create.restype, L.mock_bits_create.argtypes = C.c_void_p, [C.c_uint64, C.c_uint32]
+    L.mock_bits_destroy.restype, L.mock_bits_destroy.argtypes = None, [C.c_void_p]
+    L.mock_dict_create.restype, L.mock_dict_create.argtypes = C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint32, LOOKUP_FN]
+    L.mock_dict_destroy.restype, L.mock_dict_destroy.argtypes = None, [C.c_void_p]
+    return L
+
+
+class Handle:
+    def __init__(self, h):
+        self._h = C.c_void_p(h)
+
+
+class MockHarness:
+    """The same call the GPU harness makes, against the host-logic build."""
+
+    def __init__(self, L, index, n_slots=512):
+        self.L, self.index = L, index
+        dic = O.Dictionary(index.words)
+        words = index.words
+
+        def lookup(w, n, max_typos, is_prefix, cap1, cap2, one, n1, two, n2):
+            try:
+                a, b = O.typo_lookup(dic, bytes(w[:n]), max_typos, bool(is_prefix), cap1, cap2)
+                for i, v in enumerate(a):
+                    one[i] = int(v)
+                for i, v in enumerate(b):
+                    two[i] = int(v)
+                n1[0], n2[0] = len(a), len(b)
+                return 0
+            except Exception:   # noqa: BLE001
+                return -8
+        self._cb = LOOKUP_FN(lookup)
+        bs = [w.encode() for w in words]
+        self._concat = np.frombuffer(b"".join(bs) or b"\0", dtype=np.uint8).copy()
+        self._offs = np.zeros(len(bs) + 1, dtype=np.uint32)
+        if bs:
+            np.cumsum([len(b) for b in bs], out=self._offs[1:])
+        self.dict = Handle(L.mock_dict_create(self._concat.ctypes.data, self._offs.ctypes.data, len(bs), self._cb))
+        self.pool = Handle(L.mock_bits_create(max(index.n_docs, 1), n_slots))
+        self.cb = R.IndexCallbacks(index)
+
+    def search(self, query, tms="last", criteria=None, offset=0, limit=20, detailed=False, stop_after=None, **kw):
+        ix = self.index
+        return R.keyword_search_ranked(
+            self.dict, self.pool, self.cb, query_terms(query, stop_words=ix.stop_words),
+            criteria if criteria is not None else ix.criteria,
+            strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
+            searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
+            max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,
+            stop_after=stop_after, _entry=self.L.msi_keyword_search_ranked, **kw)
+
+    def close(self):
+        self.L.mock_bits_destroy(self.pool._h)
+        self.L.mock_dict_destroy(self.dict._h)
+
+
+def debug_score(s):
+    k = s[0]
+    if k == "Words":
+        return f"Words(Words{{matching_words:{s[1]},max_matching_words:{s[2]},}},)"
+    if k == "Typo":
+        return f"Typo(Typo{{typo_count:{s[1]},max_typo_count:{s[2]},}},)"
+    if k == "ExactWords":
+        return f"ExactWords(ExactWords{{matching_words:{s[1]},max_matching_words:{s[2]},}},)"
+    if k == "ExactAttribute":
+        return "ExactAttribute(%s,)" % {3: "ExactMatch", 2: "MatchesStart", 1: "NoExactMatch"}[s[1]]
+    if k == "Skipped":
+        return "Skipped"
+    return f"{k}(Rank{{rank:{s[1]},max_rank:{s[2]},}},)"
+
+
+def build_index(cfg, **extra):
+    return ToyMilli(cfg["docs"], searchable=cfg.get("searchable"), exact_attributes=cfg.get("exact_attributes", ()),
+                    exact_words=cfg.get("exact_words", ()), criteria=cfg.get("criteria"),
+                    min_one=cfg.get("min_one", 5), min_two=cfg.get("min_two", 9),
+                    authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"),
+                    stop_words=cfg.get("stop_words", ()), **extra)
+
+
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["level-at-once", "path-by-path"])
+def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused):
+    """All 94 reference searches, with the whole-level evaluation and with the path-by-path fallback."""
+    monkeypatch.setenv("MSI_SEARCH_FUSED_LEVELS", fused)
+    harnesses, n = {}, 0
+    for case in FIX["cases"]:
+        if case["index"] not in harnesses:
+            harnesses[case["index"]] = MockHarness(hostlib, build_index(FIX["indexes"][case["index"]]))
+        h = harnesses[case["index"]]
+        hits, _ = h.search(case["query"], tms=case["tms"], offset=case["offset"], limit=case["limit"],
+                           detailed=case["detailed"], stop_after=case.get("stop_after"))
+        ids = [d for d, _ in hits]
+        if case["ids"] is not None:
+            assert ids == case["ids"], case["src"]
+        if case.get("scores"):
+            assert "[" + "".join("[" + "".join(debug_score(s) + "," for s in sc) + "]," for _, sc in hits) + "]" == case["scores"]
+        if case.get("ids_scores"):
+            got = "[" + "".join(f"({d},[" + "".join(debug_score(s) + "," for s in sc) + "],)," for d, sc in hits) + "]"
+            assert got == case["ids_scores"], case["src"]
+        if case.get("global_scores"):
+            assert [f"{R.score_details_global_score(sc):.4f}" for _, sc in hits] == case["global_scores"]
+        n += 1
+    assert n == len(FIX["cases"]) >= 94
+    for h in harnesses.values():
+        h.close()
+
+
+def test_host_logic_matches_oracle_on_random_corpora(hostlib):
+    from oracle import ranking_oracle as RO
+    import tests.test_search_gpu as G
+    docs = G.random_corpus(31, 200)
+    for criteria in G.RULESETS[:4]:
+        for pt in (100, 3):
+            index = ToyMilli(docs, searchable=["title", "body"], criteria=criteria, prefix_threshold=pt)
+            dic = O.Dictionary(index.words)
+
+            def lookup(word, max_typos, is_prefix):
+                one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+                return [index.words[i] for i in one], [index.words[i] for i in two]
+            h = MockHarness(hostlib, index)
+            for q in G.QUERIES:
+                for tms in ("last", "all"):
+                    want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms=tms, criteria=criteria, length=25,
+                                                             detailed=True)
+                    hits, cand = h.search(q, tms=tms, criteria=criteria, limit=25, detailed=True)
+                    assert [d for d, _ in hits] == want_ids, (criteria, q, tms)
+                    assert [[tuple(s) for s in sc] for _, sc in hits] == [[G.oracle_score(s) for s in sc] for sc in want_sc]
+                    assert cand == len(want_cand)
+            h.close()
