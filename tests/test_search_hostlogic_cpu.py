@@ -167,3 +167,28 @@ def test_host_logic_matches_oracle_on_random_corpora(hostlib):
                     assert [[tuple(s) for s in sc] for _, sc in hits] == [[G.oracle_score(s) for s in sc] for sc in want_sc]
                     assert cand == len(want_cand)
             h.close()
+
+
+def test_long_queries_match_the_oracle(hostlib):
+    """6 / 8 / 10-term queries (n-gram nodes, many paths per level: both evaluation modes get used)."""
+    import random
+    from oracle import ranking_oracle as RO
+    import tests.test_search_gpu as G
+    rng = random.Random(3)
+    index = ToyMilli(G.random_corpus(41, 400), searchable=["title", "body"])
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    h = MockHarness(hostlib, index, n_slots=2048)
+    for n in (6, 8, 10):
+        for _ in range(4):
+            q = " ".join(rng.choice(G.VOCAB) for _ in range(n))
+            for tms in ("last", "all"):
+                want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms=tms, length=20, detailed=True)
+                hits, cand = h.search(q, tms=tms, limit=20, detailed=True)
+                assert [d for d, _ in hits] == want_ids, (q, tms)
+                assert [[tuple(s) for s in sc] for _, sc in hits] == [[G.oracle_score(s) for s in sc] for sc in want_sc]
+                assert cand == len(want_cand)
+    h.close()
