@@ -475,6 +475,11 @@ typedef struct msi_index_vtable {
    * words of an n-gram): pushes every synonym as its tokenised words, in stored order.  Nullable. */
   int32_t (*synonyms)(void *user, const struct msi_query_token *words, uint32_t n_words,
                       msi_synonym_sink push, void *sink);
+  /* The keys of exact_word_docids that start with `prefix`, in key order (the words of exact attributes are not
+   * in the words FST / msi_dict): find_zero_typo_prefix_derivations merges them with the word_docids keys
+   * (compute_derivations.rs:40-73).  Pushes each word as a one-token list.  Nullable = no exact attributes. */
+  int32_t (*exact_words_with_prefix)(void *user, const uint8_t *prefix, uint32_t len, msi_synonym_sink push,
+                                     void *sink);
 } msi_index_vtable;
 typedef struct msi_query_token {
   const uint8_t *word;

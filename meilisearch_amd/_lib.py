@@ -69,6 +69,9 @@ SYNONYM_SINK_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32)
 SYNONYMS_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, SYNONYM_SINK_FN, C.c_void_p)
 
 
+EXACT_PREFIX_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, SYNONYM_SINK_FN, C.c_void_p)
+
+
 class IndexVtable(C.Structure):
     _fields_ = [("user", C.c_void_p), ("word_docids", WORD_DOCIDS_FN),
                 ("word_pair_proximity_docids", PAIR_DOCIDS_FN), ("is_exact_word", EXACT_WORD_FN),
@@ -79,7 +82,7 @@ class IndexVtable(C.Structure):
                 ("word_prefix_position_docids", PREFIX_KEY_DOCIDS_FN),
                 ("word_prefix_pair_proximity_docids", PREFIX_PAIR_DOCIDS_FN),
                 ("word_prefix_fids", WORD_KEYS_FN), ("word_prefix_positions", WORD_KEYS_FN),
-                ("synonyms", SYNONYMS_FN)]
+                ("synonyms", SYNONYMS_FN), ("exact_words_with_prefix", EXACT_PREFIX_FN)]
 
 
 class ScoreDetail(C.Structure):

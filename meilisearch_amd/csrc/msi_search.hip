@@ -21,6 +21,7 @@
 // extended past a prefix whose documents are exhausted, which visits the same non-empty paths in
 // the same order.  fid/mod.rs and position/mod.rs push their edges in hash-map order (unspecified);
 // here ascending fid / ascending cost.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -335,7 +336,7 @@ struct Ctx {
   // the rules below it).
   std::map<Subset, Set> subset_cache;
   std::map<std::tuple<Subset, int, std::vector<uint32_t>>, Set> within_cache;
-  std::map<std::string, std::pair<Set, Set>> exact_attr_cache;
+  std::map<std::string, std::vector<Set>> exact_attr_cache;  // {ExactMatch, MatchesStart, position candidates}
   std::map<std::tuple<Subset, Subset, uint32_t, uint32_t>, Set> prox_cache;
   std::map<std::pair<uint32_t, bool>, Set> word_cache;
   void relieve() {  // keep the pool from running dry on long queries: drop what can be recomputed
@@ -547,14 +548,37 @@ struct Ctx {
     // word_prefix_docids has the word, or (not for n-grams) exact_word_prefix_docids (:193-205)
     if (is_prefix && add_prefix(nullptr, t.original, !is_ngram) > 0) t.use_prefix_db = (int32_t)t.original;
     if (is_prefix && t.use_prefix_db < 0) {
+      // find_zero_typo_prefix_derivations :40-73: the keys of word_docids (= the dictionary) merged in key order with
+      // the keys of exact_word_docids, the word itself left out, at most 1000
       uint32_t lo = 0, hi = 0;
       msi_dict_prefix_range(dict, (const uint8_t *)w.data(), (uint32_t)w.size(), &lo, &hi);
-      for (uint32_t i = lo; i < hi && t.prefix_of.size() < MAX_PREFIX_COUNT; ++i) {
-        const uint8_t *dw;
-        uint32_t dl;
-        msi_dict_word(dict, i, &dw, &dl);
-        if (dl == w.size()) continue;
-        t.prefix_of.push_back(word(std::string((const char *)dw, dl)));
+      std::vector<std::string> exact;
+      if (ix->exact_words_with_prefix) {
+        SynSink sk{this, {}};
+        Cb cb_;
+        if (ix->exact_words_with_prefix(ix->user, (const uint8_t *)w.data(), (uint32_t)w.size(), syn_push, &sk) < 0)
+          fail(MSI_E_INTERNAL, "exact_words_with_prefix callback failed");
+        for (Phrase &p : sk.out)
+          if (!p.empty() && p[0] >= 0) exact.push_back(words[(uint32_t)p[0]]);
+      }
+      size_t ei = 0;
+      uint32_t di = lo;
+      while ((di < hi || ei < exact.size()) && t.prefix_of.size() < MAX_PREFIX_COUNT) {
+        std::string next;
+        if (di < hi) {
+          const uint8_t *dw;
+          uint32_t dl;
+          msi_dict_word(dict, di, &dw, &dl);
+          next.assign((const char *)dw, dl);
+        }
+        if (di >= hi || (ei < exact.size() && exact[ei] < next)) {
+          next = exact[ei++];
+        } else {
+          if (ei < exact.size() && exact[ei] == next) ++ei;
+          ++di;
+        }
+        if (next == w) continue;
+        t.prefix_of.push_back(word(next));
       }
     }
     return t;
@@ -1618,11 +1642,14 @@ struct ExactAttributeRule : Rule {
         c.dev.or_(e2, S);
       }
       c.dev.sub_(e2, e1);  // a document can match exactly in one field and only start another: ExactMatch wins
-      hit = c.exact_attr_cache.emplace(sig, std::make_pair(e1, e2)).first;
+      hit = c.exact_attr_cache.emplace(sig, std::vector<Set>{e1, e2, P}).first;
     }
     // both buckets against this universe in one launch and one wait (they are disjoint, so taking the first out
     // of the universe does not change the second)
-    auto both = c.dev.and_many(universe, {hit->second.first, hit->second.second});
+    auto both = c.dev.and_many(universe, hit->second);
+    // no document has the words at their positions: the reference answers with the single NoExactMatch bucket
+    // (State::Empty, exact_attribute.rs:154-170) — same documents either way, one loop iteration instead of three
+    if (!both[2].second) return;
     exact_match = both[0].first;
     matches_start = both[1].first;
     exact_count = both[0].second;
@@ -1926,6 +1953,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     if (scores.size() > cur) scores.pop_back();
     return true;
   };
+  const bool trace = getenv("MSI_SEARCH_TRACE") != nullptr;  // one line per bucket on stderr (debugging aid)
   while (n_out < length) {
     if (uni_counts[cur] == 0 || (!detailed && uni_counts[cur] == 1)) {
       if (uni_counts[cur]) add(unis[cur], uni_counts[cur]);
@@ -1961,6 +1989,10 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     ++g_stats.buckets;
     scores.push_back(b.score);
     const bool below = p->has_score_threshold && global_score(scores) < p->score_threshold;
+    if (trace)
+      fprintf(stderr, "[msi trace] rule %zu kind %d bucket %llu left %llu score (%u,%u,%u) below %d\n", cur, rules[cur]->kind,
+              (unsigned long long)b.count, (unsigned long long)(uni_counts[cur] - b.count), b.score.kind, b.score.a,
+              b.score.b, (int)below);
     if (!b.universe_reduced) c.dev.sub_(unis[cur], b.docs);
     uni_counts[cur] -= b.count;
     if (cur == nr - 1 || (!detailed && b.count <= 1) || cur_off + b.count < from || below) {

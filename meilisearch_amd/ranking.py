@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import (EXACT_WORD_FN, FID_COUNT_DOCIDS_FN, PAIR_DOCIDS_FN, PREFIX_DOCIDS_FN, PREFIX_KEY_DOCIDS_FN,
-                   PREFIX_PAIR_DOCIDS_FN, SYNONYMS_FN, WORD_DOCIDS_FN, WORD_KEY_DOCIDS_FN, WORD_KEYS_FN,
+                   PREFIX_PAIR_DOCIDS_FN, SYNONYMS_FN, EXACT_PREFIX_FN, WORD_DOCIDS_FN, WORD_KEY_DOCIDS_FN, WORD_KEYS_FN,
                    IndexVtable, KeywordParams, LocatedTerm, QueryToken, RankBucket, ScoreDetail, SearchParams,
                    RankNode, RankQuery, RankTerm, check, lib)
 from .device import np_ptr
@@ -253,6 +253,19 @@ class IndexCallbacks:
             self._fns += (PREFIX_DOCIDS_FN(pfx_docids), PREFIX_KEY_DOCIDS_FN(pfx_fid), PREFIX_KEY_DOCIDS_FN(pfx_pos),
                           PREFIX_PAIR_DOCIDS_FN(pfx_pair), WORD_KEYS_FN(keys(index.get_word_prefix_fids)),
                           WORD_KEYS_FN(keys(index.get_word_prefix_positions)), SYNONYMS_FN(synonyms))
+            if hasattr(index, "exact_words_with_prefix"):
+                def exact_prefix(user, w, n, push, sink):
+                    try:
+                        for word in index.exact_words_with_prefix(bytes(w[:n]).decode("utf-8")):
+                            b = word.encode("utf-8")
+                            buf = C.create_string_buffer(b, len(b))
+                            tok = QueryToken(C.cast(buf, C.c_void_p), len(b), 0)
+                            if push(sink, C.cast(C.pointer(tok), C.c_void_p), 1) < 0:
+                                return -1
+                        return 0
+                    except Exception:
+                        return -1
+                self._fns += (EXACT_PREFIX_FN(exact_prefix),)
         self.vtable = IndexVtable(None, *self._fns)
 
 

@@ -25,6 +25,7 @@ Pinned against the reference's snapshots by tests/test_ranking_oracle_snapshots.
 from collections import namedtuple
 
 ALL, NONE = "all", "none"
+TRACE = False
 MAX_ONE, MAX_TWO, MAX_PREFIX = 150, 50, 1000      # limits.rs
 MAX_SYNONYM_PHRASE_COUNT, MAX_SYNONYM_WORD_COUNT = 50, 100
 MAX_WORD_LENGTH = 250
@@ -1066,6 +1067,9 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
         scores.append(score)
         assert cands <= unis[cur]
         below = threshold is not None and global_score(scores) < threshold
+        if TRACE:
+            print("[oracle trace] rule", cur, getattr(rules[cur], "kind", "?"), "bucket", len(cands), "left",
+                  len(unis[cur]) - len(cands), "score", score, "below", int(below))
         unis[cur] -= cands
         if cur == n - 1 or (not detailed and len(cands) <= 1) or cur_off + len(cands) < offset or below:
             if below:

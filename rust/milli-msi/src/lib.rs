@@ -192,7 +192,7 @@ pub fn keyword_search(dict: &GpuDictionary, sets: &mut GpuDocidSets, source: &mu
         word_fid_docids: None, word_position_docids: None, word_fids: None, word_positions: None,
         field_id_word_count_docids: None, word_prefix_docids: None, word_prefix_fid_docids: None,
         word_prefix_position_docids: None, word_prefix_pair_proximity_docids: None, word_prefix_fids: None,
-        word_prefix_positions: None, synonyms: None };
+        word_prefix_positions: None, synonyms: None, exact_words_with_prefix: None };
     let (mut ids, mut mw, mut tc, mut mt) = (vec![0u32; length], vec![0u32; length], vec![0u32; length], vec![0u32; length]);
     let (mut n, mut cand) = (0u32, 0u64);
     let (up, ul) = universe.map_or((ptr::null(), 0), |u| (u.as_ptr(), u.len()));
@@ -228,6 +228,8 @@ pub trait RankingSource: PostingSource {
     fn word_prefix_positions(&mut self, prefix: &str) -> Vec<u16>;
     /// `index.synonyms.get(words)`, each synonym tokenised.
     fn synonyms(&mut self, words: &[&str]) -> Vec<Vec<String>>;
+    /// keys of `exact_word_docids` with the prefix, in key order (compute_derivations.rs:40-73)
+    fn exact_words_with_prefix(&mut self, prefix: &str) -> Vec<String>;
 }
 
 /// One located query term of `located_query_terms_from_tokens` (parse_query.rs:28-202).
@@ -340,6 +342,15 @@ unsafe extern "C" fn r_syn(u: *mut std::ffi::c_void, ws: *const sys::msi_query_t
     0
 }
 
+unsafe extern "C" fn r_exact_prefix(u: *mut std::ffi::c_void, p: *const u8, n: u32, push: sys::msi_synonym_sink, sink: *mut std::ffi::c_void) -> i32 {
+    let Some(p) = s(p, n) else { return -1 };
+    for w in src(u).exact_words_with_prefix(p) {
+        let t = sys::msi_query_token { word: w.as_ptr(), len: w.len() as u32, is_prefix: 0 };
+        if push(sink, &t, 1) < 0 { return -1; }
+    }
+    0
+}
+
 /// `execute_search` for a keyword query (search/new/mod.rs:808-880) on the device-set engine.
 pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, source: &mut dyn RankingSource,
                              terms: &[LocatedTerm<'_>], universe: Option<&[u8]>, q: &RankedSearch<'_>)
@@ -370,7 +381,8 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
         word_position_docids: Some(r_pos), word_fids: Some(r_fids), word_positions: Some(r_positions),
         field_id_word_count_docids: Some(r_count), word_prefix_docids: Some(r_pfx), word_prefix_fid_docids: Some(r_pfx_fid),
         word_prefix_position_docids: Some(r_pfx_pos), word_prefix_pair_proximity_docids: Some(r_pfx_pair),
-        word_prefix_fids: Some(r_pfx_fids), word_prefix_positions: Some(r_pfx_positions), synonyms: Some(r_syn) };
+        word_prefix_fids: Some(r_pfx_fids), word_prefix_positions: Some(r_pfx_positions), synonyms: Some(r_syn),
+        exact_words_with_prefix: Some(r_exact_prefix) };
     let len = q.length.max(1);
     let mut ids = vec![0u32; len];
     let mut details = vec![sys::msi_score_detail::default(); len * sys::MSI_MAX_SCORE_DETAILS];

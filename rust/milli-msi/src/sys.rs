@@ -54,6 +54,7 @@ pub type prefix_docids_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, i3
 pub type prefix_key_docids_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, u32, msi_posting_sink, *mut c_void) -> i32;
 pub type prefix_pair_docids_fn = unsafe extern "C" fn(*mut c_void, u32, *const u8, u32, *const u8, u32, msi_posting_sink, *mut c_void) -> i32;
 pub type synonyms_fn = unsafe extern "C" fn(*mut c_void, *const msi_query_token, u32, msi_synonym_sink, *mut c_void) -> i32;
+pub type exact_prefix_fn = unsafe extern "C" fn(*mut c_void, *const u8, u32, msi_synonym_sink, *mut c_void) -> i32;
 pub type fid_count_docids_fn = unsafe extern "C" fn(*mut c_void, u32, u32, *mut *const u8, *mut usize) -> i32;
 #[repr(C)]
 pub struct msi_index_vtable {
@@ -73,6 +74,7 @@ pub struct msi_index_vtable {
     pub word_prefix_fids: Option<word_keys_fn>,
     pub word_prefix_positions: Option<word_keys_fn>,
     pub synonyms: Option<synonyms_fn>,
+    pub exact_words_with_prefix: Option<exact_prefix_fn>,
 }
 pub const MSI_MAX_SCORE_DETAILS: usize = 8;
 #[repr(C)] #[derive(Clone, Copy, Default)]

@@ -192,3 +192,12 @@ def test_long_queries_match_the_oracle(hostlib):
                 assert [[tuple(s) for s in sc] for _, sc in hits] == [[G.oracle_score(s) for s in sc] for sc in want_sc]
                 assert cand == len(want_cand)
     h.close()
+
+
+def test_differential_fuzz_smoke(hostlib):
+    """A short run of tools/fuzz_ranked_hostlogic.py (the long runs are manual: 79 k cases without a mismatch)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "fuzz_ranked_hostlogic.py"), "900", "8"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " bad 0" in out.stdout.strip().splitlines()[-1], out.stdout[-2000:]

@@ -254,6 +254,9 @@ class ToyMilli:
         return cbo_bytes(s) if s else None
 
 
+    def exact_words_with_prefix(self, prefix):
+        return sorted((w for w in self.exact_word_docids if w.startswith(prefix)), key=lambda w: w.encode())
+
     def get_synonyms(self, words):
         return self.synonyms.get(tuple(words), [])
 
