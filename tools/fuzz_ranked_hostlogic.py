@@ -68,10 +68,23 @@ while time.time() < t_end:
         if rng.random()<0.2: q += " "
         tms = rng.choice(["last","all"]); detailed=rng.random()<0.5; offset=rng.choice([0,0,1,5]); limit=rng.choice([1,5,20,100])
         thr = rng.choice([None,None,0.3,0.7,0.9]); sa = rng.choice([None,None,None,0,1,2,4])
+        negs = []
+        if rng.random() < 0.2:
+            negs.append(rng.choice(G.VOCAB))
+        if rng.random() < 0.1:
+            negs.append((rng.choice(G.VOCAB), rng.choice(G.VOCAB)))
         try:
-            want = RO.search(RO.Ctx(index,lookup), q, tms=tms, offset=offset, length=limit, detailed=detailed, threshold=thr, stop_after=sa)
+            want = RO.search(RO.Ctx(index,lookup), q, tms=tms, offset=offset, length=limit, detailed=detailed, threshold=thr, stop_after=sa, negatives=negs)
             deg = RO.bucket_sort.degraded if hasattr(RO.bucket_sort,'degraded') else False
-            hits, cand, gdeg = h.search(q, tms=tms, offset=offset, limit=limit, detailed=detailed, stop_after=sa, score_threshold=thr, return_degraded=True)
+            terms = query_terms(q, stop_words=index.stop_words)
+            for ng in negs:
+                terms.append(([ng], False, 0, 0, False, True) if isinstance(ng, str) else (list(ng), True, 0, 0, False, True))
+            hits, cand, gdeg = R.keyword_search_ranked(
+                h.dict, h.pool, h.cb, terms, index.criteria, strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST,
+                offset=offset, limit=limit, detailed=detailed, searchable_fids=index.searchable_fids,
+                searchable_weights=[index.weights[f] for f in index.searchable_fids], max_weight=index.max_weight,
+                authorize_typos=index.authorize_typos, min_one=index.min_one, min_two=index.min_two, stop_after=sa,
+                score_threshold=thr, return_degraded=True, _entry=L.msi_keyword_search_ranked)
         except Exception as e:
             print("EXC", seed, repr(q), criteria, kw, e); bad+=1; continue
         n+=1
