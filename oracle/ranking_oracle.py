@@ -992,8 +992,10 @@ class Deadline:
         return self.calls > self.stop_after
 
 
-def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, deadline=None, threshold=None):
-    """bucket_sort.rs:23-343 without distinct and pins (threshold = ranking_score_threshold, :286-306).
+def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, deadline=None, threshold=None,
+                distinct=None):
+    """bucket_sort.rs:23-343 without pins (threshold = ranking_score_threshold, :286-306; distinct = field name,
+    apply_distinct_rule of search/new/distinct.rs:19-36 inside maybe_add_to_results).
     -> (docids, [score details per hit], all_candidates); `bucket_sort.degraded` tells whether the deadline cut
     the last call short (graph-based rules never answer non_blocking_next_bucket: ranking_rules.rs:67-74)."""
     deadline = deadline or Deadline()
@@ -1001,7 +1003,28 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
     universe = set(universe)
     if len(universe) < offset:
         return [], [], universe
+
+    def apply_distinct(cands):
+        remaining, excluded = set(), set()
+        for d in sorted(cands):
+            if d in excluded:
+                continue
+            excluded |= ctx.index.distinct_excluded(distinct, d)
+            remaining.add(d)
+        return remaining, excluded
     if not rules:
+        if distinct:                           # bucket_sort.rs:61-92
+            excluded, results = set(), []
+            for d in sorted(universe):
+                if len(results) >= offset + length:
+                    break
+                if d in excluded:
+                    continue
+                excluded |= ctx.index.distinct_excluded(distinct, d)
+                results.append(d)
+            all_c = (universe - excluded) | set(results)
+            results = results[offset:] if len(results) >= offset else []
+            return results, [[] for _ in results], all_c
         ids = sorted(universe)[offset:offset + length]
         return ids, [[] for _ in ids], universe
     n = len(rules)
@@ -1012,6 +1035,11 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
 
     def add(cands):
         nonlocal cur_off
+        if distinct:
+            cands, excluded = apply_distinct(cands)
+            for u in unis:
+                u -= excluded
+            all_cand.difference_update(excluded)
         all_cand.update(cands)
         if not cands:
             return
@@ -1139,7 +1167,7 @@ def parse_query(ctx, query, words_limit=10):
 
 
 def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=False, universe=None, negatives=(),
-           stop_after=None, threshold=None):
+           stop_after=None, threshold=None, distinct=None):
     """execute_search, mod.rs:808-880 for a keyword query.  negatives: [word | (phrase words…)] whose documents
     Search::execute removes from the universe first (search/mod.rs:431-440, new/mod.rs:323-351)."""
     index = ctx.index
@@ -1151,11 +1179,11 @@ def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=
         else:
             universe -= ctx.phrase_docids(tuple(neg))
     if not terms:          # only stop words: a placeholder search (no keyword rule applies), mod.rs:770-800
-        return bucket_sort(ctx, [], None, universe, offset, length, detailed)
+        return bucket_sort(ctx, [], None, universe, offset, length, detailed, distinct=distinct)
     graph = QueryGraph.from_query(ctx, terms)
     rules = ranking_rules(criteria if criteria is not None else index.criteria, tms)
     reduced = graph.clone()
     if tms == "last":
         reduced.remove_nodes_keep_edges([n for ns in graph.removal_order_last(ctx) for n in sorted(ns)])
     universe &= query_graph_docids(ctx, reduced, universe)
-    return bucket_sort(ctx, rules, graph, universe, offset, length, detailed, Deadline(stop_after), threshold)
+    return bucket_sort(ctx, rules, graph, universe, offset, length, detailed, Deadline(stop_after), threshold, distinct)

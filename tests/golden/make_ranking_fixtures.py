@@ -14,7 +14,7 @@ import re
 REF = "/root/reference/crates/milli/src/search/new/tests"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ranking_snapshots.json")
 FILES = ["proximity", "attribute_fid", "word_position", "exactness", "words_tms", "typo_proximity",
-         "proximity_typo", "ngram_split_words", "typo", "stop_words"]
+         "proximity_typo", "ngram_split_words", "typo", "stop_words", "distinct"]
 CRIT = {"Words": "words", "Typo": "typo", "Proximity": "proximity", "Attribute": "attribute",
         "AttributeRank": "attributeRank", "WordPosition": "wordPosition", "Exactness": "exactness", "Sort": "sort"}
 
@@ -91,7 +91,7 @@ def parse_settings(body, cfg):
         cfg["searchable"] = re.findall(r'"([^"]+)"', m.group(1))
     m = re.search(r"set_criteria\(vec!\[(.*?)\]\)", body, re.S)
     if m:
-        cfg["criteria"] = [CRIT[c] for c in re.findall(r"Criterion::(\w+)", m.group(1))]
+        cfg["criteria"] = [CRIT.get(c, "sort") for c in re.findall(r"Criterion::(\w+)", m.group(1))]
     m = re.search(r"set_exact_attributes\(\[(.*?)\]", body, re.S)
     if m:
         cfg["exact_attributes"] = re.findall(r'"([^"]+)"', m.group(1))
@@ -110,13 +110,18 @@ def parse_settings(body, cfg):
     m = re.search(r"set_stop_words\(BTreeSet::from_iter\(\[(.*?)\]\)\)", body, re.S)
     if m:
         cfg["stop_words"] = re.findall(r'"([^"]+)"', m.group(1))
+    m = re.search(r'set_distinct_field\("([^"]+)"', body)
+    if m:
+        cfg["distinct"] = m.group(1)
+    if "reset_distinct_field()" in body:
+        cfg.pop("distinct", None)
     syn = {}
     for m in re.finditer(r'\w+\.insert\("([^"]+)"\.to_owned\(\),\s*vec!\[(.*?)\]\)', body, re.S):
         syn[m.group(1)] = re.findall(r'"([^"]+)"', m.group(2))
     if syn and "set_synonyms" in body:
         cfg["synonyms"] = syn
     for feat in ("set_dictionary", "set_separator_tokens", "set_proximity_precision",
-                 "set_searchable_fields(vec![])", "set_distinct_field", "set_sortable"):
+                 "set_searchable_fields(vec![])"):
         if feat in body:
             cfg.setdefault("unsupported", []).append(feat)
 
@@ -206,14 +211,19 @@ def main():
                 nxt = next((p for p, kd, _ in events[k + 1:] if kd == "search"), len(body))
                 chunk = body[pos:nxt]
                 q = re.search(r's\.query\("((?:[^"\\]|\\.)*)"\)', chunk)
-                if not q:
+                if not q and mod != "distinct":
                     continue
                 tms = re.search(r"TermsMatchingStrategy::(\w+)", chunk)
                 case = {"src": f"crates/milli/src/search/new/tests/{mod}.rs::{name}", "index": f"{mod}::{name}::{version}",
-                        "query": unescape(q.group(1)), "tms": (tms.group(1).lower() if tms else "last"),
+                        "query": unescape(q.group(1)) if q else "", "tms": (tms.group(1).lower() if tms else "last"),
                         "detailed": "ScoringStrategy::Detailed" in chunk, "ids": None, "scores": None}
                 lim = re.search(r"s\.limit\((\d+)\)", chunk)
                 off = re.search(r"s\.offset\((\d+)\)", chunk)
+                dm = re.search(r's\.distinct\(S\("([^"]+)"\)\)', chunk)
+                if dm:
+                    case["distinct"] = dm.group(1)
+                if "sort_criteria" in chunk:
+                    case["needs"] = "sort"
                 case["limit"] = int(lim.group(1)) if lim else 20
                 case["offset"] = int(off.group(1)) if off else 0
                 for n, (a, b) in enumerate(asserts, 1):

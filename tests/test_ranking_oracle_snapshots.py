@@ -32,7 +32,7 @@ def build_index(cfg):
                     exact_words=cfg.get("exact_words", ()), criteria=cfg.get("criteria"),
                     min_one=cfg.get("min_one", 5), min_two=cfg.get("min_two", 9),
                     authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"),
-                    stop_words=cfg.get("stop_words", ()))
+                    stop_words=cfg.get("stop_words", ()), distinct=cfg.get("distinct"))
 
 
 def debug_score(s):
@@ -67,9 +67,12 @@ def test_reference_snapshot(case):
     cfg = FIX["indexes"][case["index"]]
     if cfg.get("unsupported") or case["query"] in UNSUPPORTED:
         pytest.skip("needs " + str(cfg.get("unsupported") or UNSUPPORTED[case["query"]]))
+    if case.get("needs"):
+        pytest.skip("needs the " + case["needs"] + " ranking rule (not a keyword rule; facet databases)")
     index = build_index(cfg)
     ids, scores, _ = R.search(make_ctx(index), case["query"], tms=case["tms"], offset=case["offset"],
-                              length=case["limit"], detailed=case["detailed"], stop_after=case.get("stop_after"))
+                              length=case["limit"], detailed=case["detailed"], stop_after=case.get("stop_after"),
+                              distinct=case.get("distinct") or index.distinct_field)
     if case["ids"] is not None:
         assert ids == case["ids"]
     if case.get("scores"):

@@ -58,7 +58,7 @@ def build_index(cfg):
                     exact_words=cfg.get("exact_words", ()), criteria=cfg.get("criteria"),
                     min_one=cfg.get("min_one", 5), min_two=cfg.get("min_two", 9),
                     authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"),
-                    stop_words=cfg.get("stop_words", ()))
+                    stop_words=cfg.get("stop_words", ()), distinct=cfg.get("distinct"))
 
 
 _H = {}
@@ -70,7 +70,9 @@ def harness_for(key):
     return _H[key]
 
 
-CASES = [c for c in FIX["cases"] if not FIX["indexes"][c["index"]].get("unsupported") and c["query"] not in UNSUPPORTED]
+# distinct.rs cases are pinned in the oracle only: `distinct` (and Sort) are not built in the product yet
+CASES = [c for c in FIX["cases"] if not FIX["indexes"][c["index"]].get("unsupported") and c["query"] not in UNSUPPORTED
+         and not c.get("needs") and not c.get("distinct") and not FIX["indexes"][c["index"]].get("distinct")]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f'{c["src"].split("::")[1]}:{c["query"]}' for c in CASES])

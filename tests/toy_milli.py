@@ -45,9 +45,10 @@ def tokenize_with_positions(text, start=0, stop_words=()):
 class ToyMilli:
     def __init__(self, docs, searchable=None, exact_attributes=(), exact_words=(), criteria=None,
                  min_one=5, min_two=9, authorize_typos=True, primary_key="id", prefix_threshold=100, synonyms=None,
-                 stop_words=()):
+                 stop_words=(), distinct=None):
         self.min_one, self.min_two, self.authorize_typos = min_one, min_two, authorize_typos
         self.exact_words = set(exact_words)
+        self.distinct_field = distinct
         self.stop_words = set(stop_words)      # case sensitive, compared with the token as written
         # index.synonyms: normalised key words -> synonym phrases as word lists (settings: "a b" -> ["c d", ...])
         self.synonyms = {tuple(WORD_RE.findall(k.lower())): [WORD_RE.findall(v.lower()) for v in vs]
@@ -106,6 +107,23 @@ class ToyMilli:
                                 pairs[key] = prox
             for (w1, w2), prox in pairs.items():
                 self.pair.setdefault((prox, w1, w2), set()).add(docid)
+        # facet databases of scalar values (facet_id_string_docids / facet_id_f64_docids level 0 and the per-document
+        # field_id_docid_facet_* entries): what `distinct` reads (search/new/distinct.rs:38-62)
+        self.facet_docids, self.doc_facets = {}, {}
+        for docid, d in enumerate(merged):
+            for name, v in d.items():
+                vals = v if isinstance(v, list) else [v]
+                for x in vals:
+                    if isinstance(x, bool):
+                        key = ("s", str(x).lower())
+                    elif isinstance(x, (int, float)):
+                        key = ("n", float(x))
+                    elif isinstance(x, str) and x:
+                        key = ("s", x.lower())
+                    else:
+                        continue
+                    self.facet_docids.setdefault((name, key), set()).add(docid)
+                    self.doc_facets.setdefault((name, docid), []).append(key)
         self.words = sorted(self.word_docids, key=lambda w: w.encode())      # words fst
         self.all_words = sorted(set(self.word_docids) | set(self.exact_word_docids), key=lambda w: w.encode())
         # word-prefix databases: prefixes of 1..4 bytes (at a char boundary) shared by >= 100 words of the words
@@ -253,6 +271,13 @@ class ToyMilli:
         s = self.fid_word_count.get((fid, count))
         return cbo_bytes(s) if s else None
 
+
+    def distinct_excluded(self, field, docid):
+        """distinct_single_docid (search/new/distinct.rs:38-62): the documents that share a facet value with docid."""
+        out = set()
+        for key in self.doc_facets.get((field, docid), ()):
+            out |= self.facet_docids[(field, key)]
+        return out
 
     def exact_words_with_prefix(self, prefix):
         return sorted((w for w in self.exact_word_docids if w.startswith(prefix)), key=lambda w: w.encode())
