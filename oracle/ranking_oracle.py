@@ -704,6 +704,8 @@ def rank_to_score(kind, rank, max_rank):
 def score_rank(score):
     """ScoreDetails::rank, score_details.rs:103-121."""
     k = score[0]
+    if k == "Sort":
+        return None                       # not rank based: no part in the global score (score_details.rs:113)
     if k == "Skipped":
         return (0, 1)
     if k == "Typo":
@@ -718,6 +720,8 @@ def score_rank(score):
 def global_score(scores):
     rank, mx = 1, 1
     for s in scores:
+        if score_rank(s) is None:
+            continue
         r, m = score_rank(s)
         rank = max(0, rank - 1) * m + r
         mx *= m
@@ -941,10 +945,65 @@ class ExactAttributeRule:
         return self.graph, set(universe), ("ExactAttribute", "NoExactMatch")
 
 
-def ranking_rules(criteria, tms):
-    """get_ranking_rules_for_query_graph_search, mod.rs:510-649 (Sort / Asc / Desc are not keyword rules)."""
+class SortRule:
+    """search/new/sort.rs:95-233: one bucket per facet value of the field, numbers first then strings, each in the
+    rule's direction (ascending_facet_sort / descending_facet_sort over facet_id_f64_docids, then
+    facet_id_string_docids); a document is placed at the first of its values the iteration meets; what is left when
+    the values are exhausted comes out as one bucket with a Null value.  No query is needed: the rule also orders
+    placeholder searches."""
+    kind = "sort"
+
+    def __init__(self, field, ascending):
+        self.field, self.ascending = field, ascending
+
+    def start_iteration(self, ctx, universe, graph):
+        self.graph = graph
+        index = ctx.index
+        keys = [k for (f, k) in index.facet_docids if f == self.field]
+        nums = sorted((k for k in keys if k[0] == "n"), key=lambda k: k[1], reverse=not self.ascending)
+        strs = sorted((k for k in keys if k[0] == "s"), key=lambda k: k[1].encode(), reverse=not self.ascending)
+        left = set(universe)
+        self.buckets = []
+        for k in nums + strs:
+            docs = index.facet_docids[(self.field, k)] & left
+            if docs:
+                left -= docs
+                self.buckets.append((docs, k))
+        self.pos = 0
+
+    def next_bucket(self, universe):
+        if self.pos < len(self.buckets):
+            docs, k = self.buckets[self.pos]
+            self.pos += 1
+            value = ("Number", k[1]) if k[0] == "n" else ("String", k[1])
+            return self.graph, docs & universe, ("Sort", self.field, self.ascending, value)
+        return self.graph, set(universe), ("Sort", self.field, self.ascending, ("Null",))
+
+
+def sort_rules(criteria, sort):
+    """The Sort / Asc / Desc part of the rule list (mod.rs:366-376,640-720), also all there is for a placeholder search
+    (get_ranking_rules_for_placeholder_search, mod.rs:352-420).  sort: [(field, "asc" | "desc")] of the request."""
+    out, fields, sort_done = [], set(), False
+    for c in criteria:
+        if c == "sort" and not sort_done:
+            sort_done = True
+            for f, d in sort or ():
+                if f not in fields:
+                    fields.add(f)
+                    out.append((c, SortRule(f, d == "asc")))
+        elif c.startswith(("asc:", "desc:")):
+            d, f = c.split(":", 1)
+            if f not in fields:
+                fields.add(f)
+                out.append((c, SortRule(f, d == "asc")))
+    return out
+
+
+def ranking_rules(criteria, tms, sort=None):
+    """get_ranking_rules_for_query_graph_search, mod.rs:510-649."""
     rules, seen = [], set()
     words = tms == "all"
+    sort_done, sorted_fields = False, set()
 
     def add_words():
         nonlocal words
@@ -975,6 +1034,17 @@ def ranking_rules(criteria, tms):
         elif c == "exactness" and "exactness" not in seen:
             seen.add("exactness")
             rules += [ExactAttributeRule(), GraphRule("exactness")]
+        elif c == "sort" and not sort_done:
+            sort_done = True
+            for f, d in sort or ():
+                if f not in sorted_fields:
+                    sorted_fields.add(f)
+                    rules.append(SortRule(f, d == "asc"))
+        elif c.startswith(("asc:", "desc:")):
+            d, f = c.split(":", 1)
+            if f not in sorted_fields:
+                sorted_fields.add(f)
+                rules.append(SortRule(f, d == "asc"))
     return rules
 
 
@@ -1167,7 +1237,7 @@ def parse_query(ctx, query, words_limit=10):
 
 
 def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=False, universe=None, negatives=(),
-           stop_after=None, threshold=None, distinct=None):
+           stop_after=None, threshold=None, distinct=None, sort=None):
     """execute_search, mod.rs:808-880 for a keyword query.  negatives: [word | (phrase words…)] whose documents
     Search::execute removes from the universe first (search/mod.rs:431-440, new/mod.rs:323-351)."""
     index = ctx.index
@@ -1178,10 +1248,11 @@ def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=
             universe -= ctx.word_docids(None, neg, True) or set()
         else:
             universe -= ctx.phrase_docids(tuple(neg))
-    if not terms:          # only stop words: a placeholder search (no keyword rule applies), mod.rs:770-800
-        return bucket_sort(ctx, [], None, universe, offset, length, detailed, distinct=distinct)
+    if not terms:          # no term (or only stop words): a placeholder search — only Sort / Asc / Desc rules, mod.rs:770-800
+        rules = [r for _, r in sort_rules(criteria if criteria is not None else index.criteria, sort)]
+        return bucket_sort(ctx, rules, None, universe, offset, length, detailed, distinct=distinct)
     graph = QueryGraph.from_query(ctx, terms)
-    rules = ranking_rules(criteria if criteria is not None else index.criteria, tms)
+    rules = ranking_rules(criteria if criteria is not None else index.criteria, tms, sort)
     reduced = graph.clone()
     if tms == "last":
         reduced.remove_nodes_keep_edges([n for ns in graph.removal_order_last(ctx) for n in sorted(ns)])

@@ -14,7 +14,7 @@ import re
 REF = "/root/reference/crates/milli/src/search/new/tests"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ranking_snapshots.json")
 FILES = ["proximity", "attribute_fid", "word_position", "exactness", "words_tms", "typo_proximity",
-         "proximity_typo", "ngram_split_words", "typo", "stop_words", "distinct"]
+         "proximity_typo", "ngram_split_words", "typo", "stop_words", "distinct", "sort"]
 CRIT = {"Words": "words", "Typo": "typo", "Proximity": "proximity", "Attribute": "attribute",
         "AttributeRank": "attributeRank", "WordPosition": "wordPosition", "Exactness": "exactness", "Sort": "sort"}
 
@@ -91,7 +91,8 @@ def parse_settings(body, cfg):
         cfg["searchable"] = re.findall(r'"([^"]+)"', m.group(1))
     m = re.search(r"set_criteria\(vec!\[(.*?)\]\)", body, re.S)
     if m:
-        cfg["criteria"] = [CRIT.get(c, "sort") for c in re.findall(r"Criterion::(\w+)", m.group(1))]
+        cfg["criteria"] = [CRIT[c] if c in CRIT else f"{c.lower()}:{f}"
+                           for c, f in re.findall(r'Criterion::(\w+)(?:\(S\("([^"]+)"\)\))?', m.group(1))]
     m = re.search(r"set_exact_attributes\(\[(.*?)\]", body, re.S)
     if m:
         cfg["exact_attributes"] = re.findall(r'"([^"]+)"', m.group(1))
@@ -120,7 +121,7 @@ def parse_settings(body, cfg):
         syn[m.group(1)] = re.findall(r'"([^"]+)"', m.group(2))
     if syn and "set_synonyms" in body:
         cfg["synonyms"] = syn
-    for feat in ("set_dictionary", "set_separator_tokens", "set_proximity_precision",
+    for feat in ("set_displayed_fields", "set_dictionary", "set_separator_tokens", "set_proximity_precision",
                  "set_searchable_fields(vec![])"):
         if feat in body:
             cfg.setdefault("unsupported", []).append(feat)
@@ -211,7 +212,7 @@ def main():
                 nxt = next((p for p, kd, _ in events[k + 1:] if kd == "search"), len(body))
                 chunk = body[pos:nxt]
                 q = re.search(r's\.query\("((?:[^"\\]|\\.)*)"\)', chunk)
-                if not q and mod != "distinct":
+                if not q and mod not in ("distinct", "sort"):
                     continue
                 tms = re.search(r"TermsMatchingStrategy::(\w+)", chunk)
                 case = {"src": f"crates/milli/src/search/new/tests/{mod}.rs::{name}", "index": f"{mod}::{name}::{version}",
@@ -222,8 +223,10 @@ def main():
                 dm = re.search(r's\.distinct\(S\("([^"]+)"\)\)', chunk)
                 if dm:
                     case["distinct"] = dm.group(1)
-                if "sort_criteria" in chunk:
-                    case["needs"] = "sort"
+                sc = re.search(r"s\.sort_criteria\(vec!\[(.*?)\]\);", chunk, re.S)
+                if sc:
+                    case["sort"] = [[f, d.lower()] for d, f in
+                                    re.findall(r'AscDesc::(Asc|Desc)\(Member::Field\(S\("([^"]+)"\)\)\)', sc.group(1))]
                 case["limit"] = int(lim.group(1)) if lim else 20
                 case["offset"] = int(off.group(1)) if off else 0
                 for n, (a, b) in enumerate(asserts, 1):

@@ -48,6 +48,10 @@ def debug_score(s):
         return f"ExactAttribute({s[1]},)"
     if k == "Skipped":
         return "Skipped"
+    if k == "Sort":
+        v = s[3]
+        val = "Null" if v[0] == "Null" else (f"Number({float(v[1])!r})" if v[0] == "Number" else f'String("{v[1]}")')
+        return (f'Sort(Sort{{field_name:"{s[1]}",ascending:{str(s[2]).lower()},redacted:false,value:{val},}},)')
     return f"{k}(Rank{{rank:{s[1]},max_rank:{s[2]},}},)"
 
 
@@ -72,7 +76,7 @@ def test_reference_snapshot(case):
     index = build_index(cfg)
     ids, scores, _ = R.search(make_ctx(index), case["query"], tms=case["tms"], offset=case["offset"],
                               length=case["limit"], detailed=case["detailed"], stop_after=case.get("stop_after"),
-                              distinct=case.get("distinct") or index.distinct_field)
+                              distinct=case.get("distinct") or index.distinct_field, sort=case.get("sort"))
     if case["ids"] is not None:
         assert ids == case["ids"]
     if case.get("scores"):

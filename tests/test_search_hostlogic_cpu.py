@@ -123,7 +123,7 @@ def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused)
     """All 94 reference searches, with the whole-level evaluation and with the path-by-path fallback."""
     monkeypatch.setenv("MSI_SEARCH_FUSED_LEVELS", fused)
     harnesses, n = {}, 0
-    cases = [c for c in FIX["cases"] if not c.get("needs") and not c.get("distinct")
+    cases = [c for c in FIX["cases"] if not c.get("needs") and not c.get("sort") and not c.get("distinct")
              and not FIX["indexes"][c["index"]].get("distinct")]   # distinct / Sort: oracle only for now
     for case in cases:
         if case["index"] not in harnesses:
