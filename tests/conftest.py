@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """libmsi.so is a build artefact (git-ignored): build it when a fresh checkout runs the tests before
+    __graft_entry__.build() did (hipcc cross-compiles gfx950 without a GPU; `make` is a no-op when up to date)."""
+    import subprocess
+    so = os.path.join(ROOT, "meilisearch_amd", "libmsi.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "meilisearch_amd", "csrc"), "ARCH=gfx950"])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure; never imported by the product)."""
