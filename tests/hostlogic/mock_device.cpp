@@ -64,8 +64,15 @@ int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &b, 
     if (c.type == 0) {
       for (uint32_t i = 0; i < c.card; ++i) set(hi | rd16(2 * i));
     } else if (c.type == 1) {
-      for (uint32_t v = 0; v < 65536; ++v)
-        if ((body[v >> 3] >> (v & 7)) & 1) set(hi | v);
+      // a bitmap container is 1024 little-endian words that line up with the destination words
+      const uint64_t w0 = hi >> 6;
+      for (uint32_t w = 0; w < 1024 && w0 + w < p->n_words; ++w) {
+        uint64_t v;
+        memcpy(&v, body + 8 * w, 8);
+        const uint64_t base = (w0 + w) * 64;
+        if (base + 64 > p->n_docs) v &= base >= p->n_docs ? 0ull : (~0ull >> (64 - (p->n_docs - base)));
+        dst[w0 + w] |= v;
+      }
     } else {
       for (uint32_t r = 0; r < c.card; ++r) {
         const uint32_t start = rd16(4 * r), len = rd16(4 * r + 2);
@@ -127,8 +134,11 @@ extern "C" {
 int32_t msi_bits_fill(msi_bits *p, uint32_t slot, int32_t ones) {
   uint64_t *d = p->slot(slot);
   std::fill(d, d + p->n_words, 0ull);
-  if (ones)
-    for (uint64_t i = 0; i < p->n_docs; ++i) d[i >> 6] |= 1ull << (i & 63);
+  if (ones) {
+    const uint64_t full = p->n_docs / 64;
+    std::fill(d, d + full, ~0ull);
+    if (p->n_docs % 64) d[full] = ~0ull >> (64 - p->n_docs % 64);
+  }
   return MSI_OK;
 }
 
@@ -153,8 +163,14 @@ int32_t msi_bits_count(msi_bits *p, uint32_t slot, uint64_t *out) {
 
 int32_t msi_bits_first_k(msi_bits *p, uint32_t slot, uint32_t k, uint32_t *out_docids, uint32_t *out_n) {
   uint32_t n = 0;
-  for (uint64_t i = 0; i < p->n_docs && n < k; ++i)
-    if ((p->slot(slot)[i >> 6] >> (i & 63)) & 1) out_docids[n++] = (uint32_t)i;
+  const uint64_t *s = p->slot(slot);
+  for (uint64_t w = 0; w < p->n_words && n < k; ++w) {
+    uint64_t v = s[w];
+    while (v && n < k) {
+      out_docids[n++] = (uint32_t)(w * 64 + (uint64_t)__builtin_ctzll(v));
+      v &= v - 1;
+    }
+  }
   *out_n = n;
   return MSI_OK;
 }

@@ -6,6 +6,12 @@
 //
 //   hipcc -O2 -std=c++17 -Iinclude tools/ranked_bench.cpp -Lmeilisearch_amd -lmsi -Wl,-rpath,$PWD/meilisearch_amd -o /tmp/ranked_bench
 //   /tmp/ranked_bench <n_docs> <n_dictionary_words> <terms per query> <queries per thread> <threads...>
+//
+// -DRANKED_BENCH_CPU builds the CPU BASELINE of this leg (kind "port"): the same host logic (msi_search.hip) over the
+// plain-C++ test double of the device sets (tests/hostlogic/mock_device.cpp: dense bitsets in host memory, one
+// pass per set operation) and the CPU dictionary walk of oracle/msi_cpubase.c — never the product:
+//   hipcc -O2 -std=c++17 -DRANKED_BENCH_CPU -Iinclude tools/ranked_bench.cpp -Ltests/hostlogic/_build \
+//         -lmsi_hostlogic_test -Loracle -lmsi_cpubase -Lmeilisearch_amd -lmsi -Wl,-rpath,... -o /tmp/ranked_bench_cpu
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -188,6 +194,30 @@ int32_t cb_count(void *u, uint32_t fid, uint32_t count, const uint8_t **bytes, s
   }), bytes, out);
 }
 
+#ifdef RANKED_BENCH_CPU
+extern "C" {
+typedef int32_t (*mock_lookup_fn)(const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t *, uint32_t *,
+                                  uint32_t *, uint32_t *);
+msi_bits *mock_bits_create(uint64_t n_docs, uint32_t n_slots);
+void mock_bits_destroy(msi_bits *);
+msi_dict *mock_dict_create(const uint8_t *, const uint32_t *, uint32_t, mock_lookup_fn);
+void mock_dict_destroy(msi_dict *);
+struct cpb_dict;
+cpb_dict *cpb_dict_build(const uint8_t *words, const uint32_t *off, uint32_t n);
+void cpb_dict_lookup_mt(const cpb_dict *d, const uint8_t *qbytes, const uint32_t *qoff, const uint8_t *qflags, uint32_t nq,
+                        uint32_t cap_one, uint32_t cap_two, uint32_t threads, uint32_t *one, uint32_t *one_cnt,
+                        uint32_t *two, uint32_t *two_cnt);
+}
+static cpb_dict *g_cpb = nullptr;
+static int32_t cpu_lookup(const uint8_t *w, uint32_t n, uint32_t max_typos, uint32_t is_prefix, uint32_t cap1, uint32_t cap2,
+                          uint32_t *one, uint32_t *n1, uint32_t *two, uint32_t *n2) {
+  const uint32_t off[2] = {0, n};
+  const uint8_t flags = (uint8_t)((max_typos & 3) | (is_prefix ? 4 : 0));
+  cpb_dict_lookup_mt(g_cpb, w, off, &flags, 1, cap1, cap2, 1, one, n1, two, n2);
+  return MSI_OK;
+}
+#endif
+
 #define CK(x) do { int32_t s_ = (x); if (s_ != MSI_OK) { fprintf(stderr, "%s -> %d: %s\n", #x, s_, msi_last_error()); exit(1); } } while (0)
 
 }  // namespace
@@ -216,14 +246,19 @@ int main(int argc, char **argv) {
   std::vector<std::string> frequent(300);
   for (auto &kv : ix.rank) if (kv.second < 300) frequent[kv.second] = kv.first;
 
-  msi_ctx *ctx = nullptr;
-  CK(msi_ctx_create(-1, &ctx));
   std::vector<uint8_t> concat;
   std::vector<uint32_t> offs{0};
   for (auto &w : ix.words) { concat.insert(concat.end(), w.begin(), w.end()); offs.push_back((uint32_t)concat.size()); }
   msi_dict *dict = nullptr;
+#ifdef RANKED_BENCH_CPU
+  g_cpb = cpb_dict_build(concat.data(), offs.data(), (uint32_t)ix.words.size());
+  dict = mock_dict_create(concat.data(), offs.data(), (uint32_t)ix.words.size(), cpu_lookup);
+#else
+  msi_ctx *ctx = nullptr;
+  CK(msi_ctx_create(-1, &ctx));
   CK(msi_dict_create(ctx, concat.data(), offs.data(), (uint32_t)ix.words.size(), &dict));
   CK(msi_dict_set_microbatch(dict, 100, 64));
+#endif
 
   msi_index_vtable vt;
   memset(&vt, 0, sizeof(vt));
@@ -275,18 +310,28 @@ int main(int argc, char **argv) {
     return n;
   };
   {  // warm the synthetic index (posting generation is not what is measured)
+#ifdef RANKED_BENCH_CPU
+    msi_bits *pool = mock_bits_create(n_docs, 1024);
+    for (auto &q : queries) run_query(pool, q, nullptr);
+    mock_bits_destroy(pool);
+#else
     msi_bits *pool = nullptr;
     CK(msi_bits_create(ctx, n_docs, 1024, &pool));
     for (auto &q : queries) run_query(pool, q, nullptr);
     msi_bits_destroy(pool);
+#endif
   }
   for (int a = 5; a < argc; ++a) {
     const int n_threads = atoi(argv[a]);
     std::vector<msi_bits *> pools(n_threads);
+#ifdef RANKED_BENCH_CPU
+    for (auto &p : pools) p = mock_bits_create(n_docs, 1024);
+#else
     for (auto &p : pools) {
       CK(msi_bits_create(ctx, n_docs, 1024, &p));
       CK(msi_bits_use_private_stream(p));
     }
+#endif
     std::vector<std::vector<double>> lat(n_threads);
     std::vector<std::vector<uint64_t>> sums(n_threads, std::vector<uint64_t>(10, 0));
     const auto t0 = std::chrono::steady_clock::now();
@@ -311,16 +356,29 @@ int main(int argc, char **argv) {
     }
     std::sort(all.begin(), all.end());
     const double nq = (double)all.size();
-    printf("{\"config\": \"ranked_native\", \"docs\": %llu, \"dictionary_words\": %u, \"terms\": %u, \"threads\": %d, "
+    printf("{\"config\": \"%s\", \"docs\": %llu, \"dictionary_words\": %u, \"terms\": %u, \"threads\": %d, "
            "\"queries\": %zu, \"queries_per_s\": %.1f, \"p50_ms\": %.3f, \"p99_ms\": %.3f, \"launches_per_query\": %.1f, "
            "\"waits_per_query\": %.1f, \"decode_batches_per_query\": %.1f, \"callbacks_per_query\": %.1f, "
            "\"callback_us_per_query\": %.1f, \"device_wait_us_per_query\": %.1f}\n",
+#ifdef RANKED_BENCH_CPU
+           "ranked_cpu_port",
+#else
+           "ranked_native",
+#endif
            (unsigned long long)n_docs, n_words, n_terms, n_threads, all.size(), nq / dt, all[all.size() / 2],
            all[(size_t)(all.size() * 0.99)], tot[0] / nq, tot[1] / nq, tot[2] / nq, tot[3] / nq, tot[7] / nq, tot[8] / nq);
     fflush(stdout);
+#ifdef RANKED_BENCH_CPU
+    for (auto &p : pools) mock_bits_destroy(p);
+#else
     for (auto &p : pools) msi_bits_destroy(p);
+#endif
   }
+#ifdef RANKED_BENCH_CPU
+  mock_dict_destroy(dict);
+#else
   msi_dict_destroy(dict);
   msi_ctx_destroy(ctx);
+#endif
   return 0;
 }
