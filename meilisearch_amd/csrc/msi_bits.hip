@@ -887,6 +887,62 @@ int32_t msi_bits_clear_slots(msi_bits *p, uint32_t n, const uint32_t *slots) {
   return MSI_OK;
 }
 
+// Launches bits_paths_small_kernel for one level if it fits (<= 64 paths, <= 448 steps, <= 32 distinct conditions);
+// the counts go to region `region` of the pinned signal area.  Caller holds the pool lock.  MSI_E_UNSUPPORTED = does
+// not fit.
+static int32_t launch_paths_small(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
+                                  uint32_t bucket, uint32_t universe, uint32_t region) {
+  const uint32_t n_steps = path_off[n_paths];
+  if (n_paths > PS_PATHS || n_steps > PS_STEPS) return MSI_E_UNSUPPORTED;
+  PathsSmall a;
+  uint32_t slots[PS_CONDS], n_conds = 0;
+  for (uint32_t s = 0; s < n_steps; ++s) {
+    uint32_t c = 0;
+    while (c < n_conds && slots[c] != step_slots[s]) ++c;
+    if (c == n_conds) {
+      if (n_conds == PS_CONDS) return MSI_E_UNSUPPORTED;
+      slots[n_conds] = step_slots[s];
+      a.cond[n_conds++] = p->slot(step_slots[s]);
+    }
+    a.step[s] = (uint8_t)c;
+  }
+  for (uint32_t k = 0; k <= n_paths; ++k) a.off[k] = (uint16_t)path_off[k];
+  const uint64_t n_pairs = p->n_words / 2;
+  const uint64_t seq = ++p->seq;
+  hipLaunchKernelGGL(bits_paths_small_kernel, dim3((uint32_t)((n_pairs + PS_T - 1) / PS_T)), dim3(PS_T), 0, p->stream, a,
+                     n_conds, n_paths, p->slot(bucket), p->slot(universe), n_pairs, p->d_acc + 2 + MSI_BITS_MANY, p->d_acc,
+                     p->h_sig + 2 + MSI_BITS_MANY + (size_t)region * MSI_BITS_REGION_PATHS, p->h_sig, seq);
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+int32_t msi_bits_paths_enqueue(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
+                               uint32_t bucket, uint32_t universe, uint32_t region) {
+  if (!p || !n_paths || !path_off || region >= MSI_BITS_PATH_REGIONS || n_paths > MSI_BITS_REGION_PATHS) return MSI_E_INVALID;
+  const uint32_t n_steps = path_off[n_paths];
+  if (n_steps && !step_slots) return MSI_E_INVALID;
+  MSI_TRY(check_slot(p, bucket, "msi_bits_paths_enqueue"));
+  MSI_TRY(check_slot(p, universe, "msi_bits_paths_enqueue"));
+  for (uint32_t s = 0; s < n_steps; ++s) MSI_TRY(check_slot(p, step_slots[s], "msi_bits_paths_enqueue"));
+  std::lock_guard<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  return launch_paths_small(p, n_paths, path_off, step_slots, bucket, universe, region);
+}
+
+int32_t msi_bits_paths_collect(msi_bits *p, uint32_t n_regions, uint64_t *counts) {
+  if (!p || !n_regions || n_regions > MSI_BITS_PATH_REGIONS || !counts) return MSI_E_INVALID;
+  uint64_t seq;
+  {
+    std::lock_guard<std::mutex> lk(*p->mu);
+    seq = p->seq;  // the last level enqueued on this pool; in-stream order makes the earlier ones complete too
+  }
+  uint64_t ignored = 0;
+  MSI_TRY(wait_count(p, seq, &ignored));
+  for (uint32_t k = 0; k < n_regions * MSI_BITS_REGION_PATHS; ++k)
+    counts[k] = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2 + MSI_BITS_MANY + k]), __ATOMIC_RELAXED);
+  return MSI_OK;
+}
+
 int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
                              uint32_t bucket, uint32_t universe, uint64_t *counts) {
   if (!p || !n_paths || n_paths > MSI_BITS_MAX_PATHS || !path_off || !counts) return MSI_E_INVALID;
@@ -898,32 +954,10 @@ int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   hipStream_t st = p->stream;
-  const uint64_t n_pairs_ = p->n_words / 2;
-  if (n_paths <= PS_PATHS && n_steps <= PS_STEPS) {
-    // distinct conditions -> table indices
-    PathsSmall a;
-    uint32_t slots[PS_CONDS], n_conds = 0;
-    bool small = true;
-    for (uint32_t s = 0; s < n_steps && small; ++s) {
-      uint32_t c = 0;
-      while (c < n_conds && slots[c] != step_slots[s]) ++c;
-      if (c == n_conds) {
-        if (n_conds == PS_CONDS) {
-          small = false;
-          break;
-        }
-        slots[n_conds] = step_slots[s];
-        a.cond[n_conds++] = p->slot(step_slots[s]);
-      }
-      a.step[s] = (uint8_t)c;
-    }
-    if (small) {
-      for (uint32_t k = 0; k <= n_paths; ++k) a.off[k] = (uint16_t)path_off[k];
-      const uint64_t seq = ++p->seq;
-      hipLaunchKernelGGL(bits_paths_small_kernel, dim3((uint32_t)((n_pairs_ + PS_T - 1) / PS_T)), dim3(PS_T), 0, st, a,
-                         n_conds, n_paths, p->slot(bucket), p->slot(universe), n_pairs_, p->d_acc + 2 + MSI_BITS_MANY,
-                         p->d_acc, p->h_sig + 2 + MSI_BITS_MANY, p->h_sig, seq);
-      MSI_HIP_TRY(hipGetLastError());
+  {
+    const int32_t st_small = launch_paths_small(p, n_paths, path_off, step_slots, bucket, universe, 0);
+    if (st_small == MSI_OK) {
+      const uint64_t seq = p->seq;
       lk.unlock();
       uint64_t ignored = 0;
       MSI_TRY(wait_count(p, seq, &ignored));
@@ -931,6 +965,7 @@ int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path
         counts[k] = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2 + MSI_BITS_MANY + k]), __ATOMIC_RELAXED);
       return MSI_OK;
     }
+    if (st_small != MSI_E_UNSUPPORTED) return st_small;
   }
   const size_t steps_bytes = std::max<size_t>(1, n_steps) * sizeof(u64 *), off_bytes = (n_paths + 1) * sizeof(uint32_t);
   if (steps_bytes + off_bytes > p->desc.cap) MSI_TRY(p->desc.ensure(std::max<size_t>(steps_bytes + off_bytes, (size_t)64 << 10)));

@@ -168,6 +168,15 @@ constexpr uint32_t MSI_BITS_CLEAR_MAX = 64;
 int32_t msi_bits_clear_slots(msi_bits *p, uint32_t n, const uint32_t *slots);
 int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
                              uint32_t bucket, uint32_t universe, uint64_t *counts);
+//   paths_enqueue / paths_collect: several cost levels behind ONE completion wait.  Each enqueued level (<= 64 paths
+//   over <= 32 distinct conditions) publishes its counts into its own region (0..MSI_BITS_PATH_REGIONS-1); the
+//   levels run in stream order on the same universe, so level k+1 sees what level k left.  paths_collect waits for
+//   the last enqueued level and returns counts[region][64].  paths_enqueue returns MSI_E_UNSUPPORTED when the level
+//   does not fit the in-argument kernel (the caller then uses msi_bits_paths_claim).
+constexpr uint32_t MSI_BITS_PATH_REGIONS = 4, MSI_BITS_REGION_PATHS = 64;
+int32_t msi_bits_paths_enqueue(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
+                               uint32_t bucket, uint32_t universe, uint32_t region);
+int32_t msi_bits_paths_collect(msi_bits *p, uint32_t n_regions, uint64_t *counts);
 
 // ---- device helpers -------------------------------------------------------
 

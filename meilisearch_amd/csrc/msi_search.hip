@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <map>
 #include <memory>
 #include <set>
@@ -188,6 +189,28 @@ struct Dev {
     ++g_stats.syncs;
     ck(msi_bits_paths_claim(pool.p, (uint32_t)paths.size(), off.data(), steps.data(), bucket->slot, universe->slot,
                             counts.data()));
+    g_stats.device_wait_ms += ck_.ms();
+    return counts;
+  }
+  // the same level WITHOUT the completion wait: its counts land in `region`; false = does not fit, nothing enqueued
+  bool paths_enqueue(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe, uint32_t region) {
+    std::vector<uint32_t> off{0}, steps;
+    for (auto &p : paths) {
+      for (auto &s : p) steps.push_back(s->slot);
+      off.push_back((uint32_t)steps.size());
+    }
+    const int32_t st = msi_bits_paths_enqueue(pool.p, (uint32_t)paths.size(), off.data(), steps.data(), bucket->slot,
+                                              universe->slot, region);
+    if (st == MSI_E_UNSUPPORTED) return false;
+    ck(st);
+    ++g_stats.launches;
+    return true;
+  }
+  std::vector<uint64_t> paths_collect(uint32_t n_regions) {  // ONE wait for every level enqueued so far
+    std::vector<uint64_t> counts((size_t)n_regions * MSI_BITS_REGION_PATHS, 0);
+    Clock ck_;
+    ++g_stats.syncs;
+    ck(msi_bits_paths_collect(pool.p, n_regions, counts.data()));
     g_stats.device_wait_ms += ck_.ms();
     return counts;
   }
@@ -1259,6 +1282,14 @@ struct GraphRule : Rule {
   std::vector<std::vector<int32_t>> good;
   bool stop = false;
   uint64_t emit_epoch = 0;
+  // cost levels evaluated ahead of their turn behind one completion wait (MSI_SEARCH_LEVELS_PER_WAIT > 1)
+  struct Ready {
+    uint64_t cost;
+    Set bucket;
+    uint64_t count;
+    std::vector<std::vector<int32_t>> good;
+  };
+  std::deque<Ready> ready;
 
   GraphRule(int k, int t) : Rule(k, t) {}
 
@@ -1266,6 +1297,7 @@ struct GraphRule : Rule {
     g = graph;
     conds.clear();
     cache.clear();
+    ready.clear();
     next_max_cost = 1;
     cur_cost = 0;
     std::map<uint32_t, std::pair<uint32_t, std::set<uint32_t>>> skip_cost;
@@ -1350,8 +1382,22 @@ struct GraphRule : Rule {
     stack.clear();
     good.clear();
     stop = false;
-    std::set<uint32_t> visited, to_skip;
-    if (!fused_level(cost)) visit(Graph::ROOT, cost, visited, to_skip);
+    if (ready.empty() || ready.front().cost != cost) {
+      ready.clear();
+      look_ahead(it, rc.end());
+    }
+    if (!ready.empty()) {
+      // this level ran on a copy of the universe: take its documents out of the real one now
+      Ready r = std::move(ready.front());
+      ready.pop_front();
+      bucket = r.bucket;
+      bucket_count = r.count;
+      good = std::move(r.good);
+      if (bucket_count) c.dev.sub_(uni, bucket);
+    } else {
+      std::set<uint32_t> visited, to_skip;
+      if (!fused_level(cost)) visit(Graph::ROOT, cost, visited, to_skip);
+    }
     std::vector<PathSubsets> paths;
     for (auto &p : good) {
       PathSubsets ps;
@@ -1406,6 +1452,65 @@ struct GraphRule : Rule {
       if (!ok) return false;
     }
     return true;
+  }
+
+  // MSI_SEARCH_LEVELS_PER_WAIT=n (2..4; default 1 = off): the next n cost levels are enqueued back to back on a
+  // COPY of the universe — level k+1 claims from what level k left, exactly what the level-by-level iteration
+  // would hand it — and their per-path counts come back behind one completion wait instead of n.  The real universe
+  // loses a level's documents when bucket_sort asks for that level, so a search that stops early, a deadline or a
+  // score threshold see the same universe as without the look-ahead.  Fills `ready` or leaves it empty (a level
+  // that does not fit the in-argument kernel: the caller runs the one-level path).
+  void look_ahead(std::vector<uint64_t>::const_iterator it, std::vector<uint64_t>::const_iterator end) {
+    const char *knob = getenv("MSI_SEARCH_LEVELS_PER_WAIT");
+    const int per_wait = std::min<int>(knob ? atoi(knob) : 1, (int)MSI_BITS_PATH_REGIONS);
+    const char *fused = getenv("MSI_SEARCH_FUSED_LEVELS");
+    if (per_wait < 2 || (fused && fused[0] == '0')) return;
+    struct Plan {
+      uint64_t cost;
+      std::vector<std::vector<int32_t>> all;
+      std::vector<std::vector<Set>> sets;
+    };
+    std::vector<Plan> plan;
+    for (; it != end && (int)plan.size() < per_wait; ++it) {
+      Plan pl;
+      pl.cost = *it;
+      std::vector<int32_t> cur;
+      std::set<uint32_t> visited, to_skip;
+      size_t steps = 0;
+      if (!enumerate(Graph::ROOT, pl.cost, visited, to_skip, cur, pl.all, steps)) break;
+      if (pl.all.size() > MSI_BITS_REGION_PATHS) break;
+      for (auto &p : pl.all) {  // every condition resolved BEFORE the first level is enqueued
+        std::vector<Set> ps;
+        for (int32_t ci : p) ps.push_back(resolved(ci).docs);
+        pl.sets.push_back(std::move(ps));
+      }
+      plan.push_back(std::move(pl));
+    }
+    if (plan.size() < 2) return;
+    Set ahead = cx->dev.clone(uni);
+    std::vector<Set> buckets;
+    size_t n_enq = 0;
+    for (; n_enq < plan.size(); ++n_enq) {
+      buckets.push_back(cx->dev.zeros());
+      if (plan[n_enq].all.empty()) continue;  // no path of this cost: an empty bucket, no launch
+      if (!cx->dev.paths_enqueue(plan[n_enq].sets, buckets.back(), ahead, (uint32_t)n_enq)) break;
+    }
+    if (n_enq == 0) return;
+    const std::vector<uint64_t> counts = cx->dev.paths_collect((uint32_t)n_enq);
+    for (size_t j = 0; j < n_enq; ++j) {
+      Ready r;
+      r.cost = plan[j].cost;
+      r.bucket = buckets[j];
+      r.count = 0;
+      for (size_t k = 0; k < plan[j].all.size(); ++k) {
+        const uint64_t n = counts[j * MSI_BITS_REGION_PATHS + k];
+        if (!n) continue;
+        r.good.push_back(plan[j].all[k]);
+        ++g_stats.paths;
+        r.count += n;
+      }
+      ready.push_back(std::move(r));
+    }
   }
 
   // One launch for the whole cost level: every 16-byte chunk of documents walks the paths in order and a

@@ -16,6 +16,7 @@
 struct msi_bits {
   uint64_t n_docs = 0, n_words = 0;
   uint32_t n_slots = 0;
+  uint64_t region_counts[MSI_BITS_PATH_REGIONS * MSI_BITS_REGION_PATHS] = {};
   std::vector<uint64_t> pool;
   uint64_t *slot(uint32_t s) { return pool.data() + (uint64_t)s * n_words; }
 };
@@ -126,6 +127,25 @@ int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path
     p->slot(universe)[i] = u;
     p->slot(bucket)[i] = b;
   }
+  return MSI_OK;
+}
+
+// the device's fit rule for a level behind a shared wait: <= 64 paths, <= 448 steps, <= 32 distinct conditions
+int32_t msi_bits_paths_enqueue(msi_bits *p, uint32_t n_paths, const uint32_t *path_off, const uint32_t *step_slots,
+                               uint32_t bucket, uint32_t universe, uint32_t region) {
+  if (!n_paths || region >= MSI_BITS_PATH_REGIONS) return MSI_E_INVALID;
+  if (n_paths > MSI_BITS_REGION_PATHS || path_off[n_paths] > 448) return MSI_E_UNSUPPORTED;
+  std::vector<uint32_t> distinct;
+  for (uint32_t s = 0; s < path_off[n_paths]; ++s)
+    if (std::find(distinct.begin(), distinct.end(), step_slots[s]) == distinct.end()) distinct.push_back(step_slots[s]);
+  if (distinct.size() > 32) return MSI_E_UNSUPPORTED;
+  return msi_bits_paths_claim(p, n_paths, path_off, step_slots, bucket, universe,
+                              p->region_counts + (size_t)region * MSI_BITS_REGION_PATHS);
+}
+
+int32_t msi_bits_paths_collect(msi_bits *p, uint32_t n_regions, uint64_t *counts) {
+  if (!n_regions || n_regions > MSI_BITS_PATH_REGIONS) return MSI_E_INVALID;
+  std::copy(p->region_counts, p->region_counts + (size_t)n_regions * MSI_BITS_REGION_PATHS, counts);
   return MSI_OK;
 }
 

@@ -118,10 +118,13 @@ def build_index(cfg, **extra):
                     stop_words=cfg.get("stop_words", ()), **extra)
 
 
-@pytest.mark.parametrize("fused", ["1", "0"], ids=["level-at-once", "path-by-path"])
-def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused):
-    """All 94 reference searches, with the whole-level evaluation and with the path-by-path fallback."""
+@pytest.mark.parametrize("fused,per_wait", [("1", "1"), ("0", "1"), ("1", "2"), ("1", "4")],
+                         ids=["level-at-once", "path-by-path", "2-levels-per-wait", "4-levels-per-wait"])
+def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused, per_wait):
+    """All 94 reference searches, with the whole-level evaluation, with the path-by-path fallback, and with several
+    cost levels evaluated ahead behind one completion wait."""
     monkeypatch.setenv("MSI_SEARCH_FUSED_LEVELS", fused)
+    monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
     harnesses, n = {}, 0
     cases = [c for c in FIX["cases"] if not c.get("needs") and not c.get("sort") and not c.get("distinct")
              and not FIX["indexes"][c["index"]].get("distinct")]   # distinct / Sort: oracle only for now
@@ -147,7 +150,9 @@ def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused)
         h.close()
 
 
-def test_host_logic_matches_oracle_on_random_corpora(hostlib):
+@pytest.mark.parametrize("per_wait", ["1", "3"], ids=["one-level-per-wait", "3-levels-per-wait"])
+def test_host_logic_matches_oracle_on_random_corpora(hostlib, monkeypatch, per_wait):
+    monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
     from oracle import ranking_oracle as RO
     import tests.test_search_gpu as G
     docs = G.random_corpus(31, 200)
@@ -171,8 +176,10 @@ def test_host_logic_matches_oracle_on_random_corpora(hostlib):
             h.close()
 
 
-def test_long_queries_match_the_oracle(hostlib):
+@pytest.mark.parametrize("per_wait", ["1", "4"], ids=["one-level-per-wait", "4-levels-per-wait"])
+def test_long_queries_match_the_oracle(hostlib, monkeypatch, per_wait):
     """6 / 8 / 10-term queries (n-gram nodes, many paths per level: both evaluation modes get used)."""
+    monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
     import random
     from oracle import ranking_oracle as RO
     import tests.test_search_gpu as G
