@@ -137,6 +137,22 @@ int32_t msi_vs_search_by_item(msi_vs *vs, uint32_t docid, uint32_t k,
                               uint32_t *out_docids, float *out_dist, uint32_t *out_count,
                               int32_t *out_found);
 
+/* SURVEY §8 f2 — the dictionaries straight from milli's `fst::Set` bytes (main["words-fst"],
+ * crates/milli/src/index.rs:1225-1243 `Index::words_fst`; facet-id-string-fst,
+ * search/facet/search.rs:122-190), so that the shim passes `set.as_fst().as_bytes()` (a borrow of the LMDB
+ * page) instead of streaming every key through Rust: a host-side decoder of the `fst` 0.4 format version 3
+ * (bounds-checked, checksum-verified; anything malformed -> MSI_E_INVALID, another version ->
+ * MSI_E_UNSUPPORTED, and the caller keeps its own FST path).
+ * msi_fst_decode: keys in stream (= byte-lexicographic) order, flat as msi_dict_create takes them.  With
+ * out_concat = NULL only *out_n_words / *out_n_bytes are produced (size the buffers, then call again);
+ * out_offsets has cap_words + 1 entries. */
+#define MSI_FST_SKIP_CHECKSUM 1u /* flags: the caller verified the footer CRC already */
+int32_t msi_fst_decode(const uint8_t *fst, size_t len, uint32_t flags, uint8_t *out_concat, uint64_t cap_bytes,
+                       uint32_t *out_offsets, uint32_t cap_words, uint32_t *out_n_words, uint64_t *out_n_bytes);
+/* = msi_fst_decode + msi_dict_create / msi_dict_create_values */
+int32_t msi_dict_create_from_fst(msi_ctx *ctx, const uint8_t *fst, size_t len, msi_dict **out);
+int32_t msi_dict_create_values_from_fst(msi_ctx *ctx, const uint8_t *fst, size_t len, msi_dict **out);
+
 /* Micro-batching of concurrent callers (each tokio spawn_blocking search thread
  * calls msi_vs_search with ONE query): with max_wait_us > 0, unfiltered calls that
  * arrive within that window are fused into one HBM sweep (up to msi_vs_max_batch()

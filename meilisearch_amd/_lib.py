@@ -163,6 +163,9 @@ PROTOTYPES = {
     "msi_dict_len": (_U32, [_VP]),
     "msi_dict_lookup": (_I32, [_VP, C.POINTER(TypoQuery), _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "msi_dict_create_values": (_I32, [_VP, _VP, _VP, _U32, C.POINTER(_VP)]),
+    "msi_fst_decode": (_I32, [_VP, C.c_size_t, _U32, _VP, C.c_uint64, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_uint64)]),
+    "msi_dict_create_from_fst": (_I32, [_VP, _VP, C.c_size_t, C.POINTER(_VP)]),
+    "msi_dict_create_values_from_fst": (_I32, [_VP, _VP, C.c_size_t, C.POINTER(_VP)]),
     "msi_dict_search_values": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, C.POINTER(_U32), C.POINTER(_I32)]),
     "msi_dict_set_microbatch": (_I32, [_VP, _U32, _U32]),
     "msi_dict_microbatch_stats": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_U64)]),

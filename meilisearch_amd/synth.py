@@ -88,21 +88,23 @@ def round_to_bf16(x):
     return ((u + bias) & np.uint32(0xFFFF0000)).view(np.float32)
 
 
-def cbo_serialize(ids):
-    """CboRoaringBitmapCodec::serialize_into_writer (cbo_roaring_bitmap_codec.rs:33-51) of a sorted unique
-    u32 array: <= 7 documents as raw native-endian u32s, else the portable Roaring serialisation (array
-    containers up to 4096 values, bitmap containers above; no run containers)."""
+def roaring_serialize(ids):
+    """RoaringBitmap::serialize_into of a sorted unique u32 array (`roaring` 0.10, the portable RoaringFormatSpec
+    without run containers): cookie 12346, container count, (key, cardinality - 1) pairs, byte offset of every
+    container, then array containers (<= 4096 values) or 8 KiB bitmap containers.  Pinned byte for byte by
+    main["documents-ids"] of the reference's own index (tests/golden/index_blobs.json)."""
     import struct
     ids = np.asarray(ids, dtype=np.uint32)
-    if ids.size <= 7:
-        return ids.astype("=u4").tobytes()
     hi = (ids >> 16).astype(np.uint32)
     keys, starts = np.unique(hi, return_index=True)
     ends = np.append(starts[1:], ids.size)
     out = bytearray(struct.pack("<II", 12346, len(keys)))
     for k, a, b in zip(keys, starts, ends):
         out += struct.pack("<HH", int(k), int(b - a) - 1)
-    out += b"\0" * (4 * len(keys))
+    at = 8 + 8 * len(keys)
+    for a, b in zip(starts, ends):
+        out += struct.pack("<I", at)
+        at += 2 * int(b - a) if b - a <= 4096 else 8192
     for a, b in zip(starts, ends):
         v = (ids[a:b] & 0xFFFF).astype(np.uint16)
         if v.size <= 4096:
@@ -112,6 +114,15 @@ def cbo_serialize(ids):
             np.bitwise_or.at(words, (v >> 6).astype(np.int64), np.uint64(1) << (v & 63).astype(np.uint64))
             out += words.astype("<u8").tobytes()
     return bytes(out)
+
+
+def cbo_serialize(ids):
+    """CboRoaringBitmapCodec::serialize_into_writer (cbo_roaring_bitmap_codec.rs:33-51) of a sorted unique
+    u32 array: <= 7 documents as raw native-endian u32s, else the portable Roaring serialisation."""
+    ids = np.asarray(ids, dtype=np.uint32)
+    if ids.size <= 7:
+        return ids.astype("=u4").tobytes()
+    return roaring_serialize(ids)
 
 
 class SynthIndex:

@@ -44,8 +44,37 @@ def pack_queries(queries):
     return qb, off, fl
 
 
+FST_SKIP_CHECKSUM = 1
+
+
+def fst_decode(fst_bytes, flags=0):
+    """Keys of an `fst::Set` blob (main["words-fst"], index.rs:1225-1243) in stream order, flat:
+    (concat u8, offsets u32[n+1]) — host-side msi_fst_decode, two calls (sizes, then data)."""
+    buf = np.frombuffer(bytes(fst_bytes), dtype=np.uint8)
+    n, nb = C.c_uint32(0), C.c_uint64(0)
+    check(lib().msi_fst_decode(np_ptr(buf) if buf.size else None, buf.size, flags, None, 0, None, 0, C.byref(n), C.byref(nb)))
+    concat = np.zeros(max(nb.value, 1), dtype=np.uint8)
+    offsets = np.zeros(n.value + 1, dtype=np.uint32)
+    check(lib().msi_fst_decode(np_ptr(buf), buf.size, flags, np_ptr(concat), nb.value, np_ptr(offsets), n.value,
+                               C.byref(n), C.byref(nb)))
+    return concat[:nb.value], offsets
+
+
 class GpuDictionary:
     """Sorted, unique word list (the keys of `word_docids`, index.rs:1238-1243)."""
+
+    @classmethod
+    def from_fst(cls, ctx, fst_bytes, facet_values=False):
+        """The dictionary straight from milli's `fst::Set` bytes (msi_dict_create_from_fst /
+        msi_dict_create_values_from_fst): no key list crosses the boundary."""
+        self = cls.__new__(cls)
+        self.ctx, self.facet_values = ctx, facet_values
+        buf = np.frombuffer(bytes(fst_bytes), dtype=np.uint8)
+        self._h = C.c_void_p()
+        create = lib().msi_dict_create_values_from_fst if facet_values else lib().msi_dict_create_from_fst
+        check(create(ctx.handle, np_ptr(buf), buf.size, C.byref(self._h)))
+        self.concat, self.offsets = fst_decode(fst_bytes, FST_SKIP_CHECKSUM)   # only for word(i) on the Python side
+        return self
 
     def __init__(self, ctx, words=None, concat=None, offsets=None, facet_values=False):
         """facet_values=True stages the (sorted, unique, normalised) values of one facet for `search_values`

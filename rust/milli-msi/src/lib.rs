@@ -98,6 +98,21 @@ impl GpuDictionary {
         check(unsafe { sys::msi_dict_set_microbatch(this.h.as_ptr(), 200, 256) })?;
         Ok(this)
     }
+    /// Straight from `index.words_fst(rtxn)?.as_fst().as_bytes()` (index.rs:1225-1243): the library decodes the
+    /// `fst` 0.4 bytes itself (checksum-verified), so no key is streamed through Rust.  The flat copy kept here
+    /// only resolves indices back to words; an `Err` (older fst version, corrupt bytes) means "stream it".
+    pub fn from_fst_bytes(ctx: &GpuContext, fst: &[u8]) -> Result<Self, GpuError> {
+        let (mut n, mut nb) = (0u32, 0u64);
+        check(unsafe { sys::msi_fst_decode(fst.as_ptr(), fst.len(), 0, ptr::null_mut(), 0, ptr::null_mut(), 0, &mut n, &mut nb) })?;
+        let (mut concat, mut offsets) = (vec![0u8; nb as usize], vec![0u32; n as usize + 1]);
+        check(unsafe { sys::msi_fst_decode(fst.as_ptr(), fst.len(), 1 /* MSI_FST_SKIP_CHECKSUM */, concat.as_mut_ptr(), nb,
+                                           offsets.as_mut_ptr(), n, &mut n, &mut nb) })?;
+        let mut p = ptr::null_mut();
+        check(unsafe { sys::msi_dict_create(ctx.0.as_ptr(), concat.as_ptr(), offsets.as_ptr(), n, &mut p) })?;
+        let this = Self { h: NonNull::new(p).unwrap(), concat, offsets };
+        check(unsafe { sys::msi_dict_set_microbatch(this.h.as_ptr(), 200, 256) })?;
+        Ok(this)
+    }
     pub fn word(&self, idx: u32) -> &str {
         let (a, b) = (self.offsets[idx as usize] as usize, self.offsets[idx as usize + 1] as usize);
         std::str::from_utf8(&self.concat[a..b]).expect("dictionary words are UTF-8")

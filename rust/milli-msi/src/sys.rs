@@ -122,6 +122,10 @@ extern "C" {
                            out_one_idx: *mut u32, out_one_cnt: *mut u32, out_two_idx: *mut u32, out_two_cnt: *mut u32) -> i32;
     pub fn msi_dict_create_values(ctx: *mut msi_ctx, values_concat: *const u8, offsets: *const u32, n_values: u32,
                                   out: *mut *mut msi_dict) -> i32;
+    pub fn msi_fst_decode(fst: *const u8, len: usize, flags: u32, out_concat: *mut u8, cap_bytes: u64,
+                          out_offsets: *mut u32, cap_words: u32, out_n_words: *mut u32, out_n_bytes: *mut u64) -> i32;
+    pub fn msi_dict_create_from_fst(ctx: *mut msi_ctx, fst: *const u8, len: usize, out: *mut *mut msi_dict) -> i32;
+    pub fn msi_dict_create_values_from_fst(ctx: *mut msi_ctx, fst: *const u8, len: usize, out: *mut *mut msi_dict) -> i32;
     pub fn msi_dict_search_values(d: *mut msi_dict, query: *const u8, len: u32, max_typos: u32, cap: u32,
                                   out_idx: *mut u32, out_n: *mut u32, out_truncated: *mut i32) -> i32;
     pub fn msi_bits_set_from_docid_lists_device(p: *mut msi_bits, first_slot: u32, slot_stride: u32, d_docids: *const u32,
