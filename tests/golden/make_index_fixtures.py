@@ -13,6 +13,9 @@ below exists for that and nothing else.  Runs where /root/reference exists (this
 import json
 import os
 import struct
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 ENV = "/root/reference/crates/meilisearch/tests/upgrade/v1_12/v1_12_0.ms/indexes"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "index_blobs.json")
@@ -81,7 +84,49 @@ def main():
     for db in ("word-docids", "exact-word-docids", "word-pair-proximity-docids", "word-position-docids"):
         for k, v in env.items(db):
             out["bitmaps"].append({"name": f"{db}[{k.hex()}]", "codec": "cbo", "hex": v.hex()})
-    json.dump(out, open(OUT, "w"), indent=0, sort_keys=True)
+    # the inverted-index databases themselves (2 documents), to hold the toy indexer of tests/toy_milli.py against
+    # what milli's write path produced.  Documents as (fid -> JSON) from the obkv records; charabia already
+    # normalised the words in the databases ("très" -> "tres"), the test feeds the toy the normalised text.
+    fields = json.loads(main_db[b"fields-ids-map"])["ids_names"]
+    docs = []
+    for _, v in env.items("documents"):
+        doc, i = {}, 0
+        while i < len(v):
+            fid = struct.unpack_from(">H", v, i)[0]
+            i += 2
+            ln, shift = 0, 0
+            while True:                       # obkv: LEB128 value length
+                b = v[i]
+                i += 1
+                ln |= (b & 0x7F) << shift
+                shift += 7
+                if not b & 0x80:
+                    break
+            doc[fields[str(fid)]] = json.loads(v[i:i + ln])
+            i += ln
+        docs.append(doc)
+
+    def ids(v):
+        return list(struct.unpack("<%dI" % (len(v) // 4), v))
+    dbs = {"word_docids": [[k.decode(), ids(v)] for k, v in env.items("word-docids")],
+           "exact_word_docids": [[k.decode(), ids(v)] for k, v in env.items("exact-word-docids")],
+           "word_fid_docids": [[k[:-3].decode(), struct.unpack(">H", k[-2:])[0], ids(v)]
+                               for k, v in env.items("word-field-id-docids")],
+           "word_position_docids": [[k[:-3].decode(), struct.unpack(">H", k[-2:])[0], ids(v)]
+                                    for k, v in env.items("word-position-docids")],
+           "field_id_word_count_docids": [[struct.unpack(">H", k[:2])[0], k[2], ids(v)]
+                                          for k, v in env.items("field-id-word-count-docids")],
+           "word_pair_proximity_docids": [[k[0], k[1:].split(b"\0")[0].decode(), k[1:].split(b"\0")[1].decode(), ids(v)]
+                                          for k, v in env.items("word-pair-proximity-docids")]}
+    out["index"] = {"documents": docs, "fields": fields, "exact_attributes": ["surname"],
+                    "stop_words": [k.decode() for k in __import__("oracle.fst_oracle", fromlist=["x"]).fst_keys(main_db[b"stop-words"])],
+                    "databases": dbs}
+    # arroy item leaves of the one embedder (key = u16 index, mode byte, u32 item; value = tag 0, f32 norm, f32 x d):
+    # the norm arroy stored at indexing time pins the oracle's f32 norm on real 384-d embeddings
+    out["arroy_items"] = [{"key": k.hex(), "docid": struct.unpack(">I", k[3:7])[0], "norm_f32_hex": v[1:5].hex(),
+                           "vector_f32_hex": v[5:].hex()}
+                          for k, v in env.items("vector-arroy") if len(v) == 1 + 4 + 4 * 384 and v[0] == 0]
+    json.dump(out, open(OUT, "w"), indent=0, sort_keys=True, ensure_ascii=False)
     print(len(out["fst"]), "fst blobs,", len(out["bitmaps"]), "bitmaps ->", OUT, os.path.getsize(OUT), "bytes")
 
 

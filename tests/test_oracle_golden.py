@@ -134,3 +134,30 @@ def test_typo_cap_interplay(oracle):
     assert [words[i] for i in two] == ["aello", "bello"]
     # cello, dello arrive after `two` is full -> distance 1 -> `one`; then hallo fills it
     assert [words[i] for i in one] == ["cello", "dello", "hallo"]
+
+
+def test_norms_arroy_stored_for_real_embeddings():
+    """The reference's own index (v1.12 upgrade test) holds two 384-d all-MiniLM-L6-v2 embeddings as arroy item
+    leaves {norm: f32, vector}: the oracle's f32 norm (sequential accumulation, the crate's scalar path) must equal
+    the norm arroy computed at indexing time, bit for bit; and the distance between the two documents is pinned to
+    the f64 value within the north-star tolerance."""
+    import ctypes as C
+    import json
+    import os
+    import numpy as np
+    from oracle import oracle as O
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "index_blobs.json")))
+    items = fx["arroy_items"]
+    assert [it["docid"] for it in items] == [0, 1]
+    vecs = [np.frombuffer(bytes.fromhex(it["vector_f32_hex"]), dtype="<f4") for it in items]
+    lib = O.lib()
+    lib.orc_norm_f32.restype = C.c_float
+    for it, v in zip(items, vecs):
+        stored = np.frombuffer(bytes.fromhex(it["norm_f32_hex"]), dtype="<f4")[0]
+        v = np.ascontiguousarray(v)
+        got = np.float32(lib.orc_norm_f32(v.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(v.size)))
+        assert got.view(np.uint32) == stored.view(np.uint32)
+    a, b = (v.astype(np.float64) for v in vecs)
+    exact = (1.0 - a @ b / np.sqrt((a @ a) * (b @ b))) / 2.0
+    assert abs(O.cosine_distance(vecs[0], vecs[1]) - exact) < 1e-6
+    assert 0.0 < exact < 0.5       # two dog descriptions: similar, not identical

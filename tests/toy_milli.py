@@ -86,10 +86,25 @@ class ToyMilli:
         for docid, d in enumerate(merged):
             pairs = {}
             for name in self.searchable:
-                if name not in d or not isinstance(d[name], (str, int, float)) or isinstance(d[name], bool):
+                if name not in d or isinstance(d[name], bool):
                     continue
                 fid = self.fields[name]
-                toks = tokenize_with_positions(str(d[name]), stop_words=self.stop_words)
+                if isinstance(d[name], list):
+                    # every further value of the same field starts INDEX_MAX_DISTANCE after the last position of
+                    # the previous one (tokenize_document.rs:77-83) — pinned by the `surname` arrays of the index
+                    # milli wrote (tests/golden/index_blobs.json: kef 0, kefkef 8, kefirounet 16, boubou 24)
+                    toks, start = [], 0
+                    for v in d[name]:
+                        if isinstance(v, bool) or not isinstance(v, (str, int, float)):
+                            continue
+                        part = tokenize_with_positions(str(v), start=start, stop_words=self.stop_words)
+                        if part:
+                            toks += part
+                            start = part[-1][1] + INDEX_MAX_DISTANCE
+                elif isinstance(d[name], (str, int, float)):
+                    toks = tokenize_with_positions(str(d[name]), stop_words=self.stop_words)
+                else:
+                    continue
                 toks = [(w, p) for w, p in toks if p < MAX_POSITION_PER_ATTRIBUTE]
                 target = self.exact_word_docids if name in exact_attr else self.word_docids
                 for w, p in toks:
