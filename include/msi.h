@@ -309,6 +309,21 @@ int32_t msi_bits_set_from_docid_lists_device(msi_bits *pool, uint32_t first_slot
                                              const uint32_t *d_counts, uint32_t n_lists);
 int32_t msi_bits_set_from_cbo(msi_bits *pool, uint32_t slot,
                               const uint8_t *bytes, size_t len);
+/* SURVEY §8 f3 — the Sort / Asc / Desc ranking rules (crates/milli/src/search/new/sort.rs:95-233) without a facet
+ * database walk per query: one u32 ORDER KEY per document, resident in HBM.  key[docid] = rank of the facet value
+ * the rule's iteration meets first for that document (ascending_facet_sort / descending_facet_sort over
+ * facet_id_f64_docids, then facet_id_string_docids: numbers, then strings, each in the rule's direction; for a
+ * document with several values the first one met, i.e. its smallest for `asc`, its largest for `desc`),
+ * 0xFFFFFFFF = no value.  Built by the shim once per (index update, field, direction); the rank -> value table
+ * stays with the shim, which turns the key of a hit back into ScoreDetails::Sort{value}.
+ * msi_bits_order_next = the rule's next_bucket: bucket := the documents of `universe` that share its smallest
+ * key, universe -= bucket; *out_key that key (0xFFFFFFFF: what was left has no value — the rule's last, Null,
+ * bucket), *out_count = |bucket| (0 only for an empty universe). */
+typedef struct msi_doc_keys msi_doc_keys;
+int32_t msi_doc_keys_create(msi_ctx *ctx, const uint32_t *keys /* [n_docs] */, uint64_t n_docs, msi_doc_keys **out);
+void msi_doc_keys_destroy(msi_doc_keys *keys);
+int32_t msi_bits_order_next(msi_bits *pool, const msi_doc_keys *keys, uint32_t universe, uint32_t bucket,
+                            uint32_t *out_key, uint64_t *out_count);
 int32_t msi_bits_set_from_words(msi_bits *pool, uint32_t slot,
                                 const uint64_t *words, uint64_t n_words);
 int32_t msi_bits_fill(msi_bits *pool, uint32_t slot, int32_t ones);
@@ -538,7 +553,10 @@ int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtabl
  */
 enum {
   MSI_CRIT_WORDS = 0, MSI_CRIT_TYPO = 1, MSI_CRIT_PROXIMITY = 2, MSI_CRIT_ATTRIBUTE = 3,
-  MSI_CRIT_ATTRIBUTE_RANK = 4, MSI_CRIT_WORD_POSITION = 5, MSI_CRIT_EXACTNESS = 6, MSI_CRIT_SORT = 7
+  MSI_CRIT_ATTRIBUTE_RANK = 4, MSI_CRIT_WORD_POSITION = 5, MSI_CRIT_EXACTNESS = 6,
+  MSI_CRIT_SORT = 7,     /* ignored: the shim expands Criterion::Sort / Asc / Desc into MSI_CRIT_ORDER_BY entries */
+  MSI_CRIT_ORDER_BY = 8  /* one Sort rule (mod.rs:366-376,640-720: one per sorted field, a field only once); the
+                          * i-th MSI_CRIT_ORDER_BY of the list uses params->order_keys[i] */
 };
 enum { /* ScoreDetails variants, score_details.rs:10-27 */
   MSI_SCORE_WORDS = 0,           /* a = matching_words, b = max_matching_words */
@@ -548,7 +566,9 @@ enum { /* ScoreDetails variants, score_details.rs:10-27 */
   MSI_SCORE_POSITION = 4,        /* a = rank, b = max_rank */
   MSI_SCORE_EXACT_ATTRIBUTE = 5, /* a = 3 ExactMatch | 2 MatchesStart | 1 NoExactMatch, b = 3 */
   MSI_SCORE_EXACT_WORDS = 6,     /* a = matching_words, b = max_matching_words */
-  MSI_SCORE_SKIPPED = 7          /* the deadline cut the ranking short here; rank 0 of 1 */
+  MSI_SCORE_SKIPPED = 7,         /* the deadline cut the ranking short here; rank 0 of 1 */
+  MSI_SCORE_SORT = 8             /* a = index into order_keys, b = the bucket's order key (0xFFFFFFFF: Null); no rank
+                                  * (score_details.rs:103-121: Sort does not enter the global score) */
 };
 #define MSI_MAX_SCORE_DETAILS 8
 typedef struct msi_score_detail {
@@ -584,6 +604,10 @@ typedef struct msi_search_params {
   /* ranking_score_threshold (bucket_sort.rs:286-306): a bucket whose ScoreDetails::global_score so far is below
    * it is dropped together with what is left of that rule's universe; *out_candidates excludes both. */
   double score_threshold;
+  /* Sort / Asc / Desc rules: the key array of the i-th MSI_CRIT_ORDER_BY criterion (NULL / 0 when there is none).
+   * They also order a placeholder search (no term survived: mod.rs:352-420). */
+  const msi_doc_keys *const *order_keys;
+  uint32_t n_order_keys;
 } msi_search_params;
 /* out_scores: [length][MSI_MAX_SCORE_DETAILS], out_n_scores: [length].  The pool needs at least 64 free
  * slots above slot 0 (more for long queries: one per live condition of every active rule). */

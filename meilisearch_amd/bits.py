@@ -48,6 +48,13 @@ class BitsPool:
         s = np.ascontiguousarray(srcs, dtype=np.uint32)
         check(lib().msi_bits_union_many_and(self._h, dst, np_ptr(s) if s.size else None, s.size, universe))
 
+    def order_next(self, keys, universe, bucket):
+        """The Sort rule's next bucket: bucket := the documents of `universe` with its smallest key, universe -= bucket.
+        -> (key, count)."""
+        key, n = C.c_uint32(0), C.c_uint64(0)
+        check(lib().msi_bits_order_next(self._h, keys._h, universe, bucket, C.byref(key), C.byref(n)))
+        return int(key.value), int(n.value)
+
     def count(self, slot):
         out = C.c_uint64(0)
         check(lib().msi_bits_count(self._h, slot, C.byref(out)))
@@ -75,6 +82,28 @@ class BitsPool:
     def close(self):
         if self._h:
             lib().msi_bits_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DocKeys:
+    """One u32 order key per document, resident in HBM (msi_doc_keys_create): the Sort / Asc / Desc ranking rules
+    (search/new/sort.rs:95-233) read it instead of walking the facet databases per query."""
+
+    def __init__(self, ctx, keys):
+        self.ctx = ctx
+        self.keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        self._h = C.c_void_p()
+        check(lib().msi_doc_keys_create(ctx.handle, np_ptr(self.keys), self.keys.size, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().msi_doc_keys_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

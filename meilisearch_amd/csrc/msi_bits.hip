@@ -45,6 +45,13 @@ struct msi_bits {
   u64 *slot(uint32_t s) const { return pool.as<u64>() + (uint64_t)s * n_words; }
 };
 
+// One u32 order key per document, resident in HBM (msi_doc_keys_create)
+struct msi_doc_keys {
+  msi_ctx *ctx = nullptr;
+  uint64_t n_docs = 0;
+  DevBuf keys;
+};
+
 // accessors for the other translation units (msi_rank.hip)
 msi_ctx *msi_bits_ctx(msi_bits *p) { return p->ctx; }
 hipStream_t msi_bits_stream(msi_bits *p) { return p->stream; }
@@ -133,6 +140,58 @@ __global__ void bits_op_count_kernel(u64 *__restrict__ dst, const u64 *__restric
     c += __popcll(r.x) + __popcll(r.y);
   }
   publish_count(c, acc, sig, seq);
+}
+
+// ---- order keys (Sort / Asc / Desc ranking rules, crates/milli/src/search/new/sort.rs:95-233) ------------------------
+// One u32 key per document: its rank in the rule's iteration order over the facet values of the field (numbers, then
+// strings, each in the rule's direction), 0xFFFFFFFF = the document has no value.  The rule's next bucket is "the
+// documents of the universe with the smallest key": one pass finds the minimum, one takes its documents out.
+// One document per thread, so a wave covers exactly one 64-bit word of a set and __ballot yields the word.
+__global__ void bits_min_key_kernel(const u64 *__restrict__ universe, const uint32_t *__restrict__ keys, uint64_t n_docs,
+                                    u64 *__restrict__ best /* max over documents of 0xFFFFFFFF - key; 0 = none */) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t inv = 0;
+  if (d < n_docs && ((universe[d >> 6] >> (d & 63)) & 1ull)) inv = 0xFFFFFFFFu - keys[d];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) inv = max(inv, (uint32_t)__shfl_xor((int)inv, o));
+  if ((threadIdx.x & 63) == 0 && inv) atomicMax(best, (u64)inv);
+}
+
+// bucket = {d in universe : key[d] == the minimum found}, universe -= bucket; the last workgroup publishes
+// {|bucket|, key, seq} and re-arms `best`.  The grid covers every word of the slot, so `bucket` is fully overwritten.
+__global__ void bits_take_key_kernel(u64 *__restrict__ universe, u64 *__restrict__ bucket,
+                                     const uint32_t *__restrict__ keys, uint64_t n_docs, uint64_t n_words,
+                                     u64 *__restrict__ best, u64 *__restrict__ acc, volatile uint64_t *__restrict__ sig,
+                                     uint64_t seq) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = d >> 6;
+  const uint32_t key = 0xFFFFFFFFu - (uint32_t)__hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool hit = d < n_docs && ((universe[w] >> (d & 63)) & 1ull) && keys[d] == key;
+  const u64 mask = __ballot(hit);
+  __shared__ uint32_t part[BT / 64];
+  if ((threadIdx.x & 63) == 0) {
+    if (w < n_words) {
+      bucket[w] = mask;
+      if (mask) universe[w] &= ~mask;
+    }
+    part[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 b = 0;
+    for (int i = 0; i < BT / 64; ++i) b += part[i];
+    if (b) atomicAdd(&acc[0], b);
+    __threadfence();
+    const u64 done = atomicAdd(&acc[1], 1ull);
+    if (done == gridDim.x - 1) {
+      const u64 total = atomicExch(&acc[0], 0ull);
+      acc[1] = 0;
+      atomicExch(best, 0ull);  // every workgroup has read it: re-armed for the next call
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[0]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[2]), (uint64_t)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 struct ManyArgs {
@@ -566,9 +625,9 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   if (s == MSI_OK) s = p->small.ensure(64);
   if (s == MSI_OK) {
     void *h = nullptr;
-    if (hipHostMalloc(&h, (2 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(uint64_t), hipHostMallocCoherent) != hipSuccess ||
-        hipMalloc((void **)&p->d_acc, (2 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess ||
-        hipMemset(p->d_acc, 0, (2 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess) {
+    if (hipHostMalloc(&h, (3 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(uint64_t), hipHostMallocCoherent) != hipSuccess ||
+        hipMalloc((void **)&p->d_acc, (3 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess ||
+        hipMemset(p->d_acc, 0, (3 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess) {
       msi_set_error("msi_bits_create: allocating the completion signal failed");
       s = MSI_E_OOM;
     } else {
@@ -1118,6 +1177,76 @@ int32_t msi_bits_union_many_and(msi_bits *p, uint32_t dst, const uint32_t *srcs,
                      0, st, p->pool.as<u64>(), p->n_words, dst, p->desc.as<uint32_t>(), n, universe);
   MSI_HIP_TRY(hipGetLastError());
   MSI_HIP_TRY(hipStreamSynchronize(st));  // srcs is borrowed; desc is reused
+  return MSI_OK;
+}
+
+int32_t msi_doc_keys_create(msi_ctx *ctx, const uint32_t *keys, uint64_t n_docs, msi_doc_keys **out) {
+  if (!ctx || !out || !n_docs || !keys) {
+    msi_set_error("msi_doc_keys_create: invalid argument");
+    return MSI_E_INVALID;
+  }
+  *out = nullptr;
+  DeviceGuard g(ctx->device);
+  msi_doc_keys *k = new msi_doc_keys();
+  k->ctx = ctx;
+  k->n_docs = n_docs;
+  int32_t s = k->keys.ensure((size_t)n_docs * sizeof(uint32_t));
+  if (s == MSI_OK) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipError_t e = hipMemcpyAsync(k->keys.p, keys, (size_t)n_docs * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `keys` is borrowed for the call
+    if (e != hipSuccess) {
+      msi_set_error("msi_doc_keys_create: upload failed: %s", hipGetErrorString(e));
+      s = MSI_E_HIP;
+    }
+  }
+  if (s != MSI_OK) {
+    k->keys.release();
+    delete k;
+    return s;
+  }
+  msi_ctx_retain(ctx);
+  *out = k;
+  return MSI_OK;
+}
+
+void msi_doc_keys_destroy(msi_doc_keys *k) {
+  if (!k) return;
+  {
+    DeviceGuard g(k->ctx->device);
+    k->keys.release();
+  }
+  msi_ctx_release(k->ctx);
+  delete k;
+}
+
+int32_t msi_bits_order_next(msi_bits *p, const msi_doc_keys *keys, uint32_t universe, uint32_t bucket, uint32_t *out_key,
+                            uint64_t *out_count) {
+  if (!p || !keys || !out_key || !out_count || universe == bucket) {
+    msi_set_error("msi_bits_order_next: invalid argument");
+    return MSI_E_INVALID;
+  }
+  if (keys->ctx != p->ctx || keys->n_docs != p->n_docs) {
+    msi_set_error("msi_bits_order_next: the key array (%llu documents) does not belong to this pool (%llu documents)",
+                  (unsigned long long)keys->n_docs, (unsigned long long)p->n_docs);
+    return MSI_E_INVALID;
+  }
+  MSI_TRY(check_slot(p, universe, "msi_bits_order_next"));
+  MSI_TRY(check_slot(p, bucket, "msi_bits_order_next"));
+  std::unique_lock<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->stream;
+  u64 *best = p->d_acc + 2 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS;
+  const uint32_t blocks = (uint32_t)((p->n_words * 64 + BT - 1) / BT);
+  const uint64_t seq = ++p->seq;
+  hipLaunchKernelGGL(bits_min_key_kernel, dim3(blocks), dim3(BT), 0, st, p->slot(universe), keys->keys.as<uint32_t>(),
+                     p->n_docs, best);
+  hipLaunchKernelGGL(bits_take_key_kernel, dim3(blocks), dim3(BT), 0, st, p->slot(universe), p->slot(bucket),
+                     keys->keys.as<uint32_t>(), p->n_docs, p->n_words, best, p->d_acc, p->h_sig, seq);
+  MSI_HIP_TRY(hipGetLastError());
+  lk.unlock();
+  MSI_TRY(wait_count(p, seq, out_count));
+  *out_key = (uint32_t)__atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2]), __ATOMIC_RELAXED);
   return MSI_OK;
 }
 

@@ -192,6 +192,16 @@ struct Dev {
     g_stats.device_wait_ms += ck_.ms();
     return counts;
   }
+  // Sort rule: bucket := the documents of `universe` with its smallest order key, universe -= bucket
+  Set order_next(const msi_doc_keys *keys, const Set &universe, uint32_t *key, uint64_t *count) {
+    Set b = alloc();  // fully overwritten by the kernel
+    Clock ck_;
+    g_stats.launches += 2;
+    ++g_stats.syncs;
+    ck(msi_bits_order_next(pool.p, keys, universe->slot, b->slot, key, count));
+    g_stats.device_wait_ms += ck_.ms();
+    return b;
+  }
   // the same level WITHOUT the completion wait: its counts land in `region`; false = does not fit, nothing enqueued
   bool paths_enqueue(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe, uint32_t region) {
     std::vector<uint32_t> off{0}, steps;
@@ -312,7 +322,7 @@ struct Term {
   bool too_long = false;
 };
 
-enum RuleKind { R_WORDS, R_TYPO, R_PROXIMITY, R_FID, R_POSITION, R_EXACTNESS, R_EXACT_ATTRIBUTE };
+enum RuleKind { R_WORDS, R_TYPO, R_PROXIMITY, R_FID, R_POSITION, R_EXACTNESS, R_EXACT_ATTRIBUTE, R_ORDER_BY };
 enum CondKind { C_TERM, C_TYPO, C_PROX, C_FID, C_POSITION, C_EXACT, C_ANY };
 
 struct Condition {
@@ -1784,6 +1794,30 @@ struct ExactAttributeRule : Rule {
 };
 
 // ScoreDetails::global_score of the details pushed so far (score_details.rs:123-154)
+// sort.rs:95-233 over a per-document order key array (include/msi.h, msi_doc_keys): every bucket is the set of
+// documents that share the smallest key left in the universe; the last one (key 0xFFFFFFFF) holds the documents
+// without a value.  The rule does not look at the query: it hands the graph it was given to the next rule, and
+// it also orders placeholder searches.
+struct OrderByRule : Rule {
+  uint32_t idx;
+  const msi_doc_keys *keys;
+  Graph g;
+  OrderByRule(uint32_t i, const msi_doc_keys *k) : Rule(R_ORDER_BY, -1), idx(i), keys(k) {}
+  void start(Ctx &, const Set &, const Graph &graph) override { g = graph; }
+  bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) override {
+    if (!universe_count) return false;
+    uint32_t key = 0;
+    uint64_t n = 0;
+    out.docs = c.dev.order_next(keys, universe, &key, &n);
+    out.count = n;
+    out.score = {MSI_SCORE_SORT, idx, key};
+    out.graph = g;
+    out.universe_reduced = true;
+    return true;
+  }
+  void end() override {}
+};
+
 double global_score(const std::vector<Score> &scores) {
   std::vector<msi_score_detail> d;
   for (const Score &s : scores) d.push_back(msi_score_detail{s.kind, s.a, s.b});
@@ -1795,6 +1829,7 @@ std::vector<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
   std::vector<std::unique_ptr<Rule>> rules;
   bool words = p->strategy == MSI_TERMS_ALL, typo = false, prox = false, attribute = false, attr_rank = false,
        word_pos = false, exact = false;
+  uint32_t n_order = 0;
   auto add_words = [&]() {
     if (!words) {
       rules.emplace_back(new GraphRule(R_WORDS, p->strategy));
@@ -1838,9 +1873,27 @@ std::vector<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
         rules.emplace_back(new ExactAttributeRule());
         rules.emplace_back(new GraphRule(R_EXACTNESS, -1));
         break;
-      default: break;  // Sort / Asc / Desc: not keyword rules
+      case MSI_CRIT_ORDER_BY:
+        if (n_order < p->n_order_keys && p->order_keys && p->order_keys[n_order])
+          rules.emplace_back(new OrderByRule(n_order, p->order_keys[n_order]));
+        ++n_order;
+        break;
+      default: break;  // MSI_CRIT_SORT: expanded by the caller into MSI_CRIT_ORDER_BY entries
     }
   }
+  return rules;
+}
+
+// get_ranking_rules_for_placeholder_search, mod.rs:352-420: only the Sort / Asc / Desc rules
+std::vector<std::unique_ptr<Rule>> placeholder_rules(const msi_search_params *p) {
+  std::vector<std::unique_ptr<Rule>> rules;
+  uint32_t n_order = 0;
+  for (uint32_t i = 0; i < p->n_criteria; ++i)
+    if (p->criteria[i] == MSI_CRIT_ORDER_BY) {
+      if (n_order < p->n_order_keys && p->order_keys && p->order_keys[n_order])
+        rules.emplace_back(new OrderByRule(n_order, p->order_keys[n_order]));
+      ++n_order;
+    }
   return rules;
 }
 
@@ -1964,23 +2017,10 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       c.dev.sub_(universe, c.word_full(c.word(std::string((const char *)l.words[0].word, l.words[0].len)), true));
     }
   }
-  if (ts.empty()) {
-    // only stop words (or nothing) survived the tokenizer: a placeholder search — no keyword rule applies
-    // (mod.rs:770-800), the universe in ascending docid order
-    const uint64_t count = c.dev.count(universe);
-    if (out_candidates) *out_candidates = count;
-    *out_n = 0;
-    if (count < p->from || p->length == 0) return;
-    auto ids = c.dev.first_k(universe, p->from + p->length);
-    uint32_t n = 0;
-    for (size_t i = p->from; i < ids.size(); ++i) {
-      out_docids[n] = ids[i];
-      out_n_scores[n++] = 0;
-    }
-    *out_n = n;
-    return;
-  }
-  {
+  // only stop words (or nothing) survived the tokenizer: a placeholder search — no keyword rule applies
+  // (mod.rs:770-800): the Sort / Asc / Desc rules alone order the universe, ascending docids when there is none
+  const bool placeholder = ts.empty();
+  if (!placeholder) {
     Graph reduced = g;
     if (p->strategy == MSI_TERMS_LAST) {
       std::vector<uint32_t> rm;
@@ -1993,7 +2033,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   uint64_t universe_count = c.dev.count(universe);
 
   // ---- bucket_sort (bucket_sort.rs:23-343; no distinct, pins, deadline, score threshold) ---------
-  auto rules = ranking_rules(p);
+  auto rules = placeholder ? placeholder_rules(p) : ranking_rules(p);
   const uint32_t from = p->from, length = p->length;
   const bool detailed = p->detailed_scores != 0;
   uint32_t n_out = 0;

@@ -301,18 +301,45 @@ def keyword_search(gdict, pool, callbacks, words, last_is_prefix=True, strategy=
 
 
 CRITERIA = {"words": 0, "typo": 1, "proximity": 2, "attribute": 3, "attributeRank": 4, "wordPosition": 5,
-            "exactness": 6, "sort": 7}
-SCORE_KINDS = ["Words", "Typo", "Proximity", "Fid", "Position", "ExactAttribute", "ExactWords", "Skipped"]
+            "exactness": 6, "sort": 7, "orderBy": 8}
+SCORE_KINDS = ["Words", "Typo", "Proximity", "Fid", "Position", "ExactAttribute", "ExactWords", "Skipped", "Sort"]
+NO_ORDER_KEY = 0xFFFFFFFF
+
+
+def expand_sort_criteria(criteria, sort=None):
+    """What the shim does with Criterion::Sort / Asc / Desc (search/new/mod.rs:366-376,640-720): `sort` of the list
+    becomes one rule per field of the request's sort list, `asc:f` / `desc:f` one rule, a field is sorted only once.
+    -> (criteria with "orderBy" entries, [(field, ascending)] of those entries in order)."""
+    out, order, fields, sort_done = [], [], set(), False
+    for c in criteria:
+        if c == "sort":
+            if not sort_done:
+                sort_done = True
+                for f, d in sort or ():
+                    if f not in fields:
+                        fields.add(f)
+                        out.append("orderBy")
+                        order.append((f, d == "asc"))
+        elif c.startswith(("asc:", "desc:")):
+            d, f = c.split(":", 1)
+            if f not in fields:
+                fields.add(f)
+                out.append("orderBy")
+                order.append((f, d == "asc"))
+        else:
+            out.append(c)
+    return out, order
 MAX_SCORE_DETAILS = 8
 
 
 def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERMS_LAST, offset=0, limit=20,
                           detailed=False, searchable_fids=(), searchable_weights=(), max_weight=None,
                           authorize_typos=True, min_one=5, min_two=9, universe_cbo=None, time_budget_us=0,
-                          stop_after=None, return_degraded=False, score_threshold=None, _entry=None):
+                          stop_after=None, return_degraded=False, score_threshold=None, order_keys=(), _entry=None):
     """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
     terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
     (words: [str | None], None = a stop word inside a phrase; an optional 6th element True marks a negative term).
+    order_keys: the DocKeys of the "orderBy" entries of `criteria`, in order (expand_sort_criteria).
     -> ([(docid, [(kind name, a, b)])], candidates)."""
     n = len(terms)
     lt = (LocatedTerm * max(n, 1))()
@@ -341,6 +368,9 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
                        -1 if max_weight is None else int(max_weight), offset, limit, 1 if detailed else 0,
                        int(time_budget_us), -1 if stop_after is None else int(stop_after),
                        0 if score_threshold is None else 1, 0.0 if score_threshold is None else float(score_threshold))
+    if order_keys:
+        okeys = (C.c_void_p * len(order_keys))(*[k._h for k in order_keys])
+        prm.order_keys, prm.n_order_keys = C.cast(okeys, C.c_void_p), len(order_keys)
     L = max(limit, 1)
     ids = np.zeros(L, dtype=np.uint32)
     sc = (ScoreDetail * (L * MAX_SCORE_DETAILS))()

@@ -268,6 +268,9 @@ pub enum RankedScore {
     ExactAttribute { rank: u32 },           // 3 ExactMatch, 2 MatchesStart, 1 NoExactMatch
     ExactWords { matching_words: u32, max_matching_words: u32 },
     Skipped,
+    /// `ScoreDetails::Sort`: `rule` = index into `RankedSearch::order_keys`, `key` = the bucket's order key
+    /// (`u32::MAX`: the documents without a value, `value: Null`)
+    Sort { rule: u32, key: u32 },
 }
 
 pub struct RankedSearch<'a> {
@@ -283,7 +286,25 @@ pub struct RankedSearch<'a> {
     pub detailed_scores: bool,
     pub time_budget: Option<std::time::Duration>,
     pub ranking_score_threshold: Option<f64>,
+    /// One per `sys::MSI_CRIT_ORDER_BY` entry of `criteria`, in order: the Sort / Asc / Desc rules the shim expanded
+    /// (search/new/mod.rs:366-376,640-720).  `RankedScore::Sort { rule, key }` indexes the shim's rank -> value table.
+    pub order_keys: &'a [&'a DocOrderKeys],
 }
+
+/// One u32 order key per document in HBM (`msi_doc_keys`): rank of the first facet value of a field that
+/// `ascending_facet_sort` / `descending_facet_sort` meets for the document (sort.rs:95-233), `u32::MAX` without a value.
+/// Built once per (index update, field, direction) from `facet_id_f64_docids` + `facet_id_string_docids`.
+pub struct DocOrderKeys(NonNull<sys::msi_doc_keys>);
+unsafe impl Send for DocOrderKeys {}
+unsafe impl Sync for DocOrderKeys {}
+impl DocOrderKeys {
+    pub fn new(ctx: &GpuContext, keys: &[u32]) -> Result<Self, GpuError> {
+        let mut p = ptr::null_mut();
+        check(unsafe { sys::msi_doc_keys_create(ctx.0.as_ptr(), keys.as_ptr(), keys.len() as u64, &mut p) })?;
+        Ok(Self(NonNull::new(p).unwrap()))
+    }
+}
+impl Drop for DocOrderKeys { fn drop(&mut self) { unsafe { sys::msi_doc_keys_destroy(self.0.as_ptr()) } } }
 
 pub struct RankedOutput {
     pub hits: Vec<(u32, Vec<RankedScore>)>,
@@ -379,6 +400,7 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
         is_phrase: (t.is_phrase as u32) | ((t.is_negative as u32) << 1),
         position_start: *t.positions.start() as u32, position_end: *t.positions.end() as u32 }).collect();
     let (fids, weights): (Vec<u16>, Vec<u16>) = q.searchable.iter().copied().unzip();
+    let order_ptrs: Vec<*const sys::msi_doc_keys> = q.order_keys.iter().map(|k| k.0.as_ptr() as *const _).collect();
     let params = sys::msi_search_params {
         authorize_typos: q.authorize_typos as u32, min_word_len_one_typo: q.min_word_len_one_typo,
         min_word_len_two_typos: q.min_word_len_two_typos,
@@ -389,7 +411,8 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
         detailed_scores: q.detailed_scores as i32,
         time_budget_us: q.time_budget.map_or(0, |d| d.as_micros().max(1) as u64), stop_after: -1,
         has_score_threshold: q.ranking_score_threshold.is_some() as i32,
-        score_threshold: q.ranking_score_threshold.unwrap_or(0.0) };
+        score_threshold: q.ranking_score_threshold.unwrap_or(0.0),
+        order_keys: order_ptrs.as_ptr(), n_order_keys: order_ptrs.len() as u32 };
     let mut src_ref: Src<'_> = source;
     let vt = sys::msi_index_vtable { user: &mut src_ref as *mut _ as *mut _, word_docids: Some(r_word),
         word_pair_proximity_docids: Some(r_pair), is_exact_word: Some(r_exact), word_fid_docids: Some(r_fid),
@@ -417,6 +440,7 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
             4 => RankedScore::Position { rank: d.a, max_rank: d.b },
             5 => RankedScore::ExactAttribute { rank: d.a },
             6 => RankedScore::ExactWords { matching_words: d.a, max_matching_words: d.b },
+            8 => RankedScore::Sort { rule: d.a, key: d.b },
             _ => RankedScore::Skipped,
         }).collect())
     }).collect();

@@ -6,6 +6,7 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct msi_vs { _p: [u8; 0] }
 #[repr(C)] pub struct msi_dict { _p: [u8; 0] }
 #[repr(C)] pub struct msi_bits { _p: [u8; 0] }
+#[repr(C)] pub struct msi_doc_keys { _p: [u8; 0] }
 
 pub const MSI_OK: i32 = 0;
 pub const MSI_E_INVALID: i32 = -1;
@@ -88,6 +89,7 @@ pub struct msi_search_params {
     pub searchable_fids: *const u16, pub searchable_weights: *const u16, pub n_searchable: u32,
     pub max_weight: i32, pub from: u32, pub length: u32, pub detailed_scores: i32,
     pub time_budget_us: u64, pub stop_after: i32, pub has_score_threshold: i32, pub score_threshold: f64,
+    pub order_keys: *const *const msi_doc_keys, pub n_order_keys: u32,
 }
 
 extern "C" {
@@ -122,6 +124,10 @@ extern "C" {
                            out_one_idx: *mut u32, out_one_cnt: *mut u32, out_two_idx: *mut u32, out_two_cnt: *mut u32) -> i32;
     pub fn msi_dict_create_values(ctx: *mut msi_ctx, values_concat: *const u8, offsets: *const u32, n_values: u32,
                                   out: *mut *mut msi_dict) -> i32;
+    pub fn msi_doc_keys_create(ctx: *mut msi_ctx, keys: *const u32, n_docs: u64, out: *mut *mut msi_doc_keys) -> i32;
+    pub fn msi_doc_keys_destroy(k: *mut msi_doc_keys);
+    pub fn msi_bits_order_next(p: *mut msi_bits, keys: *const msi_doc_keys, universe: u32, bucket: u32,
+                               out_key: *mut u32, out_count: *mut u64) -> i32;
     pub fn msi_fst_decode(fst: *const u8, len: usize, flags: u32, out_concat: *mut u8, cap_bytes: u64,
                           out_offsets: *mut u32, cap_words: u32, out_n_words: *mut u32, out_n_bytes: *mut u64) -> i32;
     pub fn msi_dict_create_from_fst(ctx: *mut msi_ctx, fst: *const u8, len: usize, out: *mut *mut msi_dict) -> i32;

@@ -28,6 +28,10 @@ struct msi_dict {
   mock_lookup_fn lookup = nullptr;
 };
 
+struct msi_doc_keys {
+  std::vector<uint32_t> keys;
+};
+
 uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
 
 bool msi_dict_word(const msi_dict *d, uint32_t idx, const uint8_t **w, uint32_t *len) {
@@ -150,6 +154,32 @@ int32_t msi_bits_paths_collect(msi_bits *p, uint32_t n_regions, uint64_t *counts
 }
 
 extern "C" {
+
+msi_doc_keys *mock_doc_keys_create(const uint32_t *keys, uint64_t n) {
+  msi_doc_keys *k = new msi_doc_keys();
+  k->keys.assign(keys, keys + n);
+  return k;
+}
+void mock_doc_keys_destroy(msi_doc_keys *k) { delete k; }
+
+int32_t msi_bits_order_next(msi_bits *p, const msi_doc_keys *keys, uint32_t universe, uint32_t bucket, uint32_t *out_key,
+                            uint64_t *out_count) {
+  if (keys->keys.size() != p->n_docs) return MSI_E_INVALID;
+  uint32_t best = 0xFFFFFFFFu;
+  for (uint64_t d = 0; d < p->n_docs; ++d)
+    if ((p->slot(universe)[d >> 6] >> (d & 63)) & 1ull) best = std::min(best, keys->keys[d]);
+  std::fill(p->slot(bucket), p->slot(bucket) + p->n_words, 0ull);
+  uint64_t n = 0;
+  for (uint64_t d = 0; d < p->n_docs; ++d)
+    if (((p->slot(universe)[d >> 6] >> (d & 63)) & 1ull) && keys->keys[d] == best) {
+      p->slot(bucket)[d >> 6] |= 1ull << (d & 63);
+      p->slot(universe)[d >> 6] &= ~(1ull << (d & 63));
+      ++n;
+    }
+  *out_key = best;
+  *out_count = n;
+  return MSI_OK;
+}
 
 int32_t msi_bits_fill(msi_bits *p, uint32_t slot, int32_t ones) {
   uint64_t *d = p->slot(slot);

@@ -43,6 +43,8 @@ def hostlib():
     L.mock_bits_destroy.restype, L.mock_bits_destroy.argtypes = None, [C.c_void_p]
     L.mock_dict_create.restype, L.mock_dict_create.argtypes = C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint32, LOOKUP_FN]
     L.mock_dict_destroy.restype, L.mock_dict_destroy.argtypes = None, [C.c_void_p]
+    L.mock_doc_keys_create.restype, L.mock_doc_keys_create.argtypes = C.c_void_p, [C.c_void_p, C.c_uint64]
+    L.mock_doc_keys_destroy.restype, L.mock_doc_keys_destroy.argtypes = None, [C.c_void_p]
     return L
 
 
@@ -80,23 +82,53 @@ class MockHarness:
         self.pool = Handle(L.mock_bits_create(max(index.n_docs, 1), n_slots))
         self.cb = R.IndexCallbacks(index)
 
-    def search(self, query, tms="last", criteria=None, offset=0, limit=20, detailed=False, stop_after=None, **kw):
+    def search(self, query, tms="last", criteria=None, offset=0, limit=20, detailed=False, stop_after=None, sort=None,
+               **kw):
+        """sort: the request's [(field, "asc" | "desc")]; Sort details come back as the oracle writes them:
+        ("Sort", field, ascending, ("Number", x) | ("String", s) | ("Null",))."""
         ix = self.index
-        return R.keyword_search_ranked(
-            self.dict, self.pool, self.cb, query_terms(query, stop_words=ix.stop_words),
-            criteria if criteria is not None else ix.criteria,
-            strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
-            searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
-            max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,
-            stop_after=stop_after, _entry=self.L.msi_keyword_search_ranked, **kw)
+        crit, order = R.expand_sort_criteria(criteria if criteria is not None else ix.criteria, sort)
+        handles, tables = [], []
+        for field, asc in order:
+            keys, values = ix.order_keys(field, asc)
+            arr = np.array(keys, dtype=np.uint32)
+            handles.append(Handle(self.L.mock_doc_keys_create(arr.ctypes.data_as(C.c_void_p), arr.size)))
+            tables.append((field, asc, values))
+        try:
+            out = R.keyword_search_ranked(
+                self.dict, self.pool, self.cb, query_terms(query, stop_words=ix.stop_words), crit,
+                strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
+                searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
+                max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,
+                stop_after=stop_after, order_keys=handles, _entry=self.L.msi_keyword_search_ranked, **kw)
+        finally:
+            for h in handles:
+                self.L.mock_doc_keys_destroy(h._h)
+        return ([(d, [sort_detail(s, tables) for s in sc]) for d, sc in out[0]],) + tuple(out[1:])
 
     def close(self):
         self.L.mock_bits_destroy(self.pool._h)
         self.L.mock_dict_destroy(self.dict._h)
 
 
+def sort_detail(s, tables):
+    """(Sort, rule index, order key) -> the oracle's ("Sort", field, ascending, value): the rank -> value table is
+    the shim's."""
+    if s[0] != "Sort":
+        return s
+    field, asc, values = tables[s[1]]
+    if s[2] == R.NO_ORDER_KEY:
+        return ("Sort", field, asc, ("Null",))
+    kind, v = values[s[2]]
+    return ("Sort", field, asc, ("Number", v) if kind == "n" else ("String", v))
+
+
 def debug_score(s):
     k = s[0]
+    if k == "Sort":
+        v = s[3]
+        val = "Null" if v[0] == "Null" else (f"Number({float(v[1])!r})" if v[0] == "Number" else f'String("{v[1]}")')
+        return f'Sort(Sort{{field_name:"{s[1]}",ascending:{str(s[2]).lower()},redacted:false,value:{val},}},)'
     if k == "Words":
         return f"Words(Words{{matching_words:{s[1]},max_matching_words:{s[2]},}},)"
     if k == "Typo":
@@ -126,14 +158,14 @@ def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused,
     monkeypatch.setenv("MSI_SEARCH_FUSED_LEVELS", fused)
     monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
     harnesses, n = {}, 0
-    cases = [c for c in FIX["cases"] if not c.get("needs") and not c.get("sort") and not c.get("distinct")
-             and not FIX["indexes"][c["index"]].get("distinct")]   # distinct / Sort: oracle only for now
+    cases = [c for c in FIX["cases"] if not c.get("needs") and not c.get("distinct")
+             and not FIX["indexes"][c["index"]].get("distinct")]   # distinct: oracle only for now
     for case in cases:
         if case["index"] not in harnesses:
             harnesses[case["index"]] = MockHarness(hostlib, build_index(FIX["indexes"][case["index"]]))
         h = harnesses[case["index"]]
         hits, _ = h.search(case["query"], tms=case["tms"], offset=case["offset"], limit=case["limit"],
-                           detailed=case["detailed"], stop_after=case.get("stop_after"))
+                           detailed=case["detailed"], stop_after=case.get("stop_after"), sort=case.get("sort"))
         ids = [d for d, _ in hits]
         if case["ids"] is not None:
             assert ids == case["ids"], case["src"]
@@ -145,7 +177,7 @@ def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused,
         if case.get("global_scores"):
             assert [f"{R.score_details_global_score(sc):.4f}" for _, sc in hits] == case["global_scores"]
         n += 1
-    assert n == len(cases) >= 94
+    assert n == len(cases) >= 99   # 94 keyword searches + the 5 of sort.rs
     for h in harnesses.values():
         h.close()
 
@@ -210,3 +242,62 @@ def test_differential_fuzz_smoke(hostlib):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert " bad 0" in out.stdout.strip().splitlines()[-1], out.stdout[-2000:]
+
+
+def sortable_corpus(seed, n_docs):
+    """random_corpus plus facet fields: a float with ties and gaps, a string, a mixed number / string field and a
+    multi-valued one (a document is placed at the first of its values the rule's iteration meets)."""
+    import random
+    import tests.test_search_gpu as G
+    rng = random.Random(seed * 7 + 1)
+    docs = G.random_corpus(seed, n_docs)
+    for d in docs:
+        if rng.random() < 0.85:
+            d["price"] = rng.choice([1, 2, 2.5, 3, 10, 10, 99.5, 1000])
+        if rng.random() < 0.7:
+            d["color"] = rng.choice(["red", "green", "blue", "Blue", "ultra violet"])
+        if rng.random() < 0.6:
+            d["mixed"] = rng.choice([0, 7, "seven", "zero", 3.5])
+        if rng.random() < 0.5:
+            d["sizes"] = [rng.choice([36, 38, 40, 42, "xl"]) for _ in range(rng.randint(1, 3))]
+    return docs
+
+
+SORT_SETUPS = [
+    (["words", "typo", "proximity", "attributeRank", "sort", "wordPosition", "exactness"], [("price", "asc")]),
+    (["sort", "words", "typo"], [("color", "desc"), ("price", "asc")]),
+    (["words", "sort", "proximity"], [("sizes", "desc")]),
+    (["words", "sort"], [("sizes", "asc"), ("mixed", "asc")]),
+    (["words", "typo", "desc:price", "exactness"], None),
+    (["asc:mixed", "words", "sort"], [("mixed", "desc"), ("color", "asc")]),   # a field is sorted only once
+    (["words", "typo"], [("price", "asc")]),                                    # no `sort` criterion: the list is ignored
+]
+
+
+@pytest.mark.parametrize("per_wait", ["1", "3"], ids=["one-level-per-wait", "3-levels-per-wait"])
+def test_sort_rules_match_the_oracle(hostlib, monkeypatch, per_wait):
+    """Sort / Asc / Desc as order-key rules (msi_bits_order_next), between graph-based rules and on placeholder
+    searches: hits, score details (value per bucket, Null last) and candidates against the oracle."""
+    from oracle import ranking_oracle as RO
+    import tests.test_search_gpu as G
+    monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
+    index = ToyMilli(sortable_corpus(5, 250), searchable=["title", "body"])
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    h = MockHarness(hostlib, index)
+    n_sorted = 0
+    for criteria, sort in SORT_SETUPS:
+        for q in ["", "the", "quick fox", "sun fl", "\"lazy dog\"", "brwn fox jumps", "winter holi"]:
+            for detailed, offset, limit in ((True, 0, 30), (False, 0, 12), (True, 17, 9)):
+                want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms="last", criteria=criteria,
+                                                         offset=offset, length=limit, detailed=detailed, sort=sort)
+                hits, cand = h.search(q, criteria=criteria, offset=offset, limit=limit, detailed=detailed, sort=sort)
+                assert [d for d, _ in hits] == want_ids, (criteria, sort, q, detailed, offset)
+                assert [[tuple(s) for s in sc] for _, sc in hits] == [[G.oracle_score(s) for s in sc] for sc in want_sc]
+                assert cand == len(want_cand)
+                n_sorted += any(s[0] == "Sort" for _, sc in hits for s in sc)
+    assert n_sorted > 60
+    h.close()

@@ -287,6 +287,21 @@ class ToyMilli:
         return cbo_bytes(s) if s else None
 
 
+    def order_keys(self, field, ascending):
+        """What the shim stages for a Sort / Asc / Desc rule (include/msi.h, msi_doc_keys): per document the rank of
+        the first facet value of `field` that ascending_facet_sort / descending_facet_sort meets (numbers, then
+        strings, each in the rule's direction; sort.rs:95-233), 0xFFFFFFFF without a value.
+        -> (keys[n_docs] as a list, values[rank] = ("n", float) | ("s", str))."""
+        keys = [k for (f, k) in self.facet_docids if f == field]
+        nums = sorted((k for k in keys if k[0] == "n"), key=lambda k: k[1], reverse=not ascending)
+        strs = sorted((k for k in keys if k[0] == "s"), key=lambda k: k[1].encode(), reverse=not ascending)
+        values = nums + strs
+        out = [0xFFFFFFFF] * self.n_docs
+        for rank, k in enumerate(values):
+            for d in self.facet_docids[(field, k)]:
+                out[d] = min(out[d], rank)
+        return out, values
+
     def distinct_excluded(self, field, docid):
         """distinct_single_docid (search/new/distinct.rs:38-62): the documents that share a facet value with docid."""
         out = set()
