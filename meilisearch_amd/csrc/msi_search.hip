@@ -444,8 +444,9 @@ struct Ctx {
     const uint8_t *bytes = nullptr;
     size_t n = 0;
     Cb cb_;
-    take(b, ix->word_fid_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), fid, &bytes, &n), bytes, n,
-         "word_fid_docids");
+    // the call first: `bytes` / `n` as further arguments of the same call would be read in an unspecified order
+    const int32_t st = ix->word_fid_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), fid, &bytes, &n);
+    take(b, st, bytes, n, "word_fid_docids");
   }
   void add_word_position(MsiCboBatch &b, uint32_t w, uint32_t pos) {
     if (!ix->word_position_docids)
@@ -454,8 +455,8 @@ struct Ctx {
     const uint8_t *bytes = nullptr;
     size_t n = 0;
     Cb cb_;
-    take(b, ix->word_position_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), pos, &bytes, &n), bytes, n,
-         "word_position_docids");
+    const int32_t st = ix->word_position_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), pos, &bytes, &n);
+    take(b, st, bytes, n, "word_position_docids");
   }
   // sink of the word-prefix callbacks: every stored value goes straight into the decode batch
   struct Sink {
@@ -1747,8 +1748,8 @@ struct ExactAttributeRule : Rule {
         if (count_all < 255) {
           const uint8_t *bytes = nullptr;
           size_t n = 0;
-          c.take(wc, c.ix->field_id_word_count_docids(c.ix->user, fid, count_all, &bytes, &n), bytes, n,
-                 "field_id_word_count_docids");
+          const int32_t st = c.ix->field_id_word_count_docids(c.ix->user, fid, count_all, &bytes, &n);
+          c.take(wc, st, bytes, n, "field_id_word_count_docids");
         }
         Set W = c.dev.decode(wc);
         Set both = c.dev.and_new(S, W, nullptr);

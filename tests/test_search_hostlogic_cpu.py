@@ -48,6 +48,10 @@ def hostlib():
     return L
 
 
+def make_harness(L, index, **kw):
+    return getattr(L, "harness_cls", MockHarness)(L, index, **kw)
+
+
 class Handle:
     def __init__(self, h):
         self._h = C.c_void_p(h)
@@ -79,8 +83,22 @@ class MockHarness:
         if bs:
             np.cumsum([len(b) for b in bs], out=self._offs[1:])
         self.dict = Handle(L.mock_dict_create(self._concat.ctypes.data, self._offs.ctypes.data, len(bs), self._cb))
-        self.pool = Handle(L.mock_bits_create(max(index.n_docs, 1), n_slots))
+        self.pool = self.pool_create(max(index.n_docs, 1), n_slots)
         self.cb = R.IndexCallbacks(index)
+
+    # the device objects: test doubles here, the real msi_bits.hip under the HIP emulation in
+    # tests/test_kernels_emulated_cpu.py (EmuHarness overrides these four)
+    def pool_create(self, n_docs, n_slots):
+        return Handle(self.L.mock_bits_create(n_docs, n_slots))
+
+    def pool_destroy(self, pool):
+        self.L.mock_bits_destroy(pool._h)
+
+    def keys_create(self, arr):
+        return Handle(self.L.mock_doc_keys_create(arr.ctypes.data_as(C.c_void_p), arr.size))
+
+    def keys_destroy(self, h):
+        self.L.mock_doc_keys_destroy(h._h)
 
     def search(self, query, tms="last", criteria=None, offset=0, limit=20, detailed=False, stop_after=None, sort=None,
                **kw):
@@ -92,7 +110,7 @@ class MockHarness:
         for field, asc in order:
             keys, values = ix.order_keys(field, asc)
             arr = np.array(keys, dtype=np.uint32)
-            handles.append(Handle(self.L.mock_doc_keys_create(arr.ctypes.data_as(C.c_void_p), arr.size)))
+            handles.append(self.keys_create(arr))
             tables.append((field, asc, values))
         try:
             out = R.keyword_search_ranked(
@@ -103,11 +121,11 @@ class MockHarness:
                 stop_after=stop_after, order_keys=handles, _entry=self.L.msi_keyword_search_ranked, **kw)
         finally:
             for h in handles:
-                self.L.mock_doc_keys_destroy(h._h)
+                self.keys_destroy(h)
         return ([(d, [sort_detail(s, tables) for s in sc]) for d, sc in out[0]],) + tuple(out[1:])
 
     def close(self):
-        self.L.mock_bits_destroy(self.pool._h)
+        self.pool_destroy(self.pool)
         self.L.mock_dict_destroy(self.dict._h)
 
 
@@ -162,7 +180,7 @@ def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused,
              and not FIX["indexes"][c["index"]].get("distinct")]   # distinct: oracle only for now
     for case in cases:
         if case["index"] not in harnesses:
-            harnesses[case["index"]] = MockHarness(hostlib, build_index(FIX["indexes"][case["index"]]))
+            harnesses[case["index"]] = make_harness(hostlib, build_index(FIX["indexes"][case["index"]]))
         h = harnesses[case["index"]]
         hits, _ = h.search(case["query"], tms=case["tms"], offset=case["offset"], limit=case["limit"],
                            detailed=case["detailed"], stop_after=case.get("stop_after"), sort=case.get("sort"))
@@ -183,20 +201,20 @@ def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused,
 
 
 @pytest.mark.parametrize("per_wait", ["1", "3"], ids=["one-level-per-wait", "3-levels-per-wait"])
-def test_host_logic_matches_oracle_on_random_corpora(hostlib, monkeypatch, per_wait):
+def test_host_logic_matches_oracle_on_random_corpora(hostlib, monkeypatch, per_wait, rulesets=slice(0, 4), thresholds=(100, 3)):
     monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
     from oracle import ranking_oracle as RO
     import tests.test_search_gpu as G
     docs = G.random_corpus(31, 200)
-    for criteria in G.RULESETS[:4]:
-        for pt in (100, 3):
+    for criteria in G.RULESETS[rulesets]:
+        for pt in thresholds:
             index = ToyMilli(docs, searchable=["title", "body"], criteria=criteria, prefix_threshold=pt)
             dic = O.Dictionary(index.words)
 
             def lookup(word, max_typos, is_prefix):
                 one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
                 return [index.words[i] for i in one], [index.words[i] for i in two]
-            h = MockHarness(hostlib, index)
+            h = make_harness(hostlib, index)
             for q in G.QUERIES:
                 for tms in ("last", "all"):
                     want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms=tms, criteria=criteria, length=25,
@@ -222,7 +240,7 @@ def test_long_queries_match_the_oracle(hostlib, monkeypatch, per_wait):
     def lookup(word, max_typos, is_prefix):
         one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
         return [index.words[i] for i in one], [index.words[i] for i in two]
-    h = MockHarness(hostlib, index, n_slots=2048)
+    h = make_harness(hostlib, index, n_slots=2048)
     for n in (6, 8, 10):
         for _ in range(4):
             q = " ".join(rng.choice(G.VOCAB) for _ in range(n))
@@ -287,7 +305,7 @@ def test_sort_rules_match_the_oracle(hostlib, monkeypatch, per_wait):
     def lookup(word, max_typos, is_prefix):
         one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
         return [index.words[i] for i in one], [index.words[i] for i in two]
-    h = MockHarness(hostlib, index)
+    h = make_harness(hostlib, index)
     n_sorted = 0
     for criteria, sort in SORT_SETUPS:
         for q in ["", "the", "quick fox", "sun fl", "\"lazy dog\"", "brwn fox jumps", "winter holi"]:
