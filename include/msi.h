@@ -324,6 +324,38 @@ int32_t msi_doc_keys_create(msi_ctx *ctx, const uint32_t *keys /* [n_docs] */, u
 void msi_doc_keys_destroy(msi_doc_keys *keys);
 int32_t msi_bits_order_next(msi_bits *pool, const msi_doc_keys *keys, uint32_t universe, uint32_t bucket,
                             uint32_t *out_key, uint64_t *out_count);
+/* SURVEY §8 a10 / f3 — the `distinct` attribute (crates/milli/src/search/new/distinct.rs:19-62, applied by
+ * maybe_add_to_results, bucket_sort.rs:399-415, and by the rule-less path bucket_sort.rs:61-92) without a facet
+ * database walk per candidate: the facet values of the distinct field, PER DOCUMENT, resident in HBM as CSR —
+ * value_ids[offsets[d] .. offsets[d+1]) are the ids (< n_values) of the values of document d, numbers and strings
+ * alike (facet_number_values + facet_string_values of field_id_docid_facet_f64s / _strings); two documents share
+ * a value of the field iff they share an id.  Built by the shim once per (index update, field).
+ *
+ * msi_bits_distinct = apply_distinct_rule: `remaining` := the candidates the reference's ascending-docid loop
+ * keeps — candidate d is kept iff no smaller kept candidate shares a value with it (a document without a value
+ * is always kept) — i.e. the lexicographically first maximal independent set of the "shares a value" graph,
+ * computed in parallel rounds (a candidate that is the smallest undecided holder of each of its values is kept;
+ * the holders of its values are dropped; one round for a single-valued field, a sequential single-thread kernel
+ * finishes pathological chains after MSI_DISTINCT_MAX_ROUNDS).  `candidates` is CONSUMED (left empty).
+ * `excluded` (or MSI_BITS_NO_SLOT) := every document OF THE INDEX that holds a value of a kept candidate
+ * (DistinctOutput::excluded: the kept candidates themselves are in it when they have a value).
+ * *out_rounds (nullable): parallel rounds run; bit 31 set when the sequential kernel finished the job.
+ * msi_bits_distinct_excluded: `excluded` := every document that shares a value with a document of `kept`
+ * (distinct_single_docid over a set; the rule-less path keeps only the first from+length documents).
+ * msi_bits_andnot_many_count: slots[i] &= ~removed with the new cardinalities (n <= 16), one launch and one wait:
+ * `for universe in ranking_rule_universes { *universe -= &excluded }`. */
+typedef struct msi_doc_values msi_doc_values;
+#define MSI_BITS_NO_SLOT 0xFFFFFFFFu
+#define MSI_DISTINCT_MAX_ROUNDS 32
+int32_t msi_doc_values_create(msi_ctx *ctx, const uint64_t *offsets /* [n_docs + 1], offsets[0] = 0 */,
+                              const uint32_t *value_ids /* [offsets[n_docs]] */, uint64_t n_docs, uint32_t n_values,
+                              msi_doc_values **out);
+void msi_doc_values_destroy(msi_doc_values *values);
+int32_t msi_bits_distinct(msi_bits *pool, const msi_doc_values *values, uint32_t candidates, uint32_t remaining,
+                          uint32_t excluded, uint64_t *out_remaining, uint32_t *out_rounds);
+int32_t msi_bits_distinct_excluded(msi_bits *pool, const msi_doc_values *values, uint32_t kept, uint32_t excluded);
+int32_t msi_bits_andnot_many_count(msi_bits *pool, uint32_t removed, uint32_t n, const uint32_t *slots,
+                                   uint64_t *out_counts);
 int32_t msi_bits_set_from_words(msi_bits *pool, uint32_t slot,
                                 const uint64_t *words, uint64_t n_words);
 int32_t msi_bits_fill(msi_bits *pool, uint32_t slot, int32_t ones);
@@ -608,6 +640,10 @@ typedef struct msi_search_params {
    * They also order a placeholder search (no term survived: mod.rs:352-420). */
   const msi_doc_keys *const *order_keys;
   uint32_t n_order_keys;
+  /* The distinct field of the request or of the index (distinct_fid, distinct.rs:130-147): NULL = none.  Every
+   * bucket that reaches the results goes through msi_bits_distinct; what it excludes leaves every rule's universe
+   * and *out_candidates (bucket_sort.rs:399-415).  Also on placeholder / rule-less searches (:61-92). */
+  const msi_doc_values *distinct_values;
 } msi_search_params;
 /* out_scores: [length][MSI_MAX_SCORE_DETAILS], out_n_scores: [length].  The pool needs at least 64 free
  * slots above slot 0 (more for long queries: one per live condition of every active rule). */

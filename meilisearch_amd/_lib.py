@@ -101,7 +101,7 @@ class SearchParams(C.Structure):
                 ("n_searchable", C.c_uint32), ("max_weight", C.c_int32), ("from_", C.c_uint32),
                 ("length", C.c_uint32), ("detailed_scores", C.c_int32), ("time_budget_us", C.c_uint64),
                 ("stop_after", C.c_int32), ("has_score_threshold", C.c_int32), ("score_threshold", C.c_double),
-                ("order_keys", C.c_void_p), ("n_order_keys", C.c_uint32)]
+                ("order_keys", C.c_void_p), ("n_order_keys", C.c_uint32), ("distinct_values", C.c_void_p)]
 
 
 class QueryToken(C.Structure):
@@ -167,6 +167,11 @@ PROTOTYPES = {
     "msi_doc_keys_create": (_I32, [_VP, _VP, C.c_uint64, C.POINTER(_VP)]),
     "msi_doc_keys_destroy": (None, [_VP]),
     "msi_bits_order_next": (_I32, [_VP, _VP, _U32, _U32, C.POINTER(_U32), C.POINTER(C.c_uint64)]),
+    "msi_doc_values_create": (_I32, [_VP, _VP, _VP, C.c_uint64, _U32, C.POINTER(_VP)]),
+    "msi_doc_values_destroy": (None, [_VP]),
+    "msi_bits_distinct": (_I32, [_VP, _VP, _U32, _U32, _U32, C.POINTER(C.c_uint64), C.POINTER(_U32)]),
+    "msi_bits_distinct_excluded": (_I32, [_VP, _VP, _U32, _U32]),
+    "msi_bits_andnot_many_count": (_I32, [_VP, _U32, _U32, _VP, _VP]),
     "msi_fst_decode": (_I32, [_VP, C.c_size_t, _U32, _VP, C.c_uint64, _VP, _U32, C.POINTER(_U32), C.POINTER(C.c_uint64)]),
     "msi_dict_create_from_fst": (_I32, [_VP, _VP, C.c_size_t, C.POINTER(_VP)]),
     "msi_dict_create_values_from_fst": (_I32, [_VP, _VP, C.c_size_t, C.POINTER(_VP)]),

@@ -55,6 +55,23 @@ class BitsPool:
         check(lib().msi_bits_order_next(self._h, keys._h, universe, bucket, C.byref(key), C.byref(n)))
         return int(key.value), int(n.value)
 
+    def distinct(self, values, candidates, remaining, excluded=NO_UNIVERSE):
+        """apply_distinct_rule (search/new/distinct.rs:19-36): remaining := the candidates kept (one per value of the
+        distinct field, smallest docid first), excluded := every document that shares a value with a kept one;
+        `candidates` is consumed.  -> (|remaining|, parallel rounds, finished by the sequential kernel?)."""
+        n, rounds = C.c_uint64(0), C.c_uint32(0)
+        check(lib().msi_bits_distinct(self._h, values._h, candidates, remaining, excluded, C.byref(n), C.byref(rounds)))
+        return int(n.value), int(rounds.value & 0x7FFFFFFF), bool(rounds.value >> 31)
+
+    def distinct_excluded(self, values, kept, excluded):
+        check(lib().msi_bits_distinct_excluded(self._h, values._h, kept, excluded))
+
+    def andnot_many_count(self, removed, slots):
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        out = np.zeros(s.size, dtype=np.uint64)
+        check(lib().msi_bits_andnot_many_count(self._h, removed, s.size, np_ptr(s), np_ptr(out)))
+        return [int(x) for x in out]
+
     def count(self, slot):
         out = C.c_uint64(0)
         check(lib().msi_bits_count(self._h, slot, C.byref(out)))
@@ -104,6 +121,33 @@ class DocKeys:
     def close(self):
         if self._h:
             lib().msi_doc_keys_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DocValues:
+    """The facet values of the distinct field per document, CSR in HBM (msi_doc_values_create): what
+    apply_distinct_rule (search/new/distinct.rs:19-62) reads instead of walking the facet databases per candidate.
+    per_doc: one sequence of value ids (< n_values) per document."""
+
+    def __init__(self, ctx, per_doc, n_values):
+        self.ctx = ctx
+        self.offsets = np.zeros(len(per_doc) + 1, dtype=np.uint64)
+        np.cumsum([len(v) for v in per_doc], out=self.offsets[1:])
+        flat = [x for v in per_doc for x in v]
+        self.values = np.ascontiguousarray(flat if flat else [0], dtype=np.uint32)
+        self._h = C.c_void_p()
+        check(lib().msi_doc_values_create(ctx.handle, np_ptr(self.offsets), np_ptr(self.values), len(per_doc), int(n_values),
+                                          C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().msi_doc_values_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

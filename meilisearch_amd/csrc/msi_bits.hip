@@ -42,7 +42,20 @@ struct msi_bits {
   std::mutex own_mu;
   std::mutex *mu = nullptr;
   bool private_stream = false;
+  // distinct scratch, per pool (one search per pool): first[v] = the smallest undecided candidate holding value v
+  // this round, taken[v] = stamp of the call in which a kept candidate holds v.  Stamps instead of clears: a round
+  // writes ((~round_stamp) << 32 | docid) with atomicMin, so a newer round always beats what older rounds left.
+  DevBuf dv_first, dv_taken;
+  uint32_t dv_cap = 0, dv_round = 0, dv_call = 0;
   u64 *slot(uint32_t s) const { return pool.as<u64>() + (uint64_t)s * n_words; }
+};
+
+// The facet values of the distinct field per document, CSR in HBM (msi_doc_values_create)
+struct msi_doc_values {
+  msi_ctx *ctx = nullptr;
+  uint64_t n_docs = 0;
+  uint32_t n_values = 0;
+  DevBuf offsets, values;  // u32 [n_docs + 1], u32 [offsets[n_docs]]
 };
 
 // One u32 order key per document, resident in HBM (msi_doc_keys_create)
@@ -194,6 +207,149 @@ __global__ void bits_take_key_kernel(u64 *__restrict__ universe, u64 *__restrict
   }
 }
 
+// ---- distinct (crates/milli/src/search/new/distinct.rs:19-62) --------------------------------------------------------
+// apply_distinct_rule keeps, in ascending docid order, every candidate that shares no facet value of the distinct
+// field with a candidate kept before it: the lexicographically first maximal independent set of the "shares a value"
+// graph.  Parallel form, one document per thread (a wave = one 64-bit word of a set, __ballot = the word):
+//   propose: every undecided candidate writes its docid into first[v] (atomicMin) for each of its values v;
+//   join:    a candidate that owns first[v] for ALL its values is kept and stamps taken[v];
+//   propose (next round) first drops the undecided candidates that hold a taken value.
+// A candidate is kept in round r iff it is the smallest undecided document of its closed neighbourhood — the rounds
+// reproduce the sequential loop exactly.  A single-valued field is decided in one round.
+__device__ __forceinline__ u64 dv_pack(uint32_t round, uint32_t docid) { return ((u64)(~round) << 32) | (u64)docid; }
+
+// universe -= holders of a taken value; the survivors propose; the last workgroup publishes {|universe|, kept so far}.
+__global__ void bits_distinct_propose_kernel(u64 *__restrict__ undecided, const uint32_t *__restrict__ offsets,
+                                             const uint32_t *__restrict__ values, uint64_t n_docs, uint64_t n_words,
+                                             u64 *__restrict__ first, const uint32_t *__restrict__ taken,
+                                             uint32_t call_stamp, uint32_t round, int first_round,
+                                             u64 *__restrict__ kept_acc, u64 *__restrict__ acc,
+                                             volatile uint64_t *__restrict__ sig, uint64_t seq) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = d >> 6;
+  if (first_round && d == 0) *kept_acc = 0;  // the join kernels of this call run after this launch
+  const u64 word = w < n_words ? undecided[w] : 0ull;  // one address per wave
+  bool alive = false, pruned = false;
+  if (d < n_docs && ((word >> (d & 63)) & 1ull)) {
+    const uint32_t lo = offsets[d], hi = offsets[d + 1];
+    for (uint32_t i = lo; i < hi && !pruned; ++i) pruned = taken[values[i]] == call_stamp;
+    alive = !pruned;
+    if (alive)
+      for (uint32_t i = lo; i < hi; ++i) atomicMin(&first[values[i]], dv_pack(round, (uint32_t)d));
+  }
+  const u64 keep = __ballot(alive), drop = __ballot(pruned);
+  __shared__ uint32_t part[BT / 64];
+  if ((threadIdx.x & 63) == 0) {
+    if (drop) undecided[w] = keep;
+    part[threadIdx.x >> 6] = (uint32_t)__popcll(keep);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 b = 0;
+    for (int i = 0; i < BT / 64; ++i) b += part[i];
+    if (b) atomicAdd(&acc[0], b);
+    __threadfence();
+    const u64 done = atomicAdd(&acc[1], 1ull);
+    if (done == gridDim.x - 1) {
+      const u64 total = atomicExch(&acc[0], 0ull);
+      acc[1] = 0;
+      const u64 kept = first_round ? 0ull : __hip_atomic_load(kept_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[0]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[2]), kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// kept |= the undecided candidates that own every one of their values (first round: kept := them, the slot's old
+// content must not survive); they leave `undecided` and stamp their values
+__global__ void bits_distinct_join_kernel(u64 *__restrict__ undecided, u64 *__restrict__ kept,
+                                          const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ values,
+                                          uint64_t n_docs, uint64_t n_words, const u64 *__restrict__ first,
+                                          uint32_t *__restrict__ taken, uint32_t call_stamp, uint32_t round,
+                                          int first_round, u64 *__restrict__ kept_acc) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = d >> 6;
+  const u64 word = w < n_words ? undecided[w] : 0ull;
+  bool ok = false;
+  if (d < n_docs && ((word >> (d & 63)) & 1ull)) {
+    const uint32_t lo = offsets[d], hi = offsets[d + 1];
+    const u64 mine = dv_pack(round, (uint32_t)d);
+    ok = true;
+    for (uint32_t i = lo; i < hi && ok; ++i) ok = first[values[i]] == mine;
+    if (ok)
+      for (uint32_t i = lo; i < hi; ++i) taken[values[i]] = call_stamp;  // only the owner of a value writes it
+  }
+  const u64 joined = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && w < n_words) {
+    if (first_round) kept[w] = joined;
+    else if (joined) kept[w] |= joined;
+    if (joined) {
+      undecided[w] = word & ~joined;
+      atomicAdd(kept_acc, (u64)__popcll(joined));
+    }
+  }
+}
+
+// What the rounds left undecided, in the reference's own order, by one thread: bounds the work on pathological
+// inputs (a chain d0 - d1 - d2 - ... of shared values needs one round per two documents).
+__global__ void bits_distinct_sequential_kernel(u64 *__restrict__ undecided, u64 *__restrict__ kept,
+                                                const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ values,
+                                                uint64_t n_words, uint32_t *__restrict__ taken, uint32_t call_stamp,
+                                                u64 *__restrict__ kept_acc, volatile uint64_t *__restrict__ sig,
+                                                uint64_t seq) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  u64 n = 0;
+  for (uint64_t w = 0; w < n_words; ++w) {
+    u64 bits = undecided[w];
+    if (!bits) continue;
+    u64 add = 0;
+    while (bits) {
+      const uint32_t b = (uint32_t)__ffsll((long long)bits) - 1;
+      bits &= bits - 1;
+      const uint64_t d = w * 64 + b;
+      const uint32_t lo = offsets[d], hi = offsets[d + 1];
+      bool free_ = true;
+      for (uint32_t i = lo; i < hi && free_; ++i) free_ = taken[values[i]] != call_stamp;
+      if (!free_) continue;
+      for (uint32_t i = lo; i < hi; ++i) taken[values[i]] = call_stamp;
+      add |= 1ull << b;
+      ++n;
+    }
+    undecided[w] = 0;
+    if (add) kept[w] |= add;
+  }
+  const u64 total = *kept_acc + n;
+  __hip_atomic_store(const_cast<uint64_t *>(&sig[0]), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(const_cast<uint64_t *>(&sig[2]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// taken[v] := stamp for the values of the documents of `kept` (msi_bits_distinct_excluded)
+__global__ void bits_distinct_mark_kernel(const u64 *__restrict__ kept, const uint32_t *__restrict__ offsets,
+                                          const uint32_t *__restrict__ values, uint64_t n_docs, uint64_t n_words,
+                                          uint32_t *__restrict__ taken, uint32_t call_stamp) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = d >> 6;
+  if (d >= n_docs || w >= n_words || !((kept[w] >> (d & 63)) & 1ull)) return;
+  for (uint32_t i = offsets[d]; i < offsets[d + 1]; ++i) taken[values[i]] = call_stamp;
+}
+
+// excluded := every document of the index that holds a stamped value (the whole slot is overwritten)
+__global__ void bits_distinct_excluded_kernel(u64 *__restrict__ excluded, const uint32_t *__restrict__ offsets,
+                                              const uint32_t *__restrict__ values, uint64_t n_docs, uint64_t n_words,
+                                              const uint32_t *__restrict__ taken, uint32_t call_stamp) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = d >> 6;
+  bool ex = false;
+  if (d < n_docs) {
+    const uint32_t lo = offsets[d], hi = offsets[d + 1];
+    for (uint32_t i = lo; i < hi && !ex; ++i) ex = taken[values[i]] == call_stamp;
+  }
+  const u64 mask = __ballot(ex);
+  if ((threadIdx.x & 63) == 0 && w < n_words) excluded[w] = mask;
+}
+
 struct ManyArgs {
   const u64 *cond[MSI_BITS_MANY];
   u64 *dst[MSI_BITS_MANY];
@@ -218,6 +374,58 @@ __global__ void bits_and_many_kernel(ManyArgs a, const u64 *__restrict__ prefix,
         r.x = x.x & y.x;
         r.y = x.y & y.y;
         reinterpret_cast<ulonglong2 *>(a.dst[k])[i] = r;
+        c[k] += __popcll(r.x) + __popcll(r.y);
+      }
+    }
+  }
+  __shared__ uint32_t part[MSI_BITS_MANY];
+  if (threadIdx.x < MSI_BITS_MANY) part[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < MSI_BITS_MANY; ++k) {
+    if (k < n) {
+      uint32_t v = c[k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+      if ((threadIdx.x & 63) == 0 && v) atomicAdd(&part[k], v);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t k = 0; k < n; ++k)
+      if (part[k]) atomicAdd(&acc[2 + k], (u64)part[k]);
+    __threadfence();
+    const u64 done = atomicAdd(&acc[1], 1ull);
+    if (done == gridDim.x - 1) {
+      for (uint32_t k = 0; k < n; ++k) {
+        const u64 total = atomicExch(&acc[2 + k], 0ull);
+        __hip_atomic_store(const_cast<uint64_t *>(&sig[2 + k]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      acc[1] = 0;
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// dst[i] &= ~removed with |dst[i]| for every i < n (the universes of the rule stack after a distinct pass)
+__global__ void bits_andnot_many_kernel(ManyArgs a, const u64 *__restrict__ removed, uint32_t n, uint64_t n_pairs,
+                                        u64 *__restrict__ acc, volatile uint64_t *__restrict__ sig, uint64_t seq) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t c[MSI_BITS_MANY];
+#pragma unroll
+  for (uint32_t k = 0; k < MSI_BITS_MANY; ++k) c[k] = 0;
+  for (; i < n_pairs; i += stride) {
+    const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(removed)[i];
+#pragma unroll
+    for (uint32_t k = 0; k < MSI_BITS_MANY; ++k) {
+      if (k < n) {
+        ulonglong2 r = reinterpret_cast<const ulonglong2 *>(a.dst[k])[i];
+        if ((r.x & x.x) | (r.y & x.y)) {
+          r.x &= ~x.x;
+          r.y &= ~x.y;
+          reinterpret_cast<ulonglong2 *>(a.dst[k])[i] = r;
+        }
         c[k] += __popcll(r.x) + __popcll(r.y);
       }
     }
@@ -625,9 +833,9 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   if (s == MSI_OK) s = p->small.ensure(64);
   if (s == MSI_OK) {
     void *h = nullptr;
-    if (hipHostMalloc(&h, (3 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(uint64_t), hipHostMallocCoherent) != hipSuccess ||
-        hipMalloc((void **)&p->d_acc, (3 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess ||
-        hipMemset(p->d_acc, 0, (3 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess) {
+    if (hipHostMalloc(&h, (4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(uint64_t), hipHostMallocCoherent) != hipSuccess ||
+        hipMalloc((void **)&p->d_acc, (4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess ||
+        hipMemset(p->d_acc, 0, (4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess) {
       msi_set_error("msi_bits_create: allocating the completion signal failed");
       s = MSI_E_OOM;
     } else {
@@ -685,6 +893,8 @@ void msi_bits_destroy(msi_bits *p) {
   p->stage.release();
   p->desc.release();
   p->small_ids.release();
+  p->dv_first.release();
+  p->dv_taken.release();
   if (p->h_sig) (void)hipHostFree((void *)p->h_sig);
   if (p->d_acc) (void)hipFree(p->d_acc);
   if (p->h_ring) (void)hipHostFree(p->h_ring);
@@ -1247,6 +1457,219 @@ int32_t msi_bits_order_next(msi_bits *p, const msi_doc_keys *keys, uint32_t univ
   lk.unlock();
   MSI_TRY(wait_count(p, seq, out_count));
   *out_key = (uint32_t)__atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2]), __ATOMIC_RELAXED);
+  return MSI_OK;
+}
+
+int32_t msi_doc_values_create(msi_ctx *ctx, const uint64_t *offsets, const uint32_t *value_ids, uint64_t n_docs,
+                              uint32_t n_values, msi_doc_values **out) {
+  if (!ctx || !out || !n_docs || !offsets || offsets[0] != 0 || (offsets[n_docs] && !value_ids)) {
+    msi_set_error("msi_doc_values_create: invalid argument");
+    return MSI_E_INVALID;
+  }
+  *out = nullptr;
+  const uint64_t total = offsets[n_docs];
+  if (total >= 0xFFFFFFFFull) {
+    msi_set_error("msi_doc_values_create: %llu (document, value) pairs; the device layout holds < 2^32",
+                  (unsigned long long)total);
+    return MSI_E_UNSUPPORTED;
+  }
+  std::vector<uint32_t> off32(n_docs + 1);
+  for (uint64_t d = 0; d <= n_docs; ++d) {
+    if (d && offsets[d] < offsets[d - 1]) {
+      msi_set_error("msi_doc_values_create: offsets decrease at document %llu", (unsigned long long)d);
+      return MSI_E_INVALID;
+    }
+    off32[d] = (uint32_t)offsets[d];
+  }
+  for (uint64_t i = 0; i < total; ++i)
+    if (value_ids[i] >= n_values) {
+      msi_set_error("msi_doc_values_create: value id %u >= n_values %u", value_ids[i], n_values);
+      return MSI_E_INVALID;
+    }
+  DeviceGuard g(ctx->device);
+  msi_doc_values *v = new msi_doc_values();
+  v->ctx = ctx;
+  v->n_docs = n_docs;
+  v->n_values = n_values;
+  int32_t st = v->offsets.ensure((size_t)(n_docs + 1) * sizeof(uint32_t));
+  if (st == MSI_OK) st = v->values.ensure(std::max<size_t>(1, (size_t)total) * sizeof(uint32_t));
+  if (st == MSI_OK) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipError_t e = hipMemcpyAsync(v->offsets.p, off32.data(), (size_t)(n_docs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e == hipSuccess && total)
+      e = hipMemcpyAsync(v->values.p, value_ids, (size_t)total * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the arrays are borrowed for the call
+    if (e != hipSuccess) {
+      msi_set_error("msi_doc_values_create: upload failed: %s", hipGetErrorString(e));
+      st = MSI_E_HIP;
+    }
+  }
+  if (st != MSI_OK) {
+    v->offsets.release();
+    v->values.release();
+    delete v;
+    return st;
+  }
+  msi_ctx_retain(ctx);
+  *out = v;
+  return MSI_OK;
+}
+
+void msi_doc_values_destroy(msi_doc_values *v) {
+  if (!v) return;
+  {
+    DeviceGuard g(v->ctx->device);
+    v->offsets.release();
+    v->values.release();
+  }
+  msi_ctx_release(v->ctx);
+  delete v;
+}
+
+// The per-pool scratch of the distinct kernels, sized for `vals`; hands out the stamps of a new call.  Pool lock held.
+static int32_t distinct_scratch(msi_bits *p, const msi_doc_values *vals, uint32_t rounds_needed) {
+  hipStream_t st = p->stream;
+  const uint32_t need = std::max<uint32_t>(1, vals->n_values);
+  if (need > p->dv_cap) {
+    MSI_HIP_TRY(hipStreamSynchronize(st));  // kernels in flight may still read the old buffers
+    MSI_TRY(p->dv_first.ensure((size_t)need * sizeof(u64)));
+    MSI_TRY(p->dv_taken.ensure((size_t)need * sizeof(uint32_t)));
+    p->dv_cap = need;
+    p->dv_round = 0;
+    p->dv_call = 0;
+  }
+  if (p->dv_round == 0 || p->dv_round > 0xFFFFFFFFu - rounds_needed - 2) {
+    MSI_HIP_TRY(hipMemsetAsync(p->dv_first.p, 0xFF, (size_t)p->dv_cap * sizeof(u64), st));
+    p->dv_round = 1;
+  }
+  if (p->dv_call == 0 || p->dv_call == 0xFFFFFFFEu) {
+    MSI_HIP_TRY(hipMemsetAsync(p->dv_taken.p, 0, (size_t)p->dv_cap * sizeof(uint32_t), st));
+    p->dv_call = 0;
+  }
+  ++p->dv_call;
+  return MSI_OK;
+}
+
+static int32_t check_values(const msi_bits *p, const msi_doc_values *vals, const char *what) {
+  if (!p || !vals) {
+    msi_set_error("%s: invalid argument", what);
+    return MSI_E_INVALID;
+  }
+  if (vals->ctx != p->ctx || vals->n_docs != p->n_docs) {
+    msi_set_error("%s: the value table (%llu documents) does not belong to this pool (%llu documents)", what,
+                  (unsigned long long)vals->n_docs, (unsigned long long)p->n_docs);
+    return MSI_E_INVALID;
+  }
+  return MSI_OK;
+}
+
+int32_t msi_bits_distinct(msi_bits *p, const msi_doc_values *vals, uint32_t candidates, uint32_t remaining,
+                          uint32_t excluded, uint64_t *out_remaining, uint32_t *out_rounds) {
+  MSI_TRY(check_values(p, vals, "msi_bits_distinct"));
+  if (!out_remaining || candidates == remaining || candidates == excluded || remaining == excluded) {
+    msi_set_error("msi_bits_distinct: invalid argument (three different slots)");
+    return MSI_E_INVALID;
+  }
+  MSI_TRY(check_slot(p, candidates, "msi_bits_distinct"));
+  MSI_TRY(check_slot(p, remaining, "msi_bits_distinct"));
+  if (excluded != MSI_BITS_NO_SLOT) MSI_TRY(check_slot(p, excluded, "msi_bits_distinct"));
+  std::unique_lock<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->stream;
+  MSI_TRY(distinct_scratch(p, vals, MSI_DISTINCT_MAX_ROUNDS + 1));
+  const uint32_t call = p->dv_call;
+  const uint32_t *off = vals->offsets.as<uint32_t>(), *val = vals->values.as<uint32_t>();
+  u64 *first = p->dv_first.as<u64>();
+  uint32_t *taken = p->dv_taken.as<uint32_t>();
+  u64 *kept_acc = p->d_acc + 3 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS;
+  const dim3 grid((uint32_t)((p->n_words * 64 + BT - 1) / BT)), block(BT);
+  uint32_t round = p->dv_round++;
+  hipLaunchKernelGGL(bits_distinct_propose_kernel, grid, block, 0, st, p->slot(candidates), off, val, p->n_docs, p->n_words,
+                     first, taken, call, round, 1, kept_acc, p->d_acc, p->h_sig, ++p->seq);
+  uint32_t rounds = 0;
+  uint64_t left = 0, kept = 0;
+  for (;;) {
+    hipLaunchKernelGGL(bits_distinct_join_kernel, grid, block, 0, st, p->slot(candidates), p->slot(remaining), off, val,
+                       p->n_docs, p->n_words, first, taken, call, round, rounds == 0 ? 1 : 0, kept_acc);
+    round = p->dv_round++;
+    const uint64_t seq = ++p->seq;
+    hipLaunchKernelGGL(bits_distinct_propose_kernel, grid, block, 0, st, p->slot(candidates), off, val, p->n_docs,
+                       p->n_words, first, taken, call, round, 0, kept_acc, p->d_acc, p->h_sig, seq);
+    MSI_HIP_TRY(hipGetLastError());
+    ++rounds;
+    lk.unlock();
+    MSI_TRY(wait_count(p, seq, &left));
+    kept = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2]), __ATOMIC_RELAXED);
+    lk.lock();
+    if (!left) break;
+    if (rounds >= MSI_DISTINCT_MAX_ROUNDS) {
+      const uint64_t seq2 = ++p->seq;
+      hipLaunchKernelGGL(bits_distinct_sequential_kernel, dim3(1), dim3(64), 0, st, p->slot(candidates), p->slot(remaining),
+                         off, val, p->n_words, taken, call, kept_acc, p->h_sig, seq2);
+      MSI_HIP_TRY(hipGetLastError());
+      lk.unlock();
+      MSI_TRY(wait_count(p, seq2, &left));
+      kept = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2]), __ATOMIC_RELAXED);
+      lk.lock();
+      rounds |= 0x80000000u;
+      break;
+    }
+  }
+  if (excluded != MSI_BITS_NO_SLOT) {
+    hipLaunchKernelGGL(bits_distinct_excluded_kernel, grid, block, 0, st, p->slot(excluded), off, val, p->n_docs, p->n_words,
+                       taken, call);
+    MSI_HIP_TRY(hipGetLastError());
+  }
+  *out_remaining = kept;
+  if (out_rounds) *out_rounds = rounds;
+  return MSI_OK;
+}
+
+int32_t msi_bits_distinct_excluded(msi_bits *p, const msi_doc_values *vals, uint32_t kept, uint32_t excluded) {
+  MSI_TRY(check_values(p, vals, "msi_bits_distinct_excluded"));
+  if (kept == excluded) {
+    msi_set_error("msi_bits_distinct_excluded: kept and excluded are the same slot");
+    return MSI_E_INVALID;
+  }
+  MSI_TRY(check_slot(p, kept, "msi_bits_distinct_excluded"));
+  MSI_TRY(check_slot(p, excluded, "msi_bits_distinct_excluded"));
+  std::lock_guard<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->stream;
+  MSI_TRY(distinct_scratch(p, vals, 0));
+  const dim3 grid((uint32_t)((p->n_words * 64 + BT - 1) / BT)), block(BT);
+  hipLaunchKernelGGL(bits_distinct_mark_kernel, grid, block, 0, st, p->slot(kept), vals->offsets.as<uint32_t>(),
+                     vals->values.as<uint32_t>(), p->n_docs, p->n_words, p->dv_taken.as<uint32_t>(), p->dv_call);
+  hipLaunchKernelGGL(bits_distinct_excluded_kernel, grid, block, 0, st, p->slot(excluded), vals->offsets.as<uint32_t>(),
+                     vals->values.as<uint32_t>(), p->n_docs, p->n_words, p->dv_taken.as<uint32_t>(), p->dv_call);
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+int32_t msi_bits_andnot_many_count(msi_bits *p, uint32_t removed, uint32_t n, const uint32_t *slots, uint64_t *counts) {
+  if (!p || !n || n > MSI_BITS_MANY || !slots || !counts) return MSI_E_INVALID;
+  MSI_TRY(check_slot(p, removed, "msi_bits_andnot_many_count"));
+  ManyArgs a;
+  for (uint32_t k = 0; k < n; ++k) {
+    MSI_TRY(check_slot(p, slots[k], "msi_bits_andnot_many_count"));
+    if (slots[k] == removed) {
+      msi_set_error("msi_bits_andnot_many_count: `removed` is one of the slots");
+      return MSI_E_INVALID;
+    }
+    a.dst[k] = p->slot(slots[k]);
+  }
+  std::unique_lock<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  const uint64_t n_pairs = p->n_words / 2;
+  const uint64_t seq = ++p->seq;
+  hipLaunchKernelGGL(bits_andnot_many_kernel, dim3(grid_for(n_pairs, (uint32_t)p->ctx->n_cu * 4)), dim3(BT), 0, p->stream, a,
+                     p->slot(removed), n, n_pairs, p->d_acc, p->h_sig, seq);
+  MSI_HIP_TRY(hipGetLastError());
+  lk.unlock();
+  uint64_t ignored = 0;
+  MSI_TRY(wait_count(p, seq, &ignored));
+  for (uint32_t k = 0; k < n; ++k) counts[k] = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2 + k]), __ATOMIC_RELAXED);
   return MSI_OK;
 }
 

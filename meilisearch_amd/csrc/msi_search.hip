@@ -202,6 +202,47 @@ struct Dev {
     g_stats.device_wait_ms += ck_.ms();
     return b;
   }
+  // apply_distinct_rule (distinct.rs:19-36) on a COPY of `cands`: {kept candidates, every document of the index that
+  // shares a value with one of them}
+  std::pair<Set, Set> distinct(const msi_doc_values *vals, const Set &cands, uint64_t *kept) {
+    Set work = clone(cands);  // consumed by the rounds; `cands` may be a shared, cached set
+    Set rem = alloc(), exc = alloc();
+    Clock ck_;
+    uint32_t rounds = 0;
+    ck(msi_bits_distinct(pool.p, vals, work->slot, rem->slot, exc->slot, kept, &rounds));
+    rounds &= 0x7FFFFFFFu;
+    g_stats.launches += 2 + 2 * rounds;
+    g_stats.syncs += rounds;
+    g_stats.device_wait_ms += ck_.ms();
+    return {rem, exc};
+  }
+  Set distinct_excluded(const msi_doc_values *vals, const Set &kept) {
+    Set exc = alloc();
+    g_stats.launches += 2;
+    ck(msi_bits_distinct_excluded(pool.p, vals, kept->slot, exc->slot));
+    return exc;
+  }
+  // sets[i] -= removed, with the new cardinalities: one launch and one wait per MSI_BITS_MANY sets
+  std::vector<uint64_t> sub_many(const Set &removed, const std::vector<Set> &sets) {
+    std::vector<uint64_t> out(sets.size(), 0);
+    for (size_t base = 0; base < sets.size(); base += MSI_BITS_MANY) {
+      const uint32_t n = (uint32_t)std::min<size_t>(MSI_BITS_MANY, sets.size() - base);
+      uint32_t ss[MSI_BITS_MANY];
+      for (uint32_t k = 0; k < n; ++k) ss[k] = sets[base + k]->slot;
+      Clock ck_;
+      ++g_stats.launches;
+      ++g_stats.syncs;
+      ck(msi_bits_andnot_many_count(pool.p, removed->slot, n, ss, out.data() + base));
+      g_stats.device_wait_ms += ck_.ms();
+    }
+    return out;
+  }
+  Set from_docids(const std::vector<uint32_t> &ids) {
+    Set s = alloc();
+    ++g_stats.launches;
+    ck(msi_bits_set_from_docids(pool.p, s->slot, ids.empty() ? nullptr : ids.data(), ids.size()));
+    return s;
+  }
   // the same level WITHOUT the completion wait: its counts land in `region`; false = does not fit, nothing enqueued
   bool paths_enqueue(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe, uint32_t region) {
     std::vector<uint32_t> off{0}, steps;
@@ -1476,6 +1517,9 @@ struct GraphRule : Rule {
     const int per_wait = std::min<int>(knob ? atoi(knob) : 1, (int)MSI_BITS_PATH_REGIONS);
     const char *fused = getenv("MSI_SEARCH_FUSED_LEVELS");
     if (per_wait < 2 || (fused && fused[0] == '0')) return;
+    // `distinct` removes documents from every universe of the stack whenever a bucket reaches the results
+    // (bucket_sort.rs:404-411): a level evaluated ahead on a copy of the universe would not see that
+    if (cx->prm->distinct_values) return;
     struct Plan {
       uint64_t cost;
       std::vector<std::vector<int32_t>> all;
@@ -1783,6 +1827,13 @@ struct ExactAttributeRule : Rule {
     }
     out.docs = state == 1 ? exact_match : matches_start;
     out.count = state == 1 ? exact_count : start_count;
+    if (c.prm->distinct_values && out.count) {
+      // `candidates &= universe` at every call (exact_attribute.rs:253,275): without `distinct` the universe only
+      // loses this rule's own, disjoint buckets between start() and here; with it, whatever a deeper rule excluded
+      uint64_t n = 0;
+      out.docs = c.dev.and_new(out.docs, universe, &n);
+      out.count = n;
+    }
     out.score = {MSI_SCORE_EXACT_ATTRIBUTE, state == 1 ? 3u : 2u, 3};
     state = state == 1 ? 2 : 0;
     return true;
@@ -2041,6 +2092,32 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   *out_n = 0;
   if (out_candidates) *out_candidates = universe_count;
   if (universe_count < from || length == 0) return;
+  const msi_doc_values *dv = p->distinct_values;
+  if (rules.empty() && dv) {
+    // bucket_sort.rs:61-92: the first from + length documents the distinct loop keeps, in docid order; only THEIR
+    // values exclude documents from all_candidates
+    uint64_t n_kept = 0;
+    auto de = c.dev.distinct(dv, universe, &n_kept);
+    Set kept = de.first;
+    auto ids = c.dev.first_k(kept, (uint32_t)std::min<uint64_t>(n_kept, (uint64_t)from + length));
+    Set exc = de.second;
+    if (n_kept > (uint64_t)from + length) {
+      kept = c.dev.from_docids(ids);
+      exc = c.dev.distinct_excluded(dv, kept);
+    }
+    if (out_candidates) {
+      Set all = c.dev.clone(universe);
+      c.dev.sub_(all, exc);
+      c.dev.or_(all, kept);
+      *out_candidates = c.dev.count(all);
+    }
+    for (size_t i = from; i < ids.size(); ++i) {
+      out_docids[n_out] = ids[i];
+      out_n_scores[n_out++] = 0;
+    }
+    *out_n = n_out;
+    return;
+  }
   if (rules.empty()) {
     auto ids = c.dev.first_k(universe, from + length);
     for (size_t i = from; i < ids.size(); ++i) {
@@ -2060,7 +2137,29 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   size_t cur = 0;
   uint64_t cur_off = 0;
   Set excluded;  // documents a ranking score threshold removed from all_candidates
-  auto add = [&](const Set &cands, uint64_t count) {  // maybe_add_to_results :382-460
+  auto add = [&](Set cands, uint64_t count) {  // maybe_add_to_results :382-460
+    if (dv && count) {
+      // apply_distinct_rule, then `universe -= excluded` for every rule of the stack and all_candidates (:404-411)
+      const Set given = cands;
+      uint64_t n_kept = 0;
+      auto de = c.dev.distinct(dv, cands, &n_kept);
+      std::vector<Set> live;
+      std::vector<size_t> idx;
+      for (size_t i = 0; i < nr; ++i)
+        if (unis[i] && unis[i] != given && uni_counts[i]) {  // a universe handed over as the bucket is dropped by the caller
+          live.push_back(unis[i]);
+          idx.push_back(i);
+        }
+      if (!live.empty()) {
+        const auto counts = c.dev.sub_many(de.second, live);
+        for (size_t k = 0; k < idx.size(); ++k) uni_counts[idx[k]] = counts[k];
+      }
+      c.dev.and_(de.second, universe);  // all_candidates lives inside the initial universe
+      if (!excluded) excluded = c.dev.zeros();
+      c.dev.or_(excluded, de.second);
+      cands = de.first;
+      count = n_kept;
+    }
     if (!count) return;
     if (excluded) c.dev.sub_(excluded, cands);  // `*all_candidates |= &candidates`
     uint64_t skip = 0;

@@ -335,11 +335,13 @@ MAX_SCORE_DETAILS = 8
 def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERMS_LAST, offset=0, limit=20,
                           detailed=False, searchable_fids=(), searchable_weights=(), max_weight=None,
                           authorize_typos=True, min_one=5, min_two=9, universe_cbo=None, time_budget_us=0,
-                          stop_after=None, return_degraded=False, score_threshold=None, order_keys=(), _entry=None):
+                          stop_after=None, return_degraded=False, score_threshold=None, order_keys=(), distinct_values=None,
+                          _entry=None):
     """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
     terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
     (words: [str | None], None = a stop word inside a phrase; an optional 6th element True marks a negative term).
     order_keys: the DocKeys of the "orderBy" entries of `criteria`, in order (expand_sort_criteria).
+    distinct_values: the DocValues of the distinct field (None: no distinct).
     -> ([(docid, [(kind name, a, b)])], candidates)."""
     n = len(terms)
     lt = (LocatedTerm * max(n, 1))()
@@ -371,6 +373,8 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
     if order_keys:
         okeys = (C.c_void_p * len(order_keys))(*[k._h for k in order_keys])
         prm.order_keys, prm.n_order_keys = C.cast(okeys, C.c_void_p), len(order_keys)
+    if distinct_values is not None:
+        prm.distinct_values = distinct_values._h
     L = max(limit, 1)
     ids = np.zeros(L, dtype=np.uint32)
     sc = (ScoreDetail * (L * MAX_SCORE_DETAILS))()

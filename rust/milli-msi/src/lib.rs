@@ -289,6 +289,8 @@ pub struct RankedSearch<'a> {
     /// One per `sys::MSI_CRIT_ORDER_BY` entry of `criteria`, in order: the Sort / Asc / Desc rules the shim expanded
     /// (search/new/mod.rs:366-376,640-720).  `RankedScore::Sort { rule, key }` indexes the shim's rank -> value table.
     pub order_keys: &'a [&'a DocOrderKeys],
+    /// The distinct field of the request or of the index (`distinct_fid`, search/new/distinct.rs:130-147).
+    pub distinct: Option<&'a DocFacetValues>,
 }
 
 /// One u32 order key per document in HBM (`msi_doc_keys`): rank of the first facet value of a field that
@@ -305,6 +307,24 @@ impl DocOrderKeys {
     }
 }
 impl Drop for DocOrderKeys { fn drop(&mut self) { unsafe { sys::msi_doc_keys_destroy(self.0.as_ptr()) } } }
+
+/// The facet values of the distinct field per document, CSR in HBM (`msi_doc_values`): what `apply_distinct_rule`
+/// (search/new/distinct.rs:19-62) reads instead of walking `field_id_docid_facet_f64s` / `_strings` per candidate.
+/// `value_ids[offsets[d]..offsets[d + 1]]` = ids (< `n_values`) of the values of document `d`; two documents share a
+/// value of the field iff they share an id.  Built once per (index update, field).
+pub struct DocFacetValues(NonNull<sys::msi_doc_values>);
+unsafe impl Send for DocFacetValues {}
+unsafe impl Sync for DocFacetValues {}
+impl DocFacetValues {
+    pub fn new(ctx: &GpuContext, offsets: &[u64], value_ids: &[u32], n_values: u32) -> Result<Self, GpuError> {
+        assert!(!offsets.is_empty() && *offsets.last().unwrap() as usize == value_ids.len());
+        let mut p = ptr::null_mut();
+        check(unsafe { sys::msi_doc_values_create(ctx.0.as_ptr(), offsets.as_ptr(), value_ids.as_ptr(),
+                                                  (offsets.len() - 1) as u64, n_values, &mut p) })?;
+        Ok(Self(NonNull::new(p).unwrap()))
+    }
+}
+impl Drop for DocFacetValues { fn drop(&mut self) { unsafe { sys::msi_doc_values_destroy(self.0.as_ptr()) } } }
 
 pub struct RankedOutput {
     pub hits: Vec<(u32, Vec<RankedScore>)>,
@@ -412,7 +432,8 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
         time_budget_us: q.time_budget.map_or(0, |d| d.as_micros().max(1) as u64), stop_after: -1,
         has_score_threshold: q.ranking_score_threshold.is_some() as i32,
         score_threshold: q.ranking_score_threshold.unwrap_or(0.0),
-        order_keys: order_ptrs.as_ptr(), n_order_keys: order_ptrs.len() as u32 };
+        order_keys: order_ptrs.as_ptr(), n_order_keys: order_ptrs.len() as u32,
+        distinct_values: q.distinct.map_or(ptr::null(), |d| d.0.as_ptr() as *const _) };
     let mut src_ref: Src<'_> = source;
     let vt = sys::msi_index_vtable { user: &mut src_ref as *mut _ as *mut _, word_docids: Some(r_word),
         word_pair_proximity_docids: Some(r_pair), is_exact_word: Some(r_exact), word_fid_docids: Some(r_fid),

@@ -7,6 +7,8 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct msi_dict { _p: [u8; 0] }
 #[repr(C)] pub struct msi_bits { _p: [u8; 0] }
 #[repr(C)] pub struct msi_doc_keys { _p: [u8; 0] }
+#[repr(C)] pub struct msi_doc_values { _p: [u8; 0] }
+pub const MSI_BITS_NO_SLOT: u32 = 0xFFFF_FFFF;
 
 pub const MSI_OK: i32 = 0;
 pub const MSI_E_INVALID: i32 = -1;
@@ -90,6 +92,7 @@ pub struct msi_search_params {
     pub max_weight: i32, pub from: u32, pub length: u32, pub detailed_scores: i32,
     pub time_budget_us: u64, pub stop_after: i32, pub has_score_threshold: i32, pub score_threshold: f64,
     pub order_keys: *const *const msi_doc_keys, pub n_order_keys: u32,
+    pub distinct_values: *const msi_doc_values,
 }
 
 extern "C" {
@@ -128,6 +131,13 @@ extern "C" {
     pub fn msi_doc_keys_destroy(k: *mut msi_doc_keys);
     pub fn msi_bits_order_next(p: *mut msi_bits, keys: *const msi_doc_keys, universe: u32, bucket: u32,
                                out_key: *mut u32, out_count: *mut u64) -> i32;
+    pub fn msi_doc_values_create(ctx: *mut msi_ctx, offsets: *const u64, value_ids: *const u32, n_docs: u64, n_values: u32,
+                                 out: *mut *mut msi_doc_values) -> i32;
+    pub fn msi_doc_values_destroy(v: *mut msi_doc_values);
+    pub fn msi_bits_distinct(p: *mut msi_bits, values: *const msi_doc_values, candidates: u32, remaining: u32, excluded: u32,
+                             out_remaining: *mut u64, out_rounds: *mut u32) -> i32;
+    pub fn msi_bits_distinct_excluded(p: *mut msi_bits, values: *const msi_doc_values, kept: u32, excluded: u32) -> i32;
+    pub fn msi_bits_andnot_many_count(p: *mut msi_bits, removed: u32, n: u32, slots: *const u32, out_counts: *mut u64) -> i32;
     pub fn msi_fst_decode(fst: *const u8, len: usize, flags: u32, out_concat: *mut u8, cap_bytes: u64,
                           out_offsets: *mut u32, cap_words: u32, out_n_words: *mut u32, out_n_bytes: *mut u64) -> i32;
     pub fn msi_dict_create_from_fst(ctx: *mut msi_ctx, fst: *const u8, len: usize, out: *mut *mut msi_dict) -> i32;

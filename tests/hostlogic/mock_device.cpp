@@ -38,6 +38,11 @@ struct msi_doc_keys {
   std::vector<uint32_t> keys;
 };
 
+struct msi_doc_values {
+  std::vector<std::vector<uint32_t>> per_doc;
+  uint32_t n_values = 0;
+};
+
 uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
 #endif
 
@@ -189,6 +194,71 @@ int32_t msi_bits_order_next(msi_bits *p, const msi_doc_keys *keys, uint32_t univ
     }
   *out_key = best;
   *out_count = n;
+  return MSI_OK;
+}
+
+msi_doc_values *mock_doc_values_create(const uint64_t *offsets, const uint32_t *values, uint64_t n_docs, uint32_t n_values) {
+  msi_doc_values *v = new msi_doc_values();
+  v->n_values = n_values;
+  for (uint64_t d = 0; d < n_docs; ++d) v->per_doc.emplace_back(values + offsets[d], values + offsets[d + 1]);
+  return v;
+}
+void mock_doc_values_destroy(msi_doc_values *v) { delete v; }
+
+static bool mock_bit(msi_bits *p, uint32_t s, uint64_t d) { return (p->slot(s)[d >> 6] >> (d & 63)) & 1ull; }
+
+// the reference's loop as it is written (distinct.rs:19-62): the product's parallel rounds must agree with it
+int32_t msi_bits_distinct(msi_bits *p, const msi_doc_values *vals, uint32_t candidates, uint32_t remaining, uint32_t excluded,
+                          uint64_t *out_remaining, uint32_t *out_rounds) {
+  if (vals->per_doc.size() != p->n_docs) return MSI_E_INVALID;
+  std::vector<char> taken(vals->n_values, 0);
+  std::fill(p->slot(remaining), p->slot(remaining) + p->n_words, 0ull);
+  uint64_t n = 0;
+  for (uint64_t d = 0; d < p->n_docs; ++d) {
+    if (!mock_bit(p, candidates, d)) continue;
+    bool skip = false;
+    for (uint32_t v : vals->per_doc[d]) skip |= taken[v] != 0;
+    if (skip) continue;
+    for (uint32_t v : vals->per_doc[d]) taken[v] = 1;
+    p->slot(remaining)[d >> 6] |= 1ull << (d & 63);
+    ++n;
+  }
+  std::fill(p->slot(candidates), p->slot(candidates) + p->n_words, 0ull);
+  if (excluded != MSI_BITS_NO_SLOT) {
+    std::fill(p->slot(excluded), p->slot(excluded) + p->n_words, 0ull);
+    for (uint64_t d = 0; d < p->n_docs; ++d)
+      for (uint32_t v : vals->per_doc[d])
+        if (taken[v]) p->slot(excluded)[d >> 6] |= 1ull << (d & 63);
+  }
+  *out_remaining = n;
+  if (out_rounds) *out_rounds = 1;
+  return MSI_OK;
+}
+
+int32_t msi_bits_distinct_excluded(msi_bits *p, const msi_doc_values *vals, uint32_t kept, uint32_t excluded) {
+  std::vector<char> taken(vals->n_values, 0);
+  for (uint64_t d = 0; d < p->n_docs; ++d)
+    if (mock_bit(p, kept, d))
+      for (uint32_t v : vals->per_doc[d]) taken[v] = 1;
+  std::fill(p->slot(excluded), p->slot(excluded) + p->n_words, 0ull);
+  for (uint64_t d = 0; d < p->n_docs; ++d)
+    for (uint32_t v : vals->per_doc[d])
+      if (taken[v]) p->slot(excluded)[d >> 6] |= 1ull << (d & 63);
+  return MSI_OK;
+}
+
+int32_t msi_bits_andnot_many_count(msi_bits *p, uint32_t removed, uint32_t n, const uint32_t *slots, uint64_t *counts) {
+  for (uint32_t k = 0; k < n; ++k) {
+    for (uint64_t i = 0; i < p->n_words; ++i) p->slot(slots[k])[i] &= ~p->slot(removed)[i];
+    counts[k] = popcount_slot(p, slots[k]);
+  }
+  return MSI_OK;
+}
+
+int32_t msi_bits_set_from_docids(msi_bits *p, uint32_t slot, const uint32_t *docids, uint64_t n) {
+  std::fill(p->slot(slot), p->slot(slot) + p->n_words, 0ull);
+  for (uint64_t i = 0; i < n; ++i)
+    if (docids[i] < p->n_docs) p->slot(slot)[docids[i] >> 6] |= 1ull << (docids[i] & 63);
   return MSI_OK;
 }
 

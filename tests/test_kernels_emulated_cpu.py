@@ -91,6 +91,13 @@ class EmuHarness(_emu_harness_base()):
     def keys_destroy(self, h):
         h.close()
 
+    def values_create(self, per_doc, n_values):
+        import meilisearch_amd as ma
+        return ma.DocValues(self.L.ctx, per_doc, n_values)
+
+    def values_destroy(self, h):
+        h.close()
+
 
 # ---- the kernels against numpy: the bodies of the GPU tier ------------------------------------------------------------
 @pytest.mark.parametrize("n_docs", [1, 63, 64, 1000, 20003])
@@ -110,6 +117,18 @@ def test_order_keys(emu, n_docs):
     TO.test_order_next_against_numpy(n_docs)
 
 
+@pytest.mark.parametrize("kind", ["single", "multi", "chain", "same"])
+@pytest.mark.parametrize("n_docs", [1, 63, 64, 65, 1000, 2003])
+def test_distinct_kernels(emu, n_docs, kind):
+    import tests.test_zz_distinct_gpu as TD
+    TD.test_distinct_against_the_sequential_loop(n_docs, kind)
+
+
+def test_distinct_scratch_stamps(emu):
+    import tests.test_zz_distinct_gpu as TD
+    TD.test_many_calls_share_the_scratch_without_clearing_it()
+
+
 # ---- the ranked keyword search over the emulated kernels ---------------------------------------------------------------
 @pytest.mark.parametrize("fused,per_wait", [("1", "1"), ("0", "1"), ("1", "4")],
                          ids=["level-at-once", "path-by-path", "4-levels-per-wait"])
@@ -126,6 +145,11 @@ def test_random_corpora_over_emulated_kernels(emu, monkeypatch):
 def test_sort_rules_over_emulated_kernels(emu, monkeypatch):
     import tests.test_search_hostlogic_cpu as H
     H.test_sort_rules_match_the_oracle(emu, monkeypatch, "1")
+
+
+def test_distinct_over_emulated_kernels(emu, monkeypatch):
+    import tests.test_search_hostlogic_cpu as H
+    H.test_distinct_matches_the_oracle(emu, monkeypatch, "1", fields=("color", "sizes"), setups=H.DISTINCT_SETUPS[1:])
 
 
 def test_the_product_library_is_back(emu):

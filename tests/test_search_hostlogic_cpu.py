@@ -45,6 +45,8 @@ def hostlib():
     L.mock_dict_destroy.restype, L.mock_dict_destroy.argtypes = None, [C.c_void_p]
     L.mock_doc_keys_create.restype, L.mock_doc_keys_create.argtypes = C.c_void_p, [C.c_void_p, C.c_uint64]
     L.mock_doc_keys_destroy.restype, L.mock_doc_keys_destroy.argtypes = None, [C.c_void_p]
+    L.mock_doc_values_create.restype, L.mock_doc_values_create.argtypes = C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    L.mock_doc_values_destroy.restype, L.mock_doc_values_destroy.argtypes = None, [C.c_void_p]
     return L
 
 
@@ -62,6 +64,16 @@ class MockHarness:
 
     def __init__(self, L, index, n_slots=512):
         self.L, self.index = L, index
+        self.entry = L.msi_keyword_search_ranked
+        self.dict = self.dict_create(index)
+        self.pool = self.pool_create(max(index.n_docs, 1), n_slots)
+        self.cb = R.IndexCallbacks(index)
+
+    # the device objects: test doubles here; the real msi_bits.hip under the HIP emulation in
+    # tests/test_kernels_emulated_cpu.py (EmuHarness overrides pool / keys / values), everything real on the
+    # device (tests/test_zz_distinct_gpu.py: DeviceHarness)
+    def dict_create(self, index):
+        L = self.L
         dic = O.Dictionary(index.words)
         words = index.words
 
@@ -82,12 +94,11 @@ class MockHarness:
         self._offs = np.zeros(len(bs) + 1, dtype=np.uint32)
         if bs:
             np.cumsum([len(b) for b in bs], out=self._offs[1:])
-        self.dict = Handle(L.mock_dict_create(self._concat.ctypes.data, self._offs.ctypes.data, len(bs), self._cb))
-        self.pool = self.pool_create(max(index.n_docs, 1), n_slots)
-        self.cb = R.IndexCallbacks(index)
+        return Handle(L.mock_dict_create(self._concat.ctypes.data, self._offs.ctypes.data, len(bs), self._cb))
 
-    # the device objects: test doubles here, the real msi_bits.hip under the HIP emulation in
-    # tests/test_kernels_emulated_cpu.py (EmuHarness overrides these four)
+    def dict_destroy(self, d):
+        self.L.mock_dict_destroy(d._h)
+
     def pool_create(self, n_docs, n_slots):
         return Handle(self.L.mock_bits_create(n_docs, n_slots))
 
@@ -100,11 +111,22 @@ class MockHarness:
     def keys_destroy(self, h):
         self.L.mock_doc_keys_destroy(h._h)
 
+    def values_create(self, per_doc, n_values):
+        offsets = np.zeros(len(per_doc) + 1, dtype=np.uint64)
+        np.cumsum([len(v) for v in per_doc], out=offsets[1:])
+        flat = np.array([x for v in per_doc for x in v] or [0], dtype=np.uint32)
+        return Handle(self.L.mock_doc_values_create(offsets.ctypes.data_as(C.c_void_p), flat.ctypes.data_as(C.c_void_p),
+                                                    len(per_doc), n_values))
+
+    def values_destroy(self, h):
+        self.L.mock_doc_values_destroy(h._h)
+
     def search(self, query, tms="last", criteria=None, offset=0, limit=20, detailed=False, stop_after=None, sort=None,
-               **kw):
+               distinct=None, **kw):
         """sort: the request's [(field, "asc" | "desc")]; Sort details come back as the oracle writes them:
-        ("Sort", field, ascending, ("Number", x) | ("String", s) | ("Null",))."""
+        ("Sort", field, ascending, ("Number", x) | ("String", s) | ("Null",)).  distinct: the distinct field."""
         ix = self.index
+        dv = self.values_create(*ix.distinct_values(distinct)) if distinct else None
         crit, order = R.expand_sort_criteria(criteria if criteria is not None else ix.criteria, sort)
         handles, tables = [], []
         for field, asc in order:
@@ -118,15 +140,18 @@ class MockHarness:
                 strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
                 searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
                 max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,
-                stop_after=stop_after, order_keys=handles, _entry=self.L.msi_keyword_search_ranked, **kw)
+                stop_after=stop_after, order_keys=handles, distinct_values=dv, _entry=self.entry,
+                **kw)
         finally:
             for h in handles:
                 self.keys_destroy(h)
+            if dv is not None:
+                self.values_destroy(dv)
         return ([(d, [sort_detail(s, tables) for s in sc]) for d, sc in out[0]],) + tuple(out[1:])
 
     def close(self):
         self.pool_destroy(self.pool)
-        self.L.mock_dict_destroy(self.dict._h)
+        self.dict_destroy(self.dict)
 
 
 def sort_detail(s, tables):
@@ -165,7 +190,7 @@ def build_index(cfg, **extra):
                     exact_words=cfg.get("exact_words", ()), criteria=cfg.get("criteria"),
                     min_one=cfg.get("min_one", 5), min_two=cfg.get("min_two", 9),
                     authorize_typos=cfg.get("authorize_typos", True), synonyms=cfg.get("synonyms"),
-                    stop_words=cfg.get("stop_words", ()), **extra)
+                    stop_words=cfg.get("stop_words", ()), distinct=cfg.get("distinct"), **extra)
 
 
 @pytest.mark.parametrize("fused,per_wait", [("1", "1"), ("0", "1"), ("1", "2"), ("1", "4")],
@@ -176,14 +201,14 @@ def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused,
     monkeypatch.setenv("MSI_SEARCH_FUSED_LEVELS", fused)
     monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
     harnesses, n = {}, 0
-    cases = [c for c in FIX["cases"] if not c.get("needs") and not c.get("distinct")
-             and not FIX["indexes"][c["index"]].get("distinct")]   # distinct: oracle only for now
+    cases = [c for c in FIX["cases"] if not c.get("needs")]
     for case in cases:
         if case["index"] not in harnesses:
             harnesses[case["index"]] = make_harness(hostlib, build_index(FIX["indexes"][case["index"]]))
         h = harnesses[case["index"]]
         hits, _ = h.search(case["query"], tms=case["tms"], offset=case["offset"], limit=case["limit"],
-                           detailed=case["detailed"], stop_after=case.get("stop_after"), sort=case.get("sort"))
+                           detailed=case["detailed"], stop_after=case.get("stop_after"), sort=case.get("sort"),
+                           distinct=case.get("distinct") or h.index.distinct_field)
         ids = [d for d, _ in hits]
         if case["ids"] is not None:
             assert ids == case["ids"], case["src"]
@@ -195,7 +220,7 @@ def test_reference_snapshots_through_the_host_logic(hostlib, monkeypatch, fused,
         if case.get("global_scores"):
             assert [f"{R.score_details_global_score(sc):.4f}" for _, sc in hits] == case["global_scores"]
         n += 1
-    assert n == len(cases) >= 99   # 94 keyword searches + the 5 of sort.rs
+    assert n == len(cases) >= 108   # 94 keyword searches + the 5 of sort.rs + the 9 of distinct.rs
     for h in harnesses.values():
         h.close()
 
@@ -318,4 +343,50 @@ def test_sort_rules_match_the_oracle(hostlib, monkeypatch, per_wait):
                 assert cand == len(want_cand)
                 n_sorted += any(s[0] == "Sort" for _, sc in hits for s in sc)
     assert n_sorted > 60
+    h.close()
+
+
+DISTINCT_SETUPS = [
+    (["words", "typo", "proximity", "attributeRank", "wordPosition", "exactness"], None),
+    (["words", "typo", "proximity", "attributeRank", "sort", "wordPosition", "exactness"], [("price", "asc")]),
+    (["sort", "words", "typo"], [("color", "desc"), ("price", "asc")]),
+    (["words", "exactness"], None),
+    ([], None),                                                                  # no ranking rule at all
+]
+
+
+@pytest.mark.parametrize("per_wait", ["1", "3"], ids=["one-level-per-wait", "3-levels-per-wait"])
+def test_distinct_matches_the_oracle(hostlib, monkeypatch, per_wait, fields=("color", "sizes", "mixed", "price"),
+                                     setups=DISTINCT_SETUPS):
+    """`distinct` (search/new/distinct.rs; bucket_sort.rs:61-92,399-415) over single-valued, multi-valued and mixed
+    number / string fields, under every kind of rule and on rule-less searches: hits, score details and
+    all_candidates against the oracle; the exclusions reach every universe of the rule stack."""
+    from oracle import ranking_oracle as RO
+    import tests.test_search_gpu as G
+    monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
+    index = ToyMilli(sortable_corpus(9, 220), searchable=["title", "body"])
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    h = make_harness(hostlib, index)
+    n = 0
+    for field in fields:
+        for criteria, sort in setups:
+            for q in ["", "the", "quick fox", "sun fl", "\"lazy dog\"", "brwn fox jumps"]:
+                for detailed, offset, limit, threshold in ((True, 0, 30, None), (False, 0, 7, None), (True, 5, 9, None),
+                                                            (True, 0, 20, 0.6)):
+                    if threshold is not None and not criteria:
+                        continue
+                    want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms="last", criteria=criteria,
+                                                             offset=offset, length=limit, detailed=detailed, sort=sort,
+                                                             distinct=field, threshold=threshold)
+                    hits, cand = h.search(q, criteria=criteria, offset=offset, limit=limit, detailed=detailed, sort=sort,
+                                          distinct=field, score_threshold=threshold)
+                    assert [d for d, _ in hits] == want_ids, (field, criteria, sort, q, detailed, offset, threshold)
+                    assert [[tuple(s) for s in sc] for _, sc in hits] == [[G.oracle_score(s) for s in sc] for sc in want_sc]
+                    assert cand == len(want_cand), (field, criteria, sort, q, detailed, offset, threshold)
+                    n += 1
+    assert n >= 400 or setups is not DISTINCT_SETUPS
     h.close()

@@ -302,6 +302,14 @@ class ToyMilli:
                 out[d] = min(out[d], rank)
         return out, values
 
+    def distinct_values(self, field):
+        """What the shim stages for msi_doc_values_create: per document the ids of its facet values of `field`
+        (numbers and strings, field_id_docid_facet_f64s / _strings), and the number of distinct values."""
+        ids, per_doc = {}, []
+        for d in range(self.n_docs):
+            per_doc.append([ids.setdefault(k, len(ids)) for k in self.doc_facets.get((field, d), ())])
+        return per_doc, max(len(ids), 1)
+
     def distinct_excluded(self, field, docid):
         """distinct_single_docid (search/new/distinct.rs:38-62): the documents that share a facet value with docid."""
         out = set()
