@@ -356,6 +356,28 @@ int32_t msi_bits_distinct(msi_bits *pool, const msi_doc_values *values, uint32_t
 int32_t msi_bits_distinct_excluded(msi_bits *pool, const msi_doc_values *values, uint32_t kept, uint32_t excluded);
 int32_t msi_bits_andnot_many_count(msi_bits *pool, uint32_t removed, uint32_t n, const uint32_t *slots,
                                    uint64_t *out_counts);
+/* SURVEY §8 f3 — the GeoSort ranking rule (crates/milli/src/search/new/geo_sort.rs:14-160 over
+ * documents/geo_sort.rs:66-224) without an R-tree walk or a facet-database read per candidate: the `_geo` point of
+ * every document resident in HBM (16 bytes per document: lat, lng as f64; a NaN latitude = the document is not in
+ * geo_faceted_documents_ids).  msi_bits_geo_next = the rule's next_bucket for the target point (lat, lng):
+ * bucket := the documents of `universe` with a point whose distance (distance_between_two_points, lib.rs:388-393:
+ * geoutils' haversine, metres rounded to mm) is within `distance_error_margin` of the nearest (ascending) /
+ * farthest (descending) one, at most `max_bucket_size` of them — the nearest / farthest first, ascending docids among
+ * equal distances; universe -= bucket; *out_first_docid = the document the bucket starts with (ScoreDetails::GeoSort's
+ * `value` is ITS point; the smallest docid among equally distant ones), *out_count = |bucket|.
+ * When no document of the universe has a point: *out_first_docid = 0xFFFFFFFF, *out_count = 0, nothing is changed —
+ * the rule then answers with the whole universe and value None (geo_sort.rs:149-153).
+ * Exact distance order is what both of the reference's strategies compute when distances differ by more than a
+ * metre (its own tests assert that they agree: tests/geo_sort.rs:30-66); below that the iterative strategy's
+ * truncation to whole metres makes bucket boundaries depend on docid order — not reproduced. */
+typedef struct msi_geo_points msi_geo_points;
+int32_t msi_geo_points_create(msi_ctx *ctx, const double *lat_lng /* [n_docs][2] */, uint64_t n_docs,
+                              msi_geo_points **out);
+void msi_geo_points_destroy(msi_geo_points *points);
+int32_t msi_bits_geo_next(msi_bits *pool, const msi_geo_points *points, uint32_t universe, uint32_t bucket,
+                          uint32_t scratch /* a third slot: used when more than max_bucket_size documents fit */,
+                          double lat, double lng, int32_t ascending, uint32_t max_bucket_size,
+                          double distance_error_margin, uint32_t *out_first_docid, uint64_t *out_count);
 int32_t msi_bits_set_from_words(msi_bits *pool, uint32_t slot,
                                 const uint64_t *words, uint64_t n_words);
 int32_t msi_bits_fill(msi_bits *pool, uint32_t slot, int32_t ones);
@@ -587,8 +609,10 @@ enum {
   MSI_CRIT_WORDS = 0, MSI_CRIT_TYPO = 1, MSI_CRIT_PROXIMITY = 2, MSI_CRIT_ATTRIBUTE = 3,
   MSI_CRIT_ATTRIBUTE_RANK = 4, MSI_CRIT_WORD_POSITION = 5, MSI_CRIT_EXACTNESS = 6,
   MSI_CRIT_SORT = 7,     /* ignored: the shim expands Criterion::Sort / Asc / Desc into MSI_CRIT_ORDER_BY entries */
-  MSI_CRIT_ORDER_BY = 8  /* one Sort rule (mod.rs:366-376,640-720: one per sorted field, a field only once); the
+  MSI_CRIT_ORDER_BY = 8, /* one Sort rule (mod.rs:366-376,640-720: one per sorted field, a field only once); the
                           * i-th MSI_CRIT_ORDER_BY of the list uses params->order_keys[i] */
+  MSI_CRIT_GEO_SORT = 9  /* one GeoSort rule (mod.rs:690-712: AscDesc::{Asc,Desc}(Member::Geo(point))); the i-th
+                          * MSI_CRIT_GEO_SORT of the list uses params->geo_rules[i] */
 };
 enum { /* ScoreDetails variants, score_details.rs:10-27 */
   MSI_SCORE_WORDS = 0,           /* a = matching_words, b = max_matching_words */
@@ -599,8 +623,10 @@ enum { /* ScoreDetails variants, score_details.rs:10-27 */
   MSI_SCORE_EXACT_ATTRIBUTE = 5, /* a = 3 ExactMatch | 2 MatchesStart | 1 NoExactMatch, b = 3 */
   MSI_SCORE_EXACT_WORDS = 6,     /* a = matching_words, b = max_matching_words */
   MSI_SCORE_SKIPPED = 7,         /* the deadline cut the ranking short here; rank 0 of 1 */
-  MSI_SCORE_SORT = 8             /* a = index into order_keys, b = the bucket's order key (0xFFFFFFFF: Null); no rank
+  MSI_SCORE_SORT = 8,            /* a = index into order_keys, b = the bucket's order key (0xFFFFFFFF: Null); no rank
                                   * (score_details.rs:103-121: Sort does not enter the global score) */
+  MSI_SCORE_GEO_SORT = 9         /* a = index into geo_rules, b = the docid whose point is the bucket's `value`
+                                  * (0xFFFFFFFF: None — no _geo); no rank either */
 };
 #define MSI_MAX_SCORE_DETAILS 8
 typedef struct msi_score_detail {
@@ -615,6 +641,11 @@ typedef struct msi_located_term {
 } msi_located_term;
 #define MSI_TERM_PHRASE 1u
 #define MSI_TERM_NEGATIVE 2u
+typedef struct msi_geo_rule {
+  const msi_geo_points *points;
+  double lat, lng;   /* the target point of the request's _geoPoint(lat, lng) */
+  int32_t ascending;
+} msi_geo_rule;
 typedef struct msi_search_params {
   uint32_t authorize_typos, min_word_len_one_typo, min_word_len_two_typos;
   int32_t strategy;                    /* MSI_TERMS_LAST | MSI_TERMS_ALL */
@@ -644,6 +675,13 @@ typedef struct msi_search_params {
    * bucket that reaches the results goes through msi_bits_distinct; what it excludes leaves every rule's universe
    * and *out_candidates (bucket_sort.rs:399-415).  Also on placeholder / rule-less searches (:61-92). */
   const msi_doc_values *distinct_values;
+  /* GeoSort rules (one per MSI_CRIT_GEO_SORT criterion, in order) and the request's GeoSortParameter
+   * (documents/geo_sort.rs:12-30: max_bucket_size — 0 = its default, 1000 — and distance_error_margin, metres, 1.0 by
+   * default in the reference: passed as it is). */
+  const msi_geo_rule *geo_rules;
+  uint32_t n_geo_rules;
+  uint32_t geo_max_bucket_size;
+  double geo_distance_error_margin;
 } msi_search_params;
 /* out_scores: [length][MSI_MAX_SCORE_DETAILS], out_n_scores: [length].  The pool needs at least 64 free
  * slots above slot 0 (more for long queries: one per live condition of every active rule). */

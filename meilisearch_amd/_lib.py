@@ -101,7 +101,12 @@ class SearchParams(C.Structure):
                 ("n_searchable", C.c_uint32), ("max_weight", C.c_int32), ("from_", C.c_uint32),
                 ("length", C.c_uint32), ("detailed_scores", C.c_int32), ("time_budget_us", C.c_uint64),
                 ("stop_after", C.c_int32), ("has_score_threshold", C.c_int32), ("score_threshold", C.c_double),
-                ("order_keys", C.c_void_p), ("n_order_keys", C.c_uint32), ("distinct_values", C.c_void_p)]
+                ("order_keys", C.c_void_p), ("n_order_keys", C.c_uint32), ("distinct_values", C.c_void_p), ("geo_rules", C.c_void_p), ("n_geo_rules", C.c_uint32),
+                ("geo_max_bucket_size", C.c_uint32), ("geo_distance_error_margin", C.c_double)]
+
+
+class GeoRule(C.Structure):
+    _fields_ = [("points", C.c_void_p), ("lat", C.c_double), ("lng", C.c_double), ("ascending", C.c_int32)]
 
 
 class QueryToken(C.Structure):
@@ -167,6 +172,10 @@ PROTOTYPES = {
     "msi_doc_keys_create": (_I32, [_VP, _VP, C.c_uint64, C.POINTER(_VP)]),
     "msi_doc_keys_destroy": (None, [_VP]),
     "msi_bits_order_next": (_I32, [_VP, _VP, _U32, _U32, C.POINTER(_U32), C.POINTER(C.c_uint64)]),
+    "msi_geo_points_create": (_I32, [_VP, _VP, C.c_uint64, C.POINTER(_VP)]),
+    "msi_geo_points_destroy": (None, [_VP]),
+    "msi_bits_geo_next": (_I32, [_VP, _VP, _U32, _U32, _U32, _F64, _F64, _I32, _U32, _F64, C.POINTER(_U32),
+                                 C.POINTER(C.c_uint64)]),
     "msi_doc_values_create": (_I32, [_VP, _VP, _VP, C.c_uint64, _U32, C.POINTER(_VP)]),
     "msi_doc_values_destroy": (None, [_VP]),
     "msi_bits_distinct": (_I32, [_VP, _VP, _U32, _U32, _U32, C.POINTER(C.c_uint64), C.POINTER(_U32)]),

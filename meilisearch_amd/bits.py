@@ -55,6 +55,15 @@ class BitsPool:
         check(lib().msi_bits_order_next(self._h, keys._h, universe, bucket, C.byref(key), C.byref(n)))
         return int(key.value), int(n.value)
 
+    def geo_next(self, points, universe, bucket, scratch, lat, lng, ascending=True, max_bucket_size=1000, margin=1.0):
+        """GeoSort's next bucket (documents/geo_sort.rs:150-224): the documents of `universe` within `margin` metres of
+        the nearest (farthest) one, at most max_bucket_size; universe -= bucket.
+        -> (docid whose point is the bucket's value | None when no document of the universe has a point, count)."""
+        first, n = C.c_uint32(0), C.c_uint64(0)
+        check(lib().msi_bits_geo_next(self._h, points._h, universe, bucket, scratch, float(lat), float(lng),
+                                      1 if ascending else 0, int(max_bucket_size), float(margin), C.byref(first), C.byref(n)))
+        return (None if first.value == 0xFFFFFFFF else int(first.value)), int(n.value)
+
     def distinct(self, values, candidates, remaining, excluded=NO_UNIVERSE):
         """apply_distinct_rule (search/new/distinct.rs:19-36): remaining := the candidates kept (one per value of the
         distinct field, smallest docid first), excluded := every document that shares a value with a kept one;
@@ -148,6 +157,27 @@ class DocValues:
     def close(self):
         if self._h:
             lib().msi_doc_values_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GeoPoints:
+    """The _geo point of every document in HBM (msi_geo_points_create): lat_lng [n_docs][2] f64, NaN = no point."""
+
+    def __init__(self, ctx, lat_lng):
+        self.ctx = ctx
+        self.lat_lng = np.ascontiguousarray(lat_lng, dtype=np.float64).reshape(-1, 2)
+        self._h = C.c_void_p()
+        check(lib().msi_geo_points_create(ctx.handle, np_ptr(self.lat_lng), self.lat_lng.shape[0], C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().msi_geo_points_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -58,6 +58,13 @@ struct msi_doc_values {
   DevBuf offsets, values;  // u32 [n_docs + 1], u32 [offsets[n_docs]]
 };
 
+// The _geo point of every document, resident in HBM (msi_geo_points_create): [n_docs][2] f64, NaN latitude = none
+struct msi_geo_points {
+  msi_ctx *ctx = nullptr;
+  uint64_t n_docs = 0;
+  DevBuf lat_lng;
+};
+
 // One u32 order key per document, resident in HBM (msi_doc_keys_create)
 struct msi_doc_keys {
   msi_ctx *ctx = nullptr;
@@ -348,6 +355,114 @@ __global__ void bits_distinct_excluded_kernel(u64 *__restrict__ excluded, const 
   }
   const u64 mask = __ballot(ex);
   if ((threadIdx.x & 63) == 0 && w < n_words) excluded[w] = mask;
+}
+
+// ---- GeoSort (crates/milli/src/search/new/geo_sort.rs, documents/geo_sort.rs:150-224) --------------------------------
+// distance_between_two_points (lib.rs:388-393) = geoutils 0.5.1's haversine_distance_to: hav(t) = (1 - cos t) / 2 on
+// the radian differences, mean radius 6371 km, metres rounded to millimetres.  The operation order is the crate's;
+// the translation unit is built with -ffp-contract=off.  Distances are >= 0, so their bit patterns order like them.
+struct GeoTarget {
+  double phi, cos_phi, lam;  // of the target point, radians
+  double margin;
+  int ascending;
+};
+__device__ __forceinline__ double geo_distance_m(const GeoTarget &t, double lat, double lng) {
+  const double D2R = 3.14159265358979323846 / 180.0;  // f64::to_radians
+  const double phi2 = lat * D2R, lam2 = lng * D2R;
+  const double hav_phi = (1.0 - cos(phi2 - t.phi)) / 2.0;
+  const double hav_lam = t.cos_phi * cos(phi2) * ((1.0 - cos(lam2 - t.lam)) / 2.0);
+  const double total = hav_phi + hav_lam;
+  return round(2.0 * 6371e3 * asin(sqrt(total)) * 1000.0) / 1000.0;
+}
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int o) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
+  return ((u64)hi << 32) | lo;
+}
+// sort key of a distance: ascending rules minimise the bits, descending rules the complement; ~0 = no point
+__device__ __forceinline__ u64 geo_key(const GeoTarget &t, double dist) {
+  const u64 b = (u64)__double_as_longlong(dist);
+  return t.ascending ? b : ~b - 1;  // `- 1` keeps ~0 free for "none" (a distance of +0.0 has all-zero bits)
+}
+
+// best = min over the documents of `src` that have a point of their distance key (one document per thread)
+__global__ void bits_geo_min_kernel(const u64 *__restrict__ src, const double *__restrict__ lat_lng, uint64_t n_docs,
+                                    uint64_t n_words, GeoTarget t, u64 *__restrict__ best) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = d >> 6;
+  const u64 word = w < n_words ? src[w] : 0ull;
+  u64 k = ~0ull;
+  if (d < n_docs && ((word >> (d & 63)) & 1ull)) {
+    const double lat = lat_lng[2 * d];
+    if (lat == lat) k = geo_key(t, geo_distance_m(t, lat, lat_lng[2 * d + 1]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 other = shfl_xor_u64(k, o);
+    k = other < k ? other : k;
+  }
+  if ((threadIdx.x & 63) == 0 && k != ~0ull) atomicMin(best, k);
+}
+
+// dst := {d in src with a point : key_lo <= key(d) <= key_hi} (mode 0; mode 2: dst |= them) or, relative to the extreme found by the min
+// kernel, the documents within the error margin of it (mode 1; they also leave `src`, and the smallest docid at the
+// extreme itself is collected).  The last workgroup publishes {|dst|, first docid} and re-arms the cells.
+__global__ void bits_geo_take_kernel(u64 *__restrict__ src, u64 *__restrict__ dst, const double *__restrict__ lat_lng,
+                                     uint64_t n_docs, uint64_t n_words, GeoTarget t, int mode, u64 key_lo, u64 key_hi,
+                                     u64 *__restrict__ best, u64 *__restrict__ first, u64 *__restrict__ acc,
+                                     volatile uint64_t *__restrict__ sig, uint64_t seq) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = d >> 6;
+  const u64 word = w < n_words ? src[w] : 0ull;
+  const u64 kbest = mode == 1 ? __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  bool hit = false;
+  if (d < n_docs && ((word >> (d & 63)) & 1ull) && (mode != 1 || kbest != ~0ull)) {
+    const double lat = lat_lng[2 * d];
+    if (lat == lat) {
+      const double dist = geo_distance_m(t, lat, lat_lng[2 * d + 1]);
+      const u64 k = geo_key(t, dist);
+      if (mode != 1) {
+        hit = k >= key_lo && k <= key_hi;
+      } else {
+        const double d0 = __longlong_as_double((long long)(t.ascending ? kbest : ~(kbest + 1)));
+        hit = fabs(d0 - dist) <= t.margin;  // documents/geo_sort.rs:181
+        if (k == kbest) atomicMin(first, (u64)d);
+      }
+    }
+  }
+  const u64 mask = __ballot(hit);
+  __shared__ uint32_t part[BT / 64];
+  if ((threadIdx.x & 63) == 0) {
+    if (w < n_words) {
+      if (mode == 2) {
+        if (mask) dst[w] |= mask;
+      } else {
+        dst[w] = mask;
+      }
+      if (mode == 1 && mask) src[w] = word & ~mask;
+    }
+    part[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 b = 0;
+    for (int i = 0; i < BT / 64; ++i) b += part[i];
+    if (b) atomicAdd(&acc[0], b);
+    __threadfence();
+    const u64 done = atomicAdd(&acc[1], 1ull);
+    if (done == gridDim.x - 1) {
+      const u64 total = atomicExch(&acc[0], 0ull);
+      acc[1] = 0;
+      u64 f = ~0ull, kb = 0;
+      if (mode == 1) {
+        f = atomicExch(first, ~0ull);
+        kb = atomicExch(best, ~0ull);  // every workgroup has read it: re-armed for the next call
+      }
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[0]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[2]), f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[3]), kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 struct ManyArgs {
@@ -833,14 +948,16 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   if (s == MSI_OK) s = p->small.ensure(64);
   if (s == MSI_OK) {
     void *h = nullptr;
-    if (hipHostMalloc(&h, (4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(uint64_t), hipHostMallocCoherent) != hipSuccess ||
-        hipMalloc((void **)&p->d_acc, (4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess ||
-        hipMemset(p->d_acc, 0, (4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess) {
+    if (hipHostMalloc(&h, (6 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(uint64_t), hipHostMallocCoherent) != hipSuccess ||
+        hipMalloc((void **)&p->d_acc, (6 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess ||
+        hipMemset(p->d_acc, 0, (6 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS) * sizeof(u64)) != hipSuccess) {
       msi_set_error("msi_bits_create: allocating the completion signal failed");
       s = MSI_E_OOM;
     } else {
       p->h_sig = (volatile uint64_t *)h;
       p->h_sig[0] = p->h_sig[1] = 0;
+      // the two cells of the GeoSort kernels rest at ~0 ("no point seen")
+      if (hipMemset(p->d_acc + 4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS, 0xFF, 2 * sizeof(u64)) != hipSuccess) s = MSI_E_HIP;
     }
   }
   if (s != MSI_OK) {
@@ -1670,6 +1787,147 @@ int32_t msi_bits_andnot_many_count(msi_bits *p, uint32_t removed, uint32_t n, co
   uint64_t ignored = 0;
   MSI_TRY(wait_count(p, seq, &ignored));
   for (uint32_t k = 0; k < n; ++k) counts[k] = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2 + k]), __ATOMIC_RELAXED);
+  return MSI_OK;
+}
+
+int32_t msi_geo_points_create(msi_ctx *ctx, const double *lat_lng, uint64_t n_docs, msi_geo_points **out) {
+  if (!ctx || !out || !n_docs || !lat_lng) {
+    msi_set_error("msi_geo_points_create: invalid argument");
+    return MSI_E_INVALID;
+  }
+  *out = nullptr;
+  DeviceGuard g(ctx->device);
+  msi_geo_points *gp = new msi_geo_points();
+  gp->ctx = ctx;
+  gp->n_docs = n_docs;
+  int32_t st = gp->lat_lng.ensure((size_t)n_docs * 2 * sizeof(double));
+  if (st == MSI_OK) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipError_t e = hipMemcpyAsync(gp->lat_lng.p, lat_lng, (size_t)n_docs * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // borrowed for the call
+    if (e != hipSuccess) {
+      msi_set_error("msi_geo_points_create: upload failed: %s", hipGetErrorString(e));
+      st = MSI_E_HIP;
+    }
+  }
+  if (st != MSI_OK) {
+    gp->lat_lng.release();
+    delete gp;
+    return st;
+  }
+  msi_ctx_retain(ctx);
+  *out = gp;
+  return MSI_OK;
+}
+
+void msi_geo_points_destroy(msi_geo_points *gp) {
+  if (!gp) return;
+  {
+    DeviceGuard g(gp->ctx->device);
+    gp->lat_lng.release();
+  }
+  msi_ctx_release(gp->ctx);
+  delete gp;
+}
+
+// one launch of the take kernel in a range mode (0: dst := selection, 2: dst |= selection) -> |selection|
+static int32_t geo_range(msi_bits *p, const msi_geo_points *gp, const GeoTarget &t, uint32_t src, uint32_t dst, int mode,
+                         u64 key_lo, u64 key_hi, uint64_t *count) {
+  std::unique_lock<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  u64 *cells = p->d_acc + 4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS;
+  const dim3 grid((uint32_t)((p->n_words * 64 + BT - 1) / BT)), block(BT);
+  const uint64_t seq = ++p->seq;
+  hipLaunchKernelGGL(bits_geo_take_kernel, grid, block, 0, p->stream, p->slot(src), p->slot(dst), gp->lat_lng.as<double>(),
+                     p->n_docs, p->n_words, t, mode, key_lo, key_hi, cells, cells + 1, p->d_acc, p->h_sig, seq);
+  MSI_HIP_TRY(hipGetLastError());
+  lk.unlock();
+  return wait_count(p, seq, count);
+}
+
+int32_t msi_bits_geo_next(msi_bits *p, const msi_geo_points *gp, uint32_t universe, uint32_t bucket, uint32_t scratch,
+                          double lat, double lng, int32_t ascending, uint32_t max_bucket_size, double margin,
+                          uint32_t *out_first_docid, uint64_t *out_count) {
+  if (!p || !gp || !out_first_docid || !out_count || universe == bucket || universe == scratch || bucket == scratch ||
+      !(margin >= 0.0)) {
+    msi_set_error("msi_bits_geo_next: invalid argument (three different slots, a margin >= 0)");
+    return MSI_E_INVALID;
+  }
+  if (gp->ctx != p->ctx || gp->n_docs != p->n_docs) {
+    msi_set_error("msi_bits_geo_next: the points (%llu documents) do not belong to this pool (%llu documents)",
+                  (unsigned long long)gp->n_docs, (unsigned long long)p->n_docs);
+    return MSI_E_INVALID;
+  }
+  MSI_TRY(check_slot(p, universe, "msi_bits_geo_next"));
+  MSI_TRY(check_slot(p, bucket, "msi_bits_geo_next"));
+  MSI_TRY(check_slot(p, scratch, "msi_bits_geo_next"));
+  const double D2R = 3.14159265358979323846 / 180.0;
+  GeoTarget t;
+  t.phi = lat * D2R;
+  t.cos_phi = cos(t.phi);
+  t.lam = lng * D2R;
+  t.margin = margin;
+  t.ascending = ascending ? 1 : 0;
+  const uint64_t cap = max_bucket_size ? max_bucket_size : 1000;
+  uint64_t count = 0, first = 0, kbest = 0;
+  {
+    std::unique_lock<std::mutex> lk(*p->mu);
+    DeviceGuard g(p->ctx->device);
+    hipStream_t st = p->stream;
+    u64 *cells = p->d_acc + 4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS;
+    const dim3 grid((uint32_t)((p->n_words * 64 + BT - 1) / BT)), block(BT);
+    const uint64_t seq = ++p->seq;
+    hipLaunchKernelGGL(bits_geo_min_kernel, grid, block, 0, st, p->slot(universe), gp->lat_lng.as<double>(), p->n_docs,
+                       p->n_words, t, cells);
+    hipLaunchKernelGGL(bits_geo_take_kernel, grid, block, 0, st, p->slot(universe), p->slot(bucket),
+                       gp->lat_lng.as<double>(), p->n_docs, p->n_words, t, 1, (u64)0, (u64)0, cells, cells + 1, p->d_acc,
+                       p->h_sig, seq);
+    MSI_HIP_TRY(hipGetLastError());
+    lk.unlock();
+    MSI_TRY(wait_count(p, seq, &count));
+    first = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[2]), __ATOMIC_RELAXED);
+    kbest = __atomic_load_n(const_cast<uint64_t *>(&p->h_sig[3]), __ATOMIC_RELAXED);
+  }
+  if (kbest == ~0ull || !count) {  // no document of the universe has a point
+    *out_first_docid = 0xFFFFFFFFu;
+    *out_count = 0;
+    return MSI_OK;
+  }
+  if (count > cap) {
+    // More documents within the margin than a bucket may hold (documents/geo_sort.rs:190-193,203-205): keep the `cap`
+    // first in (distance key, docid) order.  T = the smallest key with |{key <= T}| >= cap, by bisection over the
+    // key bits; everything below T, then the smallest docids at T; the rest goes back to the universe.
+    double d0;
+    {
+      const u64 b0 = ascending ? kbest : ~(kbest + 1);
+      memcpy(&d0, &b0, sizeof(d0));
+    }
+    const double edge = ascending ? d0 + margin : std::max(0.0, d0 - margin);  // every kept key lies between the two
+    u64 edge_bits;
+    memcpy(&edge_bits, &edge, sizeof(edge));
+    u64 lo = kbest, hi = ascending ? edge_bits : ~edge_bits - 1;
+    while (lo < hi) {
+      const u64 mid = lo + (hi - lo) / 2;
+      uint64_t c = 0;
+      MSI_TRY(geo_range(p, gp, t, bucket, scratch, 0, 0, mid, &c));
+      if (c >= cap) hi = mid;
+      else lo = mid + 1;
+    }
+    uint64_t below = 0, at = 0;
+    if (lo > 0) MSI_TRY(geo_range(p, gp, t, bucket, scratch, 0, 0, lo - 1, &below));
+    MSI_TRY(geo_range(p, gp, t, bucket, scratch, 0, lo, lo, &at));
+    std::vector<uint32_t> ids((size_t)(cap - below));
+    uint32_t n_ids = 0;
+    MSI_TRY(msi_bits_first_k(p, scratch, (uint32_t)ids.size(), ids.data(), &n_ids));
+    MSI_TRY(msi_bits_set_from_docids(p, scratch, ids.data(), n_ids));
+    if (lo > 0) MSI_TRY(geo_range(p, gp, t, bucket, scratch, 2, 0, lo - 1, &below));
+    MSI_TRY(msi_bits_op(p, bucket, bucket, scratch, MSI_BITS_ANDNOT));  // what does not fit
+    MSI_TRY(msi_bits_op(p, universe, universe, bucket, MSI_BITS_OR));
+    MSI_TRY(msi_bits_op(p, bucket, scratch, scratch, MSI_BITS_AND));
+    count = cap;
+  }
+  *out_first_docid = (uint32_t)first;
+  *out_count = count;
   return MSI_OK;
 }
 

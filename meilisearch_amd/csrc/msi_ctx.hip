@@ -173,7 +173,8 @@ double msi_score_details_global_score(const msi_score_detail *details, uint32_t 
   uint32_t rank = 1, max_rank = 1;
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t r, m;
-    if (details[i].kind == MSI_SCORE_SORT) continue;  // ScoreDetails::rank() is None for Sort, score_details.rs:103-121
+    // ScoreDetails::rank() is None for Sort and GeoSort, score_details.rs:103-121
+    if (details[i].kind == MSI_SCORE_SORT || details[i].kind == MSI_SCORE_GEO_SORT) continue;
     switch (details[i].kind) {
       case MSI_SCORE_TYPO:
         m = details[i].b + 1;

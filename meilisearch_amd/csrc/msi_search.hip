@@ -202,6 +202,18 @@ struct Dev {
     g_stats.device_wait_ms += ck_.ms();
     return b;
   }
+  // GeoSort: bucket := the documents of `universe` within the error margin of the nearest / farthest one, universe -=
+  // bucket; *first = the document whose point is the bucket's value (0xFFFFFFFF: no document has a point, nothing done)
+  Set geo_next(const msi_geo_rule &r, uint32_t cap, double margin, const Set &universe, uint32_t *first, uint64_t *count) {
+    Set b = alloc(), scratch = alloc();  // the bucket is fully overwritten by the kernel
+    Clock ck_;
+    g_stats.launches += 2;
+    ++g_stats.syncs;
+    ck(msi_bits_geo_next(pool.p, r.points, universe->slot, b->slot, scratch->slot, r.lat, r.lng, r.ascending, cap, margin,
+                         first, count));
+    g_stats.device_wait_ms += ck_.ms();
+    return b;
+  }
   // apply_distinct_rule (distinct.rs:19-36) on a COPY of `cands`: {kept candidates, every document of the index that
   // shares a value with one of them}
   std::pair<Set, Set> distinct(const msi_doc_values *vals, const Set &cands, uint64_t *kept) {
@@ -1870,6 +1882,36 @@ struct OrderByRule : Rule {
   void end() override {}
 };
 
+// geo_sort.rs:14-160 over the _geo points in HBM (include/msi.h, msi_geo_points): every bucket is the set of documents
+// within the error margin of the nearest (farthest) one left in the universe; when no document of the universe has a
+// point the rule answers with the whole universe and no value (geo_sort.rs:149-153).  Like Sort it does not look at
+// the query and also orders placeholder searches.
+struct GeoSortRule : Rule {
+  uint32_t idx;
+  msi_geo_rule rule;
+  Graph g;
+  GeoSortRule(uint32_t i, const msi_geo_rule &r) : Rule(R_ORDER_BY, -1), idx(i), rule(r) {}
+  void start(Ctx &, const Set &, const Graph &graph) override { g = graph; }
+  bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) override {
+    if (!universe_count) return false;
+    uint32_t first = 0xFFFFFFFFu;
+    uint64_t n = 0;
+    Set b = c.dev.geo_next(rule, c.prm->geo_max_bucket_size, c.prm->geo_distance_error_margin, universe, &first, &n);
+    out.graph = g;
+    out.score = {MSI_SCORE_GEO_SORT, idx, first};
+    if (first == 0xFFFFFFFFu) {
+      out.docs = c.dev.clone(universe);
+      out.count = universe_count;
+      return true;
+    }
+    out.docs = b;
+    out.count = n;
+    out.universe_reduced = true;
+    return true;
+  }
+  void end() override {}
+};
+
 double global_score(const std::vector<Score> &scores) {
   std::vector<msi_score_detail> d;
   for (const Score &s : scores) d.push_back(msi_score_detail{s.kind, s.a, s.b});
@@ -1881,7 +1923,7 @@ std::vector<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
   std::vector<std::unique_ptr<Rule>> rules;
   bool words = p->strategy == MSI_TERMS_ALL, typo = false, prox = false, attribute = false, attr_rank = false,
        word_pos = false, exact = false;
-  uint32_t n_order = 0;
+  uint32_t n_order = 0, n_geo = 0;
   auto add_words = [&]() {
     if (!words) {
       rules.emplace_back(new GraphRule(R_WORDS, p->strategy));
@@ -1930,7 +1972,12 @@ std::vector<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
           rules.emplace_back(new OrderByRule(n_order, p->order_keys[n_order]));
         ++n_order;
         break;
-      default: break;  // MSI_CRIT_SORT: expanded by the caller into MSI_CRIT_ORDER_BY entries
+      case MSI_CRIT_GEO_SORT:
+        if (n_geo < p->n_geo_rules && p->geo_rules && p->geo_rules[n_geo].points)
+          rules.emplace_back(new GeoSortRule(n_geo, p->geo_rules[n_geo]));
+        ++n_geo;
+        break;
+      default: break;  // MSI_CRIT_SORT: expanded by the caller into MSI_CRIT_ORDER_BY / MSI_CRIT_GEO_SORT entries
     }
   }
   return rules;
@@ -1939,12 +1986,16 @@ std::vector<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
 // get_ranking_rules_for_placeholder_search, mod.rs:352-420: only the Sort / Asc / Desc rules
 std::vector<std::unique_ptr<Rule>> placeholder_rules(const msi_search_params *p) {
   std::vector<std::unique_ptr<Rule>> rules;
-  uint32_t n_order = 0;
+  uint32_t n_order = 0, n_geo = 0;
   for (uint32_t i = 0; i < p->n_criteria; ++i)
     if (p->criteria[i] == MSI_CRIT_ORDER_BY) {
       if (n_order < p->n_order_keys && p->order_keys && p->order_keys[n_order])
         rules.emplace_back(new OrderByRule(n_order, p->order_keys[n_order]));
       ++n_order;
+    } else if (p->criteria[i] == MSI_CRIT_GEO_SORT) {
+      if (n_geo < p->n_geo_rules && p->geo_rules && p->geo_rules[n_geo].points)
+        rules.emplace_back(new GeoSortRule(n_geo, p->geo_rules[n_geo]));
+      ++n_geo;
     }
   return rules;
 }

@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (EXACT_WORD_FN, FID_COUNT_DOCIDS_FN, PAIR_DOCIDS_FN, PREFIX_DOCIDS_FN, PREFIX_KEY_DOCIDS_FN,
+from ._lib import (GeoRule, EXACT_WORD_FN, FID_COUNT_DOCIDS_FN, PAIR_DOCIDS_FN, PREFIX_DOCIDS_FN, PREFIX_KEY_DOCIDS_FN,
                    PREFIX_PAIR_DOCIDS_FN, SYNONYMS_FN, EXACT_PREFIX_FN, WORD_DOCIDS_FN, WORD_KEY_DOCIDS_FN, WORD_KEYS_FN,
                    IndexVtable, KeywordParams, LocatedTerm, QueryToken, RankBucket, ScoreDetail, SearchParams,
                    RankNode, RankQuery, RankTerm, check, lib)
@@ -301,22 +301,26 @@ def keyword_search(gdict, pool, callbacks, words, last_is_prefix=True, strategy=
 
 
 CRITERIA = {"words": 0, "typo": 1, "proximity": 2, "attribute": 3, "attributeRank": 4, "wordPosition": 5,
-            "exactness": 6, "sort": 7, "orderBy": 8}
-SCORE_KINDS = ["Words", "Typo", "Proximity", "Fid", "Position", "ExactAttribute", "ExactWords", "Skipped", "Sort"]
+            "exactness": 6, "sort": 7, "orderBy": 8, "geoSort": 9}
+SCORE_KINDS = ["Words", "Typo", "Proximity", "Fid", "Position", "ExactAttribute", "ExactWords", "Skipped", "Sort", "GeoSort"]
 NO_ORDER_KEY = 0xFFFFFFFF
 
 
 def expand_sort_criteria(criteria, sort=None):
     """What the shim does with Criterion::Sort / Asc / Desc (search/new/mod.rs:366-376,640-720): `sort` of the list
     becomes one rule per field of the request's sort list, `asc:f` / `desc:f` one rule, a field is sorted only once.
-    -> (criteria with "orderBy" entries, [(field, ascending)] of those entries in order)."""
+    A sort entry whose field is ("_geoPoint", lat, lng) becomes a "geoSort" entry (mod.rs:690-712; never deduplicated).
+    -> (criteria with "orderBy" / "geoSort" entries, [(field, ascending)] of the orderBy entries in order); the geo
+    entries, in order, are geo_sort_entries(sort)."""
     out, order, fields, sort_done = [], [], set(), False
     for c in criteria:
         if c == "sort":
             if not sort_done:
                 sort_done = True
                 for f, d in sort or ():
-                    if f not in fields:
+                    if is_geo_point(f):
+                        out.append("geoSort")
+                    elif f not in fields:
                         fields.add(f)
                         out.append("orderBy")
                         order.append((f, d == "asc"))
@@ -329,6 +333,17 @@ def expand_sort_criteria(criteria, sort=None):
         else:
             out.append(c)
     return out, order
+
+
+def is_geo_point(field):
+    return isinstance(field, (tuple, list)) and len(field) == 3 and field[0] == "_geoPoint"
+
+
+def geo_sort_entries(criteria, sort):
+    """[(lat, lng, ascending)] of the "geoSort" entries expand_sort_criteria produces, in order."""
+    return [(float(f[1]), float(f[2]), d == "asc") for f, d in (sort or ()) if is_geo_point(f)] if "sort" in criteria else []
+
+
 MAX_SCORE_DETAILS = 8
 
 
@@ -336,12 +351,13 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
                           detailed=False, searchable_fids=(), searchable_weights=(), max_weight=None,
                           authorize_typos=True, min_one=5, min_two=9, universe_cbo=None, time_budget_us=0,
                           stop_after=None, return_degraded=False, score_threshold=None, order_keys=(), distinct_values=None,
-                          _entry=None):
+                          geo_rules=(), geo_max_bucket_size=0, geo_distance_error_margin=1.0, _entry=None):
     """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
     terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
     (words: [str | None], None = a stop word inside a phrase; an optional 6th element True marks a negative term).
     order_keys: the DocKeys of the "orderBy" entries of `criteria`, in order (expand_sort_criteria).
     distinct_values: the DocValues of the distinct field (None: no distinct).
+    geo_rules: [(GeoPoints, lat, lng, ascending)] of the "geoSort" entries of `criteria`, in order.
     -> ([(docid, [(kind name, a, b)])], candidates)."""
     n = len(terms)
     lt = (LocatedTerm * max(n, 1))()
@@ -375,6 +391,12 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
         prm.order_keys, prm.n_order_keys = C.cast(okeys, C.c_void_p), len(order_keys)
     if distinct_values is not None:
         prm.distinct_values = distinct_values._h
+    if geo_rules:
+        garr = (GeoRule * len(geo_rules))()
+        for i, (pts, lat, lng, asc) in enumerate(geo_rules):
+            garr[i].points, garr[i].lat, garr[i].lng, garr[i].ascending = pts._h, float(lat), float(lng), 1 if asc else 0
+        prm.geo_rules, prm.n_geo_rules = C.cast(garr, C.c_void_p), len(geo_rules)
+    prm.geo_max_bucket_size, prm.geo_distance_error_margin = int(geo_max_bucket_size), float(geo_distance_error_margin)
     L = max(limit, 1)
     ids = np.zeros(L, dtype=np.uint32)
     sc = (ScoreDetail * (L * MAX_SCORE_DETAILS))()

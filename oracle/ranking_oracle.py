@@ -704,8 +704,8 @@ def rank_to_score(kind, rank, max_rank):
 def score_rank(score):
     """ScoreDetails::rank, score_details.rs:103-121."""
     k = score[0]
-    if k == "Sort":
-        return None                       # not rank based: no part in the global score (score_details.rs:113)
+    if k in ("Sort", "GeoSort"):
+        return None                       # not rank based: no part in the global score (score_details.rs:113-114)
     if k == "Skipped":
         return (0, 1)
     if k == "Typo":
@@ -980,6 +980,129 @@ class SortRule:
         return self.graph, set(universe), ("Sort", self.field, self.ascending, ("Null",))
 
 
+EARTH_RADIUS_M = 6371e3
+
+
+def distance_between_two_points(a, b):
+    """lib.rs:388-393 -> geoutils 0.5.1 (Cargo.lock:2836; third party, NOT under /root/reference — restated from the
+    crate's published haversine_distance_to: hav(t) = (1 - cos t) / 2, mean radius 6371 km, rounded to millimetres;
+    parity of the VALUE is unpinned, the reference's geo_sort.rs tests pin the orders it induces)."""
+    import math
+    phi1, phi2 = math.radians(a[0]), math.radians(b[0])
+    lam1, lam2 = math.radians(a[1]), math.radians(b[1])
+
+    def hav(t):
+        return (1.0 - math.cos(t)) / 2.0
+    total = hav(phi2 - phi1) + math.cos(phi1) * math.cos(phi2) * hav(lam2 - lam1)
+    # f64::round = half away from zero; the argument is never negative
+    return math.floor(2.0 * EARTH_RADIUS_M * math.asin(math.sqrt(total)) * 1000.0 + 0.5) / 1000.0
+
+
+def lat_lng_to_xyz(p):
+    """lib.rs:397-404"""
+    import math
+    lat, lng = math.radians(p[0]), math.radians(p[1])
+    return (math.cos(lat) * math.cos(lng), math.cos(lat) * math.sin(lng), math.sin(lat))
+
+
+def opposite_of(p):
+    """documents/geo_sort.rs:279-290"""
+    return (-p[0], p[1] - 180.0 if p[1] > 0.0 else p[1] + 180.0)
+
+
+class GeoSortRule:
+    """search/new/geo_sort.rs:14-160 over documents/geo_sort.rs:66-224 (fill_cache, next_bucket), as written:
+    a cache of (docid, point) in distance order — the iterative strategy sorts ALL candidates by their distance
+    truncated to metres (stable: docid order inside a metre), the rtree strategy takes the `cache_size` nearest to the
+    point (farthest = nearest to its antipode, pushed to the front) in chord-distance order — consumed from the
+    front (asc) or the back (desc); a bucket = the run of cached documents within distance_error_margin of its first
+    one, at most max_bucket_size; what has no _geo comes last with value None.
+    strategy: ("iterative" | "rtree" | "dynamic", cache_size); the rtree's order among equal chord distances is the
+    crate's (rstar) — docid order here."""
+    kind = "geo"
+
+    def __init__(self, point, ascending, strategy=("dynamic", 1000), max_bucket_size=1000, distance_error_margin=1.0):
+        self.point, self.ascending, self.strategy = tuple(float(x) for x in point), ascending, strategy
+        self.max_bucket_size, self.margin = max_bucket_size, distance_error_margin
+
+    def fill_cache(self, geo_candidates):
+        from collections import deque
+        kind, size = self.strategy
+        use_rtree = kind == "rtree" or (kind == "dynamic" and len(geo_candidates) >= size)
+        pts = self.index.geo_points
+        cache = deque()
+        if use_rtree:
+            if self.ascending:
+                q = lat_lng_to_xyz(self.point)
+            else:
+                q = lat_lng_to_xyz(opposite_of(self.point))
+            def d2(d):
+                x = lat_lng_to_xyz(pts[d])
+                return sum((x[i] - q[i]) ** 2 for i in range(3))
+            for d in sorted(geo_candidates, key=lambda d: (d2(d), d)):
+                if self.ascending:
+                    cache.append((d, pts[d]))
+                else:
+                    cache.appendleft((d, pts[d]))
+                if len(cache) >= size:
+                    break
+        else:
+            docs = [(d, pts[d]) for d in sorted(geo_candidates)]
+            docs.sort(key=lambda x: int(distance_between_two_points(self.point, x[1])))   # sort_by_cached_key: stable
+            cache.extend(docs)
+        return cache
+
+    def start_iteration(self, ctx, universe, graph):
+        self.graph, self.index = graph, ctx.index
+        self.geo_faceted = set(ctx.index.geo_points)
+        cands = self.geo_faceted & set(universe)
+        self.cache = self.fill_cache(cands) if cands else __import__("collections").deque()
+
+    def next_bucket(self, universe):
+        def detail(point):
+            return ("GeoSort", self.point, self.ascending, point)
+        cands = self.geo_faceted & set(universe)
+        if not cands:
+            return self.graph, set(universe), detail(None)
+        bucket, cur = set(), None
+        while True:
+            if self.cache:
+                d, pt = self.cache.popleft() if self.ascending else self.cache.pop()
+                if d not in cands:
+                    continue
+                dist = distance_between_two_points(self.point, pt)
+                if cur is not None:
+                    if abs(cur[1] - dist) > self.margin:
+                        if self.ascending:
+                            self.cache.appendleft((d, pt))
+                        else:
+                            self.cache.append((d, pt))
+                        return self.graph, bucket, detail(cur[0])
+                else:
+                    cur = (pt, dist)
+                bucket.add(d)
+                cands.discard(d)
+                if len(bucket) == self.max_bucket_size:
+                    return self.graph, bucket, detail(cur[0])
+            else:
+                self.cache = self.fill_cache(cands)
+                if not self.cache:
+                    if cur is not None:
+                        return self.graph, bucket, detail(cur[0])
+                    return self.graph, set(universe), detail(None)
+
+
+def is_geo(field):
+    return isinstance(field, (tuple, list)) and len(field) == 3 and field[0] == "_geoPoint"
+
+
+GEO_PARAMS = {}   # the request's GeoSortParameter (strategy, max_bucket_size, distance_error_margin) for the next search
+
+
+def geo_rule(field, direction):
+    return GeoSortRule((field[1], field[2]), direction == "asc", **GEO_PARAMS)
+
+
 def sort_rules(criteria, sort):
     """The Sort / Asc / Desc part of the rule list (mod.rs:366-376,640-720), also all there is for a placeholder search
     (get_ranking_rules_for_placeholder_search, mod.rs:352-420).  sort: [(field, "asc" | "desc")] of the request."""
@@ -988,7 +1111,9 @@ def sort_rules(criteria, sort):
         if c == "sort" and not sort_done:
             sort_done = True
             for f, d in sort or ():
-                if f not in fields:
+                if is_geo(f):          # mod.rs:690-712 (`geo_sorted` is never set: every geo member becomes a rule)
+                    out.append((c, geo_rule(f, d)))
+                elif f not in fields:
                     fields.add(f)
                     out.append((c, SortRule(f, d == "asc")))
         elif c.startswith(("asc:", "desc:")):
@@ -1037,7 +1162,9 @@ def ranking_rules(criteria, tms, sort=None):
         elif c == "sort" and not sort_done:
             sort_done = True
             for f, d in sort or ():
-                if f not in sorted_fields:
+                if is_geo(f):
+                    rules.append(geo_rule(f, d))
+                elif f not in sorted_fields:
                     sorted_fields.add(f)
                     rules.append(SortRule(f, d == "asc"))
         elif c.startswith(("asc:", "desc:")):

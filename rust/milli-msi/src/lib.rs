@@ -271,6 +271,9 @@ pub enum RankedScore {
     /// `ScoreDetails::Sort`: `rule` = index into `RankedSearch::order_keys`, `key` = the bucket's order key
     /// (`u32::MAX`: the documents without a value, `value: Null`)
     Sort { rule: u32, key: u32 },
+    /// `ScoreDetails::GeoSort`: `rule` = index into `RankedSearch::geo_rules`; `value` = the `_geo` point of document
+    /// `first_docid` (`geo_value`), `None` for `u32::MAX` (the documents without a point)
+    GeoSort { rule: u32, first_docid: u32 },
 }
 
 pub struct RankedSearch<'a> {
@@ -291,7 +294,29 @@ pub struct RankedSearch<'a> {
     pub order_keys: &'a [&'a DocOrderKeys],
     /// The distinct field of the request or of the index (`distinct_fid`, search/new/distinct.rs:130-147).
     pub distinct: Option<&'a DocFacetValues>,
+    /// One per `sys::MSI_CRIT_GEO_SORT` entry of `criteria`, in order: `AscDesc::{Asc, Desc}(Member::Geo(point))` of the
+    /// request (search/new/mod.rs:690-712), with the request's `GeoSortParameter` (documents/geo_sort.rs:12-30).
+    pub geo_rules: &'a [GeoRule<'a>],
+    pub geo_max_bucket_size: u64,
+    pub geo_distance_error_margin: f64,
 }
+
+pub struct GeoRule<'a> { pub points: &'a DocGeoPoints, pub point: [f64; 2], pub ascending: bool }
+
+/// The `_geo` point of every document in HBM (`msi_geo_points`): `[lat, lng]` per docid, `f64::NAN` latitude for the
+/// documents outside `geo_faceted_documents_ids`.  Built once per index update from `geo_value`
+/// (documents/geo_sort.rs:247-276) over `geo_faceted_documents_ids`.
+pub struct DocGeoPoints(NonNull<sys::msi_geo_points>);
+unsafe impl Send for DocGeoPoints {}
+unsafe impl Sync for DocGeoPoints {}
+impl DocGeoPoints {
+    pub fn new(ctx: &GpuContext, lat_lng: &[[f64; 2]]) -> Result<Self, GpuError> {
+        let mut p = ptr::null_mut();
+        check(unsafe { sys::msi_geo_points_create(ctx.0.as_ptr(), lat_lng.as_ptr() as *const f64, lat_lng.len() as u64, &mut p) })?;
+        Ok(Self(NonNull::new(p).unwrap()))
+    }
+}
+impl Drop for DocGeoPoints { fn drop(&mut self) { unsafe { sys::msi_geo_points_destroy(self.0.as_ptr()) } } }
 
 /// One u32 order key per document in HBM (`msi_doc_keys`): rank of the first facet value of a field that
 /// `ascending_facet_sort` / `descending_facet_sort` meets for the document (sort.rs:95-233), `u32::MAX` without a value.
@@ -420,6 +445,8 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
         is_phrase: (t.is_phrase as u32) | ((t.is_negative as u32) << 1),
         position_start: *t.positions.start() as u32, position_end: *t.positions.end() as u32 }).collect();
     let (fids, weights): (Vec<u16>, Vec<u16>) = q.searchable.iter().copied().unzip();
+    let geo: Vec<sys::msi_geo_rule> = q.geo_rules.iter().map(|r| sys::msi_geo_rule {
+        points: r.points.0.as_ptr() as *const _, lat: r.point[0], lng: r.point[1], ascending: r.ascending as i32 }).collect();
     let order_ptrs: Vec<*const sys::msi_doc_keys> = q.order_keys.iter().map(|k| k.0.as_ptr() as *const _).collect();
     let params = sys::msi_search_params {
         authorize_typos: q.authorize_typos as u32, min_word_len_one_typo: q.min_word_len_one_typo,
@@ -433,7 +460,10 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
         has_score_threshold: q.ranking_score_threshold.is_some() as i32,
         score_threshold: q.ranking_score_threshold.unwrap_or(0.0),
         order_keys: order_ptrs.as_ptr(), n_order_keys: order_ptrs.len() as u32,
-        distinct_values: q.distinct.map_or(ptr::null(), |d| d.0.as_ptr() as *const _) };
+        distinct_values: q.distinct.map_or(ptr::null(), |d| d.0.as_ptr() as *const _),
+        geo_rules: geo.as_ptr(), n_geo_rules: geo.len() as u32,
+        geo_max_bucket_size: q.geo_max_bucket_size.min(u32::MAX as u64) as u32,
+        geo_distance_error_margin: q.geo_distance_error_margin };
     let mut src_ref: Src<'_> = source;
     let vt = sys::msi_index_vtable { user: &mut src_ref as *mut _ as *mut _, word_docids: Some(r_word),
         word_pair_proximity_docids: Some(r_pair), is_exact_word: Some(r_exact), word_fid_docids: Some(r_fid),
@@ -462,6 +492,7 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
             5 => RankedScore::ExactAttribute { rank: d.a },
             6 => RankedScore::ExactWords { matching_words: d.a, max_matching_words: d.b },
             8 => RankedScore::Sort { rule: d.a, key: d.b },
+            9 => RankedScore::GeoSort { rule: d.a, first_docid: d.b },
             _ => RankedScore::Skipped,
         }).collect())
     }).collect();

@@ -8,6 +8,11 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct msi_bits { _p: [u8; 0] }
 #[repr(C)] pub struct msi_doc_keys { _p: [u8; 0] }
 #[repr(C)] pub struct msi_doc_values { _p: [u8; 0] }
+#[repr(C)] pub struct msi_geo_points { _p: [u8; 0] }
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct msi_geo_rule { pub points: *const msi_geo_points, pub lat: f64, pub lng: f64, pub ascending: i32 }
+pub const MSI_CRIT_GEO_SORT: i32 = 9;
+pub const MSI_SCORE_GEO_SORT: u32 = 9;
 pub const MSI_BITS_NO_SLOT: u32 = 0xFFFF_FFFF;
 
 pub const MSI_OK: i32 = 0;
@@ -93,6 +98,8 @@ pub struct msi_search_params {
     pub time_budget_us: u64, pub stop_after: i32, pub has_score_threshold: i32, pub score_threshold: f64,
     pub order_keys: *const *const msi_doc_keys, pub n_order_keys: u32,
     pub distinct_values: *const msi_doc_values,
+    pub geo_rules: *const msi_geo_rule, pub n_geo_rules: u32, pub geo_max_bucket_size: u32,
+    pub geo_distance_error_margin: f64,
 }
 
 extern "C" {
@@ -131,6 +138,11 @@ extern "C" {
     pub fn msi_doc_keys_destroy(k: *mut msi_doc_keys);
     pub fn msi_bits_order_next(p: *mut msi_bits, keys: *const msi_doc_keys, universe: u32, bucket: u32,
                                out_key: *mut u32, out_count: *mut u64) -> i32;
+    pub fn msi_geo_points_create(ctx: *mut msi_ctx, lat_lng: *const f64, n_docs: u64, out: *mut *mut msi_geo_points) -> i32;
+    pub fn msi_geo_points_destroy(g: *mut msi_geo_points);
+    pub fn msi_bits_geo_next(p: *mut msi_bits, points: *const msi_geo_points, universe: u32, bucket: u32, scratch: u32,
+                             lat: f64, lng: f64, ascending: i32, max_bucket_size: u32, distance_error_margin: f64,
+                             out_first_docid: *mut u32, out_count: *mut u64) -> i32;
     pub fn msi_doc_values_create(ctx: *mut msi_ctx, offsets: *const u64, value_ids: *const u32, n_docs: u64, n_values: u32,
                                  out: *mut *mut msi_doc_values) -> i32;
     pub fn msi_doc_values_destroy(v: *mut msi_doc_values);

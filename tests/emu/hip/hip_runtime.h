@@ -14,6 +14,7 @@
 // the __syncthreads waiters are released together.  __shared__ variables are `static` (one workgroup at a time).
 // "Device" memory is host memory filled with 0xCD at allocation so that a read of uninitialised memory shows.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -358,6 +359,8 @@ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+inline long long __double_as_longlong(double d) { return hipemu::from_bits<long long>(hipemu::to_bits(d)); }
+inline double __longlong_as_double(long long v) { return hipemu::from_bits<double>(hipemu::to_bits(v)); }
 inline unsigned __float_as_uint(float f) { return hipemu::from_bits<unsigned>(hipemu::to_bits(f)); }
 inline float __uint_as_float(unsigned u) { return hipemu::from_bits<float>(hipemu::to_bits(u)); }
 

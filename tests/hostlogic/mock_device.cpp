@@ -5,6 +5,7 @@
 // CPU test tier: tests/test_search_hostlogic_cpu.py compiles msi_search.hip together with this file into
 // tests/hostlogic/_build/libmsi_hostlogic_test.so and replays the reference snapshots through it.  The GPU tier
 // (tests/test_search_gpu.py) runs the same cases through the real kernels.
+#include <math.h>
 #include <string.h>
 
 #include <algorithm>
@@ -41,6 +42,10 @@ struct msi_doc_keys {
 struct msi_doc_values {
   std::vector<std::vector<uint32_t>> per_doc;
   uint32_t n_values = 0;
+};
+
+struct msi_geo_points {
+  std::vector<double> lat_lng;
 };
 
 uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
@@ -259,6 +264,48 @@ int32_t msi_bits_set_from_docids(msi_bits *p, uint32_t slot, const uint32_t *doc
   std::fill(p->slot(slot), p->slot(slot) + p->n_words, 0ull);
   for (uint64_t i = 0; i < n; ++i)
     if (docids[i] < p->n_docs) p->slot(slot)[docids[i] >> 6] |= 1ull << (docids[i] & 63);
+  return MSI_OK;
+}
+
+msi_geo_points *mock_geo_points_create(const double *lat_lng, uint64_t n_docs) {
+  msi_geo_points *g = new msi_geo_points();
+  g->lat_lng.assign(lat_lng, lat_lng + 2 * n_docs);
+  return g;
+}
+void mock_geo_points_destroy(msi_geo_points *g) { delete g; }
+
+// documents/geo_sort.rs:150-224 over a cache in exact (distance, docid) order, written as the loop it is
+int32_t msi_bits_geo_next(msi_bits *p, const msi_geo_points *gp, uint32_t universe, uint32_t bucket, uint32_t scratch,
+                          double lat, double lng, int32_t ascending, uint32_t max_bucket_size, double margin,
+                          uint32_t *out_first_docid, uint64_t *out_count) {
+  (void)scratch;
+  const double D2R = 3.14159265358979323846 / 180.0;
+  auto distance = [&](double lat2, double lng2) {  // lib.rs:388-393 -> geoutils haversine_distance_to
+    const double phi1 = lat * D2R, phi2 = lat2 * D2R, lam1 = lng * D2R, lam2 = lng2 * D2R;
+    const double total = (1.0 - cos(phi2 - phi1)) / 2.0 + cos(phi1) * cos(phi2) * ((1.0 - cos(lam2 - lam1)) / 2.0);
+    return round(2.0 * 6371e3 * asin(sqrt(total)) * 1000.0) / 1000.0;
+  };
+  std::vector<std::pair<double, uint32_t>> cache;
+  for (uint64_t d = 0; d < p->n_docs; ++d)
+    if (mock_bit(p, universe, d) && gp->lat_lng[2 * d] == gp->lat_lng[2 * d]) {
+      const double dist = distance(gp->lat_lng[2 * d], gp->lat_lng[2 * d + 1]);
+      cache.push_back({ascending ? dist : -dist, (uint32_t)d});
+    }
+  std::fill(p->slot(bucket), p->slot(bucket) + p->n_words, 0ull);
+  *out_first_docid = 0xFFFFFFFFu;
+  *out_count = 0;
+  if (cache.empty()) return MSI_OK;
+  std::sort(cache.begin(), cache.end());
+  const uint64_t cap = max_bucket_size ? max_bucket_size : 1000;
+  uint64_t n = 0;
+  for (auto &e : cache) {
+    if (fabs(cache[0].first - e.first) > margin || n == cap) break;
+    p->slot(bucket)[e.second >> 6] |= 1ull << (e.second & 63);
+    p->slot(universe)[e.second >> 6] &= ~(1ull << (e.second & 63));
+    ++n;
+  }
+  *out_first_docid = cache[0].second;
+  *out_count = n;
   return MSI_OK;
 }
 

@@ -98,6 +98,13 @@ class EmuHarness(_emu_harness_base()):
     def values_destroy(self, h):
         h.close()
 
+    def points_create(self, lat_lng):
+        import meilisearch_amd as ma
+        return ma.GeoPoints(self.L.ctx, lat_lng)
+
+    def points_destroy(self, h):
+        h.close()
+
 
 # ---- the kernels against numpy: the bodies of the GPU tier ------------------------------------------------------------
 @pytest.mark.parametrize("n_docs", [1, 63, 64, 1000, 20003])
@@ -120,13 +127,20 @@ def test_order_keys(emu, n_docs):
 @pytest.mark.parametrize("kind", ["single", "multi", "chain", "same"])
 @pytest.mark.parametrize("n_docs", [1, 63, 64, 65, 1000, 2003])
 def test_distinct_kernels(emu, n_docs, kind):
-    import tests.test_zz_distinct_gpu as TD
+    import tests.test_zzz_distinct_gpu as TD
     TD.test_distinct_against_the_sequential_loop(n_docs, kind)
 
 
 def test_distinct_scratch_stamps(emu):
-    import tests.test_zz_distinct_gpu as TD
+    import tests.test_zzz_distinct_gpu as TD
     TD.test_many_calls_share_the_scratch_without_clearing_it()
+
+
+@pytest.mark.parametrize("ascending", [True, False], ids=["asc", "desc"])
+@pytest.mark.parametrize("n_docs", [1, 63, 64, 65, 1000])
+def test_geo_kernels(emu, n_docs, ascending):
+    import tests.test_zzz_geo_gpu as TG
+    TG.test_geo_next_against_the_bucket_rule(n_docs, ascending)
 
 
 # ---- the ranked keyword search over the emulated kernels ---------------------------------------------------------------
@@ -150,6 +164,12 @@ def test_sort_rules_over_emulated_kernels(emu, monkeypatch):
 def test_distinct_over_emulated_kernels(emu, monkeypatch):
     import tests.test_search_hostlogic_cpu as H
     H.test_distinct_matches_the_oracle(emu, monkeypatch, "1", fields=("color", "sizes"), setups=H.DISTINCT_SETUPS[1:])
+
+
+def test_geo_sort_over_emulated_kernels(emu):
+    import tests.test_search_hostlogic_cpu as H
+    H.test_geo_sort_rs_through_the_host_logic(emu)
+    H.test_geo_sort_matches_the_oracle(emu, setups=H.GEO_SETUPS[1:4])
 
 
 def test_the_product_library_is_back(emu):

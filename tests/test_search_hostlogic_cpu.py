@@ -47,6 +47,8 @@ def hostlib():
     L.mock_doc_keys_destroy.restype, L.mock_doc_keys_destroy.argtypes = None, [C.c_void_p]
     L.mock_doc_values_create.restype, L.mock_doc_values_create.argtypes = C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
     L.mock_doc_values_destroy.restype, L.mock_doc_values_destroy.argtypes = None, [C.c_void_p]
+    L.mock_geo_points_create.restype, L.mock_geo_points_create.argtypes = C.c_void_p, [C.c_void_p, C.c_uint64]
+    L.mock_geo_points_destroy.restype, L.mock_geo_points_destroy.argtypes = None, [C.c_void_p]
     return L
 
 
@@ -71,7 +73,7 @@ class MockHarness:
 
     # the device objects: test doubles here; the real msi_bits.hip under the HIP emulation in
     # tests/test_kernels_emulated_cpu.py (EmuHarness overrides pool / keys / values), everything real on the
-    # device (tests/test_zz_distinct_gpu.py: DeviceHarness)
+    # device (tests/test_zzz_distinct_gpu.py: DeviceHarness)
     def dict_create(self, index):
         L = self.L
         dic = O.Dictionary(index.words)
@@ -121,12 +123,25 @@ class MockHarness:
     def values_destroy(self, h):
         self.L.mock_doc_values_destroy(h._h)
 
+    def points_create(self, lat_lng):
+        return Handle(self.L.mock_geo_points_create(lat_lng.ctypes.data_as(C.c_void_p), lat_lng.shape[0]))
+
+    def points_destroy(self, h):
+        self.L.mock_geo_points_destroy(h._h)
+
     def search(self, query, tms="last", criteria=None, offset=0, limit=20, detailed=False, stop_after=None, sort=None,
                distinct=None, **kw):
         """sort: the request's [(field, "asc" | "desc")]; Sort details come back as the oracle writes them:
         ("Sort", field, ascending, ("Number", x) | ("String", s) | ("Null",)).  distinct: the distinct field."""
         ix = self.index
         dv = self.values_create(*ix.distinct_values(distinct)) if distinct else None
+        geo = R.geo_sort_entries(criteria if criteria is not None else ix.criteria, sort)
+        points = None
+        if geo:
+            lat_lng = np.full((max(ix.n_docs, 1), 2), np.nan)
+            for d, pt in ix.geo_points.items():
+                lat_lng[d] = pt
+            points = self.points_create(lat_lng)
         crit, order = R.expand_sort_criteria(criteria if criteria is not None else ix.criteria, sort)
         handles, tables = [], []
         for field, asc in order:
@@ -141,13 +156,21 @@ class MockHarness:
                 searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
                 max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,
                 stop_after=stop_after, order_keys=handles, distinct_values=dv, _entry=self.entry,
-                **kw)
+                geo_rules=[(points, lat, lng, asc) for lat, lng, asc in geo], **kw)
         finally:
             for h in handles:
                 self.keys_destroy(h)
             if dv is not None:
                 self.values_destroy(dv)
-        return ([(d, [sort_detail(s, tables) for s in sc]) for d, sc in out[0]],) + tuple(out[1:])
+            if points is not None:
+                self.points_destroy(points)
+
+        def detail(s):
+            if s[0] == "GeoSort":      # (GeoSort, rule index, docid of the bucket's first document): the value is the shim's
+                lat, lng, asc = geo[s[1]]
+                return ("GeoSort", (lat, lng), asc, None if s[2] == R.NO_ORDER_KEY else ix.geo_points[s[2]])
+            return sort_detail(s, tables)
+        return ([(d, [detail(s) for s in sc]) for d, sc in out[0]],) + tuple(out[1:])
 
     def close(self):
         self.pool_destroy(self.pool)
@@ -172,6 +195,10 @@ def debug_score(s):
         v = s[3]
         val = "Null" if v[0] == "Null" else (f"Number({float(v[1])!r})" if v[0] == "Number" else f'String("{v[1]}")')
         return f'Sort(Sort{{field_name:"{s[1]}",ascending:{str(s[2]).lower()},redacted:false,value:{val},}},)'
+    if k == "GeoSort":     # ("GeoSort", target point, ascending, point of the bucket's first document | None)
+        val = "None" if s[3] is None else f"Some([{float(s[3][0])!r},{float(s[3][1])!r},],)"
+        return (f"GeoSort(GeoSort{{target_point:[{float(s[1][0])!r},{float(s[1][1])!r},],ascending:{str(s[2]).lower()},"
+                f"value:{val},}},)")
     if k == "Words":
         return f"Words(Words{{matching_words:{s[1]},max_matching_words:{s[2]},}},)"
     if k == "Typo":
@@ -390,3 +417,99 @@ def test_distinct_matches_the_oracle(hostlib, monkeypatch, per_wait, fields=("co
                     n += 1
     assert n >= 400 or setups is not DISTINCT_SETUPS
     h.close()
+
+
+GEO = json.load(open(os.path.join(ROOT, "tests", "golden", "geo_snapshots.json")))
+
+
+def test_geo_sort_rs_through_the_host_logic(hostlib):
+    """The 18 searches of the reference's geo_sort.rs (docids and the score details of every hit) and the properties of
+    its max-bucket-size test, through msi_keyword_search_ranked."""
+    for case in GEO["cases"]:
+        cfg = GEO["indexes"][case["index"]]
+        index = ToyMilli(cfg["docs"], criteria=cfg["criteria"])
+        h = make_harness(hostlib, index)
+        sort = [(tuple(f) if isinstance(f, list) else f, d) for f, d in case["sort"]]
+        hits, _ = h.search(case["query"], limit=20, detailed=True, sort=sort)
+        assert [index.docs[d]["id"] for d, _ in hits] == case["ids"], (case["src"], case["sort"])
+        assert "[" + "".join("[" + "".join(debug_score(s) + "," for s in sc) + "]," for _, sc in hits) + "]" == case["scores"]
+        if "with_following_ranking_rules" in case["src"] and case["sort"][0][1] == "asc":
+            hits, _ = h.search(case["query"], limit=20, detailed=True, sort=sort, geo_max_bucket_size=2)
+            ext = [index.docs[d]["id"] for d, _ in hits]
+            assert len(ext) == 15 and all(6 <= i <= 11 for i in ext[:6]) and all(12 <= i <= 15 for i in ext[6:10])
+            assert ext[10:] == [1, 4, 3, 2, 5]
+        h.close()
+
+
+def geo_corpus(seed, n_docs):
+    """sortable_corpus plus _geo: places shared by many documents, neighbours decimetres to metres apart (the error
+    margin), a fifth of the documents without a point."""
+    import random
+    rng = random.Random(seed * 13 + 5)
+    docs = sortable_corpus(seed, n_docs)
+    places = [(rng.uniform(-80, 80), rng.uniform(-179, 179)) for _ in range(9)]
+    for d in docs:
+        r = rng.random()
+        if r < 0.2:
+            continue
+        lat, lng = rng.choice(places) if r < 0.7 else (rng.uniform(-89, 89), rng.uniform(-180, 180))
+        if 0.45 < r < 0.7:
+            lat += rng.choice([2e-6, 5e-6, 2e-5, 1e-4])
+        d["_geo"] = {"lat": lat, "lng": lng}
+    return docs
+
+
+GEO_SETUPS = [
+    (["words", "sort", "typo"], [(("_geoPoint", 10.0, 20.0), "asc")], {}),
+    (["words", "sort", "typo"], [(("_geoPoint", -35.5, 140.25), "desc"), ("price", "asc")], {}),
+    (["sort", "words", "proximity"], [("color", "asc"), (("_geoPoint", 0.0, 179.5), "asc")], {}),
+    (["words", "typo", "sort"], [(("_geoPoint", 48.85, 2.35), "asc"), ("price", "desc")], {"geo_max_bucket_size": 4}),
+    (["words", "sort"], [(("_geoPoint", 48.85, 2.35), "desc")], {"geo_distance_error_margin": 5000000.0}),
+]
+
+
+def test_geo_sort_matches_the_oracle(hostlib, setups=GEO_SETUPS, with_distinct=True):
+    """GeoSort between graph-based rules, before / after Sort rules, on placeholder searches, with a small bucket cap,
+    a huge error margin and `distinct`: hits, score details (the value of every bucket) and all_candidates against
+    the oracle's rtree strategy (exact distance order — what the device computes)."""
+    from oracle import ranking_oracle as RO
+    import tests.test_search_gpu as G
+    index = ToyMilli(geo_corpus(3, 240), searchable=["title", "body"])
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    h = make_harness(hostlib, index)
+    n = 0
+    for criteria, sort, geo in setups:
+        for q in ["", "the", "quick fox", "sun fl", "brwn fox jumps"]:
+            for detailed, offset, limit, distinct in ((True, 0, 40, None), (False, 0, 9, None), (True, 11, 9, None),
+                                                       (True, 0, 25, "color")):
+                if distinct and not with_distinct:
+                    continue
+                RO.GEO_PARAMS.clear()
+                RO.GEO_PARAMS.update(strategy=("rtree", 1000))
+                if "geo_max_bucket_size" in geo:
+                    RO.GEO_PARAMS["max_bucket_size"] = geo["geo_max_bucket_size"]
+                if "geo_distance_error_margin" in geo:
+                    RO.GEO_PARAMS["distance_error_margin"] = geo["geo_distance_error_margin"]
+                try:
+                    want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms="last", criteria=criteria,
+                                                             offset=offset, length=limit, detailed=detailed, sort=sort,
+                                                             distinct=distinct)
+                finally:
+                    RO.GEO_PARAMS.clear()
+                hits, cand = h.search(q, criteria=criteria, offset=offset, limit=limit, detailed=detailed, sort=sort,
+                                      distinct=distinct, **geo)
+                assert [d for d, _ in hits] == want_ids, (criteria, sort, geo, q, detailed, offset, distinct)
+                assert [[geo_score(s) for s in sc] for _, sc in hits] == [[geo_score(G.oracle_score(s)) for s in sc] for sc in want_sc]
+                assert cand == len(want_cand)
+                n += 1
+    assert n >= 100 or setups is not GEO_SETUPS
+    h.close()
+
+
+def geo_score(s):
+    s = tuple(s)
+    return (s[0], tuple(s[1]), s[2], None if s[3] is None else tuple(s[3])) if s[0] == "GeoSort" else s

@@ -150,6 +150,12 @@ def device_lib():
         def values_destroy(self, h):
             h.close()
 
+        def points_create(self, lat_lng):
+            return ma.GeoPoints(self.L.ctx, lat_lng)
+
+        def points_destroy(self, h):
+            h.close()
+
     return SimpleNamespace(ctx=ma.Context(0), harness_cls=DeviceHarness,
                            msi_keyword_search_ranked=_lib.lib().msi_keyword_search_ranked)
 

@@ -66,6 +66,13 @@ class ToyMilli:
                 merged.append(d)
         self.docs = merged
         self.n_docs = len(merged)
+        # geo_faceted_documents_ids + the (lat, lng) geo_value reads (documents/geo_sort.rs:247-276): numbers, or
+        # strings that parse as f64
+        self.geo_points = {}
+        for docid, d in enumerate(merged):
+            g = d.get("_geo")
+            if isinstance(g, dict) and "lat" in g and "lng" in g:
+                self.geo_points[docid] = (float(g["lat"]), float(g["lng"]))
         self.fields = {}
         for d in merged:
             for name in d:
