@@ -13,6 +13,12 @@
 
 #define MSI_WAVE 64
 
+// The dynamic LDS of a kernel (the size is the launch's).  tests/emu pre-defines it for the CPU emulation of the HIP
+// runtime, where LDS is a host buffer.
+#ifndef MSI_DYNAMIC_LDS
+#define MSI_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
 void msi_set_error(const char *fmt, ...);
 
 #define MSI_HIP_TRY(expr)                                                          \

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void vs_prep_queries_kernel(
     const float *__restrict__ q, uint32_t nq, uint32_t dim, uint32_t KB, float4 *__restrict__ qfrag,
     bf16x8 *__restrict__ qfrag_bf, float *__restrict__ qrow, float *__restrict__ qn,
     float *__restrict__ inv_qn, float *__restrict__ degth, uint32_t store16) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MSI_DYNAMIC_LDS(smem);
   float *row = reinterpret_cast<float *>(smem);  // [dpad]
   const uint32_t j = blockIdx.x;
   const uint32_t dpad = store16 ? KB * 32 : KB * 16;
@@ -345,7 +345,7 @@ struct ScanArgs {
 //          conversion; LDS holds q_hi and q_lo (2 KiB per 32 columns and query tile).
 template <int WAVES, int NQT, bool DENSE, bool BF3, bool S16>
 __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MSI_DYNAMIC_LDS(smem);
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
   const uint32_t wave = tid >> 6;
@@ -777,7 +777,7 @@ struct RescoreArgs {
 // the expensive part and one workgroup per query leaves the chip idle, so they get their own launch with one
 // thread per (query, candidate); vs_rescore_kernel then only sorts, emits and proves.
 __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_dots_kernel(RescoreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  MSI_DYNAMIC_LDS(dyn);
   float *qs = reinterpret_cast<float *>(dyn);  // [dpad]
   const uint32_t j = blockIdx.y;
   const uint32_t dpad = a.dpad;
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_dots_kernel(RescoreArg
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  MSI_DYNAMIC_LDS(dyn);
   u64 *sbuf = reinterpret_cast<u64 *>(dyn);                          // [KP_MAX]
   float *qs = reinterpret_cast<float *>(dyn + KP_MAX * sizeof(u64)); // [dpad]
   const uint32_t j = blockIdx.x;
@@ -859,7 +859,7 @@ __global__ void vs_exhaustive_kernel(const void *__restrict__ tiles, const float
                                      const float *__restrict__ qrow, const float *__restrict__ qn_p,
                                      uint32_t qj, const u64 *__restrict__ fbits, uint64_t nbits,
                                      u64 *__restrict__ keys, uint32_t dpad, uint32_t s16) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  MSI_DYNAMIC_LDS(dyn);
   float *qs = reinterpret_cast<float *>(dyn);
   for (uint32_t i = threadIdx.x; i < dpad; i += blockDim.x) qs[i] = qrow[(uint64_t)qj * dpad + i];
   __syncthreads();

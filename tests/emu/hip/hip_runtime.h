@@ -1,18 +1,22 @@
 // TEST INFRASTRUCTURE — a CPU stand-in for <hip/hip_runtime.h>, never part of the product.
 //
-// tests/test_kernels_emulated_cpu.py compiles meilisearch_amd/csrc/msi_ctx.hip + msi_bits.hip (and msi_search.hip
-// above them) with g++ against THIS header (-I tests/emu) so that the CPU test tier executes the very kernel source
-// that hipcc compiles for gfx950 — grid/block index arithmetic, wave ballots and shuffles, shared memory, atomics,
-// the "last workgroup publishes" completion protocol — without a GPU.  It checks kernel LOGIC only: it says nothing
-// about speed, memory-model races between workgroups, or code generation.  libmsi.so is never built from it and
-// meilisearch_amd never loads it.
+// tests/emu/run_emulated.py compiles every meilisearch_amd/csrc/*.hip as plain C++ (ROCm clang, -I tests/emu) against
+// THIS header, so that the CPU test tier executes the very kernel source hipcc compiles for gfx950 — grid / block
+// index arithmetic, wave ballots and shuffles, MFMA fragment layouts, LDS (static and dynamic), atomics, the "last
+// workgroup publishes" completion protocol — without a GPU (tests/test_kernels_emulated_cpu.py runs the GPU test
+// files on it).  It checks kernel LOGIC only: it says nothing about speed, memory-model races between workgroups, or
+// code generation.  libmsi.so is never built from it and meilisearch_amd never loads it.
 //
-// Execution model: one OS thread; the workgroups of a launch run one after the other; the threads of a workgroup
-// are ucontext fibers that run until they reach a wave collective (__ballot, __shfl*, __any, __all) or
-// __syncthreads.  When no lane of a 64-wide wave can run, the lanes waiting at a collective exchange their values
-// (lanes that exited or wait elsewhere are inactive, as on the hardware); when nothing in the workgroup can run,
-// the __syncthreads waiters are released together.  __shared__ variables are `static` (one workgroup at a time).
-// "Device" memory is host memory filled with 0xCD at allocation so that a read of uninitialised memory shows.
+// Execution model: the workgroups of a launch run one after the other on the launching thread (launches from
+// several host threads are serialised); the threads of a workgroup are fibers that run until they reach a wave
+// collective (__ballot, __shfl*, __any, __all, readfirstlane, wave_barrier, MFMA) or __syncthreads.  When no lane of a
+// 64-wide wave can run, the lanes waiting at a collective exchange their values (lanes that exited or wait elsewhere
+// are inactive, as on the hardware); when nothing in the workgroup can run, the __syncthreads waiters are released
+// together.  MFMA: D = A x B + C over the wave with the CDNA3/4 fragment layouts (lane l: A[l % 16][K * (l / 16) ..],
+// B[K * (l / 16) ..][l % 16], D[4 * (l / 16) + r][l % 16]); the accumulation order inside one instruction is not the
+// hardware's — the scan it serves is a candidate generator whose results are re-scored in reference arithmetic.
+// __shared__ variables are `static` (one workgroup at a time).  "Device" memory is host memory filled with 0xCD at
+// allocation so that a read of uninitialised memory shows.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -24,6 +28,7 @@
 #include <algorithm>
 #include <chrono>
 #include <functional>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -34,6 +39,7 @@
 #define __forceinline__ inline
 #define __shared__ static
 #define __launch_bounds__(...)
+#define MSI_DYNAMIC_LDS(name) unsigned char *name = hipemu::g.dyn_lds
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
@@ -54,6 +60,8 @@ struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
 inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
@@ -72,6 +80,9 @@ struct hipDeviceProp_t {
 };
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : e == hipErrorOutOfMemory ? "hipErrorOutOfMemory" : "hipError(emulated)"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <typename F>
+inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
@@ -116,7 +127,7 @@ namespace hipemu {
 
 constexpr size_t STACK_BYTES = 64 * 1024;
 enum LaneState { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
-enum WaveOp { OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_SHFL_DOWN, OP_SHFL_UP, OP_ANY, OP_ALL };
+enum WaveOp { OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_SHFL_DOWN, OP_SHFL_UP, OP_ANY, OP_ALL, OP_FIRST, OP_MFMA_F32X4, OP_MFMA_BF16X32 };
 
 // Context switch: on x86-64 six callee-saved registers and the stack pointer (swapcontext would make two signal-mask
 // system calls per switch — most of the run time of this tier); ucontext elsewhere.
@@ -145,6 +156,7 @@ struct Lane {
   int op = 0;
   int param = 0;
   uint64_t value = 0;   // deposited by the lane, replaced by the result
+  float fa[8], fb[8], fc[4];  // MFMA operands of the lane (A and B fragments widened to f32), C in / D out
   void *stack = nullptr;
 };
 
@@ -155,8 +167,11 @@ struct Sched {
   unsigned cur = 0, n = 0;
   uint64_t launches = 0, blocks = 0;
   bool in_kernel = false;
+  unsigned char *dyn_lds = nullptr;   // the launch's dynamic shared memory (16-byte aligned, poisoned per workgroup)
+  size_t dyn_bytes = 0;
 };
 inline Sched g;
+inline std::mutex launch_mu;  // host threads (one search per pool, many in flight) launch one at a time
 
 inline void set_thread(unsigned t) {
   g.cur = t;
@@ -232,6 +247,33 @@ inline void resolve_wave(unsigned w0, unsigned w1) {
       if (in[i]) {
         if (val[i]) { ballot |= 1ull << i; any = true; } else all = false;
       }
+    if (op == OP_MFMA_F32X4 || op == OP_MFMA_BF16X32) {
+      // D = A x B + C over the whole wave (CDNA3/4 ISA fragment layouts): lane l holds A[l % 16][kb .. kb + K),
+      // B[kb .. kb + K)[l % 16] with kb = K * (l / 16) (K = 1 for 16x16x4 f32, 8 for 16x16x32 bf16) and
+      // D[4 * (l / 16) + r][l % 16] in its r-th accumulator register.  A lane that is not here contributes zeros.
+      const int K = op == OP_MFMA_F32X4 ? 1 : 8;
+      float D[16][16];
+      for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+          float acc = 0.f;
+          for (int g4 = 0; g4 < 4; ++g4)
+            for (int t = 0; t < K; ++t) {
+              const unsigned la = (unsigned)(g4 * 16 + i), lb = (unsigned)(g4 * 16 + j);
+              if (w0 + la < w1 && w0 + lb < w1 && in[la] && in[lb]) acc += g.lanes[w0 + la].fa[t] * g.lanes[w0 + lb].fb[t];
+            }
+          D[i][j] = acc;
+        }
+      for (unsigned l = 0; l < w1 - w0; ++l)
+        if (in[l]) {
+          Lane &ln = g.lanes[w0 + l];
+          for (int r = 0; r < 4; ++r) ln.fc[r] += D[4 * (l / 16) + r][l % 16];
+          ln.state = RUNNABLE;
+        }
+      continue;
+    }
+    unsigned first_lane = 64;
+    for (unsigned i = 0; i < 64; ++i)
+      if (in[i]) { first_lane = i; break; }
     for (unsigned i = 0; i < w1 - w0; ++i) {
       if (!in[i]) continue;
       uint64_t r = val[i];
@@ -240,6 +282,7 @@ inline void resolve_wave(unsigned w0, unsigned w1) {
         case OP_BALLOT: r = ballot; break;
         case OP_ANY: r = any; break;
         case OP_ALL: r = all; break;
+        case OP_FIRST: r = val[first_lane]; break;
         case OP_SHFL: src = param & 63; break;
         case OP_SHFL_XOR: src = (int)(i ^ (unsigned)param); break;
         case OP_SHFL_DOWN: src = (int)i + param; break;
@@ -290,7 +333,14 @@ inline void run_block() {
   }
 }
 
-inline void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
+  if (shmem > 160 * 1024) { fprintf(stderr, "hipemu: %zu bytes of LDS requested (160 KiB per workgroup on gfx950)\n", shmem); abort(); }
+  if (shmem > g.dyn_bytes) {
+    free(g.dyn_lds);
+    g.dyn_lds = (unsigned char *)aligned_alloc(16, (shmem + 15) & ~(size_t)15);
+    g.dyn_bytes = shmem;
+  }
+  std::lock_guard<std::mutex> lk(launch_mu);
   if (g.in_kernel) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }
   const unsigned n = block.x * block.y * block.z;
   if (!n || n > 1024) { fprintf(stderr, "hipemu: bad block size %u\n", n); abort(); }
@@ -310,17 +360,18 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
       for (unsigned bx = 0; bx < grid.x; ++bx) {
         blockIdx = dim3(bx, by, bz);
         ++g.blocks;
+        if (shmem) memset(g.dyn_lds, 0xCD, shmem);
         run_block();
       }
   g.in_kernel = false;
 }
 
 template <typename F, typename... A>
-inline void launch_kernel(dim3 grid, dim3 block, F kernel, A... args) {
+inline void launch_kernel(dim3 grid, dim3 block, size_t shmem, F kernel, A... args) {
   // arguments are evaluated once and copied, as a real launch marshals them
   auto packed = std::make_tuple(args...);
   const std::function<void()> body = [&]() { std::apply(kernel, packed); };
-  launch(grid, block, body);
+  launch(grid, block, shmem, body);
 }
 
 template <typename T>
@@ -331,7 +382,7 @@ inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
 }  // namespace hipemu
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  hipemu::launch_kernel(dim3(grid), dim3(block), kernel, ##__VA_ARGS__)
+  hipemu::launch_kernel(dim3(grid), dim3(block), (size_t)(shmem), kernel, ##__VA_ARGS__)
 
 // ---- device intrinsics ----------------------------------------------------------------------------------------------
 inline void __syncthreads() {
@@ -352,6 +403,52 @@ template <typename T>
 inline T __shfl_down(T v, unsigned d, int = 64) { return hipemu::from_bits<T>(hipemu::wave_collective(hipemu::OP_SHFL_DOWN, (int)d, hipemu::to_bits(v))); }
 template <typename T>
 inline T __shfl_up(T v, unsigned d, int = 64) { return hipemu::from_bits<T>(hipemu::wave_collective(hipemu::OP_SHFL_UP, (int)d, hipemu::to_bits(v))); }
+inline void hipemu_wave_barrier() { (void)hipemu::wave_collective(hipemu::OP_ANY, -1, 0); }
+template <typename T>
+inline T hipemu_readfirstlane(T v) { return hipemu::from_bits<T>(hipemu::wave_collective(hipemu::OP_FIRST, 0, hipemu::to_bits(v))); }
+#define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier()
+#define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#if defined(__clang__)
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+inline hipemu_f32x4 hipemu_mfma_f32(float a, float b, hipemu_f32x4 c) {
+  hipemu::Lane &l = hipemu::g.lanes[hipemu::g.cur];
+  l.fa[0] = a; l.fb[0] = b;
+  for (int r = 0; r < 4; ++r) l.fc[r] = c[r];
+  (void)hipemu::wave_collective(hipemu::OP_MFMA_F32X4, 0, 0);
+  hipemu::Lane &m = hipemu::g.lanes[hipemu::g.cur];
+  hipemu_f32x4 d;
+  for (int r = 0; r < 4; ++r) d[r] = m.fc[r];
+  return d;
+}
+inline hipemu_f32x4 hipemu_mfma_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c) {
+  hipemu::Lane &l = hipemu::g.lanes[hipemu::g.cur];
+  for (int t = 0; t < 8; ++t) { l.fa[t] = (float)a[t]; l.fb[t] = (float)b[t]; }
+  for (int r = 0; r < 4; ++r) l.fc[r] = c[r];
+  (void)hipemu::wave_collective(hipemu::OP_MFMA_BF16X32, 0, 0);
+  hipemu::Lane &m = hipemu::g.lanes[hipemu::g.cur];
+  hipemu_f32x4 d;
+  for (int r = 0; r < 4; ++r) d[r] = m.fc[r];
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_f32((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu_mfma_bf16((a), (b), (c))
+#endif
+inline unsigned __funnelshift_r(unsigned lo, unsigned hi, unsigned shift) {
+  return (unsigned)((((unsigned long long)hi << 32) | lo) >> (shift & 31));
+}
+inline unsigned __funnelshift_l(unsigned lo, unsigned hi, unsigned shift) {
+  return (unsigned)(((((unsigned long long)hi << 32) | lo) << (shift & 31)) >> 32);
+}
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline float __fmaf_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+inline float __fdiv_rn(float a, float b) { return a / b; }
+inline float __fsqrt_rn(float a) { return __builtin_sqrtf(a); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }

@@ -1,0 +1,67 @@
+"""TEST INFRASTRUCTURE — runs pytest with libmsi replaced by its CPU-emulated build.
+
+    python tests/emu/run_emulated.py <pytest arguments>
+
+Builds tests/emu/_build/libmsi_emu.so from the product's own sources (every meilisearch_amd/csrc/*.hip, compiled as
+plain C++ by the ROCm clang against tests/emu/hip/hip_runtime.h: fibers for the threads of a workgroup, wave
+collectives, MFMA, atomics, LDS, the stream / memcpy API), makes it what meilisearch_amd._lib.lib() returns IN THIS
+PROCESS ONLY, and hands over to pytest.  tests/test_kernels_emulated_cpu.py starts it as a subprocess so that the GPU
+test files run unchanged — same bodies, fixtures and parameters — in the CPU tier; the product never loads this
+build (meilisearch_amd has no CPU path: on the real libmsi.so `ma.Context` fails without an MI355X).
+It checks kernel LOGIC (indexing, fragment layouts, ballots, completion protocol, stale-slot handling); speed,
+inter-workgroup memory ordering and code generation are the GPU tier's."""
+import ctypes as C
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "meilisearch_amd", "csrc")
+BUILD = os.path.join(ROOT, "tests", "emu", "_build")
+SO = os.path.join(BUILD, "libmsi_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"   # plain C++ mode: ext_vector_type and __bf16 as the kernels spell them
+
+
+def build():
+    sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = sources + [os.path.join(CSRC, "msi_common.h"), os.path.join(ROOT, "include", "msi.h"),
+                      os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h")]
+    if os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps):
+        return SO
+    os.makedirs(BUILD, exist_ok=True)
+    tmp = SO + f".{os.getpid()}.tmp"
+    subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
+                           "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
+                          + sources + ["-Wl,-Bsymbolic", "-o", tmp, "-lpthread"])
+    os.replace(tmp, SO)
+    return SO
+
+
+class EmulatedLib:
+    def __init__(self, path):
+        self._L = C.CDLL(path)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        from meilisearch_amd import _lib
+        fn = getattr(self._L, name)
+        if name in _lib.PROTOTYPES:
+            fn.restype, fn.argtypes = _lib.PROTOTYPES[name]
+        setattr(self, name, fn)
+        return fn
+
+
+def main(argv):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from meilisearch_amd import _lib
+    _lib._LIB = EmulatedLib(build())
+    assert _lib.lib().msi_abi_version() == 1
+    import pytest
+    return pytest.main(argv)
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

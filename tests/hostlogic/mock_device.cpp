@@ -14,9 +14,6 @@
 
 #include "msi_common.h"
 
-// -DMOCK_DICT_ONLY: only the dictionary double is compiled — the docid sets then come from the real msi_bits.hip
-// executed by the CPU emulation of the HIP runtime (tests/emu; tests/test_kernels_emulated_cpu.py).
-#ifndef MOCK_DICT_ONLY
 struct msi_bits {
   uint64_t n_docs = 0, n_words = 0;
   uint32_t n_slots = 0;
@@ -25,7 +22,6 @@ struct msi_bits {
   uint64_t *slot(uint32_t s) { return pool.data() + (uint64_t)s * n_words; }
 };
 
-#endif
 
 typedef int32_t (*mock_lookup_fn)(const uint8_t *word, uint32_t len, uint32_t max_typos, uint32_t is_prefix, uint32_t cap_one,
                                   uint32_t cap_two, uint32_t *one, uint32_t *n_one, uint32_t *two, uint32_t *n_two);
@@ -34,7 +30,6 @@ struct msi_dict {
   mock_lookup_fn lookup = nullptr;
 };
 
-#ifndef MOCK_DICT_ONLY
 struct msi_doc_keys {
   std::vector<uint32_t> keys;
 };
@@ -49,7 +44,6 @@ struct msi_geo_points {
 };
 
 uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
-#endif
 
 bool msi_dict_word(const msi_dict *d, uint32_t idx, const uint8_t **w, uint32_t *len) {
   if (idx >= d->words.size()) return false;
@@ -67,7 +61,6 @@ void msi_dict_prefix_range(const msi_dict *d, const uint8_t *prefix, uint32_t pl
   *hi = b;
 }
 
-#ifndef MOCK_DICT_ONLY
 static uint64_t popcount_slot(msi_bits *p, uint32_t s) {
   uint64_t c = 0;
   for (uint64_t i = 0; i < p->n_words; ++i) c += (uint64_t)__builtin_popcountll(p->slot(s)[i]);
@@ -171,11 +164,9 @@ int32_t msi_bits_paths_collect(msi_bits *p, uint32_t n_regions, uint64_t *counts
   return MSI_OK;
 }
 
-#endif  // MOCK_DICT_ONLY
 
 extern "C" {
 
-#ifndef MOCK_DICT_ONLY
 msi_doc_keys *mock_doc_keys_create(const uint32_t *keys, uint64_t n) {
   msi_doc_keys *k = new msi_doc_keys();
   k->keys.assign(keys, keys + n);
@@ -353,7 +344,6 @@ int32_t msi_bits_first_k(msi_bits *p, uint32_t slot, uint32_t k, uint32_t *out_d
   return MSI_OK;
 }
 
-#endif  // MOCK_DICT_ONLY
 
 int32_t msi_dict_lookup(msi_dict *d, const msi_typo_query *q, uint32_t n, uint32_t cap_one, uint32_t cap_two,
                         uint32_t *out_one_idx, uint32_t *out_one_cnt, uint32_t *out_two_idx, uint32_t *out_two_cnt) {
@@ -367,7 +357,6 @@ int32_t msi_dict_lookup(msi_dict *d, const msi_typo_query *q, uint32_t n, uint32
 }
 
 // ---- constructors for the test harness -----------------------------------------------------------
-#ifndef MOCK_DICT_ONLY
 msi_bits *mock_bits_create(uint64_t n_docs, uint32_t n_slots) {
   msi_bits *p = new msi_bits();
   p->n_docs = n_docs;
@@ -377,7 +366,6 @@ msi_bits *mock_bits_create(uint64_t n_docs, uint32_t n_slots) {
   return p;
 }
 void mock_bits_destroy(msi_bits *p) { delete p; }
-#endif
 msi_dict *mock_dict_create(const uint8_t *concat, const uint32_t *offsets, uint32_t n, mock_lookup_fn lookup) {
   msi_dict *d = new msi_dict();
   for (uint32_t i = 0; i < n; ++i) d->words.emplace_back((const char *)concat + offsets[i], offsets[i + 1] - offsets[i]);

@@ -71,9 +71,9 @@ class MockHarness:
         self.pool = self.pool_create(max(index.n_docs, 1), n_slots)
         self.cb = R.IndexCallbacks(index)
 
-    # the device objects: test doubles here; the real msi_bits.hip under the HIP emulation in
-    # tests/test_kernels_emulated_cpu.py (EmuHarness overrides pool / keys / values), everything real on the
-    # device (tests/test_zzz_distinct_gpu.py: DeviceHarness)
+    # the device objects: test doubles here; the product's own on the device (tests/test_zzz_distinct_gpu.py:
+    # DeviceHarness overrides these hooks — and that file also runs on the CPU emulation of the HIP runtime,
+    # tests/test_kernels_emulated_cpu.py)
     def dict_create(self, index):
         L = self.L
         dic = O.Dictionary(index.words)

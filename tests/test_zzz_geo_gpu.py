@@ -1,6 +1,6 @@
 """GeoSort on the device: msi_bits_geo_next against the bucket rule of documents/geo_sort.rs:150-224
 restated over exact distances, then the rule inside the ranked keyword search against the reference's geo_sort.rs
-snapshots and the oracle.  The same bodies run in the CPU tier on the emulated kernels."""
+snapshots and the oracle.  The same bodies run in the CPU tier on the emulated kernels (tests/test_kernels_emulated_cpu.py)."""
 import json
 import os
 
