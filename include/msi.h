@@ -102,6 +102,18 @@ int32_t msi_vs_upload(msi_vs *vs, const uint32_t *docids, const float *rows,
 int32_t msi_vs_upload_device(msi_vs *vs, const uint32_t *d_docids,
                              const float *d_rows, uint64_t n_rows);
 
+/* SURVEY §8 f2 — apply a committed update to the store without sending it over PCIe again (what
+ * update/new/indexer/write.rs:65-74,157 does to arroy / hannoy: del_item / add_item per document, then a rebuild):
+ * the documents of `remove_docids` leave the store (unknown docids are ignored, as del_item of a missing item is),
+ * the rows of `add_docids` enter it — a docid the store already holds is REPLACED.  Both lists strictly ascending;
+ * `add_rows` row-major [n_add][dim] f32.  Host pointers, borrowed for the call.  Only the two lists, the added rows
+ * and a 4-byte-per-row gather map travel; the device tiles the added rows and re-gathers the store into its next
+ * buffer in one pass (2 x store bytes of HBM traffic; the store occupies twice its size during the call).
+ * Searches on the same context are serialised with it; results afterwards equal those of msi_vs_upload of the
+ * resulting rows bit for bit. */
+int32_t msi_vs_update(msi_vs *vs, const uint32_t *remove_docids, uint64_t n_remove, const uint32_t *add_docids,
+                      const float *add_rows, uint64_t n_add);
+
 uint64_t msi_vs_len(const msi_vs *vs);
 uint32_t msi_vs_dim(const msi_vs *vs);
 /* Queries answered by ONE sweep of the store through HBM (16, 32 or 48: as many

@@ -150,6 +150,7 @@ PROTOTYPES = {
     "msi_vs_destroy": (None, [_VP]),
     "msi_vs_upload": (_I32, [_VP, _VP, _VP, _U64]),
     "msi_vs_upload_device": (_I32, [_VP, _VP, _VP, _U64]),
+    "msi_vs_update": (_I32, [_VP, _VP, _U64, _VP, _VP, _U64]),
     "msi_vs_len": (_U64, [_VP]),
     "msi_vs_dim": (_U32, [_VP]),
     "msi_vs_max_batch": (_U32, [_VP]),

@@ -189,6 +189,32 @@ __global__ void vs_check_sorted_kernel(const uint32_t *__restrict__ docids, uint
   if (i + 1 < n && docids[i] >= docids[i + 1]) *bad = 1;
 }
 
+// Incremental update (msi_vs_update): new 16-byte slot (row r', block kb, column group g) := the same (kb, g) slot of
+// the row it comes from — a row of the old store, or one of the freshly tiled added rows (bit 31 of map[r']).  The
+// tiled layout only permutes whole slots when rows move, so the kernel is the same for f32 and bf16 rows.
+__global__ void vs_regather_kernel(const uint4 *__restrict__ old_tiles, const uint4 *__restrict__ add_tiles,
+                                   const uint32_t *__restrict__ old_docids, const uint32_t *__restrict__ add_docids,
+                                   const uint32_t *__restrict__ map, uint64_t n_new, uint32_t KB,
+                                   uint4 *__restrict__ new_tiles, uint32_t *__restrict__ new_docids) {
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = ((n_new + 15) / 16) * KB * 64;
+  if (idx >= total) return;
+  const uint32_t lane = idx & 63, i = lane & 15, g = lane >> 4;
+  const uint64_t blk = idx >> 6;
+  const uint32_t kb = (uint32_t)(blk % KB);
+  const uint64_t r = (blk / KB) * 16 + i;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  uint32_t docid = 0xFFFFFFFFu;
+  if (r < n_new) {
+    const uint32_t m = map[r], src = m & 0x7FFFFFFFu;
+    const uint4 *from = (m & 0x80000000u) ? add_tiles : old_tiles;
+    v = from[((uint64_t)(src >> 4) * KB + kb) * 64 + g * 16 + (src & 15)];
+    docid = (m & 0x80000000u) ? add_docids[src] : old_docids[src];
+  }
+  new_tiles[idx] = v;
+  if (kb == 0 && g == 0) new_docids[r] = docid;  // padding rows of the last tile included
+}
+
 // ------------------------------------------------------------- query preparation
 
 // One workgroup per query slot j (0 .. 16*nqt): queries row-major [nq][dim] ->
@@ -964,6 +990,7 @@ struct msi_vs {
   bool s16 = false;                // rows stored as bf16 (MSI_VS_BF16)
   uint64_t n_rows = 0, n_tiles = 0;
   DevBuf tiles, norm, inv_norm, docids;
+  DevBuf tiles_next, docids_next, add_tiles, add_docids, row_map;  // msi_vs_update builds the next store beside the current one
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
   // scratch (guarded by ctx->mu)
   DevBuf qraw, qfrag, qfrag_bf, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fbits, out_docids,
@@ -1059,6 +1086,9 @@ int32_t ensure_scratch(msi_vs *vs) {
   return MSI_OK;
 }
 
+int32_t finish_upload(msi_vs *vs, uint64_t n_rows, const char *what);
+int32_t tile_rows(msi_vs *vs, const float *rows, bool rows_on_device, uint64_t n_rows, void *dst);
+
 int32_t upload_common(msi_vs *vs, const uint32_t *docids, bool docids_on_device, const float *rows,
                       bool rows_on_device, uint64_t n_rows) {
   msi_ctx *ctx = vs->ctx;
@@ -1085,7 +1115,13 @@ int32_t upload_common(msi_vs *vs, const uint32_t *docids, bool docids_on_device,
   if (n_rows > 1)
     hipLaunchKernelGGL(vs_check_sorted_kernel, dim3(ceil_div_u32(n_rows, 256)), dim3(256), 0, st,
                        vs->docids.as<uint32_t>(), n_rows, s.bad);
-  // re-tile in chunks (bounded staging memory for host uploads)
+  MSI_TRY(tile_rows(vs, rows, rows_on_device, n_rows, vs->tiles.p));
+  return finish_upload(vs, n_rows, "msi_vs_upload");
+}
+
+// Row-major f32 rows -> the tiled layout at `dst` (f32 or bf16 slots), in chunks: bounded staging for host rows.
+int32_t tile_rows(msi_vs *vs, const float *rows, bool rows_on_device, uint64_t n_rows, void *dst) {
+  hipStream_t st = vs->ctx->stream;
   const uint64_t chunk_rows = rows_on_device ? n_rows : std::max<uint64_t>(16, ((64ull << 20) / (vs->dim * 4ull)) & ~15ull);
   if (!rows_on_device) MSI_TRY(vs->rowtmp.ensure(std::min<uint64_t>(chunk_rows, std::max<uint64_t>(n_rows, 1)) * vs->dim * sizeof(float)));
   for (uint64_t r0 = 0; r0 < n_rows; r0 += chunk_rows) {
@@ -1101,12 +1137,23 @@ int32_t upload_common(msi_vs *vs, const uint32_t *docids, bool docids_on_device,
     const uint64_t total = ((nc + 15) / 16) * vs->KB * 64;
     if (vs->s16)
       hipLaunchKernelGGL(vs_tile_rows_bf16_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, src,
-                         r0, nc, vs->dim, vs->KB, vs->tiles.as<bf16x8>());
+                         r0, nc, vs->dim, vs->KB, reinterpret_cast<bf16x8 *>(dst));
     else
       hipLaunchKernelGGL(vs_tile_rows_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, src,
-                         r0, nc, vs->dim, vs->KB, vs->tiles.as<float4>());
+                         r0, nc, vs->dim, vs->KB, reinterpret_cast<float4 *>(dst));
     if (!rows_on_device) MSI_HIP_TRY(hipStreamSynchronize(st));  // rowtmp is reused
   }
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+// Norms, tile count, the host copy of the docids, candidate lists: what follows the tiling of a store's rows.
+int32_t finish_upload(msi_vs *vs, uint64_t n_rows, const char *what) {
+  msi_ctx *ctx = vs->ctx;
+  hipStream_t st = ctx->stream;
+  const uint64_t n_tiles = (n_rows + 15) / 16;
+  const uint64_t padded = n_tiles * 16;
+  Small s = small_of(vs);
   if (padded && vs->s16)
     hipLaunchKernelGGL(vs_row_norms_bf16_kernel, dim3((uint32_t)((padded + 255) / 256)), dim3(256), 0, st,
                        vs->tiles.p, n_rows, vs->KB, vs->dim, vs->norm.as<float>(), vs->inv_norm.as<float>());
@@ -1130,7 +1177,7 @@ int32_t upload_common(msi_vs *vs, const uint32_t *docids, bool docids_on_device,
   if (bad) {
     vs->n_rows = 0;
     vs->n_tiles = 0;
-    msi_set_error("msi_vs_upload: docids must be strictly ascending");
+    msi_set_error("%s: docids must be strictly ascending", what);
     return MSI_E_NOT_SORTED;
   }
   vs->n_rows = n_rows;
@@ -1420,7 +1467,8 @@ void msi_vs_destroy(msi_vs *vs) {
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qfrag_bf, &vs->qrow,
                       &vs->qsmall, &vs->gkeys, &vs->gcnt, &vs->gsmall, &vs->sel_keys, &vs->dense, &vs->tmask,
-                      &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp, &vs->resc_keys};
+                      &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp, &vs->resc_keys,
+                      &vs->tiles_next, &vs->docids_next, &vs->add_tiles, &vs->add_docids, &vs->row_map};
     for (DevBuf *b : bufs) b->release();
     vs->scan_timer.release();
     delete vs;
@@ -1446,6 +1494,82 @@ int32_t msi_vs_upload_device(msi_vs *vs, const uint32_t *d_docids, const float *
   std::lock_guard<std::mutex> lk(vs->ctx->mu);
   DeviceGuard g(vs->ctx->device);
   return upload_common(vs, d_docids, true, d_rows, true, n_rows);
+}
+
+// SURVEY §8 f2 — what a committed update does to a store (update/new/indexer/write.rs:65-74,157: del_item /
+// add_item per document, then a rebuild of the ANN structure) without sending the store over PCIe again: only the
+// docid lists and the ADDED rows travel; the device tiles the added rows, then re-gathers the whole store into its
+// next buffer in one pass (every 16-byte slot moves as it is), recomputes the norms and swaps.
+int32_t msi_vs_update(msi_vs *vs, const uint32_t *remove_docids, uint64_t n_remove, const uint32_t *add_docids,
+                      const float *add_rows, uint64_t n_add) {
+  if (!vs || (n_remove && !remove_docids) || (n_add && (!add_docids || !add_rows))) {
+    msi_set_error("msi_vs_update: invalid argument");
+    return MSI_E_INVALID;
+  }
+  for (uint64_t i = 1; i < n_remove; ++i)
+    if (remove_docids[i - 1] >= remove_docids[i]) {
+      msi_set_error("msi_vs_update: remove_docids must be strictly ascending");
+      return MSI_E_NOT_SORTED;
+    }
+  for (uint64_t i = 1; i < n_add; ++i)
+    if (add_docids[i - 1] >= add_docids[i]) {
+      msi_set_error("msi_vs_update: add_docids must be strictly ascending");
+      return MSI_E_NOT_SORTED;
+    }
+  std::lock_guard<std::mutex> lk(vs->ctx->mu);
+  DeviceGuard g(vs->ctx->device);
+  hipStream_t st = vs->ctx->stream;
+  // the next store's rows in docid order: an old row that is neither removed nor replaced, or an added row
+  const std::vector<uint32_t> &old = vs->h_docids;
+  std::vector<uint32_t> map;
+  map.reserve(old.size() + n_add);
+  uint64_t io = 0, ir = 0, ia = 0;
+  while (io < old.size() || ia < n_add) {
+    const bool take_add = ia < n_add && (io >= old.size() || add_docids[ia] <= old[io]);
+    if (take_add) {
+      if (io < old.size() && add_docids[ia] == old[io]) ++io;  // replaced
+      map.push_back(0x80000000u | (uint32_t)ia);
+      ++ia;
+      continue;
+    }
+    while (ir < n_remove && remove_docids[ir] < old[io]) ++ir;
+    if (!(ir < n_remove && remove_docids[ir] == old[io])) map.push_back((uint32_t)io);
+    ++io;
+  }
+  const uint64_t n_new = map.size();
+  if (n_new > 0x7FFFFFF0ull || n_add > 0x7FFFFFF0ull) {
+    msi_set_error("msi_vs_update: %llu rows exceed the row index space of an update", (unsigned long long)n_new);
+    return MSI_E_UNSUPPORTED;
+  }
+  const uint64_t n_tiles = (n_new + 15) / 16, padded = n_tiles * 16, add_tiles = (n_add + 15) / 16;
+  const size_t slot = sizeof(uint4);
+  MSI_TRY(vs->tiles_next.ensure(std::max<uint64_t>(1, n_tiles) * vs->KB * 64 * slot));
+  MSI_TRY(vs->docids_next.ensure(std::max<uint64_t>(16, padded) * sizeof(uint32_t)));
+  MSI_TRY(vs->add_tiles.ensure(std::max<uint64_t>(1, add_tiles) * vs->KB * 64 * slot));
+  MSI_TRY(vs->add_docids.ensure(std::max<uint64_t>(1, n_add) * sizeof(uint32_t)));
+  MSI_TRY(vs->row_map.ensure(std::max<uint64_t>(1, n_new) * sizeof(uint32_t)));
+  MSI_TRY(vs->norm.ensure(std::max<uint64_t>(16, padded) * sizeof(float)));
+  MSI_TRY(vs->inv_norm.ensure(std::max<uint64_t>(16, padded) * sizeof(float)));
+  MSI_TRY(ensure_scratch(vs));
+  if (n_add) {
+    MSI_TRY(tile_rows(vs, add_rows, false, n_add, vs->add_tiles.p));
+    MSI_HIP_TRY(hipMemcpyAsync(vs->add_docids.p, add_docids, n_add * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  }
+  if (n_new) MSI_HIP_TRY(hipMemcpyAsync(vs->row_map.p, map.data(), n_new * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  MSI_HIP_TRY(hipMemsetAsync(vs->docids_next.p, 0xFF, std::max<uint64_t>(16, padded) * sizeof(uint32_t), st));
+  const uint64_t total = n_tiles * vs->KB * 64;
+  if (total)
+    hipLaunchKernelGGL(vs_regather_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st,
+                       vs->tiles.as<uint4>(), vs->add_tiles.as<uint4>(), vs->docids.as<uint32_t>(),
+                       vs->add_docids.as<uint32_t>(), vs->row_map.as<uint32_t>(), n_new, vs->KB,
+                       vs->tiles_next.as<uint4>(), vs->docids_next.as<uint32_t>());
+  MSI_HIP_TRY(hipGetLastError());
+  MSI_HIP_TRY(hipStreamSynchronize(st));  // `map` and the borrowed lists are done with; searches hold the same lock
+  std::swap(vs->tiles, vs->tiles_next);
+  std::swap(vs->docids, vs->docids_next);
+  Small s = small_of(vs);
+  MSI_HIP_TRY(hipMemsetAsync(s.bad, 0, sizeof(uint32_t), st));
+  return finish_upload(vs, n_new, "msi_vs_update");
 }
 
 uint64_t msi_vs_len(const msi_vs *vs) { return vs ? vs->n_rows : 0; }

@@ -43,6 +43,16 @@ class GpuStore:
         assert rows.shape[0] == docids.shape[0]
         check(lib().msi_vs_upload(self._h, np_ptr(docids), np_ptr(rows), docids.shape[0]))
 
+    def update(self, remove_docids=(), add_docids=(), add_rows=None):
+        """msi_vs_update: the documents of remove_docids leave the store, the rows of add_docids enter it (an existing
+        docid is replaced); both lists strictly ascending.  Only the delta travels over PCIe."""
+        rm = np.ascontiguousarray(remove_docids, dtype=np.uint32)
+        ad = np.ascontiguousarray(add_docids, dtype=np.uint32)
+        rows = np.ascontiguousarray(add_rows if add_rows is not None else np.zeros((0, self.dim)), dtype=np.float32).reshape(-1, self.dim)
+        assert rows.shape[0] == ad.shape[0]
+        check(lib().msi_vs_update(self._h, np_ptr(rm) if rm.size else None, rm.size, np_ptr(ad) if ad.size else None,
+                                  np_ptr(rows) if ad.size else None, ad.size))
+
     def upload_device(self, docids_t, rows_t):
         """docids_t: cuda int32/uint32-compatible tensor, rows_t: cuda f32 [n, dim]."""
         assert rows_t.is_cuda and rows_t.is_contiguous() and docids_t.is_cuda

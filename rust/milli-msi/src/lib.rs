@@ -58,6 +58,13 @@ impl GpuVectorStore {
         assert_eq!(rows.len(), docids.len() * self.dim);
         check(unsafe { sys::msi_vs_upload(self.h.as_ptr(), docids.as_ptr(), rows.as_ptr(), docids.len() as u64) })
     }
+    /// A committed update (update/new/indexer/write.rs:65-74,157: `del_item` / `add_item` per document): `remove` leaves
+    /// the store, `add` enters it (an existing docid is replaced); both strictly ascending.  Only the delta crosses PCIe.
+    pub fn update(&mut self, remove: &[u32], add_docids: &[u32], add_rows: &[f32]) -> Result<(), GpuError> {
+        assert_eq!(add_rows.len(), add_docids.len() * self.dim);
+        check(unsafe { sys::msi_vs_update(self.h.as_ptr(), remove.as_ptr(), remove.len() as u64, add_docids.as_ptr(),
+                                          add_rows.as_ptr(), add_docids.len() as u64) })
+    }
     /// `VectorStore::nns_by_vector` for this store (crates/milli/src/vector/store.rs:638-675).
     pub fn nns_by_vector(&self, vector: &[f32], limit: usize, filter: Option<&RoaringBitmap>,
                          cancel: Option<&std::sync::atomic::AtomicI32>) -> Result<Vec<(u32, f32)>, GpuError> {

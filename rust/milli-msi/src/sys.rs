@@ -112,6 +112,8 @@ extern "C" {
     pub fn msi_vs_create(ctx: *mut msi_ctx, dim: u32, out: *mut *mut msi_vs) -> i32;
     pub fn msi_vs_create_typed(ctx: *mut msi_ctx, dim: u32, storage: i32, out: *mut *mut msi_vs) -> i32;
     pub fn msi_vs_destroy(vs: *mut msi_vs);
+    pub fn msi_vs_update(vs: *mut msi_vs, remove_docids: *const u32, n_remove: u64, add_docids: *const u32,
+                         add_rows: *const f32, n_add: u64) -> i32;
     pub fn msi_vs_upload(vs: *mut msi_vs, docids: *const u32, rows: *const f32, n_rows: u64) -> i32;
     pub fn msi_vs_len(vs: *const msi_vs) -> u64;
     pub fn msi_vs_dim(vs: *const msi_vs) -> u32;
