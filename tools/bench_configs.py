@@ -401,9 +401,123 @@ def run_rank(args):
                           "first": got[:3]}), flush=True)
 
 
+def run_rules(args):
+    """Per-bucket cost of the rules that read per-document arrays: Sort (order keys), distinct
+    (single- and multi-valued CSR) and GeoSort over `rows` documents — milliseconds per call and algorithmic
+    GB/s (DESIGN §4.8-4.10 give the byte counts).  No torch needed."""
+    import meilisearch_amd as ma
+    ctx = ma.Context(0)
+    n = args.rows
+    rng = np.random.default_rng(11)
+    pool = ma.BitsPool(ctx, n, 8)
+    words = (n + 63) // 64
+
+    def set_density(slot, p):
+        bits = rng.random(words * 64) < p
+        bits[n:] = False
+        pool.set_from_words(slot, np.packbits(bits, bitorder="little").view(np.uint64))
+    out = []
+    # Sort: 1000 distinct keys, a tenth without a value
+    keys = rng.integers(0, 1000, n).astype(np.uint32)
+    keys[rng.random(n) < 0.1] = 0xFFFFFFFF
+    dk = ma.DocKeys(ctx, keys)
+    for dens in (1.0, 0.1, 0.001):
+        def step():
+            set_density(0, dens)
+            return pool.order_next(dk, 0, 1)
+        set_density(0, dens)
+        t = []
+        for _ in range(args.reps):
+            set_density(0, dens)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            pool.order_next(dk, 0, 1)
+            t.append((time.perf_counter() - t0) * 1e3)
+        ms = statistics.median(t)
+        by = 2 * (n / 8 + 4 * n * dens)
+        out.append({"rule": "sort", "universe_density": dens, "p50_ms_per_bucket": round(ms, 4),
+                    "algorithmic_GBps": round(by / ms / 1e6, 1)})
+    # distinct: single-valued (n / 4 values) and multi-valued (0..3 of n / 3 values)
+    single = [[int(v)] for v in rng.integers(0, max(1, n // 4), n)]
+    multi_counts = rng.integers(0, 4, n)
+    multi_vals = rng.integers(0, max(1, n // 3), int(multi_counts.sum()))
+    multi, o = [], 0
+    for c in multi_counts.tolist():
+        multi.append(sorted(set(multi_vals[o:o + c].tolist())))
+        o += c
+    for name, per_doc, nv in (("single", single, max(1, n // 4)), ("multi", multi, max(1, n // 3))):
+        dv = ma.DocValues(ctx, per_doc, nv)
+        for dens in (1.0, 0.01):
+            t, rounds = [], 0
+            for _ in range(args.reps):
+                set_density(0, dens)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                _, rounds, seq = pool.distinct(dv, 0, 1, 2)
+                ctx.synchronize()
+                t.append((time.perf_counter() - t0) * 1e3)
+            out.append({"rule": "distinct", "values": name, "candidate_density": dens, "rounds": rounds, "sequential": seq,
+                        "p50_ms_per_application": round(statistics.median(t), 4)})
+        dv.close()
+    # GeoSort: uniform points, a fifth without
+    pts = np.column_stack([rng.uniform(-90, 90, n), rng.uniform(-180, 180, n)])
+    pts[rng.random(n) < 0.2] = np.nan
+    gp = ma.GeoPoints(ctx, pts)
+    for dens in (1.0, 0.01):
+        t = []
+        for _ in range(args.reps):
+            set_density(0, dens)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            pool.geo_next(gp, 0, 1, 2, 48.85, 2.35)
+            t.append((time.perf_counter() - t0) * 1e3)
+        ms = statistics.median(t)
+        out.append({"rule": "geoSort", "universe_density": dens, "p50_ms_per_bucket": round(ms, 4),
+                    "algorithmic_GBps": round(2 * (n / 8 + 16 * n * dens * 0.8) / ms / 1e6, 1)})
+    for o_ in out:
+        print(json.dumps(dict(config="rules", docs=n, **o_)), flush=True)
+
+
+def run_update(args):
+    """msi_vs_update against a full re-upload: `rows` x `dim`, 1 % of the rows replaced + 1 % removed +
+    1 % added per commit.  Reports milliseconds per commit, the bytes that crossed PCIe and the HBM rate of the
+    re-gather (2 x store bytes)."""
+    import meilisearch_amd as ma
+    ctx = ma.Context(0)
+    n, d = args.rows, args.dim
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    ids = (np.arange(n, dtype=np.uint32) * 2)
+    st = ma.GpuStore(ctx, d, storage=args.storage)
+    t0 = time.perf_counter()
+    st.upload(ids, rows)
+    ctx.synchronize()
+    full_ms = (time.perf_counter() - t0) * 1e3
+    m = max(1, n // 100)
+    t = []
+    for rep in range(args.reps):
+        rm = np.sort(rng.choice(ids, m, replace=False))
+        repl = np.sort(rng.choice(ids, m, replace=False))
+        new = np.sort(rng.choice(np.arange(1, 2 * n, 2, dtype=np.uint32), m, replace=False))
+        ad = np.union1d(repl, new).astype(np.uint32)
+        ad_rows = rng.standard_normal((ad.size, d)).astype(np.float32)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        st.update(rm, ad, ad_rows)
+        ctx.synchronize()
+        t.append((time.perf_counter() - t0) * 1e3)
+    ms = statistics.median(t)
+    elem = 2 if args.storage == "bf16" else 4
+    store_bytes = len(st) * d * elem
+    print(json.dumps({"config": "update", "rows": n, "dim": d, "storage": args.storage, "full_upload_ms": round(full_ms, 2),
+                      "update_p50_ms": round(ms, 3), "pcie_bytes_per_update": int(ad.size * d * 4 + 4 * (rm.size + ad.size + len(st))),
+                      "pcie_bytes_full_upload": int(n * d * 4 + 4 * n),
+                      "regather_GBps": round(2 * store_bytes / ms / 1e6, 1), "rows_after": len(st)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered", "c5", "ranked"])
+    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered", "c5", "ranked", "rules", "update"])
     ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--rows", type=int, default=1_000_000)
@@ -418,7 +532,8 @@ def main():
     args = ap.parse_args()
     if args.batches is None:
         args.batches = [1, 16, 48, 240] if args.config != "c3" else [1, 64, 1024, 8192]
-    {"c2": run_c2, "c3": run_c3, "rank": run_rank, "filtered": run_filtered, "c5": run_c5, "ranked": run_ranked}[args.config](args)
+    {"c2": run_c2, "c3": run_c3, "rank": run_rank, "filtered": run_filtered, "c5": run_c5, "ranked": run_ranked,
+     "rules": run_rules, "update": run_update}[args.config](args)
 
 
 if __name__ == "__main__":
