@@ -390,6 +390,35 @@ int32_t msi_bits_geo_next(msi_bits *pool, const msi_geo_points *points, uint32_t
                           uint32_t scratch /* a third slot: used when more than max_bucket_size documents fit */,
                           double lat, double lng, int32_t ascending, uint32_t max_bucket_size,
                           double distance_error_margin, uint32_t *out_first_docid, uint64_t *out_count);
+/* SURVEY §8 f1 — the LEAVES of a filter on the device (crates/milli/src/search/facet/filter/index_filter.rs:84-340,
+ * value_bounds.rs): instead of walking the facet levels of facet_id_f64_docids / facet_id_string_docids per
+ * condition (facet_range_search.rs) and densifying the resulting Roaring bitmap for the scan, the facet values of a
+ * filterable field live in HBM per document — CSR of u64 SORT KEYS, one table per (field, kind):
+ *   numbers: msi_facet_number_key(x), a monotone map f64 -> u64 (x < y <=> key(x) < key(y); -0.0 == +0.0 is the
+ *            caller's: milli stores what the document holds),
+ *   strings: the rank of the normalised value (normalize_facet, lib.rs:442-444) among the field's distinct values in
+ *            byte order — what facet_id_string_fst enumerates — so that a string range, `STARTS WITH` (the range
+ *            [prefix, prefix with its last byte + 1), index_filter.rs:198-250) and `=` are rank intervals the shim
+ *            finds with two dictionary lookups, and `CONTAINS` / `IN` are rank lists.
+ * msi_bits_facet_range: dst := {d : some key of d lies in [lo, hi]} (accumulate != 0: dst |= ...).  Exclusive bounds
+ * are the neighbouring keys (lo + 1 / hi - 1); an empty interval (lo > hi) selects nothing (index_filter.rs:315-321).
+ * msi_bits_facet_in: the same for a strictly ascending list of keys.  AND / OR / NOT of the expression are
+ * msi_bits_op over the leaves' slots; EXISTS / IS NULL / IS EMPTY are the index's own bitmaps (msi_bits_set_from_cbo).
+ * msi_bits_geo_within: dst := the documents of `src` whose _geo point is within radius_m + f64::EPSILON metres of
+ * (lat, lng) — `_geoRadius`, index_filter.rs:465-503 (distance_between_two_points over every point instead of the
+ * R-tree's nearest-neighbour walk; `_geoBoundingBox` is two msi_bits_facet_range over the _geo.lat / _geo.lng
+ * tables, as index_filter.rs:531-690 does with its own Between conditions). */
+typedef struct msi_facet_keys msi_facet_keys;
+uint64_t msi_facet_number_key(double value);
+int32_t msi_facet_keys_create(msi_ctx *ctx, const uint64_t *offsets /* [n_docs + 1] */, const uint64_t *keys,
+                              uint64_t n_docs, msi_facet_keys **out);
+void msi_facet_keys_destroy(msi_facet_keys *keys);
+int32_t msi_bits_facet_range(msi_bits *pool, const msi_facet_keys *keys, uint64_t lo, uint64_t hi, uint32_t dst,
+                             int32_t accumulate);
+int32_t msi_bits_facet_in(msi_bits *pool, const msi_facet_keys *keys, const uint64_t *sorted_keys, uint64_t n,
+                          uint32_t dst, int32_t accumulate);
+int32_t msi_bits_geo_within(msi_bits *pool, const msi_geo_points *points, uint32_t src, double lat, double lng,
+                            double radius_m, uint32_t dst);
 int32_t msi_bits_set_from_words(msi_bits *pool, uint32_t slot,
                                 const uint64_t *words, uint64_t n_words);
 int32_t msi_bits_fill(msi_bits *pool, uint32_t slot, int32_t ones);

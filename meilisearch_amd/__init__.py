@@ -9,6 +9,6 @@ from ._lib import MsiError, abi_version, lib, lib_path  # noqa: F401
 from .device import Context, DeviceBuffer  # noqa: F401
 from .vector_store import GpuStore, VectorStore, dense_filter  # noqa: F401
 from .typo import GpuDictionary, number_of_typos_allowed, pack_queries  # noqa: F401
-from .bits import BitsPool, DocKeys, DocValues, GeoPoints  # noqa: F401
+from .bits import BitsPool, DocKeys, DocValues, FacetKeys, GeoPoints, facet_number_key  # noqa: F401
 from . import scoring  # noqa: F401
 from . import ranking  # noqa: F401

@@ -173,6 +173,12 @@ PROTOTYPES = {
     "msi_doc_keys_create": (_I32, [_VP, _VP, C.c_uint64, C.POINTER(_VP)]),
     "msi_doc_keys_destroy": (None, [_VP]),
     "msi_bits_order_next": (_I32, [_VP, _VP, _U32, _U32, C.POINTER(_U32), C.POINTER(C.c_uint64)]),
+    "msi_facet_number_key": (_U64, [_F64]),
+    "msi_facet_keys_create": (_I32, [_VP, _VP, _VP, C.c_uint64, C.POINTER(_VP)]),
+    "msi_facet_keys_destroy": (None, [_VP]),
+    "msi_bits_facet_range": (_I32, [_VP, _VP, _U64, _U64, _U32, _I32]),
+    "msi_bits_facet_in": (_I32, [_VP, _VP, _VP, _U64, _U32, _I32]),
+    "msi_bits_geo_within": (_I32, [_VP, _VP, _U32, _F64, _F64, _F64, _U32]),
     "msi_geo_points_create": (_I32, [_VP, _VP, C.c_uint64, C.POINTER(_VP)]),
     "msi_geo_points_destroy": (None, [_VP]),
     "msi_bits_geo_next": (_I32, [_VP, _VP, _U32, _U32, _U32, _F64, _F64, _I32, _U32, _F64, C.POINTER(_U32),

@@ -55,6 +55,18 @@ class BitsPool:
         check(lib().msi_bits_order_next(self._h, keys._h, universe, bucket, C.byref(key), C.byref(n)))
         return int(key.value), int(n.value)
 
+    def facet_range(self, keys, lo, hi, dst, accumulate=False):
+        """dst (|)= the documents with a facet key in [lo, hi] (msi_bits_facet_range; index_filter.rs:139-153)."""
+        check(lib().msi_bits_facet_range(self._h, keys._h, int(lo), int(hi), dst, 1 if accumulate else 0))
+
+    def facet_in(self, keys, sorted_keys, dst, accumulate=False):
+        k = np.ascontiguousarray(sorted_keys, dtype=np.uint64)
+        check(lib().msi_bits_facet_in(self._h, keys._h, np_ptr(k) if k.size else None, k.size, dst, 1 if accumulate else 0))
+
+    def geo_within(self, points, src, lat, lng, radius_m, dst):
+        """dst := the documents of src within radius_m metres of (lat, lng): `_geoRadius` (index_filter.rs:465-503)."""
+        check(lib().msi_bits_geo_within(self._h, points._h, src, float(lat), float(lng), float(radius_m), dst))
+
     def geo_next(self, points, universe, bucket, scratch, lat, lng, ascending=True, max_bucket_size=1000, margin=1.0):
         """GeoSort's next bucket (documents/geo_sort.rs:150-224): the documents of `universe` within `margin` metres of
         the nearest (farthest) one, at most max_bucket_size; universe -= bucket.
@@ -178,6 +190,36 @@ class GeoPoints:
     def close(self):
         if self._h:
             lib().msi_geo_points_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def facet_number_key(x):
+    """The monotone f64 -> u64 map of the number tables (msi_facet_number_key)."""
+    return int(lib().msi_facet_number_key(float(x)))
+
+
+class FacetKeys:
+    """The facet values of one filterable field and kind per document, CSR of u64 sort keys in HBM
+    (msi_facet_keys_create).  per_doc: one sequence of keys per document."""
+
+    def __init__(self, ctx, per_doc):
+        self.ctx = ctx
+        self.offsets = np.zeros(len(per_doc) + 1, dtype=np.uint64)
+        np.cumsum([len(v) for v in per_doc], out=self.offsets[1:])
+        flat = [int(x) for v in per_doc for x in v]
+        self.keys = np.array(flat if flat else [0], dtype=np.uint64)
+        self._h = C.c_void_p()
+        check(lib().msi_facet_keys_create(ctx.handle, np_ptr(self.offsets), np_ptr(self.keys), len(per_doc), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().msi_facet_keys_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -65,6 +65,13 @@ struct msi_geo_points {
   DevBuf lat_lng;
 };
 
+// The facet values of one filterable field and kind (numbers | strings) per document: CSR of u64 sort keys
+struct msi_facet_keys {
+  msi_ctx *ctx = nullptr;
+  uint64_t n_docs = 0;
+  DevBuf offsets, keys;  // u32 [n_docs + 1], u64 [offsets[n_docs]]
+};
+
 // One u32 order key per document, resident in HBM (msi_doc_keys_create)
 struct msi_doc_keys {
   msi_ctx *ctx = nullptr;
@@ -461,6 +468,42 @@ __global__ void bits_geo_take_kernel(u64 *__restrict__ src, u64 *__restrict__ ds
       __hip_atomic_store(const_cast<uint64_t *>(&sig[2]), f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(const_cast<uint64_t *>(&sig[3]), kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(const_cast<uint64_t *>(&sig[1]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// ---- filter leaves (crates/milli/src/search/facet/filter/index_filter.rs:84-340) ---------------------------------------
+// dst (|)= {d : some key of d is in [lo, hi]} — or, with a sorted list, is one of its n keys.  One document per thread,
+// the wave's ballot is the word of the set.
+__global__ void bits_facet_select_kernel(u64 *__restrict__ dst, const uint32_t *__restrict__ offsets,
+                                         const u64 *__restrict__ keys, uint64_t n_docs, uint64_t n_words, u64 lo, u64 hi,
+                                         const u64 *__restrict__ list, uint64_t n_list, int accumulate) {
+  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t w = d >> 6;
+  bool hit = false;
+  if (d < n_docs) {
+    const uint32_t b = offsets[d], e = offsets[d + 1];
+    for (uint32_t i = b; i < e && !hit; ++i) {
+      const u64 k = keys[i];
+      if (!list) {
+        hit = k >= lo && k <= hi;
+      } else {
+        uint64_t a = 0, z = n_list;  // lower bound
+        while (a < z) {
+          const uint64_t m = (a + z) >> 1;
+          if (list[m] < k) a = m + 1;
+          else z = m;
+        }
+        hit = a < n_list && list[a] == k;
+      }
+    }
+  }
+  const u64 mask = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && w < n_words) {
+    if (accumulate) {
+      if (mask) dst[w] |= mask;
+    } else {
+      dst[w] = mask;
     }
   }
 }
@@ -1929,6 +1972,146 @@ int32_t msi_bits_geo_next(msi_bits *p, const msi_geo_points *gp, uint32_t univer
   *out_first_docid = (uint32_t)first;
   *out_count = count;
   return MSI_OK;
+}
+
+uint64_t msi_facet_number_key(double value) {
+  uint64_t b;
+  memcpy(&b, &value, sizeof(b));
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // the order of the doubles (OrderedF64Codec sorts the same way)
+}
+
+int32_t msi_facet_keys_create(msi_ctx *ctx, const uint64_t *offsets, const uint64_t *keys, uint64_t n_docs,
+                              msi_facet_keys **out) {
+  if (!ctx || !out || !n_docs || !offsets || offsets[0] != 0 || (offsets[n_docs] && !keys)) {
+    msi_set_error("msi_facet_keys_create: invalid argument");
+    return MSI_E_INVALID;
+  }
+  *out = nullptr;
+  const uint64_t total = offsets[n_docs];
+  if (total >= 0xFFFFFFFFull) {
+    msi_set_error("msi_facet_keys_create: %llu (document, value) pairs; the device layout holds < 2^32",
+                  (unsigned long long)total);
+    return MSI_E_UNSUPPORTED;
+  }
+  std::vector<uint32_t> off32(n_docs + 1);
+  for (uint64_t d = 0; d <= n_docs; ++d) {
+    if (d && offsets[d] < offsets[d - 1]) {
+      msi_set_error("msi_facet_keys_create: offsets decrease at document %llu", (unsigned long long)d);
+      return MSI_E_INVALID;
+    }
+    off32[d] = (uint32_t)offsets[d];
+  }
+  DeviceGuard g(ctx->device);
+  msi_facet_keys *f = new msi_facet_keys();
+  f->ctx = ctx;
+  f->n_docs = n_docs;
+  int32_t st = f->offsets.ensure((size_t)(n_docs + 1) * sizeof(uint32_t));
+  if (st == MSI_OK) st = f->keys.ensure(std::max<size_t>(1, (size_t)total) * sizeof(u64));
+  if (st == MSI_OK) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipError_t e = hipMemcpyAsync(f->offsets.p, off32.data(), (size_t)(n_docs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e == hipSuccess && total)
+      e = hipMemcpyAsync(f->keys.p, keys, (size_t)total * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      msi_set_error("msi_facet_keys_create: upload failed: %s", hipGetErrorString(e));
+      st = MSI_E_HIP;
+    }
+  }
+  if (st != MSI_OK) {
+    f->offsets.release();
+    f->keys.release();
+    delete f;
+    return st;
+  }
+  msi_ctx_retain(ctx);
+  *out = f;
+  return MSI_OK;
+}
+
+void msi_facet_keys_destroy(msi_facet_keys *f) {
+  if (!f) return;
+  {
+    DeviceGuard g(f->ctx->device);
+    f->offsets.release();
+    f->keys.release();
+  }
+  msi_ctx_release(f->ctx);
+  delete f;
+}
+
+static int32_t facet_select(msi_bits *p, const msi_facet_keys *f, u64 lo, u64 hi, const uint64_t *list, uint64_t n_list,
+                            uint32_t dst, int32_t accumulate, const char *what) {
+  if (!p || !f || (n_list && !list)) {
+    msi_set_error("%s: invalid argument", what);
+    return MSI_E_INVALID;
+  }
+  if (f->ctx != p->ctx || f->n_docs != p->n_docs) {
+    msi_set_error("%s: the key table (%llu documents) does not belong to this pool (%llu documents)", what,
+                  (unsigned long long)f->n_docs, (unsigned long long)p->n_docs);
+    return MSI_E_INVALID;
+  }
+  MSI_TRY(check_slot(p, dst, what));
+  for (uint64_t i = 1; i < n_list; ++i)
+    if (list[i - 1] >= list[i]) {
+      msi_set_error("%s: the key list must be strictly ascending", what);
+      return MSI_E_NOT_SORTED;
+    }
+  std::lock_guard<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->stream;
+  const u64 *d_list = nullptr;
+  if (list) {
+    // an empty list still selects through the list branch (nothing); the copy must be done before `list` goes away
+    MSI_TRY(p->small_ids.ensure(std::max<uint64_t>(1, n_list) * sizeof(u64)));
+    if (n_list) MSI_HIP_TRY(hipMemcpyAsync(p->small_ids.p, list, n_list * sizeof(u64), hipMemcpyHostToDevice, st));
+    d_list = p->small_ids.as<u64>();
+  }
+  const dim3 grid((uint32_t)((p->n_words * 64 + BT - 1) / BT)), block(BT);
+  hipLaunchKernelGGL(bits_facet_select_kernel, grid, block, 0, st, p->slot(dst), f->offsets.as<uint32_t>(), f->keys.as<u64>(),
+                     p->n_docs, p->n_words, lo, hi, d_list, n_list, accumulate ? 1 : 0);
+  MSI_HIP_TRY(hipGetLastError());
+  if (list) MSI_HIP_TRY(hipStreamSynchronize(st));  // `list` is borrowed; small_ids is shared scratch
+  return MSI_OK;
+}
+
+int32_t msi_bits_facet_range(msi_bits *p, const msi_facet_keys *f, uint64_t lo, uint64_t hi, uint32_t dst,
+                             int32_t accumulate) {
+  return facet_select(p, f, lo, hi, nullptr, 0, dst, accumulate, "msi_bits_facet_range");
+}
+
+int32_t msi_bits_facet_in(msi_bits *p, const msi_facet_keys *f, const uint64_t *sorted_keys, uint64_t n, uint32_t dst,
+                          int32_t accumulate) {
+  static const uint64_t none = 0;
+  return facet_select(p, f, 1, 0, n ? sorted_keys : &none, n, dst, accumulate, "msi_bits_facet_in");
+}
+
+int32_t msi_bits_geo_within(msi_bits *p, const msi_geo_points *gp, uint32_t src, double lat, double lng, double radius_m,
+                            uint32_t dst) {
+  if (!p || !gp || src == dst || !(radius_m >= 0.0)) {
+    msi_set_error("msi_bits_geo_within: invalid argument (two different slots, a radius >= 0)");
+    return MSI_E_INVALID;
+  }
+  if (gp->ctx != p->ctx || gp->n_docs != p->n_docs) {
+    msi_set_error("msi_bits_geo_within: the points (%llu documents) do not belong to this pool (%llu documents)",
+                  (unsigned long long)gp->n_docs, (unsigned long long)p->n_docs);
+    return MSI_E_INVALID;
+  }
+  MSI_TRY(check_slot(p, src, "msi_bits_geo_within"));
+  MSI_TRY(check_slot(p, dst, "msi_bits_geo_within"));
+  const double D2R = 3.14159265358979323846 / 180.0;
+  GeoTarget t;
+  t.phi = lat * D2R;
+  t.cos_phi = cos(t.phi);
+  t.lam = lng * D2R;
+  t.margin = 0.0;
+  t.ascending = 1;
+  const double edge = radius_m + 2.220446049250313e-16;  // `<= radius + f64::EPSILON`, index_filter.rs:496-497
+  u64 hi;
+  memcpy(&hi, &edge, sizeof(hi));
+  uint64_t ignored = 0;
+  return geo_range(p, gp, t, src, dst, 0, 0, hi, &ignored);
 }
 
 int32_t msi_bits_count(msi_bits *p, uint32_t slot, uint64_t *out) {

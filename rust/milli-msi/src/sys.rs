@@ -9,6 +9,7 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct msi_doc_keys { _p: [u8; 0] }
 #[repr(C)] pub struct msi_doc_values { _p: [u8; 0] }
 #[repr(C)] pub struct msi_geo_points { _p: [u8; 0] }
+#[repr(C)] pub struct msi_facet_keys { _p: [u8; 0] }
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct msi_geo_rule { pub points: *const msi_geo_points, pub lat: f64, pub lng: f64, pub ascending: i32 }
 pub const MSI_CRIT_GEO_SORT: i32 = 9;
@@ -140,6 +141,15 @@ extern "C" {
     pub fn msi_doc_keys_destroy(k: *mut msi_doc_keys);
     pub fn msi_bits_order_next(p: *mut msi_bits, keys: *const msi_doc_keys, universe: u32, bucket: u32,
                                out_key: *mut u32, out_count: *mut u64) -> i32;
+    pub fn msi_facet_number_key(value: f64) -> u64;
+    pub fn msi_facet_keys_create(ctx: *mut msi_ctx, offsets: *const u64, keys: *const u64, n_docs: u64,
+                                 out: *mut *mut msi_facet_keys) -> i32;
+    pub fn msi_facet_keys_destroy(k: *mut msi_facet_keys);
+    pub fn msi_bits_facet_range(p: *mut msi_bits, keys: *const msi_facet_keys, lo: u64, hi: u64, dst: u32, accumulate: i32) -> i32;
+    pub fn msi_bits_facet_in(p: *mut msi_bits, keys: *const msi_facet_keys, sorted_keys: *const u64, n: u64, dst: u32,
+                             accumulate: i32) -> i32;
+    pub fn msi_bits_geo_within(p: *mut msi_bits, points: *const msi_geo_points, src: u32, lat: f64, lng: f64, radius_m: f64,
+                               dst: u32) -> i32;
     pub fn msi_geo_points_create(ctx: *mut msi_ctx, lat_lng: *const f64, n_docs: u64, out: *mut *mut msi_geo_points) -> i32;
     pub fn msi_geo_points_destroy(g: *mut msi_geo_points);
     pub fn msi_bits_geo_next(p: *mut msi_bits, points: *const msi_geo_points, universe: u32, bucket: u32, scratch: u32,

@@ -27,7 +27,8 @@ GROUPS = {
     "docid-sets": (["tests/test_bits_gpu.py", "tests/test_zz_order_keys_gpu.py::test_order_next_against_numpy",
                     "tests/test_zzz_distinct_gpu.py::test_distinct_against_the_sequential_loop",
                     "tests/test_zzz_distinct_gpu.py::test_many_calls_share_the_scratch_without_clearing_it",
-                    "tests/test_zzz_geo_gpu.py::test_geo_next_against_the_bucket_rule"], "not 200003 and not 3001", 40),
+                    "tests/test_zzz_geo_gpu.py::test_geo_next_against_the_bucket_rule", "tests/test_zzz_filter_gpu.py"],
+                   "not 200003 and not 3001", 46),
     "ranking-kernels": (["tests/test_rank_gpu.py"], "not 50000", 8),
     "ranked-search": (["tests/test_search_gpu.py", "tests/test_zz_order_keys_gpu.py::test_sort_rs_snapshots",
                        "tests/test_zzz_distinct_gpu.py::test_reference_snapshots_with_distinct_and_sort_on_the_device",

@@ -42,6 +42,12 @@ def tokenize_with_positions(text, start=0, stop_words=()):
     return out
 
 
+def normalize_facet(s):
+    """lib.rs:442-444: CompatibilityDecompositionNormalizer (NFKD) of the trimmed value, lowercased."""
+    import unicodedata
+    return unicodedata.normalize("NFKD", s.strip()).lower()
+
+
 class ToyMilli:
     def __init__(self, docs, searchable=None, exact_attributes=(), exact_words=(), criteria=None,
                  min_one=5, min_two=9, authorize_typos=True, primary_key="id", prefix_threshold=100, synonyms=None,
@@ -141,7 +147,7 @@ class ToyMilli:
                     elif isinstance(x, (int, float)):
                         key = ("n", float(x))
                     elif isinstance(x, str) and x:
-                        key = ("s", x.lower())
+                        key = ("s", normalize_facet(x))
                     else:
                         continue
                     self.facet_docids.setdefault((name, key), set()).add(docid)
@@ -308,6 +314,30 @@ class ToyMilli:
             for d in self.facet_docids[(field, k)]:
                 out[d] = min(out[d], rank)
         return out, values
+
+    # ---- what a filter reads (search/facet/filter/index_filter.rs) --------------------------------------------------
+    def facet_numbers(self, field):
+        """per document: the numbers of facet_id_f64_docids for `field`; `_geo.lat` / `_geo.lng` come from the point."""
+        if field in ("_geo.lat", "_geo.lng"):
+            i = 0 if field.endswith("lat") else 1
+            return [[self.geo_points[d][i]] if d in self.geo_points else [] for d in range(self.n_docs)]
+        return [[k[1] for k in self.doc_facets.get((field, d), ()) if k[0] == "n"] for d in range(self.n_docs)]
+
+    def facet_strings(self, field):
+        """-> (per document: ranks of its normalised strings, the field's distinct normalised strings in byte order —
+        what facet_id_string_fst enumerates)"""
+        values = sorted({k[1] for (f, k) in self.facet_docids if f == field and k[0] == "s"}, key=lambda v: v.encode())
+        rank = {v: i for i, v in enumerate(values)}
+        return [[rank[k[1]] for k in self.doc_facets.get((field, d), ()) if k[0] == "s"] for d in range(self.n_docs)], values
+
+    def exists_docids(self, field):
+        return {d for d, doc in enumerate(self.docs) if field in doc}
+
+    def null_docids(self, field):
+        return {d for d, doc in enumerate(self.docs) if field in doc and doc[field] is None}
+
+    def empty_docids(self, field):
+        return {d for d, doc in enumerate(self.docs) if field in doc and doc[field] in ("", [], {})}
 
     def distinct_values(self, field):
         """What the shim stages for msi_doc_values_create: per document the ids of its facet values of `field`
