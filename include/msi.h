@@ -669,7 +669,7 @@ enum { /* ScoreDetails variants, score_details.rs:10-27 */
   MSI_SCORE_GEO_SORT = 9         /* a = index into geo_rules, b = the docid whose point is the bucket's `value`
                                   * (0xFFFFFFFF: None — no _geo); no rank either */
 };
-#define MSI_MAX_SCORE_DETAILS 8
+#define MSI_MAX_SCORE_DETAILS 16 /* the 7 keyword rules + the Sort / GeoSort rules of a request; a longer rule list is cut here */
 typedef struct msi_score_detail {
   uint32_t kind, a, b;
 } msi_score_detail;

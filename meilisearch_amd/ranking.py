@@ -344,7 +344,7 @@ def geo_sort_entries(criteria, sort):
     return [(float(f[1]), float(f[2]), d == "asc") for f, d in (sort or ()) if is_geo_point(f)] if "sort" in criteria else []
 
 
-MAX_SCORE_DETAILS = 8
+MAX_SCORE_DETAILS = 16
 
 
 def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERMS_LAST, offset=0, limit=20,

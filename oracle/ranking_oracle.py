@@ -1377,7 +1377,8 @@ def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=
             universe -= ctx.phrase_docids(tuple(neg))
     if not terms:          # no term (or only stop words): a placeholder search — only Sort / Asc / Desc rules, mod.rs:770-800
         rules = [r for _, r in sort_rules(criteria if criteria is not None else index.criteria, sort)]
-        return bucket_sort(ctx, rules, None, universe, offset, length, detailed, distinct=distinct)
+        # the same deadline and score threshold as a keyword search (mod.rs:874-889)
+        return bucket_sort(ctx, rules, None, universe, offset, length, detailed, Deadline(stop_after), threshold, distinct)
     graph = QueryGraph.from_query(ctx, terms)
     rules = ranking_rules(criteria if criteria is not None else index.criteria, tms, sort)
     reduced = graph.clone()

@@ -85,7 +85,7 @@ pub struct msi_index_vtable {
     pub synonyms: Option<synonyms_fn>,
     pub exact_words_with_prefix: Option<exact_prefix_fn>,
 }
-pub const MSI_MAX_SCORE_DETAILS: usize = 8;
+pub const MSI_MAX_SCORE_DETAILS: usize = 16;
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct msi_score_detail { pub kind: u32, pub a: u32, pub b: u32 }
 #[repr(C)]

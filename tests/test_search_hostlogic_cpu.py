@@ -30,6 +30,10 @@ LOOKUP_FN = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32,
 
 @pytest.fixture(scope="module")
 def hostlib():
+    return load_hostlib()
+
+
+def load_hostlib():
     _lib.lib()   # the product library first (one HIP runtime; msi_set_error / parsers come from it)
     if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in SOURCES + [_lib.lib_path()]):
         os.makedirs(BUILD, exist_ok=True)
@@ -130,7 +134,7 @@ class MockHarness:
         self.L.mock_geo_points_destroy(h._h)
 
     def search(self, query, tms="last", criteria=None, offset=0, limit=20, detailed=False, stop_after=None, sort=None,
-               distinct=None, **kw):
+               distinct=None, extra_terms=(), **kw):
         """sort: the request's [(field, "asc" | "desc")]; Sort details come back as the oracle writes them:
         ("Sort", field, ascending, ("Number", x) | ("String", s) | ("Null",)).  distinct: the distinct field."""
         ix = self.index
@@ -151,7 +155,7 @@ class MockHarness:
             tables.append((field, asc, values))
         try:
             out = R.keyword_search_ranked(
-                self.dict, self.pool, self.cb, query_terms(query, stop_words=ix.stop_words), crit,
+                self.dict, self.pool, self.cb, query_terms(query, stop_words=ix.stop_words) + list(extra_terms), crit,
                 strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
                 searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
                 max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,

@@ -2,7 +2,8 @@
 """Differential fuzzing of the ranked keyword search's HOST logic (msi_search.hip compiled against the test double
 of the device, tests/hostlogic) against the CPU oracle: random corpora, index settings (exact attributes / words,
 prefix databases, synonyms, stop words, typo thresholds), criteria lists, queries (typos, prefixes, phrases),
-strategies, offsets, limits, score thresholds and deadlines.
+strategies, offsets, limits, score thresholds, deadlines, and — every other corpus — facet fields with Sort / Asc / Desc
+rules, `_geo` points with GeoSort rules (bucket caps, error margins) and a `distinct` field.
 
     python tools/fuzz_ranked_hostlogic.py [first_seed] [seconds]
 """
@@ -18,13 +19,7 @@ import tests.test_search_gpu as G
 from oracle import oracle as O, ranking_oracle as RO
 from meilisearch_amd import _lib, ranking as R
 from tests.toy_milli import ToyMilli, query_terms
-_lib.lib()
-L = C.CDLL(H.SO)
-L.msi_keyword_search_ranked.restype, L.msi_keyword_search_ranked.argtypes = _lib.PROTOTYPES["msi_keyword_search_ranked"]
-L.mock_bits_create.restype, L.mock_bits_create.argtypes = C.c_void_p, [C.c_uint64, C.c_uint32]
-L.mock_bits_destroy.restype, L.mock_bits_destroy.argtypes = None, [C.c_void_p]
-L.mock_dict_create.restype, L.mock_dict_create.argtypes = C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint32, H.LOOKUP_FN]
-L.mock_dict_destroy.restype, L.mock_dict_destroy.argtypes = None, [C.c_void_p]
+L = H.load_hostlib()
 seed0 = int(sys.argv[1]) if len(sys.argv)>1 else 0
 budget = float(sys.argv[2]) if len(sys.argv)>2 else 120
 ALLC = ["words","typo","proximity","attribute","attributeRank","wordPosition","exactness","sort"]
@@ -36,6 +31,16 @@ while time.time() < t_end:
     docs = G.random_corpus(seed, rng.choice([40, 120, 300]))
     if rng.random()<0.5:
         for d in docs: d["tags"] = " ".join(rng.choice(G.VOCAB) for _ in range(rng.randint(0,3)))
+    faceted = rng.random() < 0.5
+    if faceted:
+        places = [(rng.uniform(-80, 80), rng.uniform(-179, 179)) for _ in range(6)]
+        for d in docs:
+            if rng.random() < 0.8: d["price"] = rng.choice([1, 2, 2.5, 3, 10, 10, 99.5])
+            if rng.random() < 0.7: d["color"] = rng.choice(["red", "green", "blue", "Blue"])
+            if rng.random() < 0.5: d["sizes"] = [rng.choice([36, 38, 40, "xl"]) for _ in range(rng.randint(1, 3))]
+            if rng.random() < 0.75:
+                lat, lng = rng.choice(places) if rng.random() < 0.6 else (rng.uniform(-89, 89), rng.uniform(-180, 180))
+                d["_geo"] = {"lat": lat + rng.choice([0, 0, 5e-6, 2e-5]), "lng": lng}
     fields = [f for f in ("title","body","tags") if f in docs[0]]
     rng.shuffle(fields)
     kw = {}
@@ -47,6 +52,8 @@ while time.time() < t_end:
     if rng.random()<0.2: kw["authorize_typos"]=False
     if rng.random()<0.2: kw["min_one"],kw["min_two"]=3,6
     criteria = rng.sample(ALLC, rng.randint(1,6))
+    if faceted and rng.random() < 0.4:
+        criteria.insert(rng.randrange(len(criteria) + 1), rng.choice(["asc:price", "desc:color", "asc:sizes"]))
     index = ToyMilli(docs, searchable=fields if rng.random()<0.8 else None, criteria=criteria, **kw)
     dic = O.Dictionary(index.words)
     def lookup(w,m,p):
@@ -73,25 +80,59 @@ while time.time() < t_end:
             negs.append(rng.choice(G.VOCAB))
         if rng.random() < 0.1:
             negs.append((rng.choice(G.VOCAB), rng.choice(G.VOCAB)))
+        sort, distinct, geo = None, None, {}
+        if faceted:
+            if rng.random() < 0.6:
+                sort = []
+                for _ in range(rng.randint(1, 2)):
+                    if rng.random() < 0.45:
+                        sort.append((("_geoPoint", rng.uniform(-60, 60), rng.uniform(-170, 170)), rng.choice(["asc", "desc"])))
+                    else:
+                        sort.append((rng.choice(["price", "color", "sizes"]), rng.choice(["asc", "desc"])))
+            if rng.random() < 0.4:
+                distinct = rng.choice(["color", "sizes", "price"])
+            if rng.random() < 0.3:
+                geo["geo_max_bucket_size"] = rng.choice([1, 3, 50])
+            if rng.random() < 0.2:
+                geo["geo_distance_error_margin"] = rng.choice([0.0, 10.0, 3e6])
+        if q.strip() == "" and negs:
+            negs = []
+        if sa is not None and distinct and (sort or any(c.startswith(("asc:", "desc:")) for c in criteria)):
+            # the reference's Sort rule hands out EMPTY buckets for values whose documents `distinct` removed since the
+            # rule started (sort.rs:214-217: `bucket.candidates &= universe`); the product's next bucket is the next key
+            # that still has a document.  Only the NUMBER of deadline checks differs — visible through `stop_after` alone.
+            sa = None
         try:
-            want = RO.search(RO.Ctx(index,lookup), q, tms=tms, offset=offset, length=limit, detailed=detailed, threshold=thr, stop_after=sa, negatives=negs)
+            RO.GEO_PARAMS.clear()
+            RO.GEO_PARAMS.update(strategy=("rtree", 1000))
+            if "geo_max_bucket_size" in geo: RO.GEO_PARAMS["max_bucket_size"] = geo["geo_max_bucket_size"]
+            if "geo_distance_error_margin" in geo: RO.GEO_PARAMS["distance_error_margin"] = geo["geo_distance_error_margin"]
+            want = RO.search(RO.Ctx(index,lookup), q, tms=tms, offset=offset, length=limit, detailed=detailed, threshold=thr,
+                             stop_after=sa, negatives=negs, sort=sort, distinct=distinct)
+            RO.GEO_PARAMS.clear()
             deg = RO.bucket_sort.degraded if hasattr(RO.bucket_sort,'degraded') else False
-            terms = query_terms(q, stop_words=index.stop_words)
-            for ng in negs:
-                terms.append(([ng], False, 0, 0, False, True) if isinstance(ng, str) else (list(ng), True, 0, 0, False, True))
-            hits, cand, gdeg = R.keyword_search_ranked(
-                h.dict, h.pool, h.cb, terms, index.criteria, strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST,
-                offset=offset, limit=limit, detailed=detailed, searchable_fids=index.searchable_fids,
-                searchable_weights=[index.weights[f] for f in index.searchable_fids], max_weight=index.max_weight,
-                authorize_typos=index.authorize_typos, min_one=index.min_one, min_two=index.min_two, stop_after=sa,
-                score_threshold=thr, return_degraded=True, _entry=L.msi_keyword_search_ranked)
+            extra = [(([ng], False, 0, 0, False, True) if isinstance(ng, str) else (list(ng), True, 0, 0, False, True)) for ng in negs]
+            hits, cand, gdeg = h.search(q, tms=tms, offset=offset, limit=limit, detailed=detailed, stop_after=sa, sort=sort,
+                                        distinct=distinct, extra_terms=extra, score_threshold=thr, return_degraded=True, **geo)
         except Exception as e:
             print("EXC", seed, repr(q), criteria, kw, e); bad+=1; continue
         n+=1
-        ok = [d for d,_ in hits]==want[0] and cand==len(want[2]) and [[tuple(s) for s in sc] for _,sc in hits]==[[G.oracle_score(s) if s[0]!="Skipped" else ("Skipped",0,1) for s in sc] for sc in want[1]]
+        def same_detail(g_, w_):
+            if g_ == w_:
+                return True
+            # GeoSort's value is the point of the bucket's first document: documents whose distances agree to the
+            # millimetre (the resolution of distance_between_two_points) are interchangeable there
+            if g_[0] == "GeoSort" and w_[0] == "GeoSort" and g_[:3] == w_[:3] and g_[3] is not None and w_[3] is not None:
+                return abs(RO.distance_between_two_points(g_[1], g_[3]) - RO.distance_between_two_points(g_[1], w_[3])) <= 1e-3
+            return False
+        got_sc = [[H.geo_score(s) for s in sc] for _, sc in hits]
+        want_sc = [[H.geo_score(G.oracle_score(s)) if s[0] != "Skipped" else ("Skipped", 0, 1) for s in sc] for sc in want[1]]
+        sc_ok = len(got_sc) == len(want_sc) and all(len(a_) == len(b_) and all(same_detail(x, y) for x, y in zip(a_, b_))
+                                                     for a_, b_ in zip(got_sc, want_sc))
+        ok = [d for d,_ in hits]==want[0] and cand==len(want[2]) and sc_ok
         if not ok:
             bad+=1
-            print("MISMATCH seed",seed,repr(q),tms,detailed,offset,limit,thr,sa,criteria,kw)
+            print("MISMATCH seed",seed,repr(q),tms,detailed,offset,limit,thr,sa,criteria,kw,"sort",sort,"distinct",distinct,geo)
             print("  want",want[0][:10],len(want[2])); print("  got ",[d for d,_ in hits][:10],cand)
             if bad>5: sys.exit(1)
     h.close()
