@@ -5,7 +5,7 @@ prefix databases, synonyms, stop words, typo thresholds), criteria lists, querie
 strategies, offsets, limits, score thresholds, deadlines, and — every other corpus — facet fields with Sort / Asc / Desc
 rules, `_geo` points with GeoSort rules (bucket caps, error margins) and a `distinct` field.
 
-    python tools/fuzz_ranked_hostlogic.py [first_seed] [seconds]
+    python tools/fuzz_ranked_hostlogic.py [first_seed] [seconds] [--emulated-kernels]
 """
 import os
 import random
@@ -19,7 +19,18 @@ import tests.test_search_gpu as G
 from oracle import oracle as O, ranking_oracle as RO
 from meilisearch_amd import _lib, ranking as R
 from tests.toy_milli import ToyMilli, query_terms
-L = H.load_hostlib()
+EMULATED = "--emulated-kernels" in sys.argv
+if EMULATED:
+    # the same cases through the product's kernels on the CPU emulation of the HIP runtime (tests/emu): every launch of
+    # the search is executed, the dictionary lookups included (test infrastructure; the product never loads that build)
+    sys.argv.remove("--emulated-kernels")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "emu"))
+    import run_emulated
+    _lib._LIB = run_emulated.EmulatedLib(run_emulated.build())
+    from tests.test_zzz_distinct_gpu import device_lib
+    L = device_lib()
+else:
+    L = H.load_hostlib()
 seed0 = int(sys.argv[1]) if len(sys.argv)>1 else 0
 budget = float(sys.argv[2]) if len(sys.argv)>2 else 120
 ALLC = ["words","typo","proximity","attribute","attributeRank","wordPosition","exactness","sort"]
@@ -58,7 +69,7 @@ while time.time() < t_end:
     dic = O.Dictionary(index.words)
     def lookup(w,m,p):
         a,b=O.typo_lookup(dic,w,m,p); return [index.words[i] for i in a],[index.words[i] for i in b]
-    h = H.MockHarness(L, index, n_slots=1024)
+    h = H.make_harness(L, index, n_slots=1024)
     for _ in range(6):
         nt = rng.randint(1,5)
         ws = []
