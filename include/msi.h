@@ -723,6 +723,12 @@ typedef struct msi_search_params {
   uint32_t n_geo_rules;
   uint32_t geo_max_bucket_size;
   double geo_distance_error_margin;
+  /* exhaustive_number_hits / max_total_hits of bucket_sort (bucket_sort.rs:187-191): with a score threshold AND an
+   * exhaustive count the rules keep running past the page — up to max_total_hits hits (0 = None) — so that every bucket
+   * below the threshold leaves *out_candidates; with a distinct field the count is what the distinct rule keeps of
+   * all_candidates (search/new/mod.rs:894-907). */
+  int32_t exhaustive_number_hits;
+  uint32_t max_total_hits;
 } msi_search_params;
 /* out_scores: [length][MSI_MAX_SCORE_DETAILS], out_n_scores: [length].  The pool needs at least 64 free
  * slots above slot 0 (more for long queries: one per live condition of every active rule). */

@@ -102,7 +102,8 @@ class SearchParams(C.Structure):
                 ("length", C.c_uint32), ("detailed_scores", C.c_int32), ("time_budget_us", C.c_uint64),
                 ("stop_after", C.c_int32), ("has_score_threshold", C.c_int32), ("score_threshold", C.c_double),
                 ("order_keys", C.c_void_p), ("n_order_keys", C.c_uint32), ("distinct_values", C.c_void_p), ("geo_rules", C.c_void_p), ("n_geo_rules", C.c_uint32),
-                ("geo_max_bucket_size", C.c_uint32), ("geo_distance_error_margin", C.c_double)]
+                ("geo_max_bucket_size", C.c_uint32), ("geo_distance_error_margin", C.c_double),
+                ("exhaustive_number_hits", C.c_int32), ("max_total_hits", C.c_uint32)]
 
 
 class GeoRule(C.Structure):

@@ -2142,8 +2142,18 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   uint32_t n_out = 0;
   *out_n = 0;
   if (out_candidates) *out_candidates = universe_count;
-  if (universe_count < from || length == 0) return;
   const msi_doc_values *dv = p->distinct_values;
+  // search/new/mod.rs:894-907: an exhaustive count under `distinct` is what the distinct rule keeps of all_candidates
+  auto exhaustive_count = [&](const Set &all) {
+    uint64_t kept = 0;
+    c.dev.distinct(dv, all, &kept);
+    return kept;
+  };
+  const bool exhaustive_distinct = p->exhaustive_number_hits && dv && out_candidates;
+  if (universe_count < from || length == 0) {
+    if (exhaustive_distinct && universe_count) *out_candidates = exhaustive_count(universe);
+    return;
+  }
   if (rules.empty() && dv) {
     // bucket_sort.rs:61-92: the first from + length documents the distinct loop keeps, in docid order; only THEIR
     // values exclude documents from all_candidates
@@ -2160,7 +2170,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       Set all = c.dev.clone(universe);
       c.dev.sub_(all, exc);
       c.dev.or_(all, kept);
-      *out_candidates = c.dev.count(all);
+      *out_candidates = exhaustive_distinct ? exhaustive_count(all) : c.dev.count(all);
     }
     for (size_t i = from; i < ids.size(); ++i) {
       out_docids[n_out] = ids[i];
@@ -2250,7 +2260,21 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     return true;
   };
   const bool trace = getenv("MSI_SEARCH_TRACE") != nullptr;  // one line per bucket on stderr (debugging aid)
-  while (n_out < length) {
+  // max_len_to_evaluate, bucket_sort.rs:187-191
+  const uint64_t max_len = (p->has_score_threshold && p->exhaustive_number_hits && p->max_total_hits) ? p->max_total_hits : length;
+  // all_candidates at the end (and, search/new/mod.rs:894-907, what `distinct` keeps of it for an exhaustive count)
+  auto finish = [&]() {
+    *out_n = n_out;
+    if (!out_candidates) return;
+    if (exhaustive_distinct) {
+      Set all = c.dev.clone(universe);
+      if (excluded) c.dev.sub_(all, excluded);
+      *out_candidates = exhaustive_count(all);
+    } else if (excluded) {
+      *out_candidates = universe_count - c.dev.count(excluded);
+    }
+  };
+  while (n_out < max_len) {
     if (uni_counts[cur] == 0 || (!detailed && uni_counts[cur] == 1)) {
       if (uni_counts[cur]) add(unis[cur], uni_counts[cur]);
       if (!back()) break;
@@ -2268,8 +2292,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
         uni_counts[cur] = 0;
         if (cur == 0) {
           if (out_degraded) *out_degraded = 1;
-          *out_n = n_out;
-          if (excluded && out_candidates) *out_candidates = universe_count - c.dev.count(excluded);
+          finish();
           return;
         }
         rules[cur]->end();
@@ -2306,8 +2329,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     uni_counts[cur] = b.count;
     rules[cur]->start(c, b.docs, b.graph);
   }
-  *out_n = n_out;
-  if (excluded && out_candidates) *out_candidates = universe_count - c.dev.count(excluded);
+  finish();
 }
 
 }  // namespace

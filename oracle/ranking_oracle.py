@@ -1190,7 +1190,7 @@ class Deadline:
 
 
 def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, deadline=None, threshold=None,
-                distinct=None):
+                distinct=None, exhaustive=False, max_total_hits=None):
     """bucket_sort.rs:23-343 without pins (threshold = ranking_score_threshold, :286-306; distinct = field name,
     apply_distinct_rule of search/new/distinct.rs:19-36 inside maybe_add_to_results).
     -> (docids, [score details per hit], all_candidates); `bucket_sort.degraded` tells whether the deadline cut
@@ -1252,7 +1252,10 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
             out_scores.extend([list(scores)] * len(take))
         cur_off += len(ids)
 
-    while len(out_ids) < length:
+    # max_len_to_evaluate, bucket_sort.rs:187-191: with a score threshold and an exhaustive count the loop goes on past
+    # the page, so that every bucket below the threshold leaves all_candidates
+    max_len = max_total_hits if (max_total_hits is not None and exhaustive and threshold is not None) else length
+    while len(out_ids) < max_len:
         if not unis[cur] or (not detailed and len(unis[cur]) == 1):
             b, unis[cur] = unis[cur], set()
             add(b)
@@ -1364,7 +1367,7 @@ def parse_query(ctx, query, words_limit=10):
 
 
 def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=False, universe=None, negatives=(),
-           stop_after=None, threshold=None, distinct=None, sort=None):
+           stop_after=None, threshold=None, distinct=None, sort=None, exhaustive=False, max_total_hits=None):
     """execute_search, mod.rs:808-880 for a keyword query.  negatives: [word | (phrase words…)] whose documents
     Search::execute removes from the universe first (search/mod.rs:431-440, new/mod.rs:323-351)."""
     index = ctx.index
@@ -1378,11 +1381,30 @@ def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=
     if not terms:          # no term (or only stop words): a placeholder search — only Sort / Asc / Desc rules, mod.rs:770-800
         rules = [r for _, r in sort_rules(criteria if criteria is not None else index.criteria, sort)]
         # the same deadline and score threshold as a keyword search (mod.rs:874-889)
-        return bucket_sort(ctx, rules, None, universe, offset, length, detailed, Deadline(stop_after), threshold, distinct)
+        return exhaustive_candidates(ctx, distinct, exhaustive, bucket_sort(
+            ctx, rules, None, universe, offset, length, detailed, Deadline(stop_after), threshold, distinct, exhaustive,
+            max_total_hits))
     graph = QueryGraph.from_query(ctx, terms)
     rules = ranking_rules(criteria if criteria is not None else index.criteria, tms, sort)
     reduced = graph.clone()
     if tms == "last":
         reduced.remove_nodes_keep_edges([n for ns in graph.removal_order_last(ctx) for n in sorted(ns)])
     universe &= query_graph_docids(ctx, reduced, universe)
-    return bucket_sort(ctx, rules, graph, universe, offset, length, detailed, Deadline(stop_after), threshold, distinct)
+    return exhaustive_candidates(ctx, distinct, exhaustive, bucket_sort(
+        ctx, rules, graph, universe, offset, length, detailed, Deadline(stop_after), threshold, distinct, exhaustive,
+        max_total_hits))
+
+
+def exhaustive_candidates(ctx, distinct, exhaustive, out):
+    """mod.rs:894-907: with exhaustive_number_hits and a distinct field the candidates are what the distinct rule keeps
+    of all_candidates."""
+    ids, scores, all_cand = out
+    if exhaustive and distinct:
+        remaining, excluded = set(), set()
+        for d in sorted(all_cand):
+            if d in excluded:
+                continue
+            excluded |= ctx.index.distinct_excluded(distinct, d)
+            remaining.add(d)
+        all_cand = remaining
+    return ids, scores, all_cand

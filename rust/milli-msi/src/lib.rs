@@ -306,6 +306,9 @@ pub struct RankedSearch<'a> {
     pub geo_rules: &'a [GeoRule<'a>],
     pub geo_max_bucket_size: u64,
     pub geo_distance_error_margin: f64,
+    /// `exhaustive_number_hits` / `max_total_hits` of `bucket_sort` (bucket_sort.rs:187-191; search/new/mod.rs:894-907)
+    pub exhaustive_number_hits: bool,
+    pub max_total_hits: Option<usize>,
 }
 
 pub struct GeoRule<'a> { pub points: &'a DocGeoPoints, pub point: [f64; 2], pub ascending: bool }
@@ -470,7 +473,9 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
         distinct_values: q.distinct.map_or(ptr::null(), |d| d.0.as_ptr() as *const _),
         geo_rules: geo.as_ptr(), n_geo_rules: geo.len() as u32,
         geo_max_bucket_size: q.geo_max_bucket_size.min(u32::MAX as u64) as u32,
-        geo_distance_error_margin: q.geo_distance_error_margin };
+        geo_distance_error_margin: q.geo_distance_error_margin,
+        exhaustive_number_hits: q.exhaustive_number_hits as i32,
+        max_total_hits: q.max_total_hits.map_or(0, |m| m.min(u32::MAX as usize) as u32) };
     let mut src_ref: Src<'_> = source;
     let vt = sys::msi_index_vtable { user: &mut src_ref as *mut _ as *mut _, word_docids: Some(r_word),
         word_pair_proximity_docids: Some(r_pair), is_exact_word: Some(r_exact), word_fid_docids: Some(r_fid),

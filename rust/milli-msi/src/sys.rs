@@ -101,6 +101,7 @@ pub struct msi_search_params {
     pub distinct_values: *const msi_doc_values,
     pub geo_rules: *const msi_geo_rule, pub n_geo_rules: u32, pub geo_max_bucket_size: u32,
     pub geo_distance_error_margin: f64,
+    pub exhaustive_number_hits: i32, pub max_total_hits: u32,
 }
 
 extern "C" {

@@ -406,20 +406,23 @@ def test_distinct_matches_the_oracle(hostlib, monkeypatch, per_wait, fields=("co
     for field in fields:
         for criteria, sort in setups:
             for q in ["", "the", "quick fox", "sun fl", "\"lazy dog\"", "brwn fox jumps"]:
-                for detailed, offset, limit, threshold in ((True, 0, 30, None), (False, 0, 7, None), (True, 5, 9, None),
-                                                            (True, 0, 20, 0.6)):
+                for detailed, offset, limit, threshold, exhaustive in (
+                        (True, 0, 30, None, False), (False, 0, 7, None, False), (True, 5, 9, None, True), (True, 0, 20, 0.6, False),
+                        (True, 0, 5, 0.6, True), (True, 500, 5, None, True)):
                     if threshold is not None and not criteria:
                         continue
+                    mth = 1000 if exhaustive else None      # exhaustive_number_hits with max_total_hits (pagination.maxTotalHits)
                     want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms="last", criteria=criteria,
                                                              offset=offset, length=limit, detailed=detailed, sort=sort,
-                                                             distinct=field, threshold=threshold)
+                                                             distinct=field, threshold=threshold, exhaustive=exhaustive,
+                                                             max_total_hits=mth)
                     hits, cand = h.search(q, criteria=criteria, offset=offset, limit=limit, detailed=detailed, sort=sort,
-                                          distinct=field, score_threshold=threshold)
+                                          distinct=field, score_threshold=threshold, exhaustive=exhaustive, max_total_hits=mth)
                     assert [d for d, _ in hits] == want_ids, (field, criteria, sort, q, detailed, offset, threshold)
                     assert [[tuple(s) for s in sc] for _, sc in hits] == [[G.oracle_score(s) for s in sc] for sc in want_sc]
                     assert cand == len(want_cand), (field, criteria, sort, q, detailed, offset, threshold)
                     n += 1
-    assert n >= 400 or setups is not DISTINCT_SETUPS
+    assert n >= 600 or setups is not DISTINCT_SETUPS
     h.close()
 
 

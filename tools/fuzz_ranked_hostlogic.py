@@ -106,6 +106,8 @@ while time.time() < t_end:
                 geo["geo_max_bucket_size"] = rng.choice([1, 3, 50])
             if rng.random() < 0.2:
                 geo["geo_distance_error_margin"] = rng.choice([0.0, 10.0, 3e6])
+        exh = rng.random() < 0.3
+        mth = rng.choice([None, 1000, 1000, 7]) if exh else None
         if q.strip() == "" and negs:
             negs = []
         if sa is not None and distinct and (sort or any(c.startswith(("asc:", "desc:")) for c in criteria)):
@@ -119,12 +121,13 @@ while time.time() < t_end:
             if "geo_max_bucket_size" in geo: RO.GEO_PARAMS["max_bucket_size"] = geo["geo_max_bucket_size"]
             if "geo_distance_error_margin" in geo: RO.GEO_PARAMS["distance_error_margin"] = geo["geo_distance_error_margin"]
             want = RO.search(RO.Ctx(index,lookup), q, tms=tms, offset=offset, length=limit, detailed=detailed, threshold=thr,
-                             stop_after=sa, negatives=negs, sort=sort, distinct=distinct)
+                             stop_after=sa, negatives=negs, sort=sort, distinct=distinct, exhaustive=exh, max_total_hits=mth)
             RO.GEO_PARAMS.clear()
             deg = RO.bucket_sort.degraded if hasattr(RO.bucket_sort,'degraded') else False
             extra = [(([ng], False, 0, 0, False, True) if isinstance(ng, str) else (list(ng), True, 0, 0, False, True)) for ng in negs]
             hits, cand, gdeg = h.search(q, tms=tms, offset=offset, limit=limit, detailed=detailed, stop_after=sa, sort=sort,
-                                        distinct=distinct, extra_terms=extra, score_threshold=thr, return_degraded=True, **geo)
+                                        distinct=distinct, extra_terms=extra, score_threshold=thr, return_degraded=True, exhaustive=exh,
+                                        max_total_hits=mth, **geo)
         except Exception as e:
             print("EXC", seed, repr(q), criteria, kw, e); bad+=1; continue
         n+=1
@@ -143,7 +146,7 @@ while time.time() < t_end:
         ok = [d for d,_ in hits]==want[0] and cand==len(want[2]) and sc_ok
         if not ok:
             bad+=1
-            print("MISMATCH seed",seed,repr(q),tms,detailed,offset,limit,thr,sa,criteria,kw,"sort",sort,"distinct",distinct,geo)
+            print("MISMATCH seed",seed,repr(q),tms,detailed,offset,limit,thr,sa,criteria,kw,"sort",sort,"distinct",distinct,geo,"exhaustive",exh,mth)
             print("  want",want[0][:10],len(want[2])); print("  got ",[d for d,_ in hits][:10],cand)
             if bad>5: sys.exit(1)
     h.close()
