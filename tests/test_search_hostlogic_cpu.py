@@ -520,3 +520,39 @@ def test_geo_sort_matches_the_oracle(hostlib, setups=GEO_SETUPS, with_distinct=T
 def geo_score(s):
     s = tuple(s)
     return (s[0], tuple(s[1]), s[2], None if s[3] is None else tuple(s[3])) if s[0] == "GeoSort" else s
+
+
+CRIT = json.load(open(os.path.join(ROOT, "tests", "golden", "criteria_fixtures.json")))
+CRIT_DOCS = json.load(open(os.path.join(ROOT, "tests", "golden", "filter_fixtures.json")))["docs"]
+
+
+def criteria_cases(every=1):
+    return [c for i, c in enumerate(CRIT["cases"]) if c["name"] != "criteria_mixup" or i % every == 0]
+
+
+def test_oracle_replays_the_reference_criteria_tests():
+    """crates/milli/tests/search/query_criteria.rs: "hello world america" over test_set.ndjson with its synonyms, the 14
+    `test_criterion!` cases and the 120 criteria orders of `criteria_mixup`; the expected order comes from the rank
+    columns of the dataset (the reference's own expected_order helper)."""
+    from oracle import ranking_oracle as RO
+    assert len(CRIT["cases"]) == 134
+    for case in CRIT["cases"]:
+        index = ToyMilli(CRIT_DOCS, searchable=CRIT["searchable"], criteria=case["criteria"], synonyms=CRIT["synonyms"])
+        dic = O.Dictionary(index.words)
+
+        def lookup(word, max_typos, is_prefix):
+            one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+            return [index.words[i] for i in one], [index.words[i] for i in two]
+        ids, _, _ = RO.search(RO.Ctx(index, lookup), CRIT["query"], tms=case["tms"], criteria=case["criteria"], length=17,
+                              sort=[tuple(x) for x in case["sort"]])
+        assert [index.docs[d]["id"] for d in ids] == case["ids"], (case["name"], case["criteria"])
+
+
+def test_reference_criteria_tests_through_the_host_logic(hostlib, every=1):
+    for case in criteria_cases(every):
+        index = ToyMilli(CRIT_DOCS, searchable=CRIT["searchable"], criteria=case["criteria"], synonyms=CRIT["synonyms"])
+        h = make_harness(hostlib, index)
+        hits, _ = h.search(CRIT["query"], tms=case["tms"], criteria=case["criteria"], limit=17,
+                           sort=[tuple(x) for x in case["sort"]])
+        assert [index.docs[d]["id"] for d, _ in hits] == case["ids"], (case["name"], case["criteria"])
+        h.close()

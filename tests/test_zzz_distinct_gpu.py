@@ -169,3 +169,9 @@ def test_reference_snapshots_with_distinct_and_sort_on_the_device(monkeypatch):
 def test_distinct_matches_the_oracle_on_the_device(monkeypatch):
     import tests.test_search_hostlogic_cpu as H
     H.test_distinct_matches_the_oracle(device_lib(), monkeypatch, "1")
+
+
+def test_reference_criteria_tests_on_the_device():
+    """query_criteria.rs: 14 criterion cases + every 4th of the 120 criteria orders over test_set.ndjson (synonyms, real text)."""
+    import tests.test_search_hostlogic_cpu as H
+    H.test_reference_criteria_tests_through_the_host_logic(device_lib(), every=4)
