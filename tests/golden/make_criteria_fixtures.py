@@ -63,11 +63,30 @@ def main():
         criteria = ["words"] + list(perm)
         cases.append({"name": "criteria_mixup", "criteria": criteria, "tms": "last", "sort": [],
                       "ids": expected_order(docs, criteria, "last", [])})
-    out = {"query": "hello world america", "searchable": ["title", "description"],
+    # crates/milli/tests/search/distinct.rs: `test_distinct!(name, field, exhaustive, limit, offset, criteria, n_candidates)` —
+    # the candidates count is a literal of the test; the ids are expected_order filtered to the first document of every
+    # distinct value, then offset / limit (distinct.rs:60-74)
+    dsrc = re.sub(r"//[^\n]*", "", open(f"{REF}/search/distinct.rs").read())
+    dcases = []
+    for m in re.finditer(r"test_distinct!\(\s*(\w+),\s*(\w+),\s*(true|false),\s*([\w.()]+),\s*(\d+),\s*vec!\[(.*?)\],\s*(\d+)\s*\);",
+                         dsrc, re.S):
+        name, field, exh, limit, offset, crit, n_res = m.groups()
+        criteria = [criterion(t) for t in re.findall(r'(?:Asc|Desc)\(S\("[^"]+"\)\)|\w+', crit)] if crit.strip() else []
+        limit = 17 if "EXTERNAL" in limit else int(limit)
+        seen, ids = set(), []
+        for did in expected_order(docs, criteria, "last", []):
+            d = next(x for x in docs if x["id"] == did)
+            if d[field] not in seen:
+                seen.add(d[field])
+                ids.append(did)
+        dcases.append({"name": name, "distinct": field, "exhaustive": exh == "true", "limit": limit, "offset": int(offset),
+                       "criteria": criteria, "candidates": int(n_res), "ids": ids[int(offset):][:limit]})
+    assert len(dcases) == 19, len(dcases)
+    out = {"distinct_cases": dcases, "query": "hello world america", "searchable": ["title", "description"],
            "synonyms": {"hello": ["good morning"], "world": ["earth"], "america": ["the united states"]},
            "cases": cases, "src": "crates/milli/tests/search/query_criteria.rs"}
     json.dump(out, open(OUT, "w"), indent=0, sort_keys=True)
-    print(len(cases), "cases ->", OUT, os.path.getsize(OUT), "bytes")
+    print(len(cases), "criteria cases,", len(dcases), "distinct cases ->", OUT, os.path.getsize(OUT), "bytes")
 
 
 if __name__ == "__main__":

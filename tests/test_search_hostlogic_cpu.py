@@ -556,3 +556,27 @@ def test_reference_criteria_tests_through_the_host_logic(hostlib, every=1):
                            sort=[tuple(x) for x in case["sort"]])
         assert [index.docs[d]["id"] for d, _ in hits] == case["ids"], (case["name"], case["criteria"])
         h.close()
+
+
+def test_reference_distinct_integration_tests(hostlib):
+    """crates/milli/tests/search/distinct.rs: 19 `test_distinct!` cases over test_set.ndjson — the literal candidates
+    counts (3 distinct tags, 7 distinct asc_desc_ranks; exhaustive or not), the first document of every value in
+    ranking order, offsets on the rule-less path, a limit of 0 — oracle and product."""
+    from oracle import ranking_oracle as RO
+    assert len(CRIT["distinct_cases"]) == 19
+    for case in CRIT["distinct_cases"]:
+        index = ToyMilli(CRIT_DOCS, searchable=CRIT["searchable"], criteria=case["criteria"], synonyms=CRIT["synonyms"])
+        dic = O.Dictionary(index.words)
+
+        def lookup(word, max_typos, is_prefix):
+            one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+            return [index.words[i] for i in one], [index.words[i] for i in two]
+        ids, _, cand = RO.search(RO.Ctx(index, lookup), CRIT["query"], criteria=case["criteria"], offset=case["offset"],
+                                 length=case["limit"], distinct=case["distinct"], exhaustive=case["exhaustive"])
+        assert [index.docs[d]["id"] for d in ids] == case["ids"] and len(cand) == case["candidates"], case["name"]
+        h = make_harness(hostlib, index)
+        hits, n_cand = h.search(CRIT["query"], criteria=case["criteria"], offset=case["offset"], limit=case["limit"],
+                                distinct=case["distinct"], exhaustive=case["exhaustive"])
+        assert [index.docs[d]["id"] for d, _ in hits] == case["ids"], case["name"]
+        assert n_cand == case["candidates"], case["name"]
+        h.close()

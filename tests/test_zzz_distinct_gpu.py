@@ -175,3 +175,8 @@ def test_reference_criteria_tests_on_the_device():
     """query_criteria.rs: 14 criterion cases + every 4th of the 120 criteria orders over test_set.ndjson (synonyms, real text)."""
     import tests.test_search_hostlogic_cpu as H
     H.test_reference_criteria_tests_through_the_host_logic(device_lib(), every=4)
+
+
+def test_reference_distinct_integration_tests_on_the_device():
+    import tests.test_search_hostlogic_cpu as H
+    H.test_reference_distinct_integration_tests(device_lib())
