@@ -580,3 +580,40 @@ def test_reference_distinct_integration_tests(hostlib):
         assert [index.docs[d]["id"] for d, _ in hits] == case["ids"], case["name"]
         assert n_cand == case["candidates"], case["name"]
         h.close()
+
+
+def test_reference_typo_tolerance_and_phrase_integration_tests(hostlib):
+    """crates/milli/tests/search/typo_tolerance.rs and phrase_search.rs over test_set.ndjson: hit counts under the typo
+    thresholds (min word length for 1 / 2 typos), exact words, exact attributes, and a phrase of stop words — oracle
+    and product."""
+    from oracle import ranking_oracle as RO
+    two = [{"id": 1, "data": "zealand"}, {"id": 2, "data": "zearand"}]
+    cases = [  # (docs, settings, criteria, query, tms, hits)
+        (CRIT_DOCS, {}, ["typo"], "zeal", "last", 1),                                     # typo_tolerance.rs:37-43
+        (CRIT_DOCS, {}, ["typo"], "zean", "last", 0),                                     # :54-60: 4 letters, no typo by default
+        (CRIT_DOCS, {"min_one": 4}, ["typo"], "zean", "last", 1),                         # :68-95
+        (CRIT_DOCS, {}, ["typo"], "zealand", "last", 1),                                  # :117-123
+        (CRIT_DOCS, {}, ["typo"], "zealemd", "last", 0),                                  # :134-140: 7 letters, one typo at most
+        (CRIT_DOCS, {"min_two": 7}, ["typo"], "zealemd", "last", 1),                      # :148-175
+        (two, {"searchable": None}, None, "zealand", "last", 2),                          # :249-255
+        (two, {"searchable": None, "exact_words": ["zealand"]}, None, "zealand", "last", 1),   # :263-292
+        (CRIT_DOCS, {}, ["typo"], "antebelum", "last", 1),                                # :315-321
+        (CRIT_DOCS, {"exact_attributes": ["description"]}, ["typo"], "antebelum", "last", 0),  # :330-356
+        (CRIT_DOCS, {"stop_words": ["a", "an", "the", "of"]}, [], '"the use of force"', "all", 1),   # phrase_search.rs:27-58
+        (CRIT_DOCS, {"stop_words": ["a", "an", "the", "of"]}, ["proximity", "attribute", "exactness"], '"the use of force"', "all", 1),
+    ]
+    for docs, settings, criteria, q, tms, n_hits in cases:
+        kw = dict(settings)
+        searchable = kw.pop("searchable", CRIT["searchable"])
+        index = ToyMilli(docs, searchable=searchable, criteria=criteria, synonyms=CRIT["synonyms"] if docs is CRIT_DOCS else None, **kw)
+        dic = O.Dictionary(index.words)
+
+        def lookup(word, max_typos, is_prefix):
+            one, two_ = O.typo_lookup(dic, word, max_typos, is_prefix)
+            return [index.words[i] for i in one], [index.words[i] for i in two_]
+        ids, _, _ = RO.search(RO.Ctx(index, lookup), q, tms=tms, criteria=index.criteria, length=10)
+        assert len(ids) == n_hits, (q, settings, "oracle")
+        h = make_harness(hostlib, index)
+        hits, _ = h.search(q, tms=tms, limit=10)
+        assert [d for d, _ in hits] == ids, (q, settings)
+        h.close()

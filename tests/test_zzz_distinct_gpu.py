@@ -180,3 +180,8 @@ def test_reference_criteria_tests_on_the_device():
 def test_reference_distinct_integration_tests_on_the_device():
     import tests.test_search_hostlogic_cpu as H
     H.test_reference_distinct_integration_tests(device_lib())
+
+
+def test_reference_typo_tolerance_and_phrase_integration_tests_on_the_device():
+    import tests.test_search_hostlogic_cpu as H
+    H.test_reference_typo_tolerance_and_phrase_integration_tests(device_lib())
