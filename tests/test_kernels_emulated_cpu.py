@@ -35,9 +35,10 @@ GROUPS = {
                        "tests/test_zzz_distinct_gpu.py::test_reference_criteria_tests_on_the_device",
                        "tests/test_zzz_distinct_gpu.py::test_reference_distinct_integration_tests_on_the_device",
                        "tests/test_zzz_distinct_gpu.py::test_reference_typo_tolerance_and_phrase_integration_tests_on_the_device",
+                       "tests/test_zzz_distinct_gpu.py::test_concurrent_searches_with_distinct_sort_and_geo",
                        "tests/test_zzz_geo_gpu.py::test_geo_sort_rs_on_the_device",
                        "tests/test_zz_levels_per_wait_gpu.py"],
-                      "not matches_oracle_on_random_corpora and not random_corpora_with_levels and not under_index_settings", 98),
+                      "not matches_oracle_on_random_corpora and not random_corpora_with_levels and not under_index_settings", 99),
     "ranked-search-vs-oracle": (["tests/test_zzz_distinct_gpu.py::test_distinct_matches_the_oracle_on_the_device",
                                  "tests/test_zzz_geo_gpu.py::test_geo_sort_matches_the_oracle_on_the_device",
                                  "tests/test_zz_order_keys_gpu.py::test_sort_rules_match_the_oracle_on_the_device"], "", 3),

@@ -133,7 +133,7 @@ def device_lib():
             d.close()
 
         def pool_create(self, n_docs, n_slots):
-            return ma.BitsPool(self.L.ctx, n_docs, n_slots)
+            return ma.BitsPool(self.L.ctx, n_docs, n_slots, private_stream=getattr(self.L, "private_streams", False))
 
         def pool_destroy(self, pool):
             pool.close()
@@ -185,3 +185,43 @@ def test_reference_distinct_integration_tests_on_the_device():
 def test_reference_typo_tolerance_and_phrase_integration_tests_on_the_device():
     import tests.test_search_hostlogic_cpu as H
     H.test_reference_typo_tolerance_and_phrase_integration_tests(device_lib())
+
+
+def test_concurrent_searches_with_distinct_sort_and_geo():
+    """One pool with a private stream per caller thread, the per-document arrays shared: 4 threads x 14 searches with
+    `distinct`, Sort and GeoSort rules equal the single-threaded results (the distinct scratch, the GeoSort cells and
+    the completion signals are per pool)."""
+    import threading
+    import tests.test_search_hostlogic_cpu as H
+    from tests.toy_milli import ToyMilli
+    index = ToyMilli(H.geo_corpus(11, 300), searchable=["title", "body"])
+    L = device_lib()
+    L.private_streams = True
+    jobs = []
+    for criteria, sort, geo in H.GEO_SETUPS[:4]:
+        for q, distinct in (("", "color"), ("the", None), ("quick fox", "sizes"), ("sun fl", "color")):
+            jobs.append((q, criteria, sort, distinct, geo))
+    jobs = jobs[:14]
+    base = H.make_harness(L, index)
+    want = [base.search(q, criteria=c, sort=s, distinct=d, limit=25, detailed=True, **g) for q, c, s, d, g in jobs]
+    base.close()
+    errors = []
+
+    def worker(k):
+        try:
+            h = H.make_harness(L, index)
+            for rep in range(2):
+                for j in range(len(jobs)):
+                    q, c, s, d, g = jobs[(j + k) % len(jobs)]
+                    got = h.search(q, criteria=c, sort=s, distinct=d, limit=25, detailed=True, **g)
+                    if got != want[(j + k) % len(jobs)]:
+                        errors.append((k, q, c, s, d))
+            h.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
