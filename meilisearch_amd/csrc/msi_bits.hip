@@ -1000,7 +1000,9 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
       p->h_sig = (volatile uint64_t *)h;
       p->h_sig[0] = p->h_sig[1] = 0;
       // the two cells of the GeoSort kernels rest at ~0 ("no point seen")
-      if (hipMemset(p->d_acc + 4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS, 0xFF, 2 * sizeof(u64)) != hipSuccess) s = MSI_E_HIP;
+      if (hipMemset(p->d_acc + 4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS, 0xFF, 2 * sizeof(u64)) != hipSuccess ||
+          hipStreamSynchronize(nullptr) != hipSuccess)  // the pool's streams do not order with the null stream's memsets
+        s = MSI_E_HIP;
     }
   }
   if (s != MSI_OK) {
