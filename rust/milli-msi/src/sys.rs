@@ -142,6 +142,13 @@ extern "C" {
     pub fn msi_doc_keys_destroy(k: *mut msi_doc_keys);
     pub fn msi_bits_order_next(p: *mut msi_bits, keys: *const msi_doc_keys, universe: u32, bucket: u32,
                                out_key: *mut u32, out_count: *mut u64) -> i32;
+    pub fn msi_bits_device_ptr(p: *mut msi_bits, slot: u32) -> *const u64;
+    pub fn msi_bits_set_from_words(p: *mut msi_bits, slot: u32, words: *const u64, n_words: u64) -> i32;
+    pub fn msi_vs_search_device(vs: *mut msi_vs, d_queries: *const f32, n_queries: u32, k: u32, d_filter_bits: *const u64,
+                                filter_nbits: u64, d_out_docids: *mut u32, d_out_dist: *mut f32, d_out_counts: *mut u32,
+                                d_inexact: *mut u32) -> i32;
+    pub fn msi_compare_scores(left: *const f64, n_left: u32, left_ratio: f32, right: *const f64, n_right: u32,
+                              right_ratio: f32) -> i32;
     pub fn msi_facet_number_key(value: f64) -> u64;
     pub fn msi_facet_keys_create(ctx: *mut msi_ctx, offsets: *const u64, keys: *const u64, n_docs: u64,
                                  out: *mut *mut msi_facet_keys) -> i32;
