@@ -48,3 +48,16 @@ def test_distance_formula_against_the_reference_dataset():
             assert math.ceil(distance_between_two_points(base, (d["_geo"]["lat"], d["_geo"]["lng"]))) == d["geo_rank"], d["id"]
             n += 1
     assert n == 17
+
+
+def test_distance_formula_against_the_geo_distance_literals_of_the_http_tests():
+    """`_geoDistance` = distance_between_two_points(...).round() (crates/meilisearch/src/search/mod.rs:2786); literals of
+    crates/meilisearch/tests/search/geo.rs:101,113,287-305 and tests/documents/add_documents.rs:1865-2067."""
+    from oracle.ranking_oracle import distance_between_two_points as dist
+    for a, b, want in [((45.4777599, 9.1967508), (45.4777599, 9.1967508), 0),
+                       ((45.4777599, 9.1967508), (34.0522, -118.2437), 9714063),
+                       ((0.0, 0.0), (-89.0, 0.0), 9896348), ((0.0, 0.0), (0.0, 178.0), 19792697),
+                       ((50.629973371633746, 3.0569447399419567), (1.0, 1.0), 5522018),
+                       ((50.629973371633746, 3.0569447399419567), (2.0, 2.0), 5408322),
+                       ((10.0, 0.0), (4.0, 0.0), 667170), ((10.0, 0.0), (3.0, 0.0), 778364), ((10.0, 0.0), (5.0, 0.0), 555975)]:
+        assert int(dist(a, b) + 0.5) == want, (a, b)
