@@ -75,3 +75,14 @@ def test_updates_equal_a_fresh_upload(ctx, oracle, n, dim, storage):
     with pytest.raises(ma.MsiError):
         st.update((), [9, 9], back[:2])
     st.close()
+
+
+def test_update_of_a_store_that_was_never_uploaded(ctx, oracle):
+    dim = 40
+    st = ma.GpuStore(ctx, dim)
+    st.update([1, 2, 3])                                     # removing from nothing
+    assert len(st) == 0
+    rows = synth.make_embeddings(50, dim, seed=3)
+    st.update((), np.arange(50, dtype=np.uint32) * 2, rows)
+    check_same(oracle, st, {2 * i: rows[i] for i in range(50)}, dim, 7, seed=1, storage="f32")
+    st.close()
