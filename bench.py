@@ -88,16 +88,15 @@ def main():
     # ---- vector store: rows ~ N(0,1)^d, seed 1234, generated in HBM -----------
     t_setup = time.time()
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1234)
+    gen.manual_seed(1234 + (rank if row_sharded else 0))   # distinct rows per shard, the same store per replica
     rows_t = torch.empty((n, d), dtype=torch.float32, device=dev)
     chunk = 1_000_000
-    for r0 in range(0, n, chunk):
-        r1 = min(n, r0 + chunk)
-        rows_t[r0:r1].normal_(generator=gen)
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        rows_t[c0:c1].normal_(generator=gen)
     ids_t = torch.arange(n, dtype=torch.int32, device=dev)
     if row_sharded:
-        ids_t += r0
-        gen.manual_seed(1234 + rank)   # distinct rows per shard
+        ids_t += r0                    # docids stay global: shard `rank` holds [r0, r1)
     torch.cuda.synchronize()
     store = ma.GpuStore(ctx, d, storage=args.storage)
     store.upload_device(ids_t, rows_t)
@@ -262,6 +261,10 @@ def main():
     stats = store.stats()
     n_inexact = int(inexact.sum().item())
 
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     total_queries = Q * (1 if row_sharded else world) * args.steps
