@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A kernel that never signals completion would leave the host polling for ever and the GPU box unusable: every
+    device test gets a wall-clock bound (pytest-timeout's thread method ends the process, which also frees the
+    device; the signal method cannot interrupt a blocked C call)."""
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(420, method="thread"))
+
+
 def pytest_sessionstart(session):
     """libmsi.so is a build artefact (git-ignored): build it when a fresh checkout runs the tests before
     __graft_entry__.build() did (hipcc cross-compiles gfx950 without a GPU; `make` is a no-op when up to date)."""
