@@ -394,8 +394,9 @@ int32_t msi_bits_geo_next(msi_bits *pool, const msi_geo_points *points, uint32_t
  * value_bounds.rs): instead of walking the facet levels of facet_id_f64_docids / facet_id_string_docids per
  * condition (facet_range_search.rs) and densifying the resulting Roaring bitmap for the scan, the facet values of a
  * filterable field live in HBM per document — CSR of u64 SORT KEYS, one table per (field, kind):
- *   numbers: msi_facet_number_key(x), a monotone map f64 -> u64 (x < y <=> key(x) < key(y); -0.0 == +0.0 is the
- *            caller's: milli stores what the document holds),
+ *   numbers: msi_facet_number_key(x), a monotone map f64 -> u64 (x < y <=> key(x) < key(y); -0.0 and +0.0 share
+ *            one key, as f64_into_bytes stores both as +0.0, facet/value_encoding.rs:5-7; non-finite values are never
+ *            indexed by milli and must not be passed),
  *   strings: the rank of the normalised value (normalize_facet, lib.rs:442-444) among the field's distinct values in
  *            byte order — what facet_id_string_fst enumerates — so that a string range, `STARTS WITH` (the range
  *            [prefix, prefix with its last byte + 1), index_filter.rs:198-250) and `=` are rank intervals the shim

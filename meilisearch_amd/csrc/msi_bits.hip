@@ -41,6 +41,9 @@ struct msi_bits {
   hipStream_t stream = nullptr;
   std::mutex own_mu;
   std::mutex *mu = nullptr;
+  // One counting operation in flight per pool: the signal cell pair {value, sequence} and the counts regions are per
+  // pool, so a caller holds wait_mu from its launch until it has read its result (lock order: wait_mu, then mu).
+  std::recursive_mutex wait_mu;  // recursive: a counting entry point may call another one of the same pool
   bool private_stream = false;
   // distinct scratch, per pool (one search per pool): first[v] = the smallest undecided candidate holding value v
   // this round, taken[v] = stamp of the call in which a kept candidate holds v.  Stamps instead of clears: a round
@@ -1240,6 +1243,7 @@ int32_t msi_bits_and_many_count(msi_bits *p, uint32_t prefix, uint32_t n, const 
     a.cond[k] = p->slot(cond[k]);
     a.dst[k] = p->slot(dst[k]);
   }
+  std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   const uint64_t n_pairs = p->n_words / 2;
@@ -1362,6 +1366,7 @@ int32_t msi_bits_paths_enqueue(msi_bits *p, uint32_t n_paths, const uint32_t *pa
 
 int32_t msi_bits_paths_collect(msi_bits *p, uint32_t n_regions, uint64_t *counts) {
   if (!p || !n_regions || n_regions > MSI_BITS_PATH_REGIONS || !counts) return MSI_E_INVALID;
+  std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
   uint64_t seq;
   {
     std::lock_guard<std::mutex> lk(*p->mu);
@@ -1382,6 +1387,7 @@ int32_t msi_bits_paths_claim(msi_bits *p, uint32_t n_paths, const uint32_t *path
   MSI_TRY(check_slot(p, bucket, "msi_bits_paths_claim"));
   MSI_TRY(check_slot(p, universe, "msi_bits_paths_claim"));
   for (uint32_t s = 0; s < n_steps; ++s) MSI_TRY(check_slot(p, step_slots[s], "msi_bits_paths_claim"));
+  std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   hipStream_t st = p->stream;
@@ -1432,9 +1438,12 @@ int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &bat
       MSI_TRY(p->stage.ensure(std::max<size_t>({batch.bytes.size(), p->stage.cap * 2, (size_t)1 << 20})));
     if (n_cont * sizeof(Container) > p->desc.cap)
       MSI_TRY(p->desc.ensure(std::max<size_t>({n_cont * sizeof(Container), p->desc.cap * 2, (size_t)64 << 10})));
-    uint8_t *hb = nullptr, *hc = nullptr;
-    MSI_TRY(ring_alloc(p, batch.bytes.size(), &hb));
-    MSI_TRY(ring_alloc(p, n_cont * sizeof(Container), &hc));
+    // ONE ring block for both pieces: a second ring_alloc may wrap onto (or, growing the ring, free) the first
+    // block before its bytes have been copied
+    const size_t bytes_al = (batch.bytes.size() + 255) & ~(size_t)255;
+    uint8_t *hb = nullptr;
+    MSI_TRY(ring_alloc(p, bytes_al + n_cont * sizeof(Container), &hb));
+    uint8_t *hc = hb + bytes_al;
     memcpy(hb, batch.bytes.data(), batch.bytes.size());
     memcpy(hc, batch.containers.data(), n_cont * sizeof(Container));
     MSI_HIP_TRY(hipMemcpyAsync(p->stage.p, hb, batch.bytes.size(), hipMemcpyHostToDevice, st));
@@ -1506,6 +1515,7 @@ int32_t msi_bits_op_count(msi_bits *p, uint32_t dst, uint32_t a, uint32_t b, int
   MSI_TRY(check_slot(p, a, "msi_bits_op_count"));
   MSI_TRY(check_slot(p, b, "msi_bits_op_count"));
   if (!out_count) return MSI_E_INVALID;
+  std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   const uint64_t n_pairs = p->n_words / 2;
@@ -1605,6 +1615,7 @@ int32_t msi_bits_order_next(msi_bits *p, const msi_doc_keys *keys, uint32_t univ
   }
   MSI_TRY(check_slot(p, universe, "msi_bits_order_next"));
   MSI_TRY(check_slot(p, bucket, "msi_bits_order_next"));
+  std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   hipStream_t st = p->stream;
@@ -1736,6 +1747,7 @@ int32_t msi_bits_distinct(msi_bits *p, const msi_doc_values *vals, uint32_t cand
   MSI_TRY(check_slot(p, candidates, "msi_bits_distinct"));
   MSI_TRY(check_slot(p, remaining, "msi_bits_distinct"));
   if (excluded != MSI_BITS_NO_SLOT) MSI_TRY(check_slot(p, excluded, "msi_bits_distinct"));
+  std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   hipStream_t st = p->stream;
@@ -1821,6 +1833,7 @@ int32_t msi_bits_andnot_many_count(msi_bits *p, uint32_t removed, uint32_t n, co
     }
     a.dst[k] = p->slot(slots[k]);
   }
+  std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   const uint64_t n_pairs = p->n_words / 2;
@@ -1878,6 +1891,7 @@ void msi_geo_points_destroy(msi_geo_points *gp) {
 // one launch of the take kernel in a range mode (0: dst := selection, 2: dst |= selection) -> |selection|
 static int32_t geo_range(msi_bits *p, const msi_geo_points *gp, const GeoTarget &t, uint32_t src, uint32_t dst, int mode,
                          u64 key_lo, u64 key_hi, uint64_t *count) {
+  std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   u64 *cells = p->d_acc + 4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS;
@@ -1916,6 +1930,7 @@ int32_t msi_bits_geo_next(msi_bits *p, const msi_geo_points *gp, uint32_t univer
   const uint64_t cap = max_bucket_size ? max_bucket_size : 1000;
   uint64_t count = 0, first = 0, kbest = 0;
   {
+    std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
     std::unique_lock<std::mutex> lk(*p->mu);
     DeviceGuard g(p->ctx->device);
     hipStream_t st = p->stream;
@@ -1977,6 +1992,8 @@ int32_t msi_bits_geo_next(msi_bits *p, const msi_geo_points *gp, uint32_t univer
 }
 
 uint64_t msi_facet_number_key(double value) {
+  // f64_into_bytes (heed_codec/facet/value_encoding.rs:5-20) stores -0.0 as +0.0: one key for both
+  if (value == 0.0) value = 0.0;
   uint64_t b;
   memcpy(&b, &value, sizeof(b));
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // the order of the doubles (OrderedF64Codec sorts the same way)
@@ -2119,6 +2136,7 @@ int32_t msi_bits_geo_within(msi_bits *p, const msi_geo_points *gp, uint32_t src,
 int32_t msi_bits_count(msi_bits *p, uint32_t slot, uint64_t *out) {
   MSI_TRY(check_slot(p, slot, "msi_bits_count"));
   if (!out) return MSI_E_INVALID;
+  std::lock_guard<std::recursive_mutex> wl(p->wait_mu);
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   hipStream_t st = p->stream;

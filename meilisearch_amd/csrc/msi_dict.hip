@@ -6,22 +6,22 @@
 // `fst.search_with_state(Levenshtein DFA ∩/∪ StartsWith)` with the 150/50 caps
 // (search/new/limits.rs:7-9).  Design:
 //
-//   HBM layout  the sorted dictionary is staged as 16-byte slots (one word per
-//               slot, zero padded) + byte/char lengths; words longer than 16
-//               bytes keep their bytes in a flat side array and are matched by a
-//               second, much smaller launch of the same kernel.
-//   dict_match  one lane per dictionary word, 64 consecutive words per wave tile,
-//               words live in registers as a 128-bit byte queue while the wave
-//               loops over the queries of its chunk.  Distance = banded (2k+1
-//               diagonals) optimal-string-alignment DP over code points, all lanes
-//               in lock step so the query characters are wave-uniform scalars.
-//               The first-letter rule turns into index ranges: the words that
-//               share the query's first char are one contiguous range [lo,hi) of
-//               the sorted dictionary; outside it only "distance <= 1" can match
-//               and a 3-compare prefilter removes almost every word.
-//   ordering    every wave owns a contiguous dictionary segment, so ballots +
-//               v_mbcnt give per-segment lists already in fst stream order;
-//               dict_finalize concatenates segments and applies the cap logic.
+//   HBM layout  the sorted dictionary (what fst.stream() yields) as 16-byte slots (one
+//               word per slot, zero padded; longer words keep their bytes in the flat
+//               array), a 64-bit char-presence signature and the char / byte lengths
+//               per word, and the table of first-char blocks.
+//   work shape  the FST ∩ DFA walk never leaves the subtrees the automaton can still
+//               accept; the sorted dictionary gives the same pruning as index ranges:
+//               (1) words that share the query's first char are ONE range [lo, hi)
+//               (first-letter rule): only that range is scanned — lane = word, a
+//               10-byte filter (length window + signature), survivors compacted into
+//               dense lanes for the banded (5 diagonal) OSA DP over code points;
+//               (2) words with another first char match only through one edit on
+//               position 0, i.e. they are exact strings (string prefixes under the
+//               prefix rule): binary searches, no scan.
+//   ordering    one workgroup per query; its waves own contiguous pieces of the range,
+//               so ballots give per-wave lists already in fst stream order and their
+//               concatenation is the stream; the cap logic runs in the same launch.
 //
 // Closed form of the reference's sequential cap logic (derived in DESIGN.md):
 //   S1/S2 = same-first-char words at distance exactly 1 / 2, X = other-first-char
@@ -41,27 +41,24 @@ typedef unsigned long long u64;
 
 namespace {
 
-constexpr int QC = 64;            // queries per workgroup chunk (6-bit query slot in a pair)
-constexpr int DW = 4;             // waves per workgroup (all on the same query chunk)
+constexpr int LW = 8;             // waves per workgroup; one workgroup walks one query's dictionary range
+constexpr int LT = LW * 64;
 constexpr int QSTRIDE = 256;      // code points reserved per query
-constexpr int QL = 32;            // query code points staged in LDS (longer queries read HBM)
-constexpr int PQ = 256;           // pair-queue ring entries per wave (power of two, >= 63 + 128)
+constexpr int PQ = 256;           // survivor ring entries per wave (power of two, >= 63 + 64)
+constexpr int XB = LT / 2;        // first-char blocks searched per round of the other-first-char step
 constexpr int DINF = 1 << 20;
 constexpr uint32_t QNONE = 0xFFFFFFFFu;  // "no such query char": never equals a word char
-constexpr uint32_t WNONE = 0xFFFFFFFDu;  // "no such word char"
 
-struct alignas(64) QueryMeta {   // one 64-byte scalar load per (tile, query) step
+struct alignas(64) QueryMeta {   // one 64-byte line per query
   uint32_t m;        // chars
   uint32_t budget;   // 1 or 2 (0 = skip)
   uint32_t prefix;
-  uint32_t _pad;
+  uint32_t qlen;     // bytes
   uint32_t lo, hi;   // dictionary range of the words starting with the query's first char
   u64 sig;           // char-presence signature (bit = sig_bit(code point))
-  // (first, second) char pairs of the four one-edit shapes that change the first char
-  u64 p12;           // (q1, q2): substitute q0 -> w[1..2];  delete q0 -> w[0..1]
-  u64 p01;           // (q0, q1): insert before q0 -> w[1..2]
-  u64 p10;           // (q1, q0): swap q0 q1 -> w[0..1]
-  u64 _pad2;
+  uint32_t l0, l1;   // byte lengths of the first and second char (l1 = 0: one char only)
+  uint32_t q0, q1;   // their code points
+  u64 _pad[2];
 };
 static_assert(sizeof(QueryMeta) == 64, "QueryMeta is one 64-byte line");
 
@@ -127,24 +124,22 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
-// Query code points of the lane's OWN query: the first QL from LDS, the rest from HBM.
+// Query code points: every lane of the workgroup works on the SAME query (staged in LDS; reads broadcast).
 struct QChars {
-  const uint32_t *lds;   // this lane's row of the staged chunk
-  const uint32_t *glb;   // this lane's row of a.qchars
+  const uint32_t *q;
   int m;
   __device__ __forceinline__ uint32_t at(int t) const {  // t is wave-uniform
     if (t < 0 || t >= m) return QNONE;
-    return t < QL ? lds[t] : glb[t];
+    return q[t];
   }
 };
 
 // Banded optimal-string-alignment distance (insert / delete / substitute /
 // adjacent transposition, each cost 1 — levenshtein_automata 0.2.1 with
 // transposition_cost_one = true, crates/milli/src/search/mod.rs:32-34) between
-// the lane's query (m chars) and the lane's word (nch chars): every lane of the
-// wave works on its OWN (query, word) pair.  The band is 5 diagonals (|i-j| <= 2)
-// for every lane; the result is exact whenever the true value is <= K (K = 1 or 2
-// per lane) and > K otherwise.  prefix: minimum over the prefixes of the word
+// the workgroup's query (m chars) and the lane's word (nch chars).  The band is 5
+// diagonals (|i-j| <= 2); the result is exact whenever the true value is <= K
+// (K = 1 or 2) and > K otherwise.  prefix: minimum over the prefixes of the word
 // (build_prefix_dfa, search/mod.rs:572-573).  All lanes step through the word
 // positions together, so the cell index i = j + d - 2 is wave-uniform and the
 // query window slides by one LDS read per step.
@@ -219,258 +214,346 @@ __device__ __forceinline__ int osa_pair(Reader rd, int nch, bool active, const Q
   return (active && nch <= m + K) ? res : DINF;
 }
 
-// First three chars (WNONE when absent) and char-presence signature of the lane's word.
-struct WordKeys {
-  u64 w01, w12, sig;
-};
-template <class Reader>
-__device__ __forceinline__ WordKeys scan_word(Reader rd, int nc, int nmax) {
-  uint32_t wc0 = WNONE, wc1 = WNONE, wc2 = WNONE;
-  u64 sig = 0;
-  for (int j = 0; j < nmax; ++j) {
-    const uint32_t c = rd.next_char();
-    if (j < nc) {
-      sig |= 1ull << sig_bit(c);
-      wc0 = j == 0 ? c : wc0;
-      wc1 = j == 1 ? c : wc1;
-      wc2 = j == 2 ? c : wc2;
-    }
-  }
-  WordKeys k;
-  k.w01 = pair_key(wc0, wc1);
-  k.w12 = pair_key(wc1, wc2);
-  k.sig = sig;
-  return k;
-}
-
-// ---- matching kernel -----------------------------------------------------------
+// ---- lookup kernel -----------------------------------------------------------------
 
 struct DictArgs {
-  const uint4 *slots;       // [n_words]
-  const uint8_t *blen;      // [n_words] byte length
-  const uint8_t *nchars;    // [n_words] char count
-  const uint8_t *flat;      // concatenated bytes
-  const uint32_t *offs;     // [n_words+1]
-  const uint32_t *long_idx; // [n_long] indices of words longer than 16 bytes (ascending)
-  uint32_t n_words;
-  uint32_t n_items;         // words handled by this launch (n_words or n_long)
-  const QueryMeta *qm;      // [nq]
-  const uint32_t *qchars;   // [nq][QSTRIDE]
+  const uint4 *slots;        // [n_words] first 16 bytes of every word, zero padded
+  const u64 *sigs;           // [n_words] char-presence signature of the whole word
+  const uint16_t *wmeta;     // [n_words] char count | byte length << 8
+  const uint8_t *flat;       // concatenated bytes
+  const uint32_t *offs;      // [n_words+1]
+  const uint32_t *fc_start;  // [n_fc+1] first word of every first-char block (non-empty words), ascending
+  uint32_t n_fc, n_words;
+  const QueryMeta *qm;       // [nq]
+  const uint32_t *qchars;    // [nq][QSTRIDE]
+  const uint8_t *qbytes;
+  const uint32_t *qoff;
   uint32_t nq;
-  uint32_t nseg;            // dictionary segments (a multiple of DW)
   uint32_t cap1, cap2, capx;
-  uint32_t *lists;          // [nq][nseg][cap1+cap2+capx]
-  uint32_t *cnts;           // [nq][nseg][3]
-  u64 *pairs;               // stats: (query, word) pairs that reached a DP lane
+  uint32_t *wlists;          // [grid][LW][cap1+cap2] per-wave hit lists (distance 1 | distance 2)
+  uint32_t *xlists;          // [grid][capx] other-first-char words at distance <= 1
+  uint32_t *ticket;          // next query to take
+  u64 *pairs;                // stats: (query, word) pairs that reached a DP lane
+  uint32_t *out_one, *out_one_cnt, *out_two, *out_two_cnt;
 };
 
-// Two phases per 64-word tile, both with every lane busy:
-//   filter  lane = word; the wave walks the queries of its chunk (wave-uniform
-//           query data) and applies the length / first-char tests; survivors are
-//           appended, in lane order, to a per-wave ring of (word lane, query, class)
-//           pairs with ballots (no atomics);
-//   match   whenever 64 pairs are queued (and at the end of the tile) every lane
-//           takes ONE pair — its own word and its own query — and runs the banded
-//           OSA DP, so the DP lanes are dense instead of following the ~5 % of the
-//           (word, query) grid that survives the filter.
-// Hits are appended to the per-(query, segment, class) lists in dictionary order:
-// pairs of one (query, class) are contiguous in the ring and ordered by word.
-template <bool LONG>
-__global__ __launch_bounds__(DW * 64) void dict_match_kernel(DictArgs a, const QueryMeta *__restrict__ qmeta) {
-  __shared__ uint32_t s_qch[QC][QL];          // staged query code points
-  __shared__ uint32_t s_qmb[QC];              // m | budget << 16 | prefix << 24
-  __shared__ uint4 s_slot[DW][64];            // the wave's current tile
-  __shared__ uint32_t s_wmeta[DW][64];        // nc | bl << 8
-  __shared__ uint32_t s_widx[DW][64];
-  __shared__ uint32_t s_pq[DW][PQ];
-  __shared__ uint32_t s_cnt[DW][QC][3];
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t bps = a.nseg / DW;           // workgroups per query chunk
-  const uint32_t chunk = blockIdx.x / bps;
-  const uint32_t seg = (blockIdx.x % bps) * DW + wave;
-  const uint32_t q_begin = chunk * QC;
-  const uint32_t nqc = min((uint32_t)QC, a.nq - q_begin);
-  for (uint32_t i = threadIdx.x; i < nqc * QL; i += DW * 64)
-    s_qch[i / QL][i % QL] = a.qchars[(size_t)(q_begin + i / QL) * QSTRIDE + (i % QL)];
-  for (uint32_t i = threadIdx.x; i < nqc; i += DW * 64) {
-    const QueryMeta &q = a.qm[q_begin + i];
-    s_qmb[i] = q.m | (q.budget << 16) | (q.prefix << 24);
+// A pattern assembled from up to three pieces of the query's bytes (the one-edit shapes that change the first
+// char: delete q0, swap q0 q1, and — behind a dictionary first char — substitute q0 / insert before q0).
+struct Pattern {
+  const uint8_t *qb;
+  uint32_t o0, l0, o1, l1, o2, l2, len;
+  __device__ __forceinline__ uint32_t at(uint32_t i) const {
+    if (i < l0) return qb[o0 + i];
+    i -= l0;
+    if (i < l1) return qb[o1 + i];
+    return qb[o2 + i - l1];
   }
-  for (uint32_t i = lane; i < QC * 3; i += 64) (&s_cnt[wave][0][0])[i] = 0;
-  __syncthreads();
+};
 
-  const uint32_t n_tiles = (a.n_items + 63) / 64;
-  const uint32_t t0 = (uint32_t)((u64)n_tiles * seg / a.nseg);
-  const uint32_t t1 = (uint32_t)((u64)n_tiles * (seg + 1) / a.nseg);
-  const uint32_t stride_l = a.cap1 + a.cap2 + a.capx;
+// word[skip..] against the pattern: -1 the tail sorts before every string the pattern is a prefix of, 0 the
+// pattern is a prefix of the tail (*exact: they are equal), +1 the tail sorts after all of them.
+__device__ __forceinline__ int cmp_tail(const DictArgs &a, uint32_t idx, uint32_t skip, const Pattern &p, bool *exact) {
+  const uint32_t o = a.offs[idx] + skip, tl = a.offs[idx + 1] - o;
+  const uint32_t n = tl < p.len ? tl : p.len;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t wb = a.flat[o + i], pb = p.at(i);
+    if (wb != pb) return wb < pb ? -1 : 1;
+  }
+  if (tl < p.len) return -1;
+  *exact = tl == p.len;
+  return 0;
+}
+
+// The words of [s, e) (all sharing their first `skip` bytes) whose tail equals the pattern (prefix = false) or
+// starts with it (prefix = true): a contiguous index range of the sorted dictionary.
+__device__ __forceinline__ void find_range(const DictArgs &a, uint32_t s, uint32_t e, uint32_t skip, const Pattern &p,
+                                           bool prefix, uint32_t *ra, uint32_t *rb) {
+  bool ex = false;
+  uint32_t lo = s, hi = e;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (cmp_tail(a, mid, skip, p, &ex) < 0) lo = mid + 1;
+    else hi = mid;
+  }
+  *ra = *rb = lo;
+  if (lo >= e) return;
+  ex = false;
+  if (cmp_tail(a, lo, skip, p, &ex) != 0) return;
+  if (!prefix) {
+    if (ex) *rb = lo + 1;   // the shortest word with this prefix sorts first: an exact match sits at the lower bound
+    return;
+  }
+  uint32_t l2 = lo + 1;
+  hi = e;
+  while (l2 < hi) {
+    const uint32_t mid = l2 + (hi - l2) / 2;
+    if (cmp_tail(a, mid, skip, p, &ex) == 0) l2 = mid + 1;
+    else hi = mid;
+  }
+  *rb = l2;
+}
+
+// The hit lists of a workgroup's waves as one ascending stream: the waves' pieces of the range are contiguous
+// dictionary ranges, so concatenation in wave order is dictionary order.
+struct WaveLists {
+  const uint32_t *base;
+  uint32_t stride, off, cls, w, i;
+  const uint32_t (*cnt)[2];
+  __device__ __forceinline__ void settle() { while (w < (uint32_t)LW && i >= cnt[w][cls]) { ++w; i = 0; } }
+  __device__ __forceinline__ bool done() const { return w >= (uint32_t)LW; }
+  __device__ __forceinline__ uint32_t peek() const { return base[(size_t)w * stride + off + i]; }
+  __device__ __forceinline__ void pop() { ++i; settle(); }
+};
+
+// One workgroup per query (queries are handed out by a ticket counter), three steps:
+//   scan    the words that share the query's first char are ONE index range [lo, hi) of the sorted dictionary
+//           (first-letter rule, compute_derivations.rs:120-124); the 8 waves split it into contiguous pieces.
+//           filter: lane = word, 10 bytes per word (signature + lengths): length window of K edits and the
+//           char-presence signature (every edit introduces at most one new char, so popc(sig_q & ~sig_w) <= K and,
+//           without the prefix rule, popc(sig_w & ~sig_q) <= K are necessary).  Survivors are queued with ballots in
+//           a per-wave LDS ring; whenever 64 are queued every lane takes ONE word and runs the banded OSA DP against
+//           the (wave-uniform) query — dense DP lanes.  Hits are appended in dictionary order to the wave's lists.
+//   search  words with ANOTHER first char match only at distance <= 1, through one edit on position 0: substitute
+//           q0 (c + q[1..]), insert before q0 (c + q), delete q0 (q[1..]), swap q0 q1 (q1 q0 q[2..]).  These are
+//           exact strings (prefix rule: string prefixes), so they are binary searches in the sorted dictionary —
+//           two per dictionary first char c, two more for the shapes without c — instead of a scan.
+//   caps    the reference's sequential cap logic in closed form (header of this file) over the three lists.
+__global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
+  __shared__ uint32_t s_q[QSTRIDE];
+  __shared__ uint8_t s_qb[256];
+  __shared__ uint32_t s_pq[LW][PQ];
+  __shared__ uint32_t s_wcnt[LW][2];
+  __shared__ uint32_t s_xr[XB][4];     // per first-char block of the round: (a) range, (c) range
+  __shared__ u64 s_xany[LW];
+  __shared__ uint32_t s_ext[2][2];     // the two shapes without a dictionary first char: delete q0, swap q0 q1
+  __shared__ uint32_t s_query, s_xdone;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 lower = (1ull << lane) - 1ull;
+  const uint32_t stride_w = a.cap1 + a.cap2;
+  uint32_t *const wl = a.wlists + ((size_t)blockIdx.x * LW + wave) * stride_w;
+  uint32_t *const xl = a.xlists + (size_t)blockIdx.x * a.capx;
   u64 pairs = 0;
-  uint32_t head = 0, qn = 0;  // ring state (wave-uniform)
-  bool tile_ascii = false;
 
-  // ---- match phase: lanes [0, n) take one queued pair each ---------------------
-  auto drain = [&](uint32_t n) {
-    const bool act = lane < n;
-    const uint32_t desc = s_pq[wave][(head + lane) & (PQ - 1)];
-    const uint32_t wl = desc & 63, ql = (desc >> 6) & 63, cls = (desc >> 12) & 1;
-    const uint32_t qlc = act ? ql : 0;
-    const uint4 slot = s_slot[wave][wl];
-    const uint32_t wm = s_wmeta[wave][wl];
-    const uint32_t widx = s_widx[wave][wl];
-    const int nc = (int)(wm & 0xFF);
-    const uint32_t qmb = s_qmb[qlc];
-    const int m = (int)(qmb & 0xFFFF);
-    const uint32_t budget = (qmb >> 16) & 0xFF;
-    const bool prefix = (qmb >> 24) != 0;
-    const int K = cls ? 1 : (int)budget;
+  for (;;) {
+    __syncthreads();  // the previous query's LDS state is no longer read
+    if (tid == 0) {
+      s_query = atomicAdd(a.ticket, 1u);
+      s_xdone = 0;
+    }
+    __syncthreads();
+    const uint32_t q = s_query;
+    if (q >= a.nq) break;
+    const QueryMeta qm = a.qm[q];
+    const int K = (int)qm.budget;
+    if (K == 0) {
+      if (tid == 0) a.out_one_cnt[q] = a.out_two_cnt[q] = 0;
+      continue;
+    }
+    const int m = (int)qm.m;
+    const bool prefix = qm.prefix != 0;
+    for (uint32_t i = tid; i < (uint32_t)m; i += LT) s_q[i] = a.qchars[(size_t)q * QSTRIDE + i];
+    for (uint32_t i = tid; i < qm.qlen; i += LT) s_qb[i] = a.qbytes[a.qoff[q] + i];
+    __syncthreads();
     QChars qs;
-    qs.lds = &s_qch[qlc][0];
-    qs.glb = a.qchars + (size_t)(q_begin + qlc) * QSTRIDE;
-    qs.m = act ? m : 0;
-    int d;
-    if (LONG) {
-      const uint32_t o0 = act ? a.offs[widx] : 0, o1 = act ? a.offs[widx + 1] : 0;
-      FlatReader r{a.flat + o0, a.flat + o1};
-      d = osa_pair(r, nc, act, qs, K, prefix);
-    } else if (tile_ascii) {
-      SlotReader<true> r{slot.x, slot.y, slot.z, slot.w};
-      d = osa_pair(r, nc, act, qs, K, prefix);
-    } else {
-      SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
-      d = osa_pair(r, nc, act, qs, K, prefix);
-    }
-    // category: 0 = S1 (same first char, distance 1), 1 = S2 (distance 2), 2 = X
-    uint32_t cat = 3;
-    if (act) {
-      if (cls == 0) cat = d == 1 ? 0u : ((budget == 2 && d == 2) ? 1u : 3u);
-      else cat = d <= 1 ? 2u : 3u;
-    }
-    // pairs of one query are contiguous: segment = run of equal query slots
-    const uint32_t prev_ql = __shfl_up(ql, 1);
-    const bool is_start = act && (lane == 0 || prev_ql != ql);
-    const u64 starts = __ballot(is_start);
-    const u64 upto = lower | (1ull << lane);
-    const uint32_t p = 63 - __clzll((long long)(starts & upto));      // segment start (act lanes only)
-    const u64 above = starts & ~upto;
-    const uint32_t nxt = above ? (uint32_t)__ffsll((long long)above) - 1 : n;
-    const u64 segmask = (nxt >= 64 ? ~0ull : ((1ull << nxt) - 1ull)) & ~((1ull << p) - 1ull);
-    uint32_t *lst = a.lists + ((size_t)(q_begin + qlc) * a.nseg + seg) * stride_l;
-#pragma unroll
-    for (uint32_t c = 0; c < 3; ++c) {
-      const u64 hb = __ballot(cat == c);
-      if (hb == 0) continue;
-      const uint32_t cap = c == 0 ? a.cap1 : (c == 1 ? a.cap2 : a.capx);
-      const uint32_t off = c == 0 ? 0 : (c == 1 ? a.cap1 : a.cap1 + a.cap2);
-      const uint32_t base = act ? s_cnt[wave][qlc][c] : 0;
-      if (cat == c) {
-        const uint32_t pos = base + __popcll(hb & segmask & lower);
-        if (pos < cap) lst[off + pos] = widx;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (is_start) s_cnt[wave][qlc][c] = base + __popcll(hb & segmask);
-    }
-    __builtin_amdgcn_wave_barrier();
-    pairs += n;
-    head = (head + n) & (PQ - 1);
-    qn -= n;
-  };
+    qs.q = s_q;
+    qs.m = m;
 
-  for (uint32_t t = t0; t < t1; ++t) {
-    const uint32_t item = t * 64 + lane;
-    const bool in_range = item < a.n_items;
-    uint32_t idx = 0xFFFFFFFFu;
-    if (in_range) idx = LONG ? a.long_idx[item] : item;
-    uint32_t bl = 0, nc = 0;
-    uint4 slot = make_uint4(0, 0, 0, 0);
-    if (in_range) {
-      bl = a.blen[idx];
-      nc = a.nchars[idx];
-      slot = a.slots[idx];
-    }
-    // words longer than a slot belong to the LONG launch; empty words never match
-    const bool mine = in_range && bl > 0 && (LONG ? true : bl <= 16);
-    tile_ascii = !LONG && (__ballot(mine && nc != bl) == 0);
-    s_slot[wave][lane] = slot;
-    s_wmeta[wave][lane] = nc | (bl << 8);
-    s_widx[wave][lane] = idx;
-    // per-word filter keys: first three chars as (w0,w1) / (w1,w2) pairs and the
-    // char-presence signature of the whole word
-    WordKeys wk;
-    {
-      const int ncm = mine ? (int)nc : 0;
-      const int nmax = wave_max_i32(ncm);
-      if (LONG) {
-        const uint32_t o0 = mine ? a.offs[idx] : 0, o1 = mine ? a.offs[idx + 1] : 0;
-        wk = scan_word(FlatReader{a.flat + o0, a.flat + o1}, ncm, nmax);
-      } else if (tile_ascii) {
-        wk = scan_word(SlotReader<true>{slot.x, slot.y, slot.z, slot.w}, ncm, nmax);
-      } else {
-        wk = scan_word(SlotReader<false>{slot.x, slot.y, slot.z, slot.w}, ncm, nmax);
+    // ---- scan: the same-first-char range ------------------------------------------------------------
+    uint32_t cnt0 = 0, cnt1 = 0;      // hits of this wave at distance 1 / 2 (wave-uniform)
+    uint32_t head = 0, qn = 0;        // ring state (wave-uniform)
+    auto drain = [&](uint32_t n) {
+      const bool act = lane < n;
+      const uint32_t idx = act ? s_pq[wave][(head + lane) & (PQ - 1)] : 0u;
+      const uint4 slot = a.slots[idx];
+      const uint32_t wm = a.wmeta[idx];
+      const int nc = (int)(wm & 0xFF);
+      const uint32_t bl = wm >> 8;
+      const bool is_long = act && bl > 16;
+      const bool is_short = act && !is_long;
+      int d = DINF;
+      if (__ballot(is_short)) {
+        if (__ballot(is_short && (uint32_t)nc != bl) == 0) {
+          SlotReader<true> r{slot.x, slot.y, slot.z, slot.w};
+          d = osa_pair(r, nc, is_short, qs, K, prefix);
+        } else {
+          SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
+          d = osa_pair(r, nc, is_short, qs, K, prefix);
+        }
       }
-    }
-    const u64 w01 = wk.w01, w12 = wk.w12, wsig = wk.sig;
-    // dictionary index range covered by this tile (ascending within the tile)
-    const uint32_t idx_first = __builtin_amdgcn_readfirstlane(__shfl(idx, 0));
-    uint32_t idx_last;
-    {
-      const u64 bm = __ballot(in_range);
-      const int last_lane = 63 - __clzll((long long)bm);
-      idx_last = __builtin_amdgcn_readfirstlane(__shfl(idx, last_lane));
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- filter phase: query data is wave-uniform (scalar loads), tests branch-free --
-    for (uint32_t ql = 0; ql < nqc; ++ql) {
-      const QueryMeta qm = qmeta[q_begin + ql];   // one 64-byte line, scalar loads
-      const uint32_t budget = qm.budget;
-      if (budget == 0) continue;
-      const uint32_t lo = qm.lo, hi = qm.hi;
-      const bool tile_hits_s = (idx_last >= lo) & (idx_first < hi);
-      const bool tile_all_s = (idx_first >= lo) & (idx_last < hi);
-      if (!tile_hits_s & (budget != 2)) continue;   // one-typo words only live in [lo, hi)
-      const int m = (int)qm.m;
-      const bool prefix = qm.prefix != 0;
-      const int K = (int)budget;
-      const bool same_first = mine & (idx >= lo) & (idx < hi);
-      // every char of the query but <= K must occur in the word (and, without the
-      // prefix rule, vice versa): each edit introduces at most one new char
-      const uint32_t q_not_w = __popcll(qm.sig & ~wsig);
-      const uint32_t w_not_q = prefix ? 0u : __popcll(wsig & ~qm.sig);
-      const uint32_t sigd = max(q_not_w, w_not_q);
-      // length window for K edits: nc + K >= m, and nc <= m + K unless the prefix rule applies
-      const int ncK_s = (int)nc + K, ncK_x = (int)nc + 1;
-      const bool len_s = (ncK_s >= m) & (prefix | ((int)nc <= m + K));
-      const bool len_x = (ncK_x >= m) & (prefix | ((int)nc <= m + 1));
-      const bool act_s = tile_hits_s & same_first & len_s & (sigd <= (uint32_t)K);
-      // A word with another first char can only be at distance <= 1 through ONE edit
-      // that touches position 0: substitute q0 (w[1..] = q[1..]), delete q0 (w = q[1..]),
-      // insert before q0 (w[1..] = q), or swap q0 q1 (w = q1 q0 q[2..]).  Two chars of
-      // each shape are tested here; the DP decides.  (Queries under 3 chars: no char test.)
-      const bool shape = (m < 3) | (w12 == qm.p12) | (w01 == qm.p12) | (w12 == qm.p01) | (w01 == qm.p10);
-      const bool act_x = (budget == 2) & !tile_all_s & mine & !same_first & len_x & (sigd <= 1u) & shape;
-      const u64 ms = __ballot(act_s);
-      const u64 mx = __ballot(act_x);
-      if ((ms | mx) == 0) continue;
-      if (ms) {
-        if (act_s) s_pq[wave][(head + qn + __popcll(ms & lower)) & (PQ - 1)] = lane | (ql << 6);
+      if (__ballot(is_long)) {   // words longer than a slot read their bytes from the flat array
+        const uint32_t o0 = is_long ? a.offs[idx] : 0, o1 = is_long ? a.offs[idx + 1] : 0;
+        FlatReader r{a.flat + o0, a.flat + o1};
+        const int dl = osa_pair(r, nc, is_long, qs, K, prefix);
+        if (is_long) d = dl;
+      }
+      const uint32_t cat = !act ? 3u : (d == 1 ? 0u : ((K == 2 && d == 2) ? 1u : 3u));
+      const u64 h0 = __ballot(cat == 0), h1 = __ballot(cat == 1);
+      if (cat == 0) {
+        const uint32_t pos = cnt0 + __popcll(h0 & lower);
+        if (pos < a.cap1) wl[pos] = idx;
+      }
+      if (cat == 1) {
+        const uint32_t pos = cnt1 + __popcll(h1 & lower);
+        if (pos < a.cap2) wl[a.cap1 + pos] = idx;
+      }
+      cnt0 += __popcll(h0);
+      cnt1 += __popcll(h1);
+      pairs += n;
+      head = (head + n) & (PQ - 1);
+      qn -= n;
+    };
+    if (qm.hi > qm.lo) {
+      const uint32_t t_lo = qm.lo >> 6, t_hi = (qm.hi + 63) >> 6, n_t = t_hi - t_lo;
+      const uint32_t t0 = t_lo + (uint32_t)((u64)n_t * wave / LW), t1 = t_lo + (uint32_t)((u64)n_t * (wave + 1) / LW);
+      for (uint32_t t = t0; t < t1; ++t) {
+        // both lists of this wave full: nothing it finds later can be among the first cap of the query
+        if (cnt0 >= a.cap1 && (K < 2 || cnt1 >= a.cap2)) {
+          qn = 0;
+          break;
+        }
+        const uint32_t idx = t * 64 + lane;
+        const bool in = idx >= qm.lo && idx < qm.hi;
+        u64 wsig = 0;
+        uint32_t wm = 0;
+        if (in) {
+          wsig = a.sigs[idx];
+          wm = a.wmeta[idx];
+        }
+        const int nc = (int)(wm & 0xFF);
+        const uint32_t q_not_w = __popcll(qm.sig & ~wsig);
+        const uint32_t w_not_q = prefix ? 0u : __popcll(wsig & ~qm.sig);
+        const bool len_ok = (nc + K >= m) & (prefix | (nc <= m + K));
+        const bool act = in & ((wm >> 8) != 0) & len_ok & (max(q_not_w, w_not_q) <= (uint32_t)K);
+        const u64 ms = __ballot(act);
+        if (ms == 0) continue;
+        if (act) s_pq[wave][(head + qn + __popcll(ms & lower)) & (PQ - 1)] = idx;
         qn += __popcll(ms);
+        __builtin_amdgcn_wave_barrier();
+        while (qn >= 64) drain(64);
       }
-      if (mx) {
-        if (act_x) s_pq[wave][(head + qn + __popcll(mx & lower)) & (PQ - 1)] = lane | (ql << 6) | (1u << 12);
-        qn += __popcll(mx);
-      }
-      __builtin_amdgcn_wave_barrier();
-      while (qn >= 64) drain(64);
+      while (qn > 0) drain(qn < 64 ? qn : 64);
     }
-    while (qn > 0) drain(qn < 64 ? qn : 64);  // the ring refers to this tile's lanes
-    __builtin_amdgcn_wave_barrier();
-  }
-  __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = lane; i < nqc * 3; i += 64) {
-    const uint32_t ql = i / 3, c = i % 3;
-    const uint32_t cap = c == 0 ? a.cap1 : (c == 1 ? a.cap2 : a.capx);
-    a.cnts[((size_t)(q_begin + ql) * a.nseg + seg) * 3 + c] = min(s_cnt[wave][ql][c], cap);
+    if (lane == 0) {
+      s_wcnt[wave][0] = min(cnt0, a.cap1);
+      s_wcnt[wave][1] = min(cnt1, a.cap2);
+    }
+
+    // ---- search: other first chars, distance <= 1 (only the two-typo automaton accepts them) --------
+    uint32_t xn = 0;  // thread 0's
+    if (K == 2 && a.n_fc > 0) {
+      Pattern pt;
+      pt.qb = s_qb;
+      if (tid < 2) {
+        uint32_t ra = 0, rb = 0;
+        if (m >= 2 && qm.q1 != qm.q0) {
+          if (tid == 0) {          // delete q0: q[1..]
+            pt.o0 = qm.l0; pt.l0 = qm.qlen - qm.l0; pt.o1 = pt.l1 = pt.o2 = pt.l2 = 0;
+          } else {                 // swap q0 q1: q1 q0 q[2..]
+            pt.o0 = qm.l0; pt.l0 = qm.l1; pt.o1 = 0; pt.l1 = qm.l0; pt.o2 = qm.l0 + qm.l1; pt.l2 = qm.qlen - pt.o2;
+          }
+          pt.len = pt.l0 + pt.l1 + pt.l2;
+          find_range(a, 0, a.n_words, 0, pt, prefix, &ra, &rb);
+        }
+        s_ext[tid][0] = ra;
+        s_ext[tid][1] = rb;
+      }
+      __syncthreads();
+      for (uint32_t base = 0; base < a.n_fc; base += XB) {
+        const uint32_t bi = tid >> 1, shape = tid & 1, bb = base + bi;
+        uint32_t ra = 0, rb = 0;
+        bool flag = false;
+        if (bb < a.n_fc) {
+          const uint32_t fs = a.fc_start[bb], fe = a.fc_start[bb + 1];
+          if (!(fs == qm.lo && qm.hi > qm.lo)) {   // not the query's own first-char block
+            const uint32_t skip = utf8_len(a.flat[a.offs[fs]]);
+            pt.o0 = shape ? 0 : qm.l0;             // shape 0: substitute q0 (c + q[1..]); shape 1: insert (c + q)
+            pt.l0 = qm.qlen - pt.o0;
+            pt.o1 = pt.l1 = pt.o2 = pt.l2 = 0;
+            pt.len = pt.l0;
+            find_range(a, fs, fe, skip, pt, prefix, &ra, &rb);
+            flag = rb > ra;
+            if (shape == 0)
+              flag |= (s_ext[0][1] > s_ext[0][0] && s_ext[0][0] >= fs && s_ext[0][0] < fe) ||
+                      (s_ext[1][1] > s_ext[1][0] && s_ext[1][0] >= fs && s_ext[1][0] < fe);
+          }
+        }
+        s_xr[bi][shape * 2] = ra;
+        s_xr[bi][shape * 2 + 1] = rb;
+        const u64 fm = __ballot(flag);
+        if (lane == 0) s_xany[wave] = fm;
+        __syncthreads();
+        if (tid == 0) {
+          // blocks in ascending order; inside a block the (at most four) ranges may nest or overlap
+          for (uint32_t w = 0; w < LW && xn < a.capx; ++w) {
+            u64 mk = s_xany[w];
+            while (mk && xn < a.capx) {
+              const uint32_t bit = (uint32_t)__ffsll((long long)mk) - 1;
+              const uint32_t k = bit >> 1;
+              mk &= ~(3ull << (2 * k));
+              const uint32_t b2 = w * 32 + k;
+              const uint32_t fs = a.fc_start[base + b2], fe = a.fc_start[base + b2 + 1];
+              uint32_t r0[4], r1[4], nr = 0;
+              for (uint32_t sh = 0; sh < 2; ++sh)
+                if (s_xr[b2][sh * 2 + 1] > s_xr[b2][sh * 2]) { r0[nr] = s_xr[b2][sh * 2]; r1[nr] = s_xr[b2][sh * 2 + 1]; ++nr; }
+              for (uint32_t e = 0; e < 2; ++e)
+                if (s_ext[e][1] > s_ext[e][0] && s_ext[e][0] >= fs && s_ext[e][0] < fe) { r0[nr] = s_ext[e][0]; r1[nr] = s_ext[e][1]; ++nr; }
+              for (uint32_t i = 1; i < nr; ++i)
+                for (uint32_t j = i; j > 0 && r0[j] < r0[j - 1]; --j) {
+                  const uint32_t x0 = r0[j], x1 = r1[j];
+                  r0[j] = r0[j - 1]; r1[j] = r1[j - 1];
+                  r0[j - 1] = x0; r1[j - 1] = x1;
+                }
+              uint32_t cur = 0;
+              for (uint32_t i = 0; i < nr; ++i) {
+                for (uint32_t x = max(r0[i], cur); x < r1[i] && xn < a.capx; ++x) xl[xn++] = x;
+                cur = max(cur, r1[i]);
+              }
+            }
+          }
+          if (xn >= a.capx) s_xdone = 1;
+        }
+        __syncthreads();
+        if (s_xdone) break;
+      }
+    }
+    __syncthreads();  // s_wcnt and the waves' lists are complete
+
+    // ---- caps: the closed form of compute_derivations.rs:129-163 ------------------------------------
+    if (tid == 0) {
+      const uint32_t *wl0 = a.wlists + (size_t)blockIdx.x * LW * stride_w;
+      WaveLists s1{wl0, stride_w, 0, 0, 0, 0, s_wcnt}, s2{wl0, stride_w, a.cap1, 1, 0, 0, s_wcnt};
+      s1.settle();
+      s2.settle();
+      uint32_t *one = a.out_one + (size_t)q * a.cap1;
+      uint32_t *two = a.out_two + (size_t)q * a.cap2;
+      uint32_t n1 = 0, n2 = 0, xi = 0;
+      // two = first cap2 of (X ∪ S2)
+      while (n2 < a.cap2 && !(s2.done() && xi >= xn)) {
+        uint32_t v;
+        if (s2.done()) v = xl[xi++];
+        else if (xi >= xn) { v = s2.peek(); s2.pop(); }
+        else if (s2.peek() < xl[xi]) { v = s2.peek(); s2.pop(); }
+        else v = xl[xi++];
+        two[n2++] = v;
+      }
+      // one = first cap1 of (S1 ∪ {x in X : x > t*}), t* = the last element of a FULL `two`
+      xi = xn;  // `two` never filled: no X word reaches `one`
+      if (n2 == a.cap2 && n2 > 0) {
+        const uint32_t tstar = two[n2 - 1];
+        xi = 0;
+        while (xi < xn && xl[xi] <= tstar) ++xi;
+      }
+      while (n1 < a.cap1 && !(s1.done() && xi >= xn)) {
+        uint32_t v;
+        if (s1.done()) v = xl[xi++];
+        else if (xi >= xn) { v = s1.peek(); s1.pop(); }
+        else if (s1.peek() < xl[xi]) { v = s1.peek(); s1.pop(); }
+        else v = xl[xi++];
+        one[n1++] = v;
+      }
+      a.out_one_cnt[q] = n1;
+      a.out_two_cnt[q] = n2;
+    }
   }
   if (lane == 0 && pairs) atomicAdd(a.pairs, pairs);
 }
@@ -490,30 +573,32 @@ __global__ void dict_prep_kernel(const uint8_t *__restrict__ qbytes, const uint3
   r.m = 0;
   r.budget = 0;
   r.prefix = (qflags[q] >> 2) & 1;
-  r._pad = 0;
-  r._pad2 = 0;
+  r.qlen = len;
+  r._pad[0] = r._pad[1] = 0;
   r.lo = r.hi = 0;
   r.sig = 0;
-  r.p12 = r.p01 = r.p10 = 0;
+  r.l0 = r.l1 = 0;
+  r.q0 = r.q1 = QNONE;
   const uint32_t bud = qflags[q] & 3;
   if (len >= 1 && len <= 250 && bud >= 1) {  // MAX_WORD_LENGTH, compute_derivations.rs:180-192
     uint32_t *out = qchars + (size_t)q * QSTRIDE;
     uint32_t n = 0, i = 0;
     while (i < len) {
       const uint32_t b0 = s[i];
-      const uint32_t cl = utf8_len(b0);
+      uint32_t cl = utf8_len(b0);
       uint32_t cp = cl == 1 ? b0 : (cl == 2 ? (b0 & 0x1F) : (cl == 3 ? (b0 & 0x0F) : (b0 & 0x07)));
       for (uint32_t e = 1; e < cl; ++e) cp = (cp << 6) | ((i + e < len ? s[i + e] : 0) & 0x3F);
+      if (i + cl > len) cl = len - i;   // a truncated last char keeps the bytes it has
+      if (n == 0) r.l0 = cl;
+      if (n == 1) r.l1 = cl;
       i += cl;
       out[n++] = cp;
     }
     r.m = n;
     r.budget = bud > 2 ? 2 : bud;
     for (uint32_t c = 0; c < n; ++c) r.sig |= 1ull << sig_bit(out[c]);
-    const uint32_t q0 = out[0], q1 = n >= 2 ? out[1] : QNONE, q2 = n >= 3 ? out[2] : QNONE;
-    r.p12 = pair_key(q1, q2);
-    r.p01 = pair_key(q0, q1);
-    r.p10 = pair_key(q1, q0);
+    r.q0 = out[0];
+    r.q1 = n >= 2 ? out[1] : QNONE;
     // words starting with a given char: compare the first clen bytes (big endian)
     auto range_of = [&](const uint8_t *c, uint32_t avail, uint32_t &rlo, uint32_t &rhi) {
       const uint32_t clen = utf8_len(c[0]);
@@ -546,154 +631,17 @@ __global__ void dict_prep_kernel(const uint8_t *__restrict__ qbytes, const uint3
   qm[q] = r;
 }
 
-// ---- finalisation --------------------------------------------------------------------
-
-// Ascending list of dictionary indices.
-struct ArrStream {
-  const uint32_t *p;
-  uint32_t n, i;
-  __device__ bool done() const { return i >= n; }
-  __device__ uint32_t peek() const { return p[i]; }
-  __device__ void pop() { ++i; }
-};
-
-struct MergedStream {  // main ∪ long, ascending
-  ArrStream a, b;
-  __device__ bool done() const { return a.done() && b.done(); }
-  __device__ uint32_t peek() const {
-    if (a.done()) return b.peek();
-    if (b.done()) return a.peek();
-    const uint32_t x = a.peek(), y = b.peek();
-    return x < y ? x : y;
-  }
-  __device__ void pop() {
-    if (a.done()) { b.pop(); return; }
-    if (b.done()) { a.pop(); return; }
-    if (a.peek() < b.peek()) a.pop(); else b.pop();
-  }
-};
-
-struct FinalArgs {
-  const QueryMeta *qm;
-  const uint32_t *lists, *cnts;       // main launch
-  const uint32_t *llists, *lcnts;     // long-word launch
-  uint32_t nq, nseg, lnseg, cap1, cap2, capx;
-  uint32_t *comp;                     // [nq][2][cap1+cap2+capx] compacted class lists
-  uint32_t *out_one, *out_one_cnt, *out_two, *out_two_cnt;
-};
-
-constexpr int FIN_THREADS = 256;
-
-// One workgroup per query.  Phase 1 (parallel): the per-segment lists of each class
-// are concatenated (segments are contiguous dictionary ranges, so concatenation in
-// segment order is ascending) into one list per (launch, class) with a block-wide
-// prefix sum over the segment counts.  Phase 2 (one lane): the reference's cap
-// logic in its closed form over those six short lists.
-__global__ __launch_bounds__(FIN_THREADS) void dict_finalize_kernel(FinalArgs f) {
-  __shared__ uint32_t s_scan[3][FIN_THREADS];
-  __shared__ uint32_t s_tot[2][3];
-  const uint32_t q = blockIdx.x;
-  const uint32_t tid = threadIdx.x;
-  const uint32_t st = f.cap1 + f.cap2 + f.capx;
-  const uint32_t caps[3] = {f.cap1, f.cap2, f.capx};
-  const uint32_t offs[3] = {0, f.cap1, f.cap1 + f.cap2};
-  uint32_t *comp = f.comp + (size_t)q * 2 * st;
-  const bool live = f.qm[q].budget != 0;
-  if (live) {
-    for (uint32_t src = 0; src < 2; ++src) {
-      const uint32_t ns = src ? f.lnseg : f.nseg;
-      const uint32_t *lists = (src ? f.llists : f.lists) + (size_t)q * ns * st;
-      const uint32_t *cnts = (src ? f.lcnts : f.cnts) + (size_t)q * ns * 3;
-      const uint32_t per = (ns + FIN_THREADS - 1) / FIN_THREADS;
-      const uint32_t seg0 = min(ns, tid * per), seg1 = min(ns, seg0 + per);
-      uint32_t loc[3] = {0, 0, 0};
-      for (uint32_t seg = seg0; seg < seg1; ++seg) {
-        loc[0] += cnts[seg * 3 + 0];
-        loc[1] += cnts[seg * 3 + 1];
-        loc[2] += cnts[seg * 3 + 2];
-      }
-      __syncthreads();  // s_scan reuse
-      for (int c = 0; c < 3; ++c) s_scan[c][tid] = loc[c];
-      __syncthreads();
-      for (uint32_t o = 1; o < FIN_THREADS; o <<= 1) {
-        uint32_t v[3];
-        for (int c = 0; c < 3; ++c) v[c] = tid >= o ? s_scan[c][tid - o] : 0;
-        __syncthreads();
-        for (int c = 0; c < 3; ++c) s_scan[c][tid] += v[c];
-        __syncthreads();
-      }
-      for (int c = 0; c < 3; ++c) {
-        uint32_t pos = s_scan[c][tid] - loc[c];  // exclusive
-        if (loc[c] && pos < caps[c]) {
-          for (uint32_t seg = seg0; seg < seg1 && pos < caps[c]; ++seg) {
-            const uint32_t n = cnts[seg * 3 + c];
-            const uint32_t *src_l = lists + (size_t)seg * st + offs[c];
-            for (uint32_t i = 0; i < n && pos < caps[c]; ++i) comp[src * st + offs[c] + pos++] = src_l[i];
-          }
-        }
-        if (tid == FIN_THREADS - 1) s_tot[src][c] = min(s_scan[c][tid], caps[c]);
-      }
-    }
-  }
-  __syncthreads();
-  if (tid != 0) return;
-  uint32_t *one = f.out_one + (size_t)q * f.cap1;
-  uint32_t *two = f.out_two + (size_t)q * f.cap2;
-  uint32_t n1 = 0, n2 = 0;
-  if (live) {
-    __threadfence_block();
-    auto mk = [&](uint32_t cls) {
-      MergedStream s;
-      s.a = ArrStream{comp + offs[cls], s_tot[0][cls], 0};
-      s.b = ArrStream{comp + st + offs[cls], s_tot[1][cls], 0};
-      return s;
-    };
-    // two = first cap2 of (X ∪ S2)
-    uint32_t tstar = 0xFFFFFFFFu;
-    {
-      MergedStream s2 = mk(1), sx = mk(2);
-      while (n2 < f.cap2 && !(s2.done() && sx.done())) {
-        uint32_t v;
-        if (s2.done()) { v = sx.peek(); sx.pop(); }
-        else if (sx.done()) { v = s2.peek(); s2.pop(); }
-        else if (s2.peek() < sx.peek()) { v = s2.peek(); s2.pop(); }
-        else { v = sx.peek(); sx.pop(); }
-        two[n2++] = v;
-      }
-      if (n2 == f.cap2 && n2 > 0) tstar = two[n2 - 1];
-    }
-    // one = first cap1 of (S1 ∪ {x in X : x > t*})
-    {
-      MergedStream s1 = mk(0), sx = mk(2);
-      if (tstar == 0xFFFFFFFFu) {
-        while (!sx.done()) sx.pop();  // two never filled: no X word reaches `one`
-      } else {
-        while (!sx.done() && sx.peek() <= tstar) sx.pop();
-      }
-      while (n1 < f.cap1 && !(s1.done() && sx.done())) {
-        uint32_t v;
-        if (s1.done()) { v = sx.peek(); sx.pop(); }
-        else if (sx.done()) { v = s1.peek(); s1.pop(); }
-        else if (s1.peek() < sx.peek()) { v = s1.peek(); s1.pop(); }
-        else { v = sx.peek(); sx.pop(); }
-        one[n1++] = v;
-      }
-    }
-  }
-  f.out_one_cnt[q] = n1;
-  f.out_two_cnt[q] = n2;
-}
-
 }  // namespace
 
 // ================================================================== host object
 
 struct msi_dict {
   msi_ctx *ctx = nullptr;
-  uint32_t n_words = 0, n_long = 0;
-  DevBuf slots, blen, nchars, flat, offs, long_idx;
+  uint32_t n_words = 0;
+  uint32_t n_fc = 0;   // first-char blocks
+  DevBuf slots, sigs, wmeta, flat, offs, fc_start;
   // scratch (guarded by ctx->mu_aux)
-  DevBuf qbytes, qoff, qflags, qm, qchars, lists, cnts, llists, lcnts, comp, pairs, out1, out1c, out2, out2c;
+  DevBuf qbytes, qoff, qflags, qm, qchars, wlists, xlists, ticket, pairs, out1, out1c, out2, out2c;
   uint64_t lookup_launches = 0, dict_bytes = 0;
   KernelTimer match_timer;
   // host copy of the sorted words (prefix ranges, idx -> word for the keyword pipeline)
@@ -759,81 +707,50 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
     return MSI_E_INVALID;
   }
   const uint32_t capx = cap1 + cap2;
-  const uint32_t stride_l = cap1 + cap2 + capx;
   MSI_TRY(d->qm.ensure((size_t)n * sizeof(QueryMeta)));
   MSI_TRY(d->qchars.ensure((size_t)n * QSTRIDE * sizeof(uint32_t)));
+  if (d->n_words == 0) {   // nothing can match: no kernel reads an empty dictionary
+    MSI_HIP_TRY(hipMemsetAsync(d_one_cnt, 0, (size_t)n * sizeof(uint32_t), st));
+    MSI_HIP_TRY(hipMemsetAsync(d_two_cnt, 0, (size_t)n * sizeof(uint32_t), st));
+    d->lookup_launches++;
+    return MSI_OK;
+  }
   hipLaunchKernelGGL(dict_prep_kernel, dim3((n + 127) / 128), dim3(128), 0, st, d_qbytes, d_qoff, d_qflags, n,
                      d->slots.as<uint4>(), d->n_words, d->qm.as<QueryMeta>(), d->qchars.as<uint32_t>());
-  const uint32_t nchunks = (n + QC - 1) / QC;
-  const uint32_t target_waves = (uint32_t)ctx->n_cu * 20;  // 5 waves per SIMD
-  auto seg_for = [&](uint32_t n_items) -> uint32_t {
-    const uint32_t n_tiles = std::max<uint32_t>(1, (n_items + 63) / 64);
-    uint32_t nseg = (target_waves + nchunks - 1) / nchunks;
-    // bound the scratch lists to ~1 GiB (of 288 GB)
-    const uint64_t per_seg = (uint64_t)n * stride_l * sizeof(uint32_t);
-    const uint32_t mem_cap = (uint32_t)std::max<uint64_t>(1, (1024ull << 20) / std::max<uint64_t>(1, per_seg));
-    nseg = std::min(nseg, mem_cap);
-    nseg = std::max<uint32_t>(1, std::min(nseg, n_tiles));
-    return ((nseg + DW - 1) / DW) * DW;  // the DW waves of a workgroup share a query chunk
-  };
-  const uint32_t nseg = seg_for(d->n_words);
-  const uint32_t lnseg = seg_for(d->n_long);
-  MSI_TRY(d->lists.ensure((size_t)n * nseg * stride_l * sizeof(uint32_t)));
-  MSI_TRY(d->cnts.ensure((size_t)n * nseg * 3 * sizeof(uint32_t)));
-  MSI_TRY(d->llists.ensure((size_t)n * lnseg * stride_l * sizeof(uint32_t)));
-  MSI_TRY(d->lcnts.ensure((size_t)n * lnseg * 3 * sizeof(uint32_t)));
-  MSI_TRY(d->comp.ensure((size_t)n * 2 * stride_l * sizeof(uint32_t)));
-  MSI_HIP_TRY(hipMemsetAsync(d->lcnts.p, 0, (size_t)n * lnseg * 3 * sizeof(uint32_t), st));
-  MSI_HIP_TRY(hipMemsetAsync(d->cnts.p, 0, (size_t)n * nseg * 3 * sizeof(uint32_t), st));
+  // one workgroup per query in flight; 4 workgroups of 8 waves fill a CU
+  const uint32_t grid = std::min<uint32_t>(n, (uint32_t)ctx->n_cu * 4);
+  MSI_TRY(d->wlists.ensure((size_t)grid * LW * (cap1 + cap2) * sizeof(uint32_t)));
+  MSI_TRY(d->xlists.ensure((size_t)grid * capx * sizeof(uint32_t)));
+  MSI_TRY(d->ticket.ensure(sizeof(uint32_t)));
+  MSI_HIP_TRY(hipMemsetAsync(d->ticket.p, 0, sizeof(uint32_t), st));
   DictArgs a;
   a.slots = d->slots.as<uint4>();
-  a.blen = d->blen.as<uint8_t>();
-  a.nchars = d->nchars.as<uint8_t>();
+  a.sigs = d->sigs.as<u64>();
+  a.wmeta = d->wmeta.as<uint16_t>();
   a.flat = d->flat.as<uint8_t>();
   a.offs = d->offs.as<uint32_t>();
-  a.long_idx = d->long_idx.as<uint32_t>();
+  a.fc_start = d->fc_start.as<uint32_t>();
+  a.n_fc = d->n_fc;
   a.n_words = d->n_words;
   a.qm = d->qm.as<QueryMeta>();
   a.qchars = d->qchars.as<uint32_t>();
+  a.qbytes = d_qbytes;
+  a.qoff = d_qoff;
   a.nq = n;
   a.cap1 = cap1;
   a.cap2 = cap2;
   a.capx = capx;
+  a.wlists = d->wlists.as<uint32_t>();
+  a.xlists = d->xlists.as<uint32_t>();
+  a.ticket = d->ticket.as<uint32_t>();
   a.pairs = d->pairs.as<u64>();
-  if (d->n_words) {
-    a.n_items = d->n_words;
-    a.nseg = nseg;
-    a.lists = d->lists.as<uint32_t>();
-    a.cnts = d->cnts.as<uint32_t>();
-    d->match_timer.begin(ctx, st);
-    hipLaunchKernelGGL(dict_match_kernel<false>, dim3((nseg / DW) * nchunks), dim3(DW * 64), 0, st, a, a.qm);
-    d->match_timer.end(ctx);
-  }
-  if (d->n_long) {
-    a.n_items = d->n_long;
-    a.nseg = lnseg;
-    a.lists = d->llists.as<uint32_t>();
-    a.cnts = d->lcnts.as<uint32_t>();
-    hipLaunchKernelGGL(dict_match_kernel<true>, dim3((lnseg / DW) * nchunks), dim3(DW * 64), 0, st, a, a.qm);
-  }
-  FinalArgs f;
-  f.qm = d->qm.as<QueryMeta>();
-  f.lists = d->lists.as<uint32_t>();
-  f.cnts = d->cnts.as<uint32_t>();
-  f.llists = d->llists.as<uint32_t>();
-  f.lcnts = d->lcnts.as<uint32_t>();
-  f.nq = n;
-  f.nseg = nseg;
-  f.lnseg = lnseg;
-  f.cap1 = cap1;
-  f.cap2 = cap2;
-  f.capx = capx;
-  f.comp = d->comp.as<uint32_t>();
-  f.out_one = d_one;
-  f.out_one_cnt = d_one_cnt;
-  f.out_two = d_two;
-  f.out_two_cnt = d_two_cnt;
-  hipLaunchKernelGGL(dict_finalize_kernel, dim3(n), dim3(FIN_THREADS), 0, st, f);
+  a.out_one = d_one;
+  a.out_one_cnt = d_one_cnt;
+  a.out_two = d_two;
+  a.out_two_cnt = d_two_cnt;
+  d->match_timer.begin(ctx, st);
+  hipLaunchKernelGGL(dict_lookup_kernel, dim3(grid), dim3(LT), 0, st, a);
+  d->match_timer.end(ctx);
   MSI_HIP_TRY(hipGetLastError());
   d->lookup_launches++;
   return MSI_OK;
@@ -850,10 +767,12 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
     return MSI_E_INVALID;
   }
   *out = nullptr;
-  // host-side staging: slots, lengths, long-word list; sortedness check
+  // host-side staging: slots, lengths, char-presence signatures, first-char blocks; sortedness check
   std::vector<uint4> slots(std::max<uint32_t>(1, n_words));
-  std::vector<uint8_t> blen(std::max<uint32_t>(1, n_words)), nch(std::max<uint32_t>(1, n_words));
-  std::vector<uint32_t> long_idx;
+  std::vector<u64> sigs(std::max<uint32_t>(1, n_words));
+  std::vector<uint16_t> wmeta(std::max<uint32_t>(1, n_words));
+  std::vector<uint32_t> fc_start;
+  uint32_t prev_fc = 0, prev_fcl = 0;   // first char of the previous non-empty word (its bytes, big endian)
   for (uint32_t i = 0; i < n_words; ++i) {
     const uint32_t o = offsets[i], len = offsets[i + 1] - o;
     if (offsets[i + 1] < o || len > 255) {
@@ -872,18 +791,37 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
     uint8_t buf[16] = {0};
     memcpy(buf, w, std::min<uint32_t>(len, 16));
     memcpy(&slots[i], buf, 16);
-    blen[i] = (uint8_t)len;
     uint32_t chars = 0;
-    for (uint32_t b = 0; b < len; ++b) chars += (w[b] & 0xC0) != 0x80;
-    nch[i] = (uint8_t)chars;
-    if (len > 16) long_idx.push_back(i);
+    u64 sig = 0;
+    for (uint32_t b = 0; b < len;) {
+      const uint32_t b0 = w[b];
+      const uint32_t cl = b0 < 0x80 ? 1u : (b0 < 0xE0 ? 2u : (b0 < 0xF0 ? 3u : 4u));
+      uint32_t cp = cl == 1 ? b0 : (cl == 2 ? (b0 & 0x1F) : (cl == 3 ? (b0 & 0x0F) : (b0 & 0x07)));
+      for (uint32_t e = 1; e < cl; ++e) cp = (cp << 6) | ((b + e < len ? w[b + e] : 0) & 0x3F);   // as the kernels decode
+      sig |= 1ull << sig_bit(cp);
+      ++chars;
+      b += cl;
+    }
+    sigs[i] = sig;
+    wmeta[i] = (uint16_t)(std::min<uint32_t>(chars, 255) | (len << 8));
+    if (len) {
+      const uint32_t b0 = w[0];
+      const uint32_t cl = std::min<uint32_t>(len, b0 < 0x80 ? 1u : (b0 < 0xE0 ? 2u : (b0 < 0xF0 ? 3u : 4u)));
+      uint32_t fc = 0;
+      for (uint32_t e = 0; e < cl; ++e) fc = (fc << 8) | w[e];
+      if (fc_start.empty() || fc != prev_fc || cl != prev_fcl) fc_start.push_back(i);
+      prev_fc = fc;
+      prev_fcl = cl;
+    }
   }
+  const uint32_t n_fc = (uint32_t)fc_start.size();
+  fc_start.push_back(n_words);
   DeviceGuard g(ctx->device);
   std::lock_guard<std::mutex> lk(ctx->mu_aux);
   msi_dict *d = new msi_dict();
   d->ctx = ctx;
   d->n_words = n_words;
-  d->n_long = (uint32_t)long_idx.size();
+  d->n_fc = n_fc;
   const size_t flat_bytes = n_words ? offsets[n_words] : 0;
   hipStream_t st = ctx->stream_aux;
   int32_t s = MSI_OK;
@@ -899,11 +837,11 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
     }
   };
   up(d->slots, slots.data(), (size_t)n_words * sizeof(uint4));
-  up(d->blen, blen.data(), n_words);
-  up(d->nchars, nch.data(), n_words);
+  up(d->sigs, sigs.data(), (size_t)n_words * sizeof(u64));
+  up(d->wmeta, wmeta.data(), (size_t)n_words * sizeof(uint16_t));
   up(d->flat, words_concat, flat_bytes);
   up(d->offs, offsets, ((size_t)n_words + 1) * sizeof(uint32_t));
-  up(d->long_idx, long_idx.data(), long_idx.size() * sizeof(uint32_t));
+  up(d->fc_start, fc_start.data(), fc_start.size() * sizeof(uint32_t));
   if (s == MSI_OK) s = d->pairs.ensure(sizeof(u64));
   if (s == MSI_OK && hipMemsetAsync(d->pairs.p, 0, sizeof(u64), st) != hipSuccess) s = MSI_E_HIP;
   if (s == MSI_OK && hipStreamSynchronize(st) != hipSuccess) {
@@ -911,12 +849,12 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
     s = MSI_E_HIP;
   }
   if (s != MSI_OK) {
-    DevBuf *bufs[] = {&d->slots, &d->blen, &d->nchars, &d->flat, &d->offs, &d->long_idx, &d->pairs};
+    DevBuf *bufs[] = {&d->slots, &d->sigs, &d->wmeta, &d->flat, &d->offs, &d->fc_start, &d->pairs};
     for (DevBuf *b : bufs) b->release();
     delete d;
     return s;
   }
-  d->dict_bytes = (uint64_t)n_words * (sizeof(uint4) + 2) + flat_bytes + ((uint64_t)n_words + 1) * 4;
+  d->dict_bytes = (uint64_t)n_words * (sizeof(uint4) + sizeof(u64) + 2) + flat_bytes + ((uint64_t)n_words + 1) * 4;
   d->h_flat.assign(words_concat, words_concat + flat_bytes);
   d->h_offs.assign(offsets, offsets + n_words + 1);
   if (n_words == 0) d->h_offs.assign(1, 0);
@@ -932,8 +870,8 @@ void msi_dict_destroy(msi_dict *d) {
   std::lock_guard<std::mutex> lk(ctx->mu_aux);
   DeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(d->ctx->stream_aux);
-  DevBuf *bufs[] = {&d->slots, &d->blen, &d->nchars, &d->flat, &d->offs, &d->long_idx, &d->qbytes, &d->qoff,
-                    &d->qflags, &d->qm, &d->qchars, &d->lists, &d->cnts, &d->llists, &d->lcnts, &d->comp, &d->pairs,
+  DevBuf *bufs[] = {&d->slots, &d->sigs, &d->wmeta, &d->flat, &d->offs, &d->fc_start, &d->qbytes, &d->qoff,
+                    &d->qflags, &d->qm, &d->qchars, &d->wlists, &d->xlists, &d->ticket, &d->pairs,
                     &d->out1, &d->out1c, &d->out2, &d->out2c};
   for (DevBuf *b : bufs) b->release();
   d->match_timer.release();

@@ -1177,6 +1177,7 @@ int32_t finish_upload(msi_vs *vs, uint64_t n_rows, const char *what) {
   if (bad) {
     vs->n_rows = 0;
     vs->n_tiles = 0;
+    vs->h_docids.clear();  // a rejected upload leaves an EMPTY store: get_vector / search_by_item / update must not see its list
     msi_set_error("%s: docids must be strictly ascending", what);
     return MSI_E_NOT_SORTED;
   }

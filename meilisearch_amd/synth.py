@@ -212,3 +212,32 @@ class SynthIndex:
             k = max(1, self.n_docs // 200)
             return np.unique(self._rng("c", fid, count).integers(0, self.n_docs, k, dtype=np.uint32))
         return self._cached(("c", fid, count), make) if count <= 30 else None
+
+
+def device_rows(n, d, dev, seed=1234, chunk=1_000_000):
+    """C2 / C4 / C5: the N x d f32 row matrix ~ N(0,1), generated IN HBM (torch generator, fixed seed, 1 M-row
+    chunks so that the stream of random numbers does not depend on how much is drawn per call).  bench.py and
+    tests/test_configs_gpu.py build their stores from this one function."""
+    import torch
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    rows_t = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for c0 in range(0, n, chunk):
+        rows_t[c0:min(n, c0 + chunk)].normal_(generator=gen)
+    return rows_t
+
+
+def device_queries(nq, d, dev, seed=5678):
+    import torch
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(seed)
+    return torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=gq)
+
+
+def random_bitset_words(n_bits, density, seed):
+    """Dense candidate bitset (u64 words, LSB first) with Bernoulli(density) bits below n_bits (C5 filters, seed 31)."""
+    rng = np.random.default_rng(seed)
+    words = (n_bits + 63) // 64
+    bits = rng.random(words * 64) < density
+    bits[n_bits:] = False
+    return np.packbits(bits, bitorder="little").view(np.uint64)

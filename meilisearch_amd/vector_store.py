@@ -86,6 +86,8 @@ class GpuStore:
         fb = None
         if filter_bits is not None:
             fb = np.ascontiguousarray(filter_bits, dtype=np.uint64)
+            if not filter_nbits:
+                filter_nbits = 64 * fb.size   # a filter without a bit count means "all of its words"
         cancel_p = None
         if cancel is not None:
             cancel_p = cancel.ctypes.data_as(C.c_void_p)
@@ -110,6 +112,8 @@ class GpuStore:
         out_s = np.zeros(max(k, 1), dtype=np.float32)
         cnt, found = C.c_uint32(0), C.c_int32(0)
         fb = None if filter_bits is None else np.ascontiguousarray(filter_bits, dtype=np.uint64)
+        if fb is not None and not filter_nbits:
+            filter_nbits = 64 * fb.size
         check(lib().msi_vs_search_by_item(self._h, int(docid), k, np_ptr(fb), filter_nbits, np_ptr(out_d), np_ptr(out_s),
                                           C.byref(cnt), C.byref(found)))
         if not found.value:

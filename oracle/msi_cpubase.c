@@ -289,16 +289,25 @@ typedef struct {
   const uint8_t *qbytes;
   const uint32_t *qoff;
   const uint8_t *qflags;
-  uint32_t q0, q1, cap_one, cap_two;
+  uint32_t nq, cap_one, cap_two;
+  uint32_t *next; /* shared work counter: queries cost 0.01 .. 5 ms each (prefix / 2-typo ones the most), so a
+                   * static split would time the unluckiest thread instead of the cores */
   uint32_t *one, *one_cnt, *two, *two_cnt;
 } dict_job;
 
+#define DICT_GRAB 4u
+
 static void *dict_worker(void *arg) {
   dict_job *j = (dict_job *)arg;
-  for (uint32_t q = j->q0; q < j->q1; ++q)
-    lookup_one(j->d, j->qbytes + j->qoff[q], j->qoff[q + 1] - j->qoff[q], j->qflags[q] & 3, (j->qflags[q] >> 2) & 1,
-               j->cap_one, j->cap_two, j->one + (size_t)q * j->cap_one, &j->one_cnt[q],
-               j->two + (size_t)q * j->cap_two, &j->two_cnt[q]);
+  for (;;) {
+    const uint32_t q0 = __atomic_fetch_add(j->next, DICT_GRAB, __ATOMIC_RELAXED);
+    if (q0 >= j->nq) break;
+    const uint32_t q1 = q0 + DICT_GRAB < j->nq ? q0 + DICT_GRAB : j->nq;
+    for (uint32_t q = q0; q < q1; ++q)
+      lookup_one(j->d, j->qbytes + j->qoff[q], j->qoff[q + 1] - j->qoff[q], j->qflags[q] & 3, (j->qflags[q] >> 2) & 1,
+                 j->cap_one, j->cap_two, j->one + (size_t)q * j->cap_one, &j->one_cnt[q],
+                 j->two + (size_t)q * j->cap_two, &j->two_cnt[q]);
+  }
   return NULL;
 }
 
@@ -306,12 +315,15 @@ void cpb_dict_lookup_mt(const cpb_dict *d, const uint8_t *qbytes, const uint32_t
                         uint32_t nq, uint32_t cap_one, uint32_t cap_two, uint32_t threads, uint32_t *one,
                         uint32_t *one_cnt, uint32_t *two, uint32_t *two_cnt) {
   if (threads < 1) threads = 1;
+  if (threads > (nq + DICT_GRAB - 1) / DICT_GRAB) threads = (nq + DICT_GRAB - 1) / DICT_GRAB;
+  if (threads < 1) threads = 1;
   pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
   dict_job *jobs = (dict_job *)calloc(threads, sizeof(dict_job));
+  uint32_t next = 0;
   for (uint32_t t = 0; t < threads; ++t) {
     dict_job *j = &jobs[t];
     j->d = d; j->qbytes = qbytes; j->qoff = qoff; j->qflags = qflags;
-    j->q0 = (uint32_t)((uint64_t)nq * t / threads); j->q1 = (uint32_t)((uint64_t)nq * (t + 1) / threads);
+    j->nq = nq; j->next = &next;
     j->cap_one = cap_one; j->cap_two = cap_two;
     j->one = one; j->one_cnt = one_cnt; j->two = two; j->two_cnt = two_cnt;
     pthread_create(&th[t], NULL, dict_worker, j);

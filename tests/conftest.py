@@ -25,6 +25,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(pytest.mark.timeout(420, method="thread"))
 
 
+def pytest_collection_finish(session):
+    """On a cold GPU box the first `import torch` pages the ROCm libraries in and has been seen to take minutes:
+    pay that here, outside the wall-clock bound of whichever device test would import it first."""
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+
 def pytest_sessionstart(session):
     """libmsi.so is a build artefact (git-ignored): build it when a fresh checkout runs the tests before
     __graft_entry__.build() did (hipcc cross-compiles gfx950 without a GPU; `make` is a no-op when up to date)."""

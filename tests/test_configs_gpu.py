@@ -1,0 +1,120 @@
+"""Parity at BASELINE.json's FULL sizes, on the device, through the C ABI.
+
+  C2  1 M x 384 f32, cosine top-20 (+ a 10 % candidate filter)         store.rs:1036-1093
+  C3  2 M-term dictionary, >= 2 048 query words, 30 % prefix, 1/2 typos  compute_derivations.rs:75-168
+  C4  10 M x 768 f32, cosine top-20, one full sweep of 48 queries        store.rs:1036-1093
+  C5  one GPU's shard: 12.5 M x 1024 bf16 rows, 1 % filter, k = 1000     (bf16 = build-side storage: the oracle
+      runs the reference arithmetic on the bf16-rounded rows)
+
+Checker: oracle/parity.py (the scalar oracle ranks the candidates of the multi-threaded CPU scan; the typo
+derivations of EVERY query word go through the oracle's literal loops).  Bit-exact bar: docids identical in
+order, f32 distances bit-identical, derivation index lists identical.  Scale-specific failure modes these sizes
+exercise and the small tests cannot: 32-bit tile/row index arithmetic at 10 M x 48 tiles, survivor-list capacity,
+sample-threshold statistics at N = 1e7, dictionary segments > 2^16 words, k' = 1250 selection over 12.5 M rows.
+"""
+import numpy as np
+import pytest
+
+import meilisearch_amd as ma
+from meilisearch_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_dev():
+    import torch
+    return torch, torch.device("cuda", 0)
+
+
+def _check_store(ctx, n, d, k, nq, storage="f32", filter_density=None, chunk=1_000_000, extra=64):
+    from oracle import parity
+    torch, dev = _torch_dev()
+    rows_t = synth.device_rows(n, d, dev, seed=1234)
+    ids_t = torch.arange(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    store = ma.GpuStore(ctx, d, storage=storage)
+    store.upload_device(ids_t, rows_t)
+    assert len(store) == n
+    q = synth.device_queries(nq, d, dev, seed=5678).cpu().numpy()
+    fb, nb, allowed_t = None, 0, None
+    if filter_density is not None:
+        fb = synth.random_bitset_words(n, filter_density, seed=31)
+        nb = n
+        allowed = np.nonzero(np.unpackbits(fb.view(np.uint8), bitorder="little")[:n])[0]
+        allowed_t = torch.from_numpy(allowed).to(dev)
+    got_ids, got_dist, got_cnt = store.search(q, k, fb, nb)        # the host entry point: exhaustive reruns included
+    # size-independent properties first: ascending (distance, docid), no duplicates, counts
+    for j in range(nq):
+        c = int(got_cnt[j])
+        assert c == min(k, n if allowed_t is None else int(allowed_t.numel()))
+        dj, ij = got_dist[j, :c], got_ids[j, :c].astype(np.int64)
+        assert (np.diff(dj) >= 0).all()
+        ties = np.diff(dj) == 0
+        assert (np.diff(ij)[ties] > 0).all()
+        assert np.unique(ij).size == c
+    chk = parity.TopkChecker(q, k, extra=extra)
+    if allowed_t is None:
+        for c0 in range(0, n, chunk):
+            c1 = min(n, c0 + chunk)
+            rows = rows_t[c0:c1].cpu().numpy()
+            if storage == "bf16":
+                rows = synth.round_to_bf16(rows)
+            chk.add_chunk(np.arange(c0, c1, dtype=np.uint32), rows)
+    else:
+        for c0 in range(0, int(allowed_t.numel()), chunk):
+            sel = allowed_t[c0:c0 + chunk]
+            rows = rows_t[sel].cpu().numpy()
+            if storage == "bf16":
+                rows = synth.round_to_bf16(rows)
+            chk.add_chunk(sel.cpu().numpy().astype(np.uint32), rows)
+        chk.rows_seen = int(allowed_t.numel())
+    v = chk.verdict(got_ids, got_dist, got_cnt)
+    assert v["mismatches"] == 0, v
+    assert v["candidate_margin"] is None or v["candidate_margin"] > 2e-6, v   # the CPU candidate set was wide enough
+    stats = store.stats()
+    store.close()
+    del rows_t
+    torch.cuda.empty_cache()
+    return v, stats
+
+
+def test_c2_1m_x_384_top20(ctx):
+    v, _ = _check_store(ctx, 1_000_000, 384, 20, 48)
+    assert v["checked_queries"] == 48 and v["rows"] == 1_000_000
+
+
+def test_c2_with_10pct_filter(ctx):
+    v, _ = _check_store(ctx, 1_000_000, 384, 20, 16, filter_density=0.1)
+    assert v["checked_queries"] == 16
+
+
+def test_c4_10m_x_768_top20(ctx):
+    v, stats = _check_store(ctx, 10_000_000, 768, 20, 48)
+    assert v["checked_queries"] == 48 and v["rows"] == 10_000_000
+    assert stats["bytes_per_tile"] == 16 * 768 * 4
+
+
+def test_c5_shard_bf16_filtered_k1000(ctx):
+    v, _ = _check_store(ctx, 12_500_000, 1024, 1000, 16, storage="bf16", filter_density=0.01)
+    assert v["checked_queries"] == 16 and v["k"] == 1000
+
+
+def test_c3_2m_term_dictionary(ctx):
+    from oracle import parity
+    words = synth.make_dictionary(2_000_000, seed=99)
+    concat, off = synth.flatten_words(words)
+    g = ma.GpuDictionary(ctx, concat=concat, offsets=off)
+    queries = synth.make_typo_queries(words, 2048, seed=7)
+    assert sum(1 for _, _, p in queries if p) > 500          # ~30 % prefix
+    assert sum(1 for _, b, _ in queries if b == 2) > 300
+    got = g.lookup(queries)
+    v = parity.check_typo_lookup(concat, off, queries, got)
+    assert v["mismatches"] == 0, v
+    assert v["checked_words"] == 2048
+    # one batch of 8192 (the largest BASELINE batch) against the same answers: batching must not change results
+    more = synth.make_typo_queries(words, 8192, seed=7)
+    assert more[:2048] == queries
+    got2 = g.lookup(more)
+    for (a1, a2), (b1, b2) in zip(got, got2[:2048]):
+        assert a1.tolist() == b1.tolist() and a2.tolist() == b2.tolist()
+    g.close()

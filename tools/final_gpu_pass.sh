@@ -13,3 +13,7 @@ timeout 300 python tools/bench_configs.py rules --rows 2000000 --reps 7 > gpurun
 timeout 300 python tools/bench_configs.py update --rows 1000000 --dim 384 --reps 5 > gpurun_out/update_c2.jsonl 2> gpurun_out/update_c2.err; echo update rc=$?; cat gpurun_out/update_c2.jsonl | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_rules -o rules -- python $GRAFT_REPO_ROOT/tools/bench_configs.py rules --rows 2000000 --reps 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_rules.log 2>&1; echo rocprof rules rc=$?
+cd $GRAFT_REPO_ROOT
+# C3 alone (dict_match not co-scheduled with the scan): words/s at the BASELINE batch sizes, CPU sample 4096 words
+timeout 400 python tools/bench_configs.py c3 --batches 1 64 1024 8192 --cpu-sample 4096 --reps 5 > gpurun_out/c3_sweep.jsonl 2> gpurun_out/c3_sweep.err; echo c3 rc=$?; cat gpurun_out/c3_sweep.jsonl | cut -c1-500
+nproc; lscpu | grep -i "model name"
