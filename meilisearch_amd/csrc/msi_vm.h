@@ -1,0 +1,83 @@
+// msi_vm.h — internal: command lists over the docid sets of a msi_bits pool, executed by ONE kernel launch per
+// dependency round and SHARED by every keyword search in flight on the context (msi_vm.hip).
+//
+// Why: the ranked keyword search (msi_search.hip) is a host control flow that needs a cardinality every few set
+// operations.  One launch per operation made a 3-term query 211 launches and 80 waits — launch-bound, ~1 % of the
+// HBM roofline, slower than its CPU port.  Here a search only RECORDS its operations; at the
+// point where it needs a result it submits the recorded list.  A combiner thread packs the lists of all the
+// searches that are waiting at that moment into one arena (one H2D copy) and runs them with one launch: a
+// workgroup owns one 65 536-document chunk (one Roaring container span, 8 KiB of a set) of one search and
+// interprets that search's commands in order.  Every command is chunk-local (set algebra, fused path claims,
+// container decode into LDS), so no workgroup ever waits for another; the last workgroup of a list publishes the
+// cardinalities (and ordered docids) into the search's pinned result block.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+struct msi_bits;
+struct MsiCboBatch;
+
+enum : uint32_t {
+  VM_END = 0,
+  VM_FILL,       // dst, ones
+  VM_OP,         // dst, a, b, op(MSI_BITS_*)
+  VM_OP_COUNT,   // dst, a, b, op, cnt
+  VM_CLEAR,      // n, slot...
+  VM_CLAIM,      // docs, bucket, universe, n, stack...
+  VM_AND_MANY,   // prefix, n, cnt_base, (cond, dst)...
+  VM_PATHS,      // n_paths, bucket, universe, cnt_base, n_steps, off[n_paths + 1], step slot...
+  VM_SUB_MANY,   // removed, n, cnt_base, slot...
+  VM_COUNT,      // slot, cnt
+  VM_DECODE,     // dst, overwrite, blob byte offset of {koff[n_chunks + 1], containers, bytes}
+  VM_FIRSTK,     // slot, k, scratch word offset (n_chunks u32 inside the list's own words)
+  VM_MINKEY,     // universe, keys lo, keys hi, cell
+  VM_TAKEKEY,    // universe, bucket, keys lo, keys hi, cell, cnt, key result index
+};
+
+constexpr uint32_t MSI_VM_MAX_COUNTS = 1024;   // cardinalities one list can ask for
+constexpr uint32_t MSI_VM_MAX_PHASES = 4;      // kernel boundaries inside one list (Sort rule: min, then take)
+constexpr uint32_t MSI_VM_MAX_FIRSTK = 8192;   // docids one list can read back
+constexpr uint32_t MSI_VM_CELLS = 4;
+
+struct MsiVmList {
+  std::vector<uint32_t> words;          // commands of all phases, each phase terminated by VM_END
+  std::vector<uint32_t> phase_start;    // word offset of each phase (phase_start[0] == 0 once anything is recorded)
+  std::vector<uint8_t> blob;            // decode payloads
+  uint32_t n_counts = 0;
+  bool wants_firstk = false;
+  bool empty() const { return words.empty(); }
+  void clear() {
+    words.clear();
+    phase_start.clear();
+    blob.clear();
+    n_counts = 0;
+    wants_firstk = false;
+  }
+  void begin() { if (phase_start.empty()) phase_start.push_back(0); }
+  void barrier() {                      // the commands recorded next run after a kernel boundary
+    begin();
+    words.push_back(VM_END);
+    phase_start.push_back((uint32_t)words.size());
+  }
+  uint32_t new_counts(uint32_t n) {
+    const uint32_t b = n_counts;
+    n_counts += n;
+    return b;
+  }
+};
+
+struct MsiVmResult {
+  std::vector<uint64_t> counts;         // [n_counts]
+  std::vector<uint32_t> firstk;         // docids of the VM_FIRSTK command (at most one per list)
+};
+
+// Appends a VM_DECODE of `batch` into `dst` (overwrite = the slot's previous content is discarded).
+void msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiCboBatch &batch, bool overwrite);
+// Runs the list on the pool's context (blocks until its results are published); the list is left untouched.
+int32_t msi_vm_run(msi_bits *pool, const MsiVmList &l, MsiVmResult *res);
+// Combiner statistics of the context the pool lives on: rounds launched, lists executed.
+void msi_vm_stats(msi_bits *pool, uint64_t *rounds, uint64_t *lists);
+
+struct msi_vm;
+void msi_vm_destroy(msi_vm *vm);
