@@ -50,6 +50,12 @@ struct msi_bits {
   // writes ((~round_stamp) << 32 | docid) with atomicMin, so a newer round always beats what older rounds left.
   DevBuf dv_first, dv_taken;
   uint32_t dv_cap = 0, dv_round = 0, dv_call = 0;
+  // result block of the command-list path (msi_vm.hip): pinned, fine-grained; [0] sequence, [1] first-k count,
+  // [2 ..] cardinalities, then the first-k docids
+  uint64_t *vm_block = nullptr;
+  uint64_t vm_seq = 0;
+  uint8_t *vm_stage = nullptr;   // pinned staging of the decode payloads of the list being recorded
+  size_t vm_stage_cap = 0;
   u64 *slot(uint32_t s) const { return pool.as<u64>() + (uint64_t)s * n_words; }
 };
 
@@ -90,6 +96,43 @@ u64 *msi_bits_slot_ptr(msi_bits *p, uint32_t slot) { return p->slot(slot); }
 uint64_t msi_bits_words_per_slot(msi_bits *p) { return p->n_words; }
 uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
 uint64_t msi_bits_n_docs(msi_bits *p) { return p->n_docs; }
+uint64_t *msi_bits_vm_block(msi_bits *p) {
+  if (!p->vm_block) {
+    DeviceGuard g(p->ctx->device);
+    void *h = nullptr;
+    const size_t bytes = (2 + 1024) * sizeof(uint64_t) + 8192 * sizeof(uint32_t);
+    if (hipHostMalloc(&h, bytes, hipHostMallocCoherent) != hipSuccess) return nullptr;
+    memset(h, 0, bytes);
+    p->vm_block = (uint64_t *)h;
+  }
+  return p->vm_block;
+}
+uint64_t msi_bits_vm_next_seq(msi_bits *p) { return ++p->vm_seq; }
+// The search thread that owns the pool records into it and waits for its list before recording again, so the buffer is
+// never in use by a kernel when it grows.
+uint8_t *msi_bits_vm_stage(msi_bits *p, size_t need, size_t keep) {
+  if (need <= p->vm_stage_cap) return p->vm_stage;
+  DeviceGuard g(p->ctx->device);
+  const size_t cap = std::max<size_t>(need * 2, (size_t)4 << 20);
+  void *h = nullptr;
+  if (hipHostMalloc(&h, cap, hipHostMallocDefault) != hipSuccess) {
+    msi_set_error("hipHostMalloc(%zu) for the posting staging buffer failed", cap);
+    return nullptr;
+  }
+  if (keep && p->vm_stage) memcpy(h, p->vm_stage, keep);
+  if (p->vm_stage) (void)hipHostFree(p->vm_stage);
+  p->vm_stage = (uint8_t *)h;
+  p->vm_stage_cap = cap;
+  return p->vm_stage;
+}
+// waits for everything enqueued on the pool's own stream (the command-list path runs on the combiner's stream)
+int32_t msi_bits_sync(msi_bits *p) {
+  std::lock_guard<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  MSI_HIP_TRY(hipStreamSynchronize(p->stream));
+  return MSI_OK;
+}
+const uint32_t *msi_doc_keys_device(const msi_doc_keys *k) { return k->keys.as<uint32_t>(); }
 
 namespace {
 
@@ -179,12 +222,24 @@ __global__ void bits_op_count_kernel(u64 *__restrict__ dst, const u64 *__restric
 // One document per thread, so a wave covers exactly one 64-bit word of a set and __ballot yields the word.
 __global__ void bits_min_key_kernel(const u64 *__restrict__ universe, const uint32_t *__restrict__ keys, uint64_t n_docs,
                                     u64 *__restrict__ best /* max over documents of 0xFFFFFFFF - key; 0 = none */) {
-  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid-stride over whole 64-document words (a wave = one word) and ONE atomic per workgroup: with one atomic per
+  // wave on a single address the kernel spent 0.25 ms on 2 M documents (r2_rules_kernel_stats_before.csv)
+  __shared__ uint32_t part[BT / 64];
+  const uint64_t n_span = ((n_docs + 63) / 64) * 64;
   uint32_t inv = 0;
-  if (d < n_docs && ((universe[d >> 6] >> (d & 63)) & 1ull)) inv = 0xFFFFFFFFu - keys[d];
+  for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_span; d += (uint64_t)gridDim.x * blockDim.x) {
+    const u64 word = universe[d >> 6];   // wave-uniform
+    if (!word) continue;
+    if (d < n_docs && ((word >> (d & 63)) & 1ull)) inv = max(inv, 0xFFFFFFFFu - keys[d]);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) inv = max(inv, (uint32_t)__shfl_xor((int)inv, o));
-  if ((threadIdx.x & 63) == 0 && inv) atomicMax(best, (u64)inv);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = inv;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < BT / 64; ++i) inv = max(inv, part[i]);
+    if (inv) atomicMax(best, (u64)inv);
+  }
 }
 
 // bucket = {d in universe : key[d] == the minimum found}, universe -= bucket; the last workgroup publishes
@@ -193,19 +248,24 @@ __global__ void bits_take_key_kernel(u64 *__restrict__ universe, u64 *__restrict
                                      const uint32_t *__restrict__ keys, uint64_t n_docs, uint64_t n_words,
                                      u64 *__restrict__ best, u64 *__restrict__ acc, volatile uint64_t *__restrict__ sig,
                                      uint64_t seq) {
-  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t w = d >> 6;
   const uint32_t key = 0xFFFFFFFFu - (uint32_t)__hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const bool hit = d < n_docs && ((universe[w] >> (d & 63)) & 1ull) && keys[d] == key;
-  const u64 mask = __ballot(hit);
   __shared__ uint32_t part[BT / 64];
-  if ((threadIdx.x & 63) == 0) {
-    if (w < n_words) {
-      bucket[w] = mask;
-      if (mask) universe[w] &= ~mask;
+  uint32_t cnt = 0;  // lane 0 of each wave
+  for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_words * 64; d += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t w = d >> 6;
+    const u64 word = universe[w];   // wave-uniform
+    u64 mask = 0;
+    if (word) {
+      const bool hit = d < n_docs && ((word >> (d & 63)) & 1ull) && keys[d] == key;
+      mask = __ballot(hit);
     }
-    part[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    if ((threadIdx.x & 63) == 0) {
+      bucket[w] = mask;
+      if (mask) universe[w] = word & ~mask;
+      cnt += (uint32_t)__popcll(mask);
+    }
   }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) {
     u64 b = 0;
@@ -397,20 +457,30 @@ __device__ __forceinline__ u64 geo_key(const GeoTarget &t, double dist) {
 // best = min over the documents of `src` that have a point of their distance key (one document per thread)
 __global__ void bits_geo_min_kernel(const u64 *__restrict__ src, const double *__restrict__ lat_lng, uint64_t n_docs,
                                     uint64_t n_words, GeoTarget t, u64 *__restrict__ best) {
-  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t w = d >> 6;
-  const u64 word = w < n_words ? src[w] : 0ull;
+  __shared__ u64 part[BT / 64];
   u64 k = ~0ull;
-  if (d < n_docs && ((word >> (d & 63)) & 1ull)) {
-    const double lat = lat_lng[2 * d];
-    if (lat == lat) k = geo_key(t, geo_distance_m(t, lat, lat_lng[2 * d + 1]));
+  for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_words * 64; d += (uint64_t)gridDim.x * blockDim.x) {
+    const u64 word = src[d >> 6];   // wave-uniform
+    if (!word) continue;
+    if (d < n_docs && ((word >> (d & 63)) & 1ull)) {
+      const double lat = lat_lng[2 * d];
+      if (lat == lat) {
+        const u64 kk = geo_key(t, geo_distance_m(t, lat, lat_lng[2 * d + 1]));
+        k = kk < k ? kk : k;
+      }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const u64 other = shfl_xor_u64(k, o);
     k = other < k ? other : k;
   }
-  if ((threadIdx.x & 63) == 0 && k != ~0ull) atomicMin(best, k);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < BT / 64; ++i) k = part[i] < k ? part[i] : k;
+    if (k != ~0ull) atomicMin(best, k);   // one atomic per workgroup
+  }
 }
 
 // dst := {d in src with a point : key_lo <= key(d) <= key_hi} (mode 0; mode 2: dst |= them) or, relative to the extreme found by the min
@@ -420,43 +490,58 @@ __global__ void bits_geo_take_kernel(u64 *__restrict__ src, u64 *__restrict__ ds
                                      uint64_t n_docs, uint64_t n_words, GeoTarget t, int mode, u64 key_lo, u64 key_hi,
                                      u64 *__restrict__ best, u64 *__restrict__ first, u64 *__restrict__ acc,
                                      volatile uint64_t *__restrict__ sig, uint64_t seq) {
-  const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t w = d >> 6;
-  const u64 word = w < n_words ? src[w] : 0ull;
   const u64 kbest = mode == 1 ? __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-  bool hit = false;
-  if (d < n_docs && ((word >> (d & 63)) & 1ull) && (mode != 1 || kbest != ~0ull)) {
-    const double lat = lat_lng[2 * d];
-    if (lat == lat) {
-      const double dist = geo_distance_m(t, lat, lat_lng[2 * d + 1]);
-      const u64 k = geo_key(t, dist);
-      if (mode != 1) {
-        hit = k >= key_lo && k <= key_hi;
-      } else {
-        const double d0 = __longlong_as_double((long long)(t.ascending ? kbest : ~(kbest + 1)));
-        hit = fabs(d0 - dist) <= t.margin;  // documents/geo_sort.rs:181
-        if (k == kbest) atomicMin(first, (u64)d);
+  __shared__ uint32_t part[BT / 64];
+  __shared__ u64 part_first[BT / 64];
+  uint32_t cnt = 0;      // lane 0 of each wave
+  u64 mine_first = ~0ull;
+  for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_words * 64; d += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t w = d >> 6;
+    const u64 word = src[w];   // wave-uniform
+    bool hit = false;
+    if (d < n_docs && ((word >> (d & 63)) & 1ull) && (mode != 1 || kbest != ~0ull)) {
+      const double lat = lat_lng[2 * d];
+      if (lat == lat) {
+        const double dist = geo_distance_m(t, lat, lat_lng[2 * d + 1]);
+        const u64 k = geo_key(t, dist);
+        if (mode != 1) {
+          hit = k >= key_lo && k <= key_hi;
+        } else {
+          const double d0 = __longlong_as_double((long long)(t.ascending ? kbest : ~(kbest + 1)));
+          hit = fabs(d0 - dist) <= t.margin;  // documents/geo_sort.rs:181
+          if (k == kbest && d < mine_first) mine_first = d;
+        }
       }
     }
-  }
-  const u64 mask = __ballot(hit);
-  __shared__ uint32_t part[BT / 64];
-  if ((threadIdx.x & 63) == 0) {
-    if (w < n_words) {
+    const u64 mask = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) {
       if (mode == 2) {
         if (mask) dst[w] |= mask;
       } else {
         dst[w] = mask;
       }
       if (mode == 1 && mask) src[w] = word & ~mask;
+      cnt += (uint32_t)__popcll(mask);
     }
-    part[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 other = shfl_xor_u64(mine_first, o);
+    mine_first = other < mine_first ? other : mine_first;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    part[threadIdx.x >> 6] = cnt;
+    part_first[threadIdx.x >> 6] = mine_first;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    u64 b = 0;
-    for (int i = 0; i < BT / 64; ++i) b += part[i];
+    u64 b = 0, f0 = ~0ull;
+    for (int i = 0; i < BT / 64; ++i) {
+      b += part[i];
+      f0 = part_first[i] < f0 ? part_first[i] : f0;
+    }
     if (b) atomicAdd(&acc[0], b);
+    if (f0 != ~0ull) atomicMin(first, f0);
     __threadfence();
     const u64 done = atomicAdd(&acc[1], 1ull);
     if (done == gridDim.x - 1) {
@@ -1063,6 +1148,8 @@ void msi_bits_destroy(msi_bits *p) {
   if (p->h_sig) (void)hipHostFree((void *)p->h_sig);
   if (p->d_acc) (void)hipFree(p->d_acc);
   if (p->h_ring) (void)hipHostFree(p->h_ring);
+  if (p->vm_block) (void)hipHostFree(p->vm_block);
+  if (p->vm_stage) (void)hipHostFree(p->vm_stage);
   if (p->private_stream) (void)hipStreamDestroy(p->stream);
   delete p;
   }
@@ -1620,7 +1707,8 @@ int32_t msi_bits_order_next(msi_bits *p, const msi_doc_keys *keys, uint32_t univ
   DeviceGuard g(p->ctx->device);
   hipStream_t st = p->stream;
   u64 *best = p->d_acc + 2 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS;
-  const uint32_t blocks = (uint32_t)((p->n_words * 64 + BT - 1) / BT);
+  // grid-stride kernels: a few workgroups per CU, whole 64-document words per wave
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((p->n_words * 64 + BT - 1) / BT, (uint64_t)p->ctx->n_cu * 4);
   const uint64_t seq = ++p->seq;
   hipLaunchKernelGGL(bits_min_key_kernel, dim3(blocks), dim3(BT), 0, st, p->slot(universe), keys->keys.as<uint32_t>(),
                      p->n_docs, best);
@@ -1895,7 +1983,7 @@ static int32_t geo_range(msi_bits *p, const msi_geo_points *gp, const GeoTarget 
   std::unique_lock<std::mutex> lk(*p->mu);
   DeviceGuard g(p->ctx->device);
   u64 *cells = p->d_acc + 4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS;
-  const dim3 grid((uint32_t)((p->n_words * 64 + BT - 1) / BT)), block(BT);
+  const dim3 grid((uint32_t)std::min<uint64_t>((p->n_words * 64 + BT - 1) / BT, (uint64_t)p->ctx->n_cu * 4)), block(BT);
   const uint64_t seq = ++p->seq;
   hipLaunchKernelGGL(bits_geo_take_kernel, grid, block, 0, p->stream, p->slot(src), p->slot(dst), gp->lat_lng.as<double>(),
                      p->n_docs, p->n_words, t, mode, key_lo, key_hi, cells, cells + 1, p->d_acc, p->h_sig, seq);
@@ -1935,7 +2023,7 @@ int32_t msi_bits_geo_next(msi_bits *p, const msi_geo_points *gp, uint32_t univer
     DeviceGuard g(p->ctx->device);
     hipStream_t st = p->stream;
     u64 *cells = p->d_acc + 4 + MSI_BITS_MANY + MSI_BITS_MAX_PATHS;
-    const dim3 grid((uint32_t)((p->n_words * 64 + BT - 1) / BT)), block(BT);
+    const dim3 grid((uint32_t)std::min<uint64_t>((p->n_words * 64 + BT - 1) / BT, (uint64_t)p->ctx->n_cu * 4)), block(BT);
     const uint64_t seq = ++p->seq;
     hipLaunchKernelGGL(bits_geo_min_kernel, grid, block, 0, st, p->slot(universe), gp->lat_lng.as<double>(), p->n_docs,
                        p->n_words, t, cells);

@@ -49,6 +49,9 @@ struct msi_ctx {
   // context (msi_vs / msi_dict / msi_bits) one more: msi_ctx_destroy only drops
   // the caller's, so objects may be destroyed after their context in any order.
   std::atomic<int> refs{1};
+  // the command-list combiner of the ranked keyword searches (msi_vm.hip), created on first use
+  struct msi_vm *vm = nullptr;
+  std::mutex vm_mu;
 };
 void msi_ctx_retain(msi_ctx *ctx);
 void msi_ctx_release(msi_ctx *ctx);

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "msi_common.h"
+#include "msi_vm.h"
 
 static thread_local char g_err[512] = "";
 
@@ -78,6 +79,8 @@ void msi_ctx_retain(msi_ctx *ctx) { ctx->refs.fetch_add(1, std::memory_order_rel
 void msi_ctx_release(msi_ctx *ctx) {
   if (!ctx) return;
   if (ctx->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+  if (ctx->vm) msi_vm_destroy(ctx->vm);   // joins the combiner thread; every pool is gone by now
+  ctx->vm = nullptr;
   DeviceGuard g(ctx->device);
   if (ctx->stream) {
     (void)hipStreamSynchronize(ctx->stream);

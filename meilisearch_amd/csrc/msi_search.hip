@@ -36,6 +36,11 @@
 #include <vector>
 
 #include "msi_common.h"
+#ifndef MSI_SEARCH_DIRECT_ONLY
+#include "msi_vm.h"
+int32_t msi_bits_sync(msi_bits *p);
+const uint32_t *msi_doc_keys_device(const msi_doc_keys *k);
+#endif
 
 struct msi_dict;
 bool msi_dict_word(const msi_dict *d, uint32_t idx, const uint8_t **w, uint32_t *len);
@@ -87,9 +92,53 @@ struct SetH {
 };
 using Set = std::shared_ptr<SetH>;
 
+// Every device operation of a search goes through Dev.  Two back ends:
+//   command lists (default; msi_vm.h): operations are RECORDED; at the points where the control flow needs a
+//   cardinality (or the ordered docids) the recorded list is submitted and runs — together with the lists of every
+//   other search waiting at that moment — as one kernel launch.  A search is then ~80 submissions instead of 211
+//   launches + 80 waits, and the launches are shared by all searches in flight;
+//   direct (MSI_SEARCH_VM=0, and the host-logic test double which has no kernels): one msi_bits call per operation.
 struct Dev {
   SetPool pool;
-  explicit Dev(msi_bits *p) : pool(p, 0) {}
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  bool vm = true;
+  MsiVmList list;
+  MsiVmResult res;
+#else
+  static constexpr bool vm = false;
+#endif
+  explicit Dev(msi_bits *p) : pool(p, 0) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    const char *knob = getenv("MSI_SEARCH_VM");
+    vm = !(knob && knob[0] == '0');
+    if (vm) ck(msi_bits_sync(p));   // whatever the caller enqueued on the pool's own stream is done before a list runs
+#endif
+  }
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  void rec(std::initializer_list<uint32_t> w) {
+    list.begin();
+    list.words.insert(list.words.end(), w.begin(), w.end());
+  }
+  // submit what was recorded and wait for it: the only blocking point of the command-list back end
+  void run() {
+    if (list.empty()) return;
+    Clock ck_;
+    ++g_stats.launches;
+    ++g_stats.syncs;
+    const int32_t st = msi_vm_run(pool.p, list, &res);
+    g_stats.device_wait_ms += ck_.ms();
+    list.clear();
+    ck(st);
+  }
+  // direct calls (GeoSort, distinct) see everything recorded so far
+  void settle() { if (vm) run(); }
+  uint32_t counts_for(uint32_t n) {   // room for n more cardinalities in this list (else it runs first)
+    if (list.n_counts + n > MSI_VM_MAX_COUNTS) run();
+    return list.new_counts(n);
+  }
+#else
+  void settle() {}
+#endif
   Set alloc() {  // content undefined: the caller overwrites every word
     if (pool.free_.empty()) {
       if (pool.clean_.empty()) fail(MSI_E_OOM, "the msi_bits pool has no free slot left (create it with more slots)");
@@ -102,14 +151,20 @@ struct Dev {
     return Set(new SetH{&pool, s});
   }
   void op(uint32_t d, uint32_t a, uint32_t b, int32_t o) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) return rec({VM_OP, d, a, b, (uint32_t)o});
+#endif
     ++g_stats.launches;
     ck(msi_bits_op(pool.p, d, a, b, o));
   }
   void fill(uint32_t d, int ones) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) return rec({VM_FILL, d, ones ? 1u : 0u});
+#endif
     ++g_stats.launches;
     ck(msi_bits_fill(pool.p, d, ones));
   }
-  // Zeroed slots are handed out from a stock that one launch refills MSI_BITS_CLEAR_MAX at a time
+  // Zeroed slots are handed out from a stock that one operation refills MSI_BITS_CLEAR_MAX at a time
   // (instead of one memset per set: a third of the launches of a search were clears).
   Set zeros() {
     if (pool.clean_.empty()) {
@@ -120,8 +175,16 @@ struct Dev {
         pool.free_.pop_back();
       }
       if (!n) fail(MSI_E_OOM, "the msi_bits pool has no free slot left (create it with more slots)");
-      ++g_stats.launches;
-      ck(msi_bits_clear_slots(pool.p, n, batch));
+#ifndef MSI_SEARCH_DIRECT_ONLY
+      if (vm) {
+        rec({VM_CLEAR, n});
+        list.words.insert(list.words.end(), batch, batch + n);
+      } else
+#endif
+      {
+        ++g_stats.launches;
+        ck(msi_bits_clear_slots(pool.p, n, batch));
+      }
       for (uint32_t k = n; k-- > 0;) pool.clean_.push_back(batch[k]);
     }
     const uint32_t s = pool.clean_.back();
@@ -144,6 +207,15 @@ struct Dev {
   Set and_new(const Set &a, const Set &b, uint64_t *count) {
     Set s = alloc();
     if (count) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+      if (vm) {
+        const uint32_t c = counts_for(1);
+        rec({VM_OP_COUNT, s->slot, a->slot, b->slot, (uint32_t)MSI_BITS_AND, c});
+        run();
+        *count = res.counts[c];
+        return s;
+      }
+#endif
       Clock ck_;
       ++g_stats.launches;
       ++g_stats.syncs;
@@ -154,9 +226,27 @@ struct Dev {
     }
     return s;
   }
-  // dst[i] = prefix & cond[i] with the cardinalities, one launch and one completion wait for all of them
+  // dst[i] = prefix & cond[i] with the cardinalities, one operation and one completion wait for all of them
   std::vector<std::pair<Set, uint64_t>> and_many(const Set &prefix, const std::vector<Set> &conds) {
     std::vector<std::pair<Set, uint64_t>> out;
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      for (size_t base = 0; base < conds.size(); base += 256) {
+        const uint32_t n = (uint32_t)std::min<size_t>(256, conds.size() - base);
+        const uint32_t cb = counts_for(n);
+        rec({VM_AND_MANY, prefix->slot, n, cb});
+        for (uint32_t k = 0; k < n; ++k) {
+          Set d = alloc();
+          list.words.push_back(conds[base + k]->slot);
+          list.words.push_back(d->slot);
+          out.push_back({d, 0});
+        }
+        run();
+        for (uint32_t k = 0; k < n; ++k) out[base + k].second = res.counts[cb + k];
+      }
+      return out;
+    }
+#endif
     for (size_t base = 0; base < conds.size(); base += MSI_BITS_MANY) {
       const uint32_t n = (uint32_t)std::min<size_t>(MSI_BITS_MANY, conds.size() - base);
       uint32_t cs[MSI_BITS_MANY], ds[MSI_BITS_MANY];
@@ -176,14 +266,40 @@ struct Dev {
     }
     return out;
   }
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  uint32_t rec_paths(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe) {
+    const uint32_t n = (uint32_t)paths.size();
+    const uint32_t cb = counts_for(n);
+    uint32_t n_steps = 0;
+    for (auto &p : paths) n_steps += (uint32_t)p.size();
+    rec({VM_PATHS, n, bucket->slot, universe->slot, cb, n_steps});
+    uint32_t o = 0;
+    list.words.push_back(0);
+    for (auto &p : paths) {
+      o += (uint32_t)p.size();
+      list.words.push_back(o);
+    }
+    for (auto &p : paths)
+      for (auto &s_ : p) list.words.push_back(s_->slot);
+    return cb;
+  }
+#endif
   // a whole cost level: path k claims universe & AND(its condition sets), in order; returns the cardinalities
   std::vector<uint64_t> paths_claim(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe) {
+    std::vector<uint64_t> counts(paths.size(), 0);
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      const uint32_t cb = rec_paths(paths, bucket, universe);
+      run();
+      for (size_t k = 0; k < paths.size(); ++k) counts[k] = res.counts[cb + k];
+      return counts;
+    }
+#endif
     std::vector<uint32_t> off{0}, steps;
     for (auto &p : paths) {
       for (auto &s : p) steps.push_back(s->slot);
       off.push_back((uint32_t)steps.size());
     }
-    std::vector<uint64_t> counts(paths.size(), 0);
     Clock ck_;
     ++g_stats.launches;
     ++g_stats.syncs;
@@ -195,6 +311,22 @@ struct Dev {
   // Sort rule: bucket := the documents of `universe` with its smallest order key, universe -= bucket
   Set order_next(const msi_doc_keys *keys, const Set &universe, uint32_t *key, uint64_t *count) {
     Set b = alloc();  // fully overwritten by the kernel
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm && list.phase_start.size() + 1 <= MSI_VM_MAX_PHASES) {
+      const uint64_t kp = (uint64_t)(uintptr_t)msi_doc_keys_device(keys);
+      const uint32_t c = counts_for(2);
+      if (list.phase_start.size() + 1 > MSI_VM_MAX_PHASES) run();
+      rec({VM_MINKEY, universe->slot, (uint32_t)kp, (uint32_t)(kp >> 32), 0});
+      list.barrier();   // every chunk has contributed its minimum before any chunk takes
+      rec({VM_TAKEKEY, universe->slot, b->slot, (uint32_t)kp, (uint32_t)(kp >> 32), 0, c, c + 1});
+      run();
+      *count = res.counts[c];
+      *key = (uint32_t)res.counts[c + 1];
+      if (!*count) *key = 0xFFFFFFFFu;
+      return b;
+    }
+    settle();
+#endif
     Clock ck_;
     g_stats.launches += 2;
     ++g_stats.syncs;
@@ -206,6 +338,7 @@ struct Dev {
   // bucket; *first = the document whose point is the bucket's value (0xFFFFFFFF: no document has a point, nothing done)
   Set geo_next(const msi_geo_rule &r, uint32_t cap, double margin, const Set &universe, uint32_t *first, uint64_t *count) {
     Set b = alloc(), scratch = alloc();  // the bucket is fully overwritten by the kernel
+    settle();
     Clock ck_;
     g_stats.launches += 2;
     ++g_stats.syncs;
@@ -219,6 +352,7 @@ struct Dev {
   std::pair<Set, Set> distinct(const msi_doc_values *vals, const Set &cands, uint64_t *kept) {
     Set work = clone(cands);  // consumed by the rounds; `cands` may be a shared, cached set
     Set rem = alloc(), exc = alloc();
+    settle();
     Clock ck_;
     uint32_t rounds = 0;
     ck(msi_bits_distinct(pool.p, vals, work->slot, rem->slot, exc->slot, kept, &rounds));
@@ -226,17 +360,39 @@ struct Dev {
     g_stats.launches += 2 + 2 * rounds;
     g_stats.syncs += rounds;
     g_stats.device_wait_ms += ck_.ms();
+    direct_done();
     return {rem, exc};
   }
   Set distinct_excluded(const msi_doc_values *vals, const Set &kept) {
     Set exc = alloc();
+    settle();
     g_stats.launches += 2;
     ck(msi_bits_distinct_excluded(pool.p, vals, kept->slot, exc->slot));
+    direct_done();
     return exc;
   }
-  // sets[i] -= removed, with the new cardinalities: one launch and one wait per MSI_BITS_MANY sets
+  // a direct call may leave work on the pool's own stream: the next list must not overtake it
+  void direct_done() {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) ck(msi_bits_sync(pool.p));
+#endif
+  }
+  // sets[i] -= removed, with the new cardinalities: one operation and one wait
   std::vector<uint64_t> sub_many(const Set &removed, const std::vector<Set> &sets) {
     std::vector<uint64_t> out(sets.size(), 0);
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      for (size_t base = 0; base < sets.size(); base += 512) {
+        const uint32_t n = (uint32_t)std::min<size_t>(512, sets.size() - base);
+        const uint32_t cb = counts_for(n);
+        rec({VM_SUB_MANY, removed->slot, n, cb});
+        for (uint32_t k = 0; k < n; ++k) list.words.push_back(sets[base + k]->slot);
+        run();
+        for (uint32_t k = 0; k < n; ++k) out[base + k] = res.counts[cb + k];
+      }
+      return out;
+    }
+#endif
     for (size_t base = 0; base < sets.size(); base += MSI_BITS_MANY) {
       const uint32_t n = (uint32_t)std::min<size_t>(MSI_BITS_MANY, sets.size() - base);
       uint32_t ss[MSI_BITS_MANY];
@@ -251,12 +407,31 @@ struct Dev {
   }
   Set from_docids(const std::vector<uint32_t> &ids) {
     Set s = alloc();
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      MsiCboBatch b;
+      b.small_ids = ids;
+      ck(msi_vm_record_decode(list, pool.p, s->slot, b, true));
+      return s;
+    }
+#endif
     ++g_stats.launches;
     ck(msi_bits_set_from_docids(pool.p, s->slot, ids.empty() ? nullptr : ids.data(), ids.size()));
     return s;
   }
   // the same level WITHOUT the completion wait: its counts land in `region`; false = does not fit, nothing enqueued
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  std::vector<std::pair<uint32_t, uint32_t>> pending_levels;  // (count base, paths) of the levels recorded ahead
+#endif
   bool paths_enqueue(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe, uint32_t region) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      if (paths.size() > MSI_BITS_REGION_PATHS || list.n_counts + paths.size() > MSI_VM_MAX_COUNTS) return false;
+      if (region == 0) pending_levels.clear();
+      pending_levels.push_back({rec_paths(paths, bucket, universe), (uint32_t)paths.size()});
+      return true;
+    }
+#endif
     std::vector<uint32_t> off{0}, steps;
     for (auto &p : paths) {
       for (auto &s : p) steps.push_back(s->slot);
@@ -271,6 +446,17 @@ struct Dev {
   }
   std::vector<uint64_t> paths_collect(uint32_t n_regions) {  // ONE wait for every level enqueued so far
     std::vector<uint64_t> counts((size_t)n_regions * MSI_BITS_REGION_PATHS, 0);
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      run();
+      // levels without a path were not recorded: the caller's regions are consecutive recorded levels
+      for (size_t j = 0; j < pending_levels.size() && j < n_regions; ++j)
+        for (uint32_t k = 0; k < pending_levels[j].second; ++k)
+          counts[j * MSI_BITS_REGION_PATHS + k] = res.counts[pending_levels[j].first + k];
+      pending_levels.clear();
+      return counts;
+    }
+#endif
     Clock ck_;
     ++g_stats.syncs;
     ck(msi_bits_paths_collect(pool.p, n_regions, counts.data()));
@@ -278,6 +464,13 @@ struct Dev {
     return counts;
   }
   void claim(const Set &docs, const Set &bucket, const Set &universe, const std::vector<Set> &stack) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      rec({VM_CLAIM, docs->slot, bucket->slot, universe->slot, (uint32_t)stack.size()});
+      for (auto &s_ : stack) list.words.push_back(s_->slot);
+      return;
+    }
+#endif
     uint32_t ss[MSI_BITS_MANY];
     if (stack.size() > MSI_BITS_MANY) fail(MSI_E_INTERNAL, "path longer than the claim kernel supports");
     for (size_t k = 0; k < stack.size(); ++k) ss[k] = stack[k]->slot;
@@ -286,6 +479,14 @@ struct Dev {
   }
   uint64_t count(const Set &a) {
     uint64_t c = 0;
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      const uint32_t ci = counts_for(1);
+      rec({VM_COUNT, a->slot, ci});
+      run();
+      return res.counts[ci];
+    }
+#endif
     Clock ck_;
     ++g_stats.launches;
     ++g_stats.syncs;
@@ -294,6 +495,16 @@ struct Dev {
     return c;
   }
   Set decode(const MsiCboBatch &b) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      if (b.containers.empty() && b.small_ids.empty()) return zeros();
+      Set s = alloc();   // overwritten chunk by chunk: no zeroed slot needed
+      ++g_stats.decodes;
+      g_stats.postings_bytes += b.bytes.size() + 4 * b.small_ids.size();
+      ck(msi_vm_record_decode(list, pool.p, s->slot, b, true));
+      return s;
+    }
+#endif
     Set s = zeros();
     if (!b.containers.empty() || !b.small_ids.empty()) {
       Clock ck_;
@@ -306,6 +517,17 @@ struct Dev {
     return s;
   }
   std::vector<uint32_t> first_k(const Set &a, uint32_t k) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm && k <= MSI_VM_MAX_FIRSTK) {
+      if (k == 0) return {};
+      const uint32_t ci = counts_for(1);
+      rec({VM_FIRSTK, a->slot, k, ci});
+      list.wants_firstk = true;
+      run();
+      return res.firstk;
+    }
+    settle();
+#endif
     std::vector<uint32_t> ids(std::max<uint32_t>(k, 1));
     uint32_t n = 0;
     Clock ck_;

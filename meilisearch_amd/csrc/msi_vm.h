@@ -29,8 +29,8 @@ enum : uint32_t {
   VM_PATHS,      // n_paths, bucket, universe, cnt_base, n_steps, off[n_paths + 1], step slot...
   VM_SUB_MANY,   // removed, n, cnt_base, slot...
   VM_COUNT,      // slot, cnt
-  VM_DECODE,     // dst, overwrite, blob byte offset of {koff[n_chunks + 1], containers, bytes}
-  VM_FIRSTK,     // slot, k, scratch word offset (n_chunks u32 inside the list's own words)
+  VM_DECODE,     // dst, overwrite, staging byte offset of {header, koff[n_chunks + 1], containers, bytes}
+  VM_FIRSTK,     // slot, k, cnt (the set's cardinality comes back too); at most one per list, in its last phase
   VM_MINKEY,     // universe, keys lo, keys hi, cell
   VM_TAKEKEY,    // universe, bucket, keys lo, keys hi, cell, cnt, key result index
 };
@@ -43,14 +43,17 @@ constexpr uint32_t MSI_VM_CELLS = 4;
 struct MsiVmList {
   std::vector<uint32_t> words;          // commands of all phases, each phase terminated by VM_END
   std::vector<uint32_t> phase_start;    // word offset of each phase (phase_start[0] == 0 once anything is recorded)
-  std::vector<uint8_t> blob;            // decode payloads
+  // decode payloads: written by the search thread straight into its pool's PINNED staging buffer and read by the
+  // kernel over PCIe (wide aligned loads, each posting byte exactly once) — no copy on the combiner thread, no DMA
+  // call per list.  `stage_used` bytes of msi_bits_vm_stage(pool) belong to this list.
+  size_t stage_used = 0;
   uint32_t n_counts = 0;
   bool wants_firstk = false;
   bool empty() const { return words.empty(); }
   void clear() {
     words.clear();
     phase_start.clear();
-    blob.clear();
+    stage_used = 0;
     n_counts = 0;
     wants_firstk = false;
   }
@@ -73,7 +76,7 @@ struct MsiVmResult {
 };
 
 // Appends a VM_DECODE of `batch` into `dst` (overwrite = the slot's previous content is discarded).
-void msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiCboBatch &batch, bool overwrite);
+int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiCboBatch &batch, bool overwrite);
 // Runs the list on the pool's context (blocks until its results are published); the list is left untouched.
 int32_t msi_vm_run(msi_bits *pool, const MsiVmList &l, MsiVmResult *res);
 // Combiner statistics of the context the pool lives on: rounds launched, lists executed.

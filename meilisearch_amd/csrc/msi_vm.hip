@@ -32,6 +32,7 @@ uint64_t msi_bits_n_docs(msi_bits *p);
 uint32_t msi_bits_n_slots(msi_bits *p);
 uint64_t *msi_bits_vm_block(msi_bits *p);     // pinned, fine-grained: [0] seq, [1] first-k count, [2..] counts, then ids
 uint64_t msi_bits_vm_next_seq(msi_bits *p);
+uint8_t *msi_bits_vm_stage(msi_bits *p, size_t need, size_t keep);   // pinned staging of the pool's decode payloads (grows, keeps `keep` bytes)
 
 namespace {
 
@@ -44,13 +45,13 @@ constexpr size_t RES_IDS = RES_COUNTS + MSI_VM_MAX_COUNTS;     // u64 index wher
 
 struct alignas(16) RoundSub {
   u64 pool_base, n_words, n_docs, host_res, seq;
+  u64 stage;                              // the pool's pinned staging buffer (decode payloads), device-visible
   uint32_t n_chunks, n_phases;
   uint32_t phase_off[MSI_VM_MAX_PHASES];  // arena word offsets of each phase's first command
   uint32_t list_off;                      // arena word offset of the list's words
-  uint32_t blob_off;                      // arena byte offset of the list's blob
-  uint32_t state_off;                     // arena word offset of {done[4] u32, cells[4] u64, counts[n_counts] u64}
+  uint32_t _pad0;
+  uint32_t state_off;                     // arena word offset of {done[4] u32, cells[4] u64, counts[n_counts] u64, chunk cardinalities[n_chunks] u32}
   uint32_t n_counts;
-  uint32_t _pad[2];
 };
 static_assert(sizeof(RoundSub) % 16 == 0, "RoundSub array stays 16-byte aligned");
 
@@ -84,6 +85,7 @@ __device__ __forceinline__ u64 doc_mask(u64 gw, u64 n_docs) {
 __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, uint32_t phase) {
   __shared__ uint32_t s_cnt[MSI_VM_MAX_COUNTS];
   __shared__ u64 s_dec[CHW];
+  __shared__ uint4 s_raw[CHW * 8 / 16 + 2];   // one container body (<= 8 KiB) + alignment slack, staged with wide loads
   __shared__ uint32_t s_scan[VT / 64 + 1];
   __shared__ uint32_t s_last;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,9 +102,10 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   uint32_t *const state = arena + r.state_off;
   u64 *const cells = reinterpret_cast<u64 *>(state + 4);
   u64 *const counts = cells + MSI_VM_CELLS;
-  const uint8_t *const blob = reinterpret_cast<const uint8_t *>(arena) + r.blob_off;
+  const uint8_t *const blob = reinterpret_cast<const uint8_t *>(r.stage);
   const uint32_t *pc = arena + r.phase_off[phase];
-  uint32_t fk_cnt = NONE, fk_scratch = 0;
+  uint32_t fk_cnt = NONE;
+  uint32_t *const chunk_card = reinterpret_cast<uint32_t *>(counts + r.n_counts);   // first-k: cardinality of the set per chunk
   auto add_count = [&](uint32_t idx, uint32_t c) {
     c = wave_sum(c);
     if (lane == 0 && c) atomicAdd(&s_cnt[idx], c);
@@ -251,11 +254,10 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         if (op == VM_COUNT) {
           add_count(pc[2], c);
           pc += 3;
-        } else {          // slot, k, scratch, cnt: this chunk's cardinality is also kept for the ordered emit
-          add_count(pc[4], c);
-          fk_cnt = pc[4];
-          fk_scratch = pc[3];
-          pc += 5;
+        } else {          // slot, k, cnt: this chunk's cardinality is also kept for the ordered emit
+          add_count(pc[3], c);
+          fk_cnt = pc[3];
+          pc += 4;
         }
         break;
       }
@@ -274,9 +276,17 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
           __syncthreads();
           for (uint32_t ci = k0; ci < k1; ++ci) {
             const MsiContainer c = cs[ci];
-            const uint8_t *body = bytes + c.offset;
+            // the body crosses PCIe once, as 16-byte aligned loads (any body alignment), and is decoded from LDS
+            const uint32_t len = c.type == 0 ? 2 * c.card : (c.type == 1 ? 8192u : 4 * c.card);
+            const uintptr_t b0 = reinterpret_cast<uintptr_t>(bytes + c.offset);
+            const uint32_t skew = (uint32_t)(b0 & 15);
+            const uint4 *src = reinterpret_cast<const uint4 *>(b0 - skew);
+            const uint32_t n16 = (skew + min(len, 8192u) + 15) / 16;
+            for (uint32_t i = tid; i < n16; i += VT) s_raw[i] = src[i];
+            __syncthreads();
+            const uint8_t *body = reinterpret_cast<const uint8_t *>(s_raw) + skew;
             if (c.type == 0) {
-              for (uint32_t i = tid; i < c.card; i += VT) {
+              for (uint32_t i = tid; i < min(c.card, 4096u); i += VT) {
                 const uint32_t v = (uint32_t)body[2 * i] | ((uint32_t)body[2 * i + 1] << 8);
                 atomicOr(&s_dec[v >> 6], 1ull << (v & 63));
               }
@@ -287,15 +297,16 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
                 if (v) atomicOr(&s_dec[w], v);
               }
             } else {
-              for (uint32_t rr = 0; rr < c.card; ++rr) {
+              for (uint32_t rr = 0; rr < min(c.card, 2048u); ++rr) {
                 const uint32_t start = (uint32_t)body[4 * rr] | ((uint32_t)body[4 * rr + 1] << 8);
-                const uint32_t len = ((uint32_t)body[4 * rr + 2] | ((uint32_t)body[4 * rr + 3] << 8)) + 1;
-                for (uint32_t i = tid; i < len; i += VT) {
+                const uint32_t rl = ((uint32_t)body[4 * rr + 2] | ((uint32_t)body[4 * rr + 3] << 8)) + 1;
+                for (uint32_t i = tid; i < rl; i += VT) {
                   const uint32_t v = start + i;
                   if (v < 65536) atomicOr(&s_dec[v >> 6], 1ull << (v & 63));
                 }
               }
             }
+            __syncthreads();   // s_raw is reused by the next container
           }
           __syncthreads();
           for (uint32_t p = tid; p < n_pairs; p += VT) {
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   __syncthreads();
   for (uint32_t i = tid; i < r.n_counts; i += VT)
     if (s_cnt[i]) atomicAdd(&counts[i], (u64)s_cnt[i]);
-  if (fk_cnt != NONE && tid == 0) (arena + r.list_off + fk_scratch)[chunk] = s_cnt[fk_cnt];
+  if (fk_cnt != NONE && tid == 0) chunk_card[chunk] = s_cnt[fk_cnt];
   __threadfence();
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(&state[phase], 1u) == r.n_chunks - 1 ? 1u : 0u;
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         default: pcf += 1; break;
       }
     }
-    const uint32_t *cc = arena + r.list_off + fk_scratch;
+    const uint32_t *cc = chunk_card;
     uint32_t *ids = reinterpret_cast<uint32_t *>(res + RES_IDS);
     uint32_t running = 0;
     for (uint32_t c = 0; c < r.n_chunks && running < k; ++c) {
@@ -490,6 +501,7 @@ struct msi_vm {
 namespace {
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+uint32_t chunks_of(msi_bits *p) { return (uint32_t)((msi_bits_words_per_slot(p) + CHW - 1) / CHW); }
 
 bool arena_ensure(msi_vm *vm, msi_vm::Arena &A, size_t bytes) {
   if (bytes <= A.cap) return true;
@@ -544,16 +556,14 @@ void msi_vm::run() {
     // ---- layout ------------------------------------------------------------------------------------------
     const size_t n_sub = batch.size();
     size_t off = 64 + align16(n_sub * sizeof(RoundSub));
-    std::vector<size_t> words_at(n_sub), state_at(n_sub), blob_at(n_sub);
+    std::vector<size_t> words_at(n_sub), state_at(n_sub);
     uint32_t max_chunks = 1, max_phases = 1;
     for (size_t i = 0; i < n_sub; ++i) {
       const MsiVmList &l = *batch[i]->list;
       words_at[i] = off;
       off = align16(off + (l.words.size() + 1) * 4);
       state_at[i] = off;
-      off = align16(off + 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8);
-      blob_at[i] = off;
-      off = align16(off + l.blob.size());
+      off = align16(off + 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)chunks_of(batch[i]->pool) * 4);
     }
     int32_t st = MSI_OK;
     if (off > 0xFFFFFFF0ull || !arena_ensure(this, A, off)) {
@@ -582,16 +592,19 @@ void msi_vm::run() {
         r.n_phases = (uint32_t)l.phase_start.size();
         for (uint32_t ph = 0; ph < r.n_phases; ++ph) r.phase_off[ph] = (uint32_t)(words_at[i] / 4) + l.phase_start[ph];
         r.list_off = (uint32_t)(words_at[i] / 4);
-        r.blob_off = (uint32_t)blob_at[i];
+        r.stage = l.stage_used ? (u64)(uintptr_t)msi_bits_vm_stage(p, 0, 0) : 0;
         r.state_off = (uint32_t)(state_at[i] / 4);
         r.n_counts = l.n_counts;
         memcpy(A.host + words_at[i], l.words.data(), l.words.size() * 4);
         reinterpret_cast<uint32_t *>(A.host + words_at[i])[l.words.size()] = VM_END;
-        memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8);
-        if (!l.blob.empty()) memcpy(A.host + blob_at[i], l.blob.data(), l.blob.size());
+        memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)r.n_chunks * 4);
         max_chunks = std::max(max_chunks, r.n_chunks);
         max_phases = std::max(max_phases, r.n_phases);
       }
+      // From the first launch on a waiter may see its sequence number and leave (its VmSub is on its stack): the
+      // combiner does not touch a VmSub after this point unless the round failed — then nothing was published and
+      // the waiter is still polling.
+      for (VmSub *s : batch) s->status.store(0, std::memory_order_release);
       if (hipMemcpyAsync(A.dev, A.host, off, hipMemcpyHostToDevice, stream) != hipSuccess) st = MSI_E_HIP;
       for (uint32_t ph = 0; ph < max_phases && st == MSI_OK; ++ph) {
         hipLaunchKernelGGL(vm_kernel, dim3(max_chunks, (uint32_t)n_sub), dim3(VT), 0, stream,
@@ -603,7 +616,8 @@ void msi_vm::run() {
     }
     rounds.fetch_add(1, std::memory_order_relaxed);
     lists.fetch_add(n_sub, std::memory_order_relaxed);
-    for (VmSub *s : batch) s->status.store(st == MSI_OK ? 0 : st, std::memory_order_release);
+    if (st != MSI_OK)
+      for (VmSub *s : batch) s->status.store(st, std::memory_order_release);
     cur ^= 1;
   }
 }
@@ -651,7 +665,7 @@ void msi_vm_stats(msi_bits *pool, uint64_t *rounds, uint64_t *lists) {
   *lists = ctx->vm ? ctx->vm->lists.load() : 0;
 }
 
-void msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiCboBatch &batch, bool overwrite) {
+int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiCboBatch &batch, bool overwrite) {
   // payload: {n_cont, cs_off, bytes_off}, koff[n_chunks + 1] (containers bucketed by chunk = Roaring key), the
   // containers, the posting bytes, and the <= 7-document raw values as array containers built here
   const uint64_t n_words = msi_bits_words_per_slot(pool);
@@ -690,10 +704,12 @@ void msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiC
   h.cs_off = (uint32_t)align16(sizeof(DecodeHdr) + (size_t)(n_chunks + 1) * 4);
   h.bytes_off = (uint32_t)align16(h.cs_off + (size_t)n_cont * sizeof(MsiContainer));
   h._pad = 0;
-  const size_t at = align16(l.blob.size());
+  const size_t at = align16(l.stage_used);
   const size_t total = h.bytes_off + batch.bytes.size() + extra_bytes.size();
-  l.blob.resize(at + total, 0);
-  uint8_t *D = l.blob.data() + at;
+  uint8_t *stage = msi_bits_vm_stage(pool, at + total + 16, l.stage_used);
+  if (!stage) return MSI_E_OOM;
+  l.stage_used = at + total;
+  uint8_t *D = stage + at;
   memcpy(D, &h, sizeof(h));
   memcpy(D + sizeof(DecodeHdr), per.data(), (size_t)(n_chunks + 1) * 4);
   MsiContainer *cs = reinterpret_cast<MsiContainer *>(D + h.cs_off);
@@ -708,6 +724,7 @@ void msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiC
   l.words.push_back(dst);
   l.words.push_back(overwrite ? 1u : 0u);
   l.words.push_back((uint32_t)at);
+  return MSI_OK;
 }
 
 int32_t msi_vm_run(msi_bits *pool, const MsiVmList &l, MsiVmResult *res) {

@@ -21,6 +21,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <random>
 #include <string>
 #include <thread>
@@ -79,7 +80,7 @@ struct Index {
   uint64_t n_docs;
   std::vector<std::string> words;                 // sorted
   std::map<std::string, uint32_t> rank;           // frequency rank
-  std::mutex mu;
+  std::shared_mutex mu;   // lookups of warm keys (all of them, after the warm-up pass) share the lock
   std::map<std::string, std::shared_ptr<std::vector<uint32_t>>> ids;
   std::map<std::string, std::shared_ptr<Bytes>> blobs;
   static constexpr uint32_t N_POS = 20;
@@ -87,7 +88,7 @@ struct Index {
 
   std::shared_ptr<std::vector<uint32_t>> posting(const std::string &w) {
     {
-      std::lock_guard<std::mutex> lk(mu);
+      std::shared_lock<std::shared_mutex> lk(mu);
       auto it = ids.find(w);
       if (it != ids.end()) return it->second;
     }
@@ -102,18 +103,18 @@ struct Index {
       std::sort(v->begin(), v->end());
       v->erase(std::unique(v->begin(), v->end()), v->end());
     }
-    std::lock_guard<std::mutex> lk(mu);
+    std::unique_lock<std::shared_mutex> lk(mu);
     return ids.emplace(w, v).first->second;
   }
   template <typename F>
   const Bytes *blob(const std::string &key, F make) {
     {
-      std::lock_guard<std::mutex> lk(mu);
+      std::shared_lock<std::shared_mutex> lk(mu);
       auto it = blobs.find(key);
       if (it != blobs.end()) return it->second->empty() ? nullptr : it->second.get();
     }
     auto b = std::make_shared<Bytes>(cbo_serialize(make()));
-    std::lock_guard<std::mutex> lk(mu);
+    std::unique_lock<std::shared_mutex> lk(mu);
     auto it = blobs.emplace(key, b).first;
     return it->second->empty() ? nullptr : it->second.get();
   }
