@@ -283,6 +283,18 @@ int32_t msi_dict_lookup_device(msi_dict *dict, const uint8_t *d_qbytes,
                                uint32_t *d_out_one_idx, uint32_t *d_out_one_cnt,
                                uint32_t *d_out_two_idx, uint32_t *d_out_two_cnt);
 
+/* HBM posting cache of one index version (owned by its dictionary handle: both are re-staged when Index::updated_at
+ * moves, so the cache can never serve a stale posting).  msi_keyword_search_ranked decodes the stored
+ * CboRoaringBitmap values of word_docids / word_fid_docids / word_position_docids / word_pair_proximity_docids /
+ * field_id_word_count_docids and the word-prefix databases on the device; with the cache enabled, the first search
+ * that reads a key leaves its bytes in HBM (`capacity_bytes` of device memory, allocated here; when it is full new
+ * keys are simply not cached) and every later search decodes that key from HBM — no host copy, no PCIe transfer.
+ * The role LMDB's page cache + DatabaseCache (search/new/db_cache.rs) play for the reference.
+ * Keys are 128-bit hashes of (database, key); the value length is checked as well.
+ * stats: [hits, misses, bytes used, capacity]. */
+int32_t msi_dict_enable_posting_cache(msi_dict *dict, uint64_t capacity_bytes);
+int32_t msi_dict_posting_cache_stats(msi_dict *dict, uint64_t out[4]);
+
 typedef struct msi_dict_stats {
   uint64_t lookup_launches;
   uint64_t pairs_scanned;   /* (query, word) pairs that reached a kernel lane */
@@ -744,6 +756,12 @@ int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, const msi_inde
  * :103-121: Typo -> (max_typo_count + 1 - typo_count, max_typo_count + 1), ExactWords -> (matching + 1, max + 1),
  * ExactAttribute -> (a, 3)): the keyword score value msi_hybrid_merge weighs against the semantic one. */
 double msi_score_details_global_score(const msi_score_detail *details, uint32_t n);
+
+/* Diagnostics of the command-list combiner of the pool's context (msi_keyword_search_ranked records its set operations
+ * and submits them as lists; the lists of all searches waiting at that moment share one kernel launch): [rounds launched,
+ * lists executed, then nanoseconds summed over lists: queued before the combiner took the list, packing, (per round)
+ * inside the HIP launch calls, from the launch calls until the caller saw its result]. */
+int32_t msi_bits_vm_stats(msi_bits *pool, uint64_t out[6]);
 
 /* Diagnostics: counters of the last msi_keyword_search_ranked on the calling thread —
  * [kernel launches, stream syncs, decode batches, index callbacks, posting bytes decoded, matching paths,

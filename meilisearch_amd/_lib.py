@@ -195,12 +195,15 @@ PROTOTYPES = {
     "msi_dict_search_values": (_I32, [_VP, _VP, _U32, _U32, _U32, _VP, C.POINTER(_U32), C.POINTER(_I32)]),
     "msi_dict_set_microbatch": (_I32, [_VP, _U32, _U32]),
     "msi_dict_microbatch_stats": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_U64)]),
+    "msi_dict_enable_posting_cache": (_I32, [_VP, _U64]),
+    "msi_dict_posting_cache_stats": (_I32, [_VP, C.POINTER(_U64)]),
     "msi_dict_lookup_device": (_I32, [_VP, _VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "msi_dict_get_stats": (_I32, [_VP, C.POINTER(DictStats)]),
     "msi_dict_match_time": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_F64)]),
     "msi_bits_create": (_I32, [_VP, _U64, _U32, C.POINTER(_VP)]),
     "msi_bits_destroy": (None, [_VP]),
     "msi_bits_use_private_stream": (_I32, [_VP]),
+    "msi_bits_vm_stats": (_I32, [_VP, C.POINTER(_U64)]),
     "msi_bits_set_from_docids": (_I32, [_VP, _U32, _VP, _U64]),
     "msi_bits_set_from_docid_lists_device": (_I32, [_VP, _U32, _U32, _VP, _U32, _VP, _U32]),
     "msi_bits_set_from_cbo": (_I32, [_VP, _U32, _VP, C.c_size_t]),

@@ -1227,7 +1227,7 @@ int32_t msi_bits_set_from_words(msi_bits *p, uint32_t slot, const uint64_t *word
 // otherwise the portable Roaring serialisation (cookies 12346 / 12347), whose
 // containers are appended to the batch with offsets into the batch buffer.
 // Returns false on a malformed value.
-bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len) {
+bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len, uint64_t cache_src, uint64_t cache_fill) {
   const size_t THRESHOLD = 7;  // cbo_roaring_bitmap_codec.rs:15
   if (len <= THRESHOLD * sizeof(uint32_t)) {
     // a trailing partial integer is ignored (read_u32 fails)
@@ -1259,7 +1259,11 @@ bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len) 
     return false;
   }
   if (n_cont > 65536 || pos + (size_t)n_cont * 4 > len) return false;
-  const size_t base = batch.bytes.size();
+  // every serialisation starts 16-byte aligned, in the staging buffer as in the posting cache: a body then has the
+  // same alignment skew in both, and the cache is filled with whole 16-byte blocks
+  const bool cached = cache_src != MSI_NO_CACHE;
+  if (!cached) batch.bytes.resize((batch.bytes.size() + 15) & ~(size_t)15, 0);
+  const size_t base = cached ? 0 : batch.bytes.size();
   const size_t first = batch.containers.size();
   batch.containers.resize(first + n_cont);
   MsiContainer *cs = batch.containers.data() + first;
@@ -1289,7 +1293,16 @@ bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len) 
     batch.containers.resize(first);
     return false;
   }
-  batch.bytes.insert(batch.bytes.end(), bytes, bytes + len);
+  if (cached || cache_fill != MSI_NO_CACHE || !batch.src.empty()) {
+    batch.src.resize(first + n_cont, MSI_NO_CACHE);
+    batch.fill.resize(first + n_cont, MSI_NO_CACHE);
+    for (uint32_t i = 0; i < n_cont; ++i) {
+      const uint64_t rel = cs[i].offset - base;   // of the body inside its serialisation
+      if (cached) batch.src[first + i] = cache_src + rel;
+      else if (cache_fill != MSI_NO_CACHE) batch.fill[first + i] = cache_fill + rel;
+    }
+  }
+  if (!cached) batch.bytes.insert(batch.bytes.end(), bytes, bytes + len);
   return true;
 }
 

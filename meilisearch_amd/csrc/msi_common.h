@@ -152,13 +152,21 @@ struct MsiContainer {
   uint32_t card;    // array: #values, run: #runs
   uint32_t offset;  // byte offset of the body inside the staged buffer
 };
+constexpr uint64_t MSI_NO_CACHE = ~0ull;
 struct MsiCboBatch {
-  std::vector<uint8_t> bytes;            // concatenated Roaring serialisations
+  std::vector<uint8_t> bytes;            // concatenated Roaring serialisations (each starts 16-byte aligned)
   std::vector<MsiContainer> containers;  // their containers, offsets into `bytes`
   std::vector<uint32_t> small_ids;       // documents of the <= 7-integer raw values
+  // HBM posting cache (msi_vm.h), per container, empty when the batch never touched the cache:
+  //   src[i]  != MSI_NO_CACHE: the body is read from the cache at this byte offset (its bytes are NOT in `bytes`);
+  //   fill[i] != MSI_NO_CACHE: the workgroup that decodes the body also stores it into the cache at this offset.
+  std::vector<uint64_t> src, fill;
+  std::vector<void *> fill_tokens;       // the cache entries this batch fills (msi_pcache_commit once its decode has run)
 };
 struct msi_bits;
-bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len);
+// cache_src / cache_fill: byte offset of the WHOLE serialisation inside the posting cache (MSI_NO_CACHE: none).
+bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len, uint64_t cache_src = MSI_NO_CACHE,
+                          uint64_t cache_fill = MSI_NO_CACHE);
 uint64_t msi_cbo_cardinality(const uint8_t *bytes, size_t len);
 int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &batch, bool clear);
 // Fused set steps of the path search (msi_search.hip), one launch each:

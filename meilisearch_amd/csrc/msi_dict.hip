@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "msi_common.h"
+#include "msi_vm.h"
 
 typedef unsigned long long u64;
 
@@ -663,9 +664,11 @@ struct msi_dict {
   uint32_t microbatch_wait_us = 0, microbatch_target = 256;
   uint64_t fused_calls = 0, fused_launches = 0;
   bool values_mode = false;  // msi_dict_create_values: every word carries the sentinel first byte
+  MsiPostingCache *pcache = nullptr;   // HBM cache of the index version's stored postings (msi_dict_enable_posting_cache)
 };
 
-// accessors for msi_keyword.hip
+// accessors for msi_keyword.hip / msi_search.hip
+MsiPostingCache *msi_dict_pcache(const msi_dict *d) { return d ? d->pcache : nullptr; }
 bool msi_dict_word(const msi_dict *d, uint32_t idx, const uint8_t **w, uint32_t *len) {
   if (!d || idx >= d->n_words) return false;
   *w = d->h_flat.data() + d->h_offs[idx];
@@ -866,6 +869,8 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
 void msi_dict_destroy(msi_dict *d) {
   if (!d) return;
   msi_ctx *ctx = d->ctx;
+  if (d->pcache) msi_pcache_destroy(d->pcache);
+  d->pcache = nullptr;
   {
   std::lock_guard<std::mutex> lk(ctx->mu_aux);
   DeviceGuard g(ctx->device);
@@ -881,6 +886,21 @@ void msi_dict_destroy(msi_dict *d) {
 }
 
 uint32_t msi_dict_len(const msi_dict *d) { return d ? d->n_words : 0; }
+
+int32_t msi_dict_enable_posting_cache(msi_dict *d, uint64_t capacity_bytes) {
+  if (!d) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(d->bmu);
+  if (d->pcache) return MSI_OK;
+  d->pcache = msi_pcache_create(d->ctx, capacity_bytes);
+  return d->pcache ? MSI_OK : MSI_E_OOM;
+}
+
+int32_t msi_dict_posting_cache_stats(msi_dict *d, uint64_t out[4]) {
+  if (!d || !out) return MSI_E_INVALID;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (d->pcache) msi_pcache_stats(d->pcache, out);
+  return MSI_OK;
+}
 
 int32_t msi_dict_lookup_device(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_qoff, const uint8_t *d_qflags,
                                uint32_t n, uint32_t cap_one, uint32_t cap_two, uint32_t *d_out_one_idx,

@@ -40,6 +40,7 @@
 #include "msi_vm.h"
 int32_t msi_bits_sync(msi_bits *p);
 const uint32_t *msi_doc_keys_device(const msi_doc_keys *k);
+MsiPostingCache *msi_dict_pcache(const msi_dict *d);
 #endif
 
 struct msi_dict;
@@ -81,14 +82,20 @@ struct SetPool {
   msi_bits *p;
   std::vector<uint32_t> free_;
   std::vector<uint32_t> clean_;  // free slots that are known to be all zero
-  SetPool(msi_bits *p_, uint32_t first) : p(p_) {
+  // command-list back end: a slot handed out as "all zero" is only zeroed when something READS it (most are first
+  // written whole — the bucket of a cost level, a decode — or never used at all)
+  std::vector<uint8_t> lazy_zero;
+  SetPool(msi_bits *p_, uint32_t first) : p(p_), lazy_zero(msi_bits_n_slots(p_), 0) {
     for (uint32_t s = msi_bits_n_slots(p_); s-- > first;) free_.push_back(s);
   }
 };
 struct SetH {
   SetPool *pool;
   uint32_t slot;
-  ~SetH() { pool->free_.push_back(slot); }
+  ~SetH() {
+    pool->lazy_zero[slot] = 0;
+    pool->free_.push_back(slot);
+  }
 };
 using Set = std::shared_ptr<SetH>;
 
@@ -104,6 +111,23 @@ struct Dev {
   bool vm = true;
   MsiVmList list;
   MsiVmResult res;
+  MsiPostingCache *pcache = nullptr;   // HBM posting cache of the index version (msi_dict_enable_posting_cache), or none
+  std::vector<void *> fills;           // cache entries the RECORDED decodes fill: ready once the list has run
+  // A stored posting value joins a decode batch: from the cache when another search left it there, else from the
+  // bytes the callback handed over (and, when there is room, into the cache on the way).
+  bool append_posting(MsiCboBatch &b, const MsiCacheKey &k, const uint8_t *bytes, size_t n) {
+    if (!vm || !pcache || n <= 7 * sizeof(uint32_t)) return msi_cbo_batch_append(b, bytes, n);
+    uint64_t off = 0;
+    void *token = nullptr;
+    const int r = msi_pcache_lookup(pcache, k, n, &off, &token);
+    if (r == 1) return msi_cbo_batch_append(b, bytes, n, off, MSI_NO_CACHE);
+    if (r == 2) {
+      if (!msi_cbo_batch_append(b, bytes, n, MSI_NO_CACHE, off)) return false;
+      b.fill_tokens.push_back(token);   // committed when the batch's decode has run (a batch that is dropped leaves
+      return true;                      // its entries reserved and unfilled: never served)
+    }
+    return msi_cbo_batch_append(b, bytes, n);
+  }
 #else
   static constexpr bool vm = false;
 #endif
@@ -119,19 +143,35 @@ struct Dev {
     list.begin();
     list.words.insert(list.words.end(), w.begin(), w.end());
   }
+  // the slot is about to be READ: a lazily zeroed slot is zeroed now
+  void rd(uint32_t slot) {
+    if (!pool.lazy_zero[slot]) return;
+    pool.lazy_zero[slot] = 0;
+    rec({VM_CLEAR, 1u, slot});
+  }
+  // the slot is about to be overwritten whole
+  void wr(uint32_t slot) { pool.lazy_zero[slot] = 0; }
   // submit what was recorded and wait for it: the only blocking point of the command-list back end
   void run() {
     if (list.empty()) return;
     Clock ck_;
     ++g_stats.launches;
     ++g_stats.syncs;
+    list.cache_base = msi_pcache_device_base(pcache);
     const int32_t st = msi_vm_run(pool.p, list, &res);
     g_stats.device_wait_ms += ck_.ms();
     list.clear();
+    if (st == MSI_OK)
+      for (void *t : fills) msi_pcache_commit(pcache, t);
+    fills.clear();
     ck(st);
   }
   // direct calls (GeoSort, distinct) see everything recorded so far
-  void settle() { if (vm) run(); }
+  void settle() {
+    if (!vm) return;
+    for (uint32_t sl = 0; sl < pool.lazy_zero.size(); ++sl) rd(sl);
+    run();
+  }
   uint32_t counts_for(uint32_t n) {   // room for n more cardinalities in this list (else it runs first)
     if (list.n_counts + n > MSI_VM_MAX_COUNTS) run();
     return list.new_counts(n);
@@ -152,14 +192,22 @@ struct Dev {
   }
   void op(uint32_t d, uint32_t a, uint32_t b, int32_t o) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
-    if (vm) return rec({VM_OP, d, a, b, (uint32_t)o});
+    if (vm) {
+      rd(a);
+      rd(b);
+      wr(d);
+      return rec({VM_OP, d, a, b, (uint32_t)o});
+    }
 #endif
     ++g_stats.launches;
     ck(msi_bits_op(pool.p, d, a, b, o));
   }
   void fill(uint32_t d, int ones) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
-    if (vm) return rec({VM_FILL, d, ones ? 1u : 0u});
+    if (vm) {
+      wr(d);
+      return rec({VM_FILL, d, ones ? 1u : 0u});
+    }
 #endif
     ++g_stats.launches;
     ck(msi_bits_fill(pool.p, d, ones));
@@ -167,6 +215,13 @@ struct Dev {
   // Zeroed slots are handed out from a stock that one operation refills MSI_BITS_CLEAR_MAX at a time
   // (instead of one memset per set: a third of the launches of a search were clears).
   Set zeros() {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      Set s = alloc();
+      pool.lazy_zero[s->slot] = 1;
+      return s;
+    }
+#endif
     if (pool.clean_.empty()) {
       uint32_t batch[MSI_BITS_CLEAR_MAX];
       uint32_t n = 0;
@@ -210,6 +265,8 @@ struct Dev {
 #ifndef MSI_SEARCH_DIRECT_ONLY
       if (vm) {
         const uint32_t c = counts_for(1);
+        rd(a->slot);
+        rd(b->slot);
         rec({VM_OP_COUNT, s->slot, a->slot, b->slot, (uint32_t)MSI_BITS_AND, c});
         run();
         *count = res.counts[c];
@@ -234,6 +291,8 @@ struct Dev {
       for (size_t base = 0; base < conds.size(); base += 256) {
         const uint32_t n = (uint32_t)std::min<size_t>(256, conds.size() - base);
         const uint32_t cb = counts_for(n);
+        rd(prefix->slot);
+        for (uint32_t k = 0; k < n; ++k) rd(conds[base + k]->slot);
         rec({VM_AND_MANY, prefix->slot, n, cb});
         for (uint32_t k = 0; k < n; ++k) {
           Set d = alloc();
@@ -272,7 +331,13 @@ struct Dev {
     const uint32_t cb = counts_for(n);
     uint32_t n_steps = 0;
     for (auto &p : paths) n_steps += (uint32_t)p.size();
-    rec({VM_PATHS, n, bucket->slot, universe->slot, cb, n_steps});
+    rd(universe->slot);
+    for (auto &p : paths)
+      for (auto &s_ : p) rd(s_->slot);
+    // a bucket that was handed out as "all zero" and never touched is written whole by the level: no clear at all
+    const uint32_t fresh = pool.lazy_zero[bucket->slot] ? 1u : 0u;
+    wr(bucket->slot);
+    rec({VM_PATHS, n, bucket->slot, universe->slot, cb, n_steps | (fresh << 31)});
     uint32_t o = 0;
     list.words.push_back(0);
     for (auto &p : paths) {
@@ -316,6 +381,8 @@ struct Dev {
       const uint64_t kp = (uint64_t)(uintptr_t)msi_doc_keys_device(keys);
       const uint32_t c = counts_for(2);
       if (list.phase_start.size() + 1 > MSI_VM_MAX_PHASES) run();
+      rd(universe->slot);
+      wr(b->slot);
       rec({VM_MINKEY, universe->slot, (uint32_t)kp, (uint32_t)(kp >> 32), 0});
       list.barrier();   // every chunk has contributed its minimum before any chunk takes
       rec({VM_TAKEKEY, universe->slot, b->slot, (uint32_t)kp, (uint32_t)(kp >> 32), 0, c, c + 1});
@@ -385,6 +452,8 @@ struct Dev {
       for (size_t base = 0; base < sets.size(); base += 512) {
         const uint32_t n = (uint32_t)std::min<size_t>(512, sets.size() - base);
         const uint32_t cb = counts_for(n);
+        rd(removed->slot);
+        for (uint32_t k = 0; k < n; ++k) rd(sets[base + k]->slot);
         rec({VM_SUB_MANY, removed->slot, n, cb});
         for (uint32_t k = 0; k < n; ++k) list.words.push_back(sets[base + k]->slot);
         run();
@@ -466,6 +535,10 @@ struct Dev {
   void claim(const Set &docs, const Set &bucket, const Set &universe, const std::vector<Set> &stack) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
+      rd(docs->slot);
+      rd(bucket->slot);
+      rd(universe->slot);
+      for (auto &s_ : stack) rd(s_->slot);
       rec({VM_CLAIM, docs->slot, bucket->slot, universe->slot, (uint32_t)stack.size()});
       for (auto &s_ : stack) list.words.push_back(s_->slot);
       return;
@@ -482,6 +555,7 @@ struct Dev {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       const uint32_t ci = counts_for(1);
+      rd(a->slot);
       rec({VM_COUNT, a->slot, ci});
       run();
       return res.counts[ci];
@@ -501,7 +575,9 @@ struct Dev {
       Set s = alloc();   // overwritten chunk by chunk: no zeroed slot needed
       ++g_stats.decodes;
       g_stats.postings_bytes += b.bytes.size() + 4 * b.small_ids.size();
+      wr(s->slot);
       ck(msi_vm_record_decode(list, pool.p, s->slot, b, true));
+      fills.insert(fills.end(), b.fill_tokens.begin(), b.fill_tokens.end());
       return s;
     }
 #endif
@@ -521,6 +597,7 @@ struct Dev {
     if (vm && k <= MSI_VM_MAX_FIRSTK) {
       if (k == 0) return {};
       const uint32_t ci = counts_for(1);
+      rd(a->slot);
       rec({VM_FIRSTK, a->slot, k, ci});
       list.wants_firstk = true;
       run();
@@ -657,7 +734,11 @@ struct Ctx {
   }
 
   Ctx(msi_dict *d, msi_bits *pool, const msi_index_vtable *i, const msi_search_params *p)
-      : dict(d), ix(i), prm(p), dev(pool) {}
+      : dict(d), ix(i), prm(p), dev(pool) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (dev.vm) dev.pcache = msi_dict_pcache(d);
+#endif
+  }
 
   uint32_t word(const std::string &w) {
     auto it = word_ids.find(w);
@@ -673,12 +754,22 @@ struct Ctx {
   }
 
   // -- the index reads (postings arrive as stored bytes and go straight into a decode batch) -----
-  void take(MsiCboBatch &b, int32_t st, const uint8_t *bytes, size_t n, const char *what) {
+  // db: which database the value came from; (s1, s2, x, y): its key there — together the posting-cache key
+  void take(MsiCboBatch &b, int32_t st, const uint8_t *bytes, size_t n, const char *what, uint32_t db,
+            const std::string &s1, const std::string &s2, uint64_t x, uint64_t y) {
     if (st < 0) {
       msi_set_error("msi_keyword_search_ranked: %s callback failed (%d)", what, st);
       throw Fail{MSI_E_INTERNAL};
     }
-    if (n && bytes && !msi_cbo_batch_append(b, bytes, n)) {
+    if (!n || !bytes) return;
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    const bool ok = dev.pcache ? dev.append_posting(b, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y), bytes, n)
+                               : msi_cbo_batch_append(b, bytes, n);
+#else
+    (void)db; (void)s1; (void)s2; (void)x; (void)y;
+    const bool ok = msi_cbo_batch_append(b, bytes, n);
+#endif
+    if (!ok) {
       msi_set_error("msi_keyword_search_ranked: malformed posting list from %s", what);
       throw Fail{MSI_E_INVALID};
     }
@@ -696,7 +787,16 @@ struct Ctx {
     size_t n = 0;
     Cb cb_;
     const int32_t st = ix->word_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), original ? 1 : 0, &bytes, &n);
-    take(b, st, bytes, n, "word_docids");
+    take(b, st, bytes, n, "word_docids", 1, s, std::string(), original ? 1 : 0, 0);
+    return n != 0;
+  }
+  bool contains_word(uint32_t w) {   // Index::contains_word: the key exists; nothing is decoded
+    const std::string &s = words[w];
+    const uint8_t *bytes = nullptr;
+    size_t n = 0;
+    Cb cb_;
+    const int32_t st = ix->word_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), 1, &bytes, &n);
+    if (st < 0) fail(MSI_E_INTERNAL, "word_docids callback failed");
     return n != 0;
   }
   uint64_t add_pair(MsiCboBatch *b, uint32_t prox, uint32_t w1, uint32_t w2) {  // returns the cardinality
@@ -710,7 +810,7 @@ struct Ctx {
     if (st < 0) fail(MSI_E_INTERNAL, "word_pair_proximity_docids callback failed");
     if (!n || !bytes) return 0;
     const uint64_t card = msi_cbo_cardinality(bytes, n);
-    if (b) take(*b, st, bytes, n, "word_pair_proximity_docids");
+    if (b) take(*b, st, bytes, n, "word_pair_proximity_docids", 2, l, r, prox, 0);
     return card;
   }
   void add_word_fid(MsiCboBatch &b, uint32_t w, uint32_t fid) {
@@ -721,7 +821,7 @@ struct Ctx {
     Cb cb_;
     // the call first: `bytes` / `n` as further arguments of the same call would be read in an unspecified order
     const int32_t st = ix->word_fid_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), fid, &bytes, &n);
-    take(b, st, bytes, n, "word_fid_docids");
+    take(b, st, bytes, n, "word_fid_docids", 3, s, std::string(), fid, 0);
   }
   void add_word_position(MsiCboBatch &b, uint32_t w, uint32_t pos) {
     if (!ix->word_position_docids)
@@ -731,17 +831,33 @@ struct Ctx {
     size_t n = 0;
     Cb cb_;
     const int32_t st = ix->word_position_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), pos, &bytes, &n);
-    take(b, st, bytes, n, "word_position_docids");
+    take(b, st, bytes, n, "word_position_docids", 4, s, std::string(), pos, 0);
   }
   // sink of the word-prefix callbacks: every stored value goes straight into the decode batch
   struct Sink {
     Ctx *c;
     MsiCboBatch *b;
     bool bad = false;
+    // posting-cache key of the i-th value the callback pushes: (db, s1, s2, x, i)
+    uint32_t db = 0;
+    const std::string *s1 = nullptr, *s2 = nullptr;
+    uint64_t x = 0, i = 0;
   };
   static int32_t sink_push(void *sink, const uint8_t *bytes, size_t n) {
     Sink *s = (Sink *)sink;
-    if (n && bytes && s->b && !msi_cbo_batch_append(*s->b, bytes, n)) {
+    const uint64_t i = s->i++;
+    if (!n || !bytes || !s->b) return 0;
+    bool ok;
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    static const std::string none;
+    if (s->c->dev.pcache && s->db) {
+      const std::string &a = s->s1 ? *s->s1 : none, &b2 = s->s2 ? *s->s2 : none;
+      ok = s->c->dev.append_posting(*s->b, msi_cache_key(s->db, a.data(), a.size(), b2.data(), b2.size(), s->x, i), bytes, n);
+    } else
+#endif
+      ok = msi_cbo_batch_append(*s->b, bytes, n);
+    (void)i;
+    if (!ok) {
       s->bad = true;
       return -1;
     }
@@ -758,6 +874,8 @@ struct Ctx {
     if (!ix->word_prefix_docids) return 0;
     const std::string &s = words[w];
     Sink sk{this, b};
+    sk.db = original ? 6 : 7;
+    sk.s1 = &s;
     Cb cb_;
     return finish(sk, ix->word_prefix_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), original ? 1 : 0,
                                              sink_push, &sk), "word_prefix_docids");
@@ -767,6 +885,9 @@ struct Ctx {
     if (!fn) fail(MSI_E_INVALID, "the index vtable has word_prefix_docids but not word_prefix_fid/position_docids");
     const std::string &s = words[w];
     Sink sk{this, &b};
+    sk.db = which == 0 ? 8 : 9;
+    sk.s1 = &s;
+    sk.x = key;
     Cb cb_;
     finish(sk, fn(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), key, sink_push, &sk), "word_prefix_*_docids");
   }
@@ -775,6 +896,10 @@ struct Ctx {
       fail(MSI_E_INVALID, "the index vtable has word_prefix_docids but not word_prefix_pair_proximity_docids");
     const std::string &l = words[w1], &r = words[prefix2];
     Sink sk{this, &b};
+    sk.db = 10;
+    sk.s1 = &l;
+    sk.s2 = &r;
+    sk.x = prox;
     Cb cb_;
     finish(sk, ix->word_prefix_pair_proximity_docids(ix->user, prox, (const uint8_t *)l.data(), (uint32_t)l.size(),
                                                       (const uint8_t *)r.data(), (uint32_t)r.size(), sink_push, &sk),
@@ -843,8 +968,7 @@ struct Ctx {
     }
     t.max_lev = max_typo;
     t.is_prefix = is_prefix;
-    MsiCboBatch probe;
-    if (add_word(probe, t.original, true)) t.exact = (int32_t)t.original;  // Index::contains_word
+    if (contains_word(t.original)) t.exact = (int32_t)t.original;  // Index::contains_word
     {  // synonyms of the word: at most 50 phrases and 100 words in total (:217-236)
       uint32_t n_words = 0, n_phr = 0;
       for (Phrase &syn : synonyms_of({t.original})) {
@@ -1747,8 +1871,10 @@ struct GraphRule : Rule {
   // score threshold see the same universe as without the look-ahead.  Fills `ready` or leaves it empty (a level
   // that does not fit the in-argument kernel: the caller runs the one-level path).
   void look_ahead(std::vector<uint64_t>::const_iterator it, std::vector<uint64_t>::const_iterator end) {
+    // with command lists a level evaluated ahead is one more command in a list that is submitted anyway, so the
+    // look-ahead is on by default there (waits per 3-term query 76 -> 41); the direct back end pays a launch per level
     const char *knob = getenv("MSI_SEARCH_LEVELS_PER_WAIT");
-    const int per_wait = std::min<int>(knob ? atoi(knob) : 1, (int)MSI_BITS_PATH_REGIONS);
+    const int per_wait = std::min<int>(knob ? atoi(knob) : (cx->dev.vm ? 4 : 1), (int)MSI_BITS_PATH_REGIONS);
     const char *fused = getenv("MSI_SEARCH_FUSED_LEVELS");
     if (per_wait < 2 || (fused && fused[0] == '0')) return;
     // `distinct` removes documents from every universe of the stack whenever a bucket reaches the results
@@ -2027,7 +2153,7 @@ struct ExactAttributeRule : Rule {
           const uint8_t *bytes = nullptr;
           size_t n = 0;
           const int32_t st = c.ix->field_id_word_count_docids(c.ix->user, fid, count_all, &bytes, &n);
-          c.take(wc, st, bytes, n, "field_id_word_count_docids");
+          c.take(wc, st, bytes, n, "field_id_word_count_docids", 5, std::string(), std::string(), fid, count_all);
         }
         Set W = c.dev.decode(wc);
         Set both = c.dev.and_new(S, W, nullptr);

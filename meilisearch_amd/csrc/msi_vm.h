@@ -29,7 +29,7 @@ enum : uint32_t {
   VM_PATHS,      // n_paths, bucket, universe, cnt_base, n_steps, off[n_paths + 1], step slot...
   VM_SUB_MANY,   // removed, n, cnt_base, slot...
   VM_COUNT,      // slot, cnt
-  VM_DECODE,     // dst, overwrite, staging byte offset of {header, koff[n_chunks + 1], containers, bytes}
+  VM_DECODE,     // dst, overwrite, index of the decode among the list's decodes
   VM_FIRSTK,     // slot, k, cnt (the set's cardinality comes back too); at most one per list, in its last phase
   VM_MINKEY,     // universe, keys lo, keys hi, cell
   VM_TAKEKEY,    // universe, bucket, keys lo, keys hi, cell, cnt, key result index
@@ -47,6 +47,15 @@ struct MsiVmList {
   // kernel over PCIe (wide aligned loads, each posting byte exactly once) — no copy on the combiner thread, no DMA
   // call per list.  `stage_used` bytes of msi_bits_vm_stage(pool) belong to this list.
   size_t stage_used = 0;
+  // descriptors of the decode commands (chunk-bucketed while recording; laid out chunk-major behind the commands when
+  // the list is submitted): start[c] .. start[c+1] = the containers of chunk c, two u64 per container
+  struct Decode {
+    std::vector<uint32_t> start;
+    std::vector<uint64_t> c;
+  };
+  std::vector<Decode> decodes;
+  uint32_t data_off = 0;                // word offset of the descriptor block inside `words` once finalised (0: none)
+  uint64_t cache_base = 0;              // device address of the posting cache the decode commands refer to (0: none)
   uint32_t n_counts = 0;
   bool wants_firstk = false;
   bool empty() const { return words.empty(); }
@@ -54,6 +63,9 @@ struct MsiVmList {
     words.clear();
     phase_start.clear();
     stage_used = 0;
+    cache_base = 0;
+    decodes.clear();
+    data_off = 0;
     n_counts = 0;
     wants_firstk = false;
   }
@@ -77,10 +89,33 @@ struct MsiVmResult {
 
 // Appends a VM_DECODE of `batch` into `dst` (overwrite = the slot's previous content is discarded).
 int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiCboBatch &batch, bool overwrite);
-// Runs the list on the pool's context (blocks until its results are published); the list is left untouched.
-int32_t msi_vm_run(msi_bits *pool, const MsiVmList &l, MsiVmResult *res);
-// Combiner statistics of the context the pool lives on: rounds launched, lists executed.
-void msi_vm_stats(msi_bits *pool, uint64_t *rounds, uint64_t *lists);
+// Runs the list on the pool's context (blocks until its results are published).  Appends the decode descriptors to
+// l.words (once): clear() the list before recording again.
+int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res);
+// Combiner statistics of the context the pool lives on: rounds launched, lists executed, then nanoseconds summed over
+// lists: queued, packed, (per round) in the launch calls, from the launch calls until the waiter saw its result.
+void msi_vm_stats(msi_bits *pool, uint64_t out[6]);
 
 struct msi_vm;
 void msi_vm_destroy(msi_vm *vm);
+
+// ---- HBM posting cache --------------------------------------------------------------------------------------------
+// The stored CboRoaringBitmap bytes of the postings a search reads (word_docids, word_fid_docids, word_position_docids,
+// word_pair_proximity_docids, ...), kept in HBM under a 128-bit hash of (database, key).  A search that reads a key
+// for the first time decodes it out of its pinned staging buffer (the bytes cross PCIe once) and the decoding
+// workgroups store the bodies into the cache on the way; every later search — any thread — decodes the same key
+// straight from HBM: no host copy, no PCIe.  Owned by the dictionary handle (one per index version: both are
+// re-staged when Index::updated_at moves), msi_dict_enable_posting_cache.
+struct MsiPostingCache;
+struct MsiCacheKey {
+  uint64_t a, b;
+};
+MsiCacheKey msi_cache_key(uint32_t db, const void *s1, size_t n1, const void *s2, size_t n2, uint64_t x, uint64_t y);
+MsiPostingCache *msi_pcache_create(msi_ctx *ctx, uint64_t capacity_bytes);
+void msi_pcache_destroy(MsiPostingCache *c);
+// -> 1: ready in the cache at *off (decode from there); 2: reserved at *off for THIS caller to fill (pass *token to
+// msi_pcache_commit once the list that fills it has run); 0: not cacheable now (being filled by someone else, or full)
+int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint64_t *off, void **token);
+void msi_pcache_commit(MsiPostingCache *c, void *token);
+uint64_t msi_pcache_device_base(const MsiPostingCache *c);
+void msi_pcache_stats(const MsiPostingCache *c, uint64_t out[4]);   // hits, misses, bytes used, capacity

@@ -13,12 +13,21 @@
 // list; the last workgroup of a list's last phase copies them into the search's pinned result block and stores the
 // sequence number with system-scope release — the search thread polls that word, no stream synchronisation.
 #include <string.h>
+#if defined(__linux__)
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
+#include <shared_mutex>
 #include <thread>
+#include <unordered_map>
 
 #include "msi_common.h"
 #include "msi_vm.h"
@@ -36,7 +45,8 @@ uint8_t *msi_bits_vm_stage(msi_bits *p, size_t need, size_t keep);   // pinned s
 
 namespace {
 
-constexpr int VT = 256;                 // threads per workgroup
+constexpr int VT = 256;                 // threads per workgroup (512 measured 30 % slower: r2 notes in DESIGN §4.7)
+constexpr int WPT = 1024 / VT;          // words of a chunk per thread in the ordered emit
 constexpr uint32_t CHW = 1024;          // u64 words per chunk (65 536 documents = one Roaring container span)
 constexpr uint32_t MAX_SUBS = 64;       // lists per round
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -46,18 +56,29 @@ constexpr size_t RES_IDS = RES_COUNTS + MSI_VM_MAX_COUNTS;     // u64 index wher
 struct alignas(16) RoundSub {
   u64 pool_base, n_words, n_docs, host_res, seq;
   u64 stage;                              // the pool's pinned staging buffer (decode payloads), device-visible
+  u64 cache;                              // device base of the HBM posting cache (0: none)
   uint32_t n_chunks, n_phases;
   uint32_t phase_off[MSI_VM_MAX_PHASES];  // arena word offsets of each phase's first command
   uint32_t list_off;                      // arena word offset of the list's words
-  uint32_t _pad0;
+  uint32_t data_off;                      // word offset, from list_off, of the chunk-major decode descriptors
   uint32_t state_off;                     // arena word offset of {done[4] u32, cells[4] u64, counts[n_counts] u64, chunk cardinalities[n_chunks] u32}
   uint32_t n_counts;
+  uint32_t n_decodes;
+  uint32_t _pad[3];
 };
 static_assert(sizeof(RoundSub) % 16 == 0, "RoundSub array stays 16-byte aligned");
 
-struct DecodeHdr {  // 16 bytes at the head of a decode payload, then koff[n_chunks + 1], containers, bytes
-  uint32_t n_cont, cs_off, bytes_off, _pad;
+// A container as the decode command reads it.  The descriptors of ALL the decode commands of a list travel with its
+// commands (arena, one bulk H2D copy per round) laid out CHUNK-MAJOR — for chunk c: how many containers each decode has
+// in c, then those containers back to back — so a workgroup reads its own, contiguous, device-resident block.  (With the
+// descriptors in the pinned staging buffer every workgroup paid three dependent PCIe reads per decode command: 90 k small
+// reads per 64-list round, 0.7 ms — r2_ranked_vm_trace_descriptor_reads_over_pcie.txt.)
+struct alignas(16) VmContainer {
+  uint32_t meta;       // card (16 bits, array: values, run: runs) | type << 16 | cached << 18
+  uint32_t fill_lo;    // low / high half of the posting-cache offset to store the body at; ~0 / ~0 = none
+  u64 src;             // byte offset of the body: in the posting cache (cached) or in the pool's pinned staging buffer
 };
+// high half of the fill offset rides in the upper bits of `meta` (bits 19..31: 13 bits -> 45-bit offsets)
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t c) {
 #pragma unroll
@@ -89,7 +110,15 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   __shared__ uint32_t s_scan[VT / 64 + 1];
   __shared__ uint32_t s_last;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const RoundSub r = reinterpret_cast<const RoundSub *>(arena + 16)[blockIdx.y];
+  // (fields are read one by one: a by-value copy of the struct lands in scratch because phase_off[] is indexed dynamically)
+  const RoundSub *const rp = reinterpret_cast<const RoundSub *>(arena + 16) + blockIdx.y;
+  struct {
+    u64 pool_base, n_words, n_docs, host_res, seq, stage, cache;
+    uint32_t n_chunks, n_phases, list_off, data_off, state_off, n_counts, n_decodes;
+  } r;
+  r.pool_base = rp->pool_base; r.n_words = rp->n_words; r.n_docs = rp->n_docs; r.host_res = rp->host_res; r.seq = rp->seq;
+  r.stage = rp->stage; r.cache = rp->cache; r.n_chunks = rp->n_chunks; r.n_phases = rp->n_phases; r.list_off = rp->list_off;
+  r.data_off = rp->data_off; r.state_off = rp->state_off; r.n_counts = rp->n_counts; r.n_decodes = rp->n_decodes;
   const uint32_t chunk = blockIdx.x;
   if (phase >= r.n_phases || chunk >= r.n_chunks) return;
   for (uint32_t i = tid; i < r.n_counts; i += VT) s_cnt[i] = 0;
@@ -102,8 +131,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   uint32_t *const state = arena + r.state_off;
   u64 *const cells = reinterpret_cast<u64 *>(state + 4);
   u64 *const counts = cells + MSI_VM_CELLS;
-  const uint8_t *const blob = reinterpret_cast<const uint8_t *>(r.stage);
-  const uint32_t *pc = arena + r.phase_off[phase];
+  const uint32_t *pc = arena + rp->phase_off[phase];
   uint32_t fk_cnt = NONE;
   uint32_t *const chunk_card = reinterpret_cast<uint32_t *>(counts + r.n_counts);   // first-k: cardinality of the set per chunk
   auto add_count = [&](uint32_t idx, uint32_t c) {
@@ -201,22 +229,40 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       case VM_PATHS: {  // the paths of one cost level in DFS order: a path claims what the earlier paths left
         const uint32_t n_paths = pc[1];
         ulonglong2 *bucket = S(pc[2]), *uni = S(pc[3]);
-        const uint32_t base = pc[4], n_steps = pc[5];
+        const uint32_t base = pc[4], n_steps = pc[5] & 0x7FFFFFFFu;
+        const bool fresh = (pc[5] >> 31) != 0;   // the bucket's previous content is garbage: this level writes it whole
         const uint32_t *off = pc + 6, *steps = off + n_paths + 1;
+        // Paths are resolved four at a time: the condition words of the four paths are loaded back to back (no load
+        // waits for the result of another), then the paths claim in order.  A serial "load, AND, test, next step" chain
+        // made a level of a few hundred steps cost hundreds of microseconds of pure memory latency per workgroup.
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           ulonglong2 u = uni[p];
-          if (!(u.x | u.y)) continue;
-          ulonglong2 b = bucket[p];
-          for (uint32_t k = 0; k < n_paths && (u.x | u.y); ++k) {
-            ulonglong2 m = u;
-            for (uint32_t s = off[k]; s < off[k + 1] && (m.x | m.y); ++s) {
-              const ulonglong2 c = S(steps[s])[p];
-              m.x &= c.x; m.y &= c.y;
+          if (!(u.x | u.y)) {
+            if (fresh) bucket[p] = make_ulonglong2(0, 0);
+            continue;
+          }
+          ulonglong2 b = fresh ? make_ulonglong2(0, 0) : bucket[p];
+          for (uint32_t k0 = 0; k0 < n_paths && (u.x | u.y); k0 += 4) {
+            ulonglong2 acc[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+              acc[j] = make_ulonglong2(~0ull, ~0ull);
+              if (k0 + j < n_paths)
+                for (uint32_t s = off[k0 + j]; s < off[k0 + j + 1]; ++s) {
+                  const ulonglong2 c = S(steps[s])[p];
+                  acc[j].x &= c.x; acc[j].y &= c.y;
+                }
             }
-            if (m.x | m.y) {
-              b.x |= m.x; b.y |= m.y;
-              u.x &= ~m.x; u.y &= ~m.y;
-              atomicAdd(&s_cnt[base + k], (uint32_t)(__popcll(m.x) + __popcll(m.y)));
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+              if (k0 + j >= n_paths) continue;
+              ulonglong2 m;
+              m.x = u.x & acc[j].x; m.y = u.y & acc[j].y;
+              if (m.x | m.y) {
+                b.x |= m.x; b.y |= m.y;
+                u.x &= ~m.x; u.y &= ~m.y;
+                atomicAdd(&s_cnt[base + k0 + j], (uint32_t)(__popcll(m.x) + __popcll(m.y)));
+              }
             }
           }
           bucket[p] = b;
@@ -264,40 +310,53 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       case VM_DECODE: {  // the containers of THIS chunk of every posting of the batch, OR-ed in LDS, written once
         ulonglong2 *d = S(pc[1]);
         const bool overwrite = pc[2] != 0;
-        const uint8_t *D = blob + pc[3];
-        const DecodeHdr h = *reinterpret_cast<const DecodeHdr *>(D);
-        const uint32_t *koff = reinterpret_cast<const uint32_t *>(D + sizeof(DecodeHdr));
-        const MsiContainer *cs = reinterpret_cast<const MsiContainer *>(D + h.cs_off);
-        const uint8_t *bytes = D + h.bytes_off;
-        const uint32_t k0 = koff[chunk], k1 = koff[chunk + 1];
-        if (k1 > k0) {
+        const uint32_t di = pc[3];                       // index of this decode among the list's decodes
+        // chunk-major descriptor block of this workgroup (device memory): counts per decode, then the containers
+        const uint32_t *data = arena + r.list_off + r.data_off;
+        const uint32_t *blk_c = data + 4 * (size_t)data[chunk];          // chunk_off[] is in 16-byte units
+        const uint32_t c_first = blk_c[di], n_here = blk_c[di + 1] - c_first;   // start[] of this chunk: n_decodes + 1 entries
+        const VmContainer *cs = reinterpret_cast<const VmContainer *>(blk_c + ((r.n_decodes + 1 + 3) & ~3u)) + c_first;
+        if (n_here) {
           __syncthreads();
           for (uint32_t i = tid; i < CHW; i += VT) s_dec[i] = 0;
           __syncthreads();
-          for (uint32_t ci = k0; ci < k1; ++ci) {
-            const MsiContainer c = cs[ci];
-            // the body crosses PCIe once, as 16-byte aligned loads (any body alignment), and is decoded from LDS
-            const uint32_t len = c.type == 0 ? 2 * c.card : (c.type == 1 ? 8192u : 4 * c.card);
-            const uintptr_t b0 = reinterpret_cast<uintptr_t>(bytes + c.offset);
+          for (uint32_t ci = 0; ci < n_here; ++ci) {
+            const VmContainer c = cs[ci];
+            const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
+            const bool cached = (c.meta >> 18) & 1u;
+            const u64 fill_off = ((u64)(c.meta >> 19) << 32) | c.fill_lo;
+            const bool do_fill = !(c.fill_lo == 0xFFFFFFFFu && (c.meta >> 19) == 0x1FFFu);
+            // the body is read once, as 16-byte aligned loads (any body alignment) — from the HBM posting cache, or over
+            // PCIe from the pinned staging buffer — and decoded from LDS
+            const uint32_t len = type == 0 ? 2 * (card + 1) : (type == 1 ? 8192u : 4 * (card + 1));
+            const uintptr_t b0 = cached ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
             const uint32_t skew = (uint32_t)(b0 & 15);
             const uint4 *src = reinterpret_cast<const uint4 *>(b0 - skew);
             const uint32_t n16 = (skew + min(len, 8192u) + 15) / 16;
-            for (uint32_t i = tid; i < n16; i += VT) s_raw[i] = src[i];
+            uint4 *fill = do_fill ? reinterpret_cast<uint4 *>((uintptr_t)(r.cache + fill_off) - skew) : nullptr;
+            for (uint32_t i = tid; i < n16; i += VT) {
+              const uint4 v = src[i];
+              s_raw[i] = v;
+              // first reader of this key: the body goes into the cache on the way (same skew there: serialisations start
+              // 16-byte aligned in both places; the partial blocks at the ends carry the neighbouring bytes of the SAME
+              // serialisation, so a racing neighbour writes identical values)
+              if (fill) fill[i] = v;
+            }
             __syncthreads();
             const uint8_t *body = reinterpret_cast<const uint8_t *>(s_raw) + skew;
-            if (c.type == 0) {
-              for (uint32_t i = tid; i < min(c.card, 4096u); i += VT) {
+            if (type == 0) {
+              for (uint32_t i = tid; i < min(card + 1, 4096u); i += VT) {
                 const uint32_t v = (uint32_t)body[2 * i] | ((uint32_t)body[2 * i + 1] << 8);
                 atomicOr(&s_dec[v >> 6], 1ull << (v & 63));
               }
-            } else if (c.type == 1) {
+            } else if (type == 1) {
               for (uint32_t w = tid; w < CHW; w += VT) {
                 u64 v = 0;
                 for (int b = 0; b < 8; ++b) v |= (u64)body[8 * w + b] << (8 * b);
                 if (v) atomicOr(&s_dec[w], v);
               }
             } else {
-              for (uint32_t rr = 0; rr < min(c.card, 2048u); ++rr) {
+              for (uint32_t rr = 0; rr < min(card + 1, 2048u); ++rr) {
                 const uint32_t start = (uint32_t)body[4 * rr] | ((uint32_t)body[4 * rr + 1] << 8);
                 const uint32_t rl = ((uint32_t)body[4 * rr + 2] | ((uint32_t)body[4 * rr + 3] << 8)) + 1;
                 for (uint32_t i = tid; i < rl; i += VT) {
@@ -308,7 +367,6 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
             }
             __syncthreads();   // s_raw is reused by the next container
           }
-          __syncthreads();
           for (uint32_t p = tid; p < n_pairs; p += VT) {
             ulonglong2 v;
             v.x = s_dec[2 * p] & doc_mask(w0 + 2 * p, r.n_docs);
@@ -391,7 +449,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   uint32_t emitted = 0;
   if (fk_cnt != NONE) {
     // ordered emit of the first k documents: chunk cardinalities are known, so only the chunks that contribute are read
-    const uint32_t *pcf = arena + r.phase_off[phase];
+    const uint32_t *pcf = arena + rp->phase_off[phase];
     // find the command again (same walk as above; commands are self-delimiting)
     uint32_t slot = 0, k = 0;
     for (;;) {
@@ -405,7 +463,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         case VM_CLEAR: pcf += 2 + pcf[1]; break;
         case VM_CLAIM: pcf += 5 + pcf[4]; break;
         case VM_AND_MANY: pcf += 4 + 2 * pcf[2]; break;
-        case VM_PATHS: pcf += 7 + pcf[1] + pcf[5]; break;
+        case VM_PATHS: pcf += 7 + pcf[1] + (pcf[5] & 0x7FFFFFFFu); break;
         case VM_SUB_MANY: pcf += 4 + pcf[2]; break;
         case VM_COUNT: pcf += 3; break;
         case VM_DECODE: pcf += 4; break;
@@ -423,11 +481,11 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       const u64 cw0 = (u64)c * CHW;
       const uint32_t cnw = (uint32_t)min((u64)CHW, r.n_words - cw0);
       const u64 *a = pool + (u64)slot * r.n_words + cw0;
-      u64 w[4];
+      u64 w[WPT];
       uint32_t mine = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {   // thread t owns words 4t .. 4t+3: ascending across threads
-        const uint32_t wi = 4 * tid + j;
+      for (int j = 0; j < WPT; ++j) {   // thread t owns words WPT*t .. WPT*t+WPT-1: ascending across threads
+        const uint32_t wi = WPT * tid + j;
         w[j] = wi < cnw ? __hip_atomic_load(&a[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         mine += (uint32_t)__popcll(w[j]);
       }
@@ -443,11 +501,11 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       for (uint32_t ww = 0; ww < wave; ++ww) before += s_scan[ww];
       uint32_t rank = before + incl - mine;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < WPT; ++j) {
         u64 x = w[j];
         while (x && rank < k) {
           const uint32_t b = (uint32_t)__ffsll((long long)x) - 1;
-          ids[rank++] = (uint32_t)((cw0 + 4 * tid + j) * 64 + b);
+          ids[rank++] = (uint32_t)((cw0 + WPT * tid + j) * 64 + b);
           x &= x - 1;
         }
       }
@@ -472,30 +530,52 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
 
 // ================================================================================================ combiner
 
+// A submitted list.  Lives in a slot OWNED BY THE VM (recycled, never freed before the VM), so the combiner may touch it
+// at any time; the search thread sleeps on `state` (futex) and is woken by the combiner, which is the only thread that
+// polls the GPU's completion words.  (Search threads that spin burn the CPU budget the searches themselves need: on a
+// 16-CPU container quota, 64 spinning waiters got the whole process throttled — r2_ranked_2m_vm_v1*.jsonl.)
 struct VmSub {
-  msi_bits *pool;
-  const MsiVmList *list;
-  uint64_t seq;
-  std::atomic<int32_t> status{1};   // 1 queued, 0 launched, < 0 failed (MSI_E_*)
+  msi_bits *pool = nullptr;
+  const MsiVmList *list = nullptr;
+  uint64_t seq = 0;
+  volatile uint64_t *blk = nullptr;        // the pool's pinned result block; blk[0] == seq when the list has run
+  std::atomic<uint32_t> state{0};          // 0 waiting, 1 done, 2 failed
+  std::atomic<uint32_t> asleep{0};         // the waiter is (about to be) blocked in futex_wait: the combiner must wake it
+  int32_t error = MSI_OK;
+  int64_t t_submit = 0, t_taken = 0, t_launch = 0, t_done = 0;   // steady-clock ns (diagnostics)
 };
 
-struct msi_vm {
+struct VmCombiner {
   msi_ctx *ctx = nullptr;
-  hipStream_t stream = nullptr;
+  static constexpr int NS = 16;     // rounds in flight: a slow list of one round must not hold up the next round's lists
+  hipStream_t streams[NS] = {};
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
-  std::vector<VmSub *> queue;
-  std::atomic<uint32_t> pending{0};
+  std::vector<VmSub *> queue;              // submitted, not yet taken (guarded by mu)
+  std::vector<VmSub *> free_slots;         // guarded by mu
+  std::vector<std::unique_ptr<VmSub>> slots;
+  bool sleeping = false;                   // the combiner waits on cv (guarded by mu)
   bool stop = false;
   struct Arena {
     uint8_t *host = nullptr, *dev = nullptr;
     size_t cap = 0;
     hipEvent_t done = nullptr;
     bool in_flight = false;
-  } ar[2];
+  } ar[NS];
   std::atomic<uint64_t> rounds{0}, lists{0};
+  // where a list's wall time goes (ns, summed over lists): queued until the combiner took it, packed until the launch
+  // calls began, launch calls (per round), from the launch calls until the combiner saw the GPU's completion word
+  std::atomic<uint64_t> ns_queued{0}, ns_packed{0}, ns_launch_calls{0}, ns_after_launch{0};
+  std::atomic<uint32_t> load{0};           // lists submitted and not finished yet
   void run();
+};
+
+// The context's combiners: pools are spread over a few of them (a combiner is one thread: packing, launching, noticing
+// completions and waking the searches of its pools cost it ~4 us per list, ~250 k lists/s — r2_ranked_2m_vm_v3*.jsonl).
+struct msi_vm {
+  msi_ctx *ctx = nullptr;
+  std::vector<std::unique_ptr<VmCombiner>> comb;
 };
 
 namespace {
@@ -503,7 +583,7 @@ namespace {
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 uint32_t chunks_of(msi_bits *p) { return (uint32_t)((msi_bits_words_per_slot(p) + CHW - 1) / CHW); }
 
-bool arena_ensure(msi_vm *vm, msi_vm::Arena &A, size_t bytes) {
+bool arena_ensure(VmCombiner *vm, VmCombiner::Arena &A, size_t bytes) {
   if (bytes <= A.cap) return true;
   if (A.in_flight) {
     (void)hipEventSynchronize(A.done);
@@ -529,31 +609,80 @@ bool arena_ensure(msi_vm *vm, msi_vm::Arena &A, size_t bytes) {
 
 }  // namespace
 
-void msi_vm::run() {
-  (void)hipSetDevice(ctx->device);
-  std::vector<VmSub *> batch;
-  int cur = 0;
-  for (;;) {
-    batch.clear();
-    {
-      // searches come back within microseconds of each other: poll briefly before sleeping
-      const auto t0 = std::chrono::steady_clock::now();
-      while (pending.load(std::memory_order_acquire) == 0) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
+static inline int64_t now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static void futex_wake_all(std::atomic<uint32_t> *w) {
+#if defined(__linux__)
+  syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, INT32_MAX, nullptr, nullptr, 0);
 #endif
+}
+static void futex_wait_for(std::atomic<uint32_t> *w, uint32_t expected, long timeout_us) {
+#if defined(__linux__)
+  struct timespec ts;
+  ts.tv_sec = timeout_us / 1000000;
+  ts.tv_nsec = (timeout_us % 1000000) * 1000;
+  syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
+#else
+  (void)w; (void)expected;
+  std::this_thread::sleep_for(std::chrono::microseconds(std::min<long>(timeout_us, 50)));
+#endif
+}
+
+void VmCombiner::run() {
+  (void)hipSetDevice(ctx->device);
+  std::vector<VmSub *> inflight, taken;
+  // Two classes of rounds, each with its own ring of arenas / streams (light: even indices, heavy: odd): a list with
+  // many decodes (the postings of a whole condition) or a large level takes 100+ us on the device, the typical list
+  // ~10 us; a kernel ends when its slowest list ends and the next kernel on that stream waits for it, so heavy lists
+  // get rounds of their own and the light ones keep flowing.
+  int cur_of[2] = {0, 1};
+  const size_t max_subs = getenv("MSI_VM_MAX_SUBS") ? std::max(1, atoi(getenv("MSI_VM_MAX_SUBS"))) : MAX_SUBS;   // experiments
+  auto is_heavy = [](const VmSub *s) { return s->list->decodes.size() > 2 || s->list->words.size() > 600; };
+  std::vector<VmSub *> waiting[2];   // taken from the queue, not launched yet (their class's arena is still in use)
+  FILE *trace = getenv("MSI_VM_TRACE") ? fopen(getenv("MSI_VM_TRACE"), "w") : nullptr;
+  auto finish = [&](VmSub *s, uint32_t st) {
+    s->t_done = now_ns();
+    if (trace && s->list) {   // diagnostics: what a list was made of and how long the device took for it
+      const std::vector<uint32_t> &w = s->list->words;
+      uint32_t ops[16] = {0}, max_paths = 0, max_steps = 0, clear_slots = 0;
+      const size_t w_end = s->list->data_off ? s->list->data_off : w.size();
+      for (size_t i = 0; i < w_end;) {
+        const uint32_t op = w[i];
+        if (op < 16) ++ops[op];
+        switch (op) {
+          case VM_END: i += 1; break;
+          case VM_FILL: i += 3; break;
+          case VM_OP: i += 5; break;
+          case VM_OP_COUNT: i += 6; break;
+          case VM_CLEAR: clear_slots += w[i + 1]; i += 2 + w[i + 1]; break;
+          case VM_CLAIM: i += 5 + w[i + 4]; break;
+          case VM_AND_MANY: i += 4 + 2 * w[i + 2]; break;
+          case VM_PATHS: max_paths = std::max(max_paths, w[i + 1]); max_steps = std::max(max_steps, w[i + 5] & 0x7FFFFFFFu); i += 7 + w[i + 1] + (w[i + 5] & 0x7FFFFFFFu); break;
+          case VM_SUB_MANY: i += 4 + w[i + 2]; break;
+          case VM_COUNT: i += 3; break;
+          case VM_DECODE: i += 4; break;
+          case VM_FIRSTK: i += 4; break;
+          case VM_MINKEY: i += 5; break;
+          case VM_TAKEKEY: i += 8; break;
+          default: i = w_end; break;
+        }
       }
-      std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return stop || !queue.empty(); });
-      if (stop && queue.empty()) return;
-      const size_t n = std::min<size_t>(queue.size(), MAX_SUBS);
-      batch.assign(queue.begin(), queue.begin() + n);
-      queue.erase(queue.begin(), queue.begin() + n);
-      pending.fetch_sub((uint32_t)n, std::memory_order_acq_rel);
+      fprintf(trace, "%.1f us words %zu stage %zu fill %u op %u opc %u clear %u(%u slots) claim %u andmany %u paths %u(max %u paths %u steps) sub %u count %u decode %u firstk %u\n",
+              (s->t_done - s->t_launch) / 1e3, w_end, s->list->stage_used, ops[VM_FILL], ops[VM_OP], ops[VM_OP_COUNT], ops[VM_CLEAR],
+              clear_slots, ops[VM_CLAIM], ops[VM_AND_MANY], ops[VM_PATHS], max_paths, max_steps, ops[VM_SUB_MANY], ops[VM_COUNT],
+              ops[VM_DECODE], ops[VM_FIRSTK]);
     }
+    s->state.store(st, std::memory_order_seq_cst);
+    // a waiter that is still polling needs no system call (the wake-up is the combiner's most expensive step)
+    if (s->asleep.load(std::memory_order_seq_cst)) futex_wake_all(&s->state);
+  };
+  // one round: pack the lists into the class's next arena, one H2D copy, one launch per phase
+  auto launch_round = [&](int cls, std::vector<VmSub *> &batch) {
+    const int cur = cur_of[cls];
     Arena &A = ar[cur];
-    // ---- layout ------------------------------------------------------------------------------------------
+    hipStream_t stream = streams[cur];
     const size_t n_sub = batch.size();
     size_t off = 64 + align16(n_sub * sizeof(RoundSub));
     std::vector<size_t> words_at(n_sub), state_at(n_sub);
@@ -570,10 +699,6 @@ void msi_vm::run() {
       msi_set_error("msi_vm: arena of %zu bytes not available", off);
       st = MSI_E_OOM;
     }
-    if (st == MSI_OK && A.in_flight) {   // the round that used this arena two rounds ago
-      if (hipEventSynchronize(A.done) != hipSuccess) st = MSI_E_HIP;
-      A.in_flight = false;
-    }
     if (st == MSI_OK) {
       memset(A.host, 0, 64);
       reinterpret_cast<uint32_t *>(A.host)[0] = (uint32_t)n_sub;
@@ -586,25 +711,26 @@ void msi_vm::run() {
         r.pool_base = (u64)(uintptr_t)msi_bits_slot_ptr(p, 0);
         r.n_words = msi_bits_words_per_slot(p);
         r.n_docs = msi_bits_n_docs(p);
-        r.host_res = (u64)(uintptr_t)msi_bits_vm_block(p);
+        r.host_res = (u64)(uintptr_t)batch[i]->blk;
         r.seq = batch[i]->seq;
         r.n_chunks = (uint32_t)((r.n_words + CHW - 1) / CHW);
         r.n_phases = (uint32_t)l.phase_start.size();
         for (uint32_t ph = 0; ph < r.n_phases; ++ph) r.phase_off[ph] = (uint32_t)(words_at[i] / 4) + l.phase_start[ph];
         r.list_off = (uint32_t)(words_at[i] / 4);
         r.stage = l.stage_used ? (u64)(uintptr_t)msi_bits_vm_stage(p, 0, 0) : 0;
+        r.cache = l.cache_base;
         r.state_off = (uint32_t)(state_at[i] / 4);
         r.n_counts = l.n_counts;
+        r.data_off = l.data_off;
+        r.n_decodes = (uint32_t)l.decodes.size();
         memcpy(A.host + words_at[i], l.words.data(), l.words.size() * 4);
         reinterpret_cast<uint32_t *>(A.host + words_at[i])[l.words.size()] = VM_END;
         memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)r.n_chunks * 4);
         max_chunks = std::max(max_chunks, r.n_chunks);
         max_phases = std::max(max_phases, r.n_phases);
       }
-      // From the first launch on a waiter may see its sequence number and leave (its VmSub is on its stack): the
-      // combiner does not touch a VmSub after this point unless the round failed — then nothing was published and
-      // the waiter is still polling.
-      for (VmSub *s : batch) s->status.store(0, std::memory_order_release);
+      const int64_t t_launch = now_ns();
+      for (VmSub *s : batch) s->t_launch = t_launch;
       if (hipMemcpyAsync(A.dev, A.host, off, hipMemcpyHostToDevice, stream) != hipSuccess) st = MSI_E_HIP;
       for (uint32_t ph = 0; ph < max_phases && st == MSI_OK; ++ph) {
         hipLaunchKernelGGL(vm_kernel, dim3(max_chunks, (uint32_t)n_sub), dim3(VT), 0, stream,
@@ -612,13 +738,78 @@ void msi_vm::run() {
         if (hipGetLastError() != hipSuccess) st = MSI_E_HIP;
       }
       if (st == MSI_OK && hipEventRecord(A.done, stream) == hipSuccess) A.in_flight = true;
+      ns_launch_calls.fetch_add((uint64_t)(now_ns() - t_launch), std::memory_order_relaxed);
       if (st != MSI_OK) msi_set_error("msi_vm: launching a round of %zu lists failed", n_sub);
     }
     rounds.fetch_add(1, std::memory_order_relaxed);
     lists.fetch_add(n_sub, std::memory_order_relaxed);
-    if (st != MSI_OK)
-      for (VmSub *s : batch) s->status.store(st, std::memory_order_release);
-    cur ^= 1;
+    if (st != MSI_OK) {
+      for (VmSub *s : batch) {
+        s->error = st;
+        finish(s, 2);
+      }
+    } else {
+      inflight.insert(inflight.end(), batch.begin(), batch.end());
+    }
+    batch.clear();
+    cur_of[cls] = (cur + 2) % NS;
+  };
+  for (;;) {
+    taken.clear();
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      if (queue.empty() && inflight.empty() && waiting[0].empty() && waiting[1].empty()) {
+        sleeping = true;
+        cv.wait(lk, [&] { return stop || !queue.empty(); });
+        sleeping = false;
+      }
+      if (stop && queue.empty() && inflight.empty() && waiting[0].empty() && waiting[1].empty()) return;
+      taken.swap(queue);
+    }
+    if (!taken.empty()) {
+      const int64_t t_taken = now_ns();
+      for (VmSub *s : taken) {
+        s->t_taken = t_taken;
+        waiting[is_heavy(s) ? 1 : 0].push_back(s);
+      }
+    }
+    // the combiner never blocks on the device (it is also the thread that notices completions): a class whose next
+    // arena is still in use keeps its lists waiting
+    for (int cls = 0; cls < 2; ++cls) {
+      if (waiting[cls].empty()) continue;
+      Arena &A0 = ar[cur_of[cls]];
+      if (A0.in_flight && hipEventQuery(A0.done) == hipSuccess) A0.in_flight = false;
+      if (A0.in_flight) continue;
+      std::vector<VmSub *> batch;
+      const size_t n = std::min<size_t>(waiting[cls].size(), std::min<size_t>(max_subs, MAX_SUBS));
+      batch.assign(waiting[cls].begin(), waiting[cls].begin() + n);
+      waiting[cls].erase(waiting[cls].begin(), waiting[cls].begin() + n);
+      launch_round(cls, batch);
+    }
+    // ---- completion: the GPU stored the list's sequence number into its pool's pinned block -------------------
+    size_t kept = 0;
+    const int64_t t_now = now_ns();
+    for (VmSub *s : inflight) {
+      if (__atomic_load_n(const_cast<uint64_t *>(&s->blk[0]), __ATOMIC_ACQUIRE) == s->seq) {
+        finish(s, 1);
+      } else if (t_now - s->t_launch > 5000000000ll) {   // 5 s: settle it with the streams, then give up on it
+        for (auto stq : streams) (void)hipStreamSynchronize(stq);
+        if (__atomic_load_n(const_cast<uint64_t *>(&s->blk[0]), __ATOMIC_ACQUIRE) == s->seq) {
+          finish(s, 1);
+        } else {
+          s->error = MSI_E_INTERNAL;
+          finish(s, 2);
+        }
+      } else {
+        inflight[kept++] = s;
+      }
+    }
+    inflight.resize(kept);
+    if (taken.empty() && !inflight.empty()) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
   }
 }
 
@@ -628,52 +819,77 @@ static msi_vm *vm_of(msi_ctx *ctx) {
     DeviceGuard g(ctx->device);
     msi_vm *vm = new msi_vm();
     vm->ctx = ctx;
-    if (hipStreamCreateWithFlags(&vm->stream, hipStreamNonBlocking) != hipSuccess) {
-      delete vm;
-      msi_set_error("msi_vm: hipStreamCreate failed");
-      return nullptr;
+    const char *knob = getenv("MSI_VM_COMBINERS");
+    const int n = std::max(1, std::min(8, knob ? atoi(knob) : 1));   // one is best: more combiners mean more, smaller rounds
+    for (int c = 0; c < n; ++c) {
+      std::unique_ptr<VmCombiner> cb(new VmCombiner());
+      cb->ctx = ctx;
+      for (int i = 0; i < VmCombiner::NS; ++i)
+        if (hipStreamCreateWithFlags(&cb->streams[i], hipStreamNonBlocking) != hipSuccess) {
+          msi_set_error("msi_vm: hipStreamCreate failed");
+          delete vm;   // (what was created so far leaks with the failed context; nothing runs on it)
+          return nullptr;
+        }
+      VmCombiner *raw = cb.get();
+      cb->th = std::thread([raw] { raw->run(); });
+      vm->comb.push_back(std::move(cb));
     }
-    vm->th = std::thread([vm] { vm->run(); });
     ctx->vm = vm;
   }
   return ctx->vm;
 }
 
-void msi_vm_destroy(msi_vm *vm) {
-  if (!vm) return;
-  {
-    std::lock_guard<std::mutex> lk(vm->mu);
-    vm->stop = true;
+void msi_vm_destroy(msi_vm *vmx) {
+  if (!vmx) return;
+  for (auto &cb : vmx->comb) {
+    VmCombiner *vm = cb.get();
+    {
+      std::lock_guard<std::mutex> lk(vm->mu);
+      vm->stop = true;
+    }
+    vm->cv.notify_all();
+    if (vm->th.joinable()) vm->th.join();
+    DeviceGuard g(vm->ctx->device);
+    for (auto st : vm->streams)
+      if (st) (void)hipStreamSynchronize(st);
+    for (auto &A : vm->ar) {
+      if (A.host) (void)hipHostFree(A.host);
+      if (A.dev) (void)hipFree(A.dev);
+      if (A.done) (void)hipEventDestroy(A.done);
+    }
+    for (auto st : vm->streams)
+      if (st) (void)hipStreamDestroy(st);
   }
-  vm->cv.notify_all();
-  if (vm->th.joinable()) vm->th.join();
-  DeviceGuard g(vm->ctx->device);
-  (void)hipStreamSynchronize(vm->stream);
-  for (auto &A : vm->ar) {
-    if (A.host) (void)hipHostFree(A.host);
-    if (A.dev) (void)hipFree(A.dev);
-    if (A.done) (void)hipEventDestroy(A.done);
-  }
-  (void)hipStreamDestroy(vm->stream);
-  delete vm;
+  delete vmx;
 }
 
-void msi_vm_stats(msi_bits *pool, uint64_t *rounds, uint64_t *lists) {
+void msi_vm_stats(msi_bits *pool, uint64_t out[6]) {
   msi_ctx *ctx = msi_bits_ctx(pool);
   std::lock_guard<std::mutex> lk(ctx->vm_mu);
-  *rounds = ctx->vm ? ctx->vm->rounds.load() : 0;
-  *lists = ctx->vm ? ctx->vm->lists.load() : 0;
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  if (!ctx->vm) return;
+  for (auto &cb : ctx->vm->comb) {
+    out[0] += cb->rounds.load();
+    out[1] += cb->lists.load();
+    out[2] += cb->ns_queued.load();
+    out[3] += cb->ns_packed.load();
+    out[4] += cb->ns_launch_calls.load();
+    out[5] += cb->ns_after_launch.load();
+  }
+}
+
+extern "C" int32_t msi_bits_vm_stats(msi_bits *pool, uint64_t out[6]) {
+  if (!pool || !out) return MSI_E_INVALID;
+  msi_vm_stats(pool, out);
+  return MSI_OK;
 }
 
 int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiCboBatch &batch, bool overwrite) {
-  // payload: {n_cont, cs_off, bytes_off}, koff[n_chunks + 1] (containers bucketed by chunk = Roaring key), the
-  // containers, the posting bytes, and the <= 7-document raw values as array containers built here
+  // Bodies that are not in the posting cache go into the pool's pinned staging buffer (read over PCIe by the decoding
+  // workgroup, once); the container descriptors are bucketed by chunk (= Roaring key) here and laid out chunk-major
+  // when the list is submitted.  The <= 7-document raw values become array containers built here.
   const uint64_t n_words = msi_bits_words_per_slot(pool);
   const uint32_t n_chunks = (uint32_t)((n_words + CHW - 1) / CHW);
-  std::vector<uint32_t> per(n_chunks + 1, 0);
-  for (const MsiContainer &c : batch.containers)
-    if (c.key < n_chunks) ++per[c.key + 1];
-  // raw ids -> per-key arrays
   std::vector<std::pair<uint32_t, uint16_t>> small;
   small.reserve(batch.small_ids.size());
   for (uint32_t id : batch.small_ids)
@@ -686,7 +902,7 @@ int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const M
     MsiContainer c;
     c.key = small[i].first;
     c.type = 0;
-    c.offset = (uint32_t)(batch.bytes.size() + extra_bytes.size());
+    c.offset = (uint32_t)extra_bytes.size();
     while (j < small.size() && small[j].first == c.key) {
       extra_bytes.push_back((uint8_t)(small[j].second & 0xFF));
       extra_bytes.push_back((uint8_t)(small[j].second >> 8));
@@ -694,93 +910,290 @@ int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const M
     }
     c.card = (uint32_t)(j - i);
     extra.push_back(c);
-    ++per[c.key + 1];
     i = j;
   }
-  for (uint32_t k = 0; k < n_chunks; ++k) per[k + 1] += per[k];
-  const uint32_t n_cont = per[n_chunks];
-  DecodeHdr h;
-  h.n_cont = n_cont;
-  h.cs_off = (uint32_t)align16(sizeof(DecodeHdr) + (size_t)(n_chunks + 1) * 4);
-  h.bytes_off = (uint32_t)align16(h.cs_off + (size_t)n_cont * sizeof(MsiContainer));
-  h._pad = 0;
+  // staging: [batch.bytes (16-aligned start)] [extra_bytes (16-aligned start)]
   const size_t at = align16(l.stage_used);
-  const size_t total = h.bytes_off + batch.bytes.size() + extra_bytes.size();
-  uint8_t *stage = msi_bits_vm_stage(pool, at + total + 16, l.stage_used);
-  if (!stage) return MSI_E_OOM;
-  l.stage_used = at + total;
-  uint8_t *D = stage + at;
-  memcpy(D, &h, sizeof(h));
-  memcpy(D + sizeof(DecodeHdr), per.data(), (size_t)(n_chunks + 1) * 4);
-  MsiContainer *cs = reinterpret_cast<MsiContainer *>(D + h.cs_off);
-  std::vector<uint32_t> fill(per.begin(), per.end() - 1);
+  const size_t extra_at = at + align16(batch.bytes.size());
+  const size_t total = extra_at + extra_bytes.size();
+  if (total > at) {
+    uint8_t *stage = msi_bits_vm_stage(pool, total + 16, l.stage_used);
+    if (!stage) return MSI_E_OOM;
+    if (!batch.bytes.empty()) memcpy(stage + at, batch.bytes.data(), batch.bytes.size());
+    if (!extra_bytes.empty()) memcpy(stage + extra_at, extra_bytes.data(), extra_bytes.size());
+    l.stage_used = total;
+  }
+  MsiVmList::Decode dec;
+  dec.start.assign(n_chunks + 1, 0);
   for (const MsiContainer &c : batch.containers)
-    if (c.key < n_chunks) cs[fill[c.key]++] = c;
-  for (const MsiContainer &c : extra) cs[fill[c.key]++] = c;
-  if (!batch.bytes.empty()) memcpy(D + h.bytes_off, batch.bytes.data(), batch.bytes.size());
-  if (!extra_bytes.empty()) memcpy(D + h.bytes_off + batch.bytes.size(), extra_bytes.data(), extra_bytes.size());
+    if (c.key < n_chunks) ++dec.start[c.key + 1];
+  for (const MsiContainer &c : extra) ++dec.start[c.key + 1];
+  for (uint32_t k = 0; k < n_chunks; ++k) dec.start[k + 1] += dec.start[k];
+  dec.c.assign((size_t)dec.start[n_chunks] * 2, 0);
+  std::vector<uint32_t> fill(dec.start.begin(), dec.start.end() - 1);
+  const bool has_cache = !batch.src.empty();
+  auto put = [&](const MsiContainer &c, bool cached, uint64_t src, uint64_t fill_off) {
+    // meta: card - 1 (16 bits) | type << 16 | cached << 18 | fill offset high 13 bits << 19; then fill offset low 32 bits
+    const uint32_t card1 = c.type == 1 ? 0u : (c.card ? c.card - 1 : 0u);
+    const uint64_t f = fill_off == MSI_NO_CACHE ? ((uint64_t)0x1FFF << 32 | 0xFFFFFFFFull) : fill_off;
+    const uint32_t meta = (card1 & 0xFFFFu) | (c.type << 16) | ((cached ? 1u : 0u) << 18) | ((uint32_t)((f >> 32) & 0x1FFF) << 19);
+    const size_t at2 = (size_t)fill[c.key]++ * 2;
+    dec.c[at2] = (uint64_t)meta | ((uint64_t)(uint32_t)f << 32);
+    dec.c[at2 + 1] = src;
+  };
+  for (size_t i = 0; i < batch.containers.size(); ++i) {
+    const MsiContainer &c = batch.containers[i];
+    if (c.key >= n_chunks) continue;
+    const bool cached = has_cache && batch.src[i] != MSI_NO_CACHE;
+    put(c, cached, cached ? batch.src[i] : (uint64_t)at + c.offset, has_cache ? batch.fill[i] : MSI_NO_CACHE);
+  }
+  for (const MsiContainer &c : extra) put(c, false, (uint64_t)extra_at + c.offset, MSI_NO_CACHE);
   l.begin();
   l.words.push_back(VM_DECODE);
   l.words.push_back(dst);
   l.words.push_back(overwrite ? 1u : 0u);
-  l.words.push_back((uint32_t)at);
+  l.words.push_back((uint32_t)l.decodes.size());
+  l.decodes.push_back(std::move(dec));
   return MSI_OK;
 }
 
-int32_t msi_vm_run(msi_bits *pool, const MsiVmList &l, MsiVmResult *res) {
+// Chunk-major layout of the list's decode descriptors, appended to its words (16-byte aligned):
+//   chunk_off[n_chunks + 1]  (16-byte units from the block start)
+//   per chunk c: start[n_decodes + 1] (containers of decode d in c: start[d] .. start[d+1]), padded to 16 bytes,
+//                then those containers, 16 bytes each, decodes back to back
+static void finalize_decodes(MsiVmList &l) {
+  if (l.decodes.empty() || l.data_off) return;
+  const uint32_t D = (uint32_t)l.decodes.size();
+  const uint32_t n_chunks = (uint32_t)l.decodes[0].start.size() - 1;
+  l.words.push_back(VM_END);                       // the last phase ends here; what follows is data
+  while (l.words.size() % 4) l.words.push_back(0);
+  l.data_off = (uint32_t)l.words.size();
+  const uint32_t hdr_words = (n_chunks + 1 + 3) & ~3u, st_words = (D + 1 + 3) & ~3u;
+  std::vector<uint32_t> chunk_off(n_chunks + 1, 0);
+  uint32_t at = hdr_words / 4;                     // 16-byte units
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    chunk_off[c] = at;
+    uint32_t n = 0;
+    for (const auto &d : l.decodes) n += d.start[c + 1] - d.start[c];
+    at += st_words / 4 + n;
+  }
+  chunk_off[n_chunks] = at;
+  const size_t base = l.words.size();
+  l.words.resize(base + (size_t)at * 4, 0);
+  uint32_t *w = l.words.data() + base;
+  memcpy(w, chunk_off.data(), (n_chunks + 1) * 4);
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    uint32_t *blk = w + (size_t)chunk_off[c] * 4;
+    uint64_t *cs = reinterpret_cast<uint64_t *>(blk + st_words);
+    uint32_t run = 0;
+    for (uint32_t d = 0; d < D; ++d) {
+      const auto &dec = l.decodes[d];
+      blk[d] = run;
+      const uint32_t n = dec.start[c + 1] - dec.start[c];
+      if (n) memcpy(cs + (size_t)run * 2, dec.c.data() + (size_t)dec.start[c] * 2, (size_t)n * 16);
+      run += n;
+    }
+    blk[D] = run;
+  }
+}
+
+
+int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
+  finalize_decodes(l);
   if (l.n_counts > MSI_VM_MAX_COUNTS || l.phase_start.size() > MSI_VM_MAX_PHASES || l.phase_start.empty()) {
     msi_set_error("msi_vm_run: list outside the supported range (%u counts, %zu phases)", l.n_counts, l.phase_start.size());
     return MSI_E_UNSUPPORTED;
   }
   msi_ctx *ctx = msi_bits_ctx(pool);
-  msi_vm *vm = vm_of(ctx);
-  if (!vm) return MSI_E_HIP;
+  msi_vm *vmx = vm_of(ctx);
+  if (!vmx) return MSI_E_HIP;
+  VmCombiner *vm = vmx->comb[(((uintptr_t)pool) >> 8) % vmx->comb.size()].get();   // a pool always talks to the same combiner
   volatile uint64_t *blk = msi_bits_vm_block(pool);
   if (!blk) return MSI_E_OOM;
-  VmSub s;
-  s.pool = pool;
-  s.list = &l;
-  s.seq = msi_bits_vm_next_seq(pool);
+  VmSub *s = nullptr;
+  bool wake = false;
   {
     std::lock_guard<std::mutex> lk(vm->mu);
-    vm->queue.push_back(&s);
-    vm->pending.fetch_add(1, std::memory_order_acq_rel);
+    if (vm->free_slots.empty()) {
+      vm->slots.emplace_back(new VmSub());
+      s = vm->slots.back().get();
+    } else {
+      s = vm->free_slots.back();
+      vm->free_slots.pop_back();
+    }
+    s->pool = pool;
+    s->list = &l;
+    s->seq = msi_bits_vm_next_seq(pool);
+    s->blk = blk;
+    s->error = MSI_OK;
+    s->state.store(0, std::memory_order_relaxed);
+    s->asleep.store(0, std::memory_order_relaxed);
+    s->t_submit = now_ns();
+    s->t_taken = s->t_launch = s->t_done = 0;
+    vm->queue.push_back(s);
+    wake = vm->sleeping;
+    vm->load.fetch_add(1, std::memory_order_relaxed);
   }
-  vm->cv.notify_one();
-  const auto t0 = std::chrono::steady_clock::now();
-  bool synced = false;
-  for (uint32_t spin = 0;; ++spin) {
-    if (__atomic_load_n(const_cast<uint64_t *>(&blk[0]), __ATOMIC_ACQUIRE) == s.seq) break;
-    const int32_t st = s.status.load(std::memory_order_acquire);
-    if (st < 0) return st;
+  if (wake) vm->cv.notify_one();
+  // A short poll when the combiner is nearly idle (a round trip is then ~25 us), else sleep until the combiner wakes
+  // us: under load a round trip takes 100+ us and polling through it would burn the CPU time the searches need.
+  const int64_t t0 = now_ns();
+  const int64_t spin_ns = vm->load.load(std::memory_order_relaxed) <= 3 ? 30000 : 0;
+  uint32_t st;
+  while ((st = s->state.load(std::memory_order_acquire)) == 0) {
+    if (now_ns() - t0 < spin_ns) {
 #if defined(__x86_64__)
-    __builtin_ia32_pause();
+      __builtin_ia32_pause();
 #endif
-    if ((spin & 255) == 255) {
-      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-      if (us > 200.0) std::this_thread::yield();
-      if (us > 2e6 && st == 0 && !synced) {   // launched long ago and still no signal: settle it with the stream
-        DeviceGuard g(ctx->device);
-        MSI_HIP_TRY(hipStreamSynchronize(vm->stream));
-        synced = true;
-        if (__atomic_load_n(const_cast<uint64_t *>(&blk[0]), __ATOMIC_ACQUIRE) != s.seq) {
-          msi_set_error("msi_vm: a round finished without publishing its results");
-          return MSI_E_INTERNAL;
-        }
-        break;
+      continue;
+    }
+    s->asleep.store(1, std::memory_order_seq_cst);
+    if ((st = s->state.load(std::memory_order_seq_cst)) != 0) break;   // completed between the poll and the flag
+    futex_wait_for(&s->state, 0, 2000);
+  }
+  int32_t ret = MSI_OK;
+  if (st == 2) {
+    ret = s->error != MSI_OK ? s->error : MSI_E_INTERNAL;
+    if (ret == MSI_E_INTERNAL) msi_set_error("msi_vm: a round finished without publishing its results");
+  } else {
+    vm->ns_queued.fetch_add((uint64_t)(s->t_taken - s->t_submit), std::memory_order_relaxed);
+    vm->ns_packed.fetch_add((uint64_t)(s->t_launch - s->t_taken), std::memory_order_relaxed);
+    vm->ns_after_launch.fetch_add((uint64_t)(s->t_done - s->t_launch), std::memory_order_relaxed);
+    if (res) {
+      res->counts.resize(l.n_counts);
+      for (uint32_t i = 0; i < l.n_counts; ++i)
+        res->counts[i] = __atomic_load_n(const_cast<uint64_t *>(&blk[RES_COUNTS + i]), __ATOMIC_RELAXED);
+      res->firstk.clear();
+      if (l.wants_firstk) {
+        const uint32_t n = (uint32_t)__atomic_load_n(const_cast<uint64_t *>(&blk[1]), __ATOMIC_RELAXED);
+        const uint32_t *ids = reinterpret_cast<const uint32_t *>(const_cast<const uint64_t *>(blk) + RES_IDS);
+        res->firstk.assign(ids, ids + std::min<uint32_t>(n, MSI_VM_MAX_FIRSTK));
       }
     }
   }
-  if (res) {
-    res->counts.resize(l.n_counts);
-    for (uint32_t i = 0; i < l.n_counts; ++i)
-      res->counts[i] = __atomic_load_n(const_cast<uint64_t *>(&blk[RES_COUNTS + i]), __ATOMIC_RELAXED);
-    res->firstk.clear();
-    if (l.wants_firstk) {
-      const uint32_t n = (uint32_t)__atomic_load_n(const_cast<uint64_t *>(&blk[1]), __ATOMIC_RELAXED);
-      const uint32_t *ids = reinterpret_cast<const uint32_t *>(const_cast<const uint64_t *>(blk) + RES_IDS);
-      res->firstk.assign(ids, ids + std::min<uint32_t>(n, MSI_VM_MAX_FIRSTK));
+  vm->load.fetch_sub(1, std::memory_order_relaxed);
+  {
+    std::lock_guard<std::mutex> lk(vm->mu);
+    vm->free_slots.push_back(s);
+  }
+  return ret;
+}
+
+
+// ================================================================================================ posting cache
+
+namespace {
+struct KeyHash {
+  size_t operator()(const MsiCacheKey &k) const { return (size_t)(k.a ^ (k.b * 0x9E3779B97F4A7C15ull)); }
+};
+struct KeyEq {
+  bool operator()(const MsiCacheKey &x, const MsiCacheKey &y) const { return x.a == y.a && x.b == y.b; }
+};
+struct CacheEntry {
+  uint64_t off = 0;
+  uint64_t len = 0;
+  std::atomic<uint32_t> ready{0};
+};
+inline uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
+  return x;
+}
+}  // namespace
+
+struct MsiPostingCache {
+  msi_ctx *ctx = nullptr;
+  uint8_t *dev = nullptr;
+  uint64_t cap = 0;
+  uint64_t used = 0;                 // guarded by mu (exclusive)
+  mutable std::shared_mutex mu;
+  std::unordered_map<MsiCacheKey, CacheEntry, KeyHash, KeyEq> map;
+  std::atomic<uint64_t> hits{0}, misses{0};
+};
+
+// Two independent 64-bit hashes over (database tag, the two strings with their lengths, two integers): a collision
+// needs both to agree (2^-128 per pair of keys); the serialisation length is checked on top of it.
+MsiCacheKey msi_cache_key(uint32_t db, const void *s1, size_t n1, const void *s2, size_t n2, uint64_t x, uint64_t y) {
+  uint64_t a = 0xCBF29CE484222325ull ^ db, b = 0x84222325CBF29CE4ull + (uint64_t)db * 0x100000001B3ull;
+  auto feed = [&](const void *s, size_t n) {
+    const uint8_t *p = (const uint8_t *)s;
+    a = (a ^ n) * 0x100000001B3ull;
+    b = mix64(b + n);
+    for (size_t i = 0; i < n; ++i) {
+      a = (a ^ p[i]) * 0x100000001B3ull;
+      b = (b + p[i]) * 0x9E3779B97F4A7C15ull;
+      b ^= b >> 29;
+    }
+  };
+  feed(s1, n1);
+  feed(s2, n2);
+  a = mix64(a ^ mix64(x + 0x1234567ull)) ^ mix64(y * 0xD6E8FEB86659FD93ull + 1);
+  b = mix64(b ^ mix64(y + 0x7654321ull)) ^ mix64(x * 0xA0761D6478BD642Full + 3);
+  return MsiCacheKey{a, b};
+}
+
+MsiPostingCache *msi_pcache_create(msi_ctx *ctx, uint64_t capacity_bytes) {
+  if (!ctx || capacity_bytes < 4096) return nullptr;
+  DeviceGuard g(ctx->device);
+  void *d = nullptr;
+  if (hipMalloc(&d, capacity_bytes) != hipSuccess) {
+    msi_set_error("hipMalloc(%llu) for the posting cache failed", (unsigned long long)capacity_bytes);
+    return nullptr;
+  }
+  MsiPostingCache *c = new MsiPostingCache();
+  c->ctx = ctx;
+  c->dev = (uint8_t *)d;
+  c->cap = capacity_bytes;
+  c->used = 16;   // offset 0 stays unused
+  return c;
+}
+
+void msi_pcache_destroy(MsiPostingCache *c) {
+  if (!c) return;
+  DeviceGuard g(c->ctx->device);
+  (void)hipDeviceSynchronize();   // no list that reads or fills the cache is in flight after this
+  (void)hipFree(c->dev);
+  delete c;
+}
+
+int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint64_t *off, void **token) {
+  *token = nullptr;
+  {
+    std::shared_lock<std::shared_mutex> lk(c->mu);
+    auto it = c->map.find(k);
+    if (it != c->map.end()) {
+      if (it->second.len == len && it->second.ready.load(std::memory_order_acquire)) {
+        *off = it->second.off;
+        c->hits.fetch_add(1, std::memory_order_relaxed);
+        return 1;
+      }
+      c->misses.fetch_add(1, std::memory_order_relaxed);
+      return 0;   // being filled by another search (or a length mismatch: never trusted)
     }
   }
-  return MSI_OK;
+  c->misses.fetch_add(1, std::memory_order_relaxed);
+  std::unique_lock<std::shared_mutex> lk(c->mu);
+  if (c->map.find(k) != c->map.end()) return 0;
+  const uint64_t need = ((uint64_t)len + 15 + 16) & ~15ull;   // + one block of slack for the last partial block
+  if (c->used + need > c->cap) return 0;
+  CacheEntry &e = c->map[k];
+  e.off = c->used;
+  e.len = len;
+  c->used += need;
+  *off = e.off;
+  *token = &e;   // node addresses of an unordered_map are stable
+  return 2;
+}
+
+void msi_pcache_commit(MsiPostingCache *, void *token) {
+  if (token) static_cast<CacheEntry *>(token)->ready.store(1, std::memory_order_release);
+}
+
+uint64_t msi_pcache_device_base(const MsiPostingCache *c) { return c ? (uint64_t)(uintptr_t)c->dev : 0; }
+
+void msi_pcache_stats(const MsiPostingCache *c, uint64_t out[4]) {
+  std::shared_lock<std::shared_mutex> lk(c->mu);
+  out[0] = c->hits.load();
+  out[1] = c->misses.load();
+  out[2] = c->used;
+  out[3] = c->cap;
 }

@@ -151,6 +151,15 @@ class GpuDictionary:
         check(lib().msi_dict_microbatch_stats(self._h, C.byref(a), C.byref(b)))
         return {"fused_calls": int(a.value), "fused_launches": int(b.value)}
 
+    def enable_posting_cache(self, capacity_bytes):
+        """HBM cache of the index version's stored postings for msi_keyword_search_ranked (msi.h)."""
+        check(lib().msi_dict_enable_posting_cache(self._h, int(capacity_bytes)))
+
+    def posting_cache_stats(self):
+        out = (C.c_uint64 * 4)()
+        check(lib().msi_dict_posting_cache_stats(self._h, out))
+        return {"hits": int(out[0]), "misses": int(out[1]), "bytes_used": int(out[2]), "capacity": int(out[3])}
+
     def match_time(self):
         n, ms = C.c_uint64(0), C.c_double(0.0)
         check(lib().msi_dict_match_time(self._h, C.byref(n), C.byref(ms)))

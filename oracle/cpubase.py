@@ -39,7 +39,23 @@ def _p(a):
 
 
 def host_threads():
-    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container with
+    cpu.max = "1600000 100000" sees 256 logical CPUs but gets 16 CPUs' worth of time — threads beyond that only
+    throttle each other, and reporting 256 "cores" would misstate the baseline's hardware)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 class CpuVectorScan:

@@ -179,6 +179,10 @@ extern "C" {
     pub fn msi_bits_set_from_docid_lists_device(p: *mut msi_bits, first_slot: u32, slot_stride: u32, d_docids: *const u32,
                                                 list_stride: u32, d_counts: *const u32, n_lists: u32) -> i32;
     pub fn msi_dict_set_microbatch(d: *mut msi_dict, max_wait_us: u32, target_words: u32) -> i32;
+    /// HBM cache of the index version's stored postings (hot keys are decoded from HBM, not over PCIe).
+    pub fn msi_dict_enable_posting_cache(d: *mut msi_dict, capacity_bytes: u64) -> i32;
+    /// out: [hits, misses, bytes used, capacity]
+    pub fn msi_dict_posting_cache_stats(d: *mut msi_dict, out: *mut u64) -> i32;
 
     pub fn msi_bits_create(ctx: *mut msi_ctx, n_docs: u64, n_slots: u32, out: *mut *mut msi_bits) -> i32;
     pub fn msi_bits_destroy(p: *mut msi_bits);

@@ -1,0 +1,85 @@
+"""The command-list back end of the ranked keyword search (msi_vm.hip) and the HBM posting cache:
+  * every reference snapshot search gives the same hits with the cache cold (postings decoded out of the pinned staging
+    buffer, bodies stored into the cache by the decoding workgroups) and warm (decoded from HBM), and the cache reports
+    hits on the second pass;
+  * the direct back end (one launch per set operation, MSI_SEARCH_VM=0) and the command lists agree hit for hit,
+    score detail for score detail;
+  * searches running concurrently (one pool per thread, one shared dictionary + cache, lists combined into shared
+    launches) return what they return alone."""
+import json
+import os
+import threading
+
+import pytest
+
+from tests.test_search_gpu import CASES, FIX, Harness, build_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(h, case):
+    hits, _ = h.search(case["query"], tms=case["tms"], offset=case["offset"], limit=case["limit"], detailed=True,
+                       stop_after=case.get("stop_after"))
+    return [(d, [tuple(s) for s in sc]) for d, sc in hits]
+
+
+def _by_index():
+    groups = {}
+    for c in CASES:
+        groups.setdefault(c["index"], []).append(c)
+    return groups
+
+
+def test_cold_and_warm_posting_cache_and_direct_backend_agree(monkeypatch):
+    checked = 0
+    for key, cases in _by_index().items():
+        h = Harness(build_index(FIX["indexes"][key]))
+        monkeypatch.setenv("MSI_SEARCH_VM", "0")
+        direct = [_search(h, c) for c in cases]
+        monkeypatch.setenv("MSI_SEARCH_VM", "1")
+        plain = [_search(h, c) for c in cases]
+        h.dict.enable_posting_cache(8 << 20)
+        cold = [_search(h, c) for c in cases]
+        s0 = h.dict.posting_cache_stats()
+        warm = [_search(h, c) for c in cases]
+        s1 = h.dict.posting_cache_stats()
+        assert direct == plain == cold == warm
+        for c, got in zip(cases, warm):
+            if c["ids"] is not None:
+                assert [d for d, _ in got] == c["ids"]
+        assert s1["hits"] >= s0["hits"]
+        assert s1["bytes_used"] <= s1["capacity"]
+        checked += len(cases)
+    assert checked >= 90
+
+
+def test_concurrent_searches_share_launches_and_the_cache():
+    key, cases = max(_by_index().items(), key=lambda kv: len(kv[1]))
+    index = build_index(FIX["indexes"][key])
+    base = Harness(index)
+    expected = [_search(base, c) for c in cases]
+    base.dict.enable_posting_cache(4 << 20)
+    import meilisearch_amd as ma
+    n_threads = 6
+    out = [None] * n_threads
+    errs = []
+
+    def worker(t):
+        try:
+            h = Harness.__new__(Harness)
+            h.R, h.index, h.ctx, h.dict, h.cb = base.R, index, base.ctx, base.dict, base.R.IndexCallbacks(index)
+            h.pool = ma.BitsPool(base.ctx, max(index.n_docs, 1), 512, private_stream=True)
+            out[t] = [[_search(h, c) for c in cases] for _ in range(3)]
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    for t in range(n_threads):
+        for rep in out[t]:
+            assert rep == expected
+    st = base.dict.posting_cache_stats()
+    assert st["bytes_used"] <= st["capacity"]     # (postings of <= 7 documents are raw ids: never cached)

@@ -223,7 +223,24 @@ static int32_t cpu_lookup(const uint8_t *w, uint32_t n, uint32_t max_typos, uint
 
 }  // namespace
 
+// cgroup v2 CPU accounting of this container: {usage_usec, throttled_usec}
+static void cpu_stat(unsigned long long out[2]) {
+  out[0] = out[1] = 0;
+  FILE *f = fopen("/sys/fs/cgroup/cpu.stat", "r");
+  if (!f) return;
+  char k[64];
+  unsigned long long v;
+  while (fscanf(f, "%63s %llu", k, &v) == 2) {
+    if (!strcmp(k, "usage_usec")) out[0] = v;
+    if (!strcmp(k, "throttled_usec")) out[1] = v;
+  }
+  fclose(f);
+}
+
 int main(int argc, char **argv) {
+  // rounds of the command-list combiner run on separate streams; the runtime maps streams onto this many hardware queues
+  // (default 4), and rounds that share a queue serialise: 8 queues measured +3..25 % (must be set before HIP starts)
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   if (argc < 6) { fprintf(stderr, "usage: %s n_docs n_words terms queries threads...\n", argv[0]); return 2; }
   const uint64_t n_docs = strtoull(argv[1], nullptr, 10);
   const uint32_t n_words = atoi(argv[2]), n_terms = atoi(argv[3]), n_queries = atoi(argv[4]);
@@ -259,6 +276,11 @@ int main(int argc, char **argv) {
   CK(msi_ctx_create(-1, &ctx));
   CK(msi_dict_create(ctx, concat.data(), offs.data(), (uint32_t)ix.words.size(), &dict));
   CK(msi_dict_set_microbatch(dict, 100, 64));
+  {
+    const char *mb = getenv("MSI_BENCH_PCACHE_MB");   // HBM posting cache of the index version; 0 = off
+    const uint64_t cap = (uint64_t)(mb ? atoll(mb) : 4096) << 20;
+    if (cap) CK(msi_dict_enable_posting_cache(dict, cap));
+  }
 #endif
 
   msi_index_vtable vt;
@@ -333,6 +355,12 @@ int main(int argc, char **argv) {
       CK(msi_bits_use_private_stream(p));
     }
 #endif
+    uint64_t vs0[6] = {0, 0, 0, 0, 0, 0}, vs1[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long cs0[2], cs1[2];
+    cpu_stat(cs0);
+#ifndef RANKED_BENCH_CPU
+    msi_bits_vm_stats(pools[0], vs0);
+#endif
     std::vector<std::vector<double>> lat(n_threads);
     std::vector<std::vector<uint64_t>> sums(n_threads, std::vector<uint64_t>(10, 0));
     const auto t0 = std::chrono::steady_clock::now();
@@ -355,19 +383,34 @@ int main(int argc, char **argv) {
       all.insert(all.end(), lat[t].begin(), lat[t].end());
       for (int k = 0; k < 10; ++k) tot[k] += sums[t][k];
     }
+    cpu_stat(cs1);
     std::sort(all.begin(), all.end());
     const double nq = (double)all.size();
+    uint64_t pc[4] = {0, 0, 0, 0};
+#ifndef RANKED_BENCH_CPU
+    msi_dict_posting_cache_stats(dict, pc);
+    msi_bits_vm_stats(pools[0], vs1);
+#endif
     printf("{\"config\": \"%s\", \"docs\": %llu, \"dictionary_words\": %u, \"terms\": %u, \"threads\": %d, "
            "\"queries\": %zu, \"queries_per_s\": %.1f, \"p50_ms\": %.3f, \"p99_ms\": %.3f, \"launches_per_query\": %.1f, "
            "\"waits_per_query\": %.1f, \"decode_batches_per_query\": %.1f, \"callbacks_per_query\": %.1f, "
-           "\"callback_us_per_query\": %.1f, \"device_wait_us_per_query\": %.1f}\n",
+           "\"callback_us_per_query\": %.1f, \"device_wait_us_per_query\": %.1f, \"posting_bytes_per_query\": %.0f, "
+           "\"posting_cache\": {\"hits\": %llu, \"misses\": %llu, \"bytes_used\": %llu}, "
+           "\"vm\": {\"rounds\": %llu, \"lists\": %llu, \"us_queued_per_list\": %.1f, \"us_packed_per_list\": %.1f, "
+           "\"us_launch_calls_per_round\": %.1f, \"us_after_launch_per_list\": %.1f}, "
+           "\"cpu\": {\"cpus_used\": %.2f, \"throttled_fraction_of_wall\": %.3f}}\n",
 #ifdef RANKED_BENCH_CPU
            "ranked_cpu_port",
 #else
            "ranked_native",
 #endif
            (unsigned long long)n_docs, n_words, n_terms, n_threads, all.size(), nq / dt, all[all.size() / 2],
-           all[(size_t)(all.size() * 0.99)], tot[0] / nq, tot[1] / nq, tot[2] / nq, tot[3] / nq, tot[7] / nq, tot[8] / nq);
+           all[(size_t)(all.size() * 0.99)], tot[0] / nq, tot[1] / nq, tot[2] / nq, tot[3] / nq, tot[7] / nq, tot[8] / nq, tot[4] / nq,
+           (unsigned long long)pc[0], (unsigned long long)pc[1], (unsigned long long)pc[2],
+           (unsigned long long)(vs1[0] - vs0[0]), (unsigned long long)(vs1[1] - vs0[1]), (vs1[2] - vs0[2]) / 1e3 / std::max<double>(1, vs1[1] - vs0[1]),
+           (vs1[3] - vs0[3]) / 1e3 / std::max<double>(1, vs1[1] - vs0[1]), (vs1[4] - vs0[4]) / 1e3 / std::max<double>(1, vs1[0] - vs0[0]),
+           (vs1[5] - vs0[5]) / 1e3 / std::max<double>(1, vs1[1] - vs0[1]),
+           (cs1[0] - cs0[0]) / 1e6 / dt, (cs1[1] - cs0[1]) / 1e6 / dt);
     fflush(stdout);
 #ifdef RANKED_BENCH_CPU
     for (auto &p : pools) mock_bits_destroy(p);
