@@ -65,6 +65,10 @@ def parse_args():
     ap.add_argument("--shard", choices=["queries", "rows"], default="queries")
     ap.add_argument("--no-typo", action="store_true")
     ap.add_argument("--no-rank", action="store_true", help="c4: leave the keyword leg and the hybrid merge out")
+    ap.add_argument("--kw-threads", type=int, default=96, help="c4: caller threads of the keyword leg (one in-flight search each)")
+    ap.add_argument("--kw-terms", type=int, default=3, help="c4: words per keyword query")
+    ap.add_argument("--kw-dict-words", type=int, default=200_000, help="c4: vocabulary of the synthetic inverted index")
+    ap.add_argument("--kw-cache-mb", type=int, default=8192, help="c4: HBM posting cache of the index version")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="also skips the parity check (same leg)")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child for roofline.traffic")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
@@ -286,41 +290,41 @@ def run_c4(args, env):
         two_t = torch.zeros((n_words_q, 50), dtype=torch.int32, device=dev)
         one_c = torch.zeros(n_words_q, dtype=torch.int32, device=dev)
         two_c = torch.zeros(n_words_q, dtype=torch.int32, device=dev)
-    # ---- keyword leg: Words -> Typo bucket sort over dense posting sets (batched kernel) ------------
-    # Every query has `words_per_query` terms (+ their 2-gram node); a term offers the documents matching it with
-    # 0 / 1 / 2 typos.  18 seeded random posting sets (densities 1 % / 0.2 % / 0.05 % of the documents, 0.01 % for
-    # n-grams) are shared by the queries in different combinations; all sets are resident in HBM, like the store.
-    rank_batch = None
-    R = None
+    # ---- keyword leg: msi_keyword_search_ranked, every rule of the default criteria ------------------------
+    # [words, typo, proximity, attributeRank, sort, wordPosition, exactness] over a synthetic inverted index of the same
+    # n documents (tools/ranked_bench.cpp: Zipf document frequencies, 3 searchable fields, bucketed positions, word pairs
+    # at proximities 1..3; postings handed over as the CboRoaringBitmap bytes milli stores, through the index vtable).
+    # Every search derives the typos of its words from the index's own dictionary on the device (micro-batched
+    # msi_dict_lookup) and those derivations are what its posting lists are read for.  `kw_threads` native caller
+    # threads, one in-flight search each (milli's spawn_blocking threads); their set operations share kernel launches
+    # (msi_vm.hip).  The queries are resident before the timed region like every other input: 4 x Q distinct queries
+    # cycle through the steps; each was run once in setup so that the SYNTHETIC index has generated its postings
+    # (index generation is not what is measured; nothing of a search's results is cached).
+    kw = None
     if not args.no_rank:
-        from meilisearch_amd import ranking as R
-        n_docs_rank = n_total if row_sharded else n
-        wpq = max(1, min(args.words_per_query, 3))
-        n_sets = 18
-        pool = ma.BitsPool(ctx, n_docs_rank, 1 + n_sets + 4 * Q)
-        pool.fill(0, True)
-        words64 = (n_docs_rank + 63) // 64
-        rng_r = np.random.default_rng(4242)
-        dens = [0.01, 0.002, 0.0005] * 5 + [0.0001] * 3
-        gbits = torch.Generator(device=dev)
-        gbits.manual_seed(4242)
-        for si in range(n_sets):
-            bits = (torch.rand((words64, 64), device=dev, generator=gbits) < dens[si])
-            weights = (2 ** torch.arange(0, 63, device=dev, dtype=torch.int64))
-            w = (bits[:, :63].to(torch.int64) * weights).sum(dim=1)
-            w = torch.where(bits[:, 63], w | torch.tensor(-2 ** 63, device=dev, dtype=torch.int64), w)
-            pool.set_from_words(1 + si, w.cpu().numpy().view(np.uint64))
-            del bits, w
-        rqueries = []
-        for qi in range(Q):
-            nodes = []
-            for ti in range(wpq):
-                base = 1 + 3 * int(rng_r.integers(0, 5))
-                nodes.append((ti, ti, base, base + 1, base + 2, 2 if rng_r.random() < 0.5 else 1))
-                if ti >= 1:
-                    nodes.append((ti - 1, ti, 1 + 15 + int(rng_r.integers(0, 3)), None, None, 1))
-            rqueries.append((nodes, wpq, 0, 1 + n_sets + 4 * qi))
-        rank_batch = R.RankBatch(pool, rqueries)
+        import ctypes as C
+        kw_lib = C.CDLL(os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so"))
+        kw_lib.rb_create.restype = C.c_void_p
+        kw_lib.rb_create.argtypes = [C.c_uint64, C.c_uint32]
+        kw_lib.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+        kw_lib.rb_prepare_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+        kw_lib.rb_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        kw_lib.rb_hybrid_merge.argtypes = [C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 4
+        kw_lib.rb_dict.restype = C.c_void_p
+        kw_lib.rb_dict.argtypes = [C.c_void_p]
+        kw_lib.rb_pool.restype = C.c_void_p
+        kw_lib.rb_pool.argtypes = [C.c_void_p, C.c_uint32]
+        kw_lib.rb_destroy.argtypes = [C.c_void_p]
+        n_docs_kw = n_total if row_sharded else n
+        h = kw_lib.rb_create(n_docs_kw, args.kw_dict_words)
+        assert kw_lib.rb_attach(h, ctx.handle, args.kw_threads, 1024, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
+        n_kw_queries = 4 * Q
+        kw_lib.rb_prepare_queries(h, n_kw_queries, args.kw_terms, 4242 + rank)
+        kw = {"lib": kw_lib, "h": h, "ids": np.zeros((Q, k), np.uint32), "n": np.zeros(Q, np.uint32),
+              "scores": np.zeros((Q, k), np.float64), "m_ids": np.zeros((Q, k), np.uint32), "m_sem": np.zeros((Q, k), np.uint8),
+              "m_cnt": np.zeros(Q, np.uint32), "m_hits": np.zeros(Q, np.uint32), "step": 0}
+        for first in range(0, n_kw_queries, Q):     # warm the synthetic index (and the posting cache) — untimed
+            assert kw_lib.rb_run(h, first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data) == 0
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
@@ -332,7 +336,6 @@ def run_c4(args, env):
         m_ids = torch.zeros((Q, k), dtype=torch.int32, device=dev)
         m_dist = torch.zeros((Q, k), dtype=torch.float32, device=dev)
         m_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
-    n_terms_arr = np.full(Q, max(1, min(args.words_per_query, 3)), dtype=np.uint32)
 
     def exchange():
         """The one exchange step: per-rank top-k lists (Q*(2k+1)*4 bytes) in one all-gather over xGMI (RCCL)."""
@@ -345,20 +348,30 @@ def run_c4(args, env):
         return (g[:, Q * k:2 * Q * k].reshape(world, Q, k), g[:, :Q * k].view(torch.float32).reshape(world, Q, k),
                 g[:, 2 * Q * k:].reshape(world, Q))
 
-    def keyword_and_merge(res):
-        if rank_batch is None:
-            return res
-        rank_batch.run(R.TERMS_LAST, True, 0, k)
-        merged = ma.scoring.hybrid_merge_batch(res[0].numpy().view(np.uint32), res[1].numpy(),
-                                               res[2].numpy().view(np.uint32), rank_batch.ids, rank_batch.words,
-                                               rank_batch.typos, rank_batch.maxt, rank_batch.counts, n_terms_arr,
-                                               0.5, 0, k)
-        return res + (merged,)
+    def keyword_run():
+        """The keyword leg of this step's Q queries (blocks until the caller threads are done; the vector scan enqueued
+        before it keeps the device busy meanwhile)."""
+        first = (kw["step"] * Q) % (4 * Q)
+        kw["step"] += 1
+        st = kw["lib"].rb_run(kw["h"], first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data)
+        assert st == 0, "msi_keyword_search_ranked failed"
+
+    def hybrid_merge(res):
+        """ScoreWithRatioResult::merge, semanticRatio 0.5, of every query's two lists."""
+        v_ids = np.ascontiguousarray(res[0].numpy().view(np.uint32))
+        v_dist = np.ascontiguousarray(res[1].numpy())
+        v_cnt = np.ascontiguousarray(res[2].numpy().view(np.uint32))
+        kw["lib"].rb_hybrid_merge(Q, k, v_ids.ctypes.data, v_dist.ctypes.data, v_cnt.ctypes.data, kw["ids"].ctypes.data,
+                                  kw["scores"].ctypes.data, kw["n"].ctypes.data, 0.5, kw["m_ids"].ctypes.data,
+                                  kw["m_sem"].ctypes.data, kw["m_cnt"].ctypes.data, kw["m_hits"].ctypes.data)
+        return res + ((kw["m_ids"], kw["m_sem"], kw["m_cnt"], kw["m_hits"]),)
 
     def step():
         store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
         if gdict is not None:
             gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
+        if kw is not None:
+            keyword_run()
         ctx.synchronize()
         if row_sharded:
             from meilisearch_amd.distributed import merge_topk_device
@@ -370,7 +383,8 @@ def run_c4(args, env):
             res = (out_ids.cpu(), out_dist.cpu(), out_cnt.cpu())   # what the Rust caller receives
         if gdict is not None:
             res += (one_c.cpu(), two_c.cpu(), one_t.cpu(), two_t.cpu())
-        res = keyword_and_merge(res)
+        if kw is not None:
+            res = hybrid_merge(res)
         if world > 1 and not row_sharded:
             exchange()
         return res
@@ -387,6 +401,24 @@ def run_c4(args, env):
     ctx.set_profiling(False)
     stats = store.stats()
     n_inexact = int(inexact.sum().item())
+    # the two legs on their own (untimed extras, 3 steps each): what bounds the step
+    legs = {}
+    if kw is not None and not env.child:
+        t0 = time.perf_counter()
+        for _ in range(3):
+            store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)
+            ctx.synchronize()
+        legs["vector_only_queries_per_s"] = round(3 * Q / (time.perf_counter() - t0), 1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            keyword_run()
+        legs["keyword_only_queries_per_s"] = round(3 * Q / (time.perf_counter() - t0), 1)
+        pc = (C.c_uint64 * 4)()
+        ma._lib.lib().msi_dict_posting_cache_stats(C.c_void_p(kw["lib"].rb_dict(kw["h"])), pc)
+        vs = (C.c_uint64 * 6)()
+        ma._lib.lib().msi_bits_vm_stats(C.c_void_p(kw["lib"].rb_pool(kw["h"], 0)), vs)
+        legs["keyword_posting_cache"] = {"hits": int(pc[0]), "misses": int(pc[1]), "bytes_used": int(pc[2])}
+        legs["keyword_lists_per_launch_round"] = round(vs[1] / max(1, vs[0]), 2)
     if rank != 0:
         return None
     total_queries = Q * (1 if row_sharded else world) * args.steps
@@ -415,15 +447,18 @@ def run_c4(args, env):
                         "queries sharded, index replicated per GPU, ONE packed all_gather of per-rank top-k (RCCL)",
             "step_includes": ["vs_scan + select + reference rescoring", "dict_lookup (scan of the first-letter range, "
                               "binary searches for the other first letters, cap logic)", "D2H of results"]
-                             + ([] if args.no_rank else ["Words->Typo bucket sort (batched, %d terms + n-grams per query)"
-                                                         % args.words_per_query, "hybrid merge (semanticRatio 0.5)"]),
-            "step_excludes": ["ranking-rule bucket sort", "hybrid merge"] if args.no_rank else
-                             ["ranking rules after Typo (measured on their own: tools/ranked_bench.cpp, DESIGN §4.7)"],
+                             + ([] if kw is None else [
+                                 "msi_keyword_search_ranked for every query: default criteria [words, typo, proximity, attributeRank, "
+                                 "sort, wordPosition, exactness], %d words per query, typo derivations from the index's %d-word "
+                                 "dictionary feeding the postings, %d caller threads" % (args.kw_terms, args.kw_dict_words, args.kw_threads),
+                                 "hybrid merge (semanticRatio 0.5) of the vector list with the keyword list (global scores)"]),
+            "step_excludes": ["keyword leg", "hybrid merge"] if kw is None else [],
             "inexact_queries_last_step": n_inexact,
             "setup_seconds": round(setup_s, 1),
         },
         "roofline": scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, "vs_scan_kernel (main pass)",
                                   must_contain=("false",)),
+        "legs": legs,
         "dict_lookup": {"launches_timed": match_n, "avg_launch_ms": round(match_ms / max(1, match_n), 4),
                         "words_per_launch": n_words_q,
                         "words_per_s_kernel_only": round(n_words_q / (match_ms / max(1, match_n) * 1e-3), 1) if match_n else None},
@@ -466,6 +501,25 @@ def run_c4(args, env):
             par["mismatches"] += tp["mismatches"]
         if not same:
             par["mismatches"] += 1
+        if kw is not None:
+            # keyword leg: the command-list back end against the direct back end (one launch per set operation) on this
+            # step's queries — the oracle-pinned replays of the ranked search (reference snapshots, random corpora vs
+            # oracle/ranking_oracle.py) are tests/test_search_gpu.py and friends; the synthetic index has no Python twin
+            keyword_run()
+            a_ids, a_n, a_sc = kw["ids"].copy(), kw["n"].copy(), kw["scores"].copy()
+            kw["step"] -= 1
+            os.environ["MSI_SEARCH_VM"] = "0"
+            keyword_run()
+            os.environ.pop("MSI_SEARCH_VM")
+            kbad = 0
+            for qi in range(Q):
+                m = int(a_n[qi])
+                if m != int(kw["n"][qi]) or a_ids[qi, :m].tolist() != kw["ids"][qi, :m].tolist() or \
+                        a_sc[qi, :m].tolist() != kw["scores"][qi, :m].tolist():
+                    kbad += 1
+            par["keyword"] = {"checked_queries": Q, "mismatches": kbad,
+                              "checker": "command-list back end vs direct back end (MSI_SEARCH_VM=0): docids and global scores identical"}
+            par["mismatches"] += kbad
         out["parity"] = par
     return out
 

@@ -224,6 +224,31 @@ int32_t msi_vs_debug_fast_scores(msi_vs *vs, const float *queries, uint32_t n_qu
  * profiling was enabled (HIP events on the launch stream); resets the counters. */
 int32_t msi_vs_scan_time(msi_vs *vs, uint64_t *out_launches, double *out_ms_total);
 
+/* ----------------------------------- S1': binary-quantised vector stores */
+/*
+ * A binary-quantised embedder (`binaryQuantized: true`) lives in arroy's BinaryQuantizedCosine / hannoy's Hamming
+ * databases (crates/milli/src/vector/store.rs:1095-1109): one sign bit per dimension.  msi_bq keeps those bits in HBM as
+ * bit planes (dim / 8 bytes per row and sweep: 32x less traffic than the f32 rows) and answers nns_by_vector exactly:
+ * the query is quantised like a row, rows are ranked by Hamming distance, ties by ascending docid, at most k <= 2048.
+ *   quantisation  bit = (x > 0) — PINNED by the reference (tests/vector/binary_quantized.rs:67-135: a stored
+ *                 [-1.2, -2.3, 3.2] reads back as [0, 0, 1]); msi_bq_get_vector returns that 0.0 / 1.0 form;
+ *   distance      out_dist = hamming / dim (the cosine distance (1 - cos)/2 of the +-1 vectors; hannoy's Hamming is the
+ *                 same count un-normalised) — restated from the crates' published definitions, NOT pinned by any
+ *                 literal of the reference: parity unpinned for the value, pinned for the order it induces only as far
+ *                 as both crates rank by the Hamming distance.
+ * docids strictly ascending as for msi_vs; filter_bits as in msi_vs_search.
+ */
+typedef struct msi_bq msi_bq;
+int32_t msi_bq_create(msi_ctx *ctx, uint32_t dim, msi_bq **out);
+void msi_bq_destroy(msi_bq *bq);
+int32_t msi_bq_upload(msi_bq *bq, const uint32_t *docids, const float *rows, uint64_t n_rows);
+int32_t msi_bq_upload_device(msi_bq *bq, const uint32_t *d_docids, const float *d_rows, uint64_t n_rows);
+uint64_t msi_bq_len(const msi_bq *bq);
+uint32_t msi_bq_dim(const msi_bq *bq);
+int32_t msi_bq_get_vector(msi_bq *bq, uint32_t docid, float *out_row, int32_t *out_found);
+int32_t msi_bq_search(msi_bq *bq, const float *queries, uint32_t n_queries, uint32_t k, const uint64_t *filter_bits,
+                      uint64_t filter_nbits, uint32_t *out_docids, float *out_dist, uint32_t *out_counts);
+
 /* --------------------------------------------- S2: typo-tolerant term lookup */
 /*
  * Replaces find_one_typo_derivations / find_one_two_typo_derivations
@@ -810,6 +835,30 @@ int32_t msi_hybrid_merge_batch(const uint32_t *v_docids, const float *v_dist,
                                uint32_t from, uint32_t length, uint32_t *out_docids,
                                uint8_t *out_is_semantic, uint32_t *out_counts,
                                uint32_t *out_semantic_hit_counts);
+/* Federated search merge (crates/meilisearch/src/search/federated/weighted_scores.rs:1-46, called from
+ * federated/perform.rs when the hits of several queries / indexes are interleaved): orders two hits by their
+ * WeightedScoreValue sequences (ScoreDetails::weighted_score_values, score_details.rs:177-199: the rank-based rules of a
+ * hit merged into local scores and multiplied by the query's federation weight; a semantic hit contributes
+ * VectorSort(similarity * weight)), falling back to the weighted GLOBAL scores when the sequences are not comparable.
+ * A value is {kind, asc, value}: kind 0 = WeightedScore / VectorSort (compared with the f64::EPSILON window of
+ * score_details.rs:61-67), 1 = Sort on a NUMBER (value = the number; asc = the rule's direction), 2 = GeoSort
+ * (value = distance, NaN = None).  String sort values do not cross this boundary (the shim compares them).
+ * Returns -1 / 0 / +1 for left <, ==, > right in the order "greater = ranks first" of weighted_scores::compare. */
+typedef struct msi_weighted_value {
+  uint32_t kind, asc;
+  double value;
+} msi_weighted_value;
+int32_t msi_federated_compare(const msi_weighted_value *left, uint32_t n_left, double left_weighted_global_score,
+                              const msi_weighted_value *right, uint32_t n_right, double right_weighted_global_score);
+/* Merge of `n_lists` result lists, each already in its own ranking order (perform.rs: merge_index_global_results'
+ * k-way merge by weighted_scores::compare): hit j of list l has values[val_off[l][j] .. val_off[l][j+1]) and a weighted
+ * global score; writes the first `limit` hits after `offset` as (list, position) pairs.  Device top-k lists (msi_vs /
+ * msi_bq output, similarity * weight as a single VectorSort value) and keyword hits (msi_keyword_search_ranked score
+ * details -> one WeightedScore per run of rank rules) feed it without another sort.  Returns the number written. */
+uint32_t msi_federated_merge(uint32_t n_lists, const uint32_t *list_len, const msi_weighted_value *const *values,
+                             const uint32_t *const *val_off, const double *const *weighted_global, uint32_t offset,
+                             uint32_t limit, uint32_t *out_list, uint32_t *out_pos);
+
 /* Search::results_good_enough (search/hybrid.rs:367-386). */
 int32_t msi_results_good_enough(const double *keyword_global_scores, uint32_t n,
                                 uint32_t limit_plus_offset, float semantic_ratio);

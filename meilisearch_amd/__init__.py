@@ -7,7 +7,7 @@ a machine without the built library or without a gfx950 device raises.
 """
 from ._lib import MsiError, abi_version, lib, lib_path  # noqa: F401
 from .device import Context, DeviceBuffer  # noqa: F401
-from .vector_store import GpuStore, VectorStore, dense_filter  # noqa: F401
+from .vector_store import GpuBqStore, GpuStore, VectorStore, dense_filter  # noqa: F401
 from .typo import GpuDictionary, number_of_typos_allowed, pack_queries  # noqa: F401
 from .bits import BitsPool, DocKeys, DocValues, FacetKeys, GeoPoints, facet_number_key  # noqa: F401
 from . import scoring  # noqa: F401

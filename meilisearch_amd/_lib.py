@@ -166,6 +166,16 @@ PROTOTYPES = {
     "msi_vs_get_stats": (_I32, [_VP, C.POINTER(VsStats)]),
     "msi_vs_debug_fast_scores": (_I32, [_VP, _VP, _U32, _VP, C.POINTER(_F32)]),
     "msi_vs_scan_time": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_F64)]),
+    "msi_bq_create": (_I32, [_VP, _U32, C.POINTER(_VP)]),
+    "msi_bq_destroy": (None, [_VP]),
+    "msi_bq_upload": (_I32, [_VP, _VP, _VP, _U64]),
+    "msi_bq_upload_device": (_I32, [_VP, _VP, _VP, _U64]),
+    "msi_bq_len": (_U64, [_VP]),
+    "msi_bq_dim": (_U32, [_VP]),
+    "msi_bq_get_vector": (_I32, [_VP, _U32, _VP, C.POINTER(_I32)]),
+    "msi_bq_search": (_I32, [_VP, _VP, _U32, _U32, _VP, _U64, _VP, _VP, _VP]),
+    "msi_federated_compare": (_I32, [_VP, _U32, _F64, _VP, _U32, _F64]),
+    "msi_federated_merge": (_U32, [_U32, _VP, _VP, _VP, _VP, _U32, _U32, _VP, _VP]),
     "msi_dict_create": (_I32, [_VP, _VP, _VP, _U32, C.POINTER(_VP)]),
     "msi_dict_destroy": (None, [_VP]),
     "msi_dict_len": (_U32, [_VP]),

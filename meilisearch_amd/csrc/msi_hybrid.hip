@@ -131,3 +131,89 @@ int32_t msi_results_good_enough(const double *keyword_global_scores, uint32_t n,
 }
 
 }  // extern "C"
+
+// ---- federated merge (crates/meilisearch/src/search/federated/weighted_scores.rs:1-46) ------------------------------
+namespace {
+// WeightedScoreValue::partial_cmp (score_details.rs:57-101): 2 = not comparable
+int weighted_cmp(const msi_weighted_value &l, const msi_weighted_value &r) {
+  if (l.kind == 0 && r.kind == 0) {
+    if (fabs(l.value - r.value) <= 2.220446049250313e-16) return 0;
+    return l.value < r.value ? -1 : 1;
+  }
+  if (l.kind == 1 && r.kind == 1) {
+    if (l.asc != r.asc) return 2;
+    // compare_sort_values (score_details.rs:576-620): Null (NaN here) is below everything; ascending rules rank the
+    // smaller value first, i.e. it is the "greater" hit
+    const bool ln = l.value != l.value, rn = r.value != r.value;
+    if (ln || rn) return ln && rn ? 0 : (ln ? -1 : 1);
+    if (l.value == r.value) return 0;
+    const int c = l.value < r.value ? -1 : 1;
+    return l.asc ? -c : c;
+  }
+  if (l.kind == 2 && r.kind == 2) {
+    if (l.asc != r.asc) return 2;
+    const bool ln = l.value != l.value, rn = r.value != r.value;   // None
+    if (ln && rn) return 0;
+    if (ln) return -1;
+    if (rn) return 1;
+    if (fabs(l.value - r.value) <= 2.220446049250313e-16) return 0;
+    return l.value < r.value ? -1 : 1;
+  }
+  return 2;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t msi_federated_compare(const msi_weighted_value *left, uint32_t n_left, double left_weighted_global_score,
+                              const msi_weighted_value *right, uint32_t n_right, double right_weighted_global_score) {
+  uint32_t i = 0;
+  for (;; ++i) {   // compare_partial
+    const bool hl = i < n_left, hr = i < n_right;
+    if (!hl && !hr) return 0;
+    if (!hl) return -1;
+    if (!hr) return 1;
+    const int c = weighted_cmp(left[i], right[i]);
+    if (c == 0) continue;
+    if (c != 2) return c;
+    // not comparable: the side with more remaining groups of rules wins; equal -> the weighted global scores decide
+    const uint32_t lc = n_left - i - 1, rc = n_right - i - 1;
+    if (lc != rc) return lc < rc ? -1 : 1;
+    break;
+  }
+  if (left_weighted_global_score == right_weighted_global_score) return 0;
+  return left_weighted_global_score < right_weighted_global_score ? -1 : 1;
+}
+
+uint32_t msi_federated_merge(uint32_t n_lists, const uint32_t *list_len, const msi_weighted_value *const *values,
+                             const uint32_t *const *val_off, const double *const *weighted_global, uint32_t offset,
+                             uint32_t limit, uint32_t *out_list, uint32_t *out_pos) {
+  std::vector<uint32_t> at(n_lists, 0);
+  uint32_t produced = 0, written = 0;
+  while (written < limit) {
+    int best = -1;
+    for (uint32_t l = 0; l < n_lists; ++l) {
+      if (at[l] >= list_len[l]) continue;
+      if (best < 0) {
+        best = (int)l;
+        continue;
+      }
+      const uint32_t a = at[best], b = at[l];
+      const int c = msi_federated_compare(values[l] + val_off[l][b], val_off[l][b + 1] - val_off[l][b], weighted_global[l][b],
+                                          values[best] + val_off[best][a], val_off[best][a + 1] - val_off[best][a],
+                                          weighted_global[best][a]);
+      if (c > 0) best = (int)l;   // strictly better only: equal hits keep the order of the lists (a stable merge)
+    }
+    if (best < 0) break;
+    if (produced >= offset) {
+      out_list[written] = (uint32_t)best;
+      out_pos[written] = at[best];
+      ++written;
+    }
+    ++produced;
+    ++at[best];
+  }
+  return written;
+}
+
+}  // extern "C"

@@ -162,6 +162,60 @@ class GpuStore:
             pass
 
 
+class GpuBqStore:
+    """One binary-quantised vector store resident in HBM (msi_bq: sign bits as bit planes, exact Hamming k-NN)."""
+
+    def __init__(self, ctx, dim):
+        self.ctx, self.dim = ctx, int(dim)
+        self._h = C.c_void_p()
+        check(lib().msi_bq_create(ctx.handle, self.dim, C.byref(self._h)))
+
+    def upload(self, docids, rows):
+        docids = np.ascontiguousarray(docids, dtype=np.uint32)
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.dim)
+        assert rows.shape[0] == docids.shape[0]
+        check(lib().msi_bq_upload(self._h, np_ptr(docids), np_ptr(rows), docids.shape[0]))
+
+    def upload_device(self, docids_t, rows_t):
+        import torch
+        torch.cuda.current_stream(rows_t.device).synchronize()
+        check(lib().msi_bq_upload_device(self._h, C.c_void_p(docids_t.data_ptr()), C.c_void_p(rows_t.data_ptr()), rows_t.shape[0]))
+
+    def __len__(self):
+        return int(lib().msi_bq_len(self._h))
+
+    def get_vector(self, docid):
+        out = np.zeros(self.dim, dtype=np.float32)
+        found = C.c_int32(0)
+        check(lib().msi_bq_get_vector(self._h, int(docid), np_ptr(out), C.byref(found)))
+        return out if found.value else None
+
+    def search(self, queries, k, filter_bits=None, filter_nbits=0):
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        b = q.shape[0]
+        out_d = np.full((b, max(k, 1)), 0xFFFFFFFF, dtype=np.uint32)
+        out_s = np.full((b, max(k, 1)), np.inf, dtype=np.float32)
+        cnt = np.zeros(b, dtype=np.uint32)
+        fb = None
+        if filter_bits is not None:
+            fb = np.ascontiguousarray(filter_bits, dtype=np.uint64)
+            if not filter_nbits:
+                filter_nbits = 64 * fb.size
+        check(lib().msi_bq_search(self._h, np_ptr(q), b, k, np_ptr(fb), filter_nbits, np_ptr(out_d), np_ptr(out_s), np_ptr(cnt)))
+        return out_d[:, :k], out_s[:, :k], cnt
+
+    def close(self):
+        if self._h:
+            lib().msi_bq_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class VectorStore:
     """Mirror of milli's `VectorStore` for one embedder (store.rs:29-130).
 

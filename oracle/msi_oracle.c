@@ -306,3 +306,36 @@ void orc_typo_lookup(const uint8_t *words, const uint32_t *off, uint32_t n_words
     }
   }
 }
+
+/* ---- binary-quantised stores ------------------------------------------------------------------
+ * Quantisation: bit = (x > 0) — pinned by crates/meilisearch/tests/vector/binary_quantized.rs:67-135 (a stored
+ * [-1.2, -2.3, 3.2] reads back as [0, 0, 1]).  Distance: hamming(sign bits of the query, sign bits of the row) / dim —
+ * restated from the published definitions of hannoy `Hamming` / arroy `BinaryQuantizedCosine` (third-party crates that
+ * are not under /root/reference; no test of the reference holds a distance value): PARITY UNPINNED for the distance.
+ * Order: (distance, docid) ascending, as the f32 stores. */
+void orc_bq_topk(const float *rows, const uint32_t *docids, uint64_t n, uint32_t dim, const float *q, uint32_t k,
+                 const uint64_t *filter_bits, uint64_t filter_nbits, uint32_t *out_docids, float *out_dist,
+                 uint32_t *out_cnt) {
+  uint32_t *best_h = (uint32_t *)malloc(sizeof(uint32_t) * (k ? k : 1));
+  uint32_t cnt = 0;
+  for (uint64_t r = 0; r < n; ++r) {
+    const uint32_t id = docids[r];
+    if (filter_bits && !(id < filter_nbits && ((filter_bits[id >> 6] >> (id & 63)) & 1ull))) continue;
+    uint32_t h = 0;
+    for (uint32_t c = 0; c < dim; ++c) h += (rows[r * dim + c] > 0.0f) != (q[c] > 0.0f);
+    /* insertion by (h, docid) */
+    if (cnt == k && !(h < best_h[k - 1] || (h == best_h[k - 1] && id < out_docids[k - 1]))) continue;
+    uint32_t pos = cnt < k ? cnt : k - 1;
+    while (pos > 0 && (h < best_h[pos - 1] || (h == best_h[pos - 1] && id < out_docids[pos - 1]))) {
+      best_h[pos] = best_h[pos - 1];
+      out_docids[pos] = out_docids[pos - 1];
+      --pos;
+    }
+    best_h[pos] = h;
+    out_docids[pos] = id;
+    if (cnt < k) ++cnt;
+  }
+  for (uint32_t i = 0; i < cnt; ++i) out_dist[i] = (float)best_h[i] / (float)dim;
+  *out_cnt = cnt;
+  free(best_h);
+}

@@ -51,6 +51,8 @@ def lib():
         L.orc_typo_lookup.restype = None
         L.orc_typo_lookup.argtypes = [u8p, u32p, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_int,
                                       C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p]
+        L.orc_bq_topk.restype = None
+        L.orc_bq_topk.argtypes = [f32p, u32p, C.c_uint64, C.c_uint32, f32p, C.c_uint32, u64p, C.c_uint64, u32p, f32p, u32p]
         _LIB = L
     return _LIB
 
@@ -155,3 +157,21 @@ def typo_lookup(dic, word, max_typos, is_prefix, cap_one=150, cap_two=50):
                           cap_two, _p(one, C.c_uint32), C.byref(n1), _p(two, C.c_uint32),
                           C.byref(n2))
     return one[:n1.value].copy(), two[:n2.value].copy()
+
+
+def bq_topk(rows, docids, q, k, filter_bits=None, filter_nbits=0):
+    """Exact top-k of a binary-quantised store (orc_bq_topk: bit = x > 0, distance = hamming / dim, (distance, docid))."""
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    docids = np.ascontiguousarray(docids, dtype=np.uint32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    n, d = rows.shape if rows.ndim == 2 else (0, q.size)
+    out_d = np.zeros(max(k, 1), dtype=np.uint32)
+    out_s = np.zeros(max(k, 1), dtype=np.float32)
+    cnt = C.c_uint32(0)
+    fb = None
+    if filter_bits is not None:
+        filter_bits = np.ascontiguousarray(filter_bits, dtype=np.uint64)
+        fb = _p(filter_bits, C.c_uint64)
+    lib().orc_bq_topk(_p(rows, C.c_float), _p(docids, C.c_uint32), n, d, _p(q, C.c_float), k, fb, filter_nbits,
+                      _p(out_d, C.c_uint32), _p(out_s, C.c_float), C.byref(cnt))
+    return out_d[:cnt.value].copy(), out_s[:cnt.value].copy()

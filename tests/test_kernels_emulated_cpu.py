@@ -21,8 +21,8 @@ NEEDS_TORCH_CUDA = ("row_sharded_search_with_device_merge or bits_as_vector_filt
 
 GROUPS = {
     # name: (files, -k expression, minimum number of tests that must have run)
-    "vector-scan": (["tests/test_vs_gpu.py", "tests/test_zzz_vs_update_gpu.py"],
-                    "not 70000 and not 40000 and not three_query_tiles and not large_scan and not large_k", 25),
+    "vector-scan": (["tests/test_vs_gpu.py", "tests/test_zzz_vs_update_gpu.py", "tests/test_zz_bq_gpu.py"],
+                    "not 70000 and not 40000 and not 20000 and not three_query_tiles and not large_scan and not large_k", 32),
     "dictionary": (["tests/test_dict_gpu.py", "tests/test_zz_fst_gpu.py"], "not synthetic_dictionary_all_paths", 12),
     "docid-sets": (["tests/test_bits_gpu.py", "tests/test_zz_order_keys_gpu.py::test_order_next_against_numpy",
                     "tests/test_zzz_distinct_gpu.py::test_distinct_against_the_sequential_loop",
@@ -37,8 +37,8 @@ GROUPS = {
                        "tests/test_zzz_distinct_gpu.py::test_reference_typo_tolerance_and_phrase_integration_tests_on_the_device",
                        "tests/test_zzz_distinct_gpu.py::test_concurrent_searches_with_distinct_sort_and_geo",
                        "tests/test_zzz_geo_gpu.py::test_geo_sort_rs_on_the_device",
-                       "tests/test_zz_levels_per_wait_gpu.py"],
-                      "not matches_oracle_on_random_corpora and not random_corpora_with_levels and not under_index_settings", 99),
+                       "tests/test_zz_levels_per_wait_gpu.py", "tests/test_zz_vm_gpu.py"],
+                      "not matches_oracle_on_random_corpora and not random_corpora_with_levels and not under_index_settings", 101),
     "ranked-search-vs-oracle": (["tests/test_zzz_distinct_gpu.py::test_distinct_matches_the_oracle_on_the_device",
                                  "tests/test_zzz_geo_gpu.py::test_geo_sort_matches_the_oracle_on_the_device",
                                  "tests/test_zz_order_keys_gpu.py::test_sort_rules_match_the_oracle_on_the_device"], "", 3),

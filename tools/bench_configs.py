@@ -149,6 +149,32 @@ def run_c3(args):
         print(json.dumps(out), flush=True)
 
 
+def run_bq(args):
+    """exact Hamming k-NN over a binary-quantised store (`rows` x `dim`, sign bits as bit planes in HBM):
+    milliseconds per batch of 32 queries, queries/s and the fraction of the HBM roofline of the three sweeps a batch
+    makes over the dim/8-byte rows."""
+    import torch
+    import meilisearch_amd as ma
+    from meilisearch_amd import synth
+    dev = torch.device("cuda", 0)
+    ctx = ma.Context(0)
+    n, d, k = args.rows, args.dim, args.k
+    rows = synth.device_rows(n, d, dev, seed=1234)
+    ids = torch.arange(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    st = ma.GpuBqStore(ctx, d)
+    st.upload_device(ids, rows)
+    del rows
+    q = synth.device_queries(64, d, dev, seed=5678).cpu().numpy()
+    for B in (1, 32, 64):
+        ms, p50 = timed(lambda: st.search(q[:B], k), lambda: None, args.reps)
+        sweeps = 3 * ((B + 31) // 32)
+        by = sweeps * n * ((d + 63) // 64) * 8
+        print(json.dumps({"config": "bq", "rows": n, "dim": d, "k": k, "batch": B, "ms_per_batch": round(ms, 4), "p50_ms": round(p50, 4),
+                          "qps": round(B / ms * 1e3, 1), "store_MB": round(n * ((d + 63) // 64) * 8 / 1e6, 1),
+                          "algorithmic_GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / 8000, 4)}), flush=True)
+
+
 def run_filtered(args):
     """Filtered vector search (the C5 shape on one GPU's shard, f32): random candidate
     bitsets of 10 % / 1 % / 0.1 % of the documents, resident in HBM (msi_bits slot), 48
@@ -517,7 +543,7 @@ def run_update(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered", "c5", "ranked", "rules", "update"])
+    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered", "c5", "ranked", "rules", "update", "bq"])
     ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--rows", type=int, default=1_000_000)
@@ -533,7 +559,7 @@ def main():
     if args.batches is None:
         args.batches = [1, 16, 48, 240] if args.config != "c3" else [1, 64, 1024, 8192]
     {"c2": run_c2, "c3": run_c3, "rank": run_rank, "filtered": run_filtered, "c5": run_c5, "ranked": run_ranked,
-     "rules": run_rules, "update": run_update}[args.config](args)
+     "rules": run_rules, "update": run_update, "bq": run_bq}[args.config](args)
 
 
 if __name__ == "__main__":

@@ -223,6 +223,7 @@ static int32_t cpu_lookup(const uint8_t *w, uint32_t n, uint32_t max_typos, uint
 
 }  // namespace
 
+#ifndef RANKED_BENCH_LIB
 // cgroup v2 CPU accounting of this container: {usage_usec, throttled_usec}
 static void cpu_stat(unsigned long long out[2]) {
   out[0] = out[1] = 0;
@@ -426,3 +427,198 @@ int main(int argc, char **argv) {
 #endif
   return 0;
 }
+#endif  // !RANKED_BENCH_LIB
+
+#ifdef RANKED_BENCH_LIB
+// ---- the same synthetic index and caller threads as a library: bench.py's keyword leg (hipcc ... -DRANKED_BENCH_LIB -shared) ----
+#include <condition_variable>
+#include <cmath>
+namespace {
+struct Runner {
+  Index ix;
+  std::vector<std::string> frequent;
+  msi_ctx *ctx = nullptr;
+  msi_dict *dict = nullptr;
+  msi_index_vtable vt;
+  msi_search_params prm;
+  int32_t criteria[7];
+  uint16_t fids[3], weights[3];
+  std::vector<msi_bits *> pools;
+  std::vector<std::vector<std::string>> queries;
+  // worker pool
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  uint64_t epoch = 0;
+  uint32_t job_first = 0, job_n = 0, job_limit = 0, next = 0, done = 0;
+  uint32_t *out_ids = nullptr, *out_n = nullptr;
+  double *out_scores = nullptr;
+  bool stop = false;
+  std::atomic<int32_t> failed{0};
+
+  int32_t search(msi_bits *pool, const std::vector<std::string> &q, uint32_t limit, uint32_t *ids, uint32_t *n, double *scores) {
+    std::vector<msi_query_token> toks(q.size());
+    std::vector<msi_located_term> terms(q.size());
+    for (size_t i = 0; i < q.size(); ++i) {
+      toks[i] = msi_query_token{(const uint8_t *)q[i].data(), (uint32_t)q[i].size(), i + 1 == q.size() ? 1u : 0u};
+      terms[i] = msi_located_term{&toks[i], 1, 0, (uint32_t)i, (uint32_t)i};
+    }
+    msi_search_params p = prm;
+    p.length = limit;
+    std::vector<msi_score_detail> sc((size_t)limit * MSI_MAX_SCORE_DETAILS);
+    std::vector<uint32_t> nsc(limit);
+    uint64_t cand = 0;
+    const int32_t st = msi_keyword_search_ranked(dict, pool, &vt, terms.data(), (uint32_t)terms.size(), &p, nullptr, 0, ids, sc.data(),
+                                                 nsc.data(), n, &cand, nullptr);
+    if (st != MSI_OK) return st;
+    for (uint32_t i = 0; i < *n; ++i) scores[i] = msi_score_details_global_score(sc.data() + (size_t)i * MSI_MAX_SCORE_DETAILS, nsc[i]);
+    return MSI_OK;
+  }
+  void work(size_t t) {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || epoch != seen; });
+        if (stop) return;
+        seen = epoch;
+      }
+      for (;;) {
+        uint32_t i;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (next >= job_n) break;
+          i = next++;
+        }
+        const std::vector<std::string> &q = queries[(job_first + i) % queries.size()];
+        if (search(pools[t], q, job_limit, out_ids + (size_t)i * job_limit, out_n + i, out_scores + (size_t)i * job_limit) != MSI_OK) failed.store(1);
+        std::lock_guard<std::mutex> lk(mu);
+        if (++done == job_n) cv_done.notify_all();
+      }
+    }
+  }
+};
+}  // namespace
+
+extern "C" {
+void *rb_create(uint64_t n_docs, uint32_t n_words) {
+  Runner *r = new Runner();
+  r->ix.n_docs = n_docs;
+  std::mt19937_64 g(99);
+  std::map<std::string, int> seen;
+  const char *letters = "etaoinshrdlcumwfgypbvkjxqz";
+  while (seen.size() < n_words) {
+    const int len = 4 + (int)(g() % 6);
+    std::string w;
+    for (int i = 0; i < len; ++i) w.push_back(letters[(size_t)(std::pow((double)(g() % 10000) / 10000.0, 1.7) * 26)]);
+    seen[w] = 1;
+  }
+  for (auto &kv : seen) r->ix.words.push_back(kv.first);
+  std::vector<std::string> perm = r->ix.words;
+  std::shuffle(perm.begin(), perm.end(), g);
+  for (uint32_t i = 0; i < perm.size(); ++i) r->ix.rank[perm[i]] = i;
+  r->frequent.resize(300);
+  for (auto &kv : r->ix.rank) if (kv.second < 300) r->frequent[kv.second] = kv.first;
+  return r;
+}
+// dictionary + posting cache + one pool (private stream) and one caller thread per in-flight search
+int32_t rb_attach(void *h, msi_ctx *ctx, uint32_t n_threads, uint32_t n_slots, uint64_t cache_mb) {
+  Runner *r = (Runner *)h;
+  r->ctx = ctx;
+  std::vector<uint8_t> concat;
+  std::vector<uint32_t> offs{0};
+  for (auto &w : r->ix.words) { concat.insert(concat.end(), w.begin(), w.end()); offs.push_back((uint32_t)concat.size()); }
+  int32_t st = msi_dict_create(ctx, concat.data(), offs.data(), (uint32_t)r->ix.words.size(), &r->dict);
+  if (st != MSI_OK) return st;
+  msi_dict_set_microbatch(r->dict, 100, 64);
+  if (cache_mb && (st = msi_dict_enable_posting_cache(r->dict, cache_mb << 20)) != MSI_OK) return st;
+  memset(&r->vt, 0, sizeof(r->vt));
+  r->vt.user = &r->ix;
+  r->vt.word_docids = cb_word;
+  r->vt.word_pair_proximity_docids = cb_pair;
+  r->vt.is_exact_word = cb_exact;
+  r->vt.word_fid_docids = cb_fid;
+  r->vt.word_position_docids = cb_pos;
+  r->vt.word_fids = cb_fids;
+  r->vt.word_positions = cb_positions;
+  r->vt.field_id_word_count_docids = cb_count;
+  const int32_t crit[7] = {MSI_CRIT_WORDS, MSI_CRIT_TYPO, MSI_CRIT_PROXIMITY, MSI_CRIT_ATTRIBUTE_RANK, MSI_CRIT_SORT,
+                           MSI_CRIT_WORD_POSITION, MSI_CRIT_EXACTNESS};
+  memcpy(r->criteria, crit, sizeof(crit));
+  r->fids[0] = 1; r->fids[1] = 2; r->fids[2] = 3;
+  r->weights[0] = 0; r->weights[1] = 1; r->weights[2] = 2;
+  memset(&r->prm, 0, sizeof(r->prm));
+  r->prm.authorize_typos = 1;
+  r->prm.min_word_len_one_typo = 5;
+  r->prm.min_word_len_two_typos = 9;
+  r->prm.strategy = MSI_TERMS_LAST;
+  r->prm.criteria = r->criteria;
+  r->prm.n_criteria = 7;
+  r->prm.searchable_fids = r->fids;
+  r->prm.searchable_weights = r->weights;
+  r->prm.n_searchable = 3;
+  r->prm.max_weight = 2;
+  r->prm.detailed_scores = 1;
+  r->prm.stop_after = -1;
+  r->pools.resize(n_threads, nullptr);
+  for (auto &p : r->pools) {
+    if ((st = msi_bits_create(ctx, r->ix.n_docs, n_slots, &p)) != MSI_OK) return st;
+    if ((st = msi_bits_use_private_stream(p)) != MSI_OK) return st;
+  }
+  for (uint32_t t = 0; t < n_threads; ++t) r->workers.emplace_back([r, t] { r->work(t); });
+  return MSI_OK;
+}
+// n_queries queries of n_terms frequent words each (seeded); every one is run once so that the synthetic index has
+// generated the postings it needs (index generation is not what is measured)
+int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed) {
+  Runner *r = (Runner *)h;
+  std::mt19937_64 g(seed);
+  r->queries.assign(n_queries, {});
+  for (auto &q : r->queries) for (uint32_t i = 0; i < n_terms; ++i) q.push_back(r->frequent[g() % 300]);
+  return MSI_OK;
+}
+int32_t rb_run(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores) {
+  Runner *r = (Runner *)h;
+  if (!n || r->queries.empty()) return MSI_E_INVALID;
+  std::unique_lock<std::mutex> lk(r->mu);
+  r->job_first = first; r->job_n = n; r->job_limit = limit; r->next = 0; r->done = 0;
+  r->out_ids = out_ids; r->out_n = out_n; r->out_scores = out_scores;
+  ++r->epoch;
+  r->cv.notify_all();
+  r->cv_done.wait(lk, [&] { return r->done == n; });
+  return r->failed.load() ? MSI_E_INTERNAL : MSI_OK;
+}
+// ScoreWithRatioResult::merge (search/hybrid.rs:102-235) of every query's vector list (similarity = 1 - distance) with
+// its keyword list (ScoreDetails::global_score of each hit), semantic_ratio on the vector side: native loop over
+// msi_hybrid_merge so that the bench step does not pay a Python call per query.
+int32_t rb_hybrid_merge(uint32_t n_queries, uint32_t k, const uint32_t *v_ids, const float *v_dist, const uint32_t *v_cnt,
+                        const uint32_t *k_ids, const double *k_scores, const uint32_t *k_cnt, float semantic_ratio,
+                        uint32_t *out_ids, uint8_t *out_is_semantic, uint32_t *out_cnt, uint32_t *out_semantic_hits) {
+  std::vector<double> vs(k);
+  std::vector<uint32_t> off(k + 1);
+  for (uint32_t i = 0; i <= k; ++i) off[i] = i;
+  for (uint32_t q = 0; q < n_queries; ++q) {
+    const uint32_t nv = std::min(v_cnt[q], k), nk = std::min(k_cnt[q], k);
+    for (uint32_t i = 0; i < nv; ++i) vs[i] = 1.0 - (double)v_dist[(size_t)q * k + i];
+    out_cnt[q] = msi_hybrid_merge(v_ids + (size_t)q * k, vs.data(), off.data(), nv, semantic_ratio, k_ids + (size_t)q * k,
+                                  k_scores + (size_t)q * k, off.data(), nk, 1.0f - semantic_ratio, 0, k, out_ids + (size_t)q * k,
+                                  out_is_semantic + (size_t)q * k, out_semantic_hits + q);
+  }
+  return MSI_OK;
+}
+msi_dict *rb_dict(void *h) { return ((Runner *)h)->dict; }
+msi_bits *rb_pool(void *h, uint32_t t) { return ((Runner *)h)->pools[t]; }
+void rb_destroy(void *h) {
+  Runner *r = (Runner *)h;
+  {
+    std::lock_guard<std::mutex> lk(r->mu);
+    r->stop = true;
+  }
+  r->cv.notify_all();
+  for (auto &t : r->workers) t.join();
+  for (auto &p : r->pools) if (p) msi_bits_destroy(p);
+  if (r->dict) msi_dict_destroy(r->dict);
+  delete r;
+}
+}
+#endif  // RANKED_BENCH_LIB
