@@ -337,13 +337,32 @@ def run_c4(args, env):
         m_dist = torch.zeros((Q, k), dtype=torch.float32, device=dev)
         m_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
 
+    # the exchange runs through libmsi's own multi-GPU entry points (RCCL inside the library: msi_group_create_rank +
+    # msi_group_allgather); rank 0's communicator id reaches the other ranks through the launcher's process group
+    group = None
+    if world > 1:
+        import ctypes as C
+        L = ma._lib.lib()
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            ma._lib.check(L.msi_group_unique_id(buf))
+            uid.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+        env.dist.broadcast(uid, 0)
+        buf = (C.c_uint8 * 128)(*uid.cpu().tolist())
+        group = C.c_void_p()
+        ma._lib.check(L.msi_group_create_rank(ctx.handle, rank, world, buf, C.byref(group)))
+
     def exchange():
-        """The one exchange step: per-rank top-k lists (Q*(2k+1)*4 bytes) in one all-gather over xGMI (RCCL)."""
+        """The one exchange step: per-rank top-k lists (Q*(2k+1)*4 bytes) in ONE all-gather over xGMI — RCCL called by
+        libmsi on the context's stream, in order with the searches that filled the lists."""
         packed[:Q * k].copy_(out_dist.view(torch.int32).reshape(-1))
         packed[Q * k:2 * Q * k].copy_(out_ids.reshape(-1))
         packed[2 * Q * k:].copy_(out_cnt)
-        env.dist.all_gather_into_tensor(gathered, packed)
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream().synchronize()      # the packing ran on torch's stream
+        ma._lib.check(ma._lib.lib().msi_group_allgather(group, C.c_void_p(packed.data_ptr()), packed.numel() * 4,
+                                                        C.c_void_p(gathered.data_ptr())))
+        ctx.synchronize()
         g = gathered.view(world, Q * (2 * k + 1))
         return (g[:, Q * k:2 * Q * k].reshape(world, Q, k), g[:, :Q * k].view(torch.float32).reshape(world, Q, k),
                 g[:, 2 * Q * k:].reshape(world, Q))
@@ -444,7 +463,7 @@ def run_c4(args, env):
                          " + exact f32 reference rescoring of K' candidates with an exactness proof",
             "sharding": ("rows sharded (%d per GPU of %d), same query batch on every GPU, ONE packed all_gather of "
                          "per-shard top-k (RCCL) + device k-way merge" % (n, n_total)) if row_sharded else
-                        "queries sharded, index replicated per GPU, ONE packed all_gather of per-rank top-k (RCCL)",
+                        "queries sharded, index replicated per GPU, ONE packed all-gather of per-rank top-k (RCCL called inside libmsi: msi_group_allgather)",
             "step_includes": ["vs_scan + select + reference rescoring", "dict_lookup (scan of the first-letter range, "
                               "binary searches for the other first letters, cap logic)", "D2H of results"]
                              + ([] if kw is None else [

@@ -207,6 +207,40 @@ int32_t msi_merge_topk_device(msi_ctx *ctx, const uint32_t *d_docids, const floa
                               uint32_t k, uint32_t *d_out_docids, float *d_out_dist,
                               uint32_t *d_out_counts);
 
+/* ---------------------------------------------------------------- multi-GPU (SURVEY §8 e) */
+/*
+ * The reference is ONE server process fanning searches out from spawn_blocking threads
+ * (crates/meilisearch/src/search/federated/perform.rs:224): the multi-device entry points are part of this ABI.
+ * msi_group_create: one context per device of `devices` + one RCCL communicator per device (ncclCommInitAll) — the
+ * in-process form.  msi_group_create_rank: the one-process-per-GPU form (bench.py under torchrun): rank 0 obtains
+ * msi_group_unique_id(), the launcher hands the 128 bytes to every rank, each rank joins with its own context.
+ * RCCL is loaded with dlopen here: a box without librccl.so gets MSI_E_UNSUPPORTED from these calls and nothing else
+ * changes.
+ * msi_vs_group (in-process): MSI_GROUP_REPLICATE — every device holds all rows and answers its slice of a query
+ * batch, no exchange step (query sharding, the default for stores that fit one GPU: 10 M x 768 f32 = 31 GB of 288);
+ * MSI_GROUP_SHARD_ROWS — contiguous row ranges per device, every device scans its rows for the whole batch, ONE
+ * ncclAllGather of the packed per-device lists ({distance, docid}[B][k] + counts[B]) over xGMI, k-way merge on the
+ * device (msi_merge_topk_device): the concatenate + sort_unstable_by_key of store.rs:1059,1090.  devices x k <= 2048.
+ * Results are identical to a single-device store holding all the rows (tie rule included) in both modes.
+ * msi_group_allgather (per-rank form): d_recv := the `bytes` of every rank's d_send in rank order, enqueued on the
+ * context's stream.
+ */
+typedef struct msi_group msi_group;
+typedef struct msi_vs_group msi_vs_group;
+enum { MSI_GROUP_REPLICATE = 0, MSI_GROUP_SHARD_ROWS = 1 };
+int32_t msi_group_create(const int32_t *devices, uint32_t n, msi_group **out);
+int32_t msi_group_unique_id(uint8_t out_id[128]);
+int32_t msi_group_create_rank(msi_ctx *ctx, uint32_t rank, uint32_t world, const uint8_t id[128], msi_group **out);
+void msi_group_destroy(msi_group *group);
+uint32_t msi_group_size(const msi_group *group);
+msi_ctx *msi_group_ctx(msi_group *group, uint32_t i);
+int32_t msi_group_allgather(msi_group *group, const void *d_send, size_t bytes, void *d_recv);
+int32_t msi_vs_group_create(msi_group *group, uint32_t dim, int32_t storage, int32_t mode, msi_vs_group **out);
+void msi_vs_group_destroy(msi_vs_group *vs);
+int32_t msi_vs_group_upload(msi_vs_group *vs, const uint32_t *docids, const float *rows, uint64_t n_rows);
+int32_t msi_vs_group_search(msi_vs_group *vs, const float *queries, uint32_t n_queries, uint32_t k, uint32_t *out_docids,
+                            float *out_dist, uint32_t *out_counts);
+
 /* Introspection for benchmarks/tests. */
 typedef struct msi_vs_stats {
   uint64_t scan_launches;      /* vs_scan kernel launches so far (sample + full sweeps) */

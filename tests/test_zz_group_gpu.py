@@ -1,0 +1,64 @@
+"""SURVEY §8 e — the multi-GPU entry points of the C ABI (msi_group / msi_vs_group, RCCL inside libmsi), on the one
+device a test box has: an in-process group of one device in both modes must answer exactly like a plain store (and like
+the oracle), and the per-rank form (the one bench.py uses under torchrun) must join a world of one and all-gather a
+device buffer onto itself.  World sizes > 1 need more devices than the test tier has; the exchange and merge logic for
+them is covered by the shard-emulation test of tests/test_vs_gpu.py and the gloo tests of tests/test_distributed_cpu.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import meilisearch_amd as ma
+from meilisearch_amd import synth
+from meilisearch_amd._lib import check, lib
+from meilisearch_amd.device import np_ptr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", [0, 1])   # MSI_GROUP_REPLICATE, MSI_GROUP_SHARD_ROWS
+def test_in_process_group_of_one_device(oracle, mode):
+    devs = (C.c_int32 * 1)(0)
+    g = C.c_void_p()
+    check(lib().msi_group_create(devs, 1, C.byref(g)))
+    assert lib().msi_group_size(g) == 1 and lib().msi_group_ctx(g, 0)
+    vs = C.c_void_p()
+    check(lib().msi_vs_group_create(g, 96, 0, mode, C.byref(vs)))
+    rows = synth.make_embeddings(7000, 96, seed=3)
+    ids = (np.arange(7000, dtype=np.uint32) * 2 + 1)
+    check(lib().msi_vs_group_upload(vs, np_ptr(ids), np_ptr(rows), 7000))
+    q = synth.make_embeddings(37, 96, seed=4)
+    k = 20
+    out_d = np.zeros((37, k), np.uint32)
+    out_s = np.zeros((37, k), np.float32)
+    cnt = np.zeros(37, np.uint32)
+    check(lib().msi_vs_group_search(vs, np_ptr(q), 37, k, np_ptr(out_d), np_ptr(out_s), np_ptr(cnt)))
+    for j in range(37):
+        e_ids, e_dist = oracle.vs_topk(rows, ids, q[j], k)
+        assert int(cnt[j]) == k and out_d[j].tolist() == e_ids.tolist()
+        assert out_s[j].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist()
+    # duplicates force the exactness proof to fail on the shard: the group falls back to the exhaustive host path
+    rows2 = np.repeat(rows[:50], 40, axis=0)
+    ids2 = np.arange(2000, dtype=np.uint32)
+    check(lib().msi_vs_group_upload(vs, np_ptr(ids2), np_ptr(rows2), 2000))
+    check(lib().msi_vs_group_search(vs, np_ptr(q[:3]), 3, k, np_ptr(out_d), np_ptr(out_s), np_ptr(cnt)))
+    for j in range(3):
+        e_ids, e_dist = oracle.vs_topk(rows2, ids2, q[j], k)
+        assert out_d[j].tolist() == e_ids.tolist()
+    lib().msi_vs_group_destroy(vs)
+    lib().msi_group_destroy(g)
+
+
+def test_per_rank_group_world_of_one(ctx):
+    import torch
+    uid = (C.c_uint8 * 128)()
+    check(lib().msi_group_unique_id(uid))
+    g = C.c_void_p()
+    check(lib().msi_group_create_rank(ctx.handle, 0, 1, uid, C.byref(g)))
+    send = torch.arange(1000, dtype=torch.int32, device="cuda:0")
+    recv = torch.zeros(1000, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    check(lib().msi_group_allgather(g, C.c_void_p(send.data_ptr()), 4000, C.c_void_p(recv.data_ptr())))
+    ctx.synchronize()
+    assert torch.equal(send, recv)
+    lib().msi_group_destroy(g)
