@@ -182,7 +182,7 @@ __device__ __forceinline__ void publish_count(uint32_t c, u64 *__restrict__ acc,
     u64 b = 0;
     for (int i = 0; i < BT / 64; ++i) b += part[i];
     if (b) atomicAdd(&acc[0], b);
-    __threadfence();
+    MSI_ORDER_ATOMICS();   // atomics only: no L2 write-back / invalidate (msi_common.h)
     const u64 done = atomicAdd(&acc[1], 1ull);
     if (done == gridDim.x - 1) {
       const u64 total = atomicExch(&acc[0], 0ull);
@@ -271,7 +271,7 @@ __global__ void bits_take_key_kernel(u64 *__restrict__ universe, u64 *__restrict
     u64 b = 0;
     for (int i = 0; i < BT / 64; ++i) b += part[i];
     if (b) atomicAdd(&acc[0], b);
-    __threadfence();
+    MSI_ORDER_ATOMICS();   // atomics only: no L2 write-back / invalidate (msi_common.h)
     const u64 done = atomicAdd(&acc[1], 1ull);
     if (done == gridDim.x - 1) {
       const u64 total = atomicExch(&acc[0], 0ull);
@@ -325,7 +325,7 @@ __global__ void bits_distinct_propose_kernel(u64 *__restrict__ undecided, const 
     u64 b = 0;
     for (int i = 0; i < BT / 64; ++i) b += part[i];
     if (b) atomicAdd(&acc[0], b);
-    __threadfence();
+    MSI_ORDER_ATOMICS();   // atomics only: no L2 write-back / invalidate (msi_common.h)
     const u64 done = atomicAdd(&acc[1], 1ull);
     if (done == gridDim.x - 1) {
       const u64 total = atomicExch(&acc[0], 0ull);
@@ -542,7 +542,7 @@ __global__ void bits_geo_take_kernel(u64 *__restrict__ src, u64 *__restrict__ ds
     }
     if (b) atomicAdd(&acc[0], b);
     if (f0 != ~0ull) atomicMin(first, f0);
-    __threadfence();
+    MSI_ORDER_ATOMICS();   // atomics only: no L2 write-back / invalidate (msi_common.h)
     const u64 done = atomicAdd(&acc[1], 1ull);
     if (done == gridDim.x - 1) {
       const u64 total = atomicExch(&acc[0], 0ull);
@@ -640,7 +640,7 @@ __global__ void bits_and_many_kernel(ManyArgs a, const u64 *__restrict__ prefix,
   if (threadIdx.x == 0) {
     for (uint32_t k = 0; k < n; ++k)
       if (part[k]) atomicAdd(&acc[2 + k], (u64)part[k]);
-    __threadfence();
+    MSI_ORDER_ATOMICS();   // atomics only: no L2 write-back / invalidate (msi_common.h)
     const u64 done = atomicAdd(&acc[1], 1ull);
     if (done == gridDim.x - 1) {
       for (uint32_t k = 0; k < n; ++k) {
@@ -692,7 +692,7 @@ __global__ void bits_andnot_many_kernel(ManyArgs a, const u64 *__restrict__ remo
   if (threadIdx.x == 0) {
     for (uint32_t k = 0; k < n; ++k)
       if (part[k]) atomicAdd(&acc[2 + k], (u64)part[k]);
-    __threadfence();
+    MSI_ORDER_ATOMICS();   // atomics only: no L2 write-back / invalidate (msi_common.h)
     const u64 done = atomicAdd(&acc[1], 1ull);
     if (done == gridDim.x - 1) {
       for (uint32_t k = 0; k < n; ++k) {
@@ -768,18 +768,17 @@ __global__ void bits_paths_kernel(const u64 *const *__restrict__ steps, const ui
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < n_paths; k += blockDim.x)
     if (cnt[k]) atomicAdd(&acc_counts[k], (u64)cnt[k]);
-  __threadfence();
+  MSI_ORDER_ATOMICS();   // atomics only: no L2 write-back / invalidate (msi_common.h)
   __syncthreads();
   __shared__ bool last;
   if (threadIdx.x == 0) last = atomicAdd(&acc[1], 1ull) == gridDim.x - 1;
   __syncthreads();
   if (last) {
-    __threadfence();
     for (uint32_t k = threadIdx.x; k < n_paths; k += blockDim.x) {
       const u64 total = atomicExch(&acc_counts[k], 0ull);
       __hip_atomic_store(const_cast<uint64_t *>(&sig_counts[k]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    MSI_ORDER_ATOMICS();
     __syncthreads();
     if (threadIdx.x == 0) {
       acc[1] = 0;
@@ -835,18 +834,17 @@ __global__ __launch_bounds__(PS_T) void bits_paths_small_kernel(PathsSmall a, ui
   }
   __syncthreads();
   if (tid < n_paths && cnt[tid]) atomicAdd(&acc_counts[tid], (u64)cnt[tid]);
-  __threadfence();
+  MSI_ORDER_ATOMICS();   // atomics only: no L2 write-back / invalidate (msi_common.h)
   __syncthreads();
   __shared__ bool last;
   if (tid == 0) last = atomicAdd(&acc[1], 1ull) == gridDim.x - 1;
   __syncthreads();
   if (last) {
-    __threadfence();
     if (tid < n_paths) {
       const u64 total = atomicExch(&acc_counts[tid], 0ull);
       __hip_atomic_store(const_cast<uint64_t *>(&sig_counts[tid]), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    MSI_ORDER_ATOMICS();
     __syncthreads();
     if (tid == 0) {
       acc[1] = 0;

@@ -12,14 +12,23 @@
 //
 // HBM layout: bit planes — word w of every row contiguous (bits[w][row]), so a wave reads 512 contiguous bytes per
 // word and a row costs dim/8 bytes per sweep: 960 MB for 10 M x 768 against 30.7 GB of f32 rows (32x less traffic).
-// Kernels (HBM / VALU-popcount bound; up to 32 queries share a sweep, their bits live in LDS):
+// Kernels.  A search of a large store is ONE sweep over the bit planes for up to 32 queries (VALU-popcount bound: a
+// row's words are loaded once into registers, the queries' words arrive through the scalar cache, 4 VALU operations per
+// 64 bits per query; 10 M x 768 x 32 queries = 0.12 ms of HBM time against ~0.4 ms of popcounts):
 //   bq_quantise      one wave per (row, word): the ballot of x > 0 IS the word
-//   bq_hist          hamming distance of every allowed row to every query -> per-query histogram over 0..dim
-//   bq_threshold     per query: t = the distance at which the k-th result lies, how many rows lie below it
-//   bq_count         per (query, block of rows): rows below t, rows at t           (ordered emit needs their prefix sums)
-//   bq_scan          per query: exclusive prefix sums over the blocks
-//   bq_emit          rows below t, and the first (k - below) rows AT t in docid order, into the result list
+//   bq_sweep<0>      histogram of the distances of a SAMPLE (the first max(65 536, 64 k) rows) to every query
+//   bq_threshold     per query: the sample's k-th distance — an upper bound `ub` of the store's k-th distance
+//   bq_pass          the sweep: every allowed row with distance <= ub is appended to the query's candidate list
+//                    (a few thousand of 10 M rows; wave-aggregated append)
+//   bq_select        per query: histogram of the candidates -> the exact k-th distance t; candidates below t, and the
+//                    first (k - below) candidates AT t in docid order, into the result list
 //   bq_sort          per query: the <= k results by (distance, docid)
+// The sweep cannot answer when the bound is useless (fewer than k allowed rows in the sample), when the candidates
+// overflow their list or more than 4096 candidates tie at t: the batch is then answered by the exhaustive form (also
+// the path of small stores): three sweeps, each recomputing the distances —
+//   bq_sweep<0>      histogram over ALL rows -> bq_threshold -> bq_sweep<1> per-block counts below / at t -> bq_scan
+//   prefix sums -> bq_sweep<2> ordered emit -> bq_sort.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -36,7 +45,7 @@ struct msi_bq {
   DevBuf bits, docids;           // u64 [W][n_pad], u32 [n_pad]
   std::vector<uint32_t> h_docids;
   // scratch (guarded by ctx->mu)
-  DevBuf qbits, hist, thr, blk_cnt, res, filt, qf, out_ids, out_dist, out_cnt;
+  DevBuf qbits, qplanes, hist, thr, blk_cnt, res, filt, qf, out_ids, out_dist, out_cnt, cand, cand_cnt;
 };
 
 namespace {
@@ -232,6 +241,132 @@ __global__ __launch_bounds__(BQ_T) void bq_sort_kernel(const u64 *__restrict__ r
   }
 }
 
+
+// every query of a batch in one launch: word w of query q -> qbits[q * W + w] (the layout bq_sweep reads) and
+// planes[w * QB + q] (the layout bq_pass reads: the QB words of a bit plane side by side)
+__global__ void bq_quantise_queries_kernel(const float *__restrict__ qf, uint32_t nq, uint32_t dim, uint32_t W, uint32_t QB,
+                                           u64 *__restrict__ qbits, u64 *__restrict__ planes) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const uint32_t q = wave / W, w = wave % W;
+  if (q >= nq) return;
+  const uint32_t c = w * 64 + lane;
+  const float x = c < dim ? qf[(size_t)q * dim + c] : 0.0f;
+  const u64 word = __ballot(x > 0.0f);
+  if (lane == 0) {
+    qbits[(size_t)q * W + w] = word;
+    planes[(size_t)w * QB + q] = word;
+  }
+}
+
+// The sweep.  One row per thread and step; the row's words pass through registers once, the QB queries' words are
+// wave-uniform (scalar loads), QB distance accumulators per thread.  A row within the bound of a query is appended to
+// that query's candidate list: one atomic per wave and query that has any.
+template <int QB>
+__global__ __launch_bounds__(BQ_T) void bq_pass_kernel(const u64 *__restrict__ bits, const uint32_t *__restrict__ docids,
+                                                      uint64_t n_rows, uint64_t n_pad, uint32_t W, uint32_t dim,
+                                                      const u64 *__restrict__ planes,       // [W][QB]
+                                                      uint32_t nq, const u64 *__restrict__ filter, uint64_t filter_nbits,
+                                                      const uint32_t *__restrict__ thr,     // [nq][4]: ub first
+                                                      uint32_t *__restrict__ cand_cnt,      // [nq]
+                                                      u64 *__restrict__ cand, uint32_t cap) {
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint64_t r = (uint64_t)blockIdx.x * BQ_T + threadIdx.x; r < n_pad; r += (uint64_t)gridDim.x * BQ_T) {   // n_pad: whole waves
+    const bool in = r < n_rows;
+    const uint32_t docid = in ? docids[r] : 0;
+    const bool ok = in && bq_allowed(filter, filter_nbits, docid);
+    uint32_t h[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) h[q] = 0;
+#pragma unroll 2
+    for (uint32_t w = 0; w < W; ++w) {
+      const uint2 x = *reinterpret_cast<const uint2 *>(bits + (uint64_t)w * n_pad + r);
+      const uint2 *qw = reinterpret_cast<const uint2 *>(planes + (size_t)w * QB);
+#pragma unroll
+      for (int q = 0; q < QB; ++q) {   // v_xor with a scalar operand, v_bcnt_u32_b32 accumulates: 4 VALU per 64 bits
+        h[q] += (uint32_t)__popc(x.x ^ qw[q].x);
+        h[q] += (uint32_t)__popc(x.y ^ qw[q].y);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const uint32_t ub = (uint32_t)q < nq ? thr[q * 4] : dim + 1;   // dim + 1: the sample gave no bound (or no such query)
+      const bool pass = ok && ub <= dim && h[q] <= ub;
+      const u64 m = __ballot(pass);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&cand_cnt[q], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader);
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pass && pos < cap) cand[(size_t)q * cap + pos] = ((u64)h[q] << 32) | docid;
+      }
+    }
+  }
+}
+
+constexpr uint32_t BQ_TIES = 4096;   // candidates AT the k-th distance the select kernel orders itself
+
+// per query: the exact k-th distance among the candidates, then the results (unordered; bq_sort orders them).
+// flags[q] != 0: the sweep could not answer (overflow / too many ties / fewer candidates than the bound promised).
+__global__ __launch_bounds__(BQ_T) void bq_select_kernel(const u64 *__restrict__ cand, const uint32_t *__restrict__ cand_cnt,
+                                                        uint32_t cap, uint32_t dim, uint32_t k, const uint32_t *__restrict__ thr,
+                                                        u64 *__restrict__ res, uint32_t *__restrict__ out_cnt,
+                                                        uint32_t *__restrict__ flags) {
+  MSI_DYNAMIC_LDS(smem);
+  uint32_t *hist = reinterpret_cast<uint32_t *>(smem);          // [dim + 1]
+  uint32_t *ties = hist + ((dim + 2) & ~1u);                     // [BQ_TIES] docids at t
+  __shared__ uint32_t s_t, s_below, s_take, s_nb, s_nt;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t total = cand_cnt[q];
+  if (thr[q * 4] > dim || total > cap || total < k) {   // no bound from the sample, or the list overflowed
+    if (tid == 0) flags[q] = 1;
+    return;
+  }
+  const u64 *c = cand + (size_t)q * cap;
+  for (uint32_t i = tid; i <= dim; i += BQ_T) hist[i] = 0;
+  if (tid == 0) s_nb = s_nt = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < total; i += BQ_T) atomicAdd(&hist[(uint32_t)(c[i] >> 32)], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t cum = 0, t = 0;
+    for (; t <= dim; ++t) {
+      if (cum + hist[t] >= k) break;
+      cum += hist[t];
+    }
+    s_t = t;
+    s_below = cum;
+    s_take = k - cum;
+  }
+  __syncthreads();
+  const uint32_t t = s_t, below = s_below, take = s_take;
+  if (hist[t] > BQ_TIES) {
+    if (tid == 0) flags[q] = 1;
+    return;
+  }
+  for (uint32_t i = tid; i < total; i += BQ_T) {
+    const u64 v = c[i];
+    const uint32_t h = (uint32_t)(v >> 32);
+    if (h < t) {
+      res[(size_t)q * k + atomicAdd(&s_nb, 1u)] = v;
+    } else if (h == t) {
+      ties[atomicAdd(&s_nt, 1u)] = (uint32_t)v;
+    }
+  }
+  __syncthreads();
+  const uint32_t nt = s_nt;
+  for (uint32_t i = tid; i < nt; i += BQ_T) {   // the first `take` of the ties in docid order (rank by counting)
+    const uint32_t d = ties[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < nt; ++j) rank += ties[j] < d ? 1u : 0u;
+    if (rank < take) res[(size_t)q * k + below + rank] = ((u64)t << 32) | d;
+  }
+  if (tid == 0) {
+    out_cnt[q] = k;
+    flags[q] = 0;
+  }
+}
+
 int32_t bq_finish_upload(msi_bq *b, uint64_t n_rows) {
   b->h_docids.resize(n_rows);
   if (n_rows) MSI_HIP_TRY(hipMemcpy(b->h_docids.data(), b->docids.p, n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -279,7 +414,7 @@ void msi_bq_destroy(msi_bq *b) {
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&b->bits, &b->docids, &b->qbits, &b->hist, &b->thr, &b->blk_cnt, &b->res, &b->filt, &b->qf,
-                      &b->out_ids, &b->out_dist, &b->out_cnt};
+                      &b->out_ids, &b->out_dist, &b->out_cnt, &b->qplanes, &b->cand, &b->cand_cnt};
     for (DevBuf *d : bufs) d->release();
     delete b;
   }
@@ -387,18 +522,24 @@ int32_t msi_bq_search(msi_bq *b, const float *queries, uint32_t n_queries, uint3
   // the histogram of a sweep lives in LDS: as many queries per sweep as fit in 64 KiB
   uint32_t q_per = BQ_QMAX;
   while (q_per > 1 && (size_t)BQ_QMAX * W * 8 + (size_t)q_per * (dim + 1) * 4 > (size_t)60 << 10) q_per /= 2;
-  for (uint32_t q0 = 0; q0 < n_queries; q0 += q_per) {
-    const uint32_t nq = std::min(q_per, n_queries - q0);
-    // the query is quantised like a row
-    MSI_HIP_TRY(hipMemcpyAsync(b->qf.p, queries + (size_t)q0 * dim, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
-    // one launch per query: with n_pad = 1 and one row the kernel writes word w at qbits[q * W + w] — the [q][W] layout
-    // the sweeps read
-    for (uint32_t q = 0; q < nq; ++q) {
-      hipLaunchKernelGGL(bq_quantise_kernel, dim3((uint32_t)(((uint64_t)W * 64 + BQ_T - 1) / BQ_T)), dim3(BQ_T), 0, st,
-                         b->qf.as<float>() + (size_t)q * dim, (uint64_t)1, dim, W, (uint64_t)1,
-                         b->qbits.as<u64>() + (size_t)q * W, (uint64_t)0);
-    }
-    MSI_HIP_TRY(hipGetLastError());
+  // the one-sweep form needs a sample that is a small part of the store, and its select kernel a histogram in LDS
+  uint64_t sample = std::max<uint64_t>(65536, (uint64_t)64 * k);
+  if (const char *knob = getenv("MSI_BQ_SAMPLE_ROWS")) sample = std::max<uint64_t>(BQ_ROWS, strtoull(knob, nullptr, 10));   // tests
+  sample = (sample + BQ_ROWS - 1) / BQ_ROWS * BQ_ROWS;
+  const bool one_sweep = b->n_rows >= 4 * sample && (size_t)(dim + 2) * 4 + BQ_TIES * 4 <= ((size_t)60 << 10);
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, std::max<uint64_t>(8192, b->n_rows / 32 + 2 * (uint64_t)k));
+  std::vector<uint32_t> flags(BQ_QMAX, 0);
+  if (one_sweep) {
+    MSI_TRY(b->qplanes.ensure((size_t)W * BQ_QMAX * sizeof(u64)));
+    MSI_TRY(b->cand.ensure((size_t)BQ_QMAX * cap * sizeof(u64)));
+    MSI_TRY(b->cand_cnt.ensure((size_t)2 * BQ_QMAX * sizeof(uint32_t)));   // counts, then flags
+  } else {
+    MSI_TRY(b->qplanes.ensure((size_t)W * BQ_QMAX * sizeof(u64)));
+  }
+  const uint32_t n_cu = (uint32_t)std::max(1, b->ctx->n_cu);
+
+  // the exhaustive form for queries q0 .. q0 + nq (qbits staged): results into out_ids / out_dist / out_cnt
+  auto exhaustive = [&](uint32_t nq) -> int32_t {
     MSI_HIP_TRY(hipMemsetAsync(b->hist.p, 0, (size_t)nq * (dim + 1) * sizeof(uint32_t), st));
     const size_t lds0 = (size_t)BQ_QMAX * W * 8 + (size_t)nq * (dim + 1) * 4;
     const size_t lds1 = (size_t)BQ_QMAX * W * 8 + (size_t)nq * 10 * 4;
@@ -417,10 +558,87 @@ int32_t msi_bq_search(msi_bq *b, const float *queries, uint32_t n_queries, uint3
     hipLaunchKernelGGL(bq_sort_kernel, dim3(nq), dim3(BQ_T), 0, st, b->res.as<u64>(), b->out_cnt.as<uint32_t>(), k, dim,
                        b->out_ids.as<uint32_t>(), b->out_dist.as<float>());
     MSI_HIP_TRY(hipGetLastError());
+    return MSI_OK;
+  };
+  auto copy_out = [&](uint32_t q0, uint32_t nq) -> int32_t {
     MSI_HIP_TRY(hipMemcpyAsync(out_docids + (size_t)q0 * k, b->out_ids.p, (size_t)nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipMemcpyAsync(out_dist + (size_t)q0 * k, b->out_dist.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipMemcpyAsync(out_counts + q0, b->out_cnt.p, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    return MSI_OK;
+  };
+  // the query is quantised like a row; QB = the batch's queries rounded up to a power of two (the sweep's template)
+  auto stage_queries = [&](uint32_t q0, uint32_t nq, uint32_t QB) -> int32_t {
+    MSI_HIP_TRY(hipMemcpyAsync(b->qf.p, queries + (size_t)q0 * dim, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
+    MSI_HIP_TRY(hipMemsetAsync(b->qplanes.p, 0, (size_t)W * QB * sizeof(u64), st));
+    hipLaunchKernelGGL(bq_quantise_queries_kernel, dim3((uint32_t)(((uint64_t)nq * W * 64 + BQ_T - 1) / BQ_T)), dim3(BQ_T), 0, st,
+                       b->qf.as<float>(), nq, dim, W, QB, b->qbits.as<u64>(), b->qplanes.as<u64>());
+    MSI_HIP_TRY(hipGetLastError());
+    return MSI_OK;
+  };
+
+  const uint32_t step = one_sweep ? BQ_QMAX : q_per;
+  for (uint32_t q0 = 0; q0 < n_queries; q0 += step) {
+    const uint32_t nq = std::min(step, n_queries - q0);
+    uint32_t QB = 1;
+    while (QB < nq) QB *= 2;
+    MSI_TRY(stage_queries(q0, nq, QB));
+    if (!one_sweep) {
+      MSI_TRY(exhaustive(nq));
+      MSI_TRY(copy_out(q0, nq));
+      MSI_HIP_TRY(hipStreamSynchronize(st));
+      continue;
+    }
+    // ---- bound from the sample (q_per queries per histogram launch) ----
+    const uint32_t s_blocks = (uint32_t)(sample / BQ_ROWS);
+    MSI_HIP_TRY(hipMemsetAsync(b->hist.p, 0, (size_t)nq * (dim + 1) * sizeof(uint32_t), st));
+    MSI_HIP_TRY(hipMemsetAsync(b->cand_cnt.p, 0, (size_t)2 * BQ_QMAX * sizeof(uint32_t), st));
+    for (uint32_t s0 = 0; s0 < nq; s0 += q_per) {
+      const uint32_t sn = std::min(q_per, nq - s0);
+      const size_t lds0 = (size_t)BQ_QMAX * W * 8 + (size_t)sn * (dim + 1) * 4;
+      hipLaunchKernelGGL(bq_sweep_kernel<0>, dim3(s_blocks), dim3(BQ_T), lds0, st, b->bits.as<u64>(), b->docids.as<uint32_t>(),
+                         sample, b->n_pad, W, dim, b->qbits.as<u64>() + (size_t)s0 * W, sn, d_filter, filter_nbits,
+                         b->hist.as<uint32_t>() + (size_t)s0 * (dim + 1), (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                         (u64 *)nullptr, k);
+    }
+    hipLaunchKernelGGL(bq_threshold_kernel, dim3(nq), dim3(64), 0, st, b->hist.as<uint32_t>(), dim, k, b->thr.as<uint32_t>(),
+                       b->out_cnt.as<uint32_t>());
+    // ---- the sweep ----
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((b->n_pad + BQ_T - 1) / BQ_T, (uint64_t)n_cu * 32);
+#define MSI_BQ_PASS(QBV)                                                                                                   \
+  hipLaunchKernelGGL(bq_pass_kernel<QBV>, dim3(grid), dim3(BQ_T), 0, st, b->bits.as<u64>(), b->docids.as<uint32_t>(),      \
+                     b->n_rows, b->n_pad, W, dim, b->qplanes.as<u64>(), nq, d_filter, filter_nbits, b->thr.as<uint32_t>(), \
+                     b->cand_cnt.as<uint32_t>(), b->cand.as<u64>(), cap)
+    switch (QB) {
+      case 1: MSI_BQ_PASS(1); break;
+      case 2: MSI_BQ_PASS(2); break;
+      case 4: MSI_BQ_PASS(4); break;
+      case 8: MSI_BQ_PASS(8); break;
+      case 16: MSI_BQ_PASS(16); break;
+      default: MSI_BQ_PASS(32); break;
+    }
+#undef MSI_BQ_PASS
+    const size_t lds_sel = (size_t)((dim + 2) & ~1u) * 4 + (size_t)BQ_TIES * 4;
+    hipLaunchKernelGGL(bq_select_kernel, dim3(nq), dim3(BQ_T), lds_sel, st, b->cand.as<u64>(), b->cand_cnt.as<uint32_t>(), cap,
+                       dim, k, b->thr.as<uint32_t>(), b->res.as<u64>(), b->out_cnt.as<uint32_t>(),
+                       b->cand_cnt.as<uint32_t>() + BQ_QMAX);
+    hipLaunchKernelGGL(bq_sort_kernel, dim3(nq), dim3(BQ_T), 0, st, b->res.as<u64>(), b->out_cnt.as<uint32_t>(), k, dim,
+                       b->out_ids.as<uint32_t>(), b->out_dist.as<float>());
+    MSI_HIP_TRY(hipGetLastError());
+    MSI_TRY(copy_out(q0, nq));
+    MSI_HIP_TRY(hipMemcpyAsync(flags.data(), b->cand_cnt.as<uint32_t>() + BQ_QMAX, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipStreamSynchronize(st));
+    bool redo = false;
+    for (uint32_t q = 0; q < nq; ++q) redo = redo || flags[q] != 0;
+    if (redo) {
+      // the sweep could not answer some query of the batch: the exhaustive form answers it (q_per queries at a time)
+      for (uint32_t s0 = 0; s0 < nq; s0 += q_per) {
+        const uint32_t sn = std::min(q_per, nq - s0);
+        MSI_TRY(stage_queries(q0 + s0, sn, 1));
+        MSI_TRY(exhaustive(sn));
+        MSI_TRY(copy_out(q0 + s0, sn));
+        MSI_HIP_TRY(hipStreamSynchronize(st));
+      }
+    }
   }
   return MSI_OK;
 }

@@ -15,6 +15,14 @@
 
 // The dynamic LDS of a kernel (the size is the launch's).  tests/emu pre-defines it for the CPU emulation of the HIP
 // runtime, where LDS is a host buffer.
+// Ordering without cache maintenance.  On gfx950 an agent-scope fence (__threadfence) is `buffer_wbl2 sc1` +
+// `buffer_inv sc1`: it writes back AND invalidates the whole L2 of the XCD the wave runs on — for every kernel resident
+// there.  A workgroup that only has to order its own device-scope ATOMICS (which are performed at the device's
+// coherence point, not in the L2) before a later atomic needs no more than "my earlier memory operations are
+// acknowledged": s_waitcnt vmcnt(0), which is what a workgroup-scope release fence compiles to.
+#ifndef MSI_ORDER_ATOMICS
+#define MSI_ORDER_ATOMICS() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#endif
 #ifndef MSI_DYNAMIC_LDS
 #define MSI_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif

@@ -438,13 +438,22 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   __syncthreads();
   for (uint32_t i = tid; i < r.n_counts; i += VT)
     if (s_cnt[i]) atomicAdd(&counts[i], (u64)s_cnt[i]);
-  if (fk_cnt != NONE && tid == 0) chunk_card[chunk] = s_cnt[fk_cnt];
-  __threadfence();
+  // What another workgroup reads of this one: the cardinalities (device-scope atomics), and — only for the ordered
+  // emit of a first-k command — the words of one set.  Only the latter needs this XCD's L2 written back; a list
+  // without first-k orders its atomics and leaves the L2 alone (a full fence per workgroup wrote back and INVALIDATED
+  // the L2 under every resident kernel 153 times per list at 10 M documents: single-list kernels took 100-300 us
+  // under load, r2_ranked10_timeline_before.txt).
+  if (fk_cnt != NONE) {
+    if (tid == 0) __hip_atomic_store(&chunk_card[chunk], s_cnt[fk_cnt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+  } else {
+    MSI_ORDER_ATOMICS();
+  }
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(&state[phase], 1u) == r.n_chunks - 1 ? 1u : 0u;
   __syncthreads();
   if (!s_last || phase != r.n_phases - 1) return;
-  __threadfence();
+  if (fk_cnt != NONE) __threadfence();   // the set words the other workgroups wrote (read below with device-scope loads)
   u64 *res = reinterpret_cast<u64 *>(r.host_res);
   uint32_t emitted = 0;
   if (fk_cnt != NONE) {
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         u64 x = w[j];
         while (x && rank < k) {
           const uint32_t b = (uint32_t)__ffsll((long long)x) - 1;
-          ids[rank++] = (uint32_t)((cw0 + WPT * tid + j) * 64 + b);
+          __hip_atomic_store(&ids[rank++], (uint32_t)((cw0 + WPT * tid + j) * 64 + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           x &= x - 1;
         }
       }
@@ -518,11 +527,14 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     const u64 v = __hip_atomic_load(&counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&res[RES_COUNTS + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __threadfence_system();
+  // the result block is pinned host memory (uncached on the device): every store above goes straight out; once they
+  // are acknowledged the sequence number follows them on the same path
+  MSI_ORDER_ATOMICS();
   __syncthreads();
   if (tid == 0) {
     __hip_atomic_store(&res[1], (u64)emitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&res[0], r.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    MSI_ORDER_ATOMICS();
+    __hip_atomic_store(&res[0], r.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -40,6 +40,7 @@
 #define __shared__ static
 #define __launch_bounds__(...)
 #define MSI_DYNAMIC_LDS(name) unsigned char *name = hipemu::g.dyn_lds
+#define MSI_ORDER_ATOMICS() ((void)0)
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3

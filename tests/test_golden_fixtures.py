@@ -38,7 +38,7 @@ def test_oracle_matches_reference_literals(oracle):
     words = sorted(set(tw["dictionary"].split()), key=lambda w: w.encode())
     odic = oracle.Dictionary(words)
     for c in tw["cases"]:
-        one, two = oracle.typo_lookup(odic, c["q"], c["typos"], False)
+        one, two = oracle.typo_lookup(odic, c["q"], c["typos"], c.get("prefix", False))
         one_w = [words[i] for i in one]
         two_w = [words[i] for i in two]
         for w in c.get("one_contains", []):
@@ -47,6 +47,8 @@ def test_oracle_matches_reference_literals(oracle):
             assert w in two_w, c
         for w in c.get("one_excludes", []):
             assert w not in one_w, c
+        for w in c.get("two_excludes", []):
+            assert w not in two_w, c
 
 
 def test_fixtures_are_reproducible(oracle):
@@ -110,12 +112,14 @@ def test_gpu_reference_literals(ctx):
     gd = ma.GpuDictionary(ctx, words=words)
     for c in tw["cases"]:
         if c["typos"] == 1:
-            one, two = gd.find_one_typo_derivations(c["q"], False), []
+            one, two = gd.find_one_typo_derivations(c["q"], c.get("prefix", False)), []
         else:
-            one, two = gd.find_one_two_typo_derivations(c["q"], False)
+            one, two = gd.find_one_two_typo_derivations(c["q"], c.get("prefix", False))
         for w in c.get("one_contains", []):
             assert w in one, c
         for w in c.get("two_contains", []):
             assert w in two, c
         for w in c.get("one_excludes", []):
             assert w not in one, c
+        for w in c.get("two_excludes", []):
+            assert w not in two, c

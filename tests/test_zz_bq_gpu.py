@@ -57,3 +57,44 @@ def test_filter_ties_and_zero_components(ctx, oracle):
             assert s[j, :c[j]].tolist() == e_dist.tolist()
     with pytest.raises(ma.MsiError):
         st.upload([3, 2], np.zeros((2, 4), np.float32))
+
+
+@pytest.mark.parametrize("n,dim,k,sample", [(5003, 130, 50, 1024), (9000, 64, 20, 2048), (20000, 768, 20, 1024),
+                                            (4100, 8, 500, 1024)])
+def test_one_sweep_form_vs_oracle(ctx, oracle, monkeypatch, n, dim, k, sample):
+    """Large stores are answered by ONE sweep bounded by a sample's k-th distance (msi_bq.hip header); the sample size
+    knob brings that path down to sizes the oracle checks in seconds.  40 queries: a full batch of 32 and one of 8."""
+    monkeypatch.setenv("MSI_BQ_SAMPLE_ROWS", str(sample))
+    rows = synth.make_embeddings(n, dim, seed=n + dim)
+    ids = np.arange(n, dtype=np.uint32) * 3 + 7
+    qs = synth.make_embeddings(40, dim, seed=1000 + n)
+    st = ma.GpuBqStore(ctx, dim)
+    st.upload(ids, rows)
+    for nq in (40, 1, 3):
+        d, s, c = st.search(qs[:nq], k)
+        for j in range(nq):
+            e_ids, e_dist = oracle.bq_topk(rows, ids, qs[j], k)
+            assert int(c[j]) == e_ids.size and d[j, :c[j]].tolist() == e_ids.tolist(), (nq, j)
+            assert s[j, :c[j]].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist()
+
+
+def test_one_sweep_form_falls_back_when_it_cannot_answer(ctx, oracle, monkeypatch):
+    """Mass ties at the k-th distance (more than the select kernel orders), a filter that leaves fewer than k rows in
+    the sample, and a filter that leaves fewer than k rows at all: the exhaustive form answers, same results."""
+    monkeypatch.setenv("MSI_BQ_SAMPLE_ROWS", "1024")
+    rng = np.random.default_rng(9)
+    rows = rng.integers(-1, 2, (30000, 2)).astype(np.float32)      # 4 codes: > 4096 rows tie at every distance
+    ids = np.arange(30000, dtype=np.uint32)
+    st = ma.GpuBqStore(ctx, 2)
+    st.upload(ids, rows)
+    qs = np.array([[1, 1], [-1, 1], [0, 0]], dtype=np.float32)
+    rare = np.nonzero(rng.random(30000) < 0.002)[0]                 # ~60 allowed rows, ~2 of them in the sample
+    few = rare[:7]
+    half = np.nonzero(rng.random(30000) < 0.5)[0]
+    for allowed, k in ((None, 10), (None, 2000), (rare, 20), (few, 20), (half, 300)):
+        flt = () if allowed is None else ma.dense_filter(allowed.tolist(), 30000)
+        d, s, c = st.search(qs, k, *flt)
+        for j in range(3):
+            e_ids, e_dist = oracle.bq_topk(rows, ids, qs[j], k, *flt)
+            assert int(c[j]) == e_ids.size and d[j, :c[j]].tolist() == e_ids.tolist(), (k, j)
+            assert s[j, :c[j]].tolist() == e_dist.tolist()
