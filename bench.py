@@ -65,7 +65,7 @@ def parse_args():
     ap.add_argument("--shard", choices=["queries", "rows"], default="queries")
     ap.add_argument("--no-typo", action="store_true")
     ap.add_argument("--no-rank", action="store_true", help="c4: leave the keyword leg and the hybrid merge out")
-    ap.add_argument("--kw-threads", type=int, default=96, help="c4: caller threads of the keyword leg (one in-flight search each)")
+    ap.add_argument("--kw-threads", type=int, default=64, help="c4: caller threads of the keyword leg (one in-flight search each)")
     ap.add_argument("--kw-terms", type=int, default=3, help="c4: words per keyword query")
     ap.add_argument("--kw-dict-words", type=int, default=200_000, help="c4: vocabulary of the synthetic inverted index")
     ap.add_argument("--kw-cache-mb", type=int, default=8192, help="c4: HBM posting cache of the index version")
@@ -241,7 +241,10 @@ def run_c4(args, env):
     n = args.rows or 10_000_000
     d = args.dim or 768
     k = args.k or 20
-    Q = args.queries or 96
+    # 768 queries per step: 16 sweeps of the vector store, and 12 searches in a row for each of the 64 keyword caller
+    # threads — a step of 96 (one search per thread) measured the latency of the slowest of 96 concurrent searches, not
+    # the throughput of the path (profiles/r2_bench_c4_96_queries_per_step.json)
+    Q = args.queries or 768
     storage = args.storage or "f32"
     n_total = n
     row_sharded = args.shard == "rows" and world > 1

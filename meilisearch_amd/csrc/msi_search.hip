@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <deque>
 #include <map>
@@ -113,6 +114,12 @@ struct Dev {
   MsiVmResult res;
   MsiPostingCache *pcache = nullptr;   // HBM posting cache of the index version (msi_dict_enable_posting_cache), or none
   std::vector<void *> fills;           // cache entries the RECORDED decodes fill: ready once the list has run
+  struct PendingFk {
+    Set set;   // keeps the slot from being reused before the list has run
+    uint32_t k, ci, base;
+    std::function<void(const uint32_t *, size_t)> sink;
+  };
+  std::vector<PendingFk> pending_fk;
   // A stored posting value joins a decode batch: from the cache when another search left it there, else from the
   // bytes the callback handed over (and, when there is room, into the cache on the way).
   bool append_posting(MsiCboBatch &b, const MsiCacheKey &k, const uint8_t *bytes, size_t n) {
@@ -164,7 +171,13 @@ struct Dev {
     if (st == MSI_OK)
       for (void *t : fills) msi_pcache_commit(pcache, t);
     fills.clear();
+    std::vector<PendingFk> fk;
+    fk.swap(pending_fk);
     ck(st);
+    for (PendingFk &f : fk) {   // a set smaller than k filled less of its block
+      const size_t n = (size_t)std::min<uint64_t>(res.counts[f.ci], f.k);
+      f.sink(res.firstk.data() + f.base, n);
+    }
   }
   // direct calls (GeoSort, distinct) see everything recorded so far
   void settle() {
@@ -176,8 +189,12 @@ struct Dev {
     if (list.n_counts + n > MSI_VM_MAX_COUNTS) run();
     return list.new_counts(n);
   }
+  void flush() {   // what is recorded runs now (deferred first-k ids are delivered)
+    if (vm) run();
+  }
 #else
   void settle() {}
+  void flush() {}
 #endif
   Set alloc() {  // content undefined: the caller overwrites every word
     if (pool.free_.empty()) {
@@ -592,16 +609,37 @@ struct Dev {
     }
     return s;
   }
+  // The first k documents of `a` handed to `sink` — with the command-list back end not now but when the list runs next
+  // (the ids of a bucket are not needed to go on with the bucket sort: only its cardinality is, and that is known):
+  // a leaf bucket costs no wait of its own.  `a` stays alive until then.
+  void first_k_later(const Set &a, uint32_t k, std::function<void(const uint32_t *, size_t)> sink) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm && k <= MSI_VM_MAX_FIRSTK) {
+      if (k == 0) {
+        sink(nullptr, 0);
+        return;
+      }
+      if (list.fk_in_phase >= MSI_VM_MAX_FK_PHASE || list.firstk_total + k > MSI_VM_MAX_FIRSTK) run();
+      const uint32_t ci = counts_for(1);
+      rd(a->slot);
+      rec({VM_FIRSTK, a->slot, k, ci, list.firstk_total});
+      pending_fk.push_back(PendingFk{a, k, ci, list.firstk_total, std::move(sink)});
+      list.firstk_total += k;
+      ++list.fk_in_phase;
+      list.max_fk_phase = std::max(list.max_fk_phase, list.fk_in_phase);
+      return;
+    }
+#endif
+    const std::vector<uint32_t> ids = first_k(a, k);
+    sink(ids.data(), ids.size());
+  }
   std::vector<uint32_t> first_k(const Set &a, uint32_t k) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm && k <= MSI_VM_MAX_FIRSTK) {
-      if (k == 0) return {};
-      const uint32_t ci = counts_for(1);
-      rd(a->slot);
-      rec({VM_FIRSTK, a->slot, k, ci});
-      list.wants_firstk = true;
+      std::vector<uint32_t> out;
+      first_k_later(a, k, [&out](const uint32_t *ids, size_t n) { out.assign(ids, ids + n); });
       run();
-      return res.firstk;
+      return out;
     }
     settle();
 #endif
@@ -2546,6 +2584,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   size_t cur = 0;
   uint64_t cur_off = 0;
   Set excluded;  // documents a ranking score threshold removed from all_candidates
+  bool ids_short = false;
   auto add = [&](Set cands, uint64_t count) {  // maybe_add_to_results :382-460
     if (dv && count) {
       // apply_distinct_rule, then `universe -= excluded` for every rule of the stack and all_candidates (:404-411)
@@ -2581,15 +2620,20 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     }
     const uint32_t take = (uint32_t)std::min<uint64_t>(count - skip, length - n_out);
     if (take) {
-      auto ids = c.dev.first_k(cands, (uint32_t)(skip + take));
-      for (size_t i = (size_t)skip; i < ids.size(); ++i) {
-        out_docids[n_out] = ids[i];
+      // count is the bucket's exact cardinality: the ids of out[n_out .. n_out + take) are known to exist, their
+      // score details are known now; the ids themselves arrive with the next list that runs (finish() at the latest)
+      const uint32_t at = n_out;
+      for (uint32_t i = 0; i < take; ++i) {
         const uint32_t ns = (uint32_t)std::min<size_t>(scores.size(), MSI_MAX_SCORE_DETAILS);
         for (uint32_t s = 0; s < ns; ++s)
           out_scores[(size_t)n_out * MSI_MAX_SCORE_DETAILS + s] = msi_score_detail{scores[s].kind, scores[s].a, scores[s].b};
         out_n_scores[n_out] = ns;
         ++n_out;
       }
+      c.dev.first_k_later(cands, (uint32_t)(skip + take), [out_docids, at, skip, take, &ids_short](const uint32_t *ids, size_t n) {
+        if (n < skip + take) ids_short = true;   // cannot happen: `count` came from the device
+        for (size_t i = (size_t)skip; i < n && i < skip + take; ++i) out_docids[at + (i - skip)] = ids[i];
+      });
     }
     cur_off += count;
   };
@@ -2612,6 +2656,8 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   const uint64_t max_len = (p->has_score_threshold && p->exhaustive_number_hits && p->max_total_hits) ? p->max_total_hits : length;
   // all_candidates at the end (and, search/new/mod.rs:894-907, what `distinct` keeps of it for an exhaustive count)
   auto finish = [&]() {
+    c.dev.flush();   // the ids of the last buckets
+    if (ids_short) fail(MSI_E_INTERNAL, "a bucket held fewer documents than its cardinality said");
     *out_n = n_out;
     if (!out_candidates) return;
     if (exhaustive_distinct) {

@@ -30,7 +30,8 @@ enum : uint32_t {
   VM_SUB_MANY,   // removed, n, cnt_base, slot...
   VM_COUNT,      // slot, cnt
   VM_DECODE,     // dst, overwrite, index of the decode among the list's decodes
-  VM_FIRSTK,     // slot, k, cnt (the set's cardinality comes back too); at most one per list, in its last phase
+  VM_FIRSTK,     // slot, k, cnt, ids base (the set's cardinality comes back too): the first k docids of the set, ascending,
+                 // at u32 offset `ids base` of the list's id block; <= MSI_VM_MAX_FK_PHASE per phase, <= MSI_VM_MAX_FIRSTK ids per list
   VM_MINKEY,     // universe, keys lo, keys hi, cell
   VM_TAKEKEY,    // universe, bucket, keys lo, keys hi, cell, cnt, key result index
 };
@@ -38,6 +39,7 @@ enum : uint32_t {
 constexpr uint32_t MSI_VM_MAX_COUNTS = 1024;   // cardinalities one list can ask for
 constexpr uint32_t MSI_VM_MAX_PHASES = 4;      // kernel boundaries inside one list (Sort rule: min, then take)
 constexpr uint32_t MSI_VM_MAX_FIRSTK = 8192;   // docids one list can read back
+constexpr uint32_t MSI_VM_MAX_FK_PHASE = 16;   // first-k commands per phase
 constexpr uint32_t MSI_VM_CELLS = 4;
 
 struct MsiVmList {
@@ -57,7 +59,8 @@ struct MsiVmList {
   uint32_t data_off = 0;                // word offset of the descriptor block inside `words` once finalised (0: none)
   uint64_t cache_base = 0;              // device address of the posting cache the decode commands refer to (0: none)
   uint32_t n_counts = 0;
-  bool wants_firstk = false;
+  uint32_t firstk_total = 0;            // ids the list's first-k commands ask for (their blocks lie back to back)
+  uint32_t fk_in_phase = 0, max_fk_phase = 1;
   bool empty() const { return words.empty(); }
   void clear() {
     words.clear();
@@ -67,13 +70,16 @@ struct MsiVmList {
     decodes.clear();
     data_off = 0;
     n_counts = 0;
-    wants_firstk = false;
+    firstk_total = 0;
+    fk_in_phase = 0;
+    max_fk_phase = 1;
   }
   void begin() { if (phase_start.empty()) phase_start.push_back(0); }
   void barrier() {                      // the commands recorded next run after a kernel boundary
     begin();
     words.push_back(VM_END);
     phase_start.push_back((uint32_t)words.size());
+    fk_in_phase = 0;
   }
   uint32_t new_counts(uint32_t n) {
     const uint32_t b = n_counts;
@@ -84,7 +90,7 @@ struct MsiVmList {
 
 struct MsiVmResult {
   std::vector<uint64_t> counts;         // [n_counts]
-  std::vector<uint32_t> firstk;         // docids of the VM_FIRSTK command (at most one per list)
+  std::vector<uint32_t> firstk;         // the id blocks of the list's VM_FIRSTK commands
 };
 
 // Appends a VM_DECODE of `batch` into `dst` (overwrite = the slot's previous content is discarded).

@@ -49,7 +49,6 @@ constexpr int VT = 256;                 // threads per workgroup (512 measured 3
 constexpr int WPT = 1024 / VT;          // words of a chunk per thread in the ordered emit
 constexpr uint32_t CHW = 1024;          // u64 words per chunk (65 536 documents = one Roaring container span)
 constexpr uint32_t MAX_SUBS = 64;       // lists per round
-constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr size_t RES_COUNTS = 2;                               // u64 index of counts[0] in the result block
 constexpr size_t RES_IDS = RES_COUNTS + MSI_VM_MAX_COUNTS;     // u64 index where the u32 ids start
 
@@ -121,6 +120,11 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   r.data_off = rp->data_off; r.state_off = rp->state_off; r.n_counts = rp->n_counts; r.n_decodes = rp->n_decodes;
   const uint32_t chunk = blockIdx.x;
   if (phase >= r.n_phases || chunk >= r.n_chunks) return;
+  // MSI_VM_PROFILE (diagnostics): thread 0's wall-clock ticks (100 MHz) per opcode, summed over all workgroups
+  u64 *const prof = reinterpret_cast<u64 *>(((u64)arena[3] << 32) | arena[2]);
+  __shared__ u64 s_prof[16];
+  if (prof && tid < 16) s_prof[tid] = 0;
+  const u64 t_begin = prof ? wall_clock64() : 0;
   for (uint32_t i = tid; i < r.n_counts; i += VT) s_cnt[i] = 0;
   __syncthreads();
   const u64 w0 = (u64)chunk * CHW;
@@ -132,7 +136,9 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   u64 *const cells = reinterpret_cast<u64 *>(state + 4);
   u64 *const counts = cells + MSI_VM_CELLS;
   const uint32_t *pc = arena + rp->phase_off[phase];
-  uint32_t fk_cnt = NONE;
+  // first-k commands of this phase: {slot, k, cardinality index, ids base} (wave-uniform; kept in LDS for the emit)
+  __shared__ uint32_t s_fk[MSI_VM_MAX_FK_PHASE][4];
+  uint32_t n_fk = 0;
   uint32_t *const chunk_card = reinterpret_cast<uint32_t *>(counts + r.n_counts);   // first-k: cardinality of the set per chunk
   auto add_count = [&](uint32_t idx, uint32_t c) {
     c = wave_sum(c);
@@ -142,6 +148,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   for (;;) {
     const uint32_t op = pc[0];
     if (op == VM_END) break;
+    const u64 t_op = prof ? wall_clock64() : 0;
     switch (op) {
       case VM_FILL: {
         ulonglong2 *d = S(pc[1]);
@@ -300,10 +307,11 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         if (op == VM_COUNT) {
           add_count(pc[2], c);
           pc += 3;
-        } else {          // slot, k, cnt: this chunk's cardinality is also kept for the ordered emit
+        } else {          // slot, k, cnt, ids base: this chunk's cardinality is also kept for the ordered emit
           add_count(pc[3], c);
-          fk_cnt = pc[3];
-          pc += 4;
+          if (tid < 4 && n_fk < MSI_VM_MAX_FK_PHASE) s_fk[n_fk][tid] = pc[1 + tid];
+          ++n_fk;
+          pc += 5;
         }
         break;
       }
@@ -432,7 +440,16 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         break;
     }
     if (!pc) break;
+    if (prof && tid == 0) s_prof[op & 15] += wall_clock64() - t_op;
   }
+  if (prof && tid == 0) {
+    for (int i = 1; i < 15; ++i)
+      if (s_prof[i]) atomicAdd(&prof[i], s_prof[i]);
+    atomicAdd(&prof[15], wall_clock64() - t_begin);   // the whole interpretation, commands + fetches
+    atomicAdd(&prof[0], 1ull);                        // workgroups
+    atomicMax(&cells[MSI_VM_CELLS - 1], ~t_begin);    // earliest start of a workgroup of this list (phase 0 profile only)
+  }
+  const u64 t_epi = prof ? wall_clock64() : 0;
 
   // ---- this workgroup's cardinalities leave LDS; the last workgroup of the list publishes --------------------
   __syncthreads();
@@ -443,8 +460,10 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   // without first-k orders its atomics and leaves the L2 alone (a full fence per workgroup wrote back and INVALIDATED
   // the L2 under every resident kernel 153 times per list at 10 M documents: single-list kernels took 100-300 us
   // under load, r2_ranked10_timeline_before.txt).
-  if (fk_cnt != NONE) {
-    if (tid == 0) __hip_atomic_store(&chunk_card[chunk], s_cnt[fk_cnt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  n_fk = min(n_fk, MSI_VM_MAX_FK_PHASE);
+  if (n_fk) {
+    if (tid < n_fk)
+      __hip_atomic_store(&chunk_card[tid * r.n_chunks + chunk], s_cnt[s_fk[tid][2]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
   } else {
     MSI_ORDER_ATOMICS();
@@ -452,37 +471,23 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(&state[phase], 1u) == r.n_chunks - 1 ? 1u : 0u;
   __syncthreads();
-  if (!s_last || phase != r.n_phases - 1) return;
-  if (fk_cnt != NONE) __threadfence();   // the set words the other workgroups wrote (read below with device-scope loads)
+  if (prof && tid == 0) atomicAdd(&prof[18], wall_clock64() - t_epi);   // counts out + ordering + ticket
+  if (!s_last) return;
+  if (prof && tid == 0) {
+    const u64 first = ~__hip_atomic_load(&cells[MSI_VM_CELLS - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(&prof[16], wall_clock64() - first);   // first workgroup's start .. last workgroup's ticket
+    atomicAdd(&prof[17], 1ull);
+  }
+  if (n_fk) __threadfence();   // the set words the other workgroups wrote (read below with device-scope loads)
   u64 *res = reinterpret_cast<u64 *>(r.host_res);
   uint32_t emitted = 0;
-  if (fk_cnt != NONE) {
+  // the first-k commands of THIS phase are emitted by this phase's last workgroup (the ids are in the host's block
+  // before the kernel of the list's last phase — a later launch on the same stream — publishes the sequence number)
+  for (uint32_t f = 0; f < n_fk; ++f) {
     // ordered emit of the first k documents: chunk cardinalities are known, so only the chunks that contribute are read
-    const uint32_t *pcf = arena + rp->phase_off[phase];
-    // find the command again (same walk as above; commands are self-delimiting)
-    uint32_t slot = 0, k = 0;
-    for (;;) {
-      const uint32_t op = pcf[0];
-      if (op == VM_END) break;
-      if (op == VM_FIRSTK) { slot = pcf[1]; k = pcf[2]; break; }
-      switch (op) {
-        case VM_FILL: pcf += 3; break;
-        case VM_OP: pcf += 5; break;
-        case VM_OP_COUNT: pcf += 6; break;
-        case VM_CLEAR: pcf += 2 + pcf[1]; break;
-        case VM_CLAIM: pcf += 5 + pcf[4]; break;
-        case VM_AND_MANY: pcf += 4 + 2 * pcf[2]; break;
-        case VM_PATHS: pcf += 7 + pcf[1] + (pcf[5] & 0x7FFFFFFFu); break;
-        case VM_SUB_MANY: pcf += 4 + pcf[2]; break;
-        case VM_COUNT: pcf += 3; break;
-        case VM_DECODE: pcf += 4; break;
-        case VM_MINKEY: pcf += 5; break;
-        case VM_TAKEKEY: pcf += 8; break;
-        default: pcf += 1; break;
-      }
-    }
-    const uint32_t *cc = chunk_card;
-    uint32_t *ids = reinterpret_cast<uint32_t *>(res + RES_IDS);
+    const uint32_t slot = s_fk[f][0], k = s_fk[f][1];
+    const uint32_t *cc = chunk_card + f * r.n_chunks;
+    uint32_t *ids = reinterpret_cast<uint32_t *>(res + RES_IDS) + s_fk[f][3];
     uint32_t running = 0;
     for (uint32_t c = 0; c < r.n_chunks && running < k; ++c) {
       const uint32_t n_c = __hip_atomic_load(&cc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -521,8 +526,9 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       __syncthreads();
       running += n_c;
     }
-    emitted = min(running, k);
+    emitted += min(running, k);
   }
+  if (phase != r.n_phases - 1) return;
   for (uint32_t i = tid; i < r.n_counts; i += VT) {
     const u64 v = __hip_atomic_load(&counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&res[RES_COUNTS + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -580,6 +586,7 @@ struct VmCombiner {
   // calls began, launch calls (per round), from the launch calls until the combiner saw the GPU's completion word
   std::atomic<uint64_t> ns_queued{0}, ns_packed{0}, ns_launch_calls{0}, ns_after_launch{0};
   std::atomic<uint32_t> load{0};           // lists submitted and not finished yet
+  u64 *d_prof = nullptr;                   // MSI_VM_PROFILE: 16 tick counters in device memory
   void run();
 };
 
@@ -654,6 +661,7 @@ void VmCombiner::run() {
   auto is_heavy = [](const VmSub *s) { return s->list->decodes.size() > 2 || s->list->words.size() > 600; };
   std::vector<VmSub *> waiting[2];   // taken from the queue, not launched yet (their class's arena is still in use)
   FILE *trace = getenv("MSI_VM_TRACE") ? fopen(getenv("MSI_VM_TRACE"), "w") : nullptr;
+  if (getenv("MSI_VM_PROFILE") && hipMalloc((void **)&d_prof, 24 * sizeof(u64)) == hipSuccess) (void)hipMemset(d_prof, 0, 24 * sizeof(u64));
   auto finish = [&](VmSub *s, uint32_t st) {
     s->t_done = now_ns();
     if (trace && s->list) {   // diagnostics: what a list was made of and how long the device took for it
@@ -675,7 +683,7 @@ void VmCombiner::run() {
           case VM_SUB_MANY: i += 4 + w[i + 2]; break;
           case VM_COUNT: i += 3; break;
           case VM_DECODE: i += 4; break;
-          case VM_FIRSTK: i += 4; break;
+          case VM_FIRSTK: i += 5; break;
           case VM_MINKEY: i += 5; break;
           case VM_TAKEKEY: i += 8; break;
           default: i = w_end; break;
@@ -704,7 +712,7 @@ void VmCombiner::run() {
       words_at[i] = off;
       off = align16(off + (l.words.size() + 1) * 4);
       state_at[i] = off;
-      off = align16(off + 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)chunks_of(batch[i]->pool) * 4);
+      off = align16(off + 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)chunks_of(batch[i]->pool) * 4 * l.max_fk_phase);
     }
     int32_t st = MSI_OK;
     if (off > 0xFFFFFFF0ull || !arena_ensure(this, A, off)) {
@@ -714,6 +722,8 @@ void VmCombiner::run() {
     if (st == MSI_OK) {
       memset(A.host, 0, 64);
       reinterpret_cast<uint32_t *>(A.host)[0] = (uint32_t)n_sub;
+      reinterpret_cast<uint32_t *>(A.host)[2] = (uint32_t)(uintptr_t)d_prof;
+      reinterpret_cast<uint32_t *>(A.host)[3] = (uint32_t)((uintptr_t)d_prof >> 32);
       RoundSub *subs = reinterpret_cast<RoundSub *>(A.host + 64);
       for (size_t i = 0; i < n_sub; ++i) {
         const MsiVmList &l = *batch[i]->list;
@@ -737,7 +747,7 @@ void VmCombiner::run() {
         r.n_decodes = (uint32_t)l.decodes.size();
         memcpy(A.host + words_at[i], l.words.data(), l.words.size() * 4);
         reinterpret_cast<uint32_t *>(A.host + words_at[i])[l.words.size()] = VM_END;
-        memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)r.n_chunks * 4);
+        memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)r.n_chunks * 4 * l.max_fk_phase);
         max_chunks = std::max(max_chunks, r.n_chunks);
         max_phases = std::max(max_phases, r.n_phases);
       }
@@ -864,6 +874,18 @@ void msi_vm_destroy(msi_vm *vmx) {
     DeviceGuard g(vm->ctx->device);
     for (auto st : vm->streams)
       if (st) (void)hipStreamSynchronize(st);
+    if (vm->d_prof) {
+      u64 t[24] = {0};
+      (void)hipMemcpy(t, vm->d_prof, sizeof t, hipMemcpyDeviceToHost);
+      static const char *names[16] = {"", "fill", "op", "op_count", "clear", "claim", "and_many", "paths", "sub_many", "count",
+                                      "decode", "firstk", "minkey", "takekey", "", "all"};
+      fprintf(stderr, "msi_vm profile: %llu workgroups, %.1f us each;", (unsigned long long)t[0], t[0] ? t[15] / 100.0 / t[0] : 0.0);
+      for (int i = 1; i < 14; ++i)
+        if (t[i]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * t[i] / (double)t[15]);
+      fprintf(stderr, "; epilogue %.1f us per workgroup; %llu list-phases, first start to last ticket %.1f us\n",
+              t[0] ? t[18] / 100.0 / t[0] : 0.0, (unsigned long long)t[17], t[17] ? t[16] / 100.0 / t[17] : 0.0);
+      (void)hipFree(vm->d_prof);
+    }
     for (auto &A : vm->ar) {
       if (A.host) (void)hipHostFree(A.host);
       if (A.dev) (void)hipFree(A.dev);
@@ -1076,10 +1098,9 @@ int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
       for (uint32_t i = 0; i < l.n_counts; ++i)
         res->counts[i] = __atomic_load_n(const_cast<uint64_t *>(&blk[RES_COUNTS + i]), __ATOMIC_RELAXED);
       res->firstk.clear();
-      if (l.wants_firstk) {
-        const uint32_t n = (uint32_t)__atomic_load_n(const_cast<uint64_t *>(&blk[1]), __ATOMIC_RELAXED);
+      if (l.firstk_total) {   // every first-k command's block of k ids, back to back (a set smaller than k fills less)
         const uint32_t *ids = reinterpret_cast<const uint32_t *>(const_cast<const uint64_t *>(blk) + RES_IDS);
-        res->firstk.assign(ids, ids + std::min<uint32_t>(n, MSI_VM_MAX_FIRSTK));
+        res->firstk.assign(ids, ids + std::min<uint32_t>(l.firstk_total, MSI_VM_MAX_FIRSTK));
       }
     }
   }

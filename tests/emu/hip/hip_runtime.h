@@ -394,6 +394,7 @@ inline void __syncthreads() {
   hipemu::g.lanes[hipemu::g.cur].state = hipemu::WAIT_BLOCK;
   hipemu::yield_to_scheduler();
 }
+inline unsigned long long wall_clock64() { return 0; }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 inline void __threadfence_system() {}
