@@ -671,7 +671,10 @@ def run_c3(args, env):
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if match_n else 0.0
     # VALU view (SURVEY §8 d: this kernel is integer-VALU bound, the dictionary is cache resident): wave-level
     # instruction counts of the two inner loops, counted in the gfx950 ISA of this build
-    I_FILTER, I_DP = 34, 900            # per 64-word filter step; per 64-pair DP drain (about 10 word chars)
+    # counted in the ISA of this build (hipcc -S of msi_dict.hip, dict_lookup_kernel): the filter step of 64 words is 31 VALU
+    # + 2 loads + 1 LDS store; a drain of 64 queued pairs is ~920 VALU to unpack the 16-byte slots into code points and set
+    # the band up, then 78-102 VALU per word char (two loop variants; ~9 chars per word on this dictionary)
+    I_FILTER, I_DP = 34, 920 + 90 * 9
     valu_instr = range_words / 64.0 * I_FILTER + dp_pairs / 64.0 * I_DP
     valu_peak = 256 * 4 * 2.4e9 / 2    # 1024 SIMDs, one wave64 VALU instruction per 2 cycles
     out = {
@@ -694,7 +697,7 @@ def run_c3(args, env):
                           "achieved": round(valu_instr / (avg_ms * 1e-3), 1) if match_n else 0.0, "peak": valu_peak,
                           "frac": round(valu_instr / (avg_ms * 1e-3) / valu_peak, 4) if match_n else 0.0,
                           "algorithmic_wave_instructions_per_launch": int(valu_instr),
-                          "model": f"{I_FILTER} per 64-word filter step + {I_DP} per 64-pair DP drain (ISA count, DESIGN §4.3)"},
+                          "model": f"{I_FILTER} per 64-word filter step + {I_DP} per 64-pair DP drain = 920 set-up + 90 per word char x 9 chars (ISA count, DESIGN §4.3)"},
     }
     if env.check:
         t_all, t_one, cores = cpu_typo_baseline(words, concat, off, args.cpu_sample_words)

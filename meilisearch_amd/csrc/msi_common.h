@@ -23,6 +23,16 @@
 #ifndef MSI_ORDER_ATOMICS
 #define MSI_ORDER_ATOMICS() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
 #endif
+// A value every lane of the wave holds alike, moved to a scalar register (uniform branches, scalar address arithmetic).
+#ifndef MSI_UNIFORM
+#define MSI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+// What a workgroup WROTE with plain stores must be in memory before another kernel — possibly on another XCD, possibly
+// started before this kernel ends — is told about it: write this XCD's L2 back (buffer_wbl2 sc1), but do not invalidate
+// it (the acquire half of __threadfence, buffer_inv sc1, is what evicts every resident kernel's cached lines).
+#ifndef MSI_RELEASE_DEVICE
+#define MSI_RELEASE_DEVICE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#endif
 #ifndef MSI_DYNAMIC_LDS
 #define MSI_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif

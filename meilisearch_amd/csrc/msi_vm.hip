@@ -49,6 +49,7 @@ constexpr int VT = 256;                 // threads per workgroup (512 measured 3
 constexpr int WPT = 1024 / VT;          // words of a chunk per thread in the ordered emit
 constexpr uint32_t CHW = 1024;          // u64 words per chunk (65 536 documents = one Roaring container span)
 constexpr uint32_t MAX_SUBS = 64;       // lists per round
+constexpr uint32_t CMD_LDS = 2048;                             // command words of a phase kept in LDS (longer phases: read from the arena)
 constexpr size_t RES_COUNTS = 2;                               // u64 index of counts[0] in the result block
 constexpr size_t RES_IDS = RES_COUNTS + MSI_VM_MAX_COUNTS;     // u64 index where the u32 ids start
 
@@ -63,7 +64,8 @@ struct alignas(16) RoundSub {
   uint32_t state_off;                     // arena word offset of {done[4] u32, cells[4] u64, counts[n_counts] u64, chunk cardinalities[n_chunks] u32}
   uint32_t n_counts;
   uint32_t n_decodes;
-  uint32_t _pad[3];
+  uint32_t n_cmd_words;                   // the list's command words (its decode descriptors follow them)
+  uint32_t _pad[2];
 };
 static_assert(sizeof(RoundSub) % 16 == 0, "RoundSub array stays 16-byte aligned");
 
@@ -102,12 +104,30 @@ __device__ __forceinline__ u64 doc_mask(u64 gw, u64 n_docs) {
   return (~0ull) >> (64 - (n_docs - lo));
 }
 
+// Every store of set words (and posting-cache bodies) is WRITE-THROUGH at device scope (global_store ... sc1): what a
+// list wrote is read by the search's next list — another kernel, on another stream and other XCDs, launched as soon as
+// the host sees this list's results, which can be before this kernel ends.  With write-back stores each workgroup had
+// to write its XCD's L2 back before its ticket (buffer_wbl2: 10 M documents, 64 threads: 1345 q/s); written through,
+// the ticket only waits for the stores' acknowledgements (2147 q/s).  The line stays valid in this XCD's L2 for the
+// commands that follow.
+__device__ __forceinline__ void put1(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void put(ulonglong2 *p, ulonglong2 v) {
+  put1(&p->x, v.x);
+  put1(&p->y, v.y);
+}
+__device__ __forceinline__ void put4(uint4 *p, uint4 v) {
+  u64 *q = reinterpret_cast<u64 *>(p);
+  put1(q, (u64)v.x | ((u64)v.y << 32));
+  put1(q + 1, (u64)v.z | ((u64)v.w << 32));
+}
+
 __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, uint32_t phase) {
   __shared__ uint32_t s_cnt[MSI_VM_MAX_COUNTS];
   __shared__ u64 s_dec[CHW];
   __shared__ uint4 s_raw[CHW * 8 / 16 + 2];   // one container body (<= 8 KiB) + alignment slack, staged with wide loads
   __shared__ uint32_t s_scan[VT / 64 + 1];
   __shared__ uint32_t s_last;
+  __shared__ uint32_t s_cmd[CMD_LDS];          // this phase's command words (read once, coalesced)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (fields are read one by one: a by-value copy of the struct lands in scratch because phase_off[] is indexed dynamically)
   const RoundSub *const rp = reinterpret_cast<const RoundSub *>(arena + 16) + blockIdx.y;
@@ -126,7 +146,18 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   if (prof && tid < 16) s_prof[tid] = 0;
   const u64 t_begin = prof ? wall_clock64() : 0;
   for (uint32_t i = tid; i < r.n_counts; i += VT) s_cnt[i] = 0;
+  // The phase's commands go to LDS and every command word is read as a wave-uniform scalar.  (Read from the arena with
+  // per-lane loads — the compiler cannot know they are uniform — each command cost two dependent trips to memory, opcode
+  // then operands, before its first set word was even requested, and the interpreter branched on vector compares.)
+  const uint32_t p_begin = rp->phase_off[phase];
+  const uint32_t p_end = phase + 1 < r.n_phases ? rp->phase_off[phase + 1] : r.list_off + rp->n_cmd_words;
+  const bool in_lds = p_end - p_begin <= CMD_LDS;
+  if (in_lds)
+    for (uint32_t i = tid; i < p_end - p_begin; i += VT) s_cmd[i] = arena[p_begin + i];
   __syncthreads();
+  const uint32_t *const cmd = in_lds ? s_cmd : arena + p_begin;
+  uint32_t pcw = 0;                              // word index of the current command
+#define W(i) MSI_UNIFORM(cmd[pcw + (i)])
   const u64 w0 = (u64)chunk * CHW;
   const uint32_t nw = (uint32_t)min((u64)CHW, r.n_words - w0);   // even: slots are whole 16-byte pairs
   const uint32_t n_pairs = nw / 2;
@@ -135,7 +166,6 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   uint32_t *const state = arena + r.state_off;
   u64 *const cells = reinterpret_cast<u64 *>(state + 4);
   u64 *const counts = cells + MSI_VM_CELLS;
-  const uint32_t *pc = arena + rp->phase_off[phase];
   // first-k commands of this phase: {slot, k, cardinality index, ids base} (wave-uniform; kept in LDS for the emit)
   __shared__ uint32_t s_fk[MSI_VM_MAX_FK_PHASE][4];
   uint32_t n_fk = 0;
@@ -146,106 +176,106 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   };
 
   for (;;) {
-    const uint32_t op = pc[0];
+    const uint32_t op = W(0);
     if (op == VM_END) break;
     const u64 t_op = prof ? wall_clock64() : 0;
     switch (op) {
       case VM_FILL: {
-        ulonglong2 *d = S(pc[1]);
-        const bool ones = pc[2] != 0;
+        ulonglong2 *d = S(W(1));
+        const bool ones = W(2) != 0;
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           ulonglong2 v = make_ulonglong2(0, 0);
           if (ones) {
             v.x = doc_mask(w0 + 2 * p, r.n_docs);
             v.y = doc_mask(w0 + 2 * p + 1, r.n_docs);
           }
-          d[p] = v;
+          put(&d[p], v);
         }
-        pc += 3;
+        pcw += 3;
         break;
       }
       case VM_OP:
       case VM_OP_COUNT: {
-        ulonglong2 *d = S(pc[1]);
-        const ulonglong2 *a = S(pc[2]), *b = S(pc[3]);
-        const uint32_t o = pc[4];
+        ulonglong2 *d = S(W(1));
+        const ulonglong2 *a = S(W(2)), *b = S(W(3));
+        const uint32_t o = W(4);
         uint32_t c = 0;
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           const ulonglong2 v = apply_op(o, a[p], b[p]);
-          d[p] = v;
+          put(&d[p], v);
           c += __popcll(v.x) + __popcll(v.y);
         }
         if (op == VM_OP_COUNT) {
-          add_count(pc[5], c);
-          pc += 6;
+          add_count(W(5), c);
+          pcw += 6;
         } else {
-          pc += 5;
+          pcw += 5;
         }
         break;
       }
       case VM_CLEAR: {
-        const uint32_t n = pc[1];
+        const uint32_t n = W(1);
         for (uint32_t k = 0; k < n; ++k) {
-          ulonglong2 *d = S(pc[2 + k]);
-          for (uint32_t p = tid; p < n_pairs; p += VT) d[p] = make_ulonglong2(0, 0);
+          ulonglong2 *d = S(W(2 + k));
+          for (uint32_t p = tid; p < n_pairs; p += VT) put(&d[p], make_ulonglong2(0, 0));
         }
-        pc += 2 + n;
+        pcw += 2 + n;
         break;
       }
       case VM_CLAIM: {  // bucket |= docs; universe &= ~docs; stack[i] &= ~docs   (docs may be one of the stack slots)
-        const ulonglong2 *docs = S(pc[1]);
-        ulonglong2 *bucket = S(pc[2]), *uni = S(pc[3]);
-        const uint32_t n = pc[4];
+        const ulonglong2 *docs = S(W(1));
+        ulonglong2 *bucket = S(W(2)), *uni = S(W(3));
+        const uint32_t n = W(4);
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           const ulonglong2 dd = docs[p];
           if (!(dd.x | dd.y)) continue;
           ulonglong2 b = bucket[p], u = uni[p];
           b.x |= dd.x; b.y |= dd.y;
           u.x &= ~dd.x; u.y &= ~dd.y;
-          bucket[p] = b;
-          uni[p] = u;
+          put(&bucket[p], b);
+          put(&uni[p], u);
           for (uint32_t k = 0; k < n; ++k) {
-            ulonglong2 *sk = S(pc[5 + k]);
+            ulonglong2 *sk = S(W(5 + k));
             ulonglong2 s = sk[p];
             s.x &= ~dd.x; s.y &= ~dd.y;
-            sk[p] = s;
+            put(&sk[p], s);
           }
         }
-        pc += 5 + n;
+        pcw += 5 + n;
         break;
       }
       case VM_AND_MANY: {  // dst[i] = prefix & cond[i], counts[base + i] = |dst[i]|
-        const ulonglong2 *pre = S(pc[1]);
-        const uint32_t n = pc[2], base = pc[3];
+        const ulonglong2 *pre = S(W(1));
+        const uint32_t n = W(2), base = W(3);
         for (uint32_t k = 0; k < n; ++k) {
-          const ulonglong2 *cnd = S(pc[4 + 2 * k]);
-          ulonglong2 *d = S(pc[5 + 2 * k]);
+          const ulonglong2 *cnd = S(W(4 + 2 * k));
+          ulonglong2 *d = S(W(5 + 2 * k));
           uint32_t c = 0;
           for (uint32_t p = tid; p < n_pairs; p += VT) {
             const ulonglong2 x = pre[p], y = cnd[p];
             ulonglong2 v;
             v.x = x.x & y.x; v.y = x.y & y.y;
-            d[p] = v;
+            put(&d[p], v);
             c += __popcll(v.x) + __popcll(v.y);
           }
           add_count(base + k, c);
         }
-        pc += 4 + 2 * n;
+        pcw += 4 + 2 * n;
         break;
       }
       case VM_PATHS: {  // the paths of one cost level in DFS order: a path claims what the earlier paths left
-        const uint32_t n_paths = pc[1];
-        ulonglong2 *bucket = S(pc[2]), *uni = S(pc[3]);
-        const uint32_t base = pc[4], n_steps = pc[5] & 0x7FFFFFFFu;
-        const bool fresh = (pc[5] >> 31) != 0;   // the bucket's previous content is garbage: this level writes it whole
-        const uint32_t *off = pc + 6, *steps = off + n_paths + 1;
+        const uint32_t n_paths = W(1);
+        ulonglong2 *bucket = S(W(2)), *uni = S(W(3));
+        const uint32_t base = W(4), n_steps = W(5) & 0x7FFFFFFFu;
+        const bool fresh = (W(5) >> 31) != 0;   // the bucket's previous content is garbage: this level writes it whole
+        const uint32_t *off = cmd + pcw + 6, *steps = off + n_paths + 1;   // read inside the per-pair loop: plain (LDS) loads
         // Paths are resolved four at a time: the condition words of the four paths are loaded back to back (no load
         // waits for the result of another), then the paths claim in order.  A serial "load, AND, test, next step" chain
         // made a level of a few hundred steps cost hundreds of microseconds of pure memory latency per workgroup.
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           ulonglong2 u = uni[p];
           if (!(u.x | u.y)) {
-            if (fresh) bucket[p] = make_ulonglong2(0, 0);
+            if (fresh) put(&bucket[p], make_ulonglong2(0, 0));
             continue;
           }
           ulonglong2 b = fresh ? make_ulonglong2(0, 0) : bucket[p];
@@ -272,53 +302,53 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
               }
             }
           }
-          bucket[p] = b;
-          uni[p] = u;
+          put(&bucket[p], b);
+          put(&uni[p], u);
         }
-        pc += 7 + n_paths + n_steps;
+        pcw += 7 + n_paths + n_steps;
         break;
       }
       case VM_SUB_MANY: {  // slot[i] &= ~removed, counts[base + i] = |slot[i]|
-        const ulonglong2 *rm = S(pc[1]);
-        const uint32_t n = pc[2], base = pc[3];
+        const ulonglong2 *rm = S(W(1));
+        const uint32_t n = W(2), base = W(3);
         for (uint32_t k = 0; k < n; ++k) {
-          ulonglong2 *d = S(pc[4 + k]);
+          ulonglong2 *d = S(W(4 + k));
           uint32_t c = 0;
           for (uint32_t p = tid; p < n_pairs; p += VT) {
             const ulonglong2 x = rm[p];
             ulonglong2 v = d[p];
             v.x &= ~x.x; v.y &= ~x.y;
-            d[p] = v;
+            put(&d[p], v);
             c += __popcll(v.x) + __popcll(v.y);
           }
           add_count(base + k, c);
         }
-        pc += 4 + n;
+        pcw += 4 + n;
         break;
       }
       case VM_COUNT:
       case VM_FIRSTK: {
-        const ulonglong2 *a = S(pc[1]);
+        const ulonglong2 *a = S(W(1));
         uint32_t c = 0;
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           const ulonglong2 v = a[p];
           c += __popcll(v.x) + __popcll(v.y);
         }
         if (op == VM_COUNT) {
-          add_count(pc[2], c);
-          pc += 3;
+          add_count(W(2), c);
+          pcw += 3;
         } else {          // slot, k, cnt, ids base: this chunk's cardinality is also kept for the ordered emit
-          add_count(pc[3], c);
-          if (tid < 4 && n_fk < MSI_VM_MAX_FK_PHASE) s_fk[n_fk][tid] = pc[1 + tid];
+          add_count(W(3), c);
+          if (tid < 4 && n_fk < MSI_VM_MAX_FK_PHASE) s_fk[n_fk][tid] = cmd[pcw + 1 + tid];
           ++n_fk;
-          pc += 5;
+          pcw += 5;
         }
         break;
       }
       case VM_DECODE: {  // the containers of THIS chunk of every posting of the batch, OR-ed in LDS, written once
-        ulonglong2 *d = S(pc[1]);
-        const bool overwrite = pc[2] != 0;
-        const uint32_t di = pc[3];                       // index of this decode among the list's decodes
+        ulonglong2 *d = S(W(1));
+        const bool overwrite = W(2) != 0;
+        const uint32_t di = W(3);                       // index of this decode among the list's decodes
         // chunk-major descriptor block of this workgroup (device memory): counts per decode, then the containers
         const uint32_t *data = arena + r.list_off + r.data_off;
         const uint32_t *blk_c = data + 4 * (size_t)data[chunk];          // chunk_off[] is in 16-byte units
@@ -348,7 +378,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
               // first reader of this key: the body goes into the cache on the way (same skew there: serialisations start
               // 16-byte aligned in both places; the partial blocks at the ends carry the neighbouring bytes of the SAME
               // serialisation, so a racing neighbour writes identical values)
-              if (fill) fill[i] = v;
+              if (fill) put4(&fill[i], v);
             }
             __syncthreads();
             const uint8_t *body = reinterpret_cast<const uint8_t *>(s_raw) + skew;
@@ -383,18 +413,18 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
               const ulonglong2 o = d[p];
               v.x |= o.x; v.y |= o.y;
             }
-            d[p] = v;
+            put(&d[p], v);
           }
         } else if (overwrite) {
-          for (uint32_t p = tid; p < n_pairs; p += VT) d[p] = make_ulonglong2(0, 0);
+          for (uint32_t p = tid; p < n_pairs; p += VT) put(&d[p], make_ulonglong2(0, 0));
         }
-        pc += 4;
+        pcw += 4;
         break;
       }
       case VM_MINKEY: {  // Sort rule, first half: the smallest order key among the documents of the universe
         __syncthreads();  // one document per thread from here: other threads' set words must be visible
-        const u64 *uni = pool + (u64)pc[1] * r.n_words + w0;
-        const uint32_t *keys = reinterpret_cast<const uint32_t *>(((u64)pc[3] << 32) | pc[2]);
+        const u64 *uni = pool + (u64)W(1) * r.n_words + w0;
+        const uint32_t *keys = reinterpret_cast<const uint32_t *>(((u64)W(3) << 32) | W(2));
         uint32_t inv = 0;
         for (uint32_t w = wave; w < nw; w += VT / 64) {
           const u64 word = uni[w];
@@ -404,16 +434,16 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) inv = max(inv, (uint32_t)__shfl_xor((int)inv, o));
-        if (lane == 0 && inv) atomicMax(&cells[pc[4]], (u64)inv);
-        pc += 5;
+        if (lane == 0 && inv) atomicMax(&cells[W(4)], (u64)inv);
+        pcw += 5;
         break;
       }
       case VM_TAKEKEY: {  // second half (next phase): bucket = the documents with that key, universe -= bucket
         __syncthreads();
-        u64 *uni = pool + (u64)pc[1] * r.n_words + w0;
-        u64 *bucket = pool + (u64)pc[2] * r.n_words + w0;
-        const uint32_t *keys = reinterpret_cast<const uint32_t *>(((u64)pc[4] << 32) | pc[3]);
-        const uint32_t key = 0xFFFFFFFFu - (uint32_t)cells[pc[5]];
+        u64 *uni = pool + (u64)W(1) * r.n_words + w0;
+        u64 *bucket = pool + (u64)W(2) * r.n_words + w0;
+        const uint32_t *keys = reinterpret_cast<const uint32_t *>(((u64)W(4) << 32) | W(3));
+        const uint32_t key = 0xFFFFFFFFu - (uint32_t)cells[W(5)];
         uint32_t c = 0;
         for (uint32_t w = wave; w < nw; w += VT / 64) {
           const u64 word = uni[w];
@@ -424,22 +454,22 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
             mask = __ballot(hit);
           }
           if (lane == 0) {
-            bucket[w] = mask;
-            if (mask) uni[w] = word & ~mask;
+            put1(&bucket[w], mask);
+            if (mask) put1(&uni[w], word & ~mask);
             c += (uint32_t)__popcll(mask);
           }
         }
-        if (lane == 0 && c) atomicAdd(&s_cnt[pc[6]], c);
-        if (chunk == 0 && tid == 0) s_cnt[pc[7]] = key;   // the key itself travels as a "count"
+        if (lane == 0 && c) atomicAdd(&s_cnt[W(6)], c);
+        if (chunk == 0 && tid == 0) s_cnt[W(7)] = key;   // the key itself travels as a "count"
         __syncthreads();
-        pc += 8;
+        pcw += 8;
         break;
       }
       default:
-        pc = nullptr;  // unknown opcode: stop (the host validates what it records)
+        pcw = 0xFFFFFFFFu;  // unknown opcode: stop (the host validates what it records)
         break;
     }
-    if (!pc) break;
+    if (pcw == 0xFFFFFFFFu) break;
     if (prof && tid == 0) s_prof[op & 15] += wall_clock64() - t_op;
   }
   if (prof && tid == 0) {
@@ -451,23 +481,20 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   }
   const u64 t_epi = prof ? wall_clock64() : 0;
 
+#undef W
   // ---- this workgroup's cardinalities leave LDS; the last workgroup of the list publishes --------------------
   __syncthreads();
   for (uint32_t i = tid; i < r.n_counts; i += VT)
     if (s_cnt[i]) atomicAdd(&counts[i], (u64)s_cnt[i]);
-  // What another workgroup reads of this one: the cardinalities (device-scope atomics), and — only for the ordered
-  // emit of a first-k command — the words of one set.  Only the latter needs this XCD's L2 written back; a list
-  // without first-k orders its atomics and leaves the L2 alone (a full fence per workgroup wrote back and INVALIDATED
-  // the L2 under every resident kernel 153 times per list at 10 M documents: single-list kernels took 100-300 us
-  // under load, r2_ranked10_timeline_before.txt).
+  // Everything this workgroup stored is write-through (put): the ticket below only has to wait until those stores
+  // and the cardinalities' atomics are acknowledged — no L2 write-back, no invalidate (a __threadfence here cost both,
+  // under every resident kernel, 153 times per list at 10 M documents: r2_ranked10_timeline_before.txt).
   n_fk = min(n_fk, MSI_VM_MAX_FK_PHASE);
   if (n_fk) {
     if (tid < n_fk)
       __hip_atomic_store(&chunk_card[tid * r.n_chunks + chunk], s_cnt[s_fk[tid][2]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-  } else {
-    MSI_ORDER_ATOMICS();
   }
+  MSI_ORDER_ATOMICS();
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(&state[phase], 1u) == r.n_chunks - 1 ? 1u : 0u;
   __syncthreads();
@@ -745,6 +772,7 @@ void VmCombiner::run() {
         r.n_counts = l.n_counts;
         r.data_off = l.data_off;
         r.n_decodes = (uint32_t)l.decodes.size();
+        r.n_cmd_words = l.data_off ? l.data_off : (uint32_t)l.words.size() + 1;
         memcpy(A.host + words_at[i], l.words.data(), l.words.size() * 4);
         reinterpret_cast<uint32_t *>(A.host + words_at[i])[l.words.size()] = VM_END;
         memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)r.n_chunks * 4 * l.max_fk_phase);

@@ -41,6 +41,8 @@
 #define __launch_bounds__(...)
 #define MSI_DYNAMIC_LDS(name) unsigned char *name = hipemu::g.dyn_lds
 #define MSI_ORDER_ATOMICS() ((void)0)
+#define MSI_RELEASE_DEVICE() ((void)0)
+#define MSI_UNIFORM(x) (x)
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
