@@ -431,10 +431,16 @@ def run_c4(args, env):
             store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)
             ctx.synchronize()
         legs["vector_only_queries_per_s"] = round(3 * Q / (time.perf_counter() - t0), 1)
+        import resource
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         for _ in range(3):
             keyword_run()
-        legs["keyword_only_queries_per_s"] = round(3 * Q / (time.perf_counter() - t0), 1)
+        dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        legs["keyword_only_queries_per_s"] = round(3 * Q / dt, 1)
+        legs["keyword_only_host_cpus_used"] = round((ru1.ru_utime + ru1.ru_stime - ru0.ru_utime - ru0.ru_stime) / dt, 2)
+        legs["host_cpus_allowed"] = len(os.sched_getaffinity(0))
         pc = (C.c_uint64 * 4)()
         ma._lib.lib().msi_dict_posting_cache_stats(C.c_void_p(kw["lib"].rb_dict(kw["h"])), pc)
         vs = (C.c_uint64 * 6)()

@@ -897,6 +897,28 @@ uint32_t msi_federated_merge(uint32_t n_lists, const uint32_t *list_len, const m
 int32_t msi_results_good_enough(const double *keyword_global_scores, uint32_t n,
                                 uint32_t limit_plus_offset, float semantic_ratio);
 
+/* ---- `_vectors` filter leaf (search/facet/filter/vector.rs:49-158) ----------------------------------------
+ * `_vectors EXISTS`-style conditions select documents by which vector stores hold an item for them.  The stores already
+ * live in HBM, so the leaf is built there: msi_vs_items_bits / msi_bq_items_bits OR a store's docids into a slot (what
+ * VectorStore::items_in_store / aggregate_stats().documents return, store.rs), and msi_bits_vector_filter is
+ * evaluate_inner (vector.rs:78-158) for ONE embedder:
+ *   NONE               the documents of the embedder's stores                                   (:146-150)
+ *   FRAGMENT           the items of the fragment's store(s) minus user_provided                  (:101-125)
+ *   DOCUMENT_TEMPLATE  nothing when the embedder has fragments, else documents - user_provided   (:126-135)
+ *   USER_PROVIDED      the index's user_provided bitmap of the embedder                          (:136-139)
+ *   REGENERATE         documents - skip_regenerate                                               (:140-145)
+ * `user_provided` / `skip_regenerate` are slots holding EmbeddingStatus's bitmaps (msi_bits_set_from_cbo); `scratch` is
+ * a slot the call may overwrite.  evaluate() (vector.rs:49-76) is the shim's loop: accumulate != 0 over the named
+ * embedder (or all of them), then one msi_bits_op AND with the universe.  Unknown embedder / fragment names are the
+ * shim's errors (it owns the embedding configs). */
+enum { MSI_VECTOR_FILTER_NONE = 0, MSI_VECTOR_FILTER_FRAGMENT = 1, MSI_VECTOR_FILTER_DOCUMENT_TEMPLATE = 2,
+       MSI_VECTOR_FILTER_USER_PROVIDED = 3, MSI_VECTOR_FILTER_REGENERATE = 4 };
+int32_t msi_vs_items_bits(msi_vs *store, msi_bits *pool, uint32_t slot);
+int32_t msi_bq_items_bits(msi_bq *store, msi_bits *pool, uint32_t slot);
+int32_t msi_bits_vector_filter(msi_bits *pool, uint32_t dst, int32_t kind, int32_t embedder_has_fragments,
+                               msi_vs *const *stores, uint32_t n_stores, msi_bq *const *bq_stores, uint32_t n_bq_stores,
+                               uint32_t user_provided, uint32_t skip_regenerate, uint32_t scratch, int32_t accumulate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,6 +185,9 @@ PROTOTYPES = {
     "msi_bq_dim": (_U32, [_VP]),
     "msi_bq_get_vector": (_I32, [_VP, _U32, _VP, C.POINTER(_I32)]),
     "msi_bq_search": (_I32, [_VP, _VP, _U32, _U32, _VP, _U64, _VP, _VP, _VP]),
+    "msi_vs_items_bits": (_I32, [_VP, _VP, _U32]),
+    "msi_bq_items_bits": (_I32, [_VP, _VP, _U32]),
+    "msi_bits_vector_filter": (_I32, [_VP, _U32, _I32, _I32, _VP, _U32, _VP, _U32, _U32, _U32, _U32, _I32]),
     "msi_federated_compare": (_I32, [_VP, _U32, _F64, _VP, _U32, _F64]),
     "msi_federated_merge": (_U32, [_U32, _VP, _VP, _VP, _VP, _U32, _U32, _VP, _VP]),
     "msi_dict_create": (_I32, [_VP, _VP, _VP, _U32, C.POINTER(_VP)]),

@@ -67,6 +67,18 @@ class BitsPool:
         """dst := the documents of src within radius_m metres of (lat, lng): `_geoRadius` (index_filter.rs:465-503)."""
         check(lib().msi_bits_geo_within(self._h, points._h, src, float(lat), float(lng), float(radius_m), dst))
 
+    VECTOR_FILTER_KINDS = {"none": 0, "fragment": 1, "documentTemplate": 2, "userProvided": 3, "regenerate": 4}
+
+    def vector_filter(self, dst, kind, stores=(), bq_stores=(), has_fragments=False, user_provided=0, skip_regenerate=0,
+                      scratch=0, accumulate=False):
+        """`_vectors.<embedder>[...]` for one embedder (search/facet/filter/vector.rs:78-158): the items of its stores
+        minus the user-provided / skip-regenerate bitmaps as `kind` asks; accumulate=True ORs into dst."""
+        import ctypes as C
+        vs = (C.c_void_p * max(1, len(stores)))(*[s._h for s in stores])
+        bq = (C.c_void_p * max(1, len(bq_stores)))(*[s._h for s in bq_stores])
+        check(lib().msi_bits_vector_filter(self._h, dst, self.VECTOR_FILTER_KINDS[kind], 1 if has_fragments else 0, vs, len(stores),
+                                           bq, len(bq_stores), user_provided, skip_regenerate, scratch, 1 if accumulate else 0))
+
     def geo_next(self, points, universe, bucket, scratch, lat, lng, ascending=True, max_bucket_size=1000, margin=1.0):
         """GeoSort's next bucket (documents/geo_sort.rs:150-224): the documents of `universe` within `margin` metres of
         the nearest (farthest) one, at most max_bucket_size; universe -= bucket.

@@ -892,6 +892,14 @@ __global__ void bits_set_docids_kernel(u64 *__restrict__ dst, uint64_t n_docs,
   if ((uint64_t)id < n_docs) atomicOr(&dst[id >> 6], 1ull << (id & 63));
 }
 
+// slot |= {docids[i] : i < n, docids[i] < n_docs} — the items of a vector store as a docid set (`_vectors` filter leaf)
+__global__ void bits_or_docids_kernel(u64 *__restrict__ slot, uint64_t n_docs, const uint32_t *__restrict__ docids, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t d = docids[i];
+    if (d < n_docs) atomicOr(&slot[d >> 6], 1ull << (d & 63));
+  }
+}
+
 // slot(first + y * stride) := the documents of list y (device-resident lists, e.g. the top-k rows of a vector
 // search: the rerank universes of many queries in two launches)
 __global__ void bits_clear_slots_kernel(u64 *__restrict__ pool, uint64_t n_words, uint32_t first, uint32_t stride) {
@@ -1198,6 +1206,58 @@ int32_t msi_bits_set_from_docid_lists_device(msi_bits *p, uint32_t first_slot, u
                      p->pool.as<u64>(), p->n_words, p->n_docs, first_slot, slot_stride, d_docids, list_stride, d_counts);
   MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
+}
+
+// internal: slot |= the docids of a device-resident ascending list (the items of a vector store)
+int32_t msi_bits_or_docids_device(msi_bits *p, uint32_t slot, const uint32_t *d_docids, uint64_t n) {
+  MSI_TRY(check_slot(p, slot, "msi_bits_or_docids_device"));
+  if (!n) return MSI_OK;
+  if (!d_docids) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((n + BT - 1) / BT, (uint64_t)std::max(1, p->ctx->n_cu) * 8);
+  hipLaunchKernelGGL(bits_or_docids_kernel, dim3(grid), dim3(BT), 0, p->stream, p->slot(slot), p->n_docs, d_docids, n);
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+// `_vectors.{embedder}[.fragments.{f} | .userProvided | .documentTemplate | .regenerate]` for ONE embedder
+// (search/facet/filter/vector.rs:78-158, evaluate_inner): the items of the embedder's stores as a docid set, minus the
+// index's user_provided / skip_regenerate bitmaps as the variant asks.
+int32_t msi_bits_vector_filter(msi_bits *p, uint32_t dst, int32_t kind, int32_t embedder_has_fragments,
+                               msi_vs *const *stores, uint32_t n_stores, msi_bq *const *bq_stores, uint32_t n_bq_stores,
+                               uint32_t user_provided, uint32_t skip_regenerate, uint32_t scratch, int32_t accumulate) {
+  if (!p || kind < MSI_VECTOR_FILTER_NONE || kind > MSI_VECTOR_FILTER_REGENERATE || (n_stores && !stores) ||
+      (n_bq_stores && !bq_stores)) {
+    msi_set_error("msi_bits_vector_filter: invalid argument");
+    return MSI_E_INVALID;
+  }
+  MSI_TRY(check_slot(p, dst, "msi_bits_vector_filter"));
+  MSI_TRY(check_slot(p, scratch, "msi_bits_vector_filter"));
+  if (scratch == dst) {
+    msi_set_error("msi_bits_vector_filter: scratch must differ from dst");
+    return MSI_E_INVALID;
+  }
+  const bool needs_up = kind == MSI_VECTOR_FILTER_FRAGMENT || kind == MSI_VECTOR_FILTER_DOCUMENT_TEMPLATE ||
+                        kind == MSI_VECTOR_FILTER_USER_PROVIDED;
+  if (needs_up) MSI_TRY(check_slot(p, user_provided, "msi_bits_vector_filter (user_provided)"));
+  if (kind == MSI_VECTOR_FILTER_REGENERATE) MSI_TRY(check_slot(p, skip_regenerate, "msi_bits_vector_filter (skip_regenerate)"));
+  if (kind == MSI_VECTOR_FILTER_USER_PROVIDED) {   // vector.rs:136-139
+    if (accumulate) return msi_bits_op(p, dst, dst, user_provided, MSI_BITS_OR);
+    return msi_bits_op(p, dst, user_provided, user_provided, MSI_BITS_OR);
+  }
+  MSI_TRY(msi_bits_fill(p, scratch, 0));
+  // DocumentTemplate on an embedder that has fragments selects nothing (vector.rs:126-129)
+  if (!(kind == MSI_VECTOR_FILTER_DOCUMENT_TEMPLATE && embedder_has_fragments)) {
+    for (uint32_t i = 0; i < n_stores; ++i) MSI_TRY(msi_vs_items_bits(stores[i], p, scratch));      // stats.documents /
+    for (uint32_t i = 0; i < n_bq_stores; ++i) MSI_TRY(msi_bq_items_bits(bq_stores[i], p, scratch));  // items_in_store
+    if (kind == MSI_VECTOR_FILTER_FRAGMENT || kind == MSI_VECTOR_FILTER_DOCUMENT_TEMPLATE)
+      MSI_TRY(msi_bits_op(p, scratch, scratch, user_provided, MSI_BITS_ANDNOT));                      // :121-124, :131-134
+    else if (kind == MSI_VECTOR_FILTER_REGENERATE)
+      MSI_TRY(msi_bits_op(p, scratch, scratch, skip_regenerate, MSI_BITS_ANDNOT));                    // :140-145
+  }
+  if (accumulate) return msi_bits_op(p, dst, dst, scratch, MSI_BITS_OR);
+  return msi_bits_op(p, dst, scratch, scratch, MSI_BITS_OR);
 }
 
 int32_t msi_bits_set_from_words(msi_bits *p, uint32_t slot, const uint64_t *words, uint64_t n_words) {

@@ -643,4 +643,13 @@ int32_t msi_bq_search(msi_bq *b, const float *queries, uint32_t n_queries, uint3
   return MSI_OK;
 }
 
+int32_t msi_bq_items_bits(msi_bq *b, msi_bits *pool, uint32_t slot) {
+  if (!b || !pool) return MSI_E_INVALID;
+  if (msi_bits_ctx(pool) != b->ctx) {
+    msi_set_error("msi_bq_items_bits: the pool and the store live on different contexts");
+    return MSI_E_INVALID;
+  }
+  return msi_bits_or_docids_device(pool, slot, b->docids.as<uint32_t>(), b->n_rows);
+}
+
 }  // extern "C"

@@ -187,6 +187,8 @@ bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len, 
                           uint64_t cache_fill = MSI_NO_CACHE);
 uint64_t msi_cbo_cardinality(const uint8_t *bytes, size_t len);
 int32_t msi_bits_decode_batch(msi_bits *p, uint32_t slot, const MsiCboBatch &batch, bool clear);
+extern "C" int32_t msi_bits_or_docids_device(msi_bits *p, uint32_t slot, const uint32_t *d_docids, uint64_t n);
+msi_ctx *msi_bits_ctx(msi_bits *p);
 // Fused set steps of the path search (msi_search.hip), one launch each:
 //   and_many:  dst[i] = prefix & cond[i], counts[i] = |dst[i]|   (n <= MSI_BITS_MANY; one completion signal)
 //   claim:     bucket |= docs; universe &= ~docs; stack[i] &= ~docs   (docs may be one of the stack slots)

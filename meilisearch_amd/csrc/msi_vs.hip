@@ -1921,4 +1921,14 @@ int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out) {
   return MSI_OK;
 }
 
+// The store's items as a docid set: pool[slot] |= {docids of the rows} (filter/vector.rs: items_in_store / aggregate_stats)
+int32_t msi_vs_items_bits(msi_vs *vs, msi_bits *pool, uint32_t slot) {
+  if (!vs || !pool) return MSI_E_INVALID;
+  if (msi_bits_ctx(pool) != vs->ctx) {
+    msi_set_error("msi_vs_items_bits: the pool and the store live on different contexts");
+    return MSI_E_INVALID;
+  }
+  return msi_bits_or_docids_device(pool, slot, vs->docids.as<uint32_t>(), vs->n_rows);
+}
+
 }  // extern "C"

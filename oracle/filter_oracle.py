@@ -132,3 +132,29 @@ def evaluate(index, e):
             lng = evaluate_condition(index, "_geo.lng", "to", [repr(left), repr(right)])
         return lat & lng
     raise ValueError(k)
+
+
+def vector_filter(kind, has_fragments, store_items, user_provided, skip_regenerate):
+    """evaluate_inner of the `_vectors` filter for one embedder, on plain sets
+    (crates/milli/src/search/facet/filter/vector.rs:78-158).  store_items: the docid sets of the stores the variant
+    looks at (Fragment: the fragment's store, :101-125; the others: every store of the embedder, i.e. what
+    VectorStore::aggregate_stats().documents holds)."""
+    documents = set().union(*store_items) if store_items else set()
+    if kind == "fragment":
+        return documents - set(user_provided)                      # :121-124
+    if kind == "documentTemplate":
+        return set() if has_fragments else documents - set(user_provided)   # :126-135
+    if kind == "userProvided":
+        return set(user_provided)                                  # :136-139
+    if kind == "regenerate":
+        return documents - set(skip_regenerate)                    # :140-145
+    return documents                                               # :146-150
+
+
+def vector_filter_all(embedders, kind, universe=None):
+    """evaluate (vector.rs:49-76): the union over the named embedders, then `& universe`.
+    embedders: [(has_fragments, store_items, user_provided, skip_regenerate)]."""
+    out = set()
+    for has_fragments, store_items, up, sr in embedders:
+        out |= vector_filter(kind, has_fragments, store_items, up, sr)
+    return out & set(universe) if universe is not None else out

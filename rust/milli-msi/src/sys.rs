@@ -6,6 +6,19 @@ use std::os::raw::{c_char, c_void};
 #[repr(C)] pub struct msi_vs { _p: [u8; 0] }
 #[repr(C)] pub struct msi_dict { _p: [u8; 0] }
 #[repr(C)] pub struct msi_bits { _p: [u8; 0] }
+#[repr(C)] pub struct msi_bq       { _p: [u8; 0] }
+#[repr(C)] pub struct msi_group    { _p: [u8; 0] }
+#[repr(C)] pub struct msi_vs_group { _p: [u8; 0] }
+/// One value of a federated hit's ordering key (search/federated/weighted_scores.rs: WeightedScoreValue)
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct msi_weighted_value { pub kind: u32, pub asc: u32, pub value: f64 }
+pub const MSI_GROUP_REPLICATE: i32 = 0;
+pub const MSI_GROUP_SHARD_ROWS: i32 = 1;
+pub const MSI_VECTOR_FILTER_NONE: i32 = 0;
+pub const MSI_VECTOR_FILTER_FRAGMENT: i32 = 1;
+pub const MSI_VECTOR_FILTER_DOCUMENT_TEMPLATE: i32 = 2;
+pub const MSI_VECTOR_FILTER_USER_PROVIDED: i32 = 3;
+pub const MSI_VECTOR_FILTER_REGENERATE: i32 = 4;
 #[repr(C)] pub struct msi_doc_keys { _p: [u8; 0] }
 #[repr(C)] pub struct msi_doc_values { _p: [u8; 0] }
 #[repr(C)] pub struct msi_geo_points { _p: [u8; 0] }
@@ -235,4 +248,42 @@ extern "C" {
                                    semantic_ratio: f32) -> i32;
     pub fn msi_distribution_shift(mean: f32, sigma: f32, score: f32) -> f32;
     pub fn msi_rank_global_score(ranks: *const u32, max_ranks: *const u32, n: u32) -> f64;
+    // ---- round 2 ---------------------------------------------------------------------------------------------------
+    // binary-quantised stores (vector/store.rs:1095-1109)
+    pub fn msi_bq_create(ctx: *mut msi_ctx, dim: u32, out: *mut *mut msi_bq) -> i32;
+    pub fn msi_bq_destroy(bq: *mut msi_bq);
+    pub fn msi_bq_upload(bq: *mut msi_bq, docids: *const u32, rows: *const f32, n_rows: u64) -> i32;
+    pub fn msi_bq_upload_device(bq: *mut msi_bq, d_docids: *const u32, d_rows: *const f32, n_rows: u64) -> i32;
+    pub fn msi_bq_len(bq: *const msi_bq) -> u64;
+    pub fn msi_bq_dim(bq: *const msi_bq) -> u32;
+    pub fn msi_bq_get_vector(bq: *mut msi_bq, docid: u32, out_row: *mut f32, out_found: *mut i32) -> i32;
+    pub fn msi_bq_search(bq: *mut msi_bq, queries: *const f32, n_queries: u32, k: u32, filter_bits: *const u64,
+                         filter_nbits: u64, out_docids: *mut u32, out_dist: *mut f32, out_counts: *mut u32) -> i32;
+    // federated merge (search/federated/weighted_scores.rs, perform.rs)
+    pub fn msi_federated_compare(left: *const msi_weighted_value, n_left: u32, left_weighted_global_score: f64,
+                                 right: *const msi_weighted_value, n_right: u32, right_weighted_global_score: f64) -> i32;
+    pub fn msi_federated_merge(n_lists: u32, list_len: *const u32, values: *const *const msi_weighted_value,
+                               val_off: *const *const u32, weighted_global: *const *const f64, offset: u32, limit: u32,
+                               out_list: *mut u32, out_pos: *mut u32) -> u32;
+    // multi-GPU (RCCL inside the library)
+    pub fn msi_group_create(devices: *const i32, n: u32, out: *mut *mut msi_group) -> i32;
+    pub fn msi_group_unique_id(out_id: *mut u8) -> i32;                       // 128 bytes
+    pub fn msi_group_create_rank(ctx: *mut msi_ctx, rank: u32, world: u32, id: *const u8, out: *mut *mut msi_group) -> i32;
+    pub fn msi_group_destroy(group: *mut msi_group);
+    pub fn msi_group_size(group: *const msi_group) -> u32;
+    pub fn msi_group_ctx(group: *mut msi_group, i: u32) -> *mut msi_ctx;
+    pub fn msi_group_allgather(group: *mut msi_group, d_send: *const c_void, bytes: usize, d_recv: *mut c_void) -> i32;
+    pub fn msi_vs_group_create(group: *mut msi_group, dim: u32, storage: i32, mode: i32, out: *mut *mut msi_vs_group) -> i32;
+    pub fn msi_vs_group_destroy(vs: *mut msi_vs_group);
+    pub fn msi_vs_group_upload(vs: *mut msi_vs_group, docids: *const u32, rows: *const f32, n_rows: u64) -> i32;
+    pub fn msi_vs_group_search(vs: *mut msi_vs_group, queries: *const f32, n_queries: u32, k: u32, out_docids: *mut u32,
+                               out_dist: *mut f32, out_counts: *mut u32) -> i32;
+    // `_vectors` filter leaf (search/facet/filter/vector.rs:49-158)
+    pub fn msi_vs_items_bits(store: *mut msi_vs, pool: *mut msi_bits, slot: u32) -> i32;
+    pub fn msi_bq_items_bits(store: *mut msi_bq, pool: *mut msi_bits, slot: u32) -> i32;
+    pub fn msi_bits_vector_filter(pool: *mut msi_bits, dst: u32, kind: i32, embedder_has_fragments: i32,
+                                  stores: *const *mut msi_vs, n_stores: u32, bq_stores: *const *mut msi_bq, n_bq_stores: u32,
+                                  user_provided: u32, skip_regenerate: u32, scratch: u32, accumulate: i32) -> i32;
+    // command-list back end statistics: rounds, lists, ns queued / packed / in launch calls / after launch
+    pub fn msi_bits_vm_stats(pool: *mut msi_bits, out: *mut u64) -> i32;
 }

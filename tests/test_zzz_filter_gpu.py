@@ -109,3 +109,44 @@ def test_kernel_against_numpy_and_argument_checks():
         pool.facet_in(fk, [5, 5], 0)
     with pytest.raises(ma.MsiError):
         pool.facet_range(ma.FacetKeys(ctx, per_doc + [[]]), 0, 1, 0)
+
+
+def test_vectors_filter_leaf(ctx):
+    """`_vectors` conditions (filter/vector.rs:49-158): the items of f32 and binary-quantised stores as docid sets on the
+    device, every variant, two embedders OR-ed and intersected with a universe — against the plain-set restatement."""
+    rng = np.random.default_rng(21)
+    n_docs = 70_000
+    pool = ma.BitsPool(ctx, n_docs, 8)
+
+    def store(kind, p):
+        ids = np.nonzero(rng.random(n_docs) < p)[0].astype(np.uint32)
+        st = ma.GpuStore(ctx, 8) if kind == "f32" else ma.GpuBqStore(ctx, 8)
+        st.upload(ids, rng.standard_normal((ids.size, 8)).astype(np.float32))
+        return st, set(ids.tolist())
+
+    a0, a0_ids = store("f32", 0.3)
+    a1, a1_ids = store("f32", 0.01)
+    b0, b0_ids = store("bq", 0.2)
+    up_a = set(rng.choice(sorted(a0_ids), 500, replace=False).tolist()) | {5, 69_999}
+    sr_a = set(rng.choice(n_docs, 3000, replace=False).tolist())
+    up_b, sr_b = set(), set(rng.choice(sorted(b0_ids), 50, replace=False).tolist())
+    universe = set(rng.choice(n_docs, 40_000, replace=False).tolist())
+    UP_A, SR_A, UP_B, SR_B, UNI, DST, SCR = 0, 1, 2, 3, 4, 5, 6
+    for slot, ids in ((UP_A, up_a), (SR_A, sr_a), (UP_B, up_b), (SR_B, sr_b), (UNI, universe)):
+        pool.set_from_docids(slot, sorted(ids))
+    for kind in ("none", "fragment", "documentTemplate", "userProvided", "regenerate"):
+        for frag_a in (False, True):
+            # embedder A: two f32 stores (a fragment condition looks at one of them), embedder B: one binary-quantised store
+            a_stores = [a1] if kind == "fragment" else [a0, a1]
+            a_items = [a1_ids] if kind == "fragment" else [a0_ids, a1_ids]
+            pool.vector_filter(DST, kind, stores=a_stores, has_fragments=frag_a, user_provided=UP_A, skip_regenerate=SR_A,
+                               scratch=SCR)
+            assert set(pool.to_docids(DST).tolist()) == FO.vector_filter(kind, frag_a, a_items, up_a, sr_a), (kind, frag_a)
+            pool.vector_filter(DST, kind, bq_stores=[b0], has_fragments=False, user_provided=UP_B, skip_regenerate=SR_B,
+                               scratch=SCR, accumulate=True)
+            pool.op(DST, DST, UNI, 0)  # AND
+            want = FO.vector_filter_all([(frag_a, a_items, up_a, sr_a), (False, [b0_ids], up_b, sr_b)], kind, universe)
+            assert set(pool.to_docids(DST).tolist()) == want, (kind, frag_a)
+    with pytest.raises(ma.MsiError):
+        pool.vector_filter(DST, "none", stores=[a0], scratch=DST)
+    pool.close()

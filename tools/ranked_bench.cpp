@@ -314,9 +314,11 @@ int main(int argc, char **argv) {
   prm.from = 0;
   prm.length = 20;
   prm.stop_after = -1;
+  prm.detailed_scores = getenv("RB_DETAILED") ? 1 : 0;   // ScoringStrategy::Detailed: what hybrid search asks for (bench.py's keyword leg)
 
   // the query set (shared by every configuration)
-  std::vector<std::vector<std::string>> queries(64);
+  // 64 distinct queries by default; RB_DISTINCT_QUERIES widens the set (bench.py's keyword leg cycles through 3072)
+  std::vector<std::vector<std::string>> queries(getenv("RB_DISTINCT_QUERIES") ? std::max(1, atoi(getenv("RB_DISTINCT_QUERIES"))) : 64);
   for (auto &q : queries) for (uint32_t i = 0; i < n_terms; ++i) q.push_back(frequent[g() % 300]);
 
   auto run_query = [&](msi_bits *pool, const std::vector<std::string> &q, uint64_t stats[10]) {
