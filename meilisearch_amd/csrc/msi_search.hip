@@ -25,7 +25,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <ucontext.h>
+
 #include <algorithm>
+#include <exception>
 #include <functional>
 #include <chrono>
 #include <deque>
@@ -77,6 +80,83 @@ void ck(int32_t st) {
   msi_set_error("msi_keyword_search_ranked: %s", msg);
   throw Fail{code};
 }
+
+// ---- cooperative tasks ---------------------------------------------------------------------------
+// bucket_sort hands every bucket to the next ranking rule; the sub-trees of sibling buckets do not depend on each
+// other (a bucket's place in the result list is fixed by the cardinalities before it), only their ORDER matters.  With
+// the command-list back end a search pays per dependency round, not per operation — so sibling sub-trees run as
+// cooperative tasks on one thread: each task is the ordinary blocking code on its own stack; where it would wait for
+// the device it parks, and when every task is parked the ONE list they recorded together runs.  A query with detailed
+// scores is then ~25 rounds deep instead of 74 waits long.
+struct Tasks {
+  struct T {
+    ucontext_t uc;
+    std::unique_ptr<char[]> stack;
+    std::function<void()> fn;
+    bool done = false, parked = false;
+    std::exception_ptr err;
+  };
+  static constexpr size_t STACK = 512u << 10;
+  ucontext_t main_uc;
+  std::vector<std::unique_ptr<T>> all;
+  T *cur = nullptr;
+  bool abort = false;
+  size_t live = 0;
+  static void entry(unsigned lo, unsigned hi) {
+    T *t = reinterpret_cast<T *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    try {
+      t->fn();
+    } catch (...) {
+      t->err = std::current_exception();
+    }
+    t->done = true;
+  }
+  void spawn(std::function<void()> fn) {
+    std::unique_ptr<T> t(new T());
+    t->stack.reset(new char[STACK]);
+    t->fn = std::move(fn);
+    getcontext(&t->uc);
+    t->uc.uc_stack.ss_sp = t->stack.get();
+    t->uc.uc_stack.ss_size = STACK;
+    t->uc.uc_link = &main_uc;
+    const uintptr_t a = (uintptr_t)t.get();
+    makecontext(&t->uc, (void (*)())entry, 2, (unsigned)(a & 0xFFFFFFFFu), (unsigned)(a >> 32));
+    ++live;
+    all.push_back(std::move(t));
+  }
+  // called by the running task where it needs the device: back to the scheduler until the list has run
+  void park() {
+    T *t = cur;
+    t->parked = true;
+    swapcontext(&t->uc, &main_uc);
+    if (abort) throw Fail{MSI_E_INTERNAL};
+  }
+  // runs every runnable task until all are parked or finished; -> true when some task is parked (the list must run)
+  bool round(std::exception_ptr &first_err) {
+    for (size_t i = 0; i < all.size(); ++i) {   // tasks spawned meanwhile run in the same round
+      T *t = all[i].get();
+      if (t->done || t->parked) continue;
+      cur = t;
+      swapcontext(&main_uc, &t->uc);
+      cur = nullptr;
+      if (t->done) {
+        --live;
+        t->stack.reset();
+        t->fn = nullptr;
+        if (t->err && !first_err) {
+          first_err = t->err;
+          abort = true;
+        }
+      }
+    }
+    bool parked = false;
+    for (auto &t : all) parked = parked || (!t->done && t->parked);
+    return parked;
+  }
+  void release() {
+    for (auto &t : all) t->parked = false;
+  }
+};
 
 // ---- device sets ------------------------------------------------------------------------------
 struct SetPool {
@@ -159,7 +239,16 @@ struct Dev {
   // the slot is about to be overwritten whole
   void wr(uint32_t slot) { pool.lazy_zero[slot] = 0; }
   // submit what was recorded and wait for it: the only blocking point of the command-list back end
+  Tasks *tasks = nullptr;   // set while the bucket sort runs as cooperative tasks
   void run() {
+    if (list.empty()) return;
+    if (tasks && tasks->cur) {   // a task: park; the scheduler runs the shared list when every task is parked
+      tasks->park();
+      return;
+    }
+    run_now();
+  }
+  void run_now() {
     if (list.empty()) return;
     Clock ck_;
     ++g_stats.launches;
@@ -186,7 +275,7 @@ struct Dev {
     run();
   }
   uint32_t counts_for(uint32_t n) {   // room for n more cardinalities in this list (else it runs first)
-    if (list.n_counts + n > MSI_VM_MAX_COUNTS) run();
+    while (list.n_counts + n > MSI_VM_MAX_COUNTS) run();   // (a loop: other tasks may have filled the next list meanwhile)
     return list.new_counts(n);
   }
   void flush() {   // what is recorded runs now (deferred first-k ids are delivered)
@@ -506,14 +595,14 @@ struct Dev {
     return s;
   }
   // the same level WITHOUT the completion wait: its counts land in `region`; false = does not fit, nothing enqueued
-#ifndef MSI_SEARCH_DIRECT_ONLY
-  std::vector<std::pair<uint32_t, uint32_t>> pending_levels;  // (count base, paths) of the levels recorded ahead
-#endif
-  bool paths_enqueue(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe, uint32_t region) {
+  // `pending_levels`: (count base, paths) of the levels recorded ahead — the CALLER's (a rule evaluation's) state: the
+  // bucket sort's tasks interleave between an enqueue and its collect
+  using PendingLevels = std::vector<std::pair<uint32_t, uint32_t>>;
+  bool paths_enqueue(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe, uint32_t region,
+                     PendingLevels &pending_levels) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       if (paths.size() > MSI_BITS_REGION_PATHS || list.n_counts + paths.size() > MSI_VM_MAX_COUNTS) return false;
-      if (region == 0) pending_levels.clear();
       pending_levels.push_back({rec_paths(paths, bucket, universe), (uint32_t)paths.size()});
       return true;
     }
@@ -530,7 +619,7 @@ struct Dev {
     ++g_stats.launches;
     return true;
   }
-  std::vector<uint64_t> paths_collect(uint32_t n_regions) {  // ONE wait for every level enqueued so far
+  std::vector<uint64_t> paths_collect(uint32_t n_regions, PendingLevels &pending_levels) {  // ONE wait for every level enqueued so far
     std::vector<uint64_t> counts((size_t)n_regions * MSI_BITS_REGION_PATHS, 0);
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
@@ -619,7 +708,7 @@ struct Dev {
         sink(nullptr, 0);
         return;
       }
-      if (list.fk_in_phase >= MSI_VM_MAX_FK_PHASE || list.firstk_total + k > MSI_VM_MAX_FIRSTK) run();
+      while (list.fk_in_phase >= MSI_VM_MAX_FK_PHASE || list.firstk_total + k > MSI_VM_MAX_FIRSTK) run();
       const uint32_t ci = counts_for(1);
       rd(a->slot);
       rec({VM_FIRSTK, a->slot, k, ci, list.firstk_total});
@@ -1942,14 +2031,15 @@ struct GraphRule : Rule {
     if (plan.size() < 2) return;
     Set ahead = cx->dev.clone(uni);
     std::vector<Set> buckets;
+    Dev::PendingLevels pending_levels;
     size_t n_enq = 0;
     for (; n_enq < plan.size(); ++n_enq) {
       buckets.push_back(cx->dev.zeros());
       if (plan[n_enq].all.empty()) continue;  // no path of this cost: an empty bucket, no launch
-      if (!cx->dev.paths_enqueue(plan[n_enq].sets, buckets.back(), ahead, (uint32_t)n_enq)) break;
+      if (!cx->dev.paths_enqueue(plan[n_enq].sets, buckets.back(), ahead, (uint32_t)n_enq, pending_levels)) break;
     }
     if (n_enq == 0) return;
-    const std::vector<uint64_t> counts = cx->dev.paths_collect((uint32_t)n_enq);
+    const std::vector<uint64_t> counts = cx->dev.paths_collect((uint32_t)n_enq, pending_levels);
     for (size_t j = 0; j < n_enq; ++j) {
       Ready r;
       r.cost = plan[j].cost;
@@ -2575,6 +2665,139 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     return;
   }
   const size_t nr = rules.size();
+  // ---- the bucket sort as a tree of tasks -------------------------------------------------------------------------
+  // Without `distinct`, a score threshold or the stop_after test hook, where a bucket's documents land in the result
+  // list is known as soon as the bucket exists (the cardinalities before it), so every bucket's sub-tree — the rules
+  // below it, on its documents — is independent of its siblings': bucket_sort.rs:187-343 as a recursion, the sub-trees
+  // as cooperative tasks (Tasks) that share the search's command list.  Same buckets, same order, same score details
+  // as the loop below; the loop stays for the sequential cases (distinct, thresholds, GeoSort's direct kernels).
+  {
+    const char *knob = getenv("MSI_SEARCH_TASKS");
+    const int max_tasks = knob ? atoi(knob) : 24;
+    // Sort / GeoSort rules stay sequential: GeoSort works through direct kernels on the pool's stream, and the Sort
+    // rule's two-phase command pair shares one accumulator cell per list
+    bool direct_rules = false;
+    for (auto &r : rules) direct_rules = direct_rules || r->kind == R_ORDER_BY;
+    const bool tree = max_tasks > 0 && !dv && !p->has_score_threshold && p->stop_after < 0 && !direct_rules &&
+                      !getenv("MSI_SEARCH_TRACE");
+    if (tree) {
+      const uint64_t page_end = (uint64_t)from + length;
+      bool ids_short = false, degraded = false;
+      // documents [off, off + count) of the final order, all with the same score details
+      auto emit = [&](const Set &docs, uint64_t count, uint64_t off, const std::vector<Score> &scores) {
+        if (!count || off >= page_end || off + count <= from) return;
+        const uint64_t skip = off < from ? from - off : 0;
+        const uint32_t take = (uint32_t)std::min<uint64_t>(count - skip, page_end - (off + skip));
+        const uint32_t at = (uint32_t)(off + skip - from);
+        const uint32_t ns = (uint32_t)std::min<size_t>(scores.size(), MSI_MAX_SCORE_DETAILS);
+        for (uint32_t i = 0; i < take; ++i) {
+          for (uint32_t sdx = 0; sdx < ns; ++sdx)
+            out_scores[(size_t)(at + i) * MSI_MAX_SCORE_DETAILS + sdx] = msi_score_detail{scores[sdx].kind, scores[sdx].a, scores[sdx].b};
+          out_n_scores[at + i] = ns;
+        }
+        c.dev.first_k_later(docs, (uint32_t)(skip + take), [out_docids, at, skip, take, &ids_short](const uint32_t *ids, size_t n) {
+          if (n < skip + take) ids_short = true;   // cannot happen: `count` came from the device
+          for (size_t i = (size_t)skip; i < n && i < skip + take; ++i) out_docids[at + (i - skip)] = ids[i];
+        });
+      };
+#ifndef MSI_SEARCH_DIRECT_ONLY
+      Tasks tasks;
+      bool coop = c.dev.vm && max_tasks > 1;
+#else
+      const bool coop = false;
+#endif
+      // rule `cur` ranks `uni` (count documents, first of them at place `off`), bucket_sort.rs:187-343
+      std::function<void(size_t, Set, uint64_t, uint64_t, std::vector<Score>, const Graph &)> rank;
+      rank = [&](size_t cur, Set uni, uint64_t left, uint64_t off, std::vector<Score> scores, const Graph &graph) {
+        auto rs = placeholder ? placeholder_rules(p) : ranking_rules(p);
+        Rule *rule = rs[cur].get();
+        rule->start(c, uni, graph);
+        for (;;) {
+          if (left == 0 || off >= page_end) break;                       // the page is full: the loop of :187 ends
+          if (!detailed && left == 1) {                                  // :195-203
+            emit(uni, left, off, scores);
+            break;
+          }
+          if (deadline_exceeded()) {                                     // :206-264: what is left goes out unranked
+            scores.push_back(Score{MSI_SCORE_SKIPPED, 0, 1});
+            emit(uni, left, off, scores);
+            degraded = true;
+            break;
+          }
+          Bucket b;
+          if (!rule->next(c, uni, left, b)) break;                       // (a rule ends with its universe empty)
+          ++g_stats.buckets;
+          if (!b.universe_reduced) c.dev.sub_(uni, b.docs);
+          left -= b.count;
+          std::vector<Score> sc = scores;
+          sc.push_back(b.score);
+          if (cur == nr - 1 || (!detailed && b.count <= 1) || off + b.count < from) {
+            emit(b.docs, b.count, off, sc);                              // :296-330
+          } else if (off < page_end && b.count) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+            // a task keeps its own working sets alive: only as many tasks as the pool has room for (a rule evaluation
+            // is given what relieve() keeps free)
+            if (coop && tasks.live < (size_t)max_tasks &&
+                c.dev.pool.free_.size() + c.dev.pool.clean_.size() >= 48 * (tasks.live + 2)) {
+              // (the graph is moved into the task: the Bucket dies at the end of this iteration)
+              auto gp = std::make_shared<Graph>(std::move(b.graph));
+              tasks.spawn([&rank, cur, docs = b.docs, cnt = b.count, off, sc, gp]() { rank(cur + 1, docs, cnt, off, sc, *gp); });
+            } else
+#endif
+              rank(cur + 1, b.docs, b.count, off, sc, b.graph);
+          }
+          off += b.count;
+        }
+        rule->end();
+      };
+      Set root = c.dev.clone(universe);
+#ifndef MSI_SEARCH_DIRECT_ONLY
+      if (coop) {
+        std::exception_ptr err;
+        c.dev.tasks = &tasks;
+        tasks.spawn([&]() { rank(0, root, universe_count, 0, {}, g); });
+        for (;;) {
+          const bool parked = tasks.round(err);
+          if (!parked) break;
+          if (!tasks.abort) {
+            try {
+              c.dev.run_now();
+            } catch (...) {
+              if (!err) err = std::current_exception();
+              tasks.abort = true;
+            }
+          }
+          tasks.release();
+        }
+        c.dev.tasks = nullptr;
+        if (err) {
+          bool oom = false;
+          try {
+            std::rethrow_exception(err);
+          } catch (const Fail &f) {
+            oom = f.code == MSI_E_OOM;
+          } catch (...) {
+          }
+          if (!oom) std::rethrow_exception(err);
+          // the tasks together held more sets than the pool has slots: once more, one bucket at a time
+          c.dev.list.clear();
+          c.dev.pending_fk.clear();
+          c.dev.fills.clear();
+          tasks.all.clear();
+          coop = false;
+          ids_short = false;
+          rank(0, c.dev.clone(universe), universe_count, 0, {}, g);
+        }
+      } else
+#endif
+        rank(0, root, universe_count, 0, {}, g);
+      c.dev.flush();   // the ids of the last buckets
+      if (ids_short) fail(MSI_E_INTERNAL, "a bucket held fewer documents than its cardinality said");
+      *out_n = (uint32_t)std::min<uint64_t>(length, universe_count - from);
+      if (degraded && out_degraded) *out_degraded = 1;
+      return;
+    }
+  }
   std::vector<Set> unis(nr);
   std::vector<uint64_t> uni_counts(nr, 0);
   std::vector<Score> scores;
