@@ -851,8 +851,22 @@ struct Ctx {
   std::map<std::string, std::vector<Set>> exact_attr_cache;  // {ExactMatch, MatchesStart, position candidates}
   std::map<std::tuple<Subset, Subset, uint32_t, uint32_t>, Set> prox_cache;
   std::map<std::pair<uint32_t, bool>, Set> word_cache;
+  void forget() {   // every cached set (all of them can be recomputed from the index)
+    subset_cache.clear();
+    within_cache.clear();
+    prox_cache.clear();
+    word_cache.clear();
+    exact_attr_cache.clear();
+    phrase_cache.clear();
+    empty_.reset();
+  }
   void relieve() {  // keep the pool from running dry on long queries: drop what can be recomputed
     if (dev.pool.free_.size() + dev.pool.clean_.size() >= 48) return;
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    // another task of the bucket sort may be parked with a reference into these maps: with tasks alive the caches stay
+    // (a search that then runs out of slots is re-run sequentially, where this works again)
+    if (dev.tasks && dev.tasks->live > 1) return;
+#endif
     subset_cache.clear();
     within_cache.clear();
     prox_cache.clear();
@@ -2702,6 +2716,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       };
 #ifndef MSI_SEARCH_DIRECT_ONLY
       Tasks tasks;
+      const bool no_gate = getenv("MSI_SEARCH_TASKS_NO_GATE") != nullptr;   // tests: provoke the out-of-slots re-run
       bool coop = c.dev.vm && max_tasks > 1;
 #else
       const bool coop = false;
@@ -2738,7 +2753,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             // a task keeps its own working sets alive: only as many tasks as the pool has room for (a rule evaluation
             // is given what relieve() keeps free)
             if (coop && tasks.live < (size_t)max_tasks &&
-                c.dev.pool.free_.size() + c.dev.pool.clean_.size() >= 48 * (tasks.live + 2)) {
+                (no_gate || c.dev.pool.free_.size() + c.dev.pool.clean_.size() >= 48 * (tasks.live + 2))) {
               // (the graph is moved into the task: the Bucket dies at the end of this iteration)
               auto gp = std::make_shared<Graph>(std::move(b.graph));
               tasks.spawn([&rank, cur, docs = b.docs, cnt = b.count, off, sc, gp]() { rank(cur + 1, docs, cnt, off, sc, *gp); });
@@ -2779,11 +2794,15 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
           } catch (...) {
           }
           if (!oom) std::rethrow_exception(err);
-          // the tasks together held more sets than the pool has slots: once more, one bucket at a time
-          c.dev.list.clear();
-          c.dev.pending_fk.clear();
-          c.dev.fills.clear();
+          // the tasks together held more sets than the pool has slots: once more, one bucket at a time.  What was
+          // recorded runs first — the list holds the zeroing of slots the pool already counts as clean and the decodes
+          // of sets the caches already hold; dropping it would leave them undefined.
+          if (getenv("MSI_SEARCH_DEBUG")) fprintf(stderr, "[msi] bucket-sort tasks ran out of pool slots: sequential re-run\n");
+          c.dev.run_now();
           tasks.all.clear();
+          // start over with nothing cached: the tasks were cut off wherever they stood, and only what they were about to do
+          // knew which of the sets they had filed were complete
+          c.forget();
           coop = false;
           ids_short = false;
           rank(0, c.dev.clone(universe), universe_count, 0, {}, g);

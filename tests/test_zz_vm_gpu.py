@@ -83,3 +83,36 @@ def test_concurrent_searches_share_launches_and_the_cache():
             assert rep == expected
     st = base.dict.posting_cache_stats()
     assert st["bytes_used"] <= st["capacity"]     # (postings of <= 7 documents are raw ids: never cached)
+
+
+def test_bucket_sort_tasks_equal_the_sequential_loop_also_when_the_pool_runs_out_of_slots(monkeypatch):
+    """The bucket sort runs sibling buckets' sub-trees as cooperative tasks that share one command list
+    (MSI_SEARCH_TASKS, default 24).  Same hits and score details as the sequential loop (MSI_SEARCH_TASKS=0); with the
+    slot gate off and a small pool the tasks run out of slots and the search is re-run one bucket at a time
+    (MSI_SEARCH_TASKS_NO_GATE is a test knob) — still the same answers."""
+    import meilisearch_amd as ma
+    checked = 0
+    for key, cases in _by_index().items():
+        index = build_index(FIX["indexes"][key])
+        h = Harness(index)
+        monkeypatch.setenv("MSI_SEARCH_TASKS", "0")
+        sequential = [_search(h, c) for c in cases]
+        monkeypatch.setenv("MSI_SEARCH_TASKS", "24")
+        tasks = [_search(h, c) for c in cases]
+        small = Harness.__new__(Harness)
+        small.R, small.index, small.ctx, small.dict, small.cb = h.R, index, h.ctx, h.dict, h.R.IndexCallbacks(index)
+        small.pool = ma.BitsPool(h.ctx, max(index.n_docs, 1), 256)
+        monkeypatch.setenv("MSI_SEARCH_TASKS_NO_GATE", "1")
+        starved = [_search(small, c) for c in cases]
+        monkeypatch.delenv("MSI_SEARCH_TASKS_NO_GATE")
+        assert sequential == tasks == starved
+        checked += len(cases)
+    assert checked >= 90
+
+
+def test_starved_tasks_are_rerun_sequentially_and_still_match_the_oracle(monkeypatch):
+    """300-document random corpora rank into many buckets: without the slot gate the bucket sort's tasks exhaust the
+    harness's pool, the search is cut off and re-run one bucket at a time — the results still equal the oracle's."""
+    import tests.test_search_gpu as G
+    monkeypatch.setenv("MSI_SEARCH_TASKS_NO_GATE", "1")
+    G.test_matches_oracle_on_random_corpora(1, 100)

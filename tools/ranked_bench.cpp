@@ -493,7 +493,14 @@ struct Runner {
           i = next++;
         }
         const std::vector<std::string> &q = queries[(job_first + i) % queries.size()];
-        if (search(pools[t], q, job_limit, out_ids + (size_t)i * job_limit, out_n + i, out_scores + (size_t)i * job_limit) != MSI_OK) failed.store(1);
+        const int32_t st = search(pools[t], q, job_limit, out_ids + (size_t)i * job_limit, out_n + i, out_scores + (size_t)i * job_limit);
+        if (st != MSI_OK) {
+          if (!failed.exchange(1)) {
+            std::string words;
+            for (auto &w : q) words += w + " ";
+            fprintf(stderr, "ranked runner: search \"%s\" failed with %d: %s\n", words.c_str(), st, msi_last_error());
+          }
+        }
         std::lock_guard<std::mutex> lk(mu);
         if (++done == job_n) cv_done.notify_all();
       }
