@@ -27,6 +27,11 @@ struct msi_bits {
   uint64_t n_words = 0;  // per slot, multiple of 2 (16-byte vector access)
   uint32_t n_slots = 0;
   DevBuf pool, tmp, small, stage, desc, small_ids;
+  // chunk summaries of the command-list path (msi_vm.hip): one bit per (65 536-document chunk, slot), chunk-major rows of
+  // 16 words; 0 = that chunk of the slot is all zero.  Kept by the command lists; anything else that may write a slot
+  // (every direct entry point goes through check_slot / msi_bits_slot_ptr) marks them stale and the next list resets them.
+  DevBuf summary;
+  bool sum_dirty = false;
   // Completion signalling without a stream synchronisation: the last workgroup of a counting kernel
   // writes {value, sequence number} into fine-grained pinned host memory and the caller polls it.
   volatile uint64_t *h_sig = nullptr;  // [0] value, [1] sequence
@@ -92,7 +97,17 @@ struct msi_doc_keys {
 msi_ctx *msi_bits_ctx(msi_bits *p) { return p->ctx; }
 hipStream_t msi_bits_stream(msi_bits *p) { return p->stream; }
 std::mutex &msi_bits_mutex(msi_bits *p) { return *p->mu; }
-u64 *msi_bits_slot_ptr(msi_bits *p, uint32_t slot) { return p->slot(slot); }
+u64 *msi_bits_slot_ptr(msi_bits *p, uint32_t slot) {   // (other modules' kernels write through this pointer)
+  p->sum_dirty = true;
+  return p->slot(slot);
+}
+u64 *msi_bits_pool_base(msi_bits *p) { return p->slot(0); }   // the command lists' own view of the pool
+u64 *msi_bits_summary(msi_bits *p) { return p->summary.p ? p->summary.as<u64>() : nullptr; }
+bool msi_bits_take_summary_dirty(msi_bits *p) {
+  const bool d = p->sum_dirty;
+  p->sum_dirty = false;
+  return d;
+}
 uint64_t msi_bits_words_per_slot(msi_bits *p) { return p->n_words; }
 uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
 uint64_t msi_bits_n_docs(msi_bits *p) { return p->n_docs; }
@@ -1060,6 +1075,7 @@ int32_t check_slot(const msi_bits *p, uint32_t s, const char *what) {
     msi_set_error("%s: slot %u out of range", what, s);
     return MSI_E_INVALID;
   }
+  const_cast<msi_bits *>(p)->sum_dirty = true;   // a direct operation: the command lists' chunk summaries may no longer hold
   return MSI_OK;
 }
 
@@ -1082,6 +1098,8 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   p->n_words = std::max<uint64_t>(2, ((n_docs + 127) / 128) * 2);
   p->n_slots = n_slots;
   int32_t s = p->pool.ensure((size_t)p->n_words * n_slots * sizeof(u64));
+  const uint64_t n_chunks = (p->n_words + 1023) / 1024;
+  if (s == MSI_OK && n_slots <= 1024) s = p->summary.ensure((size_t)n_chunks * 16 * sizeof(u64));
   if (s == MSI_OK) s = p->small.ensure(64);
   if (s == MSI_OK) {
     void *h = nullptr;
@@ -1102,6 +1120,7 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   if (s != MSI_OK) {
     p->pool.release();
     p->small.release();
+    p->summary.release();
     if (p->h_sig) (void)hipHostFree((void *)p->h_sig);
     if (p->d_acc) (void)hipFree(p->d_acc);
     delete p;
@@ -1109,6 +1128,8 @@ int32_t msi_bits_create(msi_ctx *ctx, uint64_t n_docs, uint32_t n_slots, msi_bit
   }
   std::lock_guard<std::mutex> lk(ctx->mu);
   hipError_t e = hipMemsetAsync(p->pool.p, 0, (size_t)p->n_words * n_slots * sizeof(u64), ctx->stream);
+  // every slot starts all zero, and so do the summaries ("0 = this chunk is empty")
+  if (e == hipSuccess && p->summary.p) e = hipMemsetAsync(p->summary.p, 0, (size_t)n_chunks * 16 * sizeof(u64), ctx->stream);
   if (e != hipSuccess) {
     msi_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
     p->pool.release();
@@ -1146,6 +1167,7 @@ void msi_bits_destroy(msi_bits *p) {
   p->pool.release();
   p->tmp.release();
   p->small.release();
+  p->summary.release();
   p->stage.release();
   p->desc.release();
   p->small_ids.release();

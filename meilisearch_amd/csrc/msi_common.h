@@ -25,7 +25,8 @@
 #endif
 // A value every lane of the wave holds alike, moved to a scalar register (uniform branches, scalar address arithmetic).
 #ifndef MSI_UNIFORM
-#define MSI_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#define MSI_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))   // (the builtin is int -> int: unsigned again, or a
+                                                                            // 64-bit value pieced together from two of these is sign-extended)
 #endif
 // What a workgroup WROTE with plain stores must be in memory before another kernel — possibly on another XCD, possibly
 // started before this kernel ends — is told about it: write this XCD's L2 back (buffer_wbl2 sc1), but do not invalidate

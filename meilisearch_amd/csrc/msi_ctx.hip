@@ -10,6 +10,11 @@
 #include <numeric>
 #include <vector>
 
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include "msi_common.h"
 #include "msi_vm.h"
 
@@ -21,6 +26,43 @@ void msi_set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+namespace {
+// MSI_DEBUG_ABORT=1 (diagnostics): a native backtrace on stderr when the process aborts or faults
+void msi_abort_backtrace(int sig) {
+  void *frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "[msi] fatal signal, native backtrace:\n";
+  int fd = 2;   // MSI_DEBUG_ABORT=<path>: into that file (a test runner may have redirected fd 2)
+  const char *path = getenv("MSI_DEBUG_ABORT");
+  if (path && path[0] == '/') {
+    const int f = open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (f >= 0) fd = f;
+  }
+  (void)!write(fd, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, fd);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+}  // namespace
+// re-armed by the entry points that ask for it (another library may have taken the signal since)
+extern "C" void msi_debug_arm_abort_backtrace(void) {
+  static const bool on = getenv("MSI_DEBUG_ABORT") != nullptr;
+  if (!on) return;
+  signal(SIGABRT, msi_abort_backtrace);
+  signal(SIGSEGV, msi_abort_backtrace);
+  signal(SIGBUS, msi_abort_backtrace);
+}
+namespace {
+struct AbortHook {
+  AbortHook() {
+    if (getenv("MSI_DEBUG_ABORT")) {
+      signal(SIGABRT, msi_abort_backtrace);
+      signal(SIGSEGV, msi_abort_backtrace);
+    }
+  }
+} g_abort_hook;
+}  // namespace
 
 extern "C" {
 

@@ -43,6 +43,8 @@
 #ifndef MSI_SEARCH_DIRECT_ONLY
 #include "msi_vm.h"
 int32_t msi_bits_sync(msi_bits *p);
+extern "C" void msi_debug_arm_abort_backtrace(void);
+bool msi_bits_take_summary_dirty(msi_bits *p);
 const uint32_t *msi_doc_keys_device(const msi_doc_keys *k);
 MsiPostingCache *msi_dict_pcache(const msi_dict *d);
 #endif
@@ -226,8 +228,15 @@ struct Dev {
 #endif
   }
 #ifndef MSI_SEARCH_DIRECT_ONLY
-  void rec(std::initializer_list<uint32_t> w) {
+  // The first command of a list: when something outside the command lists touched the pool since the last one (a direct
+  // kernel of this search, the caller between searches), the chunk summaries are stale and the list says so first.
+  void open_list() {
+    if (!list.empty()) return;
     list.begin();
+    if (msi_bits_take_summary_dirty(pool.p)) list.words.push_back(VM_SUMMARY_RESET);
+  }
+  void rec(std::initializer_list<uint32_t> w) {
+    open_list();
     list.words.insert(list.words.end(), w.begin(), w.end());
   }
   // the slot is about to be READ: a lazily zeroed slot is zeroed now
@@ -586,6 +595,7 @@ struct Dev {
     if (vm) {
       MsiCboBatch b;
       b.small_ids = ids;
+      open_list();
       ck(msi_vm_record_decode(list, pool.p, s->slot, b, true));
       return s;
     }
@@ -682,6 +692,7 @@ struct Dev {
       ++g_stats.decodes;
       g_stats.postings_bytes += b.bytes.size() + 4 * b.small_ids.size();
       wr(s->slot);
+      open_list();
       ck(msi_vm_record_decode(list, pool.p, s->slot, b, true));
       fills.insert(fills.end(), b.fill_tokens.begin(), b.fill_tokens.end());
       return s;
@@ -2976,6 +2987,7 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
                                              size_t universe_len, uint32_t *out_docids, msi_score_detail *out_scores,
                                              uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates,
                                              int32_t *out_degraded) {
+  msi_debug_arm_abort_backtrace();
   if (!dict || !pool || !index || !index->word_docids || !params || !out_n || (n_terms && !terms) ||
       n_terms > MSI_RANK_MAX_TERMS || (params->length && (!out_docids || !out_scores || !out_n_scores)) ||
       (params->n_criteria && !params->criteria) ||

@@ -34,6 +34,7 @@ enum : uint32_t {
                  // at u32 offset `ids base` of the list's id block; <= MSI_VM_MAX_FK_PHASE per phase, <= MSI_VM_MAX_FIRSTK ids per list
   VM_MINKEY,     // universe, keys lo, keys hi, cell
   VM_TAKEKEY,    // universe, bucket, keys lo, keys hi, cell, cnt, key result index
+  VM_SUMMARY_RESET,   // (no operand) the pool's chunk summaries no longer hold: every bit back to "may hold documents"
 };
 
 constexpr uint32_t MSI_VM_MAX_COUNTS = 1024;   // cardinalities one list can ask for

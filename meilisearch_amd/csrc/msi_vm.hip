@@ -36,6 +36,8 @@ typedef unsigned long long u64;
 
 msi_ctx *msi_bits_ctx(msi_bits *p);
 u64 *msi_bits_slot_ptr(msi_bits *p, uint32_t slot);
+u64 *msi_bits_pool_base(msi_bits *p);
+u64 *msi_bits_summary(msi_bits *p);
 uint64_t msi_bits_words_per_slot(msi_bits *p);
 uint64_t msi_bits_n_docs(msi_bits *p);
 uint32_t msi_bits_n_slots(msi_bits *p);
@@ -49,6 +51,7 @@ constexpr int VT = 256;                 // threads per workgroup (512 measured 3
 constexpr int WPT = 1024 / VT;          // words of a chunk per thread in the ordered emit
 constexpr uint32_t CHW = 1024;          // u64 words per chunk (65 536 documents = one Roaring container span)
 constexpr uint32_t MAX_SUBS = 64;       // lists per round
+constexpr uint32_t SUM_W = 16;                                  // 64-bit words of a chunk's summary row: pools of <= 1024 slots
 constexpr uint32_t CMD_LDS = 2048;                             // command words of a phase kept in LDS (longer phases: read from the arena)
 constexpr size_t RES_COUNTS = 2;                               // u64 index of counts[0] in the result block
 constexpr size_t RES_IDS = RES_COUNTS + MSI_VM_MAX_COUNTS;     // u64 index where the u32 ids start
@@ -65,7 +68,7 @@ struct alignas(16) RoundSub {
   uint32_t n_counts;
   uint32_t n_decodes;
   uint32_t n_cmd_words;                   // the list's command words (its decode descriptors follow them)
-  uint32_t _pad[2];
+  uint32_t sum_lo, sum_hi;                // device address of the pool's chunk summaries (0: none), msi_bits_summary
 };
 static_assert(sizeof(RoundSub) % 16 == 0, "RoundSub array stays 16-byte aligned");
 
@@ -127,6 +130,10 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   __shared__ uint4 s_raw[CHW * 8 / 16 + 2];   // one container body (<= 8 KiB) + alignment slack, staged with wide loads
   __shared__ uint32_t s_scan[VT / 64 + 1];
   __shared__ uint32_t s_last;
+  __shared__ int s_any;
+  __shared__ u64 s_sum[VT / 64][SUM_W];
+  __shared__ uint16_t s_whole[SUM_W * 64];
+  __shared__ uint32_t s_nzw[SUM_W * 64];
   __shared__ uint32_t s_cmd[CMD_LDS];          // this phase's command words (read once, coalesced)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (fields are read one by one: a by-value copy of the struct lands in scratch because phase_off[] is indexed dynamically)
@@ -175,14 +182,109 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     if (lane == 0 && c) atomicAdd(&s_cnt[idx], c);
   };
 
+  // ---- chunk summaries ------------------------------------------------------------------------------------------
+  // One bit per (slot, chunk): 0 = this chunk of the slot IS all zero (and its words in memory are zero), 1 = it may hold
+  // documents.  84 % of the (command, chunk) executions of a detailed search at 10 M documents work on an empty chunk
+  // of their scoping operand (a bucket of three documents occupies three of 153 chunks;
+  // profiles/r2_ranked_10m_vm_kernel_opcode_profile.txt): with the bit known, the workgroup neither loads nor stores.
+  // The row of this chunk (one bit per slot) is loaded once, kept per wave in LDS (every lane writes the same value to
+  // the same word: no barrier), and written back at the end; bits follow conservatively from the operands' bits, and a
+  // slot whose chunk was written WHOLE by this list gets its exact bit from what was stored.
+  u64 *const sum_row = reinterpret_cast<u64 *>(((u64)rp->sum_hi << 32) | rp->sum_lo);
+  const bool sum_on = sum_row != nullptr;
+  if (sum_on) {
+    if (lane < SUM_W) s_sum[wave][lane] = sum_row[(u64)chunk * SUM_W + lane];
+    for (uint32_t i = tid; i < SUM_W * 64; i += VT) {
+      s_whole[i] = 0;
+      s_nzw[i] = 0;
+    }
+  }
+  __syncthreads();
+  uint32_t cmd_no = 0;
+  // (one lane writes, the wave's lanes read: wave_barrier keeps the compiler — and the CPU emulation, whose lanes are
+  // fibers — from moving a read across a write)
+  auto E = [&](uint32_t slot) -> bool {   // this chunk of `slot` is known to be empty
+    if (!sum_on) return false;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t b = MSI_UNIFORM((uint32_t)((s_sum[wave][slot >> 6] >> (slot & 63)) & 1ull));
+    __builtin_amdgcn_wave_barrier();
+    return b == 0;
+  };
+  auto set_bit = [&](uint32_t slot, bool maybe) {
+    if (!sum_on) return;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      const u64 m = 1ull << (slot & 63), w = s_sum[wave][slot >> 6];
+      s_sum[wave][slot >> 6] = maybe ? (w | m) : (w & ~m);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // dst's chunk is written whole by the current command: its exact bit is settled at the end (nz() marks content)
+  auto whole = [&](uint32_t slot) {
+    set_bit(slot, true);
+    if (sum_on && lane == 0) s_whole[slot] = (uint16_t)cmd_no;
+  };
+  auto partial = [&](uint32_t slot) {   // written in place, pair by pair: only "may hold documents" is known
+    set_bit(slot, true);
+    if (sum_on && lane == 0) s_whole[slot] = 0;
+  };
+  // after the store loop of a whole write: did any lane store a document?  (the latest command number wins)
+  auto nz = [&](uint32_t slot, bool any) {
+    if (!sum_on) return;
+    if (__any(any) && lane == 0) atomicMax(&s_nzw[slot], cmd_no);
+  };
+  // dst := empty.  Its words are only stored when they may hold something.
+  auto make_empty = [&](uint32_t slot) {
+    if (E(slot)) return;
+    ulonglong2 *d = S(slot);
+    for (uint32_t p = tid; p < n_pairs; p += VT) put(&d[p], make_ulonglong2(0, 0));
+    set_bit(slot, false);
+    if (sum_on && lane == 0) s_whole[slot] = 0;
+  };
+
+  // MSI_VM_PROFILE: how many (command, chunk) executions work on an all-zero chunk of their scoping operand
+  auto chunk_empty = [&](uint32_t slot) -> bool {
+    const ulonglong2 *a = S(slot);
+    int nz = 0;
+    for (uint32_t p = tid; p < n_pairs; p += VT) nz |= (a[p].x | a[p].y) != 0;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    if (nz) s_any = 1;
+    __syncthreads();
+    const bool e = s_any == 0;
+    __syncthreads();
+    return e;
+  };
   for (;;) {
     const uint32_t op = W(0);
     if (op == VM_END) break;
+    if (prof) {
+      uint32_t scope = 0xFFFFFFFFu;
+      if (op == VM_PATHS) scope = W(3);
+      else if (op == VM_AND_MANY || op == VM_CLAIM || op == VM_SUB_MANY) scope = W(1);
+      else if (op == VM_OP || op == VM_OP_COUNT) scope = W(3);
+      else if (op == VM_COUNT || op == VM_FIRSTK) scope = W(1);
+      if (scope != 0xFFFFFFFFu) {
+        const bool e = chunk_empty(scope);
+        if (tid == 0) {
+          atomicAdd(&prof[20], 1ull);
+          if (e) atomicAdd(&prof[21], 1ull);
+        }
+      }
+    }
     const u64 t_op = prof ? wall_clock64() : 0;
+    ++cmd_no;
     switch (op) {
       case VM_FILL: {
         ulonglong2 *d = S(W(1));
         const bool ones = W(2) != 0;
+        if (!ones) {
+          make_empty(W(1));
+          pcw += 3;
+          break;
+        }
+        whole(W(1));
+        nz(W(1), true);   // (a chunk past n_docs holds no document: one harmless "maybe")
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           ulonglong2 v = make_ulonglong2(0, 0);
           if (ones) {
@@ -198,12 +300,26 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       case VM_OP_COUNT: {
         ulonglong2 *d = S(W(1));
         const ulonglong2 *a = S(W(2)), *b = S(W(3));
-        const uint32_t o = W(4);
+        const uint32_t o = W(4), sd = W(1), sa = W(2), sb = W(3);
         uint32_t c = 0;
-        for (uint32_t p = tid; p < n_pairs; p += VT) {
-          const ulonglong2 v = apply_op(o, a[p], b[p]);
-          put(&d[p], v);
-          c += __popcll(v.x) + __popcll(v.y);
+        const bool ea = E(sa), eb = E(sb);
+        const bool res_empty = o == MSI_BITS_AND ? (ea || eb) : (o == MSI_BITS_ANDNOT ? ea : (ea && eb));
+        if (res_empty) {
+          make_empty(sd);
+        } else if (op == VM_OP && sd == sa && eb && (o == MSI_BITS_OR || o == MSI_BITS_ANDNOT || o == MSI_BITS_XOR)) {
+          // a |= nothing, a &= ~nothing: unchanged
+        } else if (op == VM_OP && sd == sb && ea && (o == MSI_BITS_OR || o == MSI_BITS_XOR)) {
+          // b |= nothing
+        } else {
+          whole(sd);
+          u64 any = 0;
+          for (uint32_t p = tid; p < n_pairs; p += VT) {
+            const ulonglong2 v = apply_op(o, a[p], b[p]);
+            put(&d[p], v);
+            any |= v.x | v.y;
+            c += __popcll(v.x) + __popcll(v.y);
+          }
+          nz(sd, any != 0);
         }
         if (op == VM_OP_COUNT) {
           add_count(W(5), c);
@@ -215,10 +331,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       }
       case VM_CLEAR: {
         const uint32_t n = W(1);
-        for (uint32_t k = 0; k < n; ++k) {
-          ulonglong2 *d = S(W(2 + k));
-          for (uint32_t p = tid; p < n_pairs; p += VT) put(&d[p], make_ulonglong2(0, 0));
-        }
+        for (uint32_t k = 0; k < n; ++k) make_empty(W(2 + k));
         pcw += 2 + n;
         break;
       }
@@ -226,6 +339,11 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         const ulonglong2 *docs = S(W(1));
         ulonglong2 *bucket = S(W(2)), *uni = S(W(3));
         const uint32_t n = W(4);
+        if (E(W(1))) {   // nothing to claim in this chunk
+          pcw += 5 + n;
+          break;
+        }
+        partial(W(2));   // (the universe and the stack only lose documents: their bits stay)
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           const ulonglong2 dd = docs[p];
           if (!(dd.x | dd.y)) continue;
@@ -247,17 +365,27 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       case VM_AND_MANY: {  // dst[i] = prefix & cond[i], counts[base + i] = |dst[i]|
         const ulonglong2 *pre = S(W(1));
         const uint32_t n = W(2), base = W(3);
+        const bool epre = E(W(1));
         for (uint32_t k = 0; k < n; ++k) {
-          const ulonglong2 *cnd = S(W(4 + 2 * k));
-          ulonglong2 *d = S(W(5 + 2 * k));
+          const uint32_t sc = W(4 + 2 * k), sd = W(5 + 2 * k);
+          if (epre || E(sc)) {
+            make_empty(sd);
+            continue;
+          }
+          const ulonglong2 *cnd = S(sc);
+          ulonglong2 *d = S(sd);
           uint32_t c = 0;
+          whole(sd);
+          u64 any = 0;
           for (uint32_t p = tid; p < n_pairs; p += VT) {
             const ulonglong2 x = pre[p], y = cnd[p];
             ulonglong2 v;
             v.x = x.x & y.x; v.y = x.y & y.y;
             put(&d[p], v);
+            any |= v.x | v.y;
             c += __popcll(v.x) + __popcll(v.y);
           }
+          nz(sd, any != 0);
           add_count(base + k, c);
         }
         pcw += 4 + 2 * n;
@@ -272,6 +400,14 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         // Paths are resolved four at a time: the condition words of the four paths are loaded back to back (no load
         // waits for the result of another), then the paths claim in order.  A serial "load, AND, test, next step" chain
         // made a level of a few hundred steps cost hundreds of microseconds of pure memory latency per workgroup.
+        if (E(W(3))) {   // no document of the universe in this chunk: the level finds nothing here
+          if (fresh) make_empty(W(2));
+          pcw += 7 + n_paths + n_steps;
+          break;
+        }
+        if (fresh) whole(W(2));
+        else partial(W(2));
+        u64 any_b = 0;
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           ulonglong2 u = uni[p];
           if (!(u.x | u.y)) {
@@ -303,23 +439,39 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
             }
           }
           put(&bucket[p], b);
+          any_b |= b.x | b.y;
           put(&uni[p], u);
         }
+        if (fresh) nz(W(2), any_b != 0);
         pcw += 7 + n_paths + n_steps;
         break;
       }
       case VM_SUB_MANY: {  // slot[i] &= ~removed, counts[base + i] = |slot[i]|
         const ulonglong2 *rm = S(W(1));
         const uint32_t n = W(2), base = W(3);
+        const bool erm = E(W(1));
         for (uint32_t k = 0; k < n; ++k) {
-          ulonglong2 *d = S(W(4 + k));
+          const uint32_t sd = W(4 + k);
+          if (E(sd)) continue;                      // nothing to remove from, nothing to count
+          ulonglong2 *d = S(sd);
           uint32_t c = 0;
-          for (uint32_t p = tid; p < n_pairs; p += VT) {
-            const ulonglong2 x = rm[p];
-            ulonglong2 v = d[p];
-            v.x &= ~x.x; v.y &= ~x.y;
-            put(&d[p], v);
-            c += __popcll(v.x) + __popcll(v.y);
+          if (erm) {                                // nothing removed here: the cardinality is still asked for
+            for (uint32_t p = tid; p < n_pairs; p += VT) {
+              const ulonglong2 v = d[p];
+              c += __popcll(v.x) + __popcll(v.y);
+            }
+          } else {
+            whole(sd);
+            u64 any = 0;
+            for (uint32_t p = tid; p < n_pairs; p += VT) {
+              const ulonglong2 x = rm[p];
+              ulonglong2 v = d[p];
+              v.x &= ~x.x; v.y &= ~x.y;
+              put(&d[p], v);
+              any |= v.x | v.y;
+              c += __popcll(v.x) + __popcll(v.y);
+            }
+            nz(sd, any != 0);
           }
           add_count(base + k, c);
         }
@@ -330,10 +482,11 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       case VM_FIRSTK: {
         const ulonglong2 *a = S(W(1));
         uint32_t c = 0;
-        for (uint32_t p = tid; p < n_pairs; p += VT) {
-          const ulonglong2 v = a[p];
-          c += __popcll(v.x) + __popcll(v.y);
-        }
+        if (!E(W(1)))
+          for (uint32_t p = tid; p < n_pairs; p += VT) {
+            const ulonglong2 v = a[p];
+            c += __popcll(v.x) + __popcll(v.y);
+          }
         if (op == VM_COUNT) {
           add_count(W(2), c);
           pcw += 3;
@@ -355,6 +508,8 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         const uint32_t c_first = blk_c[di], n_here = blk_c[di + 1] - c_first;   // start[] of this chunk: n_decodes + 1 entries
         const VmContainer *cs = reinterpret_cast<const VmContainer *>(blk_c + ((r.n_decodes + 1 + 3) & ~3u)) + c_first;
         if (n_here) {
+          if (overwrite) whole(W(1));
+          else partial(W(1));
           __syncthreads();
           for (uint32_t i = tid; i < CHW; i += VT) s_dec[i] = 0;
           __syncthreads();
@@ -405,6 +560,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
             }
             __syncthreads();   // s_raw is reused by the next container
           }
+          u64 any_d = 0;
           for (uint32_t p = tid; p < n_pairs; p += VT) {
             ulonglong2 v;
             v.x = s_dec[2 * p] & doc_mask(w0 + 2 * p, r.n_docs);
@@ -414,9 +570,11 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
               v.x |= o.x; v.y |= o.y;
             }
             put(&d[p], v);
+            any_d |= v.x | v.y;
           }
+          if (overwrite) nz(W(1), any_d != 0);
         } else if (overwrite) {
-          for (uint32_t p = tid; p < n_pairs; p += VT) put(&d[p], make_ulonglong2(0, 0));
+          make_empty(W(1));
         }
         pcw += 4;
         break;
@@ -426,12 +584,13 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         const u64 *uni = pool + (u64)W(1) * r.n_words + w0;
         const uint32_t *keys = reinterpret_cast<const uint32_t *>(((u64)W(3) << 32) | W(2));
         uint32_t inv = 0;
-        for (uint32_t w = wave; w < nw; w += VT / 64) {
-          const u64 word = uni[w];
-          if (!word) continue;
-          const u64 doc = (w0 + w) * 64 + lane;
-          if ((word >> lane) & 1ull) inv = max(inv, 0xFFFFFFFFu - keys[doc]);
-        }
+        if (!E(W(1)))
+          for (uint32_t w = wave; w < nw; w += VT / 64) {
+            const u64 word = uni[w];
+            if (!word) continue;
+            const u64 doc = (w0 + w) * 64 + lane;
+            if ((word >> lane) & 1ull) inv = max(inv, 0xFFFFFFFFu - keys[doc]);
+          }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) inv = max(inv, (uint32_t)__shfl_xor((int)inv, o));
         if (lane == 0 && inv) atomicMax(&cells[W(4)], (u64)inv);
@@ -445,6 +604,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         const uint32_t *keys = reinterpret_cast<const uint32_t *>(((u64)W(4) << 32) | W(3));
         const uint32_t key = 0xFFFFFFFFu - (uint32_t)cells[W(5)];
         uint32_t c = 0;
+        partial(W(2));   // (written word by word by lane 0 of each wave: no exact bit)
         for (uint32_t w = wave; w < nw; w += VT / 64) {
           const u64 word = uni[w];
           u64 mask = 0;
@@ -463,6 +623,15 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         if (chunk == 0 && tid == 0) s_cnt[W(7)] = key;   // the key itself travels as a "count"
         __syncthreads();
         pcw += 8;
+        break;
+      }
+      case VM_SUMMARY_RESET: {  // something outside the command lists wrote slots of this pool: every bit back to "may hold"
+        __syncthreads();
+        if (sum_on && lane < SUM_W) s_sum[wave][lane] = ~0ull;
+        if (sum_on)
+          for (uint32_t i = tid; i < SUM_W * 64; i += VT) s_whole[i] = 0;
+        __syncthreads();
+        pcw += 1;
         break;
       }
       default:
@@ -484,6 +653,13 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
 #undef W
   // ---- this workgroup's cardinalities leave LDS; the last workgroup of the list publishes --------------------
   __syncthreads();
+  if (sum_on) {
+    // slots whose chunk this list wrote whole: the bit is exact — empty unless the last such write stored a document
+    for (uint32_t i = tid; i < SUM_W * 64; i += VT)
+      if (s_whole[i] && s_nzw[i] != (uint32_t)s_whole[i]) atomicAnd(&s_sum[0][i >> 6], ~(1ull << (i & 63)));
+    __syncthreads();
+    if (tid < SUM_W) put1(&sum_row[(u64)chunk * SUM_W + tid], s_sum[0][tid]);
+  }
   for (uint32_t i = tid; i < r.n_counts; i += VT)
     if (s_cnt[i]) atomicAdd(&counts[i], (u64)s_cnt[i]);
   // Everything this workgroup stored is write-through (put): the ticket below only has to wait until those stores
@@ -713,6 +889,7 @@ void VmCombiner::run() {
           case VM_FIRSTK: i += 5; break;
           case VM_MINKEY: i += 5; break;
           case VM_TAKEKEY: i += 8; break;
+          case VM_SUMMARY_RESET: i += 1; break;
           default: i = w_end; break;
         }
       }
@@ -757,7 +934,7 @@ void VmCombiner::run() {
         msi_bits *p = batch[i]->pool;
         RoundSub &r = subs[i];
         memset(&r, 0, sizeof(r));
-        r.pool_base = (u64)(uintptr_t)msi_bits_slot_ptr(p, 0);
+        r.pool_base = (u64)(uintptr_t)msi_bits_pool_base(p);
         r.n_words = msi_bits_words_per_slot(p);
         r.n_docs = msi_bits_n_docs(p);
         r.host_res = (u64)(uintptr_t)batch[i]->blk;
@@ -773,6 +950,12 @@ void VmCombiner::run() {
         r.data_off = l.data_off;
         r.n_decodes = (uint32_t)l.decodes.size();
         r.n_cmd_words = l.data_off ? l.data_off : (uint32_t)l.words.size() + 1;
+        {
+          static const bool sum_off = getenv("MSI_VM_SUMMARY") && getenv("MSI_VM_SUMMARY")[0] == '0';   // diagnostics
+          const uint64_t sp = sum_off ? 0 : (uint64_t)(uintptr_t)msi_bits_summary(p);
+          r.sum_lo = (uint32_t)sp;
+          r.sum_hi = (uint32_t)(sp >> 32);
+        }
         memcpy(A.host + words_at[i], l.words.data(), l.words.size() * 4);
         reinterpret_cast<uint32_t *>(A.host + words_at[i])[l.words.size()] = VM_END;
         memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)r.n_chunks * 4 * l.max_fk_phase);
@@ -910,6 +1093,7 @@ void msi_vm_destroy(msi_vm *vmx) {
       fprintf(stderr, "msi_vm profile: %llu workgroups, %.1f us each;", (unsigned long long)t[0], t[0] ? t[15] / 100.0 / t[0] : 0.0);
       for (int i = 1; i < 14; ++i)
         if (t[i]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * t[i] / (double)t[15]);
+      fprintf(stderr, "; scoped (command, chunk) executions %llu, of them on an all-zero chunk %llu", (unsigned long long)t[20], (unsigned long long)t[21]);
       fprintf(stderr, "; epilogue %.1f us per workgroup; %llu list-phases, first start to last ticket %.1f us\n",
               t[0] ? t[18] / 100.0 / t[0] : 0.0, (unsigned long long)t[17], t[17] ? t[16] / 100.0 / t[17] : 0.0);
       (void)hipFree(vm->d_prof);

@@ -990,7 +990,7 @@ struct msi_vs {
   bool s16 = false;                // rows stored as bf16 (MSI_VS_BF16)
   uint64_t n_rows = 0, n_tiles = 0;
   DevBuf tiles, norm, inv_norm, docids;
-  DevBuf tiles_next, docids_next, add_tiles, add_docids, row_map;  // msi_vs_update builds the next store beside the current one
+  DevBuf tiles_next, docids_next, norm_next, inv_norm_next, add_tiles, add_docids, row_map;  // msi_vs_update builds the next store beside the current one
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
   // scratch (guarded by ctx->mu)
   DevBuf qraw, qfrag, qfrag_bf, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fbits, out_docids,
@@ -1469,7 +1469,7 @@ void msi_vs_destroy(msi_vs *vs) {
     DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qfrag_bf, &vs->qrow,
                       &vs->qsmall, &vs->gkeys, &vs->gcnt, &vs->gsmall, &vs->sel_keys, &vs->dense, &vs->tmask,
                       &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp, &vs->resc_keys,
-                      &vs->tiles_next, &vs->docids_next, &vs->add_tiles, &vs->add_docids, &vs->row_map};
+                      &vs->tiles_next, &vs->docids_next, &vs->norm_next, &vs->inv_norm_next, &vs->add_tiles, &vs->add_docids, &vs->row_map};
     for (DevBuf *b : bufs) b->release();
     vs->scan_timer.release();
     delete vs;
@@ -1549,8 +1549,10 @@ int32_t msi_vs_update(msi_vs *vs, const uint32_t *remove_docids, uint64_t n_remo
   MSI_TRY(vs->add_tiles.ensure(std::max<uint64_t>(1, add_tiles) * vs->KB * 64 * slot));
   MSI_TRY(vs->add_docids.ensure(std::max<uint64_t>(1, n_add) * sizeof(uint32_t)));
   MSI_TRY(vs->row_map.ensure(std::max<uint64_t>(1, n_new) * sizeof(uint32_t)));
-  MSI_TRY(vs->norm.ensure(std::max<uint64_t>(16, padded) * sizeof(float)));
-  MSI_TRY(vs->inv_norm.ensure(std::max<uint64_t>(16, padded) * sizeof(float)));
+  // (the live store's norm arrays are not touched before the swap: a buffer that grows is a new allocation, and a
+  // failure further down must leave the current store whole)
+  MSI_TRY(vs->norm_next.ensure(std::max<uint64_t>(16, padded) * sizeof(float)));
+  MSI_TRY(vs->inv_norm_next.ensure(std::max<uint64_t>(16, padded) * sizeof(float)));
   MSI_TRY(ensure_scratch(vs));
   if (n_add) {
     MSI_TRY(tile_rows(vs, add_rows, false, n_add, vs->add_tiles.p));
@@ -1568,9 +1570,17 @@ int32_t msi_vs_update(msi_vs *vs, const uint32_t *remove_docids, uint64_t n_remo
   MSI_HIP_TRY(hipStreamSynchronize(st));  // `map` and the borrowed lists are done with; searches hold the same lock
   std::swap(vs->tiles, vs->tiles_next);
   std::swap(vs->docids, vs->docids_next);
+  std::swap(vs->norm, vs->norm_next);
+  std::swap(vs->inv_norm, vs->inv_norm_next);
   Small s = small_of(vs);
-  MSI_HIP_TRY(hipMemsetAsync(s.bad, 0, sizeof(uint32_t), st));
-  return finish_upload(vs, n_new, "msi_vs_update");
+  int32_t fin = hipMemsetAsync(s.bad, 0, sizeof(uint32_t), st) == hipSuccess ? MSI_OK : MSI_E_HIP;
+  if (fin == MSI_OK) fin = finish_upload(vs, n_new, "msi_vs_update");
+  if (fin != MSI_OK) {   // the new store has no valid norms: better empty than wrong
+    vs->n_rows = 0;
+    vs->n_tiles = 0;
+    vs->h_docids.clear();
+  }
+  return fin;
 }
 
 uint64_t msi_vs_len(const msi_vs *vs) { return vs ? vs->n_rows : 0; }
