@@ -43,7 +43,6 @@
 #ifndef MSI_SEARCH_DIRECT_ONLY
 #include "msi_vm.h"
 int32_t msi_bits_sync(msi_bits *p);
-extern "C" void msi_debug_arm_abort_backtrace(void);
 bool msi_bits_take_summary_dirty(msi_bits *p);
 const uint32_t *msi_doc_keys_device(const msi_doc_keys *k);
 MsiPostingCache *msi_dict_pcache(const msi_dict *d);
@@ -2987,7 +2986,6 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
                                              size_t universe_len, uint32_t *out_docids, msi_score_detail *out_scores,
                                              uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates,
                                              int32_t *out_degraded) {
-  msi_debug_arm_abort_backtrace();
   if (!dict || !pool || !index || !index->word_docids || !params || !out_n || (n_terms && !terms) ||
       n_terms > MSI_RANK_MAX_TERMS || (params->length && (!out_docids || !out_scores || !out_n_scores)) ||
       (params->n_criteria && !params->criteria) ||

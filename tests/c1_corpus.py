@@ -83,7 +83,7 @@ def run(args, env):
         s0 = time.perf_counter()
         out = RO.search(RO.Ctx(index, lookup), q, tms="last", offset=0, length=limit)
         cpu_lat.append((time.perf_counter() - s0) * 1e3)
-        expected.append([d for d, _ in out[0]] if isinstance(out, tuple) else [d for d, _ in out])
+        expected.append(list(out[0]))   # (ids, score details, all_candidates)
     # ---- product ------------------------------------------------------------------------------------------
     gdict = ma.GpuDictionary(env.ctx, [w.encode() for w in index.words])
     pool = ma.BitsPool(env.ctx, max(index.n_docs, 1), 1024)
