@@ -468,7 +468,7 @@ def run_c4(args, env):
                         f"+ {args.words_per_query} typo-tolerant words/query over a {args.dict_words}-term dictionary",
             "queries_per_step_per_gpu": Q, "words_per_step_per_gpu": n_words_q,
             "queries_per_hbm_sweep": store.max_batch,
-            "scan_math": os.environ.get("MSI_VS_SCAN_MATH", "bf16x3") + " candidate scan (f32 rows in HBM, f32 accumulate)"
+            "scan_math": os.environ.get("MSI_VS_SCAN_MATH", "bf16x2") + " candidate scan (f32 rows in HBM split hi/lo in registers, bf16 query fragments, f32 accumulate)"
                          " + exact f32 reference rescoring of K' candidates with an exactness proof",
             "sharding": ("rows sharded (%d per GPU of %d), same query batch on every GPU, ONE packed all_gather of "
                          "per-shard top-k (RCCL) + device k-way merge" % (n, n_total)) if row_sharded else

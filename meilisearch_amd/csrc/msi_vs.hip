@@ -53,7 +53,7 @@ constexpr uint32_t KP_MAX = 2048;        // K' supported by select/rescore (k <=
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_SORTCAP = 2048;        // u64 keys sorted in LDS by vs_select
 constexpr int QT = 16;                   // queries per MFMA tile
-constexpr int NQT_MAX = 3;               // query tiles per HBM sweep
+constexpr int NQT_MAX = 6;               // query tiles per HBM sweep (6 with the bf16x2 contraction, 3 otherwise)
 constexpr int NQ_MAX = QT * NQT_MAX;     // queries per HBM sweep
 constexpr int CNT_PAD = 32;              // u32 stride of the per-query counters (one 128-B line each)
 constexpr size_t LDS_MAX = 160 * 1024;
@@ -230,13 +230,14 @@ __global__ __launch_bounds__(256) void vs_prep_queries_kernel(
   MSI_DYNAMIC_LDS(smem);
   float *row = reinterpret_cast<float *>(smem);  // [dpad]
   const uint32_t j = blockIdx.x;
-  const uint32_t dpad = store16 ? KB * 32 : KB * 16;
+  const bool rows16 = store16 == 1;   // (store16 == 2: f32 rows, hi-only query fragments — the bf16x2 contraction)
+  const uint32_t dpad = rows16 ? KB * 32 : KB * 16;
   for (uint32_t k = threadIdx.x; k < dpad; k += blockDim.x)
     row[k] = (j < nq && k < dim) ? q[(uint64_t)j * dim + k] : 0.f;
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < dpad; k += blockDim.x) qrow[(uint64_t)j * dpad + k] = row[k];
   const uint32_t t = j / QT, jj = j % QT;
-  if (!store16) {
+  if (store16 == 0) {
     for (uint32_t idx = threadIdx.x; idx < KB * 4; idx += blockDim.x) {
       const uint32_t kb = idx >> 2, g = idx & 3;
       const float4 v = *reinterpret_cast<const float4 *>(row + kb * 16 + g * 4);
@@ -247,16 +248,20 @@ __global__ __launch_bounds__(256) void vs_prep_queries_kernel(
   // 32p+4g..+3 and 32p+16+4g..+3 (the same 8 a row lane holds after two 16-byte
   // loads), split as hi = bf16(x), lo = bf16(x - hi); layout [t][KB/2][hi|lo][64].
   // (bf16 store: KB counts 32-column blocks and lane (g, jj) holds columns 32p+8g..+7)
-  const uint32_t n_pairs = store16 ? KB : KB / 2;
+  const uint32_t n_pairs = rows16 ? KB : KB / 2;
   for (uint32_t idx = threadIdx.x; idx < n_pairs * 4; idx += blockDim.x) {
     const uint32_t p = idx >> 2, g = idx & 3;
     bf16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float x = store16 ? row[p * 32 + g * 8 + e] : row[p * 32 + (e >> 2) * 16 + g * 4 + (e & 3)];
+      const float x = rows16 ? row[p * 32 + g * 8 + e] : row[p * 32 + (e >> 2) * 16 + g * 4 + (e & 3)];
       const __bf16 h = (__bf16)x;
       hi[e] = h;
       lo[e] = (__bf16)(x - (float)h);
+    }
+    if (store16 == 2) {   // bf16x2: the hi halves only, [t][KB/2][64]
+      qfrag_bf[((uint64_t)t * n_pairs + p) * 64 + g * 16 + jj] = hi;
+      continue;
     }
     const uint64_t base = (((uint64_t)t * n_pairs + p) * 2) * 64 + g * 16 + jj;
     qfrag_bf[base] = hi;
@@ -369,7 +374,8 @@ struct ScanArgs {
 //   S16    the store holds bf16 rows (half the HBM bytes per row): the 16-byte loads ARE
 //          the bf16 A operands, x·(q_hi + q_lo) needs 2 MFMAs per 32 columns and no
 //          conversion; LDS holds q_hi and q_lo (2 KiB per 32 columns and query tile).
-template <int WAVES, int NQT, bool DENSE, bool BF3, bool S16>
+// MATH: 0 = f32 MFMA, 1 = bf16x3 (hi.hi + hi.lo + lo.hi), 2 = bf16x2 (row hi/lo x query hi: half the LDS per query)
+template <int WAVES, int NQT, bool DENSE, int MATH, bool S16>
 __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   MSI_DYNAMIC_LDS(smem);
   const uint32_t tid = threadIdx.x;
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   const uint32_t KB = a.KB;
 
   float4 *qf = reinterpret_cast<float4 *>(smem);
-  for (uint32_t i = tid; i < NQT * KB * 64 * (S16 ? 2 : 1); i += WAVES * 64) qf[i] = a.qfrag[i];
+  for (uint32_t i = tid; i < (MATH == 2 ? NQT * KB * 32 : NQT * KB * 64 * (S16 ? 2 : 1)); i += WAVES * 64) qf[i] = a.qfrag[i];
   __syncthreads();
 
   const uint32_t qj = lane & 15;   // this lane's query inside a tile (D column)
@@ -492,7 +498,30 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
           acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa8, qt[64], acc[t][1], 0, 0, 0);
         }
       }
-    } else if (BF3) {
+    } else if (MATH == 2) {
+      // LDS: [t][KB/2][64] bf16x8 — the queries' hi halves only; the row is split in registers as in bf16x3 and
+      // hi.hi + lo.hi is accumulated: the query's rounding (<= 2^-8 relative) is the whole first-order error, the
+      // exactness proof carries it (scan_eps) and more candidates are rescored (K').  Half the LDS per query: 96
+      // queries share a sweep at d = 768.
+      const bf16x8 *qb = reinterpret_cast<const bf16x8 *>(qf) + (size_t)sub_cmp * (SCAN_GROUP / 2) * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < SCAN_GROUP; u += 2) {
+        const float v[8] = {x[u].x, x[u].y, x[u].z, x[u].w, x[u + 1].x, x[u + 1].y, x[u + 1].z, x[u + 1].w};
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const __bf16 h = (__bf16)v[e];
+          hi[e] = h;
+          lo[e] = (__bf16)(v[e] - (float)h);
+        }
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+          const bf16x8 qh = qb[(size_t)t * (KB / 2) * 64 + (u / 2) * 64];
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, qh, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, qh, acc[t][1], 0, 0, 0);
+        }
+      }
+    } else if (MATH == 1) {
       // LDS: [t][KB/2][hi|lo][64] bf16x8; this group covers pairs sub_cmp*4 .. +3
       const bf16x8 *qb = reinterpret_cast<const bf16x8 *>(qf) + (size_t)sub_cmp * (SCAN_GROUP / 2) * 128 + lane;
 #pragma unroll
@@ -986,7 +1015,8 @@ struct msi_vs {
   msi_ctx *ctx = nullptr;
   uint32_t dim = 0, dpad = 0, KB = 0;
   uint32_t nqt_max = 1;            // query tiles per sweep the LDS admits for this dim
-  bool bf3 = true;                 // contraction of the fast scan: bf16x3 (default) or f32 MFMA
+  bool bf3 = true;                 // contraction of the fast scan: bf16 MFMA (default) or f32 MFMA
+  bool bf2 = false;                // ... bf16x2 (queries' hi halves only in LDS: twice the queries per sweep) instead of bf16x3
   bool s16 = false;                // rows stored as bf16 (MSI_VS_BF16)
   uint64_t n_rows = 0, n_tiles = 0;
   DevBuf tiles, norm, inv_norm, docids;
@@ -1047,7 +1077,8 @@ Small small_of(msi_vs *vs) {
   return s;
 }
 
-size_t scan_lds_bytes(uint32_t KB, uint32_t nqt, bool s16 = false) {
+size_t scan_lds_bytes(uint32_t KB, uint32_t nqt, bool s16 = false, bool bf2 = false) {
+  if (bf2) return (size_t)nqt * KB * 32 * sizeof(float4);
   return (size_t)nqt * KB * 64 * sizeof(float4) * (s16 ? 2 : 1);
 }
 
@@ -1070,6 +1101,9 @@ uint32_t threshold_rank(uint32_t kp, double p) {
 float scan_eps(const msi_vs *vs) {
   const float u = 5.9604645e-8f, h = 3.8146973e-6f;
   if (vs->s16) return (4.0f * (float)vs->dpad + 64.0f) * u + 1.0f * h;
+  // bf16x2: the query is rounded to bf16 (relative error <= 2^-8 per element, so |x.(q - q_hi)| <= 2^-8 |x||q|), the
+  // row's lo.lo term does not exist and its lo is rounded (2^-16); two products of dpad terms each
+  if (vs->bf2) return (4.0f * (float)vs->dpad + 64.0f) * u + 0.00390625f * 1.01f + 2.0f * 1.52587890625e-5f;
   if (vs->bf3) return (6.0f * (float)vs->dpad + 64.0f) * u + 3.0f * h;
   return (2.0f * (float)vs->dpad + 32.0f) * u;
 }
@@ -1192,7 +1226,7 @@ int32_t finish_upload(msi_vs *vs, uint64_t n_rows, const char *what) {
 
 // Launch one sweep.  `dense` selects the epilogue, nqt the number of 16-query tiles.
 void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense) {
-  const size_t lds = scan_lds_bytes(vs->KB, nqt, vs->s16);
+  const size_t lds = scan_lds_bytes(vs->KB, nqt, vs->s16, vs->bf2);
   const dim3 grid(vs->scan_grid), block(SCAN_WAVES * 64);
   hipStream_t st = vs->ctx->stream;
 #define MSI_SCAN_LAUNCH(N, D, B, S) \
@@ -1200,21 +1234,32 @@ void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense) {
 #define MSI_SCAN_CASE(N)                                              \
   case N:                                                             \
     if (vs->s16) {                                                    \
-      if (dense) MSI_SCAN_LAUNCH(N, true, true, true);                \
-      else MSI_SCAN_LAUNCH(N, false, true, true);                     \
+      if (dense) MSI_SCAN_LAUNCH(N, true, 1, true);                   \
+      else MSI_SCAN_LAUNCH(N, false, 1, true);                        \
     } else if (dense) {                                               \
-      if (vs->bf3) MSI_SCAN_LAUNCH(N, true, true, false);             \
-      else MSI_SCAN_LAUNCH(N, true, false, false);                    \
+      if (vs->bf2) MSI_SCAN_LAUNCH(N, true, 2, false);                \
+      else if (vs->bf3) MSI_SCAN_LAUNCH(N, true, 1, false);           \
+      else MSI_SCAN_LAUNCH(N, true, 0, false);                        \
     } else {                                                          \
-      if (vs->bf3) MSI_SCAN_LAUNCH(N, false, true, false);            \
-      else MSI_SCAN_LAUNCH(N, false, false, false);                   \
+      if (vs->bf2) MSI_SCAN_LAUNCH(N, false, 2, false);               \
+      else if (vs->bf3) MSI_SCAN_LAUNCH(N, false, 1, false);          \
+      else MSI_SCAN_LAUNCH(N, false, 0, false);                       \
     }                                                                 \
+    break;
+#define MSI_SCAN_CASE2(N)                                             \
+  case N:                                                             \
+    if (dense) MSI_SCAN_LAUNCH(N, true, 2, false);                    \
+    else MSI_SCAN_LAUNCH(N, false, 2, false);                         \
     break;
   switch (nqt) {
     MSI_SCAN_CASE(1)
     MSI_SCAN_CASE(2)
     MSI_SCAN_CASE(3)
+    MSI_SCAN_CASE2(4)   // (only the bf16x2 contraction admits more than 3 query tiles)
+    MSI_SCAN_CASE2(5)
+    MSI_SCAN_CASE2(6)
   }
+#undef MSI_SCAN_CASE2
 #undef MSI_SCAN_LAUNCH
 #undef MSI_SCAN_CASE
 }
@@ -1231,13 +1276,15 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
     msi_set_error("msi_vs_search: k=%u above the supported maximum %u", k, KP_MAX);
     return MSI_E_UNSUPPORTED;
   }
-  const uint32_t slack = std::max<uint32_t>(12, k / 4);
+  // candidates rescored beyond k: every row whose fast score lies within twice the proof's eps of the k-th must be among
+  // them — a handful with bf16x3 (eps ~ 1e-5), a few dozen to a hundred with bf16x2 (eps ~ 4e-3)
+  const uint32_t slack = vs->bf2 ? std::max<uint32_t>(108, 3 * k) : std::max<uint32_t>(12, k / 4);
   const uint32_t kp = std::min<uint32_t>(k + slack, KP_MAX);
   const uint32_t nqt = (nq + QT - 1) / QT;
   // 1. queries
   hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
                      d_queries, nq, vs->dim, vs->KB, vs->qfrag.as<float4>(), vs->qfrag_bf.as<bf16x8>(),
-                     vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth, vs->s16 ? 1u : 0u);
+                     vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth, vs->s16 ? 1u : (vs->bf2 ? 2u : 0u));
   MSI_HIP_TRY(hipMemsetAsync(s.overflow, 0, sizeof(uint32_t), st));
   // 2. filter
   const uint32_t *list = nullptr;
@@ -1415,8 +1462,14 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
                   scan_lds_bytes(KB, 1, s16), LDS_MAX);
     return MSI_E_UNSUPPORTED;
   }
+  // contraction of the fast scan (f32 rows), MSI_VS_SCAN_MATH: "bf16x2" (default: the queries' hi halves only in LDS —
+  // twice the queries per sweep, a wider proof margin, more rescored candidates, bf16x3 as second opinion), "bf16x3",
+  // "f32"
+  const char *math = getenv("MSI_VS_SCAN_MATH");
+  const bool bf2 = !s16 && !(math && (strcmp(math, "bf16x3") == 0 || strcmp(math, "f32") == 0));
+  const uint32_t nqt_cap = bf2 ? (uint32_t)NQT_MAX : 3u;
   uint32_t nqt_max = 1;
-  while (nqt_max < (uint32_t)NQT_MAX && scan_lds_bytes(KB, nqt_max + 1, s16) <= LDS_MAX) ++nqt_max;
+  while (nqt_max < nqt_cap && scan_lds_bytes(KB, nqt_max + 1, s16, bf2) <= LDS_MAX) ++nqt_max;
   if (const char *e = getenv("MSI_VS_MAX_QUERY_TILES")) {  // tuning/testing knob
     const int v = atoi(e);
     if (v >= 1 && (uint32_t)v < nqt_max) nqt_max = (uint32_t)v;
@@ -1424,11 +1477,13 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
   DeviceGuard g(ctx->device);
   const void *fns[] = {
 #define MSI_F(N, D, B) reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, B, false>)
-#define MSI_G(N, D) reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, true, true>)
+#define MSI_G(N, D) reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, 1, true>)
       MSI_F(1, true, true), MSI_F(1, true, false), MSI_F(1, false, true), MSI_F(1, false, false),
       MSI_F(2, true, true), MSI_F(2, true, false), MSI_F(2, false, true), MSI_F(2, false, false),
       MSI_F(3, true, true), MSI_F(3, true, false), MSI_F(3, false, true), MSI_F(3, false, false),
-      MSI_G(1, true), MSI_G(1, false), MSI_G(2, true), MSI_G(2, false), MSI_G(3, true), MSI_G(3, false)
+      MSI_G(1, true), MSI_G(1, false), MSI_G(2, true), MSI_G(2, false), MSI_G(3, true), MSI_G(3, false),
+      MSI_F(1, true, 2), MSI_F(1, false, 2), MSI_F(2, true, 2), MSI_F(2, false, 2), MSI_F(3, true, 2), MSI_F(3, false, 2),
+      MSI_F(4, true, 2), MSI_F(4, false, 2), MSI_F(5, true, 2), MSI_F(5, false, 2), MSI_F(6, true, 2), MSI_F(6, false, 2)
 #undef MSI_F
 #undef MSI_G
   };
@@ -1447,9 +1502,10 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
   vs->KB = KB;
   vs->nqt_max = nqt_max;
   vs->s16 = s16;
-  if (const char *e = getenv("MSI_VS_SCAN_MATH")) vs->bf3 = strcmp(e, "f32") != 0;  // "f32" | "bf16x3"
+  vs->bf3 = !(math && strcmp(math, "f32") == 0);
+  vs->bf2 = bf2;
   // workgroups per CU: two when the query fragments leave room (more loads in flight)
-  uint32_t wg_per_cu = scan_lds_bytes(KB, nqt_max, s16) <= LDS_MAX / 2 ? 2 : 1;
+  uint32_t wg_per_cu = scan_lds_bytes(KB, nqt_max, s16, bf2) <= LDS_MAX / 2 ? 2 : 1;
   if (const char *e = getenv("MSI_VS_WG_PER_CU")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 4) wg_per_cu = (uint32_t)v;
@@ -1837,21 +1893,76 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
                            vs->out_dist.as<float>(), s.counts, s.inexact));
     uint32_t h_inexact[NQ_MAX];
     MSI_HIP_TRY(hipMemcpyAsync(h_inexact, s.inexact, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MSI_HIP_TRY(hipMemcpyAsync(out_counts + q0, s.counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipStreamSynchronize(st));
-    for (uint32_t j = 0; j < nq; ++j) {
-      if (!h_inexact[j]) continue;
-      if (cancel && *cancel) {
-        msi_set_error("msi_vs_search: cancelled");
-        return MSI_E_CANCELLED;
+    std::vector<uint32_t> flagged;
+    for (uint32_t j = 0; j < nq; ++j)
+      if (h_inexact[j]) flagged.push_back(j);
+    if (!flagged.empty() && !vs->bf2) {
+      for (uint32_t j : flagged) {
+        if (cancel && *cancel) {
+          msi_set_error("msi_vs_search: cancelled");
+          return MSI_E_CANCELLED;
+        }
+        MSI_TRY(exhaustive_one(vs, j, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>() + (size_t)j * k,
+                               vs->out_dist.as<float>() + (size_t)j * k, s.counts + j));
       }
-      MSI_TRY(exhaustive_one(vs, j, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>() + (size_t)j * k,
-                             vs->out_dist.as<float>() + (size_t)j * k, s.counts + j));
+      MSI_HIP_TRY(hipMemcpyAsync(out_counts + q0, s.counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    } else if (!flagged.empty()) {
+      // The results of the queries that proved exact leave first: the re-runs below prepare their own query rows.
+      MSI_HIP_TRY(hipMemcpyAsync(out_docids + (size_t)q0 * k, vs->out_docids.p, (size_t)nq * k * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, st));
+      MSI_HIP_TRY(hipMemcpyAsync(out_dist + (size_t)q0 * k, vs->out_dist.p, (size_t)nq * k * sizeof(float),
+                                 hipMemcpyDeviceToHost, st));
+      MSI_HIP_TRY(hipStreamSynchronize(st));
+      // A query the bf16x2 scan could not prove (its margin is 2^-8 wide) gets a second opinion from the bf16x3
+      // contraction (margin ~1e-5), 48 to a sweep; what that cannot prove either — ties beyond K', degenerate rows — is
+      // answered exhaustively in the reference arithmetic.
+      const bool second_opinion = true;
+      const uint32_t sub = 3u * QT;
+      for (size_t f0 = 0; f0 < flagged.size(); f0 += sub) {
+        const uint32_t nf = (uint32_t)std::min<size_t>(sub, flagged.size() - f0);
+        if (cancel && *cancel) {
+          msi_set_error("msi_vs_search: cancelled");
+          return MSI_E_CANCELLED;
+        }
+        uint32_t h_in2[NQ_MAX], h_cnt2[NQ_MAX];
+        for (uint32_t i = 0; i < nf; ++i) {
+          h_in2[i] = 1;
+          MSI_HIP_TRY(hipMemcpyAsync(vs->qraw.as<float>() + (size_t)i * vs->dim,
+                                     queries + (size_t)(q0 + flagged[f0 + i]) * vs->dim, (size_t)vs->dim * sizeof(float),
+                                     hipMemcpyHostToDevice, st));
+        }
+        vs->bf2 = false;
+        const int32_t st2 = enqueue_search(vs, vs->qraw.as<float>(), nf, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>(),
+                                     vs->out_dist.as<float>(), s.counts, s.inexact);
+        vs->bf2 = true;
+        MSI_TRY(st2);
+        if (second_opinion) {
+          MSI_HIP_TRY(hipMemcpyAsync(h_in2, s.inexact, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+          MSI_HIP_TRY(hipStreamSynchronize(st));
+        }
+        for (uint32_t i = 0; i < nf; ++i)   // (query rows of THIS sub-batch: index i)
+          if (h_in2[i])
+            MSI_TRY(exhaustive_one(vs, i, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>() + (size_t)i * k,
+                                   vs->out_dist.as<float>() + (size_t)i * k, s.counts + i));
+        MSI_HIP_TRY(hipMemcpyAsync(h_cnt2, s.counts, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        for (uint32_t i = 0; i < nf; ++i) {
+          const size_t row = (size_t)(q0 + flagged[f0 + i]) * k;
+          MSI_HIP_TRY(hipMemcpyAsync(out_docids + row, vs->out_docids.as<uint32_t>() + (size_t)i * k, (size_t)k * sizeof(uint32_t),
+                                     hipMemcpyDeviceToHost, st));
+          MSI_HIP_TRY(hipMemcpyAsync(out_dist + row, vs->out_dist.as<float>() + (size_t)i * k, (size_t)k * sizeof(float),
+                                     hipMemcpyDeviceToHost, st));
+        }
+        MSI_HIP_TRY(hipStreamSynchronize(st));
+        for (uint32_t i = 0; i < nf; ++i) out_counts[q0 + flagged[f0 + i]] = h_cnt2[i];
+      }
+      continue;
     }
     MSI_HIP_TRY(hipMemcpyAsync(out_docids + (size_t)q0 * k, vs->out_docids.p, (size_t)nq * k * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipMemcpyAsync(out_dist + (size_t)q0 * k, vs->out_dist.p, (size_t)nq * k * sizeof(float),
                                hipMemcpyDeviceToHost, st));
-    MSI_HIP_TRY(hipMemcpyAsync(out_counts + q0, s.counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipStreamSynchronize(st));
   }
   return MSI_OK;
@@ -1882,7 +1993,7 @@ int32_t msi_vs_debug_fast_scores(msi_vs *vs, const float *queries, uint32_t n_qu
   MSI_HIP_TRY(hipMemcpyAsync(vs->qraw.p, queries, (size_t)n_queries * vs->dim * sizeof(float), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
                      vs->qraw.as<float>(), n_queries, vs->dim, vs->KB, vs->qfrag.as<float4>(),
-                     vs->qfrag_bf.as<bf16x8>(), vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth, vs->s16 ? 1u : 0u);
+                     vs->qfrag_bf.as<bf16x8>(), vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth, vs->s16 ? 1u : (vs->bf2 ? 2u : 0u));
   ScanArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.tiles = vs->tiles.as<float4>();
