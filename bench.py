@@ -354,7 +354,15 @@ def run_c4(args, env):
         env.dist.broadcast(uid, 0)
         buf = (C.c_uint8 * 128)(*uid.cpu().tolist())
         group = C.c_void_p()
-        ma._lib.check(L.msi_group_create_rank(ctx.handle, rank, world, buf, C.byref(group)))
+        try:
+            ma._lib.check(L.msi_group_create_rank(ctx.handle, rank, world, buf, C.byref(group)))
+        except Exception as e:   # noqa: BLE001 - the line must still be produced: the launcher's own RCCL group carries the exchange
+            print(f"[bench] rank {rank}: msi_group_create_rank failed ({e}); exchanging through torch.distributed", file=sys.stderr)
+            group = None
+        ok = torch.tensor([1 if group is not None else 0], dtype=torch.int32, device=dev)
+        env.dist.all_reduce(ok, op=env.dist.ReduceOp.MIN)    # every rank takes the same path
+        if int(ok.item()) == 0:
+            group = None
 
     def exchange():
         """The one exchange step: per-rank top-k lists (Q*(2k+1)*4 bytes) in ONE all-gather over xGMI — RCCL called by
@@ -363,9 +371,13 @@ def run_c4(args, env):
         packed[Q * k:2 * Q * k].copy_(out_ids.reshape(-1))
         packed[2 * Q * k:].copy_(out_cnt)
         torch.cuda.current_stream().synchronize()      # the packing ran on torch's stream
-        ma._lib.check(ma._lib.lib().msi_group_allgather(group, C.c_void_p(packed.data_ptr()), packed.numel() * 4,
-                                                        C.c_void_p(gathered.data_ptr())))
-        ctx.synchronize()
+        if group is not None:
+            ma._lib.check(ma._lib.lib().msi_group_allgather(group, C.c_void_p(packed.data_ptr()), packed.numel() * 4,
+                                                            C.c_void_p(gathered.data_ptr())))
+            ctx.synchronize()
+        else:
+            env.dist.all_gather_into_tensor(gathered, packed)
+            torch.cuda.synchronize()
         g = gathered.view(world, Q * (2 * k + 1))
         return (g[:, Q * k:2 * Q * k].reshape(world, Q, k), g[:, :Q * k].view(torch.float32).reshape(world, Q, k),
                 g[:, 2 * Q * k:].reshape(world, Q))
