@@ -69,6 +69,7 @@ def parse_args():
     ap.add_argument("--kw-terms", type=int, default=3, help="c4: words per keyword query")
     ap.add_argument("--kw-dict-words", type=int, default=200_000, help="c4: vocabulary of the synthetic inverted index")
     ap.add_argument("--kw-cache-mb", type=int, default=8192, help="c4: HBM posting cache of the index version")
+    ap.add_argument("--serial-legs", action="store_true", help="c4: wait for the vector leg before the keyword leg starts")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="also skips the parity check (same leg)")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child for roofline.traffic")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
@@ -405,6 +406,8 @@ def run_c4(args, env):
         if gdict is not None:
             gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
         if kw is not None:
+            if args.serial_legs:
+                ctx.synchronize()     # the scan streams HBM on its own, then the (latency-bound) keyword lists run
             keyword_run()
         ctx.synchronize()
         if row_sharded:
@@ -438,11 +441,19 @@ def run_c4(args, env):
     # the two legs on their own (untimed extras, 3 steps each): what bounds the step
     legs = {}
     if kw is not None and not env.child:
+        ctx.set_profiling(True)
+        store.scan_time()
         t0 = time.perf_counter()
         for _ in range(3):
             store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)
             ctx.synchronize()
         legs["vector_only_queries_per_s"] = round(3 * Q / (time.perf_counter() - t0), 1)
+        alone_n, alone_ms = store.scan_time()
+        ctx.set_profiling(False)
+        if alone_n:   # the same kernel without the keyword lists beside it (the timed step overlaps the two legs)
+            alone_bytes = ((n + 15) // 16) * stats["bytes_per_tile"]
+            legs["scan_kernel_alone"] = {"avg_launch_ms": round(alone_ms / alone_n, 4), "launches": alone_n,
+                                         "frac_of_8_TBps": round(alone_bytes / (alone_ms / alone_n * 1e-3) / 1e9 / 8000.0, 4)}
         import resource
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
