@@ -169,3 +169,27 @@ def test_set_from_docid_lists_device():
         want = sorted(set(int(x) for x in ids[i, :counts[i]] if x < n_docs))
         assert pool.to_docids(2 + 3 * i).tolist() == want
         assert pool.count(2 + 3 * i + 1) == n_docs   # neighbours untouched
+
+
+def test_decode_batch_larger_than_the_staging_ring(ctx):
+    """One posting of 1100 bitmap containers is 9 MB of serialised bytes plus 17.6 KB of descriptors — more than the 8 MB
+    the pinned staging ring starts with: the direct decode path takes ONE ring block for both (growing the ring), so the
+    descriptors can neither overlap the not-yet-copied bytes nor dangle (msi_bits_decode_batch)."""
+    n_cont = 1100
+    rng = np.random.default_rng(77)
+    words = rng.integers(0, 2 ** 63, size=(n_cont, 1024), dtype=np.uint64) | (rng.integers(0, 2, size=(n_cont, 1024), dtype=np.uint64) << np.uint64(63))
+    card = np.array([int(np.unpackbits(w.view(np.uint8)).sum()) for w in words])
+    assert (card > 4096).all()
+    out = bytearray(struct.pack("<II", 12346, n_cont))
+    for k in range(n_cont):
+        out += struct.pack("<HH", k, (card[k] - 1) & 0xFFFF)
+    out += b"\0" * (4 * n_cont)
+    out += words.astype("<u8").tobytes()
+    assert len(out) > 8 << 20
+    n_docs = n_cont * 65536
+    pool = ma.BitsPool(ctx, n_docs, 2)
+    pool.set_from_cbo(0, bytes(out))
+    got = pool.read_words(0)
+    assert np.array_equal(got[:n_cont * 1024], words.reshape(-1))
+    assert pool.count(0) == int(card.sum())
+    pool.close()
