@@ -7,13 +7,17 @@ BASELINE.json metric: queries/sec + p50 latency, 10 M-doc index (768-d hybrid / 
 The default (`--config c4`, the line the driver records) is the configuration the metric is quoted on; it fits
 one GPU (30.72 GB of 288 GB), so every rank holds a replica and answers its own query stream:
 
-  c4  one "step" = one batch of 96 hybrid queries per GPU through the hot path, inputs resident in HBM:
-        * 96 query vectors -> exact cosine top-20 over the 10 M x 768 f32 store (vs_scan: HBM sweeps shared by
-          msi_vs_max_batch() queries; candidates rescored with the reference arithmetic + exactness proof);
-        * 192 query words -> typo derivations (1 / 2 typos by char count, 30 % prefix) over the 2 M-term
+  c4  one "step" = one batch of 768 hybrid queries per GPU through the hot path, inputs resident in HBM:
+        * 768 query vectors -> exact cosine top-20 over the 10 M x 768 f32 store (vs_scan: one HBM sweep per
+          msi_vs_max_batch() = 96 queries; candidates rescored with the reference arithmetic + exactness proof);
+        * 1536 query words -> typo derivations (1 / 2 typos by char count, 30 % prefix) over the 2 M-term
           dictionary (dict_lookup) on the context's second stream;
-        * keyword leg + hybrid merge (semanticRatio 0.5): see `config.step_includes` of the line;
+        * keyword leg: msi_keyword_search_ranked for every query — all 7 default criteria, detailed scores (what
+          hybrid search asks for), 64 caller threads over a 10 M-document synthetic inverted index whose typo
+          derivations come from its own 200 k-word dictionary — and the hybrid merge (semanticRatio 0.5);
         * results copied to the host.
+      `legs` of the line: each leg on its own (untimed extras), the scan kernel's roofline fraction without the
+      keyword lists running beside it, host CPUs used by the keyword leg.
   c2  1 M x 384 f32, cosine top-20, 256 queries per step                       (SURVEY §8 d)
   c3  2 M-term dictionary, 8 192 query words per step (1 / 2 typos, 30 % prefix)              (C3; unit words/s)
   c5  one GPU's shard of config 5: 12.5 M x 1024 bf16 rows, 1 % candidate filter, k = 1000, Words -> Typo
@@ -27,8 +31,10 @@ correction x2 per the microarch guide), `cpu_baseline` (the CPU restatement orac
 on this box's host threads, bounded sample) and `parity` (an UNTIMED post-run check of the step's own results
 against the oracle, oracle/parity.py: part of the cpu_baseline leg, rank 0, N = 1).
 
-N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL); queries are sharded, the index is replicated
-("scaling": "weak"); per-rank top-k lists travel in ONE packed all-gather per step.  `--shard rows` (c4) shards
+N GPUs: one process per GPU (launched by torch.distributed.run); queries are sharded, the index is replicated
+("scaling": "weak"); per-rank top-k lists travel in ONE packed all-gather per step, issued by libmsi itself
+(msi_group_create_rank + msi_group_allgather: RCCL inside the library; the launcher's process group only carries the
+128-byte communicator id).  `--shard rows` (c4) shards
 the rows instead (strong scaling): same batch on every rank, all-gather of packed (distance, docid, count) + device
 k-way merge.
 """
