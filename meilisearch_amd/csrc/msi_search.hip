@@ -97,7 +97,7 @@ struct Tasks {
     bool done = false, parked = false;
     std::exception_ptr err;
   };
-  static constexpr size_t STACK = 512u << 10;
+  static constexpr size_t STACK = 1u << 20;   // (index callbacks run on it: an embedding host language needs room)
   ucontext_t main_uc;
   std::vector<std::unique_ptr<T>> all;
   T *cur = nullptr;
