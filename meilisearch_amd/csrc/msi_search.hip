@@ -28,6 +28,7 @@
 #include <ucontext.h>
 
 #include <algorithm>
+#include <unordered_map>
 #include <exception>
 #include <functional>
 #include <chrono>
@@ -773,9 +774,17 @@ struct NTypo {
     words.swap(w);
     phrases.swap(p);
   }
-  auto key() const { return std::tie(kind, words, phrases); }
-  bool operator<(const NTypo &o) const { return key() < o.key(); }
-  bool operator==(const NTypo &o) const { return key() == o.key(); }
+  // Ordered as the tuple (kind, words, phrases) — written out as ONE three-way pass: these keys are compared tens of
+  // thousands of times per query (condition tables, the caches of decoded sets), and Nothing / All carry no sets.
+  int cmp(const NTypo &o) const {
+    if (kind != o.kind) return kind < o.kind ? -1 : 1;
+    if (kind != 2) return 0;
+    if (words != o.words) return words < o.words ? -1 : 1;
+    if (phrases != o.phrases) return phrases < o.phrases ? -1 : 1;
+    return 0;
+  }
+  bool operator<(const NTypo &o) const { return cmp(o) < 0; }
+  bool operator==(const NTypo &o) const { return cmp(o) == 0; }
 };
 const NTypo NT_NONE{0, {}, {}};
 
@@ -783,17 +792,31 @@ struct Subset {
   uint32_t term = 0;
   NTypo zero, one, two;
   bool mandatory = false;
-  auto key() const { return std::tie(term, zero, one, two, mandatory); }
-  bool operator<(const Subset &o) const { return key() < o.key(); }
-  bool operator==(const Subset &o) const { return key() == o.key(); }
+  int cmp(const Subset &o) const {   // the order of the tuple (term, zero, one, two, mandatory)
+    if (term != o.term) return term < o.term ? -1 : 1;
+    if (int c = zero.cmp(o.zero)) return c;
+    if (int c = one.cmp(o.one)) return c;
+    if (int c = two.cmp(o.two)) return c;
+    if (mandatory != o.mandatory) return mandatory < o.mandatory ? -1 : 1;
+    return 0;
+  }
+  bool operator<(const Subset &o) const { return cmp(o) < 0; }
+  bool operator==(const Subset &o) const { return cmp(o) == 0; }
 };
 struct Located {
   Subset subset;
   uint32_t pos_lo = 0, pos_hi = 0, id_lo = 0, id_hi = 0;
   uint32_t n_ids() const { return id_hi - id_lo + 1; }
-  auto key() const { return std::tie(subset, pos_lo, pos_hi, id_lo, id_hi); }
-  bool operator<(const Located &o) const { return key() < o.key(); }
-  bool operator==(const Located &o) const { return key() == o.key(); }
+  int cmp(const Located &o) const {  // the order of the tuple (subset, pos_lo, pos_hi, id_lo, id_hi)
+    if (int c = subset.cmp(o.subset)) return c;
+    if (pos_lo != o.pos_lo) return pos_lo < o.pos_lo ? -1 : 1;
+    if (pos_hi != o.pos_hi) return pos_hi < o.pos_hi ? -1 : 1;
+    if (id_lo != o.id_lo) return id_lo < o.id_lo ? -1 : 1;
+    if (id_hi != o.id_hi) return id_hi < o.id_hi ? -1 : 1;
+    return 0;
+  }
+  bool operator<(const Located &o) const { return cmp(o) < 0; }
+  bool operator==(const Located &o) const { return cmp(o) == 0; }
 };
 
 struct Term {
@@ -822,8 +845,15 @@ struct Condition {
   uint32_t x = 0;          // typo count / proximity cost / fid
   bool has_fid = false;    // C_FID
   std::vector<uint16_t> positions;
-  auto key() const { return std::tie(kind, term, has_left, left, x, has_fid, positions); }
-  bool operator<(const Condition &o) const { return key() < o.key(); }
+  bool operator<(const Condition &o) const {   // the order of the tuple (kind, term, has_left, left, x, has_fid, positions)
+    if (kind != o.kind) return kind < o.kind;
+    if (int c = term.cmp(o.term)) return c < 0;
+    if (has_left != o.has_left) return has_left < o.has_left;
+    if (int c = left.cmp(o.left)) return c < 0;
+    if (x != o.x) return x < o.x;
+    if (has_fid != o.has_fid) return has_fid < o.has_fid;
+    return positions < o.positions;
+  }
 };
 
 struct GNode {
@@ -848,7 +878,7 @@ struct Ctx {
   const msi_search_params *prm;
   Dev dev;
   std::vector<std::string> words;
-  std::map<std::string, uint32_t> word_ids;
+  std::unordered_map<std::string, uint32_t> word_ids;   // (lookups only; the ids are the order of `words`)
   std::vector<Phrase> phrases;
   std::map<Phrase, uint32_t> phrase_ids;
   std::vector<Term> terms;
