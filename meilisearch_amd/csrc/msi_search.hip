@@ -208,6 +208,14 @@ using Set = std::shared_ptr<SetH>;
 //   other search waiting at that moment — as one kernel launch.  A search is then ~80 submissions instead of 211
 //   launches + 80 waits, and the launches are shared by all searches in flight;
 //   direct (MSI_SEARCH_VM=0, and the host-logic test double which has no kernels): one msi_bits call per operation.
+// the paths of one cost level as the kernels take them: path k = slots[off[k] .. off[k+1])
+struct PathSlots {
+  std::vector<uint32_t> off{0}, slots;
+  size_t size() const { return off.size() - 1; }
+  bool empty() const { return off.size() == 1; }
+  void close_path() { off.push_back((uint32_t)slots.size()); }
+};
+
 struct Dev {
   SetPool pool;
 #ifndef MSI_SEARCH_DIRECT_ONLY
@@ -461,31 +469,23 @@ struct Dev {
     return out;
   }
 #ifndef MSI_SEARCH_DIRECT_ONLY
-  uint32_t rec_paths(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe) {
+  uint32_t rec_paths(const PathSlots &paths, const Set &bucket, const Set &universe) {
     const uint32_t n = (uint32_t)paths.size();
     const uint32_t cb = counts_for(n);
-    uint32_t n_steps = 0;
-    for (auto &p : paths) n_steps += (uint32_t)p.size();
+    const uint32_t n_steps = (uint32_t)paths.slots.size();
     rd(universe->slot);
-    for (auto &p : paths)
-      for (auto &s_ : p) rd(s_->slot);
+    for (uint32_t sl : paths.slots) rd(sl);
     // a bucket that was handed out as "all zero" and never touched is written whole by the level: no clear at all
     const uint32_t fresh = pool.lazy_zero[bucket->slot] ? 1u : 0u;
     wr(bucket->slot);
     rec({VM_PATHS, n, bucket->slot, universe->slot, cb, n_steps | (fresh << 31)});
-    uint32_t o = 0;
-    list.words.push_back(0);
-    for (auto &p : paths) {
-      o += (uint32_t)p.size();
-      list.words.push_back(o);
-    }
-    for (auto &p : paths)
-      for (auto &s_ : p) list.words.push_back(s_->slot);
+    list.words.insert(list.words.end(), paths.off.begin(), paths.off.end());
+    list.words.insert(list.words.end(), paths.slots.begin(), paths.slots.end());
     return cb;
   }
 #endif
   // a whole cost level: path k claims universe & AND(its condition sets), in order; returns the cardinalities
-  std::vector<uint64_t> paths_claim(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe) {
+  std::vector<uint64_t> paths_claim(const PathSlots &paths, const Set &bucket, const Set &universe) {
     std::vector<uint64_t> counts(paths.size(), 0);
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
@@ -495,15 +495,10 @@ struct Dev {
       return counts;
     }
 #endif
-    std::vector<uint32_t> off{0}, steps;
-    for (auto &p : paths) {
-      for (auto &s : p) steps.push_back(s->slot);
-      off.push_back((uint32_t)steps.size());
-    }
     Clock ck_;
     ++g_stats.launches;
     ++g_stats.syncs;
-    ck(msi_bits_paths_claim(pool.p, (uint32_t)paths.size(), off.data(), steps.data(), bucket->slot, universe->slot,
+    ck(msi_bits_paths_claim(pool.p, (uint32_t)paths.size(), paths.off.data(), paths.slots.data(), bucket->slot, universe->slot,
                             counts.data()));
     g_stats.device_wait_ms += ck_.ms();
     return counts;
@@ -628,7 +623,7 @@ struct Dev {
   // `pending_levels`: (count base, paths) of the levels recorded ahead — the CALLER's (a rule evaluation's) state: the
   // bucket sort's tasks interleave between an enqueue and its collect
   using PendingLevels = std::vector<std::pair<uint32_t, uint32_t>>;
-  bool paths_enqueue(const std::vector<std::vector<Set>> &paths, const Set &bucket, const Set &universe, uint32_t region,
+  bool paths_enqueue(const PathSlots &paths, const Set &bucket, const Set &universe, uint32_t region,
                      PendingLevels &pending_levels) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
@@ -637,12 +632,7 @@ struct Dev {
       return true;
     }
 #endif
-    std::vector<uint32_t> off{0}, steps;
-    for (auto &p : paths) {
-      for (auto &s : p) steps.push_back(s->slot);
-      off.push_back((uint32_t)steps.size());
-    }
-    const int32_t st = msi_bits_paths_enqueue(pool.p, (uint32_t)paths.size(), off.data(), steps.data(), bucket->slot,
+    const int32_t st = msi_bits_paths_enqueue(pool.p, (uint32_t)paths.size(), paths.off.data(), paths.slots.data(), bucket->slot,
                                               universe->slot, region);
     if (st == MSI_E_UNSUPPORTED) return false;
     ck(st);
@@ -778,9 +768,89 @@ struct Dev {
 // ---- terms and subsets (query_term/mod.rs, ntypo_subset.rs) -------------------------------------------
 using Phrase = std::vector<int32_t>;  // word ids, -1 = a stop word inside the phrase
 
+// A set of small ids (word / phrase interner ids, graph nodes) in ascending order: what the reference keeps in
+// BTreeSet<u32> / SmallBitmap.  The host logic copies and compares these tens of thousands of times per query (subsets
+// inside condition keys, path bookkeeping), so up to six ids live inside the object and copying one allocates nothing.
+struct IdSet {
+  static constexpr uint32_t INL = 6;
+  uint32_t n = 0, cap = INL;
+  uint32_t inl[INL];
+  uint32_t *heap = nullptr;
+  IdSet() {}
+  IdSet(std::initializer_list<uint32_t> l) { for (uint32_t x : l) insert(x); }
+  IdSet(const IdSet &o) { assign(o); }
+  IdSet(IdSet &&o) noexcept { steal(o); }
+  IdSet &operator=(const IdSet &o) {
+    if (this != &o) { n = 0; assign(o); }
+    return *this;
+  }
+  IdSet &operator=(IdSet &&o) noexcept {
+    if (this != &o) { delete[] heap; heap = nullptr; cap = INL; steal(o); }
+    return *this;
+  }
+  ~IdSet() { delete[] heap; }
+  const uint32_t *data() const { return heap ? heap : inl; }
+  uint32_t *data() { return heap ? heap : inl; }
+  const uint32_t *begin() const { return data(); }
+  const uint32_t *end() const { return data() + n; }
+  bool empty() const { return n == 0; }
+  size_t size() const { return n; }
+  void clear() { n = 0; }
+  size_t count(uint32_t x) const { return std::binary_search(begin(), end(), x) ? 1 : 0; }
+  bool insert(uint32_t x) {
+    uint32_t *d = data();
+    uint32_t *at = std::lower_bound(d, d + n, x);
+    if (at != d + n && *at == x) return false;
+    const size_t i = at - d;
+    if (n == cap) { grow(cap * 2); d = data(); }
+    memmove(d + i + 1, d + i, (n - i) * sizeof(uint32_t));
+    d[i] = x;
+    ++n;
+    return true;
+  }
+  template <class It> void insert(It a, It b) { for (; a != b; ++a) insert((uint32_t)*a); }
+  void erase(uint32_t x) {
+    uint32_t *d = data();
+    uint32_t *at = std::lower_bound(d, d + n, x);
+    if (at == d + n || *at != x) return;
+    memmove(at, at + 1, (d + n - at - 1) * sizeof(uint32_t));
+    --n;
+  }
+  void swap(IdSet &o) { IdSet t(std::move(o)); o = std::move(*this); *this = std::move(t); }
+  int cmp(const IdSet &o) const {  // lexicographic, as std::set / BTreeSet compare
+    const uint32_t *a = data(), *b = o.data();
+    const uint32_t m = std::min(n, o.n);
+    for (uint32_t i = 0; i < m; ++i) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    return n == o.n ? 0 : (n < o.n ? -1 : 1);
+  }
+  bool operator==(const IdSet &o) const { return n == o.n && memcmp(data(), o.data(), n * sizeof(uint32_t)) == 0; }
+  bool operator!=(const IdSet &o) const { return !(*this == o); }
+  bool operator<(const IdSet &o) const { return cmp(o) < 0; }
+
+ private:
+  void grow(uint32_t want) {
+    uint32_t *h = new uint32_t[want];
+    memcpy(h, data(), n * sizeof(uint32_t));
+    delete[] heap;
+    heap = h;
+    cap = want;
+  }
+  void assign(const IdSet &o) {  // this->n == 0; keeps whatever storage this object already has
+    if (o.n > cap) { delete[] heap; heap = new uint32_t[o.n]; cap = o.n; }
+    memcpy(data(), o.data(), o.n * sizeof(uint32_t));
+    n = o.n;
+  }
+  void steal(IdSet &o) {  // this object owns no heap block
+    n = o.n;
+    if (o.heap) { heap = o.heap; cap = o.cap; o.heap = nullptr; o.cap = INL; }
+    else memcpy(inl, o.inl, o.n * sizeof(uint32_t));
+    o.n = 0;
+  }
+};
+
 struct NTypo {
   uint8_t kind = 1;  // 0 Nothing, 1 All, 2 Subset
-  std::set<uint32_t> words, phrases;
+  IdSet words, phrases;
   bool is_empty() const { return kind == 0 || (kind == 2 && words.empty() && phrases.empty()); }
   bool has_word(uint32_t w) const { return kind == 1 || (kind == 2 && words.count(w)); }
   bool has_phrase(uint32_t p) const { return kind == 1 || (kind == 2 && phrases.count(p)); }
@@ -788,7 +858,7 @@ struct NTypo {
     if (kind == 1) { *this = o; return; }
     if (kind == 0 || o.kind == 1) return;
     if (o.kind == 0) { *this = NTypo{0, {}, {}}; return; }
-    std::set<uint32_t> w, p;
+    IdSet w, p;
     for (uint32_t x : words) if (o.words.count(x)) w.insert(x);
     for (uint32_t x : phrases) if (o.phrases.count(x)) p.insert(x);
     words.swap(w);
@@ -799,9 +869,8 @@ struct NTypo {
   int cmp(const NTypo &o) const {
     if (kind != o.kind) return kind < o.kind ? -1 : 1;
     if (kind != 2) return 0;
-    if (words != o.words) return words < o.words ? -1 : 1;
-    if (phrases != o.phrases) return phrases < o.phrases ? -1 : 1;
-    return 0;
+    if (int c = words.cmp(o.words)) return c;
+    return phrases.cmp(o.phrases);
   }
   bool operator<(const NTypo &o) const { return cmp(o) < 0; }
   bool operator==(const NTypo &o) const { return cmp(o) == 0; }
@@ -879,7 +948,7 @@ struct Condition {
 struct GNode {
   int kind = 0;  // 0 start, 1 end, 2 term, 3 deleted
   Located term;
-  std::set<uint32_t> preds, succs;
+  IdSet preds, succs;
 };
 struct Graph {
   std::vector<GNode> nodes;
@@ -1314,9 +1383,9 @@ struct Ctx {
         if (ss.two.has_word(w)) out.insert({w, false});
     return out;
   }
-  std::set<uint32_t> all_phrases(const Subset &ss) {
+  IdSet all_phrases(const Subset &ss) {
     const Term &t = terms[ss.term];
-    std::set<uint32_t> out;
+    IdSet out;
     if (t.phrase >= 0) out.insert((uint32_t)t.phrase);  // regardless of the zero-typo subset, as the reference
     for (uint32_t p : t.synonyms) out.insert(p);
     if (ss.one.kind != 0 && t.split_words >= 0 && ss.one.has_phrase((uint32_t)t.split_words))
@@ -1464,7 +1533,7 @@ void build_initial_edges(Graph &g) {
     if (n.kind == 2) end_prev = (int)n.term.id_hi;
     else if (n.kind == 0) end_prev = -1;
     else continue;
-    std::set<uint32_t> succ;
+    IdSet succ;
     int mn = 1 << 30;
     for (uint32_t j = 0; j < g.nodes.size(); ++j) {
       const GNode &m = g.nodes[j];
@@ -1488,7 +1557,7 @@ void build_initial_edges(Graph &g) {
 
 void remove_nodes_keep_edges(Graph &g, const std::vector<uint32_t> &ids) {
   for (uint32_t i : ids) {
-    const std::set<uint32_t> pr = g.nodes[i].preds, su = g.nodes[i].succs;
+    const IdSet pr = g.nodes[i].preds, su = g.nodes[i].succs;
     for (uint32_t p : pr) {
       g.nodes[p].succs.erase(i);
       g.nodes[p].succs.insert(su.begin(), su.end());
@@ -1503,7 +1572,7 @@ void remove_nodes_keep_edges(Graph &g, const std::vector<uint32_t> &ids) {
 }
 
 // removal_order_for_terms_matching_strategy_last :346-406 — groups of nodes, first removed first
-std::vector<std::set<uint32_t>> removal_order_last(Ctx &c, const Graph &g) {
+std::vector<IdSet> removal_order_last(Ctx &c, const Graph &g) {
   uint32_t first = 255, last = 0;
   for (const GNode &n : g.nodes)
     if (n.kind == 2) {
@@ -1511,7 +1580,7 @@ std::vector<std::set<uint32_t>> removal_order_last(Ctx &c, const Graph &g) {
       first = std::min(first, n.term.id_lo);
     }
   if (first >= last) return {};
-  std::map<uint32_t, std::set<uint32_t>> groups;
+  std::map<uint32_t, IdSet> groups;
   bool mandatory = false;
   for (uint32_t i = 0; i < g.nodes.size(); ++i) {
     const GNode &n = g.nodes[i];
@@ -1522,7 +1591,7 @@ std::vector<std::set<uint32_t>> removal_order_last(Ctx &c, const Graph &g) {
     }
     groups[1 + last - n.term.id_lo].insert(i);  // max over the term ids of (1 + last - id)
   }
-  std::vector<std::set<uint32_t>> res;
+  std::vector<IdSet> res;
   for (auto &kv : groups) res.push_back(kv.second);
   if (!mandatory && !res.empty()) res.pop_back();
   return res;
@@ -1609,7 +1678,7 @@ Graph build_from_paths(const std::vector<PathSubsets> &paths) {
 
 // compute_query_graph_docids :133-185
 Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe) {
-  std::set<uint32_t> resolved;
+  IdSet resolved;
   std::map<uint32_t, Set> docs;
   std::vector<uint32_t> queue{Graph::ROOT};
   size_t guard = 0;
@@ -1649,6 +1718,7 @@ uint32_t cost_from_distance(uint32_t d) {  // position/mod.rs:127-143
 
 std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const Located *src, const Located &dst) {
   std::vector<std::pair<uint32_t, Condition>> out;
+  out.reserve(8);
   const uint32_t n = dst.n_ids();
   auto cond = [&](int k) {
     Condition x;
@@ -1669,7 +1739,7 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
         if (k != 1) x.term.subset.one = NT_NONE;
         if (k != 2) x.term.subset.two = NT_NONE;
         x.x = k;
-        out.push_back({k + base, x});
+        out.emplace_back(k + base, std::move(x));
       }
       break;
     }
@@ -1684,7 +1754,7 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
         x.left = *src;
         x.has_left = true;
         x.x = cost + 1;
-        out.push_back({cost, x});
+        out.emplace_back(cost, std::move(x));
       }
       out.push_back({MAX_DISTANCE - 1 + ng, cond(C_TERM)});
       break;
@@ -1712,11 +1782,11 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
         Condition x = cond(C_FID);
         x.x = f;
         x.has_fid = true;
-        out.push_back({(uint32_t)weight * n, x});
+        out.emplace_back((uint32_t)weight * n, std::move(x));
       }
       if (c.prm->max_weight >= 0 && cur_max < (uint32_t)c.prm->max_weight) {
         Condition x = cond(C_FID);
-        out.push_back({(uint32_t)c.prm->max_weight * n, x});
+        out.emplace_back((uint32_t)c.prm->max_weight * n, std::move(x));
       }
       break;
     }
@@ -1745,7 +1815,7 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
       for (auto &kv : by_cost) {
         Condition x = cond(C_POSITION);
         x.positions = kv.second;
-        out.push_back({kv.first, x});
+        out.emplace_back(kv.first, std::move(x));
       }
       if (!by_cost.count(n * 10)) out.push_back({n * 10, cond(C_POSITION)});
       break;
@@ -1868,16 +1938,15 @@ struct Edge {
   uint32_t cost;
   int32_t cond;  // -1: unconditional
   uint32_t dest;
-  std::set<uint32_t> skip;
+  IdSet skip;
 };
 
 struct GraphRule : Rule {
-  Graph g;
   std::vector<Condition> conds;
   std::vector<std::vector<Edge>> edges;
   std::vector<std::vector<uint64_t>> costs;
   std::vector<char> costs_done;
-  std::map<int32_t, Resolved> cache;
+  std::vector<std::unique_ptr<Resolved>> cache;  // by condition id
   uint64_t next_max_cost = 1, cur_cost = 0;
 
   // per next_bucket state
@@ -1906,26 +1975,29 @@ struct GraphRule : Rule {
   GraphRule(int k, int t) : Rule(k, t) {}
   Rule *fresh() const override { return new GraphRule(kind, tms); }
 
-  void start(Ctx &c, const Set &, const Graph &graph) override {
-    g = graph;
+  void start(Ctx &c, const Set &, const Graph &g) override {
     conds.clear();
     cache.clear();
     ready.clear();
     next_max_cost = 1;
     cur_cost = 0;
-    std::map<uint32_t, std::pair<uint32_t, std::set<uint32_t>>> skip_cost;
+    std::map<uint32_t, std::pair<uint32_t, IdSet>> skip_cost;
     if (tms >= 0) {
       const uint32_t wp = words_in_phrases_count(c, g);
       next_max_cost += wp > 0 ? wp - 1 : 0;
       if (tms == MSI_TERMS_LAST) {
-        std::set<uint32_t> forbidden;
+        IdSet forbidden;
         for (auto &ns : removal_order_last(c, g)) {
           for (uint32_t n : ns) skip_cost[n] = {1, forbidden};
           forbidden.insert(ns.begin(), ns.end());
         }
       }
     }
-    std::map<Condition, int32_t> cond_id;
+    // The reference interns conditions by value (DedupInterner).  The conditions of an edge are a function of its
+    // destination term and — for proximity between adjacent terms only — its source term, and one build_edges call never
+    // yields the same condition twice, so interning per (destination node, adjacent source node) hands out the same
+    // ids without comparing condition values (a graph holds a located term once).
+    std::map<std::pair<uint32_t, int32_t>, std::vector<std::pair<uint32_t, int32_t>>> interned;
     edges.assign(g.nodes.size(), {});
     for (uint32_t i = 0; i < g.nodes.size(); ++i) {
       const GNode &n = g.nodes[i];
@@ -1942,14 +2014,18 @@ struct GraphRule : Rule {
         }
         auto sk = skip_cost.find(d);
         if (sk != skip_cost.end()) push(Edge{sk->second.first * dn.term.n_ids(), -1, d, sk->second.second});
-        for (auto &ce : build_edges(c, kind, n.kind == 2 ? &n.term : nullptr, dn.term)) {
-          auto it = cond_id.find(ce.second);
-          if (it == cond_id.end()) {
-            conds.push_back(ce.second);
-            it = cond_id.emplace(ce.second, (int32_t)conds.size() - 1).first;
+        const Located *src = n.kind == 2 ? &n.term : nullptr;
+        const bool by_source = kind == R_PROXIMITY && src && src->pos_hi + 1 == dn.term.pos_lo;
+        auto memo = interned.find({d, by_source ? (int32_t)i : -1});
+        if (memo == interned.end()) {
+          std::vector<std::pair<uint32_t, int32_t>> ids;
+          for (auto &ce : build_edges(c, kind, src, dn.term)) {
+            conds.push_back(std::move(ce.second));
+            ids.push_back({ce.first, (int32_t)conds.size() - 1});
           }
-          push(Edge{ce.first, it->second, d, {}});
+          memo = interned.emplace(std::make_pair(d, by_source ? (int32_t)i : -1), std::move(ids)).first;
         }
+        for (auto &ce : memo->second) push(Edge{ce.first, ce.second, d, {}});
       }
     }
     costs.assign(g.nodes.size(), {});
@@ -1965,10 +2041,12 @@ struct GraphRule : Rule {
       costs[i] = {0};
       return costs[i];
     }
-    std::set<uint64_t> out;
+    std::vector<uint64_t> out;
     for (const Edge &e : edges[i])
-      for (uint64_t cc : costs_to_end(e.dest)) out.insert(e.cost + cc);
-    costs[i].assign(out.begin(), out.end());
+      for (uint64_t cc : costs_to_end(e.dest)) out.push_back(e.cost + cc);
+    std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+    costs[i] = std::move(out);
     return costs[i];
   }
 
@@ -2008,14 +2086,14 @@ struct GraphRule : Rule {
       good = std::move(r.good);
       if (bucket_count) c.dev.sub_(uni, bucket);
     } else {
-      std::set<uint32_t> visited, to_skip;
+      IdSet visited, to_skip;
       if (!fused_level(cost)) visit(Graph::ROOT, cost, visited, to_skip);
     }
     std::vector<PathSubsets> paths;
     for (auto &p : good) {
       PathSubsets ps;
       for (int32_t ci : p) {
-        const Resolved &r = cache[ci];
+        const Resolved &r = *cache[ci];
         ps.push_back({{r.has_start, r.start}, r.end});
       }
       paths.push_back(std::move(ps));
@@ -2032,8 +2110,15 @@ struct GraphRule : Rule {
 
   // All the paths of this cost, in the order the search would visit them, WITHOUT evaluating anything
   // (cheapest_paths.rs:147-310 minus the dead-end pruning).  False when there are too many for one launch.
-  bool enumerate(uint32_t node, uint64_t remaining, std::set<uint32_t> &visited, const std::set<uint32_t> &to_skip,
-                 std::vector<int32_t> &cur, std::vector<std::vector<int32_t>> &out, size_t &steps) {
+  struct PathList {  // path k = conds[off[k] .. off[k+1])
+    std::vector<uint32_t> off{0};
+    std::vector<int32_t> conds;
+    size_t size() const { return off.size() - 1; }
+    bool empty() const { return off.size() == 1; }
+    std::vector<int32_t> path(size_t k) const { return {conds.begin() + off[k], conds.begin() + off[k + 1]}; }
+  };
+  bool enumerate(uint32_t node, uint64_t remaining, IdSet &visited, const IdSet &to_skip,
+                 std::vector<int32_t> &cur, PathList &out, size_t &steps) {
     for (const Edge &e : edges[node]) {
       if (remaining < e.cost) continue;
       const uint64_t rem = remaining - e.cost;
@@ -2043,11 +2128,12 @@ struct GraphRule : Rule {
         if (e.dest == Graph::END) {
           steps += cur.size();
           if (out.size() >= MSI_BITS_MAX_PATHS || steps > MSI_BITS_MAX_STEPS) return false;
-          out.push_back(cur);
+          out.conds.insert(out.conds.end(), cur.begin(), cur.end());
+          out.off.push_back((uint32_t)out.conds.size());
         } else {
-          std::set<uint32_t> ts = to_skip;
-          ts.insert(e.skip.begin(), e.skip.end());
-          if (!enumerate(e.dest, rem, visited, ts, cur, out, steps)) return false;
+          IdSet ts;
+          if (!e.skip.empty()) { ts = to_skip; ts.insert(e.skip.begin(), e.skip.end()); }
+          if (!enumerate(e.dest, rem, visited, e.skip.empty() ? to_skip : ts, cur, out, steps)) return false;
         }
         continue;
       }
@@ -2057,9 +2143,9 @@ struct GraphRule : Rule {
       if (blocked) continue;
       cur.push_back(e.cond);
       visited.insert(e.dest);
-      std::set<uint32_t> ts = to_skip;
-      ts.insert(e.skip.begin(), e.skip.end());
-      const bool ok = enumerate(e.dest, rem, visited, ts, cur, out, steps);
+      IdSet ts;
+      if (!e.skip.empty()) { ts = to_skip; ts.insert(e.skip.begin(), e.skip.end()); }
+      const bool ok = enumerate(e.dest, rem, visited, e.skip.empty() ? to_skip : ts, cur, out, steps);
       visited.erase(e.dest);
       cur.pop_back();
       if (!ok) return false;
@@ -2085,23 +2171,19 @@ struct GraphRule : Rule {
     if (cx->prm->distinct_values) return;
     struct Plan {
       uint64_t cost;
-      std::vector<std::vector<int32_t>> all;
-      std::vector<std::vector<Set>> sets;
+      PathList all;
+      PathSlots sets;
     };
     std::vector<Plan> plan;
     for (; it != end && (int)plan.size() < per_wait; ++it) {
       Plan pl;
       pl.cost = *it;
       std::vector<int32_t> cur;
-      std::set<uint32_t> visited, to_skip;
+      IdSet visited, to_skip;
       size_t steps = 0;
       if (!enumerate(Graph::ROOT, pl.cost, visited, to_skip, cur, pl.all, steps)) break;
       if (pl.all.size() > MSI_BITS_REGION_PATHS) break;
-      for (auto &p : pl.all) {  // every condition resolved BEFORE the first level is enqueued
-        std::vector<Set> ps;
-        for (int32_t ci : p) ps.push_back(resolved(ci).docs);
-        pl.sets.push_back(std::move(ps));
-      }
+      slots_of(pl.all, pl.sets);  // every condition resolved BEFORE the first level is enqueued
       plan.push_back(std::move(pl));
     }
     if (plan.size() < 2) return;
@@ -2124,7 +2206,7 @@ struct GraphRule : Rule {
       for (size_t k = 0; k < plan[j].all.size(); ++k) {
         const uint64_t n = counts[j * MSI_BITS_REGION_PATHS + k];
         if (!n) continue;
-        r.good.push_back(plan[j].all[k]);
+        r.good.push_back(plan[j].all.path(k));
         ++g_stats.paths;
         r.count += n;
       }
@@ -2140,22 +2222,18 @@ struct GraphRule : Rule {
     // that the tests can hold both against the oracle
     const char *knob = getenv("MSI_SEARCH_FUSED_LEVELS");
     if (knob && knob[0] == '0') return false;
-    std::vector<std::vector<int32_t>> all;
+    PathList all;
     std::vector<int32_t> cur;
-    std::set<uint32_t> visited, to_skip;
+    IdSet visited, to_skip;
     size_t steps = 0;
     if (!enumerate(Graph::ROOT, cost, visited, to_skip, cur, all, steps)) return false;
     if (all.empty()) return true;
-    std::vector<std::vector<Set>> sets;
-    for (auto &p : all) {
-      std::vector<Set> ps;
-      for (int32_t ci : p) ps.push_back(resolved(ci).docs);
-      sets.push_back(std::move(ps));
-    }
+    PathSlots sets;
+    slots_of(all, sets);
     const std::vector<uint64_t> counts = cx->dev.paths_claim(sets, bucket, uni);
     for (size_t k = 0; k < all.size(); ++k) {
       if (!counts[k]) continue;
-      good.push_back(all[k]);
+      good.push_back(all.path(k));
       ++g_stats.paths;
       bucket_count += counts[k];
       uni_count -= counts[k];
@@ -2163,17 +2241,23 @@ struct GraphRule : Rule {
     return true;
   }
 
+  // the condition sets of every path, as slots (the sets themselves stay alive in `cache` until end())
+  void slots_of(const PathList &all, PathSlots &out) {
+    out.off = all.off;
+    out.slots.resize(all.conds.size());
+    for (size_t i = 0; i < all.conds.size(); ++i) out.slots[i] = resolved(all.conds[i]).docs->slot;
+  }
   const Resolved &resolved(int32_t ci) {
-    auto it = cache.find(ci);
-    if (it == cache.end()) it = cache.emplace(ci, resolve_condition(*cx, conds[ci])).first;
-    return it->second;
+    if (cache.size() < conds.size()) cache.resize(conds.size());
+    if (!cache[ci]) cache[ci].reset(new Resolved(resolve_condition(*cx, conds[ci])));
+    return *cache[ci];
   }
 
   // cheapest_paths.rs:147-310: edges in insertion order; a conditional edge cannot enter a node that
   // must be skipped, nor be taken once a node named by its skip list was traversed.  All the conditional
   // edges that leave a node are intersected with the path prefix in ONE launch (and one completion wait);
   // a sibling evaluated before an earlier sibling claimed documents is re-intersected when its turn comes.
-  void visit(uint32_t node, uint64_t remaining, std::set<uint32_t> &visited, const std::set<uint32_t> &to_skip) {
+  void visit(uint32_t node, uint64_t remaining, IdSet &visited, const IdSet &to_skip) {
     std::vector<const Edge *> cand;
     for (const Edge &e : edges[node]) {
       if (remaining < e.cost) continue;
@@ -2203,9 +2287,9 @@ struct GraphRule : Rule {
         if (e.dest == Graph::END) {
           emit();
         } else {
-          std::set<uint32_t> ts = to_skip;
-          ts.insert(e.skip.begin(), e.skip.end());
-          visit(e.dest, rem, visited, ts);
+          IdSet ts;
+          if (!e.skip.empty()) { ts = to_skip; ts.insert(e.skip.begin(), e.skip.end()); }
+          visit(e.dest, rem, visited, e.skip.empty() ? to_skip : ts);
         }
         continue;
       }
@@ -2218,9 +2302,9 @@ struct GraphRule : Rule {
       if (!cnt) continue;
       stack.push_back({e.cond, d, false, cnt});
       visited.insert(e.dest);
-      std::set<uint32_t> ts = to_skip;
-      ts.insert(e.skip.begin(), e.skip.end());
-      visit(e.dest, rem, visited, ts);
+      IdSet ts;
+      if (!e.skip.empty()) { ts = to_skip; ts.insert(e.skip.begin(), e.skip.end()); }
+      visit(e.dest, rem, visited, e.skip.empty() ? to_skip : ts);
       visited.erase(e.dest);
       stack.pop_back();
     }
