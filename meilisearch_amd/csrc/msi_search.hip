@@ -960,6 +960,44 @@ struct Score {
   uint32_t kind, a, b;
 };
 
+struct Resolved {
+  Set docs;
+  bool has_start = false;
+  Located start, end;
+};
+// The conditions of the edges into one located term (from one adjacent term, for proximity) and what they resolved to.
+// A query meets the same (rule, source, destination) in bucket after bucket: built once per query (Ctx::edge_memo); a rule
+// evaluation holds the entries it uses, so dropping the memo under memory pressure never pulls them from under it.
+struct EdgeSet {
+  std::vector<std::pair<uint32_t, Condition>> conds;   // (cost, condition), build_edges' order
+  std::vector<std::unique_ptr<Resolved>> resolved;     // on demand
+};
+struct EdgeKeyRef {   // a key that only points at its terms: lookups copy nothing
+  int rule;
+  const Located *dst;
+  bool adjacent;   // proximity between adjacent terms: the only case in which the source term shapes the conditions
+  const Located *src;
+};
+struct EdgeKey {
+  int rule;
+  Located dst;
+  bool adjacent;
+  Located src;
+  EdgeKeyRef ref() const { return {rule, &dst, adjacent, &src}; }
+};
+struct EdgeKeyLess {
+  using is_transparent = void;
+  static bool lt(const EdgeKeyRef &a, const EdgeKeyRef &b) {
+    if (a.rule != b.rule) return a.rule < b.rule;
+    if (int c = a.dst->cmp(*b.dst)) return c < 0;
+    if (a.adjacent != b.adjacent) return a.adjacent < b.adjacent;
+    return a.adjacent && a.src->cmp(*b.src) < 0;
+  }
+  bool operator()(const EdgeKey &a, const EdgeKey &b) const { return lt(a.ref(), b.ref()); }
+  bool operator()(const EdgeKey &a, const EdgeKeyRef &b) const { return lt(a.ref(), b); }
+  bool operator()(const EdgeKeyRef &a, const EdgeKey &b) const { return lt(a, b.ref()); }
+};
+
 // ---- the search context ---------------------------------------------------------------------
 struct Ctx {
   msi_dict *dict;
@@ -976,6 +1014,7 @@ struct Ctx {
   // the rules of a search resolve the same term subsets again and again (every bucket of a rule restarts
   // the rules below it).
   std::map<Subset, Set> subset_cache;
+  std::map<EdgeKey, std::shared_ptr<EdgeSet>, EdgeKeyLess> edge_memo;
   std::map<std::tuple<Subset, int, std::vector<uint32_t>>, Set> within_cache;
   std::map<std::string, std::vector<Set>> exact_attr_cache;  // {ExactMatch, MatchesStart, position candidates}
   std::map<std::tuple<Subset, Subset, uint32_t, uint32_t>, Set> prox_cache;
@@ -987,6 +1026,7 @@ struct Ctx {
     word_cache.clear();
     exact_attr_cache.clear();
     phrase_cache.clear();
+    edge_memo.clear();
     empty_.reset();
   }
   void relieve() {  // keep the pool from running dry on long queries: drop what can be recomputed
@@ -1001,6 +1041,7 @@ struct Ctx {
     prox_cache.clear();
     word_cache.clear();
     exact_attr_cache.clear();
+    edge_memo.clear();
   }
 
   Ctx(msi_dict *d, msi_bits *pool, const msi_index_vtable *i, const msi_search_params *p)
@@ -1828,12 +1869,6 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
   return out;
 }
 
-struct Resolved {
-  Set docs;
-  bool has_start = false;
-  Located start, end;
-};
-
 // proximity/compute_docids.rs:15-212 (no prefix DB)
 Set proximity_full(Ctx &c, const Condition &cd) {
   const uint32_t rn = cd.term.n_ids();
@@ -1942,11 +1977,11 @@ struct Edge {
 };
 
 struct GraphRule : Rule {
-  std::vector<Condition> conds;
+  std::vector<std::pair<EdgeSet *, uint32_t>> conds;   // condition id -> its entry in an edge set of the query's memo
+  std::vector<std::shared_ptr<EdgeSet>> held;          // ... which this evaluation keeps alive
   std::vector<std::vector<Edge>> edges;
   std::vector<std::vector<uint64_t>> costs;
   std::vector<char> costs_done;
-  std::vector<std::unique_ptr<Resolved>> cache;  // by condition id
   uint64_t next_max_cost = 1, cur_cost = 0;
 
   // per next_bucket state
@@ -1977,7 +2012,7 @@ struct GraphRule : Rule {
 
   void start(Ctx &c, const Set &, const Graph &g) override {
     conds.clear();
-    cache.clear();
+    held.clear();
     ready.clear();
     next_max_cost = 1;
     cur_cost = 0;
@@ -1993,11 +2028,11 @@ struct GraphRule : Rule {
         }
       }
     }
-    // The reference interns conditions by value (DedupInterner).  The conditions of an edge are a function of its
-    // destination term and — for proximity between adjacent terms only — its source term, and one build_edges call never
-    // yields the same condition twice, so interning per (destination node, adjacent source node) hands out the same
-    // ids without comparing condition values (a graph holds a located term once).
-    std::map<std::pair<uint32_t, int32_t>, std::vector<std::pair<uint32_t, int32_t>>> interned;
+    // The reference interns conditions by value (DedupInterner).  The conditions of an edge are a function of the rule,
+    // its destination term and — for proximity between adjacent terms only — its source term, and one build_edges call
+    // never yields the same condition twice: interning per edge set of the query's memo (keyed by exactly those values)
+    // hands out the same ids without comparing condition values.
+    std::map<EdgeSet *, std::vector<std::pair<uint32_t, int32_t>>> interned;
     edges.assign(g.nodes.size(), {});
     for (uint32_t i = 0; i < g.nodes.size(); ++i) {
       const GNode &n = g.nodes[i];
@@ -2016,14 +2051,23 @@ struct GraphRule : Rule {
         if (sk != skip_cost.end()) push(Edge{sk->second.first * dn.term.n_ids(), -1, d, sk->second.second});
         const Located *src = n.kind == 2 ? &n.term : nullptr;
         const bool by_source = kind == R_PROXIMITY && src && src->pos_hi + 1 == dn.term.pos_lo;
-        auto memo = interned.find({d, by_source ? (int32_t)i : -1});
+        auto known = c.edge_memo.find(EdgeKeyRef{kind, &dn.term, by_source, src});
+        if (known == c.edge_memo.end()) {
+          auto fresh_set = std::make_shared<EdgeSet>();
+          fresh_set->conds = build_edges(c, kind, src, dn.term);
+          fresh_set->resolved.resize(fresh_set->conds.size());
+          known = c.edge_memo.emplace(EdgeKey{kind, dn.term, by_source, by_source ? *src : Located()}, std::move(fresh_set)).first;
+        }
+        EdgeSet *es = known->second.get();
+        auto memo = interned.find(es);
         if (memo == interned.end()) {
+          held.push_back(known->second);
           std::vector<std::pair<uint32_t, int32_t>> ids;
-          for (auto &ce : build_edges(c, kind, src, dn.term)) {
-            conds.push_back(std::move(ce.second));
-            ids.push_back({ce.first, (int32_t)conds.size() - 1});
+          for (uint32_t k = 0; k < es->conds.size(); ++k) {
+            conds.push_back({es, k});
+            ids.push_back({es->conds[k].first, (int32_t)conds.size() - 1});
           }
-          memo = interned.emplace(std::make_pair(d, by_source ? (int32_t)i : -1), std::move(ids)).first;
+          memo = interned.emplace(es, std::move(ids)).first;
         }
         for (auto &ce : memo->second) push(Edge{ce.first, ce.second, d, {}});
       }
@@ -2093,7 +2137,7 @@ struct GraphRule : Rule {
     for (auto &p : good) {
       PathSubsets ps;
       for (int32_t ci : p) {
-        const Resolved &r = *cache[ci];
+        const Resolved &r = resolved(ci);
         ps.push_back({{r.has_start, r.start}, r.end});
       }
       paths.push_back(std::move(ps));
@@ -2248,9 +2292,10 @@ struct GraphRule : Rule {
     for (size_t i = 0; i < all.conds.size(); ++i) out.slots[i] = resolved(all.conds[i]).docs->slot;
   }
   const Resolved &resolved(int32_t ci) {
-    if (cache.size() < conds.size()) cache.resize(conds.size());
-    if (!cache[ci]) cache[ci].reset(new Resolved(resolve_condition(*cx, conds[ci])));
-    return *cache[ci];
+    EdgeSet *es = conds[ci].first;
+    const uint32_t k = conds[ci].second;
+    if (!es->resolved[k]) es->resolved[k].reset(new Resolved(resolve_condition(*cx, es->conds[k].second)));
+    return *es->resolved[k];
   }
 
   // cheapest_paths.rs:147-310: edges in insertion order; a conditional edge cannot enter a node that
@@ -2346,8 +2391,8 @@ struct GraphRule : Rule {
   }
 
   void end() override {
-    cache.clear();
     conds.clear();
+    held.clear();
     edges.clear();
   }
 };
