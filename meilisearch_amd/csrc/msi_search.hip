@@ -1951,7 +1951,14 @@ Resolved resolve_condition(Ctx &c, const Condition &cd) {
 
 // ---- rules ---------------------------------------------------------------------------------------
 struct Bucket {
-  Graph graph;
+  // The query graph of the bucket, for the rule below — wanted only when that rule actually ranks the bucket (not for the
+  // last rule's buckets, empty ones, or those before / after the page), so it is assembled on demand: from the paths
+  // that found documents (a graph rule), or it is the producing rule's own graph, which outlives the bucket.
+  Graph owned;
+  const Graph *same_as = nullptr;
+  struct Rule *maker = nullptr;                 // the graph rule that knows what `good` names
+  std::vector<std::vector<int32_t>> good;       // the paths (condition ids) that found documents
+  inline const Graph &graph();
   Set docs;
   uint64_t count = 0;
   Score score{0, 0, 0};
@@ -1967,7 +1974,16 @@ struct Rule {
   virtual bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) = 0;
   virtual void end() = 0;
   virtual Rule *fresh() const = 0;   // another instance of the same rule (the bucket sort's tasks each rank with their own)
+  virtual Graph graph_of(const std::vector<std::vector<int32_t>> &) { return Graph(); }   // Bucket::graph
 };
+
+const Graph &Bucket::graph() {
+  if (maker) {
+    owned = maker->graph_of(good);
+    maker = nullptr;
+  }
+  return same_as ? *same_as : owned;
+}
 
 struct Edge {
   uint32_t cost;
@@ -2133,16 +2149,8 @@ struct GraphRule : Rule {
       IdSet visited, to_skip;
       if (!fused_level(cost)) visit(Graph::ROOT, cost, visited, to_skip);
     }
-    std::vector<PathSubsets> paths;
-    for (auto &p : good) {
-      PathSubsets ps;
-      for (int32_t ci : p) {
-        const Resolved &r = resolved(ci);
-        ps.push_back({{r.has_start, r.start}, r.end});
-      }
-      paths.push_back(std::move(ps));
-    }
-    out.graph = build_from_paths(paths);
+    out.maker = this;
+    out.good = std::move(good);
     out.docs = bucket;
     out.count = bucket_count;
     out.universe_reduced = true;
@@ -2150,6 +2158,21 @@ struct GraphRule : Rule {
     bucket.reset();
     stack.clear();
     return true;
+  }
+
+  Graph graph_of(const std::vector<std::vector<int32_t>> &found) override {
+    std::vector<PathSubsets> paths;
+    paths.reserve(found.size());
+    for (auto &p : found) {
+      PathSubsets ps;
+      ps.reserve(p.size());
+      for (int32_t ci : p) {
+        const Resolved &r = resolved(ci);
+        ps.push_back({{r.has_start, r.start}, r.end});
+      }
+      paths.push_back(std::move(ps));
+    }
+    return build_from_paths(paths);
   }
 
   // All the paths of this cost, in the order the search would visit them, WITHOUT evaluating anything
@@ -2512,7 +2535,7 @@ struct ExactAttributeRule : Rule {
   }
 
   bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) override {
-    out.graph = g;
+    out.same_as = &g;
     if (state == 0) {
       out.docs = c.dev.clone(universe);
       out.count = universe_count;
@@ -2558,7 +2581,7 @@ struct OrderByRule : Rule {
     out.docs = c.dev.order_next(keys, universe, &key, &n);
     out.count = n;
     out.score = {MSI_SCORE_SORT, idx, key};
-    out.graph = g;
+    out.same_as = &g;
     out.universe_reduced = true;
     return true;
   }
@@ -2581,7 +2604,7 @@ struct GeoSortRule : Rule {
     uint32_t first = 0xFFFFFFFFu;
     uint64_t n = 0;
     Set b = c.dev.geo_next(rule, c.prm->geo_max_bucket_size, c.prm->geo_distance_error_margin, universe, &first, &n);
-    out.graph = g;
+    out.same_as = &g;
     out.score = {MSI_SCORE_GEO_SORT, idx, first};
     if (first == 0xFFFFFFFFu) {
       out.docs = c.dev.clone(universe);
@@ -2949,11 +2972,11 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             if (coop && tasks.live < (size_t)max_tasks &&
                 (no_gate || c.dev.pool.free_.size() + c.dev.pool.clean_.size() >= 48 * (tasks.live + 2))) {
               // (the graph is moved into the task: the Bucket dies at the end of this iteration)
-              auto gp = std::make_shared<Graph>(std::move(b.graph));
+              auto gp = std::make_shared<Graph>(b.graph());
               tasks.spawn([&rank, cur, docs = b.docs, cnt = b.count, off, sc, gp]() { rank(cur + 1, docs, cnt, off, sc, *gp); });
             } else
 #endif
-              rank(cur + 1, b.docs, b.count, off, sc, b.graph);
+              rank(cur + 1, b.docs, b.count, off, sc, b.graph());
           }
           off += b.count;
         }
@@ -3157,7 +3180,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     ++cur;
     unis[cur] = b.docs;
     uni_counts[cur] = b.count;
-    rules[cur]->start(c, b.docs, b.graph);
+    rules[cur]->start(c, b.docs, b.graph());
   }
   finish();
 }
