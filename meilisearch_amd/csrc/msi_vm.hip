@@ -407,6 +407,29 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         }
         if (fresh) whole(W(2));
         else partial(W(2));
+        // A path one of whose condition sets is empty in this chunk finds nothing here: it is neither loaded nor tested
+        // (one summary bit per step, read by the lane that owns the path; a ballot makes the verdicts wave-uniform).
+        u64 alive[(MSI_BITS_MAX_PATHS + 63) / 64];
+#pragma unroll
+        for (uint32_t g = 0; g < (MSI_BITS_MAX_PATHS + 63) / 64; ++g) alive[g] = ~0ull;
+        if (sum_on) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (uint32_t g = 0; g < (MSI_BITS_MAX_PATHS + 63) / 64; ++g) {
+            const uint32_t k = g * 64 + lane;
+            bool ok = false;
+            if (k < n_paths) {
+              ok = true;
+              for (uint32_t s = off[k]; s < off[k + 1]; ++s) {
+                const uint32_t sl = steps[s];
+                ok = ok && ((s_sum[wave][sl >> 6] >> (sl & 63)) & 1ull) != 0;
+              }
+            }
+            alive[g] = __ballot(ok);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        auto live = [&](uint32_t k) -> bool { return k < n_paths && (k >= MSI_BITS_MAX_PATHS || ((alive[k >> 6] >> (k & 63)) & 1ull)); };
         u64 any_b = 0;
         for (uint32_t p = tid; p < n_pairs; p += VT) {
           ulonglong2 u = uni[p];
@@ -416,11 +439,12 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
           }
           ulonglong2 b = fresh ? make_ulonglong2(0, 0) : bucket[p];
           for (uint32_t k0 = 0; k0 < n_paths && (u.x | u.y); k0 += 4) {
+            if (!(live(k0) || live(k0 + 1) || live(k0 + 2) || live(k0 + 3))) continue;
             ulonglong2 acc[4];
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
               acc[j] = make_ulonglong2(~0ull, ~0ull);
-              if (k0 + j < n_paths)
+              if (live(k0 + j))
                 for (uint32_t s = off[k0 + j]; s < off[k0 + j + 1]; ++s) {
                   const ulonglong2 c = S(steps[s])[p];
                   acc[j].x &= c.x; acc[j].y &= c.y;
@@ -428,7 +452,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
             }
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
-              if (k0 + j >= n_paths) continue;
+              if (!live(k0 + j)) continue;
               ulonglong2 m;
               m.x = u.x & acc[j].x; m.y = u.y & acc[j].y;
               if (m.x | m.y) {

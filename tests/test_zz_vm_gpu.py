@@ -116,3 +116,51 @@ def test_starved_tasks_are_rerun_sequentially_and_still_match_the_oracle(monkeyp
     import tests.test_search_gpu as G
     monkeypatch.setenv("MSI_SEARCH_TASKS_NO_GATE", "1")
     G.test_matches_oracle_on_random_corpora(1, 100)
+
+
+def test_documents_spread_over_many_chunks(monkeypatch):
+    """The command lists work chunk by chunk (65 536 documents each) and skip, per chunk, the sets and the paths whose
+    chunk summary says "empty here".  The reference's snapshot indexes hold a few dozen documents — one chunk — so here
+    every internal docid is multiplied by a stride that puts each document into a chunk of its own: the same searches
+    must return the same documents (times the stride), in the same order, with the same score details — also a second
+    time, on the warm posting cache."""
+    import meilisearch_amd as ma
+    import tests.toy_milli as T
+    from tests.toy_milli import query_terms
+    STRIDE = 70001
+    plain_cbo = T.cbo_bytes
+    checked = multi = 0
+    for key, cases in _by_index().items():
+        index = build_index(FIX["indexes"][key])
+        if index.n_docs < 2:
+            continue
+        h = Harness(index)
+        expected = [_search(h, c) for c in cases]
+        R = h.R
+        pool = ma.BitsPool(h.ctx, index.n_docs * STRIDE, 512)
+        dictionary = ma.GpuDictionary(h.ctx, [w.encode() for w in index.words])
+        dictionary.enable_posting_cache(8 << 20)
+        monkeypatch.setattr(T, "cbo_bytes", lambda s: plain_cbo({d * STRIDE for d in s}))
+        cb = R.IndexCallbacks(index)
+        universe = plain_cbo({d * STRIDE for d in range(index.n_docs)})
+
+        def spread(case):
+            hits, _ = R.keyword_search_ranked(
+                dictionary, pool, cb, query_terms(case["query"], stop_words=index.stop_words), index.criteria,
+                strategy=R.TERMS_ALL if case["tms"] == "all" else R.TERMS_LAST, offset=case["offset"], limit=case["limit"],
+                detailed=True, searchable_fids=index.searchable_fids,
+                searchable_weights=[index.weights[f] for f in index.searchable_fids], max_weight=index.max_weight,
+                authorize_typos=index.authorize_typos, min_one=index.min_one, min_two=index.min_two,
+                stop_after=case.get("stop_after"), universe_cbo=universe)
+            return [(d, [tuple(s) for s in sc]) for d, sc in hits]
+
+        for c, e in zip(cases, expected):   # (what the comparison stands on: the reference's own snapshot)
+            if c["ids"] is not None:
+                assert [d for d, _ in e] == c["ids"]
+        want = [[(d * STRIDE, sc) for d, sc in e] for e in expected]
+        assert [spread(c) for c in cases] == want
+        assert [spread(c) for c in cases] == want          # postings decoded out of the HBM cache this time
+        monkeypatch.setattr(T, "cbo_bytes", plain_cbo)
+        checked += len(cases)
+        multi += index.n_docs * STRIDE > 4 * 65536
+    assert checked >= 90 and multi >= 5
