@@ -2053,9 +2053,10 @@ struct GraphRule : Rule {
     for (uint32_t i = 0; i < g.nodes.size(); ++i) {
       const GNode &n = g.nodes[i];
       if (n.kind != 0 && n.kind != 2) continue;
-      std::set<std::tuple<uint32_t, uint32_t, int32_t>> seen;  // (dest, cost, cond): Edge equality, mod.rs:62-70
-      auto push = [&](Edge e) {
-        if (seen.insert({e.dest, e.cost, e.cond}).second) edges[i].push_back(std::move(e));
+      auto push = [&](Edge e) {  // (dest, cost, cond) is Edge equality, mod.rs:62-70; a node has a handful of edges
+        for (const Edge &x : edges[i])
+          if (x.dest == e.dest && x.cost == e.cost && x.cond == e.cond) return;
+        edges[i].push_back(std::move(e));
       };
       for (uint32_t d : n.succs) {
         const GNode &dn = g.nodes[d];
