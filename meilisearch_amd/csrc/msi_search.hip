@@ -2318,7 +2318,12 @@ struct GraphRule : Rule {
   const Resolved &resolved(int32_t ci) {
     EdgeSet *es = conds[ci].first;
     const uint32_t k = conds[ci].second;
-    if (!es->resolved[k]) es->resolved[k].reset(new Resolved(resolve_condition(*cx, es->conds[k].second)));
+    if (!es->resolved[k]) {
+      // resolving may park this task (a full staging ring runs the list first) and another task of the bucket sort may
+      // resolve the same condition meanwhile: the first result stays — references handed out are never invalidated
+      Resolved r = resolve_condition(*cx, es->conds[k].second);
+      if (!es->resolved[k]) es->resolved[k].reset(new Resolved(std::move(r)));
+    }
     return *es->resolved[k];
   }
 
