@@ -618,3 +618,24 @@ def test_reference_typo_tolerance_and_phrase_integration_tests(hostlib):
         hits, _ = h.search(q, tms=tms, limit=10)
         assert [d for d, _ in hits] == ids, (q, settings)
         h.close()
+
+
+# seeds of tools/fuzz_ranked_hostlogic.py (the corpus / settings / queries of seed + 1) that once disagreed with the oracle
+FUZZ_REGRESSIONS = {
+    # a rule ended before its buckets covered its universe (bucket_sort.rs `back!` drops what is left): the bucket sort's
+    # tree of tasks had handed out result places by cumulative cardinality and left holes
+    25606: "a rule that drops documents, first page", 33401: "the same below the third hit", 38598: "... and beyond the tenth",
+}
+
+
+def run_fuzz_seeds(seeds, *mode):
+    import subprocess, sys
+    for seed in seeds:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ranked_hostlogic.py"), str(seed), "0.01", *mode],
+                             cwd=ROOT, capture_output=True, text=True, timeout=600)
+        tail = out.stdout[-2000:] + out.stderr[-2000:]
+        assert out.returncode == 0 and "cases 6 bad 0" in out.stdout, tail   # (six searches per seed)
+
+
+def test_fuzz_regressions():
+    run_fuzz_seeds(FUZZ_REGRESSIONS)

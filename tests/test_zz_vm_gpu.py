@@ -164,3 +164,11 @@ def test_documents_spread_over_many_chunks(monkeypatch):
         checked += len(cases)
         multi += index.n_docs * STRIDE > 4 * 65536
     assert checked >= 90 and multi >= 5
+
+
+def test_fuzz_regressions_through_the_product():
+    """The searches that differential fuzzing once caught (tests/test_search_hostlogic_cpu.py::FUZZ_REGRESSIONS), through the
+    product's kernels: on the device — or, when this file runs in the CPU tier, on the emulated build."""
+    from meilisearch_amd import _lib
+    from tests.test_search_hostlogic_cpu import FUZZ_REGRESSIONS, run_fuzz_seeds
+    run_fuzz_seeds(FUZZ_REGRESSIONS, "--emulated-kernels" if type(_lib.lib()).__name__ == "EmulatedLib" else "--device")

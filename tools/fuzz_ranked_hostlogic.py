@@ -5,7 +5,7 @@ prefix databases, synonyms, stop words, typo thresholds), criteria lists, querie
 strategies, offsets, limits, score thresholds, deadlines, and — every other corpus — facet fields with Sort / Asc / Desc
 rules, `_geo` points with GeoSort rules (bucket caps, error margins) and a `distinct` field.
 
-    python tools/fuzz_ranked_hostlogic.py [first_seed] [seconds] [--emulated-kernels]
+    python tools/fuzz_ranked_hostlogic.py [first_seed] [seconds] [--emulated-kernels | --device]
 """
 import os
 import random
@@ -27,6 +27,11 @@ if EMULATED:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "emu"))
     import run_emulated
     _lib._LIB = run_emulated.EmulatedLib(run_emulated.build())
+    from tests.test_zzz_distinct_gpu import device_lib
+    L = device_lib()
+elif "--device" in sys.argv:
+    # ... and through the product itself on the MI355X
+    sys.argv.remove("--device")
     from tests.test_zzz_distinct_gpu import device_lib
     L = device_lib()
 else:
@@ -148,6 +153,9 @@ while time.time() < t_end:
             bad+=1
             print("MISMATCH seed",seed,repr(q),tms,detailed,offset,limit,thr,sa,criteria,kw,"sort",sort,"distinct",distinct,geo,"exhaustive",exh,mth)
             print("  want",want[0][:10],len(want[2])); print("  got ",[d for d,_ in hits][:10],cand)
+            if os.environ.get("FUZZ_VERBOSE"):   # score details side by side
+                for i in range(max(len(hits), len(want[0]))):
+                    print("   ", i, (hits[i][0], got_sc[i]) if i < len(hits) else None, "|", (want[0][i], want_sc[i]) if i < len(want[0]) else None)
             if bad>5: sys.exit(1)
     h.close()
 print("cases",n,"bad",bad)
