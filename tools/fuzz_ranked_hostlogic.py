@@ -36,6 +36,16 @@ elif "--device" in sys.argv:
     L = device_lib()
 else:
     L = H.load_hostlib()
+# FUZZ_SPREAD=<stride>: every internal docid times the stride on the product's side (the postings it is handed, its pool,
+# its universe), so that a 300-document corpus spans several 65 536-document chunks of the command lists — chunk
+# summaries, per-chunk path skipping, first-k across chunks.  Corpora without facet fields only (per-document arrays
+# are not spread).
+SPREAD = int(os.environ.get("FUZZ_SPREAD", "0"))
+if SPREAD:
+    import copy
+    import tests.toy_milli as T
+    _plain_cbo = T.cbo_bytes
+    T.cbo_bytes = lambda s_: _plain_cbo({d * SPREAD for d in s_})
 seed0 = int(sys.argv[1]) if len(sys.argv)>1 else 0
 budget = float(sys.argv[2]) if len(sys.argv)>2 else 120
 ALLC = ["words","typo","proximity","attribute","attributeRank","wordPosition","exactness","sort"]
@@ -47,7 +57,7 @@ while time.time() < t_end:
     docs = G.random_corpus(seed, rng.choice([40, 120, 300]))
     if rng.random()<0.5:
         for d in docs: d["tags"] = " ".join(rng.choice(G.VOCAB) for _ in range(rng.randint(0,3)))
-    faceted = rng.random() < 0.5
+    faceted = rng.random() < 0.5 and not SPREAD
     if faceted:
         places = [(rng.uniform(-80, 80), rng.uniform(-179, 179)) for _ in range(6)]
         for d in docs:
@@ -74,7 +84,14 @@ while time.time() < t_end:
     dic = O.Dictionary(index.words)
     def lookup(w,m,p):
         a,b=O.typo_lookup(dic,w,m,p); return [index.words[i] for i in a],[index.words[i] for i in b]
-    h = H.make_harness(L, index, n_slots=1024)
+    if SPREAD:
+        wide = copy.copy(index)
+        wide.n_docs = index.n_docs * SPREAD
+        h = H.make_harness(L, wide, n_slots=1024)
+        spread_kw = {"universe_cbo": _plain_cbo({d * SPREAD for d in range(index.n_docs)})}
+    else:
+        h = H.make_harness(L, index, n_slots=1024)
+        spread_kw = {}
     for _ in range(6):
         nt = rng.randint(1,5)
         ws = []
@@ -132,7 +149,10 @@ while time.time() < t_end:
             extra = [(([ng], False, 0, 0, False, True) if isinstance(ng, str) else (list(ng), True, 0, 0, False, True)) for ng in negs]
             hits, cand, gdeg = h.search(q, tms=tms, offset=offset, limit=limit, detailed=detailed, stop_after=sa, sort=sort,
                                         distinct=distinct, extra_terms=extra, score_threshold=thr, return_degraded=True, exhaustive=exh,
-                                        max_total_hits=mth, **geo)
+                                        max_total_hits=mth, **geo, **spread_kw)
+            if SPREAD:
+                assert all(d % SPREAD == 0 for d, _ in hits), hits
+                hits = [(d // SPREAD, sc) for d, sc in hits]
         except Exception as e:
             print("EXC", seed, repr(q), criteria, kw, e); bad+=1; continue
         n+=1
