@@ -172,3 +172,21 @@ def test_fuzz_regressions_through_the_product():
     from meilisearch_amd import _lib
     from tests.test_search_hostlogic_cpu import FUZZ_REGRESSIONS, run_fuzz_seeds
     run_fuzz_seeds(FUZZ_REGRESSIONS, "--emulated-kernels" if type(_lib.lib()).__name__ == "EmulatedLib" else "--device")
+
+
+def test_random_corpora_spread_over_chunks_match_the_oracle():
+    """A short run of the differential fuzzer with every docid multiplied on the product's side: random corpora, settings,
+    criteria and queries against the oracle while each list works over many 65 536-document chunks (on the device: 33
+    chunks; in the CPU tier's emulation: 4)."""
+    import subprocess
+    import sys
+    from meilisearch_amd import _lib
+    emulated = type(_lib.lib()).__name__ == "EmulatedLib"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_SPREAD="700" if emulated else "7001")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_ranked_hostlogic.py"), "31000", "10",
+                          "--emulated-kernels" if emulated else "--device"], cwd=root, env=env, capture_output=True, text=True,
+                         timeout=400)
+    tail = out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.returncode == 0 and " bad 0" in out.stdout, tail
+    assert int(out.stdout.split("cases")[-1].split()[0]) >= 30, tail
