@@ -107,3 +107,58 @@ def check_typo_lookup(concat, offsets, queries, got, threads=None, cap_one=150, 
             "checker": "oracle/msi_oracle.c orc_typo_lookup (literal loops of find_one_typo_derivations / "
                        "find_one_two_typo_derivations); index lists identical",
             **({"first_mismatches": [queries[i] for i in bad[:4]]} if bad else {})}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Keyword leg at the headline size: msi_keyword_search_ranked over the synthetic 10 M-document index of
+# tools/ranked_bench.cpp against oracle/ranking_oracle.py (the restatement the reference's snapshots pin, run over
+# oracle/docset.py's numpy docid sets) reading the same stored posting bytes through oracle/synth_index.py.
+class KeywordLegChecker:
+    def __init__(self, runner_lib, runner_handle, n_docs):
+        from . import synth_index as SI
+        self.SI = SI
+        self.lib, self.h = runner_lib, runner_handle
+        SI_lib = SI.runner_lib()        # the same shared object, with the checker's prototypes
+        self.index = SI.SynthIndex(SI_lib, runner_handle, n_docs)
+        self.oracle = SI.KeywordOracle(self.index)
+
+    def run_product(self, first, n, limit, max_details=16):
+        """The product's answers for prepared queries [first, first + n): rb_run_detailed (caller threads of the
+        runner, msi_keyword_search_ranked each)."""
+        ids = np.zeros((n, limit), np.uint32)
+        cnt = np.zeros(n, np.uint32)
+        scores = np.zeros((n, limit), np.float64)
+        det = np.zeros((n, limit, max_details, 3), np.uint32)
+        ndet = np.zeros((n, limit), np.uint32)
+        cand = np.zeros(n, np.uint64)
+        st = self.index.lib.rb_run_detailed(self.h, first, n, limit, ids.ctypes.data, cnt.ctypes.data, scores.ctypes.data,
+                                            det.ctypes.data, ndet.ctypes.data, cand.ctypes.data)
+        assert st == 0, "msi_keyword_search_ranked failed"
+        return ids, cnt, scores, det, ndet, cand
+
+    def verdict(self, first, n, limit, product=None):
+        """-> dict for the bench line's parity object / the test's assertion."""
+        SI = self.SI
+        ids, cnt, scores, det, ndet, cand = product if product is not None else self.run_product(first, n, limit)
+        bad, first_bad, hits, n_details = 0, None, 0, 0
+        for i in range(n):
+            q = self.index.query(first + i)
+            want_ids, want_sc, want_cand = self.oracle.search(q, limit=limit, detailed=True)
+            got = SI.product_details(ids[i], cnt[i], det[i], ndet[i], limit, det.shape[2])
+            want = [(d, [SI.oracle_detail(s) for s in sc]) for d, sc in zip(want_ids, want_sc)]
+            hits += len(want)
+            n_details += sum(len(sc) for _, sc in want)
+            if got != want or int(cand[i]) != want_cand:
+                bad += 1
+                if first_bad is None:
+                    first_bad = {"query": q, "product": str(got[:3]), "oracle": str(want[:3]),
+                                 "candidates": [int(cand[i]), want_cand]}
+        out = {"checked_queries": n, "mismatches": bad, "hits_compared": hits, "score_details_compared": n_details,
+               "documents": self.index.n_docs,
+               "checker": "oracle/ranking_oracle.py (pinned to the reference's 108 snapshot searches, here over oracle/docset.py's "
+                          "numpy docid sets) reading the synthetic index's stored CboRoaringBitmap bytes through "
+                          "oracle/synth_index.py; typo derivations from oracle/msi_oracle.c: docids in order, every hit's score "
+                          "details and the candidate counts identical"}
+        if first_bad is not None:
+            out["first_mismatch"] = first_bad
+        return out

@@ -26,6 +26,24 @@ from collections import namedtuple
 
 ALL, NONE = "all", "none"
 TRACE = False
+# The type of every docid set below.  The built-in set by default; oracle/docset.py's docset_type(n_docs) — same
+# interface over numpy arrays — for the 10 M-document index of the headline configuration (use_docset()).
+DocSet = set
+
+
+class use_docset:
+    """with use_docset(cls): ... — run the oracle over another docid-set type."""
+
+    def __init__(self, cls):
+        self.cls = cls
+
+    def __enter__(self):
+        global DocSet
+        self.prev, DocSet = DocSet, self.cls
+
+    def __exit__(self, *a):
+        global DocSet
+        DocSet = self.prev
 MAX_ONE, MAX_TWO, MAX_PREFIX = 150, 50, 1000      # limits.rs
 MAX_SYNONYM_PHRASE_COUNT, MAX_SYNONYM_WORD_COUNT = 50, 100
 MAX_WORD_LENGTH = 250
@@ -239,17 +257,17 @@ class Ctx:
 
     def _phrase_docids(self, words):
         if not words:
-            return set()
+            return DocSet()
         cand = None
         for w in words:
             if w is None:
                 continue
             d = self.word_docids(None, w, True)
             if d is None:
-                return set()
-            cand = set(d) if cand is None else cand & d
+                return DocSet()
+            cand = DocSet(d) if cand is None else cand & d
         if cand is None:
-            return set()
+            return DocSet()
         winsize = min(len(words), 3)
         for s in range(len(words) - winsize + 1):
             win = words[s:s + winsize]
@@ -263,16 +281,16 @@ class Ctx:
                     if dist == 0:
                         m = self.index.get_pair(1, s1, s2)
                         if m is None:
-                            return set()
-                        bitmaps.append(set(m))
+                            return DocSet()
+                        bitmaps.append(DocSet(m))
                     else:
-                        b = set()
+                        b = DocSet()
                         for dd in range(dist + 1):
                             m = self.index.get_pair(dd + 1, s1, s2)
                             if m is not None:
                                 b |= m
                         if not b:
-                            return set()
+                            return DocSet()
                         bitmaps.append(b)
             bitmaps.sort(key=len)
             for b in bitmaps:
@@ -283,7 +301,7 @@ class Ctx:
 
     def subset_docids(self, universe, ss):
         """compute_query_term_subset_docids, :33-59."""
-        d = set()
+        d = DocSet()
         for w, orig in self.all_single_words(ss):
             s = self.word_docids(universe, w, orig)
             if s:
@@ -292,13 +310,13 @@ class Ctx:
             d |= self.phrase_docids(p)
         pf = self.use_prefix_db(ss)
         if pf is not None:
-            d |= self.index.get_word_prefix_docids(pf[0], pf[1]) or set()
+            d |= self.index.get_word_prefix_docids(pf[0], pf[1]) or DocSet()
         return d if universe is None else d & universe
 
     def subset_docids_within(self, universe, ss, getter, key, prefix_getter=None):
         """…_within_field_id / …_within_position, :61-130 (no final intersection with the universe beyond
         the per-lookup one, as in the reference)."""
-        d = set()
+        d = DocSet()
         for w, _ in self.all_single_words(ss):
             s = getter(w, key)
             if s is not None:
@@ -511,13 +529,13 @@ def query_graph_docids(ctx, g, universe):
         if not n.preds <= resolved:
             queue.append(i)
             continue
-        pd = set()
+        pd = DocSet()
         for p in n.preds:
-            pd |= docs.get(p, set())
+            pd |= docs.get(p, DocSet())
         if n.kind == "term":
             nd = ctx.subset_docids(pd, n.term.subset)
         elif n.kind == "start":
-            nd = set(universe)
+            nd = DocSet(universe)
         elif n.kind == "end":
             return pd
         else:
@@ -615,12 +633,12 @@ def resolve_condition(ctx, cond, universe):
     if k in ("words", "typo", "term", "any"):
         return ctx.subset_docids(universe, cond[1].subset), None, cond[1]
     if k == "fid":
-        d = set() if cond[2] is None else ctx.subset_docids_within(universe, cond[1].subset,
+        d = DocSet() if cond[2] is None else ctx.subset_docids_within(universe, cond[1].subset,
                                                                   ctx.index.get_word_fid_docids, cond[2],
                                                                   ctx.index.get_word_prefix_fid_docids)
         return d, None, cond[1]
     if k == "position":
-        d = set()
+        d = DocSet()
         for pos in cond[2]:
             d |= ctx.subset_docids_within(universe, cond[1].subset, ctx.index.get_word_position_docids, pos,
                                           ctx.index.get_word_prefix_position_docids)
@@ -630,11 +648,11 @@ def resolve_condition(ctx, cond, universe):
         end = dst._replace(subset=ctx.keep_only_exact_term(dst.subset)._replace(mandatory=True))
         e = ctx.exact_term(dst.subset)
         if e is None:
-            d = set()
+            d = DocSet()
         elif e[0] == "phrase":
             d = ctx.phrase_docids(e[1]) & universe
         else:
-            d = ctx.word_docids(universe, e[1], True) or set()
+            d = ctx.word_docids(universe, e[1], True) or DocSet()
         return d, None, end
     if k == "prox":
         return proximity_docids(ctx, cond, universe)
@@ -646,7 +664,7 @@ def proximity_docids(ctx, cond, universe):
     _, left, right, cost = cond
     rn = _len(right.term_ids)
     forward, backward = 1 + cost - rn, cost - rn
-    docids = set()
+    docids = DocSet()
 
     lefts = {(None, w) for w, _ in ctx.all_single_words(left.subset)}
     for p in ctx.all_phrases(left.subset):
@@ -655,7 +673,7 @@ def proximity_docids(ctx, cond, universe):
     pf = ctx.use_prefix_db(right.subset)
     if pf is not None:                       # compute_prefix_edges, :97-147
         for lp, lw in lefts:
-            u = set(universe)
+            u = DocSet(universe)
             if lp is not None:
                 u &= ctx.phrase_docids(lp)
                 if not u:
@@ -671,7 +689,7 @@ def proximity_docids(ctx, cond, universe):
             rights.add((p[0], p))
     for lp, lw in lefts:
         for rw, rp in rights:
-            u = set(universe)
+            u = DocSet(universe)
             dead = False
             for ph in (lp, rp):
                 if ph is not None:
@@ -810,7 +828,7 @@ class GraphRule:
             return None
         self.cur_cost = cost + 1
         score = rank_to_score(self.kind, self.next_max_cost - cost, self.next_max_cost)
-        state = {"universe": set(universe), "bucket": set(), "good": [], "stop": False}
+        state = {"universe": DocSet(universe), "bucket": DocSet(), "good": [], "stop": False}
         # (condition, docids of the prefix) for every condition on the current DFS stack
         self._visit(g.root, cost, [], set(), set(), state)
         paths = []
@@ -852,7 +870,7 @@ class GraphRule:
         if not st["universe"]:
             st["stop"] = True
             return
-        docs = set(stack[-1][1]) if stack else set(st["universe"])
+        docs = DocSet(stack[-1][1]) if stack else DocSet(st["universe"])
         docs &= st["universe"]
         if not docs:
             return
@@ -894,7 +912,7 @@ class ExactAttributeRule:
             if x[0] < prev or x[0] - prev > 1:
                 return
             prev = x[0]
-        cand = set(universe)
+        cand = DocSet(universe)
         words_positions = []
         for _, e, pos, _ in infos:
             words = list(e[1]) if e[0] == "phrase" else [e[1]]
@@ -905,7 +923,7 @@ class ExactAttributeRule:
             for off, w in enumerate(words):
                 if w is None:
                     continue
-                s = ctx.index.get_word_position_docids(w, bucketed_position(pos + off)) or set()
+                s = ctx.index.get_word_position_docids(w, bucketed_position(pos + off)) or DocSet()
                 cand &= (s & universe)
                 if not cand:
                     return
@@ -918,31 +936,31 @@ class ExactAttributeRule:
                 for w in words:
                     if w is None:
                         continue
-                    s = (ctx.index.get_word_fid_docids(w, fid) or set()) & cand
+                    s = (ctx.index.get_word_fid_docids(w, fid) or DocSet()) & cand
                     inter = s if inter is None else inter & s
-            inter = inter or set()
+            inter = inter or DocSet()
             if inter:
-                wc = set()
+                wc = DocSet()
                 if count_all < 255:
-                    wc = (ctx.index.get_fid_word_count_docids(fid, count_all) or set()) & universe
+                    wc = (ctx.index.get_fid_word_count_docids(fid, count_all) or DocSet()) & universe
                 per_attr.append((inter, wc))
         self.state = ("exact", per_attr)
 
     def next_bucket(self, universe):
         st = self.state
         if st[0] == "exact":
-            c = set()
+            c = DocSet()
             for sw, wc in st[1]:
                 c |= sw & wc
             self.state = ("starts", st[1])
             return self.graph, c & universe, ("ExactAttribute", "ExactMatch")
         if st[0] == "starts":
-            c = set()
+            c = DocSet()
             for sw, wc in st[1]:
                 c |= sw - wc
             self.state = ("empty",)
             return self.graph, c & universe, ("ExactAttribute", "MatchesStart")
-        return self.graph, set(universe), ("ExactAttribute", "NoExactMatch")
+        return self.graph, DocSet(universe), ("ExactAttribute", "NoExactMatch")
 
 
 class SortRule:
@@ -962,7 +980,7 @@ class SortRule:
         keys = [k for (f, k) in index.facet_docids if f == self.field]
         nums = sorted((k for k in keys if k[0] == "n"), key=lambda k: k[1], reverse=not self.ascending)
         strs = sorted((k for k in keys if k[0] == "s"), key=lambda k: k[1].encode(), reverse=not self.ascending)
-        left = set(universe)
+        left = DocSet(universe)
         self.buckets = []
         for k in nums + strs:
             docs = index.facet_docids[(self.field, k)] & left
@@ -977,7 +995,7 @@ class SortRule:
             self.pos += 1
             value = ("Number", k[1]) if k[0] == "n" else ("String", k[1])
             return self.graph, docs & universe, ("Sort", self.field, self.ascending, value)
-        return self.graph, set(universe), ("Sort", self.field, self.ascending, ("Null",))
+        return self.graph, DocSet(universe), ("Sort", self.field, self.ascending, ("Null",))
 
 
 EARTH_RADIUS_M = 6371e3
@@ -1063,10 +1081,10 @@ class GeoSortRule:
     def next_bucket(self, universe):
         def detail(point):
             return ("GeoSort", self.point, self.ascending, point)
-        cands = self.geo_faceted & set(universe)
+        cands = self.geo_faceted & DocSet(universe)
         if not cands:
-            return self.graph, set(universe), detail(None)
-        bucket, cur = set(), None
+            return self.graph, DocSet(universe), detail(None)
+        bucket, cur = DocSet(), None
         while True:
             if self.cache:
                 d, pt = self.cache.popleft() if self.ascending else self.cache.pop()
@@ -1199,12 +1217,12 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
     the last call short (graph-based rules never answer non_blocking_next_bucket: ranking_rules.rs:67-74)."""
     deadline = deadline or Deadline()
     bucket_sort.degraded = False
-    universe = set(universe)
+    universe = DocSet(universe)
     if len(universe) < offset:
         return [], [], universe
 
     def apply_distinct(cands):
-        remaining, excluded = set(), set()
+        remaining, excluded = DocSet(), DocSet()
         for d in sorted(cands):
             if d in excluded:
                 continue
@@ -1213,7 +1231,7 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
         return remaining, excluded
     if not rules:
         if distinct:                           # bucket_sort.rs:61-92
-            excluded, results = set(), []
+            excluded, results = DocSet(), []
             for d in sorted(universe):
                 if len(results) >= offset + length:
                     break
@@ -1221,16 +1239,16 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
                     continue
                 excluded |= ctx.index.distinct_excluded(distinct, d)
                 results.append(d)
-            all_c = (universe - excluded) | set(results)
+            all_c = (universe - excluded) | DocSet(results)
             results = results[offset:] if len(results) >= offset else []
             return results, [[] for _ in results], all_c
         ids = sorted(universe)[offset:offset + length]
         return ids, [[] for _ in ids], universe
     n = len(rules)
     rules[0].start_iteration(ctx, universe, graph)
-    scores, unis = [], [set() for _ in range(n)]
-    unis[0] = set(universe)
-    cur, all_cand, out_ids, out_scores, cur_off = 0, set(universe), [], [], 0
+    scores, unis = [], [DocSet() for _ in range(n)]
+    unis[0] = DocSet(universe)
+    cur, all_cand, out_ids, out_scores, cur_off = 0, DocSet(universe), [], [], 0
 
     def add(cands):
         nonlocal cur_off
@@ -1259,9 +1277,9 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
     max_len = max_total_hits if (max_total_hits is not None and exhaustive and threshold is not None) else length
     while len(out_ids) < max_len:
         if not unis[cur] or (not detailed and len(unis[cur]) == 1):
-            b, unis[cur] = unis[cur], set()
+            b, unis[cur] = unis[cur], DocSet()
             add(b)
-            unis[cur] = set()
+            unis[cur] = DocSet()
             if cur == 0:
                 break
             cur -= 1
@@ -1271,7 +1289,7 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
         if deadline.exceeded():
             # every rule from here up is `Pending`: what is left of each universe goes out unranked (Skipped)
             while True:
-                b, unis[cur] = unis[cur], set()
+                b, unis[cur] = unis[cur], DocSet()
                 scores.append(("Skipped",))
                 if threshold is not None and global_score(scores) < threshold:
                     all_cand.difference_update(b)
@@ -1286,7 +1304,7 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
                     scores.pop()
         nb = rules[cur].next_bucket(unis[cur])
         if nb is None:
-            unis[cur] = set()
+            unis[cur] = DocSet()
             if cur == 0:
                 break
             cur -= 1
@@ -1310,7 +1328,7 @@ def bucket_sort(ctx, rules, graph, universe, offset, length, detailed=False, dea
             scores.pop()
             continue
         cur += 1
-        unis[cur] = set(cands)
+        unis[cur] = DocSet(cands)
         rules[cur].start_iteration(ctx, cands, g2)
     return out_ids, out_scores, all_cand
 
@@ -1374,10 +1392,10 @@ def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=
     Search::execute removes from the universe first (search/mod.rs:431-440, new/mod.rs:323-351)."""
     index = ctx.index
     terms = parse_query(ctx, query)
-    universe = index.all_docids() if universe is None else set(universe)
+    universe = index.all_docids() if universe is None else DocSet(universe)
     for neg in negatives:
         if isinstance(neg, str):
-            universe -= ctx.word_docids(None, neg, True) or set()
+            universe -= ctx.word_docids(None, neg, True) or DocSet()
         else:
             universe -= ctx.phrase_docids(tuple(neg))
     if not terms:          # no term (or only stop words): a placeholder search — only Sort / Asc / Desc rules, mod.rs:770-800
@@ -1402,7 +1420,7 @@ def exhaustive_candidates(ctx, distinct, exhaustive, out):
     of all_candidates."""
     ids, scores, all_cand = out
     if exhaustive and distinct:
-        remaining, excluded = set(), set()
+        remaining, excluded = DocSet(), DocSet()
         for d in sorted(all_cand):
             if d in excluded:
                 continue

@@ -39,6 +39,24 @@ def build():
     return SO
 
 
+RUNNER_SO = os.path.join(BUILD, "libmsi_rankedbench_emu.so")
+
+
+def build_runner():
+    """tools/ranked_bench.cpp (the synthetic inverted index + caller threads of bench.py's keyword leg) linked against the
+    emulated build instead of libmsi.so: tests/test_configs_gpu.py::test_c4_keyword_leg runs through it at a reduced size
+    (oracle/synth_index.py loads $MSI_RUNNER_SO when it is set)."""
+    src = os.path.join(ROOT, "tools", "ranked_bench.cpp")
+    if os.path.exists(RUNNER_SO) and all(os.path.getmtime(d) <= os.path.getmtime(RUNNER_SO) for d in (src, SO)):
+        return RUNNER_SO
+    tmp = RUNNER_SO + f".{os.getpid()}.tmp"
+    subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DRANKED_BENCH_LIB", "-x", "c++",
+                           "-I" + os.path.join(ROOT, "include"), src, "-L" + BUILD, "-lmsi_emu", "-Wl,-rpath," + BUILD,
+                           "-lpthread", "-o", tmp])
+    os.replace(tmp, RUNNER_SO)
+    return RUNNER_SO
+
+
 class EmulatedLib:
     def __init__(self, path):
         self._L = C.CDLL(path)
@@ -60,6 +78,7 @@ def main(argv):
     from meilisearch_amd import _lib
     _lib._LIB = EmulatedLib(build())
     assert _lib.lib().msi_abi_version() == 1
+    os.environ["MSI_RUNNER_SO"] = build_runner()
     import pytest
     return pytest.main(argv)
 

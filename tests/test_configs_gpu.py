@@ -118,3 +118,36 @@ def test_c3_2m_term_dictionary(ctx):
     for (a1, a2), (b1, b2) in zip(got, got2[:2048]):
         assert a1.tolist() == b1.tolist() and a2.tolist() == b2.tolist()
     g.close()
+
+
+def test_c4_keyword_leg(ctx):
+    """The keyword leg of the headline step at its own size: msi_keyword_search_ranked (7 default criteria, detailed
+    scores, 3-term queries with typo and prefix derivations, 16 caller threads sharing command-list launches) over the
+    synthetic 10 M-document inverted index of tools/ranked_bench.cpp, against oracle/ranking_oracle.py reading the same
+    stored posting bytes (bucket_sort.rs:23-343, graph_based_ranking_rule.rs:97-378).  What the toy corpora cannot show:
+    bitmap containers, 153 chunks of 65 536 documents, posting-cache reuse across searches, many searches in flight."""
+    import ctypes as C
+    from oracle import parity
+    from oracle import synth_index as SI
+    import os
+    n_docs, n_queries, limit = 10_000_000, 48, 20
+    if os.environ.get("MSI_RUNNER_SO"):        # the CPU tier's emulated kernels (tests/emu): same path, 5 chunks of documents
+        n_docs, n_queries = 300_000, 12
+    lib = SI.runner_lib()
+    lib.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    h = lib.rb_create(n_docs, 200_000)
+    try:
+        assert lib.rb_attach(h, ctx.handle, 16, 1024, 2048) == 0
+        lib.rb_prepare_queries(h, n_queries, 3, 4242)
+        chk = parity.KeywordLegChecker(lib, h, n_docs)
+        cold = chk.run_product(0, n_queries, limit)             # cold posting cache: decode out of the staging buffer
+        v = chk.verdict(0, n_queries, limit, product=cold)
+        assert v["mismatches"] == 0, v
+        assert v["checked_queries"] == n_queries and v["hits_compared"] >= 15 * n_queries and v["score_details_compared"] >= 7 * 15 * n_queries
+        # the check is not vacuous: the answers of queries 0..3 are not the oracle's answers for queries 1..4
+        assert chk.verdict(1, 4, limit, product=tuple(a[:4] for a in cold))["mismatches"] == 4
+        warm = chk.run_product(0, n_queries, limit)             # the same searches out of the HBM posting cache
+        for a, b in zip(cold, warm):
+            assert (a == b).all()
+    finally:
+        lib.rb_destroy(h)

@@ -41,7 +41,8 @@ GROUPS = {
                       "not matches_oracle_on_random_corpora and not random_corpora_with_levels and not under_index_settings", 101),
     "ranked-search-vs-oracle": (["tests/test_zzz_distinct_gpu.py::test_distinct_matches_the_oracle_on_the_device",
                                  "tests/test_zzz_geo_gpu.py::test_geo_sort_matches_the_oracle_on_the_device",
-                                 "tests/test_zz_order_keys_gpu.py::test_sort_rules_match_the_oracle_on_the_device"], "", 3),
+                                 "tests/test_zz_order_keys_gpu.py::test_sort_rules_match_the_oracle_on_the_device",
+                                 "tests/test_configs_gpu.py::test_c4_keyword_leg"], "", 4),
 }
 
 

@@ -455,10 +455,14 @@ struct Runner {
   uint32_t job_first = 0, job_n = 0, job_limit = 0, next = 0, done = 0;
   uint32_t *out_ids = nullptr, *out_n = nullptr;
   double *out_scores = nullptr;
+  msi_score_detail *out_details = nullptr;   // nullable: [n][limit][MSI_MAX_SCORE_DETAILS]
+  uint32_t *out_n_details = nullptr;         // nullable: [n][limit]
+  uint64_t *out_candidates = nullptr;        // nullable: [n]
   bool stop = false;
   std::atomic<int32_t> failed{0};
 
-  int32_t search(msi_bits *pool, const std::vector<std::string> &q, uint32_t limit, uint32_t *ids, uint32_t *n, double *scores) {
+  int32_t search(msi_bits *pool, const std::vector<std::string> &q, uint32_t limit, uint32_t *ids, uint32_t *n, double *scores,
+                 msi_score_detail *details = nullptr, uint32_t *n_details = nullptr, uint64_t *candidates = nullptr) {
     std::vector<msi_query_token> toks(q.size());
     std::vector<msi_located_term> terms(q.size());
     for (size_t i = 0; i < q.size(); ++i) {
@@ -474,6 +478,9 @@ struct Runner {
                                                  nsc.data(), n, &cand, nullptr);
     if (st != MSI_OK) return st;
     for (uint32_t i = 0; i < *n; ++i) scores[i] = msi_score_details_global_score(sc.data() + (size_t)i * MSI_MAX_SCORE_DETAILS, nsc[i]);
+    if (details) memcpy(details, sc.data(), sizeof(msi_score_detail) * (size_t)*n * MSI_MAX_SCORE_DETAILS);
+    if (n_details) memcpy(n_details, nsc.data(), sizeof(uint32_t) * *n);
+    if (candidates) *candidates = cand;
     return MSI_OK;
   }
   void work(size_t t) {
@@ -493,7 +500,10 @@ struct Runner {
           i = next++;
         }
         const std::vector<std::string> &q = queries[(job_first + i) % queries.size()];
-        const int32_t st = search(pools[t], q, job_limit, out_ids + (size_t)i * job_limit, out_n + i, out_scores + (size_t)i * job_limit);
+        const int32_t st = search(pools[t], q, job_limit, out_ids + (size_t)i * job_limit, out_n + i, out_scores + (size_t)i * job_limit,
+                                  out_details ? out_details + (size_t)i * job_limit * MSI_MAX_SCORE_DETAILS : nullptr,
+                                  out_n_details ? out_n_details + (size_t)i * job_limit : nullptr,
+                                  out_candidates ? out_candidates + i : nullptr);
         if (st != MSI_OK) {
           if (!failed.exchange(1)) {
             std::string words;
@@ -586,16 +596,68 @@ int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64
   for (auto &q : r->queries) for (uint32_t i = 0; i < n_terms; ++i) q.push_back(r->frequent[g() % 300]);
   return MSI_OK;
 }
-int32_t rb_run(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores) {
+// as rb_run, and also every hit's score details ([n][limit][MSI_MAX_SCORE_DETAILS] + their counts [n][limit]) and the
+// candidate counts [n] — what the oracle check of the keyword leg compares (any of the three may be null)
+int32_t rb_run_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores,
+                        msi_score_detail *out_details, uint32_t *out_n_details, uint64_t *out_candidates) {
   Runner *r = (Runner *)h;
   if (!n || r->queries.empty()) return MSI_E_INVALID;
   std::unique_lock<std::mutex> lk(r->mu);
   r->job_first = first; r->job_n = n; r->job_limit = limit; r->next = 0; r->done = 0;
   r->out_ids = out_ids; r->out_n = out_n; r->out_scores = out_scores;
+  r->out_details = out_details; r->out_n_details = out_n_details; r->out_candidates = out_candidates;
   ++r->epoch;
   r->cv.notify_all();
   r->cv_done.wait(lk, [&] { return r->done == n; });
   return r->failed.load() ? MSI_E_INTERNAL : MSI_OK;
+}
+int32_t rb_run(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores) {
+  return rb_run_detailed(h, first, n, limit, out_ids, out_n, out_scores, nullptr, nullptr, nullptr);
+}
+// ---- the index behind the vtable, handed to the CHECKER (oracle/synth_index.py reads the same stored bytes the
+// product's callbacks return; needs no device): the dictionary, the prepared queries, and every database read ----
+uint32_t rb_n_words(void *h) { return (uint32_t)((Runner *)h)->ix.words.size(); }
+// words concatenated in dictionary order + n+1 offsets; returns the bytes needed (call with cap 0 first)
+uint64_t rb_words(void *h, uint8_t *concat, uint64_t cap, uint32_t *offsets) {
+  Runner *r = (Runner *)h;
+  uint64_t at = 0;
+  uint32_t i = 0;
+  for (auto &w : r->ix.words) {
+    if (offsets) offsets[i] = (uint32_t)at;
+    if (concat && at + w.size() <= cap) memcpy(concat + at, w.data(), w.size());
+    at += w.size();
+    ++i;
+  }
+  if (offsets) offsets[i] = (uint32_t)at;
+  return at;
+}
+// the words of prepared query i, separated by single spaces (the last one is the prefix word); returns the length
+uint32_t rb_query(void *h, uint32_t i, char *out, uint32_t cap) {
+  Runner *r = (Runner *)h;
+  std::string s;
+  for (auto &w : r->queries[i % r->queries.size()]) s += (s.empty() ? "" : " ") + w;
+  if (out && cap) { strncpy(out, s.c_str(), cap); out[cap - 1] = 0; }
+  return (uint32_t)s.size();
+}
+// db: 0 word_docids(a) | 1 word_pair_proximity_docids(x = proximity, a, b) | 2 word_fid_docids(a, x = fid)
+//   | 3 word_position_docids(a, x = position) | 4 field_id_word_count_docids(x = fid, y = count): the stored bytes
+int32_t rb_read(void *h, uint32_t db, const uint8_t *a, uint32_t an, const uint8_t *b, uint32_t bn, uint32_t x, uint32_t y,
+                const uint8_t **bytes, size_t *n) {
+  Runner *r = (Runner *)h;
+  *bytes = nullptr; *n = 0;
+  switch (db) {
+    case 0: return cb_word(&r->ix, a, an, 1, bytes, n);
+    case 1: return cb_pair(&r->ix, x, a, an, b, bn, bytes, n);
+    case 2: return cb_fid(&r->ix, a, an, x, bytes, n);
+    case 3: return cb_pos(&r->ix, a, an, x, bytes, n);
+    case 4: return cb_count(&r->ix, x, y, bytes, n);
+  }
+  return MSI_E_INVALID;
+}
+// db: 0 the fids a word occurs in | 1 its (bucketed) positions
+int32_t rb_read_keys(void *h, uint32_t db, const uint8_t *a, uint32_t an, uint16_t *out, uint32_t cap, uint32_t *cnt) {
+  Runner *r = (Runner *)h;
+  return db == 0 ? cb_fids(&r->ix, a, an, out, cap, cnt) : cb_positions(&r->ix, a, an, out, cap, cnt);
 }
 // ScoreWithRatioResult::merge (search/hybrid.rs:102-235) of every query's vector list (similarity = 1 - distance) with
 // its keyword list (ScoreDetails::global_score of each hit), semantic_ratio on the vector side: native loop over
