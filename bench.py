@@ -80,7 +80,8 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child for roofline.traffic")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--cpu-sample-words", type=int, default=4096)
-    ap.add_argument("--parity-queries", type=int, default=16)
+    ap.add_argument("--parity-queries", type=int, default=96, help="vector queries checked against the oracle (96 = one whole 6-tile sweep)")
+    ap.add_argument("--parity-kw-queries", type=int, default=64, help="c4: keyword searches of the timed step checked against the ranking oracle")
     return ap.parse_args()
 
 
@@ -566,9 +567,23 @@ def run_c4(args, env):
         if not same:
             par["mismatches"] += 1
         if kw is not None:
-            # keyword leg: the command-list back end against the direct back end (one launch per set operation) on this
-            # step's queries — the oracle-pinned replays of the ranked search (reference snapshots, random corpora vs
-            # oracle/ranking_oracle.py) are tests/test_search_gpu.py and friends; the synthetic index has no Python twin
+            # keyword leg, checked against the ORACLE at the step's own size: the first `--parity-kw-queries` queries of the
+            # step that was just timed, through oracle/ranking_oracle.py (the restatement the reference's snapshot searches
+            # pin) reading the synthetic index's stored posting bytes — docids in order, every hit's score details and the
+            # candidate counts (oracle/parity.py: KeywordLegChecker; tests/test_configs_gpu.py::test_c4_keyword_leg)
+            first = ((kw["step"] - 1) * Q) % (4 * Q)
+            nk = min(args.parity_kw_queries, Q)
+            kchk = parity.KeywordLegChecker(kw["lib"], kw["h"], n_total if row_sharded else n)
+            prod = kchk.run_product(first, nk, k)
+            kpar = kchk.verdict(first, nk, k, product=prod)
+            # ... and the lists the last keyword_run of this process produced for the same queries are those lists
+            same_kw = bool((prod[1] == kw["n"][:nk]).all()) and all(
+                prod[0][i, :int(prod[1][i])].tolist() == kw["ids"][i, :int(prod[1][i])].tolist() for i in range(nk))
+            kpar["timed_path_equals_checked_path"] = same_kw
+            par["mismatches"] += 0 if same_kw else 1
+            # second field: the command-list back end against the direct back end (one launch per set operation) on ALL of
+            # the step's queries
+            kw["step"] -= 1
             keyword_run()
             a_ids, a_n, a_sc = kw["ids"].copy(), kw["n"].copy(), kw["scores"].copy()
             kw["step"] -= 1
@@ -581,9 +596,10 @@ def run_c4(args, env):
                 if m != int(kw["n"][qi]) or a_ids[qi, :m].tolist() != kw["ids"][qi, :m].tolist() or \
                         a_sc[qi, :m].tolist() != kw["scores"][qi, :m].tolist():
                     kbad += 1
-            par["keyword"] = {"checked_queries": Q, "mismatches": kbad,
-                              "checker": "command-list back end vs direct back end (MSI_SEARCH_VM=0): docids and global scores identical"}
-            par["mismatches"] += kbad
+            kpar["command_lists_vs_direct_back_end"] = {"checked_queries": Q, "mismatches": kbad,
+                                                        "what": "MSI_SEARCH_VM=0 against the default: docids and global scores identical"}
+            par["keyword"] = kpar
+            par["mismatches"] += kpar["mismatches"] + kbad
         out["parity"] = par
     return out
 

@@ -393,9 +393,21 @@ int32_t bq_alloc(msi_bq *b, uint64_t n_rows) {
 extern "C" {
 
 int32_t msi_bq_create(msi_ctx *ctx, uint32_t dim, msi_bq **out) {
-  if (!ctx || !out || dim == 0 || dim > 65535) {
-    msi_set_error("msi_bq_create: invalid argument (dim 1..65535)");
+  if (!ctx || !out || dim == 0) {
+    msi_set_error("msi_bq_create: invalid argument");
     return MSI_E_INVALID;
+  }
+  // a search keeps the words of the queries of a sweep and one distance histogram of dim + 1 counters per query of a
+  // sub-batch in LDS (msi_bq_search: q_per >= 1): a dimension whose ONE-query footprint does not fit the 60 KiB the
+  // launches ask for is refused here, not by a launch error at the first search
+  {
+    const size_t W = (dim + 63) / 64;
+    const size_t lds_one = (size_t)BQ_QMAX * W * 8 + ((size_t)dim + 1) * 4;
+    if (lds_one > ((size_t)60 << 10)) {
+      msi_set_error("msi_bq_create: dim %u needs %zu B of LDS per one-query sweep (max %zu): unsupported", dim, lds_one,
+                    (size_t)60 << 10);
+      return MSI_E_UNSUPPORTED;
+    }
   }
   msi_bq *b = new msi_bq();
   b->ctx = ctx;

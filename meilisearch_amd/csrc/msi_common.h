@@ -19,9 +19,16 @@
 // `buffer_inv sc1`: it writes back AND invalidates the whole L2 of the XCD the wave runs on — for every kernel resident
 // there.  A workgroup that only has to order its own device-scope ATOMICS (which are performed at the device's
 // coherence point, not in the L2) before a later atomic needs no more than "my earlier memory operations are
-// acknowledged": s_waitcnt vmcnt(0), which is what a workgroup-scope release fence compiles to.
+// acknowledged": s_waitcnt vmcnt(0).  The instruction is emitted EXPLICITLY (on gfx9 loads, stores and atomics all count
+// in vmcnt; there is no separate store counter): a workgroup-scope fence alone promises no inter-workgroup ordering under
+// the memory model and the backend is free to leave the wait out of it — the fence stays for what it does promise, that
+// the compiler moves no memory operation across this point.  `make` checks the built ISA for the wait (check_isa.py).
 #ifndef MSI_ORDER_ATOMICS
-#define MSI_ORDER_ATOMICS() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#define MSI_ORDER_ATOMICS()                                      \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             \
+  } while (0)
 #endif
 // A value every lane of the wave holds alike, moved to a scalar register (uniform branches, scalar address arithmetic).
 #ifndef MSI_UNIFORM

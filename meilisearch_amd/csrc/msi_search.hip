@@ -224,6 +224,9 @@ struct Dev {
   MsiVmResult res;
   MsiPostingCache *pcache = nullptr;   // HBM posting cache of the index version (msi_dict_enable_posting_cache), or none
   std::vector<void *> fills;           // cache entries the RECORDED decodes fill: ready once the list has run
+  ~Dev() {                             // a search that ended with a recorded list it never ran (an error unwound it)
+    for (void *t : fills) msi_pcache_abandon(pcache, t);
+  }
   struct PendingFk {
     Set set;   // keeps the slot from being reused before the list has run
     uint32_t k, ci, base;
@@ -240,8 +243,8 @@ struct Dev {
     if (r == 1) return msi_cbo_batch_append(b, bytes, n, off, MSI_NO_CACHE);
     if (r == 2) {
       if (!msi_cbo_batch_append(b, bytes, n, MSI_NO_CACHE, off)) return false;
-      b.fill_tokens.push_back(token);   // committed when the batch's decode has run (a batch that is dropped leaves
-      return true;                      // its entries reserved and unfilled: never served)
+      b.fill_tokens.push_back(token);   // committed when the batch's decode has run; a list that fails or is dropped
+      return true;                      // abandons them (msi_pcache_abandon): the next reader of the key refills
     }
     return msi_cbo_batch_append(b, bytes, n);
   }
@@ -294,8 +297,10 @@ struct Dev {
     const int32_t st = msi_vm_run(pool.p, list, &res);
     g_stats.device_wait_ms += ck_.ms();
     list.clear();
-    if (st == MSI_OK)
-      for (void *t : fills) msi_pcache_commit(pcache, t);
+    for (void *t : fills) {
+      if (st == MSI_OK) msi_pcache_commit(pcache, t);
+      else msi_pcache_abandon(pcache, t);
+    }
     fills.clear();
     std::vector<PendingFk> fk;
     fk.swap(pending_fk);

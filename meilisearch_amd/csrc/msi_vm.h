@@ -124,5 +124,6 @@ void msi_pcache_destroy(MsiPostingCache *c);
 // msi_pcache_commit once the list that fills it has run); 0: not cacheable now (being filled by someone else, or full)
 int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint64_t *off, void **token);
 void msi_pcache_commit(MsiPostingCache *c, void *token);
+void msi_pcache_abandon(MsiPostingCache *c, void *token);   // the filling list failed / was dropped: the next reader refills
 uint64_t msi_pcache_device_base(const MsiPostingCache *c);
 void msi_pcache_stats(const MsiPostingCache *c, uint64_t out[4]);   // hits, misses, bytes used, capacity

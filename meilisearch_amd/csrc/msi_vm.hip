@@ -787,6 +787,7 @@ struct VmSub {
   std::atomic<uint32_t> state{0};          // 0 waiting, 1 done, 2 failed
   std::atomic<uint32_t> asleep{0};         // the waiter is (about to be) blocked in futex_wait: the combiner must wake it
   int32_t error = MSI_OK;
+  char errmsg[192] = "";                   // the combiner thread's error text (msi_last_error is thread-local: the waiter re-issues it)
   int64_t t_submit = 0, t_taken = 0, t_launch = 0, t_done = 0;   // steady-clock ns (diagnostics)
 };
 
@@ -1006,6 +1007,7 @@ void VmCombiner::run() {
     if (st != MSI_OK) {
       for (VmSub *s : batch) {
         s->error = st;
+        snprintf(s->errmsg, sizeof(s->errmsg), "%s", msi_last_error());
         finish(s, 2);
       }
     } else {
@@ -1307,6 +1309,7 @@ int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
     s->seq = msi_bits_vm_next_seq(pool);
     s->blk = blk;
     s->error = MSI_OK;
+    s->errmsg[0] = 0;
     s->state.store(0, std::memory_order_relaxed);
     s->asleep.store(0, std::memory_order_relaxed);
     s->t_submit = now_ns();
@@ -1336,6 +1339,7 @@ int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
   if (st == 2) {
     ret = s->error != MSI_OK ? s->error : MSI_E_INTERNAL;
     if (ret == MSI_E_INTERNAL) msi_set_error("msi_vm: a round finished without publishing its results");
+    else msi_set_error("%s", s->errmsg[0] ? s->errmsg : "msi_vm: the round of this list failed");
   } else {
     vm->ns_queued.fetch_add((uint64_t)(s->t_taken - s->t_submit), std::memory_order_relaxed);
     vm->ns_packed.fetch_add((uint64_t)(s->t_launch - s->t_taken), std::memory_order_relaxed);
@@ -1372,8 +1376,8 @@ struct KeyEq {
 struct CacheEntry {
   uint64_t off = 0;
   uint64_t len = 0;
-  std::atomic<uint32_t> ready{0};
-};
+  std::atomic<uint32_t> ready{0};   // 0: reserved, being filled | 1: filled | 2: abandoned by a list that failed or was
+};                                  //    dropped — the next reader of the key takes the reservation over
 inline uint64_t mix64(uint64_t x) {
   x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
   return x;
@@ -1441,12 +1445,20 @@ int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint
     std::shared_lock<std::shared_mutex> lk(c->mu);
     auto it = c->map.find(k);
     if (it != c->map.end()) {
-      if (it->second.len == len && it->second.ready.load(std::memory_order_acquire)) {
+      const uint32_t state = it->second.ready.load(std::memory_order_acquire);
+      if (it->second.len == len && state == 1) {
         *off = it->second.off;
         c->hits.fetch_add(1, std::memory_order_relaxed);
         return 1;
       }
       c->misses.fetch_add(1, std::memory_order_relaxed);
+      uint32_t abandoned = 2;
+      if (it->second.len == len && state == 2 &&
+          it->second.ready.compare_exchange_strong(abandoned, 0, std::memory_order_acq_rel)) {
+        *off = it->second.off;    // the reservation of a list that never ran: this caller fills it
+        *token = &it->second;
+        return 2;
+      }
       return 0;   // being filled by another search (or a length mismatch: never trusted)
     }
   }
@@ -1466,6 +1478,11 @@ int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint
 
 void msi_pcache_commit(MsiPostingCache *, void *token) {
   if (token) static_cast<CacheEntry *>(token)->ready.store(1, std::memory_order_release);
+}
+
+// The list that was to fill the entry failed or was dropped: hand the reservation to the next reader of the key.
+void msi_pcache_abandon(MsiPostingCache *, void *token) {
+  if (token) static_cast<CacheEntry *>(token)->ready.store(2, std::memory_order_release);
 }
 
 uint64_t msi_pcache_device_base(const MsiPostingCache *c) { return c ? (uint64_t)(uintptr_t)c->dev : 0; }

@@ -1015,6 +1015,7 @@ struct msi_vs {
   msi_ctx *ctx = nullptr;
   uint32_t dim = 0, dpad = 0, KB = 0;
   uint32_t nqt_max = 1;            // query tiles per sweep the LDS admits for this dim
+  uint32_t nqt3_max = 1;           // ... with both halves of the queries in LDS (the bf16x3 second opinion of a bf16x2 store)
   bool bf3 = true;                 // contraction of the fast scan: bf16 MFMA (default) or f32 MFMA
   bool bf2 = false;                // ... bf16x2 (queries' hi halves only in LDS: twice the queries per sweep) instead of bf16x3
   bool s16 = false;                // rows stored as bf16 (MSI_VS_BF16)
@@ -1470,9 +1471,14 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
   const uint32_t nqt_cap = bf2 ? (uint32_t)NQT_MAX : 3u;
   uint32_t nqt_max = 1;
   while (nqt_max < nqt_cap && scan_lds_bytes(KB, nqt_max + 1, s16, bf2) <= LDS_MAX) ++nqt_max;
+  // the bf16x3 second opinion keeps hi AND lo halves of the queries in LDS: twice the bytes per query tile, so its
+  // capacity is its own (d = 1024: KB = 64 -> 2 tiles of 64 KiB, not 3; d = 1536: 1 tile)
+  uint32_t nqt3_max = 1;
+  while (nqt3_max < 3u && scan_lds_bytes(KB, nqt3_max + 1, s16, false) <= LDS_MAX) ++nqt3_max;
   if (const char *e = getenv("MSI_VS_MAX_QUERY_TILES")) {  // tuning/testing knob
     const int v = atoi(e);
     if (v >= 1 && (uint32_t)v < nqt_max) nqt_max = (uint32_t)v;
+    if (v >= 1 && (uint32_t)v < nqt3_max) nqt3_max = (uint32_t)v;
   }
   DeviceGuard g(ctx->device);
   const void *fns[] = {
@@ -1501,6 +1507,7 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
   vs->dpad = dpad;
   vs->KB = KB;
   vs->nqt_max = nqt_max;
+  vs->nqt3_max = nqt3_max;
   vs->s16 = s16;
   vs->bf3 = !(math && strcmp(math, "f32") == 0);
   vs->bf2 = bf2;
@@ -1916,10 +1923,11 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
                                  hipMemcpyDeviceToHost, st));
       MSI_HIP_TRY(hipStreamSynchronize(st));
       // A query the bf16x2 scan could not prove (its margin is 2^-8 wide) gets a second opinion from the bf16x3
-      // contraction (margin ~1e-5), 48 to a sweep; what that cannot prove either — ties beyond K', degenerate rows — is
+      // contraction (margin ~1e-5), as many to a sweep as both halves of their fragments fit in LDS (48 up to d = 768,
+      // 32 up to 1280, 16 beyond); what that cannot prove either — ties beyond K', degenerate rows — is
       // answered exhaustively in the reference arithmetic.
       const bool second_opinion = true;
-      const uint32_t sub = 3u * QT;
+      const uint32_t sub = vs->nqt3_max * QT;
       for (size_t f0 = 0; f0 < flagged.size(); f0 += sub) {
         const uint32_t nf = (uint32_t)std::min<size_t>(sub, flagged.size() - f0);
         if (cancel && *cancel) {

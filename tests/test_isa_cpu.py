@@ -1,0 +1,54 @@
+"""Code-generation checks on the built gfx950 objects (no GPU needed: llvm-objdump on the device code of
+meilisearch_amd/csrc/*.o).  ADVICE r2: the completion protocols of msi_vm.hip / msi_bits.hip order their set-word
+stores before the ticket atomic with `s_waitcnt vmcnt(0)` (MSI_ORDER_ATOMICS, msi_common.h) — that instruction must be
+IN the ISA, whatever the compiler makes of the fence beside it."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def device_isa(obj):
+    tmp = tempfile.mkdtemp(prefix="msi_isa_")
+    try:
+        local = os.path.join(tmp, os.path.basename(obj))
+        shutil.copy(obj, local)
+        subprocess.run([OBJDUMP, "--offloading", local], capture_output=True, text=True, check=True)
+        co = [f for f in os.listdir(tmp) if "gfx950" in f]
+        assert co, "no gfx950 code object in " + obj
+        return subprocess.run([OBJDUMP, "-d", os.path.join(tmp, co[0])], capture_output=True, text=True, check=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+@pytest.mark.parametrize("unit,kernels", [("msi_vm", ["vm_kernel"]),
+                                          ("msi_bits", ["bits_"])])
+def test_ticket_atomics_wait_for_the_stores_before_them(unit, kernels):
+    obj = os.path.join(ROOT, "meilisearch_amd", "csrc", unit + ".o")
+    if not os.path.exists(obj) or not os.path.exists(OBJDUMP):
+        pytest.skip("objects not built / no llvm-objdump")
+    isa = device_isa(obj)
+    funcs = re.split(r"\n(?=[0-9a-f]{16} <)", isa)      # one piece per function symbol
+    checked = 0
+    for fn in funcs:
+        head = fn.split("\n", 1)[0]
+        if not any(k in head for k in kernels):
+            continue
+        lines = fn.split("\n")
+        for i, l in enumerate(lines):
+            # a returning (sc0) global atomic add = a ticket / completion counter of the protocol
+            if re.search(r"\bglobal_atomic_add(_x2)?\b.*\bsc0\b", l):
+                window = lines[max(0, i - 60):i]
+                last_wait = max((j for j, w in enumerate(window) if "s_waitcnt" in w and "vmcnt(0)" in w), default=None)
+                assert last_wait is not None, (head, l)
+                # no store may sit between the last vmcnt(0) wait and the ticket
+                between = window[last_wait + 1:]
+                assert not any(re.search(r"\b(global|buffer|flat)_store", b) for b in between), (head, between)
+                checked += 1
+    assert checked >= 1, "no ticket atomic found in " + unit

@@ -393,3 +393,30 @@ def test_six_query_tiles_in_one_sweep_and_the_bf16x3_second_opinion(ctx, oracle)
     s3 = st.stats()
     assert s3["scan_launches"] - s2["scan_launches"] >= 3         # the bf16x3 re-run swept again
     assert s3["exhaustive_reruns"] == s2["exhaustive_reruns"]    # ... and settled it
+
+
+@pytest.mark.parametrize("dim,batch2,batch3", [(1024, 80, 32), (1536, 48, 16)])
+def test_second_opinion_capacity_at_wide_dims(ctx, oracle, dim, batch2, batch3):
+    """the bf16x3 second opinion keeps both halves of the queries in LDS, so at d > 768 it takes fewer
+    query tiles per sweep than the bf16x2 main pass (d = 1024: 2 tiles of 64 KiB; d = 1536: 1 tile of 96 KiB) — with
+    more flagged queries in one step than that, the re-run must go sub-batch by sub-batch instead of asking for 192 KiB
+    of LDS.  Every query of the step points into a crowd of near-equal scores, so every one of them is flagged."""
+    if os.environ.get("MSI_VS_SCAN_MATH") in ("bf16x3", "f32"):
+        pytest.skip("the second opinion is the bf16x2 contraction's")
+    n = 6000
+    rng = np.random.default_rng(dim)
+    rows = synth.make_embeddings(n, dim, seed=95)
+    v = rng.standard_normal(dim).astype(f32)
+    rows[:300] = v[None, :] + 0.09 * rng.standard_normal((300, dim)).astype(f32) * (np.linalg.norm(v) / np.sqrt(dim))
+    ids = np.arange(n, dtype=np.uint32) * 2 + 1
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    assert st.max_batch == batch2
+    nq = batch2                       # one full step, more flagged queries than one second-opinion sweep holds
+    assert nq > batch3
+    qs = (v[None, :] * (1.0 + 0.01 * np.arange(nq, dtype=f32))[:, None]).astype(f32)     # same direction: same crowd
+    s0 = st.stats()
+    check_against_oracle(oracle, st, rows, ids, qs, 20)
+    s1 = st.stats()
+    # one dense pass (<= 32 Ki rows), then ceil(flagged / batch3) second-opinion passes: more than one sub-batch
+    assert s1["scan_launches"] - s0["scan_launches"] >= 1 + 2
