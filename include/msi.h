@@ -535,7 +535,10 @@ const uint64_t *msi_bits_device_ptr(msi_bits *pool, uint32_t slot);
  */
 #define MSI_RANK_MAX_TERMS 10          /* words_limit, crates/milli/src/search/mod.rs:111 */
 #define MSI_NO_SLOT 0xFFFFFFFFu
-enum { MSI_TERMS_LAST = 0, MSI_TERMS_ALL = 1 };
+/* TermsMatchingStrategy (crates/milli/src/search/mod.rs:538-556).  MSI_TERMS_FREQUENCY: the terms are dropped in order of
+ * decreasing document frequency (query_graph.rs:303-344) — msi_keyword_search_ranked only; the [Words, Typo] fast path
+ * (msi_rank_query_graph / msi_keyword_search) answers MSI_E_UNSUPPORTED for it. */
+enum { MSI_TERMS_LAST = 0, MSI_TERMS_ALL = 1, MSI_TERMS_FREQUENCY = 2 };
 typedef struct msi_rank_term {
   uint32_t level_slot[3];  /* pool slot of the 0 / 1 / 2 typo documents, or MSI_NO_SLOT */
   uint32_t max_typo_cost;  /* 0..2 */
@@ -761,7 +764,7 @@ typedef struct msi_geo_rule {
 } msi_geo_rule;
 typedef struct msi_search_params {
   uint32_t authorize_typos, min_word_len_one_typo, min_word_len_two_typos;
-  int32_t strategy;                    /* MSI_TERMS_LAST | MSI_TERMS_ALL */
+  int32_t strategy;                    /* MSI_TERMS_LAST | MSI_TERMS_ALL | MSI_TERMS_FREQUENCY */
   const int32_t *criteria;             /* index.criteria as MSI_CRIT_* */
   uint32_t n_criteria;
   const uint16_t *searchable_fids;     /* searchable_fields_ids, with their weights (fieldids_weights_map) */

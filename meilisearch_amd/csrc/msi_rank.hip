@@ -391,6 +391,11 @@ int32_t build_args(msi_bits *pool, const msi_rank_node *nodes, uint32_t n_nodes,
       na.present |= 1u << s;
     }
   }
+  if (strategy != MSI_TERMS_LAST && strategy != MSI_TERMS_ALL) {
+    // MSI_TERMS_FREQUENCY orders the removals by document frequency: msi_keyword_search_ranked (msi_search.hip)
+    msi_set_error("msi_rank: this fast path knows MSI_TERMS_LAST and MSI_TERMS_ALL (use msi_keyword_search_ranked)");
+    return MSI_E_UNSUPPORTED;
+  }
   a.n_words = msi_bits_words_per_slot(pool);
   a.n_terms = n_terms;
   a.strategy_all = strategy == MSI_TERMS_ALL;

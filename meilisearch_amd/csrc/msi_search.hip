@@ -533,6 +533,7 @@ struct Dev {
     g_stats.launches += 2;
     ++g_stats.syncs;
     ck(msi_bits_order_next(pool.p, keys, universe->slot, b->slot, key, count));
+    direct_done();
     g_stats.device_wait_ms += ck_.ms();
     return b;
   }
@@ -546,6 +547,11 @@ struct Dev {
     ++g_stats.syncs;
     ck(msi_bits_geo_next(pool.p, r.points, universe->slot, b->slot, scratch->slot, r.lat, r.lng, r.ascending, cap, margin,
                          first, count));
+    // The completion signal comes from the LAST WORKGROUP of the take kernel, not from the end of the kernel: the set
+    // words the other workgroups stored may still sit in their XCDs' L2 (written back when the kernel ends).  The next
+    // command list runs on another stream — it would overtake that write-back and read stale universe / bucket words
+    // (seen on the MI355X as a rare wrong bucket with four searches in flight).  As after `distinct`: wait for the stream.
+    direct_done();
     g_stats.device_wait_ms += ck_.ms();
     return b;
   }
@@ -573,7 +579,8 @@ struct Dev {
     direct_done();
     return exc;
   }
-  // a direct call may leave work on the pool's own stream: the next list must not overtake it
+  // a direct call may leave work on the pool's own stream — or, behind a completion signal that its last workgroup
+  // raised, dirty lines in an XCD's L2 until the kernel ends: the next list (another stream) must not overtake either
   void direct_done() {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) ck(msi_bits_sync(pool.p));
@@ -680,6 +687,27 @@ struct Dev {
     for (size_t k = 0; k < stack.size(); ++k) ss[k] = stack[k]->slot;
     ++g_stats.launches;
     ck(msi_bits_claim(pool.p, docs->slot, bucket->slot, universe->slot, (uint32_t)stack.size(), ss));
+  }
+  // the cardinalities of several sets: one list, one completion wait for all of them
+  std::vector<uint64_t> count_many(const std::vector<Set> &sets) {
+    std::vector<uint64_t> out(sets.size(), 0);
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (vm) {
+      for (size_t base = 0; base < sets.size(); base += 64) {
+        const uint32_t n = (uint32_t)std::min<size_t>(64, sets.size() - base);
+        const uint32_t ci = counts_for(n);
+        for (uint32_t i = 0; i < n; ++i) {
+          rd(sets[base + i]->slot);
+          rec({VM_COUNT, sets[base + i]->slot, ci + i});
+        }
+        run();
+        for (uint32_t i = 0; i < n; ++i) out[base + i] = res.counts[ci + i];
+      }
+      return out;
+    }
+#endif
+    for (size_t i = 0; i < sets.size(); ++i) out[i] = count(sets[i]);
+    return out;
   }
   uint64_t count(const Set &a) {
     uint64_t c = 0;
@@ -1617,15 +1645,10 @@ void remove_nodes_keep_edges(Graph &g, const std::vector<uint32_t> &ids) {
   }
 }
 
-// removal_order_for_terms_matching_strategy_last :346-406 — groups of nodes, first removed first
-std::vector<IdSet> removal_order_last(Ctx &c, const Graph &g) {
-  uint32_t first = 255, last = 0;
-  for (const GNode &n : g.nodes)
-    if (n.kind == 2) {
-      last = std::max(last, n.term.id_hi);
-      first = std::min(first, n.term.id_lo);
-    }
-  if (first >= last) return {};
+// removal_order_for_terms_matching_strategy :377-406 — groups of nodes by ascending cost (the largest `order` over the
+// node's term ids), first removed first; the last group stays unless a phrase / mandatory term keeps the query alive
+template <typename Order>
+std::vector<IdSet> removal_order(Ctx &c, const Graph &g, Order order) {
   std::map<uint32_t, IdSet> groups;
   bool mandatory = false;
   for (uint32_t i = 0; i < g.nodes.size(); ++i) {
@@ -1635,12 +1658,67 @@ std::vector<IdSet> removal_order_last(Ctx &c, const Graph &g) {
       mandatory = true;
       continue;
     }
-    groups[1 + last - n.term.id_lo].insert(i);  // max over the term ids of (1 + last - id)
+    uint32_t cost = 0;
+    for (uint32_t id = n.term.id_lo; id <= n.term.id_hi; ++id) cost = std::max(cost, (uint32_t)order(id));
+    groups[cost].insert(i);
   }
   std::vector<IdSet> res;
   for (auto &kv : groups) res.push_back(kv.second);
   if (!mandatory && !res.empty()) res.pop_back();
   return res;
+}
+
+// removal_order_for_terms_matching_strategy_last :346-375
+std::vector<IdSet> removal_order_last(Ctx &c, const Graph &g) {
+  uint32_t first = 255, last = 0;
+  for (const GNode &n : g.nodes)
+    if (n.kind == 2) {
+      last = std::max(last, n.term.id_hi);
+      first = std::min(first, n.term.id_lo);
+    }
+  if (first >= last) return {};
+  return removal_order(c, g, [last](uint32_t id) { return 1 + last - id; });
+}
+
+// removal_order_for_terms_matching_strategy_frequency :303-344 — per term id the number of documents of the union of
+// the nodes that cover it (n-gram nodes count for each of their ids; no document at all counts as the LARGEST
+// frequency); the most frequent term gets weight 1 and is removed first, equal frequencies share a weight.  The unions
+// and all their cardinalities are ONE command list (VM_OP ... VM_COUNT x terms): one completion wait per call.
+std::vector<IdSet> removal_order_frequency(Ctx &c, const Graph &g) {
+  std::map<uint32_t, Set> term_docids;
+  for (const GNode &n : g.nodes) {
+    if (n.kind != 2) continue;
+    Set d = c.subset_full(n.term.subset);     // compute_query_term_subset_docids(ctx, None, subset): cached, never written
+    for (uint32_t id = n.term.id_lo; id <= n.term.id_hi; ++id) {
+      auto it = term_docids.find(id);
+      if (it == term_docids.end()) term_docids.emplace(id, c.dev.clone(d));
+      else c.dev.or_(it->second, d);
+    }
+  }
+  std::vector<Set> sets;
+  std::vector<std::pair<uint32_t, uint64_t>> tf;
+  for (auto &kv : term_docids) {
+    tf.push_back({kv.first, 0});
+    sets.push_back(kv.second);
+  }
+  const std::vector<uint64_t> counts = c.dev.count_many(sets);
+  for (size_t i = 0; i < tf.size(); ++i) tf[i].second = counts[i] ? counts[i] : ~0ull;
+  std::stable_sort(tf.begin(), tf.end(), [](const std::pair<uint32_t, uint64_t> &a, const std::pair<uint32_t, uint64_t> &b) {
+    return a.second > b.second;               // sort_by_key(Reverse(frequency)): stable over ascending term ids
+  });
+  std::map<uint32_t, uint32_t> weight_of;
+  uint32_t weight = 1;
+  for (size_t i = 0; i < tf.size(); ++i) {
+    weight_of[tf[i].first] = weight;
+    if (i + 1 < tf.size() && tf[i + 1].second != tf[i].second) ++weight;
+  }
+  return removal_order(c, g, [&weight_of](uint32_t id) { return weight_of.at(id); });
+}
+
+std::vector<IdSet> removal_order_of(Ctx &c, const Graph &g, int strategy) {
+  if (strategy == MSI_TERMS_LAST) return removal_order_last(c, g);
+  if (strategy == MSI_TERMS_FREQUENCY) return removal_order_frequency(c, g);
+  return {};
 }
 
 uint32_t words_in_phrases_count(Ctx &c, const Graph &g) {
@@ -1972,7 +2050,7 @@ struct Bucket {
 
 struct Rule {
   int kind;
-  int tms;  // -1 none, MSI_TERMS_LAST, MSI_TERMS_ALL
+  int tms;  // -1 none, MSI_TERMS_LAST, MSI_TERMS_ALL, MSI_TERMS_FREQUENCY
   Rule(int k, int t) : kind(k), tms(t) {}
   virtual ~Rule() {}
   virtual void start(Ctx &c, const Set &universe, const Graph &g) = 0;
@@ -2041,9 +2119,9 @@ struct GraphRule : Rule {
     if (tms >= 0) {
       const uint32_t wp = words_in_phrases_count(c, g);
       next_max_cost += wp > 0 ? wp - 1 : 0;
-      if (tms == MSI_TERMS_LAST) {
+      if (tms == MSI_TERMS_LAST || tms == MSI_TERMS_FREQUENCY) {
         IdSet forbidden;
-        for (auto &ns : removal_order_last(c, g)) {
+        for (auto &ns : removal_order_of(c, g, tms)) {
           for (uint32_t n : ns) skip_cost[n] = {1, forbidden};
           forbidden.insert(ns.begin(), ns.end());
         }
@@ -2843,9 +2921,9 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   const bool placeholder = ts.empty();
   if (!placeholder) {
     Graph reduced = g;
-    if (p->strategy == MSI_TERMS_LAST) {
+    if (p->strategy == MSI_TERMS_LAST || p->strategy == MSI_TERMS_FREQUENCY) {
       std::vector<uint32_t> rm;
-      for (auto &ns : removal_order_last(c, g)) rm.insert(rm.end(), ns.begin(), ns.end());
+      for (auto &ns : removal_order_of(c, g, p->strategy)) rm.insert(rm.end(), ns.begin(), ns.end());
       remove_nodes_keep_edges(reduced, rm);
     }
     Set d = query_graph_docids(c, reduced, universe);

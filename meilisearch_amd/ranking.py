@@ -13,7 +13,12 @@ from ._lib import (GeoRule, EXACT_WORD_FN, FID_COUNT_DOCIDS_FN, PAIR_DOCIDS_FN, 
 from .device import np_ptr
 
 NO_SLOT = 0xFFFFFFFF
-TERMS_LAST, TERMS_ALL = 0, 1
+TERMS_LAST, TERMS_ALL, TERMS_FREQUENCY = 0, 1, 2      # include/msi.h: MSI_TERMS_*
+
+
+def strategy_of(tms):
+    """"last" | "all" | "frequency" (the request's matchingStrategy) -> MSI_TERMS_*"""
+    return {"last": TERMS_LAST, "all": TERMS_ALL, "frequency": TERMS_FREQUENCY}[tms]
 MAX_TERMS = 10
 
 

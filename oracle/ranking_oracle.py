@@ -414,15 +414,8 @@ class QueryGraph:
                 self.nodes[s].preds |= pr
             n.kind, n.term, n.preds, n.succs = "deleted", None, set(), set()
 
-    def removal_order_last(self, ctx):
-        """removal_order_for_terms_matching_strategy_last, :346-375 + :377-406: [set(node)], first removed first."""
-        first, last = 255, 0
-        for n in self.nodes:
-            if n.kind == "term":
-                last = max(last, n.term.term_ids[1])
-                first = min(first, n.term.term_ids[0])
-        if first >= last:
-            return []
+    def removal_order(self, ctx, order):
+        """removal_order_for_terms_matching_strategy, :377-406: [set(node)], first removed first; order(term id) -> cost."""
         groups, mandatory = {}, False
         for i, n in enumerate(self.nodes):
             if n.kind != "term":
@@ -430,12 +423,50 @@ class QueryGraph:
             if ctx.original_phrase(n.term.subset) is not None or n.term.subset.mandatory:
                 mandatory = True
                 continue
-            cost = max(1 + last - t for t in range(n.term.term_ids[0], n.term.term_ids[1] + 1))
+            cost = max(order(t) for t in range(n.term.term_ids[0], n.term.term_ids[1] + 1))
             groups.setdefault(cost, set()).add(i)
         res = [groups[c] for c in sorted(groups)]
         if not mandatory and res:
             res.pop()
         return res
+
+    def removal_order_last(self, ctx):
+        """removal_order_for_terms_matching_strategy_last, :346-375."""
+        first, last = 255, 0
+        for n in self.nodes:
+            if n.kind == "term":
+                last = max(last, n.term.term_ids[1])
+                first = min(first, n.term.term_ids[0])
+        if first >= last:
+            return []
+        return self.removal_order(ctx, lambda t: 1 + last - t)
+
+    def removal_order_frequency(self, ctx):
+        """removal_order_for_terms_matching_strategy_frequency, :303-344: per term id the documents of every node that
+        covers it (universe None); no document = u64::MAX; sort_by_key(Reverse(frequency)) is stable over the BTreeMap's
+        ascending ids; the most frequent term gets weight 1 (removed first), equal frequencies share a weight."""
+        term_docids = {}
+        for n in self.nodes:
+            if n.kind != "term":
+                continue
+            docids = ctx.subset_docids(None, n.term.subset)
+            for t in range(n.term.term_ids[0], n.term.term_ids[1] + 1):
+                term_docids[t] = (term_docids[t] | docids) if t in term_docids else DocSet(docids)
+        twf = [(t, len(d) if len(d) else (1 << 64) - 1) for t, d in sorted(term_docids.items())]
+        twf.sort(key=lambda x: -x[1])
+        weight, w = {}, 1
+        for k, (t, f) in enumerate(twf):
+            weight[t] = w
+            if k + 1 < len(twf) and twf[k + 1][1] != f:
+                w += 1
+        return self.removal_order(ctx, lambda t: weight[t])
+
+    def removal_order_of(self, ctx, tms):
+        if tms == "last":
+            return self.removal_order_last(ctx)
+        if tms == "frequency":
+            return self.removal_order_frequency(ctx)
+        return []
 
     def words_in_phrases_count(self, ctx):
         c = 0
@@ -749,7 +780,7 @@ def global_score(scores):
 # ---- the generic graph-based rule ---------------------------------------------------------------------
 class GraphRule:
     def __init__(self, kind, tms=None):
-        """tms: None | "last" | "all" (terms matching strategy; only Words has one)."""
+        """tms: None | "last" | "all" | "frequency" (terms matching strategy; only Words has one)."""
         self.kind, self.tms = kind, tms
 
     def start_iteration(self, ctx, universe, graph):
@@ -758,9 +789,9 @@ class GraphRule:
         skip_cost = {}
         if self.tms is not None:
             next_max_cost += max(0, graph.words_in_phrases_count(ctx) - 1)
-            if self.tms == "last":
+            if self.tms in ("last", "frequency"):           # graph_based_ranking_rule.rs:160-190
                 forbidden = set()
-                for ns in graph.removal_order_last(ctx):
+                for ns in graph.removal_order_of(ctx, self.tms):
                     for n in ns:
                         skip_cost[n] = (1, frozenset(forbidden))
                     forbidden |= ns
@@ -1407,8 +1438,8 @@ def search(ctx, query, tms="last", criteria=None, offset=0, length=20, detailed=
     graph = QueryGraph.from_query(ctx, terms)
     rules = ranking_rules(criteria if criteria is not None else index.criteria, tms, sort)
     reduced = graph.clone()
-    if tms == "last":
-        reduced.remove_nodes_keep_edges([n for ns in graph.removal_order_last(ctx) for n in sorted(ns)])
+    if tms in ("last", "frequency"):                        # resolve_maximally_reduced_query_graph, mod.rs:273-301
+        reduced.remove_nodes_keep_edges([n for ns in graph.removal_order_of(ctx, tms) for n in sorted(ns)])
     universe &= query_graph_docids(ctx, reduced, universe)
     return exhaustive_candidates(ctx, distinct, exhaustive, bucket_sort(
         ctx, rules, graph, universe, offset, length, detailed, Deadline(stop_after), threshold, distinct, exhaustive,

@@ -283,9 +283,18 @@ pub enum RankedScore {
     GeoSort { rule: u32, first_docid: u32 },
 }
 
+/// `milli::TermsMatchingStrategy` (crates/milli/src/search/mod.rs:538-556)
+#[derive(Clone, Copy, PartialEq, Eq)]
+pub enum TermsStrategy { Last, All, Frequency }
+impl TermsStrategy {
+    fn as_msi(self) -> i32 {
+        match self { Self::Last => sys::MSI_TERMS_LAST, Self::All => sys::MSI_TERMS_ALL, Self::Frequency => sys::MSI_TERMS_FREQUENCY }
+    }
+}
+
 pub struct RankedSearch<'a> {
     pub criteria: &'a [i32],                // index.criteria() as sys::MSI_CRIT_*
-    pub all_terms: bool,
+    pub strategy: TermsStrategy,
     pub searchable: &'a [(u16, u16)],       // (fid, weight) of searchable_fields_ids / fieldids_weights_map
     pub max_weight: Option<u16>,
     pub authorize_typos: bool,
@@ -461,7 +470,7 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
     let params = sys::msi_search_params {
         authorize_typos: q.authorize_typos as u32, min_word_len_one_typo: q.min_word_len_one_typo,
         min_word_len_two_typos: q.min_word_len_two_typos,
-        strategy: if q.all_terms { sys::MSI_TERMS_ALL } else { sys::MSI_TERMS_LAST },
+        strategy: q.strategy.as_msi(),
         criteria: q.criteria.as_ptr(), n_criteria: q.criteria.len() as u32,
         searchable_fids: fids.as_ptr(), searchable_weights: weights.as_ptr(), n_searchable: fids.len() as u32,
         max_weight: q.max_weight.map_or(-1, |w| w as i32), from: q.from as u32, length: q.length as u32,

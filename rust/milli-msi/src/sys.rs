@@ -47,6 +47,7 @@ pub const MSI_BITS_ANDNOT: i32 = 2;
 pub const MSI_BITS_XOR: i32 = 3;
 pub const MSI_TERMS_LAST: i32 = 0;
 pub const MSI_TERMS_ALL: i32 = 1;
+pub const MSI_TERMS_FREQUENCY: i32 = 2;
 pub const MSI_NO_SLOT: u32 = 0xFFFF_FFFF;
 pub const MSI_RANK_MAX_TERMS: usize = 10;
 

@@ -31,7 +31,7 @@ class Harness:
         R, ix = self.R, self.index
         return R.keyword_search_ranked(
             self.dict, self.pool, self.cb, query_terms(query, stop_words=ix.stop_words), criteria if criteria is not None else ix.criteria,
-            strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
+            strategy=R.strategy_of(tms), offset=offset, limit=limit, detailed=detailed,
             searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
             max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,
             stop_after=stop_after)
@@ -139,7 +139,7 @@ def test_matches_oracle_on_random_corpora(seed, prefix_threshold):
             return [index.words[i] for i in one], [index.words[i] for i in two]
         h = Harness(index)
         for q in QUERIES:
-            for tms in ("last", "all"):
+            for tms in ("last", "all", "frequency"):
                 for detailed, offset in ((True, 0), (False, 3)):
                     want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms=tms, criteria=criteria,
                                                              offset=offset, length=25, detailed=detailed)
@@ -149,7 +149,7 @@ def test_matches_oracle_on_random_corpora(seed, prefix_threshold):
                         [[oracle_score(s) for s in sc] for sc in want_sc], (criteria, q, tms)
                     assert cand == len(want_cand)
                     checked += 1
-    assert checked == len(RULESETS) * len(QUERIES) * 4
+    assert checked == len(RULESETS) * len(QUERIES) * 6
 
 
 def oracle_score(s):
@@ -246,7 +246,7 @@ def test_matches_oracle_under_index_settings(settings):
     h = Harness(index)
     queries = QUERIES + ["fast brown fox", "sunflower holiday", "the lazy dog jumps", "quick", "qu", "\"sun flower\" the"]
     for q in queries:
-        for tms in ("last", "all"):
+        for tms in ("last", "all", "frequency"):
             for detailed, offset in ((True, 0), (False, 2)):
                 want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms=tms, offset=offset, length=30,
                                                          detailed=detailed)
@@ -293,3 +293,16 @@ def test_path_by_path_fallback_matches_too(monkeypatch):
     monkeypatch.setenv("MSI_SEARCH_FUSED_LEVELS", "0")
     for case in CASES[::3]:
         test_reference_snapshot(case)
+
+
+def test_reference_matching_strategy_literals_on_the_device():
+    """crates/meilisearch/tests/search/matching_strategy.rs: the hit ids of its 9 searches (three per strategy; the only
+    literals the reference holds for TermsMatchingStrategy::Frequency) through msi_keyword_search_ranked."""
+    from tests.toy_milli import ToyMilli
+    fix = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matching_strategy_fixtures.json")))
+    index = ToyMilli(fix["documents"])
+    h = Harness(index)
+    assert sum(1 for c in fix["cases"] if c["strategy"] == "frequency") == 3
+    for case in fix["cases"]:
+        hits, _ = h.search(case["query"], tms=case["strategy"], limit=20)
+        assert [index.docs[d]["id"] for d, _ in hits] == case["ids"], case

@@ -157,7 +157,7 @@ class MockHarness:
         try:
             out = R.keyword_search_ranked(
                 self.dict, self.pool, self.cb, query_terms(query, stop_words=ix.stop_words) + list(extra_terms), crit,
-                strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
+                strategy=R.strategy_of(tms), offset=offset, limit=limit, detailed=detailed,
                 searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
                 max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,
                 stop_after=stop_after, order_keys=handles, distinct_values=dv, _entry=self.entry,
@@ -273,7 +273,7 @@ def test_host_logic_matches_oracle_on_random_corpora(hostlib, monkeypatch, per_w
                 return [index.words[i] for i in one], [index.words[i] for i in two]
             h = make_harness(hostlib, index)
             for q in G.QUERIES:
-                for tms in ("last", "all"):
+                for tms in ("last", "all", "frequency"):
                     want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms=tms, criteria=criteria, length=25,
                                                              detailed=True)
                     hits, cand = h.search(q, tms=tms, criteria=criteria, limit=25, detailed=True)
@@ -301,7 +301,7 @@ def test_long_queries_match_the_oracle(hostlib, monkeypatch, per_wait):
     for n in (6, 8, 10):
         for _ in range(4):
             q = " ".join(rng.choice(G.VOCAB) for _ in range(n))
-            for tms in ("last", "all"):
+            for tms in ("last", "all", "frequency"):
                 want_ids, want_sc, want_cand = RO.search(RO.Ctx(index, lookup), q, tms=tms, length=20, detailed=True)
                 hits, cand = h.search(q, tms=tms, limit=20, detailed=True)
                 assert [d for d, _ in hits] == want_ids, (q, tms)
@@ -635,6 +635,19 @@ def run_fuzz_seeds(seeds, *mode):
                              cwd=ROOT, capture_output=True, text=True, timeout=600)
         tail = out.stdout[-2000:] + out.stderr[-2000:]
         assert out.returncode == 0 and "cases 6 bad 0" in out.stdout, tail   # (six searches per seed)
+
+
+def test_reference_matching_strategy_literals_through_the_host_logic(hostlib):
+    """crates/meilisearch/tests/search/matching_strategy.rs (tests/golden/matching_strategy_fixtures.json): last / all /
+    frequency, three searches each — the only literals the reference holds for TermsMatchingStrategy::Frequency."""
+    import json
+    fix = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matching_strategy_fixtures.json")))
+    index = ToyMilli(fix["documents"])
+    h = make_harness(hostlib, index)
+    for case in fix["cases"]:
+        hits, _ = h.search(case["query"], tms=case["strategy"], limit=20)
+        assert [index.docs[d]["id"] for d, _ in hits] == case["ids"], case
+    h.close()
 
 
 def test_fuzz_regressions():

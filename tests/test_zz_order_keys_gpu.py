@@ -65,7 +65,7 @@ class SortHarness:
             tables.append((field, asc, values))
         hits, cand = R.keyword_search_ranked(
             h.dict, h.pool, h.cb, query_terms(query, stop_words=ix.stop_words), crit,
-            strategy=R.TERMS_ALL if tms == "all" else R.TERMS_LAST, offset=offset, limit=limit, detailed=detailed,
+            strategy=R.strategy_of(tms), offset=offset, limit=limit, detailed=detailed,
             searchable_fids=ix.searchable_fids, searchable_weights=[ix.weights[f] for f in ix.searchable_fids],
             max_weight=ix.max_weight, authorize_typos=ix.authorize_typos, min_one=ix.min_one, min_two=ix.min_two,
             order_keys=keys)

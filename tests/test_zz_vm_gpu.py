@@ -147,7 +147,7 @@ def test_documents_spread_over_many_chunks(monkeypatch):
         def spread(case):
             hits, _ = R.keyword_search_ranked(
                 dictionary, pool, cb, query_terms(case["query"], stop_words=index.stop_words), index.criteria,
-                strategy=R.TERMS_ALL if case["tms"] == "all" else R.TERMS_LAST, offset=case["offset"], limit=case["limit"],
+                strategy=R.strategy_of(case["tms"]), offset=case["offset"], limit=case["limit"],
                 detailed=True, searchable_fids=index.searchable_fids,
                 searchable_weights=[index.weights[f] for f in index.searchable_fids], max_weight=index.max_weight,
                 authorize_typos=index.authorize_typos, min_one=index.min_one, min_two=index.min_two,

@@ -106,7 +106,7 @@ while time.time() < t_end:
         if rng.random()<0.25 and nt>=2:
             k=rng.randrange(nt-1); ws2=ws[:]; ws2[k]='"'+ws2[k]; ws2[k+1]=ws2[k+1]+'"'; q=" ".join(ws2)
         if rng.random()<0.2: q += " "
-        tms = rng.choice(["last","all"]); detailed=rng.random()<0.5; offset=rng.choice([0,0,1,5]); limit=rng.choice([1,5,20,100])
+        tms = rng.choice(["last","all","frequency"]); detailed=rng.random()<0.5; offset=rng.choice([0,0,1,5]); limit=rng.choice([1,5,20,100])
         thr = rng.choice([None,None,0.3,0.7,0.9]); sa = rng.choice([None,None,None,0,1,2,4])
         negs = []
         if rng.random() < 0.2:
