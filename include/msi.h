@@ -829,6 +829,10 @@ int32_t msi_bits_vm_stats(msi_bits *pool, uint64_t out[6]);
  * [kernel launches, stream syncs, decode batches, index callbacks, posting bytes decoded, matching paths,
  *  buckets, callback microseconds, device-wait microseconds, total microseconds]. */
 int32_t msi_search_last_stats(uint64_t out[10]);
+/* Diagnostics, process-wide: [ranked keyword searches, of them continued in the COMPACT SPACE (once a search knows its
+ * universe — the documents that match the query at all — every later set is kept over the ranks of the documents inside
+ * it, |universe| bits instead of n_docs: DESIGN.md §4.7.2), documents of those universes summed]. */
+int32_t msi_search_compaction_stats(uint64_t out[3]);
 
 /* ---------------------------------------------------- scoring arithmetic (host) */
 /* DistributionShift::shift (crates/milli/src/vector/distribution.rs:103-130). */

@@ -61,6 +61,15 @@ struct msi_bits {
   uint64_t vm_seq = 0;
   uint8_t *vm_stage = nullptr;   // pinned staging of the decode payloads of the list being recorded
   size_t vm_stage_cap = 0;
+  // Universe compaction of the ranked keyword search (msi_search.hip, "compact space"): once a search knows its initial
+  // universe U0 — typically well under 1 % of the index — every later set is a subset of it and is kept over the RANKS of
+  // the documents inside U0 instead of over docids: |U0| bits per set instead of n_docs.  The sets of that space live in
+  // a companion pool (created on first use, |U0| <= its n_docs); the tables that map between the spaces — per-chunk
+  // cardinalities of U0, exclusive prefix popcounts per word of U0, rank -> docid — are `caux`, written by the VM_RANK
+  // commands of a list on THIS pool (msi_vm.hip).
+  msi_bits *companion = nullptr;
+  DevBuf caux;
+  uint64_t caux_cap = 0;
   u64 *slot(uint32_t s) const { return pool.as<u64>() + (uint64_t)s * n_words; }
 };
 
@@ -139,6 +148,39 @@ uint8_t *msi_bits_vm_stage(msi_bits *p, size_t need, size_t keep) {
   p->vm_stage = (uint8_t *)h;
   p->vm_stage_cap = cap;
   return p->vm_stage;
+}
+// The companion pool of the compact space and the capacity (documents of U0) it was made for: an eighth of the index
+// (beyond that the set words saved no longer pay for the mapping), the whole index for pools of at most one chunk (tests).
+uint64_t msi_bits_compact_capacity(const msi_bits *p) {
+  if (p->n_docs <= 65536) return p->n_docs;
+  return std::max<uint64_t>(65536, (p->n_docs / 8 + 127) & ~127ull);
+}
+msi_bits *msi_bits_compact_pool(msi_bits *p) {
+  if (!p->companion) {
+    msi_bits *c = nullptr;
+    if (msi_bits_create(p->ctx, std::max<uint64_t>(1, msi_bits_compact_capacity(p)), p->n_slots, &c) != MSI_OK) return nullptr;
+    // its creation memsets ran on the context's stream; the command lists run on the combiner's
+    {
+      std::lock_guard<std::mutex> lk(p->ctx->mu);
+      DeviceGuard g(p->ctx->device);
+      if (hipStreamSynchronize(p->ctx->stream) != hipSuccess) {
+        msi_bits_destroy(c);
+        return nullptr;
+      }
+    }
+    p->companion = c;
+  }
+  return p->companion;
+}
+// [chunk cardinalities: n_chunks u32, padded to 4][prefix: n_words u32, padded to 4][rank -> docid: capacity u32]
+uint32_t *msi_bits_compact_aux(msi_bits *p) {
+  const uint64_t n_chunks = (p->n_words + 1023) / 1024;
+  const uint64_t words = ((n_chunks + 3) & ~3ull) + ((p->n_words + 3) & ~3ull) + ((msi_bits_compact_capacity(p) + 3) & ~3ull);
+  if (!p->caux.p) {
+    DeviceGuard g(p->ctx->device);
+    if (p->caux.ensure((size_t)words * sizeof(uint32_t)) != MSI_OK) return nullptr;
+  }
+  return p->caux.as<uint32_t>();
 }
 // waits for everything enqueued on the pool's own stream (the command-list path runs on the combiner's stream)
 int32_t msi_bits_sync(msi_bits *p) {
@@ -1179,8 +1221,11 @@ void msi_bits_destroy(msi_bits *p) {
   if (p->vm_block) (void)hipHostFree(p->vm_block);
   if (p->vm_stage) (void)hipHostFree(p->vm_stage);
   if (p->private_stream) (void)hipStreamDestroy(p->stream);
-  delete p;
+  p->caux.release();
   }
+  msi_bits *companion = p->companion;
+  delete p;
+  if (companion) msi_bits_destroy(companion);
   msi_ctx_release(ctx);
 }
 

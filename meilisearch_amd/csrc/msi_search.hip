@@ -53,6 +53,7 @@ struct msi_dict;
 bool msi_dict_word(const msi_dict *d, uint32_t idx, const uint8_t **w, uint32_t *len);
 void msi_dict_prefix_range(const msi_dict *d, const uint8_t *prefix, uint32_t plen, uint32_t *lo, uint32_t *hi);
 uint32_t msi_bits_n_slots(msi_bits *p);
+uint64_t msi_bits_n_docs(msi_bits *p);
 
 namespace {
 
@@ -71,6 +72,8 @@ struct Stats {
   double callback_ms = 0, device_wait_ms = 0, total_ms = 0;
 };
 thread_local Stats g_stats;
+// process-wide: searches that continued in the compact space, and the documents of their universes (msi_search_compaction_stats)
+std::atomic<uint64_t> g_compact_searches{0}, g_compact_docs{0}, g_ranked_searches{0};
 struct Clock {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
@@ -188,8 +191,17 @@ struct SetPool {
   // command-list back end: a slot handed out as "all zero" is only zeroed when something READS it (most are first
   // written whole — the bucket of a cost level, a decode — or never used at all)
   std::vector<uint8_t> lazy_zero;
+  // compact space (Dev::compact_begin): the decodes of a list are hoisted into a phase of their own that runs FIRST, so a
+  // slot freed while a list is being recorded must not be handed out again (as a decode's destination) before that list
+  // has run — it waits here
+  bool hold = false;
+  std::vector<uint32_t> held;
   SetPool(msi_bits *p_, uint32_t first) : p(p_), lazy_zero(msi_bits_n_slots(p_), 0) {
     for (uint32_t s = msi_bits_n_slots(p_); s-- > first;) free_.push_back(s);
+  }
+  void release_held() {
+    free_.insert(free_.end(), held.begin(), held.end());
+    held.clear();
   }
 };
 struct SetH {
@@ -197,7 +209,8 @@ struct SetH {
   uint32_t slot;
   ~SetH() {
     pool->lazy_zero[slot] = 0;
-    pool->free_.push_back(slot);
+    if (pool->hold) pool->held.push_back(slot);
+    else pool->free_.push_back(slot);
   }
 };
 using Set = std::shared_ptr<SetH>;
@@ -217,7 +230,11 @@ struct PathSlots {
 };
 
 struct Dev {
-  SetPool pool;
+  SetPool pool;                        // the caller's pool: sets over docids
+  SetPool *cur = &pool;                // the pool every operation works on: `pool`, or — after compact_begin — `cpool`
+  std::unique_ptr<SetPool> cpool;      // the companion pool: sets over the ranks of the documents of U0 (universe compaction)
+  Set u0_full;                         // U0 in the caller's pool (read by the compact lists' decodes)
+  std::vector<Set> keep_until_run;     // full-space sets the recorded list still reads
 #ifndef MSI_SEARCH_DIRECT_ONLY
   bool vm = true;
   MsiVmList list;
@@ -264,7 +281,7 @@ struct Dev {
   void open_list() {
     if (!list.empty()) return;
     list.begin();
-    if (msi_bits_take_summary_dirty(pool.p)) list.words.push_back(VM_SUMMARY_RESET);
+    if (msi_bits_take_summary_dirty(cur->p)) list.words.push_back(VM_SUMMARY_RESET);
   }
   void rec(std::initializer_list<uint32_t> w) {
     open_list();
@@ -272,12 +289,12 @@ struct Dev {
   }
   // the slot is about to be READ: a lazily zeroed slot is zeroed now
   void rd(uint32_t slot) {
-    if (!pool.lazy_zero[slot]) return;
-    pool.lazy_zero[slot] = 0;
+    if (!cur->lazy_zero[slot]) return;
+    cur->lazy_zero[slot] = 0;
     rec({VM_CLEAR, 1u, slot});
   }
   // the slot is about to be overwritten whole
-  void wr(uint32_t slot) { pool.lazy_zero[slot] = 0; }
+  void wr(uint32_t slot) { cur->lazy_zero[slot] = 0; }
   // submit what was recorded and wait for it: the only blocking point of the command-list back end
   Tasks *tasks = nullptr;   // set while the bucket sort runs as cooperative tasks
   void run() {
@@ -294,9 +311,11 @@ struct Dev {
     ++g_stats.launches;
     ++g_stats.syncs;
     list.cache_base = msi_pcache_device_base(pcache);
-    const int32_t st = msi_vm_run(pool.p, list, &res);
+    const int32_t st = msi_vm_run(cur->p, list, &res);
     g_stats.device_wait_ms += ck_.ms();
     list.clear();
+    keep_until_run.clear();
+    cur->release_held();
     for (void *t : fills) {
       if (st == MSI_OK) msi_pcache_commit(pcache, t);
       else msi_pcache_abandon(pcache, t);
@@ -313,7 +332,7 @@ struct Dev {
   // direct calls (GeoSort, distinct) see everything recorded so far
   void settle() {
     if (!vm) return;
-    for (uint32_t sl = 0; sl < pool.lazy_zero.size(); ++sl) rd(sl);
+    for (uint32_t sl = 0; sl < cur->lazy_zero.size(); ++sl) rd(sl);
     run();
   }
   uint32_t counts_for(uint32_t n) {   // room for n more cardinalities in this list (else it runs first)
@@ -327,16 +346,73 @@ struct Dev {
   void settle() {}
   void flush() {}
 #endif
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  // ---- universe compaction ------------------------------------------------------------------------------------------
+  // At 10 M documents a detailed 3-term search moved ~0.5 GB of set words per query through HBM (PMC, r3_pmc_ranked10):
+  // every set operation of every rule swept 1.25 MB sets although the search's universe — the documents that match the
+  // query at all — was 60 000 documents, 0.6 % of the index, spread over every chunk.  Every set a rule works with is a
+  // subset of that universe U0, so once U0 is known the search continues in the COMPACT SPACE: document = its rank inside
+  // U0 (monotone in the docid: ascending order, first-k and every set operation mean the same), a set = |U0| bits.
+  // Postings are decoded straight into that space (VM_DECODEC), first-k ids leave it through the rank -> docid table.
+  // The tables are filled by two commands that ride in the list that counts U0 (rank_tables).
+  static int compact_mode() {   // MSI_SEARCH_COMPACT: 0 off, 1 when it pays (default), 2 always (tests: tiny corpora too)
+    static const int m = getenv("MSI_SEARCH_COMPACT") ? atoi(getenv("MSI_SEARCH_COMPACT")) : 1;
+    return m;
+  }
+  bool compact() const { return cur != &pool; }
+  void rank_tables(const Set &u0) {
+    rd(u0->slot);
+    open_list();
+    if (list.phase_start.size() + 1 > MSI_VM_MAX_PHASES) run();
+    open_list();
+    msi_vm_record_rank(list, pool.p, u0->slot);
+  }
+  bool compact_pays(uint64_t n_u0) const {
+    const uint64_t n = msi_bits_n_docs(pool.p);
+    if (!n_u0 || n_u0 > msi_bits_compact_capacity(pool.p)) return false;
+    return compact_mode() >= 2 || (n > 65536 && n_u0 * 8 <= n);
+  }
+  void compact_begin(const Set &u0, uint64_t n_u0) {
+    if (!list.empty()) run();
+    msi_bits *cp = msi_bits_compact_pool(pool.p);
+    if (!cp) fail(MSI_E_OOM, "the companion pool of the compact space could not be created");
+    cpool.reset(new SetPool(cp, 0));
+    cpool->hold = true;
+    cur = cpool.get();
+    u0_full = u0;
+    list.clear();
+    list.geom_docs = n_u0;
+    list.full_pool = pool.p;
+    list.u0_slot = u0->slot;
+    g_compact_searches.fetch_add(1, std::memory_order_relaxed);
+    g_compact_docs.fetch_add(n_u0, std::memory_order_relaxed);
+  }
+  // the compact-space image of a set of the caller's pool (its documents that are in U0, as ranks)
+  Set compact_of(const Set &full) {
+    Set s = alloc();
+    wr(s->slot);
+    open_list();
+    msi_vm_record_compact(list, s->slot, full->slot);
+    keep_until_run.push_back(full);
+    return s;
+  }
+#endif
   Set alloc() {  // content undefined: the caller overwrites every word
-    if (pool.free_.empty()) {
-      if (pool.clean_.empty()) fail(MSI_E_OOM, "the msi_bits pool has no free slot left (create it with more slots)");
-      const uint32_t s = pool.clean_.back();
-      pool.clean_.pop_back();
-      return Set(new SetH{&pool, s});
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (cur->free_.empty() && cur->clean_.empty() && !cur->held.empty()) {
+      if (list.empty()) cur->release_held();
+      else run();   // (slots freed while this list was recorded come back once it has run)
     }
-    const uint32_t s = pool.free_.back();
-    pool.free_.pop_back();
-    return Set(new SetH{&pool, s});
+#endif
+    if (cur->free_.empty()) {
+      if (cur->clean_.empty()) fail(MSI_E_OOM, "the msi_bits pool has no free slot left (create it with more slots)");
+      const uint32_t s = cur->clean_.back();
+      cur->clean_.pop_back();
+      return Set(new SetH{cur, s});
+    }
+    const uint32_t s = cur->free_.back();
+    cur->free_.pop_back();
+    return Set(new SetH{cur, s});
   }
   void op(uint32_t d, uint32_t a, uint32_t b, int32_t o) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
@@ -348,7 +424,7 @@ struct Dev {
     }
 #endif
     ++g_stats.launches;
-    ck(msi_bits_op(pool.p, d, a, b, o));
+    ck(msi_bits_op(cur->p, d, a, b, o));
   }
   void fill(uint32_t d, int ones) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
@@ -358,7 +434,7 @@ struct Dev {
     }
 #endif
     ++g_stats.launches;
-    ck(msi_bits_fill(pool.p, d, ones));
+    ck(msi_bits_fill(cur->p, d, ones));
   }
   // Zeroed slots are handed out from a stock that one operation refills MSI_BITS_CLEAR_MAX at a time
   // (instead of one memset per set: a third of the launches of a search were clears).
@@ -366,16 +442,16 @@ struct Dev {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       Set s = alloc();
-      pool.lazy_zero[s->slot] = 1;
+      cur->lazy_zero[s->slot] = 1;
       return s;
     }
 #endif
-    if (pool.clean_.empty()) {
+    if (cur->clean_.empty()) {
       uint32_t batch[MSI_BITS_CLEAR_MAX];
       uint32_t n = 0;
-      while (n < MSI_BITS_CLEAR_MAX && !pool.free_.empty()) {
-        batch[n++] = pool.free_.back();
-        pool.free_.pop_back();
+      while (n < MSI_BITS_CLEAR_MAX && !cur->free_.empty()) {
+        batch[n++] = cur->free_.back();
+        cur->free_.pop_back();
       }
       if (!n) fail(MSI_E_OOM, "the msi_bits pool has no free slot left (create it with more slots)");
 #ifndef MSI_SEARCH_DIRECT_ONLY
@@ -386,13 +462,13 @@ struct Dev {
 #endif
       {
         ++g_stats.launches;
-        ck(msi_bits_clear_slots(pool.p, n, batch));
+        ck(msi_bits_clear_slots(cur->p, n, batch));
       }
-      for (uint32_t k = n; k-- > 0;) pool.clean_.push_back(batch[k]);
+      for (uint32_t k = n; k-- > 0;) cur->clean_.push_back(batch[k]);
     }
-    const uint32_t s = pool.clean_.back();
-    pool.clean_.pop_back();
-    return Set(new SetH{&pool, s});
+    const uint32_t s = cur->clean_.back();
+    cur->clean_.pop_back();
+    return Set(new SetH{cur, s});
   }
   Set ones() {
     Set s = alloc();
@@ -424,7 +500,7 @@ struct Dev {
       Clock ck_;
       ++g_stats.launches;
       ++g_stats.syncs;
-      ck(msi_bits_op_count(pool.p, s->slot, a->slot, b->slot, MSI_BITS_AND, count));
+      ck(msi_bits_op_count(cur->p, s->slot, a->slot, b->slot, MSI_BITS_AND, count));
       g_stats.device_wait_ms += ck_.ms();
     } else {
       op(s->slot, a->slot, b->slot, MSI_BITS_AND);
@@ -438,15 +514,17 @@ struct Dev {
     if (vm) {
       for (size_t base = 0; base < conds.size(); base += 256) {
         const uint32_t n = (uint32_t)std::min<size_t>(256, conds.size() - base);
+        // (the destinations first: an allocation may run the list recorded so far, or fail — never in mid-command)
+        std::vector<Set> ds(n);
+        for (uint32_t k = 0; k < n; ++k) ds[k] = alloc();
         const uint32_t cb = counts_for(n);
         rd(prefix->slot);
         for (uint32_t k = 0; k < n; ++k) rd(conds[base + k]->slot);
         rec({VM_AND_MANY, prefix->slot, n, cb});
         for (uint32_t k = 0; k < n; ++k) {
-          Set d = alloc();
           list.words.push_back(conds[base + k]->slot);
-          list.words.push_back(d->slot);
-          out.push_back({d, 0});
+          list.words.push_back(ds[k]->slot);
+          out.push_back({ds[k], 0});
         }
         run();
         for (uint32_t k = 0; k < n; ++k) out[base + k].second = res.counts[cb + k];
@@ -467,7 +545,7 @@ struct Dev {
       Clock ck_;
       ++g_stats.launches;
       ++g_stats.syncs;
-      ck(msi_bits_and_many_count(pool.p, prefix->slot, n, cs, ds, counts));
+      ck(msi_bits_and_many_count(cur->p, prefix->slot, n, cs, ds, counts));
       g_stats.device_wait_ms += ck_.ms();
       for (uint32_t k = 0; k < n; ++k) out.push_back({dst[k], counts[k]});
     }
@@ -481,7 +559,7 @@ struct Dev {
     rd(universe->slot);
     for (uint32_t sl : paths.slots) rd(sl);
     // a bucket that was handed out as "all zero" and never touched is written whole by the level: no clear at all
-    const uint32_t fresh = pool.lazy_zero[bucket->slot] ? 1u : 0u;
+    const uint32_t fresh = cur->lazy_zero[bucket->slot] ? 1u : 0u;
     wr(bucket->slot);
     rec({VM_PATHS, n, bucket->slot, universe->slot, cb, n_steps | (fresh << 31)});
     list.words.insert(list.words.end(), paths.off.begin(), paths.off.end());
@@ -503,7 +581,7 @@ struct Dev {
     Clock ck_;
     ++g_stats.launches;
     ++g_stats.syncs;
-    ck(msi_bits_paths_claim(pool.p, (uint32_t)paths.size(), paths.off.data(), paths.slots.data(), bucket->slot, universe->slot,
+    ck(msi_bits_paths_claim(cur->p, (uint32_t)paths.size(), paths.off.data(), paths.slots.data(), bucket->slot, universe->slot,
                             counts.data()));
     g_stats.device_wait_ms += ck_.ms();
     return counts;
@@ -532,7 +610,7 @@ struct Dev {
     Clock ck_;
     g_stats.launches += 2;
     ++g_stats.syncs;
-    ck(msi_bits_order_next(pool.p, keys, universe->slot, b->slot, key, count));
+    ck(msi_bits_order_next(cur->p, keys, universe->slot, b->slot, key, count));
     direct_done();
     g_stats.device_wait_ms += ck_.ms();
     return b;
@@ -545,7 +623,7 @@ struct Dev {
     Clock ck_;
     g_stats.launches += 2;
     ++g_stats.syncs;
-    ck(msi_bits_geo_next(pool.p, r.points, universe->slot, b->slot, scratch->slot, r.lat, r.lng, r.ascending, cap, margin,
+    ck(msi_bits_geo_next(cur->p, r.points, universe->slot, b->slot, scratch->slot, r.lat, r.lng, r.ascending, cap, margin,
                          first, count));
     // The completion signal comes from the LAST WORKGROUP of the take kernel, not from the end of the kernel: the set
     // words the other workgroups stored may still sit in their XCDs' L2 (written back when the kernel ends).  The next
@@ -563,7 +641,7 @@ struct Dev {
     settle();
     Clock ck_;
     uint32_t rounds = 0;
-    ck(msi_bits_distinct(pool.p, vals, work->slot, rem->slot, exc->slot, kept, &rounds));
+    ck(msi_bits_distinct(cur->p, vals, work->slot, rem->slot, exc->slot, kept, &rounds));
     rounds &= 0x7FFFFFFFu;
     g_stats.launches += 2 + 2 * rounds;
     g_stats.syncs += rounds;
@@ -575,7 +653,7 @@ struct Dev {
     Set exc = alloc();
     settle();
     g_stats.launches += 2;
-    ck(msi_bits_distinct_excluded(pool.p, vals, kept->slot, exc->slot));
+    ck(msi_bits_distinct_excluded(cur->p, vals, kept->slot, exc->slot));
     direct_done();
     return exc;
   }
@@ -583,7 +661,7 @@ struct Dev {
   // raised, dirty lines in an XCD's L2 until the kernel ends: the next list (another stream) must not overtake either
   void direct_done() {
 #ifndef MSI_SEARCH_DIRECT_ONLY
-    if (vm) ck(msi_bits_sync(pool.p));
+    if (vm) ck(msi_bits_sync(cur->p));
 #endif
   }
   // sets[i] -= removed, with the new cardinalities: one operation and one wait
@@ -611,7 +689,7 @@ struct Dev {
       Clock ck_;
       ++g_stats.launches;
       ++g_stats.syncs;
-      ck(msi_bits_andnot_many_count(pool.p, removed->slot, n, ss, out.data() + base));
+      ck(msi_bits_andnot_many_count(cur->p, removed->slot, n, ss, out.data() + base));
       g_stats.device_wait_ms += ck_.ms();
     }
     return out;
@@ -623,12 +701,12 @@ struct Dev {
       MsiCboBatch b;
       b.small_ids = ids;
       open_list();
-      ck(msi_vm_record_decode(list, pool.p, s->slot, b, true));
+      ck(msi_vm_record_decode(list, cur->p, s->slot, b, true));
       return s;
     }
 #endif
     ++g_stats.launches;
-    ck(msi_bits_set_from_docids(pool.p, s->slot, ids.empty() ? nullptr : ids.data(), ids.size()));
+    ck(msi_bits_set_from_docids(cur->p, s->slot, ids.empty() ? nullptr : ids.data(), ids.size()));
     return s;
   }
   // the same level WITHOUT the completion wait: its counts land in `region`; false = does not fit, nothing enqueued
@@ -644,7 +722,7 @@ struct Dev {
       return true;
     }
 #endif
-    const int32_t st = msi_bits_paths_enqueue(pool.p, (uint32_t)paths.size(), paths.off.data(), paths.slots.data(), bucket->slot,
+    const int32_t st = msi_bits_paths_enqueue(cur->p, (uint32_t)paths.size(), paths.off.data(), paths.slots.data(), bucket->slot,
                                               universe->slot, region);
     if (st == MSI_E_UNSUPPORTED) return false;
     ck(st);
@@ -666,7 +744,7 @@ struct Dev {
 #endif
     Clock ck_;
     ++g_stats.syncs;
-    ck(msi_bits_paths_collect(pool.p, n_regions, counts.data()));
+    ck(msi_bits_paths_collect(cur->p, n_regions, counts.data()));
     g_stats.device_wait_ms += ck_.ms();
     return counts;
   }
@@ -686,7 +764,7 @@ struct Dev {
     if (stack.size() > MSI_BITS_MANY) fail(MSI_E_INTERNAL, "path longer than the claim kernel supports");
     for (size_t k = 0; k < stack.size(); ++k) ss[k] = stack[k]->slot;
     ++g_stats.launches;
-    ck(msi_bits_claim(pool.p, docs->slot, bucket->slot, universe->slot, (uint32_t)stack.size(), ss));
+    ck(msi_bits_claim(cur->p, docs->slot, bucket->slot, universe->slot, (uint32_t)stack.size(), ss));
   }
   // the cardinalities of several sets: one list, one completion wait for all of them
   std::vector<uint64_t> count_many(const std::vector<Set> &sets) {
@@ -723,7 +801,7 @@ struct Dev {
     Clock ck_;
     ++g_stats.launches;
     ++g_stats.syncs;
-    ck(msi_bits_count(pool.p, a->slot, &c));
+    ck(msi_bits_count(cur->p, a->slot, &c));
     g_stats.device_wait_ms += ck_.ms();
     return c;
   }
@@ -736,7 +814,7 @@ struct Dev {
       g_stats.postings_bytes += b.bytes.size() + 4 * b.small_ids.size();
       wr(s->slot);
       open_list();
-      ck(msi_vm_record_decode(list, pool.p, s->slot, b, true));
+      ck(msi_vm_record_decode(list, cur->p, s->slot, b, true));
       fills.insert(fills.end(), b.fill_tokens.begin(), b.fill_tokens.end());
       return s;
     }
@@ -747,7 +825,7 @@ struct Dev {
       ++g_stats.decodes;
       g_stats.launches += (b.containers.empty() ? 0 : 1) + (b.small_ids.empty() ? 0 : 1);
       g_stats.postings_bytes += b.bytes.size() + 4 * b.small_ids.size();
-      ck(msi_bits_decode_batch(pool.p, s->slot, b, false));
+      ck(msi_bits_decode_batch(cur->p, s->slot, b, false));
       g_stats.device_wait_ms += ck_.ms();
     }
     return s;
@@ -791,7 +869,7 @@ struct Dev {
     Clock ck_;
     g_stats.launches += 3;
     ++g_stats.syncs;
-    ck(msi_bits_first_k(pool.p, a->slot, k, ids.data(), &n));
+    ck(msi_bits_first_k(cur->p, a->slot, k, ids.data(), &n));
     g_stats.device_wait_ms += ck_.ms();
     ids.resize(n);
     return ids;
@@ -1052,6 +1130,7 @@ struct Ctx {
   std::map<std::string, std::vector<Set>> exact_attr_cache;  // {ExactMatch, MatchesStart, position candidates}
   std::map<std::tuple<Subset, Subset, uint32_t, uint32_t>, Set> prox_cache;
   std::map<std::pair<uint32_t, bool>, Set> word_cache;
+  std::map<uint32_t, uint32_t> freq_weight;   // MSI_TERMS_FREQUENCY: removal weight per term id (removal_order_frequency)
   void forget() {   // every cached set (all of them can be recomputed from the index)
     subset_cache.clear();
     within_cache.clear();
@@ -1062,8 +1141,23 @@ struct Ctx {
     edge_memo.clear();
     empty_.reset();
   }
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  // The search moves into the compact space (Dev::compact_begin): what the caches hold so far — the term subsets, words
+  // and phrases the universe was computed from — follows as images (one VM_DECODEC from the full-space slot each);
+  // everything decoded from here on is decoded straight into that space.
+  void to_compact_space() {
+    for (auto &kv : subset_cache) kv.second = dev.compact_of(kv.second);
+    for (auto &kv : word_cache) kv.second = dev.compact_of(kv.second);
+    for (auto &kv : phrase_cache) kv.second = dev.compact_of(kv.second);
+    within_cache.clear();
+    prox_cache.clear();
+    exact_attr_cache.clear();
+    edge_memo.clear();
+    empty_.reset();
+  }
+#endif
   void relieve() {  // keep the pool from running dry on long queries: drop what can be recomputed
-    if (dev.pool.free_.size() + dev.pool.clean_.size() >= 48) return;
+    if (dev.cur->free_.size() + dev.cur->clean_.size() >= 48) return;
 #ifndef MSI_SEARCH_DIRECT_ONLY
     // another task of the bucket sort may be parked with a reference into these maps: with tasks alive the caches stay
     // (a search that then runs out of slots is re-run sequentially, where this works again)
@@ -1685,6 +1779,11 @@ std::vector<IdSet> removal_order_last(Ctx &c, const Graph &g) {
 // frequency); the most frequent term gets weight 1 and is removed first, equal frequencies share a weight.  The unions
 // and all their cardinalities are ONE command list (VM_OP ... VM_COUNT x terms): one completion wait per call.
 std::vector<IdSet> removal_order_frequency(Ctx &c, const Graph &g) {
+  // The frequencies are those of the whole index (universe None) and the graph is the query's own every time — Words is
+  // the first graph-based rule, so nothing above it rebuilds the graph: computed once per search.  (Computed again after
+  // the search moved into the compact space they would be frequencies inside U0.)
+  if (!c.freq_weight.empty())
+    return removal_order(c, g, [&c](uint32_t id) { return c.freq_weight.at(id); });
   std::map<uint32_t, Set> term_docids;
   for (const GNode &n : g.nodes) {
     if (n.kind != 2) continue;
@@ -1706,7 +1805,7 @@ std::vector<IdSet> removal_order_frequency(Ctx &c, const Graph &g) {
   std::stable_sort(tf.begin(), tf.end(), [](const std::pair<uint32_t, uint64_t> &a, const std::pair<uint32_t, uint64_t> &b) {
     return a.second > b.second;               // sort_by_key(Reverse(frequency)): stable over ascending term ids
   });
-  std::map<uint32_t, uint32_t> weight_of;
+  std::map<uint32_t, uint32_t> &weight_of = c.freq_weight;
   uint32_t weight = 1;
   for (size_t i = 0; i < tf.size(); ++i) {
     weight_of[tf[i].first] = weight;
@@ -2929,10 +3028,24 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     Set d = query_graph_docids(c, reduced, universe);
     c.dev.and_(universe, d);
   }
+  auto rules = placeholder ? placeholder_rules(p) : ranking_rules(p);
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  // Universe compaction (Dev::compact_begin): everything below works on subsets of `universe`.  Not with the rules and
+  // options that read per-document arrays by docid through direct kernels (Sort / GeoSort keys, distinct values).
+  bool may_compact = c.dev.vm && Dev::compact_mode() > 0 && !placeholder && !p->distinct_values && msi_bits_n_slots(c.dev.pool.p) <= 1024;
+  for (auto &r : rules) may_compact = may_compact && r->kind != R_ORDER_BY;
+  if (may_compact) c.dev.rank_tables(universe);   // (rides in the list that counts the universe: no round of its own)
+#endif
   uint64_t universe_count = c.dev.count(universe);
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  if (may_compact && c.dev.compact_pays(universe_count)) {
+    c.dev.compact_begin(universe, universe_count);
+    c.to_compact_space();
+    universe = c.dev.ones();     // U0 in its own space: every rank
+  }
+#endif
 
   // ---- bucket_sort (bucket_sort.rs:23-343; no distinct, pins, deadline, score threshold) ---------
-  auto rules = placeholder ? placeholder_rules(p) : ranking_rules(p);
   const uint32_t from = p->from, length = p->length;
   const bool detailed = p->detailed_scores != 0;
   uint32_t n_out = 0;
@@ -3066,7 +3179,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             // a task keeps its own working sets alive: only as many tasks as the pool has room for (a rule evaluation
             // is given what relieve() keeps free)
             if (coop && tasks.live < (size_t)max_tasks &&
-                (no_gate || c.dev.pool.free_.size() + c.dev.pool.clean_.size() >= 48 * (tasks.live + 2))) {
+                (no_gate || c.dev.cur->free_.size() + c.dev.cur->clean_.size() >= 48 * (tasks.live + 2))) {
               // (the graph is moved into the task: the Bucket dies at the end of this iteration)
               auto gp = std::make_shared<Graph>(b.graph());
               tasks.spawn([&rank, cur, docs = b.docs, cnt = b.count, off, sc, gp]() { rank(cur + 1, docs, cnt, off, sc, *gp); });
@@ -3308,6 +3421,7 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
   if (out_candidates) *out_candidates = 0;
   if (out_degraded) *out_degraded = 0;
   g_stats = Stats();
+  g_ranked_searches.fetch_add(1, std::memory_order_relaxed);
   Clock total;
   try {
     Ctx c(dict, pool, index, params);
@@ -3324,6 +3438,15 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
     msi_set_error("msi_keyword_search_ranked: %s", e.what());
     return MSI_E_INTERNAL;
   }
+}
+
+// Universe compaction, process-wide: [ranked searches, of them continued in the compact space, documents of their universes summed]
+extern "C" int32_t msi_search_compaction_stats(uint64_t out[3]) {
+  if (!out) return MSI_E_INVALID;
+  out[0] = g_ranked_searches.load();
+  out[1] = g_compact_searches.load();
+  out[2] = g_compact_docs.load();
+  return MSI_OK;
 }
 
 // Counters of the last msi_keyword_search_ranked on the calling thread: [launches, syncs, decode batches,

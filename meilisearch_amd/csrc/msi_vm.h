@@ -35,6 +35,13 @@ enum : uint32_t {
   VM_MINKEY,     // universe, keys lo, keys hi, cell
   VM_TAKEKEY,    // universe, bucket, keys lo, keys hi, cell, cnt, key result index
   VM_SUMMARY_RESET,   // (no operand) the pool's chunk summaries no longer hold: every bit back to "may hold documents"
+  // ---- universe compaction (see MsiVmList::geom_docs) ------------------------------------------------------------
+  VM_RANK_A,     // slot, aux lo, aux hi: this chunk's cardinality of the set -> aux.chunk_cnt[chunk]
+  VM_RANK_B,     // slot, aux lo, aux hi, capacity (next phase): exclusive prefix popcount of every word -> aux.prefix[word],
+                 // docid of every document by rank -> aux.c2d[rank] (ranks below the capacity)
+  VM_DECODEC,    // dst (compact slot), source: index of the decode among the list's decodes | 0x80000000 + a slot of the FULL
+                 // pool.  Only in the WIDE phase of a compact list (one workgroup per chunk of the full space): the
+                 // documents of the source that are in U0, as ranks, into the part of dst that belongs to this chunk
 };
 
 constexpr uint32_t MSI_VM_MAX_COUNTS = 1024;   // cardinalities one list can ask for
@@ -62,9 +69,22 @@ struct MsiVmList {
   uint32_t n_counts = 0;
   uint32_t firstk_total = 0;            // ids the list's first-k commands ask for (their blocks lie back to back)
   uint32_t fk_in_phase = 0, max_fk_phase = 1;
-  bool empty() const { return words.empty(); }
+  // Universe compaction.  A list with geom_docs != 0 is a COMPACT list: it runs on the companion pool of `full_pool`, its
+  // sets are geom_docs bits long (the ranks of the documents of U0 = slot `u0_slot` of the full pool; slots are
+  // geom_words apart), first-k ids are translated back to docids, and the VM_DECODEC commands recorded into `pre` run
+  // first, in a phase of their own with one workgroup per chunk of the FULL space (they read postings / full sets by
+  // docid and write ranks).  Hoisting them is safe because their destinations are slots no earlier command of the same
+  // list has touched (msi_search.hip keeps slots freed while a list is recorded out of circulation until it has run).
+  uint64_t geom_docs = 0;
+  msi_bits *full_pool = nullptr;
+  uint32_t u0_slot = 0;
+  std::vector<uint32_t> pre;
+  bool pre_merged = false;
+  bool empty() const { return words.empty() && pre.empty(); }
   void clear() {
     words.clear();
+    pre.clear();
+    pre_merged = false;
     phase_start.clear();
     stage_used = 0;
     cache_base = 0;
@@ -94,8 +114,17 @@ struct MsiVmResult {
   std::vector<uint32_t> firstk;         // the id blocks of the list's VM_FIRSTK commands
 };
 
-// Appends a VM_DECODE of `batch` into `dst` (overwrite = the slot's previous content is discarded).
+// Appends a VM_DECODE of `batch` into `dst` (overwrite = the slot's previous content is discarded).  In a compact list
+// (l.geom_docs != 0; `pool` = the companion pool): a VM_DECODEC into l.pre, dst := the ranks of the batch's documents in U0.
 int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const MsiCboBatch &batch, bool overwrite);
+// Compact list: dst := the ranks of the documents of slot `full_slot` of the full pool that are in U0 (into l.pre).
+void msi_vm_record_compact(MsiVmList &l, uint32_t dst, uint32_t full_slot);
+// Appends, to a list on the FULL pool, the two commands (a kernel boundary between them) that fill the pool's
+// compaction tables for U0 = `slot`.
+void msi_vm_record_rank(MsiVmList &l, msi_bits *pool, uint32_t slot);
+uint64_t msi_bits_compact_capacity(const msi_bits *p);
+msi_bits *msi_bits_compact_pool(msi_bits *p);
+uint32_t *msi_bits_compact_aux(msi_bits *p);
 // Runs the list on the pool's context (blocks until its results are published).  Appends the decode descriptors to
 // l.words (once): clear() the list before recording again.
 int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res);

@@ -41,6 +41,8 @@ u64 *msi_bits_summary(msi_bits *p);
 uint64_t msi_bits_words_per_slot(msi_bits *p);
 uint64_t msi_bits_n_docs(msi_bits *p);
 uint32_t msi_bits_n_slots(msi_bits *p);
+uint64_t msi_bits_compact_capacity(const msi_bits *p);
+uint32_t *msi_bits_compact_aux(msi_bits *p);
 uint64_t *msi_bits_vm_block(msi_bits *p);     // pinned, fine-grained: [0] seq, [1] first-k count, [2..] counts, then ids
 uint64_t msi_bits_vm_next_seq(msi_bits *p);
 uint8_t *msi_bits_vm_stage(msi_bits *p, size_t need, size_t keep);   // pinned staging of the pool's decode payloads (grows, keeps `keep` bytes)
@@ -69,6 +71,10 @@ struct alignas(16) RoundSub {
   uint32_t n_decodes;
   uint32_t n_cmd_words;                   // the list's command words (its decode descriptors follow them)
   uint32_t sum_lo, sum_hi;                // device address of the pool's chunk summaries (0: none), msi_bits_summary
+  // compact lists (universe compaction, msi_vm.h): the full pool's compaction tables and slots, U0, and which phases
+  // are WIDE (one workgroup per chunk of the full space: `wide_chunks` of them)
+  u64 aux, full_base;
+  uint32_t full_words, u0_slot, wide_chunks, wide_mask;
 };
 static_assert(sizeof(RoundSub) % 16 == 0, "RoundSub array stays 16-byte aligned");
 
@@ -146,7 +152,9 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   r.stage = rp->stage; r.cache = rp->cache; r.n_chunks = rp->n_chunks; r.n_phases = rp->n_phases; r.list_off = rp->list_off;
   r.data_off = rp->data_off; r.state_off = rp->state_off; r.n_counts = rp->n_counts; r.n_decodes = rp->n_decodes;
   const uint32_t chunk = blockIdx.x;
-  if (phase >= r.n_phases || chunk >= r.n_chunks) return;
+  const bool wide = ((rp->wide_mask >> phase) & 1u) != 0;       // a compact list's VM_DECODEC phase: chunks of the FULL space
+  const uint32_t my_chunks = wide ? rp->wide_chunks : r.n_chunks;
+  if (phase >= r.n_phases || chunk >= my_chunks) return;
   // MSI_VM_PROFILE (diagnostics): thread 0's wall-clock ticks (100 MHz) per opcode, summed over all workgroups
   u64 *const prof = reinterpret_cast<u64 *>(((u64)arena[3] << 32) | arena[2]);
   __shared__ u64 s_prof[16];
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   uint32_t pcw = 0;                              // word index of the current command
 #define W(i) MSI_UNIFORM(cmd[pcw + (i)])
   const u64 w0 = (u64)chunk * CHW;
-  const uint32_t nw = (uint32_t)min((u64)CHW, r.n_words - w0);   // even: slots are whole 16-byte pairs
+  const uint32_t nw = wide ? 0u : (uint32_t)min((u64)CHW, r.n_words - w0);   // even: slots are whole 16-byte pairs
   const uint32_t n_pairs = nw / 2;
   u64 *const pool = reinterpret_cast<u64 *>(r.pool_base);
   auto S = [&](uint32_t slot) -> ulonglong2 * { return reinterpret_cast<ulonglong2 *>(pool + (u64)slot * r.n_words + w0); };
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   // the same word: no barrier), and written back at the end; bits follow conservatively from the operands' bits, and a
   // slot whose chunk was written WHOLE by this list gets its exact bit from what was stored.
   u64 *const sum_row = reinterpret_cast<u64 *>(((u64)rp->sum_hi << 32) | rp->sum_lo);
-  const bool sum_on = sum_row != nullptr;
+  const bool sum_on = sum_row != nullptr && !wide;
   if (sum_on) {
     if (lane < SUM_W) s_sum[wave][lane] = sum_row[(u64)chunk * SUM_W + lane];
     for (uint32_t i = tid; i < SUM_W * 64; i += VT) {
@@ -254,6 +262,71 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     const bool e = s_any == 0;
     __syncthreads();
     return e;
+  };
+  // The containers of THIS chunk (= blockIdx.x: a chunk of the space the postings are stored in) of decode `di` of the
+  // list, OR-ed into s_dec (when want_bits); bodies whose descriptor says so go into the posting cache on the way.
+  // -> number of containers here.  Ends with every thread past the last barrier.
+  auto decode_chunk = [&](uint32_t di, bool want_bits) -> uint32_t {
+    // chunk-major descriptor block of this workgroup (device memory): counts per decode, then the containers
+    const uint32_t *data = arena + r.list_off + r.data_off;
+    const uint32_t *blk_c = data + 4 * (size_t)data[chunk];          // chunk_off[] is in 16-byte units
+    const uint32_t c_first = blk_c[di], n_here = blk_c[di + 1] - c_first;   // start[] of this chunk: n_decodes + 1 entries
+    const VmContainer *cs = reinterpret_cast<const VmContainer *>(blk_c + ((r.n_decodes + 1 + 3) & ~3u)) + c_first;
+    if (!n_here) return 0;
+    __syncthreads();
+    if (want_bits)
+      for (uint32_t i = tid; i < CHW; i += VT) s_dec[i] = 0;
+    __syncthreads();
+    for (uint32_t ci = 0; ci < n_here; ++ci) {
+      const VmContainer c = cs[ci];
+      const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
+      const bool cached = (c.meta >> 18) & 1u;
+      const u64 fill_off = ((u64)(c.meta >> 19) << 32) | c.fill_lo;
+      const bool do_fill = !(c.fill_lo == 0xFFFFFFFFu && (c.meta >> 19) == 0x1FFFu);
+      if (!want_bits && !do_fill) continue;
+      // the body is read once, as 16-byte aligned loads (any body alignment) — from the HBM posting cache, or over
+      // PCIe from the pinned staging buffer — and decoded from LDS
+      const uint32_t len = type == 0 ? 2 * (card + 1) : (type == 1 ? 8192u : 4 * (card + 1));
+      const uintptr_t b0 = cached ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
+      const uint32_t skew = (uint32_t)(b0 & 15);
+      const uint4 *src = reinterpret_cast<const uint4 *>(b0 - skew);
+      const uint32_t n16 = (skew + min(len, 8192u) + 15) / 16;
+      uint4 *fill = do_fill ? reinterpret_cast<uint4 *>((uintptr_t)(r.cache + fill_off) - skew) : nullptr;
+      for (uint32_t i = tid; i < n16; i += VT) {
+        const uint4 v = src[i];
+        s_raw[i] = v;
+        // first reader of this key: the body goes into the cache on the way (same skew there: serialisations start
+        // 16-byte aligned in both places; the partial blocks at the ends carry the neighbouring bytes of the SAME
+        // serialisation, so a racing neighbour writes identical values)
+        if (fill) put4(&fill[i], v);
+      }
+      __syncthreads();
+      const uint8_t *body = reinterpret_cast<const uint8_t *>(s_raw) + skew;
+      if (!want_bits) {
+      } else if (type == 0) {
+        for (uint32_t i = tid; i < min(card + 1, 4096u); i += VT) {
+          const uint32_t v = (uint32_t)body[2 * i] | ((uint32_t)body[2 * i + 1] << 8);
+          atomicOr(&s_dec[v >> 6], 1ull << (v & 63));
+        }
+      } else if (type == 1) {
+        for (uint32_t w = tid; w < CHW; w += VT) {
+          u64 v = 0;
+          for (int b = 0; b < 8; ++b) v |= (u64)body[8 * w + b] << (8 * b);
+          if (v) atomicOr(&s_dec[w], v);
+        }
+      } else {
+        for (uint32_t rr = 0; rr < min(card + 1, 2048u); ++rr) {
+          const uint32_t start = (uint32_t)body[4 * rr] | ((uint32_t)body[4 * rr + 1] << 8);
+          const uint32_t rl = ((uint32_t)body[4 * rr + 2] | ((uint32_t)body[4 * rr + 3] << 8)) + 1;
+          for (uint32_t i = tid; i < rl; i += VT) {
+            const uint32_t v = start + i;
+            if (v < 65536) atomicOr(&s_dec[v >> 6], 1ull << (v & 63));
+          }
+        }
+      }
+      __syncthreads();   // s_raw is reused by the next container
+    }
+    return n_here;
   };
   for (;;) {
     const uint32_t op = W(0);
@@ -525,65 +598,10 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       case VM_DECODE: {  // the containers of THIS chunk of every posting of the batch, OR-ed in LDS, written once
         ulonglong2 *d = S(W(1));
         const bool overwrite = W(2) != 0;
-        const uint32_t di = W(3);                       // index of this decode among the list's decodes
-        // chunk-major descriptor block of this workgroup (device memory): counts per decode, then the containers
-        const uint32_t *data = arena + r.list_off + r.data_off;
-        const uint32_t *blk_c = data + 4 * (size_t)data[chunk];          // chunk_off[] is in 16-byte units
-        const uint32_t c_first = blk_c[di], n_here = blk_c[di + 1] - c_first;   // start[] of this chunk: n_decodes + 1 entries
-        const VmContainer *cs = reinterpret_cast<const VmContainer *>(blk_c + ((r.n_decodes + 1 + 3) & ~3u)) + c_first;
+        const uint32_t n_here = decode_chunk(W(3), true);   // index of this decode among the list's decodes
         if (n_here) {
           if (overwrite) whole(W(1));
           else partial(W(1));
-          __syncthreads();
-          for (uint32_t i = tid; i < CHW; i += VT) s_dec[i] = 0;
-          __syncthreads();
-          for (uint32_t ci = 0; ci < n_here; ++ci) {
-            const VmContainer c = cs[ci];
-            const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
-            const bool cached = (c.meta >> 18) & 1u;
-            const u64 fill_off = ((u64)(c.meta >> 19) << 32) | c.fill_lo;
-            const bool do_fill = !(c.fill_lo == 0xFFFFFFFFu && (c.meta >> 19) == 0x1FFFu);
-            // the body is read once, as 16-byte aligned loads (any body alignment) — from the HBM posting cache, or over
-            // PCIe from the pinned staging buffer — and decoded from LDS
-            const uint32_t len = type == 0 ? 2 * (card + 1) : (type == 1 ? 8192u : 4 * (card + 1));
-            const uintptr_t b0 = cached ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
-            const uint32_t skew = (uint32_t)(b0 & 15);
-            const uint4 *src = reinterpret_cast<const uint4 *>(b0 - skew);
-            const uint32_t n16 = (skew + min(len, 8192u) + 15) / 16;
-            uint4 *fill = do_fill ? reinterpret_cast<uint4 *>((uintptr_t)(r.cache + fill_off) - skew) : nullptr;
-            for (uint32_t i = tid; i < n16; i += VT) {
-              const uint4 v = src[i];
-              s_raw[i] = v;
-              // first reader of this key: the body goes into the cache on the way (same skew there: serialisations start
-              // 16-byte aligned in both places; the partial blocks at the ends carry the neighbouring bytes of the SAME
-              // serialisation, so a racing neighbour writes identical values)
-              if (fill) put4(&fill[i], v);
-            }
-            __syncthreads();
-            const uint8_t *body = reinterpret_cast<const uint8_t *>(s_raw) + skew;
-            if (type == 0) {
-              for (uint32_t i = tid; i < min(card + 1, 4096u); i += VT) {
-                const uint32_t v = (uint32_t)body[2 * i] | ((uint32_t)body[2 * i + 1] << 8);
-                atomicOr(&s_dec[v >> 6], 1ull << (v & 63));
-              }
-            } else if (type == 1) {
-              for (uint32_t w = tid; w < CHW; w += VT) {
-                u64 v = 0;
-                for (int b = 0; b < 8; ++b) v |= (u64)body[8 * w + b] << (8 * b);
-                if (v) atomicOr(&s_dec[w], v);
-              }
-            } else {
-              for (uint32_t rr = 0; rr < min(card + 1, 2048u); ++rr) {
-                const uint32_t start = (uint32_t)body[4 * rr] | ((uint32_t)body[4 * rr + 1] << 8);
-                const uint32_t rl = ((uint32_t)body[4 * rr + 2] | ((uint32_t)body[4 * rr + 3] << 8)) + 1;
-                for (uint32_t i = tid; i < rl; i += VT) {
-                  const uint32_t v = start + i;
-                  if (v < 65536) atomicOr(&s_dec[v >> 6], 1ull << (v & 63));
-                }
-              }
-            }
-            __syncthreads();   // s_raw is reused by the next container
-          }
           u64 any_d = 0;
           for (uint32_t p = tid; p < n_pairs; p += VT) {
             ulonglong2 v;
@@ -601,6 +619,138 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
           make_empty(W(1));
         }
         pcw += 4;
+        break;
+      }
+      case VM_RANK_A: {  // universe compaction, first half (a list on the FULL pool): this chunk's cardinality of U0
+        const ulonglong2 *a = S(W(1));
+        uint32_t *aux = reinterpret_cast<uint32_t *>(((u64)W(3) << 32) | W(2));
+        uint32_t c = 0;
+        if (!E(W(1)))
+          for (uint32_t p = tid; p < n_pairs; p += VT) {
+            const ulonglong2 v = a[p];
+            c += __popcll(v.x) + __popcll(v.y);
+          }
+        c = wave_sum(c);
+        __syncthreads();
+        if (lane == 0) s_scan[wave] = c;
+        __syncthreads();
+        if (tid == 0) {
+          uint32_t t = 0;
+          for (int i = 0; i < VT / 64; ++i) t += s_scan[i];
+          __hip_atomic_store(&aux[chunk], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        pcw += 4;
+        break;
+      }
+      case VM_RANK_B: {  // second half (next phase): exclusive prefix popcounts per word of U0, and rank -> docid
+        __syncthreads();
+        const u64 *a = pool + (u64)W(1) * r.n_words + w0;
+        uint32_t *aux = reinterpret_cast<uint32_t *>(((u64)W(3) << 32) | W(2));
+        const uint32_t cap = W(4);
+        uint32_t *prefix = aux + ((r.n_chunks + 3) & ~3u);
+        uint32_t *c2d = prefix + (((uint32_t)r.n_words + 3) & ~3u);
+        uint32_t part = 0;
+        for (uint32_t c = tid; c < chunk; c += VT) part += __hip_atomic_load(&aux[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        part = wave_sum(part);
+        if (lane == 0) s_scan[wave] = part;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int i = 0; i < VT / 64; ++i) base += s_scan[i];
+        __syncthreads();
+        u64 w[WPT];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {   // thread t owns words WPT*t .. WPT*t+WPT-1: ascending across threads
+          const uint32_t wi = WPT * tid + j;
+          w[j] = wi < nw ? a[wi] : 0ull;
+          mine += (uint32_t)__popcll(w[j]);
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t v = __shfl_up((int)incl, o);
+          if ((int)lane >= o) incl += v;
+        }
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        uint32_t run = base + incl - mine;
+        for (uint32_t ww = 0; ww < wave; ++ww) run += s_scan[ww];
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+          const uint32_t wi = WPT * tid + j;
+          if (wi < nw) __hip_atomic_store(&prefix[w0 + wi], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          u64 x = w[j];
+          while (x) {
+            const uint32_t b = (uint32_t)__ffsll((long long)x) - 1;
+            if (run < cap) __hip_atomic_store(&c2d[run], (uint32_t)((w0 + wi) * 64 + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++run;
+            x &= x - 1;
+          }
+        }
+        __syncthreads();
+        pcw += 5;
+        break;
+      }
+      case VM_DECODEC: {  // compact list, wide phase: workgroup = chunk of the FULL space.  The documents of the source
+                          // (a decode batch's containers of this chunk, or this chunk of a full-space slot) that are in
+                          // U0 become ranks; this chunk's documents of U0 have the contiguous ranks [lo, hi), the part of
+                          // dst this workgroup writes WHOLE (words shared with a neighbouring chunk: its own bits, atomically).
+        const uint32_t dsts = W(1), srcw = W(2);
+        const uint32_t full_words = rp->full_words, full_chunks = rp->wide_chunks;
+        const uint32_t *aux = reinterpret_cast<const uint32_t *>(rp->aux);
+        const uint32_t *prefix = aux + ((full_chunks + 3) & ~3u);
+        const u64 fw0 = (u64)chunk * CHW;
+        const uint32_t nwf = (uint32_t)min((u64)CHW, (u64)full_words - fw0);
+        const u64 *full = reinterpret_cast<const u64 *>(rp->full_base);
+        const u64 *u0 = full + (u64)rp->u0_slot * full_words + fw0;
+        const uint32_t total = (uint32_t)r.n_docs;
+        const uint32_t lo = prefix[fw0], hi = chunk + 1 < full_chunks ? prefix[fw0 + CHW] : total;
+        const bool from_slot = (srcw >> 31) != 0;
+        const u64 *src_slot = from_slot ? full + (u64)(srcw & 0x7FFFFFFFu) * full_words + fw0 : nullptr;
+        uint32_t n_here = 0;
+        if (!from_slot) n_here = decode_chunk(srcw, hi > lo);   // (bodies still go into the posting cache when nothing of U0 is here)
+        if (hi > lo) {
+          u64 *s_out = reinterpret_cast<u64 *>(s_raw);          // [lo >> 6 .. (hi - 1) >> 6]: at most 1025 words
+          const uint32_t fwd = lo >> 6, n_out = ((hi - 1) >> 6) - fwd + 1;
+          __syncthreads();
+          for (uint32_t i = tid; i < n_out; i += VT) s_out[i] = 0;
+          __syncthreads();
+          if (from_slot || n_here)
+            for (uint32_t wi = tid; wi < nwf; wi += VT) {
+              const u64 uw = u0[wi];
+              u64 m = (from_slot ? src_slot[wi] : s_dec[wi]) & uw;
+              if (!m) continue;
+              const uint32_t base = prefix[fw0 + wi] - (fwd << 6);
+              while (m) {
+                const uint32_t b = (uint32_t)__ffsll((long long)m) - 1;
+                const uint32_t rk = base + (uint32_t)__popcll(uw & ((1ull << b) - 1ull));
+                atomicOr(&s_out[rk >> 6], 1ull << (rk & 63));
+                m &= m - 1;
+              }
+            }
+          __syncthreads();
+          u64 *dst = pool + (u64)dsts * r.n_words;
+          const bool tail = hi == total;   // the last range also owns what lies behind |U0|, up to the end of the slot
+          for (uint32_t i = tid; i < n_out; i += VT) {
+            const u64 gw = (u64)fwd + i;
+            const uint32_t lb = lo > gw * 64 ? (uint32_t)(lo - gw * 64) : 0u;
+            const uint32_t hb = hi < (gw + 1) * 64 ? (uint32_t)(hi - gw * 64) : 64u;   // 1 .. 64
+            u64 own = (hb == 64 ? ~0ull : ((1ull << hb) - 1ull)) & ~((1ull << lb) - 1ull);
+            if (tail && i == n_out - 1) own |= hb == 64 ? 0ull : ~((1ull << hb) - 1ull);
+            const u64 val = s_out[i];
+            if (own == ~0ull) {
+              put1(&dst[gw], val);
+            } else {
+              atomicAnd(&dst[gw], ~own);
+              if (val) atomicOr(&dst[gw], val);
+            }
+          }
+          if (tail)
+            for (u64 gw = (u64)fwd + n_out + tid; gw < r.n_words; gw += VT) put1(&dst[gw], 0ull);
+          __syncthreads();   // s_raw / s_dec are reused by the next command
+        }
+        pcw += 3;
         break;
       }
       case VM_MINKEY: {  // Sort rule, first half: the smallest order key among the documents of the universe
@@ -663,7 +813,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         break;
     }
     if (pcw == 0xFFFFFFFFu) break;
-    if (prof && tid == 0) s_prof[op & 15] += wall_clock64() - t_op;
+    if (prof && tid == 0 && op < 15) s_prof[op] += wall_clock64() - t_op;
   }
   if (prof && tid == 0) {
     for (int i = 1; i < 15; ++i)
@@ -696,7 +846,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   }
   MSI_ORDER_ATOMICS();
   __syncthreads();
-  if (tid == 0) s_last = atomicAdd(&state[phase], 1u) == r.n_chunks - 1 ? 1u : 0u;
+  if (tid == 0) s_last = atomicAdd(&state[phase], 1u) == my_chunks - 1 ? 1u : 0u;
   __syncthreads();
   if (prof && tid == 0) atomicAdd(&prof[18], wall_clock64() - t_epi);   // counts out + ordering + ticket
   if (!s_last) return;
@@ -708,6 +858,8 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   if (n_fk) __threadfence();   // the set words the other workgroups wrote (read below with device-scope loads)
   u64 *res = reinterpret_cast<u64 *>(r.host_res);
   uint32_t emitted = 0;
+  // a compact list's sets hold ranks inside U0: the ids leave as docids (rank -> docid table of the full pool)
+  const uint32_t *c2d = rp->aux ? reinterpret_cast<const uint32_t *>(rp->aux) + ((rp->wide_chunks + 3) & ~3u) + ((rp->full_words + 3) & ~3u) : nullptr;
   // the first-k commands of THIS phase are emitted by this phase's last workgroup (the ids are in the host's block
   // before the kernel of the list's last phase — a later launch on the same stream — publishes the sequence number)
   for (uint32_t f = 0; f < n_fk; ++f) {
@@ -746,7 +898,8 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         u64 x = w[j];
         while (x && rank < k) {
           const uint32_t b = (uint32_t)__ffsll((long long)x) - 1;
-          __hip_atomic_store(&ids[rank++], (uint32_t)((cw0 + WPT * tid + j) * 64 + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          const uint32_t id = (uint32_t)((cw0 + WPT * tid + j) * 64 + b);
+          __hip_atomic_store(&ids[rank++], c2d ? c2d[id] : id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           x &= x - 1;
         }
       }
@@ -886,6 +1039,7 @@ void VmCombiner::run() {
   // get rounds of their own and the light ones keep flowing.
   int cur_of[2] = {0, 1};
   const size_t max_subs = getenv("MSI_VM_MAX_SUBS") ? std::max(1, atoi(getenv("MSI_VM_MAX_SUBS"))) : MAX_SUBS;   // experiments
+  // (a compact list's decodes are as heavy as a full list's: they read the same posting bytes)
   auto is_heavy = [](const VmSub *s) { return s->list->decodes.size() > 2 || s->list->words.size() > 600; };
   std::vector<VmSub *> waiting[2];   // taken from the queue, not launched yet (their class's arena is still in use)
   FILE *trace = getenv("MSI_VM_TRACE") ? fopen(getenv("MSI_VM_TRACE"), "w") : nullptr;
@@ -938,13 +1092,19 @@ void VmCombiner::run() {
     const size_t n_sub = batch.size();
     size_t off = 64 + align16(n_sub * sizeof(RoundSub));
     std::vector<size_t> words_at(n_sub), state_at(n_sub);
-    uint32_t max_chunks = 1, max_phases = 1;
+    // geometry of a list: its pool's, or — a compact list — geom_docs documents per set on the companion pool
+    auto words_of = [](const VmSub *b) -> uint64_t {
+      const uint64_t g = b->list->geom_docs;
+      return g ? std::max<uint64_t>(2, ((g + 127) / 128) * 2) : msi_bits_words_per_slot(b->pool);
+    };
+    uint32_t max_chunks[MSI_VM_MAX_PHASES] = {0}, max_phases = 1;
     for (size_t i = 0; i < n_sub; ++i) {
       const MsiVmList &l = *batch[i]->list;
       words_at[i] = off;
       off = align16(off + (l.words.size() + 1) * 4);
       state_at[i] = off;
-      off = align16(off + 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)chunks_of(batch[i]->pool) * 4 * l.max_fk_phase);
+      const uint32_t n_chunks = (uint32_t)((words_of(batch[i]) + CHW - 1) / CHW);
+      off = align16(off + 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)n_chunks * 4 * l.max_fk_phase);
     }
     int32_t st = MSI_OK;
     if (off > 0xFFFFFFF0ull || !arena_ensure(this, A, off)) {
@@ -963,8 +1123,8 @@ void VmCombiner::run() {
         RoundSub &r = subs[i];
         memset(&r, 0, sizeof(r));
         r.pool_base = (u64)(uintptr_t)msi_bits_pool_base(p);
-        r.n_words = msi_bits_words_per_slot(p);
-        r.n_docs = msi_bits_n_docs(p);
+        r.n_words = words_of(batch[i]);
+        r.n_docs = l.geom_docs ? l.geom_docs : msi_bits_n_docs(p);
         r.host_res = (u64)(uintptr_t)batch[i]->blk;
         r.seq = batch[i]->seq;
         r.n_chunks = (uint32_t)((r.n_words + CHW - 1) / CHW);
@@ -978,7 +1138,16 @@ void VmCombiner::run() {
         r.data_off = l.data_off;
         r.n_decodes = (uint32_t)l.decodes.size();
         r.n_cmd_words = l.data_off ? l.data_off : (uint32_t)l.words.size() + 1;
-        {
+        if (l.geom_docs) {
+          // a compact list: the full pool's tables and slots; chunk summaries are not kept in the compact space (its sets
+          // are a chunk or two long)
+          r.aux = (u64)(uintptr_t)msi_bits_compact_aux(l.full_pool);
+          r.full_base = (u64)(uintptr_t)msi_bits_pool_base(l.full_pool);
+          r.full_words = (uint32_t)msi_bits_words_per_slot(l.full_pool);
+          r.u0_slot = l.u0_slot;
+          r.wide_chunks = (uint32_t)((r.full_words + CHW - 1) / CHW);
+          r.wide_mask = l.pre_merged ? 1u : 0u;
+        } else {
           static const bool sum_off = getenv("MSI_VM_SUMMARY") && getenv("MSI_VM_SUMMARY")[0] == '0';   // diagnostics
           const uint64_t sp = sum_off ? 0 : (uint64_t)(uintptr_t)msi_bits_summary(p);
           r.sum_lo = (uint32_t)sp;
@@ -987,14 +1156,15 @@ void VmCombiner::run() {
         memcpy(A.host + words_at[i], l.words.data(), l.words.size() * 4);
         reinterpret_cast<uint32_t *>(A.host + words_at[i])[l.words.size()] = VM_END;
         memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)r.n_chunks * 4 * l.max_fk_phase);
-        max_chunks = std::max(max_chunks, r.n_chunks);
+        for (uint32_t ph = 0; ph < r.n_phases; ++ph)
+          max_chunks[ph] = std::max(max_chunks[ph], ((r.wide_mask >> ph) & 1u) ? r.wide_chunks : r.n_chunks);
         max_phases = std::max(max_phases, r.n_phases);
       }
       const int64_t t_launch = now_ns();
       for (VmSub *s : batch) s->t_launch = t_launch;
       if (hipMemcpyAsync(A.dev, A.host, off, hipMemcpyHostToDevice, stream) != hipSuccess) st = MSI_E_HIP;
       for (uint32_t ph = 0; ph < max_phases && st == MSI_OK; ++ph) {
-        hipLaunchKernelGGL(vm_kernel, dim3(max_chunks, (uint32_t)n_sub), dim3(VT), 0, stream,
+        hipLaunchKernelGGL(vm_kernel, dim3(std::max(1u, max_chunks[ph]), (uint32_t)n_sub), dim3(VT), 0, stream,
                            reinterpret_cast<uint32_t *>(A.dev), ph);
         if (hipGetLastError() != hipSuccess) st = MSI_E_HIP;
       }
@@ -1171,7 +1341,8 @@ int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const M
   // Bodies that are not in the posting cache go into the pool's pinned staging buffer (read over PCIe by the decoding
   // workgroup, once); the container descriptors are bucketed by chunk (= Roaring key) here and laid out chunk-major
   // when the list is submitted.  The <= 7-document raw values become array containers built here.
-  const uint64_t n_words = msi_bits_words_per_slot(pool);
+  // (a compact list stores ranks, but its decodes read the postings by docid: chunks of the FULL space)
+  const uint64_t n_words = msi_bits_words_per_slot(l.geom_docs ? l.full_pool : pool);
   const uint32_t n_chunks = (uint32_t)((n_words + CHW - 1) / CHW);
   std::vector<std::pair<uint32_t, uint16_t>> small;
   small.reserve(batch.small_ids.size());
@@ -1232,12 +1403,51 @@ int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const M
   }
   for (const MsiContainer &c : extra) put(c, false, (uint64_t)extra_at + c.offset, MSI_NO_CACHE);
   l.begin();
-  l.words.push_back(VM_DECODE);
-  l.words.push_back(dst);
-  l.words.push_back(overwrite ? 1u : 0u);
-  l.words.push_back((uint32_t)l.decodes.size());
+  if (l.geom_docs) {
+    if (!overwrite) return MSI_E_UNSUPPORTED;   // (the search only decodes into fresh slots)
+    l.pre.push_back(VM_DECODEC);
+    l.pre.push_back(dst);
+    l.pre.push_back((uint32_t)l.decodes.size());
+  } else {
+    l.words.push_back(VM_DECODE);
+    l.words.push_back(dst);
+    l.words.push_back(overwrite ? 1u : 0u);
+    l.words.push_back((uint32_t)l.decodes.size());
+  }
   l.decodes.push_back(std::move(dec));
   return MSI_OK;
+}
+
+void msi_vm_record_compact(MsiVmList &l, uint32_t dst, uint32_t full_slot) {
+  l.begin();
+  l.pre.push_back(VM_DECODEC);
+  l.pre.push_back(dst);
+  l.pre.push_back(0x80000000u | full_slot);
+}
+
+void msi_vm_record_rank(MsiVmList &l, msi_bits *pool, uint32_t slot) {
+  const uint64_t aux = (uint64_t)(uintptr_t)msi_bits_compact_aux(pool);
+  l.begin();
+  l.words.insert(l.words.end(), {(uint32_t)VM_RANK_A, slot, (uint32_t)aux, (uint32_t)(aux >> 32)});
+  l.barrier();
+  const uint64_t cap = msi_bits_compact_capacity(pool);
+  l.words.insert(l.words.end(), {(uint32_t)VM_RANK_B, slot, (uint32_t)aux, (uint32_t)(aux >> 32), (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull)});
+}
+
+// A compact list's hoisted VM_DECODEC commands become its phase 0 (the wide phase).
+static void merge_pre(MsiVmList &l) {
+  if (l.pre.empty() || l.pre_merged) return;
+  const uint32_t shift = (uint32_t)l.pre.size() + 1;
+  std::vector<uint32_t> w;
+  w.reserve(l.pre.size() + 1 + l.words.size());
+  w.insert(w.end(), l.pre.begin(), l.pre.end());
+  w.push_back(VM_END);
+  w.insert(w.end(), l.words.begin(), l.words.end());
+  l.words.swap(w);
+  if (l.phase_start.empty()) l.phase_start.push_back(0);
+  for (uint32_t &x : l.phase_start) x += shift;
+  l.phase_start.insert(l.phase_start.begin(), 0u);
+  l.pre_merged = true;
 }
 
 // Chunk-major layout of the list's decode descriptors, appended to its words (16-byte aligned):
@@ -1282,6 +1492,7 @@ static void finalize_decodes(MsiVmList &l) {
 
 
 int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
+  merge_pre(l);
   finalize_decodes(l);
   if (l.n_counts > MSI_VM_MAX_COUNTS || l.phase_start.size() > MSI_VM_MAX_PHASES || l.phase_start.empty()) {
     msi_set_error("msi_vm_run: list outside the supported range (%u counts, %zu phases)", l.n_counts, l.phase_start.size());

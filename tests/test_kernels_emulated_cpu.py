@@ -43,15 +43,22 @@ GROUPS = {
                                  "tests/test_zzz_geo_gpu.py::test_geo_sort_matches_the_oracle_on_the_device",
                                  "tests/test_zz_order_keys_gpu.py::test_sort_rules_match_the_oracle_on_the_device",
                                  "tests/test_configs_gpu.py::test_c4_keyword_leg"], "", 4),
+    # universe compaction forced on (MSI_SEARCH_COMPACT=2: by default it only engages where it pays, on indexes of more
+    # than one chunk): the reference's snapshot searches, the index settings x the three strategies against the oracle,
+    # the one-document-per-chunk spread (ranges of one bit: the shared-word path of VM_DECODEC), the out-of-slots re-run
+    "ranked-search-compact-space": (["tests/test_search_gpu.py", "tests/test_zz_vm_gpu.py"],
+                                    "not matches_oracle_on_random_corpora and not starved", 100, {"MSI_SEARCH_COMPACT": "2"}),
 }
 
 
 @pytest.mark.parametrize("group", list(GROUPS))
 def test_gpu_test_bodies_on_emulated_kernels(group):
-    files, expr, at_least = GROUPS[group]
+    files, expr, at_least = GROUPS[group][:3]
+    env = dict(os.environ, **(GROUPS[group][3] if len(GROUPS[group]) > 3 else {}))
     k = f"not ({NEEDS_TORCH_CUDA})" + (f" and {expr}" if expr else "")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "run_emulated.py"), "-q", "-x", "-m", "gpu",
-                          "-p", "no:cacheprovider", "-k", k] + files, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+                          "-p", "no:cacheprovider", "-k", k] + files, cwd=ROOT, capture_output=True, text=True, timeout=1500,
+                         env=env)
     tail = out.stdout[-3000:] + out.stderr[-2000:]
     assert out.returncode == 0, tail
     m = re.search(r"(\d+) passed", out.stdout)
