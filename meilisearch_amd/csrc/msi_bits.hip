@@ -1352,6 +1352,25 @@ int32_t msi_bits_set_from_words(msi_bits *p, uint32_t slot, const uint64_t *word
 // otherwise the portable Roaring serialisation (cookies 12346 / 12347), whose
 // containers are appended to the batch with offsets into the batch buffer.
 // Returns false on a malformed value.
+// The container table of one serialisation (offsets relative to its first byte); false: malformed or a raw small value.
+bool msi_cbo_parse(const uint8_t *bytes, size_t len, std::vector<MsiContainer> &out) {
+  if (len <= 7 * sizeof(uint32_t)) return false;
+  MsiCboBatch tmp;
+  // (parsed through the batch path with a pretended cache source, so that nothing is copied and offsets are relative)
+  if (!msi_cbo_batch_append(tmp, bytes, len, 0, MSI_NO_CACHE)) return false;
+  out.swap(tmp.containers);
+  return !out.empty();
+}
+
+// A posting the cache already knows (msi_pcache_known, kind 3): its containers join the batch without its bytes.
+void msi_cbo_batch_append_known(MsiCboBatch &batch, const MsiContainer *conts, uint32_t n, uint64_t cache_off) {
+  const size_t first = batch.containers.size();
+  batch.containers.insert(batch.containers.end(), conts, conts + n);
+  batch.src.resize(first + n, MSI_NO_CACHE);
+  batch.fill.resize(first + n, MSI_NO_CACHE);
+  for (uint32_t i = 0; i < n; ++i) batch.src[first + i] = cache_off + conts[i].offset;
+}
+
 bool msi_cbo_batch_append(MsiCboBatch &batch, const uint8_t *bytes, size_t len, uint64_t cache_src, uint64_t cache_fill) {
   const size_t THRESHOLD = 7;  // cbo_roaring_bitmap_codec.rs:15
   if (len <= THRESHOLD * sizeof(uint32_t)) {

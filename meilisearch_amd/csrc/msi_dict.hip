@@ -643,6 +643,12 @@ struct msi_dict {
   DevBuf slots, sigs, wmeta, flat, offs, fc_start;
   // scratch (guarded by ctx->mu_aux)
   DevBuf qbytes, qoff, qflags, qm, qchars, wlists, xlists, ticket, pairs, out1, out1c, out2, out2c;
+  // host entry point (msi_dict_lookup): pinned staging of the packed queries and results, and an event the caller
+  // SLEEPS on — with pageable buffers every copy was a staged, spinning call and hipStreamSynchronize a busy-wait: a fifth
+  // of the host CPU of the keyword leg at 64 callers (profiles/r3_ranked_cpu_profile_before.txt)
+  uint8_t *h_stage = nullptr;
+  size_t h_stage_cap = 0;
+  hipEvent_t h_done = nullptr;
   uint64_t lookup_launches = 0, dict_bytes = 0;
   KernelTimer match_timer;
   // host copy of the sorted words (prefix ranges, idx -> word for the keyword pipeline)
@@ -880,6 +886,8 @@ void msi_dict_destroy(msi_dict *d) {
                     &d->out1, &d->out1c, &d->out2, &d->out2c};
   for (DevBuf *b : bufs) b->release();
   d->match_timer.release();
+  if (d->h_stage) (void)hipHostFree(d->h_stage);
+  if (d->h_done) (void)hipEventDestroy(d->h_done);
   delete d;
   }
   msi_ctx_release(ctx);
@@ -1127,17 +1135,41 @@ static int32_t dict_lookup_direct(msi_dict *d, const msi_typo_query *queries, ui
   MSI_TRY(d->out2.ensure((size_t)n * cap_two * sizeof(uint32_t)));
   MSI_TRY(d->out1c.ensure(n * sizeof(uint32_t)));
   MSI_TRY(d->out2c.ensure(n * sizeof(uint32_t)));
-  if (!bytes.empty()) MSI_HIP_TRY(hipMemcpyAsync(d->qbytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice, st));
-  MSI_HIP_TRY(hipMemcpyAsync(d->qoff.p, off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  MSI_HIP_TRY(hipMemcpyAsync(d->qflags.p, flags.data(), n, hipMemcpyHostToDevice, st));
+  // pinned staging: [bytes | off | flags] in, [one | two | counts one | counts two] out
+  auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t in_off = a16(bytes.size()), in_fl = in_off + a16((n + 1) * sizeof(uint32_t)), in_end = in_fl + a16(n);
+  const size_t o1 = in_end, o2 = o1 + a16((size_t)n * cap_one * 4), c1 = o2 + a16((size_t)n * cap_two * 4), c2 = c1 + a16(n * 4),
+               total = c2 + a16(n * 4);
+  if (total > d->h_stage_cap) {
+    if (d->h_stage) (void)hipHostFree(d->h_stage);
+    d->h_stage = nullptr;
+    d->h_stage_cap = 0;
+    void *h = nullptr;
+    MSI_HIP_TRY(hipHostMalloc(&h, total * 2, hipHostMallocDefault));
+    d->h_stage = (uint8_t *)h;
+    d->h_stage_cap = total * 2;
+  }
+  if (!d->h_done) MSI_HIP_TRY(hipEventCreateWithFlags(&d->h_done, hipEventBlockingSync | hipEventDisableTiming));
+  uint8_t *h = d->h_stage;
+  if (!bytes.empty()) memcpy(h, bytes.data(), bytes.size());
+  memcpy(h + in_off, off.data(), (n + 1) * sizeof(uint32_t));
+  memcpy(h + in_fl, flags.data(), n);
+  if (!bytes.empty()) MSI_HIP_TRY(hipMemcpyAsync(d->qbytes.p, h, bytes.size(), hipMemcpyHostToDevice, st));
+  MSI_HIP_TRY(hipMemcpyAsync(d->qoff.p, h + in_off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  MSI_HIP_TRY(hipMemcpyAsync(d->qflags.p, h + in_fl, n, hipMemcpyHostToDevice, st));
   MSI_TRY(enqueue_lookup(d, d->qbytes.as<uint8_t>(), d->qoff.as<uint32_t>(), d->qflags.as<uint8_t>(), n, cap_one,
                          cap_two, d->out1.as<uint32_t>(), d->out1c.as<uint32_t>(), d->out2.as<uint32_t>(),
                          d->out2c.as<uint32_t>()));
-  MSI_HIP_TRY(hipMemcpyAsync(out_one_idx, d->out1.p, (size_t)n * cap_one * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  MSI_HIP_TRY(hipMemcpyAsync(out_two_idx, d->out2.p, (size_t)n * cap_two * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  MSI_HIP_TRY(hipMemcpyAsync(out_one_cnt, d->out1c.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  MSI_HIP_TRY(hipMemcpyAsync(out_two_cnt, d->out2c.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  MSI_HIP_TRY(hipStreamSynchronize(st));
+  MSI_HIP_TRY(hipMemcpyAsync(h + o1, d->out1.p, (size_t)n * cap_one * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipMemcpyAsync(h + o2, d->out2.p, (size_t)n * cap_two * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipMemcpyAsync(h + c1, d->out1c.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipMemcpyAsync(h + c2, d->out2c.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipEventRecord(d->h_done, st));
+  MSI_HIP_TRY(hipEventSynchronize(d->h_done));   // a blocking-sync event: the caller sleeps, no busy-wait
+  memcpy(out_one_idx, h + o1, (size_t)n * cap_one * sizeof(uint32_t));
+  memcpy(out_two_idx, h + o2, (size_t)n * cap_two * sizeof(uint32_t));
+  memcpy(out_one_cnt, h + c1, n * sizeof(uint32_t));
+  memcpy(out_two_cnt, h + c2, n * sizeof(uint32_t));
   return MSI_OK;
 }
 

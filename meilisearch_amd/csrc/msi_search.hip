@@ -47,6 +47,7 @@ int32_t msi_bits_sync(msi_bits *p);
 bool msi_bits_take_summary_dirty(msi_bits *p);
 const uint32_t *msi_doc_keys_device(const msi_doc_keys *k);
 MsiPostingCache *msi_dict_pcache(const msi_dict *d);
+void msi_cbo_batch_append_known(MsiCboBatch &batch, const MsiContainer *conts, uint32_t n, uint64_t cache_off);
 #endif
 
 struct msi_dict;
@@ -260,6 +261,7 @@ struct Dev {
     if (r == 1) return msi_cbo_batch_append(b, bytes, n, off, MSI_NO_CACHE);
     if (r == 2) {
       if (!msi_cbo_batch_append(b, bytes, n, MSI_NO_CACHE, off)) return false;
+      msi_pcache_describe(pcache, token, bytes, n);   // its container table: later searches do not even ask the index
       b.fill_tokens.push_back(token);   // committed when the batch's decode has run; a list that fails or is dropped
       return true;                      // abandons them (msi_pcache_abandon): the next reader of the key refills
     }
@@ -1199,6 +1201,10 @@ struct Ctx {
       msi_set_error("msi_keyword_search_ranked: %s callback failed (%d)", what, st);
       throw Fail{MSI_E_INTERNAL};
     }
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (dev.pcache && (!n || !bytes || n <= 7 * sizeof(uint32_t)))   // "no such key" and raw small values: remembered on the host
+      msi_pcache_learn(dev.pcache, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y), bytes, bytes ? n : 0);
+#endif
     if (!n || !bytes) return;
 #ifndef MSI_SEARCH_DIRECT_ONLY
     const bool ok = dev.pcache ? dev.append_posting(b, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y), bytes, n)
@@ -1212,6 +1218,27 @@ struct Ctx {
       throw Fail{MSI_E_INVALID};
     }
   }
+  // The posting cache of the index version answers instead of the index (msi_pcache_known): the key is absent, a raw
+  // small value, or a serialisation whose body is in HBM and whose container table was parsed when it was first read.
+  // -> true: `b` (when given) has what the key holds; *card its cardinality; *present whether the key exists.
+  bool from_cache(MsiCboBatch *b, uint32_t db, const std::string &s1, const std::string &s2, uint64_t x, uint64_t y,
+                  uint64_t *card, bool *present) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (!dev.vm || !dev.pcache) return false;
+    MsiKnownPosting kp;
+    if (!msi_pcache_known(dev.pcache, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y), &kp)) return false;
+    if (card) *card = kp.card;
+    if (present) *present = kp.kind != 1;
+    if (b) {
+      if (kp.kind == 2) b->small_ids.insert(b->small_ids.end(), kp.small, kp.small + kp.n_small);
+      else if (kp.kind == 3) msi_cbo_batch_append_known(*b, kp.conts, kp.n_conts, kp.off);
+    }
+    return true;
+#else
+    (void)b; (void)db; (void)s1; (void)s2; (void)x; (void)y; (void)card; (void)present;
+    return false;
+#endif
+  }
   struct Cb {
     Clock c;
     ~Cb() {
@@ -1221,6 +1248,8 @@ struct Ctx {
   };
   bool add_word(MsiCboBatch &b, uint32_t w, bool original) {
     const std::string &s = words[w];
+    bool present = false;
+    if (from_cache(&b, 1, s, std::string(), original ? 1 : 0, 0, nullptr, &present)) return present;
     const uint8_t *bytes = nullptr;
     size_t n = 0;
     Cb cb_;
@@ -1230,6 +1259,8 @@ struct Ctx {
   }
   bool contains_word(uint32_t w) {   // Index::contains_word: the key exists; nothing is decoded
     const std::string &s = words[w];
+    bool present = false;
+    if (from_cache(nullptr, 1, s, std::string(), 1, 0, nullptr, &present)) return present;
     const uint8_t *bytes = nullptr;
     size_t n = 0;
     Cb cb_;
@@ -1240,13 +1271,20 @@ struct Ctx {
   uint64_t add_pair(MsiCboBatch *b, uint32_t prox, uint32_t w1, uint32_t w2) {  // returns the cardinality
     if (!ix->word_pair_proximity_docids) return 0;
     const std::string &l = words[w1], &r = words[w2];
+    uint64_t known_card = 0;
+    if (from_cache(b, 2, l, r, prox, 0, &known_card, nullptr)) return known_card;
     const uint8_t *bytes = nullptr;
     size_t n = 0;
     Cb cb_;
     const int32_t st = ix->word_pair_proximity_docids(ix->user, prox, (const uint8_t *)l.data(), (uint32_t)l.size(),
                                                       (const uint8_t *)r.data(), (uint32_t)r.size(), &bytes, &n);
     if (st < 0) fail(MSI_E_INTERNAL, "word_pair_proximity_docids callback failed");
-    if (!n || !bytes) return 0;
+    if (!n || !bytes) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+      if (dev.pcache) msi_pcache_learn(dev.pcache, msi_cache_key(2, l.data(), l.size(), r.data(), r.size(), prox, 0), nullptr, 0);
+#endif
+      return 0;
+    }
     const uint64_t card = msi_cbo_cardinality(bytes, n);
     if (b) take(*b, st, bytes, n, "word_pair_proximity_docids", 2, l, r, prox, 0);
     return card;
@@ -1254,6 +1292,7 @@ struct Ctx {
   void add_word_fid(MsiCboBatch &b, uint32_t w, uint32_t fid) {
     if (!ix->word_fid_docids) fail(MSI_E_INVALID, "the index vtable has no word_fid_docids (attribute / exactness rule)");
     const std::string &s = words[w];
+    if (from_cache(&b, 3, s, std::string(), fid, 0, nullptr, nullptr)) return;
     const uint8_t *bytes = nullptr;
     size_t n = 0;
     Cb cb_;
@@ -1265,6 +1304,7 @@ struct Ctx {
     if (!ix->word_position_docids)
       fail(MSI_E_INVALID, "the index vtable has no word_position_docids (position / exactness rule)");
     const std::string &s = words[w];
+    if (from_cache(&b, 4, s, std::string(), pos, 0, nullptr, nullptr)) return;
     const uint8_t *bytes = nullptr;
     size_t n = 0;
     Cb cb_;

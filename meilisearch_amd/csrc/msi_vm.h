@@ -155,4 +155,19 @@ int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint
 void msi_pcache_commit(MsiPostingCache *c, void *token);
 void msi_pcache_abandon(MsiPostingCache *c, void *token);   // the filling list failed / was dropped: the next reader refills
 uint64_t msi_pcache_device_base(const MsiPostingCache *c);
+// What the cache KNOWS about a key without asking the index again (valid for the index version the cache belongs to):
+// absent from the database | a raw value of <= 7 docids (kept on the host) | a serialisation whose body is ready in HBM,
+// with its parsed container table.  A warm search then makes no index callback and parses no posting header at all.
+struct MsiContainer;
+struct MsiKnownPosting {
+  int kind;                      // 1 absent, 2 small ids, 3 body in HBM
+  uint64_t off, len, card;       // kind 3: byte offset in the cache, serialised length; cardinality (kinds 2, 3)
+  const MsiContainer *conts;     // kind 3: offsets relative to the serialisation
+  uint32_t n_conts;
+  const uint32_t *small;         // kind 2
+  uint32_t n_small;
+};
+bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting *out);
+void msi_pcache_learn(MsiPostingCache *c, const MsiCacheKey &k, const uint8_t *bytes, size_t len);   // absent (len 0) or small values
+void msi_pcache_describe(MsiPostingCache *c, void *token, const uint8_t *bytes, size_t len);         // kind 3, before the commit
 void msi_pcache_stats(const MsiPostingCache *c, uint64_t out[4]);   // hits, misses, bytes used, capacity

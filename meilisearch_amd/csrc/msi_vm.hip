@@ -813,7 +813,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         break;
     }
     if (pcw == 0xFFFFFFFFu) break;
-    if (prof && tid == 0 && op < 15) s_prof[op] += wall_clock64() - t_op;
+    if (prof && tid == 0) s_prof[op == VM_DECODEC ? (uint32_t)VM_DECODE : (op >= 15 ? 14u : op)] += wall_clock64() - t_op;
   }
   if (prof && tid == 0) {
     for (int i = 1; i < 15; ++i)
@@ -1296,9 +1296,9 @@ void msi_vm_destroy(msi_vm *vmx) {
       u64 t[24] = {0};
       (void)hipMemcpy(t, vm->d_prof, sizeof t, hipMemcpyDeviceToHost);
       static const char *names[16] = {"", "fill", "op", "op_count", "clear", "claim", "and_many", "paths", "sub_many", "count",
-                                      "decode", "firstk", "minkey", "takekey", "", "all"};
+                                      "decode", "firstk", "minkey", "takekey", "rank", "all"};
       fprintf(stderr, "msi_vm profile: %llu workgroups, %.1f us each;", (unsigned long long)t[0], t[0] ? t[15] / 100.0 / t[0] : 0.0);
-      for (int i = 1; i < 14; ++i)
+      for (int i = 1; i < 15; ++i)
         if (t[i]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * t[i] / (double)t[15]);
       fprintf(stderr, "; scoped (command, chunk) executions %llu, of them on an all-zero chunk %llu", (unsigned long long)t[20], (unsigned long long)t[21]);
       fprintf(stderr, "; epilogue %.1f us per workgroup; %llu list-phases, first start to last ticket %.1f us\n",
@@ -1587,6 +1587,11 @@ struct KeyEq {
 struct CacheEntry {
   uint64_t off = 0;
   uint64_t len = 0;
+  // what msi_pcache_known hands out (written before `ready` / `host_kind` is released, never changed afterwards)
+  std::atomic<uint32_t> host_kind{0};   // 0 nothing, 1 absent, 2 small ids (no body in HBM: off / len unused)
+  uint64_t card = 0;
+  std::vector<MsiContainer> conts;
+  std::vector<uint32_t> small;
   std::atomic<uint32_t> ready{0};   // 0: reserved, being filled | 1: filled | 2: abandoned by a list that failed or was
 };                                  //    dropped — the next reader of the key takes the reservation over
 inline uint64_t mix64(uint64_t x) {
@@ -1689,6 +1694,65 @@ int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint
 
 void msi_pcache_commit(MsiPostingCache *, void *token) {
   if (token) static_cast<CacheEntry *>(token)->ready.store(1, std::memory_order_release);
+}
+
+bool msi_cbo_parse(const uint8_t *bytes, size_t len, std::vector<MsiContainer> &out);
+uint64_t msi_cbo_cardinality(const uint8_t *bytes, size_t len);
+
+bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting *out) {
+  std::shared_lock<std::shared_mutex> lk(c->mu);
+  auto it = c->map.find(k);
+  if (it == c->map.end()) return false;
+  const CacheEntry &e = it->second;
+  const uint32_t hk = e.host_kind.load(std::memory_order_acquire);
+  if (hk == 1 || hk == 2) {
+    out->kind = (int)hk;
+    out->off = out->len = 0;
+    out->card = e.card;
+    out->conts = nullptr;
+    out->n_conts = 0;
+    out->small = e.small.data();
+    out->n_small = (uint32_t)e.small.size();
+    c->hits.fetch_add(1, std::memory_order_relaxed);
+    return true;
+  }
+  if (e.ready.load(std::memory_order_acquire) != 1 || e.conts.empty()) return false;
+  out->kind = 3;
+  out->off = e.off;
+  out->len = e.len;
+  out->card = e.card;
+  out->conts = e.conts.data();
+  out->n_conts = (uint32_t)e.conts.size();
+  out->small = nullptr;
+  out->n_small = 0;
+  c->hits.fetch_add(1, std::memory_order_relaxed);
+  return true;
+}
+
+// the index answered "no such key" (len 0) or a raw value of <= 7 docids: remembered on the host
+void msi_pcache_learn(MsiPostingCache *c, const MsiCacheKey &k, const uint8_t *bytes, size_t len) {
+  if (len > 7 * sizeof(uint32_t)) return;
+  std::unique_lock<std::shared_mutex> lk(c->mu);
+  if (c->map.find(k) != c->map.end()) return;
+  CacheEntry &e = c->map[k];
+  for (size_t i = 0; i + 4 <= len; i += 4) {
+    uint32_t v;
+    memcpy(&v, bytes + i, 4);
+    e.small.push_back(v);
+  }
+  e.card = e.small.size();
+  e.host_kind.store(e.small.empty() ? 1u : 2u, std::memory_order_release);
+}
+
+// the reserved entry's container table, parsed once from the bytes its first reader holds (before msi_pcache_commit)
+void msi_pcache_describe(MsiPostingCache *, void *token, const uint8_t *bytes, size_t len) {
+  if (!token) return;
+  CacheEntry *e = static_cast<CacheEntry *>(token);
+  if (!e->conts.empty()) return;
+  std::vector<MsiContainer> cs;
+  if (!msi_cbo_parse(bytes, len, cs)) return;
+  e->card = msi_cbo_cardinality(bytes, len);
+  e->conts.swap(cs);
 }
 
 // The list that was to fill the entry failed or was dropped: hand the reservation to the next reader of the key.

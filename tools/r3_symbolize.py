@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Symbolises a RB_PROFILE dump of tools/ranked_bench (raw return addresses + the process's maps): inclusive and leaf
+sample counts per function.  python tools/r3_symbolize.py <dump> [top]"""
+import collections
+import os
+import subprocess
+import sys
+
+path = sys.argv[1]
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 45
+maps, samples = [], []
+for line in open(path):
+    if line.startswith("M "):
+        f = line[2:].split()
+        lo, hi = (int(x, 16) for x in f[0].split("-"))
+        off = int(f[2], 16)
+        name = f[5] if len(f) > 5 else ""
+        maps.append((lo, hi, off, name))
+    elif line.startswith("S"):
+        samples.append([int(x, 16) for x in line.split()[1:]])
+# module base = lowest mapping of each file
+base = {}
+for lo, hi, off, name in maps:
+    if name and (name not in base or lo - off < base[name]):
+        base[name] = lo - off
+def locate(pc):
+    for lo, hi, off, name in maps:
+        if lo <= pc < hi:
+            return name, pc - base[name]
+    return None, pc
+by_mod = collections.defaultdict(set)
+for s in samples:
+    for pc in s:
+        mod, rel = locate(pc - 1)
+        if mod:
+            by_mod[mod].add(rel)
+sym = {}
+SYMB = "/opt/rocm/lib/llvm/bin/llvm-symbolizer"
+for mod, rels in by_mod.items():
+    local = mod
+    if not os.path.exists(local):
+        # the GPU box's scratch path -> this checkout
+        for marker in ("/meilisearch_amd/", "/tools/bin/", "/oracle/"):
+            if marker in mod:
+                local = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), marker.strip("/"), mod.split(marker, 1)[1])
+    if not os.path.exists(local):
+        for r in rels:
+            sym[(mod, r)] = os.path.basename(mod)
+        continue
+    # nm-based: the defined text symbols of the module, bisected (llvm-symbolizer answers ?? for HIP fat binaries)
+    import bisect
+    out = subprocess.run(["nm", "-C", "--defined-only", local], capture_output=True, text=True).stdout
+    if not out.strip():
+        out = subprocess.run(["nm", "-C", "-D", "--defined-only", local], capture_output=True, text=True).stdout
+    table = []
+    for line in out.splitlines():
+        f = line.split(None, 2)
+        if len(f) == 3 and f[1] in "tTwW":
+            table.append((int(f[0], 16), f[2]))
+    table.sort()
+    addrs = [a for a, _ in table]
+    for r in rels:
+        i = bisect.bisect_right(addrs, r) - 1
+        sym[(mod, r)] = table[i][1] if i >= 0 else os.path.basename(mod)
+incl, leaf = collections.Counter(), collections.Counter()
+for s in samples:
+    names = []
+    for pc in s[2:]:   # skip the handler and the signal trampoline
+        mod, rel = locate(pc - 1)
+        names.append(sym.get((mod, rel), "?") if mod else "?")
+    if not names:
+        continue
+    leaf[names[0]] += 1
+    for n in set(names):
+        incl[n] += 1
+n = len(samples)
+print(n, "samples")
+print("---- leaf")
+for k, v in leaf.most_common(top):
+    print("%6.2f%%  %s" % (100.0 * v / n, k[:150]))
+print("---- inclusive")
+for k, v in incl.most_common(top):
+    print("%6.2f%%  %s" % (100.0 * v / n, k[:150]))

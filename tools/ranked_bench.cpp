@@ -224,6 +224,51 @@ static int32_t cpu_lookup(const uint8_t *w, uint32_t n, uint32_t max_typos, uint
 }  // namespace
 
 #ifndef RANKED_BENCH_LIB
+// RB_PROFILE=<file>: a sampling profile of the process's CPU time (ITIMER_PROF, 2 kHz; the signal lands on whichever thread
+// is burning CPU): raw return addresses + /proc/self/maps, symbolised offline (tools/r3_symbolize.py).
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/time.h>
+namespace prof {
+constexpr int DEPTH = 24, CAP = 1 << 17;
+void *g_pc[CAP][DEPTH];
+int g_n[CAP];
+std::atomic<int> g_count{0};
+void on_prof(int) {
+  const int i = g_count.fetch_add(1, std::memory_order_relaxed);
+  if (i >= CAP) return;
+  g_n[i] = backtrace(g_pc[i], DEPTH);
+}
+void start() {
+  void *warm[4];
+  backtrace(warm, 4);   // (loads libgcc outside the signal handler)
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_handler = on_prof;
+  sa.sa_flags = SA_RESTART;
+  sigaction(SIGPROF, &sa, nullptr);
+  struct itimerval it = {{0, 500}, {0, 500}};
+  setitimer(ITIMER_PROF, &it, nullptr);
+}
+void stop(const char *path) {
+  struct itimerval it = {{0, 0}, {0, 0}};
+  setitimer(ITIMER_PROF, &it, nullptr);
+  FILE *f = fopen(path, "w");
+  if (!f) return;
+  FILE *m = fopen("/proc/self/maps", "r");
+  char line[512];
+  while (m && fgets(line, sizeof(line), m))
+    if (strstr(line, " r-xp ") || strstr(line, " r--p 00000000")) fprintf(f, "M %s", line);
+  if (m) fclose(m);
+  const int n = std::min(g_count.load(), CAP);
+  for (int i = 0; i < n; ++i) {
+    fprintf(f, "S");
+    for (int k = 0; k < g_n[i]; ++k) fprintf(f, " %p", g_pc[i][k]);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+}
+}  // namespace prof
 // cgroup v2 CPU accounting of this container: {usage_usec, throttled_usec}
 static void cpu_stat(unsigned long long out[2]) {
   out[0] = out[1] = 0;
@@ -361,6 +406,7 @@ int main(int argc, char **argv) {
     uint64_t vs0[6] = {0, 0, 0, 0, 0, 0}, vs1[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long cs0[2], cs1[2];
     cpu_stat(cs0);
+    if (getenv("RB_PROFILE") && a == argc - 1) prof::start();
 #ifndef RANKED_BENCH_CPU
     msi_bits_vm_stats(pools[0], vs0);
 #endif
@@ -387,10 +433,12 @@ int main(int argc, char **argv) {
       for (int k = 0; k < 10; ++k) tot[k] += sums[t][k];
     }
     cpu_stat(cs1);
+    if (getenv("RB_PROFILE") && a == argc - 1) prof::stop(getenv("RB_PROFILE"));
     std::sort(all.begin(), all.end());
     const double nq = (double)all.size();
-    uint64_t pc[4] = {0, 0, 0, 0};
+    uint64_t pc[4] = {0, 0, 0, 0}, cst[3] = {0, 0, 0};
 #ifndef RANKED_BENCH_CPU
+    msi_search_compaction_stats(cst);
     msi_dict_posting_cache_stats(dict, pc);
     msi_bits_vm_stats(pools[0], vs1);
 #endif
@@ -401,7 +449,8 @@ int main(int argc, char **argv) {
            "\"posting_cache\": {\"hits\": %llu, \"misses\": %llu, \"bytes_used\": %llu}, "
            "\"vm\": {\"rounds\": %llu, \"lists\": %llu, \"us_queued_per_list\": %.1f, \"us_packed_per_list\": %.1f, "
            "\"us_launch_calls_per_round\": %.1f, \"us_after_launch_per_list\": %.1f}, "
-           "\"cpu\": {\"cpus_used\": %.2f, \"throttled_fraction_of_wall\": %.3f}}\n",
+           "\"cpu\": {\"cpus_used\": %.2f, \"throttled_fraction_of_wall\": %.3f}, "
+           "\"compact_space\": {\"searches\": %llu, \"of_them_compacted\": %llu, \"mean_universe_docs\": %.0f}}\n",
 #ifdef RANKED_BENCH_CPU
            "ranked_cpu_port",
 #else
@@ -413,7 +462,8 @@ int main(int argc, char **argv) {
            (unsigned long long)(vs1[0] - vs0[0]), (unsigned long long)(vs1[1] - vs0[1]), (vs1[2] - vs0[2]) / 1e3 / std::max<double>(1, vs1[1] - vs0[1]),
            (vs1[3] - vs0[3]) / 1e3 / std::max<double>(1, vs1[1] - vs0[1]), (vs1[4] - vs0[4]) / 1e3 / std::max<double>(1, vs1[0] - vs0[0]),
            (vs1[5] - vs0[5]) / 1e3 / std::max<double>(1, vs1[1] - vs0[1]),
-           (cs1[0] - cs0[0]) / 1e6 / dt, (cs1[1] - cs0[1]) / 1e6 / dt);
+           (cs1[0] - cs0[0]) / 1e6 / dt, (cs1[1] - cs0[1]) / 1e6 / dt,
+           (unsigned long long)cst[0], (unsigned long long)cst[1], cst[1] ? (double)cst[2] / (double)cst[1] : 0.0);
     fflush(stdout);
 #ifdef RANKED_BENCH_CPU
     for (auto &p : pools) mock_bits_destroy(p);
