@@ -35,6 +35,8 @@
 #include <condition_variable>
 #include <vector>
 
+#include <time.h>
+
 #include "msi_common.h"
 #include "msi_vm.h"
 
@@ -1149,7 +1151,7 @@ static int32_t dict_lookup_direct(msi_dict *d, const msi_typo_query *queries, ui
     d->h_stage = (uint8_t *)h;
     d->h_stage_cap = total * 2;
   }
-  if (!d->h_done) MSI_HIP_TRY(hipEventCreateWithFlags(&d->h_done, hipEventBlockingSync | hipEventDisableTiming));
+  if (!d->h_done) MSI_HIP_TRY(hipEventCreateWithFlags(&d->h_done, hipEventDisableTiming));
   uint8_t *h = d->h_stage;
   if (!bytes.empty()) memcpy(h, bytes.data(), bytes.size());
   memcpy(h + in_off, off.data(), (n + 1) * sizeof(uint32_t));
@@ -1165,7 +1167,17 @@ static int32_t dict_lookup_direct(msi_dict *d, const msi_typo_query *queries, ui
   MSI_HIP_TRY(hipMemcpyAsync(h + c1, d->out1c.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   MSI_HIP_TRY(hipMemcpyAsync(h + c2, d->out2c.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   MSI_HIP_TRY(hipEventRecord(d->h_done, st));
-  MSI_HIP_TRY(hipEventSynchronize(d->h_done));   // a blocking-sync event: the caller sleeps, no busy-wait
+  // Wait by polling the event with short sleeps: hipStreamSynchronize busy-waits (a fifth of the keyword leg's host CPU
+  // went there), a blocking-sync event sleeps until an interrupt that took up to hundreds of milliseconds on this box.
+  for (uint32_t spin = 0;; ++spin) {
+    const hipError_t q = hipEventQuery(d->h_done);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) MSI_HIP_TRY(q);
+    if (spin >= 4) {
+      struct timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+  }
   memcpy(out_one_idx, h + o1, (size_t)n * cap_one * sizeof(uint32_t));
   memcpy(out_two_idx, h + o2, (size_t)n * cap_two * sizeof(uint32_t));
   memcpy(out_one_cnt, h + c1, n * sizeof(uint32_t));

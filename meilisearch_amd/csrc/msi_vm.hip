@@ -208,6 +208,22 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     }
   }
   __syncthreads();
+  // wide phase (VM_DECODEC): this chunk's words of U0 and their exclusive prefix counts, once for all the phase's commands
+  uint32_t c_lo = 0, c_hi = 0;
+  if (wide) {
+    const uint32_t full_words = rp->full_words, full_chunks = rp->wide_chunks;
+    const uint32_t *prefix = reinterpret_cast<const uint32_t *>(rp->aux) + ((full_chunks + 3) & ~3u);
+    const u64 fw0 = (u64)chunk * CHW;
+    const uint32_t nwf = (uint32_t)min((u64)CHW, (u64)full_words - fw0);
+    const u64 *u0 = reinterpret_cast<const u64 *>(rp->full_base) + (u64)rp->u0_slot * full_words + fw0;
+    for (uint32_t i = tid; i < CHW; i += VT) {
+      s_dec[i] = i < nwf ? u0[i] : 0ull;
+      s_cnt[i] = i < nwf ? prefix[fw0 + i] : 0u;
+    }
+    c_lo = prefix[fw0];
+    c_hi = chunk + 1 < full_chunks ? prefix[fw0 + CHW] : (uint32_t)r.n_docs;
+    __syncthreads();
+  }
   uint32_t cmd_no = 0;
   // (one lane writes, the wave's lanes read: wave_barrier keeps the compiler — and the CPU emulation, whose lanes are
   // fibers — from moving a read across a write)
@@ -696,39 +712,103 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
                           // (a decode batch's containers of this chunk, or this chunk of a full-space slot) that are in
                           // U0 become ranks; this chunk's documents of U0 have the contiguous ranks [lo, hi), the part of
                           // dst this workgroup writes WHOLE (words shared with a neighbouring chunk: its own bits, atomically).
+                          // U0's words and prefix counts of this chunk are in LDS (s_dec / s_cnt, staged at the phase's
+                          // start); the containers are read straight from memory, a wave per container, no barrier between
+                          // them: a value only has to be looked up in U0 and, when it is there, ranked.
         const uint32_t dsts = W(1), srcw = W(2);
-        const uint32_t full_words = rp->full_words, full_chunks = rp->wide_chunks;
-        const uint32_t *aux = reinterpret_cast<const uint32_t *>(rp->aux);
-        const uint32_t *prefix = aux + ((full_chunks + 3) & ~3u);
+        const uint32_t full_words = rp->full_words;
         const u64 fw0 = (u64)chunk * CHW;
         const uint32_t nwf = (uint32_t)min((u64)CHW, (u64)full_words - fw0);
-        const u64 *full = reinterpret_cast<const u64 *>(rp->full_base);
-        const u64 *u0 = full + (u64)rp->u0_slot * full_words + fw0;
-        const uint32_t total = (uint32_t)r.n_docs;
-        const uint32_t lo = prefix[fw0], hi = chunk + 1 < full_chunks ? prefix[fw0 + CHW] : total;
+        const uint32_t lo = c_lo, hi = c_hi, total = (uint32_t)r.n_docs;
         const bool from_slot = (srcw >> 31) != 0;
-        const u64 *src_slot = from_slot ? full + (u64)(srcw & 0x7FFFFFFFu) * full_words + fw0 : nullptr;
+        const VmContainer *cs = nullptr;
         uint32_t n_here = 0;
-        if (!from_slot) n_here = decode_chunk(srcw, hi > lo);   // (bodies still go into the posting cache when nothing of U0 is here)
+        if (!from_slot) {
+          const uint32_t *data = arena + r.list_off + r.data_off;
+          const uint32_t *blk_c = data + 4 * (size_t)data[chunk];
+          const uint32_t c_first = blk_c[srcw];
+          n_here = blk_c[srcw + 1] - c_first;
+          cs = reinterpret_cast<const VmContainer *>(blk_c + ((r.n_decodes + 1 + 3) & ~3u)) + c_first;
+          // first reader of a key: its bodies go into the posting cache, whatever U0 holds in this chunk
+          for (uint32_t ci = 0; ci < n_here; ++ci) {
+            const VmContainer c = cs[ci];
+            if (c.fill_lo == 0xFFFFFFFFu && (c.meta >> 19) == 0x1FFFu) continue;
+            const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
+            const u64 fill_off = ((u64)(c.meta >> 19) << 32) | c.fill_lo;
+            const uint32_t len = type == 0 ? 2 * (card + 1) : (type == 1 ? 8192u : 4 * (card + 1));
+            const uintptr_t b0 = ((c.meta >> 18) & 1u) ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
+            const uint32_t skew = (uint32_t)(b0 & 15);
+            const uint4 *src = reinterpret_cast<const uint4 *>(b0 - skew);
+            uint4 *fill = reinterpret_cast<uint4 *>((uintptr_t)(r.cache + fill_off) - skew);
+            const uint32_t n16 = (skew + min(len, 8192u) + 15) / 16;
+            for (uint32_t i = tid; i < n16; i += VT) put4(&fill[i], src[i]);
+          }
+        }
         if (hi > lo) {
           u64 *s_out = reinterpret_cast<u64 *>(s_raw);          // [lo >> 6 .. (hi - 1) >> 6]: at most 1025 words
           const uint32_t fwd = lo >> 6, n_out = ((hi - 1) >> 6) - fwd + 1;
           __syncthreads();
           for (uint32_t i = tid; i < n_out; i += VT) s_out[i] = 0;
           __syncthreads();
-          if (from_slot || n_here)
+          // the documents `m` (bits of word wi of this chunk, all of them in U0) -> their ranks
+          auto rank_bits = [&](uint32_t wi, u64 m) {
+            const u64 uw = s_dec[wi];
+            const uint32_t base = s_cnt[wi] - (fwd << 6);
+            while (m) {
+              const uint32_t b = (uint32_t)__ffsll((long long)m) - 1;
+              const uint32_t rk = base + (uint32_t)__popcll(uw & ((1ull << b) - 1ull));
+              atomicOr(&s_out[rk >> 6], 1ull << (rk & 63));
+              m &= m - 1;
+            }
+          };
+          if (from_slot) {
+            const u64 *src_slot = reinterpret_cast<const u64 *>(rp->full_base) + (u64)(srcw & 0x7FFFFFFFu) * full_words + fw0;
             for (uint32_t wi = tid; wi < nwf; wi += VT) {
-              const u64 uw = u0[wi];
-              u64 m = (from_slot ? src_slot[wi] : s_dec[wi]) & uw;
-              if (!m) continue;
-              const uint32_t base = prefix[fw0 + wi] - (fwd << 6);
-              while (m) {
-                const uint32_t b = (uint32_t)__ffsll((long long)m) - 1;
-                const uint32_t rk = base + (uint32_t)__popcll(uw & ((1ull << b) - 1ull));
-                atomicOr(&s_out[rk >> 6], 1ull << (rk & 63));
-                m &= m - 1;
+              const u64 uw = s_dec[wi];
+              if (!uw) continue;
+              const u64 m = src_slot[wi] & uw;
+              if (m) rank_bits(wi, m);
+            }
+          } else {
+            for (uint32_t ci = wave; ci < n_here; ci += VT / 64) {   // a wave per container
+              const VmContainer c = cs[ci];
+              const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
+              const uintptr_t b0 = ((c.meta >> 18) & 1u) ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
+              const uint16_t *h = reinterpret_cast<const uint16_t *>(b0);   // bodies are 2-byte aligned
+              if (type == 0) {          // array: the values themselves
+                const uint32_t n = min(card + 1, 4096u);
+                for (uint32_t i = lane; i < n; i += 64) {
+                  const uint32_t v = h[i];
+                  if ((s_dec[v >> 6] >> (v & 63)) & 1ull) rank_bits(v >> 6, 1ull << (v & 63));
+                }
+              } else if (type == 1) {   // bitmap: only the words where U0 has a document are read
+                const bool al8 = (b0 & 7) == 0;
+                for (uint32_t wi = lane; wi < CHW; wi += 64) {
+                  const u64 uw = s_dec[wi];
+                  if (!uw) continue;
+                  u64 v;
+                  if (al8) v = reinterpret_cast<const u64 *>(b0)[wi];
+                  else v = (u64)h[4 * wi] | ((u64)h[4 * wi + 1] << 16) | ((u64)h[4 * wi + 2] << 32) | ((u64)h[4 * wi + 3] << 48);
+                  const u64 m = v & uw;
+                  if (m) rank_bits(wi, m);
+                }
+              } else {                  // runs: (start, length - 1) pairs
+                const uint32_t n_runs = min(card + 1, 2048u);
+                for (uint32_t rr = 0; rr < n_runs; ++rr) {
+                  const uint32_t start = h[2 * rr], last = min(65535u, start + (uint32_t)h[2 * rr + 1]);
+                  for (uint32_t wi = (start >> 6) + lane; wi <= (last >> 6); wi += 64) {
+                    const u64 uw = s_dec[wi];
+                    if (!uw) continue;
+                    u64 mask = ~0ull;
+                    if (wi == (start >> 6)) mask &= ~0ull << (start & 63);
+                    if (wi == (last >> 6)) mask &= (last & 63) == 63 ? ~0ull : ((1ull << ((last & 63) + 1)) - 1ull);
+                    const u64 m = uw & mask;
+                    if (m) rank_bits(wi, m);
+                  }
+                }
               }
             }
+          }
           __syncthreads();
           u64 *dst = pool + (u64)dsts * r.n_words;
           const bool tail = hi == total;   // the last range also owns what lies behind |U0|, up to the end of the slot
@@ -748,7 +828,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
           }
           if (tail)
             for (u64 gw = (u64)fwd + n_out + tid; gw < r.n_words; gw += VT) put1(&dst[gw], 0ull);
-          __syncthreads();   // s_raw / s_dec are reused by the next command
+          __syncthreads();   // s_out is reused by the next command
         }
         pcw += 3;
         break;
@@ -834,8 +914,9 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     __syncthreads();
     if (tid < SUM_W) put1(&sum_row[(u64)chunk * SUM_W + tid], s_sum[0][tid]);
   }
-  for (uint32_t i = tid; i < r.n_counts; i += VT)
-    if (s_cnt[i]) atomicAdd(&counts[i], (u64)s_cnt[i]);
+  if (!wide)   // (a wide phase keeps U0's prefix counts in s_cnt and counts nothing)
+    for (uint32_t i = tid; i < r.n_counts; i += VT)
+      if (s_cnt[i]) atomicAdd(&counts[i], (u64)s_cnt[i]);
   // Everything this workgroup stored is write-through (put): the ticket below only has to wait until those stores
   // and the cardinalities' atomics are acknowledged — no L2 write-back, no invalidate (a __threadfence here cost both,
   // under every resident kernel, 153 times per list at 10 M documents: r2_ranked10_timeline_before.txt).

@@ -120,7 +120,8 @@ def test_c3_2m_term_dictionary(ctx):
     g.close()
 
 
-def test_c4_keyword_leg(ctx):
+@pytest.mark.parametrize("run_containers", [False, True], ids=["array+bitmap", "with-run-containers"])
+def test_c4_keyword_leg(ctx, monkeypatch, run_containers):
     """The keyword leg of the headline step at its own size: msi_keyword_search_ranked (7 default criteria, detailed
     scores, 3-term queries with typo and prefix derivations, 16 caller threads sharing command-list launches) over the
     synthetic 10 M-document inverted index of tools/ranked_bench.cpp, against oracle/ranking_oracle.py reading the same
@@ -130,7 +131,9 @@ def test_c4_keyword_leg(ctx):
     from oracle import parity
     from oracle import synth_index as SI
     import os
-    n_docs, n_queries, limit = 10_000_000, 48, 20
+    if run_containers:      # every third key of the index run-encoded (cookie 12347): the third container form, also at 10 M
+        monkeypatch.setenv("RB_RUN_CONTAINERS", "1")
+    n_docs, n_queries, limit = 10_000_000, 24 if run_containers else 48, 20
     if os.environ.get("MSI_RUNNER_SO"):        # the CPU tier's emulated kernels (tests/emu): same path, 5 chunks of documents
         n_docs, n_queries = 300_000, 12
     lib = SI.runner_lib()

@@ -33,7 +33,7 @@ namespace {
 
 using Bytes = std::vector<uint8_t>;
 
-Bytes cbo_serialize(const std::vector<uint32_t> &ids) {  // cbo_roaring_bitmap_codec.rs:33-51 (array / bitmap containers)
+Bytes cbo_serialize(const std::vector<uint32_t> &ids, bool as_runs = false) {  // cbo_roaring_bitmap_codec.rs:33-51
   Bytes out;
   auto put16 = [&](uint16_t v) { out.push_back(v & 255); out.push_back(v >> 8); };
   auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; ++i) out.push_back((v >> (8 * i)) & 255); };
@@ -47,6 +47,31 @@ Bytes cbo_serialize(const std::vector<uint32_t> &ids) {  // cbo_roaring_bitmap_c
     while (j < ids.size() && (ids[j] >> 16) == (ids[i] >> 16)) ++j;
     runs.push_back({i, j});
     i = j;
+  }
+  if (as_runs) {
+    // the same set with every container run-encoded (cookie 12347, all run flags set; roaring writes these after
+    // optimize()): RB_RUN_CONTAINERS=1 serialises every third key this way so that the decoders' run path sees the
+    // 10 M-document index too
+    const uint32_t n = (uint32_t)runs.size();
+    put32(12347u | ((n - 1) << 16));
+    for (uint32_t i = 0; i < (n + 7) / 8; ++i) out.push_back(0xFF);
+    for (auto &r : runs) {
+      put16((uint16_t)(ids[r.first] >> 16));
+      put16((uint16_t)(r.second - r.first - 1));
+    }
+    if (n >= 4) for (uint32_t i = 0; i < n; ++i) put32(0);
+    for (auto &r : runs) {
+      std::vector<std::pair<uint16_t, uint16_t>> rl;
+      for (size_t i = r.first; i < r.second;) {
+        size_t j = i;
+        while (j + 1 < r.second && ids[j + 1] == ids[j] + 1) ++j;
+        rl.push_back({(uint16_t)(ids[i] & 0xFFFF), (uint16_t)(j - i)});
+        i = j + 1;
+      }
+      put16((uint16_t)rl.size());
+      for (auto &x : rl) { put16(x.first); put16(x.second); }
+    }
+    return out;
   }
   put32(12346);
   put32((uint32_t)runs.size());
@@ -113,7 +138,18 @@ struct Index {
       auto it = blobs.find(key);
       if (it != blobs.end()) return it->second->empty() ? nullptr : it->second.get();
     }
-    auto b = std::make_shared<Bytes>(cbo_serialize(make()));
+    const bool runs = getenv("RB_RUN_CONTAINERS") && getenv("RB_RUN_CONTAINERS")[0] == '1';
+    const std::vector<uint32_t> docs = make();
+    // (a chunk of more than 2047 runs does not fit the run count the decoders accept for one container: such keys stay as they are)
+    bool as_runs = runs && std::hash<std::string>{}(key) % 3 == 0;
+    if (as_runs) {
+      size_t in_chunk = 0;
+      for (size_t i = 0; i < docs.size() && as_runs; ++i) {
+        in_chunk = (i && (docs[i] >> 16) == (docs[i - 1] >> 16)) ? in_chunk + 1 : 1;
+        if (in_chunk > 2000) as_runs = false;
+      }
+    }
+    auto b = std::make_shared<Bytes>(cbo_serialize(docs, as_runs));
     std::unique_lock<std::shared_mutex> lk(mu);
     auto it = blobs.emplace(key, b).first;
     return it->second->empty() ? nullptr : it->second.get();
