@@ -1224,7 +1224,8 @@ struct Ctx {
   bool from_cache(MsiCboBatch *b, uint32_t db, const std::string &s1, const std::string &s2, uint64_t x, uint64_t y,
                   uint64_t *card, bool *present) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
-    if (!dev.vm || !dev.pcache) return false;
+    static const bool off = getenv("MSI_PCACHE_KNOWN") && getenv("MSI_PCACHE_KNOWN")[0] == '0';   // experiments
+    if (!dev.vm || !dev.pcache || off) return false;
     MsiKnownPosting kp;
     if (!msi_pcache_known(dev.pcache, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y), &kp)) return false;
     if (card) *card = kp.card;

@@ -344,7 +344,132 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     }
     return n_here;
   };
-  for (;;) {
+  // ---- wide phase, wave path ---------------------------------------------------------------------------------------
+  // A wide phase holds VM_DECODEC commands only (3 words each) and every one of them writes the SAME rank range [c_lo,
+  // c_hi) of its destination.  When that range is at most 256 words (always, unless U0 is dense), each WAVE takes
+  // commands of its own — its quarter of s_raw as the output words — and runs them without a workgroup barrier: four
+  // decodes in flight per workgroup, and a decode is a handful of dependent loads.
+  bool wide_done = false;
+  if (wide && (c_hi == c_lo || ((c_hi - 1) >> 6) - (c_lo >> 6) + 1 <= 256)) {
+    wide_done = true;
+    const uint32_t full_words = rp->full_words;
+    const u64 fw0 = (u64)chunk * CHW;
+    const uint32_t nwf = (uint32_t)min((u64)CHW, (u64)full_words - fw0);
+    const uint32_t lo = c_lo, hi = c_hi, total = (uint32_t)r.n_docs;
+    const uint32_t fwd = lo >> 6, n_out = hi > lo ? ((hi - 1) >> 6) - fwd + 1 : 0;
+    u64 *w_out = reinterpret_cast<u64 *>(s_raw) + wave * 256;
+    const uint32_t *data = arena + r.list_off + r.data_off;
+    const uint32_t *blk_c = r.n_decodes ? data + 4 * (size_t)data[chunk] : nullptr;
+    const VmContainer *cs_all = blk_c ? reinterpret_cast<const VmContainer *>(blk_c + ((r.n_decodes + 1 + 3) & ~3u)) : nullptr;
+    const uint32_t n_cmd = (p_end - p_begin) / 3;   // 3 words per command, then VM_END
+    for (uint32_t k = wave; k < n_cmd; k += VT / 64) {
+      if (MSI_UNIFORM(cmd[3 * k]) != VM_DECODEC) break;   // (cannot happen: the host records nothing else into a wide phase)
+      const uint32_t dsts = MSI_UNIFORM(cmd[3 * k + 1]), srcw = MSI_UNIFORM(cmd[3 * k + 2]);
+      const bool from_slot = (srcw >> 31) != 0;
+      const VmContainer *cs = nullptr;
+      uint32_t n_here = 0;
+      if (!from_slot) {
+        const uint32_t c_first = blk_c[srcw];
+        n_here = blk_c[srcw + 1] - c_first;
+        cs = cs_all + c_first;
+        for (uint32_t ci = 0; ci < n_here; ++ci) {   // first reader of a key: its bodies go into the posting cache
+          const VmContainer c = cs[ci];
+          if (c.fill_lo == 0xFFFFFFFFu && (c.meta >> 19) == 0x1FFFu) continue;
+          const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
+          const u64 fill_off = ((u64)(c.meta >> 19) << 32) | c.fill_lo;
+          const uint32_t len = type == 0 ? 2 * (card + 1) : (type == 1 ? 8192u : 4 * (card + 1));
+          const uintptr_t b0 = ((c.meta >> 18) & 1u) ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
+          const uint32_t skew = (uint32_t)(b0 & 15);
+          const uint4 *src = reinterpret_cast<const uint4 *>(b0 - skew);
+          uint4 *fill = reinterpret_cast<uint4 *>((uintptr_t)(r.cache + fill_off) - skew);
+          const uint32_t n16 = (skew + min(len, 8192u) + 15) / 16;
+          for (uint32_t i = lane; i < n16; i += 64) put4(&fill[i], src[i]);
+        }
+      }
+      if (!n_out) continue;
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < n_out; i += 64) w_out[i] = 0;
+      __builtin_amdgcn_wave_barrier();
+      auto rank_bits = [&](uint32_t wi, u64 m) {
+        const u64 uw = s_dec[wi];
+        const uint32_t base = s_cnt[wi] - (fwd << 6);
+        while (m) {
+          const uint32_t b = (uint32_t)__ffsll((long long)m) - 1;
+          const uint32_t rk = base + (uint32_t)__popcll(uw & ((1ull << b) - 1ull));
+          atomicOr(&w_out[rk >> 6], 1ull << (rk & 63));
+          m &= m - 1;
+        }
+      };
+      if (from_slot) {
+        const u64 *src_slot = reinterpret_cast<const u64 *>(rp->full_base) + (u64)(srcw & 0x7FFFFFFFu) * full_words + fw0;
+        for (uint32_t wi = lane; wi < nwf; wi += 64) {
+          const u64 uw = s_dec[wi];
+          if (!uw) continue;
+          const u64 m = src_slot[wi] & uw;
+          if (m) rank_bits(wi, m);
+        }
+      } else {
+        for (uint32_t ci = 0; ci < n_here; ++ci) {
+          const VmContainer c = cs[ci];
+          const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
+          const uintptr_t b0 = ((c.meta >> 18) & 1u) ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
+          const uint16_t *h = reinterpret_cast<const uint16_t *>(b0);   // bodies are 2-byte aligned
+          if (type == 0) {
+            const uint32_t n = min(card + 1, 4096u);
+            for (uint32_t i = lane; i < n; i += 64) {
+              const uint32_t v = h[i];
+              if ((s_dec[v >> 6] >> (v & 63)) & 1ull) rank_bits(v >> 6, 1ull << (v & 63));
+            }
+          } else if (type == 1) {
+            const bool al8 = (b0 & 7) == 0;
+            for (uint32_t wi = lane; wi < CHW; wi += 64) {
+              const u64 uw = s_dec[wi];
+              if (!uw) continue;
+              u64 v;
+              if (al8) v = reinterpret_cast<const u64 *>(b0)[wi];
+              else v = (u64)h[4 * wi] | ((u64)h[4 * wi + 1] << 16) | ((u64)h[4 * wi + 2] << 32) | ((u64)h[4 * wi + 3] << 48);
+              const u64 m = v & uw;
+              if (m) rank_bits(wi, m);
+            }
+          } else {
+            const uint32_t n_runs = min(card + 1, 2048u);
+            for (uint32_t rr = 0; rr < n_runs; ++rr) {
+              const uint32_t start = h[2 * rr], last = min(65535u, start + (uint32_t)h[2 * rr + 1]);
+              for (uint32_t wi = (start >> 6) + lane; wi <= (last >> 6); wi += 64) {
+                const u64 uw = s_dec[wi];
+                if (!uw) continue;
+                u64 mask = ~0ull;
+                if (wi == (start >> 6)) mask &= ~0ull << (start & 63);
+                if (wi == (last >> 6)) mask &= (last & 63) == 63 ? ~0ull : ((1ull << ((last & 63) + 1)) - 1ull);
+                const u64 m = uw & mask;
+                if (m) rank_bits(wi, m);
+              }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      u64 *dst = pool + (u64)dsts * r.n_words;
+      const bool tail = hi == total;
+      for (uint32_t i = lane; i < n_out; i += 64) {
+        const u64 gw = (u64)fwd + i;
+        const uint32_t lb = lo > gw * 64 ? (uint32_t)(lo - gw * 64) : 0u;
+        const uint32_t hb = hi < (gw + 1) * 64 ? (uint32_t)(hi - gw * 64) : 64u;
+        u64 own = (hb == 64 ? ~0ull : ((1ull << hb) - 1ull)) & ~((1ull << lb) - 1ull);
+        if (tail && i == n_out - 1) own |= hb == 64 ? 0ull : ~((1ull << hb) - 1ull);
+        const u64 val = w_out[i];
+        if (own == ~0ull) {
+          put1(&dst[gw], val);
+        } else {
+          atomicAnd(&dst[gw], ~own);
+          if (val) atomicOr(&dst[gw], val);
+        }
+      }
+      if (tail)
+        for (u64 gw = (u64)fwd + n_out + lane; gw < r.n_words; gw += 64) put1(&dst[gw], 0ull);
+    }
+  }
+  for (; !wide_done;) {
     const uint32_t op = W(0);
     if (op == VM_END) break;
     if (prof) {
@@ -1813,6 +1938,10 @@ bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting 
 // the index answered "no such key" (len 0) or a raw value of <= 7 docids: remembered on the host
 void msi_pcache_learn(MsiPostingCache *c, const MsiCacheKey &k, const uint8_t *bytes, size_t len) {
   if (len > 7 * sizeof(uint32_t)) return;
+  {
+    std::shared_lock<std::shared_mutex> rd(c->mu);   // (known keys are the rule: no writer lock for them)
+    if (c->map.find(k) != c->map.end()) return;
+  }
   std::unique_lock<std::shared_mutex> lk(c->mu);
   if (c->map.find(k) != c->map.end()) return;
   CacheEntry &e = c->map[k];
