@@ -41,6 +41,13 @@
 #ifndef MSI_RELEASE_DEVICE
 #define MSI_RELEASE_DEVICE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #endif
+// The acquire half on its own (buffer_inv sc1): lines of other XCDs' write-through stores this XCD may still hold are dropped.
+#ifndef MSI_ACQUIRE_DEVICE
+#define MSI_ACQUIRE_DEVICE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#endif
+#ifndef MSI_SLEEP
+#define MSI_SLEEP() __builtin_amdgcn_s_sleep(8)
+#endif
 #ifndef MSI_DYNAMIC_LDS
 #define MSI_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif

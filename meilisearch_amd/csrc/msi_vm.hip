@@ -130,7 +130,7 @@ __device__ __forceinline__ void put4(uint4 *p, uint4 v) {
   put1(q + 1, (u64)v.z | ((u64)v.w << 32));
 }
 
-__global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, uint32_t phase) {
+__global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, uint32_t launch_phase) {
   __shared__ uint32_t s_cnt[MSI_VM_MAX_COUNTS];
   __shared__ u64 s_dec[CHW];
   __shared__ uint4 s_raw[CHW * 8 / 16 + 2];   // one container body (<= 8 KiB) + alignment slack, staged with wide loads
@@ -151,10 +151,33 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   r.pool_base = rp->pool_base; r.n_words = rp->n_words; r.n_docs = rp->n_docs; r.host_res = rp->host_res; r.seq = rp->seq;
   r.stage = rp->stage; r.cache = rp->cache; r.n_chunks = rp->n_chunks; r.n_phases = rp->n_phases; r.list_off = rp->list_off;
   r.data_off = rp->data_off; r.state_off = rp->state_off; r.n_counts = rp->n_counts; r.n_decodes = rp->n_decodes;
-  const uint32_t chunk = blockIdx.x;
+  // A compact list whose phase 0 is WIDE (VM_DECODEC, one workgroup per chunk of the full space) and whose sets are a
+  // few chunks long runs its phases 0 and 1 in ONE launch (`fused`): the first wide_chunks workgroups of the list are the
+  // wide phase, the workgroups behind them are phase 1 and start once the list's OWN wide phase has handed in all its
+  // tickets.  (As two launches every list of a round waited for the slowest wide phase of the round before its
+  // commands could start — multi-list rounds took 4-5x a single list's time, profiles/r3_ranked10_trace_two_launches.txt.)
+  const bool fused = (rp->wide_mask & 0x80000000u) != 0;
+  uint32_t phase = launch_phase, chunk = blockIdx.x;
+  if (fused) {
+    if (launch_phase == 1) return;               // ran with launch 0
+    if (launch_phase == 0 && chunk >= rp->wide_chunks) {
+      phase = 1;
+      chunk -= rp->wide_chunks;
+    }
+  }
   const bool wide = ((rp->wide_mask >> phase) & 1u) != 0;       // a compact list's VM_DECODEC phase: chunks of the FULL space
   const uint32_t my_chunks = wide ? rp->wide_chunks : r.n_chunks;
   if (phase >= r.n_phases || chunk >= my_chunks) return;
+  if (fused && launch_phase == 0 && phase == 1) {
+    // the wide workgroups of this list were dispatched before this one (lower block indices): wait for their tickets
+    const uint32_t *done0 = arena + r.state_off;
+    if (threadIdx.x == 0)
+      while (__hip_atomic_load(done0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rp->wide_chunks) MSI_SLEEP();
+    __syncthreads();
+    // what they wrote (write-through stores and device-scope atomics) is in memory; drop what this XCD's caches may
+    // still hold of those lines
+    MSI_ACQUIRE_DEVICE();
+  }
   // MSI_VM_PROFILE (diagnostics): thread 0's wall-clock ticks (100 MHz) per opcode, summed over all workgroups
   u64 *const prof = reinterpret_cast<u64 *>(((u64)arena[3] << 32) | arena[2]);
   __shared__ u64 s_prof[16];
@@ -1353,6 +1376,9 @@ void VmCombiner::run() {
           r.u0_slot = l.u0_slot;
           r.wide_chunks = (uint32_t)((r.full_words + CHW - 1) / CHW);
           r.wide_mask = l.pre_merged ? 1u : 0u;
+          // phases 0 and 1 in one launch (vm_kernel, `fused`): only while the waiting workgroups are few
+          static const bool fuse_off = getenv("MSI_VM_FUSE") && getenv("MSI_VM_FUSE")[0] == '0';   // experiments
+          if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= 4 && !fuse_off) r.wide_mask |= 0x80000000u;
         } else {
           static const bool sum_off = getenv("MSI_VM_SUMMARY") && getenv("MSI_VM_SUMMARY")[0] == '0';   // diagnostics
           const uint64_t sp = sum_off ? 0 : (uint64_t)(uintptr_t)msi_bits_summary(p);
@@ -1362,14 +1388,20 @@ void VmCombiner::run() {
         memcpy(A.host + words_at[i], l.words.data(), l.words.size() * 4);
         reinterpret_cast<uint32_t *>(A.host + words_at[i])[l.words.size()] = VM_END;
         memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)r.n_chunks * 4 * l.max_fk_phase);
-        for (uint32_t ph = 0; ph < r.n_phases; ++ph)
+        for (uint32_t ph = 0; ph < r.n_phases; ++ph) {
+          if (r.wide_mask & 0x80000000u) {
+            if (ph == 0) max_chunks[0] = std::max(max_chunks[0], r.wide_chunks + r.n_chunks);
+            if (ph <= 1) continue;
+          }
           max_chunks[ph] = std::max(max_chunks[ph], ((r.wide_mask >> ph) & 1u) ? r.wide_chunks : r.n_chunks);
+        }
         max_phases = std::max(max_phases, r.n_phases);
       }
       const int64_t t_launch = now_ns();
       for (VmSub *s : batch) s->t_launch = t_launch;
       if (hipMemcpyAsync(A.dev, A.host, off, hipMemcpyHostToDevice, stream) != hipSuccess) st = MSI_E_HIP;
       for (uint32_t ph = 0; ph < max_phases && st == MSI_OK; ++ph) {
+        if (!max_chunks[ph]) continue;   // (phase 1 of fused lists ran with launch 0)
         hipLaunchKernelGGL(vm_kernel, dim3(std::max(1u, max_chunks[ph]), (uint32_t)n_sub), dim3(VT), 0, stream,
                            reinterpret_cast<uint32_t *>(A.dev), ph);
         if (hipGetLastError() != hipSuccess) st = MSI_E_HIP;

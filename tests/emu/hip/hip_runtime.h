@@ -42,6 +42,8 @@
 #define MSI_DYNAMIC_LDS(name) unsigned char *name = hipemu::g.dyn_lds
 #define MSI_ORDER_ATOMICS() ((void)0)
 #define MSI_RELEASE_DEVICE() ((void)0)
+#define MSI_ACQUIRE_DEVICE() ((void)0)
+#define MSI_SLEEP() ((void)0)   /* (workgroups of a launch run in block order: what a workgroup waits for has run) */
 #define MSI_UNIFORM(x) (x)
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
