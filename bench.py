@@ -52,6 +52,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The command-list rounds of the keyword leg run on 16 streams; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+# queues (default 4) and rounds that share a queue serialise: 4 -> 16 queues took the keyword leg from 2.8 k to 6.1 k
+# queries/s (profiles/r3_bench_variants.txt).  Must be set before the runtime starts (import torch); a deployment sets it
+# in the server's environment.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def parse_args():
@@ -71,7 +76,7 @@ def parse_args():
     ap.add_argument("--shard", choices=["queries", "rows"], default="queries")
     ap.add_argument("--no-typo", action="store_true")
     ap.add_argument("--no-rank", action="store_true", help="c4: leave the keyword leg and the hybrid merge out")
-    ap.add_argument("--kw-threads", type=int, default=64, help="c4: caller threads of the keyword leg (one in-flight search each)")
+    ap.add_argument("--kw-threads", type=int, default=128, help="c4: caller threads of the keyword leg (one in-flight search each)")
     ap.add_argument("--kw-terms", type=int, default=3, help="c4: words per keyword query")
     ap.add_argument("--kw-dict-words", type=int, default=200_000, help="c4: vocabulary of the synthetic inverted index")
     ap.add_argument("--kw-cache-mb", type=int, default=8192, help="c4: HBM posting cache of the index version")
@@ -335,7 +340,7 @@ def run_c4(args, env):
         kw_lib.rb_destroy.argtypes = [C.c_void_p]
         n_docs_kw = n_total if row_sharded else n
         h = kw_lib.rb_create(n_docs_kw, args.kw_dict_words)
-        assert kw_lib.rb_attach(h, ctx.handle, args.kw_threads, 1024, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
+        assert kw_lib.rb_attach(h, ctx.handle, args.kw_threads, 512, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
         n_kw_queries = 4 * Q
         kw_lib.rb_prepare_queries(h, n_kw_queries, args.kw_terms, 4242 + rank)
         kw = {"lib": kw_lib, "h": h, "ids": np.zeros((Q, k), np.uint32), "n": np.zeros(Q, np.uint32),

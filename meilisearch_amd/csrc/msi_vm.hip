@@ -1842,9 +1842,16 @@ struct MsiPostingCache {
   msi_ctx *ctx = nullptr;
   uint8_t *dev = nullptr;
   uint64_t cap = 0;
-  uint64_t used = 0;                 // guarded by mu (exclusive)
-  mutable std::shared_mutex mu;
-  std::unordered_map<MsiCacheKey, CacheEntry, KeyHash, KeyEq> map;
+  std::atomic<uint64_t> used{0};     // bump allocation of the HBM arena
+  // 64 shards by key hash: a warm search asks ~200 keys and 64+ searches ask at once — one reader-writer lock was the
+  // most contended cache line of the process (9 % of the keyword leg's host CPU, profiles/r3_ranked_cpu_profile_2.txt)
+  static constexpr uint32_t SHARDS = 64;
+  struct Shard {
+    mutable std::shared_mutex mu;
+    std::unordered_map<MsiCacheKey, CacheEntry, KeyHash, KeyEq> map;
+    char pad[64];
+  } shard[SHARDS];
+  Shard &of(const MsiCacheKey &k) { return shard[(k.b >> 7) % SHARDS]; }
   std::atomic<uint64_t> hits{0}, misses{0};
 };
 
@@ -1881,7 +1888,7 @@ MsiPostingCache *msi_pcache_create(msi_ctx *ctx, uint64_t capacity_bytes) {
   c->ctx = ctx;
   c->dev = (uint8_t *)d;
   c->cap = capacity_bytes;
-  c->used = 16;   // offset 0 stays unused
+  c->used.store(16);   // offset 0 stays unused
   return c;
 }
 
@@ -1895,19 +1902,20 @@ void msi_pcache_destroy(MsiPostingCache *c) {
 
 int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint64_t *off, void **token) {
   *token = nullptr;
+  MsiPostingCache::Shard &sh = c->of(k);
   {
-    std::shared_lock<std::shared_mutex> lk(c->mu);
-    auto it = c->map.find(k);
-    if (it != c->map.end()) {
+    std::shared_lock<std::shared_mutex> lk(sh.mu);
+    auto it = sh.map.find(k);
+    if (it != sh.map.end()) {
       const uint32_t state = it->second.ready.load(std::memory_order_acquire);
-      if (it->second.len == len && state == 1) {
+      if (it->second.host_kind.load(std::memory_order_acquire) == 0 && it->second.len == len && state == 1) {
         *off = it->second.off;
         c->hits.fetch_add(1, std::memory_order_relaxed);
         return 1;
       }
       c->misses.fetch_add(1, std::memory_order_relaxed);
       uint32_t abandoned = 2;
-      if (it->second.len == len && state == 2 &&
+      if (it->second.host_kind.load(std::memory_order_acquire) == 0 && it->second.len == len && state == 2 &&
           it->second.ready.compare_exchange_strong(abandoned, 0, std::memory_order_acq_rel)) {
         *off = it->second.off;    // the reservation of a list that never ran: this caller fills it
         *token = &it->second;
@@ -1917,14 +1925,16 @@ int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint
     }
   }
   c->misses.fetch_add(1, std::memory_order_relaxed);
-  std::unique_lock<std::shared_mutex> lk(c->mu);
-  if (c->map.find(k) != c->map.end()) return 0;
+  std::unique_lock<std::shared_mutex> lk(sh.mu);
+  if (sh.map.find(k) != sh.map.end()) return 0;
   const uint64_t need = ((uint64_t)len + 15 + 16) & ~15ull;   // + one block of slack for the last partial block
-  if (c->used + need > c->cap) return 0;
-  CacheEntry &e = c->map[k];
-  e.off = c->used;
+  uint64_t at = c->used.load(std::memory_order_relaxed);
+  do {
+    if (at + need > c->cap) return 0;
+  } while (!c->used.compare_exchange_weak(at, at + need, std::memory_order_relaxed));
+  CacheEntry &e = sh.map[k];
+  e.off = at;
   e.len = len;
-  c->used += need;
   *off = e.off;
   *token = &e;   // node addresses of an unordered_map are stable
   return 2;
@@ -1938,9 +1948,10 @@ bool msi_cbo_parse(const uint8_t *bytes, size_t len, std::vector<MsiContainer> &
 uint64_t msi_cbo_cardinality(const uint8_t *bytes, size_t len);
 
 bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting *out) {
-  std::shared_lock<std::shared_mutex> lk(c->mu);
-  auto it = c->map.find(k);
-  if (it == c->map.end()) return false;
+  MsiPostingCache::Shard &sh = c->of(k);
+  std::shared_lock<std::shared_mutex> lk(sh.mu);
+  auto it = sh.map.find(k);
+  if (it == sh.map.end()) return false;
   const CacheEntry &e = it->second;
   const uint32_t hk = e.host_kind.load(std::memory_order_acquire);
   if (hk == 1 || hk == 2) {
@@ -1970,13 +1981,14 @@ bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting 
 // the index answered "no such key" (len 0) or a raw value of <= 7 docids: remembered on the host
 void msi_pcache_learn(MsiPostingCache *c, const MsiCacheKey &k, const uint8_t *bytes, size_t len) {
   if (len > 7 * sizeof(uint32_t)) return;
+  MsiPostingCache::Shard &sh = c->of(k);
   {
-    std::shared_lock<std::shared_mutex> rd(c->mu);   // (known keys are the rule: no writer lock for them)
-    if (c->map.find(k) != c->map.end()) return;
+    std::shared_lock<std::shared_mutex> rd(sh.mu);   // (known keys are the rule: no writer lock for them)
+    if (sh.map.find(k) != sh.map.end()) return;
   }
-  std::unique_lock<std::shared_mutex> lk(c->mu);
-  if (c->map.find(k) != c->map.end()) return;
-  CacheEntry &e = c->map[k];
+  std::unique_lock<std::shared_mutex> lk(sh.mu);
+  if (sh.map.find(k) != sh.map.end()) return;
+  CacheEntry &e = sh.map[k];
   for (size_t i = 0; i + 4 <= len; i += 4) {
     uint32_t v;
     memcpy(&v, bytes + i, 4);
@@ -2005,9 +2017,8 @@ void msi_pcache_abandon(MsiPostingCache *, void *token) {
 uint64_t msi_pcache_device_base(const MsiPostingCache *c) { return c ? (uint64_t)(uintptr_t)c->dev : 0; }
 
 void msi_pcache_stats(const MsiPostingCache *c, uint64_t out[4]) {
-  std::shared_lock<std::shared_mutex> lk(c->mu);
   out[0] = c->hits.load();
   out[1] = c->misses.load();
-  out[2] = c->used;
+  out[2] = c->used.load();
   out[3] = c->cap;
 }
