@@ -101,14 +101,15 @@ int32_t msi_ctx_create(int32_t device, msi_ctx **out) {
   msi_ctx *c = new msi_ctx();
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
-  // The context's main stream carries the vector scan: 256 persistent workgroups that each want a whole CU's LDS.  The
-  // command-list kernels of the keyword searches (other streams, thousands of small workgroups) must not hold those CUs
-  // back: the scan's stream gets the highest dispatch priority (MSI_SCAN_STREAM_PRIORITY=0: plain streams).
+  // The context's main stream carries the vector scan: 256 persistent workgroups that each want a whole CU's LDS; the
+  // command-list kernels of the keyword searches run on other streams as thousands of small workgroups.  Giving the
+  // scan's stream the highest dispatch priority (MSI_SCAN_STREAM_PRIORITY=1) was measured and is OFF by default: the scan
+  // gained 3 % in the overlapped step and the keyword rounds lost more (hybrid step 157 -> 183 ms, r3_bench_variants.txt).
   {
     int least = 0, greatest = 0;
     const char *knob = getenv("MSI_SCAN_STREAM_PRIORITY");
     e = hipErrorNotSupported;
-    if (!(knob && knob[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+    if (knob && knob[0] == '1' && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
       e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest);
     if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   }
