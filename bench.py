@@ -85,6 +85,7 @@ def parse_args():
                          "streams HBM at 0.71 of peak on its own and the latency-bound keyword rounds are not stretched by it: "
                          "154 ms per step against 157-183 ms overlapped, profiles/r3_bench_variants.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="also skips the parity check (same leg)")
+    ap.add_argument("--no-also", action="store_true", help="c4: do not run the short C2 / C3 / C5 legs after the C4 line")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child for roofline.traffic")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--cpu-sample-words", type=int, default=4096)
@@ -216,36 +217,154 @@ def scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kernel_name, mu
             "timing": "HIP events on the kernel's launch stream, inside the timed region of this run"}
 
 
+def granted_cpus():
+    """CPUs this process may use: the affinity mask, capped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_thread_counts():
+    """The two thread counts every CPU baseline is timed at: what the container's CPU quota grants (oracle/cpubase.py:
+    host_threads) and every hardware thread the process may run on.  The better of the two is the reported baseline."""
+    from oracle import cpubase
+    quota = cpubase.host_threads()
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return sorted({quota, visible})
+
+
 def cpu_vector_baseline(cpu_rows, n, d, k, filter_frac=1.0):
+    """-> (seconds per query at the full size [best thread count], threads used, sample rows, {threads: queries/s})"""
     from meilisearch_amd import synth
     from oracle import cpubase
-    cores = cpubase.host_threads()
     sample = cpu_rows.shape[0]
     scan = cpubase.CpuVectorScan(cpu_rows, np.arange(sample, dtype=np.uint32))
     q = synth.make_embeddings(16, d, seed=5678)
-    scan.search(q[:2], k, threads=cores)  # warm
-    t0 = time.perf_counter()
-    scan.search(q, min(k, sample), threads=cores)
-    t_vec_sample = (time.perf_counter() - t0) / 16.0
-    t_vec = t_vec_sample * (n * filter_frac / sample)  # exact scan is linear in the rows it visits
-    return t_vec, cores, sample
+    by_threads = {}
+    for threads in cpu_thread_counts():
+        scan.search(q[:2], k, threads=threads)  # warm
+        t0 = time.perf_counter()
+        scan.search(q, min(k, sample), threads=threads)
+        t_vec_sample = (time.perf_counter() - t0) / 16.0
+        by_threads[threads] = t_vec_sample * (n * filter_frac / sample)  # exact scan is linear in the rows it visits
+    cores = min(by_threads, key=by_threads.get)
+    return by_threads[cores], cores, sample, {str(t): round(1.0 / v, 3) for t, v in by_threads.items()}
 
 
 def cpu_typo_baseline(words, concat, off, n_sample):
+    """-> (seconds per word [best thread count], seconds per word on one thread, threads used, {threads: words/s})"""
     from meilisearch_amd import synth
     from oracle import cpubase
-    cores = cpubase.host_threads()
     cdict = cpubase.CpuDictionary(concat, off)
     tq = synth.make_typo_queries(words, n_sample, seed=7)
     qb, qoff, qfl = cpubase.pack_queries(tq)
-    cdict.lookup_packed(qb[:], qoff[:65], qfl[:64], threads=cores)  # warm
-    t0 = time.perf_counter()
-    cdict.lookup_packed(qb, qoff, qfl, threads=cores)
-    t_all = (time.perf_counter() - t0) / len(tq)
+    by_threads = {}
+    for threads in cpu_thread_counts():
+        cdict.lookup_packed(qb[:], qoff[:65], qfl[:64], threads=threads)  # warm
+        t0 = time.perf_counter()
+        cdict.lookup_packed(qb, qoff, qfl, threads=threads)
+        by_threads[threads] = (time.perf_counter() - t0) / len(tq)
     t0 = time.perf_counter()
     cdict.lookup_packed(qb[:], qoff[:129], qfl[:128], threads=1)
     t_one = (time.perf_counter() - t0) / 128
-    return t_all, t_one, cores
+    cores = min(by_threads, key=by_threads.get)
+    return by_threads[cores], t_one, cores, {str(t): round(1.0 / v, 1) for t, v in by_threads.items()}
+
+
+def rocprof_exe():
+    for cand in ("rocprofv3", "/opt/rocm/bin/rocprofv3"):
+        try:
+            subprocess.run([cand, "--version"], capture_output=True, timeout=60)
+            return cand
+        except Exception:     # noqa: BLE001
+            continue
+    return None
+
+
+def pmc_rows(cmd, counters, kernel_substr, env=None, timeout=600):
+    """Runs `cmd` under `rocprofv3 --pmc <counters>` (counters in their own pass, no tracing domain) and returns
+    {counter: [values of the dispatches whose kernel name holds kernel_substr]} (None when nothing came back)."""
+    exe = rocprof_exe()
+    if exe is None:
+        return None
+    import csv
+    import glob
+    out_dir = tempfile.mkdtemp(prefix="msi_pmc_", dir="/tmp")
+    full = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out_dir, "-o", "pmc", "--"] + cmd
+    e = dict(os.environ if env is None else env, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    try:
+        subprocess.run(full, cwd="/tmp", env=e, capture_output=True, text=True, timeout=timeout)
+    except Exception:     # noqa: BLE001
+        return None
+    vals = {}
+    for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if kernel_substr in row.get("Kernel_Name", ""):
+                vals.setdefault(row.get("Counter_Name"), []).append(float(row["Counter_Value"]))
+    import shutil
+    shutil.rmtree(out_dir, ignore_errors=True)
+    return vals or None
+
+
+def keyword_roofline(n_docs, kw_threads, measured_qps):
+    """The roofline object of the keyword leg's kernel (vm_kernel, msi_vm.hip): the native driver of the same leg
+    (tools/bin/ranked_bench: same synthetic index, same queries' shape, `kw_threads` callers) runs three times as a child
+    of this process — plain (algorithmic bytes the command lists ask for, msi_bits_vm_bytes, and its own queries/s),
+    under `rocprofv3 --pmc FETCH_SIZE` and under `--pmc WRITE_SIZE` (separate passes) — and the counters are summed over
+    the vm_kernel dispatches of the measured window.  FETCH_SIZE x 2 is the guide's gfx950 correction for wide coalesced
+    loads; WRITE_SIZE is uncalibrated there and is reported as counted."""
+    exe = os.path.join(ROOT, "tools", "bin", "ranked_bench")
+    if not os.path.exists(exe):
+        return {"kernel": "vm_kernel", "note": "tools/bin/ranked_bench not built"}
+    threads = max(1, min(kw_threads, 64))
+    per_thread, distinct = 24, 512
+    cmd = [exe, str(n_docs), "200000", "3", str(per_thread), str(threads)]
+    env = dict(os.environ, RB_DETAILED="1", RB_DISTINCT_QUERIES=str(distinct), GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "16"))
+    out = {"kernel": "vm_kernel (command lists of msi_keyword_search_ranked)", "bound": "hbm", "peak": 8000.0, "unit": "GB/s"}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    except Exception as e:     # noqa: BLE001
+        out["note"] = f"child run failed: {e!r}"
+        return out
+    ab = line["algorithmic_bytes_per_query"]
+    algo = ab["set_operands"] + ab["posting_containers"]
+    n_measured = threads * per_thread
+    out.update({
+        "algorithmic_bytes_per_query": int(algo),
+        "algorithmic_bytes_breakdown_per_query": {"set_operands": int(ab["set_operands"]), "posting_containers": int(ab["posting_containers"])},
+        "child_queries_per_s": line["queries_per_s"], "child_callers": threads,
+        "universe_compaction": line.get("compact_space"),
+        "achieved": round(algo * measured_qps / 1e9, 1),
+        "achieved_is": "algorithmic bytes per query x the keyword leg's queries/s of THIS run",
+    })
+    out["frac"] = round(out["achieved"] / 8000.0, 5)
+    traffic = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        rows = pmc_rows(cmd, [counter], "vm_kernel", env=env)
+        if not rows or counter not in rows:
+            traffic[counter] = None
+            continue
+        v = rows[counter]
+        # the child first runs its `distinct` warm-up queries on one thread, then the measured ones: the counters of the
+        # whole process are split by the share of queries (the same searches, warm cache in both parts)
+        per_query_kb = sum(v) / (distinct + n_measured)
+        traffic[counter] = per_query_kb * 1024 * (2 if counter == "FETCH_SIZE" else 1)
+    out["traffic"] = None if traffic["FETCH_SIZE"] is None else round(traffic["FETCH_SIZE"] / 1e6, 2)
+    out["traffic_unit"] = "MB per query (HBM reads, PMC FETCH_SIZE x 2)"
+    out["traffic_writes_mb_per_query"] = None if traffic["WRITE_SIZE"] is None else round(traffic["WRITE_SIZE"] / 1e6, 2)
+    out["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE children of this run (tools/bin/ranked_bench, "
+                             f"{threads} callers, {distinct} + {n_measured} queries); counters summed over every vm_kernel dispatch")
+    out["reading"] = ("the leg is bound by dependent rounds (17 per query) and their launch / wake-up latency, not by bytes: "
+                      "with universe compaction a query's set traffic is megabytes, where round 2 moved ~0.5 GB per query")
+    return out
 
 
 # --------------------------------------------------------------------------------------------------- C4
@@ -320,6 +439,7 @@ def run_c4(args, env):
     # cycle through the steps; each was run once in setup so that the SYNTHETIC index has generated its postings
     # (index generation is not what is measured; nothing of a search's results is cached).
     kw = None
+    kw_threads = 0
     if not args.no_rank:
         import ctypes as C
         kw_so = os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so")
@@ -341,9 +461,15 @@ def run_c4(args, env):
         kw_lib.rb_pool.restype = C.c_void_p
         kw_lib.rb_pool.argtypes = [C.c_void_p, C.c_uint32]
         kw_lib.rb_destroy.argtypes = [C.c_void_p]
+        kw_lib.rb_last_latencies.restype = C.c_uint32
+        kw_lib.rb_last_latencies.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         n_docs_kw = n_total if row_sharded else n
         h = kw_lib.rb_create(n_docs_kw, args.kw_dict_words)
-        assert kw_lib.rb_attach(h, ctx.handle, args.kw_threads, 512, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
+        # Caller threads of this rank: a waiting search costs no CPU, but a search in flight needs ~1.3-1.8 ms of host CPU
+        # per query — N ranks share the box's CPUs, so each rank gets its share of callers (8 per granted CPU, at least 16)
+        host_cpus = granted_cpus()
+        kw_threads = args.kw_threads if world == 1 else max(16, min(args.kw_threads, host_cpus * 8 // world))
+        assert kw_lib.rb_attach(h, ctx.handle, kw_threads, 512, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
         n_kw_queries = 4 * Q
         kw_lib.rb_prepare_queries(h, n_kw_queries, args.kw_terms, 4242 + rank)
         kw = {"lib": kw_lib, "h": h, "ids": np.zeros((Q, k), np.uint32), "n": np.zeros(Q, np.uint32),
@@ -386,6 +512,22 @@ def run_c4(args, env):
         env.dist.all_reduce(ok, op=env.dist.ReduceOp.MIN)    # every rank takes the same path
         if int(ok.item()) == 0:
             group = None
+    exchange_path, rccl_ranks_seen = "none (one GPU)", 1
+    if world > 1:
+        # which exchange actually runs, and proof that every rank took part: each rank contributes its rank number
+        exchange_path = ("RCCL called inside libmsi (msi_group_create_rank + msi_group_allgather)" if group is not None else
+                         "torch.distributed all_gather_into_tensor (RCCL through the launcher's process group: "
+                         "msi_group_create_rank failed on this box)")
+        mine = torch.full((4,), rank, dtype=torch.int32, device=dev)
+        seen = torch.full((4 * world,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.current_stream().synchronize()
+        if group is not None:
+            ma._lib.check(L.msi_group_allgather(group, C.c_void_p(mine.data_ptr()), 16, C.c_void_p(seen.data_ptr())))
+            ctx.synchronize()
+        else:
+            env.dist.all_gather_into_tensor(seen, mine)
+            torch.cuda.synchronize()
+        rccl_ranks_seen = int(torch.unique(seen[seen >= 0]).numel())
 
     def exchange():
         """The one exchange step: per-rank top-k lists (Q*(2k+1)*4 bytes) in ONE all-gather over xGMI — RCCL called by
@@ -492,6 +634,103 @@ def run_c4(args, env):
         ma._lib.lib().msi_bits_vm_stats(C.c_void_p(kw["lib"].rb_pool(kw["h"], 0)), vs)
         legs["keyword_posting_cache"] = {"hits": int(pc[0]), "misses": int(pc[1]), "bytes_used": int(pc[2])}
         legs["keyword_lists_per_launch_round"] = round(vs[1] / max(1, vs[0]), 2)
+    # ---- per-QUERY latency (the metric is "queries/sec + p50 latency"; ms_per_step is the latency of a 768-query step) ----
+    latency = None
+    if kw is not None and not env.child and rank == 0:
+        def p50(xs):
+            return round(statistics.median(xs), 3)
+        q1 = q_t[:1].contiguous()
+        o_i, o_d = out_ids[:1].contiguous(), out_dist[:1].contiguous()
+        o_c, o_x = out_cnt[:1].contiguous(), inexact[:1].contiguous()
+        vec, kwl, hyb = [], [], []
+        one_ids, one_n, one_sc = np.zeros((1, k), np.uint32), np.zeros(1, np.uint32), np.zeros((1, k), np.float64)
+        for i in range(40):
+            t0 = time.perf_counter()
+            store.search_device(q1, k, o_i, o_d, o_c, o_x)          # one query: one sweep of the store for it alone
+            ctx.synchronize()
+            r_v = (o_i.cpu(), o_d.cpu(), o_c.cpu())
+            t1 = time.perf_counter()
+            assert kw["lib"].rb_run(kw["h"], i, 1, k, one_ids.ctypes.data, one_n.ctypes.data, one_sc.ctypes.data) == 0
+            t2 = time.perf_counter()
+            vec.append((t1 - t0) * 1e3)
+            kwl.append((t2 - t1) * 1e3)
+        for i in range(40):                                          # one hybrid query in flight: both legs, then the merge
+            t0 = time.perf_counter()
+            store.search_device(q1, k, o_i, o_d, o_c, o_x)          # enqueued; the keyword search runs meanwhile
+            assert kw["lib"].rb_run(kw["h"], 100 + i, 1, k, one_ids.ctypes.data, one_n.ctypes.data, one_sc.ctypes.data) == 0
+            ctx.synchronize()
+            v_ids = np.ascontiguousarray(o_i.cpu().numpy().view(np.uint32))
+            v_dist = np.ascontiguousarray(o_d.cpu().numpy())
+            v_cnt = np.ascontiguousarray(o_c.cpu().numpy().view(np.uint32))
+            kw["lib"].rb_hybrid_merge(1, k, v_ids.ctypes.data, v_dist.ctypes.data, v_cnt.ctypes.data, one_ids.ctypes.data,
+                                      one_sc.ctypes.data, one_n.ctypes.data, 0.5, kw["m_ids"].ctypes.data, kw["m_sem"].ctypes.data,
+                                      kw["m_cnt"].ctypes.data, kw["m_hits"].ctypes.data)
+            hyb.append((time.perf_counter() - t0) * 1e3)
+        keyword_run()                                                # a full step of the keyword leg: every search's own wall time
+        kw["step"] -= 1
+        at_load = np.zeros(Q, np.float64)
+        n_lat = kw["lib"].rb_last_latencies(kw["h"], at_load.ctypes.data, Q)
+        sweep_ms = scan_ms / max(1, scan_n)
+        latency = {
+            "vector_p50_ms_b1": p50(vec), "keyword_p50_ms_1_caller": p50(kwl), "hybrid_p50_ms_1_inflight": p50(hyb),
+            "keyword_p50_ms_at_load": p50(at_load[:n_lat].tolist()), "keyword_p99_ms_at_load": round(float(np.percentile(at_load[:n_lat], 99)), 3),
+            "hybrid_p50_ms_at_load": round(p50(at_load[:n_lat].tolist()) + sweep_ms, 3),
+            "at_load_is": f"{kw_threads} keyword callers in flight (wall time of each msi_keyword_search_ranked inside a {Q}-query step) "
+                          f"+ one {store.max_batch}-query HBM sweep of the store ({sweep_ms:.2f} ms) for the vector list",
+            "per": "query"}
+    # ---- N > 1: the north_star's own C4 shape beside the weak-scaling line — rows sharded over the GPUs (1 / N of the store
+    # each), the same query batch on every GPU, one packed all-gather + device k-way merge; vector leg only, untimed extra ----
+    rows_sharded_leg = None
+    if world > 1 and not row_sharded:
+        try:
+            from meilisearch_amd.distributed import merge_topk_device, row_range
+            sr0, sr1 = row_range(n_total, rank, world)
+            s_rows = synth.device_rows(sr1 - sr0, d, dev, seed=4321 + rank)
+            s_ids = torch.arange(sr0, sr1, dtype=torch.int32, device=dev)
+            sh_store = ma.GpuStore(ctx, d, storage=storage)
+            sh_store.upload_device(s_ids, s_rows)
+            del s_rows
+            sq_t = synth.device_queries(Q, d, dev, seed=999)        # the SAME batch on every rank
+            s_packed = torch.zeros(Q * (2 * k + 1), dtype=torch.int32, device=dev)
+            s_gath = torch.zeros(world * Q * (2 * k + 1), dtype=torch.int32, device=dev)
+            sm_ids = torch.zeros((Q, k), dtype=torch.int32, device=dev)
+            sm_dist = torch.zeros((Q, k), dtype=torch.float32, device=dev)
+            sm_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
+
+            def sharded_step():
+                sh_store.search_device(sq_t, k, out_ids, out_dist, out_cnt, inexact)
+                ctx.synchronize()
+                s_packed[:Q * k].copy_(out_dist.view(torch.int32).reshape(-1))
+                s_packed[Q * k:2 * Q * k].copy_(out_ids.reshape(-1))
+                s_packed[2 * Q * k:].copy_(out_cnt)
+                torch.cuda.current_stream().synchronize()
+                if group is not None:
+                    ma._lib.check(ma._lib.lib().msi_group_allgather(group, C.c_void_p(s_packed.data_ptr()), s_packed.numel() * 4,
+                                                                    C.c_void_p(s_gath.data_ptr())))
+                    ctx.synchronize()
+                else:
+                    env.dist.all_gather_into_tensor(s_gath, s_packed)
+                    torch.cuda.synchronize()
+                g = s_gath.view(world, Q * (2 * k + 1))
+                merge_topk_device(ctx, g[:, Q * k:2 * Q * k].reshape(world, Q, k).contiguous(),
+                                  g[:, :Q * k].view(torch.float32).reshape(world, Q, k).contiguous(),
+                                  g[:, 2 * Q * k:].reshape(world, Q).contiguous(), sm_ids, sm_dist, sm_cnt)
+                ctx.synchronize()
+                return sm_ids.cpu(), sm_dist.cpu(), sm_cnt.cpu()
+            s_elapsed, s_lat = env.timed(sharded_step, 10, 2)
+            rows_sharded_leg = {
+                "what": f"BASELINE config 4 as written: {n_total} docs x {d}-d sharded over {world} GPUs ({sr1 - sr0} rows on rank 0), "
+                        f"the same {Q}-query batch on every GPU, ONE packed all-gather of per-shard top-{k} + device k-way merge "
+                        "(vector leg only, 10 steps, max over ranks)",
+                "queries_per_s": round(Q * 10 / s_elapsed, 1), "ms_per_step": round(s_elapsed / 10 * 1e3, 3),
+                "p50_step_ms": round(statistics.median(s_lat), 3), "scaling": "strong", "exchange_path": exchange_path}
+        except Exception as e:      # noqa: BLE001 - an extra: the weak-scaling line must still be produced
+            rows_sharded_leg = {"error": repr(e)[:300]}
+            if env.dist is not None:
+                try:
+                    env.dist.barrier()
+                except Exception:   # noqa: BLE001
+                    pass
     if rank != 0:
         return None
     total_queries = Q * (1 if row_sharded else world) * args.steps
@@ -517,13 +756,15 @@ def run_c4(args, env):
                          " + exact f32 reference rescoring of K' candidates with an exactness proof",
             "sharding": ("rows sharded (%d per GPU of %d), same query batch on every GPU, ONE packed all_gather of "
                          "per-shard top-k (RCCL) + device k-way merge" % (n, n_total)) if row_sharded else
-                        "queries sharded, index replicated per GPU, ONE packed all-gather of per-rank top-k (RCCL called inside libmsi: msi_group_allgather)",
+                        "queries sharded, index replicated per GPU, ONE packed all-gather of per-rank top-k per step; exchange path: " + exchange_path,
+            "rccl_ranks_seen": rccl_ranks_seen,
+            "keyword_callers_per_rank": kw_threads if kw is not None else 0, "host_cpus_granted": granted_cpus(),
             "step_includes": ["vs_scan + select + reference rescoring", "dict_lookup (scan of the first-letter range, "
                               "binary searches for the other first letters, cap logic)", "D2H of results"]
                              + ([] if kw is None else [
                                  "msi_keyword_search_ranked for every query: default criteria [words, typo, proximity, attributeRank, "
                                  "sort, wordPosition, exactness], %d words per query, typo derivations from the index's %d-word "
-                                 "dictionary feeding the postings, %d caller threads" % (args.kw_terms, args.kw_dict_words, args.kw_threads),
+                                 "dictionary feeding the postings, %d caller threads" % (args.kw_terms, args.kw_dict_words, kw_threads),
                                  "hybrid merge (semanticRatio 0.5) of the vector list with the keyword list (global scores)"]),
             "step_excludes": ["keyword leg", "hybrid merge"] if kw is None else [],
             "inexact_queries_last_step": n_inexact,
@@ -532,23 +773,27 @@ def run_c4(args, env):
         "roofline": scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, "vs_scan_kernel (main pass)",
                                   must_contain=("false",)),
         "legs": legs,
+        "latency": latency,
+        "rows_sharded": rows_sharded_leg,
         "dict_lookup": {"launches_timed": match_n, "avg_launch_ms": round(match_ms / max(1, match_n), 4),
                         "words_per_launch": n_words_q,
                         "words_per_s_kernel_only": round(n_words_q / (match_ms / max(1, match_n) * 1e-3), 1) if match_n else None},
     }
     if env.check:
-        t_vec, cores, sample = cpu_vector_baseline(cpu_rows, n, d, k)
-        t_word = 0.0
+        t_vec, cores, sample, vec_by_threads = cpu_vector_baseline(cpu_rows, n, d, k)
+        t_word, typo_by_threads, typo_cores = 0.0, None, None
         if gdict is not None:
-            t_word, _, _ = cpu_typo_baseline(words, concat, off, args.cpu_sample_words)
+            t_word, _, typo_cores, typo_by_threads = cpu_typo_baseline(words, concat, off, args.cpu_sample_words)
         per_query = t_vec + args.words_per_query * t_word
         out["cpu_baseline"] = {
             "value": round(1.0 / per_query, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"vector: 16 queries x {sample} rows x {d}-d (all {cores} threads), scaled x{n / sample:.0f} to {n} "
-                      f"rows; typo: {args.cpu_sample_words} words over the full {args.dict_words}-term dictionary "
-                      "(threads take queries from a shared counter)",
-            "vector_queries_per_s": round(1.0 / t_vec, 3),
-            "typo_words_per_s": round(1.0 / t_word, 1) if t_word else None}
+            "sample": f"vector: 16 queries x {sample} rows x {d}-d, scaled x{n / sample:.0f} to {n} rows; typo: "
+                      f"{args.cpu_sample_words} words over the full {args.dict_words}-term dictionary (threads take queries from a "
+                      "shared counter); each leg timed at the container's CPU quota AND at every visible hardware thread, the "
+                      "better one kept",
+            "vector_queries_per_s": round(1.0 / t_vec, 3), "vector_queries_per_s_by_threads": vec_by_threads,
+            "typo_words_per_s": round(1.0 / t_word, 1) if t_word else None, "typo_words_per_s_by_threads": typo_by_threads,
+            "typo_threads": typo_cores}
         # ---- untimed parity check of this run's own results (the store of the timed steps, its query batch) ----
         from oracle import parity
         nqc = min(args.parity_queries, Q)
@@ -609,6 +854,39 @@ def run_c4(args, env):
             par["keyword"] = kpar
             par["mismatches"] += kpar["mismatches"] + kbad
         out["parity"] = par
+    if kw is not None:
+        kw_qps = legs.get("keyword_only_queries_per_s") or 0.0
+        kw["lib"].rb_destroy(kw["h"])      # the runner's pools go before the children / the other configurations start
+        kw = None
+        if env.rank == 0 and env.world == 1 and not env.child and not args.no_pmc:
+            # the keyword leg's kernel: algorithmic bytes and HBM traffic per query (children of this run)
+            out["keyword_roofline"] = keyword_roofline(n, kw_threads, kw_qps)
+    return out
+
+
+def also_configs(args, env):
+    """The other BASELINE configurations inside the default invocation (the driver only runs the default command): short
+    runs of C2, C3 and the C5 shard, each with its own roofline, cpu_baseline and parity objects.  Untimed extras of the C4
+    line — `value` is not affected.  Each leg frees what it allocated before the next one starts."""
+    import copy
+    import gc
+    out = {}
+    for cfg, fn, steps in (("c2", run_c2, 10), ("c3", run_c3, 5), ("c5", run_c5, 5)):
+        a = copy.copy(args)
+        a.config, a.steps, a.warmup = cfg, steps, 2
+        a.rows = a.dim = a.k = a.queries = a.storage = None
+        a.parity_queries = 16
+        t0 = time.time()
+        try:
+            line = fn(a, env)
+            keep = {k_: line[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "dtype", "config", "roofline",
+                                             "cpu_baseline", "parity", "dict_roofline") if k_ in line}
+            keep["steps"], keep["seconds"] = steps, round(time.time() - t0, 1)
+            out[cfg] = keep
+        except Exception as e:      # noqa: BLE001 - an extra: the C4 line must still be produced
+            out[cfg] = {"error": repr(e)[:300]}
+        gc.collect()
+        env.torch.cuda.empty_cache()
     return out
 
 
@@ -663,9 +941,10 @@ def run_c2(args, env):
     }
     if env.check:
         cpu_rows = rows_t[:min(n, args.cpu_sample_rows)].cpu().numpy()
-        t_vec, cores, sample = cpu_vector_baseline(cpu_rows, n, d, k)
+        t_vec, cores, sample, by_threads = cpu_vector_baseline(cpu_rows, n, d, k)
         out["cpu_baseline"] = {"value": round(1.0 / t_vec, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-                               "sample": f"16 queries x {sample} rows x {d}-d (all {cores} threads), scaled x{n / sample:.0f}"}
+                               "sample": f"16 queries x {sample} rows x {d}-d, scaled x{n / sample:.0f}; timed at the CPU quota and "
+                                         "at every visible thread, the better kept", "queries_per_s_by_threads": by_threads}
         from oracle import parity
         nqc = min(args.parity_queries, Q)
         qh = q_t[:nqc].cpu().numpy()
@@ -765,11 +1044,29 @@ def run_c3(args, env):
                           "algorithmic_wave_instructions_per_launch": int(valu_instr),
                           "model": f"{I_FILTER} per 64-word filter step + {I_DP} per 64-pair DP drain = 920 set-up + 90 per word char x 9 chars (ISA count, DESIGN §4.3)"},
     }
+    if env.check and not args.no_pmc:
+        # measured, not modelled: SQ counters of dict_lookup_kernel from a 2-step child of this configuration
+        child = [sys.executable, os.path.abspath(__file__), "--config", "c3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                 "--no-pmc", "--queries", str(B), "--dict-words", str(args.dict_words)]
+        rows = pmc_rows(child, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES"],
+                        "dict_lookup_kernel", env=dict(os.environ, MSI_BENCH_CHILD="1"))
+        if rows and rows.get("SQ_INSTS_VALU"):
+            mean = {c: sum(v) / len(v) for c, v in rows.items() if v}
+            insts = mean["SQ_INSTS_VALU"]
+            out["dict_roofline"]["measured"] = {
+                "source": "live: rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES child of this run, "
+                          "mean per dict_lookup_kernel dispatch",
+                "counters_per_launch": {c: round(v, 1) for c, v in mean.items()},
+                "valu_wave_instructions_per_s": round(insts / (avg_ms * 1e-3), 1) if match_n else None,
+                "frac_of_valu_issue_peak": round(insts / (avg_ms * 1e-3) / valu_peak, 4) if match_n else None,
+                "valu_active_per_wave_cycle": round(mean.get("SQ_ACTIVE_INST_VALU", 0.0) / max(1.0, mean.get("SQ_WAVE_CYCLES", 1.0)), 4),
+                "model_over_measured_instructions": round(valu_instr / max(1.0, insts), 3)}
     if env.check:
-        t_all, t_one, cores = cpu_typo_baseline(words, concat, off, args.cpu_sample_words)
+        t_all, t_one, cores, by_threads = cpu_typo_baseline(words, concat, off, args.cpu_sample_words)
         out["cpu_baseline"] = {"value": round(1.0 / t_all, 1), "unit": "words/s", "cores": cores, "kind": "port",
-                               "sample": f"{args.cpu_sample_words} words over the full dictionary, {cores} threads taking "
-                                         "queries from a shared counter; one thread: %.1f words/s" % (1.0 / t_one)}
+                               "sample": f"{args.cpu_sample_words} words over the full dictionary, threads taking queries from a "
+                                         "shared counter, timed at the CPU quota and at every visible thread (the better kept); "
+                                         "one thread: %.1f words/s" % (1.0 / t_one), "words_per_s_by_threads": by_threads}
         from oracle import parity
         nw = min(512, B)
         got = gdict.lookup(tq[:nw])
@@ -865,10 +1162,11 @@ def run_c5(args, env):
         allowed = np.nonzero(np.unpackbits(fb.view(np.uint8), bitorder="little")[:n])[0]
         al_t = torch.from_numpy(allowed).to(dev)
         sub = synth.round_to_bf16(rows_t[al_t].cpu().numpy()) if storage == "bf16" else rows_t[al_t].cpu().numpy()
-        t_vec, cores, sample = cpu_vector_baseline(sub[:args.cpu_sample_rows], allowed.size, d, k)
+        t_vec, cores, sample, by_threads = cpu_vector_baseline(sub[:args.cpu_sample_rows], allowed.size, d, k)
         out["cpu_baseline"] = {"value": round(1.0 / t_vec, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-                               "sample": f"vector leg only: 16 queries x {sample} allowed rows x {d}-d (all {cores} threads), "
-                                         f"scaled to the {allowed.size} allowed rows"}
+                               "sample": f"vector leg only: 16 queries x {sample} allowed rows x {d}-d, scaled to the "
+                                         f"{allowed.size} allowed rows; timed at the CPU quota and at every visible thread, the "
+                                         "better kept", "queries_per_s_by_threads": by_threads}
         from oracle import parity
         nqc = min(8, B)
         qh = q_t[:nqc].cpu().numpy()
@@ -900,6 +1198,11 @@ def main():
     args = parse_args()
     env = Env(args)
     out = {"c1": run_c1, "c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](args, env)
+    if args.config == "c4" and out is not None and env.check and not args.no_also:
+        import gc
+        gc.collect()
+        env.torch.cuda.empty_cache()
+        out["also"] = also_configs(args, env)
     env.finish()
     if env.rank == 0 and out is not None:
         print(json.dumps(out))

@@ -824,6 +824,10 @@ double msi_score_details_global_score(const msi_score_detail *details, uint32_t 
  * lists executed, then nanoseconds summed over lists: queued before the combiner took the list, packing, (per round)
  * inside the HIP launch calls, from the launch calls until the caller saw its result]. */
 int32_t msi_bits_vm_stats(msi_bits *pool, uint64_t out[6]);
+/* Diagnostics, process-wide: what the command lists executed so far ASKED the memory system for — [bytes of set operands
+ * (every operand of every command, whole), bytes of posting containers their decodes read, lists] — the algorithmic
+ * bytes of the keyword leg's roofline object (bench.py: keyword_roofline). */
+int32_t msi_bits_vm_bytes(uint64_t out[3]);
 
 /* Diagnostics: counters of the last msi_keyword_search_ranked on the calling thread —
  * [kernel launches, stream syncs, decode batches, index callbacks, posting bytes decoded, matching paths,

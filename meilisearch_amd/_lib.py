@@ -261,6 +261,7 @@ PROTOTYPES = {
                                          C.POINTER(_U32), C.POINTER(_U64), C.POINTER(_I32)]),
     "msi_search_last_stats": (_I32, [C.POINTER(_U64)]),
     "msi_search_compaction_stats": (_I32, [C.POINTER(_U64)]),
+    "msi_bits_vm_bytes": (_I32, [C.POINTER(_U64)]),
     "msi_score_details_global_score": (_F64, [_VP, _U32]),
     "msi_distribution_shift": (_F32, [_F32, _F32, _F32]),
     "msi_rank_global_score": (_F64, [_VP, _VP, _U32]),

@@ -1729,8 +1729,61 @@ static void finalize_decodes(MsiVmList &l) {
 }
 
 
+// Algorithmic bytes of a list: every set operand of every command, whole (slot words x 8), plus the container bodies its
+// decodes read and — compact lists — U0's words and prefix counts once per decode.  What the commands ASK the memory
+// system for; msi_bits_vm_bytes hands the sums out for the keyword leg's roofline object (bench.py).
+static std::atomic<uint64_t> g_vm_set_bytes{0}, g_vm_posting_bytes{0}, g_vm_lists{0};
+static void account_list(msi_bits *pool, const MsiVmList &l) {
+  const uint64_t words = l.geom_docs ? std::max<uint64_t>(2, ((l.geom_docs + 127) / 128) * 2) : msi_bits_words_per_slot(pool);
+  const uint64_t set_b = words * 8;
+  uint64_t sets = 0, wide = 0;
+  const std::vector<uint32_t> &w = l.words;
+  for (size_t i = 0; i < w.size();) {
+    switch (w[i]) {
+      case VM_END: i += 1; break;
+      case VM_FILL: sets += 1; i += 3; break;
+      case VM_OP: sets += 3; i += 5; break;
+      case VM_OP_COUNT: sets += 3; i += 6; break;
+      case VM_CLEAR: sets += w[i + 1]; i += 2 + w[i + 1]; break;
+      case VM_CLAIM: sets += 5 + 2 * w[i + 4]; i += 5 + w[i + 4]; break;
+      case VM_AND_MANY: sets += 1 + 2 * w[i + 2]; i += 4 + 2 * w[i + 2]; break;
+      case VM_PATHS: sets += 4 + (w[i + 5] & 0x7FFFFFFFu); i += 7 + w[i + 1] + (w[i + 5] & 0x7FFFFFFFu); break;
+      case VM_SUB_MANY: sets += 1 + 2 * w[i + 2]; i += 4 + w[i + 2]; break;
+      case VM_COUNT: sets += 1; i += 3; break;
+      case VM_DECODE: sets += 1; i += 4; break;
+      case VM_FIRSTK: sets += 1; i += 5; break;
+      case VM_MINKEY: sets += 1; i += 5; break;
+      case VM_TAKEKEY: sets += 3; i += 8; break;
+      case VM_SUMMARY_RESET: i += 1; break;
+      case VM_RANK_A: sets += 1; i += 4; break;
+      case VM_RANK_B: sets += 2; i += 5; break;   // U0 again + the tables (4 B per word + 4 B per document: about one set)
+      case VM_DECODEC: sets += 1; wide += 1; i += 3; break;
+      default: i = w.size(); break;
+    }
+  }
+  uint64_t posting = 0;
+  for (const auto &d : l.decodes)
+    for (size_t c = 0; c + 1 < d.c.size(); c += 2) {
+      const uint32_t meta = (uint32_t)d.c[c], type = (meta >> 16) & 3u, card = meta & 0xFFFFu;
+      posting += type == 0 ? 2 * (card + 1) : (type == 1 ? 8192u : 4 * (card + 1));
+    }
+  uint64_t total = sets * set_b;
+  if (l.geom_docs && l.full_pool) total += wide * msi_bits_words_per_slot(l.full_pool) * 12;   // U0 words + prefix counts
+  g_vm_set_bytes.fetch_add(total, std::memory_order_relaxed);
+  g_vm_posting_bytes.fetch_add(posting, std::memory_order_relaxed);
+  g_vm_lists.fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" int32_t msi_bits_vm_bytes(uint64_t out[3]) {
+  if (!out) return MSI_E_INVALID;
+  out[0] = g_vm_set_bytes.load();
+  out[1] = g_vm_posting_bytes.load();
+  out[2] = g_vm_lists.load();
+  return MSI_OK;
+}
+
 int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
   merge_pre(l);
+  account_list(pool, l);
   finalize_decodes(l);
   if (l.n_counts > MSI_VM_MAX_COUNTS || l.phase_start.size() > MSI_VM_MAX_PHASES || l.phase_start.empty()) {
     msi_set_error("msi_vm_run: list outside the supported range (%u counts, %zu phases)", l.n_counts, l.phase_start.size());

@@ -439,9 +439,12 @@ int main(int argc, char **argv) {
       CK(msi_bits_use_private_stream(p));
     }
 #endif
-    uint64_t vs0[6] = {0, 0, 0, 0, 0, 0}, vs1[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t vs0[6] = {0, 0, 0, 0, 0, 0}, vs1[6] = {0, 0, 0, 0, 0, 0}, vb0[3] = {0, 0, 0}, vb1[3] = {0, 0, 0};
     unsigned long long cs0[2], cs1[2];
     cpu_stat(cs0);
+#ifndef RANKED_BENCH_CPU
+    msi_bits_vm_bytes(vb0);
+#endif
     if (getenv("RB_PROFILE") && a == argc - 1) prof::start();
 #ifndef RANKED_BENCH_CPU
     msi_bits_vm_stats(pools[0], vs0);
@@ -469,6 +472,9 @@ int main(int argc, char **argv) {
       for (int k = 0; k < 10; ++k) tot[k] += sums[t][k];
     }
     cpu_stat(cs1);
+#ifndef RANKED_BENCH_CPU
+    msi_bits_vm_bytes(vb1);
+#endif
     if (getenv("RB_PROFILE") && a == argc - 1) prof::stop(getenv("RB_PROFILE"));
     std::sort(all.begin(), all.end());
     const double nq = (double)all.size();
@@ -486,7 +492,8 @@ int main(int argc, char **argv) {
            "\"vm\": {\"rounds\": %llu, \"lists\": %llu, \"us_queued_per_list\": %.1f, \"us_packed_per_list\": %.1f, "
            "\"us_launch_calls_per_round\": %.1f, \"us_after_launch_per_list\": %.1f}, "
            "\"cpu\": {\"cpus_used\": %.2f, \"throttled_fraction_of_wall\": %.3f}, "
-           "\"compact_space\": {\"searches\": %llu, \"of_them_compacted\": %llu, \"mean_universe_docs\": %.0f}}\n",
+           "\"compact_space\": {\"searches\": %llu, \"of_them_compacted\": %llu, \"mean_universe_docs\": %.0f}, "
+           "\"algorithmic_bytes_per_query\": {\"set_operands\": %.0f, \"posting_containers\": %.0f}, \"wall_s\": %.4f}\n",
 #ifdef RANKED_BENCH_CPU
            "ranked_cpu_port",
 #else
@@ -499,7 +506,8 @@ int main(int argc, char **argv) {
            (vs1[3] - vs0[3]) / 1e3 / std::max<double>(1, vs1[1] - vs0[1]), (vs1[4] - vs0[4]) / 1e3 / std::max<double>(1, vs1[0] - vs0[0]),
            (vs1[5] - vs0[5]) / 1e3 / std::max<double>(1, vs1[1] - vs0[1]),
            (cs1[0] - cs0[0]) / 1e6 / dt, (cs1[1] - cs0[1]) / 1e6 / dt,
-           (unsigned long long)cst[0], (unsigned long long)cst[1], cst[1] ? (double)cst[2] / (double)cst[1] : 0.0);
+           (unsigned long long)cst[0], (unsigned long long)cst[1], cst[1] ? (double)cst[2] / (double)cst[1] : 0.0,
+           (double)(vb1[0] - vb0[0]) / nq, (double)(vb1[1] - vb0[1]) / nq, dt);
     fflush(stdout);
 #ifdef RANKED_BENCH_CPU
     for (auto &p : pools) mock_bits_destroy(p);
@@ -544,6 +552,7 @@ struct Runner {
   msi_score_detail *out_details = nullptr;   // nullable: [n][limit][MSI_MAX_SCORE_DETAILS]
   uint32_t *out_n_details = nullptr;         // nullable: [n][limit]
   uint64_t *out_candidates = nullptr;        // nullable: [n]
+  std::vector<double> lat_ms;                // wall time of every search of the last job (rb_last_latencies)
   bool stop = false;
   std::atomic<int32_t> failed{0};
 
@@ -586,6 +595,7 @@ struct Runner {
           i = next++;
         }
         const std::vector<std::string> &q = queries[(job_first + i) % queries.size()];
+        const auto t_search = std::chrono::steady_clock::now();
         const int32_t st = search(pools[t], q, job_limit, out_ids + (size_t)i * job_limit, out_n + i, out_scores + (size_t)i * job_limit,
                                   out_details ? out_details + (size_t)i * job_limit * MSI_MAX_SCORE_DETAILS : nullptr,
                                   out_n_details ? out_n_details + (size_t)i * job_limit : nullptr,
@@ -597,7 +607,9 @@ struct Runner {
             fprintf(stderr, "ranked runner: search \"%s\" failed with %d: %s\n", words.c_str(), st, msi_last_error());
           }
         }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_search).count();
         std::lock_guard<std::mutex> lk(mu);
+        if (i < lat_ms.size()) lat_ms[i] = ms;
         if (++done == job_n) cv_done.notify_all();
       }
     }
@@ -692,6 +704,7 @@ int32_t rb_run_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, uin
   r->job_first = first; r->job_n = n; r->job_limit = limit; r->next = 0; r->done = 0;
   r->out_ids = out_ids; r->out_n = out_n; r->out_scores = out_scores;
   r->out_details = out_details; r->out_n_details = out_n_details; r->out_candidates = out_candidates;
+  r->lat_ms.assign(n, 0.0);
   ++r->epoch;
   r->cv.notify_all();
   r->cv_done.wait(lk, [&] { return r->done == n; });
@@ -699,6 +712,14 @@ int32_t rb_run_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, uin
 }
 int32_t rb_run(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores) {
   return rb_run_detailed(h, first, n, limit, out_ids, out_n, out_scores, nullptr, nullptr, nullptr);
+}
+// wall time (ms) of every search of the last rb_run, in query order
+uint32_t rb_last_latencies(void *h, double *out, uint32_t cap) {
+  Runner *r = (Runner *)h;
+  std::lock_guard<std::mutex> lk(r->mu);
+  const uint32_t n = (uint32_t)std::min<size_t>(cap, r->lat_ms.size());
+  memcpy(out, r->lat_ms.data(), n * sizeof(double));
+  return n;
 }
 // ---- the index behind the vtable, handed to the CHECKER (oracle/synth_index.py reads the same stored bytes the
 // product's callbacks return; needs no device): the dictionary, the prepared queries, and every database read ----
