@@ -824,6 +824,7 @@ def run_c4(args, env):
             # step that was just timed, through oracle/ranking_oracle.py (the restatement the reference's snapshot searches
             # pin) reading the synthetic index's stored posting bytes — docids in order, every hit's score details and the
             # candidate counts (oracle/parity.py: KeywordLegChecker; tests/test_configs_gpu.py::test_c4_keyword_leg)
+            keyword_run()                               # (the latency legs above ran other queries since the timed steps)
             first = ((kw["step"] - 1) * Q) % (4 * Q)
             nk = min(args.parity_kw_queries, Q)
             kchk = parity.KeywordLegChecker(kw["lib"], kw["h"], n_total if row_sharded else n)

@@ -1768,7 +1768,8 @@ static void account_list(msi_bits *pool, const MsiVmList &l) {
       posting += type == 0 ? 2 * (card + 1) : (type == 1 ? 8192u : 4 * (card + 1));
     }
   uint64_t total = sets * set_b;
-  if (l.geom_docs && l.full_pool) total += wide * msi_bits_words_per_slot(l.full_pool) * 12;   // U0 words + prefix counts
+  // (a wide phase stages U0's words and prefix counts once per workgroup, whatever the number of its decodes)
+  if (l.geom_docs && l.full_pool && wide) total += msi_bits_words_per_slot(l.full_pool) * 12;
   g_vm_set_bytes.fetch_add(total, std::memory_order_relaxed);
   g_vm_posting_bytes.fetch_add(posting, std::memory_order_relaxed);
   g_vm_lists.fetch_add(1, std::memory_order_relaxed);
