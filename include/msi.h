@@ -904,6 +904,15 @@ uint32_t msi_federated_merge(uint32_t n_lists, const uint32_t *list_len, const m
                              const uint32_t *const *val_off, const double *const *weighted_global, uint32_t offset,
                              uint32_t limit, uint32_t *out_list, uint32_t *out_pos);
 
+/* ... with the query each hit came from (query_index[l][j]; a NULL table or row = the list's own number): hits that
+ * compare Equal leave in the order of their queries — `Ordering::Equal => left.query_index < right.query_index`,
+ * perform.rs:566 (merge_index_local_results) and :609 (merge_index_global_results) — which a list-per-index merge cannot
+ * tell from the list order alone when the tied hits of two indexes come from interleaved queries. */
+uint32_t msi_federated_merge_q(uint32_t n_lists, const uint32_t *list_len, const msi_weighted_value *const *values,
+                               const uint32_t *const *val_off, const double *const *weighted_global,
+                               const uint32_t *const *query_index, uint32_t offset, uint32_t limit, uint32_t *out_list,
+                               uint32_t *out_pos);
+
 /* Search::results_good_enough (search/hybrid.rs:367-386). */
 int32_t msi_results_good_enough(const double *keyword_global_scores, uint32_t n,
                                 uint32_t limit_plus_offset, float semantic_ratio);

@@ -190,6 +190,7 @@ PROTOTYPES = {
     "msi_bits_vector_filter": (_I32, [_VP, _U32, _I32, _I32, _VP, _U32, _VP, _U32, _U32, _U32, _U32, _I32]),
     "msi_federated_compare": (_I32, [_VP, _U32, _F64, _VP, _U32, _F64]),
     "msi_federated_merge": (_U32, [_U32, _VP, _VP, _VP, _VP, _U32, _U32, _VP, _VP]),
+    "msi_federated_merge_q": (_U32, [_U32, _VP, _VP, _VP, _VP, _VP, _U32, _U32, _VP, _VP]),
     "msi_dict_create": (_I32, [_VP, _VP, _VP, _U32, C.POINTER(_VP)]),
     "msi_dict_destroy": (None, [_VP]),
     "msi_dict_len": (_U32, [_VP]),

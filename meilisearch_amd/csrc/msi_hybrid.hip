@@ -185,11 +185,13 @@ int32_t msi_federated_compare(const msi_weighted_value *left, uint32_t n_left, d
   return left_weighted_global_score < right_weighted_global_score ? -1 : 1;
 }
 
-uint32_t msi_federated_merge(uint32_t n_lists, const uint32_t *list_len, const msi_weighted_value *const *values,
-                             const uint32_t *const *val_off, const double *const *weighted_global, uint32_t offset,
-                             uint32_t limit, uint32_t *out_list, uint32_t *out_pos) {
+uint32_t msi_federated_merge_q(uint32_t n_lists, const uint32_t *list_len, const msi_weighted_value *const *values,
+                               const uint32_t *const *val_off, const double *const *weighted_global,
+                               const uint32_t *const *query_index, uint32_t offset, uint32_t limit, uint32_t *out_list,
+                               uint32_t *out_pos) {
   std::vector<uint32_t> at(n_lists, 0);
   uint32_t produced = 0, written = 0;
+  auto qi = [&](uint32_t l, uint32_t j) -> uint64_t { return query_index && query_index[l] ? query_index[l][j] : l; };
   while (written < limit) {
     int best = -1;
     for (uint32_t l = 0; l < n_lists; ++l) {
@@ -202,7 +204,9 @@ uint32_t msi_federated_merge(uint32_t n_lists, const uint32_t *list_len, const m
       const int c = msi_federated_compare(values[l] + val_off[l][b], val_off[l][b + 1] - val_off[l][b], weighted_global[l][b],
                                           values[best] + val_off[best][a], val_off[best][a + 1] - val_off[best][a],
                                           weighted_global[best][a]);
-      if (c > 0) best = (int)l;   // strictly better only: equal hits keep the order of the lists (a stable merge)
+      // the bigger score first; equal: the hit of the EARLIER QUERY (perform.rs:566,609 `left.query_index <
+      // right.query_index`), the earlier list when the query is the same
+      if (c > 0 || (c == 0 && qi(l, b) < qi((uint32_t)best, a))) best = (int)l;
     }
     if (best < 0) break;
     if (produced >= offset) {
@@ -214,6 +218,12 @@ uint32_t msi_federated_merge(uint32_t n_lists, const uint32_t *list_len, const m
     ++at[best];
   }
   return written;
+}
+
+uint32_t msi_federated_merge(uint32_t n_lists, const uint32_t *list_len, const msi_weighted_value *const *values,
+                             const uint32_t *const *val_off, const double *const *weighted_global, uint32_t offset,
+                             uint32_t limit, uint32_t *out_list, uint32_t *out_pos) {
+  return msi_federated_merge_q(n_lists, list_len, values, val_off, weighted_global, nullptr, offset, limit, out_list, out_pos);
 }
 
 }  // extern "C"

@@ -266,6 +266,10 @@ extern "C" {
     pub fn msi_federated_merge(n_lists: u32, list_len: *const u32, values: *const *const msi_weighted_value,
                                val_off: *const *const u32, weighted_global: *const *const f64, offset: u32, limit: u32,
                                out_list: *mut u32, out_pos: *mut u32) -> u32;
+    pub fn msi_federated_merge_q(n_lists: u32, list_len: *const u32, values: *const *const msi_weighted_value,
+                                 val_off: *const *const u32, weighted_global: *const *const f64,
+                                 query_index: *const *const u32, offset: u32, limit: u32, out_list: *mut u32,
+                                 out_pos: *mut u32) -> u32;
     // multi-GPU (RCCL inside the library)
     pub fn msi_group_create(devices: *const i32, n: u32, out: *mut *mut msi_group) -> i32;
     pub fn msi_group_unique_id(out_id: *mut u8) -> i32;                       // 128 bytes

@@ -121,3 +121,51 @@ def test_merge_is_the_k_way_merge_by_compare():
         lib().msi_federated_merge.restype = C.c_uint32
         n = lib().msi_federated_merge(n_lists, lens, vals, offs, glob, offset, limit, ol, op)
         assert [(ol[i], op[i]) for i in range(n)] == exp[offset:offset + limit]
+
+
+def test_reference_federated_orders_replay_through_the_merge():
+    """crates/meilisearch/tests/search/multi/mod.rs (tests/golden/federated_fixtures.json): the merged hit order of every
+    plain-keyword federated snapshot — 11 requests, 69 hits, 27 ties between hits of different queries.  Each query's own
+    list (its hits in the order the response shows them) goes back through msi_federated_merge_q with the query's number:
+    the interleaving must be the reference's, ties included (`left.query_index < right.query_index`, perform.rs:566,609).
+    The plain merge (ties by list order) is what ADVICE r2 found wrong: with the lists handed over in another order than the
+    queries it must FAIL on the same fixtures."""
+    import json
+    import os
+    fix = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "federated_fixtures.json")))
+    L = lib()
+    L.msi_federated_merge_q.restype = C.c_uint32
+    n_ties = 0
+    wrong_without_query_index = 0
+    for case in fix["cases"]:
+        hits = case["hits"]
+        queries = sorted({q for q, _ in hits})
+        # lists in REVERSE query order: only the query numbers can restore the reference's tie order
+        order = list(reversed(queries))
+        per = {q: [(i, s) for i, (qq, s) in enumerate(hits) if qq == q] for q in queries}
+        n_lists = len(order)
+        lens = (C.c_uint32 * n_lists)(*[len(per[q]) for q in order])
+        keep, vals, offs, glob, qidx = [], (C.c_void_p * n_lists)(), (C.c_void_p * n_lists)(), (C.c_void_p * n_lists)(), (C.c_void_p * n_lists)()
+        for li, q in enumerate(order):
+            n = len(per[q])
+            v = (WV * max(n, 1))()
+            o = (C.c_uint32 * (n + 1))(*range(n + 1))
+            g = (C.c_double * max(n, 1))()
+            qi = (C.c_uint32 * max(n, 1))()
+            for j, (_, s) in enumerate(per[q]):
+                v[j].kind, v[j].asc, v[j].value = 0, 0, s
+                g[j] = s
+                qi[j] = q
+            keep += [v, o, g, qi]
+            vals[li], offs[li], glob[li], qidx[li] = C.addressof(v), C.addressof(o), C.addressof(g), C.addressof(qi)
+        total = len(hits)
+        ol, op = (C.c_uint32 * total)(), (C.c_uint32 * total)()
+        n = L.msi_federated_merge_q(n_lists, lens, vals, offs, glob, qidx, 0, total, ol, op)
+        assert n == total
+        got = [per[order[ol[i]]][op[i]][0] for i in range(n)]
+        assert got == list(range(total)), (case["src"], got)
+        n_ties += sum(1 for a, b in zip(hits, hits[1:]) if a[1] == b[1] and a[0] != b[0])
+        n2 = L.msi_federated_merge(n_lists, lens, vals, offs, glob, 0, total, ol, op)
+        if [per[order[ol[i]]][op[i]][0] for i in range(n2)] != list(range(total)):
+            wrong_without_query_index += 1
+    assert n_ties >= 20 and wrong_without_query_index >= 1
