@@ -339,13 +339,15 @@ def keyword_roofline(n_docs, kw_threads, measured_qps):
     n_measured = threads * per_thread
     out.update({
         "algorithmic_bytes_per_query": int(algo),
+        "algorithmic_bytes_are": "every set operand of every recorded command counted WHOLE (slot words x 8: |universe| / 8 bytes in "
+                                 "the compact space, n_docs / 8 in the full space) + the container bodies the decodes read + the "
+                                 "universe's tables once per wide phase — an upper bound: the full-space lists (the universe "
+                                 "computation, and the ~2 % of searches whose universe is too large to compact) skip chunks their "
+                                 "summaries mark empty",
         "algorithmic_bytes_breakdown_per_query": {"set_operands": int(ab["set_operands"]), "posting_containers": int(ab["posting_containers"])},
         "child_queries_per_s": line["queries_per_s"], "child_callers": threads,
         "universe_compaction": line.get("compact_space"),
-        "achieved": round(algo * measured_qps / 1e9, 1),
-        "achieved_is": "algorithmic bytes per query x the keyword leg's queries/s of THIS run",
     })
-    out["frac"] = round(out["achieved"] / 8000.0, 5)
     traffic = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         rows = pmc_rows(cmd, [counter], "vm_kernel", env=env)
@@ -362,6 +364,11 @@ def keyword_roofline(n_docs, kw_threads, measured_qps):
     out["traffic_writes_mb_per_query"] = None if traffic["WRITE_SIZE"] is None else round(traffic["WRITE_SIZE"] / 1e6, 2)
     out["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE children of this run (tools/bin/ranked_bench, "
                              f"{threads} callers, {distinct} + {n_measured} queries); counters summed over every vm_kernel dispatch")
+    moved = (traffic["FETCH_SIZE"] or 0.0) + (traffic["WRITE_SIZE"] or 0.0)
+    out["achieved"] = round(moved * measured_qps / 1e9, 1) if moved else None
+    out["achieved_is"] = ("measured HBM bytes per query (reads + writes above) x the keyword leg's queries/s of THIS run: the leg's "
+                          "kernels together, not one launch (a round's launch is tens of microseconds of dependent commands)")
+    out["frac"] = round(out["achieved"] / 8000.0, 4) if out["achieved"] else None
     out["reading"] = ("the leg is bound by dependent rounds (17 per query) and their launch / wake-up latency, not by bytes: "
                       "with universe compaction a query's set traffic is megabytes, where round 2 moved ~0.5 GB per query")
     return out

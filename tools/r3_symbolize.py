@@ -81,3 +81,24 @@ for k, v in leaf.most_common(top):
 print("---- inclusive")
 for k, v in incl.most_common(top):
     print("%6.2f%%  %s" % (100.0 * v / n, k[:150]))
+
+# ---- who calls the allocator: for samples whose leaf is in malloc / free / operator new (or libc's unnamed internals next
+# to them), the first frame above that belongs to libmsi / the driver
+alloc_leaf = ("malloc", "free", "operator new", "operator delete", "__default_morecore", "__lll_lock", "realloc", "cfree", "_M_fill_insert")
+callers = collections.Counter()
+n_alloc = 0
+for s in samples:
+    names = []
+    for pc in s[2:]:
+        mod, rel = locate(pc - 1)
+        names.append((sym.get((mod, rel), "?"), os.path.basename(mod or "?")))
+    if not names or not any(names[0][0].startswith(a) for a in alloc_leaf):
+        continue
+    n_alloc += 1
+    for fn, mod in names[1:]:
+        if mod.startswith("libmsi") or mod.startswith("ranked_bench"):
+            callers[fn[:110]] += 1
+            break
+print("---- allocator samples: %d of %d (%.1f%%); first libmsi / driver frame above them" % (n_alloc, n, 100.0 * n_alloc / max(1, n)))
+for k, v in callers.most_common(25):
+    print("%6.2f%%  %s" % (100.0 * v / n, k))
