@@ -574,11 +574,11 @@ def run_c4(args, env):
 
     def step():
         store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
-        if gdict is not None:
+        if kw is not None and not args.overlap_legs:
+            ctx.synchronize()     # the scan streams HBM on its own, then the (latency-bound) keyword lists run
+        if gdict is not None:     # (VALU-bound, on the context's second stream: beside the keyword rounds, not beside the scan)
             gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
         if kw is not None:
-            if not args.overlap_legs:
-                ctx.synchronize()     # the scan streams HBM on its own, then the (latency-bound) keyword lists run
             keyword_run()
         ctx.synchronize()
         if row_sharded:
