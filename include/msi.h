@@ -461,6 +461,12 @@ int32_t msi_bits_geo_next(msi_bits *pool, const msi_geo_points *points, uint32_t
                           uint32_t scratch /* a third slot: used when more than max_bucket_size documents fit */,
                           double lat, double lng, int32_t ascending, uint32_t max_bucket_size,
                           double distance_error_margin, uint32_t *out_first_docid, uint64_t *out_count);
+/* The documents of `universe` that have a point, with their distance to (lat, lng) — at most `cap` of them, in no
+ * particular order — and how many there are in all (*out_total; the list is complete when *out_total <= cap).  What the
+ * iterative strategy of documents/geo_sort.rs:120-131 sorts: the ranked search orders a small candidate set on the host
+ * exactly as the reference does (distance truncated to metres, then docid). */
+int32_t msi_bits_geo_list(msi_bits *pool, const msi_geo_points *points, uint32_t universe, double lat, double lng,
+                          uint32_t cap, uint32_t *out_docids, double *out_distance, uint64_t *out_total);
 /* SURVEY §8 f1 — the LEAVES of a filter on the device (crates/milli/src/search/facet/filter/index_filter.rs:84-340,
  * value_bounds.rs): instead of walking the facet levels of facet_id_f64_docids / facet_id_string_docids per
  * condition (facet_range_search.rs) and densifying the resulting Roaring bitmap for the scan, the facet values of a
@@ -804,7 +810,14 @@ typedef struct msi_search_params {
    * all_candidates (search/new/mod.rs:894-907). */
   int32_t exhaustive_number_hits;
   uint32_t max_total_hits;
+  /* GeoSortStrategy of the request (documents/geo_sort.rs:32-63): MSI_GEO_DYNAMIC (the reference's default,
+   * Dynamic(1000)) walks the R-tree when a fill finds at least geo_cache_size candidates and sorts them ITERATIVELY below
+   * that — by distance truncated to whole metres, docid order inside a metre (:127-131) — which decides the order of
+   * documents closer than a metre to each other; geo_cache_size 0 = 1000. */
+  int32_t geo_strategy;
+  uint32_t geo_cache_size;
 } msi_search_params;
+enum { MSI_GEO_DYNAMIC = 0, MSI_GEO_ALWAYS_ITERATIVE = 1, MSI_GEO_ALWAYS_RTREE = 2 };
 /* out_scores: [length][MSI_MAX_SCORE_DETAILS], out_n_scores: [length].  The pool needs at least 64 free
  * slots above slot 0 (more for long queries: one per live condition of every active rule). */
 int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, const msi_index_vtable *index,

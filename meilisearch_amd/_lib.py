@@ -103,7 +103,8 @@ class SearchParams(C.Structure):
                 ("stop_after", C.c_int32), ("has_score_threshold", C.c_int32), ("score_threshold", C.c_double),
                 ("order_keys", C.c_void_p), ("n_order_keys", C.c_uint32), ("distinct_values", C.c_void_p), ("geo_rules", C.c_void_p), ("n_geo_rules", C.c_uint32),
                 ("geo_max_bucket_size", C.c_uint32), ("geo_distance_error_margin", C.c_double),
-                ("exhaustive_number_hits", C.c_int32), ("max_total_hits", C.c_uint32)]
+                ("exhaustive_number_hits", C.c_int32), ("max_total_hits", C.c_uint32),
+                ("geo_strategy", C.c_int32), ("geo_cache_size", C.c_uint32)]
 
 
 class GeoRule(C.Structure):
@@ -263,6 +264,7 @@ PROTOTYPES = {
     "msi_search_last_stats": (_I32, [C.POINTER(_U64)]),
     "msi_search_compaction_stats": (_I32, [C.POINTER(_U64)]),
     "msi_bits_vm_bytes": (_I32, [C.POINTER(_U64)]),
+    "msi_bits_geo_list": (_I32, [_VP, _VP, _U32, C.c_double, C.c_double, _U32, _VP, _VP, C.POINTER(_U64)]),
     "msi_score_details_global_score": (_F64, [_VP, _U32]),
     "msi_distribution_shift": (_F32, [_F32, _F32, _F32]),
     "msi_rank_global_score": (_F64, [_VP, _VP, _U32]),

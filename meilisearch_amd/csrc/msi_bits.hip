@@ -617,6 +617,27 @@ __global__ void bits_geo_take_kernel(u64 *__restrict__ src, u64 *__restrict__ ds
   }
 }
 
+// The documents of `src` that have a point, with their distance: appended in no particular order (one atomic slot per
+// document), all of them counted.
+__global__ void bits_geo_list_kernel(const u64 *__restrict__ src, const double *__restrict__ lat_lng, uint64_t n_docs,
+                                     uint64_t n_words, GeoTarget t, uint32_t cap, uint32_t *__restrict__ out_ids,
+                                     double *__restrict__ out_dist, u64 *__restrict__ counter) {
+  for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_words * 64; d += (uint64_t)gridDim.x * blockDim.x) {
+    const u64 word = src[d >> 6];   // wave-uniform
+    if (!word) continue;
+    if (d < n_docs && ((word >> (d & 63)) & 1ull)) {
+      const double lat = lat_lng[2 * d];
+      if (lat == lat) {
+        const u64 at = atomicAdd(counter, 1ull);
+        if (at < cap) {
+          out_ids[at] = (uint32_t)d;
+          out_dist[at] = geo_distance_m(t, lat, lat_lng[2 * d + 1]);
+        }
+      }
+    }
+  }
+}
+
 // ---- filter leaves (crates/milli/src/search/facet/filter/index_filter.rs:84-340) ---------------------------------------
 // dst (|)= {d : some key of d is in [lo, hi]} — or, with a sorted list, is one of its n keys.  One document per thread,
 // the wave's ballot is the word of the set.
@@ -2147,6 +2168,51 @@ static int32_t geo_range(msi_bits *p, const msi_geo_points *gp, const GeoTarget 
   MSI_HIP_TRY(hipGetLastError());
   lk.unlock();
   return wait_count(p, seq, count);
+}
+
+int32_t msi_bits_geo_list(msi_bits *p, const msi_geo_points *gp, uint32_t universe, double lat, double lng, uint32_t cap,
+                          uint32_t *out_docids, double *out_distance, uint64_t *out_total) {
+  if (!p || !gp || !out_total || (cap && (!out_docids || !out_distance))) {
+    msi_set_error("msi_bits_geo_list: invalid argument");
+    return MSI_E_INVALID;
+  }
+  if (gp->ctx != p->ctx || gp->n_docs != p->n_docs) {
+    msi_set_error("msi_bits_geo_list: the points (%llu documents) do not belong to this pool (%llu documents)",
+                  (unsigned long long)gp->n_docs, (unsigned long long)p->n_docs);
+    return MSI_E_INVALID;
+  }
+  MSI_TRY(check_slot(p, universe, "msi_bits_geo_list"));
+  const double D2R = 3.14159265358979323846 / 180.0;
+  GeoTarget t;
+  t.phi = lat * D2R;
+  t.cos_phi = cos(t.phi);
+  t.lam = lng * D2R;
+  t.margin = 0.0;
+  t.ascending = 1;
+  std::lock_guard<std::mutex> lk(*p->mu);
+  DeviceGuard g(p->ctx->device);
+  hipStream_t st = p->stream;
+  // scratch: [counter u64][ids u32 x cap][distances f64 x cap]
+  const size_t ids_at = 16, dist_at = (ids_at + (size_t)cap * 4 + 15) & ~(size_t)15, total = dist_at + (size_t)cap * 8;
+  MSI_TRY(p->tmp.ensure(std::max<size_t>(total, 64)));
+  uint8_t *base = p->tmp.as<uint8_t>();
+  MSI_HIP_TRY(hipMemsetAsync(base, 0, 16, st));
+  const dim3 grid((uint32_t)std::min<uint64_t>((p->n_words * 64 + BT - 1) / BT, (uint64_t)p->ctx->n_cu * 4)), block(BT);
+  hipLaunchKernelGGL(bits_geo_list_kernel, grid, block, 0, st, p->slot(universe), gp->lat_lng.as<double>(), p->n_docs, p->n_words,
+                     t, cap, reinterpret_cast<uint32_t *>(base + ids_at), reinterpret_cast<double *>(base + dist_at),
+                     reinterpret_cast<u64 *>(base));
+  MSI_HIP_TRY(hipGetLastError());
+  u64 n = 0;
+  MSI_HIP_TRY(hipMemcpyAsync(&n, base, sizeof(n), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  *out_total = n;
+  const size_t take = (size_t)std::min<u64>(n, cap);
+  if (take) {
+    MSI_HIP_TRY(hipMemcpyAsync(out_docids, base + ids_at, take * 4, hipMemcpyDeviceToHost, st));
+    MSI_HIP_TRY(hipMemcpyAsync(out_distance, base + dist_at, take * 8, hipMemcpyDeviceToHost, st));
+    MSI_HIP_TRY(hipStreamSynchronize(st));
+  }
+  return MSI_OK;
 }
 
 int32_t msi_bits_geo_next(msi_bits *p, const msi_geo_points *gp, uint32_t universe, uint32_t bucket, uint32_t scratch,

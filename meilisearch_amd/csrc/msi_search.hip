@@ -635,6 +635,22 @@ struct Dev {
     g_stats.device_wait_ms += ck_.ms();
     return b;
   }
+  // the documents of `universe` that have a point, with their distances (at most `cap`; *total = how many there are)
+  void geo_list(const msi_geo_rule &r, const Set &universe, uint32_t cap, std::vector<uint32_t> &ids, std::vector<double> &dist,
+                uint64_t *total) {
+    settle();
+    Clock ck_;
+    ++g_stats.launches;
+    ++g_stats.syncs;
+    ids.assign(cap, 0);
+    dist.assign(cap, 0.0);
+    ck(msi_bits_geo_list(cur->p, r.points, universe->slot, r.lat, r.lng, cap, ids.data(), dist.data(), total));
+    const size_t n = (size_t)std::min<uint64_t>(*total, cap);
+    ids.resize(n);
+    dist.resize(n);
+    direct_done();
+    g_stats.device_wait_ms += ck_.ms();
+  }
   // apply_distinct_rule (distinct.rs:19-36) on a COPY of `cands`: {kept candidates, every document of the index that
   // shares a value with one of them}
   std::pair<Set, Set> distinct(const msi_doc_values *vals, const Set &cands, uint64_t *kept) {
@@ -2825,15 +2841,78 @@ struct GeoSortRule : Rule {
   uint32_t idx;
   msi_geo_rule rule;
   Graph g;
+  // documents/geo_sort.rs keeps a cache of candidates in visiting order, filled either from the R-tree (the nearest
+  // `cache_size`, in chord-distance order = exact distance order) or ITERATIVELY (every candidate, sorted by its distance
+  // truncated to whole metres — docid order inside a metre), and refilled when it runs dry.  Which of the two a fill uses
+  // is decided by the strategy and the number of candidates at that moment (:81-94).  Here: `mode` of the current fill
+  // and how many of its documents are still to come.
+  int mode = 0;              // 0: no fill yet, 1: iterative, 2: R-tree order (the min / take kernels)
+  uint64_t cache_left = 0;
   GeoSortRule(uint32_t i, const msi_geo_rule &r) : Rule(R_ORDER_BY, -1), idx(i), rule(r) {}
   Rule *fresh() const override { return new GeoSortRule(idx, rule); }
-  void start(Ctx &, const Set &, const Graph &graph) override { g = graph; }
+  void start(Ctx &, const Set &, const Graph &graph) override {
+    g = graph;
+    mode = 0;
+    cache_left = 0;
+  }
   bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) override {
     if (!universe_count) return false;
+    const uint32_t cache_size = c.prm->geo_cache_size ? c.prm->geo_cache_size : 1000;
+    const uint32_t cap = c.prm->geo_max_bucket_size ? c.prm->geo_max_bucket_size : 1000;
+    const double margin = c.prm->geo_distance_error_margin;
+    const int strategy = c.prm->geo_strategy;
+    out.same_as = &g;
+    std::vector<uint32_t> ids;
+    std::vector<double> dist;
+    uint64_t total = 0;
+    bool listed = false;
+    if (strategy != MSI_GEO_ALWAYS_RTREE && (mode == 0 || cache_left == 0 || mode == 1)) {
+      // a fill (or the iterative cache seen through the current universe): the candidates, at most cache_size of them
+      c.dev.geo_list(rule, universe, strategy == MSI_GEO_ALWAYS_ITERATIVE ? 0xFFFFFu : cache_size, ids, dist, &total);
+      listed = true;
+    }
+    if (mode == 0 || cache_left == 0) {   // fill_cache :66-133
+      const bool use_rtree = strategy == MSI_GEO_ALWAYS_RTREE || (strategy == MSI_GEO_DYNAMIC && total >= cache_size);
+      mode = use_rtree ? 2 : 1;
+      cache_left = use_rtree ? (listed ? std::min<uint64_t>(total, cache_size) : cache_size) : total;
+    }
+    if (mode == 1 && listed && total <= ids.size()) {
+      if (!total) {   // no candidate left: what remains has no point (:161-163)
+        out.score = {MSI_SCORE_GEO_SORT, idx, 0xFFFFFFFFu};
+        out.docs = c.dev.clone(universe);
+        out.count = universe_count;
+        return true;
+      }
+      // sort_by_cached_key(distance as usize) over candidates in docid order: stable (:127-131); a descending rule pops
+      // the cache from the back
+      std::vector<uint32_t> order(ids.size());
+      for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        const uint64_t ka = (uint64_t)dist[a], kb = (uint64_t)dist[b];
+        return ka != kb ? ka < kb : ids[a] < ids[b];
+      });
+      if (!rule.ascending) std::reverse(order.begin(), order.end());
+      std::vector<uint32_t> bucket;
+      const double d0 = dist[order[0]];
+      for (uint32_t o : order) {   // next_bucket :166-206
+        if (fabs(d0 - dist[o]) > margin) break;
+        bucket.push_back(ids[o]);
+        if (bucket.size() == cap) break;
+      }
+      const uint32_t first = ids[order[0]];
+      std::sort(bucket.begin(), bucket.end());
+      out.docs = c.dev.from_docids(bucket);
+      out.count = bucket.size();
+      c.dev.sub_(universe, out.docs);
+      out.universe_reduced = true;
+      out.score = {MSI_SCORE_GEO_SORT, idx, first};
+      cache_left -= std::min<uint64_t>(cache_left, bucket.size());
+      return true;
+    }
+    // R-tree order: exact distance order on the device (min, then take within the margin)
     uint32_t first = 0xFFFFFFFFu;
     uint64_t n = 0;
-    Set b = c.dev.geo_next(rule, c.prm->geo_max_bucket_size, c.prm->geo_distance_error_margin, universe, &first, &n);
-    out.same_as = &g;
+    Set b = c.dev.geo_next(rule, c.prm->geo_max_bucket_size, margin, universe, &first, &n);
     out.score = {MSI_SCORE_GEO_SORT, idx, first};
     if (first == 0xFFFFFFFFu) {
       out.docs = c.dev.clone(universe);
@@ -2843,6 +2922,7 @@ struct GeoSortRule : Rule {
     out.docs = b;
     out.count = n;
     out.universe_reduced = true;
+    cache_left -= std::min<uint64_t>(cache_left, n);
     return true;
   }
   void end() override {}

@@ -356,7 +356,8 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
                           detailed=False, searchable_fids=(), searchable_weights=(), max_weight=None,
                           authorize_typos=True, min_one=5, min_two=9, universe_cbo=None, time_budget_us=0,
                           stop_after=None, return_degraded=False, score_threshold=None, order_keys=(), distinct_values=None,
-                          geo_rules=(), geo_max_bucket_size=0, geo_distance_error_margin=1.0, exhaustive=False,
+                          geo_rules=(), geo_max_bucket_size=0, geo_distance_error_margin=1.0, geo_strategy=("dynamic", 1000),
+                          exhaustive=False,
                           max_total_hits=None, _entry=None):
     """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
     terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
@@ -404,6 +405,9 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
         prm.geo_rules, prm.n_geo_rules = C.cast(garr, C.c_void_p), len(geo_rules)
     prm.geo_max_bucket_size, prm.geo_distance_error_margin = int(geo_max_bucket_size), float(geo_distance_error_margin)
     prm.exhaustive_number_hits, prm.max_total_hits = (1 if exhaustive else 0), int(max_total_hits or 0)
+    # GeoSortStrategy (documents/geo_sort.rs:32-63): ("dynamic" | "iterative" | "rtree", cache size)
+    prm.geo_strategy = {"dynamic": 0, "iterative": 1, "rtree": 2}[geo_strategy[0]]
+    prm.geo_cache_size = int(geo_strategy[1])
     L = max(limit, 1)
     ids = np.zeros(L, dtype=np.uint32)
     sc = (ScoreDetail * (L * MAX_SCORE_DETAILS))()

@@ -484,7 +484,8 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
         geo_max_bucket_size: q.geo_max_bucket_size.min(u32::MAX as u64) as u32,
         geo_distance_error_margin: q.geo_distance_error_margin,
         exhaustive_number_hits: q.exhaustive_number_hits as i32,
-        max_total_hits: q.max_total_hits.map_or(0, |m| m.min(u32::MAX as usize) as u32) };
+        max_total_hits: q.max_total_hits.map_or(0, |m| m.min(u32::MAX as usize) as u32),
+        geo_strategy: q.geo_strategy.0, geo_cache_size: q.geo_strategy.1 };
     let mut src_ref: Src<'_> = source;
     let vt = sys::msi_index_vtable { user: &mut src_ref as *mut _ as *mut _, word_docids: Some(r_word),
         word_pair_proximity_docids: Some(r_pair), is_exact_word: Some(r_exact), word_fid_docids: Some(r_fid),

@@ -116,10 +116,18 @@ pub struct msi_search_params {
     pub geo_rules: *const msi_geo_rule, pub n_geo_rules: u32, pub geo_max_bucket_size: u32,
     pub geo_distance_error_margin: f64,
     pub exhaustive_number_hits: i32, pub max_total_hits: u32,
+    pub geo_strategy: i32, pub geo_cache_size: u32,
 }
+pub const MSI_GEO_DYNAMIC: i32 = 0;
+pub const MSI_GEO_ALWAYS_ITERATIVE: i32 = 1;
+pub const MSI_GEO_ALWAYS_RTREE: i32 = 2;
 
 extern "C" {
     pub fn msi_abi_version() -> i32;
+    pub fn msi_bits_geo_list(pool: *mut msi_bits, points: *const msi_geo_points, universe: u32, lat: f64, lng: f64, cap: u32,
+                             out_docids: *mut u32, out_distance: *mut f64, out_total: *mut u64) -> i32;
+    pub fn msi_search_compaction_stats(out: *mut u64) -> i32;
+    pub fn msi_bits_vm_bytes(out: *mut u64) -> i32;
     pub fn msi_last_error() -> *const c_char;
     pub fn msi_ctx_create(device: i32, out: *mut *mut msi_ctx) -> i32;
     pub fn msi_ctx_destroy(ctx: *mut msi_ctx);

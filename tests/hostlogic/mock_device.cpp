@@ -265,6 +265,25 @@ msi_geo_points *mock_geo_points_create(const double *lat_lng, uint64_t n_docs) {
 }
 void mock_geo_points_destroy(msi_geo_points *g) { delete g; }
 
+int32_t msi_bits_geo_list(msi_bits *p, const msi_geo_points *gp, uint32_t universe, double lat, double lng, uint32_t cap,
+                          uint32_t *out_docids, double *out_distance, uint64_t *out_total) {
+  const double D2R = 3.14159265358979323846 / 180.0;
+  uint64_t n = 0;
+  for (uint64_t d = 0; d < p->n_docs; ++d)
+    if (mock_bit(p, universe, d) && gp->lat_lng[2 * d] == gp->lat_lng[2 * d]) {
+      if (n < cap) {
+        const double lat2 = gp->lat_lng[2 * d], lng2 = gp->lat_lng[2 * d + 1];
+        const double phi1 = lat * D2R, phi2 = lat2 * D2R, lam1 = lng * D2R, lam2 = lng2 * D2R;
+        const double total = (1.0 - cos(phi2 - phi1)) / 2.0 + cos(phi1) * cos(phi2) * ((1.0 - cos(lam2 - lam1)) / 2.0);
+        out_docids[n] = (uint32_t)d;
+        out_distance[n] = round(2.0 * 6371e3 * asin(sqrt(total)) * 1000.0) / 1000.0;
+      }
+      ++n;
+    }
+  *out_total = n;
+  return MSI_OK;
+}
+
 // documents/geo_sort.rs:150-224 over a cache in exact (distance, docid) order, written as the loop it is
 int32_t msi_bits_geo_next(msi_bits *p, const msi_geo_points *gp, uint32_t universe, uint32_t bucket, uint32_t scratch,
                           double lat, double lng, int32_t ascending, uint32_t max_bucket_size, double margin,

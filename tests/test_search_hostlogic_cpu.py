@@ -438,9 +438,11 @@ def test_geo_sort_rs_through_the_host_logic(hostlib):
         index = ToyMilli(cfg["docs"], criteria=cfg["criteria"])
         h = make_harness(hostlib, index)
         sort = [(tuple(f) if isinstance(f, list) else f, d) for f, d in case["sort"]]
-        hits, _ = h.search(case["query"], limit=20, detailed=True, sort=sort)
-        assert [index.docs[d]["id"] for d, _ in hits] == case["ids"], (case["src"], case["sort"])
-        assert "[" + "".join("[" + "".join(debug_score(s) + "," for s in sc) + "]," for _, sc in hits) + "]" == case["scores"]
+        # the strategy settings the reference itself asserts to agree on this data (tests/geo_sort.rs:30-66)
+        for strategy in (("dynamic", 1000), ("iterative", 1000), ("rtree", 1000)):
+            hits, _ = h.search(case["query"], limit=20, detailed=True, sort=sort, geo_strategy=strategy)
+            assert [index.docs[d]["id"] for d, _ in hits] == case["ids"], (case["src"], case["sort"], strategy)
+            assert "[" + "".join("[" + "".join(debug_score(s) + "," for s in sc) + "]," for _, sc in hits) + "]" == case["scores"]
         if "with_following_ranking_rules" in case["src"] and case["sort"][0][1] == "asc":
             hits, _ = h.search(case["query"], limit=20, detailed=True, sort=sort, geo_max_bucket_size=2)
             ext = [index.docs[d]["id"] for d, _ in hits]
@@ -479,7 +481,9 @@ GEO_SETUPS = [
 def test_geo_sort_matches_the_oracle(hostlib, setups=GEO_SETUPS, with_distinct=True):
     """GeoSort between graph-based rules, before / after Sort rules, on placeholder searches, with a small bucket cap,
     a huge error margin and `distinct`: hits, score details (the value of every bucket) and all_candidates against
-    the oracle's rtree strategy (exact distance order — what the device computes)."""
+    the oracle under the reference's three strategies — Dynamic(1000), the default (240 documents: every fill is
+    iterative, distances truncated to metres and docid order inside a metre decide neighbours closer than the margin),
+    always-iterative and always-rtree (exact distance order, the min / take kernels)."""
     from oracle import ranking_oracle as RO
     import tests.test_search_gpu as G
     index = ToyMilli(geo_corpus(3, 240), searchable=["title", "body"])
@@ -496,8 +500,18 @@ def test_geo_sort_matches_the_oracle(hostlib, setups=GEO_SETUPS, with_distinct=T
                                                        (True, 0, 25, "color")):
                 if distinct and not with_distinct:
                     continue
+                for strategy in (("dynamic", 1000), ("rtree", 1000), ("iterative", 1000)):
+                    n += geo_case(RO, G, index, lookup, h, criteria, sort, geo, q, detailed, offset, limit, distinct, strategy)
+    assert n >= 100 or setups is not GEO_SETUPS
+    h.close()
+
+
+def geo_case(RO, G, index, lookup, h, criteria, sort, geo, q, detailed, offset, limit, distinct, strategy):
+    if True:
+        if True:
+            if True:
                 RO.GEO_PARAMS.clear()
-                RO.GEO_PARAMS.update(strategy=("rtree", 1000))
+                RO.GEO_PARAMS.update(strategy=strategy)
                 if "geo_max_bucket_size" in geo:
                     RO.GEO_PARAMS["max_bucket_size"] = geo["geo_max_bucket_size"]
                 if "geo_distance_error_margin" in geo:
@@ -509,13 +523,11 @@ def test_geo_sort_matches_the_oracle(hostlib, setups=GEO_SETUPS, with_distinct=T
                 finally:
                     RO.GEO_PARAMS.clear()
                 hits, cand = h.search(q, criteria=criteria, offset=offset, limit=limit, detailed=detailed, sort=sort,
-                                      distinct=distinct, **geo)
-                assert [d for d, _ in hits] == want_ids, (criteria, sort, geo, q, detailed, offset, distinct)
+                                      distinct=distinct, geo_strategy=strategy, **geo)
+                assert [d for d, _ in hits] == want_ids, (criteria, sort, geo, q, detailed, offset, distinct, strategy)
                 assert [[geo_score(s) for s in sc] for _, sc in hits] == [[geo_score(G.oracle_score(s)) for s in sc] for sc in want_sc]
                 assert cand == len(want_cand)
-                n += 1
-    assert n >= 100 or setups is not GEO_SETUPS
-    h.close()
+    return 1
 
 
 def geo_score(s):

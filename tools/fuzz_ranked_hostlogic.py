@@ -139,7 +139,8 @@ while time.time() < t_end:
             sa = None
         try:
             RO.GEO_PARAMS.clear()
-            RO.GEO_PARAMS.update(strategy=("rtree", 1000))
+            geo_strategy = rng.choice([("dynamic", 1000), ("dynamic", 1000), ("rtree", 1000), ("iterative", 1000)]) if geo or sort else ("dynamic", 1000)
+            RO.GEO_PARAMS.update(strategy=geo_strategy)
             if "geo_max_bucket_size" in geo: RO.GEO_PARAMS["max_bucket_size"] = geo["geo_max_bucket_size"]
             if "geo_distance_error_margin" in geo: RO.GEO_PARAMS["distance_error_margin"] = geo["geo_distance_error_margin"]
             want = RO.search(RO.Ctx(index,lookup), q, tms=tms, offset=offset, length=limit, detailed=detailed, threshold=thr,
@@ -149,7 +150,7 @@ while time.time() < t_end:
             extra = [(([ng], False, 0, 0, False, True) if isinstance(ng, str) else (list(ng), True, 0, 0, False, True)) for ng in negs]
             hits, cand, gdeg = h.search(q, tms=tms, offset=offset, limit=limit, detailed=detailed, stop_after=sa, sort=sort,
                                         distinct=distinct, extra_terms=extra, score_threshold=thr, return_degraded=True, exhaustive=exh,
-                                        max_total_hits=mth, **geo, **spread_kw)
+                                        max_total_hits=mth, geo_strategy=geo_strategy, **geo, **spread_kw)
             if SPREAD:
                 assert all(d % SPREAD == 0 for d, _ in hits), hits
                 hits = [(d // SPREAD, sc) for d, sc in hits]
