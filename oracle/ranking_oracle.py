@@ -29,6 +29,21 @@ TRACE = False
 # The type of every docid set below.  The built-in set by default; oracle/docset.py's docset_type(n_docs) — same
 # interface over numpy arrays — for the 10 M-document index of the headline configuration (use_docset()).
 DocSet = set
+# The reference pushes the Fid / Position edges of a node in FxHashSet / FxHashMap iteration order (fid/mod.rs:60-100,
+# position/mod.rs:60-110): unspecified.  Here ascending by default; tests/test_ranking_oracle_snapshots.py replays every
+# reference search under the reversed and under shuffled orders as well and gets the same hits and score details — no
+# reference test can observe the order.  EDGE_ORDER: "asc" | "desc" | an int (shuffle seed).
+EDGE_ORDER = "asc"
+
+
+def _edge_order(items):
+    items = sorted(items)
+    if EDGE_ORDER == "desc":
+        items.reverse()
+    elif isinstance(EDGE_ORDER, int):
+        import random
+        random.Random(EDGE_ORDER * 7919 + len(items)).shuffle(items)
+    return items
 
 
 class use_docset:
@@ -623,7 +638,7 @@ def build_edges(ctx, kind, src, dst):
         if pf is not None:
             fids.update(ctx.index.get_word_prefix_fids(pf[0]))
         out, cur_max = [], 0
-        for fid in sorted(fids):
+        for fid in _edge_order(fids):
             w = ctx.index.weights.get(fid)
             if w is None:
                 continue
@@ -649,7 +664,7 @@ def build_edges(ctx, kind, src, dst):
             dist = abs(pos - dst.positions[0])
             cost = sum(cost_from_distance(dist + i) for i in range(n))
             by_cost.setdefault(cost, []).append(pos)
-        out = [(c, ("position", dst, tuple(sorted(by_cost[c])))) for c in sorted(by_cost)]
+        out = [(c, ("position", dst, tuple(sorted(by_cost[c])))) for c in _edge_order(by_cost)]
         if n * 10 not in by_cost:
             out.append((n * 10, ("position", dst, ())))
         return out

@@ -85,3 +85,28 @@ def test_reference_snapshot(case):
         assert [f"{R.global_score(sc):.4f}" for sc in scores] == case["global_scores"]
     if case.get("ids_scores"):
         assert debug_ids_scores(ids, scores) == case["ids_scores"]
+
+
+@pytest.mark.parametrize("order", ["desc", 1, 2, 3])
+def test_fid_and_position_edge_order_is_unobservable(order, monkeypatch):
+    """The reference iterates a hash set / map when it pushes the Fid and Position edges of a node (fid/mod.rs:60-100,
+    position/mod.rs:60-110) — an order nobody specified.  Every reference search with criteria that reach those rules,
+    replayed with the edges reversed and shuffled: same docids, same score details.  (The product pushes them ascending.)"""
+    monkeypatch.setattr(R, "EDGE_ORDER", order)
+    n = 0
+    for case in CASES:
+        cfg = FIX["indexes"][case["index"]]
+        if cfg.get("unsupported") or case.get("needs"):
+            continue
+        index = build_index(cfg)
+        ids, scores, _ = R.search(make_ctx(index), case["query"], tms=case["tms"], offset=case["offset"],
+                                  length=case["limit"], detailed=case["detailed"], stop_after=case.get("stop_after"),
+                                  distinct=case.get("distinct") or index.distinct_field, sort=case.get("sort"))
+        if case["ids"] is not None:
+            assert ids == case["ids"], case["query"]
+        if case.get("scores"):
+            assert debug_scores(scores) == case["scores"], case["query"]
+        if case.get("ids_scores"):
+            assert debug_ids_scores(ids, scores) == case["ids_scores"], case["query"]
+        n += 1
+    assert n >= 100
