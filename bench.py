@@ -80,10 +80,13 @@ def parse_args():
     ap.add_argument("--kw-terms", type=int, default=3, help="c4: words per keyword query")
     ap.add_argument("--kw-dict-words", type=int, default=200_000, help="c4: vocabulary of the synthetic inverted index")
     ap.add_argument("--kw-cache-mb", type=int, default=8192, help="c4: HBM posting cache of the index version")
-    ap.add_argument("--overlap-legs", action="store_true",
-                    help="c4: start the keyword leg while the vector scan still runs (default: one after the other — the scan "
-                         "streams HBM at 0.71 of peak on its own and the latency-bound keyword rounds are not stretched by it: "
-                         "154 ms per step against 157-183 ms overlapped, profiles/r3_bench_variants.txt)")
+    ap.add_argument("--legs", choices=["tail", "serial", "overlap"], default="serial",
+                    help="c4: how the two legs of a step share the device.  serial (default): the scan streams HBM on its own (0.73 of "
+                         "peak), then the keyword leg; overlap: both from the start; tail: the keyword leg first, the scan starts "
+                         "when --tail-at of its searches are done.  All three measured within 3 %% of each other (152-157 ms per "
+                         "step, profiles/r3_bench_variants.txt): a step is the SUM of its legs — the scan saturates HBM and "
+                         "stretches every keyword round beside it by as much as it gains")
+    ap.add_argument("--tail-at", type=float, default=0.8, help="c4, --legs tail: the fraction of the step's keyword searches done when the scan starts")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="also skips the parity check (same leg)")
     ap.add_argument("--no-also", action="store_true", help="c4: do not run the short C2 / C3 / C5 legs after the C4 line")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child for roofline.traffic")
@@ -468,6 +471,10 @@ def run_c4(args, env):
         kw_lib.rb_pool.restype = C.c_void_p
         kw_lib.rb_pool.argtypes = [C.c_void_p, C.c_uint32]
         kw_lib.rb_destroy.argtypes = [C.c_void_p]
+        kw_lib.rb_start_detailed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
+        kw_lib.rb_done.restype = C.c_uint32
+        kw_lib.rb_done.argtypes = [C.c_void_p]
+        kw_lib.rb_wait.argtypes = [C.c_void_p]
         kw_lib.rb_last_latencies.restype = C.c_uint32
         kw_lib.rb_last_latencies.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         n_docs_kw = n_total if row_sharded else n
@@ -573,13 +580,30 @@ def run_c4(args, env):
         return res + ((kw["m_ids"], kw["m_sem"], kw["m_cnt"], kw["m_hits"]),)
 
     def step():
-        store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
-        if kw is not None and not args.overlap_legs:
-            ctx.synchronize()     # the scan streams HBM on its own, then the (latency-bound) keyword lists run
-        if gdict is not None:     # (VALU-bound, on the context's second stream: beside the keyword rounds, not beside the scan)
-            gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
-        if kw is not None:
-            keyword_run()
+        if kw is not None and args.legs == "tail":
+            # The keyword leg is latency-bound (17 dependent rounds per search, `kw_threads` searches in flight) and ends with
+            # a TAIL: the last searches of the step run with most callers already idle.  The vector scan — 8 sweeps that
+            # saturate HBM — starts when `--tail-at` of the step's searches are done and streams beside that tail; the
+            # keyword rounds in flight at that point are slowed, the bulk of them never sees the scan.
+            first = (kw["step"] * Q) % (4 * Q)
+            kw["step"] += 1
+            assert kw["lib"].rb_start_detailed(kw["h"], first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data,
+                                               kw["scores"].ctypes.data, None, None, None) == 0
+            if gdict is not None:
+                gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
+            thr = int(args.tail_at * Q)
+            while kw["lib"].rb_done(kw["h"]) < thr:
+                time.sleep(0.0003)
+            store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
+            assert kw["lib"].rb_wait(kw["h"]) == 0, "msi_keyword_search_ranked failed"
+        else:
+            store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
+            if kw is not None and args.legs == "serial":
+                ctx.synchronize()     # the scan streams HBM on its own, then the (latency-bound) keyword lists run
+            if gdict is not None:     # (VALU-bound, on the context's second stream: beside the keyword rounds, not beside the scan)
+                gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
+            if kw is not None:
+                keyword_run()
         ctx.synchronize()
         if row_sharded:
             from meilisearch_amd.distributed import merge_topk_device

@@ -696,8 +696,9 @@ int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64
 }
 // as rb_run, and also every hit's score details ([n][limit][MSI_MAX_SCORE_DETAILS] + their counts [n][limit]) and the
 // candidate counts [n] — what the oracle check of the keyword leg compares (any of the three may be null)
-int32_t rb_run_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores,
-                        msi_score_detail *out_details, uint32_t *out_n_details, uint64_t *out_candidates) {
+// start the job and return; rb_done() = searches finished so far, rb_wait() blocks until all are (status of the job)
+int32_t rb_start_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores,
+                          msi_score_detail *out_details, uint32_t *out_n_details, uint64_t *out_candidates) {
   Runner *r = (Runner *)h;
   if (!n || r->queries.empty()) return MSI_E_INVALID;
   std::unique_lock<std::mutex> lk(r->mu);
@@ -707,8 +708,23 @@ int32_t rb_run_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, uin
   r->lat_ms.assign(n, 0.0);
   ++r->epoch;
   r->cv.notify_all();
-  r->cv_done.wait(lk, [&] { return r->done == n; });
+  return MSI_OK;
+}
+uint32_t rb_done(void *h) {
+  Runner *r = (Runner *)h;
+  std::lock_guard<std::mutex> lk(r->mu);
+  return r->done;
+}
+int32_t rb_wait(void *h) {
+  Runner *r = (Runner *)h;
+  std::unique_lock<std::mutex> lk(r->mu);
+  r->cv_done.wait(lk, [&] { return r->done == r->job_n; });
   return r->failed.load() ? MSI_E_INTERNAL : MSI_OK;
+}
+int32_t rb_run_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores,
+                        msi_score_detail *out_details, uint32_t *out_n_details, uint64_t *out_candidates) {
+  const int32_t st = rb_start_detailed(h, first, n, limit, out_ids, out_n, out_scores, out_details, out_n_details, out_candidates);
+  return st != MSI_OK ? st : rb_wait(h);
 }
 int32_t rb_run(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores) {
   return rb_run_detailed(h, first, n, limit, out_ids, out_n, out_scores, nullptr, nullptr, nullptr);
