@@ -88,6 +88,9 @@ def parse_args():
                          "stretches every keyword round beside it by as much as it gains")
     ap.add_argument("--tail-at", type=float, default=0.8, help="c4, --legs tail: the fraction of the step's keyword searches done when the scan starts")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="also skips the parity check (same leg)")
+    ap.add_argument("--no-rows-sharded-extra", action="store_true", help="c4, N > 1: skip the rows-sharded extra object")
+    ap.add_argument("--extra-timeout", type=float, default=240.0, help="c4, N > 1: seconds the rows-sharded extra may take before "
+                    "the line is printed without it")
     ap.add_argument("--no-also", action="store_true", help="c4: do not run the short C2 / C3 / C5 legs after the C4 line")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc child for roofline.traffic")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
@@ -710,9 +713,10 @@ def run_c4(args, env):
                           f"+ one {store.max_batch}-query HBM sweep of the store ({sweep_ms:.2f} ms) for the vector list",
             "per": "query"}
     # ---- N > 1: the north_star's own C4 shape beside the weak-scaling line — rows sharded over the GPUs (1 / N of the store
-    # each), the same query batch on every GPU, one packed all-gather + device k-way merge; vector leg only, untimed extra ----
-    rows_sharded_leg = None
-    if world > 1 and not row_sharded:
+    # each), the same query batch on every GPU, one packed all-gather + device k-way merge; vector leg only, untimed extra.
+    # It runs LAST and under a watchdog: a rank that fails inside it would leave the others in the all-gather, and the
+    # weak-scaling line must be printed whatever happens to the extra ----
+    def rows_sharded_extra():
         try:
             from meilisearch_amd.distributed import merge_topk_device, row_range
             sr0, sr1 = row_range(n_total, rank, world)
@@ -749,20 +753,35 @@ def run_c4(args, env):
                 ctx.synchronize()
                 return sm_ids.cpu(), sm_dist.cpu(), sm_cnt.cpu()
             s_elapsed, s_lat = env.timed(sharded_step, 10, 2)
-            rows_sharded_leg = {
+            return {
                 "what": f"BASELINE config 4 as written: {n_total} docs x {d}-d sharded over {world} GPUs ({sr1 - sr0} rows on rank 0), "
                         f"the same {Q}-query batch on every GPU, ONE packed all-gather of per-shard top-{k} + device k-way merge "
                         "(vector leg only, 10 steps, max over ranks)",
                 "queries_per_s": round(Q * 10 / s_elapsed, 1), "ms_per_step": round(s_elapsed / 10 * 1e3, 3),
                 "p50_step_ms": round(statistics.median(s_lat), 3), "scaling": "strong", "exchange_path": exchange_path}
         except Exception as e:      # noqa: BLE001 - an extra: the weak-scaling line must still be produced
-            rows_sharded_leg = {"error": repr(e)[:300]}
-            if env.dist is not None:
-                try:
-                    env.dist.barrier()
-                except Exception:   # noqa: BLE001
-                    pass
+            return {"error": repr(e)[:300]}
+
+    def guarded_extra(line):
+        import threading
+
+        def give_up():
+            if line is not None:
+                line["rows_sharded"] = {"error": f"no answer within {args.extra_timeout} s (a rank stuck in the exchange); the line itself is complete"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.extra_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            return rows_sharded_extra()
+        finally:
+            dog.cancel()
+
+    want_extra = world > 1 and not row_sharded and not args.no_rows_sharded_extra
     if rank != 0:
+        if want_extra:
+            guarded_extra(None)
         return None
     total_queries = Q * (1 if row_sharded else world) * args.steps
     algo_bytes = ((n + 15) // 16) * stats["bytes_per_tile"]  # one sweep of the tiled store
@@ -805,11 +824,13 @@ def run_c4(args, env):
                                   must_contain=("false",)),
         "legs": legs,
         "latency": latency,
-        "rows_sharded": rows_sharded_leg,
+        "rows_sharded": None,
         "dict_lookup": {"launches_timed": match_n, "avg_launch_ms": round(match_ms / max(1, match_n), 4),
                         "words_per_launch": n_words_q,
                         "words_per_s_kernel_only": round(n_words_q / (match_ms / max(1, match_n) * 1e-3), 1) if match_n else None},
     }
+    if want_extra:
+        out["rows_sharded"] = guarded_extra(out)
     if env.check:
         t_vec, cores, sample, vec_by_threads = cpu_vector_baseline(cpu_rows, n, d, k)
         t_word, typo_by_threads, typo_cores = 0.0, None, None
