@@ -8,7 +8,8 @@ import sys
 
 path = sys.argv[1]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 45
-maps, samples = [], []
+SKIP = 0 if os.environ.get("ALLOC_SITES") else 2   # tools/alloc_sites.cpp dumps start at the caller of operator new
+maps, samples, sizes = [], [], []
 for line in open(path):
     if line.startswith("M "):
         f = line[2:].split()
@@ -18,6 +19,8 @@ for line in open(path):
         maps.append((lo, hi, off, name))
     elif line.startswith("S"):
         samples.append([int(x, 16) for x in line.split()[1:]])
+    elif line.startswith("Z "):
+        sizes.append(int(line.split()[1]))
 # module base = lowest mapping of each file
 base = {}
 for lo, hi, off, name in maps:
@@ -65,7 +68,7 @@ for mod, rels in by_mod.items():
 incl, leaf = collections.Counter(), collections.Counter()
 for s in samples:
     names = []
-    for pc in s[2:]:   # skip the handler and the signal trampoline
+    for pc in s[SKIP:]:   # skip the handler and the signal trampoline
         mod, rel = locate(pc - 1)
         names.append(sym.get((mod, rel), "?") if mod else "?")
     if not names:
@@ -89,7 +92,7 @@ callers = collections.Counter()
 n_alloc = 0
 for s in samples:
     names = []
-    for pc in s[2:]:
+    for pc in s[SKIP:]:
         mod, rel = locate(pc - 1)
         names.append((sym.get((mod, rel), "?"), os.path.basename(mod or "?")))
     if not names or not any(names[0][0].startswith(a) for a in alloc_leaf):
@@ -102,3 +105,19 @@ for s in samples:
 print("---- allocator samples: %d of %d (%.1f%%); first libmsi / driver frame above them" % (n_alloc, n, 100.0 * n_alloc / max(1, n)))
 for k, v in callers.most_common(25):
     print("%6.2f%%  %s" % (100.0 * v / n, k))
+
+if sizes:   # tools/alloc_sites.cpp: bytes by allocating function (leaf) and the large requests
+    by_bytes, big = collections.Counter(), collections.Counter()
+    for s, z in zip(samples, sizes):
+        mod, rel = locate(s[0] - 1)
+        name = sym.get((mod, rel), "?") if mod else "?"
+        by_bytes[name[:110]] += z
+        if z >= 16384:
+            big[(name[:90], z)] += 1
+    tot = sum(sizes)
+    print("---- sampled bytes by allocating function (%d bytes in %d samples)" % (tot, len(sizes)))
+    for k, v in by_bytes.most_common(15):
+        print("%6.2f%%  %s" % (100.0 * v / tot, k))
+    print("---- requests of 16 KiB and more: (function, size) x samples")
+    for (k, z), v in big.most_common(15):
+        print("%5d x %8d  %s" % (v, z, k))

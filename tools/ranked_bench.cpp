@@ -12,6 +12,8 @@
 // pass per set operation) and the CPU dictionary walk of oracle/msi_cpubase.c — never the product:
 //   hipcc -O2 -std=c++17 -DRANKED_BENCH_CPU -Iinclude tools/ranked_bench.cpp -Ltests/hostlogic/_build \
 //         -lmsi_hostlogic_test -Loracle -lmsi_cpubase -Lmeilisearch_amd -lmsi -Wl,-rpath,... -o /tmp/ranked_bench_cpu
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -446,6 +448,9 @@ int main(int argc, char **argv) {
     msi_bits_vm_bytes(vb0);
 #endif
     if (getenv("RB_PROFILE") && a == argc - 1) prof::start();
+    // tools/alloc_sites.cpp preloaded: count / sample the allocations of the timed searches only
+    auto alloc_sites = (void (*)(int))dlsym(RTLD_DEFAULT, "alloc_sites_enable");
+    if (alloc_sites && a == argc - 1) alloc_sites(1);
 #ifndef RANKED_BENCH_CPU
     msi_bits_vm_stats(pools[0], vs0);
 #endif
@@ -465,6 +470,13 @@ int main(int argc, char **argv) {
       });
     for (auto &th : ths) th.join();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (alloc_sites && a == argc - 1) {
+      alloc_sites(0);
+      auto calls = (unsigned long (*)())dlsym(RTLD_DEFAULT, "alloc_sites_calls");
+      auto bytes = (unsigned long (*)())dlsym(RTLD_DEFAULT, "alloc_sites_bytes");
+      fprintf(stderr, "allocations per query: %.1f calls, %.0f bytes\n", calls() / ((double)n_threads * n_queries),
+              bytes() / ((double)n_threads * n_queries));
+    }
     std::vector<double> all;
     std::vector<uint64_t> tot(10, 0);
     for (int t = 0; t < n_threads; ++t) {
