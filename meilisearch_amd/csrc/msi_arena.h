@@ -15,6 +15,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -33,6 +34,7 @@ struct Arena {
   char *cur = nullptr, *end = nullptr;
   int depth = 0;
   bool poison = false;
+  long live = 0;      // blocks handed out and not yet given back (checked at reset under MSI_ARENA_POISON)
   // free lists: 16-byte classes up to 1 KiB, then powers of two up to BIG
   void *small_free[N_SMALL] = {};
   void *pow_free[N_POW] = {};
@@ -68,6 +70,7 @@ struct Arena {
     return p;
   }
   void *take(size_t n) {
+    ++live;
     if (n <= 1024) {
       const size_t cls = n ? (n - 1) >> 4 : 0;
       if (void *p = small_free[cls]) { small_free[cls] = *(void **)p; return p; }
@@ -78,6 +81,7 @@ struct Arena {
     return bump((size_t)2048 << k);
   }
   void give(void *p, size_t n) {
+    --live;
     if (poison) memset(p, 0xDD, n);
     if (n <= 1024) {
       const size_t cls = n ? (n - 1) >> 4 : 0;
@@ -90,7 +94,14 @@ struct Arena {
     }
   }
   void reset() {
-    if (poison) for (auto &c : chunks) memset(c.base, 0xDD, c.size);
+    if (poison) {
+      if (live != 0) {   // a container of the arena's types outlived its search (or was released twice)
+        fprintf(stderr, "msi_arena: %ld blocks still live at the end of the scope\n", live);
+        abort();
+      }
+      for (auto &c : chunks) memset(c.base, 0xDD, c.size);
+    }
+    live = 0;
     // a search that needed more than two chunks was an outlier: give the rest back
     while (chunks.size() > 2) { free(chunks.back().base); chunks.pop_back(); }
     ci = 0;

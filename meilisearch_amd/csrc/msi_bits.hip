@@ -1379,7 +1379,7 @@ bool msi_cbo_parse(const uint8_t *bytes, size_t len, std::vector<MsiContainer> &
   MsiCboBatch tmp;
   // (parsed through the batch path with a pretended cache source, so that nothing is copied and offsets are relative)
   if (!msi_cbo_batch_append(tmp, bytes, len, 0, MSI_NO_CACHE)) return false;
-  out.swap(tmp.containers);
+  out.assign(tmp.containers.begin(), tmp.containers.end());
   return !out.empty();
 }
 

@@ -1,6 +1,7 @@
 // msi_common.h — internal helpers shared by the libmsi translation units.
 // gfx950 (MI355X / CDNA4) only: 64-wide wavefronts are assumed everywhere.
 #pragma once
+#include "msi_arena.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -186,15 +187,16 @@ struct MsiContainer {
   uint32_t offset;  // byte offset of the body inside the staged buffer
 };
 constexpr uint64_t MSI_NO_CACHE = ~0ull;
+// (a batch lives inside one call; inside msi_keyword_search_ranked its vectors come from the search's arena, msi_arena.h)
 struct MsiCboBatch {
-  std::vector<uint8_t> bytes;            // concatenated Roaring serialisations (each starts 16-byte aligned)
-  std::vector<MsiContainer> containers;  // their containers, offsets into `bytes`
-  std::vector<uint32_t> small_ids;       // documents of the <= 7-integer raw values
+  msi_arena::Vec<uint8_t> bytes;            // concatenated Roaring serialisations (each starts 16-byte aligned)
+  msi_arena::Vec<MsiContainer> containers;  // their containers, offsets into `bytes`
+  msi_arena::Vec<uint32_t> small_ids;       // documents of the <= 7-integer raw values
   // HBM posting cache (msi_vm.h), per container, empty when the batch never touched the cache:
   //   src[i]  != MSI_NO_CACHE: the body is read from the cache at this byte offset (its bytes are NOT in `bytes`);
   //   fill[i] != MSI_NO_CACHE: the workgroup that decodes the body also stores it into the cache at this offset.
-  std::vector<uint64_t> src, fill;
-  std::vector<void *> fill_tokens;       // the cache entries this batch fills (msi_pcache_commit once its decode has run)
+  msi_arena::Vec<uint64_t> src, fill;
+  msi_arena::Vec<void *> fill_tokens;       // the cache entries this batch fills (msi_pcache_commit once its decode has run)
 };
 struct msi_bits;
 // cache_src / cache_fill: byte offset of the WHOLE serialisation inside the posting cache (MSI_NO_CACHE: none).

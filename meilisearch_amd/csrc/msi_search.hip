@@ -40,6 +40,7 @@
 #include <tuple>
 #include <vector>
 
+#include "msi_arena.h"
 #include "msi_common.h"
 #ifndef MSI_SEARCH_DIRECT_ONLY
 #include "msi_vm.h"
@@ -57,6 +58,11 @@ uint32_t msi_bits_n_slots(msi_bits *p);
 uint64_t msi_bits_n_docs(msi_bits *p);
 
 namespace {
+// every container below lives and dies inside one msi_keyword_search_ranked call: the thread's arena (msi_arena.h)
+using msi_arena::Vec;
+using msi_arena::Map;
+using msi_arena::OrdSet;
+
 
 constexpr uint32_t MAX_PREFIX_COUNT = 1000, MAX_ONE_TYPO_COUNT = 150, MAX_TWO_TYPOS_COUNT = 50;  // limits.rs
 constexpr uint32_t MAX_WORD_LENGTH = 250;                                                        // lib.rs:146
@@ -104,7 +110,7 @@ struct Tasks {
   };
   static constexpr size_t STACK = 1u << 20;   // (index callbacks run on it: an embedding host language needs room)
   ucontext_t main_uc;
-  std::vector<std::unique_ptr<T>> all;
+  Vec<std::unique_ptr<T>> all;
   T *cur = nullptr;
   bool abort = false;
   size_t live = 0;
@@ -119,7 +125,7 @@ struct Tasks {
   }
   // Stacks are recycled per caller thread: a fresh megabyte is an mmap, a munmap and a page fault per touched page —
   // for a dozen tasks per query that was a fifth of a millisecond of kernel time.
-  static std::vector<std::unique_ptr<char[]>> &stack_pool() {
+  static std::vector<std::unique_ptr<char[]>> &stack_pool() {   // (outlives the searches: not the arena's)
     thread_local std::vector<std::unique_ptr<char[]>> pool;
     return pool;
   }
@@ -187,16 +193,16 @@ struct Tasks {
 // ---- device sets ------------------------------------------------------------------------------
 struct SetPool {
   msi_bits *p;
-  std::vector<uint32_t> free_;
-  std::vector<uint32_t> clean_;  // free slots that are known to be all zero
+  Vec<uint32_t> free_;
+  Vec<uint32_t> clean_;  // free slots that are known to be all zero
   // command-list back end: a slot handed out as "all zero" is only zeroed when something READS it (most are first
   // written whole — the bucket of a cost level, a decode — or never used at all)
-  std::vector<uint8_t> lazy_zero;
+  Vec<uint8_t> lazy_zero;
   // compact space (Dev::compact_begin): the decodes of a list are hoisted into a phase of their own that runs FIRST, so a
   // slot freed while a list is being recorded must not be handed out again (as a decode's destination) before that list
   // has run — it waits here
   bool hold = false;
-  std::vector<uint32_t> held;
+  Vec<uint32_t> held;
   SetPool(msi_bits *p_, uint32_t first) : p(p_), lazy_zero(msi_bits_n_slots(p_), 0) {
     for (uint32_t s = msi_bits_n_slots(p_); s-- > first;) free_.push_back(s);
   }
@@ -208,6 +214,7 @@ struct SetPool {
 struct SetH {
   SetPool *pool;
   uint32_t slot;
+  SetH(SetPool *p_, uint32_t s_) : pool(p_), slot(s_) {}
   ~SetH() {
     pool->lazy_zero[slot] = 0;
     if (pool->hold) pool->held.push_back(slot);
@@ -224,7 +231,7 @@ using Set = std::shared_ptr<SetH>;
 //   direct (MSI_SEARCH_VM=0, and the host-logic test double which has no kernels): one msi_bits call per operation.
 // the paths of one cost level as the kernels take them: path k = slots[off[k] .. off[k+1])
 struct PathSlots {
-  std::vector<uint32_t> off{0}, slots;
+  Vec<uint32_t> off{0}, slots;
   size_t size() const { return off.size() - 1; }
   bool empty() const { return off.size() == 1; }
   void close_path() { off.push_back((uint32_t)slots.size()); }
@@ -235,13 +242,13 @@ struct Dev {
   SetPool *cur = &pool;                // the pool every operation works on: `pool`, or — after compact_begin — `cpool`
   std::unique_ptr<SetPool> cpool;      // the companion pool: sets over the ranks of the documents of U0 (universe compaction)
   Set u0_full;                         // U0 in the caller's pool (read by the compact lists' decodes)
-  std::vector<Set> keep_until_run;     // full-space sets the recorded list still reads
+  Vec<Set> keep_until_run;     // full-space sets the recorded list still reads
 #ifndef MSI_SEARCH_DIRECT_ONLY
   bool vm = true;
   MsiVmList list;
   MsiVmResult res;
   MsiPostingCache *pcache = nullptr;   // HBM posting cache of the index version (msi_dict_enable_posting_cache), or none
-  std::vector<void *> fills;           // cache entries the RECORDED decodes fill: ready once the list has run
+  Vec<void *> fills;           // cache entries the RECORDED decodes fill: ready once the list has run
   ~Dev() {                             // a search that ended with a recorded list it never ran (an error unwound it)
     for (void *t : fills) msi_pcache_abandon(pcache, t);
   }
@@ -250,7 +257,7 @@ struct Dev {
     uint32_t k, ci, base;
     std::function<void(const uint32_t *, size_t)> sink;
   };
-  std::vector<PendingFk> pending_fk;
+  Vec<PendingFk> pending_fk;
   // A stored posting value joins a decode batch: from the cache when another search left it there, else from the
   // bytes the callback handed over (and, when there is room, into the cache on the way).
   bool append_posting(MsiCboBatch &b, const MsiCacheKey &k, const uint8_t *bytes, size_t n) {
@@ -323,7 +330,7 @@ struct Dev {
       else msi_pcache_abandon(pcache, t);
     }
     fills.clear();
-    std::vector<PendingFk> fk;
+    Vec<PendingFk> fk;
     fk.swap(pending_fk);
     ck(st);
     for (PendingFk &f : fk) {   // a set smaller than k filled less of its block
@@ -410,11 +417,11 @@ struct Dev {
       if (cur->clean_.empty()) fail(MSI_E_OOM, "the msi_bits pool has no free slot left (create it with more slots)");
       const uint32_t s = cur->clean_.back();
       cur->clean_.pop_back();
-      return Set(new SetH{cur, s});
+      return msi_arena::make_shared<SetH>(cur, s);
     }
     const uint32_t s = cur->free_.back();
     cur->free_.pop_back();
-    return Set(new SetH{cur, s});
+    return msi_arena::make_shared<SetH>(cur, s);
   }
   void op(uint32_t d, uint32_t a, uint32_t b, int32_t o) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
@@ -470,7 +477,7 @@ struct Dev {
     }
     const uint32_t s = cur->clean_.back();
     cur->clean_.pop_back();
-    return Set(new SetH{cur, s});
+    return msi_arena::make_shared<SetH>(cur, s);
   }
   Set ones() {
     Set s = alloc();
@@ -510,14 +517,14 @@ struct Dev {
     return s;
   }
   // dst[i] = prefix & cond[i] with the cardinalities, one operation and one completion wait for all of them
-  std::vector<std::pair<Set, uint64_t>> and_many(const Set &prefix, const std::vector<Set> &conds) {
-    std::vector<std::pair<Set, uint64_t>> out;
+  Vec<std::pair<Set, uint64_t>> and_many(const Set &prefix, const Vec<Set> &conds) {
+    Vec<std::pair<Set, uint64_t>> out;
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       for (size_t base = 0; base < conds.size(); base += 256) {
         const uint32_t n = (uint32_t)std::min<size_t>(256, conds.size() - base);
         // (the destinations first: an allocation may run the list recorded so far, or fail — never in mid-command)
-        std::vector<Set> ds(n);
+        Vec<Set> ds(n);
         for (uint32_t k = 0; k < n; ++k) ds[k] = alloc();
         const uint32_t cb = counts_for(n);
         rd(prefix->slot);
@@ -538,7 +545,7 @@ struct Dev {
       const uint32_t n = (uint32_t)std::min<size_t>(MSI_BITS_MANY, conds.size() - base);
       uint32_t cs[MSI_BITS_MANY], ds[MSI_BITS_MANY];
       uint64_t counts[MSI_BITS_MANY];
-      std::vector<Set> dst;
+      Vec<Set> dst;
       for (uint32_t k = 0; k < n; ++k) {
         dst.push_back(alloc());
         cs[k] = conds[base + k]->slot;
@@ -570,8 +577,8 @@ struct Dev {
   }
 #endif
   // a whole cost level: path k claims universe & AND(its condition sets), in order; returns the cardinalities
-  std::vector<uint64_t> paths_claim(const PathSlots &paths, const Set &bucket, const Set &universe) {
-    std::vector<uint64_t> counts(paths.size(), 0);
+  Vec<uint64_t> paths_claim(const PathSlots &paths, const Set &bucket, const Set &universe) {
+    Vec<uint64_t> counts(paths.size(), 0);
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       const uint32_t cb = rec_paths(paths, bucket, universe);
@@ -636,7 +643,7 @@ struct Dev {
     return b;
   }
   // the documents of `universe` that have a point, with their distances (at most `cap`; *total = how many there are)
-  void geo_list(const msi_geo_rule &r, const Set &universe, uint32_t cap, std::vector<uint32_t> &ids, std::vector<double> &dist,
+  void geo_list(const msi_geo_rule &r, const Set &universe, uint32_t cap, Vec<uint32_t> &ids, Vec<double> &dist,
                 uint64_t *total) {
     settle();
     Clock ck_;
@@ -683,8 +690,8 @@ struct Dev {
 #endif
   }
   // sets[i] -= removed, with the new cardinalities: one operation and one wait
-  std::vector<uint64_t> sub_many(const Set &removed, const std::vector<Set> &sets) {
-    std::vector<uint64_t> out(sets.size(), 0);
+  Vec<uint64_t> sub_many(const Set &removed, const Vec<Set> &sets) {
+    Vec<uint64_t> out(sets.size(), 0);
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       for (size_t base = 0; base < sets.size(); base += 512) {
@@ -712,12 +719,12 @@ struct Dev {
     }
     return out;
   }
-  Set from_docids(const std::vector<uint32_t> &ids) {
+  Set from_docids(const Vec<uint32_t> &ids) {
     Set s = alloc();
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       MsiCboBatch b;
-      b.small_ids = ids;
+      b.small_ids.assign(ids.begin(), ids.end());
       open_list();
       ck(msi_vm_record_decode(list, cur->p, s->slot, b, true));
       return s;
@@ -730,7 +737,7 @@ struct Dev {
   // the same level WITHOUT the completion wait: its counts land in `region`; false = does not fit, nothing enqueued
   // `pending_levels`: (count base, paths) of the levels recorded ahead — the CALLER's (a rule evaluation's) state: the
   // bucket sort's tasks interleave between an enqueue and its collect
-  using PendingLevels = std::vector<std::pair<uint32_t, uint32_t>>;
+  using PendingLevels = Vec<std::pair<uint32_t, uint32_t>>;
   bool paths_enqueue(const PathSlots &paths, const Set &bucket, const Set &universe, uint32_t region,
                      PendingLevels &pending_levels) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
@@ -747,8 +754,8 @@ struct Dev {
     ++g_stats.launches;
     return true;
   }
-  std::vector<uint64_t> paths_collect(uint32_t n_regions, PendingLevels &pending_levels) {  // ONE wait for every level enqueued so far
-    std::vector<uint64_t> counts((size_t)n_regions * MSI_BITS_REGION_PATHS, 0);
+  Vec<uint64_t> paths_collect(uint32_t n_regions, PendingLevels &pending_levels) {  // ONE wait for every level enqueued so far
+    Vec<uint64_t> counts((size_t)n_regions * MSI_BITS_REGION_PATHS, 0);
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       run();
@@ -766,7 +773,7 @@ struct Dev {
     g_stats.device_wait_ms += ck_.ms();
     return counts;
   }
-  void claim(const Set &docs, const Set &bucket, const Set &universe, const std::vector<Set> &stack) {
+  void claim(const Set &docs, const Set &bucket, const Set &universe, const Vec<Set> &stack) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       rd(docs->slot);
@@ -785,8 +792,8 @@ struct Dev {
     ck(msi_bits_claim(cur->p, docs->slot, bucket->slot, universe->slot, (uint32_t)stack.size(), ss));
   }
   // the cardinalities of several sets: one list, one completion wait for all of them
-  std::vector<uint64_t> count_many(const std::vector<Set> &sets) {
-    std::vector<uint64_t> out(sets.size(), 0);
+  Vec<uint64_t> count_many(const Vec<Set> &sets) {
+    Vec<uint64_t> out(sets.size(), 0);
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       for (size_t base = 0; base < sets.size(); base += 64) {
@@ -869,20 +876,20 @@ struct Dev {
       return;
     }
 #endif
-    const std::vector<uint32_t> ids = first_k(a, k);
+    const Vec<uint32_t> ids = first_k(a, k);
     sink(ids.data(), ids.size());
   }
-  std::vector<uint32_t> first_k(const Set &a, uint32_t k) {
+  Vec<uint32_t> first_k(const Set &a, uint32_t k) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm && k <= MSI_VM_MAX_FIRSTK) {
-      std::vector<uint32_t> out;
+      Vec<uint32_t> out;
       first_k_later(a, k, [&out](const uint32_t *ids, size_t n) { out.assign(ids, ids + n); });
       run();
       return out;
     }
     settle();
 #endif
-    std::vector<uint32_t> ids(std::max<uint32_t>(k, 1));
+    Vec<uint32_t> ids(std::max<uint32_t>(k, 1));
     uint32_t n = 0;
     Clock ck_;
     g_stats.launches += 3;
@@ -895,7 +902,7 @@ struct Dev {
 };
 
 // ---- terms and subsets (query_term/mod.rs, ntypo_subset.rs) -------------------------------------------
-using Phrase = std::vector<int32_t>;  // word ids, -1 = a stop word inside the phrase
+using Phrase = Vec<int32_t>;  // word ids, -1 = a stop word inside the phrase
 
 // A set of small ids (word / phrase interner ids, graph nodes) in ascending order: what the reference keeps in
 // BTreeSet<u32> / SmallBitmap.  The host logic copies and compares these tens of thousands of times per query (subsets
@@ -1040,14 +1047,14 @@ struct Located {
 struct Term {
   uint32_t original = 0;
   bool is_ngram = false;
-  std::vector<uint32_t> ngram_words;
+  Vec<uint32_t> ngram_words;
   int32_t phrase = -1;
   uint32_t max_lev = 0;
   bool is_prefix = false;
   int32_t exact = -1;
-  std::vector<uint32_t> prefix_of, one_typo, two_typos;
+  Vec<uint32_t> prefix_of, one_typo, two_typos;
   int32_t split_words = -1;
-  std::vector<uint32_t> synonyms;  // phrase ids
+  Vec<uint32_t> synonyms;  // phrase ids
   int32_t use_prefix_db = -1;  // the word itself when it is a key of the word-prefix databases
   bool too_long = false;
 };
@@ -1062,7 +1069,7 @@ struct Condition {
   bool has_left = false;
   uint32_t x = 0;          // typo count / proximity cost / fid
   bool has_fid = false;    // C_FID
-  std::vector<uint16_t> positions;
+  Vec<uint16_t> positions;
   bool operator<(const Condition &o) const {   // the order of the tuple (kind, term, has_left, left, x, has_fid, positions)
     if (kind != o.kind) return kind < o.kind;
     if (int c = term.cmp(o.term)) return c < 0;
@@ -1080,10 +1087,10 @@ struct GNode {
   IdSet preds, succs;
 };
 struct Graph {
-  std::vector<GNode> nodes;
+  Vec<GNode> nodes;
   static constexpr uint32_t ROOT = 0, END = 1;
 };
-using PathSubsets = std::vector<std::pair<std::pair<bool, Located>, Located>>;  // (start?, dest) per condition
+using PathSubsets = Vec<std::pair<std::pair<bool, Located>, Located>>;  // (start?, dest) per condition
 
 struct Score {
   uint32_t kind, a, b;
@@ -1098,8 +1105,8 @@ struct Resolved {
 // A query meets the same (rule, source, destination) in bucket after bucket: built once per query (Ctx::edge_memo); a rule
 // evaluation holds the entries it uses, so dropping the memo under memory pressure never pulls them from under it.
 struct EdgeSet {
-  std::vector<std::pair<uint32_t, Condition>> conds;   // (cost, condition), build_edges' order
-  std::vector<std::unique_ptr<Resolved>> resolved;     // on demand
+  Vec<std::pair<uint32_t, Condition>> conds;   // (cost, condition), build_edges' order
+  Vec<std::unique_ptr<Resolved>> resolved;     // on demand
 };
 struct EdgeKeyRef {   // a key that only points at its terms: lookups copy nothing
   int rule;
@@ -1133,22 +1140,23 @@ struct Ctx {
   const msi_index_vtable *ix;
   const msi_search_params *prm;
   Dev dev;
-  std::vector<std::string> words;
-  std::unordered_map<std::string, uint32_t> word_ids;   // (lookups only; the ids are the order of `words`)
-  std::vector<Phrase> phrases;
-  std::map<Phrase, uint32_t> phrase_ids;
-  std::vector<Term> terms;
-  std::map<uint32_t, Set> phrase_cache;
+  Vec<std::string> words;
+  std::unordered_map<std::string, uint32_t, std::hash<std::string>, std::equal_to<std::string>,
+                     msi_arena::Alloc<std::pair<const std::string, uint32_t>>> word_ids;   // (lookups only; the ids are the order of `words`)
+  Vec<Phrase> phrases;
+  Map<Phrase, uint32_t> phrase_ids;
+  Vec<Term> terms;
+  Map<uint32_t, Set> phrase_cache;
   // Document sets that do not depend on a universe, decoded once per search and then only intersected:
   // the rules of a search resolve the same term subsets again and again (every bucket of a rule restarts
   // the rules below it).
-  std::map<Subset, Set> subset_cache;
-  std::map<EdgeKey, std::shared_ptr<EdgeSet>, EdgeKeyLess> edge_memo;
-  std::map<std::tuple<Subset, int, std::vector<uint32_t>>, Set> within_cache;
-  std::map<std::string, std::vector<Set>> exact_attr_cache;  // {ExactMatch, MatchesStart, position candidates}
-  std::map<std::tuple<Subset, Subset, uint32_t, uint32_t>, Set> prox_cache;
-  std::map<std::pair<uint32_t, bool>, Set> word_cache;
-  std::map<uint32_t, uint32_t> freq_weight;   // MSI_TERMS_FREQUENCY: removal weight per term id (removal_order_frequency)
+  Map<Subset, Set> subset_cache;
+  Map<EdgeKey, std::shared_ptr<EdgeSet>, EdgeKeyLess> edge_memo;
+  Map<std::tuple<Subset, int, Vec<uint32_t>>, Set> within_cache;
+  Map<std::string, Vec<Set>> exact_attr_cache;  // {ExactMatch, MatchesStart, position candidates}
+  Map<std::tuple<Subset, Subset, uint32_t, uint32_t>, Set> prox_cache;
+  Map<std::pair<uint32_t, bool>, Set> word_cache;
+  Map<uint32_t, uint32_t> freq_weight;   // MSI_TERMS_FREQUENCY: removal weight per term id (removal_order_frequency)
   void forget() {   // every cached set (all of them can be recomputed from the index)
     subset_cache.clear();
     within_cache.clear();
@@ -1403,7 +1411,7 @@ struct Ctx {
 
   struct SynSink {
     Ctx *c;
-    std::vector<Phrase> out;
+    Vec<Phrase> out;
   };
   static int32_t syn_push(void *sink, const msi_query_token *ws, uint32_t n) {
     SynSink *s = (SynSink *)sink;
@@ -1412,10 +1420,10 @@ struct Ctx {
     s->out.push_back(std::move(p));
     return 0;
   }
-  std::vector<Phrase> synonyms_of(const std::vector<uint32_t> &ws) {
+  Vec<Phrase> synonyms_of(const Vec<uint32_t> &ws) {
     if (!ix->synonyms) return {};
-    std::vector<msi_query_token> toks(ws.size());
-    std::vector<std::string> keep;
+    Vec<msi_query_token> toks(ws.size());
+    Vec<std::string> keep;
     for (uint32_t w : ws) keep.push_back(words[w]);
     for (size_t i = 0; i < ws.size(); ++i) toks[i] = msi_query_token{(const uint8_t *)keep[i].data(), (uint32_t)keep[i].size(), 0};
     SynSink sk{this, {}};
@@ -1425,13 +1433,13 @@ struct Ctx {
     return sk.out;
   }
 
-  std::vector<uint16_t> list_of(decltype(msi_index_vtable::word_fids) fn, uint32_t w, const char *what) {
+  Vec<uint16_t> list_of(decltype(msi_index_vtable::word_fids) fn, uint32_t w, const char *what) {
     if (!fn) {
       msi_set_error("msi_keyword_search_ranked: the index vtable has no %s", what);
       throw Fail{MSI_E_INVALID};
     }
     const std::string &s = words[w];
-    std::vector<uint16_t> out(64);
+    Vec<uint16_t> out(64);
     Cb cb_;
     for (;;) {
       uint32_t n = 0;
@@ -1480,7 +1488,7 @@ struct Ctx {
       // the keys of exact_word_docids, the word itself left out, at most 1000
       uint32_t lo = 0, hi = 0;
       msi_dict_prefix_range(dict, (const uint8_t *)w.data(), (uint32_t)w.size(), &lo, &hi);
-      std::vector<std::string> exact;
+      Vec<std::string> exact;
       if (ix->exact_words_with_prefix) {
         SynSink sk{this, {}};
         Cb cb_;
@@ -1514,8 +1522,8 @@ struct Ctx {
 
   // compute_fully_if_needed for every term of the query: ONE batched device dictionary lookup
   void compute_derivations() {
-    std::vector<msi_typo_query> tq;
-    std::vector<uint32_t> owner;
+    Vec<msi_typo_query> tq;
+    Vec<uint32_t> owner;
     for (uint32_t ti = 0; ti < terms.size(); ++ti) {
       Term &t = terms[ti];
       if (t.phrase >= 0 || t.too_long || t.max_lev == 0) continue;
@@ -1529,7 +1537,7 @@ struct Ctx {
       tq.push_back(q);
       owner.push_back(ti);
     }
-    std::vector<uint32_t> one(tq.size() * MAX_ONE_TYPO_COUNT), two(tq.size() * MAX_TWO_TYPOS_COUNT), n1(tq.size()),
+    Vec<uint32_t> one(tq.size() * MAX_ONE_TYPO_COUNT), two(tq.size() * MAX_TWO_TYPOS_COUNT), n1(tq.size()),
         n2(tq.size());
     if (!tq.empty())
       ck(msi_dict_lookup(dict, tq.data(), (uint32_t)tq.size(), MAX_ONE_TYPO_COUNT, MAX_TWO_TYPOS_COUNT, one.data(),
@@ -1591,10 +1599,10 @@ struct Ctx {
     if (t.use_prefix_db < 0 || !ss.zero.has_word((uint32_t)t.use_prefix_db)) return -1;
     return t.use_prefix_db;
   }
-  std::set<std::pair<uint32_t, bool>> all_single_words(const Subset &ss) {  // (word, Word::Original?)
+  OrdSet<std::pair<uint32_t, bool>> all_single_words(const Subset &ss) {  // (word, Word::Original?)
     const Term &t = terms[ss.term];
     const bool orig = !t.is_ngram;
-    std::set<std::pair<uint32_t, bool>> out;
+    OrdSet<std::pair<uint32_t, bool>> out;
     if (ss.zero.kind != 0) {
       if (t.exact >= 0 && ss.zero.has_word((uint32_t)t.exact)) out.insert({(uint32_t)t.exact, orig});
       for (uint32_t w : t.prefix_of)
@@ -1708,7 +1716,7 @@ struct Ctx {
   }
   // ..._within_field_id / ..._within_position :61-130 for one fid (which 0) or a set of positions (which 1):
   // every posting of the condition goes into ONE decode batch
-  Set within_full(const Subset &ss, int which, const std::vector<uint32_t> &keys) {
+  Set within_full(const Subset &ss, int which, const Vec<uint32_t> &keys) {
     Subset sk = ss;
     sk.mandatory = false;
     auto ck_ = std::make_tuple(sk, which, keys);
@@ -1780,7 +1788,7 @@ void build_initial_edges(Graph &g) {
   }
 }
 
-void remove_nodes_keep_edges(Graph &g, const std::vector<uint32_t> &ids) {
+void remove_nodes_keep_edges(Graph &g, const Vec<uint32_t> &ids) {
   for (uint32_t i : ids) {
     const IdSet pr = g.nodes[i].preds, su = g.nodes[i].succs;
     for (uint32_t p : pr) {
@@ -1799,8 +1807,8 @@ void remove_nodes_keep_edges(Graph &g, const std::vector<uint32_t> &ids) {
 // removal_order_for_terms_matching_strategy :377-406 — groups of nodes by ascending cost (the largest `order` over the
 // node's term ids), first removed first; the last group stays unless a phrase / mandatory term keeps the query alive
 template <typename Order>
-std::vector<IdSet> removal_order(Ctx &c, const Graph &g, Order order) {
-  std::map<uint32_t, IdSet> groups;
+Vec<IdSet> removal_order(Ctx &c, const Graph &g, Order order) {
+  Map<uint32_t, IdSet> groups;
   bool mandatory = false;
   for (uint32_t i = 0; i < g.nodes.size(); ++i) {
     const GNode &n = g.nodes[i];
@@ -1813,14 +1821,14 @@ std::vector<IdSet> removal_order(Ctx &c, const Graph &g, Order order) {
     for (uint32_t id = n.term.id_lo; id <= n.term.id_hi; ++id) cost = std::max(cost, (uint32_t)order(id));
     groups[cost].insert(i);
   }
-  std::vector<IdSet> res;
+  Vec<IdSet> res;
   for (auto &kv : groups) res.push_back(kv.second);
   if (!mandatory && !res.empty()) res.pop_back();
   return res;
 }
 
 // removal_order_for_terms_matching_strategy_last :346-375
-std::vector<IdSet> removal_order_last(Ctx &c, const Graph &g) {
+Vec<IdSet> removal_order_last(Ctx &c, const Graph &g) {
   uint32_t first = 255, last = 0;
   for (const GNode &n : g.nodes)
     if (n.kind == 2) {
@@ -1835,13 +1843,13 @@ std::vector<IdSet> removal_order_last(Ctx &c, const Graph &g) {
 // the nodes that cover it (n-gram nodes count for each of their ids; no document at all counts as the LARGEST
 // frequency); the most frequent term gets weight 1 and is removed first, equal frequencies share a weight.  The unions
 // and all their cardinalities are ONE command list (VM_OP ... VM_COUNT x terms): one completion wait per call.
-std::vector<IdSet> removal_order_frequency(Ctx &c, const Graph &g) {
+Vec<IdSet> removal_order_frequency(Ctx &c, const Graph &g) {
   // The frequencies are those of the whole index (universe None) and the graph is the query's own every time — Words is
   // the first graph-based rule, so nothing above it rebuilds the graph: computed once per search.  (Computed again after
   // the search moved into the compact space they would be frequencies inside U0.)
   if (!c.freq_weight.empty())
     return removal_order(c, g, [&c](uint32_t id) { return c.freq_weight.at(id); });
-  std::map<uint32_t, Set> term_docids;
+  Map<uint32_t, Set> term_docids;
   for (const GNode &n : g.nodes) {
     if (n.kind != 2) continue;
     Set d = c.subset_full(n.term.subset);     // compute_query_term_subset_docids(ctx, None, subset): cached, never written
@@ -1851,18 +1859,18 @@ std::vector<IdSet> removal_order_frequency(Ctx &c, const Graph &g) {
       else c.dev.or_(it->second, d);
     }
   }
-  std::vector<Set> sets;
-  std::vector<std::pair<uint32_t, uint64_t>> tf;
+  Vec<Set> sets;
+  Vec<std::pair<uint32_t, uint64_t>> tf;
   for (auto &kv : term_docids) {
     tf.push_back({kv.first, 0});
     sets.push_back(kv.second);
   }
-  const std::vector<uint64_t> counts = c.dev.count_many(sets);
+  const Vec<uint64_t> counts = c.dev.count_many(sets);
   for (size_t i = 0; i < tf.size(); ++i) tf[i].second = counts[i] ? counts[i] : ~0ull;
   std::stable_sort(tf.begin(), tf.end(), [](const std::pair<uint32_t, uint64_t> &a, const std::pair<uint32_t, uint64_t> &b) {
     return a.second > b.second;               // sort_by_key(Reverse(frequency)): stable over ascending term ids
   });
-  std::map<uint32_t, uint32_t> &weight_of = c.freq_weight;
+  Map<uint32_t, uint32_t> &weight_of = c.freq_weight;
   uint32_t weight = 1;
   for (size_t i = 0; i < tf.size(); ++i) {
     weight_of[tf[i].first] = weight;
@@ -1871,7 +1879,7 @@ std::vector<IdSet> removal_order_frequency(Ctx &c, const Graph &g) {
   return removal_order(c, g, [&weight_of](uint32_t id) { return weight_of.at(id); });
 }
 
-std::vector<IdSet> removal_order_of(Ctx &c, const Graph &g, int strategy) {
+Vec<IdSet> removal_order_of(Ctx &c, const Graph &g, int strategy) {
   if (strategy == MSI_TERMS_LAST) return removal_order_last(c, g);
   if (strategy == MSI_TERMS_FREQUENCY) return removal_order_frequency(c, g);
   return {};
@@ -1889,10 +1897,10 @@ uint32_t words_in_phrases_count(Ctx &c, const Graph &g) {
 }
 
 // QueryGraph::build_from_paths :470-544 (nodes shared by (term, suffix of the path))
-Graph build_from_paths(const std::vector<PathSubsets> &paths) {
-  std::vector<std::vector<Located>> singles;
+Graph build_from_paths(const Vec<PathSubsets> &paths) {
+  Vec<Vec<Located>> singles;
   for (const PathSubsets &path : paths) {
-    std::vector<Located> out;
+    Vec<Located> out;
     bool has_prev = false;
     Located prev;
     for (const auto &cond : path) {
@@ -1925,12 +1933,12 @@ Graph build_from_paths(const std::vector<PathSubsets> &paths) {
   g.nodes.resize(2);
   g.nodes[0].kind = 0;
   g.nodes[1].kind = 1;
-  std::map<std::vector<Located>, uint32_t> ids;  // keyed by the suffix starting at the term
-  std::vector<std::vector<uint32_t>> id_paths;
+  Map<Vec<Located>, uint32_t> ids;  // keyed by the suffix starting at the term
+  Vec<Vec<uint32_t>> id_paths;
   for (const auto &path : singles) {
-    std::vector<uint32_t> p;
+    Vec<uint32_t> p;
     for (size_t k = 0; k < path.size(); ++k) {
-      std::vector<Located> suffix(path.begin() + k, path.end());
+      Vec<Located> suffix(path.begin() + k, path.end());
       auto it = ids.find(suffix);
       if (it == ids.end()) {
         GNode n;
@@ -1959,8 +1967,8 @@ Graph build_from_paths(const std::vector<PathSubsets> &paths) {
 // compute_query_graph_docids :133-185
 Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe) {
   IdSet resolved;
-  std::map<uint32_t, Set> docs;
-  std::vector<uint32_t> queue{Graph::ROOT};
+  Map<uint32_t, Set> docs;
+  Vec<uint32_t> queue{Graph::ROOT};
   size_t guard = 0;
   while (!queue.empty()) {
     if (++guard > 100000) fail(MSI_E_INTERNAL, "query graph is not a DAG");
@@ -1996,8 +2004,8 @@ uint32_t cost_from_distance(uint32_t d) {  // position/mod.rs:127-143
   return 10;
 }
 
-std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const Located *src, const Located &dst) {
-  std::vector<std::pair<uint32_t, Condition>> out;
+Vec<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const Located *src, const Located &dst) {
+  Vec<std::pair<uint32_t, Condition>> out;
   out.reserve(8);
   const uint32_t n = dst.n_ids();
   auto cond = [&](int k) {
@@ -2040,7 +2048,7 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
       break;
     }
     case R_FID: {  // fid/mod.rs:51-121
-      std::set<uint16_t> fids;
+      OrdSet<uint16_t> fids;
       for (auto &w : c.all_single_words(dst.subset))
         for (uint16_t f : c.list_of(c.ix->word_fids, w.first, "word_fids")) fids.insert(f);
       for (uint32_t p : c.all_phrases(dst.subset))
@@ -2071,7 +2079,7 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
       break;
     }
     case R_POSITION: {  // position/mod.rs:50-125
-      std::set<uint16_t> positions;
+      OrdSet<uint16_t> positions;
       for (auto &w : c.all_single_words(dst.subset))
         for (uint16_t p : c.list_of(c.ix->word_positions, w.first, "word_positions")) positions.insert(p);
       for (uint32_t p : c.all_phrases(dst.subset))
@@ -2085,7 +2093,7 @@ std::vector<std::pair<uint32_t, Condition>> build_edges(Ctx &c, int kind, const 
         if (pf >= 0)
           for (uint16_t q : c.list_of(c.ix->word_prefix_positions, (uint32_t)pf, "word_prefix_positions")) positions.insert(q);
       }
-      std::map<uint32_t, std::vector<uint16_t>> by_cost;
+      Map<uint32_t, Vec<uint16_t>> by_cost;
       for (uint16_t pos : positions) {
         const uint32_t dist = pos > dst.pos_lo ? pos - dst.pos_lo : dst.pos_lo - pos;
         uint32_t cost = 0;
@@ -2118,7 +2126,7 @@ Set proximity_full(Ctx &c, const Condition &cd) {
   auto hit = c.prox_cache.find(key);
   if (hit != c.prox_cache.end()) return hit->second;
   c.relieve();
-  std::set<std::pair<int32_t, uint32_t>> lefts, rights;  // (phrase or -1, word)
+  OrdSet<std::pair<int32_t, uint32_t>> lefts, rights;  // (phrase or -1, word)
   for (auto &w : c.all_single_words(cd.left.subset)) lefts.insert({-1, w.first});
   for (uint32_t p : c.all_phrases(cd.left.subset))
     if (c.phrases[p].back() >= 0) lefts.insert({(int32_t)p, (uint32_t)c.phrases[p].back()});
@@ -2127,7 +2135,7 @@ Set proximity_full(Ctx &c, const Condition &cd) {
     if (c.phrases[p].front() >= 0) rights.insert({(int32_t)p, (uint32_t)c.phrases[p].front()});
   Set docids = c.dev.zeros();
   // all the word-word pairs resolve against the same universe: one decode launch for all of them
-  std::map<std::pair<int32_t, int32_t>, MsiCboBatch> groups;
+  Map<std::pair<int32_t, int32_t>, MsiCboBatch> groups;
   const int32_t pf = c.use_prefix_db(cd.term.subset);
   if (pf >= 0)  // compute_prefix_edges :97-147: (left word, right prefix) forward, (right prefix as a word, left word) backward
     for (auto &l : lefts) {
@@ -2168,7 +2176,7 @@ Resolved resolve_condition(Ctx &c, const Condition &cd) {
       break;
     case C_POSITION:
       r.docs = cd.positions.empty() ? c.empty_set()
-                                    : c.within_full(cd.term.subset, 1, std::vector<uint32_t>(cd.positions.begin(), cd.positions.end()));
+                                    : c.within_full(cd.term.subset, 1, Vec<uint32_t>(cd.positions.begin(), cd.positions.end()));
       break;
     case C_EXACT: {
       r.end.subset = c.keep_only_exact_term(cd.term.subset);
@@ -2196,7 +2204,7 @@ struct Bucket {
   Graph owned;
   const Graph *same_as = nullptr;
   struct Rule *maker = nullptr;                 // the graph rule that knows what `good` names
-  std::vector<std::vector<int32_t>> good;       // the paths (condition ids) that found documents
+  Vec<Vec<int32_t>> good;       // the paths (condition ids) that found documents
   inline const Graph &graph();
   Set docs;
   uint64_t count = 0;
@@ -2213,7 +2221,7 @@ struct Rule {
   virtual bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) = 0;
   virtual void end() = 0;
   virtual Rule *fresh() const = 0;   // another instance of the same rule (the bucket sort's tasks each rank with their own)
-  virtual Graph graph_of(const std::vector<std::vector<int32_t>> &) { return Graph(); }   // Bucket::graph
+  virtual Graph graph_of(const Vec<Vec<int32_t>> &) { return Graph(); }   // Bucket::graph
 };
 
 const Graph &Bucket::graph() {
@@ -2232,11 +2240,11 @@ struct Edge {
 };
 
 struct GraphRule : Rule {
-  std::vector<std::pair<EdgeSet *, uint32_t>> conds;   // condition id -> its entry in an edge set of the query's memo
-  std::vector<std::shared_ptr<EdgeSet>> held;          // ... which this evaluation keeps alive
-  std::vector<std::vector<Edge>> edges;
-  std::vector<std::vector<uint64_t>> costs;
-  std::vector<char> costs_done;
+  Vec<std::pair<EdgeSet *, uint32_t>> conds;   // condition id -> its entry in an edge set of the query's memo
+  Vec<std::shared_ptr<EdgeSet>> held;          // ... which this evaluation keeps alive
+  Vec<Vec<Edge>> edges;
+  Vec<Vec<uint64_t>> costs;
+  Vec<char> costs_done;
   uint64_t next_max_cost = 1, cur_cost = 0;
 
   // per next_bucket state
@@ -2249,8 +2257,8 @@ struct GraphRule : Rule {
     bool stale;
     uint64_t count;
   };
-  std::vector<StackE> stack;
-  std::vector<std::vector<int32_t>> good;
+  Vec<StackE> stack;
+  Vec<Vec<int32_t>> good;
   bool stop = false;
   uint64_t emit_epoch = 0;
   // cost levels evaluated ahead of their turn behind one completion wait (MSI_SEARCH_LEVELS_PER_WAIT > 1)
@@ -2258,7 +2266,7 @@ struct GraphRule : Rule {
     uint64_t cost;
     Set bucket;
     uint64_t count;
-    std::vector<std::vector<int32_t>> good;
+    Vec<Vec<int32_t>> good;
   };
   std::deque<Ready> ready;
 
@@ -2271,7 +2279,7 @@ struct GraphRule : Rule {
     ready.clear();
     next_max_cost = 1;
     cur_cost = 0;
-    std::map<uint32_t, std::pair<uint32_t, IdSet>> skip_cost;
+    Map<uint32_t, std::pair<uint32_t, IdSet>> skip_cost;
     if (tms >= 0) {
       const uint32_t wp = words_in_phrases_count(c, g);
       next_max_cost += wp > 0 ? wp - 1 : 0;
@@ -2287,7 +2295,7 @@ struct GraphRule : Rule {
     // its destination term and — for proximity between adjacent terms only — its source term, and one build_edges call
     // never yields the same condition twice: interning per edge set of the query's memo (keyed by exactly those values)
     // hands out the same ids without comparing condition values.
-    std::map<EdgeSet *, std::vector<std::pair<uint32_t, int32_t>>> interned;
+    Map<EdgeSet *, Vec<std::pair<uint32_t, int32_t>>> interned;
     edges.assign(g.nodes.size(), {});
     for (uint32_t i = 0; i < g.nodes.size(); ++i) {
       const GNode &n = g.nodes[i];
@@ -2309,7 +2317,7 @@ struct GraphRule : Rule {
         const bool by_source = kind == R_PROXIMITY && src && src->pos_hi + 1 == dn.term.pos_lo;
         auto known = c.edge_memo.find(EdgeKeyRef{kind, &dn.term, by_source, src});
         if (known == c.edge_memo.end()) {
-          auto fresh_set = std::make_shared<EdgeSet>();
+          auto fresh_set = msi_arena::make_shared<EdgeSet>();
           fresh_set->conds = build_edges(c, kind, src, dn.term);
           fresh_set->resolved.resize(fresh_set->conds.size());
           known = c.edge_memo.emplace(EdgeKey{kind, dn.term, by_source, by_source ? *src : Located()}, std::move(fresh_set)).first;
@@ -2318,7 +2326,7 @@ struct GraphRule : Rule {
         auto memo = interned.find(es);
         if (memo == interned.end()) {
           held.push_back(known->second);
-          std::vector<std::pair<uint32_t, int32_t>> ids;
+          Vec<std::pair<uint32_t, int32_t>> ids;
           for (uint32_t k = 0; k < es->conds.size(); ++k) {
             conds.push_back({es, k});
             ids.push_back({es->conds[k].first, (int32_t)conds.size() - 1});
@@ -2334,14 +2342,14 @@ struct GraphRule : Rule {
     next_max_cost += rc.empty() ? 0 : rc.back();
   }
 
-  const std::vector<uint64_t> &costs_to_end(uint32_t i) {  // find_all_costs_to_end, cheapest_paths.rs:312-340
+  const Vec<uint64_t> &costs_to_end(uint32_t i) {  // find_all_costs_to_end, cheapest_paths.rs:312-340
     if (costs_done[i]) return costs[i];
     costs_done[i] = 1;
     if (i == Graph::END) {
       costs[i] = {0};
       return costs[i];
     }
-    std::vector<uint64_t> out;
+    Vec<uint64_t> out;
     for (const Edge &e : edges[i])
       for (uint64_t cc : costs_to_end(e.dest)) out.push_back(e.cost + cc);
     std::sort(out.begin(), out.end());
@@ -2400,8 +2408,8 @@ struct GraphRule : Rule {
     return true;
   }
 
-  Graph graph_of(const std::vector<std::vector<int32_t>> &found) override {
-    std::vector<PathSubsets> paths;
+  Graph graph_of(const Vec<Vec<int32_t>> &found) override {
+    Vec<PathSubsets> paths;
     paths.reserve(found.size());
     for (auto &p : found) {
       PathSubsets ps;
@@ -2418,14 +2426,14 @@ struct GraphRule : Rule {
   // All the paths of this cost, in the order the search would visit them, WITHOUT evaluating anything
   // (cheapest_paths.rs:147-310 minus the dead-end pruning).  False when there are too many for one launch.
   struct PathList {  // path k = conds[off[k] .. off[k+1])
-    std::vector<uint32_t> off{0};
-    std::vector<int32_t> conds;
+    Vec<uint32_t> off{0};
+    Vec<int32_t> conds;
     size_t size() const { return off.size() - 1; }
     bool empty() const { return off.size() == 1; }
-    std::vector<int32_t> path(size_t k) const { return {conds.begin() + off[k], conds.begin() + off[k + 1]}; }
+    Vec<int32_t> path(size_t k) const { return {conds.begin() + off[k], conds.begin() + off[k + 1]}; }
   };
   bool enumerate(uint32_t node, uint64_t remaining, IdSet &visited, const IdSet &to_skip,
-                 std::vector<int32_t> &cur, PathList &out, size_t &steps) {
+                 Vec<int32_t> &cur, PathList &out, size_t &steps) {
     for (const Edge &e : edges[node]) {
       if (remaining < e.cost) continue;
       const uint64_t rem = remaining - e.cost;
@@ -2466,7 +2474,7 @@ struct GraphRule : Rule {
   // loses a level's documents when bucket_sort asks for that level, so a search that stops early, a deadline or a
   // score threshold see the same universe as without the look-ahead.  Fills `ready` or leaves it empty (a level
   // that does not fit the in-argument kernel: the caller runs the one-level path).
-  void look_ahead(std::vector<uint64_t>::const_iterator it, std::vector<uint64_t>::const_iterator end) {
+  void look_ahead(Vec<uint64_t>::const_iterator it, Vec<uint64_t>::const_iterator end) {
     // with command lists a level evaluated ahead is one more command in a list that is submitted anyway, so the
     // look-ahead is on by default there (waits per 3-term query 76 -> 41); the direct back end pays a launch per level
     const char *knob = getenv("MSI_SEARCH_LEVELS_PER_WAIT");
@@ -2481,11 +2489,11 @@ struct GraphRule : Rule {
       PathList all;
       PathSlots sets;
     };
-    std::vector<Plan> plan;
+    Vec<Plan> plan;
     for (; it != end && (int)plan.size() < per_wait; ++it) {
       Plan pl;
       pl.cost = *it;
-      std::vector<int32_t> cur;
+      Vec<int32_t> cur;
       IdSet visited, to_skip;
       size_t steps = 0;
       if (!enumerate(Graph::ROOT, pl.cost, visited, to_skip, cur, pl.all, steps)) break;
@@ -2495,7 +2503,7 @@ struct GraphRule : Rule {
     }
     if (plan.size() < 2) return;
     Set ahead = cx->dev.clone(uni);
-    std::vector<Set> buckets;
+    Vec<Set> buckets;
     Dev::PendingLevels pending_levels;
     size_t n_enq = 0;
     for (; n_enq < plan.size(); ++n_enq) {
@@ -2504,7 +2512,7 @@ struct GraphRule : Rule {
       if (!cx->dev.paths_enqueue(plan[n_enq].sets, buckets.back(), ahead, (uint32_t)n_enq, pending_levels)) break;
     }
     if (n_enq == 0) return;
-    const std::vector<uint64_t> counts = cx->dev.paths_collect((uint32_t)n_enq, pending_levels);
+    const Vec<uint64_t> counts = cx->dev.paths_collect((uint32_t)n_enq, pending_levels);
     for (size_t j = 0; j < n_enq; ++j) {
       Ready r;
       r.cost = plan[j].cost;
@@ -2530,14 +2538,14 @@ struct GraphRule : Rule {
     const char *knob = getenv("MSI_SEARCH_FUSED_LEVELS");
     if (knob && knob[0] == '0') return false;
     PathList all;
-    std::vector<int32_t> cur;
+    Vec<int32_t> cur;
     IdSet visited, to_skip;
     size_t steps = 0;
     if (!enumerate(Graph::ROOT, cost, visited, to_skip, cur, all, steps)) return false;
     if (all.empty()) return true;
     PathSlots sets;
     slots_of(all, sets);
-    const std::vector<uint64_t> counts = cx->dev.paths_claim(sets, bucket, uni);
+    const Vec<uint64_t> counts = cx->dev.paths_claim(sets, bucket, uni);
     for (size_t k = 0; k < all.size(); ++k) {
       if (!counts[k]) continue;
       good.push_back(all.path(k));
@@ -2571,7 +2579,7 @@ struct GraphRule : Rule {
   // edges that leave a node are intersected with the path prefix in ONE launch (and one completion wait);
   // a sibling evaluated before an earlier sibling claimed documents is re-intersected when its turn comes.
   void visit(uint32_t node, uint64_t remaining, IdSet &visited, const IdSet &to_skip) {
-    std::vector<const Edge *> cand;
+    Vec<const Edge *> cand;
     for (const Edge &e : edges[node]) {
       if (remaining < e.cost) continue;
       const auto &dc = costs[e.dest];
@@ -2584,11 +2592,11 @@ struct GraphRule : Rule {
       }
       cand.push_back(&e);
     }
-    std::vector<Set> cs;
+    Vec<Set> cs;
     for (const Edge *e : cand)
       if (e->cond >= 0) cs.push_back(resolved(e->cond).docs);
     // stack entries are subsets of the current universe, so only the first condition needs it
-    std::vector<std::pair<Set, uint64_t>> pre;
+    Vec<std::pair<Set, uint64_t>> pre;
     if (!cs.empty() && !stop) pre = cx->dev.and_many(stack.empty() ? uni : stack.back().docs, cs);
     const uint64_t epoch0 = emit_epoch;
     size_t k = 0;
@@ -2629,7 +2637,7 @@ struct GraphRule : Rule {
       return;
     }
     uint64_t cnt;
-    std::vector<int32_t> path;
+    Vec<int32_t> path;
     for (auto &s : stack) path.push_back(s.cond);
     if (stack.empty()) {  // a path without any condition takes the whole universe
       cnt = uni_count;
@@ -2643,7 +2651,7 @@ struct GraphRule : Rule {
       }
       cnt = top.count;
       if (!cnt) return;
-      std::vector<Set> ss;
+      Vec<Set> ss;
       for (auto &s : stack) ss.push_back(s.docs);
       cx->dev.claim(top.docs, bucket, uni, ss);
       for (auto &s : stack) s.stale = true;
@@ -2691,7 +2699,7 @@ struct ExactAttributeRule : Rule {
       std::pair<int, uint32_t> exact;
       uint32_t start_pos, n_pos;
     };
-    std::vector<Info> infos;
+    Vec<Info> infos;
     for (const GNode &n : g.nodes) {
       if (n.kind != 2) continue;
       auto e = c.exact_term(n.term.subset);
@@ -2699,7 +2707,7 @@ struct ExactAttributeRule : Rule {
       infos.push_back({n.term.id_lo, e, n.term.pos_lo, n.term.pos_hi - n.term.pos_lo + 1});
     }
     std::stable_sort(infos.begin(), infos.end(), [](const Info &a, const Info &b) { return a.start_id < b.start_id; });
-    std::vector<Info> ded;
+    Vec<Info> ded;
     for (auto &x : infos)
       if (ded.empty() || ded.back().start_id != x.start_id) ded.push_back(x);
     uint32_t count_all = 0;
@@ -2710,7 +2718,7 @@ struct ExactAttributeRule : Rule {
       if (x.start_id < prev || x.start_id - prev > 1) return;
       prev = x.start_id;
     }
-    std::vector<std::pair<Phrase, uint32_t>> words_positions;
+    Vec<std::pair<Phrase, uint32_t>> words_positions;
     std::string sig = std::to_string(count_all);
     for (auto &x : ded) {
       Phrase ws;
@@ -2764,7 +2772,7 @@ struct ExactAttributeRule : Rule {
         c.dev.or_(e2, S);
       }
       c.dev.sub_(e2, e1);  // a document can match exactly in one field and only start another: ExactMatch wins
-      hit = c.exact_attr_cache.emplace(sig, std::vector<Set>{e1, e2, P}).first;
+      hit = c.exact_attr_cache.emplace(sig, Vec<Set>{e1, e2, P}).first;
     }
     // both buckets against this universe in one launch and one wait (they are disjoint, so taking the first out
     // of the universe does not change the second)
@@ -2862,8 +2870,8 @@ struct GeoSortRule : Rule {
     const double margin = c.prm->geo_distance_error_margin;
     const int strategy = c.prm->geo_strategy;
     out.same_as = &g;
-    std::vector<uint32_t> ids;
-    std::vector<double> dist;
+    Vec<uint32_t> ids;
+    Vec<double> dist;
     uint64_t total = 0;
     bool listed = false;
     if (strategy != MSI_GEO_ALWAYS_RTREE && (mode == 0 || cache_left == 0 || mode == 1)) {
@@ -2885,14 +2893,14 @@ struct GeoSortRule : Rule {
       }
       // sort_by_cached_key(distance as usize) over candidates in docid order: stable (:127-131); a descending rule pops
       // the cache from the back
-      std::vector<uint32_t> order(ids.size());
+      Vec<uint32_t> order(ids.size());
       for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
       std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         const uint64_t ka = (uint64_t)dist[a], kb = (uint64_t)dist[b];
         return ka != kb ? ka < kb : ids[a] < ids[b];
       });
       if (!rule.ascending) std::reverse(order.begin(), order.end());
-      std::vector<uint32_t> bucket;
+      Vec<uint32_t> bucket;
       const double d0 = dist[order[0]];
       for (uint32_t o : order) {   // next_bucket :166-206
         if (fabs(d0 - dist[o]) > margin) break;
@@ -2928,15 +2936,15 @@ struct GeoSortRule : Rule {
   void end() override {}
 };
 
-double global_score(const std::vector<Score> &scores) {
-  std::vector<msi_score_detail> d;
+double global_score(const Vec<Score> &scores) {
+  Vec<msi_score_detail> d;
   for (const Score &s : scores) d.push_back(msi_score_detail{s.kind, s.a, s.b});
   return msi_score_details_global_score(d.data(), (uint32_t)d.size());
 }
 
 // get_ranking_rules_for_query_graph_search, mod.rs:510-649
-std::vector<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
-  std::vector<std::unique_ptr<Rule>> rules;
+Vec<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
+  Vec<std::unique_ptr<Rule>> rules;
   bool words = p->strategy == MSI_TERMS_ALL, typo = false, prox = false, attribute = false, attr_rank = false,
        word_pos = false, exact = false;
   uint32_t n_order = 0, n_geo = 0;
@@ -3000,8 +3008,8 @@ std::vector<std::unique_ptr<Rule>> ranking_rules(const msi_search_params *p) {
 }
 
 // get_ranking_rules_for_placeholder_search, mod.rs:352-420: only the Sort / Asc / Desc rules
-std::vector<std::unique_ptr<Rule>> placeholder_rules(const msi_search_params *p) {
-  std::vector<std::unique_ptr<Rule>> rules;
+Vec<std::unique_ptr<Rule>> placeholder_rules(const msi_search_params *p) {
+  Vec<std::unique_ptr<Rule>> rules;
   uint32_t n_order = 0, n_geo = 0;
   for (uint32_t i = 0; i < p->n_criteria; ++i)
     if (p->criteria[i] == MSI_CRIT_ORDER_BY) {
@@ -3017,13 +3025,13 @@ std::vector<std::unique_ptr<Rule>> placeholder_rules(const msi_search_params *p)
 }
 
 // make_ngram, parse_query.rs:227-300 -> term index or -1
-int32_t make_ngram(Ctx &c, const std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> &ts, size_t lo, size_t hi) {
+int32_t make_ngram(Ctx &c, const Vec<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> &ts, size_t lo, size_t hi) {
   for (size_t i = lo; i <= hi; ++i)
     if (c.terms[ts[i].first].phrase >= 0) return -1;
   for (size_t i = lo; i < hi; ++i)
     if (ts[i].second.second + 1 != ts[i + 1].second.first) return -1;
   std::string s;
-  std::vector<uint32_t> ws;
+  Vec<uint32_t> ws;
   for (size_t i = lo; i <= hi; ++i) {
     const Term &t = c.terms[ts[i].first];
     if (t.is_ngram) return -1;
@@ -3056,8 +3064,8 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   };
   const msi_search_params *p = c.prm;
   // ---- located terms -> terms -----------------------------------------------------------------
-  std::vector<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> ts;  // (term, positions)
-  std::vector<uint32_t> negatives;
+  Vec<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> ts;  // (term, positions)
+  Vec<uint32_t> negatives;
   for (uint32_t i = 0; i < n_terms; ++i) {
     const msi_located_term &l = lt[i];
     if (!l.words || l.n_words == 0) fail(MSI_E_INVALID, "a located term has no word");
@@ -3142,7 +3150,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   if (!placeholder) {
     Graph reduced = g;
     if (p->strategy == MSI_TERMS_LAST || p->strategy == MSI_TERMS_FREQUENCY) {
-      std::vector<uint32_t> rm;
+      Vec<uint32_t> rm;
       for (auto &ns : removal_order_of(c, g, p->strategy)) rm.insert(rm.end(), ns.begin(), ns.end());
       remove_nodes_keep_edges(reduced, rm);
     }
@@ -3242,7 +3250,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       // Rare (three of 230 000 random searches); the tree notices and the search is done again by the sequential loop.
       bool dropped = false;
       // documents [off, off + count) of the final order, all with the same score details
-      auto emit = [&](const Set &docs, uint64_t count, uint64_t off, const std::vector<Score> &scores) {
+      auto emit = [&](const Set &docs, uint64_t count, uint64_t off, const Vec<Score> &scores) {
         if (!count || off >= page_end || off + count <= from) return;
         const uint64_t skip = off < from ? from - off : 0;
         const uint32_t take = (uint32_t)std::min<uint64_t>(count - skip, page_end - (off + skip));
@@ -3266,8 +3274,8 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       const bool coop = false;
 #endif
       // rule `cur` ranks `uni` (count documents, first of them at place `off`), bucket_sort.rs:187-343
-      std::function<void(size_t, Set, uint64_t, uint64_t, std::vector<Score>, const Graph &)> rank;
-      rank = [&](size_t cur, Set uni, uint64_t left, uint64_t off, std::vector<Score> scores, const Graph &graph) {
+      std::function<void(size_t, Set, uint64_t, uint64_t, Vec<Score>, const Graph &)> rank;
+      rank = [&](size_t cur, Set uni, uint64_t left, uint64_t off, Vec<Score> scores, const Graph &graph) {
         std::unique_ptr<Rule> rule_owner(rules[cur]->fresh());
         Rule *rule = rule_owner.get();
         rule->start(c, uni, graph);
@@ -3291,7 +3299,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
           ++g_stats.buckets;
           if (!b.universe_reduced) c.dev.sub_(uni, b.docs);
           left -= b.count;
-          std::vector<Score> sc = scores;
+          Vec<Score> sc = scores;
           sc.push_back(b.score);
           if (cur == nr - 1 || (!detailed && b.count <= 1) || off + b.count < from) {
             emit(b.docs, b.count, off, sc);                              // :296-330
@@ -3302,7 +3310,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             if (coop && tasks.live < (size_t)max_tasks &&
                 (no_gate || c.dev.cur->free_.size() + c.dev.cur->clean_.size() >= 48 * (tasks.live + 2))) {
               // (the graph is moved into the task: the Bucket dies at the end of this iteration)
-              auto gp = std::make_shared<Graph>(b.graph());
+              auto gp = msi_arena::make_shared<Graph>(b.graph());
               tasks.spawn([&rank, cur, docs = b.docs, cnt = b.count, off, sc, gp]() { rank(cur + 1, docs, cnt, off, sc, *gp); });
             } else
 #endif
@@ -3368,9 +3376,9 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       if (getenv("MSI_SEARCH_DEBUG")) fprintf(stderr, "[msi] a rule dropped documents: sequential re-run\n");
     }
   }
-  std::vector<Set> unis(nr);
-  std::vector<uint64_t> uni_counts(nr, 0);
-  std::vector<Score> scores;
+  Vec<Set> unis(nr);
+  Vec<uint64_t> uni_counts(nr, 0);
+  Vec<Score> scores;
   unis[0] = c.dev.clone(universe);
   uni_counts[0] = universe_count;
   rules[0]->start(c, universe, g);
@@ -3384,8 +3392,8 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       const Set given = cands;
       uint64_t n_kept = 0;
       auto de = c.dev.distinct(dv, cands, &n_kept);
-      std::vector<Set> live;
-      std::vector<size_t> idx;
+      Vec<Set> live;
+      Vec<size_t> idx;
       for (size_t i = 0; i < nr; ++i)
         if (unis[i] && unis[i] != given && uni_counts[i]) {  // a universe handed over as the bucket is dropped by the caller
           live.push_back(unis[i]);
@@ -3545,6 +3553,7 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
   g_ranked_searches.fetch_add(1, std::memory_order_relaxed);
   Clock total;
   try {
+    msi_arena::ArenaScope host_memory;   // (declared before Ctx: released after everything the search built)
     Ctx c(dict, pool, index, params);
     search(c, terms, n_terms, universe_cbo, universe_len, out_docids, out_scores, out_n_scores, out_n, out_candidates,
            out_degraded);

@@ -121,3 +121,16 @@ if sizes:   # tools/alloc_sites.cpp: bytes by allocating function (leaf) and the
     print("---- requests of 16 KiB and more: (function, size) x samples")
     for (k, z), v in big.most_common(15):
         print("%5d x %8d  %s" % (v, z, k))
+
+if os.environ.get("ALLOC_SITES_CALLERS"):   # who calls the std:: internals that lead the leaf list (frame above the leaf)
+    up = collections.Counter()
+    for s in samples:
+        names = []
+        for pc in s[SKIP:SKIP + 4]:
+            mod, rel = locate(pc - 1)
+            names.append(sym.get((mod, rel), "?")[:70] if mod else "?")
+        if names and names[0].startswith(("std::", "void std::")):
+            up[" <- ".join(names[:3])] += 1
+    print("---- callers of std:: leaves")
+    for k, v in up.most_common(20):
+        print("%6.2f%%  %s" % (100.0 * v / n, k))
