@@ -33,6 +33,10 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <climits>
 #include <vector>
 
 #include <time.h>
@@ -663,10 +667,14 @@ struct msi_dict {
     uint32_t *one_idx, *one_cnt, *two_idx, *two_cnt;
     int32_t status = MSI_OK;
     std::string error;
-    bool done = false;
+    std::atomic<uint32_t> done{0};   // set by the leader LAST: the waiter may return (and its Pending vanish) right after
   };
   std::mutex bmu;
-  std::condition_variable bcv;
+  // Waiters sleep on futex words, not on a condition variable: with 128 searches in flight every arrival used to
+  // notify_all() the others so that the leader could re-count the queue, and every woken thread went through the mutex —
+  // a quarter of the keyword leg's host CPU was futex traffic (profiles/r3_ranked_arena_profile.txt).
+  std::atomic<uint32_t> bgen{0};    // bumped (under bmu) whenever a leader is done: its batch returns, one of the rest leads
+  std::atomic<uint32_t> bfill{0};   // bumped (under bmu) by the arrival that fills the queue to the target: the leader's wake-up
   std::vector<Pending *> bqueue;
   bool bleader_active = false;
   uint32_t microbatch_wait_us = 0, microbatch_target = 256;
@@ -932,6 +940,16 @@ static int32_t dict_lookup_direct(msi_dict *d, const msi_typo_query *queries, ui
                                   uint32_t cap_two, uint32_t *out_one_idx, uint32_t *out_one_cnt,
                                   uint32_t *out_two_idx, uint32_t *out_two_cnt);
 
+static void dict_futex_wake(std::atomic<uint32_t> *w, int n) {
+  syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
+}
+static void dict_futex_wait(std::atomic<uint32_t> *w, uint32_t expected, long timeout_us) {
+  struct timespec ts;
+  ts.tv_sec = timeout_us / 1000000;
+  ts.tv_nsec = (timeout_us % 1000000) * 1000;
+  syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
+}
+
 // Micro-batcher: a search derives the typos of its <= 10 words (+ n-grams) with one small
 // lookup; under load many searches do so at once (4 x cores spawn_blocking threads).  The
 // first caller leads: it waits until `microbatch_target` words are queued or
@@ -956,18 +974,31 @@ static int32_t dict_lookup_fused(msi_dict *d, const msi_typo_query *queries, uin
     for (auto *p : d->bqueue) w += p->n;
     return w;
   };
+  auto finished = [&]() -> int32_t {
+    if (me.status != MSI_OK) msi_set_error("%s", me.error.c_str());
+    return me.status;
+  };
   for (;;) {
     if (d->bleader_active) {
-      d->bcv.notify_all();
-      d->bcv.wait(lk, [&] { return me.done || !d->bleader_active; });
-      if (me.done) {
-        if (me.status != MSI_OK) msi_set_error("%s", me.error.c_str());
-        return me.status;
-      }
+      const bool filled = queued_words() >= d->microbatch_target;
+      if (filled) d->bfill.fetch_add(1, std::memory_order_release);
+      const uint32_t gen = d->bgen.load(std::memory_order_acquire);
+      lk.unlock();
+      if (filled) dict_futex_wake(&d->bfill, 1);
+      while (!me.done.load(std::memory_order_acquire) && d->bgen.load(std::memory_order_acquire) == gen)
+        dict_futex_wait(&d->bgen, gen, 2000);
+      if (me.done.load(std::memory_order_acquire)) return finished();
+      lk.lock();                       // the leader is done and my request was not in its batch (other caps, or I came late)
+      if (me.done.load(std::memory_order_acquire)) return finished();
+      continue;
     }
     d->bleader_active = true;
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(d->microbatch_wait_us);
-    d->bcv.wait_until(lk, deadline, [&] { return queued_words() >= d->microbatch_target; });
+    if (queued_words() < d->microbatch_target) {
+      const uint32_t fill = d->bfill.load(std::memory_order_acquire);
+      lk.unlock();
+      dict_futex_wait(&d->bfill, fill, d->microbatch_wait_us);
+      lk.lock();
+    }
     // take every request with MY caps (always includes me); leave the others queued
     std::vector<msi_dict::Pending *> batch, rest;
     for (auto *p : d->bqueue) (p->cap_one == cap_one && p->cap_two == cap_two ? batch : rest).push_back(p);
@@ -998,13 +1029,15 @@ static int32_t dict_lookup_fused(msi_dict *d, const msi_typo_query *queries, uin
     d->fused_calls += batch.size();
     d->fused_launches += 1;
     for (auto *p : batch) {
+      if (p == &me) continue;
       p->status = st;
       p->error = err;
-      p->done = true;
+      p->done.store(1, std::memory_order_release);   // (p may be gone from here on)
     }
     d->bleader_active = false;
+    d->bgen.fetch_add(1, std::memory_order_release);
     lk.unlock();
-    d->bcv.notify_all();
+    dict_futex_wake(&d->bgen, INT32_MAX);
     if (st != MSI_OK) msi_set_error("%s", err.c_str());
     return st;   // my own request was in the batch
   }
