@@ -1157,6 +1157,27 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
 
 // ================================================================================================ combiner
 
+// Diagnostic counters that every search thread bumps for every list: striped by thread, summed by the reader — one
+// shared cache line per counter took a million contended read-modify-writes per second at 128 callers.
+template <int N>
+struct StripedCounters {
+  static constexpr int STRIPES = 32;
+  struct alignas(64) Cell { std::atomic<uint64_t> v[N]; };
+  Cell cells[STRIPES];
+  StripedCounters() { for (auto &c : cells) for (auto &x : c.v) x.store(0, std::memory_order_relaxed); }
+  static unsigned stripe() {
+    static std::atomic<unsigned> next{0};
+    thread_local const unsigned mine = next.fetch_add(1, std::memory_order_relaxed) % STRIPES;
+    return mine;
+  }
+  void add(int i, uint64_t x) { cells[stripe()].v[i].fetch_add(x, std::memory_order_relaxed); }
+  uint64_t sum(int i) const {
+    uint64_t t = 0;
+    for (const auto &c : cells) t += c.v[i].load(std::memory_order_relaxed);
+    return t;
+  }
+};
+
 // A submitted list.  Lives in a slot OWNED BY THE VM (recycled, never freed before the VM), so the combiner may touch it
 // at any time; the search thread sleeps on `state` (futex) and is woken by the combiner, which is the only thread that
 // polls the GPU's completion words.  (Search threads that spin burn the CPU budget the searches themselves need: on a
@@ -1194,7 +1215,8 @@ struct VmCombiner {
   std::atomic<uint64_t> rounds{0}, lists{0};
   // where a list's wall time goes (ns, summed over lists): queued until the combiner took it, packed until the launch
   // calls began, launch calls (per round), from the launch calls until the combiner saw the GPU's completion word
-  std::atomic<uint64_t> ns_queued{0}, ns_packed{0}, ns_launch_calls{0}, ns_after_launch{0};
+  std::atomic<uint64_t> ns_launch_calls{0};
+  StripedCounters<3> ns_waiters;   // [queued, packed, after launch]: added by the search threads
   std::atomic<uint32_t> load{0};           // lists submitted and not finished yet
   u64 *d_prof = nullptr;                   // MSI_VM_PROFILE: 16 tick counters in device memory
   void run();
@@ -1562,10 +1584,10 @@ void msi_vm_stats(msi_bits *pool, uint64_t out[6]) {
   for (auto &cb : ctx->vm->comb) {
     out[0] += cb->rounds.load();
     out[1] += cb->lists.load();
-    out[2] += cb->ns_queued.load();
-    out[3] += cb->ns_packed.load();
+    out[2] += cb->ns_waiters.sum(0);
+    out[3] += cb->ns_waiters.sum(1);
     out[4] += cb->ns_launch_calls.load();
-    out[5] += cb->ns_after_launch.load();
+    out[5] += cb->ns_waiters.sum(2);
   }
 }
 
@@ -1732,7 +1754,7 @@ static void finalize_decodes(MsiVmList &l) {
 // Algorithmic bytes of a list: every set operand of every command, whole (slot words x 8), plus the container bodies its
 // decodes read and — compact lists — U0's words and prefix counts once per decode.  What the commands ASK the memory
 // system for; msi_bits_vm_bytes hands the sums out for the keyword leg's roofline object (bench.py).
-static std::atomic<uint64_t> g_vm_set_bytes{0}, g_vm_posting_bytes{0}, g_vm_lists{0};
+static StripedCounters<3> g_vm_bytes;   // [set operands, posting containers, lists]
 static void account_list(msi_bits *pool, const MsiVmList &l) {
   const uint64_t words = l.geom_docs ? std::max<uint64_t>(2, ((l.geom_docs + 127) / 128) * 2) : msi_bits_words_per_slot(pool);
   const uint64_t set_b = words * 8;
@@ -1770,15 +1792,13 @@ static void account_list(msi_bits *pool, const MsiVmList &l) {
   uint64_t total = sets * set_b;
   // (a wide phase stages U0's words and prefix counts once per workgroup, whatever the number of its decodes)
   if (l.geom_docs && l.full_pool && wide) total += msi_bits_words_per_slot(l.full_pool) * 12;
-  g_vm_set_bytes.fetch_add(total, std::memory_order_relaxed);
-  g_vm_posting_bytes.fetch_add(posting, std::memory_order_relaxed);
-  g_vm_lists.fetch_add(1, std::memory_order_relaxed);
+  g_vm_bytes.add(0, total);
+  g_vm_bytes.add(1, posting);
+  g_vm_bytes.add(2, 1);
 }
 extern "C" int32_t msi_bits_vm_bytes(uint64_t out[3]) {
   if (!out) return MSI_E_INVALID;
-  out[0] = g_vm_set_bytes.load();
-  out[1] = g_vm_posting_bytes.load();
-  out[2] = g_vm_lists.load();
+  for (int i = 0; i < 3; ++i) out[i] = g_vm_bytes.sum(i);
   return MSI_OK;
 }
 
@@ -1844,9 +1864,9 @@ int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
     if (ret == MSI_E_INTERNAL) msi_set_error("msi_vm: a round finished without publishing its results");
     else msi_set_error("%s", s->errmsg[0] ? s->errmsg : "msi_vm: the round of this list failed");
   } else {
-    vm->ns_queued.fetch_add((uint64_t)(s->t_taken - s->t_submit), std::memory_order_relaxed);
-    vm->ns_packed.fetch_add((uint64_t)(s->t_launch - s->t_taken), std::memory_order_relaxed);
-    vm->ns_after_launch.fetch_add((uint64_t)(s->t_done - s->t_launch), std::memory_order_relaxed);
+    vm->ns_waiters.add(0, (uint64_t)(s->t_taken - s->t_submit));
+    vm->ns_waiters.add(1, (uint64_t)(s->t_launch - s->t_taken));
+    vm->ns_waiters.add(2, (uint64_t)(s->t_done - s->t_launch));
     if (res) {
       res->counts.resize(l.n_counts);
       for (uint32_t i = 0; i < l.n_counts; ++i)
@@ -1903,10 +1923,12 @@ struct MsiPostingCache {
   struct Shard {
     mutable std::shared_mutex mu;
     std::unordered_map<MsiCacheKey, CacheEntry, KeyHash, KeyEq> map;
+    // counted per shard: one process-wide counter took ~500 k increments per second from 128 threads — the line never
+    // stayed in anybody's cache (msi_pcache_known was 12 % of the leg's host CPU, profiles/r3_ranked_arena_profile.txt)
+    std::atomic<uint64_t> hits{0}, misses{0};
     char pad[64];
   } shard[SHARDS];
   Shard &of(const MsiCacheKey &k) { return shard[(k.b >> 7) % SHARDS]; }
-  std::atomic<uint64_t> hits{0}, misses{0};
 };
 
 // Two independent 64-bit hashes over (database tag, the two strings with their lengths, two integers): a collision
@@ -1964,10 +1986,10 @@ int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint
       const uint32_t state = it->second.ready.load(std::memory_order_acquire);
       if (it->second.host_kind.load(std::memory_order_acquire) == 0 && it->second.len == len && state == 1) {
         *off = it->second.off;
-        c->hits.fetch_add(1, std::memory_order_relaxed);
+        sh.hits.fetch_add(1, std::memory_order_relaxed);
         return 1;
       }
-      c->misses.fetch_add(1, std::memory_order_relaxed);
+      sh.misses.fetch_add(1, std::memory_order_relaxed);
       uint32_t abandoned = 2;
       if (it->second.host_kind.load(std::memory_order_acquire) == 0 && it->second.len == len && state == 2 &&
           it->second.ready.compare_exchange_strong(abandoned, 0, std::memory_order_acq_rel)) {
@@ -1978,7 +2000,7 @@ int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint
       return 0;   // being filled by another search (or a length mismatch: never trusted)
     }
   }
-  c->misses.fetch_add(1, std::memory_order_relaxed);
+  sh.misses.fetch_add(1, std::memory_order_relaxed);
   std::unique_lock<std::shared_mutex> lk(sh.mu);
   if (sh.map.find(k) != sh.map.end()) return 0;
   const uint64_t need = ((uint64_t)len + 15 + 16) & ~15ull;   // + one block of slack for the last partial block
@@ -2016,7 +2038,7 @@ bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting 
     out->n_conts = 0;
     out->small = e.small.data();
     out->n_small = (uint32_t)e.small.size();
-    c->hits.fetch_add(1, std::memory_order_relaxed);
+    sh.hits.fetch_add(1, std::memory_order_relaxed);
     return true;
   }
   if (e.ready.load(std::memory_order_acquire) != 1 || e.conts.empty()) return false;
@@ -2028,7 +2050,7 @@ bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting 
   out->n_conts = (uint32_t)e.conts.size();
   out->small = nullptr;
   out->n_small = 0;
-  c->hits.fetch_add(1, std::memory_order_relaxed);
+  sh.hits.fetch_add(1, std::memory_order_relaxed);
   return true;
 }
 
@@ -2071,8 +2093,11 @@ void msi_pcache_abandon(MsiPostingCache *, void *token) {
 uint64_t msi_pcache_device_base(const MsiPostingCache *c) { return c ? (uint64_t)(uintptr_t)c->dev : 0; }
 
 void msi_pcache_stats(const MsiPostingCache *c, uint64_t out[4]) {
-  out[0] = c->hits.load();
-  out[1] = c->misses.load();
+  out[0] = out[1] = 0;
+  for (const auto &sh : c->shard) {
+    out[0] += sh.hits.load(std::memory_order_relaxed);
+    out[1] += sh.misses.load(std::memory_order_relaxed);
+  }
   out[2] = c->used.load();
   out[3] = c->cap;
 }

@@ -441,6 +441,13 @@ int main(int argc, char **argv) {
       CK(msi_bits_use_private_stream(p));
     }
 #endif
+    {  // every pool's first searches create what it keeps (its companion pool for compact universes: a hipMalloc each,
+       // serialised by the runtime — hundreds of milliseconds for the last of 128 threads): not what is measured
+      std::vector<std::thread> warm;
+      for (int t = 0; t < n_threads; ++t)
+        warm.emplace_back([&, t] { for (int i = 0; i < 2; ++i) run_query(pools[t], queries[(t * 17 + i) % queries.size()], nullptr); });
+      for (auto &th : warm) th.join();
+    }
     uint64_t vs0[6] = {0, 0, 0, 0, 0, 0}, vs1[6] = {0, 0, 0, 0, 0, 0}, vb0[3] = {0, 0, 0}, vb1[3] = {0, 0, 0};
     unsigned long long cs0[2], cs1[2];
     cpu_stat(cs0);
