@@ -76,7 +76,8 @@ def parse_args():
     ap.add_argument("--shard", choices=["queries", "rows"], default="queries")
     ap.add_argument("--no-typo", action="store_true")
     ap.add_argument("--no-rank", action="store_true", help="c4: leave the keyword leg and the hybrid merge out")
-    ap.add_argument("--kw-threads", type=int, default=128, help="c4: caller threads of the keyword leg (one in-flight search each)")
+    ap.add_argument("--kw-slots", type=int, default=512, help="c4: slots of every caller's docid-set pool (n_docs / 8 bytes each)")
+    ap.add_argument("--kw-threads", type=int, default=160, help="c4: caller threads of the keyword leg (one in-flight search each)")
     ap.add_argument("--kw-terms", type=int, default=3, help="c4: words per keyword query")
     ap.add_argument("--kw-dict-words", type=int, default=200_000, help="c4: vocabulary of the synthetic inverted index")
     ap.add_argument("--kw-cache-mb", type=int, default=8192, help="c4: HBM posting cache of the index version")
@@ -482,11 +483,13 @@ def run_c4(args, env):
         kw_lib.rb_last_latencies.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         n_docs_kw = n_total if row_sharded else n
         h = kw_lib.rb_create(n_docs_kw, args.kw_dict_words)
-        # Caller threads of this rank: a waiting search costs no CPU, but a search in flight needs ~1.3-1.8 ms of host CPU
-        # per query — N ranks share the box's CPUs, so each rank gets its share of callers (8 per granted CPU, at least 16)
+        # Caller threads of this rank: a waiting search costs no CPU, but a search in flight needs ~1.2 ms of host CPU per
+        # query (round 3; 1.7 ms in round 2) — N ranks share the box's CPUs, so each rank gets its share of callers: 10 per
+        # granted CPU (160 on a 16-CPU grant: 12.8 CPUs busy; 192 callers measured 15.5 CPUs and 256 callers ran into the
+        # quota and lost two thirds of the throughput, profiles/r3_callers.txt), at least 16
         host_cpus = granted_cpus()
-        kw_threads = args.kw_threads if world == 1 else max(16, min(args.kw_threads, host_cpus * 8 // world))
-        assert kw_lib.rb_attach(h, ctx.handle, kw_threads, 512, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
+        kw_threads = max(16, min(args.kw_threads, host_cpus * 10 // world))
+        assert kw_lib.rb_attach(h, ctx.handle, kw_threads, args.kw_slots, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
         n_kw_queries = 4 * Q
         kw_lib.rb_prepare_queries(h, n_kw_queries, args.kw_terms, 4242 + rank)
         kw = {"lib": kw_lib, "h": h, "ids": np.zeros((Q, k), np.uint32), "n": np.zeros(Q, np.uint32),
@@ -653,6 +656,8 @@ def run_c4(args, env):
             legs["scan_kernel_alone"] = {"avg_launch_ms": round(alone_ms / alone_n, 4), "launches": alone_n,
                                          "frac_of_8_TBps": round(alone_bytes / (alone_ms / alone_n * 1e-3) / 1e9 / 8000.0, 4)}
         import resource
+        vs0 = (C.c_uint64 * 6)()
+        ma._lib.lib().msi_bits_vm_stats(C.c_void_p(kw["lib"].rb_pool(kw["h"], 0)), vs0)
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         for _ in range(3):
@@ -667,7 +672,7 @@ def run_c4(args, env):
         vs = (C.c_uint64 * 6)()
         ma._lib.lib().msi_bits_vm_stats(C.c_void_p(kw["lib"].rb_pool(kw["h"], 0)), vs)
         legs["keyword_posting_cache"] = {"hits": int(pc[0]), "misses": int(pc[1]), "bytes_used": int(pc[2])}
-        legs["keyword_lists_per_launch_round"] = round(vs[1] / max(1, vs[0]), 2)
+        legs["keyword_lists_per_launch_round"] = round((vs[1] - vs0[1]) / max(1, vs[0] - vs0[0]), 2)   # of this leg only
     # ---- per-QUERY latency (the metric is "queries/sec + p50 latency"; ms_per_step is the latency of a 768-query step) ----
     latency = None
     if kw is not None and not env.child and rank == 0:

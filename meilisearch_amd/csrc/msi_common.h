@@ -74,6 +74,7 @@ void msi_set_error(const char *fmt, ...);
 struct msi_ctx {
   int device = 0;
   int n_cu = 0;
+  int n_cu_scan = 0;   // CUs the main stream may use when it was created with a CU mask (MSI_SCAN_CUS); 0: all
   hipStream_t stream = nullptr;      // vector stores, docid sets, ranking
   std::mutex mu;                     // serialises use of `stream` + per-object scratch
   hipStream_t stream_aux = nullptr;  // dictionaries: the VALU-bound typo lookup overlaps the

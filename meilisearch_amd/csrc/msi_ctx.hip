@@ -111,6 +111,23 @@ int32_t msi_ctx_create(int32_t device, msi_ctx **out) {
     e = hipErrorNotSupported;
     if (knob && knob[0] == '1' && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
       e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest);
+    // MSI_SCAN_CUS=<n>: the scan's stream may only use n of the device's CUs (hipExtStreamCreateWithCUMask) and the scan
+    // sizes its persistent grid for them: the rest stays free for the keyword searches' command lists while a sweep is
+    // in flight (a sweep otherwise holds every CU's LDS for 5 ms and a keyword round waits behind it).
+    if (const char *cus = getenv("MSI_SCAN_CUS")) {
+      const int n = atoi(cus);
+      if (e != hipSuccess && n >= 8 && n < c->n_cu) {
+        // enabled CUs spread evenly over the mask (whatever the bit -> XCD mapping is, every XCD keeps some free CUs)
+        std::vector<uint32_t> mask((size_t)(c->n_cu + 31) / 32, 0);
+        int on = 0;
+        for (int i = 0; i < c->n_cu; ++i)
+          if ((int64_t)(i + 1) * n / c->n_cu > (int64_t)i * n / c->n_cu) { mask[i / 32] |= 1u << (i % 32); ++on; }
+        if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess) {
+          e = hipSuccess;
+          c->n_cu_scan = on;
+        }
+      }
+    }
     if (e != hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking);

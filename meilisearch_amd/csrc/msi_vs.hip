@@ -1517,7 +1517,7 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
     const int v = atoi(e);
     if (v >= 1 && v <= 4) wg_per_cu = (uint32_t)v;
   }
-  vs->scan_grid = (uint32_t)ctx->n_cu * wg_per_cu;
+  vs->scan_grid = (uint32_t)(ctx->n_cu_scan ? ctx->n_cu_scan : ctx->n_cu) * wg_per_cu;
   *out = vs;
   return MSI_OK;
 }

@@ -120,6 +120,7 @@ inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(8); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, unsigned, const unsigned *) { return hipStreamCreate(s); }
 inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = *greatest = 0; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
