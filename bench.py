@@ -177,7 +177,8 @@ def pmc_traffic(args, kernel_prefix, must_contain=()):
     out_dir = tempfile.mkdtemp(prefix="msi_pmc_", dir="/tmp")
     cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
            sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-pmc"]
+           "--no-cpu-baseline", "--no-pmc", "--kw-threads", "16"]   # (the parent still holds its pools: a child of the
+    # same size would not fit beside it; the counter only needs the scan kernel's dispatches)
     for flag, val in (("--rows", args.rows), ("--dim", args.dim), ("--k", args.k), ("--queries", args.queries),
                       ("--storage", args.storage)):
         if val is not None:
