@@ -26,8 +26,8 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"   # plain C++ mode: ext_vector_type and
 def build():
     # msi_group.hip (RCCL over several devices) has nothing the one-device emulation could execute
     sources = sorted(s for s in glob.glob(os.path.join(CSRC, "*.hip")) if not s.endswith("msi_group.hip"))
-    deps = sources + [os.path.join(CSRC, "msi_common.h"), os.path.join(ROOT, "include", "msi.h"),
-                      os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h")]
+    deps = sources + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "msi.h"),
+                                                                     os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h")]
     if os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps):
         return SO
     os.makedirs(BUILD, exist_ok=True)

@@ -545,9 +545,55 @@ def run_update(args):
                       "regather_GBps": round(2 * store_bytes / ms / 1e6, 1), "rows_after": len(st)}), flush=True)
 
 
+def run_group(args):
+    """One process driving every visible GPU (msi_group_create: ncclCommInitAll, one context and one host thread per
+    device inside msi_vs_group_search) — the form a single meilisearch process would use.  Both modes at C2's shape:
+    REPLICATE (every GPU holds the store, the query batch is split) and SHARD_ROWS (every GPU holds a row range, one packed
+    all-gather of the per-shard top-k + device merge).  Host entry point: queries and results cross PCIe.  A parity
+    check against the oracle on 8 queries precedes the timing.  On a one-GPU box this is a world of one."""
+    import ctypes as C
+    import torch
+    import meilisearch_amd as ma
+    from meilisearch_amd import _lib, synth
+    from oracle import oracle as O
+    L = _lib.lib()
+    n_dev = args.devices or torch.cuda.device_count()
+    n, d, k = args.rows, args.dim, args.k
+    rows = synth.make_embeddings(n, d, seed=1234)
+    ids = np.arange(n, dtype=np.uint32)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    devs = (C.c_int32 * n_dev)(*range(n_dev))
+    g = C.c_void_p()
+    _lib.check(L.msi_group_create(devs, n_dev, C.byref(g)))
+    for mode, name in ((0, "replicate"), (1, "shard_rows")):
+        vs = C.c_void_p()
+        _lib.check(L.msi_vs_group_create(g, d, 0, mode, C.byref(vs)))
+        _lib.check(L.msi_vs_group_upload(vs, ptr(ids), ptr(rows), n))
+        q = synth.make_embeddings(max(args.batches), d, seed=5678)
+        out_d = np.zeros((max(args.batches), k), np.uint32)
+        out_s = np.zeros((max(args.batches), k), np.float32)
+        cnt = np.zeros(max(args.batches), np.uint32)
+        _lib.check(L.msi_vs_group_search(vs, ptr(q), 8, k, ptr(out_d), ptr(out_s), ptr(cnt)))
+        bad = 0
+        for j in range(8):
+            e_ids, e_dist = O.vs_topk(rows, ids, q[j], k)
+            bad += int(out_d[j].tolist() != e_ids.tolist() or out_s[j].view(np.uint32).tolist() != e_dist.view(np.uint32).tolist())
+        for B in args.batches:
+            ms, p50 = timed(lambda: _lib.check(L.msi_vs_group_search(vs, ptr(q), B, k, ptr(out_d), ptr(out_s), ptr(cnt))),
+                            lambda: None, args.reps)
+            print(json.dumps({"config": "group", "mode": name, "devices": n_dev, "rows": n, "dim": d, "k": k, "batch": B,
+                              "ms_per_batch": round(ms, 4), "p50_ms": round(p50, 4), "qps": round(B / ms * 1e3, 1),
+                              "includes": "H2D of the queries, the searches on every device, the exchange, D2H of the results",
+                              "parity": {"checked_queries": 8, "mismatches": bad,
+                                         "checker": "oracle/msi_oracle.c orc_vs_topk: docids in order, f32 distances bit-identical"}}),
+                  flush=True)
+        L.msi_vs_group_destroy(vs)
+    L.msi_group_destroy(g)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered", "c5", "ranked", "rules", "update", "bq"])
+    ap.add_argument("config", choices=["c2", "c3", "rank", "filtered", "c5", "ranked", "rules", "update", "bq", "group"])
     ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--storage", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--rows", type=int, default=1_000_000)
@@ -559,11 +605,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--slots", type=int, default=1024)
+    ap.add_argument("--devices", type=int, default=0, help="group: GPUs to drive from this process (default: all visible)")
     args = ap.parse_args()
     if args.batches is None:
         args.batches = [1, 16, 48, 240] if args.config != "c3" else [1, 64, 1024, 8192]
     {"c2": run_c2, "c3": run_c3, "rank": run_rank, "filtered": run_filtered, "c5": run_c5, "ranked": run_ranked,
-     "rules": run_rules, "update": run_update, "bq": run_bq}[args.config](args)
+     "rules": run_rules, "update": run_update, "bq": run_bq, "group": run_group}[args.config](args)
 
 
 if __name__ == "__main__":
