@@ -1306,11 +1306,11 @@ void VmCombiner::run() {
     s->t_done = now_ns();
     if (trace && s->list) {   // diagnostics: what a list was made of and how long the device took for it
       const std::vector<uint32_t> &w = s->list->words;
-      uint32_t ops[16] = {0}, max_paths = 0, max_steps = 0, clear_slots = 0;
+      uint32_t ops[32] = {0}, max_paths = 0, max_steps = 0, clear_slots = 0;
       const size_t w_end = s->list->data_off ? s->list->data_off : w.size();
       for (size_t i = 0; i < w_end;) {
         const uint32_t op = w[i];
-        if (op < 16) ++ops[op];
+        if (op < 32) ++ops[op];
         switch (op) {
           case VM_END: i += 1; break;
           case VM_FILL: i += 3; break;
@@ -1327,9 +1327,14 @@ void VmCombiner::run() {
           case VM_MINKEY: i += 5; break;
           case VM_TAKEKEY: i += 8; break;
           case VM_SUMMARY_RESET: i += 1; break;
+          case VM_RANK_A: i += 4; break;
+          case VM_RANK_B: i += 5; break;
+          case VM_DECODEC: i += 3; break;
           default: i = w_end; break;
         }
       }
+      fprintf(trace, "%s%u phases counts %u rankA %u rankB %u decodeC %u | ", s->list->geom_docs ? "compact " : "full ", (unsigned)s->list->phase_start.size(),
+              s->list->n_counts, ops[VM_RANK_A], ops[VM_RANK_B], ops[VM_DECODEC]);
       fprintf(trace, "%.1f us words %zu stage %zu fill %u op %u opc %u clear %u(%u slots) claim %u andmany %u paths %u(max %u paths %u steps) sub %u count %u decode %u firstk %u\n",
               (s->t_done - s->t_launch) / 1e3, w_end, s->list->stage_used, ops[VM_FILL], ops[VM_OP], ops[VM_OP_COUNT], ops[VM_CLEAR],
               clear_slots, ops[VM_CLAIM], ops[VM_AND_MANY], ops[VM_PATHS], max_paths, max_steps, ops[VM_SUB_MANY], ops[VM_COUNT],
