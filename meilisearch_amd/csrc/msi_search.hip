@@ -2826,19 +2826,34 @@ struct OrderByRule : Rule {
   Graph g;
   OrderByRule(uint32_t i, const msi_doc_keys *k) : Rule(R_ORDER_BY, -1), idx(i), keys(k) {}
   Rule *fresh() const override { return new OrderByRule(idx, keys); }
-  void start(Ctx &, const Set &, const Graph &graph) override { g = graph; }
+  // With `distinct` the reference's rule keeps handing out the values its iteration STARTED with: the facet iterator was
+  // built over the starting universe, and a value whose documents `distinct` removed meanwhile comes out as an empty
+  // bucket (`bucket.candidates &= universe`, sort.rs:214-217) — one more turn of bucket_sort's loop, visible through the
+  // deadline's check count.  `left` is that iterator: the starting universe, losing a value's documents per call.
+  Set left;
+  void start(Ctx &c, const Set &universe, const Graph &graph) override {
+    g = graph;
+    left.reset();
+    if (c.prm->distinct_values) left = c.dev.clone(universe);
+  }
   bool next(Ctx &c, const Set &universe, uint64_t universe_count, Bucket &out) override {
     if (!universe_count) return false;
     uint32_t key = 0;
     uint64_t n = 0;
-    out.docs = c.dev.order_next(keys, universe, &key, &n);
+    out.same_as = &g;
+    if (left) {
+      Set of_value = c.dev.order_next(keys, left, &key, &n);     // the next value of the starting universe ...
+      out.docs = c.dev.and_new(of_value, universe, &n);           // ... and what is left of its documents
+      out.universe_reduced = false;
+    } else {
+      out.docs = c.dev.order_next(keys, universe, &key, &n);
+      out.universe_reduced = true;
+    }
     out.count = n;
     out.score = {MSI_SCORE_SORT, idx, key};
-    out.same_as = &g;
-    out.universe_reduced = true;
     return true;
   }
-  void end() override {}
+  void end() override { left.reset(); }
 };
 
 // geo_sort.rs:14-160 over the _geo points in HBM (include/msi.h, msi_geo_points): every bucket is the set of documents

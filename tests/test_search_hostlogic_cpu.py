@@ -427,6 +427,42 @@ def test_distinct_matches_the_oracle(hostlib, monkeypatch, per_wait, fields=("co
     h.close()
 
 
+def test_sort_under_distinct_hands_out_the_values_distinct_emptied(hostlib):
+    """sort.rs:214-217 (`bucket.candidates &= universe`): the Sort rule's facet iterator was built over the universe the
+    rule STARTED with, so a value whose documents `distinct` removed meanwhile still comes out — as an empty bucket, one
+    more turn of bucket_sort's loop.  Only the number of deadline checks shows it: searches cut off after 0..6 loop
+    iterations (`stop_after`, the reference's own cutoff tests' device) must stop at the same bucket as the oracle —
+    same hits, same `Skipped` details, same degraded flag.  (Until round 3 the product's rule skipped those values.)"""
+    from oracle import ranking_oracle as RO
+    import tests.test_search_gpu as G
+    index = ToyMilli(sortable_corpus(9, 220), searchable=["title", "body"])
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    h = make_harness(hostlib, index)
+    n = degraded = 0
+    for field in ("color", "sizes", "price"):
+        for criteria, sort in ((["sort", "words", "typo"], [("price", "asc")]), (["words", "sort", "proximity"], [("color", "desc")]),
+                               (["sort"], [("sizes", "asc"), ("price", "desc")]), (["desc:price", "words"], None)):
+            for q in ["", "the", "quick fox", "brwn fox jumps"]:
+                for stop_after in (0, 1, 2, 3, 4, 6):
+                    want = RO.search(RO.Ctx(index, lookup), q, tms="last", criteria=criteria, offset=0, length=12, detailed=True,
+                                     sort=sort, distinct=field, stop_after=stop_after)
+                    hits, cand, deg = h.search(q, criteria=criteria, offset=0, limit=12, detailed=True, sort=sort, distinct=field,
+                                               stop_after=stop_after, return_degraded=True)
+                    assert [d for d, _ in hits] == want[0], (field, criteria, sort, q, stop_after)
+                    assert [[geo_score(s) for s in sc] for _, sc in hits] == \
+                        [[geo_score(G.oracle_score(s)) if s[0] != "Skipped" else ("Skipped", 0, 1) for s in sc] for sc in want[1]], \
+                        (field, criteria, q, stop_after)
+                    assert cand == len(want[2])
+                    degraded += int(bool(deg))
+                    n += 1
+    assert n == 288 and degraded >= 100
+    h.close()
+
+
 GEO = json.load(open(os.path.join(ROOT, "tests", "golden", "geo_snapshots.json")))
 
 

@@ -132,11 +132,8 @@ while time.time() < t_end:
         mth = rng.choice([None, 1000, 1000, 7]) if exh else None
         if q.strip() == "" and negs:
             negs = []
-        if sa is not None and distinct and (sort or any(c.startswith(("asc:", "desc:")) for c in criteria)):
-            # the reference's Sort rule hands out EMPTY buckets for values whose documents `distinct` removed since the
-            # rule started (sort.rs:214-217: `bucket.candidates &= universe`); the product's next bucket is the next key
-            # that still has a document.  Only the NUMBER of deadline checks differs — visible through `stop_after` alone.
-            sa = None
+        if os.environ.get("FUZZ_KEEP_OLD_SORT_DISTINCT_FENCE") and sa is not None and distinct and (sort or any(c.startswith(("asc:", "desc:")) for c in criteria)):
+            sa = None   # (until round 3 the product's Sort rule skipped the values `distinct` had emptied: sort.rs:214-217)
         try:
             RO.GEO_PARAMS.clear()
             geo_strategy = rng.choice([("dynamic", 1000), ("dynamic", 1000), ("rtree", 1000), ("iterative", 1000)]) if geo or sort else ("dynamic", 1000)
