@@ -2476,9 +2476,14 @@ struct GraphRule : Rule {
   // that does not fit the in-argument kernel: the caller runs the one-level path).
   void look_ahead(Vec<uint64_t>::const_iterator it, Vec<uint64_t>::const_iterator end) {
     // with command lists a level evaluated ahead is one more command in a list that is submitted anyway, so the
-    // look-ahead is on by default there (waits per 3-term query 76 -> 41); the direct back end pays a launch per level
+    // look-ahead is on by default there (waits per 3-term query 76 -> 41); the direct back end pays a launch per level.
+    // 8 levels per wait since round 3 (4 before): the Position and Fid rules have 20+ cost levels with a few documents
+    // each — waits per detailed 3-term query at 10 M documents 17.0 -> 15.1 (12: 14.7, 16: 14.6), the same conditions
+    // resolved, 1.3 % more set-operand bytes
     const char *knob = getenv("MSI_SEARCH_LEVELS_PER_WAIT");
-    const int per_wait = std::min<int>(knob ? atoi(knob) : (cx->dev.vm ? 4 : 1), (int)MSI_BITS_PATH_REGIONS);
+    // (the direct back end publishes each level's counts into one of MSI_BITS_PATH_REGIONS regions; a command list has
+    // MSI_VM_MAX_COUNTS counts and takes as many levels as fit)
+    const int per_wait = std::min<int>(knob ? atoi(knob) : (cx->dev.vm ? 8 : 1), cx->dev.vm ? 16 : (int)MSI_BITS_PATH_REGIONS);
     const char *fused = getenv("MSI_SEARCH_FUSED_LEVELS");
     if (per_wait < 2 || (fused && fused[0] == '0')) return;
     // `distinct` removes documents from every universe of the stack whenever a bucket reaches the results
@@ -3260,6 +3265,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     if (tree) {
       const uint64_t page_end = (uint64_t)from + length;
       bool ids_short = false, degraded = false;
+      const bool tree_trace = getenv("MSI_SEARCH_TREE_TRACE") != nullptr;
       // A rule may end before its buckets covered its universe (the reference drops what is left, bucket_sort.rs `back!`,
       // and the documents after it move up): then the places handed out below — cumulative cardinalities — are wrong.
       // Rare (three of 230 000 random searches); the tree notices and the search is done again by the sequential loop.
@@ -3312,6 +3318,10 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             break;
           }
           ++g_stats.buckets;
+          if (tree_trace)   // MSI_SEARCH_TREE_TRACE: one line per bucket — after which completion wait it became known
+            fprintf(stderr, "[msi tree] wait %llu rule %zu (kind %d) bucket of %llu at place %llu, %llu left, score (%u,%u,%u)\n",
+                    (unsigned long long)g_stats.syncs, cur, rule->kind, (unsigned long long)b.count, (unsigned long long)off,
+                    (unsigned long long)(left - b.count), b.score.kind, b.score.a, b.score.b);
           if (!b.universe_reduced) c.dev.sub_(uni, b.docs);
           left -= b.count;
           Vec<Score> sc = scores;

@@ -1,8 +1,8 @@
-"""MSI_SEARCH_LEVELS_PER_WAIT (default 1 = off): several cost levels of a graph-based ranking rule are enqueued back
-to back (msi_bits_paths_enqueue, one counts region per level) and collected behind ONE completion wait
-(msi_bits_paths_collect).  Same answers required: the reference snapshots, random corpora and deadlines replay with
-2 and 4 levels per wait.  The CPU tier (tests/test_search_hostlogic_cpu.py) holds the host side of this against
-the oracle; this file holds the device side.  Runs last on purpose (experimental knob, off by default)."""
+"""MSI_SEARCH_LEVELS_PER_WAIT (command lists: 8 by default, at most 16; direct back end: off by default, at most 4):
+several cost levels of a graph-based ranking rule are enqueued back to back and collected behind ONE completion wait.
+Same answers required: the reference snapshots, random corpora and deadlines replay with 1, 2, 4, 12 and 16 levels per
+wait (every other device test runs with the default).  The CPU tier (tests/test_search_hostlogic_cpu.py) holds the host side of this against
+the oracle; this file holds the device side."""
 import pytest
 
 import tests.test_search_gpu as G
@@ -10,15 +10,16 @@ import tests.test_search_gpu as G
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("per_wait", ["2", "4"])
+@pytest.mark.parametrize("per_wait", ["1", "2", "4", "12", "16"])
 def test_reference_snapshots_with_levels_per_wait(monkeypatch, per_wait):
     monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
     for case in G.CASES:
         G.test_reference_snapshot(case)
 
 
-def test_random_corpora_with_levels_per_wait(monkeypatch):
-    monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", "4")
+@pytest.mark.parametrize("per_wait", ["4", "16"])
+def test_random_corpora_with_levels_per_wait(monkeypatch, per_wait):
+    monkeypatch.setenv("MSI_SEARCH_LEVELS_PER_WAIT", per_wait)
     G.test_matches_oracle_on_random_corpora(2, 100)
     G.test_matches_oracle_on_random_corpora(3, 3)
     G.test_ranking_score_threshold()
