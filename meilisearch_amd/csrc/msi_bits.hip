@@ -117,6 +117,7 @@ bool msi_bits_take_summary_dirty(msi_bits *p) {
   p->sum_dirty = false;
   return d;
 }
+void msi_bits_mark_summary_dirty(msi_bits *p) { p->sum_dirty = true; }   // (a list that had taken the flag was dropped)
 uint64_t msi_bits_words_per_slot(msi_bits *p) { return p->n_words; }
 uint32_t msi_bits_n_slots(msi_bits *p) { return p->n_slots; }
 uint64_t msi_bits_n_docs(msi_bits *p) { return p->n_docs; }

@@ -46,6 +46,7 @@
 #include "msi_vm.h"
 int32_t msi_bits_sync(msi_bits *p);
 bool msi_bits_take_summary_dirty(msi_bits *p);
+void msi_bits_mark_summary_dirty(msi_bits *p);
 const uint32_t *msi_doc_keys_device(const msi_doc_keys *k);
 MsiPostingCache *msi_dict_pcache(const msi_dict *d);
 void msi_cbo_batch_append_known(MsiCboBatch &batch, const MsiContainer *conts, uint32_t n, uint64_t cache_off);
@@ -249,8 +250,14 @@ struct Dev {
   MsiVmResult res;
   MsiPostingCache *pcache = nullptr;   // HBM posting cache of the index version (msi_dict_enable_posting_cache), or none
   Vec<void *> fills;           // cache entries the RECORDED decodes fill: ready once the list has run
-  ~Dev() {                             // a search that ended with a recorded list it never ran (an error unwound it)
+  ~Dev() { drop_list(); }              // a search that ended with a recorded list it never ran (an error unwound it)
+  // What is recorded will not run: the cache entries it was to fill go back, and if it had taken the pool's "summaries
+  // are stale" flag (open_list) the flag returns — the next search's first list resets them.
+  void drop_list() {
     for (void *t : fills) msi_pcache_abandon(pcache, t);
+    fills.clear();
+    if (!list.empty() && !list.words.empty() && list.words[0] == VM_SUMMARY_RESET) msi_bits_mark_summary_dirty(cur->p);
+    list.clear();
   }
   struct PendingFk {
     Set set;   // keeps the slot from being reused before the list has run
@@ -335,6 +342,9 @@ struct Dev {
     ck(st);
     for (PendingFk &f : fk) {   // a set smaller than k filled less of its block
       const size_t n = (size_t)std::min<uint64_t>(res.counts[f.ci], f.k);
+      if (getenv("MSI_SEARCH_FK_TRACE"))
+        fprintf(stderr, "[msi fk] deliver slot %u k %u -> %zu ids (count %llu, base %u of %zu)\n", f.set->slot, f.k, n,
+                (unsigned long long)res.counts[f.ci], f.base, res.firstk.size());
       f.sink(res.firstk.data() + f.base, n);
     }
   }
@@ -351,9 +361,23 @@ struct Dev {
   void flush() {   // what is recorded runs now (deferred first-k ids are delivered)
     if (vm) run();
   }
+  // The end of a search: the recorded list only has to run when somebody still waits for ids out of it — what else it
+  // holds (the subtraction of the last bucket from a universe nobody will read, zeroing, decodes for rules that will not
+  // start) dies with the search, and a round that nobody waits for is a round the next search does not queue behind.
+  void finish_list() {
+    if (!vm) return;
+    if (!pending_fk.empty()) {
+      run();
+      return;
+    }
+    drop_list();
+    keep_until_run.clear();
+    cur->release_held();
+  }
 #else
   void settle() {}
   void flush() {}
+  void finish_list() {}
 #endif
 #ifndef MSI_SEARCH_DIRECT_ONLY
   // ---- universe compaction ------------------------------------------------------------------------------------------
@@ -577,11 +601,18 @@ struct Dev {
   }
 #endif
   // a whole cost level: path k claims universe & AND(its condition sets), in order; returns the cardinalities
-  Vec<uint64_t> paths_claim(const PathSlots &paths, const Set &bucket, const Set &universe) {
+  // `ids_k` / `ids`: also the bucket's first ids_k documents, in the same list (Ctx::spec_k); *ids stays null when the
+  // list has no room for the command
+  Vec<uint64_t> paths_claim(const PathSlots &paths, const Set &bucket, const Set &universe, uint32_t ids_k = 0,
+                            std::shared_ptr<Vec<uint32_t>> *ids = nullptr) {
     Vec<uint64_t> counts(paths.size(), 0);
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       const uint32_t cb = rec_paths(paths, bucket, universe);
+      if (ids_k && ids) {
+        auto box = msi_arena::make_shared<Vec<uint32_t>>();
+        if (first_k_if_room(bucket, ids_k, [box](const uint32_t *d, size_t n) { box->assign(d, d + n); })) *ids = box;
+      }
       run();
       for (size_t k = 0; k < paths.size(); ++k) counts[k] = res.counts[cb + k];
       return counts;
@@ -735,15 +766,16 @@ struct Dev {
     return s;
   }
   // the same level WITHOUT the completion wait: its counts land in `region`; false = does not fit, nothing enqueued
-  // `pending_levels`: (count base, paths) of the levels recorded ahead — the CALLER's (a rule evaluation's) state: the
+  // `pending_levels`: (count base, paths, region) of the levels recorded ahead — the CALLER's (a rule evaluation's) state: the
   // bucket sort's tasks interleave between an enqueue and its collect
-  using PendingLevels = Vec<std::pair<uint32_t, uint32_t>>;
+  struct PendingLevel { uint32_t base, n, region; };
+  using PendingLevels = Vec<PendingLevel>;
   bool paths_enqueue(const PathSlots &paths, const Set &bucket, const Set &universe, uint32_t region,
                      PendingLevels &pending_levels) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       if (paths.size() > MSI_BITS_REGION_PATHS || list.n_counts + paths.size() > MSI_VM_MAX_COUNTS) return false;
-      pending_levels.push_back({rec_paths(paths, bucket, universe), (uint32_t)paths.size()});
+      pending_levels.push_back(PendingLevel{rec_paths(paths, bucket, universe), (uint32_t)paths.size(), region});
       return true;
     }
 #endif
@@ -759,10 +791,10 @@ struct Dev {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (vm) {
       run();
-      // levels without a path were not recorded: the caller's regions are consecutive recorded levels
-      for (size_t j = 0; j < pending_levels.size() && j < n_regions; ++j)
-        for (uint32_t k = 0; k < pending_levels[j].second; ++k)
-          counts[j * MSI_BITS_REGION_PATHS + k] = res.counts[pending_levels[j].first + k];
+      // (levels without a path were not recorded: a level's counts go to the region its caller named)
+      for (const PendingLevel &pl : pending_levels)
+        if (pl.region < n_regions)
+          for (uint32_t k = 0; k < pl.n; ++k) counts[(size_t)pl.region * MSI_BITS_REGION_PATHS + k] = res.counts[pl.base + k];
       pending_levels.clear();
       return counts;
     }
@@ -865,10 +897,18 @@ struct Dev {
         sink(nullptr, 0);
         return;
       }
-      while (list.fk_in_phase >= MSI_VM_MAX_FK_PHASE || list.firstk_total + k > MSI_VM_MAX_FIRSTK) run();
-      const uint32_t ci = counts_for(1);
+      // (ONE loop over every limit: run() parks a task, and the list it comes back to has been written by the others —
+      // checking the first-k limits and then waiting for a free count let a 17th first-k into a phase of 16, whose ids
+      // came back as zeros: fuzz seed 12003397 with 16 levels per wait)
+      while (list.fk_in_phase >= MSI_VM_MAX_FK_PHASE || list.firstk_total + k > MSI_VM_MAX_FIRSTK ||
+             list.n_counts + 1 > MSI_VM_MAX_COUNTS)
+        run();
+      const uint32_t ci = list.new_counts(1);
       rd(a->slot);
       rec({VM_FIRSTK, a->slot, k, ci, list.firstk_total});
+      if (getenv("MSI_SEARCH_FK_TRACE"))
+        fprintf(stderr, "[msi fk] record slot %u k %u base %u (in phase %u, list counts %u)\n", a->slot, k, list.firstk_total,
+                list.fk_in_phase, list.n_counts);
       pending_fk.push_back(PendingFk{a, k, ci, list.firstk_total, std::move(sink)});
       list.firstk_total += k;
       ++list.fk_in_phase;
@@ -878,6 +918,20 @@ struct Dev {
 #endif
     const Vec<uint32_t> ids = first_k(a, k);
     sink(ids.data(), ids.size());
+  }
+  // The same, but only when the open list takes the command as it stands (never runs a list: for callers that sit
+  // between an enqueue and its collect).  false: nothing recorded.
+  bool first_k_if_room(const Set &a, uint32_t k, std::function<void(const uint32_t *, size_t)> sink) {
+#ifndef MSI_SEARCH_DIRECT_ONLY
+    if (!vm || !k || k > MSI_VM_MAX_FIRSTK || list.empty() || list.fk_in_phase >= MSI_VM_MAX_FK_PHASE ||
+        list.firstk_total + k > MSI_VM_MAX_FIRSTK || list.n_counts + 1 > MSI_VM_MAX_COUNTS || cur->lazy_zero[a->slot])
+      return false;
+    first_k_later(a, k, std::move(sink));
+    return true;
+#else
+    (void)a; (void)k; (void)sink;
+    return false;
+#endif
   }
   Vec<uint32_t> first_k(const Set &a, uint32_t k) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
@@ -1140,6 +1194,10 @@ struct Ctx {
   const msi_index_vtable *ix;
   const msi_search_params *prm;
   Dev dev;
+  // from + length when the page is small: the LAST rule's evaluations ask for the first ids of the first bucket they
+  // plan in the list that computes it (GraphRule::look_ahead) — a leaf bucket's ids then arrive with its cardinality, and
+  // the search ends without the one more round that only fetched ids.  0: off.
+  uint32_t spec_k = 0;
   Vec<std::string> words;
   std::unordered_map<std::string, uint32_t, std::hash<std::string>, std::equal_to<std::string>,
                      msi_arena::Alloc<std::pair<const std::string, uint32_t>>> word_ids;   // (lookups only; the ids are the order of `words`)
@@ -2210,11 +2268,13 @@ struct Bucket {
   uint64_t count = 0;
   Score score{0, 0, 0};
   bool universe_reduced = false;  // the rule already removed `docs` from the universe it was given
+  std::shared_ptr<Vec<uint32_t>> ids;   // the first min(count, Ctx::spec_k) documents, when the rule asked for them ahead
 };
 
 struct Rule {
   int kind;
   int tms;  // -1 none, MSI_TERMS_LAST, MSI_TERMS_ALL, MSI_TERMS_FREQUENCY
+  bool leaf = false;   // the last rule of the list (set by the bucket sort's tree): its buckets go straight to the results
   Rule(int k, int t) : kind(k), tms(t) {}
   virtual ~Rule() {}
   virtual void start(Ctx &c, const Set &universe, const Graph &g) = 0;
@@ -2267,8 +2327,10 @@ struct GraphRule : Rule {
     Set bucket;
     uint64_t count;
     Vec<Vec<int32_t>> good;
+    std::shared_ptr<Vec<uint32_t>> ids;
   };
   std::deque<Ready> ready;
+  std::shared_ptr<Vec<uint32_t>> level_ids;   // fused_level: the ids asked for with the level (leaf rule)
 
   GraphRule(int k, int t) : Rule(k, t) {}
   Rule *fresh() const override { return new GraphRule(kind, tms); }
@@ -2392,10 +2454,13 @@ struct GraphRule : Rule {
       bucket = r.bucket;
       bucket_count = r.count;
       good = std::move(r.good);
+      out.ids = std::move(r.ids);
       if (bucket_count) c.dev.sub_(uni, bucket);
     } else {
       IdSet visited, to_skip;
+      level_ids.reset();
       if (!fused_level(cost)) visit(Graph::ROOT, cost, visited, to_skip);
+      out.ids = std::move(level_ids);
     }
     out.maker = this;
     out.good = std::move(good);
@@ -2517,12 +2582,26 @@ struct GraphRule : Rule {
       if (!cx->dev.paths_enqueue(plan[n_enq].sets, buckets.back(), ahead, (uint32_t)n_enq, pending_levels)) break;
     }
     if (n_enq == 0) return;
+    // the last rule: the ids of the first level that has paths ride in this list (Ctx::spec_k)
+    std::shared_ptr<Vec<uint32_t>> ahead_ids;
+    size_t ahead_level = n_enq;
+    if (leaf && cx->spec_k) {
+      for (size_t j = 0; j < n_enq && ahead_level == n_enq; ++j)
+        if (!plan[j].all.empty()) ahead_level = j;
+      if (ahead_level < n_enq) {
+        auto box = msi_arena::make_shared<Vec<uint32_t>>();
+        if (cx->dev.first_k_if_room(buckets[ahead_level], cx->spec_k,
+                                    [box](const uint32_t *ids, size_t n) { box->assign(ids, ids + n); }))
+          ahead_ids = box;
+      }
+    }
     const Vec<uint64_t> counts = cx->dev.paths_collect((uint32_t)n_enq, pending_levels);
     for (size_t j = 0; j < n_enq; ++j) {
       Ready r;
       r.cost = plan[j].cost;
       r.bucket = buckets[j];
       r.count = 0;
+      if (j == ahead_level) r.ids = ahead_ids;
       for (size_t k = 0; k < plan[j].all.size(); ++k) {
         const uint64_t n = counts[j * MSI_BITS_REGION_PATHS + k];
         if (!n) continue;
@@ -2550,7 +2629,8 @@ struct GraphRule : Rule {
     if (all.empty()) return true;
     PathSlots sets;
     slots_of(all, sets);
-    const Vec<uint64_t> counts = cx->dev.paths_claim(sets, bucket, uni);
+    level_ids.reset();
+    const Vec<uint64_t> counts = cx->dev.paths_claim(sets, bucket, uni, leaf ? cx->spec_k : 0, &level_ids);
     for (size_t k = 0; k < all.size(); ++k) {
       if (!counts[k]) continue;
       good.push_back(all.path(k));
@@ -3264,6 +3344,10 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
                       !getenv("MSI_SEARCH_TRACE");
     if (tree) {
       const uint64_t page_end = (uint64_t)from + length;
+      {
+        const char *knob = getenv("MSI_SEARCH_IDS_AHEAD");   // 0: off (tests hold both against the oracle)
+        c.spec_k = (page_end <= 64 && !(knob && knob[0] == '0')) ? (uint32_t)page_end : 0;
+      }
       bool ids_short = false, degraded = false;
       const bool tree_trace = getenv("MSI_SEARCH_TREE_TRACE") != nullptr;
       // A rule may end before its buckets covered its universe (the reference drops what is left, bucket_sort.rs `back!`,
@@ -3271,7 +3355,8 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       // Rare (three of 230 000 random searches); the tree notices and the search is done again by the sequential loop.
       bool dropped = false;
       // documents [off, off + count) of the final order, all with the same score details
-      auto emit = [&](const Set &docs, uint64_t count, uint64_t off, const Vec<Score> &scores) {
+      auto emit = [&](const Set &docs, uint64_t count, uint64_t off, const Vec<Score> &scores,
+                      const std::shared_ptr<Vec<uint32_t>> &known = nullptr) {
         if (!count || off >= page_end || off + count <= from) return;
         const uint64_t skip = off < from ? from - off : 0;
         const uint32_t take = (uint32_t)std::min<uint64_t>(count - skip, page_end - (off + skip));
@@ -3281,6 +3366,13 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
           for (uint32_t sdx = 0; sdx < ns; ++sdx)
             out_scores[(size_t)(at + i) * MSI_MAX_SCORE_DETAILS + sdx] = msi_score_detail{scores[sdx].kind, scores[sdx].a, scores[sdx].b};
           out_n_scores[at + i] = ns;
+        }
+        if (getenv("MSI_SEARCH_FK_TRACE"))
+          fprintf(stderr, "[msi emit] place %llu count %llu -> at %u skip %llu take %u slot %u known %d\n", (unsigned long long)off,
+                  (unsigned long long)count, at, (unsigned long long)skip, take, docs->slot, known ? (int)known->size() : -1);
+        if (known && known->size() >= skip + take) {   // the rule asked for these ids in the list that counted the bucket
+          for (uint32_t i = 0; i < take; ++i) out_docids[at + i] = (*known)[(size_t)skip + i];
+          return;
         }
         c.dev.first_k_later(docs, (uint32_t)(skip + take), [out_docids, at, skip, take, &ids_short](const uint32_t *ids, size_t n) {
           if (n < skip + take) ids_short = true;   // cannot happen: `count` came from the device
@@ -3299,6 +3391,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       rank = [&](size_t cur, Set uni, uint64_t left, uint64_t off, Vec<Score> scores, const Graph &graph) {
         std::unique_ptr<Rule> rule_owner(rules[cur]->fresh());
         Rule *rule = rule_owner.get();
+        rule->leaf = cur == nr - 1;
         rule->start(c, uni, graph);
         for (;;) {
           if (left == 0 || off >= page_end) break;                       // the page is full: the loop of :187 ends
@@ -3319,15 +3412,16 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
           }
           ++g_stats.buckets;
           if (tree_trace)   // MSI_SEARCH_TREE_TRACE: one line per bucket — after which completion wait it became known
-            fprintf(stderr, "[msi tree] wait %llu rule %zu (kind %d) bucket of %llu at place %llu, %llu left, score (%u,%u,%u)\n",
+            fprintf(stderr, "[msi tree] wait %llu rule %zu (kind %d) bucket of %llu at place %llu, %llu left, score (%u,%u,%u)%s\n",
                     (unsigned long long)g_stats.syncs, cur, rule->kind, (unsigned long long)b.count, (unsigned long long)off,
-                    (unsigned long long)(left - b.count), b.score.kind, b.score.a, b.score.b);
+                    (unsigned long long)(left - b.count), b.score.kind, b.score.a, b.score.b,
+                    b.ids ? ", ids came along" : "");
           if (!b.universe_reduced) c.dev.sub_(uni, b.docs);
           left -= b.count;
           Vec<Score> sc = scores;
           sc.push_back(b.score);
           if (cur == nr - 1 || (!detailed && b.count <= 1) || off + b.count < from) {
-            emit(b.docs, b.count, off, sc);                              // :296-330
+            emit(b.docs, b.count, off, sc, b.ids);                       // :296-330
           } else if (off < page_end && b.count) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
             // a task keeps its own working sets alive: only as many tasks as the pool has room for (a rule evaluation
@@ -3391,7 +3485,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       } else
 #endif
         rank(0, root, universe_count, 0, {}, g);
-      c.dev.flush();   // the ids of the last buckets
+      c.dev.finish_list();   // the ids of the last buckets, when any are still to come
       if (!dropped) {
         if (ids_short) fail(MSI_E_INTERNAL, "a bucket held fewer documents than its cardinality said");
         *out_n = (uint32_t)std::min<uint64_t>(length, universe_count - from);

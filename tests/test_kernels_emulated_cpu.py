@@ -57,6 +57,13 @@ GROUPS = {
 _running = {}
 
 
+def _build_once():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import run_emulated
+    run_emulated.build()
+    run_emulated.build_runner()
+
+
 def _start_all():
     """Every group is its own subprocess; they are all started when the first one is asked for (the emulated library is
     built once, before, so that they do not race for it) and run side by side — the tier takes as long as its longest
@@ -64,10 +71,7 @@ def _start_all():
     if _running:
         return
     import tempfile
-    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
-    import run_emulated
-    run_emulated.build()
-    run_emulated.build_runner()
+    _build_once()
     for group, spec in GROUPS.items():
         files, expr = spec[:2]
         env = dict(os.environ, **(spec[3] if len(spec) > 3 else {}))
@@ -97,3 +101,27 @@ def test_gpu_test_bodies_on_emulated_kernels(group):
     m = re.search(r"(\d+) passed", stdout)
     assert m and int(m.group(1)) >= at_least, tail
     assert " failed" not in stdout and " error" not in stdout, tail
+
+
+# Searches the differential fuzzer (tools/fuzz_ranked_hostlogic.py --emulated-kernels) once got wrong, replayed: (first
+# seed argument, the query of that seed, environment).  FUZZ_ONLY runs that one query of the seed's six.
+FUZZ_REGRESSIONS = [
+    # 17 first-k commands in a phase of 16 (Dev::first_k_later checked its limits one after the other across a task park):
+    # the ids of a leaf bucket came back as zeros
+    (12003396, "sun delicious the brown sweet", {"MSI_SEARCH_LEVELS_PER_WAIT": "16"}),
+    (12003396, "sun delicious the brown sweet", {"MSI_SEARCH_LEVELS_PER_WAIT": "16", "MSI_SEARCH_COMPACT": "2"}),
+    # ... and with the default 8 levels per wait (pages of 100 hits: many leaf buckets per round)
+    (13004424, "flower sun delicious sweet", {}),
+    (14000465, "summer dogs interconnection", {"MSI_SEARCH_COMPACT": "2", "FUZZ_SPREAD": "2200"}),
+    (14000984, "sun summer sunflowlr interconnection dessert ", {"MSI_SEARCH_COMPACT": "2", "FUZZ_SPREAD": "2200"}),
+]
+
+
+@pytest.mark.parametrize("case", FUZZ_REGRESSIONS, ids=[f"{c[0] + 1}:{'+'.join(c[2].values()) or 'default'}" for c in FUZZ_REGRESSIONS])
+def test_fuzz_regression_seeds(case):
+    seed0, query, extra = case
+    _build_once()
+    env = dict(os.environ, FUZZ_ONLY=query, **extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ranked_hostlogic.py"), str(seed0), "1", "--emulated-kernels"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "cases 1 bad 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -134,6 +134,8 @@ while time.time() < t_end:
             negs = []
         if os.environ.get("FUZZ_KEEP_OLD_SORT_DISTINCT_FENCE") and sa is not None and distinct and (sort or any(c.startswith(("asc:", "desc:")) for c in criteria)):
             sa = None   # (until round 3 the product's Sort rule skipped the values `distinct` had emptied: sort.rs:214-217)
+        if os.environ.get("FUZZ_ONLY") and os.environ["FUZZ_ONLY"] != q:      # debugging: replay one query of a seed (every draw above still happens)
+            continue
         try:
             RO.GEO_PARAMS.clear()
             geo_strategy = rng.choice([("dynamic", 1000), ("dynamic", 1000), ("rtree", 1000), ("iterative", 1000)]) if geo or sort else ("dynamic", 1000)
