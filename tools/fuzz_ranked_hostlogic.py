@@ -87,10 +87,10 @@ while time.time() < t_end:
     if SPREAD:
         wide = copy.copy(index)
         wide.n_docs = index.n_docs * SPREAD
-        h = H.make_harness(L, wide, n_slots=1024)
+        h = H.make_harness(L, wide, n_slots=int(os.environ.get("FUZZ_SLOTS", "1024")))
         spread_kw = {"universe_cbo": _plain_cbo({d * SPREAD for d in range(index.n_docs)})}
     else:
-        h = H.make_harness(L, index, n_slots=1024)
+        h = H.make_harness(L, index, n_slots=int(os.environ.get("FUZZ_SLOTS", "1024")))
         spread_kw = {}
     for _ in range(6):
         nt = rng.randint(1,5)
