@@ -816,6 +816,15 @@ typedef struct msi_search_params {
    * documents closer than a metre to each other; geo_cache_size 0 = 1000. */
   int32_t geo_strategy;
   uint32_t geo_cache_size;
+  /* Which VIEW of the index the callbacks answer for; 0 = the index as it is.  A request with attributesToSearchOn reads
+   * the same databases through other functions (search/new/mod.rs:140-222, db_cache.rs:208-345,540-575: word_docids becomes
+   * the union of word_fid_docids over the restricted tolerant fields, exact_word_docids the union over the restricted exact
+   * fields, the prefix databases likewise, word_fid_docids of a field outside the restriction is absent): the shim's
+   * callbacks answer that way and name the view here — any value that identifies the restriction, e.g. a hash of the
+   * field list.  The engine keys everything it remembers about stored values (the HBM posting cache of the index version,
+   * what it knows about absent keys) by (view, key), so searches under different restrictions never read each other's
+   * postings. */
+  uint64_t index_view;
 } msi_search_params;
 enum { MSI_GEO_DYNAMIC = 0, MSI_GEO_ALWAYS_ITERATIVE = 1, MSI_GEO_ALWAYS_RTREE = 2 };
 /* out_scores: [length][MSI_MAX_SCORE_DETAILS], out_n_scores: [length].  The pool needs at least 64 free

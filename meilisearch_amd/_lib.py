@@ -104,7 +104,7 @@ class SearchParams(C.Structure):
                 ("order_keys", C.c_void_p), ("n_order_keys", C.c_uint32), ("distinct_values", C.c_void_p), ("geo_rules", C.c_void_p), ("n_geo_rules", C.c_uint32),
                 ("geo_max_bucket_size", C.c_uint32), ("geo_distance_error_margin", C.c_double),
                 ("exhaustive_number_hits", C.c_int32), ("max_total_hits", C.c_uint32),
-                ("geo_strategy", C.c_int32), ("geo_cache_size", C.c_uint32)]
+                ("geo_strategy", C.c_int32), ("geo_cache_size", C.c_uint32), ("index_view", C.c_uint64)]
 
 
 class GeoRule(C.Structure):

@@ -1285,11 +1285,11 @@ struct Ctx {
     }
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (dev.pcache && (!n || !bytes || n <= 7 * sizeof(uint32_t)))   // "no such key" and raw small values: remembered on the host
-      msi_pcache_learn(dev.pcache, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y), bytes, bytes ? n : 0);
+      msi_pcache_learn(dev.pcache, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y, prm->index_view), bytes, bytes ? n : 0);
 #endif
     if (!n || !bytes) return;
 #ifndef MSI_SEARCH_DIRECT_ONLY
-    const bool ok = dev.pcache ? dev.append_posting(b, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y), bytes, n)
+    const bool ok = dev.pcache ? dev.append_posting(b, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y, prm->index_view), bytes, n)
                                : msi_cbo_batch_append(b, bytes, n);
 #else
     (void)db; (void)s1; (void)s2; (void)x; (void)y;
@@ -1309,7 +1309,7 @@ struct Ctx {
     static const bool off = getenv("MSI_PCACHE_KNOWN") && getenv("MSI_PCACHE_KNOWN")[0] == '0';   // experiments
     if (!dev.vm || !dev.pcache || off) return false;
     MsiKnownPosting kp;
-    if (!msi_pcache_known(dev.pcache, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y), &kp)) return false;
+    if (!msi_pcache_known(dev.pcache, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y, prm->index_view), &kp)) return false;
     if (card) *card = kp.card;
     if (present) *present = kp.kind != 1;
     if (b) {
@@ -1364,7 +1364,7 @@ struct Ctx {
     if (st < 0) fail(MSI_E_INTERNAL, "word_pair_proximity_docids callback failed");
     if (!n || !bytes) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
-      if (dev.pcache) msi_pcache_learn(dev.pcache, msi_cache_key(2, l.data(), l.size(), r.data(), r.size(), prox, 0), nullptr, 0);
+      if (dev.pcache) msi_pcache_learn(dev.pcache, msi_cache_key(2, l.data(), l.size(), r.data(), r.size(), prox, 0, prm->index_view), nullptr, 0);
 #endif
       return 0;
     }
@@ -1413,7 +1413,7 @@ struct Ctx {
     static const std::string none;
     if (s->c->dev.pcache && s->db) {
       const std::string &a = s->s1 ? *s->s1 : none, &b2 = s->s2 ? *s->s2 : none;
-      ok = s->c->dev.append_posting(*s->b, msi_cache_key(s->db, a.data(), a.size(), b2.data(), b2.size(), s->x, i), bytes, n);
+      ok = s->c->dev.append_posting(*s->b, msi_cache_key(s->db, a.data(), a.size(), b2.data(), b2.size(), s->x, i, s->c->prm->index_view), bytes, n);
     } else
 #endif
       ok = msi_cbo_batch_append(*s->b, bytes, n);

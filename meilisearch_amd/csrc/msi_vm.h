@@ -146,7 +146,9 @@ struct MsiPostingCache;
 struct MsiCacheKey {
   uint64_t a, b;
 };
-MsiCacheKey msi_cache_key(uint32_t db, const void *s1, size_t n1, const void *s2, size_t n2, uint64_t x, uint64_t y);
+// `view`: msi_search_params::index_view — which view of the index the value was read through (0: the index as it is)
+MsiCacheKey msi_cache_key(uint32_t db, const void *s1, size_t n1, const void *s2, size_t n2, uint64_t x, uint64_t y,
+                          uint64_t view = 0);
 MsiPostingCache *msi_pcache_create(msi_ctx *ctx, uint64_t capacity_bytes);
 void msi_pcache_destroy(MsiPostingCache *c);
 // -> 1: ready in the cache at *off (decode from there); 2: reserved at *off for THIS caller to fill (pass *token to

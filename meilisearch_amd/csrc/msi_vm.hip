@@ -1951,7 +1951,8 @@ struct MsiPostingCache {
 
 // Two independent 64-bit hashes over (database tag, the two strings with their lengths, two integers): a collision
 // needs both to agree (2^-128 per pair of keys); the serialisation length is checked on top of it.
-MsiCacheKey msi_cache_key(uint32_t db, const void *s1, size_t n1, const void *s2, size_t n2, uint64_t x, uint64_t y) {
+MsiCacheKey msi_cache_key(uint32_t db, const void *s1, size_t n1, const void *s2, size_t n2, uint64_t x, uint64_t y,
+                          uint64_t view) {
   uint64_t a = 0xCBF29CE484222325ull ^ db, b = 0x84222325CBF29CE4ull + (uint64_t)db * 0x100000001B3ull;
   auto feed = [&](const void *s, size_t n) {
     const uint8_t *p = (const uint8_t *)s;
@@ -1967,6 +1968,10 @@ MsiCacheKey msi_cache_key(uint32_t db, const void *s1, size_t n1, const void *s2
   feed(s2, n2);
   a = mix64(a ^ mix64(x + 0x1234567ull)) ^ mix64(y * 0xD6E8FEB86659FD93ull + 1);
   b = mix64(b ^ mix64(y + 0x7654321ull)) ^ mix64(x * 0xA0761D6478BD642Full + 3);
+  if (view) {   // (0 leaves the keys of the plain index as they were)
+    a = mix64(a ^ mix64(view + 0x51ED27ull));
+    b = mix64(b + mix64(view * 0x9E3779B97F4A7C15ull + 5));
+  }
   return MsiCacheKey{a, b};
 }
 

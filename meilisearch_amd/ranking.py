@@ -358,7 +358,7 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
                           stop_after=None, return_degraded=False, score_threshold=None, order_keys=(), distinct_values=None,
                           geo_rules=(), geo_max_bucket_size=0, geo_distance_error_margin=1.0, geo_strategy=("dynamic", 1000),
                           exhaustive=False,
-                          max_total_hits=None, _entry=None):
+                          max_total_hits=None, index_view=0, _entry=None):
     """msi_keyword_search_ranked: bucket sort over every graph-based ranking rule of `criteria`.
     terms: [(words, is_phrase, position_start, position_end, is_prefix)] — the located query terms
     (words: [str | None], None = a stop word inside a phrase; an optional 6th element True marks a negative term).
@@ -408,6 +408,7 @@ def keyword_search_ranked(gdict, pool, callbacks, terms, criteria, strategy=TERM
     # GeoSortStrategy (documents/geo_sort.rs:32-63): ("dynamic" | "iterative" | "rtree", cache size)
     prm.geo_strategy = {"dynamic": 0, "iterative": 1, "rtree": 2}[geo_strategy[0]]
     prm.geo_cache_size = int(geo_strategy[1])
+    prm.index_view = int(index_view)      # attributesToSearchOn: the view of the index the callbacks answer for (include/msi.h)
     L = max(limit, 1)
     ids = np.zeros(L, dtype=np.uint32)
     sc = (ScoreDetail * (L * MAX_SCORE_DETAILS))()

@@ -318,6 +318,13 @@ pub struct RankedSearch<'a> {
     /// `exhaustive_number_hits` / `max_total_hits` of `bucket_sort` (bucket_sort.rs:187-191; search/new/mod.rs:894-907)
     pub exhaustive_number_hits: bool,
     pub max_total_hits: Option<usize>,
+    /// `GeoSortStrategy` of the request (documents/geo_sort.rs:32-63) as (`sys::MSI_GEO_*`, cache size); the reference's
+    /// default is `(sys::MSI_GEO_DYNAMIC, 1000)`.
+    pub geo_strategy: (i32, u32),
+    /// 0, or — `attributesToSearchOn` — a value naming the restriction the callbacks of `source` answer under (a hash of
+    /// the restricted field list): the engine keys what it remembers of stored values by (view, key).  See
+    /// `msi_search_params::index_view` in include/msi.h and INTEGRATION.md.
+    pub index_view: u64,
 }
 
 pub struct GeoRule<'a> { pub points: &'a DocGeoPoints, pub point: [f64; 2], pub ascending: bool }
@@ -485,7 +492,8 @@ pub fn keyword_search_ranked(dict: &GpuDictionary, sets: &mut GpuDocidSets, sour
         geo_distance_error_margin: q.geo_distance_error_margin,
         exhaustive_number_hits: q.exhaustive_number_hits as i32,
         max_total_hits: q.max_total_hits.map_or(0, |m| m.min(u32::MAX as usize) as u32),
-        geo_strategy: q.geo_strategy.0, geo_cache_size: q.geo_strategy.1 };
+        geo_strategy: q.geo_strategy.0, geo_cache_size: q.geo_strategy.1,
+        index_view: q.index_view };
     let mut src_ref: Src<'_> = source;
     let vt = sys::msi_index_vtable { user: &mut src_ref as *mut _ as *mut _, word_docids: Some(r_word),
         word_pair_proximity_docids: Some(r_pair), is_exact_word: Some(r_exact), word_fid_docids: Some(r_fid),

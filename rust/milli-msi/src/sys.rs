@@ -117,6 +117,7 @@ pub struct msi_search_params {
     pub geo_distance_error_margin: f64,
     pub exhaustive_number_hits: i32, pub max_total_hits: u32,
     pub geo_strategy: i32, pub geo_cache_size: u32,
+    pub index_view: u64,
 }
 pub const MSI_GEO_DYNAMIC: i32 = 0;
 pub const MSI_GEO_ALWAYS_ITERATIVE: i32 = 1;

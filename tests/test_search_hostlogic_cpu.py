@@ -463,6 +463,45 @@ def test_sort_under_distinct_hands_out_the_values_distinct_emptied(hostlib):
     h.close()
 
 
+@pytest.mark.parametrize("exact_attributes", [(), ("body",)], ids=["no-exact-attribute", "body-exact"])
+def test_attributes_to_search_on_views_match_the_oracle(hostlib, exact_attributes):
+    """`attributesToSearchOn` (search/new/mod.rs:140-222): the request reads the index through a restricted VIEW — word_docids
+    becomes the union of word_fid_docids over the restricted tolerant fields, exact_word_docids the union over the restricted
+    exact fields, the prefix databases likewise, word_fid_docids outside the restriction is absent (db_cache.rs:208-345,
+    540-575).  The shim's callbacks answer that way (tests/toy_milli.py: ToyMilli.restricted) and name the view in
+    msi_search_params::index_view; hits, score details and candidate counts against the oracle reading the same view."""
+    from oracle import ranking_oracle as RO
+    import tests.test_search_gpu as G
+    docs = G.random_corpus(21, 260)
+    for i, d in enumerate(docs):
+        d["tags"] = " ".join(G.VOCAB[(i * 7 + k * 3) % len(G.VOCAB)] for k in range(i % 4))
+    index = ToyMilli(docs, searchable=["title", "body", "tags"], exact_attributes=exact_attributes, prefix_threshold=3)
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    n = differs = 0
+    for attrs in (["title"], ["body"], ["tags", "title"], ["unknown"], ["*"], ["body", "tags"]):
+        view = index.restricted(attrs)
+        h = make_harness(hostlib, view)
+        for criteria in (None, ["words", "attribute", "exactness"], ["typo", "proximity", "wordPosition"]):
+            for q in ["quick fox", "the lazy dog", "sun fl", "brwn fox jumps", "\"lazy dog\" summer", "su"]:
+                for tms in ("last", "all", "frequency"):
+                    want = RO.search(RO.Ctx(view, lookup), q, tms=tms, criteria=criteria, offset=0, length=25, detailed=True)
+                    hits, cand = h.search(q, tms=tms, criteria=criteria, offset=0, limit=25, detailed=True,
+                                          index_view=getattr(view, "index_view", 0))
+                    assert [d for d, _ in hits] == want[0], (attrs, criteria, q, tms)
+                    assert [[tuple(s_) for s_ in sc] for _, sc in hits] == [[G.oracle_score(s_) for s_ in sc] for sc in want[1]], (attrs, q)
+                    assert cand == len(want[2]), (attrs, criteria, q, tms)
+                    if view is not index:
+                        plain = RO.search(RO.Ctx(index, lookup), q, tms=tms, criteria=criteria, offset=0, length=25, detailed=True)
+                        differs += int(plain[0] != want[0] or len(plain[2]) != len(want[2]))
+                    n += 1
+        h.close()
+    assert n == 6 * 3 * 6 * 3 and differs >= 100      # (the restriction changes most answers: the comparison is not vacuous)
+
+
 GEO = json.load(open(os.path.join(ROOT, "tests", "golden", "geo_snapshots.json")))
 
 

@@ -190,3 +190,54 @@ def test_random_corpora_spread_over_chunks_match_the_oracle():
     tail = out.stdout[-2000:] + out.stderr[-2000:]
     assert out.returncode == 0 and " bad 0" in out.stdout, tail
     assert int(out.stdout.split("cases")[-1].split()[0]) >= 30, tail
+
+
+def test_index_views_do_not_share_what_the_engine_remembers():
+    """`attributesToSearchOn` reads the index through a restricted view (tests/toy_milli.py: ToyMilli.restricted): the same
+    keys answer with other values.  The posting cache in HBM and what the engine knows about absent keys are kept per
+    (msi_search_params::index_view, key): searches that alternate between the index and two views of it — one dictionary,
+    one cache, one pool — each equal the oracle reading through their own view, cold and warm.  Control: with the views
+    unnamed (index_view 0 for all) the same alternation reads another view's postings and goes wrong."""
+    from oracle import oracle as O
+    from oracle import ranking_oracle as RO
+    import tests.test_search_gpu as G
+    from tests.toy_milli import ToyMilli, query_terms
+    docs = G.random_corpus(31, 300)
+    for i, d in enumerate(docs):
+        d["tags"] = " ".join(G.VOCAB[(i * 5 + k * 11) % len(G.VOCAB)] for k in range(i % 3))
+    index = ToyMilli(docs, searchable=["title", "body", "tags"], prefix_threshold=3)
+    dic = O.Dictionary(index.words)
+
+    def lookup(word, max_typos, is_prefix):
+        one, two = O.typo_lookup(dic, word, max_typos, is_prefix)
+        return [index.words[i] for i in one], [index.words[i] for i in two]
+    views = [index, index.restricted(["title"]), index.restricted(["body", "tags"])]
+    h = Harness(index)
+    h.dict.enable_posting_cache(8 << 20)
+    cbs = [h.R.IndexCallbacks(v) for v in views]
+    queries = ["quick fox", "the lazy dog", "sun fl", "brown fox jumps", "summer", "su"]
+
+    def run(named):
+        bad = n = 0
+        for rep in range(2):                       # cold, then warm
+            for q in queries:
+                for v, cb in zip(views, cbs):
+                    R = h.R
+                    hits, cand = R.keyword_search_ranked(
+                        h.dict, h.pool, cb, query_terms(q, stop_words=index.stop_words), index.criteria, strategy=R.strategy_of("last"),
+                        offset=0, limit=30, detailed=True, searchable_fids=index.searchable_fids,
+                        searchable_weights=[index.weights[f] for f in index.searchable_fids], max_weight=index.max_weight,
+                        authorize_typos=index.authorize_typos, min_one=index.min_one, min_two=index.min_two,
+                        index_view=getattr(v, "index_view", 0) if named else 0)
+                    want = RO.search(RO.Ctx(v, lookup), q, tms="last", offset=0, length=30, detailed=True)
+                    ok = [d for d, _ in hits] == want[0] and cand == len(want[2]) and \
+                        [[tuple(s_) for s_ in sc] for _, sc in hits] == [[G.oracle_score(s_) for s_ in sc] for sc in want[1]]
+                    bad += int(not ok)
+                    n += 1
+        return bad, n
+    bad, n = run(named=True)
+    assert bad == 0 and n == 36
+    stats = h.dict.posting_cache_stats()
+    assert stats["hits"] > 0
+    bad_unnamed, _ = run(named=False)              # (after the named pass: the plain index's keys are warm)
+    assert bad_unnamed > 0

@@ -93,6 +93,7 @@ class ToyMilli:
             self.max_weight = max(len(searchable) - 1, 0)
         self.searchable_fids = [self.fields[n] for n in self.searchable]
         exact_attr = set(exact_attributes)
+        self.exact_attribute_names = exact_attr
         self.word_docids, self.exact_word_docids = {}, {}
         self.word_fid_docids, self.word_position_docids = {}, {}
         self.fid_word_count, self.pair = {}, {}
@@ -192,6 +193,61 @@ class ToyMilli:
     # ---- the reads of search/new/db_cache.rs ----------------------------------------
     def all_docids(self):
         return set(range(self.n_docs))
+
+    def restricted(self, attributes_to_search_on):
+        """The view of this index a request with `attributesToSearchOn` searches (search/new/mod.rs:140-222): the same
+        databases read through other functions (db_cache.rs:208-345,540-575).  `index_view` names the view for the engine's
+        caches (msi_search_params::index_view).  "*" = no restriction (the index itself)."""
+        if "*" in attributes_to_search_on:
+            return self
+        import copy
+        import zlib
+        v = copy.copy(self)
+        exact_attr = getattr(self, "exact_attribute_names", set())
+        fids = [self.fields[n] for n in attributes_to_search_on if n in self.fields and n in self.searchable]
+        v.tolerant_fids = [f for f in fids if self.searchable[self.searchable_fids.index(f)] not in exact_attr]
+        v.exact_fids = [f for f in fids if f not in v.tolerant_fids]
+        v.index_view = 1 + zlib.crc32(",".join(sorted(attributes_to_search_on)).encode())
+        base = self
+
+        def union(keys, db):
+            found = [db[k] for k in keys if k in db]
+            if not found:
+                return None
+            out = set()
+            for s_ in found:
+                out |= s_
+            return out
+
+        def get_word_docids(w, original):   # db_cache.rs:208-269 + :183-205
+            t = union([(w, f) for f in v.tolerant_fids], base.word_fid_docids)
+            if not original:
+                return t
+            e = union([(w, f) for f in v.exact_fids], base.word_fid_docids)
+            if t is None and e is None:
+                return None
+            return (t or set()) | (e or set())
+
+        def get_word_prefix_docids(pfx, original):   # db_cache.rs:297-358 + :272-294
+            t = union([(pfx, f) for f in v.tolerant_fids], base.word_prefix_fid_docids)
+            if not original:
+                return t
+            e = union([(pfx, f) for f in v.exact_fids], base.word_prefix_fid_docids)
+            if t is None and e is None:
+                return None
+            return (t or set()) | (e or set())
+
+        v.get_word_docids = get_word_docids
+        v.get_word_prefix_docids = get_word_prefix_docids
+        v.contains_word = base.contains_word            # Index::contains_word reads the plain databases
+        v.get_word_fid_docids = lambda w, fid: base.word_fid_docids.get((w, fid)) if fid in fids else None   # :540-543
+        v.get_word_prefix_fid_docids = lambda pfx, fid: base.word_prefix_fid_docids.get((pfx, fid)) if fid in fids else None
+        # the vtable side (what the shim's callbacks hand over under this view)
+        v.word_docids_bytes = lambda word, original: (lambda s_: cbo_bytes(s_) if s_ else None)(get_word_docids(word, original))
+        v.word_fid_docids_bytes = lambda word, fid: (lambda s_: cbo_bytes(s_) if s_ else None)(v.get_word_fid_docids(word, fid))
+        v.word_prefix_docids_values = lambda pfx, original: (lambda s_: [cbo_bytes(s_)] if s_ else [])(get_word_prefix_docids(pfx, original))
+        v.word_prefix_fid_docids_values = lambda pfx, fid: (lambda s_: [cbo_bytes(s_)] if s_ else [])(v.get_word_prefix_fid_docids(pfx, fid))
+        return v
 
     def contains_word(self, w):
         return w in self.word_docids or w in self.exact_word_docids
