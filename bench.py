@@ -363,15 +363,15 @@ def keyword_roofline(n_docs, kw_threads, measured_qps):
             traffic[counter] = None
             continue
         v = rows[counter]
-        # the child first runs its `distinct` warm-up queries on one thread, then the measured ones: the counters of the
+        # the child first runs its `distinct` warm-up queries on one thread, two per caller on every pool, then the measured ones: the counters of the
         # whole process are split by the share of queries (the same searches, warm cache in both parts)
-        per_query_kb = sum(v) / (distinct + n_measured)
+        per_query_kb = sum(v) / (distinct + 2 * threads + n_measured)   # (+ two searches per caller that warm its pool)
         traffic[counter] = per_query_kb * 1024 * (2 if counter == "FETCH_SIZE" else 1)
     out["traffic"] = None if traffic["FETCH_SIZE"] is None else round(traffic["FETCH_SIZE"] / 1e6, 2)
     out["traffic_unit"] = "MB per query (HBM reads, PMC FETCH_SIZE x 2)"
     out["traffic_writes_mb_per_query"] = None if traffic["WRITE_SIZE"] is None else round(traffic["WRITE_SIZE"] / 1e6, 2)
     out["traffic_source"] = ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE children of this run (tools/bin/ranked_bench, "
-                             f"{threads} callers, {distinct} + {n_measured} queries); counters summed over every vm_kernel dispatch")
+                             f"{threads} callers, {distinct} + {2 * threads} + {n_measured} queries); counters summed over every vm_kernel dispatch")
     moved = (traffic["FETCH_SIZE"] or 0.0) + (traffic["WRITE_SIZE"] or 0.0)
     out["achieved"] = round(moved * measured_qps / 1e9, 1) if moved else None
     out["achieved_is"] = ("measured HBM bytes per query (reads + writes above) x the keyword leg's queries/s of THIS run: the leg's "
