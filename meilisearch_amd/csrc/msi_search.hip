@@ -80,6 +80,11 @@ struct Stats {
   double callback_ms = 0, device_wait_ms = 0, total_ms = 0;
 };
 thread_local Stats g_stats;
+// MSI_SEARCH_FK_TRACE: one line per first-k command recorded / delivered and per bucket emitted (debugging aid; read once)
+inline bool fk_trace() {
+  static const bool on = getenv("MSI_SEARCH_FK_TRACE") != nullptr;
+  return on;
+}
 // process-wide: searches that continued in the compact space, and the documents of their universes (msi_search_compaction_stats)
 std::atomic<uint64_t> g_compact_searches{0}, g_compact_docs{0}, g_ranked_searches{0};
 struct Clock {
@@ -342,7 +347,7 @@ struct Dev {
     ck(st);
     for (PendingFk &f : fk) {   // a set smaller than k filled less of its block
       const size_t n = (size_t)std::min<uint64_t>(res.counts[f.ci], f.k);
-      if (getenv("MSI_SEARCH_FK_TRACE"))
+      if (fk_trace())
         fprintf(stderr, "[msi fk] deliver slot %u k %u -> %zu ids (count %llu, base %u of %zu)\n", f.set->slot, f.k, n,
                 (unsigned long long)res.counts[f.ci], f.base, res.firstk.size());
       f.sink(res.firstk.data() + f.base, n);
@@ -906,7 +911,7 @@ struct Dev {
       const uint32_t ci = list.new_counts(1);
       rd(a->slot);
       rec({VM_FIRSTK, a->slot, k, ci, list.firstk_total});
-      if (getenv("MSI_SEARCH_FK_TRACE"))
+      if (fk_trace())
         fprintf(stderr, "[msi fk] record slot %u k %u base %u (in phase %u, list counts %u)\n", a->slot, k, list.firstk_total,
                 list.fk_in_phase, list.n_counts);
       pending_fk.push_back(PendingFk{a, k, ci, list.firstk_total, std::move(sink)});
@@ -3367,7 +3372,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             out_scores[(size_t)(at + i) * MSI_MAX_SCORE_DETAILS + sdx] = msi_score_detail{scores[sdx].kind, scores[sdx].a, scores[sdx].b};
           out_n_scores[at + i] = ns;
         }
-        if (getenv("MSI_SEARCH_FK_TRACE"))
+        if (fk_trace())
           fprintf(stderr, "[msi emit] place %llu count %llu -> at %u skip %llu take %u slot %u known %d\n", (unsigned long long)off,
                   (unsigned long long)count, at, (unsigned long long)skip, take, docs->slot, known ? (int)known->size() : -1);
         if (known && known->size() >= skip + take) {   // the rule asked for these ids in the list that counted the bucket
