@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSI_ABI_VERSION 1
+#define MSI_ABI_VERSION 2   /* 2: msi_search_params grew (geo_strategy, geo_cache_size, index_view), round 3 */
 
 enum {
   MSI_OK = 0,

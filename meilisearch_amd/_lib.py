@@ -313,8 +313,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if L.msi_abi_version() != 1:
-            raise ImportError(f"libmsi ABI {L.msi_abi_version()} != 1")
+        if L.msi_abi_version() != 2:
+            raise ImportError(f"libmsi ABI {L.msi_abi_version()} != 2")
         _LIB = L
     return _LIB
 

@@ -69,8 +69,12 @@ struct alignas(64) QueryMeta {   // one 64-byte line per query
 };
 static_assert(sizeof(QueryMeta) == 64, "QueryMeta is one 64-byte line");
 
-// 6-bit hash of a code point for the char-presence signatures.
-__host__ __device__ __forceinline__ uint32_t sig_bit(uint32_t cp) { return (cp * 0x9E3779B1u) >> 26; }
+// The filter word of a dictionary word: ONE 8-byte load per word in the range scan (round 3 read a 64-bit signature and
+// a 16-bit length word: two loads, 10 bytes).  bits 0..7 char count (capped at 255), bit 8 "a word of at least one byte",
+// bits 9..63 the char-presence signature: bit 9 + hash55(code point) set for every char of the word.
+constexpr u64 FILT_VALID = 1ull << 8;
+constexpr u64 FILT_SIG = ~0x1FFull;
+__host__ __device__ __forceinline__ uint32_t sig_bit(uint32_t cp) { return 9u + ((((cp * 0x9E3779B1u) >> 16) * 55u) >> 16); }
 __device__ __forceinline__ u64 pair_key(uint32_t a, uint32_t b) { return (u64)a | ((u64)b << 32); }
 
 __device__ __forceinline__ uint32_t utf8_len(uint32_t b0) {
@@ -221,11 +225,72 @@ __device__ __forceinline__ int osa_pair(Reader rd, int nch, bool active, const Q
   return (active && nch <= m + K) ? res : DINF;
 }
 
+// ---- bit-parallel OSA (the survivors' matcher since round 4) ------------------------------------------------------
+// Hyyro's bit-vector recurrence for the Damerau / optimal-string-alignment distance ("A bit-vector algorithm for computing
+// Levenshtein and Damerau edit distances", 2003): pattern = the workgroup's QUERY (one bit per query char, T = u32 for
+// m <= 32, u64 for m <= 64; longer queries take the banded DP above), text = the lane's dictionary word.  A column of the
+// DP table is two bit vectors of vertical deltas (VP / VN); one word char advances it in ~20 wave instructions whatever
+// m is, against the 78-102 of the five-diagonal band.  The tracked score is D[m][j] — the distance between the whole query
+// and the word's first j chars — which is exactly what both automata need: its value at j = |word| (build_dfa), its
+// minimum over j (build_prefix_dfa: `sunflowering` costs 0 under the prefix query `sunflower`).
+//
+// PEq[c] = the query positions holding char c: a direct table for ASCII, an open-addressing table for other code points
+// (<= 64 distinct keys in 128 slots), both in LDS, built once per query by the workgroup.
+constexpr uint32_t PEQ_EMPTY = 0xFFFFFFFFu;
+struct PEq {
+  const u64 *ascii;      // [128]
+  const uint32_t *key;   // [128]
+  const u64 *val;        // [128]
+  __device__ __forceinline__ u64 at(uint32_t c) const {
+    if (c < 128u) return ascii[c];
+    uint32_t h = (c * 0x9E3779B1u) >> 25;
+    for (;;) {
+      const uint32_t k = key[h];
+      if (k == c) return val[h];
+      if (k == PEQ_EMPTY) return 0ull;
+      h = (h + 1u) & 127u;
+    }
+  }
+};
+
+template <class T, class Reader>
+__device__ __forceinline__ int osa_pair_bits(Reader rd, int nch, bool active, const PEq &pq, int m, int K, bool prefix) {
+  const T top = (T)1 << (m - 1);
+  T VP = (T)(~(T)0), VN = 0, D0 = 0, PMp = 0;   // (bits above m - 1 never reach a bit below them)
+  int score = m, best = m;
+  const int ne = active ? min(nch, m + K) : 0;
+  const int nmax = wave_max_i32(ne);
+  for (int j = 1; j <= nmax; ++j) {
+    const uint32_t wc = rd.next_char();
+    const bool upd = j <= ne;
+    const T PM = (T)pq.at(upd ? wc : 0u);
+    const T TR = (((T)(~D0) & PM) << 1) & PMp;
+    const T D0n = ((((PM & VP) + VP) ^ VP) | PM | VN) | TR;
+    const T HP = VN | (T)(~(D0n | VP));
+    const T HN = D0n & VP;
+    const int sc = score + ((HP & top) ? 1 : 0) - ((HN & top) ? 1 : 0);
+    const T X = (T)(HP << 1) | (T)1;
+    const T VPn = (T)(HN << 1) | (T)(~(D0n | X));
+    const T VNn = D0n & X;
+    if (upd) {
+      D0 = D0n;
+      VP = VPn;
+      VN = VNn;
+      PMp = PM;
+      score = sc;
+      best = min(best, sc);
+    }
+  }
+  if (!active) return DINF;
+  if (prefix) return best;
+  return nch <= m + K ? score : DINF;
+}
+
 // ---- lookup kernel -----------------------------------------------------------------
 
 struct DictArgs {
   const uint4 *slots;        // [n_words] first 16 bytes of every word, zero padded
-  const u64 *sigs;           // [n_words] char-presence signature of the whole word
+  const u64 *filt;           // [n_words] filter word: char count | valid << 8 | char-presence signature << 9
   const uint16_t *wmeta;     // [n_words] char count | byte length << 8
   const uint8_t *flat;       // concatenated bytes
   const uint32_t *offs;      // [n_words+1]
@@ -325,7 +390,11 @@ struct WaveLists {
 //           exact strings (prefix rule: string prefixes), so they are binary searches in the sorted dictionary —
 //           two per dictionary first char c, two more for the shapes without c — instead of a scan.
 //   caps    the reference's sequential cap logic in closed form (header of this file) over the three lists.
+template <bool BITS>
 __global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
+  __shared__ u64 s_pa[128];            // PEq: ASCII chars (BITS)
+  __shared__ uint32_t s_pk[128];       //      other code points: keys ...
+  __shared__ u64 s_pv[128];            //      ... and their position masks
   __shared__ uint32_t s_q[QSTRIDE];
   __shared__ uint8_t s_qb[256];
   __shared__ uint32_t s_pq[LW][PQ];
@@ -360,10 +429,35 @@ __global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
     const bool prefix = qm.prefix != 0;
     for (uint32_t i = tid; i < (uint32_t)m; i += LT) s_q[i] = a.qchars[(size_t)q * QSTRIDE + i];
     for (uint32_t i = tid; i < qm.qlen; i += LT) s_qb[i] = a.qbytes[a.qoff[q] + i];
+    const bool bits = BITS && m <= 64;   // (wave- and workgroup-uniform: the query's)
+    if (bits && tid < 128) {
+      s_pa[tid] = 0ull;
+      s_pk[tid] = PEQ_EMPTY;
+      s_pv[tid] = 0ull;
+    }
     __syncthreads();
+    if (bits && tid < (uint32_t)m) {      // thread = query position
+      const uint32_t c = s_q[tid];
+      if (c < 128u) {
+        atomicOr(&s_pa[c], 1ull << tid);
+      } else {
+        uint32_t h = (c * 0x9E3779B1u) >> 25;
+        for (;;) {   // <= 64 distinct keys in 128 slots: a free slot always turns up
+          const uint32_t k = atomicCAS(&s_pk[h], PEQ_EMPTY, c);
+          if (k == PEQ_EMPTY || k == c) break;
+          h = (h + 1u) & 127u;
+        }
+        atomicOr(&s_pv[h], 1ull << tid);
+      }
+    }
+    if (bits) __syncthreads();
     QChars qs;
     qs.q = s_q;
     qs.m = m;
+    PEq pq;
+    pq.ascii = s_pa;
+    pq.key = s_pk;
+    pq.val = s_pv;
 
     // ---- scan: the same-first-char range ------------------------------------------------------------
     uint32_t cnt0 = 0, cnt1 = 0;      // hits of this wave at distance 1 / 2 (wave-uniform)
@@ -378,19 +472,20 @@ __global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
       const bool is_long = act && bl > 16;
       const bool is_short = act && !is_long;
       int d = DINF;
+      // the matcher: bit-parallel (32 bits for queries of <= 32 chars, else 64) or — queries above 64 chars, and the
+      // round-3 kernel kept under MSI_DICT_MATCHER=banded — the five-diagonal DP
+      auto pair = [&](auto r, bool on) -> int {
+        if (bits) return m <= 32 ? osa_pair_bits<uint32_t>(r, nc, on, pq, m, K, prefix) : osa_pair_bits<u64>(r, nc, on, pq, m, K, prefix);
+        return osa_pair(r, nc, on, qs, K, prefix);
+      };
       if (__ballot(is_short)) {
-        if (__ballot(is_short && (uint32_t)nc != bl) == 0) {
-          SlotReader<true> r{slot.x, slot.y, slot.z, slot.w};
-          d = osa_pair(r, nc, is_short, qs, K, prefix);
-        } else {
-          SlotReader<false> r{slot.x, slot.y, slot.z, slot.w};
-          d = osa_pair(r, nc, is_short, qs, K, prefix);
-        }
+        if (__ballot(is_short && (uint32_t)nc != bl) == 0) d = pair(SlotReader<true>{slot.x, slot.y, slot.z, slot.w}, is_short);
+        else d = pair(SlotReader<false>{slot.x, slot.y, slot.z, slot.w}, is_short);
+        if (!is_short) d = DINF;
       }
       if (__ballot(is_long)) {   // words longer than a slot read their bytes from the flat array
         const uint32_t o0 = is_long ? a.offs[idx] : 0, o1 = is_long ? a.offs[idx + 1] : 0;
-        FlatReader r{a.flat + o0, a.flat + o1};
-        const int dl = osa_pair(r, nc, is_long, qs, K, prefix);
+        const int dl = pair(FlatReader{a.flat + o0, a.flat + o1}, is_long);
         if (is_long) d = dl;
       }
       const uint32_t cat = !act ? 3u : (d == 1 ? 0u : ((K == 2 && d == 2) ? 1u : 3u));
@@ -412,31 +507,39 @@ __global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
     if (qm.hi > qm.lo) {
       const uint32_t t_lo = qm.lo >> 6, t_hi = (qm.hi + 63) >> 6, n_t = t_hi - t_lo;
       const uint32_t t0 = t_lo + (uint32_t)((u64)n_t * wave / LW), t1 = t_lo + (uint32_t)((u64)n_t * (wave + 1) / LW);
-      for (uint32_t t = t0; t < t1; ++t) {
-        // both lists of this wave full: nothing it finds later can be among the first cap of the query
-        if (cnt0 >= a.cap1 && (K < 2 || cnt1 >= a.cap2)) {
-          qn = 0;
-          break;
+      // The filter is a stream of 8-byte loads with a ballot behind each: one tile (64 words) per iteration left a wave
+      // with a single load in flight — latency-bound at ~2 us per 64 words (r3: 0.15 of the VALU issue peak, 11 % VALU-active).
+      // Four tiles' loads are issued before the first is looked at.
+      constexpr uint32_t UN = 4;
+      bool full = false;
+      for (uint32_t tb = t0; tb < t1 && !full; tb += UN) {
+        u64 f[UN];
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u) {
+          const uint32_t idx = (tb + u) * 64 + lane;
+          f[u] = (tb + u < t1 && idx >= qm.lo && idx < qm.hi) ? a.filt[idx] : 0ull;
         }
-        const uint32_t idx = t * 64 + lane;
-        const bool in = idx >= qm.lo && idx < qm.hi;
-        u64 wsig = 0;
-        uint32_t wm = 0;
-        if (in) {
-          wsig = a.sigs[idx];
-          wm = a.wmeta[idx];
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u) {
+          // both lists of this wave full: nothing it finds later can be among the first cap of the query
+          if (cnt0 >= a.cap1 && (K < 2 || cnt1 >= a.cap2)) {
+            qn = 0;
+            full = true;
+            break;
+          }
+          const u64 fw = f[u];
+          const int nc = (int)(fw & 0xFF);
+          const uint32_t q_not_w = __popcll(qm.sig & ~fw);
+          const uint32_t w_not_q = prefix ? 0u : __popcll((fw & FILT_SIG) & ~qm.sig);
+          const bool len_ok = (nc + K >= m) & (prefix | (nc <= m + K));
+          const bool act = ((fw & FILT_VALID) != 0) & len_ok & (max(q_not_w, w_not_q) <= (uint32_t)K);
+          const u64 ms = __ballot(act);
+          if (ms == 0) continue;
+          if (act) s_pq[wave][(head + qn + __popcll(ms & lower)) & (PQ - 1)] = (tb + u) * 64 + lane;
+          qn += __popcll(ms);
+          __builtin_amdgcn_wave_barrier();
+          while (qn >= 64) drain(64);
         }
-        const int nc = (int)(wm & 0xFF);
-        const uint32_t q_not_w = __popcll(qm.sig & ~wsig);
-        const uint32_t w_not_q = prefix ? 0u : __popcll(wsig & ~qm.sig);
-        const bool len_ok = (nc + K >= m) & (prefix | (nc <= m + K));
-        const bool act = in & ((wm >> 8) != 0) & len_ok & (max(q_not_w, w_not_q) <= (uint32_t)K);
-        const u64 ms = __ballot(act);
-        if (ms == 0) continue;
-        if (act) s_pq[wave][(head + qn + __popcll(ms & lower)) & (PQ - 1)] = idx;
-        qn += __popcll(ms);
-        __builtin_amdgcn_wave_barrier();
-        while (qn >= 64) drain(64);
       }
       while (qn > 0) drain(qn < 64 ? qn : 64);
     }
@@ -646,7 +749,7 @@ struct msi_dict {
   msi_ctx *ctx = nullptr;
   uint32_t n_words = 0;
   uint32_t n_fc = 0;   // first-char blocks
-  DevBuf slots, sigs, wmeta, flat, offs, fc_start;
+  DevBuf slots, filt, wmeta, flat, offs, fc_start;
   // scratch (guarded by ctx->mu_aux)
   DevBuf qbytes, qoff, qflags, qm, qchars, wlists, xlists, ticket, pairs, out1, out1c, out2, out2c;
   // host entry point (msi_dict_lookup): pinned staging of the packed queries and results, and an event the caller
@@ -744,7 +847,7 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   MSI_HIP_TRY(hipMemsetAsync(d->ticket.p, 0, sizeof(uint32_t), st));
   DictArgs a;
   a.slots = d->slots.as<uint4>();
-  a.sigs = d->sigs.as<u64>();
+  a.filt = d->filt.as<u64>();
   a.wmeta = d->wmeta.as<uint16_t>();
   a.flat = d->flat.as<uint8_t>();
   a.offs = d->offs.as<uint32_t>();
@@ -768,7 +871,11 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   a.out_two = d_two;
   a.out_two_cnt = d_two_cnt;
   d->match_timer.begin(ctx, st);
-  hipLaunchKernelGGL(dict_lookup_kernel, dim3(grid), dim3(LT), 0, st, a);
+  // MSI_DICT_MATCHER=banded: the round-3 five-diagonal DP for every survivor (kept for A/B runs and as the matcher of
+  // queries above 64 chars); default: the bit-parallel recurrence
+  static const bool banded = getenv("MSI_DICT_MATCHER") && !strcmp(getenv("MSI_DICT_MATCHER"), "banded");
+  if (banded) hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(grid), dim3(LT), 0, st, a);
+  else hipLaunchKernelGGL(dict_lookup_kernel<true>, dim3(grid), dim3(LT), 0, st, a);
   d->match_timer.end(ctx);
   MSI_HIP_TRY(hipGetLastError());
   d->lookup_launches++;
@@ -788,7 +895,7 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
   *out = nullptr;
   // host-side staging: slots, lengths, char-presence signatures, first-char blocks; sortedness check
   std::vector<uint4> slots(std::max<uint32_t>(1, n_words));
-  std::vector<u64> sigs(std::max<uint32_t>(1, n_words));
+  std::vector<u64> filt(std::max<uint32_t>(1, n_words));
   std::vector<uint16_t> wmeta(std::max<uint32_t>(1, n_words));
   std::vector<uint32_t> fc_start;
   uint32_t prev_fc = 0, prev_fcl = 0;   // first char of the previous non-empty word (its bytes, big endian)
@@ -821,7 +928,7 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
       ++chars;
       b += cl;
     }
-    sigs[i] = sig;
+    filt[i] = sig | (len ? FILT_VALID : 0ull) | std::min<uint32_t>(chars, 255);
     wmeta[i] = (uint16_t)(std::min<uint32_t>(chars, 255) | (len << 8));
     if (len) {
       const uint32_t b0 = w[0];
@@ -856,7 +963,7 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
     }
   };
   up(d->slots, slots.data(), (size_t)n_words * sizeof(uint4));
-  up(d->sigs, sigs.data(), (size_t)n_words * sizeof(u64));
+  up(d->filt, filt.data(), (size_t)n_words * sizeof(u64));
   up(d->wmeta, wmeta.data(), (size_t)n_words * sizeof(uint16_t));
   up(d->flat, words_concat, flat_bytes);
   up(d->offs, offsets, ((size_t)n_words + 1) * sizeof(uint32_t));
@@ -868,7 +975,7 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
     s = MSI_E_HIP;
   }
   if (s != MSI_OK) {
-    DevBuf *bufs[] = {&d->slots, &d->sigs, &d->wmeta, &d->flat, &d->offs, &d->fc_start, &d->pairs};
+    DevBuf *bufs[] = {&d->slots, &d->filt, &d->wmeta, &d->flat, &d->offs, &d->fc_start, &d->pairs};
     for (DevBuf *b : bufs) b->release();
     delete d;
     return s;
@@ -891,7 +998,7 @@ void msi_dict_destroy(msi_dict *d) {
   std::lock_guard<std::mutex> lk(ctx->mu_aux);
   DeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(d->ctx->stream_aux);
-  DevBuf *bufs[] = {&d->slots, &d->sigs, &d->wmeta, &d->flat, &d->offs, &d->fc_start, &d->qbytes, &d->qoff,
+  DevBuf *bufs[] = {&d->slots, &d->filt, &d->wmeta, &d->flat, &d->offs, &d->fc_start, &d->qbytes, &d->qoff,
                     &d->qflags, &d->qm, &d->qchars, &d->wlists, &d->xlists, &d->ticket, &d->pairs,
                     &d->out1, &d->out1c, &d->out2, &d->out2c};
   for (DevBuf *b : bufs) b->release();

@@ -1246,7 +1246,8 @@ struct Ctx {
   }
 #endif
   void relieve() {  // keep the pool from running dry on long queries: drop what can be recomputed
-    if (dev.cur->free_.size() + dev.cur->clean_.size() >= 48) return;
+    // (slots freed while a compact list is being recorded wait in `held` until it has run: they are as good as free)
+    if (dev.cur->free_.size() + dev.cur->clean_.size() + dev.cur->held.size() >= 48) return;
 #ifndef MSI_SEARCH_DIRECT_ONLY
     // another task of the bucket sort may be parked with a reference into these maps: with tasks alive the caches stay
     // (a search that then runs out of slots is re-run sequentially, where this works again)
@@ -2989,6 +2990,10 @@ struct GeoSortRule : Rule {
       mode = use_rtree ? 2 : 1;
       cache_left = use_rtree ? (listed ? std::min<uint64_t>(total, cache_size) : cache_size) : total;
     }
+    // (AlwaysIterative is a test / debugging strategy of the reference; a candidate list past the device list's cap would
+    // silently fall through to the exact-distance order below, which orders documents inside one metre differently)
+    if (strategy == MSI_GEO_ALWAYS_ITERATIVE && listed && total > ids.size())
+      fail(MSI_E_UNSUPPORTED, "GeoSort with the AlwaysIterative strategy lists at most 1 048 575 candidates");
     if (mode == 1 && listed && total <= ids.size()) {
       if (!total) {   // no candidate left: what remains has no point (:161-163)
         out.score = {MSI_SCORE_GEO_SORT, idx, 0xFFFFFFFFu};
@@ -3266,7 +3271,10 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
 #ifndef MSI_SEARCH_DIRECT_ONLY
   // Universe compaction (Dev::compact_begin): everything below works on subsets of `universe`.  Not with the rules and
   // options that read per-document arrays by docid through direct kernels (Sort / GeoSort keys, distinct values).
-  bool may_compact = c.dev.vm && Dev::compact_mode() > 0 && !placeholder && !p->distinct_values && msi_bits_n_slots(c.dev.pool.p) <= 1024;
+  // (nor with a page that reaches past what one list can read back: Dev::first_k then falls back to the direct kernel,
+  // which knows nothing of ranks — ADVICE r3: offset 8200 + limit 5 over a compact universe)
+  bool may_compact = c.dev.vm && Dev::compact_mode() > 0 && !placeholder && !p->distinct_values && msi_bits_n_slots(c.dev.pool.p) <= 1024 &&
+                     (uint64_t)p->from + p->length <= MSI_VM_MAX_FIRSTK;
   for (auto &r : rules) may_compact = may_compact && r->kind != R_ORDER_BY;
   if (may_compact) c.dev.rank_tables(universe);   // (rides in the list that counts the universe: no round of its own)
 #endif
@@ -3432,7 +3440,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             // a task keeps its own working sets alive: only as many tasks as the pool has room for (a rule evaluation
             // is given what relieve() keeps free)
             if (coop && tasks.live < (size_t)max_tasks &&
-                (no_gate || c.dev.cur->free_.size() + c.dev.cur->clean_.size() >= 48 * (tasks.live + 2))) {
+                (no_gate || c.dev.cur->free_.size() + c.dev.cur->clean_.size() + c.dev.cur->held.size() >= 48 * (tasks.live + 2))) {
               // (the graph is moved into the task: the Bucket dies at the end of this iteration)
               auto gp = msi_arena::make_shared<Graph>(b.graph());
               tasks.spawn([&rank, cur, docs = b.docs, cnt = b.count, off, sc, gp]() { rank(cur + 1, docs, cnt, off, sc, *gp); });

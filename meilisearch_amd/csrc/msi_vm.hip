@@ -57,6 +57,20 @@ constexpr uint32_t CHW = 1024;          // u64 words per chunk (65 536 documents
 constexpr uint32_t MAX_SUBS = 64;       // lists per round
 constexpr uint32_t SUM_W = 16;                                  // 64-bit words of a chunk's summary row: pools of <= 1024 slots
 constexpr uint32_t CMD_LDS = 2048;                             // command words of a phase kept in LDS (longer phases: read from the arena)
+// One LDS arena per workgroup, used three ways (the phases of a launch never mix them inside one workgroup):
+//   full-space list phases   s_dec (a chunk being decoded) | s_raw (one container body) | s_whole | s_nzw (chunk summaries)
+//   wide phase (VM_DECODEC)  s_dec (U0's words of the chunk) | s_raw (the waves' output words) | the chunk's decode descriptors
+//   compact command phase    the SET CACHE: slot -> entry map and resolved path steps per wave, then the cached sets
+#ifndef MSI_VM_ARENA_KB
+#define MSI_VM_ARENA_KB 38
+#endif
+constexpr uint32_t ARENA_BYTES = MSI_VM_ARENA_KB * 1024;
+constexpr uint32_t A_RAW = CHW * 8, A_WHOLE = A_RAW + CHW * 8 + 32, A_NZW = A_WHOLE + SUM_W * 64 * 2, A_FULL_END = A_NZW + SUM_W * 64 * 4;
+constexpr uint32_t A_DESC = A_WHOLE;                             // wide phase: the chunk's decode descriptors (as much as fits)
+constexpr uint32_t SO_CAP = 1024;                                // path steps of one VM_PATHS resolved ahead per wave (u8 each)
+constexpr uint32_t C_MAP = 0, C_SO = C_MAP + (VT / 64) * 1024, C_DATA = C_SO + (VT / 64) * SO_CAP;
+constexpr uint32_t CACHE_MAX_ENTRIES = 32;                       // an entry per lane of the bookkeeping registers' low half
+static_assert(A_FULL_END <= ARENA_BYTES && C_DATA + 8192 <= ARENA_BYTES, "the LDS arena holds every use of it");
 constexpr size_t RES_COUNTS = 2;                               // u64 index of counts[0] in the result block
 constexpr size_t RES_IDS = RES_COUNTS + MSI_VM_MAX_COUNTS;     // u64 index where the u32 ids start
 
@@ -77,6 +91,9 @@ struct alignas(16) RoundSub {
   // are WIDE (one workgroup per chunk of the full space: `wide_chunks` of them)
   u64 aux, full_base;
   uint32_t full_words, u0_slot, wide_chunks, wide_mask;
+  // words per workgroup in the list's command phases: CHW (a Roaring container span) for lists over docids; compact lists
+  // take narrower chunks — more workgroups per list, and a chunk of a set small enough that a dozen sets fit in LDS
+  uint32_t chw, cache_on, _pad[2];
 };
 static_assert(sizeof(RoundSub) % 16 == 0, "RoundSub array stays 16-byte aligned");
 
@@ -134,14 +151,15 @@ __device__ __forceinline__ void put4(uint4 *p, uint4 v) {
 
 __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, uint32_t launch_phase) {
   __shared__ uint32_t s_cnt[MSI_VM_MAX_COUNTS];
-  __shared__ u64 s_dec[CHW];
-  __shared__ uint4 s_raw[CHW * 8 / 16 + 2];   // one container body (<= 8 KiB) + alignment slack, staged with wide loads
+  __shared__ __attribute__((aligned(16))) unsigned char s_arena[ARENA_BYTES];
+  u64 *const s_dec = reinterpret_cast<u64 *>(s_arena);              // [CHW]
+  uint4 *const s_raw = reinterpret_cast<uint4 *>(s_arena + A_RAW);  // one container body (<= 8 KiB) + alignment slack, staged with wide loads
+  uint16_t *const s_whole = reinterpret_cast<uint16_t *>(s_arena + A_WHOLE);   // [SUM_W * 64]
+  uint32_t *const s_nzw = reinterpret_cast<uint32_t *>(s_arena + A_NZW);       // [SUM_W * 64]
   __shared__ uint32_t s_scan[VT / 64 + 1];
   __shared__ uint32_t s_last;
   __shared__ int s_any;
   __shared__ u64 s_sum[VT / 64][SUM_W];
-  __shared__ uint16_t s_whole[SUM_W * 64];
-  __shared__ uint32_t s_nzw[SUM_W * 64];
   __shared__ uint32_t s_cmd[CMD_LDS];          // this phase's command words (read once, coalesced)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (fields are read one by one: a by-value copy of the struct lands in scratch because phase_off[] is indexed dynamically)
@@ -198,8 +216,9 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   const uint32_t *const cmd = in_lds ? s_cmd : arena + p_begin;
   uint32_t pcw = 0;                              // word index of the current command
 #define W(i) MSI_UNIFORM(cmd[pcw + (i)])
-  const u64 w0 = (u64)chunk * CHW;
-  const uint32_t nw = wide ? 0u : (uint32_t)min((u64)CHW, r.n_words - w0);   // even: slots are whole 16-byte pairs
+  const uint32_t chw = wide ? CHW : rp->chw;     // words per workgroup (RoundSub::chw)
+  const u64 w0 = (u64)chunk * chw;
+  const uint32_t nw = wide ? 0u : (uint32_t)min((u64)chw, r.n_words - w0);   // even: slots are whole 16-byte pairs
   const uint32_t n_pairs = nw / 2;
   u64 *const pool = reinterpret_cast<u64 *>(r.pool_base);
   auto S = [&](uint32_t slot) -> ulonglong2 * { return reinterpret_cast<ulonglong2 *>(pool + (u64)slot * r.n_words + w0); };
@@ -213,6 +232,108 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   auto add_count = [&](uint32_t idx, uint32_t c) {
     c = wave_sum(c);
     if (lane == 0 && c) atomicAdd(&s_cnt[idx], c);
+  };
+
+  uint32_t cmd_no = 0;
+  // ---- set cache (compact command phases) ---------------------------------------------------------------------------
+  // Round 3 measured the keyword leg at 552 MB of set operands per query through L2 for 116 MB of HBM traffic: every
+  // command loaded its operands from memory again, and a VM_PATHS level re-read the same few dozen condition sets once
+  // per path step — a chain of dependent L2 round trips per (path group, pair).  A compact list's chunk of a set is
+  // `chw * 8` bytes (2 KiB at the default 256 words), so the sets a list works with FIT IN LDS: an entry per set, the
+  // thread that owns pair p of the chunk keeps pair p of every cached set at entry + p — the same thread <-> pair mapping
+  // as in memory, so element-wise commands still need no barrier, and the waves of the workgroup never synchronise:
+  // each keeps its own copy of the bookkeeping (slot -> entry map in LDS, entry -> slot and last-use stamps in the lanes
+  // of two registers) and, every decision being a function of the command stream alone, all copies agree.
+  // Write-through: a store goes to memory (the next list, another workgroup's first-k emit read it there) AND to the
+  // cached copy; nothing is ever written back, eviction is free.  Sets enter the cache where it pays: the operands of
+  // VM_PATHS (conditions, universe, bucket); every other command reads through it and updates what is there.
+  const uint32_t ent_pairs = chw / 2;                                   // pairs per cache entry
+  const uint32_t n_ent = min(CACHE_MAX_ENTRIES, (ARENA_BYTES - C_DATA) / (chw * 8));
+  const bool cache_on = rp->cache_on != 0 && !wide && rp->aux != 0 && ent_pairs <= (uint32_t)VT && n_ent >= 4 &&
+                        wave * 64 < n_pairs;                            // (a wave that owns no pair of this chunk keeps no cache)
+  uint8_t *const c_map = s_arena + C_MAP + wave * 1024;                 // slot -> entry + 1 (0: not cached); pools of <= 1024 slots
+  uint8_t *const c_so = s_arena + C_SO + wave * SO_CAP;                 // the current VM_PATHS: step -> entry + 1
+  ulonglong2 *const c_data = reinterpret_cast<ulonglong2 *>(s_arena + C_DATA);
+  uint32_t v_eslot = 0xFFFFFFFFu, v_estamp = 0;                         // lane e: the slot entry e holds, the command that used it last
+  if (cache_on) {
+    for (uint32_t i = lane; i < 1024 / 4; i += 64) reinterpret_cast<uint32_t *>(c_map)[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+  }
+  auto c_find = [&](uint32_t slot) -> int {   // the entry that holds `slot`, or -1 (wave-uniform)
+    if (!cache_on) return -1;
+    __builtin_amdgcn_wave_barrier();
+    const int e = (int)MSI_UNIFORM((uint32_t)c_map[slot]) - 1;
+    __builtin_amdgcn_wave_barrier();
+    return e;
+  };
+  struct Ref {
+    ulonglong2 *g, *l;   // the chunk of the set in memory; its cached copy (or null)
+  };
+  auto R = [&](uint32_t slot) -> Ref {
+    Ref x;
+    x.g = S(slot);
+    const int e = c_find(slot);
+    x.l = e >= 0 ? c_data + (size_t)e * ent_pairs : nullptr;
+    return x;
+  };
+  auto LD = [&](const Ref &x, uint32_t p) -> ulonglong2 {
+#ifdef MSI_VM_DEBUG_CACHE
+    if (x.l && (x.l[p].x != x.g[p].x || x.l[p].y != x.g[p].y))
+      printf("[cache] LD chunk %u cmd %u pair %u: lds %llx %llx mem %llx %llx\n", chunk, cmd_no, p, x.l[p].x, x.l[p].y, x.g[p].x, x.g[p].y);
+#endif
+    return x.l ? x.l[p] : x.g[p];
+  };
+  auto ST = [&](const Ref &x, uint32_t p, ulonglong2 v) {
+    put(&x.g[p], v);
+    if (x.l) x.l[p] = v;
+  };
+  // `slot` is an operand of the current command: keep it if it is cached, else give it an entry — a free one, or the one
+  // used longest ago by an EARLIER command (entries of the current command are never evicted: the command may hold
+  // references to them) — and note the fill in lane *n_fill of *v_fill.  Nothing is loaded here: the fills of a command
+  // are issued together (c_fill) so that they cost one round trip, not one each.
+  uint32_t v_fill = 0;
+  auto c_plan = [&](uint32_t slot, uint32_t &n_fill) {
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t have = MSI_UNIFORM((uint32_t)c_map[slot]);
+    if (have) {
+      if (lane == have - 1) v_estamp = cmd_no;
+      return;
+    }
+    // key per entry: 0 free, 1 + stamp used by an earlier command, ~0 in use by this command; lanes >= n_ent: ~0
+    uint32_t key = lane < n_ent ? (v_eslot == 0xFFFFFFFFu ? 0u : (v_estamp == cmd_no ? 0xFFFFFFFFu : 1u + v_estamp)) : 0xFFFFFFFFu;
+    uint32_t mn = key;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+    if (mn == 0xFFFFFFFFu) return;   // every entry belongs to this command: the set is read from memory
+    const uint32_t e = (uint32_t)__ffsll((long long)__ballot(key == mn)) - 1;
+    const uint32_t old = (uint32_t)__shfl((int)v_eslot, (int)e);
+    if (lane == 0) {
+      if (old != 0xFFFFFFFFu) c_map[old] = 0;
+      c_map[slot] = (uint8_t)(e + 1);
+    }
+    if (lane == e) {
+      v_eslot = slot;
+      v_estamp = cmd_no;
+    }
+    if (lane == n_fill) v_fill = slot | (e << 16);
+    ++n_fill;
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto c_fill = [&](uint32_t n_fill) {   // the planned entries <- memory, eight loads in flight per thread
+    const bool mine = tid < n_pairs;
+    for (uint32_t g0 = 0; g0 < n_fill; g0 += 8) {
+      ulonglong2 v[8];
+      uint32_t it[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u) {
+        it[u] = (uint32_t)__shfl((int)v_fill, (int)min(g0 + u, 63u));
+        v[u] = make_ulonglong2(0, 0);
+        if (g0 + u < n_fill && mine) v[u] = S(it[u] & 0xFFFFu)[tid];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u)
+        if (g0 + u < n_fill && mine) c_data[(size_t)(it[u] >> 16) * ent_pairs + tid] = v[u];
+    }
   };
 
   // ---- chunk summaries ------------------------------------------------------------------------------------------
@@ -249,7 +370,6 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     c_hi = chunk + 1 < full_chunks ? prefix[fw0 + CHW] : (uint32_t)r.n_docs;
     __syncthreads();
   }
-  uint32_t cmd_no = 0;
   // (one lane writes, the wave's lanes read: wave_barrier keeps the compiler — and the CPU emulation, whose lanes are
   // fibers — from moving a read across a write)
   auto E = [&](uint32_t slot) -> bool {   // this chunk of `slot` is known to be empty
@@ -285,8 +405,8 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   // dst := empty.  Its words are only stored when they may hold something.
   auto make_empty = [&](uint32_t slot) {
     if (E(slot)) return;
-    ulonglong2 *d = S(slot);
-    for (uint32_t p = tid; p < n_pairs; p += VT) put(&d[p], make_ulonglong2(0, 0));
+    const Ref d = R(slot);
+    for (uint32_t p = tid; p < n_pairs; p += VT) ST(d, p, make_ulonglong2(0, 0));
     set_bit(slot, false);
     if (sum_on && lane == 0) s_whole[slot] = 0;
   };
@@ -512,10 +632,13 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       }
     }
     const u64 t_op = prof ? wall_clock64() : 0;
+#ifdef MSI_VM_DEBUG_CACHE
+    { const u64 bb = __ballot(1); if (bb != ~0ull && rp->aux) printf("[sync] chunk %u tid %u before cmd %u op %u ballot %llx\n", chunk, tid, cmd_no + 1, op, bb); }
+#endif
     ++cmd_no;
     switch (op) {
       case VM_FILL: {
-        ulonglong2 *d = S(W(1));
+        const Ref d = R(W(1));
         const bool ones = W(2) != 0;
         if (!ones) {
           make_empty(W(1));
@@ -530,15 +653,14 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
             v.x = doc_mask(w0 + 2 * p, r.n_docs);
             v.y = doc_mask(w0 + 2 * p + 1, r.n_docs);
           }
-          put(&d[p], v);
+          ST(d, p, v);
         }
         pcw += 3;
         break;
       }
       case VM_OP:
       case VM_OP_COUNT: {
-        ulonglong2 *d = S(W(1));
-        const ulonglong2 *a = S(W(2)), *b = S(W(3));
+        const Ref d = R(W(1)), a = R(W(2)), b = R(W(3));
         const uint32_t o = W(4), sd = W(1), sa = W(2), sb = W(3);
         uint32_t c = 0;
         const bool ea = E(sa), eb = E(sb);
@@ -553,8 +675,8 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
           whole(sd);
           u64 any = 0;
           for (uint32_t p = tid; p < n_pairs; p += VT) {
-            const ulonglong2 v = apply_op(o, a[p], b[p]);
-            put(&d[p], v);
+            const ulonglong2 v = apply_op(o, LD(a, p), LD(b, p));
+            ST(d, p, v);
             any |= v.x | v.y;
             c += __popcll(v.x) + __popcll(v.y);
           }
@@ -575,34 +697,44 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         break;
       }
       case VM_CLAIM: {  // bucket |= docs; universe &= ~docs; stack[i] &= ~docs   (docs may be one of the stack slots)
-        const ulonglong2 *docs = S(W(1));
-        ulonglong2 *bucket = S(W(2)), *uni = S(W(3));
+        const Ref docs = R(W(1)), bucket = R(W(2)), uni = R(W(3));
         const uint32_t n = W(4);
         if (E(W(1))) {   // nothing to claim in this chunk
           pcw += 5 + n;
           break;
         }
         partial(W(2));   // (the universe and the stack only lose documents: their bits stay)
-        for (uint32_t p = tid; p < n_pairs; p += VT) {
-          const ulonglong2 dd = docs[p];
-          if (!(dd.x | dd.y)) continue;
-          ulonglong2 b = bucket[p], u = uni[p];
-          b.x |= dd.x; b.y |= dd.y;
-          u.x &= ~dd.x; u.y &= ~dd.y;
-          put(&bucket[p], b);
-          put(&uni[p], u);
-          for (uint32_t k = 0; k < n; ++k) {
-            ulonglong2 *sk = S(W(5 + k));
-            ulonglong2 s = sk[p];
-            s.x &= ~dd.x; s.y &= ~dd.y;
-            put(&sk[p], s);
+        // (a thread owns at most CHW / 2 / VT = 2 pairs of a chunk; the claimed documents stay in registers — `docs` may be
+        // one of the stack slots and is emptied on the way — and every set is looked up once, by the whole wave)
+        constexpr uint32_t PPT = CHW / 2 / VT;
+        ulonglong2 dd[PPT];
+#pragma unroll
+        for (uint32_t j = 0; j < PPT; ++j) {
+          const uint32_t p = tid + j * VT;
+          dd[j] = p < n_pairs ? LD(docs, p) : make_ulonglong2(0, 0);
+          if (!(dd[j].x | dd[j].y)) continue;
+          ulonglong2 b = LD(bucket, p), u = LD(uni, p);
+          b.x |= dd[j].x; b.y |= dd[j].y;
+          u.x &= ~dd[j].x; u.y &= ~dd[j].y;
+          ST(bucket, p, b);
+          ST(uni, p, u);
+        }
+        for (uint32_t k = 0; k < n; ++k) {
+          const Ref sk = R(W(5 + k));
+#pragma unroll
+          for (uint32_t j = 0; j < PPT; ++j) {
+            const uint32_t p = tid + j * VT;
+            if (!(dd[j].x | dd[j].y)) continue;
+            ulonglong2 s = LD(sk, p);
+            s.x &= ~dd[j].x; s.y &= ~dd[j].y;
+            ST(sk, p, s);
           }
         }
         pcw += 5 + n;
         break;
       }
       case VM_AND_MANY: {  // dst[i] = prefix & cond[i], counts[base + i] = |dst[i]|
-        const ulonglong2 *pre = S(W(1));
+        const Ref pre = R(W(1));
         const uint32_t n = W(2), base = W(3);
         const bool epre = E(W(1));
         for (uint32_t k = 0; k < n; ++k) {
@@ -611,16 +743,15 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
             make_empty(sd);
             continue;
           }
-          const ulonglong2 *cnd = S(sc);
-          ulonglong2 *d = S(sd);
+          const Ref cnd = R(sc), d = R(sd);
           uint32_t c = 0;
           whole(sd);
           u64 any = 0;
           for (uint32_t p = tid; p < n_pairs; p += VT) {
-            const ulonglong2 x = pre[p], y = cnd[p];
+            const ulonglong2 x = LD(pre, p), y = LD(cnd, p);
             ulonglong2 v;
             v.x = x.x & y.x; v.y = x.y & y.y;
-            put(&d[p], v);
+            ST(d, p, v);
             any |= v.x | v.y;
             c += __popcll(v.x) + __popcll(v.y);
           }
@@ -636,6 +767,129 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         const uint32_t base = W(4), n_steps = W(5) & 0x7FFFFFFFu;
         const bool fresh = (W(5) >> 31) != 0;   // the bucket's previous content is garbage: this level writes it whole
         const uint32_t *off = cmd + pcw + 6, *steps = off + n_paths + 1;   // read inside the per-pair loop: plain (LDS) loads
+        if (cache_on) {
+          // ---- the level out of LDS (compact lists) ------------------------------------------------------------------
+          // 1. residency: the universe, the bucket and every condition set of the level get a cache entry (what is cached
+          //    already — the conditions of the level before — is only marked as in use); the fills go out together;
+          // 2. every step is resolved to its entry once (c_so);
+          // 3. the thread streams the level's steps eight at a time — codes, then eight LDS reads in flight — and folds
+          //    them into the current path's AND; at a path's end the path claims what the earlier paths left.
+          // One L2 round trip per level (none when everything is resident) instead of one per group of four paths.
+          const bool mine = tid < n_pairs;
+          uint32_t n_fill = 0;
+#ifdef MSI_VM_DEBUG_CACHE
+          { const u64 bb = __ballot(1); if (lane == 0 && bb != ~0ull) printf("[sync A] wave %u cmd %u ballot %llx\n", wave, cmd_no, bb); }
+#endif
+          c_plan(W(3), n_fill);
+          c_plan(W(2), n_fill);
+          for (uint32_t s0 = 0; s0 < n_steps; s0 += 64) {   // mark what is resident, so that planning evicts none of it
+            const uint32_t sidx = s0 + lane;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t code = sidx < n_steps ? (uint32_t)c_map[steps[sidx]] : 0u;
+            uint32_t mask = code ? 1u << (code - 1) : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mask |= (uint32_t)__shfl_xor((int)mask, o);
+            if (lane < 32 && ((mask >> lane) & 1u)) v_estamp = cmd_no;
+          }
+          for (uint32_t s0 = 0; s0 < n_steps; s0 += 64) {
+            const uint32_t sidx = s0 + lane;
+            const uint32_t sl = sidx < n_steps ? steps[sidx] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            u64 miss = __ballot(sidx < n_steps && c_map[sl] == 0);
+            while (miss) {
+              const uint32_t bl = (uint32_t)__ffsll((long long)miss) - 1;
+              miss &= miss - 1;
+              c_plan((uint32_t)__shfl((int)sl, (int)bl), n_fill);   // (looks the map up again: a set planned a moment ago is there)
+            }
+          }
+          c_fill(n_fill);
+#ifdef MSI_VM_DEBUG_CACHE
+          { const u64 bb = __ballot(1); if (lane == 0 && bb != ~0ull) printf("[sync B] wave %u cmd %u ballot %llx\n", wave, cmd_no, bb); }
+#endif
+          __builtin_amdgcn_wave_barrier();
+          for (uint32_t si = lane; si < min(n_steps, SO_CAP); si += 64) c_so[si] = c_map[steps[si]];
+          __builtin_amdgcn_wave_barrier();
+          const Ref ru = R(W(3)), rb = R(W(2));
+          ulonglong2 u = make_ulonglong2(0, 0), b = make_ulonglong2(0, 0);
+          if (mine) {
+            u = LD(ru, tid);
+            if (!fresh) b = LD(rb, tid);
+          }
+          uint32_t k = 0, next_end = n_paths ? MSI_UNIFORM(off[1]) : 0xFFFFFFFFu;
+          ulonglong2 acc = make_ulonglong2(~0ull, ~0ull);
+          auto path_ends = [&]() {   // path k claims universe & AND(its conditions)
+            ulonglong2 m;
+            m.x = u.x & acc.x; m.y = u.y & acc.y;
+            if (m.x | m.y) {
+              b.x |= m.x; b.y |= m.y;
+              u.x &= ~m.x; u.y &= ~m.y;
+              atomicAdd(&s_cnt[base + k], (uint32_t)(__popcll(m.x) + __popcll(m.y)));
+            }
+            ++k;
+            acc = make_ulonglong2(~0ull, ~0ull);
+            next_end = k < n_paths ? MSI_UNIFORM(off[k + 1]) : 0xFFFFFFFFu;
+          };
+          bool left = true;
+          for (uint32_t s0 = 0; s0 < n_steps && left; s0 += 8) {
+            uint32_t code[8];
+            if (s0 + 8 <= SO_CAP) {
+              __builtin_amdgcn_wave_barrier();
+              const uint32_t c0 = MSI_UNIFORM(reinterpret_cast<const uint32_t *>(c_so + s0)[0]);
+              const uint32_t c1 = MSI_UNIFORM(reinterpret_cast<const uint32_t *>(c_so + s0)[1]);
+#pragma unroll
+              for (uint32_t i = 0; i < 4; ++i) {
+                code[i] = (c0 >> (8 * i)) & 0xFFu;
+                code[4 + i] = (c1 >> (8 * i)) & 0xFFu;
+              }
+            } else {
+#pragma unroll
+              for (uint32_t i = 0; i < 8; ++i) code[i] = s0 + i < n_steps ? MSI_UNIFORM((uint32_t)c_map[MSI_UNIFORM(steps[s0 + i])]) : 0u;
+            }
+            ulonglong2 d[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) {
+              d[i] = make_ulonglong2(0, 0);
+              if (s0 + i < n_steps) {
+                if (code[i]) d[i] = c_data[(size_t)(code[i] - 1) * ent_pairs + tid];
+                else if (mine) d[i] = S(MSI_UNIFORM(steps[s0 + i]))[tid];
+#ifdef MSI_VM_DEBUG_CACHE
+                if (mine) {
+                  const ulonglong2 g = S(steps[s0 + i])[tid];
+                  if (g.x != d[i].x || g.y != d[i].y)
+                    printf("[cache] chunk %u cmd %u step %u slot %u code %u: lds %llx %llx mem %llx %llx\n", chunk, cmd_no, s0 + i, steps[s0 + i], code[i], d[i].x, d[i].y, g.x, g.y);
+                }
+#endif
+              }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i)
+              if (s0 + i < n_steps) {
+                while (s0 + i == next_end) path_ends();
+                acc.x &= d[i].x; acc.y &= d[i].y;
+              }
+            left = __any((u.x | u.y) != 0);   // nothing left to claim in this wave's pairs: the rest of the level finds nothing
+          }
+          while (left && k < n_paths) path_ends();
+#ifdef MSI_VM_DEBUG_CACHE
+          if (mine) {
+            ulonglong2 u2 = ru.g[tid], b2 = fresh ? make_ulonglong2(0, 0) : rb.g[tid];
+            for (uint32_t kk = 0; kk < n_paths; ++kk) {
+              ulonglong2 a2 = make_ulonglong2(~0ull, ~0ull);
+              for (uint32_t ss = off[kk]; ss < off[kk + 1]; ++ss) { a2.x &= S(steps[ss])[tid].x; a2.y &= S(steps[ss])[tid].y; }
+              b2.x |= u2.x & a2.x; b2.y |= u2.y & a2.y;
+              u2.x &= ~a2.x; u2.y &= ~a2.y;
+            }
+            if (u2.x != u.x || u2.y != u.y || b2.x != b.x || b2.y != b.y)
+              printf("[cache] PATHS chunk %u cmd %u n_paths %u n_steps %u: u %llx/%llx b %llx/%llx\n", chunk, cmd_no, n_paths, n_steps, u.x, u2.x, b.x, b2.x);
+          }
+#endif
+          if (mine) {
+            ST(rb, tid, b);
+            ST(ru, tid, u);
+          }
+          pcw += 7 + n_paths + n_steps;
+          break;
+        }
         // Paths are resolved four at a time: the condition words of the four paths are loaded back to back (no load
         // waits for the result of another), then the paths claim in order.  A serial "load, AND, test, next step" chain
         // made a level of a few hundred steps cost hundreds of microseconds of pure memory latency per workgroup.
@@ -710,27 +964,27 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         break;
       }
       case VM_SUB_MANY: {  // slot[i] &= ~removed, counts[base + i] = |slot[i]|
-        const ulonglong2 *rm = S(W(1));
+        const Ref rm = R(W(1));
         const uint32_t n = W(2), base = W(3);
         const bool erm = E(W(1));
         for (uint32_t k = 0; k < n; ++k) {
           const uint32_t sd = W(4 + k);
           if (E(sd)) continue;                      // nothing to remove from, nothing to count
-          ulonglong2 *d = S(sd);
+          const Ref d = R(sd);
           uint32_t c = 0;
           if (erm) {                                // nothing removed here: the cardinality is still asked for
             for (uint32_t p = tid; p < n_pairs; p += VT) {
-              const ulonglong2 v = d[p];
+              const ulonglong2 v = LD(d, p);
               c += __popcll(v.x) + __popcll(v.y);
             }
           } else {
             whole(sd);
             u64 any = 0;
             for (uint32_t p = tid; p < n_pairs; p += VT) {
-              const ulonglong2 x = rm[p];
-              ulonglong2 v = d[p];
+              const ulonglong2 x = LD(rm, p);
+              ulonglong2 v = LD(d, p);
               v.x &= ~x.x; v.y &= ~x.y;
-              put(&d[p], v);
+              ST(d, p, v);
               any |= v.x | v.y;
               c += __popcll(v.x) + __popcll(v.y);
             }
@@ -743,11 +997,11 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       }
       case VM_COUNT:
       case VM_FIRSTK: {
-        const ulonglong2 *a = S(W(1));
+        const Ref a = R(W(1));
         uint32_t c = 0;
         if (!E(W(1)))
           for (uint32_t p = tid; p < n_pairs; p += VT) {
-            const ulonglong2 v = a[p];
+            const ulonglong2 v = LD(a, p);
             c += __popcll(v.x) + __popcll(v.y);
           }
         if (op == VM_COUNT) {
@@ -1102,8 +1356,8 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     for (uint32_t c = 0; c < r.n_chunks && running < k; ++c) {
       const uint32_t n_c = __hip_atomic_load(&cc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (!n_c) continue;
-      const u64 cw0 = (u64)c * CHW;
-      const uint32_t cnw = (uint32_t)min((u64)CHW, r.n_words - cw0);
+      const u64 cw0 = (u64)c * chw;
+      const uint32_t cnw = (uint32_t)min((u64)chw, r.n_words - cw0);
       const u64 *a = pool + (u64)slot * r.n_words + cw0;
       u64 w[WPT];
       uint32_t mine = 0;
@@ -1357,13 +1611,21 @@ void VmCombiner::run() {
       const uint64_t g = b->list->geom_docs;
       return g ? std::max<uint64_t>(2, ((g + 127) / 128) * 2) : msi_bits_words_per_slot(b->pool);
     };
+    // words per workgroup in a list's command phases (RoundSub::chw): compact lists take narrower chunks, so that a dozen
+    // sets of a chunk fit in the kernel's LDS set cache.  MSI_VM_COMPACT_CHW = 128 | 256 | 512 | 1024 (experiments)
+    static const uint32_t compact_chw = [] {
+      const int v = getenv("MSI_VM_COMPACT_CHW") ? atoi(getenv("MSI_VM_COMPACT_CHW")) : 256;
+      return (v == 128 || v == 256 || v == 512 || v == 1024) ? (uint32_t)v : 256u;
+    }();
+    static const bool cache_off = getenv("MSI_VM_CACHE") && getenv("MSI_VM_CACHE")[0] == '0';   // experiments: every operand from memory
+    auto chw_of = [&](const VmSub *b) -> uint32_t { return b->list->geom_docs ? compact_chw : CHW; };
     uint32_t max_chunks[MSI_VM_MAX_PHASES] = {0}, max_phases = 1;
     for (size_t i = 0; i < n_sub; ++i) {
       const MsiVmList &l = *batch[i]->list;
       words_at[i] = off;
       off = align16(off + (l.words.size() + 1) * 4);
       state_at[i] = off;
-      const uint32_t n_chunks = (uint32_t)((words_of(batch[i]) + CHW - 1) / CHW);
+      const uint32_t n_chunks = (uint32_t)((words_of(batch[i]) + chw_of(batch[i]) - 1) / chw_of(batch[i]));
       off = align16(off + 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)n_chunks * 4 * l.max_fk_phase);
     }
     int32_t st = MSI_OK;
@@ -1387,7 +1649,9 @@ void VmCombiner::run() {
         r.n_docs = l.geom_docs ? l.geom_docs : msi_bits_n_docs(p);
         r.host_res = (u64)(uintptr_t)batch[i]->blk;
         r.seq = batch[i]->seq;
-        r.n_chunks = (uint32_t)((r.n_words + CHW - 1) / CHW);
+        r.chw = chw_of(batch[i]);
+        r.cache_on = cache_off ? 0u : 1u;
+        r.n_chunks = (uint32_t)((r.n_words + r.chw - 1) / r.chw);
         r.n_phases = (uint32_t)l.phase_start.size();
         for (uint32_t ph = 0; ph < r.n_phases; ++ph) r.phase_off[ph] = (uint32_t)(words_at[i] / 4) + l.phase_start[ph];
         r.list_off = (uint32_t)(words_at[i] / 4);
@@ -1409,7 +1673,9 @@ void VmCombiner::run() {
           r.wide_mask = l.pre_merged ? 1u : 0u;
           // phases 0 and 1 in one launch (vm_kernel, `fused`): only while the waiting workgroups are few
           static const bool fuse_off = getenv("MSI_VM_FUSE") && getenv("MSI_VM_FUSE")[0] == '0';   // experiments
-          if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= 4 && !fuse_off) r.wide_mask |= 0x80000000u;
+          // (the waiting workgroups of a list follow its own wide workgroups in dispatch order, so they can only ever wait
+          // for workgroups that are already resident: the bound keeps spinning workgroups few, it is not what makes this safe)
+          if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= 32 && !fuse_off) r.wide_mask |= 0x80000000u;
         } else {
           static const bool sum_off = getenv("MSI_VM_SUMMARY") && getenv("MSI_VM_SUMMARY")[0] == '0';   // diagnostics
           const uint64_t sp = sum_off ? 0 : (uint64_t)(uintptr_t)msi_bits_summary(p);

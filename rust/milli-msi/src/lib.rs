@@ -24,6 +24,11 @@ unsafe impl Sync for GpuContext {} // every entry point is thread-safe; calls se
 impl GpuContext {
     /// `device < 0`: `$LOCAL_RANK` if set, else device 0.  Fails unless a gfx950 device is present.
     pub fn new(device: i32) -> Result<Self, GpuError> {
+        // the struct layouts of sys.rs are those of ABI 2 (msi_search_params: geo_strategy, geo_cache_size, index_view)
+        let abi = unsafe { sys::msi_abi_version() };
+        if abi != sys::MSI_ABI_VERSION {
+            return Err(GpuError { status: sys::MSI_E_UNSUPPORTED, message: format!("libmsi ABI {abi} != {}", sys::MSI_ABI_VERSION) });
+        }
         let mut p = ptr::null_mut();
         check(unsafe { sys::msi_ctx_create(device, &mut p) })?;
         Ok(Self(NonNull::new(p).expect("msi_ctx_create returned NULL with MSI_OK")))

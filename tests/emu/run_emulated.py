@@ -77,7 +77,7 @@ def main(argv):
         sys.path.insert(0, ROOT)
     from meilisearch_amd import _lib
     _lib._LIB = EmulatedLib(build())
-    assert _lib.lib().msi_abi_version() == 1
+    assert _lib.lib().msi_abi_version() == 2
     os.environ["MSI_RUNNER_SO"] = build_runner()
     import pytest
     return pytest.main(argv)

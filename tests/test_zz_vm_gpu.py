@@ -241,3 +241,19 @@ def test_index_views_do_not_share_what_the_engine_remembers():
     assert stats["hits"] > 0
     bad_unnamed, _ = run(named=False)              # (after the named pass: the plain index's keys are warm)
     assert bad_unnamed > 0
+
+
+def test_a_page_past_what_one_list_reads_back():
+    """offset + limit above MSI_VM_MAX_FIRSTK (8192 ids per list): the ids come from the direct first-k kernel, which reads
+    docids — so such a search must not have moved into the compact space, where a set holds ranks (with
+    MSI_SEARCH_COMPACT=2 this returned "a bucket held fewer documents than its cardinality said", or ranks as docids).
+    The CPU tier runs this file with compaction forced."""
+    from tests.toy_milli import ToyMilli
+    docs = [{"id": i, "title": "apple" if i % 2 == 0 else "pear"} for i in range(17000)]
+    index = ToyMilli(docs, searchable=["title"], criteria=["words"])
+    h = Harness(index, n_slots=128)
+    hits, cand = h.search("apple", criteria=["words"], offset=8200, limit=5)
+    assert [d for d, _ in hits] == [16400, 16402, 16404, 16406, 16408]
+    assert cand == 8500
+    hits, _ = h.search("apple", criteria=["words"], offset=8180, limit=5)     # still inside one list: the compact path
+    assert [d for d, _ in hits] == [16360, 16362, 16364, 16366, 16368]

@@ -34,7 +34,7 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed)
     alpha = ALPHABETS[int(rng.integers(len(ALPHABETS)))]
     n_words = int(rng.choice([1, 2, 30, 300, 2000, 6000]))
-    lo, hi = (1, 6) if rng.random() < 0.2 else (3, int(rng.choice([8, 14, 40])))
+    lo, hi = (1, 6) if rng.random() < 0.2 else (3, int(rng.choice([8, 14, 40, 90])))   # 90: queries past 64 chars take the banded matcher
     words = set()
     tries = 0
     while len(words) < n_words and tries < 20 * n_words + 100:
