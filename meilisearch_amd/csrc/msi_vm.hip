@@ -67,6 +67,7 @@ constexpr uint32_t CMD_LDS = 2048;                             // command words 
 constexpr uint32_t ARENA_BYTES = MSI_VM_ARENA_KB * 1024;
 constexpr uint32_t A_RAW = CHW * 8, A_WHOLE = A_RAW + CHW * 8 + 32, A_NZW = A_WHOLE + SUM_W * 64 * 2, A_FULL_END = A_NZW + SUM_W * 64 * 4;
 constexpr uint32_t A_DESC = A_WHOLE;                             // wide phase: the chunk's decode descriptors (as much as fits)
+constexpr uint32_t DESC_WORDS = (ARENA_BYTES - A_DESC) / 4;
 constexpr uint32_t SO_CAP = 1024;                                // path steps of one VM_PATHS resolved ahead per wave (u8 each)
 constexpr uint32_t C_MAP = 0, C_SO = C_MAP + (VT / 64) * 1024, C_DATA = C_SO + (VT / 64) * SO_CAP;
 constexpr uint32_t CACHE_MAX_ENTRIES = 32;                       // an entry per lane of the bookkeeping registers' low half
@@ -356,6 +357,25 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   __syncthreads();
   // wide phase (VM_DECODEC): this chunk's words of U0 and their exclusive prefix counts, once for all the phase's commands
   uint32_t c_lo = 0, c_hi = 0;
+  uint32_t *const s_desc = reinterpret_cast<uint32_t *>(s_arena + A_DESC);
+  const uint32_t *desc_g = nullptr;   // the chunk's descriptor block in memory; its first desc_n words are in s_desc
+  uint32_t desc_n = 0;
+  const uint32_t desc_st = (r.n_decodes + 1 + 3) & ~3u;   // words of the block's start[] table
+  auto DW = [&](uint32_t i) -> uint32_t { return i < desc_n ? s_desc[i] : desc_g[i]; };
+  auto DC = [&](uint32_t ci) -> VmContainer {   // container ci of the chunk's block
+    const uint32_t w = desc_st + 4 * ci;
+    if (w + 4 <= desc_n) return *reinterpret_cast<const VmContainer *>(s_desc + w);
+    return *reinterpret_cast<const VmContainer *>(desc_g + w);
+  };
+  // a 16-bit value of a container body (bodies are 2-byte aligned in every serialisation roaring writes; behind a run
+  // cookie with fewer than four containers they can start at an odd offset: bytes then)
+  auto ld16 = [&](uintptr_t b0, uint32_t i) -> uint32_t {
+    if (b0 & 1) {
+      const uint8_t *q = reinterpret_cast<const uint8_t *>(b0) + 2 * (size_t)i;
+      return (uint32_t)q[0] | ((uint32_t)q[1] << 8);
+    }
+    return reinterpret_cast<const uint16_t *>(b0)[i];
+  };
   if (wide) {
     const uint32_t full_words = rp->full_words, full_chunks = rp->wide_chunks;
     const uint32_t *prefix = reinterpret_cast<const uint32_t *>(rp->aux) + ((full_chunks + 3) & ~3u);
@@ -368,6 +388,16 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     }
     c_lo = prefix[fw0];
     c_hi = chunk + 1 < full_chunks ? prefix[fw0 + CHW] : (uint32_t)r.n_docs;
+    // this chunk's decode descriptors (one contiguous block of the list: start[n_decodes + 1], padded to 16 bytes, then the
+    // 16-byte containers) come to LDS with the tables: read from memory per command they were three dependent loads — block
+    // offset, container range, container — in front of every decode's first posting byte
+    if (r.n_decodes) {
+      const uint32_t *data = arena + r.list_off + r.data_off;
+      const uint32_t o0 = data[chunk], o1 = data[chunk + 1];   // 16-byte units
+      desc_g = data + 4 * (size_t)o0;
+      desc_n = min((o1 - o0) * 4u, DESC_WORDS);
+      for (uint32_t i = tid; i < desc_n / 4; i += VT) reinterpret_cast<uint4 *>(s_desc)[i] = reinterpret_cast<const uint4 *>(desc_g)[i];
+    }
     __syncthreads();
   }
   // (one lane writes, the wave's lanes read: wave_barrier keeps the compiler — and the CPU emulation, whose lanes are
@@ -503,22 +533,17 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     const uint32_t lo = c_lo, hi = c_hi, total = (uint32_t)r.n_docs;
     const uint32_t fwd = lo >> 6, n_out = hi > lo ? ((hi - 1) >> 6) - fwd + 1 : 0;
     u64 *w_out = reinterpret_cast<u64 *>(s_raw) + wave * 256;
-    const uint32_t *data = arena + r.list_off + r.data_off;
-    const uint32_t *blk_c = r.n_decodes ? data + 4 * (size_t)data[chunk] : nullptr;
-    const VmContainer *cs_all = blk_c ? reinterpret_cast<const VmContainer *>(blk_c + ((r.n_decodes + 1 + 3) & ~3u)) : nullptr;
     const uint32_t n_cmd = (p_end - p_begin) / 3;   // 3 words per command, then VM_END
     for (uint32_t k = wave; k < n_cmd; k += VT / 64) {
       if (MSI_UNIFORM(cmd[3 * k]) != VM_DECODEC) break;   // (cannot happen: the host records nothing else into a wide phase)
       const uint32_t dsts = MSI_UNIFORM(cmd[3 * k + 1]), srcw = MSI_UNIFORM(cmd[3 * k + 2]);
       const bool from_slot = (srcw >> 31) != 0;
-      const VmContainer *cs = nullptr;
-      uint32_t n_here = 0;
+      uint32_t n_here = 0, c_first = 0;
       if (!from_slot) {
-        const uint32_t c_first = blk_c[srcw];
-        n_here = blk_c[srcw + 1] - c_first;
-        cs = cs_all + c_first;
+        c_first = DW(srcw);
+        n_here = DW(srcw + 1) - c_first;
         for (uint32_t ci = 0; ci < n_here; ++ci) {   // first reader of a key: its bodies go into the posting cache
-          const VmContainer c = cs[ci];
+          const VmContainer c = DC(c_first + ci);
           if (c.fill_lo == 0xFFFFFFFFu && (c.meta >> 19) == 0x1FFFu) continue;
           const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
           const u64 fill_off = ((u64)(c.meta >> 19) << 32) | c.fill_lo;
@@ -555,31 +580,46 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         }
       } else {
         for (uint32_t ci = 0; ci < n_here; ++ci) {
-          const VmContainer c = cs[ci];
+          const VmContainer c = DC(c_first + ci);
           const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
           const uintptr_t b0 = ((c.meta >> 18) & 1u) ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
-          const uint16_t *h = reinterpret_cast<const uint16_t *>(b0);   // bodies are 2-byte aligned
-          if (type == 0) {
+          if (type == 0) {   // array: four loads of the wave in flight (512 bytes), then the look-ups
             const uint32_t n = min(card + 1, 4096u);
-            for (uint32_t i = lane; i < n; i += 64) {
-              const uint32_t v = h[i];
-              if ((s_dec[v >> 6] >> (v & 63)) & 1ull) rank_bits(v >> 6, 1ull << (v & 63));
+            for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+              uint32_t v[4];
+#pragma unroll
+              for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * 64 + lane;
+                v[u] = i < n ? ld16(b0, i) : 0xFFFFFFFFu;
+              }
+#pragma unroll
+              for (uint32_t u = 0; u < 4; ++u)
+                if (v[u] != 0xFFFFFFFFu && ((s_dec[v[u] >> 6] >> (v[u] & 63)) & 1ull)) rank_bits(v[u] >> 6, 1ull << (v[u] & 63));
             }
           } else if (type == 1) {
             const bool al8 = (b0 & 7) == 0;
-            for (uint32_t wi = lane; wi < CHW; wi += 64) {
-              const u64 uw = s_dec[wi];
-              if (!uw) continue;
-              u64 v;
-              if (al8) v = reinterpret_cast<const u64 *>(b0)[wi];
-              else v = (u64)h[4 * wi] | ((u64)h[4 * wi + 1] << 16) | ((u64)h[4 * wi + 2] << 32) | ((u64)h[4 * wi + 3] << 48);
-              const u64 m = v & uw;
-              if (m) rank_bits(wi, m);
+            for (uint32_t w0i = 0; w0i < CHW; w0i += 256) {   // bitmap: only the words where U0 has a document, four in flight
+              u64 uw[4], v[4];
+#pragma unroll
+              for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t wi = w0i + u * 64 + lane;
+                uw[u] = s_dec[wi];
+                v[u] = 0;
+                if (uw[u]) {
+                  if (al8) v[u] = reinterpret_cast<const u64 *>(b0)[wi];
+                  else v[u] = (u64)ld16(b0, 4 * wi) | ((u64)ld16(b0, 4 * wi + 1) << 16) | ((u64)ld16(b0, 4 * wi + 2) << 32) | ((u64)ld16(b0, 4 * wi + 3) << 48);
+                }
+              }
+#pragma unroll
+              for (uint32_t u = 0; u < 4; ++u) {
+                const u64 m = v[u] & uw[u];
+                if (m) rank_bits(w0i + u * 64 + lane, m);
+              }
             }
           } else {
             const uint32_t n_runs = min(card + 1, 2048u);
             for (uint32_t rr = 0; rr < n_runs; ++rr) {
-              const uint32_t start = h[2 * rr], last = min(65535u, start + (uint32_t)h[2 * rr + 1]);
+              const uint32_t start = ld16(b0, 2 * rr), last = min(65535u, start + ld16(b0, 2 * rr + 1));
               for (uint32_t wi = (start >> 6) + lane; wi <= (last >> 6); wi += 64) {
                 const u64 uw = s_dec[wi];
                 if (!uw) continue;
@@ -1125,17 +1165,13 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
         const uint32_t nwf = (uint32_t)min((u64)CHW, (u64)full_words - fw0);
         const uint32_t lo = c_lo, hi = c_hi, total = (uint32_t)r.n_docs;
         const bool from_slot = (srcw >> 31) != 0;
-        const VmContainer *cs = nullptr;
-        uint32_t n_here = 0;
+        uint32_t n_here = 0, c_first = 0;
         if (!from_slot) {
-          const uint32_t *data = arena + r.list_off + r.data_off;
-          const uint32_t *blk_c = data + 4 * (size_t)data[chunk];
-          const uint32_t c_first = blk_c[srcw];
-          n_here = blk_c[srcw + 1] - c_first;
-          cs = reinterpret_cast<const VmContainer *>(blk_c + ((r.n_decodes + 1 + 3) & ~3u)) + c_first;
+          c_first = DW(srcw);
+          n_here = DW(srcw + 1) - c_first;
           // first reader of a key: its bodies go into the posting cache, whatever U0 holds in this chunk
           for (uint32_t ci = 0; ci < n_here; ++ci) {
-            const VmContainer c = cs[ci];
+            const VmContainer c = DC(c_first + ci);
             if (c.fill_lo == 0xFFFFFFFFu && (c.meta >> 19) == 0x1FFFu) continue;
             const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
             const u64 fill_off = ((u64)(c.meta >> 19) << 32) | c.fill_lo;
@@ -1175,14 +1211,13 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
             }
           } else {
             for (uint32_t ci = wave; ci < n_here; ci += VT / 64) {   // a wave per container
-              const VmContainer c = cs[ci];
+              const VmContainer c = DC(c_first + ci);
               const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
               const uintptr_t b0 = ((c.meta >> 18) & 1u) ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
-              const uint16_t *h = reinterpret_cast<const uint16_t *>(b0);   // bodies are 2-byte aligned
               if (type == 0) {          // array: the values themselves
                 const uint32_t n = min(card + 1, 4096u);
                 for (uint32_t i = lane; i < n; i += 64) {
-                  const uint32_t v = h[i];
+                  const uint32_t v = ld16(b0, i);
                   if ((s_dec[v >> 6] >> (v & 63)) & 1ull) rank_bits(v >> 6, 1ull << (v & 63));
                 }
               } else if (type == 1) {   // bitmap: only the words where U0 has a document are read
@@ -1192,14 +1227,14 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
                   if (!uw) continue;
                   u64 v;
                   if (al8) v = reinterpret_cast<const u64 *>(b0)[wi];
-                  else v = (u64)h[4 * wi] | ((u64)h[4 * wi + 1] << 16) | ((u64)h[4 * wi + 2] << 32) | ((u64)h[4 * wi + 3] << 48);
+                  else v = (u64)ld16(b0, 4 * wi) | ((u64)ld16(b0, 4 * wi + 1) << 16) | ((u64)ld16(b0, 4 * wi + 2) << 32) | ((u64)ld16(b0, 4 * wi + 3) << 48);
                   const u64 m = v & uw;
                   if (m) rank_bits(wi, m);
                 }
               } else {                  // runs: (start, length - 1) pairs
                 const uint32_t n_runs = min(card + 1, 2048u);
                 for (uint32_t rr = 0; rr < n_runs; ++rr) {
-                  const uint32_t start = h[2 * rr], last = min(65535u, start + (uint32_t)h[2 * rr + 1]);
+                  const uint32_t start = ld16(b0, 2 * rr), last = min(65535u, start + ld16(b0, 2 * rr + 1));
                   for (uint32_t wi = (start >> 6) + lane; wi <= (last >> 6); wi += 64) {
                     const u64 uw = s_dec[wi];
                     if (!uw) continue;
@@ -1613,11 +1648,14 @@ void VmCombiner::run() {
     };
     // words per workgroup in a list's command phases (RoundSub::chw): compact lists take narrower chunks, so that a dozen
     // sets of a chunk fit in the kernel's LDS set cache.  MSI_VM_COMPACT_CHW = 128 | 256 | 512 | 1024 (experiments)
-    static const uint32_t compact_chw = [] {
-      const int v = getenv("MSI_VM_COMPACT_CHW") ? atoi(getenv("MSI_VM_COMPACT_CHW")) : 256;
+    // (both knobs are read per round, so that one process can measure the variants side by side: tools/ranked_bench RB_VARIANTS)
+    const uint32_t compact_chw = [] {
+      const char *e = getenv("MSI_VM_COMPACT_CHW");
+      const int v = e ? atoi(e) : 256;
       return (v == 128 || v == 256 || v == 512 || v == 1024) ? (uint32_t)v : 256u;
     }();
-    static const bool cache_off = getenv("MSI_VM_CACHE") && getenv("MSI_VM_CACHE")[0] == '0';   // experiments: every operand from memory
+    const char *cache_knob = getenv("MSI_VM_CACHE");
+    const bool cache_off = cache_knob && cache_knob[0] == '0';   // experiments: every operand from memory
     auto chw_of = [&](const VmSub *b) -> uint32_t { return b->list->geom_docs ? compact_chw : CHW; };
     uint32_t max_chunks[MSI_VM_MAX_PHASES] = {0}, max_phases = 1;
     for (size_t i = 0; i < n_sub; ++i) {
@@ -1675,7 +1713,7 @@ void VmCombiner::run() {
           static const bool fuse_off = getenv("MSI_VM_FUSE") && getenv("MSI_VM_FUSE")[0] == '0';   // experiments
           // (the waiting workgroups of a list follow its own wide workgroups in dispatch order, so they can only ever wait
           // for workgroups that are already resident: the bound keeps spinning workgroups few, it is not what makes this safe)
-          if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= 32 && !fuse_off) r.wide_mask |= 0x80000000u;
+          if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= 160 && !fuse_off) r.wide_mask |= 0x80000000u;
         } else {
           static const bool sum_off = getenv("MSI_VM_SUMMARY") && getenv("MSI_VM_SUMMARY")[0] == '0';   // diagnostics
           const uint64_t sp = sum_off ? 0 : (uint64_t)(uintptr_t)msi_bits_summary(p);

@@ -430,8 +430,30 @@ int main(int argc, char **argv) {
     msi_bits_destroy(pool);
 #endif
   }
+  // RB_VARIANTS="K=V,K=V;K=V;...": one environment per thread-count argument (in order; the library reads its experiment
+  // knobs per round), so that one process — one index, one warm posting cache — measures variants side by side
+  std::vector<std::string> variants;
+  if (const char *v = getenv("RB_VARIANTS")) {
+    std::string cur;
+    for (const char *c = v;; ++c) {
+      if (*c == ';' || !*c) { variants.push_back(cur); cur.clear(); if (!*c) break; }
+      else cur.push_back(*c);
+    }
+  }
   for (int a = 5; a < argc; ++a) {
     const int n_threads = atoi(argv[a]);
+    if ((size_t)(a - 5) < variants.size()) {
+      std::string kv;
+      const std::string &vs = variants[a - 5];
+      for (size_t i = 0; i <= vs.size(); ++i) {
+        if (i == vs.size() || vs[i] == ',') {
+          const size_t eq = kv.find('=');
+          if (eq != std::string::npos) setenv(kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str(), 1);
+          kv.clear();
+        } else kv.push_back(vs[i]);
+      }
+      fprintf(stderr, "[ranked_bench] variant %d: %s\n", a - 5, vs.c_str());
+    }
     std::vector<msi_bits *> pools(n_threads);
 #ifdef RANKED_BENCH_CPU
     for (auto &p : pools) p = mock_bits_create(n_docs, 1024);
