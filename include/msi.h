@@ -855,6 +855,10 @@ int32_t msi_bits_vm_bytes(uint64_t out[3]);
  * [kernel launches, stream syncs, decode batches, index callbacks, posting bytes decoded, matching paths,
  *  buckets, callback microseconds, device-wait microseconds, total microseconds]. */
 int32_t msi_search_last_stats(uint64_t out[10]);
+/* Diagnostics, process-wide, collected while MSI_SEARCH_CPU_PROFILE is set in the environment: HOST CPU (thread CPU time,
+ * nanoseconds; a sleeping waiter costs none) of the keyword leg — [searches, whole searches, inside the command-list
+ * submission + wait, of it finalising the list, typo derivations, index callbacks (wall), the combiner threads, lists]. */
+int32_t msi_search_cpu_profile(uint64_t out[8]);
 /* Diagnostics, process-wide: [ranked keyword searches, of them continued in the COMPACT SPACE (once a search knows its
  * universe — the documents that match the query at all — every later set is kept over the ranks of the documents inside
  * it, |universe| bits instead of n_docs: DESIGN.md §4.7.2), documents of those universes summed]. */

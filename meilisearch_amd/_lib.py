@@ -262,6 +262,7 @@ PROTOTYPES = {
                                          C.POINTER(SearchParams), _VP, C.c_size_t, _VP, _VP, _VP,
                                          C.POINTER(_U32), C.POINTER(_U64), C.POINTER(_I32)]),
     "msi_search_last_stats": (_I32, [C.POINTER(_U64)]),
+    "msi_search_cpu_profile": (_I32, [C.POINTER(_U64)]),
     "msi_search_compaction_stats": (_I32, [C.POINTER(_U64)]),
     "msi_bits_vm_bytes": (_I32, [C.POINTER(_U64)]),
     "msi_bits_geo_list": (_I32, [_VP, _VP, _U32, C.c_double, C.c_double, _U32, _VP, _VP, C.POINTER(_U64)]),

@@ -48,11 +48,14 @@ typedef unsigned long long u64;
 
 namespace {
 
-constexpr int LW = 8;             // waves per workgroup; one workgroup walks one query's dictionary range
-constexpr int LT = LW * 64;
+constexpr int LW = 4;             // waves per workgroup of the matcher kernel; one workgroup walks one query's dictionary range
+constexpr int LT = LW * 64;       // (round 4: 4 waves instead of 8 — a CU then holds as many workgroups as its registers allow waves per
+                                  //  SIMD, and the kernel is bound by how many scanning waves are resident: see dict_lookup_kernel)
+constexpr int XW = 8;             // waves per workgroup of the other-first-letter kernel
+constexpr int XT = XW * 64;
 constexpr int QSTRIDE = 256;      // code points reserved per query
 constexpr int PQ = 256;           // survivor ring entries per wave (power of two, >= 63 + 64)
-constexpr int XB = LT / 2;        // first-char blocks searched per round of the other-first-char step
+constexpr int XB = XT / 2;        // first-char blocks searched per round of the other-first-char step
 constexpr int DINF = 1 << 20;
 constexpr uint32_t QNONE = 0xFFFFFFFFu;  // "no such query char": never equals a word char
 
@@ -74,7 +77,14 @@ static_assert(sizeof(QueryMeta) == 64, "QueryMeta is one 64-byte line");
 // bits 9..63 the char-presence signature: bit 9 + hash55(code point) set for every char of the word.
 constexpr u64 FILT_VALID = 1ull << 8;
 constexpr u64 FILT_SIG = ~0x1FFull;
-__host__ __device__ __forceinline__ uint32_t sig_bit(uint32_t cp) { return 9u + ((((cp * 0x9E3779B1u) >> 16) * 55u) >> 16); }
+// The 55 signature positions: one each for a-z and 0-9 (what nearly every char of a normalised word is: no collisions
+// among them), 19 shared by every other code point.  (A plain 55-way hash of all code points let a third more words
+// through the filter than round 3's 64-bit one: 2 695 instead of 2 029 matcher pairs per query at C3.)
+__host__ __device__ __forceinline__ uint32_t sig_bit(uint32_t cp) {
+  if (cp - (uint32_t)'a' < 26u) return 9u + (cp - (uint32_t)'a');
+  if (cp - (uint32_t)'0' < 10u) return 9u + 26u + (cp - (uint32_t)'0');
+  return 9u + 36u + ((((cp * 0x9E3779B1u) >> 16) * 19u) >> 16);
+}
 __device__ __forceinline__ u64 pair_key(uint32_t a, uint32_t b) { return (u64)a | ((u64)b << 32); }
 
 __device__ __forceinline__ uint32_t utf8_len(uint32_t b0) {
@@ -303,9 +313,13 @@ struct DictArgs {
   uint32_t nq;
   uint32_t cap1, cap2, capx;
   uint32_t *wlists;          // [grid][LW][cap1+cap2] per-wave hit lists (distance 1 | distance 2)
-  uint32_t *xlists;          // [grid][capx] other-first-char words at distance <= 1
+  uint32_t *xq;              // [nq][capx] other-first-char words at distance <= 1 (dict_other_kernel) ...
+  uint32_t *xq_cnt;          // [nq]       ... and how many
   uint32_t *ticket;          // next query to take
+  uint32_t m_lo, m_hi;       // this launch matches the queries of m_lo..m_hi chars (the other launch takes the rest)
+  const uint32_t *n_long;    // queries above 64 chars in the batch (dict_prep_kernel); null = not consulted
   u64 *pairs;                // stats: (query, word) pairs that reached a DP lane
+  u64 *prof;                 // MSI_DICT_PROFILE: thread 0's wall-clock ticks (100 MHz) per phase, summed over queries (else null)
   uint32_t *out_one, *out_one_cnt, *out_two, *out_two_cnt;
 };
 
@@ -390,28 +404,20 @@ struct WaveLists {
 //           exact strings (prefix rule: string prefixes), so they are binary searches in the sorted dictionary —
 //           two per dictionary first char c, two more for the shapes without c — instead of a scan.
 //   caps    the reference's sequential cap logic in closed form (header of this file) over the three lists.
-template <bool BITS>
-__global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
-  __shared__ u64 s_pa[128];            // PEq: ASCII chars (BITS)
-  __shared__ uint32_t s_pk[128];       //      other code points: keys ...
-  __shared__ u64 s_pv[128];            //      ... and their position masks
-  __shared__ uint32_t s_q[QSTRIDE];
+// The words with ANOTHER first char than the query's: they match only at distance <= 1, through one edit on position 0 —
+// exact strings (string prefixes under the prefix rule), i.e. binary searches in the sorted dictionary.  A kernel of its own
+// since round 4: inside dict_lookup_kernel its registers (patterns, comparison loops) were what kept that kernel — bound
+// by how many range-scanning waves are resident — at one workgroup per CU.  One workgroup per budget-2 query (ticket);
+// the result, in dictionary order, goes to a.xq[q] / a.xq_cnt[q], read by the cap logic of dict_lookup_kernel.
+__global__ __launch_bounds__(XT) void dict_other_kernel(DictArgs a) {
   __shared__ uint8_t s_qb[256];
-  __shared__ uint32_t s_pq[LW][PQ];
-  __shared__ uint32_t s_wcnt[LW][2];
   __shared__ uint32_t s_xr[XB][4];     // per first-char block of the round: (a) range, (c) range
-  __shared__ u64 s_xany[LW];
+  __shared__ u64 s_xany[XW];
   __shared__ uint32_t s_ext[2][2];     // the two shapes without a dictionary first char: delete q0, swap q0 q1
   __shared__ uint32_t s_query, s_xdone;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u64 lower = (1ull << lane) - 1ull;
-  const uint32_t stride_w = a.cap1 + a.cap2;
-  uint32_t *const wl = a.wlists + ((size_t)blockIdx.x * LW + wave) * stride_w;
-  uint32_t *const xl = a.xlists + (size_t)blockIdx.x * a.capx;
-  u64 pairs = 0;
-
   for (;;) {
-    __syncthreads();  // the previous query's LDS state is no longer read
+    __syncthreads();
     if (tid == 0) {
       s_query = atomicAdd(a.ticket, 1u);
       s_xdone = 0;
@@ -421,133 +427,15 @@ __global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
     if (q >= a.nq) break;
     const QueryMeta qm = a.qm[q];
     const int K = (int)qm.budget;
-    if (K == 0) {
-      if (tid == 0) a.out_one_cnt[q] = a.out_two_cnt[q] = 0;
-      continue;
-    }
     const int m = (int)qm.m;
     const bool prefix = qm.prefix != 0;
-    for (uint32_t i = tid; i < (uint32_t)m; i += LT) s_q[i] = a.qchars[(size_t)q * QSTRIDE + i];
-    for (uint32_t i = tid; i < qm.qlen; i += LT) s_qb[i] = a.qbytes[a.qoff[q] + i];
-    const bool bits = BITS && m <= 64;   // (wave- and workgroup-uniform: the query's)
-    if (bits && tid < 128) {
-      s_pa[tid] = 0ull;
-      s_pk[tid] = PEQ_EMPTY;
-      s_pv[tid] = 0ull;
+    uint32_t *const xl = a.xq + (size_t)q * a.capx;
+    if (!(K == 2 && a.n_fc > 0)) {
+      if (tid == 0) a.xq_cnt[q] = 0;
+      continue;
     }
+    for (uint32_t i = tid; i < qm.qlen; i += XT) s_qb[i] = a.qbytes[a.qoff[q] + i];
     __syncthreads();
-    if (bits && tid < (uint32_t)m) {      // thread = query position
-      const uint32_t c = s_q[tid];
-      if (c < 128u) {
-        atomicOr(&s_pa[c], 1ull << tid);
-      } else {
-        uint32_t h = (c * 0x9E3779B1u) >> 25;
-        for (;;) {   // <= 64 distinct keys in 128 slots: a free slot always turns up
-          const uint32_t k = atomicCAS(&s_pk[h], PEQ_EMPTY, c);
-          if (k == PEQ_EMPTY || k == c) break;
-          h = (h + 1u) & 127u;
-        }
-        atomicOr(&s_pv[h], 1ull << tid);
-      }
-    }
-    if (bits) __syncthreads();
-    QChars qs;
-    qs.q = s_q;
-    qs.m = m;
-    PEq pq;
-    pq.ascii = s_pa;
-    pq.key = s_pk;
-    pq.val = s_pv;
-
-    // ---- scan: the same-first-char range ------------------------------------------------------------
-    uint32_t cnt0 = 0, cnt1 = 0;      // hits of this wave at distance 1 / 2 (wave-uniform)
-    uint32_t head = 0, qn = 0;        // ring state (wave-uniform)
-    auto drain = [&](uint32_t n) {
-      const bool act = lane < n;
-      const uint32_t idx = act ? s_pq[wave][(head + lane) & (PQ - 1)] : 0u;
-      const uint4 slot = a.slots[idx];
-      const uint32_t wm = a.wmeta[idx];
-      const int nc = (int)(wm & 0xFF);
-      const uint32_t bl = wm >> 8;
-      const bool is_long = act && bl > 16;
-      const bool is_short = act && !is_long;
-      int d = DINF;
-      // the matcher: bit-parallel (32 bits for queries of <= 32 chars, else 64) or — queries above 64 chars, and the
-      // round-3 kernel kept under MSI_DICT_MATCHER=banded — the five-diagonal DP
-      auto pair = [&](auto r, bool on) -> int {
-        if (bits) return m <= 32 ? osa_pair_bits<uint32_t>(r, nc, on, pq, m, K, prefix) : osa_pair_bits<u64>(r, nc, on, pq, m, K, prefix);
-        return osa_pair(r, nc, on, qs, K, prefix);
-      };
-      if (__ballot(is_short)) {
-        if (__ballot(is_short && (uint32_t)nc != bl) == 0) d = pair(SlotReader<true>{slot.x, slot.y, slot.z, slot.w}, is_short);
-        else d = pair(SlotReader<false>{slot.x, slot.y, slot.z, slot.w}, is_short);
-        if (!is_short) d = DINF;
-      }
-      if (__ballot(is_long)) {   // words longer than a slot read their bytes from the flat array
-        const uint32_t o0 = is_long ? a.offs[idx] : 0, o1 = is_long ? a.offs[idx + 1] : 0;
-        const int dl = pair(FlatReader{a.flat + o0, a.flat + o1}, is_long);
-        if (is_long) d = dl;
-      }
-      const uint32_t cat = !act ? 3u : (d == 1 ? 0u : ((K == 2 && d == 2) ? 1u : 3u));
-      const u64 h0 = __ballot(cat == 0), h1 = __ballot(cat == 1);
-      if (cat == 0) {
-        const uint32_t pos = cnt0 + __popcll(h0 & lower);
-        if (pos < a.cap1) wl[pos] = idx;
-      }
-      if (cat == 1) {
-        const uint32_t pos = cnt1 + __popcll(h1 & lower);
-        if (pos < a.cap2) wl[a.cap1 + pos] = idx;
-      }
-      cnt0 += __popcll(h0);
-      cnt1 += __popcll(h1);
-      pairs += n;
-      head = (head + n) & (PQ - 1);
-      qn -= n;
-    };
-    if (qm.hi > qm.lo) {
-      const uint32_t t_lo = qm.lo >> 6, t_hi = (qm.hi + 63) >> 6, n_t = t_hi - t_lo;
-      const uint32_t t0 = t_lo + (uint32_t)((u64)n_t * wave / LW), t1 = t_lo + (uint32_t)((u64)n_t * (wave + 1) / LW);
-      // The filter is a stream of 8-byte loads with a ballot behind each: one tile (64 words) per iteration left a wave
-      // with a single load in flight — latency-bound at ~2 us per 64 words (r3: 0.15 of the VALU issue peak, 11 % VALU-active).
-      // Four tiles' loads are issued before the first is looked at.
-      constexpr uint32_t UN = 4;
-      bool full = false;
-      for (uint32_t tb = t0; tb < t1 && !full; tb += UN) {
-        u64 f[UN];
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u) {
-          const uint32_t idx = (tb + u) * 64 + lane;
-          f[u] = (tb + u < t1 && idx >= qm.lo && idx < qm.hi) ? a.filt[idx] : 0ull;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < UN; ++u) {
-          // both lists of this wave full: nothing it finds later can be among the first cap of the query
-          if (cnt0 >= a.cap1 && (K < 2 || cnt1 >= a.cap2)) {
-            qn = 0;
-            full = true;
-            break;
-          }
-          const u64 fw = f[u];
-          const int nc = (int)(fw & 0xFF);
-          const uint32_t q_not_w = __popcll(qm.sig & ~fw);
-          const uint32_t w_not_q = prefix ? 0u : __popcll((fw & FILT_SIG) & ~qm.sig);
-          const bool len_ok = (nc + K >= m) & (prefix | (nc <= m + K));
-          const bool act = ((fw & FILT_VALID) != 0) & len_ok & (max(q_not_w, w_not_q) <= (uint32_t)K);
-          const u64 ms = __ballot(act);
-          if (ms == 0) continue;
-          if (act) s_pq[wave][(head + qn + __popcll(ms & lower)) & (PQ - 1)] = (tb + u) * 64 + lane;
-          qn += __popcll(ms);
-          __builtin_amdgcn_wave_barrier();
-          while (qn >= 64) drain(64);
-        }
-      }
-      while (qn > 0) drain(qn < 64 ? qn : 64);
-    }
-    if (lane == 0) {
-      s_wcnt[wave][0] = min(cnt0, a.cap1);
-      s_wcnt[wave][1] = min(cnt1, a.cap2);
-    }
-
     // ---- search: other first chars, distance <= 1 (only the two-typo automaton accepts them) --------
     uint32_t xn = 0;  // thread 0's
     if (K == 2 && a.n_fc > 0) {
@@ -594,7 +482,7 @@ __global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
         __syncthreads();
         if (tid == 0) {
           // blocks in ascending order; inside a block the (at most four) ranges may nest or overlap
-          for (uint32_t w = 0; w < LW && xn < a.capx; ++w) {
+          for (uint32_t w = 0; w < XW && xn < a.capx; ++w) {
             u64 mk = s_xany[w];
             while (mk && xn < a.capx) {
               const uint32_t bit = (uint32_t)__ffsll((long long)mk) - 1;
@@ -626,10 +514,177 @@ __global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
         if (s_xdone) break;
       }
     }
-    __syncthreads();  // s_wcnt and the waves' lists are complete
+    if (tid == 0) a.xq_cnt[q] = xn;
+  }
+}
 
+template <bool BITS>
+__device__ __forceinline__ void dict_lookup_body(const DictArgs &a) {
+  __shared__ u64 s_pa[128];            // PEq: ASCII chars (BITS)
+  __shared__ uint32_t s_pk[128];       //      other code points: keys ...
+  __shared__ u64 s_pv[128];            //      ... and their position masks
+  __shared__ uint32_t s_q[QSTRIDE];
+  __shared__ uint32_t s_pq[LW][PQ];
+  __shared__ uint32_t s_wcnt[LW][2];
+  __shared__ uint32_t s_query;
+  __shared__ u64 s_t[4];               // MSI_DICT_PROFILE: thread 0's timestamps (LDS: no register lives across the phases for them)
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u64 lower = (1ull << lane) - 1ull;
+  const uint32_t stride_w = a.cap1 + a.cap2;
+  uint32_t *const wl = a.wlists + ((size_t)blockIdx.x * LW + wave) * stride_w;
+  u64 pairs = 0;
+  if (a.n_long && *a.n_long == 0) return;   // (the launch for queries above 64 chars: the batch has none)
+
+  for (;;) {
+    __syncthreads();  // the previous query's LDS state is no longer read
+    if (tid == 0) s_query = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const uint32_t q = s_query;
+    if (q >= a.nq) break;
+    if (a.prof && tid == 0) {
+      s_t[0] = wall_clock64();
+      s_t[3] = 0;
+    }
+    const QueryMeta qm = a.qm[q];
+    const int K = (int)qm.budget;
+    if (K == 0) {
+      if (tid == 0) a.out_one_cnt[q] = a.out_two_cnt[q] = 0;
+      continue;
+    }
+    const int m = (int)qm.m;
+    if ((uint32_t)m < a.m_lo || (uint32_t)m > a.m_hi) continue;   // the other launch's query
+    const bool prefix = qm.prefix != 0;
+    for (uint32_t i = tid; i < (uint32_t)m; i += LT) s_q[i] = a.qchars[(size_t)q * QSTRIDE + i];
+    constexpr bool bits = BITS;   // (the bit-parallel launch is only given queries of <= 64 chars: no banded code in it)
+    if (bits && tid < 128) {
+      s_pa[tid] = 0ull;
+      s_pk[tid] = PEQ_EMPTY;
+      s_pv[tid] = 0ull;
+    }
+    __syncthreads();
+    if (bits && tid < (uint32_t)m) {      // thread = query position
+      const uint32_t c = s_q[tid];
+      if (c < 128u) {
+        atomicOr(&s_pa[c], 1ull << tid);
+      } else {
+        uint32_t h = (c * 0x9E3779B1u) >> 25;
+        for (;;) {   // <= 64 distinct keys in 128 slots: a free slot always turns up
+          const uint32_t k = atomicCAS(&s_pk[h], PEQ_EMPTY, c);
+          if (k == PEQ_EMPTY || k == c) break;
+          h = (h + 1u) & 127u;
+        }
+        atomicOr(&s_pv[h], 1ull << tid);
+      }
+    }
+    if (bits) __syncthreads();
+    QChars qs;
+    qs.q = s_q;
+    qs.m = m;
+    PEq pq;
+    pq.ascii = s_pa;
+    pq.key = s_pk;
+    pq.val = s_pv;
+
+    // ---- scan: the same-first-char range ------------------------------------------------------------
+    if (a.prof && tid == 0) s_t[1] = wall_clock64();
+    uint32_t cnt0 = 0, cnt1 = 0;      // hits of this wave at distance 1 / 2 (wave-uniform)
+    uint32_t head = 0, qn = 0;        // ring state (wave-uniform)
+    auto drain = [&](uint32_t n) {
+      const u64 t_d0 = a.prof ? wall_clock64() : 0;
+      const bool act = lane < n;
+      const uint32_t idx = act ? s_pq[wave][(head + lane) & (PQ - 1)] : 0u;
+      const uint4 slot = a.slots[idx];
+      const uint32_t wm = a.wmeta[idx];
+      const int nc = (int)(wm & 0xFF);
+      const uint32_t bl = wm >> 8;
+      const bool is_long = act && bl > 16;
+      const bool is_short = act && !is_long;
+      int d = DINF;
+      // the matcher: bit-parallel (32 bits for queries of <= 32 chars, else 64) or — queries above 64 chars, and the
+      // round-3 kernel kept under MSI_DICT_MATCHER=banded — the five-diagonal DP
+      auto pair = [&](auto r, bool on) -> int {
+        if constexpr (bits) return m <= 32 ? osa_pair_bits<uint32_t>(r, nc, on, pq, m, K, prefix) : osa_pair_bits<u64>(r, nc, on, pq, m, K, prefix);
+        else return osa_pair(r, nc, on, qs, K, prefix);
+      };
+      if (__ballot(is_short)) {
+        if (__ballot(is_short && (uint32_t)nc != bl) == 0) d = pair(SlotReader<true>{slot.x, slot.y, slot.z, slot.w}, is_short);
+        else d = pair(SlotReader<false>{slot.x, slot.y, slot.z, slot.w}, is_short);
+        if (!is_short) d = DINF;
+      }
+      if (__ballot(is_long)) {   // words longer than a slot read their bytes from the flat array
+        const uint32_t o0 = is_long ? a.offs[idx] : 0, o1 = is_long ? a.offs[idx + 1] : 0;
+        const int dl = pair(FlatReader{a.flat + o0, a.flat + o1}, is_long);
+        if (is_long) d = dl;
+      }
+      const uint32_t cat = !act ? 3u : (d == 1 ? 0u : ((K == 2 && d == 2) ? 1u : 3u));
+      const u64 h0 = __ballot(cat == 0), h1 = __ballot(cat == 1);
+      if (cat == 0) {
+        const uint32_t pos = cnt0 + __popcll(h0 & lower);
+        if (pos < a.cap1) wl[pos] = idx;
+      }
+      if (cat == 1) {
+        const uint32_t pos = cnt1 + __popcll(h1 & lower);
+        if (pos < a.cap2) wl[a.cap1 + pos] = idx;
+      }
+      cnt0 += __popcll(h0);
+      cnt1 += __popcll(h1);
+      pairs += n;
+      head = (head + n) & (PQ - 1);
+      qn -= n;
+      if (a.prof && tid == 0) s_t[3] += wall_clock64() - t_d0;
+    };
+    if (qm.hi > qm.lo) {
+      const uint32_t t_lo = qm.lo >> 6, t_hi = (qm.hi + 63) >> 6, n_t = t_hi - t_lo;
+      const uint32_t t0 = t_lo + (uint32_t)((u64)n_t * wave / LW), t1 = t_lo + (uint32_t)((u64)n_t * (wave + 1) / LW);
+      // The filter is a stream of 8-byte loads with a ballot behind each: one tile (64 words) per iteration left a wave
+      // with a single load in flight — latency-bound at ~2 us per 64 words (r3: 0.15 of the VALU issue peak, 11 % VALU-active).
+      // Four tiles' loads are issued before the first is looked at.
+      constexpr uint32_t UN = 4;
+      bool full = false;
+      for (uint32_t tb = t0; tb < t1 && !full; tb += UN) {
+        u64 f[UN];
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u) {
+          const uint32_t idx = (tb + u) * 64 + lane;
+          f[u] = (tb + u < t1 && idx >= qm.lo && idx < qm.hi) ? a.filt[idx] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < UN; ++u) {
+          // both lists of this wave full: nothing it finds later can be among the first cap of the query
+          if (cnt0 >= a.cap1 && (K < 2 || cnt1 >= a.cap2)) {
+            qn = 0;
+            full = true;
+            break;
+          }
+          const u64 fw = f[u];
+          const int nc = (int)(fw & 0xFF);
+          const uint32_t q_not_w = __popcll(qm.sig & ~fw);
+          const uint32_t w_not_q = prefix ? 0u : __popcll((fw & FILT_SIG) & ~qm.sig);
+          const bool len_ok = (nc + K >= m) & (prefix | (nc <= m + K));
+          const bool act = ((fw & FILT_VALID) != 0) & len_ok & (max(q_not_w, w_not_q) <= (uint32_t)K);
+          const u64 ms = __ballot(act);
+          if (ms == 0) continue;
+          if (act) s_pq[wave][(head + qn + __popcll(ms & lower)) & (PQ - 1)] = (tb + u) * 64 + lane;
+          qn += __popcll(ms);
+          __builtin_amdgcn_wave_barrier();
+          while (qn >= 64) drain(64);
+        }
+      }
+      while (qn > 0) drain(qn < 64 ? qn : 64);
+    }
+    if (lane == 0) {
+      s_wcnt[wave][0] = min(cnt0, a.cap1);
+      s_wcnt[wave][1] = min(cnt1, a.cap2);
+    }
+    if (a.prof && tid == 0) s_t[2] = wall_clock64();
+
+    // (the words with ANOTHER first char at distance <= 1 were found by dict_other_kernel: a.xq / a.xq_cnt)
+    __syncthreads();  // s_wcnt and the waves' lists are complete
     // ---- caps: the closed form of compute_derivations.rs:129-163 ------------------------------------
     if (tid == 0) {
+      const u64 t_q3 = a.prof ? wall_clock64() : 0;
+      const uint32_t *const xl = a.xq + (size_t)q * a.capx;
+      const uint32_t xn = (K == 2 && a.n_fc > 0) ? a.xq_cnt[q] : 0u;
       const uint32_t *wl0 = a.wlists + (size_t)blockIdx.x * LW * stride_w;
       WaveLists s1{wl0, stride_w, 0, 0, 0, 0, s_wcnt}, s2{wl0, stride_w, a.cap1, 1, 0, 0, s_wcnt};
       s1.settle();
@@ -663,10 +718,29 @@ __global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
       }
       a.out_one_cnt[q] = n1;
       a.out_two_cnt[q] = n2;
+      if (a.prof) {   // [queries, staging + PEq, wave 0's scan (with its drains), of that its drains, search + waiting for the
+                      //  slowest wave's scan, caps, whole query]
+        const u64 t_q4 = wall_clock64();
+        atomicAdd(&a.prof[0], 1ull);
+        atomicAdd(&a.prof[1], s_t[1] - s_t[0]);
+        atomicAdd(&a.prof[2], s_t[2] - s_t[1]);
+        atomicAdd(&a.prof[3], s_t[3]);
+        atomicAdd(&a.prof[4], t_q3 - s_t[2]);
+        atomicAdd(&a.prof[5], t_q4 - t_q3);
+        atomicAdd(&a.prof[6], t_q4 - s_t[0]);
+      }
     }
   }
   if (lane == 0 && pairs) atomicAdd(a.pairs, pairs);
 }
+// What bounds this kernel is how many range-scanning waves a CU holds (each is a chain of 8-byte loads with a ballot behind
+// every one: 11 % VALU-active in round 3): MI355X, C3, in-kernel timers — 92 us per query inside its workgroup at ONE
+// 8-wave workgroup per CU (131 registers), a launch of 8 192 queries 3.6 ms.  The bit-parallel kernel is compiled for 6
+// waves per SIMD (80 registers, three of them spilled on a cold path) = six 4-wave workgroups per CU; the banded one
+// (queries above 64 chars, MSI_DICT_MATCHER=banded) keeps what it needs.
+template <bool BITS> __global__ void dict_lookup_kernel(DictArgs a);
+template <> __global__ __launch_bounds__(LT, 6) void dict_lookup_kernel<true>(DictArgs a) { dict_lookup_body<true>(a); }
+template <> __global__ __launch_bounds__(LT) void dict_lookup_kernel<false>(DictArgs a) { dict_lookup_body<false>(a); }
 
 // ---- query preparation -------------------------------------------------------------
 
@@ -674,7 +748,7 @@ __global__ __launch_bounds__(LT) void dict_lookup_kernel(DictArgs a) {
 __global__ void dict_prep_kernel(const uint8_t *__restrict__ qbytes, const uint32_t *__restrict__ qoff,
                                  const uint8_t *__restrict__ qflags, uint32_t nq,
                                  const uint4 *__restrict__ slots, uint32_t n_words,
-                                 QueryMeta *__restrict__ qm, uint32_t *__restrict__ qchars) {
+                                 QueryMeta *__restrict__ qm, uint32_t *__restrict__ qchars, uint32_t *__restrict__ n_long) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   const uint8_t *s = qbytes + qoff[q];
@@ -737,6 +811,7 @@ __global__ void dict_prep_kernel(const uint8_t *__restrict__ qbytes, const uint3
       rhi = l2;
     };
     range_of(s, len, r.lo, r.hi);
+    if (n > 64) atomicAdd(n_long, 1u);
   }
   qm[q] = r;
 }
@@ -751,7 +826,7 @@ struct msi_dict {
   uint32_t n_fc = 0;   // first-char blocks
   DevBuf slots, filt, wmeta, flat, offs, fc_start;
   // scratch (guarded by ctx->mu_aux)
-  DevBuf qbytes, qoff, qflags, qm, qchars, wlists, xlists, ticket, pairs, out1, out1c, out2, out2c;
+  DevBuf qbytes, qoff, qflags, qm, qchars, wlists, xq, xq_cnt, ticket, pairs, out1, out1c, out2, out2c, prof;
   // host entry point (msi_dict_lookup): pinned staging of the packed queries and results, and an event the caller
   // SLEEPS on — with pageable buffers every copy was a staged, spinning call and hipStreamSynchronize a busy-wait: a fifth
   // of the host CPU of the keyword leg at 64 callers (profiles/r3_ranked_cpu_profile_before.txt)
@@ -837,14 +912,24 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
     d->lookup_launches++;
     return MSI_OK;
   }
+  // ticket[0], ticket[1]: the two lookup launches' query counters; ticket[2]: queries above 64 chars (dict_prep_kernel);
+  // ticket[3]: the other-first-letter kernel's counter
+  MSI_TRY(d->ticket.ensure(4 * sizeof(uint32_t)));
+  MSI_HIP_TRY(hipMemsetAsync(d->ticket.p, 0, 4 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(dict_prep_kernel, dim3((n + 127) / 128), dim3(128), 0, st, d_qbytes, d_qoff, d_qflags, n,
-                     d->slots.as<uint4>(), d->n_words, d->qm.as<QueryMeta>(), d->qchars.as<uint32_t>());
-  // one workgroup per query in flight; 4 workgroups of 8 waves fill a CU
-  const uint32_t grid = std::min<uint32_t>(n, (uint32_t)ctx->n_cu * 4);
+                     d->slots.as<uint4>(), d->n_words, d->qm.as<QueryMeta>(), d->qchars.as<uint32_t>(), d->ticket.as<uint32_t>() + 2);
+  // one workgroup per query in flight (persistent, queries by ticket): as many as the kernel's registers let a CU hold
+  static int wg_per_cu[2] = {0, 0};   // [banded, bit-parallel]
+  if (!wg_per_cu[0]) {
+    int nb = 0;
+    wg_per_cu[0] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dict_lookup_kernel<false>, LT, 0) == hipSuccess && nb > 0) ? nb : 2;
+    wg_per_cu[1] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dict_lookup_kernel<true>, LT, 0) == hipSuccess && nb > 0) ? nb : 2;
+  }
+  const uint32_t grid_cap = (uint32_t)ctx->n_cu * (uint32_t)std::max(wg_per_cu[0], wg_per_cu[1]);
+  const uint32_t grid = std::min<uint32_t>(n, grid_cap);
   MSI_TRY(d->wlists.ensure((size_t)grid * LW * (cap1 + cap2) * sizeof(uint32_t)));
-  MSI_TRY(d->xlists.ensure((size_t)grid * capx * sizeof(uint32_t)));
-  MSI_TRY(d->ticket.ensure(sizeof(uint32_t)));
-  MSI_HIP_TRY(hipMemsetAsync(d->ticket.p, 0, sizeof(uint32_t), st));
+  MSI_TRY(d->xq.ensure((size_t)n * capx * sizeof(uint32_t)));
+  MSI_TRY(d->xq_cnt.ensure((size_t)n * sizeof(uint32_t)));
   DictArgs a;
   a.slots = d->slots.as<uint4>();
   a.filt = d->filt.as<u64>();
@@ -863,9 +948,15 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   a.cap2 = cap2;
   a.capx = capx;
   a.wlists = d->wlists.as<uint32_t>();
-  a.xlists = d->xlists.as<uint32_t>();
+  a.xq = d->xq.as<uint32_t>();
+  a.xq_cnt = d->xq_cnt.as<uint32_t>();
   a.ticket = d->ticket.as<uint32_t>();
   a.pairs = d->pairs.as<u64>();
+  a.prof = nullptr;
+  if (getenv("MSI_DICT_PROFILE")) {   // diagnostics: where a query's time goes inside the kernel (printed by msi_dict_destroy)
+    if (!d->prof.p && d->prof.ensure(8 * sizeof(u64)) == MSI_OK) (void)hipMemsetAsync(d->prof.p, 0, 8 * sizeof(u64), st);
+    a.prof = d->prof.as<u64>();
+  }
   a.out_one = d_one;
   a.out_one_cnt = d_one_cnt;
   a.out_two = d_two;
@@ -874,8 +965,27 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   // MSI_DICT_MATCHER=banded: the round-3 five-diagonal DP for every survivor (kept for A/B runs and as the matcher of
   // queries above 64 chars); default: the bit-parallel recurrence
   static const bool banded = getenv("MSI_DICT_MATCHER") && !strcmp(getenv("MSI_DICT_MATCHER"), "banded");
-  if (banded) hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(grid), dim3(LT), 0, st, a);
-  else hipLaunchKernelGGL(dict_lookup_kernel<true>, dim3(grid), dim3(LT), 0, st, a);
+  a.m_lo = 0;
+  a.m_hi = 0xFFFFFFFFu;
+  a.n_long = nullptr;
+  {   // the other-first-letter words of every budget-2 query first: the matcher kernel's cap logic reads them
+    DictArgs x = a;
+    x.ticket = d->ticket.as<uint32_t>() + 3;
+    hipLaunchKernelGGL(dict_other_kernel, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * 2)), dim3(XT), 0, st, x);
+  }
+  if (banded) {
+    hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[0])), dim3(LT), 0, st, a);
+  } else {
+    // two launches: the bit-parallel kernel (no banded code in it: fewer registers, more workgroups per CU) for the queries
+    // of up to 64 chars, the banded kernel for the rest — its workgroups leave at once when the batch has none
+    a.m_hi = 64;
+    hipLaunchKernelGGL(dict_lookup_kernel<true>, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[1])), dim3(LT), 0, st, a);
+    a.m_lo = 65;
+    a.m_hi = 0xFFFFFFFFu;
+    a.ticket = d->ticket.as<uint32_t>() + 1;
+    a.n_long = d->ticket.as<uint32_t>() + 2;
+    hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[0])), dim3(LT), 0, st, a);
+  }
   d->match_timer.end(ctx);
   MSI_HIP_TRY(hipGetLastError());
   d->lookup_launches++;
@@ -998,8 +1108,17 @@ void msi_dict_destroy(msi_dict *d) {
   std::lock_guard<std::mutex> lk(ctx->mu_aux);
   DeviceGuard g(ctx->device);
   (void)hipStreamSynchronize(d->ctx->stream_aux);
+  if (d->prof.p) {
+    u64 t[8] = {0};
+    (void)hipMemcpy(t, d->prof.p, sizeof t, hipMemcpyDeviceToHost);
+    if (t[0])
+      fprintf(stderr, "msi_dict profile: %llu queries, %.1f us each in their workgroup: staging %.1f, wave 0's range scan %.1f (of it matcher drains %.1f), "
+              "other first letters + waiting for the slowest wave %.1f, caps %.1f\n", (unsigned long long)t[0], t[6] / 100.0 / t[0], t[1] / 100.0 / t[0],
+              t[2] / 100.0 / t[0], t[3] / 100.0 / t[0], t[4] / 100.0 / t[0], t[5] / 100.0 / t[0]);
+    d->prof.release();
+  }
   DevBuf *bufs[] = {&d->slots, &d->filt, &d->wmeta, &d->flat, &d->offs, &d->fc_start, &d->qbytes, &d->qoff,
-                    &d->qflags, &d->qm, &d->qchars, &d->wlists, &d->xlists, &d->ticket, &d->pairs,
+                    &d->qflags, &d->qm, &d->qchars, &d->wlists, &d->xq, &d->xq_cnt, &d->ticket, &d->pairs,
                     &d->out1, &d->out1c, &d->out2, &d->out2c};
   for (DevBuf *b : bufs) b->release();
   d->match_timer.release();

@@ -3231,7 +3231,16 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
     }
   }
   build_initial_edges(g);
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  {
+    const bool cpu_prof = msi_cpu_prof_on();
+    const uint64_t t0 = cpu_prof ? msi_thread_cpu_ns() : 0;
+    c.compute_derivations();
+    if (cpu_prof) msi_cpu_prof_add(4, msi_thread_cpu_ns() - t0);
+  }
+#else
   c.compute_derivations();
+#endif
 
   // ---- universe (resolve_universe, mod.rs:273-301) ---------------------------------------------
   Set universe;
@@ -3684,6 +3693,19 @@ extern "C" int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, con
   g_stats = Stats();
   g_ranked_searches.fetch_add(1, std::memory_order_relaxed);
   Clock total;
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  struct CpuProf {   // MSI_SEARCH_CPU_PROFILE (msi_vm.h): this search's thread CPU time, whichever way it ends
+    bool on = msi_cpu_prof_on();
+    uint64_t t0 = on ? msi_thread_cpu_ns() : 0;
+    ~CpuProf() {
+      if (on) {
+        msi_cpu_prof_add(1, msi_thread_cpu_ns() - t0);
+        msi_cpu_prof_add(0, 1);
+        msi_cpu_prof_add(5, (uint64_t)(g_stats.callback_ms * 1e6));   // (wall time of the callbacks: they never sleep)
+      }
+    }
+  } cpu_guard;
+#endif
   try {
     msi_arena::ArenaScope host_memory;   // (declared before Ctx: released after everything the search built)
     Ctx c(dict, pool, index, params);

@@ -135,6 +135,15 @@ void msi_vm_stats(msi_bits *pool, uint64_t out[6]);
 struct msi_vm;
 void msi_vm_destroy(msi_vm *vm);
 
+// MSI_SEARCH_CPU_PROFILE=1: where the HOST CPU of the keyword leg goes — thread CPU time (CLOCK_THREAD_CPUTIME_ID: a
+// sleeping waiter costs nothing) summed process-wide: [0] searches, [1] whole searches, [2] inside msi_vm_run (submission,
+// the poll / futex wait, the wake-up), [3] of it: finalising the list (hoisted decodes, descriptors, accounting),
+// [4] typo derivations (the batched dictionary lookup's host side), [5] index callbacks + posting parsing, [6] the
+// combiner threads, [7] lists.  msi_search_cpu_profile() hands the sums out (tools/ranked_bench prints them per query).
+bool msi_cpu_prof_on();
+uint64_t msi_thread_cpu_ns();
+void msi_cpu_prof_add(int idx, uint64_t ns);
+
 // ---- HBM posting cache --------------------------------------------------------------------------------------------
 // The stored CboRoaringBitmap bytes of the postings a search reads (word_docids, word_fid_docids, word_position_docids,
 // word_pair_proximity_docids, ...), kept in HBM under a 128-bit hash of (database, key).  A search that reads a key

@@ -61,8 +61,17 @@ constexpr uint32_t CMD_LDS = 2048;                             // command words 
 //   full-space list phases   s_dec (a chunk being decoded) | s_raw (one container body) | s_whole | s_nzw (chunk summaries)
 //   wide phase (VM_DECODEC)  s_dec (U0's words of the chunk) | s_raw (the waves' output words) | the chunk's decode descriptors
 //   compact command phase    the SET CACHE: slot -> entry map and resolved path steps per wave, then the cached sets
+// The set cache is a compile-time option, OFF by default: measured on the MI355X (round 4, profiles/r4_ranked_variants.txt) it
+// LOST — 6.6-7.2 k keyword searches/s against 9.5-9.7 k without it at 128 callers, 3.96 against 3.53 ms for one caller.  The
+// premise was wrong for compact lists: VM_PATHS is 9 % of a workgroup's time once the sets are a chunk or two long (their
+// operands sit in L2; a list's 8-480 paths are a handful of dependent round trips), the cache's bookkeeping per level
+// costs more than the round trips it removes, and its LDS took a workgroup per CU away from the wide phase, which is
+// where a round's device time goes.  -DMSI_VM_SET_CACHE=1 -DMSI_VM_ARENA_KB=38 builds it (tests: MSI_VM_CACHE=1).
+#ifndef MSI_VM_SET_CACHE
+#define MSI_VM_SET_CACHE 0
+#endif
 #ifndef MSI_VM_ARENA_KB
-#define MSI_VM_ARENA_KB 38
+#define MSI_VM_ARENA_KB (MSI_VM_SET_CACHE ? 38 : 23)
 #endif
 constexpr uint32_t ARENA_BYTES = MSI_VM_ARENA_KB * 1024;
 constexpr uint32_t A_RAW = CHW * 8, A_WHOLE = A_RAW + CHW * 8 + 32, A_NZW = A_WHOLE + SUM_W * 64 * 2, A_FULL_END = A_NZW + SUM_W * 64 * 4;
@@ -71,7 +80,7 @@ constexpr uint32_t DESC_WORDS = (ARENA_BYTES - A_DESC) / 4;
 constexpr uint32_t SO_CAP = 1024;                                // path steps of one VM_PATHS resolved ahead per wave (u8 each)
 constexpr uint32_t C_MAP = 0, C_SO = C_MAP + (VT / 64) * 1024, C_DATA = C_SO + (VT / 64) * SO_CAP;
 constexpr uint32_t CACHE_MAX_ENTRIES = 32;                       // an entry per lane of the bookkeeping registers' low half
-static_assert(A_FULL_END <= ARENA_BYTES && C_DATA + 8192 <= ARENA_BYTES, "the LDS arena holds every use of it");
+static_assert(A_FULL_END <= ARENA_BYTES && (!MSI_VM_SET_CACHE || C_DATA + 8192 <= ARENA_BYTES), "the LDS arena holds every use of it");
 constexpr size_t RES_COUNTS = 2;                               // u64 index of counts[0] in the result block
 constexpr size_t RES_IDS = RES_COUNTS + MSI_VM_MAX_COUNTS;     // u64 index where the u32 ids start
 
@@ -249,8 +258,8 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
   // cached copy; nothing is ever written back, eviction is free.  Sets enter the cache where it pays: the operands of
   // VM_PATHS (conditions, universe, bucket); every other command reads through it and updates what is there.
   const uint32_t ent_pairs = chw / 2;                                   // pairs per cache entry
-  const uint32_t n_ent = min(CACHE_MAX_ENTRIES, (ARENA_BYTES - C_DATA) / (chw * 8));
-  const bool cache_on = rp->cache_on != 0 && !wide && rp->aux != 0 && ent_pairs <= (uint32_t)VT && n_ent >= 4 &&
+  const uint32_t n_ent = ARENA_BYTES > C_DATA ? min(CACHE_MAX_ENTRIES, (ARENA_BYTES - C_DATA) / (chw * 8)) : 0u;
+  const bool cache_on = MSI_VM_SET_CACHE && rp->cache_on != 0 && !wide && rp->aux != 0 && ent_pairs <= (uint32_t)VT && n_ent >= 4 &&
                         wave * 64 < n_pairs;                            // (a wave that owns no pair of this chunk keeps no cache)
   uint8_t *const c_map = s_arena + C_MAP + wave * 1024;                 // slot -> entry + 1 (0: not cached); pools of <= 1024 slots
   uint8_t *const c_so = s_arena + C_SO + wave * SO_CAP;                 // the current VM_PATHS: step -> entry + 1
@@ -399,6 +408,10 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
       for (uint32_t i = tid; i < desc_n / 4; i += VT) reinterpret_cast<uint4 *>(s_desc)[i] = reinterpret_cast<const uint4 *>(desc_g)[i];
     }
     __syncthreads();
+    if (prof && tid == 0) {
+      atomicAdd(&prof[22], 1ull);                          // wide workgroups ...
+      atomicAdd(&prof[23], wall_clock64() - t_begin);      // ... and what staging U0's tables + the descriptors cost them
+    }
   }
   // (one lane writes, the wave's lanes read: wave_barrier keeps the compiler — and the CPU emulation, whose lanes are
   // fibers — from moving a read across a write)
@@ -598,23 +611,14 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
             }
           } else if (type == 1) {
             const bool al8 = (b0 & 7) == 0;
-            for (uint32_t w0i = 0; w0i < CHW; w0i += 256) {   // bitmap: only the words where U0 has a document, four in flight
-              u64 uw[4], v[4];
-#pragma unroll
-              for (uint32_t u = 0; u < 4; ++u) {
-                const uint32_t wi = w0i + u * 64 + lane;
-                uw[u] = s_dec[wi];
-                v[u] = 0;
-                if (uw[u]) {
-                  if (al8) v[u] = reinterpret_cast<const u64 *>(b0)[wi];
-                  else v[u] = (u64)ld16(b0, 4 * wi) | ((u64)ld16(b0, 4 * wi + 1) << 16) | ((u64)ld16(b0, 4 * wi + 2) << 32) | ((u64)ld16(b0, 4 * wi + 3) << 48);
-                }
-              }
-#pragma unroll
-              for (uint32_t u = 0; u < 4; ++u) {
-                const u64 m = v[u] & uw[u];
-                if (m) rank_bits(w0i + u * 64 + lane, m);
-              }
+            for (uint32_t wi = lane; wi < CHW; wi += 64) {   // bitmap: only the words where U0 has a document
+              const u64 uw = s_dec[wi];
+              if (!uw) continue;
+              u64 v;
+              if (al8) v = reinterpret_cast<const u64 *>(b0)[wi];
+              else v = (u64)ld16(b0, 4 * wi) | ((u64)ld16(b0, 4 * wi + 1) << 16) | ((u64)ld16(b0, 4 * wi + 2) << 32) | ((u64)ld16(b0, 4 * wi + 3) << 48);
+              const u64 m = v & uw;
+              if (m) rank_bits(wi, m);
             }
           } else {
             const uint32_t n_runs = min(card + 1, 2048u);
@@ -1338,6 +1342,7 @@ __global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, ui
     for (int i = 1; i < 15; ++i)
       if (s_prof[i]) atomicAdd(&prof[i], s_prof[i]);
     atomicAdd(&prof[15], wall_clock64() - t_begin);   // the whole interpretation, commands + fetches
+    if (wide) atomicAdd(&prof[19], wall_clock64() - t_begin);   // (of it: in wide workgroups)
     atomicAdd(&prof[0], 1ull);                        // workgroups
     atomicMax(&cells[MSI_VM_CELLS - 1], ~t_begin);    // earliest start of a workgroup of this list (phase 0 profile only)
   }
@@ -1591,6 +1596,7 @@ void VmCombiner::run() {
   const long poll_sleep_ns = (getenv("MSI_VM_POLL_SLEEP_US") ? std::max(0, atoi(getenv("MSI_VM_POLL_SLEEP_US"))) : 20) * 1000l;
   if (poll_sleep_ns > 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);   // (this thread only: the default 50 us slack would triple the sleep)
   if (getenv("MSI_VM_PROFILE") && hipMalloc((void **)&d_prof, 24 * sizeof(u64)) == hipSuccess) (void)hipMemset(d_prof, 0, 24 * sizeof(u64));
+  uint64_t cpu_seen = msi_cpu_prof_on() ? msi_thread_cpu_ns() : 0;
   auto finish = [&](VmSub *s, uint32_t st) {
     s->t_done = now_ns();
     if (trace && s->list) {   // diagnostics: what a list was made of and how long the device took for it
@@ -1655,7 +1661,7 @@ void VmCombiner::run() {
       return (v == 128 || v == 256 || v == 512 || v == 1024) ? (uint32_t)v : 256u;
     }();
     const char *cache_knob = getenv("MSI_VM_CACHE");
-    const bool cache_off = cache_knob && cache_knob[0] == '0';   // experiments: every operand from memory
+    const bool cache_off = !(cache_knob && cache_knob[0] == '1');   // the LDS set cache (builds with MSI_VM_SET_CACHE=1 only): on request
     auto chw_of = [&](const VmSub *b) -> uint32_t { return b->list->geom_docs ? compact_chw : CHW; };
     uint32_t max_chunks[MSI_VM_MAX_PHASES] = {0}, max_phases = 1;
     for (size_t i = 0; i < n_sub; ++i) {
@@ -1747,6 +1753,11 @@ void VmCombiner::run() {
     }
     rounds.fetch_add(1, std::memory_order_relaxed);
     lists.fetch_add(n_sub, std::memory_order_relaxed);
+    if (msi_cpu_prof_on()) {   // this thread's CPU since the last round
+      const uint64_t now_cpu = msi_thread_cpu_ns();
+      msi_cpu_prof_add(6, now_cpu - cpu_seen);
+      cpu_seen = now_cpu;
+    }
     if (st != MSI_OK) {
       for (VmSub *s : batch) {
         s->error = st;
@@ -1883,8 +1894,11 @@ void msi_vm_destroy(msi_vm *vmx) {
       for (int i = 1; i < 15; ++i)
         if (t[i]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * t[i] / (double)t[15]);
       fprintf(stderr, "; scoped (command, chunk) executions %llu, of them on an all-zero chunk %llu", (unsigned long long)t[20], (unsigned long long)t[21]);
-      fprintf(stderr, "; epilogue %.1f us per workgroup; %llu list-phases, first start to last ticket %.1f us\n",
+      fprintf(stderr, "; epilogue %.1f us per workgroup; %llu list-phases, first start to last ticket %.1f us",
               t[0] ? t[18] / 100.0 / t[0] : 0.0, (unsigned long long)t[17], t[17] ? t[16] / 100.0 / t[17] : 0.0);
+      fprintf(stderr, "; wide workgroups %llu, %.1f us each (staging %.1f us); the others %.1f us each\n", (unsigned long long)t[22],
+              t[22] ? t[19] / 100.0 / t[22] : 0.0, t[22] ? t[23] / 100.0 / t[22] : 0.0,
+              t[0] > t[22] ? (t[15] - t[19]) / 100.0 / (t[0] - t[22]) : 0.0);
       (void)hipFree(vm->d_prof);
     }
     for (auto &A : vm->ar) {
@@ -2124,10 +2138,40 @@ extern "C" int32_t msi_bits_vm_bytes(uint64_t out[3]) {
   return MSI_OK;
 }
 
+static StripedCounters<8> g_cpu_prof;
+bool msi_cpu_prof_on() {
+  static const bool on = getenv("MSI_SEARCH_CPU_PROFILE") != nullptr;
+  return on;
+}
+uint64_t msi_thread_cpu_ns() {
+  struct timespec ts;
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+void msi_cpu_prof_add(int idx, uint64_t ns) { g_cpu_prof.add(idx, ns); }
+extern "C" int32_t msi_search_cpu_profile(uint64_t out[8]) {
+  if (!out) return MSI_E_INVALID;
+  for (int i = 0; i < 8; ++i) out[i] = g_cpu_prof.sum(i);
+  return MSI_OK;
+}
+
 int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
+  const bool cpu_prof = msi_cpu_prof_on();
+  const uint64_t cpu0 = cpu_prof ? msi_thread_cpu_ns() : 0;
+  struct CpuProf {   // (every way out of this function)
+    bool on;
+    uint64_t t0;
+    ~CpuProf() {
+      if (on) {
+        msi_cpu_prof_add(2, msi_thread_cpu_ns() - t0);
+        msi_cpu_prof_add(7, 1);
+      }
+    }
+  } cpu_guard{cpu_prof, cpu0};
   merge_pre(l);
   account_list(pool, l);
   finalize_decodes(l);
+  if (cpu_prof) msi_cpu_prof_add(3, msi_thread_cpu_ns() - cpu0);
   if (l.n_counts > MSI_VM_MAX_COUNTS || l.phase_start.size() > MSI_VM_MAX_PHASES || l.phase_start.empty()) {
     msi_set_error("msi_vm_run: list outside the supported range (%u counts, %zu phases)", l.n_counts, l.phase_start.size());
     return MSI_E_UNSUPPORTED;

@@ -471,6 +471,10 @@ int main(int argc, char **argv) {
       for (auto &th : warm) th.join();
     }
     uint64_t vs0[6] = {0, 0, 0, 0, 0, 0}, vs1[6] = {0, 0, 0, 0, 0, 0}, vb0[3] = {0, 0, 0}, vb1[3] = {0, 0, 0};
+    uint64_t cp0[8] = {0}, cp1[8] = {0};
+#ifndef RANKED_BENCH_CPU
+    msi_search_cpu_profile(cp0);
+#endif
     unsigned long long cs0[2], cs1[2];
     cpu_stat(cs0);
 #ifndef RANKED_BENCH_CPU
@@ -515,6 +519,16 @@ int main(int argc, char **argv) {
     cpu_stat(cs1);
 #ifndef RANKED_BENCH_CPU
     msi_bits_vm_bytes(vb1);
+    msi_search_cpu_profile(cp1);
+    if (cp1[0] > cp0[0]) {   // MSI_SEARCH_CPU_PROFILE=1: host CPU per query, by where it is spent
+      const double nqq = (double)(cp1[0] - cp0[0]);
+      fprintf(stderr, "[ranked_bench] host CPU per query (us): search threads %.1f = command-list submit + wait %.1f (of it finalising lists %.1f) "
+              "+ typo derivations %.1f + index callbacks %.1f + host logic %.1f; combiner %.1f; lists per query %.2f\n",
+              (cp1[1] - cp0[1]) / 1e3 / nqq, (cp1[2] - cp0[2]) / 1e3 / nqq, (cp1[3] - cp0[3]) / 1e3 / nqq, (cp1[4] - cp0[4]) / 1e3 / nqq,
+              (cp1[5] - cp0[5]) / 1e3 / nqq,
+              ((double)(cp1[1] - cp0[1]) - (double)(cp1[2] - cp0[2]) - (double)(cp1[4] - cp0[4]) - (double)(cp1[5] - cp0[5])) / 1e3 / nqq,
+              (cp1[6] - cp0[6]) / 1e3 / nqq, (cp1[7] - cp0[7]) / nqq);
+    }
 #endif
     if (getenv("RB_PROFILE") && a == argc - 1) prof::stop(getenv("RB_PROFILE"));
     std::sort(all.begin(), all.end());
