@@ -247,6 +247,9 @@ typedef struct msi_vs_stats {
   uint64_t scan_tiles;         /* 16-row tiles streamed by those launches  */
   uint64_t exhaustive_reruns;  /* queries that needed the exhaustive path  */
   uint64_t bytes_per_tile;     /* algorithmic HBM bytes per tile           */
+  /* (ABI 2) host entry point, bf16x2 stores: queries the 96-query bf16x2 sweep could not prove and that took the bf16x3
+   * second opinion; sweeps that ran bf16x3 FIRST because most recent queries needed it (clustered data); bf16x2 sweeps */
+  uint64_t second_opinion_queries, x3_first_sweeps, x2_sweeps;
 } msi_vs_stats;
 int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out);
 /* Test instrumentation: the fast scan's raw scores (dot / |row|; -inf for padding)

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <numeric>
 #include <vector>
 
@@ -14,6 +15,8 @@
 #include <fcntl.h>
 #include <signal.h>
 #include <unistd.h>
+
+#include <atomic>
 
 #include "msi_common.h"
 #include "msi_vm.h"
@@ -98,6 +101,19 @@ int32_t msi_ctx_create(int32_t device, msi_ctx **out) {
     return MSI_E_NO_DEVICE;
   }
   DeviceGuard g(device);
+  {
+    // The command-list rounds of the keyword searches run on 16 streams; the runtime maps streams onto GPU_MAX_HW_QUEUES
+    // hardware queues (default 4) and rounds that share a queue serialise: 4 -> 16 queues took the keyword leg from 2.8 k
+    // to 6.1 k searches/s.  The variable is read when the HIP runtime starts — before this call — so
+    // the library can only say so (once per process; MSI_QUIET=1 silences it).  INTEGRATION.md: set it in the server's
+    // environment.
+    static std::atomic<bool> said{false};
+    const char *hq = getenv("GPU_MAX_HW_QUEUES");
+    if ((!hq || atoi(hq) < 16) && !getenv("MSI_QUIET") && !said.exchange(true))
+      fprintf(stderr, "libmsi: GPU_MAX_HW_QUEUES is %s: keyword searches in flight share %s hardware queues and their command-list "
+              "rounds serialise (measured: less than half the throughput of GPU_MAX_HW_QUEUES=16); set it in the environment before "
+              "the process starts\n", hq ? hq : "unset", hq ? hq : "4");
+  }
   msi_ctx *c = new msi_ctx();
   c->device = device;
   c->n_cu = prop.multiProcessorCount;

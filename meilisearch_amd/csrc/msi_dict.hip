@@ -919,11 +919,13 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   hipLaunchKernelGGL(dict_prep_kernel, dim3((n + 127) / 128), dim3(128), 0, st, d_qbytes, d_qoff, d_qflags, n,
                      d->slots.as<uint4>(), d->n_words, d->qm.as<QueryMeta>(), d->qchars.as<uint32_t>(), d->ticket.as<uint32_t>() + 2);
   // one workgroup per query in flight (persistent, queries by ticket): as many as the kernel's registers let a CU hold
+  // (what the kernels are compiled for: 5 / 6 waves per SIMD = workgroups of 4 waves per CU; tests/test_isa_cpu.py holds the
+  // register counts behind these; MSI_DICT_WG_PER_CU overrides for experiments)
   static int wg_per_cu[2] = {0, 0};   // [banded, bit-parallel]
   if (!wg_per_cu[0]) {
-    int nb = 0;
-    wg_per_cu[0] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dict_lookup_kernel<false>, LT, 0) == hipSuccess && nb > 0) ? nb : 2;
-    wg_per_cu[1] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dict_lookup_kernel<true>, LT, 0) == hipSuccess && nb > 0) ? nb : 2;
+    const int knob = getenv("MSI_DICT_WG_PER_CU") ? atoi(getenv("MSI_DICT_WG_PER_CU")) : 0;
+    wg_per_cu[1] = knob > 0 ? knob : 6;
+    wg_per_cu[0] = knob > 0 ? knob : 5;
   }
   const uint32_t grid_cap = (uint32_t)ctx->n_cu * (uint32_t)std::max(wg_per_cu[0], wg_per_cu[1]);
   const uint32_t grid = std::min<uint32_t>(n, grid_cap);

@@ -1030,6 +1030,16 @@ struct msi_vs {
   uint32_t scan_grid = 0;
   // stats
   uint64_t scan_launches = 0, scan_tiles = 0, exhaustive_reruns = 0;
+  // The first pass's arithmetic adapts to the data (host entry point, bf16x2 stores): on i.i.d. rows a few dozen candidates
+  // lie within the bf16x2 proof's margin (2 x 3.9e-3 in cosine) of the k-th neighbour and every query is proven by the
+  // 96-query sweep; on CLUSTERED embeddings — thousands of rows within 1e-2 of each other — nearly every query fails that
+  // proof and used to cost a second, 48-query bf16x3 sweep on top.  A running share of unproven queries (x2_flagged_ema)
+  // above a quarter makes bf16x3 the first pass for the next 256 sweeps (one pass over the store per 48 queries instead of
+  // three per 96), then one bf16x2 sweep probes again.  Results do not depend on it: every answer is the canonical rescoring
+  // of proven candidates either way.  MSI_VS_ADAPT=0 switches it off (tests pin both paths).
+  float x2_flagged_ema = 0.0f;
+  uint32_t x3_first_left = 0;
+  uint64_t second_opinion_queries = 0, x3_first_sweeps = 0, x2_sweeps = 0;
   KernelTimer scan_timer;
   // micro-batcher: concurrent unfiltered msi_vs_search calls are fused into one sweep
   struct Pending {
@@ -1881,14 +1891,18 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
     d_fbits = vs->fbits.as<u64>();
   }
   const uint32_t kk = std::max<uint32_t>(1, k);
-  const uint32_t step = vs->nqt_max * QT;
   MSI_TRY(vs->out_docids.ensure((size_t)NQ_MAX * kk * sizeof(uint32_t)));
   MSI_TRY(vs->out_dist.ensure((size_t)NQ_MAX * kk * sizeof(float)));
+  static const bool adapt = !(getenv("MSI_VS_ADAPT") && getenv("MSI_VS_ADAPT")[0] == '0');
+  uint32_t step = 0;
   for (uint32_t q0 = 0; q0 < n_queries; q0 += step) {
     if (cancel && *cancel) {
       msi_set_error("msi_vs_search: cancelled");
       return MSI_E_CANCELLED;
     }
+    // (see msi_vs::x2_flagged_ema) a bf16x2 store whose recent queries mostly failed the bf16x2 proof sweeps with bf16x3 first
+    const bool x3_first = vs->bf2 && adapt && vs->x3_first_left > 0;
+    step = (x3_first ? vs->nqt3_max : vs->nqt_max) * QT;
     const uint32_t nq = std::min<uint32_t>(step, n_queries - q0);
     if (k == 0 || vs->n_rows == 0) {
       for (uint32_t j = 0; j < nq; ++j) out_counts[q0 + j] = 0;
@@ -1896,8 +1910,13 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
     }
     MSI_HIP_TRY(hipMemcpyAsync(vs->qraw.p, queries + (size_t)q0 * vs->dim, (size_t)nq * vs->dim * sizeof(float),
                                hipMemcpyHostToDevice, st));
-    MSI_TRY(enqueue_search(vs, vs->qraw.as<float>(), nq, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>(),
-                           vs->out_dist.as<float>(), s.counts, s.inexact));
+    {
+      if (x3_first) vs->bf2 = false;
+      const int32_t st1 = enqueue_search(vs, vs->qraw.as<float>(), nq, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>(),
+                                         vs->out_dist.as<float>(), s.counts, s.inexact);
+      if (x3_first) vs->bf2 = true;
+      MSI_TRY(st1);
+    }
     uint32_t h_inexact[NQ_MAX];
     MSI_HIP_TRY(hipMemcpyAsync(h_inexact, s.inexact, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipMemcpyAsync(out_counts + q0, s.counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1905,7 +1924,21 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
     std::vector<uint32_t> flagged;
     for (uint32_t j = 0; j < nq; ++j)
       if (h_inexact[j]) flagged.push_back(j);
-    if (!flagged.empty() && !vs->bf2) {
+    if (x3_first) {
+      ++vs->x3_first_sweeps;
+      --vs->x3_first_left;
+    } else if (vs->bf2) {
+      ++vs->x2_sweeps;
+      vs->second_opinion_queries += flagged.size();
+      if (adapt && nq >= QT) {   // (a sweep of at least one query tile says something about the data)
+        vs->x2_flagged_ema = 0.5f * vs->x2_flagged_ema + 0.5f * (float)flagged.size() / (float)nq;
+        if (vs->x2_flagged_ema > 0.25f) {
+          vs->x3_first_left = 256;
+          vs->x2_flagged_ema = 0.25f;   // (the probing sweep after them decides again)
+        }
+      }
+    }
+    if (!flagged.empty() && (!vs->bf2 || x3_first)) {
       for (uint32_t j : flagged) {
         if (cancel && *cancel) {
           msi_set_error("msi_vs_search: cancelled");
@@ -2046,6 +2079,9 @@ int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out) {
   out->scan_launches = vs->scan_launches;
   out->scan_tiles = vs->scan_tiles;
   out->exhaustive_reruns = vs->exhaustive_reruns;
+  out->second_opinion_queries = vs->second_opinion_queries;
+  out->x3_first_sweeps = vs->x3_first_sweeps;
+  out->x2_sweeps = vs->x2_sweeps;
   out->bytes_per_tile = (uint64_t)vs->KB * 1024;
   return MSI_OK;
 }

@@ -234,6 +234,53 @@ def device_queries(nq, d, dev, seed=5678):
     return torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=gq)
 
 
+def device_rows_clustered(n, d, dev, seed=4321, n_centres=10_000, spread=(1e-3, 1e-2), dup_frac=0.01, chunk=1_000_000):
+    """Rows shaped like an embedding corpus instead of i.i.d. noise: `n_centres` centres ~ N(0,1); every row is
+    its centre plus noise whose size gives the row a cosine distance to the centre of 1 - cos in `spread` (log-uniform: tight
+    and loose members in every cluster), and `dup_frac` of the rows are exact copies of another row.  A cluster holds
+    n / n_centres rows within ~2 x spread of each other — thousands inside the bf16x2 proof's margin at 10 M rows.
+    Generated in HBM, 1 M-row chunks, fixed seed.  Returns (rows [n, d] f32, centre index of every row [n] int64)."""
+    import torch
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    centres = torch.empty((n_centres, d), dtype=torch.float32, device=dev).normal_(generator=gen)
+    rows_t = torch.empty((n, d), dtype=torch.float32, device=dev)
+    which = torch.empty(n, dtype=torch.int64, device=dev)
+    lo, hi = float(np.log(spread[0])), float(np.log(spread[1]))
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        m = c1 - c0
+        idx = torch.randint(0, n_centres, (m,), generator=gen, device=dev)
+        which[c0:c1] = idx
+        one_minus_cos = torch.exp(torch.empty(m, device=dev).uniform_(lo, hi, generator=gen))
+        # |c| ~ sqrt(d); c + s * eps with eps ~ N(0, I): 1 - cos ~ s^2 / 2  (for s << 1, relative to |c|^2 / d = 1)
+        sigma = torch.sqrt(2.0 * one_minus_cos)
+        noise = torch.empty((m, d), dtype=torch.float32, device=dev).normal_(generator=gen)
+        rows_t[c0:c1] = centres[idx] + sigma[:, None] * noise
+        del noise
+    n_dup = int(n * dup_frac)
+    if n_dup:
+        dst = torch.randint(0, n, (n_dup,), generator=gen, device=dev)
+        src = torch.randint(0, n, (n_dup,), generator=gen, device=dev)
+        rows_t[dst] = rows_t[src]
+        which[dst] = which[src]
+    return rows_t, which
+
+
+def device_queries_near_rows(rows_t, nq, seed=8765, one_minus_cos=5e-3):
+    """Queries that look like the corpus: a stored row each, moved by noise of about `one_minus_cos` — their neighbours are the
+    row's cluster, whose members' scores differ in the fourth decimal."""
+    import torch
+    dev = rows_t.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    idx = torch.randint(0, rows_t.shape[0], (nq,), generator=gen, device=dev)
+    base = rows_t[idx]
+    noise = torch.empty_like(base).normal_(generator=gen)
+    scale = base.norm(dim=1, keepdim=True) / float(np.sqrt(rows_t.shape[1]))
+    return base + float(np.sqrt(2.0 * one_minus_cos)) * scale * noise
+
+
 def random_bitset_words(n_bits, density, seed):
     """Dense candidate bitset (u64 words, LSB first) with Bernoulli(density) bits below n_bits (C5 filters, seed 31)."""
     rng = np.random.default_rng(seed)

@@ -148,7 +148,9 @@ class GpuStore:
         s = VsStats()
         check(lib().msi_vs_get_stats(self._h, C.byref(s)))
         return {"scan_launches": s.scan_launches, "scan_tiles": s.scan_tiles,
-                "exhaustive_reruns": s.exhaustive_reruns, "bytes_per_tile": s.bytes_per_tile}
+                "exhaustive_reruns": s.exhaustive_reruns, "bytes_per_tile": s.bytes_per_tile,
+                "second_opinion_queries": s.second_opinion_queries, "x3_first_sweeps": s.x3_first_sweeps,
+                "x2_sweeps": s.x2_sweeps}
 
     def close(self):
         if self._h:

@@ -85,8 +85,6 @@ struct hipDeviceProp_t {
 };
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : e == hipErrorOutOfMemory ? "hipErrorOutOfMemory" : "hipError(emulated)"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-template <typename F>
-inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, F, int, size_t) { *n = 2; return hipSuccess; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 template <typename F>
 inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }

@@ -52,3 +52,43 @@ def test_ticket_atomics_wait_for_the_stores_before_them(unit, kernels):
                 assert not any(re.search(r"\b(global|buffer|flat)_store", b) for b in between), (head, between)
                 checked += 1
     assert checked >= 1, "no ticket atomic found in " + unit
+
+
+def kernel_vgprs(obj):
+    """{kernel symbol: vgpr_count} from the code object's metadata notes."""
+    readelf = os.path.join(os.path.dirname(OBJDUMP), "llvm-readelf")
+    tmp = tempfile.mkdtemp(prefix="msi_isa_")
+    try:
+        local = os.path.join(tmp, os.path.basename(obj))
+        shutil.copy(obj, local)
+        subprocess.run([OBJDUMP, "--offloading", local], capture_output=True, text=True, check=True)
+        co = [f for f in os.listdir(tmp) if "gfx950" in f]
+        notes = subprocess.run([readelf, "--notes", os.path.join(tmp, co[0])], capture_output=True, text=True, check=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out, name = {}, None
+    for line in notes.split("\n"):
+        m = re.search(r"\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"\.vgpr_count:\s+(\d+)", line)
+        if m and name:
+            out[name] = int(m.group(1))
+    return out
+
+
+def test_occupancy_the_host_code_counts_on():
+    """msi_dict.hip launches `6 x CUs` workgroups of the bit-parallel matcher kernel and `5 x CUs` of the banded one (4 waves
+    each: 6 / 5 waves per SIMD) — the kernels are bound by how many range-scanning waves a CU holds — and the command-list
+    interpreter is budgeted for 3 waves per SIMD.  The register counts behind those numbers, on the built objects."""
+    csrc = os.path.join(ROOT, "meilisearch_amd", "csrc")
+    if not os.path.exists(os.path.join(csrc, "msi_dict.o")) or not os.path.exists(OBJDUMP):
+        pytest.skip("objects not built / no llvm-objdump")
+    d = kernel_vgprs(os.path.join(csrc, "msi_dict.o"))
+    bits = [v for k, v in d.items() if "dict_lookup_kernelILb1" in k]
+    banded = [v for k, v in d.items() if "dict_lookup_kernelILb0" in k]
+    assert bits and banded, d
+    assert bits[0] <= 80 and banded[0] <= 96, d            # 512 / 80 = 6, 512 / 96 = 5 waves per SIMD
+    v = kernel_vgprs(os.path.join(csrc, "msi_vm.o"))
+    vm = [x for k, x in v.items() if "vm_kernel" in k]
+    assert vm and vm[0] <= 168, v                          # 3 waves per SIMD = three 4-wave workgroups per CU
