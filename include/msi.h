@@ -250,6 +250,9 @@ typedef struct msi_vs_stats {
   /* (ABI 2) host entry point, bf16x2 stores: queries the 96-query bf16x2 sweep could not prove and that took the bf16x3
    * second opinion; sweeps that ran bf16x3 FIRST because most recent queries needed it (clustered data); bf16x2 sweeps */
   uint64_t second_opinion_queries, x3_first_sweeps, x2_sweeps;
+  /* sweeps by level of effort (msi_vs.hip, msi_vs::level): the store's contraction with the usual K' | the same with
+   * K' = 2048 rescored candidates | bf16x3 with K' = 2048 */
+  uint64_t level_sweeps[3];
 } msi_vs_stats;
 int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out);
 /* Test instrumentation: the fast scan's raw scores (dot / |row|; -inf for padding)

@@ -124,7 +124,8 @@ class KeywordParams(C.Structure):
 class VsStats(C.Structure):
     _fields_ = [("scan_launches", C.c_uint64), ("scan_tiles", C.c_uint64),
                 ("exhaustive_reruns", C.c_uint64), ("bytes_per_tile", C.c_uint64),
-                ("second_opinion_queries", C.c_uint64), ("x3_first_sweeps", C.c_uint64), ("x2_sweeps", C.c_uint64)]
+                ("second_opinion_queries", C.c_uint64), ("x3_first_sweeps", C.c_uint64), ("x2_sweeps", C.c_uint64),
+                ("level_sweeps", C.c_uint64 * 3)]
 
 
 class DictStats(C.Structure):

@@ -1030,16 +1030,21 @@ struct msi_vs {
   uint32_t scan_grid = 0;
   // stats
   uint64_t scan_launches = 0, scan_tiles = 0, exhaustive_reruns = 0;
-  // The first pass's arithmetic adapts to the data (host entry point, bf16x2 stores): on i.i.d. rows a few dozen candidates
-  // lie within the bf16x2 proof's margin (2 x 3.9e-3 in cosine) of the k-th neighbour and every query is proven by the
-  // 96-query sweep; on CLUSTERED embeddings — thousands of rows within 1e-2 of each other — nearly every query fails that
-  // proof and used to cost a second, 48-query bf16x3 sweep on top.  A running share of unproven queries (x2_flagged_ema)
-  // above a quarter makes bf16x3 the first pass for the next 256 sweeps (one pass over the store per 48 queries instead of
-  // three per 96), then one bf16x2 sweep probes again.  Results do not depend on it: every answer is the canonical rescoring
-  // of proven candidates either way.  MSI_VS_ADAPT=0 switches it off (tests pin both paths).
-  float x2_flagged_ema = 0.0f;
-  uint32_t x3_first_left = 0;
-  uint64_t second_opinion_queries = 0, x3_first_sweeps = 0, x2_sweeps = 0;
+  // How a query is proven adapts to the data (host entry point).  The proof needs every row whose fast score lies within
+  // 2 x eps of the k-th neighbour among the K' rescored candidates; eps is a WORST-CASE bound (3.9e-3 in cosine for bf16x2,
+  // 2.9e-4 for bf16x3 at d = 768: the f32 accumulation bound dominates) — on i.i.d. rows a few dozen rows lie that close and
+  // K' = k + max(108, 3k) proves every query in the 96-query bf16x2 sweep, on CLUSTERED embeddings (a thousand rows within
+  // 1e-2 of each other at 10 M rows / 10 k clusters) hundreds do and it proves none: round 3 then answered every such query
+  // exhaustively, 30 ms each (measured round 4: 29.9 queries/s at C4's size).  Levels of effort, each tried on the queries the
+  // one before could not prove: 0 = the store's contraction (bf16x2 by default), K' as above; 1 = the same contraction with
+  // K' = KP_MAX candidates (2 048 rows rescored per query: 2 % of a sweep's bytes); 2 = bf16x3 with K' = KP_MAX (bf16x2 stores
+  // only); then the exhaustive pass.  The level a sweep STARTS at follows the running share of queries its level could
+  // not prove (level_ema > 1/4: one level up for the next 256 sweeps, then one probing sweep a level down).  Results do not
+  // depend on any of it: every answer is the canonical rescoring of proven candidates.  MSI_VS_ADAPT=0: always start at 0.
+  uint32_t level = 0, level_left = 0;
+  float level_ema = 0.0f;
+  bool big_slack = false;          // (read by enqueue_search: K' = KP_MAX)
+  uint64_t second_opinion_queries = 0, x3_first_sweeps = 0, x2_sweeps = 0, level_sweeps[3] = {0, 0, 0};
   KernelTimer scan_timer;
   // micro-batcher: concurrent unfiltered msi_vs_search calls are fused into one sweep
   struct Pending {
@@ -1289,7 +1294,7 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   }
   // candidates rescored beyond k: every row whose fast score lies within twice the proof's eps of the k-th must be among
   // them — a handful with bf16x3 (eps ~ 1e-5), a few dozen to a hundred with bf16x2 (eps ~ 4e-3)
-  const uint32_t slack = vs->bf2 ? std::max<uint32_t>(108, 3 * k) : std::max<uint32_t>(12, k / 4);
+  const uint32_t slack = vs->big_slack ? KP_MAX : (vs->bf2 ? std::max<uint32_t>(108, 3 * k) : std::max<uint32_t>(12, k / 4));
   const uint32_t kp = std::min<uint32_t>(k + slack, KP_MAX);
   const uint32_t nqt = (nq + QT - 1) / QT;
   // 1. queries
@@ -1894,15 +1899,34 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
   MSI_TRY(vs->out_docids.ensure((size_t)NQ_MAX * kk * sizeof(uint32_t)));
   MSI_TRY(vs->out_dist.ensure((size_t)NQ_MAX * kk * sizeof(float)));
   static const bool adapt = !(getenv("MSI_VS_ADAPT") && getenv("MSI_VS_ADAPT")[0] == '0');
+  // the levels of effort of this store (msi_vs::level): {bf16x2 contraction?, K' = KP_MAX?}
+  struct Level { bool x2, big; };
+  const bool store_x2 = vs->bf2;
+  const Level levels[3] = {{store_x2, false}, {store_x2, true}, {false, true}};
+  const uint32_t n_levels = store_x2 ? 3u : 2u;
+  auto batch_of = [&](const Level &l) { return ((store_x2 && !l.x2) ? vs->nqt3_max : vs->nqt_max) * QT; };
+  // one sweep at level `l` for the nf queries whose rows are already in vs->qraw: results in vs->out_*, flags / counts in h_*
+  auto sweep = [&](const Level &l, uint32_t nf, uint32_t *h_flags, uint32_t *h_counts) -> int32_t {
+    vs->bf2 = l.x2;
+    vs->big_slack = l.big;
+    const int32_t st1 = enqueue_search(vs, vs->qraw.as<float>(), nf, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>(),
+                                       vs->out_dist.as<float>(), s.counts, s.inexact);
+    vs->bf2 = store_x2;
+    vs->big_slack = false;
+    MSI_TRY(st1);
+    MSI_HIP_TRY(hipMemcpyAsync(h_flags, s.inexact, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MSI_HIP_TRY(hipMemcpyAsync(h_counts, s.counts, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MSI_HIP_TRY(hipStreamSynchronize(st));
+    return MSI_OK;
+  };
   uint32_t step = 0;
   for (uint32_t q0 = 0; q0 < n_queries; q0 += step) {
     if (cancel && *cancel) {
       msi_set_error("msi_vs_search: cancelled");
       return MSI_E_CANCELLED;
     }
-    // (see msi_vs::x2_flagged_ema) a bf16x2 store whose recent queries mostly failed the bf16x2 proof sweeps with bf16x3 first
-    const bool x3_first = vs->bf2 && adapt && vs->x3_first_left > 0;
-    step = (x3_first ? vs->nqt3_max : vs->nqt_max) * QT;
+    const uint32_t l0 = adapt ? std::min(vs->level, n_levels - 1) : 0u;
+    step = batch_of(levels[l0]);
     const uint32_t nq = std::min<uint32_t>(step, n_queries - q0);
     if (k == 0 || vs->n_rows == 0) {
       for (uint32_t j = 0; j < nq; ++j) out_counts[q0 + j] = 0;
@@ -1910,101 +1934,102 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
     }
     MSI_HIP_TRY(hipMemcpyAsync(vs->qraw.p, queries + (size_t)q0 * vs->dim, (size_t)nq * vs->dim * sizeof(float),
                                hipMemcpyHostToDevice, st));
-    {
-      if (x3_first) vs->bf2 = false;
-      const int32_t st1 = enqueue_search(vs, vs->qraw.as<float>(), nq, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>(),
-                                         vs->out_dist.as<float>(), s.counts, s.inexact);
-      if (x3_first) vs->bf2 = true;
-      MSI_TRY(st1);
-    }
-    uint32_t h_inexact[NQ_MAX];
-    MSI_HIP_TRY(hipMemcpyAsync(h_inexact, s.inexact, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    MSI_HIP_TRY(hipMemcpyAsync(out_counts + q0, s.counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    MSI_HIP_TRY(hipStreamSynchronize(st));
-    std::vector<uint32_t> flagged;
-    for (uint32_t j = 0; j < nq; ++j)
-      if (h_inexact[j]) flagged.push_back(j);
-    if (x3_first) {
-      ++vs->x3_first_sweeps;
-      --vs->x3_first_left;
-    } else if (vs->bf2) {
-      ++vs->x2_sweeps;
-      vs->second_opinion_queries += flagged.size();
-      if (adapt && nq >= QT) {   // (a sweep of at least one query tile says something about the data)
-        vs->x2_flagged_ema = 0.5f * vs->x2_flagged_ema + 0.5f * (float)flagged.size() / (float)nq;
-        if (vs->x2_flagged_ema > 0.25f) {
-          vs->x3_first_left = 256;
-          vs->x2_flagged_ema = 0.25f;   // (the probing sweep after them decides again)
-        }
-      }
-    }
-    if (!flagged.empty() && (!vs->bf2 || x3_first)) {
-      for (uint32_t j : flagged) {
-        if (cancel && *cancel) {
-          msi_set_error("msi_vs_search: cancelled");
-          return MSI_E_CANCELLED;
-        }
-        MSI_TRY(exhaustive_one(vs, j, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>() + (size_t)j * k,
-                               vs->out_dist.as<float>() + (size_t)j * k, s.counts + j));
-      }
-      MSI_HIP_TRY(hipMemcpyAsync(out_counts + q0, s.counts, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    } else if (!flagged.empty()) {
-      // The results of the queries that proved exact leave first: the re-runs below prepare their own query rows.
-      MSI_HIP_TRY(hipMemcpyAsync(out_docids + (size_t)q0 * k, vs->out_docids.p, (size_t)nq * k * sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, st));
-      MSI_HIP_TRY(hipMemcpyAsync(out_dist + (size_t)q0 * k, vs->out_dist.p, (size_t)nq * k * sizeof(float),
-                                 hipMemcpyDeviceToHost, st));
-      MSI_HIP_TRY(hipStreamSynchronize(st));
-      // A query the bf16x2 scan could not prove (its margin is 2^-8 wide) gets a second opinion from the bf16x3
-      // contraction (margin ~1e-5), as many to a sweep as both halves of their fragments fit in LDS (48 up to d = 768,
-      // 32 up to 1280, 16 beyond); what that cannot prove either — ties beyond K', degenerate rows — is
-      // answered exhaustively in the reference arithmetic.
-      const bool second_opinion = true;
-      const uint32_t sub = vs->nqt3_max * QT;
-      for (size_t f0 = 0; f0 < flagged.size(); f0 += sub) {
-        const uint32_t nf = (uint32_t)std::min<size_t>(sub, flagged.size() - f0);
-        if (cancel && *cancel) {
-          msi_set_error("msi_vs_search: cancelled");
-          return MSI_E_CANCELLED;
-        }
-        uint32_t h_in2[NQ_MAX], h_cnt2[NQ_MAX];
-        for (uint32_t i = 0; i < nf; ++i) {
-          h_in2[i] = 1;
-          MSI_HIP_TRY(hipMemcpyAsync(vs->qraw.as<float>() + (size_t)i * vs->dim,
-                                     queries + (size_t)(q0 + flagged[f0 + i]) * vs->dim, (size_t)vs->dim * sizeof(float),
-                                     hipMemcpyHostToDevice, st));
-        }
-        vs->bf2 = false;
-        const int32_t st2 = enqueue_search(vs, vs->qraw.as<float>(), nf, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>(),
-                                     vs->out_dist.as<float>(), s.counts, s.inexact);
-        vs->bf2 = true;
-        MSI_TRY(st2);
-        if (second_opinion) {
-          MSI_HIP_TRY(hipMemcpyAsync(h_in2, s.inexact, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-          MSI_HIP_TRY(hipStreamSynchronize(st));
-        }
-        for (uint32_t i = 0; i < nf; ++i)   // (query rows of THIS sub-batch: index i)
-          if (h_in2[i])
-            MSI_TRY(exhaustive_one(vs, i, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>() + (size_t)i * k,
-                                   vs->out_dist.as<float>() + (size_t)i * k, s.counts + i));
-        MSI_HIP_TRY(hipMemcpyAsync(h_cnt2, s.counts, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        for (uint32_t i = 0; i < nf; ++i) {
-          const size_t row = (size_t)(q0 + flagged[f0 + i]) * k;
-          MSI_HIP_TRY(hipMemcpyAsync(out_docids + row, vs->out_docids.as<uint32_t>() + (size_t)i * k, (size_t)k * sizeof(uint32_t),
-                                     hipMemcpyDeviceToHost, st));
-          MSI_HIP_TRY(hipMemcpyAsync(out_dist + row, vs->out_dist.as<float>() + (size_t)i * k, (size_t)k * sizeof(float),
-                                     hipMemcpyDeviceToHost, st));
-        }
-        MSI_HIP_TRY(hipStreamSynchronize(st));
-        for (uint32_t i = 0; i < nf; ++i) out_counts[q0 + flagged[f0 + i]] = h_cnt2[i];
-      }
-      continue;
-    }
+    uint32_t h_flags[NQ_MAX], h_counts[NQ_MAX];
+    MSI_TRY(sweep(levels[l0], nq, h_flags, h_counts));
+    ++vs->level_sweeps[l0];
+    if (levels[l0].x2) ++vs->x2_sweeps;
+    else if (store_x2) ++vs->x3_first_sweeps;
+    // what this sweep proved leaves now (the re-runs below prepare their own query rows and reuse the result buffers)
     MSI_HIP_TRY(hipMemcpyAsync(out_docids + (size_t)q0 * k, vs->out_docids.p, (size_t)nq * k * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipMemcpyAsync(out_dist + (size_t)q0 * k, vs->out_dist.p, (size_t)nq * k * sizeof(float),
                                hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint32_t> pending;
+    for (uint32_t j = 0; j < nq; ++j) {
+      out_counts[q0 + j] = h_counts[j];
+      if (h_flags[j]) pending.push_back(j);
+    }
+    if (adapt && nq >= (uint32_t)QT) {   // (a sweep of at least one query tile says something about the data)
+      vs->level_ema = 0.5f * vs->level_ema + 0.5f * (float)pending.size() / (float)nq;
+      if (vs->level_left > 0 && --vs->level_left == 0 && vs->level > 0) {
+        --vs->level;                     // the probing sweep a level down comes next
+        vs->level_ema = 0.0f;
+      } else if (vs->level_ema > 0.25f && vs->level + 1 < n_levels) {
+        ++vs->level;
+        vs->level_left = 256;
+        vs->level_ema = 0.0f;
+      } else if (vs->level_ema > 0.25f) {
+        vs->level_left = 256;            // (already at the last level: stay)
+      }
+    }
+    if (levels[l0].x2 && !levels[l0].big) vs->second_opinion_queries += pending.size();
+    // What the sweep that JUST ran (its query rows are still prepared in vs->qrow, row i = query idx[i] of this chunk) could
+    // not prove and no further level can: answered exhaustively in the reference arithmetic, results straight to the caller.
+    auto exhaustive_now = [&](const std::vector<uint32_t> &rows_i, const std::vector<uint32_t> &idx) -> int32_t {
+      for (size_t t = 0; t < rows_i.size(); ++t) {
+        if (cancel && *cancel) {
+          msi_set_error("msi_vs_search: cancelled");
+          return MSI_E_CANCELLED;
+        }
+        const uint32_t i = rows_i[t], j = idx[t];
+        MSI_TRY(exhaustive_one(vs, i, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>() + (size_t)i * k,
+                               vs->out_dist.as<float>() + (size_t)i * k, s.counts + i));
+        const size_t row = (size_t)(q0 + j) * k;
+        MSI_HIP_TRY(hipMemcpyAsync(out_docids + row, vs->out_docids.as<uint32_t>() + (size_t)i * k, (size_t)k * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
+        MSI_HIP_TRY(hipMemcpyAsync(out_dist + row, vs->out_dist.as<float>() + (size_t)i * k, (size_t)k * sizeof(float),
+                                   hipMemcpyDeviceToHost, st));
+        MSI_HIP_TRY(hipMemcpyAsync(out_counts + q0 + j, s.counts + i, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      }
+      MSI_HIP_TRY(hipStreamSynchronize(st));
+      return MSI_OK;
+    };
+    if (l0 + 1 == n_levels && !pending.empty()) {   // the first sweep ran at the last level already
+      MSI_TRY(exhaustive_now(pending, pending));
+      pending.clear();
+    }
+    // the queries the sweep could not prove: level by level
+    for (uint32_t lvl = l0 + 1; lvl < n_levels && !pending.empty(); ++lvl) {
+      const uint32_t sub = batch_of(levels[lvl]);
+      std::vector<uint32_t> next;
+      for (size_t f0 = 0; f0 < pending.size(); f0 += sub) {
+        const uint32_t nf = (uint32_t)std::min<size_t>(sub, pending.size() - f0);
+        if (cancel && *cancel) {
+          msi_set_error("msi_vs_search: cancelled");
+          return MSI_E_CANCELLED;
+        }
+        for (uint32_t i = 0; i < nf; ++i)
+          MSI_HIP_TRY(hipMemcpyAsync(vs->qraw.as<float>() + (size_t)i * vs->dim,
+                                     queries + (size_t)(q0 + pending[f0 + i]) * vs->dim, (size_t)vs->dim * sizeof(float),
+                                     hipMemcpyHostToDevice, st));
+        uint32_t f2[NQ_MAX], c2[NQ_MAX];
+        MSI_TRY(sweep(levels[lvl], nf, f2, c2));
+        ++vs->level_sweeps[lvl];
+        std::vector<uint32_t> left_i, left_j;
+        for (uint32_t i = 0; i < nf; ++i) {
+          const uint32_t j = pending[f0 + i];
+          if (f2[i]) {
+            if (lvl + 1 == n_levels) {
+              left_i.push_back(i);
+              left_j.push_back(j);
+            } else {
+              next.push_back(j);
+            }
+            continue;
+          }
+          const size_t row = (size_t)(q0 + j) * k;
+          MSI_HIP_TRY(hipMemcpyAsync(out_docids + row, vs->out_docids.as<uint32_t>() + (size_t)i * k, (size_t)k * sizeof(uint32_t),
+                                     hipMemcpyDeviceToHost, st));
+          MSI_HIP_TRY(hipMemcpyAsync(out_dist + row, vs->out_dist.as<float>() + (size_t)i * k, (size_t)k * sizeof(float),
+                                     hipMemcpyDeviceToHost, st));
+          out_counts[q0 + j] = c2[i];
+        }
+        MSI_HIP_TRY(hipStreamSynchronize(st));
+        if (!left_i.empty()) MSI_TRY(exhaustive_now(left_i, left_j));
+      }
+      pending.swap(next);
+    }
   }
   return MSI_OK;
 }
@@ -2082,6 +2107,7 @@ int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out) {
   out->second_opinion_queries = vs->second_opinion_queries;
   out->x3_first_sweeps = vs->x3_first_sweeps;
   out->x2_sweeps = vs->x2_sweeps;
+  for (int i = 0; i < 3; ++i) out->level_sweeps[i] = vs->level_sweeps[i];
   out->bytes_per_tile = (uint64_t)vs->KB * 1024;
   return MSI_OK;
 }

@@ -150,7 +150,7 @@ class GpuStore:
         return {"scan_launches": s.scan_launches, "scan_tiles": s.scan_tiles,
                 "exhaustive_reruns": s.exhaustive_reruns, "bytes_per_tile": s.bytes_per_tile,
                 "second_opinion_queries": s.second_opinion_queries, "x3_first_sweeps": s.x3_first_sweeps,
-                "x2_sweeps": s.x2_sweeps}
+                "x2_sweeps": s.x2_sweeps, "level_sweeps": [int(x) for x in s.level_sweeps]}
 
     def close(self):
         if self._h:

@@ -127,9 +127,20 @@ def test_duplicates_zero_rows_and_zero_query(ctx, oracle):
     st.upload(ids, rows)
     qs = np.concatenate([base[:1] * f32(2.0), synth.make_embeddings(2, dim, seed=42),
                          np.zeros((1, dim), dtype=f32)])
-    before = st.stats()["exhaustive_reruns"]
+    before = st.stats()
     check_against_oracle(oracle, st, rows, ids, qs, 20)
-    assert st.stats()["exhaustive_reruns"] > before   # the ties forced the exhaustive path
+    after = st.stats()
+    # 200 ties are more than the usual K' holds: since round 4 the query is re-run with K' = 2048 rescored candidates
+    # (msi_vs.hip, levels of effort) and proven there — no exhaustive pass
+    assert after["level_sweeps"][1] > before["level_sweeps"][1]
+    # ... and more ties than ANY K' holds still end in the exhaustive pass (reference arithmetic for every row)
+    rows2 = np.concatenate([np.repeat(base[:1], 2100, axis=0), base])
+    ids2 = np.arange(rows2.shape[0], dtype=np.uint32) + 10
+    st2 = ma.GpuStore(ctx, dim)
+    st2.upload(ids2, rows2)
+    b2 = st2.stats()["exhaustive_reruns"]
+    check_against_oracle(oracle, st2, rows2, ids2, qs[:2], 20)
+    assert st2.stats()["exhaustive_reruns"] > b2
 
 
 def test_large_scan_and_sample_pass(ctx, oracle):
@@ -407,7 +418,11 @@ def test_second_opinion_capacity_at_wide_dims(ctx, oracle, dim, batch2, batch3):
     rng = np.random.default_rng(dim)
     rows = synth.make_embeddings(n, dim, seed=95)
     v = rng.standard_normal(dim).astype(f32)
-    rows[:300] = v[None, :] + 0.09 * rng.standard_normal((300, dim)).astype(f32) * (np.linalg.norm(v) / np.sqrt(dim))
+    # (round 4: 2 600 rows whose distance to the query direction spreads over 2e-4 .. 7e-3 — more than K' = 2048 of them inside
+    # the bf16x2 proof's margin, so also the second level of effort (bf16x2, K' = 2048) fails and the bf16x3 level is reached;
+    # a few hundred inside the bf16x3 margin, so that level proves every query)
+    scale = np.exp(rng.uniform(np.log(0.02), np.log(0.12), 2600)).astype(f32)
+    rows[:2600] = v[None, :] + scale[:, None] * rng.standard_normal((2600, dim)).astype(f32) * (np.linalg.norm(v) / np.sqrt(dim))
     ids = np.arange(n, dtype=np.uint32) * 2 + 1
     st = ma.GpuStore(ctx, dim)
     st.upload(ids, rows)
@@ -418,5 +433,7 @@ def test_second_opinion_capacity_at_wide_dims(ctx, oracle, dim, batch2, batch3):
     s0 = st.stats()
     check_against_oracle(oracle, st, rows, ids, qs, 20)
     s1 = st.stats()
-    # one dense pass (<= 32 Ki rows), then ceil(flagged / batch3) second-opinion passes: more than one sub-batch
-    assert s1["scan_launches"] - s0["scan_launches"] >= 1 + 2
+    # one dense pass (<= 32 Ki rows), one with K' = 2048, then ceil(flagged / batch3) bf16x3 passes: more than one sub-batch
+    assert s1["scan_launches"] - s0["scan_launches"] >= 1 + 1 + 2
+    assert s1["level_sweeps"][2] - s0["level_sweeps"][2] >= 2
+    assert s1["exhaustive_reruns"] == s0["exhaustive_reruns"]
