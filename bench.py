@@ -79,7 +79,12 @@ def parse_args():
     ap.add_argument("--kw-slots", type=int, default=512, help="c4: slots of every caller's docid-set pool (n_docs / 8 bytes each)")
     ap.add_argument("--kw-threads", type=int, default=160, help="c4: caller threads of the keyword leg (one in-flight search each)")
     ap.add_argument("--kw-terms", type=int, default=3, help="c4: words per keyword query")
-    ap.add_argument("--kw-dict-words", type=int, default=200_000, help="c4: vocabulary of the synthetic inverted index")
+    ap.add_argument("--kw-dict-words", type=int, default=None, help="c4: vocabulary of the keyword leg's index (default: 2 000 000 "
+                                                                   "for the coherent corpus, 200 000 for the hashed index)")
+    ap.add_argument("--kw-corpus", choices=["coherent", "hashed"], default="coherent",
+                    help="c4: the keyword leg's index — BASELINE's C4 text workload (a coherent corpus: every database derived from the "
+                         "same documents, queries taken out of them and misspelled) or round 3's independently hashed postings with "
+                         "3-word queries over the 300 most frequent words")
     ap.add_argument("--kw-cache-mb", type=int, default=8192, help="c4: HBM posting cache of the index version")
     ap.add_argument("--legs", choices=["tail", "serial", "overlap"], default="serial",
                     help="c4: how the two legs of a step share the device.  serial (default): the scan streams HBM on its own (0.73 of "
@@ -397,8 +402,9 @@ def keyword_roofline(n_docs, kw_threads, measured_qps):
                                 "wide phase.  Served by L2 almost entirely (the sets of a compact universe are kilobytes and are re-read "
                                 "by command after command): NOT a lower bound on HBM traffic and not algorithmic bytes in the roofline sense",
         "l2_request_breakdown_per_query": {"set_operands": int(ab["set_operands"]), "posting_containers": int(ab["posting_containers"])},
-        "l2_request_rate_GBps": round(req * measured_qps / 1e9, 1), "l2_peak_GBps": 34500.0,
-        "l2_request_frac": round(req * measured_qps / 1e9 / 34500.0, 4),
+        "l2_request_rate_GBps": round(req * line["queries_per_s"] / 1e9, 1), "l2_peak_GBps": 34500.0,
+        "l2_request_frac": round(req * line["queries_per_s"] / 1e9 / 34500.0, 4),
+        "rates_are": "bytes per query x the CHILD's own queries/s (the same workload as the counters)",
         "child_queries_per_s": line["queries_per_s"], "child_callers": threads,
         "universe_compaction": line.get("compact_space"),
     })
@@ -423,7 +429,7 @@ def keyword_roofline(n_docs, kw_threads, measured_qps):
                                        "source": "live: rocprofv3 --pmc FETCH_SIZE (x 2, gfx950 wide-load correction) / --pmc WRITE_SIZE children "
                                                  f"(tools/bin/ranked_bench, {threads} callers, {warm} searches), summed over every vm_kernel dispatch"}
     moved = (traffic["FETCH_SIZE"] or 0.0) + (traffic["WRITE_SIZE"] or 0.0)
-    out["hbm_GBps"] = round(moved * measured_qps / 1e9, 1) if moved else None
+    out["hbm_GBps"] = round(moved * line["queries_per_s"] / 1e9, 1) if moved else None
     out["hbm_frac"] = round(out["hbm_GBps"] / 8000.0, 4) if out["hbm_GBps"] else None
     out["reading"] = ("a query is ~14 dependent rounds (lists_per_query); each costs a launch, the chain of its commands and a wake-up "
                       "(us_per_round) and — on the host — the recording of the next list: the leg's throughput is granted CPUs / host CPU "
@@ -516,6 +522,9 @@ def run_c4(args, env):
         kw_lib = C.CDLL(kw_so)
         kw_lib.rb_create.restype = C.c_void_p
         kw_lib.rb_create.argtypes = [C.c_uint64, C.c_uint32]
+        kw_lib.rb_create_corpus.restype = C.c_void_p
+        kw_lib.rb_create_corpus.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
+        kw_lib.rb_run_detailed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
         kw_lib.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
         kw_lib.rb_prepare_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
         kw_lib.rb_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -532,7 +541,12 @@ def run_c4(args, env):
         kw_lib.rb_last_latencies.restype = C.c_uint32
         kw_lib.rb_last_latencies.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         n_docs_kw = n_total if row_sharded else n
-        h = kw_lib.rb_create(n_docs_kw, args.kw_dict_words)
+        if args.kw_dict_words is None:
+            args.kw_dict_words = 2_000_000 if args.kw_corpus == "coherent" else 200_000
+        t_corpus = time.time()
+        h = (kw_lib.rb_create_corpus(n_docs_kw, args.kw_dict_words, 42) if args.kw_corpus == "coherent"
+             else kw_lib.rb_create(n_docs_kw, args.kw_dict_words))
+        corpus_s = time.time() - t_corpus
         # Caller threads of this rank: a waiting search costs no CPU, but a search in flight needs ~1.2 ms of host CPU per
         # query (round 3; 1.7 ms in round 2) — N ranks share the box's CPUs, so each rank gets its share of callers: 10 per
         # granted CPU (160 on a 16-CPU grant: 12.8 CPUs busy; 192 callers measured 15.5 CPUs and 256 callers ran into the
@@ -545,8 +559,19 @@ def run_c4(args, env):
         kw = {"lib": kw_lib, "h": h, "ids": np.zeros((Q, k), np.uint32), "n": np.zeros(Q, np.uint32),
               "scores": np.zeros((Q, k), np.float64), "m_ids": np.zeros((Q, k), np.uint32), "m_sem": np.zeros((Q, k), np.uint8),
               "m_cnt": np.zeros(Q, np.uint32), "m_hits": np.zeros(Q, np.uint32), "step": 0}
-        for first in range(0, n_kw_queries, Q):     # warm the synthetic index (and the posting cache) — untimed
+        # Untimed: the first pass over the 4 x Q distinct queries makes the INDEX derive the databases they read (the stand-in for
+        # what LMDB holds: not the engine's work); then the HBM posting cache is emptied and the pass is repeated — that second
+        # pass is the engine with a COLD posting cache (every posting crosses PCIe once and is decoded out of the staging buffer).
+        for first in range(0, n_kw_queries, Q):
             assert kw_lib.rb_run(h, first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data) == 0
+        kw["cold_cache_queries_per_s"] = None
+        if not env.child:
+            ma._lib.check(ma._lib.lib().msi_dict_reset_posting_cache(C.c_void_p(kw_lib.rb_dict(h))))
+            t0c = time.perf_counter()
+            for first in range(0, n_kw_queries, Q):
+                assert kw_lib.rb_run(h, first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data) == 0
+            kw["cold_cache_queries_per_s"] = round(n_kw_queries / (time.perf_counter() - t0c), 1)
+        kw["corpus_seconds"] = round(corpus_s, 1)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
@@ -721,7 +746,28 @@ def run_c4(args, env):
         ma._lib.lib().msi_dict_posting_cache_stats(C.c_void_p(kw["lib"].rb_dict(kw["h"])), pc)
         vs = (C.c_uint64 * 6)()
         ma._lib.lib().msi_bits_vm_stats(C.c_void_p(kw["lib"].rb_pool(kw["h"], 0)), vs)
-        legs["keyword_posting_cache"] = {"hits": int(pc[0]), "misses": int(pc[1]), "bytes_used": int(pc[2])}
+        legs["keyword_posting_cache"] = {"hits": int(pc[0]), "misses": int(pc[1]), "bytes_used": int(pc[2]),
+                                         "hit_rate": round(pc[0] / max(1, pc[0] + pc[1]), 4)}
+        legs["keyword_cold_posting_cache_queries_per_s"] = kw.get("cold_cache_queries_per_s")
+        # sensitivity to the universe (the documents that match the query at all): one more pass with every search's candidate
+        # count and wall time at load, grouped by |universe| / documents
+        cand = np.zeros(Q, np.uint64)
+        first = (kw["step"] * Q) % (4 * Q)
+        assert kw["lib"].rb_run_detailed(kw["h"], first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data,
+                                         None, None, cand.ctypes.data) == 0
+        lat_q = np.zeros(Q, np.float64)
+        kw["lib"].rb_last_latencies(kw["h"], lat_q.ctypes.data, Q)
+        n_idx = n_total if row_sharded else n
+        sweep = {}
+        for name, lo_f, hi_f in (("<=0.1%", 0.0, 0.001), ("0.1-1%", 0.001, 0.01), ("1-12.5% (compacted)", 0.01, 0.125),
+                                 ("12.5-50% (full space)", 0.125, 0.5), (">50%", 0.5, 1.01)):
+            m_ = (cand > lo_f * n_idx) & (cand <= hi_f * n_idx) if lo_f > 0 else (cand <= hi_f * n_idx)
+            if m_.any():
+                sweep[name] = {"queries": int(m_.sum()), "p50_ms_at_load": round(float(np.median(lat_q[m_])), 3),
+                               "mean_ms_at_load": round(float(lat_q[m_].mean()), 3)}
+        legs["keyword_by_universe"] = {"buckets": sweep, "is": f"one {Q}-query pass of the keyword leg ({kw_threads} callers): searches grouped "
+                                       "by candidates / documents; a universe of <= 1/8 of the index continues in the compact space",
+                                       "mean_universe_docs": round(float(cand.mean()), 1)}
         legs["keyword_lists_per_launch_round"] = round((vs[1] - vs0[1]) / max(1, vs[0] - vs0[0]), 2)   # of this leg only
     # ---- per-QUERY latency (the metric is "queries/sec + p50 latency"; ms_per_step is the latency of a 768-query step) ----
     latency = None
@@ -854,7 +900,11 @@ def run_c4(args, env):
         "data": "synthetic (rows N(0,1) seed 1234; dictionary seed 99; query words seed 7; BASELINE.md C4/C3)",
         "config": {
             "workload": f"C4 on one GPU per rank: {n} docs x {d}-d {storage} exact cosine top-{k} "
-                        f"+ {args.words_per_query} typo-tolerant words/query over a {args.dict_words}-term dictionary",
+                        f"+ {args.words_per_query} typo-tolerant words/query over a {args.dict_words}-term dictionary"
+                        + ("" if kw is None else
+                           (f" + all-rules keyword search over a coherent {n_total if row_sharded else n}-document text corpus (BASELINE.md C4: corpus as C1 "
+                            "scaled; queries out of the documents, misspelled) + hybrid merge" if args.kw_corpus == "coherent"
+                            else " + all-rules keyword search over the round-3 hashed index (300 frequent words) + hybrid merge")),
             "queries_per_step_per_gpu": Q, "words_per_step_per_gpu": n_words_q,
             "queries_per_hbm_sweep": store.max_batch,
             "scan_math": os.environ.get("MSI_VS_SCAN_MATH", "bf16x2") + " candidate scan (f32 rows in HBM split hi/lo in registers, bf16 query fragments, f32 accumulate)"
@@ -868,11 +918,18 @@ def run_c4(args, env):
                               "binary searches for the other first letters, cap logic)", "D2H of results"]
                              + ([] if kw is None else [
                                  "msi_keyword_search_ranked for every query: default criteria [words, typo, proximity, attributeRank, "
-                                 "sort, wordPosition, exactness], %d words per query, typo derivations from the index's %d-word "
-                                 "dictionary feeding the postings, %d caller threads" % (args.kw_terms, args.kw_dict_words, kw_threads),
+                                 "sort, wordPosition, exactness], %s, typo derivations from the index's dictionary (vocabulary %d words) "
+                                 "feeding the postings, %d caller threads" % (
+                                     "BASELINE's C4 text workload: a coherent %d-document corpus (title 3-6 / overview 20-60 words, "
+                                     "Zipf(1.07), every database derived from the same tokens), queries = 1-%d consecutive words of a "
+                                     "document with 0-2 edits and a prefix last word + the shapes of workloads/search/movies.json"
+                                     % (n_total if row_sharded else n, args.kw_terms) if args.kw_corpus == "coherent" else
+                                     "%d words per query over the 300 most frequent words of an independently hashed index" % args.kw_terms,
+                                     args.kw_dict_words, kw_threads),
                                  "hybrid merge (semanticRatio 0.5) of the vector list with the keyword list (global scores)"]),
             "step_excludes": ["keyword leg", "hybrid merge"] if kw is None else [],
             "inexact_queries_last_step": n_inexact,
+            "keyword_corpus": args.kw_corpus if kw is not None else None,
             "setup_seconds": round(setup_s, 1),
         },
         "roofline": scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, "vs_scan_kernel (main pass)",
@@ -978,6 +1035,13 @@ def run_c4(args, env):
         if env.rank == 0 and env.world == 1 and not env.child and not args.no_pmc:
             # the keyword leg's kernel: algorithmic bytes and HBM traffic per query (children of this run)
             out["keyword_roofline"] = keyword_roofline(n, kw_threads, kw_qps)
+            # continuity with rounds 2-3: their keyword workload (independently hashed postings, 200 000-word dictionary, 3-word
+            # queries over the 300 most frequent words, never misspelled) is what the children above ran
+            kr = out["keyword_roofline"]
+            out["legs"]["keyword_friendly"] = {"queries_per_s": kr.get("child_queries_per_s"), "callers": kr.get("child_callers"),
+                                               "is": "tools/bin/ranked_bench on the round-3 hashed index (the keyword_roofline object's "
+                                                     "plain child): the friendliest regime — warm 300-word working set, universes of ~1 % "
+                                                     "of the index"}
     return out
 
 

@@ -359,6 +359,8 @@ int32_t msi_dict_lookup_device(msi_dict *dict, const uint8_t *d_qbytes,
  * stats: [hits, misses, bytes used, capacity]. */
 int32_t msi_dict_enable_posting_cache(msi_dict *dict, uint64_t capacity_bytes);
 int32_t msi_dict_posting_cache_stats(msi_dict *dict, uint64_t out[4]);
+/* A fresh cache of the same capacity (everything cached is forgotten).  Only while no search on `dict` is in flight. */
+int32_t msi_dict_reset_posting_cache(msi_dict *dict);
 
 typedef struct msi_dict_stats {
   uint64_t lookup_launches;

@@ -1141,6 +1141,19 @@ int32_t msi_dict_enable_posting_cache(msi_dict *d, uint64_t capacity_bytes) {
   return d->pcache ? MSI_OK : MSI_E_OOM;
 }
 
+// Forgets everything the posting cache holds (a fresh cache of the same capacity): what a server does when it wants the
+// memory back, and how the bench measures a cold-cache pass.  Only while no search on this dictionary is in flight.
+int32_t msi_dict_reset_posting_cache(msi_dict *d) {
+  if (!d) return MSI_E_INVALID;
+  std::lock_guard<std::mutex> lk(d->bmu);
+  if (!d->pcache) return MSI_OK;
+  uint64_t st[4] = {0, 0, 0, 0};
+  msi_pcache_stats(d->pcache, st);
+  msi_pcache_destroy(d->pcache);
+  d->pcache = msi_pcache_create(d->ctx, st[3]);
+  return d->pcache ? MSI_OK : MSI_E_OOM;
+}
+
 int32_t msi_dict_posting_cache_stats(msi_dict *d, uint64_t out[4]) {
   if (!d || !out) return MSI_E_INVALID;
   out[0] = out[1] = out[2] = out[3] = 0;

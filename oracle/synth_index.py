@@ -11,7 +11,11 @@ What the synthetic index is (tools/ranked_bench.cpp): a dictionary of n_words ra
 document frequencies; word_fid_docids over fids 1..3 (weights 0..2), word_position_docids over 20 bucketed positions,
 word_pair_proximity_docids at proximities 1..3 for ANY two words, field_id_word_count_docids; no exact attributes, no
 word-prefix databases, no synonyms, no stop words.  The databases are not those of one coherent corpus — the ranking
-rules only read them, and both sides read the same bytes."""
+rules only read them, and both sides read the same bytes.
+
+Round 4: rb_create_corpus builds a COHERENT corpus instead (tools/ranked_bench.cpp, struct Corpus: documents of a title and
+an overview, Zipf(1.07) words, every database derived from the same tokens the way tests/toy_milli.py derives them; two
+searchable fields) behind the same reads; queries are taken out of the documents and misspelled."""
 import bisect
 import ctypes as C
 import os
@@ -29,6 +33,10 @@ def runner_lib():
     lib = C.CDLL(os.environ.get("MSI_RUNNER_SO") or os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so"))
     lib.rb_create.restype = C.c_void_p
     lib.rb_create.argtypes = [C.c_uint64, C.c_uint32]
+    lib.rb_create_corpus.restype = C.c_void_p
+    lib.rb_create_corpus.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
+    lib.rb_n_fields.restype = C.c_uint32
+    lib.rb_n_fields.argtypes = [C.c_void_p]
     lib.rb_prepare_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
     lib.rb_destroy.argtypes = [C.c_void_p]
     lib.rb_n_words.restype = C.c_uint32
@@ -52,9 +60,10 @@ class SynthIndex:
         self.DocSet = docset.docset_type(self.n_docs)
         self.min_one, self.min_two, self.authorize_typos = min_one, min_two, True
         self.criteria = list(DEFAULT_CRITERIA)
-        self.searchable_fids = [1, 2, 3]
-        self.weights = {1: 0, 2: 1, 3: 2}
-        self.max_weight = 2
+        nf = int(lib.rb_n_fields(h))          # 3 for the hashed index, 2 (title, overview) for the coherent corpus
+        self.searchable_fids = list(range(1, nf + 1))
+        self.weights = {f: f - 1 for f in self.searchable_fids}
+        self.max_weight = nf - 1
         self.stop_words, self.exact_words, self.distinct_field = (), set(), None
         n = lib.rb_n_words(h)
         off = np.zeros(n + 1, np.uint32)

@@ -154,3 +154,37 @@ def test_c4_keyword_leg(ctx, monkeypatch, run_containers):
             assert (a == b).all()
     finally:
         lib.rb_destroy(h)
+
+
+def test_c4_keyword_leg_on_the_coherent_corpus(ctx):
+    """The same check on BASELINE's own C4 text workload: a coherent corpus (tools/ranked_bench.cpp, struct
+    Corpus: title + overview documents, Zipf(1.07) words, every database derived from the same tokens: positions with
+    hard-separator jumps, bucketed positions, forward pair proximities, field word counts), a dictionary of the words that
+    occur, and queries taken OUT of the documents — 1-3 consecutive words over the whole vocabulary, 0-2 edits, the last
+    word cut to a prefix — plus the shapes of workloads/search/movies.json ("" placeholder, two title words, the most
+    frequent word).  Against oracle/ranking_oracle.py reading the same stored bytes."""
+    import ctypes as C
+    from oracle import parity
+    from oracle import synth_index as SI
+    import os
+    n_docs, n_words, n_queries, limit = 10_000_000, 2_000_000, 80, 20
+    if os.environ.get("MSI_RUNNER_SO"):        # the CPU tier's emulated kernels: 3 chunks of documents
+        n_docs, n_words, n_queries = 150_000, 60_000, 70
+    lib = SI.runner_lib()
+    lib.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    h = lib.rb_create_corpus(n_docs, n_words, 42)
+    try:
+        assert lib.rb_attach(h, ctx.handle, 16, 1024, 2048) == 0
+        lib.rb_prepare_queries(h, n_queries, 3, 4242)
+        chk = parity.KeywordLegChecker(lib, h, n_docs)
+        queries = [chk.index.query(i) for i in range(n_queries)]
+        assert queries[0] == "" and len(queries[2].split()) == 2 and len(set(queries)) > n_queries // 2
+        cold = chk.run_product(0, n_queries, limit)
+        v = chk.verdict(0, n_queries, limit, product=cold)
+        assert v["mismatches"] == 0, v
+        assert v["checked_queries"] == n_queries and v["hits_compared"] >= 5 * n_queries
+        warm = chk.run_product(0, n_queries, limit)
+        for a, b in zip(cold, warm):
+            assert (a == b).all()
+    finally:
+        lib.rb_destroy(h)

@@ -103,8 +103,167 @@ uint64_t mix(uint64_t x) {
   return x;
 }
 
+// ---- a COHERENT corpus (round 4; VERDICT r3 #2: BASELINE.md C4 = "corpus text as C1 scaled") --------------------------
+// n_docs documents of two searchable fields — a title of 3-6 words (fid 1) and an overview of 20-60 words (fid 2, a hard
+// separator about every twelfth word) — whose words are drawn from Zipf(1.07) over the vocabulary (BASELINE.md C1's recipe).
+// The documents exist (a forward index of word ids: ~45 tokens x 4 bytes per document) and EVERY database the ranking rules
+// read is derived from those same tokens, the way milli's write path derives them (tests/toy_milli.py restates it from
+// extract_word_docids.rs:76-99,169-190, extract_word_pair_proximity_docids.rs:232-233,504-515, tokenize_document.rs:131-157):
+// word_docids (inverted at build time), and per key on first use word_fid_docids, word_position_docids (bucketed positions,
+// +1 per word, +8 over a hard separator), word_pair_proximity_docids (forward pairs, the minimum proximity 1..3 of a pair per
+// document), field_id_word_count_docids.  The dictionary is the words that occur.  Queries are taken out of the documents
+// (rb_prepare_queries), so that their words co-occur the way a user's do, then misspelled.
+struct Corpus {
+  uint64_t n_docs = 0;
+  std::vector<std::string> words;          // the vocabulary that occurs, dictionary (byte) order: word id = index
+  std::vector<uint64_t> doc_off;           // [n_docs + 1] token offsets
+  std::vector<uint32_t> tok;               // word id | OVERVIEW (this token belongs to the overview) | HARD (a hard separator before it)
+  std::vector<uint64_t> post_off;          // [n_words + 1]
+  std::vector<uint32_t> post;              // docids of every word, ascending, distinct
+  static constexpr uint32_t OVERVIEW = 1u << 31, HARD = 1u << 30, ID = (1u << 30) - 1;
+  static uint32_t bucketed(uint32_t rel) {   // lib.rs:248-262 (oracle/ranking_oracle.py: bucketed_position)
+    if (rel < 16) return rel;
+    if (rel < 24) return 24;
+    uint32_t p = 1;
+    while (p < rel) p <<= 1;
+    return p;
+  }
+  int64_t id_of(const std::string &w) const {
+    auto it = std::lower_bound(words.begin(), words.end(), w);
+    return it != words.end() && *it == w ? (int64_t)(it - words.begin()) : -1;
+  }
+  // (word id, fid, position) of every token of document d, in order
+  template <typename F>
+  void tokens(uint64_t d, F f) const {
+    uint32_t pos = 0;
+    bool first = true, in_overview = false;
+    for (uint64_t i = doc_off[d]; i < doc_off[d + 1]; ++i) {
+      const uint32_t t = tok[i];
+      const bool ov = (t & OVERVIEW) != 0;
+      if (ov != in_overview) { in_overview = ov; first = true; pos = 0; }
+      if (!first) pos += (t & HARD) ? 8u : 1u;
+      first = false;
+      f(t & ID, ov ? 2u : 1u, pos);
+    }
+  }
+  void build(uint64_t n, uint32_t vocabulary, uint64_t seed, const std::vector<std::string> &vocab_sorted, const std::vector<uint32_t> &by_rank) {
+    n_docs = n;
+    // Zipf(1.07) over the frequency ranks: alias table (Vose) — O(1) per token
+    const uint32_t V = vocabulary;
+    std::vector<double> pr(V);
+    double z = 0;
+    for (uint32_t r = 0; r < V; ++r) { pr[r] = 1.0 / std::pow((double)r + 1.0, 1.07); z += pr[r]; }
+    std::vector<float> cut(V);
+    std::vector<uint32_t> alias(V);
+    {
+      std::vector<uint32_t> small, large;
+      std::vector<double> sc(V);
+      for (uint32_t r = 0; r < V; ++r) { sc[r] = pr[r] / z * V; (sc[r] < 1.0 ? small : large).push_back(r); }
+      while (!small.empty() && !large.empty()) {
+        const uint32_t a = small.back(), b = large.back();
+        small.pop_back();
+        cut[a] = (float)sc[a];
+        alias[a] = b;
+        sc[b] = sc[b] + sc[a] - 1.0;
+        if (sc[b] < 1.0) { large.pop_back(); small.push_back(b); }
+      }
+      for (uint32_t r : large) { cut[r] = 1.0f; alias[r] = r; }
+      for (uint32_t r : small) { cut[r] = 1.0f; alias[r] = r; }
+    }
+    // document lengths first (so that every thread knows where its documents' tokens go)
+    doc_off.assign(n + 1, 0);
+    for (uint64_t d = 0; d < n; ++d) {
+      const uint64_t h = mix(seed * 0x9E3779B97F4A7C15ULL + d);
+      doc_off[d + 1] = doc_off[d] + 3 + h % 4 + 20 + (h >> 8) % 41;
+    }
+    tok.resize(doc_off[n]);
+    const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    std::vector<std::vector<uint32_t>> hist(T, std::vector<uint32_t>(V, 0));
+    for (unsigned t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        const uint64_t d0 = n * t / T, d1 = n * (t + 1) / T;
+        for (uint64_t d = d0; d < d1; ++d) {
+          const uint64_t base = mix(seed ^ (d * 0xD1B54A32D192ED03ULL));   // (a counter-based stream per document)
+          const uint64_t h = mix(seed * 0x9E3779B97F4A7C15ULL + d);
+          const uint32_t title = 3 + h % 4;
+          uint64_t at = doc_off[d];
+          const uint32_t len = (uint32_t)(doc_off[d + 1] - doc_off[d]);
+          for (uint32_t i = 0; i < len; ++i) {
+            const uint64_t x = mix(base + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ULL);
+            uint32_t r = (uint32_t)((x >> 32) % V);
+            if ((float)((x & 0xFFFFFF) / 16777216.0) >= cut[r]) r = alias[r];
+            uint32_t w = by_rank[r];
+            if (i >= title) {
+              w |= OVERVIEW;
+              if (i > title && (x >> 24 & 0xFF) < 21) w |= HARD;   // a sentence ends about every twelfth word
+            }
+            tok[at++] = w;
+            ++hist[t][w & ID];
+          }
+        }
+      });
+    for (auto &x : th) x.join();
+    th.clear();
+    // the dictionary = the words that occur; remap ids to the dictionary order of that subset
+    std::vector<uint64_t> total(V, 0);
+    for (unsigned t = 0; t < T; ++t) for (uint32_t w = 0; w < V; ++w) total[w] += hist[t][w];
+    std::vector<uint32_t> remap(V, 0xFFFFFFFFu);
+    for (uint32_t w = 0; w < V; ++w) if (total[w]) { remap[w] = (uint32_t)words.size(); words.push_back(vocab_sorted[w]); }
+    const uint32_t W = (uint32_t)words.size();
+    // inversion: per-thread ranges of documents are contiguous, so per word the threads' runs concatenate in docid order
+    post_off.assign(W + 1, 0);
+    for (uint32_t w = 0; w < V; ++w) if (total[w]) post_off[remap[w] + 1] = total[w];
+    for (uint32_t w = 0; w < W; ++w) post_off[w + 1] += post_off[w];
+    std::vector<std::vector<uint64_t>> start(T, std::vector<uint64_t>(W, 0));
+    {
+      std::vector<uint64_t> run(post_off.begin(), post_off.end() - 1);
+      for (unsigned t = 0; t < T; ++t)
+        for (uint32_t w = 0; w < V; ++w)
+          if (total[w]) { start[t][remap[w]] = run[remap[w]]; run[remap[w]] += hist[t][w]; }
+    }
+    hist.clear();
+    post.resize(post_off[W]);
+    for (unsigned t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        const uint64_t d0 = n * t / T, d1 = n * (t + 1) / T;
+        std::vector<uint64_t> &at = start[t];
+        for (uint64_t d = d0; d < d1; ++d)
+          for (uint64_t i = doc_off[d]; i < doc_off[d + 1]; ++i) {
+            const uint32_t w = remap[tok[i] & ID];
+            tok[i] = (tok[i] & ~ID) | w;
+            post[at[w]++] = (uint32_t)d;
+          }
+      });
+    for (auto &x : th) x.join();
+    // a word repeated inside a document: adjacent duplicates
+    th.clear();
+    std::vector<uint64_t> kept(W, 0);
+    for (unsigned t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        for (uint32_t w = (uint32_t)((uint64_t)W * t / T); w < (uint32_t)((uint64_t)W * (t + 1) / T); ++w) {
+          uint32_t *b = post.data() + post_off[w], *e = post.data() + post_off[w + 1];
+          kept[w] = (uint64_t)(std::unique(b, e) - b);
+        }
+      });
+    for (auto &x : th) x.join();
+    uint64_t out = 0;
+    for (uint32_t w = 0; w < W; ++w) {
+      const uint64_t from = post_off[w];
+      post_off[w] = out;
+      if (out != from) memmove(post.data() + out, post.data() + from, kept[w] * sizeof(uint32_t));
+      out += kept[w];
+    }
+    post_off[W] = out;
+    post.resize(out);
+    post.shrink_to_fit();
+  }
+  const uint32_t *posting(uint32_t w, uint64_t *n) const { *n = post_off[w + 1] - post_off[w]; return post.data() + post_off[w]; }
+};
+
 struct Index {
   uint64_t n_docs;
+  std::unique_ptr<Corpus> corpus;                 // set: the databases below are derived from the corpus's documents
   std::vector<std::string> words;                 // sorted
   std::map<std::string, uint32_t> rank;           // frequency rank
   std::shared_mutex mu;   // lookups of warm keys (all of them, after the warm-up pass) share the lock
@@ -166,15 +325,103 @@ int32_t hand(const Bytes *b, const uint8_t **bytes, size_t *n) {
 }
 std::string str(const uint8_t *w, uint32_t n) { return std::string((const char *)w, n); }
 
+// Every derived database of ONE word in one pass over its documents (a frequent word's posting is most of the corpus: its
+// fid, position and key-set reads must not scan it once per key): word_fid_docids f/<fid>/<w>, word_position_docids
+// q/<pos>/<w>, and the key sets (fids, bucketed positions) the engine's prefix_iter reads would return.
+struct WordDerived {
+  std::vector<uint16_t> fids, positions;
+};
+const WordDerived *corpus_word(Index *ix, const std::string &s) {
+  static std::mutex mu;
+  static std::map<const Index *, std::map<std::string, std::shared_ptr<WordDerived>>> all;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto &m = all[ix];
+    auto it = m.find(s);
+    if (it != m.end()) return it->second.get();
+  }
+  const Corpus &c = *ix->corpus;
+  auto wd = std::make_shared<WordDerived>();
+  const int64_t id = c.id_of(s);
+  std::map<uint32_t, std::vector<uint32_t>> by_fid, by_pos;
+  if (id >= 0) {
+    uint64_t n = 0;
+    const uint32_t *docs = c.posting((uint32_t)id, &n);
+    for (uint64_t k = 0; k < n; ++k) {
+      const uint32_t d = docs[k];
+      c.tokens(d, [&](uint32_t w, uint32_t fid, uint32_t pos) {
+        if (w != (uint32_t)id) return;
+        auto &f = by_fid[fid];
+        if (f.empty() || f.back() != d) f.push_back(d);
+        auto &q = by_pos[Corpus::bucketed(pos)];
+        if (q.empty() || q.back() != d) q.push_back(d);
+      });
+    }
+  }
+  for (auto &kv : by_fid) {
+    wd->fids.push_back((uint16_t)kv.first);
+    ix->blob("f/" + std::to_string(kv.first) + "/" + s, [&] { return kv.second; });
+  }
+  for (auto &kv : by_pos) {
+    wd->positions.push_back((uint16_t)kv.first);
+    ix->blob("q/" + std::to_string(kv.first) + "/" + s, [&] { return kv.second; });
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  return all[ix].emplace(s, wd).first->second.get();
+}
+
 int32_t cb_word(void *u, const uint8_t *w, uint32_t n, int32_t, const uint8_t **bytes, size_t *out) {
   Index *ix = (Index *)u;
   const std::string s = str(w, n);
+  if (ix->corpus)
+    return hand(ix->blob("w/" + s, [&] {
+      const int64_t id = ix->corpus->id_of(s);
+      uint64_t k = 0;
+      const uint32_t *d = id >= 0 ? ix->corpus->posting((uint32_t)id, &k) : nullptr;
+      return std::vector<uint32_t>(d, d + k);
+    }), bytes, out);
   return hand(ix->blob("w/" + s, [&] { return *ix->posting(s); }), bytes, out);
 }
 int32_t cb_pair(void *u, uint32_t prox, const uint8_t *l, uint32_t ln, const uint8_t *r, uint32_t rn, const uint8_t **bytes, size_t *out) {
   Index *ix = (Index *)u;
   const std::string a = str(l, ln), b = str(r, rn);
   if (prox < 1 || prox > 3) { *out = 0; return 0; }
+  if (ix->corpus) {
+    // the three proximities of the ordered pair (a, b) in one pass over the documents that hold both: per document the
+    // minimum over its fields of p(b) - p(a) for a before b, kept when it is 1..3 (toy_milli.py: MAX_DISTANCE 4)
+    const std::string key = "p/" + std::to_string(prox) + "/" + a + "/" + b;
+    {
+      std::shared_lock<std::shared_mutex> lk(ix->mu);
+      auto it = ix->blobs.find(key);
+      if (it != ix->blobs.end()) return hand(it->second->empty() ? nullptr : it->second.get(), bytes, out);
+    }
+    const Corpus &c = *ix->corpus;
+    const int64_t ia = c.id_of(a), ib = c.id_of(b);
+    std::vector<uint32_t> by_prox[4];
+    if (ia >= 0 && ib >= 0) {
+      uint64_t na = 0, nb = 0;
+      const uint32_t *pa = c.posting((uint32_t)ia, &na), *pb = c.posting((uint32_t)ib, &nb);
+      std::vector<uint32_t> both;
+      std::set_intersection(pa, pa + na, pb, pb + nb, std::back_inserter(both));
+      std::vector<std::pair<uint32_t, uint32_t>> pos_a;   // (fid, position) of a's occurrences seen so far in this document
+      for (uint32_t d : both) {
+        pos_a.clear();
+        uint32_t best = 4;
+        c.tokens(d, [&](uint32_t w, uint32_t fid, uint32_t pos) {
+          if (w == (uint32_t)ib)
+            for (auto &x : pos_a)
+              if (x.first == fid && pos > x.second) best = std::min(best, std::min(pos - x.second, 4u));
+          if (w == (uint32_t)ia) pos_a.push_back({fid, pos});
+        });
+        if (best >= 1 && best <= 3) by_prox[best].push_back(d);
+      }
+    }
+    for (uint32_t pr = 1; pr <= 3; ++pr)
+      ix->blob("p/" + std::to_string(pr) + "/" + a + "/" + b, [&] { return by_prox[pr]; });
+    std::shared_lock<std::shared_mutex> lk(ix->mu);
+    auto it = ix->blobs.find(key);
+    return hand(it == ix->blobs.end() || it->second->empty() ? nullptr : it->second.get(), bytes, out);
+  }
   return hand(ix->blob("p/" + std::to_string(prox) + "/" + a + "/" + b, [&] {
     auto pa = ix->posting(a), pb = ix->posting(b);
     std::vector<uint32_t> both, sel;
@@ -188,6 +435,10 @@ int32_t cb_fid(void *u, const uint8_t *w, uint32_t n, uint32_t fid, const uint8_
   Index *ix = (Index *)u;
   const std::string s = str(w, n);
   if (fid < 1 || fid > 3) { *out = 0; return 0; }
+  if (ix->corpus) {
+    corpus_word(ix, s);
+    return hand(ix->blob("f/" + std::to_string(fid) + "/" + s, [&] { return std::vector<uint32_t>(); }), bytes, out);
+  }
   return hand(ix->blob("f/" + std::to_string(fid) + "/" + s, [&] {
     std::vector<uint32_t> sel;
     for (uint32_t d : *ix->posting(s)) {
@@ -200,6 +451,10 @@ int32_t cb_fid(void *u, const uint8_t *w, uint32_t n, uint32_t fid, const uint8_
 int32_t cb_pos(void *u, const uint8_t *w, uint32_t n, uint32_t pos, const uint8_t **bytes, size_t *out) {
   Index *ix = (Index *)u;
   const std::string s = str(w, n);
+  if (ix->corpus) {
+    corpus_word(ix, s);
+    return hand(ix->blob("q/" + std::to_string(pos) + "/" + s, [&] { return std::vector<uint32_t>(); }), bytes, out);
+  }
   return hand(ix->blob("q/" + std::to_string(pos) + "/" + s, [&] {
     std::vector<uint32_t> sel;
     for (uint32_t d : *ix->posting(s)) if (Index::position((uint32_t)(mix(d + 0x77ULL * s.size()) % Index::N_POS)) == pos) sel.push_back(d);
@@ -208,6 +463,12 @@ int32_t cb_pos(void *u, const uint8_t *w, uint32_t n, uint32_t pos, const uint8_
 }
 int32_t cb_fids(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t cap, uint32_t *cnt) {
   Index *ix = (Index *)u;
+  if (ix->corpus) {
+    const WordDerived *wd = corpus_word(ix, str(w, n));
+    *cnt = (uint32_t)wd->fids.size();
+    for (uint32_t i = 0; i < wd->fids.size() && i < cap; ++i) out[i] = wd->fids[i];
+    return 0;
+  }
   const bool has = !ix->posting(str(w, n))->empty();
   *cnt = has ? 3 : 0;
   for (uint32_t i = 0; has && i < 3 && i < cap; ++i) out[i] = (uint16_t)(i + 1);
@@ -215,6 +476,12 @@ int32_t cb_fids(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t c
 }
 int32_t cb_positions(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t cap, uint32_t *cnt) {
   Index *ix = (Index *)u;
+  if (ix->corpus) {
+    const WordDerived *wd = corpus_word(ix, str(w, n));
+    *cnt = (uint32_t)wd->positions.size();
+    for (uint32_t i = 0; i < wd->positions.size() && i < cap; ++i) out[i] = wd->positions[i];
+    return 0;
+  }
   const bool has = !ix->posting(str(w, n))->empty();
   *cnt = has ? Index::N_POS : 0;
   for (uint32_t i = 0; has && i < Index::N_POS && i < cap; ++i) out[i] = (uint16_t)Index::position(i);
@@ -223,6 +490,18 @@ int32_t cb_positions(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint3
 int32_t cb_count(void *u, uint32_t fid, uint32_t count, const uint8_t **bytes, size_t *out) {
   Index *ix = (Index *)u;
   if (count > 30) { *out = 0; return 0; }
+  if (ix->corpus)   // the documents whose field holds exactly `count` words (title: 3-6, overview: 20-60 of which <= 30 are counted)
+    return hand(ix->blob("c/" + std::to_string(fid) + "/" + std::to_string(count), [&] {
+      std::vector<uint32_t> v;
+      const Corpus &c = *ix->corpus;
+      for (uint64_t d = 0; d < c.n_docs; ++d) {
+        uint32_t title = 0;
+        const uint32_t len = (uint32_t)(c.doc_off[d + 1] - c.doc_off[d]);
+        while (title < len && !(c.tok[c.doc_off[d] + title] & Corpus::OVERVIEW)) ++title;
+        if ((fid == 1 && title == count) || (fid == 2 && len - title == count)) v.push_back((uint32_t)d);
+      }
+      return v;
+    }), bytes, out);
   return hand(ix->blob("c/" + std::to_string(fid) + "/" + std::to_string(count), [&] {
     std::vector<uint32_t> v;
     std::mt19937_64 g(fid * 1000 + count);
@@ -587,6 +866,7 @@ int main(int argc, char **argv) {
 namespace {
 struct Runner {
   Index ix;
+  uint32_t n_fields = 3;                     // searchable fields of the index: fids 1..n_fields, weights 0..n_fields-1
   std::vector<std::string> frequent;
   msi_ctx *ctx = nullptr;
   msi_dict *dict = nullptr;
@@ -693,6 +973,34 @@ void *rb_create(uint64_t n_docs, uint32_t n_words) {
   for (auto &kv : r->ix.rank) if (kv.second < 300) r->frequent[kv.second] = kv.first;
   return r;
 }
+// The coherent corpus (struct Corpus) behind the same vtable: n_docs documents over a vocabulary of n_words random words,
+// every database derived from the documents' tokens.  The dictionary handed to msi_dict_create is the words that occur.
+void *rb_create_corpus(uint64_t n_docs, uint32_t n_words, uint64_t seed) {
+  Runner *r = new Runner();
+  r->ix.n_docs = n_docs;
+  std::mt19937_64 g(99);
+  std::vector<std::string> vocab;
+  {
+    std::map<std::string, int> seen;
+    const char *letters = "etaoinshrdlcumwfgypbvkjxqz";
+    while (seen.size() < n_words) {
+      const int len = 4 + (int)(g() % 6);
+      std::string w;
+      for (int i = 0; i < len; ++i) w.push_back(letters[(size_t)(std::pow((double)(g() % 10000) / 10000.0, 1.7) * 26)]);
+      seen[w] = 1;
+    }
+    for (auto &kv : seen) vocab.push_back(kv.first);
+  }
+  std::vector<uint32_t> by_rank(vocab.size());
+  for (uint32_t i = 0; i < by_rank.size(); ++i) by_rank[i] = i;
+  std::shuffle(by_rank.begin(), by_rank.end(), g);          // frequency rank -> word (index into the sorted vocabulary)
+  r->ix.corpus.reset(new Corpus());
+  r->ix.corpus->build(n_docs, (uint32_t)vocab.size(), seed, vocab, by_rank);
+  r->ix.words = r->ix.corpus->words;
+  r->n_fields = 2;
+  return r;
+}
+uint32_t rb_n_fields(void *h) { return ((Runner *)h)->n_fields; }
 // dictionary + posting cache + one pool (private stream) and one caller thread per in-flight search
 int32_t rb_attach(void *h, msi_ctx *ctx, uint32_t n_threads, uint32_t n_slots, uint64_t cache_mb) {
   Runner *r = (Runner *)h;
@@ -728,8 +1036,8 @@ int32_t rb_attach(void *h, msi_ctx *ctx, uint32_t n_threads, uint32_t n_slots, u
   r->prm.n_criteria = 7;
   r->prm.searchable_fids = r->fids;
   r->prm.searchable_weights = r->weights;
-  r->prm.n_searchable = 3;
-  r->prm.max_weight = 2;
+  r->prm.n_searchable = r->n_fields;
+  r->prm.max_weight = r->n_fields - 1;
   r->prm.detailed_scores = 1;
   r->prm.stop_after = -1;
   r->pools.resize(n_threads, nullptr);
@@ -746,6 +1054,52 @@ int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64
   Runner *r = (Runner *)h;
   std::mt19937_64 g(seed);
   r->queries.assign(n_queries, {});
+  if (r->ix.corpus) {
+    // the reference workload's shapes (workloads/search/movies.json: "" | two title words | a very
+    // frequent word | — its one-letter prefix needs the word-prefix databases and is not in the mix) once per 64 queries each,
+    // else 1..n_terms consecutive words of a random document's title or overview with 0-2 edits (a word of >= 5 chars takes one,
+    // >= 9 two: inside the typo budget, so the document can still match) and the last word cut to a prefix in a third of them
+    const Corpus &c = *r->ix.corpus;
+    const char *letters = "etaoinshrdlcumwfgypbvkjxqz";
+    auto edit = [&](std::string w) {
+      const size_t k = g() % w.size();
+      switch (g() % 4) {
+        case 0: w[k] = letters[g() % 26]; break;
+        case 1: w.insert(w.begin() + (long)k, letters[g() % 26]); break;
+        case 2: if (w.size() > 2) w.erase(w.begin() + (long)k); break;
+        default: if (k + 1 < w.size()) std::swap(w[k], w[k + 1]); break;
+      }
+      return w;
+    };
+    uint32_t most = 0;   // the word with the longest posting
+    for (uint32_t w = 1; w < c.words.size(); ++w)
+      if (c.post_off[w + 1] - c.post_off[w] > c.post_off[most + 1] - c.post_off[most]) most = w;
+    for (uint32_t qi = 0; qi < n_queries; ++qi) {
+      auto &q = r->queries[qi];
+      const uint32_t shape = qi % 64;
+      if (shape == 0) continue;                                          // "": a placeholder search
+      if (shape == 1) { q.push_back(c.words[most]); continue; }         // "the"
+      const uint64_t d = g() % c.n_docs;
+      const uint32_t len = (uint32_t)(c.doc_off[d + 1] - c.doc_off[d]);
+      uint32_t title = 0;
+      while (title < len && !(c.tok[c.doc_off[d] + title] & Corpus::OVERVIEW)) ++title;
+      uint32_t want = shape == 2 ? 2u : 1u + (uint32_t)(g() % std::max(1u, n_terms));   // ("Batman returns": two title words)
+      const bool in_title = shape == 2 || g() % 3 == 0;
+      const uint32_t f0 = in_title ? 0 : title, fl = in_title ? title : len - title;
+      want = std::min(want, fl);
+      const uint32_t at = f0 + (uint32_t)(g() % (fl - want + 1));
+      for (uint32_t i = 0; i < want; ++i) q.push_back(c.words[c.tok[c.doc_off[d] + at + i] & Corpus::ID]);
+      if (shape == 2) continue;
+      const uint32_t n_edits = (uint32_t)(g() % 10 < 5 ? 0 : (g() % 10 < 7 ? 1 : 2));
+      for (uint32_t e = 0; e < n_edits; ++e) {
+        std::string &w = q[g() % q.size()];
+        const size_t budget = w.size() >= 9 ? 2 : (w.size() >= 5 ? 1 : 0);
+        if (budget > e) w = edit(w);
+      }
+      if (g() % 3 == 0 && q.back().size() > 4) q.back().resize(4 + g() % (q.back().size() - 4));
+    }
+    return MSI_OK;
+  }
   for (auto &q : r->queries) for (uint32_t i = 0; i < n_terms; ++i) q.push_back(r->frequent[g() % 300]);
   return MSI_OK;
 }
