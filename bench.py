@@ -552,7 +552,7 @@ def run_c4(args, env):
         # granted CPU (160 on a 16-CPU grant: 12.8 CPUs busy; 192 callers measured 15.5 CPUs and 256 callers ran into the
         # quota and lost two thirds of the throughput, profiles/r3_callers.txt), at least 16
         host_cpus = granted_cpus()
-        kw_threads = max(16, min(args.kw_threads, host_cpus * 10 // world))
+        kw_threads = max(16, min(args.kw_threads, host_cpus * int(os.environ.get("MSI_BENCH_CALLERS_PER_CPU", "10")) // world))
         assert kw_lib.rb_attach(h, ctx.handle, kw_threads, args.kw_slots, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
         n_kw_queries = 4 * Q
         kw_lib.rb_prepare_queries(h, n_kw_queries, args.kw_terms, 4242 + rank)
@@ -1388,10 +1388,43 @@ def run_c5(args, env):
     nodes = [(i, i, t[0], t[1], t[2], t[3]) for i, t in enumerate(terms)]
     batch = R.RankBatch(pool, [(nodes, nt, UNI + 5 * i, UNI + 5 * i + 1) for i in range(B)])
     fptr = pool.device_ptr(FILTER)
+    # ---- the rerank as BASELINE.md C5 writes it: the FULL default criteria (words, typo, proximity, attributeRank, sort,
+    # wordPosition, exactness; detailed scores) over a text index of the same documents, every query ranked inside its own
+    # top-1000 — msi_keyword_search_ranked with the candidate set as its universe, one caller thread per query of the batch.
+    # The text index is the coherent corpus of tools/ranked_bench.cpp at this shard's size (200 000-word vocabulary).
+    import ctypes as C
+    kw_so = os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so")
+    kwl = C.CDLL(kw_so)
+    kwl.rb_create_corpus.restype = C.c_void_p
+    kwl.rb_create_corpus.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
+    kwl.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    kwl.rb_prepare_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    kwl.rb_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    kwl.rb_run_universes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+    kwl.rb_destroy.argtypes = [C.c_void_p]
+    kwh = kwl.rb_create_corpus(n, 200_000, 43)
+    assert kwl.rb_attach(kwh, ctx.handle, B, 256, 1024) == 0, "keyword runner: rb_attach failed"
+    kwl.rb_prepare_queries(kwh, 4 * B, 3, 777 + env.rank)
+    rr_ids, rr_n, rr_sc = np.zeros((B, 20), np.uint32), np.zeros(B, np.uint32), np.zeros((B, 20), np.float64)
+    for first in range(0, 4 * B, B):        # untimed: the index derives the databases these queries read
+        assert kwl.rb_run(kwh, first, B, 20, rr_ids.ctypes.data, rr_n.ctypes.data, rr_sc.ctypes.data) == 0
+    rr_step = [0]
 
     def step():
         store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact, filter_ptr=fptr, filter_nbits=n)
-        # the top-1000 of every query become the rerank universes on the device (same stream: no sync, no copy)
+        ctx.synchronize()
+        u_ids = np.ascontiguousarray(out_ids.cpu().numpy().view(np.uint32))      # what the Rust caller receives: the candidates
+        u_cnt = np.ascontiguousarray(out_cnt.cpu().numpy().view(np.uint32))
+        first = (rr_step[0] * B) % (4 * B)
+        rr_step[0] += 1
+        assert kwl.rb_run_universes(kwh, first, B, 20, u_ids.ctypes.data, u_cnt.ctypes.data, k, rr_ids.ctypes.data, rr_n.ctypes.data,
+                                    rr_sc.ctypes.data, None, None, None) == 0
+        return rr_ids, rr_n
+
+    def step_fast():
+        # rounds 1-3: the Words -> Typo prefix of the criteria as one bit-sliced kernel over synthetic term sets, the top-1000
+        # of every query turned into its universe on the device (same stream: no sync, no copy)
+        store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact, filter_ptr=fptr, filter_nbits=n)
         pool.set_from_docid_lists_device(UNI, 5, out_ids, out_cnt)
         return batch.run(R.TERMS_LAST, True, 0, 20)
 
@@ -1419,6 +1452,12 @@ def run_c5(args, env):
         for _ in range(args.steps):
             knn_only()
         knn_ms = (time.perf_counter() - t_k) / args.steps * 1e3
+        step_fast()
+        t_k = time.perf_counter()
+        for _ in range(args.steps):
+            step_fast()
+        ctx.synchronize()
+        fast_ms = (time.perf_counter() - t_k) / args.steps * 1e3
         st = store.stats()
         if env.rank != 0:
             continue
@@ -1432,6 +1471,7 @@ def run_c5(args, env):
             "value": round(B * env.world * args.steps / elapsed, 2), "unit": "queries/s",
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(statistics.median(lat), 4),
             "knn_only_ms_per_step": round(knn_ms, 4),
+            "words_typo_fast_path_ms_per_step": round(fast_ms, 4), "words_typo_fast_path_queries_per_s": round(B / (fast_ms * 1e-3), 1),
             "tiles_streamed_per_launch": allowed_tiles, "tiles_in_store": (n + 15) // 16,
             "scan_tiles_counted_by_the_library": int((st["scan_tiles"] - t0s) / max(1, st["scan_launches"] - l0s)),
             "bytes_streamed_over_allowed_row_bytes": round(algo_bytes / max(1, n_allowed * row_bytes), 2),
@@ -1468,6 +1508,14 @@ def run_c5(args, env):
             same = bool((out_ids[:nqc, :kk].cpu().numpy().view(np.uint32) == got[0][:, :kk]).all())
             par["timed_path_equals_checked_path"] = same
             par["mismatches"] += 0 if same else 1
+            if sel_d == 0.01:
+                # the rerank: 8 queries of the batch inside their own (checked) top-1000 against oracle/ranking_oracle.py
+                from oracle import synth_index as SI
+                kchk = parity.KeywordLegChecker(SI.runner_lib(), kwh, n)
+                uni = (np.ascontiguousarray(got[0][:8]), np.ascontiguousarray(got[2][:8]))
+                rpar = kchk.verdict(0, 8, 20, universes=uni)
+                par["rerank"] = rpar
+                par["mismatches"] += rpar["mismatches"]
             line["parity"] = par
             del sub, al_t
         per_density[f"{sel_d:g}"] = line
@@ -1483,8 +1531,9 @@ def run_c5(args, env):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 rows, f32 arithmetic",
         "data": "synthetic (rows N(0,1) seed 1234 rounded to bf16; filter seed 31; BASELINE.md C5)",
         "config": {"workload": f"C5 shard: {n} docs x {d}-d {storage}, candidate filter resident in HBM at 10 % / 1 % / 0.1 % (the line's own "
-                               f"numbers: 1 %), exact cosine top-{k}, Words->Typo rerank of each top-{k} (3 terms), top-20 returned; "
-                               f"{B} queries per step",
+                               f"numbers: 1 %), exact cosine top-{k}, then the keyword ranking of every query INSIDE its top-{k} with the full "
+                               f"default criteria (msi_keyword_search_ranked, candidate set = universe; coherent text corpus of the same {n} "
+                               f"documents, 1-3 word queries with typos), top-20 returned; {B} queries per step, one caller per query",
                    "tiles_streamed_per_launch": main["tiles_streamed_per_launch"], "tiles_in_store": (n + 15) // 16,
                    "scan_tiles_counted_by_the_library": main["scan_tiles_counted_by_the_library"],
                    "inexact_queries_last_step": main["inexact_queries_last_step"],
@@ -1495,6 +1544,7 @@ def run_c5(args, env):
         "roofline": main["roofline"],
         "densities": per_density,
     }
+    kwl.rb_destroy(kwh)
     if "cpu_baseline" in main:
         out["cpu_baseline"] = main["cpu_baseline"]
     if "parity" in main:

@@ -122,28 +122,37 @@ class KeywordLegChecker:
         self.index = SI.SynthIndex(SI_lib, runner_handle, n_docs)
         self.oracle = SI.KeywordOracle(self.index)
 
-    def run_product(self, first, n, limit, max_details=16):
+    def run_product(self, first, n, limit, max_details=16, universes=None):
         """The product's answers for prepared queries [first, first + n): rb_run_detailed (caller threads of the
-        runner, msi_keyword_search_ranked each)."""
+        runner, msi_keyword_search_ranked each).  universes = (docids [n, stride] u32, counts [n] u32): every search
+        restricted to its own candidate set (the rerank of a vector search's top-k, config 5)."""
         ids = np.zeros((n, limit), np.uint32)
         cnt = np.zeros(n, np.uint32)
         scores = np.zeros((n, limit), np.float64)
         det = np.zeros((n, limit, max_details, 3), np.uint32)
         ndet = np.zeros((n, limit), np.uint32)
         cand = np.zeros(n, np.uint64)
-        st = self.index.lib.rb_run_detailed(self.h, first, n, limit, ids.ctypes.data, cnt.ctypes.data, scores.ctypes.data,
-                                            det.ctypes.data, ndet.ctypes.data, cand.ctypes.data)
+        if universes is not None:
+            u_ids = np.ascontiguousarray(universes[0], dtype=np.uint32)
+            u_cnt = np.ascontiguousarray(universes[1], dtype=np.uint32)
+            st = self.index.lib.rb_run_universes(self.h, first, n, limit, u_ids.ctypes.data, u_cnt.ctypes.data, u_ids.shape[1],
+                                                 ids.ctypes.data, cnt.ctypes.data, scores.ctypes.data, det.ctypes.data,
+                                                 ndet.ctypes.data, cand.ctypes.data)
+        else:
+            st = self.index.lib.rb_run_detailed(self.h, first, n, limit, ids.ctypes.data, cnt.ctypes.data, scores.ctypes.data,
+                                                det.ctypes.data, ndet.ctypes.data, cand.ctypes.data)
         assert st == 0, "msi_keyword_search_ranked failed"
         return ids, cnt, scores, det, ndet, cand
 
-    def verdict(self, first, n, limit, product=None):
+    def verdict(self, first, n, limit, product=None, universes=None):
         """-> dict for the bench line's parity object / the test's assertion."""
         SI = self.SI
-        ids, cnt, scores, det, ndet, cand = product if product is not None else self.run_product(first, n, limit)
+        ids, cnt, scores, det, ndet, cand = product if product is not None else self.run_product(first, n, limit, universes=universes)
         bad, first_bad, hits, n_details = 0, None, 0, 0
         for i in range(n):
             q = self.index.query(first + i)
-            want_ids, want_sc, want_cand = self.oracle.search(q, limit=limit, detailed=True)
+            uni = None if universes is None else np.asarray(universes[0][i][:int(universes[1][i])])
+            want_ids, want_sc, want_cand = self.oracle.search(q, limit=limit, detailed=True, universe=uni)
             got = SI.product_details(ids[i], cnt[i], det[i], ndet[i], limit, det.shape[2])
             want = [(d, [SI.oracle_detail(s) for s in sc]) for d, sc in zip(want_ids, want_sc)]
             hits += len(want)

@@ -49,6 +49,7 @@ def runner_lib():
                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.rb_read_keys.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.rb_run_detailed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
+    lib.rb_run_universes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
     return lib
 
 
@@ -193,11 +194,12 @@ class KeywordOracle:
         w = self.index.words
         return [w[i] for i in one], [w[i] for i in two]
 
-    def search(self, query, limit=20, detailed=True, tms="last"):
+    def search(self, query, limit=20, detailed=True, tms="last", universe=None):
         from oracle import ranking_oracle as RO
         with RO.use_docset(self.index.DocSet):
+            uni = None if universe is None else self.index.DocSet.from_sorted(np.unique(np.asarray(universe, dtype=np.uint32)))
             ids, scores, cand = RO.search(RO.Ctx(self.index, self.lookup), query, tms=tms, criteria=self.index.criteria,
-                                          length=limit, detailed=detailed)
+                                          length=limit, detailed=detailed, universe=uni)
         return ids, scores, len(cand)
 
 

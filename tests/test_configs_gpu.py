@@ -188,3 +188,38 @@ def test_c4_keyword_leg_on_the_coherent_corpus(ctx):
             assert (a == b).all()
     finally:
         lib.rb_destroy(h)
+
+
+def test_rerank_inside_candidate_universes_on_the_corpus(ctx):
+    """Config 5's second half as written: the keyword ranking (all default criteria, detailed scores) of a query restricted
+    to a candidate set of 1 000 documents — what reranks a filtered vector search's top-1000 — through the runner's
+    rb_run_universes (the universe reaches msi_keyword_search_ranked as the CboRoaringBitmap the shim would pass), against
+    oracle/ranking_oracle.py given the same universe."""
+    import ctypes as C
+    from oracle import parity
+    from oracle import synth_index as SI
+    import os
+    n_docs, n_words, n_queries, limit = 2_000_000, 200_000, 32, 20
+    if os.environ.get("MSI_RUNNER_SO"):
+        n_docs, n_words, n_queries = 150_000, 60_000, 24
+    lib = SI.runner_lib()
+    lib.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    h = lib.rb_create_corpus(n_docs, n_words, 43)
+    try:
+        assert lib.rb_attach(h, ctx.handle, 8, 512, 512) == 0
+        lib.rb_prepare_queries(h, n_queries, 3, 99)
+        chk = parity.KeywordLegChecker(lib, h, n_docs)
+        rng = np.random.default_rng(5)
+        # candidate sets that hold matches: half of each from the query's own result list region (low docids are as good as any)
+        uni = np.zeros((n_queries, 1000), np.uint32)
+        cnt = np.full(n_queries, 1000, np.uint32)
+        plain = chk.run_product(0, n_queries, 200)
+        for i in range(n_queries):
+            hits = plain[0][i, :int(plain[1][i])]
+            rest = rng.choice(n_docs, 1000 - hits.size, replace=False).astype(np.uint32)
+            uni[i] = np.concatenate([hits, rest])
+        v = chk.verdict(0, n_queries, limit, universes=(uni, cnt))
+        assert v["mismatches"] == 0, v
+        assert v["hits_compared"] >= 3 * n_queries
+    finally:
+        lib.rb_destroy(h)

@@ -887,12 +887,17 @@ struct Runner {
   msi_score_detail *out_details = nullptr;   // nullable: [n][limit][MSI_MAX_SCORE_DETAILS]
   uint32_t *out_n_details = nullptr;         // nullable: [n][limit]
   uint64_t *out_candidates = nullptr;        // nullable: [n]
+  // nullable: the candidate universe of every search of the job ([n][uni_stride] docids in any order + [n] counts): the
+  // rerank of a vector search's top-k (config 5) — handed to the engine as the CboRoaringBitmap the shim would pass
+  const uint32_t *uni_ids = nullptr, *uni_cnt = nullptr, *pending_uni_ids = nullptr, *pending_uni_cnt = nullptr;
+  uint32_t uni_stride = 0, pending_uni_stride = 0;
   std::vector<double> lat_ms;                // wall time of every search of the last job (rb_last_latencies)
   bool stop = false;
   std::atomic<int32_t> failed{0};
 
   int32_t search(msi_bits *pool, const std::vector<std::string> &q, uint32_t limit, uint32_t *ids, uint32_t *n, double *scores,
-                 msi_score_detail *details = nullptr, uint32_t *n_details = nullptr, uint64_t *candidates = nullptr) {
+                 msi_score_detail *details = nullptr, uint32_t *n_details = nullptr, uint64_t *candidates = nullptr,
+                 const Bytes *universe = nullptr) {
     std::vector<msi_query_token> toks(q.size());
     std::vector<msi_located_term> terms(q.size());
     for (size_t i = 0; i < q.size(); ++i) {
@@ -904,7 +909,8 @@ struct Runner {
     std::vector<msi_score_detail> sc((size_t)limit * MSI_MAX_SCORE_DETAILS);
     std::vector<uint32_t> nsc(limit);
     uint64_t cand = 0;
-    const int32_t st = msi_keyword_search_ranked(dict, pool, &vt, terms.data(), (uint32_t)terms.size(), &p, nullptr, 0, ids, sc.data(),
+    const int32_t st = msi_keyword_search_ranked(dict, pool, &vt, terms.data(), (uint32_t)terms.size(), &p,
+                                                 universe ? universe->data() : nullptr, universe ? universe->size() : 0, ids, sc.data(),
                                                  nsc.data(), n, &cand, nullptr);
     if (st != MSI_OK) return st;
     for (uint32_t i = 0; i < *n; ++i) scores[i] = msi_score_details_global_score(sc.data() + (size_t)i * MSI_MAX_SCORE_DETAILS, nsc[i]);
@@ -931,10 +937,17 @@ struct Runner {
         }
         const std::vector<std::string> &q = queries[(job_first + i) % queries.size()];
         const auto t_search = std::chrono::steady_clock::now();
+        Bytes uni;
+        if (uni_ids) {
+          std::vector<uint32_t> u(uni_ids + (size_t)i * uni_stride, uni_ids + (size_t)i * uni_stride + uni_cnt[i]);
+          std::sort(u.begin(), u.end());
+          u.erase(std::unique(u.begin(), u.end()), u.end());
+          uni = cbo_serialize(u);
+        }
         const int32_t st = search(pools[t], q, job_limit, out_ids + (size_t)i * job_limit, out_n + i, out_scores + (size_t)i * job_limit,
                                   out_details ? out_details + (size_t)i * job_limit * MSI_MAX_SCORE_DETAILS : nullptr,
                                   out_n_details ? out_n_details + (size_t)i * job_limit : nullptr,
-                                  out_candidates ? out_candidates + i : nullptr);
+                                  out_candidates ? out_candidates + i : nullptr, uni_ids ? &uni : nullptr);
         if (st != MSI_OK) {
           if (!failed.exchange(1)) {
             std::string words;
@@ -1114,6 +1127,8 @@ int32_t rb_start_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, u
   r->job_first = first; r->job_n = n; r->job_limit = limit; r->next = 0; r->done = 0;
   r->out_ids = out_ids; r->out_n = out_n; r->out_scores = out_scores;
   r->out_details = out_details; r->out_n_details = out_n_details; r->out_candidates = out_candidates;
+  r->uni_ids = r->pending_uni_ids; r->uni_cnt = r->pending_uni_cnt; r->uni_stride = r->pending_uni_stride;
+  r->pending_uni_ids = r->pending_uni_cnt = nullptr;
   r->lat_ms.assign(n, 0.0);
   ++r->epoch;
   r->cv.notify_all();
@@ -1134,6 +1149,14 @@ int32_t rb_run_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, uin
                         msi_score_detail *out_details, uint32_t *out_n_details, uint64_t *out_candidates) {
   const int32_t st = rb_start_detailed(h, first, n, limit, out_ids, out_n, out_scores, out_details, out_n_details, out_candidates);
   return st != MSI_OK ? st : rb_wait(h);
+}
+// as rb_run_detailed, every search restricted to its own candidate universe: uni_ids [n][stride] docids (any order), uni_cnt [n]
+int32_t rb_run_universes(void *h, uint32_t first, uint32_t n, uint32_t limit, const uint32_t *uni_ids, const uint32_t *uni_cnt,
+                         uint32_t stride, uint32_t *out_ids, uint32_t *out_n, double *out_scores, msi_score_detail *out_details,
+                         uint32_t *out_n_details, uint64_t *out_candidates) {
+  Runner *r = (Runner *)h;
+  r->pending_uni_ids = uni_ids; r->pending_uni_cnt = uni_cnt; r->pending_uni_stride = stride;
+  return rb_run_detailed(h, first, n, limit, out_ids, out_n, out_scores, out_details, out_n_details, out_candidates);
 }
 int32_t rb_run(void *h, uint32_t first, uint32_t n, uint32_t limit, uint32_t *out_ids, uint32_t *out_n, double *out_scores) {
   return rb_run_detailed(h, first, n, limit, out_ids, out_n, out_scores, nullptr, nullptr, nullptr);
