@@ -914,6 +914,13 @@ def run_c4(args, env):
                         "queries sharded, index replicated per GPU, ONE packed all-gather of per-rank top-k per step; exchange path: " + exchange_path,
             "rccl_ranks_seen": rccl_ranks_seen,
             "keyword_callers_per_rank": kw_threads if kw is not None else 0, "host_cpus_granted": granted_cpus(),
+            # N > 1: all ranks share the box's granted CPUs, and a keyword search costs host CPU whichever GPU runs its sets — the
+            # keyword leg of the whole job cannot exceed granted CPUs / host CPU per query (measured on one GPU this round:
+            # ~1.0 ms per query on the round-3 workload, ~0.8 ms on the coherent corpus: profiles/r4_*), so with 16 granted CPUs
+            # the hybrid weak-scaling curve flattens near 2.5-3x whatever RCCL does; the vector leg scales with the GPUs
+            "predicted_keyword_cap_queries_per_s_whole_job": round(granted_cpus() / 0.9e-3, 0) if kw is not None else None,
+            "predicted_cap_is": "granted CPUs / 0.9 ms of host CPU per keyword query (round-4 measurement, MSI_SEARCH_CPU_PROFILE); "
+                                "the measured value of an N-GPU line is to be read against it",
             "step_includes": ["vs_scan + select + reference rescoring", "dict_lookup (scan of the first-letter range, "
                               "binary searches for the other first letters, cap logic)", "D2H of results"]
                              + ([] if kw is None else [

@@ -313,6 +313,15 @@ struct DictArgs {
   uint32_t nq;
   uint32_t cap1, cap2, capx;
   uint32_t *wlists;          // [grid][LW][cap1+cap2] per-wave hit lists (distance 1 | distance 2)
+  // The unit of work of dict_lookup_kernel is a SLICE of a query's first-letter range (slice_tiles 64-word tiles): ranges
+  // differ 20x between first letters, and with one workgroup per query a launch ended with a few workgroups walking the
+  // longest ranges (8 192 queries: 2.2 M words/s, 32 768: 4.1 M).  dict_plan_kernel lays the units out.
+  const uint32_t *unit_off;  // [nq + 1] first unit of every query; unit_off[nq] = units of the batch
+  const uint32_t *unit_q;    // [units] the query of every unit
+  uint32_t *slice_done;      // [nq] units of the query that have handed in their lists
+  uint32_t *ulists;          // [units][cap1 + cap2] a unit's hits in dictionary order (distance 1 | distance 2), capped
+  uint32_t *ucnt;            // [units][2]
+  uint32_t slice_tiles;
   uint32_t *xq;              // [nq][capx] other-first-char words at distance <= 1 (dict_other_kernel) ...
   uint32_t *xq_cnt;          // [nq]       ... and how many
   uint32_t *ticket;          // next query to take
@@ -385,8 +394,9 @@ struct WaveLists {
   const uint32_t *base;
   uint32_t stride, off, cls, w, i;
   const uint32_t (*cnt)[2];
-  __device__ __forceinline__ void settle() { while (w < (uint32_t)LW && i >= cnt[w][cls]) { ++w; i = 0; } }
-  __device__ __forceinline__ bool done() const { return w >= (uint32_t)LW; }
+  uint32_t n;    // lists (the units of a query, in order)
+  __device__ __forceinline__ void settle() { while (w < n && i >= cnt[w][cls]) { ++w; i = 0; } }
+  __device__ __forceinline__ bool done() const { return w >= n; }
   __device__ __forceinline__ uint32_t peek() const { return base[(size_t)w * stride + off + i]; }
   __device__ __forceinline__ void pop() { ++i; settle(); }
 };
@@ -404,6 +414,43 @@ struct WaveLists {
 //           exact strings (prefix rule: string prefixes), so they are binary searches in the sorted dictionary —
 //           two per dictionary first char c, two more for the shapes without c — instead of a scan.
 //   caps    the reference's sequential cap logic in closed form (header of this file) over the three lists.
+// Units of the batch: query q gets ceil(tiles of its first-letter range / slice_tiles) of them (at least one: the cap logic
+// runs for every query).  One workgroup: per-thread sums over contiguous queries, a scan over the threads, then the offsets
+// and the unit -> query table.
+__global__ __launch_bounds__(1024) void dict_plan_kernel(const QueryMeta *__restrict__ qm, uint32_t nq, uint32_t slice_tiles,
+                                                         uint32_t *__restrict__ unit_off, uint32_t *__restrict__ unit_q,
+                                                         uint32_t *__restrict__ slice_done, uint32_t max_units) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (nq + 1023) / 1024, q0 = min(nq, tid * per), q1 = min(nq, q0 + per);
+  auto units_of = [&](uint32_t q) -> uint32_t {
+    const QueryMeta m = qm[q];
+    if (m.budget == 0 || m.hi <= m.lo) return 1u;
+    const uint32_t n_t = ((m.hi + 63) >> 6) - (m.lo >> 6);
+    return (n_t + slice_tiles - 1) / slice_tiles;
+  };
+  uint32_t mine = 0;
+  for (uint32_t q = q0; q < q1; ++q) mine += units_of(q);
+  s_part[tid] = mine;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024; o <<= 1) {   // inclusive scan
+    const uint32_t v = tid >= o ? s_part[tid - o] : 0u;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t at = s_part[tid] - mine;
+  for (uint32_t q = q0; q < q1; ++q) {
+    const uint32_t n = units_of(q);
+    unit_off[q] = at;
+    slice_done[q] = 0;
+    for (uint32_t i = 0; i < n; ++i)
+      if (at + i < max_units) unit_q[at + i] = q;
+    at += n;
+  }
+  if (tid == 1023) unit_off[nq] = min(s_part[1023], max_units);   // (the host sized the lists for max_units: never exceeded by construction)
+}
+
 // The words with ANOTHER first char than the query's: they match only at distance <= 1, through one edit on position 0 —
 // exact strings (string prefixes under the prefix rule), i.e. binary searches in the sorted dictionary.  A kernel of its own
 // since round 4: inside dict_lookup_kernel its registers (patterns, comparison loops) were what kept that kernel — bound
@@ -526,7 +573,7 @@ __device__ __forceinline__ void dict_lookup_body(const DictArgs &a) {
   __shared__ uint32_t s_q[QSTRIDE];
   __shared__ uint32_t s_pq[LW][PQ];
   __shared__ uint32_t s_wcnt[LW][2];
-  __shared__ uint32_t s_query;
+  __shared__ uint32_t s_query, s_last;
   __shared__ u64 s_t[4];               // MSI_DICT_PROFILE: thread 0's timestamps (LDS: no register lives across the phases for them)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64 lower = (1ull << lane) - 1ull;
@@ -539,20 +586,22 @@ __device__ __forceinline__ void dict_lookup_body(const DictArgs &a) {
     __syncthreads();  // the previous query's LDS state is no longer read
     if (tid == 0) s_query = atomicAdd(a.ticket, 1u);
     __syncthreads();
-    const uint32_t q = s_query;
-    if (q >= a.nq) break;
+    const uint32_t u = s_query;                 // the unit: slice `sl` of query q's first-letter range
+    if (u >= a.unit_off[a.nq]) break;
+    const uint32_t q = a.unit_q[u];
+    const uint32_t sl = u - a.unit_off[q], n_sl = a.unit_off[q + 1] - a.unit_off[q];
     if (a.prof && tid == 0) {
       s_t[0] = wall_clock64();
       s_t[3] = 0;
     }
     const QueryMeta qm = a.qm[q];
     const int K = (int)qm.budget;
+    const int m = (int)qm.m;
+    if ((uint32_t)m < a.m_lo || (uint32_t)m > a.m_hi) continue;   // the other launch's query
     if (K == 0) {
       if (tid == 0) a.out_one_cnt[q] = a.out_two_cnt[q] = 0;
       continue;
     }
-    const int m = (int)qm.m;
-    if ((uint32_t)m < a.m_lo || (uint32_t)m > a.m_hi) continue;   // the other launch's query
     const bool prefix = qm.prefix != 0;
     for (uint32_t i = tid; i < (uint32_t)m; i += LT) s_q[i] = a.qchars[(size_t)q * QSTRIDE + i];
     constexpr bool bits = BITS;   // (the bit-parallel launch is only given queries of <= 64 chars: no banded code in it)
@@ -634,7 +683,9 @@ __device__ __forceinline__ void dict_lookup_body(const DictArgs &a) {
       if (a.prof && tid == 0) s_t[3] += wall_clock64() - t_d0;
     };
     if (qm.hi > qm.lo) {
-      const uint32_t t_lo = qm.lo >> 6, t_hi = (qm.hi + 63) >> 6, n_t = t_hi - t_lo;
+      // this unit's tiles of the range
+      const uint32_t r_lo = qm.lo >> 6, r_hi = (qm.hi + 63) >> 6;
+      const uint32_t t_lo = min(r_hi, r_lo + sl * a.slice_tiles), t_hi = min(r_hi, t_lo + a.slice_tiles), n_t = t_hi - t_lo;
       const uint32_t t0 = t_lo + (uint32_t)((u64)n_t * wave / LW), t1 = t_lo + (uint32_t)((u64)n_t * (wave + 1) / LW);
       // The filter is a stream of 8-byte loads with a ballot behind each: one tile (64 words) per iteration left a wave
       // with a single load in flight — latency-bound at ~2 us per 64 words (r3: 0.15 of the VALU issue peak, 11 % VALU-active).
@@ -680,13 +731,41 @@ __device__ __forceinline__ void dict_lookup_body(const DictArgs &a) {
 
     // (the words with ANOTHER first char at distance <= 1 were found by dict_other_kernel: a.xq / a.xq_cnt)
     __syncthreads();  // s_wcnt and the waves' lists are complete
+    // ---- this unit's hits, in dictionary order (wave order), capped: the unit list --------------------------------
+    {
+      uint32_t *const ul = a.ulists + (size_t)u * stride_w;
+      const uint32_t *wl0 = a.wlists + (size_t)blockIdx.x * LW * stride_w;
+      uint32_t off0 = 0, off1 = 0;
+      for (uint32_t w = 0; w < (uint32_t)LW; ++w) {
+        const uint32_t c0 = s_wcnt[w][0], c1 = s_wcnt[w][1];
+        for (uint32_t i = tid; i < c0; i += LT)
+          if (off0 + i < a.cap1) ul[off0 + i] = wl0[(size_t)w * stride_w + i];
+        for (uint32_t i = tid; i < c1; i += LT)
+          if (off1 + i < a.cap2) ul[a.cap1 + off1 + i] = wl0[(size_t)w * stride_w + a.cap1 + i];
+        off0 += c0;
+        off1 += c1;
+      }
+      if (tid == 0) {
+        a.ucnt[2 * (size_t)u] = min(off0, a.cap1);
+        a.ucnt[2 * (size_t)u + 1] = min(off1, a.cap2);
+      }
+    }
+    // the unit that completes the query runs its cap logic over the units' lists (release / acquire around the counter)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&a.slice_done[q], 1u) == n_sl - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) continue;
+    __threadfence();
+
     // ---- caps: the closed form of compute_derivations.rs:129-163 ------------------------------------
     if (tid == 0) {
       const u64 t_q3 = a.prof ? wall_clock64() : 0;
       const uint32_t *const xl = a.xq + (size_t)q * a.capx;
       const uint32_t xn = (K == 2 && a.n_fc > 0) ? a.xq_cnt[q] : 0u;
-      const uint32_t *wl0 = a.wlists + (size_t)blockIdx.x * LW * stride_w;
-      WaveLists s1{wl0, stride_w, 0, 0, 0, 0, s_wcnt}, s2{wl0, stride_w, a.cap1, 1, 0, 0, s_wcnt};
+      const uint32_t *ul0 = a.ulists + (size_t)a.unit_off[q] * stride_w;
+      const uint32_t(*uc)[2] = reinterpret_cast<const uint32_t(*)[2]>(a.ucnt + 2 * (size_t)a.unit_off[q]);
+      WaveLists s1{ul0, stride_w, 0, 0, 0, 0, uc, n_sl}, s2{ul0, stride_w, a.cap1, 1, 0, 0, uc, n_sl};
       s1.settle();
       s2.settle();
       uint32_t *one = a.out_one + (size_t)q * a.cap1;
@@ -827,6 +906,8 @@ struct msi_dict {
   DevBuf slots, filt, wmeta, flat, offs, fc_start;
   // scratch (guarded by ctx->mu_aux)
   DevBuf qbytes, qoff, qflags, qm, qchars, wlists, xq, xq_cnt, ticket, pairs, out1, out1c, out2, out2c, prof;
+  DevBuf unit_off, unit_q, slice_done, ulists, ucnt;
+  uint32_t max_block_tiles = 1;   // 64-word tiles of the largest first-letter block (what a query's range can be at most)
   // host entry point (msi_dict_lookup): pinned staging of the packed queries and results, and an event the caller
   // SLEEPS on — with pageable buffers every copy was a staged, spinning call and hipStreamSynchronize a busy-wait: a fifth
   // of the host CPU of the keyword leg at 64 callers (profiles/r3_ranked_cpu_profile_before.txt)
@@ -919,17 +1000,31 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   hipLaunchKernelGGL(dict_prep_kernel, dim3((n + 127) / 128), dim3(128), 0, st, d_qbytes, d_qoff, d_qflags, n,
                      d->slots.as<uint4>(), d->n_words, d->qm.as<QueryMeta>(), d->qchars.as<uint32_t>(), d->ticket.as<uint32_t>() + 2);
   // one workgroup per query in flight (persistent, queries by ticket): as many as the kernel's registers let a CU hold
-  // (what the kernels are compiled for: 5 / 6 waves per SIMD = workgroups of 4 waves per CU; tests/test_isa_cpu.py holds the
+  // (what the kernels are compiled for: 4 / 6 waves per SIMD = workgroups of 4 waves per CU; tests/test_isa_cpu.py holds the
   // register counts behind these; MSI_DICT_WG_PER_CU overrides for experiments)
   static int wg_per_cu[2] = {0, 0};   // [banded, bit-parallel]
   if (!wg_per_cu[0]) {
     const int knob = getenv("MSI_DICT_WG_PER_CU") ? atoi(getenv("MSI_DICT_WG_PER_CU")) : 0;
     wg_per_cu[1] = knob > 0 ? knob : 6;
-    wg_per_cu[0] = knob > 0 ? knob : 5;
+    wg_per_cu[0] = knob > 0 ? knob : 4;
   }
   const uint32_t grid_cap = (uint32_t)ctx->n_cu * (uint32_t)std::max(wg_per_cu[0], wg_per_cu[1]);
-  const uint32_t grid = std::min<uint32_t>(n, grid_cap);
+  // slices of a query's first-letter range (DictArgs::unit_off): 256 tiles = 16 384 words each — wider when the batch is so
+  // large that its units' lists would not fit a 128 Mi-entry budget (a range has at most max_block_tiles tiles)
+  uint32_t slice_tiles = 256;
+  if (const char *e = getenv("MSI_DICT_SLICE_TILES")) slice_tiles = (uint32_t)std::max(1, atoi(e));   // experiments
+  auto units_bound = [&](uint32_t st_) { return (uint64_t)n * ((d->max_block_tiles + st_ - 1) / st_); };
+  while (units_bound(slice_tiles) * (cap1 + cap2) > (128ull << 20) && slice_tiles < (1u << 24)) slice_tiles *= 2;
+  const uint32_t max_units = (uint32_t)std::min<uint64_t>(units_bound(slice_tiles), 0x7FFFFFFFull);
+  const uint32_t grid = std::min<uint32_t>(max_units, grid_cap);
   MSI_TRY(d->wlists.ensure((size_t)grid * LW * (cap1 + cap2) * sizeof(uint32_t)));
+  MSI_TRY(d->unit_off.ensure(((size_t)n + 1) * sizeof(uint32_t)));
+  MSI_TRY(d->unit_q.ensure((size_t)max_units * sizeof(uint32_t)));
+  MSI_TRY(d->slice_done.ensure((size_t)n * sizeof(uint32_t)));
+  MSI_TRY(d->ulists.ensure((size_t)max_units * (cap1 + cap2) * sizeof(uint32_t)));
+  MSI_TRY(d->ucnt.ensure((size_t)max_units * 2 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(dict_plan_kernel, dim3(1), dim3(1024), 0, st, d->qm.as<QueryMeta>(), n, slice_tiles, d->unit_off.as<uint32_t>(),
+                     d->unit_q.as<uint32_t>(), d->slice_done.as<uint32_t>(), max_units);
   MSI_TRY(d->xq.ensure((size_t)n * capx * sizeof(uint32_t)));
   MSI_TRY(d->xq_cnt.ensure((size_t)n * sizeof(uint32_t)));
   DictArgs a;
@@ -952,6 +1047,12 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   a.wlists = d->wlists.as<uint32_t>();
   a.xq = d->xq.as<uint32_t>();
   a.xq_cnt = d->xq_cnt.as<uint32_t>();
+  a.unit_off = d->unit_off.as<uint32_t>();
+  a.unit_q = d->unit_q.as<uint32_t>();
+  a.slice_done = d->slice_done.as<uint32_t>();
+  a.ulists = d->ulists.as<uint32_t>();
+  a.ucnt = d->ucnt.as<uint32_t>();
+  a.slice_tiles = slice_tiles;
   a.ticket = d->ticket.as<uint32_t>();
   a.pairs = d->pairs.as<u64>();
   a.prof = nullptr;
@@ -976,17 +1077,17 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
     hipLaunchKernelGGL(dict_other_kernel, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * 2)), dim3(XT), 0, st, x);
   }
   if (banded) {
-    hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[0])), dim3(LT), 0, st, a);
+    hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(std::min<uint32_t>(max_units, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[0])), dim3(LT), 0, st, a);
   } else {
     // two launches: the bit-parallel kernel (no banded code in it: fewer registers, more workgroups per CU) for the queries
     // of up to 64 chars, the banded kernel for the rest — its workgroups leave at once when the batch has none
     a.m_hi = 64;
-    hipLaunchKernelGGL(dict_lookup_kernel<true>, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[1])), dim3(LT), 0, st, a);
+    hipLaunchKernelGGL(dict_lookup_kernel<true>, dim3(std::min<uint32_t>(max_units, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[1])), dim3(LT), 0, st, a);
     a.m_lo = 65;
     a.m_hi = 0xFFFFFFFFu;
     a.ticket = d->ticket.as<uint32_t>() + 1;
     a.n_long = d->ticket.as<uint32_t>() + 2;
-    hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[0])), dim3(LT), 0, st, a);
+    hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(std::min<uint32_t>(max_units, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[0])), dim3(LT), 0, st, a);
   }
   d->match_timer.end(ctx);
   MSI_HIP_TRY(hipGetLastError());
@@ -1054,12 +1155,15 @@ int32_t msi_dict_create(msi_ctx *ctx, const uint8_t *words_concat, const uint32_
   }
   const uint32_t n_fc = (uint32_t)fc_start.size();
   fc_start.push_back(n_words);
+  uint32_t max_block_words = 1;
+  for (uint32_t b = 0; b < n_fc; ++b) max_block_words = std::max(max_block_words, fc_start[b + 1] - fc_start[b]);
   DeviceGuard g(ctx->device);
   std::lock_guard<std::mutex> lk(ctx->mu_aux);
   msi_dict *d = new msi_dict();
   d->ctx = ctx;
   d->n_words = n_words;
   d->n_fc = n_fc;
+  d->max_block_tiles = max_block_words / 64 + 2;
   const size_t flat_bytes = n_words ? offsets[n_words] : 0;
   hipStream_t st = ctx->stream_aux;
   int32_t s = MSI_OK;
@@ -1120,7 +1224,7 @@ void msi_dict_destroy(msi_dict *d) {
     d->prof.release();
   }
   DevBuf *bufs[] = {&d->slots, &d->filt, &d->wmeta, &d->flat, &d->offs, &d->fc_start, &d->qbytes, &d->qoff,
-                    &d->qflags, &d->qm, &d->qchars, &d->wlists, &d->xq, &d->xq_cnt, &d->ticket, &d->pairs,
+                    &d->qflags, &d->qm, &d->qchars, &d->wlists, &d->xq, &d->xq_cnt, &d->unit_off, &d->unit_q, &d->slice_done, &d->ulists, &d->ucnt, &d->ticket, &d->pairs,
                     &d->out1, &d->out1c, &d->out2, &d->out2c};
   for (DevBuf *b : bufs) b->release();
   d->match_timer.release();

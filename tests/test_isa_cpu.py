@@ -78,8 +78,8 @@ def kernel_vgprs(obj):
 
 
 def test_occupancy_the_host_code_counts_on():
-    """msi_dict.hip launches `6 x CUs` workgroups of the bit-parallel matcher kernel and `5 x CUs` of the banded one (4 waves
-    each: 6 / 5 waves per SIMD) — the kernels are bound by how many range-scanning waves a CU holds — and the command-list
+    """msi_dict.hip launches `6 x CUs` workgroups of the bit-parallel matcher kernel and `4 x CUs` of the banded one (4 waves
+    each: 6 / 4 waves per SIMD) — the kernels are bound by how many range-scanning waves a CU holds — and the command-list
     interpreter is budgeted for 3 waves per SIMD.  The register counts behind those numbers, on the built objects."""
     csrc = os.path.join(ROOT, "meilisearch_amd", "csrc")
     if not os.path.exists(os.path.join(csrc, "msi_dict.o")) or not os.path.exists(OBJDUMP):
@@ -88,7 +88,7 @@ def test_occupancy_the_host_code_counts_on():
     bits = [v for k, v in d.items() if "dict_lookup_kernelILb1" in k]
     banded = [v for k, v in d.items() if "dict_lookup_kernelILb0" in k]
     assert bits and banded, d
-    assert bits[0] <= 80 and banded[0] <= 96, d            # 512 / 80 = 6, 512 / 96 = 5 waves per SIMD
+    assert bits[0] <= 80 and banded[0] <= 128, d           # 512 / 80 = 6, 512 / 128 = 4 waves per SIMD
     v = kernel_vgprs(os.path.join(csrc, "msi_vm.o"))
     vm = [x for k, x in v.items() if "vm_kernel" in k]
     assert vm and vm[0] <= 168, v                          # 3 waves per SIMD = three 4-wave workgroups per CU
