@@ -395,9 +395,15 @@ struct WaveLists {
   uint32_t stride, off, cls, w, i;
   const uint32_t (*cnt)[2];
   uint32_t n;    // lists (the units of a query, in order)
-  __device__ __forceinline__ void settle() { while (w < n && i >= cnt[w][cls]) { ++w; i = 0; } }
+  // (device-scope loads: the lists were stored by other workgroups — dict_lookup_body)
+  __device__ __forceinline__ uint32_t count_of(uint32_t ww) const {
+    return __hip_atomic_load(const_cast<uint32_t *>(&cnt[ww][cls]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ void settle() { while (w < n && i >= count_of(w)) { ++w; i = 0; } }
   __device__ __forceinline__ bool done() const { return w >= n; }
-  __device__ __forceinline__ uint32_t peek() const { return base[(size_t)w * stride + off + i]; }
+  __device__ __forceinline__ uint32_t peek() const {
+    return __hip_atomic_load(const_cast<uint32_t *>(&base[(size_t)w * stride + off + i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   __device__ __forceinline__ void pop() { ++i; settle(); }
 };
 
@@ -738,25 +744,31 @@ __device__ __forceinline__ void dict_lookup_body(const DictArgs &a) {
       uint32_t off0 = 0, off1 = 0;
       for (uint32_t w = 0; w < (uint32_t)LW; ++w) {
         const uint32_t c0 = s_wcnt[w][0], c1 = s_wcnt[w][1];
+        // (write-through stores at device scope, as in msi_vm.hip: the unit that completes the query — another workgroup, maybe
+        // another XCD — reads them; a __threadfence here is an L2 write-back + invalidate under every resident kernel)
         for (uint32_t i = tid; i < c0; i += LT)
-          if (off0 + i < a.cap1) ul[off0 + i] = wl0[(size_t)w * stride_w + i];
+          if (off0 + i < a.cap1) __hip_atomic_store(&ul[off0 + i], wl0[(size_t)w * stride_w + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (uint32_t i = tid; i < c1; i += LT)
-          if (off1 + i < a.cap2) ul[a.cap1 + off1 + i] = wl0[(size_t)w * stride_w + a.cap1 + i];
+          if (off1 + i < a.cap2) __hip_atomic_store(&ul[a.cap1 + off1 + i], wl0[(size_t)w * stride_w + a.cap1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         off0 += c0;
         off1 += c1;
       }
       if (tid == 0) {
-        a.ucnt[2 * (size_t)u] = min(off0, a.cap1);
-        a.ucnt[2 * (size_t)u + 1] = min(off1, a.cap2);
+        __hip_atomic_store(&a.ucnt[2 * (size_t)u], min(off0, a.cap1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.ucnt[2 * (size_t)u + 1], min(off1, a.cap2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    // the unit that completes the query runs its cap logic over the units' lists (release / acquire around the counter)
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&a.slice_done[q], 1u) == n_sl - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) continue;
-    __threadfence();
+    // the unit that completes the query runs its cap logic over the units' lists: the counter's atomic follows the stores'
+    // acknowledgements (s_waitcnt vmcnt(0)), the reader loads at device scope
+    if (n_sl > 1) {
+      MSI_ORDER_ATOMICS();
+      __syncthreads();
+      if (tid == 0) s_last = atomicAdd(&a.slice_done[q], 1u) == n_sl - 1 ? 1u : 0u;
+      __syncthreads();
+      if (!s_last) continue;
+    } else {
+      __syncthreads();   // (the only unit of its query: its own stores, read back by thread 0 below)
+    }
 
     // ---- caps: the closed form of compute_derivations.rs:129-163 ------------------------------------
     if (tid == 0) {
