@@ -45,7 +45,9 @@ GROUPS = {
     "ranked-search-vs-oracle": (["tests/test_zzz_distinct_gpu.py::test_distinct_matches_the_oracle_on_the_device",
                                  "tests/test_zzz_geo_gpu.py::test_geo_sort_matches_the_oracle_on_the_device",
                                  "tests/test_zz_order_keys_gpu.py::test_sort_rules_match_the_oracle_on_the_device",
-                                 "tests/test_configs_gpu.py::test_c4_keyword_leg"], "", 5),
+                                 "tests/test_configs_gpu.py::test_c4_keyword_leg",
+                                 "tests/test_configs_gpu.py::test_c4_keyword_leg_on_the_coherent_corpus",
+                                 "tests/test_configs_gpu.py::test_rerank_inside_candidate_universes_on_the_corpus"], "", 7),
     # universe compaction forced on (MSI_SEARCH_COMPACT=2: by default it only engages where it pays, on indexes of more
     # than one chunk): the reference's snapshot searches, the index settings x the three strategies against the oracle,
     # the one-document-per-chunk spread (ranges of one bit: the shared-word path of VM_DECODEC), the out-of-slots re-run
