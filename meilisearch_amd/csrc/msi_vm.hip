@@ -1484,6 +1484,7 @@ struct VmSub {
   uint64_t seq = 0;
   volatile uint64_t *blk = nullptr;        // the pool's pinned result block; blk[0] == seq when the list has run
   std::atomic<uint32_t> state{0};          // 0 waiting, 1 done, 2 failed
+  uint32_t fused_wgs = 0;                  // waiting workgroups this list holds of the device's budget (guard of `fused`)
   std::atomic<uint32_t> asleep{0};         // the waiter is (about to be) blocked in futex_wait: the combiner must wake it
   int32_t error = MSI_OK;
   char errmsg[192] = "";                   // the combiner thread's error text (msi_last_error is thread-local: the waiter re-issues it)
@@ -1515,6 +1516,7 @@ struct VmCombiner {
   StripedCounters<3> ns_waiters;   // [queued, packed, after launch]: added by the search threads
   std::atomic<uint32_t> load{0};           // lists submitted and not finished yet
   u64 *d_prof = nullptr;                   // MSI_VM_PROFILE: 16 tick counters in device memory
+  std::atomic<int32_t> *fused_wgs = nullptr;   // msi_vm::fused_wgs: the device's waiting workgroups in flight
   void run();
 };
 
@@ -1523,7 +1525,17 @@ struct VmCombiner {
 struct msi_vm {
   msi_ctx *ctx = nullptr;
   std::vector<std::unique_ptr<VmCombiner>> comb;
+  // Workgroups of fused lists that WAIT for their list's wide phase, over all combiners' rounds in flight.  A waiting
+  // workgroup holds a CU slot and does nothing.  Measured (10 M documents, 160 callers, profiles/r4_fuse_limit.txt):
+  // lists of <= 24 chunks fused (universes <= 2 % of the index: up to 3 840 waiting workgroups in flight) run as fast as
+  // lists that are never fused on a mixed workload and through bursts of alike searches; with lists of 48-153 chunks
+  // fused, a burst of searches whose universes are 4-12 % of the index took the leg from 9 700 to 23-170 searches/s
+  // (no list failed: the device crawls while most resident workgroups wait).  Dispatch order alone should make that
+  // impossible (a waiting workgroup follows the workgroups it waits for), so the cause is not understood; the bounds
+  // are the envelope that was measured safe: MSI_VM_FUSE_MAX_CHUNKS (24) per list and this many workgroups in flight.
+  std::atomic<int32_t> fused_wgs{0};
 };
+constexpr int32_t MSI_VM_FUSED_WGS_BUDGET = 4096;
 
 namespace {
 
@@ -1599,6 +1611,10 @@ void VmCombiner::run() {
   uint64_t cpu_seen = msi_cpu_prof_on() ? msi_thread_cpu_ns() : 0;
   auto finish = [&](VmSub *s, uint32_t st) {
     s->t_done = now_ns();
+    if (s->fused_wgs) {
+      fused_wgs->fetch_sub((int32_t)s->fused_wgs, std::memory_order_relaxed);
+      s->fused_wgs = 0;
+    }
     if (trace && s->list) {   // diagnostics: what a list was made of and how long the device took for it
       const std::vector<uint32_t> &w = s->list->words;
       uint32_t ops[32] = {0}, max_paths = 0, max_steps = 0, clear_slots = 0;
@@ -1663,6 +1679,11 @@ void VmCombiner::run() {
     const char *cache_knob = getenv("MSI_VM_CACHE");
     const bool cache_off = !(cache_knob && cache_knob[0] == '1');   // the LDS set cache (builds with MSI_VM_SET_CACHE=1 only): on request
     auto chw_of = [&](const VmSub *b) -> uint32_t { return b->list->geom_docs ? compact_chw : CHW; };
+    // lists of at most this many chunks run their wide phase and their commands in one launch (`fused`); 0 = never
+    const uint32_t fuse_max_chunks = [] {
+      const char *e = getenv("MSI_VM_FUSE_MAX_CHUNKS");
+      return e ? (uint32_t)std::max(0, atoi(e)) : 24u;
+    }();
     uint32_t max_chunks[MSI_VM_MAX_PHASES] = {0}, max_phases = 1;
     for (size_t i = 0; i < n_sub; ++i) {
       const MsiVmList &l = *batch[i]->list;
@@ -1719,7 +1740,15 @@ void VmCombiner::run() {
           static const bool fuse_off = getenv("MSI_VM_FUSE") && getenv("MSI_VM_FUSE")[0] == '0';   // experiments
           // (the waiting workgroups of a list follow its own wide workgroups in dispatch order, so they can only ever wait
           // for workgroups that are already resident: the bound keeps spinning workgroups few, it is not what makes this safe)
-          if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= 160 && !fuse_off) r.wide_mask |= 0x80000000u;
+          batch[i]->fused_wgs = 0;
+          if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= fuse_max_chunks && !fuse_off) {
+            if (fused_wgs->fetch_add((int32_t)r.n_chunks, std::memory_order_relaxed) + (int32_t)r.n_chunks <= MSI_VM_FUSED_WGS_BUDGET) {
+              batch[i]->fused_wgs = r.n_chunks;
+              r.wide_mask |= 0x80000000u;
+            } else {
+              fused_wgs->fetch_sub((int32_t)r.n_chunks, std::memory_order_relaxed);   // over the budget: two launches
+            }
+          }
         } else {
           static const bool sum_off = getenv("MSI_VM_SUMMARY") && getenv("MSI_VM_SUMMARY")[0] == '0';   // diagnostics
           const uint64_t sp = sum_off ? 0 : (uint64_t)(uintptr_t)msi_bits_summary(p);
@@ -1857,6 +1886,7 @@ static msi_vm *vm_of(msi_ctx *ctx) {
     for (int c = 0; c < n; ++c) {
       std::unique_ptr<VmCombiner> cb(new VmCombiner());
       cb->ctx = ctx;
+      cb->fused_wgs = &vm->fused_wgs;
       for (int i = 0; i < VmCombiner::NS; ++i)
         if (hipStreamCreateWithFlags(&cb->streams[i], hipStreamNonBlocking) != hipSuccess) {
           msi_set_error("msi_vm: hipStreamCreate failed");

@@ -1116,6 +1116,18 @@ int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64
   for (auto &q : r->queries) for (uint32_t i = 0; i < n_terms; ++i) q.push_back(r->frequent[g() % 300]);
   return MSI_OK;
 }
+// reorder the prepared queries: query i becomes what query order[i] was (probes group the searches by universe size)
+int32_t rb_permute_queries(void *h, const uint32_t *order, uint32_t n) {
+  Runner *r = (Runner *)h;
+  if (n != r->queries.size()) return MSI_E_INVALID;
+  std::vector<std::vector<std::string>> q(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (order[i] >= n) return MSI_E_INVALID;
+    q[i] = r->queries[order[i]];
+  }
+  r->queries.swap(q);
+  return MSI_OK;
+}
 // as rb_run, and also every hit's score details ([n][limit][MSI_MAX_SCORE_DETAILS] + their counts [n][limit]) and the
 // candidate counts [n] — what the oracle check of the keyword leg compares (any of the three may be null)
 // start the job and return; rb_done() = searches finished so far, rb_wait() blocks until all are (status of the job)
