@@ -53,7 +53,14 @@ constexpr int NCCL_INT8 = 0;   // ncclInt8 / ncclChar
 int32_t rccl_load() {
   std::lock_guard<std::mutex> lk(g_rccl_mu);
   if (g_rccl.h) return MSI_OK;
-  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  // MSI_RCCL_LIBRARY: the library to load instead of the loader's librccl.so (a side-by-side ROCm; the test tier's stand-in)
+  const char *named = getenv("MSI_RCCL_LIBRARY");
+  void *h = named && named[0] ? dlopen(named, RTLD_NOW | RTLD_GLOBAL) : nullptr;
+  if (named && named[0] && !h) {
+    msi_set_error("msi_group: MSI_RCCL_LIBRARY=%s could not be loaded (%s)", named, dlerror());
+    return MSI_E_UNSUPPORTED;
+  }
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) {

@@ -159,7 +159,7 @@ __device__ __forceinline__ void put4(uint4 *p, uint4 v) {
   put1(q + 1, (u64)v.z | ((u64)v.w << 32));
 }
 
-__global__ __launch_bounds__(VT) void vm_kernel(uint32_t *__restrict__ arena, uint32_t launch_phase) {
+__global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena, uint32_t launch_phase) {
   __shared__ uint32_t s_cnt[MSI_VM_MAX_COUNTS];
   __shared__ __attribute__((aligned(16))) unsigned char s_arena[ARENA_BYTES];
   u64 *const s_dec = reinterpret_cast<u64 *>(s_arena);              // [CHW]

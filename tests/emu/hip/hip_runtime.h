@@ -88,10 +88,23 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 template <typename F>
 inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+// MSI_EMU_DEVICES emulated devices (default 1): they share the host's memory and the one launch lock — what differs per
+// device is what the host code keeps per device (contexts, streams, stores, the current-device guard of every entry point)
+inline int hipemu_device_count() {
+  const char *e = getenv("MSI_EMU_DEVICES");
+  const int n = e ? atoi(e) : 1;
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+inline thread_local int hipemu_current_device = 0;
+inline hipError_t hipGetDeviceCount(int *n) { *n = hipemu_device_count(); return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = hipemu_current_device; return hipSuccess; }
+inline hipError_t hipSetDevice(int d) {
+  if (d < 0 || d >= hipemu_device_count()) return hipErrorInvalidValue;
+  hipemu_current_device = d;
+  return hipSuccess;
+}
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int dev) {
+  if (dev < 0 || dev >= hipemu_device_count()) return hipErrorInvalidValue;
   memset(p, 0, sizeof(*p));
   strcpy(p->gcnArchName, "gfx950:emulated-on-cpu");
   strcpy(p->name, "hip emulation (tests/emu)");
@@ -99,6 +112,21 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
   p->multiProcessorCount = cu ? atoi(cu) : 2;  // small grids: the kernels are grid-stride or cover by blocks
   p->totalGlobalMem = (size_t)1 << 32;
   return hipSuccess;
+}
+struct hipemuStream { int device; };
+inline hipError_t hipStreamCreate(hipStream_t *s) {   // a stream belongs to the device that was current when it was made
+  *s = (hipStream_t)malloc(sizeof(hipemuStream));
+  (*s)->device = hipemu_current_device;
+  return hipSuccess;
+}
+// work enqueued on a stream of another device than the current one is an error on the real runtime
+// (hipErrorInvalidResourceHandle / hipErrorContextIsDestroyed): the emulation stops, so that the CPU tier catches a
+// multi-device entry point that forgot its device guard
+inline void hipemu_check_stream(hipStream_t s, const char *what) {
+  if (s && s->device != hipemu_current_device) {
+    fprintf(stderr, "hipemu: %s on a stream of device %d while device %d is current\n", what, s->device, hipemu_current_device);
+    abort();
+  }
 }
 inline hipError_t hipMalloc(void **p, size_t n) {
   *p = malloc(n ? n : 1);
@@ -114,10 +142,9 @@ template <typename T>
 inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipMalloc((void **)p, n); }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t st = nullptr) { hipemu_check_stream(st, "hipMemcpyAsync"); if (n) memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
-inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st = nullptr) { hipemu_check_stream(st, "hipMemsetAsync"); if (n) memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
 inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, unsigned, const unsigned *) { return hipStreamCreate(s); }
@@ -347,12 +374,12 @@ inline void run_block() {
 
 inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
   if (shmem > 160 * 1024) { fprintf(stderr, "hipemu: %zu bytes of LDS requested (160 KiB per workgroup on gfx950)\n", shmem); abort(); }
+  std::lock_guard<std::mutex> lk(launch_mu);   // one launch at a time, whichever emulated device or host thread it comes from
   if (shmem > g.dyn_bytes) {
     free(g.dyn_lds);
     g.dyn_lds = (unsigned char *)aligned_alloc(16, (shmem + 15) & ~(size_t)15);
     g.dyn_bytes = shmem;
   }
-  std::lock_guard<std::mutex> lk(launch_mu);
   if (g.in_kernel) { fprintf(stderr, "hipemu: nested launch\n"); abort(); }
   const unsigned n = block.x * block.y * block.z;
   if (!n || n > 1024) { fprintf(stderr, "hipemu: bad block size %u\n", n); abort(); }
@@ -394,7 +421,7 @@ inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
 }  // namespace hipemu
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  hipemu::launch_kernel(dim3(grid), dim3(block), (size_t)(shmem), kernel, ##__VA_ARGS__)
+  (hipemu_check_stream(stream, "a kernel launch"), hipemu::launch_kernel(dim3(grid), dim3(block), (size_t)(shmem), kernel, ##__VA_ARGS__))
 
 // ---- device intrinsics ----------------------------------------------------------------------------------------------
 inline void __syncthreads() {

@@ -24,8 +24,8 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"   # plain C++ mode: ext_vector_type and
 
 
 def build():
-    # msi_group.hip (RCCL over several devices) has nothing the one-device emulation could execute
-    sources = sorted(s for s in glob.glob(os.path.join(CSRC, "*.hip")) if not s.endswith("msi_group.hip"))
+    # (msi_group.hip included: MSI_EMU_DEVICES emulated devices, RCCL replaced by tests/emu/rccl_emu.cpp — build_rccl())
+    sources = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = sources + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "msi.h"),
                                                                      os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h")]
     if os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps):
@@ -34,9 +34,24 @@ def build():
     tmp = SO + f".{os.getpid()}.tmp"
     subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
                            "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
-                          + sources + ["-Wl,-Bsymbolic", "-o", tmp, "-lpthread"])
+                          + sources + ["-Wl,-Bsymbolic", "-o", tmp, "-lpthread", "-ldl"])
     os.replace(tmp, SO)
     return SO
+
+
+RCCL_SO = os.path.join(BUILD, "librccl_emu.so")
+
+
+def build_rccl():
+    """The stand-in for librccl.so (tests/emu/rccl_emu.cpp): collectives between emulated devices are memcpy."""
+    src = os.path.join(ROOT, "tests", "emu", "rccl_emu.cpp")
+    if os.path.exists(RCCL_SO) and os.path.getmtime(src) <= os.path.getmtime(RCCL_SO):
+        return RCCL_SO
+    os.makedirs(BUILD, exist_ok=True)
+    tmp = RCCL_SO + f".{os.getpid()}.tmp"
+    subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", src, "-o", tmp, "-lpthread"])
+    os.replace(tmp, RCCL_SO)
+    return RCCL_SO
 
 
 RUNNER_SO = os.path.join(BUILD, "libmsi_rankedbench_emu.so")
@@ -79,6 +94,7 @@ def main(argv):
     _lib._LIB = EmulatedLib(build())
     assert _lib.lib().msi_abi_version() == 2
     os.environ["MSI_RUNNER_SO"] = build_runner()
+    os.environ["MSI_RCCL_LIBRARY"] = build_rccl()
     import pytest
     return pytest.main(argv)
 

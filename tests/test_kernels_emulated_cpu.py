@@ -48,6 +48,12 @@ GROUPS = {
                                  "tests/test_configs_gpu.py::test_c4_keyword_leg",
                                  "tests/test_configs_gpu.py::test_c4_keyword_leg_on_the_coherent_corpus",
                                  "tests/test_configs_gpu.py::test_rerank_inside_candidate_universes_on_the_corpus"], "", 7),
+    # two emulated devices (tests/emu/hip/hip_runtime.h MSI_EMU_DEVICES; RCCL = tests/emu/rccl_emu.cpp): the N > 1 host
+    # paths of msi_group / msi_vs_group — one context, stream and store per device, one caller thread per device
+    # (replicate), rows sharded + ONE packed all-gather + device merge, the per-rank form joined from two threads — run
+    # at least once before the driver's 8-GPU node does.  The emulation stops when work is enqueued on a stream of
+    # another device than the current one (a forgotten DeviceGuard).
+    "multi-device": (["tests/test_zz_group_gpu.py"], "not world_of_one", 5, {"MSI_EMU_DEVICES": "2"}),
     # universe compaction forced on (MSI_SEARCH_COMPACT=2: by default it only engages where it pays, on indexes of more
     # than one chunk): the reference's snapshot searches, the index settings x the three strategies against the oracle,
     # the one-document-per-chunk spread (ranges of one bit: the shared-word path of VM_DECODEC), the out-of-slots re-run
@@ -64,6 +70,7 @@ def _build_once():
     import run_emulated
     run_emulated.build()
     run_emulated.build_runner()
+    run_emulated.build_rccl()
 
 
 def _start_all():

@@ -4,6 +4,8 @@ the oracle), and the per-rank form (the one bench.py uses under torchrun) must j
 device buffer onto itself.  World sizes > 1 need more devices than the test tier has; the exchange and merge logic for
 them is covered by the shard-emulation test of tests/test_vs_gpu.py and the gloo tests of tests/test_distributed_cpu.py."""
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 import pytest
@@ -14,6 +16,15 @@ from meilisearch_amd._lib import check, lib
 from meilisearch_amd.device import np_ptr
 
 pytestmark = pytest.mark.gpu
+
+
+def devices_of_the_box():
+    """Devices libmsi can open: torch's count on a GPU box; the emulated tier (tests/test_kernels_emulated_cpu.py, group
+    "multi-device") sets MSI_EMU_DEVICES and has no torch device at all."""
+    if os.environ.get("MSI_EMU_DEVICES"):
+        return int(os.environ["MSI_EMU_DEVICES"])
+    import torch
+    return torch.cuda.device_count()
 
 
 @pytest.mark.parametrize("mode", [0, 1])   # MSI_GROUP_REPLICATE, MSI_GROUP_SHARD_ROWS
@@ -69,17 +80,17 @@ def test_in_process_group_over_every_device_of_the_box(oracle, mode):
     """VERDICT r2 #6e: on a box with >= 2 devices (the driver's 8-GPU node) the in-process group spans all of them — RCCL
     with N > 1 ranks (ncclCommInitAll), rows sharded over the devices or replicated with the query batch split, one packed
     all-gather, device merge — and must still equal the oracle bit for bit.  Skipped on the one-device test boxes."""
-    import torch
-    n_dev = torch.cuda.device_count()
+    n_dev = devices_of_the_box()
     if n_dev < 2:
         pytest.skip("one device: the world-of-one forms above are what this box can run")
+    emulated = bool(os.environ.get("MSI_EMU_DEVICES"))
     devs = (C.c_int32 * n_dev)(*range(n_dev))
     g = C.c_void_p()
     check(lib().msi_group_create(devs, n_dev, C.byref(g)))
     assert lib().msi_group_size(g) == n_dev
     vs = C.c_void_p()
     check(lib().msi_vs_group_create(g, 128, 0, mode, C.byref(vs)))
-    n = 50_000
+    n = 6_000 if emulated else 50_000    # (the CPU emulation runs every lane of every workgroup in turn)
     rows = synth.make_embeddings(n, 128, seed=13)
     ids = (np.arange(n, dtype=np.uint32) * 3 + 2)
     check(lib().msi_vs_group_upload(vs, np_ptr(ids), np_ptr(rows), n))
@@ -95,3 +106,71 @@ def test_in_process_group_over_every_device_of_the_box(oracle, mode):
         assert out_s[j].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist()
     lib().msi_vs_group_destroy(vs)
     lib().msi_group_destroy(g)
+
+
+def test_per_rank_groups_of_every_device_all_gather(oracle):
+    """The one-process-per-GPU form with a world > 1, here as one thread per device: every rank joins with its own context
+    and the unique id of rank 0 (msi_group_create_rank blocks until all have), contributes its own packed buffer and must
+    receive every rank's in rank order — the exchange bench.py runs under torchrun.  Then the row-sharded search as that
+    form does it: each rank searches its rows, the packed lists travel in ONE all-gather, every rank merges and all must
+    hold the single-store answer."""
+    n_dev = devices_of_the_box()
+    if n_dev < 2:
+        pytest.skip("one device")
+    L = lib()
+    uid = (C.c_uint8 * 128)()
+    check(L.msi_group_unique_id(uid))
+    n, d, k, nq = 4000, 64, 10, 9
+    rows = synth.make_embeddings(n, d, seed=21)
+    ids = np.arange(n, dtype=np.uint32) * 5 + 1
+    q = synth.make_embeddings(nq, d, seed=22)
+    per = 2 * nq * k + nq
+    merged, errors = [None] * n_dev, []
+
+    def rank_main(r):
+        try:
+            ctx = ma.Context(r)
+            g = C.c_void_p()
+            check(L.msi_group_create_rank(ctx.handle, r, n_dev, uid, C.byref(g)))
+            assert L.msi_group_size(g) == n_dev
+            r0, r1 = n * r // n_dev, n * (r + 1) // n_dev
+            store = ma.vector_store.GpuStore(ctx, d)
+            store.upload(ids[r0:r1], rows[r0:r1])
+            o_ids, o_dist, o_cnt = store.search(q, k)
+            send_h = np.concatenate([o_dist.view(np.uint32).reshape(-1), o_ids.reshape(-1), o_cnt.astype(np.uint32)])
+            if os.environ.get("MSI_EMU_DEVICES"):     # emulated devices: host memory is device memory
+                send, recv = send_h.copy(), np.zeros(per * n_dev, np.uint32)
+                send_p, recv_p = np_ptr(send), np_ptr(recv)
+            else:
+                import torch
+                send = torch.from_numpy(send_h.view(np.int32)).to(f"cuda:{r}")
+                recv = torch.zeros(per * n_dev, dtype=torch.int32, device=f"cuda:{r}")
+                torch.cuda.synchronize(r)
+                send_p, recv_p = C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr())
+            check(L.msi_group_allgather(g, send_p, per * 4, recv_p))
+            ctx.synchronize()
+            got = (recv if isinstance(recv, np.ndarray) else recv.cpu().numpy().view(np.uint32)).reshape(n_dev, per)
+            all_dist = got[:, :nq * k].copy().view(np.float32).reshape(n_dev, nq, k)
+            all_ids = got[:, nq * k:2 * nq * k].reshape(n_dev, nq, k)
+            all_cnt = got[:, 2 * nq * k:].reshape(n_dev, nq)
+            out = []
+            for j in range(nq):
+                m_ids, m_dist = np.zeros(k, np.uint32), np.zeros(k, np.float32)
+                c = L.msi_merge_topk(np_ptr(np.ascontiguousarray(all_ids[:, j])), np_ptr(np.ascontiguousarray(all_dist[:, j])),
+                                     np_ptr(np.ascontiguousarray(all_cnt[:, j])), n_dev, k, k, np_ptr(m_ids), np_ptr(m_dist))
+                out.append((m_ids[:c].tolist(), m_dist[:c].view(np.uint32).tolist()))
+            merged[r] = out
+            L.msi_group_destroy(g)
+        except Exception as e:   # noqa: BLE001 - reported by the main thread
+            errors.append((r, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(n_dev)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errors, errors
+    for j in range(nq):
+        e_ids, e_dist = oracle.vs_topk(rows, ids, q[j], k)
+        for r in range(n_dev):
+            assert merged[r][j] == (e_ids.tolist(), e_dist.view(np.uint32).tolist()), (r, j)

@@ -47,7 +47,7 @@ for i, name in enumerate(names):
     lo, hi = int(np.searchsorted(cs, edges[i], "right" if i else "left")), int(np.searchsorted(cs, edges[i + 1], "right"))
     if hi <= lo: continue
     m = hi - lo
-    reps = max(1, 1500 // m)
+    reps = int(os.environ.get("REPS", max(1, 1500 // m)))
     m = min(m, int(os.environ.get("MAX_PER_CLASS", m)))
     c0 = os.times(); t0 = time.perf_counter()
     assert L.rb_run(h, lo, m, k, ids.ctypes.data, cnt.ctypes.data, sc.ctypes.data) == 0
