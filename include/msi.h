@@ -871,6 +871,8 @@ int32_t msi_search_cpu_profile(uint64_t out[8]);
  * universe — the documents that match the query at all — every later set is kept over the ranks of the documents inside
  * it, |universe| bits instead of n_docs: DESIGN.md §4.7.2), documents of those universes summed]. */
 int32_t msi_search_compaction_stats(uint64_t out[3]);
+/* [sub-trees of the bucket sort that continued in the compact space of their own bucket, documents of those buckets summed] */
+int32_t msi_search_late_compaction_stats(uint64_t out[2]);
 
 /* ---------------------------------------------------- scoring arithmetic (host) */
 /* DistributionShift::shift (crates/milli/src/vector/distribution.rs:103-130). */

@@ -267,6 +267,7 @@ PROTOTYPES = {
     "msi_search_last_stats": (_I32, [C.POINTER(_U64)]),
     "msi_search_cpu_profile": (_I32, [C.POINTER(_U64)]),
     "msi_search_compaction_stats": (_I32, [C.POINTER(_U64)]),
+    "msi_search_late_compaction_stats": (_I32, [C.POINTER(_U64)]),
     "msi_bits_vm_bytes": (_I32, [C.POINTER(_U64)]),
     "msi_bits_geo_list": (_I32, [_VP, _VP, _U32, C.c_double, C.c_double, _U32, _VP, _VP, C.POINTER(_U64)]),
     "msi_score_details_global_score": (_F64, [_VP, _U32]),

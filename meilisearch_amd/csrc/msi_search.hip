@@ -87,6 +87,7 @@ inline bool fk_trace() {
 }
 // process-wide: searches that continued in the compact space, and the documents of their universes (msi_search_compaction_stats)
 std::atomic<uint64_t> g_compact_searches{0}, g_compact_docs{0}, g_ranked_searches{0};
+std::atomic<uint64_t> g_late_compactions{0}, g_late_compact_docs{0};   // sub-trees of the bucket sort that moved into the space of their bucket
 struct Clock {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
@@ -397,6 +398,17 @@ struct Dev {
     static const int m = getenv("MSI_SEARCH_COMPACT") ? atoi(getenv("MSI_SEARCH_COMPACT")) : 1;
     return m;
   }
+  // MSI_SEARCH_LATE_COMPACT: 0 off; 1 (default) a sub-tree of the bucket sort moves into the compact space of its bucket
+  // where that pays (Ctx::late_enter); 2 (tests, tiny corpora) every bucket that is ranked further does, whatever its size,
+  // and the search never compacts its whole universe up front
+  static int late_mode() {
+    static const int m = getenv("MSI_SEARCH_LATE_COMPACT") ? atoi(getenv("MSI_SEARCH_LATE_COMPACT")) : 1;
+    return m;
+  }
+  bool late_pays(uint64_t n_bucket) const {
+    if (late_mode() >= 2) return n_bucket && n_bucket <= msi_bits_compact_capacity(pool.p);
+    return n_bucket >= 64 && compact_pays(n_bucket);   // (below that the sub-tree is a handful of commands either way)
+  }
   bool compact() const { return cur != &pool; }
   void rank_tables(const Set &u0) {
     rd(u0->slot);
@@ -410,10 +422,13 @@ struct Dev {
     if (!n_u0 || n_u0 > msi_bits_compact_capacity(pool.p)) return false;
     return compact_mode() >= 2 || (n > 65536 && n_u0 * 8 <= n);
   }
-  void compact_begin(const Set &u0, uint64_t n_u0) {
+  Vec<std::unique_ptr<SetPool>> retired_cpools;   // (a set handle that outlives its space still finds its SetPool)
+  bool counted_compact = false;
+  void compact_begin(const Set &u0, uint64_t n_u0, bool late = false) {
     if (!list.empty()) run();
     msi_bits *cp = msi_bits_compact_pool(pool.p);
     if (!cp) fail(MSI_E_OOM, "the companion pool of the compact space could not be created");
+    if (cpool) retired_cpools.push_back(std::move(cpool));
     cpool.reset(new SetPool(cp, 0));
     cpool->hold = true;
     cur = cpool.get();
@@ -422,8 +437,28 @@ struct Dev {
     list.geom_docs = n_u0;
     list.full_pool = pool.p;
     list.u0_slot = u0->slot;
-    g_compact_searches.fetch_add(1, std::memory_order_relaxed);
-    g_compact_docs.fetch_add(n_u0, std::memory_order_relaxed);
+    if (late) {
+      g_late_compactions.fetch_add(1, std::memory_order_relaxed);
+      g_late_compact_docs.fetch_add(n_u0, std::memory_order_relaxed);
+    }
+    if (!counted_compact) {
+      counted_compact = true;
+      g_compact_searches.fetch_add(1, std::memory_order_relaxed);
+      g_compact_docs.fetch_add(n_u0, std::memory_order_relaxed);
+    }
+  }
+  // back to the caller's pool (the sub-tree that lived in the compact space is finished: nothing recorded, nothing pending)
+  void compact_end() {
+    if (cur == &pool) return;
+    list.clear();
+    list.geom_docs = 0;
+    list.full_pool = nullptr;
+    list.u0_slot = 0;
+    keep_until_run.clear();
+    cpool->release_held();
+    retired_cpools.push_back(std::move(cpool));
+    cur = &pool;
+    u0_full.reset();
   }
   // the compact-space image of a set of the caller's pool (its documents that are in U0, as ranks)
   Set compact_of(const Set &full) {
@@ -1243,6 +1278,63 @@ struct Ctx {
     exact_attr_cache.clear();
     edge_memo.clear();
     empty_.reset();
+  }
+#endif
+#ifndef MSI_SEARCH_DIRECT_ONLY
+  // ---- a sub-tree of the bucket sort in the compact space of ITS bucket -----------------------------------------------
+  // A search whose universe is too large to compact (a query with one frequent word: the union of its words' documents)
+  // still narrows quickly: the first `words` bucket of "the matrix" is the intersection.  When a bucket that is to be
+  // ranked by the rules below holds at most an eighth of the index and nothing else of the bucket sort is alive, the rules
+  // below run in the compact space of that bucket: the full-space caches are put aside (they serve the rules above again
+  // afterwards), the term subsets / words / phrases follow as images, and when the sub-tree has finished the search is
+  // back in the caller's pool.  One space at a time (one companion pool, one set of rank tables per pool).
+  struct LateStash {
+    Map<uint32_t, Set> phrase_cache;
+    Map<Subset, Set> subset_cache;
+    Map<EdgeKey, std::shared_ptr<EdgeSet>, EdgeKeyLess> edge_memo;
+    Map<std::tuple<Subset, int, Vec<uint32_t>>, Set> within_cache;
+    Map<std::string, Vec<Set>> exact_attr_cache;
+    Map<std::tuple<Subset, Subset, uint32_t, uint32_t>, Set> prox_cache;
+    Map<std::pair<uint32_t, bool>, Set> word_cache;
+    Set empty_;
+  };
+  std::unique_ptr<LateStash> late;
+  void late_enter(const Set &bucket, uint64_t count) {
+    dev.rank_tables(bucket);                 // (rides in the list compact_begin runs before it switches pools)
+    dev.compact_begin(bucket, count, true);
+    late.reset(new LateStash());
+    late->phrase_cache.swap(phrase_cache);
+    late->subset_cache.swap(subset_cache);
+    late->edge_memo.swap(edge_memo);
+    late->within_cache.swap(within_cache);
+    late->exact_attr_cache.swap(exact_attr_cache);
+    late->prox_cache.swap(prox_cache);
+    late->word_cache.swap(word_cache);
+    late->empty_.swap(empty_);
+    for (auto &kv : late->subset_cache) subset_cache[kv.first] = dev.compact_of(kv.second);
+    for (auto &kv : late->word_cache) word_cache[kv.first] = dev.compact_of(kv.second);
+    for (auto &kv : late->phrase_cache) phrase_cache[kv.first] = dev.compact_of(kv.second);
+  }
+  // `unwinding`: an error is on its way up — nothing may block, what was recorded is dropped
+  void late_leave(bool unwinding) {
+    if (!late) return;
+    if (unwinding) {
+      dev.drop_list();
+      dev.pending_fk.clear();
+    } else {
+      dev.finish_list();   // ids still to come are fetched; anything else recorded for the finished sub-tree is dropped
+    }
+    forget();              // the compact-space caches
+    phrase_cache.swap(late->phrase_cache);
+    subset_cache.swap(late->subset_cache);
+    edge_memo.swap(late->edge_memo);
+    within_cache.swap(late->within_cache);
+    exact_attr_cache.swap(late->exact_attr_cache);
+    prox_cache.swap(late->prox_cache);
+    word_cache.swap(late->word_cache);
+    empty_.swap(late->empty_);
+    late.reset();
+    dev.compact_end();
   }
 #endif
   void relieve() {  // keep the pool from running dry on long queries: drop what can be recomputed
@@ -3289,7 +3381,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
 #endif
   uint64_t universe_count = c.dev.count(universe);
 #ifndef MSI_SEARCH_DIRECT_ONLY
-  if (may_compact && c.dev.compact_pays(universe_count)) {
+  if (may_compact && Dev::late_mode() < 2 && c.dev.compact_pays(universe_count)) {
     c.dev.compact_begin(universe, universe_count);
     c.to_compact_space();
     universe = c.dev.ones();     // U0 in its own space: every rank
@@ -3405,6 +3497,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       Tasks tasks;
       const bool no_gate = getenv("MSI_SEARCH_TASKS_NO_GATE") != nullptr;   // tests: provoke the out-of-slots re-run
       bool coop = c.dev.vm && max_tasks > 1;
+      bool late_ok = may_compact && Dev::late_mode() > 0;
 #else
       const bool coop = false;
 #endif
@@ -3446,6 +3539,22 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             emit(b.docs, b.count, off, sc, b.ids);                       // :296-330
           } else if (off < page_end && b.count) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
+            // The rules below rank this bucket in ITS compact space (Ctx::late_enter) when the search could not compact
+            // its whole universe, the bucket is at most an eighth of the index and this is the only task alive — the
+            // sub-tree's own tasks are joined before the search returns to the caller's pool.
+            if (late_ok && !c.dev.compact() && (!coop || tasks.live == 1) && c.dev.late_pays(b.count)) {
+              struct Leave {
+                Ctx &c;
+                bool done = false;
+                ~Leave() { if (!done) c.late_leave(true); }
+              } leave{c};
+              c.late_enter(b.docs, b.count);
+              rank(cur + 1, c.dev.ones(), b.count, off, sc, b.graph());
+              if (coop)
+                while (tasks.live > 1) tasks.park();   // (a yield: the scheduler runs the others' list and comes back)
+              c.late_leave(false);
+              leave.done = true;
+            } else
             // a task keeps its own working sets alive: only as many tasks as the pool has room for (a rule evaluation
             // is given what relieve() keeps free)
             if (coop && tasks.live < (size_t)max_tasks &&
@@ -3500,6 +3609,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
           // knew which of the sets they had filed were complete
           c.forget();
           coop = false;
+          late_ok = false;
           ids_short = false;
           dropped = false;
           rank(0, c.dev.clone(universe), universe_count, 0, {}, g);
@@ -3730,6 +3840,14 @@ extern "C" int32_t msi_search_compaction_stats(uint64_t out[3]) {
   out[0] = g_ranked_searches.load();
   out[1] = g_compact_searches.load();
   out[2] = g_compact_docs.load();
+  return MSI_OK;
+}
+
+// [sub-trees of the bucket sort that continued in the compact space of their bucket, documents of those buckets summed]
+extern "C" int32_t msi_search_late_compaction_stats(uint64_t out[2]) {
+  if (!out) return MSI_E_INVALID;
+  out[0] = g_late_compactions.load();
+  out[1] = g_late_compact_docs.load();
   return MSI_OK;
 }
 

@@ -179,10 +179,19 @@ def test_c4_keyword_leg_on_the_coherent_corpus(ctx):
         chk = parity.KeywordLegChecker(lib, h, n_docs)
         queries = [chk.index.query(i) for i in range(n_queries)]
         assert queries[0] == "" and len(queries[2].split()) == 2 and len(set(queries)) > n_queries // 2
+        from meilisearch_amd._lib import lib as msi
+        late0 = (C.c_uint64 * 2)()
+        msi().msi_search_late_compaction_stats(late0)
         cold = chk.run_product(0, n_queries, limit)
         v = chk.verdict(0, n_queries, limit, product=cold)
         assert v["mismatches"] == 0, v
         assert v["checked_queries"] == n_queries and v["hits_compared"] >= 5 * n_queries
+        # queries with one frequent word: the universe (the union) is too large to compact, the first `words` bucket (the
+        # intersection) is not — its sub-tree must have run in the compact space of that bucket (Ctx::late_enter)
+        late1 = (C.c_uint64 * 2)()
+        msi().msi_search_late_compaction_stats(late1)
+        if os.environ.get("MSI_SEARCH_LATE_COMPACT", "1") != "0":
+            assert late1[0] > late0[0], (late0[0], late1[0])
         warm = chk.run_product(0, n_queries, limit)
         for a, b in zip(cold, warm):
             assert (a == b).all()

@@ -62,4 +62,7 @@ for i, name in enumerate(names):
     tot += m / qps
     print(f"{name:10s} {m:5d} queries ({m / NQ:.2f})  alone {qps:8.0f} q/s  -> {m / qps * 1e3 / NQ * 768:6.1f} ms of a 768-query step   one caller p50 {np.median(one):.2f} ms", flush=True)
 print(f"sum of classes run alone: {NQ / tot:.0f} q/s")
+st = (C.c_uint64 * 3)(); lt = (C.c_uint64 * 2)()
+ma._lib.lib().msi_search_compaction_stats(st); ma._lib.lib().msi_search_late_compaction_stats(lt)
+print(f"searches {st[0]}, compacted {st[1]} (mean universe {st[2] / max(1, st[1]):.0f}); sub-trees moved into their bucket's space {lt[0]} (mean bucket {lt[1] / max(1, lt[0]):.0f})")
 L.rb_destroy(h)
