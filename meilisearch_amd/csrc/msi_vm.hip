@@ -1671,14 +1671,28 @@ void VmCombiner::run() {
     // words per workgroup in a list's command phases (RoundSub::chw): compact lists take narrower chunks, so that a dozen
     // sets of a chunk fit in the kernel's LDS set cache.  MSI_VM_COMPACT_CHW = 128 | 256 | 512 | 1024 (experiments)
     // (both knobs are read per round, so that one process can measure the variants side by side: tools/ranked_bench RB_VARIANTS)
-    const uint32_t compact_chw = [] {
-      const char *e = getenv("MSI_VM_COMPACT_CHW");
-      const int v = e ? atoi(e) : 256;
-      return (v == 128 || v == 256 || v == 512 || v == 1024) ? (uint32_t)v : 256u;
-    }();
+    // MSI_VM_COMPACT_CHW = 128 | 256 | 512 | 1024 | 2048: that width for every compact list; "auto<N>": 256 words, doubled
+    // while the list would have more than N workgroups (a universe of a million documents is 153 chunks of 256 words: as
+    // many workgroups as the full space, each with an eighth of the words — workgroup slots, not words, are what runs out)
+    uint32_t compact_chw = 256, compact_target = 0;
+    if (const char *e = getenv("MSI_VM_COMPACT_CHW")) {
+      if (!strncmp(e, "auto", 4)) compact_target = (uint32_t)std::max(1, atoi(e + 4));
+      else {
+        const int v = atoi(e);
+        if (v == 128 || v == 256 || v == 512 || v == 1024 || v == 2048) compact_chw = (uint32_t)v;
+      }
+    }
     const char *cache_knob = getenv("MSI_VM_CACHE");
     const bool cache_off = !(cache_knob && cache_knob[0] == '1');   // the LDS set cache (builds with MSI_VM_SET_CACHE=1 only): on request
-    auto chw_of = [&](const VmSub *b) -> uint32_t { return b->list->geom_docs ? compact_chw : CHW; };
+    auto chw_of = [&](const VmSub *b) -> uint32_t {
+      if (!b->list->geom_docs) return CHW;
+      uint32_t w = compact_chw;
+      if (compact_target) {
+        const uint64_t words = words_of(b);
+        while (w < CHW && (words + w - 1) / w > compact_target) w *= 2;
+      }
+      return w;
+    };
     // lists of at most this many chunks run their wide phase and their commands in one launch (`fused`); 0 = never
     const uint32_t fuse_max_chunks = [] {
       const char *e = getenv("MSI_VM_FUSE_MAX_CHUNKS");
@@ -1741,7 +1755,7 @@ void VmCombiner::run() {
           // (the waiting workgroups of a list follow its own wide workgroups in dispatch order, so they can only ever wait
           // for workgroups that are already resident: the bound keeps spinning workgroups few, it is not what makes this safe)
           batch[i]->fused_wgs = 0;
-          if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= fuse_max_chunks && !fuse_off) {
+          if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= fuse_max_chunks && r.n_words <= (u64)fuse_max_chunks * 256 && !fuse_off) {
             if (fused_wgs->fetch_add((int32_t)r.n_chunks, std::memory_order_relaxed) + (int32_t)r.n_chunks <= MSI_VM_FUSED_WGS_BUDGET) {
               batch[i]->fused_wgs = r.n_chunks;
               r.wide_mask |= 0x80000000u;

@@ -42,6 +42,19 @@
 #include "msi_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// The rows of a sweep are read once: non-temporal 16-byte loads (MSI_VS_NT=0 at build time: plain loads, for comparison)
+#ifndef MSI_VS_NT
+#define MSI_VS_NT 1
+#endif
+__device__ inline float4 vs_stream_load(const float4 *p) {
+#if MSI_VS_NT && !defined(MSI_HIP_EMULATED)
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *p;
+#endif
+}
+#define MSI_VS_STREAM_LOAD(p) vs_stream_load(p)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
@@ -476,7 +489,7 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   auto load_group = [&](float4(&x)[SCAN_GROUP]) {
     const float4 *p = a.tiles + ((uint64_t)tile_load * KB + (uint64_t)sub_load * SCAN_GROUP) * 64 + lane;
 #pragma unroll
-    for (int u = 0; u < SCAN_GROUP; ++u) x[u] = p[u * 64];
+    for (int u = 0; u < SCAN_GROUP; ++u) x[u] = MSI_VS_STREAM_LOAD(p + u * 64);
     if (++sub_load == GPT) {
       sub_load = 0;
       ++it_load;
@@ -1024,8 +1037,15 @@ struct msi_vs {
   DevBuf tiles_next, docids_next, norm_next, inv_norm_next, add_tiles, add_docids, row_map;  // msi_vs_update builds the next store beside the current one
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
   // scratch (guarded by ctx->mu)
-  DevBuf qraw, qfrag, qfrag_bf, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fbits, out_docids,
+  DevBuf qraw, qfrag, qfrag_bf, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fsmall, fbits, out_docids,
       out_dist, exh_keys, rowtmp, resc_keys;
+  // the second scratch set and stream of the device entry point's pipeline (msi_vs_search_device): allocated on first use
+  struct Scratch2 {
+    DevBuf qfrag, qfrag_bf, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, resc_keys;
+  } scr2;
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_done = nullptr, ev_pre[2] = {nullptr, nullptr}, ev_main[2] = {nullptr, nullptr};
+  uint64_t pipelined_calls = 0;
   uint32_t capg = 0;
   uint32_t scan_grid = 0;
   // stats
@@ -1241,10 +1261,10 @@ int32_t finish_upload(msi_vs *vs, uint64_t n_rows, const char *what) {
 }
 
 // Launch one sweep.  `dense` selects the epilogue, nqt the number of 16-query tiles.
-void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense) {
+void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense, hipStream_t st = nullptr) {
   const size_t lds = scan_lds_bytes(vs->KB, nqt, vs->s16, vs->bf2);
   const dim3 grid(vs->scan_grid), block(SCAN_WAVES * 64);
-  hipStream_t st = vs->ctx->stream;
+  if (!st) st = vs->ctx->stream;
 #define MSI_SCAN_LAUNCH(N, D, B, S) \
   hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, D, B, S>), grid, block, lds, st, sa)
 #define MSI_SCAN_CASE(N)                                              \
@@ -1280,48 +1300,77 @@ void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense) {
 #undef MSI_SCAN_CASE
 }
 
-// Enqueue the full pipeline for <= 16*nqt_max queries already in device memory.
-// d_fbits nullable.  Outputs are device pointers.
-int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t k, const u64 *d_fbits,
-                       uint64_t nbits, uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_counts,
-                       uint32_t *d_inexact) {
-  msi_ctx *ctx = vs->ctx;
-  hipStream_t st = ctx->stream;
+// One chunk of <= 16*nqt_max queries (one HBM sweep): planned against the scratch set that is current when it is planned,
+// then enqueued in three stages —
+//   pre   queries -> MFMA fragments, norms; the strided sample sweep and the thresholds it yields; counters zeroed
+//   main  the full sweep (the HBM-bound kernel)
+//   post  selection of the K' best candidates, canonical rescoring, exactness proof, outputs
+// enqueue_search() runs the three back to back on the context's stream; msi_vs_search_device() runs `pre` and `post` on
+// the store's second stream, double-buffered, so that they overlap the neighbouring chunks' `main` (the sweep is 89 %
+// of a chunk's time; the rest was serial in front of and behind it).
+struct Chunk {
+  ScanArgs sa;
+  SelectArgs se;
+  RescoreArgs ra;
+  const float *d_queries = nullptr;
+  Small s;
+  float4 *qfrag = nullptr;
+  bf16x8 *qfrag_bf = nullptr;
+  float *qrow = nullptr;
+  void *gcnt = nullptr;
+  uint32_t nq = 0, nqt = 0, k = 0, kp = 0, stride = 1, thr_rank = 0;
+  uint64_t n_tiles = 0, dense_items = 0;
+  bool filtered = false;
+};
+
+// the allowed-row masks and the list of tiles that hold an allowed row (the same for every chunk of a call)
+int32_t enqueue_filter(msi_vs *vs, const u64 *d_fbits, uint64_t nbits, hipStream_t st) {
   Small s = small_of(vs);
+  MSI_TRY(vs->tmask.ensure(vs->n_tiles * sizeof(uint16_t)));
+  MSI_TRY(vs->tlist.ensure(vs->n_tiles * sizeof(uint32_t)));
+  MSI_TRY(vs->fsmall.ensure(64));
+  MSI_HIP_TRY(hipMemsetAsync(vs->fsmall.p, 0, sizeof(uint32_t), st));
+  const uint64_t padded = vs->n_tiles * 16;
+  const uint64_t rows_per_block = 1024ull * FT_SUB;
+  (void)s;
+  hipLaunchKernelGGL(vs_filter_tiles_kernel, dim3((uint32_t)((padded + rows_per_block - 1) / rows_per_block)),
+                     dim3(1024), 0, st, vs->docids.as<uint32_t>(), vs->n_rows, d_fbits, nbits,
+                     vs->tmask.as<uint16_t>(), vs->tlist.as<uint32_t>(), vs->fsmall.as<uint32_t>());
+  return MSI_OK;
+}
+
+int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, uint32_t k, bool filtered,
+                   uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_counts, uint32_t *d_inexact) {
   if (k > KP_MAX) {
     msi_set_error("msi_vs_search: k=%u above the supported maximum %u", k, KP_MAX);
     return MSI_E_UNSUPPORTED;
   }
+  c.s = small_of(vs);
+  const Small &s = c.s;
+  c.d_queries = d_queries;
+  c.nq = nq;
+  c.k = k;
+  c.filtered = filtered;
   // candidates rescored beyond k: every row whose fast score lies within twice the proof's eps of the k-th must be among
   // them — a handful with bf16x3 (eps ~ 1e-5), a few dozen to a hundred with bf16x2 (eps ~ 4e-3)
   const uint32_t slack = vs->big_slack ? KP_MAX : (vs->bf2 ? std::max<uint32_t>(108, 3 * k) : std::max<uint32_t>(12, k / 4));
-  const uint32_t kp = std::min<uint32_t>(k + slack, KP_MAX);
-  const uint32_t nqt = (nq + QT - 1) / QT;
-  // 1. queries
-  hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
-                     d_queries, nq, vs->dim, vs->KB, vs->qfrag.as<float4>(), vs->qfrag_bf.as<bf16x8>(),
-                     vs->qrow.as<float>(), s.qn, s.inv_qn, s.degth, vs->s16 ? 1u : (vs->bf2 ? 2u : 0u));
-  MSI_HIP_TRY(hipMemsetAsync(s.overflow, 0, sizeof(uint32_t), st));
-  // 2. filter
+  const uint32_t kp = c.kp = std::min<uint32_t>(k + slack, KP_MAX);
+  c.nqt = (nq + QT - 1) / QT;
+  c.qfrag = vs->qfrag.as<float4>();
+  c.qfrag_bf = vs->qfrag_bf.as<bf16x8>();
+  c.qrow = vs->qrow.as<float>();
+  c.gcnt = vs->gcnt.p;
   const uint32_t *list = nullptr;
   const uint16_t *tmask = nullptr;
   const uint32_t *n_items_ptr = s.n_tiles;
-  if (d_fbits && vs->n_rows) {
-    MSI_TRY(vs->tmask.ensure(vs->n_tiles * sizeof(uint16_t)));
-    MSI_TRY(vs->tlist.ensure(vs->n_tiles * sizeof(uint32_t)));
-    MSI_HIP_TRY(hipMemsetAsync(s.n_items, 0, sizeof(uint32_t), st));
-    const uint64_t padded = vs->n_tiles * 16;
-    const uint64_t rows_per_block = 1024ull * FT_SUB;
-    hipLaunchKernelGGL(vs_filter_tiles_kernel, dim3((uint32_t)((padded + rows_per_block - 1) / rows_per_block)),
-                       dim3(1024), 0, st, vs->docids.as<uint32_t>(), vs->n_rows, d_fbits, nbits,
-                       vs->tmask.as<uint16_t>(), vs->tlist.as<uint32_t>(), s.n_items);
+  if (filtered) {
     list = vs->tlist.as<uint32_t>();
     tmask = vs->tmask.as<uint16_t>();
-    n_items_ptr = s.n_items;
+    n_items_ptr = vs->fsmall.as<uint32_t>();
   }
-  // 3. plan: small stores are scored densely in one sweep; larger ones get a dense
-  //    strided sample sweep (thresholds) followed by the sparse full sweep.
-  const uint64_t n_tiles = vs->n_tiles;
+  // plan: small stores are scored densely in one sweep; larger ones get a dense
+  // strided sample sweep (thresholds) followed by the sparse full sweep.
+  const uint64_t n_tiles = c.n_tiles = vs->n_tiles;
   const uint64_t n_rows_pad = n_tiles * 16;
   uint32_t stride = 1;
   uint32_t thr_rank = kp;
@@ -1331,11 +1380,13 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
     stride = (uint32_t)std::max<uint64_t>(1, (uint64_t)((double)n_rows_pad / s_rows));
     if (stride > 1) thr_rank = std::min(kp, threshold_rank(kp, 1.0 / (double)stride));
   }
-  const uint64_t dense_items = (n_tiles + stride - 1) / stride;
+  c.stride = stride;
+  c.thr_rank = thr_rank;
+  const uint64_t dense_items = c.dense_items = (n_tiles + stride - 1) / stride;
   const uint32_t dstride = (uint32_t)(dense_items * 16);
   MSI_TRY(vs->dense.ensure((size_t)NQ_MAX * std::max<uint32_t>(16, dstride) * sizeof(float)));
 
-  ScanArgs sa;
+  ScanArgs &sa = c.sa;
   sa.tiles = vs->tiles.as<float4>();
   sa.inv_norm = vs->inv_norm.as<float>();
   sa.qfrag = (vs->bf3 || vs->s16) ? vs->qfrag_bf.as<float4>() : vs->qfrag.as<float4>();
@@ -1354,7 +1405,7 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   sa.KB = vs->KB;
   sa.stride = stride;
   sa.nq = nq;
-  SelectArgs se;
+  SelectArgs &se = c.se;
   se.gkeys = vs->gkeys.as<u64>();
   se.gcnt = vs->gcnt.as<uint32_t>();
   se.capg = vs->capg;
@@ -1366,42 +1417,8 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   se.sel_keys = vs->sel_keys.as<u64>();
   se.sel_cnt = s.sel_cnt;
   se.theta = s.theta;
-  const float *theta_used = nullptr;
-  if (stride == 1) {
-    // dense main sweep; the K' best come straight out of the score matrix
-    vs->scan_timer.begin(ctx);
-    launch_scan(vs, sa, nqt, true);
-    vs->scan_timer.end(ctx);
-    vs->scan_launches++;
-    vs->scan_tiles += n_tiles;
-    se.K = kp;
-    se.mode = 1;
-    hipLaunchKernelGGL(vs_select_kernel, dim3(nq), dim3(SEL_THREADS), 0, st, se);
-  } else {
-    // sample sweep -> thresholds
-    launch_scan(vs, sa, nqt, true);
-    vs->scan_launches++;
-    vs->scan_tiles += dense_items;
-    se.K = thr_rank;
-    se.mode = 0;
-    hipLaunchKernelGGL(vs_select_kernel, dim3(nqt * QT), dim3(SEL_THREADS), 0, st, se);
-    // full sweep, sparse epilogue
-    MSI_HIP_TRY(hipMemsetAsync(vs->gcnt.p, 0, (size_t)NQ_MAX * CNT_PAD * sizeof(uint32_t), st));
-    sa.theta = s.theta;
-    sa.stride = 1;
-    vs->scan_timer.begin(ctx);
-    launch_scan(vs, sa, nqt, false);
-    vs->scan_timer.end(ctx);
-    vs->scan_launches++;
-    vs->scan_tiles += n_tiles;
-    se.dense = nullptr;
-    se.K = kp;
-    se.mode = 1;
-    hipLaunchKernelGGL(vs_select_kernel, dim3(nq), dim3(SEL_THREADS), 0, st, se);
-    theta_used = s.theta;
-  }
   // rescore with the reference arithmetic, order, prove exactness
-  RescoreArgs ra;
+  RescoreArgs &ra = c.ra;
   ra.tiles = vs->tiles.p;
   ra.dpad = vs->dpad;
   ra.s16 = vs->s16 ? 1u : 0u;
@@ -1423,18 +1440,158 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
   ra.out_counts = d_out_counts;
   ra.inexact = d_inexact;
   ra.overflow = s.overflow;
-  ra.theta = theta_used;
+  ra.theta = stride == 1 ? nullptr : s.theta;
   ra.pre_keys = nullptr;
   if (k > 0 && kp > 2 * SEL_THREADS) {
     MSI_TRY(vs->resc_keys.ensure((size_t)NQ_MAX * KP_MAX * sizeof(u64)));
     ra.pre_keys = vs->resc_keys.as<u64>();
-    hipLaunchKernelGGL(vs_rescore_dots_kernel, dim3((kp + SEL_THREADS - 1) / SEL_THREADS, nq), dim3(SEL_THREADS),
-                       (size_t)vs->dpad * sizeof(float), st, ra);
   }
-  if (k > 0)
-    hipLaunchKernelGGL(vs_rescore_kernel, dim3(nq), dim3(SEL_THREADS),
-                       KP_MAX * sizeof(u64) + (size_t)vs->dpad * sizeof(float), st, ra);
+  return MSI_OK;
+}
+
+int32_t chunk_pre(msi_vs *vs, Chunk &c, hipStream_t st) {
+  hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(c.nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
+                     c.d_queries, c.nq, vs->dim, vs->KB, c.qfrag, c.qfrag_bf, c.qrow, c.s.qn, c.s.inv_qn, c.s.degth,
+                     vs->s16 ? 1u : (vs->bf2 ? 2u : 0u));
+  MSI_HIP_TRY(hipMemsetAsync(c.s.overflow, 0, sizeof(uint32_t), st));
+  if (c.stride > 1) {
+    // sample sweep -> thresholds
+    launch_scan(vs, c.sa, c.nqt, true, st);
+    vs->scan_launches++;
+    vs->scan_tiles += c.dense_items;
+    c.se.K = c.thr_rank;
+    c.se.mode = 0;
+    hipLaunchKernelGGL(vs_select_kernel, dim3(c.nqt * QT), dim3(SEL_THREADS), 0, st, c.se);
+    MSI_HIP_TRY(hipMemsetAsync(c.gcnt, 0, (size_t)NQ_MAX * CNT_PAD * sizeof(uint32_t), st));
+  }
   MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+int32_t chunk_main(msi_vs *vs, Chunk &c, hipStream_t st) {
+  msi_ctx *ctx = vs->ctx;
+  if (c.stride == 1) {
+    // dense main sweep; the K' best come straight out of the score matrix
+    vs->scan_timer.begin(ctx, st);
+    launch_scan(vs, c.sa, c.nqt, true, st);
+    vs->scan_timer.end(ctx);
+  } else {
+    // full sweep, sparse epilogue
+    c.sa.theta = c.s.theta;
+    c.sa.stride = 1;
+    vs->scan_timer.begin(ctx, st);
+    launch_scan(vs, c.sa, c.nqt, false, st);
+    vs->scan_timer.end(ctx);
+    c.se.dense = nullptr;
+  }
+  vs->scan_launches++;
+  vs->scan_tiles += c.n_tiles;
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+int32_t chunk_post(msi_vs *vs, Chunk &c, hipStream_t st) {
+  c.se.K = c.kp;
+  c.se.mode = 1;
+  hipLaunchKernelGGL(vs_select_kernel, dim3(c.nq), dim3(SEL_THREADS), 0, st, c.se);
+  if (c.ra.pre_keys)
+    hipLaunchKernelGGL(vs_rescore_dots_kernel, dim3((c.kp + SEL_THREADS - 1) / SEL_THREADS, c.nq), dim3(SEL_THREADS),
+                       (size_t)vs->dpad * sizeof(float), st, c.ra);
+  if (c.k > 0)
+    hipLaunchKernelGGL(vs_rescore_kernel, dim3(c.nq), dim3(SEL_THREADS),
+                       KP_MAX * sizeof(u64) + (size_t)vs->dpad * sizeof(float), st, c.ra);
+  MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+// Enqueue the full pipeline for <= 16*nqt_max queries already in device memory, on the context's stream.
+// d_fbits nullable.  Outputs are device pointers.
+int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t k, const u64 *d_fbits,
+                       uint64_t nbits, uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_counts,
+                       uint32_t *d_inexact) {
+  hipStream_t st = vs->ctx->stream;
+  const bool filtered = d_fbits && vs->n_rows;
+  if (filtered) MSI_TRY(enqueue_filter(vs, d_fbits, nbits, st));
+  Chunk c;
+  MSI_TRY(plan_chunk(vs, c, d_queries, nq, k, filtered, d_out_docids, d_out_dist, d_out_counts, d_inexact));
+  MSI_TRY(chunk_pre(vs, c, st));
+  MSI_TRY(chunk_main(vs, c, st));
+  return chunk_post(vs, c, st);
+}
+
+// Several chunks: `pre` and `post` of a chunk run on the store's second stream against two scratch sets, `main` (the
+// sweep) on the context's stream —
+//   second stream   pre(0) | pre(1) post(0) | pre(2) post(1) | ...        | post(n-1)
+//   context stream          main(0)         | main(1)        | ... main(n-1)          | (waits for post(n-1))
+// main(i) waits for pre(i); post(i) waits for main(i); pre(i+2) follows post(i) on the same stream, so a scratch set is
+// rewritten only when the chunk that used it is finished.  The outputs are complete when the context's stream is.
+void swap_scratch(msi_vs *vs) {
+  std::swap(vs->qfrag, vs->scr2.qfrag);
+  std::swap(vs->qfrag_bf, vs->scr2.qfrag_bf);
+  std::swap(vs->qrow, vs->scr2.qrow);
+  std::swap(vs->qsmall, vs->scr2.qsmall);
+  std::swap(vs->gkeys, vs->scr2.gkeys);
+  std::swap(vs->gcnt, vs->scr2.gcnt);
+  std::swap(vs->gsmall, vs->scr2.gsmall);
+  std::swap(vs->sel_keys, vs->scr2.sel_keys);
+  std::swap(vs->dense, vs->scr2.dense);
+  std::swap(vs->resc_keys, vs->scr2.resc_keys);
+}
+
+int32_t search_device_pipelined(msi_vs *vs, const float *d_queries, uint32_t n_queries, uint32_t k, const u64 *d_fbits,
+                                uint64_t nbits, uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_counts,
+                                uint32_t *d_inexact) {
+  msi_ctx *ctx = vs->ctx;
+  hipStream_t A = ctx->stream;
+  if (!vs->aux_stream) {
+    MSI_HIP_TRY(hipStreamCreateWithFlags(&vs->aux_stream, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&vs->ev_start, &vs->ev_done, &vs->ev_pre[0], &vs->ev_pre[1], &vs->ev_main[0], &vs->ev_main[1]})
+      MSI_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  hipStream_t B = vs->aux_stream;
+  // the second scratch set (the first call allocates it)
+  swap_scratch(vs);
+  int32_t st2 = ensure_scratch(vs);
+  if (st2 == MSI_OK) st2 = vs->gkeys.ensure((size_t)NQ_MAX * vs->capg * sizeof(u64));
+  const Small s2 = small_of(vs);
+  swap_scratch(vs);
+  MSI_TRY(st2);
+  const Small s1 = small_of(vs);
+  // whatever the caller enqueued on the context's stream (the queries, the filter) is done before the second stream reads it
+  MSI_HIP_TRY(hipEventRecord(vs->ev_start, A));
+  MSI_HIP_TRY(hipStreamWaitEvent(B, vs->ev_start, 0));
+  // the store's constants of the small arrays (tile count, "everything passes" thresholds) follow into the second set
+  MSI_HIP_TRY(hipMemcpyAsync(s2.n_tiles, s1.n_tiles, sizeof(uint32_t), hipMemcpyDeviceToDevice, B));
+  MSI_HIP_TRY(hipMemcpyAsync(s2.theta_inf, s1.theta_inf, NQ_MAX * sizeof(float), hipMemcpyDeviceToDevice, B));
+  const bool filtered = d_fbits && vs->n_rows;
+  if (filtered) MSI_TRY(enqueue_filter(vs, d_fbits, nbits, B));
+  const uint32_t step = vs->nqt_max * QT;
+  Chunk ch[2];
+  uint32_t i = 0;
+  for (uint32_t q0 = 0; q0 < n_queries; q0 += step, ++i) {
+    const uint32_t nq = std::min(step, n_queries - q0);
+    const uint32_t set = i & 1;
+    if (set) swap_scratch(vs);
+    const int32_t pst = plan_chunk(vs, ch[set], d_queries + (size_t)q0 * vs->dim, nq, k, filtered, d_out_docids + (size_t)q0 * k,
+                                   d_out_dist + (size_t)q0 * k, d_out_counts + q0, d_inexact ? d_inexact + q0 : nullptr);
+    if (set) swap_scratch(vs);
+    MSI_TRY(pst);
+    MSI_TRY(chunk_pre(vs, ch[set], B));
+    MSI_HIP_TRY(hipEventRecord(vs->ev_pre[set], B));
+    if (i >= 1) {
+      MSI_HIP_TRY(hipStreamWaitEvent(B, vs->ev_main[set ^ 1], 0));
+      MSI_TRY(chunk_post(vs, ch[set ^ 1], B));
+    }
+    MSI_HIP_TRY(hipStreamWaitEvent(A, vs->ev_pre[set], 0));
+    MSI_TRY(chunk_main(vs, ch[set], A));
+    MSI_HIP_TRY(hipEventRecord(vs->ev_main[set], A));
+  }
+  const uint32_t last = (i - 1) & 1;
+  MSI_HIP_TRY(hipStreamWaitEvent(B, vs->ev_main[last], 0));
+  MSI_TRY(chunk_post(vs, ch[last], B));
+  MSI_HIP_TRY(hipEventRecord(vs->ev_done, B));
+  MSI_HIP_TRY(hipStreamWaitEvent(A, vs->ev_done, 0));
+  vs->pipelined_calls++;
   return MSI_OK;
 }
 
@@ -1549,6 +1706,15 @@ void msi_vs_destroy(msi_vs *vs) {
                       &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp, &vs->resc_keys,
                       &vs->tiles_next, &vs->docids_next, &vs->norm_next, &vs->inv_norm_next, &vs->add_tiles, &vs->add_docids, &vs->row_map};
     for (DevBuf *b : bufs) b->release();
+    DevBuf *bufs2[] = {&vs->scr2.qfrag, &vs->scr2.qfrag_bf, &vs->scr2.qrow, &vs->scr2.qsmall, &vs->scr2.gkeys, &vs->scr2.gcnt,
+                       &vs->scr2.gsmall, &vs->scr2.sel_keys, &vs->scr2.dense, &vs->scr2.resc_keys, &vs->fsmall};
+    for (DevBuf *b : bufs2) b->release();
+    if (vs->aux_stream) {
+      (void)hipStreamSynchronize(vs->aux_stream);
+      (void)hipStreamDestroy(vs->aux_stream);
+    }
+    for (hipEvent_t e : {vs->ev_start, vs->ev_done, vs->ev_pre[0], vs->ev_pre[1], vs->ev_main[0], vs->ev_main[1]})
+      if (e) (void)hipEventDestroy(e);
     vs->scan_timer.release();
     delete vs;
   }
@@ -1721,6 +1887,10 @@ int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries, uint32_t n_quer
   }
   // one HBM sweep per chunk of msi_vs_max_batch() queries
   const uint32_t step = vs->nqt_max * QT;
+  static const bool pipeline_off = getenv("MSI_VS_PIPELINE") && getenv("MSI_VS_PIPELINE")[0] == '0';
+  if (n_queries > step && !pipeline_off)
+    return search_device_pipelined(vs, d_queries, n_queries, k, (const u64 *)d_filter_bits, filter_nbits, d_out_docids, d_out_dist,
+                                   d_out_counts, d_inexact);
   for (uint32_t q0 = 0; q0 < n_queries; q0 += step) {
     const uint32_t nq = std::min(step, n_queries - q0);
     MSI_TRY(enqueue_search(vs, d_queries + (size_t)q0 * vs->dim, nq, k, (const u64 *)d_filter_bits, filter_nbits,

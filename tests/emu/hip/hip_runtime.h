@@ -157,6 +157,7 @@ inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 enum { hipEventDefault = 0, hipEventBlockingSync = 1, hipEventDisableTiming = 2 };
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t, unsigned = 0) { hipemu_check_stream(s, "hipStreamWaitEvent"); return hipSuccess; }   // launches run to completion before they return
 inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // launches run to completion before they return
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { *e = std::chrono::steady_clock::now(); return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(*b - *a).count(); return hipSuccess; }

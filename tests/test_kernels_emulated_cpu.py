@@ -48,6 +48,12 @@ GROUPS = {
                                  "tests/test_configs_gpu.py::test_c4_keyword_leg",
                                  "tests/test_configs_gpu.py::test_c4_keyword_leg_on_the_coherent_corpus",
                                  "tests/test_configs_gpu.py::test_rerank_inside_candidate_universes_on_the_corpus"], "", 7),
+    # every bucket that is ranked further moves into the compact space of ITS bucket (MSI_SEARCH_LATE_COMPACT=2: by default
+    # only buckets of a search whose universe was too large to compact, on indexes of more than a chunk): the reference's
+    # snapshot searches and the index settings against the oracle through Ctx::late_enter / late_leave — the caches put
+    # aside and restored, the sub-tree's tasks joined, the rank tables rebuilt per bucket
+    "ranked-search-bucket-space": (["tests/test_search_gpu.py"], "reference_snapshot or under_index_settings or negative_words",
+                                   90, {"MSI_SEARCH_LATE_COMPACT": "2"}),
     # two emulated devices (tests/emu/hip/hip_runtime.h MSI_EMU_DEVICES; RCCL = tests/emu/rccl_emu.cpp): the N > 1 host
     # paths of msi_group / msi_vs_group — one context, stream and store per device, one caller thread per device
     # (replicate), rows sharded + ONE packed all-gather + device merge, the per-rank form joined from two threads — run

@@ -437,3 +437,76 @@ def test_second_opinion_capacity_at_wide_dims(ctx, oracle, dim, batch2, batch3):
     assert s1["scan_launches"] - s0["scan_launches"] >= 1 + 1 + 2
     assert s1["level_sweeps"][2] - s0["level_sweeps"][2] >= 2
     assert s1["exhaustive_reruns"] == s0["exhaustive_reruns"]
+
+
+class _DeviceArrays:
+    """Arrays the device entry points can be handed: torch tensors on the context's device — or, on the CPU tier's emulated
+    kernels (tests/emu: device memory is host memory, no torch device), plain numpy arrays."""
+
+    def __init__(self, ctx):
+        self.emulated = bool(os.environ.get("MSI_RUNNER_SO"))
+        self.ctx = ctx
+        self.keep = []
+
+    def put(self, a):
+        import ctypes as C
+        if self.emulated:
+            a = np.ascontiguousarray(a).copy()
+            self.keep.append(a)
+            return a, C.c_void_p(a.ctypes.data)
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda", self.ctx.device))
+        torch.cuda.synchronize()
+        self.keep.append(t)
+        return t, C.c_void_p(t.data_ptr())
+
+    def get(self, h):
+        return h if self.emulated else h.cpu().numpy()
+
+
+@pytest.mark.parametrize("filtered", [False, True])
+def test_device_entry_point_pipelines_its_chunks(ctx, oracle, filtered):
+    """msi_vs_search_device with more queries than one sweep admits: the chunks' preparation / selection / rescoring run on
+    the store's second stream against two scratch sets while the neighbouring chunks' sweeps run on the context's stream
+    (msi_vs.hip: search_device_pipelined).  5 chunks (the scratch sets alternate 0 1 0 1 0), a ragged last chunk, with and
+    without a filter; every list against the oracle, and identical to what the host entry point (one stream, one scratch
+    set) answers.  Twice: the second call reuses the sets the first one left behind."""
+    import ctypes as C
+    from meilisearch_amd._lib import check, lib
+    n, dim, k = 20000, 64, 10
+    rows = synth.make_embeddings(n, dim, seed=77)
+    rows[7000:7040] = rows[13]                                  # ties
+    ids = (np.arange(n, dtype=np.uint32) * 3 + 1)
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    step = lib().msi_vs_max_batch(st._h)
+    nq = 4 * step + 7
+    qs = synth.make_embeddings(nq, dim, seed=78)
+    fb = nb = None
+    if filtered:
+        allowed = ids[np.random.default_rng(9).random(n) < 0.3]
+        fb, nb = ma.dense_filter(list(allowed), nbits=int(ids[-1]) + 1)
+    dv = _DeviceArrays(ctx)
+    q_h, q_p = dv.put(qs)
+    f_p = None
+    if filtered:
+        _, f_p = dv.put(np.ascontiguousarray(fb, dtype=np.uint64))
+    h_ids, h_dist, h_cnt = st.search(qs, k, fb, nb or 0)
+    for _ in range(2):
+        o_ids, o_ids_p = dv.put(np.zeros((nq, k), np.uint32))
+        o_dist, o_dist_p = dv.put(np.zeros((nq, k), np.float32))
+        o_cnt, o_cnt_p = dv.put(np.zeros(nq, np.uint32))
+        o_inx, o_inx_p = dv.put(np.zeros(nq, np.uint32))
+        check(lib().msi_vs_search_device(st._h, q_p, nq, k, f_p, nb or 0, o_ids_p, o_dist_p, o_cnt_p, o_inx_p))
+        ctx.synchronize()
+        g_ids, g_dist, g_cnt, g_inx = (dv.get(x) for x in (o_ids, o_dist, o_cnt, o_inx))
+        assert not g_inx.any()
+        assert (np.asarray(g_cnt).astype(np.uint32) == h_cnt).all()
+        for j in range(nq):
+            c = int(h_cnt[j])
+            assert np.asarray(g_ids[j][:c]).view(np.uint32).tolist() == h_ids[j][:c].tolist(), j
+            assert np.asarray(g_dist[j][:c]).view(np.uint32).tolist() == h_dist[j][:c].view(np.uint32).tolist(), j
+    for j in list(range(0, nq, 37)) + [nq - 1]:
+        e_ids, e_dist = oracle.vs_topk(rows, ids, qs[j], k, fb, nb or 0)
+        assert int(h_cnt[j]) == e_ids.size and h_ids[j][:e_ids.size].tolist() == e_ids.tolist(), j
+        assert h_dist[j][:e_ids.size].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist(), j

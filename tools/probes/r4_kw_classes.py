@@ -29,6 +29,12 @@ names = ["<=0.1%", "0.1-1%", "1-12.5%", "12.5-50%", ">50%"]
 def mixed(tag):
     t0 = time.perf_counter(); assert L.rb_run(h, 0, NQ, k, ids.ctypes.data, cnt.ctypes.data, sc.ctypes.data) == 0
     print(f"{tag}: {NQ / (time.perf_counter() - t0):.0f} q/s", flush=True)
+if os.environ.get("CHW_SWEEP"):
+    for rep in range(2):
+        for v in os.environ["CHW_SWEEP"].split(","):
+            os.environ["MSI_VM_COMPACT_CHW"] = v
+            mixed(f"compact chunk width {v:>7s}")
+    sys.exit(0)
 if os.environ.get("FUSE_SWEEP"):
     # original order first (what bench.py runs), then sorted by universe (bursts of alike searches)
     inv = np.argsort(order, kind="stable").astype(np.uint32)
