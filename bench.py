@@ -759,16 +759,26 @@ def run_c4(args, env):
         kw["lib"].rb_last_latencies(kw["h"], lat_q.ctypes.data, Q)
         n_idx = n_total if row_sharded else n
         sweep = {}
-        for name, lo_f, hi_f in (("<=0.1%", 0.0, 0.001), ("0.1-1%", 0.001, 0.01), ("1-12.5% (compacted)", 0.01, 0.125),
-                                 ("12.5-50% (full space)", 0.125, 0.5), (">50%", 0.5, 1.01)):
+        for name, lo_f, hi_f in (("<=0.1%", 0.0, 0.001), ("0.1-1%", 0.001, 0.01), ("1-12.5%", 0.01, 0.125),
+                                 ("12.5-50%", 0.125, 0.5), (">50%", 0.5, 1.01)):
             m_ = (cand > lo_f * n_idx) & (cand <= hi_f * n_idx) if lo_f > 0 else (cand <= hi_f * n_idx)
             if m_.any():
                 sweep[name] = {"queries": int(m_.sum()), "p50_ms_at_load": round(float(np.median(lat_q[m_])), 3),
                                "mean_ms_at_load": round(float(lat_q[m_].mean()), 3)}
         legs["keyword_by_universe"] = {"buckets": sweep, "is": f"one {Q}-query pass of the keyword leg ({kw_threads} callers): searches grouped "
-                                       "by candidates / documents; a universe of <= 1/8 of the index continues in the compact space",
+                                       "by candidates / documents; a universe of <= 1/8 of the index continues in the compact space, above that the sub-tree of a small enough bucket does",
                                        "mean_universe_docs": round(float(cand.mean()), 1)}
         legs["keyword_lists_per_launch_round"] = round((vs[1] - vs0[1]) / max(1, vs[0] - vs0[0]), 2)   # of this leg only
+        import ctypes as _C
+        cst, lst = (_C.c_uint64 * 3)(), (_C.c_uint64 * 2)()
+        ma._lib.lib().msi_search_compaction_stats(cst)
+        ma._lib.lib().msi_search_late_compaction_stats(lst)
+        legs["keyword_compact_space"] = {
+            "searches": int(cst[0]), "continued_in_the_space_of_their_universe_or_of_a_bucket": int(cst[1]),
+            "sub_trees_moved_into_their_bucket": int(lst[0]), "mean_bucket_docs": round(lst[1] / max(1, lst[0]), 1),
+            "is": "process-wide since start: a search whose universe is <= 1/8 of the index continues over the ranks of its "
+                  "universe; one whose universe is larger moves the sub-tree of a bucket (<= 1/8 of the index) into the ranks "
+                  "of that bucket once nothing else of its bucket sort is alive (msi_search.hip Ctx::late_enter)"}
     # ---- per-QUERY latency (the metric is "queries/sec + p50 latency"; ms_per_step is the latency of a 768-query step) ----
     latency = None
     if kw is not None and not env.child and rank == 0:

@@ -672,19 +672,51 @@ __device__ uint32_t block_select_smallest(const KeySrc &src, uint32_t c, uint32_
         atomicAdd(&hist[(uint32_t)(key >> shift) & ((1u << dbits) - 1u)], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t cum = 0, b = 0;
+    {
+      // the bin that holds the krem-th smallest key: every thread sums 8 bins, the 256 sums are scanned through LDS
+      // (eight doubling steps), and the one thread whose bins straddle krem walks them.  (One thread walking all
+      // 2 048 bins was most of this kernel's time: ~50 us per level.)
       const uint32_t nb = 1u << dbits;
-      for (; b < nb; ++b) {
-        if (cum + hist[b] >= krem) break;
-        cum += hist[b];
+      uint32_t loc[8], mine = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t b = tid * 8 + e;
+        loc[e] = b < nb ? hist[b] : 0u;
+        mine += loc[e];
       }
-      if (b == nb) b = nb - 1;  // c < K cannot happen here (c > SEL_SORTCAP >= K)
-      sh[0] = b;
-      sh[1] = cum;       // entries of this prefix strictly below bin b
-      sh[2] = hist[b];
+      uint32_t *scan = reinterpret_cast<uint32_t *>(sbuf);   // (sbuf is not in use yet: 2 x 256 words of it)
+      scan[tid] = mine;
+      __syncthreads();
+      uint32_t src_off = 0;
+      for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = scan[src_off + tid] + (tid >= d ? scan[src_off + tid - d] : 0u);
+        scan[(src_off ^ 256) + tid] = v;
+        src_off ^= 256;
+        __syncthreads();
+      }
+      const uint32_t incl = scan[src_off + tid], excl = incl - mine;
+      const uint32_t total = scan[src_off + 255];
+      if (tid == 0) sh[0] = 0xFFFFFFFFu;
+      __syncthreads();
+      if (excl < krem && krem <= incl) {   // exactly one thread (krem >= 1)
+        uint32_t cum = excl;
+        int e = 0;
+        for (; e < 7; ++e) {
+          if (cum + loc[e] >= krem) break;
+          cum += loc[e];
+        }
+        sh[0] = tid * 8 + e;
+        sh[1] = cum;       // entries of this prefix strictly below bin b
+        sh[2] = loc[e];
+      }
+      __syncthreads();
+      if (sh[0] == 0xFFFFFFFFu && tid == 0) {   // krem above the total (c < K cannot happen here: c > SEL_SORTCAP >= K)
+        sh[0] = nb - 1;
+        sh[1] = total;
+        sh[2] = hist[nb - 1];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     const uint32_t b = sh[0], below = sh[1], inbin = sh[2];
     const u64 newprefix = (prefix << dbits) | b;
     const uint32_t gather = (K - krem) + below + inbin;  // keys with top bits <= newprefix
@@ -1261,9 +1293,9 @@ int32_t finish_upload(msi_vs *vs, uint64_t n_rows, const char *what) {
 }
 
 // Launch one sweep.  `dense` selects the epilogue, nqt the number of 16-query tiles.
-void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense, hipStream_t st = nullptr) {
+void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense, hipStream_t st = nullptr, uint32_t grid_wgs = 0) {
   const size_t lds = scan_lds_bytes(vs->KB, nqt, vs->s16, vs->bf2);
-  const dim3 grid(vs->scan_grid), block(SCAN_WAVES * 64);
+  const dim3 grid(grid_wgs ? grid_wgs : vs->scan_grid), block(SCAN_WAVES * 64);
   if (!st) st = vs->ctx->stream;
 #define MSI_SCAN_LAUNCH(N, D, B, S) \
   hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, D, B, S>), grid, block, lds, st, sa)
@@ -1321,6 +1353,7 @@ struct Chunk {
   uint32_t nq = 0, nqt = 0, k = 0, kp = 0, stride = 1, thr_rank = 0;
   uint64_t n_tiles = 0, dense_items = 0;
   bool filtered = false;
+  uint32_t grid_main = 0, grid_sample = 0;   // 0 = the store's grid (one workgroup per CU); the pipeline sets both
 };
 
 // the allowed-row masks and the list of tiles that hold an allowed row (the same for every chunk of a call)
@@ -1456,7 +1489,7 @@ int32_t chunk_pre(msi_vs *vs, Chunk &c, hipStream_t st) {
   MSI_HIP_TRY(hipMemsetAsync(c.s.overflow, 0, sizeof(uint32_t), st));
   if (c.stride > 1) {
     // sample sweep -> thresholds
-    launch_scan(vs, c.sa, c.nqt, true, st);
+    launch_scan(vs, c.sa, c.nqt, true, st, c.grid_sample);
     vs->scan_launches++;
     vs->scan_tiles += c.dense_items;
     c.se.K = c.thr_rank;
@@ -1473,14 +1506,14 @@ int32_t chunk_main(msi_vs *vs, Chunk &c, hipStream_t st) {
   if (c.stride == 1) {
     // dense main sweep; the K' best come straight out of the score matrix
     vs->scan_timer.begin(ctx, st);
-    launch_scan(vs, c.sa, c.nqt, true, st);
+    launch_scan(vs, c.sa, c.nqt, true, st, c.grid_main);
     vs->scan_timer.end(ctx);
   } else {
     // full sweep, sparse epilogue
     c.sa.theta = c.s.theta;
     c.sa.stride = 1;
     vs->scan_timer.begin(ctx, st);
-    launch_scan(vs, c.sa, c.nqt, false, st);
+    launch_scan(vs, c.sa, c.nqt, false, st, c.grid_main);
     vs->scan_timer.end(ctx);
     c.se.dense = nullptr;
   }
@@ -1566,6 +1599,7 @@ int32_t search_device_pipelined(msi_vs *vs, const float *d_queries, uint32_t n_q
   const bool filtered = d_fbits && vs->n_rows;
   if (filtered) MSI_TRY(enqueue_filter(vs, d_fbits, nbits, B));
   const uint32_t step = vs->nqt_max * QT;
+  static const uint32_t spare = getenv("MSI_VS_SPARE_CUS") ? (uint32_t)std::max(0, atoi(getenv("MSI_VS_SPARE_CUS"))) : 0u;
   Chunk ch[2];
   uint32_t i = 0;
   for (uint32_t q0 = 0; q0 < n_queries; q0 += step, ++i) {
@@ -1576,6 +1610,13 @@ int32_t search_device_pipelined(msi_vs *vs, const float *d_queries, uint32_t n_q
                                    d_out_dist + (size_t)q0 * k, d_out_counts + q0, d_inexact ? d_inexact + q0 : nullptr);
     if (set) swap_scratch(vs);
     MSI_TRY(pst);
+    // A sweep's workgroup takes a whole CU (its LDS), so nothing of the second stream could run beside it: the sweeps
+    // leave `spare` CUs free (one per XCD) and the sample sweep of the next chunk is cut to fit them; selection and
+    // rescoring (40 / 19 KB of LDS per workgroup) find room there too.  MSI_VS_SPARE_CUS=0 (default): the sweeps keep every CU.
+    if (spare && vs->scan_grid > 4 * spare) {
+      ch[set].grid_main = vs->scan_grid - spare;
+      ch[set].grid_sample = spare;
+    }
     MSI_TRY(chunk_pre(vs, ch[set], B));
     MSI_HIP_TRY(hipEventRecord(vs->ev_pre[set], B));
     if (i >= 1) {
@@ -1887,8 +1928,13 @@ int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries, uint32_t n_quer
   }
   // one HBM sweep per chunk of msi_vs_max_batch() queries
   const uint32_t step = vs->nqt_max * QT;
-  static const bool pipeline_off = getenv("MSI_VS_PIPELINE") && getenv("MSI_VS_PIPELINE")[0] == '0';
-  if (n_queries > step && !pipeline_off)
+  // MSI_VS_PIPELINE=1: the chunks' stages on two streams (search_device_pipelined).  Off by default — measured at C4 (768
+  // queries, 8 sweeps): 42.25 ms against 42.05 ms on one stream; a sweep's workgroup holds its CU's whole LDS, so the
+  // second stream's kernels wait for the sweep anyway, and with CUs left free for them (MSI_VS_SPARE_CUS=8 / 16) the sample
+  // sweep crawls beside the HBM-saturating one: 50.2 / 47.0 ms (profiles/r4_vs_pipeline.txt)
+  const char *pipe_knob = getenv("MSI_VS_PIPELINE");   // (read per call: tests switch it)
+  const bool pipeline_on = pipe_knob && pipe_knob[0] == '1';
+  if (n_queries > step && pipeline_on)
     return search_device_pipelined(vs, d_queries, n_queries, k, (const u64 *)d_filter_bits, filter_nbits, d_out_docids, d_out_dist,
                                    d_out_counts, d_inexact);
   for (uint32_t q0 = 0; q0 < n_queries; q0 += step) {

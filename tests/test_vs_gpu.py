@@ -465,7 +465,7 @@ class _DeviceArrays:
 
 
 @pytest.mark.parametrize("filtered", [False, True])
-def test_device_entry_point_pipelines_its_chunks(ctx, oracle, filtered):
+def test_device_entry_point_pipelines_its_chunks(ctx, oracle, filtered, monkeypatch):
     """msi_vs_search_device with more queries than one sweep admits: the chunks' preparation / selection / rescoring run on
     the store's second stream against two scratch sets while the neighbouring chunks' sweeps run on the context's stream
     (msi_vs.hip: search_device_pipelined).  5 chunks (the scratch sets alternate 0 1 0 1 0), a ragged last chunk, with and
@@ -473,6 +473,7 @@ def test_device_entry_point_pipelines_its_chunks(ctx, oracle, filtered):
     set) answers.  Twice: the second call reuses the sets the first one left behind."""
     import ctypes as C
     from meilisearch_amd._lib import check, lib
+    monkeypatch.setenv("MSI_VS_PIPELINE", "1")     # (off by default: it measured no gain — profiles/r4_vs_pipeline.txt)
     n, dim, k = 20000, 64, 10
     rows = synth.make_embeddings(n, dim, seed=77)
     rows[7000:7040] = rows[13]                                  # ties
