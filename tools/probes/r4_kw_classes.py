@@ -30,7 +30,7 @@ def mixed(tag):
     t0 = time.perf_counter(); assert L.rb_run(h, 0, NQ, k, ids.ctypes.data, cnt.ctypes.data, sc.ctypes.data) == 0
     print(f"{tag}: {NQ / (time.perf_counter() - t0):.0f} q/s", flush=True)
 if os.environ.get("CHW_SWEEP"):
-    for rep in range(2):
+    for rep in range(int(os.environ.get("REPS", 2))):
         for v in os.environ["CHW_SWEEP"].split(","):
             os.environ["MSI_VM_COMPACT_CHW"] = v
             mixed(f"compact chunk width {v:>7s}")
