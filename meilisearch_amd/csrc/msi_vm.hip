@@ -391,12 +391,15 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
     const u64 fw0 = (u64)chunk * CHW;
     const uint32_t nwf = (uint32_t)min((u64)CHW, (u64)full_words - fw0);
     const u64 *u0 = reinterpret_cast<const u64 *>(rp->full_base) + (u64)rp->u0_slot * full_words + fw0;
-    for (uint32_t i = tid; i < CHW; i += VT) {
-      s_dec[i] = i < nwf ? u0[i] : 0ull;
-      s_cnt[i] = i < nwf ? prefix[fw0 + i] : 0u;
-    }
     c_lo = prefix[fw0];
     c_hi = chunk + 1 < full_chunks ? prefix[fw0 + CHW] : (uint32_t)r.n_docs;
+    // (a chunk without a document of U0 — most chunks of a universe of a few hundred documents — decodes nothing: its
+    // 24 KB of tables stay where they are; the workgroup still fills the posting cache with what it is first to read)
+    if (c_hi != c_lo)
+      for (uint32_t i = tid; i < CHW; i += VT) {
+        s_dec[i] = i < nwf ? u0[i] : 0ull;
+        s_cnt[i] = i < nwf ? prefix[fw0 + i] : 0u;
+      }
     // this chunk's decode descriptors (one contiguous block of the list: start[n_decodes + 1], padded to 16 bytes, then the
     // 16-byte containers) come to LDS with the tables: read from memory per command they were three dependent loads — block
     // offset, container range, container — in front of every decode's first posting byte
