@@ -1358,14 +1358,12 @@ struct Chunk {
 
 // the allowed-row masks and the list of tiles that hold an allowed row (the same for every chunk of a call)
 int32_t enqueue_filter(msi_vs *vs, const u64 *d_fbits, uint64_t nbits, hipStream_t st) {
-  Small s = small_of(vs);
   MSI_TRY(vs->tmask.ensure(vs->n_tiles * sizeof(uint16_t)));
   MSI_TRY(vs->tlist.ensure(vs->n_tiles * sizeof(uint32_t)));
   MSI_TRY(vs->fsmall.ensure(64));
   MSI_HIP_TRY(hipMemsetAsync(vs->fsmall.p, 0, sizeof(uint32_t), st));
   const uint64_t padded = vs->n_tiles * 16;
   const uint64_t rows_per_block = 1024ull * FT_SUB;
-  (void)s;
   hipLaunchKernelGGL(vs_filter_tiles_kernel, dim3((uint32_t)((padded + rows_per_block - 1) / rows_per_block)),
                      dim3(1024), 0, st, vs->docids.as<uint32_t>(), vs->n_rows, d_fbits, nbits,
                      vs->tmask.as<uint16_t>(), vs->tlist.as<uint32_t>(), vs->fsmall.as<uint32_t>());

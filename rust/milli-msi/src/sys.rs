@@ -129,6 +129,7 @@ extern "C" {
     pub fn msi_bits_geo_list(pool: *mut msi_bits, points: *const msi_geo_points, universe: u32, lat: f64, lng: f64, cap: u32,
                              out_docids: *mut u32, out_distance: *mut f64, out_total: *mut u64) -> i32;
     pub fn msi_search_compaction_stats(out: *mut u64) -> i32;
+    pub fn msi_search_late_compaction_stats(out: *mut u64) -> i32;   // [sub-trees moved into their bucket's space, documents summed]
     pub fn msi_bits_vm_bytes(out: *mut u64) -> i32;
     pub fn msi_last_error() -> *const c_char;
     pub fn msi_ctx_create(device: i32, out: *mut *mut msi_ctx) -> i32;
