@@ -38,6 +38,7 @@ def runner_lib():
     lib.rb_n_fields.restype = C.c_uint32
     lib.rb_n_fields.argtypes = [C.c_void_p]
     lib.rb_prepare_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    lib.rb_prepare_queries_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
     lib.rb_destroy.argtypes = [C.c_void_p]
     lib.rb_n_words.restype = C.c_uint32
     lib.rb_n_words.argtypes = [C.c_void_p]

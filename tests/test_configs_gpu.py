@@ -199,6 +199,41 @@ def test_c4_keyword_leg_on_the_coherent_corpus(ctx):
         lib.rb_destroy(h)
 
 
+def test_phrases_on_the_coherent_corpus(ctx):
+    """quoted phrases on an index of several chunks, through universe compaction and the bucket-space
+    sub-trees — every eighth query of the corpus workload opens with a phrase of two consecutive words of a document
+    (rb_prepare_queries_ex, flags 1), a misspelled / prefix word may follow it; against oracle/ranking_oracle.py on the same
+    stored bytes.  First written in round 4 after the round's GPU minutes were spent: it runs on the CPU tier's emulated
+    kernels (150 000 documents, three chunks) and is skipped on the device until it has been run there once."""
+    import ctypes as C
+    import os
+    from oracle import parity
+    from oracle import synth_index as SI
+    if not os.environ.get("MSI_RUNNER_SO") and not os.environ.get("MSI_TEST_UNTRIED_ON_DEVICE"):
+        pytest.skip("not yet run on an MI355X (MSI_TEST_UNTRIED_ON_DEVICE=1 runs it: 2 M documents)")
+    n_docs, n_words, n_queries, limit = 2_000_000, 400_000, 96, 20
+    if os.environ.get("MSI_RUNNER_SO"):
+        n_docs, n_words, n_queries = 150_000, 60_000, 96
+    lib = SI.runner_lib()
+    lib.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    h = lib.rb_create_corpus(n_docs, n_words, 44)
+    try:
+        assert lib.rb_attach(h, ctx.handle, 8, 1024, 1024) == 0
+        assert lib.rb_prepare_queries_ex(h, n_queries, 3, 515, 1) == 0
+        chk = parity.KeywordLegChecker(lib, h, n_docs)
+        queries = [chk.index.query(i) for i in range(n_queries)]
+        phrases = [q for q in queries if q.startswith('"')]
+        assert len(phrases) >= n_queries // 10 and any(not q.endswith('"') for q in phrases), phrases[:4]
+        got = chk.run_product(0, n_queries, limit)
+        v = chk.verdict(0, n_queries, limit, product=got)
+        assert v["mismatches"] == 0, v
+        # the phrases found documents (they are taken out of one) and their hits carry the rules' details
+        hits = [int(got[1][i]) for i, q in enumerate(queries) if q.startswith('"')]
+        assert min(hits) >= 1, (hits, phrases[:4])
+    finally:
+        lib.rb_destroy(h)
+
+
 def test_rerank_inside_candidate_universes_on_the_corpus(ctx):
     """Config 5's second half as written: the keyword ranking (all default criteria, detailed scores) of a query restricted
     to a candidate set of 1 000 documents — what reranks a filtered vector search's top-1000 — through the runner's

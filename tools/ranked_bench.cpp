@@ -898,11 +898,31 @@ struct Runner {
   int32_t search(msi_bits *pool, const std::vector<std::string> &q, uint32_t limit, uint32_t *ids, uint32_t *n, double *scores,
                  msi_score_detail *details = nullptr, uint32_t *n_details = nullptr, uint64_t *candidates = nullptr,
                  const Bytes *universe = nullptr) {
-    std::vector<msi_query_token> toks(q.size());
+    // an element of `q` is a word, or a quoted phrase `"w1 w2 ..."` (rb_prepare_queries_ex): one located term of several
+    // words; positions count words (parse_query.rs:60-120), only a trailing plain word is a prefix
+    std::vector<msi_query_token> toks;
+    std::vector<std::pair<uint32_t, uint32_t>> span;   // [first token, n tokens) of every element
+    for (const std::string &e : q) {
+      const uint32_t first = (uint32_t)toks.size();
+      if (e.size() >= 2 && e.front() == '"' && e.back() == '"') {
+        size_t at = 1;
+        while (at < e.size() - 1) {
+          size_t sp = e.find(' ', at);
+          if (sp == std::string::npos || sp > e.size() - 1) sp = e.size() - 1;
+          if (sp > at) toks.push_back(msi_query_token{(const uint8_t *)e.data() + at, (uint32_t)(sp - at), 0u});
+          at = sp + 1;
+        }
+      } else {
+        toks.push_back(msi_query_token{(const uint8_t *)e.data(), (uint32_t)e.size(), 0u});
+      }
+      span.push_back({first, (uint32_t)toks.size() - first});
+    }
     std::vector<msi_located_term> terms(q.size());
     for (size_t i = 0; i < q.size(); ++i) {
-      toks[i] = msi_query_token{(const uint8_t *)q[i].data(), (uint32_t)q[i].size(), i + 1 == q.size() ? 1u : 0u};
-      terms[i] = msi_located_term{&toks[i], 1, 0, (uint32_t)i, (uint32_t)i};
+      const bool phrase = q[i].size() >= 2 && q[i].front() == '"';
+      if (!phrase && i + 1 == q.size()) toks[span[i].first].is_prefix = 1u;
+      terms[i] = msi_located_term{&toks[span[i].first], span[i].second, phrase ? MSI_TERM_PHRASE : 0u, span[i].first,
+                                  span[i].first + span[i].second - 1};
     }
     msi_search_params p = prm;
     p.length = limit;
@@ -1063,7 +1083,13 @@ int32_t rb_attach(void *h, msi_ctx *ctx, uint32_t n_threads, uint32_t n_slots, u
 }
 // n_queries queries of n_terms frequent words each (seeded); every one is run once so that the synthetic index has
 // generated the postings it needs (index generation is not what is measured)
+// flags (corpus only): 1 = every eighth query starts with a quoted phrase of two consecutive words of the document (exact
+// words: a phrase takes no typo), a third word — misspelled / cut to a prefix as usual — may follow it
+int32_t rb_prepare_queries_ex(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed, uint32_t flags);
 int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed) {
+  return rb_prepare_queries_ex(h, n_queries, n_terms, seed, 0);
+}
+int32_t rb_prepare_queries_ex(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed, uint32_t flags) {
   Runner *r = (Runner *)h;
   std::mt19937_64 g(seed);
   r->queries.assign(n_queries, {});
@@ -1103,6 +1129,13 @@ int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64
       const uint32_t at = f0 + (uint32_t)(g() % (fl - want + 1));
       for (uint32_t i = 0; i < want; ++i) q.push_back(c.words[c.tok[c.doc_off[d] + at + i] & Corpus::ID]);
       if (shape == 2) continue;
+      if ((flags & 1u) && qi % 8 == 5 && q.size() >= 2) {   // "w1 w2" [w3]
+        const std::string ph = "\"" + q[0] + " " + q[1] + "\"";
+        q.erase(q.begin(), q.begin() + 2);
+        if (!q.empty() && g() % 2 == 0 && q[0].size() >= 5) q[0] = edit(q[0]);
+        q.insert(q.begin(), ph);
+        continue;
+      }
       const uint32_t n_edits = (uint32_t)(g() % 10 < 5 ? 0 : (g() % 10 < 7 ? 1 : 2));
       for (uint32_t e = 0; e < n_edits; ++e) {
         std::string &w = q[g() % q.size()];
