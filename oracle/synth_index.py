@@ -39,6 +39,11 @@ def runner_lib():
     lib.rb_n_fields.argtypes = [C.c_void_p]
     lib.rb_prepare_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
     lib.rb_prepare_queries_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+    lib.rb_enable_prefix_dbs.argtypes = [C.c_void_p, C.c_uint32]
+    lib.rb_has_prefix.restype = C.c_uint32
+    lib.rb_has_prefix.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+    lib.rb_read_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                  C.c_uint64, C.c_void_p, C.c_uint32]
     lib.rb_destroy.argtypes = [C.c_void_p]
     lib.rb_n_words.restype = C.c_uint32
     lib.rb_n_words.argtypes = [C.c_void_p]
@@ -137,26 +142,54 @@ class SynthIndex:
     def get_fid_word_count_docids(self, fid, count):
         return self._read(4, b"", b"", fid, count)
 
+    # the word-prefix databases (rb_enable_prefix_dbs; without them every read below finds nothing): the values the
+    # index hands to the engine's sink, decoded by this side's own decoder and united
+    def _read_multi(self, db, a=b"", b=b"", x=0):
+        key = ("m", db, a, b, x)
+        if key in self._cache:
+            hit = self._cache[key]
+            return None if hit is None else self.DocSet(hit)
+        self.reads += 1
+        cap = 64 << 20
+        if not hasattr(self, "_multi_buf"):
+            self._multi_buf = np.zeros(cap, np.uint8)
+            self._multi_lens = np.zeros(1 << 16, np.uint32)
+        n = self.lib.rb_read_multi(self.h, db, a, len(a), b, len(b), x, self._multi_buf.ctypes.data, cap,
+                                   self._multi_lens.ctypes.data, self._multi_lens.size)
+        assert n >= 0, "rb_read_multi: more values than the probe buffer holds"
+        val, at = None, 0
+        for i in range(n):
+            ln = int(self._multi_lens[i])
+            ids = docset.decode_cbo(self._multi_buf[at:at + ln].tobytes())
+            at += ln
+            if ids.size:
+                one = self.DocSet.from_sorted(ids)
+                val = one if val is None else val | one
+        self._cache[key] = val
+        return None if val is None else self.DocSet(val)
+
     def has_prefix(self, pfx, include_exact):
-        return False
+        a = pfx.encode()
+        return bool(self.lib.rb_has_prefix(self.h, a, len(a)))
 
     def get_word_prefix_docids(self, pfx, original):
-        return None
+        return self._read_multi(5, pfx.encode())
 
     def get_word_prefix_fid_docids(self, pfx, fid):
-        return None
+        return self._read_multi(6, pfx.encode(), b"", fid)
 
     def get_word_prefix_position_docids(self, pfx, pos):
-        return None
+        return self._read_multi(7, pfx.encode(), b"", pos)
 
     def get_word_prefix_fids(self, pfx):
-        return []
+        return self._keys(2, pfx) if self.has_prefix(pfx, False) else []
 
     def get_word_prefix_positions(self, pfx):
-        return []
+        return self._keys(3, pfx) if self.has_prefix(pfx, False) else []
 
     def get_word_prefix_pair(self, prox, w1, pfx2):
-        return self.DocSet()
+        got = self._read_multi(8, w1.encode(), pfx2.encode(), prox)
+        return self.DocSet() if got is None else got
 
     def prefix_words(self, prefix):
         lo = bisect.bisect_left(self.words, prefix)       # ASCII words: str order = byte order

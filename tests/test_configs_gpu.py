@@ -234,6 +234,49 @@ def test_phrases_on_the_coherent_corpus(ctx):
         lib.rb_destroy(h)
 
 
+def test_word_prefix_databases_on_the_coherent_corpus(ctx):
+    """VERDICT r3 missing #1 / weak #1 (ii): the corpus index with word-prefix databases (rb_enable_prefix_dbs: keys = the
+    prefixes of up to four bytes that enough dictionary words share; word_prefix_docids / _fid_docids / _position_docids
+    derived from the same tokens, the pair database's prefix_iter for the proximity rule) and the query shapes that read
+    them — workloads/search/movies.json's one-letter query, two- and three-letter prefixes, a word followed by a short
+    prefix — next to the usual misspelled / prefix-cut queries and quoted phrases, on three chunks of documents.  Against
+    oracle/ranking_oracle.py reading the values the index hands to the engine's sink.  Like the phrase test: written after
+    the round's GPU minutes were spent, so it runs on the CPU tier's emulated kernels and is skipped on the device."""
+    import ctypes as C
+    import os
+    from oracle import parity
+    from oracle import synth_index as SI
+    if not os.environ.get("MSI_RUNNER_SO") and not os.environ.get("MSI_TEST_UNTRIED_ON_DEVICE"):
+        pytest.skip("not yet run on an MI355X (MSI_TEST_UNTRIED_ON_DEVICE=1 runs it: 2 M documents)")
+    n_docs, n_words, n_queries, limit = 2_000_000, 400_000, 128, 20
+    if os.environ.get("MSI_RUNNER_SO"):
+        n_docs, n_words, n_queries = 150_000, 60_000, 128
+    lib = SI.runner_lib()
+    lib.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    h = lib.rb_create_corpus(n_docs, n_words, 45)
+    try:
+        assert lib.rb_enable_prefix_dbs(h, 50) == 0
+        assert lib.rb_attach(h, ctx.handle, 8, 1024, 1024) == 0
+        assert lib.rb_prepare_queries_ex(h, n_queries, 3, 616, 3) == 0
+        chk = parity.KeywordLegChecker(lib, h, n_docs)
+        queries = [chk.index.query(i) for i in range(n_queries)]
+        short = [q for q in queries if q and len(q.split()[-1]) <= 3 and not q.endswith('"')]
+        assert len(short) >= 4 and any(len(q) == 1 for q in short), short
+        assert all(chk.index.has_prefix(q.split()[-1][:1], False) for q in short)     # one letter: always a key here
+        reads0 = chk.index.reads
+        got = chk.run_product(0, n_queries, limit)
+        v = chk.verdict(0, n_queries, limit, product=got)
+        assert v["mismatches"] == 0, v
+        assert v["checked_queries"] == n_queries
+        # a one-letter prefix matches a large share of the documents: the page is full
+        for i, q in enumerate(queries):
+            if len(q) == 1:
+                assert int(got[1][i]) == limit, (q, int(got[1][i]))
+        assert chk.index.reads > reads0
+    finally:
+        lib.rb_destroy(h)
+
+
 def test_rerank_inside_candidate_universes_on_the_corpus(ctx):
     """Config 5's second half as written: the keyword ranking (all default criteria, detailed scores) of a query restricted
     to a candidate set of 1 000 documents — what reranks a filtered vector search's top-1000 — through the runner's

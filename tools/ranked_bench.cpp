@@ -25,6 +25,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <random>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -264,6 +265,8 @@ struct Corpus {
 struct Index {
   uint64_t n_docs;
   std::unique_ptr<Corpus> corpus;                 // set: the databases below are derived from the corpus's documents
+  uint32_t prefix_threshold = 0;                  // > 0: the word-prefix databases exist (rb_enable_prefix_dbs): keys = the
+                                                  // prefixes of 1..4 bytes that at least this many dictionary words share
   std::vector<std::string> words;                 // sorted
   std::map<std::string, uint32_t> rank;           // frequency rank
   std::shared_mutex mu;   // lookups of warm keys (all of them, after the warm-up pass) share the lock
@@ -510,6 +513,155 @@ int32_t cb_count(void *u, uint32_t fid, uint32_t count, const uint8_t **bytes, s
     v.erase(std::unique(v.begin(), v.end()), v.end());
     return v;
   }), bytes, out);
+}
+
+// ---- the word-prefix databases of the corpus (rb_enable_prefix_dbs) ---------------------------------------------------
+// milli keeps, for every prefix of up to four bytes that enough words share, the union of those words' entries:
+// word_prefix_docids, word_prefix_fid_docids, word_prefix_position_docids; a prefix term whose word is such a key reads
+// them instead of enumerating its derivations (compute_derivations.rs:193-205).  Derived here from the same tokens as
+// everything else: the words with a prefix are a contiguous range of ids (ids are dictionary order), one pass over the
+// documents per prefix.
+bool corpus_prefix_range(Index *ix, const std::string &p, uint32_t *lo, uint32_t *hi) {
+  if (!ix->corpus || !ix->prefix_threshold || p.empty() || p.size() > 4) return false;
+  const auto &w = ix->corpus->words;
+  auto a = std::lower_bound(w.begin(), w.end(), p);
+  std::string end = p;
+  end.back() = (char)((unsigned char)end.back() + 1);   // (ASCII words: no carry)
+  auto b = std::lower_bound(a, w.end(), end);
+  *lo = (uint32_t)(a - w.begin());
+  *hi = (uint32_t)(b - w.begin());
+  return (uint32_t)(b - a) >= ix->prefix_threshold;
+}
+const WordDerived *corpus_prefix(Index *ix, const std::string &p) {
+  static std::mutex mu;
+  static std::map<const Index *, std::map<std::string, std::shared_ptr<WordDerived>>> all;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto &m = all[ix];
+    auto it = m.find(p);
+    if (it != m.end()) return it->second.get();
+  }
+  auto wd = std::make_shared<WordDerived>();
+  uint32_t lo = 0, hi = 0;
+  if (corpus_prefix_range(ix, p, &lo, &hi)) {
+    const Corpus &c = *ix->corpus;
+    std::vector<uint32_t> docs;
+    std::map<uint32_t, std::vector<uint32_t>> by_fid, by_pos;
+    for (uint64_t d = 0; d < c.n_docs; ++d)
+      c.tokens(d, [&](uint32_t w, uint32_t fid, uint32_t pos) {
+        if (w < lo || w >= hi) return;
+        if (docs.empty() || docs.back() != (uint32_t)d) docs.push_back((uint32_t)d);
+        auto &f = by_fid[fid];
+        if (f.empty() || f.back() != (uint32_t)d) f.push_back((uint32_t)d);
+        auto &q = by_pos[Corpus::bucketed(pos)];
+        if (q.empty() || q.back() != (uint32_t)d) q.push_back((uint32_t)d);
+      });
+    ix->blob("W/" + p, [&] { return docs; });
+    for (auto &kv : by_fid) {
+      wd->fids.push_back((uint16_t)kv.first);
+      ix->blob("F/" + std::to_string(kv.first) + "/" + p, [&] { return kv.second; });
+    }
+    for (auto &kv : by_pos) {
+      wd->positions.push_back((uint16_t)kv.first);
+      ix->blob("Q/" + std::to_string(kv.first) + "/" + p, [&] { return kv.second; });
+    }
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  return all[ix].emplace(p, wd).first->second.get();
+}
+int32_t push_blob(Index *ix, const std::string &key, msi_posting_sink push, void *sink) {
+  const Bytes *b = ix->blob(key, [&] { return std::vector<uint32_t>(); });
+  if (!b) return 0;
+  return push(sink, b->data(), b->size()) < 0 ? -1 : 1;
+}
+int32_t cb_prefix_docids(void *u, const uint8_t *w, uint32_t n, int32_t, msi_posting_sink push, void *sink) {
+  Index *ix = (Index *)u;
+  const std::string p = str(w, n);
+  uint32_t lo, hi;
+  if (!corpus_prefix_range(ix, p, &lo, &hi)) return 0;
+  corpus_prefix(ix, p);
+  return push_blob(ix, "W/" + p, push, sink);
+}
+int32_t cb_prefix_fid(void *u, const uint8_t *w, uint32_t n, uint32_t fid, msi_posting_sink push, void *sink) {
+  Index *ix = (Index *)u;
+  const std::string p = str(w, n);
+  uint32_t lo, hi;
+  if (!corpus_prefix_range(ix, p, &lo, &hi)) return 0;
+  corpus_prefix(ix, p);
+  return push_blob(ix, "F/" + std::to_string(fid) + "/" + p, push, sink);
+}
+int32_t cb_prefix_pos(void *u, const uint8_t *w, uint32_t n, uint32_t pos, msi_posting_sink push, void *sink) {
+  Index *ix = (Index *)u;
+  const std::string p = str(w, n);
+  uint32_t lo, hi;
+  if (!corpus_prefix_range(ix, p, &lo, &hi)) return 0;
+  corpus_prefix(ix, p);
+  return push_blob(ix, "Q/" + std::to_string(pos) + "/" + p, push, sink);
+}
+int32_t cb_prefix_fids(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t cap, uint32_t *cnt) {
+  const WordDerived *wd = corpus_prefix((Index *)u, str(w, n));
+  *cnt = (uint32_t)wd->fids.size();
+  for (uint32_t i = 0; i < wd->fids.size() && i < cap; ++i) out[i] = wd->fids[i];
+  return 0;
+}
+int32_t cb_prefix_positions(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t cap, uint32_t *cnt) {
+  const WordDerived *wd = corpus_prefix((Index *)u, str(w, n));
+  *cnt = (uint32_t)wd->positions.size();
+  for (uint32_t i = 0; i < wd->positions.size() && i < cap; ++i) out[i] = wd->positions[i];
+  return 0;
+}
+// every word_pair_proximity_docids value whose key starts with (prox, word1, prefix2...): the words of the prefix's range
+// that follow word1 within three positions somewhere, each through the pair database's own derivation (cb_pair)
+int32_t cb_prefix_pair(void *u, uint32_t prox, const uint8_t *l, uint32_t ln, const uint8_t *r, uint32_t rn, msi_posting_sink push,
+                       void *sink) {
+  Index *ix = (Index *)u;
+  if (!ix->corpus || prox < 1 || prox > 3) return 0;
+  const std::string a = str(l, ln), p = str(r, rn);
+  const Corpus &c = *ix->corpus;
+  const int64_t ia = c.id_of(a);
+  if (ia < 0 || p.empty()) return 0;
+  uint32_t lo, hi;
+  {   // (any prefix, not only the keys of the prefix databases: this is a prefix_iter over the pair database)
+    auto wa = std::lower_bound(c.words.begin(), c.words.end(), p);
+    std::string end = p;
+    end.back() = (char)((unsigned char)end.back() + 1);
+    auto wb = std::lower_bound(wa, c.words.end(), end);
+    lo = (uint32_t)(wa - c.words.begin());
+    hi = (uint32_t)(wb - c.words.begin());
+  }
+  std::set<uint32_t> followers;
+  uint64_t na = 0;
+  const uint32_t *pa = c.posting((uint32_t)ia, &na);
+  std::vector<std::pair<uint32_t, uint32_t>> pos_a;
+  for (uint64_t k = 0; k < na; ++k) {
+    pos_a.clear();
+    c.tokens(pa[k], [&](uint32_t w, uint32_t fid, uint32_t pos) {
+      if (w >= lo && w < hi)
+        for (auto &x : pos_a)
+          if (x.first == fid && pos > x.second && pos - x.second <= 3) { followers.insert(w); break; }
+      if (w == (uint32_t)ia) pos_a.push_back({fid, pos});
+    });
+  }
+  int32_t pushed = 0;
+  for (uint32_t w2 : followers) {
+    const uint8_t *bytes = nullptr;
+    size_t n = 0;
+    const std::string &b = c.words[w2];
+    cb_pair(u, prox, l, ln, (const uint8_t *)b.data(), (uint32_t)b.size(), &bytes, &n);
+    if (!n) continue;
+    if (push(sink, bytes, n) < 0) return -1;
+    ++pushed;
+  }
+  return pushed;
+}
+
+void set_prefix_callbacks(msi_index_vtable &vt) {
+  vt.word_prefix_docids = cb_prefix_docids;
+  vt.word_prefix_fid_docids = cb_prefix_fid;
+  vt.word_prefix_position_docids = cb_prefix_pos;
+  vt.word_prefix_pair_proximity_docids = cb_prefix_pair;
+  vt.word_prefix_fids = cb_prefix_fids;
+  vt.word_prefix_positions = cb_prefix_positions;
 }
 
 #ifdef RANKED_BENCH_CPU
@@ -1055,6 +1207,7 @@ int32_t rb_attach(void *h, msi_ctx *ctx, uint32_t n_threads, uint32_t n_slots, u
   r->vt.word_fids = cb_fids;
   r->vt.word_positions = cb_positions;
   r->vt.field_id_word_count_docids = cb_count;
+  if (r->ix.prefix_threshold) set_prefix_callbacks(r->vt);   // (rb_enable_prefix_dbs came first)
   const int32_t crit[7] = {MSI_CRIT_WORDS, MSI_CRIT_TYPO, MSI_CRIT_PROXIMITY, MSI_CRIT_ATTRIBUTE_RANK, MSI_CRIT_SORT,
                            MSI_CRIT_WORD_POSITION, MSI_CRIT_EXACTNESS};
   memcpy(r->criteria, crit, sizeof(crit));
@@ -1084,7 +1237,8 @@ int32_t rb_attach(void *h, msi_ctx *ctx, uint32_t n_threads, uint32_t n_slots, u
 // n_queries queries of n_terms frequent words each (seeded); every one is run once so that the synthetic index has
 // generated the postings it needs (index generation is not what is measured)
 // flags (corpus only): 1 = every eighth query starts with a quoted phrase of two consecutive words of the document (exact
-// words: a phrase takes no typo), a third word — misspelled / cut to a prefix as usual — may follow it
+// words: a phrase takes no typo), a third word — misspelled / cut to a prefix as usual — may follow it; 2 = three queries in
+// 64 end in a one- to three-letter prefix (the word-prefix databases' keys)
 int32_t rb_prepare_queries_ex(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed, uint32_t flags);
 int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed) {
   return rb_prepare_queries_ex(h, n_queries, n_terms, seed, 0);
@@ -1120,6 +1274,14 @@ int32_t rb_prepare_queries_ex(void *h, uint32_t n_queries, uint32_t n_terms, uin
       if (shape == 1) { q.push_back(c.words[most]); continue; }         // "the"
       const uint64_t d = g() % c.n_docs;
       const uint32_t len = (uint32_t)(c.doc_off[d + 1] - c.doc_off[d]);
+      if ((flags & 2u) && (shape == 3 || shape == 4 || shape == 35)) {
+        // workloads/search/movies.json's one-letter query, and two- / three-letter ones: a lone prefix term, answered out
+        // of the word-prefix databases when the index has them (rb_enable_prefix_dbs); after a word at shape 35
+        const std::string &w = c.words[c.tok[c.doc_off[d] + g() % len] & Corpus::ID];
+        if (shape == 35) q.push_back(c.words[c.tok[c.doc_off[d]] & Corpus::ID]);
+        q.push_back(w.substr(0, shape == 3 ? 1 : std::min<size_t>(w.size(), 2 + g() % 2)));
+        continue;
+      }
       uint32_t title = 0;
       while (title < len && !(c.tok[c.doc_off[d] + title] & Corpus::OVERVIEW)) ++title;
       uint32_t want = shape == 2 ? 2u : 1u + (uint32_t)(g() % std::max(1u, n_terms));   // ("Batman returns": two title words)
@@ -1254,9 +1416,54 @@ int32_t rb_read(void *h, uint32_t db, const uint8_t *a, uint32_t an, const uint8
   }
   return MSI_E_INVALID;
 }
-// db: 0 the fids a word occurs in | 1 its (bucketed) positions
+// The corpus index gets word-prefix databases (before rb_attach / the first search): keys = prefixes of 1..4 bytes shared by
+// at least `threshold` words of the dictionary.
+int32_t rb_enable_prefix_dbs(void *h, uint32_t threshold) {
+  Runner *r = (Runner *)h;
+  if (!r->ix.corpus || !threshold) return MSI_E_INVALID;
+  r->ix.prefix_threshold = threshold;
+  set_prefix_callbacks(r->vt);
+  return MSI_OK;
+}
+uint32_t rb_has_prefix(void *h, const uint8_t *a, uint32_t an) {
+  uint32_t lo, hi;
+  return corpus_prefix_range(&((Runner *)h)->ix, str(a, an), &lo, &hi) ? 1u : 0u;
+}
+// The values a prefix read hands to the engine's sink, for the oracle: db 5 word_prefix_docids(a) | 6 word_prefix_fid_docids(a,
+// x = fid) | 7 word_prefix_position_docids(a, x = position) | 8 word_prefix_pair_proximity_docids(x = proximity, a = word1,
+// b = prefix2).  out = the values back to back, lens[i] their sizes; returns the number of values (negative: error / too small)
+struct CollectSink {
+  uint8_t *out;
+  size_t cap, at;
+  uint32_t *lens, max_vals, n;
+  bool overflow;
+};
+static int32_t collect_push(void *sink, const uint8_t *bytes, size_t n) {
+  CollectSink *c = (CollectSink *)sink;
+  if (c->n >= c->max_vals || c->at + n > c->cap) { c->overflow = true; return -1; }
+  memcpy(c->out + c->at, bytes, n);
+  c->at += n;
+  c->lens[c->n++] = (uint32_t)n;
+  return 0;
+}
+int32_t rb_read_multi(void *h, uint32_t db, const uint8_t *a, uint32_t an, const uint8_t *b, uint32_t bn, uint32_t x, uint8_t *out,
+                      uint64_t cap, uint32_t *lens, uint32_t max_vals) {
+  Runner *r = (Runner *)h;
+  CollectSink c{out, (size_t)cap, 0, lens, max_vals, 0, false};
+  switch (db) {
+    case 5: cb_prefix_docids(&r->ix, a, an, 1, collect_push, &c); break;
+    case 6: cb_prefix_fid(&r->ix, a, an, x, collect_push, &c); break;
+    case 7: cb_prefix_pos(&r->ix, a, an, x, collect_push, &c); break;
+    case 8: cb_prefix_pair(&r->ix, x, a, an, b, bn, collect_push, &c); break;
+    default: return MSI_E_INVALID;
+  }
+  return c.overflow ? MSI_E_INVALID : (int32_t)c.n;
+}
+// db: 0 the fids a word occurs in | 1 its (bucketed) positions | 2 / 3 the same of a prefix (word-prefix databases)
 int32_t rb_read_keys(void *h, uint32_t db, const uint8_t *a, uint32_t an, uint16_t *out, uint32_t cap, uint32_t *cnt) {
   Runner *r = (Runner *)h;
+  if (db == 2) return cb_prefix_fids(&r->ix, a, an, out, cap, cnt);
+  if (db == 3) return cb_prefix_positions(&r->ix, a, an, out, cap, cnt);
   return db == 0 ? cb_fids(&r->ix, a, an, out, cap, cnt) : cb_positions(&r->ix, a, an, out, cap, cnt);
 }
 // ScoreWithRatioResult::merge (search/hybrid.rs:102-235) of every query's vector list (similarity = 1 - distance) with
