@@ -40,6 +40,9 @@ def runner_lib():
     lib.rb_prepare_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
     lib.rb_prepare_queries_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
     lib.rb_enable_prefix_dbs.argtypes = [C.c_void_p, C.c_uint32]
+    lib.rb_enable_synonyms.argtypes = [C.c_void_p]
+    lib.rb_synonyms.restype = C.c_uint32
+    lib.rb_synonyms.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32]
     lib.rb_has_prefix.restype = C.c_uint32
     lib.rb_has_prefix.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
     lib.rb_read_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -200,7 +203,9 @@ class SynthIndex:
         return out
 
     def get_synonyms(self, words):
-        return []
+        buf = C.create_string_buffer(1024)
+        n = self.lib.rb_synonyms(self.h, " ".join(words).encode(), buf, 1024)
+        return [line.split(" ") for line in buf.value.decode().split("\n") if line] if n else []
 
     def budget(self, word):
         n = len(word)

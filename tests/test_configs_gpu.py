@@ -277,6 +277,42 @@ def test_word_prefix_databases_on_the_coherent_corpus(ctx):
         lib.rb_destroy(h)
 
 
+def test_synonyms_on_the_coherent_corpus(ctx):
+    """VERDICT r3 missing #1 / weak #1 (ii): synonyms on the corpus index (rb_enable_synonyms: a sixteenth of the vocabulary
+    has a one-word synonym, half of those a two-word phrase that occurs in some title; an eighth of the adjacent pairs a
+    synonym for their n-gram key) together with the word-prefix databases and quoted phrases — every eighth query is a word
+    or a pair that has synonyms — on three chunks of documents, against oracle/ranking_oracle.py.  CPU tier only for now
+    (see test_phrases_on_the_coherent_corpus)."""
+    import ctypes as C
+    import os
+    from oracle import parity
+    from oracle import synth_index as SI
+    if not os.environ.get("MSI_RUNNER_SO") and not os.environ.get("MSI_TEST_UNTRIED_ON_DEVICE"):
+        pytest.skip("not yet run on an MI355X (MSI_TEST_UNTRIED_ON_DEVICE=1 runs it: 2 M documents)")
+    n_docs, n_words, n_queries, limit = 2_000_000, 400_000, 128, 20
+    if os.environ.get("MSI_RUNNER_SO"):
+        n_docs, n_words, n_queries = 150_000, 60_000, 128
+    lib = SI.runner_lib()
+    lib.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    h = lib.rb_create_corpus(n_docs, n_words, 46)
+    try:
+        assert lib.rb_enable_prefix_dbs(h, 50) == 0 and lib.rb_enable_synonyms(h) == 0
+        assert lib.rb_attach(h, ctx.handle, 8, 1024, 1024) == 0
+        assert lib.rb_prepare_queries_ex(h, n_queries, 3, 717, 7) == 0
+        chk = parity.KeywordLegChecker(lib, h, n_docs)
+        queries = [chk.index.query(i) for i in range(n_queries)]
+        with_syn = [q for i, q in enumerate(queries) if i % 8 == 6 and q and not q.startswith('"')]
+        has = [q for q in with_syn if chk.index.get_synonyms((q.split()[0],)) or chk.index.get_synonyms(tuple(q.split()[:2]))]
+        assert len(has) >= 8, (with_syn, has)
+        assert any(len(s_) == 2 for q in has for s_ in chk.index.get_synonyms((q.split()[0],))), "no two-word synonym among them"
+        got = chk.run_product(0, n_queries, limit)
+        v = chk.verdict(0, n_queries, limit, product=got)
+        assert v["mismatches"] == 0, v
+        assert v["checked_queries"] == n_queries
+    finally:
+        lib.rb_destroy(h)
+
+
 def test_rerank_inside_candidate_universes_on_the_corpus(ctx):
     """Config 5's second half as written: the keyword ranking (all default criteria, detailed scores) of a query restricted
     to a candidate set of 1 000 documents — what reranks a filtered vector search's top-1000 — through the runner's

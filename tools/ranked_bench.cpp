@@ -262,9 +262,19 @@ struct Corpus {
   const uint32_t *posting(uint32_t w, uint64_t *n) const { *n = post_off[w + 1] - post_off[w]; return post.data() + post_off[w]; }
 };
 
+// the key sets of one word's (or prefix's) derived databases: the fids and bucketed positions it has entries for
+struct WordDerived {
+  std::vector<uint16_t> fids, positions;
+};
+
 struct Index {
   uint64_t n_docs;
+  // (per index, not per address: a static map keyed by the Index pointer handed a new corpus the key sets of a destroyed
+  // one that had lived at the same address — the engine and the oracle read the same stale sets, so parity never noticed)
+  std::mutex derived_mu;
+  std::map<std::string, std::shared_ptr<WordDerived>> word_derived, prefix_derived;
   std::unique_ptr<Corpus> corpus;                 // set: the databases below are derived from the corpus's documents
+  bool synonyms = false;                          // the index has synonyms (rb_enable_synonyms; corpus_synonyms below)
   uint32_t prefix_threshold = 0;                  // > 0: the word-prefix databases exist (rb_enable_prefix_dbs): keys = the
                                                   // prefixes of 1..4 bytes that at least this many dictionary words share
   std::vector<std::string> words;                 // sorted
@@ -331,17 +341,11 @@ std::string str(const uint8_t *w, uint32_t n) { return std::string((const char *
 // Every derived database of ONE word in one pass over its documents (a frequent word's posting is most of the corpus: its
 // fid, position and key-set reads must not scan it once per key): word_fid_docids f/<fid>/<w>, word_position_docids
 // q/<pos>/<w>, and the key sets (fids, bucketed positions) the engine's prefix_iter reads would return.
-struct WordDerived {
-  std::vector<uint16_t> fids, positions;
-};
 const WordDerived *corpus_word(Index *ix, const std::string &s) {
-  static std::mutex mu;
-  static std::map<const Index *, std::map<std::string, std::shared_ptr<WordDerived>>> all;
   {
-    std::lock_guard<std::mutex> lk(mu);
-    auto &m = all[ix];
-    auto it = m.find(s);
-    if (it != m.end()) return it->second.get();
+    std::lock_guard<std::mutex> lk(ix->derived_mu);
+    auto it = ix->word_derived.find(s);
+    if (it != ix->word_derived.end()) return it->second.get();
   }
   const Corpus &c = *ix->corpus;
   auto wd = std::make_shared<WordDerived>();
@@ -369,8 +373,8 @@ const WordDerived *corpus_word(Index *ix, const std::string &s) {
     wd->positions.push_back((uint16_t)kv.first);
     ix->blob("q/" + std::to_string(kv.first) + "/" + s, [&] { return kv.second; });
   }
-  std::lock_guard<std::mutex> lk(mu);
-  return all[ix].emplace(s, wd).first->second.get();
+  std::lock_guard<std::mutex> lk(ix->derived_mu);
+  return ix->word_derived.emplace(s, wd).first->second.get();
 }
 
 int32_t cb_word(void *u, const uint8_t *w, uint32_t n, int32_t, const uint8_t **bytes, size_t *out) {
@@ -533,13 +537,10 @@ bool corpus_prefix_range(Index *ix, const std::string &p, uint32_t *lo, uint32_t
   return (uint32_t)(b - a) >= ix->prefix_threshold;
 }
 const WordDerived *corpus_prefix(Index *ix, const std::string &p) {
-  static std::mutex mu;
-  static std::map<const Index *, std::map<std::string, std::shared_ptr<WordDerived>>> all;
   {
-    std::lock_guard<std::mutex> lk(mu);
-    auto &m = all[ix];
-    auto it = m.find(p);
-    if (it != m.end()) return it->second.get();
+    std::lock_guard<std::mutex> lk(ix->derived_mu);
+    auto it = ix->prefix_derived.find(p);
+    if (it != ix->prefix_derived.end()) return it->second.get();
   }
   auto wd = std::make_shared<WordDerived>();
   uint32_t lo = 0, hi = 0;
@@ -566,8 +567,8 @@ const WordDerived *corpus_prefix(Index *ix, const std::string &p) {
       ix->blob("Q/" + std::to_string(kv.first) + "/" + p, [&] { return kv.second; });
     }
   }
-  std::lock_guard<std::mutex> lk(mu);
-  return all[ix].emplace(p, wd).first->second.get();
+  std::lock_guard<std::mutex> lk(ix->derived_mu);
+  return ix->prefix_derived.emplace(p, wd).first->second.get();
 }
 int32_t push_blob(Index *ix, const std::string &key, msi_posting_sink push, void *sink) {
   const Bytes *b = ix->blob(key, [&] { return std::vector<uint32_t>(); });
@@ -650,6 +651,46 @@ int32_t cb_prefix_pair(void *u, uint32_t prox, const uint8_t *l, uint32_t ln, co
     cb_pair(u, prox, l, ln, (const uint8_t *)b.data(), (uint32_t)b.size(), &bytes, &n);
     if (!n) continue;
     if (push(sink, bytes, n) < 0) return -1;
+    ++pushed;
+  }
+  return pushed;
+}
+
+// ---- synonyms of the corpus (rb_enable_synonyms) ----------------------------------------------------------------------
+// index.synonyms.get(words): a sixteenth of the vocabulary has a one-word synonym (another word of the vocabulary), half of
+// those also a two-word one (the first two title words of some document: a phrase that occurs); an eighth of the adjacent
+// word pairs (the keys an n-gram of the query is looked up with, parse_query.rs:277-285) have a one-word synonym.
+std::vector<std::vector<std::string>> corpus_synonyms(Index *ix, const std::vector<std::string> &key) {
+  std::vector<std::vector<std::string>> out;
+  if (!ix->corpus || !ix->synonyms || key.empty() || key.size() > 2) return out;
+  const Corpus &c = *ix->corpus;
+  const uint32_t W = (uint32_t)c.words.size();
+  int64_t id[2] = {-1, -1};
+  for (size_t i = 0; i < key.size(); ++i)
+    if ((id[i] = c.id_of(key[i])) < 0) return out;
+  if (key.size() == 1) {
+    const uint64_t h = mix((uint64_t)id[0] * 0x9E3779B97F4A7C15ULL + 0x51);
+    if (h % 16 != 0) return out;
+    out.push_back({c.words[(h >> 8) % W]});
+    if ((h >> 4) % 2 == 0) {
+      const uint64_t d = (h >> 20) % c.n_docs;
+      out.push_back({c.words[c.tok[c.doc_off[d]] & Corpus::ID], c.words[c.tok[c.doc_off[d] + 1] & Corpus::ID]});
+    }
+  } else {
+    const uint64_t h = mix((uint64_t)id[0] * 0xD1B54A32D192ED03ULL + (uint64_t)id[1] + 0x77);
+    if (h % 8 != 0) return out;
+    out.push_back({c.words[(h >> 8) % W]});
+  }
+  return out;
+}
+int32_t cb_synonyms(void *u, const msi_query_token *words, uint32_t n_words, msi_synonym_sink push, void *sink) {
+  std::vector<std::string> key;
+  for (uint32_t i = 0; i < n_words; ++i) key.push_back(str(words[i].word, words[i].len));
+  int32_t pushed = 0;
+  for (auto &syn : corpus_synonyms((Index *)u, key)) {
+    std::vector<msi_query_token> toks;
+    for (auto &w : syn) toks.push_back(msi_query_token{(const uint8_t *)w.data(), (uint32_t)w.size(), 0u});
+    if (push(sink, toks.data(), (uint32_t)toks.size()) < 0) return -1;
     ++pushed;
   }
   return pushed;
@@ -1208,6 +1249,7 @@ int32_t rb_attach(void *h, msi_ctx *ctx, uint32_t n_threads, uint32_t n_slots, u
   r->vt.word_positions = cb_positions;
   r->vt.field_id_word_count_docids = cb_count;
   if (r->ix.prefix_threshold) set_prefix_callbacks(r->vt);   // (rb_enable_prefix_dbs came first)
+  if (r->ix.synonyms) r->vt.synonyms = cb_synonyms;
   const int32_t crit[7] = {MSI_CRIT_WORDS, MSI_CRIT_TYPO, MSI_CRIT_PROXIMITY, MSI_CRIT_ATTRIBUTE_RANK, MSI_CRIT_SORT,
                            MSI_CRIT_WORD_POSITION, MSI_CRIT_EXACTNESS};
   memcpy(r->criteria, crit, sizeof(crit));
@@ -1238,7 +1280,8 @@ int32_t rb_attach(void *h, msi_ctx *ctx, uint32_t n_threads, uint32_t n_slots, u
 // generated the postings it needs (index generation is not what is measured)
 // flags (corpus only): 1 = every eighth query starts with a quoted phrase of two consecutive words of the document (exact
 // words: a phrase takes no typo), a third word — misspelled / cut to a prefix as usual — may follow it; 2 = three queries in
-// 64 end in a one- to three-letter prefix (the word-prefix databases' keys)
+// 64 end in a one- to three-letter prefix (the word-prefix databases' keys); 4 = every eighth query is a word (or an adjacent
+// pair) that has synonyms in the index (rb_enable_synonyms)
 int32_t rb_prepare_queries_ex(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed, uint32_t flags);
 int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed) {
   return rb_prepare_queries_ex(h, n_queries, n_terms, seed, 0);
@@ -1274,6 +1317,20 @@ int32_t rb_prepare_queries_ex(void *h, uint32_t n_queries, uint32_t n_terms, uin
       if (shape == 1) { q.push_back(c.words[most]); continue; }         // "the"
       const uint64_t d = g() % c.n_docs;
       const uint32_t len = (uint32_t)(c.doc_off[d + 1] - c.doc_off[d]);
+      if ((flags & 4u) && qi % 8 == 6) {
+        // a word of the document that has synonyms (a sixteenth of the vocabulary: nearly every document holds one), alone or
+        // with the word after it; or an adjacent pair whose n-gram key has one
+        bool found = false;
+        for (uint32_t i = 0; i + 1 < len && !found; ++i) {
+          const std::string &w1 = c.words[c.tok[c.doc_off[d] + i] & Corpus::ID], &w2 = c.words[c.tok[c.doc_off[d] + i + 1] & Corpus::ID];
+          if (!corpus_synonyms(&r->ix, {w1}).empty() || ((qi / 8) % 2 && !corpus_synonyms(&r->ix, {w1, w2}).empty())) {
+            q.push_back(w1);
+            if (g() % 2 == 0 || !corpus_synonyms(&r->ix, {w1, w2}).empty()) q.push_back(w2);
+            found = true;
+          }
+        }
+        if (found) continue;
+      }
       if ((flags & 2u) && (shape == 3 || shape == 4 || shape == 35)) {
         // workloads/search/movies.json's one-letter query, and two- / three-letter ones: a lone prefix term, answered out
         // of the word-prefix databases when the index has them (rb_enable_prefix_dbs); after a word at shape 35
@@ -1291,7 +1348,8 @@ int32_t rb_prepare_queries_ex(void *h, uint32_t n_queries, uint32_t n_terms, uin
       const uint32_t at = f0 + (uint32_t)(g() % (fl - want + 1));
       for (uint32_t i = 0; i < want; ++i) q.push_back(c.words[c.tok[c.doc_off[d] + at + i] & Corpus::ID]);
       if (shape == 2) continue;
-      if ((flags & 1u) && qi % 8 == 5 && q.size() >= 2) {   // "w1 w2" [w3]
+      // "w1 w2" [w3] — when the two words are adjacent in the document (no sentence end between them: +8 positions)
+      if ((flags & 1u) && qi % 8 == 5 && q.size() >= 2 && !(c.tok[c.doc_off[d] + at + 1] & Corpus::HARD)) {
         const std::string ph = "\"" + q[0] + " " + q[1] + "\"";
         q.erase(q.begin(), q.begin() + 2);
         if (!q.empty() && g() % 2 == 0 && q[0].size() >= 5) q[0] = edit(q[0]);
@@ -1424,6 +1482,34 @@ int32_t rb_enable_prefix_dbs(void *h, uint32_t threshold) {
   r->ix.prefix_threshold = threshold;
   set_prefix_callbacks(r->vt);
   return MSI_OK;
+}
+// The corpus index gets synonyms (corpus_synonyms).  rb_synonyms: what index.synonyms.get(the words of `key`, joined by one
+// space) returns, one synonym per line, its words joined by spaces; returns the bytes written (0: none).
+int32_t rb_enable_synonyms(void *h) {
+  Runner *r = (Runner *)h;
+  if (!r->ix.corpus) return MSI_E_INVALID;
+  r->ix.synonyms = true;
+  r->vt.synonyms = cb_synonyms;
+  return MSI_OK;
+}
+uint32_t rb_synonyms(void *h, const char *key, char *out, uint32_t cap) {
+  Runner *r = (Runner *)h;
+  std::vector<std::string> words;
+  std::string cur;
+  for (const char *p = key;; ++p) {
+    if (*p == ' ' || !*p) {
+      if (!cur.empty()) words.push_back(cur);
+      cur.clear();
+      if (!*p) break;
+    } else cur.push_back(*p);
+  }
+  std::string text;
+  for (auto &syn : corpus_synonyms(&r->ix, words)) {
+    for (size_t i = 0; i < syn.size(); ++i) text += (i ? " " : "") + syn[i];
+    text += "\n";
+  }
+  if (out && cap) { strncpy(out, text.c_str(), cap); out[cap - 1] = 0; }
+  return (uint32_t)text.size();
 }
 uint32_t rb_has_prefix(void *h, const uint8_t *a, uint32_t an) {
   uint32_t lo, hi;
