@@ -3498,6 +3498,8 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       const bool no_gate = getenv("MSI_SEARCH_TASKS_NO_GATE") != nullptr;   // tests: provoke the out-of-slots re-run
       bool coop = c.dev.vm && max_tasks > 1;
       bool late_ok = may_compact && Dev::late_mode() > 0;
+      static const bool late_wait = getenv("MSI_SEARCH_LATE_WAIT") && getenv("MSI_SEARCH_LATE_WAIT")[0] == '1';
+      bool late_waiting = false;
 #else
       const bool coop = false;
 #endif
@@ -3542,7 +3544,15 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             // The rules below rank this bucket in ITS compact space (Ctx::late_enter) when the search could not compact
             // its whole universe, the bucket is at most an eighth of the index and this is the only task alive — the
             // sub-tree's own tasks are joined before the search returns to the caller's pool.
-            if (late_ok && !c.dev.compact() && (!coop || tasks.live == 1) && c.dev.late_pays(b.count)) {
+            // MSI_SEARCH_LATE_WAIT=1 (not measured yet: off): with other tasks alive, ONE task at a time may wait for
+            // them to finish and then move its bucket's sub-tree — the others neither wait nor enter meanwhile, so the wait ends
+            const bool can_late = late_ok && !c.dev.compact() && c.dev.late_pays(b.count);
+            if (can_late && coop && late_wait && !late_waiting && tasks.live > 1) {
+              late_waiting = true;
+              while (tasks.live > 1) tasks.park();
+              late_waiting = false;
+            }
+            if (can_late && !c.dev.compact() && (!coop || tasks.live == 1)) {
               struct Leave {
                 Ctx &c;
                 bool done = false;
