@@ -152,7 +152,8 @@ class KeywordLegChecker:
         for i in range(n):
             q = self.index.query(first + i)
             uni = None if universes is None else np.asarray(universes[0][i][:int(universes[1][i])])
-            want_ids, want_sc, want_cand = self.oracle.search(q, limit=limit, detailed=True, universe=uni)
+            want_ids, want_sc, want_cand = self.oracle.search(q, limit=limit, detailed=True, universe=uni,
+                                                              negatives=self.index.negatives(first + i))
             got = SI.product_details(ids[i], cnt[i], det[i], ndet[i], limit, det.shape[2])
             want = [(d, [SI.oracle_detail(s) for s in sc]) for d, sc in zip(want_ids, want_sc)]
             hits += len(want)

@@ -41,6 +41,8 @@ def runner_lib():
     lib.rb_prepare_queries_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
     lib.rb_enable_prefix_dbs.argtypes = [C.c_void_p, C.c_uint32]
     lib.rb_enable_synonyms.argtypes = [C.c_void_p]
+    lib.rb_query_negatives.restype = C.c_uint32
+    lib.rb_query_negatives.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32]
     lib.rb_synonyms.restype = C.c_uint32
     lib.rb_synonyms.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32]
     lib.rb_has_prefix.restype = C.c_uint32
@@ -218,6 +220,18 @@ class SynthIndex:
         self.lib.rb_query(self.h, i, buf, 512)
         return buf.value.decode()
 
+    def negatives(self, i):
+        """The negative terms of query i (rb_prepare_queries_ex, flag 8): [word | (phrase words...)]."""
+        if not hasattr(self.lib, "rb_query_negatives"):
+            return []
+        buf = C.create_string_buffer(512)
+        self.lib.rb_query_negatives(self.h, i, buf, 512)
+        out = []
+        for line in buf.value.decode().split("\n"):
+            if line:
+                out.append(tuple(line.strip('"').split(" ")) if line.startswith('"') else line)
+        return out
+
 
 class KeywordOracle:
     """oracle/ranking_oracle.py over a SynthIndex: search(query) -> (docids, score details per hit, n candidates)."""
@@ -233,12 +247,12 @@ class KeywordOracle:
         w = self.index.words
         return [w[i] for i in one], [w[i] for i in two]
 
-    def search(self, query, limit=20, detailed=True, tms="last", universe=None):
+    def search(self, query, limit=20, detailed=True, tms="last", universe=None, negatives=()):
         from oracle import ranking_oracle as RO
         with RO.use_docset(self.index.DocSet):
             uni = None if universe is None else self.index.DocSet.from_sorted(np.unique(np.asarray(universe, dtype=np.uint32)))
             ids, scores, cand = RO.search(RO.Ctx(self.index, self.lookup), query, tms=tms, criteria=self.index.criteria,
-                                          length=limit, detailed=detailed, universe=uni)
+                                          length=limit, detailed=detailed, universe=uni, negatives=negatives)
         return ids, scores, len(cand)
 
 

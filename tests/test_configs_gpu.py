@@ -313,6 +313,45 @@ def test_synonyms_on_the_coherent_corpus(ctx):
         lib.rb_destroy(h)
 
 
+def test_negative_terms_on_the_coherent_corpus(ctx):
+    """`-word` and `-"a phrase"` (search/mod.rs:431-440: their documents leave the universe before anything else) at corpus
+    scale: every eighth query excludes a word or an adjacent pair of some other document, next to phrases, prefix databases
+    and synonyms — the universe a search compacts (or the bucket it later moves into) is what is left.  CPU tier only for now
+    (see test_phrases_on_the_coherent_corpus)."""
+    import ctypes as C
+    import os
+    from oracle import parity
+    from oracle import synth_index as SI
+    if not os.environ.get("MSI_RUNNER_SO") and not os.environ.get("MSI_TEST_UNTRIED_ON_DEVICE"):
+        pytest.skip("not yet run on an MI355X (MSI_TEST_UNTRIED_ON_DEVICE=1 runs it: 2 M documents)")
+    n_docs, n_words, n_queries, limit = 2_000_000, 400_000, 128, 20
+    if os.environ.get("MSI_RUNNER_SO"):
+        n_docs, n_words, n_queries = 150_000, 60_000, 128
+    lib = SI.runner_lib()
+    lib.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    h = lib.rb_create_corpus(n_docs, n_words, 47)
+    try:
+        assert lib.rb_enable_prefix_dbs(h, 50) == 0 and lib.rb_enable_synonyms(h) == 0
+        assert lib.rb_attach(h, ctx.handle, 8, 1024, 1024) == 0
+        assert lib.rb_prepare_queries_ex(h, n_queries, 3, 818, 15) == 0
+        chk = parity.KeywordLegChecker(lib, h, n_docs)
+        negs = [chk.index.negatives(i) for i in range(n_queries)]
+        assert sum(1 for x in negs if x) >= n_queries // 9
+        assert any(isinstance(x[0], tuple) for x in negs if x) and any(isinstance(x[0], str) for x in negs if x)
+        got = chk.run_product(0, n_queries, limit)
+        v = chk.verdict(0, n_queries, limit, product=got)
+        assert v["mismatches"] == 0, v
+        # a negative term that bites: at least one query's candidates shrink against the same query without it
+        shrunk = 0
+        for i in range(n_queries):
+            if negs[i]:
+                plain = chk.oracle.search(chk.index.query(i), limit=limit)[2]
+                shrunk += int(got[5][i]) < plain
+        assert shrunk >= 1
+    finally:
+        lib.rb_destroy(h)
+
+
 def test_rerank_inside_candidate_universes_on_the_corpus(ctx):
     """Config 5's second half as written: the keyword ranking (all default criteria, detailed scores) of a query restricted
     to a candidate set of 1 000 documents — what reranks a filtered vector search's top-1000 — through the runner's

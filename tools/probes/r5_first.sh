@@ -5,7 +5,7 @@
 set -x
 export GPU_MAX_HW_QUEUES=16
 mkdir -p gpurun_out
-MSI_TEST_UNTRIED_ON_DEVICE=1 timeout 900 python -m pytest tests/test_configs_gpu.py -m gpu -q -x -k "phrases or word_prefix or synonyms" 2>&1 | grep -E "passed|failed|error" | tail -3
+MSI_TEST_UNTRIED_ON_DEVICE=1 timeout 900 python -m pytest tests/test_configs_gpu.py -m gpu -q -x -k "phrases or word_prefix or synonyms or negative_terms" 2>&1 | grep -E "passed|failed|error" | tail -3
 for W in 0 1; do
   echo "== MSI_SEARCH_LATE_WAIT=$W"
   MSI_SEARCH_LATE_WAIT=$W timeout 500 python tools/probes/r4_kw_classes.py 2>&1 | grep -v "amdgpu.ids\|first pass" | tail -9

@@ -1093,29 +1093,44 @@ struct Runner {
                  const Bytes *universe = nullptr) {
     // an element of `q` is a word, or a quoted phrase `"w1 w2 ..."` (rb_prepare_queries_ex): one located term of several
     // words; positions count words (parse_query.rs:60-120), only a trailing plain word is a prefix
+    // `-word` / `-"w1 w2"` (rb_prepare_queries_ex, flag 8): a negative term — it follows the positive ones, takes no position
+    // and is no part of the query text the oracle parses (rb_query / rb_query_negatives)
     std::vector<msi_query_token> toks;
     std::vector<std::pair<uint32_t, uint32_t>> span;   // [first token, n tokens) of every element
-    for (const std::string &e : q) {
+    size_t n_pos = 0;
+    for (const std::string &e0 : q) {
+      const bool neg = !e0.empty() && e0.front() == '-';
+      if (!neg) ++n_pos;
+      const char *e = e0.data() + (neg ? 1 : 0);
+      const size_t en = e0.size() - (neg ? 1 : 0);
       const uint32_t first = (uint32_t)toks.size();
-      if (e.size() >= 2 && e.front() == '"' && e.back() == '"') {
+      if (en >= 2 && e[0] == '"' && e[en - 1] == '"') {
         size_t at = 1;
-        while (at < e.size() - 1) {
-          size_t sp = e.find(' ', at);
-          if (sp == std::string::npos || sp > e.size() - 1) sp = e.size() - 1;
-          if (sp > at) toks.push_back(msi_query_token{(const uint8_t *)e.data() + at, (uint32_t)(sp - at), 0u});
+        while (at < en - 1) {
+          const void *spp = memchr(e + at, ' ', en - 1 - at);
+          const size_t sp = spp ? (size_t)((const char *)spp - e) : en - 1;
+          if (sp > at) toks.push_back(msi_query_token{(const uint8_t *)e + at, (uint32_t)(sp - at), 0u});
           at = sp + 1;
         }
       } else {
-        toks.push_back(msi_query_token{(const uint8_t *)e.data(), (uint32_t)e.size(), 0u});
+        toks.push_back(msi_query_token{(const uint8_t *)e, (uint32_t)en, 0u});
       }
       span.push_back({first, (uint32_t)toks.size() - first});
     }
     std::vector<msi_located_term> terms(q.size());
-    for (size_t i = 0; i < q.size(); ++i) {
-      const bool phrase = q[i].size() >= 2 && q[i].front() == '"';
-      if (!phrase && i + 1 == q.size()) toks[span[i].first].is_prefix = 1u;
-      terms[i] = msi_located_term{&toks[span[i].first], span[i].second, phrase ? MSI_TERM_PHRASE : 0u, span[i].first,
-                                  span[i].first + span[i].second - 1};
+    uint32_t position = 0;
+    for (size_t i = 0, seen = 0; i < q.size(); ++i) {
+      const bool neg = !q[i].empty() && q[i].front() == '-';
+      const bool phrase = q[i].size() >= (neg ? 3u : 2u) && q[i][neg ? 1 : 0] == '"';
+      if (neg) {   // (the generator puts them last)
+        terms[i] = msi_located_term{&toks[span[i].first], span[i].second, (phrase ? MSI_TERM_PHRASE : 0u) | MSI_TERM_NEGATIVE, 0, 0};
+        continue;
+      }
+      if (!phrase && ++seen == n_pos) toks[span[i].first].is_prefix = 1u;
+      else if (phrase) ++seen;
+      terms[i] = msi_located_term{&toks[span[i].first], span[i].second, phrase ? MSI_TERM_PHRASE : 0u, position,
+                                  position + span[i].second - 1};
+      position += span[i].second;
     }
     msi_search_params p = prm;
     p.length = limit;
@@ -1281,7 +1296,7 @@ int32_t rb_attach(void *h, msi_ctx *ctx, uint32_t n_threads, uint32_t n_slots, u
 // flags (corpus only): 1 = every eighth query starts with a quoted phrase of two consecutive words of the document (exact
 // words: a phrase takes no typo), a third word — misspelled / cut to a prefix as usual — may follow it; 2 = three queries in
 // 64 end in a one- to three-letter prefix (the word-prefix databases' keys); 4 = every eighth query is a word (or an adjacent
-// pair) that has synonyms in the index (rb_enable_synonyms)
+// pair) that has synonyms in the index (rb_enable_synonyms); 8 = every eighth query excludes a word or a phrase (`-word`)
 int32_t rb_prepare_queries_ex(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed, uint32_t flags);
 int32_t rb_prepare_queries(void *h, uint32_t n_queries, uint32_t n_terms, uint64_t seed) {
   return rb_prepare_queries_ex(h, n_queries, n_terms, seed, 0);
@@ -1364,6 +1379,17 @@ int32_t rb_prepare_queries_ex(void *h, uint32_t n_queries, uint32_t n_terms, uin
       }
       if (g() % 3 == 0 && q.back().size() > 4) q.back().resize(4 + g() % (q.back().size() - 4));
     }
+    if (flags & 8u)   // every eighth query also excludes a word or a phrase of some other document (`-word`, `-"w1 w2"`)
+      for (uint32_t qi = 7; qi < n_queries; qi += 8) {
+        auto &q = r->queries[qi];
+        if (q.empty()) continue;
+        const uint64_t d = g() % c.n_docs;
+        const uint32_t len = (uint32_t)(c.doc_off[d + 1] - c.doc_off[d]);
+        const uint32_t at = (uint32_t)(g() % (len - 1));
+        const std::string &w1 = c.words[c.tok[c.doc_off[d] + at] & Corpus::ID], &w2 = c.words[c.tok[c.doc_off[d] + at + 1] & Corpus::ID];
+        if ((qi / 8) % 2) q.push_back("-\"" + w1 + " " + w2 + "\"");
+        else q.push_back("-" + w1);
+      }
     return MSI_OK;
   }
   for (auto &q : r->queries) for (uint32_t i = 0; i < n_terms; ++i) q.push_back(r->frequent[g() % 300]);
@@ -1455,7 +1481,17 @@ uint64_t rb_words(void *h, uint8_t *concat, uint64_t cap, uint32_t *offsets) {
 uint32_t rb_query(void *h, uint32_t i, char *out, uint32_t cap) {
   Runner *r = (Runner *)h;
   std::string s;
-  for (auto &w : r->queries[i % r->queries.size()]) s += (s.empty() ? "" : " ") + w;
+  for (auto &w : r->queries[i % r->queries.size()])
+    if (w.empty() || w.front() != '-') s += (s.empty() ? "" : " ") + w;
+  if (out && cap) { strncpy(out, s.c_str(), cap); out[cap - 1] = 0; }
+  return (uint32_t)s.size();
+}
+// the negative terms of query i, one per line: `word` or `"w1 w2"`
+uint32_t rb_query_negatives(void *h, uint32_t i, char *out, uint32_t cap) {
+  Runner *r = (Runner *)h;
+  std::string s;
+  for (auto &w : r->queries[i % r->queries.size()])
+    if (!w.empty() && w.front() == '-') s += w.substr(1) + "\n";
   if (out && cap) { strncpy(out, s.c_str(), cap); out[cap - 1] = 0; }
   return (uint32_t)s.size();
 }
