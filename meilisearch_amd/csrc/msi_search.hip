@@ -246,6 +246,9 @@ struct PathSlots {
 
 struct Dev {
   SetPool pool;                        // the caller's pool: sets over docids
+  // compact spaces the search has left (Ctx::late_leave): a set handle that outlives its space still finds its SetPool
+  // (declared before every member that holds sets: destroyed after them)
+  Vec<std::unique_ptr<SetPool>> retired_cpools;
   SetPool *cur = &pool;                // the pool every operation works on: `pool`, or — after compact_begin — `cpool`
   std::unique_ptr<SetPool> cpool;      // the companion pool: sets over the ranks of the documents of U0 (universe compaction)
   Set u0_full;                         // U0 in the caller's pool (read by the compact lists' decodes)
@@ -422,7 +425,6 @@ struct Dev {
     if (!n_u0 || n_u0 > msi_bits_compact_capacity(pool.p)) return false;
     return compact_mode() >= 2 || (n > 65536 && n_u0 * 8 <= n);
   }
-  Vec<std::unique_ptr<SetPool>> retired_cpools;   // (a set handle that outlives its space still finds its SetPool)
   bool counted_compact = false;
   void compact_begin(const Set &u0, uint64_t n_u0, bool late = false) {
     if (!list.empty()) run();
