@@ -50,6 +50,8 @@ def runner_lib():
     lib.rb_read_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                   C.c_uint64, C.c_void_p, C.c_uint32]
     lib.rb_destroy.argtypes = [C.c_void_p]
+    lib.rb_doc_tokens.restype = C.c_uint32
+    lib.rb_doc_tokens.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.rb_n_words.restype = C.c_uint32
     lib.rb_n_words.argtypes = [C.c_void_p]
     lib.rb_words.restype = C.c_uint64

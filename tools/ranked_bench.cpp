@@ -1495,6 +1495,19 @@ uint32_t rb_query_negatives(void *h, uint32_t i, char *out, uint32_t cap) {
   if (out && cap) { strncpy(out, s.c_str(), cap); out[cap - 1] = 0; }
   return (uint32_t)s.size();
 }
+// The tokens of document d of the corpus, in order: word id (dictionary order), field id (1 title, 2 overview) and position
+// inside the field (+1 per word, +8 over a hard separator).  What every database is derived from: tests/test_corpus_runner_cpu.py
+// re-derives them from these by brute force.  Returns the number of tokens (at most `cap` written).
+uint32_t rb_doc_tokens(void *h, uint64_t d, uint32_t *word_ids, uint32_t *fids, uint32_t *positions, uint32_t cap) {
+  Runner *r = (Runner *)h;
+  if (!r->ix.corpus || d >= r->ix.corpus->n_docs) return 0;
+  uint32_t n = 0;
+  r->ix.corpus->tokens(d, [&](uint32_t w, uint32_t fid, uint32_t pos) {
+    if (n < cap) { word_ids[n] = w; fids[n] = fid; positions[n] = pos; }
+    ++n;
+  });
+  return n;
+}
 // db: 0 word_docids(a) | 1 word_pair_proximity_docids(x = proximity, a, b) | 2 word_fid_docids(a, x = fid)
 //   | 3 word_position_docids(a, x = position) | 4 field_id_word_count_docids(x = fid, y = count): the stored bytes
 int32_t rb_read(void *h, uint32_t db, const uint8_t *a, uint32_t an, const uint8_t *b, uint32_t bn, uint32_t x, uint32_t y,
