@@ -71,6 +71,13 @@ int32_t msi_ctx_device(msi_ctx *ctx);
  * bracketed by HIP events on the context stream; msi_vs_scan_time /
  * msi_dict_match_time synchronise and return the accumulated kernel time. */
 int32_t msi_ctx_set_profiling(msi_ctx *ctx, int32_t enable);
+/* Hardware queues the HIP runtime maps this process's streams onto (GPU_MAX_HW_QUEUES; the runtime's default is 4).
+ * The keyword searches' command-list rounds run on 16 streams and rounds that share a queue serialise, so libmsi
+ * sets GPU_MAX_HW_QUEUES=16 when it is LOADED (a library constructor: before the runtime's first call reads it)
+ * unless the host process already chose a value or set MSI_KEEP_HW_QUEUES=1.  Below 16 the keyword leg measured less
+ * than half its throughput; an integrator checks this once at start-up (nothing is written to stderr unasked:
+ * MSI_VERBOSE=1 prints the warning). */
+int32_t msi_runtime_hw_queues(void);
 
 /* ------------------------------------------------- S1: vector k-NN (cosine) */
 /*
@@ -871,7 +878,8 @@ int32_t msi_search_cpu_profile(uint64_t out[8]);
  * universe — the documents that match the query at all — every later set is kept over the ranks of the documents inside
  * it, |universe| bits instead of n_docs: DESIGN.md §4.7.2), documents of those universes summed]. */
 int32_t msi_search_compaction_stats(uint64_t out[3]);
-/* [sub-trees of the bucket sort that continued in the compact space of their own bucket, documents of those buckets summed] */
+/* [sub-trees of the bucket sort that continued in the compact space of their own bucket, documents of those buckets summed]
+ * — counted apart from msi_search_compaction_stats, whose [1] and [2] are about whole universes only. */
 int32_t msi_search_late_compaction_stats(uint64_t out[2]);
 
 /* ---------------------------------------------------- scoring arithmetic (host) */

@@ -16,7 +16,6 @@
 #include <signal.h>
 #include <unistd.h>
 
-#include <atomic>
 
 #include "msi_common.h"
 #include "msi_vm.h"
@@ -67,7 +66,23 @@ struct AbortHook {
 } g_abort_hook;
 }  // namespace
 
+// The command-list rounds of the keyword searches run on 16 streams; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES
+// hardware queues (default 4) and rounds that share a queue serialise: 4 -> 16 queues took the keyword leg from 2.8 k to
+// 6.1 k searches/s.  The runtime reads the variable when it STARTS (its first API call), so the library sets
+// it when it is LOADED — before any HIP call of a process whose only HIP user it is (the Rust server), and before torch's
+// lazy initialisation in the test / bench processes.  A value the host already chose is left alone; MSI_KEEP_HW_QUEUES=1
+// keeps the library from touching the environment at all.  (not an environment note for the integrator.)
+__attribute__((constructor(101))) static void msi_preset_hw_queues() {
+  if (!getenv("MSI_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
+
 extern "C" {
+
+int32_t msi_runtime_hw_queues(void) {
+  const char *hq = getenv("GPU_MAX_HW_QUEUES");
+  const int v = hq ? atoi(hq) : 4;   // the runtime's default
+  return v > 0 ? v : 4;
+}
 
 int32_t msi_abi_version(void) { return MSI_ABI_VERSION; }
 const char *msi_last_error(void) { return g_err; }
@@ -101,18 +116,13 @@ int32_t msi_ctx_create(int32_t device, msi_ctx **out) {
     return MSI_E_NO_DEVICE;
   }
   DeviceGuard g(device);
+  // (hardware queues: msi_preset_hw_queues() below ran when the library was loaded; msi_runtime_hw_queues() reports what is
+  // in effect.  MSI_VERBOSE=1 says so on stderr once — a library does not write to its host's stderr unasked: ADVICE r4)
   {
-    // The command-list rounds of the keyword searches run on 16 streams; the runtime maps streams onto GPU_MAX_HW_QUEUES
-    // hardware queues (default 4) and rounds that share a queue serialise: 4 -> 16 queues took the keyword leg from 2.8 k
-    // to 6.1 k searches/s.  The variable is read when the HIP runtime starts — before this call — so
-    // the library can only say so (once per process; MSI_QUIET=1 silences it).  INTEGRATION.md: set it in the server's
-    // environment.
     static std::atomic<bool> said{false};
-    const char *hq = getenv("GPU_MAX_HW_QUEUES");
-    if ((!hq || atoi(hq) < 16) && !getenv("MSI_QUIET") && !said.exchange(true))
-      fprintf(stderr, "libmsi: GPU_MAX_HW_QUEUES is %s: keyword searches in flight share %s hardware queues and their command-list "
-              "rounds serialise (measured: less than half the throughput of GPU_MAX_HW_QUEUES=16); set it in the environment before "
-              "the process starts\n", hq ? hq : "unset", hq ? hq : "4");
+    if (getenv("MSI_VERBOSE") && msi_runtime_hw_queues() < 16 && !said.exchange(true))
+      fprintf(stderr, "libmsi: GPU_MAX_HW_QUEUES is %d: keyword searches in flight share that many hardware queues and their "
+              "command-list rounds serialise (measured: less than half the throughput of 16)\n", msi_runtime_hw_queues());
   }
   msi_ctx *c = new msi_ctx();
   c->device = device;

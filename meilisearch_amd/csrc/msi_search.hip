@@ -439,11 +439,10 @@ struct Dev {
     list.geom_docs = n_u0;
     list.full_pool = pool.p;
     list.u0_slot = u0->slot;
-    if (late) {
+    if (late) {   // (counted apart: msi_search_compaction_stats is about whole universes — ADVICE r4)
       g_late_compactions.fetch_add(1, std::memory_order_relaxed);
       g_late_compact_docs.fetch_add(n_u0, std::memory_order_relaxed);
-    }
-    if (!counted_compact) {
+    } else if (!counted_compact) {
       counted_compact = true;
       g_compact_searches.fetch_add(1, std::memory_order_relaxed);
       g_compact_docs.fetch_add(n_u0, std::memory_order_relaxed);

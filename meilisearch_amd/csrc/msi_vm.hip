@@ -82,6 +82,12 @@ constexpr uint32_t C_MAP = 0, C_SO = C_MAP + (VT / 64) * 1024, C_DATA = C_SO + (
 constexpr uint32_t CACHE_MAX_ENTRIES = 32;                       // an entry per lane of the bookkeeping registers' low half
 static_assert(A_FULL_END <= ARENA_BYTES && (!MSI_VM_SET_CACHE || C_DATA + 8192 <= ARENA_BYTES), "the LDS arena holds every use of it");
 constexpr size_t RES_COUNTS = 2;                               // u64 index of counts[0] in the result block
+constexpr u64 MSI_VM_RES_FAILED = ~0ull;                       // res[1] of a list whose fused workgroups gave up waiting
+// ticks of the 100 MHz wall clock a workgroup of a fused list waits for the list's wide phase before it gives up: 2 s — four
+// orders of magnitude above a wide phase under load (tens of microseconds), below the host's own 5 s watchdog
+#ifndef MSI_VM_SPIN_LIMIT_TICKS
+#define MSI_VM_SPIN_LIMIT_TICKS 200000000ull
+#endif
 constexpr size_t RES_IDS = RES_COUNTS + MSI_VM_MAX_COUNTS;     // u64 index where the u32 ids start
 
 struct alignas(16) RoundSub {
@@ -103,7 +109,11 @@ struct alignas(16) RoundSub {
   uint32_t full_words, u0_slot, wide_chunks, wide_mask;
   // words per workgroup in the list's command phases: CHW (a Roaring container span) for lists over docids; compact lists
   // take narrower chunks — more workgroups per list, and a chunk of a set small enough that a dozen sets fit in LDS
-  uint32_t chw, cache_on, _pad[2];
+  uint32_t chw, cache_on;
+  // written by the DEVICE (the round's own copy of this struct): a workgroup of a fused list gave up waiting for the list's
+  // wide phase (MSI_VM_SPIN_LIMIT_TICKS).  The list still hands in its tickets, and its last workgroup publishes the failure
+  // instead of a result count, so that a stall surfaces as MSI_E_INTERNAL on the host and not as a hung device.
+  uint32_t failed, _pad;
 };
 static_assert(sizeof(RoundSub) % 16 == 0, "RoundSub array stays 16-byte aligned");
 
@@ -200,9 +210,24 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
   if (phase >= r.n_phases || chunk >= my_chunks) return;
   if (fused && launch_phase == 0 && phase == 1) {
     // the wide workgroups of this list were dispatched before this one (lower block indices): wait for their tickets
+    // (bounded: a wait that outlasts MSI_VM_SPIN_LIMIT_TICKS marks the list failed — ADVICE r4)
     const uint32_t *done0 = arena + r.state_off;
-    if (threadIdx.x == 0)
-      while (__hip_atomic_load(done0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rp->wide_chunks) MSI_SLEEP();
+    if (threadIdx.x == 0) {
+      const u64 t_wait = wall_clock64();
+      uint32_t spins = 0;
+      while (__hip_atomic_load(done0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rp->wide_chunks) {
+        MSI_SLEEP();
+        if ((++spins & 1023u) == 0 && wall_clock64() - t_wait > MSI_VM_SPIN_LIMIT_TICKS) {
+          __hip_atomic_store(const_cast<uint32_t *>(&rp->failed), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      u64 *const wprof = reinterpret_cast<u64 *>(((u64)arena[3] << 32) | arena[2]);
+      if (wprof) {   // MSI_VM_PROFILE: how long the workgroups of fused lists wait for their wide phase
+        atomicAdd(&wprof[24], wall_clock64() - t_wait);
+        atomicAdd(&wprof[25], 1ull);
+      }
+    }
     __syncthreads();
     // what they wrote (write-through stores and device-scope atomics) is in memory; drop what this XCD's caches may
     // still hold of those lines
@@ -1446,7 +1471,8 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
   MSI_ORDER_ATOMICS();
   __syncthreads();
   if (tid == 0) {
-    __hip_atomic_store(&res[1], (u64)emitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const bool gave_up = __hip_atomic_load(&rp->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    __hip_atomic_store(&res[1], gave_up ? MSI_VM_RES_FAILED : (u64)emitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     MSI_ORDER_ATOMICS();
     __hip_atomic_store(&res[0], r.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -1520,6 +1546,7 @@ struct VmCombiner {
   std::atomic<uint32_t> load{0};           // lists submitted and not finished yet
   u64 *d_prof = nullptr;                   // MSI_VM_PROFILE: 16 tick counters in device memory
   std::atomic<int32_t> *fused_wgs = nullptr;   // msi_vm::fused_wgs: the device's waiting workgroups in flight
+  int32_t fused_budget = 256;                  // msi_vm::fused_budget
   void run();
 };
 
@@ -1529,16 +1556,22 @@ struct msi_vm {
   msi_ctx *ctx = nullptr;
   std::vector<std::unique_ptr<VmCombiner>> comb;
   // Workgroups of fused lists that WAIT for their list's wide phase, over all combiners' rounds in flight.  A waiting
-  // workgroup holds a CU slot and does nothing.  Measured (10 M documents, 160 callers, profiles/r4_fuse_limit.txt):
-  // lists of <= 24 chunks fused (universes <= 2 % of the index: up to 3 840 waiting workgroups in flight) run as fast as
-  // lists that are never fused on a mixed workload and through bursts of alike searches; with lists of 48-153 chunks
-  // fused, a burst of searches whose universes are 4-12 % of the index took the leg from 9 700 to 23-170 searches/s
-  // (no list failed: the device crawls while most resident workgroups wait).  Dispatch order alone should make that
-  // impossible (a waiting workgroup follows the workgroups it waits for), so the cause is not understood; the bounds
-  // are the envelope that was measured safe: MSI_VM_FUSE_MAX_CHUNKS (24) per list and this many workgroups in flight.
+  // workgroup holds a CU slot and does nothing.  Inside ONE kernel that is harmless — a list's waiters follow its own wide
+  // workgroups in dispatch order — but rounds run as separate kernels on 16 streams, each XCD dispatches its share of a
+  // kernel's workgroups on its own, and nothing orders kernel A's waiters against kernel B's wide workgroups: once the
+  // waiters in flight exceed what the device keeps RESIDENT (CUs x workgroups per CU of vm_kernel: 256 x 4 = 1 024 on an
+  // MI355X) they can take every slot of an XCD while the wide workgroups they wait for — their own list's, assigned to
+  // that XCD — still queue behind them.  That is what round 4 measured as a collapse (9 700 -> 23-170 searches/s under
+  // a burst of alike searches with 48-153-chunk lists fused and a budget of 4 096 waiters = 4x the residency; DESIGN
+  // 4.7, profiles/r5_fuse_collapse.txt): forward progress then hangs on the hardware scheduler's queue time-slicing.
+  // The bound is therefore DERIVED FROM THE RESIDENCY: waiters in flight <= resident workgroups / 4 (MSI_VM_FUSED_WGS_PCT,
+  // per cent of the residency, default 25), so that three quarters of every XCD's slots always go to workgroups that do
+  // work; a list that does not fit the budget runs its two phases as two launches.  A waiter that still outlasts
+  // MSI_VM_SPIN_LIMIT_TICKS fails its list instead of hanging the device (vm_kernel).
   std::atomic<int32_t> fused_wgs{0};
+  int32_t resident_wgs = 1024;             // CUs x occupancy of vm_kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor)
+  int32_t fused_budget = 256;
 };
-constexpr int32_t MSI_VM_FUSED_WGS_BUDGET = 4096;
 
 namespace {
 
@@ -1610,7 +1643,7 @@ void VmCombiner::run() {
   const size_t batch_cap = getenv("MSI_VM_BATCH_CAP") ? std::max(1, atoi(getenv("MSI_VM_BATCH_CAP"))) : 32;
   const long poll_sleep_ns = (getenv("MSI_VM_POLL_SLEEP_US") ? std::max(0, atoi(getenv("MSI_VM_POLL_SLEEP_US"))) : 20) * 1000l;
   if (poll_sleep_ns > 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);   // (this thread only: the default 50 us slack would triple the sleep)
-  if (getenv("MSI_VM_PROFILE") && hipMalloc((void **)&d_prof, 24 * sizeof(u64)) == hipSuccess) (void)hipMemset(d_prof, 0, 24 * sizeof(u64));
+  if (getenv("MSI_VM_PROFILE") && hipMalloc((void **)&d_prof, 32 * sizeof(u64)) == hipSuccess) (void)hipMemset(d_prof, 0, 32 * sizeof(u64));
   uint64_t cpu_seen = msi_cpu_prof_on() ? msi_thread_cpu_ns() : 0;
   auto finish = [&](VmSub *s, uint32_t st) {
     s->t_done = now_ns();
@@ -1759,7 +1792,7 @@ void VmCombiner::run() {
           // for workgroups that are already resident: the bound keeps spinning workgroups few, it is not what makes this safe)
           batch[i]->fused_wgs = 0;
           if (l.pre_merged && r.n_phases >= 2 && r.n_chunks <= fuse_max_chunks && r.n_words <= (u64)fuse_max_chunks * 256 && !fuse_off) {
-            if (fused_wgs->fetch_add((int32_t)r.n_chunks, std::memory_order_relaxed) + (int32_t)r.n_chunks <= MSI_VM_FUSED_WGS_BUDGET) {
+            if (fused_wgs->fetch_add((int32_t)r.n_chunks, std::memory_order_relaxed) + (int32_t)r.n_chunks <= fused_budget) {
               batch[i]->fused_wgs = r.n_chunks;
               r.wide_mask |= 0x80000000u;
             } else {
@@ -1900,10 +1933,18 @@ static msi_vm *vm_of(msi_ctx *ctx) {
     vm->ctx = ctx;
     const char *knob = getenv("MSI_VM_COMBINERS");
     const int n = std::max(1, std::min(8, knob ? atoi(knob) : 1));   // one is best: more combiners mean more, smaller rounds
+    {   // the budget of waiting workgroups follows from what the device keeps resident (struct msi_vm)
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vm_kernel, VT, 0) != hipSuccess || occ <= 0) occ = 4;
+      vm->resident_wgs = std::max(1, ctx->n_cu) * occ;
+      const char *pct = getenv("MSI_VM_FUSED_WGS_PCT");   // experiments: 400 = round 4's 4 096 on an MI355X
+      vm->fused_budget = (int32_t)((int64_t)vm->resident_wgs * std::max(0, pct ? atoi(pct) : 25) / 100);
+    }
     for (int c = 0; c < n; ++c) {
       std::unique_ptr<VmCombiner> cb(new VmCombiner());
       cb->ctx = ctx;
       cb->fused_wgs = &vm->fused_wgs;
+      cb->fused_budget = vm->fused_budget;
       for (int i = 0; i < VmCombiner::NS; ++i)
         if (hipStreamCreateWithFlags(&cb->streams[i], hipStreamNonBlocking) != hipSuccess) {
           msi_set_error("msi_vm: hipStreamCreate failed");
@@ -1933,7 +1974,7 @@ void msi_vm_destroy(msi_vm *vmx) {
     for (auto st : vm->streams)
       if (st) (void)hipStreamSynchronize(st);
     if (vm->d_prof) {
-      u64 t[24] = {0};
+      u64 t[32] = {0};
       (void)hipMemcpy(t, vm->d_prof, sizeof t, hipMemcpyDeviceToHost);
       static const char *names[16] = {"", "fill", "op", "op_count", "clear", "claim", "and_many", "paths", "sub_many", "count",
                                       "decode", "firstk", "minkey", "takekey", "rank", "all"};
@@ -1946,6 +1987,8 @@ void msi_vm_destroy(msi_vm *vmx) {
       fprintf(stderr, "; wide workgroups %llu, %.1f us each (staging %.1f us); the others %.1f us each\n", (unsigned long long)t[22],
               t[22] ? t[19] / 100.0 / t[22] : 0.0, t[22] ? t[23] / 100.0 / t[22] : 0.0,
               t[0] > t[22] ? (t[15] - t[19]) / 100.0 / (t[0] - t[22]) : 0.0);
+      if (t[25]) fprintf(stderr, "msi_vm profile: %llu workgroups of fused lists waited %.1f us each for their wide phase\n",
+                         (unsigned long long)t[25], t[24] / 100.0 / t[25]);
       (void)hipFree(vm->d_prof);
     }
     for (auto &A : vm->ar) {
@@ -2276,6 +2319,9 @@ int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
     ret = s->error != MSI_OK ? s->error : MSI_E_INTERNAL;
     if (ret == MSI_E_INTERNAL) msi_set_error("msi_vm: a round finished without publishing its results");
     else msi_set_error("%s", s->errmsg[0] ? s->errmsg : "msi_vm: the round of this list failed");
+  } else if (__atomic_load_n(const_cast<uint64_t *>(&blk[1]), __ATOMIC_RELAXED) == MSI_VM_RES_FAILED) {
+    ret = MSI_E_INTERNAL;
+    msi_set_error("msi_vm: the workgroups of a fused list gave up waiting for the list's wide phase (a stalled device?)");
   } else {
     vm->ns_waiters.add(0, (uint64_t)(s->t_taken - s->t_submit));
     vm->ns_waiters.add(1, (uint64_t)(s->t_launch - s->t_taken));

@@ -684,6 +684,8 @@ __device__ uint32_t block_select_smallest(const KeySrc &src, uint32_t c, uint32_
         loc[e] = b < nb ? hist[b] : 0u;
         mine += loc[e];
       }
+      static_assert(SEL_THREADS * 8 == 2048 && SEL_SORTCAP * 2 >= 2 * SEL_THREADS,
+                    "the bin scan below is laid out for 256 threads x 8 bins and two rows of 256 words aliased onto sbuf");
       uint32_t *scan = reinterpret_cast<uint32_t *>(sbuf);   // (sbuf is not in use yet: 2 x 256 words of it)
       scan[tid] = mine;
       __syncthreads();
@@ -1569,9 +1571,25 @@ void swap_scratch(msi_vs *vs) {
   std::swap(vs->resc_keys, vs->scr2.resc_keys);
 }
 
+int32_t search_device_pipelined_impl(msi_vs *vs, const float *d_queries, uint32_t n_queries, uint32_t k, const u64 *d_fbits,
+                                     uint64_t nbits, uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_counts,
+                                     uint32_t *d_inexact);
 int32_t search_device_pipelined(msi_vs *vs, const float *d_queries, uint32_t n_queries, uint32_t k, const u64 *d_fbits,
                                 uint64_t nbits, uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_counts,
                                 uint32_t *d_inexact) {
+  const int32_t st = search_device_pipelined_impl(vs, d_queries, n_queries, k, d_fbits, nbits, d_out_docids, d_out_dist,
+                                                  d_out_counts, d_inexact);
+  if (st != MSI_OK) {
+    // an error path left work on the second stream that the context's stream never joined: settle both before the caller
+    // sees the failure (its buffers may be freed next) — ADVICE r4
+    if (vs->aux_stream) (void)hipStreamSynchronize(vs->aux_stream);
+    (void)hipStreamSynchronize(vs->ctx->stream);
+  }
+  return st;
+}
+int32_t search_device_pipelined_impl(msi_vs *vs, const float *d_queries, uint32_t n_queries, uint32_t k, const u64 *d_fbits,
+                                     uint64_t nbits, uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_counts,
+                                     uint32_t *d_inexact) {
   msi_ctx *ctx = vs->ctx;
   hipStream_t A = ctx->stream;
   if (!vs->aux_stream) {

@@ -135,6 +135,7 @@ extern "C" {
     pub fn msi_ctx_create(device: i32, out: *mut *mut msi_ctx) -> i32;
     pub fn msi_ctx_destroy(ctx: *mut msi_ctx);
     pub fn msi_ctx_synchronize(ctx: *mut msi_ctx) -> i32;
+    pub fn msi_runtime_hw_queues() -> i32;
 
     pub fn msi_vs_create(ctx: *mut msi_ctx, dim: u32, out: *mut *mut msi_vs) -> i32;
     pub fn msi_vs_create_typed(ctx: *mut msi_ctx, dim: u32, storage: i32, out: *mut *mut msi_vs) -> i32;

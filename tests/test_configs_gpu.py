@@ -203,14 +203,12 @@ def test_phrases_on_the_coherent_corpus(ctx):
     """quoted phrases on an index of several chunks, through universe compaction and the bucket-space
     sub-trees — every eighth query of the corpus workload opens with a phrase of two consecutive words of a document
     (rb_prepare_queries_ex, flags 1), a misspelled / prefix word may follow it; against oracle/ranking_oracle.py on the same
-    stored bytes.  First written in round 4 after the round's GPU minutes were spent: it runs on the CPU tier's emulated
-    kernels (150 000 documents, three chunks) and is skipped on the device until it has been run there once."""
+    stored bytes.  On the CPU tier's emulated kernels: 150 000 documents, three chunks; on the MI355X (first run there in round 5,
+    green): 2 M documents."""
     import ctypes as C
     import os
     from oracle import parity
     from oracle import synth_index as SI
-    if not os.environ.get("MSI_RUNNER_SO") and not os.environ.get("MSI_TEST_UNTRIED_ON_DEVICE"):
-        pytest.skip("not yet run on an MI355X (MSI_TEST_UNTRIED_ON_DEVICE=1 runs it: 2 M documents)")
     n_docs, n_words, n_queries, limit = 2_000_000, 400_000, 96, 20
     if os.environ.get("MSI_RUNNER_SO"):
         n_docs, n_words, n_queries = 150_000, 60_000, 96
@@ -241,13 +239,11 @@ def test_word_prefix_databases_on_the_coherent_corpus(ctx):
     them — workloads/search/movies.json's one-letter query, two- and three-letter prefixes, a word followed by a short
     prefix — next to the usual misspelled / prefix-cut queries and quoted phrases, on three chunks of documents.  Against
     oracle/ranking_oracle.py reading the values the index hands to the engine's sink.  Like the phrase test: written after
-    the round's GPU minutes were spent, so it runs on the CPU tier's emulated kernels and is skipped on the device."""
+    the round's GPU minutes were spent; first run on the MI355X in round 5 (green)."""
     import ctypes as C
     import os
     from oracle import parity
     from oracle import synth_index as SI
-    if not os.environ.get("MSI_RUNNER_SO") and not os.environ.get("MSI_TEST_UNTRIED_ON_DEVICE"):
-        pytest.skip("not yet run on an MI355X (MSI_TEST_UNTRIED_ON_DEVICE=1 runs it: 2 M documents)")
     n_docs, n_words, n_queries, limit = 2_000_000, 400_000, 128, 20
     if os.environ.get("MSI_RUNNER_SO"):
         n_docs, n_words, n_queries = 150_000, 60_000, 128
@@ -287,8 +283,6 @@ def test_synonyms_on_the_coherent_corpus(ctx):
     import os
     from oracle import parity
     from oracle import synth_index as SI
-    if not os.environ.get("MSI_RUNNER_SO") and not os.environ.get("MSI_TEST_UNTRIED_ON_DEVICE"):
-        pytest.skip("not yet run on an MI355X (MSI_TEST_UNTRIED_ON_DEVICE=1 runs it: 2 M documents)")
     n_docs, n_words, n_queries, limit = 2_000_000, 400_000, 128, 20
     if os.environ.get("MSI_RUNNER_SO"):
         n_docs, n_words, n_queries = 150_000, 60_000, 128
@@ -322,8 +316,6 @@ def test_negative_terms_on_the_coherent_corpus(ctx):
     import os
     from oracle import parity
     from oracle import synth_index as SI
-    if not os.environ.get("MSI_RUNNER_SO") and not os.environ.get("MSI_TEST_UNTRIED_ON_DEVICE"):
-        pytest.skip("not yet run on an MI355X (MSI_TEST_UNTRIED_ON_DEVICE=1 runs it: 2 M documents)")
     n_docs, n_words, n_queries, limit = 2_000_000, 400_000, 128, 20
     if os.environ.get("MSI_RUNNER_SO"):
         n_docs, n_words, n_queries = 150_000, 60_000, 128

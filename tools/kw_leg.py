@@ -1,0 +1,111 @@
+"""The keyword leg of bench.py's C4 step on its own — the same coherent corpus, the same query generator, the same
+caller threads (tools/bin/libmsi_rankedbench.so) — as a process of its own: what bench.py's `keyword_roofline` runs plain
+(MSI_SEARCH_CPU_PROFILE=1) and under `rocprofv3 --pmc ...` (counters over every vm_kernel dispatch), so that the counters
+describe the HEADLINE's workload and not the round-3 hashed index.
+
+    python tools/kw_leg.py [--docs 10000000] [--words 2000000] [--callers 160] [--queries 3072] [--passes 2] [--corpus coherent|hashed]
+
+Prints one JSON line: queries/s of the measured passes, lists / rounds / microseconds per round (msi_bits_vm_stats), host CPU per
+query by where it is spent (msi_search_cpu_profile), posting-cache hit rate, compaction counters, searches run in total
+(so that summed counters can be divided per query)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import meilisearch_amd as ma  # noqa: E402  (loads libmsi.so: GPU_MAX_HW_QUEUES is set by its constructor)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--words", type=int, default=2_000_000)
+    ap.add_argument("--callers", type=int, default=160)
+    ap.add_argument("--queries", type=int, default=3072, help="distinct queries (seeded as bench.py's)")
+    ap.add_argument("--terms", type=int, default=3)
+    ap.add_argument("--passes", type=int, default=2, help="measured passes over the queries (after one untimed pass)")
+    ap.add_argument("--corpus", choices=["coherent", "hashed"], default="coherent")
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--slots", type=int, default=512)
+    ap.add_argument("--cache-mb", type=int, default=8192)
+    ap.add_argument("--flags", type=int, default=0, help="rb_prepare_queries_ex flags (1 phrases, 2 short prefixes, 4 synonyms, 8 negatives)")
+    a = ap.parse_args()
+    L = C.CDLL(os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so"))
+    L.rb_create.restype = C.c_void_p
+    L.rb_create.argtypes = [C.c_uint64, C.c_uint32]
+    L.rb_create_corpus.restype = C.c_void_p
+    L.rb_create_corpus.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
+    L.rb_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.rb_prepare_queries_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+    L.rb_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rb_enable_prefix_dbs.argtypes = [C.c_void_p, C.c_uint32]
+    L.rb_enable_synonyms.argtypes = [C.c_void_p]
+    L.rb_pool.restype = C.c_void_p
+    L.rb_pool.argtypes = [C.c_void_p, C.c_uint32]
+    L.rb_dict.restype = C.c_void_p
+    L.rb_dict.argtypes = [C.c_void_p]
+    L.rb_destroy.argtypes = [C.c_void_p]
+    lib = ma._lib.lib()
+    ctx = ma.Context(0)
+    h = L.rb_create_corpus(a.docs, a.words, 42) if a.corpus == "coherent" else L.rb_create(a.docs, a.words)
+    if a.flags & 2:
+        assert L.rb_enable_prefix_dbs(h, 50) == 0
+    if a.flags & 4:
+        assert L.rb_enable_synonyms(h) == 0
+    assert L.rb_attach(h, ctx.handle, a.callers, a.slots, a.cache_mb) == 0
+    L.rb_prepare_queries_ex(h, a.queries, a.terms, 4242, a.flags)
+    ids = np.zeros((a.queries, a.k), np.uint32)
+    cnt = np.zeros(a.queries, np.uint32)
+    sc = np.zeros((a.queries, a.k), np.float64)
+
+    def one_pass():
+        assert L.rb_run(h, 0, a.queries, a.k, ids.ctypes.data, cnt.ctypes.data, sc.ctypes.data) == 0
+    one_pass()                                   # untimed: the index derives what the queries read; pools create their companions
+    cp0, cp1 = (C.c_uint64 * 8)(), (C.c_uint64 * 8)()
+    vs0, vs1 = (C.c_uint64 * 6)(), (C.c_uint64 * 6)()
+    lib.msi_search_cpu_profile(cp0)
+    lib.msi_bits_vm_stats(C.c_void_p(L.rb_pool(h, 0)), vs0)
+    c0 = os.times()
+    t0 = time.perf_counter()
+    for _ in range(a.passes):
+        one_pass()
+    dt = time.perf_counter() - t0
+    c1 = os.times()
+    lib.msi_search_cpu_profile(cp1)
+    lib.msi_bits_vm_stats(C.c_void_p(L.rb_pool(h, 0)), vs1)
+    nq = a.passes * a.queries
+    pc = (C.c_uint64 * 4)()
+    lib.msi_dict_posting_cache_stats(C.c_void_p(L.rb_dict(h)), pc)
+    cst, lst = (C.c_uint64 * 3)(), (C.c_uint64 * 2)()
+    lib.msi_search_compaction_stats(cst)
+    lib.msi_search_late_compaction_stats(lst)
+    lists, rounds = vs1[1] - vs0[1], vs1[0] - vs0[0]
+    out = {"corpus": a.corpus, "docs": a.docs, "dictionary_words": a.words, "callers": a.callers, "distinct_queries": a.queries,
+           "measured_searches": nq, "searches_in_this_process": nq + a.queries, "queries_per_s": round(nq / dt, 1),
+           "host_cpus_used": round((c1[0] + c1[1] - c0[0] - c0[1]) / dt, 2),
+           "vm": {"lists_per_query": round(lists / nq, 2), "lists_per_launch": round(lists / max(1, rounds), 2),
+                  "us_queued_per_list": round((vs1[2] - vs0[2]) / 1e3 / max(1, lists), 1),
+                  "us_waiting_for_company_per_list": round((vs1[3] - vs0[3]) / 1e3 / max(1, lists), 1),
+                  "us_launch_to_wake_up_per_list": round((vs1[5] - vs0[5]) / 1e3 / max(1, lists), 1)},
+           "posting_cache": {"hits": int(pc[0]), "misses": int(pc[1]), "bytes_used": int(pc[2]),
+                             "hit_rate": round(pc[0] / max(1, pc[0] + pc[1]), 4)},
+           "compact_space": {"searches": int(cst[0]), "universe_compacted": int(cst[1]), "bucket_sub_trees_moved": int(lst[0])}}
+    if cp1[0] > cp0[0]:
+        n = float(cp1[0] - cp0[0])
+        d = [(cp1[i] - cp0[i]) / 1e3 / n for i in range(8)]
+        out["host_cpu_us_per_query"] = {"search_threads": round(d[1], 1), "list_submit_and_wait": round(d[2], 1),
+                                        "of_it_finalising_lists": round(d[3], 1), "typo_derivations": round(d[4], 1),
+                                        "index_callbacks": round(d[5], 1), "host_logic": round(d[1] - d[2] - d[4] - d[5], 1),
+                                        "combiner_thread": round(d[6], 1), "lists_per_query": round((cp1[7] - cp0[7]) / n, 2)}
+    print(json.dumps(out), flush=True)
+    L.rb_destroy(h)
+
+
+if __name__ == "__main__":
+    main()
