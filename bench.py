@@ -59,6 +59,21 @@ if ROOT not in sys.path:
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
+_PHASES = []
+
+
+def phase(name):
+    """Wall-clock marks of the run (the detail object's `phase_seconds`: where the default command's minutes go)."""
+    _PHASES.append((name, time.time()))
+
+
+def phase_seconds():
+    out = {}
+    for (name, t0), (_, t1) in zip(_PHASES, _PHASES[1:] + [("end", time.time())]):
+        out[name] = round(out.get(name, 0.0) + (t1 - t0), 1)
+    return out
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["c1", "c2", "c3", "c4", "c5"], default="c4")
@@ -193,9 +208,9 @@ def pmc_traffic(args, kernel_prefix, must_contain=()):
                       ("--storage", args.storage)):
         if val is not None:
             cmd += [flag, str(val)]
-    if args.no_typo:
+    if args.no_typo or args.config == "c4":      # (c4: the child is there for the scan kernel's counters only)
         cmd.append("--no-typo")
-    if args.no_rank:
+    if args.no_rank or args.config == "c4":
         cmd.append("--no-rank")
     env = dict(os.environ, MSI_BENCH_CHILD="1", TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -222,12 +237,22 @@ def pmc_traffic(args, kernel_prefix, must_contain=()):
                           "FETCH_SIZE[KB] x 1024 x 2 (gfx950 wide-load correction, MI355X_MICROARCH.md HBM section)")
 
 
-def scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kernel_name, must_contain=()):
+def sweep_kernel(stats, n_rows):
+    """The dominant kernel of a store's level-0 search and its algorithmic bytes per sweep: the int8 candidate sweep when the
+    store keeps the int8 copy of its rows (dpad + 8 bytes per row: the int8 row, its scale, its inverse norm), else the sweep
+    over the stored rows (dpad x 4 bytes per f32 row).  -> (display name, kernel-name prefix for the counters, bytes)"""
+    tiles = (n_rows + 15) // 16
+    if stats.get("i8_bytes_per_tile"):
+        return "vs_scan_i8_kernel (main pass over the int8 copy of the rows)", "vs_scan_i8_kernel", tiles * stats["i8_bytes_per_tile"]
+    return "vs_scan_kernel (main pass)", "vs_scan_kernel", tiles * stats["bytes_per_tile"]
+
+
+def scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kernel_name, must_contain=(), kernel_prefix="vs_scan_kernel"):
     scan_avg_ms = scan_ms / max(1, scan_n)
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
     traffic, src = None, "not measured (--no-pmc, child run, or N > 1)"
     if env.rank == 0 and env.world == 1 and not args.no_pmc and not env.child:
-        traffic, src = pmc_traffic(args, "vs_scan_kernel", must_contain)
+        traffic, src = pmc_traffic(args, kernel_prefix, must_contain)
     return {"kernel": kernel_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM reads, PMC)",
             "traffic_source": src, "algorithmic_bytes_per_launch": int(algo_bytes),
@@ -428,6 +453,7 @@ def run_c4(args, env):
         r0, r1 = row_range(n_total, rank, world)
         n = r1 - r0          # this rank's shard; docids stay global
 
+    phase("c4: rows + store upload")
     t_setup = time.time()
     rows_t = synth.device_rows(n, d, dev, seed=1234 + (rank if row_sharded else 0))
     ids_t = torch.arange(n, dtype=torch.int32, device=dev)
@@ -450,6 +476,7 @@ def run_c4(args, env):
     out_cnt = torch.zeros(Q, dtype=torch.int32, device=dev)
     inexact = torch.zeros(Q, dtype=torch.int32, device=dev)
 
+    phase("c4: dictionary")
     gdict = None
     n_words_q = 0
     words = concat = off = tq = None
@@ -512,6 +539,7 @@ def run_c4(args, env):
         n_docs_kw = n_total if row_sharded else n
         if args.kw_dict_words is None:
             args.kw_dict_words = 2_000_000 if args.kw_corpus == "coherent" else 200_000
+        phase("c4: keyword corpus")
         t_corpus = time.time()
         h = (kw_lib.rb_create_corpus(n_docs_kw, args.kw_dict_words, 42) if args.kw_corpus == "coherent"
              else kw_lib.rb_create(n_docs_kw, args.kw_dict_words))
@@ -532,7 +560,7 @@ def run_c4(args, env):
         # has in HBM.  The timed steps then meet every query for the first time; the cache hit rate they see is the natural
         # one of the workload (`legs.keyword_posting_cache.hit_rate_timed_steps`).
         kw_prime = 4 * Q
-        kw_stream_steps = args.warmup + args.steps + 8          # + the untimed legs after the timed region
+        kw_stream_steps = args.steps + 4                        # the timed steps + the keyword-only leg's three + the by-universe pass
         if args.kw_stream == "cycle" or env.child:
             kw_stream_steps = 0                                 # round 4's stream: the 4 x Q primer queries, cycled
         n_kw_queries = kw_prime + kw_stream_steps * Q
@@ -541,12 +569,14 @@ def run_c4(args, env):
               "scores": np.zeros((Q, k), np.float64), "m_ids": np.zeros((Q, k), np.uint32), "m_sem": np.zeros((Q, k), np.uint8),
               "m_cnt": np.zeros(Q, np.uint32), "m_hits": np.zeros(Q, np.uint32), "step": 0, "prime": kw_prime,
               "stream_steps": kw_stream_steps, "n_queries": n_kw_queries}
+        phase("c4: index derivation pass (untimed: the synthetic index derives its databases)")
         t_derive = time.perf_counter()
         for first in range(0, n_kw_queries, Q):
             assert kw_lib.rb_run(h, first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data) == 0
         kw["index_derivation_seconds"] = round(time.perf_counter() - t_derive, 1)
         kw["cold_cache_queries_per_s"] = None
         if not env.child:
+            phase("c4: primer on a cold posting cache")
             ma._lib.check(ma._lib.lib().msi_dict_reset_posting_cache(C.c_void_p(kw_lib.rb_dict(h))))
             t0c = time.perf_counter()
             for first in range(0, kw_prime, Q):
@@ -627,6 +657,9 @@ def run_c4(args, env):
         """First query of keyword step `step` (default: the next one): fresh queries behind the primer while the stream
         lasts, then (untimed extras only) around the primer again."""
         i = kw["step"] if step is None else step
+        if i < args.warmup or not kw["stream_steps"]:
+            return (i * Q) % kw["prime"]                          # warm-up steps (and the cycled stream): primer queries again
+        i -= args.warmup
         if i < kw["stream_steps"]:
             return kw["prime"] + i * Q
         return ((i - kw["stream_steps"]) * Q) % kw["prime"]
@@ -691,6 +724,7 @@ def run_c4(args, env):
             exchange()
         return res
 
+    phase("c4: warm-up + timed steps")
     for _ in range(args.warmup):
         step()
     ctx.set_profiling(True)
@@ -712,6 +746,7 @@ def run_c4(args, env):
     ctx.set_profiling(False)
     stats = store.stats()
     n_inexact = int(inexact.sum().item())
+    phase("c4: legs on their own")
     # the two legs on their own (untimed extras, 3 steps each): what bounds the step
     legs = {}
     if kw is not None and not env.child:
@@ -725,9 +760,31 @@ def run_c4(args, env):
         alone_n, alone_ms = store.scan_time()
         ctx.set_profiling(False)
         if alone_n:   # the same kernel without the keyword lists beside it (the timed step overlaps the two legs)
-            alone_bytes = ((n + 15) // 16) * stats["bytes_per_tile"]
+            alone_bytes = sweep_kernel(stats, n)[2]
             legs["scan_kernel_alone"] = {"avg_launch_ms": round(alone_ms / alone_n, 4), "launches": alone_n,
                                          "frac_of_8_TBps": round(alone_bytes / (alone_ms / alone_n * 1e-3) / 1e9 / 8000.0, 4)}
+        if stats.get("i8_bytes_per_tile"):
+            # continuity with rounds 1-4: the same batch through the f32 sweeps (the level the int8 sweep's unproven queries fall
+            # to; MSI_VS_FIRST_LEVEL=f32 is read per call), SURVEY 8(d)'s N x d x 4 bytes per sweep
+            os.environ["MSI_VS_FIRST_LEVEL"] = "f32"
+            try:
+                ctx.set_profiling(True)
+                store.scan_time()
+                t0 = time.perf_counter()
+                store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)
+                ctx.synchronize()
+                f32_dt = time.perf_counter() - t0
+                f_n, f_ms = store.scan_time()
+                ctx.set_profiling(False)
+            finally:
+                os.environ.pop("MSI_VS_FIRST_LEVEL")
+            f32_bytes = ((n + 15) // 16) * stats["bytes_per_tile"]
+            if f_n:
+                legs["f32_sweep_level"] = {"vector_only_queries_per_s": round(Q / f32_dt, 1), "avg_launch_ms": round(f_ms / f_n, 4),
+                                           "launches": f_n, "algorithmic_bytes_per_launch": int(f32_bytes),
+                                           "frac_of_8_TBps": round(f32_bytes / (f_ms / f_n * 1e-3) / 1e9 / 8000.0, 4),
+                                           "is": "vs_scan_kernel over the f32 rows (rounds 1-4's level 0; now what the int8 sweep's "
+                                                 "unproven queries fall to)"}
         import resource
         vs0 = (C.c_uint64 * 6)()
         ma._lib.lib().msi_bits_vm_stats(C.c_void_p(kw["lib"].rb_pool(kw["h"], 0)), vs0)
@@ -784,6 +841,7 @@ def run_c4(args, env):
                   "universe; one whose universe is larger moves the sub-tree of a bucket (<= 1/8 of the index) into the ranks "
                   "of that bucket once nothing else of its bucket sort is alive (msi_search.hip Ctx::late_enter)"}
     # ---- per-QUERY latency (the metric is "queries/sec + p50 latency"; ms_per_step is the latency of a 768-query step) ----
+    phase("c4: per-query latency")
     latency = None
     if kw is not None and not env.child and rank == 0:
         def p50(xs):
@@ -898,8 +956,9 @@ def run_c4(args, env):
         if want_extra:
             guarded_extra(None)
         return None
+    phase("c4: roofline (PMC child)")
     total_queries = Q * (1 if row_sharded else world) * args.steps
-    algo_bytes = ((n + 15) // 16) * stats["bytes_per_tile"]  # one sweep of the tiled store
+    kname, kprefix, algo_bytes = sweep_kernel(stats, n)      # one sweep of the level-0 kernel
     out = {
         "metric": "hybrid-search hot path queries/sec (10M-doc index, 768-d cosine top-20 + 2-typo term lookup)",
         "value": round(total_queries / elapsed, 2),
@@ -910,7 +969,8 @@ def run_c4(args, env):
         "higher_is_better": True,
         "scaling": "strong" if row_sharded else "weak",
         "vs_baseline": None,
-        "dtype": "f32" if storage == "f32" else "bf16 rows, f32 arithmetic",
+        "dtype": ("f32 (every distance: the reference's f32 arithmetic on the f32 rows; candidates: int8 MFMA sweep of a quantised copy)"
+                  if stats.get("i8_bytes_per_tile") else "f32") if storage == "f32" else "bf16 rows, f32 arithmetic",
         "data": "synthetic (rows N(0,1) seed 1234; dictionary seed 99; query words seed 7; BASELINE.md C4/C3)",
         "config": {
             "workload": f"C4 on one GPU per rank: {n} docs x {d}-d {storage} exact cosine top-{k} "
@@ -921,8 +981,10 @@ def run_c4(args, env):
                             else " + all-rules keyword search over the round-3 hashed index (300 frequent words) + hybrid merge")),
             "queries_per_step_per_gpu": Q, "words_per_step_per_gpu": n_words_q,
             "queries_per_hbm_sweep": store.max_batch,
-            "scan_math": os.environ.get("MSI_VS_SCAN_MATH", "bf16x2") + " candidate scan (f32 rows in HBM split hi/lo in registers, bf16 query fragments, f32 accumulate)"
-                         " + exact f32 reference rescoring of K' candidates with an exactness proof",
+            "scan_math": ("level 0: int8 candidate sweep (v_mfma_i32_16x16x64_i8) over an int8 copy of the normalised rows; what it cannot prove: "
+                          if stats.get("i8_bytes_per_tile") else "") +
+                         os.environ.get("MSI_VS_SCAN_MATH", "bf16x2") + " candidate scan of the f32 rows (split hi/lo in registers, bf16 query fragments, f32 accumulate)"
+                         "; every answer = exact f32 reference rescoring of K' candidates with an exactness proof",
             "sharding": ("rows sharded (%d per GPU of %d), same query batch on every GPU, ONE packed all_gather of "
                          "per-shard top-k (RCCL) + device k-way merge" % (n, n_total)) if row_sharded else
                         "queries sharded, index replicated per GPU, ONE packed all-gather of per-rank top-k per step; exchange path: " + exchange_path,
@@ -955,13 +1017,13 @@ def run_c4(args, env):
             "inexact_queries_last_step": n_inexact,
             "keyword_corpus": args.kw_corpus if kw is not None else None,
             "keyword_stream": None if kw is None else (
-                f"fresh: {kw['stream_steps']} x {Q} distinct queries behind a {kw['prime']}-query primer, none met twice in the timed steps"
+                f"fresh: every timed step runs {Q} queries the engine meets for the first time ({kw['stream_steps']} x {Q} distinct ones "
+                f"behind a {kw['prime']}-query primer)"
                 if kw["stream_steps"] else f"cycle: {kw['prime']} distinct queries, cycled"),
             "keyword_index_derivation_seconds": kw.get("index_derivation_seconds") if kw is not None else None,
             "setup_seconds": round(setup_s, 1),
         },
-        "roofline": scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, "vs_scan_kernel (main pass)",
-                                  must_contain=("false",)),
+        "roofline": scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kname, must_contain=("false",), kernel_prefix=kprefix),
         "legs": legs,
         "latency": latency,
         "rows_sharded": None,
@@ -972,6 +1034,7 @@ def run_c4(args, env):
     if want_extra:
         out["rows_sharded"] = guarded_extra(out)
     if env.check:
+        phase("c4: cpu baselines")
         t_vec, cores, sample, vec_by_threads = cpu_vector_baseline(cpu_rows, n, d, k)
         t_word, typo_by_threads, typo_cores = 0.0, None, None
         if gdict is not None:
@@ -996,6 +1059,7 @@ def run_c4(args, env):
             "typo_words_per_s": round(1.0 / t_word, 1) if t_word else None, "typo_words_per_s_by_threads": typo_by_threads,
             "typo_threads": typo_cores}
         # ---- untimed parity check of this run's own results (the store of the timed steps, its query batch) ----
+        phase("c4: parity, vector + typo")
         from oracle import parity
         nqc = min(args.parity_queries, Q)
         got = store.search(q_t[:nqc].cpu().numpy(), k)     # host entry point: exhaustive reruns included
@@ -1025,6 +1089,7 @@ def run_c4(args, env):
             # step that was just timed, through oracle/ranking_oracle.py (the restatement the reference's snapshot searches
             # pin) reading the synthetic index's stored posting bytes — docids in order, every hit's score details and the
             # candidate counts (oracle/parity.py: KeywordLegChecker; tests/test_configs_gpu.py::test_c4_keyword_leg)
+            phase("c4: parity, keyword vs oracle")
             keyword_run()                               # (the latency legs above ran other queries since the timed steps)
             first = kw_first(kw["step"] - 1)
             nk = min(args.parity_kw_queries, Q)
@@ -1038,6 +1103,7 @@ def run_c4(args, env):
             par["mismatches"] += 0 if same_kw else 1
             # second field: the command-list back end against the direct back end (one launch per set operation) on ALL of
             # the step's queries
+            phase("c4: parity, lists vs direct back end")
             kw["step"] -= 1
             keyword_run()
             a_ids, a_n, a_sc = kw["ids"].copy(), kw["n"].copy(), kw["scores"].copy()
@@ -1079,6 +1145,7 @@ def also_configs(args, env):
         a.rows = a.dim = a.k = a.queries = a.storage = None
         a.parity_queries = 16
         t0 = time.time()
+        phase(f"also: {cfg}")
         try:
             line = fn(a, env)
             keep = {k_: line[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "p50_latency_ms", "dtype", "config", "roofline",
@@ -1095,6 +1162,7 @@ def also_configs(args, env):
         a = copy.copy(args)
         a.steps = steps
         t0 = time.time()
+        phase(f"also: clustered {tag}")
         try:
             line = run_clustered(a, env, n, d, Q, tag)
             line["seconds"] = round(time.time() - t0, 1)
@@ -1136,33 +1204,24 @@ def run_c2(args, env):
         step()
     ctx.set_profiling(True)
     store.scan_time()
-    pc_t0 = None
-    if kw is not None:
-        pc_t0 = (C.c_uint64 * 4)()
-        ma._lib.lib().msi_dict_posting_cache_stats(C.c_void_p(kw["lib"].rb_dict(kw["h"])), pc_t0)
     elapsed, lat = env.timed(step, args.steps, 0)
-    pc_timed = None
-    if kw is not None:
-        pc_t1 = (C.c_uint64 * 4)()
-        ma._lib.lib().msi_dict_posting_cache_stats(C.c_void_p(kw["lib"].rb_dict(kw["h"])), pc_t1)
-        pc_timed = (int(pc_t1[0] - pc_t0[0]), int(pc_t1[1] - pc_t0[1]))
     scan_n, scan_ms = store.scan_time()
     ctx.set_profiling(False)
     if env.rank != 0:
         return None
-    algo_bytes = ((n + 15) // 16) * store.stats()["bytes_per_tile"]
+    kname, kprefix, algo_bytes = sweep_kernel(store.stats(), n)
     out = {
         "metric": "vector k-NN queries/sec (1M docs x 384-d, exact cosine top-20)",
         "value": round(Q * env.world * args.steps / elapsed, 2), "unit": "queries/s",
         "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(statistics.median(lat), 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if storage == "f32" else "bf16 rows, f32 arithmetic",
+        "dtype": ("f32 (every distance: the reference's f32 arithmetic on the f32 rows; candidates: int8 MFMA sweep of a quantised copy)"
+                  if store.stats().get("i8_bytes_per_tile") else "f32") if storage == "f32" else "bf16 rows, f32 arithmetic",
         "data": "synthetic (rows N(0,1) seed 1234, queries seed 5678; BASELINE.md C2)",
         "config": {"workload": f"C2: {n} docs x {d}-d {storage} exact cosine top-{k}, {Q} queries per step per GPU",
                    "queries_per_hbm_sweep": store.max_batch, "inexact_queries_last_step": int(inexact.sum().item())},
-        "roofline": scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, "vs_scan_kernel (main pass)",
-                                  must_contain=("false",)),
+        "roofline": scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kname, must_contain=("false",), kernel_prefix=kprefix),
     }
     if env.check:
         cpu_rows = rows_t[:min(n, args.cpu_sample_rows)].cpu().numpy()
@@ -1219,7 +1278,8 @@ def run_clustered(args, env, n, d, Q, tag):
     s1 = store.stats()
     nq = Q * args.steps
     tiles = s1["scan_tiles"] - s0["scan_tiles"]
-    eff_bytes = tiles * s1["bytes_per_tile"]
+    tiles8 = s1["i8_scan_tiles"] - s0["i8_scan_tiles"]            # (the part of them that streamed the int8 copy)
+    eff_bytes = (tiles - tiles8) * s1["bytes_per_tile"] + tiles8 * s1["i8_bytes_per_tile"]
     x2, x3 = s1["x2_sweeps"] - s0["x2_sweeps"], s1["x3_first_sweeps"] - s0["x3_first_sweeps"]
     second, exh = s1["second_opinion_queries"] - s0["second_opinion_queries"], s1["exhaustive_reruns"] - s0["exhaustive_reruns"]
     one_sweep = ((n + 15) // 16) * s1["bytes_per_tile"]
@@ -1228,13 +1288,14 @@ def run_clustered(args, env, n, d, Q, tag):
         "value": round(nq / wall, 1), "unit": "queries/s", "steps": args.steps, "queries_per_step": Q,
         "data": "synthetic clustered (synth.device_rows_clustered seed 4321: 10 000 centres, members 1e-3..1e-2 from their centre "
                 "(1 - cos, log-uniform), 1 % exact duplicates; queries = stored rows moved by 5e-3, seed 8765)",
-        "resolved": {"queries": nq, "bf16x2_sweeps": int(x2), "bf16x3_first_sweeps": int(x3), "second_opinion_bf16x3_queries": int(second),
+        "resolved": {"queries": nq, "int8_sweeps": int(s1["i8_sweeps"] - s0["i8_sweeps"]), "bf16x2_sweeps": int(x2), "bf16x3_first_sweeps": int(x3), "second_opinion_bf16x3_queries": int(second),
                      "exhaustive_queries": int(exh),
                      "fraction_needing_more_than_the_first_pass": round((second + (exh if x3 else 0)) / max(1, nq), 4)},
-        "roofline": {"kernel": "vs_scan_kernel (every pass: samples, first passes, second opinions)", "bound": "hbm",
+        "roofline": {"kernel": "vs_scan_i8_kernel + vs_scan_kernel (every pass: samples, int8 sweeps, f32 levels)", "bound": "hbm",
                      "achieved": round(eff_bytes / max(1e-9, scan_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(eff_bytes / max(1e-9, scan_ms * 1e-3) / 1e9 / 8000.0, 4),
-                     "effective_bytes": int(eff_bytes), "passes_over_the_store": round(eff_bytes / one_sweep, 2),
+                     "effective_bytes": int(eff_bytes), "f32_passes_over_the_store": round((tiles - tiles8) * s1["bytes_per_tile"] / one_sweep, 2),
+                     "int8_passes_over_the_copy": round(tiles8 / max(1, (n + 15) // 16), 2),
                      "scan_kernel_ms": round(scan_ms, 3), "launches_timed": scan_n,
                      "end_to_end_GBps": round(eff_bytes / wall / 1e9, 1), "end_to_end_frac": round(eff_bytes / wall / 1e9 / 8000.0, 4),
                      "timing": "HIP events on the scan's launch stream (kernel) / wall clock around msi_vs_search (end to end: H2D of the "
@@ -1694,6 +1755,10 @@ def short_line(full, detail_path=None):
     if full.get("parity") is not None:
         out["parity"] = _parity_counts(full["parity"])
     legs = full.get("legs") or {}
+    if isinstance(legs.get("f32_sweep_level"), dict):
+        out.setdefault("roofline", {})
+        if isinstance(out["roofline"], dict):
+            out["roofline"]["f32_sweep_frac"] = legs["f32_sweep_level"].get("frac_of_8_TBps")
     lg = _pick(legs, ("vector_only_queries_per_s", "keyword_only_queries_per_s", "keyword_only_host_cpus_used",
                       "keyword_cold_posting_cache_queries_per_s", "keyword_lists_per_query", "keyword_host_cpu_ms_per_query"))
     if isinstance(legs.get("keyword_posting_cache"), dict):
@@ -1765,6 +1830,7 @@ def emit(full, args, final):
 def main():
     t_start = time.time()
     args = parse_args()
+    phase("start-up (import torch, context)")
     env = Env(args)
     out = {"c1": run_c1, "c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](args, env)
     want_also = args.config == "c4" and out is not None and env.check and not args.no_also
@@ -1779,6 +1845,7 @@ def main():
     env.finish()
     if env.rank == 0 and out is not None:
         out["seconds"] = round(time.time() - t_start, 1)
+        out["phase_seconds"] = phase_seconds()
         emit(out, args, final=True)
 
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MSI_ABI_VERSION 2   /* 2: msi_search_params grew (geo_strategy, geo_cache_size, index_view), round 3 */
+#define MSI_ABI_VERSION 3   /* 2: msi_search_params grew (geo_strategy, geo_cache_size, index_view), round 3; 3: msi_vs_stats grew, msi_runtime_hw_queues, round 5 */
 
 enum {
   MSI_OK = 0,
@@ -260,6 +260,11 @@ typedef struct msi_vs_stats {
   /* sweeps by level of effort (msi_vs.hip, msi_vs::level): the store's contraction with the usual K' | the same with
    * K' = 2048 rescored candidates | bf16x3 with K' = 2048 */
   uint64_t level_sweeps[3];
+  /* (ABI 3) the int8 candidate sweep (level 0 of an f32 store that keeps the int8 copy of its rows: msi_vs.hip): algorithmic
+   * HBM bytes per 16-row tile of it (0: the store has no copy), full sweeps of it so far, queries that msi_vs_search_device
+   * re-ran at a higher level of effort itself, queries per sweep of the copy / of the f32 rows, tiles of the copy streamed
+   * (sample + full sweeps: the part of scan_tiles that read the copy) */
+  uint64_t i8_bytes_per_tile, i8_sweeps, device_rerun_queries, i8_queries_per_sweep, f32_queries_per_sweep, i8_scan_tiles;
 } msi_vs_stats;
 int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out);
 /* Test instrumentation: the fast scan's raw scores (dot / |row|; -inf for padding)

@@ -125,7 +125,9 @@ class VsStats(C.Structure):
     _fields_ = [("scan_launches", C.c_uint64), ("scan_tiles", C.c_uint64),
                 ("exhaustive_reruns", C.c_uint64), ("bytes_per_tile", C.c_uint64),
                 ("second_opinion_queries", C.c_uint64), ("x3_first_sweeps", C.c_uint64), ("x2_sweeps", C.c_uint64),
-                ("level_sweeps", C.c_uint64 * 3)]
+                ("level_sweeps", C.c_uint64 * 3),
+                ("i8_bytes_per_tile", C.c_uint64), ("i8_sweeps", C.c_uint64), ("device_rerun_queries", C.c_uint64),
+                ("i8_queries_per_sweep", C.c_uint64), ("f32_queries_per_sweep", C.c_uint64), ("i8_scan_tiles", C.c_uint64)]
 
 
 class DictStats(C.Structure):
@@ -319,8 +321,8 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if L.msi_abi_version() != 2:
-            raise ImportError(f"libmsi ABI {L.msi_abi_version()} != 2")
+        if L.msi_abi_version() != 3:
+            raise ImportError(f"libmsi ABI {L.msi_abi_version()} != 3")
         _LIB = L
     return _LIB
 

@@ -56,7 +56,15 @@ __device__ inline float4 vs_stream_load(const float4 *p) {
 }
 #define MSI_VS_STREAM_LOAD(p) vs_stream_load(p)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
+__device__ inline i32x4 vs_stream_load_i8(const i32x4 *p) {
+#if MSI_VS_NT && !defined(MSI_HIP_EMULATED)
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 
 namespace {
 
@@ -66,7 +74,8 @@ constexpr uint32_t KP_MAX = 2048;        // K' supported by select/rescore (k <=
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_SORTCAP = 2048;        // u64 keys sorted in LDS by vs_select
 constexpr int QT = 16;                   // queries per MFMA tile
-constexpr int NQT_MAX = 6;               // query tiles per HBM sweep (6 with the bf16x2 contraction, 3 otherwise)
+constexpr int NQT_MAX = 12;              // query tiles per HBM sweep (12 on the int8 copy, 6 with the bf16x2 contraction, 3 otherwise)
+constexpr int NQT_F32_MAX = 6;           // ... of the sweeps over the f32 rows
 constexpr int NQ_MAX = QT * NQT_MAX;     // queries per HBM sweep
 constexpr int CNT_PAD = 32;              // u32 stride of the per-query counters (one 128-B line each)
 constexpr size_t LDS_MAX = 160 * 1024;
@@ -598,6 +607,454 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------ int8 candidate sweep
+//
+// Round 5.  The f32 sweep runs at the machine's streaming ceiling (0.77-0.82 of 8 TB/s): what is left is to stream fewer
+// bytes.  Beside its f32 rows a store keeps an INT8 COPY of them — every row divided by its norm and quantised with its
+// own scale, dpad bytes per row instead of 4 dpad — and level 0 of the search sweeps THAT copy on v_mfma_i32_16x16x64_i8
+// (twice the bf16 rate, exact integer accumulation).  The sweep is still exhaustive (every allowed row is scored) and it
+// is still only a CANDIDATE GENERATOR: the K' best rows are rescored from the f32 rows in the reference's arithmetic and
+// the exactness proof runs with the quantisation's own bound, so the answers are the same bits as before; what it cannot
+// prove falls through to the f32 sweeps (levels of effort, msi_vs::level).
+//
+//   row      u = x / |x| (the canonical norm), s_x = max|u_i| / 127, xq_i = rint(u_i / s_x), e_x = |u - s_x xq|  (per row)
+//   query    v = q / |q|,                      s_q = max|v_i| / 127, qq_i = rint(v_i / s_q), e_q = |v - s_q qq|
+//   fast     cos ~ s_x s_q (xq . qq)            — the integer dot product is exact in i32 (d * 127^2 < 2^31 for d <= 133 000)
+//   bound    u.v - s_x s_q xq.qq = r_x.v + (s_x xq).r_q,  |r_x.v| <= e_x |v|,  |(s_x xq).r_q| <= (|u| + e_x) e_q   (Cauchy-Schwarz)
+//            => |cos - fast| <= e_x + e_q + e_x e_q (+ the f32 terms every level carries): eps of query j uses ITS e_q and the
+//            largest e_x of the store (a device scalar, maintained by the quantiser).  On N(0,1) rows e_x ~ 0.008 whatever d.
+//
+// HBM layout of the copy: tile t = 16 rows = KB8 = dpad / 64 blocks of 1 KiB; in block (t, kb) lane l = g*16+i owns the 16
+// bytes of row 16t+i, columns 64kb+16g..+15 — one wave-wide 16-byte load is one contiguous KiB and IS the A operand.  The
+// queries' fragments (same k-order, so the lane -> k map of the instruction never matters) sit in LDS: 1 KiB per 64 columns and
+// 16 queries — 12 KiB per query tile at d = 768, so 192 queries share a sweep (the bf16x2 sweep: 96).  A wave holds RT row
+// tiles at a time so that every 1-KiB query fragment read from LDS feeds RT instructions (one MFMA per read would need
+// twice the LDS bandwidth a CU has).
+//
+// Algorithmic bytes: dpad + 8 per row and sweep (the int8 row, its scale, its inverse norm).
+
+struct Scan8Args {
+  const i32x4 *tiles8;
+  const float *scale8;           // [rows] s_x (NaN: the row could not be quantised — always a candidate)
+  const float *inv_norm;         // [rows] (the degenerate-row rule of the f32 sweeps)
+  const uint32_t *i8small;       // [0] largest e_x, [1] largest inverse norm of the store (ordered bits)
+  const i32x4 *qfrag8;           // [nqt][KB8][64]
+  const float *sqs;              // [NQ_MAX] s_q * |q|: fast score = dot * s_x * sqs, in the f32 sweeps' unit (x.q / |x|)
+  const float *theta;
+  const float *degth;
+  const uint32_t *n_items_ptr;
+  const uint32_t *list;
+  const uint16_t *tmask;
+  u64 *gkeys;
+  uint32_t *gcnt;
+  uint32_t *overflow;
+  float *dense;
+  uint64_t n_rows;
+  uint32_t dstride;
+  uint32_t capg;
+  uint32_t KB8;
+  uint32_t stride;
+  uint32_t nq;
+};
+
+// f32 tiles -> the int8 copy, one workgroup of 256 threads per tile: thread (i = tid & 15, c = tid >> 4) works on row i,
+// 16-column chunks c, c + 16, ...
+__global__ __launch_bounds__(256) void vs_quantize_rows_kernel(const float4 *__restrict__ tiles, const float *__restrict__ inv_norm,
+                                                               uint64_t n_rows, uint32_t KB, i32x4 *__restrict__ tiles8,
+                                                               float *__restrict__ scale8, uint32_t *__restrict__ ex_max_ord) {
+  __shared__ float s_red[16][17];
+  __shared__ float s_row[16];
+  __shared__ int s_bad[16];
+  const uint32_t tid = threadIdx.x, i = tid & 15, c = tid >> 4;
+  const uint64_t t = blockIdx.x;
+  const uint64_t r = t * 16 + i;
+  const float inv = r < n_rows ? inv_norm[r] : 0.f;
+  const uint32_t KB8 = KB / 4;
+  if (tid < 16) s_bad[tid] = 0;
+  __syncthreads();
+  const float4 *base = tiles + t * KB * 64 + i;
+  float amax = 0.f;
+  bool bad = !(inv == inv) || inv == INFINITY;
+  for (uint32_t m = c; m < KB; m += 16) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = base[(uint64_t)m * 64 + g * 16];
+      const float e[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!(fabsf(e[j]) <= FLT_MAX)) bad = true;   // NaN or infinity
+        amax = fmaxf(amax, fabsf(e[j]));
+      }
+    }
+  }
+  if (bad) s_bad[i] = 1;
+  s_red[i][c] = amax;
+  __syncthreads();
+  if (c == 0) {
+    float m = 0.f;
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, s_red[i][j]);
+    s_row[i] = m;
+  }
+  __syncthreads();
+  const float rmax = s_row[i];
+  const bool row_bad = s_bad[i] != 0;
+  const float sx = rmax > 0.f ? rmax / 127.0f : 0.f;
+  const float isx = rmax > 0.f ? 127.0f / rmax : 0.f;
+  float res = 0.f;
+  for (uint32_t m = c; m < KB; m += 16) {
+    int q[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = base[(uint64_t)m * 64 + g * 16];
+      const float e[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float qf = rintf(e[j] * isx);
+        qf = fminf(127.f, fmaxf(-127.f, qf));
+        if (row_bad) qf = 0.f;
+        const float d = __fsub_rn(e[j], __fmul_rn(sx, qf));
+        res = __fadd_rn(res, __fmul_rn(d, d));
+        q[g * 4 + j] = (int)qf;
+      }
+    }
+    i32x4 w;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      w[g] = (q[4 * g] & 255) | ((q[4 * g + 1] & 255) << 8) | ((q[4 * g + 2] & 255) << 16) | ((q[4 * g + 3] & 255) << 24);
+    tiles8[(t * KB8 + (m >> 2)) * 64 + (m & 3) * 16 + i] = w;
+  }
+  __syncthreads();
+  s_red[i][c] = res;
+  __syncthreads();
+  if (c == 0) {
+    float tot = 0.f;
+    for (int j = 0; j < 16; ++j) tot += s_red[i][j];
+    // e_x, rounded up: the f32 evaluation of the residual (relative 2^-20 at these lengths) and what u itself carries
+    const float ex = msi_sqrt_rn(tot) * 1.001f + 2e-6f;
+    if (r < n_rows) {
+      scale8[r] = row_bad ? NAN : sx;
+      if (!row_bad) atomicMax(ex_max_ord, __float_as_uint(ex));   // (non-negative floats order as their bits)
+      // [1]: the largest inverse norm of the store (+inf with a zero row): a sweep whose queries' degenerate-row thresholds
+      // all lie above it never loads inv_norm (vs_scan_i8_kernel)
+      if (inv == inv && inv > 0.f) atomicMax(ex_max_ord + 1, __float_as_uint(inv));
+      if (!(inv == inv)) atomicMax(ex_max_ord + 1, 0x7F800000u);
+    } else {
+      scale8[r] = 0.f;
+    }
+  }
+}
+
+// The queries of a sweep -> int8 fragments, score scales and each query's proof bound.  Runs behind vs_prep_queries_kernel
+// (qrow = the zero-padded rows, qn / inv_qn = canonical norm and reciprocal); one workgroup of 256 threads per query.
+__global__ __launch_bounds__(256) void vs_prep_queries_i8_kernel(const float *__restrict__ qrow, const float *__restrict__ qn,
+                                                                 const float *__restrict__ inv_qn, uint32_t nq, uint32_t dpad,
+                                                                 i32x4 *__restrict__ qfrag8, float *__restrict__ sqs,
+                                                                 float *__restrict__ epsq, const uint32_t *__restrict__ ex_max_ord,
+                                                                 float eps_base) {
+  __shared__ float s_red[256];
+  const uint32_t j = blockIdx.x, tid = threadIdx.x;
+  const uint32_t KB8 = dpad / 64;
+  const float inv = j < nq ? inv_qn[j] : 0.f;
+  const float *row = qrow + (uint64_t)j * dpad;
+  float amax = 0.f;
+  for (uint32_t k = tid; k < dpad; k += 256) amax = fmaxf(amax, fabsf(row[k] * inv));
+  s_red[tid] = amax;
+  __syncthreads();
+  for (uint32_t o = 128; o > 0; o >>= 1) {
+    if (tid < o) s_red[tid] = fmaxf(s_red[tid], s_red[tid + o]);
+    __syncthreads();
+  }
+  const float vmax = s_red[0];
+  __syncthreads();
+  const bool finite = vmax <= FLT_MAX;   // (false for NaN / infinity: the query then proves nothing at this level)
+  const float sq = (finite && vmax > 0.f) ? vmax / 127.0f : 0.f;
+  const float isq = (finite && vmax > 0.f) ? 127.0f / vmax : 0.f;
+  const uint32_t t = j / QT, jj = j % QT;
+  float res = 0.f;
+  for (uint32_t m = tid; m < dpad / 16; m += 256) {   // 16-column chunk m = (kb8 = m / 4, g = m % 4)
+    int q[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float v = row[m * 16 + e] * inv;
+      float qf = finite ? rintf(v * isq) : 0.f;
+      qf = fminf(127.f, fmaxf(-127.f, qf));
+      const float d = __fsub_rn(v, __fmul_rn(sq, qf));
+      res = __fadd_rn(res, __fmul_rn(d, d));
+      q[e] = (int)qf;
+    }
+    i32x4 w;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      w[g] = (q[4 * g] & 255) | ((q[4 * g + 1] & 255) << 8) | ((q[4 * g + 2] & 255) << 16) | ((q[4 * g + 3] & 255) << 24);
+    qfrag8[((uint64_t)t * KB8 + (m >> 2)) * 64 + (m & 3) * 16 + jj] = w;
+  }
+  s_red[tid] = res;
+  __syncthreads();
+  for (uint32_t o = 128; o > 0; o >>= 1) {
+    if (tid < o) s_red[tid] = s_red[tid] + s_red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float eq = msi_sqrt_rn(s_red[0]) * 1.001f + 2e-6f;
+    const float ex = __uint_as_float(*ex_max_ord);
+    sqs[j] = sq * (j < nq ? qn[j] : 0.f);
+    epsq[j] = finite ? (ex + eq + ex * eq) * 1.002f + eps_base : INFINITY;
+  }
+}
+
+// NQT 16-query tiles per sweep, RT row tiles per wave and step, GS KiB-blocks per software-pipeline stage (GS divides KB8).
+template <int WAVES, int NQT, int RT, int GS, bool DENSE>
+__global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
+  MSI_DYNAMIC_LDS(smem);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63;
+  const uint32_t wave = tid >> 6;
+  const uint32_t KB8 = a.KB8;
+  i32x4 *qf = reinterpret_cast<i32x4 *>(smem);   // [NQT][KB8][64]
+  for (uint32_t i = tid; i < NQT * KB8 * 64; i += WAVES * 64) qf[i] = a.qfrag8[i];
+  __syncthreads();
+
+  // per-query constants of the epilogue stay in LDS (three registers per query tile otherwise: the accumulators need them)
+  float *s_th = reinterpret_cast<float *>(smem + (size_t)NQT * KB8 * 64 * sizeof(i32x4));   // [NQT * QT] thresholds
+  float *s_dth = s_th + NQT * QT, *s_sq = s_dth + NQT * QT, *s_thq = s_sq + NQT * QT;
+  for (uint32_t i = tid; i < NQT * QT; i += WAVES * 64) {
+    const float th = DENSE ? 0.f : a.theta[i], sq = a.sqs[i];
+    s_th[i] = th;
+    s_dth[i] = a.degth[i];
+    s_sq[i] = sq;
+    // the sparse epilogue's test in the unit of (integer dot) x (row scale): score >= th  <=>  dot * s_x >= th / sq, taken a few
+    // ulps low so that rounding can only ADD survivors (their real scores are computed when they are kept); a query beyond
+    // nq keeps nothing, one whose scale is 0 scores 0 everywhere
+    float thq = sq > 0.f ? th / sq : (th <= 0.f ? -INFINITY : INFINITY);
+    if (sq > 0.f && thq == thq && fabsf(thq) <= FLT_MAX) thq -= fabsf(thq) * 4.8e-7f;
+    if (i >= a.nq) thq = INFINITY;
+    s_thq[i] = thq;
+  }
+  __syncthreads();
+  // a row is degenerate for query j when 1 / |row| >= degth[j] (pn*qn <= EPS: the reference's distance is 0): if the store's
+  // largest inverse norm lies below every threshold of this sweep (always, on sane embeddings) the test cannot fire and the
+  // epilogue does not load the rows' inverse norms at all — one dependent global load per tile less in front of the scores
+  bool check_deg = false;
+  {
+    const float inv_max = __uint_as_float(a.i8small[1]);
+    for (uint32_t i = 0; i < min(a.nq, (uint32_t)(NQT * QT)); ++i)
+      if (inv_max >= s_dth[i]) check_deg = true;
+  }
+
+  const uint32_t qj = lane & 15;   // this lane's query inside a tile (D column)
+  const uint32_t g = lane >> 4;    // this lane's row group: rows 4g..4g+3 of the tile
+  const uint32_t n_all = *a.n_items_ptr;
+  const uint32_t n_items = (n_all + a.stride - 1) / a.stride;
+  const uint64_t gw = (uint64_t)blockIdx.x * WAVES + wave;
+  const uint64_t GW = (uint64_t)gridDim.x * WAVES;
+  const uint32_t it0 = (uint32_t)((uint64_t)n_items * gw / GW);
+  const uint32_t it1 = (uint32_t)((uint64_t)n_items * (gw + 1) / GW);
+  if (it0 >= it1) return;
+  const uint32_t GPT = KB8 / GS;
+
+  auto tile_of = [&](uint32_t it) -> uint32_t {
+    const uint32_t idx = (it < it1 ? it : it1 - 1) * a.stride;   // (the last group of a wave may be short: its spare slots re-read the last tile)
+    return a.list ? a.list[idx] : idx;
+  };
+
+  auto epilogue = [&](uint32_t tile, uint32_t it, const i32x4(&acc)[NQT], const float4 sc) {
+    const uint64_t row0 = (uint64_t)tile * 16 + g * 4;
+    float4 inv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (check_deg) inv = *reinterpret_cast<const float4 *>(a.inv_norm + row0);
+    uint32_t allowed = 0xF;
+    if (a.tmask) allowed = (a.tmask[tile] >> (g * 4)) & 0xF;
+    else if (row0 + 4 > a.n_rows) allowed = row0 >= a.n_rows ? 0u : ((1u << (a.n_rows - row0)) - 1u);
+    const float iv[4] = {inv.x, inv.y, inv.z, inv.w};
+    const float sx[4] = {sc.x, sc.y, sc.z, sc.w};
+    if (!DENSE && !check_deg) {
+      // The common case of the full sweep, three instructions per score: convert, scale by the row, compare with the query's
+      // threshold in that unit (a NaN — a row that could not be quantised — passes).  Everything else happens for survivors only.
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = t * QT + qj;
+        const float thq = s_thq[q];
+        float f[4];
+        uint32_t pass = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f[r] = (float)acc[t][r] * sx[r];
+          if (!(f[r] < thq)) pass |= 1u << r;
+        }
+        pass &= allowed;
+        if (pass) {
+          if (q < a.nq) {
+            const float sq_t = s_sq[q], th_t = s_th[q];
+            uint32_t keep = 0;
+            float sv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = f[r] * sq_t;
+              if (!(v == v)) v = FLT_MAX;
+              sv[r] = v;
+              if ((pass & (1u << r)) && !(v < th_t)) keep |= 1u << r;
+            }
+            if (keep) {
+              uint32_t slot = atomicAdd(&a.gcnt[q * CNT_PAD], (uint32_t)__popc(keep));
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if (keep & (1u << r)) {
+                  if (slot < a.capg) a.gkeys[(uint64_t)q * a.capg + slot] = make_key_desc(sv[r], (uint32_t)(row0 + r));
+                  else *a.overflow = 1;
+                  ++slot;
+                }
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+      float s[4];
+      const uint32_t q = t * QT + qj;
+      const float sq_t = s_sq[q], dth_t = s_dth[q], th_t = s_th[q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = (float)acc[t][r] * sx[r] * sq_t;
+        if (check_deg && iv[r] >= dth_t) v = FLT_MAX;   // pn*qn <= EPS: reference distance is 0 (best)
+        if (!(v == v)) v = FLT_MAX;        // a row (or query) that could not be quantised: the canonical rescoring decides
+        s[r] = v;
+      }
+      if (DENSE) {
+        float4 o;
+        o.x = (allowed & 1u) ? s[0] : -INFINITY;
+        o.y = (allowed & 2u) ? s[1] : -INFINITY;
+        o.z = (allowed & 4u) ? s[2] : -INFINITY;
+        o.w = (allowed & 8u) ? s[3] : -INFINITY;
+        *reinterpret_cast<float4 *>(a.dense + (uint64_t)q * a.dstride + (uint64_t)it * 16 + g * 4) = o;
+      } else {
+        uint32_t pass = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (!(s[r] < th_t)) pass |= 1u << r;
+        pass &= allowed;
+        if (q >= a.nq) pass = 0;
+        if (pass) {
+          uint32_t slot = atomicAdd(&a.gcnt[q * CNT_PAD], (uint32_t)__popc(pass));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (pass & (1u << r)) {
+              if (slot < a.capg) a.gkeys[(uint64_t)q * a.capg + slot] = make_key_desc(s[r], (uint32_t)(row0 + r));
+              else *a.overflow = 1;
+              ++slot;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  i32x4 xa[GS][RT], xb[GS][RT];
+  i32x4 acc[RT][NQT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) acc[r][t] = (i32x4){0, 0, 0, 0};
+
+  uint32_t it_load = it0, sub_load = 0;   // first item of the group being loaded, next stage of it
+  uint32_t it_cmp = it0, sub_cmp = 0;
+  uint32_t tl[RT], tc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) tl[r] = tc[r] = tile_of(it0 + r);
+  // the rows' scales travel with the first stage of their tile group (the loads run one stage ahead of the MFMAs, so they have
+  // long arrived when the group's epilogue needs them): scn = of the group being loaded, scc = of the group being computed
+  float4 scn[RT], scc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) scn[r] = scc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto load_group = [&](i32x4(&x)[GS][RT]) {
+    if (sub_load == 0) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) scn[r] = *reinterpret_cast<const float4 *>(a.scale8 + (uint64_t)tl[r] * 16 + g * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const i32x4 *p = a.tiles8 + ((uint64_t)tl[r] * KB8 + (uint64_t)sub_load * GS) * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < GS; ++u) x[u][r] = vs_stream_load_i8(p + u * 64);
+    }
+    if (++sub_load == GPT) {
+      sub_load = 0;
+      it_load += RT;
+      if (it_load < it1) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) tl[r] = tile_of(it_load + r);
+      }
+    }
+  };
+  auto compute_group = [&](const i32x4(&x)[GS][RT]) {
+    const i32x4 *qb = qf + (size_t)sub_cmp * GS * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < GS; ++u) {
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {
+        const i32x4 b = qb[((size_t)t * KB8 + u) * 64];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(x[u][r], b, acc[r][t], 0, 0, 0);
+      }
+      // (the query fragments of ONE block in flight at a time: hoisting every block's LDS reads to the top of the group
+      // costs 16 registers per query tile and block, and the accumulators need them)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (sub_cmp == 0) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) scc[r] = scn[r];   // (this group's scales: requested with its first stage, one stage ago)
+    }
+    if (++sub_cmp == GPT) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        if (it_cmp + r < it1) epilogue(tc[r], it_cmp + r, acc[r], scc[r]);
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) acc[r][t] = (i32x4){0, 0, 0, 0};
+      }
+      sub_cmp = 0;
+      it_cmp += RT;
+      if (it_cmp < it1) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) tc[r] = tile_of(it_cmp + r);
+      }
+    }
+  };
+
+  // The wait for a stage's rows comes BEFORE the next stage's loads are issued (`landed`: an empty asm that uses every register
+  // of the stage, so the compiler's s_waitcnt sits there with nothing younger in flight).  Left to itself the compiler waits at the
+  // first MFMA that reads the stage — after the next stage's loads were issued — and, having lost count of the loads in flight at
+  // the epilogue's conditional stores, it waits for ALL of them: the next stage's too, i.e. no overlap of loads and MFMAs at all
+  // (measured: 2.06 ms per 128-query sweep of 10 M x 768; rocprofv3 / ISA in profiles/r5_i8_sweep.txt).
+  auto landed = [&](i32x4(&x)[GS][RT]) {
+#if !defined(MSI_HIP_EMULATED)
+#pragma unroll
+    for (int u = 0; u < GS; ++u)
+#pragma unroll
+      for (int r = 0; r < RT; ++r) asm volatile("" : "+v"(x[u][r]));
+#pragma unroll
+    for (int r = 0; r < RT; ++r) asm volatile("" : "+v"(scn[r].x), "+v"(scn[r].y), "+v"(scn[r].z), "+v"(scn[r].w));
+#else
+    (void)x;
+#endif
+  };
+  load_group(xa);
+  for (;;) {
+    landed(xa);
+    bool more = it_load < it1;
+    if (more) load_group(xb);
+    compute_group(xa);
+    if (!more) break;
+    landed(xb);
+    more = it_load < it1;
+    if (more) load_group(xa);
+    compute_group(xb);
+    if (!more) break;
+  }
+}
+
 // ---------------------------------------------------------------------- select
 
 // Block-wide bitonic sort (ascending) of n (power of two) keys in LDS.
@@ -866,6 +1323,7 @@ struct RescoreArgs {
   uint32_t kp;
   uint32_t k;
   float eps;               // bound on |fast cos - reference cos|
+  const float *eps_q;      // nullable [NQ_MAX]: added to eps per query (the int8 sweep: the query's own quantisation bound)
   uint32_t *out_docids;    // [nq][k]
   float *out_dist;         // [nq][k]
   uint32_t *out_counts;    // [nq]
@@ -944,7 +1402,8 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) 
     if (cnt == a.kp && out_n > 0) {
       const float smin = key_desc_score(a.sel_keys[(uint64_t)j * KP_MAX + cnt - 1]);
       const float cmin = smin * a.inv_qn[j];
-      const float bound = (1.0f - cmin - a.eps) * 0.5f - 2e-7f;
+      const float eps = a.eps + (a.eps_q ? a.eps_q[j] : 0.0f);   // (+inf: a query that could not be quantised proves nothing)
+      const float bound = (1.0f - cmin - eps) * 0.5f - 2e-7f;
       const float dk = ord_to_f32((uint32_t)(sbuf[out_n - 1] >> 32));
       if (!(dk < bound)) bad = 1;
     }
@@ -1066,22 +1525,28 @@ struct msi_vs {
   bool bf3 = true;                 // contraction of the fast scan: bf16 MFMA (default) or f32 MFMA
   bool bf2 = false;                // ... bf16x2 (queries' hi halves only in LDS: twice the queries per sweep) instead of bf16x3
   bool s16 = false;                // rows stored as bf16 (MSI_VS_BF16)
+  // the int8 copy of the rows and its sweep (f32 stores; MSI_VS_I8=0: none) — level 0 of the search when present
+  bool i8 = false;                 // the store keeps the copy
+  bool i8_now = false;             // the chunk being planned / enqueued sweeps it (set per sweep by the levels of effort)
+  uint32_t KB8 = 0, nqt8_max = 1;  // KiB blocks per tile of the copy; query tiles per sweep over it
+  DevBuf tiles8, scale8, i8small;  // [n_tiles][KB8][1 KiB] | s_x per row | {largest e_x of the store, as ordered bits}
+  uint64_t i8_sweeps = 0, i8_scan_tiles = 0, device_rerun_queries = 0;
   uint64_t n_rows = 0, n_tiles = 0;
   DevBuf tiles, norm, inv_norm, docids;
   DevBuf tiles_next, docids_next, norm_next, inv_norm_next, add_tiles, add_docids, row_map;  // msi_vs_update builds the next store beside the current one
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
   // scratch (guarded by ctx->mu)
-  DevBuf qraw, qfrag, qfrag_bf, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fsmall, fbits, out_docids,
-      out_dist, exh_keys, rowtmp, resc_keys;
+  DevBuf qraw, qfrag, qfrag_bf, qfrag8, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fsmall, fbits, out_docids,
+      out_dist, exh_keys, rowtmp, resc_keys, rerun_q, rerun_flags;
   // the second scratch set and stream of the device entry point's pipeline (msi_vs_search_device): allocated on first use
   struct Scratch2 {
-    DevBuf qfrag, qfrag_bf, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, resc_keys;
+    DevBuf qfrag, qfrag_bf, qfrag8, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, resc_keys;
   } scr2;
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_done = nullptr, ev_pre[2] = {nullptr, nullptr}, ev_main[2] = {nullptr, nullptr};
   uint64_t pipelined_calls = 0;
   uint32_t capg = 0;
-  uint32_t scan_grid = 0;
+  uint32_t scan_grid = 0, scan_grid8 = 0;
   // stats
   uint64_t scan_launches = 0, scan_tiles = 0, exhaustive_reruns = 0;
   // How a query is proven adapts to the data (host entry point).  The proof needs every row whose fast score lies within
@@ -1098,7 +1563,7 @@ struct msi_vs {
   uint32_t level = 0, level_left = 0;
   float level_ema = 0.0f;
   bool big_slack = false;          // (read by enqueue_search: K' = KP_MAX)
-  uint64_t second_opinion_queries = 0, x3_first_sweeps = 0, x2_sweeps = 0, level_sweeps[3] = {0, 0, 0};
+  uint64_t second_opinion_queries = 0, x3_first_sweeps = 0, x2_sweeps = 0, level_sweeps[5] = {0, 0, 0, 0, 0};
   KernelTimer scan_timer;
   // micro-batcher: concurrent unfiltered msi_vs_search calls are fused into one sweep
   struct Pending {
@@ -1124,7 +1589,7 @@ namespace {
 
 // layout of the small scratch arrays
 struct Small {
-  float *qn, *inv_qn, *degth, *theta_inf, *theta;
+  float *qn, *inv_qn, *degth, *theta_inf, *theta, *sqs, *epsq;
   uint32_t *sel_cnt, *n_tiles, *n_items, *overflow, *bad, *inexact, *counts;
 };
 
@@ -1136,6 +1601,8 @@ Small small_of(msi_vs *vs) {
   s.degth = f + 2 * NQ_MAX;
   s.theta_inf = f + 3 * NQ_MAX;
   s.theta = f + 4 * NQ_MAX;
+  s.sqs = f + 5 * NQ_MAX;
+  s.epsq = f + 6 * NQ_MAX;
   uint32_t *u = vs->gsmall.as<uint32_t>();
   s.sel_cnt = u;
   s.inexact = u + NQ_MAX;
@@ -1151,6 +1618,8 @@ size_t scan_lds_bytes(uint32_t KB, uint32_t nqt, bool s16 = false, bool bf2 = fa
   if (bf2) return (size_t)nqt * KB * 32 * sizeof(float4);
   return (size_t)nqt * KB * 64 * sizeof(float4) * (s16 ? 2 : 1);
 }
+
+size_t scan8_lds_bytes(uint32_t KB8, uint32_t nqt) { return (size_t)nqt * KB8 * 64 * sizeof(i32x4) + 4 * (size_t)nqt * QT * sizeof(float); }
 
 // Threshold rank r for the sample pass: the smallest r for which "fewer than kp
 // rows of the whole store beat the r-th best of a p-fraction sample" has
@@ -1183,7 +1652,8 @@ int32_t ensure_scratch(msi_vs *vs) {
   MSI_TRY(vs->qfrag.ensure((size_t)NQT_MAX * vs->KB * 64 * sizeof(float4)));
   MSI_TRY(vs->qfrag_bf.ensure((size_t)NQT_MAX * vs->KB * 64 * sizeof(float4) * (vs->s16 ? 2 : 1)));
   MSI_TRY(vs->qrow.ensure((size_t)NQ_MAX * vs->dpad * sizeof(float)));
-  MSI_TRY(vs->qsmall.ensure(5 * NQ_MAX * sizeof(float)));
+  MSI_TRY(vs->qsmall.ensure(7 * NQ_MAX * sizeof(float)));
+  if (vs->i8) MSI_TRY(vs->qfrag8.ensure((size_t)NQT_MAX * vs->KB8 * 64 * sizeof(i32x4)));
   MSI_TRY(vs->gsmall.ensure((3 * NQ_MAX + 8) * sizeof(uint32_t)));
   MSI_TRY(vs->gcnt.ensure((size_t)NQ_MAX * CNT_PAD * sizeof(uint32_t)));
   MSI_TRY(vs->sel_keys.ensure((size_t)NQ_MAX * KP_MAX * sizeof(u64)));
@@ -1265,6 +1735,17 @@ int32_t finish_upload(msi_vs *vs, uint64_t n_rows, const char *what) {
     hipLaunchKernelGGL(vs_row_norms_kernel, dim3((uint32_t)((padded + 255) / 256)), dim3(256), 0, st,
                        vs->tiles.as<float4>(), (uint64_t)0, n_rows, vs->KB, vs->norm.as<float>(),
                        vs->inv_norm.as<float>());
+  if (vs->i8) {
+    // the int8 copy follows the f32 rows (whole: an update re-gathers every tile anyway)
+    MSI_TRY(vs->tiles8.ensure(std::max<uint64_t>(1, n_tiles) * vs->KB8 * 64 * sizeof(i32x4)));
+    MSI_TRY(vs->scale8.ensure(std::max<uint64_t>(16, padded) * sizeof(float)));
+    MSI_TRY(vs->i8small.ensure(64));
+    MSI_HIP_TRY(hipMemsetAsync(vs->i8small.p, 0, 64, st));
+    if (n_tiles)
+      hipLaunchKernelGGL(vs_quantize_rows_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, vs->tiles.as<float4>(),
+                         vs->inv_norm.as<float>(), n_rows, vs->KB, vs->tiles8.as<i32x4>(), vs->scale8.as<float>(),
+                         vs->i8small.as<uint32_t>());
+  }
   uint32_t nt32 = (uint32_t)n_tiles;
   MSI_HIP_TRY(hipMemcpyAsync(s.n_tiles, &nt32, sizeof(uint32_t), hipMemcpyHostToDevice, st));
   float ninf[NQ_MAX];
@@ -1334,6 +1815,80 @@ void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense, hipSt
 #undef MSI_SCAN_CASE
 }
 
+// The int8 sweep: instantiated for 1 / 2 / 3 / 4 / 6 / 8 / 12 query tiles (a sweep of fewer queries runs the next size up: its
+// spare query slots are zero fragments whose scores nobody keeps), RT row tiles per wave step by the accumulators that leaves
+// room for, GS = the largest of 4 / 3 / 2 that divides KB8 (dpad is a multiple of 128, so KB8 is even).
+uint32_t scan8_nqt_of(uint32_t nqt) {
+  static const uint32_t sizes[] = {1, 2, 3, 4, 6, 8, 12};
+  for (uint32_t v : sizes)
+    if (nqt <= v) return v;
+  return 12;
+}
+uint32_t scan8_gs_of(uint32_t KB8) { return KB8 % 4 == 0 ? 4u : (KB8 % 3 == 0 ? 3u : 2u); }
+#define MSI_SCAN8_RT(N) ((N) <= 3 ? 4 : ((N) <= 4 ? 3 : 2))
+#define MSI_SCAN8_EACH(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12)
+template <int GS>
+int32_t scan8_set_attributes() {
+#define MSI_X(N)                                                                                                          \
+  for (const void *fn : {reinterpret_cast<const void *>(&vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, true>),      \
+                         reinterpret_cast<const void *>(&vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, false>)})    \
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) return MSI_E_HIP;
+  MSI_SCAN8_EACH(MSI_X)
+#undef MSI_X
+  return MSI_OK;
+}
+template <int GS>
+void launch_scan8_gs(const Scan8Args &sa, uint32_t n, bool dense, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  switch (n) {
+#define MSI_X(N)                                                                                                         \
+  case N:                                                                                                                \
+    if (dense) hipLaunchKernelGGL((vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, true>), grid, block, lds, st, sa); \
+    else hipLaunchKernelGGL((vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, false>), grid, block, lds, st, sa);      \
+    break;
+    MSI_SCAN8_EACH(MSI_X)
+#undef MSI_X
+  }
+}
+// Experiments (MSI_VS_I8_VARIANT=<n>, read per sweep; 8 query tiles only): other shapes of the same kernel — waves per
+// workgroup, row tiles per wave step, KiB blocks per pipeline stage.  0 / unset: the default shape.
+#define MSI_SCAN8_VARIANTS(X) X(1, 16, 1, 4) X(2, 8, 1, 4) X(3, 8, 2, 2) X(4, 16, 1, 2) X(5, 16, 2, 2) X(6, 8, 4, 2) X(7, 16, 2, 1)
+bool launch_scan8_variant(int variant, uint32_t KB8, const Scan8Args &sa, bool dense, uint32_t n_wg, size_t lds, hipStream_t st) {
+  switch (variant) {
+#define MSI_X(V, W, R, G)                                                                                                 \
+  case V: {                                                                                                               \
+    if (KB8 % G) return false;                                                                                            \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vs_scan_i8_kernel<W, 8, R, G, true>),                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vs_scan_i8_kernel<W, 8, R, G, false>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);                                \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    if (dense) hipLaunchKernelGGL((vs_scan_i8_kernel<W, 8, R, G, true>), dim3(n_wg), dim3(W * 64), lds, st, sa);            \
+    else hipLaunchKernelGGL((vs_scan_i8_kernel<W, 8, R, G, false>), dim3(n_wg), dim3(W * 64), lds, st, sa);                \
+    return true;                                                                                                          \
+  }
+    MSI_SCAN8_VARIANTS(MSI_X)
+#undef MSI_X
+  }
+  return false;
+}
+void launch_scan8(msi_vs *vs, const Scan8Args &sa, uint32_t nqt, bool dense, hipStream_t st = nullptr, uint32_t grid_wgs = 0) {
+  const uint32_t n = scan8_nqt_of(nqt);
+  const size_t lds = scan8_lds_bytes(vs->KB8, n);
+  const dim3 grid(grid_wgs ? grid_wgs : vs->scan_grid8), block(SCAN_WAVES * 64);
+  if (!st) st = vs->ctx->stream;
+  if (n == 8) {
+    const char *v = getenv("MSI_VS_I8_VARIANT");
+    if (v && atoi(v) > 0 && launch_scan8_variant(atoi(v), vs->KB8, sa, dense, grid.x, lds, st)) return;
+  }
+  const uint32_t gs = scan8_gs_of(vs->KB8);
+  if (gs == 4) launch_scan8_gs<4>(sa, n, dense, grid, block, lds, st);
+  else if (gs == 3) launch_scan8_gs<3>(sa, n, dense, grid, block, lds, st);
+  else launch_scan8_gs<2>(sa, n, dense, grid, block, lds, st);
+}
+
 // One chunk of <= 16*nqt_max queries (one HBM sweep): planned against the scratch set that is current when it is planned,
 // then enqueued in three stages —
 //   pre   queries -> MFMA fragments, norms; the strided sample sweep and the thresholds it yields; counters zeroed
@@ -1344,12 +1899,15 @@ void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense, hipSt
 // of a chunk's time; the rest was serial in front of and behind it).
 struct Chunk {
   ScanArgs sa;
+  Scan8Args s8;
+  bool i8 = false;            // this chunk sweeps the int8 copy
   SelectArgs se;
   RescoreArgs ra;
   const float *d_queries = nullptr;
   Small s;
   float4 *qfrag = nullptr;
   bf16x8 *qfrag_bf = nullptr;
+  i32x4 *qfrag8 = nullptr;
   float *qrow = nullptr;
   void *gcnt = nullptr;
   uint32_t nq = 0, nqt = 0, k = 0, kp = 0, stride = 1, thr_rank = 0;
@@ -1386,12 +1944,17 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
   c.filtered = filtered;
   // candidates rescored beyond k: every row whose fast score lies within twice the proof's eps of the k-th must be among
   // them — a handful with bf16x3 (eps ~ 1e-5), a few dozen to a hundred with bf16x2 (eps ~ 4e-3)
-  const uint32_t slack = vs->big_slack ? KP_MAX : (vs->bf2 ? std::max<uint32_t>(108, 3 * k) : std::max<uint32_t>(12, k / 4));
+  // (the int8 sweep: eps ~ 1.8e-2 in cosine — on i.i.d. rows ~200 rows of 10 M lie within it of the 20th neighbour)
+  c.i8 = vs->i8 && vs->i8_now;
+  const uint32_t slack = vs->big_slack ? KP_MAX
+                         : c.i8 ? std::max<uint32_t>(1004, 3 * k)
+                                : (vs->bf2 ? std::max<uint32_t>(108, 3 * k) : std::max<uint32_t>(12, k / 4));
   const uint32_t kp = c.kp = std::min<uint32_t>(k + slack, KP_MAX);
   c.nqt = (nq + QT - 1) / QT;
   c.qfrag = vs->qfrag.as<float4>();
   c.qfrag_bf = vs->qfrag_bf.as<bf16x8>();
   c.qrow = vs->qrow.as<float>();
+  c.qfrag8 = vs->qfrag8.as<i32x4>();
   c.gcnt = vs->gcnt.p;
   const uint32_t *list = nullptr;
   const uint16_t *tmask = nullptr;
@@ -1438,6 +2001,30 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
   sa.KB = vs->KB;
   sa.stride = stride;
   sa.nq = nq;
+  if (c.i8) {
+    Scan8Args &s8 = c.s8;
+    s8.tiles8 = vs->tiles8.as<i32x4>();
+    s8.scale8 = vs->scale8.as<float>();
+    s8.inv_norm = sa.inv_norm;
+    s8.i8small = vs->i8small.as<uint32_t>();
+    s8.qfrag8 = vs->qfrag8.as<i32x4>();
+    s8.sqs = s.sqs;
+    s8.theta = sa.theta;
+    s8.degth = sa.degth;
+    s8.n_items_ptr = sa.n_items_ptr;
+    s8.list = sa.list;
+    s8.tmask = sa.tmask;
+    s8.gkeys = sa.gkeys;
+    s8.gcnt = sa.gcnt;
+    s8.overflow = sa.overflow;
+    s8.dense = sa.dense;
+    s8.n_rows = sa.n_rows;
+    s8.dstride = sa.dstride;
+    s8.capg = sa.capg;
+    s8.KB8 = vs->KB8;
+    s8.stride = sa.stride;
+    s8.nq = nq;
+  }
   SelectArgs &se = c.se;
   se.gkeys = vs->gkeys.as<u64>();
   se.gcnt = vs->gcnt.as<uint32_t>();
@@ -1467,7 +2054,8 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
   ra.k = k;
   // bound on |fast cos - reference cos|: f32 accumulation of n terms (gamma_n, n = dpad or
   // 3·dpad, with a factor 2 for the MFMA adder tree) + the bf16x3 split's 3·2^-18 per product
-  ra.eps = scan_eps(vs);
+  ra.eps = c.i8 ? 0.0f : scan_eps(vs);   // (the int8 sweep's bound is per query: s.epsq, written by vs_prep_queries_i8_kernel)
+  ra.eps_q = c.i8 ? s.epsq : nullptr;
   ra.out_docids = d_out_docids;
   ra.out_dist = d_out_dist;
   ra.out_counts = d_out_counts;
@@ -1486,12 +2074,20 @@ int32_t chunk_pre(msi_vs *vs, Chunk &c, hipStream_t st) {
   hipLaunchKernelGGL(vs_prep_queries_kernel, dim3(c.nqt * QT), dim3(256), (size_t)vs->dpad * sizeof(float), st,
                      c.d_queries, c.nq, vs->dim, vs->KB, c.qfrag, c.qfrag_bf, c.qrow, c.s.qn, c.s.inv_qn, c.s.degth,
                      vs->s16 ? 1u : (vs->bf2 ? 2u : 0u));
+  if (c.i8) {
+    // the f32 terms every level carries (reference accumulation of dpad terms, the scales' roundings) + slack
+    const float eps_base = (4.0f * (float)vs->dpad + 64.0f) * 5.9604645e-8f + 1e-5f;
+    hipLaunchKernelGGL(vs_prep_queries_i8_kernel, dim3(c.nqt * QT), dim3(256), 0, st, c.qrow, c.s.qn, c.s.inv_qn, c.nq, vs->dpad,
+                       c.qfrag8, c.s.sqs, c.s.epsq, vs->i8small.as<uint32_t>(), eps_base);
+  }
   MSI_HIP_TRY(hipMemsetAsync(c.s.overflow, 0, sizeof(uint32_t), st));
   if (c.stride > 1) {
     // sample sweep -> thresholds
-    launch_scan(vs, c.sa, c.nqt, true, st, c.grid_sample);
+    if (c.i8) launch_scan8(vs, c.s8, c.nqt, true, st, c.grid_sample);
+    else launch_scan(vs, c.sa, c.nqt, true, st, c.grid_sample);
     vs->scan_launches++;
     vs->scan_tiles += c.dense_items;
+    if (c.i8) vs->i8_scan_tiles += c.dense_items;
     c.se.K = c.thr_rank;
     c.se.mode = 0;
     hipLaunchKernelGGL(vs_select_kernel, dim3(c.nqt * QT), dim3(SEL_THREADS), 0, st, c.se);
@@ -1506,16 +2102,22 @@ int32_t chunk_main(msi_vs *vs, Chunk &c, hipStream_t st) {
   if (c.stride == 1) {
     // dense main sweep; the K' best come straight out of the score matrix
     vs->scan_timer.begin(ctx, st);
-    launch_scan(vs, c.sa, c.nqt, true, st, c.grid_main);
+    if (c.i8) launch_scan8(vs, c.s8, c.nqt, true, st, c.grid_main);
+    else launch_scan(vs, c.sa, c.nqt, true, st, c.grid_main);
     vs->scan_timer.end(ctx);
   } else {
     // full sweep, sparse epilogue
-    c.sa.theta = c.s.theta;
-    c.sa.stride = 1;
+    c.sa.theta = c.s8.theta = c.s.theta;
+    c.sa.stride = c.s8.stride = 1;
     vs->scan_timer.begin(ctx, st);
-    launch_scan(vs, c.sa, c.nqt, false, st, c.grid_main);
+    if (c.i8) launch_scan8(vs, c.s8, c.nqt, false, st, c.grid_main);
+    else launch_scan(vs, c.sa, c.nqt, false, st, c.grid_main);
     vs->scan_timer.end(ctx);
     c.se.dense = nullptr;
+  }
+  if (c.i8) {
+    vs->i8_sweeps++;
+    vs->i8_scan_tiles += c.n_tiles;
   }
   vs->scan_launches++;
   vs->scan_tiles += c.n_tiles;
@@ -1561,6 +2163,7 @@ int32_t enqueue_search(msi_vs *vs, const float *d_queries, uint32_t nq, uint32_t
 void swap_scratch(msi_vs *vs) {
   std::swap(vs->qfrag, vs->scr2.qfrag);
   std::swap(vs->qfrag_bf, vs->scr2.qfrag_bf);
+  std::swap(vs->qfrag8, vs->scr2.qfrag8);
   std::swap(vs->qrow, vs->scr2.qrow);
   std::swap(vs->qsmall, vs->scr2.qsmall);
   std::swap(vs->gkeys, vs->scr2.gkeys);
@@ -1652,6 +2255,39 @@ int32_t search_device_pipelined_impl(msi_vs *vs, const float *d_queries, uint32_
   return MSI_OK;
 }
 
+// The levels of effort of a store, cheapest first (msi_vs::level): the int8 candidate sweep when the store keeps the copy;
+// the store's f32 contraction (bf16x2 by default) with the usual K'; the same with K' = KP_MAX; bf16x3 with K' = KP_MAX
+// (bf16x2 stores).  What the last level cannot prove is answered exhaustively.
+struct Level { bool i8, x2, big; };
+constexpr uint32_t MAX_LEVELS = 5;
+uint32_t vs_levels(const msi_vs *vs, Level out[MAX_LEVELS]) {
+  uint32_t n = 0;
+  if (vs->i8) {
+    out[n++] = Level{true, vs->bf2, false};   // the int8 sweep, K' = k + 1004 ...
+    out[n++] = Level{true, vs->bf2, true};    // ... and with K' = KP_MAX for the few queries with more rows inside its bound
+  }
+  out[n++] = Level{false, vs->bf2, false};
+  out[n++] = Level{false, vs->bf2, true};
+  if (vs->bf2) out[n++] = Level{false, false, true};
+  return n;
+}
+// MSI_VS_FIRST_LEVEL=<n> | f32 (read per call; measurements and tests): searches start at level n at least; "f32" = the first
+// level that sweeps the f32 rows (rounds 1-4's level 0)
+uint32_t vs_first_level(const Level *levels, uint32_t n_levels) {
+  const char *e = getenv("MSI_VS_FIRST_LEVEL");
+  if (!e) return 0u;
+  if (!strcmp(e, "f32")) {
+    for (uint32_t i = 0; i < n_levels; ++i)
+      if (!levels[i].i8) return i;
+    return 0u;
+  }
+  return (uint32_t)std::max(0, atoi(e));
+}
+uint32_t vs_level_batch(const msi_vs *vs, const Level &l) {
+  if (l.i8) return vs->nqt8_max * QT;
+  return ((vs->bf2 && !l.x2) ? vs->nqt3_max : vs->nqt_max) * QT;
+}
+
 int32_t exhaustive_one(msi_vs *vs, uint32_t qj, uint32_t k, const u64 *d_fbits, uint64_t nbits,
                        uint32_t *d_out_docids, float *d_out_dist, uint32_t *d_out_count) {
   hipStream_t st = vs->ctx->stream;
@@ -1697,7 +2333,7 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
   // "f32"
   const char *math = getenv("MSI_VS_SCAN_MATH");
   const bool bf2 = !s16 && !(math && (strcmp(math, "bf16x3") == 0 || strcmp(math, "f32") == 0));
-  const uint32_t nqt_cap = bf2 ? (uint32_t)NQT_MAX : 3u;
+  const uint32_t nqt_cap = bf2 ? (uint32_t)NQT_F32_MAX : 3u;
   uint32_t nqt_max = 1;
   while (nqt_max < nqt_cap && scan_lds_bytes(KB, nqt_max + 1, s16, bf2) <= LDS_MAX) ++nqt_max;
   // the bf16x3 second opinion keeps hi AND lo halves of the queries in LDS: twice the bytes per query tile, so its
@@ -1747,6 +2383,37 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
     if (v >= 1 && v <= 4) wg_per_cu = (uint32_t)v;
   }
   vs->scan_grid = (uint32_t)(ctx->n_cu_scan ? ctx->n_cu_scan : ctx->n_cu) * wg_per_cu;
+  // the int8 copy (f32 stores): MSI_VS_I8=0 keeps the store without it; MSI_VS_I8_QUERY_TILES caps the queries per sweep
+  {
+    const char *e8 = getenv("MSI_VS_I8");
+    vs->i8 = !s16 && !(e8 && e8[0] == '0') && (dpad % 64) == 0 && (uint64_t)dpad * 127ull * 127ull < (1ull << 31);
+    if (vs->i8) {
+      vs->KB8 = dpad / 64;
+      // 8 query tiles (128 queries) per sweep by default: with 12 the accumulators (2 row tiles x 12 x 4 registers) and the
+      // row buffers no longer fit the 256 registers a wave of a 512-thread workgroup has (139 spilled in the sparse epilogue)
+      uint32_t cap8 = 8;
+      if (const char *e = getenv("MSI_VS_I8_QUERY_TILES")) cap8 = (uint32_t)std::max(1, std::min<int>(NQT_MAX, atoi(e)));
+      vs->nqt8_max = 1;
+      while (vs->nqt8_max < cap8 && scan8_lds_bytes(vs->KB8, scan8_nqt_of(vs->nqt8_max + 1)) <= LDS_MAX) ++vs->nqt8_max;
+      if (scan8_lds_bytes(vs->KB8, 1) > LDS_MAX) vs->i8 = false;
+    }
+    if (vs->i8) {
+      const uint32_t gs = scan8_gs_of(vs->KB8);
+      const int32_t st8 = gs == 4 ? scan8_set_attributes<4>() : (gs == 3 ? scan8_set_attributes<3>() : scan8_set_attributes<2>());
+      if (st8 != MSI_OK) {
+        msi_set_error("hipFuncSetAttribute(vs_scan_i8) failed");
+        msi_ctx_release(ctx);
+        delete vs;
+        return st8;
+      }
+      uint32_t wg8 = scan8_lds_bytes(vs->KB8, scan8_nqt_of(vs->nqt8_max)) <= LDS_MAX / 2 ? 2 : 1;
+      if (const char *e = getenv("MSI_VS_WG_PER_CU")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4) wg8 = (uint32_t)v;
+      }
+      vs->scan_grid8 = (uint32_t)(ctx->n_cu_scan ? ctx->n_cu_scan : ctx->n_cu) * wg8;
+    }
+  }
   *out = vs;
   return MSI_OK;
 }
@@ -1761,7 +2428,8 @@ void msi_vs_destroy(msi_vs *vs) {
     DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qfrag_bf, &vs->qrow,
                       &vs->qsmall, &vs->gkeys, &vs->gcnt, &vs->gsmall, &vs->sel_keys, &vs->dense, &vs->tmask,
                       &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp, &vs->resc_keys,
-                      &vs->tiles_next, &vs->docids_next, &vs->norm_next, &vs->inv_norm_next, &vs->add_tiles, &vs->add_docids, &vs->row_map};
+                      &vs->tiles_next, &vs->docids_next, &vs->norm_next, &vs->inv_norm_next, &vs->add_tiles, &vs->add_docids, &vs->row_map,
+                      &vs->tiles8, &vs->scale8, &vs->i8small, &vs->qfrag8, &vs->rerun_q, &vs->rerun_flags, &vs->scr2.qfrag8};
     for (DevBuf *b : bufs) b->release();
     DevBuf *bufs2[] = {&vs->scr2.qfrag, &vs->scr2.qfrag_bf, &vs->scr2.qrow, &vs->scr2.qsmall, &vs->scr2.gkeys, &vs->scr2.gcnt,
                        &vs->scr2.gsmall, &vs->scr2.sel_keys, &vs->scr2.dense, &vs->scr2.resc_keys, &vs->fsmall};
@@ -1886,7 +2554,7 @@ int32_t msi_vs_update(msi_vs *vs, const uint32_t *remove_docids, uint64_t n_remo
 
 uint64_t msi_vs_len(const msi_vs *vs) { return vs ? vs->n_rows : 0; }
 uint32_t msi_vs_dim(const msi_vs *vs) { return vs ? vs->dim : 0; }
-uint32_t msi_vs_max_batch(const msi_vs *vs) { return vs ? vs->nqt_max * QT : 0; }
+uint32_t msi_vs_max_batch(const msi_vs *vs) { return vs ? (vs->i8 ? vs->nqt8_max : vs->nqt_max) * QT : 0; }
 
 int32_t msi_vs_get_vector(msi_vs *vs, uint32_t docid, float *out_row, int32_t *out_found) {
   if (!vs || !out_row || !out_found) {
@@ -1942,22 +2610,117 @@ int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries, uint32_t n_quer
     if (d_inexact) MSI_HIP_TRY(hipMemsetAsync(d_inexact, 0, n_queries * sizeof(uint32_t), vs->ctx->stream));
     return MSI_OK;
   }
-  // one HBM sweep per chunk of msi_vs_max_batch() queries
-  const uint32_t step = vs->nqt_max * QT;
-  // MSI_VS_PIPELINE=1: the chunks' stages on two streams (search_device_pipelined).  Off by default — measured at C4 (768
-  // queries, 8 sweeps): 42.25 ms against 42.05 ms on one stream; a sweep's workgroup holds its CU's whole LDS, so the
-  // second stream's kernels wait for the sweep anyway, and with CUs left free for them (MSI_VS_SPARE_CUS=8 / 16) the sample
-  // sweep crawls beside the HBM-saturating one: 50.2 / 47.0 ms (profiles/r4_vs_pipeline.txt)
+  // MSI_VS_PIPELINE=1: the chunks' stages on two streams (search_device_pipelined, the store's f32 contraction only).  Off by
+  // default — measured at C4 (768 queries, 8 sweeps): 42.25 ms against 42.05 ms on one stream; a sweep's workgroup holds its
+  // CU's whole LDS, so the second stream's kernels wait for the sweep anyway (profiles/r4_vs_pipeline.txt)
   const char *pipe_knob = getenv("MSI_VS_PIPELINE");   // (read per call: tests switch it)
   const bool pipeline_on = pipe_knob && pipe_knob[0] == '1';
-  if (n_queries > step && pipeline_on)
+  if (n_queries > vs->nqt_max * QT && pipeline_on)
     return search_device_pipelined(vs, d_queries, n_queries, k, (const u64 *)d_filter_bits, filter_nbits, d_out_docids, d_out_dist,
                                    d_out_counts, d_inexact);
+  // Levels of effort, as the host entry point runs them (vs_search_direct) — and since round 5 this entry point ALWAYS
+  // ANSWERS too (store.rs:638-675 does): the first pass sweeps every chunk at the store's current level; the queries it
+  // could not prove are gathered and re-run level by level, then exhaustively, by the library itself.  That costs one
+  // synchronisation of the context's stream per call (the flags have to be read); MSI_VS_DEVICE_RERUN=0 restores the old
+  // contract (asynchronous, unproven queries only reported through d_inexact).
+  static const bool adapt = !(getenv("MSI_VS_ADAPT") && getenv("MSI_VS_ADAPT")[0] == '0');
+  const char *rr = getenv("MSI_VS_DEVICE_RERUN");
+  const bool rerun = !(rr && rr[0] == '0');
+  hipStream_t st = vs->ctx->stream;
+  const bool store_x2 = vs->bf2;
+  Level levels[MAX_LEVELS];
+  const uint32_t n_levels = vs_levels(vs, levels);
+  const uint32_t l0 = std::min(std::max(adapt ? vs->level : 0u, vs_first_level(levels, n_levels)), n_levels - 1);
+  auto with_level = [&](const Level &l, auto &&fn) -> int32_t {
+    vs->bf2 = l.x2;
+    vs->big_slack = l.big;
+    vs->i8_now = l.i8;
+    const int32_t r = fn();
+    vs->bf2 = store_x2;
+    vs->big_slack = false;
+    vs->i8_now = false;
+    return r;
+  };
+  uint32_t *flags = d_inexact;
+  if (rerun) {
+    MSI_TRY(vs->rerun_flags.ensure((size_t)n_queries * sizeof(uint32_t)));
+    flags = vs->rerun_flags.as<uint32_t>();
+  }
+  const uint32_t step = vs_level_batch(vs, levels[l0]);
   for (uint32_t q0 = 0; q0 < n_queries; q0 += step) {
     const uint32_t nq = std::min(step, n_queries - q0);
-    MSI_TRY(enqueue_search(vs, d_queries + (size_t)q0 * vs->dim, nq, k, (const u64 *)d_filter_bits, filter_nbits,
-                           d_out_docids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k, d_out_counts + q0,
-                           d_inexact ? d_inexact + q0 : nullptr));
+    MSI_TRY(with_level(levels[l0], [&] {
+      return enqueue_search(vs, d_queries + (size_t)q0 * vs->dim, nq, k, (const u64 *)d_filter_bits, filter_nbits,
+                            d_out_docids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k, d_out_counts + q0, flags ? flags + q0 : nullptr);
+    }));
+    ++vs->level_sweeps[l0];
+  }
+  if (!rerun) return MSI_OK;
+  std::vector<uint32_t> h_flags(n_queries);
+  MSI_HIP_TRY(hipMemcpyAsync(h_flags.data(), flags, (size_t)n_queries * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MSI_HIP_TRY(hipStreamSynchronize(st));
+  if (d_inexact) MSI_HIP_TRY(hipMemsetAsync(d_inexact, 0, (size_t)n_queries * sizeof(uint32_t), st));   // every query is answered
+  std::vector<uint32_t> pending;
+  for (uint32_t j = 0; j < n_queries; ++j)
+    if (h_flags[j]) pending.push_back(j);
+  if (adapt && n_queries >= (uint32_t)QT) {   // the same running share as the host entry point keeps
+    vs->level_ema = 0.5f * vs->level_ema + 0.5f * (float)pending.size() / (float)n_queries;
+    if (vs->level_left > 0 && --vs->level_left == 0 && vs->level > 0) {
+      --vs->level;
+      vs->level_ema = 0.0f;
+    } else if (vs->level_ema > 0.25f && vs->level + 1 < n_levels) {
+      ++vs->level;
+      vs->level_left = 256;
+      vs->level_ema = 0.0f;
+    } else if (vs->level_ema > 0.25f) {
+      vs->level_left = 256;
+    }
+  }
+  if (pending.empty()) return MSI_OK;
+  vs->device_rerun_queries += pending.size();
+  const uint32_t kk = std::max<uint32_t>(1, k);
+  MSI_TRY(vs->out_docids.ensure((size_t)NQ_MAX * kk * sizeof(uint32_t)));
+  MSI_TRY(vs->out_dist.ensure((size_t)NQ_MAX * kk * sizeof(float)));
+  MSI_TRY(vs->rerun_q.ensure((size_t)NQ_MAX * vs->dim * sizeof(float)));
+  Small s = small_of(vs);
+  // (a first pass that already ran at the last level is repeated at it for the pending queries: the exhaustive pass reads
+  // the query rows the sweep before it prepared)
+  for (uint32_t lvl = std::min(l0 + 1, n_levels - 1); lvl < n_levels && !pending.empty(); ++lvl) {
+    const uint32_t sub = vs_level_batch(vs, levels[lvl]);
+    std::vector<uint32_t> next;
+    for (size_t f0 = 0; f0 < pending.size(); f0 += sub) {
+      const uint32_t nf = (uint32_t)std::min<size_t>(sub, pending.size() - f0);
+      for (uint32_t i = 0; i < nf; ++i)
+        MSI_HIP_TRY(hipMemcpyAsync(vs->rerun_q.as<float>() + (size_t)i * vs->dim, d_queries + (size_t)pending[f0 + i] * vs->dim,
+                                   (size_t)vs->dim * sizeof(float), hipMemcpyDeviceToDevice, st));
+      MSI_TRY(with_level(levels[lvl], [&] {
+        return enqueue_search(vs, vs->rerun_q.as<float>(), nf, k, (const u64 *)d_filter_bits, filter_nbits,
+                              vs->out_docids.as<uint32_t>(), vs->out_dist.as<float>(), s.counts, s.inexact);
+      }));
+      ++vs->level_sweeps[lvl];
+      uint32_t f2[NQ_MAX];
+      MSI_HIP_TRY(hipMemcpyAsync(f2, s.inexact, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      MSI_HIP_TRY(hipStreamSynchronize(st));
+      for (uint32_t i = 0; i < nf; ++i) {
+        const uint32_t j = pending[f0 + i];
+        if (f2[i]) {
+          if (lvl + 1 == n_levels) {
+            MSI_TRY(exhaustive_one(vs, i, k, (const u64 *)d_filter_bits, filter_nbits, d_out_docids + (size_t)j * k,
+                                   d_out_dist + (size_t)j * k, d_out_counts + j));
+          } else {
+            next.push_back(j);
+          }
+          continue;
+        }
+        MSI_HIP_TRY(hipMemcpyAsync(d_out_docids + (size_t)j * k, vs->out_docids.as<uint32_t>() + (size_t)i * k, (size_t)k * sizeof(uint32_t),
+                                   hipMemcpyDeviceToDevice, st));
+        MSI_HIP_TRY(hipMemcpyAsync(d_out_dist + (size_t)j * k, vs->out_dist.as<float>() + (size_t)i * k, (size_t)k * sizeof(float),
+                                   hipMemcpyDeviceToDevice, st));
+        MSI_HIP_TRY(hipMemcpyAsync(d_out_counts + j, s.counts + i, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+      }
+      MSI_HIP_TRY(hipStreamSynchronize(st));   // (the staging rows and result buffers are reused by the next batch)
+    }
+    pending.swap(next);
   }
   return MSI_OK;
 }
@@ -2131,20 +2894,21 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
   MSI_TRY(vs->out_docids.ensure((size_t)NQ_MAX * kk * sizeof(uint32_t)));
   MSI_TRY(vs->out_dist.ensure((size_t)NQ_MAX * kk * sizeof(float)));
   static const bool adapt = !(getenv("MSI_VS_ADAPT") && getenv("MSI_VS_ADAPT")[0] == '0');
-  // the levels of effort of this store (msi_vs::level): {bf16x2 contraction?, K' = KP_MAX?}
-  struct Level { bool x2, big; };
+  // the levels of effort of this store (msi_vs::level, vs_levels)
   const bool store_x2 = vs->bf2;
-  const Level levels[3] = {{store_x2, false}, {store_x2, true}, {false, true}};
-  const uint32_t n_levels = store_x2 ? 3u : 2u;
-  auto batch_of = [&](const Level &l) { return ((store_x2 && !l.x2) ? vs->nqt3_max : vs->nqt_max) * QT; };
+  Level levels[MAX_LEVELS];
+  const uint32_t n_levels = vs_levels(vs, levels);
+  auto batch_of = [&](const Level &l) { return vs_level_batch(vs, l); };
   // one sweep at level `l` for the nf queries whose rows are already in vs->qraw: results in vs->out_*, flags / counts in h_*
   auto sweep = [&](const Level &l, uint32_t nf, uint32_t *h_flags, uint32_t *h_counts) -> int32_t {
     vs->bf2 = l.x2;
     vs->big_slack = l.big;
+    vs->i8_now = l.i8;
     const int32_t st1 = enqueue_search(vs, vs->qraw.as<float>(), nf, k, d_fbits, filter_nbits, vs->out_docids.as<uint32_t>(),
                                        vs->out_dist.as<float>(), s.counts, s.inexact);
     vs->bf2 = store_x2;
     vs->big_slack = false;
+    vs->i8_now = false;
     MSI_TRY(st1);
     MSI_HIP_TRY(hipMemcpyAsync(h_flags, s.inexact, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MSI_HIP_TRY(hipMemcpyAsync(h_counts, s.counts, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -2157,7 +2921,7 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
       msi_set_error("msi_vs_search: cancelled");
       return MSI_E_CANCELLED;
     }
-    const uint32_t l0 = adapt ? std::min(vs->level, n_levels - 1) : 0u;
+    const uint32_t l0 = std::min(std::max(adapt ? vs->level : 0u, vs_first_level(levels, n_levels)), n_levels - 1);
     step = batch_of(levels[l0]);
     const uint32_t nq = std::min<uint32_t>(step, n_queries - q0);
     if (k == 0 || vs->n_rows == 0) {
@@ -2169,7 +2933,8 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
     uint32_t h_flags[NQ_MAX], h_counts[NQ_MAX];
     MSI_TRY(sweep(levels[l0], nq, h_flags, h_counts));
     ++vs->level_sweeps[l0];
-    if (levels[l0].x2) ++vs->x2_sweeps;
+    if (levels[l0].i8) {}
+    else if (levels[l0].x2) ++vs->x2_sweeps;
     else if (store_x2) ++vs->x3_first_sweeps;
     // what this sweep proved leaves now (the re-runs below prepare their own query rows and reuse the result buffers)
     MSI_HIP_TRY(hipMemcpyAsync(out_docids + (size_t)q0 * k, vs->out_docids.p, (size_t)nq * k * sizeof(uint32_t),
@@ -2195,7 +2960,7 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
         vs->level_left = 256;            // (already at the last level: stay)
       }
     }
-    if (levels[l0].x2 && !levels[l0].big) vs->second_opinion_queries += pending.size();
+    if (!levels[l0].i8 && levels[l0].x2 && !levels[l0].big) vs->second_opinion_queries += pending.size();
     // What the sweep that JUST ran (its query rows are still prepared in vs->qrow, row i = query idx[i] of this chunk) could
     // not prove and no further level can: answered exhaustively in the reference arithmetic, results straight to the caller.
     auto exhaustive_now = [&](const std::vector<uint32_t> &rows_i, const std::vector<uint32_t> &idx) -> int32_t {
@@ -2310,15 +3075,53 @@ int32_t msi_vs_debug_fast_scores(msi_vs *vs, const float *queries, uint32_t n_qu
   sa.KB = vs->KB;
   sa.stride = 1;
   sa.nq = n_queries;
-  if (vs->n_rows) launch_scan(vs, sa, nqt, true);
+  // MSI_VS_DEBUG_I8=1 (tests): the int8 sweep's scores and the largest per-query bound of the batch
+  const char *d8 = getenv("MSI_VS_DEBUG_I8");
+  const bool use8 = vs->i8 && d8 && d8[0] == '1';
+  if (use8) {
+    const float eps_base = (4.0f * (float)vs->dpad + 64.0f) * 5.9604645e-8f + 1e-5f;
+    hipLaunchKernelGGL(vs_prep_queries_i8_kernel, dim3(nqt * QT), dim3(256), 0, st, vs->qrow.as<float>(), s.qn, s.inv_qn, n_queries,
+                       vs->dpad, vs->qfrag8.as<i32x4>(), s.sqs, s.epsq, vs->i8small.as<uint32_t>(), eps_base);
+    Scan8Args s8;
+    memset(&s8, 0, sizeof(s8));
+    s8.tiles8 = vs->tiles8.as<i32x4>();
+    s8.scale8 = vs->scale8.as<float>();
+    s8.inv_norm = sa.inv_norm;
+    s8.i8small = vs->i8small.as<uint32_t>();
+    s8.qfrag8 = vs->qfrag8.as<i32x4>();
+    s8.sqs = s.sqs;
+    s8.theta = sa.theta;
+    s8.degth = sa.degth;
+    s8.n_items_ptr = sa.n_items_ptr;
+    s8.gkeys = sa.gkeys;
+    s8.gcnt = sa.gcnt;
+    s8.overflow = sa.overflow;
+    s8.dense = sa.dense;
+    s8.n_rows = sa.n_rows;
+    s8.dstride = dstride;
+    s8.capg = sa.capg;
+    s8.KB8 = vs->KB8;
+    s8.stride = 1;
+    s8.nq = n_queries;
+    if (vs->n_rows) launch_scan8(vs, s8, nqt, true);
+  } else if (vs->n_rows) {
+    launch_scan(vs, sa, nqt, true);
+  }
   MSI_HIP_TRY(hipGetLastError());
   for (uint32_t j = 0; j < n_queries; ++j)
     if (vs->n_rows)
       MSI_HIP_TRY(hipMemcpyAsync(out_scores + (size_t)j * vs->n_rows, vs->dense.as<float>() + (size_t)j * dstride,
                                  vs->n_rows * sizeof(float), hipMemcpyDeviceToHost, st));
+  float h_epsq[NQ_MAX];
+  if (use8) MSI_HIP_TRY(hipMemcpyAsync(h_epsq, s.epsq, n_queries * sizeof(float), hipMemcpyDeviceToHost, st));
   MSI_HIP_TRY(hipStreamSynchronize(st));
-  if (out_eps)
+  if (out_eps) {
     *out_eps = scan_eps(vs);
+    if (use8) {
+      *out_eps = 0.f;
+      for (uint32_t j = 0; j < n_queries; ++j) *out_eps = std::max(*out_eps, h_epsq[j]);
+    }
+  }
   return MSI_OK;
 }
 
@@ -2339,8 +3142,15 @@ int32_t msi_vs_get_stats(const msi_vs *vs, msi_vs_stats *out) {
   out->second_opinion_queries = vs->second_opinion_queries;
   out->x3_first_sweeps = vs->x3_first_sweeps;
   out->x2_sweeps = vs->x2_sweeps;
-  for (int i = 0; i < 3; ++i) out->level_sweeps[i] = vs->level_sweeps[i];
+  // (level_sweeps of the ABI: the f32 levels; a store with an int8 copy counts its level 0 in i8_sweeps)
+  for (int i = 0; i < 3; ++i) out->level_sweeps[i] = vs->level_sweeps[i + (vs->i8 ? 2 : 0)];
   out->bytes_per_tile = (uint64_t)vs->KB * 1024;
+  out->i8_bytes_per_tile = vs->i8 ? (uint64_t)vs->KB8 * 1024 + 16 * 8 : 0;
+  out->i8_sweeps = vs->i8_sweeps;
+  out->i8_scan_tiles = vs->i8_scan_tiles;
+  out->device_rerun_queries = vs->device_rerun_queries;
+  out->i8_queries_per_sweep = vs->i8 ? vs->nqt8_max * QT : 0;
+  out->f32_queries_per_sweep = vs->nqt_max * QT;
   return MSI_OK;
 }
 

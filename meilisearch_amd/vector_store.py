@@ -150,7 +150,10 @@ class GpuStore:
         return {"scan_launches": s.scan_launches, "scan_tiles": s.scan_tiles,
                 "exhaustive_reruns": s.exhaustive_reruns, "bytes_per_tile": s.bytes_per_tile,
                 "second_opinion_queries": s.second_opinion_queries, "x3_first_sweeps": s.x3_first_sweeps,
-                "x2_sweeps": s.x2_sweeps, "level_sweeps": [int(x) for x in s.level_sweeps]}
+                "x2_sweeps": s.x2_sweeps, "level_sweeps": [int(x) for x in s.level_sweeps],
+                "i8_bytes_per_tile": int(s.i8_bytes_per_tile), "i8_sweeps": int(s.i8_sweeps),
+                "device_rerun_queries": int(s.device_rerun_queries), "i8_queries_per_sweep": int(s.i8_queries_per_sweep),
+                "f32_queries_per_sweep": int(s.f32_queries_per_sweep), "i8_scan_tiles": int(s.i8_scan_tiles)}
 
     def close(self):
         if self._h:

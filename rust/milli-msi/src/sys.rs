@@ -29,7 +29,7 @@ pub const MSI_CRIT_GEO_SORT: i32 = 9;
 pub const MSI_SCORE_GEO_SORT: u32 = 9;
 pub const MSI_BITS_NO_SLOT: u32 = 0xFFFF_FFFF;
 
-pub const MSI_ABI_VERSION: i32 = 2; // include/msi.h: MSI_ABI_VERSION
+pub const MSI_ABI_VERSION: i32 = 3; // include/msi.h: MSI_ABI_VERSION
 pub const MSI_OK: i32 = 0;
 pub const MSI_E_INVALID: i32 = -1;
 pub const MSI_E_NO_DEVICE: i32 = -2;

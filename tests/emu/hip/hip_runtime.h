@@ -88,6 +88,8 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 template <typename F>
 inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+template <typename F>
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, F, int, size_t) { *n = 4; return hipSuccess; }
 // MSI_EMU_DEVICES emulated devices (default 1): they share the host's memory and the one launch lock — what differs per
 // device is what the host code keeps per device (contexts, streams, stores, the current-device guard of every entry point)
 inline int hipemu_device_count() {
@@ -167,7 +169,7 @@ namespace hipemu {
 
 constexpr size_t STACK_BYTES = 64 * 1024;
 enum LaneState { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
-enum WaveOp { OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_SHFL_DOWN, OP_SHFL_UP, OP_ANY, OP_ALL, OP_FIRST, OP_MFMA_F32X4, OP_MFMA_BF16X32 };
+enum WaveOp { OP_BALLOT, OP_SHFL, OP_SHFL_XOR, OP_SHFL_DOWN, OP_SHFL_UP, OP_ANY, OP_ALL, OP_FIRST, OP_MFMA_F32X4, OP_MFMA_BF16X32, OP_MFMA_I8X64 };
 
 // Context switch: on x86-64 six callee-saved registers and the stack pointer (swapcontext would make two signal-mask
 // system calls per switch — most of the run time of this tier); ucontext elsewhere.
@@ -197,6 +199,8 @@ struct Lane {
   int param = 0;
   uint64_t value = 0;   // deposited by the lane, replaced by the result
   float fa[8], fb[8], fc[4];  // MFMA operands of the lane (A and B fragments widened to f32), C in / D out
+  signed char ia[16], ib[16];  // v_mfma_i32_16x16x64_i8: the lane's 16 bytes of A and of B
+  int ic[4];                   // ... C in / D out
   void *stack = nullptr;
 };
 
@@ -287,6 +291,28 @@ inline void resolve_wave(unsigned w0, unsigned w1) {
       if (in[i]) {
         if (val[i]) { ballot |= 1ull << i; any = true; } else all = false;
       }
+    if (op == OP_MFMA_I8X64) {
+      // v_mfma_i32_16x16x64_i8: lane l holds A[l % 16][16 * (l / 16) .. + 16) and B[the same k][l % 16] as 16 signed bytes each,
+      // D[4 * (l / 16) + r][l % 16] in its r-th accumulator register; exact i32 accumulation
+      int D[16][16];
+      for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+          int acc = 0;
+          for (int g4 = 0; g4 < 4; ++g4)
+            for (int t = 0; t < 16; ++t) {
+              const unsigned la = (unsigned)(g4 * 16 + i), lb = (unsigned)(g4 * 16 + j);
+              if (w0 + la < w1 && w0 + lb < w1 && in[la] && in[lb]) acc += (int)g.lanes[w0 + la].ia[t] * (int)g.lanes[w0 + lb].ib[t];
+            }
+          D[i][j] = acc;
+        }
+      for (unsigned l = 0; l < w1 - w0; ++l)
+        if (in[l]) {
+          Lane &ln = g.lanes[w0 + l];
+          for (int r = 0; r < 4; ++r) ln.ic[r] += D[4 * (l / 16) + r][l % 16];
+          ln.state = RUNNABLE;
+        }
+      continue;
+    }
     if (op == OP_MFMA_F32X4 || op == OP_MFMA_BF16X32) {
       // D = A x B + C over the whole wave (CDNA3/4 ISA fragment layouts): lane l holds A[l % 16][kb .. kb + K),
       // B[kb .. kb + K)[l % 16] with kb = K * (l / 16) (K = 1 for 16x16x4 f32, 8 for 16x16x32 bf16) and
@@ -475,6 +501,19 @@ inline hipemu_f32x4 hipemu_mfma_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f3
   for (int r = 0; r < 4; ++r) d[r] = m.fc[r];
   return d;
 }
+typedef int hipemu_i32x4 __attribute__((ext_vector_type(4)));
+inline hipemu_i32x4 hipemu_mfma_i8(hipemu_i32x4 a, hipemu_i32x4 b, hipemu_i32x4 c) {
+  hipemu::Lane &l = hipemu::g.lanes[hipemu::g.cur];
+  __builtin_memcpy(l.ia, &a, 16);
+  __builtin_memcpy(l.ib, &b, 16);
+  for (int r = 0; r < 4; ++r) l.ic[r] = c[r];
+  (void)hipemu::wave_collective(hipemu::OP_MFMA_I8X64, 0, 0);
+  hipemu::Lane &m = hipemu::g.lanes[hipemu::g.cur];
+  hipemu_i32x4 d;
+  for (int r = 0; r < 4; ++r) d[r] = m.ic[r];
+  return d;
+}
+#define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, x, y, z) hipemu_mfma_i8((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu_mfma_bf16((a), (b), (c))
 #endif

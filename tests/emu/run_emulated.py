@@ -92,7 +92,7 @@ def main(argv):
         sys.path.insert(0, ROOT)
     from meilisearch_amd import _lib
     _lib._LIB = EmulatedLib(build())
-    assert _lib.lib().msi_abi_version() == 2
+    assert _lib.lib().msi_abi_version() == 3
     os.environ["MSI_RUNNER_SO"] = build_runner()
     os.environ["MSI_RCCL_LIBRARY"] = build_rccl()
     import pytest

@@ -118,7 +118,7 @@ def test_filtered_search(ctx, oracle, selectivity):
 def test_duplicates_zero_rows_and_zero_query(ctx, oracle):
     dim = 48
     base = synth.make_embeddings(50, dim, seed=41)
-    rows = np.concatenate([np.repeat(base[:1], 200, axis=0),      # 200 identical rows: ties > K'
+    rows = np.concatenate([np.repeat(base[:1], 600, axis=0),      # 600 identical rows: ties > K' (128; 512 on the int8 level)
                            base, np.zeros((5, dim), dtype=f32),   # zero vectors: distance 0 by definition
                            (base[:20] * f32(1e-30))])              # tiny norms: pn*qn <= EPS
     n = rows.shape[0]
@@ -130,9 +130,12 @@ def test_duplicates_zero_rows_and_zero_query(ctx, oracle):
     before = st.stats()
     check_against_oracle(oracle, st, rows, ids, qs, 20)
     after = st.stats()
-    # 200 ties are more than the usual K' holds: since round 4 the query is re-run with K' = 2048 rescored candidates
-    # (msi_vs.hip, levels of effort) and proven there — no exhaustive pass
+    # 600 ties are more than the usual K' holds (also the int8 level's 512): since round 4 the query is re-run with K' = 2048
+    # rescored candidates (msi_vs.hip, levels of effort) and proven there — no exhaustive pass
     assert after["level_sweeps"][1] > before["level_sweeps"][1]
+    assert after["exhaustive_reruns"] == before["exhaustive_reruns"]
+    if after["i8_bytes_per_tile"]:
+        assert after["i8_sweeps"] > before["i8_sweeps"]            # level 0 swept the int8 copy first
     # ... and more ties than ANY K' holds still end in the exhaustive pass (reference arithmetic for every row)
     rows2 = np.concatenate([np.repeat(base[:1], 2100, axis=0), base])
     ids2 = np.arange(rows2.shape[0], dtype=np.uint32) + 10
@@ -167,8 +170,11 @@ def test_three_query_tiles_sparse_and_filtered(ctx, oracle):
     qs = synth.make_embeddings(40, dim, seed=82)
     st = ma.GpuStore(ctx, dim)
     st.upload(ids, rows)
-    # 96 queries per sweep (bf16x2, the default: the queries' hi halves only in LDS), 48 with MSI_VS_SCAN_MATH=bf16x3
-    assert st.max_batch == (48 if os.environ.get("MSI_VS_SCAN_MATH") in ("bf16x3", "f32") else 96)
+    # 128 queries per sweep of the int8 copy (level 0); the f32 sweeps: 96 (bf16x2, the default: the queries' hi halves only in
+    # LDS), 48 with MSI_VS_SCAN_MATH=bf16x3
+    f32_batch = 48 if os.environ.get("MSI_VS_SCAN_MATH") in ("bf16x3", "f32") else 96
+    assert st.stats()["f32_queries_per_sweep"] == f32_batch
+    assert st.max_batch == (128 if st.stats()["i8_bytes_per_tile"] else f32_batch)
     s0 = st.stats()
     check_against_oracle(oracle, st, rows, ids, qs, 20)
     s1 = st.stats()
@@ -208,6 +214,70 @@ def test_fast_scan_error_is_inside_the_proof_bound(ctx, dim, scale):
     # (2^-8 |x||q|) and a row dominated by one coordinate realises half of it
     comfortable = 0.25 if os.environ.get("MSI_VS_SCAN_MATH") in ("bf16x3", "f32") else 0.6
     assert err <= comfortable * eps, ("the bound should be comfortable", err, eps)
+
+
+@pytest.mark.parametrize("dim,scale", [(768, 1.0), (384, 1.0), (100, 1e3), (1024, 1e-3), (64, 1.0)])
+def test_int8_sweep_error_is_inside_its_proof_bound(ctx, dim, scale, monkeypatch):
+    """Round 5: level 0 sweeps an int8 copy of the rows (msi_vs.hip: every row divided by its norm, quantised with its own
+    scale).  Its proof is only sound if |fast cos - reference cos| <= eps of the query for EVERY row, with eps = the store's
+    largest row residual + the query's own residual + their product (Cauchy-Schwarz): checked against an f64 reference on
+    heavy-tailed rows (one dominant coordinate: the coarsest quantisation a row can get), rows without cancellation, a skewed
+    query — and the bound is not loose either (the worst row comes within a factor of a few of it)."""
+    monkeypatch.setenv("MSI_VS_DEBUG_I8", "1")
+    n = 3000
+    rng = np.random.default_rng(dim + 5)
+    rows = (rng.standard_normal((n, dim)) * scale).astype(f32)
+    rows[:200] *= rng.lognormal(0, 3, size=(200, dim)).astype(f32)
+    rows[200:300] = np.abs(rows[200:300])
+    rows[300:310] = 0
+    rows[300:310, 3] = 1.0                                                  # one-hot rows: quantised exactly
+    qs = rng.standard_normal((20, dim)).astype(f32)
+    qs[1] = np.abs(qs[1])
+    qs[2] *= rng.lognormal(0, 3, size=dim).astype(f32)
+    qs[3] = rows[5]
+    st = ma.GpuStore(ctx, dim)
+    st.upload(np.arange(n, dtype=np.uint32), rows)
+    assert st.stats()["i8_bytes_per_tile"] == ((dim + 127) // 128) * 128 * 16 + 128
+    fast, eps = st.debug_fast_scores(qs)
+    r64, q64 = rows.astype(np.float64), qs.astype(np.float64)
+    ref = (q64 @ r64.T) / (np.linalg.norm(q64, axis=1)[:, None] * np.linalg.norm(r64, axis=1)[None, :])
+    got = fast.astype(np.float64) / np.linalg.norm(q64, axis=1)[:, None]
+    err = np.abs(got - ref).max()
+    assert 0.0 < eps < 0.2, eps
+    assert err <= eps, (err, eps)
+    assert err >= eps / 40.0, ("a bound this far above the worst row would waste candidates", err, eps)
+
+
+def test_int8_level_proves_iid_rows_and_hands_crowds_to_the_f32_levels(ctx, oracle):
+    """The levels of effort with the int8 copy in front: on i.i.d. rows level 0 proves every query (no f32 sweep at all); a crowd
+    of rows closer to each other than the int8 bound is handed to the f32 levels and settled there without the exhaustive pass;
+    a store created with MSI_VS_I8=0 answers the same lists (the copy never changes an answer)."""
+    n, dim = 50000, 96
+    rows = synth.make_embeddings(n, dim, seed=301)
+    ids = np.arange(n, dtype=np.uint32) * 2 + 5
+    qs = synth.make_embeddings(40, dim, seed=302)
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    s0 = st.stats()
+    if not s0["i8_bytes_per_tile"]:
+        pytest.skip("the store has no int8 copy (MSI_VS_I8=0)")
+    check_against_oracle(oracle, st, rows, ids, qs, 20)
+    s1 = st.stats()
+    assert s1["i8_sweeps"] - s0["i8_sweeps"] == 1                  # 40 queries: one sweep of the copy (after one sample sweep)
+    assert s1["scan_launches"] - s0["scan_launches"] == 2
+    assert s1["level_sweeps"] == s0["level_sweeps"] and s1["exhaustive_reruns"] == s0["exhaustive_reruns"]
+    # a crowd: 700 rows within ~1e-3 of each other in cosine around the query direction (inside the int8 bound AND more than
+    # its K' = 512 candidates; the bf16x2 level with K' = 2048 or the bf16x3 level tells them apart)
+    rng = np.random.default_rng(303)
+    v = rng.standard_normal(dim).astype(f32)
+    rows2 = rows.copy()
+    rows2[:700] = v[None, :] + 0.05 * rng.standard_normal((700, dim)).astype(f32) * (np.linalg.norm(v) / np.sqrt(dim))
+    st.upload(ids, rows2)
+    s2 = st.stats()
+    check_against_oracle(oracle, st, rows2, ids, v[None, :].astype(f32), 20)
+    s3 = st.stats()
+    assert s3["i8_sweeps"] > s2["i8_sweeps"] and sum(s3["level_sweeps"]) > sum(s2["level_sweeps"])
+    assert s3["exhaustive_reruns"] == s2["exhaustive_reruns"]
 
 
 @pytest.mark.parametrize("n,dim,k", [(37, 5, 10), (3000, 96, 20), (70000, 300, 20), (40000, 1024, 50)])
@@ -374,12 +444,13 @@ def test_errors(ctx):
     assert c.tolist() == [0, 0]
 
 
-def test_six_query_tiles_in_one_sweep_and_the_bf16x3_second_opinion(ctx, oracle):
-    """The default contraction (bf16x2: the queries' hi halves only in LDS) takes 96 queries per sweep; its proof margin is
+def test_six_query_tiles_in_one_sweep_and_the_bf16x3_second_opinion(ctx, oracle, monkeypatch):
+    """(The f32 levels on their own: the store is created without the int8 copy.)  The default contraction (bf16x2: the queries' hi halves only in LDS) takes 96 queries per sweep; its proof margin is
     2^-8 wide, so a query with a crowd of near-equal scores at the top is re-run through the bf16x3 contraction before
     anything is answered exhaustively."""
     if os.environ.get("MSI_VS_SCAN_MATH") in ("bf16x3", "f32"):
         pytest.skip("the 96-query sweep is the bf16x2 contraction's")
+    monkeypatch.setenv("MSI_VS_I8", "0")
     n, dim = 60000, 128
     rows = synth.make_embeddings(n, dim, seed=91)
     ids = np.arange(n, dtype=np.uint32) * 3
@@ -407,13 +478,14 @@ def test_six_query_tiles_in_one_sweep_and_the_bf16x3_second_opinion(ctx, oracle)
 
 
 @pytest.mark.parametrize("dim,batch2,batch3", [(1024, 80, 32), (1536, 48, 16)])
-def test_second_opinion_capacity_at_wide_dims(ctx, oracle, dim, batch2, batch3):
-    """the bf16x3 second opinion keeps both halves of the queries in LDS, so at d > 768 it takes fewer
+def test_second_opinion_capacity_at_wide_dims(ctx, oracle, dim, batch2, batch3, monkeypatch):
+    """(The f32 levels on their own: the store is created without the int8 copy.)  ADVICE r2 (high): the bf16x3 second opinion keeps both halves of the queries in LDS, so at d > 768 it takes fewer
     query tiles per sweep than the bf16x2 main pass (d = 1024: 2 tiles of 64 KiB; d = 1536: 1 tile of 96 KiB) — with
     more flagged queries in one step than that, the re-run must go sub-batch by sub-batch instead of asking for 192 KiB
     of LDS.  Every query of the step points into a crowd of near-equal scores, so every one of them is flagged."""
     if os.environ.get("MSI_VS_SCAN_MATH") in ("bf16x3", "f32"):
         pytest.skip("the second opinion is the bf16x2 contraction's")
+    monkeypatch.setenv("MSI_VS_I8", "0")
     n = 6000
     rng = np.random.default_rng(dim)
     rows = synth.make_embeddings(n, dim, seed=95)
@@ -511,3 +583,63 @@ def test_device_entry_point_pipelines_its_chunks(ctx, oracle, filtered, monkeypa
         e_ids, e_dist = oracle.vs_topk(rows, ids, qs[j], k, fb, nb or 0)
         assert int(h_cnt[j]) == e_ids.size and h_ids[j][:e_ids.size].tolist() == e_ids.tolist(), j
         assert h_dist[j][:e_ids.size].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist(), j
+
+
+@pytest.mark.parametrize("first_level", [None, "f32"])
+def test_device_entry_point_answers_its_unproven_queries_itself(ctx, oracle, monkeypatch, first_level):
+    """msi_vs_search_device used to REPORT the queries its sweep could not prove (d_inexact) and leave the re-run
+    to its caller; store.rs:638-675 always answers, and so does the entry point now — the queries a pass cannot prove are gathered
+    on the device and re-run level by level, then exhaustively, inside the call.  Three kinds of query in one call of more than
+    one sweep: plain ones (proven at the first level), ones that point into a crowd of 700 near-equal rows (the f32 levels settle
+    them) and ones that point into 2 100 identical rows (more ties than any K': the exhaustive pass).  Every list against the
+    oracle; d_inexact comes back all zero.  Once from the store's first level (the int8 sweep when it has the copy), once with
+    the search starting at the f32 level (MSI_VS_FIRST_LEVEL=f32)."""
+    import ctypes as C
+    from meilisearch_amd._lib import check, lib
+    if first_level:
+        monkeypatch.setenv("MSI_VS_FIRST_LEVEL", first_level)
+    n, dim, k = 30000, 64, 10
+    rng = np.random.default_rng(401)
+    rows = synth.make_embeddings(n, dim, seed=402)
+    v = rng.standard_normal(dim).astype(f32)
+    rows[:700] = v[None, :] + 0.05 * rng.standard_normal((700, dim)).astype(f32) * (np.linalg.norm(v) / np.sqrt(dim))
+    w = rng.standard_normal(dim).astype(f32)
+    rows[1000:3100] = w[None, :]
+    ids = np.arange(n, dtype=np.uint32) * 2 + 3
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    step = lib().msi_vs_max_batch(st._h)
+    nq = step + 21
+    qs = synth.make_embeddings(nq, dim, seed=403)
+    crowd = [3, step - 1, step + 5]
+    ties = [0, 40, step + 20]
+    for j in crowd:
+        qs[j] = v * f32(1.0 + 0.01 * j)
+    for j in ties:
+        qs[j] = w * f32(2.0 + 0.5 * j)
+    dv = _DeviceArrays(ctx)
+    _, q_p = dv.put(qs)
+    s0 = st.stats()
+    o_ids, o_ids_p = dv.put(np.zeros((nq, k), np.uint32))
+    o_dist, o_dist_p = dv.put(np.zeros((nq, k), np.float32))
+    o_cnt, o_cnt_p = dv.put(np.zeros(nq, np.uint32))
+    o_inx, o_inx_p = dv.put(np.ones(nq, np.uint32))
+    check(lib().msi_vs_search_device(st._h, q_p, nq, k, None, 0, o_ids_p, o_dist_p, o_cnt_p, o_inx_p))
+    ctx.synchronize()
+    g_ids, g_dist, g_cnt, g_inx = (np.asarray(dv.get(x)) for x in (o_ids, o_dist, o_cnt, o_inx))
+    s1 = st.stats()
+    assert not g_inx.any()
+    assert s1["device_rerun_queries"] - s0["device_rerun_queries"] >= len(crowd) + len(ties)
+    assert s1["exhaustive_reruns"] - s0["exhaustive_reruns"] >= len(ties)
+    for j in sorted(set(crowd + ties + list(range(0, nq, 11)))):
+        e_ids, e_dist = oracle.vs_topk(rows, ids, qs[j], k)
+        assert int(g_cnt[j]) == e_ids.size, j
+        assert g_ids[j][:e_ids.size].view(np.uint32).tolist() == e_ids.tolist(), j
+        assert g_dist[j][:e_ids.size].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist(), j
+    # the old contract on request: unproven queries only reported
+    monkeypatch.setenv("MSI_VS_DEVICE_RERUN", "0")
+    o_inx2, o_inx2_p = dv.put(np.zeros(nq, np.uint32))
+    check(lib().msi_vs_search_device(st._h, q_p, nq, k, None, 0, o_ids_p, o_dist_p, o_cnt_p, o_inx2_p))
+    ctx.synchronize()
+    flagged = np.nonzero(np.asarray(dv.get(o_inx2)))[0].tolist()
+    assert set(ties) <= set(flagged)

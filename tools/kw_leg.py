@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--slots", type=int, default=512)
     ap.add_argument("--cache-mb", type=int, default=8192)
+    ap.add_argument("--fresh", type=int, default=0, help="measure on this many queries BEHIND the --queries primer, each met for the "
+                    "first time by the engine (the index has derived their keys in an untimed pass; the posting cache holds what the "
+                    "primer left) — bench.py's keyword stream")
     ap.add_argument("--flags", type=int, default=0, help="rb_prepare_queries_ex flags (1 phrases, 2 short prefixes, 4 synonyms, 8 negatives)")
     a = ap.parse_args()
     L = C.CDLL(os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so"))
@@ -59,35 +62,58 @@ def main():
     if a.flags & 4:
         assert L.rb_enable_synonyms(h) == 0
     assert L.rb_attach(h, ctx.handle, a.callers, a.slots, a.cache_mb) == 0
-    L.rb_prepare_queries_ex(h, a.queries, a.terms, 4242, a.flags)
-    ids = np.zeros((a.queries, a.k), np.uint32)
-    cnt = np.zeros(a.queries, np.uint32)
-    sc = np.zeros((a.queries, a.k), np.float64)
+    total = a.queries + a.fresh
+    L.rb_prepare_queries_ex(h, total, a.terms, 4242, a.flags)
+    ids = np.zeros((total, a.k), np.uint32)
+    cnt = np.zeros(total, np.uint32)
+    sc = np.zeros((total, a.k), np.float64)
+
+    def run(first, n):
+        assert L.rb_run(h, first, n, a.k, ids.ctypes.data, cnt.ctypes.data, sc.ctypes.data) == 0
 
     def one_pass():
-        assert L.rb_run(h, 0, a.queries, a.k, ids.ctypes.data, cnt.ctypes.data, sc.ctypes.data) == 0
-    one_pass()                                   # untimed: the index derives what the queries read; pools create their companions
+        if a.fresh:
+            run(a.queries, a.fresh)
+        else:
+            run(0, a.queries)
+    t_d = time.perf_counter()
+    run(0, total)                                # untimed: the index derives what the queries read; pools create their companions
+    derive_s = time.perf_counter() - t_d
+    if a.fresh:
+        a.passes = 1
+        ma._lib.check(lib.msi_dict_reset_posting_cache(C.c_void_p(L.rb_dict(h))))
+        run(0, a.queries)                        # the primer: what a serving process has in HBM
+    pc0 = (C.c_uint64 * 4)()
+    lib.msi_dict_posting_cache_stats(C.c_void_p(L.rb_dict(h)), pc0)
     cp0, cp1 = (C.c_uint64 * 8)(), (C.c_uint64 * 8)()
     vs0, vs1 = (C.c_uint64 * 6)(), (C.c_uint64 * 6)()
     lib.msi_search_cpu_profile(cp0)
     lib.msi_bits_vm_stats(C.c_void_p(L.rb_pool(h, 0)), vs0)
+    prof_path = os.environ.get("KW_PROFILE")      # a sampling CPU profile of the measured passes (tools/r3_symbolize.py reads it)
+    if prof_path:
+        L.rb_profile_stop.argtypes = [C.c_char_p]
+        L.rb_profile_start()
     c0 = os.times()
     t0 = time.perf_counter()
     for _ in range(a.passes):
         one_pass()
     dt = time.perf_counter() - t0
     c1 = os.times()
+    if prof_path:
+        L.rb_profile_stop(prof_path.encode())
     lib.msi_search_cpu_profile(cp1)
     lib.msi_bits_vm_stats(C.c_void_p(L.rb_pool(h, 0)), vs1)
-    nq = a.passes * a.queries
+    nq = a.passes * (a.fresh or a.queries)
     pc = (C.c_uint64 * 4)()
     lib.msi_dict_posting_cache_stats(C.c_void_p(L.rb_dict(h)), pc)
+    pc = [int(pc[0] - pc0[0]), int(pc[1] - pc0[1]), int(pc[2]), 0]
     cst, lst = (C.c_uint64 * 3)(), (C.c_uint64 * 2)()
     lib.msi_search_compaction_stats(cst)
     lib.msi_search_late_compaction_stats(lst)
     lists, rounds = vs1[1] - vs0[1], vs1[0] - vs0[0]
     out = {"corpus": a.corpus, "docs": a.docs, "dictionary_words": a.words, "callers": a.callers, "distinct_queries": a.queries,
-           "measured_searches": nq, "searches_in_this_process": nq + a.queries, "queries_per_s": round(nq / dt, 1),
+           "measured_searches": nq, "searches_in_this_process": nq + total + (a.queries if a.fresh else 0),
+           "fresh_stream": bool(a.fresh), "index_derivation_seconds": round(derive_s, 1), "queries_per_s": round(nq / dt, 1),
            "host_cpus_used": round((c1[0] + c1[1] - c0[0] - c0[1]) / dt, 2),
            "vm": {"lists_per_query": round(lists / nq, 2), "lists_per_launch": round(lists / max(1, rounds), 2),
                   "us_queued_per_list": round((vs1[2] - vs0[2]) / 1e3 / max(1, lists), 1),

@@ -26,14 +26,24 @@ assert L.rb_permute_queries(h, order.ctypes.data, NQ) == 0
 cs = cand[order].astype(np.float64) / n
 edges = [0, 0.001, 0.01, 0.125, 0.5, 1.01]
 names = ["<=0.1%", "0.1-1%", "1-12.5%", "12.5-50%", ">50%"]
-def mixed(tag):
-    t0 = time.perf_counter(); assert L.rb_run(h, 0, NQ, k, ids.ctypes.data, cnt.ctypes.data, sc.ctypes.data) == 0
-    print(f"{tag}: {NQ / (time.perf_counter() - t0):.0f} q/s", flush=True)
+def mixed(tag, lo=0, n=None):
+    n = NQ if n is None else n
+    t0 = time.perf_counter(); assert L.rb_run(h, lo, n, k, ids.ctypes.data, cnt.ctypes.data, sc.ctypes.data) == 0
+    print(f"{tag}: {n / (time.perf_counter() - t0):.0f} q/s", flush=True)
 if os.environ.get("CHW_SWEEP"):
     for rep in range(int(os.environ.get("REPS", 2))):
         for v in os.environ["CHW_SWEEP"].split(","):
             os.environ["MSI_VM_COMPACT_CHW"] = v
             mixed(f"compact chunk width {v:>7s}")
+    sys.exit(0)
+if os.environ.get("BURST"):
+    # round 5: the burst that collapsed the leg in round 4 — the searches whose universe is 1-12.5 % of the index (48-153-chunk
+    # compact lists), in sorted order, all callers alike; FUSE max chunks per list from BURST="24,160"
+    lo, hi = int(np.searchsorted(cs, 0.01, "right")), int(np.searchsorted(cs, 0.125, "right"))
+    for fm in os.environ["BURST"].split(","):
+        os.environ["MSI_VM_FUSE_MAX_CHUNKS"] = fm
+        for rep in range(2): mixed(f"burst of {hi - lo} alike searches (universe 1-12.5 %), fuse_max_chunks {fm:>4s}", lo, hi - lo)
+    L.rb_destroy(h)
     sys.exit(0)
 if os.environ.get("FUSE_SWEEP"):
     # original order first (what bench.py runs), then sorted by universe (bursts of alike searches)

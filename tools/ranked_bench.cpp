@@ -271,7 +271,9 @@ struct Index {
   uint64_t n_docs;
   // (per index, not per address: a static map keyed by the Index pointer handed a new corpus the key sets of a destroyed
   // one that had lived at the same address — the engine and the oracle read the same stale sets, so parity never noticed)
-  std::mutex derived_mu;
+  std::shared_mutex derived_mu;   // (lookups of derived key sets — every fid / position read of a warm index — share the lock:
+                                  // a plain mutex here serialised 160 caller threads, 1.7 ms of WALL time per callback on a stream of
+                                  // fresh queries; an LMDB read takes no lock at all)
   std::map<std::string, std::shared_ptr<WordDerived>> word_derived, prefix_derived;
   std::unique_ptr<Corpus> corpus;                 // set: the databases below are derived from the corpus's documents
   bool synonyms = false;                          // the index has synonyms (rb_enable_synonyms; corpus_synonyms below)
@@ -343,7 +345,7 @@ std::string str(const uint8_t *w, uint32_t n) { return std::string((const char *
 // q/<pos>/<w>, and the key sets (fids, bucketed positions) the engine's prefix_iter reads would return.
 const WordDerived *corpus_word(Index *ix, const std::string &s) {
   {
-    std::lock_guard<std::mutex> lk(ix->derived_mu);
+    std::shared_lock<std::shared_mutex> lk(ix->derived_mu);
     auto it = ix->word_derived.find(s);
     if (it != ix->word_derived.end()) return it->second.get();
   }
@@ -373,7 +375,7 @@ const WordDerived *corpus_word(Index *ix, const std::string &s) {
     wd->positions.push_back((uint16_t)kv.first);
     ix->blob("q/" + std::to_string(kv.first) + "/" + s, [&] { return kv.second; });
   }
-  std::lock_guard<std::mutex> lk(ix->derived_mu);
+  std::unique_lock<std::shared_mutex> lk(ix->derived_mu);
   return ix->word_derived.emplace(s, wd).first->second.get();
 }
 
@@ -409,7 +411,19 @@ int32_t cb_pair(void *u, uint32_t prox, const uint8_t *l, uint32_t ln, const uin
       uint64_t na = 0, nb = 0;
       const uint32_t *pa = c.posting((uint32_t)ia, &na), *pb = c.posting((uint32_t)ib, &nb);
       std::vector<uint32_t> both;
-      std::set_intersection(pa, pa + na, pb, pb + nb, std::back_inserter(both));
+      // (a typo derivation paired with a frequent word: a posting of a few documents against one of millions — galloping over
+      // the long one instead of walking it: the linear merge was most of the index-derivation pass of a fresh query stream)
+      if (na > 16 * nb || nb > 16 * na) {
+        const uint32_t *sp = na < nb ? pa : pb, *lp = na < nb ? pb : pa;
+        const uint64_t sn = std::min(na, nb), ln = std::max(na, nb);
+        const uint32_t *at = lp;
+        for (uint64_t i = 0; i < sn && at < lp + ln; ++i) {
+          at = std::lower_bound(at, lp + ln, sp[i]);
+          if (at < lp + ln && *at == sp[i]) both.push_back(sp[i]);
+        }
+      } else {
+        std::set_intersection(pa, pa + na, pb, pb + nb, std::back_inserter(both));
+      }
       std::vector<std::pair<uint32_t, uint32_t>> pos_a;   // (fid, position) of a's occurrences seen so far in this document
       for (uint32_t d : both) {
         pos_a.clear();
@@ -538,7 +552,7 @@ bool corpus_prefix_range(Index *ix, const std::string &p, uint32_t *lo, uint32_t
 }
 const WordDerived *corpus_prefix(Index *ix, const std::string &p) {
   {
-    std::lock_guard<std::mutex> lk(ix->derived_mu);
+    std::shared_lock<std::shared_mutex> lk(ix->derived_mu);
     auto it = ix->prefix_derived.find(p);
     if (it != ix->prefix_derived.end()) return it->second.get();
   }
@@ -567,7 +581,7 @@ const WordDerived *corpus_prefix(Index *ix, const std::string &p) {
       ix->blob("Q/" + std::to_string(kv.first) + "/" + p, [&] { return kv.second; });
     }
   }
-  std::lock_guard<std::mutex> lk(ix->derived_mu);
+  std::unique_lock<std::shared_mutex> lk(ix->derived_mu);
   return ix->prefix_derived.emplace(p, wd).first->second.get();
 }
 int32_t push_blob(Index *ix, const std::string &key, msi_posting_sink push, void *sink) {
@@ -733,7 +747,6 @@ static int32_t cpu_lookup(const uint8_t *w, uint32_t n, uint32_t max_typos, uint
 
 }  // namespace
 
-#ifndef RANKED_BENCH_LIB
 // RB_PROFILE=<file>: a sampling profile of the process's CPU time (ITIMER_PROF, 2 kHz; the signal lands on whichever thread
 // is burning CPU): raw return addresses + /proc/self/maps, symbolised offline (tools/r3_symbolize.py).
 #include <execinfo.h>
@@ -779,6 +792,7 @@ void stop(const char *path) {
   fclose(f);
 }
 }  // namespace prof
+#ifndef RANKED_BENCH_LIB
 // cgroup v2 CPU accounting of this container: {usage_usec, throttled_usec}
 static void cpu_stat(unsigned long long out[2]) {
   out[0] = out[1] = 0;
@@ -1619,6 +1633,9 @@ int32_t rb_hybrid_merge(uint32_t n_queries, uint32_t k, const uint32_t *v_ids, c
   }
   return MSI_OK;
 }
+// a sampling CPU profile of the process between the two calls (namespace prof above; symbolise with tools/r3_symbolize.py)
+void rb_profile_start(void) { prof::start(); }
+void rb_profile_stop(const char *path) { prof::stop(path); }
 msi_dict *rb_dict(void *h) { return ((Runner *)h)->dict; }
 msi_bits *rb_pool(void *h, uint32_t t) { return ((Runner *)h)->pools[t]; }
 void rb_destroy(void *h) {
