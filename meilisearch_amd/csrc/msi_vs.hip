@@ -963,13 +963,14 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
   uint32_t tl[RT], tc[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) tl[r] = tc[r] = tile_of(it0 + r);
-  // the rows' scales travel with the first stage of their tile group (the loads run one stage ahead of the MFMAs, so they have
-  // long arrived when the group's epilogue needs them): scn = of the group being loaded, scc = of the group being computed
-  float4 scn[RT], scc[RT];
+  // the rows' scales travel with the first stage of their tile group, into the scale registers of the SAME buffer (sca with
+  // xa, scb with xb: a buffer is never loaded again before it was computed, whatever the number of stages per group); the
+  // group's first compute stage moves them to scc, where the epilogue finds them
+  float4 sca[RT], scb[RT], scc[RT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r) scn[r] = scc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < RT; ++r) sca[r] = scb[r] = scc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto load_group = [&](i32x4(&x)[GS][RT]) {
+  auto load_group = [&](i32x4(&x)[GS][RT], float4(&scn)[RT]) {
     if (sub_load == 0) {
 #pragma unroll
       for (int r = 0; r < RT; ++r) scn[r] = *reinterpret_cast<const float4 *>(a.scale8 + (uint64_t)tl[r] * 16 + g * 4);
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
       }
     }
   };
-  auto compute_group = [&](const i32x4(&x)[GS][RT]) {
+  auto compute_group = [&](const i32x4(&x)[GS][RT], const float4(&scn)[RT]) {
     const i32x4 *qb = qf + (size_t)sub_cmp * GS * 64 + lane;
 #pragma unroll
     for (int u = 0; u < GS; ++u) {
@@ -1028,7 +1029,7 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
   // first MFMA that reads the stage — after the next stage's loads were issued — and, having lost count of the loads in flight at
   // the epilogue's conditional stores, it waits for ALL of them: the next stage's too, i.e. no overlap of loads and MFMAs at all
   // (measured: 2.06 ms per 128-query sweep of 10 M x 768; rocprofv3 / ISA in profiles/r5_i8_sweep.txt).
-  auto landed = [&](i32x4(&x)[GS][RT]) {
+  auto landed = [&](i32x4(&x)[GS][RT], float4(&scn)[RT]) {
 #if !defined(MSI_HIP_EMULATED)
 #pragma unroll
     for (int u = 0; u < GS; ++u)
@@ -1038,19 +1039,20 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
     for (int r = 0; r < RT; ++r) asm volatile("" : "+v"(scn[r].x), "+v"(scn[r].y), "+v"(scn[r].z), "+v"(scn[r].w));
 #else
     (void)x;
+    (void)scn;
 #endif
   };
-  load_group(xa);
+  load_group(xa, sca);
   for (;;) {
-    landed(xa);
+    landed(xa, sca);
     bool more = it_load < it1;
-    if (more) load_group(xb);
-    compute_group(xa);
+    if (more) load_group(xb, scb);
+    compute_group(xa, sca);
     if (!more) break;
-    landed(xb);
+    landed(xb, scb);
     more = it_load < it1;
-    if (more) load_group(xa);
-    compute_group(xb);
+    if (more) load_group(xa, sca);
+    compute_group(xb, scb);
     if (!more) break;
   }
 }
@@ -1333,6 +1335,21 @@ struct RescoreArgs {
   u64 *pre_keys;           // nullable [NQ_MAX][KP_MAX]: distances computed by vs_rescore_dots_kernel (large K')
 };
 
+// Which of the K' selected candidates need the reference arithmetic at all.  They arrive ordered by fast score; at least k
+// rows have a reference cosine >= (k-th fast cosine) - eps, so a candidate whose fast cosine lies more than 2 eps below the
+// k-th fast cosine cannot be among the k nearest (its reference cosine is below that of k other rows).  With the int8
+// sweep's eps (~1.8e-2) and K' = 1 024 that is most of them: on i.i.d. rows ~200 candidates are rescored per query, not 1 024.
+// (The exactness proof is unchanged: it speaks about the rows that were NOT selected.)
+__device__ __forceinline__ bool candidate_matters(const RescoreArgs &a, uint32_t j, uint32_t i, uint32_t cnt) {
+  if (i < a.k || cnt < a.k || a.k == 0) return true;
+  const float eps = a.eps + (a.eps_q ? a.eps_q[j] : 0.0f);
+  const float inv = a.inv_qn[j];
+  const float ck = key_desc_score(a.sel_keys[(uint64_t)j * KP_MAX + a.k - 1]) * inv;
+  const float ci = key_desc_score(a.sel_keys[(uint64_t)j * KP_MAX + i]) * inv;
+  if (!(fabsf(ck) < 1e30f)) return true;    // k degenerate rows (distance 0 by definition) in front: a row at cosine 1 ties with them
+  return !(ci < ck - 2.0f * eps - 1e-6f);   // (1e-6: a strictly larger distance, never a tie that the docid would decide; NaN: keep)
+}
+
 // Large K' (k in the hundreds: the rerank pool of BASELINE config 5): the reference-arithmetic dot products are
 // the expensive part and one workgroup per query leaves the chip idle, so they get their own launch with one
 // thread per (query, candidate); vs_rescore_kernel then only sorts, emits and proves.
@@ -1347,6 +1364,10 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_dots_kernel(RescoreArg
   __syncthreads();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cnt) return;
+  if (!candidate_matters(a, j, i, cnt)) {
+    a.pre_keys[(uint64_t)j * KP_MAX + i] = ~0ull;   // (sorts behind every rescored candidate)
+    return;
+  }
   const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
   const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
   const float d = canonical_distance(pq, a.norm[row], a.qn[j]);
@@ -1369,7 +1390,7 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) 
     if (i < cnt) {
       if (a.pre_keys) {
         key = a.pre_keys[(uint64_t)j * KP_MAX + i];
-      } else {
+      } else if (candidate_matters(a, j, i, cnt)) {
         const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
         const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
         const float d = canonical_distance(pq, a.norm[row], qn);
@@ -1944,10 +1965,12 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
   c.filtered = filtered;
   // candidates rescored beyond k: every row whose fast score lies within twice the proof's eps of the k-th must be among
   // them — a handful with bf16x3 (eps ~ 1e-5), a few dozen to a hundred with bf16x2 (eps ~ 4e-3)
-  // (the int8 sweep: eps ~ 1.8e-2 in cosine — on i.i.d. rows ~200 rows of 10 M lie within it of the 20th neighbour)
+  // (the int8 sweep: eps ~ 1.8e-2 in cosine — on i.i.d. rows ~200 rows of 10 M lie within it of the 20th neighbour, a few
+  // per cent of the queries see 500+; the count grows with the store, so K' does too: 256 / 512 / 1 024 candidates, of which
+  // only those within 2 eps of the k-th are rescored (candidate_matters); the next level takes K' = KP_MAX)
   c.i8 = vs->i8 && vs->i8_now;
   const uint32_t slack = vs->big_slack ? KP_MAX
-                         : c.i8 ? std::max<uint32_t>(1004, 3 * k)
+                         : c.i8 ? std::max<uint32_t>(vs->n_rows > 5000000 ? 1004u : (vs->n_rows > 1500000 ? 492u : 236u), 3 * k)
                                 : (vs->bf2 ? std::max<uint32_t>(108, 3 * k) : std::max<uint32_t>(12, k / 4));
   const uint32_t kp = c.kp = std::min<uint32_t>(k + slack, KP_MAX);
   c.nqt = (nq + QT - 1) / QT;

@@ -118,7 +118,7 @@ def test_filtered_search(ctx, oracle, selectivity):
 def test_duplicates_zero_rows_and_zero_query(ctx, oracle):
     dim = 48
     base = synth.make_embeddings(50, dim, seed=41)
-    rows = np.concatenate([np.repeat(base[:1], 600, axis=0),      # 600 identical rows: ties > K' (128; 512 on the int8 level)
+    rows = np.concatenate([np.repeat(base[:1], 1500, axis=0),     # 1 500 identical rows: ties > K' (128; 1 024 on the int8 level)
                            base, np.zeros((5, dim), dtype=f32),   # zero vectors: distance 0 by definition
                            (base[:20] * f32(1e-30))])              # tiny norms: pn*qn <= EPS
     n = rows.shape[0]
@@ -130,12 +130,14 @@ def test_duplicates_zero_rows_and_zero_query(ctx, oracle):
     before = st.stats()
     check_against_oracle(oracle, st, rows, ids, qs, 20)
     after = st.stats()
-    # 600 ties are more than the usual K' holds (also the int8 level's 512): since round 4 the query is re-run with K' = 2048
+    # 1 500 ties are more than the usual K' holds (also the int8 level's 1 024): since round 4 the query is re-run with K' = 2048
     # rescored candidates (msi_vs.hip, levels of effort) and proven there — no exhaustive pass
-    assert after["level_sweeps"][1] > before["level_sweeps"][1]
     assert after["exhaustive_reruns"] == before["exhaustive_reruns"]
     if after["i8_bytes_per_tile"]:
-        assert after["i8_sweeps"] > before["i8_sweeps"]            # level 0 swept the int8 copy first
+        assert after["i8_sweeps"] - before["i8_sweeps"] >= 2       # the int8 sweep, then the int8 sweep with K' = 2048
+        assert after["level_sweeps"] == before["level_sweeps"]     # ... which settled it: no sweep of the f32 rows
+    else:
+        assert after["level_sweeps"][1] > before["level_sweeps"][1]
     # ... and more ties than ANY K' holds still end in the exhaustive pass (reference arithmetic for every row)
     rows2 = np.concatenate([np.repeat(base[:1], 2100, axis=0), base])
     ids2 = np.arange(rows2.shape[0], dtype=np.uint32) + 10
@@ -216,7 +218,7 @@ def test_fast_scan_error_is_inside_the_proof_bound(ctx, dim, scale):
     assert err <= comfortable * eps, ("the bound should be comfortable", err, eps)
 
 
-@pytest.mark.parametrize("dim,scale", [(768, 1.0), (384, 1.0), (100, 1e3), (1024, 1e-3), (64, 1.0)])
+@pytest.mark.parametrize("dim,scale", [(768, 1.0), (384, 1.0), (100, 1e3), (1024, 1e-3), (64, 1.0), (130, 1.0), (256, 1.0), (200, 1.0)])
 def test_int8_sweep_error_is_inside_its_proof_bound(ctx, dim, scale, monkeypatch):
     """Round 5: level 0 sweeps an int8 copy of the rows (msi_vs.hip: every row divided by its norm, quantised with its own
     scale).  Its proof is only sound if |fast cos - reference cos| <= eps of the query for EVERY row, with eps = the store's
@@ -266,12 +268,12 @@ def test_int8_level_proves_iid_rows_and_hands_crowds_to_the_f32_levels(ctx, orac
     assert s1["i8_sweeps"] - s0["i8_sweeps"] == 1                  # 40 queries: one sweep of the copy (after one sample sweep)
     assert s1["scan_launches"] - s0["scan_launches"] == 2
     assert s1["level_sweeps"] == s0["level_sweeps"] and s1["exhaustive_reruns"] == s0["exhaustive_reruns"]
-    # a crowd: 700 rows within ~1e-3 of each other in cosine around the query direction (inside the int8 bound AND more than
-    # its K' = 512 candidates; the bf16x2 level with K' = 2048 or the bf16x3 level tells them apart)
+    # a crowd: 2 500 rows within ~1e-3 of each other in cosine around the query direction (inside the int8 bound AND more than
+    # any K' of the int8 levels; the f32 levels tell them apart)
     rng = np.random.default_rng(303)
     v = rng.standard_normal(dim).astype(f32)
     rows2 = rows.copy()
-    rows2[:700] = v[None, :] + 0.05 * rng.standard_normal((700, dim)).astype(f32) * (np.linalg.norm(v) / np.sqrt(dim))
+    rows2[:2500] = v[None, :] + 0.05 * rng.standard_normal((2500, dim)).astype(f32) * (np.linalg.norm(v) / np.sqrt(dim))
     st.upload(ids, rows2)
     s2 = st.stats()
     check_against_oracle(oracle, st, rows2, ids, v[None, :].astype(f32), 20)
@@ -590,7 +592,7 @@ def test_device_entry_point_answers_its_unproven_queries_itself(ctx, oracle, mon
     """msi_vs_search_device used to REPORT the queries its sweep could not prove (d_inexact) and leave the re-run
     to its caller; store.rs:638-675 always answers, and so does the entry point now — the queries a pass cannot prove are gathered
     on the device and re-run level by level, then exhaustively, inside the call.  Three kinds of query in one call of more than
-    one sweep: plain ones (proven at the first level), ones that point into a crowd of 700 near-equal rows (the f32 levels settle
+    one sweep: plain ones (proven at the first level), ones that point into a crowd of 2 500 near-equal rows (the f32 levels settle
     them) and ones that point into 2 100 identical rows (more ties than any K': the exhaustive pass).  Every list against the
     oracle; d_inexact comes back all zero.  Once from the store's first level (the int8 sweep when it has the copy), once with
     the search starting at the f32 level (MSI_VS_FIRST_LEVEL=f32)."""
@@ -602,9 +604,9 @@ def test_device_entry_point_answers_its_unproven_queries_itself(ctx, oracle, mon
     rng = np.random.default_rng(401)
     rows = synth.make_embeddings(n, dim, seed=402)
     v = rng.standard_normal(dim).astype(f32)
-    rows[:700] = v[None, :] + 0.05 * rng.standard_normal((700, dim)).astype(f32) * (np.linalg.norm(v) / np.sqrt(dim))
+    rows[:2500] = v[None, :] + 0.05 * rng.standard_normal((2500, dim)).astype(f32) * (np.linalg.norm(v) / np.sqrt(dim))
     w = rng.standard_normal(dim).astype(f32)
-    rows[1000:3100] = w[None, :]
+    rows[3000:5100] = w[None, :]
     ids = np.arange(n, dtype=np.uint32) * 2 + 3
     st = ma.GpuStore(ctx, dim)
     st.upload(ids, rows)
