@@ -172,11 +172,23 @@ class Env:
             lat.append((time.perf_counter() - s0) * 1e3)
         self.sync_all()
         elapsed = time.perf_counter() - t0
+        self.per_rank_elapsed = [elapsed]
         if self.dist is not None:
-            tt = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
-            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+            mine = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev)
+            every = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.dev)
+            self.dist.all_gather_into_tensor(every, mine)          # every rank's own clock (the line reports them beside the MAX)
+            self.per_rank_elapsed = [float(x) for x in every.cpu().tolist()]
+            elapsed = max(self.per_rank_elapsed)
         return elapsed, lat
+
+    def gather_scalar(self, x):
+        """One float per rank -> the list of them on every rank (N = 1: [x])."""
+        if self.dist is None:
+            return [float(x)]
+        mine = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.dev)
+        every = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.dev)
+        self.dist.all_gather_into_tensor(every, mine)
+        return [float(v) for v in every.cpu().tolist()]
 
     def finish(self):
         if self.dist is not None:
@@ -319,14 +331,17 @@ def cpu_typo_baseline(words, concat, off, n_sample):
     return by_threads[cores], t_one, cores, {str(t): round(1.0 / v, 1) for t, v in by_threads.items()}
 
 
-def cpu_keyword_baseline(n_docs, dict_words, n_terms):
+def cpu_keyword_baseline(n_docs, dict_words, n_terms, universe=0):
     """tools/bin/ranked_bench_cpu as a child: the keyword leg's CPU port on a bounded sample (16 distinct queries of the same
-    shape as the step's, two per thread after one warm-up pass that also generates the synthetic index's postings)."""
+    shape as the step's, two per thread after one warm-up pass that also generates the synthetic index's postings).
+    universe > 0: every search ranks inside a candidate universe of that many documents (config 5's rerank of a top-k)."""
     exe = os.path.join(ROOT, "tools", "bin", "ranked_bench_cpu")
     if not os.path.exists(exe):
         return {"note": "tools/bin/ranked_bench_cpu not built (__graft_entry__.build())"}
     threads = granted_cpus()
     env = dict(os.environ, RB_DETAILED="1", RB_DISTINCT_QUERIES="16")
+    if universe:
+        env["RB_UNIVERSE"] = str(int(universe))
     try:
         r = subprocess.run([exe, str(n_docs), str(dict_words), str(n_terms), "2", str(threads)], env=env, capture_output=True,
                            text=True, timeout=300)
@@ -634,6 +649,7 @@ def run_c4(args, env):
             env.dist.all_gather_into_tensor(seen, mine)
             torch.cuda.synchronize()
         rccl_ranks_seen = int(torch.unique(seen[seen >= 0]).numel())
+        assert rccl_ranks_seen == world, f"the exchange saw {rccl_ranks_seen} of {world} ranks"
 
     def exchange():
         """The one exchange step: per-rank top-k lists (Q*(2k+1)*4 bytes) in ONE all-gather over xGMI — RCCL called by
@@ -698,6 +714,17 @@ def run_c4(args, env):
             while kw["lib"].rb_done(kw["h"]) < thr:
                 time.sleep(0.0003)
             store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
+            assert kw["lib"].rb_wait(kw["h"]) == 0, "msi_keyword_search_ranked failed"
+        elif kw is not None and args.legs == "overlap":
+            # Both legs from the start: the keyword searches are started on their caller threads, the vector leg runs on this
+            # thread beside them (msi_vs_search_device returns when every query is answered), then the keyword job is joined.
+            first = kw_first()
+            kw["step"] += 1
+            assert kw["lib"].rb_start_detailed(kw["h"], first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data,
+                                               kw["scores"].ctypes.data, None, None, None) == 0
+            if gdict is not None:
+                gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
+            store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)
             assert kw["lib"].rb_wait(kw["h"]) == 0, "msi_keyword_search_ranked failed"
         else:
             store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
@@ -841,6 +868,10 @@ def run_c4(args, env):
                   "universe; one whose universe is larger moves the sub-tree of a bucket (<= 1/8 of the index) into the ranks "
                   "of that bucket once nothing else of its bucket sort is alive (msi_search.hip Ctx::late_enter)"}
     # ---- per-QUERY latency (the metric is "queries/sec + p50 latency"; ms_per_step is the latency of a 768-query step) ----
+    # N > 1: every rank measured its keyword leg at the same time on the CPUs the ranks share: their sum is the whole job's
+    # measured keyword throughput, to be read against the prediction (granted CPUs / host CPU per query)
+    kw_only_by_rank = env.gather_scalar(legs.get("keyword_only_queries_per_s") or 0.0) if kw is not None else None
+    vec_only_by_rank = env.gather_scalar(legs.get("vector_only_queries_per_s") or 0.0) if kw is not None else None
     phase("c4: per-query latency")
     latency = None
     if kw is not None and not env.child and rank == 0:
@@ -989,14 +1020,20 @@ def run_c4(args, env):
                          "per-shard top-k (RCCL) + device k-way merge" % (n, n_total)) if row_sharded else
                         "queries sharded, index replicated per GPU, ONE packed all-gather of per-rank top-k per step; exchange path: " + exchange_path,
             "rccl_ranks_seen": rccl_ranks_seen,
+            "per_rank_values": [round(Q * args.steps / e, 1) for e in getattr(env, "per_rank_elapsed", [elapsed])],
+            "keyword_cap_measured": round(sum(kw_only_by_rank), 1) if kw_only_by_rank else None,
+            "keyword_only_queries_per_s_by_rank": [round(x, 1) for x in kw_only_by_rank] if kw_only_by_rank else None,
+            "vector_only_queries_per_s_by_rank": [round(x, 1) for x in vec_only_by_rank] if vec_only_by_rank else None,
             "keyword_callers_per_rank": kw_threads if kw is not None else 0, "host_cpus_granted": granted_cpus(),
             # N > 1: all ranks share the box's granted CPUs, and a keyword search costs host CPU whichever GPU runs its sets — the
             # keyword leg of the whole job cannot exceed granted CPUs / host CPU per query (measured on one GPU this round:
             # ~1.0 ms per query on the round-3 workload, ~0.8 ms on the coherent corpus: profiles/r4_*), so with 16 granted CPUs
             # the hybrid weak-scaling curve flattens near 2.5-3x whatever RCCL does; the vector leg scales with the GPUs
-            "predicted_keyword_cap_queries_per_s_whole_job": round(granted_cpus() / 0.9e-3, 0) if kw is not None else None,
-            "predicted_cap_is": "granted CPUs / 0.9 ms of host CPU per keyword query (round-4 measurement, MSI_SEARCH_CPU_PROFILE); "
-                                "the measured value of an N-GPU line is to be read against it",
+            "keyword_cap_predicted": round(granted_cpus() / 1.3e-3, 0) if kw is not None else None,
+            "predicted_cap_is": "granted CPUs / 1.3 ms of host CPU per keyword query on a fresh query stream (round 5, legs."
+                                "keyword_host_cpu_ms_per_query at N = 1): every rank's searches draw on the same granted CPUs, so the whole "
+                                "job's keyword leg cannot exceed it whatever the number of GPUs; keyword_cap_measured = the ranks' keyword-only "
+                                "rates, measured at the same time, summed",
             "step_includes": ["vs_scan + select + reference rescoring", "dict_lookup (scan of the first-letter range, "
                               "binary searches for the other first letters, cap logic)", "D2H of results"]
                              + ([] if kw is None else [
@@ -1582,12 +1619,21 @@ def run_c5(args, env):
             allowed = np.nonzero(np.unpackbits(fb.view(np.uint8), bitorder="little")[:n])[0]
             al_t = torch.from_numpy(allowed).to(dev)
             sub = synth.round_to_bf16(rows_t[al_t].cpu().numpy()) if storage == "bf16" else rows_t[al_t].cpu().numpy()
-            if sel_d == 0.01:
-                t_vec, cores, sample, by_threads = cpu_vector_baseline(sub[:args.cpu_sample_rows], allowed.size, d, k)
-                line["cpu_baseline"] = {"value": round(1.0 / t_vec, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-                                        "sample": f"vector leg only: 16 queries x {sample} allowed rows x {d}-d, scaled to the "
-                                                  f"{allowed.size} allowed rows; timed at the CPU quota and at every visible thread, the "
-                                                  "better kept", "queries_per_s_by_threads": by_threads}
+            # the CPU port of the WHOLE step at this density: the exact scan over the allowed rows (bounded sample,
+            # scaled: linear in the rows it visits) + the all-criteria rerank inside a top-k universe (tools/bin/ranked_bench_cpu
+            # with RB_UNIVERSE=k: the product's host logic over host bitsets; measured once, the same for every density)
+            t_vec, cores, sample, by_threads = cpu_vector_baseline(sub[:min(args.cpu_sample_rows, 50_000)], allowed.size, d, k)
+            if "rerank_cpu" not in per_density:
+                per_density["rerank_cpu"] = cpu_keyword_baseline(n, 200_000, 3, universe=k)
+            rr = per_density["rerank_cpu"]
+            t_rr = 1.0 / rr["queries_per_s"] if rr.get("queries_per_s") else 0.0
+            line["cpu_baseline"] = {"value": round(1.0 / (t_vec + t_rr), 3), "unit": "queries/s", "cores": cores, "kind": "port",
+                                    "value_covers": "filtered exact scan + all-criteria rerank inside the top-k, one after the other",
+                                    "vector_queries_per_s": round(1.0 / t_vec, 3),
+                                    "rerank_queries_per_s": rr.get("queries_per_s"), "rerank": rr,
+                                    "sample": f"vector: 16 queries x {sample} allowed rows x {d}-d, scaled to the {allowed.size} allowed "
+                                              f"rows; rerank: ranked_bench_cpu, universes of {k} documents; each timed at the CPU quota "
+                                              "and at every visible thread, the better kept", "queries_per_s_by_threads": by_threads}
             from oracle import parity
             nqc = min(16, B)
             qh = q_t[:nqc].cpu().numpy()
@@ -1614,6 +1660,7 @@ def run_c5(args, env):
         per_density[f"{sel_d:g}"] = line
         if sel_d == 0.01:
             main = line
+    per_density.pop("rerank_cpu", None)
     if env.rank != 0:
         return None
     out = {

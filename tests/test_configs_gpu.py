@@ -195,8 +195,76 @@ def test_c4_keyword_leg_on_the_coherent_corpus(ctx):
         warm = chk.run_product(0, n_queries, limit)
         for a, b in zip(cold, warm):
             assert (a == b).all()
+        _index_seen_from_outside(lib, h, chk, queries)
     finally:
         lib.rb_destroy(h)
+
+
+def _index_seen_from_outside(lib, h, chk, queries, window=20000):
+    """engine and oracle read the index through the same runner object, so a stale database fools both.
+    On the very handle the device just searched, the documents of a window are read back token by token (rb_doc_tokens) and the
+    postings of the queries' own words, their fid / position splits and the pairs of two documents are re-derived from them
+    the way milli's write path does (tests/test_corpus_runner_cpu.py does it for the whole index of a small corpus)."""
+    import ctypes as C
+    w_, f_, p_ = (np.zeros(256, np.uint32) for _ in range(3))
+    lib.rb_doc_tokens.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 3 + [C.c_uint32]
+    lib.rb_doc_tokens.restype = C.c_uint32
+    docs = []
+    for d in range(window):
+        nt = lib.rb_doc_tokens(h, d, w_.ctypes.data, f_.ctypes.data, p_.ctypes.data, 256)
+        assert 0 < nt <= 256
+        docs.append(list(zip(w_[:nt].tolist(), f_[:nt].tolist(), p_[:nt].tolist())))
+    W = chk.index.words
+    wid = {w: i for i, w in enumerate(W)}
+    probe = []
+    for q in queries:
+        for w in q.split():
+            if w in wid and wid[w] not in probe:
+                probe.append(wid[w])
+    probe = probe[:12]
+    assert len(probe) >= 6
+
+    def in_window(ds):
+        return [] if ds is None else sorted(int(x) for x in ds.to_array() if x < window)
+
+    def bucketed(rel):
+        if rel < 16:
+            return rel
+        if rel < 24:
+            return 24
+        p2 = 1
+        while p2 < rel:
+            p2 <<= 1
+        return p2
+    for w in probe:
+        assert in_window(chk.index.get_word_docids(W[w], True)) == [d for d, t in enumerate(docs) if any(x == w for x, _, _ in t)], W[w]
+        for fid in (1, 2):
+            assert in_window(chk.index.get_word_fid_docids(W[w], fid)) == \
+                [d for d, t in enumerate(docs) if any(x == w and f == fid for x, f, _ in t)], (W[w], fid)
+    w0 = probe[0]
+    for pos in chk.index.get_word_positions(W[w0])[:6]:
+        assert in_window(chk.index.get_word_position_docids(W[w0], pos)) == \
+            [d for d, t in enumerate(docs) if any(x == w0 and bucketed(p) == pos for x, _, p in t)], (W[w0], pos)
+    checked_pairs = 0
+    for d in range(8):          # adjacent words of a few documents: the pair database of their smallest proximity
+        (a, fa, pa), (b, fb, pb) = docs[d][0], docs[d][1]
+        if fa != fb or not 1 <= pb - pa <= 3 or a == b:
+            continue
+        best = {}
+        for dd, t in enumerate(docs):
+            m = 4
+            for i, (x, fx, px) in enumerate(t):
+                if x != a:
+                    continue
+                for y, fy, py in t[i + 1:]:
+                    if fy == fx and y == b and 0 < py - px < m:
+                        m = py - px
+            if m <= 3:
+                best[dd] = m
+        for pr in (1, 2, 3):
+            assert in_window(chk.index.get_pair(pr, W[a], W[b])) == sorted(dd for dd, m in best.items() if m == pr), (pr, W[a], W[b])
+        checked_pairs += 1
+    assert checked_pairs >= 2
 
 
 def test_phrases_on_the_coherent_corpus(ctx):

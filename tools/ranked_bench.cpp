@@ -890,6 +890,17 @@ int main(int argc, char **argv) {
   std::vector<std::vector<std::string>> queries(getenv("RB_DISTINCT_QUERIES") ? std::max(1, atoi(getenv("RB_DISTINCT_QUERIES"))) : 64);
   for (auto &q : queries) for (uint32_t i = 0; i < n_terms; ++i) q.push_back(frequent[g() % 300]);
 
+  // RB_UNIVERSE=<n>: every search is restricted to a candidate universe of n random documents (the rerank of a vector search's
+  // top-n, BASELINE config 5), handed over as the CboRoaringBitmap bytes the shim would pass
+  std::map<const void *, Bytes> universes;
+  if (const char *u = getenv("RB_UNIVERSE")) {
+    const uint64_t nu = std::max(1, atoi(u));
+    for (auto &q : queries) {
+      std::set<uint32_t> ids;
+      while (ids.size() < std::min<uint64_t>(nu, n_docs)) ids.insert((uint32_t)(g() % n_docs));
+      universes[&q] = cbo_serialize(std::vector<uint32_t>(ids.begin(), ids.end()));
+    }
+  }
   auto run_query = [&](msi_bits *pool, const std::vector<std::string> &q, uint64_t stats[10]) {
     std::vector<msi_query_token> toks(q.size());
     std::vector<msi_located_term> terms(q.size());
@@ -900,7 +911,10 @@ int main(int argc, char **argv) {
     uint32_t ids[20], nsc[20], n = 0;
     msi_score_detail sc[20 * MSI_MAX_SCORE_DETAILS];
     uint64_t cand = 0;
-    CK(msi_keyword_search_ranked(dict, pool, &vt, terms.data(), (uint32_t)terms.size(), &prm, nullptr, 0, ids, sc, nsc, &n, &cand, nullptr));
+    auto uni = universes.find(&q);
+    CK(msi_keyword_search_ranked(dict, pool, &vt, terms.data(), (uint32_t)terms.size(), &prm,
+                                 uni != universes.end() ? uni->second.data() : nullptr, uni != universes.end() ? uni->second.size() : 0,
+                                 ids, sc, nsc, &n, &cand, nullptr));
     if (stats) msi_search_last_stats(stats);
     return n;
   };
