@@ -836,6 +836,14 @@ def run_c4(args, env):
         legs["keyword_lists_per_query"] = round((vs[1] - vs0[1]) / (3.0 * Q), 2)
         legs["keyword_host_cpu_ms_per_query"] = round(legs["keyword_only_host_cpus_used"] / max(1e-9, legs["keyword_only_queries_per_s"]) * 1e3, 3)
         legs["keyword_cold_posting_cache_queries_per_s"] = kw.get("cold_cache_queries_per_s")
+        if kw["stream_steps"]:
+            # the two ends the fresh stream lies between: the cold cache above, and round 4's stream (queries the engine has met
+            # before, here the primer's: posting cache hit rate ~0.98) — what a server converges to on a query mix that repeats
+            t0 = time.perf_counter()
+            for first in range(0, 3 * Q, Q):
+                assert kw["lib"].rb_run(kw["h"], first % kw["prime"], Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data,
+                                        kw["scores"].ctypes.data) == 0
+            legs["keyword_cycled_queries_per_s"] = round(3 * Q / (time.perf_counter() - t0), 1)
         # sensitivity to the universe (the documents that match the query at all): one more pass with every search's candidate
         # count and wall time at load, grouped by |universe| / documents
         cand = np.zeros(Q, np.uint64)
@@ -997,6 +1005,7 @@ def run_c4(args, env):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "p50_latency_ms": round(statistics.median(lat), 4),
+        "step_ms": [round(x, 1) for x in lat],
         "higher_is_better": True,
         "scaling": "strong" if row_sharded else "weak",
         "vs_baseline": None,
@@ -1807,7 +1816,8 @@ def short_line(full, detail_path=None):
         if isinstance(out["roofline"], dict):
             out["roofline"]["f32_sweep_frac"] = legs["f32_sweep_level"].get("frac_of_8_TBps")
     lg = _pick(legs, ("vector_only_queries_per_s", "keyword_only_queries_per_s", "keyword_only_host_cpus_used",
-                      "keyword_cold_posting_cache_queries_per_s", "keyword_lists_per_query", "keyword_host_cpu_ms_per_query"))
+                      "keyword_cold_posting_cache_queries_per_s", "keyword_cycled_queries_per_s", "keyword_lists_per_query",
+                      "keyword_host_cpu_ms_per_query"))
     if isinstance(legs.get("keyword_posting_cache"), dict):
         lg["keyword_posting_cache_hit_rate"] = legs["keyword_posting_cache"].get("hit_rate")
     if lg:

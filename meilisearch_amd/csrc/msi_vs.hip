@@ -73,6 +73,7 @@ constexpr int SCAN_GROUP = 8;            // KiB blocks per software-pipeline sta
 constexpr uint32_t KP_MAX = 2048;        // K' supported by select/rescore (k <= 2048; k + max(12, k/4) candidates are rescored)
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_SORTCAP = 2048;        // u64 keys sorted in LDS by vs_select
+constexpr int SEL_UNROLL = 8;            // independent key loads in flight per thread in the selection's passes
 constexpr int QT = 16;                   // queries per MFMA tile
 constexpr int NQT_MAX = 12;              // query tiles per HBM sweep (12 on the int8 copy, 6 with the bf16x2 contraction, 3 otherwise)
 constexpr int NQT_F32_MAX = 6;           // ... of the sweeps over the f32 rows
@@ -1125,10 +1126,20 @@ __device__ uint32_t block_select_smallest(const KeySrc &src, uint32_t c, uint32_
     const uint32_t shift = 64 - pbits - dbits;
     for (uint32_t i = tid; i < 2048; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < c; i += blockDim.x) {
-      u64 key = src.get(i);
-      if (pbits == 0 || (key >> (64 - pbits)) == prefix)
-        atomicAdd(&hist[(uint32_t)(key >> shift) & ((1u << dbits) - 1u)], 1u);
+    // (eight independent loads in flight per thread: with one load per iteration a pass over the ~200 k sampled scores of a
+    // query was a chain of 790 memory round trips per thread — most of this kernel's 0.3-0.7 ms, profiles/r5_i8_vector_leg_*)
+    for (uint32_t i0 = tid; i0 < c; i0 += SEL_UNROLL * blockDim.x) {
+      u64 kk[SEL_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SEL_UNROLL; ++u) {
+        const uint32_t i = i0 + u * blockDim.x;
+        kk[u] = i < c ? src.get(i) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < SEL_UNROLL; ++u) {
+        if (i0 + u * blockDim.x < c && (pbits == 0 || (kk[u] >> (64 - pbits)) == prefix))
+          atomicAdd(&hist[(uint32_t)(kk[u] >> shift) & ((1u << dbits) - 1u)], 1u);
+      }
     }
     __syncthreads();
     {
@@ -1185,11 +1196,19 @@ __device__ uint32_t block_select_smallest(const KeySrc &src, uint32_t c, uint32_
     if (gather <= SEL_SORTCAP || level == 5) {
       if (tid == 0) sh[3] = 0;
       __syncthreads();
-      for (uint32_t i = tid; i < c; i += blockDim.x) {
-        u64 key = src.get(i);
-        if ((key >> shift) <= newprefix) {
-          uint32_t slot = atomicAdd(&sh[3], 1u);
-          if (slot < SEL_SORTCAP) sbuf[slot] = key;
+      for (uint32_t i0 = tid; i0 < c; i0 += SEL_UNROLL * blockDim.x) {
+        u64 kk[SEL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SEL_UNROLL; ++u) {
+          const uint32_t i = i0 + u * blockDim.x;
+          kk[u] = i < c ? src.get(i) : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < SEL_UNROLL; ++u) {
+          if (i0 + u * blockDim.x < c && (kk[u] >> shift) <= newprefix) {
+            uint32_t slot = atomicAdd(&sh[3], 1u);
+            if (slot < SEL_SORTCAP) sbuf[slot] = kk[u];
+          }
         }
       }
       __syncthreads();
