@@ -2356,6 +2356,7 @@ struct KeyEq {
   bool operator()(const MsiCacheKey &x, const MsiCacheKey &y) const { return x.a == y.a && x.b == y.b; }
 };
 struct CacheEntry {
+  MsiCacheKey key{};
   uint64_t off = 0;
   uint64_t len = 0;
   // what msi_pcache_known hands out (written before `ready` / `host_kind` is released, never changed afterwards)
@@ -2376,18 +2377,90 @@ struct MsiPostingCache {
   uint8_t *dev = nullptr;
   uint64_t cap = 0;
   std::atomic<uint64_t> used{0};     // bump allocation of the HBM arena
-  // 64 shards by key hash: a warm search asks ~200 keys and 64+ searches ask at once — one reader-writer lock was the
-  // most contended cache line of the process (9 % of the keyword leg's host CPU, profiles/r3_ranked_cpu_profile_2.txt)
+  // The host table: key -> entry.  A search asks ~135 keys and 160 searches ask at once.  Round 3 sharded one reader-writer
+  // lock 64 ways; on a stream of fresh queries (round 5) the READ locks were still a fifth of the keyword leg's host CPU
+  // (pthread_rwlock_rdlock / unlock: every reader writes the lock word, the line bounces between 13 busy CPUs) and the per-shard
+  // hit counters did the same.  Readers now write nothing shared: each shard is an open-addressing table of atomic pointers
+  // to entries that never move (an entry is published with a release store once it is initialised; a table that fills up is
+  // replaced by one of twice the size and RETIRED, not freed, so a reader that still probes it stays safe — it may miss a key
+  // inserted meanwhile, which sends it down the writers' path where the current table is probed again under the shard's
+  // mutex).  Entries are removed only with the cache (msi_dict_reset_posting_cache: no search in flight).  Counters are
+  // striped by thread.
   static constexpr uint32_t SHARDS = 64;
-  struct Shard {
-    mutable std::shared_mutex mu;
-    std::unordered_map<MsiCacheKey, CacheEntry, KeyHash, KeyEq> map;
-    // counted per shard: one process-wide counter took ~500 k increments per second from 128 threads — the line never
-    // stayed in anybody's cache (msi_pcache_known was 12 % of the leg's host CPU, profiles/r3_ranked_arena_profile.txt)
-    std::atomic<uint64_t> hits{0}, misses{0};
-    char pad[64];
+  struct Table {
+    uint64_t mask = 0;
+    std::atomic<CacheEntry *> *slots = nullptr;
+    explicit Table(uint64_t cap) : mask(cap - 1), slots(new std::atomic<CacheEntry *>[cap]) {
+      for (uint64_t i = 0; i < cap; ++i) slots[i].store(nullptr, std::memory_order_relaxed);
+    }
+    ~Table() { delete[] slots; }
+  };
+  struct alignas(64) Shard {
+    std::atomic<Table *> table{nullptr};
+    std::mutex wmu;                      // a key's first appearance (and table growth)
+    uint64_t count = 0;
+    std::vector<Table *> retired;
+    std::vector<CacheEntry *> entries;   // owned
   } shard[SHARDS];
+  StripedCounters<2> counters;           // [hits, misses]
   Shard &of(const MsiCacheKey &k) { return shard[(k.b >> 7) % SHARDS]; }
+  static uint64_t slot_of(const MsiCacheKey &k) { return (k.a ^ (k.a >> 31)) * 0x9E3779B97F4A7C15ull >> 20; }
+  static CacheEntry *probe(const Table *t, const MsiCacheKey &k) {
+    for (uint64_t i = slot_of(k) & t->mask;; i = (i + 1) & t->mask) {
+      CacheEntry *e = t->slots[i].load(std::memory_order_acquire);
+      if (!e) return nullptr;
+      if (e->key.a == k.a && e->key.b == k.b) return e;
+    }
+  }
+  // readers: no lock, no shared write
+  CacheEntry *find(const MsiCacheKey &k) {
+    const Table *t = of(k).table.load(std::memory_order_acquire);
+    return t ? probe(t, k) : nullptr;
+  }
+  // writers, under sh.wmu: the entry of k, created and initialised by `init` (before it becomes visible) when it is new
+  template <typename Init>
+  CacheEntry *find_or_insert(Shard &sh, const MsiCacheKey &k, bool *created, Init init) {
+    Table *t = sh.table.load(std::memory_order_relaxed);
+    *created = false;
+    if (t) {
+      if (CacheEntry *e = probe(t, k)) return e;
+    }
+    if (!t || (sh.count + 1) * 2 > t->mask + 1) {
+      Table *nt = new Table(t ? (t->mask + 1) * 2 : 1024);
+      if (t) {
+        for (uint64_t i = 0; i <= t->mask; ++i) {
+          CacheEntry *e = t->slots[i].load(std::memory_order_relaxed);
+          if (!e) continue;
+          uint64_t j = slot_of(e->key) & nt->mask;
+          while (nt->slots[j].load(std::memory_order_relaxed)) j = (j + 1) & nt->mask;
+          nt->slots[j].store(e, std::memory_order_relaxed);
+        }
+        sh.retired.push_back(t);
+      }
+      sh.table.store(nt, std::memory_order_release);
+      t = nt;
+    }
+    CacheEntry *e = new CacheEntry();
+    e->key = k;
+    if (!init(*e)) {   // (nothing to remember: e.g. the HBM arena is full)
+      delete e;
+      return nullptr;
+    }
+    sh.entries.push_back(e);
+    ++sh.count;
+    uint64_t j = slot_of(k) & t->mask;
+    while (t->slots[j].load(std::memory_order_relaxed)) j = (j + 1) & t->mask;
+    t->slots[j].store(e, std::memory_order_release);
+    *created = true;
+    return e;
+  }
+  ~MsiPostingCache() {
+    for (auto &sh : shard) {
+      for (CacheEntry *e : sh.entries) delete e;
+      for (Table *t : sh.retired) delete t;
+      delete sh.table.load();
+    }
+  }
 };
 
 // Two independent 64-bit hashes over (database tag, the two strings with their lengths, two integers): a collision
@@ -2442,41 +2515,41 @@ void msi_pcache_destroy(MsiPostingCache *c) {
 
 int msi_pcache_lookup(MsiPostingCache *c, const MsiCacheKey &k, size_t len, uint64_t *off, void **token) {
   *token = nullptr;
-  MsiPostingCache::Shard &sh = c->of(k);
-  {
-    std::shared_lock<std::shared_mutex> lk(sh.mu);
-    auto it = sh.map.find(k);
-    if (it != sh.map.end()) {
-      const uint32_t state = it->second.ready.load(std::memory_order_acquire);
-      if (it->second.host_kind.load(std::memory_order_acquire) == 0 && it->second.len == len && state == 1) {
-        *off = it->second.off;
-        sh.hits.fetch_add(1, std::memory_order_relaxed);
-        return 1;
-      }
-      sh.misses.fetch_add(1, std::memory_order_relaxed);
-      uint32_t abandoned = 2;
-      if (it->second.host_kind.load(std::memory_order_acquire) == 0 && it->second.len == len && state == 2 &&
-          it->second.ready.compare_exchange_strong(abandoned, 0, std::memory_order_acq_rel)) {
-        *off = it->second.off;    // the reservation of a list that never ran: this caller fills it
-        *token = &it->second;
-        return 2;
-      }
-      return 0;   // being filled by another search (or a length mismatch: never trusted)
+  auto existing = [&](CacheEntry *e) -> int {
+    const uint32_t state = e->ready.load(std::memory_order_acquire);
+    if (e->host_kind.load(std::memory_order_acquire) == 0 && e->len == len && state == 1) {
+      *off = e->off;
+      c->counters.add(0, 1);
+      return 1;
     }
-  }
-  sh.misses.fetch_add(1, std::memory_order_relaxed);
-  std::unique_lock<std::shared_mutex> lk(sh.mu);
-  if (sh.map.find(k) != sh.map.end()) return 0;
-  const uint64_t need = ((uint64_t)len + 15 + 16) & ~15ull;   // + one block of slack for the last partial block
-  uint64_t at = c->used.load(std::memory_order_relaxed);
-  do {
-    if (at + need > c->cap) return 0;
-  } while (!c->used.compare_exchange_weak(at, at + need, std::memory_order_relaxed));
-  CacheEntry &e = sh.map[k];
-  e.off = at;
-  e.len = len;
-  *off = e.off;
-  *token = &e;   // node addresses of an unordered_map are stable
+    c->counters.add(1, 1);
+    uint32_t abandoned = 2;
+    if (e->host_kind.load(std::memory_order_acquire) == 0 && e->len == len && state == 2 &&
+        e->ready.compare_exchange_strong(abandoned, 0, std::memory_order_acq_rel)) {
+      *off = e->off;    // the reservation of a list that never ran: this caller fills it
+      *token = e;
+      return 2;
+    }
+    return 0;   // being filled by another search (or a length mismatch: never trusted)
+  };
+  if (CacheEntry *e = c->find(k)) return existing(e);
+  MsiPostingCache::Shard &sh = c->of(k);
+  std::lock_guard<std::mutex> lk(sh.wmu);
+  bool created = false;
+  CacheEntry *e = c->find_or_insert(sh, k, &created, [&](CacheEntry &ne) {
+    const uint64_t need = ((uint64_t)len + 15 + 16) & ~15ull;   // + one block of slack for the last partial block
+    uint64_t at = c->used.load(std::memory_order_relaxed);
+    do {
+      if (at + need > c->cap) return false;
+    } while (!c->used.compare_exchange_weak(at, at + need, std::memory_order_relaxed));
+    ne.off = at;
+    ne.len = len;
+    return true;
+  });
+  c->counters.add(1, 1);
+  if (!e || !created) return 0;   // (somebody else's entry appeared meanwhile: it is being filled; or the arena is full)
+  *off = e->off;
+  *token = e;   // entries never move
   return 2;
 }
 
@@ -2488,11 +2561,9 @@ bool msi_cbo_parse(const uint8_t *bytes, size_t len, std::vector<MsiContainer> &
 uint64_t msi_cbo_cardinality(const uint8_t *bytes, size_t len);
 
 bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting *out) {
-  MsiPostingCache::Shard &sh = c->of(k);
-  std::shared_lock<std::shared_mutex> lk(sh.mu);
-  auto it = sh.map.find(k);
-  if (it == sh.map.end()) return false;
-  const CacheEntry &e = it->second;
+  const CacheEntry *ep = c->find(k);
+  if (!ep) return false;
+  const CacheEntry &e = *ep;
   const uint32_t hk = e.host_kind.load(std::memory_order_acquire);
   if (hk == 1 || hk == 2) {
     out->kind = (int)hk;
@@ -2502,7 +2573,7 @@ bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting 
     out->n_conts = 0;
     out->small = e.small.data();
     out->n_small = (uint32_t)e.small.size();
-    sh.hits.fetch_add(1, std::memory_order_relaxed);
+    c->counters.add(0, 1);
     return true;
   }
   if (e.ready.load(std::memory_order_acquire) != 1 || e.conts.empty()) return false;
@@ -2514,28 +2585,27 @@ bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting 
   out->n_conts = (uint32_t)e.conts.size();
   out->small = nullptr;
   out->n_small = 0;
-  sh.hits.fetch_add(1, std::memory_order_relaxed);
+  c->counters.add(0, 1);
   return true;
 }
 
 // the index answered "no such key" (len 0) or a raw value of <= 7 docids: remembered on the host
 void msi_pcache_learn(MsiPostingCache *c, const MsiCacheKey &k, const uint8_t *bytes, size_t len) {
   if (len > 7 * sizeof(uint32_t)) return;
+  if (c->find(k)) return;   // (known keys are the rule: no lock for them)
   MsiPostingCache::Shard &sh = c->of(k);
-  {
-    std::shared_lock<std::shared_mutex> rd(sh.mu);   // (known keys are the rule: no writer lock for them)
-    if (sh.map.find(k) != sh.map.end()) return;
-  }
-  std::unique_lock<std::shared_mutex> lk(sh.mu);
-  if (sh.map.find(k) != sh.map.end()) return;
-  CacheEntry &e = sh.map[k];
-  for (size_t i = 0; i + 4 <= len; i += 4) {
-    uint32_t v;
-    memcpy(&v, bytes + i, 4);
-    e.small.push_back(v);
-  }
-  e.card = e.small.size();
-  e.host_kind.store(e.small.empty() ? 1u : 2u, std::memory_order_release);
+  std::lock_guard<std::mutex> lk(sh.wmu);
+  bool created = false;
+  (void)c->find_or_insert(sh, k, &created, [&](CacheEntry &e) {
+    for (size_t i = 0; i + 4 <= len; i += 4) {
+      uint32_t v;
+      memcpy(&v, bytes + i, 4);
+      e.small.push_back(v);
+    }
+    e.card = e.small.size();
+    e.host_kind.store(e.small.empty() ? 1u : 2u, std::memory_order_release);
+    return true;
+  });
 }
 
 // the reserved entry's container table, parsed once from the bytes its first reader holds (before msi_pcache_commit)
@@ -2557,11 +2627,8 @@ void msi_pcache_abandon(MsiPostingCache *, void *token) {
 uint64_t msi_pcache_device_base(const MsiPostingCache *c) { return c ? (uint64_t)(uintptr_t)c->dev : 0; }
 
 void msi_pcache_stats(const MsiPostingCache *c, uint64_t out[4]) {
-  out[0] = out[1] = 0;
-  for (const auto &sh : c->shard) {
-    out[0] += sh.hits.load(std::memory_order_relaxed);
-    out[1] += sh.misses.load(std::memory_order_relaxed);
-  }
+  out[0] = c->counters.sum(0);
+  out[1] = c->counters.sum(1);
   out[2] = c->used.load();
   out[3] = c->cap;
 }

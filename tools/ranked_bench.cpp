@@ -457,8 +457,14 @@ int32_t cb_fid(void *u, const uint8_t *w, uint32_t n, uint32_t fid, const uint8_
   const std::string s = str(w, n);
   if (fid < 1 || fid > 3) { *out = 0; return 0; }
   if (ix->corpus) {
+    const std::string key = "f/" + std::to_string(fid) + "/" + s;
+    {   // a warm key is one lookup (the derivation below registers the word's fid and position values in one pass)
+      std::shared_lock<std::shared_mutex> lk(ix->mu);
+      auto it = ix->blobs.find(key);
+      if (it != ix->blobs.end()) return hand(it->second->empty() ? nullptr : it->second.get(), bytes, out);
+    }
     corpus_word(ix, s);
-    return hand(ix->blob("f/" + std::to_string(fid) + "/" + s, [&] { return std::vector<uint32_t>(); }), bytes, out);
+    return hand(ix->blob(key, [&] { return std::vector<uint32_t>(); }), bytes, out);
   }
   return hand(ix->blob("f/" + std::to_string(fid) + "/" + s, [&] {
     std::vector<uint32_t> sel;
@@ -473,8 +479,14 @@ int32_t cb_pos(void *u, const uint8_t *w, uint32_t n, uint32_t pos, const uint8_
   Index *ix = (Index *)u;
   const std::string s = str(w, n);
   if (ix->corpus) {
+    const std::string key = "q/" + std::to_string(pos) + "/" + s;
+    {
+      std::shared_lock<std::shared_mutex> lk(ix->mu);
+      auto it = ix->blobs.find(key);
+      if (it != ix->blobs.end()) return hand(it->second->empty() ? nullptr : it->second.get(), bytes, out);
+    }
     corpus_word(ix, s);
-    return hand(ix->blob("q/" + std::to_string(pos) + "/" + s, [&] { return std::vector<uint32_t>(); }), bytes, out);
+    return hand(ix->blob(key, [&] { return std::vector<uint32_t>(); }), bytes, out);
   }
   return hand(ix->blob("q/" + std::to_string(pos) + "/" + s, [&] {
     std::vector<uint32_t> sel;
@@ -752,6 +764,9 @@ static int32_t cpu_lookup(const uint8_t *w, uint32_t n, uint32_t max_typos, uint
 #include <execinfo.h>
 #include <signal.h>
 #include <sys/time.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
 namespace prof {
 constexpr int DEPTH = 24, CAP = 1 << 17;
 void *g_pc[CAP][DEPTH];
@@ -762,6 +777,7 @@ void on_prof(int) {
   if (i >= CAP) return;
   g_n[i] = backtrace(g_pc[i], DEPTH);
 }
+std::atomic<int> g_per_thread{0};   // > 0: the caller threads arm a timer on their OWN CPU clock (arm_this_thread)
 void start() {
   void *warm[4];
   backtrace(warm, 4);   // (loads libgcc outside the signal handler)
@@ -770,12 +786,35 @@ void start() {
   sa.sa_handler = on_prof;
   sa.sa_flags = SA_RESTART;
   sigaction(SIGPROF, &sa, nullptr);
+  if (getenv("RB_PROFILE_PER_THREAD")) {   // (inside a Python process the process-wide timer's signals mostly got lost: 85 samples)
+    g_per_thread.fetch_add(1);
+    return;
+  }
   struct itimerval it = {{0, 500}, {0, 500}};
   setitimer(ITIMER_PROF, &it, nullptr);
+}
+// a SIGPROF for THIS thread every millisecond of its own CPU time (SIGEV_THREAD_ID): one timer per caller thread
+void arm_this_thread() {
+  thread_local bool armed = false;
+  if (armed || g_per_thread.load() <= 0) return;
+  armed = true;
+  struct sigevent sev;
+  memset(&sev, 0, sizeof(sev));
+  sev.sigev_notify = SIGEV_THREAD_ID;
+  sev.sigev_signo = SIGPROF;
+  sev._sigev_un._tid = (pid_t)syscall(SYS_gettid);
+  timer_t tm;
+  if (timer_create(CLOCK_THREAD_CPUTIME_ID, &sev, &tm) != 0) return;
+  struct itimerspec its = {{0, 1000000}, {0, 1000000}};
+  timer_settime(tm, 0, &its, nullptr);
 }
 void stop(const char *path) {
   struct itimerval it = {{0, 0}, {0, 0}};
   setitimer(ITIMER_PROF, &it, nullptr);
+  if (g_per_thread.load() > 0) {   // (the per-thread timers keep firing: later samples fall off the end of the table)
+    signal(SIGPROF, SIG_IGN);
+    g_per_thread.store(-1);
+  }
   FILE *f = fopen(path, "w");
   if (!f) return;
   FILE *m = fopen("/proc/self/maps", "r");
@@ -1184,6 +1223,7 @@ struct Runner {
         if (stop) return;
         seen = epoch;
       }
+      prof::arm_this_thread();
       for (;;) {
         uint32_t i;
         {
