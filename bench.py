@@ -589,6 +589,11 @@ def run_c4(args, env):
         for first in range(0, n_kw_queries, Q):
             assert kw_lib.rb_run(h, first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data) == 0
         kw["index_derivation_seconds"] = round(time.perf_counter() - t_derive, 1)
+        if hasattr(kw_lib, "rb_freeze"):
+            # what the index derived becomes a snapshot its callbacks read without a lock, as LMDB's readers do (the runner's
+            # reader-writer lock was a sixth of the leg's host CPU on the fresh stream: harness, not engine)
+            kw_lib.rb_freeze.argtypes = [C.c_void_p]
+            assert kw_lib.rb_freeze(h) == 0
         kw["cold_cache_queries_per_s"] = None
         if not env.child:
             phase("c4: primer on a cold posting cache")

@@ -79,6 +79,8 @@ def main():
     t_d = time.perf_counter()
     run(0, total)                                # untimed: the index derives what the queries read; pools create their companions
     derive_s = time.perf_counter() - t_d
+    L.rb_freeze.argtypes = [C.c_void_p]
+    assert L.rb_freeze(h) == 0                   # the index's derived databases: read without a lock from here on (as LMDB's are)
     if a.fresh:
         a.passes = 1
         ma._lib.check(lib.msi_dict_reset_posting_cache(C.c_void_p(L.rb_dict(h))))

@@ -28,6 +28,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "msi.h"
@@ -284,6 +285,21 @@ struct Index {
   std::shared_mutex mu;   // lookups of warm keys (all of them, after the warm-up pass) share the lock
   std::map<std::string, std::shared_ptr<std::vector<uint32_t>>> ids;
   std::map<std::string, std::shared_ptr<Bytes>> blobs;
+  // rb_freeze(): an immutable snapshot of every value and key set derived so far, read WITHOUT any lock (an LMDB read takes
+  // none either; the reader-writer lock above was a sixth of the keyword leg's host CPU on a fresh query stream: every reader
+  // writes the lock word).  Keys derived after the snapshot are found through the locked maps as before.
+  struct Frozen {
+    std::unordered_map<std::string, std::shared_ptr<Bytes>> blobs;
+    std::unordered_map<std::string, std::shared_ptr<WordDerived>> words, prefixes;
+  };
+  std::atomic<const Frozen *> frozen{nullptr};
+  std::vector<std::unique_ptr<Frozen>> frozen_owned;
+  const std::shared_ptr<Bytes> *frozen_blob(const std::string &key) const {
+    const Frozen *f = frozen.load(std::memory_order_acquire);
+    if (!f) return nullptr;
+    auto it = f->blobs.find(key);
+    return it == f->blobs.end() ? nullptr : &it->second;
+  }
   static constexpr uint32_t N_POS = 20;
   static uint32_t position(uint32_t i) { static const uint32_t p[N_POS] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,24,32,64,128}; return p[i]; }
 
@@ -309,6 +325,7 @@ struct Index {
   }
   template <typename F>
   const Bytes *blob(const std::string &key, F make) {
+    if (const std::shared_ptr<Bytes> *b = frozen_blob(key)) return (*b)->empty() ? nullptr : b->get();
     {
       std::shared_lock<std::shared_mutex> lk(mu);
       auto it = blobs.find(key);
@@ -344,6 +361,10 @@ std::string str(const uint8_t *w, uint32_t n) { return std::string((const char *
 // fid, position and key-set reads must not scan it once per key): word_fid_docids f/<fid>/<w>, word_position_docids
 // q/<pos>/<w>, and the key sets (fids, bucketed positions) the engine's prefix_iter reads would return.
 const WordDerived *corpus_word(Index *ix, const std::string &s) {
+  if (const Index::Frozen *f = ix->frozen.load(std::memory_order_acquire)) {
+    auto it = f->words.find(s);
+    if (it != f->words.end()) return it->second.get();
+  }
   {
     std::shared_lock<std::shared_mutex> lk(ix->derived_mu);
     auto it = ix->word_derived.find(s);
@@ -399,6 +420,7 @@ int32_t cb_pair(void *u, uint32_t prox, const uint8_t *l, uint32_t ln, const uin
     // the three proximities of the ordered pair (a, b) in one pass over the documents that hold both: per document the
     // minimum over its fields of p(b) - p(a) for a before b, kept when it is 1..3 (toy_milli.py: MAX_DISTANCE 4)
     const std::string key = "p/" + std::to_string(prox) + "/" + a + "/" + b;
+    if (const std::shared_ptr<Bytes> *fb = ix->frozen_blob(key)) return hand((*fb)->empty() ? nullptr : fb->get(), bytes, out);
     {
       std::shared_lock<std::shared_mutex> lk(ix->mu);
       auto it = ix->blobs.find(key);
@@ -458,6 +480,7 @@ int32_t cb_fid(void *u, const uint8_t *w, uint32_t n, uint32_t fid, const uint8_
   if (fid < 1 || fid > 3) { *out = 0; return 0; }
   if (ix->corpus) {
     const std::string key = "f/" + std::to_string(fid) + "/" + s;
+    if (const std::shared_ptr<Bytes> *fb = ix->frozen_blob(key)) return hand((*fb)->empty() ? nullptr : fb->get(), bytes, out);
     {   // a warm key is one lookup (the derivation below registers the word's fid and position values in one pass)
       std::shared_lock<std::shared_mutex> lk(ix->mu);
       auto it = ix->blobs.find(key);
@@ -480,6 +503,7 @@ int32_t cb_pos(void *u, const uint8_t *w, uint32_t n, uint32_t pos, const uint8_
   const std::string s = str(w, n);
   if (ix->corpus) {
     const std::string key = "q/" + std::to_string(pos) + "/" + s;
+    if (const std::shared_ptr<Bytes> *fb = ix->frozen_blob(key)) return hand((*fb)->empty() ? nullptr : fb->get(), bytes, out);
     {
       std::shared_lock<std::shared_mutex> lk(ix->mu);
       auto it = ix->blobs.find(key);
@@ -1685,6 +1709,25 @@ int32_t rb_hybrid_merge(uint32_t n_queries, uint32_t k, const uint32_t *v_ids, c
                                   k_scores + (size_t)q * k, off.data(), nk, 1.0f - semantic_ratio, 0, k, out_ids + (size_t)q * k,
                                   out_is_semantic + (size_t)q * k, out_semantic_hits + q);
   }
+  return MSI_OK;
+}
+// Everything the index has derived so far becomes an immutable snapshot that the callbacks read without a lock (Index::Frozen).
+// Call it between jobs (no search in flight); keys derived later are still found (through the locked maps).
+int32_t rb_freeze(void *h) {
+  Runner *r = (Runner *)h;
+  std::unique_ptr<Index::Frozen> f(new Index::Frozen());
+  {
+    std::shared_lock<std::shared_mutex> lk(r->ix.mu);
+    f->blobs.reserve(r->ix.blobs.size() * 2);
+    for (auto &kv : r->ix.blobs) f->blobs.emplace(kv.first, kv.second);
+  }
+  {
+    std::shared_lock<std::shared_mutex> lk(r->ix.derived_mu);
+    for (auto &kv : r->ix.word_derived) f->words.emplace(kv.first, kv.second);
+    for (auto &kv : r->ix.prefix_derived) f->prefixes.emplace(kv.first, kv.second);
+  }
+  r->ix.frozen.store(f.get(), std::memory_order_release);
+  r->ix.frozen_owned.push_back(std::move(f));
   return MSI_OK;
 }
 // a sampling CPU profile of the process between the two calls (namespace prof above; symbolise with tools/r3_symbolize.py)
