@@ -92,7 +92,7 @@ def parse_args():
     ap.add_argument("--no-typo", action="store_true")
     ap.add_argument("--no-rank", action="store_true", help="c4: leave the keyword leg and the hybrid merge out")
     ap.add_argument("--kw-slots", type=int, default=512, help="c4: slots of every caller's docid-set pool (n_docs / 8 bytes each)")
-    ap.add_argument("--kw-threads", type=int, default=160, help="c4: caller threads of the keyword leg (one in-flight search each)")
+    ap.add_argument("--kw-threads", type=int, default=256, help="c4: caller threads of the keyword leg (one in-flight search each)")
     ap.add_argument("--kw-terms", type=int, default=3, help="c4: words per keyword query")
     ap.add_argument("--kw-dict-words", type=int, default=None, help="c4: vocabulary of the keyword leg's index (default: 2 000 000 "
                                                                    "for the coherent corpus, 200 000 for the hashed index)")
@@ -559,12 +559,13 @@ def run_c4(args, env):
         h = (kw_lib.rb_create_corpus(n_docs_kw, args.kw_dict_words, 42) if args.kw_corpus == "coherent"
              else kw_lib.rb_create(n_docs_kw, args.kw_dict_words))
         corpus_s = time.time() - t_corpus
-        # Caller threads of this rank: a waiting search costs no CPU, but a search in flight needs ~1.2 ms of host CPU per
-        # query (round 3; 1.7 ms in round 2) — N ranks share the box's CPUs, so each rank gets its share of callers: 10 per
-        # granted CPU (160 on a 16-CPU grant: 12.8 CPUs busy; 192 callers measured 15.5 CPUs and 256 callers ran into the
-        # quota and lost two thirds of the throughput, profiles/r3_callers.txt), at least 16
+        # Caller threads of this rank: a waiting search costs no CPU, a search in flight ~0.9-1.0 ms of host CPU per fresh query
+        # (round 5; 1.2 ms in round 3, 1.7 ms in round 2) — N ranks share the box's CPUs, so each rank gets its share of callers:
+        # 16 per granted CPU (256 on a 16-CPU grant: 11.3 CPUs busy, 9 055 hybrid q/s against 8 284 at 160 callers and 8 530 at
+        # 208, keyword p50 at load 17.0 / 11.9 / 14.0 ms: profiles/r5_callers.log; round 3's 10 per CPU dates from 1.2 ms per
+        # query, when 256 callers ran into the CPU quota), at least 16
         host_cpus = granted_cpus()
-        kw_threads = max(16, min(args.kw_threads, host_cpus * int(os.environ.get("MSI_BENCH_CALLERS_PER_CPU", "10")) // world))
+        kw_threads = max(16, min(args.kw_threads, host_cpus * int(os.environ.get("MSI_BENCH_CALLERS_PER_CPU", "16")) // world))
         assert kw_lib.rb_attach(h, ctx.handle, kw_threads, args.kw_slots, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
         # The keyword stream does NOT repeat (round 4 cycled 4 x Q queries through 20 steps against a posting
         # cache at hit rate 0.98): `kw_prime` primer queries — what the index served before the measurement started — and then

@@ -92,3 +92,45 @@ def test_occupancy_the_host_code_counts_on():
     v = kernel_vgprs(os.path.join(csrc, "msi_vm.o"))
     vm = [x for k, x in v.items() if "vm_kernel" in k]
     assert vm and vm[0] <= 128, v                          # 4 waves per SIMD = four 4-wave workgroups per CU (LDS: 36.8 KB each)
+
+
+def test_the_int8_sweep_as_it_was_compiled():
+    """Round 5's dominant kernel on the built object: the default shapes of vs_scan_i8_kernel (8 waves; 8 / 6 / 4 query tiles)
+    keep their accumulators and row buffers in registers (a 512-thread workgroup leaves 256 per wave: no scratch in the sparse
+    main pass), the matrix work is v_mfma_i32_16x16x64_i8, and the rows are streamed with non-temporal 16-byte loads."""
+    csrc = os.path.join(ROOT, "meilisearch_amd", "csrc")
+    obj = os.path.join(csrc, "msi_vs.o")
+    if not os.path.exists(obj) or not os.path.exists(OBJDUMP):
+        pytest.skip("objects not built / no llvm-objdump")
+    readelf = os.path.join(os.path.dirname(OBJDUMP), "llvm-readelf")
+    tmp = tempfile.mkdtemp(prefix="msi_isa_")
+    try:
+        local = os.path.join(tmp, "msi_vs.o")
+        shutil.copy(obj, local)
+        subprocess.run([OBJDUMP, "--offloading", local], capture_output=True, text=True, check=True)
+        co = os.path.join(tmp, [f for f in os.listdir(tmp) if "gfx950" in f][0])
+        notes = subprocess.run([readelf, "--notes", co], capture_output=True, text=True, check=True).stdout
+        asm = subprocess.run([OBJDUMP, "-d", co], capture_output=True, text=True, check=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    meta, name = {}, None
+    for line in notes.split("\n"):
+        m = re.search(r"\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+            meta[name] = {}
+        for key in ("vgpr_count", "vgpr_spill_count"):
+            m = re.search(r"\." + key + r":\s+(\d+)", line)
+            if m and name:
+                meta[name][key] = int(m.group(1))
+    # vs_scan_i8_kernel<WAVES = 8, NQT, RT, GS, DENSE = false>: the sparse main pass of the shapes the library launches by default
+    main = {k: v for k, v in meta.items() if "vs_scan_i8_kernelILi8E" in k and k.endswith("Lb0EEEvNS_9Scan8ArgsE")}
+    for nqt, rt in ((8, 2), (6, 2), (4, 3)):
+        hit = {k: v for k, v in main.items() if f"ILi8ELi{nqt}ELi{rt}ELi" in k}
+        assert len(hit) == 3, (nqt, rt, sorted(main))                         # one per pipeline depth GS = 4 / 3 / 2
+        for k, v in hit.items():
+            assert v["vgpr_count"] <= 256 and v["vgpr_spill_count"] == 0, (k, v)
+    body = asm.split("<_ZN12_GLOBAL__N_117vs_scan_i8_kernelILi8ELi8ELi2ELi4ELb0EEEvNS_9Scan8ArgsE>:")[1].split("s_endpgm")[0]
+    assert body.count("v_mfma_i32_16x16x64_i8") == 8 * 2 * 4 * 2              # NQT x RT x GS, for each of the two row buffers
+    loads = [ln for ln in body.split("\n") if "global_load_dwordx4" in ln and " nt" in ln]
+    assert len(loads) >= 2 * 4 * 2                                            # RT x GS per buffer, non-temporal
