@@ -259,11 +259,14 @@ def sweep_kernel(stats, n_rows):
     return "vs_scan_kernel (main pass)", "vs_scan_kernel", tiles * stats["bytes_per_tile"]
 
 
-def scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kernel_name, must_contain=(), kernel_prefix="vs_scan_kernel"):
+def scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kernel_name, must_contain=(), kernel_prefix="vs_scan_kernel",
+                  measured=None):
     scan_avg_ms = scan_ms / max(1, scan_n)
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
     traffic, src = None, "not measured (--no-pmc, child run, or N > 1)"
-    if env.rank == 0 and env.world == 1 and not args.no_pmc and not env.child:
+    if measured is not None:
+        traffic, src = measured
+    elif env.rank == 0 and env.world == 1 and not args.no_pmc and not env.child:
         traffic, src = pmc_traffic(args, kernel_prefix, must_contain)
     return {"kernel": kernel_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM reads, PMC)",
@@ -468,6 +471,14 @@ def run_c4(args, env):
         r0, r1 = row_range(n_total, rank, world)
         n = r1 - r0          # this rank's shard; docids stay global
 
+    # roofline.traffic comes from a child of this run under `rocprofv3 --pmc` that builds the same store: it runs FIRST, while this
+    # process holds nothing on the device (behind 256 caller pools, the store, its rows and the posting cache the child's
+    # 70 GB no longer fit: the round's first 256-caller line came back with traffic null)
+    pmc_early = None
+    if env.rank == 0 and env.world == 1 and not args.no_pmc and not env.child:
+        phase("c4: roofline (PMC child)")
+        has_i8 = (args.storage or "f32") == "f32" and os.environ.get("MSI_VS_I8", "1") != "0"
+        pmc_early = pmc_traffic(args, "vs_scan_i8_kernel" if has_i8 else "vs_scan_kernel", ("false",))
     phase("c4: rows + store upload")
     t_setup = time.time()
     rows_t = synth.device_rows(n, d, dev, seed=1234 + (rank if row_sharded else 0))
@@ -1001,7 +1012,7 @@ def run_c4(args, env):
         if want_extra:
             guarded_extra(None)
         return None
-    phase("c4: roofline (PMC child)")
+    phase("c4: assembling the line")
     total_queries = Q * (1 if row_sharded else world) * args.steps
     kname, kprefix, algo_bytes = sweep_kernel(stats, n)      # one sweep of the level-0 kernel
     out = {
@@ -1075,7 +1086,8 @@ def run_c4(args, env):
             "keyword_index_derivation_seconds": kw.get("index_derivation_seconds") if kw is not None else None,
             "setup_seconds": round(setup_s, 1),
         },
-        "roofline": scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kname, must_contain=("false",), kernel_prefix=kprefix),
+        "roofline": scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kname, must_contain=("false",), kernel_prefix=kprefix,
+                                  measured=pmc_early),
         "legs": legs,
         "latency": latency,
         "rows_sharded": None,
