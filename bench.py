@@ -268,7 +268,12 @@ def scan_roofline(args, env, store, scan_n, scan_ms, algo_bytes, kernel_name, mu
         traffic, src = measured
     elif env.rank == 0 and env.world == 1 and not args.no_pmc and not env.child:
         traffic, src = pmc_traffic(args, kernel_prefix, must_contain)
+    n_rows = len(store)
     return {"kernel": kernel_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+            "bytes_per_row": round(algo_bytes / n_rows, 1) if n_rows else None,
+            "bytes_per_row_is": "algorithmic bytes of one launch / rows of the store: dpad + 8 for the int8 sweep (the int8 row, its scale, "
+                                "its inverse norm), dpad x 4 for a sweep of f32 rows (SURVEY 8 d), dpad x 2 for bf16 rows; a filtered "
+                                "sweep streams only the tiles that hold an allowed row",
             "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_unit": "GB per launch (HBM reads, PMC)",
             "traffic_source": src, "algorithmic_bytes_per_launch": int(algo_bytes),
             "avg_launch_ms": round(scan_avg_ms, 4), "launches_timed": scan_n,
@@ -1752,7 +1757,7 @@ def _roofline_short(r):
     if not isinstance(r, dict):
         return None
     o = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_timed",
-                  "algorithmic_bytes_per_launch"))
+                  "algorithmic_bytes_per_launch", "bytes_per_row"))
     if "kernel" in o:
         o["kernel"] = _clip(o["kernel"], 48)
     if "traffic" not in o:
@@ -1810,7 +1815,7 @@ def short_line(full, detail_path=None):
     out["scaling"] = full.get("scaling", "weak")
     out["vs_baseline"] = full.get("vs_baseline")
     out["dtype"] = full.get("dtype")
-    out["data"] = _clip(full.get("data", "synthetic"), 100)
+    out["data"] = _clip(full.get("data", "synthetic"), 72)
     c = {"workload": _clip(cfg.get("workload", ""), 420)}
     c.update(_pick(cfg, ("queries_per_step_per_gpu", "words_per_step_per_gpu", "queries_per_hbm_sweep", "rccl_ranks_seen",
                          "keyword_callers_per_rank", "host_cpus_granted", "keyword_corpus", "keyword_stream",

@@ -82,3 +82,20 @@ def test_a_line_without_side_configurations():
         full.pop(k, None)
     got = json.loads(b.short_line(full))
     assert got["value"] == full["value"] and "also" not in got and got["roofline"]["frac"] == full["roofline"]["frac"]
+
+
+def test_round_5_object_fits_too():
+    """The round-5 result object (int8 level, per-rank fields, C5 CPU baselines at three densities, phase and step times)."""
+    b = _bench()
+    with open(os.path.join(ROOT, "profiles", "r5_bench_c4.json")) as f:
+        full = json.load(f)
+    line = b.short_line(full, "gpurun_out/bench_detail_c4_n1.json")
+    assert len(line.encode()) < 4096
+    got = json.loads(line)
+    for key in REQUIRED:
+        assert key in got, key
+    assert got["config"]["rccl_ranks_seen"] == 1 and abs(got["config"]["per_rank_values"][0] - full["value"]) < 0.1
+    assert got["roofline"]["kernel"].startswith("vs_scan_i8_kernel") and got["roofline"]["traffic"] is not None
+    assert set(got["also"]["c5"]["by_filter_density"]) == {"0.1", "0.01", "0.001"}
+    assert all(v.get("cpu") for v in got["also"]["c5"]["by_filter_density"].values())      # the CPU port at every density
+    assert "step_ms" not in got and "phase_seconds" not in got                             # detail only
