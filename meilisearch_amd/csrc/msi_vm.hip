@@ -1547,7 +1547,24 @@ struct VmCombiner {
   u64 *d_prof = nullptr;                   // MSI_VM_PROFILE: 16 tick counters in device memory
   std::atomic<int32_t> *fused_wgs = nullptr;   // msi_vm::fused_wgs: the device's waiting workgroups in flight
   int32_t fused_budget = 256;                  // msi_vm::fused_budget
+  // The reaper (MSI_VM_REAPER, default on): a second thread that only watches the completion words of the rounds in flight
+  // and wakes their searches.  One thread doing everything served a round in ~120 us (pack 23 lists, one copy, 2-3 launch
+  // calls, then 23 futex wake-ups: the most expensive step) and was busy 0.66-0.73 of the time at 12-13 k searches/s — a
+  // completion that arrived while it packed the next round was noticed only after that round's launch calls, and a list that
+  // arrived while it woke 23 sleepers waited for that.  The launching thread now hands a launched round over and goes back
+  // to its queue.
+  bool split = true;
+  std::thread reaper_th;
+  std::mutex hand_mu, trace_mu;
+  std::condition_variable hand_cv;
+  std::vector<VmSub *> handed;             // launched, not yet seen by the reaper (guarded by hand_mu)
+  bool reaper_stop = false;                // guarded by hand_mu
+  std::atomic<uint32_t> n_inflight{0};     // launched and not finished (either thread's view of "rounds in flight")
+  FILE *trace = nullptr;
+  void finish(VmSub *s, uint32_t st);
+  bool settle(VmSub *s, int64_t t_now);    // -> true when `s` is finished (completion word seen, or given up on after 5 s)
   void run();
+  void reap();
 };
 
 // The context's combiners: pools are spread over a few of them (a combiner is one thread: packing, launching, noticing
@@ -1625,6 +1642,114 @@ static void futex_wait_for(std::atomic<uint32_t> *w, uint32_t expected, long tim
 #endif
 }
 
+void VmCombiner::finish(VmSub *s, uint32_t st) {
+  s->t_done = now_ns();
+  if (s->fused_wgs) {
+    fused_wgs->fetch_sub((int32_t)s->fused_wgs, std::memory_order_relaxed);
+    s->fused_wgs = 0;
+  }
+  if (trace && s->list) {   // diagnostics: what a list was made of and how long the device took for it
+    std::lock_guard<std::mutex> tlk(trace_mu);
+    const std::vector<uint32_t> &w = s->list->words;
+    uint32_t ops[32] = {0}, max_paths = 0, max_steps = 0, clear_slots = 0;
+    const size_t w_end = s->list->data_off ? s->list->data_off : w.size();
+    for (size_t i = 0; i < w_end;) {
+      const uint32_t op = w[i];
+      if (op < 32) ++ops[op];
+      switch (op) {
+        case VM_END: i += 1; break;
+        case VM_FILL: i += 3; break;
+        case VM_OP: i += 5; break;
+        case VM_OP_COUNT: i += 6; break;
+        case VM_CLEAR: clear_slots += w[i + 1]; i += 2 + w[i + 1]; break;
+        case VM_CLAIM: i += 5 + w[i + 4]; break;
+        case VM_AND_MANY: i += 4 + 2 * w[i + 2]; break;
+        case VM_PATHS: max_paths = std::max(max_paths, w[i + 1]); max_steps = std::max(max_steps, w[i + 5] & 0x7FFFFFFFu); i += 7 + w[i + 1] + (w[i + 5] & 0x7FFFFFFFu); break;
+        case VM_SUB_MANY: i += 4 + w[i + 2]; break;
+        case VM_COUNT: i += 3; break;
+        case VM_DECODE: i += 4; break;
+        case VM_FIRSTK: i += 5; break;
+        case VM_MINKEY: i += 5; break;
+        case VM_TAKEKEY: i += 8; break;
+        case VM_SUMMARY_RESET: i += 1; break;
+        case VM_RANK_A: i += 4; break;
+        case VM_RANK_B: i += 5; break;
+        case VM_DECODEC: i += 3; break;
+        default: i = w_end; break;
+      }
+    }
+    fprintf(trace, "%s%u phases counts %u rankA %u rankB %u decodeC %u | ", s->list->geom_docs ? "compact " : "full ", (unsigned)s->list->phase_start.size(),
+            s->list->n_counts, ops[VM_RANK_A], ops[VM_RANK_B], ops[VM_DECODEC]);
+    fprintf(trace, "%.1f us words %zu stage %zu fill %u op %u opc %u clear %u(%u slots) claim %u andmany %u paths %u(max %u paths %u steps) sub %u count %u decode %u firstk %u\n",
+            (s->t_done - s->t_launch) / 1e3, w_end, s->list->stage_used, ops[VM_FILL], ops[VM_OP], ops[VM_OP_COUNT], ops[VM_CLEAR],
+            clear_slots, ops[VM_CLAIM], ops[VM_AND_MANY], ops[VM_PATHS], max_paths, max_steps, ops[VM_SUB_MANY], ops[VM_COUNT],
+            ops[VM_DECODE], ops[VM_FIRSTK]);
+  }
+  s->state.store(st, std::memory_order_seq_cst);
+  // a waiter that is still polling needs no system call (the wake-up is the combiner's most expensive step)
+  if (s->asleep.load(std::memory_order_seq_cst)) futex_wake_all(&s->state);
+}
+
+// one list in flight: has the GPU stored its sequence number into its pool's pinned block?
+bool VmCombiner::settle(VmSub *s, int64_t t_now) {
+  if (__atomic_load_n(const_cast<uint64_t *>(&s->blk[0]), __ATOMIC_ACQUIRE) == s->seq) {
+    finish(s, 1);
+    return true;
+  }
+  if (t_now - s->t_launch > 5000000000ll) {   // 5 s: settle it with the streams, then give up on it
+    for (auto stq : streams) (void)hipStreamSynchronize(stq);
+    if (__atomic_load_n(const_cast<uint64_t *>(&s->blk[0]), __ATOMIC_ACQUIRE) == s->seq) {
+      finish(s, 1);
+    } else {
+      s->error = MSI_E_INTERNAL;
+      finish(s, 2);
+    }
+    return true;
+  }
+  return false;
+}
+
+// The reaper's loop: the rounds handed over by the launching thread, polled until their lists have run.
+void VmCombiner::reap() {
+  (void)hipSetDevice(ctx->device);
+  const long poll_sleep_ns = (getenv("MSI_VM_POLL_SLEEP_US") ? std::max(0, atoi(getenv("MSI_VM_POLL_SLEEP_US"))) : 20) * 1000l;
+  if (poll_sleep_ns > 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);
+  std::vector<VmSub *> mine;
+  uint64_t cpu_seen = msi_cpu_prof_on() ? msi_thread_cpu_ns() : 0;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(hand_mu);
+      if (mine.empty()) hand_cv.wait(lk, [&] { return reaper_stop || !handed.empty(); });
+      if (reaper_stop && handed.empty() && mine.empty()) return;
+      mine.insert(mine.end(), handed.begin(), handed.end());
+      handed.clear();
+    }
+    size_t kept = 0;
+    const int64_t t_now = now_ns();
+    for (VmSub *s : mine) {
+      if (settle(s, t_now)) n_inflight.fetch_sub(1, std::memory_order_release);
+      else mine[kept++] = s;
+    }
+    const bool progress = kept != mine.size();
+    mine.resize(kept);
+    if (progress && msi_cpu_prof_on()) {   // this thread's CPU joins the combiner's (msi_search_cpu_profile [6])
+      const uint64_t now_cpu = msi_thread_cpu_ns();
+      msi_cpu_prof_add(6, now_cpu - cpu_seen);
+      cpu_seen = now_cpu;
+    }
+    if (!mine.empty() && !progress) {   // (as the combiner's own polling: a nap under load, a spin when a search's latency is the round trip)
+      if (poll_sleep_ns > 0 && load.load(std::memory_order_relaxed) > 3) {
+        struct timespec ts = {0, poll_sleep_ns};
+        nanosleep(&ts, nullptr);
+      } else {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+    }
+  }
+}
+
 void VmCombiner::run() {
   (void)hipSetDevice(ctx->device);
   std::vector<VmSub *> inflight, taken;
@@ -1637,7 +1762,7 @@ void VmCombiner::run() {
   // (a compact list's decodes are as heavy as a full list's: they read the same posting bytes)
   auto is_heavy = [](const VmSub *s) { return s->list->decodes.size() > 2 || s->list->words.size() > 600; };
   std::vector<VmSub *> waiting[2];   // taken from the queue, not launched yet (their class's arena is still in use)
-  FILE *trace = getenv("MSI_VM_TRACE") ? fopen(getenv("MSI_VM_TRACE"), "w") : nullptr;
+  trace = getenv("MSI_VM_TRACE") ? fopen(getenv("MSI_VM_TRACE"), "w") : nullptr;
   const int64_t batch_wait_ns = (getenv("MSI_VM_BATCH_WAIT_US") ? atoi(getenv("MSI_VM_BATCH_WAIT_US")) : 200) * 1000ll;
   const size_t batch_div = getenv("MSI_VM_BATCH_DIV") ? std::max(1, atoi(getenv("MSI_VM_BATCH_DIV"))) : 2;
   const size_t batch_cap = getenv("MSI_VM_BATCH_CAP") ? std::max(1, atoi(getenv("MSI_VM_BATCH_CAP"))) : 32;
@@ -1645,58 +1770,16 @@ void VmCombiner::run() {
   if (poll_sleep_ns > 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);   // (this thread only: the default 50 us slack would triple the sleep)
   if (getenv("MSI_VM_PROFILE") && hipMalloc((void **)&d_prof, 32 * sizeof(u64)) == hipSuccess) (void)hipMemset(d_prof, 0, 32 * sizeof(u64));
   uint64_t cpu_seen = msi_cpu_prof_on() ? msi_thread_cpu_ns() : 0;
-  auto finish = [&](VmSub *s, uint32_t st) {
-    s->t_done = now_ns();
-    if (s->fused_wgs) {
-      fused_wgs->fetch_sub((int32_t)s->fused_wgs, std::memory_order_relaxed);
-      s->fused_wgs = 0;
-    }
-    if (trace && s->list) {   // diagnostics: what a list was made of and how long the device took for it
-      const std::vector<uint32_t> &w = s->list->words;
-      uint32_t ops[32] = {0}, max_paths = 0, max_steps = 0, clear_slots = 0;
-      const size_t w_end = s->list->data_off ? s->list->data_off : w.size();
-      for (size_t i = 0; i < w_end;) {
-        const uint32_t op = w[i];
-        if (op < 32) ++ops[op];
-        switch (op) {
-          case VM_END: i += 1; break;
-          case VM_FILL: i += 3; break;
-          case VM_OP: i += 5; break;
-          case VM_OP_COUNT: i += 6; break;
-          case VM_CLEAR: clear_slots += w[i + 1]; i += 2 + w[i + 1]; break;
-          case VM_CLAIM: i += 5 + w[i + 4]; break;
-          case VM_AND_MANY: i += 4 + 2 * w[i + 2]; break;
-          case VM_PATHS: max_paths = std::max(max_paths, w[i + 1]); max_steps = std::max(max_steps, w[i + 5] & 0x7FFFFFFFu); i += 7 + w[i + 1] + (w[i + 5] & 0x7FFFFFFFu); break;
-          case VM_SUB_MANY: i += 4 + w[i + 2]; break;
-          case VM_COUNT: i += 3; break;
-          case VM_DECODE: i += 4; break;
-          case VM_FIRSTK: i += 5; break;
-          case VM_MINKEY: i += 5; break;
-          case VM_TAKEKEY: i += 8; break;
-          case VM_SUMMARY_RESET: i += 1; break;
-          case VM_RANK_A: i += 4; break;
-          case VM_RANK_B: i += 5; break;
-          case VM_DECODEC: i += 3; break;
-          default: i = w_end; break;
-        }
-      }
-      fprintf(trace, "%s%u phases counts %u rankA %u rankB %u decodeC %u | ", s->list->geom_docs ? "compact " : "full ", (unsigned)s->list->phase_start.size(),
-              s->list->n_counts, ops[VM_RANK_A], ops[VM_RANK_B], ops[VM_DECODEC]);
-      fprintf(trace, "%.1f us words %zu stage %zu fill %u op %u opc %u clear %u(%u slots) claim %u andmany %u paths %u(max %u paths %u steps) sub %u count %u decode %u firstk %u\n",
-              (s->t_done - s->t_launch) / 1e3, w_end, s->list->stage_used, ops[VM_FILL], ops[VM_OP], ops[VM_OP_COUNT], ops[VM_CLEAR],
-              clear_slots, ops[VM_CLAIM], ops[VM_AND_MANY], ops[VM_PATHS], max_paths, max_steps, ops[VM_SUB_MANY], ops[VM_COUNT],
-              ops[VM_DECODE], ops[VM_FIRSTK]);
-    }
-    s->state.store(st, std::memory_order_seq_cst);
-    // a waiter that is still polling needs no system call (the wake-up is the combiner's most expensive step)
-    if (s->asleep.load(std::memory_order_seq_cst)) futex_wake_all(&s->state);
-  };
   // one round: pack the lists into the class's next arena, one H2D copy, one launch per phase
   auto launch_round = [&](int cls, std::vector<VmSub *> &batch) {
     const int cur = cur_of[cls];
     Arena &A = ar[cur];
     hipStream_t stream = streams[cur];
     const size_t n_sub = batch.size();
+    {   // (read per round, as the knobs below: one process can hold the two forms side by side — tools/kw_leg.py --sweep)
+      const char *rk = getenv("MSI_VM_REAPER");   // 0: this thread also notices the round's completion (rounds 2-4)
+      split = reaper_th.joinable() && !(rk && rk[0] == '0');
+    }
     size_t off = 64 + align16(n_sub * sizeof(RoundSub));
     std::vector<size_t> words_at(n_sub), state_at(n_sub);
     // geometry of a list: its pool's, or — a compact list — geom_docs documents per set on the companion pool
@@ -1844,7 +1927,16 @@ void VmCombiner::run() {
         finish(s, 2);
       }
     } else {
-      inflight.insert(inflight.end(), batch.begin(), batch.end());
+      n_inflight.fetch_add((uint32_t)batch.size(), std::memory_order_relaxed);
+      if (split) {   // the reaper watches them from here on
+        {
+          std::lock_guard<std::mutex> lk(hand_mu);
+          handed.insert(handed.end(), batch.begin(), batch.end());
+        }
+        hand_cv.notify_one();
+      } else {
+        inflight.insert(inflight.end(), batch.begin(), batch.end());
+      }
     }
     batch.clear();
     cur_of[cls] = (cur + 2) % NS;
@@ -1853,12 +1945,13 @@ void VmCombiner::run() {
     taken.clear();
     {
       std::unique_lock<std::mutex> lk(mu);
-      if (queue.empty() && inflight.empty() && waiting[0].empty() && waiting[1].empty()) {
+      const bool flying = n_inflight.load(std::memory_order_acquire) != 0;
+      if (queue.empty() && !flying && waiting[0].empty() && waiting[1].empty()) {
         sleeping = true;
         cv.wait(lk, [&] { return stop || !queue.empty(); });
         sleeping = false;
       }
-      if (stop && queue.empty() && inflight.empty() && waiting[0].empty() && waiting[1].empty()) return;
+      if (stop && queue.empty() && n_inflight.load(std::memory_order_acquire) == 0 && waiting[0].empty() && waiting[1].empty()) return;
       taken.swap(queue);
     }
     if (!taken.empty()) {
@@ -1877,7 +1970,7 @@ void VmCombiner::run() {
       // the searches in flight (at most 32) waits up to 200 us for company.  10 M documents, detailed scores, 64 callers:
       // 3 250 -> 4 555 queries/s, p50 19.3 -> 13.3 ms; one caller is never held (nothing else is in flight).
       // (MSI_VM_BATCH_WAIT_US / _DIV / _CAP: experiments; profiles/r2_ranked_10m_batching.txt)
-      if (batch_wait_ns && !inflight.empty() && waiting[cls].size() < std::min<size_t>(batch_cap, load.load(std::memory_order_relaxed) / batch_div) &&
+      if (batch_wait_ns && n_inflight.load(std::memory_order_relaxed) != 0 && waiting[cls].size() < std::min<size_t>(batch_cap, load.load(std::memory_order_relaxed) / batch_div) &&
           now_ns() - waiting[cls].front()->t_taken < batch_wait_ns)
         continue;
       Arena &A0 = ar[cur_of[cls]];
@@ -1889,26 +1982,18 @@ void VmCombiner::run() {
       waiting[cls].erase(waiting[cls].begin(), waiting[cls].begin() + n);
       launch_round(cls, batch);
     }
-    // ---- completion: the GPU stored the list's sequence number into its pool's pinned block -------------------
-    size_t kept = 0;
-    const int64_t t_now = now_ns();
-    for (VmSub *s : inflight) {
-      if (__atomic_load_n(const_cast<uint64_t *>(&s->blk[0]), __ATOMIC_ACQUIRE) == s->seq) {
-        finish(s, 1);
-      } else if (t_now - s->t_launch > 5000000000ll) {   // 5 s: settle it with the streams, then give up on it
-        for (auto stq : streams) (void)hipStreamSynchronize(stq);
-        if (__atomic_load_n(const_cast<uint64_t *>(&s->blk[0]), __ATOMIC_ACQUIRE) == s->seq) {
-          finish(s, 1);
-        } else {
-          s->error = MSI_E_INTERNAL;
-          finish(s, 2);
-        }
-      } else {
-        inflight[kept++] = s;
+    // ---- completion: the GPU stored the list's sequence number into its pool's pinned block (the reaper's work when
+    // there is one: VmCombiner::reap) -----------------------------------------------------------------------------
+    if (!inflight.empty()) {   // (rounds this thread kept: MSI_VM_REAPER=0 when they were launched)
+      size_t kept = 0;
+      const int64_t t_now = now_ns();
+      for (VmSub *s : inflight) {
+        if (settle(s, t_now)) n_inflight.fetch_sub(1, std::memory_order_release);
+        else inflight[kept++] = s;
       }
+      inflight.resize(kept);
     }
-    inflight.resize(kept);
-    if (taken.empty() && !inflight.empty()) {
+    if (taken.empty() && n_inflight.load(std::memory_order_relaxed) != 0) {
       // Nothing new and rounds in flight: the combiner polls their completion words.  With a few searches in flight it
       // spins (their latency is the round trip); under load it sleeps 20 us between polls (MSI_VM_POLL_SLEEP_US, 0 = always
       // spin): measured free on one GPU (8.1 k -> 8.2-8.3 k keyword searches/s, half a CPU less: profiles/r3_pollsleep.txt),
@@ -1952,6 +2037,7 @@ static msi_vm *vm_of(msi_ctx *ctx) {
           return nullptr;
         }
       VmCombiner *raw = cb.get();
+      cb->reaper_th = std::thread([raw] { raw->reap(); });   // (asleep while MSI_VM_REAPER=0 keeps the rounds with the combiner)
       cb->th = std::thread([raw] { raw->run(); });
       vm->comb.push_back(std::move(cb));
     }
@@ -1969,7 +2055,13 @@ void msi_vm_destroy(msi_vm *vmx) {
       vm->stop = true;
     }
     vm->cv.notify_all();
-    if (vm->th.joinable()) vm->th.join();
+    if (vm->th.joinable()) vm->th.join();   // (returns once nothing is queued, waiting or in flight: the reaper is still there for that)
+    {
+      std::lock_guard<std::mutex> lk(vm->hand_mu);
+      vm->reaper_stop = true;
+    }
+    vm->hand_cv.notify_all();
+    if (vm->reaper_th.joinable()) vm->reaper_th.join();
     DeviceGuard g(vm->ctx->device);
     for (auto st : vm->streams)
       if (st) (void)hipStreamSynchronize(st);

@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
+#include <pthread.h>
+#include <signal.h>
 
 #include <algorithm>
 #include <chrono>
@@ -402,6 +404,12 @@ inline void run_block() {
 inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
   if (shmem > 160 * 1024) { fprintf(stderr, "hipemu: %zu bytes of LDS requested (160 KiB per workgroup on gfx950)\n", shmem); abort(); }
   std::lock_guard<std::mutex> lk(launch_mu);   // one launch at a time, whichever emulated device or host thread it comes from
+  // a sampling profiler's SIGPROF (tools/kw_leg.py --emulated with KW_PROFILE) must not unwind a lane's hand-made stack
+  struct ProfMask {
+    sigset_t old;
+    ProfMask() { sigset_t s; sigemptyset(&s); sigaddset(&s, SIGPROF); pthread_sigmask(SIG_BLOCK, &s, &old); }
+    ~ProfMask() { pthread_sigmask(SIG_SETMASK, &old, nullptr); }
+  } prof_mask;
   if (shmem > g.dyn_bytes) {
     free(g.dyn_lds);
     g.dyn_lds = (unsigned char *)aligned_alloc(16, (shmem + 15) & ~(size_t)15);

@@ -18,7 +18,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "meilisearch_amd", "csrc")
-BUILD = os.path.join(ROOT, "tests", "emu", "_build")
+# MSI_EMU_OPT (e.g. "-O2"): a second build in its own directory, for HOST CPU profiles of the search threads (tools/kw_leg.py
+# --emulated); the test tier always runs the -O1 build
+OPT = os.environ.get("MSI_EMU_OPT", "-O1")
+BUILD = os.path.join(ROOT, "tests", "emu", "_build" if OPT == "-O1" else "_build" + OPT.replace("-", "_"))
 SO = os.path.join(BUILD, "libmsi_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"   # plain C++ mode: ext_vector_type and __bf16 as the kernels spell them
 
@@ -32,7 +35,7 @@ def build():
         return SO
     os.makedirs(BUILD, exist_ok=True)
     tmp = SO + f".{os.getpid()}.tmp"
-    subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
+    subprocess.check_call([CLANG, "-std=c++17", OPT, "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
                            "-I" + os.path.join(ROOT, "tests", "emu"), "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
                           + sources + ["-Wl,-Bsymbolic", "-o", tmp, "-lpthread", "-ldl"])
     os.replace(tmp, SO)
@@ -49,7 +52,7 @@ def build_rccl():
         return RCCL_SO
     os.makedirs(BUILD, exist_ok=True)
     tmp = RCCL_SO + f".{os.getpid()}.tmp"
-    subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", src, "-o", tmp, "-lpthread"])
+    subprocess.check_call([CLANG, "-std=c++17", OPT, "-g", "-fPIC", "-shared", src, "-o", tmp, "-lpthread"])
     os.replace(tmp, RCCL_SO)
     return RCCL_SO
 
@@ -65,7 +68,7 @@ def build_runner():
     if os.path.exists(RUNNER_SO) and all(os.path.getmtime(d) <= os.path.getmtime(RUNNER_SO) for d in (src, SO)):
         return RUNNER_SO
     tmp = RUNNER_SO + f".{os.getpid()}.tmp"
-    subprocess.check_call([CLANG, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DRANKED_BENCH_LIB", "-x", "c++",
+    subprocess.check_call([CLANG, "-std=c++17", OPT, "-g", "-fPIC", "-shared", "-DRANKED_BENCH_LIB", "-x", "c++",
                            "-I" + os.path.join(ROOT, "include"), src, "-L" + BUILD, "-lmsi_emu", "-Wl,-rpath," + BUILD,
                            "-lpthread", "-o", tmp])
     os.replace(tmp, RUNNER_SO)

@@ -65,6 +65,17 @@ for mod, rels in by_mod.items():
     for r in rels:
         i = bisect.bisect_right(addrs, r) - 1
         sym[(mod, r)] = table[i][1] if i >= 0 else os.path.basename(mod)
+# EXCLUDE="a,b": drop the samples with a frame whose name contains one of these (an emulated run's kernel emulation:
+# EXCLUDE=hipemu::,pthread_sigmask leaves the host logic of the search threads)
+excl = [x for x in os.environ.get("EXCLUDE", "").split(",") if x]
+if excl:
+    kept = []
+    for s in samples:
+        names = [sym.get(locate(pc - 1), "?") for pc in s[SKIP:]]
+        if not any(x in nm for nm in names for x in excl):
+            kept.append(s)
+    print("EXCLUDE: kept", len(kept), "of", len(samples), "samples")
+    samples = kept
 incl, leaf = collections.Counter(), collections.Counter()
 for s in samples:
     names = []

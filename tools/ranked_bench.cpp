@@ -1178,6 +1178,7 @@ struct Runner {
   std::vector<double> lat_ms;                // wall time of every search of the last job (rb_last_latencies)
   bool stop = false;
   std::atomic<int32_t> failed{0};
+  std::atomic<size_t> active_callers{~(size_t)0};   // callers that take searches (the others sit a job out)
 
   int32_t search(msi_bits *pool, const std::vector<std::string> &q, uint32_t limit, uint32_t *ids, uint32_t *n, double *scores,
                  msi_score_detail *details = nullptr, uint32_t *n_details = nullptr, uint64_t *candidates = nullptr,
@@ -1247,6 +1248,7 @@ struct Runner {
         if (stop) return;
         seen = epoch;
       }
+      if (t >= active_callers.load(std::memory_order_relaxed)) continue;   // rb_set_active_callers: this job runs with fewer callers
       prof::arm_this_thread();
       for (;;) {
         uint32_t i;
@@ -1516,6 +1518,12 @@ int32_t rb_start_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, u
   ++r->epoch;
   r->cv.notify_all();
   return MSI_OK;
+}
+// the next jobs run with the first n of the attached callers (0 or more than attached: all of them) — a sweep over the number
+// of callers in one process, on one index and one posting cache (tools/kw_leg.py --sweep)
+void rb_set_active_callers(void *h, uint32_t n) {
+  Runner *r = (Runner *)h;
+  r->active_callers.store(n ? (size_t)n : ~(size_t)0);
 }
 uint32_t rb_done(void *h) {
   Runner *r = (Runner *)h;
