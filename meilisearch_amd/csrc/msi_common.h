@@ -46,6 +46,11 @@
 #ifndef MSI_ACQUIRE_DEVICE
 #define MSI_ACQUIRE_DEVICE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #endif
+// The CPU emulation of the test tier attributes the device-scope stores of a kernel to what the storing lane is doing (the
+// command of a list: tests/emu counts stored bytes per tag when HIPEMU_STORE_BYTES names a file).  Nothing on the device.
+#ifndef MSI_EMU_TAG
+#define MSI_EMU_TAG(x) ((void)0)
+#endif
 #ifndef MSI_SLEEP
 #define MSI_SLEEP() __builtin_amdgcn_s_sleep(8)
 #endif

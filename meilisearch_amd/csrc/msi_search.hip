@@ -311,6 +311,12 @@ struct Dev {
   void rec(std::initializer_list<uint32_t> w) {
     open_list();
     list.words.insert(list.words.end(), w.begin(), w.end());
+    static const bool op_trace = getenv("MSI_SEARCH_OP_TRACE") != nullptr;   // debugging aid: every recorded command, in order
+    if (op_trace) {
+      fprintf(stderr, "[msi op] list %llu %s:", (unsigned long long)g_stats.syncs, compact() ? "compact" : "full");
+      for (uint32_t x : w) fprintf(stderr, " %u", x);
+      fprintf(stderr, "\n");
+    }
   }
   // the slot is about to be READ: a lazily zeroed slot is zeroed now
   void rd(uint32_t slot) {
@@ -2122,9 +2128,15 @@ Graph build_from_paths(const Vec<PathSubsets> &paths) {
 }
 
 // compute_query_graph_docids :133-185
+// `universe` may be null: "every document" (no filter, no negative term) — intersecting with it and uniting into it are
+// then no operations at all, and the result may be null for the same reason (a graph whose root reaches its end).
+// What comes back is only ever READ by the caller: it may be one of the search's shared, cached sets (a term subset's
+// documents) or `universe` itself.  (As first written — a zeroed set per node, united with every predecessor, the root a
+// copy of the universe — a one-word search recorded a fill, five set operations and two clears over the whole index
+// before its first wait, a three-word search eleven and four; the same documents take none and three.)
 Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe) {
   IdSet resolved;
-  Map<uint32_t, Set> docs;
+  Map<uint32_t, Set> docs;       // (a null entry: every document)
   Vec<uint32_t> queue{Graph::ROOT};
   size_t guard = 0;
   while (!queue.empty()) {
@@ -2138,12 +2150,22 @@ Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe) {
       queue.push_back(i);
       continue;
     }
-    Set pd = c.dev.zeros();
-    for (uint32_t p : n.preds) c.dev.or_(pd, docs[p]);
+    // the union of the predecessors' documents: nothing (no predecessor), one of them as it is, or a set of its own
+    Set pd;
+    bool everything = false, first = true;
+    for (uint32_t p : n.preds) everything = everything || !docs[p];
+    if (!everything) {
+      for (uint32_t p : n.preds) {
+        if (first) pd = n.preds.size() == 1 ? docs[p] : c.dev.clone(docs[p]);
+        else c.dev.or_(pd, docs[p]);
+        first = false;
+      }
+      if (n.preds.empty()) pd = c.empty_set();
+    }
     Set nd;
-    if (n.kind == 2) nd = c.dev.and_new(c.subset_full(n.term.subset), pd, nullptr);
-    else if (n.kind == 0) nd = c.dev.clone(universe);
-    else if (n.kind == 1) return pd;
+    if (n.kind == 2) nd = everything ? c.subset_full(n.term.subset) : c.dev.and_new(c.subset_full(n.term.subset), pd, nullptr);
+    else if (n.kind == 0) nd = universe;
+    else if (n.kind == 1) return pd;   // (null when `everything`)
     else fail(MSI_E_INTERNAL, "deleted node reached");
     resolved.insert(i);
     docs[i] = nd;
@@ -3336,12 +3358,14 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
 #endif
 
   // ---- universe (resolve_universe, mod.rs:273-301) ---------------------------------------------
+  // (null while it is "every document": a search without a filter and without negative terms never materialises that set —
+  // its universe is what its query graph matches, query_graph_docids)
   Set universe;
   if (universe_cbo) {
     MsiCboBatch ub;
     if (!msi_cbo_batch_append(ub, universe_cbo, universe_len)) fail(MSI_E_INVALID, "malformed universe bitmap");
     universe = c.dev.decode(ub);
-  } else {
+  } else if (!negatives.empty()) {
     universe = c.dev.ones();
   }
   // resolve_negative_words / resolve_negative_phrases (mod.rs:323-351), applied by Search::execute (mod.rs:431-440)
@@ -3367,8 +3391,10 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       remove_nodes_keep_edges(reduced, rm);
     }
     Set d = query_graph_docids(c, reduced, universe);
-    c.dev.and_(universe, d);
+    if (!universe) universe = d;               // (read-only from here on: it may be a shared set)
+    else if (d) c.dev.and_(universe, d);
   }
+  if (!universe) universe = c.dev.ones();
   auto rules = placeholder ? placeholder_rules(p) : ranking_rules(p);
 #ifndef MSI_SEARCH_DIRECT_ONLY
   // Universe compaction (Dev::compact_begin): everything below works on subsets of `universe`.  Not with the rules and

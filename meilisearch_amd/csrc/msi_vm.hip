@@ -708,6 +708,7 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
     { const u64 bb = __ballot(1); if (bb != ~0ull && rp->aux) printf("[sync] chunk %u tid %u before cmd %u op %u ballot %llx\n", chunk, tid, cmd_no + 1, op, bb); }
 #endif
     ++cmd_no;
+    MSI_EMU_TAG(op + (rp->aux ? 32u : 0u));   // (compact lists: + 32)
     switch (op) {
       case VM_FILL: {
         const Ref d = R(W(1));
@@ -1547,13 +1548,15 @@ struct VmCombiner {
   u64 *d_prof = nullptr;                   // MSI_VM_PROFILE: 16 tick counters in device memory
   std::atomic<int32_t> *fused_wgs = nullptr;   // msi_vm::fused_wgs: the device's waiting workgroups in flight
   int32_t fused_budget = 256;                  // msi_vm::fused_budget
-  // The reaper (MSI_VM_REAPER, default on): a second thread that only watches the completion words of the rounds in flight
-  // and wakes their searches.  One thread doing everything served a round in ~120 us (pack 23 lists, one copy, 2-3 launch
-  // calls, then 23 futex wake-ups: the most expensive step) and was busy 0.66-0.73 of the time at 12-13 k searches/s — a
-  // completion that arrived while it packed the next round was noticed only after that round's launch calls, and a list that
-  // arrived while it woke 23 sleepers waited for that.  The launching thread now hands a launched round over and goes back
-  // to its queue.
-  bool split = true;
+  // The reaper (MSI_VM_REAPER=1; the thread exists when the variable is set at all, the value is read per round): a second
+  // thread that only watches the completion words of the rounds in flight and wakes their searches.  The hypothesis: one
+  // thread doing everything serves a round in ~120 us (pack 23 lists, one copy, 2-3 launch calls, then 23 futex wake-ups)
+  // and is busy 0.66-0.73 of the time at 12-13 k searches/s, so completions are noticed late and lists queue behind the
+  // wake-ups.  MEASURED (profiles/r5_reaper.log, 10 M documents, fresh queries, same process): 12.4 / 13.0 k searches/s with
+  // it against 12.8 / 13.2 k without at 256 callers, launch -> wake-up 887-913 us per list either way — the time between a
+  // round's launch and its searches' wake-up is the device running the round's kernels beside 5 other rounds, not the
+  // host noticing late.  Off by default.
+  bool split = false;
   std::thread reaper_th;
   std::mutex hand_mu, trace_mu;
   std::condition_variable hand_cv;
@@ -1777,8 +1780,8 @@ void VmCombiner::run() {
     hipStream_t stream = streams[cur];
     const size_t n_sub = batch.size();
     {   // (read per round, as the knobs below: one process can hold the two forms side by side — tools/kw_leg.py --sweep)
-      const char *rk = getenv("MSI_VM_REAPER");   // 0: this thread also notices the round's completion (rounds 2-4)
-      split = reaper_th.joinable() && !(rk && rk[0] == '0');
+      const char *rk = getenv("MSI_VM_REAPER");   // 1: the reaper notices the round's completion (off by default: no gain measured)
+      split = reaper_th.joinable() && rk && rk[0] == '1';
     }
     size_t off = 64 + align16(n_sub * sizeof(RoundSub));
     std::vector<size_t> words_at(n_sub), state_at(n_sub);
@@ -2037,7 +2040,7 @@ static msi_vm *vm_of(msi_ctx *ctx) {
           return nullptr;
         }
       VmCombiner *raw = cb.get();
-      cb->reaper_th = std::thread([raw] { raw->reap(); });   // (asleep while MSI_VM_REAPER=0 keeps the rounds with the combiner)
+      if (getenv("MSI_VM_REAPER")) cb->reaper_th = std::thread([raw] { raw->reap(); });   // (an experiment: asleep unless a round is handed to it)
       cb->th = std::thread([raw] { raw->run(); });
       vm->comb.push_back(std::move(cb));
     }
@@ -2273,12 +2276,44 @@ static void finalize_decodes(MsiVmList &l) {
 // decodes read and — compact lists — U0's words and prefix counts once per decode.  What the commands ASK the memory
 // system for; msi_bits_vm_bytes hands the sums out for the keyword leg's roofline object (bench.py).
 static StripedCounters<3> g_vm_bytes;   // [set operands, posting containers, lists]
+// MSI_VM_BYTES_BY_OP=<file>: the same model by command and space (full / compact), written when the process ends:
+// [space][command] -> commands, sets they sweep, bytes (sets x the list's set size) — where a query's set traffic comes from
+struct BytesByOp {
+  std::mutex mu;
+  uint64_t n[2][32] = {}, sets[2][32] = {}, bytes[2][32] = {}, lists[2] = {}, list_bytes[2] = {};
+  const char *path = getenv("MSI_VM_BYTES_BY_OP");
+  ~BytesByOp() {
+    if (!path) return;
+    FILE *f = fopen(path, "w");
+    if (!f) return;
+    static const char *names[32] = {"end", "fill", "op", "op_count", "clear", "claim", "and_many", "paths", "sub_many", "count", "decode",
+                                    "firstk", "minkey", "takekey", "summary_reset", "rank_a", "rank_b", "decodec"};
+    for (int sp = 0; sp < 2; ++sp) {
+      fprintf(f, "%s lists %llu bytes %llu\n", sp ? "compact" : "full", (unsigned long long)lists[sp], (unsigned long long)list_bytes[sp]);
+      for (int op = 0; op < 32; ++op)
+        if (n[sp][op])
+          fprintf(f, "  %-14s commands %10llu sets %10llu bytes %14llu\n", names[op] ? names[op] : "?", (unsigned long long)n[sp][op],
+                  (unsigned long long)sets[sp][op], (unsigned long long)bytes[sp][op]);
+    }
+    fclose(f);
+  }
+};
+static BytesByOp g_by_op;
+
 static void account_list(msi_bits *pool, const MsiVmList &l) {
   const uint64_t words = l.geom_docs ? std::max<uint64_t>(2, ((l.geom_docs + 127) / 128) * 2) : msi_bits_words_per_slot(pool);
   const uint64_t set_b = words * 8;
   uint64_t sets = 0, wide = 0;
   const std::vector<uint32_t> &w = l.words;
+  const bool by_op = g_by_op.path != nullptr;
+  uint64_t op_n[32] = {}, op_sets[32] = {};
   for (size_t i = 0; i < w.size();) {
+    const uint32_t op_now = w[i];
+    const uint64_t sets_before = sets;
+    struct Tally {   // (every way out of the switch)
+      bool on; uint64_t *n, *s; const uint64_t &sets, &before; uint32_t op;
+      ~Tally() { if (on && op < 32) { ++n[op]; s[op] += sets - before; } }
+    } tally{by_op, op_n, op_sets, sets, sets_before, op_now};
     switch (w[i]) {
       case VM_END: i += 1; break;
       case VM_FILL: sets += 1; i += 3; break;
@@ -2313,6 +2348,17 @@ static void account_list(msi_bits *pool, const MsiVmList &l) {
   g_vm_bytes.add(0, total);
   g_vm_bytes.add(1, posting);
   g_vm_bytes.add(2, 1);
+  if (by_op) {
+    std::lock_guard<std::mutex> lk(g_by_op.mu);
+    const int sp = l.geom_docs ? 1 : 0;
+    ++g_by_op.lists[sp];
+    g_by_op.list_bytes[sp] += total;
+    for (int op = 0; op < 32; ++op) {
+      g_by_op.n[sp][op] += op_n[op];
+      g_by_op.sets[sp][op] += op_sets[op];
+      g_by_op.bytes[sp][op] += op_sets[op] * set_b;
+    }
+  }
 }
 extern "C" int32_t msi_bits_vm_bytes(uint64_t out[3]) {
   if (!out) return MSI_E_INVALID;

@@ -203,6 +203,7 @@ struct Lane {
   float fa[8], fb[8], fc[4];  // MFMA operands of the lane (A and B fragments widened to f32), C in / D out
   signed char ia[16], ib[16];  // v_mfma_i32_16x16x64_i8: the lane's 16 bytes of A and of B
   int ic[4];                   // ... C in / D out
+  int tag = 0;                 // MSI_EMU_TAG: what the lane is doing (store accounting)
   void *stack = nullptr;
 };
 
@@ -368,6 +369,7 @@ inline void run_block() {
   for (unsigned t = 0; t < n; ++t) {
     Lane &l = g.lanes[t];
     prepare_lane(l);
+    l.tag = 0;
     l.state = RUNNABLE;
   }
   for (;;) {
@@ -569,7 +571,28 @@ inline T atomicXor(T *p, U v) { T o = *p; *p = (T)(o ^ (T)v); return o; }
 template <typename T, typename U, typename V>
 inline T atomicCAS(T *p, U cmp, V v) { T o = *p; if (o == (T)cmp) *p = (T)v; return o; }
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
-#define __hip_atomic_store(ptr, v, order, scope) ((void)(*(ptr) = (v)))
+// HIPEMU_STORE_BYTES=<file>: bytes stored with device-scope stores (the interpreter's set words, tables, results), by the tag
+// the storing lane set last (MSI_EMU_TAG: the command of a list it is executing; 0: none) — written when the process ends
+namespace hipemu {
+struct StoreBytes {
+  unsigned long long by_tag[64] = {};
+  const char *path = getenv("HIPEMU_STORE_BYTES");
+  ~StoreBytes() {
+    if (!path) return;
+    FILE *f = fopen(path, "w");
+    if (!f) return;
+    for (int t = 0; t < 64; ++t)
+      if (by_tag[t]) fprintf(f, "tag %2d %s bytes %llu\n", t & 31, t >= 32 ? "compact" : "full   ", by_tag[t]);
+    fclose(f);
+  }
+};
+inline StoreBytes store_bytes;
+inline void count_store(size_t n) {
+  if (store_bytes.path && g.in_kernel) store_bytes.by_tag[g.lanes[g.cur].tag & 63] += n;
+}
+}  // namespace hipemu
+#define MSI_EMU_TAG(x) (hipemu::g.lanes[hipemu::g.cur].tag = (int)(x))
+#define __hip_atomic_store(ptr, v, order, scope) ((void)(hipemu::count_store(sizeof(*(ptr))), *(ptr) = (v)))
 #define __hip_atomic_fetch_add(ptr, v, order, scope) atomicAdd((ptr), (v))
 #define __hip_atomic_fetch_or(ptr, v, order, scope) atomicOr((ptr), (v))
 #define __hip_atomic_fetch_and(ptr, v, order, scope) atomicAnd((ptr), (v))
