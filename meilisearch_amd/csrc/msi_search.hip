@@ -1434,15 +1434,18 @@ struct Ctx {
       g_stats.callback_ms += c.ms();
     }
   };
-  bool add_word(MsiCboBatch &b, uint32_t w, bool original) {
+  // (*card, when asked for: how many documents the word has — from the posting cache, or the stored value's header)
+  bool add_word(MsiCboBatch &b, uint32_t w, bool original, uint64_t *card = nullptr) {
     const std::string &s = words[w];
     bool present = false;
-    if (from_cache(&b, 1, s, std::string(), original ? 1 : 0, 0, nullptr, &present)) return present;
+    if (card) *card = 0;
+    if (from_cache(&b, 1, s, std::string(), original ? 1 : 0, 0, card, &present)) return present;
     const uint8_t *bytes = nullptr;
     size_t n = 0;
     Cb cb_;
     const int32_t st = ix->word_docids(ix->user, (const uint8_t *)s.data(), (uint32_t)s.size(), original ? 1 : 0, &bytes, &n);
     take(b, st, bytes, n, "word_docids", 1, s, std::string(), original ? 1 : 0, 0);
+    if (card && n && bytes) *card = msi_cbo_cardinality(bytes, n);
     return n != 0;
   }
   bool contains_word(uint32_t w) {   // Index::contains_word: the key exists; nothing is decoded
@@ -1868,14 +1871,28 @@ struct Ctx {
     if (it == subset_cache.end()) {
       relieve();
       MsiCboBatch b;
-      for (auto &w : all_single_words(ss)) add_word(b, w.first, w.second);
+      uint64_t floor = 0;   // the subset's documents are at least those of its most frequent word
+      for (auto &w : all_single_words(ss)) {
+        uint64_t card = 0;
+        add_word(b, w.first, w.second, &card);
+        floor = std::max(floor, card);
+      }
       const int32_t pf = use_prefix_db(ss);
       if (pf >= 0) add_prefix(&b, (uint32_t)pf, !terms[ss.term].is_ngram);
       Set d = dev.decode(b);
       for (uint32_t p : all_phrases(ss)) dev.or_(d, phrase_docids(p));
       it = subset_cache.emplace(key, d).first;
+      subset_floor[key] = floor;
     }
     return it->second;
+  }
+  // a lower bound of |subset_full(ss)| known on the host (0: nothing known) — valid once subset_full(ss) has been called
+  Map<Subset, uint64_t> subset_floor;
+  uint64_t floor_of(const Subset &ss) {
+    Subset key = ss;
+    key.mandatory = false;
+    auto it = subset_floor.find(key);
+    return it == subset_floor.end() ? 0 : it->second;
   }
   // ..._within_field_id / ..._within_position :61-130 for one fid (which 0) or a set of positions (which 1):
   // every posting of the condition goes into ONE decode batch
@@ -2134,9 +2151,13 @@ Graph build_from_paths(const Vec<PathSubsets> &paths) {
 // documents) or `universe` itself.  (As first written — a zeroed set per node, united with every predecessor, the root a
 // copy of the universe — a one-word search recorded a fill, five set operations and two clears over the whole index
 // before its first wait, a three-word search eleven and four; the same documents take none and three.)
-Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe) {
+// *at_least (when asked for): a lower bound of the result's cardinality known on the host without waiting for the device — the
+// most frequent word of a term that is united into it (0: nothing known)
+Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe, uint64_t *at_least = nullptr) {
   IdSet resolved;
   Map<uint32_t, Set> docs;       // (a null entry: every document)
+  Map<uint32_t, uint64_t> floor; // lower bound of |docs[i]| (only tracked through "every document" and unions)
+  if (at_least) *at_least = 0;
   Vec<uint32_t> queue{Graph::ROOT};
   size_t guard = 0;
   while (!queue.empty()) {
@@ -2153,7 +2174,11 @@ Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe) {
     // the union of the predecessors' documents: nothing (no predecessor), one of them as it is, or a set of its own
     Set pd;
     bool everything = false, first = true;
-    for (uint32_t p : n.preds) everything = everything || !docs[p];
+    uint64_t pd_floor = 0;   // a union holds at least what its largest member holds
+    for (uint32_t p : n.preds) {
+      everything = everything || !docs[p];
+      pd_floor = std::max(pd_floor, floor[p]);
+    }
     if (!everything) {
       for (uint32_t p : n.preds) {
         if (first) pd = n.preds.size() == 1 ? docs[p] : c.dev.clone(docs[p]);
@@ -2163,12 +2188,22 @@ Set query_graph_docids(Ctx &c, const Graph &g, const Set &universe) {
       if (n.preds.empty()) pd = c.empty_set();
     }
     Set nd;
-    if (n.kind == 2) nd = everything ? c.subset_full(n.term.subset) : c.dev.and_new(c.subset_full(n.term.subset), pd, nullptr);
-    else if (n.kind == 0) nd = universe;
-    else if (n.kind == 1) return pd;   // (null when `everything`)
-    else fail(MSI_E_INTERNAL, "deleted node reached");
+    uint64_t nd_floor = 0;
+    if (n.kind == 2) {
+      const Set sub = c.subset_full(n.term.subset);
+      nd = everything ? sub : c.dev.and_new(sub, pd, nullptr);
+      if (everything) nd_floor = c.floor_of(n.term.subset);   // (an intersection with less than everything: nothing known)
+    } else if (n.kind == 0) {
+      nd = universe;
+    } else if (n.kind == 1) {
+      if (at_least) *at_least = everything ? 0 : pd_floor;
+      return pd;   // (null when `everything`)
+    } else {
+      fail(MSI_E_INTERNAL, "deleted node reached");
+    }
     resolved.insert(i);
     docs[i] = nd;
+    floor[i] = nd_floor;
     for (uint32_t s : n.succs)
       if (!resolved.count(s) && std::find(queue.begin(), queue.end(), s) == queue.end()) queue.push_back(s);
   }
@@ -3361,6 +3396,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   // (null while it is "every document": a search without a filter and without negative terms never materialises that set —
   // its universe is what its query graph matches, query_graph_docids)
   Set universe;
+  uint64_t universe_floor = 0;   // documents the universe holds at least, as far as the host knows before the device has counted
   if (universe_cbo) {
     MsiCboBatch ub;
     if (!msi_cbo_batch_append(ub, universe_cbo, universe_len)) fail(MSI_E_INVALID, "malformed universe bitmap");
@@ -3390,9 +3426,14 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
       for (auto &ns : removal_order_of(c, g, p->strategy)) rm.insert(rm.end(), ns.begin(), ns.end());
       remove_nodes_keep_edges(reduced, rm);
     }
-    Set d = query_graph_docids(c, reduced, universe);
-    if (!universe) universe = d;               // (read-only from here on: it may be a shared set)
-    else if (d) c.dev.and_(universe, d);
+    uint64_t d_floor = 0;
+    Set d = query_graph_docids(c, reduced, universe, &d_floor);
+    if (!universe) {
+      universe = d;               // (read-only from here on: it may be a shared set)
+      universe_floor = d_floor;
+    } else if (d) {
+      c.dev.and_(universe, d);
+    }
   }
   if (!universe) universe = c.dev.ones();
   auto rules = placeholder ? placeholder_rules(p) : ranking_rules(p);
@@ -3404,11 +3445,15 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
   bool may_compact = c.dev.vm && Dev::compact_mode() > 0 && !placeholder && !p->distinct_values && msi_bits_n_slots(c.dev.pool.p) <= 1024 &&
                      (uint64_t)p->from + p->length <= MSI_VM_MAX_FIRSTK;
   for (auto &r : rules) may_compact = may_compact && r->kind != R_ORDER_BY;
-  if (may_compact) c.dev.rank_tables(universe);   // (rides in the list that counts the universe: no round of its own)
+  // (the tables ride in the list that counts the universe: no round of its own.  Not for a universe that is known to be too
+  // large for the compact space before it is counted — a search for a frequent word: two more sweeps of the index, the
+  // prefix table and 5 MB of rank -> docid entries written for nothing, and a second phase in the search's first list)
+  const bool tables_now = may_compact && universe_floor <= msi_bits_compact_capacity(c.dev.pool.p);
+  if (tables_now) c.dev.rank_tables(universe);
 #endif
   uint64_t universe_count = c.dev.count(universe);
 #ifndef MSI_SEARCH_DIRECT_ONLY
-  if (may_compact && Dev::late_mode() < 2 && c.dev.compact_pays(universe_count)) {
+  if (tables_now && Dev::late_mode() < 2 && c.dev.compact_pays(universe_count)) {
     c.dev.compact_begin(universe, universe_count);
     c.to_compact_space();
     universe = c.dev.ones();     // U0 in its own space: every rank

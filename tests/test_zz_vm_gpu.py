@@ -257,3 +257,28 @@ def test_a_page_past_what_one_list_reads_back():
     assert cand == 8500
     hits, _ = h.search("apple", criteria=["words"], offset=8180, limit=5)     # still inside one list: the compact path
     assert [d for d, _ in hits] == [16360, 16362, 16364, 16366, 16368]
+
+
+def test_the_universe_of_an_unfiltered_search_is_not_materialised():
+    """Round 5: without a filter and without negative terms the universe of a search is what its query graph matches — the
+    engine records no "every document" set, no copy of it and no zeroed set per graph node (resolve_universe,
+    search/new/mod.rs:273-301, computes the same documents).  A one-word search used to sweep 18 more sets over the whole
+    index before its first wait: fill, five operations, two clears (byte model of the lists, msi_bits_vm_bytes)."""
+    import ctypes as C
+
+    from meilisearch_amd import _lib
+    ix = build_index(FIX["indexes"][sorted(FIX["indexes"])[0]])
+    h = Harness(ix)
+    lib = _lib.lib()
+    word = ix.words[len(ix.words) // 2]
+    a, b = (C.c_uint64 * 3)(), (C.c_uint64 * 3)()
+    lib.msi_bits_vm_bytes(a)
+    hits, _ = h.search(word, criteria=["words"])
+    lib.msi_bits_vm_bytes(b)
+    assert hits
+    set_bytes = 16   # (a pool of <= 128 documents: two 64-bit words per set)
+    assert ix.n_docs <= 128
+    sets, lists = (b[0] - a[0]) // set_bytes, b[2] - a[2]
+    # 14 sets in 2 lists by default; a few more with the compact space forced (MSI_SEARCH_COMPACT=2: rank tables, the images
+    # of the cached sets); 32 and more before
+    assert lists <= 3 and sets <= 22, (sets, lists)
