@@ -1057,11 +1057,11 @@ def run_c4(args, env):
             "vector_only_queries_per_s_by_rank": [round(x, 1) for x in vec_only_by_rank] if vec_only_by_rank else None,
             "keyword_callers_per_rank": kw_threads if kw is not None else 0, "host_cpus_granted": granted_cpus(),
             # N > 1: all ranks share the box's granted CPUs, and a keyword search costs host CPU whichever GPU runs its sets — the
-            # keyword leg of the whole job cannot exceed granted CPUs / host CPU per query (measured on one GPU this round:
-            # ~1.0 ms per query on the round-3 workload, ~0.8 ms on the coherent corpus: profiles/r4_*), so with 16 granted CPUs
-            # the hybrid weak-scaling curve flattens near 2.5-3x whatever RCCL does; the vector leg scales with the GPUs
-            "keyword_cap_predicted": round(granted_cpus() / 1.3e-3, 0) if kw is not None else None,
-            "predicted_cap_is": "granted CPUs / 1.3 ms of host CPU per keyword query on a fresh query stream (round 5, legs."
+            # keyword leg of the whole job cannot exceed granted CPUs / host CPU per query (1.04 ms per fresh query at N = 1 on
+            # the round's final tree, profiles/r5_bench_c4_final.json: 13.9 k q/s at 14.5 of 16 CPUs), so with 16 granted CPUs
+            # the hybrid weak-scaling curve flattens just above the one-GPU value whatever RCCL does; the vector leg scales
+            "keyword_cap_predicted": round(granted_cpus() / 1.04e-3, 0) if kw is not None else None,
+            "predicted_cap_is": "granted CPUs / 1.04 ms of host CPU per keyword query on a fresh query stream (round 5, legs."
                                 "keyword_host_cpu_ms_per_query at N = 1): every rank's searches draw on the same granted CPUs, so the whole "
                                 "job's keyword leg cannot exceed it whatever the number of GPUs; keyword_cap_measured = the ranks' keyword-only "
                                 "rates, measured at the same time, summed",
