@@ -646,10 +646,23 @@ def run_c4(args, env):
         env.dist.broadcast(uid, 0)
         buf = (C.c_uint8 * 128)(*uid.cpu().tolist())
         group = C.c_void_p()
-        try:
-            ma._lib.check(L.msi_group_create_rank(ctx.handle, rank, world, buf, C.byref(group)))
-        except Exception as e:   # noqa: BLE001 - the line must still be produced: the launcher's own RCCL group carries the exchange
-            print(f"[bench] rank {rank}: msi_group_create_rank failed ({e}); exchanging through torch.distributed", file=sys.stderr)
+        # (under a watchdog: the library's own RCCL instance beside torch's has never run on an 8-GPU node — a communicator
+        # that does not come up within two minutes must not cost the whole line; ctypes releases the GIL during the call)
+        import threading
+        init = {}
+
+        def _init_group():
+            try:
+                ma._lib.check(L.msi_group_create_rank(ctx.handle, rank, world, buf, C.byref(group)))
+                init["ok"] = True
+            except Exception as e:   # noqa: BLE001 - the line must still be produced: the launcher's own RCCL group carries the exchange
+                init["err"] = e
+        th = threading.Thread(target=_init_group, daemon=True)
+        th.start()
+        th.join(timeout=120.0)
+        if not init.get("ok"):
+            why = "no answer within 120 s" if th.is_alive() else str(init.get("err"))
+            print(f"[bench] rank {rank}: msi_group_create_rank failed ({why}); exchanging through torch.distributed", file=sys.stderr)
             group = None
         ok = torch.tensor([1 if group is not None else 0], dtype=torch.int32, device=dev)
         env.dist.all_reduce(ok, op=env.dist.ReduceOp.MIN)    # every rank takes the same path
