@@ -69,6 +69,10 @@ GROUPS = {
     # the one-document-per-chunk spread (ranges of one bit: the shared-word path of VM_DECODEC), the out-of-slots re-run
     "ranked-search-compact-space": (["tests/test_search_gpu.py", "tests/test_zz_vm_gpu.py"],
                                     "not matches_oracle_on_random_corpora and not starved", 100, {"MSI_SEARCH_COMPACT": "2"}),
+    # the reaper (MSI_VM_REAPER=1: rounds handed to a second thread that notices their completion and wakes the searches
+    # — an experiment that stays off by default): the hand-over, concurrent searches, shutdown
+    "ranked-search-reaper": (["tests/test_zz_vm_gpu.py"], "concurrent_searches or cold_and_warm or universe_of_an_unfiltered or index_views",
+                             4, {"MSI_VM_REAPER": "1"}),
 }
 
 
@@ -83,15 +87,25 @@ def _build_once():
     run_emulated.build_rccl()
 
 
-def _start_all():
-    """Every group is its own subprocess; they are all started when the first one is asked for (the emulated library is
-    built once, before, so that they do not race for it) and run side by side — the tier takes as long as its longest
-    group instead of their sum."""
+def _start_all(selected):
+    """Every group is its own subprocess; the groups this session runs (`-k` may have selected some) are all started when
+    the first one is asked for (the emulated library is built once, before, so that they do not race for it) and run
+    side by side — the tier takes as long as its longest group instead of their sum.  What is still running when the
+    session ends is stopped."""
     if _running:
         return
+    import atexit
     import tempfile
     _build_once()
+
+    def _stop_leftovers():
+        for proc, _, _ in _running.values():
+            if proc.poll() is None:
+                proc.kill()
+    atexit.register(_stop_leftovers)
     for group, spec in GROUPS.items():
+        if group not in selected:
+            continue
         files, expr = spec[:2]
         env = dict(os.environ, **(spec[3] if len(spec) > 3 else {}))
         k = f"not ({NEEDS_TORCH_CUDA})" + (f" and {expr}" if expr else "")
@@ -103,9 +117,10 @@ def _start_all():
 
 
 @pytest.mark.parametrize("group", list(GROUPS))
-def test_gpu_test_bodies_on_emulated_kernels(group):
+def test_gpu_test_bodies_on_emulated_kernels(group, request):
     at_least = GROUPS[group][2]
-    _start_all()
+    _start_all({it.callspec.params["group"] for it in request.session.items
+                if getattr(it, "callspec", None) is not None and "group" in it.callspec.params})
     proc, out, err = _running[group]
     try:
         proc.wait(timeout=1500)
