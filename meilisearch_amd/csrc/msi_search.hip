@@ -3616,7 +3616,10 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
                     (unsigned long long)g_stats.syncs, cur, rule->kind, (unsigned long long)b.count, (unsigned long long)off,
                     (unsigned long long)(left - b.count), b.score.kind, b.score.a, b.score.b,
                     b.ids ? ", ids came along" : "");
-          if (!b.universe_reduced) c.dev.sub_(uni, b.docs);
+          // what is left of `uni` is only read by this loop's next round — and there is none when the bucket took the rest
+          // of it or fills the page (most rule evaluations of a search end that way: six set operations over the whole
+          // index in a search for a frequent word)
+          if (!b.universe_reduced && left != b.count && off + b.count < page_end) c.dev.sub_(uni, b.docs);
           left -= b.count;
           Vec<Score> sc = scores;
           sc.push_back(b.score);
