@@ -2433,6 +2433,10 @@ struct Rule {
   int kind;
   int tms;  // -1 none, MSI_TERMS_LAST, MSI_TERMS_ALL, MSI_TERMS_FREQUENCY
   bool leaf = false;   // the last rule of the list (set by the bucket sort's tree): its buckets go straight to the results
+  // documents the page still takes from this rule's buckets (set by the bucket sort's tree before every next(); 0: not
+  // known — the sequential loop): a bucket that fills it, or takes the rest of the universe, is the last one asked for,
+  // and what is left of the universe afterwards is read by nobody
+  uint64_t page_room = 0;
   Rule(int k, int t) : kind(k), tms(t) {}
   virtual ~Rule() {}
   virtual void start(Ctx &c, const Set &universe, const Graph &g) = 0;
@@ -2613,7 +2617,8 @@ struct GraphRule : Rule {
       bucket_count = r.count;
       good = std::move(r.good);
       out.ids = std::move(r.ids);
-      if (bucket_count) c.dev.sub_(uni, bucket);
+      const bool last_asked_for = page_room && (bucket_count == uni_count || bucket_count >= page_room);
+      if (bucket_count && !last_asked_for) c.dev.sub_(uni, bucket);
     } else {
       IdSet visited, to_skip;
       level_ids.reset();
@@ -3606,6 +3611,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             break;
           }
           Bucket b;
+          rule->page_room = page_end - off;
           if (!rule->next(c, uni, left, b)) {                            // (a rule normally ends with its universe empty)
             if (left) dropped = true;
             break;
