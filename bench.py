@@ -603,7 +603,20 @@ def run_c4(args, env):
               "stream_steps": kw_stream_steps, "n_queries": n_kw_queries}
         phase("c4: index derivation pass (untimed: the synthetic index derives its databases)")
         t_derive = time.perf_counter()
-        for first in range(0, n_kw_queries, Q):
+        kw["stream_distinct"] = kw_stream_steps
+        derive_from, n_derive = 0, n_kw_queries
+        if world > 1 and kw_stream_steps:
+            # N ranks derive their streams on the SAME granted CPUs (the pass costs ~60 ms of CPU per query: 84 s at N = 1 on
+            # 16 CPUs — eleven minutes for eight ranks): the primer first, then as many fresh steps as fit a budget at the rate
+            # the primer showed (the slowest rank's), at least four; the timed steps cycle through those (the line says so)
+            for first in range(0, kw_prime, Q):
+                assert kw_lib.rb_run(h, first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data) == 0
+            t_primer = max(env.gather_scalar(time.perf_counter() - t_derive))
+            budget_s = float(os.environ.get("MSI_BENCH_DERIVE_BUDGET_S", "300"))
+            fit = int(max(0.0, budget_s - t_primer) / max(1e-3, t_primer / (kw_prime // Q)))
+            kw["stream_distinct"] = max(4, min(kw_stream_steps, fit))
+            derive_from, n_derive = kw_prime, kw_prime + kw["stream_distinct"] * Q
+        for first in range(derive_from, n_derive, Q):
             assert kw_lib.rb_run(h, first, Q, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data) == 0
         kw["index_derivation_seconds"] = round(time.perf_counter() - t_derive, 1)
         if hasattr(kw_lib, "rb_freeze"):
@@ -712,7 +725,7 @@ def run_c4(args, env):
             return (i * Q) % kw["prime"]                          # warm-up steps (and the cycled stream): primer queries again
         i -= args.warmup
         if i < kw["stream_steps"]:
-            return kw["prime"] + i * Q
+            return kw["prime"] + (i % kw["stream_distinct"]) * Q   # (stream_distinct < stream_steps only at N > 1, time-boxed)
         return ((i - kw["stream_steps"]) * Q) % kw["prime"]
 
     def keyword_run():
@@ -1100,6 +1113,8 @@ def run_c4(args, env):
             "keyword_stream": None if kw is None else (
                 f"fresh: every timed step runs {Q} queries the engine meets for the first time ({kw['stream_steps']} x {Q} distinct ones "
                 f"behind a {kw['prime']}-query primer)"
+                + ("" if kw["stream_distinct"] == kw["stream_steps"] else
+                   f"; N > 1: the index derivation pass was time-boxed, {kw['stream_distinct']} distinct steps cycled")
                 if kw["stream_steps"] else f"cycle: {kw['prime']} distinct queries, cycled"),
             "keyword_index_derivation_seconds": kw.get("index_derivation_seconds") if kw is not None else None,
             "setup_seconds": round(setup_s, 1),
