@@ -1360,11 +1360,18 @@ struct Ctx {
     edge_memo.clear();
   }
 
+  // The knobs every rule evaluation asks for, read ONCE per search (a getenv is a walk over the whole environment: with two
+  // of them per look-ahead and one per level, ~90 walks per query; the tests that flip them do so between searches)
+  int knob_levels_per_wait = -1;    // MSI_SEARCH_LEVELS_PER_WAIT (-1: not set)
+  bool knob_fused_off = false;      // MSI_SEARCH_FUSED_LEVELS=0
   Ctx(msi_dict *d, msi_bits *pool, const msi_index_vtable *i, const msi_search_params *p)
       : dict(d), ix(i), prm(p), dev(pool) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
     if (dev.vm) dev.pcache = msi_dict_pcache(d);
 #endif
+    if (const char *k = getenv("MSI_SEARCH_LEVELS_PER_WAIT")) knob_levels_per_wait = std::max(0, atoi(k));
+    const char *f = getenv("MSI_SEARCH_FUSED_LEVELS");
+    knob_fused_off = f && f[0] == '0';
   }
 
   uint32_t word(const std::string &w) {
@@ -2708,12 +2715,11 @@ struct GraphRule : Rule {
     // 8 levels per wait since round 3 (4 before): the Position and Fid rules have 20+ cost levels with a few documents
     // each — waits per detailed 3-term query at 10 M documents 17.0 -> 15.1 (12: 14.7, 16: 14.6), the same conditions
     // resolved, 1.3 % more set-operand bytes
-    const char *knob = getenv("MSI_SEARCH_LEVELS_PER_WAIT");
     // (the direct back end publishes each level's counts into one of MSI_BITS_PATH_REGIONS regions; a command list has
     // MSI_VM_MAX_COUNTS counts and takes as many levels as fit)
-    const int per_wait = std::min<int>(knob ? atoi(knob) : (cx->dev.vm ? 8 : 1), cx->dev.vm ? 16 : (int)MSI_BITS_PATH_REGIONS);
-    const char *fused = getenv("MSI_SEARCH_FUSED_LEVELS");
-    if (per_wait < 2 || (fused && fused[0] == '0')) return;
+    const int per_wait = std::min<int>(cx->knob_levels_per_wait >= 0 ? cx->knob_levels_per_wait : (cx->dev.vm ? 8 : 1),
+                                       cx->dev.vm ? 16 : (int)MSI_BITS_PATH_REGIONS);
+    if (per_wait < 2 || cx->knob_fused_off) return;
     // `distinct` removes documents from every universe of the stack whenever a bucket reaches the results
     // (bucket_sort.rs:404-411): a level evaluated ahead on a copy of the universe would not see that
     if (cx->prm->distinct_values) return;
@@ -2782,8 +2788,7 @@ struct GraphRule : Rule {
   bool fused_level(uint64_t cost) {
     // MSI_SEARCH_FUSED_LEVELS=0 forces the path-by-path search (the fallback for levels with > 256 paths), so
     // that the tests can hold both against the oracle
-    const char *knob = getenv("MSI_SEARCH_FUSED_LEVELS");
-    if (knob && knob[0] == '0') return false;
+    if (cx->knob_fused_off) return false;
     PathList all;
     Vec<int32_t> cur;
     IdSet visited, to_skip;
