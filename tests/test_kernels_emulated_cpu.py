@@ -159,3 +159,20 @@ def test_fuzz_regression_seeds(case):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ranked_hostlogic.py"), str(seed0), "1", "--emulated-kernels"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "cases 1 bad 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_the_keyword_leg_tool_sweeps_configurations_in_one_process():
+    """tools/kw_leg.py --emulated --sweep: the measurement tool of round 5's A/B (profiles/r5_reaper.log) on a small corpus
+    through the emulated kernels — every configuration (MSI_VM_REAPER read per round, callers through rb_set_active_callers)
+    on its own segment of fresh queries, one JSON object each, the host CPU profile of the search threads filled in."""
+    import json
+    env = dict(os.environ, MSI_SEARCH_CPU_PROFILE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kw_leg.py"), "--emulated", "--docs", "20000", "--words", "8000",
+                          "--callers", "4", "--queries", "32", "--segment", "16", "--sweep", "1:2,0:4", "--cache-mb", "64"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [(l["MSI_VM_REAPER"], l["callers"]) for l in lines] == [("1", 2), ("0", 4)]
+    for l in lines:
+        assert l["measured_searches"] == 16 and l["fresh_stream"] and l["queries_per_s"] > 0
+        assert l["vm"]["lists_per_query"] > 1 and l["host_cpu_us_per_query"]["search_threads"] > 0
