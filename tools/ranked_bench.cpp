@@ -282,6 +282,14 @@ struct Index {
                                                   // prefixes of 1..4 bytes that at least this many dictionary words share
   std::vector<std::string> words;                 // sorted
   std::map<std::string, uint32_t> rank;           // frequency rank
+  // One derivation per key at a time: 256 callers meeting the corpus' most frequent word in their first queries each scanned
+  // its ten million documents (2.8 s a piece; 0.56 s for a pair of frequent words) — most of the index-derivation pass was
+  // the same work done dozens of times side by side.  A caller that finds nothing takes the key's stripe, looks again, and
+  // only then derives; whoever waited finds the value.  (Separate stripe sets: a word's derivation stores blobs while it
+  // holds its stripe — word -> blob is the only nesting, and no lock is taken in the other order.)
+  static constexpr size_t N_STRIPES = 1024;
+  std::mutex word_stripes[N_STRIPES], pair_stripes[N_STRIPES], blob_stripes[N_STRIPES];
+  static size_t stripe_of(const std::string &k) { return std::hash<std::string>{}(k) % N_STRIPES; }
   std::shared_mutex mu;   // lookups of warm keys (all of them, after the warm-up pass) share the lock
   std::map<std::string, std::shared_ptr<std::vector<uint32_t>>> ids;
   std::map<std::string, std::shared_ptr<Bytes>> blobs;
@@ -331,6 +339,12 @@ struct Index {
       auto it = blobs.find(key);
       if (it != blobs.end()) return it->second->empty() ? nullptr : it->second.get();
     }
+    std::lock_guard<std::mutex> once(blob_stripes[stripe_of(key)]);
+    {
+      std::shared_lock<std::shared_mutex> lk(mu);
+      auto it = blobs.find(key);
+      if (it != blobs.end()) return it->second->empty() ? nullptr : it->second.get();
+    }
     const bool runs = getenv("RB_RUN_CONTAINERS") && getenv("RB_RUN_CONTAINERS")[0] == '1';
     const std::vector<uint32_t> docs = make();
     // (a chunk of more than 2047 runs does not fit the run count the decoders accept for one container: such keys stay as they are)
@@ -370,10 +384,20 @@ const WordDerived *corpus_word(Index *ix, const std::string &s) {
     auto it = ix->word_derived.find(s);
     if (it != ix->word_derived.end()) return it->second.get();
   }
+  std::lock_guard<std::mutex> once(ix->word_stripes[Index::stripe_of(s)]);
+  {
+    std::shared_lock<std::shared_mutex> lk(ix->derived_mu);
+    auto it = ix->word_derived.find(s);
+    if (it != ix->word_derived.end()) return it->second.get();
+  }
   const Corpus &c = *ix->corpus;
   auto wd = std::make_shared<WordDerived>();
   const int64_t id = c.id_of(s);
-  std::map<uint32_t, std::vector<uint32_t>> by_fid, by_pos;
+  // (plain arrays instead of maps: the most frequent word has 50 million occurrences, two lookups each.  Bucketed positions
+  // are 0..15, 24 and the powers of two from 32 on: slot 0..15, 16, 17 + log2 - 5 — ascending in the value)
+  std::vector<uint32_t> by_fid[4], by_pos[48];
+  auto pos_slot = [](uint32_t b) -> uint32_t { return b < 16 ? b : (b == 24 ? 16u : 17u + (uint32_t)__builtin_ctz(b) - 5u); };
+  auto pos_value = [](uint32_t slot) -> uint32_t { return slot < 16 ? slot : (slot == 16 ? 24u : 1u << (slot - 17 + 5)); };
   if (id >= 0) {
     uint64_t n = 0;
     const uint32_t *docs = c.posting((uint32_t)id, &n);
@@ -381,20 +405,23 @@ const WordDerived *corpus_word(Index *ix, const std::string &s) {
       const uint32_t d = docs[k];
       c.tokens(d, [&](uint32_t w, uint32_t fid, uint32_t pos) {
         if (w != (uint32_t)id) return;
-        auto &f = by_fid[fid];
+        auto &f = by_fid[fid & 3];
         if (f.empty() || f.back() != d) f.push_back(d);
-        auto &q = by_pos[Corpus::bucketed(pos)];
+        auto &q = by_pos[pos_slot(Corpus::bucketed(pos))];
         if (q.empty() || q.back() != d) q.push_back(d);
       });
     }
   }
-  for (auto &kv : by_fid) {
-    wd->fids.push_back((uint16_t)kv.first);
-    ix->blob("f/" + std::to_string(kv.first) + "/" + s, [&] { return kv.second; });
+  for (uint32_t fid = 0; fid < 4; ++fid) {
+    if (by_fid[fid].empty()) continue;
+    wd->fids.push_back((uint16_t)fid);
+    ix->blob("f/" + std::to_string(fid) + "/" + s, [&] { return by_fid[fid]; });
   }
-  for (auto &kv : by_pos) {
-    wd->positions.push_back((uint16_t)kv.first);
-    ix->blob("q/" + std::to_string(kv.first) + "/" + s, [&] { return kv.second; });
+  for (uint32_t slot = 0; slot < 48; ++slot) {
+    if (by_pos[slot].empty()) continue;
+    const uint32_t v = pos_value(slot);
+    wd->positions.push_back((uint16_t)v);
+    ix->blob("q/" + std::to_string(v) + "/" + s, [&] { return by_pos[slot]; });
   }
   std::unique_lock<std::shared_mutex> lk(ix->derived_mu);
   return ix->word_derived.emplace(s, wd).first->second.get();
@@ -421,6 +448,12 @@ int32_t cb_pair(void *u, uint32_t prox, const uint8_t *l, uint32_t ln, const uin
     // minimum over its fields of p(b) - p(a) for a before b, kept when it is 1..3 (toy_milli.py: MAX_DISTANCE 4)
     const std::string key = "p/" + std::to_string(prox) + "/" + a + "/" + b;
     if (const std::shared_ptr<Bytes> *fb = ix->frozen_blob(key)) return hand((*fb)->empty() ? nullptr : fb->get(), bytes, out);
+    {
+      std::shared_lock<std::shared_mutex> lk(ix->mu);
+      auto it = ix->blobs.find(key);
+      if (it != ix->blobs.end()) return hand(it->second->empty() ? nullptr : it->second.get(), bytes, out);
+    }
+    std::lock_guard<std::mutex> once(ix->pair_stripes[Index::stripe_of(a + "/" + b)]);
     {
       std::shared_lock<std::shared_mutex> lk(ix->mu);
       auto it = ix->blobs.find(key);
