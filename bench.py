@@ -101,6 +101,10 @@ def parse_args():
                          "same documents, queries taken out of them and misspelled) or round 3's independently hashed postings with "
                          "3-word queries over the 300 most frequent words")
     ap.add_argument("--kw-cache-mb", type=int, default=8192, help="c4: HBM posting cache of the index version")
+    ap.add_argument("--kw-stage", type=int, default=1, help="c4, coherent corpus: 1 (default) = the index's word_docids / word_fid_docids / "
+                    "word_position_docids / field_id_word_count_docids are staged into the HBM posting cache when the index opens "
+                    "(msi_dict_stage_postings: the north_star's 'staged once into HBM'); 0 = every posting reaches the engine "
+                    "through the index callbacks on first use, as in rounds 1-5")
     ap.add_argument("--kw-stream", choices=["fresh", "cycle"], default="fresh",
                     help="c4: the keyword queries of the steps — fresh (default): no query is met twice, the posting cache holds what "
                          "4 x Q primer queries of the same generator left behind; cycle: round 4's stream (the 4 x Q primer queries cycled)")
@@ -583,6 +587,19 @@ def run_c4(args, env):
         host_cpus = granted_cpus()
         kw_threads = max(16, min(args.kw_threads, host_cpus * int(os.environ.get("MSI_BENCH_CALLERS_PER_CPU", "16")) // world))
         assert kw_lib.rb_attach(h, ctx.handle, kw_threads, args.kw_slots, args.kw_cache_mb) == 0, "keyword runner: rb_attach failed"
+        kw_staged = None
+        if args.kw_stage and args.kw_corpus == "coherent" and hasattr(kw_lib, "rb_stage_postings"):
+            # index-open: the shim walks the three word databases once and hands their stored values to the engine (here the
+            # runner derives them from the corpus' tokens, one pass per word on the granted CPUs); untimed, like an index load
+            phase("c4: staging the postings into HBM (index-open)")
+            kw_lib.rb_stage_postings.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+            sec, cnts = C.c_double(0), (C.c_uint64 * 4)()
+            st_ = kw_lib.rb_stage_postings(h, max(4, host_cpus // world), C.byref(sec), cnts)
+            assert st_ == 0, f"keyword runner: rb_stage_postings failed ({st_}): {ma._lib.lib().msi_last_error()}"
+            kw_staged = {"seconds": round(sec.value, 1), "values": int(cnts[0]), "bodies_in_hbm": int(cnts[1]),
+                         "kept_on_host": int(cnts[2]), "stored_bytes_in_hbm": int(cnts[3]),
+                         "databases": "word_docids, word_fid_docids, word_position_docids, field_id_word_count_docids (complete); "
+                                      "word_pair_proximity_docids stays with the callback + cache"}
         # The keyword stream does NOT repeat (round 4 cycled 4 x Q queries through 20 steps against a posting
         # cache at hit rate 0.98): `kw_prime` primer queries — what the index served before the measurement started — and then
         # Q fresh queries for every warm-up, timed and leg step, all drawn from the same generator (one seeded sequence).
@@ -600,7 +617,7 @@ def run_c4(args, env):
         kw = {"lib": kw_lib, "h": h, "ids": np.zeros((Q, k), np.uint32), "n": np.zeros(Q, np.uint32),
               "scores": np.zeros((Q, k), np.float64), "m_ids": np.zeros((Q, k), np.uint32), "m_sem": np.zeros((Q, k), np.uint8),
               "m_cnt": np.zeros(Q, np.uint32), "m_hits": np.zeros(Q, np.uint32), "step": 0, "prime": kw_prime,
-              "stream_steps": kw_stream_steps, "n_queries": n_kw_queries}
+              "stream_steps": kw_stream_steps, "n_queries": n_kw_queries, "staged": kw_staged}
         phase("c4: index derivation pass (untimed: the synthetic index derives its databases)")
         t_derive = time.perf_counter()
         kw["stream_distinct"] = kw_stream_steps
@@ -884,6 +901,12 @@ def run_c4(args, env):
         legs["keyword_lists_per_query"] = round((vs[1] - vs0[1]) / (3.0 * Q), 2)
         legs["keyword_host_cpu_ms_per_query"] = round(legs["keyword_only_host_cpus_used"] / max(1e-9, legs["keyword_only_queries_per_s"]) * 1e3, 3)
         legs["keyword_cold_posting_cache_queries_per_s"] = kw.get("cold_cache_queries_per_s")
+        if kw.get("staged"):
+            ss_ = (C.c_uint64 * 4)()
+            ma._lib.lib().msi_dict_staged_stats(C.c_void_p(kw["lib"].rb_dict(kw["h"])), ss_)
+            legs["keyword_postings_staged_at_index_open"] = dict(kw["staged"], absent_answers_from_complete_dbs=int(ss_[3]),
+                                                                 cold_is="the cache as msi_dict_reset_posting_cache leaves it: "
+                                                                         "what was staged, no pair proximity")
         if kw["stream_steps"]:
             # the two ends the fresh stream lies between: the cold cache above, and round 4's stream (queries the engine has met
             # before, here the primer's: posting cache hit rate ~0.98) — what a server converges to on a query mix that repeats
@@ -1871,6 +1894,8 @@ def short_line(full, detail_path=None):
                       "keyword_host_cpu_ms_per_query"))
     if isinstance(legs.get("keyword_posting_cache"), dict):
         lg["keyword_posting_cache_hit_rate"] = legs["keyword_posting_cache"].get("hit_rate")
+    if isinstance(legs.get("keyword_postings_staged_at_index_open"), dict):
+        lg["keyword_postings_staged_gb"] = round(legs["keyword_postings_staged_at_index_open"].get("stored_bytes_in_hbm", 0) / 1e9, 2)
     if lg:
         out["legs"] = lg
     if isinstance(full.get("latency"), dict):

@@ -371,8 +371,48 @@ int32_t msi_dict_lookup_device(msi_dict *dict, const uint8_t *d_qbytes,
  * stats: [hits, misses, bytes used, capacity]. */
 int32_t msi_dict_enable_posting_cache(msi_dict *dict, uint64_t capacity_bytes);
 int32_t msi_dict_posting_cache_stats(msi_dict *dict, uint64_t out[4]);
-/* A fresh cache of the same capacity (everything cached is forgotten).  Only while no search on `dict` is in flight. */
+/* Everything the SEARCHES left in the cache is forgotten (what msi_dict_stage_postings staged stays: it is the index).
+ * Only while no search on `dict` is in flight. */
 int32_t msi_dict_reset_posting_cache(msi_dict *dict);
+
+/* Staging the postings at index-open ("the FST bytes and document embeddings are staged once into HBM": the postings too).
+ * The reference reads a posting from the LMDB mmap when a search first asks for it (db_cache.rs:50-84: one lookup, no
+ * copy); without staging, msi_keyword_search_ranked does the same through the index vtable and keeps the bytes in the HBM
+ * cache.  With the databases staged — the shim walks word_docids, word_fid_docids, word_position_docids (and whatever else
+ * it wants resident) once when the index opens or its updated_at moves — a search's read is one probe of the cache's host
+ * table and its decode reads HBM: no callback, no host copy, no PCIe, for the first search as for the millionth.
+ * A value is exactly what the vtable's callback of that database would hand over for that key:
+ *   db 1  word_docids(word = key1, original = x)        x = 1: word_docids ∪ exact_word_docids, x = 0: word_docids only
+ *   db 2  word_pair_proximity_docids(proximity = x, left = key1, right = key2)
+ *   db 3  word_fid_docids(word = key1, fid = x)
+ *   db 4  word_position_docids(word = key1, position = x)
+ *   db 5  field_id_word_count_docids(fid = x, count = y)
+ * (n = 0: "no such key" is remembered as well).  Values of <= 7 docids (CboRoaringBitmap's raw form) stay on the host.
+ * Consecutive values that point at the SAME bytes (word_docids under x = 0 and x = 1 of an index without exact attributes)
+ * share one body in HBM.
+ * index_view: msi_search_params::index_view of the searches that will read them (0: the index as it is).
+ * Thread-safe: several threads may stage different slices at once, searches may run meanwhile.  One call reserves its
+ * bodies' HBM in one piece and copies them with one transfer: hand over megabytes per call, not single values.
+ * out_counts (nullable): [bodies staged in HBM, values kept on the host, keys the cache already knew]. */
+enum { MSI_DB_WORD_DOCIDS = 1, MSI_DB_WORD_PAIR_PROXIMITY = 2, MSI_DB_WORD_FID = 3, MSI_DB_WORD_POSITION = 4,
+       MSI_DB_FIELD_ID_WORD_COUNT = 5 };
+typedef struct msi_staged_posting {
+  uint32_t db;
+  const uint8_t *key1;
+  uint32_t key1_len;
+  const uint8_t *key2;
+  uint32_t key2_len;
+  uint64_t x, y;
+  const uint8_t *bytes; /* the stored CboRoaringBitmap value */
+  size_t n;
+} msi_staged_posting;
+int32_t msi_dict_stage_postings(msi_dict *dict, uint64_t index_view, const msi_staged_posting *values,
+                                uint64_t n_values, uint64_t out_counts[3]);
+/* Every key of the databases in db_mask (bit MSI_DB_*) of that view has been staged: a key the cache does not hold does
+ * not exist — msi_keyword_search_ranked answers "absent" itself instead of asking the vtable. */
+int32_t msi_dict_stage_complete(msi_dict *dict, uint64_t index_view, uint32_t db_mask);
+/* [bodies staged in HBM, values kept on the host, stored bytes of the staged bodies, reads answered "absent" by a complete db] */
+int32_t msi_dict_staged_stats(msi_dict *dict, uint64_t out[4]);
 
 typedef struct msi_dict_stats {
   uint64_t lookup_launches;
@@ -742,7 +782,7 @@ int32_t msi_keyword_search(msi_dict *dict, msi_bits *pool, const msi_index_vtabl
  * (compute_phrase_docids, resolve_query_graph.rs:187-268).  The control flow (small graphs) runs on the
  * caller's thread; every docid set lives in the msi_bits pool and every set operation — posting decode,
  * union, intersection, difference, cardinality, ordered extraction — is a device kernel.
- * Not handled: distinct, pins.
+ * Pins: msi_inject_pins around this call (the reference injects them after the bucket sort too).
  * The tokenizer stays with the caller: it hands over the located terms of
  * located_query_terms_from_tokens (parse_query.rs:28-202); stop words are its business (dropped, or empty
  * tokens inside a phrase); n_terms = 0 (only stop words) is a placeholder search: the universe in docid order.
@@ -767,8 +807,10 @@ enum { /* ScoreDetails variants, score_details.rs:10-27 */
   MSI_SCORE_SKIPPED = 7,         /* the deadline cut the ranking short here; rank 0 of 1 */
   MSI_SCORE_SORT = 8,            /* a = index into order_keys, b = the bucket's order key (0xFFFFFFFF: Null); no rank
                                   * (score_details.rs:103-121: Sort does not enter the global score) */
-  MSI_SCORE_GEO_SORT = 9         /* a = index into geo_rules, b = the docid whose point is the bucket's `value`
+  MSI_SCORE_GEO_SORT = 9,        /* a = index into geo_rules, b = the docid whose point is the bucket's `value`
                                   * (0xFFFFFFFF: None — no _geo); no rank either */
+  MSI_SCORE_PIN = 10             /* a = position: the only detail of a pinned hit (msi_inject_pins); no rank, not part of
+                                  * the global score (score_details.rs:123,135) */
 };
 #define MSI_MAX_SCORE_DETAILS 16 /* the 7 keyword rules + the Sort / GeoSort rules of a request; a longer rule list is cut here */
 typedef struct msi_score_detail {
@@ -855,6 +897,25 @@ int32_t msi_keyword_search_ranked(msi_dict *dict, msi_bits *pool, const msi_inde
                                   size_t universe_len, uint32_t *out_docids, msi_score_detail *out_scores,
                                   uint32_t *out_n_scores, uint32_t *out_n, uint64_t *out_candidates,
                                   int32_t *out_degraded /* nullable */);
+
+/* Pins (dynamic search rules).  The reference resolves a request's pins before the ranking (resolve_pins,
+ * dynamic_search_rules.rs:73-96: every surviving pin's document LEAVES the universe), runs the bucket sort for the organic
+ * prefix [0, from + length) when there are pins (bucket_sort.rs:45-50) and merges the pins into it (inject_pins,
+ * bucket_sort.rs:345-377, over merge_positioned_hits_into_page, search/mod.rs:579-625).  The shim does the same around
+ * msi_keyword_search_ranked: pinned documents out of universe_cbo, params.from = 0, params.length = from + length, then
+ * this call with the organic hits it got.  pins: in resolve_pins' order (the merge consumes them front to back; a pin whose
+ * position lies beyond the organic hits is pumped forward).  scores / n_scores / out_scores / out_n_scores nullable
+ * ([..][MSI_MAX_SCORE_DETAILS] rows as msi_keyword_search_ranked writes them); a pinned hit carries the single detail
+ * {MSI_SCORE_PIN, position}.  out_*: caller-allocated, `length` entries.  Returns the number of hits of the page.
+ * (all_candidates gains the pins: the caller adds n_pins to its count.)  The hybrid path merges its pins with the same
+ * function after ScoreWithRatioResult::merge (hybrid.rs:239-260): call this on msi_hybrid_merge's list the same way. */
+typedef struct msi_pin {
+  uint32_t position;
+  uint32_t docid;
+} msi_pin;
+uint32_t msi_inject_pins(const msi_pin *pins, uint32_t n_pins, uint32_t from, uint32_t length,
+                         const uint32_t *docids, const msi_score_detail *scores, const uint32_t *n_scores,
+                         uint32_t n, uint32_t *out_docids, msi_score_detail *out_scores, uint32_t *out_n_scores);
 
 /* ScoreDetails::global_score over the details of one hit (score_details.rs:123-154, ranks per variant
  * :103-121: Typo -> (max_typo_count + 1 - typo_count, max_typo_count + 1), ExactWords -> (matching + 1, max + 1),

@@ -229,6 +229,10 @@ PROTOTYPES = {
     "msi_dict_enable_posting_cache": (_I32, [_VP, _U64]),
     "msi_dict_posting_cache_stats": (_I32, [_VP, C.POINTER(_U64)]),
     "msi_dict_reset_posting_cache": (_I32, [_VP]),
+    "msi_inject_pins": (_U32, [_VP, _U32, _U32, _U32, _VP, _VP, _VP, _U32, _VP, _VP, _VP]),
+    "msi_dict_stage_postings": (_I32, [_VP, _U64, _VP, _U64, C.POINTER(_U64)]),
+    "msi_dict_stage_complete": (_I32, [_VP, _U64, _U32]),
+    "msi_dict_staged_stats": (_I32, [_VP, C.POINTER(_U64)]),
     "msi_dict_lookup_device": (_I32, [_VP, _VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP, _VP, _VP]),
     "msi_dict_get_stats": (_I32, [_VP, C.POINTER(DictStats)]),
     "msi_dict_match_time": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_F64)]),

@@ -273,7 +273,8 @@ double msi_score_details_global_score(const msi_score_detail *details, uint32_t 
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t r, m;
     // ScoreDetails::rank() is None for Sort and GeoSort, score_details.rs:103-121
-    if (details[i].kind == MSI_SCORE_SORT || details[i].kind == MSI_SCORE_GEO_SORT) continue;
+    // ... and for Pin ("a placement directive, not a score", score_details.rs:123,135)
+    if (details[i].kind == MSI_SCORE_SORT || details[i].kind == MSI_SCORE_GEO_SORT || details[i].kind == MSI_SCORE_PIN) continue;
     switch (details[i].kind) {
       case MSI_SCORE_TYPO:
         m = details[i].b + 1;
@@ -298,6 +299,54 @@ double msi_score_details_global_score(const msi_score_detail *details, uint32_t 
     rank += r;
   }
   return (double)rank / (double)max_rank;
+}
+
+// inject_pins (search/new/bucket_sort.rs:345-377) over merge_positioned_hits_into_page (search/mod.rs:579-625): the pins —
+// in resolve_pins' order — are merged into the organic prefix [0, from + length) the bucket sort produced, a pin taking
+// the combined index its position names (or the next one when earlier pins pushed it on; or the end of the organic hits
+// when they run out: "pumping"), and the page [from, from + length) is cut out of the combined list.
+uint32_t msi_inject_pins(const msi_pin *pins, uint32_t n_pins, uint32_t from, uint32_t length, const uint32_t *docids,
+                         const msi_score_detail *scores, const uint32_t *n_scores, uint32_t n, uint32_t *out_docids,
+                         msi_score_detail *out_scores, uint32_t *out_n_scores) {
+  if ((n_pins && !pins) || (n && !docids) || !out_docids) return 0;
+  const uint64_t page_end = (uint64_t)from + (uint64_t)length;
+  uint32_t written = 0, pi = 0, oi = 0;
+  auto put_organic = [&](uint32_t i, bool keep) {
+    if (!keep) return;
+    out_docids[written] = docids[i];
+    if (out_scores && out_n_scores) {
+      const uint32_t ns = scores && n_scores ? n_scores[i] : 0;
+      if (ns) memcpy(out_scores + (size_t)written * MSI_MAX_SCORE_DETAILS, scores + (size_t)i * MSI_MAX_SCORE_DETAILS, ns * sizeof(msi_score_detail));
+      out_n_scores[written] = ns;
+    }
+    ++written;
+  };
+  auto put_pin = [&](const msi_pin &p, bool keep) {
+    if (!keep) return;
+    out_docids[written] = p.docid;
+    if (out_scores && out_n_scores) {   // vec![ScoreDetails::Pin { position }]
+      out_scores[(size_t)written * MSI_MAX_SCORE_DETAILS] = msi_score_detail{MSI_SCORE_PIN, p.position, 0};
+      out_n_scores[written] = 1;
+    }
+    ++written;
+  };
+  if (n_pins == 0) {   // (the reference returns the organic hits as they are: the caller asked the bucket sort for the page itself)
+    for (uint32_t i = 0; i < n && written < length; ++i) put_organic(i, true);
+    return written;
+  }
+  for (uint64_t combined = 0; combined < page_end; ++combined) {
+    const bool keep = combined >= from;
+    if (pi < n_pins) {
+      if ((uint64_t)pins[pi].position <= combined) put_pin(pins[pi++], keep);
+      else if (oi < n) put_organic(oi++, keep);
+      else put_pin(pins[pi++], keep);
+    } else if (oi < n) {
+      put_organic(oi++, keep);
+    } else {
+      break;
+    }
+  }
+  return written;
 }
 
 // compare_scores over ScoreValue::Score sequences — search/hybrid.rs:32-80.

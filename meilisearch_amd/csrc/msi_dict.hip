@@ -1263,11 +1263,52 @@ int32_t msi_dict_reset_posting_cache(msi_dict *d) {
   if (!d) return MSI_E_INVALID;
   std::lock_guard<std::mutex> lk(d->bmu);
   if (!d->pcache) return MSI_OK;
-  uint64_t st[4] = {0, 0, 0, 0};
-  msi_pcache_stats(d->pcache, st);
-  msi_pcache_destroy(d->pcache);
-  d->pcache = msi_pcache_create(d->ctx, st[3]);
-  return d->pcache ? MSI_OK : MSI_E_OOM;
+  msi_pcache_reset(d->pcache);   // (what msi_dict_stage_postings put there stays: it is the index, not a search's leftovers)
+  return MSI_OK;
+}
+
+// Index-open staging of stored postings (north_star: "staged once into HBM"; the reference reads every posting from the
+// mmap on demand, db_cache.rs:50-84 — one lookup, no copy: with the databases staged a search's lookup is one probe of the
+// cache's host table and its decode reads HBM).
+int32_t msi_dict_stage_postings(msi_dict *d, uint64_t index_view, const msi_staged_posting *values, uint64_t n_values,
+                                uint64_t out_counts[3]) {
+  if (out_counts) out_counts[0] = out_counts[1] = out_counts[2] = 0;
+  if (!d || (!values && n_values)) {
+    msi_set_error("msi_dict_stage_postings: invalid argument");
+    return MSI_E_INVALID;
+  }
+  if (!d->pcache) {
+    msi_set_error("msi_dict_stage_postings: the dictionary has no posting cache (msi_dict_enable_posting_cache first)");
+    return MSI_E_INVALID;
+  }
+  std::vector<MsiStageValue> v(n_values);
+  for (uint64_t i = 0; i < n_values; ++i) {
+    const msi_staged_posting &s = values[i];
+    if (s.db == 0 || s.db >= 32 || (s.key1_len && !s.key1) || (s.key2_len && !s.key2) || (s.n && !s.bytes)) {
+      msi_set_error("msi_dict_stage_postings: value %llu is malformed", (unsigned long long)i);
+      return MSI_E_INVALID;
+    }
+    v[i].key = msi_cache_key(s.db, s.key1, s.key1_len, s.key2, s.key2_len, s.x, s.y, index_view);
+    v[i].bytes = s.n ? s.bytes : nullptr;
+    v[i].len = s.n;
+  }
+  return msi_pcache_stage(d->pcache, v.data(), n_values, out_counts);
+}
+
+int32_t msi_dict_stage_complete(msi_dict *d, uint64_t index_view, uint32_t db_mask) {
+  if (!d || !d->pcache || (db_mask & 1u)) {
+    msi_set_error("msi_dict_stage_complete: invalid argument (no posting cache, or database 0)");
+    return MSI_E_INVALID;
+  }
+  msi_pcache_set_complete(d->pcache, index_view, db_mask);
+  return MSI_OK;
+}
+
+int32_t msi_dict_staged_stats(msi_dict *d, uint64_t out[4]) {
+  if (!d || !out) return MSI_E_INVALID;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (d->pcache) msi_pcache_staged_stats(d->pcache, out);
+  return MSI_OK;
 }
 
 int32_t msi_dict_posting_cache_stats(msi_dict *d, uint64_t out[4]) {

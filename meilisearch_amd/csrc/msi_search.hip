@@ -1421,7 +1421,13 @@ struct Ctx {
     static const bool off = getenv("MSI_PCACHE_KNOWN") && getenv("MSI_PCACHE_KNOWN")[0] == '0';   // experiments
     if (!dev.vm || !dev.pcache || off) return false;
     MsiKnownPosting kp;
-    if (!msi_pcache_known(dev.pcache, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y, prm->index_view), &kp)) return false;
+    if (!msi_pcache_known(dev.pcache, msi_cache_key(db, s1.data(), s1.size(), s2.data(), s2.size(), x, y, prm->index_view), &kp)) {
+      // a database staged whole at index-open (msi_dict_stage_complete): what the cache does not hold does not exist
+      if (!msi_pcache_complete(dev.pcache, db, prm->index_view)) return false;
+      if (card) *card = 0;
+      if (present) *present = false;
+      return true;
+    }
     if (card) *card = kp.card;
     if (present) *present = kp.kind != 1;
     if (b) {
@@ -3017,9 +3023,10 @@ struct ExactAttributeRule : Rule {
           }
         if (!S) S = c.dev.clone(P);
         MsiCboBatch wc;
-        if (count_all < 255) {
+        if (count_all < 255 && !c.from_cache(&wc, 5, std::string(), std::string(), fid, count_all, nullptr, nullptr)) {
           const uint8_t *bytes = nullptr;
           size_t n = 0;
+          Ctx::Cb cb_;
           const int32_t st = c.ix->field_id_word_count_docids(c.ix->user, fid, count_all, &bytes, &n);
           c.take(wc, st, bytes, n, "field_id_word_count_docids", 5, std::string(), std::string(), fid, count_all);
         }

@@ -182,3 +182,22 @@ bool msi_pcache_known(MsiPostingCache *c, const MsiCacheKey &k, MsiKnownPosting 
 void msi_pcache_learn(MsiPostingCache *c, const MsiCacheKey &k, const uint8_t *bytes, size_t len);   // absent (len 0) or small values
 void msi_pcache_describe(MsiPostingCache *c, void *token, const uint8_t *bytes, size_t len);         // kind 3, before the commit
 void msi_pcache_stats(const MsiPostingCache *c, uint64_t out[4]);   // hits, misses, bytes used, capacity
+// ---- staging at index-open (msi_dict_stage_postings) ----------------------------------------------------------------
+// The stored values of whole databases put into the cache before the first search: bodies in HBM with their container
+// tables parsed, "no such key" and raw small values on the host — what a search's first reader would have left there, for
+// every key at once (one reservation and one host-to-device copy per call).  Thread-safe against searches and other calls.
+struct MsiStageValue {
+  MsiCacheKey key;
+  const uint8_t *bytes;   // the stored value (null / len 0: the key is absent)
+  size_t len;
+};
+// -> MSI_OK | MSI_E_OOM (the cache's HBM arena cannot hold the call's bodies: nothing of the call is staged) | MSI_E_INVALID (a value
+// that does not parse as a CboRoaringBitmap); out: [bodies staged in HBM, values kept on the host, keys that were already known]
+int32_t msi_pcache_stage(MsiPostingCache *c, const MsiStageValue *values, uint64_t n, uint64_t out[3]);
+// Every key of database `db` (1 word_docids, 3 word_fid_docids, 4 word_position_docids, ...) of view `view` has been staged:
+// a key the cache does not know DOES NOT EXIST in that database — the search asks nobody.
+void msi_pcache_set_complete(MsiPostingCache *c, uint64_t view, uint32_t db_mask);
+bool msi_pcache_complete(MsiPostingCache *c, uint32_t db, uint64_t view);   // (counts a hit when true)
+// Forget what searches left in the cache; what was STAGED stays (bodies, tables, completeness).  No search in flight.
+void msi_pcache_reset(MsiPostingCache *c);
+void msi_pcache_staged_stats(const MsiPostingCache *c, uint64_t out[4]);   // staged: bodies, host-kept values, HBM bytes, complete-db answers

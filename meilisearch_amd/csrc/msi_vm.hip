@@ -1502,6 +1502,7 @@ struct StripedCounters {
     for (const auto &c : cells) t += c.v[i].load(std::memory_order_relaxed);
     return t;
   }
+  void reset() { for (auto &c : cells) for (auto &x : c.v) x.store(0, std::memory_order_relaxed); }
 };
 
 // A submitted list.  Lives in a slot OWNED BY THE VM (recycled, never freed before the VM), so the combiner may touch it
@@ -1519,6 +1520,7 @@ struct VmSub {
   int32_t error = MSI_OK;
   char errmsg[192] = "";                   // the combiner thread's error text (msi_last_error is thread-local: the waiter re-issues it)
   int64_t t_submit = 0, t_taken = 0, t_launch = 0, t_done = 0;   // steady-clock ns (diagnostics)
+  VmSub *next = nullptr;                   // the combiner's submission stack (VmCombiner::q_head)
 };
 
 struct VmCombiner {
@@ -1526,13 +1528,19 @@ struct VmCombiner {
   static constexpr int NS = 16;     // rounds in flight: a slow list of one round must not hold up the next round's lists
   hipStream_t streams[NS] = {};
   std::thread th;
+  // Submission takes no lock (round 6).  Every list used to take `mu` twice — to queue itself and to hand its slot back —
+  // and the combiner took it once per loop turn: with 256 searches in flight on a 16-CPU quota, pthread_mutex_lock / unlock and
+  // the futex calls under them were a quarter of the keyword leg's host CPU (profiles/r6_kw_fresh_profile_before.txt:
+  // __lll_lock_wait_private 10 %, __lll_lock_wake_private 8.5 %, pthread_mutex_lock / unlock 6.4 %).  Now a search pushes its
+  // VmSub (one per calling thread, never freed) onto an intrusive stack with one compare-exchange; the combiner takes the
+  // whole stack with one exchange and reverses it (arrival order).  `mu` / `cv` only serve the combiner's sleep when nothing
+  // at all is in flight: the combiner announces `sleeping` BEFORE it re-reads the stack (both seq_cst), a submitter reads
+  // `sleeping` AFTER its push — one of the two sees the other — and passes through `mu` before notifying.
   std::mutex mu;
   std::condition_variable cv;
-  std::vector<VmSub *> queue;              // submitted, not yet taken (guarded by mu)
-  std::vector<VmSub *> free_slots;         // guarded by mu
-  std::vector<std::unique_ptr<VmSub>> slots;
-  bool sleeping = false;                   // the combiner waits on cv (guarded by mu)
-  bool stop = false;
+  std::atomic<VmSub *> q_head{nullptr};    // submitted, not yet taken (newest first)
+  std::atomic<uint32_t> sleeping{0};       // the combiner waits on cv
+  std::atomic<bool> stop{false};
   struct Arena {
     uint8_t *host = nullptr, *dev = nullptr;
     size_t cap = 0;
@@ -1947,15 +1955,19 @@ void VmCombiner::run() {
   for (;;) {
     taken.clear();
     {
-      std::unique_lock<std::mutex> lk(mu);
-      const bool flying = n_inflight.load(std::memory_order_acquire) != 0;
-      if (queue.empty() && !flying && waiting[0].empty() && waiting[1].empty()) {
-        sleeping = true;
-        cv.wait(lk, [&] { return stop || !queue.empty(); });
-        sleeping = false;
+      VmSub *h = q_head.exchange(nullptr, std::memory_order_acquire);
+      const bool idle = n_inflight.load(std::memory_order_acquire) == 0 && waiting[0].empty() && waiting[1].empty();
+      if (!h && idle) {
+        std::unique_lock<std::mutex> lk(mu);
+        sleeping.store(1, std::memory_order_seq_cst);
+        cv.wait(lk, [&] { return stop.load(std::memory_order_seq_cst) || q_head.load(std::memory_order_seq_cst) != nullptr; });
+        sleeping.store(0, std::memory_order_seq_cst);
+        lk.unlock();
+        h = q_head.exchange(nullptr, std::memory_order_acquire);
       }
-      if (stop && queue.empty() && n_inflight.load(std::memory_order_acquire) == 0 && waiting[0].empty() && waiting[1].empty()) return;
-      taken.swap(queue);
+      if (!h && idle && stop.load(std::memory_order_acquire)) return;
+      for (; h; h = h->next) taken.push_back(h);
+      std::reverse(taken.begin(), taken.end());   // (the stack holds the newest first)
     }
     if (!taken.empty()) {
       const int64_t t_taken = now_ns();
@@ -2055,7 +2067,7 @@ void msi_vm_destroy(msi_vm *vmx) {
     VmCombiner *vm = cb.get();
     {
       std::lock_guard<std::mutex> lk(vm->mu);
-      vm->stop = true;
+      vm->stop.store(true, std::memory_order_seq_cst);
     }
     vm->cv.notify_all();
     if (vm->th.joinable()) vm->th.join();   // (returns once nothing is queued, waiting or in flight: the reaper is still there for that)
@@ -2410,32 +2422,30 @@ int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
   VmCombiner *vm = vmx->comb[(((uintptr_t)pool) >> 8) % vmx->comb.size()].get();   // a pool always talks to the same combiner
   volatile uint64_t *blk = msi_bits_vm_block(pool);
   if (!blk) return MSI_E_OOM;
-  VmSub *s = nullptr;
-  bool wake = false;
-  {
-    std::lock_guard<std::mutex> lk(vm->mu);
-    if (vm->free_slots.empty()) {
-      vm->slots.emplace_back(new VmSub());
-      s = vm->slots.back().get();
-    } else {
-      s = vm->free_slots.back();
-      vm->free_slots.pop_back();
-    }
-    s->pool = pool;
-    s->list = &l;
-    s->seq = msi_bits_vm_next_seq(pool);
-    s->blk = blk;
-    s->error = MSI_OK;
-    s->errmsg[0] = 0;
-    s->state.store(0, std::memory_order_relaxed);
-    s->asleep.store(0, std::memory_order_relaxed);
-    s->t_submit = now_ns();
-    s->t_taken = s->t_launch = s->t_done = 0;
-    vm->queue.push_back(s);
-    wake = vm->sleeping;
-    vm->load.fetch_add(1, std::memory_order_relaxed);
+  // one submission record per calling thread (a thread has one list in flight at a time).  It is never freed: the combiner
+  // may still read `asleep` of a record whose waiter has already left (finish()), so the memory has to outlive the thread.
+  static thread_local VmSub *tl_sub = nullptr;
+  if (!tl_sub) tl_sub = new VmSub();
+  VmSub *s = tl_sub;
+  s->pool = pool;
+  s->list = &l;
+  s->seq = msi_bits_vm_next_seq(pool);
+  s->blk = blk;
+  s->error = MSI_OK;
+  s->errmsg[0] = 0;
+  s->fused_wgs = 0;
+  s->state.store(0, std::memory_order_relaxed);
+  s->asleep.store(0, std::memory_order_relaxed);
+  s->t_submit = now_ns();
+  s->t_taken = s->t_launch = s->t_done = 0;
+  vm->load.fetch_add(1, std::memory_order_relaxed);
+  s->next = vm->q_head.load(std::memory_order_relaxed);
+  while (!vm->q_head.compare_exchange_weak(s->next, s, std::memory_order_seq_cst, std::memory_order_relaxed)) {
   }
-  if (wake) vm->cv.notify_one();
+  if (vm->sleeping.load(std::memory_order_seq_cst)) {
+    { std::lock_guard<std::mutex> lk(vm->mu); }   // (the combiner is inside cv.wait once this lock is granted)
+    vm->cv.notify_one();
+  }
   // A short poll when the combiner is nearly idle (a round trip is then ~25 us), else sleep until the combiner wakes
   // us: under load a round trip takes 100+ us and polling through it would burn the CPU time the searches need.
   const int64_t t0 = now_ns();
@@ -2476,10 +2486,6 @@ int32_t msi_vm_run(msi_bits *pool, MsiVmList &l, MsiVmResult *res) {
     }
   }
   vm->load.fetch_sub(1, std::memory_order_relaxed);
-  {
-    std::lock_guard<std::mutex> lk(vm->mu);
-    vm->free_slots.push_back(s);
-  }
   return ret;
 }
 
@@ -2503,7 +2509,9 @@ struct CacheEntry {
   std::vector<MsiContainer> conts;
   std::vector<uint32_t> small;
   std::atomic<uint32_t> ready{0};   // 0: reserved, being filled | 1: filled | 2: abandoned by a list that failed or was
-};                                  //    dropped — the next reader of the key takes the reservation over
+                                    //    dropped — the next reader of the key takes the reservation over
+  bool staged = false;              // put there by msi_pcache_stage (index-open): survives msi_pcache_reset
+};
 inline uint64_t mix64(uint64_t x) {
   x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull; x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull; x ^= x >> 33;
   return x;
@@ -2541,6 +2549,15 @@ struct MsiPostingCache {
     std::vector<CacheEntry *> entries;   // owned
   } shard[SHARDS];
   StripedCounters<2> counters;           // [hits, misses]
+  // staging at index-open (msi_pcache_stage): what was staged, and which databases of which view are complete
+  std::atomic<uint64_t> staged_bodies{0}, staged_host{0}, staged_bytes{0}, staged_hi{16};
+  StripedCounters<1> complete_answers;
+  struct Complete {
+    std::atomic<uint64_t> view{0};
+    std::atomic<uint32_t> mask{0};
+  } complete[8];
+  std::atomic<uint32_t> n_complete{0};
+  std::mutex complete_mu;
   Shard &of(const MsiCacheKey &k) { return shard[(k.b >> 7) % SHARDS]; }
   static uint64_t slot_of(const MsiCacheKey &k) { return (k.a ^ (k.a >> 31)) * 0x9E3779B97F4A7C15ull >> 20; }
   static CacheEntry *probe(const Table *t, const MsiCacheKey &k) {
@@ -2755,6 +2772,173 @@ void msi_pcache_describe(MsiPostingCache *, void *token, const uint8_t *bytes, s
   if (!msi_cbo_parse(bytes, len, cs)) return;
   e->card = msi_cbo_cardinality(bytes, len);
   e->conts.swap(cs);
+}
+
+// ---- staging at index-open ------------------------------------------------------------------------------------------
+int32_t msi_pcache_stage(MsiPostingCache *c, const MsiStageValue *values, uint64_t n, uint64_t out[3]) {
+  if (out) out[0] = out[1] = out[2] = 0;
+  if (!c || (!values && n)) return MSI_E_INVALID;
+  auto need_of = [](size_t len) { return ((uint64_t)len + 15 + 16) & ~15ull; };   // (as msi_pcache_lookup reserves)
+  // the call's bodies: parsed first (a malformed value fails the call before anything is reserved), one reservation
+  struct Body {
+    uint64_t rel;
+    std::vector<MsiContainer> conts;
+    uint64_t card;
+  };
+  std::vector<Body> bodies(n);
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const MsiStageValue &v = values[i];
+    if (!v.bytes || v.len <= 7 * sizeof(uint32_t)) continue;
+    if (!msi_cbo_parse(v.bytes, v.len, bodies[i].conts) || bodies[i].conts.empty()) {
+      msi_set_error("msi_dict_stage_postings: value %llu (%zu bytes) is not a CboRoaringBitmap serialisation", (unsigned long long)i, v.len);
+      return MSI_E_INVALID;
+    }
+    bodies[i].card = msi_cbo_cardinality(v.bytes, v.len);
+    if (i && values[i - 1].bytes == v.bytes && values[i - 1].len == v.len) {   // the same stored value under two keys: one body
+      bodies[i].rel = bodies[i - 1].rel;
+      continue;
+    }
+    bodies[i].rel = total;
+    total += need_of(v.len);
+  }
+  uint64_t base = 0;
+  if (total) {
+    base = c->used.load(std::memory_order_relaxed);
+    do {
+      if (base + total > c->cap) {
+        msi_set_error("msi_dict_stage_postings: %llu bytes of postings do not fit the posting cache (%llu of %llu bytes used)",
+                      (unsigned long long)total, (unsigned long long)base, (unsigned long long)c->cap);
+        return MSI_E_OOM;
+      }
+    } while (!c->used.compare_exchange_weak(base, base + total, std::memory_order_relaxed));
+    std::unique_ptr<uint8_t[]> host(new uint8_t[total]);
+    for (uint64_t i = 0; i < n; ++i) {
+      if (bodies[i].conts.empty()) continue;
+      memcpy(host.get() + bodies[i].rel, values[i].bytes, values[i].len);
+      memset(host.get() + bodies[i].rel + values[i].len, 0, need_of(values[i].len) - values[i].len);
+    }
+    DeviceGuard g(c->ctx->device);
+    // (a blocking copy: the bodies are in HBM before any entry that points at them becomes visible)
+    if (hipMemcpy(c->dev + base, host.get(), total, hipMemcpyHostToDevice) != hipSuccess) {
+      msi_set_error("msi_dict_stage_postings: copying %llu bytes to the device failed", (unsigned long long)total);
+      return MSI_E_HIP;
+    }
+    uint64_t hi = c->staged_hi.load(std::memory_order_relaxed);
+    while (hi < base + total && !c->staged_hi.compare_exchange_weak(hi, base + total, std::memory_order_relaxed)) {
+    }
+  }
+  uint64_t n_body = 0, n_host = 0, n_known = 0, bytes_body = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const MsiStageValue &v = values[i];
+    if (c->find(v.key)) {
+      ++n_known;
+      continue;
+    }
+    MsiPostingCache::Shard &sh = c->of(v.key);
+    std::lock_guard<std::mutex> lk(sh.wmu);
+    bool created = false;
+    (void)c->find_or_insert(sh, v.key, &created, [&](CacheEntry &e) {
+      e.staged = true;
+      if (bodies[i].conts.empty()) {   // absent, or a raw value of <= 7 docids: kept on the host (msi_pcache_learn)
+        const size_t len = v.bytes ? v.len : 0;
+        for (size_t b = 0; b + 4 <= len; b += 4) {
+          uint32_t d;
+          memcpy(&d, v.bytes + b, 4);
+          e.small.push_back(d);
+        }
+        e.card = e.small.size();
+        e.host_kind.store(e.small.empty() ? 1u : 2u, std::memory_order_release);
+        return true;
+      }
+      e.off = base + bodies[i].rel;
+      e.len = v.len;
+      e.card = bodies[i].card;
+      e.conts.swap(bodies[i].conts);
+      e.ready.store(1, std::memory_order_release);
+      return true;
+    });
+    if (!created) ++n_known;
+    else if (v.bytes && v.len > 7 * sizeof(uint32_t)) {
+      ++n_body;
+      bytes_body += v.len;
+    } else ++n_host;
+  }
+  c->staged_bodies.fetch_add(n_body, std::memory_order_relaxed);
+  c->staged_host.fetch_add(n_host, std::memory_order_relaxed);
+  c->staged_bytes.fetch_add(bytes_body, std::memory_order_relaxed);
+  if (out) {
+    out[0] = n_body;
+    out[1] = n_host;
+    out[2] = n_known;
+  }
+  return MSI_OK;
+}
+
+void msi_pcache_set_complete(MsiPostingCache *c, uint64_t view, uint32_t db_mask) {
+  if (!c) return;
+  std::lock_guard<std::mutex> lk(c->complete_mu);
+  const uint32_t n = c->n_complete.load(std::memory_order_relaxed);
+  for (uint32_t i = 0; i < n; ++i)
+    if (c->complete[i].view.load(std::memory_order_relaxed) == view) {
+      c->complete[i].mask.fetch_or(db_mask, std::memory_order_release);
+      return;
+    }
+  if (n >= 8) return;   // (more views than slots: the ninth view's databases are simply asked for as before)
+  c->complete[n].view.store(view, std::memory_order_relaxed);
+  c->complete[n].mask.store(db_mask, std::memory_order_relaxed);
+  c->n_complete.store(n + 1, std::memory_order_release);
+}
+
+bool msi_pcache_complete(MsiPostingCache *c, uint32_t db, uint64_t view) {
+  if (!c || db >= 32) return false;
+  const uint32_t n = c->n_complete.load(std::memory_order_acquire);
+  for (uint32_t i = 0; i < n; ++i)
+    if (c->complete[i].view.load(std::memory_order_relaxed) == view) {
+      if (!((c->complete[i].mask.load(std::memory_order_acquire) >> db) & 1u)) return false;
+      c->complete_answers.add(0, 1);
+      c->counters.add(0, 1);
+      return true;
+    }
+  return false;
+}
+
+void msi_pcache_reset(MsiPostingCache *c) {
+  if (!c) return;
+  DeviceGuard g(c->ctx->device);
+  (void)hipDeviceSynchronize();   // no list that reads or fills the cache is in flight after this
+  for (auto &sh : c->shard) {
+    std::lock_guard<std::mutex> lk(sh.wmu);
+    std::vector<CacheEntry *> kept;
+    for (CacheEntry *e : sh.entries) {
+      if (e->staged) kept.push_back(e);
+      else delete e;
+    }
+    sh.entries.swap(kept);
+    sh.count = sh.entries.size();
+    uint64_t cap = 1024;
+    while (cap < 2 * (sh.count + 1)) cap *= 2;
+    MsiPostingCache::Table *nt = new MsiPostingCache::Table(cap);
+    for (CacheEntry *e : sh.entries) {
+      uint64_t j = MsiPostingCache::slot_of(e->key) & nt->mask;
+      while (nt->slots[j].load(std::memory_order_relaxed)) j = (j + 1) & nt->mask;
+      nt->slots[j].store(e, std::memory_order_relaxed);
+    }
+    MsiPostingCache::Table *old = sh.table.load(std::memory_order_relaxed);
+    sh.table.store(nt, std::memory_order_release);
+    delete old;   // (no reader in flight: nothing probes it)
+    for (MsiPostingCache::Table *t : sh.retired) delete t;
+    sh.retired.clear();
+  }
+  c->used.store(std::max<uint64_t>(16, c->staged_hi.load()));
+  c->counters.reset();
+}
+
+void msi_pcache_staged_stats(const MsiPostingCache *c, uint64_t out[4]) {
+  out[0] = c->staged_bodies.load();
+  out[1] = c->staged_host.load();
+  out[2] = c->staged_bytes.load();
+  out[3] = c->complete_answers.sum(0);
 }
 
 // The list that was to fill the entry failed or was dropped: hand the reservation to the next reader of the key.

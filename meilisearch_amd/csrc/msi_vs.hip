@@ -1095,8 +1095,10 @@ struct KeySrc {
   const float *dense;
   const uint32_t *list;
   uint32_t stride;
+  uint32_t base = 0;   // dense: entry i of this source is entry base + i of the row (vs_select_part_kernel's slices)
   __device__ __forceinline__ u64 get(uint32_t i) const {
     if (keys) return keys[i];
+    i += base;
     const float s = dense[i];
     if (s == -INFINITY) return ~0ull;
     const uint32_t item = (i >> 4) * stride;
@@ -1253,6 +1255,7 @@ struct SelectArgs {
   uint32_t *sel_cnt;           // [NQ_MAX]           (mode 1)
   float *theta;                // [NQ_MAX]           (mode 0: threshold for the sparse pass)
   int mode;                    // 0 = threshold only, 1 = keep the keys
+  uint32_t fixed_c;            // sparse input: every query has this many keys (0: gcnt says) — the lists vs_select_part_kernel left
 };
 
 __global__ __launch_bounds__(SEL_THREADS) void vs_select_kernel(SelectArgs a) {
@@ -1275,7 +1278,7 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_select_kernel(SelectArgs a) {
     src.dense = nullptr;
     src.list = nullptr;
     src.stride = 1;
-    c = a.gcnt[j * CNT_PAD];
+    c = a.fixed_c ? a.fixed_c : a.gcnt[j * CNT_PAD];
     if (c > a.capg) c = a.capg;
   }
   const uint32_t got = block_select_smallest(src, c, a.K, sbuf, hist, sh);
@@ -1289,6 +1292,31 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_select_kernel(SelectArgs a) {
   }
 }
 
+// The threshold of the sparse pass sits in front of every sweep, and one workgroup per query walking its ~200 k sampled scores
+// (10 M rows, K' = 1 024) two or three times was 0.3-0.75 ms of it with half the CUs idle (profiles/r5_i8_vector_leg_kernel_
+// stats.csv: vs_select_kernel).  The K smallest keys of a row are among the K smallest of each of its slices: gridDim.x
+// workgroups per query select inside one slice each and leave their K best in sel_keys[j][slice][K] (free until the chunk's
+// second selection); vs_select_kernel then reads those gridDim.x * K keys (SelectArgs::fixed_c) instead of the row.
+__global__ __launch_bounds__(SEL_THREADS) void vs_select_part_kernel(SelectArgs a) {
+  __shared__ u64 sbuf[SEL_SORTCAP];
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t sh[4];
+  const uint32_t p = blockIdx.x, P = gridDim.x, j = blockIdx.y;
+  const uint32_t n_all = *a.n_items_ptr;
+  const uint32_t c = ((n_all + a.stride - 1) / a.stride) * 16;
+  const uint32_t lo = (uint32_t)((uint64_t)c * p / P), hi = (uint32_t)((uint64_t)c * (p + 1) / P);
+  KeySrc src;
+  src.keys = nullptr;
+  src.dense = a.dense + (uint64_t)j * a.dstride;
+  src.list = a.list;
+  src.stride = a.stride;
+  src.base = lo;
+  const uint32_t got = block_select_smallest(src, hi - lo, a.K, sbuf, hist, sh);
+  __syncthreads();
+  u64 *out = a.sel_keys + (uint64_t)j * KP_MAX + (uint64_t)p * a.K;
+  for (uint32_t i = threadIdx.x; i < a.K; i += blockDim.x) out[i] = i < got ? sbuf[i] : ~0ull;
+}
+
 // --------------------------------------------------------------------- rescore
 
 // Reference arithmetic for one (row, query) pair from the tiled layout:
@@ -1296,21 +1324,55 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_select_kernel(SelectArgs a) {
 template <bool S16>
 __device__ __forceinline__ float canonical_dot_t(const void *__restrict__ tiles, uint32_t KB, uint32_t row,
                                                  const float *__restrict__ q, uint32_t dpad) {
+  // The additions are one dependent chain (the reference's order), the LOADS are not: a row's 16-byte pieces sit 256 B
+  // apart (four per KiB block), so one load per step of the chain was one memory round trip per 4 (8) columns — 192 of
+  // them for a row of 768 floats, 0.52 ms per 128-query chunk of C4 in vs_rescore_dots_kernel
+  // (profiles/r5_i8_vector_leg_kernel_stats.csv).  CD_UNR blocks = 4 CD_UNR pieces are requested before the first is used.
+  constexpr int CD_UNR = 8;
   float acc = 0.f;
   if (S16) {
-    for (uint32_t k = 0; k < dpad; ++k) acc = __fadd_rn(acc, __fmul_rn(tile_elem<true>(tiles, KB, row, k), q[k]));
+    const bf16x8 *base = reinterpret_cast<const bf16x8 *>(tiles) + (uint64_t)(row >> 4) * KB * 64 + (row & 15);
+    for (uint32_t kb0 = 0; kb0 < KB; kb0 += CD_UNR) {
+      bf16x8 v[CD_UNR][4];
+#pragma unroll
+      for (int u = 0; u < CD_UNR; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (kb0 + u < KB) v[u][g] = base[(uint64_t)(kb0 + u) * 64 + g * 16];
+#pragma unroll
+      for (int u = 0; u < CD_UNR; ++u) {
+        if (kb0 + u < KB) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float *qq = q + (kb0 + u) * 32 + g * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __fadd_rn(acc, __fmul_rn((float)v[u][g][e], qq[e]));
+          }
+        }
+      }
+    }
     return acc;
   }
   const float4 *base = reinterpret_cast<const float4 *>(tiles) + (uint64_t)(row >> 4) * KB * 64 + (row & 15);
-  for (uint32_t kb = 0; kb < KB; ++kb) {
+  for (uint32_t kb0 = 0; kb0 < KB; kb0 += CD_UNR) {
+    float4 v[CD_UNR][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 v = base[(uint64_t)kb * 64 + g * 16];
-      const float *qq = q + kb * 16 + g * 4;
-      acc = __fadd_rn(acc, __fmul_rn(v.x, qq[0]));
-      acc = __fadd_rn(acc, __fmul_rn(v.y, qq[1]));
-      acc = __fadd_rn(acc, __fmul_rn(v.z, qq[2]));
-      acc = __fadd_rn(acc, __fmul_rn(v.w, qq[3]));
+    for (int u = 0; u < CD_UNR; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (kb0 + u < KB) v[u][g] = base[(uint64_t)(kb0 + u) * 64 + g * 16];
+#pragma unroll
+    for (int u = 0; u < CD_UNR; ++u) {
+      if (kb0 + u < KB) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float *qq = q + (kb0 + u) * 16 + g * 4;
+          acc = __fadd_rn(acc, __fmul_rn(v[u][g].x, qq[0]));
+          acc = __fadd_rn(acc, __fmul_rn(v[u][g].y, qq[1]));
+          acc = __fadd_rn(acc, __fmul_rn(v[u][g].z, qq[2]));
+          acc = __fadd_rn(acc, __fmul_rn(v[u][g].w, qq[3]));
+        }
+      }
     }
   }
   return acc;
@@ -1366,6 +1428,10 @@ __device__ __forceinline__ bool candidate_matters(const RescoreArgs &a, uint32_t
   const float ck = key_desc_score(a.sel_keys[(uint64_t)j * KP_MAX + a.k - 1]) * inv;
   const float ci = key_desc_score(a.sel_keys[(uint64_t)j * KP_MAX + i]) * inv;
   if (!(fabsf(ck) < 1e30f)) return true;    // k degenerate rows (distance 0 by definition) in front: a row at cosine 1 ties with them
+  // Rows keyed FLT_MAX (degenerate, or not quantisable: NaN scale) sit in front and obey no bound on their reference cosine:
+  // with m < k of them only k - m rows back the claim above, so nothing is pruned then
+  const float c0 = key_desc_score(a.sel_keys[(uint64_t)j * KP_MAX]) * inv;
+  if (!(fabsf(c0) < 1e30f)) return true;
   return !(ci < ck - 2.0f * eps - 1e-6f);   // (1e-6: a strictly larger distance, never a tie that the docid would decide; NaN: keep)
 }
 
@@ -1379,14 +1445,19 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_dots_kernel(RescoreArg
   const uint32_t dpad = a.dpad;
   const uint32_t cnt = a.sel_cnt[j];
   if (blockIdx.x * blockDim.x >= cnt) return;
-  for (uint32_t i = threadIdx.x; i < dpad; i += blockDim.x) qs[i] = a.qrow[(uint64_t)j * dpad + i];
-  __syncthreads();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cnt) return;
-  if (!candidate_matters(a, j, i, cnt)) {
-    a.pre_keys[(uint64_t)j * KP_MAX + i] = ~0ull;   // (sorts behind every rescored candidate)
-    return;
-  }
+  const bool matters = i < cnt && candidate_matters(a, j, i, cnt);
+  if (i < cnt && !matters) a.pre_keys[(uint64_t)j * KP_MAX + i] = ~0ull;   // (sorts behind every rescored candidate)
+  // (the candidates arrive ordered by fast score: the ones that matter are a prefix, most workgroups of a query have none)
+  __shared__ uint32_t s_any;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  if (matters) s_any = 1;
+  __syncthreads();
+  if (!s_any) return;
+  for (uint32_t i2 = threadIdx.x; i2 < dpad; i2 += blockDim.x) qs[i2] = a.qrow[(uint64_t)j * dpad + i2];
+  __syncthreads();
+  if (!matters) return;
   const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
   const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
   const float d = canonical_distance(pq, a.norm[row], a.qn[j]);
@@ -1401,12 +1472,24 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) 
   const uint32_t dpad = a.dpad;
   for (uint32_t i = threadIdx.x; i < dpad; i += blockDim.x) qs[i] = a.qrow[(uint64_t)j * dpad + i];
   const uint32_t cnt = a.sel_cnt[j];
-  const uint32_t n = next_pow2(cnt < 2 ? 2 : cnt);
+  // Only the candidates that matter are sorted: the others carry the sentinel key, and — ordered by fast score as the
+  // candidates are — they follow the last one that matters (K' = 1 024 with ~200 that matter: a sort of 256 keys, not 1 024)
+  __shared__ uint32_t s_last;
+  if (threadIdx.x == 0) s_last = 0;
   __syncthreads();
+  {
+    uint32_t last = 0;
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x)
+      if (a.pre_keys ? a.pre_keys[(uint64_t)j * KP_MAX + i] != ~0ull : candidate_matters(a, j, i, cnt)) last = i + 1;
+    if (last) atomicMax(&s_last, last);
+  }
+  __syncthreads();
+  const uint32_t m = s_last;
+  const uint32_t n = next_pow2(m < 2 ? 2 : m);
   const float qn = a.qn[j];
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     u64 key = ~0ull;
-    if (i < cnt) {
+    if (i < m) {
       if (a.pre_keys) {
         key = a.pre_keys[(uint64_t)j * KP_MAX + i];
       } else if (candidate_matters(a, j, i, cnt)) {
@@ -2079,6 +2162,7 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
   se.sel_keys = vs->sel_keys.as<u64>();
   se.sel_cnt = s.sel_cnt;
   se.theta = s.theta;
+  se.fixed_c = 0;
   // rescore with the reference arithmetic, order, prove exactness
   RescoreArgs &ra = c.ra;
   ra.tiles = vs->tiles.p;
@@ -2132,7 +2216,23 @@ int32_t chunk_pre(msi_vs *vs, Chunk &c, hipStream_t st) {
     if (c.i8) vs->i8_scan_tiles += c.dense_items;
     c.se.K = c.thr_rank;
     c.se.mode = 0;
-    hipLaunchKernelGGL(vs_select_kernel, dim3(c.nqt * QT), dim3(SEL_THREADS), 0, st, c.se);
+    // a large sample is selected from in slices, by the whole chip (vs_select_part_kernel); MSI_VS_SELECT_PARTS=0: one
+    // workgroup per query as before
+    static const int parts_knob = getenv("MSI_VS_SELECT_PARTS") ? atoi(getenv("MSI_VS_SELECT_PARTS")) : -1;
+    uint32_t parts = parts_knob >= 0 ? (uint32_t)parts_knob : 32u;
+    parts = std::min<uint32_t>(parts, KP_MAX / std::max<uint32_t>(1, c.thr_rank));
+    if (c.dense_items * 16 < 16384) parts = 0;
+    if (parts >= 2) {
+      hipLaunchKernelGGL(vs_select_part_kernel, dim3(parts, c.nqt * QT), dim3(SEL_THREADS), 0, st, c.se);
+      SelectArgs fin = c.se;
+      fin.dense = nullptr;
+      fin.gkeys = c.se.sel_keys;
+      fin.capg = KP_MAX;
+      fin.fixed_c = parts * c.thr_rank;
+      hipLaunchKernelGGL(vs_select_kernel, dim3(c.nqt * QT), dim3(SEL_THREADS), 0, st, fin);
+    } else {
+      hipLaunchKernelGGL(vs_select_kernel, dim3(c.nqt * QT), dim3(SEL_THREADS), 0, st, c.se);
+    }
     MSI_HIP_TRY(hipMemsetAsync(c.gcnt, 0, (size_t)NQ_MAX * CNT_PAD * sizeof(uint32_t), st));
   }
   MSI_HIP_TRY(hipGetLastError());

@@ -92,3 +92,24 @@ def hybrid_merge_batch(v_docids, v_dist, v_counts, k_docids, k_words, k_typos, k
                                        np.float32(semantic_ratio), offset, limit, np_ptr(out_d), np_ptr(out_s),
                                        np_ptr(out_c), np_ptr(out_h)))
     return out_d, out_s, out_c, out_h
+
+
+def inject_pins(pins, organic, offset=0, limit=20):
+    """inject_pins / merge_positioned_hits_into_page — search/new/bucket_sort.rs:345-377, search/mod.rs:579-625.
+    pins: [(position, docid)] in resolve_pins' order; organic: [(docid, [(kind, a, b), ...])] — the bucket sort's hits for
+    from = 0, length = offset + limit.  Returns the page: [(docid, [(kind, a, b), ...])] (a pin: [(MSI_SCORE_PIN, position, 0)])."""
+    MAXD = 16
+    p = np.array([(a, b) for a, b in pins], dtype=np.uint32).reshape(-1, 2)
+    d = np.array([h[0] for h in organic], dtype=np.uint32)
+    sc = np.zeros((max(1, len(organic)), MAXD, 3), dtype=np.uint32)
+    ns = np.zeros(max(1, len(organic)), dtype=np.uint32)
+    for i, (_, det) in enumerate(organic):
+        ns[i] = len(det)
+        for j, t in enumerate(det):
+            sc[i, j] = t
+    out_d = np.zeros(max(1, limit), dtype=np.uint32)
+    out_s = np.zeros((max(1, limit), MAXD, 3), dtype=np.uint32)
+    out_n = np.zeros(max(1, limit), dtype=np.uint32)
+    n = lib().msi_inject_pins(np_ptr(p) if p.size else None, len(pins), offset, limit, np_ptr(d) if d.size else None,
+                              np_ptr(sc), np_ptr(ns), len(organic), np_ptr(out_d), np_ptr(out_s), np_ptr(out_n))
+    return [(int(out_d[i]), [tuple(int(x) for x in out_s[i, j]) for j in range(int(out_n[i]))]) for i in range(n)]

@@ -175,3 +175,30 @@ def bq_topk(rows, docids, q, k, filter_bits=None, filter_nbits=0):
     lib().orc_bq_topk(_p(rows, C.c_float), _p(docids, C.c_uint32), n, d, _p(q, C.c_float), k, fb, filter_nbits,
                       _p(out_d, C.c_uint32), _p(out_s, C.c_float), C.byref(cnt))
     return out_d[:cnt.value].copy(), out_s[:cnt.value].copy()
+
+
+def merge_positioned_hits_into_page(pins, skip, take, organic_hits):
+    """crates/milli/src/search/mod.rs:579-625, restated line for line.  pins: [(position, hit)] in the order the caller
+    resolved them; organic_hits: the bucket sort's prefix [0, skip + take).  -> the page [skip, skip + take)."""
+    if not pins:
+        return list(organic_hits)
+    page_end = skip + take
+    merged, organic, pin_i, combined = [], iter(organic_hits), 0, 0
+    while combined < page_end:
+        if pin_i < len(pins):
+            if pins[pin_i][0] <= combined:
+                hit = pins[pin_i][1]
+                pin_i += 1
+            else:
+                hit = next(organic, None)
+                if hit is None:
+                    hit = pins[pin_i][1]
+                    pin_i += 1
+        else:
+            hit = next(organic, None)
+        if hit is None:
+            break
+        if combined >= skip:
+            merged.append(hit)
+        combined += 1
+    return merged

@@ -55,3 +55,47 @@ def test_product_never_imports_oracle():
                 assert "oracle" not in text.lower().replace("the oracle", "").replace("oracle/", "") or \
                     "import oracle" not in text and "from oracle" not in text, f
                 assert "from oracle" not in text and "import oracle" not in text, f
+
+
+def _header_arities():
+    """name -> number of parameters, from include/msi.h (comments stripped; function-pointer typedefs and members skipped)"""
+    src = open(os.path.join(ROOT, "include", "msi.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"^[ \t]*#[^\n]*$", "", src, flags=re.M)
+    out = {}
+    for m in re.finditer(r"\b(msi_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        args = " ".join(m.group(2).split())
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_rust_shim_declares_the_header():
+    """VERDICT r5 missing #6: rust/milli-msi/src/sys.rs is GENERATED from include/msi.h (tools/gen_rust_sys.py) and must be
+    current; independently of the generator, every function of the header is declared there with the same arity, every
+    struct with the same number of fields, and the ABI version constant agrees."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_sys.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rs = open(os.path.join(ROOT, "rust", "milli-msi", "src", "sys.rs")).read()
+    rs = re.sub(r"//[^\n]*", "", rs)
+    rust = {}
+    for m in re.finditer(r"pub fn (msi_\w+)\((.*?)\)\s*(?:->\s*[^;]+)?;", rs, flags=re.S):
+        args = " ".join(m.group(2).split())
+        rust[m.group(1)] = 0 if not args else args.count(":")
+    want = _header_arities()
+    assert sorted(want) == declared_symbols()
+    assert sorted(rust) == sorted(want), (sorted(set(want) - set(rust)), sorted(set(rust) - set(want)))
+    for name, n in want.items():
+        assert rust[name] == n, (name, rust[name], n)
+    assert re.search(r"pub const MSI_ABI_VERSION: i32 = 3;", rs)
+    # structs: same names, same field counts as the header's typedefs
+    hdr = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "msi.h")).read(), flags=re.S)
+    for m in re.finditer(r"typedef struct (\w+) \{(.*?)\} (\w+);", hdr, flags=re.S):
+        body = m.group(2)
+        n_fields = 0
+        for f in [x for x in body.split(";") if x.strip()]:
+            n_fields += 1 if "(" in f else f.count(",") + 1
+        rm = re.search(r"pub struct %s \{(.*?)\n\}" % m.group(3), rs, flags=re.S)
+        assert rm, m.group(3)
+        assert len(re.findall(r"^\s*pub \w+(?:#\w+)?:", rm.group(1), flags=re.M)) == n_fields, m.group(3)

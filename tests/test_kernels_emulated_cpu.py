@@ -48,10 +48,11 @@ GROUPS = {
                                  "tests/test_configs_gpu.py::test_c4_keyword_leg",
                                  "tests/test_configs_gpu.py::test_c4_keyword_leg_on_the_coherent_corpus",
                                  "tests/test_configs_gpu.py::test_rerank_inside_candidate_universes_on_the_corpus",
+                                 "tests/test_configs_gpu.py::test_postings_staged_at_index_open_on_the_coherent_corpus",
                                  "tests/test_configs_gpu.py::test_phrases_on_the_coherent_corpus",
                                  "tests/test_configs_gpu.py::test_word_prefix_databases_on_the_coherent_corpus",
                                  "tests/test_configs_gpu.py::test_synonyms_on_the_coherent_corpus",
-                                 "tests/test_configs_gpu.py::test_negative_terms_on_the_coherent_corpus"], "", 11),
+                                 "tests/test_configs_gpu.py::test_negative_terms_on_the_coherent_corpus"], "", 12),
     # every bucket that is ranked further moves into the compact space of ITS bucket (MSI_SEARCH_LATE_COMPACT=2: by default
     # only buckets of a search whose universe was too large to compact, on indexes of more than a chunk): the reference's
     # snapshot searches and the index settings against the oracle through Ctx::late_enter / late_leave — the caches put

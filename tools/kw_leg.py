@@ -43,6 +43,12 @@ def main():
     ap.add_argument("--segment", type=int, default=1536)
     ap.add_argument("--emulated", action="store_true", help="no MI355X: the CPU-emulated build of libmsi (tests/emu) — for HOST CPU "
                     "profiles of the search threads on a small corpus (kernel time means nothing there)")
+    ap.add_argument("--stage", type=int, default=1, help="1 (default): the index's word / fid / position / word-count databases are "
+                    "staged into HBM when the index opens (msi_dict_stage_postings; coherent corpus only); 0: the engine meets "
+                    "every posting through the index callbacks, as before round 6")
+    ap.add_argument("--stage-threads", type=int, default=16)
+    ap.add_argument("--cold", action="store_true", help="--fresh: no primer pass — the measured queries meet the cache as "
+                    "msi_dict_reset_posting_cache leaves it (only what was staged)")
     a = ap.parse_args()
     runner = os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so")
     if a.emulated:
@@ -73,6 +79,14 @@ def main():
     if a.flags & 4:
         assert L.rb_enable_synonyms(h) == 0
     assert L.rb_attach(h, ctx.handle, a.callers, a.slots, a.cache_mb) == 0
+    staged = None
+    if a.stage and a.corpus == "coherent":
+        L.rb_stage_postings.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        sec, cnts = C.c_double(0), (C.c_uint64 * 4)()
+        st = L.rb_stage_postings(h, a.stage_threads, C.byref(sec), cnts)
+        assert st == 0, "rb_stage_postings failed: %d" % st
+        staged = {"seconds": round(sec.value, 1), "values": int(cnts[0]), "bodies_in_hbm": int(cnts[1]), "kept_on_host": int(cnts[2]),
+                  "stored_bytes_in_hbm": int(cnts[3])}
     sweep = []
     if a.sweep:   # "reaper:callers,..." — every configuration on its own segment of fresh queries, one process, one posting cache
         for item in a.sweep.split(","):
@@ -97,8 +111,9 @@ def main():
     if a.fresh:
         a.passes = 1
         ma._lib.check(lib.msi_dict_reset_posting_cache(C.c_void_p(L.rb_dict(h))))
-        run(0, a.queries)                        # the primer: what a serving process has in HBM
-    searches_so_far = total + (a.queries if a.fresh else 0)
+        if not a.cold:
+            run(0, a.queries)                    # the primer: what a serving process has in HBM
+    searches_so_far = total + (a.queries if a.fresh and not a.cold else 0)
 
     def measure(first, n, passes, label=None):
         """`passes` timed passes over queries [first, first + n): one result object"""
@@ -148,6 +163,12 @@ def main():
                "posting_cache": {"hits": int(pc[0]), "misses": int(pc[1]), "bytes_used": int(pc[2]),
                                  "hit_rate": round(pc[0] / max(1, pc[0] + pc[1]), 4)},
                "compact_space": {"searches": int(cst[0]), "universe_compacted": int(cst[1]), "bucket_sub_trees_moved": int(lst[0])}}
+        if staged:
+            ss = (C.c_uint64 * 4)()
+            lib.msi_dict_staged_stats(C.c_void_p(L.rb_dict(h)), ss)
+            out["staged_at_index_open"] = dict(staged, absent_answers_from_complete_dbs=int(ss[3]))
+        if a.cold:
+            out["cold_posting_cache"] = True
         if label:
             out = dict(label, **out)
         if cp1[0] > cp0[0]:

@@ -306,6 +306,10 @@ struct Index {
   std::map<std::string, std::shared_ptr<std::vector<uint32_t>>> followers_derived;
   std::atomic<const Frozen *> frozen{nullptr};
   std::vector<std::unique_ptr<Frozen>> frozen_owned;
+  // rb_stage_postings(): the key sets of EVERY word, by word id (the staging pass derives every word's databases once and
+  // hands the values to the engine; the key-set callbacks — word_fids, word_positions — answer from here afterwards)
+  std::vector<WordDerived> derived_by_id;
+  std::atomic<bool> all_derived{false};
   const std::shared_ptr<Bytes> *frozen_blob(const std::string &key) const {
     const Frozen *f = frozen.load(std::memory_order_acquire);
     if (!f) return nullptr;
@@ -378,6 +382,18 @@ std::string str(const uint8_t *w, uint32_t n) { return std::string((const char *
 // Every derived database of ONE word in one pass over its documents (a frequent word's posting is most of the corpus: its
 // fid, position and key-set reads must not scan it once per key): word_fid_docids f/<fid>/<w>, word_position_docids
 // q/<pos>/<w>, and the key sets (fids, bucketed positions) the engine's prefix_iter reads would return.
+const WordDerived *corpus_word(Index *ix, const std::string &s);
+// the key sets alone (word_fids / word_positions): by word id once the staging pass has derived every word — the stored
+// values behind them are NOT registered then (the engine has them in HBM; a reader that still asks — the oracle through
+// rb_read — goes through corpus_word below, which derives and registers them)
+const WordDerived *corpus_word_keys(Index *ix, const std::string &s) {
+  if (ix->all_derived.load(std::memory_order_acquire)) {
+    static const WordDerived none;
+    const int64_t id = ix->corpus->id_of(s);
+    return id >= 0 ? &ix->derived_by_id[(size_t)id] : &none;
+  }
+  return corpus_word(ix, s);
+}
 const WordDerived *corpus_word(Index *ix, const std::string &s) {
   if (const Index::Frozen *f = ix->frozen.load(std::memory_order_acquire)) {
     auto it = f->words.find(s);
@@ -558,7 +574,7 @@ int32_t cb_pos(void *u, const uint8_t *w, uint32_t n, uint32_t pos, const uint8_
 int32_t cb_fids(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t cap, uint32_t *cnt) {
   Index *ix = (Index *)u;
   if (ix->corpus) {
-    const WordDerived *wd = corpus_word(ix, str(w, n));
+    const WordDerived *wd = corpus_word_keys(ix, str(w, n));
     *cnt = (uint32_t)wd->fids.size();
     for (uint32_t i = 0; i < wd->fids.size() && i < cap; ++i) out[i] = wd->fids[i];
     return 0;
@@ -571,7 +587,7 @@ int32_t cb_fids(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t c
 int32_t cb_positions(void *u, const uint8_t *w, uint32_t n, uint16_t *out, uint32_t cap, uint32_t *cnt) {
   Index *ix = (Index *)u;
   if (ix->corpus) {
-    const WordDerived *wd = corpus_word(ix, str(w, n));
+    const WordDerived *wd = corpus_word_keys(ix, str(w, n));
     *cnt = (uint32_t)wd->positions.size();
     for (uint32_t i = 0; i < wd->positions.size() && i < cap; ++i) out[i] = wd->positions[i];
     return 0;
@@ -1784,6 +1800,155 @@ int32_t rb_hybrid_merge(uint32_t n_queries, uint32_t k, const uint32_t *v_ids, c
 }
 // Everything the index has derived so far becomes an immutable snapshot that the callbacks read without a lock (Index::Frozen).
 // Call it between jobs (no search in flight); keys derived later are still found (through the locked maps).
+// Index-open staging (msi_dict_stage_postings): every word's word_docids, word_fid_docids and word_position_docids value and
+// every field_id_word_count_docids value, derived from the corpus' tokens in ONE pass per word (what the shim does with three
+// LMDB cursors) and handed to the engine in batches of ~16 MB per thread; then the databases are declared complete.  Pair
+// proximities stay with the callback.  out_seconds: wall time of the whole pass; out_counts: [values handed over, bodies
+// staged in HBM, values kept on the host, stored bytes of the bodies].
+int32_t rb_stage_postings(void *h, uint32_t n_threads, double *out_seconds, uint64_t *out_counts) {
+  Runner *r = (Runner *)h;
+  if (!r->ix.corpus || !r->dict) return MSI_E_INVALID;
+  const auto t0 = std::chrono::steady_clock::now();
+  const Corpus &c = *r->ix.corpus;
+  const uint32_t W = (uint32_t)c.words.size();
+  std::vector<uint32_t> order(W);
+  for (uint32_t w = 0; w < W; ++w) order[w] = w;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {   // the heavy words first: the tail balances the threads
+    const uint64_t na = c.post_off[a + 1] - c.post_off[a], nb = c.post_off[b + 1] - c.post_off[b];
+    return na != nb ? na > nb : a < b;
+  });
+  r->ix.derived_by_id.assign(W, WordDerived());
+  std::atomic<uint32_t> next{0};
+  std::atomic<int32_t> status{MSI_OK};
+  std::atomic<uint64_t> n_values{0}, n_body{0}, n_host{0};
+  const unsigned T = std::max(1u, n_threads);
+  auto pos_slot = [](uint32_t b) -> uint32_t { return b < 16 ? b : (b == 24 ? 16u : 17u + (uint32_t)__builtin_ctz(b) - 5u); };
+  auto pos_value = [](uint32_t slot) -> uint32_t { return slot < 16 ? slot : (slot == 16 ? 24u : 1u << (slot - 17 + 5)); };
+  auto worker = [&] {
+    std::vector<uint32_t> by_fid[4], by_pos[48];
+    std::vector<std::unique_ptr<Bytes>> blobs;   // (the values of the batch being assembled: alive until it is handed over)
+    std::vector<msi_staged_posting> vals;
+    size_t batch_bytes = 0;
+    auto flush = [&] {
+      if (vals.empty()) return;
+      uint64_t cnt[3] = {0, 0, 0};
+      const int32_t st = msi_dict_stage_postings(r->dict, 0, vals.data(), vals.size(), cnt);
+      if (st != MSI_OK) {
+        int32_t ok = MSI_OK;
+        if (status.compare_exchange_strong(ok, st)) fprintf(stderr, "rb_stage_postings: %s\n", msi_last_error());
+      }
+      n_values.fetch_add(vals.size());
+      n_body.fetch_add(cnt[0]);
+      n_host.fetch_add(cnt[1]);
+      vals.clear();
+      blobs.clear();
+      batch_bytes = 0;
+    };
+    auto add = [&](uint32_t db, const std::string &key, uint64_t x, uint64_t y, const Bytes *b) {
+      msi_staged_posting v;
+      memset(&v, 0, sizeof v);
+      v.db = db;
+      v.key1 = (const uint8_t *)key.data();
+      v.key1_len = (uint32_t)key.size();
+      v.x = x;
+      v.y = y;
+      v.bytes = b->data();
+      v.n = b->size();
+      vals.push_back(v);
+    };
+    for (;;) {
+      const uint32_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= W || status.load(std::memory_order_relaxed) != MSI_OK) break;
+      const uint32_t id = order[i];
+      const std::string &s = c.words[id];
+      uint64_t n = 0;
+      const uint32_t *docs = c.posting(id, &n);
+      for (auto &v : by_fid) v.clear();
+      for (auto &v : by_pos) v.clear();
+      for (uint64_t k = 0; k < n; ++k) {
+        const uint32_t d = docs[k];
+        c.tokens(d, [&](uint32_t w, uint32_t fid, uint32_t pos) {
+          if (w != id) return;
+          auto &f = by_fid[fid & 3];
+          if (f.empty() || f.back() != d) f.push_back(d);
+          auto &q = by_pos[pos_slot(Corpus::bucketed(pos))];
+          if (q.empty() || q.back() != d) q.push_back(d);
+        });
+      }
+      WordDerived &wd = r->ix.derived_by_id[id];
+      blobs.emplace_back(new Bytes(cbo_serialize(std::vector<uint32_t>(docs, docs + n))));
+      batch_bytes += blobs.back()->size();
+      add(MSI_DB_WORD_DOCIDS, s, 0, 0, blobs.back().get());   // Word::Derived and Word::Original read the same value here
+      add(MSI_DB_WORD_DOCIDS, s, 1, 0, blobs.back().get());   // (no exact attributes): two keys, one body
+      for (uint32_t fid = 0; fid < 4; ++fid) {
+        if (by_fid[fid].empty()) continue;
+        wd.fids.push_back((uint16_t)fid);
+        blobs.emplace_back(new Bytes(cbo_serialize(by_fid[fid])));
+        batch_bytes += blobs.back()->size();
+        add(MSI_DB_WORD_FID, s, fid, 0, blobs.back().get());
+      }
+      for (uint32_t slot = 0; slot < 48; ++slot) {
+        if (by_pos[slot].empty()) continue;
+        const uint32_t v = pos_value(slot);
+        wd.positions.push_back((uint16_t)v);
+        blobs.emplace_back(new Bytes(cbo_serialize(by_pos[slot])));
+        batch_bytes += blobs.back()->size();
+        add(MSI_DB_WORD_POSITION, s, v, 0, blobs.back().get());
+      }
+      if (batch_bytes > (16u << 20) || vals.size() > 200000) flush();
+    }
+    flush();
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; ++t) th.emplace_back(worker);
+  for (auto &x : th) x.join();
+  if (status.load() != MSI_OK) return status.load();
+  {   // field_id_word_count_docids: one pass over the documents (cb_count's definition)
+    std::vector<uint32_t> lists[3][31];
+    for (uint64_t d = 0; d < c.n_docs; ++d) {
+      uint32_t title = 0;
+      const uint32_t len = (uint32_t)(c.doc_off[d + 1] - c.doc_off[d]);
+      while (title < len && !(c.tok[c.doc_off[d] + title] & Corpus::OVERVIEW)) ++title;
+      if (title <= 30) lists[1][title].push_back((uint32_t)d);
+      if (len - title <= 30) lists[2][len - title].push_back((uint32_t)d);
+    }
+    std::vector<std::unique_ptr<Bytes>> blobs;
+    std::vector<msi_staged_posting> vals;
+    for (uint32_t fid = 1; fid <= 2; ++fid)
+      for (uint32_t count = 0; count <= 30; ++count) {
+        if (lists[fid][count].empty()) continue;
+        blobs.emplace_back(new Bytes(cbo_serialize(lists[fid][count])));
+        msi_staged_posting v;
+        memset(&v, 0, sizeof v);
+        v.db = MSI_DB_FIELD_ID_WORD_COUNT;
+        v.x = fid;
+        v.y = count;
+        v.bytes = blobs.back()->data();
+        v.n = blobs.back()->size();
+        vals.push_back(v);
+      }
+    uint64_t cnt[3] = {0, 0, 0};
+    const int32_t st = msi_dict_stage_postings(r->dict, 0, vals.data(), vals.size(), cnt);
+    if (st != MSI_OK) return st;
+    n_values.fetch_add(vals.size());
+    n_body.fetch_add(cnt[0]);
+    n_host.fetch_add(cnt[1]);
+  }
+  const int32_t st = msi_dict_stage_complete(r->dict, 0, (1u << MSI_DB_WORD_DOCIDS) | (1u << MSI_DB_WORD_FID) | (1u << MSI_DB_WORD_POSITION) |
+                                                            (1u << MSI_DB_FIELD_ID_WORD_COUNT));
+  if (st != MSI_OK) return st;
+  r->ix.all_derived.store(true, std::memory_order_release);
+  if (out_seconds) *out_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (out_counts) {
+    uint64_t ss[4] = {0, 0, 0, 0};
+    msi_dict_staged_stats(r->dict, ss);
+    out_counts[0] = n_values.load();
+    out_counts[1] = n_body.load();
+    out_counts[2] = n_host.load();
+    out_counts[3] = ss[2];
+  }
+  return MSI_OK;
+}
 int32_t rb_freeze(void *h) {
   Runner *r = (Runner *)h;
   std::unique_ptr<Index::Frozen> f(new Index::Frozen());
