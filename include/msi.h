@@ -76,8 +76,18 @@ int32_t msi_ctx_set_profiling(msi_ctx *ctx, int32_t enable);
  * sets GPU_MAX_HW_QUEUES=16 when it is LOADED (a library constructor: before the runtime's first call reads it)
  * unless the host process already chose a value or set MSI_KEEP_HW_QUEUES=1.  Below 16 the keyword leg measured less
  * than half its throughput; an integrator checks this once at start-up (nothing is written to stderr unasked:
- * MSI_VERBOSE=1 prints the warning). */
+ * MSI_VERBOSE=1 prints the warning).
+ * What the return value means: the number the ENVIRONMENT asks of the runtime.  It is what the runtime uses only if the
+ * runtime had not started when the variable was set — true for a process that links libmsi (the constructor runs before
+ * main) or sets the variable itself; NOT guaranteed for a process that dlopen()s libmsi after its first HIP call (another
+ * HIP user, torch used before the import): then the runtime keeps the value it started with.  msi_runtime_hw_queues_source
+ * says where the number comes from: 0 = the host's own setting (or MSI_KEEP_HW_QUEUES: the runtime's default 4 if unset),
+ * 1 = set by libmsi's constructor at load time (in effect only under the condition above).
+ * dlopen() from an already multi-threaded process: setenv is not thread-safe against concurrent getenv — such a host sets
+ * GPU_MAX_HW_QUEUES=16 in its own environment before it starts and MSI_KEEP_HW_QUEUES=1, and the constructor touches
+ * nothing. */
 int32_t msi_runtime_hw_queues(void);
+int32_t msi_runtime_hw_queues_source(void);
 
 /* ------------------------------------------------- S1: vector k-NN (cosine) */
 /*
@@ -181,10 +191,18 @@ int32_t msi_vs_set_microbatch(msi_vs *vs, uint32_t max_wait_us);
 int32_t msi_vs_microbatch_stats(msi_vs *vs, uint64_t *out_fused_calls,
                                 uint64_t *out_fused_sweeps);
 
-/* Device-pointer variant: all pointers are device memory, work is enqueued on
- * msi_ctx_stream() and NOT synchronised.  `d_inexact[n_queries]` (nullable)
- * receives 1 where the exactness proof failed and the host variant would have
- * re-run the query exhaustively (the caller must do so: msi_vs_search). */
+/* Device-pointer variant: all pointers are device memory.
+ * CONTRACT (since ABI 3, round 5): the call ALWAYS ANSWERS, as VectorStore::nns_by_vector does (store.rs:638-675) — the
+ * queries whose top-k the first sweep could not prove are gathered and re-run by the library, level by level and finally
+ * exhaustively, so on return every list is the exact one and `d_inexact[n_queries]` (nullable) reads 0 everywhere.  The
+ * price is ONE hipStreamSynchronize of msi_ctx_stream() inside every call (the proof flags have to be read): the call is
+ * not asynchronous — when it returns the outputs are complete on the stream (a re-run's copies may still be in flight:
+ * order later work on msi_ctx_stream() or msi_ctx_synchronize()).  A host that relied on the call returning before the
+ * sweeps ran must move its own work onto another thread / stream.
+ * MSI_VS_DEVICE_RERUN=0 in the environment restores the OLD contract for the whole process: work is only enqueued, nothing
+ * is synchronised, and `d_inexact` receives 1 where the exactness proof failed — the caller must re-run those queries
+ * (msi_vs_search).  MSI_VS_PIPELINE=1 (two-stream chunk pipeline, f32 contraction only) is honoured under the old contract
+ * only: it flags unproven queries, it does not re-run them. */
 int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries,
                              uint32_t n_queries, uint32_t k,
                              const uint64_t *d_filter_bits,

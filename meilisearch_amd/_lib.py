@@ -152,6 +152,7 @@ PROTOTYPES = {
     "msi_ctx_device": (_I32, [_VP]),
     "msi_ctx_set_profiling": (_I32, [_VP, _I32]),
     "msi_runtime_hw_queues": (_I32, []),
+    "msi_runtime_hw_queues_source": (_I32, []),
     "msi_vs_create": (_I32, [_VP, _U32, C.POINTER(_VP)]),
     "msi_vs_create_typed": (_I32, [_VP, _U32, _I32, C.POINTER(_VP)]),
     "msi_vs_destroy": (None, [_VP]),

@@ -72,8 +72,14 @@ struct AbortHook {
 // it when it is LOADED — before any HIP call of a process whose only HIP user it is (the Rust server), and before torch's
 // lazy initialisation in the test / bench processes.  A value the host already chose is left alone; MSI_KEEP_HW_QUEUES=1
 // keeps the library from touching the environment at all.  (not an environment note for the integrator.)
+// (setenv is not thread-safe against a concurrent getenv: a host that dlopen()s the library from a multi-threaded process
+// sets the variable itself and MSI_KEEP_HW_QUEUES=1 — include/msi.h at msi_runtime_hw_queues)
+static int g_hw_queues_source = 0;   // 1: the constructor below set the variable
 __attribute__((constructor(101))) static void msi_preset_hw_queues() {
-  if (!getenv("MSI_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+  if (!getenv("MSI_KEEP_HW_QUEUES") && !getenv("GPU_MAX_HW_QUEUES")) {
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    g_hw_queues_source = 1;
+  }
 }
 
 extern "C" {
@@ -83,6 +89,8 @@ int32_t msi_runtime_hw_queues(void) {
   const int v = hq ? atoi(hq) : 4;   // the runtime's default
   return v > 0 ? v : 4;
 }
+
+int32_t msi_runtime_hw_queues_source(void) { return g_hw_queues_source; }
 
 int32_t msi_abi_version(void) { return MSI_ABI_VERSION; }
 const char *msi_last_error(void) { return g_err; }

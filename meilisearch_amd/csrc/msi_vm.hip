@@ -208,6 +208,11 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
   const bool wide = ((rp->wide_mask >> phase) & 1u) != 0;       // a compact list's VM_DECODEC phase: chunks of the FULL space
   const uint32_t my_chunks = wide ? rp->wide_chunks : r.n_chunks;
   if (phase >= r.n_phases || chunk >= my_chunks) return;
+  // a waiter that gave up: its workgroup runs NO command (the wide phase's data is incomplete: nothing may be computed from
+  // it into pool slots or posting-cache entries that other searches share — ADVICE r5), it only hands in its ticket so
+  // that the list's last workgroup can publish the failure
+  __shared__ uint32_t s_abandon;
+  if (threadIdx.x == 0) s_abandon = 0;
   if (fused && launch_phase == 0 && phase == 1) {
     // the wide workgroups of this list were dispatched before this one (lower block indices): wait for their tickets
     // (bounded: a wait that outlasts MSI_VM_SPIN_LIMIT_TICKS marks the list failed — ADVICE r4)
@@ -219,9 +224,12 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
         MSI_SLEEP();
         if ((++spins & 1023u) == 0 && wall_clock64() - t_wait > MSI_VM_SPIN_LIMIT_TICKS) {
           __hip_atomic_store(const_cast<uint32_t *>(&rp->failed), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_abandon = 1;
           break;
         }
       }
+      // (a sibling workgroup's give-up counts too: the list is failed as a whole)
+      if (__hip_atomic_load(&rp->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) s_abandon = 1;
       u64 *const wprof = reinterpret_cast<u64 *>(((u64)arena[3] << 32) | arena[2]);
       if (wprof) {   // MSI_VM_PROFILE: how long the workgroups of fused lists wait for their wide phase
         atomicAdd(&wprof[24], wall_clock64() - t_wait);
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
     for (uint32_t i = tid; i < p_end - p_begin; i += VT) s_cmd[i] = arena[p_begin + i];
   __syncthreads();
   const uint32_t *const cmd = in_lds ? s_cmd : arena + p_begin;
+  const bool abandoned = s_abandon != 0;   // (written by thread 0 before the barrier above)
   uint32_t pcw = 0;                              // word index of the current command
 #define W(i) MSI_UNIFORM(cmd[pcw + (i)])
   const uint32_t chw = wide ? CHW : rp->chw;     // words per workgroup (RoundSub::chw)
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
         for (u64 gw = (u64)fwd + n_out + lane; gw < r.n_words; gw += 64) put1(&dst[gw], 0ull);
     }
   }
-  for (; !wide_done;) {
+  for (; !wide_done && !abandoned;) {
     const uint32_t op = W(0);
     if (op == VM_END) break;
     if (prof) {

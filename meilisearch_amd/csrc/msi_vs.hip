@@ -1650,6 +1650,7 @@ struct msi_vs {
   bool s16 = false;                // rows stored as bf16 (MSI_VS_BF16)
   // the int8 copy of the rows and its sweep (f32 stores; MSI_VS_I8=0: none) — level 0 of the search when present
   bool i8 = false;                 // the store keeps the copy
+  bool i8_dropped = false;         // ... it did, until its memory could not be had (finish_upload; msi_vs_stats::i8_bytes_per_tile reads 0 then)
   bool i8_now = false;             // the chunk being planned / enqueued sweeps it (set per sweep by the levels of effort)
   uint32_t KB8 = 0, nqt8_max = 1;  // KiB blocks per tile of the copy; query tiles per sweep over it
   DevBuf tiles8, scale8, i8small;  // [n_tiles][KB8][1 KiB] | s_x per row | {largest e_x of the store, as ordered bits}
@@ -1859,10 +1860,19 @@ int32_t finish_upload(msi_vs *vs, uint64_t n_rows, const char *what) {
                        vs->tiles.as<float4>(), (uint64_t)0, n_rows, vs->KB, vs->norm.as<float>(),
                        vs->inv_norm.as<float>());
   if (vs->i8) {
-    // the int8 copy follows the f32 rows (whole: an update re-gathers every tile anyway)
-    MSI_TRY(vs->tiles8.ensure(std::max<uint64_t>(1, n_tiles) * vs->KB8 * 64 * sizeof(i32x4)));
-    MSI_TRY(vs->scale8.ensure(std::max<uint64_t>(16, padded) * sizeof(float)));
-    MSI_TRY(vs->i8small.ensure(64));
+    // the int8 copy follows the f32 rows (whole: an update re-gathers every tile anyway).  It is an accelerator, not the
+    // store: when its memory cannot be had — an update holds two f32 copies at this point — the store goes on WITHOUT it
+    // (level 0 becomes the f32 contraction) instead of failing an upload / emptying a store that was serving
+    if (vs->tiles8.ensure(std::max<uint64_t>(1, n_tiles) * vs->KB8 * 64 * sizeof(i32x4)) != MSI_OK ||
+        vs->scale8.ensure(std::max<uint64_t>(16, padded) * sizeof(float)) != MSI_OK || vs->i8small.ensure(64) != MSI_OK) {
+      (void)hipGetLastError();   // (the failed allocation's sticky error)
+      vs->tiles8.release();
+      vs->scale8.release();
+      vs->i8 = false;
+      vs->i8_dropped = true;
+    }
+  }
+  if (vs->i8) {
     MSI_HIP_TRY(hipMemsetAsync(vs->i8small.p, 0, 64, st));
     if (n_tiles)
       hipLaunchKernelGGL(vs_quantize_rows_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, vs->tiles.as<float4>(),
@@ -2757,9 +2767,17 @@ int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries, uint32_t n_quer
   // CU's whole LDS, so the second stream's kernels wait for the sweep anyway (profiles/r4_vs_pipeline.txt)
   const char *pipe_knob = getenv("MSI_VS_PIPELINE");   // (read per call: tests switch it)
   const bool pipeline_on = pipe_knob && pipe_knob[0] == '1';
-  if (n_queries > vs->nqt_max * QT && pipeline_on)
-    return search_device_pipelined(vs, d_queries, n_queries, k, (const u64 *)d_filter_bits, filter_nbits, d_out_docids, d_out_dist,
-                                   d_out_counts, d_inexact);
+  // The pipeline answers as the OLD contract does — asynchronous, f32 contraction only, unproven queries merely flagged in
+  // d_inexact — so it is taken only when the caller asked for that contract (MSI_VS_DEVICE_RERUN=0): under the default
+  // contract ("every query is answered, d_inexact reads 0") a caller would otherwise be handed unproven lists it has been
+  // told it may trust.
+  {
+    const char *rr0 = getenv("MSI_VS_DEVICE_RERUN");
+    const bool old_contract = rr0 && rr0[0] == '0';
+    if (n_queries > vs->nqt_max * QT && pipeline_on && old_contract)
+      return search_device_pipelined(vs, d_queries, n_queries, k, (const u64 *)d_filter_bits, filter_nbits, d_out_docids, d_out_dist,
+                                     d_out_counts, d_inexact);
+  }
   // Levels of effort, as the host entry point runs them (vs_search_direct) — and since round 5 this entry point ALWAYS
   // ANSWERS too (store.rs:638-675 does): the first pass sweeps every chunk at the store's current level; the queries it
   // could not prove are gathered and re-run level by level, then exhaustively, by the library itself.  That costs one

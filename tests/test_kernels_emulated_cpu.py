@@ -21,7 +21,7 @@ NEEDS_TORCH_CUDA = ("row_sharded_search_with_device_merge or bits_as_vector_filt
 
 GROUPS = {
     # name: (files, -k expression, minimum number of tests that must have run)
-    "vector-scan": (["tests/test_vs_gpu.py", "tests/test_zzz_vs_update_gpu.py", "tests/test_zz_bq_gpu.py"],
+    "vector-scan": (["tests/test_vs_gpu.py", "tests/test_zzz_vs_update_gpu.py", "tests/test_zz_bq_gpu.py", "tests/test_zz_i8_proof_gpu.py"],
                     "not 70000 and not 40000 and not 20000 and not three_query_tiles and not large_scan and not large_k", 32),
     "dictionary": (["tests/test_dict_gpu.py", "tests/test_zz_fst_gpu.py"], "not synthetic_dictionary_all_paths", 12),
     "docid-sets": (["tests/test_bits_gpu.py", "tests/test_zz_order_keys_gpu.py::test_order_next_against_numpy",

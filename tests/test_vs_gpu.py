@@ -548,6 +548,9 @@ def test_device_entry_point_pipelines_its_chunks(ctx, oracle, filtered, monkeypa
     import ctypes as C
     from meilisearch_amd._lib import check, lib
     monkeypatch.setenv("MSI_VS_PIPELINE", "1")     # (off by default: it measured no gain — profiles/r4_vs_pipeline.txt)
+    # the pipeline reports unproven queries instead of re-running them: it is taken under the old contract only (ADVICE r5;
+    # include/msi.h at the prototype) — under the default contract the knob is ignored and the call answers every query itself
+    monkeypatch.setenv("MSI_VS_DEVICE_RERUN", "0")
     n, dim, k = 20000, 64, 10
     rows = synth.make_embeddings(n, dim, seed=77)
     rows[7000:7040] = rows[13]                                  # ties

@@ -1,0 +1,170 @@
+"""The int8 candidate sweep's exactness proof, attacked (VERDICT r5 weak #1b / next #5).
+
+Level 0 of an f32 store sweeps an int8 copy of its rows; its proof assumes |fast cos - reference cos| <= eps_q for EVERY row,
+eps_q = (e_x + e_q + e_x e_q) * 1.002 + eps_base (msi_vs.hip: vs_prep_queries_i8_kernel; e_x the store's largest row residual,
+e_q the query's own).  tests/test_vs_gpu.py checks that on random shapes; here the pairs are CONSTRUCTED to sit on the bound:
+
+  * residual of the row parallel to the query (Cauchy-Schwarz with equality): every component of the row a hair under a
+    half step above an even level, the query the matching +-1 pattern (quantised exactly) -> error ~ e_x;
+  * the mirrored construction for the query's residual -> error ~ e_q;  both at once -> error ~ e_x + e_q;
+  * components at +-127 (the clamp), one-hot x dense, dense x one-hot, rows scaled to 1e-18 / 1e+18 (the scale is per row
+    and relative: nothing may change), rows so small that their norm underflows (the degenerate-row rule answers);
+  * d = 64 (one pipeline stage per tile group) and d = 4096 (64 KiB of int8 per 16 rows, the largest accumulations).
+
+Every pair against an f64 cosine; the observed slack (worst error / bound) is printed and must show that the constructions
+do reach the bound (>= 0.5 of it) without crossing it.  Then a randomized differential run: the same rows in a store WITH
+the copy and in one created with MSI_VS_I8=0, >= 1e5 queries through msi_vs_search, docids and distance bits identical."""
+import os
+
+import numpy as np
+import pytest
+
+import meilisearch_amd as ma
+from meilisearch_amd import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _half_step_vector(d, rng, frac=0.499):
+    """u with u_0 = 127 s (the row's maximum, quantised exactly) and every other component (2 m + frac) s, m >= 0: rint() takes
+    each down to 2 m — a residual of +frac * s in EVERY component, all of one sign."""
+    m = rng.integers(0, 60, size=d).astype(np.float64)
+    u = 2.0 * m + frac
+    u[0] = 127.0
+    return u
+
+
+def _bound_check(ctx, dim, rows, queries, label, want_tight=None):
+    st = ma.GpuStore(ctx, dim)
+    n = rows.shape[0]
+    st.upload(np.arange(n, dtype=np.uint32), rows)
+    if not st.stats()["i8_bytes_per_tile"]:
+        pytest.skip("the store has no int8 copy (MSI_VS_I8=0)")
+    r64 = rows.astype(np.float64)
+    rn = np.linalg.norm(r64, axis=1)
+    worst = 0.0
+    for j in range(queries.shape[0]):           # one query per call: eps is THAT query's bound
+        q = queries[j:j + 1]
+        fast, eps = st.debug_fast_scores(q)
+        q64 = q[0].astype(np.float64)
+        qn = np.linalg.norm(q64)
+        ok = (rn > 0) & np.isfinite(fast[0]) & (np.abs(fast[0]) < 1e30)   # (degenerate rows carry the FLT_MAX sentinel: the rescoring decides)
+        ref = (r64[ok] @ q64) / (rn[ok] * qn)
+        got = fast[0][ok].astype(np.float64) / qn
+        err = float(np.abs(got - ref).max())
+        assert 0.0 < eps < 0.5, (label, j, eps)
+        assert err <= eps, (label, j, err, eps)
+        worst = max(worst, err / eps)
+    print(f"[int8 proof] {label}: d = {dim}, worst |fast - cos| / eps = {worst:.3f}")
+    if want_tight is not None:
+        assert worst >= want_tight, (label, worst, "the construction should come close to the bound")
+    return st
+
+
+@pytest.mark.parametrize("dim", [64, 4096])
+def test_pairs_constructed_on_the_bound(ctx, dim, monkeypatch):
+    monkeypatch.setenv("MSI_VS_DEBUG_I8", "1")
+    rng = np.random.default_rng(dim)
+    n = 64
+    # (1) the row's residual parallel to the query: rows on half steps, the query all ones (exact at 127 everywhere)
+    rows = np.stack([_half_step_vector(dim, rng) for _ in range(n)]).astype(f32)
+    ones = np.ones((1, dim), dtype=f32)
+    _bound_check(ctx, dim, rows, ones, "row residual || query", want_tight=0.5)
+    # (2) mirrored: the query on half steps, uniform rows (+ a few random ones so that the store's e_x is not zero)
+    rows2 = np.ones((n, dim), dtype=f32)
+    rows2[n // 2:] = rng.standard_normal((n - n // 2, dim)).astype(f32)
+    q2 = np.stack([_half_step_vector(dim, rng) for _ in range(4)]).astype(f32)
+    _bound_check(ctx, dim, rows2, q2, "query residual || row")
+    # (3) both at once, same pattern: the two first-order terms add up
+    pat = _half_step_vector(dim, rng)
+    rows3 = np.stack([pat * s for s in (1.0, 3.0, 1e-18, 1e18)] + [_half_step_vector(dim, rng) for _ in range(n - 4)]).astype(f32)
+    q3 = np.stack([pat, pat * 7.0]).astype(f32)
+    _bound_check(ctx, dim, rows3, q3, "both residuals aligned", want_tight=0.5)
+    # (4) alternating signs of the residual against a query of alternating signs (the same alignment through cancellation)
+    sgn = np.where(np.arange(dim) % 2 == 0, 1.0, -1.0)
+    rows4 = np.stack([_half_step_vector(dim, rng) * sgn for _ in range(n)]).astype(f32)
+    _bound_check(ctx, dim, rows4, (sgn[None, :]).astype(f32), "alternating residual", want_tight=0.5)
+
+
+@pytest.mark.parametrize("dim", [64, 4096])
+def test_clamps_one_hots_and_extreme_scales(ctx, dim, monkeypatch):
+    monkeypatch.setenv("MSI_VS_DEBUG_I8", "1")
+    rng = np.random.default_rng(dim + 1)
+    n = 96
+    rows = rng.standard_normal((n, dim)).astype(f32)
+    rows[0:8] = np.sign(rows[0:8])                              # every component at +-127
+    rows[8:16] = 0
+    rows[8:16, rng.integers(0, dim, 8)] = 1.0                   # one-hot (some rows may end up with one or two ones)
+    rows[16:24] *= f32(1e-18)                                   # tiny rows: norm^2 ~ 1e-36 * d, still a normal float
+    rows[24:32] *= f32(1e18)                                    # huge rows: norm^2 ~ 1e36 * d
+    rows[32:40] = np.abs(rows[32:40]) + f32(0.5)                # no cancellation, small dynamic range
+    rows[40:48, 0] = f32(1e6)                                   # one dominant coordinate: the coarsest grid a row can get
+    qs = rng.standard_normal((6, dim)).astype(f32)
+    qs[1] = 0
+    qs[1, 5] = 1.0                                              # one-hot query x dense rows
+    qs[2] = np.sign(qs[2])
+    qs[3] *= f32(1e-18)
+    qs[4] *= f32(1e18)
+    qs[5, 0] = f32(1e6)
+    _bound_check(ctx, dim, rows, qs, "clamps / one-hots / scales")
+
+
+def test_rows_whose_norm_underflows_and_the_search_around_them(ctx):
+    """Rows of magnitude 1e-25: their squared norm underflows to 0 in f32, the reference's distance is 0 by its pn*qn <= EPS
+    rule (arroy / hannoy's cosine), the int8 copy marks them unquantisable — they must come out FIRST, exactly as the oracle
+    orders them, at every level."""
+    from oracle import oracle as orc
+    dim, n = 64, 4000
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((n, dim)).astype(f32)
+    rows[100:105] *= f32(1e-25)
+    rows[200] = 0
+    ids = np.arange(n, dtype=np.uint32) * 3
+    st = ma.GpuStore(ctx, dim)
+    st.upload(ids, rows)
+    qs = rng.standard_normal((9, dim)).astype(f32)
+    d, s, c = st.search(qs, 20)
+    for j in range(qs.shape[0]):
+        e_ids, e_dist = orc.vs_topk(rows, ids, qs[j], 20)
+        assert d[j, :int(c[j])].tolist() == e_ids.tolist(), j
+        assert s[j, :int(c[j])].view(np.uint32).tolist() == e_dist.view(np.uint32).tolist(), j
+    assert set(d[0, :6].tolist()) == {300, 303, 306, 309, 312, 600}
+
+
+def test_differential_with_and_without_the_copy(ctx, monkeypatch):
+    """>= 1e5 random queries (heavy-tailed, clustered and plain mixed) through msi_vs_search on two stores of the same rows,
+    one with the int8 copy, one created with MSI_VS_I8=0: docids and the bits of every distance identical."""
+    emulated = bool(os.environ.get("MSI_RUNNER_SO"))
+    n, dim, k = (6000, 64, 10) if emulated else (200_000, 64, 20)
+    n_queries = 1536 if emulated else 102_400
+    rng = np.random.default_rng(2026)
+    rows = rng.standard_normal((n, dim)).astype(f32)
+    centres = rng.standard_normal((50, dim)).astype(f32)
+    m = n // 4
+    rows[:m] = centres[rng.integers(0, 50, m)] + f32(0.05) * rng.standard_normal((m, dim)).astype(f32)   # clusters: close calls
+    rows[m:m + 200] *= rng.lognormal(0, 3, size=(200, dim)).astype(f32)
+    ids = np.arange(n, dtype=np.uint32) * 2 + 1
+    st8 = ma.GpuStore(ctx, dim)
+    st8.upload(ids, rows)
+    if not st8.stats()["i8_bytes_per_tile"]:
+        pytest.skip("the store has no int8 copy (MSI_VS_I8=0)")
+    monkeypatch.setenv("MSI_VS_I8", "0")
+    st32 = ma.GpuStore(ctx, dim)
+    st32.upload(ids, rows)
+    monkeypatch.delenv("MSI_VS_I8")
+    assert st32.stats()["i8_bytes_per_tile"] == 0
+    step = 4096 if not emulated else 512
+    done = 0
+    while done < n_queries:
+        b = min(step, n_queries - done)
+        qs = rng.standard_normal((b, dim)).astype(f32)
+        qs[: b // 4] = rows[rng.integers(0, m, b // 4)] + f32(0.02) * rng.standard_normal((b // 4, dim)).astype(f32)
+        qs[b // 4: b // 4 + 16] *= rng.lognormal(0, 3, size=(16, dim)).astype(f32)
+        d8, s8, c8 = st8.search(qs, k)
+        d32, s32, c32 = st32.search(qs, k)
+        assert (c8 == c32).all()
+        assert (d8 == d32).all(), int(np.argwhere((d8 != d32).any(axis=1))[0, 0])
+        assert (s8.view(np.uint32) == s32.view(np.uint32)).all()
+        done += b
+    assert st8.stats()["i8_sweeps"] > 0 and st32.stats()["i8_sweeps"] == 0
