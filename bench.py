@@ -105,6 +105,10 @@ def parse_args():
                     "word_position_docids / field_id_word_count_docids are staged into the HBM posting cache when the index opens "
                     "(msi_dict_stage_postings: the north_star's 'staged once into HBM'); 0 = every posting reaches the engine "
                     "through the index callbacks on first use, as in rounds 1-5")
+    ap.add_argument("--kw-features", type=int, default=1, help="c4, coherent corpus: 1 (default) = after the timed steps, one more keyword "
+                    "leg on the same index with the features a real index has — word-prefix databases (one- to three-letter "
+                    "prefix queries such as workloads/search/movies.json's \"t\"), synonyms, quoted phrases, negative terms — "
+                    "on fresh queries, checked against the oracle: legs.keyword_with_features")
     ap.add_argument("--kw-stream", choices=["fresh", "cycle"], default="fresh",
                     help="c4: the keyword queries of the steps — fresh (default): no query is met twice, the posting cache holds what "
                          "4 x Q primer queries of the same generator left behind; cycle: round 4's stream (the 4 x Q primer queries cycled)")
@@ -1242,6 +1246,10 @@ def run_c4(args, env):
             par["keyword"] = kpar
             par["mismatches"] += kpar["mismatches"] + kbad
         out["parity"] = par
+    if kw is not None and args.kw_features and args.kw_corpus == "coherent" and not env.child and world == 1:
+        out["legs"]["keyword_with_features"] = keyword_features_leg(args, kw, Q, k, phase, n_total if row_sharded else n)
+        if out.get("parity") is not None and isinstance(out["legs"]["keyword_with_features"].get("parity"), dict):
+            out["parity"]["mismatches"] += out["legs"]["keyword_with_features"]["parity"]["mismatches"]
     if kw is not None:
         kw_qps = legs.get("keyword_only_queries_per_s") or 0.0
         kw["lib"].rb_destroy(kw["h"])      # the runner's pools go before the children / the other configurations start
@@ -1250,6 +1258,80 @@ def run_c4(args, env):
             # the keyword leg's kernel: HBM traffic and L2 counters per query, host CPU by where it is spent (children of this run)
             out["keyword_roofline"] = keyword_roofline(n, kw_threads, kw_qps, args.kw_dict_words, args.kw_corpus)
     return out
+
+
+def keyword_features_leg(args, kw, Q, k, phase, n_docs):
+    """the index shapes of a real index in a timed keyword stream.  The SAME index (runner handle, staged
+    postings, caller threads) gets what milli builds beside the word databases — word-prefix databases (prefixes of 1-4 bytes
+    that >= 50 dictionary words share: a prefix term whose word is such a key reads them instead of enumerating its
+    derivations, compute_derivations.rs:193-205) and synonyms — and a new query stream out of the same documents in which
+    every eighth query opens with a quoted phrase, three in 64 end in a one- to three-letter prefix (movies.json's "t"), every
+    eighth is a word or pair with synonyms and every eighth excludes a word or a phrase (rb_prepare_queries_ex flags 15).
+    Untimed: one pass in which the synthetic index derives the databases these queries read, the posting cache forgets what
+    searches left (the staged databases stay), a primer of Q queries.  Timed: 2 x Q queries the engine meets for the first
+    time.  Parity: the first `--parity-kw-queries` of them against oracle/ranking_oracle.py."""
+    import ctypes as C
+    import resource
+    import meilisearch_amd as ma
+    from oracle import parity
+    L, h = kw["lib"], kw["h"]
+    lib = ma._lib.lib()
+    phase("c4: keyword leg with index features (prefix databases, synonyms, phrases, negatives)")
+    L.rb_enable_prefix_dbs.argtypes = [C.c_void_p, C.c_uint32]
+    L.rb_enable_synonyms.argtypes = [C.c_void_p]
+    L.rb_prepare_queries_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+    assert L.rb_enable_prefix_dbs(h, 50) == 0 and L.rb_enable_synonyms(h) == 0
+    n_q = 3 * Q
+    assert L.rb_prepare_queries_ex(h, n_q, args.kw_terms, 5151, 15) == 0
+
+    def run(first, n):
+        assert L.rb_run(h, first, n, k, kw["ids"].ctypes.data, kw["n"].ctypes.data, kw["scores"].ctypes.data) == 0, \
+            "msi_keyword_search_ranked failed (features leg)"
+    t0 = time.perf_counter()
+    for first in range(0, n_q, Q):
+        run(first, Q)                              # untimed: the synthetic index derives what these queries read
+    derive_s = time.perf_counter() - t0
+    if hasattr(L, "rb_freeze"):
+        assert L.rb_freeze(h) == 0
+    ma._lib.check(lib.msi_dict_reset_posting_cache(C.c_void_p(L.rb_dict(h))))
+    run(0, Q)                                      # the primer
+    lib.msi_search_cpu_profile_enable(1)
+    cp0, cp1 = (C.c_uint64 * 8)(), (C.c_uint64 * 8)()
+    pc0, pc1 = (C.c_uint64 * 4)(), (C.c_uint64 * 4)()
+    lib.msi_search_cpu_profile(cp0)
+    lib.msi_dict_posting_cache_stats(C.c_void_p(L.rb_dict(h)), pc0)
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    t0 = time.perf_counter()
+    run(Q, Q)
+    run(2 * Q, Q)
+    dt = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    lib.msi_search_cpu_profile(cp1)
+    lib.msi_dict_posting_cache_stats(C.c_void_p(L.rb_dict(h)), pc1)
+    lib.msi_search_cpu_profile_enable(0)
+    m = max(1.0, float(cp1[0] - cp0[0]))
+    d = [(cp1[i] - cp0[i]) / 1e3 / m for i in range(8)]
+    res = {"queries_per_s": round(2 * Q / dt, 1), "timed_queries": 2 * Q, "fresh": True,
+           "host_cpus_used": round((ru1.ru_utime + ru1.ru_stime - ru0.ru_utime - ru0.ru_stime) / dt, 2),
+           "host_cpu_us_per_query": {"search_threads": round(d[1], 1), "index_callbacks": round(d[5], 1),
+                                     "index_callbacks_share": round(d[5] / max(1e-9, d[1]), 3),
+                                     "typo_derivations": round(d[4], 1), "list_submit_and_wait": round(d[2], 1)},
+           "lists_per_query": round((cp1[7] - cp0[7]) / m, 2),
+           "posting_cache_hit_rate": round((pc1[0] - pc0[0]) / max(1, (pc1[0] - pc0[0]) + (pc1[1] - pc0[1])), 4),
+           "index_derivation_seconds": round(derive_s, 1),
+           "stream": "rb_prepare_queries_ex flags 15: phrases, 1-3 letter prefixes over the word-prefix databases (threshold 50), "
+                     "synonyms, negative terms; callbacks of the prefix / synonym databases are the synthetic index's own "
+                     "(memoised scans: an LMDB read would be microseconds)"}
+    nk = min(args.parity_kw_queries, Q)
+    if not args.no_cpu_baseline and nk:
+        phase("c4: parity, keyword leg with features vs oracle")
+        kchk = parity.KeywordLegChecker(L, h, n_docs)
+        prod = kchk.run_product(Q, nk, k)
+        res["parity"] = kchk.verdict(Q, nk, k, product=prod)
+        qs_ = [kchk.index.query(Q + i) for i in range(nk)]
+        res["parity"]["queries_with_a_phrase"] = sum(1 for q in qs_ if '"' in q)
+        res["parity"]["queries_ending_in_a_short_prefix"] = sum(1 for q in qs_ if q.split() and len(q.split()[-1]) <= 3 and '"' not in q.split()[-1])
+    return res
 
 
 def also_configs(args, env):
@@ -1894,6 +1976,12 @@ def short_line(full, detail_path=None):
                       "keyword_host_cpu_ms_per_query"))
     if isinstance(legs.get("keyword_posting_cache"), dict):
         lg["keyword_posting_cache_hit_rate"] = legs["keyword_posting_cache"].get("hit_rate")
+    if isinstance(legs.get("keyword_with_features"), dict):
+        kf = legs["keyword_with_features"]
+        lg["keyword_with_features_queries_per_s"] = kf.get("queries_per_s")
+        lg["keyword_with_features_index_callbacks_share"] = (kf.get("host_cpu_us_per_query") or {}).get("index_callbacks_share")
+        if isinstance(kf.get("parity"), dict):
+            lg["keyword_with_features_parity"] = [kf["parity"].get("checked_queries"), kf["parity"].get("mismatches")]
     if isinstance(legs.get("keyword_postings_staged_at_index_open"), dict):
         lg["keyword_postings_staged_gb"] = round(legs["keyword_postings_staged_at_index_open"].get("stored_bytes_in_hbm", 0) / 1e9, 2)
     if lg:

@@ -958,6 +958,8 @@ int32_t msi_search_last_stats(uint64_t out[10]);
  * nanoseconds; a sleeping waiter costs none) of the keyword leg — [searches, whole searches, inside the command-list
  * submission + wait, of it finalising the list, typo derivations, index callbacks (wall), the combiner threads, lists]. */
 int32_t msi_search_cpu_profile(uint64_t out[8]);
+/* Switches that collection on / off while the process runs (the environment variable is read once, at the first search). */
+int32_t msi_search_cpu_profile_enable(int32_t on);
 /* Diagnostics, process-wide: [ranked keyword searches, of them continued in the COMPACT SPACE (once a search knows its
  * universe — the documents that match the query at all — every later set is kept over the ranks of the documents inside
  * it, |universe| bits instead of n_docs: DESIGN.md §4.7.2), documents of those universes summed]. */

@@ -274,6 +274,7 @@ PROTOTYPES = {
                                          C.POINTER(_U32), C.POINTER(_U64), C.POINTER(_I32)]),
     "msi_search_last_stats": (_I32, [C.POINTER(_U64)]),
     "msi_search_cpu_profile": (_I32, [C.POINTER(_U64)]),
+    "msi_search_cpu_profile_enable": (_I32, [_I32]),
     "msi_search_compaction_stats": (_I32, [C.POINTER(_U64)]),
     "msi_search_late_compaction_stats": (_I32, [C.POINTER(_U64)]),
     "msi_bits_vm_bytes": (_I32, [C.POINTER(_U64)]),

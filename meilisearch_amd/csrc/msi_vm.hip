@@ -2388,9 +2388,15 @@ extern "C" int32_t msi_bits_vm_bytes(uint64_t out[3]) {
 }
 
 static StripedCounters<8> g_cpu_prof;
+static std::atomic<int> g_cpu_prof_switch{-1};   // -1: the environment decides (MSI_SEARCH_CPU_PROFILE), 0 / 1: msi_search_cpu_profile_enable
 bool msi_cpu_prof_on() {
-  static const bool on = getenv("MSI_SEARCH_CPU_PROFILE") != nullptr;
-  return on;
+  static const bool env_on = getenv("MSI_SEARCH_CPU_PROFILE") != nullptr;
+  const int sw = g_cpu_prof_switch.load(std::memory_order_relaxed);
+  return sw < 0 ? env_on : sw != 0;
+}
+extern "C" int32_t msi_search_cpu_profile_enable(int32_t on) {
+  g_cpu_prof_switch.store(on ? 1 : 0, std::memory_order_relaxed);
+  return MSI_OK;
 }
 uint64_t msi_thread_cpu_ns() {
   struct timespec ts;

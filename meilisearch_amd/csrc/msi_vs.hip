@@ -1317,6 +1317,109 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_select_part_kernel(SelectArgs 
   for (uint32_t i = threadIdx.x; i < a.K; i += blockDim.x) out[i] = i < got ? sbuf[i] : ~0ull;
 }
 
+// ---- the sparse pass's threshold from two histogram passes (round 6) --------------------------------------------------
+// The threshold only has to be CONSERVATIVE: any value at or below the r-th best sampled score keeps the guarantee the
+// rank r was chosen for (a lower threshold can only add survivors).  So nothing is selected or sorted: the sampled scores
+// of a query are counted by the top 11 bits of their descending key (workgroups over slices of the row, LDS histograms
+// merged into a global one), the bin that holds rank r is picked, the scores of THAT bin are counted by the next 11 bits,
+// and the threshold is the smallest score of the 22-bit bucket that holds rank r — at most 2^-13 relative below the exact
+// one.  Four short launches that use the whole chip instead of one workgroup per query radix-selecting and sorting
+// (vs_select_kernel: 0.3-0.75 ms per 128-query chunk at C4 in round 5; in slices, with a sort per slice: 0.15-0.2 ms).
+struct ThrArgs {
+  const float *dense;            // [NQ_MAX][dstride]
+  uint32_t dstride;
+  const uint32_t *n_items_ptr;
+  uint32_t stride;
+  uint32_t rank;                 // r
+  uint32_t *hist;                // [2][NQ_MAX][2048]
+  uint32_t *pick;                // [NQ_MAX][2]: the level-0 bin, the rank still to find inside it
+  float *theta;                  // [NQ_MAX]
+};
+__device__ __forceinline__ uint32_t thr_inv(float s) { return ~f32_to_ord(s); }   // ascending = best score first (make_key_desc)
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void vs_thr_hist_kernel(ThrArgs a) {
+  __shared__ uint32_t h[2048];
+  const uint32_t p = blockIdx.x, P = gridDim.x, j = blockIdx.y, tid = threadIdx.x;
+  for (uint32_t i = tid; i < 2048; i += 256) h[i] = 0;
+  const uint32_t n_all = *a.n_items_ptr;
+  const uint32_t c = ((n_all + a.stride - 1) / a.stride) * 16;
+  const uint32_t lo = (uint32_t)((uint64_t)c * p / P), hi = (uint32_t)((uint64_t)c * (p + 1) / P);
+  const uint32_t b0 = LEVEL ? a.pick[j * 2] : 0u;
+  __syncthreads();
+  if (LEVEL && b0 == 0xFFFFFFFFu) return;   // fewer than r scores: the threshold is -inf already
+  const float *row = a.dense + (uint64_t)j * a.dstride;
+  for (uint32_t i0 = lo + tid; i0 < hi; i0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < hi ? row[i0 + u * 256] : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (v[u] == -INFINITY) continue;   // a disallowed row (or the tail)
+      const uint32_t k = thr_inv(v[u]);
+      if (LEVEL == 0) atomicAdd(&h[k >> 21], 1u);
+      else if ((k >> 21) == b0) atomicAdd(&h[(k >> 10) & 2047u], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t *g = a.hist + ((size_t)LEVEL * NQ_MAX + j) * 2048;
+  for (uint32_t i = tid; i < 2048; i += 256)
+    if (h[i]) atomicAdd(&g[i], h[i]);
+}
+
+// one workgroup per query: the bin of `hist` that holds rank r (LEVEL 0: -> pick) / the threshold (LEVEL 1)
+template <int LEVEL>
+__global__ __launch_bounds__(256) void vs_thr_pick_kernel(ThrArgs a) {
+  __shared__ uint32_t scan[512];
+  __shared__ uint32_t found[2];
+  const uint32_t j = blockIdx.x, tid = threadIdx.x;
+  const uint32_t *g = a.hist + ((size_t)LEVEL * NQ_MAX + j) * 2048;
+  const uint32_t b0 = LEVEL ? a.pick[j * 2] : 0u;
+  const uint32_t r = LEVEL ? a.pick[j * 2 + 1] : a.rank;
+  if (LEVEL && b0 == 0xFFFFFFFFu) {
+    if (tid == 0) a.theta[j] = -INFINITY;
+    return;
+  }
+  uint32_t loc[8], mine = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    loc[e] = g[tid * 8 + e];
+    mine += loc[e];
+  }
+  scan[tid] = mine;
+  if (tid == 0) found[0] = 0xFFFFFFFFu;
+  __syncthreads();
+  uint32_t src = 0;
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    const uint32_t v = scan[src + tid] + (tid >= d ? scan[src + tid - d] : 0u);
+    scan[(src ^ 256) + tid] = v;
+    src ^= 256;
+    __syncthreads();
+  }
+  const uint32_t incl = scan[src + tid], excl = incl - mine;
+  if (r >= 1 && excl < r && r <= incl) {   // exactly one thread
+    uint32_t cum = excl;
+    int e = 0;
+    for (; e < 7; ++e) {
+      if (cum + loc[e] >= r) break;
+      cum += loc[e];
+    }
+    found[0] = tid * 8 + e;
+    found[1] = r - cum;   // rank inside the bin (>= 1)
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (LEVEL == 0) {
+      a.pick[j * 2] = found[0];   // 0xFFFFFFFF: fewer than r scores in the sample
+      a.pick[j * 2 + 1] = found[0] == 0xFFFFFFFFu ? 0u : found[1];
+    } else {
+      // the smallest score of the 22-bit bucket: every score of the bucket (the r-th best among them) passes !(s < theta)
+      const uint32_t inv = found[0] == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((b0 << 21) | (found[0] << 10) | 0x3FFu);
+      a.theta[j] = found[0] == 0xFFFFFFFFu ? -INFINITY : ord_to_f32(~inv);
+    }
+  }
+}
+
 // --------------------------------------------------------------------- rescore
 
 // Reference arithmetic for one (row, query) pair from the tiled layout:
@@ -1413,7 +1516,7 @@ struct RescoreArgs {
   uint32_t *inexact;       // [nq]
   const uint32_t *overflow;
   const float *theta;      // nullable: thresholds the sparse pass ran with
-  u64 *pre_keys;           // nullable [NQ_MAX][KP_MAX]: distances computed by vs_rescore_dots_kernel (large K')
+  float *refined;          // nullable [NQ_MAX][KP_MAX]: the candidates' refined cosines (vs_refine_kernel); -inf: cannot matter
 };
 
 // Which of the K' selected candidates need the reference arithmetic at all.  They arrive ordered by fast score; at least k
@@ -1435,74 +1538,160 @@ __device__ __forceinline__ bool candidate_matters(const RescoreArgs &a, uint32_t
   return !(ci < ck - 2.0f * eps - 1e-6f);   // (1e-6: a strictly larger distance, never a tie that the docid would decide; NaN: keep)
 }
 
-// Large K' (k in the hundreds: the rerank pool of BASELINE config 5): the reference-arithmetic dot products are
-// the expensive part and one workgroup per query leaves the chip idle, so they get their own launch with one
-// thread per (query, candidate); vs_rescore_kernel then only sorts, emits and proves.
-__global__ __launch_bounds__(SEL_THREADS) void vs_rescore_dots_kernel(RescoreArgs a) {
+// ---- second opinion on the candidates (round 6) ---------------------------------------------------------------------
+// The int8 sweep's bound is wide (eps ~ 1.8e-2 in cosine): at 10 M rows EVERY one of the K' = 1 024 selected candidates
+// lies within 2 eps of the 20th, so round 5 ran the reference's sequential dot product — one dependent chain of 768
+// additions over a row whose 16-byte pieces lie 256 B apart — for all 131 072 (candidate, query) pairs of a chunk: 0.51 ms of
+// a 2.6 ms chunk, whatever the access pattern (one thread per row: 64 tiles per wave-load; 16 lanes per row with the
+// products in LDS: too few chains in flight — both measured, profiles/r6_vector_leg_c4_kernel_stats*.csv).
+// Now the candidates first get a PARALLEL f32 dot product (16 lanes share a row: its pieces side by side, partial sums,
+// a shuffle tree): the same rounded products as the reference adds, in another order, so
+//     |refined cos - reference cos| <= eps32 = (2 dpad + 64) u + 1e-6          (two orders of summing the same terms)
+// and the reference arithmetic is only run for the candidates whose refined cosine lies within 2 eps32 of the k-th best
+// refined cosine (k of them have a reference cosine >= that - eps32; anything below by more than 2 eps32 + 1e-6 has a
+// strictly larger distance than k candidates) — a few dozen per query instead of 1 024.  Degenerate rows (distance 0 by the
+// reference's pn*qn <= EPS rule) and NaNs always go to the reference arithmetic.  Every returned distance is still the
+// reference's; the proof about UNSELECTED rows (vs_rescore_kernel's epilogue) is untouched.
+constexpr uint32_t RD_WGS_PER_QUERY = 8;
+__device__ __forceinline__ float refine_eps(uint32_t dpad) { return (2.0f * (float)dpad + 64.0f) * 5.9604645e-8f * 1.01f + 1e-6f; }
+
+__global__ __launch_bounds__(SEL_THREADS) void vs_refine_kernel(RescoreArgs a) {
   MSI_DYNAMIC_LDS(dyn);
-  float *qs = reinterpret_cast<float *>(dyn);  // [dpad]
-  const uint32_t j = blockIdx.y;
   const uint32_t dpad = a.dpad;
+  float *qs = reinterpret_cast<float *>(dyn);          // [dpad]
+  __shared__ uint32_t s_last;
+  const uint32_t j = blockIdx.y, tid = threadIdx.x;
   const uint32_t cnt = a.sel_cnt[j];
-  if (blockIdx.x * blockDim.x >= cnt) return;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool matters = i < cnt && candidate_matters(a, j, i, cnt);
-  if (i < cnt && !matters) a.pre_keys[(uint64_t)j * KP_MAX + i] = ~0ull;   // (sorts behind every rescored candidate)
-  // (the candidates arrive ordered by fast score: the ones that matter are a prefix, most workgroups of a query have none)
-  __shared__ uint32_t s_any;
-  if (threadIdx.x == 0) s_any = 0;
+  if (tid == 0) s_last = 0;
+  for (uint32_t i = tid; i < dpad; i += blockDim.x) qs[i] = a.qrow[(uint64_t)j * dpad + i];
   __syncthreads();
-  if (matters) s_any = 1;
+  {   // the candidates that matter by the SWEEP's bound (ordered by fast score: a prefix); the others can never matter
+    uint32_t last = 0;
+    for (uint32_t i = tid; i < cnt; i += blockDim.x) {
+      if (candidate_matters(a, j, i, cnt)) last = i + 1;
+      else if (blockIdx.x == 0) a.refined[(uint64_t)j * KP_MAX + i] = -INFINITY;
+    }
+    if (last) atomicMax(&s_last, last);
+  }
   __syncthreads();
-  if (!s_any) return;
-  for (uint32_t i2 = threadIdx.x; i2 < dpad; i2 += blockDim.x) qs[i2] = a.qrow[(uint64_t)j * dpad + i2];
-  __syncthreads();
-  if (!matters) return;
-  const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
-  const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
-  const float d = canonical_distance(pq, a.norm[row], a.qn[j]);
-  a.pre_keys[(uint64_t)j * KP_MAX + i] = ((u64)f32_to_ord(d) << 32) | row;
+  const uint32_t m = s_last;
+  const uint32_t grp = tid >> 4, l16 = tid & 15;
+  const float qn = a.qn[j];
+  const bool s16 = a.s16 != 0;
+  const uint32_t pieces = a.KB * 4;                    // 16-byte pieces of a row
+  for (uint32_t i0 = blockIdx.x * 16; i0 < m; i0 += gridDim.x * 16) {   // (uniform trip count: the shuffles below see whole waves)
+    const uint32_t i = i0 + grp;
+    const bool active = i < m && candidate_matters(a, j, i, cnt);
+    const uint32_t row = active ? (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i] : 0u;
+    float part = 0.f;
+    if (!active) {
+    } else if (s16) {
+      const bf16x8 *base = reinterpret_cast<const bf16x8 *>(a.tiles) + (uint64_t)(row >> 4) * a.KB * 64 + (row & 15);
+      for (uint32_t p0 = l16; p0 < pieces; p0 += 16 * 4) {
+        bf16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t p = p0 + u * 16;
+          if (p < pieces) v[u] = base[(uint64_t)(p >> 2) * 64 + (p & 3) * 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t p = p0 + u * 16;
+          if (p >= pieces) continue;
+          const uint32_t col = (p >> 2) * 32 + (p & 3) * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) part = __fadd_rn(part, __fmul_rn((float)v[u][e], qs[col + e]));
+        }
+      }
+    } else {
+      const float4 *base = reinterpret_cast<const float4 *>(a.tiles) + (uint64_t)(row >> 4) * a.KB * 64 + (row & 15);
+      for (uint32_t p0 = l16; p0 < pieces; p0 += 16 * 6) {
+        float4 v[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const uint32_t p = p0 + u * 16;
+          if (p < pieces) v[u] = base[(uint64_t)(p >> 2) * 64 + (p & 3) * 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const uint32_t p = p0 + u * 16;
+          if (p >= pieces) continue;
+          const uint32_t col = (p >> 2) * 16 + (p & 3) * 4;
+          part = __fadd_rn(part, __fmul_rn(v[u].x, qs[col]));
+          part = __fadd_rn(part, __fmul_rn(v[u].y, qs[col + 1]));
+          part = __fadd_rn(part, __fmul_rn(v[u].z, qs[col + 2]));
+          part = __fadd_rn(part, __fmul_rn(v[u].w, qs[col + 3]));
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) part = __fadd_rn(part, __shfl_xor(part, o));   // (o < 16: inside the group)
+    if (active && l16 == 0) {
+      const float pnqn = __fmul_rn(a.norm[row], qn);
+      float c = INFINITY;                                // degenerate (distance 0 by definition): always to the reference arithmetic
+      if (pnqn > FLT_EPSILON) c = msi_div_rn(part, pnqn);
+      if (!(c == c)) c = INFINITY;                       // NaN: likewise
+      a.refined[(uint64_t)j * KP_MAX + i] = c;
+    }
+  }
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void vs_rescore_kernel(RescoreArgs a) {
   MSI_DYNAMIC_LDS(dyn);
-  u64 *sbuf = reinterpret_cast<u64 *>(dyn);                          // [KP_MAX]
-  float *qs = reinterpret_cast<float *>(dyn + KP_MAX * sizeof(u64)); // [dpad]
+  u64 *sbuf = reinterpret_cast<u64 *>(dyn);                              // [KP_MAX]: candidates by refined cosine
+  u64 *sbuf2 = sbuf + KP_MAX;                                            // [KP_MAX]: the rescored ones by reference distance
+  float *qs = reinterpret_cast<float *>(dyn + 2 * KP_MAX * sizeof(u64)); // [dpad]
+  __shared__ uint32_t s_last;
   const uint32_t j = blockIdx.x;
   const uint32_t dpad = a.dpad;
   for (uint32_t i = threadIdx.x; i < dpad; i += blockDim.x) qs[i] = a.qrow[(uint64_t)j * dpad + i];
   const uint32_t cnt = a.sel_cnt[j];
-  // Only the candidates that matter are sorted: the others carry the sentinel key, and — ordered by fast score as the
-  // candidates are — they follow the last one that matters (K' = 1 024 with ~200 that matter: a sort of 256 keys, not 1 024)
-  __shared__ uint32_t s_last;
   if (threadIdx.x == 0) s_last = 0;
+  // (1) the candidates ordered by refined cosine, best first (ties: by position = by fast score)
+  const uint32_t n1 = next_pow2(cnt < 2 ? 2 : cnt);
+  for (uint32_t i = threadIdx.x; i < n1; i += blockDim.x) {
+    u64 key = ~0ull;
+    if (i < cnt) {
+      float c = a.refined ? a.refined[(uint64_t)j * KP_MAX + i] : INFINITY;   // (no refinement: everything is rescored)
+      if (c == INFINITY) c = FLT_MAX;
+      key = make_key_desc(c, i);
+    }
+    sbuf[i] = key;
+  }
   __syncthreads();
+  block_bitonic_sort(sbuf, n1);
+  // (2) which of them need the reference arithmetic: a prefix of that order
   {
+    const float eps2 = 2.0f * refine_eps(dpad) + 1e-6f;
+    float tau = cnt >= a.k && a.k > 0 ? key_desc_score(sbuf[a.k - 1]) : -INFINITY;
+    // a degenerate / NaN candidate in front obeys no bound on its reference cosine: then nothing is pruned
+    if (cnt && !(fabsf(key_desc_score(sbuf[0])) < 1e30f)) tau = -INFINITY;
     uint32_t last = 0;
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x)
-      if (a.pre_keys ? a.pre_keys[(uint64_t)j * KP_MAX + i] != ~0ull : candidate_matters(a, j, i, cnt)) last = i + 1;
+    for (uint32_t p = threadIdx.x; p < cnt; p += blockDim.x) {
+      const float c = key_desc_score(sbuf[p]);
+      if (c == -INFINITY) continue;                        // outside the sweep's own window (vs_refine_kernel)
+      if (p < a.k || tau == -INFINITY || !(c < tau - eps2)) last = p + 1;
+    }
     if (last) atomicMax(&s_last, last);
   }
   __syncthreads();
   const uint32_t m = s_last;
   const uint32_t n = next_pow2(m < 2 ? 2 : m);
   const float qn = a.qn[j];
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+  for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) {
     u64 key = ~0ull;
-    if (i < m) {
-      if (a.pre_keys) {
-        key = a.pre_keys[(uint64_t)j * KP_MAX + i];
-      } else if (candidate_matters(a, j, i, cnt)) {
-        const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
-        const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
-        const float d = canonical_distance(pq, a.norm[row], qn);
-        key = ((u64)f32_to_ord(d) << 32) | row;  // rows ascend with docids
-      }
+    if (p < m && key_desc_score(sbuf[p]) != -INFINITY) {
+      const uint32_t i = (uint32_t)sbuf[p];
+      const uint32_t row = (uint32_t)a.sel_keys[(uint64_t)j * KP_MAX + i];
+      const float pq = canonical_dot(a.tiles, a.KB, row, qs, dpad, a.s16 != 0);
+      const float d = canonical_distance(pq, a.norm[row], qn);
+      key = ((u64)f32_to_ord(d) << 32) | row;  // rows ascend with docids
     }
-    sbuf[i] = key;
+    sbuf2[p] = key;
   }
   __syncthreads();
-  block_bitonic_sort(sbuf, n);
+  block_bitonic_sort(sbuf2, n);
+  sbuf = sbuf2;
   const uint32_t out_n = cnt < a.k ? cnt : a.k;
   for (uint32_t i = threadIdx.x; i < a.k; i += blockDim.x) {
     uint32_t id = 0xFFFFFFFFu;
@@ -1661,7 +1850,7 @@ struct msi_vs {
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
   // scratch (guarded by ctx->mu)
   DevBuf qraw, qfrag, qfrag_bf, qfrag8, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fsmall, fbits, out_docids,
-      out_dist, exh_keys, rowtmp, resc_keys, rerun_q, rerun_flags;
+      out_dist, exh_keys, rowtmp, resc_keys, rerun_q, rerun_flags, thr;
   // the second scratch set and stream of the device entry point's pipeline (msi_vs_search_device): allocated on first use
   struct Scratch2 {
     DevBuf qfrag, qfrag_bf, qfrag8, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, resc_keys;
@@ -2198,11 +2387,14 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
   ra.inexact = d_inexact;
   ra.overflow = s.overflow;
   ra.theta = stride == 1 ? nullptr : s.theta;
-  ra.pre_keys = nullptr;
-  if (k > 0 && kp > 2 * SEL_THREADS) {
+  // (MSI_VS_REFINE=0: every candidate inside the sweep's window goes to the reference arithmetic, as in round 5)
+  static const bool refine_off = getenv("MSI_VS_REFINE") && getenv("MSI_VS_REFINE")[0] == '0';
+  ra.refined = nullptr;
+  if (k > 0 && !refine_off) {
     MSI_TRY(vs->resc_keys.ensure((size_t)NQ_MAX * KP_MAX * sizeof(u64)));
-    ra.pre_keys = vs->resc_keys.as<u64>();
+    ra.refined = vs->resc_keys.as<float>();
   }
+  MSI_TRY(vs->thr.ensure(((size_t)2 * NQ_MAX * 2048 + (size_t)NQ_MAX * 2) * sizeof(uint32_t)));
   return MSI_OK;
 }
 
@@ -2228,6 +2420,31 @@ int32_t chunk_pre(msi_vs *vs, Chunk &c, hipStream_t st) {
     c.se.mode = 0;
     // a large sample is selected from in slices, by the whole chip (vs_select_part_kernel); MSI_VS_SELECT_PARTS=0: one
     // workgroup per query as before
+    // MSI_VS_THRESHOLD=select: the exact r-th best sampled score (round 5's selection; in slices when the sample is large);
+    // default: the conservative threshold of two histogram passes (vs_thr_hist_kernel)
+    static const bool thr_select = getenv("MSI_VS_THRESHOLD") && !strcmp(getenv("MSI_VS_THRESHOLD"), "select");
+    if (!thr_select) {
+      ThrArgs ta;
+      ta.dense = c.se.dense;
+      ta.dstride = c.se.dstride;
+      ta.n_items_ptr = c.se.n_items_ptr;
+      ta.stride = c.se.stride;
+      ta.rank = c.thr_rank;
+      ta.hist = vs->thr.as<uint32_t>();
+      ta.pick = ta.hist + (size_t)2 * NQ_MAX * 2048;
+      ta.theta = c.se.theta;
+      MSI_HIP_TRY(hipMemsetAsync(ta.hist, 0, (size_t)2 * NQ_MAX * 2048 * sizeof(uint32_t), st));
+      // slices so that ~1 000 workgroups share the pass (one workgroup per query left half the chip idle)
+      const uint32_t nqp = c.nqt * QT;
+      const uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(64, (1024 + nqp - 1) / nqp));
+      hipLaunchKernelGGL(vs_thr_hist_kernel<0>, dim3(slices, nqp), dim3(256), 0, st, ta);
+      hipLaunchKernelGGL(vs_thr_pick_kernel<0>, dim3(nqp), dim3(256), 0, st, ta);
+      hipLaunchKernelGGL(vs_thr_hist_kernel<1>, dim3(slices, nqp), dim3(256), 0, st, ta);
+      hipLaunchKernelGGL(vs_thr_pick_kernel<1>, dim3(nqp), dim3(256), 0, st, ta);
+      MSI_HIP_TRY(hipMemsetAsync(c.gcnt, 0, (size_t)NQ_MAX * CNT_PAD * sizeof(uint32_t), st));
+      MSI_HIP_TRY(hipGetLastError());
+      return MSI_OK;
+    }
     static const int parts_knob = getenv("MSI_VS_SELECT_PARTS") ? atoi(getenv("MSI_VS_SELECT_PARTS")) : -1;
     uint32_t parts = parts_knob >= 0 ? (uint32_t)parts_knob : 32u;
     parts = std::min<uint32_t>(parts, KP_MAX / std::max<uint32_t>(1, c.thr_rank));
@@ -2281,12 +2498,11 @@ int32_t chunk_post(msi_vs *vs, Chunk &c, hipStream_t st) {
   c.se.K = c.kp;
   c.se.mode = 1;
   hipLaunchKernelGGL(vs_select_kernel, dim3(c.nq), dim3(SEL_THREADS), 0, st, c.se);
-  if (c.ra.pre_keys)
-    hipLaunchKernelGGL(vs_rescore_dots_kernel, dim3((c.kp + SEL_THREADS - 1) / SEL_THREADS, c.nq), dim3(SEL_THREADS),
-                       (size_t)vs->dpad * sizeof(float), st, c.ra);
+  if (c.ra.refined)
+    hipLaunchKernelGGL(vs_refine_kernel, dim3(RD_WGS_PER_QUERY, c.nq), dim3(SEL_THREADS), (size_t)vs->dpad * sizeof(float), st, c.ra);
   if (c.k > 0)
     hipLaunchKernelGGL(vs_rescore_kernel, dim3(c.nq), dim3(SEL_THREADS),
-                       KP_MAX * sizeof(u64) + (size_t)vs->dpad * sizeof(float), st, c.ra);
+                       2 * KP_MAX * sizeof(u64) + (size_t)vs->dpad * sizeof(float), st, c.ra);
   MSI_HIP_TRY(hipGetLastError());
   return MSI_OK;
 }

@@ -1,0 +1,21 @@
+# Round 6, fourth device call: the vector leg with the histogram threshold and the cooperative rescoring — device tests,
+# kernel traces at C4's and C2's shapes, the C2 and C5 lines
+set -x
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+cd $R
+timeout 1500 python -m pytest -x -q -m gpu tests/test_vs_gpu.py tests/test_zz_i8_proof_gpu.py tests/test_zzz_vs_update_gpu.py "tests/test_configs_gpu.py::test_c4_10m_x_768_top20" "tests/test_configs_gpu.py::test_c2_1m_x_384_top20" "tests/test_configs_gpu.py::test_c2_with_10pct_filter" "tests/test_configs_gpu.py::test_c5_shard_bf16_filtered_k1000" -s 2>&1 | grep -a "int8 proof\|passed\|failed\|Error\|error" | tail -25 > gpurun_out/r6_fourth_tests.log
+cat gpurun_out/r6_fourth_tests.log
+cd /tmp && export TMPDIR=/tmp
+for shape in "c4 10000000 768 768" "c2 1000000 384 256"; do
+  set -- $shape
+  rm -rf /tmp/tr_$1
+  N_ROWS=$2 DIM=$3 Q=$4 VARIANTS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_$1 -o tr -- python $R/tools/probes/r5_i8_variants.py > /tmp/tr_$1.log 2>&1
+  F=$(find /tmp/tr_$1 -name "*kernel_stats.csv" | head -1)
+  [ -n "$F" ] && cp $F $R/gpurun_out/r6_vector_leg_$1_kernel_stats_b.csv && head -16 $F | cut -c1-200
+  grep -a -v amdgpu.ids /tmp/tr_$1.log | tail -3 | tee -a $R/gpurun_out/r6_vector_leg_lines.log
+done
+cd $R
+for cfg in c2 c5; do
+  timeout 600 python bench.py --config $cfg --no-pmc 2>/dev/null | tail -1 | cut -c1-1800 | tee gpurun_out/r6_bench_$cfg.json
+done
