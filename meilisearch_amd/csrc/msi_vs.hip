@@ -66,6 +66,22 @@ __device__ inline i32x4 vs_stream_load_i8(const i32x4 *p) {
 #endif
 }
 
+// Where the 16-byte piece (row i of the tile, column group g) of a KiB block of the f32 / bf16 ROW tiles lives, in pieces.
+// Rounds 1-5: g * 16 + i — the lane order of the MFMA A operand, so the sweep's lane l read piece l.  Round 6: i * 4 + g —
+// a row's four pieces of a block are one 64-byte sector.  The sweep's wave still reads the same contiguous KiB (lane l reads
+// piece MSI_TILE_PIECE(l & 15, l >> 4): a permutation inside the block), but everything that reads ONE row — the second
+// opinion on the candidates, the reference rescoring, the exhaustive pass, get_vector — now touches a quarter of the
+// sectors: 3 KB per 768-float row instead of 12.  MSI_VS_TILE_ROW_SECTORS=0 at build time: the old order
+// (A/B measurements).  The int8 copy and the queries' fragments keep the operand order.
+#ifndef MSI_VS_TILE_ROW_SECTORS
+#define MSI_VS_TILE_ROW_SECTORS 1
+#endif
+#if MSI_VS_TILE_ROW_SECTORS
+#define MSI_TILE_PIECE(i, g) ((i) * 4u + (g))
+#else
+#define MSI_TILE_PIECE(i, g) ((g) * 16u + (i))
+#endif
+
 namespace {
 
 constexpr int SCAN_WAVES = 8;            // waves per workgroup (512 threads)
@@ -111,7 +127,7 @@ __global__ void vs_tile_rows_kernel(const float *__restrict__ rows, uint64_t row
     for (int j = 0; j < 4; ++j)
       if (k0 + j < dim) v[j] = src[k0 + j];
   }
-  tiles[(row0 / 16) * KB * 64 + idx] = make_float4(v[0], v[1], v[2], v[3]);
+  tiles[(row0 / 16) * KB * 64 + blk * 64 + MSI_TILE_PIECE(i, g)] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // bf16 store: row-major f32 chunk -> bf16 (round to nearest even) tiles.  Block (t,kb)
@@ -137,7 +153,7 @@ __global__ void vs_tile_rows_bf16_kernel(const float *__restrict__ rows, uint64_
     if (r < n_chunk && k0 + j < dim) x = rows[r * (uint64_t)dim + k0 + j];
     v[j] = (__bf16)x;
   }
-  tiles[(row0 / 16) * KB * 64 + idx] = v;
+  tiles[(row0 / 16) * KB * 64 + blk * 64 + MSI_TILE_PIECE(i, g)] = v;
 }
 
 // Element (row, column) of the tiled store as f32, for the canonical (sequential) paths.
@@ -145,11 +161,11 @@ template <bool S16>
 __device__ __forceinline__ float tile_elem(const void *__restrict__ tiles, uint32_t KB, uint32_t row, uint32_t k) {
   if (S16) {
     const __bf16 *p = reinterpret_cast<const __bf16 *>(tiles);
-    const uint64_t slot = ((uint64_t)(row >> 4) * KB + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (row & 15);
+    const uint64_t slot = ((uint64_t)(row >> 4) * KB + (k >> 5)) * 64 + MSI_TILE_PIECE(row & 15, (k >> 3) & 3);
     return (float)p[slot * 8 + (k & 7)];
   }
   const float *p = reinterpret_cast<const float *>(tiles);
-  const uint64_t slot = ((uint64_t)(row >> 4) * KB + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (row & 15);
+  const uint64_t slot = ((uint64_t)(row >> 4) * KB + (k >> 4)) * 64 + MSI_TILE_PIECE(row & 15, (k >> 2) & 3);
   return p[slot * 4 + (k & 3)];
 }
 
@@ -189,12 +205,12 @@ __global__ void vs_row_norms_kernel(const float4 *__restrict__ tiles, uint64_t r
   }
   uint64_t t = r >> 4;
   uint32_t i = r & 15;
-  const float4 *base = tiles + t * KB * 64 + i;
+  const float4 *base = tiles + t * KB * 64;
   float acc = 0.f;
   for (uint32_t kb = 0; kb < KB; ++kb) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float4 v = base[(uint64_t)kb * 64 + g * 16];
+      float4 v = base[(uint64_t)kb * 64 + MSI_TILE_PIECE(i, (uint32_t)g)];
       acc = __fadd_rn(acc, __fmul_rn(v.x, v.x));
       acc = __fadd_rn(acc, __fmul_rn(v.y, v.y));
       acc = __fadd_rn(acc, __fmul_rn(v.z, v.z));
@@ -231,10 +247,10 @@ __global__ void vs_regather_kernel(const uint4 *__restrict__ old_tiles, const ui
   if (r < n_new) {
     const uint32_t m = map[r], src = m & 0x7FFFFFFFu;
     const uint4 *from = (m & 0x80000000u) ? add_tiles : old_tiles;
-    v = from[((uint64_t)(src >> 4) * KB + kb) * 64 + g * 16 + (src & 15)];
+    v = from[((uint64_t)(src >> 4) * KB + kb) * 64 + MSI_TILE_PIECE(src & 15, g)];
     docid = (m & 0x80000000u) ? add_docids[src] : old_docids[src];
   }
-  new_tiles[idx] = v;
+  new_tiles[blk * 64 + MSI_TILE_PIECE(i, g)] = v;
   if (kb == 0 && g == 0) new_docids[r] = docid;  // padding rows of the last tile included
 }
 
@@ -497,7 +513,8 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   uint32_t tile_cmp = tile_load;
 
   auto load_group = [&](float4(&x)[SCAN_GROUP]) {
-    const float4 *p = a.tiles + ((uint64_t)tile_load * KB + (uint64_t)sub_load * SCAN_GROUP) * 64 + lane;
+    // (lane l holds row l & 15, column group l >> 4 of the block: MSI_TILE_PIECE says where that piece lives)
+    const float4 *p = a.tiles + ((uint64_t)tile_load * KB + (uint64_t)sub_load * SCAN_GROUP) * 64 + MSI_TILE_PIECE(lane & 15u, lane >> 4);
 #pragma unroll
     for (int u = 0; u < SCAN_GROUP; ++u) x[u] = MSI_VS_STREAM_LOAD(p + u * 64);
     if (++sub_load == GPT) {
@@ -674,13 +691,13 @@ __global__ __launch_bounds__(256) void vs_quantize_rows_kernel(const float4 *__r
   const uint32_t KB8 = KB / 4;
   if (tid < 16) s_bad[tid] = 0;
   __syncthreads();
-  const float4 *base = tiles + t * KB * 64 + i;
+  const float4 *base = tiles + t * KB * 64;
   float amax = 0.f;
   bool bad = !(inv == inv) || inv == INFINITY;
   for (uint32_t m = c; m < KB; m += 16) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 v = base[(uint64_t)m * 64 + g * 16];
+      const float4 v = base[(uint64_t)m * 64 + MSI_TILE_PIECE(i, (uint32_t)g)];
       const float e[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -707,7 +724,7 @@ __global__ __launch_bounds__(256) void vs_quantize_rows_kernel(const float4 *__r
     int q[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 v = base[(uint64_t)m * 64 + g * 16];
+      const float4 v = base[(uint64_t)m * 64 + MSI_TILE_PIECE(i, (uint32_t)g)];
       const float e[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1434,14 +1451,15 @@ __device__ __forceinline__ float canonical_dot_t(const void *__restrict__ tiles,
   constexpr int CD_UNR = 8;
   float acc = 0.f;
   if (S16) {
-    const bf16x8 *base = reinterpret_cast<const bf16x8 *>(tiles) + (uint64_t)(row >> 4) * KB * 64 + (row & 15);
+    const bf16x8 *base = reinterpret_cast<const bf16x8 *>(tiles) + (uint64_t)(row >> 4) * KB * 64;
+    const uint32_t ri = row & 15;
     for (uint32_t kb0 = 0; kb0 < KB; kb0 += CD_UNR) {
       bf16x8 v[CD_UNR][4];
 #pragma unroll
       for (int u = 0; u < CD_UNR; ++u)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          if (kb0 + u < KB) v[u][g] = base[(uint64_t)(kb0 + u) * 64 + g * 16];
+          if (kb0 + u < KB) v[u][g] = base[(uint64_t)(kb0 + u) * 64 + MSI_TILE_PIECE(ri, (uint32_t)g)];
 #pragma unroll
       for (int u = 0; u < CD_UNR; ++u) {
         if (kb0 + u < KB) {
@@ -1456,14 +1474,15 @@ __device__ __forceinline__ float canonical_dot_t(const void *__restrict__ tiles,
     }
     return acc;
   }
-  const float4 *base = reinterpret_cast<const float4 *>(tiles) + (uint64_t)(row >> 4) * KB * 64 + (row & 15);
+  const float4 *base = reinterpret_cast<const float4 *>(tiles) + (uint64_t)(row >> 4) * KB * 64;
+  const uint32_t ri = row & 15;
   for (uint32_t kb0 = 0; kb0 < KB; kb0 += CD_UNR) {
     float4 v[CD_UNR][4];
 #pragma unroll
     for (int u = 0; u < CD_UNR; ++u)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        if (kb0 + u < KB) v[u][g] = base[(uint64_t)(kb0 + u) * 64 + g * 16];
+        if (kb0 + u < KB) v[u][g] = base[(uint64_t)(kb0 + u) * 64 + MSI_TILE_PIECE(ri, (uint32_t)g)];
 #pragma unroll
     for (int u = 0; u < CD_UNR; ++u) {
       if (kb0 + u < KB) {
@@ -1586,13 +1605,13 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_refine_kernel(RescoreArgs a) {
     float part = 0.f;
     if (!active) {
     } else if (s16) {
-      const bf16x8 *base = reinterpret_cast<const bf16x8 *>(a.tiles) + (uint64_t)(row >> 4) * a.KB * 64 + (row & 15);
+      const bf16x8 *base = reinterpret_cast<const bf16x8 *>(a.tiles) + (uint64_t)(row >> 4) * a.KB * 64;
       for (uint32_t p0 = l16; p0 < pieces; p0 += 16 * 4) {
         bf16x8 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const uint32_t p = p0 + u * 16;
-          if (p < pieces) v[u] = base[(uint64_t)(p >> 2) * 64 + (p & 3) * 16];
+          if (p < pieces) v[u] = base[(uint64_t)(p >> 2) * 64 + MSI_TILE_PIECE(row & 15u, p & 3u)];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1604,13 +1623,13 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_refine_kernel(RescoreArgs a) {
         }
       }
     } else {
-      const float4 *base = reinterpret_cast<const float4 *>(a.tiles) + (uint64_t)(row >> 4) * a.KB * 64 + (row & 15);
+      const float4 *base = reinterpret_cast<const float4 *>(a.tiles) + (uint64_t)(row >> 4) * a.KB * 64;
       for (uint32_t p0 = l16; p0 < pieces; p0 += 16 * 6) {
         float4 v[6];
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
           const uint32_t p = p0 + u * 16;
-          if (p < pieces) v[u] = base[(uint64_t)(p >> 2) * 64 + (p & 3) * 16];
+          if (p < pieces) v[u] = base[(uint64_t)(p >> 2) * 64 + MSI_TILE_PIECE(row & 15u, p & 3u)];
         }
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
