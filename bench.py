@@ -136,6 +136,32 @@ def parse_args():
 
 # ----------------------------------------------------------------------------------------------- harness
 
+def _emulate_the_device(torch):
+    """MSI_BENCH_EMULATED=1 (the CPU tier's two-rank run, tests/test_bench_two_ranks_cpu.py — never a measurement): libmsi is the
+    CPU-emulated build of tests/emu (every csrc/*.hip compiled as plain C++: "device" pointers are host pointers), torch
+    tensors live on the CPU, the process group is gloo and RCCL is the stand-in of tests/emu/rccl_emu.cpp joined through
+    shared memory.  What runs is the HOST side of the N > 1 line — sharding, the exchange through msi_group_*, the merge, the
+    line's fields — on sizes the emulation finishes in a minute."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import run_emulated as E
+    import meilisearch_amd as ma
+    ma._lib._LIB = E.EmulatedLib(E.build())
+    os.environ["MSI_RUNNER_SO"] = E.build_runner()
+    os.environ["MSI_RCCL_LIBRARY"] = E.build_rccl()
+    os.environ["MSI_RCCL_EMU_SHM"] = "1"
+
+    class _Stream:
+        cuda_stream = 0
+
+        def synchronize(self):
+            pass
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.empty_cache = lambda *a, **k: None
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    return E
+
+
 class Env:
     def __init__(self, args):
         import torch
@@ -144,15 +170,21 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
+        self.emulated = os.environ.get("MSI_BENCH_EMULATED") == "1"
+        if self.emulated:
+            self.emu = _emulate_the_device(torch)
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            if self.emulated:
+                dist.init_process_group("gloo")
+            else:
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
         assert self.world == args.gpus or self.world == 1, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
-        self.dev = torch.device("cuda", self.local_rank)
+        self.dev = torch.device("cpu") if self.emulated else torch.device("cuda", self.local_rank)
         torch.cuda.set_device(self.dev)
         import meilisearch_amd as ma
         self.ma = ma
@@ -548,6 +580,8 @@ def run_c4(args, env):
     if not args.no_rank:
         import ctypes as C
         kw_so = os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so")
+        if env.emulated:
+            kw_so = os.environ["MSI_RUNNER_SO"]
         if not os.path.exists(kw_so):      # a tree that was never built: __graft_entry__.build() makes it (hipcc, seconds)
             if rank == 0:
                 import __graft_entry__
@@ -1110,11 +1144,11 @@ def run_c4(args, env):
             "vector_only_queries_per_s_by_rank": [round(x, 1) for x in vec_only_by_rank] if vec_only_by_rank else None,
             "keyword_callers_per_rank": kw_threads if kw is not None else 0, "host_cpus_granted": granted_cpus(),
             # N > 1: all ranks share the box's granted CPUs, and a keyword search costs host CPU whichever GPU runs its sets — the
-            # keyword leg of the whole job cannot exceed granted CPUs / host CPU per query (1.04 ms per fresh query at N = 1 on
-            # the round's final tree, profiles/r5_bench_c4_final.json: 13.9 k q/s at 14.5 of 16 CPUs), so with 16 granted CPUs
-            # the hybrid weak-scaling curve flattens just above the one-GPU value whatever RCCL does; the vector leg scales
-            "keyword_cap_predicted": round(granted_cpus() / 1.04e-3, 0) if kw is not None else None,
-            "predicted_cap_is": "granted CPUs / 1.04 ms of host CPU per keyword query on a fresh query stream (round 5, legs."
+            # keyword leg of the whole job cannot exceed granted CPUs / host CPU per query (0.66 ms per fresh query at N = 1 with
+            # the postings staged, profiles/r6_kw_stage.log: 17.0 k q/s at 12.0 of 16 CPUs; round 5: 1.04 ms), so with 16 granted
+            # CPUs the hybrid weak-scaling curve flattens near 1.4 GPUs' worth whatever RCCL does; the vector leg scales
+            "keyword_cap_predicted": round(granted_cpus() / 0.66e-3, 0) if kw is not None else None,
+            "predicted_cap_is": "granted CPUs / 0.66 ms of host CPU per keyword query on a fresh query stream (round 6, postings staged; legs."
                                 "keyword_host_cpu_ms_per_query at N = 1): every rank's searches draw on the same granted CPUs, so the whole "
                                 "job's keyword leg cannot exceed it whatever the number of GPUs; keyword_cap_measured = the ranks' keyword-only "
                                 "rates, measured at the same time, summed",

@@ -312,6 +312,12 @@ def _share_torch_hip_runtime():
             pass
 
 
+def on_device(tensor):
+    """The tensor's memory is what libmsi may be handed as a device pointer: a CUDA (HIP) tensor — or any tensor when the
+    test tier has swapped in the CPU-emulated build of the library (tests/emu: "device" pointers are host pointers)."""
+    return bool(tensor.is_cuda) or type(_LIB).__name__ == "EmulatedLib"
+
+
 def lib():
     """Load libmsi.so.  No fallback: a missing library is an error."""
     global _LIB

@@ -80,11 +80,14 @@ struct MsiVmList {
   uint32_t u0_slot = 0;
   std::vector<uint32_t> pre;
   bool pre_merged = false;
+  bool any_fill = false;                // a decode of this list is the FIRST reader of its key: its decode phase stores the bodies
+                                        // into the posting cache on its way (the by-rank phase only looks for them when told so)
   bool empty() const { return words.empty() && pre.empty(); }
   void clear() {
     words.clear();
     pre.clear();
     pre_merged = false;
+    any_fill = false;
     phase_start.clear();
     stage_used = 0;
     cache_base = 0;

@@ -113,7 +113,10 @@ struct alignas(16) RoundSub {
   // written by the DEVICE (the round's own copy of this struct): a workgroup of a fused list gave up waiting for the list's
   // wide phase (MSI_VM_SPIN_LIMIT_TICKS).  The list still hands in its tickets, and its last workgroup publishes the failure
   // instead of a result count, so that a stall surfaces as MSI_E_INTERNAL on the host and not as a hung device.
-  uint32_t failed, _pad;
+  uint32_t failed;
+  // workgroups of the list's phase 0 when it is a decode phase of its own: `wide_chunks` (one per chunk of the full space) or,
+  // BY RANK (wide_mask bit 30), one per 64 documents of U0
+  uint32_t p0_wgs;
 };
 static_assert(sizeof(RoundSub) % 16 == 0, "RoundSub array stays 16-byte aligned");
 
@@ -200,13 +203,14 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
   uint32_t phase = launch_phase, chunk = blockIdx.x;
   if (fused) {
     if (launch_phase == 1) return;               // ran with launch 0
-    if (launch_phase == 0 && chunk >= rp->wide_chunks) {
+    if (launch_phase == 0 && chunk >= rp->p0_wgs) {
       phase = 1;
-      chunk -= rp->wide_chunks;
+      chunk -= rp->p0_wgs;
     }
   }
   const bool wide = ((rp->wide_mask >> phase) & 1u) != 0;       // a compact list's VM_DECODEC phase: chunks of the FULL space
-  const uint32_t my_chunks = wide ? rp->wide_chunks : r.n_chunks;
+  const bool by_rank = wide && (rp->wide_mask & 0x40000000u) != 0;   // ... or, for a small U0, 64 documents of U0 per workgroup
+  const uint32_t my_chunks = wide ? rp->p0_wgs : r.n_chunks;
   if (phase >= r.n_phases || chunk >= my_chunks) return;
   // a waiter that gave up: its workgroup runs NO command (the wide phase's data is incomplete: nothing may be computed from
   // it into pool slots or posting-cache entries that other searches share — ADVICE r5), it only hands in its ticket so
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
     if (threadIdx.x == 0) {
       const u64 t_wait = wall_clock64();
       uint32_t spins = 0;
-      while (__hip_atomic_load(done0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rp->wide_chunks) {
+      while (__hip_atomic_load(done0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rp->p0_wgs) {
         MSI_SLEEP();
         if ((++spins & 1023u) == 0 && wall_clock64() - t_wait > MSI_VM_SPIN_LIMIT_TICKS) {
           __hip_atomic_store(const_cast<uint32_t *>(&rp->failed), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
     }
     return reinterpret_cast<const uint16_t *>(b0)[i];
   };
-  if (wide) {
+  if (wide && !by_rank) {
     const uint32_t full_words = rp->full_words, full_chunks = rp->wide_chunks;
     const uint32_t *prefix = reinterpret_cast<const uint32_t *>(rp->aux) + ((full_chunks + 3) & ~3u);
     const u64 fw0 = (u64)chunk * CHW;
@@ -575,7 +579,104 @@ __global__ __launch_bounds__(VT, 4) void vm_kernel(uint32_t *__restrict__ arena,
   // commands of its own — its quarter of s_raw as the output words — and runs them without a workgroup barrier: four
   // decodes in flight per workgroup, and a decode is a handful of dependent loads.
   bool wide_done = false;
-  if (wide && (c_hi == c_lo || ((c_hi - 1) >> 6) - (c_lo >> 6) + 1 <= 256)) {
+  // ---- decode phase BY RANK (round 6) ----------------------------------------------------------------------------------
+  // The wide phase costs a workgroup per chunk of the FULL space — 153 of them at 10 M documents, ~25 us each — whatever
+  // |U0| is, and it reads the postings from THEIR side (every value of an array container is looked up in U0): 36 % of the
+  // keyword leg's workgroup time (MSI_VM_PROFILE, profiles/r6_vm_profile.log), most of it for universes of a few hundred
+  // or thousand documents.  For those the host asks for this phase instead: one workgroup per 64 documents of U0, lane =
+  // document (rank -> docid through the compaction table), wave w takes the commands w, w + 4, ...: the posting's container
+  // of the document's chunk is probed for the ONE value (binary search in an array / among the runs, a bit test in a
+  // bitmap), the wave's ballot IS the destination's 64-bit word.  No U0 words, no prefix counts, no atomics.
+  if (by_rank) {
+    wide_done = true;
+    const uint32_t total = (uint32_t)r.n_docs;
+    const uint32_t rk = chunk * 64 + lane;
+    const bool live = rk < total;
+    const uint32_t *c2d = reinterpret_cast<const uint32_t *>(rp->aux) + ((rp->wide_chunks + 3) & ~3u) + ((rp->full_words + 3) & ~3u);
+    const uint32_t d = live ? c2d[rk] : 0u;
+    const uint32_t lo16 = d & 0xFFFFu;
+    const uint32_t *blk = nullptr;
+    if (live && r.n_decodes) {
+      const uint32_t *data = arena + r.list_off + r.data_off;
+      blk = data + 4 * (size_t)data[d >> 16];
+    }
+    const uint32_t n_cmd = (p_end - p_begin) / 3;
+    const uint32_t last_word = (uint32_t)(r.n_words - 1);
+    const bool fills = (rp->wide_mask & 0x20000000u) != 0;   // a decode of this list is the first reader of its posting
+    for (uint32_t k = wave; k < n_cmd; k += VT / 64) {
+      if (MSI_UNIFORM(cmd[3 * k]) != VM_DECODEC) break;
+      const uint32_t dsts = MSI_UNIFORM(cmd[3 * k + 1]), srcw = MSI_UNIFORM(cmd[3 * k + 2]);
+      // the FIRST reader of a posting also stores its bodies into the posting cache (the host commits the entries when the
+      // list has run): the wide phase does that per chunk; here the list's workgroups share the chunks of the full space
+      if (fills && !(srcw >> 31) && r.n_decodes) {
+        const uint32_t *data = arena + r.list_off + r.data_off;
+        for (uint32_t fc = chunk; fc < rp->wide_chunks; fc += my_chunks) {
+          const uint32_t *fb = data + 4 * (size_t)MSI_UNIFORM(data[fc]);
+          const uint32_t f_first = MSI_UNIFORM(fb[srcw]), f_n = MSI_UNIFORM(fb[srcw + 1]) - f_first;
+          for (uint32_t ci = 0; ci < f_n; ++ci) {
+            const VmContainer c = *reinterpret_cast<const VmContainer *>(fb + desc_st + 4 * (size_t)(f_first + ci));
+            if (c.fill_lo == 0xFFFFFFFFu && (c.meta >> 19) == 0x1FFFu) continue;
+            const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
+            const u64 fill_off = ((u64)(c.meta >> 19) << 32) | c.fill_lo;
+            const uint32_t len = type == 0 ? 2 * (card + 1) : (type == 1 ? 8192u : 4 * (card + 1));
+            const uintptr_t b0 = ((c.meta >> 18) & 1u) ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
+            const uint32_t skew = (uint32_t)(b0 & 15);
+            const uint4 *src = reinterpret_cast<const uint4 *>(b0 - skew);
+            uint4 *fill = reinterpret_cast<uint4 *>((uintptr_t)(r.cache + fill_off) - skew);
+            const uint32_t n16 = (skew + min(len, 8192u) + 15) / 16;
+            for (uint32_t i = lane; i < n16; i += 64) put4(&fill[i], src[i]);
+          }
+        }
+      }
+      bool hit = false;
+      if (live) {
+        if (srcw >> 31) {
+          const u64 *src_slot = reinterpret_cast<const u64 *>(rp->full_base) + (u64)(srcw & 0x7FFFFFFFu) * rp->full_words;
+          hit = ((src_slot[d >> 6] >> (d & 63)) & 1ull) != 0;
+        } else if (blk) {
+          const uint32_t c_first = blk[srcw], n_here = blk[srcw + 1] - c_first;
+          for (uint32_t ci = 0; ci < n_here && !hit; ++ci) {
+            const VmContainer c = *reinterpret_cast<const VmContainer *>(blk + desc_st + 4 * (size_t)(c_first + ci));
+            const uint32_t card = c.meta & 0xFFFFu, type = (c.meta >> 16) & 3u;
+            const uintptr_t b0 = ((c.meta >> 18) & 1u) ? (uintptr_t)(r.cache + c.src) : (uintptr_t)(r.stage + c.src);
+            if (type == 1) {
+              const uint8_t byte = reinterpret_cast<const uint8_t *>(b0)[lo16 >> 3];
+              hit = ((byte >> (lo16 & 7)) & 1u) != 0;
+            } else if (type == 0) {
+              uint32_t lo = 0, hi = min(card + 1, 4096u);   // the value is in [lo, hi) if anywhere
+              while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1, v = ld16(b0, mid);
+                if (v == lo16) {
+                  hit = true;
+                  break;
+                }
+                if (v < lo16) lo = mid + 1;
+                else hi = mid;
+              }
+            } else {
+              uint32_t lo = 0, hi = min(card + 1, 2048u);   // the last run that starts at or before the value
+              while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ld16(b0, 2 * mid) <= lo16) lo = mid + 1;
+                else hi = mid;
+              }
+              if (lo > 0) {
+                const uint32_t start = ld16(b0, 2 * (lo - 1)), last = min(65535u, start + ld16(b0, 2 * (lo - 1) + 1));
+                hit = lo16 <= last;
+              }
+            }
+          }
+        }
+      }
+      const u64 word = __ballot(hit ? 1 : 0);
+      u64 *dst = pool + (u64)dsts * r.n_words;
+      if (lane == 0 && chunk <= last_word) put1(&dst[chunk], word);
+      // the workgroup of U0's last documents also clears what lies behind them in the slot
+      if (chunk + 1 == my_chunks)
+        for (u64 gw = (u64)chunk + 1 + lane; gw < r.n_words; gw += 64) put1(&dst[gw], 0ull);
+    }
+  }
+  if (!by_rank && wide && (c_hi == c_lo || ((c_hi - 1) >> 6) - (c_lo >> 6) + 1 <= 256)) {
     wide_done = true;
     const uint32_t full_words = rp->full_words;
     const u64 fw0 = (u64)chunk * CHW;
@@ -1889,6 +1990,17 @@ void VmCombiner::run() {
           r.u0_slot = l.u0_slot;
           r.wide_chunks = (uint32_t)((r.full_words + CHW - 1) / CHW);
           r.wide_mask = l.pre_merged ? 1u : 0u;
+          r.p0_wgs = r.wide_chunks;
+          // the decode phase by rank (vm_kernel): a workgroup per 64 documents of U0 instead of one per chunk of the full space,
+          // when that is clearly less work — each of its lanes pays a binary search per command where a wide workgroup pays
+          // its staging once.  MSI_VM_BY_RANK_MAX_DOCS (experiments; 0: never) caps |U0|.
+          static const uint32_t by_rank_max = getenv("MSI_VM_BY_RANK_MAX_DOCS") ? (uint32_t)std::max(0, atoi(getenv("MSI_VM_BY_RANK_MAX_DOCS"))) : 4096u;
+          // (MSI_VM_BY_RANK_FORCE=1, tests: also when the full space has fewer chunks than U0 has words — small corpora)
+          static const bool by_rank_force = getenv("MSI_VM_BY_RANK_FORCE") && getenv("MSI_VM_BY_RANK_FORCE")[0] == '1';
+          if (l.pre_merged && l.geom_docs <= by_rank_max && ((l.geom_docs + 63) / 64 < r.wide_chunks || by_rank_force)) {
+            r.wide_mask |= 0x40000000u | (l.any_fill ? 0x20000000u : 0u);
+            r.p0_wgs = (uint32_t)std::max<uint64_t>(1, (l.geom_docs + 63) / 64);
+          }
           // phases 0 and 1 in one launch (vm_kernel, `fused`): only while the waiting workgroups are few
           static const bool fuse_off = getenv("MSI_VM_FUSE") && getenv("MSI_VM_FUSE")[0] == '0';   // experiments
           // (the waiting workgroups of a list follow its own wide workgroups in dispatch order, so they can only ever wait
@@ -1913,10 +2025,10 @@ void VmCombiner::run() {
         memset(A.host + state_at[i], 0, 16 + MSI_VM_CELLS * 8 + (size_t)l.n_counts * 8 + (size_t)r.n_chunks * 4 * l.max_fk_phase);
         for (uint32_t ph = 0; ph < r.n_phases; ++ph) {
           if (r.wide_mask & 0x80000000u) {
-            if (ph == 0) max_chunks[0] = std::max(max_chunks[0], r.wide_chunks + r.n_chunks);
+            if (ph == 0) max_chunks[0] = std::max(max_chunks[0], r.p0_wgs + r.n_chunks);
             if (ph <= 1) continue;
           }
-          max_chunks[ph] = std::max(max_chunks[ph], ((r.wide_mask >> ph) & 1u) ? r.wide_chunks : r.n_chunks);
+          max_chunks[ph] = std::max(max_chunks[ph], ((r.wide_mask >> ph) & 1u) ? r.p0_wgs : r.n_chunks);
         }
         max_phases = std::max(max_phases, r.n_phases);
       }
@@ -2192,6 +2304,7 @@ int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const M
     // meta: card - 1 (16 bits) | type << 16 | cached << 18 | fill offset high 13 bits << 19; then fill offset low 32 bits
     const uint32_t card1 = c.type == 1 ? 0u : (c.card ? c.card - 1 : 0u);
     const uint64_t f = fill_off == MSI_NO_CACHE ? ((uint64_t)0x1FFF << 32 | 0xFFFFFFFFull) : fill_off;
+    if (fill_off != MSI_NO_CACHE) l.any_fill = true;
     const uint32_t meta = (card1 & 0xFFFFu) | (c.type << 16) | ((cached ? 1u : 0u) << 18) | ((uint32_t)((f >> 32) & 0x1FFF) << 19);
     const size_t at2 = (size_t)fill[c.key]++ * 2;
     dec.c[at2] = (uint64_t)meta | ((uint64_t)(uint32_t)f << 32);

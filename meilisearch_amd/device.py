@@ -3,6 +3,7 @@ import ctypes as C
 
 import numpy as np
 
+from . import _lib
 from ._lib import check, lib
 
 
@@ -52,7 +53,7 @@ class DeviceBuffer:
     """A torch CUDA tensor viewed as a raw device pointer."""
 
     def __init__(self, tensor):
-        assert tensor.is_cuda and tensor.is_contiguous()
+        assert _lib.on_device(tensor) and tensor.is_contiguous()
         self.tensor = tensor
 
     @property

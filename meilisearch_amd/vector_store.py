@@ -10,6 +10,7 @@ import ctypes as C
 
 import numpy as np
 
+from . import _lib
 from ._lib import VsStats, check, lib
 from .device import np_ptr
 
@@ -55,7 +56,7 @@ class GpuStore:
 
     def upload_device(self, docids_t, rows_t):
         """docids_t: cuda int32/uint32-compatible tensor, rows_t: cuda f32 [n, dim]."""
-        assert rows_t.is_cuda and rows_t.is_contiguous() and docids_t.is_cuda
+        assert _lib.on_device(rows_t) and rows_t.is_contiguous() and _lib.on_device(docids_t)
         import torch
         torch.cuda.current_stream(rows_t.device).synchronize()   # libmsi works on its own stream
         n = rows_t.shape[0]

@@ -70,6 +70,19 @@ GROUPS = {
     # the one-document-per-chunk spread (ranges of one bit: the shared-word path of VM_DECODEC), the out-of-slots re-run
     "ranked-search-compact-space": (["tests/test_search_gpu.py", "tests/test_zz_vm_gpu.py"],
                                     "not matches_oracle_on_random_corpora and not starved", 100, {"MSI_SEARCH_COMPACT": "2"}),
+    # the decode phase BY RANK (round 6: a compact list's postings probed from the universe's side, one workgroup per 64
+    # documents of U0, instead of the wide phase's workgroup per chunk of the full space) forced wherever a compact list has
+    # no cache fill to do — the test corpora are 1-3 chunks long, so the default rule (fewer workgroups than chunks) would
+    # only take it for universes of <= 128 documents: the vm tests and the corpus tests (array / bitmap containers, staged and
+    # first-read postings, phrases, prefix databases; universe and bucket spaces as the search chooses them).  The forced
+    # compact space of every search (MSI_SEARCH_COMPACT=2) with it: tools/fuzz_ranked_hostlogic.py --emulated-kernels, 99 k cases
+    "ranked-search-by-rank": (["tests/test_search_gpu.py", "tests/test_zz_vm_gpu.py",
+                               "tests/test_configs_gpu.py::test_c4_keyword_leg_on_the_coherent_corpus",
+                               "tests/test_configs_gpu.py::test_postings_staged_at_index_open_on_the_coherent_corpus",
+                               "tests/test_configs_gpu.py::test_phrases_on_the_coherent_corpus",
+                               "tests/test_configs_gpu.py::test_word_prefix_databases_on_the_coherent_corpus"],
+                              "not matches_oracle_on_random_corpora and not starved", 100,
+                              {"MSI_VM_BY_RANK_FORCE": "1", "MSI_VM_BY_RANK_MAX_DOCS": "1000000"}),
     # the reaper (MSI_VM_REAPER=1: rounds handed to a second thread that notices their completion and wakes the searches
     # — an experiment that stays off by default): the hand-over, concurrent searches, shutdown
     "ranked-search-reaper": (["tests/test_zz_vm_gpu.py"], "concurrent_searches or cold_and_warm or universe_of_an_unfiltered or index_views",
