@@ -1255,6 +1255,12 @@ struct Runner {
   const uint32_t *uni_ids = nullptr, *uni_cnt = nullptr, *pending_uni_ids = nullptr, *pending_uni_cnt = nullptr;
   uint32_t uni_stride = 0, pending_uni_stride = 0;
   std::vector<double> lat_ms;                // wall time of every search of the last job (rb_last_latencies)
+  // The order in which the callers take a job's searches: the expensive ones first (the searches whose most frequent word
+  // has the longest posting: their universes cannot be compacted and every one of their ~17 rounds runs in the full docid
+  // space).  A batch of 768 searches on 256 callers otherwise ends with a tail — the last callers working on a slow search
+  // that happened to be handed out late while the others idle; a server's stream has no such barrier.  RB_ORDER=fifo: as
+  // the queries come.  Results land at the query's own index either way.
+  std::vector<uint32_t> job_order;
   bool stop = false;
   std::atomic<int32_t> failed{0};
   std::atomic<size_t> active_callers{~(size_t)0};   // callers that take searches (the others sit a job out)
@@ -1335,6 +1341,7 @@ struct Runner {
           std::lock_guard<std::mutex> lk(mu);
           if (next >= job_n) break;
           i = next++;
+          if (!job_order.empty()) i = job_order[i];
         }
         const std::vector<std::string> &q = queries[(job_first + i) % queries.size()];
         const auto t_search = std::chrono::steady_clock::now();
@@ -1594,6 +1601,21 @@ int32_t rb_start_detailed(void *h, uint32_t first, uint32_t n, uint32_t limit, u
   r->uni_ids = r->pending_uni_ids; r->uni_cnt = r->pending_uni_cnt; r->uni_stride = r->pending_uni_stride;
   r->pending_uni_ids = r->pending_uni_cnt = nullptr;
   r->lat_ms.assign(n, 0.0);
+  r->job_order.clear();
+  static const bool fifo = getenv("RB_ORDER") && !strcmp(getenv("RB_ORDER"), "fifo");
+  if (r->ix.corpus && !fifo && n > 1) {
+    const Corpus &c = *r->ix.corpus;
+    std::vector<uint64_t> cost(n, 0);
+    for (uint32_t i = 0; i < n; ++i)
+      for (const std::string &w : r->queries[(first + i) % r->queries.size()]) {
+        if (w.empty() || w[0] == '-' || w[0] == '"') continue;
+        const int64_t id = c.id_of(w);
+        if (id >= 0) cost[i] = std::max<uint64_t>(cost[i], c.post_off[id + 1] - c.post_off[id]);
+      }
+    r->job_order.resize(n);
+    for (uint32_t i = 0; i < n; ++i) r->job_order[i] = i;
+    std::stable_sort(r->job_order.begin(), r->job_order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+  }
   ++r->epoch;
   r->cv.notify_all();
   return MSI_OK;
