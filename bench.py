@@ -1790,10 +1790,13 @@ def run_c5(args, env):
         st = store.stats()
         if env.rank != 0:
             continue
-        # with a candidate filter only the tiles that hold an allowed row are streamed
+        # with a candidate filter a sweep visits ITEMS of 16 rows (msi_vs_filter_stats: counted by the device): the allowed rows
+        # of a region compacted, or its tiles that hold an allowed row where that moves fewer bytes per unit of bandwidth
         allowed_tiles = int(np.count_nonzero(fb.view(np.uint16)[: (n + 15) // 16]))
         n_allowed = int(np.unpackbits(fb.view(np.uint8), bitorder="little")[:n].sum())
-        algo_bytes = allowed_tiles * st["bytes_per_tile"]
+        fstats = store.filter_stats()
+        assert fstats["allowed_rows"] == n_allowed, (fstats, n_allowed)
+        algo_bytes = fstats["items"] * st["bytes_per_tile"]
         row_bytes = st["bytes_per_tile"] // 16
         line = {
             "filter_density": sel_d, "allowed_rows": n_allowed,
@@ -1801,7 +1804,9 @@ def run_c5(args, env):
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(statistics.median(lat), 4),
             "knn_only_ms_per_step": round(knn_ms, 4),
             "words_typo_fast_path_ms_per_step": round(fast_ms, 4), "words_typo_fast_path_queries_per_s": round(B / (fast_ms * 1e-3), 1),
-            "tiles_streamed_per_launch": allowed_tiles, "tiles_in_store": (n + 15) // 16,
+            "tiles_streamed_per_launch": fstats["items"], "tiles_in_store": (n + 15) // 16,
+            "items": dict(fstats, tiles_that_hold_an_allowed_row=allowed_tiles,
+                          is="16-row items a sweep visits: compacted allowed rows (gathered, 64-byte sectors) / whole tiles (streamed)"),
             "scan_tiles_counted_by_the_library": int((st["scan_tiles"] - t0s) / max(1, st["scan_launches"] - l0s)),
             "bytes_streamed_over_allowed_row_bytes": round(algo_bytes / max(1, n_allowed * row_bytes), 2),
             "scan_share_of_the_step": round((scan_ms / max(1, scan_n)) / (elapsed / args.steps * 1e3), 4),
@@ -1876,10 +1881,9 @@ def run_c5(args, env):
                    "tiles_streamed_per_launch": main["tiles_streamed_per_launch"], "tiles_in_store": (n + 15) // 16,
                    "scan_tiles_counted_by_the_library": main["scan_tiles_counted_by_the_library"],
                    "inexact_queries_last_step": main["inexact_queries_last_step"],
-                   "low_density_note": "a tile is 16 rows, so a 1 % filter streams ~15 % of the store and a 0.1 % filter 1.6 % (16x the "
-                                       "allowed rows' bytes: bytes_streamed_over_allowed_row_bytes); a row-granular gather path was NOT "
-                                       "built: at <= 1 % the scan is a small share of the step (scan_share_of_the_step) — selection of "
-                                       "the top-1000, its exact rescoring and the rerank are what the step is made of"},
+                   "row_granular_note": "round 6: a filtered sweep gathers the allowed rows at 64-byte-sector granularity "
+                                        "(bytes_streamed_over_allowed_row_bytes ~1 at every density of this line; rounds 1-5 streamed "
+                                        "every 16-row tile that held an allowed row: 8 / 15 / 16 x at 10 / 1 / 0.1 %)"},
         "roofline": main["roofline"],
         "densities": per_density,
     }

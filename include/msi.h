@@ -293,6 +293,13 @@ int32_t msi_vs_debug_fast_scores(msi_vs *vs, const float *queries, uint32_t n_qu
 /* Accumulated duration of the full-sweep vs_scan launches recorded while
  * profiling was enabled (HIP events on the launch stream); resets the counters. */
 int32_t msi_vs_scan_time(msi_vs *vs, uint64_t *out_launches, double *out_ms_total);
+/* The last filtered search of this store, as the device counted it (synchronises the store's streams):
+ *   out[0] items its sweeps visited (an item = 16 rows of one MFMA tile; x 16 x the row's bytes = what a sweep moves),
+ *   out[1] allowed rows, out[2] items written as COMPACTED allowed rows (gathered at 64-byte-sector granularity),
+ *   out[3] items written as whole 16-row tiles that hold an allowed row (streamed).
+ * hannoy's linear mode scores only the candidates (vector/store.rs:1079-1080); a sweep here visits the allowed rows plus,
+ * where a region of the store is dense in them, their tile neighbours (msi_vs.hip: vs_filter_rows_kernel). */
+int32_t msi_vs_filter_stats(msi_vs *vs, uint64_t out[4]);
 
 /* ----------------------------------- S1': binary-quantised vector stores */
 /*

@@ -173,6 +173,7 @@ PROTOTYPES = {
     "msi_vs_get_stats": (_I32, [_VP, C.POINTER(VsStats)]),
     "msi_vs_debug_fast_scores": (_I32, [_VP, _VP, _U32, _VP, C.POINTER(_F32)]),
     "msi_vs_scan_time": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_F64)]),
+    "msi_vs_filter_stats": (_I32, [_VP, C.POINTER(_U64)]),
     "msi_group_create": (_I32, [_VP, _U32, C.POINTER(_VP)]),
     "msi_group_unique_id": (_I32, [_VP]),
     "msi_group_create_rank": (_I32, [_VP, _U32, _U32, _VP, C.POINTER(_VP)]),

@@ -1635,7 +1635,8 @@ struct VmSub {
 
 struct VmCombiner {
   msi_ctx *ctx = nullptr;
-  static constexpr int NS = 16;     // rounds in flight: a slow list of one round must not hold up the next round's lists
+  static constexpr int NS = 32;     // rounds in flight AT MOST: a slow list of one round must not hold up the next round's lists
+  int ns = 16;                      // ... of which this many are used (MSI_VM_STREAMS: even, 4..NS; half per class of rounds)
   hipStream_t streams[NS] = {};
   std::thread th;
   // Submission takes no lock (round 6).  Every list used to take `mu` twice — to queue itself and to hand its slot back —
@@ -1888,6 +1889,7 @@ void VmCombiner::run() {
   const size_t batch_div = getenv("MSI_VM_BATCH_DIV") ? std::max(1, atoi(getenv("MSI_VM_BATCH_DIV"))) : 2;
   const size_t batch_cap = getenv("MSI_VM_BATCH_CAP") ? std::max(1, atoi(getenv("MSI_VM_BATCH_CAP"))) : 32;
   const long poll_sleep_ns = (getenv("MSI_VM_POLL_SLEEP_US") ? std::max(0, atoi(getenv("MSI_VM_POLL_SLEEP_US"))) : 20) * 1000l;
+  const bool arena_fifo = getenv("MSI_VM_ARENA_FIFO") && getenv("MSI_VM_ARENA_FIFO")[0] == '1';
   if (poll_sleep_ns > 0) prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0);   // (this thread only: the default 50 us slack would triple the sleep)
   if (getenv("MSI_VM_PROFILE") && hipMalloc((void **)&d_prof, 32 * sizeof(u64)) == hipSuccess) (void)hipMemset(d_prof, 0, 32 * sizeof(u64));
   uint64_t cpu_seen = msi_cpu_prof_on() ? msi_thread_cpu_ns() : 0;
@@ -2071,7 +2073,7 @@ void VmCombiner::run() {
       }
     }
     batch.clear();
-    cur_of[cls] = (cur + 2) % NS;
+    cur_of[cls] = (cur + 2) % ns;
   };
   for (;;) {
     taken.clear();
@@ -2109,9 +2111,18 @@ void VmCombiner::run() {
       if (batch_wait_ns && n_inflight.load(std::memory_order_relaxed) != 0 && waiting[cls].size() < std::min<size_t>(batch_cap, load.load(std::memory_order_relaxed) / batch_div) &&
           now_ns() - waiting[cls].front()->t_taken < batch_wait_ns)
         continue;
-      Arena &A0 = ar[cur_of[cls]];
-      if (A0.in_flight && hipEventQuery(A0.done) == hipSuccess) A0.in_flight = false;
-      if (A0.in_flight) continue;
+      // the class's next arena — or, when that one's round is still running, any other arena of the class whose round has
+      // finished (rounds differ in length by an order of magnitude: the next in line is not the next to finish)
+      int free_at = -1;
+      for (int k = 0; k < ns / 2 && free_at < 0; ++k) {
+        const int idx = (cur_of[cls] + 2 * k) % ns;
+        Arena &Ak = ar[idx];
+        if (Ak.in_flight && hipEventQuery(Ak.done) == hipSuccess) Ak.in_flight = false;
+        if (!Ak.in_flight) free_at = idx;
+        if (arena_fifo) break;   // (MSI_VM_ARENA_FIFO=1: round 5's strict rotation)
+      }
+      if (free_at < 0) continue;
+      cur_of[cls] = free_at;
       std::vector<VmSub *> batch;
       const size_t n = std::min<size_t>(waiting[cls].size(), std::min<size_t>(max_subs, MAX_SUBS));
       batch.assign(waiting[cls].begin(), waiting[cls].begin() + n);
@@ -2166,7 +2177,8 @@ static msi_vm *vm_of(msi_ctx *ctx) {
       cb->ctx = ctx;
       cb->fused_wgs = &vm->fused_wgs;
       cb->fused_budget = vm->fused_budget;
-      for (int i = 0; i < VmCombiner::NS; ++i)
+      if (const char *e = getenv("MSI_VM_STREAMS")) cb->ns = std::max(4, std::min((int)VmCombiner::NS, atoi(e) & ~1));
+      for (int i = 0; i < cb->ns; ++i)
         if (hipStreamCreateWithFlags(&cb->streams[i], hipStreamNonBlocking) != hipSuccess) {
           msi_set_error("msi_vm: hipStreamCreate failed");
           delete vm;   // (what was created so far leaks with the failed context; nothing runs on it)

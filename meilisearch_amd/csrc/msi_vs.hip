@@ -319,18 +319,27 @@ __global__ __launch_bounds__(256) void vs_prep_queries_kernel(
 
 // ------------------------------------------------------------------- filter path
 
-// Per-tile 16-bit "row allowed" masks + compacted list of the tiles with any
-// allowed row.  A workgroup of 1024 threads covers FT_SUB*64 consecutive tiles and
-// reserves its slice of the list with ONE global atomic (the list is ordered
-// inside a workgroup; workgroups land in arrival order, which only permutes the
-// order tiles are streamed in).
+// The ITEMS a filtered sweep visits (round 6: row-granular).  An item is 16 entries of `rows`: the rows of one 16 x 16 MFMA
+// tile, each entry a row index of the store, bit 31 set for a row that is loaded but not allowed (0xFFFFFFFF: padding).
+// hannoy's linear mode only touches candidate rows (vector/store.rs:1079-1080); rounds 1-5 streamed every 16-row tile that
+// held an allowed row — 8 / 15 / 16 times the allowed rows' bytes at 10 / 1 / 0.1 %.  Since the row tiles
+// keep a row's pieces of a KiB block in one 64-byte sector (MSI_TILE_PIECE) a wave can gather 16 ARBITRARY rows into the A
+// operand at sector granularity, so a workgroup of this kernel (8 192 consecutive rows) writes its allowed rows either
+//   compacted  ceil(allowed / 16) items of allowed rows only (gathered: ~2.5 TB/s of useful bytes), or
+//   as tiles   one item per 16-row tile that holds an allowed row, its other rows flagged (streamed: ~5.8 TB/s),
+// whichever moves fewer bytes per unit of bandwidth: compacted when allowed rows x gather_num < tile rows x gather_den
+// (MSI_VS_GATHER_PCT, default 250 = 2.5: below ~40 % density on uniform filters; 0: always, >= 1600: never).  One global atomic per workgroup
+// reserves its slice; items land in workgroup arrival order, which only permutes the order rows are visited in.
+// small: [0] items, [1] allowed rows, [2] items written compacted, [3] items written as tiles (msi_vs_filter_stats).
 constexpr int FT_SUB = 8;
-__global__ __launch_bounds__(1024) void vs_filter_tiles_kernel(
+constexpr uint32_t FROW_OFF = 0x80000000u;   // entry flag: the row is not allowed (padding: every bit set)
+__device__ __forceinline__ uint32_t frow_id(uint32_t e) { return e == 0xFFFFFFFFu ? 0u : (e & 0x7FFFFFFFu); }
+__device__ __forceinline__ uint32_t frow_safe(uint32_t e) { return (e >> 31) ? 0u : e; }   // (per-row arrays are not padded to tiles)
+__global__ __launch_bounds__(1024) void vs_filter_rows_kernel(
     const uint32_t *__restrict__ docids, uint64_t n_rows, const u64 *__restrict__ fbits,
-    uint64_t nbits, uint16_t *__restrict__ tmask, uint32_t *__restrict__ list,
-    uint32_t *__restrict__ n_items) {
-  __shared__ uint32_t s_cnt[FT_SUB * 16];
-  __shared__ uint32_t s_base;
+    uint64_t nbits, uint32_t *__restrict__ rows, uint32_t *__restrict__ small, uint32_t gather_num, uint32_t gather_den) {
+  __shared__ uint32_t s_rows[FT_SUB * 16], s_tiles[FT_SUB * 16];
+  __shared__ uint32_t s_base, s_compact, s_total, s_items;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t padded = ((n_rows + 15) / 16) * 16;
   const uint64_t blk_row0 = (uint64_t)blockIdx.x * (1024ull * FT_SUB);
@@ -348,33 +357,56 @@ __global__ __launch_bounds__(1024) void vs_filter_tiles_kernel(
     uint32_t c = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) c += ((b >> (16 * t)) & 0xFFFFull) != 0;
-    if (lane == 0) s_cnt[u * 16 + wave] = c;
+    if (lane == 0) {
+      s_tiles[u * 16 + wave] = c;
+      s_rows[u * 16 + wave] = (uint32_t)__popcll(b);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t tot = 0;
+    uint32_t tot_t = 0, tot_r = 0;
     for (int i = 0; i < FT_SUB * 16; ++i) {
-      const uint32_t c = s_cnt[i];
-      s_cnt[i] = tot;
-      tot += c;
+      const uint32_t ct = s_tiles[i], cr = s_rows[i];
+      s_tiles[i] = tot_t;
+      s_rows[i] = tot_r;
+      tot_t += ct;
+      tot_r += cr;
     }
-    s_base = tot ? atomicAdd(n_items, tot) : 0;
+    const bool compact = (u64)tot_r * gather_num < (u64)tot_t * 16ull * gather_den;
+    const uint32_t items = compact ? (tot_r + 15) / 16 : tot_t;
+    s_compact = compact ? 1u : 0u;
+    s_total = tot_r;
+    s_items = items;
+    s_base = items ? atomicAdd(&small[0], items) : 0;
+    if (items) {
+      atomicAdd(&small[1], tot_r);
+      atomicAdd(&small[compact ? 2 : 3], items);
+    }
   }
   __syncthreads();
-  const uint32_t base = s_base;
+  const uint64_t base = (uint64_t)s_base * 16;
+  if (s_compact) {
+#pragma unroll
+    for (int u = 0; u < FT_SUB; ++u) {
+      const u64 b = bal[u];
+      if ((b >> lane) & 1ull) {
+        const uint64_t r = blk_row0 + (uint64_t)u * 1024 + threadIdx.x;
+        const uint32_t pos = s_rows[u * 16 + wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        rows[base + pos] = (uint32_t)r;
+      }
+    }
+    for (uint32_t i = s_total + threadIdx.x; i < s_items * 16; i += 1024) rows[base + i] = 0xFFFFFFFFu;
+    return;
+  }
   const uint32_t ts = lane >> 4;  // tile slot of this lane inside the wave-row
 #pragma unroll
   for (int u = 0; u < FT_SUB; ++u) {
     const uint64_t r = blk_row0 + (uint64_t)u * 1024 + threadIdx.x;
-    if (r < padded && (lane & 15) == 0) {
-      const u64 b = bal[u];
-      const uint16_t m = (uint16_t)((b >> (16 * ts)) & 0xFFFFull);
-      tmask[r >> 4] = m;
-      if (m) {
-        uint32_t before = 0;
-        for (uint32_t t = 0; t < ts; ++t) before += ((b >> (16 * t)) & 0xFFFFull) != 0;
-        list[base + s_cnt[u * 16 + wave] + before] = (uint32_t)(r >> 4);
-      }
+    const u64 b = bal[u];
+    if (r < padded && ((b >> (16 * ts)) & 0xFFFFull)) {
+      uint32_t before = 0;
+      for (uint32_t t = 0; t < ts; ++t) before += ((b >> (16 * t)) & 0xFFFFull) != 0;
+      rows[base + (uint64_t)(s_tiles[u * 16 + wave] + before) * 16 + (lane & 15)] = (uint32_t)r | (((b >> lane) & 1ull) ? 0u : FROW_OFF);
     }
   }
 }
@@ -387,9 +419,8 @@ struct ScanArgs {
   const float4 *qfrag;           // [nqt][KB][64]
   const float *theta;            // [NQ_MAX] sparse: pass if !(score < theta)
   const float *degth;            // [NQ_MAX]
-  const uint32_t *n_items_ptr;   // number of entries of `list` (or tiles when list==null)
-  const uint32_t *list;          // nullable: active tile ids
-  const uint16_t *tmask;         // nullable: per-tile allowed-row masks
+  const uint32_t *n_items_ptr;   // number of items: 16-entry groups of `rows` (tiles of the store when rows == null)
+  const uint32_t *rows;          // nullable (FILT): the items of a filtered sweep, vs_filter_rows_kernel
   u64 *gkeys;                    // sparse: [NQ_MAX][capg]
   uint32_t *gcnt;                // sparse: [NQ_MAX][CNT_PAD]
   uint32_t *overflow;            // set to 1 if a global list overflowed
@@ -414,7 +445,9 @@ struct ScanArgs {
 //          the bf16 A operands, x·(q_hi + q_lo) needs 2 MFMAs per 32 columns and no
 //          conversion; LDS holds q_hi and q_lo (2 KiB per 32 columns and query tile).
 // MATH: 0 = f32 MFMA, 1 = bf16x3 (hi.hi + hi.lo + lo.hi), 2 = bf16x2 (row hi/lo x query hi: half the LDS per query)
-template <int WAVES, int NQT, bool DENSE, int MATH, bool S16>
+// FILT: the sweep visits the items of `a.rows` — lane (i, g) gathers the pieces of row rows[16 item + i] (a 64-byte sector per
+// row and KiB block), the epilogue reads the rows' ids, flags and inverse norms through the same list
+template <int WAVES, int NQT, bool DENSE, int MATH, bool S16, bool FILT>
 __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   MSI_DYNAMIC_LDS(smem);
   const uint32_t tid = threadIdx.x;
@@ -446,19 +479,29 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
 
   const uint32_t GPT = KB / SCAN_GROUP;  // pipeline groups per tile
 
-  auto tile_of = [&](uint32_t it) -> uint32_t {
-    const uint32_t idx = it * a.stride;
-    return a.list ? a.list[idx] : idx;
-  };
+  auto tile_of = [&](uint32_t it) -> uint32_t { return it * a.stride; };
 
   // ---- epilogue -----------------------------------------------------------------
   auto epilogue = [&](uint32_t tile, uint32_t it, const f32x4(&acc)[NQT][2]) {
     const uint64_t row0 = (uint64_t)tile * 16 + g * 4;
-    const float4 inv = *reinterpret_cast<const float4 *>(a.inv_norm + row0);
     uint32_t allowed = 0xF;
-    if (a.tmask) allowed = (a.tmask[tile] >> (g * 4)) & 0xF;
-    else if (row0 + 4 > a.n_rows) allowed = row0 >= a.n_rows ? 0u : ((1u << (a.n_rows - row0)) - 1u);
-    const float iv[4] = {inv.x, inv.y, inv.z, inv.w};
+    uint32_t ids[4] = {(uint32_t)row0, (uint32_t)row0 + 1u, (uint32_t)row0 + 2u, (uint32_t)row0 + 3u};
+    float iv[4];
+    if constexpr (FILT) {
+      const uint4 e4 = *reinterpret_cast<const uint4 *>(a.rows + (uint64_t)tile * 16 + g * 4);   // (tile: the item's place in the list)
+      const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+      allowed = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ids[r] = frow_id(ee[r]);
+        if (!(ee[r] >> 31)) allowed |= 1u << r;
+        iv[r] = (ee[r] >> 31) ? 0.f : a.inv_norm[ids[r]];
+      }
+    } else {
+      const float4 inv = *reinterpret_cast<const float4 *>(a.inv_norm + row0);
+      if (row0 + 4 > a.n_rows) allowed = row0 >= a.n_rows ? 0u : ((1u << (a.n_rows - row0)) - 1u);
+      iv[0] = inv.x, iv[1] = inv.y, iv[2] = inv.z, iv[3] = inv.w;
+    }
 #pragma unroll
     for (int t = 0; t < NQT; ++t) {
       float s[4];
@@ -489,7 +532,7 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (pass & (1u << r)) {
-              if (slot < a.capg) a.gkeys[(uint64_t)q * a.capg + slot] = make_key_desc(s[r], (uint32_t)(row0 + r));
+              if (slot < a.capg) a.gkeys[(uint64_t)q * a.capg + slot] = make_key_desc(s[r], ids[r]);
               else *a.overflow = 1;
               ++slot;
             }
@@ -512,15 +555,35 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_kernel(ScanArgs a) {
   uint32_t tile_load = tile_of(it_load);
   uint32_t tile_cmp = tile_load;
 
+  // FILT: where this lane's row of the item being loaded starts (its piece of block 0)
+  // (the NEXT item's entry is requested when an item's loads begin: the list read is off the address path)
+  const float4 *row_load = a.tiles;
+  uint32_t entry_next = 0;
+  auto entry_of = [&](uint32_t item) -> uint32_t { return a.rows[(uint64_t)item * 16 + (lane & 15u)]; };
+  auto row_ptr_of = [&](uint32_t entry) -> const float4 * {
+    const uint32_t row = frow_id(entry);
+    return a.tiles + (uint64_t)(row >> 4) * KB * 64 + MSI_TILE_PIECE(row & 15u, lane >> 4);
+  };
+  if constexpr (FILT) {
+    row_load = row_ptr_of(entry_of(tile_load));
+    if (it_load + 1 < it1) entry_next = entry_of(tile_of(it_load + 1));
+  }
   auto load_group = [&](float4(&x)[SCAN_GROUP]) {
     // (lane l holds row l & 15, column group l >> 4 of the block: MSI_TILE_PIECE says where that piece lives)
-    const float4 *p = a.tiles + ((uint64_t)tile_load * KB + (uint64_t)sub_load * SCAN_GROUP) * 64 + MSI_TILE_PIECE(lane & 15u, lane >> 4);
+    const float4 *p = FILT ? row_load + (uint64_t)sub_load * SCAN_GROUP * 64
+                           : a.tiles + ((uint64_t)tile_load * KB + (uint64_t)sub_load * SCAN_GROUP) * 64 + MSI_TILE_PIECE(lane & 15u, lane >> 4);
 #pragma unroll
     for (int u = 0; u < SCAN_GROUP; ++u) x[u] = MSI_VS_STREAM_LOAD(p + u * 64);
     if (++sub_load == GPT) {
       sub_load = 0;
       ++it_load;
-      if (it_load < it1) tile_load = tile_of(it_load);
+      if (it_load < it1) {
+        tile_load = tile_of(it_load);
+        if constexpr (FILT) {
+          row_load = row_ptr_of(entry_next);
+          if (it_load + 1 < it1) entry_next = entry_of(tile_of(it_load + 1));
+        }
+      }
     }
   };
   auto compute_group = [&](const float4(&x)[SCAN_GROUP]) {
@@ -662,6 +725,10 @@ struct Scan8Args {
   const float *theta;
   const float *degth;
   const uint32_t *n_items_ptr;
+  const uint32_t *rows;          // nullable (FILT): the items of a filtered sweep, as ScanArgs::rows
+  // Rounds 1-5's tile list and allowed-row masks of a filtered sweep: ALWAYS null since round 6 (filtered sweeps go through
+  // `rows`).  They stay because the unfiltered kernel's code depends on their uniform branches: without them the same source
+  // compiles to 256 registers and 22 spilled ones instead of 230 and none (llvm's scheduling of the epilogue; tools/isa_excerpt.py)
   const uint32_t *list;
   const uint16_t *tmask;
   u64 *gkeys;
@@ -676,9 +743,32 @@ struct Scan8Args {
   uint32_t nq;
 };
 
-// f32 tiles -> the int8 copy, one workgroup of 256 threads per tile: thread (i = tid & 15, c = tid >> 4) works on row i,
-// 16-column chunks c, c + 16, ...
-__global__ __launch_bounds__(256) void vs_quantize_rows_kernel(const float4 *__restrict__ tiles, const float *__restrict__ inv_norm,
+// the 16 consecutive columns 16m .. 16m + 15 of row i of a tile: KiB block m of an f32 tile (four pieces), half of KiB block
+// m / 2 of a bf16 tile (two pieces of eight)
+template <bool S16>
+__device__ __forceinline__ void vs_row_chunk16(const void *__restrict__ tile_base, uint32_t i, uint32_t m, float (&e)[16]) {
+  if constexpr (S16) {
+    const bf16x8 *base = reinterpret_cast<const bf16x8 *>(tile_base) + (uint64_t)(m >> 1) * 64;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bf16x8 v = base[MSI_TILE_PIECE(i, (m & 1u) * 2u + (uint32_t)h)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[h * 8 + j] = (float)v[j];
+    }
+  } else {
+    const float4 *base = reinterpret_cast<const float4 *>(tile_base) + (uint64_t)m * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = base[MSI_TILE_PIECE(i, (uint32_t)g)];
+      e[g * 4] = v.x, e[g * 4 + 1] = v.y, e[g * 4 + 2] = v.z, e[g * 4 + 3] = v.w;
+    }
+  }
+}
+
+// f32 / bf16 tiles -> the int8 copy, one workgroup of 256 threads per tile: thread (i = tid & 15, c = tid >> 4) works on row
+// i, 16-column chunks c, c + 16, ...  (KB: KiB blocks of the source tile — dpad / 16 of f32 rows, dpad / 32 of bf16 rows)
+template <bool S16>
+__global__ __launch_bounds__(256) void vs_quantize_rows_kernel(const void *__restrict__ tiles, const float *__restrict__ inv_norm,
                                                                uint64_t n_rows, uint32_t KB, i32x4 *__restrict__ tiles8,
                                                                float *__restrict__ scale8, uint32_t *__restrict__ ex_max_ord) {
   __shared__ float s_red[16][17];
@@ -688,22 +778,21 @@ __global__ __launch_bounds__(256) void vs_quantize_rows_kernel(const float4 *__r
   const uint64_t t = blockIdx.x;
   const uint64_t r = t * 16 + i;
   const float inv = r < n_rows ? inv_norm[r] : 0.f;
-  const uint32_t KB8 = KB / 4;
+  const uint32_t NM = S16 ? KB * 2 : KB;   // 16-column chunks of a row
+  const uint32_t KB8 = NM / 4;
   if (tid < 16) s_bad[tid] = 0;
   __syncthreads();
-  const float4 *base = tiles + t * KB * 64;
+  const void *base = reinterpret_cast<const char *>(tiles) + t * KB * 1024;
   float amax = 0.f;
   bool bad = !(inv == inv) || inv == INFINITY;
-  for (uint32_t m = c; m < KB; m += 16) {
+  for (uint32_t m = c; m < NM; m += 16) {
+    float x[16];
+    vs_row_chunk16<S16>(base, i, m, x);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 v = base[(uint64_t)m * 64 + MSI_TILE_PIECE(i, (uint32_t)g)];
-      const float e[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (!(fabsf(e[j]) <= FLT_MAX)) bad = true;   // NaN or infinity
-        amax = fmaxf(amax, fabsf(e[j]));
-      }
+    for (int j = 0; j < 16; ++j) {
+      const float e = x[j] * inv;
+      if (!(fabsf(e) <= FLT_MAX)) bad = true;   // NaN or infinity
+      amax = fmaxf(amax, fabsf(e));
     }
   }
   if (bad) s_bad[i] = 1;
@@ -720,27 +809,25 @@ __global__ __launch_bounds__(256) void vs_quantize_rows_kernel(const float4 *__r
   const float sx = rmax > 0.f ? rmax / 127.0f : 0.f;
   const float isx = rmax > 0.f ? 127.0f / rmax : 0.f;
   float res = 0.f;
-  for (uint32_t m = c; m < KB; m += 16) {
+  for (uint32_t m = c; m < NM; m += 16) {
     int q[16];
+    float x[16];
+    vs_row_chunk16<S16>(base, i, m, x);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 v = base[(uint64_t)m * 64 + MSI_TILE_PIECE(i, (uint32_t)g)];
-      const float e[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float qf = rintf(e[j] * isx);
-        qf = fminf(127.f, fmaxf(-127.f, qf));
-        if (row_bad) qf = 0.f;
-        const float d = __fsub_rn(e[j], __fmul_rn(sx, qf));
-        res = __fadd_rn(res, __fmul_rn(d, d));
-        q[g * 4 + j] = (int)qf;
-      }
+    for (int j = 0; j < 16; ++j) {
+      const float e = x[j] * inv;
+      float qf = rintf(e * isx);
+      qf = fminf(127.f, fmaxf(-127.f, qf));
+      if (row_bad) qf = 0.f;
+      const float d = __fsub_rn(e, __fmul_rn(sx, qf));
+      res = __fadd_rn(res, __fmul_rn(d, d));
+      q[j] = (int)qf;
     }
     i32x4 w;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       w[g] = (q[4 * g] & 255) | ((q[4 * g + 1] & 255) << 8) | ((q[4 * g + 2] & 255) << 16) | ((q[4 * g + 3] & 255) << 24);
-    tiles8[(t * KB8 + (m >> 2)) * 64 + (m & 3) * 16 + i] = w;
+    tiles8[(t * KB8 + (m >> 2)) * 64 + MSI_TILE_PIECE(i, m & 3u)] = w;
   }
   __syncthreads();
   s_red[i][c] = res;
@@ -822,7 +909,7 @@ __global__ __launch_bounds__(256) void vs_prep_queries_i8_kernel(const float *__
 }
 
 // NQT 16-query tiles per sweep, RT row tiles per wave and step, GS KiB-blocks per software-pipeline stage (GS divides KB8).
-template <int WAVES, int NQT, int RT, int GS, bool DENSE>
+template <int WAVES, int NQT, int RT, int GS, bool DENSE, bool FILT>
 __global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
   MSI_DYNAMIC_LDS(smem);
   const uint32_t tid = threadIdx.x;
@@ -871,19 +958,36 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
   if (it0 >= it1) return;
   const uint32_t GPT = KB8 / GS;
 
+  // (FILT: the "tile" of an item is its place in the list of items, a.rows + 16 tile)
   auto tile_of = [&](uint32_t it) -> uint32_t {
     const uint32_t idx = (it < it1 ? it : it1 - 1) * a.stride;   // (the last group of a wave may be short: its spare slots re-read the last tile)
+    if constexpr (FILT) return idx;
     return a.list ? a.list[idx] : idx;
   };
 
   auto epilogue = [&](uint32_t tile, uint32_t it, const i32x4(&acc)[NQT], const float4 sc) {
     const uint64_t row0 = (uint64_t)tile * 16 + g * 4;
-    float4 inv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (check_deg) inv = *reinterpret_cast<const float4 *>(a.inv_norm + row0);
     uint32_t allowed = 0xF;
-    if (a.tmask) allowed = (a.tmask[tile] >> (g * 4)) & 0xF;
-    else if (row0 + 4 > a.n_rows) allowed = row0 >= a.n_rows ? 0u : ((1u << (a.n_rows - row0)) - 1u);
-    const float iv[4] = {inv.x, inv.y, inv.z, inv.w};
+    uint32_t fids[4] = {0u, 0u, 0u, 0u};   // FILT: the rows' indices (else row0 + r)
+    float iv[4] = {0.f, 0.f, 0.f, 0.f};
+    auto id_of = [&](int r) -> uint32_t { return FILT ? fids[r] : (uint32_t)(row0 + r); };
+    if constexpr (FILT) {
+      const uint4 e4 = *reinterpret_cast<const uint4 *>(a.rows + (uint64_t)tile * 16 + g * 4);
+      const uint32_t ee[4] = {e4.x, e4.y, e4.z, e4.w};
+      allowed = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        fids[r] = frow_id(ee[r]);
+        if (!(ee[r] >> 31)) allowed |= 1u << r;
+        if (check_deg && !(ee[r] >> 31)) iv[r] = a.inv_norm[fids[r]];
+      }
+    } else {
+      float4 inv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (check_deg) inv = *reinterpret_cast<const float4 *>(a.inv_norm + row0);
+      if (a.tmask) allowed = (a.tmask[tile] >> (g * 4)) & 0xF;
+      else if (row0 + 4 > a.n_rows) allowed = row0 >= a.n_rows ? 0u : ((1u << (a.n_rows - row0)) - 1u);
+      iv[0] = inv.x, iv[1] = inv.y, iv[2] = inv.z, iv[3] = inv.w;
+    }
     const float sx[4] = {sc.x, sc.y, sc.z, sc.w};
     if (!DENSE && !check_deg) {
       // The common case of the full sweep, three instructions per score: convert, scale by the row, compare with the query's
@@ -917,7 +1021,7 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 if (keep & (1u << r)) {
-                  if (slot < a.capg) a.gkeys[(uint64_t)q * a.capg + slot] = make_key_desc(sv[r], (uint32_t)(row0 + r));
+                  if (slot < a.capg) a.gkeys[(uint64_t)q * a.capg + slot] = make_key_desc(sv[r], id_of(r));
                   else *a.overflow = 1;
                   ++slot;
                 }
@@ -959,7 +1063,7 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (pass & (1u << r)) {
-              if (slot < a.capg) a.gkeys[(uint64_t)q * a.capg + slot] = make_key_desc(s[r], (uint32_t)(row0 + r));
+              if (slot < a.capg) a.gkeys[(uint64_t)q * a.capg + slot] = make_key_desc(s[r], id_of(r));
               else *a.overflow = 1;
               ++slot;
             }
@@ -988,14 +1092,35 @@ __global__ __launch_bounds__(WAVES * 64) void vs_scan_i8_kernel(Scan8Args a) {
 #pragma unroll
   for (int r = 0; r < RT; ++r) sca[r] = scb[r] = scc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // FILT: where this lane's row of each item being loaded starts (its piece of block 0); an item's entries are read when its
+  // first stage is requested (the rows' ids for the loads, the four rows of the lane's D fragment for their scales)
+  const uint32_t piece_of_lane = MSI_TILE_PIECE(lane & 15u, lane >> 4);   // (where this lane's piece of a KiB block lives)
+  const i32x4 *rowp[FILT ? RT : 1];
+  if constexpr (FILT) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r) rowp[r] = a.tiles8;
+  }
   auto load_group = [&](i32x4(&x)[GS][RT], float4(&scn)[RT]) {
     if (sub_load == 0) {
 #pragma unroll
-      for (int r = 0; r < RT; ++r) scn[r] = *reinterpret_cast<const float4 *>(a.scale8 + (uint64_t)tl[r] * 16 + g * 4);
+      for (int r = 0; r < RT; ++r) {
+        if constexpr (FILT) {
+          const uint32_t *ent = a.rows + (uint64_t)tl[r] * 16;
+          const uint32_t row = frow_id(ent[lane & 15u]);
+          rowp[r] = a.tiles8 + (uint64_t)(row >> 4) * KB8 * 64 + MSI_TILE_PIECE(row & 15u, lane >> 4);
+          const uint4 e4 = *reinterpret_cast<const uint4 *>(ent + g * 4);
+          // (a row that is not allowed is loaded all the same — it shares its tile's sectors — but nobody reads its score)
+          scn[r] = make_float4(a.scale8[frow_safe(e4.x)], a.scale8[frow_safe(e4.y)], a.scale8[frow_safe(e4.z)], a.scale8[frow_safe(e4.w)]);
+        } else {
+          scn[r] = *reinterpret_cast<const float4 *>(a.scale8 + (uint64_t)tl[r] * 16 + g * 4);
+        }
+      }
     }
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-      const i32x4 *p = a.tiles8 + ((uint64_t)tl[r] * KB8 + (uint64_t)sub_load * GS) * 64 + lane;
+      const i32x4 *p;
+      if constexpr (FILT) p = rowp[r] + (uint64_t)sub_load * GS * 64;
+      else p = a.tiles8 + ((uint64_t)tl[r] * KB8 + (uint64_t)sub_load * GS) * 64 + piece_of_lane;
 #pragma unroll
       for (int u = 0; u < GS; ++u) x[u][r] = vs_stream_load_i8(p + u * 64);
     }
@@ -1110,7 +1235,7 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t v) {
 struct KeySrc {
   const u64 *keys;
   const float *dense;
-  const uint32_t *list;
+  const uint32_t *rows;   // nullable: the items of a filtered sweep (vs_filter_rows_kernel)
   uint32_t stride;
   uint32_t base = 0;   // dense: entry i of this source is entry base + i of the row (vs_select_part_kernel's slices)
   __device__ __forceinline__ u64 get(uint32_t i) const {
@@ -1119,8 +1244,7 @@ struct KeySrc {
     const float s = dense[i];
     if (s == -INFINITY) return ~0ull;
     const uint32_t item = (i >> 4) * stride;
-    const uint32_t tile = list ? list[item] : item;
-    return make_key_desc(s, tile * 16 + (i & 15));
+    return make_key_desc(s, rows ? frow_id(rows[(uint64_t)item * 16 + (i & 15)]) : item * 16 + (i & 15));
   }
 };
 
@@ -1264,7 +1388,7 @@ struct SelectArgs {
   const float *dense;          // [NQ_MAX][dstride]; null = sparse input
   uint32_t dstride;
   const uint32_t *n_items_ptr;
-  const uint32_t *list;
+  const uint32_t *rows;
   uint32_t stride;
   // output
   uint32_t K;                  // mode 0: the threshold rank r, mode 1: K'
@@ -1286,14 +1410,14 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_select_kernel(SelectArgs a) {
   if (a.dense) {
     src.keys = nullptr;
     src.dense = a.dense + (uint64_t)j * a.dstride;
-    src.list = a.list;
+    src.rows = a.rows;
     src.stride = a.stride;
     const uint32_t n_all = *a.n_items_ptr;
     c = ((n_all + a.stride - 1) / a.stride) * 16;
   } else {
     src.keys = a.gkeys + (uint64_t)j * a.capg;
     src.dense = nullptr;
-    src.list = nullptr;
+    src.rows = nullptr;
     src.stride = 1;
     c = a.fixed_c ? a.fixed_c : a.gcnt[j * CNT_PAD];
     if (c > a.capg) c = a.capg;
@@ -1325,7 +1449,7 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_select_part_kernel(SelectArgs 
   KeySrc src;
   src.keys = nullptr;
   src.dense = a.dense + (uint64_t)j * a.dstride;
-  src.list = a.list;
+  src.rows = a.rows;
   src.stride = a.stride;
   src.base = lo;
   const uint32_t got = block_select_smallest(src, hi - lo, a.K, sbuf, hist, sh);
@@ -1781,7 +1905,7 @@ __global__ __launch_bounds__(SEL_THREADS) void vs_exhaustive_select_kernel(
   KeySrc src;
   src.keys = keys;
   src.dense = nullptr;
-  src.list = nullptr;
+  src.rows = nullptr;
   src.stride = 1;
   const uint32_t got = block_select_smallest(src, c, k, sbuf, hist, sh);
   __syncthreads();
@@ -1868,7 +1992,7 @@ struct msi_vs {
   DevBuf tiles_next, docids_next, norm_next, inv_norm_next, add_tiles, add_docids, row_map;  // msi_vs_update builds the next store beside the current one
   std::vector<uint32_t> h_docids;  // for get_vector's binary search
   // scratch (guarded by ctx->mu)
-  DevBuf qraw, qfrag, qfrag_bf, qfrag8, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, tmask, tlist, fsmall, fbits, out_docids,
+  DevBuf qraw, qfrag, qfrag_bf, qfrag8, qrow, qsmall, gkeys, gcnt, gsmall, sel_keys, dense, frows, fsmall, fbits, out_docids,
       out_dist, exh_keys, rowtmp, resc_keys, rerun_q, rerun_flags, thr;
   // the second scratch set and stream of the device entry point's pipeline (msi_vs_search_device): allocated on first use
   struct Scratch2 {
@@ -1880,7 +2004,7 @@ struct msi_vs {
   uint32_t capg = 0;
   uint32_t scan_grid = 0, scan_grid8 = 0;
   // stats
-  uint64_t scan_launches = 0, scan_tiles = 0, exhaustive_reruns = 0;
+  uint64_t scan_launches = 0, scan_tiles = 0, exhaustive_reruns = 0, filtered_calls = 0;
   // How a query is proven adapts to the data (host entry point).  The proof needs every row whose fast score lies within
   // 2 x eps of the k-th neighbour among the K' rescored candidates; eps is a WORST-CASE bound (3.9e-3 in cosine for bf16x2,
   // 2.9e-4 for bf16x3 at d = 768: the f32 accumulation bound dominates) — on i.i.d. rows a few dozen rows lie that close and
@@ -2082,8 +2206,12 @@ int32_t finish_upload(msi_vs *vs, uint64_t n_rows, const char *what) {
   }
   if (vs->i8) {
     MSI_HIP_TRY(hipMemsetAsync(vs->i8small.p, 0, 64, st));
-    if (n_tiles)
-      hipLaunchKernelGGL(vs_quantize_rows_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, vs->tiles.as<float4>(),
+    if (n_tiles && vs->s16)
+      hipLaunchKernelGGL(vs_quantize_rows_kernel<true>, dim3((uint32_t)n_tiles), dim3(256), 0, st, (const void *)vs->tiles.p,
+                         vs->inv_norm.as<float>(), n_rows, vs->KB, vs->tiles8.as<i32x4>(), vs->scale8.as<float>(),
+                         vs->i8small.as<uint32_t>());
+    else if (n_tiles)
+      hipLaunchKernelGGL(vs_quantize_rows_kernel<false>, dim3((uint32_t)n_tiles), dim3(256), 0, st, (const void *)vs->tiles.p,
                          vs->inv_norm.as<float>(), n_rows, vs->KB, vs->tiles8.as<i32x4>(), vs->scale8.as<float>(),
                          vs->i8small.as<uint32_t>());
   }
@@ -2121,8 +2249,11 @@ void launch_scan(msi_vs *vs, const ScanArgs &sa, uint32_t nqt, bool dense, hipSt
   const size_t lds = scan_lds_bytes(vs->KB, nqt, vs->s16, vs->bf2);
   const dim3 grid(grid_wgs ? grid_wgs : vs->scan_grid), block(SCAN_WAVES * 64);
   if (!st) st = vs->ctx->stream;
-#define MSI_SCAN_LAUNCH(N, D, B, S) \
-  hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, D, B, S>), grid, block, lds, st, sa)
+#define MSI_SCAN_LAUNCH(N, D, B, S)                                                                            \
+  do {                                                                                                         \
+    if (sa.rows) hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, D, B, S, true>), grid, block, lds, st, sa); \
+    else hipLaunchKernelGGL((vs_scan_kernel<SCAN_WAVES, N, D, B, S, false>), grid, block, lds, st, sa);        \
+  } while (0)
 #define MSI_SCAN_CASE(N)                                              \
   case N:                                                             \
     if (vs->s16) {                                                    \
@@ -2171,8 +2302,10 @@ uint32_t scan8_gs_of(uint32_t KB8) { return KB8 % 4 == 0 ? 4u : (KB8 % 3 == 0 ? 
 template <int GS>
 int32_t scan8_set_attributes() {
 #define MSI_X(N)                                                                                                          \
-  for (const void *fn : {reinterpret_cast<const void *>(&vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, true>),      \
-                         reinterpret_cast<const void *>(&vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, false>)})    \
+  for (const void *fn : {reinterpret_cast<const void *>(&vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, true, false>),      \
+                         reinterpret_cast<const void *>(&vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, false, false>),     \
+                         reinterpret_cast<const void *>(&vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, true, true>),       \
+                         reinterpret_cast<const void *>(&vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, false, true>)})     \
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) return MSI_E_HIP;
   MSI_SCAN8_EACH(MSI_X)
 #undef MSI_X
@@ -2183,8 +2316,11 @@ void launch_scan8_gs(const Scan8Args &sa, uint32_t n, bool dense, dim3 grid, dim
   switch (n) {
 #define MSI_X(N)                                                                                                         \
   case N:                                                                                                                \
-    if (dense) hipLaunchKernelGGL((vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, true>), grid, block, lds, st, sa); \
-    else hipLaunchKernelGGL((vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, false>), grid, block, lds, st, sa);      \
+    if (sa.rows) {                                                                                                       \
+      if (dense) hipLaunchKernelGGL((vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, true, true>), grid, block, lds, st, sa);   \
+      else hipLaunchKernelGGL((vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, false, true>), grid, block, lds, st, sa);        \
+    } else if (dense) hipLaunchKernelGGL((vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, true, false>), grid, block, lds, st, sa); \
+    else hipLaunchKernelGGL((vs_scan_i8_kernel<SCAN_WAVES, N, MSI_SCAN8_RT(N), GS, false, false>), grid, block, lds, st, sa);      \
     break;
     MSI_SCAN8_EACH(MSI_X)
 #undef MSI_X
@@ -2194,20 +2330,21 @@ void launch_scan8_gs(const Scan8Args &sa, uint32_t n, bool dense, dim3 grid, dim
 // workgroup, row tiles per wave step, KiB blocks per pipeline stage.  0 / unset: the default shape.
 #define MSI_SCAN8_VARIANTS(X) X(1, 16, 1, 4) X(2, 8, 1, 4) X(3, 8, 2, 2) X(4, 16, 1, 2) X(5, 16, 2, 2) X(6, 8, 4, 2) X(7, 16, 2, 1)
 bool launch_scan8_variant(int variant, uint32_t KB8, const Scan8Args &sa, bool dense, uint32_t n_wg, size_t lds, hipStream_t st) {
+  if (sa.rows) return false;   // (the experiments' shapes exist for unfiltered sweeps only)
   switch (variant) {
 #define MSI_X(V, W, R, G)                                                                                                 \
   case V: {                                                                                                               \
     if (KB8 % G) return false;                                                                                            \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vs_scan_i8_kernel<W, 8, R, G, true>),                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vs_scan_i8_kernel<W, 8, R, G, true, false>),                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vs_scan_i8_kernel<W, 8, R, G, false>),                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vs_scan_i8_kernel<W, 8, R, G, false, false>),                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);                                \
       attr = true;                                                                                                        \
     }                                                                                                                     \
-    if (dense) hipLaunchKernelGGL((vs_scan_i8_kernel<W, 8, R, G, true>), dim3(n_wg), dim3(W * 64), lds, st, sa);            \
-    else hipLaunchKernelGGL((vs_scan_i8_kernel<W, 8, R, G, false>), dim3(n_wg), dim3(W * 64), lds, st, sa);                \
+    if (dense) hipLaunchKernelGGL((vs_scan_i8_kernel<W, 8, R, G, true, false>), dim3(n_wg), dim3(W * 64), lds, st, sa);            \
+    else hipLaunchKernelGGL((vs_scan_i8_kernel<W, 8, R, G, false, false>), dim3(n_wg), dim3(W * 64), lds, st, sa);                \
     return true;                                                                                                          \
   }
     MSI_SCAN8_VARIANTS(MSI_X)
@@ -2257,17 +2394,25 @@ struct Chunk {
   uint32_t grid_main = 0, grid_sample = 0;   // 0 = the store's grid (one workgroup per CU); the pipeline sets both
 };
 
-// the allowed-row masks and the list of tiles that hold an allowed row (the same for every chunk of a call)
+// the items a filtered sweep visits (vs_filter_rows_kernel; the same for every chunk of a call)
 int32_t enqueue_filter(msi_vs *vs, const u64 *d_fbits, uint64_t nbits, hipStream_t st) {
-  MSI_TRY(vs->tmask.ensure(vs->n_tiles * sizeof(uint16_t)));
-  MSI_TRY(vs->tlist.ensure(vs->n_tiles * sizeof(uint32_t)));
+  if (vs->n_rows >= 0x7FFFFFFFull) {
+    msi_set_error("msi_vs_search: a candidate filter over a store of 2^31 rows or more is not supported");
+    return MSI_E_UNSUPPORTED;
+  }
+  MSI_TRY(vs->frows.ensure(vs->n_tiles * 16 * sizeof(uint32_t)));
   MSI_TRY(vs->fsmall.ensure(64));
-  MSI_HIP_TRY(hipMemsetAsync(vs->fsmall.p, 0, sizeof(uint32_t), st));
+  MSI_HIP_TRY(hipMemsetAsync(vs->fsmall.p, 0, 4 * sizeof(uint32_t), st));
   const uint64_t padded = vs->n_tiles * 16;
   const uint64_t rows_per_block = 1024ull * FT_SUB;
-  hipLaunchKernelGGL(vs_filter_tiles_kernel, dim3((uint32_t)((padded + rows_per_block - 1) / rows_per_block)),
+  // MSI_VS_GATHER_PCT (read per call; measurements and tests): what a gathered row costs in units of a streamed row, in per
+  // cent (default 250; 0: every region compacts its allowed rows; 1600 and above: none does — rounds 1-5's tile-granular sweep)
+  const char *e = getenv("MSI_VS_GATHER_PCT");
+  const uint32_t pct = e ? (uint32_t)std::max(0, atoi(e)) : 250u;
+  hipLaunchKernelGGL(vs_filter_rows_kernel, dim3((uint32_t)((padded + rows_per_block - 1) / rows_per_block)),
                      dim3(1024), 0, st, vs->docids.as<uint32_t>(), vs->n_rows, d_fbits, nbits,
-                     vs->tmask.as<uint16_t>(), vs->tlist.as<uint32_t>(), vs->fsmall.as<uint32_t>());
+                     vs->frows.as<uint32_t>(), vs->fsmall.as<uint32_t>(), pct, 100u);
+  vs->filtered_calls++;
   return MSI_OK;
 }
 
@@ -2299,12 +2444,10 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
   c.qrow = vs->qrow.as<float>();
   c.qfrag8 = vs->qfrag8.as<i32x4>();
   c.gcnt = vs->gcnt.p;
-  const uint32_t *list = nullptr;
-  const uint16_t *tmask = nullptr;
+  const uint32_t *frows = nullptr;
   const uint32_t *n_items_ptr = s.n_tiles;
   if (filtered) {
-    list = vs->tlist.as<uint32_t>();
-    tmask = vs->tmask.as<uint16_t>();
+    frows = vs->frows.as<uint32_t>();
     n_items_ptr = vs->fsmall.as<uint32_t>();
   }
   // plan: small stores are scored densely in one sweep; larger ones get a dense
@@ -2332,8 +2475,7 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
   sa.theta = s.theta_inf;
   sa.degth = s.degth;
   sa.n_items_ptr = n_items_ptr;
-  sa.list = list;
-  sa.tmask = tmask;
+  sa.rows = frows;
   sa.gkeys = vs->gkeys.as<u64>();
   sa.gcnt = vs->gcnt.as<uint32_t>();
   sa.overflow = s.overflow;
@@ -2355,8 +2497,9 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
     s8.theta = sa.theta;
     s8.degth = sa.degth;
     s8.n_items_ptr = sa.n_items_ptr;
-    s8.list = sa.list;
-    s8.tmask = sa.tmask;
+    s8.rows = sa.rows;
+    s8.list = nullptr;
+    s8.tmask = nullptr;
     s8.gkeys = sa.gkeys;
     s8.gcnt = sa.gcnt;
     s8.overflow = sa.overflow;
@@ -2375,7 +2518,7 @@ int32_t plan_chunk(msi_vs *vs, Chunk &c, const float *d_queries, uint32_t nq, ui
   se.dense = vs->dense.as<float>();
   se.dstride = dstride;
   se.n_items_ptr = n_items_ptr;
-  se.list = list;
+  se.rows = frows;
   se.stride = stride;
   se.sel_keys = vs->sel_keys.as<u64>();
   se.sel_cnt = s.sel_cnt;
@@ -2734,8 +2877,12 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
   }
   DeviceGuard g(ctx->device);
   const void *fns[] = {
-#define MSI_F(N, D, B) reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, B, false>)
-#define MSI_G(N, D) reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, 1, true>)
+#define MSI_F(N, D, B)                                                                     \
+  reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, B, false, false>),      \
+      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, B, false, true>)
+#define MSI_G(N, D)                                                                        \
+  reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, 1, true, false>),       \
+      reinterpret_cast<const void *>(&vs_scan_kernel<SCAN_WAVES, N, D, 1, true, true>)
       MSI_F(1, true, true), MSI_F(1, true, false), MSI_F(1, false, true), MSI_F(1, false, false),
       MSI_F(2, true, true), MSI_F(2, true, false), MSI_F(2, false, true), MSI_F(2, false, false),
       MSI_F(3, true, true), MSI_F(3, true, false), MSI_F(3, false, true), MSI_F(3, false, false),
@@ -2773,7 +2920,9 @@ int32_t msi_vs_create_typed(msi_ctx *ctx, uint32_t dim, int32_t storage, msi_vs 
   // the int8 copy (f32 stores): MSI_VS_I8=0 keeps the store without it; MSI_VS_I8_QUERY_TILES caps the queries per sweep
   {
     const char *e8 = getenv("MSI_VS_I8");
-    vs->i8 = !s16 && !(e8 && e8[0] == '0') && (dpad % 64) == 0 && (uint64_t)dpad * 127ull * 127ull < (1ull << 31);
+    // (round 6: bf16 stores keep the copy too — half the bytes of their rows per sweep; MSI_VS_I8_BF16=0: only f32 stores)
+    const char *e16 = getenv("MSI_VS_I8_BF16");
+    vs->i8 = !(s16 && e16 && e16[0] == '0') && !(e8 && e8[0] == '0') && (dpad % 64) == 0 && (uint64_t)dpad * 127ull * 127ull < (1ull << 31);
     if (vs->i8) {
       vs->KB8 = dpad / 64;
       // 8 query tiles (128 queries) per sweep by default: with 12 the accumulators (2 row tiles x 12 x 4 registers) and the
@@ -2813,8 +2962,8 @@ void msi_vs_destroy(msi_vs *vs) {
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&vs->tiles, &vs->norm, &vs->inv_norm, &vs->docids, &vs->qraw, &vs->qfrag, &vs->qfrag_bf, &vs->qrow,
-                      &vs->qsmall, &vs->gkeys, &vs->gcnt, &vs->gsmall, &vs->sel_keys, &vs->dense, &vs->tmask,
-                      &vs->tlist, &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp, &vs->resc_keys,
+                      &vs->qsmall, &vs->gkeys, &vs->gcnt, &vs->gsmall, &vs->sel_keys, &vs->dense, &vs->frows,
+                      &vs->fbits, &vs->out_docids, &vs->out_dist, &vs->exh_keys, &vs->rowtmp, &vs->resc_keys,
                       &vs->tiles_next, &vs->docids_next, &vs->norm_next, &vs->inv_norm_next, &vs->add_tiles, &vs->add_docids, &vs->row_map,
                       &vs->tiles8, &vs->scale8, &vs->i8small, &vs->qfrag8, &vs->rerun_q, &vs->rerun_flags, &vs->scr2.qfrag8};
     for (DevBuf *b : bufs) b->release();
@@ -3526,6 +3675,20 @@ int32_t msi_vs_scan_time(msi_vs *vs, uint64_t *out_launches, double *out_ms_tota
   DeviceGuard g(vs->ctx->device);
   MSI_HIP_TRY(hipStreamSynchronize(vs->ctx->stream));
   vs->scan_timer.drain(out_launches, out_ms_total);
+  return MSI_OK;
+}
+
+int32_t msi_vs_filter_stats(msi_vs *vs, uint64_t out[4]) {
+  if (!vs || !out) return MSI_E_INVALID;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!vs->filtered_calls || !vs->fsmall.p) return MSI_OK;
+  std::lock_guard<std::mutex> lk(vs->ctx->mu);
+  DeviceGuard g(vs->ctx->device);
+  MSI_HIP_TRY(hipStreamSynchronize(vs->ctx->stream));
+  if (vs->aux_stream) MSI_HIP_TRY(hipStreamSynchronize(vs->aux_stream));
+  uint32_t h[4] = {0, 0, 0, 0};
+  MSI_HIP_TRY(hipMemcpy(h, vs->fsmall.p, sizeof(h), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; ++i) out[i] = h[i];
   return MSI_OK;
 }
 

@@ -145,6 +145,13 @@ class GpuStore:
         check(lib().msi_vs_scan_time(self._h, C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
 
+    def filter_stats(self):
+        """The last filtered search as the device counted it: items visited (16 rows each), allowed rows, items written as
+        compacted allowed rows / as whole tiles (msi_vs_filter_stats)."""
+        o = (C.c_uint64 * 4)()
+        check(lib().msi_vs_filter_stats(self._h, o))
+        return {"items": int(o[0]), "allowed_rows": int(o[1]), "compact_items": int(o[2]), "tile_items": int(o[3])}
+
     def stats(self):
         s = VsStats()
         check(lib().msi_vs_get_stats(self._h, C.byref(s)))

@@ -123,14 +123,16 @@ def test_the_int8_sweep_as_it_was_compiled():
             m = re.search(r"\." + key + r":\s+(\d+)", line)
             if m and name:
                 meta[name][key] = int(m.group(1))
-    # vs_scan_i8_kernel<WAVES = 8, NQT, RT, GS, DENSE = false>: the sparse main pass of the shapes the library launches by default
-    main = {k: v for k, v in meta.items() if "vs_scan_i8_kernelILi8E" in k and k.endswith("Lb0EEEvNS_9Scan8ArgsE")}
+    # vs_scan_i8_kernel<WAVES = 8, NQT, RT, GS, DENSE = false, FILT = false>: the sparse main pass of the shapes the library
+    # launches by default (round 6 added FILT — the row-granular filtered sweep — and the unfiltered kernel kept two always-null
+    # arguments because without their uniform branches the same source spilled 22 registers: Scan8Args::list)
+    main = {k: v for k, v in meta.items() if "vs_scan_i8_kernelILi8E" in k and k.endswith("Lb0ELb0EEEvNS_9Scan8ArgsE")}
     for nqt, rt in ((8, 2), (6, 2), (4, 3)):
         hit = {k: v for k, v in main.items() if f"ILi8ELi{nqt}ELi{rt}ELi" in k}
         assert len(hit) == 3, (nqt, rt, sorted(main))                         # one per pipeline depth GS = 4 / 3 / 2
         for k, v in hit.items():
             assert v["vgpr_count"] <= 256 and v["vgpr_spill_count"] == 0, (k, v)
-    body = asm.split("<_ZN12_GLOBAL__N_117vs_scan_i8_kernelILi8ELi8ELi2ELi4ELb0EEEvNS_9Scan8ArgsE>:")[1].split("s_endpgm")[0]
+    body = asm.split("<_ZN12_GLOBAL__N_117vs_scan_i8_kernelILi8ELi8ELi2ELi4ELb0ELb0EEEvNS_9Scan8ArgsE>:")[1].split("s_endpgm")[0]
     assert body.count("v_mfma_i32_16x16x64_i8") == 8 * 2 * 4 * 2              # NQT x RT x GS, for each of the two row buffers
     loads = [ln for ln in body.split("\n") if "global_load_dwordx4" in ln and " nt" in ln]
     assert len(loads) >= 2 * 4 * 2                                            # RT x GS per buffer, non-temporal

@@ -115,6 +115,52 @@ def test_filtered_search(ctx, oracle, selectivity):
     assert c.tolist() == [0, 0, 0, 0]
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("gather_pct", ["0", "250", "1600"])
+def test_filtered_sweeps_are_row_granular(ctx, oracle, storage, gather_pct, monkeypatch):
+    """Round 6: a filtered sweep visits ITEMS of 16 rows — the allowed rows of a region compacted (gathered at
+    64-byte-sector granularity from the row-sector tiles) or its tiles that hold an allowed row, whichever is cheaper
+    (vs_filter_rows_kernel; MSI_VS_GATHER_PCT: 0 = always compacted, 1600 and above = always tiles as in rounds 1-5).  hannoy's linear
+    mode scores only candidates (vector/store.rs:1079-1080).  Every density x mode against the oracle — the sample pass and
+    the sparse pass (store above 32 768 rows), the int8 level of the f32 store, the bf16 store's f32 levels, a filter
+    denser in one half of the store than in the other (regions decide for themselves), k above the allowed rows — and the
+    device's own count of what it visited."""
+    monkeypatch.setenv("MSI_VS_GATHER_PCT", gather_pct)
+    n, dim = 70000, 128
+    rows = synth.make_embeddings(n, dim, seed=131)
+    if storage == "bf16":
+        rows = synth.round_to_bf16(rows)
+    ids = (np.arange(n, dtype=np.uint32) * 3 + 7).astype(np.uint32)
+    st = ma.GpuStore(ctx, dim, storage=storage)
+    st.upload(ids, rows)
+    qs = synth.make_embeddings(5, dim, seed=132)
+    rng = np.random.default_rng(133)
+    for density in (0.5, 0.1, 0.01, 0.001):
+        keep = rng.random(n) < density
+        if density == 0.1:
+            keep[: n // 2] = rng.random(n // 2) < 0.9     # a dense half and a sparse half
+        allowed = ids[keep]
+        fb, nb = ma.dense_filter(list(allowed), nbits=int(ids[-1]) + 1)
+        check_against_oracle(oracle, st, rows, ids, qs, 20, fb, nb)
+        fs = st.filter_stats()
+        assert fs["allowed_rows"] == allowed.size, (density, fs)
+        assert fs["items"] == fs["compact_items"] + fs["tile_items"]
+        tiles_with_allowed = int(np.count_nonzero(np.add.reduceat(keep.astype(np.int64), np.arange(0, n, 16))))
+        if gather_pct == "1600":
+            assert fs["compact_items"] == 0 and fs["items"] == tiles_with_allowed, (density, fs)
+        elif gather_pct == "0":
+            # every region compacts: at most one padded item per region of 8 192 rows above the allowed rows' own items
+            assert fs["tile_items"] == 0 and fs["items"] <= (allowed.size + 15) // 16 + (n + 8191) // 8192, (density, fs)
+        else:
+            assert fs["items"] <= tiles_with_allowed, (density, fs)
+            if density <= 0.01:
+                assert fs["tile_items"] == 0 and fs["items"] * 16 <= 2 * allowed.size + 16 * ((n + 8191) // 8192), (density, fs)
+    # more neighbours asked for than rows allowed
+    few = ids[rng.choice(n, 11, replace=False)]
+    fb, nb = ma.dense_filter(list(few), nbits=int(ids[-1]) + 1)
+    check_against_oracle(oracle, st, rows, ids, qs, 20, fb, nb)
+
+
 def test_duplicates_zero_rows_and_zero_query(ctx, oracle):
     dim = 48
     base = synth.make_embeddings(50, dim, seed=41)

@@ -27,7 +27,7 @@ def main():
         isa = subprocess.run([BIN + "/llvm-objdump", "-d", "--demangle", co], capture_output=True, text=True, check=True).stdout
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    want = "vs_scan_i8_kernel<8, 8, 2, 4, false>"
+    want = "vs_scan_i8_kernel<8, 8, 2, 4, false, false>"
     # metadata of every int8 sweep instantiation
     print("# code object metadata (llvm-readelf --notes), int8 sweep instantiations of meilisearch_amd/csrc/msi_vs.o")
     blocks = re.split(r"\n\s*- \.agpr_count:", notes)
