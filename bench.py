@@ -918,6 +918,8 @@ def run_c4(args, env):
         import resource
         vs0 = (C.c_uint64 * 6)()
         ma._lib.lib().msi_bits_vm_stats(C.c_void_p(kw["lib"].rb_pool(kw["h"], 0)), vs0)
+        vb0, vb1 = (C.c_uint64 * 3)(), (C.c_uint64 * 3)()
+        ma._lib.lib().msi_bits_vm_bytes(vb0)
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         for _ in range(3):
@@ -937,6 +939,16 @@ def run_c4(args, env):
                                                         "primer queries left)" if kw["stream_steps"] else "of the timed steps (cycled queries)",
                                          "hit_rate_since_the_cache_was_emptied": round(pc[0] / max(1, pc[0] + pc[1]), 4)}
         legs["keyword_lists_per_query"] = round((vs[1] - vs0[1]) / (3.0 * Q), 2)
+        # the leg's ALGORITHMIC denominator: the stored posting bytes a query's decodes read — what milli's
+        # db_cache hands its RoaringBitmaps (db_cache.rs:50-84) — beside what the command lists ask the memory system for (every
+        # operand of every command, whole: dense sets of the docid space or of the search's compact space)
+        ma._lib.lib().msi_bits_vm_bytes(vb1)
+        legs["keyword_algorithmic_bytes_per_query"] = {
+            "stored_posting_bytes_read": round((vb1[1] - vb0[1]) / (3.0 * Q), 1),
+            "set_operand_bytes_of_the_command_lists": round((vb1[0] - vb0[0]) / (3.0 * Q), 1),
+            "operand_bytes_over_posting_bytes": round((vb1[0] - vb0[0]) / max(1.0, float(vb1[1] - vb0[1])), 1),
+            "is": "msi_bits_vm_bytes over the keyword-only passes; the ratio is what dense sets cost over the stored containers "
+                  "(HBM traffic per query measured by PMC: --kw-roofline)"}
         legs["keyword_host_cpu_ms_per_query"] = round(legs["keyword_only_host_cpus_used"] / max(1e-9, legs["keyword_only_queries_per_s"]) * 1e3, 3)
         legs["keyword_cold_posting_cache_queries_per_s"] = kw.get("cold_cache_queries_per_s")
         if kw.get("staged"):
@@ -1720,7 +1732,7 @@ def run_c5(args, env):
     # top-1000 — msi_keyword_search_ranked with the candidate set as its universe, one caller thread per query of the batch.
     # The text index is the coherent corpus of tools/ranked_bench.cpp at this shard's size (200 000-word vocabulary).
     import ctypes as C
-    kw_so = os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so")
+    kw_so = os.environ["MSI_RUNNER_SO"] if env.emulated else os.path.join(ROOT, "tools", "bin", "libmsi_rankedbench.so")
     kwl = C.CDLL(kw_so)
     kwl.rb_create_corpus.restype = C.c_void_p
     kwl.rb_create_corpus.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
@@ -1806,7 +1818,7 @@ def run_c5(args, env):
             "words_typo_fast_path_ms_per_step": round(fast_ms, 4), "words_typo_fast_path_queries_per_s": round(B / (fast_ms * 1e-3), 1),
             "tiles_streamed_per_launch": fstats["items"], "tiles_in_store": (n + 15) // 16,
             "items": dict(fstats, tiles_that_hold_an_allowed_row=allowed_tiles,
-                          is="16-row items a sweep visits: compacted allowed rows (gathered, 64-byte sectors) / whole tiles (streamed)"),
+                          **{"is": "16-row items a sweep visits: compacted allowed rows (gathered, 64-byte sectors) / whole tiles (streamed)"}),
             "scan_tiles_counted_by_the_library": int((st["scan_tiles"] - t0s) / max(1, st["scan_launches"] - l0s)),
             "bytes_streamed_over_allowed_row_bytes": round(algo_bytes / max(1, n_allowed * row_bytes), 2),
             "scan_share_of_the_step": round((scan_ms / max(1, scan_n)) / (elapsed / args.steps * 1e3), 4),
@@ -2010,8 +2022,10 @@ def short_line(full, detail_path=None):
         if isinstance(out["roofline"], dict):
             out["roofline"]["f32_sweep_frac"] = legs["f32_sweep_level"].get("frac_of_8_TBps")
     lg = _pick(legs, ("vector_only_queries_per_s", "keyword_only_queries_per_s", "keyword_only_host_cpus_used",
-                      "keyword_cold_posting_cache_queries_per_s", "keyword_cycled_queries_per_s", "keyword_lists_per_query",
+                      "keyword_cold_posting_cache_queries_per_s", "keyword_cycled_queries_per_s", "keyword_lists_per_query", "keyword_algorithmic_bytes_per_query",
                       "keyword_host_cpu_ms_per_query"))
+    if isinstance(lg.get("keyword_algorithmic_bytes_per_query"), dict):
+        lg["keyword_algorithmic_bytes_per_query"] = {k_: v for k_, v in lg["keyword_algorithmic_bytes_per_query"].items() if k_ != "is"}
     if isinstance(legs.get("keyword_posting_cache"), dict):
         lg["keyword_posting_cache_hit_rate"] = legs["keyword_posting_cache"].get("hit_rate")
     if isinstance(legs.get("keyword_with_features"), dict):

@@ -2803,9 +2803,18 @@ uint32_t vs_levels(const msi_vs *vs, Level out[MAX_LEVELS]) {
 }
 // MSI_VS_FIRST_LEVEL=<n> | f32 (read per call; measurements and tests): searches start at level n at least; "f32" = the first
 // level that sweeps the f32 rows (rounds 1-4's level 0)
-uint32_t vs_first_level(const Level *levels, uint32_t n_levels) {
+uint32_t vs_first_level(const Level *levels, uint32_t n_levels, uint32_t k) {
   const char *e = getenv("MSI_VS_FIRST_LEVEL");
-  if (!e) return 0u;
+  if (!e) {
+    // The int8 level's bound is wide (eps ~ 1.8e-2 in cosine): the rows inside 2 eps of the k-th neighbour number several
+    // times k, and K' = k + 3 k candidates is what it is planned with (plan_chunk).  Above KP_MAX / 4 neighbours that no longer
+    // fits the KP_MAX candidates a query can rescore — the level would prove nothing and every query would sweep twice (C5's
+    // k = 1 000): such searches start at the first level that sweeps the stored rows.
+    if (4ull * k > KP_MAX)
+      for (uint32_t i = 0; i < n_levels; ++i)
+        if (!levels[i].i8) return i;
+    return 0u;
+  }
   if (!strcmp(e, "f32")) {
     for (uint32_t i = 0; i < n_levels; ++i)
       if (!levels[i].i8) return i;
@@ -3174,7 +3183,7 @@ int32_t msi_vs_search_device(msi_vs *vs, const float *d_queries, uint32_t n_quer
   const bool store_x2 = vs->bf2;
   Level levels[MAX_LEVELS];
   const uint32_t n_levels = vs_levels(vs, levels);
-  const uint32_t l0 = std::min(std::max(adapt ? vs->level : 0u, vs_first_level(levels, n_levels)), n_levels - 1);
+  const uint32_t l0 = std::min(std::max(adapt ? vs->level : 0u, vs_first_level(levels, n_levels, k)), n_levels - 1);
   auto with_level = [&](const Level &l, auto &&fn) -> int32_t {
     vs->bf2 = l.x2;
     vs->big_slack = l.big;
@@ -3465,7 +3474,7 @@ static int32_t vs_search_direct(msi_vs *vs, const float *queries, uint32_t n_que
       msi_set_error("msi_vs_search: cancelled");
       return MSI_E_CANCELLED;
     }
-    const uint32_t l0 = std::min(std::max(adapt ? vs->level : 0u, vs_first_level(levels, n_levels)), n_levels - 1);
+    const uint32_t l0 = std::min(std::max(adapt ? vs->level : 0u, vs_first_level(levels, n_levels, k)), n_levels - 1);
     step = batch_of(levels[l0]);
     const uint32_t nq = std::min<uint32_t>(step, n_queries - q0);
     if (k == 0 || vs->n_rows == 0) {

@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 ctx = ma.Context(0)
 rows = synth.device_rows(n, d, dev, seed=1234)
 ids = torch.arange(n, dtype=torch.int32, device=dev)
-st = ma.GpuStore(ctx, d)
+st = ma.GpuStore(ctx, d, storage=os.environ.get("STORAGE", "f32"))   # (STORAGE=bf16: round 6, the int8 copy of a bf16 store)
 st.upload_device(ids, rows)
 del rows
 q = synth.device_queries(Q, d, dev, seed=5678)

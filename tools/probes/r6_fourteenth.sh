@@ -1,21 +1,11 @@
-# Round 6, thirteenth device call: ROW-GRANULAR filtered sweeps (vs_filter_rows_kernel: compacted allowed rows gathered at
-# 64-byte-sector granularity / whole tiles, per region), the int8 copy in row-sector order, the int8 copy for bf16 stores.
-# Device tests of the vector tier, the vector leg's traces at C4 / C2 (the int8 sweep now reads the permuted block), C5 with
-# the gather, without it (MSI_VS_GATHER_PCT=1600: rounds 1-5's tile-granular sweep) and without the bf16 stores' int8 copy.
+# Round 6, fourteenth device call: what the thirteenth did not get to (bench.py had a syntax error in its C5 leg): C5 with the
+# row-granular sweep / the tile-granular one / other gather thresholds, the bf16 store's int8 copy at k = 20, the C5 step's
+# kernel trace, and the typo lookup's kernels at the batch the C4 step issues (1 536 words) and at C3's (8 192)
 set -x
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-cd $R
-timeout 1800 python -m pytest -x -q -m gpu tests/test_vs_gpu.py tests/test_zz_i8_proof_gpu.py tests/test_zzz_vs_update_gpu.py tests/test_zzz_filter_gpu.py tests/test_zz_group_gpu.py "tests/test_configs_gpu.py::test_c4_10m_x_768_top20" "tests/test_configs_gpu.py::test_c2_1m_x_384_top20" "tests/test_configs_gpu.py::test_c2_with_10pct_filter" "tests/test_configs_gpu.py::test_c5_shard_bf16_filtered_k1000" 2>&1 | grep -a "passed\|failed\|error\|Error\|assert" | tail -12 | tee gpurun_out/r6_thirteenth_tests.log
-cd /tmp && export TMPDIR=/tmp
-for shape in "c4 10000000 768 768" "c2 1000000 384 256"; do
-  set -- $shape
-  rm -rf /tmp/tr_$1
-  N_ROWS=$2 DIM=$3 Q=$4 VARIANTS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_$1 -o tr -- python $R/tools/probes/r5_i8_variants.py > /tmp/tr_$1.log 2>&1
-  F=$(find /tmp/tr_$1 -name "*kernel_stats.csv" | head -1)
-  [ -n "$F" ] && cp $F $R/gpurun_out/r6_vector_leg_$1_kernel_stats_e.csv && head -12 $F | cut -c1-200
-  grep -a "variant 0\|f32 level" /tmp/tr_$1.log | tee -a $R/gpurun_out/r6_vector_leg_lines_e.log
-done
+export TMPDIR=/tmp
+timeout 600 python -m pytest -x -q -m gpu tests/test_vs_gpu.py -k "row_granular or bf16" "tests/test_configs_gpu.py::test_c5_shard_bf16_filtered_k1000" 2>&1 | grep -a "passed\|failed\|error\|Error\|assert" | tail -8 | tee $R/gpurun_out/r6_fourteenth_tests.log
 cd $R
 c5() {
   label="$1"; shift
@@ -57,3 +47,11 @@ rm -rf /tmp/tr_c5
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_c5 -o tr -- python $R/bench.py --config c5 --no-pmc --no-cpu-baseline > /tmp/tr_c5.log 2>&1
 F=$(find /tmp/tr_c5 -name "*kernel_stats.csv" | head -1)
 [ -n "$F" ] && cp $F $R/gpurun_out/r6_bench_c5_kernel_stats.csv && head -16 $F | cut -c1-220
+cd /tmp
+for B in 1536 8192; do
+  rm -rf /tmp/tr_c3_$B
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_c3_$B -o tr -- python $R/bench.py --config c3 --queries $B --no-pmc --no-cpu-baseline > /tmp/tr_c3_$B.log 2>&1
+  F=$(find /tmp/tr_c3_$B -name "*kernel_stats.csv" | head -1)
+  [ -n "$F" ] && cp $F $R/gpurun_out/r6_c3_${B}_kernel_stats.csv && head -8 $F | cut -c1-200
+  tail -1 /tmp/tr_c3_$B.log | cut -c1-400
+done
