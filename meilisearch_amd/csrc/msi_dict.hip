@@ -330,6 +330,7 @@ struct DictArgs {
   u64 *pairs;                // stats: (query, word) pairs that reached a DP lane
   u64 *prof;                 // MSI_DICT_PROFILE: thread 0's wall-clock ticks (100 MHz) per phase, summed over queries (else null)
   uint32_t *out_one, *out_one_cnt, *out_two, *out_two_cnt;
+  uint32_t defer_caps;       // 1: the cap logic runs in dict_caps_kernel, after dict_other_kernel AND the lookup launches (round 6)
 };
 
 // A pattern assembled from up to three pieces of the query's bytes (the one-edit shapes that change the first
@@ -571,6 +572,49 @@ __global__ __launch_bounds__(XT) void dict_other_kernel(DictArgs a) {
   }
 }
 
+// ---- caps: the closed form of compute_derivations.rs:129-163 over a query's unit lists and its other-first-char words.
+// Run by ONE thread per query: thread 0 of the workgroup that completed the query's last unit (small batches), or a thread of
+// dict_caps_kernel (DictArgs::defer_caps).
+__device__ __forceinline__ void dict_caps_of_query(const DictArgs &a, uint32_t q, int K, uint32_t n_sl) {
+  const uint32_t stride_w = a.cap1 + a.cap2;
+  const uint32_t *const xl = a.xq + (size_t)q * a.capx;
+  const uint32_t xn = (K == 2 && a.n_fc > 0) ? a.xq_cnt[q] : 0u;
+  const uint32_t *ul0 = a.ulists + (size_t)a.unit_off[q] * stride_w;
+  const uint32_t(*uc)[2] = reinterpret_cast<const uint32_t(*)[2]>(a.ucnt + 2 * (size_t)a.unit_off[q]);
+  WaveLists s1{ul0, stride_w, 0, 0, 0, 0, uc, n_sl}, s2{ul0, stride_w, a.cap1, 1, 0, 0, uc, n_sl};
+  s1.settle();
+  s2.settle();
+  uint32_t *one = a.out_one + (size_t)q * a.cap1;
+  uint32_t *two = a.out_two + (size_t)q * a.cap2;
+  uint32_t n1 = 0, n2 = 0, xi = 0;
+  // two = first cap2 of (X ∪ S2)
+  while (n2 < a.cap2 && !(s2.done() && xi >= xn)) {
+    uint32_t v;
+    if (s2.done()) v = xl[xi++];
+    else if (xi >= xn) { v = s2.peek(); s2.pop(); }
+    else if (s2.peek() < xl[xi]) { v = s2.peek(); s2.pop(); }
+    else v = xl[xi++];
+    two[n2++] = v;
+  }
+  // one = first cap1 of (S1 ∪ {x in X : x > t*}), t* = the last element of a FULL `two`
+  xi = xn;  // `two` never filled: no X word reaches `one`
+  if (n2 == a.cap2 && n2 > 0) {
+    const uint32_t tstar = two[n2 - 1];
+    xi = 0;
+    while (xi < xn && xl[xi] <= tstar) ++xi;
+  }
+  while (n1 < a.cap1 && !(s1.done() && xi >= xn)) {
+    uint32_t v;
+    if (s1.done()) v = xl[xi++];
+    else if (xi >= xn) { v = s1.peek(); s1.pop(); }
+    else if (s1.peek() < xl[xi]) { v = s1.peek(); s1.pop(); }
+    else v = xl[xi++];
+    one[n1++] = v;
+  }
+  a.out_one_cnt[q] = n1;
+  a.out_two_cnt[q] = n2;
+}
+
 template <bool BITS>
 __device__ __forceinline__ void dict_lookup_body(const DictArgs &a) {
   __shared__ u64 s_pa[128];            // PEq: ASCII chars (BITS)
@@ -771,44 +815,10 @@ __device__ __forceinline__ void dict_lookup_body(const DictArgs &a) {
     }
 
     // ---- caps: the closed form of compute_derivations.rs:129-163 ------------------------------------
+    if (a.defer_caps) continue;   // (dict_caps_kernel: the other-first-char words are being found beside this kernel)
     if (tid == 0) {
       const u64 t_q3 = a.prof ? wall_clock64() : 0;
-      const uint32_t *const xl = a.xq + (size_t)q * a.capx;
-      const uint32_t xn = (K == 2 && a.n_fc > 0) ? a.xq_cnt[q] : 0u;
-      const uint32_t *ul0 = a.ulists + (size_t)a.unit_off[q] * stride_w;
-      const uint32_t(*uc)[2] = reinterpret_cast<const uint32_t(*)[2]>(a.ucnt + 2 * (size_t)a.unit_off[q]);
-      WaveLists s1{ul0, stride_w, 0, 0, 0, 0, uc, n_sl}, s2{ul0, stride_w, a.cap1, 1, 0, 0, uc, n_sl};
-      s1.settle();
-      s2.settle();
-      uint32_t *one = a.out_one + (size_t)q * a.cap1;
-      uint32_t *two = a.out_two + (size_t)q * a.cap2;
-      uint32_t n1 = 0, n2 = 0, xi = 0;
-      // two = first cap2 of (X ∪ S2)
-      while (n2 < a.cap2 && !(s2.done() && xi >= xn)) {
-        uint32_t v;
-        if (s2.done()) v = xl[xi++];
-        else if (xi >= xn) { v = s2.peek(); s2.pop(); }
-        else if (s2.peek() < xl[xi]) { v = s2.peek(); s2.pop(); }
-        else v = xl[xi++];
-        two[n2++] = v;
-      }
-      // one = first cap1 of (S1 ∪ {x in X : x > t*}), t* = the last element of a FULL `two`
-      xi = xn;  // `two` never filled: no X word reaches `one`
-      if (n2 == a.cap2 && n2 > 0) {
-        const uint32_t tstar = two[n2 - 1];
-        xi = 0;
-        while (xi < xn && xl[xi] <= tstar) ++xi;
-      }
-      while (n1 < a.cap1 && !(s1.done() && xi >= xn)) {
-        uint32_t v;
-        if (s1.done()) v = xl[xi++];
-        else if (xi >= xn) { v = s1.peek(); s1.pop(); }
-        else if (s1.peek() < xl[xi]) { v = s1.peek(); s1.pop(); }
-        else v = xl[xi++];
-        one[n1++] = v;
-      }
-      a.out_one_cnt[q] = n1;
-      a.out_two_cnt[q] = n2;
+      dict_caps_of_query(a, q, K, n_sl);
       if (a.prof) {   // [queries, staging + PEq, wave 0's scan (with its drains), of that its drains, search + waiting for the
                       //  slowest wave's scan, caps, whole query]
         const u64 t_q4 = wall_clock64();
@@ -829,6 +839,18 @@ __device__ __forceinline__ void dict_lookup_body(const DictArgs &a) {
 // 8-wave workgroup per CU (131 registers), a launch of 8 192 queries 3.6 ms.  The bit-parallel kernel is compiled for 6
 // waves per SIMD (80 registers, three of them spilled on a cold path) = six 4-wave workgroups per CU; the banded one
 // (queries above 64 chars, MSI_DICT_MATCHER=banded) keeps what it needs.
+// DictArgs::defer_caps (batches of 512 words and more): the cap logic of every query, one thread each, after BOTH the lookup
+// launches (the units' lists) and dict_other_kernel (the other-first-char words) — which then runs BESIDE the range scans on a
+// stream of its own instead of in front of them (it was 16 % of a launch at 8 192 words: binary searches, latency-bound,
+// one workgroup per budget-2 query).
+__global__ __launch_bounds__(64) void dict_caps_kernel(DictArgs a) {
+  const uint32_t q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= a.nq) return;
+  const int K = (int)a.qm[q].budget;
+  if (K == 0) return;   // (the lookup kernels wrote its zero counts)
+  dict_caps_of_query(a, q, K, a.unit_off[q + 1] - a.unit_off[q]);
+}
+
 template <bool BITS> __global__ void dict_lookup_kernel(DictArgs a);
 template <> __global__ __launch_bounds__(LT, 6) void dict_lookup_kernel<true>(DictArgs a) { dict_lookup_body<true>(a); }
 template <> __global__ __launch_bounds__(LT) void dict_lookup_kernel<false>(DictArgs a) { dict_lookup_body<false>(a); }
@@ -926,6 +948,9 @@ struct msi_dict {
   uint8_t *h_stage = nullptr;
   size_t h_stage_cap = 0;
   hipEvent_t h_done = nullptr;
+  // dict_other_kernel's own stream and the two events that fork it off the lookup's stream and join it again (defer_caps)
+  hipStream_t other_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint64_t lookup_launches = 0, dict_bytes = 0;
   KernelTimer match_timer;
   // host copy of the sorted words (prefix ranges, idx -> word for the keyword pipeline)
@@ -1076,6 +1101,19 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   a.out_one_cnt = d_one_cnt;
   a.out_two = d_two;
   a.out_two_cnt = d_two_cnt;
+  // batches (C3, the C4 step's 1 536 words): dict_other_kernel beside the range scans, the caps behind both; a search's own
+  // one-to-three-word lookups keep the cap logic inside the lookup kernel (one launch and two event waits less)
+  static const uint32_t defer_min = getenv("MSI_DICT_DEFER_CAPS_MIN") ? (uint32_t)atoi(getenv("MSI_DICT_DEFER_CAPS_MIN")) : 512u;
+  bool defer = defer_min > 0 && n >= defer_min;
+  if (defer && !d->other_stream) {
+    if (hipStreamCreateWithFlags(&d->other_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      defer = false;   // (no second stream to be had: the serial order of rounds 4-5)
+    }
+  }
+  a.defer_caps = defer ? 1u : 0u;
   d->match_timer.begin(ctx, st);
   // MSI_DICT_MATCHER=banded: the round-3 five-diagonal DP for every survivor (kept for A/B runs and as the matcher of
   // queries above 64 chars); default: the bit-parallel recurrence
@@ -1086,7 +1124,12 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
   {   // the other-first-letter words of every budget-2 query first: the matcher kernel's cap logic reads them
     DictArgs x = a;
     x.ticket = d->ticket.as<uint32_t>() + 3;
-    hipLaunchKernelGGL(dict_other_kernel, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * 2)), dim3(XT), 0, st, x);
+    if (defer) {
+      MSI_HIP_TRY(hipEventRecord(d->ev_fork, st));
+      MSI_HIP_TRY(hipStreamWaitEvent(d->other_stream, d->ev_fork, 0));
+    }
+    hipLaunchKernelGGL(dict_other_kernel, dim3(std::min<uint32_t>(n, (uint32_t)ctx->n_cu * 2)), dim3(XT), 0, defer ? d->other_stream : st, x);
+    if (defer) MSI_HIP_TRY(hipEventRecord(d->ev_join, d->other_stream));
   }
   if (banded) {
     hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(std::min<uint32_t>(max_units, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[0])), dim3(LT), 0, st, a);
@@ -1100,6 +1143,10 @@ int32_t enqueue_lookup(msi_dict *d, const uint8_t *d_qbytes, const uint32_t *d_q
     a.ticket = d->ticket.as<uint32_t>() + 1;
     a.n_long = d->ticket.as<uint32_t>() + 2;
     hipLaunchKernelGGL(dict_lookup_kernel<false>, dim3(std::min<uint32_t>(max_units, (uint32_t)ctx->n_cu * (uint32_t)wg_per_cu[0])), dim3(LT), 0, st, a);
+  }
+  if (defer) {
+    MSI_HIP_TRY(hipStreamWaitEvent(st, d->ev_join, 0));
+    hipLaunchKernelGGL(dict_caps_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a);
   }
   d->match_timer.end(ctx);
   MSI_HIP_TRY(hipGetLastError());
@@ -1242,6 +1289,12 @@ void msi_dict_destroy(msi_dict *d) {
   d->match_timer.release();
   if (d->h_stage) (void)hipHostFree(d->h_stage);
   if (d->h_done) (void)hipEventDestroy(d->h_done);
+  if (d->other_stream) {
+    (void)hipStreamSynchronize(d->other_stream);
+    (void)hipStreamDestroy(d->other_stream);
+  }
+  if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+  if (d->ev_join) (void)hipEventDestroy(d->ev_join);
   delete d;
   }
   msi_ctx_release(ctx);

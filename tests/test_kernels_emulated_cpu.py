@@ -24,6 +24,9 @@ GROUPS = {
     "vector-scan": (["tests/test_vs_gpu.py", "tests/test_zzz_vs_update_gpu.py", "tests/test_zz_bq_gpu.py", "tests/test_zz_i8_proof_gpu.py"],
                     "not 70000 and not 40000 and not 20000 and not three_query_tiles and not large_scan and not large_k", 32),
     "dictionary": (["tests/test_dict_gpu.py", "tests/test_zz_fst_gpu.py"], "not synthetic_dictionary_all_paths", 12),
+    # round 6: batches of 512 words and more run dict_other_kernel on a stream of its own beside the range scans and the cap
+    # logic in dict_caps_kernel behind both (DictArgs::defer_caps) — here forced for every batch size
+    "dictionary-deferred-caps": (["tests/test_dict_gpu.py"], "not synthetic_dictionary_all_paths", 8, {"MSI_DICT_DEFER_CAPS_MIN": "1"}),
     "docid-sets": (["tests/test_bits_gpu.py", "tests/test_zz_order_keys_gpu.py::test_order_next_against_numpy",
                     "tests/test_zzz_distinct_gpu.py::test_distinct_against_the_sequential_loop",
                     "tests/test_zzz_distinct_gpu.py::test_many_calls_share_the_scratch_without_clearing_it",
