@@ -2178,8 +2178,15 @@ static msi_vm *vm_of(msi_ctx *ctx) {
       cb->fused_wgs = &vm->fused_wgs;
       cb->fused_budget = vm->fused_budget;
       if (const char *e = getenv("MSI_VM_STREAMS")) cb->ns = std::max(4, std::min((int)VmCombiner::NS, atoi(e) & ~1));
+      // MSI_VM_STREAM_PRIORITY=1 (experiment, round 6): the rounds' streams at the device's highest dispatch priority — beside
+      // a vector sweep launched as many SHORT workgroups (MSI_VS_GRID_MULT) a round's workgroups are then dispatched as soon
+      // as a sweep's workgroup ends instead of behind the whole sweep
+      int prio_least = 0, prio_greatest = 0;
+      const char *pk = getenv("MSI_VM_STREAM_PRIORITY");
+      const bool high = pk && pk[0] == '1' && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_greatest != prio_least;
       for (int i = 0; i < cb->ns; ++i)
-        if (hipStreamCreateWithFlags(&cb->streams[i], hipStreamNonBlocking) != hipSuccess) {
+        if ((high ? hipStreamCreateWithPriority(&cb->streams[i], hipStreamNonBlocking, prio_greatest)
+                  : hipStreamCreateWithFlags(&cb->streams[i], hipStreamNonBlocking)) != hipSuccess) {
           msi_set_error("msi_vm: hipStreamCreate failed");
           delete vm;   // (what was created so far leaks with the failed context; nothing runs on it)
           return nullptr;

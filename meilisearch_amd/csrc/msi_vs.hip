@@ -2352,10 +2352,17 @@ bool launch_scan8_variant(int variant, uint32_t KB8, const Scan8Args &sa, bool d
   }
   return false;
 }
+// MSI_VS_GRID_MULT=<n> (read per sweep; experiment, round 6): a sweep as n times the workgroups, each with 1 / n of the rows —
+// short workgroups that let the keyword searches' rounds in between (their streams at a higher priority: MSI_VM_STREAM_PRIORITY)
+// at the price of n times the query fragments' LDS fills
+static uint32_t scan_grid_mult() {
+  const char *e = getenv("MSI_VS_GRID_MULT");
+  return e ? (uint32_t)std::max(1, std::min(64, atoi(e))) : 1u;
+}
 void launch_scan8(msi_vs *vs, const Scan8Args &sa, uint32_t nqt, bool dense, hipStream_t st = nullptr, uint32_t grid_wgs = 0) {
   const uint32_t n = scan8_nqt_of(nqt);
   const size_t lds = scan8_lds_bytes(vs->KB8, n);
-  const dim3 grid(grid_wgs ? grid_wgs : vs->scan_grid8), block(SCAN_WAVES * 64);
+  const dim3 grid(grid_wgs ? grid_wgs : vs->scan_grid8 * (dense ? 1u : scan_grid_mult())), block(SCAN_WAVES * 64);
   if (!st) st = vs->ctx->stream;
   if (n == 8) {
     const char *v = getenv("MSI_VS_I8_VARIANT");
