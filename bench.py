@@ -1570,6 +1570,8 @@ def run_c3(args, env):
     concat, off = synth.flatten_words(words)
     gdict = ma.GpuDictionary(ctx, concat=concat, offsets=off)
     tq = synth.make_typo_queries(words, B, seed=7 + env.rank)
+    if os.environ.get("MSI_BENCH_C3_SORTED") == "1":   # experiment: the batch in dictionary order (the same first letters side by side)
+        tq = sorted(tq, key=lambda t: t[0].encode("utf-8"))
     qb, qoff, qfl = ma.pack_queries(tq)
     qb_t = torch.from_numpy(qb).to(dev)
     qoff_t = torch.from_numpy(qoff.astype(np.int32)).to(dev)

@@ -99,6 +99,16 @@ def test_c5_shard_bf16_filtered_k1000(ctx):
     assert v["checked_queries"] == 16 and v["k"] == 1000
 
 
+@pytest.mark.parametrize("density", [0.001, 0.1])
+def test_c5_shard_bf16_filtered_k1000_other_densities(ctx, density):
+    """BASELINE.md C5's other two filter densities at the shard's full size: 0.1 % — 12 433 allowed rows, a sweep
+    of ~1 500 gathered items — and 10 % — 1.25 M allowed rows, compacted 8:1 against the tiles that hold them.  k = 1 000
+    starts at the level that sweeps the stored rows (the int8 level cannot prove that many neighbours: vs_first_level)."""
+    v, stats = _check_store(ctx, 12_500_000, 1024, 1000, 8, storage="bf16", filter_density=density)
+    assert v["checked_queries"] == 8 and v["k"] == 1000
+    assert stats["i8_sweeps"] == 0
+
+
 def test_c3_2m_term_dictionary(ctx):
     from oracle import parity
     words = synth.make_dictionary(2_000_000, seed=99)
