@@ -166,6 +166,7 @@ PROTOTYPES = {
     "msi_vs_search": (_I32, [_VP, _VP, _U32, _U32, _VP, _U64, _VP, _VP, _VP, _VP]),
     "msi_vs_search_by_item": (_I32, [_VP, _U32, _U32, _VP, _U64, _VP, _VP, C.POINTER(_U32), C.POINTER(_I32)]),
     "msi_vs_set_microbatch": (_I32, [_VP, _U32]),
+    "msi_vs_set_sweep_split": (_I32, [_VP, _U32]),
     "msi_vs_microbatch_stats": (_I32, [_VP, C.POINTER(_U64), C.POINTER(_U64)]),
     "msi_vs_search_device": (_I32, [_VP, _VP, _U32, _U32, _VP, _U64, _VP, _VP, _VP, _VP]),
     "msi_merge_topk": (_U32, [_VP, _VP, _VP, _U32, _U32, _U32, _VP, _VP]),

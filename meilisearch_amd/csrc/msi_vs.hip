@@ -2039,6 +2039,7 @@ struct msi_vs {
   bool bleader_active = false;
   uint32_t microbatch_wait_us = 0;   // 0 = off
   uint64_t fused_calls = 0, fused_sweeps = 0;
+  uint32_t sweep_split = 1;          // msi_vs_set_sweep_split
 };
 
 namespace {
@@ -2352,17 +2353,18 @@ bool launch_scan8_variant(int variant, uint32_t KB8, const Scan8Args &sa, bool d
   }
   return false;
 }
-// MSI_VS_GRID_MULT=<n> (read per sweep; experiment, round 6): a sweep as n times the workgroups, each with 1 / n of the rows —
-// short workgroups that let the keyword searches' rounds in between (their streams at a higher priority: MSI_VM_STREAM_PRIORITY)
-// at the price of n times the query fragments' LDS fills
-static uint32_t scan_grid_mult() {
+// msi_vs_set_sweep_split(vs, n) / MSI_VS_GRID_MULT=<n> (read per sweep): a full sweep of the int8 copy as n times the
+// workgroups, each with 1 / n of the rows — short workgroups (~90 us at n = 16, C4) that let the keyword searches' rounds in
+// between when both legs of a hybrid step share the device, at the price of n times the query fragments' LDS fills (the
+// sweep alone: 67 -> 63 k q/s at n = 16).  Measured (profiles/r6_overlap_short_wgs.log): the overlapped step 61.5 -> 58.6-59.2 ms.
+static uint32_t scan_grid_mult(const msi_vs *vs) {
   const char *e = getenv("MSI_VS_GRID_MULT");
-  return e ? (uint32_t)std::max(1, std::min(64, atoi(e))) : 1u;
+  return e ? (uint32_t)std::max(1, std::min(64, atoi(e))) : std::max(1u, vs->sweep_split);
 }
 void launch_scan8(msi_vs *vs, const Scan8Args &sa, uint32_t nqt, bool dense, hipStream_t st = nullptr, uint32_t grid_wgs = 0) {
   const uint32_t n = scan8_nqt_of(nqt);
   const size_t lds = scan8_lds_bytes(vs->KB8, n);
-  const dim3 grid(grid_wgs ? grid_wgs : vs->scan_grid8 * (dense ? 1u : scan_grid_mult())), block(SCAN_WAVES * 64);
+  const dim3 grid(grid_wgs ? grid_wgs : vs->scan_grid8 * (dense ? 1u : scan_grid_mult(vs))), block(SCAN_WAVES * 64);
   if (!st) st = vs->ctx->stream;
   if (n == 8) {
     const char *v = getenv("MSI_VS_I8_VARIANT");
@@ -3393,6 +3395,16 @@ int32_t msi_merge_topk_device(msi_ctx *ctx, const uint32_t *d_docids, const floa
   hipLaunchKernelGGL(vs_merge_lists_kernel, dim3(n_queries), dim3(SEL_THREADS), 0, ctx->stream, d_docids, d_dist,
                      d_counts, n_lists, n_queries, k, d_out_docids, d_out_dist, d_out_counts);
   MSI_HIP_TRY(hipGetLastError());
+  return MSI_OK;
+}
+
+int32_t msi_vs_set_sweep_split(msi_vs *vs, uint32_t n) {
+  if (!vs || n == 0 || n > 64) {
+    msi_set_error("msi_vs_set_sweep_split: n must be in 1..64");
+    return MSI_E_INVALID;
+  }
+  std::lock_guard<std::mutex> lk(vs->ctx->mu);
+  vs->sweep_split = n;
   return MSI_OK;
 }
 

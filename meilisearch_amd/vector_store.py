@@ -121,6 +121,10 @@ class GpuStore:
             return None
         return out_d[:cnt.value].copy(), out_s[:cnt.value].copy()
 
+    def set_sweep_split(self, n):
+        """A full sweep as n times the workgroups (short workgroups: for a host that runs other device work beside the sweeps)."""
+        check(lib().msi_vs_set_sweep_split(self._h, int(n)))
+
     def set_microbatch(self, max_wait_us):
         """Fuse concurrent unfiltered `search` calls (other threads) into shared HBM sweeps."""
         check(lib().msi_vs_set_microbatch(self._h, int(max_wait_us)))
