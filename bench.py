@@ -118,6 +118,9 @@ def parse_args():
                          "when --tail-at of its searches are done.  All three measured within 3 %% of each other (152-157 ms per "
                          "step, profiles/r3_bench_variants.txt): a step is the SUM of its legs — the scan saturates HBM and "
                          "stretches every keyword round beside it by as much as it gains")
+    ap.add_argument("--sweep-split", type=int, default=16, help="c4: msi_vs_set_sweep_split for the side-by-side leg (and for the timed "
+                    "steps under --legs overlap / tail)")
+    ap.add_argument("--no-overlapped-leg", action="store_true", help="c4: skip legs.hybrid_legs_side_by_side")
     ap.add_argument("--tail-at", type=float, default=0.8, help="c4, --legs tail: the fraction of the step's keyword searches done when the scan starts")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="also skips the parity check (same leg)")
     ap.add_argument("--no-rows-sharded-extra", action="store_true", help="c4, N > 1: skip the rows-sharded extra object")
@@ -801,8 +804,9 @@ def run_c4(args, env):
                                   kw["m_sem"].ctypes.data, kw["m_cnt"].ctypes.data, kw["m_hits"].ctypes.data)
         return res + ((kw["m_ids"], kw["m_sem"], kw["m_cnt"], kw["m_hits"]),)
 
-    def step():
-        if kw is not None and args.legs == "tail":
+    def step(legs_order=None):
+        legs_order = legs_order or args.legs
+        if kw is not None and legs_order == "tail":
             # The keyword leg is latency-bound (17 dependent rounds per search, `kw_threads` searches in flight) and ends with
             # a TAIL: the last searches of the step run with most callers already idle.  The vector scan — 8 sweeps that
             # saturate HBM — starts when `--tail-at` of the step's searches are done and streams beside that tail; the
@@ -818,7 +822,7 @@ def run_c4(args, env):
                 time.sleep(0.0003)
             store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
             assert kw["lib"].rb_wait(kw["h"]) == 0, "msi_keyword_search_ranked failed"
-        elif kw is not None and args.legs == "overlap":
+        elif kw is not None and legs_order == "overlap":
             # Both legs from the start: the keyword searches are started on their caller threads, the vector leg runs on this
             # thread beside them (msi_vs_search_device returns when every query is answered), then the keyword job is joined.
             first = kw_first()
@@ -831,7 +835,7 @@ def run_c4(args, env):
             assert kw["lib"].rb_wait(kw["h"]) == 0, "msi_keyword_search_ranked failed"
         else:
             store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
-            if kw is not None and args.legs == "serial":
+            if kw is not None and legs_order == "serial":
                 ctx.synchronize()     # the scan streams HBM on its own, then the (latency-bound) keyword lists run
             if gdict is not None:     # (VALU-bound, on the context's second stream: beside the keyword rounds, not beside the scan)
                 gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
@@ -855,6 +859,8 @@ def run_c4(args, env):
         return res
 
     phase("c4: warm-up + timed steps")
+    if kw is not None and args.legs != "serial":
+        store.set_sweep_split(args.sweep_split)      # the sweeps share the device with the keyword rounds: short workgroups
     for _ in range(args.warmup):
         step()
     ctx.set_profiling(True)
@@ -999,6 +1005,39 @@ def run_c4(args, env):
     # ---- per-QUERY latency (the metric is "queries/sec + p50 latency"; ms_per_step is the latency of a 768-query step) ----
     # N > 1: every rank measured its keyword leg at the same time on the CPUs the ranks share: their sum is the whole job's
     # measured keyword throughput, to be read against the prediction (granted CPUs / host CPU per query)
+    if kw is not None and args.legs == "serial" and env.world == 1 and not env.emulated and not env.child and not args.no_overlapped_leg:
+        # The same step with its two legs SIDE BY SIDE and the sweep cut into short workgroups (msi_vs_set_sweep_split: the
+        # keyword rounds' kernels get in between the sweep's workgroups instead of behind the sweep) — what a server that runs
+        # both legs of execute_hybrid concurrently gets.  Not the line's `value`: beside the keyword rounds a sweep takes 3-4x
+        # its own time, and the roofline object must describe the sweep, so the timed steps keep the legs one after the other.
+        phase("c4: the step with its legs side by side")
+        store.set_sweep_split(args.sweep_split)
+        try:
+            for _ in range(2):
+                step("overlap")
+            env.sync_all()
+            ctx.set_profiling(True)
+            store.scan_time()
+            n_ov = max(3, min(10, args.steps))
+            t0 = time.perf_counter()
+            lat_ov = []
+            for _ in range(n_ov):
+                s0 = time.perf_counter()
+                step("overlap")
+                lat_ov.append((time.perf_counter() - s0) * 1e3)
+            env.sync_all()
+            dt_ov = time.perf_counter() - t0
+            ov_n, ov_ms = store.scan_time()
+            ctx.set_profiling(False)
+        finally:
+            store.set_sweep_split(1)
+        ov_bytes = sweep_kernel(stats, n)[2]
+        legs["hybrid_legs_side_by_side"] = {
+            "queries_per_s": round(n_ov * Q / dt_ov, 1), "ms_per_step": round(dt_ov / n_ov * 1e3, 3),
+            "p50_latency_ms": round(statistics.median(lat_ov), 3), "steps": n_ov, "sweep_split": args.sweep_split,
+            "sweep_avg_launch_ms_beside_the_keyword_rounds": round(ov_ms / max(1, ov_n), 4),
+            "sweep_frac_of_8_TBps_beside_the_keyword_rounds": round(ov_bytes / max(1e-9, ov_ms / max(1, ov_n) * 1e-3) / 1e9 / 8000.0, 4),
+            "is": "the timed step with --legs overlap and msi_vs_set_sweep_split(%d): both legs from the start" % args.sweep_split}
     kw_only_by_rank = env.gather_scalar(legs.get("keyword_only_queries_per_s") or 0.0) if kw is not None else None
     vec_only_by_rank = env.gather_scalar(legs.get("vector_only_queries_per_s") or 0.0) if kw is not None else None
     phase("c4: per-query latency")
@@ -2030,6 +2069,9 @@ def short_line(full, detail_path=None):
         lg["keyword_algorithmic_bytes_per_query"] = {k_: v for k_, v in lg["keyword_algorithmic_bytes_per_query"].items() if k_ != "is"}
     if isinstance(legs.get("keyword_posting_cache"), dict):
         lg["keyword_posting_cache_hit_rate"] = legs["keyword_posting_cache"].get("hit_rate")
+    if isinstance(legs.get("hybrid_legs_side_by_side"), dict):
+        lg["hybrid_legs_side_by_side"] = _pick(legs["hybrid_legs_side_by_side"], ("queries_per_s", "ms_per_step", "sweep_split",
+                                                                                "sweep_frac_of_8_TBps_beside_the_keyword_rounds"))
     if isinstance(legs.get("keyword_with_features"), dict):
         kf = legs["keyword_with_features"]
         lg["keyword_with_features_queries_per_s"] = kf.get("queries_per_s")

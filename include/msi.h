@@ -190,9 +190,9 @@ int32_t msi_dict_create_values_from_fst(msi_ctx *ctx, const uint8_t *fst, size_t
 int32_t msi_vs_set_microbatch(msi_vs *vs, uint32_t max_wait_us);
 /* How finely a full sweep of the store is cut into workgroups: n = 1 (default) = one persistent workgroup per CU slot, each
  * streaming 1 / grid of the rows for the whole sweep (1.4 ms at 10 M x 768); n = 2..64 = n times as many workgroups, each n
- * times shorter.  For a host that runs the vector searches BESIDE other device work of the same process (the keyword
- * searches of a hybrid query: milli's execute_hybrid runs both legs, hybrid.rs:145-200): short workgroups let that work's
- * kernels in between instead of behind the sweep; the sweep on its own loses ~6 % at n = 16 (the query fragments are staged
+ * times shorter.  For a host that runs the vector searches BESIDE other device work of the same process (a server's
+ * concurrent queries: one query's vector search beside the others' keyword searches — execute_hybrid, hybrid.rs:264-340,
+ * runs both for every hybrid query): short workgroups let that work's kernels in between instead of behind the sweep; the sweep on its own loses ~6 % at n = 16 (the query fragments are staged
  * into LDS once per workgroup).  Answers do not depend on it. */
 int32_t msi_vs_set_sweep_split(msi_vs *vs, uint32_t n);
 int32_t msi_vs_microbatch_stats(msi_vs *vs, uint64_t *out_fused_calls,
