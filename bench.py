@@ -1216,9 +1216,8 @@ def run_c4(args, env):
                                      "%d words per query over the 300 most frequent words of an independently hashed index" % args.kw_terms,
                                      args.kw_dict_words, kw_threads),
                                  "hybrid merge (semanticRatio 0.5) of the vector list with the keyword list (global scores)"]),
-            "step_includes_short": ["vs_scan + select + f32 rescoring + exactness proof", "dict_lookup (typo derivations)", "D2H of results"]
-                                   + ([] if kw is None else ["msi_keyword_search_ranked, 7 default criteria, detailed scores",
-                                                             "hybrid merge (semanticRatio 0.5)"]),
+            "step_includes_short": ["vs_scan+select+f32 rescoring+proof", "dict_lookup (typo derivations)", "D2H of results"]
+                                   + ([] if kw is None else ["keyword search, 7 criteria, detailed", "hybrid merge (ratio 0.5)"]),
             "step_excludes": ["keyword leg", "hybrid merge"] if kw is None else [],
             "inexact_queries_last_step": n_inexact,
             "keyword_corpus": args.kw_corpus if kw is not None else None,
@@ -2040,20 +2039,22 @@ def short_line(full, detail_path=None):
     out["vs_baseline"] = full.get("vs_baseline")
     out["dtype"] = full.get("dtype")
     out["data"] = _clip(full.get("data", "synthetic"), 72)
-    c = {"workload": _clip(cfg.get("workload", ""), 420)}
+    c = {"workload": _clip(cfg.get("workload", ""), 210)}
     c.update(_pick(cfg, ("queries_per_step_per_gpu", "words_per_step_per_gpu", "queries_per_hbm_sweep", "rccl_ranks_seen",
                          "keyword_callers_per_rank", "host_cpus_granted", "keyword_corpus", "keyword_stream",
                          "inexact_queries_last_step", "per_rank_values", "keyword_cap_predicted", "keyword_cap_measured")))
     if cfg.get("sharding"):
-        c["sharding"] = _clip(cfg["sharding"], 150)
-    c["step_includes"] = [_clip(s, 60) for s in cfg.get("step_includes_short", cfg.get("step_includes", []))]
+        c["sharding"] = _clip(cfg["sharding"], 70)
+    if isinstance(c.get("keyword_stream"), str):
+        c["keyword_stream"] = _clip(c["keyword_stream"], 60)
+    c["step_includes"] = [_clip(s, 36) for s in cfg.get("step_includes_short", cfg.get("step_includes", []))]
     c["step_excludes"] = cfg.get("step_excludes", [])
     out["config"] = c
     out["roofline"] = _roofline_short(full.get("roofline"))
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         o = _pick(cb, ("value", "unit", "cores", "kind", "vector_queries_per_s", "typo_words_per_s", "keyword_queries_per_s"))
-        o["sample"] = _clip(cb.get("sample", ""), 200)
+        o["sample"] = _clip(cb.get("sample", ""), 130)
         out["cpu_baseline"] = o
     if full.get("parity") is not None:
         out["parity"] = _parity_counts(full["parity"])
@@ -2070,8 +2071,10 @@ def short_line(full, detail_path=None):
     if isinstance(legs.get("keyword_posting_cache"), dict):
         lg["keyword_posting_cache_hit_rate"] = legs["keyword_posting_cache"].get("hit_rate")
     if isinstance(legs.get("hybrid_legs_side_by_side"), dict):
-        lg["hybrid_legs_side_by_side"] = _pick(legs["hybrid_legs_side_by_side"], ("queries_per_s", "ms_per_step", "sweep_split",
-                                                                                "sweep_frac_of_8_TBps_beside_the_keyword_rounds"))
+        sbs = legs["hybrid_legs_side_by_side"]
+        lg["legs_side_by_side"] = {"queries_per_s": sbs.get("queries_per_s"), "ms_per_step": sbs.get("ms_per_step"),
+                                   "sweep_split": sbs.get("sweep_split"),
+                                   "sweep_frac": sbs.get("sweep_frac_of_8_TBps_beside_the_keyword_rounds")}
     if isinstance(legs.get("keyword_with_features"), dict):
         kf = legs["keyword_with_features"]
         lg["keyword_with_features_queries_per_s"] = kf.get("queries_per_s")
@@ -2101,7 +2104,8 @@ def short_line(full, detail_path=None):
                 per = {}
                 for dens, line in (c5.get("densities") or {}).items():
                     o = _also_one(line)
-                    o.pop("unit", None)
+                    for key in ("unit", "bound", "cpu_cores"):
+                        o.pop(key, None)
                     if isinstance(line.get("cpu_baseline"), dict):
                         o["cpu"] = line["cpu_baseline"].get("value")
                     per[dens] = o
@@ -2117,7 +2121,7 @@ def short_line(full, detail_path=None):
     if detail_path:
         out["detail"] = detail_path
     # never longer than the driver reads: drop the optional groups, least important first
-    for drop in (None, "latency_ms", "legs", "rows_sharded", "also", "data"):
+    for drop in (None, "latency_ms", "rows_sharded", "data", "legs", "also"):
         if drop is not None:
             out.pop(drop, None)
         line = json.dumps(out, separators=(",", ":"))
