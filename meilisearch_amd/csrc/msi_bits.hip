@@ -159,10 +159,11 @@ uint64_t msi_bits_compact_capacity(const msi_bits *p) {
 msi_bits *msi_bits_compact_pool(msi_bits *p) {
   if (!p->companion) {
     msi_bits *c = nullptr;
-    // (a set of the compact space is an eighth of a set of the full one: the companion holds TWICE the slots — a search's
-    // sibling sub-trees are admitted as cooperative tasks by the slots that are free, and more tasks are fewer rounds;
-    // the command lists address pools of up to 1024 slots)
-    static const uint32_t mult = getenv("MSI_BITS_COMPANION_SLOTS_X") ? (uint32_t)std::max(1, atoi(getenv("MSI_BITS_COMPANION_SLOTS_X"))) : 2u;
+    // MSI_BITS_COMPANION_SLOTS_X=2: the companion holds twice the slots (a set of the compact space is an eighth of a set of
+    // the full one; a search's sibling sub-trees are admitted as cooperative tasks by the slots that are free, and more tasks
+    // are fewer rounds: 10.79 -> 10.16 lists per fresh query at 10 M documents).  Measured at the same throughput (19.7 k q/s
+    // either way, profiles/r6_callers_and_slots.log) for 80 MB more per caller: off by default.
+    static const uint32_t mult = getenv("MSI_BITS_COMPANION_SLOTS_X") ? (uint32_t)std::max(1, atoi(getenv("MSI_BITS_COMPANION_SLOTS_X"))) : 1u;
     const uint32_t c_slots = std::min<uint32_t>(1024u, std::max<uint32_t>(p->n_slots, p->n_slots * mult));
     if (msi_bits_create(p->ctx, std::max<uint64_t>(1, msi_bits_compact_capacity(p)), c_slots, &c) != MSI_OK) return nullptr;
     // its creation memsets ran on the context's stream; the command lists run on the combiner's

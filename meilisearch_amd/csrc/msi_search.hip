@@ -2618,6 +2618,23 @@ struct GraphRule : Rule {
     stack.clear();
     good.clear();
     stop = false;
+    if (known_outcome(c)) {
+      // ONE term, ONE path, ONE condition — "the document holds the term" — and every document of the universe does: the
+      // universe of any rule is a subset of the search's, which is query_graph_docids of this very graph (or of a graph this
+      // one was reduced from, by paths whose documents are the universe).  The bucket IS the universe: no command, no wait.
+      // (the Words and Proximity evaluations of a one-word search: two of its eight dependent rounds)
+      good.clear();
+      good.push_back({edges[Graph::ROOT][0].cond});
+      ++g_stats.paths;
+      out.maker = this;
+      out.good = std::move(good);
+      out.docs = universe;
+      out.count = universe_count;
+      out.universe_reduced = true;   // (nothing is left of it: the bucket sort's tree does not read it again)
+      uni.reset();
+      bucket.reset();
+      return true;
+    }
     if (ready.empty() || ready.front().cost != cost) {
       ready.clear();
       look_ahead(it, rc.end());
@@ -2647,6 +2664,21 @@ struct GraphRule : Rule {
     bucket.reset();
     stack.clear();
     return true;
+  }
+
+  // The Words and Proximity rules over a graph of one term node (root -> term -> end: one conditional edge of one cost) inside
+  // the bucket sort's tree (page_room is only set there: the sequential loop keeps reading the universe a rule was given).
+  // MSI_SEARCH_KNOWN_OUTCOMES=0: off (the tests hold both against the oracle).
+  bool known_outcome(Ctx &c) const {
+    static const bool off = getenv("MSI_SEARCH_KNOWN_OUTCOMES") && getenv("MSI_SEARCH_KNOWN_OUTCOMES")[0] == '0';
+    // (Typo too when the term has ONE typo level — a word too short for typos, an exact term: its one condition holds the
+    // term's zero-typo derivations, which are all the term has)
+    if (off || !page_room || !c.dev.vm || (kind != R_WORDS && kind != R_PROXIMITY && kind != R_TYPO)) return false;
+    if (costs[Graph::ROOT].size() != 1 || edges[Graph::ROOT].size() != 1) return false;
+    const Edge &e = edges[Graph::ROOT][0];
+    if (e.cond < 0 || !e.skip.empty() || e.dest == Graph::END || e.dest >= edges.size()) return false;
+    const auto &out_edges = edges[e.dest];
+    return out_edges.size() == 1 && out_edges[0].dest == Graph::END && out_edges[0].cond < 0 && out_edges[0].cost == 0;
   }
 
   Graph graph_of(const Vec<Vec<int32_t>> &found) override {
@@ -2723,7 +2755,9 @@ struct GraphRule : Rule {
     // resolved, 1.3 % more set-operand bytes
     // (the direct back end publishes each level's counts into one of MSI_BITS_PATH_REGIONS regions; a command list has
     // MSI_VM_MAX_COUNTS counts and takes as many levels as fit)
-    const int per_wait = std::min<int>(cx->knob_levels_per_wait >= 0 ? cx->knob_levels_per_wait : (cx->dev.vm ? 8 : 1),
+    // 12 since round 6: lists per fresh query 10.79 -> 10.6 at 10 M documents (profiles/r6_queues.log), 10.52 -> 10.29 on the
+    // emulated corpus; 16 adds nothing (10.28)
+    const int per_wait = std::min<int>(cx->knob_levels_per_wait >= 0 ? cx->knob_levels_per_wait : (cx->dev.vm ? 12 : 1),
                                        cx->dev.vm ? 16 : (int)MSI_BITS_PATH_REGIONS);
     if (per_wait < 2 || cx->knob_fused_off) return;
     // `distinct` removes documents from every universe of the stack whenever a bucket reaches the results
@@ -3596,6 +3630,8 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
 #ifndef MSI_SEARCH_DIRECT_ONLY
       Tasks tasks;
       const bool no_gate = getenv("MSI_SEARCH_TASKS_NO_GATE") != nullptr;   // tests: provoke the out-of-slots re-run
+      // free slots a task is admitted against (MSI_SEARCH_TASK_SLOTS; a search that runs out of slots is done again, one bucket at a time)
+      static const size_t task_slots = getenv("MSI_SEARCH_TASK_SLOTS") ? (size_t)std::max(1, atoi(getenv("MSI_SEARCH_TASK_SLOTS"))) : 48;
       bool coop = c.dev.vm && max_tasks > 1;
       bool late_ok = may_compact && Dev::late_mode() > 0;
       static const bool late_wait = getenv("MSI_SEARCH_LATE_WAIT") && getenv("MSI_SEARCH_LATE_WAIT")[0] == '1';
@@ -3672,7 +3708,7 @@ void search(Ctx &c, const msi_located_term *lt, uint32_t n_terms, const uint8_t 
             // a task keeps its own working sets alive: only as many tasks as the pool has room for (a rule evaluation
             // is given what relieve() keeps free)
             if (coop && tasks.live < (size_t)max_tasks &&
-                (no_gate || c.dev.cur->free_.size() + c.dev.cur->clean_.size() + c.dev.cur->held.size() >= 48 * (tasks.live + 2))) {
+                (no_gate || c.dev.cur->free_.size() + c.dev.cur->clean_.size() + c.dev.cur->held.size() >= task_slots * (tasks.live + 2))) {
               // (the graph is moved into the task: the Bucket dies at the end of this iteration)
               auto gp = msi_arena::make_shared<Graph>(b.graph());
               tasks.spawn([&rank, cur, docs = b.docs, cnt = b.count, off, sc, gp]() { rank(cur + 1, docs, cnt, off, sc, *gp); });
