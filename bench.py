@@ -804,6 +804,8 @@ def run_c4(args, env):
                                   kw["m_sem"].ctypes.data, kw["m_cnt"].ctypes.data, kw["m_hits"].ctypes.data)
         return res + ((kw["m_ids"], kw["m_sem"], kw["m_cnt"], kw["m_hits"]),)
 
+    step_parts = {"vector_leg": 0.0, "typo_lookup_enqueue_and_keyword_leg": 0.0, "sync_d2h_merge_exchange": 0.0, "n": 0}
+
     def step(legs_order=None):
         legs_order = legs_order or args.legs
         if kw is not None and legs_order == "tail":
@@ -834,13 +836,19 @@ def run_c4(args, env):
             store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)
             assert kw["lib"].rb_wait(kw["h"]) == 0, "msi_keyword_search_ranked failed"
         else:
+            t_a = time.perf_counter()
             store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)  # ceil(Q / max_batch) HBM sweeps
             if kw is not None and legs_order == "serial":
                 ctx.synchronize()     # the scan streams HBM on its own, then the (latency-bound) keyword lists run
+            t_b = time.perf_counter()
             if gdict is not None:     # (VALU-bound, on the context's second stream: beside the keyword rounds, not beside the scan)
                 gdict.lookup_device(qb_t, qoff_t, qfl_t, n_words_q, one_t, one_c, two_t, two_c)
             if kw is not None:
                 keyword_run()
+            step_parts["vector_leg"] += t_b - t_a          # (host clocks around the parts of a serial step: legs.step_parts_ms)
+            step_parts["typo_lookup_enqueue_and_keyword_leg"] += time.perf_counter() - t_b
+            step_parts["n"] += 1
+        t_c = time.perf_counter()
         ctx.synchronize()
         if row_sharded:
             from meilisearch_amd.distributed import merge_topk_device
@@ -856,6 +864,7 @@ def run_c4(args, env):
             res = hybrid_merge(res)
         if world > 1 and not row_sharded:
             exchange()
+        step_parts["sync_d2h_merge_exchange"] += time.perf_counter() - t_c
         return res
 
     phase("c4: warm-up + timed steps")
@@ -871,7 +880,10 @@ def run_c4(args, env):
     if kw is not None:
         pc_t0 = (C.c_uint64 * 4)()
         ma._lib.lib().msi_dict_posting_cache_stats(C.c_void_p(kw["lib"].rb_dict(kw["h"])), pc_t0)
+    for key in step_parts:
+        step_parts[key] = 0
     elapsed, lat = env.timed(step, args.steps, 0)
+    timed_parts = dict(step_parts)
     pc_timed = None
     if kw is not None:
         pc_t1 = (C.c_uint64 * 4)()
@@ -885,6 +897,9 @@ def run_c4(args, env):
     phase("c4: legs on their own")
     # the two legs on their own (untimed extras, 3 steps each): what bounds the step
     legs = {}
+    if timed_parts.get("n"):
+        legs["step_parts_ms"] = {key: round(v / timed_parts["n"] * 1e3, 2) for key, v in timed_parts.items() if key != "n"}
+        legs["step_parts_ms"]["is"] = "host clocks around the parts of the timed (serial) steps, mean per step"
     if kw is not None and not env.child:
         ctx.set_profiling(True)
         store.scan_time()
@@ -1427,7 +1442,7 @@ def also_configs(args, env):
     out = {}
     for cfg, fn, steps in (("c2", run_c2, 10), ("c3", run_c3, 5), ("c5", run_c5, 5)):
         a = copy.copy(args)
-        a.config, a.steps, a.warmup = cfg, steps, 2
+        a.config, a.steps, a.warmup = cfg, steps, (4 if cfg == "c5" else 2)   # (c5's steps cycle through four query sets)
         a.rows = a.dim = a.k = a.queries = a.storage = None
         a.parity_queries = 16
         t0 = time.time()
@@ -1854,6 +1869,7 @@ def run_c5(args, env):
             "filter_density": sel_d, "allowed_rows": n_allowed,
             "value": round(B * env.world * args.steps / elapsed, 2), "unit": "queries/s",
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "p50_latency_ms": round(statistics.median(lat), 4),
+            "step_ms": [round(x, 1) for x in lat],
             "knn_only_ms_per_step": round(knn_ms, 4),
             "words_typo_fast_path_ms_per_step": round(fast_ms, 4), "words_typo_fast_path_queries_per_s": round(B / (fast_ms * 1e-3), 1),
             "tiles_streamed_per_launch": fstats["items"], "tiles_in_store": (n + 15) // 16,
@@ -2054,7 +2070,7 @@ def short_line(full, detail_path=None):
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         o = _pick(cb, ("value", "unit", "cores", "kind", "vector_queries_per_s", "typo_words_per_s", "keyword_queries_per_s"))
-        o["sample"] = _clip(cb.get("sample", ""), 130)
+        o["sample"] = _clip(cb.get("sample", ""), 100)
         out["cpu_baseline"] = o
     if full.get("parity") is not None:
         out["parity"] = _parity_counts(full["parity"])
@@ -2067,7 +2083,13 @@ def short_line(full, detail_path=None):
                       "keyword_cold_posting_cache_queries_per_s", "keyword_cycled_queries_per_s", "keyword_lists_per_query", "keyword_algorithmic_bytes_per_query",
                       "keyword_host_cpu_ms_per_query"))
     if isinstance(lg.get("keyword_algorithmic_bytes_per_query"), dict):
-        lg["keyword_algorithmic_bytes_per_query"] = {k_: v for k_, v in lg["keyword_algorithmic_bytes_per_query"].items() if k_ != "is"}
+        ab = lg.pop("keyword_algorithmic_bytes_per_query")
+        lg["keyword_mb_per_query"] = {"stored_postings_read": round((ab.get("stored_posting_bytes_read") or 0) / 1e6, 1),
+                                      "set_operands": round((ab.get("set_operand_bytes_of_the_command_lists") or 0) / 1e6, 1),
+                                      "ratio": ab.get("operand_bytes_over_posting_bytes")}
+    if isinstance(legs.get("step_parts_ms"), dict):
+        sp = legs["step_parts_ms"]
+        lg["step_parts_ms"] = [sp.get("vector_leg"), sp.get("typo_lookup_enqueue_and_keyword_leg"), sp.get("sync_d2h_merge_exchange")]
     if isinstance(legs.get("keyword_posting_cache"), dict):
         lg["keyword_posting_cache_hit_rate"] = legs["keyword_posting_cache"].get("hit_rate")
     if isinstance(legs.get("hybrid_legs_side_by_side"), dict):
@@ -2078,7 +2100,7 @@ def short_line(full, detail_path=None):
     if isinstance(legs.get("keyword_with_features"), dict):
         kf = legs["keyword_with_features"]
         lg["keyword_with_features_queries_per_s"] = kf.get("queries_per_s")
-        lg["keyword_with_features_index_callbacks_share"] = (kf.get("host_cpu_us_per_query") or {}).get("index_callbacks_share")
+        lg["keyword_with_features_callbacks_share"] = (kf.get("host_cpu_us_per_query") or {}).get("index_callbacks_share")
         if isinstance(kf.get("parity"), dict):
             lg["keyword_with_features_parity"] = [kf["parity"].get("checked_queries"), kf["parity"].get("mismatches")]
     if isinstance(legs.get("keyword_postings_staged_at_index_open"), dict):

@@ -1364,6 +1364,7 @@ struct Ctx {
   // of them per look-ahead and one per level, ~90 walks per query; the tests that flip them do so between searches)
   int knob_levels_per_wait = -1;    // MSI_SEARCH_LEVELS_PER_WAIT (-1: not set)
   bool knob_fused_off = false;      // MSI_SEARCH_FUSED_LEVELS=0
+  bool knob_known_off = false;      // MSI_SEARCH_KNOWN_OUTCOMES=0
   Ctx(msi_dict *d, msi_bits *pool, const msi_index_vtable *i, const msi_search_params *p)
       : dict(d), ix(i), prm(p), dev(pool) {
 #ifndef MSI_SEARCH_DIRECT_ONLY
@@ -1372,6 +1373,8 @@ struct Ctx {
     if (const char *k = getenv("MSI_SEARCH_LEVELS_PER_WAIT")) knob_levels_per_wait = std::max(0, atoi(k));
     const char *f = getenv("MSI_SEARCH_FUSED_LEVELS");
     knob_fused_off = f && f[0] == '0';
+    const char *ko = getenv("MSI_SEARCH_KNOWN_OUTCOMES");
+    knob_known_off = ko && ko[0] == '0';
   }
 
   uint32_t word(const std::string &w) {
@@ -2670,7 +2673,7 @@ struct GraphRule : Rule {
   // the bucket sort's tree (page_room is only set there: the sequential loop keeps reading the universe a rule was given).
   // MSI_SEARCH_KNOWN_OUTCOMES=0: off (the tests hold both against the oracle).
   bool known_outcome(Ctx &c) const {
-    static const bool off = getenv("MSI_SEARCH_KNOWN_OUTCOMES") && getenv("MSI_SEARCH_KNOWN_OUTCOMES")[0] == '0';
+    const bool off = c.knob_known_off;
     // (Typo too when the term has ONE typo level — a word too short for typos, an exact term: its one condition holds the
     // term's zero-typo derivations, which are all the term has)
     if (off || !page_room || !c.dev.vm || (kind != R_WORDS && kind != R_PROXIMITY && kind != R_TYPO)) return false;

@@ -295,6 +295,17 @@ def test_path_by_path_fallback_matches_too(monkeypatch):
         test_reference_snapshot(case)
 
 
+def test_known_outcomes_off_matches_too(monkeypatch):
+    """A one-word search's Words / Proximity / single-level Typo evaluations are answered on the host (the bucket is the
+    universe: msi_search.hip, GraphRule::known_outcome); MSI_SEARCH_KNOWN_OUTCOMES=0 sends them through the device again.
+    Every other test runs with the shortcut on; the reference snapshots and a random corpus (its one-word queries under every
+    rule order and matching strategy) must replay without it too."""
+    monkeypatch.setenv("MSI_SEARCH_KNOWN_OUTCOMES", "0")
+    for case in CASES[::2]:
+        test_reference_snapshot(case)
+    test_matches_oracle_on_random_corpora(2, 100)
+
+
 def test_reference_matching_strategy_literals_on_the_device():
     """crates/meilisearch/tests/search/matching_strategy.rs: the hit ids of its 9 searches (three per strategy; the only
     literals the reference holds for TermsMatchingStrategy::Frequency) through msi_keyword_search_ranked."""
