@@ -2060,7 +2060,10 @@ def short_line(full, detail_path=None):
                          "keyword_callers_per_rank", "host_cpus_granted", "keyword_corpus", "keyword_stream",
                          "inexact_queries_last_step", "per_rank_values", "keyword_cap_predicted", "keyword_cap_measured")))
     if cfg.get("sharding"):
-        c["sharding"] = _clip(cfg["sharding"], 70)
+        sh = cfg["sharding"]                      # (the short line keeps what is sharded and the exchange path, not the prose between)
+        if "; exchange path: " in sh:
+            sh = sh.split(",")[0] + "; exchange: " + sh.split("; exchange path: ", 1)[1]
+        c["sharding"] = _clip(sh, 110)
     if isinstance(c.get("keyword_stream"), str):
         c["keyword_stream"] = _clip(c["keyword_stream"], 60)
     c["step_includes"] = [_clip(s, 36) for s in cfg.get("step_includes_short", cfg.get("step_includes", []))]
