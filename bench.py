@@ -121,6 +121,7 @@ def parse_args():
     ap.add_argument("--sweep-split", type=int, default=16, help="c4: msi_vs_set_sweep_split for the side-by-side leg (and for the timed "
                     "steps under --legs overlap / tail)")
     ap.add_argument("--no-overlapped-leg", action="store_true", help="c4: skip legs.hybrid_legs_side_by_side")
+    ap.add_argument("--kw-gap-probe", action="store_true", help="c4: legs.keyword_gap_probe (the keyword leg behind idle time / behind the vector leg)")
     ap.add_argument("--tail-at", type=float, default=0.8, help="c4, --legs tail: the fraction of the step's keyword searches done when the scan starts")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="also skips the parity check (same leg)")
     ap.add_argument("--no-rows-sharded-extra", action="store_true", help="c4, N > 1: skip the rows-sharded extra object")
@@ -947,6 +948,30 @@ def run_c4(args, env):
             keyword_run()
         dt = time.perf_counter() - t0
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        if args.kw_gap_probe:
+            # why is the keyword leg slower inside the serial step (legs.step_parts_ms) than on its own?  The same three passes
+            # with 12 ms of idle host and device in front of each, then with the vector leg in front of each
+            def kw_ms():
+                t_ = time.perf_counter()
+                keyword_run()
+                return (time.perf_counter() - t_) * 1e3
+            saved_step = kw["step"]
+            kw["step"] = max(kw["step"], args.warmup + kw["stream_steps"])    # primer queries again, for all three variants
+            b2b, idle, after_vec = [], [], []
+            kw_ms()
+            for _ in range(3):
+                b2b.append(kw_ms())
+            for _ in range(3):
+                time.sleep(0.012)
+                idle.append(kw_ms())
+            for _ in range(3):
+                store.search_device(q_t, k, out_ids, out_dist, out_cnt, inexact)
+                ctx.synchronize()
+                after_vec.append(kw_ms())
+            kw["step"] = saved_step
+            legs["keyword_gap_probe"] = {"fresh_back_to_back_ms": round(dt / 3 * 1e3, 2), "cycled_back_to_back_ms": [round(x, 2) for x in b2b],
+                                         "cycled_behind_12_ms_idle_ms": [round(x, 2) for x in idle],
+                                         "cycled_behind_the_vector_leg_ms": [round(x, 2) for x in after_vec]}
         legs["keyword_only_queries_per_s"] = round(3 * Q / dt, 1)
         legs["keyword_only_host_cpus_used"] = round((ru1.ru_utime + ru1.ru_stime - ru0.ru_utime - ru0.ru_stime) / dt, 2)
         legs["host_cpus_allowed"] = len(os.sched_getaffinity(0))

@@ -424,7 +424,7 @@ struct Dev {
     open_list();
     if (list.phase_start.size() + 1 > MSI_VM_MAX_PHASES) run();
     open_list();
-    msi_vm_record_rank(list, pool.p, u0->slot);
+    if (!msi_vm_record_rank(list, pool.p, u0->slot)) fail(MSI_E_OOM, "the rank tables of the compact space could not be allocated");
   }
   bool compact_pays(uint64_t n_u0) const {
     const uint64_t n = msi_bits_n_docs(pool.p);

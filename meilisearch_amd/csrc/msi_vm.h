@@ -124,7 +124,7 @@ int32_t msi_vm_record_decode(MsiVmList &l, msi_bits *pool, uint32_t dst, const M
 void msi_vm_record_compact(MsiVmList &l, uint32_t dst, uint32_t full_slot);
 // Appends, to a list on the FULL pool, the two commands (a kernel boundary between them) that fill the pool's
 // compaction tables for U0 = `slot`.
-void msi_vm_record_rank(MsiVmList &l, msi_bits *pool, uint32_t slot);
+bool msi_vm_record_rank(MsiVmList &l, msi_bits *pool, uint32_t slot);   // false: the pool's rank tables could not be allocated
 uint64_t msi_bits_compact_capacity(const msi_bits *p);
 msi_bits *msi_bits_compact_pool(msi_bits *p);
 uint32_t *msi_bits_compact_aux(msi_bits *p);

@@ -2359,13 +2359,17 @@ void msi_vm_record_compact(MsiVmList &l, uint32_t dst, uint32_t full_slot) {
   l.pre.push_back(0x80000000u | full_slot);
 }
 
-void msi_vm_record_rank(MsiVmList &l, msi_bits *pool, uint32_t slot) {
+bool msi_vm_record_rank(MsiVmList &l, msi_bits *pool, uint32_t slot) {
+  // (the tables are allocated when a pool first needs them: with HBM exhausted that fails, and commands that write through a
+  // null table fault the device — a run of 384 callers beside the C4 store dumped a GPU core here, profiles/r6_step_callers_and_slots.log)
   const uint64_t aux = (uint64_t)(uintptr_t)msi_bits_compact_aux(pool);
+  if (!aux) return false;
   l.begin();
   l.words.insert(l.words.end(), {(uint32_t)VM_RANK_A, slot, (uint32_t)aux, (uint32_t)(aux >> 32)});
   l.barrier();
   const uint64_t cap = msi_bits_compact_capacity(pool);
   l.words.insert(l.words.end(), {(uint32_t)VM_RANK_B, slot, (uint32_t)aux, (uint32_t)(aux >> 32), (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFull)});
+  return true;
 }
 
 // A compact list's hoisted VM_DECODEC commands become its phase 0 (the wide phase).

@@ -133,6 +133,21 @@ inline void hipemu_check_stream(hipStream_t s, const char *what) {
   }
 }
 inline hipError_t hipMalloc(void **p, size_t n) {
+  // MSI_EMU_FAIL_MALLOC=<k> (tests: set and cleared between calls): HBM is exhausted after k more allocations — the
+  // count starts whenever the variable's value changes
+  if (const char *lim = getenv("MSI_EMU_FAIL_MALLOC")) {
+    static char seen[32] = "";
+    static long left = 0;
+    if (strncmp(seen, lim, sizeof(seen) - 1) != 0) {
+      strncpy(seen, lim, sizeof(seen) - 1);
+      left = atol(lim);
+    }
+    if (left <= 0) {
+      *p = nullptr;
+      return hipErrorOutOfMemory;
+    }
+    --left;
+  }
   *p = malloc(n ? n : 1);
   if (!*p) return hipErrorOutOfMemory;
   memset(*p, getenv("MSI_EMU_FILL") ? atoi(getenv("MSI_EMU_FILL")) : 0xCD, n);

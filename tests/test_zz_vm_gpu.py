@@ -118,6 +118,42 @@ def test_starved_tasks_are_rerun_sequentially_and_still_match_the_oracle(monkeyp
     G.test_matches_oracle_on_random_corpora(1, 100)
 
 
+def test_a_search_that_cannot_allocate_fails_with_an_error_wherever_hbm_runs_out(monkeypatch):
+    """What a search allocates when it first needs it — the list arenas, the compact space's companion pool and rank tables,
+    staging buffers — fails when HBM is exhausted.  Wherever that happens the search must come back with MSI_E_OOM (or
+    MSI_E_HIP) and the pool must serve the next search: commands recorded against a null rank table faulted the device (a
+    384-caller run beside the C4 store dumped a GPU core, profiles/r6_step_callers_and_slots.log).  The CPU emulation of
+    HIP injects the failure after k more allocations, k = 0, 1, 2, ... until the search gets through: the test is skipped
+    on a device."""
+    import tests.test_search_gpu as G
+    from meilisearch_amd import _lib
+    if type(_lib.lib()).__name__ != "EmulatedLib":
+        pytest.skip("allocation failures are injected by the CPU emulation of HIP (tests/emu)")
+    monkeypatch.setenv("MSI_SEARCH_COMPACT", "2")          # every universe is compacted
+    case = [c for c in G.CASES if c["ids"] and c["detailed"]][0]
+    kw = dict(tms=case["tms"], offset=case["offset"], limit=case["limit"], detailed=case["detailed"])
+    failures = set()
+    for k in range(64):
+        h = G.Harness(G.build_index(G.FIX["indexes"][case["index"]]))   # a fresh pool: nothing of its compact space exists yet
+        monkeypatch.setenv("MSI_EMU_FAIL_MALLOC", str(k))
+        try:
+            hits, _ = h.search(case["query"], **kw)
+            failed = None
+        except _lib.MsiError as e:
+            failed = str(e)
+        monkeypatch.delenv("MSI_EMU_FAIL_MALLOC")
+        if failed is not None:
+            assert failed.startswith(("MSI_E_OOM", "MSI_E_HIP")), failed
+            failures.add(failed)
+            hits, _ = h.search(case["query"], **kw)       # the same pool, HBM available again
+        assert [d for d, _ in hits] == case["ids"], (k, failed)
+        if failed is None:
+            break
+    else:
+        raise AssertionError("the search never got through")
+    assert len(failures) >= 3, failures                   # (arena, rank tables, companion pool, ...: several places)
+
+
 def test_documents_spread_over_many_chunks(monkeypatch):
     """The command lists work chunk by chunk (65 536 documents each) and skip, per chunk, the sets and the paths whose
     chunk summary says "empty here".  The reference's snapshot indexes hold a few dozen documents — one chunk — so here
