@@ -62,6 +62,17 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 _PHASES = []
 
 
+_HBM_FREE = []
+
+
+def note_hbm(torch_mod):
+    """Free HBM right now (the whole device: hipMemGetInfo) — the line carries the minimum over the marks of the run."""
+    try:
+        _HBM_FREE.append(torch_mod.cuda.mem_get_info()[0] / 1e9)
+    except Exception:      # noqa: BLE001 - the emulated tier has no device to ask
+        pass
+
+
 def phase(name):
     """Wall-clock marks of the run (the detail object's `phase_seconds`: where the default command's minutes go)."""
     _PHASES.append((name, time.time()))
@@ -1080,6 +1091,7 @@ def run_c4(args, env):
             "is": "the timed step with --legs overlap and msi_vs_set_sweep_split(%d): both legs from the start" % args.sweep_split}
     kw_only_by_rank = env.gather_scalar(legs.get("keyword_only_queries_per_s") or 0.0) if kw is not None else None
     vec_only_by_rank = env.gather_scalar(legs.get("vector_only_queries_per_s") or 0.0) if kw is not None else None
+    note_hbm(torch)
     phase("c4: per-query latency")
     latency = None
     if kw is not None and not env.child and rank == 0:
@@ -1372,9 +1384,13 @@ def run_c4(args, env):
         out["parity"] = par
     if kw is not None and args.kw_features and args.kw_corpus == "coherent" and not env.child and world == 1:
         out["legs"]["keyword_with_features"] = keyword_features_leg(args, kw, Q, k, phase, n_total if row_sharded else n)
+        note_hbm(torch)
         if out.get("parity") is not None and isinstance(out["legs"]["keyword_with_features"].get("parity"), dict):
             out["parity"]["mismatches"] += out["legs"]["keyword_with_features"]["parity"]["mismatches"]
     if kw is not None:
+        note_hbm(torch)
+        if _HBM_FREE:
+            out["config"]["hbm_free_gb_min"] = round(min(_HBM_FREE), 1)     # (with the store, the cache and every caller's pools resident)
         kw_qps = legs.get("keyword_only_queries_per_s") or 0.0
         kw["lib"].rb_destroy(kw["h"])      # the runner's pools go before the children / the other configurations start
         kw = None
@@ -2083,7 +2099,7 @@ def short_line(full, detail_path=None):
     c = {"workload": _clip(cfg.get("workload", ""), 210)}
     c.update(_pick(cfg, ("queries_per_step_per_gpu", "words_per_step_per_gpu", "queries_per_hbm_sweep", "rccl_ranks_seen",
                          "keyword_callers_per_rank", "host_cpus_granted", "keyword_corpus", "keyword_stream",
-                         "inexact_queries_last_step", "per_rank_values", "keyword_cap_predicted", "keyword_cap_measured")))
+                         "inexact_queries_last_step", "per_rank_values", "keyword_cap_predicted", "keyword_cap_measured", "hbm_free_gb_min")))
     if cfg.get("sharding"):
         sh = cfg["sharding"]                      # (the short line keeps what is sharded and the exchange path, not the prose between)
         if "; exchange path: " in sh:
