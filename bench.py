@@ -541,7 +541,8 @@ def run_c4(args, env):
         pmc_early = pmc_traffic(args, "vs_scan_i8_kernel" if has_i8 else "vs_scan_kernel", ("false",))
     phase("c4: rows + store upload")
     t_setup = time.time()
-    rows_t = synth.device_rows(n, d, dev, seed=1234 + (rank if row_sharded else 0))
+    rows_seed = 1234 + (rank if row_sharded else 0)
+    rows_t = synth.device_rows(n, d, dev, seed=rows_seed)
     ids_t = torch.arange(n, dtype=torch.int32, device=dev)
     if row_sharded:
         ids_t += r0
@@ -551,10 +552,13 @@ def run_c4(args, env):
     cpu_rows = None
     if env.check:
         cpu_rows = rows_t[:min(n, args.cpu_sample_rows)].cpu().numpy()
-    else:
-        del rows_t
-        rows_t = None
-        torch.cuda.empty_cache()
+    # the rows leave HBM once the store holds them (30.7 GB at C4's size, beside 256 callers' pools): the full-size parity check
+    # draws them again, a chunk at a time, from the same generator (synth.device_rows_chunks)
+    ctx.synchronize()
+    del rows_t
+    rows_t = None
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
 
     q_t = synth.device_queries(Q, d, dev, seed=5678 + (0 if row_sharded else rank))
     out_ids = torch.zeros((Q, k), dtype=torch.int32, device=dev)
@@ -1324,10 +1328,9 @@ def run_c4(args, env):
         nqc = min(args.parity_queries, Q)
         got = store.search(q_t[:nqc].cpu().numpy(), k)     # host entry point: exhaustive reruns included
         chk = parity.TopkChecker(q_t[:nqc].cpu().numpy(), k)
-        chunk = 1_000_000
-        for c0 in range(0, n, chunk):
-            c1 = min(n, c0 + chunk)
-            rows = rows_t[c0:c1].cpu().numpy()
+        for c0, c1, rows_chunk in synth.device_rows_chunks(n, d, dev, seed=rows_seed):
+            rows = rows_chunk.cpu().numpy()
+            del rows_chunk
             if storage == "bf16":
                 rows = synth.round_to_bf16(rows)
             chk.add_chunk(np.arange(c0, c1, dtype=np.uint32), rows)

@@ -227,6 +227,18 @@ def device_rows(n, d, dev, seed=1234, chunk=1_000_000):
     return rows_t
 
 
+def device_rows_chunks(n, d, dev, seed=1234, chunk=1_000_000):
+    """The rows of device_rows(n, d, dev, seed) AGAIN, one chunk at a time: (c0, c1, rows[c0:c1]) from the same generator, the
+    same draws in the same order — for a full-size parity check that does not keep the 30 GB of C4's rows in HBM beside the
+    store built from them (bench.py frees them after the upload)."""
+    import torch
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        yield c0, c1, torch.empty((c1 - c0, d), dtype=torch.float32, device=dev).normal_(generator=gen)
+
+
 def device_queries(nq, d, dev, seed=5678):
     import torch
     gq = torch.Generator(device=dev)
